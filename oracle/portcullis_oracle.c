@@ -1,0 +1,1069 @@
+/*
+ * portcullis_oracle.c -- CPU ORACLE (TEST INFRASTRUCTURE ONLY; see portcullis_oracle.h).
+ *
+ * Literal plain-C restatement of the reference `junc` path.  Every function
+ * cites the reference file:line it follows (paths relative to /root/reference).
+ * The restatement deliberately keeps the reference's structure -- strings are
+ * built and compared character by character, junctions are grouped through a
+ * hash map in first-seen order -- so that it fails differently from the HIP
+ * path if either is wrong.
+ */
+#include "portcullis_oracle.h"
+
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+static __thread char g_err[1024];
+
+static int fail(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+const char *orc_last_error(void) { return g_err; }
+
+/* ------------------------------------------------------------------ */
+/* small string builder                                               */
+/* ------------------------------------------------------------------ */
+typedef struct {
+    char *p;
+    size_t n, cap;
+} sbuf;
+
+static int sb_reserve(sbuf *s, size_t extra) {
+    if (s->n + extra + 1 <= s->cap) return 0;
+    size_t nc = s->cap ? s->cap * 2 : 256;
+    while (nc < s->n + extra + 1) nc *= 2;
+    char *np = (char *)realloc(s->p, nc);
+    if (!np) return -1;
+    s->p = np;
+    s->cap = nc;
+    return 0;
+}
+static int sb_put(sbuf *s, const char *d, size_t n) {
+    if (sb_reserve(s, n)) return -1;
+    memcpy(s->p + s->n, d, n);
+    s->n += n;
+    s->p[s->n] = 0;
+    return 0;
+}
+static int sb_fill(sbuf *s, char c, size_t n) {
+    if (sb_reserve(s, n)) return -1;
+    memset(s->p + s->n, c, n);
+    s->n += n;
+    s->p[s->n] = 0;
+    return 0;
+}
+static int sb_printf(sbuf *s, const char *fmt, ...) {
+    va_list ap, ap2;
+    va_start(ap, fmt);
+    va_copy(ap2, ap);
+    int k = vsnprintf(NULL, 0, fmt, ap);
+    va_end(ap);
+    if (k < 0 || sb_reserve(s, (size_t)k)) {
+        va_end(ap2);
+        return -1;
+    }
+    vsnprintf(s->p + s->n, (size_t)k + 1, fmt, ap2);
+    va_end(ap2);
+    s->n += (size_t)k;
+    return 0;
+}
+static void sb_free(sbuf *s) {
+    free(s->p);
+    s->p = NULL;
+    s->n = s->cap = 0;
+}
+
+/* ------------------------------------------------------------------ */
+/* CIGAR helpers (lib/include/portcullis/bam/bam_alignment.hpp:44-99) */
+/* ------------------------------------------------------------------ */
+static const char CIGAR_CHARS[] = "MIDNSHP=XB??????";
+static inline char op_chr(uint32_t c) { return CIGAR_CHARS[c & 0xf]; }
+static inline int32_t op_len(uint32_t c) { return (int32_t)(c >> 4); }
+
+/* CigarOp::opConsumesQuery, bam_alignment.hpp:75-86 */
+static inline int consumes_query(char op) {
+    return op == 'M' || op == 'I' || op == 'S' || op == '=' || op == 'X';
+}
+/* CigarOp::opConsumesReference, bam_alignment.hpp:88-99 */
+static inline int consumes_ref(char op) {
+    return op == 'M' || op == 'D' || op == 'N' || op == '=' || op == 'X';
+}
+
+static inline char up(char c) { return (c >= 'a' && c <= 'z') ? (char)(c - 32) : c; }
+
+/* ------------------------------------------------------------------ */
+/* SeqUtils (lib/include/portcullis/seq_utils.hpp)                    */
+/* ------------------------------------------------------------------ */
+
+/* SeqUtils::hammingDistance, seq_utils.hpp:62-77: throws on size mismatch, upper-cases both. */
+int orc_hamming(const char *a, size_t na, const char *b, size_t nb) {
+    if (na != nb)
+        return fail(ORC_ERR_HAMMING_LEN, "Can't find hamming distance of strings that are not the same length (%zu vs %zu)", na, nb);
+    int sum = 0;
+    for (size_t i = 0; i < na; i++)
+        if (up(a[i]) != up(b[i])) sum++;
+    return sum;
+}
+
+/* REVCOMP_LOOKUP, seq_utils.hpp:33-40.  Index = c - 'A'.  Characters outside
+ * 'A'..'Z' index out of bounds in the reference (undefined behaviour); the
+ * restatement returns NUL for them. */
+static const char REVCOMP_LOOKUP[26] = {'T', 0, 'G', 'H', 0, 0, 'C', 'D', 0, 0, 0, 0, 'K',
+                                        'N', 0, 0,   0,   'Y', 'W', 'A', 'A', 'B', 'S', 'X', 'R', 0};
+
+/* SeqUtils::reverseComplement, seq_utils.hpp:110-118 */
+void orc_revcomp(const char *in, size_t n, char *out) {
+    for (size_t i = 0; i < n; i++) {
+        int k = (int)(unsigned char)in[i] - 65;
+        char c = (k >= 0 && k < 26) ? REVCOMP_LOOKUP[k] : 0;
+        out[n - 1 - i] = c;
+    }
+}
+
+/* ------------------------------------------------------------------ */
+/* Intron (lib/src/intron.cc)                                         */
+/* ------------------------------------------------------------------ */
+
+/* Intron::minAnchorLength, intron.cc:67-83 */
+int64_t orc_min_anchor(int32_t start, int32_t end, int32_t left, int32_t right) {
+    if (left > start)
+        return fail(ORC_ERR_MIN_ANCHOR, "The intron start position must be greater than the left anchor start position: %d **** %d-%d **** %d", left, start, end, right);
+    if (right < end)
+        return fail(ORC_ERR_MIN_ANCHOR, "The intron end position must be less than the right anchor end position: (%d **** %d-%d **** %d)", left, start, end, right);
+    int32_t l = start - left, r = right - end;
+    return (int64_t)(uint32_t)(l < r ? l : r);
+}
+
+/* ------------------------------------------------------------------ */
+/* BamAlignment padded sequences (lib/src/bam_alignment.cc)           */
+/* ------------------------------------------------------------------ */
+
+/* BamAlignment::getQuerySeqAfterClipping(seq), bam_alignment.cc:256-264.
+ * Returns offset/length of the substr (std::string::substr semantics, size_t
+ * arithmetic including the "+ 1"). */
+static int clip_query(const uint32_t *cigar, int n_cigar, size_t qsize, size_t *off, size_t *len) {
+    int32_t dS = 0, dE = 0;
+    if (n_cigar > 0) {
+        if (op_chr(cigar[0]) == 'S') dS = op_len(cigar[0]);
+        if (op_chr(cigar[n_cigar - 1]) == 'S') dE = op_len(cigar[n_cigar - 1]);
+    }
+    if ((size_t)dS > qsize) return fail(ORC_ERR_CLIP_RANGE, "basic_string::substr: pos %d > size %zu", dS, qsize);
+    size_t count = qsize - (size_t)dS - (size_t)dE + 1; /* may wrap, as in the reference */
+    size_t avail = qsize - (size_t)dS;
+    *off = (size_t)dS;
+    *len = count < avail ? count : avail;
+    return 0;
+}
+
+/* BamAlignment::getPaddedQuerySeq, bam_alignment.cc:341-403 (include_soft_clips=false) */
+static int padded_query(const uint32_t *cigar, int n_cigar, int32_t position, int32_t aligned_len,
+                        const char *query_seq, size_t qsize, int32_t start, int32_t end,
+                        int32_t *actual_start, int32_t *actual_end, sbuf *out) {
+    int32_t getEnd = position + aligned_len - 1;
+    if (start > getEnd || end < position)
+        return fail(ORC_ERR_NO_PRESENCE, "Found an alignment that does not have a presence in the requested region");
+    int32_t qPos = 0, rPos = position;
+    size_t coff = 0, clen = 0;
+    int rc = clip_query(cigar, n_cigar, qsize, &coff, &clen);
+    if (rc) return rc;
+    const char *query = query_seq + coff;
+    out->n = 0;
+    if (sb_reserve(out, 1)) return fail(ORC_ERR_NOMEM, "oom");
+    out->p[0] = 0;
+    for (int k = 0; k < n_cigar; k++) {
+        char type = op_chr(cigar[k]);
+        int32_t length = op_len(cigar[k]);
+        int cRef = consumes_ref(type);
+        int cQry = consumes_query(type) && type != 'S';
+        if (rPos < start) { /* :353-357 whole op skipped */
+            if (cRef) rPos += length;
+            if (cQry) qPos += length;
+            continue;
+        }
+        if ((rPos > end && type != 'I') || (type == 'N' && rPos + length > end)) break; /* :359 */
+        if (cQry) {
+            int32_t len = (rPos + length > end && type != 'I') ? end - rPos + 1 : length; /* :362 */
+            if (len == 0)
+                return fail(ORC_ERR_ZERO_LEN_OP, "Can't extract cigar op sequence from query string when length has been calculated as 0.");
+            if (qPos < 0 || qPos + len > (int32_t)clen)
+                return fail(ORC_ERR_QUERY_RANGE, "Can't extract cigar op sequence from query string. qPos=%d len=%d query.size=%zu", qPos, len, clen);
+            /* query.substr(qPos, len): len<0 converts to huge count -> to end of string */
+            size_t take = len < 0 ? clen - (size_t)qPos : (size_t)len;
+            if (sb_put(out, query + qPos, take)) return fail(ORC_ERR_NOMEM, "oom");
+        } else if (cRef) { /* D or N: pad with 'X' (BAM_CIGAR_DIFF_CHAR), :390-396 */
+            uint32_t len = (rPos + length > end) ? (uint32_t)(end - rPos + 1) : (uint32_t)length;
+            if (sb_fill(out, 'X', len)) return fail(ORC_ERR_NOMEM, "oom");
+        }
+        if (cRef) rPos += length;
+        if (cQry) qPos += length;
+    }
+    *actual_start = position > start ? position : start; /* :400 */
+    *actual_end = rPos <= end ? rPos - 1 : end;           /* :401 */
+    return 0;
+}
+
+/* BamAlignment::getPaddedGenomeSeq, bam_alignment.cc:405-462 (include_soft_clips=false) */
+static int padded_genome(const uint32_t *cigar, int n_cigar, int32_t position, int32_t aligned_len,
+                         const char *genome_seq, size_t gsize, int32_t start, int32_t end,
+                         int32_t q_start, int32_t q_end, sbuf *out) {
+    int32_t getEnd = position + aligned_len - 1;
+    if (start > getEnd || end < position)
+        return fail(ORC_ERR_NO_PRESENCE, "Found an alignment that does not have a presence in the requested region");
+    int32_t rPos = position;
+    if (q_start - start < 0)
+        return fail(ORC_ERR_QREGION, "Query start position was before genomic region start position.  Query start: %d; Genomic start: %d", q_start, start);
+    if (end - q_end < 0)
+        return fail(ORC_ERR_QREGION, "Query end position was beyond genomic region end position.  Query end: %d; Genomic end: %d", q_end, end);
+    out->n = 0;
+    if (sb_reserve(out, 1)) return fail(ORC_ERR_NOMEM, "oom");
+    out->p[0] = 0;
+    for (int k = 0; k < n_cigar; k++) {
+        char type = op_chr(cigar[k]);
+        int32_t length = op_len(cigar[k]);
+        int cRef = consumes_ref(type);
+        int cQry = consumes_query(type) && type != 'S';
+        if (rPos < q_start) { /* :427-431 */
+            if (cRef) rPos += length;
+            continue;
+        }
+        if (rPos > q_end && type != 'I') break; /* :433 */
+        if (cRef) {
+            int32_t seqOffset = rPos - start;
+            int32_t len = rPos + length > q_end ? q_end - rPos + 1 : length;
+            if (seqOffset < 0 || seqOffset + len > (int32_t)gsize)
+                return fail(ORC_ERR_GENOME_RANGE, "Can't extract cigar op sequence from extracted genome region. offset=%d len=%d region=%zu", seqOffset, len, gsize);
+            size_t take = len < 0 ? gsize - (size_t)seqOffset : (size_t)len;
+            if (sb_put(out, genome_seq + seqOffset, take)) return fail(ORC_ERR_NOMEM, "oom");
+        } else if (cQry) { /* 'I' */
+            if (sb_fill(out, 'X', (size_t)length)) return fail(ORC_ERR_NOMEM, "oom");
+        }
+        if (cRef) rPos += length;
+    }
+    return 0;
+}
+
+int orc_padded_query_seq(const uint32_t *cigar, int n_cigar, int32_t position, int32_t aligned_len,
+                         const char *query, int32_t start, int32_t end, int32_t *actual_start,
+                         int32_t *actual_end, char *out, size_t out_cap) {
+    sbuf s = {0};
+    int rc = padded_query(cigar, n_cigar, position, aligned_len, query, strlen(query), start, end,
+                          actual_start, actual_end, &s);
+    if (rc == 0) {
+        if (s.n + 1 > out_cap) rc = fail(ORC_ERR_ARG, "output buffer too small");
+        else {
+            memcpy(out, s.p, s.n + 1);
+            rc = (int)s.n;
+        }
+    }
+    sb_free(&s);
+    return rc;
+}
+
+int orc_padded_genome_seq(const uint32_t *cigar, int n_cigar, int32_t position, int32_t aligned_len,
+                          const char *genome_seq, int32_t start, int32_t end, int32_t q_start,
+                          int32_t q_end, char *out, size_t out_cap) {
+    sbuf s = {0};
+    int rc = padded_genome(cigar, n_cigar, position, aligned_len, genome_seq, strlen(genome_seq),
+                           start, end, q_start, q_end, &s);
+    if (rc == 0) {
+        if (s.n + 1 > out_cap) rc = fail(ORC_ERR_ARG, "output buffer too small");
+        else {
+            memcpy(out, s.p, s.n + 1);
+            rc = (int)s.n;
+        }
+    }
+    sb_free(&s);
+    return rc;
+}
+
+/* ------------------------------------------------------------------ */
+/* Junction pieces (lib/src/junction.cc)                              */
+/* ------------------------------------------------------------------ */
+
+static int str4eq(const char *s, const char *lit) { return memcmp(s, lit, 4) == 0; }
+
+/* Junction::hasCanonicalSpliceSites :289-304, predictedStrandFromSpliceSites :306-326,
+ * setDonorAndAcceptorMotif :504-516.  CANONICAL_SEQ etc: junction.hpp:73-79. */
+int orc_donor_acceptor(const char *seq1, size_t n1, const char *seq2, size_t n2, int read_strand,
+                       int *ss_strand, int *cons_strand, uint8_t da1[2], uint8_t da2[2]) {
+    if (n1 != 2 || n2 != 2)
+        return fail(ORC_ERR_SPLICE_SITE_LEN, "Can't test for valid donor / acceptor when either string are not of length two");
+    char seq[4] = {seq1[0], seq1[1], seq2[0], seq2[1]};
+    /* reverse complements: GTAG->CTAC, ATAC->GTAT, GCAG->CTGC */
+    int css;
+    if (str4eq(seq, "GTAG") || str4eq(seq, "CTAC")) css = ORC_CSS_CANONICAL;
+    else if (str4eq(seq, "ATAC") || str4eq(seq, "GTAT") || str4eq(seq, "GCAG") || str4eq(seq, "CTGC")) css = ORC_CSS_SEMI;
+    else css = ORC_CSS_NO;
+    int ss;
+    if (str4eq(seq, "GTAG")) ss = ORC_STRAND_POS;
+    else if (str4eq(seq, "CTAC")) ss = ORC_STRAND_NEG;
+    else if (str4eq(seq, "ATAC") || str4eq(seq, "GCAG")) ss = ORC_STRAND_POS;
+    else if (str4eq(seq, "GTAT") || str4eq(seq, "CTGC")) ss = ORC_STRAND_NEG;
+    else ss = ORC_STRAND_UNK;
+    int cons = read_strand == ss ? read_strand
+               : read_strand == ORC_STRAND_UNK ? ss
+               : ss == ORC_STRAND_UNK ? read_strand
+                                      : ORC_STRAND_UNK;
+    if (cons == ORC_STRAND_NEG) {
+        orc_revcomp(seq2, 2, (char *)da1);
+        orc_revcomp(seq1, 2, (char *)da2);
+    } else {
+        memcpy(da1, seq1, 2);
+        memcpy(da2, seq2, 2);
+    }
+    *ss_strand = ss;
+    *cons_strand = cons;
+    return css;
+}
+
+/* Junction::calcEntropy(const vector<int32_t>), junction.cc:730-749 */
+double orc_entropy(const int32_t *p, size_t n) {
+    if (n <= 1) return 0;
+    double sum = 0.0;
+    int32_t lastOffset = p[0];
+    uint32_t readsAtOffset = 0;
+    for (size_t i = 0; i < n; i++) {
+        int32_t pos = p[i];
+        readsAtOffset++;
+        if (pos != lastOffset || i == n - 1) {
+            double pI = (double)readsAtOffset / (double)n;
+            sum += pI * log2(pI);
+            lastOffset = pos;
+            readsAtOffset = 0;
+        }
+    }
+    return fabs(sum);
+}
+
+/* substr helper with std::string semantics */
+static void substr(const char *s, size_t n, size_t pos, size_t cnt, const char **o, size_t *on) {
+    if (pos > n) pos = n; /* callers never exceed; keep defined */
+    size_t a = n - pos;
+    *o = s + pos;
+    *on = cnt < a ? cnt : a;
+}
+
+/* Junction::calcHammingScores, junction.cc:823-857 */
+int orc_hamming_scores(const char *la0, size_t nla, const char *li0, size_t nli, const char *ri0,
+                       size_t nri, const char *ra0, size_t nra, int cons_strand, uint32_t *h5,
+                       uint32_t *h3) {
+    int32_t leftDelta = (int32_t)(nla - nri);
+    int32_t leftOffset = leftDelta <= 0 ? 0 : leftDelta;
+    uint32_t leftLen = (uint32_t)(nla < nri ? nla : nri);
+    uint32_t rightLen = (uint32_t)(nli < nra ? nli : nra);
+    const char *la, *li, *ri, *ra;
+    size_t zla, zli, zri, zra;
+    if (nla > leftLen) substr(la0, nla, (size_t)leftOffset, leftLen, &la, &zla);
+    else { la = la0; zla = nla; }
+    if (nli > rightLen) substr(li0, nli, 0, rightLen, &li, &zli);
+    else { li = li0; zli = nli; }
+    if (nri > leftLen) substr(ri0, nri, (size_t)leftOffset, leftLen, &ri, &zri);
+    else { ri = ri0; zri = nri; }
+    if (nra > rightLen) substr(ra0, nra, 0, rightLen, &ra, &zra);
+    else { ra = ra0; zra = nra; }
+    char a5[16], i5[16], i3[16], a3[16];
+    size_t na5, ni5, ni3, na3;
+    if (zla > 15 || zli > 15 || zri > 15 || zra > 15) return fail(ORC_ERR_ARG, "hamming window > 15");
+    if (cons_strand == ORC_STRAND_NEG) {
+        orc_revcomp(ra, zra, a5); na5 = zra;
+        orc_revcomp(ri, zri, i5); ni5 = zri;
+        orc_revcomp(li, zli, i3); ni3 = zli;
+        orc_revcomp(la, zla, a3); na3 = zla;
+    } else {
+        memcpy(a5, la, zla); na5 = zla;
+        memcpy(i5, li, zli); ni5 = zli;
+        memcpy(i3, ri, zri); ni3 = zri;
+        memcpy(a3, ra, zra); na3 = zra;
+    }
+    int d5 = orc_hamming(a5, na5, i3, ni3);
+    if (d5 < 0) return d5;
+    int d3 = orc_hamming(a3, na3, i5, ni5);
+    if (d3 < 0) return d3;
+    *h5 = (uint32_t)d5;
+    *h3 = (uint32_t)d3;
+    return 0;
+}
+
+/* ------------------------------------------------------------------ */
+/* path: per-contig junction building                                 */
+/* ------------------------------------------------------------------ */
+
+typedef struct {
+    int64_t read; /* index into orc_reads */
+    /* AlignmentInfo stats, junction.hpp:138-171 (ctor zeroes all) */
+    uint32_t totalUpMatches, totalDownMatches, totalUpMism, totalDownMism;
+    uint32_t upMatches, downMatches, minMatch, maxMatch, nbMismatches, mmes;
+} alninfo;
+
+typedef struct {
+    orc_row r;
+    alninfo *al;
+    size_t n_al, cap_al;
+} junc;
+
+typedef struct {
+    int32_t start, end;
+    int64_t j; /* -1 empty */
+} hslot;
+
+typedef struct {
+    int32_t tid, ref_len;
+    const char *genome;
+    const orc_reads *rd;
+    junc *list;
+    size_t n, cap;
+    hslot *tab;
+    size_t tcap;
+} jsys;
+
+static uint64_t hkey(int32_t s, int32_t e) {
+    uint64_t x = ((uint64_t)(uint32_t)s << 32) | (uint32_t)e;
+    x ^= x >> 33;
+    x *= 0xff51afd7ed558ccdULL;
+    x ^= x >> 33;
+    x *= 0xc4ceb9fe1a85ec53ULL;
+    x ^= x >> 33;
+    return x;
+}
+
+static int tab_grow(jsys *js) {
+    size_t nc = js->tcap ? js->tcap * 2 : 1024;
+    hslot *nt = (hslot *)malloc(nc * sizeof(hslot));
+    if (!nt) return -1;
+    for (size_t i = 0; i < nc; i++) nt[i].j = -1;
+    for (size_t i = 0; i < js->tcap; i++) {
+        if (js->tab[i].j < 0) continue;
+        size_t h = hkey(js->tab[i].start, js->tab[i].end) & (nc - 1);
+        while (nt[h].j >= 0) h = (h + 1) & (nc - 1);
+        nt[h] = js->tab[i];
+    }
+    free(js->tab);
+    js->tab = nt;
+    js->tcap = nc;
+    return 0;
+}
+
+static int64_t tab_find(jsys *js, int32_t s, int32_t e) {
+    if (!js->tcap) return -1;
+    size_t h = hkey(s, e) & (js->tcap - 1);
+    while (js->tab[h].j >= 0) {
+        if (js->tab[h].start == s && js->tab[h].end == e) return js->tab[h].j;
+        h = (h + 1) & (js->tcap - 1);
+    }
+    return -1;
+}
+
+static int tab_put(jsys *js, int32_t s, int32_t e, int64_t j) {
+    if ((js->n + 1) * 2 > js->tcap && tab_grow(js)) return -1;
+    size_t h = hkey(s, e) & (js->tcap - 1);
+    while (js->tab[h].j >= 0) h = (h + 1) & (js->tcap - 1);
+    js->tab[h].start = s;
+    js->tab[h].end = e;
+    js->tab[h].j = j;
+    return 0;
+}
+
+static int nb_junctions_in_read(const orc_reads *rd, int64_t i) { /* bam_alignment.cc:303-311 */
+    int n = 0;
+    for (uint32_t k = rd->cig_off[i]; k < rd->cig_off[i + 1]; k++)
+        if (op_chr(rd->cigar[k]) == 'N') n++;
+    return n;
+}
+
+/* Junction::addJunctionAlignment, junction.cc:477-502 */
+static int add_junction_alignment(jsys *js, junc *j, int64_t i) {
+    if (j->n_al == j->cap_al) {
+        size_t nc = j->cap_al ? j->cap_al * 2 : 4;
+        alninfo *na = (alninfo *)realloc(j->al, nc * sizeof(alninfo));
+        if (!na) return fail(ORC_ERR_NOMEM, "oom");
+        j->al = na;
+        j->cap_al = nc;
+    }
+    alninfo *a = &j->al[j->n_al++];
+    memset(a, 0, sizeof *a);
+    a->read = i;
+    j->r.nb_raw = (uint32_t)j->n_al;
+    uint16_t flag = js->rd->flag[i];
+    int first = (flag & 0x40) != 0, rev = (flag & 0x10) != 0;
+    if (first) { if (!rev) j->r.r1pos++; else j->r.r1neg++; }
+    else       { if (!rev) j->r.r2pos++; else j->r.r2neg++; }
+    if (nb_junctions_in_read(js->rd, i) > 1) j->r.nb_ms++;
+    return 0;
+}
+
+/* JunctionSystem::addJunctions, junction_system.cc:140-210 (recursive, as written) */
+static int add_junctions(jsys *js, int64_t i, size_t startOp, int32_t offset, int *found) {
+    const orc_reads *rd = js->rd;
+    const uint32_t *cig = rd->cigar + rd->cig_off[i];
+    size_t nbOps = rd->cig_off[i + 1] - rd->cig_off[i];
+    int32_t lStart = offset, lEndExc = lStart, rStart = lStart, rEndExc = lStart;
+    for (size_t k = startOp; k < nbOps; k++) {
+        char type = op_chr(cig[k]);
+        int32_t length = op_len(cig[k]);
+        if (type == 'N') {
+            *found = 1;
+            int32_t refLength = js->ref_len;
+            rStart = lEndExc + length;
+            rEndExc = rStart;
+            size_t j = k + 1;
+            while (j < nbOps && rEndExc <= refLength && op_chr(cig[j]) != 'N') {
+                uint32_t r = cig[j++];
+                if (consumes_ref(op_chr(r))) rEndExc += op_len(r);
+            }
+            if (rStart - 1 >= refLength) rStart = refLength - 1; /* :169-171 */
+            if (rEndExc - 1 >= refLength) rEndExc = refLength;   /* :172-174 */
+            int32_t istart = lEndExc, iend = rStart - 1;
+            int64_t jx = tab_find(js, istart, iend);
+            if (jx < 0) {
+                /* Junction ctor, junction.cc:328-387: maxMinAnchor = minAnchorLength(...) */
+                int64_t mma = orc_min_anchor(istart, iend, lStart, rEndExc - 1);
+                if (mma < 0) return (int)mma;
+                if (js->n == js->cap) {
+                    size_t nc = js->cap ? js->cap * 2 : 256;
+                    junc *nl = (junc *)realloc(js->list, nc * sizeof(junc));
+                    if (!nl) return fail(ORC_ERR_NOMEM, "oom");
+                    js->list = nl;
+                    js->cap = nc;
+                }
+                junc *J = &js->list[js->n];
+                memset(J, 0, sizeof *J);
+                J->r.refid = js->tid;
+                J->r.start = istart;
+                J->r.end = iend;
+                J->r.left = lStart;
+                J->r.right = rEndExc - 1;
+                J->r.read_strand = J->r.ss_strand = J->r.cons_strand = ORC_STRAND_UNK;
+                J->r.canonical = ORC_CSS_NO;
+                J->r.max_min_anc = (uint32_t)mma;
+                J->r.hamming5p = J->r.hamming3p = 10;
+                int rc = add_junction_alignment(js, J, i);
+                if (rc) return rc;
+                if (tab_put(js, istart, iend, (int64_t)js->n)) return fail(ORC_ERR_NOMEM, "oom");
+                js->n++;
+            } else {
+                junc *J = &js->list[jx];
+                int rc = add_junction_alignment(js, J, i);
+                if (rc) return rc;
+                /* Junction::extendAnchors, junction.cc:524-529 */
+                int32_t oS = lStart, oE = rEndExc - 1;
+                if (oS < J->r.left) J->r.left = oS;
+                if (oE > J->r.right) J->r.right = oE;
+                int64_t mma = orc_min_anchor(J->r.start, J->r.end, oS, oE);
+                if (mma < 0) return (int)mma;
+                if ((uint32_t)mma > J->r.max_min_anc) J->r.max_min_anc = (uint32_t)mma;
+            }
+            if (j < nbOps) { /* :199-202 */
+                int dummy = 0;
+                int rc = add_junctions(js, i, k + 1, rStart, &dummy);
+                if (rc) return rc;
+                break;
+            }
+        } else if (consumes_ref(type)) {
+            lEndExc += length;
+        }
+    }
+    return 0;
+}
+
+static int32_t aligned_length(const orc_reads *rd, int64_t i) { /* bam_alignment.cc:78-88 */
+    int32_t a = 0;
+    for (uint32_t k = rd->cig_off[i]; k < rd->cig_off[i + 1]; k++)
+        if (consumes_ref(op_chr(rd->cigar[k]))) a += op_len(rd->cigar[k]);
+    return a;
+}
+
+/* read strand: BamAlignment::init :89-99 -> XS tag else calcStrand(), which
+ * returns UNKNOWN because the reader's alignments carry Strandedness::UNKNOWN
+ * (bam_alignment.cc:154-165, bam_reader.hpp:68). */
+static int read_strand(const orc_reads *rd, int64_t i) {
+    switch (rd->xs[i]) {
+    case 1: return ORC_STRAND_POS;
+    case 2: return ORC_STRAND_NEG;
+    default: return ORC_STRAND_UNK;
+    }
+}
+
+/* BamAlignment::calcIfProperPair, bam_alignment.cc:271-292 */
+static int calc_if_proper_pair(const orc_reads *rd, int64_t i, int32_t tid, int orientation) {
+    uint16_t f = rd->flag[i];
+    int paired = (f & 0x1) != 0, mateMapped = !(f & 0x8);
+    if (!paired || !mateMapped) return 0;
+    if (tid != rd->mtid[i]) return 0;
+    int rev = (f & 0x10) != 0, mrev = (f & 0x20) != 0;
+    int diffStrand = rev != mrev;
+    int posGap = !rev ? rd->pos[i] < rd->mpos[i] : rd->pos[i] > rd->mpos[i];
+    if (orientation == ORC_OR_FR) return diffStrand && posGap;
+    if (orientation == ORC_OR_RF) return diffStrand && !posGap;
+    if (orientation == ORC_OR_FF) return !diffStrand && posGap;
+    return 0;
+}
+
+static int cmp_i32(const void *a, const void *b) {
+    int32_t x = *(const int32_t *)a, y = *(const int32_t *)b;
+    return x < y ? -1 : x > y;
+}
+
+/* Junction::calcMetrics(orientation), junction.cc:683-687 */
+static int calc_metrics(jsys *js, junc *J, int orientation) {
+    const orc_reads *rd = js->rd;
+    /* determineStrandFromReads :531-559 */
+    uint32_t nb_pos = 0, nb_neg = 0, nb_unk = 0;
+    for (size_t a = 0; a < J->n_al; a++) {
+        switch (read_strand(rd, J->al[a].read)) {
+        case ORC_STRAND_POS: nb_pos++; break;
+        case ORC_STRAND_NEG: nb_neg++; break;
+        default: nb_unk++; break;
+        }
+    }
+    uint32_t total = nb_pos + nb_neg + nb_unk;
+    const double threshold = 0.95;
+    if ((double)nb_pos / (double)total >= threshold) J->r.read_strand = ORC_STRAND_POS;
+    else if ((double)nb_neg / (double)total >= threshold) J->r.read_strand = ORC_STRAND_NEG;
+    else J->r.read_strand = ORC_STRAND_UNK;
+    /* calcEntropy :718-728 */
+    int32_t *pp = (int32_t *)malloc((J->n_al ? J->n_al : 1) * sizeof(int32_t));
+    if (!pp) return fail(ORC_ERR_NOMEM, "oom");
+    for (size_t a = 0; a < J->n_al; a++) pp[a] = rd->pos[J->al[a].read];
+    qsort(pp, J->n_al, sizeof(int32_t), cmp_i32);
+    if (J->n_al > 1) J->r.entropy = orc_entropy(pp, J->n_al); /* n<=1 returns 0 without storing */
+    free(pp);
+    /* calcAlignmentStats :755-814 */
+    int32_t lastStart = -1, lastEnd = -1;
+    J->r.nb_dist = 0;
+    J->r.nb_rel = 0;
+    J->r.nb_up_juncs = 0;
+    J->r.nb_down_juncs = 0;
+    int properPairedCheck = orientation == ORC_OR_FR || orientation == ORC_OR_FF || orientation == ORC_OR_RF;
+    for (size_t a = 0; a < J->n_al; a++) {
+        int64_t i = J->al[a].read;
+        int32_t start = rd->pos[i];
+        int32_t end = rd->pos[i] + aligned_length(rd, i) - 1;
+        if (start != lastStart || end != lastEnd) {
+            J->r.nb_dist++;
+            lastStart = start;
+            lastEnd = end;
+        }
+        int reliable = 1;
+        if (rd->mapq[i] >= 30) J->r.nb_um++; /* MAP_QUALITY_THRESHOLD junction.hpp:65 */
+        else reliable = 0;
+        if (rd->flag[i] & 0x2) J->r.nb_bpp++;
+        if (properPairedCheck) {
+            if (calc_if_proper_pair(rd, i, js->tid, orientation)) J->r.nb_ppp++;
+            else reliable = 0;
+        }
+        if (reliable) J->r.nb_rel++;
+        uint32_t upj = 0, downj = 0;
+        int32_t pos = start;
+        for (uint32_t k = rd->cig_off[i]; k < rd->cig_off[i + 1]; k++) {
+            char type = op_chr(rd->cigar[k]);
+            if (consumes_ref(type)) pos += op_len(rd->cigar[k]);
+            if (type == 'N') {
+                if (pos < J->r.start) upj++;
+                else if (pos > J->r.end + 1) downj++;
+            }
+        }
+        if (upj > J->r.nb_up_juncs) J->r.nb_up_juncs = upj;
+        if (downj > J->r.nb_down_juncs) J->r.nb_down_juncs = downj;
+    }
+    return 0;
+}
+
+/* faidx_fetch_seq clamping, deps/htslib-1.3/faidx.c:439-476, on an in-memory contig. */
+static void fetch_bases(const char *genome, int32_t glen, int32_t beg, int32_t end, sbuf *out) {
+    if (end < beg) beg = end;
+    if (beg < 0) beg = 0;
+    else if (glen <= beg) beg = glen - 1;
+    if (end < 0) end = 0;
+    else if (glen <= end) end = glen - 1;
+    out->n = 0;
+    sb_reserve(out, 1);
+    out->p[0] = 0;
+    if (glen <= 0) return;
+    sb_put(out, genome + beg, (size_t)(end - beg + 1));
+}
+
+static void to_upper(sbuf *s) {
+    for (size_t i = 0; i < s->n; i++) s->p[i] = up(s->p[i]);
+}
+
+static const char NT16[] = "=ACMGRSVTWYHKDBN"; /* seq_nt16_str, deps/htslib-1.3/hts.c */
+
+/* BamAlignment::getQuerySeq, bam_alignment.cc:244-250 */
+static int get_query_seq(const orc_reads *rd, int64_t i, sbuf *out) {
+    out->n = 0;
+    if (sb_reserve(out, (size_t)(rd->l_qseq[i] > 0 ? rd->l_qseq[i] : 0) + 1)) return -1;
+    out->p[0] = 0;
+    const uint8_t *s = rd->seq4 + rd->seq_off[i];
+    for (int32_t k = 0; k < rd->l_qseq[i]; k++) {
+        uint8_t b = s[k >> 1];
+        int c = (k & 1) ? (b & 0xf) : (b >> 4);
+        out->p[out->n++] = NT16[c];
+    }
+    out->p[out->n] = 0;
+    return 0;
+}
+
+/* AlignmentInfo::getNbMatchesFromStart / FromEnd, junction.cc:263-280 */
+static uint32_t matches_from_start(const char *q, const char *a, size_t n) {
+    for (size_t i = 0; i < n; i++)
+        if (q[i] != a[i]) return (uint32_t)i;
+    return (uint32_t)n;
+}
+static uint32_t matches_from_end(const char *q, const char *a, size_t n) {
+    for (size_t j = n; j > 0; j--) {
+        size_t i = j - 1;
+        if (q[i] != a[i]) return (uint32_t)(n - i - 1);
+    }
+    return (uint32_t)n;
+}
+
+/* AlignmentInfo::calcMatchStats, junction.cc:147-240 */
+static int calc_match_stats(jsys *js, junc *J, alninfo *A, const sbuf *ancLeft, const sbuf *ancRight,
+                            sbuf *query, sbuf *qL, sbuf *qR, sbuf *gL, sbuf *gR) {
+    const orc_reads *rd = js->rd;
+    int64_t i = A->read;
+    uint32_t leftStart = (uint32_t)J->r.left, rightEnd = (uint32_t)J->r.right;
+    int32_t leftEnd = J->r.start - 1, rightStart = J->r.end + 1;
+    int32_t qLeftStart = (int32_t)leftStart, qLeftEnd = leftEnd, qRightStart = rightStart, qRightEnd = (int32_t)rightEnd;
+    if (get_query_seq(rd, i, query)) return fail(ORC_ERR_NOMEM, "oom");
+    if (query->n <= 1) { /* :168-185 */
+        A->totalUpMism = 0;
+        A->totalDownMism = 0;
+        A->totalUpMatches = (uint32_t)(leftEnd - (int32_t)leftStart + 1);
+        A->totalDownMatches = (uint32_t)((int32_t)rightEnd - rightStart + 1);
+        A->nbMismatches = 0;
+        A->upMatches = 0;
+        A->downMatches = 0;
+        A->minMatch = 0;
+        A->maxMatch = 0;
+        A->mmes = A->totalUpMatches < A->totalDownMatches ? A->totalUpMatches : A->totalDownMatches;
+        return 0;
+    }
+    const uint32_t *cig = rd->cigar + rd->cig_off[i];
+    int nc = (int)(rd->cig_off[i + 1] - rd->cig_off[i]);
+    int32_t pos = rd->pos[i], alen = aligned_length(rd, i);
+    int rc;
+    if ((rc = padded_query(cig, nc, pos, alen, query->p, query->n, (int32_t)leftStart, leftEnd, &qLeftStart, &qLeftEnd, qL))) return rc;
+    if ((rc = padded_query(cig, nc, pos, alen, query->p, query->n, rightStart, (int32_t)rightEnd, &qRightStart, &qRightEnd, qR))) return rc;
+    if ((rc = padded_genome(cig, nc, pos, alen, ancLeft->p, ancLeft->n, (int32_t)leftStart, leftEnd, qLeftStart, qLeftEnd, gL))) return rc;
+    if ((rc = padded_genome(cig, nc, pos, alen, ancRight->p, ancRight->n, rightStart, (int32_t)rightEnd, qRightStart, qRightEnd, gR))) return rc;
+    if (qL->n != gL->n || qL->n == 0)
+        return fail(ORC_ERR_ANCHOR_MISMATCH, "Left anchor region for query and genome are not the same size (%zu vs %zu), read %lld", qL->n, gL->n, (long long)i);
+    if (qR->n != gR->n || qR->n == 0)
+        return fail(ORC_ERR_ANCHOR_MISMATCH, "Right Anchor region for query and genome are not the same size (%zu vs %zu), read %lld", qR->n, gR->n, (long long)i);
+    int hl = orc_hamming(qL->p, qL->n, gL->p, gL->n);
+    int hr = orc_hamming(qR->p, qR->n, gR->p, gR->n);
+    A->totalUpMism = (uint32_t)hl;
+    A->totalDownMism = (uint32_t)hr;
+    A->totalUpMatches = (uint32_t)(qL->n - (size_t)hl);
+    A->totalDownMatches = (uint32_t)(qR->n - (size_t)hr);
+    A->nbMismatches = A->totalUpMism + A->totalDownMism;
+    A->upMatches = matches_from_end(qL->p, gL->p, qL->n);
+    A->downMatches = matches_from_start(qR->p, gR->p, qR->n);
+    A->minMatch = A->upMatches < A->downMatches ? A->upMatches : A->downMatches;
+    A->maxMatch = A->upMatches > A->downMatches ? A->upMatches : A->downMatches;
+    A->mmes = A->totalUpMatches < A->totalDownMatches ? A->totalUpMatches : A->totalDownMatches;
+    return 0;
+}
+
+/* Junction::processJunctionWindow, junction.cc:561-649 */
+static int process_junction_window(jsys *js, junc *J) {
+    sbuf donor = {0}, acceptor = {0}, leftAnc = {0}, rightAnc = {0}, leftInt = {0}, rightInt = {0};
+    sbuf query = {0}, qL = {0}, qR = {0}, gL = {0}, gR = {0};
+    int rc = 0;
+    fetch_bases(js->genome, js->ref_len, J->r.start, J->r.start + 1, &donor);
+    fetch_bases(js->genome, js->ref_len, J->r.end - 1, J->r.end, &acceptor);
+    if (donor.n != 2 || acceptor.n != 2) {
+        rc = fail(ORC_ERR_SPLICE_SITE_LEN, "Retrieved sequence for splice site of junction (%d,%d) is not the expected length", J->r.start, J->r.end);
+        goto done;
+    }
+    to_upper(&donor);
+    to_upper(&acceptor);
+    {
+        int ss, cons;
+        int css = orc_donor_acceptor(donor.p, 2, acceptor.p, 2, J->r.read_strand, &ss, &cons, J->r.da1, J->r.da2);
+        if (css < 0) { rc = css; goto done; }
+        J->r.canonical = (uint8_t)css;
+        J->r.ss_strand = (uint8_t)ss;
+        J->r.cons_strand = (uint8_t)cons;
+    }
+    fetch_bases(js->genome, js->ref_len, J->r.left, J->r.start - 1, &leftAnc);
+    fetch_bases(js->genome, js->ref_len, J->r.end + 1, J->r.right, &rightAnc);
+    fetch_bases(js->genome, js->ref_len, J->r.start, J->r.start + 9, &leftInt);
+    fetch_bases(js->genome, js->ref_len, J->r.end - 9, J->r.end, &rightInt);
+    {
+        int expLeftLen = J->r.start - J->r.left;
+        if ((int)leftAnc.n != expLeftLen && expLeftLen > 0) { rc = fail(ORC_ERR_ANCHOR_LEN, "Retrieved sequence for left anchor of junction (%d,%d) is not the expected length", J->r.start, J->r.end); goto done; }
+        int expRightLen = J->r.right - J->r.end;
+        if ((int)rightAnc.n != expRightLen && expRightLen > 0) { rc = fail(ORC_ERR_ANCHOR_LEN, "Retrieved sequence for right anchor of junction (%d,%d) is not the expected length", J->r.start, J->r.end); goto done; }
+        if (leftInt.n != 10 || rightInt.n != 10) { rc = fail(ORC_ERR_INTRON_FLANK_LEN, "Retrieved sequence for intron region of junction (%d,%d) is not the expected length", J->r.start, J->r.end); goto done; }
+    }
+    to_upper(&leftAnc);
+    to_upper(&rightAnc);
+    to_upper(&leftInt);
+    to_upper(&rightInt);
+    {
+        const char *la10 = leftAnc.n < 10 ? leftAnc.p : leftAnc.p + (leftAnc.n - 10);
+        size_t nla10 = leftAnc.n < 10 ? leftAnc.n : 10;
+        size_t nra10 = rightAnc.n < 10 ? rightAnc.n : 10;
+        rc = orc_hamming_scores(la10, nla10, leftInt.p, leftInt.n, rightInt.p, rightInt.n, rightAnc.p, nra10, J->r.cons_strand, &J->r.hamming5p, &J->r.hamming3p);
+        if (rc) goto done;
+    }
+    for (size_t a = 0; a < J->n_al; a++) {
+        rc = calc_match_stats(js, J, &J->al[a], &leftAnc, &rightAnc, &query, &qL, &qR, &gL, &gR);
+        if (rc) goto done;
+    }
+    /* calcMismatchStats, junction.cc:862-909 (aJAD/junctionAnchorClarity never reach output) */
+    {
+        uint32_t nbMismatches = 0, firstMismatch = 100000000;
+        for (size_t a = 0; a < J->n_al; a++) {
+            alninfo *A = &J->al[a];
+            if (A->mmes > J->r.maxmmes) J->r.maxmmes = A->mmes;
+            nbMismatches += A->nbMismatches;
+            if (A->minMatch > 0 && A->minMatch < firstMismatch) firstMismatch = A->minMatch;
+            for (uint16_t k = 0; k < 20 && k < A->minMatch; k++) J->r.jad[k]++;
+        }
+        J->r.sum_mismatches = nbMismatches;
+        J->r.mean_mismatches = (double)nbMismatches / (double)J->n_al;
+        if (nbMismatches > 0 && firstMismatch < 20) {
+            int found = 0;
+            for (size_t a = 0; a < J->n_al; a++)
+                if (J->al[a].minMatch > firstMismatch) { found = 1; break; }
+            if (!found) J->r.suspicious = 1;
+        }
+    }
+done:
+    sb_free(&donor); sb_free(&acceptor); sb_free(&leftAnc); sb_free(&rightAnc);
+    sb_free(&leftInt); sb_free(&rightInt); sb_free(&query); sb_free(&qL); sb_free(&qR);
+    sb_free(&gL); sb_free(&gR);
+    return rc;
+}
+
+/* JunctionBuilder::findJuncs, src/junction_builder.cc:314-357.  Junctions are
+ * finalised after the read loop instead of as soon as `al.pos > intron.end`
+ * (:324-331); with coordinate-sorted input the two are equivalent because no
+ * later read can support an already-passed intron. */
+int orc_find_juncs(int32_t tid, int32_t ref_len, const char *genome, const orc_reads *rd,
+                   int orientation, orc_row **rows_out, int64_t *n_rows_out, orc_region *reg) {
+    jsys js;
+    memset(&js, 0, sizeof js);
+    js.tid = tid;
+    js.ref_len = ref_len;
+    js.genome = genome;
+    js.rd = rd;
+    int rc = 0;
+    uint64_t spliced = 0, unspliced = 0, sumLen = 0;
+    int32_t minLen = INT32_MAX, maxLen = 0;
+    *rows_out = NULL;
+    *n_rows_out = 0;
+    for (int64_t i = 0; i < rd->n; i++) {
+        if (rd->xs[i] == 3) { rc = fail(ORC_ERR_BAD_XS, "Unknown strand (XS tag) on read %lld", (long long)i); goto done; }
+        if (i > 0 && rd->pos[i] < rd->pos[i - 1]) { rc = fail(ORC_ERR_UNSORTED, "reads are not coordinate sorted at %lld", (long long)i); goto done; }
+        int32_t len = rd->l_qseq[i];
+        if (len < minLen) minLen = len;
+        if (len > maxLen) maxLen = len;
+        sumLen += (uint64_t)(int64_t)len;
+        int found = 0;
+        rc = add_junctions(&js, i, 0, rd->pos[i], &found);
+        if (rc) goto done;
+        if (found) spliced++;
+        else unspliced++;
+    }
+    for (size_t j = 0; j < js.n; j++) {
+        rc = calc_metrics(&js, &js.list[j], orientation);
+        if (rc) goto done;
+        rc = process_junction_window(&js, &js.list[j]);
+        if (rc) goto done;
+    }
+    {
+        orc_row *rows = (orc_row *)malloc((js.n ? js.n : 1) * sizeof(orc_row));
+        if (!rows) { rc = fail(ORC_ERR_NOMEM, "oom"); goto done; }
+        for (size_t j = 0; j < js.n; j++) rows[j] = js.list[j].r;
+        *rows_out = rows;
+        *n_rows_out = (int64_t)js.n;
+    }
+    if (reg) {
+        reg->spliced = spliced;
+        reg->unspliced = unspliced;
+        reg->sum_len = sumLen;
+        reg->min_len = minLen;
+        reg->max_len = maxLen;
+    }
+done:
+    for (size_t j = 0; j < js.n; j++) free(js.list[j].al);
+    free(js.list);
+    free(js.tab);
+    return rc;
+}
+
+void orc_free_rows(orc_row *rows) { free(rows); }
+
+/* ------------------------------------------------------------------ */
+/* merge: sort / index / calcJunctionStats                            */
+/* ------------------------------------------------------------------ */
+
+/* JunctionComparator -> IntronComparator, junction.hpp:1415-1420, intron.cc:111-127 */
+static int cmp_row(const void *a, const void *b) {
+    const orc_row *x = (const orc_row *)a, *y = (const orc_row *)b;
+    if (x->refid != y->refid) return x->refid < y->refid ? -1 : 1;
+    if (x->start != y->start) return x->start < y->start ? -1 : 1;
+    if (x->end != y->end) return x->end < y->end ? -1 : 1;
+    return 0;
+}
+
+static int shares(const orc_row *a, const orc_row *b) { /* intron.cc:55-58 */
+    return a->refid == b->refid && (a->start == b->start || a->end == b->end);
+}
+
+void orc_finalize(orc_row *rows, int64_t n, double meanQueryLength) {
+    qsort(rows, (size_t)n, sizeof(orc_row), cmp_row); /* junction_system.cc:322-324 */
+    for (int64_t i = 0; i < n; i++) rows[i].id = (uint32_t)i; /* :326-330 */
+    if (n <= 1) return; /* src/junction_builder.cc:285 */
+    /* calcJunctionStats, junction_system.cc:250-320; createJunctionGroup :55-70 */
+    for (int64_t i = 0; i < n; i++) {
+        int64_t gs = i, ge = i; /* group = rows[gs..ge] */
+        {
+            int64_t cur = i, ret = n - 1;
+            for (int64_t j = i + 1; j < n; j++) {
+                if (shares(&rows[cur], &rows[j])) { ge = j; cur = j; }
+                else { ret = j - 1; break; }
+            }
+            i = ret;
+        }
+        uint32_t maxReads = 0;
+        int64_t maxIndex = 0;
+        int uniqueJunction = (ge - gs + 1) == 1;
+        for (int64_t j = 0; j <= ge - gs; j++) {
+            orc_row *r = &rows[gs + j];
+            if (maxReads < r->nb_raw) { maxReads = r->nb_raw; maxIndex = j; }
+            r->uniq = (uint8_t)uniqueJunction;
+        }
+        rows[gs + maxIndex].primary = 1;
+    }
+    {
+        int64_t i = 0;
+        int lastdiffseq = 0;
+        while (i < n - 1) {
+            orc_row *first = &rows[i], *second = &rows[i + 1];
+            int32_t diff = second->start - first->end;
+            diff = diff < 0 ? 0 : diff;
+            if (first->refid != second->refid) {
+                first->dist_up = (uint32_t)-1;
+                second->dist_down = (uint32_t)-1;
+                if (i == 0 || lastdiffseq) first->dist_down = (uint32_t)-1;
+                if (i == n - 2) second->dist_up = (uint32_t)-1;
+                lastdiffseq = 1;
+            } else if (i == 0) {
+                first->dist_down = (uint32_t)-1;
+                first->dist_up = (uint32_t)diff;
+                second->dist_down = (uint32_t)diff;
+                lastdiffseq = 0;
+            } else if (i == n - 2) {
+                first->dist_up = (uint32_t)diff;
+                second->dist_down = (uint32_t)diff;
+                second->dist_up = (uint32_t)-1;
+                lastdiffseq = 0;
+            } else {
+                first->dist_up = (uint32_t)diff;
+                second->dist_down = (uint32_t)diff;
+                lastdiffseq = 0;
+            }
+            i++;
+        }
+    }
+    for (int64_t i = 0; i < n; i++) {
+        orc_row *r = &rows[i];
+        int32_t down = (int32_t)r->dist_down, upd = (int32_t)r->dist_up;
+        int32_t nearest = (down == -1 || upd == -1) ? (down > upd ? down : upd) : (down < upd ? down : upd);
+        r->dist_nearest = (uint32_t)nearest;
+        r->mean_readlen = (double)(uint32_t)meanQueryLength; /* setMeanReadLength(uint32_t), junction.hpp:928 */
+        if (r->suspicious) {
+            double prob = 1.0 - pow(((double)r->maxmmes / (meanQueryLength / 2.0)), (double)r->nb_raw);
+            if (prob > 0.99) r->pfp = 1;
+        }
+    }
+}
+
+/* ------------------------------------------------------------------ */
+/* writers                                                            */
+/* ------------------------------------------------------------------ */
+static char strand_chr(int s) { return s == ORC_STRAND_POS ? '+' : s == ORC_STRAND_NEG ? '-' : '?'; }
+static char css_chr(int c) { return c == ORC_CSS_CANONICAL ? 'C' : c == ORC_CSS_SEMI ? 'S' : 'N'; }
+
+static const char *TAB_HEADER =
+    "index\trefid\trefname\treflen\tstart\tend\tsize\tleft\tright\tread-strand\tss-strand\tconsensus-strand\tss1\tss2\t"
+    "canonical_ss\tscore\tsuspicious\tpfp\tnb_raw_aln\tnb_dist_aln\tnb_us_aln\tnb_ms_aln\tnb_um_aln\tnb_mm_aln\tnb_bpp_aln\t"
+    "nb_ppp_aln\tnb_rel_aln\trel2raw\tnb_r1_pos\tnb_r1_neg\tnb_r2_pos\tnb_r2_neg\tentropy\tmean_mismatches\tmean_readlen\t"
+    "max_min_anc\tmaxmmes\tintron_score\thamming5p\thamming3p\tcoding\tpws\tsplice_sig\tuniq_junc\tprimary_junc\tnb_up_juncs\t"
+    "nb_down_juncs\tdist_2_up_junc\tdist_2_down_junc\tdist_nearest_junc\tmm_score\tcoverage\tup_aln\tdown_aln\tnb_samples\t"
+    "JAD01\tJAD02\tJAD03\tJAD04\tJAD05\tJAD06\tJAD07\tJAD08\tJAD09\tJAD10\tJAD11\tJAD12\tJAD13\tJAD14\tJAD15\tJAD16\tJAD17\t"
+    "JAD18\tJAD19\tJAD20";
+
+/* operator<<(ostream&, Junction&), junction.hpp:1260-1319: default ostream => %g, bools 0/1 */
+char *orc_write_tab(const orc_row *rows, int64_t n, const char *const *ref_names,
+                    const int32_t *ref_lens, size_t *len_out) {
+    sbuf s = {0};
+    sb_printf(&s, "%s\n", TAB_HEADER);
+    for (int64_t i = 0; i < n; i++) {
+        const orc_row *r = &rows[i];
+        sb_printf(&s, "%u\t%d\t%s\t%d\t%d\t%d\t%u\t%d\t%d\t%c\t%c\t%c\t", r->id, r->refid, ref_names[r->refid],
+                  ref_lens[r->refid], r->start, r->end, (uint32_t)(r->end - r->start + 1), r->left, r->right,
+                  strand_chr(r->read_strand), strand_chr(r->ss_strand), strand_chr(r->cons_strand));
+        sb_put(&s, (const char *)r->da1, 2);
+        sb_put(&s, "\t", 1);
+        sb_put(&s, (const char *)r->da2, 2);
+        sb_printf(&s, "\t%c\t0\t%d\t%d\t%u\t%u\t%u\t%u\t%u\t%u\t%u\t%u\t%u\t%g\t%u\t%u\t%u\t%u\t%g\t%g\t%g\t%u\t%u\t0\t%u\t%u\t0\t0\t0\t%d\t%d\t%u\t%u\t%u\t%u\t%u\t0\t0\t0\t0\t1",
+                  css_chr(r->canonical), r->suspicious, r->pfp, r->nb_raw, r->nb_dist, r->nb_raw - r->nb_ms,
+                  r->nb_ms, r->nb_um, r->nb_raw - r->nb_um, r->nb_bpp, r->nb_ppp, r->nb_rel,
+                  (double)r->nb_rel / (double)r->nb_raw, r->r1pos, r->r1neg, r->r2pos, r->r2neg, r->entropy,
+                  r->mean_mismatches, r->mean_readlen, r->max_min_anc, r->maxmmes, r->hamming5p, r->hamming3p,
+                  r->uniq, r->primary, r->nb_up_juncs, r->nb_down_juncs, r->dist_up, r->dist_down, r->dist_nearest);
+        for (int k = 0; k < 20; k++) sb_printf(&s, "\t%u", r->jad[k]);
+        sb_put(&s, "\n", 1);
+    }
+    sb_put(&s, "\n", 1); /* saveAll streams `(*this) << endl`, junction_system.cc:356 */
+    *len_out = s.n;
+    return s.p;
+}
+
+/* JunctionSystem::outputBED junction_system.cc:411-418 + Junction::outputBED junction.cc:1189-1214 */
+char *orc_write_bed(const orc_row *rows, int64_t n, const char *const *ref_names, const char *source,
+                    const char *version, size_t *len_out) {
+    sbuf s = {0};
+    sb_printf(&s, "track name=\"junctions\" description=\"Portcullis V%s junctions\"\n", (version && version[0]) ? version : "X.X.X");
+    for (int64_t i = 0; i < n; i++) {
+        const orc_row *r = &rows[i];
+        char strand = r->cons_strand == ORC_STRAND_UNK ? '.' : strand_chr(r->cons_strand);
+        sb_printf(&s, "%s\t%d\t%d\t%s_%u\t%.3f\t%c\t%d\t%d\t255,0,0\t2\t%d,%d\t0,%d\n", ref_names[r->refid], r->left,
+                  r->right + 1, source, r->id, (double)r->nb_raw, strand, r->start, r->end + 1, r->start - r->left,
+                  r->right - r->end, r->end - r->left + 1);
+    }
+    *len_out = s.n;
+    return s.p;
+}
+
+/* Junction::outputIntronGFF, junction.cc:1102-1129 */
+char *orc_write_intron_gff(const orc_row *rows, int64_t n, const char *const *ref_names,
+                           const char *source, size_t *len_out) {
+    sbuf s = {0};
+    sb_reserve(&s, 1);
+    s.p[0] = 0;
+    for (int64_t i = 0; i < n; i++) {
+        const orc_row *r = &rows[i];
+        char strand = r->cons_strand == ORC_STRAND_UNK ? '?' : strand_chr(r->cons_strand);
+        sb_printf(&s, "%s\t%s\tintron\t%d\t%d\t%u\t%c\t.\tmult=%u;grp=junc_%u;src=E\n", ref_names[r->refid], source,
+                  r->start + 1, r->end + 1, r->nb_raw, strand, r->nb_raw, r->id);
+    }
+    *len_out = s.n;
+    return s.p;
+}
+
+void orc_free_text(char *p) { free(p); }

@@ -1,0 +1,267 @@
+"""Pure-Python BAM / BGZF / BAI / FASTA helpers for tests (no htslib in the image).
+
+The reader feeds the CPU oracle; the writer builds prep directories
+(`portcullis.sorted.alignments.bam[.bai]`, `portcullis.genome.fa[.fai]`,
+names from src/prepare.hpp:114-140) for the product's own C++ BAM reader, so
+the two sides parse files with independent code.
+"""
+import gzip
+import os
+import struct
+import zlib
+
+import numpy as np
+
+from portcullis_amd.records import CIGAR_CHARS, NT16, ReadBatch, encode_cigar, encode_seq
+
+PREP_BAM = "portcullis.sorted.alignments.bam"
+PREP_FA = "portcullis.genome.fa"
+
+
+# ------------------------------------------------------------------ reading
+def read_bam(path):
+    """Returns (refs [(name, len)], records list of dicts incl. 'tid')."""
+    with gzip.open(path, "rb") as f:
+        data = f.read()
+    assert data[:4] == b"BAM\x01"
+    (l_text,) = struct.unpack_from("<i", data, 4)
+    o = 8 + l_text
+    (n_ref,) = struct.unpack_from("<i", data, o)
+    o += 4
+    refs = []
+    for _ in range(n_ref):
+        (l_name,) = struct.unpack_from("<i", data, o)
+        o += 4
+        name = data[o:o + l_name - 1].decode()
+        o += l_name
+        (l_ref,) = struct.unpack_from("<i", data, o)
+        o += 4
+        refs.append((name, l_ref))
+    recs = []
+    while o < len(data):
+        (bs,) = struct.unpack_from("<i", data, o)
+        o += 4
+        end = o + bs
+        tid, pos, l_rn, mapq, _bin, n_cig, flag, l_seq, mtid, mpos, _tlen = struct.unpack_from("<iiBBHHHiiii", data, o)
+        p = o + 32
+        name = data[p:p + l_rn - 1].decode()
+        p += l_rn
+        cigar = np.frombuffer(data, dtype="<u4", count=n_cig, offset=p).copy()
+        p += 4 * n_cig
+        nb = (l_seq + 1) // 2
+        seq4 = np.frombuffer(data, dtype=np.uint8, count=nb, offset=p).copy()
+        p += nb + l_seq
+        xs = None
+        has_xs = False
+        while p < end:  # aux
+            tag = data[p:p + 2]
+            ty = chr(data[p + 2])
+            p += 3
+            if ty == "A":
+                val = chr(data[p]); p += 1
+            elif ty in "cC":
+                val = None; p += 1
+            elif ty in "sS":
+                val = None; p += 2
+            elif ty in "iIf":
+                val = None; p += 4
+            elif ty in "ZH":
+                e = data.index(b"\x00", p); val = None; p = e + 1
+            elif ty == "B":
+                sub = chr(data[p]); (cnt,) = struct.unpack_from("<i", data, p + 1)
+                p += 5 + cnt * {"c": 1, "C": 1, "s": 2, "S": 2, "i": 4, "I": 4, "f": 4}[sub]
+                val = None
+            else:
+                raise ValueError("bad aux type " + ty)
+            if tag == b"XS" and not has_xs:
+                has_xs = True
+                xs = val if ty == "A" else "\x00"  # bam_aux2A returns 0 for non-'A' types
+        recs.append(dict(tid=tid, pos=pos, mapq=mapq, flag=flag, mtid=mtid, mpos=mpos, name=name, cigar=cigar,
+                         l_qseq=l_seq, seq4=seq4, xs=xs))
+        o = end
+    return refs, recs
+
+
+def records_to_batch(recs):
+    """List of read_bam() records (one contig, file order) -> ReadBatch."""
+    out = []
+    for r in recs:
+        if r["l_qseq"] > 0:
+            b = r["seq4"]
+            seq = "".join(NT16[(b[i >> 1] >> 4) if (i & 1) == 0 else (b[i >> 1] & 15)] for i in range(r["l_qseq"]))
+        else:
+            seq = None
+        out.append(dict(pos=r["pos"], flag=r["flag"], mapq=r["mapq"], xs=r["xs"], mtid=r["mtid"], mpos=r["mpos"],
+                        cigar=r["cigar"], seq=seq))
+    return ReadBatch.from_reads(out)
+
+
+# ------------------------------------------------------------------ writing
+def _reg2bin(beg, end):
+    end -= 1
+    if beg >> 14 == end >> 14:
+        return ((1 << 15) - 1) // 7 + (beg >> 14)
+    if beg >> 17 == end >> 17:
+        return ((1 << 12) - 1) // 7 + (beg >> 17)
+    if beg >> 20 == end >> 20:
+        return ((1 << 9) - 1) // 7 + (beg >> 20)
+    if beg >> 23 == end >> 23:
+        return ((1 << 6) - 1) // 7 + (beg >> 23)
+    if beg >> 26 == end >> 26:
+        return ((1 << 3) - 1) // 7 + (beg >> 26)
+    return 0
+
+
+def _ref_span(cigar):
+    span = 0
+    for c in cigar:
+        if CIGAR_CHARS[int(c) & 15] in "MDN=X":
+            span += int(c) >> 4
+    return span
+
+
+def _bgzf_block(payload, level=1):
+    co = zlib.compressobj(level, zlib.DEFLATED, -15)
+    cdata = co.compress(payload) + co.flush()
+    bsize = len(cdata) + 25
+    hdr = struct.pack("<BBBBIBBHBBHH", 31, 139, 8, 4, 0, 0, 255, 6, 66, 67, 2, bsize)
+    return hdr + cdata + struct.pack("<II", zlib.crc32(payload) & 0xFFFFFFFF, len(payload))
+
+
+BGZF_EOF = bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000")
+
+
+def write_bam(path, refs, reads, block_size=0xFF00, header_text=None, write_index=True):
+    """reads: dicts with tid,pos,cigar(str|array),seq(str|None),flag,mapq,xs,mtid,mpos,name,
+    optionally aux (raw bytes appended).  Must already be coordinate sorted.
+    Records may straddle BGZF blocks (block_size is a plain byte cut)."""
+    if header_text is None:
+        header_text = "@HD\tVN:1.4\tSO:coordinate\n" + "".join(f"@SQ\tSN:{n}\tLN:{l}\n" for n, l in refs)
+    ht = header_text.encode()
+    stream = bytearray()
+    stream += b"BAM\x01" + struct.pack("<i", len(ht)) + ht + struct.pack("<i", len(refs))
+    for n, l in refs:
+        nb = n.encode() + b"\x00"
+        stream += struct.pack("<i", len(nb)) + nb + struct.pack("<i", l)
+    starts = []  # (tid, pos, end, ustart)
+    for k, r in enumerate(reads):
+        cig = r["cigar"]
+        cig = encode_cigar(cig) if isinstance(cig, str) else np.asarray(cig, np.uint32)
+        seq = r.get("seq")
+        if seq is None or seq == "*":
+            l_seq, sb, qb = 0, b"", b""
+        else:
+            l_seq = len(seq)
+            sb = encode_seq(seq).tobytes()
+            qb = b"\xff" * l_seq
+        name = (r.get("name") or f"r{k}").encode() + b"\x00"
+        pos, tid = r["pos"], r["tid"]
+        span = _ref_span(cig)
+        end = pos + (span if span > 0 else 1)
+        aux = b""
+        xs = r.get("xs")
+        if xs is not None:
+            aux += b"XSA" + xs.encode()
+        aux += r.get("aux", b"")
+        body = struct.pack("<iiBBHHHiiii", tid, pos, len(name), r.get("mapq", 60), _reg2bin(pos, end), len(cig),
+                           r.get("flag", 0), l_seq, r.get("mtid", -1), r.get("mpos", -1), 0)
+        body += name + cig.astype("<u4").tobytes() + sb + qb + aux
+        starts.append((tid, pos, end, len(stream)))
+        stream += struct.pack("<i", len(body)) + body
+    total = len(stream)
+    # cut into BGZF blocks
+    blocks, ustarts, coffs = [], [], []
+    co = 0
+    for u in range(0, total, block_size):
+        blk = _bgzf_block(bytes(stream[u:u + block_size]))
+        ustarts.append(u)
+        coffs.append(co)
+        blocks.append(blk)
+        co += len(blk)
+    with open(path, "wb") as f:
+        for b in blocks:
+            f.write(b)
+        f.write(BGZF_EOF)
+    if not write_index:
+        return
+    ust = np.array(ustarts, dtype=np.int64)
+
+    def voff(u):
+        if u >= total:  # end of data: start of the EOF block
+            return co << 16
+        b = int(np.searchsorted(ust, u, side="right") - 1)
+        return (coffs[b] << 16) | (u - ustarts[b])
+
+    n_ref = len(refs)
+    bins = [dict() for _ in range(n_ref)]
+    lin = [dict() for _ in range(n_ref)]
+    for k, (tid, pos, end, us) in enumerate(starts):
+        if tid < 0:
+            continue
+        ue = starts[k + 1][3] if k + 1 < len(starts) else total
+        vs, ve = voff(us), voff(ue)
+        b = _reg2bin(pos, end)
+        ch = bins[tid].setdefault(b, [])
+        if ch and ch[-1][1] == vs:
+            ch[-1][1] = ve
+        else:
+            ch.append([vs, ve])
+        for w in range(pos >> 14, ((end - 1) >> 14) + 1):
+            if w not in lin[tid]:
+                lin[tid][w] = vs
+    with open(path + ".bai", "wb") as f:
+        f.write(b"BAI\x01" + struct.pack("<i", n_ref))
+        for t in range(n_ref):
+            f.write(struct.pack("<i", len(bins[t])))
+            for b in sorted(bins[t]):
+                f.write(struct.pack("<Ii", b, len(bins[t][b])))
+                for vs, ve in bins[t][b]:
+                    f.write(struct.pack("<QQ", vs, ve))
+            n_intv = (max(lin[t]) + 1) if lin[t] else 0
+            f.write(struct.pack("<i", n_intv))
+            last = 0
+            for w in range(n_intv):
+                last = lin[t].get(w, last)
+                f.write(struct.pack("<Q", last))
+
+
+def write_fasta(path, contigs, width=60, write_index=True):
+    """contigs: list of (name, sequence str/bytes)."""
+    fai = []
+    with open(path, "wb") as f:
+        for name, seq in contigs:
+            if isinstance(seq, str):
+                seq = seq.encode()
+            f.write(b">" + name.encode() + b"\n")
+            off = f.tell()
+            for i in range(0, len(seq), width):
+                f.write(seq[i:i + width] + b"\n")
+            fai.append((name, len(seq), off, width, width + 1))
+    if write_index:
+        with open(path + ".fai", "w") as f:
+            for name, ln, off, lb, lw in fai:
+                f.write(f"{name}\t{ln}\t{off}\t{lb}\t{lw}\n")
+
+
+def read_fasta(path):
+    out = []
+    name, parts = None, []
+    with open(path, "rb") as f:
+        for line in f:
+            if line.startswith(b">"):
+                if name is not None:
+                    out.append((name, b"".join(parts)))
+                name = line[1:].split()[0].decode()
+                parts = []
+            else:
+                parts.append(bytes(c for c in line if 33 <= c <= 126))
+    if name is not None:
+        out.append((name, b"".join(parts)))
+    return out
+
+
+def make_prep_dir(d, refs, contigs, reads, **kw):
+    os.makedirs(d, exist_ok=True)
+    write_bam(os.path.join(d, PREP_BAM), refs, reads, **kw)
+    write_fasta(os.path.join(d, PREP_FA), contigs)
+    return d
