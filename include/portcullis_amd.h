@@ -1,0 +1,204 @@
+/*
+ * portcullis_amd.h -- C ABI of the MI355X-native `junc` hot path.
+ *
+ * This is the drop-in boundary: everything HIP lives behind these entry
+ * points; the host side (C++ JunctionBuilder / JunctionSystem mirror in
+ * portcullis_amd/host/, or any other binding) only sees plain pointers and
+ * sizes.  No exceptions cross the boundary: every call returns PJB_OK (0) or
+ * a negative PJB_ERR_* code and pjb_last_error() gives the message.
+ *
+ * What each entry point replaces in the reference (paths relative to the
+ * reference checkout):
+ *
+ *   pjb_set_refs          BamReader::createRefList           src/junction_builder.cc:103-108
+ *   pjb_upload_contig     GenomeMapper::fetchBases (6 faidx fetches per junction)
+ *                                                            lib/src/junction.cc:566-593,
+ *                                                            lib/src/genome_mapper.cc:111-118
+ *   pjb_submit_batch      the per-record body of findJuncs: BamAlignment::init,
+ *                         length stats, JunctionSystem::addJunctions
+ *                                                            src/junction_builder.cc:322-343,
+ *                                                            lib/src/bam_alignment.cc:71-100,
+ *                                                            lib/src/junction_system.cc:140-210
+ *   pjb_finish_contig     junction finalisation for one target sequence:
+ *                         Junction::calcMetrics + processJunctionWindow and the
+ *                         RegionResult counters                src/junction_builder.cc:324-356,
+ *                                                            lib/src/junction.cc:561-649,683-909
+ *   pjb_collect           JunctionSystem::append of the per-contig systems
+ *                                                            src/junction_builder.cc:258-269
+ *
+ * A context is bound to one HIP device and is not thread-safe; use one
+ * context per host thread / per GPU.  One contig is "open" at a time: submit
+ * its batches in BAM file order, then finish it.
+ */
+#ifndef PORTCULLIS_AMD_H
+#define PORTCULLIS_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PJB_ABI_VERSION 1
+
+/* ---- status codes ------------------------------------------------------ */
+#define PJB_OK 0
+/* data conditions under which the reference throws / crashes (fatal there, reported here) */
+#define PJB_ERR_BAD_XS (-1)          /* strandFromChar, bam_master.hpp:60-72 */
+#define PJB_ERR_NO_PRESENCE (-2)     /* bam_alignment.cc:342,406 */
+#define PJB_ERR_ZERO_LEN_OP (-3)     /* bam_alignment.cc:363 */
+#define PJB_ERR_QUERY_RANGE (-4)     /* bam_alignment.cc:376 */
+#define PJB_ERR_GENOME_RANGE (-5)    /* bam_alignment.cc:437 */
+#define PJB_ERR_QREGION (-6)         /* bam_alignment.cc:414-421 */
+#define PJB_ERR_ANCHOR_MISMATCH (-7) /* junction.cc:192-223 */
+#define PJB_ERR_SPLICE_SITE_LEN (-8) /* junction.cc:570-585 */
+#define PJB_ERR_ANCHOR_LEN (-9)      /* junction.cc:610-623 */
+#define PJB_ERR_INTRON_FLANK_LEN (-10) /* junction.cc:624-633 */
+#define PJB_ERR_MIN_ANCHOR (-11)     /* intron.cc:67-83 */
+#define PJB_ERR_HAMMING_LEN (-12)    /* seq_utils.hpp:62-67 */
+#define PJB_ERR_CLIP_RANGE (-13)     /* substr out_of_range, bam_alignment.cc:263 */
+#define PJB_ERR_UNSORTED (-14)       /* input contract: coordinate-sorted BAM */
+/* API / runtime conditions */
+#define PJB_ERR_NOMEM (-15)
+#define PJB_ERR_ARG (-16)
+#define PJB_ERR_HIP (-17)            /* a HIP runtime call failed */
+#define PJB_ERR_NO_DEVICE (-18)      /* no usable gfx950 device: there is NO CPU fallback */
+#define PJB_ERR_STATE (-19)          /* calls out of order */
+#define PJB_ERR_DIVERGENT (-20)      /* malformed CIGAR: padded query/genome walks emit different
+                                        lengths for one op (the reference would compare misaligned
+                                        strings or crash; we refuse) */
+#define PJB_ERR_NO_SEQ (-21)         /* a spliced read was submitted without its sequence bytes */
+
+/* enums follow the reference's order (bam_master.hpp:50-54,92-97,133-139; junction.hpp:86-91) */
+enum { PJB_STRAND_POS = 0, PJB_STRAND_NEG = 1, PJB_STRAND_UNK = 2 };
+enum { PJB_CSS_CANONICAL = 0, PJB_CSS_SEMI = 1, PJB_CSS_NO = 2 };
+enum { PJB_OR_SE = 0, PJB_OR_FR = 1, PJB_OR_RF = 2, PJB_OR_FF = 3, PJB_OR_UNKNOWN = 4 };
+enum { PJB_SS_UNSTRANDED = 0, PJB_SS_FIRSTSTRAND = 1, PJB_SS_SECONDSTRAND = 2, PJB_SS_UNKNOWN = 3 };
+
+typedef struct pjb_ctx pjb_ctx;
+
+typedef struct pjb_config {
+    int32_t abi_version;  /* PJB_ABI_VERSION */
+    int32_t device;       /* HIP device ordinal */
+    int32_t orientation;  /* PJB_OR_*  (JunctionBuilder::setOrientation, src/junction_builder.hpp:190) */
+    int32_t strandedness; /* PJB_SS_*  accepted for API parity; like the reference it does not
+                             change junc output (the reader's alignments carry
+                             Strandedness::UNKNOWN, lib/src/bam_alignment.cc:154-165) */
+    uint32_t flags;       /* reserved, 0 */
+} pjb_config;
+
+/* One batch of fixed-width alignment records of ONE contig, in BAM file order
+ * (structure of arrays; BAM-native encodings):
+ *   cigar    uint32 len<<4|op, op indexes "MIDNSHP=XB"
+ *   cig_off  n_reads+1 offsets into cigar
+ *   seq4     4-bit packed bases, high nibble first; each read's bytes start on a
+ *            4-byte boundary
+ *   seq_off  n_reads+1 offsets into seq4 in 4-byte WORDS; only reads with an N
+ *            operation need sequence bytes, others may be empty
+ *   xs       0 = no XS:A tag / '?' / '.', 1 = '+', 2 = '-', 3 = any other value
+ */
+typedef struct pjb_batch {
+    int64_t n_reads;
+    const int32_t *pos;
+    const uint16_t *flag;
+    const uint8_t *mapq;
+    const uint8_t *xs;
+    const int32_t *l_qseq;
+    const int32_t *mtid;
+    const int32_t *mpos;
+    const uint32_t *cig_off;
+    const uint32_t *cigar;
+    const uint32_t *seq_off;
+    const uint8_t *seq4;
+} pjb_batch;
+
+/* RegionResult (src/junction_builder.hpp:62-76) plus sizes of what was built */
+typedef struct pjb_region_result {
+    uint64_t spliced;
+    uint64_t unspliced;
+    uint64_t sum_len;
+    int32_t min_len; /* INT32_MAX when the contig has no reads (src/junction_builder.cc:319) */
+    int32_t max_len;
+    int64_t n_reads;
+    int64_t n_pairs;     /* (alignment, junction) pairs = N operations walked */
+    int64_t n_junctions; /* distinct introns on this contig */
+} pjb_region_result;
+
+/* One junction as it stands after Junction::calcMetrics + processJunctionWindow
+ * (i.e. before the cross-junction pass JunctionSystem::calcJunctionStats, which
+ * is O(J) host work above this ABI).  Field names follow the .tab columns. */
+typedef struct pjb_junction_row {
+    int32_t refid;
+    int32_t start, end;   /* intron, 0-based inclusive */
+    int32_t left, right;  /* leftAncStart, rightAncEnd */
+    uint8_t read_strand, ss_strand, cons_strand; /* PJB_STRAND_* */
+    uint8_t canonical;                           /* PJB_CSS_* */
+    uint8_t da1[2], da2[2];                      /* ss1 / ss2; may hold NUL (REVCOMP_LOOKUP quirk) */
+    uint8_t suspicious;
+    uint8_t _pad[3];
+    uint32_t nb_raw, nb_dist, nb_ms, nb_um, nb_bpp, nb_ppp, nb_rel;
+    uint32_t r1pos, r1neg, r2pos, r2neg;
+    uint32_t max_min_anc, maxmmes, hamming5p, hamming3p;
+    uint32_t nb_up_juncs, nb_down_juncs;
+    uint32_t jad[20];
+    uint32_t _pad2;
+    uint64_t sum_mismatches; /* mean_mismatches = sum_mismatches / nb_raw (junction.cc:893) */
+    double entropy;
+} pjb_junction_row;
+
+/* Device-side timing of the last pjb_finish_contig (HIP events on the context's stream) */
+#define PJB_N_STAGES 8
+typedef struct pjb_timing {
+    float total_ms;               /* first kernel -> rows resident on host */
+    float stage_ms[PJB_N_STAGES]; /* scan/emit, sort, group, anchors, pair stats, finalise, d2h, (spare) */
+    int64_t sort_passes;
+} pjb_timing;
+
+/* ---- entry points ------------------------------------------------------ */
+
+int pjb_create(pjb_ctx **out, const pjb_config *cfg);
+void pjb_destroy(pjb_ctx *ctx);
+
+/* Message for the last failing call on ctx (ctx == NULL: last failing pjb_create on this thread). */
+const char *pjb_last_error(const pjb_ctx *ctx);
+
+/* Reference sequence lengths, indexed by BAM tid. */
+int pjb_set_refs(pjb_ctx *ctx, int32_t n_refs, const int32_t *ref_len);
+
+/* Bases of one contig exactly as faidx returns them (isgraph characters, any case);
+ * copied to HBM and upper-cased there (junction.cc:586-587,635-638). */
+int pjb_upload_contig(pjb_ctx *ctx, int32_t tid, const uint8_t *bases, int64_t len);
+/* Same, for bases that are ALREADY upper-cased and resident in HBM; borrowed until
+ * pjb_release_contig / pjb_destroy. */
+int pjb_upload_contig_device(pjb_ctx *ctx, int32_t tid, const uint8_t *d_bases_upper, int64_t len);
+int pjb_release_contig(pjb_ctx *ctx, int32_t tid);
+
+/* Append a batch to the open contig `tid` (opens it if none is open).  Host
+ * arrays are copied to HBM asynchronously on the context's stream (pinned
+ * memory makes the copy truly asynchronous) and may be reused once the call
+ * returns only if they are not pinned; pinned buffers must stay valid until
+ * pjb_finish_contig returns. */
+int pjb_submit_batch(pjb_ctx *ctx, int32_t tid, const pjb_batch *host_batch);
+/* Same for arrays already resident in HBM: borrowed until pjb_finish_contig returns. */
+int pjb_submit_batch_device(pjb_ctx *ctx, int32_t tid, const pjb_batch *device_batch);
+
+/* Run the device pipeline over the open contig and close it.  The contig's
+ * genome must have been uploaded.  On return the contig's rows are on the
+ * host (appended to the table pjb_collect returns). */
+int pjb_finish_contig(pjb_ctx *ctx, int32_t tid, pjb_region_result *result);
+
+/* All rows built so far, contig by contig in finish order, (start,end)-sorted
+ * within a contig.  The pointer stays valid until the next finish/clear/destroy. */
+int pjb_collect(pjb_ctx *ctx, const pjb_junction_row **rows, int64_t *n_rows);
+int pjb_clear_rows(pjb_ctx *ctx);
+
+int pjb_get_timing(const pjb_ctx *ctx, pjb_timing *out);
+
+/* Number of visible HIP devices (0 if none); does not create a context. */
+int pjb_device_count(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,611 @@
+// pjb_api.hip -- C ABI (include/portcullis_amd.h) over the HIP kernels.
+// One context = one HIP device + one stream + a grow-only scratch arena.
+#include "pjb_kernels.hip.h"
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace pjb;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct Buf {
+    void *p = nullptr;
+    size_t cap = 0;
+};
+
+struct Contig {
+    uint8_t *d = nullptr;
+    int64_t len = 0;
+    bool owned = false;
+    bool has_x = false;
+    bool present = false;
+};
+
+struct OwnedBatch { // device copies made by pjb_submit_batch
+    void *ptrs[11] = {nullptr};
+};
+
+enum { ST_SCAN = 0, ST_SORT, ST_GROUP, ST_ANCH, ST_PAIRS, ST_FINAL, ST_D2H };
+
+} // namespace
+
+struct pjb_ctx {
+    pjb_config cfg;
+    hipStream_t stream = nullptr;
+    std::string err;
+    std::vector<int32_t> ref_len;
+    std::vector<Contig> contigs;
+    int32_t open_tid = -1;
+    std::vector<DevBatch> batches;
+    std::vector<OwnedBatch> owned;
+    std::vector<pjb_junction_row> rows;
+    pjb_timing timing;
+    hipEvent_t ev[PJB_N_STAGES + 2];
+    int radix_max_bits = 8;
+    // scratch
+    Buf b_batches, b_tile_cnt, b_tile_stats, b_cstats, b_err, b_total;
+    Buf b_key[2], b_idx[2], b_g, b_lstart, b_rend, b_pos, b_aend, b_meta, b_updown;
+    Buf b_hist, b_hist_scan, b_scan_tiles;
+    Buf b_jid, b_seg, b_runfirst, b_runstart;
+    Buf b_frag, b_fragj, b_fragl, b_fragr, b_acc, b_ancl, b_ancr, b_rows, b_hasx;
+};
+
+namespace {
+
+int fail(pjb_ctx *c, int code, const char *fmt, ...) {
+    char tmp[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(tmp, sizeof tmp, fmt, ap);
+    va_end(ap);
+    if (c) c->err = tmp;
+    else g_create_error = tmp;
+    return code;
+}
+
+#define HIP_TRY(c, call)                                                                                   \
+    do {                                                                                                   \
+        hipError_t e_ = (call);                                                                            \
+        if (e_ != hipSuccess)                                                                              \
+            return fail((c), PJB_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, \
+                        __LINE__);                                                                         \
+    } while (0)
+
+int ensure(pjb_ctx *c, Buf &b, size_t bytes) {
+    if (bytes <= b.cap && b.p) return PJB_OK;
+    if (b.p) HIP_TRY(c, hipFree(b.p));
+    b.p = nullptr;
+    b.cap = 0;
+    size_t want = std::max<size_t>(bytes + bytes / 4, 256);
+    hipError_t e = hipMalloc(&b.p, want);
+    if (e != hipSuccess) {
+        want = std::max<size_t>(bytes, 256);
+        e = hipMalloc(&b.p, want);
+        if (e != hipSuccess) return fail(c, PJB_ERR_NOMEM, "hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+    }
+    b.cap = want;
+    return PJB_OK;
+}
+
+void release(Buf &b) {
+    if (b.p) (void)hipFree(b.p);
+    b.p = nullptr;
+    b.cap = 0;
+}
+
+const char *err_text(int code) {
+    switch (code) {
+    case PJB_ERR_BAD_XS: return "Unknown strand: XS tag is not one of + - ? .";
+    case PJB_ERR_NO_PRESENCE: return "Found an alignment that does not have a presence in the requested region";
+    case PJB_ERR_ZERO_LEN_OP: return "Can't extract cigar op sequence from query string when length has been calculated as 0";
+    case PJB_ERR_QUERY_RANGE: return "Can't extract cigar op sequence from query string";
+    case PJB_ERR_GENOME_RANGE: return "Can't extract cigar op sequence from extracted genome region";
+    case PJB_ERR_QREGION: return "Query region is outside the genomic region";
+    case PJB_ERR_ANCHOR_MISMATCH: return "Anchor region for query and genome are not the same size";
+    case PJB_ERR_SPLICE_SITE_LEN: return "Retrieved sequence for splice site of junction is not the expected length";
+    case PJB_ERR_ANCHOR_LEN: return "Retrieved sequence for anchor of junction is not the expected length";
+    case PJB_ERR_INTRON_FLANK_LEN: return "Retrieved sequence for intron region of junction is not the expected length";
+    case PJB_ERR_MIN_ANCHOR: return "The intron must lie inside its anchors (Intron::minAnchorLength)";
+    case PJB_ERR_HAMMING_LEN: return "Can't find hamming distance of strings that are not the same length";
+    case PJB_ERR_CLIP_RANGE: return "Soft clip longer than the read (basic_string::substr)";
+    case PJB_ERR_UNSORTED: return "Alignments are not coordinate sorted";
+    case PJB_ERR_DIVERGENT: return "Malformed CIGAR: padded query and genome walks disagree";
+    case PJB_ERR_NO_SEQ: return "A spliced alignment was submitted without its sequence";
+    default: return "unknown error";
+    }
+}
+
+int check_device_error(pjb_ctx *c, u64 e) {
+    if (e == ~0ull) return PJB_OK;
+    const int code = -(int)(e & 0xff);
+    const unsigned long long ord = e >> 8;
+    return fail(c, code, "%s (alignment ordinal %llu on target %d)", err_text(code), ord, c->open_tid);
+}
+
+int bits_of(uint64_t v) {
+    int b = 0;
+    while (v) {
+        b++;
+        v >>= 1;
+    }
+    return b;
+}
+
+// generic scan launchers ------------------------------------------------------------------------
+template <typename F, typename G>
+int run_scan(pjb_ctx *c, F f, G g, u64 n, u64 *d_total) {
+    const u32 nt = (u32)((n + SCAN_TILE - 1) / SCAN_TILE);
+    int rc = ensure(c, c->b_scan_tiles, (size_t)nt * 8);
+    if (rc) return rc;
+    u64 *ts = (u64 *)c->b_scan_tiles.p;
+    hipLaunchKernelGGL((scan_reduce_kernel<F>), dim3(nt), dim3(256), 0, c->stream, f, n, ts);
+    hipLaunchKernelGGL(scan_tiles_kernel, dim3(1), dim3(1024), 0, c->stream, ts, nt, d_total);
+    hipLaunchKernelGGL((scan_apply_kernel<F, G>), dim3(nt), dim3(256), 0, c->stream, f, g, n, (const u64 *)ts);
+    return PJB_OK;
+}
+
+struct HistFn {
+    const u32 *h;
+    __device__ u64 operator()(u64 i) const { return h[i]; }
+};
+struct HistSink {
+    u32 *o;
+    __device__ void operator()(u64 i, u64, u64 ex) const { o[i] = (u32)ex; }
+};
+
+int close_contig(pjb_ctx *c) {
+    for (auto &ob : c->owned)
+        for (void *p : ob.ptrs)
+            if (p) (void)hipFree(p);
+    c->owned.clear();
+    c->batches.clear();
+    c->open_tid = -1;
+    return PJB_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int pjb_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int pjb_create(pjb_ctx **out, const pjb_config *cfg) {
+    if (!out || !cfg) return fail(nullptr, PJB_ERR_ARG, "pjb_create: null argument");
+    *out = nullptr;
+    if (cfg->abi_version != PJB_ABI_VERSION)
+        return fail(nullptr, PJB_ERR_ARG, "pjb_create: ABI version %d, library is %d", cfg->abi_version, PJB_ABI_VERSION);
+    if (cfg->orientation < PJB_OR_SE || cfg->orientation > PJB_OR_UNKNOWN)
+        return fail(nullptr, PJB_ERR_ARG, "pjb_create: bad orientation %d", cfg->orientation);
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(nullptr, PJB_ERR_NO_DEVICE,
+                    "no HIP device available (%s); the junc hot path has no CPU fallback",
+                    e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+    if (cfg->device < 0 || cfg->device >= n)
+        return fail(nullptr, PJB_ERR_ARG, "pjb_create: device %d out of range (have %d)", cfg->device, n);
+    e = hipSetDevice(cfg->device);
+    if (e != hipSuccess) return fail(nullptr, PJB_ERR_HIP, "hipSetDevice(%d): %s", cfg->device, hipGetErrorString(e));
+    hipDeviceProp_t prop;
+    e = hipGetDeviceProperties(&prop, cfg->device);
+    if (e != hipSuccess) return fail(nullptr, PJB_ERR_HIP, "hipGetDeviceProperties: %s", hipGetErrorString(e));
+    if (prop.warpSize != 64)
+        return fail(nullptr, PJB_ERR_NO_DEVICE, "device %d (%s) is not a wave64 CDNA device", cfg->device, prop.gcnArchName);
+    pjb_ctx *c = new (std::nothrow) pjb_ctx();
+    if (!c) return fail(nullptr, PJB_ERR_NOMEM, "out of host memory");
+    c->cfg = *cfg;
+    memset(&c->timing, 0, sizeof c->timing);
+    e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        delete c;
+        return fail(nullptr, PJB_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e));
+    }
+    for (auto &ev : c->ev) (void)hipEventCreate(&ev);
+    if (const char *s = getenv("PJB_RADIX_BITS")) {
+        int v = atoi(s);
+        if (v >= 4 && v <= RS_MAX_BITS) c->radix_max_bits = v;
+    }
+    *out = c;
+    return PJB_OK;
+}
+
+void pjb_destroy(pjb_ctx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->cfg.device);
+    (void)hipStreamSynchronize(c->stream);
+    close_contig(c);
+    for (auto &g : c->contigs)
+        if (g.owned && g.d) (void)hipFree(g.d);
+    Buf *all[] = {&c->b_batches, &c->b_tile_cnt, &c->b_tile_stats, &c->b_cstats, &c->b_err, &c->b_total, &c->b_key[0],
+                  &c->b_key[1], &c->b_idx[0], &c->b_idx[1], &c->b_g, &c->b_lstart, &c->b_rend, &c->b_pos, &c->b_aend,
+                  &c->b_meta, &c->b_updown, &c->b_hist, &c->b_hist_scan, &c->b_scan_tiles, &c->b_jid, &c->b_seg,
+                  &c->b_runfirst, &c->b_runstart, &c->b_frag, &c->b_fragj, &c->b_fragl, &c->b_fragr, &c->b_acc,
+                  &c->b_ancl, &c->b_ancr, &c->b_rows, &c->b_hasx};
+    for (Buf *b : all) release(*b);
+    for (auto &ev : c->ev) (void)hipEventDestroy(ev);
+    (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char *pjb_last_error(const pjb_ctx *c) { return c ? c->err.c_str() : g_create_error.c_str(); }
+
+int pjb_set_refs(pjb_ctx *c, int32_t n_refs, const int32_t *ref_len) {
+    if (!c) return PJB_ERR_ARG;
+    if (n_refs < 0 || (n_refs > 0 && !ref_len)) return fail(c, PJB_ERR_ARG, "pjb_set_refs: bad arguments");
+    if (c->open_tid >= 0) return fail(c, PJB_ERR_STATE, "pjb_set_refs: contig %d is still open", c->open_tid);
+    for (auto &g : c->contigs)
+        if (g.owned && g.d) (void)hipFree(g.d);
+    c->ref_len.assign(ref_len, ref_len + n_refs);
+    c->contigs.assign((size_t)n_refs, Contig());
+    return PJB_OK;
+}
+
+static int upload_common(pjb_ctx *c, int32_t tid, uint8_t *d, int64_t len, bool owned, bool do_upper) {
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    int rc = ensure(c, c->b_hasx, sizeof(int));
+    if (rc) return rc;
+    HIP_TRY(c, hipMemsetAsync(c->b_hasx.p, 0, sizeof(int), c->stream));
+    if (len > 0) {
+        const int64_t nthreads = (len + 15) / 16;
+        const unsigned nblk = (unsigned)((nthreads + 255) / 256);
+        hipLaunchKernelGGL(k0_upper, dim3(nblk), dim3(256), 0, c->stream, d, len, do_upper ? 1 : 0, (int *)c->b_hasx.p);
+    }
+    int hx = 0;
+    HIP_TRY(c, hipMemcpyAsync(&hx, c->b_hasx.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    Contig &g = c->contigs[(size_t)tid];
+    if (g.owned && g.d) (void)hipFree(g.d);
+    g.d = d;
+    g.len = len;
+    g.owned = owned;
+    g.has_x = hx != 0;
+    g.present = true;
+    return PJB_OK;
+}
+
+int pjb_upload_contig(pjb_ctx *c, int32_t tid, const uint8_t *bases, int64_t len) {
+    if (!c) return PJB_ERR_ARG;
+    if (tid < 0 || (size_t)tid >= c->contigs.size() || len < 0 || (len > 0 && !bases))
+        return fail(c, PJB_ERR_ARG, "pjb_upload_contig: bad arguments (tid %d)", tid);
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    uint8_t *d = nullptr;
+    hipError_t e = hipMalloc((void **)&d, (size_t)std::max<int64_t>(len, 16));
+    if (e != hipSuccess) return fail(c, PJB_ERR_NOMEM, "hipMalloc(genome %lld): %s", (long long)len, hipGetErrorString(e));
+    if (len > 0) {
+        e = hipMemcpyAsync(d, bases, (size_t)len, hipMemcpyHostToDevice, c->stream);
+        if (e != hipSuccess) {
+            (void)hipFree(d);
+            return fail(c, PJB_ERR_HIP, "hipMemcpy(genome): %s", hipGetErrorString(e));
+        }
+    }
+    int rc = upload_common(c, tid, d, len, true, true);
+    if (rc) (void)hipFree(d);
+    return rc;
+}
+
+int pjb_upload_contig_device(pjb_ctx *c, int32_t tid, const uint8_t *d_bases_upper, int64_t len) {
+    if (!c) return PJB_ERR_ARG;
+    if (tid < 0 || (size_t)tid >= c->contigs.size() || len < 0 || (len > 0 && !d_bases_upper))
+        return fail(c, PJB_ERR_ARG, "pjb_upload_contig_device: bad arguments (tid %d)", tid);
+    return upload_common(c, tid, const_cast<uint8_t *>(d_bases_upper), len, false, false);
+}
+
+int pjb_release_contig(pjb_ctx *c, int32_t tid) {
+    if (!c) return PJB_ERR_ARG;
+    if (tid < 0 || (size_t)tid >= c->contigs.size()) return fail(c, PJB_ERR_ARG, "pjb_release_contig: bad tid %d", tid);
+    Contig &g = c->contigs[(size_t)tid];
+    if (g.owned && g.d) {
+        (void)hipStreamSynchronize(c->stream);
+        (void)hipFree(g.d);
+    }
+    g = Contig();
+    return PJB_OK;
+}
+
+static int add_batch(pjb_ctx *c, int32_t tid, const pjb_batch *b, bool device) {
+    if (!c) return PJB_ERR_ARG;
+    if (!b || b->n_reads < 0) return fail(c, PJB_ERR_ARG, "submit: bad batch");
+    if (tid < 0 || (size_t)tid >= c->ref_len.size()) return fail(c, PJB_ERR_ARG, "submit: bad tid %d", tid);
+    if (c->open_tid >= 0 && c->open_tid != tid)
+        return fail(c, PJB_ERR_STATE, "submit: contig %d is open, finish it before submitting to %d", c->open_tid, tid);
+    c->open_tid = tid;
+    if (b->n_reads == 0) return PJB_OK;
+    if (!b->pos || !b->flag || !b->mapq || !b->xs || !b->l_qseq || !b->mtid || !b->mpos || !b->cig_off || !b->cigar ||
+        !b->seq_off)
+        return fail(c, PJB_ERR_ARG, "submit: null array in batch");
+    uint64_t total = 0;
+    for (auto &x : c->batches) total += (uint64_t)x.n;
+    if (total + (uint64_t)b->n_reads >= 0xffffff00ull)
+        return fail(c, PJB_ERR_ARG, "submit: more than 2^32 alignments on one target are not supported");
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    DevBatch d;
+    memset(&d, 0, sizeof d);
+    d.n = b->n_reads;
+    d.base = (uint32_t)total;
+    if (device) {
+        d.pos = b->pos; d.flag = b->flag; d.mapq = b->mapq; d.xs = b->xs; d.l_qseq = b->l_qseq; d.mtid = b->mtid;
+        d.mpos = b->mpos; d.cig_off = b->cig_off; d.cigar = b->cigar; d.seq_off = b->seq_off; d.seq4 = b->seq4;
+    } else {
+        const size_t n = (size_t)b->n_reads;
+        const size_t n_ops = b->cig_off[n], n_words = b->seq_off[n];
+        const void *src[11] = {b->pos, b->flag, b->mapq, b->xs, b->l_qseq, b->mtid, b->mpos, b->cig_off, b->cigar, b->seq_off, b->seq4};
+        const size_t bytes[11] = {n * 4, n * 2, n, n, n * 4, n * 4, n * 4, (n + 1) * 4, n_ops * 4, (n + 1) * 4, n_words * 4};
+        OwnedBatch ob;
+        for (int k = 0; k < 11; k++) {
+            hipError_t e = hipMalloc(&ob.ptrs[k], std::max<size_t>(bytes[k], 16));
+            if (e == hipSuccess && bytes[k] && src[k])
+                e = hipMemcpyAsync(ob.ptrs[k], src[k], bytes[k], hipMemcpyHostToDevice, c->stream);
+            if (e != hipSuccess) {
+                for (void *p : ob.ptrs)
+                    if (p) (void)hipFree(p);
+                return fail(c, PJB_ERR_HIP, "submit: H2D copy failed: %s", hipGetErrorString(e));
+            }
+        }
+        c->owned.push_back(ob);
+        d.pos = (const int32_t *)ob.ptrs[0]; d.flag = (const uint16_t *)ob.ptrs[1]; d.mapq = (const uint8_t *)ob.ptrs[2];
+        d.xs = (const uint8_t *)ob.ptrs[3]; d.l_qseq = (const int32_t *)ob.ptrs[4]; d.mtid = (const int32_t *)ob.ptrs[5];
+        d.mpos = (const int32_t *)ob.ptrs[6]; d.cig_off = (const uint32_t *)ob.ptrs[7]; d.cigar = (const uint32_t *)ob.ptrs[8];
+        d.seq_off = (const uint32_t *)ob.ptrs[9]; d.seq4 = (const uint8_t *)ob.ptrs[10];
+    }
+    c->batches.push_back(d);
+    return PJB_OK;
+}
+
+int pjb_submit_batch(pjb_ctx *c, int32_t tid, const pjb_batch *b) { return add_batch(c, tid, b, false); }
+int pjb_submit_batch_device(pjb_ctx *c, int32_t tid, const pjb_batch *b) { return add_batch(c, tid, b, true); }
+
+int pjb_finish_contig(pjb_ctx *c, int32_t tid, pjb_region_result *res) {
+    if (!c) return PJB_ERR_ARG;
+    if (tid < 0 || (size_t)tid >= c->ref_len.size()) return fail(c, PJB_ERR_ARG, "finish: bad tid %d", tid);
+    if (c->open_tid >= 0 && c->open_tid != tid)
+        return fail(c, PJB_ERR_STATE, "finish: contig %d is open, not %d", c->open_tid, tid);
+    c->open_tid = tid;
+    struct Closer {
+        pjb_ctx *c;
+        ~Closer() { close_contig(c); }
+    } closer{c};
+    pjb_region_result R;
+    memset(&R, 0, sizeof R);
+    R.min_len = INT32_MAX;
+    memset(&c->timing, 0, sizeof c->timing);
+    if (res) *res = R;
+    if (c->batches.empty()) return PJB_OK;
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    hipStream_t st = c->stream;
+    const int32_t ref_len = c->ref_len[(size_t)tid];
+    int rc;
+
+    // ---- K1a: count
+    u32 n_tiles = 0;
+    int32_t prev_pos = INT32_MIN;
+    int64_t n_reads = 0;
+    for (auto &b : c->batches) {
+        b.tile_base = n_tiles;
+        n_tiles += (u32)((b.n + K1_TILE - 1) / K1_TILE);
+        b.prev_pos = prev_pos;
+        n_reads += b.n;
+        // last position of this batch is needed by the next one: read it back lazily on device instead
+    }
+    // prev_pos across batches: fetch each batch's last pos (tiny D2H, only when there are several batches)
+    if (c->batches.size() > 1) {
+        for (size_t k = 0; k + 1 < c->batches.size(); k++) {
+            int32_t last = INT32_MIN;
+            HIP_TRY(c, hipMemcpyAsync(&last, c->batches[k].pos + (c->batches[k].n - 1), 4, hipMemcpyDeviceToHost, st));
+            HIP_TRY(c, hipStreamSynchronize(st));
+            c->batches[k + 1].prev_pos = last;
+        }
+    }
+    if ((rc = ensure(c, c->b_batches, c->batches.size() * sizeof(DevBatch)))) return rc;
+    if ((rc = ensure(c, c->b_tile_cnt, (size_t)n_tiles * 4))) return rc;
+    if ((rc = ensure(c, c->b_tile_stats, (size_t)n_tiles * sizeof(TileStats)))) return rc;
+    if ((rc = ensure(c, c->b_cstats, sizeof(ContigStats)))) return rc;
+    if ((rc = ensure(c, c->b_err, 8))) return rc;
+    if ((rc = ensure(c, c->b_total, 8))) return rc;
+    HIP_TRY(c, hipMemcpyAsync(c->b_batches.p, c->batches.data(), c->batches.size() * sizeof(DevBatch), hipMemcpyHostToDevice, st));
+    HIP_TRY(c, hipMemsetAsync(c->b_err.p, 0xff, 8, st));
+    u64 *d_err = (u64 *)c->b_err.p;
+    ContigStats *d_cs = (ContigStats *)c->b_cstats.p;
+    HIP_TRY(c, hipEventRecord(c->ev[0], st));
+    for (auto &b : c->batches) {
+        const u32 nt = (u32)((b.n + K1_TILE - 1) / K1_TILE);
+        hipLaunchKernelGGL(k1_count, dim3(nt), dim3(256), 0, st, b, (u32 *)c->b_tile_cnt.p, (TileStats *)c->b_tile_stats.p, d_err);
+    }
+    hipLaunchKernelGGL(k1_scan_tiles, dim3(1), dim3(1024), 0, st, (u32 *)c->b_tile_cnt.p, (const TileStats *)c->b_tile_stats.p, n_tiles, d_cs);
+    ContigStats cs;
+    u64 herr = ~0ull;
+    HIP_TRY(c, hipMemcpyAsync(&cs, d_cs, sizeof cs, hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipMemcpyAsync(&herr, d_err, 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipStreamSynchronize(st));
+    if ((rc = check_device_error(c, herr))) return rc;
+    R.spliced = cs.spliced;
+    R.unspliced = cs.unspliced;
+    R.sum_len = cs.sum_len;
+    R.min_len = cs.min_len;
+    R.max_len = cs.max_len;
+    R.n_reads = n_reads;
+    R.n_pairs = (int64_t)cs.n_pairs;
+    const u64 P64 = cs.n_pairs;
+    if (P64 == 0) {
+        if (res) *res = R;
+        return PJB_OK;
+    }
+    if (P64 >= 0xfffffff0ull) return fail(c, PJB_ERR_ARG, "finish: more than 2^32 spliced pairs on one target are not supported");
+    const u32 P = (u32)P64;
+    const Contig &G = c->contigs[(size_t)tid];
+    if (!G.present) return fail(c, PJB_ERR_STATE, "finish: genome of target %d was not uploaded", tid);
+    if (G.len != ref_len)
+        return fail(c, PJB_ERR_ARG, "finish: genome of target %d has %lld bases, header says %d", tid, (long long)G.len, ref_len);
+
+    // ---- key format
+    KeyFmt kf;
+    if (cs.min_pos < 0 || cs.max_end > ref_len || cs.max_end < 0) {
+        kf.raw = 1;
+        kf.lbits = 32;
+        kf.total_bits = 64;
+    } else {
+        kf.raw = 0;
+        kf.lbits = std::max(1, bits_of((uint64_t)cs.max_nlen));
+        kf.total_bits = kf.lbits + std::max(1, bits_of((uint64_t)cs.max_end));
+    }
+
+    // ---- K1b: emit
+    Pairs pr;
+    if ((rc = ensure(c, c->b_key[0], (size_t)P * 8))) return rc;
+    if ((rc = ensure(c, c->b_key[1], (size_t)P * 8))) return rc;
+    if ((rc = ensure(c, c->b_idx[0], (size_t)P * 4))) return rc;
+    if ((rc = ensure(c, c->b_idx[1], (size_t)P * 4))) return rc;
+    Buf *pb[] = {&c->b_g, &c->b_lstart, &c->b_rend, &c->b_pos, &c->b_aend, &c->b_meta, &c->b_updown};
+    for (Buf *b : pb)
+        if ((rc = ensure(c, *b, (size_t)P * 4))) return rc;
+    pr.key = (u64 *)c->b_key[0].p;
+    pr.g = (u32 *)c->b_g.p;
+    pr.lstart = (int32_t *)c->b_lstart.p;
+    pr.rend = (int32_t *)c->b_rend.p;
+    pr.pos = (int32_t *)c->b_pos.p;
+    pr.aend = (int32_t *)c->b_aend.p;
+    pr.meta = (u32 *)c->b_meta.p;
+    pr.updown = (u32 *)c->b_updown.p;
+    for (auto &b : c->batches) {
+        const u32 nt = (u32)((b.n + K1_TILE - 1) / K1_TILE);
+        hipLaunchKernelGGL(k1_emit, dim3(nt), dim3(256), 0, st, b, (const u32 *)c->b_tile_cnt.p, pr, kf, ref_len, tid,
+                           (int)c->cfg.orientation, d_err);
+    }
+    HIP_TRY(c, hipEventRecord(c->ev[1], st));
+
+    // ---- K2: radix sort (key, pair index)
+    const u32 rs_tiles = (P + RS_TILE - 1) / RS_TILE;
+    int n_pass = (kf.total_bits + c->radix_max_bits - 1) / c->radix_max_bits;
+    if (n_pass < 1) n_pass = 1;
+    const int dbits = (kf.total_bits + n_pass - 1) / n_pass;
+    if ((rc = ensure(c, c->b_hist, (size_t)rs_tiles * (1u << dbits) * 4))) return rc;
+    if ((rc = ensure(c, c->b_hist_scan, (size_t)rs_tiles * (1u << dbits) * 4))) return rc;
+    int cur = 0;
+    for (int p = 0; p < n_pass; p++) {
+        const int shift = p * dbits;
+        const int bits = std::min(dbits, kf.total_bits - shift);
+        if (bits <= 0) break;
+        const u64 *kin = (const u64 *)c->b_key[cur].p;
+        u64 *kout = (u64 *)c->b_key[cur ^ 1].p;
+        const u32 *vin = p == 0 ? nullptr : (const u32 *)c->b_idx[cur].p;
+        u32 *vout = (u32 *)c->b_idx[cur ^ 1].p;
+        hipLaunchKernelGGL(rs_hist, dim3(rs_tiles), dim3(256), 0, st, kin, P, shift, bits, (u32 *)c->b_hist.p, rs_tiles);
+        HistFn hf{(const u32 *)c->b_hist.p};
+        HistSink hs{(u32 *)c->b_hist_scan.p};
+        if ((rc = run_scan(c, hf, hs, (u64)rs_tiles << bits, (u64 *)c->b_total.p))) return rc;
+        hipLaunchKernelGGL(rs_scatter, dim3(rs_tiles), dim3(256), 0, st, kin, vin, kout, vout, P, shift, bits,
+                           (const u32 *)c->b_hist_scan.p, rs_tiles);
+        cur ^= 1;
+    }
+    c->timing.sort_passes = n_pass;
+    const u64 *skey = (const u64 *)c->b_key[cur].p;
+    const u32 *sidx = (const u32 *)c->b_idx[cur].p;
+    HIP_TRY(c, hipEventRecord(c->ev[2], st));
+
+    // ---- K2s: junction ids, position runs
+    if ((rc = ensure(c, c->b_jid, (size_t)P * 4))) return rc;
+    if ((rc = ensure(c, c->b_seg, ((size_t)P + 1) * 4))) return rc;
+    if ((rc = ensure(c, c->b_runfirst, ((size_t)P + 1) * 4))) return rc;
+    if ((rc = ensure(c, c->b_runstart, ((size_t)P + 1) * 4))) return rc;
+    {
+        HeadFn hf{skey, sidx, pr.pos};
+        HeadSink hs{(u32 *)c->b_jid.p, (u32 *)c->b_seg.p, (u32 *)c->b_runfirst.p, (u32 *)c->b_runstart.p};
+        if ((rc = run_scan(c, hf, hs, (u64)P, (u64 *)c->b_total.p))) return rc;
+        hipLaunchKernelGGL(k2_close, dim3(1), dim3(1), 0, st, (u64 *)c->b_total.p, (u32 *)c->b_seg.p, (u32 *)c->b_runfirst.p,
+                           (u32 *)c->b_runstart.p, P, d_cs);
+    }
+    HIP_TRY(c, hipMemcpyAsync(&cs, d_cs, sizeof cs, hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipMemcpyAsync(&herr, d_err, 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipEventRecord(c->ev[3], st));
+    HIP_TRY(c, hipStreamSynchronize(st));
+    if ((rc = check_device_error(c, herr))) return rc;
+    const u32 J = cs.n_junc;
+    R.n_junctions = J;
+
+    // ---- K3: anchors
+    const u32 n_slices = (P + 63) / 64;
+    const u32 n_slots = J + n_slices;
+    if ((rc = ensure(c, c->b_frag, (size_t)n_slots * F_WORDS * 4))) return rc;
+    if ((rc = ensure(c, c->b_fragj, (size_t)n_slots * 4))) return rc;
+    if ((rc = ensure(c, c->b_fragl, (size_t)n_slots * 4))) return rc;
+    if ((rc = ensure(c, c->b_fragr, (size_t)n_slots * 4))) return rc;
+    if ((rc = ensure(c, c->b_acc, (size_t)J * F_WORDS * 4))) return rc;
+    if ((rc = ensure(c, c->b_ancl, (size_t)J * 4))) return rc;
+    if ((rc = ensure(c, c->b_ancr, (size_t)J * 4))) return rc;
+    if ((rc = ensure(c, c->b_rows, (size_t)J * sizeof(pjb_junction_row)))) return rc;
+    HIP_TRY(c, hipMemsetAsync(c->b_fragj.p, 0xff, (size_t)n_slots * 4, st));
+    hipLaunchKernelGGL(k5_init_acc, dim3((J * F_WORDS + 255) / 256), dim3(256), 0, st, (u32 *)c->b_acc.p, J,
+                       (int32_t *)c->b_ancl.p, (int32_t *)c->b_ancr.p);
+    const u32 pair_blocks = (P + 255) / 256, slot_blocks = (n_slots + 255) / 256;
+    hipLaunchKernelGGL(k3_anchors_frag, dim3(pair_blocks), dim3(256), 0, st, sidx, (const u32 *)c->b_jid.p,
+                       (const int32_t *)pr.lstart, (const int32_t *)pr.rend, P, (int32_t *)c->b_fragl.p,
+                       (int32_t *)c->b_fragr.p, (int32_t *)c->b_fragj.p);
+    hipLaunchKernelGGL(k3_anchors_junc, dim3(slot_blocks), dim3(256), 0, st, (const int32_t *)c->b_fragl.p,
+                       (const int32_t *)c->b_fragr.p, (const int32_t *)c->b_fragj.p, n_slots, (int32_t *)c->b_ancl.p,
+                       (int32_t *)c->b_ancr.p);
+    HIP_TRY(c, hipEventRecord(c->ev[4], st));
+
+    // ---- K4: per-pair match statistics -> fragments
+    hipLaunchKernelGGL(k4_pairs, dim3(pair_blocks), dim3(256), 0, st, skey, sidx, (const u32 *)c->b_jid.p, pr, kf,
+                       (const DevBatch *)c->b_batches.p, (int)c->batches.size(), (const int32_t *)c->b_ancl.p,
+                       (const int32_t *)c->b_ancr.p, (const uint8_t *)G.d, (int32_t)G.len, G.has_x ? 1 : 0, P,
+                       (u32 *)c->b_frag.p, (int32_t *)c->b_fragj.p, d_err);
+    HIP_TRY(c, hipEventRecord(c->ev[5], st));
+
+    // ---- K5: fragments -> junctions -> rows
+    hipLaunchKernelGGL(k5_frag_reduce, dim3(slot_blocks), dim3(256), 0, st, (const u32 *)c->b_frag.p,
+                       (const int32_t *)c->b_fragj.p, n_slots, (u32 *)c->b_acc.p);
+    hipLaunchKernelGGL(k5_finalize, dim3((J + 255) / 256), dim3(256), 0, st, skey, (const u32 *)c->b_seg.p,
+                       (const u32 *)c->b_runfirst.p, (const u32 *)c->b_runstart.p, (const u32 *)c->b_acc.p,
+                       (const int32_t *)c->b_ancl.p, (const int32_t *)c->b_ancr.p, kf, (const uint8_t *)G.d, (int32_t)G.len,
+                       tid, J, (pjb_junction_row *)c->b_rows.p, d_err);
+    HIP_TRY(c, hipEventRecord(c->ev[6], st));
+
+    // ---- rows to host
+    const size_t old = c->rows.size();
+    c->rows.resize(old + J);
+    HIP_TRY(c, hipMemcpyAsync(c->rows.data() + old, c->b_rows.p, (size_t)J * sizeof(pjb_junction_row), hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipMemcpyAsync(&herr, d_err, 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipEventRecord(c->ev[7], st));
+    HIP_TRY(c, hipStreamSynchronize(st));
+    if ((rc = check_device_error(c, herr))) {
+        c->rows.resize(old);
+        return rc;
+    }
+    for (int k = 0; k < 7; k++) (void)hipEventElapsedTime(&c->timing.stage_ms[k], c->ev[k], c->ev[k + 1]);
+    (void)hipEventElapsedTime(&c->timing.total_ms, c->ev[0], c->ev[7]);
+    if (res) *res = R;
+    return PJB_OK;
+}
+
+int pjb_collect(pjb_ctx *c, const pjb_junction_row **rows, int64_t *n) {
+    if (!c || !rows || !n) return PJB_ERR_ARG;
+    *rows = c->rows.data();
+    *n = (int64_t)c->rows.size();
+    return PJB_OK;
+}
+
+int pjb_clear_rows(pjb_ctx *c) {
+    if (!c) return PJB_ERR_ARG;
+    c->rows.clear();
+    return PJB_OK;
+}
+
+int pjb_get_timing(const pjb_ctx *c, pjb_timing *out) {
+    if (!c || !out) return PJB_ERR_ARG;
+    *out = c->timing;
+    return PJB_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,1352 @@
+// pjb_kernels.hip.h -- hand-written HIP kernels (gfx950 / CDNA4, wave64) for the
+// Portcullis `junc` hot path.  Integer / byte work bounded by HBM bandwidth; no MFMA.
+//
+// Pipeline per contig (DESIGN.md has the data layout and byte counts):
+//   K1a k1_count        per-read CIGAR walk: N-op count, length stats, sortedness    (a1,a2)
+//   K1b k1_emit         per-read CIGAR walk: emit (intron key, anchors, flags) pairs (a3,a5,a8)
+//   K2  radix sort      stable LSD sort of pairs by intron key (start,end)           (a3 grouping)
+//   K2s k2_* scans      segment heads -> junction ids, position runs                 (a3,a7)
+//   K3  k3_anchors      per-junction leftAncStart / rightAncEnd                      (a5)
+//   K4  k4_pairs        per-pair padded query/genome comparison + fragment reduce    (a12,a13,a8)
+//   K5  k5_*            fragment -> junction reduce, entropy, splice motif, hamming  (a6,a7,a9-a11,a13)
+// References in comments are file:line in the reference checkout.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/portcullis_amd.h"
+
+namespace pjb {
+
+typedef unsigned long long u64;
+typedef unsigned int u32;
+
+// ---------------------------------------------------------------------------------------------
+// device-side structures
+// ---------------------------------------------------------------------------------------------
+struct DevBatch {
+    const int32_t *pos;
+    const uint16_t *flag;
+    const uint8_t *mapq;
+    const uint8_t *xs;
+    const int32_t *l_qseq;
+    const int32_t *mtid;
+    const int32_t *mpos;
+    const uint32_t *cig_off;
+    const uint32_t *cigar;
+    const uint32_t *seq_off;
+    const uint8_t *seq4;
+    int64_t n;
+    uint32_t base;      // global read ordinal of record 0 within the contig
+    uint32_t tile_base; // first K1 tile index of this batch
+    int32_t prev_pos;   // pos of the last record of the previous batch (sortedness across batches)
+    int32_t _pad;
+};
+
+// error word: min over (ordinal << 8 | -code); ~0 = no error
+__device__ inline void set_error(u64 *err, u32 ordinal, int code) {
+    atomicMin(err, ((u64)ordinal << 8) | (u64)(u32)(-code));
+}
+
+struct TileStats { // per K1 tile
+    u32 spliced, unspliced;
+    u64 sum_len;
+    int32_t min_len, max_len;
+    int32_t max_end;   // max(pos + alignedLength)
+    int32_t max_nlen;  // longest N op
+    int32_t min_pos;
+    int32_t _pad;
+};
+
+struct ContigStats {
+    u64 spliced, unspliced, sum_len;
+    int32_t min_len, max_len;
+    int32_t max_end, max_nlen, min_pos;
+    u32 n_tiles;
+    u64 n_pairs;
+    u64 err;
+    u32 n_junc, n_runs;
+};
+
+// pairs, structure of arrays (one entry per N operation walked)
+struct Pairs {
+    u64 *key;        // packed intron key (see make_key)
+    u32 *g;          // global read ordinal
+    int32_t *lstart; // lStart  (left anchor start of this pair)
+    int32_t *rend;   // rEndExc-1
+    int32_t *pos;    // read position   (entropy / distinct-alignment runs)
+    int32_t *aend;   // read end = pos + alignedLength - 1
+    u32 *meta;       // bit field, see META_*
+    u32 *updown;     // upjuncs | downjuncs << 16
+};
+
+enum : u32 {
+    META_CAT_MASK = 3u,      // 0 r1pos, 1 r1neg, 2 r2pos, 3 r2neg   (junction.cc:483-498)
+    META_MULTI = 1u << 2,    // read has > 1 N op                    (junction.cc:499)
+    META_XS_SHIFT = 3,       // 2 bits: 0 unknown, 1 '+', 2 '-'
+    META_UM = 1u << 5,       // mapq >= 30                           (junction.cc:773)
+    META_BPP = 1u << 6,      // BAM proper-pair flag                 (junction.cc:780)
+    META_PPP = 1u << 7,      // calcIfProperPair                     (junction.cc:784)
+    META_REL = 1u << 8,      // reliable                             (junction.cc:792)
+};
+
+// key packing: normal case (start << lbits) | intron_len, fallback raw (start << 32) | (u32)end
+struct KeyFmt {
+    int raw;   // 1 = raw 64-bit (weird coordinates present)
+    int lbits; // bits of intron length
+    int total_bits;
+};
+__device__ __host__ inline u64 make_key(const KeyFmt &f, int32_t istart, int32_t iend) {
+    if (f.raw) return ((u64)(u32)istart << 32) | (u64)(u32)iend;
+    return ((u64)(u32)istart << f.lbits) | (u64)(u32)(iend - istart + 1);
+}
+__device__ __host__ inline void unpack_key(const KeyFmt &f, u64 k, int32_t &istart, int32_t &iend) {
+    if (f.raw) {
+        istart = (int32_t)(u32)(k >> 32);
+        iend = (int32_t)(u32)k;
+    } else {
+        istart = (int32_t)(u32)(k >> f.lbits);
+        iend = istart + (int32_t)(u32)(k & ((1ull << f.lbits) - 1)) - 1;
+    }
+}
+
+// CIGAR op classes by BAM op code "MIDNSHP=XB" (bam_alignment.hpp:75-99)
+__device__ __forceinline__ bool op_consumes_ref(u32 op) { return (0x18Du >> op) & 1u; }   // M D N = X
+__device__ __forceinline__ bool op_consumes_query(u32 op) { return (0x193u >> op) & 1u; } // M I S = X
+enum : u32 { OP_M = 0, OP_I = 1, OP_D = 2, OP_N = 3, OP_S = 4 };
+
+// ---------------------------------------------------------------------------------------------
+// wave / block primitives (wave = 64 lanes)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+
+template <typename T>
+__device__ __forceinline__ T wave_sum(T v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+template <typename T>
+__device__ __forceinline__ T wave_max(T v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        T t = __shfl_down(v, o, 64);
+        v = t > v ? t : v;
+    }
+    return v;
+}
+template <typename T>
+__device__ __forceinline__ T wave_min(T v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        T t = __shfl_down(v, o, 64);
+        v = t < v ? t : v;
+    }
+    return v;
+}
+// inclusive scan across the wave
+template <typename T>
+__device__ __forceinline__ T wave_iscan(T v) {
+    int l = lane_id();
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        T t = __shfl_up(v, o, 64);
+        if (l >= o) v += t;
+    }
+    return v;
+}
+
+// exclusive scan over the 256 threads of a block in thread order; returns exclusive prefix, total in *total.
+// smem: at least 4 elements of T.  Contains __syncthreads (call uniformly).
+template <typename T>
+__device__ __forceinline__ T block_escan_256(T v, T *smem, T *total) {
+    T inc = wave_iscan(v);
+    int w = threadIdx.x >> 6, l = lane_id();
+    __syncthreads();
+    if (l == 63) smem[w] = inc;
+    __syncthreads();
+    T base = 0, tot = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        T s = smem[i];
+        if (i < w) base += s;
+        tot += s;
+    }
+    *total = tot;
+    return base + inc - v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// generic multi-block exclusive scan of u64 values produced by a functor (3 kernels)
+// ---------------------------------------------------------------------------------------------
+constexpr int SCAN_TILE = 2048; // 256 threads x 8
+
+template <typename F>
+__global__ __launch_bounds__(256) void scan_reduce_kernel(F f, u64 n, u64 *tile_sums) {
+    __shared__ u64 sm[4];
+    u64 base = (u64)blockIdx.x * SCAN_TILE;
+    u64 s = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        u64 i = base + (u64)k * 256 + threadIdx.x;
+        if (i < n) s += f(i);
+    }
+    s = wave_sum(s);
+    if (lane_id() == 0) sm[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) tile_sums[blockIdx.x] = sm[0] + sm[1] + sm[2] + sm[3];
+}
+
+// single block: in-place exclusive scan of tile sums; writes grand total to *total
+__global__ __launch_bounds__(1024) void scan_tiles_kernel(u64 *tile_sums, u32 n_tiles, u64 *total) {
+    __shared__ u64 wsum[16];
+    __shared__ u64 carry_s;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (u32 base = 0; base < n_tiles; base += 1024) {
+        u32 i = base + threadIdx.x;
+        u64 v = i < n_tiles ? tile_sums[i] : 0;
+        u64 inc = wave_iscan(v);
+        int w = threadIdx.x >> 6;
+        if (lane_id() == 63) wsum[w] = inc;
+        __syncthreads();
+        u64 wb = 0, tot = 0;
+        for (int k = 0; k < 16; k++) {
+            u64 s = wsum[k];
+            if (k < w) wb += s;
+            tot += s;
+        }
+        u64 carry = carry_s;
+        if (i < n_tiles) tile_sums[i] = carry + wb + inc - v;
+        __syncthreads();
+        if (threadIdx.x == 0) carry_s = carry + tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *total = carry_s;
+}
+
+// third kernel: recompute values, exclusive prefix handed to the sink g(i, value, exclusive_prefix)
+template <typename F, typename G>
+__global__ __launch_bounds__(256) void scan_apply_kernel(F f, G g, u64 n, const u64 *tile_sums) {
+    __shared__ u64 sm[4];
+    u64 base = (u64)blockIdx.x * SCAN_TILE;
+    u64 run = tile_sums[blockIdx.x];
+    // thread order within the tile must equal element order: round k covers [base+k*256, +256)
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        u64 i = base + (u64)k * 256 + threadIdx.x;
+        u64 v = i < n ? f(i) : 0;
+        u64 tot;
+        u64 ex = block_escan_256<u64>(v, sm, &tot);
+        if (i < n) g(i, v, run + ex);
+        run += tot;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K0: upper-case contig bases in place (boost::to_upper on fetched strings, junction.cc:586-587,635-638)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k0_upper(uint8_t *g, int64_t n, int do_upper, int *has_x) {
+    int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 16;
+    bool x = false;
+    for (int64_t j = i; j < n && j < i + 16; j++) {
+        uint8_t c = g[j];
+        x |= (c == 'X' || (do_upper && c == 'x'));
+    }
+    if (__ballot(x) && lane_id() == 0) atomicOr(has_x, 1);
+    if (!do_upper) return;
+    if (i + 16 <= n && ((uintptr_t)(g + i) & 15) == 0) {
+        uint4 v = *reinterpret_cast<uint4 *>(g + i);
+        u32 *w = reinterpret_cast<u32 *>(&v);
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            u32 x = w[k], r = 0;
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                u32 c = (x >> (8 * b)) & 0xff;
+                if (c >= 'a' && c <= 'z') c -= 32;
+                r |= c << (8 * b);
+            }
+            w[k] = r;
+        }
+        *reinterpret_cast<uint4 *>(g + i) = v;
+    } else {
+        for (int64_t j = i; j < n && j < i + 16; j++) {
+            uint8_t c = g[j];
+            if (c >= 'a' && c <= 'z') g[j] = c - 32;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K1a: per-read CIGAR walk, pass 1 (BamAlignment::init bam_alignment.cc:71-100, findJuncs length
+// stats src/junction_builder.cc:333-343).  One thread per read; a tile is 1024 consecutive reads.
+// ---------------------------------------------------------------------------------------------
+constexpr int K1_TILE = 1024;
+
+__global__ __launch_bounds__(256) void k1_count(DevBatch b, u32 *tile_cnt, TileStats *tile_stats, u64 *err) {
+    __shared__ u64 sm64[4];
+    __shared__ int32_t smi[4][6];
+    int64_t base = (int64_t)blockIdx.x * K1_TILE;
+    u32 cnt = 0, spl = 0, uns = 0;
+    u64 sum = 0;
+    int32_t mn = INT32_MAX, mx = 0, max_end = 0, max_nlen = 0, min_pos = INT32_MAX;
+#pragma unroll
+    for (int it = 0; it < 4; it++) {
+        int64_t r = base + it * 256 + threadIdx.x;
+        if (r < b.n) {
+            u32 c0 = b.cig_off[r], c1 = b.cig_off[r + 1];
+            int32_t p = b.pos[r];
+            int32_t prev = r > 0 ? b.pos[r - 1] : b.prev_pos;
+            if (p < prev) set_error(err, b.base + (u32)r, PJB_ERR_UNSORTED);
+            if (b.xs[r] > 2) set_error(err, b.base + (u32)r, PJB_ERR_BAD_XS);
+            u32 c = 0;
+            int32_t al = 0;
+            for (u32 k = c0; k < c1; k++) {
+                u32 op = b.cigar[k];
+                u32 ty = op & 15u;
+                int32_t ln = (int32_t)(op >> 4);
+                if (op_consumes_ref(ty)) al += ln;
+                if (ty == OP_N) {
+                    c++;
+                    max_nlen = ln > max_nlen ? ln : max_nlen;
+                }
+            }
+            int32_t len = b.l_qseq[r];
+            mn = len < mn ? len : mn;
+            mx = len > mx ? len : mx;
+            sum += (u64)(int64_t)len;
+            cnt += c;
+            if (c) {
+                spl++;
+                int32_t e = p + al;
+                max_end = e > max_end ? e : max_end;
+                min_pos = p < min_pos ? p : min_pos;
+            } else
+                uns++;
+        }
+    }
+    // block reduce
+    u64 packed = ((u64)cnt << 32) | ((u64)spl << 16) | (u64)uns; // per tile: spl,uns <= 1024; cnt <= 1024*65535 < 2^26
+    packed = wave_sum(packed);
+    sum = wave_sum(sum);
+    mn = wave_min(mn);
+    mx = wave_max(mx);
+    max_end = wave_max(max_end);
+    max_nlen = wave_max(max_nlen);
+    min_pos = wave_min(min_pos);
+    int w = threadIdx.x >> 6;
+    __shared__ u64 smp[4];
+    if (lane_id() == 0) {
+        smp[w] = packed;
+        sm64[w] = sum;
+        smi[w][0] = mn;
+        smi[w][1] = mx;
+        smi[w][2] = max_end;
+        smi[w][3] = max_nlen;
+        smi[w][4] = min_pos;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        u64 p = smp[0] + smp[1] + smp[2] + smp[3];
+        TileStats t;
+        t.spliced = (u32)((p >> 16) & 0xffff);
+        t.unspliced = (u32)(p & 0xffff);
+        t.sum_len = sm64[0] + sm64[1] + sm64[2] + sm64[3];
+        t.min_len = min(min(smi[0][0], smi[1][0]), min(smi[2][0], smi[3][0]));
+        t.max_len = max(max(smi[0][1], smi[1][1]), max(smi[2][1], smi[3][1]));
+        t.max_end = max(max(smi[0][2], smi[1][2]), max(smi[2][2], smi[3][2]));
+        t.max_nlen = max(max(smi[0][3], smi[1][3]), max(smi[2][3], smi[3][3]));
+        t.min_pos = min(min(smi[0][4], smi[1][4]), min(smi[2][4], smi[3][4]));
+        t._pad = 0;
+        tile_stats[b.tile_base + blockIdx.x] = t;
+        tile_cnt[b.tile_base + blockIdx.x] = (u32)(p >> 32);
+    }
+}
+
+// single block: exclusive scan of per-tile pair counts (in place) + reduction of tile stats
+__global__ __launch_bounds__(1024) void k1_scan_tiles(u32 *tile_cnt, const TileStats *ts, u32 n_tiles, ContigStats *out) {
+    __shared__ u64 wsum[16];
+    __shared__ u64 carry_s;
+    __shared__ u64 r_spl[16], r_uns[16], r_sum[16];
+    __shared__ int32_t r_i[16][5];
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    u64 spl = 0, uns = 0, sum = 0;
+    int32_t mn = INT32_MAX, mx = 0, max_end = 0, max_nlen = 0, min_pos = INT32_MAX;
+    for (u32 base = 0; base < n_tiles; base += 1024) {
+        u32 i = base + threadIdx.x;
+        u64 v = 0;
+        if (i < n_tiles) {
+            v = tile_cnt[i];
+            TileStats t = ts[i];
+            spl += t.spliced;
+            uns += t.unspliced;
+            sum += t.sum_len;
+            mn = min(mn, t.min_len);
+            mx = max(mx, t.max_len);
+            max_end = max(max_end, t.max_end);
+            max_nlen = max(max_nlen, t.max_nlen);
+            min_pos = min(min_pos, t.min_pos);
+        }
+        u64 inc = wave_iscan(v);
+        int w = threadIdx.x >> 6;
+        if (lane_id() == 63) wsum[w] = inc;
+        __syncthreads();
+        u64 wb = 0, tot = 0;
+        for (int k = 0; k < 16; k++) {
+            u64 s = wsum[k];
+            if (k < w) wb += s;
+            tot += s;
+        }
+        u64 carry = carry_s;
+        // NOTE: exclusive offsets are stored as 32-bit: a contig is limited to < 2^32 pairs
+        if (i < n_tiles) tile_cnt[i] = (u32)(carry + wb + inc - v);
+        __syncthreads();
+        if (threadIdx.x == 0) carry_s = carry + tot;
+        __syncthreads();
+    }
+    spl = wave_sum(spl);
+    uns = wave_sum(uns);
+    sum = wave_sum(sum);
+    mn = wave_min(mn);
+    mx = wave_max(mx);
+    max_end = wave_max(max_end);
+    max_nlen = wave_max(max_nlen);
+    min_pos = wave_min(min_pos);
+    int w = threadIdx.x >> 6;
+    if (lane_id() == 0) {
+        r_spl[w] = spl;
+        r_uns[w] = uns;
+        r_sum[w] = sum;
+        r_i[w][0] = mn;
+        r_i[w][1] = mx;
+        r_i[w][2] = max_end;
+        r_i[w][3] = max_nlen;
+        r_i[w][4] = min_pos;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        u64 a = 0, b2 = 0, c = 0;
+        int32_t m0 = INT32_MAX, m1 = 0, m2 = 0, m3 = 0, m4 = INT32_MAX;
+        for (int k = 0; k < 16; k++) {
+            a += r_spl[k];
+            b2 += r_uns[k];
+            c += r_sum[k];
+            m0 = min(m0, r_i[k][0]);
+            m1 = max(m1, r_i[k][1]);
+            m2 = max(m2, r_i[k][2]);
+            m3 = max(m3, r_i[k][3]);
+            m4 = min(m4, r_i[k][4]);
+        }
+        out->spliced = a;
+        out->unspliced = b2;
+        out->sum_len = c;
+        out->min_len = m0;
+        out->max_len = m1;
+        out->max_end = m2;
+        out->max_nlen = m3;
+        out->min_pos = m4;
+        out->n_tiles = n_tiles;
+        out->n_pairs = carry_s;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K1b: per-read CIGAR walk, pass 2: emit one pair per N op in BAM order
+// (JunctionSystem::addJunctions junction_system.cc:140-210 restated iteratively:
+//  after an N op the next left anchor starts at the CLAMPED rStart; rEndExc is the UNCLAMPED
+//  rStart plus the reference-consuming ops up to the next N, then clamped).
+// Per-pair predicates of Junction::addJunctionAlignment (junction.cc:477-502) and
+// calcAlignmentStats (junction.cc:755-814) are evaluated here, where the read's fixed-width
+// fields are read coalesced, and packed into `meta`.
+// ---------------------------------------------------------------------------------------------
+struct NCursor { // walks the N ops of one CIGAR yielding the unclamped position after each N
+    u32 i;
+    int32_t acc;
+    bool has;
+    int32_t peek;
+};
+__device__ __forceinline__ void ncursor_advance(NCursor &c, const uint32_t *cig, u32 n) {
+    c.has = false;
+    while (c.i < n) {
+        u32 op = cig[c.i++];
+        u32 ty = op & 15u;
+        if (op_consumes_ref(ty)) c.acc += (int32_t)(op >> 4);
+        if (ty == OP_N) {
+            c.has = true;
+            c.peek = c.acc;
+            return;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k1_emit(DevBatch b, const u32 *tile_off, Pairs P, KeyFmt kf, int32_t ref_len,
+                                                int32_t tid, int orientation, u64 *err) {
+    __shared__ u32 sm[4];
+    int64_t base = (int64_t)blockIdx.x * K1_TILE;
+    u32 run = tile_off[b.tile_base + blockIdx.x];
+    const bool pp_check = orientation == PJB_OR_FR || orientation == PJB_OR_RF || orientation == PJB_OR_FF;
+#pragma unroll 1
+    for (int it = 0; it < 4; it++) {
+        int64_t r = base + it * 256 + threadIdx.x;
+        u32 c0 = 0, c1 = 0, nN = 0;
+        if (r < b.n) {
+            c0 = b.cig_off[r];
+            c1 = b.cig_off[r + 1];
+            for (u32 k = c0; k < c1; k++) nN += ((b.cigar[k] & 15u) == OP_N);
+        }
+        u32 tot;
+        u32 off = run + block_escan_256<u32>(nN, sm, &tot);
+        run += tot;
+        if (nN == 0) continue;
+        const uint32_t *cig = b.cigar + c0;
+        const u32 n = c1 - c0;
+        const int32_t pos = b.pos[r];
+        const u32 g = b.base + (u32)r;
+        // ---- per-read predicates
+        const u32 flag = b.flag[r];
+        const bool first = flag & 0x40, rev = flag & 0x10;
+        u32 meta = (first ? 0u : 2u) + (rev ? 1u : 0u);
+        if (nN > 1) meta |= META_MULTI;
+        meta |= ((u32)b.xs[r] & 3u) << META_XS_SHIFT;
+        const bool um = b.mapq[r] >= 30;
+        if (um) meta |= META_UM;
+        if (flag & 0x2) meta |= META_BPP;
+        bool ppp = false;
+        if (pp_check) { // BamAlignment::calcIfProperPair, bam_alignment.cc:271-292
+            const bool paired = flag & 0x1, mate_mapped = !(flag & 0x8);
+            if (paired && mate_mapped && tid == b.mtid[r]) {
+                const bool mrev = flag & 0x20;
+                const bool diff = rev != mrev;
+                const int32_t mp = b.mpos[r];
+                const bool gap = !rev ? pos < mp : pos > mp;
+                ppp = orientation == PJB_OR_FR ? (diff && gap) : orientation == PJB_OR_RF ? (diff && !gap) : (!diff && gap);
+            }
+        }
+        if (ppp) meta |= META_PPP;
+        if (um && (!pp_check || ppp)) meta |= META_REL;
+        // ---- walk
+        int32_t lStart = pos, lEndExc = pos, aligned = 0, sumAfter = 0, prevRStartU = 0;
+        int64_t prev = -1;
+        u32 k = 0;
+        for (u32 i = 0; i < n; i++) {
+            const u32 op = cig[i];
+            const u32 ty = op & 15u;
+            const int32_t ln = (int32_t)(op >> 4);
+            if (ty == OP_N) {
+                if (prev >= 0) {
+                    int32_t rEndExc = prevRStartU + sumAfter;
+                    if (rEndExc - 1 >= ref_len) rEndExc = ref_len; // junction_system.cc:172-174
+                    P.rend[prev] = rEndExc - 1;
+                }
+                const int32_t istart = lEndExc;
+                const int32_t rStartU = lEndExc + ln;
+                int32_t rStart = rStartU;
+                if (rStart - 1 >= ref_len) rStart = ref_len - 1; // junction_system.cc:169-171
+                const int32_t iend = rStart - 1;
+                const int64_t idx = (int64_t)off + k;
+                P.key[idx] = make_key(kf, istart, iend);
+                P.g[idx] = g;
+                P.lstart[idx] = lStart;
+                P.pos[idx] = pos;
+                P.meta[idx] = meta;
+                if (lStart > istart) set_error(err, g, PJB_ERR_MIN_ANCHOR); // intron.cc:68
+                prev = idx;
+                prevRStartU = rStartU;
+                sumAfter = 0;
+                lStart = rStart;
+                lEndExc = rStart;
+                aligned += ln;
+                k++;
+            } else if (op_consumes_ref(ty)) {
+                lEndExc += ln;
+                sumAfter += ln;
+                aligned += ln;
+            }
+        }
+        {
+            int32_t rEndExc = prevRStartU + sumAfter;
+            if (rEndExc - 1 >= ref_len) rEndExc = ref_len;
+            P.rend[prev] = rEndExc - 1;
+        }
+        // ---- phase 2: read end, up/down junction counts (junction.cc:795-812) with two monotone cursors
+        const int32_t aend = pos + aligned - 1;
+        NCursor U = {0, pos, false, 0}, D = {0, pos, false, 0};
+        ncursor_advance(U, cig, n);
+        ncursor_advance(D, cig, n);
+        u32 cntU = 0, cntD = 0;
+        for (u32 q = 0; q < nN; q++) {
+            const int64_t idx = (int64_t)off + q;
+            int32_t istart, iend;
+            unpack_key(kf, P.key[idx], istart, iend);
+            if (P.rend[idx] < iend) set_error(err, g, PJB_ERR_MIN_ANCHOR); // intron.cc:76
+            while (U.has && U.peek < istart) {
+                cntU++;
+                ncursor_advance(U, cig, n);
+            }
+            while (D.has && D.peek <= iend + 1) {
+                cntD++;
+                ncursor_advance(D, cig, n);
+            }
+            P.aend[idx] = aend;
+            P.updown[idx] = cntU | ((nN - cntD) << 16);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K2: stable LSD radix sort of (key, pair index).  Classic 3-step passes: per-tile digit
+// histogram -> exclusive scan of the bin-major count matrix -> ranked scatter.  Stability comes
+// from ranking in memory order: wave w of a tile owns a contiguous 1/4 of it, rounds are
+// contiguous 64-element slices, and equal digits inside a round are ranked by lane with a
+// ballot-based match-any.
+// ---------------------------------------------------------------------------------------------
+constexpr int RS_ITEMS = 16;
+constexpr int RS_TILE = 256 * RS_ITEMS; // 4096 keys per block
+constexpr int RS_MAX_BITS = 11;
+constexpr int RS_MAX_BINS = 1 << RS_MAX_BITS;
+
+__global__ __launch_bounds__(256) void rs_hist(const u64 *keys, u32 n, int shift, int bits, u32 *hist, u32 n_tiles) {
+    __shared__ u32 h[RS_MAX_BINS];
+    const u32 nb = 1u << bits;
+    for (u32 d = threadIdx.x; d < nb; d += 256) h[d] = 0;
+    __syncthreads();
+    const u32 base = blockIdx.x * RS_TILE;
+    const u32 mask = nb - 1;
+#pragma unroll
+    for (int k = 0; k < RS_ITEMS; k++) {
+        u32 i = base + k * 256 + threadIdx.x;
+        if (i < n) atomicAdd(&h[(u32)(keys[i] >> shift) & mask], 1u);
+    }
+    __syncthreads();
+    for (u32 d = threadIdx.x; d < nb; d += 256) hist[(size_t)d * n_tiles + blockIdx.x] = h[d];
+}
+
+__global__ __launch_bounds__(256) void rs_scatter(const u64 *kin, const u32 *vin, u64 *kout, u32 *vout, u32 n, int shift,
+                                                   int bits, const u32 *hist_scan, u32 n_tiles) {
+    __shared__ u32 wcnt[4][RS_MAX_BINS];
+    const u32 nb = 1u << bits;
+    const u32 mask = nb - 1;
+    for (u32 d = threadIdx.x; d < 4 * RS_MAX_BINS; d += 256) (&wcnt[0][0])[d] = 0;
+    __syncthreads();
+    const int w = threadIdx.x >> 6, lane = lane_id();
+    const u32 base = blockIdx.x * RS_TILE + w * (RS_TILE / 4);
+    const u64 lt = (1ull << lane) - 1;
+    u64 key[RS_ITEMS];
+    u32 rk[RS_ITEMS];
+#pragma unroll
+    for (int r = 0; r < RS_ITEMS; r++) {
+        const u32 i = base + r * 64 + lane;
+        const bool valid = i < n;
+        const u64 kk = valid ? kin[i] : 0;
+        const u32 d = (u32)(kk >> shift) & mask;
+        u64 peers = __ballot(valid);
+        for (int bit = 0; bit < bits; bit++) {
+            const bool bset = (d >> bit) & 1u;
+            const u64 bb = __ballot(bset);
+            peers &= bset ? bb : ~bb;
+        }
+        u32 before = 0;
+        if (valid) {
+            const int leader = __ffsll((long long)peers) - 1;
+            if (lane == leader) {
+                before = wcnt[w][d];
+                wcnt[w][d] = before + (u32)__popcll(peers);
+            }
+            before = __shfl(before, leader, 64);
+        } else {
+            (void)__shfl(before, 0, 64);
+        }
+        rk[r] = before + (u32)__popcll(peers & lt);
+        key[r] = kk;
+    }
+    __syncthreads();
+    // per digit: base = exclusive scan entry (bin-major matrix) ; then prefix over the 4 waves
+    for (u32 d = threadIdx.x; d < nb; d += 256) {
+        u32 b0 = hist_scan[(size_t)d * n_tiles + blockIdx.x];
+        u32 c0 = wcnt[0][d], c1 = wcnt[1][d], c2 = wcnt[2][d];
+        wcnt[0][d] = b0;
+        wcnt[1][d] = b0 + c0;
+        wcnt[2][d] = b0 + c0 + c1;
+        wcnt[3][d] = b0 + c0 + c1 + c2;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < RS_ITEMS; r++) {
+        const u32 i = base + r * 64 + lane;
+        if (i < n) {
+            const u32 d = (u32)(key[r] >> shift) & mask;
+            const u32 dst = wcnt[w][d] + rk[r];
+            kout[dst] = key[r];
+            vout[dst] = vin ? vin[i] : i;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K2s: segment heads.  For sorted position i:  head_j = new intron key; head_r = head_j or read
+// position differs from the previous pair of the junction (entropy runs, junction.cc:730-749).
+// One u64 scan carries both counters (junction count << 32 | run count).
+// ---------------------------------------------------------------------------------------------
+struct HeadFn {
+    const u64 *skey;
+    const u32 *sidx;
+    const int32_t *ppos;
+    __device__ u64 operator()(u64 i) const {
+        if (i == 0) return (1ull << 32) | 1ull;
+        const bool hj = skey[i] != skey[i - 1];
+        const bool hr = hj || ppos[sidx[i]] != ppos[sidx[i - 1]];
+        return ((u64)hj << 32) | (u64)hr;
+    }
+};
+struct HeadSink {
+    u32 *jid_of;    // [P]   junction id per sorted pair
+    u32 *seg_off;   // [J+1] first sorted pair of junction
+    u32 *run_first; // [J+1] first run of junction
+    u32 *run_start; // [R+1] first sorted pair of run
+    __device__ void operator()(u64 i, u64 v, u64 ex) const {
+        const u32 j = (u32)(ex >> 32) + (u32)(v >> 32) - 1; // inclusive count - 1
+        const u32 r = (u32)ex + (u32)v - 1;
+        jid_of[i] = j;
+        if (v >> 32) {
+            seg_off[j] = (u32)i;
+            run_first[j] = r;
+        }
+        if ((u32)v) run_start[r] = (u32)i;
+    }
+};
+__global__ void k2_close(u64 *total, u32 *seg_off, u32 *run_first, u32 *run_start, u32 n_pairs, ContigStats *cs) {
+    const u32 J = (u32)(*total >> 32), R = (u32)*total;
+    seg_off[J] = n_pairs;
+    run_first[J] = R;
+    run_start[R] = n_pairs;
+    cs->n_junc = J;
+    cs->n_runs = R;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Fragments.  The sorted pair array is processed in fixed 64-pair slices (one wavefront each).
+// A fragment is a maximal run of one junction inside one slice; its slot is jid + slice index,
+// which is unique and increasing along the array (a slot is skipped when a junction starts
+// exactly on a slice boundary).  Kernels reduce pairs -> fragment slots with a segmented wave
+// reduction, a second small kernel reduces slots -> junctions (segmented again, then one atomic
+// per wave and junction), so a junction with 10^6 pairs costs ~250 same-address atomics, not 10^6.
+// ---------------------------------------------------------------------------------------------
+
+// segmented (by key) reduce towards the segment's FIRST lane; keys are sorted across lanes
+template <typename T, typename OP>
+__device__ __forceinline__ T seg_reduce_to_head(T v, u32 segkey, OP op) {
+    const int l = lane_id();
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        T t = __shfl_down(v, o, 64);
+        u32 k = __shfl_down(segkey, o, 64);
+        if (l + o < 64 && k == segkey) v = op(v, t);
+    }
+    return v;
+}
+struct OpMin { template <typename T> __device__ T operator()(T a, T b) const { return a < b ? a : b; } };
+struct OpMax { template <typename T> __device__ T operator()(T a, T b) const { return a > b ? a : b; } };
+struct OpAdd { template <typename T> __device__ T operator()(T a, T b) const { return a + b; } };
+
+// K3: anchors per fragment
+__global__ __launch_bounds__(256) void k3_anchors_frag(const u32 *sidx, const u32 *jid_of, const int32_t *lstart,
+                                                        const int32_t *rend, u32 n, int32_t *frag_l, int32_t *frag_r,
+                                                        int32_t *frag_j) {
+    const u32 i = blockIdx.x * 256 + threadIdx.x;
+    const bool valid = i < n;
+    const u32 p = valid ? sidx[i] : 0;
+    const u32 j = valid ? jid_of[i] : 0xffffffffu;
+    int32_t l = valid ? lstart[p] : INT32_MAX;
+    int32_t r = valid ? rend[p] : INT32_MIN;
+    l = seg_reduce_to_head(l, j, OpMin());
+    r = seg_reduce_to_head(r, j, OpMax());
+    const u32 jprev = __shfl_up(j, 1, 64);
+    const bool head = valid && (lane_id() == 0 || jprev != j);
+    if (head) {
+        const u32 slot = j + (i >> 6);
+        frag_l[slot] = l;
+        frag_r[slot] = r;
+        frag_j[slot] = (int32_t)j;
+    }
+}
+// K3b: fragment slots -> junction anchors (anc_l/anc_r pre-initialised to INT32_MAX / INT32_MIN)
+__global__ __launch_bounds__(256) void k3_anchors_junc(const int32_t *frag_l, const int32_t *frag_r, const int32_t *frag_j,
+                                                        u32 n_slots, int32_t *anc_l, int32_t *anc_r) {
+    const u32 s = blockIdx.x * 256 + threadIdx.x;
+    const bool in = s < n_slots;
+    const int32_t jj = in ? frag_j[s] : -1;
+    const bool valid = jj >= 0;
+    // unused slots get a key that never equals a neighbour's
+    const u32 key = valid ? (u32)jj : (0x80000000u | s);
+    int32_t l = valid ? frag_l[s] : INT32_MAX;
+    int32_t r = valid ? frag_r[s] : INT32_MIN;
+    l = seg_reduce_to_head(l, key, OpMin());
+    r = seg_reduce_to_head(r, key, OpMax());
+    const u32 kprev = __shfl_up(key, 1, 64);
+    if (valid && (lane_id() == 0 || kprev != key)) {
+        atomicMin(&anc_l[jj], l);
+        atomicMax(&anc_r[jj], r);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K4: per-pair match statistics (AlignmentInfo::calcMatchStats junction.cc:147-240 on top of
+// BamAlignment::getPaddedQuerySeq / getPaddedGenomeSeq bam_alignment.cc:341-462), computed by
+// counting instead of building strings: the query walk and the genome walk are advanced in
+// lock-step over the CIGAR and their emissions compared op by op.
+// ---------------------------------------------------------------------------------------------
+struct Side {
+    int32_t len, mism, first_mis, last_mis;
+    int err;
+};
+
+__device__ __forceinline__ u32 nt16_ascii(u32 c) { // seq_nt16_str "=ACMGRSVTWYHKDBN"
+    // bytes: '=' 3D, 'A' 41, 'C' 43, 'M' 4D, 'G' 47, 'R' 52, 'S' 53, 'V' 56 | 'T' 54,'W' 57,'Y' 59,'H' 48,'K' 4B,'D' 44,'B' 42,'N' 4E
+    const u64 t0 = 0x565352474D43413DULL;
+    const u64 t1 = 0x4E42444B48595754ULL;
+    const u64 t = (c & 8u) ? t1 : t0;
+    return (u32)(t >> ((c & 7u) * 8)) & 0xffu;
+}
+
+__device__ Side anchor_side(const uint32_t *cig, u32 n, int32_t position, int32_t aligned, const uint8_t *seq, int32_t lq,
+                            const uint8_t *genome, int32_t glen, bool genome_has_x, int32_t start, int32_t end) {
+    Side S;
+    S.len = 0;
+    S.mism = 0;
+    S.first_mis = -1;
+    S.last_mis = -1;
+    S.err = 0;
+    const int32_t get_end = position + aligned - 1;
+    if (start > get_end || end < position) { // bam_alignment.cc:342
+        S.err = PJB_ERR_NO_PRESENCE;
+        return S;
+    }
+    // getQuerySeqAfterClipping, bam_alignment.cc:256-264 (size_t arithmetic incl. the "+1")
+    int32_t dS = 0, dE = 0;
+    if ((cig[0] & 15u) == OP_S) dS = (int32_t)(cig[0] >> 4);
+    if ((cig[n - 1] & 15u) == OP_S) dE = (int32_t)(cig[n - 1] >> 4);
+    if (dS > lq) {
+        S.err = PJB_ERR_CLIP_RANGE;
+        return S;
+    }
+    const u64 cnt = (u64)(int64_t)lq - (u64)(int64_t)dS - (u64)(int64_t)dE + 1ull;
+    const u64 avail = (u64)(lq - dS);
+    const int32_t clen = (int32_t)(cnt < avail ? cnt : avail);
+    // ---- pass A: query walk over ops only -> where it stops (actual_start / actual_end)
+    int32_t rPos = position, qPos = 0;
+    for (u32 k = 0; k < n; k++) {
+        const u32 op = cig[k], ty = op & 15u;
+        const int32_t ln = (int32_t)(op >> 4);
+        const bool cRef = op_consumes_ref(ty);
+        const bool cQry = op_consumes_query(ty) && ty != OP_S;
+        if (rPos < start) {
+            if (cRef) rPos += ln;
+            if (cQry) qPos += ln;
+            continue;
+        }
+        if ((rPos > end && ty != OP_I) || (ty == OP_N && rPos + ln > end)) break; // :359
+        if (cQry) {
+            const int32_t l = (rPos + ln > end && ty != OP_I) ? end - rPos + 1 : ln;
+            if (l == 0) {
+                S.err = PJB_ERR_ZERO_LEN_OP;
+                return S;
+            }
+            if (qPos < 0 || qPos + l > clen) {
+                S.err = PJB_ERR_QUERY_RANGE;
+                return S;
+            }
+        }
+        if (cRef) rPos += ln;
+        if (cQry) qPos += ln;
+    }
+    const int32_t q_start = position > start ? position : start; // :400
+    const int32_t q_end = rPos <= end ? rPos - 1 : end;          // :401
+    if (q_start - start < 0 || end - q_end < 0) {                // :414-421 (unreachable, kept for parity)
+        S.err = PJB_ERR_QREGION;
+        return S;
+    }
+    const int32_t gsize = end - start + 1; // length of the fetched anchor string
+    // ---- pass B: both walks in lock-step, comparing emissions
+    rPos = position;
+    qPos = 0;
+    bool qDone = false, gDone = false, diverged = false;
+    int32_t qTot = 0, gTot = 0, mism = 0, first_mis = -1, last_mis = -1;
+    for (u32 k = 0; k < n; k++) {
+        const u32 op = cig[k], ty = op & 15u;
+        const int32_t ln = (int32_t)(op >> 4);
+        const bool cRef = op_consumes_ref(ty);
+        const bool cQry = op_consumes_query(ty) && ty != OP_S;
+        int32_t qEmit = 0, gEmit = 0;
+        int qKind = 0, gKind = 0; // 1 = bases, 2 = 'X' padding
+        if (!qDone && rPos >= start) {
+            if ((rPos > end && ty != OP_I) || (ty == OP_N && rPos + ln > end)) qDone = true;
+            else if (cQry) {
+                qEmit = (rPos + ln > end && ty != OP_I) ? end - rPos + 1 : ln;
+                qKind = 1;
+            } else if (cRef) {
+                qEmit = rPos + ln > end ? end - rPos + 1 : ln;
+                qKind = 2;
+            }
+        }
+        if (!gDone && rPos >= q_start) {
+            if (rPos > q_end && ty != OP_I) gDone = true;
+            else if (cRef) {
+                const int32_t so = rPos - start;
+                gEmit = rPos + ln > q_end ? q_end - rPos + 1 : ln;
+                if (so < 0 || so + gEmit > gsize) { // :437
+                    S.err = PJB_ERR_GENOME_RANGE;
+                    return S;
+                }
+                gKind = 1;
+            } else if (cQry) {
+                gEmit = ln;
+                gKind = 2;
+            }
+        }
+        if (qEmit != gEmit) diverged = true;
+        if (!diverged && qEmit > 0) {
+            if (qKind == 1 && gKind == 1) {
+                const int32_t qb = dS + qPos;
+                for (int32_t t = 0; t < qEmit; t++) {
+                    const int32_t qi = qb + t;
+                    const u32 byte = seq[qi >> 1];
+                    const u32 code = (qi & 1) ? (byte & 15u) : (byte >> 4);
+                    const int32_t gi = rPos + t;
+                    const u32 gc = (gi >= 0 && gi < glen) ? genome[gi] : 0u;
+                    if (nt16_ascii(code) != gc) {
+                        mism++;
+                        if (first_mis < 0) first_mis = qTot + t;
+                        last_mis = qTot + t;
+                    }
+                }
+            } else if (qKind == 1) { // read letters vs 'X' (insertion): never equal
+                mism += qEmit;
+                if (first_mis < 0) first_mis = qTot;
+                last_mis = qTot + qEmit - 1;
+            } else if (!genome_has_x) { // 'X' padding (deletion / enclosed intron) vs genome bases without any 'X'
+                mism += qEmit;
+                if (first_mis < 0) first_mis = qTot;
+                last_mis = qTot + qEmit - 1;
+            } else { // contig really contains 'X' characters: compare byte by byte
+                for (int32_t t = 0; t < qEmit; t++) {
+                    const int32_t gi = rPos + t;
+                    const u32 gc = (gi >= 0 && gi < glen) ? genome[gi] : 0u;
+                    if (gc != (u32)'X') {
+                        mism++;
+                        if (first_mis < 0) first_mis = qTot + t;
+                        last_mis = qTot + t;
+                    }
+                }
+            }
+        }
+        qTot += qEmit;
+        gTot += gEmit;
+        if (cRef) rPos += ln;
+        if (cQry) qPos += ln;
+        if (qDone && gDone) break;
+    }
+    if (qTot != gTot || qTot == 0) { // junction.cc:192,208
+        S.err = PJB_ERR_ANCHOR_MISMATCH;
+        return S;
+    }
+    if (diverged) {
+        S.err = PJB_ERR_DIVERGENT;
+        return S;
+    }
+    S.len = qTot;
+    S.mism = mism;
+    S.first_mis = first_mis;
+    S.last_mis = last_mis;
+    return S;
+}
+
+// fragment record: 48 words
+enum {
+    F_N = 0, F_R1P, F_R1N, F_R2P, F_R2N, F_MS, F_XSP, F_XSN, F_UM, F_BPP, F_PPP, F_REL, F_DIST, // sums
+    F_MAXMINANC, F_UP, F_DOWN, F_MAXMMES, F_MAXMINMATCH,                                       // max
+    F_FIRSTMIS,                                                                                 // min
+    F_PAD19,                                                                                    // keeps the next pair 8-byte aligned
+    F_MISM_LO, F_MISM_HI,                                                                       // 64-bit sum
+    F_JAD0,                                                                                     // 20 sums
+    F_WORDS = 48
+};
+
+__global__ __launch_bounds__(256) void k4_pairs(const u64 *skey, const u32 *sidx, const u32 *jid_of, Pairs P, KeyFmt kf,
+                                                 const DevBatch *batches, int n_batches, const int32_t *anc_l,
+                                                 const int32_t *anc_r, const uint8_t *genome, int32_t glen, int genome_has_x,
+                                                 u32 n, u32 *frag, int32_t *frag_j, u64 *err) {
+    const u32 i = blockIdx.x * 256 + threadIdx.x;
+    const bool valid = i < n;
+    const int lane = lane_id();
+    u32 j = 0xffffffffu;
+    u32 vals[F_WORDS];
+#pragma unroll
+    for (int k = 0; k < F_WORDS; k++) vals[k] = 0;
+    vals[F_FIRSTMIS] = 100000000u; // junction.cc:864
+    u64 mism64 = 0;
+    if (valid) {
+        const u32 p = sidx[i];
+        j = jid_of[i];
+        const u32 g = P.g[p];
+        // locate the batch holding read ordinal g
+        int lo = 0, hi = n_batches - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (batches[mid].base <= g) lo = mid;
+            else hi = mid - 1;
+        }
+        const DevBatch &b = batches[lo];
+        const u32 r = g - b.base;
+        int32_t istart, iend;
+        unpack_key(kf, skey[i], istart, iend);
+        const int32_t left = anc_l[j], right = anc_r[j];
+        const u32 c0 = b.cig_off[r], c1 = b.cig_off[r + 1];
+        const uint32_t *cig = b.cigar + c0;
+        const u32 nc = c1 - c0;
+        const int32_t pos = P.pos[p], aend = P.aend[p];
+        const int32_t aligned = aend - pos + 1;
+        const int32_t lq = b.l_qseq[r];
+        u32 upM = 0, downM = 0, minMatch = 0, mmes = 0, nbMis = 0;
+        if (lq <= 1) { // junction.cc:168-185
+            const u32 totUp = (u32)((istart - 1) - left + 1);
+            const u32 totDown = (u32)(right - (iend + 1) + 1);
+            mmes = totUp < totDown ? totUp : totDown;
+        } else {
+            const u32 words = b.seq_off[r + 1] - b.seq_off[r];
+            if ((u64)words * 8ull < (u64)lq) set_error(err, g, PJB_ERR_NO_SEQ);
+            else {
+                const uint8_t *seq = b.seq4 + (size_t)b.seq_off[r] * 4;
+                const Side L = anchor_side(cig, nc, pos, aligned, seq, lq, genome, glen, genome_has_x != 0, left, istart - 1);
+                Side R;
+                R.err = 0;
+                if (L.err) set_error(err, g, L.err);
+                else {
+                    R = anchor_side(cig, nc, pos, aligned, seq, lq, genome, glen, genome_has_x != 0, iend + 1, right);
+                    if (R.err) set_error(err, g, R.err);
+                }
+                if (!L.err && !R.err) {
+                    upM = L.last_mis < 0 ? (u32)L.len : (u32)(L.len - 1 - L.last_mis);  // getNbMatchesFromEnd :272
+                    downM = R.first_mis < 0 ? (u32)R.len : (u32)R.first_mis;           // getNbMatchesFromStart :263
+                    minMatch = upM < downM ? upM : downM;
+                    const u32 tu = (u32)(L.len - L.mism), td = (u32)(R.len - R.mism);
+                    mmes = tu < td ? tu : td;
+                    nbMis = (u32)(L.mism + R.mism);
+                }
+            }
+        }
+        const u32 meta = P.meta[p];
+        vals[F_N] = 1;
+        const u32 cat = meta & META_CAT_MASK;
+        vals[F_R1P] = cat == 0;
+        vals[F_R1N] = cat == 1;
+        vals[F_R2P] = cat == 2;
+        vals[F_R2N] = cat == 3;
+        vals[F_MS] = (meta & META_MULTI) != 0;
+        const u32 xs = (meta >> META_XS_SHIFT) & 3u;
+        vals[F_XSP] = xs == 1;
+        vals[F_XSN] = xs == 2;
+        vals[F_UM] = (meta & META_UM) != 0;
+        vals[F_BPP] = (meta & META_BPP) != 0;
+        vals[F_PPP] = (meta & META_PPP) != 0;
+        vals[F_REL] = (meta & META_REL) != 0;
+        // distinct alignment runs in BAM order (junction.cc:763-771): compare with the previous pair of the junction
+        bool dist_head = true;
+        if (i > 0 && jid_of[i - 1] == j) {
+            const u32 q = sidx[i - 1];
+            dist_head = P.pos[q] != pos || P.aend[q] != aend;
+        }
+        vals[F_DIST] = dist_head;
+        const int32_t la = istart - P.lstart[p], ra = P.rend[p] - iend; // Intron::minAnchorLength intron.cc:81-83
+        vals[F_MAXMINANC] = (u32)(la < ra ? la : ra);
+        const u32 ud = P.updown[p];
+        vals[F_UP] = ud & 0xffffu;
+        vals[F_DOWN] = ud >> 16;
+        vals[F_MAXMMES] = mmes;
+        vals[F_MAXMINMATCH] = minMatch;
+        vals[F_FIRSTMIS] = minMatch > 0 ? minMatch : 100000000u;
+        mism64 = nbMis;
+#pragma unroll
+        for (int k = 0; k < 20; k++) vals[F_JAD0 + k] = (u32)k < minMatch; // junction.cc:875-877
+    }
+    // ---- segmented wave reduce to fragment heads
+#pragma unroll
+    for (int k = F_N; k <= F_DIST; k++) vals[k] = seg_reduce_to_head(vals[k], j, OpAdd());
+#pragma unroll
+    for (int k = F_MAXMINANC; k <= F_MAXMINMATCH; k++) vals[k] = seg_reduce_to_head(vals[k], j, OpMax());
+    vals[F_FIRSTMIS] = seg_reduce_to_head(vals[F_FIRSTMIS], j, OpMin());
+    mism64 = seg_reduce_to_head(mism64, j, OpAdd());
+#pragma unroll
+    for (int k = 0; k < 20; k++) vals[F_JAD0 + k] = seg_reduce_to_head(vals[F_JAD0 + k], j, OpAdd());
+    const u32 jprev = __shfl_up(j, 1, 64);
+    if (valid && (lane == 0 || jprev != j)) {
+        const u32 slot = j + (i >> 6);
+        vals[F_MISM_LO] = (u32)mism64;
+        vals[F_MISM_HI] = (u32)(mism64 >> 32);
+        uint4 *dst = reinterpret_cast<uint4 *>(frag + (size_t)slot * F_WORDS);
+#pragma unroll
+        for (int k = 0; k < F_WORDS / 4; k++) dst[k] = make_uint4(vals[4 * k], vals[4 * k + 1], vals[4 * k + 2], vals[4 * k + 3]);
+        frag_j[slot] = (int32_t)j;
+    }
+}
+
+// K5a: fragment slots -> junction accumulators (acc pre-initialised: sums 0, max 0, min 100000000)
+__global__ __launch_bounds__(256) void k5_frag_reduce(const u32 *frag, const int32_t *frag_j, u32 n_slots, u32 *acc) {
+    const u32 s = blockIdx.x * 256 + threadIdx.x;
+    const bool in = s < n_slots;
+    const int32_t jj = in ? frag_j[s] : -1;
+    const bool valid = jj >= 0;
+    const u32 key = valid ? (u32)jj : (0x80000000u | s);
+    const u32 kprev = __shfl_up(key, 1, 64);
+    const bool head = valid && (lane_id() == 0 || kprev != key);
+    const u32 *src = frag + (size_t)s * F_WORDS;
+    u32 *dst = acc + (size_t)(valid ? jj : 0) * F_WORDS;
+    u64 m64 = 0;
+    for (int k = 0; k < F_WORDS; k++) {
+        if (k == F_MISM_LO) {
+            m64 = valid ? ((u64)src[F_MISM_LO] | ((u64)src[F_MISM_HI] << 32)) : 0;
+            m64 = seg_reduce_to_head(m64, key, OpAdd());
+            if (head) atomicAdd(reinterpret_cast<u64 *>(dst + F_MISM_LO), m64);
+            k++; // skip HI
+            continue;
+        }
+        if (k >= F_JAD0 + 20) break;
+        u32 v;
+        if (k >= F_MAXMINANC && k <= F_MAXMINMATCH) {
+            v = valid ? src[k] : 0u;
+            v = seg_reduce_to_head(v, key, OpMax());
+            if (head) atomicMax(dst + k, v);
+        } else if (k == F_FIRSTMIS) {
+            v = valid ? src[k] : 100000000u;
+            v = seg_reduce_to_head(v, key, OpMin());
+            if (head) atomicMin(dst + k, v);
+        } else {
+            v = valid ? src[k] : 0u;
+            v = seg_reduce_to_head(v, key, OpAdd());
+            if (head) atomicAdd(dst + k, v);
+        }
+    }
+}
+__global__ __launch_bounds__(256) void k5_init_acc(u32 *acc, u32 n_junc, int32_t *anc_l, int32_t *anc_r) {
+    const u32 t = blockIdx.x * 256 + threadIdx.x;
+    if (t < n_junc * F_WORDS) acc[t] = (t % F_WORDS) == F_FIRSTMIS ? 100000000u : 0u;
+    if (t < n_junc) {
+        anc_l[t] = INT32_MAX;
+        anc_r[t] = INT32_MIN;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K5b: one thread per junction: strand from reads, entropy over position runs, splice motif,
+// hamming scores, suspicious flag -> output row.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint8_t revcomp_char(uint8_t c) { // REVCOMP_LOOKUP seq_utils.hpp:33-40 (NUL outside A-Z)
+    switch (c) {
+    case 'A': return 'T';
+    case 'C': return 'G';
+    case 'D': return 'H';
+    case 'G': return 'C';
+    case 'H': return 'D';
+    case 'M': return 'K';
+    case 'N': return 'N';
+    case 'R': return 'Y';
+    case 'S': return 'W';
+    case 'T': return 'A';
+    case 'U': return 'A';
+    case 'V': return 'B';
+    case 'W': return 'S';
+    case 'X': return 'X';
+    case 'Y': return 'R';
+    default: return 0;
+    }
+}
+
+// faidx_fetch_seq clamping (deps/htslib-1.3/faidx.c:453-457): returns clamped [b,e]
+__device__ __forceinline__ void fetch_clamp(int32_t glen, int32_t &b, int32_t &e) {
+    if (e < b) b = e;
+    if (b < 0) b = 0;
+    else if (glen <= b) b = glen - 1;
+    if (e < 0) e = 0;
+    else if (glen <= e) e = glen - 1;
+}
+
+__global__ __launch_bounds__(256) void k5_finalize(const u64 *skey, const u32 *seg_off, const u32 *run_first,
+                                                    const u32 *run_start, const u32 *acc, const int32_t *anc_l,
+                                                    const int32_t *anc_r, KeyFmt kf, const uint8_t *genome, int32_t glen,
+                                                    int32_t tid, u32 n_junc, pjb_junction_row *rows, u64 *err) {
+    const u32 j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= n_junc) return;
+    const u32 *a = acc + (size_t)j * F_WORDS;
+    pjb_junction_row R;
+    memset(&R, 0, sizeof R);
+    int32_t istart, iend;
+    const u32 s0 = seg_off[j];
+    unpack_key(kf, skey[s0], istart, iend);
+    R.refid = tid;
+    R.start = istart;
+    R.end = iend;
+    R.left = anc_l[j];
+    R.right = anc_r[j];
+    const u32 n = a[F_N];
+    R.nb_raw = n;
+    R.nb_dist = a[F_DIST];
+    R.nb_ms = a[F_MS];
+    R.nb_um = a[F_UM];
+    R.nb_bpp = a[F_BPP];
+    R.nb_ppp = a[F_PPP];
+    R.nb_rel = a[F_REL];
+    R.r1pos = a[F_R1P];
+    R.r1neg = a[F_R1N];
+    R.r2pos = a[F_R2P];
+    R.r2neg = a[F_R2N];
+    R.max_min_anc = a[F_MAXMINANC];
+    R.maxmmes = a[F_MAXMMES];
+    R.nb_up_juncs = a[F_UP];
+    R.nb_down_juncs = a[F_DOWN];
+    const u64 mism = (u64)a[F_MISM_LO] | ((u64)a[F_MISM_HI] << 32);
+    R.sum_mismatches = mism;
+    for (int k = 0; k < 20; k++) R.jad[k] = a[F_JAD0 + k];
+    // suspicious, junction.cc:897-908.  (nbMismatches is a uint32 in the reference; the test is > 0)
+    {
+        const u32 first_mis = a[F_FIRSTMIS];
+        if ((u32)mism > 0 && first_mis < 20 && !(a[F_MAXMINMATCH] > first_mis)) R.suspicious = 1;
+    }
+    // determineStrandFromReads, junction.cc:531-559
+    {
+        const u32 np = a[F_XSP], nn = a[F_XSN];
+        const double tot = (double)n;
+        if ((double)np / tot >= 0.95) R.read_strand = PJB_STRAND_POS;
+        else if ((double)nn / tot >= 0.95) R.read_strand = PJB_STRAND_NEG;
+        else R.read_strand = PJB_STRAND_UNK;
+    }
+    // calcEntropy, junction.cc:730-749, on run lengths: with runs r_0..r_m of equal read position the
+    // reference's flush rule yields counts (r_0+1, r_1, ..., r_{m-1}, r_m-1) (last dropped if 0), summed in order.
+    {
+        double ent = 0.0;
+        if (n > 1) {
+            const u32 rf = run_first[j], rl = run_first[j + 1];
+            const u32 m = rl - rf; // number of runs
+            double sum = 0.0;
+            if (m == 1) {
+                const double pI = (double)n / (double)n;
+                sum = __dadd_rn(sum, __dmul_rn(pI, log2(pI)));
+            } else {
+                for (u32 r = rf; r < rl; r++) {
+                    u32 c = run_start[r + 1] - run_start[r];
+                    if (r == rf) c += 1;          // first flush also swallows the first read of run 1
+                    else if (r == rl - 1) c -= 1; // ... so the last run is one short (and vanishes if it was 1)
+                    if (c == 0) continue;
+                    const double pI = (double)c / (double)n;
+                    sum = __dadd_rn(sum, __dmul_rn(pI, log2(pI)));
+                }
+            }
+            ent = fabs(sum);
+        }
+        R.entropy = ent;
+    }
+    // processJunctionWindow, junction.cc:561-649
+    {
+        int32_t b = istart, e = istart + 1;
+        fetch_clamp(glen, b, e);
+        int32_t b2 = iend - 1, e2 = iend;
+        fetch_clamp(glen, b2, e2);
+        if (e - b + 1 != 2 || e2 - b2 + 1 != 2 || glen <= 0) {
+            set_error(err, 0xffffff00u + 0, PJB_ERR_SPLICE_SITE_LEN);
+            rows[j] = R;
+            return;
+        }
+        uint8_t d0 = genome[b], d1 = genome[b + 1], a0 = genome[b2], a1 = genome[b2 + 1];
+        const u32 m4 = ((u32)d0 << 24) | ((u32)d1 << 16) | ((u32)a0 << 8) | (u32)a1;
+        const u32 GTAG = 0x47544147u, CTAC = 0x43544143u, ATAC = 0x41544143u, GTAT = 0x47544154u, GCAG = 0x47434147u,
+                  CTGC = 0x43544743u;
+        int css, ss;
+        if (m4 == GTAG || m4 == CTAC) css = PJB_CSS_CANONICAL;
+        else if (m4 == ATAC || m4 == GTAT || m4 == GCAG || m4 == CTGC) css = PJB_CSS_SEMI;
+        else css = PJB_CSS_NO;
+        if (m4 == GTAG || m4 == ATAC || m4 == GCAG) ss = PJB_STRAND_POS;
+        else if (m4 == CTAC || m4 == GTAT || m4 == CTGC) ss = PJB_STRAND_NEG;
+        else ss = PJB_STRAND_UNK;
+        const int rs = R.read_strand;
+        const int cons = rs == ss ? rs : rs == PJB_STRAND_UNK ? ss : ss == PJB_STRAND_UNK ? rs : PJB_STRAND_UNK;
+        R.canonical = (uint8_t)css;
+        R.ss_strand = (uint8_t)ss;
+        R.cons_strand = (uint8_t)cons;
+        if (cons == PJB_STRAND_NEG) {
+            R.da1[0] = revcomp_char(a1);
+            R.da1[1] = revcomp_char(a0);
+            R.da2[0] = revcomp_char(d1);
+            R.da2[1] = revcomp_char(d0);
+        } else {
+            R.da1[0] = d0;
+            R.da1[1] = d1;
+            R.da2[0] = a0;
+            R.da2[1] = a1;
+        }
+        // anchors / intron flanks
+        int32_t lb = R.left, le = istart - 1;
+        fetch_clamp(glen, lb, le);
+        int32_t rb = iend + 1, re = R.right;
+        fetch_clamp(glen, rb, re);
+        int32_t lib = istart, lie = istart + 9;
+        fetch_clamp(glen, lib, lie);
+        int32_t rib = iend - 9, rie = iend;
+        fetch_clamp(glen, rib, rie);
+        const int32_t leftAncLen = le - lb + 1, rightAncLen = re - rb + 1;
+        const int32_t expL = istart - R.left, expR = R.right - iend;
+        if ((leftAncLen != expL && expL > 0) || (rightAncLen != expR && expR > 0)) {
+            set_error(err, 0xffffff00u + 1, PJB_ERR_ANCHOR_LEN);
+            rows[j] = R;
+            return;
+        }
+        if (lie - lib + 1 != 10 || rie - rib + 1 != 10) {
+            set_error(err, 0xffffff00u + 2, PJB_ERR_INTRON_FLANK_LEN);
+            rows[j] = R;
+            return;
+        }
+        // calcHammingScores, junction.cc:823-857
+        const int32_t nla = leftAncLen < 10 ? leftAncLen : 10;  // last <=10 of left anchor
+        const int32_t la_b = leftAncLen < 10 ? lb : le - 9;
+        const int32_t nra = rightAncLen < 10 ? rightAncLen : 10; // first <=10 of right anchor
+        const int32_t ra_b = rb;
+        const int32_t nli = 10, nri = 10;
+        const int32_t leftDelta = nla - nri;
+        const int32_t leftOffset = leftDelta <= 0 ? 0 : leftDelta;
+        const int32_t leftLen = nla < nri ? nla : nri;
+        const int32_t rightLen = nli < nra ? nli : nra;
+        // la' = nla > leftLen ? la.substr(leftOffset,leftLen) : la   (nla <= 10 = nri so never longer)
+        const int32_t zla = nla, la_o = 0;
+        const int32_t zli = nli > rightLen ? rightLen : nli, li_o = 0;
+        const int32_t zri = nri > leftLen ? leftLen : nri, ri_o = nri > leftLen ? leftOffset : 0;
+        const int32_t zra = nra > rightLen ? rightLen : nra, ra_o = 0;
+        (void)la_o; (void)li_o; (void)ra_o;
+        u32 h5 = 0, h3 = 0;
+        if (zla != zri || zra != zli) {
+            set_error(err, 0xffffff00u + 3, PJB_ERR_HAMMING_LEN);
+            rows[j] = R;
+            return;
+        }
+        if (cons == PJB_STRAND_NEG) {
+            // anchor5p = rc(ra), intron3p = rc(li): H over reversed+complemented strings
+            for (int32_t t = 0; t < zra; t++) {
+                const uint8_t x = revcomp_char(genome[ra_b + (zra - 1 - t)]);
+                const uint8_t y = revcomp_char(genome[lib + (zli - 1 - t)]);
+                h5 += x != y;
+            }
+            for (int32_t t = 0; t < zla; t++) {
+                const uint8_t x = revcomp_char(genome[la_b + (zla - 1 - t)]);
+                const uint8_t y = revcomp_char(genome[rib + ri_o + (zri - 1 - t)]);
+                h3 += x != y;
+            }
+        } else {
+            for (int32_t t = 0; t < zla; t++) h5 += genome[la_b + t] != genome[rib + ri_o + t];
+            for (int32_t t = 0; t < zra; t++) h3 += genome[ra_b + t] != genome[lib + t];
+        }
+        R.hamming5p = h5;
+        R.hamming3p = h3;
+    }
+    rows[j] = R;
+}
+
+} // namespace pjb

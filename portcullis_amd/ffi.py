@@ -1,0 +1,213 @@
+"""ctypes binding of the C ABI (include/portcullis_amd.h).
+
+This is the Python-side stub a maintainer would write to drive the device
+path; it adds no computation of its own.  There is deliberately no CPU
+fallback: if libportcullis_amd.so is missing, or no MI355X is visible,
+loading / creating a context raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from .records import ORIENTATION, ReadBatch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libportcullis_amd.so")
+ABI_VERSION = 1
+N_STAGES = 8
+STAGE_NAMES = ["scan_emit", "sort", "group", "anchors", "pair_stats", "finalize", "d2h", "spare"]
+
+EXPORTS = [
+    "pjb_create", "pjb_destroy", "pjb_last_error", "pjb_set_refs", "pjb_upload_contig", "pjb_upload_contig_device",
+    "pjb_release_contig", "pjb_submit_batch", "pjb_submit_batch_device", "pjb_finish_contig", "pjb_collect",
+    "pjb_clear_rows", "pjb_get_timing", "pjb_device_count",
+]
+
+
+class PjbConfig(C.Structure):
+    _fields_ = [("abi_version", C.c_int32), ("device", C.c_int32), ("orientation", C.c_int32),
+                ("strandedness", C.c_int32), ("flags", C.c_uint32)]
+
+
+class PjbBatch(C.Structure):
+    _fields_ = [("n_reads", C.c_int64)] + [
+        (n, C.c_void_p) for n in ("pos", "flag", "mapq", "xs", "l_qseq", "mtid", "mpos", "cig_off", "cigar", "seq_off", "seq4")
+    ]
+
+
+class PjbRegionResult(C.Structure):
+    _fields_ = [("spliced", C.c_uint64), ("unspliced", C.c_uint64), ("sum_len", C.c_uint64), ("min_len", C.c_int32),
+                ("max_len", C.c_int32), ("n_reads", C.c_int64), ("n_pairs", C.c_int64), ("n_junctions", C.c_int64)]
+
+
+class PjbTiming(C.Structure):
+    _fields_ = [("total_ms", C.c_float), ("stage_ms", C.c_float * N_STAGES), ("sort_passes", C.c_int64)]
+
+
+ROW_DTYPE = np.dtype(
+    [
+        ("refid", "<i4"), ("start", "<i4"), ("end", "<i4"), ("left", "<i4"), ("right", "<i4"),
+        ("read_strand", "u1"), ("ss_strand", "u1"), ("cons_strand", "u1"), ("canonical", "u1"),
+        ("da1", "u1", (2,)), ("da2", "u1", (2,)), ("suspicious", "u1"), ("_pad", "u1", (3,)),
+        ("nb_raw", "<u4"), ("nb_dist", "<u4"), ("nb_ms", "<u4"), ("nb_um", "<u4"), ("nb_bpp", "<u4"), ("nb_ppp", "<u4"),
+        ("nb_rel", "<u4"), ("r1pos", "<u4"), ("r1neg", "<u4"), ("r2pos", "<u4"), ("r2neg", "<u4"),
+        ("max_min_anc", "<u4"), ("maxmmes", "<u4"), ("hamming5p", "<u4"), ("hamming3p", "<u4"),
+        ("nb_up_juncs", "<u4"), ("nb_down_juncs", "<u4"), ("jad", "<u4", (20,)), ("_pad2", "<u4"),
+        ("sum_mismatches", "<u8"), ("entropy", "<f8"),
+    ]
+)
+assert ROW_DTYPE.itemsize == 200
+
+
+class PjbError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"pjb error {code}: {msg}")
+        self.code = code
+
+
+_LIB = None
+
+
+def load():
+    """Load the HIP library; raises (never falls back) if it has not been built."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(the junc hot path is HIP-only; there is no CPU fallback)"
+            )
+        L = C.CDLL(LIB_PATH)
+        L.pjb_last_error.restype = C.c_char_p
+        L.pjb_last_error.argtypes = [C.c_void_p]
+        L.pjb_create.argtypes = [C.POINTER(C.c_void_p), C.POINTER(PjbConfig)]
+        L.pjb_destroy.argtypes = [C.c_void_p]
+        L.pjb_destroy.restype = None
+        L.pjb_set_refs.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
+        L.pjb_upload_contig.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64]
+        L.pjb_upload_contig_device.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64]
+        L.pjb_release_contig.argtypes = [C.c_void_p, C.c_int32]
+        L.pjb_submit_batch.argtypes = [C.c_void_p, C.c_int32, C.POINTER(PjbBatch)]
+        L.pjb_submit_batch_device.argtypes = [C.c_void_p, C.c_int32, C.POINTER(PjbBatch)]
+        L.pjb_finish_contig.argtypes = [C.c_void_p, C.c_int32, C.POINTER(PjbRegionResult)]
+        L.pjb_collect.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
+        L.pjb_clear_rows.argtypes = [C.c_void_p]
+        L.pjb_get_timing.argtypes = [C.c_void_p, C.POINTER(PjbTiming)]
+        _LIB = L
+    return _LIB
+
+
+def device_count():
+    return load().pjb_device_count()
+
+
+_FIELDS = [("pos", np.int32), ("flag", np.uint16), ("mapq", np.uint8), ("xs", np.uint8), ("l_qseq", np.int32),
+           ("mtid", np.int32), ("mpos", np.int32), ("cig_off", np.uint32), ("cigar", np.uint32),
+           ("seq_off", np.uint32), ("seq4", np.uint8)]
+
+
+class Context:
+    """One device context (pjb_ctx).  Mirrors the calls JunctionBuilder::findJunctions makes."""
+
+    def __init__(self, device=0, orientation="UNKNOWN", strandedness=3):
+        self._L = load()
+        self._h = C.c_void_p()
+        ori = ORIENTATION[orientation] if isinstance(orientation, str) else int(orientation)
+        cfg = PjbConfig(ABI_VERSION, device, ori, strandedness, 0)
+        rc = self._L.pjb_create(C.byref(self._h), C.byref(cfg))
+        if rc:
+            raise PjbError(rc, self._L.pjb_last_error(None).decode())
+        self._keep = []
+
+    def close(self):
+        if self._h:
+            self._L.pjb_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc:
+            raise PjbError(rc, self._L.pjb_last_error(self._h).decode(errors="replace"))
+
+    def set_refs(self, ref_lens):
+        a = np.ascontiguousarray(ref_lens, dtype=np.int32)
+        self._check(self._L.pjb_set_refs(self._h, len(a), a.ctypes.data))
+
+    def upload_contig(self, tid, bases):
+        b = bases if isinstance(bases, (bytes, bytearray)) else bytes(bases)
+        self._check(self._L.pjb_upload_contig(self._h, tid, b, len(b)))
+
+    def upload_contig_device(self, tid, tensor):
+        """tensor: torch uint8 CUDA tensor of UPPER-CASE bases; must outlive the context's use of it."""
+        self._keep.append(tensor)
+        self._check(self._L.pjb_upload_contig_device(self._h, tid, tensor.data_ptr(), tensor.numel()))
+
+    def release_contig(self, tid):
+        self._check(self._L.pjb_release_contig(self._h, tid))
+
+    def submit_batch(self, tid, batch: ReadBatch):
+        pb = PjbBatch()
+        pb.n_reads = batch.n
+        keep = []
+        for name, dt in _FIELDS:
+            a = np.ascontiguousarray(getattr(batch, name), dtype=dt)
+            if a.size == 0:
+                a = np.zeros(4, dtype=dt)
+            keep.append(a)
+            setattr(pb, name, a.ctypes.data)
+        self._check(self._L.pjb_submit_batch(self._h, tid, C.byref(pb)))
+
+    def submit_batch_device(self, tid, tensors, n_reads):
+        """tensors: dict name -> torch CUDA tensor with the dtypes of `pjb_batch`; borrowed until finish."""
+        pb = PjbBatch()
+        pb.n_reads = int(n_reads)
+        for name, _ in _FIELDS:
+            t = tensors[name]
+            self._keep.append(t)
+            setattr(pb, name, t.data_ptr())
+        self._check(self._L.pjb_submit_batch_device(self._h, tid, C.byref(pb)))
+
+    def finish_contig(self, tid):
+        r = PjbRegionResult()
+        self._check(self._L.pjb_finish_contig(self._h, tid, C.byref(r)))
+        return {k: getattr(r, k) for k, _ in PjbRegionResult._fields_}
+
+    def collect(self):
+        p = C.c_void_p()
+        n = C.c_int64()
+        self._check(self._L.pjb_collect(self._h, C.byref(p), C.byref(n)))
+        if n.value == 0:
+            return np.zeros(0, dtype=ROW_DTYPE)
+        buf = (C.c_char * (n.value * ROW_DTYPE.itemsize)).from_address(p.value)
+        return np.frombuffer(buf, dtype=ROW_DTYPE, count=n.value).copy()
+
+    def clear_rows(self):
+        self._check(self._L.pjb_clear_rows(self._h))
+
+    def timing(self):
+        t = PjbTiming()
+        self._check(self._L.pjb_get_timing(self._h, C.byref(t)))
+        return dict(total_ms=t.total_ms, stage_ms={STAGE_NAMES[i]: t.stage_ms[i] for i in range(N_STAGES)},
+                    sort_passes=t.sort_passes)
+
+
+def run_contig(ctx, tid, genome, batches):
+    """Convenience: upload genome, submit batches, finish; returns (rows, region)."""
+    ctx.upload_contig(tid, genome)
+    ctx.clear_rows()
+    for b in batches:
+        ctx.submit_batch(tid, b)
+    reg = ctx.finish_contig(tid)
+    return ctx.collect(), reg

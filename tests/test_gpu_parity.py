@@ -1,0 +1,142 @@
+"""Parity tests proper: the HIP path (through the C ABI) against the CPU oracle
+on the same seeded inputs, plus the committed reference fixtures."""
+import os
+
+import numpy as np
+import pytest
+
+from fixtures_micro import micro1, micro2
+from fuzzgen import make_reads, to_batch
+from parity import assert_rows_equal, region_equal
+from portcullis_amd.records import ReadBatch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def orc():
+    from oracle import oracle
+    return oracle
+
+
+@pytest.fixture(scope="module")
+def ffi():
+    from portcullis_amd import ffi
+    assert ffi.device_count() >= 1, "no HIP device visible"
+    return ffi
+
+
+def run_both(ffi, orc, genome, batch, orientation="UNKNOWN", split=None, ref_len=None):
+    ref_len = ref_len or len(genome)
+    orows, oreg = orc.find_juncs(0, ref_len, genome, batch.to_oracle(), orientation)
+    with ffi.Context(0, orientation) as ctx:
+        ctx.set_refs([ref_len])
+        if split is not None:
+            cuts = [0] + sorted(set(int(x) for x in split if 0 < x < batch.n)) + [batch.n]
+            batches = [batch.slice(a, b) for a, b in zip(cuts[:-1], cuts[1:])]
+        else:
+            batches = [batch]
+        drows, dreg = ffi.run_contig(ctx, 0, genome.encode() if isinstance(genome, str) else genome, batches)
+    region_equal(dreg, oreg)
+    assert dreg["n_junctions"] == len(orows)
+    return assert_rows_equal(drows, orows), drows, orows
+
+
+def test_micro_fixture_1(ffi, orc, spombe30k):
+    _, genome = spombe30k
+    _, drows, _ = run_both(ffi, orc, genome, ReadBatch.from_reads(micro1(genome)))
+    # spot-check the reference-recorded values directly on the device rows
+    d = {(int(r["start"]), int(r["end"])): r for r in drows}
+    j2 = d[(1170, 1369)]
+    assert j2["nb_raw"] == 3 and j2["sum_mismatches"] == 103 and f"{j2['entropy']:g}" == "0.918296"
+    assert list(j2["jad"][:10]) == [3] * 10 and list(j2["jad"][10:]) == [2] * 10
+
+
+def test_micro_fixture_2(ffi, orc, spombe30k):
+    _, genome = spombe30k
+    for ori in ("FR", "UNKNOWN", "RF", "FF", "SE"):
+        run_both(ffi, orc, genome, ReadBatch.from_reads(micro2(genome)), ori)
+
+
+def test_clipped3(ffi, orc, golden_dir):
+    from util_bam import read_bam, records_to_batch
+    refs, recs = read_bam(os.path.join(golden_dir, "clipped3.bam"))
+    batch = records_to_batch([r for r in recs if r["tid"] == 0])
+    rng = np.random.default_rng(4)
+    genome = rng.choice(np.frombuffer(b"ACGT", np.uint8), size=refs[0][1]).tobytes()
+    _, drows, _ = run_both(ffi, orc, genome, batch, ref_len=refs[0][1])
+    r = drows[0]
+    # reference row, SURVEY App. B (genome independent columns)
+    assert (r["start"], r["end"], r["left"], r["right"]) == (6442658, 6442841, 6442559, 6442940)
+    assert (r["nb_raw"], r["nb_dist"], r["nb_um"], r["nb_bpp"], r["nb_rel"]) == (135, 37, 131, 83, 131)
+    assert f"{r['entropy']:g}" == "4.89824"
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_fuzz(ffi, orc, seed):
+    genome, reads = make_reads(seed, n_reads=2500, paired=(seed % 2 == 1))
+    ori = ["UNKNOWN", "FR", "RF", "FF"][seed % 4]
+    run_both(ffi, orc, genome, to_batch(reads), ori)
+
+
+@pytest.mark.parametrize("seed", [100, 101, 102])
+def test_fuzz_multibatch(ffi, orc, seed):
+    genome, reads = make_reads(seed, n_reads=4000, paired=True)
+    b = to_batch(reads)
+    rng = np.random.default_rng(seed)
+    run_both(ffi, orc, genome, b, "FR", split=rng.integers(1, b.n, size=5))
+
+
+def test_deep_junction(ffi, orc):
+    """One junction with tens of thousands of alignments (fragment reduction across many wavefronts)."""
+    genome, reads = make_reads(7, n_reads=60000, n_tx=2, L=(60, 110))
+    run_both(ffi, orc, genome, to_batch(reads))
+
+
+def test_no_spliced_reads(ffi, orc):
+    rng = np.random.default_rng(1)
+    genome = "".join(rng.choice(list("ACGT"), size=5000))
+    reads = [dict(pos=int(p), cigar="50M", seq=None, flag=0) for p in sorted(rng.integers(0, 4000, size=300))]
+    ent, drows, orows = run_both(ffi, orc, genome, ReadBatch.from_reads(reads))
+    assert len(drows) == 0
+
+
+def test_empty_contig(ffi):
+    with ffi.Context(0) as ctx:
+        ctx.set_refs([1000])
+        reg = ctx.finish_contig(0)
+        assert reg["n_reads"] == 0 and reg["min_len"] == 2**31 - 1 and reg["max_len"] == 0
+        assert len(ctx.collect()) == 0
+
+
+def test_error_unsorted(ffi):
+    reads = [dict(pos=500, cigar="20M100N20M", seq="A" * 40), dict(pos=100, cigar="20M100N20M", seq="A" * 40)]
+    with ffi.Context(0) as ctx:
+        ctx.set_refs([5000])
+        ctx.upload_contig(0, b"A" * 5000)
+        ctx.submit_batch(0, ReadBatch.from_reads(reads))
+        with pytest.raises(ffi.PjbError) as e:
+            ctx.finish_contig(0)
+        assert e.value.code == -14
+
+
+def test_error_cigar_ends_with_refskip(ffi, orc):
+    """CIGAR ending in N: the reference throws in getPaddedQuerySeq (bam_alignment.cc:342)."""
+    genome = "ACGT" * 500
+    reads = [dict(pos=100, cigar="30M100N", seq="A" * 30, xs="+")]
+    b = ReadBatch.from_reads(reads)
+    with pytest.raises(orc.OracleError):
+        orc.find_juncs(0, len(genome), genome, b.to_oracle(), "UNKNOWN")
+    with ffi.Context(0) as ctx:
+        ctx.set_refs([len(genome)])
+        ctx.upload_contig(0, genome.encode())
+        ctx.submit_batch(0, b)
+        with pytest.raises(ffi.PjbError):
+            ctx.finish_contig(0)
+
+
+def test_seq_star_fallback(ffi, orc):
+    """SEQ '*' (l_qseq 0): calcMatchStats fallback branch, junction.cc:168-185."""
+    genome = ("ACGTTGCA" * 400)
+    reads = [dict(pos=100, cigar="30M100N40M", seq=None, xs="+"), dict(pos=110, cigar="20M100N45M", seq=None, xs="-")]
+    run_both(ffi, orc, genome, ReadBatch.from_reads(reads))
