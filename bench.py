@@ -1,0 +1,246 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the MI355X `junc` hot path on BASELINE.json's synthetic workload.
+
+A "step" is one pass of the hot path over one contig's alignment records that are
+already resident in HBM: pjb_submit_batch_device + pjb_finish_contig (CIGAR scan/emit,
+sort/group, anchors, per-pair match statistics, junction reduce) + the junction rows
+copied back to the host.  At N > 1 every rank owns one contig of the same size (the path
+shards by reference contig, src/junction_builder.cc:241-245) and the only exchange is the
+RCCL all-gather that merges the per-rank junction tables.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def algorithmic_bytes(name, N, C, S, Cs, P, J, L, passes):
+    """Algorithmic HBM bytes of ONE launch of kernel `name` (each byte counted once per logical
+    pass, caches ignored; DESIGN.md section 4 derives these).  N reads, C cigar ops, S spliced
+    reads, Cs cigar ops of spliced reads, P pairs, J junctions, L read length."""
+    frags = P / 64.0 + J
+    table = {
+        # pos, cig_off, l_qseq, xs + every cigar op ; per-tile stats are negligible
+        "k1_count": N * 13 + C * 4,
+        # cig_off + all ops (count pass), spliced reads: pos/flag/mapq/xs + ops twice more; 36 B written per pair
+        "k1_emit": N * 4 + C * 4 + S * 8 + Cs * 8 + P * 36,
+        "rs_hist": P * 8,
+        "rs_scatter": P * 24,
+        "k2_heads_reduce": P * 20,
+        "k2_heads_apply": P * 20 + P * 4 + (J + J + P / 8) * 4,
+        "k3_anchors_frag": P * 16 + frags * 12,
+        # key, idx, jid, 7 pair fields, previous pair (12), read offsets (20), ops, packed bases of both
+        # anchors (~L/2), genome bytes under both anchors (~L), junction anchors (8); one 192-B fragment record
+        "k4_pairs": P * (8 + 4 + 4 + 28 + 12 + 20 + 4 * (Cs / max(S, 1)) + L / 2 + L + 8) + frags * 196,
+        "k5_frag_reduce": frags * 196 + J * 164,
+        "k5_finalize": J * (192 + 24 + 48 + 200),
+    }
+    return table.get(name)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default=os.environ.get("PJB_BENCH_CONFIG", "C2"))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    from portcullis_amd import ffi, synth
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    cfg = synth.CONFIGS[args.config]
+    t_gen = time.time()
+    data = synth.generate(cfg, device=dev, seed=cfg.seed + rank)
+    torch.cuda.synchronize()
+    t_gen = time.time() - t_gen
+    batch, genome = data["batch"], data["genome"]
+    N, P, C, S = data["n_reads"], data["n_pairs"], data["n_cigar_ops"], data["n_spliced"]
+    L = cfg.read_len
+
+    ctx = ffi.Context(device=local_rank, orientation="UNKNOWN", flags=ffi.FLAG_KERNEL_TIMING)
+    ctx.set_refs([cfg.contig_len])
+    ctx.upload_contig_device(0, genome)
+
+    state = {}
+
+    def step():
+        ctx.clear_rows()
+        ctx.submit_batch_device(0, batch, N)
+        reg = ctx.finish_contig(0)
+        rows = ctx.collect()
+        if world > 1:
+            # merge the final junction table: all-gather of the POD rows (variable J per rank -> pad)
+            nj = torch.tensor([len(rows)], device=dev, dtype=torch.int64)
+            allj = [torch.zeros_like(nj) for _ in range(world)]
+            dist.all_gather(allj, nj)
+            jmax = int(max(int(x) for x in allj))
+            buf = torch.zeros((jmax, ffi.ROW_DTYPE.itemsize), dtype=torch.uint8, device=dev)
+            if len(rows):
+                buf[: len(rows)] = torch.from_numpy(rows.view(np.uint8).reshape(len(rows), -1)).to(dev)
+            out = [torch.empty_like(buf) for _ in range(world)]
+            dist.all_gather(out, buf)
+            state["merged"] = sum(int(x) for x in allj)
+        state["reg"] = reg
+        state["rows"] = rows
+
+    for _ in range(args.warmup):
+        step()
+    ctx.reset_kernel_timing()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    reg, rows = state["reg"], state["rows"]
+    J = int(reg["n_junctions"])
+    assert reg["n_pairs"] == P and reg["n_reads"] == N
+    # size-independent sanity (full-size parity properties are in tests/test_gpu_fullsize.py)
+    assert int(rows["nb_raw"].sum()) == P
+
+    totals = torch.tensor([N, J], device=dev, dtype=torch.int64)
+    if world > 1:
+        dist.all_reduce(totals)
+    reads_total, junc_total = int(totals[0]), int(totals[1])
+
+    # ---- per-kernel device time over the timed region (HIP events on the context's stream)
+    kt = ctx.kernel_timing()
+    timing = ctx.timing()
+    sort_passes = int(timing["sort_passes"])
+    cs_ops = None
+    if rank == 0:
+        # cigar ops of spliced reads (for the byte formulas)
+        cig_off = batch["cig_off"].to(torch.int64)
+        n_ops = cig_off[1:] - cig_off[:-1]
+        seq_off = batch["seq_off"].to(torch.int64)
+        spl = (seq_off[1:] - seq_off[:-1]) > 0
+        cs_ops = int(n_ops[spl].sum())
+    result = None
+    if rank == 0:
+        kern = []
+        for name, (launches, ms) in kt.items():
+            if launches == 0:
+                continue
+            avg = ms / launches
+            b = algorithmic_bytes(name, N, C, S, cs_ops, P, J, L, sort_passes)
+            kern.append(dict(name=name, launches=launches, avg_ms=avg, total_ms=ms,
+                             alg_bytes=b, gbps=(b / (avg * 1e-3) / 1e9) if b else None))
+        kern.sort(key=lambda k: -k["total_ms"])
+        dom = kern[0]
+        peak = 8000.0
+        roofline = dict(bound="hbm", kernel=dom["name"], achieved=round(dom["gbps"], 1) if dom["gbps"] else None,
+                        peak=peak, unit="GB/s", frac=round(dom["gbps"] / peak, 4) if dom["gbps"] else None,
+                        traffic=None, avg_kernel_ms=round(dom["avg_ms"], 4),
+                        alg_bytes_per_launch=int(dom["alg_bytes"]) if dom["alg_bytes"] else None)
+        kernel_ms_per_step = sum(k["total_ms"] for k in kern) / args.steps
+
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            cpu = cpu_baseline(data, cfg, ctx, ffi, synth)
+
+        result = {
+            "metric": "junc_reads_per_sec",
+            "value": reads_total * args.steps / elapsed,
+            "unit": "reads/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "int32",
+            "data": "synthetic",
+            "config": {"workload": f"BASELINE configs[1] ({cfg.name}): synthetic {cfg.n_reads} single-end {L}-bp reads, "
+                                   f"1 contig of {cfg.contig_len} bp per GPU, {J} junctions, {P} spliced pairs",
+                       "reads_per_gpu": N, "pairs_per_gpu": P, "junctions_per_gpu": J, "sharding": "by contig",
+                       "input": "device-resident SoA records (pjb_submit_batch_device)"},
+            "junctions_per_sec": junc_total * args.steps / elapsed,
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+            "device_kernel_ms_per_step": round(kernel_ms_per_step, 4),
+            "pipeline_gbps": None,
+            "sort_passes": sort_passes,
+            "kernels": [dict(name=k["name"], launches_per_step=k["launches"] / args.steps, avg_ms=round(k["avg_ms"], 4),
+                             gbps=round(k["gbps"], 1) if k["gbps"] else None) for k in kern],
+            "datagen_s": round(t_gen, 2),
+        }
+        # pipeline_gbps: sum over kernels of (bytes per launch x launches per step) / device kernel time per step
+        tot_bytes = sum((k["alg_bytes"] or 0) * k["launches"] / args.steps for k in kern)
+        result["pipeline_gbps"] = round(tot_bytes / (kernel_ms_per_step * 1e-3) / 1e9, 1)
+        print(json.dumps(result))
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(data, cfg, ctx, ffi, synth):
+    """Time the CPU oracle (single thread, kind "port") on a bounded prefix of the same records
+    and check the device rows for that prefix against it."""
+    import numpy as np
+
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle import oracle as orc
+    from parity import assert_rows_equal, region_equal
+
+    N = data["n_reads"]
+    genome_host = data["genome"].cpu().numpy().tobytes()
+    # pilot on 1M reads to size the sample for ~15 s of CPU work
+    pilot = min(N, 1_000_000)
+    hb = synth.batch_to_numpy(data["batch"], 0, pilot)
+    t = time.perf_counter()
+    orows, oreg = orc.find_juncs(0, cfg.contig_len, genome_host, hb.to_oracle(), "UNKNOWN")
+    dt = time.perf_counter() - t
+    rate = pilot / dt
+    M = int(min(N, max(pilot, rate * 15.0)))
+    if M > pilot:
+        hb = synth.batch_to_numpy(data["batch"], 0, M)
+        t = time.perf_counter()
+        orows, oreg = orc.find_juncs(0, cfg.contig_len, genome_host, hb.to_oracle(), "UNKNOWN")
+        dt = time.perf_counter() - t
+    # parity of the device path on exactly this sample
+    ctx.clear_rows()
+    ctx.submit_batch(0, hb)
+    dreg = ctx.finish_contig(0)
+    drows = ctx.collect()
+    region_equal(dreg, oreg)
+    max_ent = assert_rows_equal(drows, orows)
+    return {"value": M / dt, "unit": "reads/s", "cores": 1, "kind": "port",
+            "sample": f"first {M} of {N} records of the same workload ({len(orows)} junctions), oracle/portcullis_oracle.c, "
+                      f"{dt:.1f} s; device rows for the sample match the oracle (max |entropy diff| {max_ent:.2g})",
+            "junctions_per_sec": len(orows) / dt}
+
+
+if __name__ == "__main__":
+    main()

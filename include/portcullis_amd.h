@@ -85,8 +85,12 @@ typedef struct pjb_config {
     int32_t strandedness; /* PJB_SS_*  accepted for API parity; like the reference it does not
                              change junc output (the reader's alignments carry
                              Strandedness::UNKNOWN, lib/src/bam_alignment.cc:154-165) */
-    uint32_t flags;       /* reserved, 0 */
+    uint32_t flags;       /* PJB_FLAG_* */
 } pjb_config;
+
+/* record a HIP event pair around every kernel launch and accumulate per-kernel time
+ * (pjb_get_kernel_timing); costs ~1 us per launch, off by default */
+#define PJB_FLAG_KERNEL_TIMING 1u
 
 /* One batch of fixed-width alignment records of ONE contig, in BAM file order
  * (structure of arrays; BAM-native encodings):
@@ -194,6 +198,16 @@ int pjb_collect(pjb_ctx *ctx, const pjb_junction_row **rows, int64_t *n_rows);
 int pjb_clear_rows(pjb_ctx *ctx);
 
 int pjb_get_timing(const pjb_ctx *ctx, pjb_timing *out);
+
+/* Per-kernel device time (HIP events on the context's stream), accumulated over all
+ * pjb_finish_contig calls since creation / the last reset.  Needs PJB_FLAG_KERNEL_TIMING. */
+typedef struct pjb_kernel_time {
+    char name[32];
+    int64_t launches;
+    double total_ms;
+} pjb_kernel_time;
+int pjb_get_kernel_timing(const pjb_ctx *ctx, pjb_kernel_time *out, int32_t cap, int32_t *n);
+int pjb_reset_kernel_timing(pjb_ctx *ctx);
 
 /* Number of visible HIP devices (0 if none); does not create a context. */
 int pjb_device_count(void);

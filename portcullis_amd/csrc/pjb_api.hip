@@ -50,6 +50,14 @@ struct pjb_ctx {
     pjb_timing timing;
     hipEvent_t ev[PJB_N_STAGES + 2];
     int radix_max_bits = 8;
+    // optional per-kernel timing
+    bool ktime = false;
+    std::vector<hipEvent_t> ev_pool;
+    size_t ev_used = 0;
+    std::vector<int> ev_name; // kernel-name index per event pair
+    std::vector<std::string> knames;
+    std::vector<int64_t> kcount;
+    std::vector<double> kms;
     // scratch
     Buf b_batches, b_tile_cnt, b_tile_stats, b_cstats, b_err, b_total;
     Buf b_key[2], b_idx[2], b_g, b_lstart, b_rend, b_pos, b_aend, b_meta, b_updown;
@@ -139,16 +147,57 @@ int bits_of(uint64_t v) {
     return b;
 }
 
+// kernel launch with optional event bracketing -------------------------------------------------
+int kname_index(pjb_ctx *c, const char *name) {
+    for (size_t i = 0; i < c->knames.size(); i++)
+        if (c->knames[i] == name) return (int)i;
+    c->knames.push_back(name);
+    c->kcount.push_back(0);
+    c->kms.push_back(0.0);
+    return (int)c->knames.size() - 1;
+}
+void ev_begin(pjb_ctx *c, const char *name) {
+    if (c->ev_used + 2 > c->ev_pool.size()) {
+        c->ev_pool.resize(c->ev_used + 2);
+        (void)hipEventCreate(&c->ev_pool[c->ev_used]);
+        (void)hipEventCreate(&c->ev_pool[c->ev_used + 1]);
+    }
+    c->ev_name.push_back(kname_index(c, name));
+    (void)hipEventRecord(c->ev_pool[c->ev_used], c->stream);
+}
+void ev_end(pjb_ctx *c) {
+    (void)hipEventRecord(c->ev_pool[c->ev_used + 1], c->stream);
+    c->ev_used += 2;
+}
+void ev_collect(pjb_ctx *c) { // stream must be synchronised
+    for (size_t k = 0; k < c->ev_name.size(); k++) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, c->ev_pool[2 * k], c->ev_pool[2 * k + 1]) == hipSuccess) {
+            c->kcount[(size_t)c->ev_name[k]]++;
+            c->kms[(size_t)c->ev_name[k]] += ms;
+        }
+    }
+    c->ev_name.clear();
+    c->ev_used = 0;
+}
+#define LAUNCH(c, name, kern, grid, block, ...)                                   \
+    do {                                                                          \
+        if ((c)->ktime) ev_begin((c), name);                                      \
+        hipLaunchKernelGGL(kern, grid, block, 0, (c)->stream, __VA_ARGS__);       \
+        if ((c)->ktime) ev_end((c));                                              \
+    } while (0)
+
 // generic scan launchers ------------------------------------------------------------------------
 template <typename F, typename G>
-int run_scan(pjb_ctx *c, F f, G g, u64 n, u64 *d_total) {
+int run_scan(pjb_ctx *c, const char *tag, F f, G g, u64 n, u64 *d_total) {
     const u32 nt = (u32)((n + SCAN_TILE - 1) / SCAN_TILE);
     int rc = ensure(c, c->b_scan_tiles, (size_t)nt * 8);
     if (rc) return rc;
     u64 *ts = (u64 *)c->b_scan_tiles.p;
-    hipLaunchKernelGGL((scan_reduce_kernel<F>), dim3(nt), dim3(256), 0, c->stream, f, n, ts);
-    hipLaunchKernelGGL(scan_tiles_kernel, dim3(1), dim3(1024), 0, c->stream, ts, nt, d_total);
-    hipLaunchKernelGGL((scan_apply_kernel<F, G>), dim3(nt), dim3(256), 0, c->stream, f, g, n, (const u64 *)ts);
+    std::string t = tag;
+    LAUNCH(c, (t + "_reduce").c_str(), (scan_reduce_kernel<F>), dim3(nt), dim3(256), f, n, ts);
+    LAUNCH(c, (t + "_tiles").c_str(), scan_tiles_kernel, dim3(1), dim3(1024), ts, nt, d_total);
+    LAUNCH(c, (t + "_apply").c_str(), (scan_apply_kernel<F, G>), dim3(nt), dim3(256), f, g, n, (const u64 *)ts);
     return PJB_OK;
 }
 
@@ -213,6 +262,7 @@ int pjb_create(pjb_ctx **out, const pjb_config *cfg) {
         return fail(nullptr, PJB_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e));
     }
     for (auto &ev : c->ev) (void)hipEventCreate(&ev);
+    c->ktime = (cfg->flags & PJB_FLAG_KERNEL_TIMING) != 0;
     if (const char *s = getenv("PJB_RADIX_BITS")) {
         int v = atoi(s);
         if (v >= 4 && v <= RS_MAX_BITS) c->radix_max_bits = v;
@@ -235,6 +285,7 @@ void pjb_destroy(pjb_ctx *c) {
                   &c->b_ancl, &c->b_ancr, &c->b_rows, &c->b_hasx};
     for (Buf *b : all) release(*b);
     for (auto &ev : c->ev) (void)hipEventDestroy(ev);
+    for (auto &ev : c->ev_pool) (void)hipEventDestroy(ev);
     (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -380,6 +431,8 @@ int pjb_finish_contig(pjb_ctx *c, int32_t tid, pjb_region_result *res) {
     memset(&R, 0, sizeof R);
     R.min_len = INT32_MAX;
     memset(&c->timing, 0, sizeof c->timing);
+    c->ev_name.clear();
+    c->ev_used = 0;
     if (res) *res = R;
     if (c->batches.empty()) return PJB_OK;
     HIP_TRY(c, hipSetDevice(c->cfg.device));
@@ -420,9 +473,9 @@ int pjb_finish_contig(pjb_ctx *c, int32_t tid, pjb_region_result *res) {
     HIP_TRY(c, hipEventRecord(c->ev[0], st));
     for (auto &b : c->batches) {
         const u32 nt = (u32)((b.n + K1_TILE - 1) / K1_TILE);
-        hipLaunchKernelGGL(k1_count, dim3(nt), dim3(256), 0, st, b, (u32 *)c->b_tile_cnt.p, (TileStats *)c->b_tile_stats.p, d_err);
+        LAUNCH(c, "k1_count", k1_count, dim3(nt), dim3(256), b, (u32 *)c->b_tile_cnt.p, (TileStats *)c->b_tile_stats.p, d_err);
     }
-    hipLaunchKernelGGL(k1_scan_tiles, dim3(1), dim3(1024), 0, st, (u32 *)c->b_tile_cnt.p, (const TileStats *)c->b_tile_stats.p, n_tiles, d_cs);
+    LAUNCH(c, "k1_scan_tiles", k1_scan_tiles, dim3(1), dim3(1024), (u32 *)c->b_tile_cnt.p, (const TileStats *)c->b_tile_stats.p, n_tiles, d_cs);
     ContigStats cs;
     u64 herr = ~0ull;
     HIP_TRY(c, hipMemcpyAsync(&cs, d_cs, sizeof cs, hipMemcpyDeviceToHost, st));
@@ -479,8 +532,8 @@ int pjb_finish_contig(pjb_ctx *c, int32_t tid, pjb_region_result *res) {
     pr.updown = (u32 *)c->b_updown.p;
     for (auto &b : c->batches) {
         const u32 nt = (u32)((b.n + K1_TILE - 1) / K1_TILE);
-        hipLaunchKernelGGL(k1_emit, dim3(nt), dim3(256), 0, st, b, (const u32 *)c->b_tile_cnt.p, pr, kf, ref_len, tid,
-                           (int)c->cfg.orientation, d_err);
+        LAUNCH(c, "k1_emit", k1_emit, dim3(nt), dim3(256), b, (const u32 *)c->b_tile_cnt.p, pr, kf, ref_len, tid,
+               (int)c->cfg.orientation, d_err);
     }
     HIP_TRY(c, hipEventRecord(c->ev[1], st));
 
@@ -500,12 +553,12 @@ int pjb_finish_contig(pjb_ctx *c, int32_t tid, pjb_region_result *res) {
         u64 *kout = (u64 *)c->b_key[cur ^ 1].p;
         const u32 *vin = p == 0 ? nullptr : (const u32 *)c->b_idx[cur].p;
         u32 *vout = (u32 *)c->b_idx[cur ^ 1].p;
-        hipLaunchKernelGGL(rs_hist, dim3(rs_tiles), dim3(256), 0, st, kin, P, shift, bits, (u32 *)c->b_hist.p, rs_tiles);
+        LAUNCH(c, "rs_hist", rs_hist, dim3(rs_tiles), dim3(256), kin, P, shift, bits, (u32 *)c->b_hist.p, rs_tiles);
         HistFn hf{(const u32 *)c->b_hist.p};
         HistSink hs{(u32 *)c->b_hist_scan.p};
-        if ((rc = run_scan(c, hf, hs, (u64)rs_tiles << bits, (u64 *)c->b_total.p))) return rc;
-        hipLaunchKernelGGL(rs_scatter, dim3(rs_tiles), dim3(256), 0, st, kin, vin, kout, vout, P, shift, bits,
-                           (const u32 *)c->b_hist_scan.p, rs_tiles);
+        if ((rc = run_scan(c, "rs_scan", hf, hs, (u64)rs_tiles << bits, (u64 *)c->b_total.p))) return rc;
+        LAUNCH(c, "rs_scatter", rs_scatter, dim3(rs_tiles), dim3(256), kin, vin, kout, vout, P, shift, bits,
+               (const u32 *)c->b_hist_scan.p, rs_tiles);
         cur ^= 1;
     }
     c->timing.sort_passes = n_pass;
@@ -521,9 +574,9 @@ int pjb_finish_contig(pjb_ctx *c, int32_t tid, pjb_region_result *res) {
     {
         HeadFn hf{skey, sidx, pr.pos};
         HeadSink hs{(u32 *)c->b_jid.p, (u32 *)c->b_seg.p, (u32 *)c->b_runfirst.p, (u32 *)c->b_runstart.p};
-        if ((rc = run_scan(c, hf, hs, (u64)P, (u64 *)c->b_total.p))) return rc;
-        hipLaunchKernelGGL(k2_close, dim3(1), dim3(1), 0, st, (u64 *)c->b_total.p, (u32 *)c->b_seg.p, (u32 *)c->b_runfirst.p,
-                           (u32 *)c->b_runstart.p, P, d_cs);
+        if ((rc = run_scan(c, "k2_heads", hf, hs, (u64)P, (u64 *)c->b_total.p))) return rc;
+        LAUNCH(c, "k2_close", k2_close, dim3(1), dim3(1), (u64 *)c->b_total.p, (u32 *)c->b_seg.p, (u32 *)c->b_runfirst.p,
+               (u32 *)c->b_runstart.p, P, d_cs);
     }
     HIP_TRY(c, hipMemcpyAsync(&cs, d_cs, sizeof cs, hipMemcpyDeviceToHost, st));
     HIP_TRY(c, hipMemcpyAsync(&herr, d_err, 8, hipMemcpyDeviceToHost, st));
@@ -545,31 +598,31 @@ int pjb_finish_contig(pjb_ctx *c, int32_t tid, pjb_region_result *res) {
     if ((rc = ensure(c, c->b_ancr, (size_t)J * 4))) return rc;
     if ((rc = ensure(c, c->b_rows, (size_t)J * sizeof(pjb_junction_row)))) return rc;
     HIP_TRY(c, hipMemsetAsync(c->b_fragj.p, 0xff, (size_t)n_slots * 4, st));
-    hipLaunchKernelGGL(k5_init_acc, dim3((J * F_WORDS + 255) / 256), dim3(256), 0, st, (u32 *)c->b_acc.p, J,
-                       (int32_t *)c->b_ancl.p, (int32_t *)c->b_ancr.p);
+    LAUNCH(c, "k5_init_acc", k5_init_acc, dim3((J * F_WORDS + 255) / 256), dim3(256), (u32 *)c->b_acc.p, J,
+           (int32_t *)c->b_ancl.p, (int32_t *)c->b_ancr.p);
     const u32 pair_blocks = (P + 255) / 256, slot_blocks = (n_slots + 255) / 256;
-    hipLaunchKernelGGL(k3_anchors_frag, dim3(pair_blocks), dim3(256), 0, st, sidx, (const u32 *)c->b_jid.p,
-                       (const int32_t *)pr.lstart, (const int32_t *)pr.rend, P, (int32_t *)c->b_fragl.p,
-                       (int32_t *)c->b_fragr.p, (int32_t *)c->b_fragj.p);
-    hipLaunchKernelGGL(k3_anchors_junc, dim3(slot_blocks), dim3(256), 0, st, (const int32_t *)c->b_fragl.p,
-                       (const int32_t *)c->b_fragr.p, (const int32_t *)c->b_fragj.p, n_slots, (int32_t *)c->b_ancl.p,
-                       (int32_t *)c->b_ancr.p);
+    LAUNCH(c, "k3_anchors_frag", k3_anchors_frag, dim3(pair_blocks), dim3(256), sidx, (const u32 *)c->b_jid.p,
+           (const int32_t *)pr.lstart, (const int32_t *)pr.rend, P, (int32_t *)c->b_fragl.p, (int32_t *)c->b_fragr.p,
+           (int32_t *)c->b_fragj.p);
+    LAUNCH(c, "k3_anchors_junc", k3_anchors_junc, dim3(slot_blocks), dim3(256), (const int32_t *)c->b_fragl.p,
+           (const int32_t *)c->b_fragr.p, (const int32_t *)c->b_fragj.p, n_slots, (int32_t *)c->b_ancl.p,
+           (int32_t *)c->b_ancr.p);
     HIP_TRY(c, hipEventRecord(c->ev[4], st));
 
     // ---- K4: per-pair match statistics -> fragments
-    hipLaunchKernelGGL(k4_pairs, dim3(pair_blocks), dim3(256), 0, st, skey, sidx, (const u32 *)c->b_jid.p, pr, kf,
-                       (const DevBatch *)c->b_batches.p, (int)c->batches.size(), (const int32_t *)c->b_ancl.p,
-                       (const int32_t *)c->b_ancr.p, (const uint8_t *)G.d, (int32_t)G.len, G.has_x ? 1 : 0, P,
-                       (u32 *)c->b_frag.p, (int32_t *)c->b_fragj.p, d_err);
+    LAUNCH(c, "k4_pairs", k4_pairs, dim3(pair_blocks), dim3(256), skey, sidx, (const u32 *)c->b_jid.p, pr, kf,
+           (const DevBatch *)c->b_batches.p, (int)c->batches.size(), (const int32_t *)c->b_ancl.p,
+           (const int32_t *)c->b_ancr.p, (const uint8_t *)G.d, (int32_t)G.len, G.has_x ? 1 : 0, P, (u32 *)c->b_frag.p,
+           (int32_t *)c->b_fragj.p, d_err);
     HIP_TRY(c, hipEventRecord(c->ev[5], st));
 
     // ---- K5: fragments -> junctions -> rows
-    hipLaunchKernelGGL(k5_frag_reduce, dim3(slot_blocks), dim3(256), 0, st, (const u32 *)c->b_frag.p,
-                       (const int32_t *)c->b_fragj.p, n_slots, (u32 *)c->b_acc.p);
-    hipLaunchKernelGGL(k5_finalize, dim3((J + 255) / 256), dim3(256), 0, st, skey, (const u32 *)c->b_seg.p,
-                       (const u32 *)c->b_runfirst.p, (const u32 *)c->b_runstart.p, (const u32 *)c->b_acc.p,
-                       (const int32_t *)c->b_ancl.p, (const int32_t *)c->b_ancr.p, kf, (const uint8_t *)G.d, (int32_t)G.len,
-                       tid, J, (pjb_junction_row *)c->b_rows.p, d_err);
+    LAUNCH(c, "k5_frag_reduce", k5_frag_reduce, dim3(slot_blocks), dim3(256), (const u32 *)c->b_frag.p,
+           (const int32_t *)c->b_fragj.p, n_slots, (u32 *)c->b_acc.p);
+    LAUNCH(c, "k5_finalize", k5_finalize, dim3((J + 255) / 256), dim3(256), skey, (const u32 *)c->b_seg.p,
+           (const u32 *)c->b_runfirst.p, (const u32 *)c->b_runstart.p, (const u32 *)c->b_acc.p,
+           (const int32_t *)c->b_ancl.p, (const int32_t *)c->b_ancr.p, kf, (const uint8_t *)G.d, (int32_t)G.len, tid, J,
+           (pjb_junction_row *)c->b_rows.p, d_err);
     HIP_TRY(c, hipEventRecord(c->ev[6], st));
 
     // ---- rows to host
@@ -583,6 +636,7 @@ int pjb_finish_contig(pjb_ctx *c, int32_t tid, pjb_region_result *res) {
         c->rows.resize(old);
         return rc;
     }
+    if (c->ktime) ev_collect(c);
     for (int k = 0; k < 7; k++) (void)hipEventElapsedTime(&c->timing.stage_ms[k], c->ev[k], c->ev[k + 1]);
     (void)hipEventElapsedTime(&c->timing.total_ms, c->ev[0], c->ev[7]);
     if (res) *res = R;
@@ -599,6 +653,25 @@ int pjb_collect(pjb_ctx *c, const pjb_junction_row **rows, int64_t *n) {
 int pjb_clear_rows(pjb_ctx *c) {
     if (!c) return PJB_ERR_ARG;
     c->rows.clear();
+    return PJB_OK;
+}
+
+int pjb_get_kernel_timing(const pjb_ctx *c, pjb_kernel_time *out, int32_t cap, int32_t *n) {
+    if (!c || !n) return PJB_ERR_ARG;
+    *n = (int32_t)c->knames.size();
+    for (int32_t i = 0; out && i < cap && i < *n; i++) {
+        memset(&out[i], 0, sizeof out[i]);
+        strncpy(out[i].name, c->knames[(size_t)i].c_str(), sizeof(out[i].name) - 1);
+        out[i].launches = c->kcount[(size_t)i];
+        out[i].total_ms = c->kms[(size_t)i];
+    }
+    return PJB_OK;
+}
+
+int pjb_reset_kernel_timing(pjb_ctx *c) {
+    if (!c) return PJB_ERR_ARG;
+    std::fill(c->kcount.begin(), c->kcount.end(), 0);
+    std::fill(c->kms.begin(), c->kms.end(), 0.0);
     return PJB_OK;
 }
 

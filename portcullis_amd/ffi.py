@@ -21,8 +21,9 @@ STAGE_NAMES = ["scan_emit", "sort", "group", "anchors", "pair_stats", "finalize"
 EXPORTS = [
     "pjb_create", "pjb_destroy", "pjb_last_error", "pjb_set_refs", "pjb_upload_contig", "pjb_upload_contig_device",
     "pjb_release_contig", "pjb_submit_batch", "pjb_submit_batch_device", "pjb_finish_contig", "pjb_collect",
-    "pjb_clear_rows", "pjb_get_timing", "pjb_device_count",
+    "pjb_clear_rows", "pjb_get_timing", "pjb_device_count", "pjb_get_kernel_timing", "pjb_reset_kernel_timing",
 ]
+FLAG_KERNEL_TIMING = 1
 
 
 class PjbConfig(C.Structure):
@@ -43,6 +44,10 @@ class PjbRegionResult(C.Structure):
 
 class PjbTiming(C.Structure):
     _fields_ = [("total_ms", C.c_float), ("stage_ms", C.c_float * N_STAGES), ("sort_passes", C.c_int64)]
+
+
+class PjbKernelTime(C.Structure):
+    _fields_ = [("name", C.c_char * 32), ("launches", C.c_int64), ("total_ms", C.c_double)]
 
 
 ROW_DTYPE = np.dtype(
@@ -94,6 +99,8 @@ def load():
         L.pjb_collect.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
         L.pjb_clear_rows.argtypes = [C.c_void_p]
         L.pjb_get_timing.argtypes = [C.c_void_p, C.POINTER(PjbTiming)]
+        L.pjb_get_kernel_timing.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]
+        L.pjb_reset_kernel_timing.argtypes = [C.c_void_p]
         _LIB = L
     return _LIB
 
@@ -110,11 +117,11 @@ _FIELDS = [("pos", np.int32), ("flag", np.uint16), ("mapq", np.uint8), ("xs", np
 class Context:
     """One device context (pjb_ctx).  Mirrors the calls JunctionBuilder::findJunctions makes."""
 
-    def __init__(self, device=0, orientation="UNKNOWN", strandedness=3):
+    def __init__(self, device=0, orientation="UNKNOWN", strandedness=3, flags=0):
         self._L = load()
         self._h = C.c_void_p()
         ori = ORIENTATION[orientation] if isinstance(orientation, str) else int(orientation)
-        cfg = PjbConfig(ABI_VERSION, device, ori, strandedness, 0)
+        cfg = PjbConfig(ABI_VERSION, device, ori, strandedness, flags)
         rc = self._L.pjb_create(C.byref(self._h), C.byref(cfg))
         if rc:
             raise PjbError(rc, self._L.pjb_last_error(None).decode())
@@ -201,6 +208,22 @@ class Context:
         self._check(self._L.pjb_get_timing(self._h, C.byref(t)))
         return dict(total_ms=t.total_ms, stage_ms={STAGE_NAMES[i]: t.stage_ms[i] for i in range(N_STAGES)},
                     sort_passes=t.sort_passes)
+
+
+def _kernel_timing(self):
+    n = C.c_int32()
+    self._check(self._L.pjb_get_kernel_timing(self._h, None, 0, C.byref(n)))
+    arr = (PjbKernelTime * max(1, n.value))()
+    self._check(self._L.pjb_get_kernel_timing(self._h, arr, n.value, C.byref(n)))
+    return {arr[i].name.decode(): (arr[i].launches, arr[i].total_ms) for i in range(n.value)}
+
+
+def _reset_kernel_timing(self):
+    self._check(self._L.pjb_reset_kernel_timing(self._h))
+
+
+Context.kernel_timing = _kernel_timing
+Context.reset_kernel_timing = _reset_kernel_timing
 
 
 def run_contig(ctx, tid, genome, batches):
