@@ -138,7 +138,7 @@ def lib():
         ]
         L.orc_free_rows.argtypes = [C.c_void_p]
         L.orc_finalize.argtypes = [C.c_void_p, C.c_int64, C.c_double]
-        for f in ("orc_write_tab", "orc_write_bed", "orc_write_intron_gff"):
+        for f in ("orc_write_tab", "orc_write_bed", "orc_write_intron_gff", "orc_write_exon_gff"):
             getattr(L, f).restype = C.c_void_p
         L.orc_free_text.argtypes = [C.c_void_p]
         assert C.sizeof(OrcRegion) == 32
@@ -329,3 +329,33 @@ def write_bed(rows, ref_names, source="portcullis", version=""):
 def write_intron_gff(rows, ref_names, source="portcullis"):
     rows = np.ascontiguousarray(rows)
     return _text("orc_write_intron_gff", rows.ctypes.data_as(C.c_void_p), C.c_int64(len(rows)), _names(ref_names), source.encode())
+
+
+def write_exon_gff(rows, ref_names, source="portcullis"):
+    rows = np.ascontiguousarray(rows)
+    return _text("orc_write_exon_gff", rows.ctypes.data_as(C.c_void_p), C.c_int64(len(rows)), _names(ref_names), source.encode())
+
+
+def run_prep_like(refs, genomes, batches_by_tid, orientation="UNKNOWN"):
+    """The whole junc stage on in-memory inputs: per-contig find_juncs, merge, finalize.
+    refs: [(name, len)], genomes: {tid: bytes/str}, batches_by_tid: {tid: ReadBatch-like with to_oracle()}.
+    Returns (rows, totals dict)."""
+    all_rows = []
+    spliced = unspliced = sum_len = 0
+    mn, mx = 2**31 - 1, 0
+    for tid, (name, ln) in enumerate(refs):
+        b = batches_by_tid.get(tid)
+        if b is None or b.n == 0:
+            continue
+        rows, reg = find_juncs(tid, ln, genomes[tid], b.to_oracle(), orientation)
+        all_rows.append(rows)
+        spliced += reg["spliced"]
+        unspliced += reg["unspliced"]
+        sum_len += reg["sum_len"]
+        mn = min(mn, reg["min_len"])
+        mx = max(mx, reg["max_len"])
+    rows = np.concatenate(all_rows) if all_rows else np.zeros(0, dtype=ROW_DTYPE)
+    total = spliced + unspliced
+    mean = (sum_len / total) if total else float("nan")
+    rows = finalize(rows, mean)
+    return rows, dict(spliced=spliced, unspliced=unspliced, sum_len=sum_len, min_len=mn, max_len=mx, mean=mean)

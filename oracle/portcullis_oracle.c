@@ -1066,4 +1066,33 @@ char *orc_write_intron_gff(const orc_row *rows, int64_t n, const char *const *re
     return s.p;
 }
 
+/* Junction::outputJunctionGFF + condensedOutputDescription, junction.cc:1082-1183: entropy is
+ * printed with setprecision(4) in the Note and with the precision 9 that is left on the stream in
+ * the trailing attributes; bools are boolalpha there. */
+char *orc_write_exon_gff(const orc_row *rows, int64_t n, const char *const *ref_names,
+                         const char *source, size_t *len_out) {
+    static const char *STRAND_STR[] = {"POSITIVE", "NEGATIVE", "UNKNOWN"};
+    static const char *CSS_STR[] = {"Canonical", "Semi-canonical", "No"};
+    sbuf s = {0};
+    sb_reserve(&s, 1);
+    s.p[0] = 0;
+    for (int64_t i = 0; i < n; i++) {
+        const orc_row *r = &rows[i];
+        char strand = r->cons_strand == ORC_STRAND_UNK ? '?' : strand_chr(r->cons_strand);
+        uint32_t ham = r->hamming3p < r->hamming5p ? r->hamming3p : r->hamming5p;
+        sb_printf(&s, "%s\t%s\tmatch\t%d\t%d\t0.0\t%c\t.\tID=junc_%u;Name=junc_%u;Note=cov:%u|rel:%u|ent:%.4g|maxmmes:%u|ham:%u;mult=%u;grp=junc_%u;src=E;",
+                  ref_names[r->refid], source, r->left + 1, r->right + 1, strand, r->id, r->id, r->nb_raw, r->nb_rel,
+                  r->entropy, r->maxmmes, ham, r->nb_raw, r->id);
+        sb_printf(&s, "Strand: %s;Canonical?=%s;Score=0;NbAlignments=%u;NbDistinct=%u;NbReliable=%u;Entropy=%.9g;MaxMMES=%u;HammingDistance5=%u;HammingDistance3=%u;UniqueJunction=%s;PrimaryJunction=%s;\n",
+                  STRAND_STR[r->cons_strand], CSS_STR[r->canonical], r->nb_raw, r->nb_dist, r->nb_rel, r->entropy,
+                  r->maxmmes, r->hamming5p, r->hamming3p, r->uniq ? "true" : "false", r->primary ? "true" : "false");
+        sb_printf(&s, "%s\t%s\tmatch_part\t%d\t%d\t0.0\t%c\t.\tID=junc_%u_left;Parent=junc_%u\n", ref_names[r->refid], source,
+                  r->left + 1, r->start, strand, r->id, r->id);
+        sb_printf(&s, "%s\t%s\tmatch_part\t%d\t%d\t0.0\t%c\t.\tID=junc_%u_right;Parent=junc_%u\n", ref_names[r->refid], source,
+                  r->end + 2, r->right + 1, strand, r->id, r->id);
+    }
+    *len_out = s.n;
+    return s.p;
+}
+
 void orc_free_text(char *p) { free(p); }

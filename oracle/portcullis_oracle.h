@@ -165,6 +165,8 @@ char *orc_write_bed(const orc_row *rows, int64_t n, const char *const *ref_names
                     const char *source, const char *version, size_t *len_out);
 char *orc_write_intron_gff(const orc_row *rows, int64_t n, const char *const *ref_names,
                            const char *source, size_t *len_out);
+char *orc_write_exon_gff(const orc_row *rows, int64_t n, const char *const *ref_names,
+                         const char *source, size_t *len_out);
 void orc_free_text(char *p);
 
 const char *orc_last_error(void);

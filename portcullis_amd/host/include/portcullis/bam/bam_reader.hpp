@@ -1,0 +1,90 @@
+// BamReader: BGZF + BAM + BAI reader that transcodes alignment records straight into the
+// fixed-width structure-of-arrays batches the device path consumes (pjb_batch), without building
+// per-record objects.  Plays the role of lib/src/bam_reader.cc + BamAlignment::init
+// (lib/src/bam_alignment.cc:71-100) of the reference; written from the SAM/BAM specification on
+// top of zlib only.
+#pragma once
+
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "bam_master.hpp"
+
+struct pjb_batch;
+
+namespace portcullis {
+namespace bam {
+
+// One batch of alignment records of one target sequence, in file order (layout of pjb_batch).
+struct ReadBatch {
+    std::vector<int32_t> pos, l_qseq, mtid, mpos;
+    std::vector<uint16_t> flag;
+    std::vector<uint8_t> mapq, xs;
+    std::vector<uint32_t> cig_off, cigar, seq_off;
+    std::vector<uint8_t> seq4;
+    uint64_t n_refskip = 0;
+
+    size_t size() const { return pos.size(); }
+    void clear();
+    void reserve(size_t n);
+    void view(pjb_batch& out) const;  // fill a pjb_batch with pointers into this object
+};
+
+// Sequential reader over the inflated byte stream of a BGZF file with virtual-offset seeking.
+class BgzfStream {
+    FILE* fp = nullptr;
+    std::vector<uint8_t> comp, block;
+    size_t block_pos = 0;
+    uint64_t block_coffset = 0, next_coffset = 0;
+    bool at_eof = false;
+    bool loadBlock();
+
+public:
+    ~BgzfStream() { close(); }
+    void open(const std::string& path);
+    void close();
+    bool isOpen() const { return fp != nullptr; }
+    void seek(uint64_t voffset);
+    size_t read(void* dst, size_t n);  // returns bytes read (< n only at end of file)
+};
+
+class BamReader {
+    std::string bamFile;
+    BgzfStream bgzf;
+    std::string headerText;
+    std::vector<RefSeq> targets;
+    std::vector<uint64_t> firstOffset;  // per target: virtual offset of its first record, ~0 = none
+    bool indexLoaded = false;
+    int32_t regionTid = -1;
+    int32_t regionLen = 0;
+    bool regionDone = true;
+    std::vector<uint8_t> rec;
+
+    void loadIndex(bool useCsi);
+
+public:
+    explicit BamReader(const std::string& path) : bamFile(path) {}
+
+    void open(bool useCsi = false);
+    void close() { bgzf.close(); }
+
+    std::shared_ptr<RefSeqPtrList> createRefList() const;
+    std::shared_ptr<RefSeqPtrIndexMap> createRefMap(const RefSeqPtrList& refs) const;
+    std::string bamDetails() const;
+    const std::string& getHeaderText() const { return headerText; }
+
+    // true if the index lists at least one alignment on the target
+    bool hasAlignments(int32_t tid) const { return firstOffset[(size_t)tid] != ~0ull; }
+
+    // Visit every alignment placed on `tid` with pos < length(tid), like
+    // BamReader::setRegion(tid, 0, len) + next() of the reference (src/junction_builder.cc:321-322):
+    // no flag is filtered, unplaced reads are never seen.
+    void setRegion(int32_t tid);
+    // Append up to maxRecords records of the region to `out`; false when the region is exhausted
+    // and nothing was appended.
+    bool nextBatch(ReadBatch& out, size_t maxRecords);
+};
+
+}  // namespace bam
+}  // namespace portcullis

@@ -1,0 +1,110 @@
+// JunctionBuilder: the `junc` stage driver.  Same construction / setter / process() surface as
+// portcullis::JunctionBuilder (src/junction_builder.hpp:82-259 of the reference); the work that
+// the reference does per alignment on CPU threads (findJuncs, src/junction_builder.cc:314-357)
+// is streamed in batches to the MI355X through the C ABI in include/portcullis_amd.h.
+#pragma once
+
+#include <string>
+#include <vector>
+
+#include "bam/bam_reader.hpp"
+#include "bam/genome_mapper.hpp"
+#include "junction_system.hpp"
+#include "prepared_files.hpp"
+
+struct pjb_junction_row;
+
+namespace portcullis {
+
+const std::string DEFAULT_JUNC_OUTPUT = "portcullis_junc/portcullis";
+const std::string DEFAULT_JUNC_SOURCE = "portcullis";
+const uint16_t DEFAULT_JUNC_THREADS = 1;
+
+struct JunctionBuilderException : public PortcullisException {
+    explicit JunctionBuilderException(const std::string& m) : PortcullisException(m) {}
+};
+
+// per target sequence outcome (RegionResult, src/junction_builder.hpp:62-76)
+struct RegionResult {
+    uint64_t splicedCount = 0;
+    uint64_t unsplicedCount = 0;
+    uint64_t sumQueryLengths = 0;
+    int32_t minQueryLength = INT32_MAX;
+    int32_t maxQueryLength = 0;
+    std::string name;
+    JunctionSystem js;
+};
+
+class JunctionBuilder {
+    PreparedFiles prepData;
+    std::string outputDir;
+    std::string outputPrefix;
+    uint16_t threads = 1;
+    bam::Strandedness strandSpecific = bam::Strandedness::UNKNOWN;
+    bam::Orientation orientation = bam::Orientation::UNKNOWN;
+    bool extra = false;
+    bool separate = false;
+    bool useCsi = false;
+    bool outputExonGFF = false;
+    bool outputIntronGFF = false;
+    std::string source = DEFAULT_JUNC_SOURCE;
+    bool verbose = false;
+    int devices = 0;               // 0 = every visible GPU
+    size_t batchRecords = 1 << 20; // alignments per batch sent to the device
+
+    JunctionSystem junctionSystem;
+    std::shared_ptr<bam::RefSeqPtrList> refs;
+    std::shared_ptr<bam::RefSeqPtrIndexMap> refMap;
+    std::vector<RegionResult> results;
+
+protected:
+    void findJunctions();
+    // decode one target sequence and run it through the device path (worker body)
+    void findJuncs(void* deviceContext, bam::BamReader& reader, bam::GenomeMapper& gmap, int32_t seq);
+
+public:
+    JunctionBuilder(const std::string& prepDir, const std::string& output);
+    virtual ~JunctionBuilder() = default;
+
+    std::string getRefName(int32_t seqId) { return refs->at((size_t)seqId)->name; }
+    PreparedFiles& getPreparedFiles() { return prepData; }
+    JunctionSystem& getJunctionSystem() { return junctionSystem; }
+
+    bool isExtra() const { return extra; }
+    void setExtra(bool v) { extra = v; }
+    uint16_t getThreads() const { return threads; }
+    void setThreads(uint16_t v) { threads = v; }
+    bool isVerbose() const { return verbose; }
+    void setVerbose(bool v) { verbose = v; }
+    bool isSeparate() const { return separate; }
+    void setSeparate(bool v) { separate = v; }
+    std::string getSource() const { return source; }
+    void setSource(const std::string& v) { source = v; }
+    bam::Strandedness getStrandSpecific() const { return strandSpecific; }
+    void setStrandSpecific(bam::Strandedness v) { strandSpecific = v; }
+    bam::Orientation getOrientation() const { return orientation; }
+    void setOrientation(bam::Orientation v) { orientation = v; }
+    bool isUseCsi() const { return useCsi; }
+    void setUseCsi(bool v) { useCsi = v; }
+    bool isOutputExonGFF() const { return outputExonGFF; }
+    void setOutputExonGFF(bool v) { outputExonGFF = v; }
+    bool isOutputIntronGFF() const { return outputIntronGFF; }
+    void setOutputIntronGFF(bool v) { outputIntronGFF = v; }
+    // additions of this implementation
+    int getDevices() const { return devices; }
+    void setDevices(int n) { devices = n; }
+    void setBatchRecords(size_t n) { batchRecords = n ? n : 1; }
+
+    void process();
+
+    static std::string title() { return "Portcullis Junction Builder Mode Help"; }
+    static std::string description() {
+        return std::string("Analyses all potential junctions found in the input BAM file.\n") +
+               "Run \"portcullis prep ...\" to generate data suitable for junction finding\n" +
+               "before running \"portcullis junc ...\"";
+    }
+    static std::string usage() { return "portcullis junc [options] <prep_data_dir>"; }
+    static int main(int argc, char* argv[]);
+};
+
+}  // namespace portcullis

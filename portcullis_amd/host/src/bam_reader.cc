@@ -1,0 +1,325 @@
+#include <portcullis/bam/bam_reader.hpp>
+
+#include <cstring>
+#include <sstream>
+#include <zlib.h>
+
+#include "../../../include/portcullis_amd.h"
+
+namespace portcullis {
+namespace bam {
+
+// ------------------------------------------------------------------ ReadBatch
+void ReadBatch::clear() {
+    pos.clear(); l_qseq.clear(); mtid.clear(); mpos.clear(); flag.clear(); mapq.clear(); xs.clear();
+    cig_off.assign(1, 0);
+    cigar.clear();
+    seq_off.assign(1, 0);
+    seq4.clear();
+    n_refskip = 0;
+}
+
+void ReadBatch::reserve(size_t n) {
+    pos.reserve(n); l_qseq.reserve(n); mtid.reserve(n); mpos.reserve(n); flag.reserve(n); mapq.reserve(n); xs.reserve(n);
+    cig_off.reserve(n + 1);
+    seq_off.reserve(n + 1);
+    cigar.reserve(n * 2);
+}
+
+void ReadBatch::view(pjb_batch& b) const {
+    b.n_reads = (int64_t)pos.size();
+    b.pos = pos.data(); b.flag = flag.data(); b.mapq = mapq.data(); b.xs = xs.data(); b.l_qseq = l_qseq.data();
+    b.mtid = mtid.data(); b.mpos = mpos.data(); b.cig_off = cig_off.data(); b.cigar = cigar.data();
+    b.seq_off = seq_off.data(); b.seq4 = seq4.data();
+}
+
+// ------------------------------------------------------------------ BGZF
+static inline uint16_t le16(const uint8_t* p) { return (uint16_t)(p[0] | (p[1] << 8)); }
+static inline uint32_t le32(const uint8_t* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
+static inline uint64_t le64(const uint8_t* p) { return (uint64_t)le32(p) | ((uint64_t)le32(p + 4) << 32); }
+
+void BgzfStream::open(const std::string& path) {
+    close();
+    fp = fopen(path.c_str(), "rb");
+    if (!fp) throw BamException("Could not open BAM file: " + path);
+    setvbuf(fp, nullptr, _IOFBF, 1 << 20);
+    block.clear();
+    block_pos = 0;
+    block_coffset = next_coffset = 0;
+    at_eof = false;
+}
+
+void BgzfStream::close() {
+    if (fp) fclose(fp);
+    fp = nullptr;
+}
+
+bool BgzfStream::loadBlock() {
+    uint8_t hdr[18];
+    block_coffset = next_coffset;
+    size_t got = fread(hdr, 1, 18, fp);
+    if (got == 0) {
+        at_eof = true;
+        block.clear();
+        block_pos = 0;
+        return false;
+    }
+    if (got != 18 || hdr[0] != 31 || hdr[1] != 139 || hdr[2] != 8 || !(hdr[3] & 4))
+        throw BamException("Invalid BGZF block header");
+    uint16_t xlen = le16(hdr + 10);
+    // find the BC subfield (normally the first and only one)
+    std::vector<uint8_t> extra(xlen);
+    memcpy(extra.data(), hdr + 12, std::min<size_t>(6, xlen));
+    if (xlen > 6 && fread(extra.data() + 6, 1, xlen - 6, fp) != (size_t)(xlen - 6)) throw BamException("Truncated BGZF block");
+    int bsize = -1;
+    for (size_t o = 0; o + 4 <= extra.size();) {
+        uint16_t slen = le16(&extra[o + 2]);
+        if (extra[o] == 'B' && extra[o + 1] == 'C' && slen == 2) bsize = le16(&extra[o + 4]);
+        o += 4 + slen;
+    }
+    if (bsize < 0) throw BamException("BGZF block without BC field");
+    const size_t total = (size_t)bsize + 1;
+    const size_t cdata = total - 12 - xlen - 8;
+    comp.resize(cdata + 8);
+    if (fread(comp.data(), 1, cdata + 8, fp) != cdata + 8) throw BamException("Truncated BGZF block");
+    const uint32_t isize = le32(&comp[cdata + 4]);
+    block.resize(isize);
+    if (isize) {
+        z_stream zs;
+        memset(&zs, 0, sizeof zs);
+        if (inflateInit2(&zs, -15) != Z_OK) throw BamException("inflateInit2 failed");
+        zs.next_in = comp.data();
+        zs.avail_in = (uInt)cdata;
+        zs.next_out = block.data();
+        zs.avail_out = isize;
+        int rc = inflate(&zs, Z_FINISH);
+        inflateEnd(&zs);
+        if (rc != Z_STREAM_END || zs.avail_out != 0) throw BamException("BGZF inflate failed");
+    }
+    next_coffset = block_coffset + total;
+    block_pos = 0;
+    return true;
+}
+
+void BgzfStream::seek(uint64_t voffset) {
+    const uint64_t co = voffset >> 16;
+    const size_t uo = (size_t)(voffset & 0xffff);
+    if (fseeko(fp, (off_t)co, SEEK_SET) != 0) throw BamException("BGZF seek failed");
+    next_coffset = co;
+    at_eof = false;
+    if (!loadBlock()) return;
+    if (uo > block.size()) throw BamException("BGZF virtual offset beyond block");
+    block_pos = uo;
+}
+
+size_t BgzfStream::read(void* dst, size_t n) {
+    uint8_t* d = (uint8_t*)dst;
+    size_t done = 0;
+    while (done < n) {
+        if (block_pos >= block.size()) {
+            if (at_eof || !loadBlock()) break;
+            continue;
+        }
+        const size_t take = std::min(n - done, block.size() - block_pos);
+        memcpy(d + done, block.data() + block_pos, take);
+        block_pos += take;
+        done += take;
+    }
+    return done;
+}
+
+// ------------------------------------------------------------------ BAM
+void BamReader::open(bool useCsi) {
+    bgzf.open(bamFile);
+    uint8_t b4[4];
+    if (bgzf.read(b4, 4) != 4 || memcmp(b4, "BAM\1", 4) != 0) throw BamException("Not a BAM file: " + bamFile);
+    if (bgzf.read(b4, 4) != 4) throw BamException("Truncated BAM header");
+    const uint32_t l_text = le32(b4);
+    headerText.resize(l_text);
+    if (l_text && bgzf.read(&headerText[0], l_text) != l_text) throw BamException("Truncated BAM header");
+    if (bgzf.read(b4, 4) != 4) throw BamException("Truncated BAM header");
+    const uint32_t n_ref = le32(b4);
+    targets.clear();
+    for (uint32_t i = 0; i < n_ref; i++) {
+        if (bgzf.read(b4, 4) != 4) throw BamException("Truncated BAM header");
+        const uint32_t l_name = le32(b4);
+        std::string name(l_name, 0);
+        if (bgzf.read(&name[0], l_name) != l_name || bgzf.read(b4, 4) != 4) throw BamException("Truncated BAM header");
+        if (!name.empty() && name.back() == 0) name.pop_back();
+        targets.emplace_back((int32_t)i, name, (int32_t)le32(b4));
+    }
+    loadIndex(useCsi);
+}
+
+void BamReader::loadIndex(bool useCsi) {
+    if (useCsi) throw BamException("CSI indices are not supported by this reader yet; use a BAI index");
+    const std::string path = bamFile + ".bai";
+    FILE* f = fopen(path.c_str(), "rb");
+    if (!f) throw BamException("Could not open BAM index: " + path);
+    std::vector<uint8_t> buf;
+    fseeko(f, 0, SEEK_END);
+    const off_t sz = ftello(f);
+    fseeko(f, 0, SEEK_SET);
+    buf.resize((size_t)sz);
+    if (sz && fread(buf.data(), 1, (size_t)sz, f) != (size_t)sz) {
+        fclose(f);
+        throw BamException("Could not read BAM index: " + path);
+    }
+    fclose(f);
+    if (buf.size() < 8 || memcmp(buf.data(), "BAI\1", 4) != 0) throw BamException("Not a BAI index: " + path);
+    size_t o = 4;
+    const uint32_t n_ref = le32(&buf[o]);
+    o += 4;
+    firstOffset.assign(targets.size(), ~0ull);
+    for (uint32_t r = 0; r < n_ref; r++) {
+        if (o + 4 > buf.size()) throw BamException("Truncated BAI index");
+        const uint32_t n_bin = le32(&buf[o]);
+        o += 4;
+        uint64_t first = ~0ull;
+        for (uint32_t b = 0; b < n_bin; b++) {
+            if (o + 8 > buf.size()) throw BamException("Truncated BAI index");
+            const uint32_t bin = le32(&buf[o]);
+            const uint32_t n_chunk = le32(&buf[o + 4]);
+            o += 8;
+            if (o + 16ull * n_chunk > buf.size()) throw BamException("Truncated BAI index");
+            if (bin != 37450)  // pseudo-bin holding metadata, not chunks
+                for (uint32_t c = 0; c < n_chunk; c++) first = std::min(first, le64(&buf[o + 16 * c]));
+            o += 16ull * n_chunk;
+        }
+        if (o + 4 > buf.size()) throw BamException("Truncated BAI index");
+        const uint32_t n_intv = le32(&buf[o]);
+        o += 4 + 8ull * n_intv;
+        if (r < firstOffset.size()) firstOffset[r] = first;
+    }
+    indexLoaded = true;
+}
+
+std::shared_ptr<RefSeqPtrList> BamReader::createRefList() const {
+    auto l = std::make_shared<RefSeqPtrList>();
+    for (const RefSeq& t : targets) l->push_back(std::make_shared<RefSeq>(t));
+    return l;
+}
+
+std::shared_ptr<RefSeqPtrIndexMap> BamReader::createRefMap(const RefSeqPtrList& refs) const {
+    auto m = std::make_shared<RefSeqPtrIndexMap>();
+    for (const auto& r : refs) (*m)[r->index] = r;
+    return m;
+}
+
+std::string BamReader::bamDetails() const {
+    std::stringstream ss;
+    ss << "BAM details:" << std::endl << " - File: " << bamFile << std::endl << " - # Target sequences: " << targets.size() << std::endl;
+    return ss.str();
+}
+
+void BamReader::setRegion(int32_t tid) {
+    if (tid < 0 || (size_t)tid >= targets.size()) throw BamException("setRegion: target out of range");
+    regionTid = tid;
+    regionLen = targets[(size_t)tid].length;
+    regionDone = firstOffset[(size_t)tid] == ~0ull;
+    if (!regionDone) bgzf.seek(firstOffset[(size_t)tid]);
+}
+
+// XS:A aux tag -> code (0 absent / '?' / '.', 1 '+', 2 '-', 3 anything else incl. a non-'A' typed XS,
+// for which bam_aux2A returns 0 and strandFromChar throws in the reference)
+static uint8_t xsCode(const uint8_t* aux, const uint8_t* end) {
+    const uint8_t* p = aux;
+    while (p + 3 <= end) {
+        const uint8_t t0 = p[0], t1 = p[1], ty = p[2];
+        p += 3;
+        const bool isXS = t0 == 'X' && t1 == 'S';
+        size_t sz = 0;
+        switch (ty) {
+        case 'A': case 'c': case 'C': sz = 1; break;
+        case 's': case 'S': sz = 2; break;
+        case 'i': case 'I': case 'f': sz = 4; break;
+        case 'd': sz = 8; break;
+        case 'Z': case 'H': {
+            const uint8_t* q = p;
+            while (q < end && *q) q++;
+            sz = (size_t)(q - p) + 1;
+            break;
+        }
+        case 'B': {
+            if (p + 5 > end) return isXS ? 3 : 0;
+            const uint8_t sub = p[0];
+            const uint32_t cnt = le32(p + 1);
+            size_t es = (sub == 'c' || sub == 'C') ? 1 : (sub == 's' || sub == 'S') ? 2 : 4;
+            sz = 5 + es * cnt;
+            break;
+        }
+        default: return isXS ? 3 : 0;  // malformed aux block
+        }
+        if (isXS) {
+            if (ty != 'A' || p >= end) return 3;
+            const char c = (char)p[0];
+            return c == '+' ? 1 : c == '-' ? 2 : (c == '?' || c == '.') ? 0 : 3;
+        }
+        p += sz;
+    }
+    return 0;
+}
+
+bool BamReader::nextBatch(ReadBatch& out, size_t maxRecords) {
+    if (out.cig_off.empty()) out.clear();
+    size_t added = 0;
+    while (!regionDone && added < maxRecords) {
+        uint8_t b4[4];
+        if (bgzf.read(b4, 4) != 4) {
+            regionDone = true;
+            break;
+        }
+        const uint32_t bs = le32(b4);
+        if (bs < 32) throw BamException("Invalid BAM record");
+        rec.resize(bs);
+        if (bgzf.read(rec.data(), bs) != bs) throw BamException("Truncated BAM record");
+        const uint8_t* r = rec.data();
+        const int32_t tid = (int32_t)le32(r);
+        const int32_t pos = (int32_t)le32(r + 4);
+        if (tid != regionTid || pos >= regionLen) {
+            regionDone = true;
+            break;
+        }
+        const uint32_t l_name = r[8];
+        const uint8_t mapq = r[9];
+        const uint32_t n_cig = le16(r + 12);
+        const uint16_t flag = le16(r + 14);
+        const int32_t l_seq = (int32_t)le32(r + 16);
+        const int32_t mtid = (int32_t)le32(r + 20);
+        const int32_t mpos = (int32_t)le32(r + 24);
+        const size_t cig_at = 32 + l_name;
+        const size_t seq_at = cig_at + 4ull * n_cig;
+        const size_t seq_bytes = (size_t)((l_seq + 1) / 2);
+        const size_t aux_at = seq_at + seq_bytes + (size_t)(l_seq > 0 ? l_seq : 0);
+        if (l_seq < 0 || aux_at > bs) throw BamException("Invalid BAM record layout");
+        out.pos.push_back(pos);
+        out.flag.push_back(flag);
+        out.mapq.push_back(mapq);
+        out.l_qseq.push_back(l_seq);
+        out.mtid.push_back(mtid);
+        out.mpos.push_back(mpos);
+        out.xs.push_back(xsCode(r + aux_at, r + bs));
+        bool spliced = false;
+        for (uint32_t k = 0; k < n_cig; k++) {
+            const uint32_t op = le32(r + cig_at + 4 * k);
+            out.cigar.push_back(op);
+            if ((op & 15u) == 3u) {
+                spliced = true;
+                out.n_refskip++;
+            }
+        }
+        out.cig_off.push_back((uint32_t)out.cigar.size());
+        if (spliced && seq_bytes) {  // only spliced alignments need their bases on the device
+            const size_t words = (seq_bytes + 3) / 4;
+            const size_t at = out.seq4.size();
+            out.seq4.resize(at + words * 4, 0);
+            memcpy(&out.seq4[at], r + seq_at, seq_bytes);
+        }
+        out.seq_off.push_back((uint32_t)(out.seq4.size() / 4));
+        added++;
+    }
+    return added > 0;
+}
+
+}  // namespace bam
+}  // namespace portcullis

@@ -1,0 +1,113 @@
+#include <portcullis/bam/genome_mapper.hpp>
+
+#include <cctype>
+#include <cstdio>
+#include <fstream>
+#include <sstream>
+
+namespace portcullis {
+namespace bam {
+
+GenomeMapper::~GenomeMapper() {
+    if (fp) fclose(fp);
+}
+
+void GenomeMapper::buildFastaIndex() {
+    std::ifstream in(genomeFile.c_str(), std::ios::binary);
+    if (!in) throw BamException("Could not open genome file: " + genomeFile);
+    std::ofstream out(getFastaIndexFile().c_str());
+    std::string line, name;
+    int64_t off = 0, len = 0, seqOff = 0;
+    int32_t lb = 0, lw = 0;
+    auto flush = [&]() {
+        if (!name.empty()) out << name << "\t" << len << "\t" << seqOff << "\t" << lb << "\t" << lw << "\n";
+    };
+    while (std::getline(in, line)) {
+        const int64_t raw = (int64_t)line.size() + 1;
+        if (!line.empty() && line[0] == '>') {
+            flush();
+            std::stringstream ss(line.substr(1));
+            ss >> name;
+            len = 0;
+            lb = lw = 0;
+            seqOff = off + raw;
+        } else {
+            size_t n = line.size();
+            while (n && (line[n - 1] == '\r')) n--;
+            if (lb == 0 && n) {
+                lb = (int32_t)n;
+                lw = (int32_t)raw;
+            }
+            len += (int64_t)n;
+        }
+        off += raw;
+    }
+    flush();
+}
+
+void GenomeMapper::loadFastaIndex() {
+    std::ifstream in(getFastaIndexFile().c_str());
+    if (!in) throw BamException("Could not open genome index: " + getFastaIndexFile());
+    entries.clear();
+    byName.clear();
+    std::string line;
+    while (std::getline(in, line)) {
+        if (line.empty()) continue;
+        std::stringstream ss(line);
+        Entry e;
+        std::string f;
+        std::getline(ss, e.name, '\t');
+        ss >> e.len >> e.offset >> e.line_blen >> e.line_len;
+        if (!ss) throw BamException("Malformed line in " + getFastaIndexFile() + ": " + line);
+        byName[e.name] = entries.size();
+        entries.push_back(e);
+    }
+    if (fp) fclose(fp);
+    fp = fopen(genomeFile.c_str(), "rb");
+    if (!fp) throw BamException("Could not open genome file: " + genomeFile);
+}
+
+int64_t GenomeMapper::getSeqLength(const std::string& name) const {
+    auto it = byName.find(name);
+    return it == byName.end() ? -1 : entries[it->second].len;
+}
+
+// read `count` graphic characters starting at base `beg` of the sequence
+std::string GenomeMapper::readSpan(const Entry& e, int64_t beg, int64_t count) const {
+    std::string out;
+    if (count <= 0 || e.line_blen <= 0) return out;
+    out.reserve((size_t)count);
+    const int64_t start = e.offset + beg / e.line_blen * e.line_len + beg % e.line_blen;
+    if (fseeko(fp, (off_t)start, SEEK_SET) != 0) throw BamException("Seek failed in genome file");
+    // upper bound of bytes to read: bases plus line terminators
+    const int64_t lines = count / e.line_blen + 2;
+    const int64_t maxBytes = count + lines * (e.line_len - e.line_blen) + 2;
+    std::string buf((size_t)maxBytes, 0);
+    const size_t got = fread(&buf[0], 1, (size_t)maxBytes, fp);
+    for (size_t i = 0; i < got && (int64_t)out.size() < count; i++)
+        if (isgraph((unsigned char)buf[i])) out.push_back(buf[i]);
+    return out;
+}
+
+std::string GenomeMapper::fetchBases(const char* name, int start, int end) const {
+    auto it = byName.find(name);
+    if (it == byName.end()) return std::string();
+    const Entry& e = entries[it->second];
+    int64_t b = start, x = end;
+    if (x < b) b = x;
+    if (b < 0) b = 0;
+    else if (e.len <= b) b = e.len - 1;
+    if (x < 0) x = 0;
+    else if (e.len <= x) x = e.len - 1;
+    return readSpan(e, b, x - b + 1);
+}
+
+std::string GenomeMapper::fetchContig(const std::string& name) const {
+    auto it = byName.find(name);
+    if (it == byName.end()) throw BamException("The sequence \"" + name + "\" not found in " + genomeFile);
+    const Entry& e = entries[it->second];
+    return readSpan(e, 0, e.len);
+}
+
+}  // namespace bam
+}  // namespace portcullis

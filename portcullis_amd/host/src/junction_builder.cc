@@ -1,0 +1,322 @@
+// JunctionBuilder: orchestration of the junc stage on top of the device path.
+// Flow and console output follow src/junction_builder.cc:84-291 of the reference.
+#include <portcullis/junction_builder.hpp>
+
+#include <chrono>
+#include <condition_variable>
+#include <cstdlib>
+#include <cstring>
+#include <iomanip>
+#include <iostream>
+#include <mutex>
+#include <queue>
+#include <sys/stat.h>
+#include <thread>
+
+#include "../../../include/portcullis_amd.h"
+
+namespace portcullis {
+
+using bam::BamReader;
+using bam::GenomeMapper;
+using std::cerr;
+using std::cout;
+using std::endl;
+
+static bool pathExists(const std::string& p) {
+    struct stat st;
+    return stat(p.c_str(), &st) == 0;
+}
+
+static bool makeDirs(const std::string& p) {
+    if (p.empty() || pathExists(p)) return true;
+    const size_t slash = p.find_last_of('/');
+    if (slash != std::string::npos && slash > 0 && !makeDirs(p.substr(0, slash))) return false;
+    return mkdir(p.c_str(), 0777) == 0 || pathExists(p);
+}
+
+namespace {
+struct WallTimer {  // prints like boost::timer::auto_cpu_timer(1, " = Wall time taken: %ws\n\n")
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    ~WallTimer() {
+        const double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        std::ios::fmtflags f(cout.flags());
+        cout << " = Wall time taken: " << std::fixed << std::setprecision(1) << s << "s" << endl << endl;
+        cout.flags(f);
+    }
+};
+}  // namespace
+
+JunctionBuilder::JunctionBuilder(const std::string& prepDir, const std::string& output) {
+    prepData = PreparedFiles(prepDir);
+    if (output.empty()) {
+        outputDir = ".";
+        outputPrefix = "portcullis";
+    } else {
+        const size_t slash = output.find_last_of('/');
+        outputDir = slash == std::string::npos ? "" : output.substr(0, slash);
+        outputPrefix = slash == std::string::npos ? output : output.substr(slash + 1);
+        if (slash == 0) outputDir = "/";
+    }
+    if (const char* e = getenv("PORTCULLIS_GPUS")) devices = atoi(e);
+    if (const char* e = getenv("PJB_TEST_BATCH")) setBatchRecords((size_t)atol(e));
+}
+
+void JunctionBuilder::process() {
+    const std::string outDir = outputDir.empty() ? "." : outputDir;
+    if (!pathExists(outDir) && !makeDirs(outDir))
+        throw JunctionBuilderException("Could not create output directory at: " + outDir);
+    if (!pathExists(prepData.getSortedBamFilePath()))
+        throw JunctionBuilderException("Could not find prepared BAM file at: " + prepData.getSortedBamFilePath());
+    try {
+        prepData.valid(useCsi);
+    } catch (const PrepareException& e) {
+        throw JunctionBuilderException(std::string("Prepared data is not complete: ") + prepData.getPrepDir() + " (" + e.what() + ")");
+    }
+    BamReader reader(prepData.getSortedBamFilePath());
+    reader.open(useCsi);
+    refs = reader.createRefList();
+    refMap = reader.createRefMap(*refs);
+    reader.close();
+    junctionSystem = JunctionSystem();
+    junctionSystem.setRefs(refs);
+    if (refs->size() < threads) {
+        cerr << "Warning: User requested " << threads << " threads but there are only " << refs->size()
+             << " target sequences to process.  Setting number of threads to " << refs->size() << "." << endl << endl;
+        threads = (uint16_t)refs->size();
+    }
+    if (extra || separate)
+        throw JunctionBuilderException("--separate / --extra (coverage, flanking alignments, multiple mapping score) are not "
+                                       "implemented by the MI355X junc path; run without them");
+    cout << "Settings:" << endl
+         << std::boolalpha << " - BAM Strandedness: " << bam::strandednessToString(strandSpecific) << endl
+         << " - BAM Read Orientation: " << bam::orientationToString(orientation) << endl
+         << " - BAM Indexing mode: " << (useCsi ? "CSI" : "BAI") << endl
+         << " - Threads: " << threads << endl
+         << " - Separate BAMs: " << separate << endl
+         << endl;
+    cout << reader.bamDetails() << endl;
+    findJunctions();
+    cout << "Saving junctions: " << endl;
+    {
+        WallTimer t;
+        junctionSystem.saveAll(outDir + "/" + outputPrefix, source, false, outputExonGFF, outputIntronGFF);
+    }
+    std::pair<bam::Orientation, bam::Strandedness> actual = junctionSystem.determineStrandedness(true);
+    cout << "Determined sequence orientation to be: " << bam::orientationToLongString(actual.first) << endl;
+    cout << "Determined RNAseq strandedness to be: " << bam::strandednessToLongString(actual.second) << endl << endl;
+    if (strandSpecific != bam::Strandedness::UNKNOWN && strandSpecific != actual.second)
+        cerr << "Warning!  User input and portcullis disagree about the strandedness of the dataset" << endl << endl;
+}
+
+static void pjbCheck(pjb_ctx* c, int rc, const char* what) {
+    if (rc != PJB_OK) throw JunctionBuilderException(std::string(what) + ": " + pjb_last_error(c) + " (code " + std::to_string(rc) + ")");
+}
+
+// One target sequence: FASTA -> HBM, BAM records -> SoA batches -> HBM, device pipeline, rows back.
+void JunctionBuilder::findJuncs(void* deviceContext, BamReader& reader, GenomeMapper& gmap, int32_t seq) {
+    pjb_ctx* ctx = (pjb_ctx*)deviceContext;
+    RegionResult& res = results[(size_t)seq];
+    if (!reader.hasAlignments(seq)) return;  // nothing placed on this target: counters keep their neutral values
+    reader.setRegion(seq);
+    bam::ReadBatch batch;
+    bool uploaded = false;
+    bool any = false;
+    while (true) {
+        batch.clear();
+        batch.reserve(batchRecords);
+        if (!reader.nextBatch(batch, batchRecords)) break;
+        any = true;
+        if (!uploaded) {
+            const std::string contig = gmap.fetchContig(refs->at((size_t)seq)->name);
+            if ((int64_t)contig.size() != refs->at((size_t)seq)->length)
+                throw JunctionBuilderException("Genome sequence " + refs->at((size_t)seq)->name + " has " +
+                                               std::to_string(contig.size()) + " bases but the BAM header says " +
+                                               std::to_string(refs->at((size_t)seq)->length));
+            pjbCheck(ctx, pjb_upload_contig(ctx, seq, (const uint8_t*)contig.data(), (int64_t)contig.size()), "pjb_upload_contig");
+            uploaded = true;
+        }
+        pjb_batch pb;
+        batch.view(pb);
+        pjbCheck(ctx, pjb_submit_batch(ctx, seq, &pb), "pjb_submit_batch");
+    }
+    if (!any) return;
+    pjb_region_result rr;
+    pjbCheck(ctx, pjb_finish_contig(ctx, seq, &rr), "pjb_finish_contig");
+    const pjb_junction_row* rows = nullptr;
+    int64_t n = 0;
+    pjbCheck(ctx, pjb_collect(ctx, &rows, &n), "pjb_collect");
+    res.js.appendRows(rows, (size_t)n);
+    pjbCheck(ctx, pjb_clear_rows(ctx), "pjb_clear_rows");
+    pjbCheck(ctx, pjb_release_contig(ctx, seq), "pjb_release_contig");
+    res.splicedCount = rr.spliced;
+    res.unsplicedCount = rr.unspliced;
+    res.sumQueryLengths = rr.sum_len;
+    res.minQueryLength = rr.min_len;
+    res.maxQueryLength = rr.max_len;
+}
+
+void JunctionBuilder::findJunctions() {
+    WallTimer timer;
+    results.clear();
+    results.resize(refs->size());
+    const int visible = pjb_device_count();
+    if (visible <= 0)
+        throw JunctionBuilderException("No MI355X (HIP device) is visible: the junc hot path runs on the GPU and has no CPU fallback");
+    int ndev = devices > 0 ? std::min(devices, visible) : visible;
+    const int nthreads = std::max<int>(1, threads);
+    ndev = std::min(ndev, nthreads);
+    cout << "Creating " << nthreads << " threads, each with BAM and genome indicies loaded, on " << ndev << " GPU(s) ...";
+    cout.flush();
+    std::vector<int32_t> order;  // longest targets first: better balance across workers
+    for (size_t i = 0; i < refs->size(); i++) {
+        results[i].js.setRefs(refs);
+        results[i].name = refs->at(i)->name;
+        order.push_back((int32_t)i);
+    }
+    std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return refs->at((size_t)a)->length > refs->at((size_t)b)->length; });
+    std::mutex mu;
+    size_t nextTask = 0;
+    std::string firstError;
+    std::vector<int32_t> lens;
+    for (auto& r : *refs) lens.push_back(r->length);
+    auto worker = [&](int w) {
+        pjb_ctx* ctx = nullptr;
+        try {
+            pjb_config cfg;
+            memset(&cfg, 0, sizeof cfg);
+            cfg.abi_version = PJB_ABI_VERSION;
+            cfg.device = w % ndev;
+            cfg.orientation = (int32_t)orientation;
+            cfg.strandedness = (int32_t)strandSpecific;
+            int rc = pjb_create(&ctx, &cfg);
+            if (rc != PJB_OK) throw JunctionBuilderException(std::string("pjb_create: ") + pjb_last_error(nullptr));
+            pjbCheck(ctx, pjb_set_refs(ctx, (int32_t)lens.size(), lens.data()), "pjb_set_refs");
+            GenomeMapper gmap(prepData.getGenomeFilePath());
+            gmap.loadFastaIndex();
+            BamReader reader(prepData.getSortedBamFilePath());
+            reader.open(useCsi);
+            while (true) {
+                int32_t tid;
+                {
+                    std::lock_guard<std::mutex> lk(mu);
+                    if (nextTask >= order.size() || !firstError.empty()) break;
+                    tid = order[nextTask++];
+                }
+                findJuncs(ctx, reader, gmap, tid);
+            }
+        } catch (const std::exception& e) {
+            std::lock_guard<std::mutex> lk(mu);
+            if (firstError.empty()) firstError = e.what();
+        }
+        if (ctx) pjb_destroy(ctx);
+    };
+    cout << " done." << endl;
+    cout << "Finding junctions and calculating basic metrics:" << endl;
+    cout << " - Queueing " << refs->size() << " target sequences for processing in the thread pool" << endl;
+    cout << " - Processing: " << endl;
+    std::vector<std::thread> pool;
+    for (int w = 0; w < nthreads; w++) pool.emplace_back(worker, w);
+    for (auto& t : pool) t.join();
+    if (!firstError.empty()) throw JunctionBuilderException(firstError);
+    cout << " - All threads completed." << endl << " - Combining results from threads." << endl << endl;
+    uint64_t unsplicedCount = 0, splicedCount = 0, sumQueryLengths = 0;
+    int32_t minQueryLength = INT32_MAX, maxQueryLength = 0;
+    cout << std::left << std::setw(12) << "Sequence"
+         << "\t" << std::right << std::setw(12) << "unspliced"
+         << "\t" << std::right << std::setw(12) << "spliced"
+         << "\t" << std::right << std::setw(12) << "total" << endl;
+    for (auto& res : results) {
+        junctionSystem.append(res.js);
+        unsplicedCount += res.unsplicedCount;
+        splicedCount += res.splicedCount;
+        sumQueryLengths += res.sumQueryLengths;
+        minQueryLength = std::min(minQueryLength, res.minQueryLength);
+        maxQueryLength = std::max(maxQueryLength, res.maxQueryLength);
+        cout << std::left << std::setw(12) << res.name << "\t" << std::right << std::setw(12) << res.unsplicedCount << "\t"
+             << std::right << std::setw(12) << res.splicedCount << "\t" << std::right << std::setw(12)
+             << res.splicedCount + res.unsplicedCount << endl;
+    }
+    cout << endl << "Sorting and reindexing merged junctions...";
+    cout.flush();
+    junctionSystem.sort();
+    junctionSystem.index();
+    cout << " done." << endl << endl;
+    const uint64_t totalAlignments = splicedCount + unsplicedCount;
+    const double meanQueryLength = (double)sumQueryLengths / (double)totalAlignments;
+    junctionSystem.setQueryLengthStats(minQueryLength, meanQueryLength, maxQueryLength);
+    cout << "Final stats:" << endl
+         << " - Processed " << totalAlignments << " alignments." << endl
+         << " - Alignment query length statistics: min: " << minQueryLength << "; mean: " << meanQueryLength
+         << "; max: " << maxQueryLength << ";" << endl
+         << " - Found " << junctionSystem.size() << " junctions from " << splicedCount << " spliced alignments." << endl
+         << " - Found " << unsplicedCount << " unspliced alignments." << endl;
+    if (junctionSystem.size() > 1) {
+        cout << " - Calculating junctions stats that require comparisons with other junctions...";
+        cout.flush();
+        junctionSystem.calcJunctionStats();
+        cout << " done." << endl;
+    }
+}
+
+// command line of `portcullis junc` (src/junction_builder.cc:359-454); a small hand-rolled parser
+// replaces boost::program_options.
+int JunctionBuilder::main(int argc, char* argv[]) {
+    std::string prepDir, output = DEFAULT_JUNC_OUTPUT, source = DEFAULT_JUNC_SOURCE, ori = "UNKNOWN", strand = "UNKNOWN";
+    int threads = DEFAULT_JUNC_THREADS, devices = 0;
+    bool extra = false, separate = false, useCsi = false, exonGff = false, intronGff = false, verbose = false, help = false;
+    auto need = [&](int& i) -> std::string {
+        if (i + 1 >= argc) throw JunctionBuilderException(std::string("Missing value for option ") + argv[i]);
+        return argv[++i];
+    };
+    for (int i = 1; i < argc; i++) {
+        const std::string a = argv[i];
+        if (a == "-o" || a == "--output") output = need(i);
+        else if (a == "-t" || a == "--threads") threads = atoi(need(i).c_str());
+        else if (a == "--orientation") ori = need(i);
+        else if (a == "--strandedness") strand = need(i);
+        else if (a == "--source") source = need(i);
+        else if (a == "--devices") devices = atoi(need(i).c_str());
+        else if (a == "--separate") separate = true;
+        else if (a == "--extra") extra = true;
+        else if (a == "-c" || a == "--use_csi") useCsi = true;
+        else if (a == "--exon_gff") exonGff = true;
+        else if (a == "--intron_gff") intronGff = true;
+        else if (a == "-v" || a == "--verbose") verbose = true;
+        else if (a == "--help" || a == "-h") help = true;
+        else if (!a.empty() && a[0] == '-') throw JunctionBuilderException("Unknown option: " + a);
+        else prepDir = a;
+    }
+    if (help || prepDir.empty()) {
+        cout << title() << endl << endl << description() << endl << endl << "Usage: " << usage() << endl
+             << "  -o, --output <prefix>      Output prefix for files generated by this program (default " << DEFAULT_JUNC_OUTPUT << ")" << endl
+             << "  -t, --threads <n>          Host decode threads; one target sequence per thread at a time" << endl
+             << "      --orientation <o>      SE, FR, RF, FF or UNKNOWN" << endl
+             << "      --strandedness <s>     unstranded, firststrand, secondstrand or UNKNOWN" << endl
+             << "      --source <name>        Source column of the BED/GFF output (default portcullis)" << endl
+             << "      --exon_gff             Also write <prefix>.junctions.exon.gff3" << endl
+             << "      --intron_gff           Also write <prefix>.junctions.intron.gff3" << endl
+             << "  -c, --use_csi              Use a CSI index (not supported yet)" << endl
+             << "      --devices <n>          Number of GPUs to use (default: all visible)" << endl
+             << "  -v, --verbose" << endl;
+        return help ? 0 : 1;
+    }
+    WallTimer timer;
+    cout << "Running portcullis in junction builder mode" << endl << "------------------------------------------" << endl << endl;
+    JunctionBuilder jb(prepDir, output);
+    jb.setThreads((uint16_t)std::max(1, threads));
+    jb.setExtra(extra);
+    jb.setSeparate(separate);
+    jb.setSource(source);
+    jb.setUseCsi(useCsi);
+    jb.setOutputExonGFF(exonGff);
+    jb.setOutputIntronGFF(intronGff);
+    jb.setVerbose(verbose);
+    jb.setOrientation(bam::orientationFromString(ori));
+    jb.setStrandSpecific(bam::strandednessFromString(strand));
+    if (devices > 0) jb.setDevices(devices);
+    jb.process();
+    return 0;
+}
+
+}  // namespace portcullis

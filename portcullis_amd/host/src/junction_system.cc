@@ -1,0 +1,277 @@
+// JunctionSystem: merge, sort/index, calcJunctionStats, strandedness report, writers, loader.
+// Behaviour follows lib/src/junction_system.cc of the reference (line numbers in comments).
+#include <portcullis/junction_system.hpp>
+
+#include <algorithm>
+#include <cmath>
+#include <fstream>
+#include <iostream>
+#include <sys/stat.h>
+
+#include "../../../include/portcullis_amd.h"
+
+namespace portcullis {
+
+std::string JunctionSystem::version = "";
+
+// junction_system.cc:55-70: chain of consecutive junctions sharing a donor or acceptor with the
+// previous member; returns the index of the last member
+size_t JunctionSystem::createJunctionGroup(size_t index, std::vector<JunctionPtr>& group) {
+    JunctionPtr cur = junctionList[index];
+    group.push_back(cur);
+    for (size_t j = index + 1; j < junctionList.size(); j++) {
+        JunctionPtr next = junctionList[j];
+        if (!cur->sharesDonorOrAcceptor(next)) return j - 1;
+        group.push_back(next);
+        cur = next;
+    }
+    return junctionList.size() - 1;
+}
+
+void JunctionSystem::findJunctions(int32_t refId, JunctionList& subset) {
+    subset.clear();
+    for (const JunctionPtr& j : junctionList)
+        if (j->getIntron()->ref.index == refId) subset.push_back(j);
+}
+
+void JunctionSystem::addJunction(JunctionPtr j) {
+    distinctJunctions[*(j->getIntron())] = j;
+    junctionList.push_back(j);
+}
+
+void JunctionSystem::append(JunctionSystem& other) {
+    for (const auto& j : other.getJunctions()) addJunction(j);
+}
+
+void JunctionSystem::appendRows(const pjb_junction_row* rows, size_t n) {
+    if (!refs) throw JunctionException("JunctionSystem::appendRows: reference sequence list is not set");
+    junctionList.reserve(junctionList.size() + n);
+    for (size_t i = 0; i < n; i++) addJunction(Junction::fromRow(rows[i], *refs));
+}
+
+JunctionPtr JunctionSystem::getJunction(const Intron& intron) const {
+    auto it = distinctJunctions.find(intron);
+    return it == distinctJunctions.end() ? nullptr : it->second;
+}
+
+// junction_system.cc:250-320
+void JunctionSystem::calcJunctionStats() {
+    if (junctionList.empty()) return;
+    const size_t n = junctionList.size();
+    for (size_t i = 0; i < n; i++) {
+        std::vector<JunctionPtr> group;
+        i = createJunctionGroup(i, group);
+        uint32_t maxReads = 0;
+        size_t maxIndex = 0;
+        const bool unique = group.size() == 1;
+        for (size_t k = 0; k < group.size(); k++) {
+            if (maxReads < group[k]->getNbSplicedAlignments()) {
+                maxReads = group[k]->getNbSplicedAlignments();
+                maxIndex = k;
+            }
+            group[k]->setUniqueJunction(unique);
+        }
+        group[maxIndex]->setPrimaryJunction(true);
+    }
+    // distances to the neighbouring junctions; -1 (stored in a uint32_t) marks "none on this contig"
+    size_t i = 0;
+    bool lastdiffseq = false;
+    while (i + 1 < n) {
+        JunctionPtr first = junctionList[i], second = junctionList[i + 1];
+        int32_t diff = second->getIntron()->start - first->getIntron()->end;
+        diff = diff < 0 ? 0 : diff;
+        if (first->getIntron()->ref.index != second->getIntron()->ref.index) {
+            first->setDistanceToNextUpstreamJunction((uint32_t)-1);
+            second->setDistanceToNextDownstreamJunction((uint32_t)-1);
+            if (i == 0 || lastdiffseq) first->setDistanceToNextDownstreamJunction((uint32_t)-1);
+            if (i == n - 2) second->setDistanceToNextUpstreamJunction((uint32_t)-1);
+            lastdiffseq = true;
+        } else if (i == 0) {
+            first->setDistanceToNextDownstreamJunction((uint32_t)-1);
+            first->setDistanceToNextUpstreamJunction((uint32_t)diff);
+            second->setDistanceToNextDownstreamJunction((uint32_t)diff);
+            lastdiffseq = false;
+        } else if (i == n - 2) {
+            first->setDistanceToNextUpstreamJunction((uint32_t)diff);
+            second->setDistanceToNextDownstreamJunction((uint32_t)diff);
+            second->setDistanceToNextUpstreamJunction((uint32_t)-1);
+            lastdiffseq = false;
+        } else {
+            first->setDistanceToNextUpstreamJunction((uint32_t)diff);
+            second->setDistanceToNextDownstreamJunction((uint32_t)diff);
+            lastdiffseq = false;
+        }
+        i++;
+    }
+    for (auto& junc : junctionList) {
+        const int32_t down = (int32_t)junc->getDistanceToNextDownstreamJunction();
+        const int32_t up = (int32_t)junc->getDistanceToNextUpstreamJunction();
+        junc->setDistanceToNearestJunction((uint32_t)((down == -1 || up == -1) ? std::max(down, up) : std::min(down, up)));
+        junc->setMeanReadLength((uint32_t)this->meanQueryLength);
+        if (junc->isSuspicious()) {
+            const double prob = 1.0 - std::pow((junc->getMaxMMES() / (this->meanQueryLength / 2.0)), junc->getNbSplicedAlignments());
+            if (prob > 0.99) junc->setPotentialFalsePositive(true);
+        }
+    }
+}
+
+void JunctionSystem::sort() { std::sort(junctionList.begin(), junctionList.end(), JunctionComparator()); }
+
+void JunctionSystem::index() {
+    for (size_t i = 0; i < this->size() && i < junctionList.size(); i++) junctionList[i]->setId((uint32_t)i);
+}
+
+// junction_system.cc:455-560 (stdout report + inferred protocol)
+std::pair<Orientation, Strandedness> JunctionSystem::determineStrandedness(bool verbose) const {
+    uint32_t r1p_p = 0, r1n_p = 0, r2p_p = 0, r2n_p = 0, r1p_n = 0, r1n_n = 0, r2p_n = 0, r2n_n = 0;
+    for (const JunctionPtr& j : junctionList) {
+        if (j->getSpliceSiteStrand() == Strand::POSITIVE) {
+            r1p_p += j->getNbR1PosAlignments();
+            r1n_p += j->getNbR1NegAlignments();
+            r2p_p += j->getNbR2PosAlignments();
+            r2n_p += j->getNbR2NegAlignments();
+        } else if (j->getSpliceSiteStrand() == Strand::NEGATIVE) {
+            r1p_n += j->getNbR1PosAlignments();
+            r1n_n += j->getNbR1NegAlignments();
+            r2p_n += j->getNbR2PosAlignments();
+            r2n_n += j->getNbR2NegAlignments();
+        }
+    }
+    const double posr1 = ((double)((int32_t)r1p_p - (int32_t)r1n_p)) / ((double)(r1p_p + r1n_p));
+    const double negr1 = ((double)((int32_t)r1n_n - (int32_t)r1p_n)) / ((double)(r1p_n + r1n_n));
+    const double posr2 = ((double)((int32_t)r2p_p - (int32_t)r2n_p)) / ((double)(r2p_p + r2n_p));
+    const double negr2 = ((double)((int32_t)r2n_n - (int32_t)r2p_n)) / ((double)(r2p_n + r2n_n));
+    const uint32_t totalr1 = r1p_p + r1n_p + r1p_n + r1n_n;
+    const uint32_t totalr2 = r2p_p + r2n_p + r2p_n + r2n_n;
+    if (verbose) {
+        using std::cout;
+        using std::endl;
+        cout << "Strand Analysis" << endl << "---------------" << endl << endl;
+        cout << "Total Alignments:" << endl << " - R1:" << totalr1 << endl << " - R2:" << totalr2 << endl;
+        cout << "Alignment counts when splice site suggests +ve strand:" << endl
+             << " - R1+: " << r1p_p << endl << " - R1-: " << r1n_p << endl << " - R2+: " << r2p_p << endl << " - R2-: " << r2n_p << endl
+             << "Alignment counts when splice site suggests -ve strand:" << endl
+             << " - R1+: " << r1p_n << endl << " - R1-: " << r1n_n << endl << " - R2+: " << r2p_n << endl << " - R2-: " << r2n_n << endl;
+        cout << "Correlation of read strand to splice site strand (1.0 = complete agreement, -1.0 = complete disagreement):" << endl
+             << " - R1+: " << posr1 << endl << " - R1-: " << negr1 << endl << " - R2+: " << posr2 << endl << " - R2-: " << negr2 << endl << endl;
+    }
+    Strandedness s = Strandedness::UNKNOWN;
+    Orientation o = Orientation::UNKNOWN;
+    if (totalr1 == 0 && totalr2 == 0) {
+    } else if (totalr2 == 0) {
+        o = Orientation::SE;
+        if (posr1 > 0.5 && negr1 > 0.5) s = Strandedness::SECONDSTRAND;
+        else if (posr1 < -0.5 && negr1 < -0.5) s = Strandedness::FIRSTSTRAND;
+    } else {
+        o = Orientation::FR;
+        if (posr1 > 0.5 && negr1 > 0.5 && posr2 < -0.5 && negr2 < -0.5) s = Strandedness::SECONDSTRAND;
+        else if (posr1 < -0.5 && negr1 < -0.5 && posr2 > 0.5 && negr2 > 0.5) s = Strandedness::FIRSTSTRAND;
+        else if (posr1 > 0.5 && negr1 > 0.5 && posr2 > 0.5 && negr2 > 0.5) {
+            s = Strandedness::SECONDSTRAND;
+            o = Orientation::FF;
+        } else if (posr1 < -0.5 && negr1 < -0.5 && posr2 < -0.5 && negr2 < -0.5) {
+            s = Strandedness::FIRSTSTRAND;
+            o = Orientation::FF;
+        }
+    }
+    if (std::fabs(posr1) <= 0.5 && std::fabs(negr1) <= 0.5 && std::fabs(posr2) <= 0.5 && std::fabs(negr2) <= 0.5)
+        s = Strandedness::UNSTRANDED;
+    return std::make_pair(o, s);
+}
+
+void JunctionSystem::saveAll(const std::string& outputPrefix, const std::string& source) {
+    saveAll(outputPrefix, source, false, false, false);
+}
+
+// junction_system.cc:336-383
+void JunctionSystem::saveAll(const std::string& outputPrefix, const std::string& source, bool bedscore, bool outputExonGFF,
+                             bool outputIntronGFF) {
+    using std::cout;
+    using std::endl;
+    const std::string tabPath = outputPrefix + ".junctions.tab";
+    const std::string exonGffPath = outputPrefix + ".junctions.exon.gff3";
+    const std::string intronGffPath = outputPrefix + ".junctions.intron.gff3";
+    const std::string bedPath = outputPrefix + ".junctions.bed";
+    cout << " - Saving junction table to: " << tabPath << " ... ";
+    cout.flush();
+    {
+        std::ofstream f(tabPath.c_str());
+        f << (*this) << endl;  // header, rows, and one more empty line
+    }
+    cout << "done." << endl;
+    if (outputExonGFF) {
+        cout << " - Saving junction GFF file to: " << exonGffPath << " ... ";
+        cout.flush();
+        std::ofstream f(exonGffPath.c_str());
+        writeExonGFF(f, source);
+        cout << "done." << endl;
+    }
+    if (outputIntronGFF) {
+        cout << " - Saving intron GFF file to: " << intronGffPath << " ... ";
+        cout.flush();
+        std::ofstream f(intronGffPath.c_str());
+        writeIntronGFF(f, source);
+        cout << "done." << endl;
+    }
+    cout << " - Saving BED file with all junctions to: " << bedPath << " ... ";
+    cout.flush();
+    outputBED(bedPath, CanonicalSS::ALL, source, bedscore);
+    cout << "done." << endl;
+}
+
+void JunctionSystem::outputDescription(std::ostream& strm) {
+    for (const JunctionPtr& j : junctionList) {
+        strm << "Junction " << j->getId() << ":" << std::endl;
+        j->outputDescription(strm);
+        strm << std::endl;
+    }
+}
+
+std::ostream& operator<<(std::ostream& strm, const JunctionSystem& js) {
+    strm << Junction::junctionOutputHeader() << std::endl;
+    for (const auto& j : js.junctionList) strm << *j << std::endl;
+    return strm;
+}
+
+void JunctionSystem::writeExonGFF(std::ostream& strm, const std::string& source) {
+    for (const JunctionPtr& j : junctionList) j->outputJunctionGFF(strm, source);
+}
+
+void JunctionSystem::writeIntronGFF(std::ostream& strm, const std::string& source) {
+    for (const JunctionPtr& j : junctionList) j->outputIntronGFF(strm, source);
+}
+
+void JunctionSystem::outputBED(const std::string& path, CanonicalSS type, const std::string& prefix, bool bedscore) {
+    std::ofstream f(path.c_str());
+    outputBED(f, type, prefix, bedscore);
+}
+
+void JunctionSystem::outputBED(std::ostream& strm, CanonicalSS type, const std::string& prefix, bool bedscore) {
+    strm << "track name=\"junctions\" description=\"Portcullis V" << (version.empty() ? "X.X.X" : version) << " junctions\""
+         << std::endl;
+    for (const JunctionPtr& j : junctionList)
+        if (type == CanonicalSS::ALL || j->getSpliceSiteType() == type) j->outputBED(strm, prefix, bedscore);
+}
+
+// junction_system.cc:424-444: skips empty lines and any line containing "index"
+void JunctionSystem::load(const std::string& junctionTabFile, bool simple) {
+    struct stat st;
+    if (stat(junctionTabFile.c_str(), &st) != 0)
+        throw JunctionException("Could not find Portcullis junction tab file at: " + junctionTabFile);
+    std::ifstream ifs(junctionTabFile.c_str());
+    std::string line;
+    while (std::getline(ifs, line)) {
+        // boost::trim
+        size_t a = 0, b = line.size();
+        while (a < b && isspace((unsigned char)line[a])) a++;
+        while (b > a && isspace((unsigned char)line[b - 1])) b--;
+        line = line.substr(a, b - a);
+        if (!line.empty() && line.find("index") == std::string::npos) {
+            JunctionPtr j = Junction::parse(line);
+            junctionList.push_back(j);
+            if (!simple) distinctJunctions[*(j->getIntron())] = j;
+        }
+    }
+}
+
+}  // namespace portcullis

@@ -1,0 +1,31 @@
+// portcullis_amd: command line entry.  Only the `junc` mode exists here; prep / filt / bamfilt
+// remain the reference's programs and interoperate through the prep directory and the .tab file.
+#include <portcullis/junction_builder.hpp>
+
+#include <cstring>
+#include <iostream>
+
+#ifndef PORTCULLIS_AMD_VERSION
+#define PORTCULLIS_AMD_VERSION "1.2.4"
+#endif
+
+int main(int argc, char* argv[]) {
+    // exit codes as in src/portcullis.cc:497-515 of the reference
+    try {
+        if (argc < 2 || strcmp(argv[1], "junc") != 0) {
+            std::cerr << "Usage: portcullis_amd junc [options] <prep_data_dir>" << std::endl;
+            return 1;
+        }
+        portcullis::JunctionSystem::version = PORTCULLIS_AMD_VERSION;
+        return portcullis::JunctionBuilder::main(argc - 1, argv + 1);
+    } catch (const portcullis::PortcullisException& e) {
+        std::cerr << "Error: " << e.what() << std::endl;
+        return 4;
+    } catch (const std::exception& e) {
+        std::cerr << "Error: " << e.what() << std::endl;
+        return 5;
+    } catch (...) {
+        std::cerr << "Error: Exception of unknown type!" << std::endl;
+        return 7;
+    }
+}

@@ -1,0 +1,132 @@
+"""Drop-in check of the C++ host layer: a hand-made prep directory goes through the
+`portcullis_amd junc` program (own BGZF/BAM/BAI/FASTA readers -> C ABI -> HIP kernels ->
+JunctionSystem writers) and the .tab / .bed / .gff3 files must equal, byte for byte, what the CPU
+oracle writes for the same alignments (parsed by the independent Python BAM reader)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from fixtures_micro import micro1, micro2
+from fuzzgen import make_reads
+from util_bam import PREP_BAM, make_prep_dir, read_bam, records_to_batch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "portcullis_amd", "host", "portcullis_amd")
+
+
+@pytest.fixture(scope="module")
+def orc():
+    from oracle import oracle
+    return oracle
+
+
+def oracle_outputs(orc, prep, orientation, source="portcullis", version="1.2.4"):
+    from util_bam import read_fasta
+    refs, recs = read_bam(os.path.join(prep, PREP_BAM))
+    contigs = dict(read_fasta(os.path.join(prep, "portcullis.genome.fa")))
+    batches, genomes = {}, {}
+    for tid, (name, ln) in enumerate(refs):
+        rr = [r for r in recs if r["tid"] == tid and r["pos"] < ln]
+        if rr:
+            batches[tid] = records_to_batch(rr)
+        genomes[tid] = contigs[name]
+    rows, tot = orc.run_prep_like(refs, genomes, batches, orientation)
+    names = [n for n, _ in refs]
+    lens = [l for _, l in refs]
+    return dict(
+        tab=orc.write_tab(rows, names, lens), bed=orc.write_bed(rows, names, source, version),
+        intron=orc.write_intron_gff(rows, names, source), exon=orc.write_exon_gff(rows, names, source), rows=rows, tot=tot,
+    )
+
+
+def run_cli(prep, out_prefix, *opts):
+    assert os.path.exists(EXE), f"{EXE} missing: run __graft_entry__.build()"
+    cmd = [EXE, "junc", "-o", out_prefix, "--exon_gff", "--intron_gff", *opts, prep]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    return p
+
+
+def check(prep, tmp_path, orc, orientation="UNKNOWN", threads=1, extra_opts=()):
+    out = str(tmp_path / "out" / "pc")
+    p = run_cli(prep, out, "--orientation", orientation, "-t", str(threads), *extra_opts)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    exp = oracle_outputs(orc, prep, orientation)
+    for ext, key in ((".junctions.tab", "tab"), (".junctions.bed", "bed"), (".junctions.intron.gff3", "intron"),
+                     (".junctions.exon.gff3", "exon")):
+        got = open(out + ext, "rb").read()
+        if got != exp[key]:
+            gl, el = got.split(b"\n"), exp[key].split(b"\n")
+            for i, (a, b) in enumerate(zip(gl, el)):
+                if a != b:
+                    ga, ea = a.split(b"\t"), b.split(b"\t")
+                    diff = [(k, x, y) for k, (x, y) in enumerate(zip(ga, ea)) if x != y]
+                    raise AssertionError(f"{ext} line {i} differs at columns {diff[:6]}")
+            raise AssertionError(f"{ext}: line count {len(gl)} vs {len(el)}")
+    return p, exp
+
+
+def test_micro_fixtures_cli(tmp_path, orc, spombe30k):
+    name, genome = spombe30k
+    reads = micro1(genome) + micro2(genome)
+    reads.sort(key=lambda r: r["pos"])
+    for r in reads:
+        r["tid"] = 0
+        if r.get("mtid", -1) == 0:
+            r["mtid"] = 0
+    prep = make_prep_dir(str(tmp_path / "prep"), [(name, len(genome))], [(name, genome)], reads)
+    p, exp = check(prep, tmp_path, orc, "FR")
+    assert "Determined sequence orientation" in p.stdout
+    assert len(exp["rows"]) == 7
+
+
+def multi_contig(tmp_path, seeds, n_reads=1500, block_size=0xFF00):
+    refs, contigs, reads = [], [], []
+    for tid, seed in enumerate(seeds):
+        if seed is None:  # contig without alignments
+            g = "ACGT" * 500
+            refs.append((f"empty{tid}", len(g)))
+            contigs.append((f"empty{tid}", g))
+            continue
+        genome, rr = make_reads(seed, n_reads=n_reads, paired=True, glen=20000 + 1000 * tid)
+        for r in rr:
+            r["tid"] = tid
+            if r.get("mtid", -1) >= 0:
+                r["mtid"] = tid if r["mtid"] == 0 else (tid + 1) % len(seeds)
+        refs.append((f"chr{tid + 1}", len(genome)))
+        contigs.append((f"chr{tid + 1}", genome))
+        reads += rr
+    # unplaced unmapped reads at the end of the file are never visited
+    reads.append(dict(tid=-1, pos=-1, cigar="", seq="ACGTACGT", flag=4, mapq=0))
+    return make_prep_dir(str(tmp_path / "prep"), refs, contigs, reads, block_size=block_size)
+
+
+def test_multi_contig_single_thread(tmp_path, orc):
+    prep = multi_contig(tmp_path, [11, None, 12, 13])
+    check(prep, tmp_path, orc, "FR", threads=1)
+
+
+def test_multi_contig_threads_and_small_blocks(tmp_path, orc):
+    """records straddle BGZF blocks (tiny blocks), 3 decode threads, small device batches"""
+    prep = multi_contig(tmp_path, [21, 22, None, 23], block_size=997)
+    os.environ["PJB_TEST_BATCH"] = "257"
+    try:
+        check(prep, tmp_path, orc, "UNKNOWN", threads=3)
+    finally:
+        del os.environ["PJB_TEST_BATCH"]
+
+
+def test_missing_prep_dir(tmp_path):
+    p = run_cli(str(tmp_path / "nope"), str(tmp_path / "o" / "x"))
+    assert p.returncode == 4 and "Could not find prepared BAM file" in p.stderr
+
+
+def test_tab_roundtrip_loads(tmp_path, orc):
+    """The .tab we write parses with the reference's column contract (75 columns, header skipped)."""
+    prep = multi_contig(tmp_path, [31])
+    p, exp = check(prep, tmp_path, orc)
+    lines = exp["tab"].decode(errors="replace").split("\n")
+    assert lines[0].split("\t")[0] == "index" and all(len(l.split("\t")) == 75 for l in lines[:-2])
