@@ -58,6 +58,7 @@ def main():
     import torch
     import torch.distributed as dist
 
+    from portcullis_amd import distributed as pd
     from portcullis_amd import ffi, synth
 
     rank = int(os.environ.get("RANK", "0"))
@@ -92,17 +93,10 @@ def main():
         reg = ctx.finish_contig(0)
         rows = ctx.collect()
         if world > 1:
-            # merge the final junction table: all-gather of the POD rows (variable J per rank -> pad)
-            nj = torch.tensor([len(rows)], device=dev, dtype=torch.int64)
-            allj = [torch.zeros_like(nj) for _ in range(world)]
-            dist.all_gather(allj, nj)
-            jmax = int(max(int(x) for x in allj))
-            buf = torch.zeros((jmax, ffi.ROW_DTYPE.itemsize), dtype=torch.uint8, device=dev)
-            if len(rows):
-                buf[: len(rows)] = torch.from_numpy(rows.view(np.uint8).reshape(len(rows), -1)).to(dev)
-            out = [torch.empty_like(buf) for _ in range(world)]
-            dist.all_gather(out, buf)
-            state["merged"] = sum(int(x) for x in allj)
+            # the path's only exchange: read-length counters (all-reduce) and the merge of the
+            # per-rank junction tables (all-gather over RCCL)
+            state["totals"] = pd.allreduce_region(reg, dev)
+            state["merged"] = len(pd.allgather_rows(rows, dev))
         state["reg"] = reg
         state["rows"] = rows
 
