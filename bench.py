@@ -91,7 +91,7 @@ def main():
         ctx.clear_rows()
         ctx.submit_batch_device(0, batch, N)
         reg = ctx.finish_contig(0)
-        rows = ctx.collect()
+        rows = ctx.collect(copy=False)  # view of the pinned row table
         if world > 1:
             # the path's only exchange: read-length counters (all-reduce) and the merge of the
             # per-rank junction tables (all-gather over RCCL)
@@ -117,7 +117,7 @@ def main():
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    reg, rows = state["reg"], state["rows"]
+    reg, rows = state["reg"], state["rows"].copy()
     J = int(reg["n_junctions"])
     assert reg["n_pairs"] == P and reg["n_reads"] == N
     # size-independent sanity (full-size parity properties are in tests/test_gpu_fullsize.py)
@@ -189,6 +189,7 @@ def main():
             "kernels": [dict(name=k["name"], launches_per_step=k["launches"] / args.steps, avg_ms=round(k["avg_ms"], 4),
                              gbps=round(k["gbps"], 1) if k["gbps"] else None) for k in kern],
             "datagen_s": round(t_gen, 2),
+            "finish_contig_event_ms": round(timing["total_ms"], 4),
         }
         # pipeline_gbps: sum over kernels of (bytes per launch x launches per step) / device kernel time per step
         tot_bytes = sum((k["alg_bytes"] or 0) * k["launches"] / args.steps for k in kern)

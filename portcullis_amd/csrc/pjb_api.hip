@@ -27,7 +27,14 @@ struct Contig {
     bool owned = false;
     bool has_x = false;
     bool present = false;
+    u32 *codes = nullptr; // packed 4-bit codes (k0_encode); nullptr when the contig is "exotic"
 };
+
+void free_contig(Contig &g) {
+    if (g.owned && g.d) (void)hipFree(g.d);
+    if (g.codes) (void)hipFree(g.codes);
+    g = Contig();
+}
 
 struct OwnedBatch { // device copies made by pjb_submit_batch
     void *ptrs[11] = {nullptr};
@@ -46,7 +53,9 @@ struct pjb_ctx {
     int32_t open_tid = -1;
     std::vector<DevBatch> batches;
     std::vector<OwnedBatch> owned;
-    std::vector<pjb_junction_row> rows;
+    // junction rows live in a grow-only pinned host buffer so the D2H copy is a single DMA
+    pjb_junction_row *rows_pinned = nullptr;
+    size_t rows_n = 0, rows_cap = 0;
     pjb_timing timing;
     hipEvent_t ev[PJB_N_STAGES + 2];
     int radix_max_bits = 8;
@@ -276,8 +285,8 @@ void pjb_destroy(pjb_ctx *c) {
     (void)hipSetDevice(c->cfg.device);
     (void)hipStreamSynchronize(c->stream);
     close_contig(c);
-    for (auto &g : c->contigs)
-        if (g.owned && g.d) (void)hipFree(g.d);
+    for (auto &g : c->contigs) free_contig(g);
+    if (c->rows_pinned) (void)hipHostFree(c->rows_pinned);
     Buf *all[] = {&c->b_batches, &c->b_tile_cnt, &c->b_tile_stats, &c->b_cstats, &c->b_err, &c->b_total, &c->b_key[0],
                   &c->b_key[1], &c->b_idx[0], &c->b_idx[1], &c->b_g, &c->b_lstart, &c->b_rend, &c->b_pos, &c->b_aend,
                   &c->b_meta, &c->b_updown, &c->b_hist, &c->b_hist_scan, &c->b_scan_tiles, &c->b_jid, &c->b_seg,
@@ -296,8 +305,7 @@ int pjb_set_refs(pjb_ctx *c, int32_t n_refs, const int32_t *ref_len) {
     if (!c) return PJB_ERR_ARG;
     if (n_refs < 0 || (n_refs > 0 && !ref_len)) return fail(c, PJB_ERR_ARG, "pjb_set_refs: bad arguments");
     if (c->open_tid >= 0) return fail(c, PJB_ERR_STATE, "pjb_set_refs: contig %d is still open", c->open_tid);
-    for (auto &g : c->contigs)
-        if (g.owned && g.d) (void)hipFree(g.d);
+    for (auto &g : c->contigs) free_contig(g);
     c->ref_len.assign(ref_len, ref_len + n_refs);
     c->contigs.assign((size_t)n_refs, Contig());
     return PJB_OK;
@@ -315,14 +323,36 @@ static int upload_common(pjb_ctx *c, int32_t tid, uint8_t *d, int64_t len, bool 
     }
     int hx = 0;
     HIP_TRY(c, hipMemcpyAsync(&hx, c->b_hasx.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    // 4-bit codes for the word-parallel compare in k4 (after upper-casing)
+    u32 *codes = nullptr;
+    int exotic = 0;
+    const int64_t n_words = (len + 7) / 8;
+    if (len > 0) {
+        hipError_t e = hipMalloc((void **)&codes, (size_t)(n_words + 2) * 4);
+        if (e != hipSuccess) return fail(c, PJB_ERR_NOMEM, "hipMalloc(genome codes): %s", hipGetErrorString(e));
+        (void)hipMemsetAsync(c->b_hasx.p, 0, sizeof(int), c->stream);
+        (void)hipMemsetAsync(codes + n_words, 0, 8, c->stream);
+        hipLaunchKernelGGL(k0_encode, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, c->stream, (const uint8_t *)d, len,
+                           codes, n_words, (int *)c->b_hasx.p);
+        (void)hipMemcpyAsync(&exotic, c->b_hasx.p, sizeof(int), hipMemcpyDeviceToHost, c->stream);
+    }
+    hipError_t se = hipStreamSynchronize(c->stream);
+    if (se != hipSuccess) {
+        if (codes) (void)hipFree(codes);
+        return fail(c, PJB_ERR_HIP, "upload: %s", hipGetErrorString(se));
+    }
+    if (exotic && codes) {
+        (void)hipFree(codes);
+        codes = nullptr;
+    }
     Contig &g = c->contigs[(size_t)tid];
-    if (g.owned && g.d) (void)hipFree(g.d);
+    free_contig(g);
     g.d = d;
     g.len = len;
     g.owned = owned;
     g.has_x = hx != 0;
     g.present = true;
+    g.codes = codes;
     return PJB_OK;
 }
 
@@ -357,11 +387,8 @@ int pjb_release_contig(pjb_ctx *c, int32_t tid) {
     if (!c) return PJB_ERR_ARG;
     if (tid < 0 || (size_t)tid >= c->contigs.size()) return fail(c, PJB_ERR_ARG, "pjb_release_contig: bad tid %d", tid);
     Contig &g = c->contigs[(size_t)tid];
-    if (g.owned && g.d) {
-        (void)hipStreamSynchronize(c->stream);
-        (void)hipFree(g.d);
-    }
-    g = Contig();
+    (void)hipStreamSynchronize(c->stream);
+    free_contig(g);
     return PJB_OK;
 }
 
@@ -612,8 +639,8 @@ int pjb_finish_contig(pjb_ctx *c, int32_t tid, pjb_region_result *res) {
     // ---- K4: per-pair match statistics -> fragments
     LAUNCH(c, "k4_pairs", k4_pairs, dim3(pair_blocks), dim3(256), skey, sidx, (const u32 *)c->b_jid.p, pr, kf,
            (const DevBatch *)c->b_batches.p, (int)c->batches.size(), (const int32_t *)c->b_ancl.p,
-           (const int32_t *)c->b_ancr.p, (const uint8_t *)G.d, (int32_t)G.len, G.has_x ? 1 : 0, P, (u32 *)c->b_frag.p,
-           (int32_t *)c->b_fragj.p, d_err);
+           (const int32_t *)c->b_ancr.p, (const uint8_t *)G.d, (int32_t)G.len, G.has_x ? 1 : 0,
+           (const u32 *)(G.has_x ? nullptr : G.codes), P, (u32 *)c->b_frag.p, (int32_t *)c->b_fragj.p, d_err);
     HIP_TRY(c, hipEventRecord(c->ev[5], st));
 
     // ---- K5: fragments -> junctions -> rows
@@ -626,16 +653,23 @@ int pjb_finish_contig(pjb_ctx *c, int32_t tid, pjb_region_result *res) {
     HIP_TRY(c, hipEventRecord(c->ev[6], st));
 
     // ---- rows to host
-    const size_t old = c->rows.size();
-    c->rows.resize(old + J);
-    HIP_TRY(c, hipMemcpyAsync(c->rows.data() + old, c->b_rows.p, (size_t)J * sizeof(pjb_junction_row), hipMemcpyDeviceToHost, st));
+    const size_t old = c->rows_n;
+    if (old + J > c->rows_cap) {
+        const size_t ncap = std::max<size_t>((old + J) * 3 / 2, 1024);
+        pjb_junction_row *np = nullptr;
+        hipError_t e = hipHostMalloc((void **)&np, ncap * sizeof(pjb_junction_row), hipHostMallocDefault);
+        if (e != hipSuccess) return fail(c, PJB_ERR_NOMEM, "hipHostMalloc(rows): %s", hipGetErrorString(e));
+        if (old) memcpy(np, c->rows_pinned, old * sizeof(pjb_junction_row));
+        if (c->rows_pinned) (void)hipHostFree(c->rows_pinned);
+        c->rows_pinned = np;
+        c->rows_cap = ncap;
+    }
+    HIP_TRY(c, hipMemcpyAsync(c->rows_pinned + old, c->b_rows.p, (size_t)J * sizeof(pjb_junction_row), hipMemcpyDeviceToHost, st));
     HIP_TRY(c, hipMemcpyAsync(&herr, d_err, 8, hipMemcpyDeviceToHost, st));
     HIP_TRY(c, hipEventRecord(c->ev[7], st));
     HIP_TRY(c, hipStreamSynchronize(st));
-    if ((rc = check_device_error(c, herr))) {
-        c->rows.resize(old);
-        return rc;
-    }
+    if ((rc = check_device_error(c, herr))) return rc;
+    c->rows_n = old + J;
     if (c->ktime) ev_collect(c);
     for (int k = 0; k < 7; k++) (void)hipEventElapsedTime(&c->timing.stage_ms[k], c->ev[k], c->ev[k + 1]);
     (void)hipEventElapsedTime(&c->timing.total_ms, c->ev[0], c->ev[7]);
@@ -645,14 +679,14 @@ int pjb_finish_contig(pjb_ctx *c, int32_t tid, pjb_region_result *res) {
 
 int pjb_collect(pjb_ctx *c, const pjb_junction_row **rows, int64_t *n) {
     if (!c || !rows || !n) return PJB_ERR_ARG;
-    *rows = c->rows.data();
-    *n = (int64_t)c->rows.size();
+    *rows = c->rows_pinned;
+    *n = (int64_t)c->rows_n;
     return PJB_OK;
 }
 
 int pjb_clear_rows(pjb_ctx *c) {
     if (!c) return PJB_ERR_ARG;
-    c->rows.clear();
+    c->rows_n = 0;
     return PJB_OK;
 }
 

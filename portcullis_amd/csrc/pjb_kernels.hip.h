@@ -279,6 +279,46 @@ __global__ __launch_bounds__(256) void k0_upper(uint8_t *g, int64_t n, int do_up
     }
 }
 
+// K0b: contig bases -> 4-bit nt16 codes, two per byte, LOW nibble first (base i at bits 4*(i&7) of
+// word i>>3).  A byte outside the 16-letter alphabet "=ACMGRSVTWYHKDBN" has no code: the contig is
+// flagged "exotic" and k4 then uses its byte-wise path, so equality semantics stay exact.
+__device__ __forceinline__ u32 nt16_code(u32 c, bool &exotic) {
+    switch (c) {
+    case '=': return 0;
+    case 'A': return 1;
+    case 'C': return 2;
+    case 'M': return 3;
+    case 'G': return 4;
+    case 'R': return 5;
+    case 'S': return 6;
+    case 'V': return 7;
+    case 'T': return 8;
+    case 'W': return 9;
+    case 'Y': return 10;
+    case 'H': return 11;
+    case 'K': return 12;
+    case 'D': return 13;
+    case 'B': return 14;
+    case 'N': return 15;
+    default: exotic = true; return 0;
+    }
+}
+__global__ __launch_bounds__(256) void k0_encode(const uint8_t *g, int64_t n, u32 *codes, int64_t n_words, int *exotic_flag) {
+    const int64_t w = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    bool exotic = false;
+    if (w < n_words) {
+        u32 out = 0;
+        const int64_t b0 = w * 8;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int64_t i = b0 + k;
+            if (i < n) out |= nt16_code(g[i], exotic) << (4 * k);
+        }
+        codes[w] = out;
+    }
+    if (__ballot(exotic) && lane_id() == 0) atomicOr(exotic_flag, 1);
+}
+
 // ---------------------------------------------------------------------------------------------
 // K1a: per-read CIGAR walk, pass 1 (BamAlignment::init bam_alignment.cc:71-100, findJuncs length
 // stats src/junction_builder.cc:333-343).  One thread per read; a tile is 1024 consecutive reads.
@@ -811,8 +851,42 @@ __device__ __forceinline__ u32 nt16_ascii(u32 c) { // seq_nt16_str "=ACMGRSVTWYH
     return (u32)(t >> ((c & 7u) * 8)) & 0xffu;
 }
 
+// 8 bases per step: read nibbles [qi, qi+l) (BAM order: high nibble first) against genome codes
+// [gi, gi+l) (low nibble first); mismatch positions are reported relative to `out_base`.
+__device__ __forceinline__ u32 swap_nibbles(u32 x) { return ((x & 0x0F0F0F0Fu) << 4) | ((x >> 4) & 0x0F0F0F0Fu); }
+__device__ __forceinline__ void cmp_words(const u32 *seqw, int32_t qi, const u32 *gw, int32_t gi, int32_t g_words,
+                                          int32_t l, int32_t out_base, int32_t &mism, int32_t &first_mis,
+                                          int32_t &last_mis) {
+    int32_t wq = qi >> 3, wg = gi >> 3;
+    const int shq = (qi & 7) * 4, shg = (gi & 7) * 4;
+    u32 q0 = swap_nibbles(seqw[wq]);
+    u32 g0 = (wg >= 0 && wg < g_words) ? gw[wg] : 0u;
+    for (int32_t t = 0; t < l; t += 8) {
+        const int32_t rem = l - t;
+        // second words only when the window really reaches into them
+        const u32 q1 = (shq && (shq + 4 * (rem < 8 ? rem : 8) > 32)) || (rem > 8) ? swap_nibbles(seqw[wq + 1]) : 0u;
+        const int32_t wg1 = wg + 1;
+        const u32 g1 = ((shg && (shg + 4 * (rem < 8 ? rem : 8) > 32)) || (rem > 8)) && wg1 >= 0 && wg1 < g_words ? gw[wg1] : 0u;
+        const u32 q = (u32)((((u64)q1 << 32) | q0) >> shq);
+        const u32 g = (u32)((((u64)g1 << 32) | g0) >> shg);
+        u32 x = q ^ g;
+        u32 m = (x | (x >> 1) | (x >> 2) | (x >> 3)) & 0x11111111u;
+        if (rem < 8) m &= (1u << (4 * rem)) - 1u;
+        if (m) {
+            mism += __popc(m);
+            if (first_mis < 0) first_mis = out_base + t + ((__ffs((int)m) - 1) >> 2);
+            last_mis = out_base + t + ((31 - __clz((int)m)) >> 2);
+        }
+        q0 = q1;
+        g0 = g1;
+        wq++;
+        wg++;
+    }
+}
+
 __device__ Side anchor_side(const uint32_t *cig, u32 n, int32_t position, int32_t aligned, const uint8_t *seq, int32_t lq,
-                            const uint8_t *genome, int32_t glen, bool genome_has_x, int32_t start, int32_t end) {
+                            const uint8_t *genome, int32_t glen, bool genome_has_x, const u32 *gcodes, int32_t start,
+                            int32_t end) {
     Side S;
     S.len = 0;
     S.mism = 0;
@@ -908,7 +982,10 @@ __device__ Side anchor_side(const uint32_t *cig, u32 n, int32_t position, int32_
         }
         if (qEmit != gEmit) diverged = true;
         if (!diverged && qEmit > 0) {
-            if (qKind == 1 && gKind == 1) {
+            if (qKind == 1 && gKind == 1 && gcodes != nullptr && rPos >= 0 && rPos + qEmit <= glen) {
+                cmp_words(reinterpret_cast<const u32 *>(seq), dS + qPos, gcodes, rPos, (glen + 7) / 8 + 1, qEmit, qTot, mism,
+                          first_mis, last_mis);
+            } else if (qKind == 1 && gKind == 1) {
                 const int32_t qb = dS + qPos;
                 for (int32_t t = 0; t < qEmit; t++) {
                     const int32_t qi = qb + t;
@@ -977,7 +1054,7 @@ enum {
 __global__ __launch_bounds__(256) void k4_pairs(const u64 *skey, const u32 *sidx, const u32 *jid_of, Pairs P, KeyFmt kf,
                                                  const DevBatch *batches, int n_batches, const int32_t *anc_l,
                                                  const int32_t *anc_r, const uint8_t *genome, int32_t glen, int genome_has_x,
-                                                 u32 n, u32 *frag, int32_t *frag_j, u64 *err) {
+                                                 const u32 *gcodes, u32 n, u32 *frag, int32_t *frag_j, u64 *err) {
     const u32 i = blockIdx.x * 256 + threadIdx.x;
     const bool valid = i < n;
     const int lane = lane_id();
@@ -1019,12 +1096,12 @@ __global__ __launch_bounds__(256) void k4_pairs(const u64 *skey, const u32 *sidx
             if ((u64)words * 8ull < (u64)lq) set_error(err, g, PJB_ERR_NO_SEQ);
             else {
                 const uint8_t *seq = b.seq4 + (size_t)b.seq_off[r] * 4;
-                const Side L = anchor_side(cig, nc, pos, aligned, seq, lq, genome, glen, genome_has_x != 0, left, istart - 1);
+                const Side L = anchor_side(cig, nc, pos, aligned, seq, lq, genome, glen, genome_has_x != 0, gcodes, left, istart - 1);
                 Side R;
                 R.err = 0;
                 if (L.err) set_error(err, g, L.err);
                 else {
-                    R = anchor_side(cig, nc, pos, aligned, seq, lq, genome, glen, genome_has_x != 0, iend + 1, right);
+                    R = anchor_side(cig, nc, pos, aligned, seq, lq, genome, glen, genome_has_x != 0, gcodes, iend + 1, right);
                     if (R.err) set_error(err, g, R.err);
                 }
                 if (!L.err && !R.err) {
@@ -1092,42 +1169,53 @@ __global__ __launch_bounds__(256) void k4_pairs(const u64 *skey, const u32 *sidx
     }
 }
 
-// K5a: fragment slots -> junction accumulators (acc pre-initialised: sums 0, max 0, min 100000000)
+// K5a: fragment slots -> junction accumulators (acc pre-initialised: sums 0, max 0, min 100000000).
+// One wavefront walks 64 consecutive slots; lane k owns word k of the 48-word record, so every
+// load is one coalesced 192-byte row and a junction's run of slots is folded in registers; the run
+// is flushed with one atomic per word when the junction changes (same-address chain <= P_j/4096).
+__device__ __forceinline__ u32 frag_combine(int k, u32 a, u32 b) {
+    if (k >= F_MAXMINANC && k <= F_MAXMINMATCH) return a > b ? a : b;
+    if (k == F_FIRSTMIS) return a < b ? a : b;
+    return a + b; // sums; F_MISM_LO/HI are handled as one 64-bit add by the caller
+}
 __global__ __launch_bounds__(256) void k5_frag_reduce(const u32 *frag, const int32_t *frag_j, u32 n_slots, u32 *acc) {
-    const u32 s = blockIdx.x * 256 + threadIdx.x;
-    const bool in = s < n_slots;
-    const int32_t jj = in ? frag_j[s] : -1;
-    const bool valid = jj >= 0;
-    const u32 key = valid ? (u32)jj : (0x80000000u | s);
-    const u32 kprev = __shfl_up(key, 1, 64);
-    const bool head = valid && (lane_id() == 0 || kprev != key);
-    const u32 *src = frag + (size_t)s * F_WORDS;
-    u32 *dst = acc + (size_t)(valid ? jj : 0) * F_WORDS;
-    u64 m64 = 0;
-    for (int k = 0; k < F_WORDS; k++) {
-        if (k == F_MISM_LO) {
-            m64 = valid ? ((u64)src[F_MISM_LO] | ((u64)src[F_MISM_HI] << 32)) : 0;
-            m64 = seg_reduce_to_head(m64, key, OpAdd());
-            if (head) atomicAdd(reinterpret_cast<u64 *>(dst + F_MISM_LO), m64);
-            k++; // skip HI
-            continue;
-        }
-        if (k >= F_JAD0 + 20) break;
-        u32 v;
-        if (k >= F_MAXMINANC && k <= F_MAXMINMATCH) {
-            v = valid ? src[k] : 0u;
-            v = seg_reduce_to_head(v, key, OpMax());
-            if (head) atomicMax(dst + k, v);
-        } else if (k == F_FIRSTMIS) {
-            v = valid ? src[k] : 100000000u;
-            v = seg_reduce_to_head(v, key, OpMin());
-            if (head) atomicMin(dst + k, v);
+    const u32 wave = (blockIdx.x * 256 + threadIdx.x) >> 6;
+    const int k = lane_id();
+    const u32 s0 = wave * 64;
+    if (s0 >= n_slots) return;
+    const u32 s1 = min(s0 + 64, n_slots);
+    const int32_t myj = (s0 + k < n_slots) ? frag_j[s0 + k] : -1;
+    int32_t cur = -1;
+    u32 v = 0, carry_lo = 0; // lane F_MISM_HI also keeps the low word to do the 64-bit add
+    auto flush = [&](int32_t j) {
+        if (j < 0 || k >= F_JAD0 + 20) return;
+        u32 *dst = acc + (size_t)j * F_WORDS + k;
+        if (k == F_MISM_LO) return; // done by lane F_MISM_HI as one 64-bit atomic
+        if (k == F_MISM_HI) {
+            atomicAdd(reinterpret_cast<u64 *>(dst - 1), ((u64)v << 32) | carry_lo);
+        } else if (k >= F_MAXMINANC && k <= F_MAXMINMATCH) atomicMax(dst, v);
+        else if (k == F_FIRSTMIS) atomicMin(dst, v);
+        else if (v) atomicAdd(dst, v);
+    };
+    for (u32 s = s0; s < s1; s++) {
+        const int32_t j = __shfl(myj, (int)(s - s0), 64);
+        if (j < 0) continue; // unused slot
+        const u32 w = k < F_WORDS ? frag[(size_t)s * F_WORDS + k] : 0u;
+        const u32 wlo = __shfl(w, F_MISM_LO, 64);
+        if (j != cur) {
+            flush(cur);
+            cur = j;
+            v = w;
+            carry_lo = wlo;
+        } else if (k == F_MISM_HI) {
+            const u64 sum = (((u64)v << 32) | carry_lo) + (((u64)w << 32) | wlo);
+            v = (u32)(sum >> 32);
+            carry_lo = (u32)sum;
         } else {
-            v = valid ? src[k] : 0u;
-            v = seg_reduce_to_head(v, key, OpAdd());
-            if (head) atomicAdd(dst + k, v);
+            v = frag_combine(k, v, w);
         }
     }
+    flush(cur);
 }
 __global__ __launch_bounds__(256) void k5_init_acc(u32 *acc, u32 n_junc, int32_t *anc_l, int32_t *anc_r) {
     const u32 t = blockIdx.x * 256 + threadIdx.x;

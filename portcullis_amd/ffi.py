@@ -126,6 +126,7 @@ class Context:
         if rc:
             raise PjbError(rc, self._L.pjb_last_error(None).decode())
         self._keep = []
+        self._keep_batch = []
 
     def close(self):
         if self._h:
@@ -182,23 +183,29 @@ class Context:
         pb.n_reads = int(n_reads)
         for name, _ in _FIELDS:
             t = tensors[name]
-            self._keep.append(t)
+            self._keep_batch.append(t)
             setattr(pb, name, t.data_ptr())
         self._check(self._L.pjb_submit_batch_device(self._h, tid, C.byref(pb)))
 
     def finish_contig(self, tid):
         r = PjbRegionResult()
-        self._check(self._L.pjb_finish_contig(self._h, tid, C.byref(r)))
+        try:
+            self._check(self._L.pjb_finish_contig(self._h, tid, C.byref(r)))
+        finally:
+            self._keep_batch = []
         return {k: getattr(r, k) for k, _ in PjbRegionResult._fields_}
 
-    def collect(self):
+    def collect(self, copy=True):
+        """Rows built so far.  copy=False returns a view of the context's pinned buffer that is only
+        valid until the next finish_contig / clear_rows / close."""
         p = C.c_void_p()
         n = C.c_int64()
         self._check(self._L.pjb_collect(self._h, C.byref(p), C.byref(n)))
         if n.value == 0:
             return np.zeros(0, dtype=ROW_DTYPE)
         buf = (C.c_char * (n.value * ROW_DTYPE.itemsize)).from_address(p.value)
-        return np.frombuffer(buf, dtype=ROW_DTYPE, count=n.value).copy()
+        a = np.frombuffer(buf, dtype=ROW_DTYPE, count=n.value)
+        return a.copy() if copy else a
 
     def clear_rows(self):
         self._check(self._L.pjb_clear_rows(self._h))
