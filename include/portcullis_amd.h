@@ -208,6 +208,8 @@ typedef struct pjb_kernel_time {
 } pjb_kernel_time;
 int pjb_get_kernel_timing(const pjb_ctx *ctx, pjb_kernel_time *out, int32_t cap, int32_t *n);
 int pjb_reset_kernel_timing(pjb_ctx *ctx);
+/* Restrict the event bracketing to the named kernels ("k4_pairs,rs_scatter"); "" or NULL = all. */
+int pjb_select_timed_kernels(pjb_ctx *ctx, const char *comma_separated_names);
 
 /* Number of visible HIP devices (0 if none); does not create a context. */
 int pjb_device_count(void);

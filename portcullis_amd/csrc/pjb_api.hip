@@ -58,7 +58,8 @@ struct pjb_ctx {
     size_t rows_n = 0, rows_cap = 0;
     pjb_timing timing;
     hipEvent_t ev[PJB_N_STAGES + 2];
-    int radix_max_bits = 8;
+    int radix_max_bits = 11;
+    int ablate = 0;
     // optional per-kernel timing
     bool ktime = false;
     std::vector<hipEvent_t> ev_pool;
@@ -67,6 +68,7 @@ struct pjb_ctx {
     std::vector<std::string> knames;
     std::vector<int64_t> kcount;
     std::vector<double> kms;
+    std::vector<std::string> ktime_only; // if non-empty, only these kernel names are bracketed
     // scratch
     Buf b_batches, b_tile_cnt, b_tile_stats, b_cstats, b_err, b_total;
     Buf b_key[2], b_idx[2], b_g, b_lstart, b_rend, b_pos, b_aend, b_meta, b_updown;
@@ -189,11 +191,19 @@ void ev_collect(pjb_ctx *c) { // stream must be synchronised
     c->ev_name.clear();
     c->ev_used = 0;
 }
+bool ktime_wanted(pjb_ctx *c, const char *name) {
+    if (!c->ktime) return false;
+    if (c->ktime_only.empty()) return true;
+    for (auto &n : c->ktime_only)
+        if (n == name) return true;
+    return false;
+}
 #define LAUNCH(c, name, kern, grid, block, ...)                                   \
     do {                                                                          \
-        if ((c)->ktime) ev_begin((c), name);                                      \
+        const bool timed_ = ktime_wanted((c), name);                              \
+        if (timed_) ev_begin((c), name);                                          \
         hipLaunchKernelGGL(kern, grid, block, 0, (c)->stream, __VA_ARGS__);       \
-        if ((c)->ktime) ev_end((c));                                              \
+        if (timed_) ev_end((c));                                                  \
     } while (0)
 
 // generic scan launchers ------------------------------------------------------------------------
@@ -272,6 +282,7 @@ int pjb_create(pjb_ctx **out, const pjb_config *cfg) {
     }
     for (auto &ev : c->ev) (void)hipEventCreate(&ev);
     c->ktime = (cfg->flags & PJB_FLAG_KERNEL_TIMING) != 0;
+    if (const char *s = getenv("PJB_ABLATE")) c->ablate = atoi(s);
     if (const char *s = getenv("PJB_RADIX_BITS")) {
         int v = atoi(s);
         if (v >= 4 && v <= RS_MAX_BITS) c->radix_max_bits = v;
@@ -640,7 +651,7 @@ int pjb_finish_contig(pjb_ctx *c, int32_t tid, pjb_region_result *res) {
     LAUNCH(c, "k4_pairs", k4_pairs, dim3(pair_blocks), dim3(256), skey, sidx, (const u32 *)c->b_jid.p, pr, kf,
            (const DevBatch *)c->b_batches.p, (int)c->batches.size(), (const int32_t *)c->b_ancl.p,
            (const int32_t *)c->b_ancr.p, (const uint8_t *)G.d, (int32_t)G.len, G.has_x ? 1 : 0,
-           (const u32 *)(G.has_x ? nullptr : G.codes), P, (u32 *)c->b_frag.p, (int32_t *)c->b_fragj.p, d_err);
+           (const u32 *)(G.has_x ? nullptr : G.codes), P, (u32 *)c->b_frag.p, (int32_t *)c->b_fragj.p, d_err, c->ablate);
     HIP_TRY(c, hipEventRecord(c->ev[5], st));
 
     // ---- K5: fragments -> junctions -> rows
@@ -698,6 +709,20 @@ int pjb_get_kernel_timing(const pjb_ctx *c, pjb_kernel_time *out, int32_t cap, i
         strncpy(out[i].name, c->knames[(size_t)i].c_str(), sizeof(out[i].name) - 1);
         out[i].launches = c->kcount[(size_t)i];
         out[i].total_ms = c->kms[(size_t)i];
+    }
+    return PJB_OK;
+}
+
+int pjb_select_timed_kernels(pjb_ctx *c, const char *comma_separated_names) {
+    if (!c) return PJB_ERR_ARG;
+    c->ktime_only.clear();
+    std::string s = comma_separated_names ? comma_separated_names : "";
+    size_t a = 0;
+    while (a < s.size()) {
+        size_t b = s.find(',', a);
+        if (b == std::string::npos) b = s.size();
+        if (b > a) c->ktime_only.push_back(s.substr(a, b - a));
+        a = b + 1;
     }
     return PJB_OK;
 }

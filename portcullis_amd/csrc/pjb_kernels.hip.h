@@ -645,7 +645,7 @@ __global__ __launch_bounds__(256) void k1_emit(DevBatch b, const u32 *tile_off, 
 // ---------------------------------------------------------------------------------------------
 constexpr int RS_ITEMS = 16;
 constexpr int RS_TILE = 256 * RS_ITEMS; // 4096 keys per block
-constexpr int RS_MAX_BITS = 11;
+constexpr int RS_MAX_BITS = 12;
 constexpr int RS_MAX_BINS = 1 << RS_MAX_BITS;
 
 __global__ __launch_bounds__(256) void rs_hist(const u64 *keys, u32 n, int shift, int bits, u32 *hist, u32 n_tiles) {
@@ -857,34 +857,51 @@ __device__ __forceinline__ u32 swap_nibbles(u32 x) { return ((x & 0x0F0F0F0Fu) <
 __device__ __forceinline__ void cmp_words(const u32 *seqw, int32_t qi, const u32 *gw, int32_t gi, int32_t g_words,
                                           int32_t l, int32_t out_base, int32_t &mism, int32_t &first_mis,
                                           int32_t &last_mis) {
-    int32_t wq = qi >> 3, wg = gi >> 3;
     const int shq = (qi & 7) * 4, shg = (gi & 7) * 4;
-    u32 q0 = swap_nibbles(seqw[wq]);
-    u32 g0 = (wg >= 0 && wg < g_words) ? gw[wg] : 0u;
-    for (int32_t t = 0; t < l; t += 8) {
-        const int32_t rem = l - t;
-        // second words only when the window really reaches into them
-        const u32 q1 = (shq && (shq + 4 * (rem < 8 ? rem : 8) > 32)) || (rem > 8) ? swap_nibbles(seqw[wq + 1]) : 0u;
-        const int32_t wg1 = wg + 1;
-        const u32 g1 = ((shg && (shg + 4 * (rem < 8 ? rem : 8) > 32)) || (rem > 8)) && wg1 >= 0 && wg1 < g_words ? gw[wg1] : 0u;
-        const u32 q = (u32)((((u64)q1 << 32) | q0) >> shq);
-        const u32 g = (u32)((((u64)g1 << 32) | g0) >> shg);
-        u32 x = q ^ g;
-        u32 m = (x | (x >> 1) | (x >> 2) | (x >> 3)) & 0x11111111u;
-        if (rem < 8) m &= (1u << (4 * rem)) - 1u;
-        if (m) {
-            mism += __popc(m);
-            if (first_mis < 0) first_mis = out_base + t + ((__ffs((int)m) - 1) >> 2);
-            last_mis = out_base + t + ((31 - __clz((int)m)) >> 2);
+    const int32_t lastq = (qi + l - 1) >> 3, lastg = (gi + l - 1) >> 3;
+    int32_t wq = qi >> 3, wg = gi >> 3;
+    for (int32_t t = 0; t < l; t += 32) {
+        // issue all loads of this 32-base stretch before using any (memory-level parallelism)
+        u32 qw[5], gg[5];
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            qw[k] = (wq + k <= lastq) ? seqw[wq + k] : 0u;
+            const int32_t w = wg + k;
+            gg[k] = (w <= lastg && w >= 0 && w < g_words) ? gw[w] : 0u;
         }
-        q0 = q1;
-        g0 = g1;
-        wq++;
-        wg++;
+#pragma unroll
+        for (int k = 0; k < 5; k++) qw[k] = swap_nibbles(qw[k]);
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            const int32_t rem = l - t - 8 * c;
+            if (rem > 0) {
+                const u32 q = (u32)((((u64)qw[c + 1] << 32) | qw[c]) >> shq);
+                const u32 g = (u32)((((u64)gg[c + 1] << 32) | gg[c]) >> shg);
+                const u32 x = q ^ g;
+                u32 m = (x | (x >> 1) | (x >> 2) | (x >> 3)) & 0x11111111u;
+                if (rem < 8) m &= (1u << (4 * rem)) - 1u;
+                if (m) {
+                    mism += __popc(m);
+                    if (first_mis < 0) first_mis = out_base + t + 8 * c + ((__ffs((int)m) - 1) >> 2);
+                    last_mis = out_base + t + 8 * c + ((31 - __clz((int)m)) >> 2);
+                }
+            }
+        }
+        wq += 4;
+        wg += 4;
     }
 }
 
-__device__ Side anchor_side(const uint32_t *cig, u32 n, int32_t position, int32_t aligned, const uint8_t *seq, int32_t lq,
+// CIGAR ops of one alignment: the first OPS_LDS ops are staged in LDS (one column per thread), the
+// rest (long reads) are read from global memory
+constexpr int OPS_LDS = 8;
+struct OpsView {
+    const uint32_t *g;
+    const u32 *lds; // &s_ops[0][threadIdx.x], stride 256
+    __device__ __forceinline__ u32 operator[](u32 k) const { return k < (u32)OPS_LDS ? lds[k * 256] : g[k]; }
+};
+
+__device__ Side anchor_side(const OpsView cig, u32 n, int32_t position, int32_t aligned, const uint8_t *seq, int32_t lq,
                             const uint8_t *genome, int32_t glen, bool genome_has_x, const u32 *gcodes, int32_t start,
                             int32_t end) {
     Side S;
@@ -1054,15 +1071,14 @@ enum {
 __global__ __launch_bounds__(256) void k4_pairs(const u64 *skey, const u32 *sidx, const u32 *jid_of, Pairs P, KeyFmt kf,
                                                  const DevBatch *batches, int n_batches, const int32_t *anc_l,
                                                  const int32_t *anc_r, const uint8_t *genome, int32_t glen, int genome_has_x,
-                                                 const u32 *gcodes, u32 n, u32 *frag, int32_t *frag_j, u64 *err) {
+                                                 const u32 *gcodes, u32 n, u32 *frag, int32_t *frag_j, u64 *err, int ablate) {
+    __shared__ u32 s_ops[OPS_LDS][256];
     const u32 i = blockIdx.x * 256 + threadIdx.x;
     const bool valid = i < n;
     const int lane = lane_id();
     u32 j = 0xffffffffu;
-    u32 vals[F_WORDS];
-#pragma unroll
-    for (int k = 0; k < F_WORDS; k++) vals[k] = 0;
-    vals[F_FIRSTMIS] = 100000000u; // junction.cc:864
+    u32 cnt[4] = {0, 0, 0, 0}, jadp[5] = {0, 0, 0, 0, 0}, mx[5] = {0, 0, 0, 0, 0};
+    u32 first_mis = 100000000u; // junction.cc:864
     u64 mism64 = 0;
     if (valid) {
         const u32 p = sidx[i];
@@ -1081,13 +1097,18 @@ __global__ __launch_bounds__(256) void k4_pairs(const u64 *skey, const u32 *sidx
         unpack_key(kf, skey[i], istart, iend);
         const int32_t left = anc_l[j], right = anc_r[j];
         const u32 c0 = b.cig_off[r], c1 = b.cig_off[r + 1];
-        const uint32_t *cig = b.cigar + c0;
         const u32 nc = c1 - c0;
+        OpsView cig;
+        cig.g = b.cigar + c0;
+        cig.lds = &s_ops[0][threadIdx.x];
+#pragma unroll
+        for (int k = 0; k < OPS_LDS; k++) s_ops[k][threadIdx.x] = (u32)k < nc ? cig.g[k] : 0u;
         const int32_t pos = P.pos[p], aend = P.aend[p];
         const int32_t aligned = aend - pos + 1;
         const int32_t lq = b.l_qseq[r];
         u32 upM = 0, downM = 0, minMatch = 0, mmes = 0, nbMis = 0;
-        if (lq <= 1) { // junction.cc:168-185
+        if (ablate & 1) {
+        } else if (lq <= 1) { // junction.cc:168-185
             const u32 totUp = (u32)((istart - 1) - left + 1);
             const u32 totDown = (u32)(right - (iend + 1) + 1);
             mmes = totUp < totDown ? totUp : totDown;
@@ -1115,53 +1136,96 @@ __global__ __launch_bounds__(256) void k4_pairs(const u64 *skey, const u32 *sidx
             }
         }
         const u32 meta = P.meta[p];
-        vals[F_N] = 1;
         const u32 cat = meta & META_CAT_MASK;
-        vals[F_R1P] = cat == 0;
-        vals[F_R1N] = cat == 1;
-        vals[F_R2P] = cat == 2;
-        vals[F_R2N] = cat == 3;
-        vals[F_MS] = (meta & META_MULTI) != 0;
         const u32 xs = (meta >> META_XS_SHIFT) & 3u;
-        vals[F_XSP] = xs == 1;
-        vals[F_XSN] = xs == 2;
-        vals[F_UM] = (meta & META_UM) != 0;
-        vals[F_BPP] = (meta & META_BPP) != 0;
-        vals[F_PPP] = (meta & META_PPP) != 0;
-        vals[F_REL] = (meta & META_REL) != 0;
         // distinct alignment runs in BAM order (junction.cc:763-771): compare with the previous pair of the junction
         bool dist_head = true;
         if (i > 0 && jid_of[i - 1] == j) {
             const u32 q = sidx[i - 1];
             dist_head = P.pos[q] != pos || P.aend[q] != aend;
         }
-        vals[F_DIST] = dist_head;
+        // 8-bit lanes: a wavefront adds at most 64 per field
+        cnt[0] = 1u | ((u32)(cat == 0) << 8) | ((u32)(cat == 1) << 16) | ((u32)(cat == 2) << 24);
+        cnt[1] = (u32)(cat == 3) | ((u32)((meta & META_MULTI) != 0) << 8) | ((u32)(xs == 1) << 16) | ((u32)(xs == 2) << 24);
+        cnt[2] = (u32)((meta & META_UM) != 0) | ((u32)((meta & META_BPP) != 0) << 8) | ((u32)((meta & META_PPP) != 0) << 16) |
+                 ((u32)((meta & META_REL) != 0) << 24);
+        cnt[3] = (u32)dist_head;
+#pragma unroll
+        for (int w = 0; w < 5; w++) // junction.cc:875-877: JAD[k]++ for k < min(20, minMatch)
+            jadp[w] = (u32)((u32)(4 * w) < minMatch) | ((u32)((u32)(4 * w + 1) < minMatch) << 8) |
+                      ((u32)((u32)(4 * w + 2) < minMatch) << 16) | ((u32)((u32)(4 * w + 3) < minMatch) << 24);
         const int32_t la = istart - P.lstart[p], ra = P.rend[p] - iend; // Intron::minAnchorLength intron.cc:81-83
-        vals[F_MAXMINANC] = (u32)(la < ra ? la : ra);
+        mx[0] = (u32)(la < ra ? la : ra);
         const u32 ud = P.updown[p];
-        vals[F_UP] = ud & 0xffffu;
-        vals[F_DOWN] = ud >> 16;
-        vals[F_MAXMMES] = mmes;
-        vals[F_MAXMINMATCH] = minMatch;
-        vals[F_FIRSTMIS] = minMatch > 0 ? minMatch : 100000000u;
+        mx[1] = ud & 0xffffu;
+        mx[2] = ud >> 16;
+        mx[3] = mmes;
+        mx[4] = minMatch;
+        first_mis = minMatch > 0 ? minMatch : 100000000u;
         mism64 = nbMis;
-#pragma unroll
-        for (int k = 0; k < 20; k++) vals[F_JAD0 + k] = (u32)k < minMatch; // junction.cc:875-877
     }
-    // ---- segmented wave reduce to fragment heads
+    if (ablate & 2) {
+        if (valid && (lane == 0)) frag_j[j + (i >> 6)] = (int32_t)(j + mx[3] + cnt[3] + (u32)mism64);
+        return;
+    }
+    // ---- segmented wave reduce to fragment heads; the "same junction at distance o" tests are done once
+    u32 take = 0;
 #pragma unroll
-    for (int k = F_N; k <= F_DIST; k++) vals[k] = seg_reduce_to_head(vals[k], j, OpAdd());
+    for (int sft = 0; sft < 6; sft++) {
+        const int o = 1 << sft;
+        const u32 kk = __shfl_down(j, o, 64);
+        if (lane + o < 64 && kk == j) take |= 1u << sft;
+    }
+    auto red_add = [&](u32 v) {
 #pragma unroll
-    for (int k = F_MAXMINANC; k <= F_MAXMINMATCH; k++) vals[k] = seg_reduce_to_head(vals[k], j, OpMax());
-    vals[F_FIRSTMIS] = seg_reduce_to_head(vals[F_FIRSTMIS], j, OpMin());
-    mism64 = seg_reduce_to_head(mism64, j, OpAdd());
+        for (int sft = 0; sft < 6; sft++) {
+            const u32 t = __shfl_down(v, 1 << sft, 64);
+            if ((take >> sft) & 1u) v += t;
+        }
+        return v;
+    };
+    auto red_max = [&](u32 v) {
 #pragma unroll
-    for (int k = 0; k < 20; k++) vals[F_JAD0 + k] = seg_reduce_to_head(vals[F_JAD0 + k], j, OpAdd());
+        for (int sft = 0; sft < 6; sft++) {
+            const u32 t = __shfl_down(v, 1 << sft, 64);
+            if (((take >> sft) & 1u) && t > v) v = t;
+        }
+        return v;
+    };
+#pragma unroll
+    for (int w = 0; w < 4; w++) cnt[w] = red_add(cnt[w]);
+#pragma unroll
+    for (int w = 0; w < 5; w++) jadp[w] = red_add(jadp[w]);
+#pragma unroll
+    for (int w = 0; w < 5; w++) mx[w] = red_max(mx[w]);
+#pragma unroll
+    for (int sft = 0; sft < 6; sft++) {
+        const u32 t = __shfl_down(first_mis, 1 << sft, 64);
+        const u64 t64 = __shfl_down(mism64, 1 << sft, 64);
+        if ((take >> sft) & 1u) {
+            first_mis = t < first_mis ? t : first_mis;
+            mism64 += t64;
+        }
+    }
     const u32 jprev = __shfl_up(j, 1, 64);
     if (valid && (lane == 0 || jprev != j)) {
         const u32 slot = j + (i >> 6);
+        u32 vals[F_WORDS];
+#pragma unroll
+        for (int k = 0; k < F_WORDS; k++) vals[k] = 0;
+        // a full wavefront of one junction makes the first field 64: it still fits its byte (max 64 < 256)
+#pragma unroll
+        for (int k = 0; k < 13; k++) vals[F_N + k] = (cnt[k >> 2] >> (8 * (k & 3))) & 0xffu;
+        vals[F_MAXMINANC] = mx[0];
+        vals[F_UP] = mx[1];
+        vals[F_DOWN] = mx[2];
+        vals[F_MAXMMES] = mx[3];
+        vals[F_MAXMINMATCH] = mx[4];
+        vals[F_FIRSTMIS] = first_mis;
         vals[F_MISM_LO] = (u32)mism64;
         vals[F_MISM_HI] = (u32)(mism64 >> 32);
+#pragma unroll
+        for (int k = 0; k < 20; k++) vals[F_JAD0 + k] = (jadp[k >> 2] >> (8 * (k & 3))) & 0xffu;
         uint4 *dst = reinterpret_cast<uint4 *>(frag + (size_t)slot * F_WORDS);
 #pragma unroll
         for (int k = 0; k < F_WORDS / 4; k++) dst[k] = make_uint4(vals[4 * k], vals[4 * k + 1], vals[4 * k + 2], vals[4 * k + 3]);

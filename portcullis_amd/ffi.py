@@ -22,6 +22,7 @@ EXPORTS = [
     "pjb_create", "pjb_destroy", "pjb_last_error", "pjb_set_refs", "pjb_upload_contig", "pjb_upload_contig_device",
     "pjb_release_contig", "pjb_submit_batch", "pjb_submit_batch_device", "pjb_finish_contig", "pjb_collect",
     "pjb_clear_rows", "pjb_get_timing", "pjb_device_count", "pjb_get_kernel_timing", "pjb_reset_kernel_timing",
+    "pjb_select_timed_kernels",
 ]
 FLAG_KERNEL_TIMING = 1
 
@@ -101,6 +102,7 @@ def load():
         L.pjb_get_timing.argtypes = [C.c_void_p, C.POINTER(PjbTiming)]
         L.pjb_get_kernel_timing.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]
         L.pjb_reset_kernel_timing.argtypes = [C.c_void_p]
+        L.pjb_select_timed_kernels.argtypes = [C.c_void_p, C.c_char_p]
         _LIB = L
     return _LIB
 
@@ -229,6 +231,11 @@ def _reset_kernel_timing(self):
     self._check(self._L.pjb_reset_kernel_timing(self._h))
 
 
+def _select_timed_kernels(self, names):
+    self._check(self._L.pjb_select_timed_kernels(self._h, ",".join(names).encode()))
+
+
+Context.select_timed_kernels = _select_timed_kernels
 Context.kernel_timing = _kernel_timing
 Context.reset_kernel_timing = _reset_kernel_timing
 
