@@ -27,10 +27,10 @@ def algorithmic_bytes(name, N, C, S, Cs, P, J, L, passes):
     reads, Cs cigar ops of spliced reads, P pairs, J junctions, L read length."""
     frags = P / 64.0 + J
     table = {
-        # pos, cig_off, l_qseq, xs + every cigar op ; per-tile stats are negligible
-        "k1_count": N * 13 + C * 4,
-        # cig_off + all ops (count pass), spliced reads: pos/flag/mapq/xs + ops twice more; 36 B written per pair
-        "k1_emit": N * 4 + C * 4 + S * 8 + Cs * 8 + P * 36,
+        # pos, cig_off, l_qseq, xs + every cigar op; 8 B written per spliced read (compacted index + pair offset)
+        "k1_count": N * 13 + C * 4 + S * 8,
+        # spliced reads only: compacted slot (8), cig_off (8), pos/flag/mapq/xs (8), ops walked 3x; 36 B written per pair
+        "k1_emit": S * 24 + Cs * 12 + P * 36,
         "rs_hist": P * 8,
         "rs_scatter": P * 24,
         "k2_heads_reduce": P * 20,
@@ -41,6 +41,7 @@ def algorithmic_bytes(name, N, C, S, Cs, P, J, L, passes):
         "k4_pairs": P * (8 + 4 + 4 + 28 + 12 + 20 + 4 * (Cs / max(S, 1)) + L / 2 + L + 8) + frags * 196,
         "k5_frag_reduce": frags * 196 + J * 164,
         "k5_finalize": J * (192 + 24 + 48 + 200),
+        "k5_entropy_terms": P * 0 + J * 8,
     }
     return table.get(name)
 

@@ -70,11 +70,11 @@ struct pjb_ctx {
     std::vector<double> kms;
     std::vector<std::string> ktime_only; // if non-empty, only these kernel names are bracketed
     // scratch
-    Buf b_batches, b_tile_cnt, b_tile_stats, b_cstats, b_err, b_total;
+    Buf b_batches, b_tile_cnt, b_tile_stats, b_cstats, b_err, b_total, b_splidx, b_splpoff;
     Buf b_key[2], b_idx[2], b_g, b_lstart, b_rend, b_pos, b_aend, b_meta, b_updown;
     Buf b_hist, b_hist_scan, b_scan_tiles;
     Buf b_jid, b_seg, b_runfirst, b_runstart;
-    Buf b_frag, b_fragj, b_fragl, b_fragr, b_acc, b_ancl, b_ancr, b_rows, b_hasx;
+    Buf b_frag, b_fragj, b_fragl, b_fragr, b_acc, b_ancl, b_ancr, b_rows, b_hasx, b_ent;
 };
 
 namespace {
@@ -302,7 +302,7 @@ void pjb_destroy(pjb_ctx *c) {
                   &c->b_key[1], &c->b_idx[0], &c->b_idx[1], &c->b_g, &c->b_lstart, &c->b_rend, &c->b_pos, &c->b_aend,
                   &c->b_meta, &c->b_updown, &c->b_hist, &c->b_hist_scan, &c->b_scan_tiles, &c->b_jid, &c->b_seg,
                   &c->b_runfirst, &c->b_runstart, &c->b_frag, &c->b_fragj, &c->b_fragl, &c->b_fragr, &c->b_acc,
-                  &c->b_ancl, &c->b_ancr, &c->b_rows, &c->b_hasx};
+                  &c->b_ancl, &c->b_ancr, &c->b_rows, &c->b_hasx, &c->b_ent, &c->b_splidx, &c->b_splpoff};
     for (Buf *b : all) release(*b);
     for (auto &ev : c->ev) (void)hipEventDestroy(ev);
     for (auto &ev : c->ev_pool) (void)hipEventDestroy(ev);
@@ -502,6 +502,8 @@ int pjb_finish_contig(pjb_ctx *c, int32_t tid, pjb_region_result *res) {
     if ((rc = ensure(c, c->b_tile_cnt, (size_t)n_tiles * 4))) return rc;
     if ((rc = ensure(c, c->b_tile_stats, (size_t)n_tiles * sizeof(TileStats)))) return rc;
     if ((rc = ensure(c, c->b_cstats, sizeof(ContigStats)))) return rc;
+    if ((rc = ensure(c, c->b_splidx, (size_t)n_tiles * K1_TILE * 4))) return rc;
+    if ((rc = ensure(c, c->b_splpoff, (size_t)n_tiles * K1_TILE * 4))) return rc;
     if ((rc = ensure(c, c->b_err, 8))) return rc;
     if ((rc = ensure(c, c->b_total, 8))) return rc;
     HIP_TRY(c, hipMemcpyAsync(c->b_batches.p, c->batches.data(), c->batches.size() * sizeof(DevBatch), hipMemcpyHostToDevice, st));
@@ -511,7 +513,8 @@ int pjb_finish_contig(pjb_ctx *c, int32_t tid, pjb_region_result *res) {
     HIP_TRY(c, hipEventRecord(c->ev[0], st));
     for (auto &b : c->batches) {
         const u32 nt = (u32)((b.n + K1_TILE - 1) / K1_TILE);
-        LAUNCH(c, "k1_count", k1_count, dim3(nt), dim3(256), b, (u32 *)c->b_tile_cnt.p, (TileStats *)c->b_tile_stats.p, d_err);
+        LAUNCH(c, "k1_count", k1_count, dim3(nt), dim3(256), b, (u32 *)c->b_tile_cnt.p, (TileStats *)c->b_tile_stats.p,
+               (u32 *)c->b_splidx.p, (u32 *)c->b_splpoff.p, d_err);
     }
     LAUNCH(c, "k1_scan_tiles", k1_scan_tiles, dim3(1), dim3(1024), (u32 *)c->b_tile_cnt.p, (const TileStats *)c->b_tile_stats.p, n_tiles, d_cs);
     ContigStats cs;
@@ -570,8 +573,9 @@ int pjb_finish_contig(pjb_ctx *c, int32_t tid, pjb_region_result *res) {
     pr.updown = (u32 *)c->b_updown.p;
     for (auto &b : c->batches) {
         const u32 nt = (u32)((b.n + K1_TILE - 1) / K1_TILE);
-        LAUNCH(c, "k1_emit", k1_emit, dim3(nt), dim3(256), b, (const u32 *)c->b_tile_cnt.p, pr, kf, ref_len, tid,
-               (int)c->cfg.orientation, d_err);
+        LAUNCH(c, "k1_emit", k1_emit, dim3(nt), dim3(256), b, (const u32 *)c->b_tile_cnt.p,
+               (const TileStats *)c->b_tile_stats.p, (const u32 *)c->b_splidx.p, (const u32 *)c->b_splpoff.p, pr, kf, ref_len,
+               tid, (int)c->cfg.orientation, d_err);
     }
     HIP_TRY(c, hipEventRecord(c->ev[1], st));
 
@@ -657,10 +661,14 @@ int pjb_finish_contig(pjb_ctx *c, int32_t tid, pjb_region_result *res) {
     // ---- K5: fragments -> junctions -> rows
     LAUNCH(c, "k5_frag_reduce", k5_frag_reduce, dim3(slot_blocks), dim3(256), (const u32 *)c->b_frag.p,
            (const int32_t *)c->b_fragj.p, n_slots, (u32 *)c->b_acc.p);
+    const u32 R_runs = cs.n_runs;
+    if ((rc = ensure(c, c->b_ent, (size_t)R_runs * 8))) return rc;
+    LAUNCH(c, "k5_entropy_terms", k5_entropy_terms, dim3((R_runs + 255) / 256), dim3(256), (const u32 *)c->b_jid.p,
+           (const u32 *)c->b_seg.p, (const u32 *)c->b_runfirst.p, (const u32 *)c->b_runstart.p, R_runs, (double *)c->b_ent.p);
     LAUNCH(c, "k5_finalize", k5_finalize, dim3((J + 255) / 256), dim3(256), skey, (const u32 *)c->b_seg.p,
            (const u32 *)c->b_runfirst.p, (const u32 *)c->b_runstart.p, (const u32 *)c->b_acc.p,
            (const int32_t *)c->b_ancl.p, (const int32_t *)c->b_ancr.p, kf, (const uint8_t *)G.d, (int32_t)G.len, tid, J,
-           (pjb_junction_row *)c->b_rows.p, d_err);
+           (const double *)c->b_ent.p, (pjb_junction_row *)c->b_rows.p, d_err);
     HIP_TRY(c, hipEventRecord(c->ev[6], st));
 
     // ---- rows to host

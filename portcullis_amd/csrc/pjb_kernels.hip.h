@@ -325,8 +325,11 @@ __global__ __launch_bounds__(256) void k0_encode(const uint8_t *g, int64_t n, u3
 // ---------------------------------------------------------------------------------------------
 constexpr int K1_TILE = 1024;
 
-__global__ __launch_bounds__(256) void k1_count(DevBatch b, u32 *tile_cnt, TileStats *tile_stats, u64 *err) {
+__global__ __launch_bounds__(256) void k1_count(DevBatch b, u32 *tile_cnt, TileStats *tile_stats, u32 *spl_idx,
+                                                 u32 *spl_poff, u64 *err) {
     __shared__ u64 sm64[4];
+    __shared__ u64 sm_scan[4];
+    u64 run = 0; // (pairs << 16 | spliced reads) of the rounds done so far, in read order
     __shared__ int32_t smi[4][6];
     int64_t base = (int64_t)blockIdx.x * K1_TILE;
     u32 cnt = 0, spl = 0, uns = 0;
@@ -335,6 +338,7 @@ __global__ __launch_bounds__(256) void k1_count(DevBatch b, u32 *tile_cnt, TileS
 #pragma unroll
     for (int it = 0; it < 4; it++) {
         int64_t r = base + it * 256 + threadIdx.x;
+        u32 cthis = 0;
         if (r < b.n) {
             u32 c0 = b.cig_off[r], c1 = b.cig_off[r + 1];
             int32_t p = b.pos[r];
@@ -365,6 +369,20 @@ __global__ __launch_bounds__(256) void k1_count(DevBatch b, u32 *tile_cnt, TileS
                 min_pos = p < min_pos ? p : min_pos;
             } else
                 uns++;
+            cthis = c;
+        }
+        // ordered compaction of the spliced reads of this tile: slot k holds the k-th spliced read
+        // (batch-local index) and the tile-local offset of its first pair
+        {
+            const u64 v = ((u64)cthis << 16) | (u64)(cthis ? 1u : 0u);
+            u64 tot;
+            const u64 ex = run + block_escan_256<u64>(v, sm_scan, &tot);
+            run += tot;
+            if (cthis) {
+                const size_t slot = (size_t)(b.tile_base + blockIdx.x) * K1_TILE + (u32)(ex & 0xffffu);
+                spl_idx[slot] = (u32)r;
+                spl_poff[slot] = (u32)(ex >> 16);
+            }
         }
     }
     // block reduce
@@ -522,25 +540,18 @@ __device__ __forceinline__ void ncursor_advance(NCursor &c, const uint32_t *cig,
     }
 }
 
-__global__ __launch_bounds__(256) void k1_emit(DevBatch b, const u32 *tile_off, Pairs P, KeyFmt kf, int32_t ref_len,
+__global__ __launch_bounds__(256) void k1_emit(DevBatch b, const u32 *tile_off, const TileStats *tile_stats,
+                                                const u32 *spl_idx, const u32 *spl_poff, Pairs P, KeyFmt kf, int32_t ref_len,
                                                 int32_t tid, int orientation, u64 *err) {
-    __shared__ u32 sm[4];
-    int64_t base = (int64_t)blockIdx.x * K1_TILE;
-    u32 run = tile_off[b.tile_base + blockIdx.x];
+    const u32 tile = b.tile_base + blockIdx.x;
+    const u32 nspl = tile_stats[tile].spliced;
+    const u32 toff = tile_off[tile];
     const bool pp_check = orientation == PJB_OR_FR || orientation == PJB_OR_RF || orientation == PJB_OR_FF;
-#pragma unroll 1
-    for (int it = 0; it < 4; it++) {
-        int64_t r = base + it * 256 + threadIdx.x;
-        u32 c0 = 0, c1 = 0, nN = 0;
-        if (r < b.n) {
-            c0 = b.cig_off[r];
-            c1 = b.cig_off[r + 1];
-            for (u32 k = c0; k < c1; k++) nN += ((b.cigar[k] & 15u) == OP_N);
-        }
-        u32 tot;
-        u32 off = run + block_escan_256<u32>(nN, sm, &tot);
-        run += tot;
-        if (nN == 0) continue;
+    for (u32 ks = threadIdx.x; ks < nspl; ks += 256) {
+        const size_t slot = (size_t)tile * K1_TILE + ks;
+        const int64_t r = spl_idx[slot];
+        const u32 off = toff + spl_poff[slot];
+        const u32 c0 = b.cig_off[r], c1 = b.cig_off[r + 1];
         const uint32_t *cig = b.cigar + c0;
         const u32 n = c1 - c0;
         const int32_t pos = b.pos[r];
@@ -549,6 +560,8 @@ __global__ __launch_bounds__(256) void k1_emit(DevBatch b, const u32 *tile_off, 
         const u32 flag = b.flag[r];
         const bool first = flag & 0x40, rev = flag & 0x10;
         u32 meta = (first ? 0u : 2u) + (rev ? 1u : 0u);
+        u32 nN = 0;
+        for (u32 q = 0; q < n; q++) nN += ((cig[q] & 15u) == OP_N);
         if (nN > 1) meta |= META_MULTI;
         meta |= ((u32)b.xs[r] & 3u) << META_XS_SHIFT;
         const bool um = b.mapq[r] >= 30;
@@ -1324,10 +1337,36 @@ __device__ __forceinline__ void fetch_clamp(int32_t glen, int32_t &b, int32_t &e
     else if (glen <= e) e = glen - 1;
 }
 
+// Entropy terms, one thread per position run: p*log2(p) with the reference's grouping
+// (junction.cc:730-749): with runs r_0..r_m of equal read position the flush rule yields the counts
+// (r_0+1, r_1, ..., r_{m-1}, r_m-1); a zero count contributes nothing.  k5_finalize adds the terms
+// of a junction sequentially, in run order, so the sum rounds like the reference's loop.
+__global__ __launch_bounds__(256) void k5_entropy_terms(const u32 *jid_of, const u32 *seg_off, const u32 *run_first,
+                                                         const u32 *run_start, u32 n_runs, double *term) {
+    const u32 r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= n_runs) return;
+    const u32 s = run_start[r];
+    const u32 j = jid_of[s];
+    const u32 n = seg_off[j + 1] - seg_off[j];
+    const u32 rf = run_first[j], rl = run_first[j + 1];
+    u32 c = run_start[r + 1] - s;
+    if (rl - rf > 1) {
+        if (r == rf) c += 1;
+        else if (r == rl - 1) c -= 1;
+    }
+    double t = 0.0;
+    if (c != 0 && n > 1) {
+        const double pI = (double)c / (double)n;
+        t = __dmul_rn(pI, log2(pI));
+    }
+    term[r] = t;
+}
+
 __global__ __launch_bounds__(256) void k5_finalize(const u64 *skey, const u32 *seg_off, const u32 *run_first,
                                                     const u32 *run_start, const u32 *acc, const int32_t *anc_l,
                                                     const int32_t *anc_r, KeyFmt kf, const uint8_t *genome, int32_t glen,
-                                                    int32_t tid, u32 n_junc, pjb_junction_row *rows, u64 *err) {
+                                                    int32_t tid, u32 n_junc, const double *ent_term, pjb_junction_row *rows,
+                                                    u64 *err) {
     const u32 j = blockIdx.x * 256 + threadIdx.x;
     if (j >= n_junc) return;
     const u32 *a = acc + (size_t)j * F_WORDS;
@@ -1373,30 +1412,14 @@ __global__ __launch_bounds__(256) void k5_finalize(const u64 *skey, const u32 *s
         else if ((double)nn / tot >= 0.95) R.read_strand = PJB_STRAND_NEG;
         else R.read_strand = PJB_STRAND_UNK;
     }
-    // calcEntropy, junction.cc:730-749, on run lengths: with runs r_0..r_m of equal read position the
-    // reference's flush rule yields counts (r_0+1, r_1, ..., r_{m-1}, r_m-1) (last dropped if 0), summed in order.
+    // calcEntropy, junction.cc:730-749: sequential sum of the per-run terms (k5_entropy_terms), then fabs
     {
-        double ent = 0.0;
+        double sum = 0.0;
         if (n > 1) {
             const u32 rf = run_first[j], rl = run_first[j + 1];
-            const u32 m = rl - rf; // number of runs
-            double sum = 0.0;
-            if (m == 1) {
-                const double pI = (double)n / (double)n;
-                sum = __dadd_rn(sum, __dmul_rn(pI, log2(pI)));
-            } else {
-                for (u32 r = rf; r < rl; r++) {
-                    u32 c = run_start[r + 1] - run_start[r];
-                    if (r == rf) c += 1;          // first flush also swallows the first read of run 1
-                    else if (r == rl - 1) c -= 1; // ... so the last run is one short (and vanishes if it was 1)
-                    if (c == 0) continue;
-                    const double pI = (double)c / (double)n;
-                    sum = __dadd_rn(sum, __dmul_rn(pI, log2(pI)));
-                }
-            }
-            ent = fabs(sum);
+            for (u32 r = rf; r < rl; r++) sum = __dadd_rn(sum, ent_term[r]);
         }
-        R.entropy = ent;
+        R.entropy = n > 1 ? fabs(sum) : 0.0;
     }
     // processJunctionWindow, junction.cc:561-649
     {
