@@ -170,6 +170,18 @@ def main():
                         traffic=None, avg_kernel_ms=round(dom["avg_ms"], 4),
                         alg_bytes_per_launch=int(dom["alg_bytes"]) if dom["alg_bytes"] else None)
         kernel_ms_per_step = sum(k["total_ms"] for k in kern) / args.steps
+        # HBM bytes per launch from the PMC counters (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 --pmc
+        # passes of this same command: tools/pmc_traffic.sh -> tools/summarize_pmc.py); counters cannot be
+        # read from inside the process, so the last committed measurement for this workload is attached
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic_latest.json")
+        if args.config == "C2" and os.path.exists(tpath):
+            try:
+                tr = json.load(open(tpath)).get("pjb::" + dom["name"])
+                if tr:
+                    roofline["traffic"] = tr["hbm_bytes_per_launch"]
+                    roofline["traffic_source"] = "profiles/pmc_traffic_latest.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"
+            except Exception:
+                pass
 
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
