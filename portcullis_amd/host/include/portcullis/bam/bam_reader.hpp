@@ -6,6 +6,7 @@
 #pragma once
 
 #include <cstdio>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -84,6 +85,13 @@ public:
     // Append up to maxRecords records of the region to `out`; false when the region is exhausted
     // and nothing was appended.
     bool nextBatch(ReadBatch& out, size_t maxRecords);
+
+    // Same visit as setRegion(tid) + nextBatch(...) but with `nthreads` workers inside the target:
+    // BGZF blocks are located from their headers, inflated in parallel into a contiguous buffer,
+    // and the records are transcoded in parallel into batches of at most maxRecords alignments,
+    // which are handed to `sink` in file order.  (The reference can only use one thread per target
+    // sequence, src/junction_builder.cc:109-112; this is SURVEY row f1, host ingest.)
+    void decodeRegionParallel(int32_t tid, int nthreads, size_t maxRecords, const std::function<void(ReadBatch&)>& sink);
 };
 
 }  // namespace bam

@@ -50,7 +50,9 @@ class JunctionBuilder {
     std::string source = DEFAULT_JUNC_SOURCE;
     bool verbose = false;
     int devices = 0;               // 0 = every visible GPU
+    int hostThreads = 0;           // 0 = use `threads`; otherwise total host decode threads
     size_t batchRecords = 1 << 20; // alignments per batch sent to the device
+    int innerThreads = 1;          // decode threads inside one target sequence (set by findJunctions)
 
     JunctionSystem junctionSystem;
     std::shared_ptr<bam::RefSeqPtrList> refs;
@@ -94,6 +96,9 @@ public:
     int getDevices() const { return devices; }
     void setDevices(int n) { devices = n; }
     void setBatchRecords(size_t n) { batchRecords = n ? n : 1; }
+    // total host decode threads, independent of the number of target sequences (the reference's
+    // --threads is capped at the number of targets; this one is not)
+    void setHostThreads(int n) { hostThreads = n; }
 
     void process();
 

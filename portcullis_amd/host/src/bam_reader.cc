@@ -1,7 +1,13 @@
 #include <portcullis/bam/bam_reader.hpp>
 
+#include <atomic>
 #include <cstring>
+#include <fcntl.h>
 #include <sstream>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <thread>
+#include <unistd.h>
 #include <zlib.h>
 
 #include "../../../include/portcullis_amd.h"
@@ -319,6 +325,239 @@ bool BamReader::nextBatch(ReadBatch& out, size_t maxRecords) {
         added++;
     }
     return added > 0;
+}
+
+// ------------------------------------------------------------------ parallel region decode
+namespace {
+
+struct Block {
+    uint64_t coff;
+    uint32_t csize, isize, xlen;
+};
+
+struct Mapped {
+    const uint8_t* p = nullptr;
+    size_t n = 0;
+    int fd = -1;
+    ~Mapped() {
+        if (p) munmap((void*)p, n);
+        if (fd >= 0) ::close(fd);
+    }
+};
+
+template <typename F>
+void parallelFor(int nthreads, size_t n, F f) {  // f(thread, begin, end) over contiguous slices
+    if (nthreads <= 1 || n < 2) {
+        f(0, (size_t)0, n);
+        return;
+    }
+    std::vector<std::thread> th;
+    const size_t per = (n + (size_t)nthreads - 1) / (size_t)nthreads;
+    for (int t = 0; t < nthreads; t++) {
+        const size_t a = std::min(n, per * (size_t)t), b = std::min(n, a + per);
+        if (a < b) th.emplace_back(f, t, a, b);
+    }
+    for (auto& x : th) x.join();
+}
+
+}  // namespace
+
+void BamReader::decodeRegionParallel(int32_t tid, int nthreads, size_t maxRecords, const std::function<void(ReadBatch&)>& sink) {
+    if (tid < 0 || (size_t)tid >= targets.size()) throw BamException("decodeRegionParallel: target out of range");
+    if (firstOffset[(size_t)tid] == ~0ull) return;
+    nthreads = std::max(1, nthreads);
+    const int32_t refLen = targets[(size_t)tid].length;
+    Mapped m;
+    m.fd = ::open(bamFile.c_str(), O_RDONLY);
+    if (m.fd < 0) throw BamException("Could not open BAM file: " + bamFile);
+    struct stat st;
+    if (fstat(m.fd, &st) != 0) throw BamException("Could not stat BAM file: " + bamFile);
+    m.n = (size_t)st.st_size;
+    m.p = (const uint8_t*)mmap(nullptr, m.n, PROT_READ, MAP_PRIVATE, m.fd, 0);
+    if (m.p == MAP_FAILED) {
+        m.p = nullptr;
+        throw BamException("Could not map BAM file: " + bamFile);
+    }
+    const uint64_t start = firstOffset[(size_t)tid];
+    // the target's records end no later than the block holding the next target's first record
+    uint64_t endCoff = m.n;
+    for (uint64_t fo : firstOffset)
+        if (fo != ~0ull && fo > start) endCoff = std::min<uint64_t>(endCoff, fo >> 16);
+    // ---- locate blocks from their headers
+    std::vector<Block> blocks;
+    for (uint64_t co = start >> 16; co < m.n;) {
+        if (co + 18 > m.n) break;
+        const uint8_t* h = m.p + co;
+        if (h[0] != 31 || h[1] != 139 || h[2] != 8 || !(h[3] & 4)) throw BamException("Invalid BGZF block header");
+        const uint32_t xlen = le16(h + 10);
+        int bsize = -1;
+        for (uint32_t o = 0; o + 4 <= xlen;) {
+            const uint8_t* x = h + 12 + o;
+            const uint32_t slen = le16(x + 2);
+            if (x[0] == 'B' && x[1] == 'C' && slen == 2) bsize = le16(x + 4);
+            o += 4 + slen;
+        }
+        if (bsize < 0) throw BamException("BGZF block without BC field");
+        const uint32_t total = (uint32_t)bsize + 1;
+        if (co + total > m.n) throw BamException("Truncated BGZF block");
+        blocks.push_back({co, total, le32(h + total - 4), xlen});
+        const bool last = co >= endCoff;  // this block may still hold the tail of the target
+        co += total;
+        if (last) break;
+    }
+    // ---- chunks of blocks
+    const uint64_t CHUNK = 192ull << 20;
+    std::vector<uint8_t> buf;
+    size_t carry = 0;
+    bool done = false, first = true;
+    std::vector<uint64_t> recOff;
+    ReadBatch batch;
+    for (size_t b0 = 0; b0 < blocks.size() && !done;) {
+        size_t b1 = b0;
+        uint64_t total = 0;
+        std::vector<uint64_t> uoff;
+        while (b1 < blocks.size() && (total == 0 || total + blocks[b1].isize <= CHUNK)) {
+            uoff.push_back(total);
+            total += blocks[b1].isize;
+            b1++;
+        }
+        buf.resize(carry + total);
+        {
+            std::atomic<size_t> next(b0);
+            std::atomic<bool> bad(false);
+            uint8_t* base = buf.data() + carry;
+            auto work = [&](int, size_t, size_t) {
+                for (;;) {
+                    const size_t b = next.fetch_add(1);
+                    if (b >= b1) break;
+                    const Block& k = blocks[b];
+                    if (!k.isize) continue;
+                    z_stream zs;
+                    memset(&zs, 0, sizeof zs);
+                    if (inflateInit2(&zs, -15) != Z_OK) {
+                        bad = true;
+                        break;
+                    }
+                    zs.next_in = const_cast<uint8_t*>(m.p + k.coff + 12 + k.xlen);
+                    zs.avail_in = k.csize - 12 - k.xlen - 8;
+                    zs.next_out = base + uoff[b - b0];
+                    zs.avail_out = k.isize;
+                    const int rc = inflate(&zs, Z_FINISH);
+                    inflateEnd(&zs);
+                    if (rc != Z_STREAM_END || zs.avail_out != 0) bad = true;
+                }
+            };
+            if (nthreads <= 1) work(0, 0, 0);
+            else {
+                std::vector<std::thread> th;
+                for (int t = 0; t < nthreads; t++) th.emplace_back(work, t, (size_t)0, (size_t)0);
+                for (auto& x : th) x.join();
+            }
+            if (bad) throw BamException("BGZF inflate failed");
+        }
+        // ---- record boundaries (sequential chain of block_size fields)
+        size_t cur = first ? (size_t)(start & 0xffff) : 0;
+        first = false;
+        const size_t end = buf.size();
+        recOff.clear();
+        while (cur + 4 <= end) {
+            const uint32_t bs = le32(&buf[cur]);
+            if (bs < 32) throw BamException("Invalid BAM record");
+            if (cur + 4 + bs > end) break;
+            const int32_t rt = (int32_t)le32(&buf[cur + 4]), rp = (int32_t)le32(&buf[cur + 8]);
+            if (rt != tid || rp >= refLen) {
+                done = true;
+                break;
+            }
+            recOff.push_back(cur);
+            cur += 4 + (size_t)bs;
+        }
+        // ---- transcode in batches of maxRecords, in parallel inside a batch
+        for (size_t r0 = 0; r0 < recOff.size(); r0 += maxRecords) {
+            const size_t r1 = std::min(recOff.size(), r0 + maxRecords), n = r1 - r0;
+            std::vector<uint64_t> nOps((size_t)nthreads + 1, 0), nWords((size_t)nthreads + 1, 0), nSkip((size_t)nthreads + 1, 0);
+            std::vector<size_t> lo((size_t)nthreads + 1, n), hi((size_t)nthreads + 1, n);
+            parallelFor(nthreads, n, [&](int t, size_t a, size_t b) {
+                uint64_t ops = 0, words = 0, skips = 0;
+                for (size_t i = a; i < b; i++) {
+                    const uint8_t* r = &buf[recOff[r0 + i] + 4];
+                    const uint32_t l_name = r[8], n_cig = le16(r + 12);
+                    const int32_t l_seq = (int32_t)le32(r + 16);
+                    const uint8_t* cg = r + 32 + l_name;
+                    bool spl = false;
+                    for (uint32_t k = 0; k < n_cig; k++)
+                        if ((cg[4 * k] & 15u) == 3u) {
+                            spl = true;
+                            skips++;
+                        }
+                    ops += n_cig;
+                    if (spl && l_seq > 0) words += ((size_t)((l_seq + 1) / 2) + 3) / 4;
+                }
+                nOps[(size_t)t + 1] = ops;
+                nWords[(size_t)t + 1] = words;
+                nSkip[(size_t)t + 1] = skips;
+                lo[(size_t)t] = a;
+                hi[(size_t)t] = b;
+            });
+            for (int t = 0; t < nthreads; t++) {
+                nOps[(size_t)t + 1] += nOps[(size_t)t];
+                nWords[(size_t)t + 1] += nWords[(size_t)t];
+                nSkip[(size_t)t + 1] += nSkip[(size_t)t];
+            }
+            batch.pos.resize(n); batch.flag.resize(n); batch.mapq.resize(n); batch.xs.resize(n); batch.l_qseq.resize(n);
+            batch.mtid.resize(n); batch.mpos.resize(n);
+            batch.cig_off.resize(n + 1);
+            batch.seq_off.resize(n + 1);
+            batch.cigar.resize(nOps[(size_t)nthreads]);
+            batch.seq4.assign(nWords[(size_t)nthreads] * 4, 0);
+            batch.n_refskip = nSkip[(size_t)nthreads];
+            std::atomic<bool> badRec(false);
+            parallelFor(nthreads, n, [&](int t, size_t a, size_t b) {
+                uint64_t co = nOps[(size_t)t], so = nWords[(size_t)t];
+                for (size_t i = a; i < b; i++) {
+                    const size_t off = recOff[r0 + i];
+                    const uint32_t bs = le32(&buf[off]);
+                    const uint8_t* r = &buf[off + 4];
+                    const uint32_t l_name = r[8], n_cig = le16(r + 12);
+                    const int32_t l_seq = (int32_t)le32(r + 16);
+                    const size_t cig_at = 32 + l_name, seq_at = cig_at + 4ull * n_cig;
+                    const size_t seq_bytes = (size_t)((l_seq + 1) / 2);
+                    const size_t aux_at = seq_at + seq_bytes + (size_t)(l_seq > 0 ? l_seq : 0);
+                    if (l_seq < 0 || aux_at > bs) {
+                        badRec = true;
+                        return;
+                    }
+                    batch.pos[i] = (int32_t)le32(r + 4);
+                    batch.mapq[i] = r[9];
+                    batch.flag[i] = le16(r + 14);
+                    batch.l_qseq[i] = l_seq;
+                    batch.mtid[i] = (int32_t)le32(r + 20);
+                    batch.mpos[i] = (int32_t)le32(r + 24);
+                    batch.xs[i] = xsCode(r + aux_at, r + bs);
+                    batch.cig_off[i] = (uint32_t)co;
+                    batch.seq_off[i] = (uint32_t)so;
+                    bool spl = false;
+                    for (uint32_t k = 0; k < n_cig; k++) {
+                        const uint32_t op = le32(r + cig_at + 4 * k);
+                        batch.cigar[co++] = op;
+                        spl |= (op & 15u) == 3u;
+                    }
+                    if (spl && seq_bytes) {
+                        memcpy(&batch.seq4[so * 4], r + seq_at, seq_bytes);
+                        so += (seq_bytes + 3) / 4;
+                    }
+                }
+            });
+            if (badRec) throw BamException("Invalid BAM record layout");
+            batch.cig_off[n] = (uint32_t)nOps[(size_t)nthreads];
+            batch.seq_off[n] = (uint32_t)nWords[(size_t)nthreads];
+            sink(batch);
+        }
+        // ---- carry the partial record at the end of the chunk
+        carry = done ? 0 : end - cur;
+        if (carry) memmove(buf.data(), buf.data() + cur, carry);
+        b0 = b1;
+    }
 }
 
 }  // namespace bam

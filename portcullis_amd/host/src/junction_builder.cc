@@ -80,6 +80,7 @@ void JunctionBuilder::process() {
     reader.close();
     junctionSystem = JunctionSystem();
     junctionSystem.setRefs(refs);
+    if (hostThreads == 0) hostThreads = threads;  // total decode threads survive the per-target cap below
     if (refs->size() < threads) {
         cerr << "Warning: User requested " << threads << " threads but there are only " << refs->size()
              << " target sequences to process.  Setting number of threads to " << refs->size() << "." << endl << endl;
@@ -118,14 +119,9 @@ void JunctionBuilder::findJuncs(void* deviceContext, BamReader& reader, GenomeMa
     pjb_ctx* ctx = (pjb_ctx*)deviceContext;
     RegionResult& res = results[(size_t)seq];
     if (!reader.hasAlignments(seq)) return;  // nothing placed on this target: counters keep their neutral values
-    reader.setRegion(seq);
-    bam::ReadBatch batch;
     bool uploaded = false;
     bool any = false;
-    while (true) {
-        batch.clear();
-        batch.reserve(batchRecords);
-        if (!reader.nextBatch(batch, batchRecords)) break;
+    auto submit = [&](bam::ReadBatch& batch) {
         any = true;
         if (!uploaded) {
             const std::string contig = gmap.fetchContig(refs->at((size_t)seq)->name);
@@ -139,6 +135,18 @@ void JunctionBuilder::findJuncs(void* deviceContext, BamReader& reader, GenomeMa
         pjb_batch pb;
         batch.view(pb);
         pjbCheck(ctx, pjb_submit_batch(ctx, seq, &pb), "pjb_submit_batch");
+    };
+    if (innerThreads > 1) {
+        reader.decodeRegionParallel(seq, innerThreads, batchRecords, submit);
+    } else {
+        reader.setRegion(seq);
+        bam::ReadBatch batch;
+        while (true) {
+            batch.clear();
+            batch.reserve(batchRecords);
+            if (!reader.nextBatch(batch, batchRecords)) break;
+            submit(batch);
+        }
     }
     if (!any) return;
     pjb_region_result rr;
@@ -164,7 +172,17 @@ void JunctionBuilder::findJunctions() {
     if (visible <= 0)
         throw JunctionBuilderException("No MI355X (HIP device) is visible: the junc hot path runs on the GPU and has no CPU fallback");
     int ndev = devices > 0 ? std::min(devices, visible) : visible;
-    const int nthreads = std::max<int>(1, threads);
+    // `threads` host threads in total: one worker per target sequence in flight, the rest decode
+    // inside the targets (a single big contig still uses every thread)
+    int withReads = 0;
+    {
+        BamReader probe(prepData.getSortedBamFilePath());
+        probe.open(useCsi);
+        for (size_t i = 0; i < refs->size(); i++) withReads += probe.hasAlignments((int32_t)i) ? 1 : 0;
+    }
+    const int total = std::max<int>(1, hostThreads > 0 ? hostThreads : threads);
+    const int nthreads = std::max(1, std::min(total, std::max(1, withReads)));
+    innerThreads = std::max(1, total / nthreads);
     ndev = std::min(ndev, nthreads);
     cout << "Creating " << nthreads << " threads, each with BAM and genome indicies loaded, on " << ndev << " GPU(s) ...";
     cout.flush();
@@ -264,6 +282,7 @@ void JunctionBuilder::findJunctions() {
 int JunctionBuilder::main(int argc, char* argv[]) {
     std::string prepDir, output = DEFAULT_JUNC_OUTPUT, source = DEFAULT_JUNC_SOURCE, ori = "UNKNOWN", strand = "UNKNOWN";
     int threads = DEFAULT_JUNC_THREADS, devices = 0;
+    size_t batch = 0;
     bool extra = false, separate = false, useCsi = false, exonGff = false, intronGff = false, verbose = false, help = false;
     auto need = [&](int& i) -> std::string {
         if (i + 1 >= argc) throw JunctionBuilderException(std::string("Missing value for option ") + argv[i]);
@@ -277,6 +296,7 @@ int JunctionBuilder::main(int argc, char* argv[]) {
         else if (a == "--strandedness") strand = need(i);
         else if (a == "--source") source = need(i);
         else if (a == "--devices") devices = atoi(need(i).c_str());
+        else if (a == "--batch") batch = (size_t)atol(need(i).c_str());
         else if (a == "--separate") separate = true;
         else if (a == "--extra") extra = true;
         else if (a == "-c" || a == "--use_csi") useCsi = true;
@@ -315,6 +335,7 @@ int JunctionBuilder::main(int argc, char* argv[]) {
     jb.setOrientation(bam::orientationFromString(ori));
     jb.setStrandSpecific(bam::strandednessFromString(strand));
     if (devices > 0) jb.setDevices(devices);
+    if (batch > 0) jb.setBatchRecords(batch);
     jb.process();
     return 0;
 }

@@ -130,3 +130,25 @@ def test_tab_roundtrip_loads(tmp_path, orc):
     p, exp = check(prep, tmp_path, orc)
     lines = exp["tab"].decode(errors="replace").split("\n")
     assert lines[0].split("\t")[0] == "index" and all(len(l.split("\t")) == 75 for l in lines[:-2])
+
+
+def test_e2e_synthetic_parallel_decode(tmp_path):
+    """A 200k-read single-contig BAM decoded with 4 threads inside the contig (block-parallel
+    inflate + parallel transcode, bam_reader.cc decodeRegionParallel) must give the oracle's .tab."""
+    import json
+    import sys
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "e2e_bench.py"), "--config", "C2-small", "--threads", "4",
+                        "--workdir", str(tmp_path / "e2e"), "--repeat", "1"], capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    res = json.loads(p.stdout.strip().split("\n")[-1])
+    assert res["tab_identical_to_oracle"] and res["junctions"] > 900
+
+
+def test_e2e_synthetic_multi_contig(tmp_path):
+    import json
+    import sys
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "e2e_bench.py"), "--config", "C2-tiny", "--threads", "6",
+                        "--contigs", "3", "--workdir", str(tmp_path / "e2e"), "--repeat", "1"], capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    res = json.loads(p.stdout.strip().split("\n")[-1])
+    assert res["tab_identical_to_oracle"]
