@@ -56,6 +56,7 @@ class BamReader {
     std::string headerText;
     std::vector<RefSeq> targets;
     std::vector<uint64_t> firstOffset;  // per target: virtual offset of its first record, ~0 = none
+    std::vector<std::vector<uint64_t>> restart;  // per target: sorted virtual offsets the index names (all are record starts)
     bool indexLoaded = false;
     int32_t regionTid = -1;
     int32_t regionLen = 0;

@@ -1,6 +1,8 @@
 #include <portcullis/bam/bam_reader.hpp>
 
+#include <algorithm>
 #include <atomic>
+#include <memory>
 #include <cstring>
 #include <fcntl.h>
 #include <sstream>
@@ -177,7 +179,9 @@ void BamReader::loadIndex(bool useCsi) {
     const uint32_t n_ref = le32(&buf[o]);
     o += 4;
     firstOffset.assign(targets.size(), ~0ull);
+    restart.assign(targets.size(), std::vector<uint64_t>());
     for (uint32_t r = 0; r < n_ref; r++) {
+        std::vector<uint64_t> pts;
         if (o + 4 > buf.size()) throw BamException("Truncated BAI index");
         const uint32_t n_bin = le32(&buf[o]);
         o += 4;
@@ -189,13 +193,28 @@ void BamReader::loadIndex(bool useCsi) {
             o += 8;
             if (o + 16ull * n_chunk > buf.size()) throw BamException("Truncated BAI index");
             if (bin != 37450)  // pseudo-bin holding metadata, not chunks
-                for (uint32_t c = 0; c < n_chunk; c++) first = std::min(first, le64(&buf[o + 16 * c]));
+                for (uint32_t c = 0; c < n_chunk; c++) {
+                    const uint64_t v = le64(&buf[o + 16 * c]);
+                    first = std::min(first, v);
+                    pts.push_back(v);
+                }
             o += 16ull * n_chunk;
         }
         if (o + 4 > buf.size()) throw BamException("Truncated BAI index");
         const uint32_t n_intv = le32(&buf[o]);
-        o += 4 + 8ull * n_intv;
-        if (r < firstOffset.size()) firstOffset[r] = first;
+        o += 4;
+        if (o + 8ull * n_intv > buf.size()) throw BamException("Truncated BAI index");
+        for (uint32_t k = 0; k < n_intv; k++) {
+            const uint64_t v = le64(&buf[o + 8ull * k]);
+            if (v) pts.push_back(v);  // first alignment overlapping each 16 kb window
+        }
+        o += 8ull * n_intv;
+        if (r < firstOffset.size()) {
+            firstOffset[r] = first;
+            std::sort(pts.begin(), pts.end());
+            pts.erase(std::unique(pts.begin(), pts.end()), pts.end());
+            restart[r] = std::move(pts);
+        }
     }
     indexLoaded = true;
 }
@@ -405,13 +424,22 @@ void BamReader::decodeRegionParallel(int32_t tid, int nthreads, size_t maxRecord
         co += total;
         if (last) break;
     }
-    // ---- chunks of blocks
-    const uint64_t CHUNK = 192ull << 20;
-    std::vector<uint8_t> buf;
+    // ---- chunks of blocks: one chunk = one batch.  Each chunk is inflated in parallel, then split
+    // at record starts named by the index (chunk begins / linear index) so that the block_size
+    // chain -- a pointer chase through DRAM -- is walked by all threads at once.
+    const uint64_t CHUNK = std::min<uint64_t>(256ull << 20, std::max<uint64_t>(64ull << 10, (uint64_t)maxRecords * 192ull));
+    const std::vector<uint64_t>& rpts = restart[(size_t)tid];
+    size_t bufCap = 0;
+    std::unique_ptr<uint8_t[]> buf;  // raw storage: no zero fill
     size_t carry = 0;
     bool done = false, first = true;
-    std::vector<uint64_t> recOff;
     ReadBatch batch;
+    struct Slice {
+        std::vector<uint64_t> off;
+        uint64_t ops = 0, words = 0, skips = 0;
+        size_t stop = 0;  // where the walk stopped
+        bool ended = false, bad = false;
+    };
     for (size_t b0 = 0; b0 < blocks.size() && !done;) {
         size_t b1 = b0;
         uint64_t total = 0;
@@ -421,11 +449,18 @@ void BamReader::decodeRegionParallel(int32_t tid, int nthreads, size_t maxRecord
             total += blocks[b1].isize;
             b1++;
         }
-        buf.resize(carry + total);
+        const size_t end = carry + total;
+        if (end + 8 > bufCap) {
+            const size_t ncap = std::max<size_t>(end + 8, (size_t)CHUNK + (4u << 20));
+            std::unique_ptr<uint8_t[]> nb(new uint8_t[ncap]);
+            if (carry) memcpy(nb.get(), buf.get(), carry);
+            buf.swap(nb);
+            bufCap = ncap;
+        }
         {
             std::atomic<size_t> next(b0);
             std::atomic<bool> bad(false);
-            uint8_t* base = buf.data() + carry;
+            uint8_t* base = buf.get() + carry;
             auto work = [&](int, size_t, size_t) {
                 for (;;) {
                     const size_t b = next.fetch_add(1);
@@ -447,77 +482,130 @@ void BamReader::decodeRegionParallel(int32_t tid, int nthreads, size_t maxRecord
                     if (rc != Z_STREAM_END || zs.avail_out != 0) bad = true;
                 }
             };
-            if (nthreads <= 1) work(0, 0, 0);
+            const int nt = (int)std::min<size_t>((size_t)nthreads, b1 - b0);
+            if (nt <= 1) work(0, 0, 0);
             else {
                 std::vector<std::thread> th;
-                for (int t = 0; t < nthreads; t++) th.emplace_back(work, t, (size_t)0, (size_t)0);
+                for (int t = 0; t < nt; t++) th.emplace_back(work, t, (size_t)0, (size_t)0);
                 for (auto& x : th) x.join();
             }
             if (bad) throw BamException("BGZF inflate failed");
         }
-        // ---- record boundaries (sequential chain of block_size fields)
-        size_t cur = first ? (size_t)(start & 0xffff) : 0;
+        // ---- split points inside this chunk
+        const size_t cur0 = first ? (size_t)(start & 0xffff) : 0;
         first = false;
-        const size_t end = buf.size();
-        recOff.clear();
-        while (cur + 4 <= end) {
-            const uint32_t bs = le32(&buf[cur]);
-            if (bs < 32) throw BamException("Invalid BAM record");
-            if (cur + 4 + bs > end) break;
-            const int32_t rt = (int32_t)le32(&buf[cur + 4]), rp = (int32_t)le32(&buf[cur + 8]);
-            if (rt != tid || rp >= refLen) {
+        std::vector<size_t> pts;
+        pts.push_back(cur0);
+        {
+            const uint64_t vlo = blocks[b0].coff << 16, vhi = ((blocks[b1 - 1].coff + 1) << 16);
+            auto it = std::lower_bound(rpts.begin(), rpts.end(), vlo);
+            size_t bi = b0;
+            for (; it != rpts.end() && *it < vhi; ++it) {
+                const uint64_t co = *it >> 16;
+                while (bi < b1 && blocks[bi].coff < co) bi++;
+                if (bi >= b1 || blocks[bi].coff != co) continue;  // not a block start we know: ignore
+                const size_t p = carry + (size_t)uoff[bi - b0] + (size_t)(*it & 0xffff);
+                if (p > pts.back() && p + 36 <= end) pts.push_back(p);
+            }
+        }
+        // thin the points to at most nthreads slices of similar byte size
+        std::vector<size_t> cut;
+        {
+            const int want = std::max(1, std::min<int>(nthreads, (int)pts.size()));
+            cut.push_back(pts[0]);
+            for (int k = 1; k < want; k++) {
+                const size_t target = cur0 + (size_t)((double)(end - cur0) * k / want);
+                auto it = std::lower_bound(pts.begin(), pts.end(), target);
+                if (it != pts.end() && *it > cut.back()) cut.push_back(*it);
+            }
+        }
+        const size_t ns = cut.size();
+        std::vector<Slice> sl(ns);
+        auto walk = [&](int t, size_t, size_t) {
+            Slice& S = sl[(size_t)t];
+            const size_t limit = (size_t)t + 1 < ns ? cut[(size_t)t + 1] : end;
+            const bool lastSlice = (size_t)t + 1 == ns;
+            S.off.reserve((limit - cut[(size_t)t]) / 160 + 16);
+            size_t cur = cut[(size_t)t];
+            const uint8_t* B = buf.get();
+            while (cur < limit) {
+                if (cur + 4 > end) break;
+                const uint32_t bs = le32(B + cur);
+                if (bs < 32) {
+                    S.bad = true;
+                    break;
+                }
+                if (cur + 4 + (size_t)bs > end) break;  // partial record at the end of the chunk
+                const uint8_t* r = B + cur + 4;
+                const int32_t rt = (int32_t)le32(r), rp = (int32_t)le32(r + 4);
+                if (rt != tid || rp >= refLen) {
+                    S.ended = true;
+                    break;
+                }
+                const uint32_t l_name = r[8], n_cig = le16(r + 12);
+                const int32_t l_seq = (int32_t)le32(r + 16);
+                if (32 + (size_t)l_name + 4ull * n_cig > bs) {
+                    S.bad = true;
+                    break;
+                }
+                const uint8_t* cg = r + 32 + l_name;
+                bool spl = false;
+                for (uint32_t k = 0; k < n_cig; k++)
+                    if ((cg[4 * k] & 15u) == 3u) {
+                        spl = true;
+                        S.skips++;
+                    }
+                S.ops += n_cig;
+                if (spl && l_seq > 0) S.words += ((size_t)((l_seq + 1) / 2) + 3) / 4;
+                S.off.push_back(cur);
+                cur += 4 + (size_t)bs;
+            }
+            if (!lastSlice && !S.ended && !S.bad && cur != limit) S.bad = true;  // the index named a non-boundary
+            S.stop = cur;
+        };
+        if (ns <= 1) walk(0, 0, 0);
+        else {
+            std::vector<std::thread> th;
+            for (size_t t = 0; t < ns; t++) th.emplace_back(walk, (int)t, (size_t)0, (size_t)0);
+            for (auto& x : th) x.join();
+        }
+        // ---- assemble the batch: prefix sums over slices (stop at the first slice that saw the end)
+        size_t nsUse = 0, nrec = 0;
+        std::vector<uint64_t> recBase(ns + 1, 0), opBase(ns + 1, 0), wordBase(ns + 1, 0);
+        uint64_t skips = 0;
+        size_t stopAt = end;
+        for (size_t t = 0; t < ns; t++) {
+            if (sl[t].bad) throw BamException("Invalid BAM record (or the index names an offset that is not a record start)");
+            nsUse = t + 1;
+            recBase[t + 1] = recBase[t] + sl[t].off.size();
+            opBase[t + 1] = opBase[t] + sl[t].ops;
+            wordBase[t + 1] = wordBase[t] + sl[t].words;
+            skips += sl[t].skips;
+            stopAt = sl[t].stop;
+            if (sl[t].ended) {
                 done = true;
                 break;
             }
-            recOff.push_back(cur);
-            cur += 4 + (size_t)bs;
         }
-        // ---- transcode in batches of maxRecords, in parallel inside a batch
-        for (size_t r0 = 0; r0 < recOff.size(); r0 += maxRecords) {
-            const size_t r1 = std::min(recOff.size(), r0 + maxRecords), n = r1 - r0;
-            std::vector<uint64_t> nOps((size_t)nthreads + 1, 0), nWords((size_t)nthreads + 1, 0), nSkip((size_t)nthreads + 1, 0);
-            std::vector<size_t> lo((size_t)nthreads + 1, n), hi((size_t)nthreads + 1, n);
-            parallelFor(nthreads, n, [&](int t, size_t a, size_t b) {
-                uint64_t ops = 0, words = 0, skips = 0;
-                for (size_t i = a; i < b; i++) {
-                    const uint8_t* r = &buf[recOff[r0 + i] + 4];
-                    const uint32_t l_name = r[8], n_cig = le16(r + 12);
-                    const int32_t l_seq = (int32_t)le32(r + 16);
-                    const uint8_t* cg = r + 32 + l_name;
-                    bool spl = false;
-                    for (uint32_t k = 0; k < n_cig; k++)
-                        if ((cg[4 * k] & 15u) == 3u) {
-                            spl = true;
-                            skips++;
-                        }
-                    ops += n_cig;
-                    if (spl && l_seq > 0) words += ((size_t)((l_seq + 1) / 2) + 3) / 4;
-                }
-                nOps[(size_t)t + 1] = ops;
-                nWords[(size_t)t + 1] = words;
-                nSkip[(size_t)t + 1] = skips;
-                lo[(size_t)t] = a;
-                hi[(size_t)t] = b;
-            });
-            for (int t = 0; t < nthreads; t++) {
-                nOps[(size_t)t + 1] += nOps[(size_t)t];
-                nWords[(size_t)t + 1] += nWords[(size_t)t];
-                nSkip[(size_t)t + 1] += nSkip[(size_t)t];
-            }
+        nrec = (size_t)recBase[nsUse];
+        if (nrec) {
+            const size_t n = nrec;
             batch.pos.resize(n); batch.flag.resize(n); batch.mapq.resize(n); batch.xs.resize(n); batch.l_qseq.resize(n);
             batch.mtid.resize(n); batch.mpos.resize(n);
             batch.cig_off.resize(n + 1);
             batch.seq_off.resize(n + 1);
-            batch.cigar.resize(nOps[(size_t)nthreads]);
-            batch.seq4.assign(nWords[(size_t)nthreads] * 4, 0);
-            batch.n_refskip = nSkip[(size_t)nthreads];
+            batch.cigar.resize(opBase[nsUse]);
+            batch.seq4.resize(wordBase[nsUse] * 4);
+            batch.n_refskip = skips;
             std::atomic<bool> badRec(false);
-            parallelFor(nthreads, n, [&](int t, size_t a, size_t b) {
-                uint64_t co = nOps[(size_t)t], so = nWords[(size_t)t];
-                for (size_t i = a; i < b; i++) {
-                    const size_t off = recOff[r0 + i];
-                    const uint32_t bs = le32(&buf[off]);
-                    const uint8_t* r = &buf[off + 4];
+            auto fill = [&](int t, size_t, size_t) {
+                const Slice& S = sl[(size_t)t];
+                uint64_t co = opBase[(size_t)t], so = wordBase[(size_t)t];
+                size_t i = (size_t)recBase[(size_t)t];
+                const uint8_t* B = buf.get();
+                for (uint64_t off : S.off) {
+                    const uint32_t bs = le32(B + off);
+                    const uint8_t* r = B + off + 4;
                     const uint32_t l_name = r[8], n_cig = le16(r + 12);
                     const int32_t l_seq = (int32_t)le32(r + 16);
                     const size_t cig_at = 32 + l_name, seq_at = cig_at + 4ull * n_cig;
@@ -543,19 +631,28 @@ void BamReader::decodeRegionParallel(int32_t tid, int nthreads, size_t maxRecord
                         spl |= (op & 15u) == 3u;
                     }
                     if (spl && seq_bytes) {
+                        const size_t w = (seq_bytes + 3) / 4;
+                        memset(&batch.seq4[(so + w - 1) * 4], 0, 4);  // zero the padding of the last word
                         memcpy(&batch.seq4[so * 4], r + seq_at, seq_bytes);
-                        so += (seq_bytes + 3) / 4;
+                        so += w;
                     }
+                    i++;
                 }
-            });
+            };
+            if (nsUse <= 1) fill(0, 0, 0);
+            else {
+                std::vector<std::thread> th;
+                for (size_t t = 0; t < nsUse; t++) th.emplace_back(fill, (int)t, (size_t)0, (size_t)0);
+                for (auto& x : th) x.join();
+            }
             if (badRec) throw BamException("Invalid BAM record layout");
-            batch.cig_off[n] = (uint32_t)nOps[(size_t)nthreads];
-            batch.seq_off[n] = (uint32_t)nWords[(size_t)nthreads];
+            batch.cig_off[n] = (uint32_t)opBase[nsUse];
+            batch.seq_off[n] = (uint32_t)wordBase[nsUse];
             sink(batch);
         }
         // ---- carry the partial record at the end of the chunk
-        carry = done ? 0 : end - cur;
-        if (carry) memmove(buf.data(), buf.data() + cur, carry);
+        carry = done ? 0 : end - stopAt;
+        if (carry) memmove(buf.get(), buf.get() + stopAt, carry);
         b0 = b1;
     }
 }

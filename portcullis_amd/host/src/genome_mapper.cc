@@ -1,6 +1,8 @@
 #include <portcullis/bam/genome_mapper.hpp>
 
+#include <algorithm>
 #include <cctype>
+#include <cstring>
 #include <cstdio>
 #include <fstream>
 #include <sstream>
@@ -84,6 +86,45 @@ std::string GenomeMapper::readSpan(const Entry& e, int64_t beg, int64_t count) c
     const int64_t maxBytes = count + lines * (e.line_len - e.line_blen) + 2;
     std::string buf((size_t)maxBytes, 0);
     const size_t got = fread(&buf[0], 1, (size_t)maxBytes, fp);
+    // fast path: well-formed lines (line_blen graphic characters, then the terminator) are copied
+    // line by line; anything else falls back to the character filter faidx applies
+    {
+        out.resize((size_t)count);
+        size_t i = 0, o = 0;
+        int64_t col = beg % e.line_blen;
+        bool ok = true;
+        while (o < (size_t)count && ok) {
+            const size_t take = std::min<size_t>((size_t)(e.line_blen - col), (size_t)count - o);
+            if (i + take > got) {
+                ok = false;
+                break;
+            }
+            const char* src = &buf[i];
+            unsigned char acc_lo = 0xff, acc_hi = 0;
+            for (size_t k = 0; k < take; k++) {
+                const unsigned char ch = (unsigned char)src[k];
+                acc_lo = ch < acc_lo ? ch : acc_lo;
+                acc_hi = ch > acc_hi ? ch : acc_hi;
+            }
+            if (acc_lo <= 32 || acc_hi >= 127) {
+                ok = false;
+                break;
+            }
+            memcpy(&out[o], src, take);
+            o += take;
+            i += take;
+            if (o < (size_t)count) {
+                // skip the line terminator (line_len - line_blen bytes, none of them graphic)
+                const size_t term = (size_t)(e.line_len - e.line_blen);
+                for (size_t k = 0; k < term; k++)
+                    if (i + k >= got || isgraph((unsigned char)buf[i + k])) ok = false;
+                i += term;
+            }
+            col = 0;
+        }
+        if (ok) return out;
+    }
+    out.clear();
     for (size_t i = 0; i < got && (int64_t)out.size() < count; i++)
         if (isgraph((unsigned char)buf[i])) out.push_back(buf[i]);
     return out;

@@ -110,6 +110,16 @@ void JunctionBuilder::process() {
         cerr << "Warning!  User input and portcullis disagree about the strandedness of the dataset" << endl << endl;
 }
 
+namespace {
+struct HostProfile {  // PJB_PROFILE_HOST=1: where the host side of findJuncs spends its time
+    bool on = getenv("PJB_PROFILE_HOST") != nullptr;
+    std::mutex mu;
+    double genome = 0, submit = 0, finish = 0, total = 0;
+    static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+};
+HostProfile g_prof;
+}  // namespace
+
 static void pjbCheck(pjb_ctx* c, int rc, const char* what) {
     if (rc != PJB_OK) throw JunctionBuilderException(std::string(what) + ": " + pjb_last_error(c) + " (code " + std::to_string(rc) + ")");
 }
@@ -121,8 +131,11 @@ void JunctionBuilder::findJuncs(void* deviceContext, BamReader& reader, GenomeMa
     if (!reader.hasAlignments(seq)) return;  // nothing placed on this target: counters keep their neutral values
     bool uploaded = false;
     bool any = false;
+    const double t_begin = HostProfile::now();
+    double t_genome = 0, t_submit = 0;
     auto submit = [&](bam::ReadBatch& batch) {
         any = true;
+        const double t0 = HostProfile::now();
         if (!uploaded) {
             const std::string contig = gmap.fetchContig(refs->at((size_t)seq)->name);
             if ((int64_t)contig.size() != refs->at((size_t)seq)->length)
@@ -131,10 +144,13 @@ void JunctionBuilder::findJuncs(void* deviceContext, BamReader& reader, GenomeMa
                                                std::to_string(refs->at((size_t)seq)->length));
             pjbCheck(ctx, pjb_upload_contig(ctx, seq, (const uint8_t*)contig.data(), (int64_t)contig.size()), "pjb_upload_contig");
             uploaded = true;
+            t_genome += HostProfile::now() - t0;
         }
+        const double t1 = HostProfile::now();
         pjb_batch pb;
         batch.view(pb);
         pjbCheck(ctx, pjb_submit_batch(ctx, seq, &pb), "pjb_submit_batch");
+        t_submit += HostProfile::now() - t1;
     };
     if (innerThreads > 1) {
         reader.decodeRegionParallel(seq, innerThreads, batchRecords, submit);
@@ -149,6 +165,7 @@ void JunctionBuilder::findJuncs(void* deviceContext, BamReader& reader, GenomeMa
         }
     }
     if (!any) return;
+    const double t_fin0 = HostProfile::now();
     pjb_region_result rr;
     pjbCheck(ctx, pjb_finish_contig(ctx, seq, &rr), "pjb_finish_contig");
     const pjb_junction_row* rows = nullptr;
@@ -162,6 +179,17 @@ void JunctionBuilder::findJuncs(void* deviceContext, BamReader& reader, GenomeMa
     res.sumQueryLengths = rr.sum_len;
     res.minQueryLength = rr.min_len;
     res.maxQueryLength = rr.max_len;
+    if (g_prof.on) {
+        const double t_end = HostProfile::now();
+        std::lock_guard<std::mutex> lk(g_prof.mu);
+        g_prof.genome += t_genome;
+        g_prof.submit += t_submit;
+        g_prof.finish += t_end - t_fin0;
+        g_prof.total += t_end - t_begin;
+        cerr << "[host profile] " << refs->at((size_t)seq)->name << ": total " << (t_end - t_begin) << " s = genome " << t_genome
+             << " + submit(H2D) " << t_submit << " + finish+rows " << (t_end - t_fin0) << " + decode "
+             << (t_end - t_begin - t_genome - t_submit - (t_end - t_fin0)) << endl;
+    }
 }
 
 void JunctionBuilder::findJunctions() {
