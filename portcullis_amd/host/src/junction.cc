@@ -267,7 +267,7 @@ void Junction::outputIntronGFF(std::ostream& strm, const std::string& source) co
          << "mult=" << nbAlRaw << ";"
          << "grp=" << juncId << ";"
          << "src=E";
-    strm << std::endl;
+    strm << "\n";
 }
 
 void Junction::outputJunctionGFF(std::ostream& strm, const std::string& source) const {
@@ -288,7 +288,7 @@ void Junction::outputJunctionGFF(std::ostream& strm, const std::string& source) 
          << "grp=" << juncId << ";"
          << "src=E;";
     condensedOutputDescription(strm, ";");
-    strm << std::endl;
+    strm << "\n";
     strm << intron->ref.name << "\t" << source << "\t"
          << "match_part"
          << "\t" << leftAncStart + 1 << "\t" << (intron->start) << "\t"
@@ -298,7 +298,7 @@ void Junction::outputJunctionGFF(std::ostream& strm, const std::string& source) 
          << "\t"
          << "ID=" << juncId << "_left"
          << ";"
-         << "Parent=" << juncId << std::endl;
+         << "Parent=" << juncId << "\n";
     strm << intron->ref.name << "\t" << source << "\t"
          << "match_part"
          << "\t" << (intron->end + 2) << "\t" << rightAncEnd + 1 << "\t"
@@ -308,7 +308,7 @@ void Junction::outputJunctionGFF(std::ostream& strm, const std::string& source) 
          << "\t"
          << "ID=" << juncId << "_right"
          << ";"
-         << "Parent=" << juncId << std::endl;
+         << "Parent=" << juncId << "\n";
 }
 
 void Junction::outputBED(std::ostream& strm, const std::string& prefix, bool bedscore) const {
@@ -326,7 +326,7 @@ void Junction::outputBED(std::ostream& strm, const std::string& prefix, bool bed
          << "255,0,0"
          << "\t"
          << "2"
-         << "\t" << blockSizes << "\t" << blockStarts << std::endl;
+         << "\t" << blockSizes << "\t" << blockStarts << "\n";
 }
 
 static std::vector<std::string> splitTabsCompress(const std::string& line) {

@@ -33,6 +33,7 @@ class SynthConfig:
     spliced_frac: float = 0.30
     zipf_s: float = 1.1
     seed: int = 20260101
+    paired: bool = False   # FR paired-end flags / mate fields (BASELINE configs[2..4])
 
 
 CONFIGS = {
@@ -40,6 +41,8 @@ CONFIGS = {
     "C2": SynthConfig(),
     "C2-small": SynthConfig("C2-small", 2_000_000, 200_000, 1_000, 100),
     "C2-tiny": SynthConfig("C2-tiny", 200_000, 20_000, 120, 100),
+    # scaled-down shape of BASELINE configs[2]: paired-end 150-bp reads; used per contig by the multi-contig tests
+    "C3-contig": SynthConfig("C3-contig", 1_000_000, 60_000, 400, 150, paired=True),
 }
 
 
@@ -51,7 +54,7 @@ def _rand(g, n, dev):
     return torch.rand(n, generator=g, device=dev)
 
 
-def generate(cfg: SynthConfig, device="cpu", seed=None):
+def generate(cfg: SynthConfig, device="cpu", seed=None, tid=0):
     """Returns dict(genome=uint8[Lg] upper-case ASCII, batch={name: tensor}, n_reads, n_pairs, n_cigar_ops, ...)."""
     dev = torch.device(device)
     g = torch.Generator(device=dev)
@@ -277,14 +280,34 @@ def generate(cfg: SynthConfig, device="cpu", seed=None):
     seq_off[1:] = torch.cumsum(seq_words, 0)
     seq4 = packed[o_s].reshape(-1).contiguous()
     n_pairs = int(((op_all == OP_N) & present).sum())
+    mtid_t = torch.full((N,), -1, dtype=torch.int64, device=dev)
+    mpos_t = torch.full((N,), -1, dtype=torch.int64, device=dev)
+    if cfg.paired:
+        # FR library: forward read upstream of its reverse mate.  ~8 % of pairs are broken in assorted ways.
+        rev = (flag & 16) != 0
+        first_mate = _randint(g, 0, 2, (N,), dev) == 1
+        pr = _rand(g, N, dev)
+        gap = _randint(g, 50, 400, (N,), dev)
+        sp = pos[order]
+        mp = torch.where(rev, sp - gap, sp + gap).clamp(min=0)
+        wrong_side = (pr >= 0.92) & (pr < 0.94)
+        mp = torch.where(wrong_side, torch.where(rev, sp + gap, (sp - gap).clamp(min=0)), mp)
+        same_strand = (pr >= 0.94) & (pr < 0.96)
+        mate_unmapped = (pr >= 0.96) & (pr < 0.98)
+        other_contig = pr >= 0.98
+        mrev = torch.where(same_strand, rev, ~rev)
+        flag = flag | 1 | torch.where(first_mate, 0x40, 0x80) | torch.where(mrev, 0x20, 0) | torch.where(pr < 0.92, 2, 0) \
+            | torch.where(mate_unmapped, 8, 0)
+        mtid_t = torch.where(other_contig, tid + 1, tid) + torch.zeros_like(sp)
+        mpos_t = mp
     batch = dict(
         pos=pos[order].to(torch.int32).contiguous(),
         flag=flag.to(torch.int16),  # bit pattern of uint16
         mapq=mapq.to(torch.uint8),
         xs=xs.to(torch.uint8),
         l_qseq=lq.to(torch.int32),
-        mtid=torch.full((N,), -1, dtype=torch.int32, device=dev),
-        mpos=torch.full((N,), -1, dtype=torch.int32, device=dev),
+        mtid=mtid_t.to(torch.int32),
+        mpos=mpos_t.to(torch.int32),
         cig_off=cig_off.to(torch.int32),
         cigar=cigar,
         seq_off=seq_off.to(torch.int32),

@@ -1,0 +1,79 @@
+"""Parity at BASELINE.json's full single-GPU size (configs[1]: 10 M reads, 1 contig, ~50 k
+junctions): the oracle finishes this workload in about a second, so the device rows are compared
+with it directly, plus the size-independent properties (conservation of pairs, determinism,
+batch-split invariance)."""
+import hashlib
+
+import numpy as np
+import pytest
+
+from parity import assert_rows_equal, region_equal, sort_rows
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def c2():
+    import torch
+    from portcullis_amd import ffi, synth
+
+    assert ffi.device_count() >= 1
+    cfg = synth.CONFIGS["C2"]
+    data = synth.generate(cfg, device="cuda")
+    torch.cuda.synchronize()
+    ctx = ffi.Context(0, "UNKNOWN")
+    ctx.set_refs([cfg.contig_len])
+    ctx.upload_contig_device(0, data["genome"])
+    ctx.clear_rows()
+    ctx.submit_batch_device(0, data["batch"], data["n_reads"])
+    reg = ctx.finish_contig(0)
+    rows = ctx.collect()
+    yield cfg, data, ctx, reg, rows
+    ctx.close()
+
+
+def test_fullsize_properties(c2):
+    cfg, data, ctx, reg, rows = c2
+    assert reg["n_reads"] == cfg.n_reads and reg["n_pairs"] == data["n_pairs"]
+    assert reg["spliced"] == data["n_spliced"] and reg["spliced"] + reg["unspliced"] == cfg.n_reads
+    assert reg["sum_len"] == cfg.n_reads * cfg.read_len
+    assert int(rows["nb_raw"].sum()) == data["n_pairs"]                      # every N op lands in exactly one junction
+    assert (rows["r1pos"] + rows["r1neg"] + rows["r2pos"] + rows["r2neg"] == rows["nb_raw"]).all()
+    assert (rows["nb_dist"] <= rows["nb_raw"]).all() and (rows["nb_dist"] >= 1).all()
+    assert (rows["left"] <= rows["start"]).all() and (rows["end"] <= rows["right"]).all()
+    assert (rows["jad"][:, :-1] >= rows["jad"][:, 1:]).all()                 # JAD is non-increasing
+    assert (rows["jad"][:, 0] <= rows["nb_raw"]).all()
+    assert (rows["entropy"] >= 0).all() and (rows["entropy"] <= np.log2(np.maximum(rows["nb_raw"], 2)) + 1e-9).all()
+    key = rows["start"].astype(np.int64) << 32 | rows["end"].astype(np.int64)
+    assert (np.diff(key) > 0).all()                                          # one row per intron, sorted
+    assert rows["canonical"].max() <= 2 and len(rows) > 45_000
+
+
+def test_fullsize_deterministic_and_split_invariant(c2):
+    cfg, data, ctx, reg, rows = c2
+    from portcullis_amd import synth
+
+    ctx.clear_rows()
+    ctx.submit_batch_device(0, data["batch"], data["n_reads"])
+    ctx.finish_contig(0)
+    again = ctx.collect()
+    assert hashlib.md5(again.tobytes()).hexdigest() == hashlib.md5(rows.tobytes()).hexdigest()
+    # the same records submitted as three host batches
+    n = cfg.n_reads
+    ctx.clear_rows()
+    for lo, hi in ((0, n // 3), (n // 3, n // 3 + 1_000_001), (n // 3 + 1_000_001, n)):
+        ctx.submit_batch(0, synth.batch_to_numpy(data["batch"], lo, hi))
+    ctx.finish_contig(0)
+    split = ctx.collect()
+    assert hashlib.md5(split.tobytes()).hexdigest() == hashlib.md5(rows.tobytes()).hexdigest()
+
+
+def test_fullsize_matches_oracle(c2):
+    cfg, data, ctx, reg, rows = c2
+    from oracle import oracle as orc
+    from portcullis_amd import synth
+
+    hb = synth.batch_to_numpy(data["batch"])
+    orows, oreg = orc.find_juncs(0, cfg.contig_len, data["genome"].cpu().numpy().tobytes(), hb.to_oracle(), "UNKNOWN")
+    region_equal(reg, oreg)
+    assert_rows_equal(rows, orows)

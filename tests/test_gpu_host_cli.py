@@ -152,3 +152,27 @@ def test_e2e_synthetic_multi_contig(tmp_path):
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
     res = json.loads(p.stdout.strip().split("\n")[-1])
     assert res["tab_identical_to_oracle"]
+
+
+def _e2e(tmp_path, *args):
+    import json
+    import sys
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "e2e_bench.py"), "--workdir", str(tmp_path / "e2e"),
+                        "--repeat", "1", *args], capture_output=True, text=True, timeout=1200)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    return json.loads(p.stdout.strip().split("\n")[-1])
+
+
+def test_e2e_paired_end_multi_contig_fr(tmp_path):
+    """Scaled-down BASELINE configs[2]: paired-end 150-bp reads on several contigs of decreasing size,
+    --orientation FR (portcullis proper-pair logic), every host thread busy."""
+    res = _e2e(tmp_path, "--config", "C3-contig", "--contigs", "6", "--scale-contigs", "--threads", "12", "--orientation", "FR")
+    assert res["tab_identical_to_oracle"] and res["junctions"] > 500
+
+
+def test_strandedness_has_no_effect_on_junc_output(tmp_path):
+    """BASELINE configs[4] asks for strandedness=firststrand: like the reference (the reader's
+    alignments carry Strandedness::UNKNOWN, lib/src/bam_alignment.cc:154-165) the tables are identical."""
+    a = _e2e(tmp_path, "--config", "C2-small", "--threads", "4", "--strandedness", "firststrand")
+    b = _e2e(tmp_path, "--config", "C2-small", "--threads", "4", "--strandedness", "UNKNOWN")
+    assert a["tab_identical_to_oracle"] and a["tab_md5"] == b["tab_md5"]

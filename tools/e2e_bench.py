@@ -43,6 +43,9 @@ def main():
     ap.add_argument("--keep", action="store_true")
     ap.add_argument("--no-oracle", action="store_true")
     ap.add_argument("--repeat", type=int, default=2)
+    ap.add_argument("--orientation", default="UNKNOWN")
+    ap.add_argument("--strandedness", default="UNKNOWN")
+    ap.add_argument("--scale-contigs", action="store_true", help="contig k gets 1/(k+1) of the reads and length")
     args = ap.parse_args()
     import torch
     from portcullis_amd import synth
@@ -55,8 +58,16 @@ def main():
     os.makedirs(prep)
     t0 = time.time()
     datas, dirs = [], []
+    import dataclasses
+    cfgs = []
     for c in range(args.contigs):
-        d = synth.generate(cfg, device=dev, seed=cfg.seed + c)
+        cc = cfg
+        if args.scale_contigs and c > 0:
+            f = 1.0 / (c + 1)
+            cc = dataclasses.replace(cfg, contig_len=max(20_000, int(cfg.contig_len * f)), n_reads=max(500, int(cfg.n_reads * f)),
+                                     n_junctions=max(8, int(cfg.n_junctions * f)))
+        cfgs.append(cc)
+        d = synth.generate(cc, device=dev, seed=cfg.seed + c, tid=c)
         datas.append(d)
         cd = os.path.join(wd, f"contig{c}")
         dump_contig(cd, f"chr{c + 1}", d)
@@ -73,7 +84,8 @@ def main():
     for rep in range(args.repeat):
         out = os.path.join(wd, f"out{rep}", "pc")
         t = time.time()
-        p = subprocess.run([cli, "junc", "-t", str(args.threads), "-o", out, prep], capture_output=True, text=True)
+        p = subprocess.run([cli, "junc", "-t", str(args.threads), "--orientation", args.orientation, "--strandedness",
+                            args.strandedness, "-o", out, prep], capture_output=True, text=True)
         walls.append(time.time() - t)
         if p.returncode != 0:
             print(p.stdout[-3000:], p.stderr[-3000:])
@@ -84,11 +96,11 @@ def main():
                junctions=tab.count(b"\n") - 2, prep_s=round(t_prep, 1), host_cores=os.cpu_count())
     if not args.no_oracle:
         from oracle import oracle as orc
-        refs = [(f"chr{c + 1}", cfg.contig_len) for c in range(args.contigs)]
+        refs = [(f"chr{c + 1}", cfgs[c].contig_len) for c in range(args.contigs)]
         genomes = {c: datas[c]["genome"].cpu().numpy().tobytes() for c in range(args.contigs)}
         batches = {c: synth.batch_to_numpy(datas[c]["batch"]) for c in range(args.contigs)}
         t = time.time()
-        rows, tot = orc.run_prep_like(refs, genomes, batches, "UNKNOWN")
+        rows, tot = orc.run_prep_like(refs, genomes, batches, args.orientation)
         res["oracle_s"] = round(time.time() - t, 2)
         otab = orc.write_tab(rows, [n for n, _ in refs], [l for _, l in refs])
         res["tab_identical_to_oracle"] = otab == tab
