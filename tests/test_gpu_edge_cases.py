@@ -1,0 +1,122 @@
+"""Edge cases the reference's code paths treat specially (clamps at contig ends, clipping quirks,
+zero-length operations, exotic genome characters, error conditions).  For every case the HIP path
+and the oracle must either both fail or produce identical rows."""
+import numpy as np
+import pytest
+
+from fixtures_micro import read_from_genome
+from parity import assert_rows_equal, region_equal
+from portcullis_amd.records import ReadBatch
+
+pytestmark = pytest.mark.gpu
+
+RNG = np.random.default_rng(99)
+G = "".join(RNG.choice(list("ACGT"), size=6000))
+
+
+def both(ffi, orc, genome, reads, orientation="UNKNOWN", ref_len=None):
+    ref_len = ref_len or len(genome)
+    b = ReadBatch.from_reads(reads)
+    oerr = derr = None
+    orows = oreg = None
+    try:
+        orows, oreg = orc.find_juncs(0, ref_len, genome, b.to_oracle(), orientation)
+    except orc.OracleError as e:
+        oerr = e
+    with ffi.Context(0, orientation) as ctx:
+        ctx.set_refs([ref_len])
+        try:
+            drows, dreg = ffi.run_contig(ctx, 0, genome.encode(), [b])
+        except ffi.PjbError as e:
+            derr = e
+    assert (oerr is None) == (derr is None), f"oracle error: {oerr}; device error: {derr}"
+    if oerr is None:
+        region_equal(dreg, oreg)
+        assert_rows_equal(drows, orows)
+        return "ok", orows
+    return "error", (oerr.code, derr.code)
+
+
+@pytest.fixture(scope="module")
+def orc():
+    from oracle import oracle
+    return oracle
+
+
+@pytest.fixture(scope="module")
+def ffi():
+    from portcullis_amd import ffi
+    return ffi
+
+
+def rd(pos, cigar, **kw):
+    return read_from_genome(G, pos, cigar, **kw)
+
+
+CASES = {
+    "hardclip_then_softclip": [rd(1000, "5H3S50M100N47M"), rd(1010, "40M100N57M3S4H")],
+    "softclip_both_ends": [rd(1000, "7S50M100N50M9S"), rd(1001, "49M100N51M")],
+    "insertion_adjacent_to_intron": [rd(1000, "50M2I100N48M"), rd(1000, "50M100N3I47M"), rd(1005, "45M100N50M")],
+    "deletion_adjacent_to_intron": [rd(1000, "48M2D100N50M"), rd(1000, "50M100N2D48M")],
+    "pad_and_eqx_ops": [rd(1000, "20=5X25M1P100N10=40X"), rd(1002, "48M100N50M")],
+    "back_op_and_unknown_op": [dict(pos=1000, cigar=np.array([(50 << 4) | 0, (3 << 4) | 9, (100 << 4) | 3, (50 << 4) | 0], np.uint32),
+                                    seq=G[1000:1050] + G[1150:1200], xs="+")],
+    "zero_length_refskip": [rd(1000, "50M0N50M"), rd(1000, "50M100N50M")],
+    "zero_length_match_in_anchor": [rd(1000, "50M100N0M50M")],
+    "two_introns_back_to_back": [rd(1000, "50M100N200N50M"), rd(1000, "50M100N10M200N40M")],
+    "one_base_anchors": [rd(1049, "1M100N99M"), rd(1000, "50M100N1M"), rd(1020, "30M100N30M")],
+    "read_of_length_one_base_each_side": [rd(1049, "1M100N1M")],
+    "seq_length_one": [dict(pos=1000, cigar="50M100N50M", seq="A", xs="+")],
+    "intron_enclosed_in_other_window": [rd(900, "150M100N50M"), rd(950, "30M40N30M100N50M"), rd(990, "60M100N40M")],
+    "isoform_overlapping_region_end": [rd(1000, "50M100N50M"), rd(1000, "50M100N20M300N30M"), rd(1100, "60M40N50M")],
+    "intron_at_contig_start": [rd(3, "6M100N50M")],
+    "anchor_reaches_contig_end": [rd(5850, "50M50N50M")],
+    "read_runs_off_contig_end": [rd(5900, "50M100N60M")],
+    "refskip_runs_off_contig_end": [rd(5900, "50M200N50M")],
+    "cigar_starts_with_refskip": [dict(pos=1000, cigar="100N50M", seq=G[1100:1150], xs="+")],
+    "cigar_ends_with_refskip": [dict(pos=1000, cigar="50M100N", seq=G[1000:1050], xs="+")],
+    "softclip_longer_than_read": [dict(pos=1000, cigar="60S50M100N50M", seq="ACGT" * 10, xs="+")],
+    "sequence_shorter_than_cigar": [dict(pos=1000, cigar="50M100N50M", seq="ACGT" * 10, xs="+")],
+    "bad_xs_value": [dict(pos=1000, cigar="50M100N50M", seq=G[1000:1050] + G[1150:1200], xs="*")],
+    "bad_xs_on_unspliced_read": [dict(pos=900, cigar="50M", seq=None, xs="x"), rd(1000, "50M100N50M")],
+    "secondary_supplementary_qcfail_dup": [rd(1000, "50M100N50M", flag=0x100 | 0x800 | 0x200 | 0x400), rd(1000, "50M100N50M", flag=4)],
+    "mapq_threshold": [rd(1000, "50M100N50M", mapq=30), rd(1001, "49M100N51M", mapq=29), rd(1002, "48M100N52M", mapq=255)],
+    "xs_mixture_below_threshold": [rd(1000 + i, f"{50 - i}M100N{50 + i}M", xs=("+" if i < 18 else "-")) for i in range(19)]
+    + [rd(1025, "25M100N75M", xs=None)],
+    "xs_exactly_95_percent": [rd(1000 + i, f"{50 - i}M100N{50 + i}M", xs=("+" if i < 19 else None)) for i in range(20)],
+    "many_reads_same_position_interleaved_ends": [rd(1000, c) for c in ["50M100N50M", "50M100N40M", "50M100N50M", "50M100N40M", "50M100N30M"]],
+}
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_edge_case(ffi, orc, name):
+    reads = sorted(CASES[name], key=lambda r: r["pos"])
+    both(ffi, orc, G, reads)
+    both(ffi, orc, G, reads, orientation="FR")
+
+
+def test_exotic_genome_characters(ffi, orc):
+    """'X' in the contig (query padding really matches it), characters outside the nt16 alphabet,
+    soft-masked and IUPAC bases: the byte-wise path of k4 must give the oracle's numbers."""
+    g = list(G)
+    for p, c in ((1010, "X"), (1011, "x"), (1105, "X"), (1120, "*"), (1160, "-"), (1170, "n"), (1171, "R"), (1172, "y"), (1030, "=")):
+        g[p] = c
+    for p in range(1180, 1200):
+        g[p] = g[p].lower()
+    genome = "".join(g)
+    reads = [read_from_genome(G, 1000, "50M100N50M"), read_from_genome(G, 1001, "20M3D26M100N51M"),
+             read_from_genome(G, 990, "15M60N55M100N30M"), read_from_genome(G, 985, "165M100N15M")]
+    status, rows = both(ffi, orc, genome, reads)
+    assert status == "ok" and rows["sum_mismatches"].sum() > 0
+
+
+def test_long_read_many_ops(ffi, orc):
+    """CIGAR with more ops than the LDS staging holds (long reads): ops beyond the 8th come from global memory."""
+    parts, pos = [], 500
+    cig = ""
+    for k in range(12):
+        cig += f"{20 + k}M{3 + (k % 3)}{'ID'[k % 2]}{15}M{60 + 7 * k}N"
+    cig += "40M"
+    reads = [read_from_genome(G, 500, cig), read_from_genome(G, 520, "16M60N40M")]
+    status, rows = both(ffi, orc, G, reads)
+    assert status == "ok" and len(rows) >= 12
