@@ -581,15 +581,17 @@ int pjb_finish_contig(pjb_ctx *c, int32_t tid, pjb_region_result *res) {
 
     // ---- K2: radix sort (key, pair index)
     const u32 rs_tiles = (P + RS_TILE - 1) / RS_TILE;
+    // digits: as few passes as the widest digit (radix_max_bits) allows, bits spread evenly over them
     int n_pass = (kf.total_bits + c->radix_max_bits - 1) / c->radix_max_bits;
     if (n_pass < 1) n_pass = 1;
-    const int dbits = (kf.total_bits + n_pass - 1) / n_pass;
+    std::vector<int> pass_bits((size_t)n_pass, kf.total_bits / n_pass);
+    for (int p = 0; p < kf.total_bits % n_pass; p++) pass_bits[(size_t)p]++;
+    const int dbits = pass_bits[0];
     if ((rc = ensure(c, c->b_hist, (size_t)rs_tiles * (1u << dbits) * 4))) return rc;
     if ((rc = ensure(c, c->b_hist_scan, (size_t)rs_tiles * (1u << dbits) * 4))) return rc;
-    int cur = 0;
+    int cur = 0, shift = 0;
     for (int p = 0; p < n_pass; p++) {
-        const int shift = p * dbits;
-        const int bits = std::min(dbits, kf.total_bits - shift);
+        const int bits = pass_bits[(size_t)p];
         if (bits <= 0) break;
         const u64 *kin = (const u64 *)c->b_key[cur].p;
         u64 *kout = (u64 *)c->b_key[cur ^ 1].p;
@@ -602,6 +604,7 @@ int pjb_finish_contig(pjb_ctx *c, int32_t tid, pjb_region_result *res) {
         LAUNCH(c, "rs_scatter", rs_scatter, dim3(rs_tiles), dim3(256), kin, vin, kout, vout, P, shift, bits,
                (const u32 *)c->b_hist_scan.p, rs_tiles);
         cur ^= 1;
+        shift += bits;
     }
     c->timing.sort_passes = n_pass;
     const u64 *skey = (const u64 *)c->b_key[cur].p;
@@ -659,13 +662,13 @@ int pjb_finish_contig(pjb_ctx *c, int32_t tid, pjb_region_result *res) {
     HIP_TRY(c, hipEventRecord(c->ev[5], st));
 
     // ---- K5: fragments -> junctions -> rows
-    LAUNCH(c, "k5_frag_reduce", k5_frag_reduce, dim3(slot_blocks), dim3(256), (const u32 *)c->b_frag.p,
+    LAUNCH(c, "k5_frag_reduce", k5_frag_reduce, dim3((n_slots + 4 * FRAG_SLOTS_PER_WAVE - 1) / (4 * FRAG_SLOTS_PER_WAVE)), dim3(256), (const u32 *)c->b_frag.p,
            (const int32_t *)c->b_fragj.p, n_slots, (u32 *)c->b_acc.p);
     const u32 R_runs = cs.n_runs;
     if ((rc = ensure(c, c->b_ent, (size_t)R_runs * 8))) return rc;
     LAUNCH(c, "k5_entropy_terms", k5_entropy_terms, dim3((R_runs + 255) / 256), dim3(256), (const u32 *)c->b_jid.p,
            (const u32 *)c->b_seg.p, (const u32 *)c->b_runfirst.p, (const u32 *)c->b_runstart.p, R_runs, (double *)c->b_ent.p);
-    LAUNCH(c, "k5_finalize", k5_finalize, dim3((J + 255) / 256), dim3(256), skey, (const u32 *)c->b_seg.p,
+    LAUNCH(c, "k5_finalize", k5_finalize, dim3((J + 63) / 64), dim3(64), skey, (const u32 *)c->b_seg.p,
            (const u32 *)c->b_runfirst.p, (const u32 *)c->b_runstart.p, (const u32 *)c->b_acc.p,
            (const int32_t *)c->b_ancl.p, (const int32_t *)c->b_ancr.p, kf, (const uint8_t *)G.d, (int32_t)G.len, tid, J,
            (const double *)c->b_ent.p, (pjb_junction_row *)c->b_rows.p, d_err);

@@ -1255,13 +1255,14 @@ __device__ __forceinline__ u32 frag_combine(int k, u32 a, u32 b) {
     if (k == F_FIRSTMIS) return a < b ? a : b;
     return a + b; // sums; F_MISM_LO/HI are handled as one 64-bit add by the caller
 }
+constexpr int FRAG_SLOTS_PER_WAVE = 16; // short per-wave chains keep enough wavefronts in flight
 __global__ __launch_bounds__(256) void k5_frag_reduce(const u32 *frag, const int32_t *frag_j, u32 n_slots, u32 *acc) {
     const u32 wave = (blockIdx.x * 256 + threadIdx.x) >> 6;
     const int k = lane_id();
-    const u32 s0 = wave * 64;
+    const u32 s0 = wave * FRAG_SLOTS_PER_WAVE;
     if (s0 >= n_slots) return;
-    const u32 s1 = min(s0 + 64, n_slots);
-    const int32_t myj = (s0 + k < n_slots) ? frag_j[s0 + k] : -1;
+    const u32 s1 = min(s0 + FRAG_SLOTS_PER_WAVE, n_slots);
+    const int32_t myj = (k < FRAG_SLOTS_PER_WAVE && s0 + k < n_slots) ? frag_j[s0 + k] : -1;
     int32_t cur = -1;
     u32 v = 0, carry_lo = 0; // lane F_MISM_HI also keeps the low word to do the 64-bit add
     auto flush = [&](int32_t j) {
@@ -1362,12 +1363,12 @@ __global__ __launch_bounds__(256) void k5_entropy_terms(const u32 *jid_of, const
     term[r] = t;
 }
 
-__global__ __launch_bounds__(256) void k5_finalize(const u64 *skey, const u32 *seg_off, const u32 *run_first,
+__global__ __launch_bounds__(64) void k5_finalize(const u64 *skey, const u32 *seg_off, const u32 *run_first,
                                                     const u32 *run_start, const u32 *acc, const int32_t *anc_l,
                                                     const int32_t *anc_r, KeyFmt kf, const uint8_t *genome, int32_t glen,
                                                     int32_t tid, u32 n_junc, const double *ent_term, pjb_junction_row *rows,
                                                     u64 *err) {
-    const u32 j = blockIdx.x * 256 + threadIdx.x;
+    const u32 j = blockIdx.x * 64 + threadIdx.x;
     if (j >= n_junc) return;
     const u32 *a = acc + (size_t)j * F_WORDS;
     pjb_junction_row R;

@@ -1,4 +1,4 @@
-for b in 8 9 10 11 12; do echo "bits $b"; PJB_RADIX_BITS=$b python bench.py --steps 10 --warmup 3 --no-cpu-baseline 2>&1 | tail -1 | python -c "
+for b in 11 12; do echo "max bits $b"; PJB_RADIX_BITS=$b python bench.py --steps 20 --warmup 3 --no-cpu-baseline 2>&1 | tail -1 | python -c "
 import sys,json
 d=json.loads(sys.stdin.read())
 k={x['name']:x for x in d['kernels']}
