@@ -668,7 +668,7 @@ int pjb_finish_contig(pjb_ctx *c, int32_t tid, pjb_region_result *res) {
     if ((rc = ensure(c, c->b_ent, (size_t)R_runs * 8))) return rc;
     LAUNCH(c, "k5_entropy_terms", k5_entropy_terms, dim3((R_runs + 255) / 256), dim3(256), (const u32 *)c->b_jid.p,
            (const u32 *)c->b_seg.p, (const u32 *)c->b_runfirst.p, (const u32 *)c->b_runstart.p, R_runs, (double *)c->b_ent.p);
-    LAUNCH(c, "k5_finalize", k5_finalize, dim3((J + 63) / 64), dim3(64), skey, (const u32 *)c->b_seg.p,
+    LAUNCH(c, "k5_finalize", k5_finalize, dim3((J + 255) / 256), dim3(256), skey, (const u32 *)c->b_seg.p,
            (const u32 *)c->b_runfirst.p, (const u32 *)c->b_runstart.p, (const u32 *)c->b_acc.p,
            (const int32_t *)c->b_ancl.p, (const int32_t *)c->b_ancr.p, kf, (const uint8_t *)G.d, (int32_t)G.len, tid, J,
            (const double *)c->b_ent.p, (pjb_junction_row *)c->b_rows.p, d_err);

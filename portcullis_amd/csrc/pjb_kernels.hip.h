@@ -1363,12 +1363,12 @@ __global__ __launch_bounds__(256) void k5_entropy_terms(const u32 *jid_of, const
     term[r] = t;
 }
 
-__global__ __launch_bounds__(64) void k5_finalize(const u64 *skey, const u32 *seg_off, const u32 *run_first,
+__global__ __launch_bounds__(256) void k5_finalize(const u64 *skey, const u32 *seg_off, const u32 *run_first,
                                                     const u32 *run_start, const u32 *acc, const int32_t *anc_l,
                                                     const int32_t *anc_r, KeyFmt kf, const uint8_t *genome, int32_t glen,
                                                     int32_t tid, u32 n_junc, const double *ent_term, pjb_junction_row *rows,
                                                     u64 *err) {
-    const u32 j = blockIdx.x * 64 + threadIdx.x;
+    const u32 j = blockIdx.x * 256 + threadIdx.x;
     if (j >= n_junc) return;
     const u32 *a = acc + (size_t)j * F_WORDS;
     pjb_junction_row R;
