@@ -4,6 +4,7 @@
 // is streamed in batches to the MI355X through the C ABI in include/portcullis_amd.h.
 #pragma once
 
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -61,8 +62,9 @@ class JunctionBuilder {
 
 protected:
     void findJunctions();
-    // decode one target sequence and run it through the device path (worker body)
-    void findJuncs(void* deviceContext, bam::BamReader& reader, bam::GenomeMapper& gmap, int32_t seq);
+    // decode one target sequence and run it through the device path (worker body); the device
+    // context is obtained lazily so that HIP start-up overlaps the first BGZF blocks
+    void findJuncs(const std::function<void*()>& deviceContext, bam::BamReader& reader, bam::GenomeMapper& gmap, int32_t seq);
 
 public:
     JunctionBuilder(const std::string& prepDir, const std::string& output);

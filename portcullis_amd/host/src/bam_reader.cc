@@ -2,7 +2,9 @@
 
 #include <algorithm>
 #include <atomic>
+#include <condition_variable>
 #include <memory>
+#include <mutex>
 #include <cstring>
 #include <fcntl.h>
 #include <sstream>
@@ -364,6 +366,63 @@ struct Mapped {
     }
 };
 
+// Fixed set of worker threads for the phases of decodeRegionParallel (inflate / walk / fill): a phase
+// is `n` independent tasks, run(n, fn) returns when all of them are done.
+class PhasePool {
+    std::vector<std::thread> threads;
+    std::mutex mu;
+    std::condition_variable cvWork, cvDone;
+    std::function<void(size_t)> fn;
+    size_t nTasks = 0, nextTask = 0, pending = 0;
+    uint64_t generation = 0;
+    bool stop = false;
+
+    void loop() {
+        uint64_t seen = 0;
+        for (;;) {
+            std::unique_lock<std::mutex> lk(mu);
+            cvWork.wait(lk, [&] { return stop || (generation != seen && nextTask < nTasks); });
+            if (stop) return;
+            seen = generation;
+            while (nextTask < nTasks) {
+                const size_t t = nextTask++;
+                lk.unlock();
+                fn(t);
+                lk.lock();
+                if (--pending == 0) cvDone.notify_all();
+            }
+        }
+    }
+
+public:
+    explicit PhasePool(int n) {
+        for (int i = 0; i < n; i++) threads.emplace_back([this] { loop(); });
+    }
+    ~PhasePool() {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            stop = true;
+        }
+        cvWork.notify_all();
+        for (auto& t : threads) t.join();
+    }
+    void run(size_t n, std::function<void(size_t)> f) {
+        if (n == 0) return;
+        if (threads.empty() || n == 1) {
+            for (size_t t = 0; t < n; t++) f(t);
+            return;
+        }
+        std::unique_lock<std::mutex> lk(mu);
+        fn = std::move(f);
+        nTasks = n;
+        nextTask = 0;
+        pending = n;
+        generation++;
+        cvWork.notify_all();
+        cvDone.wait(lk, [&] { return pending == 0; });
+    }
+};
+
 template <typename F>
 void parallelFor(int nthreads, size_t n, F f) {  // f(thread, begin, end) over contiguous slices
     if (nthreads <= 1 || n < 2) {
@@ -385,6 +444,7 @@ void BamReader::decodeRegionParallel(int32_t tid, int nthreads, size_t maxRecord
     if (tid < 0 || (size_t)tid >= targets.size()) throw BamException("decodeRegionParallel: target out of range");
     if (firstOffset[(size_t)tid] == ~0ull) return;
     nthreads = std::max(1, nthreads);
+    PhasePool pool(nthreads > 1 ? nthreads : 0);
     const int32_t refLen = targets[(size_t)tid].length;
     Mapped m;
     m.fd = ::open(bamFile.c_str(), O_RDONLY);
@@ -482,13 +542,8 @@ void BamReader::decodeRegionParallel(int32_t tid, int nthreads, size_t maxRecord
                     if (rc != Z_STREAM_END || zs.avail_out != 0) bad = true;
                 }
             };
-            const int nt = (int)std::min<size_t>((size_t)nthreads, b1 - b0);
-            if (nt <= 1) work(0, 0, 0);
-            else {
-                std::vector<std::thread> th;
-                for (int t = 0; t < nt; t++) th.emplace_back(work, t, (size_t)0, (size_t)0);
-                for (auto& x : th) x.join();
-            }
+            const size_t nt = std::min<size_t>((size_t)nthreads, b1 - b0);
+            pool.run(nt, [&](size_t t) { work((int)t, 0, 0); });
             if (bad) throw BamException("BGZF inflate failed");
         }
         // ---- split points inside this chunk
@@ -563,12 +618,7 @@ void BamReader::decodeRegionParallel(int32_t tid, int nthreads, size_t maxRecord
             if (!lastSlice && !S.ended && !S.bad && cur != limit) S.bad = true;  // the index named a non-boundary
             S.stop = cur;
         };
-        if (ns <= 1) walk(0, 0, 0);
-        else {
-            std::vector<std::thread> th;
-            for (size_t t = 0; t < ns; t++) th.emplace_back(walk, (int)t, (size_t)0, (size_t)0);
-            for (auto& x : th) x.join();
-        }
+        pool.run(ns, [&](size_t t) { walk((int)t, 0, 0); });
         // ---- assemble the batch: prefix sums over slices (stop at the first slice that saw the end)
         size_t nsUse = 0, nrec = 0;
         std::vector<uint64_t> recBase(ns + 1, 0), opBase(ns + 1, 0), wordBase(ns + 1, 0);
@@ -639,12 +689,7 @@ void BamReader::decodeRegionParallel(int32_t tid, int nthreads, size_t maxRecord
                     i++;
                 }
             };
-            if (nsUse <= 1) fill(0, 0, 0);
-            else {
-                std::vector<std::thread> th;
-                for (size_t t = 0; t < nsUse; t++) th.emplace_back(fill, (int)t, (size_t)0, (size_t)0);
-                for (auto& x : th) x.join();
-            }
+            pool.run(nsUse, [&](size_t t) { fill((int)t, 0, 0); });
             if (badRec) throw BamException("Invalid BAM record layout");
             batch.cig_off[n] = (uint32_t)opBase[nsUse];
             batch.seq_off[n] = (uint32_t)wordBase[nsUse];

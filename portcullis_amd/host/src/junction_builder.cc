@@ -4,6 +4,8 @@
 
 #include <chrono>
 #include <condition_variable>
+#include <deque>
+#include <future>
 #include <cstdlib>
 #include <cstring>
 #include <iomanip>
@@ -124,46 +126,126 @@ static void pjbCheck(pjb_ctx* c, int rc, const char* what) {
     if (rc != PJB_OK) throw JunctionBuilderException(std::string(what) + ": " + pjb_last_error(c) + " (code " + std::to_string(rc) + ")");
 }
 
-// One target sequence: FASTA -> HBM, BAM records -> SoA batches -> HBM, device pipeline, rows back.
-void JunctionBuilder::findJuncs(void* deviceContext, BamReader& reader, GenomeMapper& gmap, int32_t seq) {
-    pjb_ctx* ctx = (pjb_ctx*)deviceContext;
-    RegionResult& res = results[(size_t)seq];
-    if (!reader.hasAlignments(seq)) return;  // nothing placed on this target: counters keep their neutral values
-    bool uploaded = false;
-    bool any = false;
-    const double t_begin = HostProfile::now();
-    double t_genome = 0, t_submit = 0;
-    auto submit = [&](bam::ReadBatch& batch) {
-        any = true;
-        const double t0 = HostProfile::now();
-        if (!uploaded) {
-            const std::string contig = gmap.fetchContig(refs->at((size_t)seq)->name);
-            if ((int64_t)contig.size() != refs->at((size_t)seq)->length)
-                throw JunctionBuilderException("Genome sequence " + refs->at((size_t)seq)->name + " has " +
-                                               std::to_string(contig.size()) + " bases but the BAM header says " +
-                                               std::to_string(refs->at((size_t)seq)->length));
-            pjbCheck(ctx, pjb_upload_contig(ctx, seq, (const uint8_t*)contig.data(), (int64_t)contig.size()), "pjb_upload_contig");
-            uploaded = true;
-            t_genome += HostProfile::now() - t0;
+namespace {
+// hand-off of decoded batches from the decode thread to the thread that owns the device context
+class BatchQueue {
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<bam::ReadBatch> full, spare;
+    bool closed = false;
+    size_t cap;
+
+public:
+    explicit BatchQueue(size_t c) : cap(c) {}
+    void push(bam::ReadBatch& b) {  // takes b's storage, gives back a recycled (or empty) one
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return full.size() < cap; });
+        full.emplace_back();
+        std::swap(full.back(), b);
+        if (!spare.empty()) {
+            std::swap(b, spare.front());
+            spare.pop_front();
         }
-        const double t1 = HostProfile::now();
-        pjb_batch pb;
-        batch.view(pb);
-        pjbCheck(ctx, pjb_submit_batch(ctx, seq, &pb), "pjb_submit_batch");
-        t_submit += HostProfile::now() - t1;
-    };
-    if (innerThreads > 1) {
-        reader.decodeRegionParallel(seq, innerThreads, batchRecords, submit);
-    } else {
-        reader.setRegion(seq);
-        bam::ReadBatch batch;
-        while (true) {
-            batch.clear();
-            batch.reserve(batchRecords);
-            if (!reader.nextBatch(batch, batchRecords)) break;
-            submit(batch);
+        cv.notify_all();
+    }
+    bool pop(bam::ReadBatch& b) {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return !full.empty() || closed; });
+        if (full.empty()) return false;
+        std::swap(b, full.front());
+        full.pop_front();
+        cv.notify_all();
+        return true;
+    }
+    void recycle(bam::ReadBatch& b) {
+        std::lock_guard<std::mutex> lk(mu);
+        if (spare.size() < cap) {
+            spare.emplace_back();
+            std::swap(spare.back(), b);
         }
     }
+    void close() {
+        std::lock_guard<std::mutex> lk(mu);
+        closed = true;
+        cv.notify_all();
+    }
+};
+}  // namespace
+
+// One target sequence: FASTA -> HBM, BAM records -> SoA batches -> HBM, device pipeline, rows back.
+// Three things run concurrently: the decode thread (with its inner pool), the genome read, and this
+// thread, which waits for the device context, uploads the genome and submits batches as they come.
+void JunctionBuilder::findJuncs(const std::function<void*()>& deviceContext, BamReader& reader, GenomeMapper& gmap, int32_t seq) {
+    RegionResult& res = results[(size_t)seq];
+    if (!reader.hasAlignments(seq)) return;  // nothing placed on this target: counters keep their neutral values
+    const double t_begin = HostProfile::now();
+    const std::string name = refs->at((size_t)seq)->name;
+    std::future<std::string> genome = std::async(std::launch::async, [&gmap, name] { return gmap.fetchContig(name); });
+    BatchQueue queue(3);
+    std::string decodeError;
+    std::thread decoder([&] {
+        try {
+            if (innerThreads > 1) {
+                reader.decodeRegionParallel(seq, innerThreads, batchRecords, [&](bam::ReadBatch& b) { queue.push(b); });
+            } else {
+                reader.setRegion(seq);
+                bam::ReadBatch b;
+                while (true) {
+                    b.clear();
+                    b.reserve(batchRecords);
+                    if (!reader.nextBatch(b, batchRecords)) break;
+                    queue.push(b);
+                }
+            }
+        } catch (const std::exception& e) {
+            decodeError = e.what();
+        }
+        queue.close();
+    });
+    pjb_ctx* ctx = nullptr;
+    bool any = false;
+    double t_genome = 0, t_submit = 0, t_wait = 0;
+    std::string submitError;
+    bam::ReadBatch batch;
+    while (true) {
+        const double tw = HostProfile::now();
+        if (!queue.pop(batch)) break;
+        t_wait += HostProfile::now() - tw;
+        if (!submitError.empty()) {  // keep draining so the decoder can finish
+            queue.recycle(batch);
+            continue;
+        }
+        try {
+            if (!any) {
+                const double t0 = HostProfile::now();
+                ctx = (pjb_ctx*)deviceContext();
+                const std::string contig = genome.get();
+                if ((int64_t)contig.size() != refs->at((size_t)seq)->length)
+                    throw JunctionBuilderException("Genome sequence " + name + " has " + std::to_string(contig.size()) +
+                                                   " bases but the BAM header says " + std::to_string(refs->at((size_t)seq)->length));
+                pjbCheck(ctx, pjb_upload_contig(ctx, seq, (const uint8_t*)contig.data(), (int64_t)contig.size()), "pjb_upload_contig");
+                t_genome += HostProfile::now() - t0;
+                any = true;
+            }
+            const double t1 = HostProfile::now();
+            pjb_batch pb;
+            batch.view(pb);
+            pjbCheck(ctx, pjb_submit_batch(ctx, seq, &pb), "pjb_submit_batch");
+            t_submit += HostProfile::now() - t1;
+        } catch (const std::exception& e) {
+            submitError = e.what();
+        }
+        queue.recycle(batch);
+    }
+    decoder.join();
+    if (genome.valid()) {
+        try {
+            genome.get();
+        } catch (...) {
+        }
+    }
+    if (!decodeError.empty()) throw JunctionBuilderException(decodeError);
+    if (!submitError.empty()) throw JunctionBuilderException(submitError);
     if (!any) return;
     const double t_fin0 = HostProfile::now();
     pjb_region_result rr;
@@ -182,13 +264,8 @@ void JunctionBuilder::findJuncs(void* deviceContext, BamReader& reader, GenomeMa
     if (g_prof.on) {
         const double t_end = HostProfile::now();
         std::lock_guard<std::mutex> lk(g_prof.mu);
-        g_prof.genome += t_genome;
-        g_prof.submit += t_submit;
-        g_prof.finish += t_end - t_fin0;
-        g_prof.total += t_end - t_begin;
-        cerr << "[host profile] " << refs->at((size_t)seq)->name << ": total " << (t_end - t_begin) << " s = genome " << t_genome
-             << " + submit(H2D) " << t_submit << " + finish+rows " << (t_end - t_fin0) << " + decode "
-             << (t_end - t_begin - t_genome - t_submit - (t_end - t_fin0)) << endl;
+        cerr << "[host profile] " << name << ": total " << (t_end - t_begin) << " s; consumer: waiting for decode " << t_wait
+             << ", context+genome upload " << t_genome << ", submit(H2D) " << t_submit << ", finish+rows " << (t_end - t_fin0) << endl;
     }
 }
 
@@ -228,16 +305,31 @@ void JunctionBuilder::findJunctions() {
     for (auto& r : *refs) lens.push_back(r->length);
     auto worker = [&](int w) {
         pjb_ctx* ctx = nullptr;
+        std::future<pjb_ctx*> ctxFuture;
         try {
-            pjb_config cfg;
-            memset(&cfg, 0, sizeof cfg);
-            cfg.abi_version = PJB_ABI_VERSION;
-            cfg.device = w % ndev;
-            cfg.orientation = (int32_t)orientation;
-            cfg.strandedness = (int32_t)strandSpecific;
-            int rc = pjb_create(&ctx, &cfg);
-            if (rc != PJB_OK) throw JunctionBuilderException(std::string("pjb_create: ") + pjb_last_error(nullptr));
-            pjbCheck(ctx, pjb_set_refs(ctx, (int32_t)lens.size(), lens.data()), "pjb_set_refs");
+            // HIP start-up (~0.2 s) runs beside the index load and the first BGZF blocks
+            ctxFuture = std::async(std::launch::async, [&, w]() -> pjb_ctx* {
+                pjb_config cfg;
+                memset(&cfg, 0, sizeof cfg);
+                cfg.abi_version = PJB_ABI_VERSION;
+                cfg.device = w % ndev;
+                cfg.orientation = (int32_t)orientation;
+                cfg.strandedness = (int32_t)strandSpecific;
+                pjb_ctx* c = nullptr;
+                int rc = pjb_create(&c, &cfg);
+                if (rc != PJB_OK) throw JunctionBuilderException(std::string("pjb_create: ") + pjb_last_error(nullptr));
+                rc = pjb_set_refs(c, (int32_t)lens.size(), lens.data());
+                if (rc != PJB_OK) {
+                    const std::string m = pjb_last_error(c);
+                    pjb_destroy(c);
+                    throw JunctionBuilderException("pjb_set_refs: " + m);
+                }
+                return c;
+            });
+            auto getCtx = [&]() -> void* {
+                if (!ctx) ctx = ctxFuture.get();
+                return ctx;
+            };
             GenomeMapper gmap(prepData.getGenomeFilePath());
             gmap.loadFastaIndex();
             BamReader reader(prepData.getSortedBamFilePath());
@@ -249,11 +341,19 @@ void JunctionBuilder::findJunctions() {
                     if (nextTask >= order.size() || !firstError.empty()) break;
                     tid = order[nextTask++];
                 }
-                findJuncs(ctx, reader, gmap, tid);
+                findJuncs(getCtx, reader, gmap, tid);
             }
         } catch (const std::exception& e) {
             std::lock_guard<std::mutex> lk(mu);
             if (firstError.empty()) firstError = e.what();
+        }
+        if (!ctx && ctxFuture.valid()) {
+            try {
+                ctx = ctxFuture.get();
+            } catch (const std::exception& e) {
+                std::lock_guard<std::mutex> lk(mu);
+                if (firstError.empty()) firstError = e.what();
+            }
         }
         if (ctx) pjb_destroy(ctx);
     };
