@@ -36,8 +36,9 @@ void free_contig(Contig &g) {
     g = Contig();
 }
 
-struct OwnedBatch { // device copies made by pjb_submit_batch
-    void *ptrs[11] = {nullptr};
+struct Slab { // device memory for the batches copied in by pjb_submit_batch; reused contig after contig
+    uint8_t *p = nullptr;
+    size_t cap = 0, used = 0;
 };
 
 enum { ST_SCAN = 0, ST_SORT, ST_GROUP, ST_ANCH, ST_PAIRS, ST_FINAL, ST_D2H };
@@ -52,7 +53,7 @@ struct pjb_ctx {
     std::vector<Contig> contigs;
     int32_t open_tid = -1;
     std::vector<DevBatch> batches;
-    std::vector<OwnedBatch> owned;
+    std::vector<Slab> slabs;
     // junction rows live in a grow-only pinned host buffer so the D2H copy is a single DMA
     pjb_junction_row *rows_pinned = nullptr;
     size_t rows_n = 0, rows_cap = 0;
@@ -229,11 +230,27 @@ struct HistSink {
     __device__ void operator()(u64 i, u64, u64 ex) const { o[i] = (u32)ex; }
 };
 
+void *slab_alloc(pjb_ctx *c, size_t bytes) {
+    bytes = (std::max<size_t>(bytes, 16) + 255) & ~(size_t)255;
+    for (auto &s : c->slabs)
+        if (s.cap - s.used >= bytes) {
+            void *r = s.p + s.used;
+            s.used += bytes;
+            return r;
+        }
+    Slab s;
+    s.cap = std::max<size_t>(bytes, (size_t)256 << 20);
+    if (hipMalloc((void **)&s.p, s.cap) != hipSuccess) {
+        s.cap = bytes;
+        if (hipMalloc((void **)&s.p, s.cap) != hipSuccess) return nullptr;
+    }
+    s.used = bytes;
+    c->slabs.push_back(s);
+    return s.p;
+}
+
 int close_contig(pjb_ctx *c) {
-    for (auto &ob : c->owned)
-        for (void *p : ob.ptrs)
-            if (p) (void)hipFree(p);
-    c->owned.clear();
+    for (auto &s : c->slabs) s.used = 0;
     c->batches.clear();
     c->open_tid = -1;
     return PJB_OK;
@@ -297,6 +314,8 @@ void pjb_destroy(pjb_ctx *c) {
     (void)hipStreamSynchronize(c->stream);
     close_contig(c);
     for (auto &g : c->contigs) free_contig(g);
+    for (auto &sl : c->slabs)
+        if (sl.p) (void)hipFree(sl.p);
     if (c->rows_pinned) (void)hipHostFree(c->rows_pinned);
     Buf *all[] = {&c->b_batches, &c->b_tile_cnt, &c->b_tile_stats, &c->b_cstats, &c->b_err, &c->b_total, &c->b_key[0],
                   &c->b_key[1], &c->b_idx[0], &c->b_idx[1], &c->b_g, &c->b_lstart, &c->b_rend, &c->b_pos, &c->b_aend,
@@ -431,22 +450,19 @@ static int add_batch(pjb_ctx *c, int32_t tid, const pjb_batch *b, bool device) {
         const size_t n_ops = b->cig_off[n], n_words = b->seq_off[n];
         const void *src[11] = {b->pos, b->flag, b->mapq, b->xs, b->l_qseq, b->mtid, b->mpos, b->cig_off, b->cigar, b->seq_off, b->seq4};
         const size_t bytes[11] = {n * 4, n * 2, n, n, n * 4, n * 4, n * 4, (n + 1) * 4, n_ops * 4, (n + 1) * 4, n_words * 4};
-        OwnedBatch ob;
+        void *ptrs[11];
         for (int k = 0; k < 11; k++) {
-            hipError_t e = hipMalloc(&ob.ptrs[k], std::max<size_t>(bytes[k], 16));
-            if (e == hipSuccess && bytes[k] && src[k])
-                e = hipMemcpyAsync(ob.ptrs[k], src[k], bytes[k], hipMemcpyHostToDevice, c->stream);
-            if (e != hipSuccess) {
-                for (void *p : ob.ptrs)
-                    if (p) (void)hipFree(p);
-                return fail(c, PJB_ERR_HIP, "submit: H2D copy failed: %s", hipGetErrorString(e));
+            ptrs[k] = slab_alloc(c, bytes[k]);
+            if (!ptrs[k]) return fail(c, PJB_ERR_NOMEM, "submit: out of device memory for a batch array of %zu bytes", bytes[k]);
+            if (bytes[k] && src[k]) {
+                hipError_t e = hipMemcpyAsync(ptrs[k], src[k], bytes[k], hipMemcpyHostToDevice, c->stream);
+                if (e != hipSuccess) return fail(c, PJB_ERR_HIP, "submit: H2D copy failed: %s", hipGetErrorString(e));
             }
         }
-        c->owned.push_back(ob);
-        d.pos = (const int32_t *)ob.ptrs[0]; d.flag = (const uint16_t *)ob.ptrs[1]; d.mapq = (const uint8_t *)ob.ptrs[2];
-        d.xs = (const uint8_t *)ob.ptrs[3]; d.l_qseq = (const int32_t *)ob.ptrs[4]; d.mtid = (const int32_t *)ob.ptrs[5];
-        d.mpos = (const int32_t *)ob.ptrs[6]; d.cig_off = (const uint32_t *)ob.ptrs[7]; d.cigar = (const uint32_t *)ob.ptrs[8];
-        d.seq_off = (const uint32_t *)ob.ptrs[9]; d.seq4 = (const uint8_t *)ob.ptrs[10];
+        d.pos = (const int32_t *)ptrs[0]; d.flag = (const uint16_t *)ptrs[1]; d.mapq = (const uint8_t *)ptrs[2];
+        d.xs = (const uint8_t *)ptrs[3]; d.l_qseq = (const int32_t *)ptrs[4]; d.mtid = (const int32_t *)ptrs[5];
+        d.mpos = (const int32_t *)ptrs[6]; d.cig_off = (const uint32_t *)ptrs[7]; d.cigar = (const uint32_t *)ptrs[8];
+        d.seq_off = (const uint32_t *)ptrs[9]; d.seq4 = (const uint8_t *)ptrs[10];
     }
     c->batches.push_back(d);
     return PJB_OK;

@@ -5,6 +5,7 @@
 #pragma once
 
 #include <functional>
+#include <future>
 #include <string>
 #include <vector>
 
@@ -54,6 +55,8 @@ class JunctionBuilder {
     int hostThreads = 0;           // 0 = use `threads`; otherwise total host decode threads
     size_t batchRecords = 1 << 20; // alignments per batch sent to the device
     int innerThreads = 1;          // decode threads inside one target sequence (set by findJunctions)
+
+    std::shared_future<int> deviceCount;  // pjb_device_count() evaluated in the background
 
     JunctionSystem junctionSystem;
     std::shared_ptr<bam::RefSeqPtrList> refs;

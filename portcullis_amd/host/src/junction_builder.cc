@@ -65,6 +65,8 @@ JunctionBuilder::JunctionBuilder(const std::string& prepDir, const std::string& 
 }
 
 void JunctionBuilder::process() {
+    // the HIP runtime takes ~0.2 s to come up: start it now, beside the header / index reads
+    deviceCount = std::async(std::launch::async, [] { return pjb_device_count(); }).share();
     const std::string outDir = outputDir.empty() ? "." : outputDir;
     if (!pathExists(outDir) && !makeDirs(outDir))
         throw JunctionBuilderException("Could not create output directory at: " + outDir);
@@ -273,10 +275,14 @@ void JunctionBuilder::findJunctions() {
     WallTimer timer;
     results.clear();
     results.resize(refs->size());
-    const int visible = pjb_device_count();
-    if (visible <= 0)
-        throw JunctionBuilderException("No MI355X (HIP device) is visible: the junc hot path runs on the GPU and has no CPU fallback");
-    int ndev = devices > 0 ? std::min(devices, visible) : visible;
+    if (!deviceCount.valid()) deviceCount = std::async(std::launch::async, [] { return pjb_device_count(); }).share();
+    // resolved lazily by the workers (first use of the device), so decoding starts before HIP is up
+    auto resolveDevices = [this]() -> int {
+        const int visible = deviceCount.get();
+        if (visible <= 0)
+            throw JunctionBuilderException("No MI355X (HIP device) is visible: the junc hot path runs on the GPU and has no CPU fallback");
+        return devices > 0 ? std::min(devices, visible) : visible;
+    };
     // `threads` host threads in total: one worker per target sequence in flight, the rest decode
     // inside the targets (a single big contig still uses every thread)
     int withReads = 0;
@@ -288,8 +294,7 @@ void JunctionBuilder::findJunctions() {
     const int total = std::max<int>(1, hostThreads > 0 ? hostThreads : threads);
     const int nthreads = std::max(1, std::min(total, std::max(1, withReads)));
     innerThreads = std::max(1, total / nthreads);
-    ndev = std::min(ndev, nthreads);
-    cout << "Creating " << nthreads << " threads, each with BAM and genome indicies loaded, on " << ndev << " GPU(s) ...";
+    cout << "Creating " << nthreads << " threads, each with BAM and genome indicies loaded ...";
     cout.flush();
     std::vector<int32_t> order;  // longest targets first: better balance across workers
     for (size_t i = 0; i < refs->size(); i++) {
@@ -312,7 +317,7 @@ void JunctionBuilder::findJunctions() {
                 pjb_config cfg;
                 memset(&cfg, 0, sizeof cfg);
                 cfg.abi_version = PJB_ABI_VERSION;
-                cfg.device = w % ndev;
+                cfg.device = w % std::max(1, std::min(resolveDevices(), nthreads));
                 cfg.orientation = (int32_t)orientation;
                 cfg.strandedness = (int32_t)strandSpecific;
                 pjb_ctx* c = nullptr;
@@ -355,8 +360,14 @@ void JunctionBuilder::findJunctions() {
                 if (firstError.empty()) firstError = e.what();
             }
         }
+        const double td0 = HostProfile::now();
         if (ctx) pjb_destroy(ctx);
+        if (g_prof.on) {
+            std::lock_guard<std::mutex> lk(mu);
+            cerr << "[host profile] worker " << w << ": pjb_destroy " << (HostProfile::now() - td0) << " s" << endl;
+        }
     };
+    const double t_workers0 = HostProfile::now();
     cout << " done." << endl;
     cout << "Finding junctions and calculating basic metrics:" << endl;
     cout << " - Queueing " << refs->size() << " target sequences for processing in the thread pool" << endl;
@@ -365,6 +376,7 @@ void JunctionBuilder::findJunctions() {
     for (int w = 0; w < nthreads; w++) pool.emplace_back(worker, w);
     for (auto& t : pool) t.join();
     if (!firstError.empty()) throw JunctionBuilderException(firstError);
+    const double t_workers1 = HostProfile::now();
     cout << " - All threads completed." << endl << " - Combining results from threads." << endl << endl;
     uint64_t unsplicedCount = 0, splicedCount = 0, sumQueryLengths = 0;
     int32_t minQueryLength = INT32_MAX, maxQueryLength = 0;
@@ -397,12 +409,16 @@ void JunctionBuilder::findJunctions() {
          << "; max: " << maxQueryLength << ";" << endl
          << " - Found " << junctionSystem.size() << " junctions from " << splicedCount << " spliced alignments." << endl
          << " - Found " << unsplicedCount << " unspliced alignments." << endl;
+    const double t_merge1 = HostProfile::now();
     if (junctionSystem.size() > 1) {
         cout << " - Calculating junctions stats that require comparisons with other junctions...";
         cout.flush();
         junctionSystem.calcJunctionStats();
         cout << " done." << endl;
     }
+    if (g_prof.on)
+        cerr << "[host profile] workers " << (t_workers1 - t_workers0) << " s, merge+sort+index " << (t_merge1 - t_workers1)
+             << " s, calcJunctionStats " << (HostProfile::now() - t_merge1) << " s" << endl;
 }
 
 // command line of `portcullis junc` (src/junction_builder.cc:359-454); a small hand-rolled parser
