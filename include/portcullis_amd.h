@@ -179,10 +179,10 @@ int pjb_upload_contig_device(pjb_ctx *ctx, int32_t tid, const uint8_t *d_bases_u
 int pjb_release_contig(pjb_ctx *ctx, int32_t tid);
 
 /* Append a batch to the open contig `tid` (opens it if none is open).  Host
- * arrays are copied to HBM asynchronously on the context's stream (pinned
- * memory makes the copy truly asynchronous) and may be reused once the call
- * returns only if they are not pinned; pinned buffers must stay valid until
- * pjb_finish_contig returns. */
+ * arrays are copied to HBM on the context's stream and the call returns when
+ * the copies are complete, so the buffers may be reused at once.  Arrays that
+ * live in page-locked memory (pjb_host_alloc) are moved by DMA at PCIe speed;
+ * pageable arrays are staged by the runtime and are several times slower. */
 int pjb_submit_batch(pjb_ctx *ctx, int32_t tid, const pjb_batch *host_batch);
 /* Same for arrays already resident in HBM: borrowed until pjb_finish_contig returns. */
 int pjb_submit_batch_device(pjb_ctx *ctx, int32_t tid, const pjb_batch *device_batch);
@@ -210,6 +210,10 @@ int pjb_get_kernel_timing(const pjb_ctx *ctx, pjb_kernel_time *out, int32_t cap,
 int pjb_reset_kernel_timing(pjb_ctx *ctx);
 /* Restrict the event bracketing to the named kernels ("k4_pairs,rs_scatter"); "" or NULL = all. */
 int pjb_select_timed_kernels(pjb_ctx *ctx, const char *comma_separated_names);
+
+/* Page-locked host memory for batch arrays (hipHostMalloc); NULL if it cannot be had. */
+void *pjb_host_alloc(size_t bytes);
+void pjb_host_free(void *p);
 
 /* Number of visible HIP devices (0 if none); does not create a context. */
 int pjb_device_count(void);

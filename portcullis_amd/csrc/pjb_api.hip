@@ -260,6 +260,16 @@ int close_contig(pjb_ctx *c) {
 
 extern "C" {
 
+void *pjb_host_alloc(size_t bytes) {
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) return nullptr;
+    return p;
+}
+
+void pjb_host_free(void *p) {
+    if (p) (void)hipHostFree(p);
+}
+
 int pjb_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
@@ -463,6 +473,7 @@ static int add_batch(pjb_ctx *c, int32_t tid, const pjb_batch *b, bool device) {
         d.xs = (const uint8_t *)ptrs[3]; d.l_qseq = (const int32_t *)ptrs[4]; d.mtid = (const int32_t *)ptrs[5];
         d.mpos = (const int32_t *)ptrs[6]; d.cig_off = (const uint32_t *)ptrs[7]; d.cigar = (const uint32_t *)ptrs[8];
         d.seq_off = (const uint32_t *)ptrs[9]; d.seq4 = (const uint8_t *)ptrs[10];
+        HIP_TRY(c, hipStreamSynchronize(c->stream)); // the caller may reuse its arrays now
     }
     c->batches.push_back(d);
     return PJB_OK;

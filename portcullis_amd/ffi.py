@@ -22,7 +22,7 @@ EXPORTS = [
     "pjb_create", "pjb_destroy", "pjb_last_error", "pjb_set_refs", "pjb_upload_contig", "pjb_upload_contig_device",
     "pjb_release_contig", "pjb_submit_batch", "pjb_submit_batch_device", "pjb_finish_contig", "pjb_collect",
     "pjb_clear_rows", "pjb_get_timing", "pjb_device_count", "pjb_get_kernel_timing", "pjb_reset_kernel_timing",
-    "pjb_select_timed_kernels",
+    "pjb_select_timed_kernels", "pjb_host_alloc", "pjb_host_free",
 ]
 FLAG_KERNEL_TIMING = 1
 
