@@ -178,11 +178,11 @@ int pjb_upload_contig(pjb_ctx *ctx, int32_t tid, const uint8_t *bases, int64_t l
 int pjb_upload_contig_device(pjb_ctx *ctx, int32_t tid, const uint8_t *d_bases_upper, int64_t len);
 int pjb_release_contig(pjb_ctx *ctx, int32_t tid);
 
-/* Append a batch to the open contig `tid` (opens it if none is open).  Host
- * arrays are copied to HBM on the context's stream and the call returns when
- * the copies are complete, so the buffers may be reused at once.  Arrays that
- * live in page-locked memory (pjb_host_alloc) are moved by DMA at PCIe speed;
- * pageable arrays are staged by the runtime and are several times slower. */
+/* Append a batch to the open contig `tid` (opens it if none is open).  The host
+ * arrays are packed into one of the context's two page-locked staging buffers
+ * and moved to HBM by DMA on the context's stream; the call returns as soon as
+ * the arrays have been packed, so they may be reused at once while the DMA of
+ * this batch overlaps the decoding of the next. */
 int pjb_submit_batch(pjb_ctx *ctx, int32_t tid, const pjb_batch *host_batch);
 /* Same for arrays already resident in HBM: borrowed until pjb_finish_contig returns. */
 int pjb_submit_batch_device(pjb_ctx *ctx, int32_t tid, const pjb_batch *device_batch);

@@ -54,6 +54,13 @@ struct pjb_ctx {
     int32_t open_tid = -1;
     std::vector<DevBatch> batches;
     std::vector<Slab> slabs;
+    // two page-locked staging buffers: pjb_submit_batch packs the caller's arrays into one of them
+    // (plain memcpy) and the DMA engine moves it to HBM while the caller decodes the next batch
+    uint8_t *stage[2] = {nullptr, nullptr};
+    size_t stage_cap[2] = {0, 0};
+    hipEvent_t stage_ev[2] = {nullptr, nullptr};
+    bool stage_busy[2] = {false, false};
+    unsigned stage_next = 0;
     // junction rows live in a grow-only pinned host buffer so the D2H copy is a single DMA
     pjb_junction_row *rows_pinned = nullptr;
     size_t rows_n = 0, rows_cap = 0;
@@ -327,6 +334,10 @@ void pjb_destroy(pjb_ctx *c) {
     for (auto &sl : c->slabs)
         if (sl.p) (void)hipFree(sl.p);
     if (c->rows_pinned) (void)hipHostFree(c->rows_pinned);
+    for (int k = 0; k < 2; k++) {
+        if (c->stage[k]) (void)hipHostFree(c->stage[k]);
+        if (c->stage_ev[k]) (void)hipEventDestroy(c->stage_ev[k]);
+    }
     Buf *all[] = {&c->b_batches, &c->b_tile_cnt, &c->b_tile_stats, &c->b_cstats, &c->b_err, &c->b_total, &c->b_key[0],
                   &c->b_key[1], &c->b_idx[0], &c->b_idx[1], &c->b_g, &c->b_lstart, &c->b_rend, &c->b_pos, &c->b_aend,
                   &c->b_meta, &c->b_updown, &c->b_hist, &c->b_hist_scan, &c->b_scan_tiles, &c->b_jid, &c->b_seg,
@@ -460,20 +471,41 @@ static int add_batch(pjb_ctx *c, int32_t tid, const pjb_batch *b, bool device) {
         const size_t n_ops = b->cig_off[n], n_words = b->seq_off[n];
         const void *src[11] = {b->pos, b->flag, b->mapq, b->xs, b->l_qseq, b->mtid, b->mpos, b->cig_off, b->cigar, b->seq_off, b->seq4};
         const size_t bytes[11] = {n * 4, n * 2, n, n, n * 4, n * 4, n * 4, (n + 1) * 4, n_ops * 4, (n + 1) * 4, n_words * 4};
+        // pack into a staging buffer, one DMA to a device slab region with the same packing
+        size_t offs[11], total_b = 0;
+        for (int k = 0; k < 11; k++) {
+            offs[k] = total_b;
+            total_b += (std::max<size_t>(bytes[k], 16) + 255) & ~(size_t)255;
+        }
+        const unsigned si = c->stage_next++ & 1u;
+        if (c->stage_busy[si]) {
+            HIP_TRY(c, hipEventSynchronize(c->stage_ev[si]));
+            c->stage_busy[si] = false;
+        }
+        if (c->stage_cap[si] < total_b) {
+            if (c->stage[si]) (void)hipHostFree(c->stage[si]);
+            c->stage[si] = nullptr;
+            c->stage_cap[si] = 0;
+            const size_t want = total_b + total_b / 8;
+            if (hipHostMalloc((void **)&c->stage[si], want, hipHostMallocDefault) != hipSuccess)
+                return fail(c, PJB_ERR_NOMEM, "submit: cannot allocate %zu bytes of page-locked staging memory", want);
+            c->stage_cap[si] = want;
+        }
+        if (!c->stage_ev[si]) HIP_TRY(c, hipEventCreateWithFlags(&c->stage_ev[si], hipEventDisableTiming));
+        uint8_t *dev = (uint8_t *)slab_alloc(c, total_b);
+        if (!dev) return fail(c, PJB_ERR_NOMEM, "submit: out of device memory for a batch of %zu bytes", total_b);
         void *ptrs[11];
         for (int k = 0; k < 11; k++) {
-            ptrs[k] = slab_alloc(c, bytes[k]);
-            if (!ptrs[k]) return fail(c, PJB_ERR_NOMEM, "submit: out of device memory for a batch array of %zu bytes", bytes[k]);
-            if (bytes[k] && src[k]) {
-                hipError_t e = hipMemcpyAsync(ptrs[k], src[k], bytes[k], hipMemcpyHostToDevice, c->stream);
-                if (e != hipSuccess) return fail(c, PJB_ERR_HIP, "submit: H2D copy failed: %s", hipGetErrorString(e));
-            }
+            if (bytes[k] && src[k]) memcpy(c->stage[si] + offs[k], src[k], bytes[k]);
+            ptrs[k] = dev + offs[k];
         }
+        HIP_TRY(c, hipMemcpyAsync(dev, c->stage[si], total_b, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipEventRecord(c->stage_ev[si], c->stream));
+        c->stage_busy[si] = true;
         d.pos = (const int32_t *)ptrs[0]; d.flag = (const uint16_t *)ptrs[1]; d.mapq = (const uint8_t *)ptrs[2];
         d.xs = (const uint8_t *)ptrs[3]; d.l_qseq = (const int32_t *)ptrs[4]; d.mtid = (const int32_t *)ptrs[5];
         d.mpos = (const int32_t *)ptrs[6]; d.cig_off = (const uint32_t *)ptrs[7]; d.cigar = (const uint32_t *)ptrs[8];
         d.seq_off = (const uint32_t *)ptrs[9]; d.seq4 = (const uint8_t *)ptrs[10];
-        HIP_TRY(c, hipStreamSynchronize(c->stream)); // the caller may reuse its arrays now
     }
     c->batches.push_back(d);
     return PJB_OK;

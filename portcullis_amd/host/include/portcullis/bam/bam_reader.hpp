@@ -17,33 +17,13 @@ struct pjb_batch;
 namespace portcullis {
 namespace bam {
 
-// Allocator that puts batch arrays in page-locked memory (pjb_host_alloc) so that pjb_submit_batch
-// moves them by DMA; falls back to the heap when no device runtime is available.
-void* batchAlloc(size_t bytes);
-void batchFree(void* p);
-template <class T>
-struct BatchAllocator {
-    typedef T value_type;
-    BatchAllocator() = default;
-    template <class U>
-    BatchAllocator(const BatchAllocator<U>&) {}
-    T* allocate(size_t n) { return static_cast<T*>(batchAlloc(n * sizeof(T))); }
-    void deallocate(T* p, size_t) { batchFree(p); }
-    template <class U>
-    bool operator==(const BatchAllocator<U>&) const { return true; }
-    template <class U>
-    bool operator!=(const BatchAllocator<U>&) const { return false; }
-};
-template <class T>
-using BatchVector = std::vector<T, BatchAllocator<T>>;
-
 // One batch of alignment records of one target sequence, in file order (layout of pjb_batch).
 struct ReadBatch {
-    BatchVector<int32_t> pos, l_qseq, mtid, mpos;
-    BatchVector<uint16_t> flag;
-    BatchVector<uint8_t> mapq, xs;
-    BatchVector<uint32_t> cig_off, cigar, seq_off;
-    BatchVector<uint8_t> seq4;
+    std::vector<int32_t> pos, l_qseq, mtid, mpos;
+    std::vector<uint16_t> flag;
+    std::vector<uint8_t> mapq, xs;
+    std::vector<uint32_t> cig_off, cigar, seq_off;
+    std::vector<uint8_t> seq4;
     uint64_t n_refskip = 0;
 
     size_t size() const { return pos.size(); }

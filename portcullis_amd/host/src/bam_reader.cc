@@ -12,50 +12,12 @@
 #include <sys/stat.h>
 #include <thread>
 #include <unistd.h>
-#include <cstdlib>
-#include <new>
 #include <zlib.h>
 
 #include "../../../include/portcullis_amd.h"
 
 namespace portcullis {
 namespace bam {
-
-// ------------------------------------------------------------------ batch memory
-namespace {
-struct AllocHeader {  // sits 64 bytes in front of every batch array
-    uint64_t magic;
-    uint64_t pinned;
-};
-const uint64_t ALLOC_MAGIC = 0x706a625f62617463ull;
-std::atomic<bool> g_pinnedUnavailable(false);
-}  // namespace
-
-void* batchAlloc(size_t bytes) {
-    const size_t total = bytes + 64;
-    void* raw = nullptr;
-    bool pinned = false;
-    if (!g_pinnedUnavailable.load() && bytes >= (64u << 10)) {  // small arrays are not worth pinning
-        raw = pjb_host_alloc(total);
-        if (raw) pinned = true;
-        else g_pinnedUnavailable = true;
-    }
-    if (!raw) {
-        if (posix_memalign(&raw, 64, total) != 0) throw std::bad_alloc();
-    }
-    AllocHeader* h = static_cast<AllocHeader*>(raw);
-    h->magic = ALLOC_MAGIC;
-    h->pinned = pinned ? 1 : 0;
-    return static_cast<uint8_t*>(raw) + 64;
-}
-
-void batchFree(void* p) {
-    if (!p) return;
-    uint8_t* raw = static_cast<uint8_t*>(p) - 64;
-    AllocHeader* h = reinterpret_cast<AllocHeader*>(raw);
-    if (h->magic == ALLOC_MAGIC && h->pinned) pjb_host_free(raw);
-    else free(raw);
-}
 
 // ------------------------------------------------------------------ ReadBatch
 void ReadBatch::clear() {
