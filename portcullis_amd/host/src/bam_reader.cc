@@ -446,44 +446,17 @@ void BamReader::decodeRegionParallel(int32_t tid, int nthreads, size_t maxRecord
     nthreads = std::max(1, nthreads);
     PhasePool pool(nthreads > 1 ? nthreads : 0);
     const int32_t refLen = targets[(size_t)tid].length;
-    Mapped m;
+    Mapped m;  // only the descriptor is used: compressed bytes are pread() into a reusable buffer
     m.fd = ::open(bamFile.c_str(), O_RDONLY);
     if (m.fd < 0) throw BamException("Could not open BAM file: " + bamFile);
     struct stat st;
     if (fstat(m.fd, &st) != 0) throw BamException("Could not stat BAM file: " + bamFile);
-    m.n = (size_t)st.st_size;
-    m.p = (const uint8_t*)mmap(nullptr, m.n, PROT_READ, MAP_PRIVATE, m.fd, 0);
-    if (m.p == MAP_FAILED) {
-        m.p = nullptr;
-        throw BamException("Could not map BAM file: " + bamFile);
-    }
+    const uint64_t fileSize = (uint64_t)st.st_size;
     const uint64_t start = firstOffset[(size_t)tid];
     // the target's records end no later than the block holding the next target's first record
-    uint64_t endCoff = m.n;
+    uint64_t endCoff = fileSize;
     for (uint64_t fo : firstOffset)
         if (fo != ~0ull && fo > start) endCoff = std::min<uint64_t>(endCoff, fo >> 16);
-    // ---- locate blocks from their headers
-    std::vector<Block> blocks;
-    for (uint64_t co = start >> 16; co < m.n;) {
-        if (co + 18 > m.n) break;
-        const uint8_t* h = m.p + co;
-        if (h[0] != 31 || h[1] != 139 || h[2] != 8 || !(h[3] & 4)) throw BamException("Invalid BGZF block header");
-        const uint32_t xlen = le16(h + 10);
-        int bsize = -1;
-        for (uint32_t o = 0; o + 4 <= xlen;) {
-            const uint8_t* x = h + 12 + o;
-            const uint32_t slen = le16(x + 2);
-            if (x[0] == 'B' && x[1] == 'C' && slen == 2) bsize = le16(x + 4);
-            o += 4 + slen;
-        }
-        if (bsize < 0) throw BamException("BGZF block without BC field");
-        const uint32_t total = (uint32_t)bsize + 1;
-        if (co + total > m.n) throw BamException("Truncated BGZF block");
-        blocks.push_back({co, total, le32(h + total - 4), xlen});
-        const bool last = co >= endCoff;  // this block may still hold the tail of the target
-        co += total;
-        if (last) break;
-    }
     // ---- chunks of blocks: one chunk = one batch.  Each chunk is inflated in parallel, then split
     // at record starts named by the index (chunk begins / linear index) so that the block_size
     // chain -- a pointer chase through DRAM -- is walked by all threads at once.
@@ -500,15 +473,70 @@ void BamReader::decodeRegionParallel(int32_t tid, int nthreads, size_t maxRecord
         size_t stop = 0;  // where the walk stopped
         bool ended = false, bad = false;
     };
-    for (size_t b0 = 0; b0 < blocks.size() && !done;) {
-        size_t b1 = b0;
-        uint64_t total = 0;
-        std::vector<uint64_t> uoff;
-        while (b1 < blocks.size() && (total == 0 || total + blocks[b1].isize <= CHUNK)) {
-            uoff.push_back(total);
-            total += blocks[b1].isize;
-            b1++;
+    // compressed side: a window of the file, refilled by parallel pread
+    const size_t CREAD = (size_t)std::min<uint64_t>(CHUNK, 96ull << 20) + (128u << 10);
+    std::unique_ptr<uint8_t[]> cbuf(new uint8_t[CREAD]);
+    size_t cHave = 0;                   // valid bytes in cbuf
+    uint64_t cBase = start >> 16;       // file offset of cbuf[0]
+    uint64_t fileOff = cBase;           // next file offset to read
+    bool sawLastBlock = false;
+    std::vector<Block> blocks;          // blocks of the current chunk; coff is the offset inside cbuf
+    while (!done) {
+        // ---- refill
+        if (fileOff < fileSize && cHave < CREAD) {
+            const size_t want = (size_t)std::min<uint64_t>(CREAD - cHave, fileSize - fileOff);
+            const size_t nsl = std::max<size_t>(1, std::min<size_t>((size_t)nthreads, want >> 20));
+            std::atomic<bool> ioBad(false);
+            pool.run(nsl, [&](size_t t) {
+                const size_t per = (want + nsl - 1) / nsl, a = std::min(want, per * t), b = std::min(want, a + per);
+                size_t got = 0;
+                while (a + got < b) {
+                    const ssize_t r = pread(m.fd, cbuf.get() + cHave + a + got, b - a - got, (off_t)(fileOff + a + got));
+                    if (r <= 0) {
+                        ioBad = true;
+                        return;
+                    }
+                    got += (size_t)r;
+                }
+            });
+            if (ioBad) throw BamException("Could not read BAM file: " + bamFile);
+            cHave += want;
+            fileOff += want;
         }
+        // ---- blocks of this chunk, from their headers
+        blocks.clear();
+        std::vector<uint64_t> uoff;
+        uint64_t total = 0;
+        size_t cpos = 0;
+        while (!sawLastBlock && cpos + 18 <= cHave) {
+            const uint8_t* h = cbuf.get() + cpos;
+            if (h[0] != 31 || h[1] != 139 || h[2] != 8 || !(h[3] & 4)) throw BamException("Invalid BGZF block header");
+            const uint32_t xlen = le16(h + 10);
+            if (cpos + 12 + xlen > cHave) break;
+            int bsize = -1;
+            for (uint32_t o = 0; o + 4 <= xlen;) {
+                const uint8_t* x = h + 12 + o;
+                const uint32_t slen = le16(x + 2);
+                if (x[0] == 'B' && x[1] == 'C' && slen == 2) bsize = le16(x + 4);
+                o += 4 + slen;
+            }
+            if (bsize < 0) throw BamException("BGZF block without BC field");
+            const uint32_t tot = (uint32_t)bsize + 1;
+            if (cpos + tot > cHave) break;  // incomplete in the window: next refill
+            const uint32_t isz = le32(h + tot - 4);
+            if (total != 0 && total + isz > CHUNK) break;
+            blocks.push_back({(uint64_t)cpos, tot, isz, xlen});
+            uoff.push_back(total);
+            total += isz;
+            if (cBase + cpos >= endCoff) sawLastBlock = true;  // this block may still hold the tail of the target
+            cpos += tot;
+        }
+        if (blocks.empty()) {
+            if (fileOff >= fileSize || sawLastBlock) break;  // nothing more to decode
+            if (cHave >= CREAD) throw BamException("BGZF block larger than the read window");
+            continue;
+        }
+        const size_t b0 = 0, b1 = blocks.size();
         const size_t end = carry + total;
         if (end + 8 > bufCap) {
             const size_t ncap = std::max<size_t>(end + 8, (size_t)CHUNK + (4u << 20));
@@ -533,7 +561,7 @@ void BamReader::decodeRegionParallel(int32_t tid, int nthreads, size_t maxRecord
                         bad = true;
                         break;
                     }
-                    zs.next_in = const_cast<uint8_t*>(m.p + k.coff + 12 + k.xlen);
+                    zs.next_in = cbuf.get() + k.coff + 12 + k.xlen;
                     zs.avail_in = k.csize - 12 - k.xlen - 8;
                     zs.next_out = base + uoff[b - b0];
                     zs.avail_out = k.isize;
@@ -552,13 +580,13 @@ void BamReader::decodeRegionParallel(int32_t tid, int nthreads, size_t maxRecord
         std::vector<size_t> pts;
         pts.push_back(cur0);
         {
-            const uint64_t vlo = blocks[b0].coff << 16, vhi = ((blocks[b1 - 1].coff + 1) << 16);
+            const uint64_t vlo = (cBase + blocks[b0].coff) << 16, vhi = ((cBase + blocks[b1 - 1].coff + 1) << 16);
             auto it = std::lower_bound(rpts.begin(), rpts.end(), vlo);
             size_t bi = b0;
             for (; it != rpts.end() && *it < vhi; ++it) {
                 const uint64_t co = *it >> 16;
-                while (bi < b1 && blocks[bi].coff < co) bi++;
-                if (bi >= b1 || blocks[bi].coff != co) continue;  // not a block start we know: ignore
+                while (bi < b1 && cBase + blocks[bi].coff < co) bi++;
+                if (bi >= b1 || cBase + blocks[bi].coff != co) continue;  // not a block start we know: ignore
                 const size_t p = carry + (size_t)uoff[bi - b0] + (size_t)(*it & 0xffff);
                 if (p > pts.back() && p + 36 <= end) pts.push_back(p);
             }
@@ -698,7 +726,12 @@ void BamReader::decodeRegionParallel(int32_t tid, int nthreads, size_t maxRecord
         // ---- carry the partial record at the end of the chunk
         carry = done ? 0 : end - stopAt;
         if (carry) memmove(buf.get(), buf.get() + stopAt, carry);
-        b0 = b1;
+        // ---- slide the compressed window
+        const size_t consumed = (size_t)blocks.back().coff + blocks.back().csize;
+        if (consumed < cHave) memmove(cbuf.get(), cbuf.get() + consumed, cHave - consumed);
+        cHave -= consumed;
+        cBase += consumed;
+        if (sawLastBlock) break;
     }
 }
 
