@@ -17,13 +17,34 @@ struct pjb_batch;
 namespace portcullis {
 namespace bam {
 
+// Large host arrays (decode buffers, batch arrays) come from 2 MiB-aligned blocks that ask for
+// transparent huge pages: with 100+ decode threads faulting in fresh 4 KiB pages the kernel's
+// address-space lock, not zlib, sets the pace.
+void* bigAlloc(size_t bytes);
+void bigFree(void* p);
+template <class T>
+struct BigAllocator {
+    typedef T value_type;
+    BigAllocator() = default;
+    template <class U>
+    BigAllocator(const BigAllocator<U>&) {}
+    T* allocate(size_t n) { return static_cast<T*>(bigAlloc(n * sizeof(T))); }
+    void deallocate(T* p, size_t) { bigFree(p); }
+    template <class U>
+    bool operator==(const BigAllocator<U>&) const { return true; }
+    template <class U>
+    bool operator!=(const BigAllocator<U>&) const { return false; }
+};
+template <class T>
+using BatchVector = std::vector<T, BigAllocator<T>>;
+
 // One batch of alignment records of one target sequence, in file order (layout of pjb_batch).
 struct ReadBatch {
-    std::vector<int32_t> pos, l_qseq, mtid, mpos;
-    std::vector<uint16_t> flag;
-    std::vector<uint8_t> mapq, xs;
-    std::vector<uint32_t> cig_off, cigar, seq_off;
-    std::vector<uint8_t> seq4;
+    BatchVector<int32_t> pos, l_qseq, mtid, mpos;
+    BatchVector<uint16_t> flag;
+    BatchVector<uint8_t> mapq, xs;
+    BatchVector<uint32_t> cig_off, cigar, seq_off;
+    BatchVector<uint8_t> seq4;
     uint64_t n_refskip = 0;
 
     size_t size() const { return pos.size(); }

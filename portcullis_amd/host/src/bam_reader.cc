@@ -12,12 +12,30 @@
 #include <sys/stat.h>
 #include <thread>
 #include <unistd.h>
+#include <cstdlib>
+#include <new>
 #include <zlib.h>
 
 #include "../../../include/portcullis_amd.h"
 
 namespace portcullis {
 namespace bam {
+
+// ------------------------------------------------------------------ big allocations
+void* bigAlloc(size_t bytes) {
+    void* p = nullptr;
+    if (bytes >= (1u << 20)) {
+        const size_t rounded = (bytes + (2u << 20) - 1) & ~(size_t)((2u << 20) - 1);
+        if (posix_memalign(&p, 2u << 20, rounded) != 0) throw std::bad_alloc();
+        (void)madvise(p, rounded, MADV_HUGEPAGE);
+    } else {
+        p = malloc(bytes ? bytes : 1);
+        if (!p) throw std::bad_alloc();
+    }
+    return p;
+}
+
+void bigFree(void* p) { free(p); }
 
 // ------------------------------------------------------------------ ReadBatch
 void ReadBatch::clear() {
@@ -463,7 +481,10 @@ void BamReader::decodeRegionParallel(int32_t tid, int nthreads, size_t maxRecord
     const uint64_t CHUNK = std::min<uint64_t>(256ull << 20, std::max<uint64_t>(64ull << 10, (uint64_t)maxRecords * 192ull));
     const std::vector<uint64_t>& rpts = restart[(size_t)tid];
     size_t bufCap = 0;
-    std::unique_ptr<uint8_t[]> buf;  // raw storage: no zero fill
+    struct BigFree {
+        void operator()(uint8_t* p) const { bigFree(p); }
+    };
+    std::unique_ptr<uint8_t[], BigFree> buf;  // raw storage: no zero fill, huge pages
     size_t carry = 0;
     bool done = false, first = true;
     ReadBatch batch;
@@ -475,7 +496,7 @@ void BamReader::decodeRegionParallel(int32_t tid, int nthreads, size_t maxRecord
     };
     // compressed side: a window of the file, refilled by parallel pread
     const size_t CREAD = (size_t)std::min<uint64_t>(CHUNK, 96ull << 20) + (128u << 10);
-    std::unique_ptr<uint8_t[]> cbuf(new uint8_t[CREAD]);
+    std::unique_ptr<uint8_t[], BigFree> cbuf((uint8_t*)bigAlloc(CREAD));
     size_t cHave = 0;                   // valid bytes in cbuf
     uint64_t cBase = start >> 16;       // file offset of cbuf[0]
     uint64_t fileOff = cBase;           // next file offset to read
@@ -540,7 +561,7 @@ void BamReader::decodeRegionParallel(int32_t tid, int nthreads, size_t maxRecord
         const size_t end = carry + total;
         if (end + 8 > bufCap) {
             const size_t ncap = std::max<size_t>(end + 8, (size_t)CHUNK + (4u << 20));
-            std::unique_ptr<uint8_t[]> nb(new uint8_t[ncap]);
+            std::unique_ptr<uint8_t[], BigFree> nb((uint8_t*)bigAlloc(ncap));
             if (carry) memcpy(nb.get(), buf.get(), carry);
             buf.swap(nb);
             bufCap = ncap;
