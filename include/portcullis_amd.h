@@ -27,8 +27,9 @@
  *                                                            src/junction_builder.cc:258-269
  *
  * A context is bound to one HIP device and is not thread-safe; use one
- * context per host thread / per GPU.  One contig is "open" at a time: submit
- * its batches in BAM file order, then finish it.
+ * context per GPU and call it from one thread.  Several contigs may be open at
+ * once: the batches of one contig must arrive in BAM file order, batches of
+ * different contigs may interleave, and pjb_finish_contig closes one contig.
  */
 #ifndef PORTCULLIS_AMD_H
 #define PORTCULLIS_AMD_H
@@ -178,7 +179,7 @@ int pjb_upload_contig(pjb_ctx *ctx, int32_t tid, const uint8_t *bases, int64_t l
 int pjb_upload_contig_device(pjb_ctx *ctx, int32_t tid, const uint8_t *d_bases_upper, int64_t len);
 int pjb_release_contig(pjb_ctx *ctx, int32_t tid);
 
-/* Append a batch to the open contig `tid` (opens it if none is open).  The host
+/* Append a batch to contig `tid` (opens it if it is not open).  The host
  * arrays are packed into one of the context's two page-locked staging buffers
  * and moved to HBM by DMA on the context's stream; the call returns as soon as
  * the arrays have been packed, so they may be reused at once while the DMA of
@@ -187,7 +188,7 @@ int pjb_submit_batch(pjb_ctx *ctx, int32_t tid, const pjb_batch *host_batch);
 /* Same for arrays already resident in HBM: borrowed until pjb_finish_contig returns. */
 int pjb_submit_batch_device(pjb_ctx *ctx, int32_t tid, const pjb_batch *device_batch);
 
-/* Run the device pipeline over the open contig and close it.  The contig's
+/* Run the device pipeline over everything submitted for contig `tid` and close it.  The contig's
  * genome must have been uploaded.  On return the contig's rows are on the
  * host (appended to the table pjb_collect returns). */
 int pjb_finish_contig(pjb_ctx *ctx, int32_t tid, pjb_region_result *result);

@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <string>
 #include <vector>
 
@@ -41,7 +42,13 @@ struct Slab { // device memory for the batches copied in by pjb_submit_batch; re
     size_t cap = 0, used = 0;
 };
 
-enum { ST_SCAN = 0, ST_SORT, ST_GROUP, ST_ANCH, ST_PAIRS, ST_FINAL, ST_D2H };
+// a contig that has received batches and is not finished yet; several may be open at once
+struct OpenContig {
+    std::vector<DevBatch> batches;
+    std::vector<int32_t> last_pos;  // pos of the last record of each batch (sortedness across batches)
+    std::vector<char> last_known;   // 0 = must be read back from the device (device-resident batch)
+    std::vector<Slab> slabs;        // device memory holding this contig's host-submitted batches
+};
 
 } // namespace
 
@@ -51,9 +58,9 @@ struct pjb_ctx {
     std::string err;
     std::vector<int32_t> ref_len;
     std::vector<Contig> contigs;
-    int32_t open_tid = -1;
-    std::vector<DevBatch> batches;
-    std::vector<Slab> slabs;
+    int32_t cur_tid = -1; // contig of the call in progress (error messages)
+    std::map<int32_t, OpenContig> open;
+    std::vector<Slab> slab_pool; // free slabs, reused contig after contig
     // two page-locked staging buffers: pjb_submit_batch packs the caller's arrays into one of them
     // (plain memcpy) and the DMA engine moves it to HBM while the caller decodes the next batch
     uint8_t *stage[2] = {nullptr, nullptr};
@@ -154,7 +161,7 @@ int check_device_error(pjb_ctx *c, u64 e) {
     if (e == ~0ull) return PJB_OK;
     const int code = -(int)(e & 0xff);
     const unsigned long long ord = e >> 8;
-    return fail(c, code, "%s (alignment ordinal %llu on target %d)", err_text(code), ord, c->open_tid);
+    return fail(c, code, "%s (alignment ordinal %llu on target %d)", err_text(code), ord, c->cur_tid);
 }
 
 int bits_of(uint64_t v) {
@@ -237,29 +244,41 @@ struct HistSink {
     __device__ void operator()(u64 i, u64, u64 ex) const { o[i] = (u32)ex; }
 };
 
-void *slab_alloc(pjb_ctx *c, size_t bytes) {
+void *slab_alloc(pjb_ctx *c, OpenContig &oc, size_t bytes) {
     bytes = (std::max<size_t>(bytes, 16) + 255) & ~(size_t)255;
-    for (auto &s : c->slabs)
+    for (auto &s : oc.slabs)
         if (s.cap - s.used >= bytes) {
             void *r = s.p + s.used;
             s.used += bytes;
             return r;
         }
+    for (size_t k = 0; k < c->slab_pool.size(); k++)
+        if (c->slab_pool[k].cap >= bytes) {
+            Slab s = c->slab_pool[k];
+            c->slab_pool.erase(c->slab_pool.begin() + (long)k);
+            s.used = bytes;
+            oc.slabs.push_back(s);
+            return s.p;
+        }
     Slab s;
-    s.cap = std::max<size_t>(bytes, (size_t)256 << 20);
+    s.cap = std::max<size_t>(bytes, (size_t)128 << 20);
     if (hipMalloc((void **)&s.p, s.cap) != hipSuccess) {
         s.cap = bytes;
         if (hipMalloc((void **)&s.p, s.cap) != hipSuccess) return nullptr;
     }
     s.used = bytes;
-    c->slabs.push_back(s);
+    oc.slabs.push_back(s);
     return s.p;
 }
 
-int close_contig(pjb_ctx *c) {
-    for (auto &s : c->slabs) s.used = 0;
-    c->batches.clear();
-    c->open_tid = -1;
+int close_contig(pjb_ctx *c, int32_t tid) {
+    auto it = c->open.find(tid);
+    if (it == c->open.end()) return PJB_OK;
+    for (auto &s : it->second.slabs) {
+        s.used = 0;
+        c->slab_pool.push_back(s);
+    }
+    c->open.erase(it);
     return PJB_OK;
 }
 
@@ -329,9 +348,9 @@ void pjb_destroy(pjb_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->cfg.device);
     (void)hipStreamSynchronize(c->stream);
-    close_contig(c);
+    while (!c->open.empty()) close_contig(c, c->open.begin()->first);
     for (auto &g : c->contigs) free_contig(g);
-    for (auto &sl : c->slabs)
+    for (auto &sl : c->slab_pool)
         if (sl.p) (void)hipFree(sl.p);
     if (c->rows_pinned) (void)hipHostFree(c->rows_pinned);
     for (int k = 0; k < 2; k++) {
@@ -355,7 +374,7 @@ const char *pjb_last_error(const pjb_ctx *c) { return c ? c->err.c_str() : g_cre
 int pjb_set_refs(pjb_ctx *c, int32_t n_refs, const int32_t *ref_len) {
     if (!c) return PJB_ERR_ARG;
     if (n_refs < 0 || (n_refs > 0 && !ref_len)) return fail(c, PJB_ERR_ARG, "pjb_set_refs: bad arguments");
-    if (c->open_tid >= 0) return fail(c, PJB_ERR_STATE, "pjb_set_refs: contig %d is still open", c->open_tid);
+    if (!c->open.empty()) return fail(c, PJB_ERR_STATE, "pjb_set_refs: contig %d is still open", c->open.begin()->first);
     for (auto &g : c->contigs) free_contig(g);
     c->ref_len.assign(ref_len, ref_len + n_refs);
     c->contigs.assign((size_t)n_refs, Contig());
@@ -447,15 +466,14 @@ static int add_batch(pjb_ctx *c, int32_t tid, const pjb_batch *b, bool device) {
     if (!c) return PJB_ERR_ARG;
     if (!b || b->n_reads < 0) return fail(c, PJB_ERR_ARG, "submit: bad batch");
     if (tid < 0 || (size_t)tid >= c->ref_len.size()) return fail(c, PJB_ERR_ARG, "submit: bad tid %d", tid);
-    if (c->open_tid >= 0 && c->open_tid != tid)
-        return fail(c, PJB_ERR_STATE, "submit: contig %d is open, finish it before submitting to %d", c->open_tid, tid);
-    c->open_tid = tid;
+    c->cur_tid = tid;
+    OpenContig &oc = c->open[tid];
     if (b->n_reads == 0) return PJB_OK;
     if (!b->pos || !b->flag || !b->mapq || !b->xs || !b->l_qseq || !b->mtid || !b->mpos || !b->cig_off || !b->cigar ||
         !b->seq_off)
         return fail(c, PJB_ERR_ARG, "submit: null array in batch");
     uint64_t total = 0;
-    for (auto &x : c->batches) total += (uint64_t)x.n;
+    for (auto &x : oc.batches) total += (uint64_t)x.n;
     if (total + (uint64_t)b->n_reads >= 0xffffff00ull)
         return fail(c, PJB_ERR_ARG, "submit: more than 2^32 alignments on one target are not supported");
     HIP_TRY(c, hipSetDevice(c->cfg.device));
@@ -492,7 +510,7 @@ static int add_batch(pjb_ctx *c, int32_t tid, const pjb_batch *b, bool device) {
             c->stage_cap[si] = want;
         }
         if (!c->stage_ev[si]) HIP_TRY(c, hipEventCreateWithFlags(&c->stage_ev[si], hipEventDisableTiming));
-        uint8_t *dev = (uint8_t *)slab_alloc(c, total_b);
+        uint8_t *dev = (uint8_t *)slab_alloc(c, oc, total_b);
         if (!dev) return fail(c, PJB_ERR_NOMEM, "submit: out of device memory for a batch of %zu bytes", total_b);
         void *ptrs[11];
         for (int k = 0; k < 11; k++) {
@@ -507,7 +525,9 @@ static int add_batch(pjb_ctx *c, int32_t tid, const pjb_batch *b, bool device) {
         d.mpos = (const int32_t *)ptrs[6]; d.cig_off = (const uint32_t *)ptrs[7]; d.cigar = (const uint32_t *)ptrs[8];
         d.seq_off = (const uint32_t *)ptrs[9]; d.seq4 = (const uint8_t *)ptrs[10];
     }
-    c->batches.push_back(d);
+    oc.batches.push_back(d);
+    oc.last_known.push_back(device ? 0 : 1);
+    oc.last_pos.push_back(device ? INT32_MIN : b->pos[b->n_reads - 1]);
     return PJB_OK;
 }
 
@@ -517,13 +537,15 @@ int pjb_submit_batch_device(pjb_ctx *c, int32_t tid, const pjb_batch *b) { retur
 int pjb_finish_contig(pjb_ctx *c, int32_t tid, pjb_region_result *res) {
     if (!c) return PJB_ERR_ARG;
     if (tid < 0 || (size_t)tid >= c->ref_len.size()) return fail(c, PJB_ERR_ARG, "finish: bad tid %d", tid);
-    if (c->open_tid >= 0 && c->open_tid != tid)
-        return fail(c, PJB_ERR_STATE, "finish: contig %d is open, not %d", c->open_tid, tid);
-    c->open_tid = tid;
+    c->cur_tid = tid;
     struct Closer {
         pjb_ctx *c;
-        ~Closer() { close_contig(c); }
-    } closer{c};
+        int32_t tid;
+        ~Closer() { close_contig(c, tid); }
+    } closer{c, tid};
+    static std::vector<DevBatch> no_batches;
+    auto open_it = c->open.find(tid);
+    std::vector<DevBatch> &batches = open_it == c->open.end() ? no_batches : open_it->second.batches;
     pjb_region_result R;
     memset(&R, 0, sizeof R);
     R.min_len = INT32_MAX;
@@ -531,7 +553,7 @@ int pjb_finish_contig(pjb_ctx *c, int32_t tid, pjb_region_result *res) {
     c->ev_name.clear();
     c->ev_used = 0;
     if (res) *res = R;
-    if (c->batches.empty()) return PJB_OK;
+    if (batches.empty()) return PJB_OK;
     HIP_TRY(c, hipSetDevice(c->cfg.device));
     hipStream_t st = c->stream;
     const int32_t ref_len = c->ref_len[(size_t)tid];
@@ -541,7 +563,7 @@ int pjb_finish_contig(pjb_ctx *c, int32_t tid, pjb_region_result *res) {
     u32 n_tiles = 0;
     int32_t prev_pos = INT32_MIN;
     int64_t n_reads = 0;
-    for (auto &b : c->batches) {
+    for (auto &b : batches) {
         b.tile_base = n_tiles;
         n_tiles += (u32)((b.n + K1_TILE - 1) / K1_TILE);
         b.prev_pos = prev_pos;
@@ -549,15 +571,18 @@ int pjb_finish_contig(pjb_ctx *c, int32_t tid, pjb_region_result *res) {
         // last position of this batch is needed by the next one: read it back lazily on device instead
     }
     // prev_pos across batches: fetch each batch's last pos (tiny D2H, only when there are several batches)
-    if (c->batches.size() > 1) {
-        for (size_t k = 0; k + 1 < c->batches.size(); k++) {
-            int32_t last = INT32_MIN;
-            HIP_TRY(c, hipMemcpyAsync(&last, c->batches[k].pos + (c->batches[k].n - 1), 4, hipMemcpyDeviceToHost, st));
-            HIP_TRY(c, hipStreamSynchronize(st));
-            c->batches[k + 1].prev_pos = last;
+    if (batches.size() > 1) {
+        OpenContig &oc = open_it->second;
+        for (size_t k = 0; k + 1 < batches.size(); k++) {
+            int32_t last = oc.last_pos[k];
+            if (!oc.last_known[k]) {
+                HIP_TRY(c, hipMemcpyAsync(&last, batches[k].pos + (batches[k].n - 1), 4, hipMemcpyDeviceToHost, st));
+                HIP_TRY(c, hipStreamSynchronize(st));
+            }
+            batches[k + 1].prev_pos = last;
         }
     }
-    if ((rc = ensure(c, c->b_batches, c->batches.size() * sizeof(DevBatch)))) return rc;
+    if ((rc = ensure(c, c->b_batches, batches.size() * sizeof(DevBatch)))) return rc;
     if ((rc = ensure(c, c->b_tile_cnt, (size_t)n_tiles * 4))) return rc;
     if ((rc = ensure(c, c->b_tile_stats, (size_t)n_tiles * sizeof(TileStats)))) return rc;
     if ((rc = ensure(c, c->b_cstats, sizeof(ContigStats)))) return rc;
@@ -565,12 +590,12 @@ int pjb_finish_contig(pjb_ctx *c, int32_t tid, pjb_region_result *res) {
     if ((rc = ensure(c, c->b_splpoff, (size_t)n_tiles * K1_TILE * 4))) return rc;
     if ((rc = ensure(c, c->b_err, 8))) return rc;
     if ((rc = ensure(c, c->b_total, 8))) return rc;
-    HIP_TRY(c, hipMemcpyAsync(c->b_batches.p, c->batches.data(), c->batches.size() * sizeof(DevBatch), hipMemcpyHostToDevice, st));
+    HIP_TRY(c, hipMemcpyAsync(c->b_batches.p, batches.data(), batches.size() * sizeof(DevBatch), hipMemcpyHostToDevice, st));
     HIP_TRY(c, hipMemsetAsync(c->b_err.p, 0xff, 8, st));
     u64 *d_err = (u64 *)c->b_err.p;
     ContigStats *d_cs = (ContigStats *)c->b_cstats.p;
     HIP_TRY(c, hipEventRecord(c->ev[0], st));
-    for (auto &b : c->batches) {
+    for (auto &b : batches) {
         const u32 nt = (u32)((b.n + K1_TILE - 1) / K1_TILE);
         LAUNCH(c, "k1_count", k1_count, dim3(nt), dim3(256), b, (u32 *)c->b_tile_cnt.p, (TileStats *)c->b_tile_stats.p,
                (u32 *)c->b_splidx.p, (u32 *)c->b_splpoff.p, d_err);
@@ -630,7 +655,7 @@ int pjb_finish_contig(pjb_ctx *c, int32_t tid, pjb_region_result *res) {
     pr.aend = (int32_t *)c->b_aend.p;
     pr.meta = (u32 *)c->b_meta.p;
     pr.updown = (u32 *)c->b_updown.p;
-    for (auto &b : c->batches) {
+    for (auto &b : batches) {
         const u32 nt = (u32)((b.n + K1_TILE - 1) / K1_TILE);
         LAUNCH(c, "k1_emit", k1_emit, dim3(nt), dim3(256), b, (const u32 *)c->b_tile_cnt.p,
                (const TileStats *)c->b_tile_stats.p, (const u32 *)c->b_splidx.p, (const u32 *)c->b_splpoff.p, pr, kf, ref_len,
@@ -715,7 +740,7 @@ int pjb_finish_contig(pjb_ctx *c, int32_t tid, pjb_region_result *res) {
 
     // ---- K4: per-pair match statistics -> fragments
     LAUNCH(c, "k4_pairs", k4_pairs, dim3(pair_blocks), dim3(256), skey, sidx, (const u32 *)c->b_jid.p, pr, kf,
-           (const DevBatch *)c->b_batches.p, (int)c->batches.size(), (const int32_t *)c->b_ancl.p,
+           (const DevBatch *)c->b_batches.p, (int)batches.size(), (const int32_t *)c->b_ancl.p,
            (const int32_t *)c->b_ancr.p, (const uint8_t *)G.d, (int32_t)G.len, G.has_x ? 1 : 0,
            (const u32 *)(G.has_x ? nullptr : G.codes), P, (u32 *)c->b_frag.p, (int32_t *)c->b_fragj.p, d_err, c->ablate);
     HIP_TRY(c, hipEventRecord(c->ev[5], st));

@@ -65,9 +65,8 @@ class JunctionBuilder {
 
 protected:
     void findJunctions();
-    // decode one target sequence and run it through the device path (worker body); the device
-    // context is obtained lazily so that HIP start-up overlaps the first BGZF blocks
-    void findJuncs(const std::function<void*()>& deviceContext, bam::BamReader& reader, bam::GenomeMapper& gmap, int32_t seq);
+    // decode one target sequence (worker body) and feed it to the thread that owns the GPU context
+    void findJuncs(class DeviceThread& device, bam::BamReader& reader, bam::GenomeMapper& gmap, int32_t seq);
 
 public:
     JunctionBuilder(const std::string& prepDir, const std::string& output);

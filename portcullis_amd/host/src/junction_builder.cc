@@ -10,6 +10,8 @@
 #include <cstring>
 #include <iomanip>
 #include <iostream>
+#include <map>
+#include <memory>
 #include <mutex>
 #include <queue>
 #include <sys/stat.h>
@@ -124,71 +126,154 @@ struct HostProfile {  // PJB_PROFILE_HOST=1: where the host side of findJuncs sp
 HostProfile g_prof;
 }  // namespace
 
-static void pjbCheck(pjb_ctx* c, int rc, const char* what) {
-    if (rc != PJB_OK) throw JunctionBuilderException(std::string(what) + ": " + pjb_last_error(c) + " (code " + std::to_string(rc) + ")");
-}
 
-namespace {
-// hand-off of decoded batches from the decode thread to the thread that owns the device context
-class BatchQueue {
+// ---------------------------------------------------------------------------------------------
+// DeviceThread: the one thread that talks to a GPU.  It owns the pjb context (created here, so HIP
+// start-up overlaps the first BGZF blocks) and executes commands from the decode workers in order:
+// genome uploads, batches (of several contigs at once, interleaved) and contig finishes.  Keeping a
+// single context per GPU avoids the runtime-lock contention of one context per worker.
+// ---------------------------------------------------------------------------------------------
+struct ContigDone {
+    pjb_region_result rr;
+    std::vector<pjb_junction_row> rows;
+};
+
+class DeviceThread {
+public:
+    struct Cmd {
+        enum Kind { GENOME, BATCH, FINISH, STOP } kind = STOP;
+        int32_t tid = -1;
+        std::string genome;
+        bam::ReadBatch batch;
+        std::vector<bam::ReadBatch>* spare = nullptr;  // where the batch storage goes back to
+        std::mutex* spareMu = nullptr;
+        std::promise<ContigDone>* done = nullptr;
+    };
+
+private:
+    std::thread th;
     std::mutex mu;
     std::condition_variable cv;
-    std::deque<bam::ReadBatch> full, spare;
-    bool closed = false;
-    size_t cap;
+    std::deque<Cmd> q;
+    size_t cap = 6;
+    std::map<int32_t, std::string> failed;  // contig -> first error
+    std::string fatal;                      // context creation failed
+
+    void run(int device, bam::Orientation orientation, bam::Strandedness strandedness, std::vector<int32_t> lens,
+             std::shared_future<int> deviceCount) {
+        pjb_ctx* ctx = nullptr;
+        try {
+            if (deviceCount.get() <= 0)
+                throw JunctionBuilderException("No MI355X (HIP device) is visible: the junc hot path runs on the GPU and has no CPU fallback");
+            pjb_config cfg;
+            memset(&cfg, 0, sizeof cfg);
+            cfg.abi_version = PJB_ABI_VERSION;
+            cfg.device = device;
+            cfg.orientation = (int32_t)orientation;
+            cfg.strandedness = (int32_t)strandedness;
+            if (pjb_create(&ctx, &cfg) != PJB_OK) throw JunctionBuilderException(std::string("pjb_create: ") + pjb_last_error(nullptr));
+            if (pjb_set_refs(ctx, (int32_t)lens.size(), lens.data()) != PJB_OK)
+                throw JunctionBuilderException(std::string("pjb_set_refs: ") + pjb_last_error(ctx));
+        } catch (const std::exception& e) {
+            fatal = e.what();
+        }
+        for (;;) {
+            Cmd c;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return !q.empty(); });
+                c = std::move(q.front());
+                q.pop_front();
+                cv.notify_all();
+            }
+            if (c.kind == Cmd::STOP) break;
+            std::string err = fatal;
+            if (err.empty() && failed.count(c.tid)) err = failed[c.tid];
+            if (c.kind == Cmd::GENOME) {
+                if (err.empty() && pjb_upload_contig(ctx, c.tid, (const uint8_t*)c.genome.data(), (int64_t)c.genome.size()) != PJB_OK)
+                    failed[c.tid] = std::string("pjb_upload_contig: ") + pjb_last_error(ctx);
+            } else if (c.kind == Cmd::BATCH) {
+                if (err.empty()) {
+                    pjb_batch pb;
+                    c.batch.view(pb);
+                    if (pjb_submit_batch(ctx, c.tid, &pb) != PJB_OK) failed[c.tid] = std::string("pjb_submit_batch: ") + pjb_last_error(ctx);
+                }
+                if (c.spare) {
+                    std::lock_guard<std::mutex> lk(*c.spareMu);
+                    if (c.spare->size() < 4) c.spare->emplace_back(std::move(c.batch));
+                }
+            } else if (c.kind == Cmd::FINISH) {
+                ContigDone d;
+                memset(&d.rr, 0, sizeof d.rr);
+                if (err.empty()) {
+                    const pjb_junction_row* rows = nullptr;
+                    int64_t n = 0;
+                    if (pjb_finish_contig(ctx, c.tid, &d.rr) != PJB_OK) err = std::string("pjb_finish_contig: ") + pjb_last_error(ctx);
+                    else if (pjb_collect(ctx, &rows, &n) != PJB_OK) err = std::string("pjb_collect: ") + pjb_last_error(ctx);
+                    else d.rows.assign(rows, rows + n);
+                    (void)pjb_clear_rows(ctx);
+                } else if (ctx) {
+                    pjb_region_result dummy;
+                    (void)pjb_finish_contig(ctx, c.tid, &dummy);  // drop whatever was submitted
+                    (void)pjb_clear_rows(ctx);
+                }
+                if (ctx) (void)pjb_release_contig(ctx, c.tid);
+                failed.erase(c.tid);
+                if (err.empty()) c.done->set_value(std::move(d));
+                else c.done->set_exception(std::make_exception_ptr(JunctionBuilderException(err)));
+            }
+        }
+        if (ctx) pjb_destroy(ctx);
+    }
 
 public:
-    explicit BatchQueue(size_t c) : cap(c) {}
-    void push(bam::ReadBatch& b) {  // takes b's storage, gives back a recycled (or empty) one
+    DeviceThread(int device, bam::Orientation o, bam::Strandedness s, const std::vector<int32_t>& lens, std::shared_future<int> dc) {
+        th = std::thread([=] { run(device, o, s, lens, dc); });
+    }
+    ~DeviceThread() {
+        Cmd c;
+        c.kind = Cmd::STOP;
+        push(std::move(c));
+        th.join();
+    }
+    void push(Cmd&& c) {
         std::unique_lock<std::mutex> lk(mu);
-        cv.wait(lk, [&] { return full.size() < cap; });
-        full.emplace_back();
-        std::swap(full.back(), b);
-        if (!spare.empty()) {
-            std::swap(b, spare.front());
-            spare.pop_front();
-        }
-        cv.notify_all();
-    }
-    bool pop(bam::ReadBatch& b) {
-        std::unique_lock<std::mutex> lk(mu);
-        cv.wait(lk, [&] { return !full.empty() || closed; });
-        if (full.empty()) return false;
-        std::swap(b, full.front());
-        full.pop_front();
-        cv.notify_all();
-        return true;
-    }
-    void recycle(bam::ReadBatch& b) {
-        std::lock_guard<std::mutex> lk(mu);
-        if (spare.size() < cap) {
-            spare.emplace_back();
-            std::swap(spare.back(), b);
-        }
-    }
-    void close() {
-        std::lock_guard<std::mutex> lk(mu);
-        closed = true;
+        cv.wait(lk, [&] { return q.size() < cap; });
+        q.emplace_back(std::move(c));
         cv.notify_all();
     }
 };
-}  // namespace
 
-// One target sequence: FASTA -> HBM, BAM records -> SoA batches -> HBM, device pipeline, rows back.
-// Three things run concurrently: the decode thread (with its inner pool), the genome read, and this
-// thread, which waits for the device context, uploads the genome and submits batches as they come.
-void JunctionBuilder::findJuncs(const std::function<void*()>& deviceContext, BamReader& reader, GenomeMapper& gmap, int32_t seq) {
+// One target sequence: the decode thread (with its inner pool) pushes batches straight to the device
+// thread, this thread reads the genome meanwhile, then asks for the contig to be finished.
+void JunctionBuilder::findJuncs(DeviceThread& device, BamReader& reader, GenomeMapper& gmap, int32_t seq) {
     RegionResult& res = results[(size_t)seq];
     if (!reader.hasAlignments(seq)) return;  // nothing placed on this target: counters keep their neutral values
     const double t_begin = HostProfile::now();
     const std::string name = refs->at((size_t)seq)->name;
-    std::future<std::string> genome = std::async(std::launch::async, [&gmap, name] { return gmap.fetchContig(name); });
-    BatchQueue queue(3);
+    std::vector<bam::ReadBatch> spare;
+    std::mutex spareMu;
     std::string decodeError;
+    bool any = false;
     std::thread decoder([&] {
+        auto send = [&](bam::ReadBatch& b) {
+            DeviceThread::Cmd c;
+            c.kind = DeviceThread::Cmd::BATCH;
+            c.tid = seq;
+            std::swap(c.batch, b);
+            c.spare = &spare;
+            c.spareMu = &spareMu;
+            any = true;
+            device.push(std::move(c));
+            std::lock_guard<std::mutex> lk(spareMu);
+            if (!spare.empty()) {
+                std::swap(b, spare.back());
+                spare.pop_back();
+            }
+        };
         try {
             if (innerThreads > 1) {
-                reader.decodeRegionParallel(seq, innerThreads, batchRecords, [&](bam::ReadBatch& b) { queue.push(b); });
+                reader.decodeRegionParallel(seq, innerThreads, batchRecords, send);
             } else {
                 reader.setRegion(seq);
                 bam::ReadBatch b;
@@ -196,78 +281,64 @@ void JunctionBuilder::findJuncs(const std::function<void*()>& deviceContext, Bam
                     b.clear();
                     b.reserve(batchRecords);
                     if (!reader.nextBatch(b, batchRecords)) break;
-                    queue.push(b);
+                    send(b);
                 }
             }
         } catch (const std::exception& e) {
             decodeError = e.what();
         }
-        queue.close();
     });
-    pjb_ctx* ctx = nullptr;
-    bool any = false;
-    double t_genome = 0, t_submit = 0, t_wait = 0;
-    std::string submitError;
-    bam::ReadBatch batch;
-    while (true) {
-        const double tw = HostProfile::now();
-        if (!queue.pop(batch)) break;
-        t_wait += HostProfile::now() - tw;
-        if (!submitError.empty()) {  // keep draining so the decoder can finish
-            queue.recycle(batch);
-            continue;
-        }
-        try {
-            if (!any) {
-                const double t0 = HostProfile::now();
-                ctx = (pjb_ctx*)deviceContext();
-                const std::string contig = genome.get();
-                if ((int64_t)contig.size() != refs->at((size_t)seq)->length)
-                    throw JunctionBuilderException("Genome sequence " + name + " has " + std::to_string(contig.size()) +
-                                                   " bases but the BAM header says " + std::to_string(refs->at((size_t)seq)->length));
-                pjbCheck(ctx, pjb_upload_contig(ctx, seq, (const uint8_t*)contig.data(), (int64_t)contig.size()), "pjb_upload_contig");
-                t_genome += HostProfile::now() - t0;
-                any = true;
-            }
-            const double t1 = HostProfile::now();
-            pjb_batch pb;
-            batch.view(pb);
-            pjbCheck(ctx, pjb_submit_batch(ctx, seq, &pb), "pjb_submit_batch");
-            t_submit += HostProfile::now() - t1;
-        } catch (const std::exception& e) {
-            submitError = e.what();
-        }
-        queue.recycle(batch);
+    std::string genomeError;
+    double t_genome = 0;
+    try {
+        const double t0 = HostProfile::now();
+        std::string contig = gmap.fetchContig(name);
+        t_genome = HostProfile::now() - t0;
+        if ((int64_t)contig.size() != refs->at((size_t)seq)->length)
+            throw JunctionBuilderException("Genome sequence " + name + " has " + std::to_string(contig.size()) +
+                                           " bases but the BAM header says " + std::to_string(refs->at((size_t)seq)->length));
+        DeviceThread::Cmd c;
+        c.kind = DeviceThread::Cmd::GENOME;
+        c.tid = seq;
+        c.genome = std::move(contig);
+        device.push(std::move(c));
+    } catch (const std::exception& e) {
+        genomeError = e.what();
     }
     decoder.join();
-    if (genome.valid()) {
-        try {
-            genome.get();
-        } catch (...) {
-        }
+    const double t_decoded = HostProfile::now();
+    // always close the contig on the device, also after a host-side error
+    std::promise<ContigDone> done;
+    std::future<ContigDone> fut = done.get_future();
+    {
+        DeviceThread::Cmd c;
+        c.kind = DeviceThread::Cmd::FINISH;
+        c.tid = seq;
+        c.done = &done;
+        device.push(std::move(c));
+    }
+    ContigDone d;
+    std::string finishError;
+    try {
+        d = fut.get();
+    } catch (const std::exception& e) {
+        finishError = e.what();
     }
     if (!decodeError.empty()) throw JunctionBuilderException(decodeError);
-    if (!submitError.empty()) throw JunctionBuilderException(submitError);
+    if (!genomeError.empty()) throw JunctionBuilderException(genomeError);
+    if (!finishError.empty()) throw JunctionBuilderException(finishError);
     if (!any) return;
-    const double t_fin0 = HostProfile::now();
-    pjb_region_result rr;
-    pjbCheck(ctx, pjb_finish_contig(ctx, seq, &rr), "pjb_finish_contig");
-    const pjb_junction_row* rows = nullptr;
-    int64_t n = 0;
-    pjbCheck(ctx, pjb_collect(ctx, &rows, &n), "pjb_collect");
-    res.js.appendRows(rows, (size_t)n);
-    pjbCheck(ctx, pjb_clear_rows(ctx), "pjb_clear_rows");
-    pjbCheck(ctx, pjb_release_contig(ctx, seq), "pjb_release_contig");
-    res.splicedCount = rr.spliced;
-    res.unsplicedCount = rr.unspliced;
-    res.sumQueryLengths = rr.sum_len;
-    res.minQueryLength = rr.min_len;
-    res.maxQueryLength = rr.max_len;
+    res.js.appendRows(d.rows.data(), d.rows.size());
+    res.splicedCount = d.rr.spliced;
+    res.unsplicedCount = d.rr.unspliced;
+    res.sumQueryLengths = d.rr.sum_len;
+    res.minQueryLength = d.rr.min_len;
+    res.maxQueryLength = d.rr.max_len;
     if (g_prof.on) {
         const double t_end = HostProfile::now();
         std::lock_guard<std::mutex> lk(g_prof.mu);
-        cerr << "[host profile] " << name << ": total " << (t_end - t_begin) << " s; consumer: waiting for decode " << t_wait
-             << ", context+genome upload " << t_genome << ", submit(H2D) " << t_submit << ", finish+rows " << (t_end - t_fin0) << endl;
+        cerr << "[host profile] " << name << ": total " << (t_end - t_begin) << " s = decode (incl. queueing) " << (t_decoded - t_begin)
+             << " + finish/rows " << (t_end - t_decoded) << "; genome read " << t_genome << endl;
     }
 }
 
@@ -276,13 +347,6 @@ void JunctionBuilder::findJunctions() {
     results.clear();
     results.resize(refs->size());
     if (!deviceCount.valid()) deviceCount = std::async(std::launch::async, [] { return pjb_device_count(); }).share();
-    // resolved lazily by the workers (first use of the device), so decoding starts before HIP is up
-    auto resolveDevices = [this]() -> int {
-        const int visible = deviceCount.get();
-        if (visible <= 0)
-            throw JunctionBuilderException("No MI355X (HIP device) is visible: the junc hot path runs on the GPU and has no CPU fallback");
-        return devices > 0 ? std::min(devices, visible) : visible;
-    };
     // `threads` host threads in total: one worker per target sequence in flight, the rest decode
     // inside the targets (a single big contig still uses every thread)
     int withReads = 0;
@@ -308,37 +372,30 @@ void JunctionBuilder::findJunctions() {
     std::string firstError;
     std::vector<int32_t> lens;
     for (auto& r : *refs) lens.push_back(r->length);
+    // one device thread per GPU in use; decode workers are assigned round robin
+    const int ndevWanted = devices > 0 ? devices : 0;
+    std::vector<std::unique_ptr<DeviceThread>> deviceThreads;
+    auto deviceFor = [&](int w) -> DeviceThread& {
+        std::lock_guard<std::mutex> lk(mu);
+        if (deviceThreads.empty()) {
+            // the device count is only known once HIP is up; until then assume one GPU per requested device
+            int nd = 1;
+            if (ndevWanted > 1 || devices == 0) {
+                const int visible = deviceCount.get();
+                nd = std::max(1, std::min(ndevWanted > 0 ? ndevWanted : visible, std::min(visible, nthreads)));
+            }
+            for (int d = 0; d < nd; d++)
+                deviceThreads.emplace_back(new DeviceThread(d, orientation, strandSpecific, lens, deviceCount));
+        }
+        return *deviceThreads[(size_t)w % deviceThreads.size()];
+    };
     auto worker = [&](int w) {
-        pjb_ctx* ctx = nullptr;
-        std::future<pjb_ctx*> ctxFuture;
         try {
-            // HIP start-up (~0.2 s) runs beside the index load and the first BGZF blocks
-            ctxFuture = std::async(std::launch::async, [&, w]() -> pjb_ctx* {
-                pjb_config cfg;
-                memset(&cfg, 0, sizeof cfg);
-                cfg.abi_version = PJB_ABI_VERSION;
-                cfg.device = w % std::max(1, std::min(resolveDevices(), nthreads));
-                cfg.orientation = (int32_t)orientation;
-                cfg.strandedness = (int32_t)strandSpecific;
-                pjb_ctx* c = nullptr;
-                int rc = pjb_create(&c, &cfg);
-                if (rc != PJB_OK) throw JunctionBuilderException(std::string("pjb_create: ") + pjb_last_error(nullptr));
-                rc = pjb_set_refs(c, (int32_t)lens.size(), lens.data());
-                if (rc != PJB_OK) {
-                    const std::string m = pjb_last_error(c);
-                    pjb_destroy(c);
-                    throw JunctionBuilderException("pjb_set_refs: " + m);
-                }
-                return c;
-            });
-            auto getCtx = [&]() -> void* {
-                if (!ctx) ctx = ctxFuture.get();
-                return ctx;
-            };
             GenomeMapper gmap(prepData.getGenomeFilePath());
             gmap.loadFastaIndex();
             BamReader reader(prepData.getSortedBamFilePath());
             reader.open(useCsi);
+            DeviceThread& dev = deviceFor(w);
             while (true) {
                 int32_t tid;
                 {
@@ -346,25 +403,11 @@ void JunctionBuilder::findJunctions() {
                     if (nextTask >= order.size() || !firstError.empty()) break;
                     tid = order[nextTask++];
                 }
-                findJuncs(getCtx, reader, gmap, tid);
+                findJuncs(dev, reader, gmap, tid);
             }
         } catch (const std::exception& e) {
             std::lock_guard<std::mutex> lk(mu);
             if (firstError.empty()) firstError = e.what();
-        }
-        if (!ctx && ctxFuture.valid()) {
-            try {
-                ctx = ctxFuture.get();
-            } catch (const std::exception& e) {
-                std::lock_guard<std::mutex> lk(mu);
-                if (firstError.empty()) firstError = e.what();
-            }
-        }
-        const double td0 = HostProfile::now();
-        if (ctx) pjb_destroy(ctx);
-        if (g_prof.on) {
-            std::lock_guard<std::mutex> lk(mu);
-            cerr << "[host profile] worker " << w << ": pjb_destroy " << (HostProfile::now() - td0) << " s" << endl;
         }
     };
     const double t_workers0 = HostProfile::now();
@@ -375,6 +418,7 @@ void JunctionBuilder::findJunctions() {
     std::vector<std::thread> pool;
     for (int w = 0; w < nthreads; w++) pool.emplace_back(worker, w);
     for (auto& t : pool) t.join();
+    deviceThreads.clear();  // joins the device threads (destroys the contexts)
     if (!firstError.empty()) throw JunctionBuilderException(firstError);
     const double t_workers1 = HostProfile::now();
     cout << " - All threads completed." << endl << " - Combining results from threads." << endl << endl;
