@@ -226,6 +226,10 @@ public:
     void outputJunctionGFF(std::ostream& strm, const std::string& source) const;
     void outputBED(std::ostream& strm, const std::string& prefix, bool bedscore) const;
     friend std::ostream& operator<<(std::ostream& strm, const Junction& j);
+    // the same bytes as `strm << j` / outputBED(strm, ...), appended to a string without going through
+    // iostream formatting (the writers of a few hundred thousand junctions spend their time there)
+    void appendTabRow(std::string& out) const;
+    void appendBedRow(std::string& out, const std::string& prefix, bool bedscore) const;
 
     static std::string junctionOutputHeader();
     static std::shared_ptr<Junction> parse(const std::string& line);

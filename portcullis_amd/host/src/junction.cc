@@ -5,6 +5,7 @@
 #include <portcullis/junction.hpp>
 
 #include <cmath>
+#include <cstdio>
 #include <iomanip>
 #include <sstream>
 
@@ -194,6 +195,80 @@ std::ostream& operator<<(std::ostream& strm, const Junction& j) {
          << j.nbSamples;
     for (size_t i = 0; i < Junction::JAD_NAMES.size(); i++) strm << "\t" << j.junctionAnchorDepth[i];
     return strm;
+}
+
+namespace {
+inline void putU(std::string& o, uint64_t v) {
+    char b[24];
+    int n = 0;
+    do {
+        b[n++] = (char)('0' + v % 10);
+        v /= 10;
+    } while (v);
+    while (n) o.push_back(b[--n]);
+}
+inline void putI(std::string& o, int64_t v) {
+    if (v < 0) {
+        o.push_back('-');
+        putU(o, (uint64_t)(-v));
+    } else
+        putU(o, (uint64_t)v);
+}
+inline void putG(std::string& o, double v) {  // default ostream formatting of a double: %g
+    if (v == 0.0 && !std::signbit(v)) {
+        o.push_back('0');
+        return;
+    }
+    char b[40];
+    const int n = snprintf(b, sizeof b, "%g", v);
+    o.append(b, (size_t)n);
+}
+inline void tab(std::string& o) { o.push_back('\t'); }
+}  // namespace
+
+void Junction::appendTabRow(std::string& o) const {
+    putU(o, id); tab(o);
+    putI(o, intron->ref.index); tab(o); o += intron->ref.name; tab(o); putI(o, intron->ref.length); tab(o);
+    putI(o, intron->start); tab(o); putI(o, intron->end); tab(o);
+    putU(o, getIntronSize()); tab(o); putI(o, leftAncStart); tab(o); putI(o, rightAncEnd); tab(o);
+    o.push_back(bam::strandToChar(readStrand)); tab(o); o.push_back(bam::strandToChar(ssStrand)); tab(o);
+    o.push_back(bam::strandToChar(consensusStrand)); tab(o);
+    o += da1; tab(o); o += da2; tab(o); o.push_back(cssToChar(canonicalSpliceSites)); tab(o);
+    putG(o, score); tab(o); o.push_back(suspicious ? '1' : '0'); tab(o); o.push_back(pfp ? '1' : '0'); tab(o);
+    putU(o, nbAlRaw); tab(o); putU(o, nbAlDistinct); tab(o); putU(o, getNbUniquelySplicedAlignments()); tab(o);
+    putU(o, nbAlMultiplySpliced); tab(o); putU(o, nbAlUniquelyMapped); tab(o); putU(o, getNbMultiplyMappedAlignments()); tab(o);
+    putU(o, nbAlBamProperlyPaired); tab(o); putU(o, nbAlPortcullisProperlyPaired); tab(o); putU(o, nbAlReliable); tab(o);
+    putG(o, getReliable2RawAlignmentRatio()); tab(o);
+    putU(o, nbAlR1Pos); tab(o); putU(o, nbAlR1Neg); tab(o); putU(o, nbAlR2Pos); tab(o); putU(o, nbAlR2Neg); tab(o);
+    putG(o, entropy); tab(o); putG(o, meanMismatches); tab(o); putG(o, meanReadLength); tab(o);
+    putU(o, maxMinAnchor); tab(o); putU(o, maxMMES); tab(o); putG(o, intronScore); tab(o);
+    putU(o, hammingDistance5p); tab(o); putU(o, hammingDistance3p); tab(o);
+    putG(o, codingPotential); tab(o); putG(o, positionWeightScore); tab(o); putG(o, splicingSignal); tab(o);
+    o.push_back(uniqueJunction ? '1' : '0'); tab(o); o.push_back(primaryJunction ? '1' : '0'); tab(o);
+    putU(o, nbUpstreamJunctions); tab(o); putU(o, nbDownstreamJunctions); tab(o);
+    putU(o, distanceToNextUpstreamJunction); tab(o); putU(o, distanceToNextDownstreamJunction); tab(o);
+    putU(o, distanceToNearestJunction); tab(o);
+    putG(o, multipleMappingScore); tab(o); putG(o, coverage); tab(o);
+    putU(o, nbUpstreamFlankingAlignments); tab(o); putU(o, nbDownstreamFlankingAlignments); tab(o); putU(o, nbSamples);
+    for (size_t i = 0; i < JAD_NAMES.size(); i++) {
+        tab(o);
+        putU(o, junctionAnchorDepth[i]);
+    }
+}
+
+void Junction::appendBedRow(std::string& o, const std::string& prefix, bool bedscore) const {
+    const char strand = consensusStrand == Strand::UNKNOWN ? '.' : bam::strandToChar(consensusStrand);
+    o += intron->ref.name; tab(o); putI(o, leftAncStart); tab(o); putI(o, rightAncEnd + 1); tab(o);
+    o += prefix; o.push_back('_'); putU(o, id); tab(o);
+    {   // fixed, precision 3 (the stream state outputBED sets)
+        char b[64];
+        const int n = snprintf(b, sizeof b, "%.3f", bedscore ? getScore() : (double)getNbSplicedAlignments());
+        o.append(b, (size_t)n);
+    }
+    tab(o); o.push_back(strand); tab(o); putI(o, intron->start); tab(o); putI(o, intron->end + 1); tab(o);
+    o += "255,0,0\t2\t";
+    putI(o, intron->start - leftAncStart); o.push_back(','); putI(o, rightAncEnd - intron->end); tab(o);
+    o += "0,"; putI(o, intron->end - leftAncStart + 1); o.push_back('\n');
 }
 
 static std::string join(const std::vector<std::string>& v, const char* sep) {

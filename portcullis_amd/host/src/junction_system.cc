@@ -195,8 +195,18 @@ void JunctionSystem::saveAll(const std::string& outputPrefix, const std::string&
     cout << " - Saving junction table to: " << tabPath << " ... ";
     cout.flush();
     {
-        std::ofstream f(tabPath.c_str());
-        f << (*this) << endl;  // header, rows, and one more empty line
+        // same bytes as `f << (*this) << endl` (header, rows, one more empty line), formatted without iostreams
+        std::string out;
+        out.reserve(junctionList.size() * 320 + 1024);
+        out += Junction::junctionOutputHeader();
+        out.push_back('\n');
+        for (const auto& j : junctionList) {
+            j->appendTabRow(out);
+            out.push_back('\n');
+        }
+        out.push_back('\n');
+        std::ofstream f(tabPath.c_str(), std::ios::binary);
+        f.write(out.data(), (std::streamsize)out.size());
     }
     cout << "done." << endl;
     if (outputExonGFF) {
@@ -242,8 +252,13 @@ void JunctionSystem::writeIntronGFF(std::ostream& strm, const std::string& sourc
 }
 
 void JunctionSystem::outputBED(const std::string& path, CanonicalSS type, const std::string& prefix, bool bedscore) {
-    std::ofstream f(path.c_str());
-    outputBED(f, type, prefix, bedscore);
+    std::string out = "track name=\"junctions\" description=\"Portcullis V" + (version.empty() ? std::string("X.X.X") : version) +
+                      " junctions\"\n";
+    out.reserve(junctionList.size() * 96 + 128);
+    for (const JunctionPtr& j : junctionList)
+        if (type == CanonicalSS::ALL || j->getSpliceSiteType() == type) j->appendBedRow(out, prefix, bedscore);
+    std::ofstream f(path.c_str(), std::ios::binary);
+    f.write(out.data(), (std::streamsize)out.size());
 }
 
 void JunctionSystem::outputBED(std::ostream& strm, CanonicalSS type, const std::string& prefix, bool bedscore) {

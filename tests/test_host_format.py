@@ -1,0 +1,16 @@
+"""Host writers: the string formatters used by saveAll() equal the iostream formatters byte for byte."""
+import os
+import subprocess
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_fast_formatters_match_iostream(tmp_path):
+    host = os.path.join(ROOT, "portcullis_amd", "host")
+    csrc = os.path.join(ROOT, "portcullis_amd", "csrc")
+    exe = str(tmp_path / "fmt")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", f"-I{host}/include", f"-I{ROOT}/include", "-o", exe,
+                           os.path.join(ROOT, "tests", "cpp", "format_equivalence.cc"), f"-L{host}", "-lportcullis_host",
+                           f"-L{csrc}", "-lportcullis_amd", f"-Wl,-rpath,{host}", f"-Wl,-rpath,{csrc}"])
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0 and "mismatches: 0" in out.stdout, out.stdout + out.stderr
