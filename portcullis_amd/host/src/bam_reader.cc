@@ -494,6 +494,7 @@ void BamReader::decodeRegionParallel(int32_t tid, int nthreads, size_t maxRecord
         size_t stop = 0;  // where the walk stopped
         bool ended = false, bad = false;
     };
+    std::vector<Slice> sl;
     // compressed side: a window of the file, refilled by parallel pread
     const size_t CREAD = (size_t)std::min<uint64_t>(CHUNK, 96ull << 20) + (128u << 10);
     std::unique_ptr<uint8_t[], BigFree> cbuf((uint8_t*)bigAlloc(CREAD));
@@ -624,7 +625,13 @@ void BamReader::decodeRegionParallel(int32_t tid, int nthreads, size_t maxRecord
             }
         }
         const size_t ns = cut.size();
-        std::vector<Slice> sl(ns);
+        if (sl.size() < ns) sl.resize(ns);
+        for (size_t t = 0; t < ns; t++) {  // reuse the offset arrays of the previous chunk (no malloc / munmap churn)
+            sl[t].off.clear();
+            sl[t].ops = sl[t].words = sl[t].skips = 0;
+            sl[t].stop = 0;
+            sl[t].ended = sl[t].bad = false;
+        }
         auto walk = [&](int t, size_t, size_t) {
             Slice& S = sl[(size_t)t];
             const size_t limit = (size_t)t + 1 < ns ? cut[(size_t)t + 1] : end;

@@ -10,6 +10,7 @@
 #include <cstring>
 #include <iomanip>
 #include <iostream>
+#include <malloc.h>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -67,6 +68,10 @@ JunctionBuilder::JunctionBuilder(const std::string& prepDir, const std::string& 
 }
 
 void JunctionBuilder::process() {
+    // many decode threads allocate and free multi-megabyte arrays: keep them on the heap instead of
+    // one mmap/munmap pair each (munmap broadcasts TLB shootdowns to every core running a thread)
+    mallopt(M_MMAP_THRESHOLD, 1 << 30);
+    mallopt(M_TRIM_THRESHOLD, -1);
     // the HIP runtime takes ~0.2 s to come up: start it now, beside the header / index reads
     deviceCount = std::async(std::launch::async, [] { return pjb_device_count(); }).share();
     const std::string outDir = outputDir.empty() ? "." : outputDir;
@@ -255,8 +260,10 @@ void JunctionBuilder::findJuncs(DeviceThread& device, BamReader& reader, GenomeM
     std::mutex spareMu;
     std::string decodeError;
     bool any = false;
+    double t_blocked = 0;
     std::thread decoder([&] {
         auto send = [&](bam::ReadBatch& b) {
+            const double tb0 = HostProfile::now();
             DeviceThread::Cmd c;
             c.kind = DeviceThread::Cmd::BATCH;
             c.tid = seq;
@@ -265,6 +272,7 @@ void JunctionBuilder::findJuncs(DeviceThread& device, BamReader& reader, GenomeM
             c.spareMu = &spareMu;
             any = true;
             device.push(std::move(c));
+            t_blocked += HostProfile::now() - tb0;
             std::lock_guard<std::mutex> lk(spareMu);
             if (!spare.empty()) {
                 std::swap(b, spare.back());
@@ -338,7 +346,8 @@ void JunctionBuilder::findJuncs(DeviceThread& device, BamReader& reader, GenomeM
         const double t_end = HostProfile::now();
         std::lock_guard<std::mutex> lk(g_prof.mu);
         cerr << "[host profile] " << name << ": total " << (t_end - t_begin) << " s = decode (incl. queueing) " << (t_decoded - t_begin)
-             << " + finish/rows " << (t_end - t_decoded) << "; genome read " << t_genome << endl;
+             << " (of which blocked on the device queue " << t_blocked << ") + finish/rows " << (t_end - t_decoded)
+             << "; genome read " << t_genome << endl;
     }
 }
 
