@@ -2,6 +2,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <memory>
 #include <mutex>
@@ -495,6 +496,10 @@ void BamReader::decodeRegionParallel(int32_t tid, int nthreads, size_t maxRecord
         bool ended = false, bad = false;
     };
     std::vector<Slice> sl;
+    const bool prof = getenv("PJB_PROFILE_HOST") != nullptr;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double tRefill = 0, tScan = 0, tInflate = 0, tWalk = 0, tFill = 0, tSink = 0, tMove = 0;
+    size_t nChunks = 0;
     // compressed side: a window of the file, refilled by parallel pread
     const size_t CREAD = (size_t)std::min<uint64_t>(CHUNK, 96ull << 20) + (128u << 10);
     std::unique_ptr<uint8_t[], BigFree> cbuf((uint8_t*)bigAlloc(CREAD));
@@ -505,6 +510,8 @@ void BamReader::decodeRegionParallel(int32_t tid, int nthreads, size_t maxRecord
     std::vector<Block> blocks;          // blocks of the current chunk; coff is the offset inside cbuf
     while (!done) {
         // ---- refill
+        double t0 = now();
+        nChunks++;
         if (fileOff < fileSize && cHave < CREAD) {
             const size_t want = (size_t)std::min<uint64_t>(CREAD - cHave, fileSize - fileOff);
             const size_t nsl = std::max<size_t>(1, std::min<size_t>((size_t)nthreads, want >> 20));
@@ -525,6 +532,8 @@ void BamReader::decodeRegionParallel(int32_t tid, int nthreads, size_t maxRecord
             cHave += want;
             fileOff += want;
         }
+        tRefill += now() - t0;
+        t0 = now();
         // ---- blocks of this chunk, from their headers
         blocks.clear();
         std::vector<uint64_t> uoff;
@@ -559,6 +568,8 @@ void BamReader::decodeRegionParallel(int32_t tid, int nthreads, size_t maxRecord
             continue;
         }
         const size_t b0 = 0, b1 = blocks.size();
+        tScan += now() - t0;
+        t0 = now();
         const size_t end = carry + total;
         if (end + 8 > bufCap) {
             const size_t ncap = std::max<size_t>(end + 8, (size_t)CHUNK + (4u << 20));
@@ -596,6 +607,8 @@ void BamReader::decodeRegionParallel(int32_t tid, int nthreads, size_t maxRecord
             pool.run(nt, [&](size_t t) { work((int)t, 0, 0); });
             if (bad) throw BamException("BGZF inflate failed");
         }
+        tInflate += now() - t0;
+        t0 = now();
         // ---- split points inside this chunk
         const size_t cur0 = first ? (size_t)(start & 0xffff) : 0;
         first = false;
@@ -675,6 +688,8 @@ void BamReader::decodeRegionParallel(int32_t tid, int nthreads, size_t maxRecord
             S.stop = cur;
         };
         pool.run(ns, [&](size_t t) { walk((int)t, 0, 0); });
+        tWalk += now() - t0;
+        t0 = now();
         // ---- assemble the batch: prefix sums over slices (stop at the first slice that saw the end)
         size_t nsUse = 0, nrec = 0;
         std::vector<uint64_t> recBase(ns + 1, 0), opBase(ns + 1, 0), wordBase(ns + 1, 0);
@@ -749,7 +764,11 @@ void BamReader::decodeRegionParallel(int32_t tid, int nthreads, size_t maxRecord
             if (badRec) throw BamException("Invalid BAM record layout");
             batch.cig_off[n] = (uint32_t)opBase[nsUse];
             batch.seq_off[n] = (uint32_t)wordBase[nsUse];
+            tFill += now() - t0;
+            t0 = now();
             sink(batch);
+            tSink += now() - t0;
+            t0 = now();
         }
         // ---- carry the partial record at the end of the chunk
         carry = done ? 0 : end - stopAt;
@@ -759,8 +778,12 @@ void BamReader::decodeRegionParallel(int32_t tid, int nthreads, size_t maxRecord
         if (consumed < cHave) memmove(cbuf.get(), cbuf.get() + consumed, cHave - consumed);
         cHave -= consumed;
         cBase += consumed;
+        tMove += now() - t0;
         if (sawLastBlock) break;
     }
+    if (prof)
+        fprintf(stderr, "[host profile] decode tid %d (%d threads, %zu chunks): refill %.3f scan %.3f inflate %.3f walk %.3f fill %.3f sink %.3f carry %.3f\n",
+                tid, nthreads, nChunks, tRefill, tScan, tInflate, tWalk, tFill, tSink, tMove);
 }
 
 }  // namespace bam

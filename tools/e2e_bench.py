@@ -91,7 +91,13 @@ def main():
             print(p.stdout[-3000:], p.stderr[-3000:])
             raise SystemExit("portcullis_amd failed")
     tab = open(out + ".junctions.tab", "rb").read()
-    res = dict(config=cfg.name, contigs=args.contigs, reads=n_reads, threads=args.threads, bam_mb=round(bam_bytes / 1e6, 1),
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        quota = None if q == "max" else round(int(q) / int(per), 1)
+    except Exception:
+        pass
+    res = dict(cpu_quota_cores=quota, config=cfg.name, contigs=args.contigs, reads=n_reads, threads=args.threads, bam_mb=round(bam_bytes / 1e6, 1),
                wall_s=[round(w, 3) for w in walls], reads_per_s=n_reads / min(walls), tab_md5=hashlib.md5(tab).hexdigest(),
                junctions=tab.count(b"\n") - 2, prep_s=round(t_prep, 1), host_cores=os.cpu_count())
     if not args.no_oracle:
