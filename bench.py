@@ -21,7 +21,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 
-def algorithmic_bytes(name, N, C, S, Cs, P, J, L, passes):
+def algorithmic_bytes(name, N, C, S, Cs, P, J, L, passes, Pg=0):
     """Algorithmic HBM bytes of ONE launch of kernel `name` (each byte counted once per logical
     pass, caches ignored; DESIGN.md section 4 derives these).  N reads, C cigar ops, S spliced
     reads, Cs cigar ops of spliced reads, P pairs, J junctions, L read length."""
@@ -36,9 +36,14 @@ def algorithmic_bytes(name, N, C, S, Cs, P, J, L, passes):
         "k2_heads_reduce": P * 20,
         "k2_heads_apply": P * 20 + P * 4 + (J + J + P / 8) * 4,
         "k3_anchors_frag": P * 16 + frags * 12,
-        # key, idx, jid, 7 pair fields, previous pair (12), read offsets (20), ops, packed bases of both
-        # anchors (~L/2), genome bytes under both anchors (~L), junction anchors (8); one 192-B fragment record
-        "k4_pairs": P * (8 + 4 + 4 + 28 + 12 + 20 + 4 * (Cs / max(S, 1)) + L / 2 + L + 8) + frags * 196,
+        # simple pairs: meta, read ordinal, key, pos, rend, seq_off (8), packed read bases L/2, 4-bit genome codes L/2,
+        # 8-byte result; other pairs only read their meta word
+        "k4a_simple": (P - Pg) * (4 + 4 + 8 + 4 + 4 + 8 + L + 8) + Pg * 4,
+        # generic pairs: list entry, idx, jid, key, ordinal, cig_off (8), ops, pos/aend, l_qseq, seq_off (8), anchors (8),
+        # read bases + genome codes (L), result
+        "k4b_generic": Pg * (4 + 4 + 4 + 8 + 4 + 8 + 4 * (Cs / max(S, 1)) + 8 + 4 + 8 + 8 + L + 8),
+        # key, idx, jid, pos, aend, result, meta, previous pair (16), lstart, rend, updown; one 192-B fragment record
+        "k4_pairs": P * (8 + 4 + 4 + 4 + 4 + 8 + 4 + 16 + 4 + 4 + 4) + frags * 196,
         "k5_frag_reduce": frags * 196 + J * 164,
         "k5_finalize": J * (192 + 24 + 48 + 200),
         "k5_entropy_terms": P * 0 + J * 8,
@@ -159,7 +164,7 @@ def main():
             if launches == 0:
                 continue
             avg = ms / launches
-            b = algorithmic_bytes(name, N, C, S, cs_ops, P, J, L, sort_passes)
+            b = algorithmic_bytes(name, N, C, S, cs_ops, P, J, L, sort_passes, int(timing.get("generic_pairs", 0)))
             kern.append(dict(name=name, launches=launches, avg_ms=avg, total_ms=ms,
                              alg_bytes=b, gbps=(b / (avg * 1e-3) / 1e9) if b else None))
         kern.sort(key=lambda k: -k["total_ms"])
@@ -210,6 +215,7 @@ def main():
             "device_kernel_ms_per_step": round(kernel_ms_per_step, 4),
             "pipeline_gbps": None,
             "sort_passes": sort_passes,
+            "generic_pairs": int(timing.get("generic_pairs", 0)),
             "kernels": [dict(name=k["name"], launches_per_step=k["launches"] / args.steps, avg_ms=round(k["avg_ms"], 4),
                              gbps=round(k["gbps"], 1) if k["gbps"] else None) for k in kern],
             "datagen_s": round(t_gen, 2),

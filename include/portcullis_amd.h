@@ -158,6 +158,7 @@ typedef struct pjb_timing {
     float total_ms;               /* first kernel -> rows resident on host */
     float stage_ms[PJB_N_STAGES]; /* scan/emit, sort, group, anchors, pair stats, finalise, d2h, (spare) */
     int64_t sort_passes;
+    int64_t generic_pairs; /* pairs that took the generic CIGAR walks (k4b) instead of the [S]MNM[S] fast path (k4a) */
 } pjb_timing;
 
 /* ---- entry points ------------------------------------------------------ */

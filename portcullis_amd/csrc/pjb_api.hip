@@ -75,7 +75,6 @@ struct pjb_ctx {
     pjb_timing timing;
     hipEvent_t ev[PJB_N_STAGES + 2];
     int radix_max_bits = 11;
-    int ablate = 0;
     // optional per-kernel timing
     bool ktime = false;
     std::vector<hipEvent_t> ev_pool;
@@ -90,7 +89,7 @@ struct pjb_ctx {
     Buf b_key[2], b_idx[2], b_g, b_lstart, b_rend, b_pos, b_aend, b_meta, b_updown;
     Buf b_hist, b_hist_scan, b_scan_tiles;
     Buf b_jid, b_seg, b_runfirst, b_runstart;
-    Buf b_frag, b_fragj, b_fragl, b_fragr, b_acc, b_ancl, b_ancr, b_rows, b_hasx, b_ent;
+    Buf b_frag, b_fragj, b_fragl, b_fragr, b_acc, b_ancl, b_ancr, b_rows, b_hasx, b_ent, b_res, b_genlist, b_gencount;
 };
 
 namespace {
@@ -354,7 +353,6 @@ int pjb_create(pjb_ctx **out, const pjb_config *cfg) {
     }
     for (auto &ev : c->ev) (void)hipEventCreate(&ev);
     c->ktime = (cfg->flags & PJB_FLAG_KERNEL_TIMING) != 0;
-    if (const char *s = getenv("PJB_ABLATE")) c->ablate = atoi(s);
     if (const char *s = getenv("PJB_RADIX_BITS")) {
         int v = atoi(s);
         if (v >= 4 && v <= RS_MAX_BITS) c->radix_max_bits = v;
@@ -380,7 +378,7 @@ void pjb_destroy(pjb_ctx *c) {
                   &c->b_key[1], &c->b_idx[0], &c->b_idx[1], &c->b_g, &c->b_lstart, &c->b_rend, &c->b_pos, &c->b_aend,
                   &c->b_meta, &c->b_updown, &c->b_hist, &c->b_hist_scan, &c->b_scan_tiles, &c->b_jid, &c->b_seg,
                   &c->b_runfirst, &c->b_runstart, &c->b_frag, &c->b_fragj, &c->b_fragl, &c->b_fragr, &c->b_acc,
-                  &c->b_ancl, &c->b_ancr, &c->b_rows, &c->b_hasx, &c->b_ent, &c->b_splidx, &c->b_splpoff};
+                  &c->b_ancl, &c->b_ancr, &c->b_rows, &c->b_hasx, &c->b_ent, &c->b_splidx, &c->b_splpoff, &c->b_res, &c->b_genlist, &c->b_gencount};
     for (Buf *b : all) release(*b);
     for (auto &ev : c->ev) (void)hipEventDestroy(ev);
     for (auto &ev : c->ev_pool) (void)hipEventDestroy(ev);
@@ -702,6 +700,15 @@ int pjb_finish_contig(pjb_ctx *c, int32_t tid, pjb_region_result *res) {
                (const TileStats *)c->b_tile_stats.p, (const u32 *)c->b_splidx.p, (const u32 *)c->b_splpoff.p, pr, kf, ref_len,
                tid, (int)c->cfg.orientation, d_err);
     }
+    // ---- K4a: match statistics of the common [S] M N M [S] shape, in BAM order, while the keys are still unsorted
+    if ((rc = ensure(c, c->b_res, (size_t)P * 8))) return rc;
+    if ((rc = ensure(c, c->b_genlist, (size_t)P * 4))) return rc;
+    if ((rc = ensure(c, c->b_gencount, 4))) return rc;
+    HIP_TRY(c, hipMemsetAsync(c->b_gencount.p, 0, 4, st));
+    const bool fast_codes = G.codes != nullptr && !G.has_x;
+    if (fast_codes)
+        LAUNCH(c, "k4a_simple", k4a_simple, dim3((P + 255) / 256), dim3(256), pr, kf, (const DevBatch *)c->b_batches.p,
+               (int)batches.size(), (const u32 *)G.codes, (int32_t)G.len, P, (u64 *)c->b_res.p);
     HIP_TRY(c, hipEventRecord(c->ev[1], st));
 
     // ---- K2: radix sort (key, pair index)
@@ -772,18 +779,22 @@ int pjb_finish_contig(pjb_ctx *c, int32_t tid, pjb_region_result *res) {
            (int32_t *)c->b_ancl.p, (int32_t *)c->b_ancr.p);
     const u32 pair_blocks = (P + 255) / 256, slot_blocks = (n_slots + 255) / 256;
     LAUNCH(c, "k3_anchors_frag", k3_anchors_frag, dim3(pair_blocks), dim3(256), sidx, (const u32 *)c->b_jid.p,
-           (const int32_t *)pr.lstart, (const int32_t *)pr.rend, P, (int32_t *)c->b_fragl.p, (int32_t *)c->b_fragr.p,
-           (int32_t *)c->b_fragj.p);
+           (const int32_t *)pr.lstart, (const int32_t *)pr.rend, (const u32 *)pr.meta, fast_codes ? 0 : 1, P,
+           (int32_t *)c->b_fragl.p, (int32_t *)c->b_fragr.p, (int32_t *)c->b_fragj.p, (u32 *)c->b_genlist.p,
+           (u32 *)c->b_gencount.p);
     LAUNCH(c, "k3_anchors_junc", k3_anchors_junc, dim3(slot_blocks), dim3(256), (const int32_t *)c->b_fragl.p,
            (const int32_t *)c->b_fragr.p, (const int32_t *)c->b_fragj.p, n_slots, (int32_t *)c->b_ancl.p,
            (int32_t *)c->b_ancr.p);
     HIP_TRY(c, hipEventRecord(c->ev[4], st));
 
-    // ---- K4: per-pair match statistics -> fragments
+    // ---- K4b: the pairs that need the generic walks (list length lives on the device; the grid covers the
+    // worst case and surplus blocks exit at once), then K4: gather + segmented reduce -> fragments
+    LAUNCH(c, "k4b_generic", k4b_generic, dim3(pair_blocks), dim3(256), (const u32 *)c->b_genlist.p,
+           (const u32 *)c->b_gencount.p, skey, sidx, (const u32 *)c->b_jid.p, pr, kf, (const DevBatch *)c->b_batches.p,
+           (int)batches.size(), (const int32_t *)c->b_ancl.p, (const int32_t *)c->b_ancr.p, (const uint8_t *)G.d,
+           (int32_t)G.len, G.has_x ? 1 : 0, (const u32 *)(G.has_x ? nullptr : G.codes), (u64 *)c->b_res.p, d_err);
     LAUNCH(c, "k4_pairs", k4_pairs, dim3(pair_blocks), dim3(256), skey, sidx, (const u32 *)c->b_jid.p, pr, kf,
-           (const DevBatch *)c->b_batches.p, (int)batches.size(), (const int32_t *)c->b_ancl.p,
-           (const int32_t *)c->b_ancr.p, (const uint8_t *)G.d, (int32_t)G.len, G.has_x ? 1 : 0,
-           (const u32 *)(G.has_x ? nullptr : G.codes), P, (u32 *)c->b_frag.p, (int32_t *)c->b_fragj.p, d_err, c->ablate);
+           (const u64 *)c->b_res.p, P, (u32 *)c->b_frag.p, (int32_t *)c->b_fragj.p);
     HIP_TRY(c, hipEventRecord(c->ev[5], st));
 
     // ---- K5: fragments -> junctions -> rows
@@ -813,10 +824,13 @@ int pjb_finish_contig(pjb_ctx *c, int32_t tid, pjb_region_result *res) {
     }
     HIP_TRY(c, hipMemcpyAsync(c->rows_pinned + old, c->b_rows.p, (size_t)J * sizeof(pjb_junction_row), hipMemcpyDeviceToHost, st));
     HIP_TRY(c, hipMemcpyAsync(&herr, d_err, 8, hipMemcpyDeviceToHost, st));
+    u32 n_generic = 0;
+    HIP_TRY(c, hipMemcpyAsync(&n_generic, c->b_gencount.p, 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(c, hipEventRecord(c->ev[7], st));
     HIP_TRY(c, hipStreamSynchronize(st));
     if ((rc = check_device_error(c, herr))) return rc;
     c->rows_n = old + J;
+    c->timing.generic_pairs = n_generic;
     if (c->ktime) ev_collect(c);
     for (int k = 0; k < 7; k++) (void)hipEventElapsedTime(&c->timing.stage_ms[k], c->ev[k], c->ev[k + 1]);
     (void)hipEventElapsedTime(&c->timing.total_ms, c->ev[0], c->ev[7]);

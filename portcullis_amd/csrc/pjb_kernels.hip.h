@@ -89,7 +89,15 @@ enum : u32 {
     META_BPP = 1u << 6,      // BAM proper-pair flag                 (junction.cc:780)
     META_PPP = 1u << 7,      // calcIfProperPair                     (junction.cc:784)
     META_REL = 1u << 8,      // reliable                             (junction.cc:792)
+    META_SIMPLE = 1u << 9,   // CIGAR is [S] M N M [S] and l_qseq matches it: both anchors are single
+                             // contiguous compares that do not depend on the junction-level window
+    META_DS_SHIFT = 16,      // 12 bits: leading soft clip of a simple pair
 };
+// per-pair match statistics packed in 64 bits: minMatch | mmes << 20 | mismatches << 40
+__device__ __forceinline__ u64 pack_res(u32 minMatch, u32 mmes, u32 mis) {
+    return (u64)(minMatch & 0xfffffu) | ((u64)(mmes & 0xfffffu) << 20) | ((u64)mis << 40);
+}
+constexpr u32 RES_FIELD_MAX = 0xfffffu; // anchors longer than this take the generic path
 
 // key packing: normal case (start << lbits) | intron_len, fallback raw (start << 32) | (u32)end
 struct KeyFmt {
@@ -580,6 +588,21 @@ __global__ __launch_bounds__(256) void k1_emit(DevBatch b, const u32 *tile_off, 
         }
         if (ppp) meta |= META_PPP;
         if (um && (!pp_check || ppp)) meta |= META_REL;
+        // ---- shape: [S] M N M [S] with the read length matching the CIGAR
+        if (nN == 1 && n >= 3 && n <= 5) {
+            u32 k0 = 0, k1 = n;
+            u32 dS = 0, dE = 0;
+            if ((cig[0] & 15u) == OP_S) { dS = cig[0] >> 4; k0 = 1; }
+            if ((cig[n - 1] & 15u) == OP_S) { dE = cig[n - 1] >> 4; k1 = n - 1; }
+            if (k1 - k0 == 3 && (cig[k0] & 15u) == OP_M && (cig[k0 + 1] & 15u) == OP_N && (cig[k0 + 2] & 15u) == OP_M) {
+                const u32 a = cig[k0] >> 4, b2 = cig[k0 + 2] >> 4;
+                const int32_t lq = b.l_qseq[r];
+                const u32 words = b.seq_off[r + 1] - b.seq_off[r];
+                if (a > 0 && b2 > 0 && a <= RES_FIELD_MAX && b2 <= RES_FIELD_MAX && dS < 4096u && lq > 1 &&
+                    (u64)lq == (u64)dS + a + b2 + dE && (u64)words * 8ull >= (u64)lq)
+                    meta |= META_SIMPLE | (dS << META_DS_SHIFT);
+            }
+        }
         // ---- walk
         int32_t lStart = pos, lEndExc = pos, aligned = 0, sumAfter = 0, prevRStartU = 0;
         int64_t prev = -1;
@@ -806,11 +829,23 @@ struct OpAdd { template <typename T> __device__ T operator()(T a, T b) const { r
 
 // K3: anchors per fragment
 __global__ __launch_bounds__(256) void k3_anchors_frag(const u32 *sidx, const u32 *jid_of, const int32_t *lstart,
-                                                        const int32_t *rend, u32 n, int32_t *frag_l, int32_t *frag_r,
-                                                        int32_t *frag_j) {
+                                                        const int32_t *rend, const u32 *meta, int all_generic, u32 n,
+                                                        int32_t *frag_l, int32_t *frag_r, int32_t *frag_j, u32 *gen_list,
+                                                        u32 *gen_count) {
     const u32 i = blockIdx.x * 256 + threadIdx.x;
     const bool valid = i < n;
     const u32 p = valid ? sidx[i] : 0;
+    {   // compact the sorted positions whose pair needs the generic compare (order is irrelevant)
+        const bool gen = valid && (all_generic || !(meta[p] & META_SIMPLE));
+        const u64 m = __ballot(gen);
+        if (m) {
+            u32 base = 0;
+            const int leader = __ffsll((long long)m) - 1;
+            if (lane_id() == leader) base = atomicAdd(gen_count, (u32)__popcll(m));
+            base = __shfl(base, leader, 64);
+            if (gen) gen_list[base + (u32)__popcll(m & ((1ull << lane_id()) - 1))] = i;
+        }
+    }
     const u32 j = valid ? jid_of[i] : 0xffffffffu;
     int32_t l = valid ? lstart[p] : INT32_MAX;
     int32_t r = valid ? rend[p] : INT32_MIN;
@@ -1070,6 +1105,107 @@ __device__ Side anchor_side(const OpsView cig, u32 n, int32_t position, int32_t 
     return S;
 }
 
+// per-pair match statistics through the generic lock-step walks (any CIGAR)
+__device__ __forceinline__ u64 pair_stats_generic(const OpsView cig, u32 nc, int32_t pos, int32_t aligned, const uint8_t *seq,
+                                                  int32_t lq, const uint8_t *genome, int32_t glen, bool has_x, const u32 *gcodes,
+                                                  int32_t left, int32_t istart, int32_t iend, int32_t right, u32 g, u64 *err) {
+    if (lq <= 1) { // junction.cc:168-185
+        const u32 totUp = (u32)((istart - 1) - left + 1);
+        const u32 totDown = (u32)(right - (iend + 1) + 1);
+        return pack_res(0, totUp < totDown ? totUp : totDown, 0);
+    }
+    const Side L = anchor_side(cig, nc, pos, aligned, seq, lq, genome, glen, has_x, gcodes, left, istart - 1);
+    if (L.err) {
+        set_error(err, g, L.err);
+        return 0;
+    }
+    const Side R = anchor_side(cig, nc, pos, aligned, seq, lq, genome, glen, has_x, gcodes, iend + 1, right);
+    if (R.err) {
+        set_error(err, g, R.err);
+        return 0;
+    }
+    const u32 upM = L.last_mis < 0 ? (u32)L.len : (u32)(L.len - 1 - L.last_mis);  // getNbMatchesFromEnd :272
+    const u32 downM = R.first_mis < 0 ? (u32)R.len : (u32)R.first_mis;            // getNbMatchesFromStart :263
+    const u32 tu = (u32)(L.len - L.mism), td = (u32)(R.len - R.mism);
+    return pack_res(upM < downM ? upM : downM, tu < td ? tu : td, (u32)(L.mism + R.mism));
+}
+
+__device__ __forceinline__ const DevBatch &find_batch(const DevBatch *batches, int n_batches, u32 g) {
+    int lo = 0, hi = n_batches - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (batches[mid].base <= g) lo = mid;
+        else hi = mid - 1;
+    }
+    return batches[lo];
+}
+
+// K4a: the common shape [S] M N M [S], one thread per pair IN EMISSION (BAM) ORDER, before the sort:
+// the left anchor is read[dS, dS+a) against genome[pos, pos+a), the right one read[dS+a, dS+a+b)
+// against genome[iend+1, iend+1+b); neither depends on the junction-level window, the walk rules
+// of bam_alignment.cc:341-462 reduce to exactly this for the shape.  Consecutive threads touch
+// consecutive reads and genome positions.
+__global__ __launch_bounds__(256) void k4a_simple(Pairs P, KeyFmt kf, const DevBatch *batches, int n_batches, const u32 *gcodes,
+                                                   int32_t glen, u32 n, u64 *res) {
+    const u32 p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= n) return;
+    const u32 meta = P.meta[p];
+    if (!(meta & META_SIMPLE)) return;
+    const u32 g = P.g[p];
+    const DevBatch &b = find_batch(batches, n_batches, g);
+    const u32 r = g - b.base;
+    int32_t istart, iend;
+    unpack_key(kf, P.key[p], istart, iend);
+    const int32_t pos = P.pos[p];
+    const int32_t a = istart - pos, bb = P.rend[p] - iend;
+    const int32_t dS = (int32_t)((meta >> META_DS_SHIFT) & 0xfffu);
+    const u32 *seqw = reinterpret_cast<const u32 *>(b.seq4 + (size_t)b.seq_off[r] * 4);
+    const int32_t g_words = (glen + 7) / 8 + 1;
+    int32_t misL = 0, firstL = -1, lastL = -1, misR = 0, firstR = -1, lastR = -1;
+    cmp_words(seqw, dS, gcodes, pos, g_words, a, 0, misL, firstL, lastL);
+    cmp_words(seqw, dS + a, gcodes, iend + 1, g_words, bb, 0, misR, firstR, lastR);
+    const u32 upM = lastL < 0 ? (u32)a : (u32)(a - 1 - lastL);
+    const u32 downM = firstR < 0 ? (u32)bb : (u32)firstR;
+    const u32 tu = (u32)(a - misL), td = (u32)(bb - misR);
+    res[p] = pack_res(upM < downM ? upM : downM, tu < td ? tu : td, (u32)(misL + misR));
+}
+
+// K4b: every other pair (multi-junction reads, indels, = X P H ops, exotic contigs, SEQ '*'), one
+// thread per entry of a compacted list of sorted positions; needs the junction-level anchors.
+__global__ __launch_bounds__(256) void k4b_generic(const u32 *list, const u32 *n_list, const u64 *skey, const u32 *sidx,
+                                                    const u32 *jid_of, Pairs P, KeyFmt kf, const DevBatch *batches, int n_batches,
+                                                    const int32_t *anc_l, const int32_t *anc_r, const uint8_t *genome,
+                                                    int32_t glen, int genome_has_x, const u32 *gcodes, u64 *res, u64 *err) {
+    __shared__ u32 s_ops[OPS_LDS][256];
+    const u32 t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= *n_list) return;
+    const u32 i = list[t];
+    const u32 p = sidx[i], j = jid_of[i];
+    const u32 g = P.g[p];
+    const DevBatch &b = find_batch(batches, n_batches, g);
+    const u32 r = g - b.base;
+    int32_t istart, iend;
+    unpack_key(kf, skey[i], istart, iend);
+    const u32 c0 = b.cig_off[r], c1 = b.cig_off[r + 1];
+    const u32 nc = c1 - c0;
+    OpsView cig;
+    cig.g = b.cigar + c0;
+    cig.lds = &s_ops[0][threadIdx.x];
+#pragma unroll
+    for (int k = 0; k < OPS_LDS; k++) s_ops[k][threadIdx.x] = (u32)k < nc ? cig.g[k] : 0u;
+    const int32_t pos = P.pos[p], aend = P.aend[p];
+    const int32_t lq = b.l_qseq[r];
+    const u32 words = b.seq_off[r + 1] - b.seq_off[r];
+    if (lq > 1 && (u64)words * 8ull < (u64)lq) {
+        set_error(err, g, PJB_ERR_NO_SEQ);
+        res[p] = 0;
+        return;
+    }
+    const uint8_t *seq = b.seq4 + (size_t)b.seq_off[r] * 4;
+    res[p] = pair_stats_generic(cig, nc, pos, aend - pos + 1, seq, lq, genome, glen, genome_has_x != 0, gcodes, anc_l[j],
+                                istart, iend, anc_r[j], g, err);
+}
+
 // fragment record: 48 words
 enum {
     F_N = 0, F_R1P, F_R1N, F_R2P, F_R2N, F_MS, F_XSP, F_XSN, F_UM, F_BPP, F_PPP, F_REL, F_DIST, // sums
@@ -1081,11 +1217,10 @@ enum {
     F_WORDS = 48
 };
 
+// K4: gather the per-pair predicates and match statistics in sorted order and fold them to fragment
+// heads with a segmented wave reduction (junction.cc:862-909 accumulators, :755-814 counters).
 __global__ __launch_bounds__(256) void k4_pairs(const u64 *skey, const u32 *sidx, const u32 *jid_of, Pairs P, KeyFmt kf,
-                                                 const DevBatch *batches, int n_batches, const int32_t *anc_l,
-                                                 const int32_t *anc_r, const uint8_t *genome, int32_t glen, int genome_has_x,
-                                                 const u32 *gcodes, u32 n, u32 *frag, int32_t *frag_j, u64 *err, int ablate) {
-    __shared__ u32 s_ops[OPS_LDS][256];
+                                                 const u64 *res, u32 n, u32 *frag, int32_t *frag_j) {
     const u32 i = blockIdx.x * 256 + threadIdx.x;
     const bool valid = i < n;
     const int lane = lane_id();
@@ -1096,58 +1231,11 @@ __global__ __launch_bounds__(256) void k4_pairs(const u64 *skey, const u32 *sidx
     if (valid) {
         const u32 p = sidx[i];
         j = jid_of[i];
-        const u32 g = P.g[p];
-        // locate the batch holding read ordinal g
-        int lo = 0, hi = n_batches - 1;
-        while (lo < hi) {
-            const int mid = (lo + hi + 1) >> 1;
-            if (batches[mid].base <= g) lo = mid;
-            else hi = mid - 1;
-        }
-        const DevBatch &b = batches[lo];
-        const u32 r = g - b.base;
         int32_t istart, iend;
         unpack_key(kf, skey[i], istart, iend);
-        const int32_t left = anc_l[j], right = anc_r[j];
-        const u32 c0 = b.cig_off[r], c1 = b.cig_off[r + 1];
-        const u32 nc = c1 - c0;
-        OpsView cig;
-        cig.g = b.cigar + c0;
-        cig.lds = &s_ops[0][threadIdx.x];
-#pragma unroll
-        for (int k = 0; k < OPS_LDS; k++) s_ops[k][threadIdx.x] = (u32)k < nc ? cig.g[k] : 0u;
         const int32_t pos = P.pos[p], aend = P.aend[p];
-        const int32_t aligned = aend - pos + 1;
-        const int32_t lq = b.l_qseq[r];
-        u32 upM = 0, downM = 0, minMatch = 0, mmes = 0, nbMis = 0;
-        if (ablate & 1) {
-        } else if (lq <= 1) { // junction.cc:168-185
-            const u32 totUp = (u32)((istart - 1) - left + 1);
-            const u32 totDown = (u32)(right - (iend + 1) + 1);
-            mmes = totUp < totDown ? totUp : totDown;
-        } else {
-            const u32 words = b.seq_off[r + 1] - b.seq_off[r];
-            if ((u64)words * 8ull < (u64)lq) set_error(err, g, PJB_ERR_NO_SEQ);
-            else {
-                const uint8_t *seq = b.seq4 + (size_t)b.seq_off[r] * 4;
-                const Side L = anchor_side(cig, nc, pos, aligned, seq, lq, genome, glen, genome_has_x != 0, gcodes, left, istart - 1);
-                Side R;
-                R.err = 0;
-                if (L.err) set_error(err, g, L.err);
-                else {
-                    R = anchor_side(cig, nc, pos, aligned, seq, lq, genome, glen, genome_has_x != 0, gcodes, iend + 1, right);
-                    if (R.err) set_error(err, g, R.err);
-                }
-                if (!L.err && !R.err) {
-                    upM = L.last_mis < 0 ? (u32)L.len : (u32)(L.len - 1 - L.last_mis);  // getNbMatchesFromEnd :272
-                    downM = R.first_mis < 0 ? (u32)R.len : (u32)R.first_mis;           // getNbMatchesFromStart :263
-                    minMatch = upM < downM ? upM : downM;
-                    const u32 tu = (u32)(L.len - L.mism), td = (u32)(R.len - R.mism);
-                    mmes = tu < td ? tu : td;
-                    nbMis = (u32)(L.mism + R.mism);
-                }
-            }
-        }
+        const u64 rs = res[p];
+        const u32 minMatch = (u32)(rs & 0xfffffu), mmes = (u32)((rs >> 20) & 0xfffffu), nbMis = (u32)(rs >> 40);
         const u32 meta = P.meta[p];
         const u32 cat = meta & META_CAT_MASK;
         const u32 xs = (meta >> META_XS_SHIFT) & 3u;
@@ -1176,10 +1264,6 @@ __global__ __launch_bounds__(256) void k4_pairs(const u64 *skey, const u32 *sidx
         mx[4] = minMatch;
         first_mis = minMatch > 0 ? minMatch : 100000000u;
         mism64 = nbMis;
-    }
-    if (ablate & 2) {
-        if (valid && (lane == 0)) frag_j[j + (i >> 6)] = (int32_t)(j + mx[3] + cnt[3] + (u32)mism64);
-        return;
     }
     // ---- segmented wave reduce to fragment heads; the "same junction at distance o" tests are done once
     u32 take = 0;

@@ -44,7 +44,8 @@ class PjbRegionResult(C.Structure):
 
 
 class PjbTiming(C.Structure):
-    _fields_ = [("total_ms", C.c_float), ("stage_ms", C.c_float * N_STAGES), ("sort_passes", C.c_int64)]
+    _fields_ = [("total_ms", C.c_float), ("stage_ms", C.c_float * N_STAGES), ("sort_passes", C.c_int64),
+                ("generic_pairs", C.c_int64)]
 
 
 class PjbKernelTime(C.Structure):
@@ -216,7 +217,7 @@ class Context:
         t = PjbTiming()
         self._check(self._L.pjb_get_timing(self._h, C.byref(t)))
         return dict(total_ms=t.total_ms, stage_ms={STAGE_NAMES[i]: t.stage_ms[i] for i in range(N_STAGES)},
-                    sort_passes=t.sort_passes)
+                    sort_passes=t.sort_passes, generic_pairs=t.generic_pairs)
 
 
 def _kernel_timing(self):
