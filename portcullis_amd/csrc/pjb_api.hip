@@ -56,6 +56,8 @@ struct OpenContig {
 struct pjb_ctx {
     pjb_config cfg;
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr; // side stream: work that does not depend on the sort (k4a_simple)
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     std::string err;
     std::vector<int32_t> ref_len;
     std::vector<Contig> contigs;
@@ -351,6 +353,9 @@ int pjb_create(pjb_ctx **out, const pjb_config *cfg) {
         delete c;
         return fail(nullptr, PJB_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e));
     }
+    (void)hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking);
+    (void)hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
+    (void)hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming);
     for (auto &ev : c->ev) (void)hipEventCreate(&ev);
     c->ktime = (cfg->flags & PJB_FLAG_KERNEL_TIMING) != 0;
     if (const char *s = getenv("PJB_RADIX_BITS")) {
@@ -382,6 +387,9 @@ void pjb_destroy(pjb_ctx *c) {
     for (Buf *b : all) release(*b);
     for (auto &ev : c->ev) (void)hipEventDestroy(ev);
     for (auto &ev : c->ev_pool) (void)hipEventDestroy(ev);
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    if (c->stream2) (void)hipStreamDestroy(c->stream2);
     (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -702,13 +710,24 @@ int pjb_finish_contig(pjb_ctx *c, int32_t tid, pjb_region_result *res) {
     }
     // ---- K4a: match statistics of the common [S] M N M [S] shape, in BAM order, while the keys are still unsorted
     if ((rc = ensure(c, c->b_res, (size_t)P * 8))) return rc;
-    if ((rc = ensure(c, c->b_genlist, (size_t)P * 4))) return rc;
-    if ((rc = ensure(c, c->b_gencount, 4))) return rc;
-    HIP_TRY(c, hipMemsetAsync(c->b_gencount.p, 0, 4, st));
+    const u32 gen_cap = (((P + 255) / 256 + GEN_SHARDS - 1) / GEN_SHARDS) * 256; // entries per sub-list
+    if ((rc = ensure(c, c->b_genlist, (size_t)gen_cap * GEN_SHARDS * 4))) return rc;
+    if ((rc = ensure(c, c->b_gencount, GEN_SHARDS * 4))) return rc;
+    HIP_TRY(c, hipMemsetAsync(c->b_gencount.p, 0, GEN_SHARDS * 4, st));
     const bool fast_codes = G.codes != nullptr && !G.has_x;
-    if (fast_codes)
+    // it runs on the side stream, beside the sort of the main stream (joined before K4b)
+    if (fast_codes) {
+        HIP_TRY(c, hipEventRecord(c->ev_fork, st));
+        HIP_TRY(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
+        const bool timed = ktime_wanted(c, "k4a_simple");
+        hipStream_t main_stream = c->stream;
+        c->stream = c->stream2; // LAUNCH (and its event bracket) follow c->stream
         LAUNCH(c, "k4a_simple", k4a_simple, dim3((P + 255) / 256), dim3(256), pr, kf, (const DevBatch *)c->b_batches.p,
                (int)batches.size(), (const u32 *)G.codes, (int32_t)G.len, P, (u64 *)c->b_res.p);
+        c->stream = main_stream;
+        (void)timed;
+        HIP_TRY(c, hipEventRecord(c->ev_join, c->stream2));
+    }
     HIP_TRY(c, hipEventRecord(c->ev[1], st));
 
     // ---- K2: radix sort (key, pair index)
@@ -725,6 +744,8 @@ int pjb_finish_contig(pjb_ctx *c, int32_t tid, pjb_region_result *res) {
     for (int p = 0; p < n_pass; p++) {
         const int bits = pass_bits[(size_t)p];
         if (bits <= 0) break;
+        // pass 1 starts overwriting the unsorted keys that k4a_simple (side stream) reads
+        if (p == 1 && fast_codes) HIP_TRY(c, hipStreamWaitEvent(st, c->ev_join, 0));
         const u64 *kin = (const u64 *)c->b_key[cur].p;
         u64 *kout = (u64 *)c->b_key[cur ^ 1].p;
         const u32 *vin = p == 0 ? nullptr : (const u32 *)c->b_idx[cur].p;
@@ -787,10 +808,11 @@ int pjb_finish_contig(pjb_ctx *c, int32_t tid, pjb_region_result *res) {
            (int32_t *)c->b_ancr.p);
     HIP_TRY(c, hipEventRecord(c->ev[4], st));
 
+    if (fast_codes) HIP_TRY(c, hipStreamWaitEvent(st, c->ev_join, 0));
     // ---- K4b: the pairs that need the generic walks (list length lives on the device; the grid covers the
     // worst case and surplus blocks exit at once), then K4: gather + segmented reduce -> fragments
-    LAUNCH(c, "k4b_generic", k4b_generic, dim3(pair_blocks), dim3(256), (const u32 *)c->b_genlist.p,
-           (const u32 *)c->b_gencount.p, skey, sidx, (const u32 *)c->b_jid.p, pr, kf, (const DevBatch *)c->b_batches.p,
+    LAUNCH(c, "k4b_generic", k4b_generic, dim3((gen_cap * GEN_SHARDS + 255) / 256), dim3(256), (const u32 *)c->b_genlist.p,
+           (const u32 *)c->b_gencount.p, pair_blocks, skey, sidx, (const u32 *)c->b_jid.p, pr, kf, (const DevBatch *)c->b_batches.p,
            (int)batches.size(), (const int32_t *)c->b_ancl.p, (const int32_t *)c->b_ancr.p, (const uint8_t *)G.d,
            (int32_t)G.len, G.has_x ? 1 : 0, (const u32 *)(G.has_x ? nullptr : G.codes), (u64 *)c->b_res.p, d_err);
     LAUNCH(c, "k4_pairs", k4_pairs, dim3(pair_blocks), dim3(256), skey, sidx, (const u32 *)c->b_jid.p, pr, kf,
@@ -824,13 +846,14 @@ int pjb_finish_contig(pjb_ctx *c, int32_t tid, pjb_region_result *res) {
     }
     HIP_TRY(c, hipMemcpyAsync(c->rows_pinned + old, c->b_rows.p, (size_t)J * sizeof(pjb_junction_row), hipMemcpyDeviceToHost, st));
     HIP_TRY(c, hipMemcpyAsync(&herr, d_err, 8, hipMemcpyDeviceToHost, st));
-    u32 n_generic = 0;
-    HIP_TRY(c, hipMemcpyAsync(&n_generic, c->b_gencount.p, 4, hipMemcpyDeviceToHost, st));
+    u32 gen_counts[GEN_SHARDS];
+    HIP_TRY(c, hipMemcpyAsync(gen_counts, c->b_gencount.p, GEN_SHARDS * 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(c, hipEventRecord(c->ev[7], st));
     HIP_TRY(c, hipStreamSynchronize(st));
     if ((rc = check_device_error(c, herr))) return rc;
     c->rows_n = old + J;
-    c->timing.generic_pairs = n_generic;
+    c->timing.generic_pairs = 0;
+    for (u32 k = 0; k < GEN_SHARDS; k++) c->timing.generic_pairs += gen_counts[k];
     if (c->ktime) ev_collect(c);
     for (int k = 0; k < 7; k++) (void)hipEventElapsedTime(&c->timing.stage_ms[k], c->ev[k], c->ev[k + 1]);
     (void)hipEventElapsedTime(&c->timing.total_ms, c->ev[0], c->ev[7]);

@@ -827,6 +827,7 @@ struct OpMin { template <typename T> __device__ T operator()(T a, T b) const { r
 struct OpMax { template <typename T> __device__ T operator()(T a, T b) const { return a > b ? a : b; } };
 struct OpAdd { template <typename T> __device__ T operator()(T a, T b) const { return a + b; } };
 
+constexpr u32 GEN_SHARDS = 256;
 // K3: anchors per fragment
 __global__ __launch_bounds__(256) void k3_anchors_frag(const u32 *sidx, const u32 *jid_of, const int32_t *lstart,
                                                         const int32_t *rend, const u32 *meta, int all_generic, u32 n,
@@ -835,15 +836,18 @@ __global__ __launch_bounds__(256) void k3_anchors_frag(const u32 *sidx, const u3
     const u32 i = blockIdx.x * 256 + threadIdx.x;
     const bool valid = i < n;
     const u32 p = valid ? sidx[i] : 0;
-    {   // compact the sorted positions whose pair needs the generic compare (order is irrelevant)
+    {   // compact the sorted positions whose pair needs the generic compare (order is irrelevant).
+        // GEN_SHARDS independent sub-lists keep the returning atomics off a single address.
         const bool gen = valid && (all_generic || !(meta[p] & META_SIMPLE));
         const u64 m = __ballot(gen);
         if (m) {
+            const u32 shard = blockIdx.x % GEN_SHARDS;
+            const u32 cap = ((gridDim.x + GEN_SHARDS - 1) / GEN_SHARDS) * 256;
             u32 base = 0;
             const int leader = __ffsll((long long)m) - 1;
-            if (lane_id() == leader) base = atomicAdd(gen_count, (u32)__popcll(m));
+            if (lane_id() == leader) base = atomicAdd(&gen_count[shard], (u32)__popcll(m));
             base = __shfl(base, leader, 64);
-            if (gen) gen_list[base + (u32)__popcll(m & ((1ull << lane_id()) - 1))] = i;
+            if (gen) gen_list[(size_t)shard * cap + base + (u32)__popcll(m & ((1ull << lane_id()) - 1))] = i;
         }
     }
     const u32 j = valid ? jid_of[i] : 0xffffffffu;
@@ -1172,13 +1176,16 @@ __global__ __launch_bounds__(256) void k4a_simple(Pairs P, KeyFmt kf, const DevB
 
 // K4b: every other pair (multi-junction reads, indels, = X P H ops, exotic contigs, SEQ '*'), one
 // thread per entry of a compacted list of sorted positions; needs the junction-level anchors.
-__global__ __launch_bounds__(256) void k4b_generic(const u32 *list, const u32 *n_list, const u64 *skey, const u32 *sidx,
+__global__ __launch_bounds__(256) void k4b_generic(const u32 *list, const u32 *n_list, u32 pair_blocks, const u64 *skey, const u32 *sidx,
                                                     const u32 *jid_of, Pairs P, KeyFmt kf, const DevBatch *batches, int n_batches,
                                                     const int32_t *anc_l, const int32_t *anc_r, const uint8_t *genome,
                                                     int32_t glen, int genome_has_x, const u32 *gcodes, u64 *res, u64 *err) {
     __shared__ u32 s_ops[OPS_LDS][256];
+    // sub-list `shard` occupies [shard * cap, shard * cap + n_list[shard]); pair_blocks is the K3 grid size
+    const u32 cap = ((pair_blocks + GEN_SHARDS - 1) / GEN_SHARDS) * 256;
     const u32 t = blockIdx.x * 256 + threadIdx.x;
-    if (t >= *n_list) return;
+    const u32 shard = t / cap, k_in = t % cap;
+    if (shard >= GEN_SHARDS || k_in >= n_list[shard]) return;
     const u32 i = list[t];
     const u32 p = sidx[i], j = jid_of[i];
     const u32 g = P.g[p];
