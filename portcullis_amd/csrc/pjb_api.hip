@@ -89,7 +89,7 @@ struct pjb_ctx {
     // scratch
     Buf b_batches, b_tile_cnt, b_tile_stats, b_cstats, b_err, b_total, b_splidx, b_splpoff;
     Buf b_key[2], b_idx[2], b_g, b_lstart, b_rend, b_pos, b_aend, b_meta, b_updown;
-    Buf b_hist, b_hist_scan, b_scan_tiles;
+    Buf b_hist, b_hist_scan, b_scan_tiles, b_bintotal;
     Buf b_jid, b_seg, b_runfirst, b_runstart;
     Buf b_frag, b_fragj, b_fragl, b_fragr, b_acc, b_ancl, b_ancr, b_rows, b_hasx, b_ent, b_res, b_genlist, b_gencount;
 };
@@ -383,7 +383,7 @@ void pjb_destroy(pjb_ctx *c) {
                   &c->b_key[1], &c->b_idx[0], &c->b_idx[1], &c->b_g, &c->b_lstart, &c->b_rend, &c->b_pos, &c->b_aend,
                   &c->b_meta, &c->b_updown, &c->b_hist, &c->b_hist_scan, &c->b_scan_tiles, &c->b_jid, &c->b_seg,
                   &c->b_runfirst, &c->b_runstart, &c->b_frag, &c->b_fragj, &c->b_fragl, &c->b_fragr, &c->b_acc,
-                  &c->b_ancl, &c->b_ancr, &c->b_rows, &c->b_hasx, &c->b_ent, &c->b_splidx, &c->b_splpoff, &c->b_res, &c->b_genlist, &c->b_gencount};
+                  &c->b_ancl, &c->b_ancr, &c->b_rows, &c->b_hasx, &c->b_ent, &c->b_splidx, &c->b_splpoff, &c->b_res, &c->b_genlist, &c->b_gencount, &c->b_bintotal};
     for (Buf *b : all) release(*b);
     for (auto &ev : c->ev) (void)hipEventDestroy(ev);
     for (auto &ev : c->ev_pool) (void)hipEventDestroy(ev);
@@ -740,6 +740,7 @@ int pjb_finish_contig(pjb_ctx *c, int32_t tid, pjb_region_result *res) {
     const int dbits = pass_bits[0];
     if ((rc = ensure(c, c->b_hist, (size_t)rs_tiles * (1u << dbits) * 4))) return rc;
     if ((rc = ensure(c, c->b_hist_scan, (size_t)rs_tiles * (1u << dbits) * 4))) return rc;
+    if ((rc = ensure(c, c->b_bintotal, (size_t)4 << dbits))) return rc;
     int cur = 0, shift = 0;
     for (int p = 0; p < n_pass; p++) {
         const int bits = pass_bits[(size_t)p];
@@ -750,10 +751,11 @@ int pjb_finish_contig(pjb_ctx *c, int32_t tid, pjb_region_result *res) {
         u64 *kout = (u64 *)c->b_key[cur ^ 1].p;
         const u32 *vin = p == 0 ? nullptr : (const u32 *)c->b_idx[cur].p;
         u32 *vout = (u32 *)c->b_idx[cur ^ 1].p;
-        LAUNCH(c, "rs_hist", rs_hist, dim3(rs_tiles), dim3(256), kin, P, shift, bits, (u32 *)c->b_hist.p, rs_tiles);
-        HistFn hf{(const u32 *)c->b_hist.p};
-        HistSink hs{(u32 *)c->b_hist_scan.p};
-        if ((rc = run_scan(c, "rs_scan", hf, hs, (u64)rs_tiles << bits, (u64 *)c->b_total.p))) return rc;
+        HIP_TRY(c, hipMemsetAsync(c->b_bintotal.p, 0, (size_t)4 << bits, st));
+        LAUNCH(c, "rs_hist", rs_hist, dim3(rs_tiles), dim3(256), kin, P, shift, bits, (u32 *)c->b_hist.p, rs_tiles,
+               (u32 *)c->b_bintotal.p);
+        LAUNCH(c, "rs_rowscan", rs_rowscan, dim3(1u << bits), dim3(256), (const u32 *)c->b_hist.p,
+               (const u32 *)c->b_bintotal.p, rs_tiles, (u32 *)c->b_hist_scan.p);
         LAUNCH(c, "rs_scatter", rs_scatter, dim3(rs_tiles), dim3(256), kin, vin, kout, vout, P, shift, bits,
                (const u32 *)c->b_hist_scan.p, rs_tiles);
         cur ^= 1;

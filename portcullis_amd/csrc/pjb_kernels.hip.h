@@ -684,7 +684,8 @@ constexpr int RS_TILE = 256 * RS_ITEMS; // 4096 keys per block
 constexpr int RS_MAX_BITS = 12;
 constexpr int RS_MAX_BINS = 1 << RS_MAX_BITS;
 
-__global__ __launch_bounds__(256) void rs_hist(const u64 *keys, u32 n, int shift, int bits, u32 *hist, u32 n_tiles) {
+__global__ __launch_bounds__(256) void rs_hist(const u64 *keys, u32 n, int shift, int bits, u32 *hist, u32 n_tiles,
+                                                u32 *bin_total) {
     __shared__ u32 h[RS_MAX_BINS];
     const u32 nb = 1u << bits;
     for (u32 d = threadIdx.x; d < nb; d += 256) h[d] = 0;
@@ -697,7 +698,38 @@ __global__ __launch_bounds__(256) void rs_hist(const u64 *keys, u32 n, int shift
         if (i < n) atomicAdd(&h[(u32)(keys[i] >> shift) & mask], 1u);
     }
     __syncthreads();
-    for (u32 d = threadIdx.x; d < nb; d += 256) hist[(size_t)d * n_tiles + blockIdx.x] = h[d];
+    for (u32 d = threadIdx.x; d < nb; d += 256) {
+        const u32 v = h[d];
+        hist[(size_t)d * n_tiles + blockIdx.x] = v;
+        if (v) atomicAdd(&bin_total[d], v); // n_tiles adds per bin, spread over 2^bits addresses
+    }
+}
+
+// One block per digit value: exclusive scan of that digit's row of per-tile counts, offset by the
+// number of keys with a smaller digit (sum of bin totals below it).  Replaces a generic 3-kernel scan
+// of the whole [bins x tiles] matrix.
+__global__ __launch_bounds__(256) void rs_rowscan(const u32 *hist, const u32 *bin_total, u32 n_tiles, u32 *hist_scan) {
+    __shared__ u32 sm[4];
+    __shared__ u32 s_base;
+    const u32 d = blockIdx.x;
+    u32 part = 0;
+    for (u32 k = threadIdx.x; k < d; k += 256) part += bin_total[k];
+    part = wave_sum(part);
+    if (lane_id() == 0) sm[threadIdx.x >> 6] = part;
+    __syncthreads();
+    if (threadIdx.x == 0) s_base = sm[0] + sm[1] + sm[2] + sm[3];
+    __syncthreads();
+    u32 run = s_base;
+    const u32 *row = hist + (size_t)d * n_tiles;
+    u32 *out = hist_scan + (size_t)d * n_tiles;
+    for (u32 t0 = 0; t0 < n_tiles; t0 += 256) {
+        const u32 t = t0 + threadIdx.x;
+        const u32 v = t < n_tiles ? row[t] : 0u;
+        u32 tot;
+        const u32 ex = block_escan_256<u32>(v, sm, &tot);
+        if (t < n_tiles) out[t] = run + ex;
+        run += tot;
+    }
 }
 
 __global__ __launch_bounds__(256) void rs_scatter(const u64 *kin, const u32 *vin, u64 *kout, u32 *vout, u32 n, int shift,

@@ -180,40 +180,67 @@ void BamReader::open(bool useCsi) {
     loadIndex(useCsi);
 }
 
+// BAI (SAM spec section 5.2) or CSI (htslib CSIv1: BGZF-compressed, bins carry loffset, no linear
+// index).  Only two things are kept per target: the smallest chunk start (where its records begin)
+// and every virtual offset the index names, all of which are record starts (decodeRegionParallel).
 void BamReader::loadIndex(bool useCsi) {
-    if (useCsi) throw BamException("CSI indices are not supported by this reader yet; use a BAI index");
-    const std::string path = bamFile + ".bai";
-    FILE* f = fopen(path.c_str(), "rb");
-    if (!f) throw BamException("Could not open BAM index: " + path);
+    const std::string path = bamFile + (useCsi ? ".csi" : ".bai");
     std::vector<uint8_t> buf;
-    fseeko(f, 0, SEEK_END);
-    const off_t sz = ftello(f);
-    fseeko(f, 0, SEEK_SET);
-    buf.resize((size_t)sz);
-    if (sz && fread(buf.data(), 1, (size_t)sz, f) != (size_t)sz) {
+    {
+        FILE* f = fopen(path.c_str(), "rb");
+        if (!f) throw BamException("Could not open BAM index: " + path);
+        fseeko(f, 0, SEEK_END);
+        const off_t sz = ftello(f);
+        fseeko(f, 0, SEEK_SET);
+        buf.resize((size_t)sz);
+        const bool ok = !sz || fread(buf.data(), 1, (size_t)sz, f) == (size_t)sz;
         fclose(f);
-        throw BamException("Could not read BAM index: " + path);
+        if (!ok) throw BamException("Could not read BAM index: " + path);
     }
-    fclose(f);
-    if (buf.size() < 8 || memcmp(buf.data(), "BAI\1", 4) != 0) throw BamException("Not a BAI index: " + path);
+    if (buf.size() >= 2 && buf[0] == 31 && buf[1] == 139) {  // BGZF container (CSI files are compressed)
+        BgzfStream z;
+        z.open(path);
+        std::vector<uint8_t> out;
+        uint8_t tmp[65536];
+        for (;;) {
+            const size_t n = z.read(tmp, sizeof tmp);
+            out.insert(out.end(), tmp, tmp + n);
+            if (n < sizeof tmp) break;
+        }
+        buf.swap(out);
+    }
+    const bool csi = buf.size() >= 4 && memcmp(buf.data(), "CSI\1", 4) == 0;
+    const bool bai = buf.size() >= 4 && memcmp(buf.data(), "BAI\1", 4) == 0;
+    if (!csi && !bai) throw BamException("Not a BAI or CSI index: " + path);
     size_t o = 4;
+    uint32_t pseudoBin = 37450;
+    if (csi) {
+        if (o + 12 > buf.size()) throw BamException("Truncated CSI index");
+        const int32_t depth = (int32_t)le32(&buf[o + 4]);
+        const uint32_t l_aux = le32(&buf[o + 8]);
+        o += 12 + l_aux;
+        pseudoBin = (uint32_t)(((1ull << (depth * 3 + 3)) - 1) / 7 + 1);
+    }
+    if (o + 4 > buf.size()) throw BamException("Truncated BAM index");
     const uint32_t n_ref = le32(&buf[o]);
     o += 4;
     firstOffset.assign(targets.size(), ~0ull);
     restart.assign(targets.size(), std::vector<uint64_t>());
     for (uint32_t r = 0; r < n_ref; r++) {
         std::vector<uint64_t> pts;
-        if (o + 4 > buf.size()) throw BamException("Truncated BAI index");
+        if (o + 4 > buf.size()) throw BamException("Truncated BAM index");
         const uint32_t n_bin = le32(&buf[o]);
         o += 4;
         uint64_t first = ~0ull;
         for (uint32_t b = 0; b < n_bin; b++) {
-            if (o + 8 > buf.size()) throw BamException("Truncated BAI index");
+            if (o + (csi ? 16 : 8) > buf.size()) throw BamException("Truncated BAM index");
             const uint32_t bin = le32(&buf[o]);
-            const uint32_t n_chunk = le32(&buf[o + 4]);
-            o += 8;
-            if (o + 16ull * n_chunk > buf.size()) throw BamException("Truncated BAI index");
-            if (bin != 37450)  // pseudo-bin holding metadata, not chunks
+            o += 4;
+            if (csi) o += 8;  // loffset: the start of the first record overlapping the bin, not of a record IN it
+            const uint32_t n_chunk = le32(&buf[o]);
+            o += 4;
+            if (o + 16ull * n_chunk > buf.size()) throw BamException("Truncated BAM index");
+            if (bin != pseudoBin)  // the pseudo-bin holds metadata, not chunks
                 for (uint32_t c = 0; c < n_chunk; c++) {
                     const uint64_t v = le64(&buf[o + 16 * c]);
                     first = std::min(first, v);
@@ -221,15 +248,17 @@ void BamReader::loadIndex(bool useCsi) {
                 }
             o += 16ull * n_chunk;
         }
-        if (o + 4 > buf.size()) throw BamException("Truncated BAI index");
-        const uint32_t n_intv = le32(&buf[o]);
-        o += 4;
-        if (o + 8ull * n_intv > buf.size()) throw BamException("Truncated BAI index");
-        for (uint32_t k = 0; k < n_intv; k++) {
-            const uint64_t v = le64(&buf[o + 8ull * k]);
-            if (v) pts.push_back(v);  // first alignment overlapping each 16 kb window
+        if (!csi) {
+            if (o + 4 > buf.size()) throw BamException("Truncated BAI index");
+            const uint32_t n_intv = le32(&buf[o]);
+            o += 4;
+            if (o + 8ull * n_intv > buf.size()) throw BamException("Truncated BAI index");
+            for (uint32_t k = 0; k < n_intv; k++) {
+                const uint64_t v = le64(&buf[o + 8ull * k]);
+                if (v) pts.push_back(v);  // first alignment overlapping each 16 kb window
+            }
+            o += 8ull * n_intv;
         }
-        o += 8ull * n_intv;
         if (r < firstOffset.size()) {
             firstOffset[r] = first;
             std::sort(pts.begin(), pts.end());

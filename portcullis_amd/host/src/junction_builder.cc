@@ -513,7 +513,7 @@ int JunctionBuilder::main(int argc, char* argv[]) {
              << "      --source <name>        Source column of the BED/GFF output (default portcullis)" << endl
              << "      --exon_gff             Also write <prefix>.junctions.exon.gff3" << endl
              << "      --intron_gff           Also write <prefix>.junctions.intron.gff3" << endl
-             << "  -c, --use_csi              Use a CSI index (not supported yet)" << endl
+             << "  -c, --use_csi              Use the CSI index of the prepared BAM instead of the BAI" << endl
              << "      --devices <n>          Number of GPUs to use (default: all visible)" << endl
              << "  -v, --verbose" << endl;
         return help ? 0 : 1;

@@ -176,3 +176,13 @@ def test_strandedness_has_no_effect_on_junc_output(tmp_path):
     a = _e2e(tmp_path, "--config", "C2-small", "--threads", "4", "--strandedness", "firststrand")
     b = _e2e(tmp_path, "--config", "C2-small", "--threads", "4", "--strandedness", "UNKNOWN")
     assert a["tab_identical_to_oracle"] and a["tab_md5"] == b["tab_md5"]
+
+
+def test_csi_index(tmp_path, orc):
+    """-c / --use_csi: the CSI index (BGZF-compressed, no linear index) drives the same decode."""
+    from util_bam import bai_to_csi
+    prep = multi_contig(tmp_path, [41, 42])
+    bam = os.path.join(prep, PREP_BAM)
+    bai_to_csi(bam + ".bai", bam + ".csi")
+    os.remove(bam + ".bai")
+    check(prep, tmp_path, orc, "FR", threads=4, extra_opts=("-c",))

@@ -225,6 +225,32 @@ def write_bam(path, refs, reads, block_size=0xFF00, header_text=None, write_inde
                 f.write(struct.pack("<Q", last))
 
 
+def bai_to_csi(bai_path, csi_path):
+    """Re-encode a BAI as a CSI (min_shift 14, depth 5: same binning scheme), BGZF-compressed like htslib writes it."""
+    d = open(bai_path, "rb").read()
+    assert d[:4] == b"BAI\x01"
+    (n_ref,) = struct.unpack_from("<i", d, 4)
+    o = 8
+    out = bytearray(b"CSI\x01" + struct.pack("<iii", 14, 5, 0) + struct.pack("<i", n_ref))
+    for _ in range(n_ref):
+        (n_bin,) = struct.unpack_from("<i", d, o)
+        o += 4
+        out += struct.pack("<i", n_bin)
+        for _b in range(n_bin):
+            b, n_chunk = struct.unpack_from("<Ii", d, o)
+            o += 8
+            chunks = d[o:o + 16 * n_chunk]
+            o += 16 * n_chunk
+            loff = struct.unpack_from("<Q", chunks, 0)[0] if n_chunk else 0
+            out += struct.pack("<IQi", b, loff, n_chunk) + chunks
+        (n_intv,) = struct.unpack_from("<i", d, o)
+        o += 4 + 8 * n_intv
+    with open(csi_path, "wb") as f:
+        for u in range(0, len(out), 0xFF00):
+            f.write(_bgzf_block(bytes(out[u:u + 0xFF00])))
+        f.write(BGZF_EOF)
+
+
 def write_fasta(path, contigs, width=60, write_index=True):
     """contigs: list of (name, sequence str/bytes)."""
     fai = []
