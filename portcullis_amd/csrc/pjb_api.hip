@@ -233,13 +233,15 @@ bool ktime_wanted(pjb_ctx *c, const char *name) {
         if (n == name) return true;
     return false;
 }
-#define LAUNCH(c, name, kern, grid, block, ...)                                   \
-    do {                                                                          \
-        const bool timed_ = ktime_wanted((c), name);                              \
-        if (timed_) ev_begin((c), name);                                          \
-        hipLaunchKernelGGL(kern, grid, block, 0, (c)->stream, __VA_ARGS__);       \
-        if (timed_) ev_end((c));                                                  \
+#define LAUNCH_LDS(c, name, kern, grid, block, lds_bytes, ...)                       \
+    do {                                                                            \
+        const bool timed_ = ktime_wanted((c), name);                                \
+        if (timed_) ev_begin((c), name);                                            \
+        hipLaunchKernelGGL(kern, grid, block, lds_bytes, (c)->stream, __VA_ARGS__); \
+        if (timed_) ev_end((c));                                                    \
+        HIP_TRY((c), hipGetLastError());                                            \
     } while (0)
+#define LAUNCH(c, name, kern, grid, block, ...) LAUNCH_LDS(c, name, kern, grid, block, 0, __VA_ARGS__)
 
 // generic scan launchers ------------------------------------------------------------------------
 template <typename F, typename G>
@@ -362,6 +364,9 @@ int pjb_create(pjb_ctx **out, const pjb_config *cfg) {
         int v = atoi(s);
         if (v >= 4 && v <= RS_MAX_BITS) c->radix_max_bits = v;
     }
+    // 12-bit digits need more dynamic LDS than the 64 KB a kernel gets without asking
+    (void)hipFuncSetAttribute((const void *)rs_scatter<0>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)rs_scatter_lds_bytes(RS_MAX_BITS));
     *out = c;
     return PJB_OK;
 }
@@ -687,10 +692,11 @@ int pjb_finish_contig(pjb_ctx *c, int32_t tid, pjb_region_result *res) {
 
     // ---- K1b: emit
     Pairs pr;
-    if ((rc = ensure(c, c->b_key[0], (size_t)P * 8))) return rc;
-    if ((rc = ensure(c, c->b_key[1], (size_t)P * 8))) return rc;
-    if ((rc = ensure(c, c->b_idx[0], (size_t)P * 4))) return rc;
-    if ((rc = ensure(c, c->b_idx[1], (size_t)P * 4))) return rc;
+    // one sort tile of slack: rs_pass loads whole tiles unguarded
+    if ((rc = ensure(c, c->b_key[0], ((size_t)P + RS_TILE) * 8))) return rc;
+    if ((rc = ensure(c, c->b_key[1], ((size_t)P + RS_TILE) * 8))) return rc;
+    if ((rc = ensure(c, c->b_idx[0], ((size_t)P + RS_TILE) * 4))) return rc;
+    if ((rc = ensure(c, c->b_idx[1], ((size_t)P + RS_TILE) * 4))) return rc;
     Buf *pb[] = {&c->b_g, &c->b_lstart, &c->b_rend, &c->b_pos, &c->b_aend, &c->b_meta, &c->b_updown};
     for (Buf *b : pb)
         if ((rc = ensure(c, *b, (size_t)P * 4))) return rc;
@@ -751,13 +757,19 @@ int pjb_finish_contig(pjb_ctx *c, int32_t tid, pjb_region_result *res) {
         u64 *kout = (u64 *)c->b_key[cur ^ 1].p;
         const u32 *vin = p == 0 ? nullptr : (const u32 *)c->b_idx[cur].p;
         u32 *vout = (u32 *)c->b_idx[cur ^ 1].p;
-        HIP_TRY(c, hipMemsetAsync(c->b_bintotal.p, 0, (size_t)4 << bits, st));
-        LAUNCH(c, "rs_hist", rs_hist, dim3(rs_tiles), dim3(256), kin, P, shift, bits, (u32 *)c->b_hist.p, rs_tiles,
-               (u32 *)c->b_bintotal.p);
-        LAUNCH(c, "rs_rowscan", rs_rowscan, dim3(1u << bits), dim3(256), (const u32 *)c->b_hist.p,
-               (const u32 *)c->b_bintotal.p, rs_tiles, (u32 *)c->b_hist_scan.p);
-        LAUNCH(c, "rs_scatter", rs_scatter, dim3(rs_tiles), dim3(256), kin, vin, kout, vout, P, shift, bits,
-               (const u32 *)c->b_hist_scan.p, rs_tiles);
+        LAUNCH(c, "rs_hist", rs_hist, dim3(rs_tiles), dim3(256), kin, P, shift, bits, (u32 *)c->b_hist.p, rs_tiles);
+        LAUNCH(c, "rs_rowscan", rs_rowscan, dim3(1u << bits), dim3(256), (const u32 *)c->b_hist.p, rs_tiles,
+               (u32 *)c->b_hist_scan.p, (u32 *)c->b_bintotal.p);
+#define RS_SCATTER(B)                                                                                                     \
+    LAUNCH_LDS(c, "rs_scatter", rs_scatter<B>, dim3(rs_tiles), dim3(256), rs_scatter_lds_bytes(bits), kin, vin, kout, vout, P, \
+               shift, bits, (const u32 *)c->b_hist_scan.p, (const u32 *)c->b_bintotal.p, rs_tiles)
+        switch (bits) { // the usual digit widths get an unrolled match loop
+        case 9: RS_SCATTER(9); break;
+        case 10: RS_SCATTER(10); break;
+        case 11: RS_SCATTER(11); break;
+        default: RS_SCATTER(0); break;
+        }
+#undef RS_SCATTER
         cur ^= 1;
         shift += bits;
     }

@@ -77,3 +77,24 @@ def test_fullsize_matches_oracle(c2):
     orows, oreg = orc.find_juncs(0, cfg.contig_len, data["genome"].cpu().numpy().tobytes(), hb.to_oracle(), "UNKNOWN")
     region_equal(reg, oreg)
     assert_rows_equal(rows, orows)
+
+
+@pytest.mark.parametrize("env", [{"PJB_RADIX_BITS": "6"}, {"PJB_RADIX_BITS": "10"}, {"PJB_RADIX_BITS": "12"}])
+def test_sort_variants_agree(c2, monkeypatch, env):
+    """The radix sort's digit width (unrolled 9/10/11-bit and generic match loops, 12-bit digits with
+    more than 64 KB of LDS) must not change a single byte of the row table."""
+    cfg, data, ctx0, reg, rows = c2
+    from portcullis_amd import ffi
+
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    with ffi.Context(0, "UNKNOWN") as ctx:
+        ctx.set_refs([cfg.contig_len])
+        ctx.upload_contig_device(0, data["genome"])
+        for _ in range(2):
+            ctx.clear_rows()
+            ctx.submit_batch_device(0, data["batch"], data["n_reads"])
+            reg2 = ctx.finish_contig(0)
+            again = ctx.collect()
+            assert reg2 == reg
+            assert hashlib.md5(again.tobytes()).hexdigest() == hashlib.md5(rows.tobytes()).hexdigest()
