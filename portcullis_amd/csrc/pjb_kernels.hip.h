@@ -528,13 +528,22 @@ __global__ __launch_bounds__(1024) void k1_scan_tiles(u32 *tile_cnt, const TileS
 // calcAlignmentStats (junction.cc:755-814) are evaluated here, where the read's fixed-width
 // fields are read coalesced, and packed into `meta`.
 // ---------------------------------------------------------------------------------------------
+// CIGAR ops of one alignment: the first OPS_LDS ops are staged in LDS (one column per thread), the
+// rest (long reads) are read from global memory
+constexpr int OPS_LDS = 8;
+struct OpsView {
+    const uint32_t *g;
+    const u32 *lds; // &s_ops[0][threadIdx.x], stride 256
+    __device__ __forceinline__ u32 operator[](u32 k) const { return k < (u32)OPS_LDS ? lds[k * 256] : g[k]; }
+};
+
 struct NCursor { // walks the N ops of one CIGAR yielding the unclamped position after each N
     u32 i;
     int32_t acc;
     bool has;
     int32_t peek;
 };
-__device__ __forceinline__ void ncursor_advance(NCursor &c, const uint32_t *cig, u32 n) {
+__device__ __forceinline__ void ncursor_advance(NCursor &c, const OpsView cig, u32 n) {
     c.has = false;
     while (c.i < n) {
         u32 op = cig[c.i++];
@@ -548,9 +557,13 @@ __device__ __forceinline__ void ncursor_advance(NCursor &c, const uint32_t *cig,
     }
 }
 
+// Thread per spliced read (dense, from the list k1_count compacted).  The read's CIGAR is fetched
+// once (8 independent loads into an LDS column, the walks below then run at LDS latency); one walk
+// writes every field of the read's pairs.
 __global__ __launch_bounds__(256) void k1_emit(DevBatch b, const u32 *tile_off, const TileStats *tile_stats,
                                                 const u32 *spl_idx, const u32 *spl_poff, Pairs P, KeyFmt kf, int32_t ref_len,
                                                 int32_t tid, int orientation, u64 *err) {
+    __shared__ u32 s_ops[OPS_LDS][256];
     const u32 tile = b.tile_base + blockIdx.x;
     const u32 nspl = tile_stats[tile].spliced;
     const u32 toff = tile_off[tile];
@@ -560,17 +573,18 @@ __global__ __launch_bounds__(256) void k1_emit(DevBatch b, const u32 *tile_off, 
         const int64_t r = spl_idx[slot];
         const u32 off = toff + spl_poff[slot];
         const u32 c0 = b.cig_off[r], c1 = b.cig_off[r + 1];
-        const uint32_t *cig = b.cigar + c0;
         const u32 n = c1 - c0;
+        OpsView cig;
+        cig.g = b.cigar + c0;
+        cig.lds = &s_ops[0][threadIdx.x];
+#pragma unroll
+        for (int k = 0; k < OPS_LDS; k++) s_ops[k][threadIdx.x] = (u32)k < n ? cig.g[k] : 0u;
         const int32_t pos = b.pos[r];
         const u32 g = b.base + (u32)r;
         // ---- per-read predicates
         const u32 flag = b.flag[r];
         const bool first = flag & 0x40, rev = flag & 0x10;
         u32 meta = (first ? 0u : 2u) + (rev ? 1u : 0u);
-        u32 nN = 0;
-        for (u32 q = 0; q < n; q++) nN += ((cig[q] & 15u) == OP_N);
-        if (nN > 1) meta |= META_MULTI;
         meta |= ((u32)b.xs[r] & 3u) << META_XS_SHIFT;
         const bool um = b.mapq[r] >= 30;
         if (um) meta |= META_UM;
@@ -588,23 +602,41 @@ __global__ __launch_bounds__(256) void k1_emit(DevBatch b, const u32 *tile_off, 
         }
         if (ppp) meta |= META_PPP;
         if (um && (!pp_check || ppp)) meta |= META_REL;
+        u32 nN = 0;
+        int32_t aligned = 0;
+        for (u32 q = 0; q < n; q++) {
+            const u32 op = cig[q];
+            nN += ((op & 15u) == OP_N);
+            if (op_consumes_ref(op & 15u)) aligned += (int32_t)(op >> 4);
+        }
+        if (nN > 1) meta |= META_MULTI;
         // ---- shape: [S] M N M [S] with the read length matching the CIGAR
         if (nN == 1 && n >= 3 && n <= 5) {
             u32 k0 = 0, k1 = n;
             u32 dS = 0, dE = 0;
-            if ((cig[0] & 15u) == OP_S) { dS = cig[0] >> 4; k0 = 1; }
-            if ((cig[n - 1] & 15u) == OP_S) { dE = cig[n - 1] >> 4; k1 = n - 1; }
-            if (k1 - k0 == 3 && (cig[k0] & 15u) == OP_M && (cig[k0 + 1] & 15u) == OP_N && (cig[k0 + 2] & 15u) == OP_M) {
-                const u32 a = cig[k0] >> 4, b2 = cig[k0 + 2] >> 4;
-                const int32_t lq = b.l_qseq[r];
-                const u32 words = b.seq_off[r + 1] - b.seq_off[r];
-                if (a > 0 && b2 > 0 && a <= RES_FIELD_MAX && b2 <= RES_FIELD_MAX && dS < 4096u && lq > 1 &&
-                    (u64)lq == (u64)dS + a + b2 + dE && (u64)words * 8ull >= (u64)lq)
-                    meta |= META_SIMPLE | (dS << META_DS_SHIFT);
+            const u32 opF = cig[0], opL = cig[n - 1];
+            if ((opF & 15u) == OP_S) { dS = opF >> 4; k0 = 1; }
+            if ((opL & 15u) == OP_S) { dE = opL >> 4; k1 = n - 1; }
+            if (k1 - k0 == 3) {
+                const u32 oa = cig[k0], on = cig[k0 + 1], ob = cig[k0 + 2];
+                if ((oa & 15u) == OP_M && (on & 15u) == OP_N && (ob & 15u) == OP_M) {
+                    const u32 a = oa >> 4, b2 = ob >> 4;
+                    const int32_t lq = b.l_qseq[r];
+                    const u32 words = b.seq_off[r + 1] - b.seq_off[r];
+                    if (a > 0 && b2 > 0 && a <= RES_FIELD_MAX && b2 <= RES_FIELD_MAX && dS < 4096u && lq > 1 &&
+                        (u64)lq == (u64)dS + a + b2 + dE && (u64)words * 8ull >= (u64)lq)
+                        meta |= META_SIMPLE | (dS << META_DS_SHIFT);
+                }
             }
         }
-        // ---- walk
-        int32_t lStart = pos, lEndExc = pos, aligned = 0, sumAfter = 0, prevRStartU = 0;
+        // ---- walk: pairs (junction_system.cc:140-210) and, with two monotone cursors over the read's own
+        // introns, the up/down junction counts (junction.cc:795-812)
+        const int32_t aend = pos + aligned - 1;
+        NCursor U = {0, pos, false, 0}, D = {0, pos, false, 0};
+        ncursor_advance(U, cig, n);
+        ncursor_advance(D, cig, n);
+        u32 cntU = 0, cntD = 0;
+        int32_t lStart = pos, lEndExc = pos, sumAfter = 0, prevRStartU = 0, prevIend = 0;
         int64_t prev = -1;
         u32 k = 0;
         for (u32 i = 0; i < n; i++) {
@@ -616,58 +648,47 @@ __global__ __launch_bounds__(256) void k1_emit(DevBatch b, const u32 *tile_off, 
                     int32_t rEndExc = prevRStartU + sumAfter;
                     if (rEndExc - 1 >= ref_len) rEndExc = ref_len; // junction_system.cc:172-174
                     P.rend[prev] = rEndExc - 1;
+                    if (rEndExc - 1 < prevIend) set_error(err, g, PJB_ERR_MIN_ANCHOR); // intron.cc:76
                 }
                 const int32_t istart = lEndExc;
                 const int32_t rStartU = lEndExc + ln;
                 int32_t rStart = rStartU;
                 if (rStart - 1 >= ref_len) rStart = ref_len - 1; // junction_system.cc:169-171
                 const int32_t iend = rStart - 1;
+                while (U.has && U.peek < istart) {
+                    cntU++;
+                    ncursor_advance(U, cig, n);
+                }
+                while (D.has && D.peek <= iend + 1) {
+                    cntD++;
+                    ncursor_advance(D, cig, n);
+                }
                 const int64_t idx = (int64_t)off + k;
                 P.key[idx] = make_key(kf, istart, iend);
                 P.g[idx] = g;
                 P.lstart[idx] = lStart;
                 P.pos[idx] = pos;
                 P.meta[idx] = meta;
+                P.aend[idx] = aend;
+                P.updown[idx] = cntU | ((nN - cntD) << 16);
                 if (lStart > istart) set_error(err, g, PJB_ERR_MIN_ANCHOR); // intron.cc:68
                 prev = idx;
+                prevIend = iend;
                 prevRStartU = rStartU;
                 sumAfter = 0;
                 lStart = rStart;
                 lEndExc = rStart;
-                aligned += ln;
                 k++;
             } else if (op_consumes_ref(ty)) {
                 lEndExc += ln;
                 sumAfter += ln;
-                aligned += ln;
             }
         }
         {
             int32_t rEndExc = prevRStartU + sumAfter;
             if (rEndExc - 1 >= ref_len) rEndExc = ref_len;
             P.rend[prev] = rEndExc - 1;
-        }
-        // ---- phase 2: read end, up/down junction counts (junction.cc:795-812) with two monotone cursors
-        const int32_t aend = pos + aligned - 1;
-        NCursor U = {0, pos, false, 0}, D = {0, pos, false, 0};
-        ncursor_advance(U, cig, n);
-        ncursor_advance(D, cig, n);
-        u32 cntU = 0, cntD = 0;
-        for (u32 q = 0; q < nN; q++) {
-            const int64_t idx = (int64_t)off + q;
-            int32_t istart, iend;
-            unpack_key(kf, P.key[idx], istart, iend);
-            if (P.rend[idx] < iend) set_error(err, g, PJB_ERR_MIN_ANCHOR); // intron.cc:76
-            while (U.has && U.peek < istart) {
-                cntU++;
-                ncursor_advance(U, cig, n);
-            }
-            while (D.has && D.peek <= iend + 1) {
-                cntD++;
-                ncursor_advance(D, cig, n);
-            }
-            P.aend[idx] = aend;
-            P.updown[idx] = cntU | ((nN - cntD) << 16);
+            if (rEndExc - 1 < prevIend) set_error(err, g, PJB_ERR_MIN_ANCHOR);
         }
     }
 }
@@ -1090,14 +1111,6 @@ __device__ __forceinline__ void cmp_words(const u32 *seqw, int32_t qi, const u32
     }
 }
 
-// CIGAR ops of one alignment: the first OPS_LDS ops are staged in LDS (one column per thread), the
-// rest (long reads) are read from global memory
-constexpr int OPS_LDS = 8;
-struct OpsView {
-    const uint32_t *g;
-    const u32 *lds; // &s_ops[0][threadIdx.x], stride 256
-    __device__ __forceinline__ u32 operator[](u32 k) const { return k < (u32)OPS_LDS ? lds[k * 256] : g[k]; }
-};
 
 __device__ Side anchor_side(const OpsView cig, u32 n, int32_t position, int32_t aligned, const uint8_t *seq, int32_t lq,
                             const uint8_t *genome, int32_t glen, bool genome_has_x, const u32 *gcodes, int32_t start,
