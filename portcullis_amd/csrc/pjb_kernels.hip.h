@@ -336,36 +336,56 @@ constexpr int K1_TILE = 1024;
 __global__ __launch_bounds__(256) void k1_count(DevBatch b, u32 *tile_cnt, TileStats *tile_stats, u32 *spl_idx,
                                                  u32 *spl_poff, u64 *err) {
     __shared__ u64 sm64[4];
-    __shared__ u64 sm_scan[4];
-    u64 run = 0; // (pairs << 16 | spliced reads) of the rounds done so far, in read order
+    __shared__ u64 sm_scan4[4][4];
     __shared__ int32_t smi[4][6];
     int64_t base = (int64_t)blockIdx.x * K1_TILE;
     u32 cnt = 0, spl = 0, uns = 0;
     u64 sum = 0;
     int32_t mn = INT32_MAX, mx = 0, max_end = 0, max_nlen = 0, min_pos = INT32_MAX;
+    // all loads of the thread's 4 reads are issued before anything is consumed: offsets, then the first
+    // K1_OPS ops of every CIGAR (longer CIGARs continue from global memory), then the per-read scalars
+    constexpr int K1_OPS = 4;
+    u32 c0[4], nop[4], ops[4][K1_OPS];
+    int32_t pos4[4], prev4[4], len4[4];
+    u32 xs4[4], c4[4];
 #pragma unroll
     for (int it = 0; it < 4; it++) {
-        int64_t r = base + it * 256 + threadIdx.x;
+        const int64_t r = base + it * 256 + threadIdx.x;
+        const bool on = r < b.n;
+        c0[it] = on ? b.cig_off[r] : 0u;
+        nop[it] = on ? b.cig_off[r + 1] - c0[it] : 0u;
+        pos4[it] = on ? b.pos[r] : 0;
+        prev4[it] = on ? (r > 0 ? b.pos[r - 1] : b.prev_pos) : 0;
+        xs4[it] = on ? (u32)b.xs[r] : 0u;
+        len4[it] = on ? b.l_qseq[r] : 0;
+    }
+#pragma unroll
+    for (int it = 0; it < 4; it++)
+#pragma unroll
+        for (int k = 0; k < K1_OPS; k++) ops[it][k] = (u32)k < nop[it] ? b.cigar[c0[it] + k] : 0u;
+#pragma unroll
+    for (int it = 0; it < 4; it++) {
+        const int64_t r = base + it * 256 + threadIdx.x;
         u32 cthis = 0;
         if (r < b.n) {
-            u32 c0 = b.cig_off[r], c1 = b.cig_off[r + 1];
-            int32_t p = b.pos[r];
-            int32_t prev = r > 0 ? b.pos[r - 1] : b.prev_pos;
-            if (p < prev) set_error(err, b.base + (u32)r, PJB_ERR_UNSORTED);
-            if (b.xs[r] > 2) set_error(err, b.base + (u32)r, PJB_ERR_BAD_XS);
+            const int32_t p = pos4[it];
+            if (p < prev4[it]) set_error(err, b.base + (u32)r, PJB_ERR_UNSORTED);
+            if (xs4[it] > 2) set_error(err, b.base + (u32)r, PJB_ERR_BAD_XS);
             u32 c = 0;
             int32_t al = 0;
-            for (u32 k = c0; k < c1; k++) {
-                u32 op = b.cigar[k];
-                u32 ty = op & 15u;
-                int32_t ln = (int32_t)(op >> 4);
+            auto count_op = [&](u32 op) {
+                const u32 ty = op & 15u;
+                const int32_t ln = (int32_t)(op >> 4);
                 if (op_consumes_ref(ty)) al += ln;
                 if (ty == OP_N) {
                     c++;
                     max_nlen = ln > max_nlen ? ln : max_nlen;
                 }
-            }
-            int32_t len = b.l_qseq[r];
+            };
+#pragma unroll
+            for (int k = 0; k < K1_OPS; k++) count_op(ops[it][k]); // padding ops are 0M: no effect
+            for (u32 k = K1_OPS; k < nop[it]; k++) count_op(b.cigar[c0[it] + k]);
+            const int32_t len = len4[it];
             mn = len < mn ? len : mn;
             mx = len > mx ? len : mx;
             sum += (u64)(int64_t)len;
@@ -379,16 +399,34 @@ __global__ __launch_bounds__(256) void k1_count(DevBatch b, u32 *tile_cnt, TileS
                 uns++;
             cthis = c;
         }
-        // ordered compaction of the spliced reads of this tile: slot k holds the k-th spliced read
-        // (batch-local index) and the tile-local offset of its first pair
-        {
-            const u64 v = ((u64)cthis << 16) | (u64)(cthis ? 1u : 0u);
-            u64 tot;
-            const u64 ex = run + block_escan_256<u64>(v, sm_scan, &tot);
-            run += tot;
-            if (cthis) {
+        c4[it] = cthis;
+    }
+    // ordered compaction of the spliced reads of this tile: slot k holds the k-th spliced read
+    // (batch-local index) and the tile-local offset of its first pair.  Read order is round-major
+    // (r = base + it * 256 + thread): one wave scan per round, one barrier for all four.
+    {
+        u64 inc[4];
+        const int w = threadIdx.x >> 6;
+#pragma unroll
+        for (int it = 0; it < 4; it++) {
+            inc[it] = wave_iscan<u64>(((u64)c4[it] << 16) | (u64)(c4[it] ? 1u : 0u));
+            if (lane_id() == 63) sm_scan4[it][w] = inc[it];
+        }
+        __syncthreads();
+        u64 run = 0; // (pairs << 16 | spliced reads) of everything before, in read order
+#pragma unroll
+        for (int it = 0; it < 4; it++) {
+            u64 before = run;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const u64 t = sm_scan4[it][i];
+                if (i < w) before += t;
+                run += t;
+            }
+            if (c4[it]) {
+                const u64 ex = before + inc[it] - (((u64)c4[it] << 16) | 1u);
                 const size_t slot = (size_t)(b.tile_base + blockIdx.x) * K1_TILE + (u32)(ex & 0xffffu);
-                spl_idx[slot] = (u32)r;
+                spl_idx[slot] = (u32)(base + it * 256 + threadIdx.x);
                 spl_poff[slot] = (u32)(ex >> 16);
             }
         }
