@@ -29,8 +29,8 @@ def algorithmic_bytes(name, N, C, S, Cs, P, J, L, passes, Pg=0):
     table = {
         # pos, cig_off, l_qseq, xs + every cigar op; 8 B written per spliced read (compacted index + pair offset)
         "k1_count": N * 13 + C * 4 + S * 8,
-        # spliced reads only: compacted slot (8), cig_off (8), pos/flag/mapq/xs (8), ops walked 3x; 36 B written per pair
-        "k1_emit": S * 24 + Cs * 12 + P * 36,
+        # spliced reads only: compacted slot (8), cig_off (8), pos/flag/mapq/xs (8), ops fetched once; 36 B written per pair
+        "k1_emit": S * 24 + Cs * 4 + P * 36,
         "rs_hist": P * 8,
         "rs_scatter": P * 24,
         "k2_heads_reduce": P * 20,

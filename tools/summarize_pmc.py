@@ -11,7 +11,7 @@ d, out = sys.argv[1], sys.argv[2]
 res = defaultdict(lambda: defaultdict(list))
 for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
     for r in csv.DictReader(open(f"{d}/{ctr}/pmc_counter_collection.csv")):
-        name = r["Kernel_Name"].split("(")[0].replace("void ", "")
+        name = r["Kernel_Name"].split("(")[0].replace("void ", "").split("<")[0]  # template arguments dropped
         if "pjb::" not in name or r["Counter_Name"] != ctr:
             continue
         res[name][ctr].append(float(r["Counter_Value"]))
