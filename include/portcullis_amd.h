@@ -69,6 +69,7 @@ extern "C" {
 #define PJB_ERR_DIVERGENT (-20)      /* malformed CIGAR: padded query/genome walks emit different
                                         lengths for one op (the reference would compare misaligned
                                         strings or crash; we refuse) */
+#define PJB_ERR_BGZF (-22)           /* corrupt BGZF / DEFLATE data (bgzf.c:292-316 returns BGZF_ERR_ZLIB) */
 #define PJB_ERR_NO_SEQ (-21)         /* a spliced read was submitted without its sequence bytes */
 
 /* enums follow the reference's order (bam_master.hpp:50-54,92-97,133-139; junction.hpp:86-91) */
@@ -219,6 +220,17 @@ void pjb_host_free(void *p);
 
 /* Number of visible HIP devices (0 if none); does not create a context. */
 int pjb_device_count(void);
+
+/* ---- device-side ingest -------------------------------------------------------
+ * Inflate a run of whole BGZF blocks on the device: replaces the bgzf_read_block / inflate_block loop of
+ * htslib (deps/htslib-1.3/bgzf.c:292-316, 421-540) that BamReader::next drives one block at a time
+ * (lib/src/bam_reader.cc:134-142).  `comp` holds `comp_bytes` bytes of consecutive BGZF blocks (host
+ * memory; page-locked memory from pjb_host_alloc makes the copy asynchronous); the inflated bytes of all
+ * blocks are written back to `out` (capacity `out_cap`) and their count to *out_bytes.  Like
+ * inflate_block, the footer CRC32 is not verified; a block whose inflated size differs from its ISIZE
+ * field is an error (PJB_ERR_BGZF, message names the block).  An empty block (the BGZF EOF marker)
+ * contributes nothing. */
+int pjb_inflate_bgzf(pjb_ctx* ctx, const uint8_t* comp, int64_t comp_bytes, uint8_t* out, int64_t out_cap, int64_t* out_bytes);
 
 #ifdef __cplusplus
 }

@@ -1,6 +1,7 @@
 // pjb_api.hip -- C ABI (include/portcullis_amd.h) over the HIP kernels.
 // One context = one HIP device + one stream + a grow-only scratch arena.
 #include "pjb_kernels.hip.h"
+#include "pjb_ingest.hip.h"
 
 #include <algorithm>
 #include <cstdarg>
@@ -90,6 +91,7 @@ struct pjb_ctx {
     Buf b_batches, b_tile_cnt, b_tile_stats, b_cstats, b_err, b_total, b_splidx, b_splpoff;
     Buf b_key[2], b_idx[2], b_g, b_lstart, b_rend, b_pos, b_aend, b_meta, b_updown;
     Buf b_hist, b_hist_scan, b_scan_tiles, b_bintotal;
+    Buf b_inf_comp, b_inf_out, b_inf_blocks, b_inf_status, b_inf_scratch; // device-side BGZF inflate
     Buf b_jid, b_seg, b_runfirst, b_runstart;
     Buf b_frag, b_fragj, b_fragl, b_fragr, b_acc, b_ancl, b_ancr, b_rows, b_hasx, b_ent, b_res, b_genlist, b_gencount;
 };
@@ -388,7 +390,7 @@ void pjb_destroy(pjb_ctx *c) {
                   &c->b_key[1], &c->b_idx[0], &c->b_idx[1], &c->b_g, &c->b_lstart, &c->b_rend, &c->b_pos, &c->b_aend,
                   &c->b_meta, &c->b_updown, &c->b_hist, &c->b_hist_scan, &c->b_scan_tiles, &c->b_jid, &c->b_seg,
                   &c->b_runfirst, &c->b_runstart, &c->b_frag, &c->b_fragj, &c->b_fragl, &c->b_fragr, &c->b_acc,
-                  &c->b_ancl, &c->b_ancr, &c->b_rows, &c->b_hasx, &c->b_ent, &c->b_splidx, &c->b_splpoff, &c->b_res, &c->b_genlist, &c->b_gencount, &c->b_bintotal};
+                  &c->b_ancl, &c->b_ancr, &c->b_rows, &c->b_hasx, &c->b_ent, &c->b_splidx, &c->b_splpoff, &c->b_res, &c->b_genlist, &c->b_gencount, &c->b_bintotal, &c->b_inf_comp, &c->b_inf_out, &c->b_inf_blocks, &c->b_inf_status, &c->b_inf_scratch};
     for (Buf *b : all) release(*b);
     for (auto &ev : c->ev) (void)hipEventDestroy(ev);
     for (auto &ev : c->ev_pool) (void)hipEventDestroy(ev);
@@ -928,3 +930,113 @@ int pjb_get_timing(const pjb_ctx *c, pjb_timing *out) {
 }
 
 } // extern "C"
+
+// ---- device-side ingest ---------------------------------------------------------------------------
+namespace {
+const char *inf_text(int code) {
+    switch (code) {
+    case INF_ERR_BTYPE: return "reserved DEFLATE block type";
+    case INF_ERR_STORED: return "stored block length check failed";
+    case INF_ERR_CODELENS: return "invalid code length set";
+    case INF_ERR_CODE: return "invalid Huffman code";
+    case INF_ERR_DIST: return "match distance before the start of the block";
+    case INF_ERR_OVERRUN: return "block inflates or reads past its declared size";
+    case INF_ERR_SIZE: return "block inflates to fewer bytes than its ISIZE";
+    case INF_ERR_TABLE: return "Huffman table space exhausted";
+    default: return "bad block";
+    }
+}
+
+// hop over the BGZF block headers (bgzf.c:348-356 check_header, BSIZE from the BC extra subfield)
+int scan_bgzf(pjb_ctx *c, const uint8_t *comp, int64_t n, std::vector<InfBlock> &blocks, int64_t &total_out) {
+    int64_t off = 0;
+    total_out = 0;
+    while (off < n) {
+        if (off + 18 > n) return fail(c, PJB_ERR_BGZF, "truncated BGZF block header at byte %lld", (long long)off);
+        const uint8_t *h = comp + off;
+        if (h[0] != 31 || h[1] != 139 || h[2] != 8 || !(h[3] & 4))
+            return fail(c, PJB_ERR_BGZF, "not a BGZF block header at byte %lld", (long long)off);
+        const uint32_t xlen = h[10] | (uint32_t)h[11] << 8;
+        if (off + 12 + xlen > n) return fail(c, PJB_ERR_BGZF, "truncated BGZF extra field at byte %lld", (long long)off);
+        int64_t bsize = -1;
+        for (uint32_t x = 0; x + 4 <= xlen;) {
+            const uint8_t *f = h + 12 + x;
+            const uint32_t slen = f[2] | (uint32_t)f[3] << 8;
+            if (f[0] == 'B' && f[1] == 'C' && slen == 2 && x + 6 <= xlen) bsize = (int64_t)(f[4] | (uint32_t)f[5] << 8) + 1;
+            x += 4 + slen;
+        }
+        if (bsize < 0) return fail(c, PJB_ERR_BGZF, "BGZF block at byte %lld has no BC field", (long long)off);
+        if (bsize < (int64_t)xlen + 20 || off + bsize > n)
+            return fail(c, PJB_ERR_BGZF, "BGZF block at byte %lld has an impossible size %lld", (long long)off, (long long)bsize);
+        const uint8_t *foot = comp + off + bsize - 8;
+        const uint32_t isize = foot[4] | (uint32_t)foot[5] << 8 | (uint32_t)foot[6] << 16 | (uint32_t)foot[7] << 24;
+        if (isize > 65536u) return fail(c, PJB_ERR_BGZF, "BGZF block at byte %lld declares %u inflated bytes", (long long)off, isize);
+        InfBlock b;
+        b.in_off = (iu64)(off + 12 + xlen);
+        b.in_len = (iu32)(bsize - xlen - 20);
+        b.out_off = (iu64)total_out;
+        b.out_len = isize;
+        blocks.push_back(b);
+        total_out += isize;
+        off += bsize;
+    }
+    return PJB_OK;
+}
+
+constexpr uint32_t INF_BLOCKS_PER_LAUNCH = 768 * 64; // three 64-lane workgroups per CU hold their tables in LDS
+
+// comp already on the device (padded); blocks on the host
+int inflate_on_device(pjb_ctx *c, const uint8_t *d_comp, const std::vector<InfBlock> &blocks, uint8_t *d_out) {
+    int rc;
+    const size_t nb = blocks.size();
+    if (nb == 0) return PJB_OK;
+    if ((rc = ensure(c, c->b_inf_blocks, nb * sizeof(InfBlock)))) return rc;
+    if ((rc = ensure(c, c->b_inf_status, nb * 4 + 4))) return rc;
+    const size_t per_launch = std::min<size_t>(nb, INF_BLOCKS_PER_LAUNCH);
+    if ((rc = ensure(c, c->b_inf_scratch, ((per_launch + 63) / 64 * 64) * INF_SCRATCH_PER_LANE))) return rc;
+    hipStream_t st = c->stream;
+    HIP_TRY(c, hipMemcpyAsync(c->b_inf_blocks.p, blocks.data(), nb * sizeof(InfBlock), hipMemcpyHostToDevice, st));
+    int *d_status = (int *)c->b_inf_status.p;
+    int *d_any = d_status + nb;
+    HIP_TRY(c, hipMemsetAsync(d_any, 0, 4, st));
+    for (size_t b0 = 0; b0 < nb; b0 += per_launch) {
+        const uint32_t cnt = (uint32_t)std::min(per_launch, nb - b0);
+        LAUNCH_LDS(c, "bgzf_inflate", bgzf_inflate, dim3((cnt + 63) / 64), dim3(64), INF_LDS_BYTES, d_comp,
+                   (const InfBlock *)c->b_inf_blocks.p + b0, cnt, d_out, (uint8_t *)c->b_inf_scratch.p, d_status + b0, d_any);
+    }
+    int any = 0;
+    HIP_TRY(c, hipMemcpyAsync(&any, d_any, 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipStreamSynchronize(st));
+    if (any) {
+        std::vector<int> status(nb);
+        HIP_TRY(c, hipMemcpy(status.data(), d_status, nb * 4, hipMemcpyDeviceToHost));
+        for (size_t b = 0; b < nb; b++)
+            if (status[b])
+                return fail(c, PJB_ERR_BGZF, "BGZF block %zu (payload at byte %llu): %s", b, (unsigned long long)blocks[b].in_off,
+                            inf_text(status[b]));
+        return fail(c, PJB_ERR_BGZF, "BGZF inflate failed");
+    }
+    return PJB_OK;
+}
+} // namespace
+
+extern "C" int pjb_inflate_bgzf(pjb_ctx *c, const uint8_t *comp, int64_t comp_bytes, uint8_t *out, int64_t out_cap,
+                                int64_t *out_bytes) {
+    if (!c || !out_bytes || comp_bytes < 0 || (comp_bytes && !comp)) return fail(c, PJB_ERR_ARG, "inflate_bgzf: bad arguments");
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    std::vector<InfBlock> blocks;
+    int64_t total = 0;
+    int rc = scan_bgzf(c, comp, comp_bytes, blocks, total);
+    if (rc) return rc;
+    *out_bytes = total;
+    if (total > out_cap) return fail(c, PJB_ERR_ARG, "inflate_bgzf: output needs %lld bytes, capacity is %lld", (long long)total, (long long)out_cap);
+    if (total == 0) return PJB_OK;
+    if (!out) return fail(c, PJB_ERR_ARG, "inflate_bgzf: no output buffer");
+    if ((rc = ensure(c, c->b_inf_comp, (size_t)comp_bytes + INF_PAD))) return rc;
+    if ((rc = ensure(c, c->b_inf_out, (size_t)total + 16))) return rc;
+    HIP_TRY(c, hipMemcpyAsync(c->b_inf_comp.p, comp, (size_t)comp_bytes, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemsetAsync((uint8_t *)c->b_inf_comp.p + comp_bytes, 0, INF_PAD, c->stream));
+    if ((rc = inflate_on_device(c, (const uint8_t *)c->b_inf_comp.p, blocks, (uint8_t *)c->b_inf_out.p))) return rc;
+    HIP_TRY(c, hipMemcpy(out, c->b_inf_out.p, (size_t)total, hipMemcpyDeviceToHost));
+    return PJB_OK;
+}

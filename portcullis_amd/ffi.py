@@ -22,7 +22,7 @@ EXPORTS = [
     "pjb_create", "pjb_destroy", "pjb_last_error", "pjb_set_refs", "pjb_upload_contig", "pjb_upload_contig_device",
     "pjb_release_contig", "pjb_submit_batch", "pjb_submit_batch_device", "pjb_finish_contig", "pjb_collect",
     "pjb_clear_rows", "pjb_get_timing", "pjb_device_count", "pjb_get_kernel_timing", "pjb_reset_kernel_timing",
-    "pjb_select_timed_kernels", "pjb_host_alloc", "pjb_host_free",
+    "pjb_select_timed_kernels", "pjb_host_alloc", "pjb_host_free", "pjb_inflate_bgzf",
 ]
 FLAG_KERNEL_TIMING = 1
 
@@ -98,6 +98,7 @@ def load():
         L.pjb_submit_batch.argtypes = [C.c_void_p, C.c_int32, C.POINTER(PjbBatch)]
         L.pjb_submit_batch_device.argtypes = [C.c_void_p, C.c_int32, C.POINTER(PjbBatch)]
         L.pjb_finish_contig.argtypes = [C.c_void_p, C.c_int32, C.POINTER(PjbRegionResult)]
+        L.pjb_inflate_bgzf.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
         L.pjb_collect.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
         L.pjb_clear_rows.argtypes = [C.c_void_p]
         L.pjb_get_timing.argtypes = [C.c_void_p, C.POINTER(PjbTiming)]
@@ -212,6 +213,18 @@ class Context:
 
     def clear_rows(self):
         self._check(self._L.pjb_clear_rows(self._h))
+
+    def inflate_bgzf(self, comp):
+        """Inflate a run of whole BGZF blocks (bytes-like) on the device; returns the inflated bytes."""
+        comp = np.frombuffer(bytes(comp), dtype=np.uint8)
+        n = C.c_int64()
+        # capacity from the ISIZE fields is not known up front: BGZF blocks inflate to at most 64 KB each,
+        # a block is at least 28 bytes
+        cap = max(65536, (len(comp) // 28 + 1) * 65536) if len(comp) < (1 << 22) else len(comp) * 12
+        out = np.empty(cap, dtype=np.uint8)
+        self._check(self._L.pjb_inflate_bgzf(self._h, comp.ctypes.data_as(C.c_void_p), len(comp),
+                                             out.ctypes.data_as(C.c_void_p), cap, C.byref(n)))
+        return out[:n.value].tobytes()
 
     def timing(self):
         t = PjbTiming()
