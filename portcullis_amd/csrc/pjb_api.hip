@@ -1007,6 +1007,7 @@ int inflate_on_device(pjb_ctx *c, const uint8_t *d_comp, const std::vector<InfBl
     int any = 0;
     HIP_TRY(c, hipMemcpyAsync(&any, d_any, 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(c, hipStreamSynchronize(st));
+    if (c->ktime) ev_collect(c);
     if (any) {
         std::vector<int> status(nb);
         HIP_TRY(c, hipMemcpy(status.data(), d_status, nb * 4, hipMemcpyDeviceToHost));

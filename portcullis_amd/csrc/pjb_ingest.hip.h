@@ -66,19 +66,44 @@ struct LaneLds {
 };
 constexpr iu32 L_LIT = 0, L_DIST = 1u << INF_ROOT_L, L_COUNT = L_DIST + (1u << INF_ROOT_D), L_NEXT = L_COUNT + 16;
 
+__device__ __forceinline__ iu64 load64u(const uint8_t *p) {
+    iu64 v;
+    __builtin_memcpy(&v, p, 8);
+    return v;
+}
+__device__ __forceinline__ void store64u(uint8_t *p, iu64 v) { __builtin_memcpy(p, &v, 8); }
+
+// LSB-first bit reader.  Input is fetched 8 bytes at a time, two words ahead of the bit buffer, so
+// the load a refill depends on was issued at least 64 input bits earlier.
 struct BitReader {
-    const uint8_t *ip; // next byte to fetch
-    iu64 bb;           // bit buffer, LSB first
+    const uint8_t *ip; // next byte to fetch into the reservoir
+    iu64 bb;           // bit buffer
     int nb;            // valid bits in bb
-    __device__ __forceinline__ void refill() { // at least 33 valid bits afterwards (the buffer is padded by 8 bytes)
+    iu64 r0, r1;       // reservoir: r0 is consumed 32 bits at a time, r1 is the word after it
+    int r0w;           // 32-bit halves left in r0 (2, 1)
+    __device__ __forceinline__ void start(const uint8_t *p) {
+        r0 = load64u(p);
+        r1 = load64u(p + 8);
+        ip = p + 16;
+        r0w = 2;
+        bb = 0;
+        nb = 0;
+    }
+    __device__ __forceinline__ void refill() { // at least 33 valid bits afterwards
         if (nb <= 32) {
-            iu32 w;
-            __builtin_memcpy(&w, ip, 4);
-            bb |= (iu64)w << nb;
-            ip += 4;
+            bb |= (r0 & 0xffffffffull) << nb;
             nb += 32;
+            r0 >>= 32;
+            if (--r0w == 0) {
+                r0 = r1;
+                r0w = 2;
+                r1 = load64u(ip);
+                ip += 8;
+            }
         }
     }
+    // address of the next input byte not yet moved into the bit buffer's whole bytes
+    __device__ __forceinline__ const uint8_t *byte_pos() const { return ip - 8 - 4 * r0w - (nb >> 3); }
     __device__ __forceinline__ iu32 peek(int n) const { return (iu32)bb & ((1u << n) - 1u); }
     __device__ __forceinline__ void drop(int n) {
         bb >>= n;
@@ -88,6 +113,66 @@ struct BitReader {
         const iu32 v = peek(n);
         drop(n);
         return v;
+    }
+};
+
+// Output of one block: bytes are collected 8 at a time before they are stored, and the last 16 bytes
+// stay in registers so that matches with distance <= 16 never read memory (and longer ones never read
+// bytes that are still pending).  BAM blocks are full of them: every quality-less read carries a run of
+// 0xff as long as the read (distance 1).
+struct OutWriter {
+    uint8_t *base;  // first byte of the block
+    iu32 pos;       // bytes produced
+    iu64 acc;       // bytes of the current 8-byte group [pos & ~7, pos)
+    iu64 wlo, whi;  // the last 16 bytes, oldest in the low byte of wlo
+    __device__ __forceinline__ void put(iu32 x) {
+        acc |= (iu64)x << (8 * (pos & 7u));
+        wlo = (wlo >> 8) | (whi << 56);
+        whi = (whi >> 8) | ((iu64)x << 56);
+        pos++;
+        if ((pos & 7u) == 0) {
+            store64u(base + pos - 8, acc);
+            acc = 0;
+        }
+    }
+    __device__ __forceinline__ void put8(iu64 v) {
+        const iu32 k = pos & 7u;
+        if (k == 0) {
+            store64u(base + pos, v);
+        } else {
+            store64u(base + pos - k, acc | (v << (8 * k)));
+            acc = v >> (64 - 8 * k);
+        }
+        wlo = whi;
+        whi = v;
+        pos += 8;
+    }
+    // n (1..7) bytes, low bytes of v first
+    __device__ __forceinline__ void putn(iu64 v, iu32 n) {
+        v &= (1ull << (8 * n)) - 1ull;
+        const iu32 k = pos & 7u;
+        acc |= v << (8 * k);
+        if (k + n >= 8) {
+            store64u(base + pos - k, acc);
+            acc = k ? v >> (64 - 8 * k) : 0ull;
+        }
+        wlo = (wlo >> (8 * n)) | (whi << (64 - 8 * n));
+        whi = (whi >> (8 * n)) | (v << (64 - 8 * n));
+        pos += n;
+    }
+    // the next 8 bytes of a match with distance 1..16, from the register window (periodic if dist < 8)
+    __device__ __forceinline__ iu64 ahead(iu32 dist) const {
+        if (dist >= 8) {
+            const iu32 sh = 8 * (16 - dist); // 0..64
+            return sh == 0 ? wlo : sh == 64 ? whi : (wlo >> sh) | (whi << (64 - sh));
+        }
+        iu64 v = whi >> (8 * (8 - dist)); // the last `dist` bytes
+        for (iu32 sh = 8 * dist; sh < 64; sh <<= 1) v |= v << sh;
+        return v;
+    }
+    __device__ __forceinline__ void flush() {
+        const iu32 k = pos & 7u;
+        for (iu32 i = 0; i < k; i++) base[pos - k + i] = (uint8_t)(acc >> (8 * i));
     }
 };
 
@@ -166,6 +251,9 @@ __device__ __forceinline__ iu32 inf_decode(const LaneLds L, iu32 root, int root_
         const int sb = (int)(e & 15u) + 1;
         const iu32 off = ((e >> 4) & 0x7ffu) << 1;
         e = sub[off + (((iu32)(br.bb >> root_bits)) & ((1u << sb) - 1u))];
+        // consume the load inside the branch: the wait for it (which also drains this lane's pending stores)
+        // must not sit at the join, where every first-level hit would pay it too
+        asm volatile("" : "+v"(e));
     }
     br.drop((int)(e & 15u));
     return e;
@@ -186,11 +274,14 @@ __global__ __launch_bounds__(64) void bgzf_inflate(const uint8_t *comp, const In
     uint8_t *lens = (uint8_t *)(sub_d + INF_SUB_D);
     const InfBlock B = blocks[b];
     BitReader br;
-    br.ip = comp + B.in_off;
-    br.bb = 0;
-    br.nb = 0;
-    const uint8_t *in_end = br.ip + B.in_len;
-    uint8_t *op0 = out + B.out_off, *op = op0, *op_end = op0 + B.out_len;
+    br.start(comp + B.in_off);
+    const uint8_t *in_end = comp + B.in_off + B.in_len;
+    OutWriter ow;
+    ow.base = out + B.out_off;
+    ow.pos = 0;
+    ow.acc = 0;
+    ow.wlo = ow.whi = 0;
+    const iu32 out_len = B.out_len;
     int err = 0;
     bool last = false;
     while (!last && !err) {
@@ -207,16 +298,15 @@ __global__ __launch_bounds__(64) void bgzf_inflate(const uint8_t *comp, const In
                 err = INF_ERR_STORED;
                 break;
             }
-            const uint8_t *src = br.ip - (br.nb >> 3); // bytes still in the buffer are the next input bytes
-            if (src + len > in_end || op + len > op_end) {
+            const uint8_t *src = br.byte_pos();
+            if (src + len > in_end || ow.pos + len > out_len) {
                 err = INF_ERR_OVERRUN;
                 break;
             }
-            for (iu32 i = 0; i < len; i++) op[i] = src[i];
-            op += len;
-            br.ip = src + len;
-            br.bb = 0;
-            br.nb = 0;
+            iu32 i = 0;
+            for (; i + 8 <= len; i += 8) ow.put8(load64u(src + i));
+            for (; i < len; i++) ow.put(src[i]);
+            br.start(src + len);
             continue;
         }
         if (type == 3) {
@@ -286,12 +376,22 @@ __global__ __launch_bounds__(64) void bgzf_inflate(const uint8_t *comp, const In
                 break;
             }
         }
-        // lens[] is overwritten by nothing below, but the distance lengths start at nlit: build distance first
         if ((err = inf_build(L, L_DIST, INF_ROOT_D, sub_d, INF_SUB_D, lens + nlit, ndist))) break;
         if ((err = inf_build(L, L_LIT, INF_ROOT_L, sub_l, INF_SUB_L, lens, nlit))) break;
-        // ---- symbols
+        // ---- symbols.  One flat loop: an iteration either decodes a symbol or moves up to 8 bytes of the
+        // pending match, so a lane in a long copy does not stall the 63 others for its whole length.
+        iu32 mlen = 0, mdist = 0;
         for (;;) {
-            if (br.ip > in_end + 8) { // garbage can decode for a long time: never read far past the payload
+            if (mlen) {
+                const iu32 n = mlen < 8 ? mlen : 8;
+                // distance >= 17: the 8 bytes read were stored at least 9 positions back (at most 7 are pending)
+                const iu64 v = mdist <= 16 ? ow.ahead(mdist) : load64u(ow.base + ow.pos - mdist);
+                if (n == 8) ow.put8(v);
+                else ow.putn(v, n);
+                mlen -= n;
+                continue;
+            }
+            if (br.ip > in_end + 32) { // garbage can decode for a long time: never read far past the payload
                 err = INF_ERR_OVERRUN;
                 break;
             }
@@ -303,11 +403,11 @@ __global__ __launch_bounds__(64) void bgzf_inflate(const uint8_t *comp, const In
             }
             iu32 sym = e >> 4;
             if (sym < 256) {
-                if (op >= op_end) {
+                if (ow.pos >= out_len) {
                     err = INF_ERR_OVERRUN;
                     break;
                 }
-                *op++ = (uint8_t)sym;
+                ow.put(sym);
                 continue;
             }
             if (sym == 256) break;
@@ -316,7 +416,7 @@ __global__ __launch_bounds__(64) void bgzf_inflate(const uint8_t *comp, const In
                 err = INF_ERR_CODE;
                 break;
             }
-            iu32 len = c_len_base[sym] + br.take(c_len_extra[sym]);
+            const iu32 len = c_len_base[sym] + br.take(c_len_extra[sym]);
             br.refill();
             e = inf_decode(L, L_DIST, INF_ROOT_D, sub_d, br);
             if (e == 0 || (e >> 4) >= 30) {
@@ -325,38 +425,21 @@ __global__ __launch_bounds__(64) void bgzf_inflate(const uint8_t *comp, const In
             }
             const iu32 ds = e >> 4;
             const iu32 dist = c_dist_base[ds] + br.take(c_dist_extra[ds]);
-            if (dist > (iu32)(op - op0)) {
+            if (dist > ow.pos) {
                 err = INF_ERR_DIST;
                 break;
             }
-            if (op + len > op_end) {
+            if (ow.pos + len > out_len) {
                 err = INF_ERR_OVERRUN;
                 break;
             }
-            const uint8_t *src = op - dist;
-            if (dist >= 8) { // 8 bytes per step; source and destination do not overlap within a step
-                while (len >= 8) {
-                    iu64 v;
-                    __builtin_memcpy(&v, src, 8);
-                    __builtin_memcpy(op, &v, 8);
-                    src += 8;
-                    op += 8;
-                    len -= 8;
-                }
-                while (len--) *op++ = *src++;
-            } else { // short period: the pattern is read once, then only stores
-                iu64 pat = 0;
-                for (iu32 k = 0; k < dist; k++) pat |= (iu64)src[k] << (8 * k);
-                iu32 ph = 0;
-                while (len--) {
-                    *op++ = (uint8_t)(pat >> (8 * ph));
-                    ph = ph + 1 == dist ? 0 : ph + 1;
-                }
-            }
+            mlen = len;
+            mdist = dist;
         }
-        if (!err && br.ip - (br.nb >> 3) > in_end) err = INF_ERR_OVERRUN;
+        if (!err && br.byte_pos() > in_end) err = INF_ERR_OVERRUN;
     }
-    if (!err && op != op_end) err = INF_ERR_SIZE;
+    if (!err && ow.pos != out_len) err = INF_ERR_SIZE;
+    ow.flush();
     status[b] = err;
     if (err) atomicOr(any_error, 1);
 }
