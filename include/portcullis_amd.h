@@ -232,6 +232,21 @@ int pjb_device_count(void);
  * contributes nothing. */
 int pjb_inflate_bgzf(pjb_ctx* ctx, const uint8_t* comp, int64_t comp_bytes, uint8_t* out, int64_t out_cap, int64_t* out_bytes);
 
+/* One target's alignments straight from the file bytes: inflate + BAM record parse + transcode to the
+ * pjb_batch layout, all on the device; the records are appended to target `tid` exactly as a
+ * pjb_submit_batch of the same alignments would be.  Replaces the reader loop of
+ * JunctionBuilder::findJuncs (src/junction_builder.cc:322-343: BamReader::setRegion / next /
+ * BamAlignment::init, lib/src/bam_reader.cc:78-146, lib/src/bam_alignment.cc:71-100) for the whole target.
+ *   comp, comp_bytes : consecutive whole BGZF blocks (host memory), from the block that holds the target's
+ *                      first record through (at least) the block that holds its last one;
+ *   first_uoffset    : offset of that first record inside the first block's inflated bytes (the low
+ *                      16 bits of the index's virtual offset).
+ * Records are taken until the first one whose refID is not `tid` (or whose position is past the
+ * target's end, as hts_itr would stop) or the end of the data; a record cut off by the end of the data
+ * is ignored.  One call per target.  *n_records (optional) receives the number of alignments added.
+ * Errors: PJB_ERR_BGZF for corrupt BGZF / DEFLATE / BAM record data. */
+int pjb_submit_bam(pjb_ctx* ctx, int32_t tid, const uint8_t* comp, int64_t comp_bytes, int32_t first_uoffset, int64_t* n_records);
+
 #ifdef __cplusplus
 }
 #endif

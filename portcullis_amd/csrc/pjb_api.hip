@@ -92,6 +92,7 @@ struct pjb_ctx {
     Buf b_key[2], b_idx[2], b_g, b_lstart, b_rend, b_pos, b_aend, b_meta, b_updown;
     Buf b_hist, b_hist_scan, b_scan_tiles, b_bintotal;
     Buf b_inf_comp, b_inf_out, b_inf_blocks, b_inf_status, b_inf_scratch; // device-side BGZF inflate
+    Buf b_bam_seg, b_bam_rec, b_bam_ctl;                                  // device-side BAM record parse
     Buf b_jid, b_seg, b_runfirst, b_runstart;
     Buf b_frag, b_fragj, b_fragl, b_fragr, b_acc, b_ancl, b_ancr, b_rows, b_hasx, b_ent, b_res, b_genlist, b_gencount;
 };
@@ -390,7 +391,7 @@ void pjb_destroy(pjb_ctx *c) {
                   &c->b_key[1], &c->b_idx[0], &c->b_idx[1], &c->b_g, &c->b_lstart, &c->b_rend, &c->b_pos, &c->b_aend,
                   &c->b_meta, &c->b_updown, &c->b_hist, &c->b_hist_scan, &c->b_scan_tiles, &c->b_jid, &c->b_seg,
                   &c->b_runfirst, &c->b_runstart, &c->b_frag, &c->b_fragj, &c->b_fragl, &c->b_fragr, &c->b_acc,
-                  &c->b_ancl, &c->b_ancr, &c->b_rows, &c->b_hasx, &c->b_ent, &c->b_splidx, &c->b_splpoff, &c->b_res, &c->b_genlist, &c->b_gencount, &c->b_bintotal, &c->b_inf_comp, &c->b_inf_out, &c->b_inf_blocks, &c->b_inf_status, &c->b_inf_scratch};
+                  &c->b_ancl, &c->b_ancr, &c->b_rows, &c->b_hasx, &c->b_ent, &c->b_splidx, &c->b_splpoff, &c->b_res, &c->b_genlist, &c->b_gencount, &c->b_bintotal, &c->b_inf_comp, &c->b_inf_out, &c->b_inf_blocks, &c->b_inf_status, &c->b_inf_scratch, &c->b_bam_seg, &c->b_bam_rec, &c->b_bam_ctl};
     for (Buf *b : all) release(*b);
     for (auto &ev : c->ev) (void)hipEventDestroy(ev);
     for (auto &ev : c->ev_pool) (void)hipEventDestroy(ev);
@@ -1039,5 +1040,125 @@ extern "C" int pjb_inflate_bgzf(pjb_ctx *c, const uint8_t *comp, int64_t comp_by
     HIP_TRY(c, hipMemsetAsync((uint8_t *)c->b_inf_comp.p + comp_bytes, 0, INF_PAD, c->stream));
     if ((rc = inflate_on_device(c, (const uint8_t *)c->b_inf_comp.p, blocks, (uint8_t *)c->b_inf_out.p))) return rc;
     HIP_TRY(c, hipMemcpy(out, c->b_inf_out.p, (size_t)total, hipMemcpyDeviceToHost));
+    return PJB_OK;
+}
+
+extern "C" int pjb_submit_bam(pjb_ctx *c, int32_t tid, const uint8_t *comp, int64_t comp_bytes, int32_t first_uoffset,
+                              int64_t *n_records) {
+    if (!c) return PJB_ERR_ARG;
+    if (n_records) *n_records = 0;
+    if (comp_bytes < 0 || (comp_bytes && !comp) || first_uoffset < 0) return fail(c, PJB_ERR_ARG, "submit_bam: bad arguments");
+    if (tid < 0 || (size_t)tid >= c->ref_len.size()) return fail(c, PJB_ERR_ARG, "submit_bam: bad tid %d", tid);
+    c->cur_tid = tid;
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    OpenContig &oc = c->open[tid];
+    if (!oc.batches.empty()) return fail(c, PJB_ERR_STATE, "submit_bam: target %d already has batches (one call per target)", tid);
+    std::vector<InfBlock> blocks;
+    int64_t total = 0;
+    int rc = scan_bgzf(c, comp, comp_bytes, blocks, total);
+    if (rc) return rc;
+    if (total == 0 || (int64_t)first_uoffset >= total) return PJB_OK;
+    hipStream_t st = c->stream;
+    if ((rc = ensure(c, c->b_inf_comp, (size_t)comp_bytes + INF_PAD))) return rc;
+    if ((rc = ensure(c, c->b_inf_out, (size_t)total + 64))) return rc;
+    HIP_TRY(c, hipMemcpyAsync(c->b_inf_comp.p, comp, (size_t)comp_bytes, hipMemcpyHostToDevice, st));
+    HIP_TRY(c, hipMemsetAsync((uint8_t *)c->b_inf_comp.p + comp_bytes, 0, INF_PAD, st));
+    HIP_TRY(c, hipMemsetAsync((uint8_t *)c->b_inf_out.p + total, 0, 64, st));
+    if ((rc = inflate_on_device(c, (const uint8_t *)c->b_inf_comp.p, blocks, (uint8_t *)c->b_inf_out.p))) return rc;
+
+    // ---- record boundaries
+    BamRegion R;
+    R.U = (const uint8_t *)c->b_inf_out.p;
+    R.total = (iu64)total;
+    R.first = (iu64)first_uoffset;
+    R.tid = tid;
+    R.ref_len = c->ref_len[(size_t)tid];
+    R.n_ref = (int32_t)c->ref_len.size();
+    const uint32_t n_seg = (uint32_t)(((iu64)total + BAM_SEG - 1) / BAM_SEG);
+    // seg_start u64 | seg_base u64 | seg_n u32
+    if ((rc = ensure(c, c->b_bam_seg, (size_t)n_seg * 20 + 64))) return rc;
+    if ((rc = ensure(c, c->b_bam_ctl, 64))) return rc;
+    iu64 *seg_start = (iu64 *)c->b_bam_seg.p;
+    iu64 *seg_base = seg_start + n_seg;
+    iu32 *seg_n = (iu32 *)(seg_base + n_seg);
+    iu32 *ctl = (iu32 *)c->b_bam_ctl.p; // [0..2] end / mismatch / bad segment, [4..5] u64 total of a scan
+    iu64 *d_total = (iu64 *)(ctl + 4);
+    HIP_TRY(c, hipMemsetAsync(ctl, 0xff, 16, st));
+    BamWalkOut O;
+    O.seg_n = seg_n;
+    O.rec_off = nullptr;
+    O.seg_base = seg_base;
+    O.ctl = ctl;
+    LAUNCH(c, "bam_find_starts", bam_find_starts, dim3(n_seg), dim3(64), R, n_seg, seg_start);
+    LAUNCH(c, "bam_walk_count", bam_walk<false>, dim3((n_seg + 255) / 256), dim3(256), R, n_seg, (const iu64 *)seg_start, O);
+    LAUNCH(c, "bam_trim_segments", bam_trim_segments, dim3((n_seg + 255) / 256), dim3(256), seg_n, n_seg, (const iu32 *)ctl);
+    if ((rc = run_scan(c, "bam_seg", SegCountFn{seg_n}, SegBaseSink{seg_base}, n_seg, d_total))) return rc;
+    uint32_t h_ctl[6];
+    HIP_TRY(c, hipMemcpyAsync(h_ctl, ctl, 24, hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipStreamSynchronize(st));
+    const uint32_t end_seg = h_ctl[0];
+    if (h_ctl[2] != 0xffffffffu && h_ctl[2] <= end_seg) return fail(c, PJB_ERR_BGZF, "Invalid BAM record layout on target %d (inflated offset %llu..)", tid,
+                                         (unsigned long long)h_ctl[2] * BAM_SEG);
+    if (h_ctl[1] != 0xffffffffu && h_ctl[1] <= end_seg)
+        return fail(c, PJB_ERR_BGZF, "BAM record chain of target %d is inconsistent near inflated offset %llu", tid,
+                    (unsigned long long)h_ctl[1] * BAM_SEG);
+    iu64 n64;
+    memcpy(&n64, &h_ctl[4], 8);
+    if (n64 == 0) return PJB_OK;
+    if (n64 >= 0xffffff00ull) return fail(c, PJB_ERR_ARG, "submit_bam: more than 2^32 alignments on one target are not supported");
+    const size_t n = (size_t)n64;
+    if ((rc = ensure(c, c->b_bam_rec, n * 8))) return rc;
+    O.rec_off = (iu64 *)c->b_bam_rec.p;
+    LAUNCH(c, "bam_walk_fill", bam_walk<true>, dim3((n_seg + 255) / 256), dim3(256), R, n_seg, (const iu64 *)seg_start, O);
+
+    // ---- SoA arrays in the target's slabs (same packing as a host-submitted batch)
+    const size_t fixed[8] = {n * 4, n * 2, n, n, n * 4, n * 4, n * 4, (n + 1) * 4}; // pos flag mapq xs l_qseq mtid mpos cig_off
+    size_t offs[9], tot_b = 0;
+    for (int k = 0; k < 8; k++) {
+        offs[k] = tot_b;
+        tot_b += (std::max<size_t>(fixed[k], 16) + 255) & ~(size_t)255;
+    }
+    offs[8] = tot_b; // seq_off
+    tot_b += (((n + 1) * 4) + 255) & ~(size_t)255;
+    uint8_t *dev = (uint8_t *)slab_alloc(c, oc, tot_b);
+    if (!dev) return fail(c, PJB_ERR_NOMEM, "submit_bam: out of device memory for %zu alignments", n);
+    BamSoA B;
+    B.pos = (int32_t *)(dev + offs[0]);
+    B.flag = (uint16_t *)(dev + offs[1]);
+    B.mapq = dev + offs[2];
+    B.xs = dev + offs[3];
+    B.l_qseq = (int32_t *)(dev + offs[4]);
+    B.mtid = (int32_t *)(dev + offs[5]);
+    B.mpos = (int32_t *)(dev + offs[6]);
+    B.cig_off = (iu32 *)(dev + offs[7]);
+    B.seq_off = (iu32 *)(dev + offs[8]);
+    B.cigar = nullptr;
+    B.seq4 = nullptr;
+    if ((rc = run_scan(c, "bam_sizes", BamSizesFn{R.U, (const iu64 *)c->b_bam_rec.p}, BamOffsetsSink{B.cig_off, B.seq_off}, n, d_total)))
+        return rc;
+    iu64 tot = 0;
+    HIP_TRY(c, hipMemcpyAsync(&tot, d_total, 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipStreamSynchronize(st));
+    const uint32_t n_ops = (uint32_t)(tot >> 32), n_words = (uint32_t)tot;
+    // (a carry out of the low half would mean 2^32 sequence words: 16 GB of bases on one target)
+    const uint32_t tails[2] = {n_ops, n_words};
+    HIP_TRY(c, hipMemcpyAsync(B.cig_off + n, &tails[0], 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(c, hipMemcpyAsync(B.seq_off + n, &tails[1], 4, hipMemcpyHostToDevice, st));
+    B.cigar = (iu32 *)slab_alloc(c, oc, (size_t)n_ops * 4 + 16);
+    B.seq4 = (uint8_t *)slab_alloc(c, oc, (size_t)n_words * 4 + 16);
+    if (!B.cigar || !B.seq4) return fail(c, PJB_ERR_NOMEM, "submit_bam: out of device memory for CIGARs / bases");
+    LAUNCH(c, "bam_transcode", bam_transcode, dim3((unsigned)((n + 255) / 256)), dim3(256), R.U, (const iu64 *)c->b_bam_rec.p, (iu64)n, B);
+    HIP_TRY(c, hipStreamSynchronize(st)); // `tails` is on this stack frame
+    if (c->ktime) ev_collect(c);
+    DevBatch d;
+    memset(&d, 0, sizeof d);
+    d.n = (int64_t)n;
+    d.base = 0;
+    d.pos = B.pos; d.flag = B.flag; d.mapq = B.mapq; d.xs = B.xs; d.l_qseq = B.l_qseq; d.mtid = B.mtid; d.mpos = B.mpos;
+    d.cig_off = B.cig_off; d.cigar = B.cigar; d.seq_off = B.seq_off; d.seq4 = B.seq4;
+    oc.batches.push_back(d);
+    oc.last_known.push_back(0);
+    oc.last_pos.push_back(INT32_MIN);
+    if (n_records) *n_records = (int64_t)n;
     return PJB_OK;
 }

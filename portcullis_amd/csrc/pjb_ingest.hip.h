@@ -444,4 +444,295 @@ __global__ __launch_bounds__(64) void bgzf_inflate(const uint8_t *comp, const In
     if (err) atomicOr(any_error, 1);
 }
 
+
+// =================================================================================================
+// BAM records on the device: the inflated bytes of one target's region -> the SoA batch of pjb_batch.
+// Replaces BamReader::next + BamAlignment::init per record (lib/src/bam_reader.cc:134-142,
+// lib/src/bam_alignment.cc:71-100).  Records are a linked list (block_size hops), so:
+//   bam_find_starts : one wave per 64 KB segment finds the first byte that starts a record.  A candidate
+//                     must look like a record (field ranges, sizes that add up, printable NUL-terminated
+//                     name, legal CIGAR ops) and so must the next two records after it.  This is a guess,
+//                     verified below.
+//   bam_walk        : one thread per segment follows the list from its start to the next segment's start
+//                     and must land on it exactly (that is the verification: by induction from the true
+//                     first record every start is then a true record boundary), counting records; run a
+//                     second time it writes the record offsets.
+//   BamSizes scan   : CIGAR ops and sequence words per record -> cig_off / seq_off (generic u64 scan).
+//   bam_transcode   : one thread per record writes the fixed-width fields, CIGAR, 4-bit bases of spliced
+//                     reads and the XS code (same rules as the host transcoder's xsCode).
+// =================================================================================================
+constexpr iu32 BAM_SEG = 1u << 16;
+constexpr iu64 BAM_NONE = ~0ull;
+
+struct BamRegion {
+    const uint8_t *U; // inflated bytes
+    iu64 total;       // bytes in U
+    iu64 first;       // offset of the first record (known from the index)
+    int32_t tid, ref_len, n_ref;
+};
+
+__device__ __forceinline__ iu32 ld32u(const uint8_t *p) {
+    iu32 v;
+    __builtin_memcpy(&v, p, 4);
+    return v;
+}
+__device__ __forceinline__ iu32 ld16u(const uint8_t *p) {
+    unsigned short v;
+    __builtin_memcpy(&v, p, 2);
+    return v;
+}
+
+// header-level plausibility of a record at offset c; returns its block_size, 0 if implausible.
+// A record cut off by the end of the buffer is plausible as far as it can be checked.
+__device__ iu32 bam_header_ok(const BamRegion R, iu64 c) {
+    if (c + 36 > R.total) return 0;
+    const uint8_t *r = R.U + c + 4;
+    const iu32 bs = ld32u(R.U + c);
+    if (bs < 32 || bs > (1u << 28)) return 0;
+    const int32_t rt = (int32_t)ld32u(r), rp = (int32_t)ld32u(r + 4);
+    if (rt < -1 || rt >= R.n_ref || rp < -1) return 0;
+    const iu32 l_name = r[8], n_cig = ld16u(r + 12);
+    const int32_t l_seq = (int32_t)ld32u(r + 16);
+    const int32_t mt = (int32_t)ld32u(r + 20), mp = (int32_t)ld32u(r + 24);
+    if (l_name < 1 || l_seq < 0 || mt < -1 || mt >= R.n_ref || mp < -1) return 0;
+    if (32ull + l_name + 4ull * n_cig + (iu64)((l_seq + 1) / 2) + (iu64)l_seq > bs) return 0;
+    return bs;
+}
+
+__device__ bool bam_record_ok(const BamRegion R, iu64 c) {
+    iu32 bs = bam_header_ok(R, c);
+    if (!bs) return false;
+    const uint8_t *r = R.U + c + 4;
+    const iu32 l_name = r[8], n_cig = ld16u(r + 12);
+    // name: printable, NUL-terminated; CIGAR: op codes 0..8 -- as far as the buffer reaches
+    const iu64 avail = R.total - (c + 4);
+    for (iu32 k = 0; k < l_name; k++) {
+        if (32ull + k >= avail) return true;
+        const uint8_t ch = r[32 + k];
+        if (k + 1 == l_name ? ch != 0 : (ch < 33 || ch > 126)) return false;
+    }
+    for (iu32 k = 0; k < n_cig; k++) {
+        if (32ull + l_name + 4ull * k + 4 > avail) return true;
+        if ((r[32 + l_name + 4 * k] & 15u) > 8u) return false;
+    }
+    // the two records after it
+    iu64 nx = c + 4 + bs;
+    for (int hop = 0; hop < 2; hop++) {
+        if (nx + 36 > R.total) return true;
+        bs = bam_header_ok(R, nx);
+        if (!bs) return false;
+        nx += 4 + bs;
+    }
+    return true;
+}
+
+__global__ __launch_bounds__(64) void bam_find_starts(BamRegion R, iu32 n_seg, iu64 *seg_start) {
+    const iu32 s = blockIdx.x;
+    if (s >= n_seg) return;
+    const iu64 lo = (iu64)s * BAM_SEG, hi = lo + BAM_SEG < R.total ? lo + BAM_SEG : R.total;
+    if (R.first >= lo && R.first < hi) { // the one start that is known: nothing before it belongs to the target
+        if (threadIdx.x == 0) seg_start[s] = R.first;
+        return;
+    }
+    if (hi <= R.first) {
+        if (threadIdx.x == 0) seg_start[s] = BAM_NONE;
+        return;
+    }
+    for (iu64 c0 = lo; c0 < hi; c0 += 64) {
+        const iu64 c = c0 + threadIdx.x;
+        const bool ok = c < hi && bam_record_ok(R, c);
+        const iu64 m = __ballot(ok);
+        if (m) {
+            if (threadIdx.x == 0) seg_start[s] = c0 + (iu32)(__ffsll((long long)m) - 1);
+            return;
+        }
+    }
+    if (threadIdx.x == 0) seg_start[s] = BAM_NONE; // a record longer than the segment covers it entirely
+}
+
+struct BamWalkOut {
+    iu32 *seg_n;       // records per segment
+    iu64 *rec_off;     // (fill pass) offset of every record
+    const iu64 *seg_base; // (fill pass) exclusive scan of seg_n
+    iu32 *ctl;         // [0] smallest segment index in which the target's records ended, [1] smallest segment whose
+                       // walk did not land on the next start, [2] smallest segment with an invalid record (atomicMin)
+};
+
+template <bool FILL>
+__global__ __launch_bounds__(256) void bam_walk(BamRegion R, iu32 n_seg, const iu64 *seg_start, BamWalkOut O) {
+    const iu32 s = blockIdx.x * 256 + threadIdx.x;
+    if (s >= n_seg) return;
+    iu64 cur = seg_start[s];
+    if (cur == BAM_NONE) {
+        if (!FILL) O.seg_n[s] = 0;
+        return;
+    }
+    iu64 limit = R.total;
+    for (iu32 t = s + 1; t < n_seg; t++) { // next segment that has a start (almost always t = s + 1)
+        const iu64 v = seg_start[t];
+        if (v != BAM_NONE) {
+            limit = v;
+            break;
+        }
+    }
+    iu32 n = 0;
+    iu64 at = FILL ? O.seg_base[s] : 0;
+    const iu32 n_take = FILL ? O.seg_n[s] : 0xffffffffu; // the fill pass stops where the (possibly trimmed) count says
+    bool ended = false, partial = false;
+    while (cur < limit && n < n_take) {
+        if (cur + 36 > R.total) {
+            partial = true;
+            break;
+        }
+        const iu32 bs = ld32u(R.U + cur);
+        const uint8_t *r = R.U + cur + 4;
+        if (bs < 32) {
+            if (!FILL) atomicMin(&O.ctl[2], s);
+            break;
+        }
+        const int32_t rt = (int32_t)ld32u(r), rp = (int32_t)ld32u(r + 4);
+        if (rt != R.tid || rp >= R.ref_len) { // first record that is not the target's: the region ends here
+            ended = true;
+            break;
+        }
+        if (cur + 4 + (iu64)bs > R.total) {
+            partial = true;
+            break;
+        }
+        const iu32 l_name = r[8], n_cig = ld16u(r + 12);
+        const int32_t l_seq = (int32_t)ld32u(r + 16);
+        if (l_seq < 0 || 32ull + l_name + 4ull * n_cig + (iu64)((l_seq + 1) / 2) + (iu64)l_seq > bs) {
+            if (!FILL) atomicMin(&O.ctl[2], s);
+            break;
+        }
+        if (FILL) O.rec_off[at + n] = cur;
+        n++;
+        cur += 4 + (iu64)bs;
+    }
+    if (!FILL) {
+        O.seg_n[s] = n;
+        if (ended) atomicMin(&O.ctl[0], s);
+        else if (!partial && cur != limit) atomicMin(&O.ctl[1], s); // overshot the next start: that start was not a record
+    }
+}
+
+// records of segments after the one in which the target ended do not belong to it
+__global__ void bam_trim_segments(iu32 *seg_n, iu32 n_seg, const iu32 *ctl) {
+    const iu32 s = blockIdx.x * 256 + threadIdx.x;
+    if (s < n_seg && s > ctl[0]) seg_n[s] = 0;
+}
+
+struct SegCountFn {
+    const iu32 *seg_n;
+    __device__ iu64 operator()(iu64 i) const { return seg_n[i]; }
+};
+struct SegBaseSink {
+    iu64 *seg_base;
+    __device__ void operator()(iu64 i, iu64, iu64 ex) const { seg_base[i] = ex; }
+};
+
+// per record: CIGAR ops << 32 | sequence words (4-byte words of packed bases, only for reads with an N op)
+struct BamSizesFn {
+    const uint8_t *U;
+    const iu64 *rec_off;
+    __device__ iu64 operator()(iu64 i) const {
+        const uint8_t *r = U + rec_off[i] + 4;
+        const iu32 l_name = r[8], n_cig = ld16u(r + 12);
+        const int32_t l_seq = (int32_t)ld32u(r + 16);
+        const uint8_t *cg = r + 32 + l_name;
+        bool spl = false;
+        for (iu32 k = 0; k < n_cig; k++) spl |= (cg[4 * k] & 15u) == 3u;
+        const iu64 words = (spl && l_seq > 0) ? ((iu64)((l_seq + 1) / 2) + 3) / 4 : 0;
+        return ((iu64)n_cig << 32) | words;
+    }
+};
+struct BamOffsetsSink {
+    iu32 *cig_off, *seq_off;
+    __device__ void operator()(iu64 i, iu64, iu64 ex) const {
+        cig_off[i] = (iu32)(ex >> 32);
+        seq_off[i] = (iu32)ex;
+    }
+};
+
+struct BamSoA {
+    int32_t *pos;
+    uint16_t *flag;
+    uint8_t *mapq, *xs;
+    int32_t *l_qseq, *mtid, *mpos;
+    iu32 *cig_off, *cigar, *seq_off;
+    uint8_t *seq4;
+};
+
+// XS:A aux tag -> 0 absent / '?' / '.', 1 '+', 2 '-', 3 anything else (same rules as the host transcoder)
+__device__ uint8_t bam_xs_code(const uint8_t *p, const uint8_t *end) {
+    while (p + 3 <= end) {
+        const uint8_t t0 = p[0], t1 = p[1], ty = p[2];
+        p += 3;
+        const bool is_xs = t0 == 'X' && t1 == 'S';
+        iu64 sz = 0;
+        switch (ty) {
+        case 'A': case 'c': case 'C': sz = 1; break;
+        case 's': case 'S': sz = 2; break;
+        case 'i': case 'I': case 'f': sz = 4; break;
+        case 'd': sz = 8; break;
+        case 'Z': case 'H': {
+            const uint8_t *q = p;
+            while (q < end && *q) q++;
+            sz = (iu64)(q - p) + 1;
+            break;
+        }
+        case 'B': {
+            if (p + 5 > end) return is_xs ? 3 : 0;
+            const uint8_t sub = p[0];
+            const iu32 cnt = ld32u(p + 1);
+            const iu64 es = (sub == 'c' || sub == 'C') ? 1 : (sub == 's' || sub == 'S') ? 2 : 4;
+            sz = 5 + es * cnt;
+            break;
+        }
+        default: return is_xs ? 3 : 0;
+        }
+        if (is_xs) {
+            if (ty != 'A' || p >= end) return 3;
+            const char ch = (char)p[0];
+            return ch == '+' ? 1 : ch == '-' ? 2 : (ch == '?' || ch == '.') ? 0 : 3;
+        }
+        if (sz > (iu64)(end - p)) return 0;
+        p += sz;
+    }
+    return 0;
+}
+
+__global__ __launch_bounds__(256) void bam_transcode(const uint8_t *U, const iu64 *rec_off, iu64 n, BamSoA B) {
+    const iu64 i = (iu64)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const iu64 off = rec_off[i];
+    const iu32 bs = ld32u(U + off);
+    const uint8_t *r = U + off + 4;
+    const iu32 l_name = r[8], n_cig = ld16u(r + 12);
+    const int32_t l_seq = (int32_t)ld32u(r + 16);
+    const iu64 cig_at = 32 + l_name, seq_at = cig_at + 4ull * n_cig;
+    const iu64 seq_bytes = (iu64)((l_seq + 1) / 2);
+    const iu64 aux_at = seq_at + seq_bytes + (iu64)l_seq;
+    B.pos[i] = (int32_t)ld32u(r + 4);
+    B.mapq[i] = r[9];
+    B.flag[i] = (uint16_t)ld16u(r + 14);
+    B.l_qseq[i] = l_seq;
+    B.mtid[i] = (int32_t)ld32u(r + 20);
+    B.mpos[i] = (int32_t)ld32u(r + 24);
+    B.xs[i] = bam_xs_code(r + aux_at, r + bs);
+    const iu32 co = B.cig_off[i];
+    for (iu32 k = 0; k < n_cig; k++) B.cigar[co + k] = ld32u(r + cig_at + 4 * k);
+    const iu32 so = B.seq_off[i], words = B.seq_off[i + 1] - so;
+    if (words) {
+        iu32 *dst = (iu32 *)B.seq4 + so;
+        const uint8_t *src = r + seq_at;
+        for (iu32 w = 0; w < words; w++) {
+            iu32 v = ld32u(src + 4 * w); // may read up to 3 bytes past the bases: still inside the record (qualities follow)
+            const iu64 have = seq_bytes - 4ull * w;
+            if (have < 4) v &= (1u << (8 * (iu32)have)) - 1u; // zero the padding of the last word
+            dst[w] = v;
+        }
+    }
+}
+
 } // namespace pjb

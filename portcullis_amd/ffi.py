@@ -22,7 +22,7 @@ EXPORTS = [
     "pjb_create", "pjb_destroy", "pjb_last_error", "pjb_set_refs", "pjb_upload_contig", "pjb_upload_contig_device",
     "pjb_release_contig", "pjb_submit_batch", "pjb_submit_batch_device", "pjb_finish_contig", "pjb_collect",
     "pjb_clear_rows", "pjb_get_timing", "pjb_device_count", "pjb_get_kernel_timing", "pjb_reset_kernel_timing",
-    "pjb_select_timed_kernels", "pjb_host_alloc", "pjb_host_free", "pjb_inflate_bgzf",
+    "pjb_select_timed_kernels", "pjb_host_alloc", "pjb_host_free", "pjb_inflate_bgzf", "pjb_submit_bam",
 ]
 FLAG_KERNEL_TIMING = 1
 
@@ -99,6 +99,7 @@ def load():
         L.pjb_submit_batch_device.argtypes = [C.c_void_p, C.c_int32, C.POINTER(PjbBatch)]
         L.pjb_finish_contig.argtypes = [C.c_void_p, C.c_int32, C.POINTER(PjbRegionResult)]
         L.pjb_inflate_bgzf.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
+        L.pjb_submit_bam.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_int32, C.POINTER(C.c_int64)]
         L.pjb_collect.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
         L.pjb_clear_rows.argtypes = [C.c_void_p]
         L.pjb_get_timing.argtypes = [C.c_void_p, C.POINTER(PjbTiming)]
@@ -213,6 +214,15 @@ class Context:
 
     def clear_rows(self):
         self._check(self._L.pjb_clear_rows(self._h))
+
+    def submit_bam(self, tid, comp, first_uoffset):
+        """All alignments of target `tid` from the BGZF bytes `comp` (whole blocks, starting with the block
+        that holds the target's first record at inflated offset `first_uoffset`): inflate, parse and
+        transcode on the device.  Returns the number of alignments added."""
+        comp = np.frombuffer(bytes(comp), dtype=np.uint8) if not isinstance(comp, np.ndarray) else comp
+        n = C.c_int64()
+        self._check(self._L.pjb_submit_bam(self._h, tid, comp.ctypes.data_as(C.c_void_p), len(comp), first_uoffset, C.byref(n)))
+        return n.value
 
     def inflate_bgzf(self, comp):
         """Inflate a run of whole BGZF blocks (bytes-like) on the device; returns the inflated bytes."""

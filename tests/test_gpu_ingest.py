@@ -109,3 +109,108 @@ def test_corrupt_input_fails_cleanly(ctx):
     with pytest.raises(ffi.PjbError):
         ctx.inflate_bgzf(b"\x1f\x8b\x08\x00" + bytes(40))  # gzip without the BGZF extra field
     assert ctx.inflate_bgzf(good) == data  # the context still works afterwards
+
+
+# ------------------------------------------------------------------ BAM records on the device
+def bam_targets(path):
+    """(refs, {tid: (file offset of the block holding the first record, offset inside that block)})."""
+    raw = open(path, "rb").read()
+    # block table
+    blocks, o = [], 0
+    while o < len(raw):
+        bs = (raw[o + 16] | raw[o + 17] << 8) + 1
+        isz = struct.unpack_from("<I", raw, o + bs - 4)[0]
+        blocks.append((o, isz))
+        o += bs
+    ustart = np.cumsum([0] + [b[1] for b in blocks])
+    data = gzip.decompress(raw)
+    (l_text,) = struct.unpack_from("<i", data, 4)
+    p = 8 + l_text
+    (n_ref,) = struct.unpack_from("<i", data, p)
+    p += 4
+    refs = []
+    for _ in range(n_ref):
+        (l_name,) = struct.unpack_from("<i", data, p)
+        name = data[p + 4:p + 4 + l_name - 1].decode()
+        (l_ref,) = struct.unpack_from("<i", data, p + 4 + l_name)
+        refs.append((name, l_ref))
+        p += 8 + l_name
+    first = {}
+    while p + 4 <= len(data):
+        (bs,) = struct.unpack_from("<i", data, p)
+        (tid,) = struct.unpack_from("<i", data, p + 4)
+        if tid >= 0 and tid not in first:
+            b = int(np.searchsorted(ustart, p, side="right") - 1)
+            first[tid] = (blocks[b][0], p - int(ustart[b]))
+        p += 4 + bs
+    return raw, refs, first
+
+
+def run_targets_from_bam(ctx, orc, path, genomes, orientation="UNKNOWN"):
+    from parity import assert_rows_equal, region_equal
+    from util_bam import read_bam, records_to_batch
+    raw, refs, first = bam_targets(path)
+    _, recs = read_bam(path)
+    ctx.set_refs([l for _, l in refs])
+    n_checked = 0
+    for tid, (coff, uoff) in sorted(first.items()):
+        mine = [r for r in recs if r["tid"] == tid]
+        batch = records_to_batch(mine)
+        orows, oreg = orc.find_juncs(tid, refs[tid][1], genomes[tid], batch.to_oracle(), orientation)
+        ctx.upload_contig(tid, genomes[tid])
+        ctx.clear_rows()
+        n = ctx.submit_bam(tid, raw[coff:], uoff)
+        assert n == len(mine)
+        dreg = ctx.finish_contig(tid)
+        drows = ctx.collect()
+        region_equal(dreg, oreg)
+        assert_rows_equal(drows, orows)
+        n_checked += len(orows)
+    return n_checked
+
+
+@pytest.fixture(scope="module")
+def orc():
+    from oracle import oracle
+    return oracle
+
+
+@pytest.mark.parametrize("block_size", [0xFF00, 700, 4096])
+def test_submit_bam_matches_oracle(orc, tmp_path, block_size):
+    """Three targets of fuzz reads (every CIGAR op, aux tags of every type before / after XS, SEQ '*'),
+    BGZF blocks that cut records anywhere: the device ingest must give the oracle's rows."""
+    from fuzzgen import make_reads
+    from portcullis_amd import ffi
+    from util_bam import write_bam
+    reads, refs, genomes = [], [], {}
+    for tid in range(3):
+        genome, rs = make_reads(40 + tid, n_reads=1500 + 900 * tid, paired=(tid == 1))
+        refs.append((f"chr{tid + 1}", len(genome)))
+        genomes[tid] = genome.encode() if isinstance(genome, str) else genome
+        for k, r in enumerate(rs):
+            r = dict(r)
+            r["tid"] = tid
+            if r.get("mtid", -1) >= 0:
+                r["mtid"] = tid
+            r["name"] = f"t{tid}r{k}" + "x" * (k % 23)
+            other = b"NMC\x03" + b"MDZ" + b"10A5^AC6\x00" + b"ZBBs" + struct.pack("<i", 3) + b"\x01\x00\x02\x00\x03\x00"
+            if k % 3 == 0:   # aux fields of several types after XS ...
+                r["aux"] = other
+            elif k % 3 == 1 and r.get("xs") is not None:   # ... or before it
+                r["aux"] = other + b"XSA" + r["xs"].encode()
+                r["xs"] = None
+            reads.append(r)
+    path = str(tmp_path / "a.bam")
+    write_bam(path, refs, reads, block_size=block_size)
+    with ffi.Context(0, "FR") as ctx:
+        assert run_targets_from_bam(ctx, orc, path, genomes, "FR") > 50
+
+
+def test_submit_bam_reference_fixture(orc, golden_dir):
+    from portcullis_amd import ffi
+    path = os.path.join(golden_dir, "clipped3.bam")
+    raw, refs, first = bam_targets(path)
+    rng = np.random.default_rng(4)
+    genomes = {t: rng.choice(np.frombuffer(b"ACGT", np.uint8), size=refs[t][1]).tobytes() for t in first}
+    with ffi.Context(0, "UNKNOWN") as ctx:
+        assert run_targets_from_bam(ctx, orc, path, genomes) >= 1
