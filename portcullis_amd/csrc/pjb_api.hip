@@ -984,6 +984,34 @@ int scan_bgzf(pjb_ctx *c, const uint8_t *comp, int64_t n, std::vector<InfBlock> 
     return PJB_OK;
 }
 
+// pageable host memory -> device through the two page-locked staging buffers: a few threads memcpy a
+// piece into one buffer while the DMA engine drains the other
+int upload_staged(pjb_ctx *c, void *dst, const uint8_t *src, size_t bytes) {
+    const size_t PIECE = (size_t)64 << 20;
+    for (size_t off = 0; off < bytes; off += PIECE) {
+        const size_t nb = std::min(PIECE, bytes - off);
+        const unsigned si = c->stage_next++ & 1u;
+        if (c->stage_busy[si]) {
+            HIP_TRY(c, hipEventSynchronize(c->stage_ev[si]));
+            c->stage_busy[si] = false;
+        }
+        if (c->stage_cap[si] < nb) {
+            if (c->stage[si]) (void)hipHostFree(c->stage[si]);
+            c->stage[si] = nullptr;
+            c->stage_cap[si] = 0;
+            if (hipHostMalloc((void **)&c->stage[si], PIECE, hipHostMallocDefault) != hipSuccess)
+                return fail(c, PJB_ERR_NOMEM, "cannot allocate %zu bytes of page-locked staging memory", PIECE);
+            c->stage_cap[si] = PIECE;
+        }
+        if (!c->stage_ev[si]) HIP_TRY(c, hipEventCreateWithFlags(&c->stage_ev[si], hipEventDisableTiming));
+        parallel_copy(c->stage[si], src + off, nb);
+        HIP_TRY(c, hipMemcpyAsync((uint8_t *)dst + off, c->stage[si], nb, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipEventRecord(c->stage_ev[si], c->stream));
+        c->stage_busy[si] = true;
+    }
+    return PJB_OK;
+}
+
 constexpr uint32_t INF_BLOCKS_PER_LAUNCH = 768 * 64; // three 64-lane workgroups per CU hold their tables in LDS
 
 // comp already on the device (padded); blocks on the host
@@ -1061,7 +1089,7 @@ extern "C" int pjb_submit_bam(pjb_ctx *c, int32_t tid, const uint8_t *comp, int6
     hipStream_t st = c->stream;
     if ((rc = ensure(c, c->b_inf_comp, (size_t)comp_bytes + INF_PAD))) return rc;
     if ((rc = ensure(c, c->b_inf_out, (size_t)total + 64))) return rc;
-    HIP_TRY(c, hipMemcpyAsync(c->b_inf_comp.p, comp, (size_t)comp_bytes, hipMemcpyHostToDevice, st));
+    if ((rc = upload_staged(c, c->b_inf_comp.p, comp, (size_t)comp_bytes))) return rc;
     HIP_TRY(c, hipMemsetAsync((uint8_t *)c->b_inf_comp.p + comp_bytes, 0, INF_PAD, st));
     HIP_TRY(c, hipMemsetAsync((uint8_t *)c->b_inf_out.p + total, 0, 64, st));
     if ((rc = inflate_on_device(c, (const uint8_t *)c->b_inf_comp.p, blocks, (uint8_t *)c->b_inf_out.p))) return rc;

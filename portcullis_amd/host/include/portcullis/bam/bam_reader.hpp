@@ -114,6 +114,13 @@ public:
     // which are handed to `sink` in file order.  (The reference can only use one thread per target
     // sequence, src/junction_builder.cc:109-112; this is SURVEY row f1, host ingest.)
     void decodeRegionParallel(int32_t tid, int nthreads, size_t maxRecords, const std::function<void(ReadBatch&)>& sink);
+
+    // The file bytes that hold target `tid`'s records, untouched (whole BGZF blocks: from the block with its
+    // first record through the block in which the next target starts, or the end of the file), read with
+    // `nthreads` parallel preads into one bigAlloc buffer the caller frees with bigFree.  firstU = offset of
+    // the first record inside the first block's inflated bytes.  Feeds pjb_submit_bam (device-side ingest).
+    // Returns nullptr if the target has no records.
+    uint8_t* readRegionBytes(int32_t tid, int nthreads, size_t& bytes, uint32_t& firstU);
 };
 
 }  // namespace bam

@@ -55,6 +55,7 @@ class JunctionBuilder {
     int hostThreads = 0;           // 0 = use `threads`; otherwise total host decode threads
     size_t batchRecords = 1 << 20; // alignments per batch sent to the device
     int innerThreads = 1;          // decode threads inside one target sequence (set by findJunctions)
+    bool deviceIngest = false;     // BGZF inflate + BAM record parse on the GPU (pjb_submit_bam) instead of host threads
 
     std::shared_future<int> deviceCount;  // pjb_device_count() evaluated in the background
 
@@ -100,6 +101,8 @@ public:
     int getDevices() const { return devices; }
     void setDevices(int n) { devices = n; }
     void setBatchRecords(size_t n) { batchRecords = n ? n : 1; }
+    void setDeviceIngest(bool on) { deviceIngest = on; }
+    bool isDeviceIngest() const { return deviceIngest; }
     // total host decode threads, independent of the number of target sequences (the reference's
     // --threads is capped at the number of targets; this one is not)
     void setHostThreads(int n) { hostThreads = n; }

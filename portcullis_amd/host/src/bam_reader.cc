@@ -488,6 +488,68 @@ void parallelFor(int nthreads, size_t n, F f) {  // f(thread, begin, end) over c
 
 }  // namespace
 
+uint8_t* BamReader::readRegionBytes(int32_t tid, int nthreads, size_t& bytes, uint32_t& firstU) {
+    bytes = 0;
+    firstU = 0;
+    if (tid < 0 || (size_t)tid >= targets.size()) throw BamException("readRegionBytes: target out of range");
+    if (firstOffset[(size_t)tid] == ~0ull) return nullptr;
+    const int fd = ::open(bamFile.c_str(), O_RDONLY);
+    if (fd < 0) throw BamException("Could not open BAM file: " + bamFile);
+    struct Closer {
+        int fd;
+        ~Closer() { ::close(fd); }
+    } closer{fd};
+    struct stat st;
+    if (fstat(fd, &st) != 0) throw BamException("Could not stat BAM file: " + bamFile);
+    const uint64_t fileSize = (uint64_t)st.st_size;
+    const uint64_t start = firstOffset[(size_t)tid];
+    uint64_t endCoff = fileSize;
+    for (uint64_t fo : firstOffset)
+        if (fo != ~0ull && fo > start) endCoff = std::min<uint64_t>(endCoff, fo >> 16);
+    uint64_t end = fileSize;
+    if (endCoff < fileSize) {  // the block in which the next target starts may hold this target's tail: include it
+        uint8_t h[18];
+        if (pread(fd, h, 18, (off_t)endCoff) != 18 || h[0] != 31 || h[1] != 139 || h[2] != 8 || !(h[3] & 4) || le16(h + 10) != 6 ||
+            h[12] != 'B' || h[13] != 'C')
+            end = fileSize;  // unusual header layout: take everything (the device stops at the first foreign record)
+        else
+            end = std::min<uint64_t>(fileSize, endCoff + (uint64_t)le16(h + 16) + 1);
+    }
+    const uint64_t lo = start >> 16;
+    if (end <= lo) return nullptr;
+    const size_t want = (size_t)(end - lo);
+    uint8_t* buf = (uint8_t*)bigAlloc(want + 64);
+    nthreads = std::max(1, nthreads);
+    const size_t nsl = std::max<size_t>(1, std::min<size_t>((size_t)nthreads, want >> 22));
+    std::atomic<bool> bad(false);
+    auto readSlice = [&](size_t t) {
+        const size_t per = (want + nsl - 1) / nsl, a = std::min(want, per * t), b = std::min(want, a + per);
+        size_t got = 0;
+        while (a + got < b) {
+            const ssize_t r = pread(fd, buf + a + got, b - a - got, (off_t)(lo + a + got));
+            if (r <= 0) {
+                bad = true;
+                return;
+            }
+            got += (size_t)r;
+        }
+    };
+    if (nsl == 1) {
+        readSlice(0);
+    } else {
+        std::vector<std::thread> th;
+        for (size_t t = 0; t < nsl; t++) th.emplace_back(readSlice, t);
+        for (auto& x : th) x.join();
+    }
+    if (bad) {
+        bigFree(buf);
+        throw BamException("Could not read BAM file: " + bamFile);
+    }
+    bytes = want;
+    firstU = (uint32_t)(start & 0xffff);
+    return buf;
+}
+
 void BamReader::decodeRegionParallel(int32_t tid, int nthreads, size_t maxRecords, const std::function<void(ReadBatch&)>& sink) {
     if (tid < 0 || (size_t)tid >= targets.size()) throw BamException("decodeRegionParallel: target out of range");
     if (firstOffset[(size_t)tid] == ~0ull) return;

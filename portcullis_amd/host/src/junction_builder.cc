@@ -65,6 +65,7 @@ JunctionBuilder::JunctionBuilder(const std::string& prepDir, const std::string& 
     }
     if (const char* e = getenv("PORTCULLIS_GPUS")) devices = atoi(e);
     if (const char* e = getenv("PJB_TEST_BATCH")) setBatchRecords((size_t)atol(e));
+    if (const char* e = getenv("PORTCULLIS_INGEST")) setDeviceIngest(std::string(e) == "device");
 }
 
 void JunctionBuilder::process() {
@@ -146,13 +147,18 @@ struct ContigDone {
 class DeviceThread {
 public:
     struct Cmd {
-        enum Kind { GENOME, BATCH, FINISH, STOP } kind = STOP;
+        enum Kind { GENOME, BATCH, BAM, FINISH, STOP } kind = STOP;
         int32_t tid = -1;
         std::string genome;
         bam::ReadBatch batch;
         std::vector<bam::ReadBatch>* spare = nullptr;  // where the batch storage goes back to
         std::mutex* spareMu = nullptr;
         std::promise<ContigDone>* done = nullptr;
+        // BAM: the target's file bytes for the device-side ingest (freed by the device thread)
+        uint8_t* bamBytes = nullptr;
+        size_t bamSize = 0;
+        uint32_t bamFirst = 0;
+        std::promise<int64_t>* bamDone = nullptr;
     };
 
 private:
@@ -207,6 +213,12 @@ private:
                     std::lock_guard<std::mutex> lk(*c.spareMu);
                     if (c.spare->size() < 4) c.spare->emplace_back(std::move(c.batch));
                 }
+            } else if (c.kind == Cmd::BAM) {
+                int64_t n = 0;
+                if (err.empty() && pjb_submit_bam(ctx, c.tid, c.bamBytes, (int64_t)c.bamSize, (int32_t)c.bamFirst, &n) != PJB_OK)
+                    failed[c.tid] = std::string("pjb_submit_bam: ") + pjb_last_error(ctx);
+                bam::bigFree(c.bamBytes);
+                c.bamDone->set_value(n);
             } else if (c.kind == Cmd::FINISH) {
                 ContigDone d;
                 memset(&d.rr, 0, sizeof d.rr);
@@ -280,7 +292,25 @@ void JunctionBuilder::findJuncs(DeviceThread& device, BamReader& reader, GenomeM
             }
         };
         try {
-            if (innerThreads > 1) {
+            if (deviceIngest) {
+                // the device inflates and parses: this thread only moves the target's file bytes
+                size_t nb = 0;
+                uint32_t firstU = 0;
+                uint8_t* bytes = reader.readRegionBytes(seq, innerThreads, nb, firstU);
+                if (bytes) {
+                    std::promise<int64_t> got;
+                    std::future<int64_t> f = got.get_future();
+                    DeviceThread::Cmd c;
+                    c.kind = DeviceThread::Cmd::BAM;
+                    c.tid = seq;
+                    c.bamBytes = bytes;
+                    c.bamSize = nb;
+                    c.bamFirst = firstU;
+                    c.bamDone = &got;
+                    device.push(std::move(c));
+                    any = f.get() > 0;
+                }
+            } else if (innerThreads > 1) {
                 reader.decodeRegionParallel(seq, innerThreads, batchRecords, send);
             } else {
                 reader.setRegion(seq);
@@ -480,6 +510,7 @@ int JunctionBuilder::main(int argc, char* argv[]) {
     std::string prepDir, output = DEFAULT_JUNC_OUTPUT, source = DEFAULT_JUNC_SOURCE, ori = "UNKNOWN", strand = "UNKNOWN";
     int threads = DEFAULT_JUNC_THREADS, devices = 0;
     size_t batch = 0;
+    std::string ingest;
     bool extra = false, separate = false, useCsi = false, exonGff = false, intronGff = false, verbose = false, help = false;
     auto need = [&](int& i) -> std::string {
         if (i + 1 >= argc) throw JunctionBuilderException(std::string("Missing value for option ") + argv[i]);
@@ -494,6 +525,7 @@ int JunctionBuilder::main(int argc, char* argv[]) {
         else if (a == "--source") source = need(i);
         else if (a == "--devices") devices = atoi(need(i).c_str());
         else if (a == "--batch") batch = (size_t)atol(need(i).c_str());
+        else if (a == "--ingest") ingest = need(i);
         else if (a == "--separate") separate = true;
         else if (a == "--extra") extra = true;
         else if (a == "-c" || a == "--use_csi") useCsi = true;
@@ -515,6 +547,7 @@ int JunctionBuilder::main(int argc, char* argv[]) {
              << "      --intron_gff           Also write <prefix>.junctions.intron.gff3" << endl
              << "  -c, --use_csi              Use the CSI index of the prepared BAM instead of the BAI" << endl
              << "      --devices <n>          Number of GPUs to use (default: all visible)" << endl
+             << "      --ingest <host|device> Where BGZF inflate and BAM record parsing run (default host; env PORTCULLIS_INGEST)" << endl
              << "  -v, --verbose" << endl;
         return help ? 0 : 1;
     }
@@ -533,6 +566,10 @@ int JunctionBuilder::main(int argc, char* argv[]) {
     jb.setStrandSpecific(bam::strandednessFromString(strand));
     if (devices > 0) jb.setDevices(devices);
     if (batch > 0) jb.setBatchRecords(batch);
+    if (!ingest.empty()) {
+        if (ingest != "host" && ingest != "device") throw JunctionBuilderException("--ingest takes host or device");
+        jb.setDeviceIngest(ingest == "device");
+    }
     jb.process();
     return 0;
 }

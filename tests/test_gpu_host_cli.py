@@ -186,3 +186,32 @@ def test_csi_index(tmp_path, orc):
     bai_to_csi(bam + ".bai", bam + ".csi")
     os.remove(bam + ".bai")
     check(prep, tmp_path, orc, "FR", threads=4, extra_opts=("-c",))
+
+
+# ------------------------------------------------------------------ --ingest device (BGZF inflate + BAM parse on the GPU)
+@pytest.mark.parametrize("block_size,threads", [(0xFF00, 1), (997, 3), (5000, 4)])
+def test_device_ingest_multi_contig(tmp_path, orc, block_size, threads):
+    """Same prepared directories, same byte-for-byte outputs, with the file bytes going straight to the
+    device (pjb_submit_bam): targets without reads, records straddling tiny BGZF blocks, several workers."""
+    prep = multi_contig(tmp_path, [51, None, 52, 53], block_size=block_size)
+    check(prep, tmp_path, orc, "FR", threads=threads, extra_opts=("--ingest", "device"))
+
+
+def test_device_ingest_csi_and_micro(tmp_path, orc, spombe30k):
+    from util_bam import bai_to_csi
+    prep = multi_contig(tmp_path, [61, 62])
+    bam = os.path.join(prep, PREP_BAM)
+    bai_to_csi(bam + ".bai", bam + ".csi")
+    os.remove(bam + ".bai")
+    check(prep, tmp_path, orc, "UNKNOWN", threads=2, extra_opts=("-c", "--ingest", "device"))
+
+
+def test_device_ingest_e2e_synthetic(tmp_path):
+    """2 M-read synthetic BAM (C2-small) and a paired-end multi-contig one through --ingest device."""
+    os.environ["PORTCULLIS_INGEST"] = "device"
+    try:
+        a = _e2e(tmp_path, "--config", "C2-small", "--threads", "4")
+        b = _e2e(tmp_path, "--config", "C3-contig", "--contigs", "4", "--scale-contigs", "--threads", "8", "--orientation", "FR")
+    finally:
+        del os.environ["PORTCULLIS_INGEST"]
+    assert a["tab_identical_to_oracle"] and b["tab_identical_to_oracle"] and b["junctions"] > 500
