@@ -4,6 +4,7 @@
 #include "pjb_ingest.hip.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -1081,19 +1082,29 @@ extern "C" int pjb_submit_bam(pjb_ctx *c, int32_t tid, const uint8_t *comp, int6
     HIP_TRY(c, hipSetDevice(c->cfg.device));
     OpenContig &oc = c->open[tid];
     if (!oc.batches.empty()) return fail(c, PJB_ERR_STATE, "submit_bam: target %d already has batches (one call per target)", tid);
+    const bool prof = getenv("PJB_PROFILE_HOST") != nullptr;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t0 = now(), t_scan, t_up, t_inf, t_walk;
     std::vector<InfBlock> blocks;
     int64_t total = 0;
     int rc = scan_bgzf(c, comp, comp_bytes, blocks, total);
     if (rc) return rc;
     if (total == 0 || (int64_t)first_uoffset >= total) return PJB_OK;
+    t_scan = now() - t0;
+    t0 = now();
     hipStream_t st = c->stream;
     if ((rc = ensure(c, c->b_inf_comp, (size_t)comp_bytes + INF_PAD))) return rc;
     if ((rc = ensure(c, c->b_inf_out, (size_t)total + 64))) return rc;
     if ((rc = upload_staged(c, c->b_inf_comp.p, comp, (size_t)comp_bytes))) return rc;
     HIP_TRY(c, hipMemsetAsync((uint8_t *)c->b_inf_comp.p + comp_bytes, 0, INF_PAD, st));
     HIP_TRY(c, hipMemsetAsync((uint8_t *)c->b_inf_out.p + total, 0, 64, st));
+    if (prof) (void)hipStreamSynchronize(st);
+    t_up = now() - t0;
+    t0 = now();
     if ((rc = inflate_on_device(c, (const uint8_t *)c->b_inf_comp.p, blocks, (uint8_t *)c->b_inf_out.p))) return rc;
 
+    t_inf = now() - t0;
+    t0 = now();
     // ---- record boundaries
     BamRegion R;
     R.U = (const uint8_t *)c->b_inf_out.p;
@@ -1130,6 +1141,8 @@ extern "C" int pjb_submit_bam(pjb_ctx *c, int32_t tid, const uint8_t *comp, int6
     if (h_ctl[1] != 0xffffffffu && h_ctl[1] <= end_seg)
         return fail(c, PJB_ERR_BGZF, "BAM record chain of target %d is inconsistent near inflated offset %llu", tid,
                     (unsigned long long)h_ctl[1] * BAM_SEG);
+    t_walk = now() - t0;
+    t0 = now();
     iu64 n64;
     memcpy(&n64, &h_ctl[4], 8);
     if (n64 == 0) return PJB_OK;
@@ -1178,6 +1191,10 @@ extern "C" int pjb_submit_bam(pjb_ctx *c, int32_t tid, const uint8_t *comp, int6
     LAUNCH(c, "bam_transcode", bam_transcode, dim3((unsigned)((n + 255) / 256)), dim3(256), R.U, (const iu64 *)c->b_bam_rec.p, (iu64)n, B);
     HIP_TRY(c, hipStreamSynchronize(st)); // `tails` is on this stack frame
     if (c->ktime) ev_collect(c);
+    if (prof)
+        fprintf(stderr, "[host profile] submit_bam tid %d: %zu blocks, %.1f MB -> %.1f MB, %zu records: header scan %.3f, upload %.3f, inflate %.3f, "
+                        "boundaries %.3f, fill+sizes+transcode %.3f s\n",
+                tid, blocks.size(), comp_bytes / 1e6, total / 1e6, n, t_scan, t_up, t_inf, t_walk, now() - t0);
     DevBatch d;
     memset(&d, 0, sizeof d);
     d.n = (int64_t)n;

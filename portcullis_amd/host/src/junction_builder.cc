@@ -43,6 +43,7 @@ static bool makeDirs(const std::string& p) {
 namespace {
 struct WallTimer {  // prints like boost::timer::auto_cpu_timer(1, " = Wall time taken: %ws\n\n")
     std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    double elapsed() const { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
     ~WallTimer() {
         const double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         std::ios::fmtflags f(cout.flags());
@@ -68,7 +69,18 @@ JunctionBuilder::JunctionBuilder(const std::string& prepDir, const std::string& 
     if (const char* e = getenv("PORTCULLIS_INGEST")) setDeviceIngest(std::string(e) == "device");
 }
 
+namespace {
+struct HostProfile {  // PJB_PROFILE_HOST=1: where the host side of findJuncs spends its time
+    bool on = getenv("PJB_PROFILE_HOST") != nullptr;
+    std::mutex mu;
+    double genome = 0, submit = 0, finish = 0, total = 0;
+    static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+};
+HostProfile g_prof;
+}  // namespace
+
 void JunctionBuilder::process() {
+    const double t_p0 = HostProfile::now();
     // many decode threads allocate and free multi-megabyte arrays: keep them on the heap instead of
     // one mmap/munmap pair each (munmap broadcasts TLB shootdowns to every core running a thread)
     mallopt(M_MMAP_THRESHOLD, 1 << 30);
@@ -109,12 +121,17 @@ void JunctionBuilder::process() {
          << " - Separate BAMs: " << separate << endl
          << endl;
     cout << reader.bamDetails() << endl;
+    const double t_p1 = HostProfile::now();
     findJunctions();
+    const double t_p2 = HostProfile::now();
     cout << "Saving junctions: " << endl;
     {
         WallTimer t;
         junctionSystem.saveAll(outDir + "/" + outputPrefix, source, false, outputExonGFF, outputIntronGFF);
     }
+    if (g_prof.on)
+        cerr << "[host profile] process: header+index " << (t_p1 - t_p0) << " s, findJunctions " << (t_p2 - t_p1) << " s, saveAll "
+             << (HostProfile::now() - t_p2) << " s" << endl;
     std::pair<bam::Orientation, bam::Strandedness> actual = junctionSystem.determineStrandedness(true);
     cout << "Determined sequence orientation to be: " << bam::orientationToLongString(actual.first) << endl;
     cout << "Determined RNAseq strandedness to be: " << bam::strandednessToLongString(actual.second) << endl << endl;
@@ -122,15 +139,6 @@ void JunctionBuilder::process() {
         cerr << "Warning!  User input and portcullis disagree about the strandedness of the dataset" << endl << endl;
 }
 
-namespace {
-struct HostProfile {  // PJB_PROFILE_HOST=1: where the host side of findJuncs spends its time
-    bool on = getenv("PJB_PROFILE_HOST") != nullptr;
-    std::mutex mu;
-    double genome = 0, submit = 0, finish = 0, total = 0;
-    static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
-};
-HostProfile g_prof;
-}  // namespace
 
 
 // ---------------------------------------------------------------------------------------------
@@ -547,7 +555,7 @@ int JunctionBuilder::main(int argc, char* argv[]) {
              << "      --intron_gff           Also write <prefix>.junctions.intron.gff3" << endl
              << "  -c, --use_csi              Use the CSI index of the prepared BAM instead of the BAI" << endl
              << "      --devices <n>          Number of GPUs to use (default: all visible)" << endl
-             << "      --ingest <host|device> Where BGZF inflate and BAM record parsing run (default host; env PORTCULLIS_INGEST)" << endl
+             << "      --ingest <device|host> Where BGZF inflate and BAM record parsing run (default device; env PORTCULLIS_INGEST)" << endl
              << "  -v, --verbose" << endl;
         return help ? 0 : 1;
     }
@@ -571,6 +579,7 @@ int JunctionBuilder::main(int argc, char* argv[]) {
         jb.setDeviceIngest(ingest == "device");
     }
     jb.process();
+    if (getenv("PJB_PROFILE_HOST")) cerr << "[host profile] main: " << timer.elapsed() << " s until process() returned" << endl;
     return 0;
 }
 

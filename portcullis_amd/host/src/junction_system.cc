@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <cmath>
 #include <fstream>
+#include <thread>
 #include <iostream>
 #include <sys/stat.h>
 
@@ -183,6 +184,28 @@ void JunctionSystem::saveAll(const std::string& outputPrefix, const std::string&
     saveAll(outputPrefix, source, false, false, false);
 }
 
+namespace {
+// text of items [0, n) in order, formatted by up to 8 threads on contiguous slices
+template <typename F>
+std::vector<std::string> formatSlices(size_t n, size_t bytesPerItem, F fn) {
+    const size_t nt = n < 20000 ? 1 : std::min<size_t>(8, std::max(1u, std::thread::hardware_concurrency()));
+    std::vector<std::string> parts(nt);
+    auto work = [&](size_t t) {
+        const size_t a = n * t / nt, b = n * (t + 1) / nt;
+        parts[t].reserve((b - a) * bytesPerItem + 64);
+        for (size_t i = a; i < b; i++) fn(i, parts[t]);
+    };
+    if (nt == 1) {
+        work(0);
+    } else {
+        std::vector<std::thread> th;
+        for (size_t t = 0; t < nt; t++) th.emplace_back(work, t);
+        for (auto& x : th) x.join();
+    }
+    return parts;
+}
+}  // namespace
+
 // junction_system.cc:336-383
 void JunctionSystem::saveAll(const std::string& outputPrefix, const std::string& source, bool bedscore, bool outputExonGFF,
                              bool outputIntronGFF) {
@@ -195,18 +218,18 @@ void JunctionSystem::saveAll(const std::string& outputPrefix, const std::string&
     cout << " - Saving junction table to: " << tabPath << " ... ";
     cout.flush();
     {
-        // same bytes as `f << (*this) << endl` (header, rows, one more empty line), formatted without iostreams
-        std::string out;
-        out.reserve(junctionList.size() * 320 + 1024);
-        out += Junction::junctionOutputHeader();
-        out.push_back('\n');
-        for (const auto& j : junctionList) {
-            j->appendTabRow(out);
+        // same bytes as `f << (*this) << endl` (header, rows, one more empty line), formatted without iostreams,
+        // slices of the list on a few threads
+        std::string head = Junction::junctionOutputHeader();
+        head.push_back('\n');
+        std::vector<std::string> parts = formatSlices(junctionList.size(), 320, [&](size_t i, std::string& out) {
+            junctionList[i]->appendTabRow(out);
             out.push_back('\n');
-        }
-        out.push_back('\n');
+        });
         std::ofstream f(tabPath.c_str(), std::ios::binary);
-        f.write(out.data(), (std::streamsize)out.size());
+        f.write(head.data(), (std::streamsize)head.size());
+        for (const std::string& p : parts) f.write(p.data(), (std::streamsize)p.size());
+        f.put('\n');
     }
     cout << "done." << endl;
     if (outputExonGFF) {
@@ -254,11 +277,13 @@ void JunctionSystem::writeIntronGFF(std::ostream& strm, const std::string& sourc
 void JunctionSystem::outputBED(const std::string& path, CanonicalSS type, const std::string& prefix, bool bedscore) {
     std::string out = "track name=\"junctions\" description=\"Portcullis V" + (version.empty() ? std::string("X.X.X") : version) +
                       " junctions\"\n";
-    out.reserve(junctionList.size() * 96 + 128);
-    for (const JunctionPtr& j : junctionList)
-        if (type == CanonicalSS::ALL || j->getSpliceSiteType() == type) j->appendBedRow(out, prefix, bedscore);
+    std::vector<std::string> parts = formatSlices(junctionList.size(), 96, [&](size_t i, std::string& o) {
+        const JunctionPtr& j = junctionList[i];
+        if (type == CanonicalSS::ALL || j->getSpliceSiteType() == type) j->appendBedRow(o, prefix, bedscore);
+    });
     std::ofstream f(path.c_str(), std::ios::binary);
     f.write(out.data(), (std::streamsize)out.size());
+    for (const std::string& p : parts) f.write(p.data(), (std::streamsize)p.size());
 }
 
 void JunctionSystem::outputBED(std::ostream& strm, CanonicalSS type, const std::string& prefix, bool bedscore) {

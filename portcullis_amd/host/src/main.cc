@@ -3,6 +3,7 @@
 #include <portcullis/junction_builder.hpp>
 
 #include <cstring>
+#include <unistd.h>
 #include <iostream>
 
 #ifndef PORTCULLIS_AMD_VERSION
@@ -17,7 +18,12 @@ int main(int argc, char* argv[]) {
             return 1;
         }
         portcullis::JunctionSystem::version = PORTCULLIS_AMD_VERSION;
-        return portcullis::JunctionBuilder::main(argc - 1, argv + 1);
+        const int rc = portcullis::JunctionBuilder::main(argc - 1, argv + 1);
+        // every output file is written and closed: leave without unloading the HIP runtime and walking the
+        // heap (0.15-0.2 s at process exit)
+        std::cout.flush();
+        std::cerr.flush();
+        _exit(rc);
     } catch (const portcullis::PortcullisException& e) {
         std::cerr << "Error: " << e.what() << std::endl;
         return 4;

@@ -45,6 +45,8 @@ def oracle_outputs(orc, prep, orientation, source="portcullis", version="1.2.4")
 
 def run_cli(prep, out_prefix, *opts):
     assert os.path.exists(EXE), f"{EXE} missing: run __graft_entry__.build()"
+    if "--ingest" not in opts:  # the tests above the device-ingest section exercise the host decode threads
+        opts = ("--ingest", "host", *opts)
     cmd = [EXE, "junc", "-o", out_prefix, "--exon_gff", "--intron_gff", *opts, prep]
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
     return p
@@ -138,7 +140,8 @@ def test_e2e_synthetic_parallel_decode(tmp_path):
     import json
     import sys
     p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "e2e_bench.py"), "--config", "C2-small", "--threads", "4",
-                        "--workdir", str(tmp_path / "e2e"), "--repeat", "1"], capture_output=True, text=True, timeout=900)
+                        "--workdir", str(tmp_path / "e2e"), "--repeat", "1"], capture_output=True, text=True, timeout=900,
+                       env=dict(os.environ, PORTCULLIS_INGEST="host"))
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
     res = json.loads(p.stdout.strip().split("\n")[-1])
     assert res["tab_identical_to_oracle"] and res["junctions"] > 900
@@ -148,7 +151,8 @@ def test_e2e_synthetic_multi_contig(tmp_path):
     import json
     import sys
     p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "e2e_bench.py"), "--config", "C2-tiny", "--threads", "6",
-                        "--contigs", "3", "--workdir", str(tmp_path / "e2e"), "--repeat", "1"], capture_output=True, text=True, timeout=900)
+                        "--contigs", "3", "--workdir", str(tmp_path / "e2e"), "--repeat", "1"], capture_output=True, text=True, timeout=900,
+                       env=dict(os.environ, PORTCULLIS_INGEST="host"))
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
     res = json.loads(p.stdout.strip().split("\n")[-1])
     assert res["tab_identical_to_oracle"]
@@ -157,8 +161,10 @@ def test_e2e_synthetic_multi_contig(tmp_path):
 def _e2e(tmp_path, *args):
     import json
     import sys
+    env = dict(os.environ)
+    env.setdefault("PORTCULLIS_INGEST", "host")
     p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "e2e_bench.py"), "--workdir", str(tmp_path / "e2e"),
-                        "--repeat", "1", *args], capture_output=True, text=True, timeout=1200)
+                        "--repeat", "1", *args], capture_output=True, text=True, timeout=1200, env=env)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
     return json.loads(p.stdout.strip().split("\n")[-1])
 
