@@ -368,6 +368,7 @@ int pjb_create(pjb_ctx **out, const pjb_config *cfg) {
         int v = atoi(s);
         if (v >= 4 && v <= RS_MAX_BITS) c->radix_max_bits = v;
     }
+    (void)hipFuncSetAttribute((const void *)bgzf_inflate, hipFuncAttributeMaxDynamicSharedMemorySize, I2_LDS_BYTES); // 80 KB
     // 12-bit digits need more dynamic LDS than the 64 KB a kernel gets without asking
     (void)hipFuncSetAttribute((const void *)rs_scatter<0>, hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)rs_scatter_lds_bytes(RS_MAX_BITS));
@@ -944,7 +945,6 @@ const char *inf_text(int code) {
     case INF_ERR_DIST: return "match distance before the start of the block";
     case INF_ERR_OVERRUN: return "block inflates or reads past its declared size";
     case INF_ERR_SIZE: return "block inflates to fewer bytes than its ISIZE";
-    case INF_ERR_TABLE: return "Huffman table space exhausted";
     default: return "bad block";
     }
 }
@@ -1013,7 +1013,7 @@ int upload_staged(pjb_ctx *c, void *dst, const uint8_t *src, size_t bytes) {
     return PJB_OK;
 }
 
-constexpr uint32_t INF_BLOCKS_PER_LAUNCH = 768 * 64; // three 64-lane workgroups per CU hold their tables in LDS
+constexpr uint32_t INF_BLOCKS_PER_LAUNCH = 1u << 18; // bounds the per-lane scratch (80 MB); two 64-lane workgroups fit a CU's LDS
 
 // comp already on the device (padded); blocks on the host
 int inflate_on_device(pjb_ctx *c, const uint8_t *d_comp, const std::vector<InfBlock> &blocks, uint8_t *d_out) {
@@ -1031,7 +1031,7 @@ int inflate_on_device(pjb_ctx *c, const uint8_t *d_comp, const std::vector<InfBl
     HIP_TRY(c, hipMemsetAsync(d_any, 0, 4, st));
     for (size_t b0 = 0; b0 < nb; b0 += per_launch) {
         const uint32_t cnt = (uint32_t)std::min(per_launch, nb - b0);
-        LAUNCH_LDS(c, "bgzf_inflate", bgzf_inflate, dim3((cnt + 63) / 64), dim3(64), INF_LDS_BYTES, d_comp,
+        LAUNCH_LDS(c, "bgzf_inflate", bgzf_inflate, dim3((cnt + 63) / 64), dim3(64), I2_LDS_BYTES, d_comp,
                    (const InfBlock *)c->b_inf_blocks.p + b0, cnt, d_out, (uint8_t *)c->b_inf_scratch.p, d_status + b0, d_any);
     }
     int any = 0;

@@ -1,17 +1,12 @@
-// Device-side ingest of prepared BAM files: BGZF inflate on the GPU.
+// Device-side ingest of prepared BAM files: BGZF inflate and BAM record parsing on the GPU.
 //
-// Replaces, for the junc path, htslib's bgzf_read_block / inflate_block
+// bgzf_inflate replaces, for the junc path, htslib's bgzf_read_block / inflate_block
 // (deps/htslib-1.3/bgzf.c:292-316, 421-540): every BGZF block is an independent raw-DEFLATE stream of
 // at most 64 KB of output, so a file is tens of thousands of independent decodes.  One LANE owns one
 // BGZF block (a 64-lane workgroup = 64 blocks): DEFLATE is serial inside a stream, the parallelism
 // is across streams.  Like inflate_block, the CRC32 of the footer is not checked; unlike it, the
 // inflated size must equal the footer's ISIZE (it fixes where the block lands in the output).
-//
-// Huffman decode: first-level tables (8 bits literal/length, 5 bits distance) live in LDS, laid out
-// [entry][lane] so the 64 lanes of a wave hit 64 different banks; codes longer than the first level
-// continue in second-level tables in a per-lane global scratch area.  Entries are 16 bit:
-//   direct  : symbol << 4 | code length (1..15)          (0 = invalid code)
-//   link    : 0x8000 | (sub-table offset / 2) << 4 | (sub-table index bits - 1)
+// All per-lane state lives in LDS, laid out [entry][lane] so the 64 lanes of a wave hit 64 different banks.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -23,13 +18,9 @@ typedef uint32_t iu32;
 
 constexpr int INF_ROOT_L = 8;        // first-level bits, literal/length code
 constexpr int INF_ROOT_D = 5;        // first-level bits, distance code
-constexpr int INF_SUB_L = 2048;      // second-level entries per lane, literal/length
-constexpr int INF_SUB_D = 1024;      // second-level entries per lane, distance
 constexpr int INF_PAD = 4096;        // zeroed bytes the compressed buffer carries after its last block
 constexpr int INF_LENS = 320;        // code lengths being read (288 + 32)
-constexpr int INF_LANE_U16 = (1 << INF_ROOT_L) + (1 << INF_ROOT_D) + 32; // + count[16] + next_code[16]
-constexpr int INF_LDS_BYTES = INF_LANE_U16 * 2 * 64;                      // per 64-lane workgroup
-constexpr size_t INF_SCRATCH_PER_LANE = (size_t)(INF_SUB_L + INF_SUB_D) * 2 + INF_LENS; // bytes
+constexpr size_t INF_SCRATCH_PER_LANE = INF_LENS; // global scratch per lane: the code lengths of the block header being read
 
 enum : int { // per-block status
     INF_OK = 0,
@@ -41,7 +32,6 @@ enum : int { // per-block status
     INF_ERR_DIST = 6,      // distance reaches before the start of the block
     INF_ERR_OVERRUN = 7,   // more output than ISIZE / more input than the block holds
     INF_ERR_SIZE = 8,      // stream ended before ISIZE bytes
-    INF_ERR_TABLE = 9,     // second-level table space exhausted
 };
 
 struct InfBlock { // one BGZF block, filled by the host while it hops over the block headers
@@ -58,13 +48,6 @@ __constant__ unsigned short c_dist_base[30] = {1,   2,   3,   4,   5,   7,    9,
                                                193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
 __constant__ unsigned char c_dist_extra[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
 __constant__ unsigned char c_clen_order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
-
-// per-lane LDS area, u16 entries, interleaved over the wave: entry e of lane l sits at ((e >> 1) * 64 + l) * 2 + (e & 1)
-struct LaneLds {
-    unsigned short *p; // &lds[lane * 2]
-    __device__ __forceinline__ unsigned short &operator[](iu32 e) const { return p[(e >> 1) * 128 + (e & 1)]; }
-};
-constexpr iu32 L_LIT = 0, L_DIST = 1u << INF_ROOT_L, L_COUNT = L_DIST + (1u << INF_ROOT_D), L_NEXT = L_COUNT + 16;
 
 __device__ __forceinline__ iu64 load64u(const uint8_t *p) {
     iu64 v;
@@ -116,334 +99,481 @@ struct BitReader {
     }
 };
 
-// Output of one block: bytes are collected 8 at a time before they are stored, and the last 16 bytes
-// stay in registers so that matches with distance <= 16 never read memory (and longer ones never read
-// bytes that are still pending).  BAM blocks are full of them: every quality-less read carries a run of
-// 0xff as long as the read (distance 1).
-struct OutWriter {
-    uint8_t *base;  // first byte of the block
-    iu32 pos;       // bytes produced
-    iu64 acc;       // bytes of the current 8-byte group [pos & ~7, pos)
-    iu64 wlo, whi;  // the last 16 bytes, oldest in the low byte of wlo
-    __device__ __forceinline__ void put(iu32 x) {
-        acc |= (iu64)x << (8 * (pos & 7u));
-        wlo = (wlo >> 8) | (whi << 56);
-        whi = (whi >> 8) | ((iu64)x << 56);
-        pos++;
-        if ((pos & 7u) == 0) {
-            store64u(base + pos - 8, acc);
-            acc = 0;
-        }
-    }
-    __device__ __forceinline__ void put8(iu64 v) {
-        const iu32 k = pos & 7u;
-        if (k == 0) {
-            store64u(base + pos, v);
-        } else {
-            store64u(base + pos - k, acc | (v << (8 * k)));
-            acc = v >> (64 - 8 * k);
-        }
-        wlo = whi;
-        whi = v;
-        pos += 8;
-    }
-    // n (1..7) bytes, low bytes of v first
-    __device__ __forceinline__ void putn(iu64 v, iu32 n) {
-        v &= (1ull << (8 * n)) - 1ull;
-        const iu32 k = pos & 7u;
-        acc |= v << (8 * k);
-        if (k + n >= 8) {
-            store64u(base + pos - k, acc);
-            acc = k ? v >> (64 - 8 * k) : 0ull;
-        }
-        wlo = (wlo >> (8 * n)) | (whi << (64 - 8 * n));
-        whi = (whi >> (8 * n)) | (v << (64 - 8 * n));
-        pos += n;
-    }
-    // the next 8 bytes of a match with distance 1..16, from the register window (periodic if dist < 8)
-    __device__ __forceinline__ iu64 ahead(iu32 dist) const {
-        if (dist >= 8) {
-            const iu32 sh = 8 * (16 - dist); // 0..64
-            return sh == 0 ? wlo : sh == 64 ? whi : (wlo >> sh) | (whi << (64 - sh));
-        }
-        iu64 v = whi >> (8 * (8 - dist)); // the last `dist` bytes
-        for (iu32 sh = 8 * dist; sh < 64; sh <<= 1) v |= v << sh;
-        return v;
-    }
-    __device__ __forceinline__ void flush() {
-        const iu32 k = pos & 7u;
-        for (iu32 i = 0; i < k; i++) base[pos - k + i] = (uint8_t)(acc >> (8 * i));
+__device__ __forceinline__ iu32 bitrev16(iu32 v, int len) { return __brev(v) >> (32 - len); }
+
+// =================================================================================================
+// bgzf_inflate: the memory accesses of the 64 lanes are lined up.
+//
+// A first version decoded straight from and to global memory; some lane then needs memory in practically
+// every iteration (a fifth of all symbols are matches further back than any register window, plus input
+// refills and second-level table lookups) and a wave waits as a whole: one memory round trip per
+// iteration, 2 us each, 20 GB/s.  Here a lane never touches global memory while it decodes:
+//   * the Huffman tables are complete in LDS: 8-bit / 5-bit first levels, longer codes by canonical
+//     arithmetic (upper bound per code length, symbols in code order) without branches;
+//   * input comes from a 64-byte LDS ring per lane, matches go to a 16-entry LDS queue per lane
+//     (decoding does not depend on what a match copies); literals are plain byte stores;
+//   * when any lane runs low on input or has a full queue, ALL lanes take a memory phase together:
+//     one round trip tops up the rings and fetches the first 16 bytes of every queued match whose source
+//     lies before the queue's first destination; the few remaining steps (overlapping, long or
+//     short-period copies) follow in order, one step of every lane per round trip.
+// Block headers and table builds still read the stream directly (a few per block).  41 GB/s of inflated
+// bytes on the 10 M-read BAM (2.1 GB in 50 ms), 100x one zlib thread.
+// =================================================================================================
+constexpr int I2_QUEUE = 16;                    // queued matches per lane
+constexpr iu32 I2_LIT = 0;                      // u16 entry offsets inside a lane's LDS area
+constexpr iu32 I2_DIST = 256;                   // 32 entries
+constexpr iu32 I2_LLIM = 288, I2_LADJ = 304;    // literal/length tree: per code length, upper bound and slot adjustment of long codes
+constexpr iu32 I2_DLIM = 320, I2_DADJ = 336;    // distance tree
+constexpr iu32 I2_LLONG = 352;                  // symbols of long literal/length codes: 286 low bytes (143) + 286 high bits (18)
+constexpr iu32 I2_LLONG_HI = I2_LLONG + 143;
+constexpr iu32 I2_DLONG = I2_LLONG + 162;       // symbols of long distance codes: 30 bytes (15)
+constexpr iu32 I2_RING = I2_DLONG + 16;         // 16 words of input
+constexpr iu32 I2_Q = I2_RING + 32;             // I2_QUEUE x 2 words
+constexpr iu32 I2_LANE_U16 = I2_Q + 4 * I2_QUEUE;
+constexpr int I2_LDS_BYTES = (int)I2_LANE_U16 * 2 * 64 + 256; // + the shared length / distance tables (2 x 32 words)
+static_assert(I2_LANE_U16 % 2 == 0 && I2_RING % 2 == 0 && I2_Q % 2 == 0, "word-aligned LDS areas");
+
+struct Lane2 {
+    unsigned short *p; // &lds[lane * 2]
+    __device__ __forceinline__ unsigned short &h(iu32 e) const { return p[(e >> 1) * 128 + (e & 1)]; }
+    __device__ __forceinline__ iu32 &w(iu32 e_even) const { return *(iu32 *)(p + (e_even >> 1) * 128); } // 32-bit word at an even entry
+    __device__ __forceinline__ iu32 byte(iu32 base, iu32 i) const { return (h(base + (i >> 1)) >> ((i & 1) * 8)) & 0xffu; }
+    __device__ __forceinline__ void set_byte(iu32 base, iu32 i, iu32 v) const {
+        unsigned short &x = h(base + (i >> 1));
+        x = (unsigned short)((i & 1) ? ((x & 0x00ffu) | (v << 8)) : ((x & 0xff00u) | v));
     }
 };
 
-__device__ __forceinline__ iu32 bitrev16(iu32 v, int len) { return __brev(v) >> (32 - len); }
-
-// Canonical Huffman tables from lens[0..n): first level in LDS at `root` (2^root_bits entries), longer
-// codes in sub[0..sub_cap).  Returns 0 or an INF_ERR_* code.
-__device__ int inf_build(const LaneLds L, iu32 root, int root_bits, unsigned short *sub, int sub_cap, const uint8_t *lens, int n) {
-    for (int i = 0; i < 16; i++) L[L_COUNT + i] = 0;
-    for (int i = 0; i < n; i++) L[L_COUNT + lens[i]] = L[L_COUNT + lens[i]] + 1;
+// Tables of one tree.  root: first level (2^root_bits entries: symbol << 4 | len, 0x8000 = longer code, 0 = invalid).
+// Longer codes are decoded canonically: with v = the next 15 bits, first bit on top, the code length is the
+// smallest len with v < lim[len] (lim[len] = (first code + count of length len) << (15 - len), a non-decreasing
+// sequence), and the symbol is lng[(v >> (15 - len)) + adj[len]] where lng lists the long symbols in code
+// order (bytes, plus their 9th bit at lng_hi for the literal/length tree) and adj[len] = slot of the first
+// code of that length - that first code (mod 2^16).
+__device__ int inf2_build(const Lane2 L, iu32 root, int root_bits, iu32 lim, iu32 adj, iu32 lng, iu32 lng_hi, const uint8_t *lens, int n) {
+    // lim / adj double as scratch: codes per length in lim, running code / slot in adj
+    for (int i = 0; i < 16; i++) L.h(lim + i) = 0;
+    for (int i = 0; i < n; i++) L.h(lim + lens[i]) = L.h(lim + lens[i]) + 1;
     const iu32 rsize = 1u << root_bits;
-    for (iu32 e = 0; e < rsize; e++) L[root + e] = 0;
-    if (L[L_COUNT] == (unsigned short)n) return 0; // no codes at all: every lookup is invalid (legal for an unused distance tree)
-    // over-subscription check and first code of every length
+    for (iu32 e = 0; e < rsize; e++) L.h(root + e) = 0;
+    L.h(lim) = 0; // unused codes do not count
     int left = 1;
-    iu32 code = 0;
     for (int len = 1; len <= 15; len++) {
         left <<= 1;
-        left -= (int)L[L_COUNT + len];
+        left -= (int)L.h(lim + len);
         if (left < 0) return INF_ERR_CODELENS;
-        code = (code + (len > 1 ? L[L_COUNT + len - 1] : 0)) << 1;
-        L[L_NEXT + len] = (unsigned short)code;
     }
-    // pass 1: the longest code under every first-level prefix that has long codes (kept in the root entry)
+    // long symbols in code order
+    iu32 slot = 0;
+    for (int len = root_bits + 1; len <= 15; len++) {
+        L.h(adj + len) = (unsigned short)slot;
+        slot += L.h(lim + len);
+    }
     for (int s = 0; s < n; s++) {
         const int len = lens[s];
         if (len > root_bits) {
-            const iu32 c = L[L_NEXT + len];
-            L[L_NEXT + len] = (unsigned short)(c + 1);
-            const iu32 pre = bitrev16(c, len) & (rsize - 1);
-            if (L[root + pre] < (unsigned short)len) L[root + pre] = (unsigned short)len;
+            const iu32 at = L.h(adj + len);
+            L.h(adj + len) = (unsigned short)(at + 1);
+            L.set_byte(lng, at, (iu32)s & 0xffu);
+            if (lng_hi) {
+                unsigned short &m = L.h(lng_hi + (at >> 4));
+                m = (unsigned short)((s & 0x100) ? (m | (1u << (at & 15))) : (m & ~(1u << (at & 15))));
+            }
         }
     }
-    int used = 0;
-    for (iu32 e = 0; e < rsize; e++) {
-        const int mx = L[root + e];
-        if (mx) {
-            const int sb = mx - root_bits; // 1..7 (15 - 8) or 1..10 (15 - 5)
-            if (used + (1 << sb) > sub_cap) return INF_ERR_TABLE;
-            // link: offset / 2 in 11 bits (sub-table sizes are even, so offsets are), index bits - 1 in the low 4
-            L[root + e] = (unsigned short)(0x8000u | ((iu32)(used >> 1) << 4) | (iu32)(sb - 1));
-            for (int k = 0; k < (1 << sb); k++) sub[used + k] = 0;
-            used += 1 << sb;
-        }
-    }
-    // pass 2: fill
-    code = 0;
+    // first level, with canonical codes assigned in symbol order
+    iu32 code = 0;
     for (int len = 1; len <= 15; len++) {
-        code = (code + (len > 1 ? L[L_COUNT + len - 1] : 0)) << 1;
-        L[L_NEXT + len] = (unsigned short)code;
+        code = (code + (len > 1 ? L.h(lim + len - 1) : 0)) << 1;
+        L.h(adj + len) = (unsigned short)code;
     }
     for (int s = 0; s < n; s++) {
         const int len = lens[s];
         if (len == 0) continue;
-        const iu32 c = L[L_NEXT + len];
-        L[L_NEXT + len] = (unsigned short)(c + 1);
+        const iu32 c = L.h(adj + len);
+        L.h(adj + len) = (unsigned short)(c + 1);
         const iu32 rev = bitrev16(c, len);
-        const unsigned short ent = (unsigned short)(((iu32)s << 4) | (iu32)len);
         if (len <= root_bits) {
-            for (iu32 e = rev; e < rsize; e += 1u << len) L[root + e] = ent;
+            const unsigned short ent = (unsigned short)(((iu32)s << 4) | (iu32)len);
+            for (iu32 e = rev; e < rsize; e += 1u << len) L.h(root + e) = ent;
         } else {
-            const iu32 link = L[root + (rev & (rsize - 1))];
-            const int sb = (int)(link & 15u) + 1;
-            const iu32 off = ((link >> 4) & 0x7ffu) << 1;
-            const int rest = len - root_bits;
-            for (iu32 k = rev >> root_bits; k < (1u << sb); k += 1u << rest) sub[off + k] = ent;
+            L.h(root + (rev & (rsize - 1))) = 0x8000u;
         }
+    }
+    // adj[len] holds first code + count now; lim[len] the count
+    slot = 0;
+    for (int len = 1; len <= 15; len++) {
+        const iu32 cnt = L.h(lim + len), end = L.h(adj + len), first = end - cnt;
+        L.h(lim + len) = (unsigned short)(end << (15 - len)); // <= 2^15
+        L.h(adj + len) = (unsigned short)(slot - first);
+        if (len > root_bits) slot += cnt;
     }
     return 0;
 }
 
-// decode one symbol; returns the entry (symbol << 4 | len) with the bits consumed, 0 if the code is invalid
-__device__ __forceinline__ iu32 inf_decode(const LaneLds L, iu32 root, int root_bits, const unsigned short *sub, BitReader &br) {
-    iu32 e = L[root + br.peek(root_bits)];
+// symbol << 4 | len of the code at the low end of `bits` (at least 15 valid bits), 0 if invalid
+template <int ROOT_BITS>
+__device__ __forceinline__ iu32 inf2_decode(const Lane2 L, iu32 root, iu32 lim, iu32 adj, iu32 lng, iu32 lng_hi, iu32 bits) {
+    iu32 e = L.h(root + (bits & ((1u << ROOT_BITS) - 1u)));
     if (e & 0x8000u) {
-        const int sb = (int)(e & 15u) + 1;
-        const iu32 off = ((e >> 4) & 0x7ffu) << 1;
-        e = sub[off + (((iu32)(br.bb >> root_bits)) & ((1u << sb) - 1u))];
-        // consume the load inside the branch: the wait for it (which also drains this lane's pending stores)
-        // must not sit at the join, where every first-level hit would pay it too
-        asm volatile("" : "+v"(e));
+        const iu32 v15 = __brev(bits) >> 17; // the next 15 bits, first bit in the top position
+        iu32 len = ROOT_BITS + 1;
+#pragma unroll
+        for (int l = ROOT_BITS + 1; l <= 15; l++) len += v15 >= (iu32)L.h(lim + l) ? 1u : 0u; // independent reads, no branches
+        e = 0;
+        if (len <= 15) {
+            const iu32 i = ((v15 >> (15 - len)) + L.h(adj + len)) & 0x1ffu; // < 286 for a valid code set
+            iu32 sym = L.byte(lng, i);
+            if (lng_hi) sym |= ((L.h(lng_hi + (i >> 4)) >> (i & 15)) & 1u) << 8;
+            e = (sym << 4) | len;
+        }
     }
-    br.drop((int)(e & 15u));
     return e;
 }
 
-// One lane inflates one BGZF block.  `comp` must be readable INF_PAD bytes past the last payload (a
-// truncated last block reads its code lengths before the overrun checks of the symbol loop apply).
+// every vector memory operation of this wave has completed (vmcnt = 0, other counters untouched).  Placed where
+// conditionally issued loads end, so that the compiler does not have to assume them pending later on -- it would
+// then drain the stores of the decode loop whenever one of their registers is reused.
+__device__ __forceinline__ void wait_vm() { __builtin_amdgcn_s_waitcnt(0x0F70); }
+
+struct Ring2 { // 16-word LDS ring + bit buffer
+    iu32 ri, rf;       // read index, words available
+    const uint8_t *gp; // next input byte to fetch into the ring
+    iu64 bb;
+    int nb;
+};
+
 __global__ __launch_bounds__(64) void bgzf_inflate(const uint8_t *comp, const InfBlock *blocks, iu32 n_blocks, uint8_t *out,
-                                                    uint8_t *scratch, int *status, int *any_error) {
+                                                     uint8_t *scratch, int *status, int *any_error) {
     extern __shared__ __attribute__((aligned(16))) unsigned short inf_lds[];
+    // shared tables behind the per-lane areas
+    iu32 *s_len = (iu32 *)(inf_lds + (size_t)I2_LANE_U16 * 64); // base | extra bits << 16
+    iu32 *s_dist = s_len + 32;
+    if (threadIdx.x < 29) s_len[threadIdx.x] = (iu32)c_len_base[threadIdx.x] | ((iu32)c_len_extra[threadIdx.x] << 16);
+    if (threadIdx.x < 30) s_dist[threadIdx.x] = (iu32)c_dist_base[threadIdx.x] | ((iu32)c_dist_extra[threadIdx.x] << 16);
+    __syncthreads();
     const iu32 b = blockIdx.x * 64 + threadIdx.x;
-    if (b >= n_blocks) return;
-    LaneLds L;
+    const bool have = b < n_blocks;
+    Lane2 L;
     L.p = inf_lds + threadIdx.x * 2;
-    uint8_t *my = scratch + (size_t)b * INF_SCRATCH_PER_LANE;
-    unsigned short *sub_l = (unsigned short *)my;
-    unsigned short *sub_d = sub_l + INF_SUB_L;
-    uint8_t *lens = (uint8_t *)(sub_d + INF_SUB_D);
-    const InfBlock B = blocks[b];
-    BitReader br;
-    br.start(comp + B.in_off);
-    const uint8_t *in_end = comp + B.in_off + B.in_len;
-    OutWriter ow;
-    ow.base = out + B.out_off;
-    ow.pos = 0;
-    ow.acc = 0;
-    ow.wlo = ow.whi = 0;
+    uint8_t *lens = scratch + (size_t)b * INF_SCRATCH_PER_LANE;
+    InfBlock B;
+    B.in_off = B.out_off = 0;
+    B.in_len = B.out_len = 0;
+    if (have) B = blocks[b];
+    const uint8_t *in0 = comp + B.in_off, *in_end = in0 + B.in_len;
+    uint8_t *base = out + B.out_off;
     const iu32 out_len = B.out_len;
+    enum { ST_HEADER, ST_SYMBOLS, ST_DONE };
+    int state = have ? ST_HEADER : ST_DONE;
     int err = 0;
     bool last = false;
-    while (!last && !err) {
-        br.refill();
-        last = br.take(1);
-        const iu32 type = br.take(2);
-        if (type == 0) { // stored: byte-align, LEN, NLEN, raw bytes
-            br.drop(br.nb & 7);
-            br.refill();
-            const iu32 len = br.take(16);
-            br.refill();
-            const iu32 nlen = br.take(16);
-            if ((len ^ 0xffffu) != nlen) {
-                err = INF_ERR_STORED;
-                break;
-            }
-            const uint8_t *src = br.byte_pos();
-            if (src + len > in_end || ow.pos + len > out_len) {
-                err = INF_ERR_OVERRUN;
-                break;
-            }
-            iu32 i = 0;
-            for (; i + 8 <= len; i += 8) ow.put8(load64u(src + i));
-            for (; i < len; i++) ow.put(src[i]);
-            br.start(src + len);
-            continue;
-        }
-        if (type == 3) {
-            err = INF_ERR_BTYPE;
-            break;
-        }
-        int nlit, ndist;
-        if (type == 1) { // fixed codes
-            for (int i = 0; i < 144; i++) lens[i] = 8;
-            for (int i = 144; i < 256; i++) lens[i] = 9;
-            for (int i = 256; i < 280; i++) lens[i] = 7;
-            for (int i = 280; i < 288; i++) lens[i] = 8;
-            for (int i = 288; i < 320; i++) lens[i] = 5;
-            nlit = 288;
-            ndist = 32;
-        } else { // dynamic codes
-            br.refill();
-            nlit = (int)br.take(5) + 257;
-            ndist = (int)br.take(5) + 1;
-            const int ncl = (int)br.take(4) + 4;
-            if (nlit > 286 || ndist > 30) {
-                err = INF_ERR_CODELENS;
-                break;
-            }
-            for (int i = 0; i < 19; i++) lens[i] = 0;
-            for (int i = 0; i < ncl; i++) {
-                br.refill();
-                lens[c_clen_order[i]] = (uint8_t)br.take(3);
-            }
-            // the code-length code: 7-bit first level in the literal root area, never needs a second level
-            if ((err = inf_build(L, L_LIT, 7, sub_l, 0, lens, 19))) break;
-            int i = 0;
-            while (i < nlit + ndist) {
-                br.refill();
-                const iu32 e = inf_decode(L, L_LIT, 7, sub_l, br);
-                if (e == 0) {
-                    err = INF_ERR_CODELENS;
-                    break;
+    iu64 bitpos = 0; // stream position (bits from in0) where the next header starts
+    iu32 pos = 0;    // bytes produced
+    iu32 qn = 0;     // queued matches
+    Ring2 R;
+    R.ri = R.rf = 0;
+    R.gp = in0;
+    R.bb = 0;
+    R.nb = 0;
+
+    // all lanes: top up the input rings and resolve the queued matches
+    auto memory_phase = [&]() {
+        // one round trip for the ring refill and for the first (up to) 16 bytes of every queued match whose source
+        // lies entirely before the first queued destination (nothing in the queue can have written it)
+        const iu32 pairs = state == ST_SYMBOLS ? (16 - R.rf) >> 1 : 0;
+        iu64 v[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) v[k] = load64u(R.gp + 8 * k); // unconditional: the buffer is padded
+        const iu32 g_first = qn ? (L.w(I2_Q) & 0xffffu) : 0u;
+        iu64 va[I2_QUEUE], vb[I2_QUEUE];
+        iu32 tk[I2_QUEUE];
+#pragma unroll
+        for (int q = 0; q < I2_QUEUE; q++) {
+            tk[q] = 0;
+            va[q] = vb[q] = 0;
+            if ((iu32)q < qn) {
+                const iu32 w0 = L.w(I2_Q + 4 * q), dist = L.w(I2_Q + 4 * q + 2);
+                const iu32 dst = w0 & 0xffffu, len = w0 >> 16;
+                const iu32 take = len < 16 ? len : 16;
+                if (dist >= 16 && dst - dist + ((take + 7) & ~7u) <= g_first) {
+                    va[q] = load64u(base + dst - dist);
+                    if (take > 8) vb[q] = load64u(base + dst - dist + 8);
+                    tk[q] = take;
                 }
-                const iu32 sym = e >> 4;
-                if (sym < 16) {
-                    lens[i++] = (uint8_t)sym;
+            }
+        }
+        wait_vm();
+        {
+            const iu32 wi = (R.ri + R.rf) & 15u;
+#pragma unroll
+            for (int k = 0; k < 8; k++)
+                if ((iu32)k < pairs) {
+                    L.w(I2_RING + 2 * ((wi + 2 * k) & 15u)) = (iu32)v[k];
+                    L.w(I2_RING + 2 * ((wi + 2 * k + 1) & 15u)) = (iu32)(v[k] >> 32);
+                }
+            R.rf += 2 * pairs;
+            R.gp += 8 * pairs;
+        }
+#pragma unroll
+        for (int q = 0; q < I2_QUEUE; q++) {
+            const iu32 n = tk[q];
+            if (n) {
+                const iu32 w0 = L.w(I2_Q + 4 * q);
+                const iu32 dst = w0 & 0xffffu, len = w0 >> 16;
+                if (n >= 8) store64u(base + dst, va[q]);
+                else
+                    for (iu32 k = 0; k < n; k++) base[dst + k] = (uint8_t)(va[q] >> (8 * k));
+                if (n == 16) store64u(base + dst + 8, vb[q]);
+                else if (n > 8)
+                    for (iu32 k = 0; k < n - 8; k++) base[dst + 8 + k] = (uint8_t)(vb[q] >> (8 * k));
+                L.w(I2_Q + 4 * q) = ((dst + n) & 0xffffu) | ((len - n) << 16); // what is left of it (usually nothing;
+                                                                                // a copy may end at byte 65536)
+            }
+        }
+        // The rest in order -- sources inside the queue, copies longer than 16 bytes, short periods -- one 8-byte
+        // step of every lane's first unfinished entry per round trip.
+        iu32 qi = 0;
+        for (;;) {
+            iu32 w0 = 0;
+            while (qi < qn) {
+                w0 = L.w(I2_Q + 4 * qi);
+                if (w0 >> 16) break;
+                qi++;
+            }
+            const bool on = qi < qn;
+            if (!__any(on)) break;
+            if (on) {
+                const iu32 dst = w0 & 0xffffu, len = w0 >> 16;
+                iu32 dist = L.w(I2_Q + 4 * qi + 2);
+                const iu32 n = len < 8 ? len : 8;
+                iu64 x = load64u(base + dst - dist);
+                wait_vm();
+                if (dist < 8) { // a period shorter than the step: replicate it, then continue a multiple of it back
+                    x &= (1ull << (8 * dist)) - 1ull;
+                    for (iu32 sh = 8 * dist; sh < 64; sh <<= 1) x |= x << sh;
+                    dist *= (7 + dist) / dist;
+                    L.w(I2_Q + 4 * qi + 2) = dist;
+                }
+                if (n == 8) store64u(base + dst, x);
+                else
+                    for (iu32 k = 0; k < n; k++) base[dst + k] = (uint8_t)(x >> (8 * k));
+                L.w(I2_Q + 4 * qi) = ((dst + n) & 0xffffu) | ((len - n) << 16);
+            }
+        }
+        qn = 0;
+    };
+
+    while (__any(state != ST_DONE)) {
+        if (state == ST_HEADER) {
+            // ---- block header and tables, read straight from the stream
+            BitReader br;
+            br.start(in0 + (bitpos >> 3));
+            br.refill();
+            br.drop((int)(bitpos & 7));
+            iu64 used = bitpos & 7; // bits taken from in0 + (bitpos >> 3)
+            auto take = [&](int n) -> iu32 {
+                br.refill();
+                used += (iu64)n;
+                return br.take(n);
+            };
+            last = take(1);
+            const iu32 type = take(2);
+            if (type == 0) { // stored
+                const int pad = (int)((8 - ((bitpos + 3) & 7)) & 7);
+                (void)take(pad);
+                const iu32 len = take(16), nlen = take(16);
+                const uint8_t *src = in0 + ((bitpos + 3 + (iu64)pad + 32) >> 3);
+                if ((len ^ 0xffffu) != nlen) err = INF_ERR_STORED;
+                else if (src + len > in_end || pos + len > out_len) err = INF_ERR_OVERRUN;
+                else {
+                    for (iu32 i = 0; i < len; i++) base[pos + i] = src[i];
+                    pos += len;
+                    bitpos = (iu64)(src + len - in0) * 8;
+                }
+                if (err || last) state = ST_DONE; // else: next header
+            } else if (type == 3) {
+                err = INF_ERR_BTYPE;
+                state = ST_DONE;
+            } else {
+                int nlit = 288, ndist = 32;
+                if (type == 1) {
+                    for (int i = 0; i < 144; i++) lens[i] = 8;
+                    for (int i = 144; i < 256; i++) lens[i] = 9;
+                    for (int i = 256; i < 280; i++) lens[i] = 7;
+                    for (int i = 280; i < 288; i++) lens[i] = 8;
+                    for (int i = 288; i < 320; i++) lens[i] = 5;
                 } else {
-                    iu32 rep, val = 0;
-                    if (sym == 16) {
-                        if (i == 0) {
+                    nlit = (int)take(5) + 257;
+                    ndist = (int)take(5) + 1;
+                    const int ncl = (int)take(4) + 4;
+                    if (nlit > 286 || ndist > 30) err = INF_ERR_CODELENS;
+                    if (!err) {
+                        for (int i = 0; i < 19; i++) lens[i] = 0;
+                        for (int i = 0; i < ncl; i++) lens[c_clen_order[i]] = (uint8_t)take(3);
+                        err = inf2_build(L, I2_LIT, 7, I2_LLIM, I2_LADJ, I2_LLONG, 0, lens, 19);
+                    }
+                    int i = 0;
+                    while (!err && i < nlit + ndist) {
+                        br.refill();
+                        const iu32 e = inf2_decode<7>(L, I2_LIT, I2_LLIM, I2_LADJ, I2_LLONG, 0, (iu32)br.bb);
+                        if (e == 0) {
                             err = INF_ERR_CODELENS;
                             break;
                         }
-                        val = lens[i - 1];
-                        rep = 3 + br.take(2);
-                    } else if (sym == 17) {
-                        rep = 3 + br.take(3);
-                    } else {
-                        rep = 11 + br.take(7);
+                        br.drop((int)(e & 15u));
+                        used += e & 15u;
+                        const iu32 sym = e >> 4;
+                        if (sym < 16) {
+                            lens[i++] = (uint8_t)sym;
+                        } else {
+                            iu32 rep, val = 0;
+                            if (sym == 16) {
+                                if (i == 0) {
+                                    err = INF_ERR_CODELENS;
+                                    break;
+                                }
+                                val = lens[i - 1];
+                                rep = 3 + take(2);
+                            } else if (sym == 17) {
+                                rep = 3 + take(3);
+                            } else {
+                                rep = 11 + take(7);
+                            }
+                            if (i + (int)rep > nlit + ndist) {
+                                err = INF_ERR_CODELENS;
+                                break;
+                            }
+                            while (rep--) lens[i++] = (uint8_t)val;
+                        }
                     }
-                    if (i + (int)rep > nlit + ndist) {
-                        err = INF_ERR_CODELENS;
-                        break;
-                    }
-                    while (rep--) lens[i++] = (uint8_t)val;
+                    if (!err && lens[256] == 0) err = INF_ERR_CODELENS;
                 }
-            }
-            if (err) break;
-            if (lens[256] == 0) { // no end-of-block code
-                err = INF_ERR_CODELENS;
-                break;
+                if (!err) err = inf2_build(L, I2_DIST, INF_ROOT_D, I2_DLIM, I2_DADJ, I2_DLONG, 0, lens + nlit, ndist);
+                if (!err) err = inf2_build(L, I2_LIT, INF_ROOT_L, I2_LLIM, I2_LADJ, I2_LLONG, I2_LLONG_HI, lens, nlit);
+                if (err) {
+                    state = ST_DONE;
+                } else {
+                    // the symbols start at bitpos + used: prime the ring from there
+                    const iu64 sp = (bitpos & ~7ull) + used;
+                    R.gp = in0 + (sp >> 3);
+                    R.ri = 0;
+#pragma unroll
+                    for (int k = 0; k < 8; k++) {
+                        const iu64 v = load64u(R.gp + 8 * k);
+                        L.w(I2_RING + 4 * k) = (iu32)v;
+                        L.w(I2_RING + 4 * k + 2) = (iu32)(v >> 32);
+                    }
+                    R.gp += 64;
+                    R.rf = 16;
+                    R.bb = 0;
+                    R.nb = 0;
+                    // first word, minus the bits before sp inside its first byte
+                    R.bb = (iu64)L.w(I2_RING) | ((iu64)L.w(I2_RING + 2) << 32);
+                    R.ri = 2;
+                    R.rf = 14;
+                    R.nb = 64 - (int)(sp & 7);
+                    R.bb >>= (sp & 7);
+                    state = ST_SYMBOLS;
+                }
             }
         }
-        if ((err = inf_build(L, L_DIST, INF_ROOT_D, sub_d, INF_SUB_D, lens + nlit, ndist))) break;
-        if ((err = inf_build(L, L_LIT, INF_ROOT_L, sub_l, INF_SUB_L, lens, nlit))) break;
-        // ---- symbols.  One flat loop: an iteration either decodes a symbol or moves up to 8 bytes of the
-        // pending match, so a lane in a long copy does not stall the 63 others for its whole length.
-        iu32 mlen = 0, mdist = 0;
+        wait_vm(); // nothing of the header's direct reads is in flight when the decode loop starts
+        // ---- symbols: every lane that has a block in progress decodes one symbol per iteration
         for (;;) {
-            if (mlen) {
-                const iu32 n = mlen < 8 ? mlen : 8;
-                // distance >= 17: the 8 bytes read were stored at least 9 positions back (at most 7 are pending)
-                const iu64 v = mdist <= 16 ? ow.ahead(mdist) : load64u(ow.base + ow.pos - mdist);
-                if (n == 8) ow.put8(v);
-                else ow.putn(v, n);
-                mlen -= n;
-                continue;
+            const bool sym_on = state == ST_SYMBOLS;
+            if (!__any(sym_on)) break;
+            if (__any(sym_on && (R.rf < 4 || qn == I2_QUEUE))) memory_phase();
+            if (!sym_on) continue;
+            if (R.nb <= 32) { // one more word from the ring (never empty here: at least 4 words at the top of the iteration)
+                R.bb |= (iu64)L.w(I2_RING + 2 * R.ri) << R.nb;
+                R.ri = (R.ri + 1) & 15u;
+                R.rf--;
+                R.nb += 32;
             }
-            if (br.ip > in_end + 32) { // garbage can decode for a long time: never read far past the payload
-                err = INF_ERR_OVERRUN;
-                break;
-            }
-            br.refill();
-            iu32 e = inf_decode(L, L_LIT, INF_ROOT_L, sub_l, br);
+            iu32 e = inf2_decode<INF_ROOT_L>(L, I2_LIT, I2_LLIM, I2_LADJ, I2_LLONG, I2_LLONG_HI, (iu32)R.bb);
             if (e == 0) {
                 err = INF_ERR_CODE;
-                break;
-            }
-            iu32 sym = e >> 4;
-            if (sym < 256) {
-                if (ow.pos >= out_len) {
-                    err = INF_ERR_OVERRUN;
-                    break;
-                }
-                ow.put(sym);
+                state = ST_DONE;
                 continue;
             }
-            if (sym == 256) break;
+            R.bb >>= (e & 15u);
+            R.nb -= (int)(e & 15u);
+            iu32 sym = e >> 4;
+            if (sym < 256) {
+                if (pos >= out_len) {
+                    err = INF_ERR_OVERRUN;
+                    state = ST_DONE;
+                    continue;
+                }
+                base[pos++] = (uint8_t)sym;
+                continue;
+            }
+            if (sym == 256) { // end of block: where the next header starts
+                const iu64 consumed = (iu64)(R.gp - in0) * 8 - 32ull * R.rf - (iu64)R.nb;
+                if (consumed > (iu64)B.in_len * 8) {
+                    err = INF_ERR_OVERRUN;
+                    state = ST_DONE;
+                    continue;
+                }
+                bitpos = consumed;
+                state = last ? ST_DONE : ST_HEADER;
+                continue;
+            }
             sym -= 257;
             if (sym >= 29) {
                 err = INF_ERR_CODE;
-                break;
+                state = ST_DONE;
+                continue;
             }
-            const iu32 len = c_len_base[sym] + br.take(c_len_extra[sym]);
-            br.refill();
-            e = inf_decode(L, L_DIST, INF_ROOT_D, sub_d, br);
+            const iu32 lt = s_len[sym];
+            const int xl = (int)(lt >> 16);
+            const iu32 len = (lt & 0xffffu) + ((iu32)R.bb & ((1u << xl) - 1u));
+            R.bb >>= xl;
+            R.nb -= xl;
+            if (R.nb <= 32) {
+                R.bb |= (iu64)L.w(I2_RING + 2 * R.ri) << R.nb;
+                R.ri = (R.ri + 1) & 15u;
+                R.rf--;
+                R.nb += 32;
+            }
+            e = inf2_decode<INF_ROOT_D>(L, I2_DIST, I2_DLIM, I2_DADJ, I2_DLONG, 0, (iu32)R.bb);
             if (e == 0 || (e >> 4) >= 30) {
                 err = INF_ERR_CODE;
-                break;
+                state = ST_DONE;
+                continue;
             }
+            R.bb >>= (e & 15u);
+            R.nb -= (int)(e & 15u);
             const iu32 ds = e >> 4;
-            const iu32 dist = c_dist_base[ds] + br.take(c_dist_extra[ds]);
-            if (dist > ow.pos) {
+            const iu32 dt = s_dist[ds];
+            const int xd = (int)(dt >> 16);
+            const iu32 dist = (dt & 0xffffu) + ((iu32)R.bb & ((1u << xd) - 1u));
+            R.bb >>= xd;
+            R.nb -= xd;
+            if (dist > pos) {
                 err = INF_ERR_DIST;
-                break;
+                state = ST_DONE;
+                continue;
             }
-            if (ow.pos + len > out_len) {
+            if (pos + len > out_len) {
                 err = INF_ERR_OVERRUN;
-                break;
+                state = ST_DONE;
+                continue;
             }
-            mlen = len;
-            mdist = dist;
+            L.w(I2_Q + 4 * qn) = pos | (len << 16);
+            L.w(I2_Q + 4 * qn + 2) = dist;
+            qn++;
+            pos += len;
         }
-        if (!err && br.byte_pos() > in_end) err = INF_ERR_OVERRUN;
     }
-    if (!err && ow.pos != out_len) err = INF_ERR_SIZE;
-    ow.flush();
-    status[b] = err;
-    if (err) atomicOr(any_error, 1);
+    memory_phase(); // what is still queued
+    if (have) {
+        if (!err && pos != out_len) err = INF_ERR_SIZE;
+        status[b] = err;
+        if (err) atomicOr(any_error, 1);
+    }
 }
-
 
 // =================================================================================================
 // BAM records on the device: the inflated bytes of one target's region -> the SoA batch of pjb_batch.

@@ -59,6 +59,15 @@ def test_inflate_matches_zlib(ctx, name, mode):
     assert ctx.inflate_bgzf(comp) == data
 
 
+def test_full_64k_blocks(ctx):
+    """Blocks of exactly 65536 inflated bytes (the BGZF maximum; match destinations reach offset 65536)."""
+    rng = np.random.default_rng(9)
+    data = bytes(70000) + (rng.integers(0, 3, 200000, dtype=np.uint8) + 65).tobytes() + b"ACGT" * 40000
+    for level in (1, 6):
+        comp = bgzf(data, level, block=65536)
+        assert ctx.inflate_bgzf(comp) == data
+
+
 def test_many_blocks_and_eof_markers(ctx):
     rng = np.random.default_rng(5)
     parts, comp = [], bytearray()
