@@ -41,6 +41,7 @@ public:
 
     const JunctionList& getJunctions() const { return junctionList; }
     size_t size() const { return distinctJunctions.size(); }
+    void reserve(size_t n);  // room for n junctions (list and intron map) before a run of addJunction / append
     bool empty() const { return junctionList.empty(); }
 
     void setRefs(std::shared_ptr<bam::RefSeqPtrList> r) { refs = r; }

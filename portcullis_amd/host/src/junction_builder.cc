@@ -431,8 +431,14 @@ void JunctionBuilder::findJunctions() {
                 const int visible = deviceCount.get();
                 nd = std::max(1, std::min(ndevWanted > 0 ? ndevWanted : visible, std::min(visible, nthreads)));
             }
-            for (int d = 0; d < nd; d++)
-                deviceThreads.emplace_back(new DeviceThread(d, orientation, strandSpecific, lens, deviceCount));
+            // two contexts (device threads, streams) per GPU: while one target's kernels run, the other target's
+            // file bytes and genome cross PCIe
+            int per = 2;
+            if (const char* e = getenv("PORTCULLIS_CTX_PER_GPU")) per = std::max(1, atoi(e));
+            per = std::max(1, std::min(per, nthreads / nd));
+            for (int k = 0; k < per; k++)
+                for (int d = 0; d < nd; d++)
+                    deviceThreads.emplace_back(new DeviceThread(d, orientation, strandSpecific, lens, deviceCount));
         }
         return *deviceThreads[(size_t)w % deviceThreads.size()];
     };
@@ -475,6 +481,11 @@ void JunctionBuilder::findJunctions() {
          << "\t" << std::right << std::setw(12) << "unspliced"
          << "\t" << std::right << std::setw(12) << "spliced"
          << "\t" << std::right << std::setw(12) << "total" << endl;
+    {
+        size_t total = 0;
+        for (auto& res : results) total += res.js.getJunctions().size();
+        junctionSystem.reserve(total);
+    }
     for (auto& res : results) {
         junctionSystem.append(res.js);
         unsplicedCount += res.unsplicedCount;
@@ -561,7 +572,9 @@ int JunctionBuilder::main(int argc, char* argv[]) {
     }
     WallTimer timer;
     cout << "Running portcullis in junction builder mode" << endl << "------------------------------------------" << endl << endl;
-    JunctionBuilder jb(prepDir, output);
+    // deliberately never destroyed: the program ends right after process() and freeing every junction object
+    // one by one would only delay that
+    JunctionBuilder& jb = *new JunctionBuilder(prepDir, output);
     jb.setThreads((uint16_t)std::max(1, threads));
     jb.setExtra(extra);
     jb.setSeparate(separate);

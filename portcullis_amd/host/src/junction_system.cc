@@ -116,7 +116,17 @@ void JunctionSystem::calcJunctionStats() {
     }
 }
 
-void JunctionSystem::sort() { std::sort(junctionList.begin(), junctionList.end(), JunctionComparator()); }
+void JunctionSystem::sort() {
+    // the device returns every target's junctions in (start, end) order and targets are appended in index order, so
+    // the merged list is usually sorted already: one linear check instead of n log n pointer-chasing compares
+    if (!std::is_sorted(junctionList.begin(), junctionList.end(), JunctionComparator()))
+        std::sort(junctionList.begin(), junctionList.end(), JunctionComparator());
+}
+
+void JunctionSystem::reserve(size_t n) {
+    junctionList.reserve(n);
+    distinctJunctions.reserve(n);
+}
 
 void JunctionSystem::index() {
     for (size_t i = 0; i < this->size() && i < junctionList.size(); i++) junctionList[i]->setId((uint32_t)i);
