@@ -237,7 +237,9 @@ int pjb_inflate_bgzf(pjb_ctx* ctx, const uint8_t* comp, int64_t comp_bytes, uint
  * pjb_submit_batch of the same alignments would be.  Replaces the reader loop of
  * JunctionBuilder::findJuncs (src/junction_builder.cc:322-343: BamReader::setRegion / next /
  * BamAlignment::init, lib/src/bam_reader.cc:78-146, lib/src/bam_alignment.cc:71-100) for the whole target.
- *   comp, comp_bytes : consecutive whole BGZF blocks (host memory), from the block that holds the target's
+ *   comp, comp_bytes : consecutive whole BGZF blocks (host memory; page-locked memory from pjb_host_alloc is
+ *                      DMA'd directly, anything else goes through the context's staging buffers), from the
+ *                      block that holds the target's
  *                      first record through (at least) the block that holds its last one;
  *   first_uoffset    : offset of that first record inside the first block's inflated bytes (the low
  *                      16 bits of the index's virtual offset).

@@ -1095,7 +1095,14 @@ extern "C" int pjb_submit_bam(pjb_ctx *c, int32_t tid, const uint8_t *comp, int6
     hipStream_t st = c->stream;
     if ((rc = ensure(c, c->b_inf_comp, (size_t)comp_bytes + INF_PAD))) return rc;
     if ((rc = ensure(c, c->b_inf_out, (size_t)total + 64))) return rc;
-    if ((rc = upload_staged(c, c->b_inf_comp.p, comp, (size_t)comp_bytes))) return rc;
+    {
+        // page-locked input (pjb_host_alloc): one DMA, no staging copy
+        hipPointerAttribute_t at;
+        const bool pinned = hipPointerGetAttributes(&at, comp) == hipSuccess && at.type == hipMemoryTypeHost;
+        if (!pinned) (void)hipGetLastError();
+        if (pinned) HIP_TRY(c, hipMemcpyAsync(c->b_inf_comp.p, comp, (size_t)comp_bytes, hipMemcpyHostToDevice, st));
+        else if ((rc = upload_staged(c, c->b_inf_comp.p, comp, (size_t)comp_bytes))) return rc;
+    }
     HIP_TRY(c, hipMemsetAsync((uint8_t *)c->b_inf_comp.p + comp_bytes, 0, INF_PAD, st));
     HIP_TRY(c, hipMemsetAsync((uint8_t *)c->b_inf_out.p + total, 0, 64, st));
     if (prof) (void)hipStreamSynchronize(st);

@@ -121,6 +121,10 @@ public:
     // the first record inside the first block's inflated bytes.  Feeds pjb_submit_bam (device-side ingest).
     // Returns nullptr if the target has no records.
     uint8_t* readRegionBytes(int32_t tid, int nthreads, size_t& bytes, uint32_t& firstU);
+    // The same in two steps, for callers that bring their own (e.g. page-locked) buffer: where the bytes are ...
+    bool regionSpan(int32_t tid, uint64_t& fileOff, size_t& bytes, uint32_t& firstU);
+    // ... and `bytes` bytes from `fileOff` into dst with `nthreads` parallel preads.
+    void readSpan(uint64_t fileOff, size_t bytes, uint8_t* dst, int nthreads);
 };
 
 }  // namespace bam

@@ -488,11 +488,12 @@ void parallelFor(int nthreads, size_t n, F f) {  // f(thread, begin, end) over c
 
 }  // namespace
 
-uint8_t* BamReader::readRegionBytes(int32_t tid, int nthreads, size_t& bytes, uint32_t& firstU) {
+bool BamReader::regionSpan(int32_t tid, uint64_t& fileOff, size_t& bytes, uint32_t& firstU) {
     bytes = 0;
     firstU = 0;
-    if (tid < 0 || (size_t)tid >= targets.size()) throw BamException("readRegionBytes: target out of range");
-    if (firstOffset[(size_t)tid] == ~0ull) return nullptr;
+    fileOff = 0;
+    if (tid < 0 || (size_t)tid >= targets.size()) throw BamException("regionSpan: target out of range");
+    if (firstOffset[(size_t)tid] == ~0ull) return false;
     const int fd = ::open(bamFile.c_str(), O_RDONLY);
     if (fd < 0) throw BamException("Could not open BAM file: " + bamFile);
     struct Closer {
@@ -516,9 +517,20 @@ uint8_t* BamReader::readRegionBytes(int32_t tid, int nthreads, size_t& bytes, ui
             end = std::min<uint64_t>(fileSize, endCoff + (uint64_t)le16(h + 16) + 1);
     }
     const uint64_t lo = start >> 16;
-    if (end <= lo) return nullptr;
-    const size_t want = (size_t)(end - lo);
-    uint8_t* buf = (uint8_t*)bigAlloc(want + 64);
+    if (end <= lo) return false;
+    fileOff = lo;
+    bytes = (size_t)(end - lo);
+    firstU = (uint32_t)(start & 0xffff);
+    return true;
+}
+
+void BamReader::readSpan(uint64_t fileOff, size_t want, uint8_t* buf, int nthreads) {
+    const int fd = ::open(bamFile.c_str(), O_RDONLY);
+    if (fd < 0) throw BamException("Could not open BAM file: " + bamFile);
+    struct Closer {
+        int fd;
+        ~Closer() { ::close(fd); }
+    } closer{fd};
     nthreads = std::max(1, nthreads);
     const size_t nsl = std::max<size_t>(1, std::min<size_t>((size_t)nthreads, want >> 22));
     std::atomic<bool> bad(false);
@@ -526,7 +538,7 @@ uint8_t* BamReader::readRegionBytes(int32_t tid, int nthreads, size_t& bytes, ui
         const size_t per = (want + nsl - 1) / nsl, a = std::min(want, per * t), b = std::min(want, a + per);
         size_t got = 0;
         while (a + got < b) {
-            const ssize_t r = pread(fd, buf + a + got, b - a - got, (off_t)(lo + a + got));
+            const ssize_t r = pread(fd, buf + a + got, b - a - got, (off_t)(fileOff + a + got));
             if (r <= 0) {
                 bad = true;
                 return;
@@ -541,12 +553,19 @@ uint8_t* BamReader::readRegionBytes(int32_t tid, int nthreads, size_t& bytes, ui
         for (size_t t = 0; t < nsl; t++) th.emplace_back(readSlice, t);
         for (auto& x : th) x.join();
     }
-    if (bad) {
+    if (bad) throw BamException("Could not read BAM file: " + bamFile);
+}
+
+uint8_t* BamReader::readRegionBytes(int32_t tid, int nthreads, size_t& bytes, uint32_t& firstU) {
+    uint64_t lo = 0;
+    if (!regionSpan(tid, lo, bytes, firstU)) return nullptr;
+    uint8_t* buf = (uint8_t*)bigAlloc(bytes + 64);
+    try {
+        readSpan(lo, bytes, buf, nthreads);
+    } catch (...) {
         bigFree(buf);
-        throw BamException("Could not read BAM file: " + bamFile);
+        throw;
     }
-    bytes = want;
-    firstU = (uint32_t)(start & 0xffff);
     return buf;
 }
 

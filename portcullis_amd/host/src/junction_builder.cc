@@ -147,6 +147,59 @@ void JunctionBuilder::process() {
 // genome uploads, batches (of several contigs at once, interleaved) and contig finishes.  Keeping a
 // single context per GPU avoids the runtime-lock contention of one context per worker.
 // ---------------------------------------------------------------------------------------------
+// A few page-locked buffers for the file bytes of large inputs (device ingest): a worker preads straight into one,
+// the device thread DMAs from it without the staging copy and hands it back.  Allocated on first use and kept.
+class PinnedPool {
+    struct Buf {
+        uint8_t* p = nullptr;
+        size_t cap = 0;
+        bool busy = false;
+    };
+    std::mutex mu;
+    std::condition_variable cv;
+    std::vector<Buf> bufs;
+
+public:
+    explicit PinnedPool(size_t n) : bufs(n) {}
+    ~PinnedPool() {
+        for (auto& b : bufs) pjb_host_free(b.p);
+    }
+    uint8_t* acquire(size_t bytes) {
+        Buf* mine = nullptr;
+        {
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&] {
+                for (auto& b : bufs)
+                    if (!b.busy) return true;
+                return false;
+            });
+            for (auto& b : bufs)  // prefer one that is large enough already
+                if (!b.busy && b.cap >= bytes) mine = &b;
+            if (!mine)
+                for (auto& b : bufs)
+                    if (!b.busy) mine = &b;
+            mine->busy = true;
+        }
+        if (mine->cap < bytes) {
+            pjb_host_free(mine->p);
+            mine->cap = bytes + bytes / 8;
+            mine->p = (uint8_t*)pjb_host_alloc(mine->cap);
+            if (!mine->p) {
+                mine->cap = 0;
+                release(nullptr, mine);
+                return nullptr;
+            }
+        }
+        return mine->p;
+    }
+    void release(uint8_t* p, void* which = nullptr) {
+        std::lock_guard<std::mutex> lk(mu);
+        for (auto& b : bufs)
+            if ((p && b.p == p) || (which && &b == which)) b.busy = false;
+        cv.notify_all();
+    }
+};
+
 struct ContigDone {
     pjb_region_result rr;
     std::vector<pjb_junction_row> rows;
@@ -166,6 +219,7 @@ public:
         uint8_t* bamBytes = nullptr;
         size_t bamSize = 0;
         uint32_t bamFirst = 0;
+        PinnedPool* bamPool = nullptr;  // where bamBytes goes back to (nullptr: bigFree)
         std::promise<int64_t>* bamDone = nullptr;
     };
 
@@ -225,7 +279,8 @@ private:
                 int64_t n = 0;
                 if (err.empty() && pjb_submit_bam(ctx, c.tid, c.bamBytes, (int64_t)c.bamSize, (int32_t)c.bamFirst, &n) != PJB_OK)
                     failed[c.tid] = std::string("pjb_submit_bam: ") + pjb_last_error(ctx);
-                bam::bigFree(c.bamBytes);
+                if (c.bamPool) c.bamPool->release(c.bamBytes);
+                else bam::bigFree(c.bamBytes);
                 c.bamDone->set_value(n);
             } else if (c.kind == Cmd::FINISH) {
                 ContigDone d;
@@ -304,7 +359,20 @@ void JunctionBuilder::findJuncs(DeviceThread& device, BamReader& reader, GenomeM
                 // the device inflates and parses: this thread only moves the target's file bytes
                 size_t nb = 0;
                 uint32_t firstU = 0;
-                uint8_t* bytes = reader.readRegionBytes(seq, innerThreads, nb, firstU);
+                uint64_t fileOff = 0;
+                uint8_t* bytes = nullptr;
+                PinnedPool* pool = nullptr;
+                if (reader.regionSpan(seq, fileOff, nb, firstU)) {
+                    if (pinnedPool && nb >= ((size_t)64 << 20) && (bytes = pinnedPool->acquire(nb + 64)) != nullptr) pool = pinnedPool.get();
+                    if (!bytes) bytes = (uint8_t*)bam::bigAlloc(nb + 64);
+                    try {
+                        reader.readSpan(fileOff, nb, bytes, innerThreads);
+                    } catch (...) {
+                        if (pool) pool->release(bytes);
+                        else bam::bigFree(bytes);
+                        throw;
+                    }
+                }
                 if (bytes) {
                     std::promise<int64_t> got;
                     std::future<int64_t> f = got.get_future();
@@ -314,6 +382,7 @@ void JunctionBuilder::findJuncs(DeviceThread& device, BamReader& reader, GenomeM
                     c.bamBytes = bytes;
                     c.bamSize = nb;
                     c.bamFirst = firstU;
+                    c.bamPool = pool;
                     c.bamDone = &got;
                     device.push(std::move(c));
                     any = f.get() > 0;
@@ -419,6 +488,13 @@ void JunctionBuilder::findJunctions() {
     std::string firstError;
     std::vector<int32_t> lens;
     for (auto& r : *refs) lens.push_back(r->length);
+    // large inputs: page-locked buffers for the file bytes (allocating them costs ~0.15 s per GB once, so small runs
+    // keep the pageable path whose staging copy is cheaper than that)
+    pinnedPool.reset();
+    if (deviceIngest) {
+        struct stat bst;
+        if (stat(prepData.getSortedBamFilePath().c_str(), &bst) == 0 && (uint64_t)bst.st_size >= (8ull << 30)) pinnedPool.reset(new PinnedPool(3));
+    }
     // one device thread per GPU in use; decode workers are assigned round robin
     const int ndevWanted = devices > 0 ? devices : 0;
     std::vector<std::unique_ptr<DeviceThread>> deviceThreads;

@@ -7,7 +7,9 @@
 #include <fstream>
 #include <thread>
 #include <iostream>
+#include <fcntl.h>
 #include <sys/stat.h>
+#include <unistd.h>
 
 #include "../../../include/portcullis_amd.h"
 
@@ -214,6 +216,43 @@ std::vector<std::string> formatSlices(size_t n, size_t bytesPerItem, F fn) {
     }
     return parts;
 }
+
+// the parts, concatenated, as the content of `path`; large outputs are written by one thread per part (pwrite)
+void writeParts(const std::string& path, const std::vector<std::string>& parts) {
+    size_t total = 0;
+    for (const auto& p : parts) total += p.size();
+    const int fd = ::open(path.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0666);
+    if (fd < 0) throw portcullis::JunctionException("Could not open output file: " + path);
+    bool ok = true;
+    auto put = [&](const std::string& p, size_t at) {
+        size_t done = 0;
+        while (done < p.size()) {
+            const ssize_t w = pwrite(fd, p.data() + done, p.size() - done, (off_t)(at + done));
+            if (w <= 0) {
+                ok = false;
+                return;
+            }
+            done += (size_t)w;
+        }
+    };
+    if (total < ((size_t)16 << 20)) {
+        size_t at = 0;
+        for (const auto& p : parts) {
+            put(p, at);
+            at += p.size();
+        }
+    } else {
+        std::vector<std::thread> th;
+        size_t at = 0;
+        for (const auto& p : parts) {
+            th.emplace_back(put, std::cref(p), at);
+            at += p.size();
+        }
+        for (auto& x : th) x.join();
+    }
+    ::close(fd);
+    if (!ok) throw portcullis::JunctionException("Could not write output file: " + path);
+}
 }  // namespace
 
 // junction_system.cc:336-383
@@ -236,10 +275,9 @@ void JunctionSystem::saveAll(const std::string& outputPrefix, const std::string&
             junctionList[i]->appendTabRow(out);
             out.push_back('\n');
         });
-        std::ofstream f(tabPath.c_str(), std::ios::binary);
-        f.write(head.data(), (std::streamsize)head.size());
-        for (const std::string& p : parts) f.write(p.data(), (std::streamsize)p.size());
-        f.put('\n');
+        parts.insert(parts.begin(), head);
+        parts.push_back("\n");
+        writeParts(tabPath, parts);
     }
     cout << "done." << endl;
     if (outputExonGFF) {
@@ -291,9 +329,8 @@ void JunctionSystem::outputBED(const std::string& path, CanonicalSS type, const 
         const JunctionPtr& j = junctionList[i];
         if (type == CanonicalSS::ALL || j->getSpliceSiteType() == type) j->appendBedRow(o, prefix, bedscore);
     });
-    std::ofstream f(path.c_str(), std::ios::binary);
-    f.write(out.data(), (std::streamsize)out.size());
-    for (const std::string& p : parts) f.write(p.data(), (std::streamsize)p.size());
+    parts.insert(parts.begin(), out);
+    writeParts(path, parts);
 }
 
 void JunctionSystem::outputBED(std::ostream& strm, CanonicalSS type, const std::string& prefix, bool bedscore) {
