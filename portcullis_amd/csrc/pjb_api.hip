@@ -261,15 +261,6 @@ int run_scan(pjb_ctx *c, const char *tag, F f, G g, u64 n, u64 *d_total) {
     return PJB_OK;
 }
 
-struct HistFn {
-    const u32 *h;
-    __device__ u64 operator()(u64 i) const { return h[i]; }
-};
-struct HistSink {
-    u32 *o;
-    __device__ void operator()(u64 i, u64, u64 ex) const { o[i] = (u32)ex; }
-};
-
 void *slab_alloc(pjb_ctx *c, OpenContig &oc, size_t bytes) {
     bytes = (std::max<size_t>(bytes, 16) + 255) & ~(size_t)255;
     for (auto &s : oc.slabs)
