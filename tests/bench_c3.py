@@ -7,7 +7,7 @@ Not the driver's bench (bench.py measures configs[1], the configuration the metr
 this shows the same hot path at the 200 M-read scale, every contig's records resident in HBM.
 One step = submit + finish every contig on one context + collect the merged row table.
 
-    python tools/bench_c3.py [--reads 200000000] [--junctions 250000] [--steps 3] [--check-contigs 1]
+    python tests/bench_c3.py [--reads 200000000] [--junctions 250000] [--steps 3] [--check-contigs 1]
 
 Prints one JSON line.  --check-contigs K re-runs the first K contigs through the CPU oracle and
 compares the device rows (bit-exact integers, entropy 1e-6).
@@ -18,7 +18,7 @@ import os
 import sys
 import time
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))  # repository root (this file lives in tests/: it checks against the oracle)
 # chr1..22, X, Y, M
 GRCH38 = [248956422, 242193529, 198295559, 190214555, 181538259, 170805979, 159345973, 145138636, 138394717, 133797422,
           135086622, 133275309, 114364328, 107043718, 101991189, 90338345, 83257441, 80373285, 58617616, 64444167,
@@ -94,7 +94,7 @@ def main():
 
     checked = None
     if args.check_contigs > 0:
-        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
         from oracle import oracle as orc
         from parity import assert_rows_equal, region_equal
 

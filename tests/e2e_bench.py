@@ -3,7 +3,7 @@
 -> H2D -> HIP pipeline -> .tab/.bed, through the portcullis_amd program, checked byte for byte
 against the CPU oracle's .tab for the same records.
 
-    python tools/e2e_bench.py --config C2 --threads 8 [--workdir /tmp/e2e] [--keep]
+    python tests/e2e_bench.py --config C2 --threads 8 [--workdir /tmp/e2e] [--keep]
 
 Prints one JSON line with wall-clock reads/s.  Reference points for the same stage (SURVEY.md
 section 6, measured with the real reference during the survey): 0.37-0.39 M reads/s per thread,
@@ -17,9 +17,9 @@ import subprocess
 import sys
 import time
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))  # repository root (this file lives in tests/: it checks against the oracle)
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 
 def dump_contig(d, name, data):

@@ -139,7 +139,7 @@ def test_e2e_synthetic_parallel_decode(tmp_path):
     inflate + parallel transcode, bam_reader.cc decodeRegionParallel) must give the oracle's .tab."""
     import json
     import sys
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "e2e_bench.py"), "--config", "C2-small", "--threads", "4",
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "e2e_bench.py"), "--config", "C2-small", "--threads", "4",
                         "--workdir", str(tmp_path / "e2e"), "--repeat", "1"], capture_output=True, text=True, timeout=900,
                        env=dict(os.environ, PORTCULLIS_INGEST="host"))
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
@@ -150,7 +150,7 @@ def test_e2e_synthetic_parallel_decode(tmp_path):
 def test_e2e_synthetic_multi_contig(tmp_path):
     import json
     import sys
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "e2e_bench.py"), "--config", "C2-tiny", "--threads", "6",
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "e2e_bench.py"), "--config", "C2-tiny", "--threads", "6",
                         "--contigs", "3", "--workdir", str(tmp_path / "e2e"), "--repeat", "1"], capture_output=True, text=True, timeout=900,
                        env=dict(os.environ, PORTCULLIS_INGEST="host"))
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
@@ -163,7 +163,7 @@ def _e2e(tmp_path, *args):
     import sys
     env = dict(os.environ)
     env.setdefault("PORTCULLIS_INGEST", "host")
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "e2e_bench.py"), "--workdir", str(tmp_path / "e2e"),
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "e2e_bench.py"), "--workdir", str(tmp_path / "e2e"),
                         "--repeat", "1", *args], capture_output=True, text=True, timeout=1200, env=env)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
     return json.loads(p.stdout.strip().split("\n")[-1])

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Throughput of the device-side BGZF inflate on a synthetic prepared BAM (run under gpurun):
-builds the C2 BAM with tools/e2e_bench.py, inflates it through pjb_inflate_bgzf in chunks of whole
+builds the C2 BAM with tests/e2e_bench.py, inflates it through pjb_inflate_bgzf in chunks of whole
 blocks and reports the kernel rate (HIP events) beside single-thread zlib on the same bytes.
 
     python tools/bench_inflate.py [--config C2] [--chunk-mb 256]
@@ -32,7 +32,7 @@ def main():
     ap.add_argument("--chunk-mb", type=int, default=256)
     ap.add_argument("--workdir", default="/tmp/pjb_inflate")
     args = ap.parse_args()
-    e2e = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "e2e_bench.py"), "--config", args.config, "--threads", "16",
+    e2e = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "e2e_bench.py"), "--config", args.config, "--threads", "16",
                           "--workdir", args.workdir, "--keep", "--no-oracle", "--repeat", "2"], capture_output=True, text=True)
     if e2e.returncode != 0:
         print(e2e.stdout[-2000:], e2e.stderr[-2000:])

@@ -5,7 +5,7 @@
 CFG=${1:-C2}; NC=${2:-1}; REP=${3:-3}
 cd $GRAFT_REPO_ROOT
 cat /sys/fs/cgroup/memory.max 2>/dev/null | sed 's/^/memory.max /'
-PORTCULLIS_INGEST=host python tools/e2e_bench.py --config $CFG --contigs $NC --threads 16 --workdir /tmp/e2e --keep --no-oracle --repeat $REP > gpurun_out/e2e_host.json 2> gpurun_out/e2e_host.err || { tail -5 gpurun_out/e2e_host.err; exit 1; }
+PORTCULLIS_INGEST=host python tests/e2e_bench.py --config $CFG --contigs $NC --threads 16 --workdir /tmp/e2e --keep --no-oracle --repeat $REP > gpurun_out/e2e_host.json 2> gpurun_out/e2e_host.err || { tail -5 gpurun_out/e2e_host.err; exit 1; }
 rm -rf /tmp/e2e/contig*   # the SoA dumps are no longer needed
 ls -la /tmp/e2e/prep | tail -4
 for i in $(seq $REP); do
