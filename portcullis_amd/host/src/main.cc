@@ -12,26 +12,27 @@
 
 int main(int argc, char* argv[]) {
     // exit codes as in src/portcullis.cc:497-515 of the reference
+    int rc = 0;
     try {
         if (argc < 2 || strcmp(argv[1], "junc") != 0) {
             std::cerr << "Usage: portcullis_amd junc [options] <prep_data_dir>" << std::endl;
             return 1;
         }
         portcullis::JunctionSystem::version = PORTCULLIS_AMD_VERSION;
-        const int rc = portcullis::JunctionBuilder::main(argc - 1, argv + 1);
-        // every output file is written and closed: leave without unloading the HIP runtime and walking the
-        // heap (0.15-0.2 s at process exit)
-        std::cout.flush();
-        std::cerr.flush();
-        _exit(rc);
+        rc = portcullis::JunctionBuilder::main(argc - 1, argv + 1);
     } catch (const portcullis::PortcullisException& e) {
         std::cerr << "Error: " << e.what() << std::endl;
-        return 4;
+        rc = 4;
     } catch (const std::exception& e) {
         std::cerr << "Error: " << e.what() << std::endl;
-        return 5;
+        rc = 5;
     } catch (...) {
         std::cerr << "Error: Exception of unknown type!" << std::endl;
-        return 7;
+        rc = 7;
     }
+    // every output file is written and closed: leave without unloading the HIP runtime (which may still be starting
+    // on its own thread after an early error) and without walking the heap (0.15-0.2 s at process exit)
+    std::cout.flush();
+    std::cerr.flush();
+    _exit(rc);
 }
