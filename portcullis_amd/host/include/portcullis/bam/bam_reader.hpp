@@ -77,6 +77,7 @@ class BamReader {
     std::string headerText;
     std::vector<RefSeq> targets;
     std::vector<uint64_t> firstOffset;  // per target: virtual offset of its first record, ~0 = none
+    std::vector<uint64_t> lastOffset;   // per target: largest chunk end in the index (just past its last record)
     std::vector<std::vector<uint64_t>> restart;  // per target: sorted virtual offsets the index names (all are record starts)
     bool indexLoaded = false;
     int32_t regionTid = -1;

@@ -225,13 +225,14 @@ void BamReader::loadIndex(bool useCsi) {
     const uint32_t n_ref = le32(&buf[o]);
     o += 4;
     firstOffset.assign(targets.size(), ~0ull);
+    lastOffset.assign(targets.size(), 0ull);
     restart.assign(targets.size(), std::vector<uint64_t>());
     for (uint32_t r = 0; r < n_ref; r++) {
         std::vector<uint64_t> pts;
         if (o + 4 > buf.size()) throw BamException("Truncated BAM index");
         const uint32_t n_bin = le32(&buf[o]);
         o += 4;
-        uint64_t first = ~0ull;
+        uint64_t first = ~0ull, last = 0;
         for (uint32_t b = 0; b < n_bin; b++) {
             if (o + (csi ? 16 : 8) > buf.size()) throw BamException("Truncated BAM index");
             const uint32_t bin = le32(&buf[o]);
@@ -244,6 +245,7 @@ void BamReader::loadIndex(bool useCsi) {
                 for (uint32_t c = 0; c < n_chunk; c++) {
                     const uint64_t v = le64(&buf[o + 16 * c]);
                     first = std::min(first, v);
+                    last = std::max(last, le64(&buf[o + 16 * c + 8]));  // chunk end: just past the chunk's last record
                     pts.push_back(v);
                 }
             o += 16ull * n_chunk;
@@ -261,6 +263,7 @@ void BamReader::loadIndex(bool useCsi) {
         }
         if (r < firstOffset.size()) {
             firstOffset[r] = first;
+            lastOffset[r] = last;
             std::sort(pts.begin(), pts.end());
             pts.erase(std::unique(pts.begin(), pts.end()), pts.end());
             restart[r] = std::move(pts);
@@ -507,8 +510,10 @@ bool BamReader::regionSpan(int32_t tid, uint64_t& fileOff, size_t& bytes, uint32
     uint64_t endCoff = fileSize;
     for (uint64_t fo : firstOffset)
         if (fo != ~0ull && fo > start) endCoff = std::min<uint64_t>(endCoff, fo >> 16);
+    // the index also says where the target's last chunk ends (unmapped reads may follow the last target for gigabytes)
+    if (lastOffset[(size_t)tid] > start) endCoff = std::min<uint64_t>(endCoff, lastOffset[(size_t)tid] >> 16);
     uint64_t end = fileSize;
-    if (endCoff < fileSize) {  // the block in which the next target starts may hold this target's tail: include it
+    if (endCoff < fileSize) {  // the block in which the next target starts / the last chunk ends may hold the tail: include it
         uint8_t h[18];
         if (pread(fd, h, 18, (off_t)endCoff) != 18 || h[0] != 31 || h[1] != 139 || h[2] != 8 || !(h[3] & 4) || le16(h + 10) != 6 ||
             h[12] != 'B' || h[13] != 'C')

@@ -85,7 +85,7 @@ def test_micro_fixtures_cli(tmp_path, orc, spombe30k):
     assert len(exp["rows"]) == 7
 
 
-def multi_contig(tmp_path, seeds, n_reads=1500, block_size=0xFF00):
+def multi_contig(tmp_path, seeds, n_reads=1500, block_size=0xFF00, n_unmapped=1):
     refs, contigs, reads = [], [], []
     for tid, seed in enumerate(seeds):
         if seed is None:  # contig without alignments
@@ -102,7 +102,8 @@ def multi_contig(tmp_path, seeds, n_reads=1500, block_size=0xFF00):
         contigs.append((f"chr{tid + 1}", genome))
         reads += rr
     # unplaced unmapped reads at the end of the file are never visited
-    reads.append(dict(tid=-1, pos=-1, cigar="", seq="ACGTACGT", flag=4, mapq=0))
+    for k in range(n_unmapped):
+        reads.append(dict(tid=-1, pos=-1, cigar="", seq="ACGTACGT" * (1 + k % 9), flag=4, mapq=0, name=f"unmapped{k}"))
     return make_prep_dir(str(tmp_path / "prep"), refs, contigs, reads, block_size=block_size)
 
 
@@ -201,6 +202,13 @@ def test_device_ingest_multi_contig(tmp_path, orc, block_size, threads):
     device (pjb_submit_bam): targets without reads, records straddling tiny BGZF blocks, several workers."""
     prep = multi_contig(tmp_path, [51, None, 52, 53], block_size=block_size)
     check(prep, tmp_path, orc, "FR", threads=threads, extra_opts=("--ingest", "device"))
+
+
+@pytest.mark.parametrize("ingest", ["device", "host"])
+def test_unmapped_tail(tmp_path, orc, ingest):
+    """Thousands of unplaced reads after the last target: the index's last chunk end bounds what is read."""
+    prep = multi_contig(tmp_path, [71, 72], block_size=3000, n_unmapped=4000)
+    check(prep, tmp_path, orc, "FR", threads=2, extra_opts=("--ingest", ingest))
 
 
 def test_device_ingest_csi_and_micro(tmp_path, orc, spombe30k):
