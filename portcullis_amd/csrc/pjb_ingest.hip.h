@@ -55,6 +55,26 @@ __device__ __forceinline__ iu64 load64u(const uint8_t *p) {
     return v;
 }
 __device__ __forceinline__ void store64u(uint8_t *p, iu64 v) { __builtin_memcpy(p, &v, 8); }
+// the low n (0..8) bytes of v in at most three stores (4 + 2 + 1) instead of n byte stores
+__device__ __forceinline__ void store_low(uint8_t *p, iu64 v, iu32 n) {
+    if (n >= 8) {
+        store64u(p, v);
+        return;
+    }
+    if (n & 4u) {
+        const iu32 w = (iu32)v;
+        __builtin_memcpy(p, &w, 4);
+        p += 4;
+        v >>= 32;
+    }
+    if (n & 2u) {
+        const unsigned short h = (unsigned short)v;
+        __builtin_memcpy(p, &h, 2);
+        p += 2;
+        v >>= 16;
+    }
+    if (n & 1u) *p = (uint8_t)v;
+}
 
 // LSB-first bit reader.  Input is fetched 8 bytes at a time, two words ahead of the bit buffer, so
 // the load a refill depends on was issued at least 64 input bits earlier.
@@ -120,6 +140,10 @@ __device__ __forceinline__ iu32 bitrev16(iu32 v, int len) { return __brev(v) >> 
 // bytes on the 10 M-read BAM (2.1 GB in 50 ms), 100x one zlib thread.
 // =================================================================================================
 constexpr int I2_QUEUE = 16;                    // queued matches per lane
+#ifndef PJB_I2_LITS
+#define PJB_I2_LITS 3
+#endif
+constexpr int I2_LITS = PJB_I2_LITS;            // literals decoded per iteration before the (one) length/distance pair
 constexpr iu32 I2_LIT = 0;                      // u16 entry offsets inside a lane's LDS area
 constexpr iu32 I2_DIST = 256;                   // 32 entries
 constexpr iu32 I2_LLIM = 288, I2_LADJ = 304;    // literal/length tree: per code length, upper bound and slot adjustment of long codes
@@ -321,12 +345,8 @@ __global__ __launch_bounds__(64) void bgzf_inflate(const uint8_t *comp, const In
             if (n) {
                 const iu32 w0 = L.w(I2_Q + 4 * q);
                 const iu32 dst = w0 & 0xffffu, len = w0 >> 16;
-                if (n >= 8) store64u(base + dst, va[q]);
-                else
-                    for (iu32 k = 0; k < n; k++) base[dst + k] = (uint8_t)(va[q] >> (8 * k));
-                if (n == 16) store64u(base + dst + 8, vb[q]);
-                else if (n > 8)
-                    for (iu32 k = 0; k < n - 8; k++) base[dst + 8 + k] = (uint8_t)(vb[q] >> (8 * k));
+                store_low(base + dst, va[q], n);
+                if (n > 8) store_low(base + dst + 8, vb[q], n - 8);
                 L.w(I2_Q + 4 * q) = ((dst + n) & 0xffffu) | ((len - n) << 16); // what is left of it (usually nothing;
                                                                                 // a copy may end at byte 65536)
             }
@@ -345,20 +365,27 @@ __global__ __launch_bounds__(64) void bgzf_inflate(const uint8_t *comp, const In
             if (!__any(on)) break;
             if (on) {
                 const iu32 dst = w0 & 0xffffu, len = w0 >> 16;
-                iu32 dist = L.w(I2_Q + 4 * qi + 2);
-                const iu32 n = len < 8 ? len : 8;
+                const iu32 dist = L.w(I2_Q + 4 * qi + 2);
                 iu64 x = load64u(base + dst - dist);
                 wait_vm();
-                if (dist < 8) { // a period shorter than the step: replicate it, then continue a multiple of it back
-                    x &= (1ull << (8 * dist)) - 1ull;
-                    for (iu32 sh = 8 * dist; sh < 64; sh <<= 1) x |= x << sh;
-                    dist *= (7 + dist) / dist;
-                    L.w(I2_Q + 4 * qi + 2) = dist;
+                if (dist <= 8) {
+                    // a period of at most 8 bytes (runs of one byte above all: the 0xff qualities of every read):
+                    // the whole copy comes out of registers, chunk k starting at phase 8k mod dist of the period
+                    const iu64 pmask = dist == 8 ? ~0ull : (1ull << (8 * dist)) - 1ull;
+                    const iu64 per = x & pmask;
+                    iu32 ph = 0;
+                    for (iu32 done = 0; done < len; done += 8) {
+                        iu64 y = ph ? ((per >> (8 * ph)) | (per << (8 * (dist - ph)))) & pmask : per; // rotated period
+                        for (iu32 sh = 8 * dist; sh < 64; sh <<= 1) y |= y << sh;
+                        store_low(base + dst + done, y, len - done);
+                        ph = (ph + 8) % dist;
+                    }
+                    L.w(I2_Q + 4 * qi) = (dst + len) & 0xffffu;
+                } else {
+                    const iu32 n = len < 8 ? len : 8;
+                    store_low(base + dst, x, n);
+                    L.w(I2_Q + 4 * qi) = ((dst + n) & 0xffffu) | ((len - n) << 16);
                 }
-                if (n == 8) store64u(base + dst, x);
-                else
-                    for (iu32 k = 0; k < n; k++) base[dst + k] = (uint8_t)(x >> (8 * k));
-                L.w(I2_Q + 4 * qi) = ((dst + n) & 0xffffu) | ((len - n) << 16);
             }
         }
         qn = 0;
@@ -479,36 +506,48 @@ __global__ __launch_bounds__(64) void bgzf_inflate(const uint8_t *comp, const In
             }
         }
         wait_vm(); // nothing of the header's direct reads is in flight when the decode loop starts
-        // ---- symbols: every lane that has a block in progress decodes one symbol per iteration
+        // ---- symbols
         for (;;) {
             const bool sym_on = state == ST_SYMBOLS;
             if (!__any(sym_on)) break;
-            if (__any(sym_on && (R.rf < 4 || qn == I2_QUEUE))) memory_phase();
+            if (__any(sym_on && (R.rf < I2_LITS + 3 || qn == I2_QUEUE))) memory_phase(); // an iteration takes at most I2_LITS + 2 words
             if (!sym_on) continue;
-            if (R.nb <= 32) { // one more word from the ring (never empty here: at least 4 words at the top of the iteration)
-                R.bb |= (iu64)L.w(I2_RING + 2 * R.ri) << R.nb;
-                R.ri = (R.ri + 1) & 15u;
-                R.rf--;
-                R.nb += 32;
+            // up to I2_LITS literals, then at most one end-of-block or length/distance pair: the literal step is short
+            // and most symbols are literals, the pair step is long and some lane needs it in every iteration anyway
+            iu32 e = 0, sym = 0;
+            bool bad = false;
+#pragma unroll
+            for (int rep = 0; rep < I2_LITS; rep++) {
+                if (sym >= 256 || bad) break;
+                if (R.nb <= 32) { // one more word from the ring (never empty here: the top of the iteration saw enough)
+                    R.bb |= (iu64)L.w(I2_RING + 2 * R.ri) << R.nb;
+                    R.ri = (R.ri + 1) & 15u;
+                    R.rf--;
+                    R.nb += 32;
+                }
+                e = inf2_decode<INF_ROOT_L>(L, I2_LIT, I2_LLIM, I2_LADJ, I2_LLONG, I2_LLONG_HI, (iu32)R.bb);
+                if (e == 0) {
+                    err = INF_ERR_CODE;
+                    bad = true;
+                    break;
+                }
+                R.bb >>= (e & 15u);
+                R.nb -= (int)(e & 15u);
+                sym = e >> 4;
+                if (sym < 256) {
+                    if (pos >= out_len) {
+                        err = INF_ERR_OVERRUN;
+                        bad = true;
+                        break;
+                    }
+                    base[pos++] = (uint8_t)sym;
+                }
             }
-            iu32 e = inf2_decode<INF_ROOT_L>(L, I2_LIT, I2_LLIM, I2_LADJ, I2_LLONG, I2_LLONG_HI, (iu32)R.bb);
-            if (e == 0) {
-                err = INF_ERR_CODE;
+            if (bad) {
                 state = ST_DONE;
                 continue;
             }
-            R.bb >>= (e & 15u);
-            R.nb -= (int)(e & 15u);
-            iu32 sym = e >> 4;
-            if (sym < 256) {
-                if (pos >= out_len) {
-                    err = INF_ERR_OVERRUN;
-                    state = ST_DONE;
-                    continue;
-                }
-                base[pos++] = (uint8_t)sym;
-                continue;
-            }
+            if (sym < 256) continue;
             if (sym == 256) { // end of block: where the next header starts
                 const iu64 consumed = (iu64)(R.gp - in0) * 8 - 32ull * R.rf - (iu64)R.nb;
                 if (consumed > (iu64)B.in_len * 8) {
