@@ -136,8 +136,8 @@ __device__ __forceinline__ iu32 bitrev16(iu32 v, int len) { return __brev(v) >> 
 //     one round trip tops up the rings and fetches the first 16 bytes of every queued match whose source
 //     lies before the queue's first destination; the few remaining steps (overlapping, long or
 //     short-period copies) follow in order, one step of every lane per round trip.
-// Block headers and table builds still read the stream directly (a few per block).  41 GB/s of inflated
-// bytes on the 10 M-read BAM (2.1 GB in 50 ms), 100x one zlib thread.
+// Block headers and table builds still read the stream directly (a few per block).  52 GB/s of inflated
+// bytes on the 10 M-read BAM (2.1 GB in 40 ms), 130x one zlib thread.
 // =================================================================================================
 constexpr int I2_QUEUE = 16;                    // queued matches per lane
 #ifndef PJB_I2_LITS
