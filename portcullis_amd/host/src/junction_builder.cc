@@ -278,7 +278,8 @@ private:
             } else if (c.kind == Cmd::BAM) {
                 int64_t n = 0;
                 if (err.empty() && pjb_submit_bam(ctx, c.tid, c.bamBytes, (int64_t)c.bamSize, (int32_t)c.bamFirst, &n) != PJB_OK)
-                    failed[c.tid] = std::string("pjb_submit_bam: ") + pjb_last_error(ctx);
+                    failed[c.tid] = std::string("pjb_submit_bam: ") + pjb_last_error(ctx) +
+                                    " (--ingest host decodes the file on the host threads and streams batches instead)";
                 if (c.bamPool) c.bamPool->release(c.bamBytes);
                 else bam::bigFree(c.bamBytes);
                 c.bamDone->set_value(n);
