@@ -272,3 +272,39 @@ def test_submit_bam_corrupt_records_fail_cleanly(orc, tmp_path):
         n = ctx.submit_bam(0, bgzf(bytes(data), 6), uoff)
         assert n == len(rs)
         ctx.finish_contig(0)
+
+
+@pytest.mark.parametrize("name", ["bam1.bam", "bam2.bam", "sorted.bam", "unsorted.bam", "clipped3.bam"])
+def test_reference_bam_fixtures_inflate(ctx, golden_dir, name):
+    raw = open(os.path.join(golden_dir, name), "rb").read()
+    assert ctx.inflate_bgzf(raw) == gzip.decompress(raw)
+
+
+def test_reference_unspliced_fixtures(golden_dir):
+    """The reference's E. coli fixtures (100 bwa alignments each, XS:i:<score> tags): `junc` refuses them like
+    the reference does -- BamAlignment::init calls getXSStrand, bam_aux2A of a non-'A' XS is 0 and strandFromChar
+    throws "Unknown strand" (bam_alignment.cc:226-231, bam_master.hpp:60-72); the unsorted one may also be
+    refused for its order, whichever alignment comes first.  File bytes and SoA batches must agree."""
+    from portcullis_amd import ffi
+    from util_bam import read_bam, records_to_batch
+    for name in ("sorted.bam", "unsorted.bam", "bam1.bam", "bam2.bam"):
+        path = os.path.join(golden_dir, name)
+        raw, refs, first = bam_targets(path)
+        _, recs = read_bam(path)
+        assert any(r["xs"] == "\x00" for r in recs)  # typed XS:i
+        batch = records_to_batch(recs)
+        codes = []
+        with ffi.Context(0, "UNKNOWN") as ctx:
+            ctx.set_refs([l for _, l in refs])
+            coff, uoff = first[0]
+            for via_bam in (True, False):
+                ctx.clear_rows()
+                if via_bam:
+                    assert ctx.submit_bam(0, raw[coff:], uoff) == len(recs)
+                else:
+                    ctx.submit_batch(0, batch)
+                with pytest.raises(ffi.PjbError) as ei:
+                    ctx.finish_contig(0)
+                codes.append((ei.value.code, str(ei.value)))
+        assert codes[0] == codes[1], codes
+        assert codes[0][0] in ((-1, -14) if name != "sorted.bam" else (-1,)), codes
