@@ -52,6 +52,9 @@ def algorithmic_bytes(name, N, C, S, Cs, P, J, L, passes, Pg=0):
 
 
 def main():
+    # exactly one line on stdout: everything the libraries print (RCCL banners, ...) goes to stderr
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -74,9 +77,16 @@ def main():
         raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False (no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # PJB_BENCH_FORCE_EXCHANGE=1 runs the N > 1 exchange code with a one-rank group (single-GPU check of that path)
+    force_x = world == 1 and os.environ.get("PJB_BENCH_FORCE_EXCHANGE") == "1"
+    if world > 1 or force_x:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if force_x:
+            os.environ.setdefault("MASTER_PORT", "29533")
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        else:
+            dist.init_process_group("nccl", device_id=dev)
+    multi = world > 1 or force_x
 
     cfg = synth.CONFIGS[args.config]
     t_gen = time.time()
@@ -92,38 +102,68 @@ def main():
     ctx.upload_contig_device(0, genome)
 
     state = {}
+    xchg = None
+    row_bytes = ffi.ROW_DTYPE.itemsize
 
     def step():
         ctx.clear_rows()
         ctx.submit_batch_device(0, batch, N)
         reg = ctx.finish_contig(0)
         rows = ctx.collect(copy=False)  # view of the pinned row table
-        if world > 1:
-            # the path's only exchange: read-length counters (all-reduce) and the merge of the
-            # per-rank junction tables (all-gather over RCCL)
-            state["totals"] = pd.allreduce_region(reg, dev)
-            state["merged"] = len(pd.allgather_rows(rows, dev))
+        if xchg is not None:
+            # the path's only exchange: the read-length counters (one small asynchronous all-gather per contig, folded
+            # at the end) and the merge of the per-rank junction tables: all-gather over RCCL / xGMI straight from
+            # HBM, asynchronous -- it overlaps the next contig's kernels.  Every rank's own rows are on its host
+            # after finish_contig; rank 0 copies the merged table to its host once, at the end of the timed region
+            # (a job merges once, not once per contig)
+            state["regions"].add(reg)
+            ptr, n = ctx.collect_device()
+            view = state.get("rows_view")
+            if view is None or view[0] != ptr or view[1] < n:  # the library's row buffer only moves when it grows
+                view = (ptr, max(n, 1) * 2, torch.as_tensor(pd.DeviceRows(ptr, max(n, 1) * 2 * row_bytes), device=dev))
+                state["rows_view"] = view
+            xchg.start(view[2], n)
         state["reg"] = reg
         state["rows"] = rows
 
     for _ in range(args.warmup):
         step()
+    if multi:
+        if not state:
+            step()
+        # slot size of the row exchange: the largest table any rank produced in the warm-up, with headroom
+        jmax = torch.tensor([int(state["reg"]["n_junctions"])], device=dev, dtype=torch.int64)
+        dist.all_reduce(jmax, op=dist.ReduceOp.MAX)
+        xchg = pd.RowExchange(row_bytes, int(jmax.item()) * 5 // 4 + 64, dev, host_copy="final")
+        state["regions"] = pd.RegionExchange(8, dev)
+        step()  # one untimed step with the exchange (buffers, communicator warm-up)
+        xchg.finish()
+        state["regions"].result()
     # per-kernel table from a few fully instrumented steps (outside the timed region) ...
     ctx.reset_kernel_timing()
     n_prof = 3
+    if multi:
+        state["regions"] = pd.RegionExchange(n_prof, dev)
     for _ in range(n_prof):
         step()
+    if multi:
+        state["regions"].result()
     kt_all = ctx.kernel_timing()
     dominant = max(kt_all.items(), key=lambda kv: kv[1][1])[0]
     # ... and only the dominant kernel keeps its HIP-event bracket inside the timed region
     ctx.select_timed_kernels([dominant])
     ctx.reset_kernel_timing()
+    if multi:
+        state["regions"] = pd.RegionExchange(args.steps, dev)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    merged = xchg.finish() if xchg is not None else None  # the last exchange completes inside the timed region
+    if xchg is not None:
+        state["totals"] = state["regions"].result()  # global read-length counters of all steps
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -133,6 +173,11 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     reg, rows = state["reg"], state["rows"].copy()
+    if xchg is not None and rank == 0:
+        # merged table on rank 0: every rank's rows, in rank order; this rank's part must be its own table
+        mt = merged.view(ffi.ROW_DTYPE)
+        assert len(mt) == sum(xchg.counts) and xchg.counts[0] == len(rows)
+        assert mt[: len(rows)].tobytes() == rows.tobytes()
     J = int(reg["n_junctions"])
     assert reg["n_pairs"] == P and reg["n_reads"] == N
     # size-independent sanity (full-size parity properties are in tests/test_gpu_fullsize.py)
@@ -224,9 +269,9 @@ def main():
         # pipeline_gbps: sum over kernels of (bytes per launch x launches per step) / device kernel time per step
         tot_bytes = sum((k["alg_bytes"] or 0) * k["launches"] / args.steps for k in kern)
         result["pipeline_gbps"] = round(tot_bytes / (kernel_ms_per_step * 1e-3) / 1e9, 1)
-        print(json.dumps(result))
+        os.write(real_stdout, (json.dumps(result) + "\n").encode())
     ctx.close()
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
 
 

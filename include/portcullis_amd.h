@@ -198,6 +198,10 @@ int pjb_finish_contig(pjb_ctx *ctx, int32_t tid, pjb_region_result *result);
 /* All rows built so far, contig by contig in finish order, (start,end)-sorted
  * within a contig.  The pointer stays valid until the next finish/clear/destroy. */
 int pjb_collect(pjb_ctx *ctx, const pjb_junction_row **rows, int64_t *n_rows);
+/* The rows of the contig finished last, still in HBM (device pointer; valid until the next
+ * pjb_finish_contig / pjb_destroy): what a multi-GPU merge all-gathers over xGMI without a detour
+ * through host memory. */
+int pjb_collect_device(pjb_ctx *ctx, const pjb_junction_row **device_rows, int64_t *n_rows);
 int pjb_clear_rows(pjb_ctx *ctx);
 
 int pjb_get_timing(const pjb_ctx *ctx, pjb_timing *out);

@@ -76,6 +76,7 @@ struct pjb_ctx {
     // junction rows live in a grow-only pinned host buffer so the D2H copy is a single DMA
     pjb_junction_row *rows_pinned = nullptr;
     size_t rows_n = 0, rows_cap = 0;
+    size_t last_rows_n = 0; // rows of the contig finished last (still in b_rows)
     pjb_timing timing;
     hipEvent_t ev[PJB_N_STAGES + 2];
     int radix_max_bits = 11;
@@ -598,6 +599,7 @@ int pjb_finish_contig(pjb_ctx *c, int32_t tid, pjb_region_result *res) {
     memset(&R, 0, sizeof R);
     R.min_len = INT32_MAX;
     memset(&c->timing, 0, sizeof c->timing);
+    c->last_rows_n = 0;
     c->ev_name.clear();
     c->ev_used = 0;
     if (res) *res = R;
@@ -862,6 +864,7 @@ int pjb_finish_contig(pjb_ctx *c, int32_t tid, pjb_region_result *res) {
     HIP_TRY(c, hipStreamSynchronize(st));
     if ((rc = check_device_error(c, herr))) return rc;
     c->rows_n = old + J;
+    c->last_rows_n = J;
     c->timing.generic_pairs = 0;
     for (u32 k = 0; k < GEN_SHARDS; k++) c->timing.generic_pairs += gen_counts[k];
     if (c->ktime) ev_collect(c);
@@ -875,6 +878,13 @@ int pjb_collect(pjb_ctx *c, const pjb_junction_row **rows, int64_t *n) {
     if (!c || !rows || !n) return PJB_ERR_ARG;
     *rows = c->rows_pinned;
     *n = (int64_t)c->rows_n;
+    return PJB_OK;
+}
+
+int pjb_collect_device(pjb_ctx *c, const pjb_junction_row **rows, int64_t *n) {
+    if (!c || !rows || !n) return PJB_ERR_ARG;
+    *rows = (const pjb_junction_row *)c->b_rows.p;
+    *n = (int64_t)c->last_rows_n;
     return PJB_OK;
 }
 

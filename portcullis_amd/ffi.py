@@ -22,7 +22,7 @@ EXPORTS = [
     "pjb_create", "pjb_destroy", "pjb_last_error", "pjb_set_refs", "pjb_upload_contig", "pjb_upload_contig_device",
     "pjb_release_contig", "pjb_submit_batch", "pjb_submit_batch_device", "pjb_finish_contig", "pjb_collect",
     "pjb_clear_rows", "pjb_get_timing", "pjb_device_count", "pjb_get_kernel_timing", "pjb_reset_kernel_timing",
-    "pjb_select_timed_kernels", "pjb_host_alloc", "pjb_host_free", "pjb_inflate_bgzf", "pjb_submit_bam",
+    "pjb_select_timed_kernels", "pjb_host_alloc", "pjb_host_free", "pjb_inflate_bgzf", "pjb_submit_bam", "pjb_collect_device",
 ]
 FLAG_KERNEL_TIMING = 1
 
@@ -98,6 +98,7 @@ def load():
         L.pjb_submit_batch.argtypes = [C.c_void_p, C.c_int32, C.POINTER(PjbBatch)]
         L.pjb_submit_batch_device.argtypes = [C.c_void_p, C.c_int32, C.POINTER(PjbBatch)]
         L.pjb_finish_contig.argtypes = [C.c_void_p, C.c_int32, C.POINTER(PjbRegionResult)]
+        L.pjb_collect_device.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
         L.pjb_inflate_bgzf.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
         L.pjb_submit_bam.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_int32, C.POINTER(C.c_int64)]
         L.pjb_collect.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
@@ -211,6 +212,13 @@ class Context:
         buf = (C.c_char * (n.value * ROW_DTYPE.itemsize)).from_address(p.value)
         a = np.frombuffer(buf, dtype=ROW_DTYPE, count=n.value)
         return a.copy() if copy else a
+
+    def collect_device(self):
+        """(device pointer, row count) of the rows of the contig finished last, still in HBM."""
+        p = C.c_void_p()
+        n = C.c_int64()
+        self._check(self._L.pjb_collect_device(self._h, C.byref(p), C.byref(n)))
+        return (p.value or 0), n.value
 
     def clear_rows(self):
         self._check(self._L.pjb_clear_rows(self._h))

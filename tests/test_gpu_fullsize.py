@@ -98,3 +98,19 @@ def test_sort_variants_agree(c2, monkeypatch, env):
             again = ctx.collect()
             assert reg2 == reg
             assert hashlib.md5(again.tobytes()).hexdigest() == hashlib.md5(rows.tobytes()).hexdigest()
+
+
+def test_bench_exchange_path_single_rank(tmp_path):
+    """bench.py's N > 1 step (device-side all-gather of the row table over RCCL, asynchronous, plus the counter
+    exchange) with a one-rank process group: the CUDA-specific parts of RowExchange on real hardware."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PJB_BENCH_FORCE_EXCHANGE="1", MASTER_ADDR="127.0.0.1")
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--config", "C2-small", "--steps", "4", "--warmup", "1",
+                        "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    d = json.loads([l for l in p.stdout.split("\n") if l.startswith("{")][-1])
+    assert d["n_gpus"] == 1 and d["value"] > 0
