@@ -21,6 +21,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seeds", type=int, default=100)
     ap.add_argument("--start", type=int, default=1000)
+    ap.add_argument("--max-reads", type=int, default=6000)
     args = ap.parse_args()
     from fuzzgen import make_reads, to_batch
     from oracle import oracle as orc
@@ -39,7 +40,7 @@ def main():
         rng = np.random.default_rng(seed)
         ori = oris[seed % len(oris)]
         opts = opt_sets[(seed // 5) % len(opt_sets)]
-        n_reads = int(rng.integers(200, 6000))
+        n_reads = int(rng.integers(200, args.max_reads))
         glen = int(rng.integers(8000, 60000))
         L = (int(rng.integers(20, 60)), int(rng.integers(60, 260)))
         genome, reads = make_reads(seed, glen=glen, n_reads=n_reads, paired=(seed % 2 == 1), opts=opts, L=L, n_tx=int(rng.integers(2, 30)))
