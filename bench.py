@@ -294,11 +294,19 @@ def cpu_baseline(data, cfg, ctx, ffi, synth):
     dt = time.perf_counter() - t
     rate = pilot / dt
     M = int(min(N, max(pilot, rate * 15.0)))
+    reps = 1
     if M > pilot:
         hb = synth.batch_to_numpy(data["batch"], 0, M)
-        t = time.perf_counter()
-        orows, oreg = orc.find_juncs(0, cfg.contig_len, genome_host, hb.to_oracle(), "UNKNOWN")
-        dt = time.perf_counter() - t
+        ob = hb.to_oracle()
+        # the whole workload fits the budget several times over: repeat it (about 10 s of CPU work) and take the median
+        reps = int(max(1, min(12, round(10.0 / max(M / rate, 1e-3)))))
+        times = []
+        for _ in range(reps):
+            t = time.perf_counter()
+            orows, oreg = orc.find_juncs(0, cfg.contig_len, genome_host, ob, "UNKNOWN")
+            times.append(time.perf_counter() - t)
+        times.sort()
+        dt = times[len(times) // 2]
     # parity of the device path on exactly this sample
     ctx.clear_rows()
     ctx.submit_batch(0, hb)
@@ -308,7 +316,8 @@ def cpu_baseline(data, cfg, ctx, ffi, synth):
     max_ent = assert_rows_equal(drows, orows)
     return {"value": M / dt, "unit": "reads/s", "cores": 1, "kind": "port",
             "sample": f"first {M} of {N} records of the same workload ({len(orows)} junctions), oracle/portcullis_oracle.c, "
-                      f"{dt:.1f} s; device rows for the sample match the oracle (max |entropy diff| {max_ent:.2g})",
+                      f"median of {reps} runs of {dt:.2f} s; device rows for the sample match the oracle "
+                      f"(max |entropy diff| {max_ent:.2g})",
             "junctions_per_sec": len(orows) / dt}
 
 
