@@ -200,7 +200,8 @@ int main(int argc, char** argv) {
             const size_t off = b * BLK, len = std::min(BLK, u.size() - off);
             z_stream zs;
             memset(&zs, 0, sizeof zs);
-            deflateInit2(&zs, 1, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY);
+            static const int level = getenv("SOA2BAM_LEVEL") ? atoi(getenv("SOA2BAM_LEVEL")) : 1;  // samtools writes level 6
+            deflateInit2(&zs, level, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY);
             zs.next_in = &u[off];
             zs.avail_in = (uInt)len;
             zs.next_out = out.data();
