@@ -1122,33 +1122,62 @@ extern "C" int pjb_submit_bam(pjb_ctx *c, int32_t tid, const uint8_t *comp, int6
     R.ref_len = c->ref_len[(size_t)tid];
     R.n_ref = (int32_t)c->ref_len.size();
     const uint32_t n_seg = (uint32_t)(((iu64)total + BAM_SEG - 1) / BAM_SEG);
-    // seg_start u64 | seg_base u64 | seg_n u32
-    if ((rc = ensure(c, c->b_bam_seg, (size_t)n_seg * 20 + 64))) return rc;
+    // seg_start u64 | seg_base u64 | land u64 | seg_n u32
+    if ((rc = ensure(c, c->b_bam_seg, (size_t)n_seg * 28 + 64))) return rc;
     if ((rc = ensure(c, c->b_bam_ctl, 64))) return rc;
     iu64 *seg_start = (iu64 *)c->b_bam_seg.p;
     iu64 *seg_base = seg_start + n_seg;
-    iu32 *seg_n = (iu32 *)(seg_base + n_seg);
+    iu64 *land = seg_base + n_seg;
+    iu32 *seg_n = (iu32 *)(land + n_seg);
     iu32 *ctl = (iu32 *)c->b_bam_ctl.p; // [0..2] end / mismatch / bad segment, [4..5] u64 total of a scan
     iu64 *d_total = (iu64 *)(ctl + 4);
     HIP_TRY(c, hipMemsetAsync(ctl, 0xff, 16, st));
     BamWalkOut O;
     O.seg_n = seg_n;
+    O.land = land;
     O.rec_off = nullptr;
     O.seg_base = seg_base;
     O.ctl = ctl;
     LAUNCH(c, "bam_find_starts", bam_find_starts, dim3(n_seg), dim3(64), R, n_seg, seg_start);
-    LAUNCH(c, "bam_walk_count", bam_walk<false>, dim3((n_seg + 255) / 256), dim3(256), R, n_seg, (const iu64 *)seg_start, O);
+    if (const char *e = getenv("PJB_TEST_FALSE_START")) { // test hook: damage the guessed start of one segment
+        const uint32_t k = (uint32_t)atoi(e);
+        if (k > 0 && k < n_seg) {
+            iu64 v = 0;
+            HIP_TRY(c, hipMemcpyAsync(&v, seg_start + k, 8, hipMemcpyDeviceToHost, st));
+            HIP_TRY(c, hipStreamSynchronize(st));
+            if (v != BAM_NONE) {
+                v += 1;
+                HIP_TRY(c, hipMemcpyAsync(seg_start + k, &v, 8, hipMemcpyHostToDevice, st));
+                HIP_TRY(c, hipStreamSynchronize(st));
+            }
+        }
+    }
+    uint32_t h_ctl[6];
+    uint32_t end_seg = 0xffffffffu;
+    for (int attempt = 0;; attempt++) {
+        HIP_TRY(c, hipMemsetAsync(ctl, 0xff, 16, st));
+        LAUNCH(c, "bam_walk_count", bam_walk<false>, dim3((n_seg + 255) / 256), dim3(256), R, n_seg, (const iu64 *)seg_start, O);
+        HIP_TRY(c, hipMemcpyAsync(h_ctl, ctl, 16, hipMemcpyDeviceToHost, st));
+        HIP_TRY(c, hipStreamSynchronize(st));
+        end_seg = h_ctl[0];
+        if (h_ctl[2] != 0xffffffffu && h_ctl[2] <= end_seg && (h_ctl[1] == 0xffffffffu || h_ctl[2] <= h_ctl[1]))
+            return fail(c, PJB_ERR_BGZF, "Invalid BAM record layout on target %d (inflated offset %llu..)", tid,
+                        (unsigned long long)h_ctl[2] * BAM_SEG);
+        if (h_ctl[1] == 0xffffffffu || h_ctl[1] > end_seg) break; // every walk landed on the next start
+        // a guessed start was not a record boundary: replace it by the boundary the verified walk reached, walk again
+        if (attempt >= 16)
+            return fail(c, PJB_ERR_BGZF, "BAM record chain of target %d is inconsistent near inflated offset %llu", tid,
+                        (unsigned long long)h_ctl[1] * BAM_SEG);
+        LAUNCH(c, "bam_repair_start", bam_repair_start, dim3(1), dim3(1), seg_start, n_seg, h_ctl[1], (const iu64 *)land, (iu64)total, ctl);
+        HIP_TRY(c, hipMemcpyAsync(h_ctl, ctl, 16, hipMemcpyDeviceToHost, st));
+        HIP_TRY(c, hipStreamSynchronize(st));
+        if (h_ctl[3] != 0xffffffffu)
+            return fail(c, PJB_ERR_BGZF, "Invalid BAM record on target %d (inflated offset %llu..)", tid, (unsigned long long)h_ctl[3] * BAM_SEG);
+    }
     LAUNCH(c, "bam_trim_segments", bam_trim_segments, dim3((n_seg + 255) / 256), dim3(256), seg_n, n_seg, (const iu32 *)ctl);
     if ((rc = run_scan(c, "bam_seg", SegCountFn{seg_n}, SegBaseSink{seg_base}, n_seg, d_total))) return rc;
-    uint32_t h_ctl[6];
     HIP_TRY(c, hipMemcpyAsync(h_ctl, ctl, 24, hipMemcpyDeviceToHost, st));
     HIP_TRY(c, hipStreamSynchronize(st));
-    const uint32_t end_seg = h_ctl[0];
-    if (h_ctl[2] != 0xffffffffu && h_ctl[2] <= end_seg) return fail(c, PJB_ERR_BGZF, "Invalid BAM record layout on target %d (inflated offset %llu..)", tid,
-                                         (unsigned long long)h_ctl[2] * BAM_SEG);
-    if (h_ctl[1] != 0xffffffffu && h_ctl[1] <= end_seg)
-        return fail(c, PJB_ERR_BGZF, "BAM record chain of target %d is inconsistent near inflated offset %llu", tid,
-                    (unsigned long long)h_ctl[1] * BAM_SEG);
     t_walk = now() - t0;
     t0 = now();
     iu64 n64;

@@ -624,7 +624,8 @@ __global__ __launch_bounds__(64) void bgzf_inflate(const uint8_t *comp, const In
 //                     verified below.
 //   bam_walk        : one thread per segment follows the list from its start to the next segment's start
 //                     and must land on it exactly (that is the verification: by induction from the true
-//                     first record every start is then a true record boundary), counting records; run a
+//                     first record every start is then a true record boundary; a start it contradicts is replaced
+//                     by the boundary it reached, bam_repair_start, and the walk repeated), counting records; run a
 //                     second time it writes the record offsets.
 //   BamSizes scan   : CIGAR ops and sequence words per record -> cig_off / seq_off (generic u64 scan).
 //   bam_transcode   : one thread per record writes the fixed-width fields, CIGAR, 4-bit bases of spliced
@@ -721,6 +722,7 @@ __global__ __launch_bounds__(64) void bam_find_starts(BamRegion R, iu32 n_seg, i
 
 struct BamWalkOut {
     iu32 *seg_n;       // records per segment
+    iu64 *land;        // (count pass) where the segment's walk stopped
     iu64 *rec_off;     // (fill pass) offset of every record
     const iu64 *seg_base; // (fill pass) exclusive scan of seg_n
     iu32 *ctl;         // [0] smallest segment index in which the target's records ended, [1] smallest segment whose
@@ -780,8 +782,33 @@ __global__ __launch_bounds__(256) void bam_walk(BamRegion R, iu32 n_seg, const i
     }
     if (!FILL) {
         O.seg_n[s] = n;
+        O.land[s] = cur;
         if (ended) atomicMin(&O.ctl[0], s);
         else if (!partial && cur != limit) atomicMin(&O.ctl[1], s); // overshot the next start: that start was not a record
+    }
+}
+
+// The walk of segment s (whose own start is verified: every earlier walk landed) ran past the start guessed for a later
+// segment and stopped at `land[s]`, a true record boundary: the guess was not a record.  Segments the overshooting
+// record covers entirely have no start, the one holding the boundary starts there.
+__global__ void bam_repair_start(iu64 *seg_start, iu32 n_seg, iu32 s, const iu64 *land, iu64 total, iu32 *ctl) {
+    if (blockIdx.x || threadIdx.x) return;
+    const iu64 cur = land[s];
+    iu32 t = s + 1;
+    while (t < n_seg && seg_start[t] == BAM_NONE) t++;
+    if (t >= n_seg || cur <= seg_start[t]) { // stopped short of the next start: a damaged record, not a false guess
+        ctl[3] = s;
+        return;
+    }
+    for (iu32 v = t; v < n_seg; v++) {
+        const iu64 hi = (iu64)(v + 1) * BAM_SEG;
+        if (cur >= hi || cur >= total) {
+            seg_start[v] = BAM_NONE;
+            if (cur >= total && hi >= total) break;
+        } else {
+            seg_start[v] = cur;
+            break;
+        }
     }
 }
 

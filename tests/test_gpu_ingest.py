@@ -308,3 +308,24 @@ def test_reference_unspliced_fixtures(golden_dir):
                 codes.append((ei.value.code, str(ei.value)))
         assert codes[0] == codes[1], codes
         assert codes[0][0] in ((-1, -14) if name != "sorted.bam" else (-1,)), codes
+
+
+@pytest.mark.parametrize("seg", [1, 2, 5])
+def test_false_record_start_is_repaired(orc, tmp_path, monkeypatch, seg):
+    """A guessed record start that is not a boundary (injected through the PJB_TEST_FALSE_START hook: the start of
+    one 64 KB segment is moved by a byte) is caught by the chain walk and replaced by the boundary the verified walk
+    reaches; the result is the oracle's."""
+    from fuzzgen import make_reads
+    from portcullis_amd import ffi
+    from util_bam import write_bam
+    genome, rs = make_reads(91, n_reads=6000, L=(60, 150))
+    for k, r in enumerate(rs):
+        r["tid"] = 0
+        r["name"] = f"read{k:06d}"
+        if r.get("mtid", -1) >= 0:
+            r["mtid"] = 0
+    path = str(tmp_path / "f.bam")
+    write_bam(path, [("chr1", len(genome))], rs)
+    monkeypatch.setenv("PJB_TEST_FALSE_START", str(seg))
+    with ffi.Context(0, "UNKNOWN") as ctx:
+        assert run_targets_from_bam(ctx, orc, path, {0: genome.encode()}) > 10
