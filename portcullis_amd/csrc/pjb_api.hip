@@ -1023,7 +1023,8 @@ int inflate_on_device(pjb_ctx *c, const uint8_t *d_comp, const std::vector<InfBl
     if (nb == 0) return PJB_OK;
     if ((rc = ensure(c, c->b_inf_blocks, nb * sizeof(InfBlock)))) return rc;
     if ((rc = ensure(c, c->b_inf_status, nb * 4 + 4))) return rc;
-    const size_t per_launch = std::min<size_t>(nb, INF_BLOCKS_PER_LAUNCH);
+    size_t per_launch = std::min<size_t>(nb, INF_BLOCKS_PER_LAUNCH);
+    if (const char *e = getenv("PJB_INF_BLOCKS_PER_LAUNCH")) per_launch = std::min<size_t>(nb, std::max(64, atoi(e))); // tests: several launches
     if ((rc = ensure(c, c->b_inf_scratch, ((per_launch + 63) / 64 * 64) * INF_SCRATCH_PER_LANE))) return rc;
     hipStream_t st = c->stream;
     HIP_TRY(c, hipMemcpyAsync(c->b_inf_blocks.p, blocks.data(), nb * sizeof(InfBlock), hipMemcpyHostToDevice, st));

@@ -68,7 +68,10 @@ def test_full_64k_blocks(ctx):
         assert ctx.inflate_bgzf(comp) == data
 
 
-def test_many_blocks_and_eof_markers(ctx):
+@pytest.mark.parametrize("per_launch", [None, "128"])
+def test_many_blocks_and_eof_markers(ctx, monkeypatch, per_launch):
+    if per_launch:
+        monkeypatch.setenv("PJB_INF_BLOCKS_PER_LAUNCH", per_launch)  # the scratch area is reused launch after launch
     rng = np.random.default_rng(5)
     parts, comp = [], bytearray()
     for i in range(700):  # more than one 64-lane workgroup per launch, ragged sizes, EOF markers in between
