@@ -25,6 +25,13 @@
  *                                                            lib/src/junction.cc:561-649,683-909
  *   pjb_collect           JunctionSystem::append of the per-contig systems
  *                                                            src/junction_builder.cc:258-269
+ *   pjb_collect_device    the same rows, still in HBM (multi-GPU merge over xGMI)
+ *   pjb_submit_bam        the reader loop itself: BamReader::setRegion / next and htslib's
+ *                         bgzf_read_block / inflate_block / bam_read1 for one target
+ *                                                            lib/src/bam_reader.cc:78-146,
+ *                                                            deps/htslib-1.3/bgzf.c:292-316,421-540
+ *   pjb_inflate_bgzf      inflate_block for a run of BGZF blocks
+ *                                                            deps/htslib-1.3/bgzf.c:292-316
  *
  * A context is bound to one HIP device and is not thread-safe; use one
  * context per GPU and call it from one thread.  Several contigs may be open at
