@@ -197,10 +197,10 @@ void JunctionSystem::saveAll(const std::string& outputPrefix, const std::string&
 }
 
 namespace {
-// text of items [0, n) in order, formatted by up to 8 threads on contiguous slices
+// text of items [0, n) in order, formatted by up to 16 threads on contiguous slices
 template <typename F>
 std::vector<std::string> formatSlices(size_t n, size_t bytesPerItem, F fn) {
-    const size_t nt = n < 20000 ? 1 : std::min<size_t>(8, std::max(1u, std::thread::hardware_concurrency()));
+    const size_t nt = n < 20000 ? 1 : std::min<size_t>(16, std::max(1u, std::thread::hardware_concurrency()));
     std::vector<std::string> parts(nt);
     auto work = [&](size_t t) {
         const size_t a = n * t / nt, b = n * (t + 1) / nt;
