@@ -108,21 +108,16 @@ def main():
     def step():
         ctx.clear_rows()
         ctx.submit_batch_device(0, batch, N)
+        if xchg is not None:
+            ctx.set_row_mirror(*xchg.slot_for_next_finish())  # finish_contig leaves header + rows in the exchange slot
         reg = ctx.finish_contig(0)
         rows = ctx.collect(copy=False)  # view of the pinned row table
         if xchg is not None:
-            # the path's only exchange: the read-length counters (one small asynchronous all-gather per contig, folded
-            # at the end) and the merge of the per-rank junction tables: all-gather over RCCL / xGMI straight from
-            # HBM, asynchronous -- it overlaps the next contig's kernels.  Every rank's own rows are on its host
-            # after finish_contig; rank 0 copies the merged table to its host once, at the end of the timed region
-            # (a job merges once, not once per contig)
-            state["regions"].add(reg)
-            ptr, n = ctx.collect_device()
-            view = state.get("rows_view")
-            if view is None or view[0] != ptr or view[1] < n:  # the library's row buffer only moves when it grows
-                view = (ptr, max(n, 1) * 2, torch.as_tensor(pd.DeviceRows(ptr, max(n, 1) * 2 * row_bytes), device=dev))
-                state["rows_view"] = view
-            xchg.start(view[2], n)
+            # the path's only exchange: the merge of the per-rank junction tables and read-length counters (they ride in
+            # the slot's header): all-gather over RCCL / xGMI straight from HBM, asynchronous -- it overlaps the next
+            # contig's kernels.  Every rank's own rows are on its host after finish_contig; rank 0 copies the merged
+            # table to its host once, at the end of the timed region (a job merges once, not once per contig)
+            xchg.launch()
         state["reg"] = reg
         state["rows"] = rows
 
@@ -134,27 +129,19 @@ def main():
         # slot size of the row exchange: the largest table any rank produced in the warm-up, with headroom
         jmax = torch.tensor([int(state["reg"]["n_junctions"])], device=dev, dtype=torch.int64)
         dist.all_reduce(jmax, op=dist.ReduceOp.MAX)
-        xchg = pd.RowExchange(row_bytes, int(jmax.item()) * 5 // 4 + 64, dev, host_copy="final")
-        state["regions"] = pd.RegionExchange(8, dev)
+        xchg = pd.MirrorExchange(row_bytes, int(jmax.item()) * 5 // 4 + 64, dev)
         step()  # one untimed step with the exchange (buffers, communicator warm-up)
         xchg.finish()
-        state["regions"].result()
     # per-kernel table from a few fully instrumented steps (outside the timed region) ...
     ctx.reset_kernel_timing()
     n_prof = 3
-    if multi:
-        state["regions"] = pd.RegionExchange(n_prof, dev)
     for _ in range(n_prof):
         step()
-    if multi:
-        state["regions"].result()
     kt_all = ctx.kernel_timing()
     dominant = max(kt_all.items(), key=lambda kv: kv[1][1])[0]
     # ... and only the dominant kernel keeps its HIP-event bracket inside the timed region
     ctx.select_timed_kernels([dominant])
     ctx.reset_kernel_timing()
-    if multi:
-        state["regions"] = pd.RegionExchange(args.steps, dev)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -162,8 +149,12 @@ def main():
     for _ in range(args.steps):
         step()
     merged = xchg.finish() if xchg is not None else None  # the last exchange completes inside the timed region
-    if xchg is not None:
-        state["totals"] = state["regions"].result()  # global read-length counters of all steps
+    if xchg is not None and rank == 0:
+        tot = xchg.regions  # per-rank read-length counters of the last exchange -> the global ones
+        state["totals"] = dict(spliced=sum(r["spliced"] for r in tot), unspliced=sum(r["unspliced"] for r in tot),
+                               sum_len=sum(r["sum_len"] for r in tot), min_len=min(r["min_len"] for r in tot),
+                               max_len=max(r["max_len"] for r in tot))
+        assert state["totals"]["spliced"] + state["totals"]["unspliced"] >= N
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -270,6 +261,7 @@ def main():
         tot_bytes = sum((k["alg_bytes"] or 0) * k["launches"] / args.steps for k in kern)
         result["pipeline_gbps"] = round(tot_bytes / (kernel_ms_per_step * 1e-3) / 1e9, 1)
         os.write(real_stdout, (json.dumps(result) + "\n").encode())
+    ctx.set_row_mirror(0, 0)
     ctx.close()
     if multi:
         dist.destroy_process_group()

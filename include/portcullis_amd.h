@@ -209,6 +209,13 @@ int pjb_collect(pjb_ctx *ctx, const pjb_junction_row **rows, int64_t *n_rows);
  * pjb_finish_contig / pjb_destroy): what a multi-GPU merge all-gathers over xGMI without a detour
  * through host memory. */
 int pjb_collect_device(pjb_ctx *ctx, const pjb_junction_row **device_rows, int64_t *n_rows);
+/* A device buffer of the caller's (cap_bytes, 0 / NULL to stop) that every following pjb_finish_contig fills
+ * before it returns: a 64-byte header of int64 { n_rows, spliced, unspliced, sum_len, min_len, max_len, 0, 0 }
+ * followed by the contig's rows.  It is the send slot of the multi-GPU merge: when pjb_finish_contig returns
+ * the slot can go straight into an all-gather, without a copy or a synchronisation on the caller's side.
+ * A contig whose rows do not fit fails with PJB_ERR_ARG. */
+#define PJB_MIRROR_HEADER_BYTES 64
+int pjb_set_row_mirror(pjb_ctx *ctx, void *device_buffer, int64_t cap_bytes);
 int pjb_clear_rows(pjb_ctx *ctx);
 
 int pjb_get_timing(const pjb_ctx *ctx, pjb_timing *out);

@@ -77,6 +77,9 @@ struct pjb_ctx {
     pjb_junction_row *rows_pinned = nullptr;
     size_t rows_n = 0, rows_cap = 0;
     size_t last_rows_n = 0; // rows of the contig finished last (still in b_rows)
+    uint8_t *mirror = nullptr; // caller's device buffer filled by every finish (header + rows)
+    size_t mirror_cap = 0;
+    int64_t *mirror_hdr = nullptr; // page-locked staging of the header
     pjb_timing timing;
     hipEvent_t ev[PJB_N_STAGES + 2];
     int radix_max_bits = 11;
@@ -377,6 +380,7 @@ void pjb_destroy(pjb_ctx *c) {
     for (auto &sl : c->slab_pool)
         if (sl.p) (void)hipFree(sl.p);
     if (c->rows_pinned) (void)hipHostFree(c->rows_pinned);
+    if (c->mirror_hdr) (void)hipHostFree(c->mirror_hdr);
     for (int k = 0; k < 2; k++) {
         if (c->stage[k]) (void)hipHostFree(c->stage[k]);
         if (c->stage_ev[k]) (void)hipEventDestroy(c->stage_ev[k]);
@@ -583,6 +587,17 @@ static int add_batch(pjb_ctx *c, int32_t tid, const pjb_batch *b, bool device) {
 int pjb_submit_batch(pjb_ctx *c, int32_t tid, const pjb_batch *b) { return add_batch(c, tid, b, false); }
 int pjb_submit_batch_device(pjb_ctx *c, int32_t tid, const pjb_batch *b) { return add_batch(c, tid, b, true); }
 
+// a contig without junctions still reports its counters through the row mirror
+static int mirror_header_only(pjb_ctx *c, const pjb_region_result &R) {
+    if (!c->mirror) return PJB_OK;
+    int64_t *h = c->mirror_hdr;
+    h[0] = 0; h[1] = (int64_t)R.spliced; h[2] = (int64_t)R.unspliced; h[3] = (int64_t)R.sum_len;
+    h[4] = (int64_t)R.min_len; h[5] = (int64_t)R.max_len; h[6] = h[7] = 0;
+    HIP_TRY(c, hipMemcpyAsync(c->mirror, h, PJB_MIRROR_HEADER_BYTES, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return PJB_OK;
+}
+
 int pjb_finish_contig(pjb_ctx *c, int32_t tid, pjb_region_result *res) {
     if (!c) return PJB_ERR_ARG;
     if (tid < 0 || (size_t)tid >= c->ref_len.size()) return fail(c, PJB_ERR_ARG, "finish: bad tid %d", tid);
@@ -603,7 +618,10 @@ int pjb_finish_contig(pjb_ctx *c, int32_t tid, pjb_region_result *res) {
     c->ev_name.clear();
     c->ev_used = 0;
     if (res) *res = R;
-    if (batches.empty()) return PJB_OK;
+    if (batches.empty()) {
+        HIP_TRY(c, hipSetDevice(c->cfg.device));
+        return mirror_header_only(c, R);
+    }
     HIP_TRY(c, hipSetDevice(c->cfg.device));
     hipStream_t st = c->stream;
     const int32_t ref_len = c->ref_len[(size_t)tid];
@@ -667,7 +685,7 @@ int pjb_finish_contig(pjb_ctx *c, int32_t tid, pjb_region_result *res) {
     const u64 P64 = cs.n_pairs;
     if (P64 == 0) {
         if (res) *res = R;
-        return PJB_OK;
+        return mirror_header_only(c, R);
     }
     if (P64 >= 0xfffffff0ull) return fail(c, PJB_ERR_ARG, "finish: more than 2^32 spliced pairs on one target are not supported");
     const u32 P = (u32)P64;
@@ -857,6 +875,15 @@ int pjb_finish_contig(pjb_ctx *c, int32_t tid, pjb_region_result *res) {
         c->rows_cap = ncap;
     }
     HIP_TRY(c, hipMemcpyAsync(c->rows_pinned + old, c->b_rows.p, (size_t)J * sizeof(pjb_junction_row), hipMemcpyDeviceToHost, st));
+    if (c->mirror) { // header + rows into the caller's exchange slot, covered by the synchronisation below
+        const size_t need = PJB_MIRROR_HEADER_BYTES + (size_t)J * sizeof(pjb_junction_row);
+        if (need > c->mirror_cap) return fail(c, PJB_ERR_ARG, "finish: %u rows do not fit the row mirror (%zu bytes)", J, c->mirror_cap);
+        int64_t *h = c->mirror_hdr;
+        h[0] = (int64_t)J; h[1] = (int64_t)R.spliced; h[2] = (int64_t)R.unspliced; h[3] = (int64_t)R.sum_len;
+        h[4] = (int64_t)R.min_len; h[5] = (int64_t)R.max_len; h[6] = h[7] = 0;
+        HIP_TRY(c, hipMemcpyAsync(c->mirror, h, PJB_MIRROR_HEADER_BYTES, hipMemcpyHostToDevice, st));
+        HIP_TRY(c, hipMemcpyAsync(c->mirror + PJB_MIRROR_HEADER_BYTES, c->b_rows.p, (size_t)J * sizeof(pjb_junction_row), hipMemcpyDeviceToDevice, st));
+    }
     HIP_TRY(c, hipMemcpyAsync(&herr, d_err, 8, hipMemcpyDeviceToHost, st));
     u32 gen_counts[GEN_SHARDS];
     HIP_TRY(c, hipMemcpyAsync(gen_counts, c->b_gencount.p, GEN_SHARDS * 4, hipMemcpyDeviceToHost, st));
@@ -885,6 +912,18 @@ int pjb_collect_device(pjb_ctx *c, const pjb_junction_row **rows, int64_t *n) {
     if (!c || !rows || !n) return PJB_ERR_ARG;
     *rows = (const pjb_junction_row *)c->b_rows.p;
     *n = (int64_t)c->last_rows_n;
+    return PJB_OK;
+}
+
+int pjb_set_row_mirror(pjb_ctx *c, void *device_buffer, int64_t cap_bytes) {
+    if (!c) return PJB_ERR_ARG;
+    if (device_buffer && cap_bytes < PJB_MIRROR_HEADER_BYTES) return fail(c, PJB_ERR_ARG, "set_row_mirror: buffer smaller than its header");
+    c->mirror = (uint8_t *)device_buffer;
+    c->mirror_cap = device_buffer ? (size_t)cap_bytes : 0;
+    if (c->mirror && !c->mirror_hdr) {
+        HIP_TRY(c, hipSetDevice(c->cfg.device));
+        HIP_TRY(c, hipHostMalloc((void **)&c->mirror_hdr, PJB_MIRROR_HEADER_BYTES, hipHostMallocDefault));
+    }
     return PJB_OK;
 }
 

@@ -214,3 +214,67 @@ class RowExchange:
         self.counts = counts
         parts = [h[r, self.HDR:self.HDR + counts[r] * self.row_bytes] for r in range(self.world) if counts[r]]
         return np.concatenate(parts) if parts else np.zeros(0, dtype=np.uint8)
+
+
+class MirrorExchange:
+    """RowExchange without a copy or a synchronisation of its own on the sending side: the send slots are handed to
+    the library (pjb_set_row_mirror), whose pjb_finish_contig leaves header + rows in them, so that after
+    finish_contig returns launch() only starts the asynchronous all-gather.
+
+    Two send slots alternate: the collective of contig k reads slot k % 2 while finish_contig of contig k + 1 fills
+    the other one; launch() first makes sure the previous collective is complete (it had a whole contig's time), so
+    the slot handed out next is free again.  Header: int64 n_rows, spliced, unspliced, sum_len, min_len, max_len.
+    """
+    HDR = 64
+
+    def __init__(self, row_bytes, cap_rows, device, group=None, root=0):
+        self.group, self.device, self.row_bytes = group, torch.device(device), row_bytes
+        self.world, self.rank, self.root = dist.get_world_size(group), dist.get_rank(group), root
+        self.cuda = self.device.type == "cuda"
+        self.nccl = dist.get_backend(group) == "nccl"
+        self.cap = int(cap_rows)
+        self.slot = self.HDR + self.cap * row_bytes
+        self.send = [torch.zeros(self.slot, dtype=torch.uint8, device=self.device) for _ in range(2)]
+        self.recv = torch.zeros(self.world * self.slot, dtype=torch.uint8, device=self.device)
+        self.host = torch.zeros(self.world * self.slot, dtype=torch.uint8, pin_memory=self.cuda) if self.rank == root else None
+        self.k = 0
+        self.work = None
+        self.counts = None
+        self.regions = None
+
+    def slot_for_next_finish(self):
+        """(device pointer, bytes) of the slot the next finish_contig must fill."""
+        return self.send[self.k].data_ptr(), self.slot
+
+    def _drain(self):
+        if self.work is not None:
+            self.work.wait()
+            if self.cuda:
+                torch.cuda.current_stream(self.device).synchronize()  # host-side: the other slot may be rewritten now
+            self.work = None
+
+    def launch(self):
+        """The slot handed out last is filled (finish_contig has returned): start its all-gather."""
+        self._drain()
+        src = self.send[self.k]
+        if self.nccl:
+            self.work = dist.all_gather_into_tensor(self.recv, src, group=self.group, async_op=True)
+        else:
+            self.work = dist.all_gather(list(self.recv.view(self.world, self.slot).unbind(0)), src, group=self.group, async_op=True)
+        self.k ^= 1
+
+    def finish(self):
+        """Wait for the exchange in flight; on the root: the merged table of the last exchange (uint8 numpy, rank
+        order), with .counts (rows per rank) and .regions (the five counters per rank) set."""
+        self._drain()
+        if self.rank != self.root:
+            return None
+        self.host.copy_(self.recv)
+        if self.cuda:
+            torch.cuda.current_stream(self.device).synchronize()
+        h = self.host.numpy().reshape(self.world, self.slot)
+        hdr = np.stack([h[r, :48].view(np.int64) for r in range(self.world)])
+        self.counts = [int(x) for x in hdr[:, 0]]
+        self.regions = [dict(spliced=int(a[1]), unspliced=int(a[2]), sum_len=int(a[3]), min_len=int(a[4]), max_len=int(a[5])) for a in hdr]
+        parts = [h[r, self.HDR:self.HDR + self.counts[r] * self.row_bytes] for r in range(self.world) if self.counts[r]]
+        return np.concatenate(parts) if parts else np.zeros(0, dtype=np.uint8)

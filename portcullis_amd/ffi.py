@@ -22,7 +22,7 @@ EXPORTS = [
     "pjb_create", "pjb_destroy", "pjb_last_error", "pjb_set_refs", "pjb_upload_contig", "pjb_upload_contig_device",
     "pjb_release_contig", "pjb_submit_batch", "pjb_submit_batch_device", "pjb_finish_contig", "pjb_collect",
     "pjb_clear_rows", "pjb_get_timing", "pjb_device_count", "pjb_get_kernel_timing", "pjb_reset_kernel_timing",
-    "pjb_select_timed_kernels", "pjb_host_alloc", "pjb_host_free", "pjb_inflate_bgzf", "pjb_submit_bam", "pjb_collect_device",
+    "pjb_select_timed_kernels", "pjb_host_alloc", "pjb_host_free", "pjb_inflate_bgzf", "pjb_submit_bam", "pjb_collect_device", "pjb_set_row_mirror",
 ]
 FLAG_KERNEL_TIMING = 1
 
@@ -98,6 +98,7 @@ def load():
         L.pjb_submit_batch.argtypes = [C.c_void_p, C.c_int32, C.POINTER(PjbBatch)]
         L.pjb_submit_batch_device.argtypes = [C.c_void_p, C.c_int32, C.POINTER(PjbBatch)]
         L.pjb_finish_contig.argtypes = [C.c_void_p, C.c_int32, C.POINTER(PjbRegionResult)]
+        L.pjb_set_row_mirror.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
         L.pjb_collect_device.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
         L.pjb_inflate_bgzf.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
         L.pjb_submit_bam.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_int32, C.POINTER(C.c_int64)]
@@ -212,6 +213,11 @@ class Context:
         buf = (C.c_char * (n.value * ROW_DTYPE.itemsize)).from_address(p.value)
         a = np.frombuffer(buf, dtype=ROW_DTYPE, count=n.value)
         return a.copy() if copy else a
+
+    def set_row_mirror(self, device_ptr, cap_bytes):
+        """Every following finish_contig writes a 64-byte header (int64 n_rows, spliced, unspliced, sum_len, min_len,
+        max_len) and the contig's rows into this device buffer (0 to stop)."""
+        self._check(self._L.pjb_set_row_mirror(self._h, C.c_void_p(device_ptr or None), cap_bytes))
 
     def collect_device(self):
         """(device pointer, row count) of the rows of the contig finished last, still in HBM."""

@@ -124,3 +124,45 @@ def test_row_exchange_world2(mode, monkeypatch):
                 assert outs[step] == expect.tobytes()
             else:
                 assert outs[step] is None
+
+
+def _worker_mirror(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    x = pd.MirrorExchange(ROW_DTYPE.itemsize, cap_rows=8, device=torch.device("cpu"))
+    outs = []
+    for step, n in enumerate([[3, 0], [8, 5], [1, 2]]):
+        ptr, nbytes = x.slot_for_next_finish()
+        slot = x.send[x.k]
+        assert slot.data_ptr() == ptr and nbytes == 64 + 8 * ROW_DTYPE.itemsize
+        # what pjb_finish_contig does with the mirror: header + rows
+        rows = _rows(rank + 10 * step, n[rank])
+        hdr = np.array([n[rank], 7 + rank, 1, 100 * (step + 1), 40 + rank, 90 + step, 0, 0], dtype=np.int64)
+        slot[:64] = torch.from_numpy(hdr.view(np.uint8).copy())
+        if n[rank]:
+            slot[64:64 + rows.nbytes] = torch.from_numpy(rows.view(np.uint8).copy())
+        x.launch()
+    merged = x.finish()
+    q.put((rank, None if merged is None else merged.tobytes(), x.counts, x.regions))
+    dist.destroy_process_group()
+
+
+def test_mirror_exchange_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_mirror, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=120) for _ in range(2)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, blob, counts, regions in got:
+        if rank == 0:
+            assert blob == np.concatenate([_rows(20, 1), _rows(21, 2)]).tobytes()
+            assert counts == [1, 2]
+            assert regions[1] == dict(spliced=8, unspliced=1, sum_len=300, min_len=41, max_len=92)
+        else:
+            assert blob is None
