@@ -77,7 +77,10 @@ _LIB = None
 
 
 def load():
-    """Load the HIP library; raises (never falls back) if it has not been built."""
+    """Load the HIP library; raises (never falls back) if it has not been built.
+
+    In a process that also uses torch on the GPU, import torch first: torch ships its own libamdhip64 and the copy
+    that is loaded first serves both libraries (torch does not find its devices through the system one)."""
     global _LIB
     if _LIB is None:
         if not os.path.exists(LIB_PATH):

@@ -2,6 +2,8 @@ import os
 import sys
 
 import pytest
+import torch  # noqa: F401  -- before the HIP library is loaded: torch ships its own HIP runtime, and whichever
+# copy of libamdhip64 is loaded first serves both; torch only finds its GPUs through its own
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:

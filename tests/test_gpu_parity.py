@@ -140,3 +140,37 @@ def test_seq_star_fallback(ffi, orc):
     genome = ("ACGTTGCA" * 400)
     reads = [dict(pos=100, cigar="30M100N40M", seq=None, xs="+"), dict(pos=110, cigar="20M100N45M", seq=None, xs="-")]
     run_both(ffi, orc, genome, ReadBatch.from_reads(reads))
+
+
+def test_row_mirror(ffi, orc):
+    """pjb_set_row_mirror: finish_contig leaves { n_rows, spliced, unspliced, sum_len, min_len, max_len } and the rows
+    in the caller's device buffer -- also for a contig without junctions -- and refuses a buffer that is too small."""
+    import torch
+    torch.zeros(1, device="cuda")  # torch brings its own HIP runtime: it must come up before the library's
+    genome, reads = make_reads(5, n_reads=2000)
+    batch = to_batch(reads)
+    unspliced = to_batch([r for r in reads if "N" not in r["cigar"]][:50]) if isinstance(reads[0]["cigar"], str) else None
+    with ffi.Context(0, "UNKNOWN") as ctx:
+        ctx.set_refs([len(genome)])
+        buf = torch.zeros(64 + 4000 * ffi.ROW_DTYPE.itemsize, dtype=torch.uint8, device="cuda")
+        ctx.set_row_mirror(buf.data_ptr(), buf.numel())
+        rows, reg = ffi.run_contig(ctx, 0, genome.encode(), [batch])
+        h = buf.cpu().numpy()
+        hdr = h[:48].view(np.int64)
+        assert list(hdr) == [len(rows), reg["spliced"], reg["unspliced"], reg["sum_len"], reg["min_len"], reg["max_len"]]
+        assert h[64:64 + rows.nbytes].tobytes() == rows.tobytes()
+        if unspliced is not None and unspliced.n:
+            ctx.clear_rows()
+            ctx.submit_batch(0, unspliced)
+            reg2 = ctx.finish_contig(0)
+            hdr = buf.cpu().numpy()[:48].view(np.int64)
+            assert reg2["n_junctions"] == 0 and list(hdr) == [0, 0, reg2["unspliced"], reg2["sum_len"], reg2["min_len"], reg2["max_len"]]
+        small = torch.zeros(64 + ffi.ROW_DTYPE.itemsize, dtype=torch.uint8, device="cuda")
+        ctx.set_row_mirror(small.data_ptr(), small.numel())
+        ctx.clear_rows()
+        ctx.submit_batch(0, batch)
+        with pytest.raises(ffi.PjbError):
+            ctx.finish_contig(0)
+        ctx.set_row_mirror(0, 0)
+        rows3, _ = ffi.run_contig(ctx, 0, genome.encode(), [batch])
+        assert rows3.tobytes() == rows.tobytes()
