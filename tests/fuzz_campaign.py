@@ -68,7 +68,8 @@ def main():
                     for i, r in enumerate(reads):
                         r["tid"] = 0
                         r["name"] = f"s{seed}r{i}"
-                    write_bam(path, [("c", len(genome)), ("d", 1000)], reads, block_size=int(rng.integers(300, 0xFF00)), write_index=False)
+                    write_bam(path, [("c", len(genome)), ("d", 1000)], reads, block_size=int(rng.integers(300, 0xFF00)), write_index=False,
+                              level=int(rng.integers(0, 10)))
                     raw, _, first = bam_targets(path)
                 if 0 in first:
                     coff, uoff = first[0]

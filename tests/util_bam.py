@@ -131,7 +131,7 @@ def _bgzf_block(payload, level=1):
 BGZF_EOF = bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000")
 
 
-def write_bam(path, refs, reads, block_size=0xFF00, header_text=None, write_index=True):
+def write_bam(path, refs, reads, block_size=0xFF00, header_text=None, write_index=True, level=1):
     """reads: dicts with tid,pos,cigar(str|array),seq(str|None),flag,mapq,xs,mtid,mpos,name,
     optionally aux (raw bytes appended).  Must already be coordinate sorted.
     Records may straddle BGZF blocks (block_size is a plain byte cut)."""
@@ -173,7 +173,7 @@ def write_bam(path, refs, reads, block_size=0xFF00, header_text=None, write_inde
     blocks, ustarts, coffs = [], [], []
     co = 0
     for u in range(0, total, block_size):
-        blk = _bgzf_block(bytes(stream[u:u + block_size]))
+        blk = _bgzf_block(bytes(stream[u:u + block_size]), level)
         ustarts.append(u)
         coffs.append(co)
         blocks.append(blk)
