@@ -229,3 +229,11 @@ def test_device_ingest_e2e_synthetic(tmp_path):
     finally:
         del os.environ["PORTCULLIS_INGEST"]
     assert a["tab_identical_to_oracle"] and b["tab_identical_to_oracle"] and b["junctions"] > 500
+
+
+@pytest.mark.parametrize("per_gpu", ["1", "3"])
+def test_contexts_per_gpu(tmp_path, orc, per_gpu, monkeypatch):
+    """One or several device contexts (device threads, streams) per GPU: same files."""
+    monkeypatch.setenv("PORTCULLIS_CTX_PER_GPU", per_gpu)
+    prep = multi_contig(tmp_path, [81, 82, 83, None, 84], block_size=20000)
+    check(prep, tmp_path, orc, "RF", threads=5, extra_opts=("--ingest", "device", "--devices", "1"))
