@@ -1,30 +1,48 @@
 #!/usr/bin/env python3
-"""bench.py -- throughput of the MI355X `junc` hot path on BASELINE.json's synthetic workload.
+"""bench.py -- throughput of the MI355X `junc` hot path on BASELINE.json's headline workload.
 
-A "step" is one pass of the hot path over one contig's alignment records that are
-already resident in HBM: pjb_submit_batch_device + pjb_finish_contig (CIGAR scan/emit,
-sort/group, anchors, per-pair match statistics, junction reduce) + the junction rows
-copied back to the host.  At N > 1 every rank owns one contig of the same size (the path
-shards by reference contig, src/junction_builder.cc:241-245) and the only exchange is the
-RCCL all-gather that merges the per-rank junction tables.
+Workload (every N): BASELINE.json configs[2] -- 200 M synthetic paired-end 150-bp reads over 25 contigs with
+GRCh38 lengths, ~250 k junctions, orientation FR (`portcullis_amd.synth.c3_contig_configs`).
 
-    python bench.py --gpus N --steps K --warmup W
+A "step" is one pass of the hot path over every contig's alignment records, already resident in HBM: per contig
+pjb_submit_batch_device + pjb_finish_contig (CIGAR scan/emit, sort/group, anchors, per-pair match statistics,
+junction reduce, rows to the host), then the merged row table.
+
+  N = 1   configs[2]: one GPU does all 25 contigs.
+  N > 1   configs[3]: the SAME 25 contigs sharded over the ranks by read count (longest-processing-time,
+          `distributed.shard_contigs`; the reference shards the same way over threads,
+          src/junction_builder.cc:241-245); the path's only exchange is one RCCL all-gather per step of every
+          rank's rows + read-length counters; rank 0 holds the merged table and, after the timed region, checks
+          it byte for byte against the table one GPU produces alone.  `value` = reads of the whole set / time
+          (strong scaling: the total work is fixed as N grows).
+
+    python bench.py --gpus N --steps K --warmup W      (N > 1 without a launcher: starts the N ranks itself)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One JSON line on stdout.  Beside the contract's fields it carries `roofline` (dominant kernel, HIP events inside
+the timed region), `cpu_baseline` (the oracle over the WHOLE workload on the box's host cores, one thread per
+contig like the reference; every device row compared with it) and `e2e` (the same alignments as a BGZF BAM on
+disk -> `portcullis_amd junc` -> .tab, compared with the oracle's .tab).
 """
 import argparse
+import hashlib
 import json
 import os
+import shutil
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+PEAK_HBM_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 
 
-def algorithmic_bytes(name, N, C, S, Cs, P, J, L, passes, Pg=0):
-    """Algorithmic HBM bytes of ONE launch of kernel `name` (each byte counted once per logical
-    pass, caches ignored; DESIGN.md section 4 derives these).  N reads, C cigar ops, S spliced
-    reads, Cs cigar ops of spliced reads, P pairs, J junctions, L read length."""
+def algorithmic_bytes(name, N, C, S, Cs, P, J, L, Pg=0):
+    """Algorithmic HBM bytes of ONE launch of kernel `name` over one contig (each byte counted once per logical
+    pass, caches ignored; DESIGN.md section 4 derives these).  N reads, C cigar ops, S spliced reads, Cs cigar ops
+    of spliced reads, P pairs, J junctions, L read length, Pg pairs that take the generic walks."""
     frags = P / 64.0 + J
     table = {
         # pos, cig_off, l_qseq, xs + every cigar op; 8 B written per spliced read (compacted index + pair offset)
@@ -46,22 +64,64 @@ def algorithmic_bytes(name, N, C, S, Cs, P, J, L, passes, Pg=0):
         "k4_pairs": P * (8 + 4 + 4 + 4 + 4 + 8 + 4 + 16 + 4 + 4 + 4) + frags * 196,
         "k5_frag_reduce": frags * 196 + J * 164,
         "k5_finalize": J * (192 + 24 + 48 + 200),
-        "k5_entropy_terms": P * 0 + J * 8,
+        "k5_entropy_terms": J * 8,
     }
     return table.get(name)
 
 
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as child processes.  Nothing in this
+    process has touched the GPU (torch is not even imported yet); the children inherit a clean state."""
+    port = os.environ.get("MASTER_PORT") or str(free_port())
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=port, HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    sys.exit(rc)
+
+
+def contig_stats(batch):
+    """Counts the byte formulas need (cigar ops of spliced reads)."""
+    import torch
+    cig_off = batch["cig_off"].to(torch.int64)
+    n_ops = cig_off[1:] - cig_off[:-1]
+    seq_off = batch["seq_off"].to(torch.int64)
+    spl = (seq_off[1:] - seq_off[:-1]) > 0
+    return int(n_ops[spl].sum())
+
+
 def main():
-    # exactly one line on stdout: everything the libraries print (RCCL banners, ...) goes to stderr
-    real_stdout = os.dup(1)
-    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", default=os.environ.get("PJB_BENCH_CONFIG", "C2"))
+    ap.add_argument("--reads", type=int, default=int(os.environ.get("PJB_BENCH_READS", 200_000_000)),
+                    help="total reads of the 25-contig set (200 M = BASELINE configs[2]; smaller values are for tests)")
+    ap.add_argument("--junctions", type=int, default=int(os.environ.get("PJB_BENCH_JUNCTIONS", 250_000)))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-e2e", action="store_true", default=os.environ.get("PJB_BENCH_E2E", "1") == "0")
+    ap.add_argument("--e2e-workdir", default=os.environ.get("PJB_BENCH_WORKDIR", "/tmp/pjb_bench_e2e"))
+    ap.add_argument("--no-verify", action="store_true", help="N > 1: skip rank 0's single-GPU re-run of the whole set")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args.gpus)
+
+    # exactly one line on stdout: everything the libraries print (RCCL banners, ...) goes to stderr
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
 
     import numpy as np
     import torch
@@ -75,31 +135,52 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False (no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # PJB_BENCH_SHARE_GPU=1: every rank uses GPU 0 and the exchange runs over gloo (a one-GPU box can then walk
+    # through the N > 1 code path; never a measurement)
+    share = os.environ.get("PJB_BENCH_SHARE_GPU") == "1"
+    dev_index = 0 if share else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     # PJB_BENCH_FORCE_EXCHANGE=1 runs the N > 1 exchange code with a one-rank group (single-GPU check of that path)
     force_x = world == 1 and os.environ.get("PJB_BENCH_FORCE_EXCHANGE") == "1"
-    if world > 1 or force_x:
+    multi = world > 1 or force_x
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if force_x:
-            os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        if share:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        elif force_x:
             dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
         else:
             dist.init_process_group("nccl", device_id=dev)
-    multi = world > 1 or force_x
 
-    cfg = synth.CONFIGS[args.config]
+    # ------------------------------------------------------------------ workload: the 25-contig set, sharded by contig
+    cfgs = synth.c3_contig_configs(args.reads, args.junctions)
+    lens = [c.contig_len for c in cfgs]
+    shards = pd.shard_contigs([c.n_reads for c in cfgs], world)
+    mine = shards[rank]
+    L = cfgs[0].read_len
+    ORI = "FR"
+
+    ctx = ffi.Context(device=dev_index, orientation=ORI, flags=ffi.FLAG_KERNEL_TIMING)
+    ctx.set_refs(lens)
     t_gen = time.time()
-    data = synth.generate(cfg, device=dev, seed=cfg.seed + rank)
+    contigs = {}  # tid -> dict(batch, n, P, C, S, Cs)
+
+    def load_contig(tid, into_ctx):
+        d = synth.generate(cfgs[tid], device=dev, tid=tid)
+        into_ctx.upload_contig_device(tid, d["genome"])
+        return dict(batch=d["batch"], genome=d["genome"], n=d["n_reads"], P=d["n_pairs"], C=d["n_cigar_ops"],
+                    S=d["n_spliced"], Cs=contig_stats(d["batch"]))
+
+    for tid in mine:
+        contigs[tid] = load_contig(tid, ctx)
     torch.cuda.synchronize()
     t_gen = time.time() - t_gen
-    batch, genome = data["batch"], data["genome"]
-    N, P, C, S = data["n_reads"], data["n_pairs"], data["n_cigar_ops"], data["n_spliced"]
-    L = cfg.read_len
-
-    ctx = ffi.Context(device=local_rank, orientation="UNKNOWN", flags=ffi.FLAG_KERNEL_TIMING)
-    ctx.set_refs([cfg.contig_len])
-    ctx.upload_contig_device(0, genome)
+    hbm_gb = torch.cuda.memory_allocated() / 1e9
+    N_mine = sum(c["n"] for c in contigs.values())
+    P_mine = sum(c["P"] for c in contigs.values())
+    N_total = sum(c.n_reads for c in cfgs)
 
     state = {}
     xchg = None
@@ -107,40 +188,54 @@ def main():
 
     def step():
         ctx.clear_rows()
-        ctx.submit_batch_device(0, batch, N)
         if xchg is not None:
-            ctx.set_row_mirror(*xchg.slot_for_next_finish())  # finish_contig leaves header + rows in the exchange slot
-        reg = ctx.finish_contig(0)
+            ctx.set_row_mirror(*xchg.slot_for_next_finish())  # every finish appends header + rows to the exchange slot
+        regs = {}
+        for tid in mine:
+            c = contigs[tid]
+            ctx.submit_batch_device(tid, c["batch"], c["n"])
+            regs[tid] = ctx.finish_contig(tid)
+            if state.get("want_timing"):
+                state.setdefault("per_contig", {})[tid] = ctx.timing()
+        if not mine:
+            ctx.finish_contig(0)  # a rank without contigs still publishes an (empty) header
         rows = ctx.collect(copy=False)  # view of the pinned row table
         if xchg is not None:
-            # the path's only exchange: the merge of the per-rank junction tables and read-length counters (they ride in
-            # the slot's header): all-gather over RCCL / xGMI straight from HBM, asynchronous -- it overlaps the next
-            # contig's kernels.  Every rank's own rows are on its host after finish_contig; rank 0 copies the merged
-            # table to its host once, at the end of the timed region (a job merges once, not once per contig)
+            # the path's only exchange: the merge of the per-rank junction tables and read-length counters (they
+            # ride in the slot's header): ONE all-gather per step over RCCL / xGMI straight from HBM, asynchronous
+            # -- it overlaps the next step's kernels.  Rank 0 copies the merged table to its host once, at the end
+            # of the timed region (a job merges once)
             xchg.launch()
-        state["reg"] = reg
+        state["regs"] = regs
         state["rows"] = rows
 
-    for _ in range(args.warmup):
+    for _ in range(max(args.warmup, 1 if multi else 0)):
         step()
     if multi:
-        if not state:
-            step()
         # slot size of the row exchange: the largest table any rank produced in the warm-up, with headroom
-        jmax = torch.tensor([int(state["reg"]["n_junctions"])], device=dev, dtype=torch.int64)
+        jmax = torch.tensor([len(state["rows"])], dtype=torch.int64, device="cpu" if share else dev)
         dist.all_reduce(jmax, op=dist.ReduceOp.MAX)
         xchg = pd.MirrorExchange(row_bytes, int(jmax.item()) * 5 // 4 + 64, dev)
         step()  # one untimed step with the exchange (buffers, communicator warm-up)
         xchg.finish()
     # per-kernel table from a few fully instrumented steps (outside the timed region) ...
     ctx.reset_kernel_timing()
-    n_prof = 3
+    n_prof = 2
+    state["want_timing"] = True  # sort passes / generic pairs per contig, for the byte formulas
     for _ in range(n_prof):
         step()
+    state["want_timing"] = False
+    if xchg is not None:
+        xchg.finish()
     kt_all = ctx.kernel_timing()
-    dominant = max(kt_all.items(), key=lambda kv: kv[1][1])[0]
+    dominant = max(kt_all.items(), key=lambda kv: kv[1][1])[0] if kt_all else None
+    if multi:  # every rank brackets the same kernel (rank 0's choice)
+        names = sorted(kt_all)
+        pick = torch.tensor([names.index(dominant) if dominant else 0], dtype=torch.int64, device="cpu" if share else dev)
+        dist.broadcast(pick, 0)
+        dominant = names[int(pick.item())] if names else None
     # ... and only the dominant kernel keeps its HIP-event bracket inside the timed region
-    ctx.select_timed_kernels([dominant])
+    ctx.select_timed_kernels([dominant] if dominant else [])
     ctx.reset_kernel_timing()
     if world > 1:
         dist.barrier()
@@ -149,117 +244,158 @@ def main():
     for _ in range(args.steps):
         step()
     merged = xchg.finish() if xchg is not None else None  # the last exchange completes inside the timed region
-    if xchg is not None and rank == 0:
-        tot = xchg.regions  # per-rank read-length counters of the last exchange -> the global ones
-        state["totals"] = dict(spliced=sum(r["spliced"] for r in tot), unspliced=sum(r["unspliced"] for r in tot),
-                               sum_len=sum(r["sum_len"] for r in tot), min_len=min(r["min_len"] for r in tot),
-                               max_len=max(r["max_len"] for r in tot))
-        assert state["totals"]["spliced"] + state["totals"]["unspliced"] >= N
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if share else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    reg, rows = state["reg"], state["rows"].copy()
-    if xchg is not None and rank == 0:
-        # merged table on rank 0: every rank's rows, in rank order; this rank's part must be its own table
+    regs, rows = state["regs"], state["rows"].copy()
+    assert sum(r["n_reads"] for r in regs.values()) == N_mine and sum(r["n_pairs"] for r in regs.values()) == P_mine
+    assert int(rows["nb_raw"].astype(np.int64).sum()) == P_mine  # every N op lands in exactly one junction row
+    J_mine = len(rows)
+
+    n_ranks_seen = dist.get_world_size() if multi else 1
+    merged_rows = rows
+    if multi and rank == 0:
+        # merged table on rank 0: every rank's rows in rank order -> contig order, counters folded
         mt = merged.view(ffi.ROW_DTYPE)
         assert len(mt) == sum(xchg.counts) and xchg.counts[0] == len(rows)
         assert mt[: len(rows)].tobytes() == rows.tobytes()
-    J = int(reg["n_junctions"])
-    assert reg["n_pairs"] == P and reg["n_reads"] == N
-    # size-independent sanity (full-size parity properties are in tests/test_gpu_fullsize.py)
-    assert int(rows["nb_raw"].sum()) == P
+        merged_rows, totals = pd.merge_rank_tables(merged, ffi.ROW_DTYPE, xchg.regions)
+        assert totals["spliced"] + totals["unspliced"] == N_total, (totals, N_total)
+        assert totals["sum_len"] == N_total * L
+    J_total = len(merged_rows) if rank == 0 else 0
 
-    totals = torch.tensor([N, J], device=dev, dtype=torch.int64)
-    if world > 1:
-        dist.all_reduce(totals)
-    reads_total, junc_total = int(totals[0]), int(totals[1])
+    # ---- N > 1: the merged table must equal what ONE GPU produces for the whole set
+    verify = None
+    if world > 1 and not args.no_verify:
+        if rank == 0:
+            t_v = time.time()
+            ctx1 = ffi.Context(device=dev_index, orientation=ORI)
+            ctx1.set_refs(lens)
+            ctx1.clear_rows()
+            for tid in range(len(cfgs)):
+                c = contigs.get(tid) or load_contig(tid, ctx1)
+                if tid in contigs:
+                    ctx1.upload_contig_device(tid, c["genome"])
+                ctx1.submit_batch_device(tid, c["batch"], c["n"])
+                ctx1.finish_contig(tid)
+                ctx1.release_contig(tid)
+                del c
+            single = ctx1.collect()
+            ctx1.close()
+            same = single.tobytes() == merged_rows.tobytes()
+            verify = dict(merged_equals_single_gpu_table=bool(same), rows=len(single), md5=hashlib.md5(single.tobytes()).hexdigest(),
+                          seconds=round(time.time() - t_v, 1))
+            assert same, "merged multi-GPU table differs from the single-GPU table"
+        dist.barrier()
 
     # ---- per-kernel device time over the timed region (HIP events on the context's stream)
-    kt_timed = ctx.kernel_timing()
-    kt = {k: (v[0] / n_prof * args.steps, v[1] / n_prof * args.steps) for k, v in kt_all.items()}
-    kt[dominant] = kt_timed[dominant]  # measured live over the timed region
-    timing = ctx.timing()
-    sort_passes = int(timing["sort_passes"])
-    cs_ops = None
-    if rank == 0:
-        # cigar ops of spliced reads (for the byte formulas)
-        cig_off = batch["cig_off"].to(torch.int64)
-        n_ops = cig_off[1:] - cig_off[:-1]
-        seq_off = batch["seq_off"].to(torch.int64)
-        spl = (seq_off[1:] - seq_off[:-1]) > 0
-        cs_ops = int(n_ops[spl].sum())
     result = None
     if rank == 0:
+        kt_timed = ctx.kernel_timing()
+        kt = {k: (v[0] / n_prof * args.steps, v[1] / n_prof * args.steps) for k, v in kt_all.items()}
+        if dominant:
+            kt[dominant] = kt_timed[dominant]  # measured live over the timed region
+        per = state.get("per_contig", {})
         kern = []
         for name, (launches, ms) in kt.items():
             if launches == 0:
                 continue
-            avg = ms / launches
-            b = algorithmic_bytes(name, N, C, S, cs_ops, P, J, L, sort_passes, int(timing.get("generic_pairs", 0)))
-            kern.append(dict(name=name, launches=launches, avg_ms=avg, total_ms=ms,
-                             alg_bytes=b, gbps=(b / (avg * 1e-3) / 1e9) if b else None))
+            # algorithmic bytes of this kernel over one step = sum over this rank's contigs (x sort passes)
+            tot_b = 0.0
+            known = True
+            for tid in mine:
+                c = contigs[tid]
+                Jc = int(regs[tid]["n_junctions"])
+                b = algorithmic_bytes(name, c["n"], c["C"], c["S"], c["Cs"], c["P"], Jc, L, int(per[tid].get("generic_pairs", 0)))
+                if b is None:
+                    known = False
+                    break
+                mult = int(per[tid]["sort_passes"]) if name in ("rs_hist", "rs_scatter") else 1
+                tot_b += b * mult
+            per_step = launches / args.steps
+            kern.append(dict(name=name, launches=launches, avg_ms=ms / launches, total_ms=ms,
+                             alg_bytes=(tot_b / per_step) if known and per_step else None))
+        for k in kern:
+            k["gbps"] = (k["alg_bytes"] / (k["avg_ms"] * 1e-3) / 1e9) if k["alg_bytes"] else None
         kern.sort(key=lambda k: -k["total_ms"])
-        dom = kern[0]
-        peak = 8000.0
+        dom = next((k for k in kern if k["name"] == dominant), kern[0])
         roofline = dict(bound="hbm", kernel=dom["name"], achieved=round(dom["gbps"], 1) if dom["gbps"] else None,
-                        peak=peak, unit="GB/s", frac=round(dom["gbps"] / peak, 4) if dom["gbps"] else None,
-                        traffic=None, avg_kernel_ms=round(dom["avg_ms"], 4),
-                        alg_bytes_per_launch=int(dom["alg_bytes"]) if dom["alg_bytes"] else None)
+                        peak=PEAK_HBM_GBPS, unit="GB/s", frac=round(dom["gbps"] / PEAK_HBM_GBPS, 4) if dom["gbps"] else None,
+                        traffic=None, avg_kernel_ms=round(dom["avg_ms"], 5),
+                        alg_bytes_per_launch=int(dom["alg_bytes"]) if dom["alg_bytes"] else None,
+                        launches_per_step=dom["launches"] / args.steps,
+                        note="achieved = algorithmic bytes per launch (DESIGN.md section 4, averaged over the step's launches: "
+                             "contigs differ in size) / average launch duration, HIP events on the context's stream inside the timed region")
         kernel_ms_per_step = sum(k["total_ms"] for k in kern) / args.steps
-        # HBM bytes per launch from the PMC counters (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 --pmc
-        # passes of this same command: tools/pmc_traffic.sh -> tools/summarize_pmc.py); counters cannot be
-        # read from inside the process, so the last committed measurement for this workload is attached
+        # HBM bytes per launch from the PMC counters (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 --pmc passes of
+        # this same command: tools/pmc_traffic.sh -> tools/summarize_pmc.py).  Counters cannot be read from inside
+        # the process; the committed measurement for this workload is attached with the commit it was taken at.
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic_latest.json")
-        if args.config == "C2" and os.path.exists(tpath):
+        if world == 1 and args.reads == 200_000_000 and os.path.exists(tpath):
             try:
-                tr = json.load(open(tpath)).get("pjb::" + dom["name"])
-                if tr:
-                    roofline["traffic"] = tr["hbm_bytes_per_launch"]
-                    roofline["traffic_source"] = "profiles/pmc_traffic_latest.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"
+                tj = json.load(open(tpath))
+                if tj.get("_workload") == "C3":
+                    tr = tj.get("pjb::" + dom["name"])
+                    if tr:
+                        roofline["traffic"] = tr["hbm_bytes_per_launch"]
+                        roofline["traffic_source"] = ("profiles/pmc_traffic_latest.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
+                                                      f"passes of this command at commit {tj.get('_commit', '?')})")
             except Exception:
                 pass
 
         cpu = None
+        oracle_tab_md5 = None
         if world == 1 and not args.no_cpu_baseline:
-            cpu = cpu_baseline(data, cfg, ctx, ffi, synth)
+            cpu, oracle_tab_md5, oracle_tab_len = cpu_baseline(contigs, cfgs, rows, regs, ORI, synth)
+        e2e = None
+        if world == 1 and not args.no_e2e:
+            try:
+                e2e = e2e_leg(contigs, cfgs, args.e2e_workdir, ORI, oracle_tab_md5)
+            except Exception as ex:  # the e2e leg must never cost the bench line
+                e2e = {"error": f"{type(ex).__name__}: {ex}"[:500]}
+            shutil.rmtree(args.e2e_workdir, ignore_errors=True)
 
+        tot_bytes = sum((k["alg_bytes"] or 0) * k["launches"] / args.steps for k in kern)
+        cfg_name = "configs[2]" if world == 1 else "configs[3]"
         result = {
             "metric": "junc_reads_per_sec",
-            "value": reads_total * args.steps / elapsed,
+            "value": N_total * args.steps / elapsed,
             "unit": "reads/s",
-            "n_gpus": world,
+            "n_gpus": n_ranks_seen,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong",
             "vs_baseline": None,
             "dtype": "int32",
             "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[1] ({cfg.name}): synthetic {cfg.n_reads} single-end {L}-bp reads, "
-                                   f"1 contig of {cfg.contig_len} bp per GPU, {J} junctions, {P} spliced pairs",
-                       "reads_per_gpu": N, "pairs_per_gpu": P, "junctions_per_gpu": J, "sharding": "by contig",
-                       "input": "device-resident SoA records (pjb_submit_batch_device)"},
-            "junctions_per_sec": junc_total * args.steps / elapsed,
+            "config": {"workload": f"BASELINE {cfg_name}: synthetic {N_total} paired-end {L}-bp reads, {len(cfgs)} contigs of "
+                                   f"GRCh38 lengths ({sum(lens)} bp), {J_total} junctions, orientation {ORI}"
+                                   + ("" if world == 1 else f", contigs sharded over {world} GPUs by read count (LPT), "
+                                      "one RCCL all-gather of rows + counters per step"),
+                       "reads_total": N_total, "junctions_total": J_total, "contigs": len(cfgs),
+                       "contigs_per_rank": [len(s) for s in shards], "reads_rank0": N_mine, "pairs_rank0": P_mine,
+                       "sharding": "by contig", "input": "device-resident SoA records (pjb_submit_batch_device)",
+                       "hbm_resident_gb_rank0": round(hbm_gb, 2)},
+            "junctions_per_sec": J_total * args.steps / elapsed,
             "roofline": roofline,
             "cpu_baseline": cpu,
+            "e2e": e2e,
+            "multi_gpu_check": verify,
             "device_kernel_ms_per_step": round(kernel_ms_per_step, 4),
-            "pipeline_gbps": None,
-            "sort_passes": sort_passes,
-            "generic_pairs": int(timing.get("generic_pairs", 0)),
-            "kernels": [dict(name=k["name"], launches_per_step=k["launches"] / args.steps, avg_ms=round(k["avg_ms"], 4),
+            "non_kernel_share": round(1.0 - kernel_ms_per_step / (elapsed / args.steps * 1e3), 4),
+            "pipeline_gbps": round(tot_bytes / (kernel_ms_per_step * 1e-3) / 1e9, 1) if kernel_ms_per_step else None,
+            "kernels": [dict(name=k["name"], launches_per_step=k["launches"] / args.steps, avg_ms=round(k["avg_ms"], 5),
+                             ms_per_step=round(k["total_ms"] / args.steps, 4),
                              gbps=round(k["gbps"], 1) if k["gbps"] else None) for k in kern],
             "datagen_s": round(t_gen, 2),
-            "finish_contig_event_ms": round(timing["total_ms"], 4),
         }
-        # pipeline_gbps: sum over kernels of (bytes per launch x launches per step) / device kernel time per step
-        tot_bytes = sum((k["alg_bytes"] or 0) * k["launches"] / args.steps for k in kern)
-        result["pipeline_gbps"] = round(tot_bytes / (kernel_ms_per_step * 1e-3) / 1e9, 1)
         os.write(real_stdout, (json.dumps(result) + "\n").encode())
     ctx.set_row_mirror(0, 0)
     ctx.close()
@@ -267,50 +403,132 @@ def main():
         dist.destroy_process_group()
 
 
-def cpu_baseline(data, cfg, ctx, ffi, synth):
-    """Time the CPU oracle (single thread, kind "port") on a bounded prefix of the same records
-    and check the device rows for that prefix against it."""
+def host_cores():
+    """Cores this process may really use: the cgroup quota if there is one, else the affinity mask."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(per))))
+    except Exception:
+        pass
+    return n
+
+
+def cpu_baseline(contigs, cfgs, dev_rows, dev_regs, orientation, synth):
+    """The CPU oracle (oracle/portcullis_oracle.c, kind "port") over the WHOLE workload on the box's host cores:
+    one thread per contig, longest first, exactly the parallelism the reference has (one thread per target,
+    src/junction_builder.cc:241-245).  The sample is bounded by construction (about 25 s of single-core work for
+    the 200 M-read set).  Every device row of the timed run is compared with the oracle's."""
+    import concurrent.futures as cf
+
     import numpy as np
 
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from oracle import oracle as orc
     from parity import assert_rows_equal, region_equal
 
-    N = data["n_reads"]
-    genome_host = data["genome"].cpu().numpy().tobytes()
-    # pilot on 1M reads to size the sample for ~15 s of CPU work
-    pilot = min(N, 1_000_000)
-    hb = synth.batch_to_numpy(data["batch"], 0, pilot)
-    t = time.perf_counter()
-    orows, oreg = orc.find_juncs(0, cfg.contig_len, genome_host, hb.to_oracle(), "UNKNOWN")
-    dt = time.perf_counter() - t
-    rate = pilot / dt
-    M = int(min(N, max(pilot, rate * 15.0)))
-    reps = 1
-    if M > pilot:
-        hb = synth.batch_to_numpy(data["batch"], 0, M)
-        ob = hb.to_oracle()
-        # the whole workload fits the budget several times over: repeat it (about 10 s of CPU work) and take the median
-        reps = int(max(1, min(12, round(10.0 / max(M / rate, 1e-3)))))
-        times = []
-        for _ in range(reps):
-            t = time.perf_counter()
-            orows, oreg = orc.find_juncs(0, cfg.contig_len, genome_host, ob, "UNKNOWN")
-            times.append(time.perf_counter() - t)
-        times.sort()
-        dt = times[len(times) // 2]
-    # parity of the device path on exactly this sample
-    ctx.clear_rows()
-    ctx.submit_batch(0, hb)
-    dreg = ctx.finish_contig(0)
-    drows = ctx.collect()
-    region_equal(dreg, oreg)
-    max_ent = assert_rows_equal(drows, orows)
-    return {"value": M / dt, "unit": "reads/s", "cores": 1, "kind": "port",
-            "sample": f"first {M} of {N} records of the same workload ({len(orows)} junctions), oracle/portcullis_oracle.c, "
-                      f"median of {reps} runs of {dt:.2f} s; device rows for the sample match the oracle "
-                      f"(max |entropy diff| {max_ent:.2g})",
-            "junctions_per_sec": len(orows) / dt}
+    cores = min(host_cores(), len(contigs))
+    order = sorted(contigs, key=lambda t: -contigs[t]["n"])
+    lens = [c.contig_len for c in cfgs]
+
+    def run(tid):
+        c = contigs[tid]
+        hb = synth.batch_to_numpy(c["batch"], 0, c["n"]).to_oracle()
+        g = c["genome"].cpu().numpy().tobytes()
+        t = time.perf_counter()
+        orows, oreg = orc.find_juncs(tid, lens[tid], g, hb, orientation)  # the C call releases the GIL
+        return tid, orows, oreg, time.perf_counter() - t
+
+    orc.lib()
+    t0 = time.perf_counter()
+    out = {}
+    with cf.ThreadPoolExecutor(max_workers=cores) as ex:
+        for tid, orows, oreg, dt in ex.map(run, order):
+            out[tid] = (orows, oreg, dt)
+    wall = time.perf_counter() - t0
+    cpu_s = sum(v[2] for v in out.values())
+    worst = 0.0
+    n_reads = 0
+    for tid in sorted(out):
+        orows, oreg, _ = out[tid]
+        region_equal(dev_regs[tid], oreg)
+        worst = max(worst, assert_rows_equal(dev_rows[dev_rows["refid"] == tid], orows))
+        n_reads += contigs[tid]["n"]
+    # the oracle's .tab for the whole set (merge, global mean read length, calcJunctionStats, writer)
+    allrows = np.concatenate([out[t][0] for t in sorted(out)])
+    tot = sum(out[t][1]["spliced"] + out[t][1]["unspliced"] for t in out)
+    mean = sum(out[t][1]["sum_len"] for t in out) / tot
+    allrows = orc.finalize(allrows, mean)
+    tab = orc.write_tab(allrows, list(synth.GRCH38_NAMES[: len(cfgs)]), lens)
+    longest = max(v[2] for v in out.values())
+    return ({"value": n_reads / wall, "unit": "reads/s", "cores": cores, "kind": "port",
+             "sample": f"the whole workload: {n_reads} records of {len(out)} contigs ({len(allrows)} junctions), "
+                       f"oracle/portcullis_oracle.c on pre-decoded records, one thread per contig on {cores} cores: "
+                       f"{wall:.1f} s wall including the records' copy out of HBM, {cpu_s:.1f} s of oracle CPU time, longest contig {longest:.1f} s; "
+                       f"every device row of the timed run equals the oracle's (integers bit-exact, max |entropy diff| {worst:.2g})",
+             "single_core_reads_per_sec": n_reads / cpu_s,
+             "junctions_per_sec": len(allrows) / wall},
+            hashlib.md5(tab).hexdigest(), len(tab))
+
+
+def e2e_leg(contigs, cfgs, workdir, orientation, oracle_tab_md5):
+    """End to end on the same alignments: BGZF BAM + FASTA on disk (a Portcullis prep directory written by
+    tools/soa2bam from the records in HBM) -> `portcullis_amd junc` (file bytes -> pjb_submit_bam: inflate, record
+    parse and the junc pipeline on the device; merge, calcJunctionStats and the writers on the host) -> .tab,
+    whose md5 must equal the oracle's .tab for the whole workload."""
+    from portcullis_amd import synth
+
+    t_all = time.time()
+    shutil.rmtree(workdir, ignore_errors=True)
+    prep = os.path.join(workdir, "prep")
+    os.makedirs(prep)
+    ext = dict(pos="i32", flag="u16", mapq="u8", xs="u8", l_qseq="i32", mtid="i32", mpos="i32", cig_off="u32",
+               cigar="u32", seq_off="u32", seq4="u8")
+    dirs = []
+    t0 = time.time()
+    for tid in sorted(contigs):
+        d = os.path.join(workdir, f"contig{tid}")
+        os.makedirs(d)
+        open(os.path.join(d, "name.txt"), "w").write(synth.GRCH38_NAMES[tid])
+        contigs[tid]["genome"].cpu().numpy().tofile(os.path.join(d, "genome.u8"))
+        for k, e in ext.items():
+            contigs[tid]["batch"][k].cpu().numpy().tofile(os.path.join(d, f"{k}.{e}"))
+        dirs.append(d)
+    t_dump = time.time() - t0
+    exe = os.path.join(ROOT, "tools", "soa2bam")
+    if not os.path.exists(exe):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-o", exe, os.path.join(ROOT, "tools", "soa2bam.cc"), "-lz", "-lpthread"])
+    cores = host_cores()
+    t0 = time.time()
+    subprocess.check_call([exe, prep, str(cores)] + dirs, stdout=subprocess.DEVNULL)
+    t_bam = time.time() - t0
+    for d in dirs:
+        shutil.rmtree(d, ignore_errors=True)
+    bam = os.path.join(prep, "portcullis.sorted.alignments.bam")
+    bam_bytes = os.path.getsize(bam)
+    cli = os.path.join(ROOT, "portcullis_amd", "host", "portcullis_amd")
+    n_reads = sum(c["n"] for c in contigs.values())
+    walls = []
+    out = os.path.join(workdir, "out", "pc")
+    for _ in range(2):
+        t = time.time()
+        p = subprocess.run([cli, "junc", "-t", str(cores), "--orientation", orientation, "-o", out, prep],
+                           capture_output=True, text=True)
+        walls.append(time.time() - t)
+        if p.returncode != 0:
+            raise RuntimeError("portcullis_amd junc failed: " + (p.stderr or p.stdout)[-400:])
+    tab = open(out + ".junctions.tab", "rb").read()
+    md5 = hashlib.md5(tab).hexdigest()
+    res = {"wall_s": round(min(walls), 3), "runs_s": [round(w, 3) for w in walls], "reads_per_sec": n_reads / min(walls),
+           "reads": n_reads, "bam_gb": round(bam_bytes / 1e9, 2), "host_cores": cores,
+           "junctions": tab.count(b"\n") - 2, "tab_md5": md5, "oracle_tab_md5": oracle_tab_md5,
+           "tab_identical_to_oracle": (md5 == oracle_tab_md5) if oracle_tab_md5 else None,
+           "path": "BGZF BAM bytes on disk (page cache warm) -> portcullis_amd junc (device ingest: pjb_submit_bam) -> .junctions.tab/.bed",
+           "prep_s": {"dump_soa": round(t_dump, 1), "soa2bam": round(t_bam, 1)}, "leg_s": round(time.time() - t_all, 1)}
+    if oracle_tab_md5 and md5 != oracle_tab_md5:
+        raise RuntimeError(f"e2e .tab md5 {md5} differs from the oracle's {oracle_tab_md5}")
+    return res
 
 
 if __name__ == "__main__":

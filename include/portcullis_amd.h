@@ -211,9 +211,12 @@ int pjb_collect(pjb_ctx *ctx, const pjb_junction_row **rows, int64_t *n_rows);
 int pjb_collect_device(pjb_ctx *ctx, const pjb_junction_row **device_rows, int64_t *n_rows);
 /* A device buffer of the caller's (cap_bytes, 0 / NULL to stop) that every following pjb_finish_contig fills
  * before it returns: a 64-byte header of int64 { n_rows, spliced, unspliced, sum_len, min_len, max_len, 0, 0 }
- * followed by the contig's rows.  It is the send slot of the multi-GPU merge: when pjb_finish_contig returns
- * the slot can go straight into an all-gather, without a copy or a synchronisation on the caller's side.
- * A contig whose rows do not fit fails with PJB_ERR_ARG. */
+ * followed by rows.  The buffer ACCUMULATES: the rows of every contig finished since the last
+ * pjb_set_row_mirror / pjb_clear_rows are appended in finish order and the header holds the row total and the
+ * folded counters (sums, min, max), so a rank that owns several contigs has ONE send slot per merge.  It is the
+ * send slot of the multi-GPU merge (JunctionSystem::append + the counter sums of src/junction_builder.cc:258-269):
+ * when pjb_finish_contig returns the slot can go straight into an all-gather, without a copy or a
+ * synchronisation on the caller's side.  Rows that do not fit fail with PJB_ERR_ARG. */
 #define PJB_MIRROR_HEADER_BYTES 64
 int pjb_set_row_mirror(pjb_ctx *ctx, void *device_buffer, int64_t cap_bytes);
 int pjb_clear_rows(pjb_ctx *ctx);

@@ -80,6 +80,10 @@ struct pjb_ctx {
     uint8_t *mirror = nullptr; // caller's device buffer filled by every finish (header + rows)
     size_t mirror_cap = 0;
     int64_t *mirror_hdr = nullptr; // page-locked staging of the header
+    // the mirror accumulates: rows of every finish since the last pjb_set_row_mirror / pjb_clear_rows are appended and
+    // the header holds the folded counters (a rank that owns several contigs sends ONE slot per merge)
+    size_t mirror_rows = 0;
+    int64_t mirror_acc[5] = {0, 0, 0, INT32_MAX, 0}; // spliced, unspliced, sum_len, min_len, max_len
     pjb_timing timing;
     hipEvent_t ev[PJB_N_STAGES + 2];
     int radix_max_bits = 11;
@@ -588,12 +592,28 @@ int pjb_submit_batch(pjb_ctx *c, int32_t tid, const pjb_batch *b) { return add_b
 int pjb_submit_batch_device(pjb_ctx *c, int32_t tid, const pjb_batch *b) { return add_batch(c, tid, b, true); }
 
 // a contig without junctions still reports its counters through the row mirror
+static void mirror_fold(pjb_ctx *c, const pjb_region_result &R, size_t new_rows) {
+    c->mirror_rows += new_rows;
+    c->mirror_acc[0] += (int64_t)R.spliced;
+    c->mirror_acc[1] += (int64_t)R.unspliced;
+    c->mirror_acc[2] += (int64_t)R.sum_len;
+    c->mirror_acc[3] = std::min<int64_t>(c->mirror_acc[3], R.min_len);
+    c->mirror_acc[4] = std::max<int64_t>(c->mirror_acc[4], R.max_len);
+    int64_t *h = c->mirror_hdr;
+    h[0] = (int64_t)c->mirror_rows;
+    for (int k = 0; k < 5; k++) h[1 + k] = c->mirror_acc[k];
+    h[6] = h[7] = 0;
+}
+static void mirror_reset(pjb_ctx *c) {
+    c->mirror_rows = 0;
+    c->mirror_acc[0] = c->mirror_acc[1] = c->mirror_acc[2] = 0;
+    c->mirror_acc[3] = INT32_MAX;
+    c->mirror_acc[4] = 0;
+}
 static int mirror_header_only(pjb_ctx *c, const pjb_region_result &R) {
     if (!c->mirror) return PJB_OK;
-    int64_t *h = c->mirror_hdr;
-    h[0] = 0; h[1] = (int64_t)R.spliced; h[2] = (int64_t)R.unspliced; h[3] = (int64_t)R.sum_len;
-    h[4] = (int64_t)R.min_len; h[5] = (int64_t)R.max_len; h[6] = h[7] = 0;
-    HIP_TRY(c, hipMemcpyAsync(c->mirror, h, PJB_MIRROR_HEADER_BYTES, hipMemcpyHostToDevice, c->stream));
+    mirror_fold(c, R, 0);
+    HIP_TRY(c, hipMemcpyAsync(c->mirror, c->mirror_hdr, PJB_MIRROR_HEADER_BYTES, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return PJB_OK;
 }
@@ -876,13 +896,13 @@ int pjb_finish_contig(pjb_ctx *c, int32_t tid, pjb_region_result *res) {
     }
     HIP_TRY(c, hipMemcpyAsync(c->rows_pinned + old, c->b_rows.p, (size_t)J * sizeof(pjb_junction_row), hipMemcpyDeviceToHost, st));
     if (c->mirror) { // header + rows into the caller's exchange slot, covered by the synchronisation below
-        const size_t need = PJB_MIRROR_HEADER_BYTES + (size_t)J * sizeof(pjb_junction_row);
-        if (need > c->mirror_cap) return fail(c, PJB_ERR_ARG, "finish: %u rows do not fit the row mirror (%zu bytes)", J, c->mirror_cap);
-        int64_t *h = c->mirror_hdr;
-        h[0] = (int64_t)J; h[1] = (int64_t)R.spliced; h[2] = (int64_t)R.unspliced; h[3] = (int64_t)R.sum_len;
-        h[4] = (int64_t)R.min_len; h[5] = (int64_t)R.max_len; h[6] = h[7] = 0;
-        HIP_TRY(c, hipMemcpyAsync(c->mirror, h, PJB_MIRROR_HEADER_BYTES, hipMemcpyHostToDevice, st));
-        HIP_TRY(c, hipMemcpyAsync(c->mirror + PJB_MIRROR_HEADER_BYTES, c->b_rows.p, (size_t)J * sizeof(pjb_junction_row), hipMemcpyDeviceToDevice, st));
+        const size_t at = PJB_MIRROR_HEADER_BYTES + c->mirror_rows * sizeof(pjb_junction_row);
+        const size_t need = at + (size_t)J * sizeof(pjb_junction_row);
+        if (need > c->mirror_cap)
+            return fail(c, PJB_ERR_ARG, "finish: %zu rows do not fit the row mirror (%zu bytes)", c->mirror_rows + J, c->mirror_cap);
+        mirror_fold(c, R, J);
+        HIP_TRY(c, hipMemcpyAsync(c->mirror, c->mirror_hdr, PJB_MIRROR_HEADER_BYTES, hipMemcpyHostToDevice, st));
+        HIP_TRY(c, hipMemcpyAsync(c->mirror + at, c->b_rows.p, (size_t)J * sizeof(pjb_junction_row), hipMemcpyDeviceToDevice, st));
     }
     HIP_TRY(c, hipMemcpyAsync(&herr, d_err, 8, hipMemcpyDeviceToHost, st));
     u32 gen_counts[GEN_SHARDS];
@@ -920,6 +940,7 @@ int pjb_set_row_mirror(pjb_ctx *c, void *device_buffer, int64_t cap_bytes) {
     if (device_buffer && cap_bytes < PJB_MIRROR_HEADER_BYTES) return fail(c, PJB_ERR_ARG, "set_row_mirror: buffer smaller than its header");
     c->mirror = (uint8_t *)device_buffer;
     c->mirror_cap = device_buffer ? (size_t)cap_bytes : 0;
+    mirror_reset(c);
     if (c->mirror && !c->mirror_hdr) {
         HIP_TRY(c, hipSetDevice(c->cfg.device));
         HIP_TRY(c, hipHostMalloc((void **)&c->mirror_hdr, PJB_MIRROR_HEADER_BYTES, hipHostMallocDefault));
@@ -930,6 +951,7 @@ int pjb_set_row_mirror(pjb_ctx *c, void *device_buffer, int64_t cap_bytes) {
 int pjb_clear_rows(pjb_ctx *c) {
     if (!c) return PJB_ERR_ARG;
     c->rows_n = 0;
+    mirror_reset(c);
     return PJB_OK;
 }
 

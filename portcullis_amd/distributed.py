@@ -29,6 +29,20 @@ def shard_contigs(weights, world_size):
     return out
 
 
+def merge_rank_tables(merged_u8, row_dtype, regions):
+    """What rank 0 does with the gathered slots: the ranks' rows (rank order, each rank's contigs in its finish
+    order) become ONE table in contig order -- every contig's rows are contiguous and already (start, end)-sorted, so
+    a stable sort on refid is JunctionSystem::sort (lib/src/junction_system.cc:322-330) -- and the per-rank
+    read-length counters fold into the global ones (src/junction_builder.cc:258-278).
+    Returns (rows, totals dict)."""
+    rows = np.ascontiguousarray(merged_u8).view(row_dtype)
+    rows = rows[np.argsort(rows["refid"], kind="stable")]
+    totals = dict(spliced=sum(r["spliced"] for r in regions), unspliced=sum(r["unspliced"] for r in regions),
+                  sum_len=sum(r["sum_len"] for r in regions), min_len=min(r["min_len"] for r in regions),
+                  max_len=max(r["max_len"] for r in regions))
+    return rows, totals
+
+
 def allreduce_region(region, device, group=None):
     """Sum / min / max of the RegionResult counters over ranks (dict in, dict out)."""
     s = torch.tensor([region["spliced"], region["unspliced"], region["sum_len"]], dtype=torch.int64, device=device)
@@ -259,6 +273,11 @@ class MirrorExchange:
         src = self.send[self.k]
         if self.nccl:
             self.work = dist.all_gather_into_tensor(self.recv, src, group=self.group, async_op=True)
+        elif self.cuda:
+            # gloo cannot all-gather device tensors: staged through the host (debug runs of several ranks on one GPU)
+            parts = [torch.empty(self.slot, dtype=torch.uint8) for _ in range(self.world)]
+            dist.all_gather(parts, src.cpu(), group=self.group)
+            self.recv.copy_(torch.cat(parts))
         else:
             self.work = dist.all_gather(list(self.recv.view(self.world, self.slot).unbind(0)), src, group=self.group, async_op=True)
         self.k ^= 1

@@ -46,6 +46,24 @@ CONFIGS = {
 }
 
 
+# BASELINE.json configs[2] / configs[3]: 200 M paired-end 150-bp reads over 25 contigs with the lengths of GRCh38
+# chr1..22, X, Y, M (3.09 Gb); reads and ~250 k junctions spread in proportion to contig length.  One SynthConfig per
+# contig (its own seed), so any rank can generate exactly the contigs it owns and get the same records as a
+# single-GPU run of the whole set.
+GRCH38 = [248956422, 242193529, 198295559, 190214555, 181538259, 170805979, 159345973, 145138636, 138394717, 133797422,
+          135086622, 133275309, 114364328, 107043718, 101991189, 90338345, 83257441, 80373285, 58617616, 64444167,
+          46709983, 50818468, 156040895, 57227415, 16569]
+GRCH38_NAMES = [f"chr{i}" for i in range(1, 23)] + ["chrX", "chrY", "chrM"]
+
+
+def c3_contig_configs(total_reads=200_000_000, total_junctions=250_000, read_len=150, lens=None, paired=True):
+    """The per-contig configurations of the BASELINE configs[2] workload (scaled by the two totals)."""
+    lens = GRCH38 if lens is None else lens
+    tot = sum(lens)
+    return [SynthConfig(f"C3-{i}", ln, max(200, round(total_reads * ln / tot)), max(2, round(total_junctions * ln / tot)),
+                        read_len, paired=paired, seed=77_000 + i) for i, ln in enumerate(lens)]
+
+
 def _randint(g, lo, hi, shape, dev, dtype=torch.int64):
     return torch.randint(int(lo), int(hi), shape, generator=g, device=dev, dtype=dtype)
 

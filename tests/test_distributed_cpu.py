@@ -166,3 +166,85 @@ def test_mirror_exchange_world2():
             assert regions[1] == dict(spliced=8, unspliced=1, sum_len=300, min_len=41, max_len=92)
         else:
             assert blob is None
+
+
+# ---- configs[3]: the same contig set sharded over ranks, one exchange per step, merged table == single-GPU table
+_WEIGHTS = [2490, 2420, 1980, 1900, 1810, 1700, 1590, 1450, 1380, 1330, 1350, 1330, 1140, 1070, 1010, 900, 830, 800, 580,
+            640, 460, 500, 1560, 570, 1]
+
+
+def _contig_rows(tid):
+    n = (_WEIGHTS[tid] % 7) + (0 if tid == 24 else 1)  # the last contig has no junction at all
+    r = np.zeros(n, dtype=ROW_DTYPE)
+    r["refid"] = tid
+    r["start"] = 100 * np.arange(n) + tid
+    r["end"] = r["start"] + 50
+    r["nb_raw"] = 1 + np.arange(n) + tid
+    return r
+
+
+def _contig_region(tid):
+    w = _WEIGHTS[tid]
+    return dict(spliced=w // 3, unspliced=w - w // 3, sum_len=150 * w, min_len=150 - (tid % 3), max_len=150 + (tid % 5))
+
+
+def _finish_into_slot(slot, tid, state):
+    """What pjb_finish_contig does with the row mirror: rows appended, header = row total + folded counters."""
+    rows, reg = _contig_rows(tid), _contig_region(tid)
+    at = 64 + state["rows"] * ROW_DTYPE.itemsize
+    if len(rows):
+        slot[at:at + rows.nbytes] = torch.from_numpy(rows.view(np.uint8).copy())
+    state["rows"] += len(rows)
+    state["acc"] = [state["acc"][0] + reg["spliced"], state["acc"][1] + reg["unspliced"], state["acc"][2] + reg["sum_len"],
+                    min(state["acc"][3], reg["min_len"]), max(state["acc"][4], reg["max_len"])]
+    hdr = np.array([state["rows"]] + state["acc"] + [0, 0], dtype=np.int64)
+    slot[:64] = torch.from_numpy(hdr.view(np.uint8).copy())
+
+
+def _worker_sharded(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    mine = pd.shard_contigs(_WEIGHTS, world)[rank]
+    cap = sum(len(_contig_rows(t)) for t in range(len(_WEIGHTS)))
+    x = pd.MirrorExchange(ROW_DTYPE.itemsize, cap_rows=cap, device=torch.device("cpu"))
+    for _step in range(3):
+        x.slot_for_next_finish()
+        slot = x.send[x.k]
+        st = dict(rows=0, acc=[0, 0, 0, 2**31 - 1, 0])  # pjb_clear_rows / pjb_set_row_mirror reset the accumulation
+        for tid in mine:
+            _finish_into_slot(slot, tid, st)
+        x.launch()
+    merged = x.finish()
+    out = None
+    if rank == 0:
+        rows, totals = pd.merge_rank_tables(merged, ROW_DTYPE, x.regions)
+        out = (rows.tobytes(), totals, x.counts)
+    q.put((rank, mine, out))
+    dist.destroy_process_group()
+
+
+def test_sharded_contig_set_merges_to_single_table_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_sharded, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted((q.get(timeout=120) for _ in range(2)), key=lambda g: g[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    (_, mine0, out0), (_, mine1, out1) = got
+    assert sorted(mine0 + mine1) == list(range(len(_WEIGHTS))) and not set(mine0) & set(mine1)
+    load = [sum(_WEIGHTS[t] for t in m) for m in (mine0, mine1)]
+    assert abs(load[0] - load[1]) <= 0.02 * sum(_WEIGHTS)  # longest-processing-time balance
+    blob, totals, counts = out0
+    single = np.concatenate([_contig_rows(t) for t in range(len(_WEIGHTS))])  # what one GPU produces: contigs in order
+    assert blob == single.tobytes()
+    assert counts == [sum(len(_contig_rows(t)) for t in m) for m in (mine0, mine1)]
+    regs = [_contig_region(t) for t in range(len(_WEIGHTS))]
+    assert totals == dict(spliced=sum(r["spliced"] for r in regs), unspliced=sum(r["unspliced"] for r in regs),
+                          sum_len=sum(r["sum_len"] for r in regs), min_len=min(r["min_len"] for r in regs),
+                          max_len=max(r["max_len"] for r in regs))
+    assert out1 is None

@@ -165,6 +165,27 @@ def test_row_mirror(ffi, orc):
             reg2 = ctx.finish_contig(0)
             hdr = buf.cpu().numpy()[:48].view(np.int64)
             assert reg2["n_junctions"] == 0 and list(hdr) == [0, 0, reg2["unspliced"], reg2["sum_len"], reg2["min_len"], reg2["max_len"]]
+        # the mirror accumulates: two contigs finished without a clear in between -> rows appended, counters folded
+        genome_b, reads_b = make_reads(6, n_reads=1500)
+        batch_b = to_batch(reads_b)
+        ctx.set_refs([len(genome), len(genome_b)])
+        ctx.upload_contig(0, genome.encode())
+        ctx.upload_contig(1, genome_b.encode())
+        ctx.clear_rows()
+        ctx.set_row_mirror(buf.data_ptr(), buf.numel())
+        ctx.submit_batch(0, batch)
+        ra = ctx.finish_contig(0)
+        ctx.submit_batch(1, batch_b)
+        rb = ctx.finish_contig(1)
+        both = ctx.collect()
+        h = buf.cpu().numpy()
+        assert list(h[:48].view(np.int64)) == [len(both), ra["spliced"] + rb["spliced"], ra["unspliced"] + rb["unspliced"],
+                                              ra["sum_len"] + rb["sum_len"], min(ra["min_len"], rb["min_len"]),
+                                              max(ra["max_len"], rb["max_len"])]
+        assert len(both) == ra["n_junctions"] + rb["n_junctions"] and set(both["refid"]) == {0, 1}
+        assert h[64:64 + both.nbytes].tobytes() == both.tobytes()
+        ctx.set_refs([len(genome)])
+        ctx.upload_contig(0, genome.encode())
         small = torch.zeros(64 + ffi.ROW_DTYPE.itemsize, dtype=torch.uint8, device="cuda")
         ctx.set_row_mirror(small.data_ptr(), small.numel())
         ctx.clear_rows()

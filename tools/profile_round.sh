@@ -1,9 +1,15 @@
 #!/bin/bash
-# usage: tools/profile_round.sh <tag>   (run under gpurun): kernel-trace stats + PMC traffic of the bench command
+# usage: tools/profile_round.sh <tag> [commit]   (run under gpurun): rocprofv3 kernel-trace stats + PMC traffic of the
+# bench command (BASELINE configs[2]), then the plain bench line.  Summaries land in gpurun_out/; copy to profiles/.
 TAG=$1
+COMMIT=${2:-unknown}
 OUT=$GRAFT_REPO_ROOT/gpurun_out
+mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$TAG -o $TAG -- python3 $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline > $OUT/bench_prof_$TAG.log 2>&1
-cd $GRAFT_REPO_ROOT && bash tools/pmc_traffic.sh $TAG
-python3 bench.py --steps 20 --warmup 3 > $OUT/bench_$TAG.json 2> $OUT/bench_$TAG.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$TAG -o $TAG -- python3 $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-e2e > $OUT/bench_prof_$TAG.log 2>&1
+cd $GRAFT_REPO_ROOT
+python3 tools/summarize_rocprof.py $(find $OUT/prof_$TAG -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_bench_C3_kernel_stats.csv
+bash tools/pmc_traffic.sh $TAG
+python3 tools/summarize_pmc.py $OUT/pmc_$TAG $OUT/${TAG}_pmc_traffic.json C3 $COMMIT
+python3 bench.py --steps 20 --warmup 3 ${BENCH_FLAGS:-} > $OUT/${TAG}_bench_C3.json 2> $OUT/bench_$TAG.err
 tail -c 300 $OUT/bench_$TAG.err

@@ -8,6 +8,8 @@ import sys
 from collections import defaultdict
 
 d, out = sys.argv[1], sys.argv[2]
+workload = sys.argv[3] if len(sys.argv) > 3 else None
+commit = sys.argv[4] if len(sys.argv) > 4 else None
 res = defaultdict(lambda: defaultdict(list))
 for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
     for r in csv.DictReader(open(f"{d}/{ctr}/pmc_counter_collection.csv")):
@@ -23,6 +25,11 @@ for name, v in sorted(res.items()):
     wk = sum(w) / len(w) if w else 0.0
     summary[name] = dict(launches=len(f), fetch_kib_raw=round(fk, 1), write_kib=round(wk, 1),
                          hbm_bytes_per_launch=int((2 * fk + wk) * 1024))
-json.dump(summary, open(out, "w"), indent=1)
+meta = {}
+if workload:
+    meta["_workload"] = workload  # bench.py attaches the traffic figure only to a run of the same workload
+if commit:
+    meta["_commit"] = commit
+json.dump({**meta, **summary}, open(out, "w"), indent=1)
 for k, v in summary.items():
     print(f"{k:45s} fetch_raw {v['fetch_kib_raw'] / 1024:9.1f} MiB  write {v['write_kib'] / 1024:9.1f} MiB  corrected {v['hbm_bytes_per_launch'] / 1e6:9.1f} MB")
