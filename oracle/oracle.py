@@ -79,6 +79,10 @@ ROW_DTYPE = np.dtype(
         ("jad", "<u4", (20,)),
         ("_pad1", "<u4"),
         ("sum_mismatches", "<u8"),
+        ("mm_score", "<f8"),
+        ("coverage", "<f8"),
+        ("up_aln", "<u4"),
+        ("down_aln", "<u4"),
     ],
     align=False,
 )
@@ -142,6 +146,15 @@ def lib():
             getattr(L, f).restype = C.c_void_p
         L.orc_free_text.argtypes = [C.c_void_p]
         assert C.sizeof(OrcRegion) == 32
+        L.orc_sizeof_row.restype = C.c_size_t
+        assert L.orc_sizeof_row() == ROW_DTYPE.itemsize, (L.orc_sizeof_row(), ROW_DTYPE.itemsize)
+        L.orc_name_hash.restype = C.c_uint64
+        L.orc_name_hash.argtypes = [C.c_char_p, C.c_size_t, C.c_uint16]
+        L.orc_depth.restype = C.c_int64
+        L.orc_depth.argtypes = [C.c_int32, C.POINTER(OrcReads), C.c_void_p]
+        L.orc_calc_coverage.restype = C.c_double
+        L.orc_calc_coverage.argtypes = [C.c_int32, C.c_int32, C.c_void_p, C.c_size_t]
+        L.orc_extra.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32]
         _LIB = L
     return _LIB
 
@@ -293,6 +306,52 @@ def find_juncs(tid, ref_len, genome, soa, orientation="UNKNOWN"):
     L.orc_free_rows(rows_p)
     region = dict(spliced=reg.spliced, unspliced=reg.unspliced, sum_len=reg.sum_len, min_len=reg.min_len, max_len=reg.max_len)
     return rows, region
+
+
+def name_hash(qname, flag):
+    """std::hash<std::string>()(deriveName()) of one record (bytes / str name without the NUL)."""
+    q = qname.encode() if isinstance(qname, str) else bytes(qname)
+    return lib().orc_name_hash(q, len(q), int(flag) & 0xffff)
+
+
+def depth(ref_len, soa):
+    """DepthParser's vector for one target's records (unspliced.bam view); returns (uint32[ref_len], records kept)."""
+    r, keep = _reads_struct(soa)
+    out = np.zeros(max(ref_len, 1), dtype=np.uint32)
+    n = lib().orc_depth(ref_len, C.byref(r), out.ctypes.data_as(C.c_void_p))
+    if n < 0:
+        _err(int(n))
+    return out[:ref_len], int(n)
+
+
+def calc_coverage(start, end, levels):
+    lv = np.ascontiguousarray(levels, dtype=np.uint32)
+    return lib().orc_calc_coverage(start, end, lv.ctypes.data_as(C.c_void_p), len(lv))
+
+
+def extra(ref_lens, soa_by_tid, name_hash_by_tid, rows, max_query_len):
+    """calcExtraMetrics on finalised rows.  soa_by_tid / name_hash_by_tid: {tid: soa dict} / {tid: uint64 array}."""
+    n = len(ref_lens)
+    structs = (OrcReads * n)()
+    keep = []
+    hp = (C.c_void_p * n)()
+    for t in range(n):
+        if t in soa_by_tid and len(soa_by_tid[t]["pos"]):
+            r, k = _reads_struct(soa_by_tid[t])
+            h = np.ascontiguousarray(name_hash_by_tid[t], dtype=np.uint64)
+            assert len(h) == r.n
+            keep += [k, h]
+            structs[t] = r
+            hp[t] = h.ctypes.data
+        else:
+            structs[t].n = 0
+    lens = np.ascontiguousarray(ref_lens, dtype=np.int32)
+    rows = np.ascontiguousarray(rows)
+    rc = lib().orc_extra(n, lens.ctypes.data_as(C.c_void_p), C.cast(structs, C.c_void_p), C.cast(hp, C.c_void_p),
+                         rows.ctypes.data_as(C.c_void_p), len(rows), int(max_query_len))
+    if rc < 0:
+        _err(rc)
+    return rows
 
 
 def finalize(rows, mean_query_len):

@@ -27,6 +27,7 @@ static int fail(int code, const char *fmt, ...) {
 }
 
 const char *orc_last_error(void) { return g_err; }
+size_t orc_sizeof_row(void) { return sizeof(orc_row); }
 
 /* ------------------------------------------------------------------ */
 /* small string builder                                               */
@@ -906,6 +907,273 @@ done:
 
 void orc_free_rows(orc_row *rows) { free(rows); }
 
+static int cmp_row(const void *a, const void *b);
+/* ------------------------------------------------------------------ */
+/* junc --extra                                                       */
+/* ------------------------------------------------------------------ */
+
+/* libstdc++ std::_Hash_bytes, 64-bit (libstdc++-v3/libsupc++/hash_bytes.cc) */
+static inline uint64_t hb_shift_mix(uint64_t v) { return v ^ (v >> 47); }
+static uint64_t std_hash_bytes(const void *ptr, size_t len, uint64_t seed) {
+    static const uint64_t mul = (((uint64_t)0xc6a4a793UL) << 32UL) + (uint64_t)0x5bd1e995UL;
+    const unsigned char *buf = (const unsigned char *)ptr;
+    const size_t len_aligned = len & ~(size_t)0x7;
+    const unsigned char *end = buf + len_aligned;
+    uint64_t hash = seed ^ (len * mul);
+    for (const unsigned char *p = buf; p != end; p += 8) {
+        uint64_t w;
+        memcpy(&w, p, 8);
+        const uint64_t data = hb_shift_mix(w * mul) * mul;
+        hash ^= data;
+        hash *= mul;
+    }
+    if ((len & 0x7) != 0) {
+        uint64_t data = 0;
+        int n = (int)(len & 0x7);
+        --n;
+        do data = (data << 8) + end[n]; while (--n >= 0);
+        hash ^= data;
+        hash *= mul;
+    }
+    hash = hb_shift_mix(hash) * mul;
+    hash = hb_shift_mix(hash);
+    return hash;
+}
+
+/* BamAlignment::deriveName, bam_alignment.cc:233-242, then std::hash<string> (junction.hpp:158) */
+uint64_t orc_name_hash(const char *qname, size_t n, uint16_t flag) {
+    char tmp[300];
+    if (n > 255) n = 255; /* l_read_name is 8 bits incl. NUL */
+    memcpy(tmp, qname, n);
+    size_t len = n;
+    if (flag & 0x1) {
+        const char *suf = (flag & 0x40) ? "_R1" : (flag & 0x80) ? "_R2" : "_R?";
+        memcpy(tmp + len, suf, 3);
+        len += 3;
+    }
+    return std_hash_bytes(tmp, len, 0xc70f6907UL);
+}
+
+static int has_refskip(const orc_reads *rd, int64_t i) { /* BamAlignment::isSplicedRead, bam_alignment.cc:294-301 */
+    for (uint32_t k = rd->cig_off[i]; k < rd->cig_off[i + 1]; k++)
+        if (op_chr(rd->cigar[k]) == 'N') return 1;
+    return 0;
+}
+/* a record of unspliced.bam: not spliced, and mapped (src/junction_builder.cc:168-186) */
+static int is_unspliced_mapped(const orc_reads *rd, int64_t i) { return !has_refskip(rd, i) && !(rd->flag[i] & 0x4); }
+
+/* bam_endpos (deps/htslib-1.3/sam.c: bam_cigar2rlen, 0 -> pos + 1) */
+static int32_t end_excl(const orc_reads *rd, int64_t i) {
+    int32_t a = aligned_length(rd, i);
+    return rd->pos[i] + (a > 0 ? a : 1);
+}
+
+/* The pileup of unspliced.bam for one target, deps/htslib-1.3/sam.c:1853-1975 driven by
+ * DepthParser::read_bam_skip_gapped (depth_parser.cc:60-83; min_mapQ 0 and min_len 0 filter nothing).
+ * bam_plp_push keeps every mapped record except: one that starts at the position the iterator stands on
+ * (the start of the last record it kept) while more than maxcnt = 8000 list nodes are allocated -- the
+ * records not yet passed (end > every position already piled up) plus the list's sentinel and the dummy.
+ * Every position covered by a kept record is reported; its depth is the number of kept records there
+ * minus those in a deletion (is_del; is_refskip cannot occur without N operations). */
+int64_t orc_depth(int32_t ref_len, const orc_reads *rd, uint32_t *depth) {
+    if (ref_len < 0) return fail(ORC_ERR_ARG, "bad ref_len");
+    memset(depth, 0, (size_t)ref_len * sizeof(uint32_t));
+    /* ends of the kept records still in the list, as a multiset by value: cnt_end[e] */
+    uint32_t *cnt_end = (uint32_t *)calloc((size_t)ref_len + 2, sizeof(uint32_t));
+    int32_t *diff = (int32_t *)calloc((size_t)ref_len + 2, sizeof(int32_t));
+    if (!cnt_end || !diff) { free(cnt_end); free(diff); return fail(ORC_ERR_NOMEM, "oom"); }
+    int64_t kept = 0, in_list = 0;
+    int32_t iter_pos = -1; /* start of the last kept record of this target (none yet) */
+    int32_t swept = 0;     /* ends < swept have been taken out of in_list */
+    for (int64_t i = 0; i < rd->n; i++) {
+        if (!is_unspliced_mapped(rd, i)) continue;
+        const int32_t p = rd->pos[i];
+        int32_t e = end_excl(rd, i);
+        if (p < 0) continue;
+        /* the iterator has piled up every position < iter_pos: records with end <= iter_pos - 1 ... are freed
+         * when position (end) is visited, i.e. all ends <= iter_pos - 1 + 1 - 1; the list therefore holds the
+         * kept records with end >= iter_pos (sam.c:1861-1864 frees `end <= pos` at each visited pos < iter_pos) */
+        if (iter_pos >= 0) {
+            while (swept < iter_pos && swept <= ref_len + 1) { in_list -= cnt_end[swept]; swept++; }
+        }
+        if (iter_pos == p && in_list + 2 > 8000) continue; /* sam.c:1906-1910 */
+        kept++;
+        in_list++;
+        { int32_t ce = e > ref_len + 1 ? ref_len + 1 : e; if (ce < swept) ce = swept; cnt_end[ce]++; }
+        iter_pos = p;
+        /* depth contribution: M / = / X runs */
+        int32_t x = p;
+        for (uint32_t k = rd->cig_off[i]; k < rd->cig_off[i + 1]; k++) {
+            char t = op_chr(rd->cigar[k]);
+            int32_t l = op_len(rd->cigar[k]);
+            if (t == 'M' || t == '=' || t == 'X') {
+                int32_t a = x, b = x + l;
+                if (a < 0) a = 0;
+                if (b > ref_len) b = ref_len;
+                if (a < b) { diff[a]++; diff[b]--; }
+            }
+            if (consumes_ref(t)) x += l;
+        }
+    }
+    int64_t run = 0;
+    for (int32_t x = 0; x < ref_len; x++) {
+        run += diff[x];
+        if (x + 1 < ref_len) depth[x + 1] = (uint32_t)run; /* depths[pos + 1] = cnt, depth_parser.cc:127,147-150 */
+    }
+    free(cnt_end);
+    free(diff);
+    return kept;
+}
+
+/* Junction::calcCoverage(int32_t a, int32_t b, const vector<uint32_t>&), junction.cc:923-933 */
+static double cov_window(int32_t a, int32_t b, const uint32_t *lv, size_t n) {
+    double multiplier = 1.0 / (b - a);
+    uint32_t readCount = 0;
+    for (int32_t i = a; i <= b; i++)
+        if (i >= 0 && i < (int32_t)n) readCount += lv[i];
+    return multiplier * (double)readCount;
+}
+double orc_calc_coverage(int32_t start, int32_t end, const uint32_t *lv, size_t n) { /* junction.cc:935-951 */
+    const int32_t REGION_LENGTH = 10;
+    int32_t donorStart = start - 2 * REGION_LENGTH, donorMid = start - REGION_LENGTH, donorEnd = start;
+    int32_t acceptorStart = end, acceptorMid = end + REGION_LENGTH, acceptorEnd = end + 2 * REGION_LENGTH;
+    double donorCoverage = cov_window(donorStart, donorMid - 1, lv, n) - cov_window(donorMid, donorEnd, lv, n);
+    double acceptorCoverage = cov_window(acceptorMid, acceptorEnd, lv, n) - cov_window(acceptorStart, acceptorMid - 1, lv, n);
+    return donorCoverage + acceptorCoverage;
+}
+
+typedef struct { uint64_t code; uint32_t count; } nslot;
+
+int orc_extra(int32_t n_refs, const int32_t *ref_len, const orc_reads *reads, const uint64_t *const *name_hash,
+              orc_row *rows, int64_t n_rows, int32_t max_query_len) {
+    int rc = 0;
+    /* ---- splicedAlignmentMap[hash(deriveName)]++ for every spliced record of the file, junction_builder.cc:168-176 */
+    size_t n_spliced = 0;
+    for (int32_t t = 0; t < n_refs; t++)
+        for (int64_t i = 0; i < reads[t].n; i++) n_spliced += (size_t)has_refskip(&reads[t], i);
+    size_t cap = 16;
+    while (cap < 2 * n_spliced + 1) cap <<= 1;
+    nslot *map = (nslot *)calloc(cap, sizeof(nslot));
+    if (!map) return fail(ORC_ERR_NOMEM, "oom");
+    for (int32_t t = 0; t < n_refs; t++)
+        for (int64_t i = 0; i < reads[t].n; i++) {
+            if (!has_refskip(&reads[t], i)) continue;
+            uint64_t c = name_hash[t][i];
+            size_t h = (size_t)(c * 0x9e3779b97f4a7c15ULL) & (cap - 1);
+            while (map[h].count && map[h].code != c) h = (h + 1) & (cap - 1);
+            map[h].code = c;
+            map[h].count++;
+        }
+    /* ---- per target: group again (JunctionSystem::addJunctions) to get every junction's alignment list */
+    int64_t r0 = 0;
+    for (int32_t t = 0; t < n_refs && !rc; t++) {
+        int64_t r1 = r0;
+        while (r1 < n_rows && rows[r1].refid == t) r1++;
+        const orc_reads *rd = &reads[t];
+        if (r1 > r0) {
+            jsys js;
+            memset(&js, 0, sizeof js);
+            js.tid = t;
+            js.ref_len = ref_len[t];
+            js.rd = rd;
+            for (int64_t i = 0; i < rd->n && !rc; i++) {
+                int found = 0;
+                rc = add_junctions(&js, i, 0, rd->pos[i], &found);
+            }
+            /* calcMultipleMappingScore, junction.cc:914-921: N / M, M a uint32_t sum of map[code] */
+            for (size_t j = 0; j < js.n && !rc; j++) {
+                junc *J = &js.list[j];
+                orc_row key = J->r, *row;
+                key.refid = t;
+                row = (orc_row *)bsearch(&key, rows + r0, (size_t)(r1 - r0), sizeof(orc_row), cmp_row);
+                if (!row) { rc = fail(ORC_ERR_ARG, "orc_extra: rows do not match the reads"); break; }
+                uint32_t M = 0;
+                for (size_t a = 0; a < J->n_al; a++) {
+                    uint64_t c = name_hash[t][J->al[a].read];
+                    size_t h = (size_t)(c * 0x9e3779b97f4a7c15ULL) & (cap - 1);
+                    while (map[h].count && map[h].code != c) h = (h + 1) & (cap - 1);
+                    M += map[h].count;
+                }
+                row->mm_score = (double)J->n_al / (double)M;
+            }
+            for (size_t j = 0; j < js.n; j++) free(js.list[j].al);
+            free(js.list);
+            free(js.tab);
+        }
+        /* ---- Junction::processJunctionVicinity over unspliced.bam, junction.cc:651-677.  The region query
+         * (sam_itr_queryi: records with pos < regionEnd and bam_endpos > regionStart) never cuts off a record
+         * the two tests accept, but it is applied as written. */
+        int32_t maxspan = 1; /* longest reference span of a record: nothing further left than this can reach a region */
+        for (int64_t i = 0; i < rd->n && r1 > r0; i++) {
+            int32_t a = aligned_length(rd, i);
+            if (a > maxspan) maxspan = a;
+        }
+        for (int64_t r = r0; r < r1 && !rc; r++) {
+            orc_row *row = &rows[r];
+            int32_t regionStart = row->left - max_query_len - 1;
+            regionStart = regionStart < 0 ? 0 : regionStart;
+            int32_t regionEnd = row->right + max_query_len + 1;
+            regionEnd = regionEnd >= ref_len[t] ? ref_len[t] - 1 : regionEnd;
+            uint32_t up = 0, down = 0;
+            /* records are sorted by pos: stop at pos >= regionEnd */
+            int64_t lo = 0, hi = rd->n; /* first record with pos > regionStart - maxspan */
+            while (lo < hi) {
+                int64_t mid = (lo + hi) / 2;
+                if ((int64_t)rd->pos[mid] + maxspan <= regionStart) lo = mid + 1;
+                else hi = mid;
+            }
+            for (int64_t i = lo; i < rd->n && rd->pos[i] < regionEnd; i++) {
+                if (!is_unspliced_mapped(rd, i)) continue;
+                if (end_excl(rd, i) <= regionStart) continue;
+                int32_t pos = rd->pos[i], end = pos + aligned_length(rd, i) - 1; /* getStart / getEnd */
+                if (row->start > pos && row->left <= end) up++;
+                if (row->right >= pos && row->end < pos) down++;
+            }
+            row->up_aln = up;
+            row->down_aln = down;
+        }
+        r0 = r1;
+    }
+    /* ---- JunctionSystem::calcCoverage, junction_system.cc:231-242.  loadNextBatch (depth_parser.cc:112-164)
+     * fills the vector of the target the previous call stopped in and stops at the first pileup position of
+     * the NEXT target, which it records in `last`; getCurrentRefIndex() then names that next target, so a
+     * batch is applied to the junctions of the target AFTER the one it was computed for -- except the last
+     * batch (the pileup ended: `last` still names its own target).  Targets without an unspliced record never
+     * appear. */
+    if (!rc) {
+        int32_t prev = -1;
+        uint32_t *depth_prev = NULL;
+        int32_t last = -1;
+        for (int32_t t = 0; t < n_refs; t++) {
+            int any = 0;
+            for (int64_t i = 0; i < reads[t].n && !any; i++) any = is_unspliced_mapped(&reads[t], i);
+            if (any) last = t;
+        }
+        for (int32_t t = 0; t < n_refs && !rc; t++) {
+            int any = 0;
+            for (int64_t i = 0; i < reads[t].n && !any; i++) any = is_unspliced_mapped(&reads[t], i);
+            if (!any) continue;
+            uint32_t *depth = (uint32_t *)malloc(((size_t)ref_len[t] + 1) * sizeof(uint32_t));
+            if (!depth) { rc = fail(ORC_ERR_NOMEM, "oom"); break; }
+            if (orc_depth(ref_len[t], &reads[t], depth) < 0) { free(depth); rc = ORC_ERR_NOMEM; break; }
+            if (prev >= 0) /* the batch of `prev` is handed to the junctions of `t` */
+                for (int64_t r = 0; r < n_rows; r++)
+                    if (rows[r].refid == t)
+                        rows[r].coverage = orc_calc_coverage(rows[r].start, rows[r].end, depth_prev, (size_t)ref_len[prev]);
+            if (t == last)
+                for (int64_t r = 0; r < n_rows; r++)
+                    if (rows[r].refid == t)
+                        rows[r].coverage = orc_calc_coverage(rows[r].start, rows[r].end, depth, (size_t)ref_len[t]);
+            free(depth_prev);
+            depth_prev = depth;
+            prev = t;
+        }
+        free(depth_prev);
+    }
+    free(map);
+    return rc;
+}
+
 /* ------------------------------------------------------------------ */
 /* merge: sort / index / calcJunctionStats                            */
 /* ------------------------------------------------------------------ */
@@ -1020,12 +1288,13 @@ char *orc_write_tab(const orc_row *rows, int64_t n, const char *const *ref_names
         sb_put(&s, (const char *)r->da1, 2);
         sb_put(&s, "\t", 1);
         sb_put(&s, (const char *)r->da2, 2);
-        sb_printf(&s, "\t%c\t0\t%d\t%d\t%u\t%u\t%u\t%u\t%u\t%u\t%u\t%u\t%u\t%g\t%u\t%u\t%u\t%u\t%g\t%g\t%g\t%u\t%u\t0\t%u\t%u\t0\t0\t0\t%d\t%d\t%u\t%u\t%u\t%u\t%u\t0\t0\t0\t0\t1",
+        sb_printf(&s, "\t%c\t0\t%d\t%d\t%u\t%u\t%u\t%u\t%u\t%u\t%u\t%u\t%u\t%g\t%u\t%u\t%u\t%u\t%g\t%g\t%g\t%u\t%u\t0\t%u\t%u\t0\t0\t0\t%d\t%d\t%u\t%u\t%u\t%u\t%u\t%g\t%g\t%u\t%u\t1",
                   css_chr(r->canonical), r->suspicious, r->pfp, r->nb_raw, r->nb_dist, r->nb_raw - r->nb_ms,
                   r->nb_ms, r->nb_um, r->nb_raw - r->nb_um, r->nb_bpp, r->nb_ppp, r->nb_rel,
                   (double)r->nb_rel / (double)r->nb_raw, r->r1pos, r->r1neg, r->r2pos, r->r2neg, r->entropy,
                   r->mean_mismatches, r->mean_readlen, r->max_min_anc, r->maxmmes, r->hamming5p, r->hamming3p,
-                  r->uniq, r->primary, r->nb_up_juncs, r->nb_down_juncs, r->dist_up, r->dist_down, r->dist_nearest);
+                  r->uniq, r->primary, r->nb_up_juncs, r->nb_down_juncs, r->dist_up, r->dist_down, r->dist_nearest,
+                  r->mm_score, r->coverage, r->up_aln, r->down_aln);
         for (int k = 0; k < 20; k++) sb_printf(&s, "\t%u", r->jad[k]);
         sb_put(&s, "\n", 1);
     }

@@ -96,6 +96,9 @@ typedef struct orc_row {
     uint32_t dist_up, dist_down, dist_nearest;
     uint32_t jad[20];
     uint64_t sum_mismatches;     /* numerator of mean_mismatches (integer, for bit-exact checks) */
+    /* --extra columns (0 unless orc_extra ran): junction.hpp:240-243 */
+    double mm_score, coverage;
+    uint32_t up_aln, down_aln;
 } orc_row;
 
 /* RegionResult (src/junction_builder.hpp:62-76) */
@@ -155,6 +158,33 @@ void orc_free_rows(orc_row *rows);
  * (lib/src/junction_system.cc:250-320).  mean_query_len = sum/(spliced+unspliced). */
 void orc_finalize(orc_row *rows, int64_t n, double mean_query_len);
 
+/* ---- `junc --extra` (hidden flag; src/junction_builder.cc:152-226,293-312) ------------------------------
+ * std::hash<std::string>()(BamAlignment::deriveName()) (lib/include/portcullis/junction.hpp:158,
+ * lib/src/bam_alignment.cc:233-242).  std::hash<std::string> is not in the reference checkout: it is the
+ * C++ standard library's (GNU libstdc++, the toolchain the reference's autotools build uses on Linux;
+ * libstdc++-v3/libsupc++/hash_bytes.cc, 64-bit _Hash_bytes = a MurmurHash64A variant, seed 0xc70f6907),
+ * restated here from its published algorithm.  Only equality of codes reaches the output (mm_score). */
+uint64_t orc_name_hash(const char *qname, size_t n, uint16_t flag);
+
+/* Per-base depth of the unspliced alignments of ONE contig as DepthParser::loadNextBatch builds it
+ * (lib/src/depth_parser.cc:112-164) on top of htslib-1.3's pileup (deps/htslib-1.3/sam.c:1853-1975):
+ * depth[x + 1] = alignments with an M/=/X base on x, among the records bam_plp_push accepts (mapped, and not
+ * dropped by the 8000-read cap: a record starting at the pileup's current position while more than
+ * maxcnt records are buffered).  `depth` has ref_len entries (the write for x + 1 == ref_len is out of
+ * bounds in the reference and skipped here).  Returns the number of records that took part, or < 0. */
+int64_t orc_depth(int32_t ref_len, const orc_reads *reads, uint32_t *depth);
+
+/* Junction::calcCoverage(const vector<uint32_t>&) (lib/src/junction.cc:923-951). */
+double orc_calc_coverage(int32_t start, int32_t end, const uint32_t *levels, size_t n_levels);
+
+/* JunctionBuilder::separateBams' name map + calcExtraMetrics (src/junction_builder.cc:168-176,293-312):
+ * mm_score (junction.cc:914-921), up_aln / down_aln (junction.cc:651-677) and coverage
+ * (junction_system.cc:231-242 incl. the batch / contig pairing of DepthParser::getCurrentRefIndex) for
+ * finalised rows (sorted by refid,start,end).  reads[t] / name_hash[t] are the records of target t in file
+ * order (n = 0: none); max_query_len as JunctionSystem::setQueryLengthStats got it. */
+int orc_extra(int32_t n_refs, const int32_t *ref_len, const orc_reads *reads, const uint64_t *const *name_hash,
+              orc_row *rows, int64_t n_rows, int32_t max_query_len);
+
 /* Writers.  Return a malloc'd buffer (caller frees with orc_free_text) and its length.
  * ref_names[refid], ref_lens[refid].  (.tab: junction.hpp:1260-1319 + junction_system.hpp:154-160
  * + junction_system.cc:356; .bed: junction_system.cc:411-418 + junction.cc:1189-1214;
@@ -170,6 +200,7 @@ char *orc_write_exon_gff(const orc_row *rows, int64_t n, const char *const *ref_
 void orc_free_text(char *p);
 
 const char *orc_last_error(void);
+size_t orc_sizeof_row(void); /* binding check */
 
 #ifdef __cplusplus
 }

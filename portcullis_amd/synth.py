@@ -121,9 +121,19 @@ def generate(cfg: SynthConfig, device="cpu", seed=None, tid=0):
     kind = torch.where(m < 0.425, 0, torch.where(m < 0.85, 1, torch.where(m < 0.875, 2, torch.where(m < 0.90, 3, -1))))
     pl = (kind >= 0) & ok
     kk = kind.clamp(min=0)
+    def plant(idx, val):
+        # junctions that share a donor or an acceptor write the same bases: the junction with the highest id wins,
+        # whatever order the device processes an index_put with duplicate indices in (a rank that regenerates a
+        # contig must get the bytes every other rank got)
+        o = torch.argsort(idx, stable=True)
+        i_s, v_s = idx[o], val[o]
+        last = torch.ones_like(i_s, dtype=torch.bool)
+        last[:-1] = i_s[1:] != i_s[:-1]
+        genome[i_s[last]] = v_s[last]
+
     for t in range(2):
-        genome[(jstart + t)[pl]] = donor[kk[pl], t]
-        genome[(jend - 1 + t)[pl]] = accpt[kk[pl], t]
+        plant((jstart + t)[pl], donor[kk[pl], t])
+        plant((jend - 1 + t)[pl], accpt[kk[pl], t])
 
     # ------------------------------------------------------------------ reads
     is_spl = _rand(g, N, dev) < cfg.spliced_frac

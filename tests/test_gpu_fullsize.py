@@ -100,17 +100,41 @@ def test_sort_variants_agree(c2, monkeypatch, env):
             assert hashlib.md5(again.tobytes()).hexdigest() == hashlib.md5(rows.tobytes()).hexdigest()
 
 
-def test_bench_exchange_path_single_rank(tmp_path):
-    """bench.py's N > 1 step (device-side all-gather of the row table over RCCL, asynchronous, plus the counter
-    exchange) with a one-rank process group: the CUDA-specific parts of RowExchange on real hardware."""
+def _run_bench(extra_args, env_extra, timeout=900):
     import json
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, PJB_BENCH_FORCE_EXCHANGE="1", MASTER_ADDR="127.0.0.1")
-    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--config", "C2-small", "--steps", "4", "--warmup", "1",
-                        "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, env=env)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", **env_extra)
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--reads", "4000000", "--junctions", "5000", "--steps", "3",
+                        "--warmup", "1"] + extra_args, capture_output=True, text=True, timeout=timeout, env=env)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
-    d = json.loads([l for l in p.stdout.split("\n") if l.startswith("{")][-1])
-    assert d["n_gpus"] == 1 and d["value"] > 0
+    return json.loads([l for l in p.stdout.split("\n") if l.startswith("{")][-1])
+
+
+def test_bench_exchange_path_single_rank():
+    """bench.py's N > 1 step (device-side all-gather of the row mirror over RCCL, asynchronous, counters in the slot
+    header) with a one-rank process group: the CUDA-specific parts of MirrorExchange on real hardware."""
+    d = _run_bench(["--no-cpu-baseline", "--no-e2e"], {"PJB_BENCH_FORCE_EXCHANGE": "1"})
+    assert d["n_gpus"] == 1 and d["value"] > 0 and d["config"]["contigs"] == 25
+
+
+def test_bench_two_ranks_share_one_gpu():
+    """`bench.py --gpus 2` starts its two ranks itself; they share GPU 0 and exchange over gloo
+    (PJB_BENCH_SHARE_GPU=1: a debug mode for one-GPU boxes).  The contig set is sharded by read count, every rank's
+    mirror slot accumulates its contigs' rows, and rank 0 checks the merged table byte for byte against the table a
+    single context produces for all 25 contigs (BASELINE configs[3] in miniature)."""
+    d = _run_bench(["--gpus", "2"], {"PJB_BENCH_SHARE_GPU": "1"})
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong"
+    assert d["multi_gpu_check"]["merged_equals_single_gpu_table"] is True
+    assert sorted(d["config"]["contigs_per_rank"]) == [12, 13] and d["config"]["junctions_total"] == d["multi_gpu_check"]["rows"]
+
+
+def test_bench_line_small_workload(tmp_path):
+    """The whole bench line (roofline, cpu_baseline over every contig with parity, e2e through BAM bytes) on a
+    scaled-down 25-contig set."""
+    d = _run_bench(["--e2e-workdir", str(tmp_path / "e2e")], {})
+    assert d["roofline"]["frac"] > 0 and d["roofline"]["alg_bytes_per_launch"] > 0
+    assert d["cpu_baseline"]["value"] > 0 and "every device row" in d["cpu_baseline"]["sample"]
+    assert d["e2e"]["tab_identical_to_oracle"] is True and d["e2e"]["reads"] == d["config"]["reads_total"]

@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <map>
 #include <string>
 #include <thread>
@@ -68,7 +69,20 @@ int main(int argc, char** argv) {
     const int ncontig = argc - 3;
     std::vector<std::string> names(ncontig);
     std::vector<int64_t> lens(ncontig);
-    // ---- FASTA + fai
+    auto parallel_for = [&](size_t n, size_t grain, const std::function<void(size_t, size_t)>& fn) {
+        std::atomic<size_t> next(0);
+        std::vector<std::thread> th;
+        for (int t = 0; t < nthreads; t++)
+            th.emplace_back([&] {
+                for (;;) {
+                    const size_t a = next.fetch_add(grain);
+                    if (a >= n) break;
+                    fn(a, std::min(n, a + grain));
+                }
+            });
+        for (auto& t : th) t.join();
+    };
+    // ---- FASTA + fai (60 bases per line; every contig's text is laid out in parallel, one write per contig)
     {
         FILE* fa = fopen((prep + "/portcullis.genome.fa").c_str(), "wb");
         FILE* fai = fopen((prep + "/portcullis.genome.fa.fai").c_str(), "wb");
@@ -86,21 +100,25 @@ int main(int argc, char** argv) {
             lens[c] = (int64_t)g.size();
             off += fprintf(fa, ">%s\n", names[c].c_str());
             fprintf(fai, "%s\t%lld\t%lld\t60\t61\n", names[c].c_str(), (long long)g.size(), (long long)off);
-            std::vector<char> line(61);
-            for (size_t i = 0; i < g.size(); i += 60) {
-                const size_t n = std::min<size_t>(60, g.size() - i);
-                memcpy(line.data(), &g[i], n);
-                line[n] = '\n';
-                fwrite(line.data(), 1, n + 1, fa);
-                off += (int64_t)n + 1;
-            }
+            const size_t nlines = (g.size() + 59) / 60;
+            std::vector<char> text(g.size() + nlines);
+            parallel_for(nlines, 1 << 16, [&](size_t l0, size_t l1) {
+                for (size_t l = l0; l < l1; l++) {
+                    const size_t i = l * 60, n = std::min<size_t>(60, g.size() - i);
+                    memcpy(&text[l * 61], &g[i], n);
+                    text[l * 61 + n] = '\n';
+                }
+            });
+            fwrite(text.data(), 1, text.size(), fa);
+            off += (int64_t)text.size();
         }
         fclose(fa);
         fclose(fai);
     }
-    // ---- uncompressed BAM stream
+    // ---- uncompressed BAM stream: record sizes first (so every record knows its offset), then all records are
+    // laid out in parallel.  Bases of unspliced reads and all qualities come from a generator seeded by the
+    // record's ordinal, so the file does not depend on the thread count.
     std::vector<uint8_t> u;
-    std::vector<Rec> recs;
     {
         std::string text = "@HD\tVN:1.4\tSO:coordinate\n";
         for (int c = 0; c < ncontig; c++) text += "@SQ\tSN:" + names[c] + "\tLN:" + std::to_string(lens[c]) + "\n";
@@ -115,77 +133,120 @@ int main(int argc, char** argv) {
             put32(u, (uint32_t)lens[c]);
         }
     }
-    uint64_t ordinal = 0;
-    uint32_t lcg = 12345;
+    struct Contig {
+        std::vector<int32_t> pos, lq, mtid, mpos;
+        std::vector<uint16_t> flag;
+        std::vector<uint8_t> mapq, xs, seq4;
+        std::vector<uint32_t> cig_off, cigar, seq_off;
+        size_t first = 0;  // index of its first record in `recs`
+    };
+    std::vector<Contig> cs(ncontig);
+    size_t total = 0;
     for (int c = 0; c < ncontig; c++) {
         const std::string d = argv[3 + c];
-        auto pos = slurp<int32_t>(d + "/pos.i32", true);
-        if (pos.empty()) continue;
-        auto flag = slurp<uint16_t>(d + "/flag.u16");
-        auto mapq = slurp<uint8_t>(d + "/mapq.u8");
-        auto xs = slurp<uint8_t>(d + "/xs.u8");
-        auto lq = slurp<int32_t>(d + "/l_qseq.i32");
-        auto mtid = slurp<int32_t>(d + "/mtid.i32");
-        auto mpos = slurp<int32_t>(d + "/mpos.i32");
-        auto cig_off = slurp<uint32_t>(d + "/cig_off.u32");
-        auto cigar = slurp<uint32_t>(d + "/cigar.u32");
-        auto seq_off = slurp<uint32_t>(d + "/seq_off.u32");
-        auto seq4 = slurp<uint8_t>(d + "/seq4.u8");
-        const size_t n = pos.size();
-        u.reserve(u.size() + n * 170);
-        recs.reserve(recs.size() + n);
-        for (size_t i = 0; i < n; i++, ordinal++) {
-            char name[16];
-            const int ln = snprintf(name, sizeof name, "s%010llu", (unsigned long long)ordinal) + 1;
-            const uint32_t c0 = cig_off[i], c1 = cig_off[i + 1];
-            int64_t span = 0;
-            for (uint32_t k = c0; k < c1; k++) {
-                const uint32_t op = cigar[k] & 15u;
-                if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) span += cigar[k] >> 4;
-            }
-            const int64_t end = pos[i] + (span > 0 ? span : 1);
-            const int32_t l = lq[i];
-            const size_t sb = (size_t)(l + 1) / 2;
-            const bool has_xs = xs[i] == 1 || xs[i] == 2;
-            const uint32_t bs = 32 + (uint32_t)ln + 4 * (c1 - c0) + (uint32_t)sb + (uint32_t)l + (has_xs ? 4 : 0) + 4;
-            recs.push_back({c, pos[i], (int32_t)end, (uint64_t)u.size()});
-            put32(u, bs);
-            put32(u, (uint32_t)c);
-            put32(u, (uint32_t)pos[i]);
-            u.push_back((uint8_t)ln);
-            u.push_back(mapq[i]);
-            put16(u, (uint16_t)reg2bin(pos[i], end));
-            put16(u, (uint16_t)(c1 - c0));
-            put16(u, flag[i]);
-            put32(u, (uint32_t)l);
-            put32(u, (uint32_t)mtid[i]);
-            put32(u, (uint32_t)mpos[i]);
-            put32(u, 0);
-            u.insert(u.end(), name, name + ln);
-            for (uint32_t k = c0; k < c1; k++) put32(u, cigar[k]);
-            const uint32_t words = seq_off[i + 1] - seq_off[i];
-            if ((size_t)words * 4 >= sb && sb) u.insert(u.end(), &seq4[(size_t)seq_off[i] * 4], &seq4[(size_t)seq_off[i] * 4] + sb);
-            else
-                for (size_t k = 0; k < sb; k++) {  // unspliced reads carry no bases in the SoA: synthesise some
-                    lcg = lcg * 1664525u + 1013904223u;
-                    const uint8_t a = (uint8_t)(1u << ((lcg >> 24) & 3)), b = (uint8_t)(1u << ((lcg >> 26) & 3));
-                    u.push_back((uint8_t)((a << 4) | b));
+        Contig& k = cs[c];
+        k.first = total;
+        k.pos = slurp<int32_t>(d + "/pos.i32", true);
+        if (k.pos.empty()) continue;
+        k.flag = slurp<uint16_t>(d + "/flag.u16");
+        k.mapq = slurp<uint8_t>(d + "/mapq.u8");
+        k.xs = slurp<uint8_t>(d + "/xs.u8");
+        k.lq = slurp<int32_t>(d + "/l_qseq.i32");
+        k.mtid = slurp<int32_t>(d + "/mtid.i32");
+        k.mpos = slurp<int32_t>(d + "/mpos.i32");
+        k.cig_off = slurp<uint32_t>(d + "/cig_off.u32");
+        k.cigar = slurp<uint32_t>(d + "/cigar.u32");
+        k.seq_off = slurp<uint32_t>(d + "/seq_off.u32");
+        k.seq4 = slurp<uint8_t>(d + "/seq4.u8");
+        total += k.pos.size();
+    }
+    std::vector<Rec> recs(total);
+    const int NAME_LEN = 12;  // "s%010llu" + NUL
+    for (int c = 0; c < ncontig; c++) {
+        Contig& k = cs[c];
+        parallel_for(k.pos.size(), 1 << 16, [&](size_t i0, size_t i1) {
+            for (size_t i = i0; i < i1; i++) {
+                const uint32_t c0 = k.cig_off[i], c1 = k.cig_off[i + 1];
+                int64_t span = 0;
+                for (uint32_t q = c0; q < c1; q++) {
+                    const uint32_t op = k.cigar[q] & 15u;
+                    if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) span += k.cigar[q] >> 4;
                 }
-            for (int32_t k = 0; k < l; k++) {  // qualities with realistic entropy
-                lcg = lcg * 1664525u + 1013904223u;
-                u.push_back((uint8_t)(2 + ((lcg >> 20) % 39)));
+                const int32_t l = k.lq[i];
+                const bool has_xs = k.xs[i] == 1 || k.xs[i] == 2;
+                const uint64_t bs = 32 + NAME_LEN + 4ull * (c1 - c0) + (uint64_t)(l + 1) / 2 + (uint64_t)l + (has_xs ? 4 : 0) + 4;
+                recs[k.first + i] = {c, k.pos[i], (int32_t)(k.pos[i] + (span > 0 ? span : 1)), bs + 4};  // size for now
             }
-            if (has_xs) {
-                u.push_back('X');
-                u.push_back('S');
-                u.push_back('A');
-                u.push_back(xs[i] == 1 ? '+' : '-');
-            }
-            u.push_back('N');
-            u.push_back('H');
-            u.push_back('C');
-            u.push_back(1);
+        });
+    }
+    {
+        uint64_t at = u.size();
+        for (auto& r : recs) {
+            const uint64_t sz = r.ustart;
+            r.ustart = at;
+            at += sz;
         }
+        u.resize(at);
+    }
+    for (int c = 0; c < ncontig; c++) {
+        Contig& k = cs[c];
+        parallel_for(k.pos.size(), 1 << 15, [&](size_t i0, size_t i1) {
+            for (size_t i = i0; i < i1; i++) {
+                const size_t ordinal = k.first + i;
+                const Rec& r = recs[ordinal];
+                uint8_t* w = &u[r.ustart];
+                const uint64_t next = ordinal + 1 < recs.size() ? recs[ordinal + 1].ustart : u.size();
+                auto w32 = [&](uint32_t v) { memcpy(w, &v, 4); w += 4; };
+                auto w16 = [&](uint16_t v) { memcpy(w, &v, 2); w += 2; };
+                const uint32_t c0 = k.cig_off[i], c1 = k.cig_off[i + 1];
+                const int32_t l = k.lq[i];
+                const size_t sb = (size_t)(l + 1) / 2;
+                const bool has_xs = k.xs[i] == 1 || k.xs[i] == 2;
+                w32((uint32_t)(next - r.ustart - 4));
+                w32((uint32_t)c);
+                w32((uint32_t)k.pos[i]);
+                *w++ = (uint8_t)NAME_LEN;
+                *w++ = k.mapq[i];
+                w16((uint16_t)reg2bin(r.pos, r.end));
+                w16((uint16_t)(c1 - c0));
+                w16(k.flag[i]);
+                w32((uint32_t)l);
+                w32((uint32_t)k.mtid[i]);
+                w32((uint32_t)k.mpos[i]);
+                w32(0);
+                char name[16];
+                snprintf(name, sizeof name, "s%010llu", (unsigned long long)ordinal);
+                memcpy(w, name, NAME_LEN);
+                w += NAME_LEN;
+                memcpy(w, &k.cigar[c0], 4ull * (c1 - c0));
+                w += 4ull * (c1 - c0);
+                uint32_t lcg = (uint32_t)(ordinal * 2654435761ull) ^ 12345u;
+                const uint32_t words = k.seq_off[i + 1] - k.seq_off[i];
+                if ((size_t)words * 4 >= sb && sb) {
+                    memcpy(w, &k.seq4[(size_t)k.seq_off[i] * 4], sb);
+                    w += sb;
+                } else
+                    for (size_t q = 0; q < sb; q++) {  // unspliced reads carry no bases in the SoA: synthesise some
+                        lcg = lcg * 1664525u + 1013904223u;
+                        const uint8_t a = (uint8_t)(1u << ((lcg >> 24) & 3)), b = (uint8_t)(1u << ((lcg >> 26) & 3));
+                        *w++ = (uint8_t)((a << 4) | b);
+                    }
+                for (int32_t q = 0; q < l; q++) {  // qualities with realistic entropy
+                    lcg = lcg * 1664525u + 1013904223u;
+                    *w++ = (uint8_t)(2 + ((lcg >> 20) % 39));
+                }
+                if (has_xs) {
+                    *w++ = 'X'; *w++ = 'S'; *w++ = 'A';
+                    *w++ = k.xs[i] == 1 ? '+' : '-';
+                }
+                *w++ = 'N'; *w++ = 'H'; *w++ = 'C'; *w++ = 1;
+                if ((uint64_t)(w - &u[0]) != next) {
+                    fprintf(stderr, "soa2bam: record %zu laid out wrong\n", ordinal);
+                    abort();
+                }
+            }
+        });
+        k = Contig();  // the SoA arrays of this contig are no longer needed
     }
     // ---- BGZF, compressed in parallel
     const size_t BLK = 0xff00;
@@ -241,10 +302,19 @@ int main(int argc, char** argv) {
     };
     std::vector<std::map<uint32_t, std::vector<std::pair<uint64_t, uint64_t>>>> bins(ncontig);
     std::vector<std::vector<uint64_t>> lin(ncontig);
+    std::vector<std::pair<uint64_t, uint64_t>>* cur = nullptr;
+    int32_t cur_tid = -1;
+    uint32_t cur_bin = 0;
     for (size_t i = 0; i < recs.size(); i++) {
         const Rec& r = recs[i];
         const uint64_t vs = voff(r.ustart), ve = voff(i + 1 < recs.size() ? recs[i + 1].ustart : u.size());
-        auto& ch = bins[r.tid][(uint32_t)reg2bin(r.pos, r.end)];
+        const uint32_t bin = (uint32_t)reg2bin(r.pos, r.end);
+        if (r.tid != cur_tid || bin != cur_bin) {
+            cur = &bins[r.tid][bin];
+            cur_tid = r.tid;
+            cur_bin = bin;
+        }
+        auto& ch = *cur;
         if (!ch.empty() && ch.back().second == vs) ch.back().second = ve;
         else ch.push_back({vs, ve});
         const size_t w0 = (size_t)(r.pos >> 14), w1 = (size_t)((r.end - 1) >> 14);
