@@ -48,7 +48,7 @@
 extern "C" {
 #endif
 
-#define PJB_ABI_VERSION 1
+#define PJB_ABI_VERSION 2 /* 2: pjb_batch.name_hash, PJB_FLAG_EXTRA, pjb_extra_finish */
 
 /* ---- status codes ------------------------------------------------------ */
 #define PJB_OK 0
@@ -100,6 +100,11 @@ typedef struct pjb_config {
 /* record a HIP event pair around every kernel launch and accumulate per-kernel time
  * (pjb_get_kernel_timing); costs ~1 us per launch, off by default */
 #define PJB_FLAG_KERNEL_TIMING 1u
+/* `junc --extra` (JunctionBuilder::setExtra, src/junction_builder.hpp:166; calcExtraMetrics,
+ * src/junction_builder.cc:293-312): every pjb_finish_contig also builds the contig's unspliced per-base depth,
+ * the flanking alignment counts of its junctions and keeps the name codes of its spliced records; pjb_extra_finish
+ * then yields mm_score / coverage / up_aln / down_aln for every row.  Batches must carry name_hash. */
+#define PJB_FLAG_EXTRA 2u
 
 /* One batch of fixed-width alignment records of ONE contig, in BAM file order
  * (structure of arrays; BAM-native encodings):
@@ -124,6 +129,10 @@ typedef struct pjb_batch {
     const uint32_t *cigar;
     const uint32_t *seq_off;
     const uint8_t *seq4;
+    /* std::hash<std::string>()(BamAlignment::deriveName()) per record (lib/include/portcullis/junction.hpp:158,
+     * lib/src/bam_alignment.cc:233-242: QNAME, plus "_R1" / "_R2" / "_R?" for paired reads); only read by
+     * contexts created with PJB_FLAG_EXTRA, may be NULL otherwise. */
+    const uint64_t *name_hash;
 } pjb_batch;
 
 /* RegionResult (src/junction_builder.hpp:62-76) plus sizes of what was built */
@@ -220,6 +229,21 @@ int pjb_collect_device(pjb_ctx *ctx, const pjb_junction_row **device_rows, int64
 #define PJB_MIRROR_HEADER_BYTES 64
 int pjb_set_row_mirror(pjb_ctx *ctx, void *device_buffer, int64_t cap_bytes);
 int pjb_clear_rows(pjb_ctx *ctx);
+
+/* The --extra columns of one junction (lib/include/portcullis/junction.hpp:240-243). */
+typedef struct pjb_extra_row {
+    double mm_score;  /* Junction::calcMultipleMappingScore, lib/src/junction.cc:914-921 */
+    double coverage;  /* Junction::calcCoverage, lib/src/junction.cc:935-951, on DepthParser's vector
+                         (lib/src/depth_parser.cc:112-164), handed out per JunctionSystem::calcCoverage
+                         (lib/src/junction_system.cc:231-242) */
+    uint32_t up_aln;  /* nbUpstreamFlankingAlignments, lib/src/junction.cc:651-677 */
+    uint32_t down_aln;
+} pjb_extra_row;
+/* JunctionBuilder::calcExtraMetrics (src/junction_builder.cc:293-312) once every contig of the FILE has been
+ * finished on this context (the name multiplicities and the depth hand-over between consecutive targets are
+ * file-wide): one pjb_extra_row per row of pjb_collect, same order.  Needs PJB_FLAG_EXTRA.  The pointer stays
+ * valid until the next pjb_clear_rows / pjb_destroy. */
+int pjb_extra_finish(pjb_ctx *ctx, const pjb_extra_row **rows, int64_t *n_rows);
 
 int pjb_get_timing(const pjb_ctx *ctx, pjb_timing *out);
 

@@ -1,6 +1,7 @@
 // pjb_api.hip -- C ABI (include/portcullis_amd.h) over the HIP kernels.
 // One context = one HIP device + one stream + a grow-only scratch arena.
 #include "pjb_kernels.hip.h"
+#include "pjb_extra.hip.h"
 #include "pjb_ingest.hip.h"
 
 #include <algorithm>
@@ -55,6 +56,21 @@ struct OpenContig {
 
 } // namespace
 
+// --extra: what is kept of a finished contig until pjb_extra_finish
+struct ExtraContig {
+    int32_t tid = -1;
+    int32_t len = 0;
+    u32 *cover = nullptr;      // per-base depth of the unspliced records (len + 2 entries), nullptr: none
+    bool has_unspliced = false;
+    size_t row_base = 0, n_rows = 0;
+    ExtraRow *xr = nullptr;    // n_rows entries (flanking counts now; m_sum / mm_score / coverage in phase 2)
+    u64 *pair_code = nullptr;  // per sorted pair: name code of its record
+    u32 *pair_row = nullptr;   //                  row (index into the context's row table)
+    u32 n_pairs = 0;
+    u64 *spl_codes = nullptr;  // name codes of the contig's spliced records
+    u32 n_spl = 0;
+};
+
 struct pjb_ctx {
     pjb_config cfg;
     hipStream_t stream = nullptr;
@@ -103,6 +119,11 @@ struct pjb_ctx {
     Buf b_inf_comp, b_inf_out, b_inf_blocks, b_inf_status, b_inf_scratch; // device-side BGZF inflate
     Buf b_bam_seg, b_bam_rec, b_bam_ctl;                                  // device-side BAM record parse
     Buf b_jid, b_seg, b_runfirst, b_runstart;
+    // --extra
+    bool extra = false;
+    std::vector<ExtraContig> xc;
+    std::vector<pjb_extra_row> xrows_host;
+    Buf x_pos, x_endx, x_q, x_prefq, x_ce, x_bound, x_de, x_dropped, x_zlist, x_cnt, x_tabk, x_tabc, x_rs, x_re, x_rr;
     Buf b_frag, b_fragj, b_fragl, b_fragr, b_acc, b_ancl, b_ancr, b_rows, b_hasx, b_ent, b_res, b_genlist, b_gencount;
 };
 
@@ -296,6 +317,18 @@ void *slab_alloc(pjb_ctx *c, OpenContig &oc, size_t bytes) {
     return s.p;
 }
 
+void extra_clear(pjb_ctx *c) {
+    for (auto &x : c->xc) {
+        if (x.cover) (void)hipFree(x.cover);
+        if (x.xr) (void)hipFree(x.xr);
+        if (x.pair_code) (void)hipFree(x.pair_code);
+        if (x.pair_row) (void)hipFree(x.pair_row);
+        if (x.spl_codes) (void)hipFree(x.spl_codes);
+    }
+    c->xc.clear();
+    c->xrows_host.clear();
+}
+
 int close_contig(pjb_ctx *c, int32_t tid) {
     auto it = c->open.find(tid);
     if (it == c->open.end()) return PJB_OK;
@@ -363,6 +396,7 @@ int pjb_create(pjb_ctx **out, const pjb_config *cfg) {
     (void)hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming);
     for (auto &ev : c->ev) (void)hipEventCreate(&ev);
     c->ktime = (cfg->flags & PJB_FLAG_KERNEL_TIMING) != 0;
+    c->extra = (cfg->flags & PJB_FLAG_EXTRA) != 0;
     if (const char *s = getenv("PJB_RADIX_BITS")) {
         int v = atoi(s);
         if (v >= 4 && v <= RS_MAX_BITS) c->radix_max_bits = v;
@@ -380,6 +414,7 @@ void pjb_destroy(pjb_ctx *c) {
     (void)hipSetDevice(c->cfg.device);
     (void)hipStreamSynchronize(c->stream);
     while (!c->open.empty()) close_contig(c, c->open.begin()->first);
+    extra_clear(c);
     for (auto &g : c->contigs) free_contig(g);
     for (auto &sl : c->slab_pool)
         if (sl.p) (void)hipFree(sl.p);
@@ -393,7 +428,9 @@ void pjb_destroy(pjb_ctx *c) {
                   &c->b_key[1], &c->b_idx[0], &c->b_idx[1], &c->b_g, &c->b_lstart, &c->b_rend, &c->b_pos, &c->b_aend,
                   &c->b_meta, &c->b_updown, &c->b_hist, &c->b_hist_scan, &c->b_scan_tiles, &c->b_jid, &c->b_seg,
                   &c->b_runfirst, &c->b_runstart, &c->b_frag, &c->b_fragj, &c->b_fragl, &c->b_fragr, &c->b_acc,
-                  &c->b_ancl, &c->b_ancr, &c->b_rows, &c->b_hasx, &c->b_ent, &c->b_splidx, &c->b_splpoff, &c->b_res, &c->b_genlist, &c->b_gencount, &c->b_bintotal, &c->b_inf_comp, &c->b_inf_out, &c->b_inf_blocks, &c->b_inf_status, &c->b_inf_scratch, &c->b_bam_seg, &c->b_bam_rec, &c->b_bam_ctl};
+                  &c->b_ancl, &c->b_ancr, &c->b_rows, &c->b_hasx, &c->b_ent, &c->b_splidx, &c->b_splpoff, &c->b_res, &c->b_genlist, &c->b_gencount, &c->b_bintotal, &c->b_inf_comp, &c->b_inf_out, &c->b_inf_blocks, &c->b_inf_status, &c->b_inf_scratch, &c->b_bam_seg, &c->b_bam_rec, &c->b_bam_ctl,
+                  &c->x_pos, &c->x_endx, &c->x_q, &c->x_prefq, &c->x_ce, &c->x_bound, &c->x_de, &c->x_dropped, &c->x_zlist, &c->x_cnt,
+                  &c->x_tabk, &c->x_tabc, &c->x_rs, &c->x_re, &c->x_rr};
     for (Buf *b : all) release(*b);
     for (auto &ev : c->ev) (void)hipEventDestroy(ev);
     for (auto &ev : c->ev_pool) (void)hipEventDestroy(ev);
@@ -529,6 +566,7 @@ static int add_batch(pjb_ctx *c, int32_t tid, const pjb_batch *b, bool device) {
     if (!b->pos || !b->flag || !b->mapq || !b->xs || !b->l_qseq || !b->mtid || !b->mpos || !b->cig_off || !b->cigar ||
         !b->seq_off)
         return fail(c, PJB_ERR_ARG, "submit: null array in batch");
+    if (c->extra && !b->name_hash) return fail(c, PJB_ERR_ARG, "submit: a PJB_FLAG_EXTRA context needs pjb_batch.name_hash");
     uint64_t total = 0;
     for (auto &x : oc.batches) total += (uint64_t)x.n;
     if (total + (uint64_t)b->n_reads >= 0xffffff00ull)
@@ -541,14 +579,17 @@ static int add_batch(pjb_ctx *c, int32_t tid, const pjb_batch *b, bool device) {
     if (device) {
         d.pos = b->pos; d.flag = b->flag; d.mapq = b->mapq; d.xs = b->xs; d.l_qseq = b->l_qseq; d.mtid = b->mtid;
         d.mpos = b->mpos; d.cig_off = b->cig_off; d.cigar = b->cigar; d.seq_off = b->seq_off; d.seq4 = b->seq4;
+        d.name_hash = c->extra ? (const u64 *)b->name_hash : nullptr;
     } else {
         const size_t n = (size_t)b->n_reads;
         const size_t n_ops = b->cig_off[n], n_words = b->seq_off[n];
-        const void *src[11] = {b->pos, b->flag, b->mapq, b->xs, b->l_qseq, b->mtid, b->mpos, b->cig_off, b->cigar, b->seq_off, b->seq4};
-        const size_t bytes[11] = {n * 4, n * 2, n, n, n * 4, n * 4, n * 4, (n + 1) * 4, n_ops * 4, (n + 1) * 4, n_words * 4};
+        const void *src[12] = {b->pos, b->flag, b->mapq, b->xs, b->l_qseq, b->mtid, b->mpos, b->cig_off, b->cigar, b->seq_off, b->seq4,
+                               c->extra ? b->name_hash : nullptr};
+        const size_t bytes[12] = {n * 4, n * 2, n, n, n * 4, n * 4, n * 4, (n + 1) * 4, n_ops * 4, (n + 1) * 4, n_words * 4,
+                                  c->extra ? n * 8 : 0};
         // pack into a staging buffer, one DMA to a device slab region with the same packing
-        size_t offs[11], total_b = 0;
-        for (int k = 0; k < 11; k++) {
+        size_t offs[12], total_b = 0;
+        for (int k = 0; k < 12; k++) {
             offs[k] = total_b;
             total_b += (std::max<size_t>(bytes[k], 16) + 255) & ~(size_t)255;
         }
@@ -569,8 +610,8 @@ static int add_batch(pjb_ctx *c, int32_t tid, const pjb_batch *b, bool device) {
         if (!c->stage_ev[si]) HIP_TRY(c, hipEventCreateWithFlags(&c->stage_ev[si], hipEventDisableTiming));
         uint8_t *dev = (uint8_t *)slab_alloc(c, oc, total_b);
         if (!dev) return fail(c, PJB_ERR_NOMEM, "submit: out of device memory for a batch of %zu bytes", total_b);
-        void *ptrs[11];
-        for (int k = 0; k < 11; k++) {
+        void *ptrs[12];
+        for (int k = 0; k < 12; k++) {
             if (bytes[k] && src[k]) parallel_copy(c->stage[si] + offs[k], src[k], bytes[k]);
             ptrs[k] = dev + offs[k];
         }
@@ -581,6 +622,7 @@ static int add_batch(pjb_ctx *c, int32_t tid, const pjb_batch *b, bool device) {
         d.xs = (const uint8_t *)ptrs[3]; d.l_qseq = (const int32_t *)ptrs[4]; d.mtid = (const int32_t *)ptrs[5];
         d.mpos = (const int32_t *)ptrs[6]; d.cig_off = (const uint32_t *)ptrs[7]; d.cigar = (const uint32_t *)ptrs[8];
         d.seq_off = (const uint32_t *)ptrs[9]; d.seq4 = (const uint8_t *)ptrs[10];
+        d.name_hash = c->extra ? (const u64 *)ptrs[11] : nullptr;
     }
     oc.batches.push_back(d);
     oc.last_known.push_back(device ? 0 : 1);
@@ -615,6 +657,102 @@ static int mirror_header_only(pjb_ctx *c, const pjb_region_result &R) {
     mirror_fold(c, R, 0);
     HIP_TRY(c, hipMemcpyAsync(c->mirror, c->mirror_hdr, PJB_MIRROR_HEADER_BYTES, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return PJB_OK;
+}
+
+// --extra, per contig (calcExtraMetrics' per-target work, src/junction_builder.cc:293-312): the unspliced records'
+// per-base depth, the junctions' flanking alignment counts, and the name codes phase 2 needs.  Runs after the
+// contig's rows exist (b_rows, sidx, jid are still this contig's).
+constexpr u32 X_ZCAP = 1u << 20;
+static int extra_contig(pjb_ctx *c, int32_t tid, std::vector<DevBatch> &batches, int64_t n_reads, u64 n_spliced, u32 P, u32 J,
+                        const u32 *sidx, const u32 *pair_g, size_t row_base) {
+    hipStream_t st = c->stream;
+    const int32_t L = c->ref_len[(size_t)tid];
+    const size_t N = (size_t)n_reads;
+    ExtraContig X;
+    X.tid = tid;
+    X.len = L;
+    X.row_base = row_base;
+    X.n_rows = J;
+    X.n_pairs = P;
+    int rc;
+    if ((rc = ensure(c, c->x_pos, N * 4 + 16))) return rc;
+    if ((rc = ensure(c, c->x_endx, N * 4 + 16))) return rc;
+    if ((rc = ensure(c, c->x_q, N + 16))) return rc;
+    if ((rc = ensure(c, c->x_prefq, (N + 1) * 4))) return rc;
+    if ((rc = ensure(c, c->x_ce, ((size_t)L + 2) * 4))) return rc;
+    if ((rc = ensure(c, c->x_zlist, (size_t)X_ZCAP * 4))) return rc;
+    if ((rc = ensure(c, c->x_cnt, sizeof(ExtraCounters)))) return rc;
+    struct Guard { // frees what this contig allocated unless it is handed over to the context
+        ExtraContig *x;
+        ~Guard() {
+            if (!x) return;
+            if (x->cover) (void)hipFree(x->cover);
+            if (x->xr) (void)hipFree(x->xr);
+            if (x->pair_code) (void)hipFree(x->pair_code);
+            if (x->pair_row) (void)hipFree(x->pair_row);
+            if (x->spl_codes) (void)hipFree(x->spl_codes);
+        }
+    } guard{&X};
+    if (hipMalloc((void **)&X.cover, ((size_t)L + 2) * 4) != hipSuccess) return fail(c, PJB_ERR_NOMEM, "extra: depth array of target %d", tid);
+    if (hipMalloc((void **)&X.spl_codes, std::max<size_t>((size_t)n_spliced, 1) * 8) != hipSuccess)
+        return fail(c, PJB_ERR_NOMEM, "extra: name codes of target %d", tid);
+    HIP_TRY(c, hipMemsetAsync(X.cover, 0, ((size_t)L + 2) * 4, st));
+    HIP_TRY(c, hipMemsetAsync(c->x_ce.p, 0, ((size_t)L + 2) * 4, st));
+    HIP_TRY(c, hipMemsetAsync((uint8_t *)c->x_q.p + N, 0, 1, st));
+    ExtraCounters hc;
+    memset(&hc, 0, sizeof hc);
+    hc.hot_first = 0xffffffffu;
+    HIP_TRY(c, hipMemcpyAsync(c->x_cnt.p, &hc, sizeof hc, hipMemcpyHostToDevice, st));
+    ExtraCounters *d_cnt = (ExtraCounters *)c->x_cnt.p;
+    int32_t *x_pos = (int32_t *)c->x_pos.p, *x_endx = (int32_t *)c->x_endx.p;
+    uint8_t *x_q = (uint8_t *)c->x_q.p;
+    u32 *prefq = (u32 *)c->x_prefq.p, *ce = (u32 *)c->x_ce.p;
+    for (auto &b : batches)
+        LAUNCH(c, "kx_classify", kx_classify, dim3((unsigned)((b.n + 255) / 256)), dim3(256), b, L, x_pos, x_endx, x_q, ce,
+               (int32_t *)X.cover, (u32 *)c->x_zlist.p, X_ZCAP, X.spl_codes, d_cnt);
+    if ((rc = run_scan(c, "kx_ends", ArrU32Fn{ce}, ExclusiveU32Sink{ce}, (u64)L + 2, (u64 *)c->b_total.p))) return rc;
+    if ((rc = run_scan(c, "kx_unspl", ArrU8Fn{x_q}, ExclusiveU32Sink{prefq}, (u64)N + 1, (u64 *)c->b_total.p))) return rc;
+    LAUNCH(c, "kx_cap_bound", kx_cap_bound, dim3((unsigned)((N + 255) / 256)), dim3(256), (const int32_t *)x_pos, (const uint8_t *)x_q,
+           (const u32 *)prefq, (const u32 *)ce, (u32)N, L, (u32 *)nullptr, d_cnt);
+    u32 n_unspl = 0;
+    HIP_TRY(c, hipMemcpyAsync(&hc, d_cnt, sizeof hc, hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipMemcpyAsync(&n_unspl, prefq + N, 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipStreamSynchronize(st));
+    if (hc.n_zero > X_ZCAP)
+        return fail(c, PJB_ERR_ARG, "extra: target %d has %u mapped records without a reference span (limit %u)", tid, hc.n_zero, X_ZCAP);
+    if (hc.max_buffered + 2 > PLP_MAXCNT) { // the pileup's record cap may bite: replay it over the hot span
+        if ((rc = ensure(c, c->x_bound, N * 4 + 16))) return rc;
+        if ((rc = ensure(c, c->x_de, ((size_t)L + 2) * 4))) return rc;
+        if ((rc = ensure(c, c->x_dropped, N + 16))) return rc;
+        HIP_TRY(c, hipMemsetAsync(c->x_de.p, 0, ((size_t)L + 2) * 4, st));
+        HIP_TRY(c, hipMemsetAsync(c->x_dropped.p, 0, N + 16, st));
+        LAUNCH(c, "kx_cap_bound", kx_cap_bound, dim3((unsigned)((N + 255) / 256)), dim3(256), (const int32_t *)x_pos,
+               (const uint8_t *)x_q, (const u32 *)prefq, (const u32 *)ce, (u32)N, L, (u32 *)c->x_bound.p, d_cnt);
+        LAUNCH(c, "kx_cap_replay", kx_cap_replay, dim3(1), dim3(64), (const int32_t *)x_pos, (const int32_t *)x_endx, (const uint8_t *)x_q,
+               (const u32 *)c->x_bound.p, (u32)N, L, (u32 *)c->x_de.p, (uint8_t *)c->x_dropped.p, d_cnt);
+        for (auto &b : batches)
+            LAUNCH(c, "kx_undo_dropped", kx_undo_dropped, dim3((unsigned)((b.n + 255) / 256)), dim3(256), b, L,
+                   (const uint8_t *)c->x_dropped.p, (int32_t *)X.cover);
+    }
+    if ((rc = run_scan(c, "kx_depth", ArrI32Fn{(const int32_t *)X.cover}, InclusiveU32Sink{X.cover}, (u64)L + 1, (u64 *)c->b_total.p)))
+        return rc;
+    X.has_unspliced = n_unspl > 0;
+    X.n_spl = hc.n_spliced;
+    if (J > 0) {
+        if (hipMalloc((void **)&X.xr, (size_t)J * sizeof(ExtraRow)) != hipSuccess) return fail(c, PJB_ERR_NOMEM, "extra: rows of target %d", tid);
+        HIP_TRY(c, hipMemsetAsync(X.xr, 0, (size_t)J * sizeof(ExtraRow), st));
+        LAUNCH(c, "kx_flank", kx_flank, dim3((J + 255) / 256), dim3(256), (const pjb_junction_row *)c->b_rows.p, J, (const int32_t *)x_pos,
+               (u32)N, (const u32 *)prefq, (const u32 *)ce, L, (const u32 *)c->x_zlist.p, (const ExtraCounters *)d_cnt, X_ZCAP, X.xr);
+        if (hipMalloc((void **)&X.pair_code, (size_t)P * 8) != hipSuccess || hipMalloc((void **)&X.pair_row, (size_t)P * 4) != hipSuccess)
+            return fail(c, PJB_ERR_NOMEM, "extra: pair codes of target %d", tid);
+        LAUNCH(c, "kx_pair_codes", kx_pair_codes, dim3((P + 255) / 256), dim3(256), sidx, (const u32 *)c->b_jid.p, pair_g,
+               (const DevBatch *)c->b_batches.p, (int)batches.size(), P, (u32)row_base, X.pair_code, X.pair_row);
+    }
+    HIP_TRY(c, hipStreamSynchronize(st));
+    if (c->ktime) ev_collect(c);
+    c->xc.push_back(X);
+    guard.x = nullptr;
     return PJB_OK;
 }
 
@@ -705,6 +843,7 @@ int pjb_finish_contig(pjb_ctx *c, int32_t tid, pjb_region_result *res) {
     const u64 P64 = cs.n_pairs;
     if (P64 == 0) {
         if (res) *res = R;
+        if (c->extra && (rc = extra_contig(c, tid, batches, n_reads, cs.spliced, 0, 0, nullptr, nullptr, c->rows_n))) return rc;
         return mirror_header_only(c, R);
     }
     if (P64 >= 0xfffffff0ull) return fail(c, PJB_ERR_ARG, "finish: more than 2^32 spliced pairs on one target are not supported");
@@ -910,6 +1049,7 @@ int pjb_finish_contig(pjb_ctx *c, int32_t tid, pjb_region_result *res) {
     HIP_TRY(c, hipEventRecord(c->ev[7], st));
     HIP_TRY(c, hipStreamSynchronize(st));
     if ((rc = check_device_error(c, herr))) return rc;
+    if (c->extra && (rc = extra_contig(c, tid, batches, n_reads, cs.spliced, P, J, sidx, pr.g, old))) return rc;
     c->rows_n = old + J;
     c->last_rows_n = J;
     c->timing.generic_pairs = 0;
@@ -952,6 +1092,99 @@ int pjb_clear_rows(pjb_ctx *c) {
     if (!c) return PJB_ERR_ARG;
     c->rows_n = 0;
     mirror_reset(c);
+    if (c->extra) {
+        (void)hipSetDevice(c->cfg.device);
+        (void)hipStreamSynchronize(c->stream);
+        extra_clear(c);
+    }
+    return PJB_OK;
+}
+
+int pjb_extra_finish(pjb_ctx *c, const pjb_extra_row **rows_out, int64_t *n_out) {
+    if (!c || !rows_out || !n_out) return PJB_ERR_ARG;
+    if (!c->extra) return fail(c, PJB_ERR_STATE, "pjb_extra_finish: the context was not created with PJB_FLAG_EXTRA");
+    if (!c->open.empty()) return fail(c, PJB_ERR_STATE, "pjb_extra_finish: target %d is still open", c->open.begin()->first);
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    hipStream_t st = c->stream;
+    int rc;
+    const size_t Jall = c->rows_n;
+    c->xrows_host.assign(Jall, pjb_extra_row{0.0, 0.0, 0u, 0u});
+    *rows_out = c->xrows_host.data();
+    *n_out = (int64_t)Jall;
+    if (Jall == 0) return PJB_OK;
+    // ---- splicedAlignmentMap over every spliced record of the file (src/junction_builder.cc:168-176)
+    size_t S = 0;
+    for (auto &x : c->xc) S += x.n_spl;
+    size_t cap = 1024;
+    while (cap < 2 * S + 1) cap <<= 1;
+    if (cap > (1ull << 32)) return fail(c, PJB_ERR_ARG, "pjb_extra_finish: more than 2^31 spliced records");
+    if ((rc = ensure(c, c->x_tabk, cap * 8))) return rc;
+    if ((rc = ensure(c, c->x_tabc, cap * 4))) return rc;
+    HIP_TRY(c, hipMemsetAsync(c->x_tabk.p, 0xff, cap * 8, st));
+    HIP_TRY(c, hipMemsetAsync(c->x_tabc.p, 0, cap * 4, st));
+    const u32 mask = (u32)(cap - 1);
+    for (auto &x : c->xc)
+        if (x.n_spl)
+            LAUNCH(c, "kx_name_insert", kx_name_insert, dim3((x.n_spl + 255) / 256), dim3(256), (const u64 *)x.spl_codes, x.n_spl,
+                   (u64 *)c->x_tabk.p, (u32 *)c->x_tabc.p, mask);
+    for (auto &x : c->xc)
+        if (x.n_pairs && x.xr)
+            LAUNCH(c, "kx_name_sum", kx_name_sum, dim3((x.n_pairs + 255) / 256), dim3(256), (const u64 *)x.pair_code, (const u32 *)x.pair_row,
+                   x.n_pairs, (const u64 *)c->x_tabk.p, (const u32 *)c->x_tabc.p, mask, x.xr - x.row_base);
+    // ---- rows as SoA on the device (start, end, nb_raw)
+    std::vector<int32_t> hs(Jall), he(Jall);
+    std::vector<uint32_t> hr(Jall);
+    for (size_t j = 0; j < Jall; j++) {
+        hs[j] = c->rows_pinned[j].start;
+        he[j] = c->rows_pinned[j].end;
+        hr[j] = c->rows_pinned[j].nb_raw;
+    }
+    if ((rc = ensure(c, c->x_rs, Jall * 4))) return rc;
+    if ((rc = ensure(c, c->x_re, Jall * 4))) return rc;
+    if ((rc = ensure(c, c->x_rr, Jall * 4))) return rc;
+    HIP_TRY(c, hipMemcpyAsync(c->x_rs.p, hs.data(), Jall * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(c, hipMemcpyAsync(c->x_re.p, he.data(), Jall * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(c, hipMemcpyAsync(c->x_rr.p, hr.data(), Jall * 4, hipMemcpyHostToDevice, st));
+    // ---- JunctionSystem::calcCoverage (lib/src/junction_system.cc:231-242).  DepthParser::loadNextBatch
+    // (lib/src/depth_parser.cc:112-164) returns the vector of the target it started in, but by then `last`
+    // names the target the pileup has moved on to, and getCurrentRefIndex() selects THAT target's junctions:
+    // every batch is applied to the junctions of the next target that has unspliced records; only the final
+    // batch (the pileup ended inside it) meets its own junctions, after they were first given the previous
+    // target's.  Targets without unspliced records never appear.
+    std::vector<const ExtraContig *> T;
+    for (auto &x : c->xc)
+        if (x.has_unspliced) T.push_back(&x);
+    std::sort(T.begin(), T.end(), [](const ExtraContig *a, const ExtraContig *b) { return a->tid < b->tid; });
+    for (size_t k = 0; k < T.size(); k++) {
+        const ExtraContig &x = *T[k];
+        if (!x.n_rows) continue;
+        const ExtraContig *src = (k + 1 == T.size()) ? &x : (k > 0 ? T[k - 1] : nullptr);
+        if (!src) continue; // the first target's junctions are never visited (unless it is also the last)
+        LAUNCH(c, "kx_coverage", kx_coverage, dim3((unsigned)((x.n_rows + 255) / 256)), dim3(256), (const int32_t *)c->x_rs.p,
+               (const int32_t *)c->x_re.p, (const uint32_t *)c->x_rr.p, (u32)x.row_base, (u32)x.n_rows, (const u32 *)src->cover, src->len,
+               x.xr - x.row_base);
+    }
+    std::vector<ExtraRow> tmp;
+    for (auto &x : c->xc) {
+        if (!x.n_rows) continue;
+        LAUNCH(c, "kx_mm_score", kx_mm_score, dim3((unsigned)((x.n_rows + 255) / 256)), dim3(256), (const uint32_t *)c->x_rr.p + x.row_base,
+               (u32)x.n_rows, x.xr);
+    }
+    for (auto &x : c->xc) {
+        if (!x.n_rows) continue;
+        tmp.resize(x.n_rows);
+        HIP_TRY(c, hipMemcpyAsync(tmp.data(), x.xr, x.n_rows * sizeof(ExtraRow), hipMemcpyDeviceToHost, st));
+        HIP_TRY(c, hipStreamSynchronize(st));
+        for (size_t j = 0; j < x.n_rows; j++) {
+            pjb_extra_row &o = c->xrows_host[x.row_base + j];
+            o.mm_score = tmp[j].mm_score;
+            o.coverage = tmp[j].coverage;
+            o.up_aln = tmp[j].up_aln;
+            o.down_aln = tmp[j].down_aln;
+        }
+    }
+    HIP_TRY(c, hipStreamSynchronize(st));
+    if (c->ktime) ev_collect(c);
     return PJB_OK;
 }
 
@@ -1274,6 +1507,11 @@ extern "C" int pjb_submit_bam(pjb_ctx *c, int32_t tid, const uint8_t *comp, int6
     B.seq_off = (iu32 *)(dev + offs[8]);
     B.cigar = nullptr;
     B.seq4 = nullptr;
+    B.name_hash = nullptr;
+    if (c->extra) {
+        B.name_hash = (iu64 *)slab_alloc(c, oc, n * 8 + 16);
+        if (!B.name_hash) return fail(c, PJB_ERR_NOMEM, "submit_bam: out of device memory for name codes");
+    }
     if ((rc = run_scan(c, "bam_sizes", BamSizesFn{R.U, (const iu64 *)c->b_bam_rec.p}, BamOffsetsSink{B.cig_off, B.seq_off}, n, d_total)))
         return rc;
     iu64 tot = 0;
@@ -1300,6 +1538,7 @@ extern "C" int pjb_submit_bam(pjb_ctx *c, int32_t tid, const uint8_t *comp, int6
     d.base = 0;
     d.pos = B.pos; d.flag = B.flag; d.mapq = B.mapq; d.xs = B.xs; d.l_qseq = B.l_qseq; d.mtid = B.mtid; d.mpos = B.mpos;
     d.cig_off = B.cig_off; d.cigar = B.cigar; d.seq_off = B.seq_off; d.seq4 = B.seq4;
+    d.name_hash = (const u64 *)B.name_hash;
     oc.batches.push_back(d);
     oc.last_known.push_back(0);
     oc.last_pos.push_back(INT32_MIN);

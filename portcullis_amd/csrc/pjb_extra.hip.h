@@ -1,0 +1,366 @@
+// pjb_extra.hip.h -- `junc --extra` on the device: the three metric families the
+// reference computes after the main pass, single-threaded, by re-reading BAM files it has just split off
+// (src/junction_builder.cc:152-226,293-312):
+//   mm_score          Junction::calcMultipleMappingScore              lib/src/junction.cc:914-921
+//   up_aln, down_aln  Junction::processJunctionVicinity               lib/src/junction.cc:651-677
+//   coverage          DepthParser::loadNextBatch + Junction::calcCoverage
+//                                                                     lib/src/depth_parser.cc:112-164, junction.cc:923-951
+// Here they come from the alignment records that are already in HBM for the main pass:
+//   * "unspliced.bam" = records without an N operation that are mapped (junction_builder.cc:168-186);
+//   * per-base depth = difference array over their M / = / X runs + one scan (replaces htslib's pileup,
+//     deps/htslib-1.3/sam.c:1853-1975, including its 8000-record cap -- see kx_cap_*);
+//   * flanking counts = two rank queries: records starting before the intron minus records ending before
+//     the left anchor; records starting inside the right anchor;
+//   * name multiplicities = one open-addressing table over the 64-bit codes of every spliced record.
+#pragma once
+
+#include "pjb_kernels.hip.h"
+
+namespace pjb {
+
+// ---- std::hash<std::string> (libstdc++ _Hash_bytes, 64-bit: a MurmurHash64A variant, seed 0xc70f6907) of
+// BamAlignment::deriveName() (lib/src/bam_alignment.cc:233-242; lib/include/portcullis/junction.hpp:158).
+// `name` has `len` bytes without the NUL.  Used by the device record transcoder; the host transcoder has the
+// same function (portcullis/bam/name_hash.hpp).
+__host__ __device__ inline u64 std_hash_shift_mix(u64 v) { return v ^ (v >> 47); }
+__host__ __device__ inline u64 derive_name_hash(const uint8_t *name, u32 len, u32 flag) {
+    const u64 mul = (((u64)0xc6a4a793UL) << 32) + (u64)0x5bd1e995UL;
+    uint8_t suf[3] = {'_', 'R', '?'};
+    u32 total = len;
+    if (flag & 0x1u) {
+        suf[2] = (flag & 0x40u) ? '1' : (flag & 0x80u) ? '2' : '?';
+        total += 3;
+    }
+    auto at = [&](u32 i) -> u64 { return i < len ? name[i] : suf[i - len]; };
+    u64 hash = 0xc70f6907ULL ^ ((u64)total * mul);
+    const u32 aligned = total & ~7u;
+    for (u32 p = 0; p < aligned; p += 8) {
+        u64 w = 0;
+        for (int k = 7; k >= 0; k--) w = (w << 8) | at(p + (u32)k); // little-endian unaligned load
+        const u64 data = std_hash_shift_mix(w * mul) * mul;
+        hash ^= data;
+        hash *= mul;
+    }
+    if (total & 7u) {
+        u64 data = 0;
+        for (int n = (int)(total & 7u) - 1; n >= 0; n--) data = (data << 8) + at(aligned + (u32)n);
+        hash ^= data;
+        hash *= mul;
+    }
+    hash = std_hash_shift_mix(hash) * mul;
+    hash = std_hash_shift_mix(hash);
+    return hash;
+}
+
+constexpr u32 PLP_MAXCNT = 8000; // bam_plp_init, deps/htslib-1.3/sam.c:1622
+
+struct ExtraCounters { // one per contig, device memory
+    u32 n_zero;       // unspliced mapped records with no reference-consuming op (zlist entries)
+    u32 n_spliced;    // spliced records appended to the name-code list
+    u32 max_buffered; // max over unspliced records of the pileup's buffered-record upper bound (cap detection)
+    u32 n_unspliced;  // unspliced mapped records with a reference span
+    u32 hot_first, hot_last; // first / last record ordinal whose bound reaches the cap
+    u32 n_dropped;
+    u32 _pad;
+};
+
+// KX1: one thread per record (every record of the contig).  Classifies the record as the reference's
+// separateBams does, records its position / exclusive end for the rank queries, counts its end in `ce`
+// and adds its M / = / X runs to the depth difference array; the name codes of spliced records are appended
+// (order is irrelevant: they only feed a multiset).
+__global__ __launch_bounds__(256) void kx_classify(DevBatch b, int32_t ref_len, int32_t *x_pos,
+                                                    int32_t *x_endx, uint8_t *q_flag, u32 *ce, int32_t *dd, u32 *zlist,
+                                                    u32 zcap, u64 *spl_codes, ExtraCounters *cnt) {
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool on = r < b.n;
+    bool spliced = false;
+    u64 code = 0;
+    if (on) {
+        const u32 g = b.base + (u32)r;
+        const u32 c0 = b.cig_off[r], c1 = b.cig_off[r + 1];
+        const int32_t pos = b.pos[r];
+        int32_t aligned = 0;
+        for (u32 k = c0; k < c1; k++) {
+            const u32 op = b.cigar[k];
+            const u32 ty = op & 15u;
+            if (ty == OP_N) spliced = true;
+            if (op_consumes_ref(ty)) aligned += (int32_t)(op >> 4);
+        }
+        const bool mapped = !(b.flag[r] & 0x4u);
+        const bool unspliced = !spliced && mapped; // a record of unspliced.bam
+        const bool spans = unspliced && aligned > 0 && pos >= 0;
+        x_pos[g] = pos;
+        x_endx[g] = pos + (aligned > 0 ? aligned : 1); // bam_endpos
+        q_flag[g] = spans ? 1 : 0;
+        if (unspliced && aligned == 0) { // getEnd() == pos - 1: handled one by one in kx_flank (practically never)
+            const u32 z = atomicAdd(&cnt->n_zero, 1u);
+            if (z < zcap) zlist[z] = (u32)pos;
+        }
+        if (spans) {
+            int32_t e = pos + aligned - 1; // getEnd()
+            if (e > ref_len) e = ref_len;
+            atomicAdd(&ce[e], 1u);
+            int32_t x = pos;
+            for (u32 k = c0; k < c1; k++) {
+                const u32 op = b.cigar[k];
+                const u32 ty = op & 15u;
+                const int32_t ln = (int32_t)(op >> 4);
+                if (ty == OP_M || ty == 7u || ty == 8u) {
+                    int32_t a = x, bb = x + ln;
+                    if (a < 0) a = 0;
+                    if (bb > ref_len) bb = ref_len;
+                    if (a < bb) {
+                        atomicAdd(&dd[a], 1);
+                        atomicAdd(&dd[bb], -1);
+                    }
+                }
+                if (op_consumes_ref(ty)) x += ln;
+            }
+        }
+        if (spliced) code = b.name_hash[r];
+    }
+    // wave-aggregated append of the spliced records' codes
+    const u64 m = __ballot(spliced);
+    if (m) {
+        const int leader = __ffsll((long long)m) - 1;
+        u32 base = 0;
+        if (lane_id() == leader) base = atomicAdd(&cnt->n_spliced, (u32)__popcll(m));
+        base = __shfl(base, leader, 64);
+        if (spliced) spl_codes[base + (u32)__popcll(m & ((1ull << lane_id()) - 1))] = code;
+    }
+}
+
+// scan functors -----------------------------------------------------------------------------------------------
+struct ArrU32Fn {
+    const u32 *a;
+    __device__ u64 operator()(u64 i) const { return a[i]; }
+};
+struct ArrU8Fn {
+    const uint8_t *a;
+    __device__ u64 operator()(u64 i) const { return a[i]; }
+};
+struct ArrI32Fn { // signed terms, summed modulo 2^64
+    const int32_t *a;
+    __device__ u64 operator()(u64 i) const { return (u64)(int64_t)a[i]; }
+};
+struct ExclusiveU32Sink { // out[i] = sum of the terms before i (may alias the input)
+    u32 *out;
+    __device__ void operator()(u64 i, u64, u64 ex) const { out[i] = (u32)ex; }
+};
+struct InclusiveU32Sink { // out[i] = sum of the terms up to and including i (may alias the input)
+    u32 *out;
+    __device__ void operator()(u64 i, u64 v, u64 ex) const { out[i] = (u32)(ex + v); }
+};
+
+// KX3: the pileup's record cap.  bam_plp_push (sam.c:1906) drops a record that starts where the iterator
+// stands -- the start of the last record it kept -- while more than maxcnt list nodes exist: the kept records
+// with bam_endpos >= that position, plus two.  An upper bound for record i: every earlier unspliced record with
+// endpos >= pos_i, kept or not = (unspliced records before i) - (unspliced records with endpos < pos_i).  If
+// the bound stays below maxcnt - 1 everywhere, nothing is dropped and the difference array already holds the
+// reference's depth (the normal case: it takes 8000-fold coverage of unspliced records).
+__global__ __launch_bounds__(256) void kx_cap_bound(const int32_t *x_pos, const uint8_t *q_flag, const u32 *prefix_q,
+                                                     const u32 *pe, u32 n, int32_t ref_len, u32 *bound, ExtraCounters *cnt) {
+    const u32 g = blockIdx.x * 256 + threadIdx.x;
+    u32 u = 0;
+    bool hot = false;
+    if (g < n && q_flag[g]) {
+        const int32_t p = x_pos[g];
+        // records with endpos < p  <=>  getEnd() < p - 1
+        const int32_t idx = p - 1 < 0 ? 0 : (p - 1 > ref_len + 1 ? ref_len + 1 : p - 1);
+        u = prefix_q[g] - pe[idx];
+        if (bound) bound[g] = u;
+        hot = u + 2 > PLP_MAXCNT;
+    }
+    const u32 wm = wave_max(u);
+    if (lane_id() == 0 && wm) atomicMax(&cnt->max_buffered, wm);
+    if (hot) {
+        atomicMin(&cnt->hot_first, g);
+        atomicMax(&cnt->hot_last, g);
+    }
+}
+
+// KX3b: exact replay of the cap over the span of records whose bound reaches it (outside the span every record
+// is kept whatever happened before: its list is at most its bound).  Sequential by nature -- whether a record is
+// kept depends on which earlier ones were -- so one lane walks the span; `de` (zeroed, ref_len + 2 entries)
+// counts dropped records by endpos.  Kept records inside the list = bound - dropped records still inside.
+__global__ void kx_cap_replay(const int32_t *x_pos, const int32_t *x_endx, const uint8_t *q_flag, const u32 *bound, u32 n,
+                              int32_t ref_len, u32 *de, uint8_t *dropped, ExtraCounters *cnt) {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    const u32 g0 = cnt->hot_first, g1 = cnt->hot_last;
+    if (g0 > g1 || g0 >= n) return;
+    // start of the last unspliced record before the span (it was kept: nothing before the span is dropped)
+    int32_t last_kept_pos = -1;
+    for (u32 g = g0; g-- > 0;)
+        if (q_flag[g]) {
+            last_kept_pos = x_pos[g];
+            break;
+        }
+    u32 dtotal = 0, dgone = 0;
+    int32_t sweep = x_pos[g0];
+    for (u32 g = g0; g <= g1; g++) {
+        if (!q_flag[g]) continue;
+        const int32_t p = x_pos[g];
+        while (sweep < p && sweep <= ref_len + 1) dgone += de[sweep++];
+        const u32 in_list = bound[g] - (dtotal - dgone);
+        if (p == last_kept_pos && in_list + 2 > PLP_MAXCNT) {
+            dropped[g] = 1;
+            int32_t e = x_endx[g];
+            if (e > ref_len + 1) e = ref_len + 1;
+            if (e < sweep) e = sweep;
+            de[e]++;
+            dtotal++;
+        } else
+            last_kept_pos = p;
+    }
+    cnt->n_dropped = dtotal;
+}
+
+// KX3c: take the dropped records' M / = / X runs back out of the difference array (before the scan).
+__global__ __launch_bounds__(256) void kx_undo_dropped(DevBatch b, int32_t ref_len, const uint8_t *dropped, int32_t *dd) {
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= b.n || !dropped[b.base + (u32)r]) return;
+    int32_t x = b.pos[r];
+    for (u32 k = b.cig_off[r]; k < b.cig_off[r + 1]; k++) {
+        const u32 op = b.cigar[k];
+        const u32 ty = op & 15u;
+        const int32_t ln = (int32_t)(op >> 4);
+        if (ty == OP_M || ty == 7u || ty == 8u) {
+            int32_t a = x, bb = x + ln;
+            if (a < 0) a = 0;
+            if (bb > ref_len) bb = ref_len;
+            if (a < bb) {
+                atomicAdd(&dd[a], -1);
+                atomicAdd(&dd[bb], 1);
+            }
+        }
+        if (op_consumes_ref(ty)) x += ln;
+    }
+}
+
+__device__ __forceinline__ u32 lower_bound_i32(const int32_t *a, u32 n, int32_t v) { // first index with a[i] >= v
+    u32 lo = 0, hi = n;
+    while (lo < hi) {
+        const u32 mid = lo + ((hi - lo) >> 1);
+        if (a[mid] < v) lo = mid + 1;
+        else hi = mid;
+    }
+    return lo;
+}
+
+struct ExtraRow { // what pjb_extra_finish hands back, parallel to the junction rows
+    double mm_score, coverage;
+    u32 up_aln, down_aln;
+    u32 m_sum; // sum of name multiplicities (uint32 arithmetic as in junction.cc:916-919)
+    u32 _pad;
+};
+
+// KX4: flanking alignment counts, one thread per junction (processJunctionVicinity, junction.cc:651-677):
+//   up   = unspliced records with  intron.start > pos  and  leftAncStart <= getEnd()
+//   down = unspliced records with  rightAncEnd >= pos  and  intron.end < pos
+// A record with a reference span has getEnd() >= pos, so "getEnd() < left" implies "pos < intron.start" and
+//   up = #{pos < start} - #{getEnd() < left};  down = #{pos <= right} - #{pos <= end}.
+// prefix_q[i] = such records among the first i records (all records are position sorted); pe[x] = such records
+// with getEnd() < x.  The reference's region query (sam_itr_queryi over [left - maxQueryLength - 1, right +
+// maxQueryLength + 1)) cannot exclude a record either test accepts.  Records without a reference span
+// (getEnd() == pos - 1) are tested one by one from `zlist`.
+__global__ __launch_bounds__(256) void kx_flank(const pjb_junction_row *rows, u32 n_rows, const int32_t *x_pos, u32 n_reads,
+                                                 const u32 *prefix_q, const u32 *pe, int32_t ref_len, const u32 *zlist,
+                                                 const ExtraCounters *cnt, u32 zcap, ExtraRow *out) {
+    const u32 j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= n_rows) return;
+    const int32_t s = rows[j].start, e = rows[j].end, l = rows[j].left, r = rows[j].right;
+    auto before = [&](int32_t v) -> u32 { return prefix_q[lower_bound_i32(x_pos, n_reads, v)]; }; // #{pos < v}
+    auto clampx = [&](int32_t v) -> int32_t { return v < 0 ? 0 : (v > ref_len + 1 ? ref_len + 1 : v); };
+    u32 up = before(s) - pe[clampx(l)];
+    u32 down = before(r == INT32_MAX ? r : r + 1) - before(e == INT32_MAX ? e : e + 1);
+    u32 nz = cnt->n_zero;
+    if (nz > zcap) nz = zcap;
+    for (u32 k = 0; k < nz; k++) {
+        const int32_t pos = (int32_t)zlist[k], end = pos - 1;
+        if (s > pos && l <= end) up++;
+        if (r >= pos && e < pos) down++;
+    }
+    out[j].up_aln = up;
+    out[j].down_aln = down;
+}
+
+// KX5: per sorted pair, the name code of its record and the global row it belongs to (kept until pjb_extra_finish)
+__global__ __launch_bounds__(256) void kx_pair_codes(const u32 *sidx, const u32 *jid_of, const u32 *pair_g, const DevBatch *batches,
+                                                      int n_batches, u32 n, u32 row_base,
+                                                      u64 *pair_code, u32 *pair_row) {
+    const u32 i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const u32 g = pair_g[sidx[i]];
+    int bi = n_batches - 1;
+    while (bi > 0 && g < batches[bi].base) bi--;
+    pair_code[i] = batches[bi].name_hash[g - batches[bi].base];
+    pair_row[i] = row_base + jid_of[i];
+}
+
+// ---- phase 2 (all contigs done) ---------------------------------------------------------------------------
+constexpr u64 NAME_EMPTY = ~0ull;
+__device__ __forceinline__ u64 name_slot_key(u64 code) { return code == NAME_EMPTY ? code - 1 : code; }
+__device__ __forceinline__ u32 name_slot_of(u64 key, u32 mask) { return (u32)((key * 0x9e3779b97f4a7c15ULL) >> 32) & mask; }
+
+// splicedAlignmentMap[code]++ (junction_builder.cc:173-174) for every spliced record of the file
+__global__ __launch_bounds__(256) void kx_name_insert(const u64 *codes, u32 n, u64 *keys, u32 *counts, u32 mask) {
+    const u32 i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const u64 key = name_slot_key(codes[i]);
+    u32 h = name_slot_of(key, mask);
+    for (;;) {
+        u64 cur = keys[h];
+        if (cur == NAME_EMPTY) cur = atomicCAS((unsigned long long *)&keys[h], (unsigned long long)NAME_EMPTY, (unsigned long long)key);
+        if (cur == NAME_EMPTY || cur == key) {
+            atomicAdd(&counts[h], 1u);
+            return;
+        }
+        h = (h + 1) & mask;
+    }
+}
+// M of every junction: sum over its alignments of the map entry of their code (junction.cc:916-919, uint32)
+__global__ __launch_bounds__(256) void kx_name_sum(const u64 *pair_code, const u32 *pair_row, u32 n, const u64 *keys,
+                                                    const u32 *counts, u32 mask, ExtraRow *out) {
+    const u32 i = blockIdx.x * 256 + threadIdx.x;
+    const bool on = i < n;
+    u32 c = 0, row = 0xffffffffu;
+    if (on) {
+        const u64 key = name_slot_key(pair_code[i]);
+        u32 h = name_slot_of(key, mask);
+        while (keys[h] != key && keys[h] != NAME_EMPTY) h = (h + 1) & mask;
+        c = keys[h] == key ? counts[h] : 0u;
+        row = pair_row[i];
+    }
+    // pairs are stored junction by junction: fold equal rows inside the wave before the atomic
+    c = seg_reduce_to_head(c, row, OpAdd());
+    const u32 prev = __shfl_up(row, 1, 64);
+    if (on && (lane_id() == 0 || prev != row)) atomicAdd(&out[row].m_sum, c);
+}
+
+// Junction::calcCoverage (junction.cc:923-951) for the rows [row0, row0 + n) against the depth vector of one
+// target: levels[i] = cover[i - 1] (DepthParser stores a position's depth at pos + 1, depth_parser.cc:127,147),
+// entries outside [0, len_src) are skipped as the reference's bounds test does.
+__device__ __forceinline__ double cov_window(const u32 *cover, int32_t len, int32_t a, int32_t b) {
+    const double multiplier = 1.0 / (double)(b - a);
+    u32 readCount = 0;
+    for (int32_t i = a; i <= b; i++)
+        if (i >= 1 && i < len) readCount += cover[i - 1];
+    return multiplier * (double)readCount;
+}
+__global__ __launch_bounds__(256) void kx_coverage(const int32_t *row_start, const int32_t *row_end, const uint32_t *row_raw,
+                                                    u32 row0, u32 n, const u32 *cover, int32_t len_src, ExtraRow *out) {
+    const u32 k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= n) return;
+    const u32 j = row0 + k;
+    const int32_t s = row_start[j], e = row_end[j];
+    const double donor = cov_window(cover, len_src, s - 20, s - 11) - cov_window(cover, len_src, s - 10, s);
+    const double acceptor = cov_window(cover, len_src, e + 10, e + 20) - cov_window(cover, len_src, e, e + 9);
+    out[j].coverage = donor + acceptor;
+}
+__global__ __launch_bounds__(256) void kx_mm_score(const uint32_t *row_raw, u32 n, ExtraRow *out) {
+    const u32 j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= n) return;
+    out[j].mm_score = (double)row_raw[j] / (double)out[j].m_sum; // N / M, junction.cc:920
+}
+
+} // namespace pjb

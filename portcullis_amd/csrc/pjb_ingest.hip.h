@@ -857,6 +857,7 @@ struct BamSoA {
     int32_t *l_qseq, *mtid, *mpos;
     iu32 *cig_off, *cigar, *seq_off;
     uint8_t *seq4;
+    iu64 *name_hash; // junc --extra only (nullptr otherwise): std::hash of deriveName(), see pjb_extra.hip.h
 };
 
 // XS:A aux tag -> 0 absent / '?' / '.', 1 '+', 2 '-', 3 anything else (same rules as the host transcoder)
@@ -916,6 +917,7 @@ __global__ __launch_bounds__(256) void bam_transcode(const uint8_t *U, const iu6
     B.mtid[i] = (int32_t)ld32u(r + 20);
     B.mpos[i] = (int32_t)ld32u(r + 24);
     B.xs[i] = bam_xs_code(r + aux_at, r + bs);
+    if (B.name_hash) B.name_hash[i] = derive_name_hash(r + 32, l_name ? l_name - 1 : 0, ld16u(r + 14));
     const iu32 co = B.cig_off[i];
     for (iu32 k = 0; k < n_cig; k++) B.cigar[co + k] = ld32u(r + cig_at + 4 * k);
     const iu32 so = B.seq_off[i], words = B.seq_off[i + 1] - so;

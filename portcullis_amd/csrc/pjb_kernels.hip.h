@@ -37,6 +37,7 @@ struct DevBatch {
     const uint32_t *cigar;
     const uint32_t *seq_off;
     const uint8_t *seq4;
+    const u64 *name_hash; // --extra only (nullptr otherwise)
     int64_t n;
     uint32_t base;      // global read ordinal of record 0 within the contig
     uint32_t tile_base; // first K1 tile index of this batch

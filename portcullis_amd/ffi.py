@@ -14,7 +14,7 @@ from .records import ORIENTATION, ReadBatch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libportcullis_amd.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 N_STAGES = 8
 STAGE_NAMES = ["scan_emit", "sort", "group", "anchors", "pair_stats", "finalize", "d2h", "spare"]
 
@@ -23,8 +23,10 @@ EXPORTS = [
     "pjb_release_contig", "pjb_submit_batch", "pjb_submit_batch_device", "pjb_finish_contig", "pjb_collect",
     "pjb_clear_rows", "pjb_get_timing", "pjb_device_count", "pjb_get_kernel_timing", "pjb_reset_kernel_timing",
     "pjb_select_timed_kernels", "pjb_host_alloc", "pjb_host_free", "pjb_inflate_bgzf", "pjb_submit_bam", "pjb_collect_device", "pjb_set_row_mirror",
+    "pjb_extra_finish",
 ]
 FLAG_KERNEL_TIMING = 1
+FLAG_EXTRA = 2  # junc --extra: batches carry name_hash, extra_finish() yields mm_score / coverage / up_aln / down_aln
 
 
 class PjbConfig(C.Structure):
@@ -34,7 +36,8 @@ class PjbConfig(C.Structure):
 
 class PjbBatch(C.Structure):
     _fields_ = [("n_reads", C.c_int64)] + [
-        (n, C.c_void_p) for n in ("pos", "flag", "mapq", "xs", "l_qseq", "mtid", "mpos", "cig_off", "cigar", "seq_off", "seq4")
+        (n, C.c_void_p) for n in ("pos", "flag", "mapq", "xs", "l_qseq", "mtid", "mpos", "cig_off", "cigar", "seq_off", "seq4",
+                                  "name_hash")
     ]
 
 
@@ -65,6 +68,8 @@ ROW_DTYPE = np.dtype(
     ]
 )
 assert ROW_DTYPE.itemsize == 200
+EXTRA_DTYPE = np.dtype([("mm_score", "<f8"), ("coverage", "<f8"), ("up_aln", "<u4"), ("down_aln", "<u4")])
+assert EXTRA_DTYPE.itemsize == 24
 
 
 class PjbError(RuntimeError):
@@ -106,6 +111,13 @@ def load():
         L.pjb_inflate_bgzf.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
         L.pjb_submit_bam.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_int32, C.POINTER(C.c_int64)]
         L.pjb_collect.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
+        L.pjb_extra_finish.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
+        L.pjb_host_alloc.restype = C.c_void_p
+        L.pjb_host_alloc.argtypes = [C.c_size_t]
+        L.pjb_host_free.restype = None
+        L.pjb_host_free.argtypes = [C.c_void_p]
+        L.pjb_device_count.restype = C.c_int
+        L.pjb_device_count.argtypes = []
         L.pjb_clear_rows.argtypes = [C.c_void_p]
         L.pjb_get_timing.argtypes = [C.c_void_p, C.POINTER(PjbTiming)]
         L.pjb_get_kernel_timing.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]
@@ -185,6 +197,13 @@ class Context:
                 a = np.zeros(4, dtype=dt)
             keep.append(a)
             setattr(pb, name, a.ctypes.data)
+        nh = getattr(batch, "name_hash", None)
+        if nh is not None:
+            nh = np.ascontiguousarray(nh, dtype=np.uint64)
+            if nh.size == 0:
+                nh = np.zeros(2, dtype=np.uint64)
+            keep.append(nh)
+            pb.name_hash = nh.ctypes.data
         self._check(self._L.pjb_submit_batch(self._h, tid, C.byref(pb)))
 
     def submit_batch_device(self, tid, tensors, n_reads):
@@ -195,6 +214,9 @@ class Context:
             t = tensors[name]
             self._keep_batch.append(t)
             setattr(pb, name, t.data_ptr())
+        if tensors.get("name_hash") is not None:
+            self._keep_batch.append(tensors["name_hash"])
+            pb.name_hash = tensors["name_hash"].data_ptr()
         self._check(self._L.pjb_submit_batch_device(self._h, tid, C.byref(pb)))
 
     def finish_contig(self, tid):
@@ -228,6 +250,17 @@ class Context:
         n = C.c_int64()
         self._check(self._L.pjb_collect_device(self._h, C.byref(p), C.byref(n)))
         return (p.value or 0), n.value
+
+    def extra_finish(self):
+        """calcExtraMetrics once every contig of the file is finished (FLAG_EXTRA contexts): one EXTRA_DTYPE record
+        per row of collect(), same order."""
+        p = C.c_void_p()
+        n = C.c_int64()
+        self._check(self._L.pjb_extra_finish(self._h, C.byref(p), C.byref(n)))
+        if n.value == 0:
+            return np.zeros(0, dtype=EXTRA_DTYPE)
+        buf = (C.c_char * (n.value * EXTRA_DTYPE.itemsize)).from_address(p.value)
+        return np.frombuffer(buf, dtype=EXTRA_DTYPE, count=n.value).copy()
 
     def clear_rows(self):
         self._check(self._L.pjb_clear_rows(self._h))

@@ -45,6 +45,7 @@ struct ReadBatch {
     BatchVector<uint8_t> mapq, xs;
     BatchVector<uint32_t> cig_off, cigar, seq_off;
     BatchVector<uint8_t> seq4;
+    BatchVector<uint64_t> name_hash;  // only filled by a reader with setNameHashes(true) (junc --extra)
     uint64_t n_refskip = 0;
 
     size_t size() const { return pos.size(); }
@@ -83,6 +84,7 @@ class BamReader {
     int32_t regionTid = -1;
     int32_t regionLen = 0;
     bool regionDone = true;
+    bool wantNames = false;
     std::vector<uint8_t> rec;
 
     void loadIndex(bool useCsi);
@@ -92,6 +94,8 @@ public:
 
     void open(bool useCsi = false);
     void close() { bgzf.close(); }
+    // also transcode std::hash(deriveName()) of every record (pjb_batch.name_hash; junc --extra)
+    void setNameHashes(bool on) { wantNames = on; }
 
     std::shared_ptr<RefSeqPtrList> createRefList() const;
     std::shared_ptr<RefSeqPtrIndexMap> createRefMap(const RefSeqPtrList& refs) const;

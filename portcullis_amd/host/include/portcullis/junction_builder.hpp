@@ -35,6 +35,7 @@ struct RegionResult {
     int32_t maxQueryLength = 0;
     std::string name;
     JunctionSystem js;
+    size_t rowBase = 0;  // --extra: where this target's rows start in the device context's row table
 };
 
 class JunctionBuilder {

@@ -1,4 +1,5 @@
 #include <portcullis/bam/bam_reader.hpp>
+#include <portcullis/bam/name_hash.hpp>
 
 #include <algorithm>
 #include <atomic>
@@ -45,6 +46,7 @@ void ReadBatch::clear() {
     cigar.clear();
     seq_off.assign(1, 0);
     seq4.clear();
+    name_hash.clear();
     n_refskip = 0;
 }
 
@@ -60,6 +62,7 @@ void ReadBatch::view(pjb_batch& b) const {
     b.pos = pos.data(); b.flag = flag.data(); b.mapq = mapq.data(); b.xs = xs.data(); b.l_qseq = l_qseq.data();
     b.mtid = mtid.data(); b.mpos = mpos.data(); b.cig_off = cig_off.data(); b.cigar = cigar.data();
     b.seq_off = seq_off.data(); b.seq4 = seq4.data();
+    b.name_hash = name_hash.size() == pos.size() && !pos.empty() ? name_hash.data() : nullptr;
 }
 
 // ------------------------------------------------------------------ BGZF
@@ -377,6 +380,7 @@ bool BamReader::nextBatch(ReadBatch& out, size_t maxRecords) {
         out.mtid.push_back(mtid);
         out.mpos.push_back(mpos);
         out.xs.push_back(xsCode(r + aux_at, r + bs));
+        if (wantNames) out.name_hash.push_back(deriveNameHash(r + 32, l_name ? l_name - 1 : 0, flag));
         bool spliced = false;
         for (uint32_t k = 0; k < n_cig; k++) {
             const uint32_t op = le32(r + cig_at + 4 * k);
@@ -832,6 +836,8 @@ void BamReader::decodeRegionParallel(int32_t tid, int nthreads, size_t maxRecord
             batch.seq_off.resize(n + 1);
             batch.cigar.resize(opBase[nsUse]);
             batch.seq4.resize(wordBase[nsUse] * 4);
+            if (wantNames) batch.name_hash.resize(n);
+            else batch.name_hash.clear();
             batch.n_refskip = skips;
             std::atomic<bool> badRec(false);
             auto fill = [&](int t, size_t, size_t) {
@@ -858,6 +864,7 @@ void BamReader::decodeRegionParallel(int32_t tid, int nthreads, size_t maxRecord
                     batch.mtid[i] = (int32_t)le32(r + 20);
                     batch.mpos[i] = (int32_t)le32(r + 24);
                     batch.xs[i] = xsCode(r + aux_at, r + bs);
+                    if (wantNames) batch.name_hash[i] = deriveNameHash(r + 32, l_name ? l_name - 1 : 0, batch.flag[i]);
                     batch.cig_off[i] = (uint32_t)co;
                     batch.seq_off[i] = (uint32_t)so;
                     bool spl = false;

@@ -110,9 +110,9 @@ void JunctionBuilder::process() {
              << " target sequences to process.  Setting number of threads to " << refs->size() << "." << endl << endl;
         threads = (uint16_t)refs->size();
     }
-    if (extra || separate)
-        throw JunctionBuilderException("--separate / --extra (coverage, flanking alignments, multiple mapping score) are not "
-                                       "implemented by the MI355X junc path; run without them");
+    if (separate)
+        throw JunctionBuilderException("--separate (spliced / unspliced / unmapped BAM files) is not implemented by the MI355X junc path; "
+                                       "run without it (--extra does not need the files here: it works on the records in device memory)");
     cout << "Settings:" << endl
          << std::boolalpha << " - BAM Strandedness: " << bam::strandednessToString(strandSpecific) << endl
          << " - BAM Read Orientation: " << bam::orientationToString(orientation) << endl
@@ -203,12 +203,13 @@ public:
 struct ContigDone {
     pjb_region_result rr;
     std::vector<pjb_junction_row> rows;
+    size_t rowBase = 0;  // --extra: index of rows[0] in the context's row table (pjb_extra_finish's order)
 };
 
 class DeviceThread {
 public:
     struct Cmd {
-        enum Kind { GENOME, BATCH, BAM, FINISH, STOP } kind = STOP;
+        enum Kind { GENOME, BATCH, BAM, FINISH, EXTRA, STOP } kind = STOP;
         int32_t tid = -1;
         std::string genome;
         bam::ReadBatch batch;
@@ -221,6 +222,7 @@ public:
         uint32_t bamFirst = 0;
         PinnedPool* bamPool = nullptr;  // where bamBytes goes back to (nullptr: bigFree)
         std::promise<int64_t>* bamDone = nullptr;
+        std::promise<std::vector<pjb_extra_row>>* extraDone = nullptr;  // EXTRA: calcExtraMetrics for every row so far
     };
 
 private:
@@ -233,7 +235,7 @@ private:
     std::string fatal;                      // context creation failed
 
     void run(int device, bam::Orientation orientation, bam::Strandedness strandedness, std::vector<int32_t> lens,
-             std::shared_future<int> deviceCount) {
+             std::shared_future<int> deviceCount, bool extra) {
         pjb_ctx* ctx = nullptr;
         try {
             if (deviceCount.get() <= 0)
@@ -244,12 +246,14 @@ private:
             cfg.device = device;
             cfg.orientation = (int32_t)orientation;
             cfg.strandedness = (int32_t)strandedness;
+            if (extra) cfg.flags |= PJB_FLAG_EXTRA;
             if (pjb_create(&ctx, &cfg) != PJB_OK) throw JunctionBuilderException(std::string("pjb_create: ") + pjb_last_error(nullptr));
             if (pjb_set_refs(ctx, (int32_t)lens.size(), lens.data()) != PJB_OK)
                 throw JunctionBuilderException(std::string("pjb_set_refs: ") + pjb_last_error(ctx));
         } catch (const std::exception& e) {
             fatal = e.what();
         }
+        size_t rowsSoFar = 0;  // --extra keeps every contig's rows in the context until pjb_extra_finish
         for (;;) {
             Cmd c;
             {
@@ -291,25 +295,36 @@ private:
                     int64_t n = 0;
                     if (pjb_finish_contig(ctx, c.tid, &d.rr) != PJB_OK) err = std::string("pjb_finish_contig: ") + pjb_last_error(ctx);
                     else if (pjb_collect(ctx, &rows, &n) != PJB_OK) err = std::string("pjb_collect: ") + pjb_last_error(ctx);
-                    else d.rows.assign(rows, rows + n);
-                    (void)pjb_clear_rows(ctx);
+                    else if (extra) {
+                        d.rows.assign(rows + rowsSoFar, rows + n);
+                        d.rowBase = rowsSoFar;
+                        rowsSoFar = (size_t)n;
+                    } else d.rows.assign(rows, rows + n);
+                    if (!extra) (void)pjb_clear_rows(ctx);
                 } else if (ctx) {
                     pjb_region_result dummy;
                     (void)pjb_finish_contig(ctx, c.tid, &dummy);  // drop whatever was submitted
-                    (void)pjb_clear_rows(ctx);
+                    if (!extra) (void)pjb_clear_rows(ctx);
                 }
                 if (ctx) (void)pjb_release_contig(ctx, c.tid);
                 failed.erase(c.tid);
                 if (err.empty()) c.done->set_value(std::move(d));
                 else c.done->set_exception(std::make_exception_ptr(JunctionBuilderException(err)));
+            } else if (c.kind == Cmd::EXTRA) {
+                const pjb_extra_row* xr = nullptr;
+                int64_t n = 0;
+                if (err.empty() && pjb_extra_finish(ctx, &xr, &n) != PJB_OK) err = std::string("pjb_extra_finish: ") + pjb_last_error(ctx);
+                if (err.empty()) c.extraDone->set_value(std::vector<pjb_extra_row>(xr, xr + n));
+                else c.extraDone->set_exception(std::make_exception_ptr(JunctionBuilderException(err)));
             }
         }
         if (ctx) pjb_destroy(ctx);
     }
 
 public:
-    DeviceThread(int device, bam::Orientation o, bam::Strandedness s, const std::vector<int32_t>& lens, std::shared_future<int> dc) {
-        th = std::thread([=] { run(device, o, s, lens, dc); });
+    DeviceThread(int device, bam::Orientation o, bam::Strandedness s, const std::vector<int32_t>& lens, std::shared_future<int> dc,
+                 bool extra = false) {
+        th = std::thread([=] { run(device, o, s, lens, dc, extra); });
     }
     ~DeviceThread() {
         Cmd c;
@@ -445,6 +460,7 @@ void JunctionBuilder::findJuncs(DeviceThread& device, BamReader& reader, GenomeM
     if (!finishError.empty()) throw JunctionBuilderException(finishError);
     if (!any) return;
     res.js.appendRows(d.rows.data(), d.rows.size());
+    res.rowBase = d.rowBase;
     res.splicedCount = d.rr.spliced;
     res.unsplicedCount = d.rr.unspliced;
     res.sumQueryLengths = d.rr.sum_len;
@@ -513,9 +529,10 @@ void JunctionBuilder::findJunctions() {
             int per = 2;
             if (const char* e = getenv("PORTCULLIS_CTX_PER_GPU")) per = std::max(1, atoi(e));
             per = std::max(1, std::min(per, nthreads / nd));
+            if (extra) nd = per = 1;  // the name multiplicities and the depth hand-over between targets are file-wide: one context
             for (int k = 0; k < per; k++)
                 for (int d = 0; d < nd; d++)
-                    deviceThreads.emplace_back(new DeviceThread(d, orientation, strandSpecific, lens, deviceCount));
+                    deviceThreads.emplace_back(new DeviceThread(d, orientation, strandSpecific, lens, deviceCount, extra));
         }
         return *deviceThreads[(size_t)w % deviceThreads.size()];
     };
@@ -525,6 +542,7 @@ void JunctionBuilder::findJunctions() {
             gmap.loadFastaIndex();
             BamReader reader(prepData.getSortedBamFilePath());
             reader.open(useCsi);
+            reader.setNameHashes(extra);
             DeviceThread& dev = deviceFor(w);
             while (true) {
                 int32_t tid;
@@ -548,6 +566,31 @@ void JunctionBuilder::findJunctions() {
     std::vector<std::thread> pool;
     for (int w = 0; w < nthreads; w++) pool.emplace_back(worker, w);
     for (auto& t : pool) t.join();
+    if (extra && firstError.empty() && !deviceThreads.empty()) {
+        // calcExtraMetrics (src/junction_builder.cc:293-312): multiple mapping score, flanking alignments, coverage
+        cout << "Calculating extra junction metrics:" << endl;
+        try {
+            std::promise<std::vector<pjb_extra_row>> got;
+            std::future<std::vector<pjb_extra_row>> f = got.get_future();
+            DeviceThread::Cmd c;
+            c.kind = DeviceThread::Cmd::EXTRA;
+            c.extraDone = &got;
+            deviceThreads[0]->push(std::move(c));
+            const std::vector<pjb_extra_row> xr = f.get();
+            for (auto& res : results) {
+                const JunctionList& jl = res.js.getJunctions();
+                for (size_t k = 0; k < jl.size(); k++) {
+                    const pjb_extra_row& x = xr.at(res.rowBase + k);
+                    jl[k]->setMultipleMappingScore(x.mm_score);
+                    jl[k]->setCoverage(x.coverage);
+                    jl[k]->setNbUpstreamFlankingAlignments(x.up_aln);
+                    jl[k]->setNbDownstreamFlankingAlignments(x.down_aln);
+                }
+            }
+        } catch (const std::exception& e) {
+            firstError = e.what();
+        }
+    }
     deviceThreads.clear();  // joins the device threads (destroys the contexts)
     if (!firstError.empty()) throw JunctionBuilderException(firstError);
     const double t_workers1 = HostProfile::now();

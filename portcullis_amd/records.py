@@ -65,6 +65,7 @@ class ReadBatch:
     cigar: np.ndarray     # uint32[cig_off[n]]
     seq_off: np.ndarray   # uint32[n+1]  (4-byte words)
     seq4: np.ndarray      # uint8[4*seq_off[n]]
+    name_hash: np.ndarray = None  # uint64[n], optional: std::hash of BamAlignment::deriveName() (junc --extra)
 
     @property
     def n(self):
@@ -135,4 +136,5 @@ class ReadBatch:
             self.l_qseq[lo:hi].copy(), self.mtid[lo:hi].copy(), self.mpos[lo:hi].copy(),
             (self.cig_off[lo:hi + 1] - np.uint32(c0)).astype(np.uint32), self.cigar[c0:c1].copy(),
             (self.seq_off[lo:hi + 1] - np.uint32(s0)).astype(np.uint32), self.seq4[4 * s0:4 * s1].copy(),
+            None if self.name_hash is None else self.name_hash[lo:hi].copy(),
         )

@@ -24,7 +24,8 @@ def test_struct_sizes():
     from portcullis_amd import ffi
 
     assert ffi.ROW_DTYPE.itemsize == 200
-    assert ctypes.sizeof(ffi.PjbBatch) == 8 + 11 * 8
+    assert ctypes.sizeof(ffi.PjbBatch) == 8 + 12 * 8
+    assert ffi.EXTRA_DTYPE.itemsize == 24
     assert ctypes.sizeof(ffi.PjbRegionResult) == 56
     assert ctypes.sizeof(ffi.PjbConfig) == 20
 

@@ -24,7 +24,7 @@ def orc():
     return oracle
 
 
-def oracle_outputs(orc, prep, orientation, source="portcullis", version="1.2.4"):
+def oracle_outputs(orc, prep, orientation, source="portcullis", version="1.2.4", extra=False):
     from util_bam import read_fasta
     refs, recs = read_bam(os.path.join(prep, PREP_BAM))
     contigs = dict(read_fasta(os.path.join(prep, "portcullis.genome.fa")))
@@ -37,6 +37,11 @@ def oracle_outputs(orc, prep, orientation, source="portcullis", version="1.2.4")
     rows, tot = orc.run_prep_like(refs, genomes, batches, orientation)
     names = [n for n, _ in refs]
     lens = [l for _, l in refs]
+    if extra:  # calcExtraMetrics (src/junction_builder.cc:293-312) on the same records
+        soa = {t: b.to_oracle() for t, b in batches.items()}
+        nh = {t: np.array([orc.name_hash(r["name"], r["flag"]) for r in recs if r["tid"] == t and r["pos"] < lens[t]], dtype=np.uint64)
+              for t in batches}
+        rows = orc.extra(lens, soa, nh, rows, tot["max_len"])
     return dict(
         tab=orc.write_tab(rows, names, lens), bed=orc.write_bed(rows, names, source, version),
         intron=orc.write_intron_gff(rows, names, source), exon=orc.write_exon_gff(rows, names, source), rows=rows, tot=tot,
@@ -56,7 +61,7 @@ def check(prep, tmp_path, orc, orientation="UNKNOWN", threads=1, extra_opts=()):
     out = str(tmp_path / "out" / "pc")
     p = run_cli(prep, out, "--orientation", orientation, "-t", str(threads), *extra_opts)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
-    exp = oracle_outputs(orc, prep, orientation)
+    exp = oracle_outputs(orc, prep, orientation, extra="--extra" in extra_opts)
     for ext, key in ((".junctions.tab", "tab"), (".junctions.bed", "bed"), (".junctions.intron.gff3", "intron"),
                      (".junctions.exon.gff3", "exon")):
         got = open(out + ext, "rb").read()
@@ -237,3 +242,34 @@ def test_contexts_per_gpu(tmp_path, orc, per_gpu, monkeypatch):
     monkeypatch.setenv("PORTCULLIS_CTX_PER_GPU", per_gpu)
     prep = multi_contig(tmp_path, [81, 82, 83, None, 84], block_size=20000)
     check(prep, tmp_path, orc, "RF", threads=5, extra_opts=("--ingest", "device", "--devices", "1"))
+
+
+@pytest.mark.parametrize("ingest", ["host", "device"])
+def test_extra_metrics_cli(tmp_path, orc, ingest):
+    """`junc --extra`: mm_score, coverage, up_aln, down_aln columns of the .tab equal the oracle's, with the records
+    decoded on the host threads and on the device (names hashed by both transcoders)."""
+    refs, contigs, reads = [], [], []
+    rng = np.random.default_rng(99)
+    pool = []
+    for tid, seed in enumerate([31, 32, 33]):
+        genome, rr = make_reads(seed, n_reads=1500, paired=True, glen=20000 + 1000 * tid)
+        for k, r in enumerate(rr):
+            r["tid"] = tid
+            if r.get("mtid", -1) >= 0:
+                r["mtid"] = tid if r["mtid"] == 0 else (tid + 1) % 3
+            # read names: a quarter are multi-mapped fragments (same QNAME on several records, also across contigs)
+            if pool and rng.random() < 0.25:
+                r["name"] = pool[int(rng.integers(0, len(pool)))]
+            else:
+                r["name"] = f"frag{tid}_{k}"
+                pool.append(r["name"])
+            if "N" not in r["cigar"] and rng.random() < 0.02:
+                r["flag"] |= 0x4
+        refs.append((f"chr{tid + 1}", len(genome)))
+        contigs.append((f"chr{tid + 1}", genome))
+        reads += rr
+    prep = make_prep_dir(str(tmp_path / "prep"), refs, contigs, reads)
+    p, exp = check(prep, tmp_path, orc, "FR", threads=3, extra_opts=("--extra", "--ingest", ingest))
+    rows = exp["rows"]
+    assert (rows["up_aln"] > 0).any() and (rows["coverage"] != 0).any() and (rows["mm_score"] < 1).any()
+    assert "Calculating extra junction metrics" in p.stdout

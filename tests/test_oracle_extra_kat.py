@@ -1,0 +1,120 @@
+"""`junc --extra` in the oracle against what the reference holds for it: the calcCoverage vectors of
+tests/junction_tests.cpp:110-148 (the reference asserts the sign; the value follows from junction.cc:923-951), the
+DepthParser relation of tests/bam_tests.cpp:100-133 on the reference's own sorted.bam, std::hash vectors from the real
+libstdc++ (tools/gen_std_hash_vectors.sh), and hand-worked cases of the pileup cap and the flanking counts."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+from portcullis_amd.records import ReadBatch
+from util_bam import read_bam
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def test_calc_coverage_reference_vectors():
+    c1 = [10] * 15 + [8, 6, 4, 3, 2] + [0] * 10 + [2, 3, 4, 7, 8] + [10] * 15   # junction_tests.cpp:115-119, intron 20-30
+    c2 = [0] * 15 + [2, 3, 5, 7, 8] + [10] * 10 + [8, 6, 4, 3, 2] + [0] * 15     # junction_tests.cpp:134-138
+    v1, v2 = orc.calc_coverage(20, 30, c1), orc.calc_coverage(20, 30, c2)
+    assert v1 > 0 and v2 < 0                                                       # what the reference asserts
+    # windows [0,9]/9, [10,20]/10, [40,50]/10 (50 is out of range), [30,39]/9
+    assert v1 == (1.0 / 9 * 100 - 1.0 / 10 * 73) + (1.0 / 10 * 100 - 1.0 / 9 * 74)
+    assert v2 == (1.0 / 9 * 0 - 1.0 / 10 * 35) + (1.0 / 10 * 0 - 1.0 / 9 * 23)
+
+
+def test_name_hash_matches_libstdcxx():
+    vec = json.load(open(os.path.join(HERE, "golden", "std_hash_vectors.json")))
+    for name, h in vec.items():
+        assert orc.name_hash(name, 0) == h, name
+    # deriveName, bam_alignment.cc:233-242
+    assert orc.name_hash("read_12345", 0x1 | 0x40) == vec["read_12345_R1"]
+    assert orc.name_hash("read_12345", 0x1 | 0x80) == vec["read_12345_R2"]
+    assert orc.name_hash("read_12345", 0x1) == vec["read_12345_R?"]
+    assert orc.name_hash("read_12345_R1", 0x40) == vec["read_12345_R1"]   # unpaired: the flag bits alone add nothing
+
+
+def _batch(reads):
+    return ReadBatch.from_reads(reads).to_oracle()
+
+
+def test_depth_of_reference_sorted_bam():
+    """bam_tests.cpp:100-133 runs DepthParser over sorted.bam with and without gapped alignments and expects
+    count2 <= count1; the file has no gapped alignment, so both equal the number of aligned M bases."""
+    refs, recs = read_bam(os.path.join(HERE, "golden", "sorted.bam"))
+    total = 0
+    for tid, (name, ln) in enumerate(refs):
+        rs = [r for r in recs if r["tid"] == tid]
+        if not rs:
+            continue
+        b = ReadBatch.from_reads(rs)
+        depth, kept = orc.depth(ln, b.to_oracle())
+        mapped = [r for r in rs if not (r["flag"] & 4)]
+        assert kept == len(mapped)
+        m_bases = sum(int(op) >> 4 for r in mapped for op in r["cigar"] if (int(op) & 15) in (0, 7, 8))
+        assert int(depth.sum()) == m_bases and depth[0] == 0     # stored at pos + 1
+        total += int(depth.sum())
+    assert total > 0
+
+
+def test_depth_shift_deletion_and_filters():
+    reads = [dict(pos=10, cigar="5M2D5M", seq="A" * 10),                  # deletion: not counted on 15,16
+             dict(pos=12, cigar="3S4M", seq="A" * 7),                     # soft clip consumes nothing
+             dict(pos=12, cigar="4M", seq="A" * 4, flag=0x4),             # unmapped: not in unspliced.bam
+             dict(pos=13, cigar="2M10N2M", seq="A" * 4),                  # spliced: not in unspliced.bam
+             dict(pos=14, cigar="2=1X", seq="A" * 3, flag=0x400 | 0x100)]  # duplicates / secondary DO count (sam.c:1905)
+    depth, kept = orc.depth(40, _batch(reads))
+    assert kept == 3
+    cover = np.zeros(40, int)
+    cover[10:15] += 1; cover[17:22] += 1; cover[12:16] += 1; cover[14:17] += 1
+    assert (depth[1:] == cover[:-1]).all() and depth[0] == 0
+
+
+def test_pileup_cap_drops_only_ties_at_the_current_position():
+    """bam_plp_push (sam.c:1906): a record is dropped iff it starts where the last kept record started and more than
+    8000 nodes are allocated (kept records not yet passed + 2).  The first record of a new position is always kept."""
+    n = 9000
+    reads = [dict(pos=100, cigar="50M", seq=None, l_qseq=50) for _ in range(n)]
+    reads += [dict(pos=101, cigar="50M", seq=None, l_qseq=50) for _ in range(3)]
+    reads += [dict(pos=200, cigar="10M", seq=None, l_qseq=10) for _ in range(5)]
+    depth, kept = orc.depth(400, _batch(reads))
+    # at pos 100: record 1 kept (new position); records 2.. kept while list + 2 <= 8000 -> 7999 kept in total
+    # at pos 101: first kept (new position), the next two see 8000 records in the list -> dropped
+    assert kept == 7999 + 1 + 5
+    assert depth[101] == 7999 and depth[102] == 8000 and depth[150] == 8000 and depth[151] == 1 and depth[152] == 0
+    assert depth[201] == 5
+
+
+def test_flanking_counts_and_contig_pairing():
+    """processJunctionVicinity (junction.cc:651-677) and the hand-over of depth vectors between consecutive targets
+    (junction_system.cc:231-242 with depth_parser.cc:112-164)."""
+    g = "ACGT" * 250
+    def contig(shift):
+        return [dict(pos=100 + shift, cigar="50M", seq="A" * 50, name="u1"),
+                dict(pos=120, cigar="30M100N30M", seq="A" * 60, name="s1", xs="+"),
+                dict(pos=125, cigar="25M100N35M", seq="A" * 60, name="s1", xs="+"),      # same name: multiplicity 2
+                dict(pos=149, cigar="10M", seq="A" * 10, name="u2"),                    # pos < start(150), end 158 >= left
+                dict(pos=150, cigar="10M", seq="A" * 10, name="u3"),                    # pos == intron start: not upstream
+                dict(pos=250, cigar="20M", seq="A" * 20, name="u4"),                    # intron.end(249) < pos <= right
+                dict(pos=285, cigar="20M", seq="A" * 20, name="u5")]                    # right = 284: pos 285 is outside
+    soa, nh, rows_all = {}, {}, []
+    for tid in range(3):
+        reads = contig(0) if tid != 1 else [r for r in contig(0) if "N" in r["cigar"]]  # target 1 has no unspliced record
+        b = ReadBatch.from_reads(reads)
+        soa[tid] = b.to_oracle()
+        nh[tid] = np.array([orc.name_hash(r["name"] + (f"_{tid}" if r["name"] == "s1" and tid == 2 else ""), 0) for r in reads], dtype=np.uint64)
+        rows, _ = orc.find_juncs(tid, len(g), g, soa[tid], "UNKNOWN")
+        rows_all.append(rows)
+    rows = orc.finalize(np.concatenate(rows_all), 50.0)
+    rows = orc.extra([len(g)] * 3, soa, nh, rows, 60)
+    assert list(rows["refid"]) == [0, 1, 2] and (rows["start"] == 150).all() and (rows["end"] == 249).all()
+    assert (rows["left"] == 120).all() and (rows["right"] == 284).all()
+    assert list(rows["up_aln"]) == [2, 0, 2] and list(rows["down_aln"]) == [1, 0, 1]
+    # name "s1" occurs on 4 spliced records (targets 0 and 1), target 2 uses its own name
+    assert list(rows["mm_score"]) == [2 / 8, 2 / 8, 2 / 4]
+    # targets with unspliced records: 0 and 2.  Target 0's junction is never visited; target 2 is the last batch.
+    assert rows["coverage"][0] == 0 and rows["coverage"][1] == 0 and rows["coverage"][2] != 0
+    depth2, _ = orc.depth(len(g), soa[2])
+    assert rows["coverage"][2] == orc.calc_coverage(150, 249, depth2)

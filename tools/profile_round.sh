@@ -13,3 +13,8 @@ bash tools/pmc_traffic.sh $TAG
 python3 tools/summarize_pmc.py $OUT/pmc_$TAG $OUT/${TAG}_pmc_traffic.json C3 $COMMIT
 python3 bench.py --steps 20 --warmup 3 ${BENCH_FLAGS:-} > $OUT/${TAG}_bench_C3.json 2> $OUT/bench_$TAG.err
 tail -c 300 $OUT/bench_$TAG.err
+# keep what travels back small: the raw traces stay on the box
+rm -rf $OUT/prof_$TAG/*/*.db $OUT/prof_$TAG/*/*_kernel_trace.csv $OUT/pmc_$TAG/*/*/pmc_kernel_trace.csv 2>/dev/null
+find $OUT -name "*kernel_trace.csv" -size +2M -delete 2>/dev/null
+find $OUT -name "*counter_collection.csv" -size +8M -delete 2>/dev/null
+du -sh $OUT | tail -1
