@@ -61,7 +61,8 @@ def test_extra_batches_and_empty_targets(ffi, orc):
     assert_rows_equal(rows, orows)
     assert_extra_equal(rows, extra, orows)
     assert (extra["coverage"][rows["refid"] == 0] == 0).all()      # first target: never visited
-    assert (extra["coverage"][rows["refid"] == 2] != 0).any()      # spliced-only target gets target 0's depth
+    assert (extra["coverage"][rows["refid"] == 2] == 0).all()      # spliced-only target: not in the pileup, never visited
+    assert (extra["coverage"][rows["refid"] == 3] != 0).any()      # gets target 0's depth vector (the hand-over quirk)
 
 
 def test_extra_pileup_cap(ffi, orc):
