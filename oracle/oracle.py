@@ -354,6 +354,20 @@ def extra(ref_lens, soa_by_tid, name_hash_by_tid, rows, max_query_len):
     return rows
 
 
+ORIENTATION_LONG = {0: "Single-End (SE)", 1: "Paired-End (FR): Forward Reverse (-> <-)", 2: "Paired-End (RF): Reverse Forward (<- ->)",
+                    3: "Paired-End (FF): Forward Forward (-> ->)", 4: "Unknown"}                 # bam_master.hpp:166-175
+STRANDEDNESS_LONG = {0: "Unstranded - can't determine transcript strand from read strand", 1: "Firststrand - R1 is not on transcript strand",
+                     2: "Secondstrand - R1 is on transcript strand", 3: "Unknown strand protocol"}  # bam_master.hpp:115-123
+
+
+def determine_strandedness(rows):
+    """JunctionSystem::determineStrandedness -> (orientation code, strandedness code)."""
+    rows = np.ascontiguousarray(rows)
+    o, s = C.c_int(), C.c_int()
+    lib().orc_determine_strandedness(rows.ctypes.data_as(C.c_void_p), C.c_int64(len(rows)), C.byref(o), C.byref(s))
+    return o.value, s.value
+
+
 def finalize(rows, mean_query_len):
     rows = np.ascontiguousarray(rows)
     lib().orc_finalize(rows.ctypes.data_as(C.c_void_p), len(rows), C.c_double(mean_query_len))

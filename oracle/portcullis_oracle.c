@@ -1260,6 +1260,37 @@ void orc_finalize(orc_row *rows, int64_t n, double meanQueryLength) {
     }
 }
 
+/* JunctionSystem::determineStrandedness, junction_system.cc:455-560 */
+void orc_determine_strandedness(const orc_row *rows, int64_t n, int *orientation, int *strandedness) {
+    uint32_t pp1 = 0, pn1 = 0, pp2 = 0, pn2 = 0, np1 = 0, nn1 = 0, np2 = 0, nn2 = 0; /* tot_r{1,2}_{pos,neg}_when_ss_{pos,neg} */
+    for (int64_t i = 0; i < n; i++) {
+        const orc_row *j = &rows[i];
+        if (j->ss_strand == ORC_STRAND_POS) { pp1 += j->r1pos; pn1 += j->r1neg; pp2 += j->r2pos; pn2 += j->r2neg; }
+        else if (j->ss_strand == ORC_STRAND_NEG) { np1 += j->r1pos; nn1 += j->r1neg; np2 += j->r2pos; nn2 += j->r2neg; }
+    }
+    double posr1 = ((double)((int32_t)pp1 - (int32_t)pn1)) / ((double)(pp1 + pn1));
+    double negr1 = ((double)((int32_t)nn1 - (int32_t)np1)) / ((double)(np1 + nn1));
+    double posr2 = ((double)((int32_t)pp2 - (int32_t)pn2)) / ((double)(pp2 + pn2));
+    double negr2 = ((double)((int32_t)nn2 - (int32_t)np2)) / ((double)(np2 + nn2));
+    uint32_t totalr1 = pp1 + pn1 + np1 + nn1, totalr2 = pp2 + pn2 + np2 + nn2;
+    int s = 3 /* UNKNOWN */, o = ORC_OR_UNKNOWN;
+    if (totalr1 == 0 && totalr2 == 0) {
+    } else if (totalr2 == 0) {
+        o = ORC_OR_SE;
+        if (posr1 > 0.5 && negr1 > 0.5) s = 2;
+        else if (posr1 < -0.5 && negr1 < -0.5) s = 1;
+    } else {
+        o = ORC_OR_FR;
+        if (posr1 > 0.5 && negr1 > 0.5 && posr2 < -0.5 && negr2 < -0.5) s = 2;
+        else if (posr1 < -0.5 && negr1 < -0.5 && posr2 > 0.5 && negr2 > 0.5) s = 1;
+        else if (posr1 > 0.5 && negr1 > 0.5 && posr2 > 0.5 && negr2 > 0.5) { s = 2; o = ORC_OR_FF; }
+        else if (posr1 < -0.5 && negr1 < -0.5 && posr2 < -0.5 && negr2 < -0.5) { s = 1; o = ORC_OR_FF; }
+    }
+    if (fabs(posr1) <= 0.5 && fabs(negr1) <= 0.5 && fabs(posr2) <= 0.5 && fabs(negr2) <= 0.5) s = 0;
+    *orientation = o;
+    *strandedness = s;
+}
+
 /* ------------------------------------------------------------------ */
 /* writers                                                            */
 /* ------------------------------------------------------------------ */

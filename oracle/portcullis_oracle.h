@@ -185,6 +185,12 @@ double orc_calc_coverage(int32_t start, int32_t end, const uint32_t *levels, siz
 int orc_extra(int32_t n_refs, const int32_t *ref_len, const orc_reads *reads, const uint64_t *const *name_hash,
               orc_row *rows, int64_t n_rows, int32_t max_query_len);
 
+/* JunctionSystem::determineStrandedness (lib/src/junction_system.cc:455-560): orientation (ORC_OR_*) and
+ * strandedness (bam_master.hpp:92-97 order: 0 UNSTRANDED, 1 FIRSTSTRAND, 2 SECONDSTRAND, 3 UNKNOWN) inferred from
+ * the R1/R2 x splice-site-strand totals.  The unqualified `abs` of :553 is taken as std::abs(double) (what a
+ * libstdc++ with <cmath> in scope resolves it to). */
+void orc_determine_strandedness(const orc_row *rows, int64_t n, int *orientation, int *strandedness);
+
 /* Writers.  Return a malloc'd buffer (caller frees with orc_free_text) and its length.
  * ref_names[refid], ref_lens[refid].  (.tab: junction.hpp:1260-1319 + junction_system.hpp:154-160
  * + junction_system.cc:356; .bed: junction_system.cc:411-418 + junction.cc:1189-1214;

@@ -138,3 +138,104 @@ def test_bench_line_small_workload(tmp_path):
     assert d["roofline"]["frac"] > 0 and d["roofline"]["alg_bytes_per_launch"] > 0
     assert d["cpu_baseline"]["value"] > 0 and "every device row" in d["cpu_baseline"]["sample"]
     assert d["e2e"]["tab_identical_to_oracle"] is True and d["e2e"]["reads"] == d["config"]["reads_total"]
+
+
+# ---- BASELINE configs[2] at full size: 200 M paired-end reads over 25 GRCh38-sized contigs, one context
+@pytest.fixture(scope="module")
+def c3_full():
+    import torch
+    from portcullis_amd import ffi, synth
+
+    cfgs = synth.c3_contig_configs()
+    ctx = ffi.Context(0, "FR")
+    ctx.set_refs([c.contig_len for c in cfgs])
+    data = []
+    for tid, c in enumerate(cfgs):
+        d = synth.generate(c, device="cuda", tid=tid)
+        ctx.upload_contig_device(tid, d["genome"])
+        data.append(d)
+    torch.cuda.synchronize()
+
+    def run():
+        ctx.clear_rows()
+        regs = []
+        for tid, d in enumerate(data):
+            ctx.submit_batch_device(tid, d["batch"], d["n_reads"])
+            regs.append(ctx.finish_contig(tid))
+        return ctx.collect(), regs
+
+    rows, regs = run()
+    yield cfgs, data, rows, regs, run
+    ctx.close()
+
+
+def test_c3_fullsize_properties_and_oracle(c3_full):
+    from oracle import oracle as orc
+    from portcullis_amd import synth
+
+    cfgs, data, rows, regs, run = c3_full
+    n_reads = sum(c.n_reads for c in cfgs)
+    n_pairs = sum(d["n_pairs"] for d in data)
+    assert n_reads >= 199_999_000 and len(cfgs) == 25
+    assert sum(r["n_reads"] for r in regs) == n_reads and sum(r["n_pairs"] for r in regs) == n_pairs
+    assert sum(r["spliced"] + r["unspliced"] for r in regs) == n_reads
+    assert int(rows["nb_raw"].astype(np.int64).sum()) == n_pairs            # conservation: every N op lands in one junction
+    assert (rows["r1pos"] + rows["r1neg"] + rows["r2pos"] + rows["r2neg"] == rows["nb_raw"]).all()
+    assert (rows["nb_ppp"] <= rows["nb_bpp"] + rows["nb_raw"]).all() and (rows["nb_rel"] <= rows["nb_um"]).all()
+    key = (rows["refid"].astype(np.int64) << 48) | (rows["start"].astype(np.int64) << 20)
+    assert (np.diff(key) >= 0).all()                                          # contig-major, start-sorted
+    assert len(np.unique(rows[["refid", "start", "end"]])) == len(rows)       # one row per intron
+    again, _ = run()
+    assert hashlib.md5(again.tobytes()).hexdigest() == hashlib.md5(rows.tobytes()).hexdigest()   # deterministic
+    worst = 0.0
+    for tid in (0, 1, 24):                                                     # chr1, chr2 (16 M reads each) and chrM vs the oracle
+        hb = synth.batch_to_numpy(data[tid]["batch"], 0, data[tid]["n_reads"])
+        orows, oreg = orc.find_juncs(tid, cfgs[tid].contig_len, data[tid]["genome"].cpu().numpy().tobytes(), hb.to_oracle(), "FR")
+        region_equal(regs[tid], oreg)
+        worst = max(worst, assert_rows_equal(rows[rows["refid"] == tid], orows))
+    assert worst <= 1e-6
+
+
+# ---- BASELINE configs[4], one rank's share: 125 M reads of a 1 B-read run on one 248 Mb contig, 300 k junctions,
+# Zipf depth (the deepest junction holds millions of alignments); strandedness=firststrand does not change junc output
+def test_c5_rank_share_properties_and_prefix_oracle():
+    import torch
+    from oracle import oracle as orc
+    from portcullis_amd import ffi, synth
+
+    cfg = synth.SynthConfig("C5-share", 248_956_422, 125_000_000, 300_000, 100, seed=5_000_001)
+    d = synth.generate(cfg, device="cuda")
+    torch.cuda.synchronize()
+    with ffi.Context(0, "UNKNOWN", strandedness=1) as ctx:      # PJB_SS_FIRSTSTRAND: accepted, no effect
+        ctx.set_refs([cfg.contig_len])
+        ctx.upload_contig_device(0, d["genome"])
+
+        def run(n):
+            ctx.clear_rows()
+            b = d["batch"] if n == d["n_reads"] else {k: v for k, v in d["batch"].items()}
+            ctx.submit_batch_device(0, b, n)
+            return ctx.finish_contig(0), ctx.collect()
+
+        reg, rows = run(d["n_reads"])
+        assert reg["n_reads"] == cfg.n_reads and reg["n_pairs"] == d["n_pairs"]
+        assert int(rows["nb_raw"].astype(np.int64).sum()) == d["n_pairs"]
+        assert int(rows["nb_raw"].max()) > 1_000_000                           # a junction with > 10^6 supporting alignments
+        deep = rows[np.argmax(rows["nb_raw"])]
+        assert deep["jad"][0] <= deep["nb_raw"] and deep["nb_dist"] >= 1 and 0 <= deep["entropy"] <= np.log2(deep["nb_raw"]) + 1e-9
+        key = rows["start"].astype(np.int64) << 32 | rows["end"].astype(np.int64)
+        assert (np.diff(key) > 0).all() and len(rows) > 250_000
+        reg2, rows2 = run(d["n_reads"])
+        assert hashlib.md5(rows2.tobytes()).hexdigest() == hashlib.md5(rows.tobytes()).hexdigest()
+    # a 3 M-read prefix of the same records against the oracle (cig_off / seq_off of a prefix are a valid batch)
+    n = 3_000_000
+    hb = synth.batch_to_numpy(d["batch"], 0, n)
+    genome = d["genome"].cpu().numpy().tobytes()
+    orows, oreg = orc.find_juncs(0, cfg.contig_len, genome, hb.to_oracle(), "UNKNOWN")
+    with ffi.Context(0, "UNKNOWN", strandedness=1) as ctx:
+        ctx.set_refs([cfg.contig_len])
+        ctx.upload_contig_device(0, d["genome"])
+        ctx.clear_rows()
+        ctx.submit_batch(0, hb)
+        dreg = ctx.finish_contig(0)
+        region_equal(dreg, oreg)
+        assert assert_rows_equal(ctx.collect(), orows) <= 1e-6

@@ -73,6 +73,11 @@ def check(prep, tmp_path, orc, orientation="UNKNOWN", threads=1, extra_opts=()):
                     diff = [(k, x, y) for k, (x, y) in enumerate(zip(ga, ea)) if x != y]
                     raise AssertionError(f"{ext} line {i} differs at columns {diff[:6]}")
             raise AssertionError(f"{ext}: line count {len(gl)} vs {len(el)}")
+    # JunctionSystem::determineStrandedness (row a17): the two enums the program reports must be the oracle's
+    o, s = orc.determine_strandedness(exp["rows"])
+    assert f"Determined sequence orientation to be: {orc.ORIENTATION_LONG[o]}\n" in p.stdout, (o, p.stdout[-600:])
+    assert f"Determined RNAseq strandedness to be: {orc.STRANDEDNESS_LONG[s]}\n" in p.stdout, (s, p.stdout[-600:])
+    exp["strand_call"] = (o, s)
     return p, exp
 
 
@@ -273,3 +278,42 @@ def test_extra_metrics_cli(tmp_path, orc, ingest):
     rows = exp["rows"]
     assert (rows["up_aln"] > 0).any() and (rows["coverage"] != 0).any() and (rows["mm_score"] < 1).any()
     assert "Calculating extra junction metrics" in p.stdout
+
+
+@pytest.mark.parametrize("protocol", ["firststrand", "secondstrand", "ff_second", "se_first"])
+def test_determine_strandedness_protocols(tmp_path, orc, spombe30k, protocol):
+    """Libraries whose read strand follows the transcript strand: the inferred orientation / strandedness pair
+    (lib/src/junction_system.cc:455-560) equals the oracle's and is the expected protocol."""
+    name, genome = spombe30k
+    g = list(genome.upper())
+    # two introns with planted motifs: GT..AG (splice-site strand +) at 5000, CT..AC (strand -) at 12000
+    for start, d, a in ((5050, "GT", "AG"), (12050, "CT", "AC")):
+        g[start:start + 2] = list(d)
+        g[start + 98:start + 100] = list(a)
+    genome = "".join(g)
+    reads = []
+    for start, plus in ((5050, True), (12050, False)):
+        for k in range(12):
+            pos = start - 50 + k
+            seq = genome[pos:start] + genome[start + 100:start + 100 + 50 + k]
+            cigar = f"{start - pos}M100N{50 + k}M"
+            first = k % 2 == 0
+            if protocol == "firststrand":      # R1 antisense to the transcript, R2 sense
+                rev = (plus if first else not plus)
+            elif protocol == "secondstrand":   # R1 sense, R2 antisense
+                rev = ((not plus) if first else plus)
+            elif protocol == "ff_second":      # both mates sense
+                rev = not plus
+            else:                              # single-end, reads antisense
+                rev = plus
+            if protocol == "se_first":
+                flag = 0x40 | (0x10 if rev else 0)     # an unpaired R1 (flag 0 alone would land in the R2 bucket)
+            else:
+                flag = 1 | (0x40 if first else 0x80) | (0x10 if rev else 0x20)
+            reads.append(dict(tid=0, pos=pos, cigar=cigar, seq=seq, flag=flag, mapq=60, xs="+" if plus else "-",
+                              mtid=0 if protocol != "se_first" else -1, mpos=pos + 200 if protocol != "se_first" else -1, name=f"p{start}_{k}"))
+    reads.sort(key=lambda r: r["pos"])
+    prep = make_prep_dir(str(tmp_path / "prep"), [(name, len(genome))], [(name, genome)], reads)
+    p, exp = check(prep, tmp_path, orc, "FR" if protocol != "se_first" else "SE")
+    want = {"firststrand": (1, 1), "secondstrand": (1, 2), "ff_second": (3, 2), "se_first": (0, 1)}[protocol]
+    assert exp["strand_call"] == want, (exp["strand_call"], want)
