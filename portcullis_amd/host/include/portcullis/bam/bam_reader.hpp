@@ -10,6 +10,7 @@
 #include <string>
 #include <vector>
 
+#include "bam_alignment.hpp"
 #include "bam_master.hpp"
 
 struct pjb_batch;
@@ -86,6 +87,8 @@ class BamReader {
     bool regionDone = true;
     bool wantNames = false;
     std::vector<uint8_t> rec;
+    BamAlignment cur;      // next() / current(): the record-at-a-time view of the reference's reader
+    ReadBatch one;
 
     void loadIndex(bool useCsi);
 
@@ -112,6 +115,10 @@ public:
     // Append up to maxRecords records of the region to `out`; false when the region is exhausted
     // and nothing was appended.
     bool nextBatch(ReadBatch& out, size_t maxRecords);
+    // Record at a time, as lib/src/bam_reader.cc:134-142 of the reference: next() advances inside the region set by
+    // setRegion(tid), current() is a reference to an internal object that the next call overwrites.
+    bool next();
+    const BamAlignment& current() const { return cur; }
 
     // Same visit as setRegion(tid) + nextBatch(...) but with `nthreads` workers inside the target:
     // BGZF blocks are located from their headers, inflated in parallel into a contiguous buffer,

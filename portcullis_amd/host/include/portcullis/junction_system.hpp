@@ -1,7 +1,8 @@
 // JunctionSystem: the ordered collection of junctions of a run, the cross-junction pass and the
 // writers.  API of lib/include/portcullis/junction_system.hpp:48-181 of the reference for the junc
-// path.  (The per-alignment entry point addJunctions(const BamAlignment&) of the reference has no
-// equivalent here: alignments go to the GPU in batches through portcullis::JunctionBuilder.)
+// path.  The bulk route is portcullis::JunctionBuilder (alignments go to the GPU in batches); the reference's
+// per-alignment entry point addJunctions(const BamAlignment&) (junction_system.hpp:128-132) is kept for library
+// callers: it queues the alignment, and finish() runs the device over everything queued.
 #pragma once
 
 #include <ostream>
@@ -9,6 +10,8 @@
 #include <unordered_map>
 #include <utility>
 
+#include "bam/bam_reader.hpp"
+#include "bam/genome_mapper.hpp"
 #include "junction.hpp"
 
 namespace portcullis {
@@ -24,6 +27,7 @@ private:
     int32_t minQueryLength = 0;
     double meanQueryLength = 0.0;
     int32_t maxQueryLength = 0;
+    std::unordered_map<int32_t, bam::ReadBatch> pending;  // addJunctions(): alignments queued per target, in arrival order
 
 protected:
     size_t createJunctionGroup(size_t index, std::vector<JunctionPtr>& group);
@@ -55,6 +59,18 @@ public:
     int32_t getMinQueryLength() const { return minQueryLength; }
     double getMeanQueryLength() const { return meanQueryLength; }
     int32_t getMaxQueryLength() const { return maxQueryLength; }
+
+    // JunctionSystem::addJunctions(const BamAlignment&) of the reference (lib/src/junction_system.cc:140-210) found the
+    // alignment's junctions on the spot; here the alignment is queued (alignments of one target must arrive in
+    // coordinate order, as a region iterator delivers them) and the return value is the reference's: whether the
+    // alignment is spliced.  Call finish() once every alignment has been added.
+    bool addJunctions(const bam::BamAlignment& al);
+    bool addJunctions(const bam::BamAlignment& al, size_t startOp, int32_t offset) { (void)startOp; (void)offset; return addJunctions(al); }
+    // Runs the device path over the queued alignments, target by target (the genome of each comes from `gmap`), and
+    // fills the junction list: what the reference's callers did with Junction::calcMetrics(orientation) +
+    // processJunctionWindow(gmap) per junction (lib/include/portcullis/junction.hpp:1038-1100).  Returns the number of
+    // junctions added.  Throws JunctionException for the data conditions under which the reference throws.
+    size_t finish(const bam::GenomeMapper& gmap, Orientation orientation = Orientation::UNKNOWN, int device = 0);
 
     void addJunction(JunctionPtr j);
     void append(JunctionSystem& other);

@@ -341,6 +341,109 @@ static uint8_t xsCode(const uint8_t* aux, const uint8_t* end) {
     return 0;
 }
 
+// ------------------------------------------------------------------ BamAlignment (library-level entry)
+static const char* const CIGAR_LETTERS = "MIDNSHP=XB";
+static const char* const NT16_LETTERS = "=ACMGRSVTWYHKDBN";
+
+BamAlignment::BamAlignment(const std::string& nm, int32_t ref, int32_t pos, uint16_t flag, uint8_t mq, const std::string& cigarText,
+                           const std::string& bases, char xs, int32_t mId, int32_t mPos) {
+    name = nm;
+    refId = ref;
+    position = pos;
+    alFlag = flag;
+    mapq = mq;
+    mateId = mId;
+    matePos = mPos;
+    xsCode = xs == '+' ? 1 : xs == '-' ? 2 : (xs == 0 || xs == '?' || xs == '.') ? 0 : 3;
+    int64_t num = 0;
+    bool any = false;
+    for (char ch : cigarText) {
+        if (ch >= '0' && ch <= '9') {
+            num = num * 10 + (ch - '0');
+            any = true;
+            continue;
+        }
+        const char* at = strchr(CIGAR_LETTERS, ch);
+        if (!at || !any || ch == '*') throw BamException("BamAlignment: bad CIGAR text: " + cigarText);
+        cigar.emplace_back(ch, (int32_t)num);
+        rawCigar.push_back(((uint32_t)num << 4) | (uint32_t)(at - CIGAR_LETTERS));
+        if (CigarOp::opConsumesReference(ch)) alignedLength += (int32_t)num;
+        num = 0;
+        any = false;
+    }
+    if (bases != "*" && !bases.empty()) {
+        lQseq = (int32_t)bases.size();
+        seq4.assign((bases.size() + 1) / 2, 0);
+        for (size_t i = 0; i < bases.size(); i++) {
+            const char* at = strchr(NT16_LETTERS, bases[i] >= 'a' && bases[i] <= 'z' ? bases[i] - 32 : bases[i]);
+            const uint8_t code = at ? (uint8_t)(at - NT16_LETTERS) : 15;
+            seq4[i / 2] |= (uint8_t)(code << ((i & 1) ? 0 : 4));
+        }
+    }
+}
+
+std::string BamAlignment::deriveName() const {
+    return isPaired() ? name + (isFirstMate() ? "_R1" : isSecondMate() ? "_R2" : "_R?") : name;
+}
+
+bool BamAlignment::isSplicedRead() const {
+    for (const auto& op : cigar)
+        if (op.type == 'N') return true;
+    return false;
+}
+
+uint32_t BamAlignment::getNbJunctionsInRead() const {
+    uint32_t n = 0;
+    for (const auto& op : cigar) n += op.type == 'N';
+    return n;
+}
+
+std::string BamAlignment::getQuerySeq() const {
+    std::string s((size_t)lQseq, '=');
+    for (int32_t i = 0; i < lQseq && (size_t)(i / 2) < seq4.size(); i++) s[(size_t)i] = NT16_LETTERS[(seq4[(size_t)i / 2] >> ((i & 1) ? 0 : 4)) & 15];
+    return s;
+}
+
+bool BamReader::next() {
+    // one record through the batch transcoder, then unpacked into the object view (names are read separately:
+    // the batch layout does not carry them)
+    if (regionDone) return false;
+    one.clear();
+    const bool keep = wantNames;
+    wantNames = true;
+    bool ok = false;
+    try {
+        ok = nextBatch(one, 1);
+    } catch (...) {
+        wantNames = keep;
+        throw;
+    }
+    wantNames = keep;
+    if (!ok) return false;
+    const uint8_t* r = rec.data();
+    const uint32_t l_name = r[8];
+    cur = BamAlignment();
+    cur.name.assign((const char*)r + 32, l_name ? l_name - 1 : 0);
+    cur.refId = regionTid;
+    cur.position = one.pos[0];
+    cur.alFlag = one.flag[0];
+    cur.mapq = one.mapq[0];
+    cur.xsCode = one.xs[0];
+    cur.lQseq = one.l_qseq[0];
+    cur.mateId = one.mtid[0];
+    cur.matePos = one.mpos[0];
+    cur.rawCigar.assign(one.cigar.begin(), one.cigar.end());
+    for (uint32_t op : cur.rawCigar) {
+        const char t = CIGAR_LETTERS[(op & 15u) < 10u ? (op & 15u) : 9u];
+        cur.cigar.emplace_back(t, (int32_t)(op >> 4));
+        if (CigarOp::opConsumesReference(t)) cur.alignedLength += (int32_t)(op >> 4);
+    }
+    const uint32_t n_cig = le16(r + 12);
+    const size_t seq_at = 32 + (size_t)l_name + 4ull * n_cig;
+    cur.seq4.assign(r + seq_at, r + seq_at + (size_t)((cur.lQseq + 1) / 2));
+    return true;
+}
+
 bool BamReader::nextBatch(ReadBatch& out, size_t maxRecords) {
     if (out.cig_off.empty()) out.clear();
     size_t added = 0;

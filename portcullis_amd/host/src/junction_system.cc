@@ -4,6 +4,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstring>
 #include <fstream>
 #include <thread>
 #include <iostream>
@@ -50,6 +51,80 @@ void JunctionSystem::appendRows(const pjb_junction_row* rows, size_t n) {
     if (!refs) throw JunctionException("JunctionSystem::appendRows: reference sequence list is not set");
     junctionList.reserve(junctionList.size() + n);
     for (size_t i = 0; i < n; i++) addJunction(Junction::fromRow(rows[i], *refs));
+}
+
+bool JunctionSystem::addJunctions(const bam::BamAlignment& al) {
+    if (!refs) throw JunctionException("JunctionSystem::addJunctions: reference sequence list is not set");
+    const int32_t tid = al.getReferenceId();
+    if (tid < 0 || (size_t)tid >= refs->size()) throw JunctionException("JunctionSystem::addJunctions: alignment is not placed on a known target");
+    bam::ReadBatch& b = pending[tid];
+    if (b.cig_off.empty()) b.clear();
+    b.pos.push_back(al.getPosition());
+    b.flag.push_back(al.getAlignmentFlag());
+    b.mapq.push_back(al.getMapQuality());
+    b.xs.push_back(al.getXsCode());
+    b.l_qseq.push_back(al.getLength());
+    b.mtid.push_back(al.getMateReferenceId());
+    b.mpos.push_back(al.getMatePosition());
+    for (uint32_t op : al.getRawCigar()) b.cigar.push_back(op);
+    b.cig_off.push_back((uint32_t)b.cigar.size());
+    const bool spliced = al.isSplicedRead();
+    if (spliced && !al.getPackedSeq().empty()) {  // only spliced alignments need their bases on the device
+        const std::vector<uint8_t>& s = al.getPackedSeq();
+        const size_t words = (s.size() + 3) / 4, at = b.seq4.size();
+        b.seq4.resize(at + words * 4, 0);
+        memcpy(&b.seq4[at], s.data(), s.size());
+        b.n_refskip += al.getNbJunctionsInRead();
+    }
+    b.seq_off.push_back((uint32_t)(b.seq4.size() / 4));
+    return spliced;
+}
+
+size_t JunctionSystem::finish(const bam::GenomeMapper& gmap, Orientation orientation, int device) {
+    if (!refs) throw JunctionException("JunctionSystem::finish: reference sequence list is not set");
+    if (pending.empty()) return 0;
+    pjb_config cfg;
+    memset(&cfg, 0, sizeof cfg);
+    cfg.abi_version = PJB_ABI_VERSION;
+    cfg.device = device;
+    cfg.orientation = (int32_t)orientation;
+    cfg.strandedness = PJB_SS_UNKNOWN;
+    pjb_ctx* ctx = nullptr;
+    if (pjb_create(&ctx, &cfg) != PJB_OK) throw JunctionException(std::string("pjb_create: ") + pjb_last_error(nullptr));
+    struct Closer {
+        pjb_ctx* c;
+        ~Closer() { pjb_destroy(c); }
+    } closer{ctx};
+    std::vector<int32_t> lens;
+    for (auto& r : *refs) lens.push_back(r->length);
+    auto check = [&](int rc, const char* what) {
+        if (rc != PJB_OK) throw JunctionException(std::string(what) + ": " + pjb_last_error(ctx));
+    };
+    check(pjb_set_refs(ctx, (int32_t)lens.size(), lens.data()), "pjb_set_refs");
+    std::vector<int32_t> tids;
+    for (auto& kv : pending) tids.push_back(kv.first);
+    std::sort(tids.begin(), tids.end());
+    size_t added = 0;
+    for (int32_t tid : tids) {
+        bam::ReadBatch& b = pending[tid];
+        if (b.size() == 0) continue;
+        const std::string contig = gmap.fetchContig(refs->at((size_t)tid)->name);
+        check(pjb_upload_contig(ctx, tid, (const uint8_t*)contig.data(), (int64_t)contig.size()), "pjb_upload_contig");
+        pjb_batch pb;
+        b.view(pb);
+        check(pjb_submit_batch(ctx, tid, &pb), "pjb_submit_batch");
+        pjb_region_result rr;
+        check(pjb_finish_contig(ctx, tid, &rr), "pjb_finish_contig");
+        const pjb_junction_row* rows = nullptr;
+        int64_t n = 0;
+        check(pjb_collect(ctx, &rows, &n), "pjb_collect");
+        appendRows(rows, (size_t)n);
+        added += (size_t)n;
+        check(pjb_clear_rows(ctx), "pjb_clear_rows");
+        check(pjb_release_contig(ctx, tid), "pjb_release_contig");
+    }
+    pending.clear();
+    return added;
 }
 
 JunctionPtr JunctionSystem::getJunction(const Intron& intron) const {

@@ -285,6 +285,7 @@ def test_determine_strandedness_protocols(tmp_path, orc, spombe30k, protocol):
     """Libraries whose read strand follows the transcript strand: the inferred orientation / strandedness pair
     (lib/src/junction_system.cc:455-560) equals the oracle's and is the expected protocol."""
     name, genome = spombe30k
+    genome = genome.decode() if isinstance(genome, (bytes, bytearray)) else genome
     g = list(genome.upper())
     # two introns with planted motifs: GT..AG (splice-site strand +) at 5000, CT..AC (strand -) at 12000
     for start, d, a in ((5050, "GT", "AG"), (12050, "CT", "AC")):
@@ -317,3 +318,23 @@ def test_determine_strandedness_protocols(tmp_path, orc, spombe30k, protocol):
     p, exp = check(prep, tmp_path, orc, "FR" if protocol != "se_first" else "SE")
     want = {"firststrand": (1, 1), "secondstrand": (1, 2), "ff_second": (3, 2), "se_first": (0, 1)}[protocol]
     assert exp["strand_call"] == want, (exp["strand_call"], want)
+
+
+def test_library_level_entry(tmp_path, orc):
+    """The reference's per-alignment API (lib/include/portcullis/junction_system.hpp:128-132): BamReader::next() /
+    current() -> JunctionSystem::addJunctions(const BamAlignment&) -> finish() gives the same .tab as the bulk route."""
+    host = os.path.join(ROOT, "portcullis_amd", "host")
+    csrc = os.path.join(ROOT, "portcullis_amd", "csrc")
+    exe = str(tmp_path / "library_entry")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", f"-I{host}/include", f"-I{ROOT}/include", "-o", exe,
+                           os.path.join(ROOT, "tests", "cpp", "library_entry.cc"), f"-L{host}", "-lportcullis_host",
+                           f"-L{csrc}", "-lportcullis_amd", f"-Wl,-rpath,{host}", f"-Wl,-rpath,{csrc}"])
+    prep = multi_contig(tmp_path, [41, None, 42])
+    out = str(tmp_path / "lib" / "pc")
+    os.makedirs(os.path.dirname(out))
+    p = subprocess.run([exe, prep, out, "FR"], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    exp = oracle_outputs(orc, prep, "FR")
+    assert open(out + ".junctions.tab", "rb").read() == exp["tab"]
+    spliced = int(p.stdout.split("spliced=")[1].split()[0])
+    assert spliced == exp["tot"]["spliced"]
