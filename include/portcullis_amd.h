@@ -289,8 +289,8 @@ int pjb_inflate_bgzf(pjb_ctx* ctx, const uint8_t* comp, int64_t comp_bytes, uint
  *   first_uoffset    : offset of that first record inside the first block's inflated bytes (the low
  *                      16 bits of the index's virtual offset).
  * Records are taken until the first one whose refID is not `tid` (or whose position is past the
- * target's end, as hts_itr would stop) or the end of the data; a record cut off by the end of the data
- * is ignored.  One call per target.  *n_records (optional) receives the number of alignments added.
+ * target's end, as hts_itr would stop) or the end of the data.  Data that ends inside one of the target's
+ * records (before any record of another target) is an error: PJB_ERR_BGZF.  One call per target.  *n_records (optional) receives the number of alignments added.
  * Errors: PJB_ERR_BGZF for corrupt BGZF / DEFLATE / BAM record data. */
 int pjb_submit_bam(pjb_ctx* ctx, int32_t tid, const uint8_t* comp, int64_t comp_bytes, int32_t first_uoffset, int64_t* n_records);
 

@@ -760,10 +760,14 @@ int pjb_finish_contig(pjb_ctx *c, int32_t tid, pjb_region_result *res) {
     if (!c) return PJB_ERR_ARG;
     if (tid < 0 || (size_t)tid >= c->ref_len.size()) return fail(c, PJB_ERR_ARG, "finish: bad tid %d", tid);
     c->cur_tid = tid;
-    struct Closer {
+    struct Closer { // also on every error path: the side stream (k4a_simple) may still read the contig's batches
         pjb_ctx *c;
         int32_t tid;
-        ~Closer() { close_contig(c, tid); }
+        bool forked = false;
+        ~Closer() {
+            if (forked) (void)hipStreamSynchronize(c->stream2);
+            close_contig(c, tid);
+        }
     } closer{c, tid};
     static std::vector<DevBatch> no_batches;
     auto open_it = c->open.find(tid);
@@ -907,6 +911,7 @@ int pjb_finish_contig(pjb_ctx *c, int32_t tid, pjb_region_result *res) {
                (int)batches.size(), (const u32 *)G.codes, (int32_t)G.len, P, (u64 *)c->b_res.p);
         c->stream = main_stream;
         (void)timed;
+        closer.forked = true;
         HIP_TRY(c, hipEventRecord(c->ev_join, c->stream2));
     }
     HIP_TRY(c, hipEventRecord(c->ev[1], st));
@@ -1447,12 +1452,13 @@ extern "C" int pjb_submit_bam(pjb_ctx *c, int32_t tid, const uint8_t *comp, int6
             }
         }
     }
-    uint32_t h_ctl[6];
+    uint32_t h_ctl[8];
     uint32_t end_seg = 0xffffffffu;
     for (int attempt = 0;; attempt++) {
         HIP_TRY(c, hipMemsetAsync(ctl, 0xff, 16, st));
+        HIP_TRY(c, hipMemsetAsync(ctl + 6, 0xff, 4, st));
         LAUNCH(c, "bam_walk_count", bam_walk<false>, dim3((n_seg + 255) / 256), dim3(256), R, n_seg, (const iu64 *)seg_start, O);
-        HIP_TRY(c, hipMemcpyAsync(h_ctl, ctl, 16, hipMemcpyDeviceToHost, st));
+        HIP_TRY(c, hipMemcpyAsync(h_ctl, ctl, 32, hipMemcpyDeviceToHost, st));
         HIP_TRY(c, hipStreamSynchronize(st));
         end_seg = h_ctl[0];
         if (h_ctl[2] != 0xffffffffu && h_ctl[2] <= end_seg && (h_ctl[1] == 0xffffffffu || h_ctl[2] <= h_ctl[1]))
@@ -1469,6 +1475,12 @@ extern "C" int pjb_submit_bam(pjb_ctx *c, int32_t tid, const uint8_t *comp, int6
         if (h_ctl[3] != 0xffffffffu)
             return fail(c, PJB_ERR_BGZF, "Invalid BAM record on target %d (inflated offset %llu..)", tid, (unsigned long long)h_ctl[3] * BAM_SEG);
     }
+    // The data ends inside a record of this target and no record of another target (or past the target's end) was seen:
+    // the bytes handed over stop short of the target's last alignment (a stale index, a truncated file).  The reference
+    // fails on a truncated file too (bgzf_read / bam_read1); dropping the tail silently would change counts.
+    if (end_seg == 0xffffffffu && h_ctl[6] != 0xffffffffu)
+        return fail(c, PJB_ERR_BGZF, "the data for target %d ends inside an alignment record (inflated offset %llu..): truncated "
+                                     "file, or the index's span for the target is too short", tid, (unsigned long long)h_ctl[6] * BAM_SEG);
     LAUNCH(c, "bam_trim_segments", bam_trim_segments, dim3((n_seg + 255) / 256), dim3(256), seg_n, n_seg, (const iu32 *)ctl);
     if ((rc = run_scan(c, "bam_seg", SegCountFn{seg_n}, SegBaseSink{seg_base}, n_seg, d_total))) return rc;
     HIP_TRY(c, hipMemcpyAsync(h_ctl, ctl, 24, hipMemcpyDeviceToHost, st));

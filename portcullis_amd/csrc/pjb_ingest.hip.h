@@ -174,19 +174,24 @@ struct Lane2 {
 // sequence), and the symbol is lng[(v >> (15 - len)) + adj[len]] where lng lists the long symbols in code
 // order (bytes, plus their 9th bit at lng_hi for the literal/length tree) and adj[len] = slot of the first
 // code of that length - that first code (mod 2^16).
-__device__ int inf2_build(const Lane2 L, iu32 root, int root_bits, iu32 lim, iu32 adj, iu32 lng, iu32 lng_hi, const uint8_t *lens, int n) {
+// `codes`: the tree of the code-length alphabet.  Like zlib's inflate_table (inftrees.c), an over-subscribed set is an
+// error and so is an incomplete one, except a literal/length or distance set that consists of a single 1-bit code.
+__device__ int inf2_build(const Lane2 L, iu32 root, int root_bits, iu32 lim, iu32 adj, iu32 lng, iu32 lng_hi, const uint8_t *lens, int n,
+                          bool codes = false) {
     // lim / adj double as scratch: codes per length in lim, running code / slot in adj
     for (int i = 0; i < 16; i++) L.h(lim + i) = 0;
     for (int i = 0; i < n; i++) L.h(lim + lens[i]) = L.h(lim + lens[i]) + 1;
     const iu32 rsize = 1u << root_bits;
     for (iu32 e = 0; e < rsize; e++) L.h(root + e) = 0;
     L.h(lim) = 0; // unused codes do not count
-    int left = 1;
+    int left = 1, max_len = 0;
     for (int len = 1; len <= 15; len++) {
         left <<= 1;
         left -= (int)L.h(lim + len);
         if (left < 0) return INF_ERR_CODELENS;
+        if (L.h(lim + len)) max_len = len;
     }
+    if (max_len > 0 && left > 0 && (codes || max_len != 1)) return INF_ERR_CODELENS; // incomplete set
     // long symbols in code order
     iu32 slot = 0;
     for (int len = root_bits + 1; len <= 15; len++) {
@@ -303,6 +308,14 @@ __global__ __launch_bounds__(64) void bgzf_inflate(const uint8_t *comp, const In
 
     // all lanes: top up the input rings and resolve the queued matches
     auto memory_phase = [&]() {
+        // A lane whose ring has run further than its block's payload plus what a ring can hold ahead is decoding bytes
+        // that are not its own (a stream without an end-of-block code in reach): stop it here, so that no lane ever
+        // reads more than 256 bytes past its payload -- the compressed buffer carries INF_PAD zero bytes behind its
+        // last block for exactly that.
+        if (state == ST_SYMBOLS && R.gp > in_end + 128) {
+            err = INF_ERR_OVERRUN;
+            state = ST_DONE;
+        }
         // one round trip for the ring refill and for the first (up to) 16 bytes of every queued match whose source
         // lies entirely before the first queued destination (nothing in the queue can have written it)
         const iu32 pairs = state == ST_SYMBOLS ? (16 - R.rf) >> 1 : 0;
@@ -438,7 +451,7 @@ __global__ __launch_bounds__(64) void bgzf_inflate(const uint8_t *comp, const In
                     if (!err) {
                         for (int i = 0; i < 19; i++) lens[i] = 0;
                         for (int i = 0; i < ncl; i++) lens[c_clen_order[i]] = (uint8_t)take(3);
-                        err = inf2_build(L, I2_LIT, 7, I2_LLIM, I2_LADJ, I2_LLONG, 0, lens, 19);
+                        err = inf2_build(L, I2_LIT, 7, I2_LLIM, I2_LADJ, I2_LLONG, 0, lens, 19, true);
                     }
                     int i = 0;
                     while (!err && i < nlit + ndist) {
@@ -511,7 +524,7 @@ __global__ __launch_bounds__(64) void bgzf_inflate(const uint8_t *comp, const In
             const bool sym_on = state == ST_SYMBOLS;
             if (!__any(sym_on)) break;
             if (__any(sym_on && (R.rf < I2_LITS + 3 || qn == I2_QUEUE))) memory_phase(); // an iteration takes at most I2_LITS + 2 words
-            if (!sym_on) continue;
+            if (state != ST_SYMBOLS) continue; // (the memory phase may have stopped this lane)
             // up to I2_LITS literals, then at most one end-of-block or length/distance pair: the literal step is short
             // and most symbols are literals, the pair step is long and some lane needs it in every iteration anyway
             iu32 e = 0, sym = 0;
@@ -785,6 +798,7 @@ __global__ __launch_bounds__(256) void bam_walk(BamRegion R, iu32 n_seg, const i
         O.land[s] = cur;
         if (ended) atomicMin(&O.ctl[0], s);
         else if (!partial && cur != limit) atomicMin(&O.ctl[1], s); // overshot the next start: that start was not a record
+        if (partial && !ended) atomicMin(&O.ctl[6], s);             // the data ends inside one of the target's records
     }
 }
 

@@ -106,15 +106,17 @@ bool BgzfStream::loadBlock() {
     int bsize = -1;
     for (size_t o = 0; o + 4 <= extra.size();) {
         uint16_t slen = le16(&extra[o + 2]);
-        if (extra[o] == 'B' && extra[o + 1] == 'C' && slen == 2) bsize = le16(&extra[o + 4]);
+        if (extra[o] == 'B' && extra[o + 1] == 'C' && slen == 2 && o + 6 <= extra.size()) bsize = le16(&extra[o + 4]);
         o += 4 + slen;
     }
     if (bsize < 0) throw BamException("BGZF block without BC field");
     const size_t total = (size_t)bsize + 1;
+    if (total < (size_t)xlen + 20) throw BamException("Invalid BGZF block: BSIZE is smaller than the block's header and footer");
     const size_t cdata = total - 12 - xlen - 8;
     comp.resize(cdata + 8);
     if (fread(comp.data(), 1, cdata + 8, fp) != cdata + 8) throw BamException("Truncated BGZF block");
     const uint32_t isize = le32(&comp[cdata + 4]);
+    if (isize > 65536) throw BamException("Invalid BGZF block: ISIZE exceeds 64 KiB");
     block.resize(isize);
     if (isize) {
         z_stream zs;
@@ -770,13 +772,15 @@ void BamReader::decodeRegionParallel(int32_t tid, int nthreads, size_t maxRecord
             for (uint32_t o = 0; o + 4 <= xlen;) {
                 const uint8_t* x = h + 12 + o;
                 const uint32_t slen = le16(x + 2);
-                if (x[0] == 'B' && x[1] == 'C' && slen == 2) bsize = le16(x + 4);
+                if (x[0] == 'B' && x[1] == 'C' && slen == 2 && o + 6 <= xlen) bsize = le16(x + 4);
                 o += 4 + slen;
             }
             if (bsize < 0) throw BamException("BGZF block without BC field");
             const uint32_t tot = (uint32_t)bsize + 1;
+            if (tot < xlen + 20) throw BamException("Invalid BGZF block: BSIZE is smaller than the block's header and footer");
             if (cpos + tot > cHave) break;  // incomplete in the window: next refill
             const uint32_t isz = le32(h + tot - 4);
+            if (isz > 65536) throw BamException("Invalid BGZF block: ISIZE exceeds 64 KiB");
             if (total != 0 && total + isz > CHUNK) break;
             blocks.push_back({(uint64_t)cpos, tot, isz, xlen});
             uoff.push_back(total);

@@ -15,6 +15,13 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.fixture(scope="module")
+def ffi_mod():
+    from portcullis_amd import ffi
+    assert ffi.device_count() >= 1
+    return ffi
+
+
+@pytest.fixture(scope="module")
 def ctx():
     from portcullis_amd import ffi
     assert ffi.device_count() >= 1
@@ -121,6 +128,135 @@ def test_corrupt_input_fails_cleanly(ctx):
     with pytest.raises(ffi.PjbError):
         ctx.inflate_bgzf(b"\x1f\x8b\x08\x00" + bytes(40))  # gzip without the BGZF extra field
     assert ctx.inflate_bgzf(good) == data  # the context still works afterwards
+
+
+class _Bits:
+    """LSB-first bit packing of a DEFLATE stream; Huffman codes go in MSB-first."""
+
+    def __init__(self):
+        self.acc, self.n, self.out = 0, 0, bytearray()
+
+    def put(self, value, nbits):
+        self.acc |= value << self.n
+        self.n += nbits
+        while self.n >= 8:
+            self.out.append(self.acc & 0xff)
+            self.acc >>= 8
+            self.n -= 8
+
+    def code(self, code, nbits):
+        for k in range(nbits - 1, -1, -1):
+            self.put((code >> k) & 1, 1)
+
+    def bytes(self):
+        return bytes(self.out) + (bytes([self.acc & 0xff]) if self.n else b"")
+
+
+def _raw_block(payload, isize):
+    """A BGZF block around a hand-made DEFLATE payload (CRC is not checked by either decoder here)."""
+    hdr = bytes([31, 139, 8, 4, 0, 0, 0, 0, 0, 255, 6, 0, 66, 67, 2, 0])
+    total = len(hdr) + 2 + len(payload) + 8
+    return hdr + struct.pack("<H", total - 1) + payload + struct.pack("<II", 0, isize)
+
+
+def _endless_literals_header():
+    """Dynamic block whose literal/length set is { literal 0: '0', end-of-block: '1' } (complete): a zero-filled
+    stream behind it decodes as literal 0 for ever, one bit each."""
+    b = _Bits()
+    b.put(1, 1); b.put(2, 2)                    # BFINAL, dynamic
+    b.put(0, 5); b.put(0, 5); b.put(14, 4)      # 257 lit/len codes, 1 distance code, 18 code-length codes
+    order = [16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15]
+    cl = {18: 2, 0: 2, 1: 1}
+    for sym in order[:18]:
+        b.put(cl.get(sym, 0), 3)
+    # code-length alphabet codes: '1' -> 0, '0' -> 10, '18' -> 11
+    b.code(0, 1)                                # literal 0: length 1
+    b.code(3, 2); b.put(138 - 11, 7)            # 138 zeros
+    b.code(3, 2); b.put(117 - 11, 7)            # 117 zeros (literals 1..255)
+    b.code(0, 1)                                # end-of-block: length 1
+    b.code(2, 2)                                # the one distance code: length 0
+    return b
+
+
+def test_streams_that_run_past_their_block(ctx):
+    """A block whose symbols never reach an end-of-block code inside its payload must fail cleanly (PJB_ERR_BGZF) after
+    reading at most a few hundred bytes past the payload -- never the tens of kilobytes its ISIZE would allow -- and an
+    incomplete code set is refused as zlib refuses it."""
+    import zlib
+
+    from portcullis_amd import ffi
+    b = _endless_literals_header()
+    payload = b.bytes() + bytes(24)              # zeros: literal 0, literal 0, ...
+    good_tail = bgzf(b"tail" * 1000, 6)
+    for comp in (_raw_block(payload, 65536),                                  # last block: only the zero padding follows
+                 _raw_block(payload, 65536) + good_tail,                      # another block's bytes follow
+                 good_tail + _raw_block(payload, 60000) + BGZF_EOF):
+        with pytest.raises(ffi.PjbError) as e:
+            ctx.inflate_bgzf(comp)
+        assert e.value.code == -22
+    # the same header with a proper end: 100 literal zeros then end-of-block -> decodes
+    b2 = _endless_literals_header()
+    for _ in range(100):
+        b2.code(0, 1)
+    b2.code(1, 1)
+    ok = b2.bytes()
+    assert zlib.decompressobj(-15).decompress(ok) == bytes(100)
+    assert ctx.inflate_bgzf(_raw_block(ok, 100) + BGZF_EOF) == bytes(100)
+    # incomplete literal/length set: literal 0 and end-of-block both 2 bits long, nothing else
+    b3 = _Bits()
+    b3.put(1, 1); b3.put(2, 2); b3.put(0, 5); b3.put(0, 5); b3.put(14, 4)
+    order = [16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15]
+    cl = {18: 2, 0: 2, 2: 1}
+    for sym in order[:18]:
+        b3.put(cl.get(sym, 0), 3)
+    b3.code(0, 1); b3.code(3, 2); b3.put(127, 7); b3.code(3, 2); b3.put(106, 7); b3.code(0, 1); b3.code(2, 2)
+    b3.code(0, 2); b3.code(1, 2)
+    bad = b3.bytes() + bytes(8)
+    with pytest.raises(zlib.error):
+        zlib.decompressobj(-15).decompress(bad)
+    with pytest.raises(ffi.PjbError):
+        ctx.inflate_bgzf(_raw_block(bad, 1) + BGZF_EOF)
+    assert ctx.inflate_bgzf(good_tail) == b"tail" * 1000   # the context still works
+
+
+def test_bam_data_ending_inside_a_record_is_an_error(ffi_mod, orc):
+    """pjb_submit_bam: the bytes of a target must not stop inside one of its records (a span cut short by a stale
+    index or a truncated file would silently lose the tail)."""
+    genome, reads = make_reads(8, n_reads=400)
+    for k, r in enumerate(reads):
+        r["tid"] = 0
+        r["name"] = f"r{k}"
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, "t.bam")
+        write_bam(path, [("chr1", len(genome))], reads, write_index=False, block_size=2000)
+        raw = open(path, "rb").read()
+    blocks, o = [], 0
+    while o < len(raw):
+        bs = (raw[o + 16] | raw[o + 17] << 8) + 1
+        blocks.append((o, bs))
+        o += bs
+    hdr = gzip.decompress(raw[: blocks[0][1]])
+    (l_text,) = struct.unpack_from("<i", hdr, 4)
+    first = 8 + l_text + 4 + (4 + len("chr1") + 1 + 4)
+    with ffi_mod.Context(0, "UNKNOWN") as ctx:
+        ctx.set_refs([len(genome)])
+        ctx.upload_contig(0, genome.encode())
+        raised = 0
+        for k in (len(blocks) // 3, len(blocks) // 2, len(blocks) // 2 + 1):
+            cut = blocks[k][0]                       # whole blocks, but the record chain is (almost surely) cut
+            try:
+                n = ctx.submit_bam(0, raw[:cut], first)
+                assert n < len(reads)                # the cut fell on a record boundary
+            except ffi_mod.PjbError as e:
+                assert e.code == -22 and "ends inside" in str(e)
+                raised += 1
+            ctx.finish_contig(0)
+            ctx.clear_rows()
+        assert raised >= 1
+        n = ctx.submit_bam(0, raw, first)            # the whole file is fine
+        assert n == len(reads)
+        ctx.finish_contig(0)
 
 
 # ------------------------------------------------------------------ BAM records on the device
