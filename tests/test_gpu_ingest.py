@@ -9,7 +9,8 @@ import zlib
 import numpy as np
 import pytest
 
-from util_bam import BGZF_EOF, _bgzf_block
+from fuzzgen import make_reads
+from util_bam import BGZF_EOF, _bgzf_block, write_bam
 
 pytestmark = pytest.mark.gpu
 
