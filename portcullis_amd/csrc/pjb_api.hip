@@ -91,6 +91,10 @@ struct pjb_ctx {
     unsigned stage_next = 0;
     // junction rows live in a grow-only pinned host buffer so the D2H copy is a single DMA
     pjb_junction_row *rows_pinned = nullptr;
+    pjb_junction_row *rows_pinned_dev = nullptr; // the same memory as the device sees it (k6_rows_out writes it)
+    void *res_pinned = nullptr;                  // control block + error word + list counters of the last contig
+    u32 junc_seen = 0;                           // most junctions a contig has had so far (junction limit of the next contig)
+    int lbits_seen = 18;                         // bits of the longest intron this context has met (key format of the next contig)
     size_t rows_n = 0, rows_cap = 0;
     size_t last_rows_n = 0; // rows of the contig finished last (still in b_rows)
     uint8_t *mirror = nullptr; // caller's device buffer filled by every finish (header + rows)
@@ -278,15 +282,15 @@ bool ktime_wanted(pjb_ctx *c, const char *name) {
 
 // generic scan launchers ------------------------------------------------------------------------
 template <typename F, typename G>
-int run_scan(pjb_ctx *c, const char *tag, F f, G g, u64 n, u64 *d_total) {
-    const u32 nt = (u32)((n + SCAN_TILE - 1) / SCAN_TILE);
+int run_scan(pjb_ctx *c, const char *tag, F f, G g, u64 n, u64 *d_total, const u32 *d_n = nullptr) {
+    const u32 nt = std::max<u32>(1, (u32)((n + SCAN_TILE - 1) / SCAN_TILE)); // (an empty input still gets its total written)
     int rc = ensure(c, c->b_scan_tiles, (size_t)nt * 8);
     if (rc) return rc;
     u64 *ts = (u64 *)c->b_scan_tiles.p;
     std::string t = tag;
-    LAUNCH(c, (t + "_reduce").c_str(), (scan_reduce_kernel<F>), dim3(nt), dim3(256), f, n, ts);
+    LAUNCH(c, (t + "_reduce").c_str(), (scan_reduce_kernel<F>), dim3(nt), dim3(256), f, n, ts, d_n);
     LAUNCH(c, (t + "_tiles").c_str(), scan_tiles_kernel, dim3(1), dim3(1024), ts, nt, d_total);
-    LAUNCH(c, (t + "_apply").c_str(), (scan_apply_kernel<F, G>), dim3(nt), dim3(256), f, g, n, (const u64 *)ts);
+    LAUNCH(c, (t + "_apply").c_str(), (scan_apply_kernel<F, G>), dim3(nt), dim3(256), f, g, n, (const u64 *)ts, d_n);
     return PJB_OK;
 }
 
@@ -419,6 +423,7 @@ void pjb_destroy(pjb_ctx *c) {
     for (auto &sl : c->slab_pool)
         if (sl.p) (void)hipFree(sl.p);
     if (c->rows_pinned) (void)hipHostFree(c->rows_pinned);
+    if (c->res_pinned) (void)hipHostFree(c->res_pinned);
     if (c->mirror_hdr) (void)hipHostFree(c->mirror_hdr);
     for (int k = 0; k < 2; k++) {
         if (c->stage[k]) (void)hipHostFree(c->stage[k]);
@@ -756,6 +761,239 @@ static int extra_contig(pjb_ctx *c, int32_t tid, std::vector<DevBatch> &batches,
     return PJB_OK;
 }
 
+// The device work of one contig, queued in one go.  The host does not learn a single count while the kernels run:
+// buffers and grids are sized from LIMITS (pair_limit, junc_limit, the key format kf), the kernels read the actual
+// counts from the control block in device memory (ContigStats) and stand still when a limit is exceeded.  The only
+// host synchronisation is at the end, when the control block -- counters, error word, overflow bits -- is back; the
+// rows have by then been written into page-locked host memory by the last kernels of the chain.
+struct ContigLimits {
+    u32 pair_limit = 0, junc_limit = 0;
+    KeyFmt kf;
+};
+
+static int run_contig_once(pjb_ctx *c, int32_t tid, std::vector<DevBatch> &batches, int64_t n_reads, u32 n_tiles, const ContigLimits &lim,
+                           ContigStats &cs_out, u64 &err_out, const u32 *&sidx_out, Pairs &pr_out, bool &forked) {
+    hipStream_t st = c->stream;
+    const int32_t ref_len = c->ref_len[(size_t)tid];
+    const Contig &G = c->contigs[(size_t)tid];
+    const KeyFmt kf = lim.kf;
+    const u32 PL = lim.pair_limit, JL = lim.junc_limit;
+    int rc;
+    if ((rc = ensure(c, c->b_batches, batches.size() * sizeof(DevBatch)))) return rc;
+    if ((rc = ensure(c, c->b_tile_cnt, (size_t)n_tiles * 4))) return rc;
+    if ((rc = ensure(c, c->b_tile_stats, (size_t)n_tiles * sizeof(TileStats)))) return rc;
+    if ((rc = ensure(c, c->b_cstats, sizeof(ContigStats)))) return rc;
+    if ((rc = ensure(c, c->b_splidx, (size_t)n_tiles * K1_TILE * 4))) return rc;
+    if ((rc = ensure(c, c->b_splpoff, (size_t)n_tiles * K1_TILE * 4))) return rc;
+    if ((rc = ensure(c, c->b_err, 8))) return rc;
+    if ((rc = ensure(c, c->b_total, 8))) return rc;
+    // ---- pair-sized buffers (one sort tile of slack: rs_scatter loads whole tiles unguarded)
+    if ((rc = ensure(c, c->b_key[0], ((size_t)PL + RS_TILE) * 8))) return rc;
+    if ((rc = ensure(c, c->b_key[1], ((size_t)PL + RS_TILE) * 8))) return rc;
+    if ((rc = ensure(c, c->b_idx[0], ((size_t)PL + RS_TILE) * 4))) return rc;
+    if ((rc = ensure(c, c->b_idx[1], ((size_t)PL + RS_TILE) * 4))) return rc;
+    Buf *pb[] = {&c->b_g, &c->b_lstart, &c->b_rend, &c->b_pos, &c->b_aend, &c->b_meta, &c->b_updown, &c->b_jid};
+    for (Buf *b : pb)
+        if ((rc = ensure(c, *b, (size_t)PL * 4 + 16))) return rc;
+    if ((rc = ensure(c, c->b_res, (size_t)PL * 8 + 16))) return rc;
+    if ((rc = ensure(c, c->b_seg, ((size_t)PL + 1) * 4))) return rc;
+    if ((rc = ensure(c, c->b_runfirst, ((size_t)PL + 1) * 4))) return rc;
+    if ((rc = ensure(c, c->b_runstart, ((size_t)PL + 1) * 4))) return rc;
+    if ((rc = ensure(c, c->b_ent, (size_t)PL * 8 + 16))) return rc;
+    const u32 pair_blocks = std::max<u32>(1, (PL + 255) / 256);
+    const u32 gen_cap = ((pair_blocks + GEN_SHARDS - 1) / GEN_SHARDS) * 256; // entries per sub-list
+    if ((rc = ensure(c, c->b_genlist, (size_t)gen_cap * GEN_SHARDS * 4))) return rc;
+    if ((rc = ensure(c, c->b_gencount, GEN_SHARDS * 4))) return rc;
+    // ---- junction-sized buffers
+    const u32 slots_lim = JL + (PL + 63) / 64 + 1;
+    if ((rc = ensure(c, c->b_frag, (size_t)slots_lim * F_WORDS * 4))) return rc;
+    if ((rc = ensure(c, c->b_fragj, (size_t)slots_lim * 4))) return rc;
+    if ((rc = ensure(c, c->b_fragl, (size_t)slots_lim * 4))) return rc;
+    if ((rc = ensure(c, c->b_fragr, (size_t)slots_lim * 4))) return rc;
+    if ((rc = ensure(c, c->b_acc, (size_t)JL * F_WORDS * 4 + 16))) return rc;
+    if ((rc = ensure(c, c->b_ancl, (size_t)JL * 4 + 16))) return rc;
+    if ((rc = ensure(c, c->b_ancr, (size_t)JL * 4 + 16))) return rc;
+    if ((rc = ensure(c, c->b_rows, (size_t)JL * sizeof(pjb_junction_row) + 16))) return rc;
+    // rows leave through page-locked host memory (grow-only; the kernel chain writes at rows_pinned + rows_n)
+    const size_t old = c->rows_n;
+    if (old + JL > c->rows_cap) {
+        const size_t ncap = std::max<size_t>((old + JL) * 3 / 2, 1024);
+        pjb_junction_row *np = nullptr;
+        hipError_t e = hipHostMalloc((void **)&np, ncap * sizeof(pjb_junction_row), hipHostMallocMapped | hipHostMallocPortable);
+        if (e != hipSuccess) return fail(c, PJB_ERR_NOMEM, "hipHostMalloc(rows): %s", hipGetErrorString(e));
+        if (old) memcpy(np, c->rows_pinned, old * sizeof(pjb_junction_row));
+        if (c->rows_pinned) (void)hipHostFree(c->rows_pinned);
+        c->rows_pinned = np;
+        c->rows_cap = ncap;
+        void *dp = nullptr;
+        if (hipHostGetDevicePointer(&dp, np, 0) != hipSuccess || !dp) return fail(c, PJB_ERR_HIP, "hipHostGetDevicePointer(rows) failed");
+        c->rows_pinned_dev = (pjb_junction_row *)dp;
+    }
+    if (!c->res_pinned) HIP_TRY(c, hipHostMalloc((void **)&c->res_pinned, 4096, hipHostMallocDefault));
+
+    HIP_TRY(c, hipMemcpyAsync(c->b_batches.p, batches.data(), batches.size() * sizeof(DevBatch), hipMemcpyHostToDevice, st));
+    HIP_TRY(c, hipMemsetAsync(c->b_err.p, 0xff, 8, st));
+    HIP_TRY(c, hipMemsetAsync(c->b_gencount.p, 0, GEN_SHARDS * 4, st));
+    u64 *d_err = (u64 *)c->b_err.p;
+    ContigStats *d_cs = (ContigStats *)c->b_cstats.p;
+    const u32 *d_P = &d_cs->P, *d_J = &d_cs->J, *d_R = &d_cs->R, *d_slots = &d_cs->n_slots;
+    HIP_TRY(c, hipEventRecord(c->ev[0], st));
+    // ---- K1a: count
+    for (auto &b : batches) {
+        const u32 nt = (u32)((b.n + K1_TILE - 1) / K1_TILE);
+        LAUNCH(c, "k1_count", k1_count, dim3(nt), dim3(256), b, (u32 *)c->b_tile_cnt.p, (TileStats *)c->b_tile_stats.p,
+               (u32 *)c->b_splidx.p, (u32 *)c->b_splpoff.p, d_err);
+    }
+    LAUNCH(c, "k1_scan_tiles", k1_scan_tiles, dim3(1), dim3(1024), (u32 *)c->b_tile_cnt.p, (const TileStats *)c->b_tile_stats.p, n_tiles, d_cs,
+           PL, kf, ref_len);
+    // ---- K1b: emit
+    Pairs pr;
+    pr.key = (u64 *)c->b_key[0].p;
+    pr.g = (u32 *)c->b_g.p;
+    pr.lstart = (int32_t *)c->b_lstart.p;
+    pr.rend = (int32_t *)c->b_rend.p;
+    pr.pos = (int32_t *)c->b_pos.p;
+    pr.aend = (int32_t *)c->b_aend.p;
+    pr.meta = (u32 *)c->b_meta.p;
+    pr.updown = (u32 *)c->b_updown.p;
+    pr_out = pr;
+    for (auto &b : batches) {
+        const u32 nt = (u32)((b.n + K1_TILE - 1) / K1_TILE);
+        LAUNCH(c, "k1_emit", k1_emit, dim3(nt), dim3(256), b, (const u32 *)c->b_tile_cnt.p,
+               (const TileStats *)c->b_tile_stats.p, (const u32 *)c->b_splidx.p, (const u32 *)c->b_splpoff.p, pr, kf, ref_len,
+               tid, (int)c->cfg.orientation, d_err, (const ContigStats *)d_cs);
+    }
+    // ---- K4a: match statistics of the common [S] M N M [S] shape, in BAM order, while the keys are still unsorted:
+    // on the side stream, beside the sort of the main stream (joined before pass 1 overwrites the keys)
+    const bool fast_codes = G.codes != nullptr && !G.has_x;
+    if (fast_codes) {
+        HIP_TRY(c, hipEventRecord(c->ev_fork, st));
+        HIP_TRY(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
+        hipStream_t main_stream = c->stream;
+        c->stream = c->stream2; // LAUNCH (and its event bracket) follow c->stream
+        forked = true;
+        LAUNCH(c, "k4a_simple", k4a_simple, dim3(pair_blocks), dim3(256), pr, kf, (const DevBatch *)c->b_batches.p,
+               (int)batches.size(), (const u32 *)G.codes, (int32_t)G.len, d_P, (u64 *)c->b_res.p);
+        c->stream = main_stream;
+        HIP_TRY(c, hipEventRecord(c->ev_join, c->stream2));
+    }
+    HIP_TRY(c, hipEventRecord(c->ev[1], st));
+
+    // ---- K2: radix sort (key, pair index); digits: as few passes as the widest digit allows, bits spread evenly
+    const u32 rs_tiles = std::max<u32>(1, (PL + RS_TILE - 1) / RS_TILE);
+    int n_pass = (kf.total_bits + c->radix_max_bits - 1) / c->radix_max_bits;
+    if (n_pass < 1) n_pass = 1;
+    std::vector<int> pass_bits((size_t)n_pass, kf.total_bits / n_pass);
+    for (int p = 0; p < kf.total_bits % n_pass; p++) pass_bits[(size_t)p]++;
+    const int dbits = pass_bits[0];
+    if ((rc = ensure(c, c->b_hist, (size_t)rs_tiles * (1u << dbits) * 4))) return rc;
+    if ((rc = ensure(c, c->b_hist_scan, (size_t)rs_tiles * (1u << dbits) * 4))) return rc;
+    if ((rc = ensure(c, c->b_bintotal, (size_t)4 << dbits))) return rc;
+    int cur = 0, shift = 0;
+    for (int p = 0; p < n_pass; p++) {
+        const int bits = pass_bits[(size_t)p];
+        if (bits <= 0) break;
+        if (p == 1 && fast_codes) HIP_TRY(c, hipStreamWaitEvent(st, c->ev_join, 0));
+        const u64 *kin = (const u64 *)c->b_key[cur].p;
+        u64 *kout = (u64 *)c->b_key[cur ^ 1].p;
+        const u32 *vin = p == 0 ? nullptr : (const u32 *)c->b_idx[cur].p;
+        u32 *vout = (u32 *)c->b_idx[cur ^ 1].p;
+        LAUNCH(c, "rs_hist", rs_hist, dim3(rs_tiles), dim3(256), kin, d_P, shift, bits, (u32 *)c->b_hist.p, rs_tiles);
+        LAUNCH(c, "rs_rowscan", rs_rowscan, dim3(1u << bits), dim3(256), (const u32 *)c->b_hist.p, rs_tiles,
+               (u32 *)c->b_hist_scan.p, (u32 *)c->b_bintotal.p);
+#define RS_SCATTER(B)                                                                                                     \
+    LAUNCH_LDS(c, "rs_scatter", rs_scatter<B>, dim3(rs_tiles), dim3(256), rs_scatter_lds_bytes(bits), kin, vin, kout, vout, d_P, \
+               shift, bits, (const u32 *)c->b_hist_scan.p, (const u32 *)c->b_bintotal.p, rs_tiles)
+        switch (bits) { // the usual digit widths get an unrolled match loop
+        case 9: RS_SCATTER(9); break;
+        case 10: RS_SCATTER(10); break;
+        case 11: RS_SCATTER(11); break;
+        default: RS_SCATTER(0); break;
+        }
+#undef RS_SCATTER
+        cur ^= 1;
+        shift += bits;
+    }
+    if (n_pass < 2 && fast_codes) HIP_TRY(c, hipStreamWaitEvent(st, c->ev_join, 0));
+    c->timing.sort_passes = n_pass;
+    const u64 *skey = (const u64 *)c->b_key[cur].p;
+    const u32 *sidx = (const u32 *)c->b_idx[cur].p;
+    sidx_out = sidx;
+    HIP_TRY(c, hipEventRecord(c->ev[2], st));
+
+    // ---- K2s: junction ids, position runs
+    {
+        HeadFn hf{skey, sidx, pr.pos};
+        HeadSink hs{(u32 *)c->b_jid.p, (u32 *)c->b_seg.p, (u32 *)c->b_runfirst.p, (u32 *)c->b_runstart.p};
+        if ((rc = run_scan(c, "k2_heads", hf, hs, (u64)PL, (u64 *)c->b_total.p, d_P))) return rc;
+        LAUNCH(c, "k2_close", k2_close, dim3(1), dim3(1), (u64 *)c->b_total.p, (u32 *)c->b_seg.p, (u32 *)c->b_runfirst.p,
+               (u32 *)c->b_runstart.p, d_cs, JL);
+    }
+    HIP_TRY(c, hipEventRecord(c->ev[3], st));
+
+    // ---- K3: anchors
+    const u32 slot_blocks = (slots_lim + 255) / 256;
+    const u32 init_n = std::max<u32>(slots_lim, JL * F_WORDS);
+    LAUNCH(c, "k5_init_acc", k5_init_acc, dim3((init_n + 255) / 256), dim3(256), (u32 *)c->b_acc.p, d_J, (int32_t *)c->b_ancl.p,
+           (int32_t *)c->b_ancr.p, (int32_t *)c->b_fragj.p, d_slots);
+    LAUNCH(c, "k3_anchors_frag", k3_anchors_frag, dim3(pair_blocks), dim3(256), sidx, (const u32 *)c->b_jid.p,
+           (const int32_t *)pr.lstart, (const int32_t *)pr.rend, (const u32 *)pr.meta, fast_codes ? 0 : 1, d_P,
+           (int32_t *)c->b_fragl.p, (int32_t *)c->b_fragr.p, (int32_t *)c->b_fragj.p, (u32 *)c->b_genlist.p,
+           (u32 *)c->b_gencount.p);
+    LAUNCH(c, "k3_anchors_junc", k3_anchors_junc, dim3(slot_blocks), dim3(256), (const int32_t *)c->b_fragl.p,
+           (const int32_t *)c->b_fragr.p, (const int32_t *)c->b_fragj.p, d_slots, (int32_t *)c->b_ancl.p,
+           (int32_t *)c->b_ancr.p);
+    HIP_TRY(c, hipEventRecord(c->ev[4], st));
+
+    // ---- K4b: the pairs that need the generic walks (list length lives on the device; the grid covers the
+    // worst case and surplus blocks exit at once), then K4: gather + segmented reduce -> fragments
+    LAUNCH(c, "k4b_generic", k4b_generic, dim3((gen_cap * GEN_SHARDS + 255) / 256), dim3(256), (const u32 *)c->b_genlist.p,
+           (const u32 *)c->b_gencount.p, pair_blocks, skey, sidx, (const u32 *)c->b_jid.p, pr, kf, (const DevBatch *)c->b_batches.p,
+           (int)batches.size(), (const int32_t *)c->b_ancl.p, (const int32_t *)c->b_ancr.p, (const uint8_t *)G.d,
+           (int32_t)G.len, G.has_x ? 1 : 0, (const u32 *)(G.has_x ? nullptr : G.codes), (u64 *)c->b_res.p, d_err);
+    LAUNCH(c, "k4_pairs", k4_pairs, dim3(pair_blocks), dim3(256), skey, sidx, (const u32 *)c->b_jid.p, pr, kf,
+           (const u64 *)c->b_res.p, d_P, (u32 *)c->b_frag.p, (int32_t *)c->b_fragj.p);
+    HIP_TRY(c, hipEventRecord(c->ev[5], st));
+
+    // ---- K5: fragments -> junctions -> rows
+    LAUNCH(c, "k5_frag_reduce", k5_frag_reduce, dim3((slots_lim + 4 * FRAG_SLOTS_PER_WAVE - 1) / (4 * FRAG_SLOTS_PER_WAVE)), dim3(256),
+           (const u32 *)c->b_frag.p, (const int32_t *)c->b_fragj.p, d_slots, (u32 *)c->b_acc.p);
+    LAUNCH(c, "k5_entropy_terms", k5_entropy_terms, dim3(pair_blocks), dim3(256), (const u32 *)c->b_jid.p,
+           (const u32 *)c->b_seg.p, (const u32 *)c->b_runfirst.p, (const u32 *)c->b_runstart.p, d_R, (double *)c->b_ent.p);
+    LAUNCH(c, "k5_finalize", k5_finalize, dim3(std::max<u32>(1, (JL + 255) / 256)), dim3(256), skey, (const u32 *)c->b_seg.p,
+           (const u32 *)c->b_runfirst.p, (const u32 *)c->b_runstart.p, (const u32 *)c->b_acc.p,
+           (const int32_t *)c->b_ancl.p, (const int32_t *)c->b_ancr.p, kf, (const uint8_t *)G.d, (int32_t)G.len, tid, d_J,
+           (const double *)c->b_ent.p, (pjb_junction_row *)c->b_rows.p, d_err);
+    HIP_TRY(c, hipEventRecord(c->ev[6], st));
+
+    // ---- rows to the host (and into the caller's exchange slot), control block last
+    u64 *mirror_rows = nullptr;
+    u32 mirror_room = 0; // rows the caller's slot can still take (the kernel leaves the slot alone if the contig has more)
+    if (c->mirror) {
+        const size_t at = PJB_MIRROR_HEADER_BYTES + c->mirror_rows * sizeof(pjb_junction_row);
+        if (at <= c->mirror_cap) {
+            mirror_rows = (u64 *)(c->mirror + at);
+            mirror_room = (u32)std::min<size_t>((c->mirror_cap - at) / sizeof(pjb_junction_row), 0xffffffffu);
+        }
+    }
+    {
+        const u64 units = std::max<u64>(1, (u64)JL * ROW_U64);
+        LAUNCH(c, "k6_rows_out", k6_rows_out, dim3((unsigned)((units + 255) / 256)), dim3(256), (const u64 *)c->b_rows.p, d_J,
+               (u64 *)(c->rows_pinned_dev + old), mirror_rows, mirror_room);
+    }
+    uint8_t *hres = (uint8_t *)c->res_pinned;
+    HIP_TRY(c, hipMemcpyAsync(hres, d_cs, sizeof(ContigStats), hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipMemcpyAsync(hres + 256, d_err, 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipMemcpyAsync(hres + 512, c->b_gencount.p, GEN_SHARDS * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipEventRecord(c->ev[7], st));
+    HIP_TRY(c, hipStreamSynchronize(st)); // THE synchronisation of this contig
+    memcpy(&cs_out, hres, sizeof cs_out);
+    memcpy(&err_out, hres + 256, 8);
+    c->timing.generic_pairs = 0;
+    for (u32 k = 0; k < GEN_SHARDS; k++) c->timing.generic_pairs += ((const u32 *)(hres + 512))[k];
+    return PJB_OK;
+}
+
 int pjb_finish_contig(pjb_ctx *c, int32_t tid, pjb_region_result *res) {
     if (!c) return PJB_ERR_ARG;
     if (tid < 0 || (size_t)tid >= c->ref_len.size()) return fail(c, PJB_ERR_ARG, "finish: bad tid %d", tid);
@@ -780,63 +1018,83 @@ int pjb_finish_contig(pjb_ctx *c, int32_t tid, pjb_region_result *res) {
     c->ev_name.clear();
     c->ev_used = 0;
     if (res) *res = R;
-    if (batches.empty()) {
-        HIP_TRY(c, hipSetDevice(c->cfg.device));
-        return mirror_header_only(c, R);
-    }
     HIP_TRY(c, hipSetDevice(c->cfg.device));
-    hipStream_t st = c->stream;
+    if (batches.empty()) return mirror_header_only(c, R);
     const int32_t ref_len = c->ref_len[(size_t)tid];
     int rc;
-
-    // ---- K1a: count
     u32 n_tiles = 0;
-    int32_t prev_pos = INT32_MIN;
     int64_t n_reads = 0;
-    for (auto &b : batches) {
-        b.tile_base = n_tiles;
-        n_tiles += (u32)((b.n + K1_TILE - 1) / K1_TILE);
-        b.prev_pos = prev_pos;
-        n_reads += b.n;
-        // last position of this batch is needed by the next one: read it back lazily on device instead
-    }
-    // prev_pos across batches: fetch each batch's last pos (tiny D2H, only when there are several batches)
-    if (batches.size() > 1) {
+    {
+        int32_t prev_pos = INT32_MIN;
+        const int32_t *prev_ptr = nullptr;
         OpenContig &oc = open_it->second;
-        for (size_t k = 0; k + 1 < batches.size(); k++) {
-            int32_t last = oc.last_pos[k];
-            if (!oc.last_known[k]) {
-                HIP_TRY(c, hipMemcpyAsync(&last, batches[k].pos + (batches[k].n - 1), 4, hipMemcpyDeviceToHost, st));
-                HIP_TRY(c, hipStreamSynchronize(st));
-            }
-            batches[k + 1].prev_pos = last;
+        for (size_t k = 0; k < batches.size(); k++) {
+            DevBatch &b = batches[k];
+            b.tile_base = n_tiles;
+            n_tiles += (u32)((b.n + K1_TILE - 1) / K1_TILE);
+            b.prev_pos = prev_pos;
+            b.prev_pos_ptr = prev_ptr; // sortedness across batches: the last position of the previous batch, wherever it is known
+            n_reads += b.n;
+            if (oc.last_known[k]) {
+                prev_pos = oc.last_pos[k];
+                prev_ptr = nullptr;
+            } else
+                prev_ptr = b.pos + (b.n - 1);
         }
     }
-    if ((rc = ensure(c, c->b_batches, batches.size() * sizeof(DevBatch)))) return rc;
-    if ((rc = ensure(c, c->b_tile_cnt, (size_t)n_tiles * 4))) return rc;
-    if ((rc = ensure(c, c->b_tile_stats, (size_t)n_tiles * sizeof(TileStats)))) return rc;
-    if ((rc = ensure(c, c->b_cstats, sizeof(ContigStats)))) return rc;
-    if ((rc = ensure(c, c->b_splidx, (size_t)n_tiles * K1_TILE * 4))) return rc;
-    if ((rc = ensure(c, c->b_splpoff, (size_t)n_tiles * K1_TILE * 4))) return rc;
-    if ((rc = ensure(c, c->b_err, 8))) return rc;
-    if ((rc = ensure(c, c->b_total, 8))) return rc;
-    HIP_TRY(c, hipMemcpyAsync(c->b_batches.p, batches.data(), batches.size() * sizeof(DevBatch), hipMemcpyHostToDevice, st));
-    HIP_TRY(c, hipMemsetAsync(c->b_err.p, 0xff, 8, st));
-    u64 *d_err = (u64 *)c->b_err.p;
-    ContigStats *d_cs = (ContigStats *)c->b_cstats.p;
-    HIP_TRY(c, hipEventRecord(c->ev[0], st));
-    for (auto &b : batches) {
-        const u32 nt = (u32)((b.n + K1_TILE - 1) / K1_TILE);
-        LAUNCH(c, "k1_count", k1_count, dim3(nt), dim3(256), b, (u32 *)c->b_tile_cnt.p, (TileStats *)c->b_tile_stats.p,
-               (u32 *)c->b_splidx.p, (u32 *)c->b_splpoff.p, d_err);
+    const Contig &G = c->contigs[(size_t)tid];
+    // ---- limits.  Pairs: what the arena already holds, at least a share of the reads (a contig with more N operations
+    // than that is repeated once with the exact count).  Junctions: an eighth of the pair limit.  Key: contig coordinates
+    // and the longest intron seen by this context so far.
+    ContigLimits lim;
+    {
+        const u64 guess = std::min<u64>(0xffffff00ull, (u64)n_reads * 5 / 8 + 4096);
+        lim.pair_limit = (u32)std::max<u64>(guess, 4096);
+        lim.junc_limit = std::max<u32>(std::max<u32>(lim.pair_limit / 32, 4096), 2 * c->junc_seen);
+        // without the contig's genome only the counting stage may run: any pair then shows up as an overflow
+        if (!G.present || G.len != ref_len) lim.pair_limit = 0;
+        lim.kf.raw = 0;
+        lim.kf.lbits = std::max(1, c->lbits_seen);
+        lim.kf.total_bits = lim.kf.lbits + std::max(1, bits_of((uint64_t)std::max(ref_len, 1)));
     }
-    LAUNCH(c, "k1_scan_tiles", k1_scan_tiles, dim3(1), dim3(1024), (u32 *)c->b_tile_cnt.p, (const TileStats *)c->b_tile_stats.p, n_tiles, d_cs);
     ContigStats cs;
     u64 herr = ~0ull;
-    HIP_TRY(c, hipMemcpyAsync(&cs, d_cs, sizeof cs, hipMemcpyDeviceToHost, st));
-    HIP_TRY(c, hipMemcpyAsync(&herr, d_err, 8, hipMemcpyDeviceToHost, st));
-    HIP_TRY(c, hipStreamSynchronize(st));
-    if ((rc = check_device_error(c, herr))) return rc;
+    const u32 *sidx = nullptr;
+    Pairs pr;
+    memset(&pr, 0, sizeof pr);
+    for (int attempt = 0;; attempt++) {
+        if ((rc = run_contig_once(c, tid, batches, n_reads, n_tiles, lim, cs, herr, sidx, pr, closer.forked))) return rc;
+        if ((rc = check_device_error(c, herr))) return rc;
+        if (cs.n_pairs > 0 && !G.present) return fail(c, PJB_ERR_STATE, "finish: genome of target %d was not uploaded", tid);
+        if (cs.n_pairs > 0 && G.len != ref_len)
+            return fail(c, PJB_ERR_ARG, "finish: genome of target %d has %lld bases, header says %d", tid, (long long)G.len, ref_len);
+        if (!cs.overflow) break;
+        if (attempt >= 3) return fail(c, PJB_ERR_STATE, "finish: limits of target %d did not settle (overflow bits %u)", tid, cs.overflow);
+        // a limit was too small: the control block says by how much; everything is queued again
+        if (cs.overflow & OVF_PAIRS) {
+            if (cs.n_pairs >= 0xfffffff0ull) return fail(c, PJB_ERR_ARG, "finish: more than 2^32 spliced pairs on one target are not supported");
+            lim.pair_limit = (u32)cs.n_pairs + 64;
+            lim.junc_limit = std::max<u32>(lim.junc_limit, lim.pair_limit / 8);
+        }
+        if (cs.overflow & OVF_KEYFMT) {
+            if (cs.min_pos < 0 || cs.max_end > ref_len || cs.max_end < 0) {
+                lim.kf.raw = 1;
+                lim.kf.lbits = 32;
+                lim.kf.total_bits = 64;
+            } else {
+                lim.kf.lbits = std::max(1, bits_of((uint64_t)cs.max_nlen));
+                lim.kf.total_bits = lim.kf.lbits + std::max(1, bits_of((uint64_t)std::max(ref_len, 1)));
+            }
+        }
+        if (cs.overflow & OVF_JUNC) lim.junc_limit = cs.n_junc + 64;
+        if (closer.forked) {
+            (void)hipStreamSynchronize(c->stream2);
+            closer.forked = false;
+        }
+        c->ev_name.clear();
+        c->ev_used = 0;
+    }
+    if (!lim.kf.raw) c->lbits_seen = std::max(c->lbits_seen, std::max(1, bits_of((uint64_t)cs.max_nlen)));
     R.spliced = cs.spliced;
     R.unspliced = cs.unspliced;
     R.sum_len = cs.sum_len;
@@ -844,221 +1102,20 @@ int pjb_finish_contig(pjb_ctx *c, int32_t tid, pjb_region_result *res) {
     R.max_len = cs.max_len;
     R.n_reads = n_reads;
     R.n_pairs = (int64_t)cs.n_pairs;
-    const u64 P64 = cs.n_pairs;
-    if (P64 == 0) {
-        if (res) *res = R;
-        if (c->extra && (rc = extra_contig(c, tid, batches, n_reads, cs.spliced, 0, 0, nullptr, nullptr, c->rows_n))) return rc;
-        return mirror_header_only(c, R);
-    }
-    if (P64 >= 0xfffffff0ull) return fail(c, PJB_ERR_ARG, "finish: more than 2^32 spliced pairs on one target are not supported");
-    const u32 P = (u32)P64;
-    const Contig &G = c->contigs[(size_t)tid];
-    if (!G.present) return fail(c, PJB_ERR_STATE, "finish: genome of target %d was not uploaded", tid);
-    if (G.len != ref_len)
-        return fail(c, PJB_ERR_ARG, "finish: genome of target %d has %lld bases, header says %d", tid, (long long)G.len, ref_len);
-
-    // ---- key format
-    KeyFmt kf;
-    if (cs.min_pos < 0 || cs.max_end > ref_len || cs.max_end < 0) {
-        kf.raw = 1;
-        kf.lbits = 32;
-        kf.total_bits = 64;
-    } else {
-        kf.raw = 0;
-        kf.lbits = std::max(1, bits_of((uint64_t)cs.max_nlen));
-        kf.total_bits = kf.lbits + std::max(1, bits_of((uint64_t)cs.max_end));
-    }
-
-    // ---- K1b: emit
-    Pairs pr;
-    // one sort tile of slack: rs_pass loads whole tiles unguarded
-    if ((rc = ensure(c, c->b_key[0], ((size_t)P + RS_TILE) * 8))) return rc;
-    if ((rc = ensure(c, c->b_key[1], ((size_t)P + RS_TILE) * 8))) return rc;
-    if ((rc = ensure(c, c->b_idx[0], ((size_t)P + RS_TILE) * 4))) return rc;
-    if ((rc = ensure(c, c->b_idx[1], ((size_t)P + RS_TILE) * 4))) return rc;
-    Buf *pb[] = {&c->b_g, &c->b_lstart, &c->b_rend, &c->b_pos, &c->b_aend, &c->b_meta, &c->b_updown};
-    for (Buf *b : pb)
-        if ((rc = ensure(c, *b, (size_t)P * 4))) return rc;
-    pr.key = (u64 *)c->b_key[0].p;
-    pr.g = (u32 *)c->b_g.p;
-    pr.lstart = (int32_t *)c->b_lstart.p;
-    pr.rend = (int32_t *)c->b_rend.p;
-    pr.pos = (int32_t *)c->b_pos.p;
-    pr.aend = (int32_t *)c->b_aend.p;
-    pr.meta = (u32 *)c->b_meta.p;
-    pr.updown = (u32 *)c->b_updown.p;
-    for (auto &b : batches) {
-        const u32 nt = (u32)((b.n + K1_TILE - 1) / K1_TILE);
-        LAUNCH(c, "k1_emit", k1_emit, dim3(nt), dim3(256), b, (const u32 *)c->b_tile_cnt.p,
-               (const TileStats *)c->b_tile_stats.p, (const u32 *)c->b_splidx.p, (const u32 *)c->b_splpoff.p, pr, kf, ref_len,
-               tid, (int)c->cfg.orientation, d_err);
-    }
-    // ---- K4a: match statistics of the common [S] M N M [S] shape, in BAM order, while the keys are still unsorted
-    if ((rc = ensure(c, c->b_res, (size_t)P * 8))) return rc;
-    const u32 gen_cap = (((P + 255) / 256 + GEN_SHARDS - 1) / GEN_SHARDS) * 256; // entries per sub-list
-    if ((rc = ensure(c, c->b_genlist, (size_t)gen_cap * GEN_SHARDS * 4))) return rc;
-    if ((rc = ensure(c, c->b_gencount, GEN_SHARDS * 4))) return rc;
-    HIP_TRY(c, hipMemsetAsync(c->b_gencount.p, 0, GEN_SHARDS * 4, st));
-    const bool fast_codes = G.codes != nullptr && !G.has_x;
-    // it runs on the side stream, beside the sort of the main stream (joined before K4b)
-    if (fast_codes) {
-        HIP_TRY(c, hipEventRecord(c->ev_fork, st));
-        HIP_TRY(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
-        const bool timed = ktime_wanted(c, "k4a_simple");
-        hipStream_t main_stream = c->stream;
-        c->stream = c->stream2; // LAUNCH (and its event bracket) follow c->stream
-        LAUNCH(c, "k4a_simple", k4a_simple, dim3((P + 255) / 256), dim3(256), pr, kf, (const DevBatch *)c->b_batches.p,
-               (int)batches.size(), (const u32 *)G.codes, (int32_t)G.len, P, (u64 *)c->b_res.p);
-        c->stream = main_stream;
-        (void)timed;
-        closer.forked = true;
-        HIP_TRY(c, hipEventRecord(c->ev_join, c->stream2));
-    }
-    HIP_TRY(c, hipEventRecord(c->ev[1], st));
-
-    // ---- K2: radix sort (key, pair index)
-    const u32 rs_tiles = (P + RS_TILE - 1) / RS_TILE;
-    // digits: as few passes as the widest digit (radix_max_bits) allows, bits spread evenly over them
-    int n_pass = (kf.total_bits + c->radix_max_bits - 1) / c->radix_max_bits;
-    if (n_pass < 1) n_pass = 1;
-    std::vector<int> pass_bits((size_t)n_pass, kf.total_bits / n_pass);
-    for (int p = 0; p < kf.total_bits % n_pass; p++) pass_bits[(size_t)p]++;
-    const int dbits = pass_bits[0];
-    if ((rc = ensure(c, c->b_hist, (size_t)rs_tiles * (1u << dbits) * 4))) return rc;
-    if ((rc = ensure(c, c->b_hist_scan, (size_t)rs_tiles * (1u << dbits) * 4))) return rc;
-    if ((rc = ensure(c, c->b_bintotal, (size_t)4 << dbits))) return rc;
-    int cur = 0, shift = 0;
-    for (int p = 0; p < n_pass; p++) {
-        const int bits = pass_bits[(size_t)p];
-        if (bits <= 0) break;
-        // pass 1 starts overwriting the unsorted keys that k4a_simple (side stream) reads
-        if (p == 1 && fast_codes) HIP_TRY(c, hipStreamWaitEvent(st, c->ev_join, 0));
-        const u64 *kin = (const u64 *)c->b_key[cur].p;
-        u64 *kout = (u64 *)c->b_key[cur ^ 1].p;
-        const u32 *vin = p == 0 ? nullptr : (const u32 *)c->b_idx[cur].p;
-        u32 *vout = (u32 *)c->b_idx[cur ^ 1].p;
-        LAUNCH(c, "rs_hist", rs_hist, dim3(rs_tiles), dim3(256), kin, P, shift, bits, (u32 *)c->b_hist.p, rs_tiles);
-        LAUNCH(c, "rs_rowscan", rs_rowscan, dim3(1u << bits), dim3(256), (const u32 *)c->b_hist.p, rs_tiles,
-               (u32 *)c->b_hist_scan.p, (u32 *)c->b_bintotal.p);
-#define RS_SCATTER(B)                                                                                                     \
-    LAUNCH_LDS(c, "rs_scatter", rs_scatter<B>, dim3(rs_tiles), dim3(256), rs_scatter_lds_bytes(bits), kin, vin, kout, vout, P, \
-               shift, bits, (const u32 *)c->b_hist_scan.p, (const u32 *)c->b_bintotal.p, rs_tiles)
-        switch (bits) { // the usual digit widths get an unrolled match loop
-        case 9: RS_SCATTER(9); break;
-        case 10: RS_SCATTER(10); break;
-        case 11: RS_SCATTER(11); break;
-        default: RS_SCATTER(0); break;
-        }
-#undef RS_SCATTER
-        cur ^= 1;
-        shift += bits;
-    }
-    c->timing.sort_passes = n_pass;
-    const u64 *skey = (const u64 *)c->b_key[cur].p;
-    const u32 *sidx = (const u32 *)c->b_idx[cur].p;
-    HIP_TRY(c, hipEventRecord(c->ev[2], st));
-
-    // ---- K2s: junction ids, position runs
-    if ((rc = ensure(c, c->b_jid, (size_t)P * 4))) return rc;
-    if ((rc = ensure(c, c->b_seg, ((size_t)P + 1) * 4))) return rc;
-    if ((rc = ensure(c, c->b_runfirst, ((size_t)P + 1) * 4))) return rc;
-    if ((rc = ensure(c, c->b_runstart, ((size_t)P + 1) * 4))) return rc;
-    {
-        HeadFn hf{skey, sidx, pr.pos};
-        HeadSink hs{(u32 *)c->b_jid.p, (u32 *)c->b_seg.p, (u32 *)c->b_runfirst.p, (u32 *)c->b_runstart.p};
-        if ((rc = run_scan(c, "k2_heads", hf, hs, (u64)P, (u64 *)c->b_total.p))) return rc;
-        LAUNCH(c, "k2_close", k2_close, dim3(1), dim3(1), (u64 *)c->b_total.p, (u32 *)c->b_seg.p, (u32 *)c->b_runfirst.p,
-               (u32 *)c->b_runstart.p, P, d_cs);
-    }
-    HIP_TRY(c, hipMemcpyAsync(&cs, d_cs, sizeof cs, hipMemcpyDeviceToHost, st));
-    HIP_TRY(c, hipMemcpyAsync(&herr, d_err, 8, hipMemcpyDeviceToHost, st));
-    HIP_TRY(c, hipEventRecord(c->ev[3], st));
-    HIP_TRY(c, hipStreamSynchronize(st));
-    if ((rc = check_device_error(c, herr))) return rc;
-    const u32 J = cs.n_junc;
+    const u32 P = cs.P, J = cs.J;
     R.n_junctions = J;
-
-    // ---- K3: anchors
-    const u32 n_slices = (P + 63) / 64;
-    const u32 n_slots = J + n_slices;
-    if ((rc = ensure(c, c->b_frag, (size_t)n_slots * F_WORDS * 4))) return rc;
-    if ((rc = ensure(c, c->b_fragj, (size_t)n_slots * 4))) return rc;
-    if ((rc = ensure(c, c->b_fragl, (size_t)n_slots * 4))) return rc;
-    if ((rc = ensure(c, c->b_fragr, (size_t)n_slots * 4))) return rc;
-    if ((rc = ensure(c, c->b_acc, (size_t)J * F_WORDS * 4))) return rc;
-    if ((rc = ensure(c, c->b_ancl, (size_t)J * 4))) return rc;
-    if ((rc = ensure(c, c->b_ancr, (size_t)J * 4))) return rc;
-    if ((rc = ensure(c, c->b_rows, (size_t)J * sizeof(pjb_junction_row)))) return rc;
-    HIP_TRY(c, hipMemsetAsync(c->b_fragj.p, 0xff, (size_t)n_slots * 4, st));
-    LAUNCH(c, "k5_init_acc", k5_init_acc, dim3((J * F_WORDS + 255) / 256), dim3(256), (u32 *)c->b_acc.p, J,
-           (int32_t *)c->b_ancl.p, (int32_t *)c->b_ancr.p);
-    const u32 pair_blocks = (P + 255) / 256, slot_blocks = (n_slots + 255) / 256;
-    LAUNCH(c, "k3_anchors_frag", k3_anchors_frag, dim3(pair_blocks), dim3(256), sidx, (const u32 *)c->b_jid.p,
-           (const int32_t *)pr.lstart, (const int32_t *)pr.rend, (const u32 *)pr.meta, fast_codes ? 0 : 1, P,
-           (int32_t *)c->b_fragl.p, (int32_t *)c->b_fragr.p, (int32_t *)c->b_fragj.p, (u32 *)c->b_genlist.p,
-           (u32 *)c->b_gencount.p);
-    LAUNCH(c, "k3_anchors_junc", k3_anchors_junc, dim3(slot_blocks), dim3(256), (const int32_t *)c->b_fragl.p,
-           (const int32_t *)c->b_fragr.p, (const int32_t *)c->b_fragj.p, n_slots, (int32_t *)c->b_ancl.p,
-           (int32_t *)c->b_ancr.p);
-    HIP_TRY(c, hipEventRecord(c->ev[4], st));
-
-    if (fast_codes) HIP_TRY(c, hipStreamWaitEvent(st, c->ev_join, 0));
-    // ---- K4b: the pairs that need the generic walks (list length lives on the device; the grid covers the
-    // worst case and surplus blocks exit at once), then K4: gather + segmented reduce -> fragments
-    LAUNCH(c, "k4b_generic", k4b_generic, dim3((gen_cap * GEN_SHARDS + 255) / 256), dim3(256), (const u32 *)c->b_genlist.p,
-           (const u32 *)c->b_gencount.p, pair_blocks, skey, sidx, (const u32 *)c->b_jid.p, pr, kf, (const DevBatch *)c->b_batches.p,
-           (int)batches.size(), (const int32_t *)c->b_ancl.p, (const int32_t *)c->b_ancr.p, (const uint8_t *)G.d,
-           (int32_t)G.len, G.has_x ? 1 : 0, (const u32 *)(G.has_x ? nullptr : G.codes), (u64 *)c->b_res.p, d_err);
-    LAUNCH(c, "k4_pairs", k4_pairs, dim3(pair_blocks), dim3(256), skey, sidx, (const u32 *)c->b_jid.p, pr, kf,
-           (const u64 *)c->b_res.p, P, (u32 *)c->b_frag.p, (int32_t *)c->b_fragj.p);
-    HIP_TRY(c, hipEventRecord(c->ev[5], st));
-
-    // ---- K5: fragments -> junctions -> rows
-    LAUNCH(c, "k5_frag_reduce", k5_frag_reduce, dim3((n_slots + 4 * FRAG_SLOTS_PER_WAVE - 1) / (4 * FRAG_SLOTS_PER_WAVE)), dim3(256), (const u32 *)c->b_frag.p,
-           (const int32_t *)c->b_fragj.p, n_slots, (u32 *)c->b_acc.p);
-    const u32 R_runs = cs.n_runs;
-    if ((rc = ensure(c, c->b_ent, (size_t)R_runs * 8))) return rc;
-    LAUNCH(c, "k5_entropy_terms", k5_entropy_terms, dim3((R_runs + 255) / 256), dim3(256), (const u32 *)c->b_jid.p,
-           (const u32 *)c->b_seg.p, (const u32 *)c->b_runfirst.p, (const u32 *)c->b_runstart.p, R_runs, (double *)c->b_ent.p);
-    LAUNCH(c, "k5_finalize", k5_finalize, dim3((J + 255) / 256), dim3(256), skey, (const u32 *)c->b_seg.p,
-           (const u32 *)c->b_runfirst.p, (const u32 *)c->b_runstart.p, (const u32 *)c->b_acc.p,
-           (const int32_t *)c->b_ancl.p, (const int32_t *)c->b_ancr.p, kf, (const uint8_t *)G.d, (int32_t)G.len, tid, J,
-           (const double *)c->b_ent.p, (pjb_junction_row *)c->b_rows.p, d_err);
-    HIP_TRY(c, hipEventRecord(c->ev[6], st));
-
-    // ---- rows to host
+    c->junc_seen = std::max(c->junc_seen, J);
     const size_t old = c->rows_n;
-    if (old + J > c->rows_cap) {
-        const size_t ncap = std::max<size_t>((old + J) * 3 / 2, 1024);
-        pjb_junction_row *np = nullptr;
-        hipError_t e = hipHostMalloc((void **)&np, ncap * sizeof(pjb_junction_row), hipHostMallocDefault);
-        if (e != hipSuccess) return fail(c, PJB_ERR_NOMEM, "hipHostMalloc(rows): %s", hipGetErrorString(e));
-        if (old) memcpy(np, c->rows_pinned, old * sizeof(pjb_junction_row));
-        if (c->rows_pinned) (void)hipHostFree(c->rows_pinned);
-        c->rows_pinned = np;
-        c->rows_cap = ncap;
-    }
-    HIP_TRY(c, hipMemcpyAsync(c->rows_pinned + old, c->b_rows.p, (size_t)J * sizeof(pjb_junction_row), hipMemcpyDeviceToHost, st));
-    if (c->mirror) { // header + rows into the caller's exchange slot, covered by the synchronisation below
-        const size_t at = PJB_MIRROR_HEADER_BYTES + c->mirror_rows * sizeof(pjb_junction_row);
-        const size_t need = at + (size_t)J * sizeof(pjb_junction_row);
-        if (need > c->mirror_cap)
-            return fail(c, PJB_ERR_ARG, "finish: %zu rows do not fit the row mirror (%zu bytes)", c->mirror_rows + J, c->mirror_cap);
+    if (c->mirror) { // the rows are in the exchange slot already (k6_rows_out); the header follows, covered by a small wait
+        const size_t need = PJB_MIRROR_HEADER_BYTES + (c->mirror_rows + J) * sizeof(pjb_junction_row);
+        if (need > c->mirror_cap) return fail(c, PJB_ERR_ARG, "finish: %zu rows do not fit the row mirror (%zu bytes)", c->mirror_rows + J, c->mirror_cap);
         mirror_fold(c, R, J);
-        HIP_TRY(c, hipMemcpyAsync(c->mirror, c->mirror_hdr, PJB_MIRROR_HEADER_BYTES, hipMemcpyHostToDevice, st));
-        HIP_TRY(c, hipMemcpyAsync(c->mirror + at, c->b_rows.p, (size_t)J * sizeof(pjb_junction_row), hipMemcpyDeviceToDevice, st));
+        HIP_TRY(c, hipMemcpyAsync(c->mirror, c->mirror_hdr, PJB_MIRROR_HEADER_BYTES, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
     }
-    HIP_TRY(c, hipMemcpyAsync(&herr, d_err, 8, hipMemcpyDeviceToHost, st));
-    u32 gen_counts[GEN_SHARDS];
-    HIP_TRY(c, hipMemcpyAsync(gen_counts, c->b_gencount.p, GEN_SHARDS * 4, hipMemcpyDeviceToHost, st));
-    HIP_TRY(c, hipEventRecord(c->ev[7], st));
-    HIP_TRY(c, hipStreamSynchronize(st));
-    if ((rc = check_device_error(c, herr))) return rc;
     if (c->extra && (rc = extra_contig(c, tid, batches, n_reads, cs.spliced, P, J, sidx, pr.g, old))) return rc;
     c->rows_n = old + J;
     c->last_rows_n = J;
-    c->timing.generic_pairs = 0;
-    for (u32 k = 0; k < GEN_SHARDS; k++) c->timing.generic_pairs += gen_counts[k];
     if (c->ktime) ev_collect(c);
     for (int k = 0; k < 7; k++) (void)hipEventElapsedTime(&c->timing.stage_ms[k], c->ev[k], c->ev[k + 1]);
     (void)hipEventElapsedTime(&c->timing.total_ms, c->ev[0], c->ev[7]);

@@ -43,6 +43,7 @@ struct DevBatch {
     uint32_t tile_base; // first K1 tile index of this batch
     int32_t prev_pos;   // pos of the last record of the previous batch (sortedness across batches)
     int32_t _pad;
+    const int32_t *prev_pos_ptr; // where that position is, when only the device knows it (nullptr: prev_pos holds it)
 };
 
 // error word: min over (ordinal << 8 | -code); ~0 = no error
@@ -60,14 +61,24 @@ struct TileStats { // per K1 tile
     int32_t _pad;
 };
 
+// Per-contig control block in device memory.  The host sizes buffers and grids from LIMITS it chooses before anything
+// runs (pairs, junctions, key format); the kernels read the actual counts from here, and a count that exceeds its limit
+// raises an overflow bit and zeroes the count so that everything downstream does nothing.  pjb_finish_contig reads the
+// block back once, at the end, and repeats the contig with larger limits if a bit is set.
+enum : u32 { OVF_PAIRS = 1u, OVF_KEYFMT = 2u, OVF_JUNC = 4u };
 struct ContigStats {
     u64 spliced, unspliced, sum_len;
     int32_t min_len, max_len;
     int32_t max_end, max_nlen, min_pos;
     u32 n_tiles;
-    u64 n_pairs;
+    u64 n_pairs;   // pairs found (whatever the limit)
     u64 err;
-    u32 n_junc, n_runs;
+    u32 n_junc, n_runs; // junctions / position runs found (whatever the limit)
+    u32 P;         // pairs the pipeline works on: n_pairs, or 0 after an overflow
+    u32 J, R;      // junctions / runs the pipeline works on
+    u32 n_slots;   // J + ceil(P / 64) fragment slots
+    u32 overflow;  // OVF_*
+    u32 _pad;
 };
 
 // pairs, structure of arrays (one entry per N operation walked)
@@ -192,8 +203,9 @@ __device__ __forceinline__ T block_escan_256(T v, T *smem, T *total) {
 constexpr int SCAN_TILE = 2048; // 256 threads x 8
 
 template <typename F>
-__global__ __launch_bounds__(256) void scan_reduce_kernel(F f, u64 n, u64 *tile_sums) {
+__global__ __launch_bounds__(256) void scan_reduce_kernel(F f, u64 n, u64 *tile_sums, const u32 *np) {
     __shared__ u64 sm[4];
+    if (np) n = *np; // length known on the device only: the grid covers the host's limit
     u64 base = (u64)blockIdx.x * SCAN_TILE;
     u64 s = 0;
 #pragma unroll
@@ -237,8 +249,10 @@ __global__ __launch_bounds__(1024) void scan_tiles_kernel(u64 *tile_sums, u32 n_
 
 // third kernel: recompute values, exclusive prefix handed to the sink g(i, value, exclusive_prefix)
 template <typename F, typename G>
-__global__ __launch_bounds__(256) void scan_apply_kernel(F f, G g, u64 n, const u64 *tile_sums) {
+__global__ __launch_bounds__(256) void scan_apply_kernel(F f, G g, u64 n, const u64 *tile_sums, const u32 *np) {
     __shared__ u64 sm[4];
+    if (np) n = *np;
+    if ((u64)blockIdx.x * SCAN_TILE >= n) return;
     u64 base = (u64)blockIdx.x * SCAN_TILE;
     u64 run = tile_sums[blockIdx.x];
     // thread order within the tile must equal element order: round k covers [base+k*256, +256)
@@ -356,7 +370,7 @@ __global__ __launch_bounds__(256) void k1_count(DevBatch b, u32 *tile_cnt, TileS
         c0[it] = on ? b.cig_off[r] : 0u;
         nop[it] = on ? b.cig_off[r + 1] - c0[it] : 0u;
         pos4[it] = on ? b.pos[r] : 0;
-        prev4[it] = on ? (r > 0 ? b.pos[r - 1] : b.prev_pos) : 0;
+        prev4[it] = on ? (r > 0 ? b.pos[r - 1] : (b.prev_pos_ptr ? *b.prev_pos_ptr : b.prev_pos)) : 0;
         xs4[it] = on ? (u32)b.xs[r] : 0u;
         len4[it] = on ? b.l_qseq[r] : 0;
     }
@@ -471,7 +485,8 @@ __global__ __launch_bounds__(256) void k1_count(DevBatch b, u32 *tile_cnt, TileS
 }
 
 // single block: exclusive scan of per-tile pair counts (in place) + reduction of tile stats
-__global__ __launch_bounds__(1024) void k1_scan_tiles(u32 *tile_cnt, const TileStats *ts, u32 n_tiles, ContigStats *out) {
+__global__ __launch_bounds__(1024) void k1_scan_tiles(u32 *tile_cnt, const TileStats *ts, u32 n_tiles, ContigStats *out, u32 pair_limit,
+                                                       KeyFmt kf, int32_t ref_len) {
     __shared__ u64 wsum[16];
     __shared__ u64 carry_s;
     __shared__ u64 r_spl[16], r_uns[16], r_sum[16];
@@ -555,6 +570,21 @@ __global__ __launch_bounds__(1024) void k1_scan_tiles(u32 *tile_cnt, const TileS
         out->min_pos = m4;
         out->n_tiles = n_tiles;
         out->n_pairs = carry_s;
+        // limits the host assumed: pair capacity and key format (the keys of k1_emit must fit the digits it planned)
+        u32 ovf = 0;
+        if (carry_s > (u64)pair_limit) ovf |= OVF_PAIRS;
+        if (carry_s > 0) {
+            const bool weird = m4 < 0 || m2 > ref_len || m2 < 0;
+            if (!kf.raw) {
+                int need = 0;
+                for (u32 v = (u32)m3; v; v >>= 1) need++;
+                if (weird || need > kf.lbits) ovf |= OVF_KEYFMT;
+            }
+        }
+        out->overflow = ovf;
+        out->P = ovf ? 0u : (u32)carry_s;
+        out->J = out->R = out->n_slots = 0;
+        out->n_junc = out->n_runs = 0;
     }
 }
 
@@ -601,8 +631,9 @@ __device__ __forceinline__ void ncursor_advance(NCursor &c, const OpsView cig, u
 // writes every field of the read's pairs.
 __global__ __launch_bounds__(256) void k1_emit(DevBatch b, const u32 *tile_off, const TileStats *tile_stats,
                                                 const u32 *spl_idx, const u32 *spl_poff, Pairs P, KeyFmt kf, int32_t ref_len,
-                                                int32_t tid, int orientation, u64 *err) {
+                                                int32_t tid, int orientation, u64 *err, const ContigStats *cs) {
     __shared__ u32 s_ops[OPS_LDS][256];
+    if (cs->P == 0) return; // no pairs, or a limit was exceeded: the contig is repeated with larger buffers
     const u32 tile = b.tile_base + blockIdx.x;
     const u32 nspl = tile_stats[tile].spliced;
     const u32 toff = tile_off[tile];
@@ -763,8 +794,9 @@ __device__ __forceinline__ void wave_hist_add(u32 *h, u32 d, bool valid) {
     if ((rem >> lane) & 1ull) atomicAdd(&h[d], 1u);
 }
 
-__global__ __launch_bounds__(256) void rs_hist(const u64 *keys, u32 n, int shift, int bits, u32 *hist, u32 n_tiles) {
+__global__ __launch_bounds__(256) void rs_hist(const u64 *keys, const u32 *np, int shift, int bits, u32 *hist, u32 n_tiles) {
     __shared__ u32 h[RS_MAX_BINS];
+    const u32 n = *np; // the grid covers the host's limit; tiles past the data count nothing
     const u32 nb = 1u << bits;
     for (u32 d = threadIdx.x; d < nb; d += 256) h[d] = 0;
     __syncthreads();
@@ -843,10 +875,12 @@ __device__ __forceinline__ u64 wave_match_digit(u32 d, bool valid, int bits) {
 // hist + rowscan + scatter: with every tile resident at once the look-back chain costs more than the
 // two small kernels, so it was dropped.
 template <int BITS>
-__global__ __launch_bounds__(256, 4) void rs_scatter(const u64 *kin, const u32 *vin, u64 *kout, u32 *vout, u32 n, int shift,
+__global__ __launch_bounds__(256, 4) void rs_scatter(const u64 *kin, const u32 *vin, u64 *kout, u32 *vout, const u32 *np, int shift,
                                                       int bits, const u32 *hist_scan, const u32 *row_total, u32 n_tiles) {
     extern __shared__ __attribute__((aligned(16))) unsigned char rs_smem[];
     __shared__ u64 s_scan[4];
+    const u32 n = *np;
+    if ((u64)blockIdx.x * RS_TILE >= n) return; // the grid covers the host's limit
     if (BITS > 0) bits = BITS;
     const u32 nb = 1u << bits;
     const u32 mask = nb - 1;
@@ -999,13 +1033,23 @@ struct HeadSink {
         if ((u32)v) run_start[r] = (u32)i;
     }
 };
-__global__ void k2_close(u64 *total, u32 *seg_off, u32 *run_first, u32 *run_start, u32 n_pairs, ContigStats *cs) {
+__global__ void k2_close(u64 *total, u32 *seg_off, u32 *run_first, u32 *run_start, ContigStats *cs, u32 junc_limit) {
+    const u32 n_pairs = cs->P;
+    if (n_pairs == 0) return;
     const u32 J = (u32)(*total >> 32), R = (u32)*total;
     seg_off[J] = n_pairs;
     run_first[J] = R;
     run_start[R] = n_pairs;
     cs->n_junc = J;
     cs->n_runs = R;
+    if (J > junc_limit) { // the junction-sized buffers are too small: everything downstream stands still
+        cs->overflow |= OVF_JUNC;
+        cs->P = 0;
+        return;
+    }
+    cs->J = J;
+    cs->R = R;
+    cs->n_slots = J + (n_pairs + 63) / 64;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1036,9 +1080,11 @@ struct OpAdd { template <typename T> __device__ T operator()(T a, T b) const { r
 constexpr u32 GEN_SHARDS = 256;
 // K3: anchors per fragment
 __global__ __launch_bounds__(256) void k3_anchors_frag(const u32 *sidx, const u32 *jid_of, const int32_t *lstart,
-                                                        const int32_t *rend, const u32 *meta, int all_generic, u32 n,
+                                                        const int32_t *rend, const u32 *meta, int all_generic, const u32 *np,
                                                         int32_t *frag_l, int32_t *frag_r, int32_t *frag_j, u32 *gen_list,
                                                         u32 *gen_count) {
+    const u32 n = *np;
+    if (blockIdx.x * 256u >= n) return;
     const u32 i = blockIdx.x * 256 + threadIdx.x;
     const bool valid = i < n;
     const u32 p = valid ? sidx[i] : 0;
@@ -1072,7 +1118,9 @@ __global__ __launch_bounds__(256) void k3_anchors_frag(const u32 *sidx, const u3
 }
 // K3b: fragment slots -> junction anchors (anc_l/anc_r pre-initialised to INT32_MAX / INT32_MIN)
 __global__ __launch_bounds__(256) void k3_anchors_junc(const int32_t *frag_l, const int32_t *frag_r, const int32_t *frag_j,
-                                                        u32 n_slots, int32_t *anc_l, int32_t *anc_r) {
+                                                        const u32 *n_slots_p, int32_t *anc_l, int32_t *anc_r) {
+    const u32 n_slots = *n_slots_p;
+    if (blockIdx.x * 256u >= n_slots) return;
     const u32 s = blockIdx.x * 256 + threadIdx.x;
     const bool in = s < n_slots;
     const int32_t jj = in ? frag_j[s] : -1;
@@ -1348,7 +1396,8 @@ __device__ __forceinline__ const DevBatch &find_batch(const DevBatch *batches, i
 // of bam_alignment.cc:341-462 reduce to exactly this for the shape.  Consecutive threads touch
 // consecutive reads and genome positions.
 __global__ __launch_bounds__(256) void k4a_simple(Pairs P, KeyFmt kf, const DevBatch *batches, int n_batches, const u32 *gcodes,
-                                                   int32_t glen, u32 n, u64 *res) {
+                                                   int32_t glen, const u32 *np, u64 *res) {
+    const u32 n = *np;
     const u32 p = blockIdx.x * 256 + threadIdx.x;
     if (p >= n) return;
     const u32 meta = P.meta[p];
@@ -1425,7 +1474,9 @@ enum {
 // K4: gather the per-pair predicates and match statistics in sorted order and fold them to fragment
 // heads with a segmented wave reduction (junction.cc:862-909 accumulators, :755-814 counters).
 __global__ __launch_bounds__(256) void k4_pairs(const u64 *skey, const u32 *sidx, const u32 *jid_of, Pairs P, KeyFmt kf,
-                                                 const u64 *res, u32 n, u32 *frag, int32_t *frag_j) {
+                                                 const u64 *res, const u32 *np, u32 *frag, int32_t *frag_j) {
+    const u32 n = *np;
+    if (blockIdx.x * 256u >= n) return;
     const u32 i = blockIdx.x * 256 + threadIdx.x;
     const bool valid = i < n;
     const int lane = lane_id();
@@ -1545,7 +1596,8 @@ __device__ __forceinline__ u32 frag_combine(int k, u32 a, u32 b) {
     return a + b; // sums; F_MISM_LO/HI are handled as one 64-bit add by the caller
 }
 constexpr int FRAG_SLOTS_PER_WAVE = 16; // short per-wave chains keep enough wavefronts in flight
-__global__ __launch_bounds__(256) void k5_frag_reduce(const u32 *frag, const int32_t *frag_j, u32 n_slots, u32 *acc) {
+__global__ __launch_bounds__(256) void k5_frag_reduce(const u32 *frag, const int32_t *frag_j, const u32 *n_slots_p, u32 *acc) {
+    const u32 n_slots = *n_slots_p;
     const u32 wave = (blockIdx.x * 256 + threadIdx.x) >> 6;
     const int k = lane_id();
     const u32 s0 = wave * FRAG_SLOTS_PER_WAVE;
@@ -1584,8 +1636,11 @@ __global__ __launch_bounds__(256) void k5_frag_reduce(const u32 *frag, const int
     }
     flush(cur);
 }
-__global__ __launch_bounds__(256) void k5_init_acc(u32 *acc, u32 n_junc, int32_t *anc_l, int32_t *anc_r) {
+__global__ __launch_bounds__(256) void k5_init_acc(u32 *acc, const u32 *n_junc_p, int32_t *anc_l, int32_t *anc_r, int32_t *frag_j,
+                                                    const u32 *n_slots_p) {
+    const u32 n_junc = *n_junc_p, n_slots = *n_slots_p;
     const u32 t = blockIdx.x * 256 + threadIdx.x;
+    if (t < n_slots) frag_j[t] = -1; // unused fragment slot
     if (t < n_junc * F_WORDS) acc[t] = (t % F_WORDS) == F_FIRSTMIS ? 100000000u : 0u;
     if (t < n_junc) {
         anc_l[t] = INT32_MAX;
@@ -1632,7 +1687,8 @@ __device__ __forceinline__ void fetch_clamp(int32_t glen, int32_t &b, int32_t &e
 // (r_0+1, r_1, ..., r_{m-1}, r_m-1); a zero count contributes nothing.  k5_finalize adds the terms
 // of a junction sequentially, in run order, so the sum rounds like the reference's loop.
 __global__ __launch_bounds__(256) void k5_entropy_terms(const u32 *jid_of, const u32 *seg_off, const u32 *run_first,
-                                                         const u32 *run_start, u32 n_runs, double *term) {
+                                                         const u32 *run_start, const u32 *n_runs_p, double *term) {
+    const u32 n_runs = *n_runs_p;
     const u32 r = blockIdx.x * 256 + threadIdx.x;
     if (r >= n_runs) return;
     const u32 s = run_start[r];
@@ -1655,8 +1711,9 @@ __global__ __launch_bounds__(256) void k5_entropy_terms(const u32 *jid_of, const
 __global__ __launch_bounds__(256) void k5_finalize(const u64 *skey, const u32 *seg_off, const u32 *run_first,
                                                     const u32 *run_start, const u32 *acc, const int32_t *anc_l,
                                                     const int32_t *anc_r, KeyFmt kf, const uint8_t *genome, int32_t glen,
-                                                    int32_t tid, u32 n_junc, const double *ent_term, pjb_junction_row *rows,
+                                                    int32_t tid, const u32 *n_junc_p, const double *ent_term, pjb_junction_row *rows,
                                                     u64 *err) {
+    const u32 n_junc = *n_junc_p;
     const u32 j = blockIdx.x * 256 + threadIdx.x;
     if (j >= n_junc) return;
     const u32 *a = acc + (size_t)j * F_WORDS;
@@ -1812,6 +1869,22 @@ __global__ __launch_bounds__(256) void k5_finalize(const u64 *skey, const u32 *s
         R.hamming3p = h3;
     }
     rows[j] = R;
+}
+
+// K6: the contig's rows leave the device inside the kernel chain -- the host does not know the row count when it
+// queues the work, so it cannot size a copy: 8-byte units go straight into page-locked host memory (mapped into the
+// device's address space; consecutive lanes write consecutive addresses, PCIe posted writes) and, if the caller set a
+// row mirror, into its exchange slot; the control block follows as the last thing on the stream.
+constexpr int ROW_U64 = (int)(sizeof(pjb_junction_row) / 8);
+static_assert(sizeof(pjb_junction_row) % 8 == 0, "rows are copied in 8-byte units");
+__global__ __launch_bounds__(256) void k6_rows_out(const u64 *rows, const u32 *n_junc_p, u64 *host_rows, u64 *mirror_rows, u32 mirror_room) {
+    const u32 nj = *n_junc_p;
+    const u64 n = (u64)nj * ROW_U64;
+    const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const u64 v = rows[i];
+    host_rows[i] = v;
+    if (mirror_rows && nj <= mirror_room) mirror_rows[i] = v;
 }
 
 } // namespace pjb
