@@ -122,7 +122,7 @@ struct pjb_ctx {
     Buf b_hist, b_hist_scan, b_scan_tiles, b_bintotal;
     Buf b_inf_comp, b_inf_out, b_inf_blocks, b_inf_status, b_inf_scratch; // device-side BGZF inflate
     Buf b_bam_seg, b_bam_rec, b_bam_ctl;                                  // device-side BAM record parse
-    Buf b_jid, b_seg, b_runfirst, b_runstart;
+    Buf b_jid, b_seg, b_runfirst, b_runstart, b_entsum;
     // --extra
     bool extra = false;
     std::vector<ExtraContig> xc;
@@ -433,7 +433,7 @@ void pjb_destroy(pjb_ctx *c) {
                   &c->b_key[1], &c->b_idx[0], &c->b_idx[1], &c->b_g, &c->b_lstart, &c->b_rend, &c->b_pos, &c->b_aend,
                   &c->b_meta, &c->b_updown, &c->b_hist, &c->b_hist_scan, &c->b_scan_tiles, &c->b_jid, &c->b_seg,
                   &c->b_runfirst, &c->b_runstart, &c->b_frag, &c->b_fragj, &c->b_fragl, &c->b_fragr, &c->b_acc,
-                  &c->b_ancl, &c->b_ancr, &c->b_rows, &c->b_hasx, &c->b_ent, &c->b_splidx, &c->b_splpoff, &c->b_res, &c->b_genlist, &c->b_gencount, &c->b_bintotal, &c->b_inf_comp, &c->b_inf_out, &c->b_inf_blocks, &c->b_inf_status, &c->b_inf_scratch, &c->b_bam_seg, &c->b_bam_rec, &c->b_bam_ctl,
+                  &c->b_ancl, &c->b_ancr, &c->b_rows, &c->b_hasx, &c->b_ent, &c->b_splidx, &c->b_splpoff, &c->b_res, &c->b_genlist, &c->b_gencount, &c->b_bintotal, &c->b_inf_comp, &c->b_inf_out, &c->b_inf_blocks, &c->b_inf_status, &c->b_inf_scratch, &c->b_bam_seg, &c->b_bam_rec, &c->b_bam_ctl, &c->b_entsum,
                   &c->x_pos, &c->x_endx, &c->x_q, &c->x_prefq, &c->x_ce, &c->x_bound, &c->x_de, &c->x_dropped, &c->x_zlist, &c->x_cnt,
                   &c->x_tabk, &c->x_tabc, &c->x_rs, &c->x_re, &c->x_rr};
     for (Buf *b : all) release(*b);
@@ -960,10 +960,13 @@ static int run_contig_once(pjb_ctx *c, int32_t tid, std::vector<DevBatch> &batch
            (const u32 *)c->b_frag.p, (const int32_t *)c->b_fragj.p, d_slots, (u32 *)c->b_acc.p);
     LAUNCH(c, "k5_entropy_terms", k5_entropy_terms, dim3(pair_blocks), dim3(256), (const u32 *)c->b_jid.p,
            (const u32 *)c->b_seg.p, (const u32 *)c->b_runfirst.p, (const u32 *)c->b_runstart.p, d_R, (double *)c->b_ent.p);
+    if ((rc = ensure(c, c->b_entsum, (size_t)JL * 8 + 16))) return rc;
+    LAUNCH(c, "k5_entropy_sum", k5_entropy_sum, dim3(std::max<u32>(1, (JL + 3) / 4)), dim3(256), (const u32 *)c->b_runfirst.p,
+           (const double *)c->b_ent.p, d_J, (double *)c->b_entsum.p);
     LAUNCH(c, "k5_finalize", k5_finalize, dim3(std::max<u32>(1, (JL + 255) / 256)), dim3(256), skey, (const u32 *)c->b_seg.p,
            (const u32 *)c->b_runfirst.p, (const u32 *)c->b_runstart.p, (const u32 *)c->b_acc.p,
            (const int32_t *)c->b_ancl.p, (const int32_t *)c->b_ancr.p, kf, (const uint8_t *)G.d, (int32_t)G.len, tid, d_J,
-           (const double *)c->b_ent.p, (pjb_junction_row *)c->b_rows.p, d_err);
+           (const double *)c->b_entsum.p, (pjb_junction_row *)c->b_rows.p, d_err);
     HIP_TRY(c, hipEventRecord(c->ev[6], st));
 
     // ---- rows to the host (and into the caller's exchange slot), control block last

@@ -1708,10 +1708,29 @@ __global__ __launch_bounds__(256) void k5_entropy_terms(const u32 *jid_of, const
     term[r] = t;
 }
 
+// Entropy of a junction = |sum of its runs' terms|, added one after the other in run order so that the sum rounds like
+// the reference's loop (junction.cc:742-748).  One wavefront per junction: the terms arrive 64 at a time with one
+// coalesced load and are folded in lane order through scalar reads (the chain of dependent adds is the same, the chain
+// of dependent memory loads is gone).
+__global__ __launch_bounds__(256) void k5_entropy_sum(const u32 *run_first, const double *term, const u32 *n_junc_p, double *ent_sum) {
+    const u32 j = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (j >= *n_junc_p) return;
+    const int lane = lane_id();
+    const u32 rf = run_first[j], rl = run_first[j + 1];
+    double sum = 0.0;
+    for (u32 r0 = rf; r0 < rl; r0 += 64) {
+        const u32 r = r0 + (u32)lane;
+        const double t = r < rl ? term[r] : 0.0;
+        const u32 cnt = rl - r0 < 64u ? rl - r0 : 64u;
+        for (u32 k = 0; k < cnt; k++) sum = __dadd_rn(sum, __shfl(t, (int)k, 64));
+    }
+    if (lane == 0) ent_sum[j] = sum;
+}
+
 __global__ __launch_bounds__(256) void k5_finalize(const u64 *skey, const u32 *seg_off, const u32 *run_first,
                                                     const u32 *run_start, const u32 *acc, const int32_t *anc_l,
                                                     const int32_t *anc_r, KeyFmt kf, const uint8_t *genome, int32_t glen,
-                                                    int32_t tid, const u32 *n_junc_p, const double *ent_term, pjb_junction_row *rows,
+                                                    int32_t tid, const u32 *n_junc_p, const double *ent_sum, pjb_junction_row *rows,
                                                     u64 *err) {
     const u32 n_junc = *n_junc_p;
     const u32 j = blockIdx.x * 256 + threadIdx.x;
@@ -1759,15 +1778,8 @@ __global__ __launch_bounds__(256) void k5_finalize(const u64 *skey, const u32 *s
         else if ((double)nn / tot >= 0.95) R.read_strand = PJB_STRAND_NEG;
         else R.read_strand = PJB_STRAND_UNK;
     }
-    // calcEntropy, junction.cc:730-749: sequential sum of the per-run terms (k5_entropy_terms), then fabs
-    {
-        double sum = 0.0;
-        if (n > 1) {
-            const u32 rf = run_first[j], rl = run_first[j + 1];
-            for (u32 r = rf; r < rl; r++) sum = __dadd_rn(sum, ent_term[r]);
-        }
-        R.entropy = n > 1 ? fabs(sum) : 0.0;
-    }
+    // calcEntropy, junction.cc:730-749: the per-run terms (k5_entropy_terms) summed in run order (k5_entropy_sum), then fabs
+    R.entropy = n > 1 ? fabs(ent_sum[j]) : 0.0;
     // processJunctionWindow, junction.cc:561-649
     {
         int32_t b = istart, e = istart + 1;
