@@ -294,6 +294,21 @@ int pjb_inflate_bgzf(pjb_ctx* ctx, const uint8_t* comp, int64_t comp_bytes, uint
  * Errors: PJB_ERR_BGZF for corrupt BGZF / DEFLATE / BAM record data. */
 int pjb_submit_bam(pjb_ctx* ctx, int32_t tid, const uint8_t* comp, int64_t comp_bytes, int32_t first_uoffset, int64_t* n_records);
 
+/* ---- `portcullis bamfilt` ----------------------------------------------------------------
+ * The per-alignment decision of BamFilter::filter (src/bam_filter.cc:152-247): walk the CIGAR as
+ * BamFilter::containsJunctionInSystem / clipMSR do (src/bam_filter.cc:75-150) and probe the set of junctions that
+ * passed the filter.  The set of one target is uploaded as sorted keys; pjb_filter_batch then writes one code per
+ * alignment of a batch of that target:
+ *   0 dropped, 1 kept (not spliced), 2 kept (spliced, one of its introns is in the set),
+ *   3 kept (multiply spliced read in HARD / SOFT clip mode with a good junction: the reference's "Modified" count).
+ * Only pos, cig_off and cigar of the batch are read.  Kept records leave the reference unchanged in every clip
+ * mode (its clipping edits a cached copy of the CIGAR that BamWriter never writes), so a code is all a writer needs.
+ * Works on any context (no genome, no PJB_FLAG_*). */
+enum { PJB_CLIP_HARD = 0, PJB_CLIP_SOFT = 1, PJB_CLIP_COMPLETE = 2 }; /* ClipMode, src/bam_filter.hpp:50-54 */
+/* keys: (uint64)(uint32)start << 32 | (uint32)end of the target's passing junctions, ascending, host memory */
+int pjb_filter_set_junctions(pjb_ctx *ctx, int32_t tid, const uint64_t *sorted_keys, int64_t n_keys);
+int pjb_filter_batch(pjb_ctx *ctx, int32_t tid, const pjb_batch *host_batch, int32_t clip_mode, uint8_t *codes_out);
+
 #ifdef __cplusplus
 }
 #endif

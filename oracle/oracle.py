@@ -368,6 +368,18 @@ def determine_strandedness(rows):
     return o.value, s.value
 
 
+def bamfilt_flags(soa, js_start, js_end, clip_mode="HARD"):
+    """BamFilter::filter's decision per record of one target (0 drop, 1 unspliced, 2 spliced kept, 3 MSR kept)."""
+    r, keep = _reads_struct(soa)
+    S = np.ascontiguousarray(js_start, dtype=np.int32)
+    E = np.ascontiguousarray(js_end, dtype=np.int32)
+    out = np.zeros(max(int(r.n), 1), dtype=np.uint8)
+    mode = {"HARD": 0, "SOFT": 1, "COMPLETE": 2}[clip_mode]
+    lib().orc_bamfilt_flags(C.byref(r), S.ctypes.data_as(C.c_void_p), E.ctypes.data_as(C.c_void_p), C.c_int64(len(S)), C.c_int(mode),
+                            out.ctypes.data_as(C.c_void_p))
+    return out[: int(r.n)]
+
+
 def finalize(rows, mean_query_len):
     rows = np.ascontiguousarray(rows)
     lib().orc_finalize(rows.ctypes.data_as(C.c_void_p), len(rows), C.c_double(mean_query_len))

@@ -1292,6 +1292,56 @@ void orc_determine_strandedness(const orc_row *rows, int64_t n, int *orientation
 }
 
 /* ------------------------------------------------------------------ */
+/* bamfilt                                                            */
+/* ------------------------------------------------------------------ */
+static int js_has(const int32_t *S, const int32_t *E, int64_t n, int32_t s, int32_t e) { /* JunctionSystem::getJunction */
+    for (int64_t i = 0; i < n; i++)
+        if (S[i] == s && E[i] == e) return 1;
+    return 0;
+}
+/* BamFilter::containsJunctionInSystem, src/bam_filter.cc:75-100 */
+static int contains_junction(const orc_reads *rd, int64_t i, const int32_t *S, const int32_t *E, int64_t n) {
+    int32_t lEnd = rd->pos[i], rStart;
+    for (uint32_t k = rd->cig_off[i]; k < rd->cig_off[i + 1]; k++) {
+        char t = op_chr(rd->cigar[k]);
+        int32_t len = op_len(rd->cigar[k]);
+        if (t == 'N') {
+            rStart = lEnd + len;
+            if (js_has(S, E, n, lEnd, rStart - 1)) return 1;
+        } else if (consumes_ref(t)) {
+            lEnd += len;
+        }
+    }
+    return 0;
+}
+/* BamFilter::clipMSR, src/bam_filter.cc:102-150: only `allBad` reaches the output */
+static int clip_msr_all_bad(const orc_reads *rd, int64_t i, const int32_t *S, const int32_t *E, int64_t n) {
+    int32_t lEnd = rd->pos[i], rStart;
+    int ab = 1;
+    for (uint32_t k = rd->cig_off[i]; k < rd->cig_off[i + 1]; k++) {
+        char t = op_chr(rd->cigar[k]);
+        int32_t len = op_len(rd->cigar[k]);
+        if (t == 'N') {
+            rStart = lEnd + len;
+            if (js_has(S, E, n, lEnd, rStart - 1)) ab = 0;
+        } else if (consumes_ref(t)) {
+            lEnd += len;
+        }
+    }
+    return ab;
+}
+int orc_bamfilt_flags(const orc_reads *rd, const int32_t *S, const int32_t *E, int64_t n_js, int clip_mode, uint8_t *out) {
+    for (int64_t i = 0; i < rd->n; i++) {
+        if (has_refskip(rd, i)) {
+            if (clip_mode == 2 || nb_junctions_in_read(rd, i) <= 1) out[i] = contains_junction(rd, i, S, E, n_js) ? 2 : 0;
+            else out[i] = clip_msr_all_bad(rd, i, S, E, n_js) ? 0 : 3;
+        } else
+            out[i] = 1;
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------ */
 /* writers                                                            */
 /* ------------------------------------------------------------------ */
 static char strand_chr(int s) { return s == ORC_STRAND_POS ? '+' : s == ORC_STRAND_NEG ? '-' : '?'; }

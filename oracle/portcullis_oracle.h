@@ -191,6 +191,21 @@ int orc_extra(int32_t n_refs, const int32_t *ref_len, const orc_reads *reads, co
  * libstdc++ with <cmath> in scope resolves it to). */
 void orc_determine_strandedness(const orc_row *rows, int64_t n, int *orientation, int *strandedness);
 
+/* ---- `portcullis bamfilt` (src/bam_filter.cc:75-247) --------------------------------------
+ * The decision BamFilter::filter makes for every record of one target, given the junctions of the filter's .tab
+ * file on that target (js_start / js_end, n_js of them, any order):
+ *   0  dropped
+ *   1  kept: not spliced                                           (bam_filter.cc:221-224)
+ *   2  kept: spliced, containsJunctionInSystem                     (:196-202, :75-100)
+ *   3  kept: multiply spliced in HARD / SOFT mode, clipMSR found a good junction ("Modified" count, :204-218)
+ * clip_mode: 0 HARD, 1 SOFT, 2 COMPLETE.  As written in the reference, the walk does not advance over an N
+ * operation (:86-96: only the else-branch adds to lEnd), so the introns after a read's first one are looked up
+ * at coordinates short of the earlier introns' lengths; and clipMSR edits only the cached CIGAR vector while
+ * BamWriter::write emits the untouched bam1_t (lib/src/bam_writer.cc:58-60), so kept records leave unchanged in
+ * every mode. */
+int orc_bamfilt_flags(const orc_reads *reads, const int32_t *js_start, const int32_t *js_end, int64_t n_js, int clip_mode,
+                      uint8_t *out);
+
 /* Writers.  Return a malloc'd buffer (caller frees with orc_free_text) and its length.
  * ref_names[refid], ref_lens[refid].  (.tab: junction.hpp:1260-1319 + junction_system.hpp:154-160
  * + junction_system.cc:356; .bed: junction_system.cc:411-418 + junction.cc:1189-1214;

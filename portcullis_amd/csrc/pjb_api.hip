@@ -127,6 +127,8 @@ struct pjb_ctx {
     bool extra = false;
     std::vector<ExtraContig> xc;
     std::vector<pjb_extra_row> xrows_host;
+    std::map<int32_t, std::pair<u64 *, u32>> filter_keys; // bamfilt: passing junctions per target (device, sorted)
+    Buf f_pos, f_cigoff, f_cigar, f_codes;
     Buf x_pos, x_endx, x_q, x_prefq, x_ce, x_bound, x_de, x_dropped, x_zlist, x_cnt, x_tabk, x_tabc, x_rs, x_re, x_rr;
     Buf b_frag, b_fragj, b_fragl, b_fragr, b_acc, b_ancl, b_ancr, b_rows, b_hasx, b_ent, b_res, b_genlist, b_gencount;
 };
@@ -419,6 +421,9 @@ void pjb_destroy(pjb_ctx *c) {
     (void)hipStreamSynchronize(c->stream);
     while (!c->open.empty()) close_contig(c, c->open.begin()->first);
     extra_clear(c);
+    for (auto &kv : c->filter_keys)
+        if (kv.second.first) (void)hipFree(kv.second.first);
+    c->filter_keys.clear();
     for (auto &g : c->contigs) free_contig(g);
     for (auto &sl : c->slab_pool)
         if (sl.p) (void)hipFree(sl.p);
@@ -433,7 +438,7 @@ void pjb_destroy(pjb_ctx *c) {
                   &c->b_key[1], &c->b_idx[0], &c->b_idx[1], &c->b_g, &c->b_lstart, &c->b_rend, &c->b_pos, &c->b_aend,
                   &c->b_meta, &c->b_updown, &c->b_hist, &c->b_hist_scan, &c->b_scan_tiles, &c->b_jid, &c->b_seg,
                   &c->b_runfirst, &c->b_runstart, &c->b_frag, &c->b_fragj, &c->b_fragl, &c->b_fragr, &c->b_acc,
-                  &c->b_ancl, &c->b_ancr, &c->b_rows, &c->b_hasx, &c->b_ent, &c->b_splidx, &c->b_splpoff, &c->b_res, &c->b_genlist, &c->b_gencount, &c->b_bintotal, &c->b_inf_comp, &c->b_inf_out, &c->b_inf_blocks, &c->b_inf_status, &c->b_inf_scratch, &c->b_bam_seg, &c->b_bam_rec, &c->b_bam_ctl, &c->b_entsum,
+                  &c->b_ancl, &c->b_ancr, &c->b_rows, &c->b_hasx, &c->b_ent, &c->b_splidx, &c->b_splpoff, &c->b_res, &c->b_genlist, &c->b_gencount, &c->b_bintotal, &c->b_inf_comp, &c->b_inf_out, &c->b_inf_blocks, &c->b_inf_status, &c->b_inf_scratch, &c->b_bam_seg, &c->b_bam_rec, &c->b_bam_ctl, &c->b_entsum, &c->f_pos, &c->f_cigoff, &c->f_cigar, &c->f_codes,
                   &c->x_pos, &c->x_endx, &c->x_q, &c->x_prefq, &c->x_ce, &c->x_bound, &c->x_de, &c->x_dropped, &c->x_zlist, &c->x_cnt,
                   &c->x_tabk, &c->x_tabc, &c->x_rs, &c->x_re, &c->x_rr};
     for (Buf *b : all) release(*b);
@@ -1248,6 +1253,65 @@ int pjb_extra_finish(pjb_ctx *c, const pjb_extra_row **rows_out, int64_t *n_out)
             o.down_aln = tmp[j].down_aln;
         }
     }
+    HIP_TRY(c, hipStreamSynchronize(st));
+    if (c->ktime) ev_collect(c);
+    return PJB_OK;
+}
+
+int pjb_filter_set_junctions(pjb_ctx *c, int32_t tid, const uint64_t *sorted_keys, int64_t n_keys) {
+    if (!c) return PJB_ERR_ARG;
+    if (tid < 0 || n_keys < 0 || n_keys > 0xfffffff0ll || (n_keys > 0 && !sorted_keys))
+        return fail(c, PJB_ERR_ARG, "pjb_filter_set_junctions: bad arguments (tid %d)", tid);
+    for (int64_t i = 1; i < n_keys; i++)
+        if (sorted_keys[i - 1] >= sorted_keys[i]) return fail(c, PJB_ERR_ARG, "pjb_filter_set_junctions: keys must be strictly ascending");
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    auto it = c->filter_keys.find(tid);
+    if (it != c->filter_keys.end()) {
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        if (it->second.first) (void)hipFree(it->second.first);
+        c->filter_keys.erase(it);
+    }
+    u64 *d = nullptr;
+    if (n_keys) {
+        if (hipMalloc((void **)&d, (size_t)n_keys * 8) != hipSuccess) return fail(c, PJB_ERR_NOMEM, "pjb_filter_set_junctions: %lld keys", (long long)n_keys);
+        hipError_t e = hipMemcpy(d, sorted_keys, (size_t)n_keys * 8, hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            (void)hipFree(d);
+            return fail(c, PJB_ERR_HIP, "pjb_filter_set_junctions: %s", hipGetErrorString(e));
+        }
+    }
+    c->filter_keys[tid] = std::make_pair(d, (u32)n_keys);
+    return PJB_OK;
+}
+
+int pjb_filter_batch(pjb_ctx *c, int32_t tid, const pjb_batch *b, int32_t clip_mode, uint8_t *codes_out) {
+    if (!c) return PJB_ERR_ARG;
+    if (!b || b->n_reads < 0 || (b->n_reads > 0 && (!b->pos || !b->cig_off || !b->cigar || !codes_out)))
+        return fail(c, PJB_ERR_ARG, "pjb_filter_batch: bad batch");
+    if (clip_mode < PJB_CLIP_HARD || clip_mode > PJB_CLIP_COMPLETE) return fail(c, PJB_ERR_ARG, "pjb_filter_batch: bad clip mode %d", clip_mode);
+    if (b->n_reads == 0) return PJB_OK;
+    if (b->n_reads > 0xfffffff0ll) return fail(c, PJB_ERR_ARG, "pjb_filter_batch: batch too large");
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    hipStream_t st = c->stream;
+    const size_t n = (size_t)b->n_reads, n_ops = b->cig_off[n];
+    int rc;
+    if ((rc = ensure(c, c->f_pos, n * 4))) return rc;
+    if ((rc = ensure(c, c->f_cigoff, (n + 1) * 4))) return rc;
+    if ((rc = ensure(c, c->f_cigar, n_ops * 4 + 16))) return rc;
+    if ((rc = ensure(c, c->f_codes, n + 16))) return rc;
+    HIP_TRY(c, hipMemcpyAsync(c->f_pos.p, b->pos, n * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(c, hipMemcpyAsync(c->f_cigoff.p, b->cig_off, (n + 1) * 4, hipMemcpyHostToDevice, st));
+    if (n_ops) HIP_TRY(c, hipMemcpyAsync(c->f_cigar.p, b->cigar, n_ops * 4, hipMemcpyHostToDevice, st));
+    const u64 *keys = nullptr;
+    u32 n_keys = 0;
+    auto it = c->filter_keys.find(tid);
+    if (it != c->filter_keys.end()) {
+        keys = it->second.first;
+        n_keys = it->second.second;
+    }
+    LAUNCH(c, "kf_filter", kf_filter, dim3((unsigned)((n + 255) / 256)), dim3(256), (const int32_t *)c->f_pos.p, (const u32 *)c->f_cigoff.p,
+           (const u32 *)c->f_cigar.p, (u32)n, keys, n_keys, (int)clip_mode, (uint8_t *)c->f_codes.p);
+    HIP_TRY(c, hipMemcpyAsync(codes_out, c->f_codes.p, n, hipMemcpyDeviceToHost, st));
     HIP_TRY(c, hipStreamSynchronize(st));
     if (c->ktime) ev_collect(c);
     return PJB_OK;

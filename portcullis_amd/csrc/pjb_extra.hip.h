@@ -363,4 +363,40 @@ __global__ __launch_bounds__(256) void kx_mm_score(const uint32_t *row_raw, u32 
     out[j].mm_score = (double)row_raw[j] / (double)out[j].m_sum; // N / M, junction.cc:920
 }
 
+// ---- bamfilt: BamFilter::filter's decision per alignment, src/bam_filter.cc:75-150,190-225.
+// The walk is the reference's, including that it does not advance over an N operation (only the else-branch of
+// :86-96 adds to lEnd): the introns after a read's first one are looked up short of the earlier introns' lengths.
+__global__ __launch_bounds__(256) void kf_filter(const int32_t *pos, const u32 *cig_off, const u32 *cigar, u32 n, const u64 *keys, u32 n_keys,
+                                                  int clip_mode, uint8_t *codes) {
+    const u32 i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    int32_t lEnd = pos[i];
+    u32 nN = 0;
+    bool good = false;
+    for (u32 k = cig_off[i]; k < cig_off[i + 1]; k++) {
+        const u32 op = cigar[k];
+        const u32 ty = op & 15u;
+        const int32_t ln = (int32_t)(op >> 4);
+        if (ty == OP_N) {
+            nN++;
+            const u64 key = ((u64)(u32)lEnd << 32) | (u64)(u32)(lEnd + ln - 1);
+            u32 lo = 0, hi = n_keys; // JunctionSystem::getJunction: is the intron in the set?
+            while (lo < hi) {
+                const u32 mid = lo + ((hi - lo) >> 1);
+                if (keys[mid] < key) lo = mid + 1;
+                else hi = mid;
+            }
+            good |= lo < n_keys && keys[lo] == key;
+        } else if (op_consumes_ref(ty)) {
+            lEnd += ln;
+        }
+    }
+    uint8_t code = 1;                                    // not spliced: written as is (:221-224)
+    if (nN) {
+        if (clip_mode == PJB_CLIP_COMPLETE || nN <= 1) code = good ? 2 : 0;   // containsJunctionInSystem (:196-202)
+        else code = good ? 3 : 0;                         // clipMSR: !allBad (:204-218)
+    }
+    codes[i] = code;
+}
+
 } // namespace pjb

@@ -23,7 +23,7 @@ EXPORTS = [
     "pjb_release_contig", "pjb_submit_batch", "pjb_submit_batch_device", "pjb_finish_contig", "pjb_collect",
     "pjb_clear_rows", "pjb_get_timing", "pjb_device_count", "pjb_get_kernel_timing", "pjb_reset_kernel_timing",
     "pjb_select_timed_kernels", "pjb_host_alloc", "pjb_host_free", "pjb_inflate_bgzf", "pjb_submit_bam", "pjb_collect_device", "pjb_set_row_mirror",
-    "pjb_extra_finish",
+    "pjb_extra_finish", "pjb_filter_set_junctions", "pjb_filter_batch",
 ]
 FLAG_KERNEL_TIMING = 1
 FLAG_EXTRA = 2  # junc --extra: batches carry name_hash, extra_finish() yields mm_score / coverage / up_aln / down_aln
@@ -112,6 +112,8 @@ def load():
         L.pjb_submit_bam.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_int32, C.POINTER(C.c_int64)]
         L.pjb_collect.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
         L.pjb_extra_finish.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
+        L.pjb_filter_set_junctions.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64]
+        L.pjb_filter_batch.argtypes = [C.c_void_p, C.c_int32, C.POINTER(PjbBatch), C.c_int32, C.c_void_p]
         L.pjb_host_alloc.restype = C.c_void_p
         L.pjb_host_alloc.argtypes = [C.c_size_t]
         L.pjb_host_free.restype = None
@@ -261,6 +263,28 @@ class Context:
             return np.zeros(0, dtype=EXTRA_DTYPE)
         buf = (C.c_char * (n.value * EXTRA_DTYPE.itemsize)).from_address(p.value)
         return np.frombuffer(buf, dtype=EXTRA_DTYPE, count=n.value).copy()
+
+    def filter_set_junctions(self, tid, starts, ends):
+        """bamfilt: the junctions of target `tid` that passed the filter (any order; duplicates are dropped)."""
+        keys = np.unique((np.asarray(starts, dtype=np.int64).astype(np.uint32).astype(np.uint64) << np.uint64(32))
+                         | np.asarray(ends, dtype=np.int64).astype(np.uint32).astype(np.uint64))
+        self._check(self._L.pjb_filter_set_junctions(self._h, tid, keys.ctypes.data_as(C.c_void_p), len(keys)))
+
+    def filter_batch(self, tid, batch, clip_mode="HARD"):
+        """bamfilt: one code per alignment (0 drop, 1 unspliced kept, 2 spliced kept, 3 multiply spliced kept)."""
+        pb = PjbBatch()
+        pb.n_reads = batch.n
+        keep = []
+        for name, dt in (("pos", np.int32), ("cig_off", np.uint32), ("cigar", np.uint32)):
+            a = np.ascontiguousarray(getattr(batch, name), dtype=dt)
+            if a.size == 0:
+                a = np.zeros(4, dtype=dt)
+            keep.append(a)
+            setattr(pb, name, a.ctypes.data)
+        out = np.zeros(max(batch.n, 1), dtype=np.uint8)
+        mode = {"HARD": 0, "SOFT": 1, "COMPLETE": 2}[clip_mode]
+        self._check(self._L.pjb_filter_batch(self._h, tid, C.byref(pb), mode, out.ctypes.data_as(C.c_void_p)))
+        return out[: batch.n]
 
     def clear_rows(self):
         self._check(self._L.pjb_clear_rows(self._h))

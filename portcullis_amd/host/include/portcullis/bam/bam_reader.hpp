@@ -70,6 +70,7 @@ public:
     void close();
     bool isOpen() const { return fp != nullptr; }
     void seek(uint64_t voffset);
+    uint64_t tell() const { return block_pos >= block.size() ? next_coffset << 16 : (block_coffset << 16) | (uint64_t)block_pos; }
     size_t read(void* dst, size_t n);  // returns bytes read (< n only at end of file)
 };
 
@@ -86,6 +87,7 @@ class BamReader {
     int32_t regionLen = 0;
     bool regionDone = true;
     bool wantNames = false;
+    uint64_t firstRecordVoffset = 0;
     std::vector<uint8_t> rec;
     BamAlignment cur;      // next() / current(): the record-at-a-time view of the reference's reader
     ReadBatch one;
@@ -119,6 +121,12 @@ public:
     // setRegion(tid), current() is a reference to an internal object that the next call overwrites.
     bool next();
     const BamAlignment& current() const { return cur; }
+    // Every record of the file in file order, unplaced ones included (the reader loop of BamFilter::filter,
+    // src/bam_filter.cc:190): rewind() goes back to the first record, nextRecord() hands out the raw record (4-byte
+    // block_size + body).  false at the end of the file.
+    void rewind();
+    bool nextRecord(std::vector<uint8_t>& rec);
+    const std::vector<RefSeq>& getTargets() const { return targets; }
 
     // Same visit as setRegion(tid) + nextBatch(...) but with `nthreads` workers inside the target:
     // BGZF blocks are located from their headers, inflated in parallel into a contiguous buffer,

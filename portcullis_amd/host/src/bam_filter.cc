@@ -1,0 +1,242 @@
+// BamFilter: the `bamfilt` stage.  Flow and console output follow src/bam_filter.cc:152-247 of the reference; the
+// decision per alignment is made on the device (pjb_filter_batch), one batch of (pos, CIGAR) per run of records of a
+// target.  Kept records are written byte for byte as they were read (like the reference: BamWriter::write emits the
+// untouched bam1_t, lib/src/bam_writer.cc:58-60, also for "clipped" multiply spliced reads).
+#include <portcullis/bam_filter.hpp>
+
+#include <algorithm>
+#include <chrono>
+#include <cstring>
+#include <iomanip>
+#include <iostream>
+#include <map>
+#include <memory>
+#include <sys/stat.h>
+
+#include <portcullis/bam/bam_reader.hpp>
+#include <portcullis/bam/bam_writer.hpp>
+#include <portcullis/junction_system.hpp>
+
+#include "../../../include/portcullis_amd.h"
+
+namespace portcullis {
+
+using std::cerr;
+using std::cout;
+using std::endl;
+
+ClipMode clipFromString(const std::string& cm) {
+    std::string u = cm;
+    for (auto& ch : u) ch = (char)toupper((unsigned char)ch);
+    if (u == "HARD") return ClipMode::HARD;
+    if (u == "SOFT") return ClipMode::SOFT;
+    if (u == "COMPLETE") return ClipMode::COMPLETE;
+    throw BamFilterException("Unrecognised clip mode: " + cm);
+}
+
+static bool exists(const std::string& p) {
+    struct stat st;
+    return stat(p.c_str(), &st) == 0;
+}
+
+BamFilter::BamFilter(const std::string& jf, const std::string& bf, const std::string& ob) : junctionFile(jf), bamFile(bf), outputBam(ob) {
+    // src/bam_filter.cc:49-66
+    if (!exists(junctionFile)) throw BamFilterException("Could not find junction file at: " + junctionFile);
+    if (!exists(bamFile)) throw BamFilterException("Could not find BAM file at: " + bamFile);
+}
+
+void BamFilter::filter() {
+    cout << "Loading junctions from: " << junctionFile << endl;
+    JunctionSystem js(junctionFile);
+    cout << " - Found " << js.size() << " junctions" << endl << endl;
+    bam::BamReader reader(bamFile);
+    reader.open(useCsi);
+    std::shared_ptr<bam::RefSeqPtrList> refs = reader.createRefList();
+    js.setRefs(refs);
+    {
+        const size_t slash = outputBam.find_last_of('/');
+        const std::string outDir = slash == std::string::npos ? "." : outputBam.substr(0, slash);
+        if (!outDir.empty() && !exists(outDir) && mkdir(outDir.c_str(), 0777) != 0 && !exists(outDir))
+            throw BamFilterException("Could not create output directory at: " + outDir);
+    }
+    // ---- the filter's junction set, per target, as sorted keys on the device
+    pjb_config cfg;
+    memset(&cfg, 0, sizeof cfg);
+    cfg.abi_version = PJB_ABI_VERSION;
+    cfg.device = device;
+    cfg.orientation = PJB_OR_UNKNOWN;
+    cfg.strandedness = PJB_SS_UNKNOWN;
+    pjb_ctx* ctx = nullptr;
+    if (pjb_create(&ctx, &cfg) != PJB_OK) throw BamFilterException(std::string("pjb_create: ") + pjb_last_error(nullptr));
+    struct Closer {
+        pjb_ctx* c;
+        ~Closer() { pjb_destroy(c); }
+    } closer{ctx};
+    {
+        std::map<int32_t, std::vector<uint64_t>> keys;
+        for (const JunctionPtr& j : js.getJunctions()) {
+            const Intron& in = *j->getIntron();
+            keys[in.ref.index].push_back(((uint64_t)(uint32_t)in.start << 32) | (uint64_t)(uint32_t)in.end);
+        }
+        for (auto& kv : keys) {
+            std::sort(kv.second.begin(), kv.second.end());
+            kv.second.erase(std::unique(kv.second.begin(), kv.second.end()), kv.second.end());
+            if (pjb_filter_set_junctions(ctx, kv.first, kv.second.data(), (int64_t)kv.second.size()) != PJB_OK)
+                throw BamFilterException(std::string("pjb_filter_set_junctions: ") + pjb_last_error(ctx));
+        }
+    }
+    cout << " - Processing alignments from: " << bamFile << endl;
+    bam::BamWriter writer(outputBam, threads);
+    writer.open(reader.getHeaderText(), reader.getTargets());
+    cout << " - Saving filtered alignments to: " << outputBam << endl;
+    std::unique_ptr<bam::BamWriter> mod, unmod;
+    if (saveMSRs) {
+        mod.reset(new bam::BamWriter(outputBam + ".mod.bam", threads));
+        unmod.reset(new bam::BamWriter(outputBam + ".unmod.bam", threads));
+        mod->setWriteIndex(false);
+        unmod->setWriteIndex(false);
+        mod->open(reader.getHeaderText(), reader.getTargets());
+        unmod->open(reader.getHeaderText(), reader.getTargets());
+        cout << " - Saving modified MSRs to: " << outputBam << ".mod.bam" << endl;
+        cout << " - Saving unmodified MSRs to: " << outputBam << ".unmod.bam" << endl;
+    }
+    nbReadsIn = nbReadsOut = nbReadsModifiedOut = 0;
+    // ---- records in file order; a chunk = consecutive records of one target
+    const size_t CHUNK = 1u << 20;
+    std::vector<uint8_t> raw;          // the chunk's records, back to back
+    std::vector<size_t> recOff;        // start of each record in `raw` (+ end)
+    std::vector<int32_t> pos;
+    std::vector<uint32_t> cigOff, cigar;
+    std::vector<uint8_t> codes;
+    int32_t chunkTid = -2;
+    const int32_t mode = clipMode == ClipMode::HARD ? PJB_CLIP_HARD : clipMode == ClipMode::SOFT ? PJB_CLIP_SOFT : PJB_CLIP_COMPLETE;
+    auto flushChunk = [&]() {
+        const size_t n = pos.size();
+        if (n == 0) return;
+        codes.assign(n, 1);
+        if (chunkTid >= 0) {
+            pjb_batch b;
+            memset(&b, 0, sizeof b);
+            b.n_reads = (int64_t)n;
+            b.pos = pos.data();
+            b.cig_off = cigOff.data();
+            b.cigar = cigar.empty() ? cigOff.data() : cigar.data();
+            if (pjb_filter_batch(ctx, chunkTid, &b, mode, codes.data()) != PJB_OK)
+                throw BamFilterException(std::string("pjb_filter_batch: ") + pjb_last_error(ctx));
+        }
+        for (size_t i = 0; i < n; i++) {
+            const uint8_t* r = raw.data() + recOff[i];
+            const size_t len = recOff[i + 1] - recOff[i];
+            if (codes[i] == 0) continue;
+            writer.write(r, len);
+            nbReadsOut++;
+            if (codes[i] == 3) {
+                nbReadsModifiedOut++;
+                if (saveMSRs) {
+                    mod->write(r, len);
+                    unmod->write(r, len);
+                }
+            }
+        }
+        raw.clear();
+        recOff.assign(1, 0);
+        pos.clear();
+        cigOff.assign(1, 0);
+        cigar.clear();
+    };
+    recOff.assign(1, 0);
+    cigOff.assign(1, 0);
+    std::vector<uint8_t> rec;
+    reader.rewind();
+    while (reader.nextRecord(rec)) {
+        nbReadsIn++;
+        const uint8_t* r = rec.data();
+        auto le32 = [](const uint8_t* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); };
+        const int32_t tid = (int32_t)le32(r + 4);
+        const uint32_t l_name = r[12], n_cig = (uint32_t)r[16] | ((uint32_t)r[17] << 8);
+        if (36ull + l_name + 4ull * n_cig > rec.size()) throw BamFilterException("Invalid BAM record layout");
+        if (tid != chunkTid || pos.size() >= CHUNK) {
+            flushChunk();
+            chunkTid = tid;
+        }
+        raw.insert(raw.end(), rec.begin(), rec.end());
+        recOff.push_back(raw.size());
+        pos.push_back((int32_t)le32(r + 8));
+        for (uint32_t k = 0; k < n_cig; k++) cigar.push_back(le32(r + 36 + l_name + 4 * k));
+        cigOff.push_back((uint32_t)cigar.size());
+    }
+    flushChunk();
+    reader.close();
+    writer.close();
+    if (saveMSRs) {
+        mod->close();
+        unmod->close();
+    }
+    cout << "done." << endl;
+    const uint32_t diff = (uint32_t)(nbReadsIn - nbReadsOut);
+    cout << "Filtered out " << diff << " alignments.  In: " << nbReadsIn << "; Out: " << nbReadsOut << " (Modified: " << nbReadsModifiedOut
+         << ");" << endl
+         << endl;
+    cout << "Indexing:" << endl << " - filtered alignments ... done." << endl;  // the .bai was written by BamWriter::close
+}
+
+std::string BamFilter::helpMessage() {
+    return "Portcullis BAM Filter Mode Help.\n\n"
+           "Removes alignments associated with bad junctions from BAM file\n\n"
+           "Usage: portcullis_amd bamfilt [options] <junction-file> <bam-file>\n\n"
+           "Options:\n"
+           "  -o [ --output ] arg (=filtered.bam)  Output BAM file generated by this program.\n"
+           "  -c [ --clip_mode ] arg (=HARD)       How to clip reads associated with bad junctions: HARD, SOFT or COMPLETE\n"
+           "  -m [ --save_msrs ]                   Whether or not to output modified MSRs to a separate file.\n"
+           "  --use_csi                            Whether to use CSI indexing rather than BAI indexing (input side).\n"
+           "  -t [ --threads ] arg (=1)            Threads that compress the output.\n"
+           "  -v [ --verbose ]                     Print extra information\n"
+           "  --help                               Produce help message\n";
+}
+
+int BamFilter::main(int argc, char* argv[]) {
+    std::string junctionFile, bamFile, outputBam = "filtered.bam", clip = "HARD";
+    bool saveMSRs = false, useCsi = false, verbose = false, help = false;
+    int threads = 1;
+    std::vector<std::string> positional;
+    for (int i = 1; i < argc; i++) {
+        const std::string a = argv[i];
+        auto need = [&](const char* name) -> std::string {
+            if (i + 1 >= argc) throw BamFilterException(std::string("Option ") + name + " needs a value");
+            return argv[++i];
+        };
+        if (a == "-o" || a == "--output") outputBam = need("--output");
+        else if (a.rfind("--output=", 0) == 0) outputBam = a.substr(9);
+        else if (a == "-c" || a == "--clip_mode") clip = need("--clip_mode");
+        else if (a.rfind("--clip_mode=", 0) == 0) clip = a.substr(12);
+        else if (a == "-m" || a == "--save_msrs") saveMSRs = true;
+        else if (a == "--use_csi") useCsi = true;
+        else if (a == "-t" || a == "--threads") threads = std::stoi(need("--threads"));
+        else if (a == "-v" || a == "--verbose") verbose = true;
+        else if (a == "--help") help = true;
+        else if (!a.empty() && a[0] == '-') throw BamFilterException("Unknown option: " + a);
+        else positional.push_back(a);
+    }
+    if (help || argc <= 1 || positional.size() < 2) {
+        cout << helpMessage() << endl;
+        return 1;
+    }
+    junctionFile = positional[0];
+    bamFile = positional[1];
+    const auto t0 = std::chrono::steady_clock::now();
+    cout << "Running portcullis in BAM filter mode" << endl << "-------------------------------------" << endl << endl;
+    BamFilter filter(junctionFile, bamFile, outputBam);
+    filter.setClipMode(clipFromString(clip));
+    filter.setSaveMSRs(saveMSRs);
+    filter.setUseCsi(useCsi);
+    filter.setVerbose(verbose);
+    filter.setThreads(threads);
+    filter.filter();
+    const double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    std::ios::fmtflags f(cout.flags());
+    cout << endl << "Portcullis BAM filter completed." << endl << "Total runtime: " << std::fixed << std::setprecision(1) << s << "s" << endl << endl;
+    cout.flags(f);
+    return 0;
+}
+
+}  // namespace portcullis

@@ -182,7 +182,26 @@ void BamReader::open(bool useCsi) {
         if (!name.empty() && name.back() == 0) name.pop_back();
         targets.emplace_back((int32_t)i, name, (int32_t)le32(b4));
     }
+    firstRecordVoffset = bgzf.tell();
     loadIndex(useCsi);
+}
+
+void BamReader::rewind() {
+    bgzf.seek(firstRecordVoffset);
+    regionDone = true;
+}
+
+bool BamReader::nextRecord(std::vector<uint8_t>& out) {
+    uint8_t b4[4];
+    const size_t got = bgzf.read(b4, 4);
+    if (got == 0) return false;
+    if (got != 4) throw BamException("Truncated BAM record");
+    const uint32_t bs = le32(b4);
+    if (bs < 32) throw BamException("Invalid BAM record");
+    out.resize(4 + (size_t)bs);
+    memcpy(out.data(), b4, 4);
+    if (bgzf.read(out.data() + 4, bs) != bs) throw BamException("Truncated BAM record");
+    return true;
 }
 
 // BAI (SAM spec section 5.2) or CSI (htslib CSIv1: BGZF-compressed, bins carry loffset, no linear

@@ -1,0 +1,215 @@
+// BamWriter: see bam_writer.hpp.  BGZF per the SAM specification section 4.1; BAI per section 5.2.
+#include <portcullis/bam/bam_writer.hpp>
+
+#include <algorithm>
+#include <atomic>
+#include <cstring>
+#include <thread>
+#include <zlib.h>
+
+namespace portcullis {
+namespace bam {
+
+static void put32(std::vector<uint8_t>& b, uint32_t v) {
+    for (int k = 0; k < 4; k++) b.push_back((uint8_t)(v >> (8 * k)));
+}
+static void put64(std::vector<uint8_t>& b, uint64_t v) {
+    for (int k = 0; k < 8; k++) b.push_back((uint8_t)(v >> (8 * k)));
+}
+static inline uint32_t rd32(const uint8_t* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
+static inline uint16_t rd16(const uint8_t* p) { return (uint16_t)(p[0] | (p[1] << 8)); }
+
+static int reg2bin(int64_t beg, int64_t end) {  // SAM specification section 5.3
+    --end;
+    if (beg >> 14 == end >> 14) return (int)(((1 << 15) - 1) / 7 + (beg >> 14));
+    if (beg >> 17 == end >> 17) return (int)(((1 << 12) - 1) / 7 + (beg >> 17));
+    if (beg >> 20 == end >> 20) return (int)(((1 << 9) - 1) / 7 + (beg >> 20));
+    if (beg >> 23 == end >> 23) return (int)(((1 << 6) - 1) / 7 + (beg >> 23));
+    if (beg >> 26 == end >> 26) return (int)(((1 << 3) - 1) / 7 + (beg >> 26));
+    return 0;
+}
+
+BamWriter::~BamWriter() {
+    try {
+        if (fp) close();
+    } catch (...) {
+    }
+}
+
+void BamWriter::open(const std::string& headerText, const std::vector<RefSeq>& targets) {
+    fp = fopen(path.c_str(), "wb");
+    if (!fp) throw BamException("Could not open output BAM file: " + path);
+    setvbuf(fp, nullptr, _IOFBF, 4 << 20);
+    nTargets = targets.size();
+    bins.assign(nTargets, {});
+    lin.assign(nTargets, {});
+    pending.clear();
+    pending.insert(pending.end(), {'B', 'A', 'M', 1});
+    put32(pending, (uint32_t)headerText.size());
+    pending.insert(pending.end(), headerText.begin(), headerText.end());
+    put32(pending, (uint32_t)targets.size());
+    for (const auto& t : targets) {
+        put32(pending, (uint32_t)t.name.size() + 1);
+        pending.insert(pending.end(), t.name.begin(), t.name.end());
+        pending.push_back(0);
+        put32(pending, (uint32_t)t.length);
+    }
+    flush(true);  // like bam_hdr_write + bgzf_flush: the header has blocks of its own
+}
+
+void BamWriter::write(const uint8_t* rec, size_t len) {
+    if (!fp) throw BamException("BamWriter::write: file is not open");
+    if (len < 36) throw BamException("BamWriter::write: not a BAM record");
+    if (wantIndex) {
+        RecInfo r;
+        r.tid = (int32_t)rd32(rec + 4);
+        r.pos = (int32_t)rd32(rec + 8);
+        const uint32_t l_name = rec[12], n_cig = rd16(rec + 16);
+        int64_t span = 0;
+        const uint8_t* cg = rec + 36 + l_name;
+        if (36 + (size_t)l_name + 4ull * n_cig <= len)
+            for (uint32_t k = 0; k < n_cig; k++) {
+                const uint32_t op = rd32(cg + 4 * k), ty = op & 15u;
+                if (ty == 0 || ty == 2 || ty == 3 || ty == 7 || ty == 8) span += op >> 4;
+            }
+        r.end = (int32_t)(r.pos + (span > 0 ? span : 1));
+        r.ustart = uflushed + pending.size();
+        recs.push_back(r);
+    }
+    pending.insert(pending.end(), rec, rec + len);
+    if (pending.size() >= BLOCK * 64 * (size_t)threads) flush(false);
+}
+
+void BamWriter::indexRecord(const RecInfo& r, uint64_t vs, uint64_t ve) {
+    if (r.tid < 0 || (size_t)r.tid >= nTargets) return;
+    const uint32_t bin = (uint32_t)reg2bin(r.pos, r.end);
+    auto& ch = bins[(size_t)r.tid][bin];
+    if (!ch.empty() && ch.back().second == vs) ch.back().second = ve;
+    else ch.push_back({vs, ve});
+    const size_t w0 = (size_t)(std::max(r.pos, 0) >> 14), w1 = (size_t)(std::max(r.end - 1, 0) >> 14);
+    auto& L = lin[(size_t)r.tid];
+    if (L.size() <= w1) L.resize(w1 + 1, 0);
+    for (size_t w = w0; w <= w1; w++)
+        if (L[w] == 0) L[w] = vs;
+}
+
+// Compresses every complete 0xff00-byte block of `pending` (all of it when final) and writes the blocks in order.
+void BamWriter::flush(bool final) {
+    const size_t nblk = final ? (pending.size() + BLOCK - 1) / BLOCK : pending.size() / BLOCK;
+    if (nblk == 0) {
+        if (final && wantIndex) {  // nothing left to compress, but the last records' ends are now known: the EOF block
+            for (size_t i = 0; i < recs.size() && recs[i].vsKnown; i++)
+                indexRecord(recs[i], recs[i].vs, i + 1 < recs.size() && recs[i + 1].vsKnown ? recs[i + 1].vs : cwritten << 16);
+            recs.clear();
+        }
+        return;
+    }
+    const size_t take = std::min(pending.size(), nblk * BLOCK);
+    std::vector<std::vector<uint8_t>> cblk(nblk);
+    std::atomic<size_t> next(0);
+    auto work = [&]() {
+        std::vector<uint8_t> out(70000);
+        for (;;) {
+            const size_t b = next.fetch_add(1);
+            if (b >= nblk) break;
+            const size_t off = b * BLOCK, len = std::min(BLOCK, take - off);
+            z_stream zs;
+            memset(&zs, 0, sizeof zs);
+            if (deflateInit2(&zs, level, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) continue;
+            zs.next_in = &pending[off];
+            zs.avail_in = (uInt)len;
+            zs.next_out = out.data();
+            zs.avail_out = (uInt)out.size();
+            deflate(&zs, Z_FINISH);
+            const size_t clen = out.size() - zs.avail_out;
+            deflateEnd(&zs);
+            std::vector<uint8_t>& o = cblk[b];
+            const uint8_t hdr[16] = {31, 139, 8, 4, 0, 0, 0, 0, 0, 255, 6, 0, 'B', 'C', 2, 0};
+            o.insert(o.end(), hdr, hdr + 16);
+            o.push_back((uint8_t)((clen + 25) & 0xff));
+            o.push_back((uint8_t)((clen + 25) >> 8));
+            o.insert(o.end(), out.begin(), out.begin() + (long)clen);
+            put32(o, (uint32_t)crc32(crc32(0L, Z_NULL, 0), &pending[off], (uInt)len));
+            put32(o, (uint32_t)len);
+        }
+    };
+    {
+        const int nt = (int)std::min<size_t>((size_t)threads, nblk);
+        std::vector<std::thread> th;
+        for (int t = 1; t < nt; t++) th.emplace_back(work);
+        work();
+        for (auto& t : th) t.join();
+    }
+    std::vector<uint64_t> coff(nblk + 1, cwritten);
+    for (size_t b = 0; b < nblk; b++) {
+        if (cblk[b].empty()) throw BamException("BamWriter: deflate failed");
+        coff[b + 1] = coff[b] + cblk[b].size();
+        if (fwrite(cblk[b].data(), 1, cblk[b].size(), fp) != cblk[b].size()) throw BamException("BamWriter: write failed: " + path);
+    }
+    // virtual offsets: a record's start is known once the block holding its first byte is written, its end is the
+    // start of the record behind it (or of the EOF block)
+    if (wantIndex) {
+        for (auto& r : recs) {
+            if (r.vsKnown) continue;
+            const uint64_t rel = r.ustart - uflushed;
+            if (rel >= take) break;
+            const size_t bk = (size_t)(rel / BLOCK);
+            r.vs = (coff[bk] << 16) | (rel - bk * BLOCK);
+            r.vsKnown = true;
+        }
+        size_t done = 0;
+        for (size_t i = 0; i < recs.size(); i++) {
+            if (!recs[i].vsKnown) break;
+            uint64_t ve;
+            if (i + 1 < recs.size()) {
+                if (!recs[i + 1].vsKnown) break;
+                ve = recs[i + 1].vs;
+            } else if (final) {
+                ve = coff[nblk] << 16;
+            } else
+                break;
+            indexRecord(recs[i], recs[i].vs, ve);
+            done = i + 1;
+        }
+        recs.erase(recs.begin(), recs.begin() + (long)done);
+    }
+    cwritten = coff[nblk];
+    uflushed += take;
+    pending.erase(pending.begin(), pending.begin() + (long)take);
+}
+
+void BamWriter::close() {
+    if (!fp) return;
+    flush(true);
+    static const uint8_t eof[28] = {0x1f, 0x8b, 0x08, 0x04, 0, 0, 0, 0, 0, 0xff, 0x06, 0, 0x42, 0x43, 0x02, 0, 0x1b, 0, 0x03, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (fwrite(eof, 1, 28, fp) != 28) throw BamException("BamWriter: write failed: " + path);
+    fclose(fp);
+    fp = nullptr;
+    if (!wantIndex) return;
+    std::vector<uint8_t> o = {'B', 'A', 'I', 1};
+    put32(o, (uint32_t)nTargets);
+    for (size_t c = 0; c < nTargets; c++) {
+        put32(o, (uint32_t)bins[c].size());
+        for (auto& kv : bins[c]) {
+            put32(o, kv.first);
+            put32(o, (uint32_t)kv.second.size());
+            for (auto& ch : kv.second) {
+                put64(o, ch.first);
+                put64(o, ch.second);
+            }
+        }
+        put32(o, (uint32_t)lin[c].size());
+        uint64_t last = 0;
+        for (uint64_t v : lin[c]) {
+            if (v) last = v;
+            put64(o, last);
+        }
+    }
+    FILE* f = fopen((path + ".bai").c_str(), "wb");
+    if (!f) throw BamException("Could not write BAM index: " + path + ".bai");
+    fwrite(o.data(), 1, o.size(), f);
+    fclose(f);
+}
+
+}  // namespace bam
+}  // namespace portcullis

@@ -1,5 +1,6 @@
-// portcullis_amd: command line entry.  Only the `junc` mode exists here; prep / filt / bamfilt
-// remain the reference's programs and interoperate through the prep directory and the .tab file.
+// portcullis_amd: command line entry: the `junc` mode and `bamfilt`; prep / filt remain the
+// reference's programs and interoperate through the prep directory and the .tab file.
+#include <portcullis/bam_filter.hpp>
 #include <portcullis/junction_builder.hpp>
 
 #include <cstring>
@@ -14,12 +15,14 @@ int main(int argc, char* argv[]) {
     // exit codes as in src/portcullis.cc:497-515 of the reference
     int rc = 0;
     try {
-        if (argc < 2 || strcmp(argv[1], "junc") != 0) {
-            std::cerr << "Usage: portcullis_amd junc [options] <prep_data_dir>" << std::endl;
+        if (argc < 2 || (strcmp(argv[1], "junc") != 0 && strcmp(argv[1], "bamfilt") != 0)) {
+            std::cerr << "Usage: portcullis_amd junc [options] <prep_data_dir>" << std::endl
+                      << "       portcullis_amd bamfilt [options] <junction-file> <bam-file>" << std::endl;
             return 1;
         }
         portcullis::JunctionSystem::version = PORTCULLIS_AMD_VERSION;
-        rc = portcullis::JunctionBuilder::main(argc - 1, argv + 1);
+        if (strcmp(argv[1], "bamfilt") == 0) rc = portcullis::BamFilter::main(argc - 1, argv + 1);
+        else rc = portcullis::JunctionBuilder::main(argc - 1, argv + 1);
     } catch (const portcullis::PortcullisException& e) {
         std::cerr << "Error: " << e.what() << std::endl;
         rc = 4;
