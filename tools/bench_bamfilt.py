@@ -44,7 +44,7 @@ def main():
     n = d["n_reads"]
     alg = n * (4 + 4 + 1) + 4 * d["n_cigar_ops"] + 8 * d["n_pairs"]
     kms = kt[1] / kt[0]
-    m = 1_000_000
+    m = 200_000
     sub = hb.slice(0, m)
     t0 = time.perf_counter()
     want = orc.bamfilt_flags(sub.to_oracle(), rows["start"][keep], rows["end"][keep], "HARD")
