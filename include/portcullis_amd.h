@@ -294,6 +294,31 @@ int pjb_inflate_bgzf(pjb_ctx* ctx, const uint8_t* comp, int64_t comp_bytes, uint
  * Errors: PJB_ERR_BGZF for corrupt BGZF / DEFLATE / BAM record data. */
 int pjb_submit_bam(pjb_ctx* ctx, int32_t tid, const uint8_t* comp, int64_t comp_bytes, int32_t first_uoffset, int64_t* n_records);
 
+/* ---- `portcullis filt` feature rows -------------------------------------------------------
+ * ModelFeatures::setRow (lib/src/model_features.cc:161-212) for a list of junctions: the columns of VAR_NAMES +
+ * JAD_NAMES (lib/include/portcullis/ml/model_features.hpp:45-60), i.e. the row getters, calcIntronScore
+ * (lib/src/junction.cc:953-956), Junction::calcCodingPotential / calcSplicingScores /
+ * calcJunctionAnchorDepthLogDeviation (lib/src/junction.cc:1328-1391) with the Markov scores of
+ * KmerMarkovModel::getScore / PosMarkovModel::getScore (lib/src/markov_model.cc:57-78,101-115) over genome windows.
+ * The models arrive as dense tables over the alphabet makeClean leaves (A C G T N -> 0..4): a k-mer model of order
+ * 5 is [5^5 contexts][5 next letters] probabilities (0 = never seen), a position model [PJB_PW_LEN positions][5].
+ * A NULL table is an untrained model.  *_size: the reference's model.size() (contexts / positions trained; 0 =
+ * empty -> the column is 0 as isCodingPotentialModelEmpty / isPWModelEmpty make it).  The genome of every target
+ * the junctions lie on must have been uploaded (pjb_upload_contig).  mean_read_length: what
+ * Junction::setMeanReadLength stored (the truncated mean, lib/include/portcullis/junction.hpp:928). */
+#define PJB_N_FEATURES 34
+#define PJB_KMER_ORDER 5
+#define PJB_KMER_TABLE (3125 * 5)
+#define PJB_PW_LEN 32
+typedef struct pjb_markov_models {
+    const double *exon, *intron;                               /* coding potential, ModelFeatures::exonModel / intronModel */
+    const double *donor_t, *donor_f, *acceptor_t, *acceptor_f; /* splicing signal: true / false models */
+    const double *donor_pw, *acceptor_pw;                      /* position weights, order 1 */
+    int32_t exon_size, intron_size, donor_pw_size, acceptor_pw_size;
+} pjb_markov_models;
+int pjb_filt_features(pjb_ctx *ctx, const pjb_junction_row *rows, int64_t n_rows, double mean_read_length, uint32_t l95,
+                      const pjb_markov_models *models, double *features_out /* n_rows x PJB_N_FEATURES, host */);
+
 /* ---- `portcullis bamfilt` ----------------------------------------------------------------
  * The per-alignment decision of BamFilter::filter (src/bam_filter.cc:152-247): walk the CIGAR as
  * BamFilter::containsJunctionInSystem / clipMSR do (src/bam_filter.cc:75-150) and probe the set of junctions that

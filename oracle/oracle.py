@@ -380,6 +380,44 @@ def bamfilt_flags(soa, js_start, js_end, clip_mode="HARD"):
     return out[: int(r.n)]
 
 
+N_FEATURES, KMER_TABLE, PW_LEN = 34, 3125 * 5, 32
+
+
+def filt_features(ref_lens, genomes, rows, l95_idx, cp_idx, pass_idx, fail_idx):
+    """ModelFeatures: train (L95, coding potential, splicing models) and one feature row per junction.
+    genomes: {tid: str/bytes}.  Returns (features [n, 34], models dict in the layout pjb_filt_features takes, L95)."""
+    L = lib()
+    n = len(ref_lens)
+    lens = np.ascontiguousarray(ref_lens, dtype=np.int32)
+    bufs = [(genomes[t].encode() if isinstance(genomes.get(t), str) else bytes(genomes.get(t, b""))) for t in range(n)]
+    gp = (C.c_char_p * n)(*bufs)
+    rows = np.ascontiguousarray(rows)
+
+    def idx(a):
+        a = np.ascontiguousarray(a, dtype=np.int64)
+        return a, a.ctypes.data_as(C.c_void_p), C.c_int64(len(a))
+
+    a1, p1, n1 = idx(l95_idx)
+    a2, p2, n2 = idx(cp_idx)
+    a3, p3, n3 = idx(pass_idx)
+    a4, p4, n4 = idx(fail_idx)
+    F = np.zeros((max(len(rows), 1), N_FEATURES), dtype=np.float64)
+    M = np.zeros(6 * KMER_TABLE + 2 * PW_LEN * 5 + 8, dtype=np.float64)
+    l95 = C.c_uint32()
+    rc = L.orc_filt_features(C.c_int32(n), lens.ctypes.data_as(C.c_void_p), gp, rows.ctypes.data_as(C.c_void_p), C.c_int64(len(rows)),
+                             p1, n1, p2, n2, p3, n3, p4, n4, F.ctypes.data_as(C.c_void_p), M.ctypes.data_as(C.c_void_p), C.byref(l95))
+    if rc < 0:
+        _err(rc)
+    names = ["exon", "intron", "donor_t", "donor_f", "acceptor_t", "acceptor_f"]
+    models = {nm: M[k * KMER_TABLE:(k + 1) * KMER_TABLE].copy() for k, nm in enumerate(names)}
+    o = 6 * KMER_TABLE
+    models["donor_pw"] = M[o:o + PW_LEN * 5].copy()
+    models["acceptor_pw"] = M[o + PW_LEN * 5:o + 2 * PW_LEN * 5].copy()
+    tail = M[o + 2 * PW_LEN * 5:]
+    models.update(exon_size=int(tail[0]), intron_size=int(tail[1]), donor_pw_size=int(tail[2]), acceptor_pw_size=int(tail[3]))
+    return F[: len(rows)], models, int(l95.value)
+
+
 def finalize(rows, mean_query_len):
     rows = np.ascontiguousarray(rows)
     lib().orc_finalize(rows.ctypes.data_as(C.c_void_p), len(rows), C.c_double(mean_query_len))

@@ -1342,6 +1342,242 @@ int orc_bamfilt_flags(const orc_reads *rd, const int32_t *S, const int32_t *E, i
 }
 
 /* ------------------------------------------------------------------ */
+/* filt: Markov models and the feature rows                           */
+/* ------------------------------------------------------------------ */
+/* SeqUtils::makeClean, seq_utils.hpp:54-60: upper-case, anything but A C G T becomes N */
+static int clean_code(char c) {
+    c = up(c);
+    return c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : c == 'T' ? 3 : 4;
+}
+static void make_clean(const sbuf *in, sbuf *out) {
+    out->n = 0;
+    for (size_t i = 0; i < in->n; i++) {
+        char c = "ACGTN"[clean_code(in->p[i])];
+        sb_put(out, &c, 1);
+    }
+}
+/* KmerMarkovModel (lib/src/markov_model.cc:31-78) as a dense table over the cleaned alphabet; `seen` marks the
+ * contexts the unordered_map holds (model.size() of :88-90 is their count) */
+typedef struct {
+    int order;
+    double *tab;      /* [5^order][5] counts, then probabilities */
+    uint8_t *seen;    /* [5^order] */
+    size_t n_ctx;
+} kmm;
+static size_t pow5(int k) { size_t r = 1; while (k-- > 0) r *= 5; return r; }
+static int kmm_init(kmm *m, int order) {
+    m->order = order;
+    m->n_ctx = pow5(order);
+    m->tab = (double *)calloc(m->n_ctx * 5, sizeof(double));
+    m->seen = (uint8_t *)calloc(m->n_ctx, 1);
+    return m->tab && m->seen ? 0 : -1;
+}
+static void kmm_free(kmm *m) { free(m->tab); free(m->seen); }
+static size_t ctx_index(const char *s, int order) {
+    size_t x = 0;
+    for (int k = 0; k < order; k++) x = x * 5 + (size_t)clean_code(s[k]);
+    return x;
+}
+static void kmm_count(kmm *m, const sbuf *clean) { /* train, :34-41: only strings longer than order + 1 */
+    if (clean->n > (size_t)m->order + 1)
+        for (size_t i = (size_t)m->order; i < clean->n; i++) {
+            size_t c = ctx_index(clean->p + i - m->order, m->order);
+            m->tab[c * 5 + (size_t)clean_code(clean->p[i])] += 1.0;
+            m->seen[c] = 1;
+        }
+}
+static void kmm_normalise(kmm *m) { /* :43-53 */
+    for (size_t c = 0; c < m->n_ctx; c++) {
+        double sum = 0;
+        for (int k = 0; k < 5; k++) sum += m->tab[c * 5 + k];
+        if (sum > 0)
+            for (int k = 0; k < 5; k++) m->tab[c * 5 + k] = m->tab[c * 5 + k] / sum;
+    }
+}
+static size_t kmm_size(const kmm *m) { size_t n = 0; for (size_t c = 0; c < m->n_ctx; c++) n += m->seen[c]; return n; }
+static double kmm_score(kmm *m, const sbuf *raw) { /* getScore, :57-78 (operator[] inserts the contexts it looks up) */
+    sbuf s = {0};
+    make_clean(raw, &s);
+    double score = 1.0;
+    uint32_t no_count = 0;
+    for (size_t i = (size_t)m->order; i < s.n; i++) {
+        size_t c = ctx_index(s.p + i - m->order, m->order);
+        m->seen[c] = 1;
+        double v = m->tab[c * 5 + (size_t)clean_code(s.p[i])];
+        if (v != 0.0) score *= v;
+        else no_count++;
+    }
+    sb_free(&s);
+    if (score == 0.0) return -100.0;
+    else if (no_count > 2) score /= ((double)no_count * 0.5);
+    return log(score);
+}
+/* PosMarkovModel, markov_model.cc:80-115 */
+typedef struct { int order; double tab[ORC_PW_LEN][5]; uint8_t seen[ORC_PW_LEN]; } pmm;
+static void pmm_count(pmm *m, const sbuf *clean) {
+    for (size_t i = (size_t)m->order; i < clean->n && i < ORC_PW_LEN; i++) {
+        m->tab[i][clean_code(clean->p[i])] += 1.0;
+        m->seen[i] = 1;
+    }
+}
+static void pmm_normalise(pmm *m) {
+    for (int i = 0; i < ORC_PW_LEN; i++) {
+        double sum = 0;
+        for (int k = 0; k < 5; k++) sum += m->tab[i][k];
+        if (sum > 0)
+            for (int k = 0; k < 5; k++) m->tab[i][k] = m->tab[i][k] / sum;
+    }
+}
+static size_t pmm_size(const pmm *m) { size_t n = 0; for (int i = 0; i < ORC_PW_LEN; i++) n += m->seen[i]; return n; }
+static double pmm_score(pmm *m, const sbuf *raw) {
+    sbuf s = {0};
+    make_clean(raw, &s);
+    double score = 1.0;
+    for (size_t i = (size_t)m->order; i < s.n && i < ORC_PW_LEN; i++) {
+        m->seen[i] = 1;
+        score *= m->tab[i][clean_code(s.p[i])];
+    }
+    sb_free(&s);
+    if (score == 0.0) return -300.0;
+    return log(score);
+}
+/* gmap.fetchBases + SeqUtils::reverseComplement when the consensus strand is negative.  The reference does not
+ * upper-case the fetched bases first, so a lower-case letter indexes REVCOMP_LOOKUP (26 entries from 'A') out of
+ * bounds there -- undefined behaviour.  Here the bases are upper-cased first, as the junc stage does with everything it
+ * fetches (junction.cc:586-587,635-638); for upper-case contigs the two are the same thing. */
+static void fetch_oriented(const char *genome, int32_t glen, int32_t beg, int32_t end, int neg, sbuf *out) {
+    out->n = 0;
+    fetch_bases(genome, glen, beg, end, out);
+    to_upper(out);
+    if (neg && out->n) {
+        char *tmp = (char *)malloc(out->n);
+        orc_revcomp(out->p, out->n, tmp);
+        memcpy(out->p, tmp, out->n);
+        free(tmp);
+    }
+}
+static int cmp_u32(const void *a, const void *b) {
+    uint32_t x = *(const uint32_t *)a, y = *(const uint32_t *)b;
+    return x < y ? -1 : x > y;
+}
+
+int orc_filt_features(int32_t n_refs, const int32_t *ref_len, const char *const *genomes, const orc_row *rows, int64_t n_rows,
+                      const int64_t *l95_idx, int64_t n_l95, const int64_t *cp_idx, int64_t n_cp, const int64_t *pass_idx,
+                      int64_t n_pass, const int64_t *fail_idx, int64_t n_fail, double *F, double *models_out, uint32_t *l95_out) {
+    kmm exon, intron, donT, donF, accT, accF;
+    pmm donP, accP;
+    memset(&donP, 0, sizeof donP);
+    memset(&accP, 0, sizeof accP);
+    donP.order = accP.order = 1;
+    if (kmm_init(&exon, 5) || kmm_init(&intron, 5) || kmm_init(&donT, 5) || kmm_init(&donF, 5) || kmm_init(&accT, 5) || kmm_init(&accF, 5))
+        return fail(ORC_ERR_NOMEM, "oom");
+    sbuf a = {0}, b = {0}, cl = {0};
+    /* calcIntronThreshold, model_features.cc:67-75 */
+    uint32_t L95 = 0;
+    if (n_l95 > 0) {
+        uint32_t *sz = (uint32_t *)malloc((size_t)n_l95 * 4);
+        for (int64_t k = 0; k < n_l95; k++) sz[k] = (uint32_t)(rows[l95_idx[k]].end - rows[l95_idx[k]].start + 1);
+        qsort(sz, (size_t)n_l95, 4, cmp_u32);
+        L95 = sz[(size_t)((double)n_l95 * 0.95)];
+        free(sz);
+    }
+    if (l95_out) *l95_out = L95;
+    /* trainCodingPotentialModel, model_features.cc:77-112 */
+    for (int64_t k = 0; k < n_cp; k++) {
+        const orc_row *j = &rows[cp_idx[k]];
+        const char *g = genomes[j->refid];
+        const int32_t gl = ref_len[j->refid];
+        const int neg = j->cons_strand == ORC_STRAND_NEG;
+        fetch_oriented(g, gl, j->start - 202, j->start - 2, neg, &a); make_clean(&a, &cl); kmm_count(&exon, &cl);
+        fetch_oriented(g, gl, j->start, j->end, neg, &a);             make_clean(&a, &cl); kmm_count(&intron, &cl);
+        fetch_oriented(g, gl, j->end + 1, j->end + 201, neg, &a);     make_clean(&a, &cl); kmm_count(&exon, &cl);
+    }
+    kmm_normalise(&exon);
+    kmm_normalise(&intron);
+    /* trainSplicingModels, model_features.cc:114-158 */
+    for (int pass = 0; pass < 2; pass++) {
+        const int64_t *idx = pass == 0 ? pass_idx : fail_idx;
+        const int64_t n = pass == 0 ? n_pass : n_fail;
+        for (int64_t k = 0; k < n; k++) {
+            const orc_row *j = &rows[idx[k]];
+            const char *g = genomes[j->refid];
+            const int32_t gl = ref_len[j->refid];
+            const int neg = j->cons_strand == ORC_STRAND_NEG;
+            fetch_oriented(g, gl, j->start - 3, j->start + 20, neg, &a); /* left */
+            fetch_oriented(g, gl, j->end - 20, j->end + 2, neg, &b);     /* right */
+            const sbuf *don = neg ? &b : &a, *acc = neg ? &a : &b;
+            make_clean(don, &cl);
+            if (pass == 0) { pmm_count(&donP, &cl); kmm_count(&donT, &cl); } else kmm_count(&donF, &cl);
+            make_clean(acc, &cl);
+            if (pass == 0) { pmm_count(&accP, &cl); kmm_count(&accT, &cl); } else kmm_count(&accF, &cl);
+        }
+    }
+    pmm_normalise(&donP); pmm_normalise(&accP);
+    kmm_normalise(&donT); kmm_normalise(&accT); kmm_normalise(&donF); kmm_normalise(&accF);
+    if (models_out) {
+        double *o = models_out;
+        const kmm *ks[6] = {&exon, &intron, &donT, &donF, &accT, &accF};
+        for (int m = 0; m < 6; m++) { memcpy(o, ks[m]->tab, ORC_KMER_TABLE * sizeof(double)); o += ORC_KMER_TABLE; }
+        memcpy(o, donP.tab, sizeof donP.tab); o += ORC_PW_LEN * 5;
+        memcpy(o, accP.tab, sizeof accP.tab); o += ORC_PW_LEN * 5;
+        o[0] = (double)kmm_size(&exon); o[1] = (double)kmm_size(&intron); o[2] = (double)pmm_size(&donP); o[3] = (double)pmm_size(&accP);
+        o[4] = o[5] = o[6] = o[7] = 0;
+    }
+    /* setRow, model_features.cc:161-212 */
+    for (int64_t r = 0; r < n_rows; r++) {
+        const orc_row *j = &rows[r];
+        const char *g = genomes[j->refid];
+        const int32_t gl = ref_len[j->refid];
+        const int neg = j->cons_strand == ORC_STRAND_NEG;
+        double *f = F + (size_t)r * ORC_N_FEATURES;
+        /* calcSplicingScores, junction.cc:1361-1382 (always evaluated, and its lookups insert into the maps) */
+        fetch_oriented(g, gl, j->start - 3, j->start + 20, neg, &a);
+        fetch_oriented(g, gl, j->end - 20, j->end + 2, neg, &b);
+        const sbuf *don = neg ? &b : &a, *acc = neg ? &a : &b;
+        const double pws = pmm_score(&donP, don) + pmm_score(&accP, acc);
+        const double ss = (kmm_score(&donT, don) - kmm_score(&donF, don)) + (kmm_score(&accT, acc) - kmm_score(&accF, acc));
+        const uint32_t size = (uint32_t)(j->end - j->start + 1);
+        f[0] = 0.0; /* isGenuine(): false unless a truth set marked it */
+        f[1] = (double)(j->nb_raw - j->nb_ms);
+        f[2] = (double)j->nb_dist;
+        f[3] = (double)j->nb_rel;
+        f[4] = j->entropy;
+        f[5] = (double)j->nb_rel / (double)j->nb_raw;
+        f[6] = (double)j->max_min_anc;
+        f[7] = (double)j->maxmmes;
+        f[8] = j->mean_mismatches;
+        f[9] = L95 == 0 ? 0.0 : (size <= L95 ? 0.0 : log((double)(size - L95))); /* calcIntronScore, junction.cc:953-956 */
+        f[10] = (double)(j->hamming5p < j->hamming3p ? j->hamming5p : j->hamming3p);
+        if (kmm_size(&exon) == 0 || kmm_size(&intron) == 0) f[11] = 0.0;
+        else { /* calcCodingPotential, junction.cc:1328-1359 */
+            double cp = 0;
+            fetch_oriented(g, gl, j->start - 82, j->start - 2, neg, &a);
+            cp = (kmm_score(&exon, &a) - kmm_score(&intron, &a));
+            fetch_oriented(g, gl, j->start, j->start + 80, neg, &a);
+            cp = cp + (kmm_score(&intron, &a) - kmm_score(&exon, &a));
+            fetch_oriented(g, gl, j->end - 80, j->end, neg, &a);
+            cp = cp + (kmm_score(&intron, &a) - kmm_score(&exon, &a));
+            fetch_oriented(g, gl, j->end + 1, j->end + 81, neg, &a);
+            cp = cp + (kmm_score(&exon, &a) - kmm_score(&intron, &a));
+            f[11] = cp;
+        }
+        const int pw_empty = pmm_size(&donP) == 0 || pmm_size(&accP) == 0;
+        f[12] = pw_empty ? 0.0 : pws;
+        f[13] = pw_empty ? 0.0 : ss;
+        for (int i = 0; i < 20; i++) { /* calcJunctionAnchorDepthLogDeviation, junction.cc:1384-1391 */
+            double Ni = (double)j->jad[i];
+            if (Ni == 0.0) Ni = 0.000000000001;
+            double Pi = 1.0 - ((double)i / (double)(j->mean_readlen / 2.0));
+            double Ei = (double)j->nb_raw * Pi;
+            f[14 + i] = log2(Ni / Ei);
+        }
+    }
+    sb_free(&a); sb_free(&b); sb_free(&cl);
+    kmm_free(&exon); kmm_free(&intron); kmm_free(&donT); kmm_free(&donF); kmm_free(&accT); kmm_free(&accF);
+    return 0;
+}
+
+/* ------------------------------------------------------------------ */
 /* writers                                                            */
 /* ------------------------------------------------------------------ */
 static char strand_chr(int s) { return s == ORC_STRAND_POS ? '+' : s == ORC_STRAND_NEG ? '-' : '?'; }

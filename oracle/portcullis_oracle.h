@@ -206,6 +206,26 @@ void orc_determine_strandedness(const orc_row *rows, int64_t n, int *orientation
 int orc_bamfilt_flags(const orc_reads *reads, const int32_t *js_start, const int32_t *js_end, int64_t n_js, int clip_mode,
                       uint8_t *out);
 
+/* ---- `portcullis filt` feature extraction -------------------------------------------------
+ * ModelFeatures::setRow (lib/src/model_features.cc:161-212) with Junction::calcSplicingScores / calcCodingPotential
+ * / calcJunctionAnchorDepthLogDeviation / calcIntronScore (lib/src/junction.cc:1328-1391,953-956) over the Markov
+ * models of lib/src/markov_model.cc, trained as ModelFeatures does (model_features.cc:67-158):
+ *   L95                calcIntronThreshold over the junctions l95_idx (0 of them: L95 = 0)
+ *   exon / intron      trainCodingPotentialModel over cp_idx
+ *   donor / acceptor   trainSplicingModels over pass_idx (true + position-weight models) and fail_idx (false models)
+ * then one row of ORC_N_FEATURES doubles per junction, in the column order of VAR_NAMES + JAD_NAMES
+ * (lib/include/portcullis/ml/model_features.hpp:45-60).  genomes[t] / ref_len[t]: the contigs as faidx returns them.
+ * rows must be finalised (mean_readlen set).  `models_out` (optional, ORC_MODEL_DOUBLES doubles) receives the
+ * trained tables in the dense layout the device path takes (see pjb_markov_models). */
+#define ORC_N_FEATURES 34
+#define ORC_KMER_TABLE (3125 * 5)                 /* order 5 over A C G T N: [context][next] */
+#define ORC_PW_LEN 32                             /* positions of a position-weight model (windows are 24 / 23 long) */
+#define ORC_MODEL_DOUBLES (6 * ORC_KMER_TABLE + 2 * ORC_PW_LEN * 5 + 8)
+int orc_filt_features(int32_t n_refs, const int32_t *ref_len, const char *const *genomes, const orc_row *rows, int64_t n_rows,
+                      const int64_t *l95_idx, int64_t n_l95, const int64_t *cp_idx, int64_t n_cp, const int64_t *pass_idx,
+                      int64_t n_pass, const int64_t *fail_idx, int64_t n_fail, double *features_out, double *models_out,
+                      uint32_t *l95_out);
+
 /* Writers.  Return a malloc'd buffer (caller frees with orc_free_text) and its length.
  * ref_names[refid], ref_lens[refid].  (.tab: junction.hpp:1260-1319 + junction_system.hpp:154-160
  * + junction_system.cc:356; .bed: junction_system.cc:411-418 + junction.cc:1189-1214;

@@ -129,6 +129,7 @@ struct pjb_ctx {
     std::vector<pjb_extra_row> xrows_host;
     std::map<int32_t, std::pair<u64 *, u32>> filter_keys; // bamfilt: passing junctions per target (device, sorted)
     Buf f_pos, f_cigoff, f_cigar, f_codes;
+    Buf g_rows, g_models, g_refs, g_out, g_bad; // filt feature rows
     Buf x_pos, x_endx, x_q, x_prefq, x_ce, x_bound, x_de, x_dropped, x_zlist, x_cnt, x_tabk, x_tabc, x_rs, x_re, x_rr;
     Buf b_frag, b_fragj, b_fragl, b_fragr, b_acc, b_ancl, b_ancr, b_rows, b_hasx, b_ent, b_res, b_genlist, b_gencount;
 };
@@ -438,7 +439,7 @@ void pjb_destroy(pjb_ctx *c) {
                   &c->b_key[1], &c->b_idx[0], &c->b_idx[1], &c->b_g, &c->b_lstart, &c->b_rend, &c->b_pos, &c->b_aend,
                   &c->b_meta, &c->b_updown, &c->b_hist, &c->b_hist_scan, &c->b_scan_tiles, &c->b_jid, &c->b_seg,
                   &c->b_runfirst, &c->b_runstart, &c->b_frag, &c->b_fragj, &c->b_fragl, &c->b_fragr, &c->b_acc,
-                  &c->b_ancl, &c->b_ancr, &c->b_rows, &c->b_hasx, &c->b_ent, &c->b_splidx, &c->b_splpoff, &c->b_res, &c->b_genlist, &c->b_gencount, &c->b_bintotal, &c->b_inf_comp, &c->b_inf_out, &c->b_inf_blocks, &c->b_inf_status, &c->b_inf_scratch, &c->b_bam_seg, &c->b_bam_rec, &c->b_bam_ctl, &c->b_entsum, &c->f_pos, &c->f_cigoff, &c->f_cigar, &c->f_codes,
+                  &c->b_ancl, &c->b_ancr, &c->b_rows, &c->b_hasx, &c->b_ent, &c->b_splidx, &c->b_splpoff, &c->b_res, &c->b_genlist, &c->b_gencount, &c->b_bintotal, &c->b_inf_comp, &c->b_inf_out, &c->b_inf_blocks, &c->b_inf_status, &c->b_inf_scratch, &c->b_bam_seg, &c->b_bam_rec, &c->b_bam_ctl, &c->b_entsum, &c->f_pos, &c->f_cigoff, &c->f_cigar, &c->f_codes, &c->g_rows, &c->g_models, &c->g_refs, &c->g_out, &c->g_bad,
                   &c->x_pos, &c->x_endx, &c->x_q, &c->x_prefq, &c->x_ce, &c->x_bound, &c->x_de, &c->x_dropped, &c->x_zlist, &c->x_cnt,
                   &c->x_tabk, &c->x_tabc, &c->x_rs, &c->x_re, &c->x_rr};
     for (Buf *b : all) release(*b);
@@ -1314,6 +1315,59 @@ int pjb_filter_batch(pjb_ctx *c, int32_t tid, const pjb_batch *b, int32_t clip_m
     HIP_TRY(c, hipMemcpyAsync(codes_out, c->f_codes.p, n, hipMemcpyDeviceToHost, st));
     HIP_TRY(c, hipStreamSynchronize(st));
     if (c->ktime) ev_collect(c);
+    return PJB_OK;
+}
+
+int pjb_filt_features(pjb_ctx *c, const pjb_junction_row *rows, int64_t n_rows, double mean_read_length, uint32_t l95,
+                      const pjb_markov_models *models, double *features_out) {
+    if (!c) return PJB_ERR_ARG;
+    if (n_rows < 0 || (n_rows > 0 && (!rows || !features_out)) || !models || n_rows > 0xfffffff0ll)
+        return fail(c, PJB_ERR_ARG, "pjb_filt_features: bad arguments");
+    if (n_rows == 0) return PJB_OK;
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    hipStream_t st = c->stream;
+    const size_t n = (size_t)n_rows;
+    int rc;
+    if ((rc = ensure(c, c->g_rows, n * sizeof(pjb_junction_row)))) return rc;
+    if ((rc = ensure(c, c->g_models, ((size_t)6 * PJB_KMER_TABLE + 2 * PJB_PW_LEN * 5) * sizeof(double)))) return rc;
+    if ((rc = ensure(c, c->g_refs, std::max<size_t>(c->contigs.size(), 1) * sizeof(GenomeRef)))) return rc;
+    if ((rc = ensure(c, c->g_out, n * PJB_N_FEATURES * sizeof(double)))) return rc;
+    if ((rc = ensure(c, c->g_bad, sizeof(int)))) return rc;
+    HIP_TRY(c, hipMemcpyAsync(c->g_rows.p, rows, n * sizeof(pjb_junction_row), hipMemcpyHostToDevice, st));
+    DevModels M;
+    memset(&M, 0, sizeof M);
+    double *dm = (double *)c->g_models.p;
+    const double *src[8] = {models->exon, models->intron, models->donor_t, models->donor_f, models->acceptor_t, models->acceptor_f,
+                            models->donor_pw, models->acceptor_pw};
+    const double **dst[8] = {&M.exon, &M.intron, &M.don_t, &M.don_f, &M.acc_t, &M.acc_f, &M.don_pw, &M.acc_pw};
+    size_t at = 0;
+    for (int k = 0; k < 8; k++) {
+        const size_t cnt = k < 6 ? (size_t)PJB_KMER_TABLE : (size_t)PJB_PW_LEN * 5;
+        if (src[k]) {
+            HIP_TRY(c, hipMemcpyAsync(dm + at, src[k], cnt * sizeof(double), hipMemcpyHostToDevice, st));
+            *dst[k] = dm + at;
+        }
+        at += cnt;
+    }
+    M.exon_size = models->exon ? models->exon_size : 0;
+    M.intron_size = models->intron ? models->intron_size : 0;
+    M.don_pw_size = models->donor_pw ? models->donor_pw_size : 0;
+    M.acc_pw_size = models->acceptor_pw ? models->acceptor_pw_size : 0;
+    std::vector<GenomeRef> refs(std::max<size_t>(c->contigs.size(), 1));
+    for (size_t t = 0; t < c->contigs.size(); t++) {
+        refs[t].d = c->contigs[t].present ? c->contigs[t].d : nullptr;
+        refs[t].len = (int32_t)c->contigs[t].len;
+    }
+    HIP_TRY(c, hipMemcpyAsync(c->g_refs.p, refs.data(), refs.size() * sizeof(GenomeRef), hipMemcpyHostToDevice, st));
+    HIP_TRY(c, hipMemsetAsync(c->g_bad.p, 0, sizeof(int), st));
+    LAUNCH(c, "kg_features", kg_features, dim3((unsigned)((n + 255) / 256)), dim3(256), (const pjb_junction_row *)c->g_rows.p, (u32)n,
+           (const GenomeRef *)c->g_refs.p, (int)c->contigs.size(), M, mean_read_length, (u32)l95, (double *)c->g_out.p, (int *)c->g_bad.p);
+    int bad = 0;
+    HIP_TRY(c, hipMemcpyAsync(features_out, c->g_out.p, n * PJB_N_FEATURES * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipMemcpyAsync(&bad, c->g_bad.p, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipStreamSynchronize(st));
+    if (c->ktime) ev_collect(c);
+    if (bad) return fail(c, PJB_ERR_STATE, "pjb_filt_features: a junction lies on a target whose genome was not uploaded");
     return PJB_OK;
 }
 

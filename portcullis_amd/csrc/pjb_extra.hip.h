@@ -363,6 +363,113 @@ __global__ __launch_bounds__(256) void kx_mm_score(const uint32_t *row_raw, u32 
     out[j].mm_score = (double)row_raw[j] / (double)out[j].m_sum; // N / M, junction.cc:920
 }
 
+// ---- filt feature rows: ModelFeatures::setRow, lib/src/model_features.cc:161-212 ------------------
+struct DevModels {
+    const double *exon, *intron, *don_t, *don_f, *acc_t, *acc_f, *don_pw, *acc_pw; // device tables, nullptr = untrained
+    int exon_size, intron_size, don_pw_size, acc_pw_size;
+};
+struct GenomeRef {
+    const uint8_t *d; // upper-cased bases
+    int32_t len;
+};
+// SeqUtils::makeClean code of the base at window position i of [b, e] (faidx-clamped), read backwards and complemented
+// when the junction's consensus strand is negative (SeqUtils::reverseComplement of the fetched string)
+__device__ __forceinline__ int window_code(const uint8_t *g, int32_t b, int32_t e, int neg, int32_t i) {
+    uint8_t c = neg ? revcomp_char(g[e - i]) : g[b + i];
+    return c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : c == 'T' ? 3 : 4;
+}
+// KmerMarkovModel::getScore, markov_model.cc:57-78 (order 5)
+__device__ double kmer_score(const double *tab, const uint8_t *g, int32_t glen, int32_t beg, int32_t end, int neg) {
+    int32_t b = beg, e = end;
+    fetch_clamp(glen, b, e);
+    const int32_t n = glen > 0 ? e - b + 1 : 0;
+    double score = 1.0;
+    u32 no_count = 0;
+    u32 ctx = 0;
+    for (int32_t i = 0; i < n; i++) {
+        const int c = window_code(g, b, e, neg, i);
+        if (i >= PJB_KMER_ORDER) {
+            const double m = tab ? tab[(size_t)ctx * 5 + (u32)c] : 0.0;
+            if (m != 0.0) score = __dmul_rn(score, m);
+            else no_count++;
+        }
+        ctx = (ctx * 5u + (u32)c) % 3125u;
+    }
+    if (score == 0.0) return -100.0;
+    if (no_count > 2) score = score / ((double)no_count * 0.5);
+    return log(score);
+}
+// PosMarkovModel::getScore, markov_model.cc:101-115 (order 1); *len_out = length of the window
+__device__ double pos_score(const double *tab, const uint8_t *g, int32_t glen, int32_t beg, int32_t end, int neg, int32_t *len_out) {
+    int32_t b = beg, e = end;
+    fetch_clamp(glen, b, e);
+    const int32_t n = glen > 0 ? e - b + 1 : 0;
+    *len_out = n;
+    double score = 1.0;
+    for (int32_t i = 1; i < n && i < PJB_PW_LEN; i++) {
+        const int c = window_code(g, b, e, neg, i);
+        score = __dmul_rn(score, tab ? tab[i * 5 + c] : 0.0);
+    }
+    if (score == 0.0) return -300.0;
+    return log(score);
+}
+__global__ __launch_bounds__(256) void kg_features(const pjb_junction_row *rows, u32 n, const GenomeRef *genomes, int n_refs, DevModels M,
+                                                    double mean_read_length, u32 l95, double *out, int *bad) {
+    const u32 r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= n) return;
+    const pjb_junction_row &j = rows[r];
+    double *f = out + (size_t)r * PJB_N_FEATURES;
+    if (j.refid < 0 || j.refid >= n_refs || !genomes[j.refid].d) {
+        atomicOr(bad, 1);
+        return;
+    }
+    const uint8_t *g = genomes[j.refid].d;
+    const int32_t gl = genomes[j.refid].len;
+    const int neg = j.cons_strand == PJB_STRAND_NEG;
+    const int32_t s = j.start, e = j.end;
+    // calcSplicingScores, junction.cc:1361-1382: left = [start-3, start+20], right = [end-20, end+2]; on the negative
+    // strand the reverse complement of `right` is the donor and that of `left` the acceptor
+    const int32_t db = neg ? e - 20 : s - 3, de = neg ? e + 2 : s + 20;
+    const int32_t ab = neg ? s - 3 : e - 20, ae = neg ? s + 20 : e + 2;
+    int32_t don_len, acc_len;
+    const double pws = pos_score(M.don_pw, g, gl, db, de, neg, &don_len) + pos_score(M.acc_pw, g, gl, ab, ae, neg, &acc_len);
+    const double ss = (kmer_score(M.don_t, g, gl, db, de, neg) - kmer_score(M.don_f, g, gl, db, de, neg)) +
+                      (kmer_score(M.acc_t, g, gl, ab, ae, neg) - kmer_score(M.acc_f, g, gl, ab, ae, neg));
+    const u32 size = (u32)(e - s + 1);
+    f[0] = 0.0; // isGenuine()
+    f[1] = (double)(j.nb_raw - j.nb_ms);
+    f[2] = (double)j.nb_dist;
+    f[3] = (double)j.nb_rel;
+    f[4] = j.entropy;
+    f[5] = (double)j.nb_rel / (double)j.nb_raw;
+    f[6] = (double)j.max_min_anc;
+    f[7] = (double)j.maxmmes;
+    f[8] = (double)(u32)j.sum_mismatches / (double)j.nb_raw; // nbMismatches is a uint32 in the reference (junction.cc:893)
+    f[9] = l95 == 0 ? 0.0 : (size <= l95 ? 0.0 : log((double)(size - l95)));
+    f[10] = (double)(j.hamming5p < j.hamming3p ? j.hamming5p : j.hamming3p);
+    if (M.exon_size == 0 || M.intron_size == 0) f[11] = 0.0;
+    else { // calcCodingPotential, junction.cc:1328-1359
+        double cp = kmer_score(M.exon, g, gl, s - 82, s - 2, neg) - kmer_score(M.intron, g, gl, s - 82, s - 2, neg);
+        cp = cp + (kmer_score(M.intron, g, gl, s, s + 80, neg) - kmer_score(M.exon, g, gl, s, s + 80, neg));
+        cp = cp + (kmer_score(M.intron, g, gl, e - 80, e, neg) - kmer_score(M.exon, g, gl, e - 80, e, neg));
+        cp = cp + (kmer_score(M.exon, g, gl, e + 1, e + 81, neg) - kmer_score(M.intron, g, gl, e + 1, e + 81, neg));
+        f[11] = cp;
+    }
+    // isPWModelEmpty() is asked after calcSplicingScores, whose lookups (operator[]) have by then put every position
+    // of a window longer than the model's order into an untrained model's map
+    const bool pw_empty = (M.don_pw_size == 0 && don_len <= 1) || (M.acc_pw_size == 0 && acc_len <= 1);
+    f[12] = pw_empty ? 0.0 : pws;
+    f[13] = pw_empty ? 0.0 : ss;
+#pragma unroll
+    for (int i = 0; i < 20; i++) { // calcJunctionAnchorDepthLogDeviation, junction.cc:1384-1391
+        double Ni = (double)j.jad[i];
+        if (Ni == 0.0) Ni = 0.000000000001;
+        const double Pi = 1.0 - ((double)i / (double)(mean_read_length / 2.0));
+        const double Ei = (double)j.nb_raw * Pi;
+        f[14 + i] = log2(Ni / Ei);
+    }
+}
+
 // ---- bamfilt: BamFilter::filter's decision per alignment, src/bam_filter.cc:75-150,190-225.
 // The walk is the reference's, including that it does not advance over an N operation (only the else-branch of
 // :86-96 adds to lEnd): the introns after a read's first one are looked up short of the earlier introns' lengths.

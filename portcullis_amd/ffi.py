@@ -23,8 +23,13 @@ EXPORTS = [
     "pjb_release_contig", "pjb_submit_batch", "pjb_submit_batch_device", "pjb_finish_contig", "pjb_collect",
     "pjb_clear_rows", "pjb_get_timing", "pjb_device_count", "pjb_get_kernel_timing", "pjb_reset_kernel_timing",
     "pjb_select_timed_kernels", "pjb_host_alloc", "pjb_host_free", "pjb_inflate_bgzf", "pjb_submit_bam", "pjb_collect_device", "pjb_set_row_mirror",
-    "pjb_extra_finish", "pjb_filter_set_junctions", "pjb_filter_batch",
+    "pjb_extra_finish", "pjb_filter_set_junctions", "pjb_filter_batch", "pjb_filt_features",
 ]
+N_FEATURES = 34
+KMER_TABLE = 3125 * 5
+PW_LEN = 32
+FEATURE_NAMES = ["Genuine", "rna_usrs", "rna_dist", "rna_rel", "rna_entropy", "rna_rel2raw", "rna_maxminanc", "rna_maxmmes",
+                 "rna_missmatch", "rna_intron", "dna_minhamm", "dna_coding", "dna_pws", "dna_ss"] + [f"JAD{i:02d}" for i in range(1, 21)]
 FLAG_KERNEL_TIMING = 1
 FLAG_EXTRA = 2  # junc --extra: batches carry name_hash, extra_finish() yields mm_score / coverage / up_aln / down_aln
 
@@ -39,6 +44,11 @@ class PjbBatch(C.Structure):
         (n, C.c_void_p) for n in ("pos", "flag", "mapq", "xs", "l_qseq", "mtid", "mpos", "cig_off", "cigar", "seq_off", "seq4",
                                   "name_hash")
     ]
+
+
+class PjbMarkovModels(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("exon", "intron", "donor_t", "donor_f", "acceptor_t", "acceptor_f", "donor_pw", "acceptor_pw")] + [
+        (n, C.c_int32) for n in ("exon_size", "intron_size", "donor_pw_size", "acceptor_pw_size")]
 
 
 class PjbRegionResult(C.Structure):
@@ -114,6 +124,7 @@ def load():
         L.pjb_extra_finish.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
         L.pjb_filter_set_junctions.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64]
         L.pjb_filter_batch.argtypes = [C.c_void_p, C.c_int32, C.POINTER(PjbBatch), C.c_int32, C.c_void_p]
+        L.pjb_filt_features.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_double, C.c_uint32, C.POINTER(PjbMarkovModels), C.c_void_p]
         L.pjb_host_alloc.restype = C.c_void_p
         L.pjb_host_alloc.argtypes = [C.c_size_t]
         L.pjb_host_free.restype = None
@@ -285,6 +296,27 @@ class Context:
         mode = {"HARD": 0, "SOFT": 1, "COMPLETE": 2}[clip_mode]
         self._check(self._L.pjb_filter_batch(self._h, tid, C.byref(pb), mode, out.ctypes.data_as(C.c_void_p)))
         return out[: batch.n]
+
+    def filt_features(self, rows, mean_read_length, l95, models):
+        """ModelFeatures::setRow for `rows` (ROW_DTYPE): float64 [n, N_FEATURES].  models: dict name -> float64 table
+        (exon, intron, donor_t, donor_f, acceptor_t, acceptor_f: KMER_TABLE; donor_pw, acceptor_pw: PW_LEN * 5; missing /
+        None = untrained) plus exon_size, intron_size, donor_pw_size, acceptor_pw_size."""
+        rows = np.ascontiguousarray(rows, dtype=ROW_DTYPE)
+        m = PjbMarkovModels()
+        keep = []
+        for name in ("exon", "intron", "donor_t", "donor_f", "acceptor_t", "acceptor_f", "donor_pw", "acceptor_pw"):
+            t = models.get(name)
+            if t is not None:
+                t = np.ascontiguousarray(t, dtype=np.float64)
+                assert t.size == (PW_LEN * 5 if name.endswith("_pw") else KMER_TABLE), name
+                keep.append(t)
+                setattr(m, name, t.ctypes.data)
+        for name in ("exon_size", "intron_size", "donor_pw_size", "acceptor_pw_size"):
+            setattr(m, name, int(models.get(name, 0)))
+        out = np.zeros((max(len(rows), 1), N_FEATURES), dtype=np.float64)
+        self._check(self._L.pjb_filt_features(self._h, rows.ctypes.data_as(C.c_void_p), len(rows), float(mean_read_length), int(l95),
+                                              C.byref(m), out.ctypes.data_as(C.c_void_p)))
+        return out[: len(rows)]
 
     def clear_rows(self):
         self._check(self._L.pjb_clear_rows(self._h))
