@@ -118,3 +118,54 @@ def test_feature_windows_at_contig_edges(ffi, orc):
         with pytest.raises(ffi.PjbError):
             ctx.release_contig(0)
             ctx.filt_features(drows, 30.0, l95, models)   # genome gone
+
+
+def test_model_features_class_from_tab(tmp_path, orc):
+    """The host-side mirror of the reference's ModelFeatures (train on the host, matrix from the device) on a .tab the
+    junc program wrote, against the oracle fed with the same junctions and the same positive / negative sets."""
+    import os
+    import subprocess
+
+    from util_bam import make_prep_dir
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    host = os.path.join(root, "portcullis_amd", "host")
+    csrc = os.path.join(root, "portcullis_amd", "csrc")
+    exe = str(tmp_path / "model_features")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", f"-I{host}/include", f"-I{root}/include", "-o", exe,
+                           os.path.join(root, "tests", "cpp", "model_features.cc"), f"-L{host}", "-lportcullis_host",
+                           f"-L{csrc}", "-lportcullis_amd", f"-Wl,-rpath,{host}", f"-Wl,-rpath,{csrc}"])
+    refs, contigs, reads, rows_all = [], [], [], []
+    tot_len = tot_n = 0
+    for tid, seed in enumerate([71, 72]):
+        genome, rr = make_reads(seed, n_reads=2500, glen=22000)
+        genome = genome.upper()
+        for k, r in enumerate(rr):
+            r["tid"] = tid
+        refs.append((f"chr{tid + 1}", len(genome)))
+        contigs.append((f"chr{tid + 1}", genome))
+        reads += rr
+        rows, reg = orc.find_juncs(tid, len(genome), genome, to_batch(rr).to_oracle(), "UNKNOWN")
+        rows_all.append(rows)
+        tot_len += reg["sum_len"]
+        tot_n += reg["spliced"] + reg["unspliced"]
+    prep = make_prep_dir(str(tmp_path / "prep"), refs, contigs, reads)
+    out = str(tmp_path / "junc" / "pc")
+    p = subprocess.run([os.path.join(host, "portcullis_amd"), "junc", "-o", out, prep], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    txt = str(tmp_path / "features.txt")
+    p = subprocess.run([exe, os.path.join(prep, "portcullis.genome.fa"), out + ".junctions.tab", txt], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-1000:] + p.stderr[-2000:]
+    lines = open(txt).read().strip().split("\n")
+    F = np.array([[float(v) for v in l.split("\t")] for l in lines[1:]])
+    orows = orc.finalize(np.concatenate(rows_all), tot_len / tot_n)
+    idx = np.arange(len(orows))
+    good, bad = idx[orows["nb_raw"] >= 3], idx[orows["nb_raw"] < 3]
+    G, models, l95 = orc.filt_features([l for _, l in refs], {t: g for t, (_, g) in enumerate(contigs)}, orows, idx, good, good, bad)
+    assert lines[0] == f"# L95={l95} exon={models['exon_size']} intron={models['intron_size']} donorPW={models['donor_pw_size']}"
+    assert F.shape == G.shape
+    loose = [4, 8]                                        # entropy and mean_mismatches pass through the .tab's 6 significant digits
+    for k in range(F.shape[1]):
+        tol = (1e-5 if k in loose else 1e-6) * np.maximum(1.0, np.abs(G[:, k]))
+        fin = np.isfinite(G[:, k])
+        assert (np.isfinite(F[:, k]) == fin).all()
+        assert (np.abs(F[fin, k] - G[fin, k]) <= tol[fin]).all(), (k, np.abs(F[fin, k] - G[fin, k]).max())
