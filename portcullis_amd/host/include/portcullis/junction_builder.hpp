@@ -85,6 +85,11 @@ public:
     void setThreads(uint16_t v) { threads = v; }
     bool isVerbose() const { return verbose; }
     void setVerbose(bool v) { verbose = v; }
+    std::string getUnsplicedBamFile() const { return (outputDir.empty() ? std::string(".") : outputDir) + "/" + outputPrefix + ".unspliced.bam"; }
+    std::string getSplicedBamFile() const { return (outputDir.empty() ? std::string(".") : outputDir) + "/" + outputPrefix + ".spliced.bam"; }
+    std::string getUnmappedBamFile() const { return (outputDir.empty() ? std::string(".") : outputDir) + "/" + outputPrefix + ".unmapped.bam"; }
+    // --separate (src/junction_builder.cc:152-226): the prepared BAM split into spliced / unspliced / unmapped files
+    void separateBams();
     bool isSeparate() const { return separate; }
     void setSeparate(bool v) { separate = v; }
     std::string getSource() const { return source; }

@@ -1,6 +1,7 @@
 // JunctionBuilder: orchestration of the junc stage on top of the device path.
 // Flow and console output follow src/junction_builder.cc:84-291 of the reference.
 #include <portcullis/junction_builder.hpp>
+#include <portcullis/bam/bam_writer.hpp>
 
 #include <chrono>
 #include <condition_variable>
@@ -110,9 +111,8 @@ void JunctionBuilder::process() {
              << " target sequences to process.  Setting number of threads to " << refs->size() << "." << endl << endl;
         threads = (uint16_t)refs->size();
     }
-    if (separate)
-        throw JunctionBuilderException("--separate (spliced / unspliced / unmapped BAM files) is not implemented by the MI355X junc path; "
-                                       "run without it (--extra does not need the files here: it works on the records in device memory)");
+    // (the reference forces --separate when --extra is given because calcExtraMetrics re-reads the split files,
+    // src/junction_builder.cc:113-117; here --extra works on the records in device memory and writes no files)
     cout << "Settings:" << endl
          << std::boolalpha << " - BAM Strandedness: " << bam::strandednessToString(strandSpecific) << endl
          << " - BAM Read Orientation: " << bam::orientationToString(orientation) << endl
@@ -122,6 +122,7 @@ void JunctionBuilder::process() {
          << endl;
     cout << reader.bamDetails() << endl;
     const double t_p1 = HostProfile::now();
+    if (separate) separateBams();
     findJunctions();
     const double t_p2 = HostProfile::now();
     cout << "Saving junctions: " << endl;
@@ -140,6 +141,59 @@ void JunctionBuilder::process() {
 }
 
 
+
+// src/junction_builder.cc:152-226: one pass over the whole prepared BAM (unplaced records included); a record with an N
+// operation goes to <prefix>.spliced.bam, another mapped one to <prefix>.unspliced.bam, the rest to <prefix>.unmapped.bam.
+// The reference then shells out to `samtools index` for the first two; BamWriter writes the .bai itself.
+void JunctionBuilder::separateBams() {
+    WallTimer timer;
+    uint64_t splicedCount = 0, unsplicedCount = 0, unmappedCount = 0;
+    bam::BamReader reader(prepData.getSortedBamFilePath());
+    reader.open(useCsi);
+    const int wt = std::max(1, (int)threads);
+    bam::BamWriter unsplicedWriter(getUnsplicedBamFile(), wt), splicedWriter(getSplicedBamFile(), wt), unmappedWriter(getUnmappedBamFile(), wt);
+    unmappedWriter.setWriteIndex(false);
+    cout << "Splitting BAM:" << endl;
+    cout << " - Saving unspliced alignments to: " << getUnsplicedBamFile() << endl;
+    unsplicedWriter.open(reader.getHeaderText(), reader.getTargets());
+    cout << " - Saving spliced alignments to: " << getSplicedBamFile() << endl;
+    splicedWriter.open(reader.getHeaderText(), reader.getTargets());
+    cout << " - Saving unmapped reads to: " << getUnmappedBamFile() << endl;
+    unmappedWriter.open(reader.getHeaderText(), reader.getTargets());
+    cout << " - Processing BAM ...";
+    cout.flush();
+    std::vector<uint8_t> rec;
+    reader.rewind();
+    while (reader.nextRecord(rec)) {
+        const uint8_t* r = rec.data();
+        const uint32_t l_name = r[12], n_cig = (uint32_t)r[16] | ((uint32_t)r[17] << 8);
+        const uint32_t flag = (uint32_t)r[18] | ((uint32_t)r[19] << 8);
+        if (36ull + l_name + 4ull * n_cig > rec.size()) throw JunctionBuilderException("Invalid BAM record layout");
+        bool spliced = false;  // BamAlignment::isSplicedRead, lib/src/bam_alignment.cc:294-301
+        for (uint32_t k = 0; k < n_cig && !spliced; k++) spliced = (r[36 + l_name + 4 * k] & 15u) == 3u;
+        if (spliced) {
+            splicedWriter.write(r, rec.size());
+            splicedCount++;
+        } else if (!(flag & 0x4u)) {
+            unsplicedWriter.write(r, rec.size());
+            unsplicedCount++;
+        } else {
+            unmappedWriter.write(r, rec.size());
+            unmappedCount++;
+        }
+    }
+    cout << " done." << endl;
+    cout << " - Found " << splicedCount << " spliced alignments." << endl;
+    cout << " - Found " << unsplicedCount << " unspliced alignments." << endl;
+    cout << " - Found " << unmappedCount << " unmapped reads." << endl;
+    reader.close();
+    cout << " - Indexing unspliced alignments ... ";
+    unsplicedWriter.close();
+    cout << "done." << endl << " - Indexing spliced alignments ... ";
+    splicedWriter.close();
+    unmappedWriter.close();
+    cout << "done." << endl;
+}
 
 // ---------------------------------------------------------------------------------------------
 // DeviceThread: the one thread that talks to a GPU.  It owns the pjb context (created here, so HIP

@@ -338,3 +338,43 @@ def test_library_level_entry(tmp_path, orc):
     assert open(out + ".junctions.tab", "rb").read() == exp["tab"]
     spliced = int(p.stdout.split("spliced=")[1].split()[0])
     assert spliced == exp["tot"]["spliced"]
+
+
+def test_separate_bams(tmp_path, orc):
+    """--separate (src/junction_builder.cc:152-226): the prepared BAM split into spliced / unspliced / unmapped files,
+    records unchanged and in file order, the first two indexed; the junction outputs are what they are without it."""
+    import gzip
+    import struct
+    prep = multi_contig(tmp_path, [81, 82], n_unmapped=4)
+    p, exp = check(prep, tmp_path, orc, "FR", threads=2, extra_opts=("--separate",))
+    out = str(tmp_path / "out" / "pc")
+
+    def records(path):
+        data = gzip.open(path, "rb").read()
+        (l_text,) = struct.unpack_from("<i", data, 4)
+        o = 8 + l_text
+        (n_ref,) = struct.unpack_from("<i", data, o)
+        o += 4
+        for _ in range(n_ref):
+            (l_name,) = struct.unpack_from("<i", data, o)
+            o += 8 + l_name
+        hdr, recs = data[:o], []
+        while o < len(data):
+            (bs,) = struct.unpack_from("<i", data, o)
+            recs.append(data[o:o + 4 + bs])
+            o += 4 + bs
+        return hdr, recs
+
+    hdr, allr = records(os.path.join(prep, PREP_BAM))
+    want = {"spliced": [], "unspliced": [], "unmapped": []}
+    for r in allr:
+        l_name, n_cig, flag = r[12], struct.unpack_from("<H", r, 16)[0], struct.unpack_from("<H", r, 18)[0]
+        cig = struct.unpack_from(f"<{n_cig}I", r, 36 + l_name) if n_cig else ()
+        kind = "spliced" if any((c & 15) == 3 for c in cig) else ("unspliced" if not flag & 4 else "unmapped")
+        want[kind].append(r)
+    for kind in want:
+        h2, got = records(f"{out}.{kind}.bam")
+        assert h2 == hdr and got == want[kind], kind
+    assert len(want["unmapped"]) >= 4 and len(want["spliced"]) > 100
+    assert os.path.exists(out + ".spliced.bam.bai") and os.path.exists(out + ".unspliced.bam.bai")
+    assert f" - Found {len(want['spliced'])} spliced alignments." in p.stdout
