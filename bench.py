@@ -434,7 +434,7 @@ def cpu_baseline(contigs, cfgs, dev_rows, dev_regs, orientation, synth):
 
     def run(tid):
         c = contigs[tid]
-        hb = synth.batch_to_numpy(c["batch"], 0, c["n"]).to_oracle()
+        hb = synth.batch_to_numpy(c["batch"], 0, c["n"])
         g = c["genome"].cpu().numpy().tobytes()
         t = time.perf_counter()
         orows, oreg = orc.find_juncs(tid, lens[tid], g, hb, orientation)  # the C call releases the GIL

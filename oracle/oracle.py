@@ -263,8 +263,19 @@ def hamming_scores(la, li, ri, ra, cons_strand):
 
 
 # ---------------------------------------------------------------- path level
+def as_soa(x):
+    """The records as the oracle's C struct takes them: a dict of numpy arrays with byte-granular uint64 sequence
+    offsets.  Accepts such a dict, or a batch in the product's layout (attributes pos, flag, ..., seq_off counted in
+    4-byte words: portcullis_amd.records.ReadBatch)."""
+    if isinstance(x, dict):
+        return x
+    return dict(pos=x.pos, flag=x.flag, mapq=x.mapq, xs=x.xs, l_qseq=x.l_qseq, mtid=x.mtid, mpos=x.mpos, cig_off=x.cig_off,
+                cigar=x.cigar, seq_off=np.asarray(x.seq_off).astype(np.uint64) * 4, seq4=x.seq4)
+
+
 def _reads_struct(soa):
-    """soa: dict of numpy arrays (see portcullis_amd.records.ReadBatch.to_oracle())."""
+    """soa: dict of numpy arrays or a ReadBatch (see as_soa)."""
+    soa = as_soa(soa)
     keep = {}
     r = OrcReads()
     r.n = int(len(soa["pos"]))
@@ -336,7 +347,7 @@ def extra(ref_lens, soa_by_tid, name_hash_by_tid, rows, max_query_len):
     keep = []
     hp = (C.c_void_p * n)()
     for t in range(n):
-        if t in soa_by_tid and len(soa_by_tid[t]["pos"]):
+        if t in soa_by_tid and len(as_soa(soa_by_tid[t])["pos"]):
             r, k = _reads_struct(soa_by_tid[t])
             h = np.ascontiguousarray(name_hash_by_tid[t], dtype=np.uint64)
             assert len(h) == r.n
@@ -470,7 +481,7 @@ def run_prep_like(refs, genomes, batches_by_tid, orientation="UNKNOWN"):
         b = batches_by_tid.get(tid)
         if b is None or b.n == 0:
             continue
-        rows, reg = find_juncs(tid, ln, genomes[tid], b.to_oracle(), orientation)
+        rows, reg = find_juncs(tid, ln, genomes[tid], b, orientation)
         all_rows.append(rows)
         spliced += reg["spliced"]
         unspliced += reg["unspliced"]

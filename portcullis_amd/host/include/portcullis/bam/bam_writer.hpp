@@ -40,7 +40,7 @@ class BamWriter {
     void indexRecord(const RecInfo& r, uint64_t vs, uint64_t ve);
 
 public:
-    static const size_t BLOCK = 0xff00;
+    static constexpr size_t BLOCK = 0xff00;
     BamWriter(const std::string& path, int threads = 1, int level = 6) : path(path), threads(threads < 1 ? 1 : threads), level(level) {}
     ~BamWriter();
     void setWriteIndex(bool on) { wantIndex = on; }

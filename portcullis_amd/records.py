@@ -119,14 +119,6 @@ class ReadBatch:
         seq4 = np.concatenate(seqs) if seqs else np.zeros(0, np.uint8)
         return ReadBatch(pos, flag, mapq, xs, lq, mtid, mpos, cig_off, cigar.astype(np.uint32), seq_off, seq4)
 
-    def to_oracle(self):
-        """dict for oracle.find_juncs (byte-granular uint64 seq offsets)."""
-        return dict(
-            pos=self.pos, flag=self.flag, mapq=self.mapq, xs=self.xs, l_qseq=self.l_qseq, mtid=self.mtid,
-            mpos=self.mpos, cig_off=self.cig_off, cigar=self.cigar,
-            seq_off=self.seq_off.astype(np.uint64) * 4, seq4=self.seq4,
-        )
-
     def slice(self, lo, hi):
         """Records [lo, hi) as an independent batch (offsets rebased)."""
         c0, c1 = int(self.cig_off[lo]), int(self.cig_off[hi])

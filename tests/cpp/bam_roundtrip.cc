@@ -1,0 +1,66 @@
+// Host BAM I/O under AddressSanitizer / UBSan (no GPU): BamReader's record-at-a-time view (next / current), its raw
+// sequential walk (rewind / nextRecord), and BamWriter (parallel BGZF, in-process .bai) -- the file written here is
+// read back through its own index and must hold the same records.
+//   bam_roundtrip <in.bam> <out.bam> <threads>
+#include <portcullis/bam/bam_reader.hpp>
+#include <portcullis/bam/bam_writer.hpp>
+
+#include <cstdio>
+#include <iostream>
+
+using namespace portcullis::bam;
+
+struct Sum {
+    unsigned long long n = 0, h = 1469598103934665603ull;
+    void add(const BamAlignment& a) {
+        n++;
+        auto mix = [&](unsigned long long v) { h = (h ^ v) * 1099511628211ull; };
+        mix((unsigned long long)a.getPosition());
+        mix(a.getAlignmentFlag());
+        mix((unsigned long long)a.getEnd());
+        mix(a.getXsCode());
+        for (const auto& op : a.getCigar()) mix(((unsigned long long)op.length << 8) | (unsigned char)op.type);
+        for (char c : a.deriveName()) mix((unsigned char)c);
+        for (char c : a.getQuerySeq()) mix((unsigned char)c);
+    }
+};
+
+static Sum walk(const std::string& path) {
+    BamReader r(path);
+    r.open();
+    Sum s;
+    auto refs = r.createRefList();
+    for (size_t t = 0; t < refs->size(); t++) {
+        if (!r.hasAlignments((int32_t)t)) continue;
+        r.setRegion((int32_t)t);
+        while (r.next()) s.add(r.current());
+    }
+    return s;
+}
+
+int main(int argc, char** argv) {
+    if (argc < 4) return 2;
+    try {
+        const Sum a = walk(argv[1]);
+        unsigned long long raw = 0;
+        {
+            BamReader r(argv[1]);
+            r.open();
+            BamWriter w(argv[2], atoi(argv[3]));
+            w.open(r.getHeaderText(), r.getTargets());
+            std::vector<uint8_t> rec;
+            r.rewind();
+            while (r.nextRecord(rec)) {
+                w.write(rec.data(), rec.size());
+                raw++;
+            }
+            w.close();
+        }
+        const Sum b = walk(argv[2]);
+        printf("placed=%llu raw=%llu hash_in=%llx hash_out=%llx\n", a.n, raw, a.h, b.h);
+        return a.n == b.n && a.h == b.h && raw >= a.n ? 0 : 1;
+    } catch (const std::exception& e) {
+        std::cerr << "Error: " << e.what() << std::endl;
+        return 3;
+    }
+}

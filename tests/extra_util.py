@@ -41,7 +41,7 @@ def oracle_extra(orc, contigs, orientation="UNKNOWN"):
         if not reads:
             continue
         b = batch_with_names(orc, reads)
-        soa[tid] = b.to_oracle()
+        soa[tid] = b
         nh[tid] = b.name_hash
         rows, reg = orc.find_juncs(tid, len(genome), genome, soa[tid], orientation)
         rows_all.append(rows)

@@ -46,7 +46,7 @@ def main():
         genome, reads = make_reads(seed, glen=glen, n_reads=n_reads, paired=(seed % 2 == 1), opts=opts, L=L, n_tx=int(rng.integers(2, 30)))
         batch = to_batch(reads)
         try:
-            orows, oreg = orc.find_juncs(0, len(genome), genome, batch.to_oracle(), ori)
+            orows, oreg = orc.find_juncs(0, len(genome), genome, batch, ori)
             with ffi.Context(0, ori) as ctx:
                 ctx.set_refs([len(genome), 1000])
                 # 1. one batch

@@ -32,7 +32,7 @@ def orc():
 
 
 def _junction_subset(orc, genome, batch, rng, keep_frac=0.6):
-    rows, _ = orc.find_juncs(0, len(genome), genome, batch.to_oracle(), "UNKNOWN")
+    rows, _ = orc.find_juncs(0, len(genome), genome, batch, "UNKNOWN")
     keep = rng.random(len(rows)) < keep_frac
     s, e = list(rows["start"][keep]), list(rows["end"][keep])
     # decoys: near misses that no read supports
@@ -49,7 +49,7 @@ def test_filter_codes_match_oracle(ffi, orc, seed, mode):
     genome, reads = make_reads(100 + seed, n_reads=4000, paired=seed % 2 == 0)
     batch = to_batch(reads)
     js_s, js_e = _junction_subset(orc, genome, batch, rng)
-    want = orc.bamfilt_flags(batch.to_oracle(), js_s, js_e, mode)
+    want = orc.bamfilt_flags(batch, js_s, js_e, mode)
     with ffi.Context(0, "UNKNOWN") as ctx:
         ctx.set_refs([len(genome)])
         ctx.filter_set_junctions(0, js_s, js_e)
@@ -130,7 +130,7 @@ def test_bamfilt_program(tmp_path, orc, mode, threads):
         idx = [i for i, r in enumerate(parsed) if r["tid"] == tid]
         b = records_to_batch([parsed[i] for i in idx])
         s, e = js.get(tid, ([], []))
-        codes[idx] = orc.bamfilt_flags(b.to_oracle(), s, e, mode)
+        codes[idx] = orc.bamfilt_flags(b, s, e, mode)
     want = header + b"".join(r for r, c in zip(recs_in, codes) if c)
     got = _decompressed(outbam)
     assert got == want

@@ -20,7 +20,7 @@ def both(ffi, orc, genome, reads, orientation="UNKNOWN", ref_len=None):
     oerr = derr = None
     orows = oreg = None
     try:
-        orows, oreg = orc.find_juncs(0, ref_len, genome, b.to_oracle(), orientation)
+        orows, oreg = orc.find_juncs(0, ref_len, genome, b, orientation)
     except orc.OracleError as e:
         oerr = e
     with ffi.Context(0, orientation) as ctx:

@@ -81,7 +81,7 @@ def test_extra_pileup_cap(ffi, orc):
     add_names(allr, rng, "d", unmapped_frac=0.0)
     contigs = [(genome, allr)]
     orows, _ = oracle_extra(orc, contigs)
-    depth, kept = orc.depth(len(genome), __import__("extra_util").batch_with_names(orc, allr).to_oracle())
+    depth, kept = orc.depth(len(genome), __import__("extra_util").batch_with_names(orc, allr))
     n_unspliced = sum(1 for r in allr if "N" not in r["cigar"] and not (r.get("flag", 0) & 4))
     assert kept < n_unspliced and depth.max() >= 7999          # the cap really dropped records in the oracle
     rows, extra = device_extra(ffi, orc, contigs)

@@ -39,7 +39,7 @@ def _setup(ffi, orc, seeds, paired=False, upper=True):
     for tid, seed in enumerate(seeds):
         genome, reads = make_reads(seed, n_reads=2500, paired=paired, glen=24000)
         b = to_batch(reads)
-        rows, reg = orc.find_juncs(tid, len(contigs[tid]), contigs[tid], b.to_oracle(), "FR" if paired else "UNKNOWN")
+        rows, reg = orc.find_juncs(tid, len(contigs[tid]), contigs[tid], b, "FR" if paired else "UNKNOWN")
         rows_all.append(rows)
         tot_len += reg["sum_len"]
         tot_n += reg["spliced"] + reg["unspliced"]
@@ -101,7 +101,7 @@ def test_feature_windows_at_contig_edges(ffi, orc):
     reads = [dict(pos=0, cigar="4M20N30M", seq="A" * 34, xs="+"), dict(pos=2, cigar="3M19N30M", seq="C" * 33, xs="-"),
              dict(pos=150, cigar="20M25N5M", seq="G" * 25, xs="-"), dict(pos=151, cigar="20M20N9M", seq="T" * 29, xs="+")]
     b = ReadBatch.from_reads(reads)
-    rows, reg = orc.find_juncs(0, len(g), g, b.to_oracle(), "UNKNOWN")
+    rows, reg = orc.find_juncs(0, len(g), g, b, "UNKNOWN")
     orows = orc.finalize(rows, 30.0)
     with ffi.Context(0, "UNKNOWN") as ctx:
         ctx.set_refs([len(g)])
@@ -144,7 +144,7 @@ def test_model_features_class_from_tab(tmp_path, orc):
         refs.append((f"chr{tid + 1}", len(genome)))
         contigs.append((f"chr{tid + 1}", genome))
         reads += rr
-        rows, reg = orc.find_juncs(tid, len(genome), genome, to_batch(rr).to_oracle(), "UNKNOWN")
+        rows, reg = orc.find_juncs(tid, len(genome), genome, to_batch(rr), "UNKNOWN")
         rows_all.append(rows)
         tot_len += reg["sum_len"]
         tot_n += reg["spliced"] + reg["unspliced"]

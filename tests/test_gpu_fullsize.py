@@ -74,7 +74,7 @@ def test_fullsize_matches_oracle(c2):
     from portcullis_amd import synth
 
     hb = synth.batch_to_numpy(data["batch"])
-    orows, oreg = orc.find_juncs(0, cfg.contig_len, data["genome"].cpu().numpy().tobytes(), hb.to_oracle(), "UNKNOWN")
+    orows, oreg = orc.find_juncs(0, cfg.contig_len, data["genome"].cpu().numpy().tobytes(), hb, "UNKNOWN")
     region_equal(reg, oreg)
     assert_rows_equal(rows, orows)
 
@@ -190,7 +190,7 @@ def test_c3_fullsize_properties_and_oracle(c3_full):
     worst = 0.0
     for tid in (0, 1, 24):                                                     # chr1, chr2 (16 M reads each) and chrM vs the oracle
         hb = synth.batch_to_numpy(data[tid]["batch"], 0, data[tid]["n_reads"])
-        orows, oreg = orc.find_juncs(tid, cfgs[tid].contig_len, data[tid]["genome"].cpu().numpy().tobytes(), hb.to_oracle(), "FR")
+        orows, oreg = orc.find_juncs(tid, cfgs[tid].contig_len, data[tid]["genome"].cpu().numpy().tobytes(), hb, "FR")
         region_equal(regs[tid], oreg)
         worst = max(worst, assert_rows_equal(rows[rows["refid"] == tid], orows))
     assert worst <= 1e-6
@@ -230,7 +230,7 @@ def test_c5_rank_share_properties_and_prefix_oracle():
     n = 3_000_000
     hb = synth.batch_to_numpy(d["batch"], 0, n)
     genome = d["genome"].cpu().numpy().tobytes()
-    orows, oreg = orc.find_juncs(0, cfg.contig_len, genome, hb.to_oracle(), "UNKNOWN")
+    orows, oreg = orc.find_juncs(0, cfg.contig_len, genome, hb, "UNKNOWN")
     with ffi.Context(0, "UNKNOWN", strandedness=1) as ctx:
         ctx.set_refs([cfg.contig_len])
         ctx.upload_contig_device(0, d["genome"])

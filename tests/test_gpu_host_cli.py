@@ -38,7 +38,7 @@ def oracle_outputs(orc, prep, orientation, source="portcullis", version="1.2.4",
     names = [n for n, _ in refs]
     lens = [l for _, l in refs]
     if extra:  # calcExtraMetrics (src/junction_builder.cc:293-312) on the same records
-        soa = {t: b.to_oracle() for t, b in batches.items()}
+        soa = {t: b for t, b in batches.items()}
         nh = {t: np.array([orc.name_hash(r["name"], r["flag"]) for r in recs if r["tid"] == t and r["pos"] < lens[t]], dtype=np.uint64)
               for t in batches}
         rows = orc.extra(lens, soa, nh, rows, tot["max_len"])

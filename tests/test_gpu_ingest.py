@@ -305,7 +305,7 @@ def run_targets_from_bam(ctx, orc, path, genomes, orientation="UNKNOWN"):
     for tid, (coff, uoff) in sorted(first.items()):
         mine = [r for r in recs if r["tid"] == tid]
         batch = records_to_batch(mine)
-        orows, oreg = orc.find_juncs(tid, refs[tid][1], genomes[tid], batch.to_oracle(), orientation)
+        orows, oreg = orc.find_juncs(tid, refs[tid][1], genomes[tid], batch, orientation)
         ctx.upload_contig(tid, genomes[tid])
         ctx.clear_rows()
         n = ctx.submit_bam(tid, raw[coff:], uoff)

@@ -28,7 +28,7 @@ def ffi():
 
 def run_both(ffi, orc, genome, batch, orientation="UNKNOWN", split=None, ref_len=None):
     ref_len = ref_len or len(genome)
-    orows, oreg = orc.find_juncs(0, ref_len, genome, batch.to_oracle(), orientation)
+    orows, oreg = orc.find_juncs(0, ref_len, genome, batch, orientation)
     with ffi.Context(0, orientation) as ctx:
         ctx.set_refs([ref_len])
         if split is not None:
@@ -126,7 +126,7 @@ def test_error_cigar_ends_with_refskip(ffi, orc):
     reads = [dict(pos=100, cigar="30M100N", seq="A" * 30, xs="+")]
     b = ReadBatch.from_reads(reads)
     with pytest.raises(orc.OracleError):
-        orc.find_juncs(0, len(genome), genome, b.to_oracle(), "UNKNOWN")
+        orc.find_juncs(0, len(genome), genome, b, "UNKNOWN")
     with ffi.Context(0) as ctx:
         ctx.set_refs([len(genome)])
         ctx.upload_contig(0, genome.encode())

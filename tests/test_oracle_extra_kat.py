@@ -37,7 +37,7 @@ def test_name_hash_matches_libstdcxx():
 
 
 def _batch(reads):
-    return ReadBatch.from_reads(reads).to_oracle()
+    return ReadBatch.from_reads(reads)
 
 
 def test_depth_of_reference_sorted_bam():
@@ -50,7 +50,7 @@ def test_depth_of_reference_sorted_bam():
         if not rs:
             continue
         b = ReadBatch.from_reads(rs)
-        depth, kept = orc.depth(ln, b.to_oracle())
+        depth, kept = orc.depth(ln, b)
         mapped = [r for r in rs if not (r["flag"] & 4)]
         assert kept == len(mapped)
         m_bases = sum(int(op) >> 4 for r in mapped for op in r["cigar"] if (int(op) & 15) in (0, 7, 8))
@@ -103,7 +103,7 @@ def test_flanking_counts_and_contig_pairing():
     for tid in range(3):
         reads = contig(0) if tid != 1 else [r for r in contig(0) if "N" in r["cigar"]]  # target 1 has no unspliced record
         b = ReadBatch.from_reads(reads)
-        soa[tid] = b.to_oracle()
+        soa[tid] = b
         nh[tid] = np.array([orc.name_hash(r["name"] + (f"_{tid}" if r["name"] == "s1" and tid == 2 else ""), 0) for r in reads], dtype=np.uint64)
         rows, _ = orc.find_juncs(tid, len(g), g, soa[tid], "UNKNOWN")
         rows_all.append(rows)

@@ -17,7 +17,7 @@ U32_MINUS1 = 4294967295
 
 def run(genome, reads, orientation="UNKNOWN", ref_len=None):
     b = ReadBatch.from_reads(reads)
-    rows, reg = orc.find_juncs(0, ref_len or len(genome), genome, b.to_oracle(), orientation)
+    rows, reg = orc.find_juncs(0, ref_len or len(genome), genome, b, orientation)
     mean = reg["sum_len"] / (reg["spliced"] + reg["unspliced"])
     rows = orc.finalize(rows, mean)
     return rows, reg
@@ -103,7 +103,7 @@ def test_clipped3_genome_independent_columns(golden_dir):
     batch = records_to_batch(recs)
     rng = np.random.default_rng(4)
     genome = rng.choice(np.frombuffer(b"ACGT", np.uint8), size=refs[0][1]).tobytes()
-    rows, reg = orc.find_juncs(0, refs[0][1], genome, batch.to_oracle(), "UNKNOWN")
+    rows, reg = orc.find_juncs(0, refs[0][1], genome, batch, "UNKNOWN")
     rows = orc.finalize(rows, reg["sum_len"] / (reg["spliced"] + reg["unspliced"]))
     assert len(rows) == 1 and reg["spliced"] == 135
     tab = orc.write_tab(rows, ["Chr4"], [18585056]).decode().split("\n")
