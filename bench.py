@@ -49,6 +49,11 @@ def algorithmic_bytes(name, N, C, S, Cs, P, J, L, Pg=0):
         "k1_count": N * 13 + C * 4 + S * 8,
         # spliced reads only: compacted slot (8), cig_off (8), pos/flag/mapq/xs (8), ops fetched once; 36 B written per pair
         "k1_emit": S * 24 + Cs * 4 + P * 36,
+        # K2d, ordered dense junction ids: keys read three times (8 B), ids written once (8 B); the bitmap / rank / end tables are
+        # contig-sized and small beside the pairs
+        "kd_mark": P * 8,
+        "kd_ends": P * 8,
+        "kd_assign": P * 16,
         "rs_hist": P * 8,
         "rs_scatter": P * 24,
         "k2_heads_reduce": P * 20,

@@ -93,6 +93,7 @@ struct pjb_ctx {
     pjb_junction_row *rows_pinned = nullptr;
     pjb_junction_row *rows_pinned_dev = nullptr; // the same memory as the device sees it (k6_rows_out writes it)
     void *res_pinned = nullptr;                  // control block + error word + list counters of the last contig
+    bool dense_ids = true;                       // K2d (PJB_DENSE_IDS=0 sorts the full keys as round 1 did)
     u32 junc_seen = 0;                           // most junctions a contig has had so far (junction limit of the next contig)
     int lbits_seen = 18;                         // bits of the longest intron this context has met (key format of the next contig)
     size_t rows_n = 0, rows_cap = 0;
@@ -118,7 +119,8 @@ struct pjb_ctx {
     std::vector<std::string> ktime_only; // if non-empty, only these kernel names are bracketed
     // scratch
     Buf b_batches, b_tile_cnt, b_tile_stats, b_cstats, b_err, b_total, b_splidx, b_splpoff;
-    Buf b_key[2], b_idx[2], b_g, b_lstart, b_rend, b_pos, b_aend, b_meta, b_updown;
+    Buf b_bitmap, b_wrank, b_ends, b_firstid; // K2d
+    Buf b_okey, b_key[2], b_idx[2], b_g, b_lstart, b_rend, b_pos, b_aend, b_meta, b_updown;
     Buf b_hist, b_hist_scan, b_scan_tiles, b_bintotal;
     Buf b_inf_comp, b_inf_out, b_inf_blocks, b_inf_status, b_inf_scratch; // device-side BGZF inflate
     Buf b_bam_seg, b_bam_rec, b_bam_ctl;                                  // device-side BAM record parse
@@ -404,6 +406,7 @@ int pjb_create(pjb_ctx **out, const pjb_config *cfg) {
     for (auto &ev : c->ev) (void)hipEventCreate(&ev);
     c->ktime = (cfg->flags & PJB_FLAG_KERNEL_TIMING) != 0;
     c->extra = (cfg->flags & PJB_FLAG_EXTRA) != 0;
+    if (const char *s = getenv("PJB_DENSE_IDS")) c->dense_ids = atoi(s) != 0;
     if (const char *s = getenv("PJB_RADIX_BITS")) {
         int v = atoi(s);
         if (v >= 4 && v <= RS_MAX_BITS) c->radix_max_bits = v;
@@ -435,7 +438,7 @@ void pjb_destroy(pjb_ctx *c) {
         if (c->stage[k]) (void)hipHostFree(c->stage[k]);
         if (c->stage_ev[k]) (void)hipEventDestroy(c->stage_ev[k]);
     }
-    Buf *all[] = {&c->b_batches, &c->b_tile_cnt, &c->b_tile_stats, &c->b_cstats, &c->b_err, &c->b_total, &c->b_key[0],
+    Buf *all[] = {&c->b_batches, &c->b_tile_cnt, &c->b_tile_stats, &c->b_cstats, &c->b_err, &c->b_total, &c->b_bitmap, &c->b_wrank, &c->b_ends, &c->b_firstid, &c->b_okey, &c->b_key[0],
                   &c->b_key[1], &c->b_idx[0], &c->b_idx[1], &c->b_g, &c->b_lstart, &c->b_rend, &c->b_pos, &c->b_aend,
                   &c->b_meta, &c->b_updown, &c->b_hist, &c->b_hist_scan, &c->b_scan_tiles, &c->b_jid, &c->b_seg,
                   &c->b_runfirst, &c->b_runstart, &c->b_frag, &c->b_fragj, &c->b_fragl, &c->b_fragr, &c->b_acc,
@@ -775,6 +778,7 @@ static int extra_contig(pjb_ctx *c, int32_t tid, std::vector<DevBatch> &batches,
 struct ContigLimits {
     u32 pair_limit = 0, junc_limit = 0;
     KeyFmt kf;
+    bool dense = false; // sort ordered dense junction ids (K2d) instead of the full keys
 };
 
 static int run_contig_once(pjb_ctx *c, int32_t tid, std::vector<DevBatch> &batches, int64_t n_reads, u32 n_tiles, const ContigLimits &lim,
@@ -794,6 +798,7 @@ static int run_contig_once(pjb_ctx *c, int32_t tid, std::vector<DevBatch> &batch
     if ((rc = ensure(c, c->b_err, 8))) return rc;
     if ((rc = ensure(c, c->b_total, 8))) return rc;
     // ---- pair-sized buffers (one sort tile of slack: rs_scatter loads whole tiles unguarded)
+    if ((rc = ensure(c, c->b_okey, ((size_t)PL + RS_TILE) * 8))) return rc; // the pairs' keys as emitted (BAM order): kept, the sort works on copies
     if ((rc = ensure(c, c->b_key[0], ((size_t)PL + RS_TILE) * 8))) return rc;
     if ((rc = ensure(c, c->b_key[1], ((size_t)PL + RS_TILE) * 8))) return rc;
     if ((rc = ensure(c, c->b_idx[0], ((size_t)PL + RS_TILE) * 4))) return rc;
@@ -854,7 +859,7 @@ static int run_contig_once(pjb_ctx *c, int32_t tid, std::vector<DevBatch> &batch
            PL, kf, ref_len);
     // ---- K1b: emit
     Pairs pr;
-    pr.key = (u64 *)c->b_key[0].p;
+    pr.key = (u64 *)c->b_okey.p;
     pr.g = (u32 *)c->b_g.p;
     pr.lstart = (int32_t *)c->b_lstart.p;
     pr.rend = (int32_t *)c->b_rend.p;
@@ -885,12 +890,37 @@ static int run_contig_once(pjb_ctx *c, int32_t tid, std::vector<DevBatch> &batch
     }
     HIP_TRY(c, hipEventRecord(c->ev[1], st));
 
+    // ---- K2d: ordered dense junction ids (the sort then works on 15-19 bits instead of 46-48)
+    int sort_bits = kf.total_bits;
+    if (lim.dense) {
+        const size_t n_words = ((size_t)std::max(ref_len, 1) + 63) / 64;
+        if ((rc = ensure(c, c->b_bitmap, n_words * 8 + 16))) return rc;
+        if ((rc = ensure(c, c->b_wrank, n_words * 4 + 16))) return rc;
+        if ((rc = ensure(c, c->b_ends, (size_t)JL * DENSE_ENDS * 4 + 32))) return rc;
+        if ((rc = ensure(c, c->b_firstid, (size_t)JL * 4 + 16))) return rc;
+        HIP_TRY(c, hipMemsetAsync(c->b_bitmap.p, 0, n_words * 8, st));
+        HIP_TRY(c, hipMemsetAsync(c->b_ends.p, 0xff, (size_t)JL * DENSE_ENDS * 4, st));
+        const u64 *okey = (const u64 *)pr.key;
+        LAUNCH(c, "kd_mark", kd_mark, dim3(pair_blocks), dim3(256), okey, d_P, kf, (u64 *)c->b_bitmap.p);
+        if ((rc = run_scan(c, "kd_rank", PopcFn{(const u64 *)c->b_bitmap.p}, ExclusiveU32Sink{(u32 *)c->b_wrank.p}, (u64)n_words,
+                           (u64 *)c->b_total.p)))
+            return rc;
+        LAUNCH(c, "kd_ends", kd_ends, dim3(pair_blocks), dim3(256), okey, d_P, kf, (const u64 *)c->b_bitmap.p, (const u32 *)c->b_wrank.p, JL,
+               (u32 *)c->b_ends.p, d_cs);
+        if ((rc = run_scan(c, "kd_first", EndsCountFn{(const u32 *)c->b_ends.p}, ExclusiveU32Sink{(u32 *)c->b_firstid.p}, (u64)JL,
+                           (u64 *)c->b_total.p)))
+            return rc;
+        LAUNCH(c, "kd_close", kd_close, dim3(1), dim3(1), d_cs);
+        LAUNCH(c, "kd_assign", kd_assign, dim3(pair_blocks), dim3(256), okey, d_P, kf, (const u64 *)c->b_bitmap.p, (const u32 *)c->b_wrank.p,
+               (const u32 *)c->b_ends.p, (const u32 *)c->b_firstid.p, (u64 *)c->b_key[0].p);
+        sort_bits = std::max(1, bits_of((uint64_t)JL));
+    }
     // ---- K2: radix sort (key, pair index); digits: as few passes as the widest digit allows, bits spread evenly
     const u32 rs_tiles = std::max<u32>(1, (PL + RS_TILE - 1) / RS_TILE);
-    int n_pass = (kf.total_bits + c->radix_max_bits - 1) / c->radix_max_bits;
+    int n_pass = (sort_bits + c->radix_max_bits - 1) / c->radix_max_bits;
     if (n_pass < 1) n_pass = 1;
-    std::vector<int> pass_bits((size_t)n_pass, kf.total_bits / n_pass);
-    for (int p = 0; p < kf.total_bits % n_pass; p++) pass_bits[(size_t)p]++;
+    std::vector<int> pass_bits((size_t)n_pass, sort_bits / n_pass);
+    for (int p = 0; p < sort_bits % n_pass; p++) pass_bits[(size_t)p]++;
     const int dbits = pass_bits[0];
     if ((rc = ensure(c, c->b_hist, (size_t)rs_tiles * (1u << dbits) * 4))) return rc;
     if ((rc = ensure(c, c->b_hist_scan, (size_t)rs_tiles * (1u << dbits) * 4))) return rc;
@@ -899,8 +929,7 @@ static int run_contig_once(pjb_ctx *c, int32_t tid, std::vector<DevBatch> &batch
     for (int p = 0; p < n_pass; p++) {
         const int bits = pass_bits[(size_t)p];
         if (bits <= 0) break;
-        if (p == 1 && fast_codes) HIP_TRY(c, hipStreamWaitEvent(st, c->ev_join, 0));
-        const u64 *kin = (const u64 *)c->b_key[cur].p;
+        const u64 *kin = p == 0 && !lim.dense ? (const u64 *)c->b_okey.p : (const u64 *)c->b_key[cur].p; // (dense ids were written to b_key[0])
         u64 *kout = (u64 *)c->b_key[cur ^ 1].p;
         const u32 *vin = p == 0 ? nullptr : (const u32 *)c->b_idx[cur].p;
         u32 *vout = (u32 *)c->b_idx[cur ^ 1].p;
@@ -920,7 +949,6 @@ static int run_contig_once(pjb_ctx *c, int32_t tid, std::vector<DevBatch> &batch
         cur ^= 1;
         shift += bits;
     }
-    if (n_pass < 2 && fast_codes) HIP_TRY(c, hipStreamWaitEvent(st, c->ev_join, 0));
     c->timing.sort_passes = n_pass;
     const u64 *skey = (const u64 *)c->b_key[cur].p;
     const u32 *sidx = (const u32 *)c->b_idx[cur].p;
@@ -951,6 +979,7 @@ static int run_contig_once(pjb_ctx *c, int32_t tid, std::vector<DevBatch> &batch
            (int32_t *)c->b_ancr.p);
     HIP_TRY(c, hipEventRecord(c->ev[4], st));
 
+    if (fast_codes) HIP_TRY(c, hipStreamWaitEvent(st, c->ev_join, 0)); // k4a_simple's results (side stream) are needed from here on
     // ---- K4b: the pairs that need the generic walks (list length lives on the device; the grid covers the
     // worst case and surplus blocks exit at once), then K4: gather + segmented reduce -> fragments
     LAUNCH(c, "k4b_generic", k4b_generic, dim3((gen_cap * GEN_SHARDS + 255) / 256), dim3(256), (const u32 *)c->b_genlist.p,
@@ -969,7 +998,7 @@ static int run_contig_once(pjb_ctx *c, int32_t tid, std::vector<DevBatch> &batch
     if ((rc = ensure(c, c->b_entsum, (size_t)JL * 8 + 16))) return rc;
     LAUNCH(c, "k5_entropy_sum", k5_entropy_sum, dim3(std::max<u32>(1, (JL + 3) / 4)), dim3(256), (const u32 *)c->b_runfirst.p,
            (const double *)c->b_ent.p, d_J, (double *)c->b_entsum.p);
-    LAUNCH(c, "k5_finalize", k5_finalize, dim3(std::max<u32>(1, (JL + 255) / 256)), dim3(256), skey, (const u32 *)c->b_seg.p,
+    LAUNCH(c, "k5_finalize", k5_finalize, dim3(std::max<u32>(1, (JL + 255) / 256)), dim3(256), (const u64 *)pr.key, sidx, (const u32 *)c->b_seg.p,
            (const u32 *)c->b_runfirst.p, (const u32 *)c->b_runstart.p, (const u32 *)c->b_acc.p,
            (const int32_t *)c->b_ancl.p, (const int32_t *)c->b_ancr.p, kf, (const uint8_t *)G.d, (int32_t)G.len, tid, d_J,
            (const double *)c->b_entsum.p, (pjb_junction_row *)c->b_rows.p, d_err);
@@ -1065,6 +1094,7 @@ int pjb_finish_contig(pjb_ctx *c, int32_t tid, pjb_region_result *res) {
         lim.kf.raw = 0;
         lim.kf.lbits = std::max(1, c->lbits_seen);
         lim.kf.total_bits = lim.kf.lbits + std::max(1, bits_of((uint64_t)std::max(ref_len, 1)));
+        lim.dense = c->dense_ids;
     }
     ContigStats cs;
     u64 herr = ~0ull;
@@ -1090,12 +1120,14 @@ int pjb_finish_contig(pjb_ctx *c, int32_t tid, pjb_region_result *res) {
                 lim.kf.raw = 1;
                 lim.kf.lbits = 32;
                 lim.kf.total_bits = 64;
+                lim.dense = false; // the bitmap of intron starts needs coordinates inside the contig
             } else {
                 lim.kf.lbits = std::max(1, bits_of((uint64_t)cs.max_nlen));
                 lim.kf.total_bits = lim.kf.lbits + std::max(1, bits_of((uint64_t)std::max(ref_len, 1)));
             }
         }
-        if (cs.overflow & OVF_JUNC) lim.junc_limit = cs.n_junc + 64;
+        if (cs.overflow & OVF_JUNC) lim.junc_limit = std::max<u32>(cs.n_junc + 64, (cs.overflow & OVF_DENSE) || !lim.dense ? 0u : lim.junc_limit * 4);
+        if (cs.overflow & OVF_DENSE) lim.dense = false; // a donor with more alternative acceptors than K2d keeps: sort the full keys
         if (closer.forked) {
             (void)hipStreamSynchronize(c->stream2);
             closer.forked = false;

@@ -65,7 +65,7 @@ struct TileStats { // per K1 tile
 // runs (pairs, junctions, key format); the kernels read the actual counts from here, and a count that exceeds its limit
 // raises an overflow bit and zeroes the count so that everything downstream does nothing.  pjb_finish_contig reads the
 // block back once, at the end, and repeats the contig with larger limits if a bit is set.
-enum : u32 { OVF_PAIRS = 1u, OVF_KEYFMT = 2u, OVF_JUNC = 4u };
+enum : u32 { OVF_PAIRS = 1u, OVF_KEYFMT = 2u, OVF_JUNC = 4u, OVF_DENSE = 8u };
 struct ContigStats {
     u64 spliced, unspliced, sum_len;
     int32_t min_len, max_len;
@@ -764,6 +764,91 @@ __global__ __launch_bounds__(256) void k1_emit(DevBatch b, const u32 *tile_off, 
 }
 
 // ---------------------------------------------------------------------------------------------
+// K2d: ordered dense junction ids.  The intron key is 46-48 bits wide (contig coordinate + intron length): five radix
+// passes, the first of them over digits that differ for every junction of a tile.  But a contig has 10^4-10^5
+// distinct introns, and their RANK in (start, end) order needs 15-19 bits: two passes -- and because the ranks of
+// the junctions a tile touches are neighbours (pairs arrive in BAM order, ranks are ordered by start), both passes
+// scatter into a few long runs per tile.  The rank comes without sorting anything:
+//   kd_mark    one bit per contig base: an intron starts here
+//   scan       prefix popcount over the bitmap words  -> rank of a start among the distinct starts
+//   kd_ends    per start rank, the distinct intron ends seen (alternative acceptors: a handful; DENSE_ENDS slots)
+//   scan       number of ends per start rank           -> first junction id of every start
+//   kd_assign  id of a pair = first id of its start + number of that start's ends below its own end
+// Grouping by id is grouping by (start, end), id order is (start, end) order, so everything downstream -- segment
+// heads, fragments, row order -- works on the ids as it did on the keys.  A start with more than DENSE_ENDS different
+// ends raises OVF_DENSE and the contig is repeated with the full-key sort.
+// ---------------------------------------------------------------------------------------------
+constexpr int DENSE_ENDS = 8;
+constexpr u32 DENSE_EMPTY = 0xffffffffu;
+
+__device__ __forceinline__ u32 start_rank(const u64 *bitmap, const u32 *wrank, int32_t start) {
+    const u32 w = (u32)start >> 6;
+    return wrank[w] + (u32)__popcll(bitmap[w] & ((1ull << (start & 63)) - 1ull));
+}
+__global__ __launch_bounds__(256) void kd_mark(const u64 *key, const u32 *np, KeyFmt kf, u64 *bitmap) {
+    const u32 p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= *np) return;
+    int32_t s, e;
+    unpack_key(kf, key[p], s, e);
+    const u64 bit = 1ull << (s & 63);
+    u64 *w = bitmap + ((u32)s >> 6);
+    if (!(*w & bit)) atomicOr((unsigned long long *)w, (unsigned long long)bit); // (a stale read only costs a redundant atomic)
+}
+struct PopcFn {
+    const u64 *words;
+    __device__ u64 operator()(u64 i) const { return (u64)__popcll(words[i]); }
+};
+__global__ __launch_bounds__(256) void kd_ends(const u64 *key, const u32 *np, KeyFmt kf, const u64 *bitmap, const u32 *wrank, u32 junc_limit,
+                                               u32 *ends, ContigStats *cs) {
+    const u32 p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= *np) return;
+    int32_t s, e;
+    unpack_key(kf, key[p], s, e);
+    const u32 rs = start_rank(bitmap, wrank, s);
+    if (rs >= junc_limit) {
+        atomicOr(&cs->overflow, OVF_JUNC);
+        return;
+    }
+    u32 *slot = ends + (size_t)rs * DENSE_ENDS;
+    const u32 ue = (u32)e;
+    for (int k = 0; k < DENSE_ENDS; k++) {
+        u32 cur = slot[k];
+        if (cur == ue) return;
+        if (cur == DENSE_EMPTY) {
+            cur = atomicCAS(&slot[k], DENSE_EMPTY, ue);
+            if (cur == DENSE_EMPTY || cur == ue) return;
+        } // else: the slot holds another end (slots never change once set)
+    }
+    atomicOr(&cs->overflow, OVF_DENSE);
+}
+struct EndsCountFn {
+    const u32 *ends;
+    __device__ u64 operator()(u64 rs) const {
+        const uint4 *q = reinterpret_cast<const uint4 *>(ends + rs * DENSE_ENDS);
+        const uint4 a = q[0], b = q[1];
+        return (u64)((a.x != DENSE_EMPTY) + (a.y != DENSE_EMPTY) + (a.z != DENSE_EMPTY) + (a.w != DENSE_EMPTY) + (b.x != DENSE_EMPTY) +
+                     (b.y != DENSE_EMPTY) + (b.z != DENSE_EMPTY) + (b.w != DENSE_EMPTY));
+    }
+};
+// one thread: a limit was exceeded while the ids were built -> nothing downstream runs (the host repeats the contig)
+__global__ void kd_close(ContigStats *cs) {
+    if (cs->overflow) cs->P = 0;
+}
+__global__ __launch_bounds__(256) void kd_assign(const u64 *key, const u32 *np, KeyFmt kf, const u64 *bitmap, const u32 *wrank, const u32 *ends,
+                                                 const u32 *first_id, u64 *jid_key) {
+    const u32 p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= *np) return;
+    int32_t s, e;
+    unpack_key(kf, key[p], s, e);
+    const u32 rs = start_rank(bitmap, wrank, s);
+    const uint4 *q = reinterpret_cast<const uint4 *>(ends + (size_t)rs * DENSE_ENDS);
+    const uint4 a = q[0], b = q[1];
+    const u32 ue = (u32)e; // DENSE_EMPTY slots compare as larger than any end
+    const u32 below = (a.x < ue) + (a.y < ue) + (a.z < ue) + (a.w < ue) + (b.x < ue) + (b.y < ue) + (b.z < ue) + (b.w < ue);
+    jid_key[p] = (u64)(first_id[rs] + below);
+}
+
+// ---------------------------------------------------------------------------------------------
 // K2: stable LSD radix sort of (key, pair index).  Classic 3-step passes: per-tile digit
 // histogram -> exclusive scan of the bin-major count matrix -> ranked scatter.  Stability comes
 // from ranking in memory order: wave w of a tile owns a contiguous 1/4 of it, rounds are
@@ -1439,7 +1524,7 @@ __global__ __launch_bounds__(256) void k4b_generic(const u32 *list, const u32 *n
     const DevBatch &b = find_batch(batches, n_batches, g);
     const u32 r = g - b.base;
     int32_t istart, iend;
-    unpack_key(kf, skey[i], istart, iend);
+    unpack_key(kf, P.key[p], istart, iend); // (the sorted key array may hold dense junction ids instead of coordinates)
     const u32 c0 = b.cig_off[r], c1 = b.cig_off[r + 1];
     const u32 nc = c1 - c0;
     OpsView cig;
@@ -1488,7 +1573,7 @@ __global__ __launch_bounds__(256) void k4_pairs(const u64 *skey, const u32 *sidx
         const u32 p = sidx[i];
         j = jid_of[i];
         int32_t istart, iend;
-        unpack_key(kf, skey[i], istart, iend);
+        unpack_key(kf, P.key[p], istart, iend);
         const int32_t pos = P.pos[p], aend = P.aend[p];
         const u64 rs = res[p];
         const u32 minMatch = (u32)(rs & 0xfffffu), mmes = (u32)((rs >> 20) & 0xfffffu), nbMis = (u32)(rs >> 40);
@@ -1727,7 +1812,7 @@ __global__ __launch_bounds__(256) void k5_entropy_sum(const u32 *run_first, cons
     if (lane == 0) ent_sum[j] = sum;
 }
 
-__global__ __launch_bounds__(256) void k5_finalize(const u64 *skey, const u32 *seg_off, const u32 *run_first,
+__global__ __launch_bounds__(256) void k5_finalize(const u64 *pair_key, const u32 *sidx, const u32 *seg_off, const u32 *run_first,
                                                     const u32 *run_start, const u32 *acc, const int32_t *anc_l,
                                                     const int32_t *anc_r, KeyFmt kf, const uint8_t *genome, int32_t glen,
                                                     int32_t tid, const u32 *n_junc_p, const double *ent_sum, pjb_junction_row *rows,
@@ -1740,7 +1825,7 @@ __global__ __launch_bounds__(256) void k5_finalize(const u64 *skey, const u32 *s
     memset(&R, 0, sizeof R);
     int32_t istart, iend;
     const u32 s0 = seg_off[j];
-    unpack_key(kf, skey[s0], istart, iend);
+    unpack_key(kf, pair_key[sidx[s0]], istart, iend);
     R.refid = tid;
     R.start = istart;
     R.end = iend;
