@@ -901,11 +901,14 @@ static int run_contig_once(pjb_ctx *c, int32_t tid, std::vector<DevBatch> &batch
         HIP_TRY(c, hipMemsetAsync(c->b_bitmap.p, 0, n_words * 8, st));
         HIP_TRY(c, hipMemsetAsync(c->b_ends.p, 0xff, (size_t)JL * DENSE_ENDS * 4, st));
         const u64 *okey = (const u64 *)pr.key;
-        LAUNCH(c, "kd_mark", kd_mark, dim3(pair_blocks), dim3(256), okey, d_P, kf, (u64 *)c->b_bitmap.p);
+        const u32 kd_tiles = std::max<u32>(1, (PL + KD_TILE - 1) / KD_TILE);
+        u64 *cand = (u64 *)c->b_key[1].p; // (free until the first scatter; the candidates are used up before it)
+        LAUNCH(c, "kd_unique", kd_unique, dim3(kd_tiles), dim3(256), okey, d_P, cand, d_cs);
+        LAUNCH(c, "kd_mark", kd_mark, dim3(pair_blocks), dim3(256), (const u64 *)cand, (const ContigStats *)d_cs, kf, (u64 *)c->b_bitmap.p);
         if ((rc = run_scan(c, "kd_rank", PopcFn{(const u64 *)c->b_bitmap.p}, ExclusiveU32Sink{(u32 *)c->b_wrank.p}, (u64)n_words,
                            (u64 *)c->b_total.p)))
             return rc;
-        LAUNCH(c, "kd_ends", kd_ends, dim3(pair_blocks), dim3(256), okey, d_P, kf, (const u64 *)c->b_bitmap.p, (const u32 *)c->b_wrank.p, JL,
+        LAUNCH(c, "kd_ends", kd_ends, dim3(pair_blocks), dim3(256), (const u64 *)cand, kf, (const u64 *)c->b_bitmap.p, (const u32 *)c->b_wrank.p, JL,
                (u32 *)c->b_ends.p, d_cs);
         if ((rc = run_scan(c, "kd_first", EndsCountFn{(const u32 *)c->b_ends.p}, ExclusiveU32Sink{(u32 *)c->b_firstid.p}, (u64)JL,
                            (u64 *)c->b_total.p)))

@@ -78,7 +78,7 @@ struct ContigStats {
     u32 J, R;      // junctions / runs the pipeline works on
     u32 n_slots;   // J + ceil(P / 64) fragment slots
     u32 overflow;  // OVF_*
-    u32 _pad;
+    u32 n_cand;    // K2d: keys in the candidate list (every junction at least once, few of them more often)
 };
 
 // pairs, structure of arrays (one entry per N operation walked)
@@ -585,6 +585,7 @@ __global__ __launch_bounds__(1024) void k1_scan_tiles(u32 *tile_cnt, const TileS
         out->P = ovf ? 0u : (u32)carry_s;
         out->J = out->R = out->n_slots = 0;
         out->n_junc = out->n_runs = 0;
+        out->n_cand = 0;
     }
 }
 
@@ -769,6 +770,7 @@ __global__ __launch_bounds__(256) void k1_emit(DevBatch b, const u32 *tile_off, 
 // distinct introns, and their RANK in (start, end) order needs 15-19 bits: two passes -- and because the ranks of
 // the junctions a tile touches are neighbours (pairs arrive in BAM order, ranks are ordered by start), both passes
 // scatter into a few long runs per tile.  The rank comes without sorting anything:
+//   kd_unique  pairs -> candidate keys (distinct per tile)
 //   kd_mark    one bit per contig base: an intron starts here
 //   scan       prefix popcount over the bitmap words  -> rank of a start among the distinct starts
 //   kd_ends    per start rank, the distinct intron ends seen (alternative acceptors: a handful; DENSE_ENDS slots)
@@ -785,25 +787,81 @@ __device__ __forceinline__ u32 start_rank(const u64 *bitmap, const u32 *wrank, i
     const u32 w = (u32)start >> 6;
     return wrank[w] + (u32)__popcll(bitmap[w] & ((1ull << (start & 63)) - 1ull));
 }
-__global__ __launch_bounds__(256) void kd_mark(const u64 *key, const u32 *np, KeyFmt kf, u64 *bitmap) {
+// Pairs arrive in BAM order, so the pairs of a junction sit close together, and a deep junction is one key repeated 10^5
+// times.  Operations on device memory that many waves aim at one address (or one cache line: the bitmap words of
+// neighbouring starts) are served one after the other by a single L2 channel -- measured, 0.5 ns each, 1.4 ms for the
+// pairs of one contig.  So the pairs are first reduced to a CANDIDATE list: every tile of KD_TILE pairs inserts its
+// keys (run heads only) into a hash set in LDS and appends the distinct ones; a junction appears once per tile it
+// touches, the list is 1-2x the number of junctions, and only it touches the bitmap and the end slots.
+constexpr int KD_TILE = 2048;  // pairs per block (256 threads x 8)
+constexpr int KD_SLOTS = 4096; // LDS set: at most half full
+constexpr u64 KD_EMPTY = ~0ull; // no key: a packed key has fewer than 64 bits
+__device__ __forceinline__ bool first_of_key_run(u64 k, bool on) {
+    const u64 prev = __shfl_up(k, 1, 64);
+    const bool prev_on = __shfl_up((int)on, 1, 64) != 0;
+    return on && (lane_id() == 0 || !prev_on || prev != k);
+}
+__global__ __launch_bounds__(256) void kd_unique(const u64 *key, const u32 *np, u64 *cand, ContigStats *cs) {
+    __shared__ u64 set[KD_SLOTS];
+    __shared__ u32 sm[4];
+    __shared__ u32 base_s;
+    const u32 n = *np;
+    const u32 tile0 = blockIdx.x * KD_TILE;
+    if (tile0 >= n) return;
+    for (int i = threadIdx.x; i < KD_SLOTS; i += 256) set[i] = KD_EMPTY;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < KD_TILE / 256; i++) {
+        const u32 p = tile0 + i * 256 + threadIdx.x;
+        const bool on = p < n;
+        const u64 k = on ? key[p] : 0;
+        if (!first_of_key_run(k, on)) continue;
+        u32 h = (u32)((k * 0x9E3779B97F4A7C15ull) >> 52) & (KD_SLOTS - 1);
+        for (;;) { // look first: after the first round most keys are there already, and a read of one address by many lanes is a broadcast
+            u64 old = set[h];
+            if (old == k) break;
+            if (old == KD_EMPTY) {
+                old = atomicCAS((unsigned long long *)&set[h], (unsigned long long)KD_EMPTY, (unsigned long long)k);
+                if (old == KD_EMPTY || old == k) break;
+            }
+            h = (h + 1) & (KD_SLOTS - 1);
+        }
+    }
+    __syncthreads();
+    u64 mine[KD_SLOTS / 256];
+    u32 cnt = 0;
+#pragma unroll
+    for (int i = 0; i < KD_SLOTS / 256; i++) {
+        mine[i] = set[i * 256 + threadIdx.x];
+        cnt += mine[i] != KD_EMPTY;
+    }
+    u32 total;
+    const u32 excl = block_escan_256(cnt, sm, &total);
+    if (threadIdx.x == 0) base_s = atomicAdd(&cs->n_cand, total);
+    __syncthreads();
+    u32 o = base_s + excl;
+#pragma unroll
+    for (int i = 0; i < KD_SLOTS / 256; i++)
+        if (mine[i] != KD_EMPTY) cand[o++] = mine[i];
+}
+// candidates -> one bit per contig base: an intron starts here
+__global__ __launch_bounds__(256) void kd_mark(const u64 *cand, const ContigStats *cs, KeyFmt kf, u64 *bitmap) {
     const u32 p = blockIdx.x * 256 + threadIdx.x;
-    if (p >= *np) return;
+    if (p >= cs->n_cand) return;
     int32_t s, e;
-    unpack_key(kf, key[p], s, e);
-    const u64 bit = 1ull << (s & 63);
-    u64 *w = bitmap + ((u32)s >> 6);
-    if (!(*w & bit)) atomicOr((unsigned long long *)w, (unsigned long long)bit); // (a stale read only costs a redundant atomic)
+    unpack_key(kf, cand[p], s, e);
+    atomicOr((unsigned long long *)(bitmap + ((u32)s >> 6)), 1ull << (s & 63));
 }
 struct PopcFn {
     const u64 *words;
     __device__ u64 operator()(u64 i) const { return (u64)__popcll(words[i]); }
 };
-__global__ __launch_bounds__(256) void kd_ends(const u64 *key, const u32 *np, KeyFmt kf, const u64 *bitmap, const u32 *wrank, u32 junc_limit,
-                                               u32 *ends, ContigStats *cs) {
+__global__ __launch_bounds__(256) void kd_ends(const u64 *cand, KeyFmt kf, const u64 *bitmap, const u32 *wrank, u32 junc_limit, u32 *ends,
+                                               ContigStats *cs) {
     const u32 p = blockIdx.x * 256 + threadIdx.x;
-    if (p >= *np) return;
+    if (p >= cs->n_cand) return;
     int32_t s, e;
-    unpack_key(kf, key[p], s, e);
+    unpack_key(kf, cand[p], s, e);
     const u32 rs = start_rank(bitmap, wrank, s);
     if (rs >= junc_limit) {
         atomicOr(&cs->overflow, OVF_JUNC);
@@ -812,12 +870,9 @@ __global__ __launch_bounds__(256) void kd_ends(const u64 *key, const u32 *np, Ke
     u32 *slot = ends + (size_t)rs * DENSE_ENDS;
     const u32 ue = (u32)e;
     for (int k = 0; k < DENSE_ENDS; k++) {
-        u32 cur = slot[k];
-        if (cur == ue) return;
-        if (cur == DENSE_EMPTY) {
-            cur = atomicCAS(&slot[k], DENSE_EMPTY, ue);
-            if (cur == DENSE_EMPTY || cur == ue) return;
-        } // else: the slot holds another end (slots never change once set)
+        const u32 cur = atomicCAS(&slot[k], DENSE_EMPTY, ue);
+        if (cur == DENSE_EMPTY || cur == ue) return;
+        // else: the slot holds another end (slots never change once set)
     }
     atomicOr(&cs->overflow, OVF_DENSE);
 }

@@ -142,6 +142,71 @@ def test_seq_star_fallback(ffi, orc):
     run_both(ffi, orc, genome, ReadBatch.from_reads(reads))
 
 
+def _donor_with_acceptors(n_acc, depth=6):
+    rng = np.random.default_rng(n_acc)
+    genome = "".join(rng.choice(list("ACGT"), size=20000))
+    reads = []
+    for k in range(depth):
+        for a in range(n_acc):  # one donor at 1040, acceptors 100 + 37 a bases on; plus an ordinary junction further along
+            reads.append(dict(pos=1000 + k, cigar=f"{40 - k}M{100 + 37 * a}N{30 + k}M", seq="A" * 70, xs="+", flag=0))
+    for k in range(20):
+        reads.append(dict(pos=9000 + k, cigar=f"{50 - k}M500N{20 + k}M", seq="C" * 70, xs="-", flag=0))
+    reads.sort(key=lambda r: r["pos"])
+    return genome, reads
+
+
+@pytest.mark.parametrize("n_acc", [8, 9, 40])
+def test_dense_ids_many_acceptors(ffi, orc, n_acc):
+    """K2d keeps 8 intron ends per intron start; a donor with more alternative acceptors sends the contig through
+    the full-key sort instead (same rows either way)."""
+    genome, reads = _donor_with_acceptors(n_acc)
+    batch = ReadBatch.from_reads(reads)
+    orows, oreg = orc.find_juncs(0, len(genome), genome, batch, "UNKNOWN")
+    with ffi.Context(0, "UNKNOWN") as ctx:
+        ctx.set_refs([len(genome)])
+        drows, dreg = ffi.run_contig(ctx, 0, genome.encode(), [batch])
+        passes = ctx.timing()["sort_passes"]
+    region_equal(dreg, oreg)
+    assert_rows_equal(drows, orows)
+    assert len(drows) == n_acc + 1
+    assert (passes <= 2) == (n_acc <= 8), passes  # ids: 12 bits; keys: 15 + 18 bits
+
+
+def test_dense_ids_off(ffi, orc, monkeypatch):
+    """PJB_DENSE_IDS=0: the round-1 sort of the full intron keys."""
+    monkeypatch.setenv("PJB_DENSE_IDS", "0")
+    genome, reads = make_reads(5, n_reads=2500, paired=True)
+    batch = to_batch(reads)
+    orows, oreg = orc.find_juncs(0, len(genome), genome, batch, "FR")
+    with ffi.Context(0, "FR") as ctx:
+        ctx.set_refs([len(genome)])
+        drows, dreg = ffi.run_contig(ctx, 0, genome.encode(), [batch])
+        assert ctx.timing()["sort_passes"] >= 3
+    region_equal(dreg, oreg)
+    assert_rows_equal(drows, orows)
+
+
+def test_dense_ids_junction_limit(ffi, orc):
+    """More junctions than the context planned for (limit: pairs / 32, at least 4096): the control block reports the
+    overflow and the contig is queued again with the count it found."""
+    rng = np.random.default_rng(11)
+    glen = 400000
+    genome = "".join(rng.choice(list("ACGT"), size=glen))
+    reads = [dict(pos=20 + 60 * k, cigar=f"25M{30 + (k % 7)}N25M", seq="G" * 50, xs="+", flag=0) for k in range(6000)]
+    batch = ReadBatch.from_reads(reads)
+    orows, oreg = orc.find_juncs(0, glen, genome, batch, "UNKNOWN")
+    assert len(orows) == 6000
+    with ffi.Context(0, "UNKNOWN") as ctx:
+        ctx.set_refs([glen])
+        drows, dreg = ffi.run_contig(ctx, 0, genome.encode(), [batch])
+        region_equal(dreg, oreg)
+        assert_rows_equal(drows, orows)
+        # the context remembers: the same contig again settles at once
+        ctx.clear_rows()
+        drows2, _ = ffi.run_contig(ctx, 0, genome.encode(), [batch])
+        assert drows2.tobytes() == drows.tobytes()
+
+
 def test_row_mirror(ffi, orc):
     """pjb_set_row_mirror: finish_contig leaves { n_rows, spliced, unspliced, sum_len, min_len, max_len } and the rows
     in the caller's device buffer -- also for a contig without junctions -- and refuses a buffer that is too small."""
