@@ -196,12 +196,20 @@ def main():
         if xchg is not None:
             ctx.set_row_mirror(*xchg.slot_for_next_finish())  # every finish appends header + rows to the exchange slot
         regs = {}
+        prev = None  # two contigs queued: the device never waits for the host between contigs
         for tid in mine:
             c = contigs[tid]
             ctx.submit_batch_device(tid, c["batch"], c["n"])
-            regs[tid] = ctx.finish_contig(tid)
+            ctx.finish_contig_begin(tid)
+            if prev is not None:
+                regs[prev] = ctx.finish_contig_end(prev)
+                if state.get("want_timing"):
+                    state.setdefault("per_contig", {})[prev] = ctx.timing()
+            prev = tid
+        if prev is not None:
+            regs[prev] = ctx.finish_contig_end(prev)
             if state.get("want_timing"):
-                state.setdefault("per_contig", {})[tid] = ctx.timing()
+                state.setdefault("per_contig", {})[prev] = ctx.timing()
         if not mine:
             ctx.finish_contig(0)  # a rank without contigs still publishes an (empty) header
         rows = ctx.collect(copy=False)  # view of the pinned row table

@@ -173,7 +173,8 @@ typedef struct pjb_junction_row {
 #define PJB_N_STAGES 8
 typedef struct pjb_timing {
     float total_ms;               /* first kernel -> rows resident on host */
-    float stage_ms[PJB_N_STAGES]; /* scan/emit, sort, group, anchors, pair stats, finalise, d2h, (spare) */
+    float stage_ms[PJB_N_STAGES]; /* scan/emit, sort, group, anchors, pair stats, finalise, d2h, (spare): filled only under
+                                     PJB_FLAG_KERNEL_TIMING with no kernel selection (an event between kernels costs a bubble) */
     int64_t sort_passes;
     int64_t generic_pairs; /* pairs that took the generic CIGAR walks (k4b) instead of the [S]MNM[S] fast path (k4a) */
 } pjb_timing;
@@ -203,13 +204,25 @@ int pjb_release_contig(pjb_ctx *ctx, int32_t tid);
  * the arrays have been packed, so they may be reused at once while the DMA of
  * this batch overlaps the decoding of the next. */
 int pjb_submit_batch(pjb_ctx *ctx, int32_t tid, const pjb_batch *host_batch);
-/* Same for arrays already resident in HBM: borrowed until pjb_finish_contig returns. */
+/* Same for arrays already resident in HBM: borrowed until pjb_finish_contig (or pjb_finish_contig_end) returns. */
 int pjb_submit_batch_device(pjb_ctx *ctx, int32_t tid, const pjb_batch *device_batch);
 
 /* Run the device pipeline over everything submitted for contig `tid` and close it.  The contig's
  * genome must have been uploaded.  On return the contig's rows are on the
  * host (appended to the table pjb_collect returns). */
 int pjb_finish_contig(pjb_ctx *ctx, int32_t tid, pjb_region_result *result);
+
+/* The same in two halves, so that the device never waits for the host between contigs (the reference gets the
+ * same effect from its thread pool: one findJuncs per target in flight per thread, src/junction_builder.cc:215-247).
+ * _begin queues the whole kernel chain of the contig and returns without waiting; _end waits for the contig's rows
+ * and control block, repeats the contig if a limit it was queued with turned out too small, and closes it --
+ * pjb_finish_contig is _begin followed by _end.  Up to TWO contigs may be queued; they are collected in the order
+ * they were queued and their rows land in that order.  Between the two calls the contig's batches (and device
+ * arrays lent by pjb_submit_batch_device) must stay as they are; batches for OTHER targets may be submitted, genomes
+ * uploaded.  pjb_collect covers collected contigs only; pjb_clear_rows / pjb_set_row_mirror need an empty queue.
+ * With PJB_FLAG_EXTRA one contig is queued at a time. */
+int pjb_finish_contig_begin(pjb_ctx *ctx, int32_t tid);
+int pjb_finish_contig_end(pjb_ctx *ctx, int32_t tid, pjb_region_result *result);
 
 /* All rows built so far, contig by contig in finish order, (start,end)-sorted
  * within a contig.  The pointer stays valid until the next finish/clear/destroy. */

@@ -71,11 +71,64 @@ struct ExtraContig {
     u32 n_spl = 0;
 };
 
+// limits a contig is queued with (the kernels check them; see pjb_finish_contig_end)
+struct ContigLimits {
+    u32 pair_limit = 0, junc_limit = 0;
+    KeyFmt kf;
+    bool dense = false; // sort ordered dense junction ids (K2d) instead of the full keys
+};
+
+// What two queued contigs must not share: control block, error word, list counters, batch descriptors and the device
+// copy of the rows (the rows stream still reads them while the next contig's kernels run), the published block on the
+// host, and the timing events.  Everything else is scratch of the main stream and protected by stream order.
+struct CtlSlot {
+    Buf cstats, err, gencount, batches, rows;
+    uint8_t *pub = nullptr, *pub_dev = nullptr; // page-locked: what k7_publish writes (host view, device view)
+    DevBatch *batches_pinned = nullptr;         // page-locked staging of the batch descriptors
+    size_t batches_pinned_cap = 0;
+    bool at_rest = false;                       // error word / list counters are in their rest state (k7_publish restores it)
+    hipEvent_t ev[PJB_N_STAGES + 2] = {};
+    hipEvent_t ev_rows = nullptr, ev_done = nullptr;
+};
+// optional per-kernel event brackets: one pool per control slot (collected when that contig is), one for everything
+// launched outside a contig's chain (ingest, filters; collected when the timing table is read)
+struct EvPool {
+    std::vector<hipEvent_t> ev;
+    size_t used = 0;
+    std::vector<int> name; // kernel-name index per event pair
+};
+constexpr int MISC_POOL = 2;
+
+// a contig between pjb_finish_contig_begin and pjb_finish_contig_end
+struct Flight {
+    int32_t tid = -1;
+    int slot = 0;
+    bool queued = false;   // its kernels are on the streams
+    bool empty = false;    // no batches: nothing to queue
+    bool forked = false;   // k4a_simple went to the side stream (the contig's batches must outlive it)
+    ContigLimits lim;
+    int64_t n_reads = 0;
+    u32 n_tiles = 0;
+    int attempt = 0;
+    int n_pass = 0;
+    const u32 *sidx = nullptr;
+    Pairs pr;
+};
+
 struct pjb_ctx {
     pjb_config cfg;
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr; // side stream: work that does not depend on the sort (k4a_simple)
+    hipStream_t stream3 = nullptr; // rows stream: k6_rows_out + k7_publish of a contig, beside the next contig's first kernels
+    hipStream_t stream4 = nullptr; // header of the row mirror
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    CtlSlot sl[2];
+    Flight fl[2]; // FIFO: fl[0] is the oldest
+    int n_fl = 0;
+    int cur_slot = 0; // slot of the contig being queued / collected (extra)
+    EvPool pools[3];
+    int cur_pool = MISC_POOL;
+    Buf b_cursor;     // RowCursor
     std::string err;
     std::vector<int32_t> ref_len;
     std::vector<Contig> contigs;
@@ -92,7 +145,10 @@ struct pjb_ctx {
     // junction rows live in a grow-only pinned host buffer so the D2H copy is a single DMA
     pjb_junction_row *rows_pinned = nullptr;
     pjb_junction_row *rows_pinned_dev = nullptr; // the same memory as the device sees it (k6_rows_out writes it)
-    void *res_pinned = nullptr;                  // control block + error word + list counters of the last contig
+    // buffers with a rest state that the kernel chain itself restores (no per-contig memsets): error word / list
+    // counters (k7_publish; per slot), start bitmap / end slots (kd_reset).  false: set by a memset before use
+    bool dense_at_rest = false;
+    int last_slot = 0; // slot of the contig collected last (pjb_collect_device)
     bool dense_ids = true;                       // K2d (PJB_DENSE_IDS=0 sorts the full keys as round 1 did)
     u32 junc_seen = 0;                           // most junctions a contig has had so far (junction limit of the next contig)
     int lbits_seen = 18;                         // bits of the longest intron this context has met (key format of the next contig)
@@ -106,19 +162,15 @@ struct pjb_ctx {
     size_t mirror_rows = 0;
     int64_t mirror_acc[5] = {0, 0, 0, INT32_MAX, 0}; // spliced, unspliced, sum_len, min_len, max_len
     pjb_timing timing;
-    hipEvent_t ev[PJB_N_STAGES + 2];
     int radix_max_bits = 11;
-    // optional per-kernel timing
+    // optional per-kernel timing (the events live in the control slots)
     bool ktime = false;
-    std::vector<hipEvent_t> ev_pool;
-    size_t ev_used = 0;
-    std::vector<int> ev_name; // kernel-name index per event pair
     std::vector<std::string> knames;
     std::vector<int64_t> kcount;
     std::vector<double> kms;
     std::vector<std::string> ktime_only; // if non-empty, only these kernel names are bracketed
     // scratch
-    Buf b_batches, b_tile_cnt, b_tile_stats, b_cstats, b_err, b_total, b_splidx, b_splpoff;
+    Buf b_tile_cnt, b_tile_stats, b_total, b_splidx, b_splpoff;
     Buf b_bitmap, b_wrank, b_ends, b_firstid; // K2d
     Buf b_okey, b_key[2], b_idx[2], b_g, b_lstart, b_rend, b_pos, b_aend, b_meta, b_updown;
     Buf b_hist, b_hist_scan, b_scan_tiles, b_bintotal;
@@ -133,7 +185,7 @@ struct pjb_ctx {
     Buf f_pos, f_cigoff, f_cigar, f_codes;
     Buf g_rows, g_models, g_refs, g_out, g_bad; // filt feature rows
     Buf x_pos, x_endx, x_q, x_prefq, x_ce, x_bound, x_de, x_dropped, x_zlist, x_cnt, x_tabk, x_tabc, x_rs, x_re, x_rr;
-    Buf b_frag, b_fragj, b_fragl, b_fragr, b_acc, b_ancl, b_ancr, b_rows, b_hasx, b_ent, b_res, b_genlist, b_gencount;
+    Buf b_frag, b_fragj, b_fragl, b_fragr, b_acc, b_ancl, b_ancr, b_hasx, b_ent, b_res, b_genlist;
 };
 
 namespace {
@@ -245,28 +297,35 @@ int kname_index(pjb_ctx *c, const char *name) {
     return (int)c->knames.size() - 1;
 }
 void ev_begin(pjb_ctx *c, const char *name) {
-    if (c->ev_used + 2 > c->ev_pool.size()) {
-        c->ev_pool.resize(c->ev_used + 2);
-        (void)hipEventCreate(&c->ev_pool[c->ev_used]);
-        (void)hipEventCreate(&c->ev_pool[c->ev_used + 1]);
+    EvPool &S = c->pools[c->cur_pool];
+    if (S.used + 2 > S.ev.size()) {
+        S.ev.resize(S.used + 2);
+        (void)hipEventCreate(&S.ev[S.used]);
+        (void)hipEventCreate(&S.ev[S.used + 1]);
     }
-    c->ev_name.push_back(kname_index(c, name));
-    (void)hipEventRecord(c->ev_pool[c->ev_used], c->stream);
+    S.name.push_back(kname_index(c, name));
+    (void)hipEventRecord(S.ev[S.used], c->stream);
 }
 void ev_end(pjb_ctx *c) {
-    (void)hipEventRecord(c->ev_pool[c->ev_used + 1], c->stream);
-    c->ev_used += 2;
+    EvPool &S = c->pools[c->cur_pool];
+    (void)hipEventRecord(S.ev[S.used + 1], c->stream);
+    S.used += 2;
 }
-void ev_collect(pjb_ctx *c) { // stream must be synchronised
-    for (size_t k = 0; k < c->ev_name.size(); k++) {
+void ev_collect(pjb_ctx *c, int pool) { // the pool's events must have completed
+    EvPool &S = c->pools[pool];
+    for (size_t k = 0; k < S.name.size(); k++) {
         float ms = 0.f;
-        if (hipEventElapsedTime(&ms, c->ev_pool[2 * k], c->ev_pool[2 * k + 1]) == hipSuccess) {
-            c->kcount[(size_t)c->ev_name[k]]++;
-            c->kms[(size_t)c->ev_name[k]] += ms;
+        if (hipEventElapsedTime(&ms, S.ev[2 * k], S.ev[2 * k + 1]) == hipSuccess) {
+            c->kcount[(size_t)S.name[k]]++;
+            c->kms[(size_t)S.name[k]] += ms;
         }
     }
-    c->ev_name.clear();
-    c->ev_used = 0;
+    S.name.clear();
+    S.used = 0;
+}
+void ev_drop(pjb_ctx *c, int pool) {
+    c->pools[pool].name.clear();
+    c->pools[pool].used = 0;
 }
 bool ktime_wanted(pjb_ctx *c, const char *name) {
     if (!c->ktime) return false;
@@ -401,9 +460,17 @@ int pjb_create(pjb_ctx **out, const pjb_config *cfg) {
         return fail(nullptr, PJB_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e));
     }
     (void)hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking);
+    (void)hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking);
+    (void)hipStreamCreateWithFlags(&c->stream4, hipStreamNonBlocking);
     (void)hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
     (void)hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming);
-    for (auto &ev : c->ev) (void)hipEventCreate(&ev);
+    for (int k = 0; k < 2; k++) {
+        CtlSlot &S = c->sl[k];
+        for (auto &ev : S.ev) (void)hipEventCreate(&ev);
+        (void)hipEventCreateWithFlags(&S.ev_rows, hipEventDisableTiming);
+        (void)hipEventCreateWithFlags(&S.ev_done, hipEventDisableTiming);
+        c->fl[k].slot = k;
+    }
     c->ktime = (cfg->flags & PJB_FLAG_KERNEL_TIMING) != 0;
     c->extra = (cfg->flags & PJB_FLAG_EXTRA) != 0;
     if (const char *s = getenv("PJB_DENSE_IDS")) c->dense_ids = atoi(s) != 0;
@@ -422,7 +489,7 @@ int pjb_create(pjb_ctx **out, const pjb_config *cfg) {
 void pjb_destroy(pjb_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->cfg.device);
-    (void)hipStreamSynchronize(c->stream);
+    (void)hipDeviceSynchronize(); // (contigs may still be queued)
     while (!c->open.empty()) close_contig(c, c->open.begin()->first);
     extra_clear(c);
     for (auto &kv : c->filter_keys)
@@ -432,25 +499,36 @@ void pjb_destroy(pjb_ctx *c) {
     for (auto &sl : c->slab_pool)
         if (sl.p) (void)hipFree(sl.p);
     if (c->rows_pinned) (void)hipHostFree(c->rows_pinned);
-    if (c->res_pinned) (void)hipHostFree(c->res_pinned);
+    for (int k = 0; k < 2; k++) {
+        CtlSlot &S = c->sl[k];
+        if (S.pub) (void)hipHostFree(S.pub);
+        if (S.batches_pinned) (void)hipHostFree(S.batches_pinned);
+        for (auto &ev : S.ev) (void)hipEventDestroy(ev);
+        if (S.ev_rows) (void)hipEventDestroy(S.ev_rows);
+        if (S.ev_done) (void)hipEventDestroy(S.ev_done);
+        Buf *sb[] = {&S.cstats, &S.err, &S.gencount, &S.batches, &S.rows};
+        for (Buf *b : sb) release(*b);
+    }
     if (c->mirror_hdr) (void)hipHostFree(c->mirror_hdr);
     for (int k = 0; k < 2; k++) {
         if (c->stage[k]) (void)hipHostFree(c->stage[k]);
         if (c->stage_ev[k]) (void)hipEventDestroy(c->stage_ev[k]);
     }
-    Buf *all[] = {&c->b_batches, &c->b_tile_cnt, &c->b_tile_stats, &c->b_cstats, &c->b_err, &c->b_total, &c->b_bitmap, &c->b_wrank, &c->b_ends, &c->b_firstid, &c->b_okey, &c->b_key[0],
+    Buf *all[] = {&c->b_cursor, &c->b_tile_cnt, &c->b_tile_stats, &c->b_total, &c->b_bitmap, &c->b_wrank, &c->b_ends, &c->b_firstid, &c->b_okey, &c->b_key[0],
                   &c->b_key[1], &c->b_idx[0], &c->b_idx[1], &c->b_g, &c->b_lstart, &c->b_rend, &c->b_pos, &c->b_aend,
                   &c->b_meta, &c->b_updown, &c->b_hist, &c->b_hist_scan, &c->b_scan_tiles, &c->b_jid, &c->b_seg,
                   &c->b_runfirst, &c->b_runstart, &c->b_frag, &c->b_fragj, &c->b_fragl, &c->b_fragr, &c->b_acc,
-                  &c->b_ancl, &c->b_ancr, &c->b_rows, &c->b_hasx, &c->b_ent, &c->b_splidx, &c->b_splpoff, &c->b_res, &c->b_genlist, &c->b_gencount, &c->b_bintotal, &c->b_inf_comp, &c->b_inf_out, &c->b_inf_blocks, &c->b_inf_status, &c->b_inf_scratch, &c->b_bam_seg, &c->b_bam_rec, &c->b_bam_ctl, &c->b_entsum, &c->f_pos, &c->f_cigoff, &c->f_cigar, &c->f_codes, &c->g_rows, &c->g_models, &c->g_refs, &c->g_out, &c->g_bad,
+                  &c->b_ancl, &c->b_ancr, &c->b_hasx, &c->b_ent, &c->b_splidx, &c->b_splpoff, &c->b_res, &c->b_genlist, &c->b_bintotal, &c->b_inf_comp, &c->b_inf_out, &c->b_inf_blocks, &c->b_inf_status, &c->b_inf_scratch, &c->b_bam_seg, &c->b_bam_rec, &c->b_bam_ctl, &c->b_entsum, &c->f_pos, &c->f_cigoff, &c->f_cigar, &c->f_codes, &c->g_rows, &c->g_models, &c->g_refs, &c->g_out, &c->g_bad,
                   &c->x_pos, &c->x_endx, &c->x_q, &c->x_prefq, &c->x_ce, &c->x_bound, &c->x_de, &c->x_dropped, &c->x_zlist, &c->x_cnt,
                   &c->x_tabk, &c->x_tabc, &c->x_rs, &c->x_re, &c->x_rr};
     for (Buf *b : all) release(*b);
-    for (auto &ev : c->ev) (void)hipEventDestroy(ev);
-    for (auto &ev : c->ev_pool) (void)hipEventDestroy(ev);
+    for (auto &pool : c->pools)
+        for (auto &ev : pool.ev) (void)hipEventDestroy(ev);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
+    if (c->stream3) (void)hipStreamDestroy(c->stream3);
+    if (c->stream4) (void)hipStreamDestroy(c->stream4);
     (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -669,8 +747,8 @@ static void mirror_reset(pjb_ctx *c) {
 static int mirror_header_only(pjb_ctx *c, const pjb_region_result &R) {
     if (!c->mirror) return PJB_OK;
     mirror_fold(c, R, 0);
-    HIP_TRY(c, hipMemcpyAsync(c->mirror, c->mirror_hdr, PJB_MIRROR_HEADER_BYTES, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->mirror, c->mirror_hdr, PJB_MIRROR_HEADER_BYTES, hipMemcpyHostToDevice, c->stream4));
+    HIP_TRY(c, hipStreamSynchronize(c->stream4));
     return PJB_OK;
 }
 
@@ -756,15 +834,15 @@ static int extra_contig(pjb_ctx *c, int32_t tid, std::vector<DevBatch> &batches,
     if (J > 0) {
         if (hipMalloc((void **)&X.xr, (size_t)J * sizeof(ExtraRow)) != hipSuccess) return fail(c, PJB_ERR_NOMEM, "extra: rows of target %d", tid);
         HIP_TRY(c, hipMemsetAsync(X.xr, 0, (size_t)J * sizeof(ExtraRow), st));
-        LAUNCH(c, "kx_flank", kx_flank, dim3((J + 255) / 256), dim3(256), (const pjb_junction_row *)c->b_rows.p, J, (const int32_t *)x_pos,
+        LAUNCH(c, "kx_flank", kx_flank, dim3((J + 255) / 256), dim3(256), (const pjb_junction_row *)c->sl[c->cur_slot].rows.p, J, (const int32_t *)x_pos,
                (u32)N, (const u32 *)prefq, (const u32 *)ce, L, (const u32 *)c->x_zlist.p, (const ExtraCounters *)d_cnt, X_ZCAP, X.xr);
         if (hipMalloc((void **)&X.pair_code, (size_t)P * 8) != hipSuccess || hipMalloc((void **)&X.pair_row, (size_t)P * 4) != hipSuccess)
             return fail(c, PJB_ERR_NOMEM, "extra: pair codes of target %d", tid);
         LAUNCH(c, "kx_pair_codes", kx_pair_codes, dim3((P + 255) / 256), dim3(256), sidx, (const u32 *)c->b_jid.p, pair_g,
-               (const DevBatch *)c->b_batches.p, (int)batches.size(), P, (u32)row_base, X.pair_code, X.pair_row);
+               (const DevBatch *)c->sl[c->cur_slot].batches.p, (int)batches.size(), P, (u32)row_base, X.pair_code, X.pair_row);
     }
     HIP_TRY(c, hipStreamSynchronize(st));
-    if (c->ktime) ev_collect(c);
+    if (c->ktime) ev_collect(c, MISC_POOL);
     c->xc.push_back(X);
     guard.x = nullptr;
     return PJB_OK;
@@ -772,30 +850,58 @@ static int extra_contig(pjb_ctx *c, int32_t tid, std::vector<DevBatch> &batches,
 
 // The device work of one contig, queued in one go.  The host does not learn a single count while the kernels run:
 // buffers and grids are sized from LIMITS (pair_limit, junc_limit, the key format kf), the kernels read the actual
-// counts from the control block in device memory (ContigStats) and stand still when a limit is exceeded.  The only
-// host synchronisation is at the end, when the control block -- counters, error word, overflow bits -- is back; the
-// rows have by then been written into page-locked host memory by the last kernels of the chain.
-struct ContigLimits {
-    u32 pair_limit = 0, junc_limit = 0;
-    KeyFmt kf;
-    bool dense = false; // sort ordered dense junction ids (K2d) instead of the full keys
-};
+// counts from the control block in device memory (ContigStats) and stand still when a limit is exceeded.  Nothing
+// here waits for the device: the last kernels (rows stream) write rows and control block into page-locked host memory
+// and pjb_finish_contig_end waits for their event -- by which time the next contig may be queued behind this one.
+static void wait_flight(pjb_ctx *c, Flight &f);
 
-static int run_contig_once(pjb_ctx *c, int32_t tid, std::vector<DevBatch> &batches, int64_t n_reads, u32 n_tiles, const ContigLimits &lim,
-                           ContigStats &cs_out, u64 &err_out, const u32 *&sidx_out, Pairs &pr_out, bool &forked) {
+// rows of the contigs collected so far plus the most the queued ones can add
+static size_t rows_upper_bound(const pjb_ctx *c) {
+    size_t n = c->rows_n;
+    for (int k = 0; k < c->n_fl; k++)
+        if (c->fl[k].queued) n += c->fl[k].lim.junc_limit;
+    return n;
+}
+
+static int queue_contig(pjb_ctx *c, Flight &f, std::vector<DevBatch> &batches) {
     hipStream_t st = c->stream;
+    const int32_t tid = f.tid;
+    const u32 n_tiles = f.n_tiles;
+    const ContigLimits &lim = f.lim;
+    CtlSlot &S = c->sl[f.slot];
     const int32_t ref_len = c->ref_len[(size_t)tid];
     const Contig &G = c->contigs[(size_t)tid];
     const KeyFmt kf = lim.kf;
     const u32 PL = lim.pair_limit, JL = lim.junc_limit;
     int rc;
-    if ((rc = ensure(c, c->b_batches, batches.size() * sizeof(DevBatch)))) return rc;
+    // the place of this contig's rows: known here if nothing is queued ahead of it, else it follows on the device
+    bool ahead = false;
+    for (int k = 0; k < c->n_fl; k++) ahead |= c->fl[k].queued && &c->fl[k] != &f;
+    const int64_t row_base = ahead ? -1 : (int64_t)c->rows_n, mirror_base = ahead ? -1 : (int64_t)c->mirror_rows;
+    struct PoolScope { // LAUNCH brackets of this chain belong to the contig's slot
+        pjb_ctx *c;
+        ~PoolScope() { c->cur_pool = MISC_POOL; }
+    } pool_scope{c};
+    c->cur_pool = f.slot;
+    c->cur_slot = f.slot;
+    ev_drop(c, f.slot);
+    if ((rc = ensure(c, S.batches, batches.size() * sizeof(DevBatch)))) return rc;
+    if (batches.size() > S.batches_pinned_cap) {
+        if (S.batches_pinned) (void)hipHostFree(S.batches_pinned);
+        S.batches_pinned = nullptr;
+        S.batches_pinned_cap = 0;
+        const size_t cap = std::max<size_t>(batches.size() * 2, 16);
+        HIP_TRY(c, hipHostMalloc((void **)&S.batches_pinned, cap * sizeof(DevBatch), hipHostMallocDefault));
+        S.batches_pinned_cap = cap;
+    }
+    memcpy(S.batches_pinned, batches.data(), batches.size() * sizeof(DevBatch));
+    if ((rc = ensure(c, S.cstats, sizeof(ContigStats)))) return rc;
+    if ((rc = ensure(c, S.err, 8))) return rc;
+    if ((rc = ensure(c, c->b_cursor, sizeof(RowCursor)))) return rc;
     if ((rc = ensure(c, c->b_tile_cnt, (size_t)n_tiles * 4))) return rc;
     if ((rc = ensure(c, c->b_tile_stats, (size_t)n_tiles * sizeof(TileStats)))) return rc;
-    if ((rc = ensure(c, c->b_cstats, sizeof(ContigStats)))) return rc;
     if ((rc = ensure(c, c->b_splidx, (size_t)n_tiles * K1_TILE * 4))) return rc;
     if ((rc = ensure(c, c->b_splpoff, (size_t)n_tiles * K1_TILE * 4))) return rc;
-    if ((rc = ensure(c, c->b_err, 8))) return rc;
     if ((rc = ensure(c, c->b_total, 8))) return rc;
     // ---- pair-sized buffers (one sort tile of slack: rs_scatter loads whole tiles unguarded)
     if ((rc = ensure(c, c->b_okey, ((size_t)PL + RS_TILE) * 8))) return rc; // the pairs' keys as emitted (BAM order): kept, the sort works on copies
@@ -814,7 +920,7 @@ static int run_contig_once(pjb_ctx *c, int32_t tid, std::vector<DevBatch> &batch
     const u32 pair_blocks = std::max<u32>(1, (PL + 255) / 256);
     const u32 gen_cap = ((pair_blocks + GEN_SHARDS - 1) / GEN_SHARDS) * 256; // entries per sub-list
     if ((rc = ensure(c, c->b_genlist, (size_t)gen_cap * GEN_SHARDS * 4))) return rc;
-    if ((rc = ensure(c, c->b_gencount, GEN_SHARDS * 4))) return rc;
+    if ((rc = ensure(c, S.gencount, GEN_SHARDS * 4))) return rc;
     // ---- junction-sized buffers
     const u32 slots_lim = JL + (PL + 63) / 64 + 1;
     if ((rc = ensure(c, c->b_frag, (size_t)slots_lim * F_WORDS * 4))) return rc;
@@ -824,10 +930,13 @@ static int run_contig_once(pjb_ctx *c, int32_t tid, std::vector<DevBatch> &batch
     if ((rc = ensure(c, c->b_acc, (size_t)JL * F_WORDS * 4 + 16))) return rc;
     if ((rc = ensure(c, c->b_ancl, (size_t)JL * 4 + 16))) return rc;
     if ((rc = ensure(c, c->b_ancr, (size_t)JL * 4 + 16))) return rc;
-    if ((rc = ensure(c, c->b_rows, (size_t)JL * sizeof(pjb_junction_row) + 16))) return rc;
-    // rows leave through page-locked host memory (grow-only; the kernel chain writes at rows_pinned + rows_n)
-    const size_t old = c->rows_n;
+    if ((rc = ensure(c, S.rows, (size_t)JL * sizeof(pjb_junction_row) + 16))) return rc;
+    // rows leave through page-locked host memory (grow-only; the rows stream writes behind the rows that are there)
+    size_t old = rows_upper_bound(c);
     if (old + JL > c->rows_cap) {
+        for (int k = 0; k < c->n_fl; k++) // (the table moves: nothing may be writing to it)
+            if (c->fl[k].queued && &c->fl[k] != &f) wait_flight(c, c->fl[k]);
+        old = std::min(old, c->rows_cap);
         const size_t ncap = std::max<size_t>((old + JL) * 3 / 2, 1024);
         pjb_junction_row *np = nullptr;
         hipError_t e = hipHostMalloc((void **)&np, ncap * sizeof(pjb_junction_row), hipHostMallocMapped | hipHostMallocPortable);
@@ -840,15 +949,29 @@ static int run_contig_once(pjb_ctx *c, int32_t tid, std::vector<DevBatch> &batch
         if (hipHostGetDevicePointer(&dp, np, 0) != hipSuccess || !dp) return fail(c, PJB_ERR_HIP, "hipHostGetDevicePointer(rows) failed");
         c->rows_pinned_dev = (pjb_junction_row *)dp;
     }
-    if (!c->res_pinned) HIP_TRY(c, hipHostMalloc((void **)&c->res_pinned, 4096, hipHostMallocDefault));
+    if (!S.pub) {
+        HIP_TRY(c, hipHostMalloc((void **)&S.pub, PUB_BYTES, hipHostMallocMapped | hipHostMallocPortable));
+        void *dp = nullptr;
+        if (hipHostGetDevicePointer(&dp, S.pub, 0) != hipSuccess || !dp) return fail(c, PJB_ERR_HIP, "hipHostGetDevicePointer(control block) failed");
+        S.pub_dev = (uint8_t *)dp;
+    }
 
-    HIP_TRY(c, hipMemcpyAsync(c->b_batches.p, batches.data(), batches.size() * sizeof(DevBatch), hipMemcpyHostToDevice, st));
-    HIP_TRY(c, hipMemsetAsync(c->b_err.p, 0xff, 8, st));
-    HIP_TRY(c, hipMemsetAsync(c->b_gencount.p, 0, GEN_SHARDS * 4, st));
-    u64 *d_err = (u64 *)c->b_err.p;
-    ContigStats *d_cs = (ContigStats *)c->b_cstats.p;
+    HIP_TRY(c, hipMemcpyAsync(S.batches.p, S.batches_pinned, batches.size() * sizeof(DevBatch), hipMemcpyHostToDevice, st));
+    if (!S.at_rest) {
+        HIP_TRY(c, hipMemsetAsync(S.err.p, 0xff, 8, st));
+        HIP_TRY(c, hipMemsetAsync(S.gencount.p, 0, GEN_SHARDS * 4, st));
+    }
+    S.at_rest = false; // until k7_publish is queued
+    u64 *d_err = (u64 *)S.err.p;
+    ContigStats *d_cs = (ContigStats *)S.cstats.p;
     const u32 *d_P = &d_cs->P, *d_J = &d_cs->J, *d_R = &d_cs->R, *d_slots = &d_cs->n_slots;
-    HIP_TRY(c, hipEventRecord(c->ev[0], st));
+    // stage boundaries are timed only under full instrumentation: an event between two kernels costs a ~6 us bubble
+    const bool stage_events = c->ktime && c->ktime_only.empty();
+#define STAGE_EVENT(k)                                            \
+    do {                                                          \
+        if (stage_events) HIP_TRY(c, hipEventRecord(S.ev[k], st));  \
+    } while (0)
+    HIP_TRY(c, hipEventRecord(S.ev[0], st));
     // ---- K1a: count
     for (auto &b : batches) {
         const u32 nt = (u32)((b.n + K1_TILE - 1) / K1_TILE);
@@ -867,7 +990,7 @@ static int run_contig_once(pjb_ctx *c, int32_t tid, std::vector<DevBatch> &batch
     pr.aend = (int32_t *)c->b_aend.p;
     pr.meta = (u32 *)c->b_meta.p;
     pr.updown = (u32 *)c->b_updown.p;
-    pr_out = pr;
+    f.pr = pr;
     for (auto &b : batches) {
         const u32 nt = (u32)((b.n + K1_TILE - 1) / K1_TILE);
         LAUNCH(c, "k1_emit", k1_emit, dim3(nt), dim3(256), b, (const u32 *)c->b_tile_cnt.p,
@@ -882,24 +1005,28 @@ static int run_contig_once(pjb_ctx *c, int32_t tid, std::vector<DevBatch> &batch
         HIP_TRY(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
         hipStream_t main_stream = c->stream;
         c->stream = c->stream2; // LAUNCH (and its event bracket) follow c->stream
-        forked = true;
-        LAUNCH(c, "k4a_simple", k4a_simple, dim3(pair_blocks), dim3(256), pr, kf, (const DevBatch *)c->b_batches.p,
+        f.forked = true;
+        LAUNCH(c, "k4a_simple", k4a_simple, dim3(pair_blocks), dim3(256), pr, kf, (const DevBatch *)S.batches.p,
                (int)batches.size(), (const u32 *)G.codes, (int32_t)G.len, d_P, (u64 *)c->b_res.p);
         c->stream = main_stream;
         HIP_TRY(c, hipEventRecord(c->ev_join, c->stream2));
     }
-    HIP_TRY(c, hipEventRecord(c->ev[1], st));
+    STAGE_EVENT(1);
 
     // ---- K2d: ordered dense junction ids (the sort then works on 15-19 bits instead of 46-48)
     int sort_bits = kf.total_bits;
     if (lim.dense) {
         const size_t n_words = ((size_t)std::max(ref_len, 1) + 63) / 64;
+        const void *was[2] = {c->b_bitmap.p, c->b_ends.p};
         if ((rc = ensure(c, c->b_bitmap, n_words * 8 + 16))) return rc;
         if ((rc = ensure(c, c->b_wrank, n_words * 4 + 16))) return rc;
         if ((rc = ensure(c, c->b_ends, (size_t)JL * DENSE_ENDS * 4 + 32))) return rc;
         if ((rc = ensure(c, c->b_firstid, (size_t)JL * 4 + 16))) return rc;
-        HIP_TRY(c, hipMemsetAsync(c->b_bitmap.p, 0, n_words * 8, st));
-        HIP_TRY(c, hipMemsetAsync(c->b_ends.p, 0xff, (size_t)JL * DENSE_ENDS * 4, st));
+        if (!c->dense_at_rest || was[0] != c->b_bitmap.p || was[1] != c->b_ends.p) { // (first use, new memory, or a chain that broke off)
+            HIP_TRY(c, hipMemsetAsync(c->b_bitmap.p, 0, c->b_bitmap.cap, st));
+            HIP_TRY(c, hipMemsetAsync(c->b_ends.p, 0xff, c->b_ends.cap, st));
+        }
+        c->dense_at_rest = false; // until kd_reset is queued
         const u64 *okey = (const u64 *)pr.key;
         const u32 kd_tiles = std::max<u32>(1, (PL + KD_TILE - 1) / KD_TILE);
         u64 *cand = (u64 *)c->b_key[1].p; // (free until the first scatter; the candidates are used up before it)
@@ -908,14 +1035,18 @@ static int run_contig_once(pjb_ctx *c, int32_t tid, std::vector<DevBatch> &batch
         if ((rc = run_scan(c, "kd_rank", PopcFn{(const u64 *)c->b_bitmap.p}, ExclusiveU32Sink{(u32 *)c->b_wrank.p}, (u64)n_words,
                            (u64 *)c->b_total.p)))
             return rc;
+        u32 *cand_rank = (u32 *)c->b_idx[1].p; // (free until the first scatter as well)
         LAUNCH(c, "kd_ends", kd_ends, dim3(pair_blocks), dim3(256), (const u64 *)cand, kf, (const u64 *)c->b_bitmap.p, (const u32 *)c->b_wrank.p, JL,
-               (u32 *)c->b_ends.p, d_cs);
+               (u32 *)c->b_ends.p, cand_rank, d_cs);
         if ((rc = run_scan(c, "kd_first", EndsCountFn{(const u32 *)c->b_ends.p}, ExclusiveU32Sink{(u32 *)c->b_firstid.p}, (u64)JL,
                            (u64 *)c->b_total.p)))
             return rc;
         LAUNCH(c, "kd_close", kd_close, dim3(1), dim3(1), d_cs);
         LAUNCH(c, "kd_assign", kd_assign, dim3(pair_blocks), dim3(256), okey, d_P, kf, (const u64 *)c->b_bitmap.p, (const u32 *)c->b_wrank.p,
                (const u32 *)c->b_ends.p, (const u32 *)c->b_firstid.p, (u64 *)c->b_key[0].p);
+        LAUNCH(c, "kd_reset", kd_reset, dim3(pair_blocks), dim3(256), (const u64 *)cand, (const u32 *)cand_rank, kf, JL, (const ContigStats *)d_cs,
+               (u64 *)c->b_bitmap.p, (u32 *)c->b_ends.p);
+        c->dense_at_rest = true;
         sort_bits = std::max(1, bits_of((uint64_t)JL));
     }
     // ---- K2: radix sort (key, pair index); digits: as few passes as the widest digit allows, bits spread evenly
@@ -952,11 +1083,11 @@ static int run_contig_once(pjb_ctx *c, int32_t tid, std::vector<DevBatch> &batch
         cur ^= 1;
         shift += bits;
     }
-    c->timing.sort_passes = n_pass;
+    f.n_pass = n_pass;
     const u64 *skey = (const u64 *)c->b_key[cur].p;
     const u32 *sidx = (const u32 *)c->b_idx[cur].p;
-    sidx_out = sidx;
-    HIP_TRY(c, hipEventRecord(c->ev[2], st));
+    f.sidx = sidx;
+    STAGE_EVENT(2);
 
     // ---- K2s: junction ids, position runs
     {
@@ -966,7 +1097,7 @@ static int run_contig_once(pjb_ctx *c, int32_t tid, std::vector<DevBatch> &batch
         LAUNCH(c, "k2_close", k2_close, dim3(1), dim3(1), (u64 *)c->b_total.p, (u32 *)c->b_seg.p, (u32 *)c->b_runfirst.p,
                (u32 *)c->b_runstart.p, d_cs, JL);
     }
-    HIP_TRY(c, hipEventRecord(c->ev[3], st));
+    STAGE_EVENT(3);
 
     // ---- K3: anchors
     const u32 slot_blocks = (slots_lim + 255) / 256;
@@ -976,22 +1107,22 @@ static int run_contig_once(pjb_ctx *c, int32_t tid, std::vector<DevBatch> &batch
     LAUNCH(c, "k3_anchors_frag", k3_anchors_frag, dim3(pair_blocks), dim3(256), sidx, (const u32 *)c->b_jid.p,
            (const int32_t *)pr.lstart, (const int32_t *)pr.rend, (const u32 *)pr.meta, fast_codes ? 0 : 1, d_P,
            (int32_t *)c->b_fragl.p, (int32_t *)c->b_fragr.p, (int32_t *)c->b_fragj.p, (u32 *)c->b_genlist.p,
-           (u32 *)c->b_gencount.p);
+           (u32 *)S.gencount.p);
     LAUNCH(c, "k3_anchors_junc", k3_anchors_junc, dim3(slot_blocks), dim3(256), (const int32_t *)c->b_fragl.p,
            (const int32_t *)c->b_fragr.p, (const int32_t *)c->b_fragj.p, d_slots, (int32_t *)c->b_ancl.p,
            (int32_t *)c->b_ancr.p);
-    HIP_TRY(c, hipEventRecord(c->ev[4], st));
+    STAGE_EVENT(4);
 
     if (fast_codes) HIP_TRY(c, hipStreamWaitEvent(st, c->ev_join, 0)); // k4a_simple's results (side stream) are needed from here on
     // ---- K4b: the pairs that need the generic walks (list length lives on the device; the grid covers the
     // worst case and surplus blocks exit at once), then K4: gather + segmented reduce -> fragments
     LAUNCH(c, "k4b_generic", k4b_generic, dim3((gen_cap * GEN_SHARDS + 255) / 256), dim3(256), (const u32 *)c->b_genlist.p,
-           (const u32 *)c->b_gencount.p, pair_blocks, skey, sidx, (const u32 *)c->b_jid.p, pr, kf, (const DevBatch *)c->b_batches.p,
+           (const u32 *)S.gencount.p, pair_blocks, skey, sidx, (const u32 *)c->b_jid.p, pr, kf, (const DevBatch *)S.batches.p,
            (int)batches.size(), (const int32_t *)c->b_ancl.p, (const int32_t *)c->b_ancr.p, (const uint8_t *)G.d,
            (int32_t)G.len, G.has_x ? 1 : 0, (const u32 *)(G.has_x ? nullptr : G.codes), (u64 *)c->b_res.p, d_err);
     LAUNCH(c, "k4_pairs", k4_pairs, dim3(pair_blocks), dim3(256), skey, sidx, (const u32 *)c->b_jid.p, pr, kf,
            (const u64 *)c->b_res.p, d_P, (u32 *)c->b_frag.p, (int32_t *)c->b_fragj.p);
-    HIP_TRY(c, hipEventRecord(c->ev[5], st));
+    STAGE_EVENT(5);
 
     // ---- K5: fragments -> junctions -> rows
     LAUNCH(c, "k5_frag_reduce", k5_frag_reduce, dim3((slots_lim + 4 * FRAG_SLOTS_PER_WAVE - 1) / (4 * FRAG_SLOTS_PER_WAVE)), dim3(256),
@@ -1004,78 +1135,102 @@ static int run_contig_once(pjb_ctx *c, int32_t tid, std::vector<DevBatch> &batch
     LAUNCH(c, "k5_finalize", k5_finalize, dim3(std::max<u32>(1, (JL + 255) / 256)), dim3(256), (const u64 *)pr.key, sidx, (const u32 *)c->b_seg.p,
            (const u32 *)c->b_runfirst.p, (const u32 *)c->b_runstart.p, (const u32 *)c->b_acc.p,
            (const int32_t *)c->b_ancl.p, (const int32_t *)c->b_ancr.p, kf, (const uint8_t *)G.d, (int32_t)G.len, tid, d_J,
-           (const double *)c->b_entsum.p, (pjb_junction_row *)c->b_rows.p, d_err);
-    HIP_TRY(c, hipEventRecord(c->ev[6], st));
+           (const double *)c->b_entsum.p, (pjb_junction_row *)S.rows.p, d_err);
+    STAGE_EVENT(6);
 
-    // ---- rows to the host (and into the caller's exchange slot), control block last
-    u64 *mirror_rows = nullptr;
-    u32 mirror_room = 0; // rows the caller's slot can still take (the kernel leaves the slot alone if the contig has more)
-    if (c->mirror) {
-        const size_t at = PJB_MIRROR_HEADER_BYTES + c->mirror_rows * sizeof(pjb_junction_row);
-        if (at <= c->mirror_cap) {
-            mirror_rows = (u64 *)(c->mirror + at);
-            mirror_room = (u32)std::min<size_t>((c->mirror_cap - at) / sizeof(pjb_junction_row), 0xffffffffu);
-        }
+    // ---- rows to the host (and into the caller's exchange slot), control block last: on the rows stream, so that the
+    // next contig's first kernels need not wait for the PCIe writes
+    u64 *mirror_table = nullptr;
+    u32 mirror_room = 0; // rows the caller's slot can take (the kernel leaves the slot alone if the contig does not fit)
+    if (c->mirror && c->mirror_cap >= PJB_MIRROR_HEADER_BYTES) {
+        mirror_table = (u64 *)(c->mirror + PJB_MIRROR_HEADER_BYTES);
+        mirror_room = (u32)std::min<size_t>((c->mirror_cap - PJB_MIRROR_HEADER_BYTES) / sizeof(pjb_junction_row), 0xffffffffu);
     }
+    HIP_TRY(c, hipEventRecord(S.ev_rows, st));
+    HIP_TRY(c, hipStreamWaitEvent(c->stream3, S.ev_rows, 0));
     {
+        struct StreamScope {
+            pjb_ctx *c;
+            hipStream_t main;
+            ~StreamScope() { c->stream = main; }
+        } scope{c, c->stream};
+        c->stream = c->stream3; // LAUNCH (and its event bracket) follow c->stream
         const u64 units = std::max<u64>(1, (u64)JL * ROW_U64);
-        LAUNCH(c, "k6_rows_out", k6_rows_out, dim3((unsigned)((units + 255) / 256)), dim3(256), (const u64 *)c->b_rows.p, d_J,
-               (u64 *)(c->rows_pinned_dev + old), mirror_rows, mirror_room);
+        LAUNCH(c, "k6_rows_out", k6_rows_out, dim3((unsigned)((units + 255) / 256)), dim3(256), (const u64 *)S.rows.p, (const ContigStats *)d_cs,
+               (u64 *)c->rows_pinned_dev, row_base, mirror_base, (const RowCursor *)c->b_cursor.p, mirror_table, mirror_room);
+        LAUNCH(c, "k7_publish", k7_publish, dim3(1), dim3(256), (const ContigStats *)d_cs, d_err, (u32 *)S.gencount.p, S.pub_dev, row_base,
+               mirror_base, (RowCursor *)c->b_cursor.p);
     }
-    uint8_t *hres = (uint8_t *)c->res_pinned;
-    HIP_TRY(c, hipMemcpyAsync(hres, d_cs, sizeof(ContigStats), hipMemcpyDeviceToHost, st));
-    HIP_TRY(c, hipMemcpyAsync(hres + 256, d_err, 8, hipMemcpyDeviceToHost, st));
-    HIP_TRY(c, hipMemcpyAsync(hres + 512, c->b_gencount.p, GEN_SHARDS * 4, hipMemcpyDeviceToHost, st));
-    HIP_TRY(c, hipEventRecord(c->ev[7], st));
-    HIP_TRY(c, hipStreamSynchronize(st)); // THE synchronisation of this contig
-    memcpy(&cs_out, hres, sizeof cs_out);
-    memcpy(&err_out, hres + 256, 8);
-    c->timing.generic_pairs = 0;
-    for (u32 k = 0; k < GEN_SHARDS; k++) c->timing.generic_pairs += ((const u32 *)(hres + 512))[k];
+    S.at_rest = true;
+    HIP_TRY(c, hipEventRecord(S.ev[7], c->stream3));
+    HIP_TRY(c, hipEventRecord(S.ev_done, c->stream3));
+#undef STAGE_EVENT
+    f.queued = true;
     return PJB_OK;
 }
 
-int pjb_finish_contig(pjb_ctx *c, int32_t tid, pjb_region_result *res) {
+// blocks until the contig's rows and control block are on the host
+static void wait_flight(pjb_ctx *c, Flight &f) {
+    if (f.queued) (void)hipEventSynchronize(c->sl[f.slot].ev_done);
+}
+
+// The contigs queued behind fl[0] are taken back (after an overflow or an error of fl[0] their rows are in the wrong
+// place): their device work is allowed to finish and is thrown away; their own pjb_finish_contig_end queues them again.
+static void unqueue_followers(pjb_ctx *c) {
+    for (int k = 1; k < c->n_fl; k++) {
+        Flight &g = c->fl[k];
+        if (!g.queued) continue;
+        wait_flight(c, g);
+        if (g.forked) (void)hipStreamSynchronize(c->stream2);
+        g.queued = false;
+        g.forked = false;
+        ev_drop(c, g.slot);
+    }
+}
+
+static void pop_flight(pjb_ctx *c) {
+    if (c->n_fl <= 0) return;
+    const int slot0 = c->fl[0].slot;
+    if (c->n_fl == 2) c->fl[0] = c->fl[1];
+    c->n_fl--;
+    c->fl[c->n_fl] = Flight();
+    c->fl[c->n_fl].slot = c->n_fl == 1 ? 1 - c->fl[0].slot : slot0;
+    if (c->n_fl == 0) c->fl[1].slot = 1 - c->fl[0].slot;
+}
+
+static std::vector<DevBatch> g_no_batches;
+
+int pjb_finish_contig_begin(pjb_ctx *c, int32_t tid) {
     if (!c) return PJB_ERR_ARG;
     if (tid < 0 || (size_t)tid >= c->ref_len.size()) return fail(c, PJB_ERR_ARG, "finish: bad tid %d", tid);
+    if (c->n_fl >= 2) return fail(c, PJB_ERR_STATE, "finish: two targets are queued already (%d, %d); collect one first", c->fl[0].tid, c->fl[1].tid);
+    if (c->n_fl == 1 && c->fl[0].tid == tid) return fail(c, PJB_ERR_STATE, "finish: target %d is queued already", tid);
+    if (c->n_fl == 1 && c->extra) return fail(c, PJB_ERR_STATE, "finish: with PJB_FLAG_EXTRA targets are finished one at a time");
     c->cur_tid = tid;
-    struct Closer { // also on every error path: the side stream (k4a_simple) may still read the contig's batches
-        pjb_ctx *c;
-        int32_t tid;
-        bool forked = false;
-        ~Closer() {
-            if (forked) (void)hipStreamSynchronize(c->stream2);
-            close_contig(c, tid);
-        }
-    } closer{c, tid};
-    static std::vector<DevBatch> no_batches;
-    auto open_it = c->open.find(tid);
-    std::vector<DevBatch> &batches = open_it == c->open.end() ? no_batches : open_it->second.batches;
-    pjb_region_result R;
-    memset(&R, 0, sizeof R);
-    R.min_len = INT32_MAX;
-    memset(&c->timing, 0, sizeof c->timing);
-    c->last_rows_n = 0;
-    c->ev_name.clear();
-    c->ev_used = 0;
-    if (res) *res = R;
     HIP_TRY(c, hipSetDevice(c->cfg.device));
-    if (batches.empty()) return mirror_header_only(c, R);
-    const int32_t ref_len = c->ref_len[(size_t)tid];
-    int rc;
-    u32 n_tiles = 0;
-    int64_t n_reads = 0;
+    Flight &f = c->fl[c->n_fl];
+    const int slot = f.slot;
+    f = Flight();
+    f.slot = slot;
+    f.tid = tid;
+    auto open_it = c->open.find(tid);
+    if (open_it == c->open.end() || open_it->second.batches.empty()) {
+        f.empty = true;
+        c->n_fl++;
+        return PJB_OK;
+    }
+    std::vector<DevBatch> &batches = open_it->second.batches;
     {
         int32_t prev_pos = INT32_MIN;
         const int32_t *prev_ptr = nullptr;
         OpenContig &oc = open_it->second;
         for (size_t k = 0; k < batches.size(); k++) {
             DevBatch &b = batches[k];
-            b.tile_base = n_tiles;
-            n_tiles += (u32)((b.n + K1_TILE - 1) / K1_TILE);
+            b.tile_base = f.n_tiles;
+            f.n_tiles += (u32)((b.n + K1_TILE - 1) / K1_TILE);
             b.prev_pos = prev_pos;
             b.prev_pos_ptr = prev_ptr; // sortedness across batches: the last position of the previous batch, wherever it is known
-            n_reads += b.n;
+            f.n_reads += b.n;
             if (oc.last_known[k]) {
                 prev_pos = oc.last_pos[k];
                 prev_ptr = nullptr;
@@ -1083,13 +1238,14 @@ int pjb_finish_contig(pjb_ctx *c, int32_t tid, pjb_region_result *res) {
                 prev_ptr = b.pos + (b.n - 1);
         }
     }
+    const int32_t ref_len = c->ref_len[(size_t)tid];
     const Contig &G = c->contigs[(size_t)tid];
-    // ---- limits.  Pairs: what the arena already holds, at least a share of the reads (a contig with more N operations
-    // than that is repeated once with the exact count).  Junctions: an eighth of the pair limit.  Key: contig coordinates
-    // and the longest intron seen by this context so far.
-    ContigLimits lim;
+    // ---- limits.  Pairs: a share of the reads (a contig with more N operations than that is repeated once with the
+    // exact count).  Junctions: a share of the pair limit, at least twice what a contig of this context has had.  Key:
+    // contig coordinates and the longest intron seen by this context so far.
+    ContigLimits &lim = f.lim;
     {
-        const u64 guess = std::min<u64>(0xffffff00ull, (u64)n_reads * 5 / 8 + 4096);
+        const u64 guess = std::min<u64>(0xffffff00ull, (u64)f.n_reads * 5 / 8 + 4096);
         lim.pair_limit = (u32)std::max<u64>(guess, 4096);
         lim.junc_limit = std::max<u32>(std::max<u32>(lim.pair_limit / 32, 4096), 2 * c->junc_seen);
         // without the contig's genome only the counting stage may run: any pair then shows up as an overflow
@@ -1099,20 +1255,81 @@ int pjb_finish_contig(pjb_ctx *c, int32_t tid, pjb_region_result *res) {
         lim.kf.total_bits = lim.kf.lbits + std::max(1, bits_of((uint64_t)std::max(ref_len, 1)));
         lim.dense = c->dense_ids;
     }
+    c->n_fl++;
+    if (c->extra) return PJB_OK; // (queued by pjb_finish_contig_end: the extra metrics need this contig's scratch untouched)
+    // a follower that was taken back goes first (rows are in contig order)
+    if (c->n_fl == 2 && !c->fl[0].queued && !c->fl[0].empty) return PJB_OK; // (both are queued in order by the first one's end)
+    const int rc = queue_contig(c, f, batches);
+    if (rc) { // nothing of this contig stays behind
+        (void)hipDeviceSynchronize();
+        c->n_fl--;
+        const int sl = c->fl[c->n_fl].slot;
+        c->fl[c->n_fl] = Flight();
+        c->fl[c->n_fl].slot = sl;
+        close_contig(c, tid);
+    }
+    return rc;
+}
+
+int pjb_finish_contig_end(pjb_ctx *c, int32_t tid, pjb_region_result *res) {
+    if (!c) return PJB_ERR_ARG;
+    if (c->n_fl <= 0 || c->fl[0].tid != tid)
+        return fail(c, PJB_ERR_STATE, "finish: target %d is not the oldest queued target (pjb_finish_contig_begin first; collect in the same order)", tid);
+    c->cur_tid = tid;
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    struct Closer { // also on every error path: the side stream (k4a_simple) may still read the contig's batches
+        pjb_ctx *c;
+        int32_t tid;
+        bool ok = false;
+        ~Closer() {
+            Flight &f = c->fl[0];
+            if (!ok) { // whatever is queued is in an unknown place now
+                (void)hipDeviceSynchronize();
+                unqueue_followers(c);
+            } else if (f.forked && f.queued)
+                (void)0; // (joined by the main stream before k4b; the chain has completed)
+            pop_flight(c);
+            close_contig(c, tid);
+        }
+    } closer{c, tid};
+    Flight &f = c->fl[0];
+    pjb_region_result R;
+    memset(&R, 0, sizeof R);
+    R.min_len = INT32_MAX;
+    memset(&c->timing, 0, sizeof c->timing);
+    c->last_rows_n = 0;
+    if (res) *res = R;
+    if (f.empty) {
+        const int rc = mirror_header_only(c, R);
+        closer.ok = rc == PJB_OK;
+        return rc;
+    }
+    auto open_it = c->open.find(tid);
+    if (open_it == c->open.end()) return fail(c, PJB_ERR_STATE, "finish: target %d lost its batches", tid);
+    std::vector<DevBatch> &batches = open_it->second.batches;
+    const int32_t ref_len = c->ref_len[(size_t)tid];
+    const Contig &G = c->contigs[(size_t)tid];
+    CtlSlot &S = c->sl[f.slot];
+    ContigLimits &lim = f.lim;
+    int rc;
     ContigStats cs;
     u64 herr = ~0ull;
-    const u32 *sidx = nullptr;
-    Pairs pr;
-    memset(&pr, 0, sizeof pr);
-    for (int attempt = 0;; attempt++) {
-        if ((rc = run_contig_once(c, tid, batches, n_reads, n_tiles, lim, cs, herr, sidx, pr, closer.forked))) return rc;
+    for (;; f.attempt++) {
+        if (!f.queued && (rc = queue_contig(c, f, batches))) return rc;
+        wait_flight(c, f);
+        memcpy(&cs, S.pub, sizeof cs);
+        memcpy(&herr, S.pub + PUB_ERR_AT, 8);
         if ((rc = check_device_error(c, herr))) return rc;
         if (cs.n_pairs > 0 && !G.present) return fail(c, PJB_ERR_STATE, "finish: genome of target %d was not uploaded", tid);
         if (cs.n_pairs > 0 && G.len != ref_len)
             return fail(c, PJB_ERR_ARG, "finish: genome of target %d has %lld bases, header says %d", tid, (long long)G.len, ref_len);
         if (!cs.overflow) break;
-        if (attempt >= 3) return fail(c, PJB_ERR_STATE, "finish: limits of target %d did not settle (overflow bits %u)", tid, cs.overflow);
-        // a limit was too small: the control block says by how much; everything is queued again
+        if (f.attempt >= 3) return fail(c, PJB_ERR_STATE, "finish: limits of target %d did not settle (overflow bits %u)", tid, cs.overflow);
+        // a limit was too small: the control block says by how much; everything is queued again (and so is the contig
+        // queued behind this one: its rows went where this one's belong)
+        unqueue_followers(c);
+        if (f.forked) (void)hipStreamSynchronize(c->stream2);
+        f.queued = f.forked = false;
         if (cs.overflow & OVF_PAIRS) {
             if (cs.n_pairs >= 0xfffffff0ull) return fail(c, PJB_ERR_ARG, "finish: more than 2^32 spliced pairs on one target are not supported");
             lim.pair_limit = (u32)cs.n_pairs + 64;
@@ -1131,12 +1348,6 @@ int pjb_finish_contig(pjb_ctx *c, int32_t tid, pjb_region_result *res) {
         }
         if (cs.overflow & OVF_JUNC) lim.junc_limit = std::max<u32>(cs.n_junc + 64, (cs.overflow & OVF_DENSE) || !lim.dense ? 0u : lim.junc_limit * 4);
         if (cs.overflow & OVF_DENSE) lim.dense = false; // a donor with more alternative acceptors than K2d keeps: sort the full keys
-        if (closer.forked) {
-            (void)hipStreamSynchronize(c->stream2);
-            closer.forked = false;
-        }
-        c->ev_name.clear();
-        c->ev_used = 0;
     }
     if (!lim.kf.raw) c->lbits_seen = std::max(c->lbits_seen, std::max(1, bits_of((uint64_t)cs.max_nlen)));
     R.spliced = cs.spliced;
@@ -1144,27 +1355,55 @@ int pjb_finish_contig(pjb_ctx *c, int32_t tid, pjb_region_result *res) {
     R.sum_len = cs.sum_len;
     R.min_len = cs.min_len;
     R.max_len = cs.max_len;
-    R.n_reads = n_reads;
+    R.n_reads = f.n_reads;
     R.n_pairs = (int64_t)cs.n_pairs;
     const u32 P = cs.P, J = cs.J;
     R.n_junctions = J;
     c->junc_seen = std::max(c->junc_seen, J);
+    c->timing.sort_passes = f.n_pass;
+    c->timing.generic_pairs = 0;
+    for (u32 k = 0; k < GEN_SHARDS; k++) c->timing.generic_pairs += ((const u32 *)(S.pub + PUB_GEN_AT))[k];
     const size_t old = c->rows_n;
+    {
+        u32 at[2];
+        memcpy(at, S.pub + PUB_BASE_AT, 8);
+        if (at[0] != (u32)old || (c->mirror && at[1] != (u32)c->mirror_rows))
+            return fail(c, PJB_ERR_STATE, "finish: rows of target %d went to %u (exchange slot %u), expected %zu (%zu)", tid, at[0], at[1], old, c->mirror_rows);
+    }
     if (c->mirror) { // the rows are in the exchange slot already (k6_rows_out); the header follows, covered by a small wait
         const size_t need = PJB_MIRROR_HEADER_BYTES + (c->mirror_rows + J) * sizeof(pjb_junction_row);
         if (need > c->mirror_cap) return fail(c, PJB_ERR_ARG, "finish: %zu rows do not fit the row mirror (%zu bytes)", c->mirror_rows + J, c->mirror_cap);
         mirror_fold(c, R, J);
-        HIP_TRY(c, hipMemcpyAsync(c->mirror, c->mirror_hdr, PJB_MIRROR_HEADER_BYTES, hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        HIP_TRY(c, hipMemcpyAsync(c->mirror, c->mirror_hdr, PJB_MIRROR_HEADER_BYTES, hipMemcpyHostToDevice, c->stream4));
+        HIP_TRY(c, hipStreamSynchronize(c->stream4));
     }
-    if (c->extra && (rc = extra_contig(c, tid, batches, n_reads, cs.spliced, P, J, sidx, pr.g, old))) return rc;
+    c->cur_slot = f.slot;
+    if (c->extra && (rc = extra_contig(c, tid, batches, f.n_reads, cs.spliced, P, J, f.sidx, f.pr.g, old))) return rc;
     c->rows_n = old + J;
     c->last_rows_n = J;
-    if (c->ktime) ev_collect(c);
-    for (int k = 0; k < 7; k++) (void)hipEventElapsedTime(&c->timing.stage_ms[k], c->ev[k], c->ev[k + 1]);
-    (void)hipEventElapsedTime(&c->timing.total_ms, c->ev[0], c->ev[7]);
+    c->last_slot = f.slot;
+    if (c->ktime) ev_collect(c, f.slot);
+    if (c->ktime && c->ktime_only.empty())
+        for (int k = 0; k < 7; k++) (void)hipEventElapsedTime(&c->timing.stage_ms[k], S.ev[k], S.ev[k + 1]);
+    (void)hipEventElapsedTime(&c->timing.total_ms, S.ev[0], S.ev[7]);
     if (res) *res = R;
+    closer.ok = true;
+    // a follower that was taken back (or waited for this one) is queued now, its place known
+    if (c->n_fl == 2 && !c->fl[1].queued && !c->fl[1].empty && !c->extra) {
+        auto it = c->open.find(c->fl[1].tid);
+        if (it != c->open.end()) {
+            // (fl[0] is still this contig: count its rows as collected -- they are -- and skip it as "ahead")
+            f.queued = false;
+            if ((rc = queue_contig(c, c->fl[1], it->second.batches))) return rc;
+        }
+    }
     return PJB_OK;
+}
+
+int pjb_finish_contig(pjb_ctx *c, int32_t tid, pjb_region_result *res) {
+    const int rc = pjb_finish_contig_begin(c, tid);
+    if (rc) return rc;
+    return pjb_finish_contig_end(c, tid, res);
 }
 
 int pjb_collect(pjb_ctx *c, const pjb_junction_row **rows, int64_t *n) {
@@ -1176,7 +1415,7 @@ int pjb_collect(pjb_ctx *c, const pjb_junction_row **rows, int64_t *n) {
 
 int pjb_collect_device(pjb_ctx *c, const pjb_junction_row **rows, int64_t *n) {
     if (!c || !rows || !n) return PJB_ERR_ARG;
-    *rows = (const pjb_junction_row *)c->b_rows.p;
+    *rows = (const pjb_junction_row *)c->sl[c->last_slot].rows.p;
     *n = (int64_t)c->last_rows_n;
     return PJB_OK;
 }
@@ -1184,6 +1423,7 @@ int pjb_collect_device(pjb_ctx *c, const pjb_junction_row **rows, int64_t *n) {
 int pjb_set_row_mirror(pjb_ctx *c, void *device_buffer, int64_t cap_bytes) {
     if (!c) return PJB_ERR_ARG;
     if (device_buffer && cap_bytes < PJB_MIRROR_HEADER_BYTES) return fail(c, PJB_ERR_ARG, "set_row_mirror: buffer smaller than its header");
+    if (c->n_fl) return fail(c, PJB_ERR_STATE, "set_row_mirror: target %d is still queued", c->fl[0].tid);
     c->mirror = (uint8_t *)device_buffer;
     c->mirror_cap = device_buffer ? (size_t)cap_bytes : 0;
     mirror_reset(c);
@@ -1196,6 +1436,7 @@ int pjb_set_row_mirror(pjb_ctx *c, void *device_buffer, int64_t cap_bytes) {
 
 int pjb_clear_rows(pjb_ctx *c) {
     if (!c) return PJB_ERR_ARG;
+    if (c->n_fl) return fail(c, PJB_ERR_STATE, "clear_rows: target %d is still queued", c->fl[0].tid);
     c->rows_n = 0;
     mirror_reset(c);
     if (c->extra) {
@@ -1290,7 +1531,7 @@ int pjb_extra_finish(pjb_ctx *c, const pjb_extra_row **rows_out, int64_t *n_out)
         }
     }
     HIP_TRY(c, hipStreamSynchronize(st));
-    if (c->ktime) ev_collect(c);
+    if (c->ktime) ev_collect(c, MISC_POOL);
     return PJB_OK;
 }
 
@@ -1349,7 +1590,7 @@ int pjb_filter_batch(pjb_ctx *c, int32_t tid, const pjb_batch *b, int32_t clip_m
            (const u32 *)c->f_cigar.p, (u32)n, keys, n_keys, (int)clip_mode, (uint8_t *)c->f_codes.p);
     HIP_TRY(c, hipMemcpyAsync(codes_out, c->f_codes.p, n, hipMemcpyDeviceToHost, st));
     HIP_TRY(c, hipStreamSynchronize(st));
-    if (c->ktime) ev_collect(c);
+    if (c->ktime) ev_collect(c, MISC_POOL);
     return PJB_OK;
 }
 
@@ -1401,7 +1642,7 @@ int pjb_filt_features(pjb_ctx *c, const pjb_junction_row *rows, int64_t n_rows, 
     HIP_TRY(c, hipMemcpyAsync(features_out, c->g_out.p, n * PJB_N_FEATURES * sizeof(double), hipMemcpyDeviceToHost, st));
     HIP_TRY(c, hipMemcpyAsync(&bad, c->g_bad.p, sizeof(int), hipMemcpyDeviceToHost, st));
     HIP_TRY(c, hipStreamSynchronize(st));
-    if (c->ktime) ev_collect(c);
+    if (c->ktime) ev_collect(c, MISC_POOL);
     if (bad) return fail(c, PJB_ERR_STATE, "pjb_filt_features: a junction lies on a target whose genome was not uploaded");
     return PJB_OK;
 }
@@ -1551,7 +1792,7 @@ int inflate_on_device(pjb_ctx *c, const uint8_t *d_comp, const std::vector<InfBl
     int any = 0;
     HIP_TRY(c, hipMemcpyAsync(&any, d_any, 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(c, hipStreamSynchronize(st));
-    if (c->ktime) ev_collect(c);
+    if (c->ktime) ev_collect(c, MISC_POOL);
     if (any) {
         std::vector<int> status(nb);
         HIP_TRY(c, hipMemcpy(status.data(), d_status, nb * 4, hipMemcpyDeviceToHost));
@@ -1752,7 +1993,7 @@ extern "C" int pjb_submit_bam(pjb_ctx *c, int32_t tid, const uint8_t *comp, int6
     if (!B.cigar || !B.seq4) return fail(c, PJB_ERR_NOMEM, "submit_bam: out of device memory for CIGARs / bases");
     LAUNCH(c, "bam_transcode", bam_transcode, dim3((unsigned)((n + 255) / 256)), dim3(256), R.U, (const iu64 *)c->b_bam_rec.p, (iu64)n, B);
     HIP_TRY(c, hipStreamSynchronize(st)); // `tails` is on this stack frame
-    if (c->ktime) ev_collect(c);
+    if (c->ktime) ev_collect(c, MISC_POOL);
     if (prof)
         fprintf(stderr, "[host profile] submit_bam tid %d: %zu blocks, %.1f MB -> %.1f MB, %zu records: header scan %.3f, upload %.3f, inflate %.3f, "
                         "boundaries %.3f, fill+sizes+transcode %.3f s\n",

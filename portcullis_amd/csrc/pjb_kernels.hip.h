@@ -857,12 +857,13 @@ struct PopcFn {
     __device__ u64 operator()(u64 i) const { return (u64)__popcll(words[i]); }
 };
 __global__ __launch_bounds__(256) void kd_ends(const u64 *cand, KeyFmt kf, const u64 *bitmap, const u32 *wrank, u32 junc_limit, u32 *ends,
-                                               ContigStats *cs) {
+                                               u32 *cand_rank, ContigStats *cs) {
     const u32 p = blockIdx.x * 256 + threadIdx.x;
     if (p >= cs->n_cand) return;
     int32_t s, e;
     unpack_key(kf, cand[p], s, e);
     const u32 rs = start_rank(bitmap, wrank, s);
+    cand_rank[p] = rs;
     if (rs >= junc_limit) {
         atomicOr(&cs->overflow, OVF_JUNC);
         return;
@@ -875,6 +876,21 @@ __global__ __launch_bounds__(256) void kd_ends(const u64 *cand, KeyFmt kf, const
         // else: the slot holds another end (slots never change once set)
     }
     atomicOr(&cs->overflow, OVF_DENSE);
+}
+// Bitmap and end slots are all-clear at rest: instead of two memsets over contig-sized buffers per contig, the
+// candidates wipe exactly what they set (after kd_assign has read it).
+__global__ __launch_bounds__(256) void kd_reset(const u64 *cand, const u32 *cand_rank, KeyFmt kf, u32 junc_limit, const ContigStats *cs,
+                                                u64 *bitmap, u32 *ends) {
+    const u32 p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= cs->n_cand) return;
+    int32_t s, e;
+    unpack_key(kf, cand[p], s, e);
+    bitmap[(u32)s >> 6] = 0;
+    const u32 rs = cand_rank[p];
+    if (rs < junc_limit) {
+        uint4 *q = reinterpret_cast<uint4 *>(ends + (size_t)rs * DENSE_ENDS);
+        q[0] = q[1] = make_uint4(DENSE_EMPTY, DENSE_EMPTY, DENSE_EMPTY, DENSE_EMPTY);
+    }
 }
 struct EndsCountFn {
     const u32 *ends;
@@ -2029,14 +2045,51 @@ __global__ __launch_bounds__(256) void k5_finalize(const u64 *pair_key, const u3
 // row mirror, into its exchange slot; the control block follows as the last thing on the stream.
 constexpr int ROW_U64 = (int)(sizeof(pjb_junction_row) / 8);
 static_assert(sizeof(pjb_junction_row) % 8 == 0, "rows are copied in 8-byte units");
-__global__ __launch_bounds__(256) void k6_rows_out(const u64 *rows, const u32 *n_junc_p, u64 *host_rows, u64 *mirror_rows, u32 mirror_room) {
-    const u32 nj = *n_junc_p;
+// Where a contig's rows go is known to the host only when the contigs before it have been collected.  With two contigs
+// queued (pjb_finish_contig_begin) the second one's place follows from the first one's junction count, which lives on
+// the device: a cursor (rows written so far: host table, exchange slot), read by k6_rows_out and advanced by
+// k7_publish, both on the rows stream and so in contig order.  base < 0: take the cursor.
+struct RowCursor {
+    u32 rows, mirror_rows;
+};
+__global__ __launch_bounds__(256) void k6_rows_out(const u64 *rows, const ContigStats *cs, u64 *host_table, int64_t base, int64_t mirror_base,
+                                                   const RowCursor *cur, u64 *mirror_table, u32 mirror_room) {
+    const u32 nj = cs->J;
     const u64 n = (u64)nj * ROW_U64;
     const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
+    const u64 at = base >= 0 ? (u64)base : (u64)cur->rows;
     const u64 v = rows[i];
-    host_rows[i] = v;
-    if (mirror_rows && nj <= mirror_room) mirror_rows[i] = v;
+    host_table[at * ROW_U64 + i] = v;
+    if (mirror_table) { // (the slot is left alone by a contig that does not fit: the host reports it)
+        const u64 mat = mirror_base >= 0 ? (u64)mirror_base : (u64)cur->mirror_rows;
+        if (mat + nj <= (u64)mirror_room) mirror_table[mat * ROW_U64 + i] = v;
+    }
+}
+
+// The last kernel of a contig: control block, error word and list counters go to page-locked host memory in one go
+// (three small copies otherwise), error word and counters return to their rest state for the contig that uses this
+// control slot next, and the row cursor moves on.
+constexpr int PUB_BASE_AT = 240, PUB_ERR_AT = 256, PUB_GEN_AT = 512, PUB_BYTES = 2048; // byte offsets in the published block
+__global__ __launch_bounds__(256) void k7_publish(const ContigStats *cs, u64 *err, u32 *gencount, uint8_t *host, int64_t base, int64_t mirror_base,
+                                                  RowCursor *cur) {
+    const u32 t = threadIdx.x;
+    static_assert(sizeof(ContigStats) % 8 == 0 && sizeof(ContigStats) <= PUB_BASE_AT, "control block layout");
+    static_assert(PUB_GEN_AT + GEN_SHARDS * 4 <= PUB_BYTES, "control block layout");
+    if (t < sizeof(ContigStats) / 8) reinterpret_cast<u64 *>(host)[t] = reinterpret_cast<const u64 *>(cs)[t];
+    if (t < GEN_SHARDS) {
+        reinterpret_cast<u32 *>(host + PUB_GEN_AT)[t] = gencount[t];
+        gencount[t] = 0;
+    }
+    if (t == 0) {
+        *reinterpret_cast<u64 *>(host + PUB_ERR_AT) = *err;
+        *err = ~0ull;
+        const u32 at = base >= 0 ? (u32)base : cur->rows, mat = mirror_base >= 0 ? (u32)mirror_base : cur->mirror_rows;
+        reinterpret_cast<u32 *>(host + PUB_BASE_AT)[0] = at;
+        reinterpret_cast<u32 *>(host + PUB_BASE_AT)[1] = mat;
+        cur->rows = at + cs->J;
+        cur->mirror_rows = mat + cs->J;
+    }
 }
 
 } // namespace pjb

@@ -20,7 +20,8 @@ STAGE_NAMES = ["scan_emit", "sort", "group", "anchors", "pair_stats", "finalize"
 
 EXPORTS = [
     "pjb_create", "pjb_destroy", "pjb_last_error", "pjb_set_refs", "pjb_upload_contig", "pjb_upload_contig_device",
-    "pjb_release_contig", "pjb_submit_batch", "pjb_submit_batch_device", "pjb_finish_contig", "pjb_collect",
+    "pjb_release_contig", "pjb_submit_batch", "pjb_submit_batch_device", "pjb_finish_contig", "pjb_finish_contig_begin",
+    "pjb_finish_contig_end", "pjb_collect",
     "pjb_clear_rows", "pjb_get_timing", "pjb_device_count", "pjb_get_kernel_timing", "pjb_reset_kernel_timing",
     "pjb_select_timed_kernels", "pjb_host_alloc", "pjb_host_free", "pjb_inflate_bgzf", "pjb_submit_bam", "pjb_collect_device", "pjb_set_row_mirror",
     "pjb_extra_finish", "pjb_filter_set_junctions", "pjb_filter_batch", "pjb_filt_features",
@@ -116,6 +117,8 @@ def load():
         L.pjb_submit_batch.argtypes = [C.c_void_p, C.c_int32, C.POINTER(PjbBatch)]
         L.pjb_submit_batch_device.argtypes = [C.c_void_p, C.c_int32, C.POINTER(PjbBatch)]
         L.pjb_finish_contig.argtypes = [C.c_void_p, C.c_int32, C.POINTER(PjbRegionResult)]
+        L.pjb_finish_contig_begin.argtypes = [C.c_void_p, C.c_int32]
+        L.pjb_finish_contig_end.argtypes = [C.c_void_p, C.c_int32, C.POINTER(PjbRegionResult)]
         L.pjb_set_row_mirror.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
         L.pjb_collect_device.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
         L.pjb_inflate_bgzf.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
@@ -161,7 +164,7 @@ class Context:
         if rc:
             raise PjbError(rc, self._L.pjb_last_error(None).decode())
         self._keep = []
-        self._keep_batch = []
+        self._keep_batch = {}  # tid -> device tensors lent to the context until the contig is collected
 
     def close(self):
         if self._h:
@@ -225,10 +228,10 @@ class Context:
         pb.n_reads = int(n_reads)
         for name, _ in _FIELDS:
             t = tensors[name]
-            self._keep_batch.append(t)
+            self._keep_batch.setdefault(tid, []).append(t)
             setattr(pb, name, t.data_ptr())
         if tensors.get("name_hash") is not None:
-            self._keep_batch.append(tensors["name_hash"])
+            self._keep_batch.setdefault(tid, []).append(tensors["name_hash"])
             pb.name_hash = tensors["name_hash"].data_ptr()
         self._check(self._L.pjb_submit_batch_device(self._h, tid, C.byref(pb)))
 
@@ -237,7 +240,23 @@ class Context:
         try:
             self._check(self._L.pjb_finish_contig(self._h, tid, C.byref(r)))
         finally:
-            self._keep_batch = []
+            self._keep_batch.pop(tid, None)
+        return {k: getattr(r, k) for k, _ in PjbRegionResult._fields_}
+
+    def finish_contig_begin(self, tid):
+        """Queue the contig's kernel chain without waiting (at most two contigs queued; collect in the same order)."""
+        try:
+            self._check(self._L.pjb_finish_contig_begin(self._h, tid))
+        except Exception:
+            self._keep_batch.pop(tid, None)
+            raise
+
+    def finish_contig_end(self, tid):
+        r = PjbRegionResult()
+        try:
+            self._check(self._L.pjb_finish_contig_end(self._h, tid, C.byref(r)))
+        finally:
+            self._keep_batch.pop(tid, None)
         return {k: getattr(r, k) for k, _ in PjbRegionResult._fields_}
 
     def collect(self, copy=True):

@@ -207,6 +207,111 @@ def test_dense_ids_junction_limit(ffi, orc):
         assert drows2.tobytes() == drows.tobytes()
 
 
+def _three_contigs(orc, seeds=(21, 22, 23)):
+    out = []
+    for tid, seed in enumerate(seeds):
+        genome, reads = make_reads(seed, n_reads=2500, paired=True)
+        batch = to_batch(reads)
+        orows, oreg = orc.find_juncs(tid, len(genome), genome, batch, "FR")
+        out.append((genome, batch, orows, oreg))
+    return out
+
+
+def _run_queued(ffi, ctx, contigs, depth):
+    """Contigs through pjb_finish_contig_begin / _end with `depth` contigs queued (1: plain finish order)."""
+    ctx.set_refs([len(g) for g, _, _, _ in contigs])
+    for tid, (g, _, _, _) in enumerate(contigs):
+        ctx.upload_contig(tid, g.encode() if isinstance(g, str) else g)
+    ctx.clear_rows()
+    regs, queued = {}, []
+    for tid, (_, b, _, _) in enumerate(contigs):
+        ctx.submit_batch(tid, b)
+        ctx.finish_contig_begin(tid)
+        queued.append(tid)
+        if len(queued) >= depth:
+            t = queued.pop(0)
+            regs[t] = ctx.finish_contig_end(t)
+    for t in queued:
+        regs[t] = ctx.finish_contig_end(t)
+    return ctx.collect(), regs
+
+
+def test_two_contigs_queued(ffi, orc):
+    """pjb_finish_contig_begin / _end: the second contig is queued before the first is collected; its rows follow the
+    first one's through the device-side row cursor.  Same table as finishing one contig at a time."""
+    contigs = _three_contigs(orc)
+    want = np.concatenate([c[2] for c in contigs])
+    with ffi.Context(0, "FR") as ctx:
+        for depth in (2, 1, 2):
+            rows, regs = _run_queued(ffi, ctx, contigs, depth)
+            for tid, c in enumerate(contigs):
+                region_equal(regs[tid], c[3])
+            assert_rows_equal(rows, want)
+        # out of order / too many
+        ctx.clear_rows()
+        ctx.submit_batch(0, contigs[0][1])
+        ctx.submit_batch(1, contigs[1][1])
+        ctx.submit_batch(2, contigs[2][1])
+        ctx.finish_contig_begin(0)
+        ctx.finish_contig_begin(1)
+        with pytest.raises(ffi.PjbError):
+            ctx.finish_contig_begin(2)
+        with pytest.raises(ffi.PjbError):
+            ctx.finish_contig_end(1)
+        with pytest.raises(ffi.PjbError):
+            ctx.clear_rows()
+        ctx.finish_contig_end(0)
+        ctx.finish_contig_begin(2)
+        ctx.finish_contig_end(1)
+        ctx.finish_contig_end(2)
+        assert_rows_equal(ctx.collect(), want)
+
+
+def test_queued_behind_an_overflow(ffi, orc):
+    """The first of two queued contigs exceeds the junction limit it was queued with: it is repeated, and the contig
+    queued behind it (whose rows went to the wrong place meanwhile) is queued again."""
+    rng = np.random.default_rng(11)
+    glen = 400000
+    genome = "".join(rng.choice(list("ACGT"), size=glen))
+    reads = [dict(pos=20 + 60 * k, cigar=f"25M{30 + (k % 7)}N25M", seq="G" * 50, xs="+", flag=0) for k in range(6000)]
+    big = ReadBatch.from_reads(reads)
+    orows_big, oreg_big = orc.find_juncs(0, glen, genome, big, "UNKNOWN")
+    g2, reads2 = make_reads(31, n_reads=2500)
+    b2 = to_batch(reads2)
+    orows2, oreg2 = orc.find_juncs(1, len(g2), g2, b2, "UNKNOWN")
+    contigs = [(genome, big, orows_big, oreg_big), (g2, b2, orows2, oreg2)]
+    with ffi.Context(0, "UNKNOWN") as ctx:
+        rows, regs = _run_queued(ffi, ctx, contigs, 2)
+        region_equal(regs[0], oreg_big)
+        region_equal(regs[1], oreg2)
+        assert_rows_equal(rows, np.concatenate([orows_big, orows2]))
+
+
+def test_queued_behind_an_error(ffi, orc):
+    """The first of two queued contigs fails (unsorted records): its end reports the error, the second contig still
+    yields its rows."""
+    g1 = "ACGT" * 2000
+    bad = ReadBatch.from_reads([dict(pos=500, cigar="30M100N40M", seq="A" * 70, xs="+"), dict(pos=100, cigar="70M", seq=None)])
+    g2, reads2 = make_reads(32, n_reads=2500)
+    b2 = to_batch(reads2)
+    orows2, oreg2 = orc.find_juncs(1, len(g2), g2, b2, "UNKNOWN")
+    with ffi.Context(0, "UNKNOWN") as ctx:
+        ctx.set_refs([len(g1), len(g2)])
+        ctx.upload_contig(0, g1.encode())
+        ctx.upload_contig(1, g2.encode())
+        ctx.clear_rows()
+        ctx.submit_batch(0, bad)
+        ctx.submit_batch(1, b2)
+        ctx.finish_contig_begin(0)
+        ctx.finish_contig_begin(1)
+        with pytest.raises(ffi.PjbError) as e:
+            ctx.finish_contig_end(0)
+        assert e.value.code == -14
+        reg = ctx.finish_contig_end(1)
+        region_equal(reg, oreg2)
+        assert_rows_equal(ctx.collect(), orows2)
+
+
 def test_row_mirror(ffi, orc):
     """pjb_set_row_mirror: finish_contig leaves { n_rows, spliced, unspliced, sum_len, min_len, max_len } and the rows
     in the caller's device buffer -- also for a contig without junctions -- and refuses a buffer that is too small."""
