@@ -353,6 +353,10 @@ int run_scan(pjb_ctx *c, const char *tag, F f, G g, u64 n, u64 *d_total, const u
     u64 *ts = (u64 *)c->b_scan_tiles.p;
     std::string t = tag;
     LAUNCH(c, (t + "_reduce").c_str(), (scan_reduce_kernel<F>), dim3(nt), dim3(256), f, n, ts, d_n);
+    if (nt <= SCAN2_MAX_TILES) { // contig-sized: the apply blocks add up the tile sums before them themselves
+        LAUNCH(c, (t + "_apply").c_str(), (scan_apply2_kernel<F, G>), dim3(nt), dim3(256), f, g, n, (const u64 *)ts, d_n, d_total);
+        return PJB_OK;
+    }
     LAUNCH(c, (t + "_tiles").c_str(), scan_tiles_kernel, dim3(1), dim3(1024), ts, nt, d_total);
     LAUNCH(c, (t + "_apply").c_str(), (scan_apply_kernel<F, G>), dim3(nt), dim3(256), f, g, n, (const u64 *)ts, d_n);
     return PJB_OK;
