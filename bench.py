@@ -47,21 +47,21 @@ def algorithmic_bytes(name, N, C, S, Cs, P, J, L, Pg=0):
     table = {
         # pos, cig_off, l_qseq, xs + every cigar op; 8 B written per spliced read (compacted index + pair offset)
         "k1_count": N * 13 + C * 4 + S * 8,
-        # spliced reads only: compacted slot (8), cig_off (8), pos/flag/mapq/xs (8), ops fetched once; 36 B written per pair
-        "k1_emit": S * 24 + Cs * 4 + P * 36,
+        # spliced reads only: compacted slot (8), cig_off (8), pos/flag/mapq/xs (8), ops fetched once; 44 B written per pair
+        # (36 B of pair fields + the address of the read's bases for k4a_simple)
+        "k1_emit": S * 24 + Cs * 4 + P * 44,
         # K2d, ordered dense junction ids: keys read three times (8 B), ids written once (8 B); the bitmap / rank / end tables are
         # contig-sized and small beside the pairs
-        "kd_mark": P * 8,
-        "kd_ends": P * 8,
+        "kd_unique": P * 8,
         "kd_assign": P * 16,
         "rs_hist": P * 8,
         "rs_scatter": P * 24,
         "k2_heads_reduce": P * 20,
         "k2_heads_apply": P * 20 + P * 4 + (J + J + P / 8) * 4,
         "k3_anchors_frag": P * 16 + frags * 12,
-        # simple pairs: meta, read ordinal, key, pos, rend, seq_off (8), packed read bases L/2, 4-bit genome codes L/2,
-        # 8-byte result; other pairs only read their meta word
-        "k4a_simple": (P - Pg) * (4 + 4 + 8 + 4 + 4 + 8 + L + 8) + Pg * 4,
+        # simple pairs: meta, key, pos, rend, address of the bases (8), packed read bases L/2, 4-bit genome codes L/2,
+        # 8-byte result; other pairs read the same 28 B of pair fields and stop
+        "k4a_simple": (P - Pg) * (4 + 8 + 4 + 4 + 8 + L + 8) + Pg * 28,
         # generic pairs: list entry, idx, jid, key, ordinal, cig_off (8), ops, pos/aend, l_qseq, seq_off (8), anchors (8),
         # read bases + genome codes (L), result
         "k4b_generic": Pg * (4 + 4 + 4 + 8 + 4 + 8 + 4 * (Cs / max(S, 1)) + 8 + 4 + 8 + 8 + L + 8),

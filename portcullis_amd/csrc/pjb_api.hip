@@ -149,6 +149,7 @@ struct pjb_ctx {
     // counters (k7_publish; per slot), start bitmap / end slots (kd_reset).  false: set by a memset before use
     bool dense_at_rest = false;
     int last_slot = 0; // slot of the contig collected last (pjb_collect_device)
+    bool side_stream = true;                     // k4a_simple beside the sort (PJB_SIDE_STREAM=0: on the main stream)
     bool dense_ids = true;                       // K2d (PJB_DENSE_IDS=0 sorts the full keys as round 1 did)
     u32 junc_seen = 0;                           // most junctions a contig has had so far (junction limit of the next contig)
     int lbits_seen = 18;                         // bits of the longest intron this context has met (key format of the next contig)
@@ -172,7 +173,7 @@ struct pjb_ctx {
     // scratch
     Buf b_tile_cnt, b_tile_stats, b_total, b_splidx, b_splpoff;
     Buf b_bitmap, b_wrank, b_ends, b_firstid; // K2d
-    Buf b_okey, b_key[2], b_idx[2], b_g, b_lstart, b_rend, b_pos, b_aend, b_meta, b_updown;
+    Buf b_okey, b_key[2], b_idx[2], b_g, b_lstart, b_rend, b_pos, b_aend, b_meta, b_updown, b_seqw;
     Buf b_hist, b_hist_scan, b_scan_tiles, b_bintotal;
     Buf b_inf_comp, b_inf_out, b_inf_blocks, b_inf_status, b_inf_scratch; // device-side BGZF inflate
     Buf b_bam_seg, b_bam_rec, b_bam_ctl;                                  // device-side BAM record parse
@@ -478,6 +479,7 @@ int pjb_create(pjb_ctx **out, const pjb_config *cfg) {
     c->ktime = (cfg->flags & PJB_FLAG_KERNEL_TIMING) != 0;
     c->extra = (cfg->flags & PJB_FLAG_EXTRA) != 0;
     if (const char *s = getenv("PJB_DENSE_IDS")) c->dense_ids = atoi(s) != 0;
+    if (const char *s = getenv("PJB_SIDE_STREAM")) c->side_stream = atoi(s) != 0;
     if (const char *s = getenv("PJB_RADIX_BITS")) {
         int v = atoi(s);
         if (v >= 4 && v <= RS_MAX_BITS) c->radix_max_bits = v;
@@ -520,7 +522,7 @@ void pjb_destroy(pjb_ctx *c) {
     }
     Buf *all[] = {&c->b_cursor, &c->b_tile_cnt, &c->b_tile_stats, &c->b_total, &c->b_bitmap, &c->b_wrank, &c->b_ends, &c->b_firstid, &c->b_okey, &c->b_key[0],
                   &c->b_key[1], &c->b_idx[0], &c->b_idx[1], &c->b_g, &c->b_lstart, &c->b_rend, &c->b_pos, &c->b_aend,
-                  &c->b_meta, &c->b_updown, &c->b_hist, &c->b_hist_scan, &c->b_scan_tiles, &c->b_jid, &c->b_seg,
+                  &c->b_meta, &c->b_updown, &c->b_seqw, &c->b_hist, &c->b_hist_scan, &c->b_scan_tiles, &c->b_jid, &c->b_seg,
                   &c->b_runfirst, &c->b_runstart, &c->b_frag, &c->b_fragj, &c->b_fragl, &c->b_fragr, &c->b_acc,
                   &c->b_ancl, &c->b_ancr, &c->b_hasx, &c->b_ent, &c->b_splidx, &c->b_splpoff, &c->b_res, &c->b_genlist, &c->b_bintotal, &c->b_inf_comp, &c->b_inf_out, &c->b_inf_blocks, &c->b_inf_status, &c->b_inf_scratch, &c->b_bam_seg, &c->b_bam_rec, &c->b_bam_ctl, &c->b_entsum, &c->f_pos, &c->f_cigoff, &c->f_cigar, &c->f_codes, &c->g_rows, &c->g_models, &c->g_refs, &c->g_out, &c->g_bad,
                   &c->x_pos, &c->x_endx, &c->x_q, &c->x_prefq, &c->x_ce, &c->x_bound, &c->x_de, &c->x_dropped, &c->x_zlist, &c->x_cnt,
@@ -917,6 +919,7 @@ static int queue_contig(pjb_ctx *c, Flight &f, std::vector<DevBatch> &batches) {
     for (Buf *b : pb)
         if ((rc = ensure(c, *b, (size_t)PL * 4 + 16))) return rc;
     if ((rc = ensure(c, c->b_res, (size_t)PL * 8 + 16))) return rc;
+    if ((rc = ensure(c, c->b_seqw, (size_t)PL * 8 + 16))) return rc;
     if ((rc = ensure(c, c->b_seg, ((size_t)PL + 1) * 4))) return rc;
     if ((rc = ensure(c, c->b_runfirst, ((size_t)PL + 1) * 4))) return rc;
     if ((rc = ensure(c, c->b_runstart, ((size_t)PL + 1) * 4))) return rc;
@@ -994,6 +997,7 @@ static int queue_contig(pjb_ctx *c, Flight &f, std::vector<DevBatch> &batches) {
     pr.aend = (int32_t *)c->b_aend.p;
     pr.meta = (u32 *)c->b_meta.p;
     pr.updown = (u32 *)c->b_updown.p;
+    pr.seqw = (u64 *)c->b_seqw.p;
     f.pr = pr;
     for (auto &b : batches) {
         const u32 nt = (u32)((b.n + K1_TILE - 1) / K1_TILE);
@@ -1004,14 +1008,15 @@ static int queue_contig(pjb_ctx *c, Flight &f, std::vector<DevBatch> &batches) {
     // ---- K4a: match statistics of the common [S] M N M [S] shape, in BAM order, while the keys are still unsorted:
     // on the side stream, beside the sort of the main stream (joined before pass 1 overwrites the keys)
     const bool fast_codes = G.codes != nullptr && !G.has_x;
-    if (fast_codes) {
+    if (fast_codes && !c->side_stream) { // (PJB_SIDE_STREAM=0: one kernel at a time, for clean per-kernel timings)
+        LAUNCH(c, "k4a_simple", k4a_simple, dim3(pair_blocks), dim3(256), pr, kf, (const u32 *)G.codes, (int32_t)G.len, d_P, (u64 *)c->b_res.p);
+    } else if (fast_codes) {
         HIP_TRY(c, hipEventRecord(c->ev_fork, st));
         HIP_TRY(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
         hipStream_t main_stream = c->stream;
         c->stream = c->stream2; // LAUNCH (and its event bracket) follow c->stream
         f.forked = true;
-        LAUNCH(c, "k4a_simple", k4a_simple, dim3(pair_blocks), dim3(256), pr, kf, (const DevBatch *)S.batches.p,
-               (int)batches.size(), (const u32 *)G.codes, (int32_t)G.len, d_P, (u64 *)c->b_res.p);
+        LAUNCH(c, "k4a_simple", k4a_simple, dim3(pair_blocks), dim3(256), pr, kf, (const u32 *)G.codes, (int32_t)G.len, d_P, (u64 *)c->b_res.p);
         c->stream = main_stream;
         HIP_TRY(c, hipEventRecord(c->ev_join, c->stream2));
     }
@@ -1117,7 +1122,7 @@ static int queue_contig(pjb_ctx *c, Flight &f, std::vector<DevBatch> &batches) {
            (int32_t *)c->b_ancr.p);
     STAGE_EVENT(4);
 
-    if (fast_codes) HIP_TRY(c, hipStreamWaitEvent(st, c->ev_join, 0)); // k4a_simple's results (side stream) are needed from here on
+    if (f.forked) HIP_TRY(c, hipStreamWaitEvent(st, c->ev_join, 0)); // k4a_simple's results (side stream) are needed from here on
     // ---- K4b: the pairs that need the generic walks (list length lives on the device; the grid covers the
     // worst case and surplus blocks exit at once), then K4: gather + segmented reduce -> fragments
     LAUNCH(c, "k4b_generic", k4b_generic, dim3((gen_cap * GEN_SHARDS + 255) / 256), dim3(256), (const u32 *)c->b_genlist.p,

@@ -91,6 +91,8 @@ struct Pairs {
     int32_t *aend;   // read end = pos + alignedLength - 1
     u32 *meta;       // bit field, see META_*
     u32 *updown;     // upjuncs | downjuncs << 16
+    u64 *seqw;       // META_SIMPLE pairs: device address of the read's packed bases (k4a_simple then needs no walk
+                     // pair -> read ordinal -> batch -> seq_off -> bases: four dependent loads less)
 };
 
 enum : u32 {
@@ -735,6 +737,7 @@ __global__ __launch_bounds__(256) void k1_emit(DevBatch b, const u32 *tile_off, 
                 }
             }
         }
+        const u64 seq_addr = (meta & META_SIMPLE) ? (u64)(uintptr_t)(b.seq4 + (size_t)b.seq_off[r] * 4) : 0ull;
         // ---- walk: pairs (junction_system.cc:140-210) and, with two monotone cursors over the read's own
         // introns, the up/down junction counts (junction.cc:795-812)
         const int32_t aend = pos + aligned - 1;
@@ -777,6 +780,7 @@ __global__ __launch_bounds__(256) void k1_emit(DevBatch b, const u32 *tile_off, 
                 P.meta[idx] = meta;
                 P.aend[idx] = aend;
                 P.updown[idx] = cntU | ((nN - cntD) << 16);
+                P.seqw[idx] = seq_addr;
                 if (lStart > istart) set_error(err, g, PJB_ERR_MIN_ANCHOR); // intron.cc:68
                 prev = idx;
                 prevIend = iend;
@@ -1581,31 +1585,95 @@ __device__ __forceinline__ const DevBatch &find_batch(const DevBatch *batches, i
     return batches[lo];
 }
 
+// 64 bases of one anchor = 9 words of read bases and 9 of genome codes.  A lane's words are consecutive but the next
+// lane's are somewhere else, so every load instruction of the wave touches 64 cache lines whatever its width, and
+// the number of load INSTRUCTIONS sets the pace (measured: 19 per-word loads per read cost 80 us per contig, the
+// compare itself nothing).  So the words come as two 16-byte loads and one 4-byte load per stream -- 4-byte aligned
+// (reads start on word boundaries), which global_load_dwordx4 accepts -- guarded so that nothing is read past the
+// read's last word / the contig's last code word; the short tail of a stream takes guarded word loads.  The chunks
+// of both anchors are issued together: a 150-base read is two round trips.
+struct __attribute__((packed, aligned(4))) Words4 {
+    u32 x, y, z, w;
+};
+struct CmpChunk {
+    u32 qw[9], gg[9];
+};
+// d[k] = p[first + k] for 0 <= first + k <= last, else 0 (first + 8 <= last: three loads)
+__device__ __forceinline__ void load9(u32 (&d)[9], const u32 *p, int32_t first, int32_t last) {
+    if (first >= 0 && first + 8 <= last) {
+        const Words4 a = *reinterpret_cast<const Words4 *>(p + first), b = *reinterpret_cast<const Words4 *>(p + first + 4);
+        d[0] = a.x, d[1] = a.y, d[2] = a.z, d[3] = a.w;
+        d[4] = b.x, d[5] = b.y, d[6] = b.z, d[7] = b.w;
+        d[8] = p[first + 8];
+    } else {
+#pragma unroll
+        for (int k = 0; k < 9; k++) d[k] = (first + k >= 0 && first + k <= last) ? p[first + k] : 0u;
+    }
+}
+// anchor bases [t, t + 64) of an anchor of l bases: read bases from qi (words of the read up to word q_last may be
+// touched), genome from gi
+__device__ __forceinline__ void chunk_load(CmpChunk &C, bool active, const u32 *seqw, int32_t qi, int32_t q_last, const u32 *gw, int32_t gi,
+                                           int32_t g_words, int32_t l, int32_t t) {
+    if (!active) return;
+    const int32_t lastg = (gi + l - 1) >> 3;
+    load9(C.qw, seqw, (qi + t) >> 3, q_last);
+    // (genome words outside [0, g_words) and past the anchor's last word read as 0, as they always did)
+    load9(C.gg, gw, (gi + t) >> 3, lastg < g_words - 1 ? lastg : g_words - 1);
+}
+__device__ __forceinline__ void chunk_cmp(CmpChunk &C, bool active, int32_t qi, int32_t gi, int32_t l, int32_t t, int32_t &mism,
+                                          int32_t &first_mis, int32_t &last_mis) {
+    if (!active) return;
+    const u32 shq = (u32)(qi & 7) * 4u, shg = (u32)(gi & 7) * 4u; // (t is a multiple of 8: the shifts do not move)
+#pragma unroll
+    for (int k = 0; k < 9; k++) C.qw[k] = swap_nibbles(C.qw[k]);
+#pragma unroll
+    for (int c = 0; c < 8; c++) {
+        const int32_t rem = l - t - 8 * c;
+        if (rem > 0) {
+            const u32 q = __builtin_amdgcn_alignbit(C.qw[c + 1], C.qw[c], shq);
+            const u32 g = __builtin_amdgcn_alignbit(C.gg[c + 1], C.gg[c], shg);
+            const u32 x = q ^ g;
+            u32 m = (x | (x >> 1) | (x >> 2) | (x >> 3)) & 0x11111111u;
+            if (rem < 8) m &= (1u << (4 * rem)) - 1u;
+            if (m) {
+                mism += __popc(m);
+                if (first_mis < 0) first_mis = t + 8 * c + ((__ffs((int)m) - 1) >> 2);
+                last_mis = t + 8 * c + ((31 - __clz((int)m)) >> 2);
+            }
+        }
+    }
+}
+
 // K4a: the common shape [S] M N M [S], one thread per pair IN EMISSION (BAM) ORDER, before the sort:
 // the left anchor is read[dS, dS+a) against genome[pos, pos+a), the right one read[dS+a, dS+a+b)
 // against genome[iend+1, iend+1+b); neither depends on the junction-level window, the walk rules
-// of bam_alignment.cc:341-462 reduce to exactly this for the shape.  Consecutive threads touch
-// consecutive reads and genome positions.
-__global__ __launch_bounds__(256) void k4a_simple(Pairs P, KeyFmt kf, const DevBatch *batches, int n_batches, const u32 *gcodes,
-                                                   int32_t glen, const u32 *np, u64 *res) {
+// of bam_alignment.cc:341-462 reduce to exactly this for the shape.  Everything a pair needs is in the pair arrays
+// (k1_emit left the address of the read's bases there): one round of coalesced loads, then the bases.
+__global__ __launch_bounds__(256) void k4a_simple(Pairs P, KeyFmt kf, const u32 *gcodes, int32_t glen, const u32 *np, u64 *res) {
     const u32 n = *np;
     const u32 p = blockIdx.x * 256 + threadIdx.x;
     if (p >= n) return;
     const u32 meta = P.meta[p];
+    const u64 key = P.key[p];
+    const int32_t pos = P.pos[p], rend = P.rend[p];
+    const u32 *seqw = reinterpret_cast<const u32 *>((uintptr_t)P.seqw[p]);
     if (!(meta & META_SIMPLE)) return;
-    const u32 g = P.g[p];
-    const DevBatch &b = find_batch(batches, n_batches, g);
-    const u32 r = g - b.base;
     int32_t istart, iend;
-    unpack_key(kf, P.key[p], istart, iend);
-    const int32_t pos = P.pos[p];
-    const int32_t a = istart - pos, bb = P.rend[p] - iend;
+    unpack_key(kf, key, istart, iend);
+    const int32_t a = istart - pos, bb = rend - iend;
     const int32_t dS = (int32_t)((meta >> META_DS_SHIFT) & 0xfffu);
-    const u32 *seqw = reinterpret_cast<const u32 *>(b.seq4 + (size_t)b.seq_off[r] * 4);
     const int32_t g_words = (glen + 7) / 8 + 1;
+    const int32_t q_last = (dS + a + bb - 1) >> 3; // last word of the read that holds aligned bases
     int32_t misL = 0, firstL = -1, lastL = -1, misR = 0, firstR = -1, lastR = -1;
-    cmp_words(seqw, dS, gcodes, pos, g_words, a, 0, misL, firstL, lastL);
-    cmp_words(seqw, dS + a, gcodes, iend + 1, g_words, bb, 0, misR, firstR, lastR);
+    const int32_t longest = a > bb ? a : bb;
+    for (int32_t t = 0; t < longest; t += 64) {
+        CmpChunk L, R;
+        const bool onL = t < a, onR = t < bb;
+        chunk_load(L, onL, seqw, dS, q_last, gcodes, pos, g_words, a, t);
+        chunk_load(R, onR, seqw, dS + a, q_last, gcodes, iend + 1, g_words, bb, t);
+        chunk_cmp(L, onL, dS, pos, a, t, misL, firstL, lastL);
+        chunk_cmp(R, onR, dS + a, iend + 1, bb, t, misR, firstR, lastR);
+    }
     const u32 upM = lastL < 0 ? (u32)a : (u32)(a - 1 - lastL);
     const u32 downM = firstR < 0 ? (u32)bb : (u32)firstR;
     const u32 tu = (u32)(a - misL), td = (u32)(bb - misR);

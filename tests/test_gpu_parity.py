@@ -312,6 +312,12 @@ def test_queued_behind_an_error(ffi, orc):
         assert_rows_equal(ctx.collect(), orows2)
 
 
+def test_long_reads(ffi, orc):
+    """Reads longer than the 160 bases k4a_simple stages per read in LDS (per-lane loads instead), mixed with short ones."""
+    genome, reads = make_reads(41, n_reads=3000, paired=True, L=(120, 400))
+    run_both(ffi, orc, genome, to_batch(reads), "FR")
+
+
 def test_row_mirror(ffi, orc):
     """pjb_set_row_mirror: finish_contig leaves { n_rows, spliced, unspliced, sum_len, min_len, max_len } and the rows
     in the caller's device buffer -- also for a contig without junctions -- and refuses a buffer that is too small."""
