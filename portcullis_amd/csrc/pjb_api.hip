@@ -121,7 +121,7 @@ struct pjb_ctx {
     hipStream_t stream2 = nullptr; // side stream: work that does not depend on the sort (k4a_simple)
     hipStream_t stream3 = nullptr; // rows stream: k6_rows_out + k7_publish of a contig, beside the next contig's first kernels
     hipStream_t stream4 = nullptr; // header of the row mirror
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_fork2 = nullptr, ev_join2 = nullptr;
     CtlSlot sl[2];
     Flight fl[2]; // FIFO: fl[0] is the oldest
     int n_fl = 0;
@@ -469,6 +469,8 @@ int pjb_create(pjb_ctx **out, const pjb_config *cfg) {
     (void)hipStreamCreateWithFlags(&c->stream4, hipStreamNonBlocking);
     (void)hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
     (void)hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming);
+    (void)hipEventCreateWithFlags(&c->ev_fork2, hipEventDisableTiming);
+    (void)hipEventCreateWithFlags(&c->ev_join2, hipEventDisableTiming);
     for (int k = 0; k < 2; k++) {
         CtlSlot &S = c->sl[k];
         for (auto &ev : S.ev) (void)hipEventCreate(&ev);
@@ -532,6 +534,8 @@ void pjb_destroy(pjb_ctx *c) {
         for (auto &ev : pool.ev) (void)hipEventDestroy(ev);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    if (c->ev_fork2) (void)hipEventDestroy(c->ev_fork2);
+    if (c->ev_join2) (void)hipEventDestroy(c->ev_join2);
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
     if (c->stream3) (void)hipStreamDestroy(c->stream3);
     if (c->stream4) (void)hipStreamDestroy(c->stream4);
@@ -1108,6 +1112,29 @@ static int queue_contig(pjb_ctx *c, Flight &f, std::vector<DevBatch> &batches) {
     }
     STAGE_EVENT(3);
 
+    // ---- entropy terms and sums need the position runs only: on the side stream, beside the anchors and the generic
+    // pairs (a chain of small and latency-bound kernels that leaves most of the chip idle)
+    if ((rc = ensure(c, c->b_entsum, (size_t)JL * 8 + 16))) return rc;
+    bool entropy_forked = false;
+    {
+        hipStream_t main_stream = c->stream;
+        struct StreamScope {
+            pjb_ctx *c;
+            hipStream_t main;
+            ~StreamScope() { c->stream = main; }
+        } scope{c, main_stream};
+        if (c->side_stream) {
+            HIP_TRY(c, hipEventRecord(c->ev_fork2, st));
+            HIP_TRY(c, hipStreamWaitEvent(c->stream2, c->ev_fork2, 0));
+            c->stream = c->stream2;
+            entropy_forked = true;
+        }
+        LAUNCH(c, "k5_entropy_terms", k5_entropy_terms, dim3(pair_blocks), dim3(256), (const u32 *)c->b_jid.p,
+               (const u32 *)c->b_seg.p, (const u32 *)c->b_runfirst.p, (const u32 *)c->b_runstart.p, d_R, (double *)c->b_ent.p);
+        LAUNCH(c, "k5_entropy_sum", k5_entropy_sum, dim3(std::max<u32>(1, (JL + 3) / 4)), dim3(256), (const u32 *)c->b_runfirst.p,
+               (const double *)c->b_ent.p, d_J, (double *)c->b_entsum.p);
+        if (entropy_forked) HIP_TRY(c, hipEventRecord(c->ev_join2, c->stream2));
+    }
     // ---- K3: anchors
     const u32 slot_blocks = (slots_lim + 255) / 256;
     const u32 init_n = std::max<u32>(slots_lim, JL * F_WORDS);
@@ -1136,11 +1163,7 @@ static int queue_contig(pjb_ctx *c, Flight &f, std::vector<DevBatch> &batches) {
     // ---- K5: fragments -> junctions -> rows
     LAUNCH(c, "k5_frag_reduce", k5_frag_reduce, dim3((slots_lim + 4 * FRAG_SLOTS_PER_WAVE - 1) / (4 * FRAG_SLOTS_PER_WAVE)), dim3(256),
            (const u32 *)c->b_frag.p, (const int32_t *)c->b_fragj.p, d_slots, (u32 *)c->b_acc.p);
-    LAUNCH(c, "k5_entropy_terms", k5_entropy_terms, dim3(pair_blocks), dim3(256), (const u32 *)c->b_jid.p,
-           (const u32 *)c->b_seg.p, (const u32 *)c->b_runfirst.p, (const u32 *)c->b_runstart.p, d_R, (double *)c->b_ent.p);
-    if ((rc = ensure(c, c->b_entsum, (size_t)JL * 8 + 16))) return rc;
-    LAUNCH(c, "k5_entropy_sum", k5_entropy_sum, dim3(std::max<u32>(1, (JL + 3) / 4)), dim3(256), (const u32 *)c->b_runfirst.p,
-           (const double *)c->b_ent.p, d_J, (double *)c->b_entsum.p);
+    if (entropy_forked) HIP_TRY(c, hipStreamWaitEvent(st, c->ev_join2, 0));
     LAUNCH(c, "k5_finalize", k5_finalize, dim3(std::max<u32>(1, (JL + 255) / 256)), dim3(256), (const u64 *)pr.key, sidx, (const u32 *)c->b_seg.p,
            (const u32 *)c->b_runfirst.p, (const u32 *)c->b_runstart.p, (const u32 *)c->b_acc.p,
            (const int32_t *)c->b_ancl.p, (const int32_t *)c->b_ancr.p, kf, (const uint8_t *)G.d, (int32_t)G.len, tid, d_J,
