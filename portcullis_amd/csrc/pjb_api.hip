@@ -52,6 +52,7 @@ struct OpenContig {
     std::vector<int32_t> last_pos;  // pos of the last record of each batch (sortedness across batches)
     std::vector<char> last_known;   // 0 = must be read back from the device (device-resident batch)
     std::vector<Slab> slabs;        // device memory holding this contig's host-submitted batches
+    bool on_main_stream = false;    // some batch was produced by work queued on the main stream (host copies, BAM ingest)
 };
 
 } // namespace
@@ -83,6 +84,12 @@ struct ContigLimits {
 // host, and the timing events.  Everything else is scratch of the main stream and protected by stream order.
 struct CtlSlot {
     Buf cstats, err, gencount, batches, rows;
+    // what the first kernels of a contig (k1_count, k1_scan_tiles, k1_emit: the front stream) write and the rest of its
+    // chain reads: the next contig's first kernels run beside this contig's last ones
+    Buf tile_cnt, tile_stats, splidx, splpoff;
+    Buf okey, g, lstart, rend, pos, aend, meta, updown, seqw; // the pairs (BAM order)
+    Buf res;                                                  // k4a_simple / k4b_generic results per pair
+    hipEvent_t ev_k1 = nullptr;
     uint8_t *pub = nullptr, *pub_dev = nullptr; // page-locked: what k7_publish writes (host view, device view)
     DevBatch *batches_pinned = nullptr;         // page-locked staging of the batch descriptors
     size_t batches_pinned_cap = 0;
@@ -121,7 +128,8 @@ struct pjb_ctx {
     hipStream_t stream2 = nullptr; // side stream: work that does not depend on the sort (k4a_simple)
     hipStream_t stream3 = nullptr; // rows stream: k6_rows_out + k7_publish of a contig, beside the next contig's first kernels
     hipStream_t stream4 = nullptr; // header of the row mirror
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_fork2 = nullptr, ev_join2 = nullptr;
+    hipStream_t stream5 = nullptr; // front stream: a contig's first kernels (K1), beside the previous contig's last ones
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_fork2 = nullptr, ev_join2 = nullptr, ev_front = nullptr;
     CtlSlot sl[2];
     Flight fl[2]; // FIFO: fl[0] is the oldest
     int n_fl = 0;
@@ -171,9 +179,9 @@ struct pjb_ctx {
     std::vector<double> kms;
     std::vector<std::string> ktime_only; // if non-empty, only these kernel names are bracketed
     // scratch
-    Buf b_tile_cnt, b_tile_stats, b_total, b_splidx, b_splpoff;
+    Buf b_total;
     Buf b_bitmap, b_wrank, b_ends, b_firstid; // K2d
-    Buf b_okey, b_key[2], b_idx[2], b_g, b_lstart, b_rend, b_pos, b_aend, b_meta, b_updown, b_seqw;
+    Buf b_key[2], b_idx[2];
     Buf b_hist, b_hist_scan, b_scan_tiles, b_bintotal;
     Buf b_inf_comp, b_inf_out, b_inf_blocks, b_inf_status, b_inf_scratch; // device-side BGZF inflate
     Buf b_bam_seg, b_bam_rec, b_bam_ctl;                                  // device-side BAM record parse
@@ -186,7 +194,7 @@ struct pjb_ctx {
     Buf f_pos, f_cigoff, f_cigar, f_codes;
     Buf g_rows, g_models, g_refs, g_out, g_bad; // filt feature rows
     Buf x_pos, x_endx, x_q, x_prefq, x_ce, x_bound, x_de, x_dropped, x_zlist, x_cnt, x_tabk, x_tabc, x_rs, x_re, x_rr;
-    Buf b_frag, b_fragj, b_fragl, b_fragr, b_acc, b_ancl, b_ancr, b_hasx, b_ent, b_res, b_genlist;
+    Buf b_frag, b_fragj, b_fragl, b_fragr, b_acc, b_ancl, b_ancr, b_hasx, b_ent, b_genlist;
 };
 
 namespace {
@@ -467,15 +475,18 @@ int pjb_create(pjb_ctx **out, const pjb_config *cfg) {
     (void)hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking);
     (void)hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking);
     (void)hipStreamCreateWithFlags(&c->stream4, hipStreamNonBlocking);
+    (void)hipStreamCreateWithFlags(&c->stream5, hipStreamNonBlocking);
     (void)hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
     (void)hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming);
     (void)hipEventCreateWithFlags(&c->ev_fork2, hipEventDisableTiming);
+    (void)hipEventCreateWithFlags(&c->ev_front, hipEventDisableTiming);
     (void)hipEventCreateWithFlags(&c->ev_join2, hipEventDisableTiming);
     for (int k = 0; k < 2; k++) {
         CtlSlot &S = c->sl[k];
         for (auto &ev : S.ev) (void)hipEventCreate(&ev);
         (void)hipEventCreateWithFlags(&S.ev_rows, hipEventDisableTiming);
         (void)hipEventCreateWithFlags(&S.ev_done, hipEventDisableTiming);
+        (void)hipEventCreateWithFlags(&S.ev_k1, hipEventDisableTiming);
         c->fl[k].slot = k;
     }
     c->ktime = (cfg->flags & PJB_FLAG_KERNEL_TIMING) != 0;
@@ -514,7 +525,9 @@ void pjb_destroy(pjb_ctx *c) {
         for (auto &ev : S.ev) (void)hipEventDestroy(ev);
         if (S.ev_rows) (void)hipEventDestroy(S.ev_rows);
         if (S.ev_done) (void)hipEventDestroy(S.ev_done);
-        Buf *sb[] = {&S.cstats, &S.err, &S.gencount, &S.batches, &S.rows};
+        Buf *sb[] = {&S.cstats, &S.err, &S.gencount, &S.batches, &S.rows, &S.tile_cnt, &S.tile_stats, &S.splidx, &S.splpoff, &S.okey, &S.g,
+                     &S.lstart, &S.rend, &S.pos, &S.aend, &S.meta, &S.updown, &S.seqw, &S.res};
+        if (S.ev_k1) (void)hipEventDestroy(S.ev_k1);
         for (Buf *b : sb) release(*b);
     }
     if (c->mirror_hdr) (void)hipHostFree(c->mirror_hdr);
@@ -522,11 +535,10 @@ void pjb_destroy(pjb_ctx *c) {
         if (c->stage[k]) (void)hipHostFree(c->stage[k]);
         if (c->stage_ev[k]) (void)hipEventDestroy(c->stage_ev[k]);
     }
-    Buf *all[] = {&c->b_cursor, &c->b_tile_cnt, &c->b_tile_stats, &c->b_total, &c->b_bitmap, &c->b_wrank, &c->b_ends, &c->b_firstid, &c->b_okey, &c->b_key[0],
-                  &c->b_key[1], &c->b_idx[0], &c->b_idx[1], &c->b_g, &c->b_lstart, &c->b_rend, &c->b_pos, &c->b_aend,
-                  &c->b_meta, &c->b_updown, &c->b_seqw, &c->b_hist, &c->b_hist_scan, &c->b_scan_tiles, &c->b_jid, &c->b_seg,
+    Buf *all[] = {&c->b_cursor, &c->b_total, &c->b_bitmap, &c->b_wrank, &c->b_ends, &c->b_firstid, &c->b_key[0],
+                  &c->b_key[1], &c->b_idx[0], &c->b_idx[1], &c->b_hist, &c->b_hist_scan, &c->b_scan_tiles, &c->b_jid, &c->b_seg,
                   &c->b_runfirst, &c->b_runstart, &c->b_frag, &c->b_fragj, &c->b_fragl, &c->b_fragr, &c->b_acc,
-                  &c->b_ancl, &c->b_ancr, &c->b_hasx, &c->b_ent, &c->b_splidx, &c->b_splpoff, &c->b_res, &c->b_genlist, &c->b_bintotal, &c->b_inf_comp, &c->b_inf_out, &c->b_inf_blocks, &c->b_inf_status, &c->b_inf_scratch, &c->b_bam_seg, &c->b_bam_rec, &c->b_bam_ctl, &c->b_entsum, &c->f_pos, &c->f_cigoff, &c->f_cigar, &c->f_codes, &c->g_rows, &c->g_models, &c->g_refs, &c->g_out, &c->g_bad,
+                  &c->b_ancl, &c->b_ancr, &c->b_hasx, &c->b_ent, &c->b_genlist, &c->b_bintotal, &c->b_inf_comp, &c->b_inf_out, &c->b_inf_blocks, &c->b_inf_status, &c->b_inf_scratch, &c->b_bam_seg, &c->b_bam_rec, &c->b_bam_ctl, &c->b_entsum, &c->f_pos, &c->f_cigoff, &c->f_cigar, &c->f_codes, &c->g_rows, &c->g_models, &c->g_refs, &c->g_out, &c->g_bad,
                   &c->x_pos, &c->x_endx, &c->x_q, &c->x_prefq, &c->x_ce, &c->x_bound, &c->x_de, &c->x_dropped, &c->x_zlist, &c->x_cnt,
                   &c->x_tabk, &c->x_tabc, &c->x_rs, &c->x_re, &c->x_rr};
     for (Buf *b : all) release(*b);
@@ -535,10 +547,12 @@ void pjb_destroy(pjb_ctx *c) {
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->ev_fork2) (void)hipEventDestroy(c->ev_fork2);
+    if (c->ev_front) (void)hipEventDestroy(c->ev_front);
     if (c->ev_join2) (void)hipEventDestroy(c->ev_join2);
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
     if (c->stream3) (void)hipStreamDestroy(c->stream3);
     if (c->stream4) (void)hipStreamDestroy(c->stream4);
+    if (c->stream5) (void)hipStreamDestroy(c->stream5);
     (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -727,6 +741,7 @@ static int add_batch(pjb_ctx *c, int32_t tid, const pjb_batch *b, bool device) {
         d.name_hash = c->extra ? (const u64 *)ptrs[11] : nullptr;
     }
     oc.batches.push_back(d);
+    if (!device) oc.on_main_stream = true;
     oc.last_known.push_back(device ? 0 : 1);
     oc.last_pos.push_back(device ? INT32_MIN : b->pos[b->n_reads - 1]);
     return PJB_OK;
@@ -874,7 +889,7 @@ static size_t rows_upper_bound(const pjb_ctx *c) {
 }
 
 static int queue_contig(pjb_ctx *c, Flight &f, std::vector<DevBatch> &batches) {
-    hipStream_t st = c->stream;
+    const hipStream_t st = c->stream;
     const int32_t tid = f.tid;
     const u32 n_tiles = f.n_tiles;
     const ContigLimits &lim = f.lim;
@@ -908,22 +923,22 @@ static int queue_contig(pjb_ctx *c, Flight &f, std::vector<DevBatch> &batches) {
     if ((rc = ensure(c, S.cstats, sizeof(ContigStats)))) return rc;
     if ((rc = ensure(c, S.err, 8))) return rc;
     if ((rc = ensure(c, c->b_cursor, sizeof(RowCursor)))) return rc;
-    if ((rc = ensure(c, c->b_tile_cnt, (size_t)n_tiles * 4))) return rc;
-    if ((rc = ensure(c, c->b_tile_stats, (size_t)n_tiles * sizeof(TileStats)))) return rc;
-    if ((rc = ensure(c, c->b_splidx, (size_t)n_tiles * K1_TILE * 4))) return rc;
-    if ((rc = ensure(c, c->b_splpoff, (size_t)n_tiles * K1_TILE * 4))) return rc;
+    if ((rc = ensure(c, S.tile_cnt, (size_t)n_tiles * 4))) return rc;
+    if ((rc = ensure(c, S.tile_stats, (size_t)n_tiles * sizeof(TileStats)))) return rc;
+    if ((rc = ensure(c, S.splidx, (size_t)n_tiles * K1_TILE * 4))) return rc;
+    if ((rc = ensure(c, S.splpoff, (size_t)n_tiles * K1_TILE * 4))) return rc;
     if ((rc = ensure(c, c->b_total, 8))) return rc;
     // ---- pair-sized buffers (one sort tile of slack: rs_scatter loads whole tiles unguarded)
-    if ((rc = ensure(c, c->b_okey, ((size_t)PL + RS_TILE) * 8))) return rc; // the pairs' keys as emitted (BAM order): kept, the sort works on copies
+    if ((rc = ensure(c, S.okey, ((size_t)PL + RS_TILE) * 8))) return rc; // the pairs' keys as emitted (BAM order): kept, the sort works on copies
     if ((rc = ensure(c, c->b_key[0], ((size_t)PL + RS_TILE) * 8))) return rc;
     if ((rc = ensure(c, c->b_key[1], ((size_t)PL + RS_TILE) * 8))) return rc;
     if ((rc = ensure(c, c->b_idx[0], ((size_t)PL + RS_TILE) * 4))) return rc;
     if ((rc = ensure(c, c->b_idx[1], ((size_t)PL + RS_TILE) * 4))) return rc;
-    Buf *pb[] = {&c->b_g, &c->b_lstart, &c->b_rend, &c->b_pos, &c->b_aend, &c->b_meta, &c->b_updown, &c->b_jid};
+    Buf *pb[] = {&S.g, &S.lstart, &S.rend, &S.pos, &S.aend, &S.meta, &S.updown, &c->b_jid};
     for (Buf *b : pb)
         if ((rc = ensure(c, *b, (size_t)PL * 4 + 16))) return rc;
-    if ((rc = ensure(c, c->b_res, (size_t)PL * 8 + 16))) return rc;
-    if ((rc = ensure(c, c->b_seqw, (size_t)PL * 8 + 16))) return rc;
+    if ((rc = ensure(c, S.res, (size_t)PL * 8 + 16))) return rc;
+    if ((rc = ensure(c, S.seqw, (size_t)PL * 8 + 16))) return rc;
     if ((rc = ensure(c, c->b_seg, ((size_t)PL + 1) * 4))) return rc;
     if ((rc = ensure(c, c->b_runfirst, ((size_t)PL + 1) * 4))) return rc;
     if ((rc = ensure(c, c->b_runstart, ((size_t)PL + 1) * 4))) return rc;
@@ -967,10 +982,28 @@ static int queue_contig(pjb_ctx *c, Flight &f, std::vector<DevBatch> &batches) {
         S.pub_dev = (uint8_t *)dp;
     }
 
-    HIP_TRY(c, hipMemcpyAsync(S.batches.p, S.batches_pinned, batches.size() * sizeof(DevBatch), hipMemcpyHostToDevice, st));
+    // ---- the contig's first kernels (count, tile scan, emit) go on the FRONT stream: they touch the records and this
+    // slot's arrays only, so they run beside the previous contig's last kernels (anchors, generic pairs, fragments:
+    // latency-bound, most of the chip idle).  The main stream picks up behind them (ev_k1) and behind the previous
+    // contig's chain (stream order).
+    const hipStream_t front = c->side_stream ? c->stream5 : st;
+    struct StreamScope {
+        pjb_ctx *c;
+        hipStream_t main;
+        ~StreamScope() { c->stream = main; }
+    } front_scope{c, st};
+    if (front != st) {
+        auto oit = c->open.find(tid);
+        if (oit != c->open.end() && oit->second.on_main_stream) { // records still being produced on the main stream
+            HIP_TRY(c, hipEventRecord(c->ev_front, st));
+            HIP_TRY(c, hipStreamWaitEvent(front, c->ev_front, 0));
+        }
+    }
+    c->stream = front; // LAUNCH (and its event bracket) follow c->stream
+    HIP_TRY(c, hipMemcpyAsync(S.batches.p, S.batches_pinned, batches.size() * sizeof(DevBatch), hipMemcpyHostToDevice, front));
     if (!S.at_rest) {
-        HIP_TRY(c, hipMemsetAsync(S.err.p, 0xff, 8, st));
-        HIP_TRY(c, hipMemsetAsync(S.gencount.p, 0, GEN_SHARDS * 4, st));
+        HIP_TRY(c, hipMemsetAsync(S.err.p, 0xff, 8, front));
+        HIP_TRY(c, hipMemsetAsync(S.gencount.p, 0, GEN_SHARDS * 4, front));
     }
     S.at_rest = false; // until k7_publish is queued
     u64 *d_err = (u64 *)S.err.p;
@@ -982,47 +1015,50 @@ static int queue_contig(pjb_ctx *c, Flight &f, std::vector<DevBatch> &batches) {
     do {                                                          \
         if (stage_events) HIP_TRY(c, hipEventRecord(S.ev[k], st));  \
     } while (0)
-    HIP_TRY(c, hipEventRecord(S.ev[0], st));
+    HIP_TRY(c, hipEventRecord(S.ev[0], front));
     // ---- K1a: count
     for (auto &b : batches) {
         const u32 nt = (u32)((b.n + K1_TILE - 1) / K1_TILE);
-        LAUNCH(c, "k1_count", k1_count, dim3(nt), dim3(256), b, (u32 *)c->b_tile_cnt.p, (TileStats *)c->b_tile_stats.p,
-               (u32 *)c->b_splidx.p, (u32 *)c->b_splpoff.p, d_err);
+        LAUNCH(c, "k1_count", k1_count, dim3(nt), dim3(256), b, (u32 *)S.tile_cnt.p, (TileStats *)S.tile_stats.p,
+               (u32 *)S.splidx.p, (u32 *)S.splpoff.p, d_err);
     }
-    LAUNCH(c, "k1_scan_tiles", k1_scan_tiles, dim3(1), dim3(1024), (u32 *)c->b_tile_cnt.p, (const TileStats *)c->b_tile_stats.p, n_tiles, d_cs,
+    LAUNCH(c, "k1_scan_tiles", k1_scan_tiles, dim3(1), dim3(1024), (u32 *)S.tile_cnt.p, (const TileStats *)S.tile_stats.p, n_tiles, d_cs,
            PL, kf, ref_len);
     // ---- K1b: emit
     Pairs pr;
-    pr.key = (u64 *)c->b_okey.p;
-    pr.g = (u32 *)c->b_g.p;
-    pr.lstart = (int32_t *)c->b_lstart.p;
-    pr.rend = (int32_t *)c->b_rend.p;
-    pr.pos = (int32_t *)c->b_pos.p;
-    pr.aend = (int32_t *)c->b_aend.p;
-    pr.meta = (u32 *)c->b_meta.p;
-    pr.updown = (u32 *)c->b_updown.p;
-    pr.seqw = (u64 *)c->b_seqw.p;
+    pr.key = (u64 *)S.okey.p;
+    pr.g = (u32 *)S.g.p;
+    pr.lstart = (int32_t *)S.lstart.p;
+    pr.rend = (int32_t *)S.rend.p;
+    pr.pos = (int32_t *)S.pos.p;
+    pr.aend = (int32_t *)S.aend.p;
+    pr.meta = (u32 *)S.meta.p;
+    pr.updown = (u32 *)S.updown.p;
+    pr.seqw = (u64 *)S.seqw.p;
     f.pr = pr;
     for (auto &b : batches) {
         const u32 nt = (u32)((b.n + K1_TILE - 1) / K1_TILE);
-        LAUNCH(c, "k1_emit", k1_emit, dim3(nt), dim3(256), b, (const u32 *)c->b_tile_cnt.p,
-               (const TileStats *)c->b_tile_stats.p, (const u32 *)c->b_splidx.p, (const u32 *)c->b_splpoff.p, pr, kf, ref_len,
+        LAUNCH(c, "k1_emit", k1_emit, dim3(nt), dim3(256), b, (const u32 *)S.tile_cnt.p,
+               (const TileStats *)S.tile_stats.p, (const u32 *)S.splidx.p, (const u32 *)S.splpoff.p, pr, kf, ref_len,
                tid, (int)c->cfg.orientation, d_err, (const ContigStats *)d_cs);
     }
     // ---- K4a: match statistics of the common [S] M N M [S] shape, in BAM order, while the keys are still unsorted:
     // on the side stream, beside the sort of the main stream (joined before pass 1 overwrites the keys)
     const bool fast_codes = G.codes != nullptr && !G.has_x;
     if (fast_codes && !c->side_stream) { // (PJB_SIDE_STREAM=0: one kernel at a time, for clean per-kernel timings)
-        LAUNCH(c, "k4a_simple", k4a_simple, dim3(pair_blocks), dim3(256), pr, kf, (const u32 *)G.codes, (int32_t)G.len, d_P, (u64 *)c->b_res.p);
+        LAUNCH(c, "k4a_simple", k4a_simple, dim3(pair_blocks), dim3(256), pr, kf, (const u32 *)G.codes, (int32_t)G.len, d_P, (u64 *)S.res.p);
     } else if (fast_codes) {
-        HIP_TRY(c, hipEventRecord(c->ev_fork, st));
+        HIP_TRY(c, hipEventRecord(c->ev_fork, front));
         HIP_TRY(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
-        hipStream_t main_stream = c->stream;
-        c->stream = c->stream2; // LAUNCH (and its event bracket) follow c->stream
+        c->stream = c->stream2;
         f.forked = true;
-        LAUNCH(c, "k4a_simple", k4a_simple, dim3(pair_blocks), dim3(256), pr, kf, (const u32 *)G.codes, (int32_t)G.len, d_P, (u64 *)c->b_res.p);
-        c->stream = main_stream;
+        LAUNCH(c, "k4a_simple", k4a_simple, dim3(pair_blocks), dim3(256), pr, kf, (const u32 *)G.codes, (int32_t)G.len, d_P, (u64 *)S.res.p);
         HIP_TRY(c, hipEventRecord(c->ev_join, c->stream2));
+    }
+    c->stream = st;
+    if (front != st) {
+        HIP_TRY(c, hipEventRecord(S.ev_k1, front));
+        HIP_TRY(c, hipStreamWaitEvent(st, S.ev_k1, 0));
     }
     STAGE_EVENT(1);
 
@@ -1076,7 +1112,7 @@ static int queue_contig(pjb_ctx *c, Flight &f, std::vector<DevBatch> &batches) {
     for (int p = 0; p < n_pass; p++) {
         const int bits = pass_bits[(size_t)p];
         if (bits <= 0) break;
-        const u64 *kin = p == 0 && !lim.dense ? (const u64 *)c->b_okey.p : (const u64 *)c->b_key[cur].p; // (dense ids were written to b_key[0])
+        const u64 *kin = p == 0 && !lim.dense ? (const u64 *)S.okey.p : (const u64 *)c->b_key[cur].p; // (dense ids were written to b_key[0])
         u64 *kout = (u64 *)c->b_key[cur ^ 1].p;
         const u32 *vin = p == 0 ? nullptr : (const u32 *)c->b_idx[cur].p;
         u32 *vout = (u32 *)c->b_idx[cur ^ 1].p;
@@ -1155,9 +1191,9 @@ static int queue_contig(pjb_ctx *c, Flight &f, std::vector<DevBatch> &batches) {
     LAUNCH(c, "k4b_generic", k4b_generic, dim3((gen_cap * GEN_SHARDS + 255) / 256), dim3(256), (const u32 *)c->b_genlist.p,
            (const u32 *)S.gencount.p, pair_blocks, skey, sidx, (const u32 *)c->b_jid.p, pr, kf, (const DevBatch *)S.batches.p,
            (int)batches.size(), (const int32_t *)c->b_ancl.p, (const int32_t *)c->b_ancr.p, (const uint8_t *)G.d,
-           (int32_t)G.len, G.has_x ? 1 : 0, (const u32 *)(G.has_x ? nullptr : G.codes), (u64 *)c->b_res.p, d_err);
+           (int32_t)G.len, G.has_x ? 1 : 0, (const u32 *)(G.has_x ? nullptr : G.codes), (u64 *)S.res.p, d_err);
     LAUNCH(c, "k4_pairs", k4_pairs, dim3(pair_blocks), dim3(256), skey, sidx, (const u32 *)c->b_jid.p, pr, kf,
-           (const u64 *)c->b_res.p, d_P, (u32 *)c->b_frag.p, (int32_t *)c->b_fragj.p);
+           (const u64 *)S.res.p, d_P, (u32 *)c->b_frag.p, (int32_t *)c->b_fragj.p);
     STAGE_EVENT(5);
 
     // ---- K5: fragments -> junctions -> rows
@@ -2037,6 +2073,7 @@ extern "C" int pjb_submit_bam(pjb_ctx *c, int32_t tid, const uint8_t *comp, int6
     d.pos = B.pos; d.flag = B.flag; d.mapq = B.mapq; d.xs = B.xs; d.l_qseq = B.l_qseq; d.mtid = B.mtid; d.mpos = B.mpos;
     d.cig_off = B.cig_off; d.cigar = B.cigar; d.seq_off = B.seq_off; d.seq4 = B.seq4;
     d.name_hash = (const u64 *)B.name_hash;
+    oc.on_main_stream = true;
     oc.batches.push_back(d);
     oc.last_known.push_back(0);
     oc.last_pos.push_back(INT32_MIN);
