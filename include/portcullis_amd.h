@@ -224,6 +224,15 @@ int pjb_finish_contig(pjb_ctx *ctx, int32_t tid, pjb_region_result *result);
 int pjb_finish_contig_begin(pjb_ctx *ctx, int32_t tid);
 int pjb_finish_contig_end(pjb_ctx *ctx, int32_t tid, pjb_region_result *result);
 
+/* Tuning switches (queue must be empty).  Results never depend on them.
+ *   "overlap"    1 (default): a contig's kernels are spread over several HIP streams -- its first kernels beside the
+ *                previous contig's last ones, match statistics and entropy beside the sort and the anchors; 0: one
+ *                kernel at a time on one stream (clean per-kernel timings; also the environment variable
+ *                PJB_SIDE_STREAM=0)
+ *   "dense_ids"  1 (default): the sort works on ordered dense junction ids; 0: on the full intron keys
+ *                (PJB_DENSE_IDS=0) */
+int pjb_set_option(pjb_ctx *ctx, const char *name, int64_t value);
+
 /* All rows built so far, contig by contig in finish order, (start,end)-sorted
  * within a contig.  The pointer stays valid until the next finish/clear/destroy. */
 int pjb_collect(pjb_ctx *ctx, const pjb_junction_row **rows, int64_t *n_rows);

@@ -1748,6 +1748,16 @@ int pjb_reset_kernel_timing(pjb_ctx *c) {
     return PJB_OK;
 }
 
+int pjb_set_option(pjb_ctx *c, const char *name, int64_t value) {
+    if (!c || !name) return PJB_ERR_ARG;
+    if (c->n_fl) return fail(c, PJB_ERR_STATE, "set_option: target %d is still queued", c->fl[0].tid);
+    const std::string n = name;
+    if (n == "overlap") c->side_stream = value != 0;
+    else if (n == "dense_ids") c->dense_ids = value != 0;
+    else return fail(c, PJB_ERR_ARG, "set_option: unknown option '%s'", name);
+    return PJB_OK;
+}
+
 int pjb_get_timing(const pjb_ctx *c, pjb_timing *out) {
     if (!c || !out) return PJB_ERR_ARG;
     *out = c->timing;

@@ -1352,44 +1352,73 @@ __device__ __forceinline__ u32 nt16_ascii(u32 c) { // seq_nt16_str "=ACMGRSVTWYH
     return (u32)(t >> ((c & 7u) * 8)) & 0xffu;
 }
 
-// 8 bases per step: read nibbles [qi, qi+l) (BAM order: high nibble first) against genome codes
-// [gi, gi+l) (low nibble first); mismatch positions are reported relative to `out_base`.
+// Read nibbles [qi, qi+l) (BAM order: high nibble first) against genome codes [gi, gi+l) (low nibble first), 64 bases
+// = 9 words of each per round; mismatch positions are reported relative to `out_base`.
+//   A lane's words are consecutive but the next lane's are somewhere else, so every load instruction of the wave
+// touches 64 cache lines whatever its width, and the number of load INSTRUCTIONS sets the pace (measured in
+// k4a_simple: 19 per-word loads per read cost 80 us per contig, the compare itself nothing).  So the words come as two
+// 16-byte loads and one 4-byte load per stream -- 4-byte aligned (reads start on word boundaries), which
+// global_load_dwordx4 accepts -- guarded so that nothing is read past the read's last word / the contig's last code
+// word; the short tail of a stream takes guarded word loads.
 __device__ __forceinline__ u32 swap_nibbles(u32 x) { return ((x & 0x0F0F0F0Fu) << 4) | ((x >> 4) & 0x0F0F0F0Fu); }
-__device__ __forceinline__ void cmp_words(const u32 *seqw, int32_t qi, const u32 *gw, int32_t gi, int32_t g_words,
-                                          int32_t l, int32_t out_base, int32_t &mism, int32_t &first_mis,
-                                          int32_t &last_mis) {
-    const int shq = (qi & 7) * 4, shg = (gi & 7) * 4;
-    const int32_t lastq = (qi + l - 1) >> 3, lastg = (gi + l - 1) >> 3;
-    int32_t wq = qi >> 3, wg = gi >> 3;
-    for (int32_t t = 0; t < l; t += 32) {
-        // issue all loads of this 32-base stretch before using any (memory-level parallelism)
-        u32 qw[5], gg[5];
+struct __attribute__((packed, aligned(4))) Words4 {
+    u32 x, y, z, w;
+};
+struct CmpChunk {
+    u32 qw[9], gg[9];
+};
+// d[k] = p[first + k] for 0 <= first + k <= last, else 0 (first + 8 <= last: three loads)
+__device__ __forceinline__ void load9(u32 (&d)[9], const u32 *p, int32_t first, int32_t last) {
+    if (first >= 0 && first + 8 <= last) {
+        const Words4 a = *reinterpret_cast<const Words4 *>(p + first), b = *reinterpret_cast<const Words4 *>(p + first + 4);
+        d[0] = a.x, d[1] = a.y, d[2] = a.z, d[3] = a.w;
+        d[4] = b.x, d[5] = b.y, d[6] = b.z, d[7] = b.w;
+        d[8] = p[first + 8];
+    } else {
 #pragma unroll
-        for (int k = 0; k < 5; k++) {
-            qw[k] = (wq + k <= lastq) ? seqw[wq + k] : 0u;
-            const int32_t w = wg + k;
-            gg[k] = (w <= lastg && w >= 0 && w < g_words) ? gw[w] : 0u;
-        }
+        for (int k = 0; k < 9; k++) d[k] = (first + k >= 0 && first + k <= last) ? p[first + k] : 0u;
+    }
+}
+// anchor bases [t, t + 64) of an anchor of l bases: read bases from qi (words of the read up to word q_last may be
+// touched: whatever lies past the anchor only feeds bits that the length mask removes), genome from gi
+__device__ __forceinline__ void chunk_load(CmpChunk &C, bool active, const u32 *seqw, int32_t qi, int32_t q_last, const u32 *gw, int32_t gi,
+                                           int32_t g_words, int32_t l, int32_t t) {
+    if (!active) return;
+    const int32_t lastg = (gi + l - 1) >> 3;
+    load9(C.qw, seqw, (qi + t) >> 3, q_last);
+    // (genome words outside [0, g_words) and past the anchor's last word read as 0, as they always did)
+    load9(C.gg, gw, (gi + t) >> 3, lastg < g_words - 1 ? lastg : g_words - 1);
+}
+__device__ __forceinline__ void chunk_cmp(CmpChunk &C, bool active, int32_t qi, int32_t gi, int32_t l, int32_t t, int32_t out_base,
+                                          int32_t &mism, int32_t &first_mis, int32_t &last_mis) {
+    if (!active) return;
+    const u32 shq = (u32)(qi & 7) * 4u, shg = (u32)(gi & 7) * 4u; // (t is a multiple of 8: the shifts do not move)
 #pragma unroll
-        for (int k = 0; k < 5; k++) qw[k] = swap_nibbles(qw[k]);
+    for (int k = 0; k < 9; k++) C.qw[k] = swap_nibbles(C.qw[k]);
 #pragma unroll
-        for (int c = 0; c < 4; c++) {
-            const int32_t rem = l - t - 8 * c;
-            if (rem > 0) {
-                const u32 q = (u32)((((u64)qw[c + 1] << 32) | qw[c]) >> shq);
-                const u32 g = (u32)((((u64)gg[c + 1] << 32) | gg[c]) >> shg);
-                const u32 x = q ^ g;
-                u32 m = (x | (x >> 1) | (x >> 2) | (x >> 3)) & 0x11111111u;
-                if (rem < 8) m &= (1u << (4 * rem)) - 1u;
-                if (m) {
-                    mism += __popc(m);
-                    if (first_mis < 0) first_mis = out_base + t + 8 * c + ((__ffs((int)m) - 1) >> 2);
-                    last_mis = out_base + t + 8 * c + ((31 - __clz((int)m)) >> 2);
-                }
+    for (int c = 0; c < 8; c++) {
+        const int32_t rem = l - t - 8 * c;
+        if (rem > 0) {
+            const u32 q = __builtin_amdgcn_alignbit(C.qw[c + 1], C.qw[c], shq);
+            const u32 g = __builtin_amdgcn_alignbit(C.gg[c + 1], C.gg[c], shg);
+            const u32 x = q ^ g;
+            u32 m = (x | (x >> 1) | (x >> 2) | (x >> 3)) & 0x11111111u;
+            if (rem < 8) m &= (1u << (4 * rem)) - 1u;
+            if (m) {
+                mism += __popc(m);
+                if (first_mis < 0) first_mis = out_base + t + 8 * c + ((__ffs((int)m) - 1) >> 2);
+                last_mis = out_base + t + 8 * c + ((31 - __clz((int)m)) >> 2);
             }
         }
-        wq += 4;
-        wg += 4;
+    }
+}
+// one stretch of l bases (the generic walks: one call per CIGAR operation that emits bases on both sides)
+__device__ __forceinline__ void cmp_words(const u32 *seqw, int32_t qi, int32_t q_last, const u32 *gw, int32_t gi, int32_t g_words, int32_t l,
+                                          int32_t out_base, int32_t &mism, int32_t &first_mis, int32_t &last_mis) {
+    for (int32_t t = 0; t < l; t += 64) {
+        CmpChunk C;
+        chunk_load(C, true, seqw, qi, q_last, gw, gi, g_words, l, t);
+        chunk_cmp(C, true, qi, gi, l, t, out_base, mism, first_mis, last_mis);
     }
 }
 
@@ -1493,8 +1522,8 @@ __device__ Side anchor_side(const OpsView cig, u32 n, int32_t position, int32_t 
         if (qEmit != gEmit) diverged = true;
         if (!diverged && qEmit > 0) {
             if (qKind == 1 && gKind == 1 && gcodes != nullptr && rPos >= 0 && rPos + qEmit <= glen) {
-                cmp_words(reinterpret_cast<const u32 *>(seq), dS + qPos, gcodes, rPos, (glen + 7) / 8 + 1, qEmit, qTot, mism,
-                          first_mis, last_mis);
+                cmp_words(reinterpret_cast<const u32 *>(seq), dS + qPos, ((lq + 7) >> 3) - 1, gcodes, rPos, (glen + 7) / 8 + 1, qEmit, qTot,
+                          mism, first_mis, last_mis);
             } else if (qKind == 1 && gKind == 1) {
                 const int32_t qb = dS + qPos;
                 for (int32_t t = 0; t < qEmit; t++) {
@@ -1585,65 +1614,6 @@ __device__ __forceinline__ const DevBatch &find_batch(const DevBatch *batches, i
     return batches[lo];
 }
 
-// 64 bases of one anchor = 9 words of read bases and 9 of genome codes.  A lane's words are consecutive but the next
-// lane's are somewhere else, so every load instruction of the wave touches 64 cache lines whatever its width, and
-// the number of load INSTRUCTIONS sets the pace (measured: 19 per-word loads per read cost 80 us per contig, the
-// compare itself nothing).  So the words come as two 16-byte loads and one 4-byte load per stream -- 4-byte aligned
-// (reads start on word boundaries), which global_load_dwordx4 accepts -- guarded so that nothing is read past the
-// read's last word / the contig's last code word; the short tail of a stream takes guarded word loads.  The chunks
-// of both anchors are issued together: a 150-base read is two round trips.
-struct __attribute__((packed, aligned(4))) Words4 {
-    u32 x, y, z, w;
-};
-struct CmpChunk {
-    u32 qw[9], gg[9];
-};
-// d[k] = p[first + k] for 0 <= first + k <= last, else 0 (first + 8 <= last: three loads)
-__device__ __forceinline__ void load9(u32 (&d)[9], const u32 *p, int32_t first, int32_t last) {
-    if (first >= 0 && first + 8 <= last) {
-        const Words4 a = *reinterpret_cast<const Words4 *>(p + first), b = *reinterpret_cast<const Words4 *>(p + first + 4);
-        d[0] = a.x, d[1] = a.y, d[2] = a.z, d[3] = a.w;
-        d[4] = b.x, d[5] = b.y, d[6] = b.z, d[7] = b.w;
-        d[8] = p[first + 8];
-    } else {
-#pragma unroll
-        for (int k = 0; k < 9; k++) d[k] = (first + k >= 0 && first + k <= last) ? p[first + k] : 0u;
-    }
-}
-// anchor bases [t, t + 64) of an anchor of l bases: read bases from qi (words of the read up to word q_last may be
-// touched), genome from gi
-__device__ __forceinline__ void chunk_load(CmpChunk &C, bool active, const u32 *seqw, int32_t qi, int32_t q_last, const u32 *gw, int32_t gi,
-                                           int32_t g_words, int32_t l, int32_t t) {
-    if (!active) return;
-    const int32_t lastg = (gi + l - 1) >> 3;
-    load9(C.qw, seqw, (qi + t) >> 3, q_last);
-    // (genome words outside [0, g_words) and past the anchor's last word read as 0, as they always did)
-    load9(C.gg, gw, (gi + t) >> 3, lastg < g_words - 1 ? lastg : g_words - 1);
-}
-__device__ __forceinline__ void chunk_cmp(CmpChunk &C, bool active, int32_t qi, int32_t gi, int32_t l, int32_t t, int32_t &mism,
-                                          int32_t &first_mis, int32_t &last_mis) {
-    if (!active) return;
-    const u32 shq = (u32)(qi & 7) * 4u, shg = (u32)(gi & 7) * 4u; // (t is a multiple of 8: the shifts do not move)
-#pragma unroll
-    for (int k = 0; k < 9; k++) C.qw[k] = swap_nibbles(C.qw[k]);
-#pragma unroll
-    for (int c = 0; c < 8; c++) {
-        const int32_t rem = l - t - 8 * c;
-        if (rem > 0) {
-            const u32 q = __builtin_amdgcn_alignbit(C.qw[c + 1], C.qw[c], shq);
-            const u32 g = __builtin_amdgcn_alignbit(C.gg[c + 1], C.gg[c], shg);
-            const u32 x = q ^ g;
-            u32 m = (x | (x >> 1) | (x >> 2) | (x >> 3)) & 0x11111111u;
-            if (rem < 8) m &= (1u << (4 * rem)) - 1u;
-            if (m) {
-                mism += __popc(m);
-                if (first_mis < 0) first_mis = t + 8 * c + ((__ffs((int)m) - 1) >> 2);
-                last_mis = t + 8 * c + ((31 - __clz((int)m)) >> 2);
-            }
-        }
-    }
-}
-
 // K4a: the common shape [S] M N M [S], one thread per pair IN EMISSION (BAM) ORDER, before the sort:
 // the left anchor is read[dS, dS+a) against genome[pos, pos+a), the right one read[dS+a, dS+a+b)
 // against genome[iend+1, iend+1+b); neither depends on the junction-level window, the walk rules
@@ -1671,8 +1641,8 @@ __global__ __launch_bounds__(256) void k4a_simple(Pairs P, KeyFmt kf, const u32 
         const bool onL = t < a, onR = t < bb;
         chunk_load(L, onL, seqw, dS, q_last, gcodes, pos, g_words, a, t);
         chunk_load(R, onR, seqw, dS + a, q_last, gcodes, iend + 1, g_words, bb, t);
-        chunk_cmp(L, onL, dS, pos, a, t, misL, firstL, lastL);
-        chunk_cmp(R, onR, dS + a, iend + 1, bb, t, misR, firstR, lastR);
+        chunk_cmp(L, onL, dS, pos, a, t, 0, misL, firstL, lastL);
+        chunk_cmp(R, onR, dS + a, iend + 1, bb, t, 0, misR, firstR, lastR);
     }
     const u32 upM = lastL < 0 ? (u32)a : (u32)(a - 1 - lastL);
     const u32 downM = firstR < 0 ? (u32)bb : (u32)firstR;

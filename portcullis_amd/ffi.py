@@ -24,7 +24,7 @@ EXPORTS = [
     "pjb_finish_contig_end", "pjb_collect",
     "pjb_clear_rows", "pjb_get_timing", "pjb_device_count", "pjb_get_kernel_timing", "pjb_reset_kernel_timing",
     "pjb_select_timed_kernels", "pjb_host_alloc", "pjb_host_free", "pjb_inflate_bgzf", "pjb_submit_bam", "pjb_collect_device", "pjb_set_row_mirror",
-    "pjb_extra_finish", "pjb_filter_set_junctions", "pjb_filter_batch", "pjb_filt_features",
+    "pjb_extra_finish", "pjb_set_option", "pjb_filter_set_junctions", "pjb_filter_batch", "pjb_filt_features",
 ]
 N_FEATURES = 34
 KMER_TABLE = 3125 * 5
@@ -117,6 +117,7 @@ def load():
         L.pjb_submit_batch.argtypes = [C.c_void_p, C.c_int32, C.POINTER(PjbBatch)]
         L.pjb_submit_batch_device.argtypes = [C.c_void_p, C.c_int32, C.POINTER(PjbBatch)]
         L.pjb_finish_contig.argtypes = [C.c_void_p, C.c_int32, C.POINTER(PjbRegionResult)]
+        L.pjb_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
         L.pjb_finish_contig_begin.argtypes = [C.c_void_p, C.c_int32]
         L.pjb_finish_contig_end.argtypes = [C.c_void_p, C.c_int32, C.POINTER(PjbRegionResult)]
         L.pjb_set_row_mirror.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
@@ -242,6 +243,9 @@ class Context:
         finally:
             self._keep_batch.pop(tid, None)
         return {k: getattr(r, k) for k, _ in PjbRegionResult._fields_}
+
+    def set_option(self, name, value):
+        self._check(self._L.pjb_set_option(self._h, name.encode(), int(value)))
 
     def finish_contig_begin(self, tid):
         """Queue the contig's kernel chain without waiting (at most two contigs queued; collect in the same order)."""
