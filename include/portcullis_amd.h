@@ -208,8 +208,8 @@ int pjb_submit_batch(pjb_ctx *ctx, int32_t tid, const pjb_batch *host_batch);
 int pjb_submit_batch_device(pjb_ctx *ctx, int32_t tid, const pjb_batch *device_batch);
 
 /* Run the device pipeline over everything submitted for contig `tid` and close it.  The contig's
- * genome must have been uploaded.  On return the contig's rows are on the
- * host (appended to the table pjb_collect returns). */
+ * genome must have been uploaded.  On return the contig's counters are in *result and its rows are appended to the
+ * table pjb_collect returns (they travel to the host by DMA; pjb_collect waits for them). */
 int pjb_finish_contig(pjb_ctx *ctx, int32_t tid, pjb_region_result *result);
 
 /* The same in two halves, so that the device never waits for the host between contigs (the reference gets the

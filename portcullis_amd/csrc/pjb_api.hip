@@ -152,7 +152,8 @@ struct pjb_ctx {
     unsigned stage_next = 0;
     // junction rows live in a grow-only pinned host buffer so the D2H copy is a single DMA
     pjb_junction_row *rows_pinned = nullptr;
-    pjb_junction_row *rows_pinned_dev = nullptr; // the same memory as the device sees it (k6_rows_out writes it)
+    pjb_junction_row *rows_table = nullptr;      // the same table in HBM (k6_rows_out appends; a DMA per contig fills rows_pinned)
+    bool rows_copy_pending = false;              // a DMA into rows_pinned is on stream4
     // buffers with a rest state that the kernel chain itself restores (no per-contig memsets): error word / list
     // counters (k7_publish; per slot), start bitmap / end slots (kd_reset).  false: set by a memset before use
     bool dense_at_rest = false;
@@ -518,6 +519,7 @@ void pjb_destroy(pjb_ctx *c) {
     for (auto &sl : c->slab_pool)
         if (sl.p) (void)hipFree(sl.p);
     if (c->rows_pinned) (void)hipHostFree(c->rows_pinned);
+    if (c->rows_table) (void)hipFree(c->rows_table);
     for (int k = 0; k < 2; k++) {
         CtlSlot &S = c->sl[k];
         if (S.pub) (void)hipHostFree(S.pub);
@@ -880,6 +882,14 @@ static int extra_contig(pjb_ctx *c, int32_t tid, std::vector<DevBatch> &batches,
 // and pjb_finish_contig_end waits for their event -- by which time the next contig may be queued behind this one.
 static void wait_flight(pjb_ctx *c, Flight &f);
 
+// the host row table is complete up to rows_n
+static int rows_sync(pjb_ctx *c) {
+    if (!c->rows_copy_pending) return PJB_OK;
+    HIP_TRY(c, hipStreamSynchronize(c->stream4));
+    c->rows_copy_pending = false;
+    return PJB_OK;
+}
+
 // rows of the contigs collected so far plus the most the queued ones can add
 static size_t rows_upper_bound(const pjb_ctx *c) {
     size_t n = c->rows_n;
@@ -888,6 +898,7 @@ static size_t rows_upper_bound(const pjb_ctx *c) {
     return n;
 }
 
+constexpr unsigned K6_BLOCKS = 128;
 static int queue_contig(pjb_ctx *c, Flight &f, std::vector<DevBatch> &batches) {
     const hipStream_t st = c->stream;
     const int32_t tid = f.tid;
@@ -957,23 +968,34 @@ static int queue_contig(pjb_ctx *c, Flight &f, std::vector<DevBatch> &batches) {
     if ((rc = ensure(c, c->b_ancl, (size_t)JL * 4 + 16))) return rc;
     if ((rc = ensure(c, c->b_ancr, (size_t)JL * 4 + 16))) return rc;
     if ((rc = ensure(c, S.rows, (size_t)JL * sizeof(pjb_junction_row) + 16))) return rc;
-    // rows leave through page-locked host memory (grow-only; the rows stream writes behind the rows that are there)
+    // The row table lives twice, both grow-only: in HBM, where the rows stream appends each contig's rows (k6_rows_out),
+    // and in page-locked host memory, filled by a DMA per contig once its row count is known (pjb_finish_contig_end).
+    // (The kernel used to write the host table itself: 2 MB of PCIe stores per contig that slowed whatever ran beside
+    // them -- the next contig's k1_count by 40 %.)
     size_t old = rows_upper_bound(c);
     if (old + JL > c->rows_cap) {
-        for (int k = 0; k < c->n_fl; k++) // (the table moves: nothing may be writing to it)
+        for (int k = 0; k < c->n_fl; k++) // (the tables move: nothing may be writing to them)
             if (c->fl[k].queued && &c->fl[k] != &f) wait_flight(c, c->fl[k]);
+        if ((rc = rows_sync(c))) return rc;
         old = std::min(old, c->rows_cap);
         const size_t ncap = std::max<size_t>((old + JL) * 3 / 2, 1024);
-        pjb_junction_row *np = nullptr;
-        hipError_t e = hipHostMalloc((void **)&np, ncap * sizeof(pjb_junction_row), hipHostMallocMapped | hipHostMallocPortable);
+        pjb_junction_row *np = nullptr, *nd = nullptr;
+        hipError_t e = hipHostMalloc((void **)&np, ncap * sizeof(pjb_junction_row), hipHostMallocPortable);
         if (e != hipSuccess) return fail(c, PJB_ERR_NOMEM, "hipHostMalloc(rows): %s", hipGetErrorString(e));
-        if (old) memcpy(np, c->rows_pinned, old * sizeof(pjb_junction_row));
+        e = hipMalloc((void **)&nd, ncap * sizeof(pjb_junction_row));
+        if (e != hipSuccess) {
+            (void)hipHostFree(np);
+            return fail(c, PJB_ERR_NOMEM, "hipMalloc(row table): %s", hipGetErrorString(e));
+        }
+        if (old) {
+            memcpy(np, c->rows_pinned, old * sizeof(pjb_junction_row));
+            (void)hipMemcpy(nd, c->rows_table, old * sizeof(pjb_junction_row), hipMemcpyDeviceToDevice);
+        }
         if (c->rows_pinned) (void)hipHostFree(c->rows_pinned);
+        if (c->rows_table) (void)hipFree(c->rows_table);
         c->rows_pinned = np;
+        c->rows_table = nd;
         c->rows_cap = ncap;
-        void *dp = nullptr;
-        if (hipHostGetDevicePointer(&dp, np, 0) != hipSuccess || !dp) return fail(c, PJB_ERR_HIP, "hipHostGetDevicePointer(rows) failed");
-        c->rows_pinned_dev = (pjb_junction_row *)dp;
     }
     if (!S.pub) {
         HIP_TRY(c, hipHostMalloc((void **)&S.pub, PUB_BYTES, hipHostMallocMapped | hipHostMallocPortable));
@@ -1214,24 +1236,26 @@ static int queue_contig(pjb_ctx *c, Flight &f, std::vector<DevBatch> &batches) {
         mirror_table = (u64 *)(c->mirror + PJB_MIRROR_HEADER_BYTES);
         mirror_room = (u32)std::min<size_t>((c->mirror_cap - PJB_MIRROR_HEADER_BYTES) / sizeof(pjb_junction_row), 0xffffffffu);
     }
-    HIP_TRY(c, hipEventRecord(S.ev_rows, st));
-    HIP_TRY(c, hipStreamWaitEvent(c->stream3, S.ev_rows, 0));
+    const hipStream_t rows_stream = c->side_stream ? c->stream3 : st;
+    if (rows_stream != st) {
+        HIP_TRY(c, hipEventRecord(S.ev_rows, st));
+        HIP_TRY(c, hipStreamWaitEvent(rows_stream, S.ev_rows, 0));
+    }
     {
         struct StreamScope {
             pjb_ctx *c;
             hipStream_t main;
             ~StreamScope() { c->stream = main; }
         } scope{c, c->stream};
-        c->stream = c->stream3; // LAUNCH (and its event bracket) follow c->stream
-        const u64 units = std::max<u64>(1, (u64)JL * ROW_U64);
-        LAUNCH(c, "k6_rows_out", k6_rows_out, dim3((unsigned)((units + 255) / 256)), dim3(256), (const u64 *)S.rows.p, (const ContigStats *)d_cs,
-               (u64 *)c->rows_pinned_dev, row_base, mirror_base, (const RowCursor *)c->b_cursor.p, mirror_table, mirror_room);
+        c->stream = rows_stream; // LAUNCH (and its event bracket) follow c->stream
+        LAUNCH(c, "k6_rows_out", k6_rows_out, dim3(K6_BLOCKS), dim3(256), (const u64 *)S.rows.p, (const ContigStats *)d_cs,
+               (u64 *)c->rows_table, row_base, mirror_base, (const RowCursor *)c->b_cursor.p, mirror_table, mirror_room);
         LAUNCH(c, "k7_publish", k7_publish, dim3(1), dim3(256), (const ContigStats *)d_cs, d_err, (u32 *)S.gencount.p, S.pub_dev, row_base,
                mirror_base, (RowCursor *)c->b_cursor.p);
     }
     S.at_rest = true;
-    HIP_TRY(c, hipEventRecord(S.ev[7], c->stream3));
-    HIP_TRY(c, hipEventRecord(S.ev_done, c->stream3));
+    HIP_TRY(c, hipEventRecord(S.ev[7], rows_stream));
+    HIP_TRY(c, hipEventRecord(S.ev_done, rows_stream));
 #undef STAGE_EVENT
     f.queued = true;
     return PJB_OK;
@@ -1445,6 +1469,10 @@ int pjb_finish_contig_end(pjb_ctx *c, int32_t tid, pjb_region_result *res) {
         HIP_TRY(c, hipMemcpyAsync(c->mirror, c->mirror_hdr, PJB_MIRROR_HEADER_BYTES, hipMemcpyHostToDevice, c->stream4));
         HIP_TRY(c, hipStreamSynchronize(c->stream4));
     }
+    if (J) { // the contig's rows: HBM table -> host table, by DMA, behind whatever the caller does next
+        HIP_TRY(c, hipMemcpyAsync(c->rows_pinned + old, c->rows_table + old, (size_t)J * sizeof(pjb_junction_row), hipMemcpyDeviceToHost, c->stream4));
+        c->rows_copy_pending = true;
+    }
     c->cur_slot = f.slot;
     if (c->extra && (rc = extra_contig(c, tid, batches, f.n_reads, cs.spliced, P, J, f.sidx, f.pr.g, old))) return rc;
     c->rows_n = old + J;
@@ -1476,6 +1504,8 @@ int pjb_finish_contig(pjb_ctx *c, int32_t tid, pjb_region_result *res) {
 
 int pjb_collect(pjb_ctx *c, const pjb_junction_row **rows, int64_t *n) {
     if (!c || !rows || !n) return PJB_ERR_ARG;
+    const int rc = rows_sync(c);
+    if (rc) return rc;
     *rows = c->rows_pinned;
     *n = (int64_t)c->rows_n;
     return PJB_OK;
@@ -1505,6 +1535,7 @@ int pjb_set_row_mirror(pjb_ctx *c, void *device_buffer, int64_t cap_bytes) {
 int pjb_clear_rows(pjb_ctx *c) {
     if (!c) return PJB_ERR_ARG;
     if (c->n_fl) return fail(c, PJB_ERR_STATE, "clear_rows: target %d is still queued", c->fl[0].tid);
+    (void)rows_sync(c);
     c->rows_n = 0;
     mirror_reset(c);
     if (c->extra) {
@@ -1547,6 +1578,7 @@ int pjb_extra_finish(pjb_ctx *c, const pjb_extra_row **rows_out, int64_t *n_out)
             LAUNCH(c, "kx_name_sum", kx_name_sum, dim3((x.n_pairs + 255) / 256), dim3(256), (const u64 *)x.pair_code, (const u32 *)x.pair_row,
                    x.n_pairs, (const u64 *)c->x_tabk.p, (const u32 *)c->x_tabc.p, mask, x.xr - x.row_base);
     // ---- rows as SoA on the device (start, end, nb_raw)
+    if ((rc = rows_sync(c))) return rc;
     std::vector<int32_t> hs(Jall), he(Jall);
     std::vector<uint32_t> hr(Jall);
     for (size_t j = 0; j < Jall; j++) {

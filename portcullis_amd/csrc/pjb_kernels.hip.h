@@ -2127,16 +2127,17 @@ struct RowCursor {
 };
 __global__ __launch_bounds__(256) void k6_rows_out(const u64 *rows, const ContigStats *cs, u64 *host_table, int64_t base, int64_t mirror_base,
                                                    const RowCursor *cur, u64 *mirror_table, u32 mirror_room) {
+    // a grid of a few dozen blocks walks the rows: the kernel runs beside the next contig's first kernels, its stores
+    // wait on PCIe, and it should not sit on their wave slots meanwhile
     const u32 nj = cs->J;
     const u64 n = (u64)nj * ROW_U64;
-    const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
     const u64 at = base >= 0 ? (u64)base : (u64)cur->rows;
-    const u64 v = rows[i];
-    host_table[at * ROW_U64 + i] = v;
-    if (mirror_table) { // (the slot is left alone by a contig that does not fit: the host reports it)
-        const u64 mat = mirror_base >= 0 ? (u64)mirror_base : (u64)cur->mirror_rows;
-        if (mat + nj <= (u64)mirror_room) mirror_table[mat * ROW_U64 + i] = v;
+    const u64 mat = mirror_base >= 0 ? (u64)mirror_base : (u64)cur->mirror_rows;
+    const bool to_mirror = mirror_table && mat + nj <= (u64)mirror_room; // (the slot is left alone by a contig that does not fit: the host reports it)
+    for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < n; i += (u64)gridDim.x * 256) {
+        const u64 v = rows[i];
+        host_table[at * ROW_U64 + i] = v;
+        if (to_mirror) mirror_table[mat * ROW_U64 + i] = v;
     }
 }
 
