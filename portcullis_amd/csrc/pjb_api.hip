@@ -90,6 +90,13 @@ struct CtlSlot {
     Buf okey, g, lstart, rend, pos, aend, meta, updown, seqw; // the pairs (BAM order)
     Buf res;                                                  // k4a_simple / k4b_generic results per pair
     hipEvent_t ev_k1 = nullptr;
+    // the rest of the chain's scratch, and its streams: the chains of the two slots run side by side (most kernels of a
+    // contig-sized chain are latency-bound and leave the chip half idle)
+    Buf total, bitmap, wrank, ends, firstid, key[2], idx[2], hist, hist_scan, bintotal, scan_tiles;
+    Buf jid, seg, runfirst, runstart, ent, entsum, frag, fragj, fragl, fragr, acc, ancl, ancr, genlist;
+    bool dense_at_rest = false;
+    hipStream_t main = nullptr, side = nullptr; // chain; match statistics / entropy beside it
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_fork2 = nullptr, ev_join2 = nullptr;
     uint8_t *pub = nullptr, *pub_dev = nullptr; // page-locked: what k7_publish writes (host view, device view)
     DevBatch *batches_pinned = nullptr;         // page-locked staging of the batch descriptors
     size_t batches_pinned_cap = 0;
@@ -124,12 +131,11 @@ struct Flight {
 
 struct pjb_ctx {
     pjb_config cfg;
-    hipStream_t stream = nullptr;
-    hipStream_t stream2 = nullptr; // side stream: work that does not depend on the sort (k4a_simple)
+    hipStream_t stream = nullptr;  // service stream: uploads, host batches, BAM ingest, filters, extra metrics; a contig's chain runs
+                                   // on its slot's streams (CtlSlot::main / side)
     hipStream_t stream3 = nullptr; // rows stream: k6_rows_out + k7_publish of a contig, beside the next contig's first kernels
     hipStream_t stream4 = nullptr; // header of the row mirror
-    hipStream_t stream5 = nullptr; // front stream: a contig's first kernels (K1), beside the previous contig's last ones
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_fork2 = nullptr, ev_join2 = nullptr, ev_front = nullptr;
+    hipEvent_t ev_front = nullptr; // service stream -> chain stream
     CtlSlot sl[2];
     Flight fl[2]; // FIFO: fl[0] is the oldest
     int n_fl = 0;
@@ -156,7 +162,6 @@ struct pjb_ctx {
     bool rows_copy_pending = false;              // a DMA into rows_pinned is on stream4
     // buffers with a rest state that the kernel chain itself restores (no per-contig memsets): error word / list
     // counters (k7_publish; per slot), start bitmap / end slots (kd_reset).  false: set by a memset before use
-    bool dense_at_rest = false;
     int last_slot = 0; // slot of the contig collected last (pjb_collect_device)
     bool side_stream = true;                     // k4a_simple beside the sort (PJB_SIDE_STREAM=0: on the main stream)
     bool dense_ids = true;                       // K2d (PJB_DENSE_IDS=0 sorts the full keys as round 1 did)
@@ -180,13 +185,10 @@ struct pjb_ctx {
     std::vector<double> kms;
     std::vector<std::string> ktime_only; // if non-empty, only these kernel names are bracketed
     // scratch
-    Buf b_total;
-    Buf b_bitmap, b_wrank, b_ends, b_firstid; // K2d
-    Buf b_key[2], b_idx[2];
-    Buf b_hist, b_hist_scan, b_scan_tiles, b_bintotal;
+    Buf *scan_tiles = nullptr; // run_scan's tile sums: the service buffer, or the slot's while a chain is being queued
+    Buf b_scan_tiles;
     Buf b_inf_comp, b_inf_out, b_inf_blocks, b_inf_status, b_inf_scratch; // device-side BGZF inflate
     Buf b_bam_seg, b_bam_rec, b_bam_ctl;                                  // device-side BAM record parse
-    Buf b_jid, b_seg, b_runfirst, b_runstart, b_entsum;
     // --extra
     bool extra = false;
     std::vector<ExtraContig> xc;
@@ -195,7 +197,7 @@ struct pjb_ctx {
     Buf f_pos, f_cigoff, f_cigar, f_codes;
     Buf g_rows, g_models, g_refs, g_out, g_bad; // filt feature rows
     Buf x_pos, x_endx, x_q, x_prefq, x_ce, x_bound, x_de, x_dropped, x_zlist, x_cnt, x_tabk, x_tabc, x_rs, x_re, x_rr;
-    Buf b_frag, b_fragj, b_fragl, b_fragr, b_acc, b_ancl, b_ancr, b_hasx, b_ent, b_genlist;
+    Buf b_hasx, b_xtotal;
 };
 
 namespace {
@@ -358,9 +360,10 @@ bool ktime_wanted(pjb_ctx *c, const char *name) {
 template <typename F, typename G>
 int run_scan(pjb_ctx *c, const char *tag, F f, G g, u64 n, u64 *d_total, const u32 *d_n = nullptr) {
     const u32 nt = std::max<u32>(1, (u32)((n + SCAN_TILE - 1) / SCAN_TILE)); // (an empty input still gets its total written)
-    int rc = ensure(c, c->b_scan_tiles, (size_t)nt * 8);
+    Buf &tiles = c->scan_tiles ? *c->scan_tiles : c->b_scan_tiles;
+    int rc = ensure(c, tiles, (size_t)nt * 8);
     if (rc) return rc;
-    u64 *ts = (u64 *)c->b_scan_tiles.p;
+    u64 *ts = (u64 *)tiles.p;
     std::string t = tag;
     LAUNCH(c, (t + "_reduce").c_str(), (scan_reduce_kernel<F>), dim3(nt), dim3(256), f, n, ts, d_n);
     if (nt <= SCAN2_MAX_TILES) { // contig-sized: the apply blocks add up the tile sums before them themselves
@@ -473,21 +476,22 @@ int pjb_create(pjb_ctx **out, const pjb_config *cfg) {
         delete c;
         return fail(nullptr, PJB_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e));
     }
-    (void)hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking);
     (void)hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking);
     (void)hipStreamCreateWithFlags(&c->stream4, hipStreamNonBlocking);
-    (void)hipStreamCreateWithFlags(&c->stream5, hipStreamNonBlocking);
-    (void)hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
-    (void)hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming);
-    (void)hipEventCreateWithFlags(&c->ev_fork2, hipEventDisableTiming);
     (void)hipEventCreateWithFlags(&c->ev_front, hipEventDisableTiming);
-    (void)hipEventCreateWithFlags(&c->ev_join2, hipEventDisableTiming);
+    c->scan_tiles = &c->b_scan_tiles;
     for (int k = 0; k < 2; k++) {
         CtlSlot &S = c->sl[k];
         for (auto &ev : S.ev) (void)hipEventCreate(&ev);
         (void)hipEventCreateWithFlags(&S.ev_rows, hipEventDisableTiming);
         (void)hipEventCreateWithFlags(&S.ev_done, hipEventDisableTiming);
         (void)hipEventCreateWithFlags(&S.ev_k1, hipEventDisableTiming);
+        (void)hipEventCreateWithFlags(&S.ev_fork, hipEventDisableTiming);
+        (void)hipEventCreateWithFlags(&S.ev_join, hipEventDisableTiming);
+        (void)hipEventCreateWithFlags(&S.ev_fork2, hipEventDisableTiming);
+        (void)hipEventCreateWithFlags(&S.ev_join2, hipEventDisableTiming);
+        (void)hipStreamCreateWithFlags(&S.main, hipStreamNonBlocking);
+        (void)hipStreamCreateWithFlags(&S.side, hipStreamNonBlocking);
         c->fl[k].slot = k;
     }
     c->ktime = (cfg->flags & PJB_FLAG_KERNEL_TIMING) != 0;
@@ -528,33 +532,32 @@ void pjb_destroy(pjb_ctx *c) {
         if (S.ev_rows) (void)hipEventDestroy(S.ev_rows);
         if (S.ev_done) (void)hipEventDestroy(S.ev_done);
         Buf *sb[] = {&S.cstats, &S.err, &S.gencount, &S.batches, &S.rows, &S.tile_cnt, &S.tile_stats, &S.splidx, &S.splpoff, &S.okey, &S.g,
-                     &S.lstart, &S.rend, &S.pos, &S.aend, &S.meta, &S.updown, &S.seqw, &S.res};
-        if (S.ev_k1) (void)hipEventDestroy(S.ev_k1);
+                     &S.lstart, &S.rend, &S.pos, &S.aend, &S.meta, &S.updown, &S.seqw, &S.res, &S.total, &S.bitmap, &S.wrank, &S.ends, &S.firstid,
+                     &S.key[0], &S.key[1], &S.idx[0], &S.idx[1], &S.hist, &S.hist_scan, &S.bintotal, &S.scan_tiles, &S.jid, &S.seg, &S.runfirst,
+                     &S.runstart, &S.ent, &S.entsum, &S.frag, &S.fragj, &S.fragl, &S.fragr, &S.acc, &S.ancl, &S.ancr, &S.genlist};
         for (Buf *b : sb) release(*b);
+        hipEvent_t evs[] = {S.ev_k1, S.ev_fork, S.ev_join, S.ev_fork2, S.ev_join2};
+        for (hipEvent_t e : evs)
+            if (e) (void)hipEventDestroy(e);
+        if (S.main) (void)hipStreamDestroy(S.main);
+        if (S.side) (void)hipStreamDestroy(S.side);
     }
     if (c->mirror_hdr) (void)hipHostFree(c->mirror_hdr);
     for (int k = 0; k < 2; k++) {
         if (c->stage[k]) (void)hipHostFree(c->stage[k]);
         if (c->stage_ev[k]) (void)hipEventDestroy(c->stage_ev[k]);
     }
-    Buf *all[] = {&c->b_cursor, &c->b_total, &c->b_bitmap, &c->b_wrank, &c->b_ends, &c->b_firstid, &c->b_key[0],
-                  &c->b_key[1], &c->b_idx[0], &c->b_idx[1], &c->b_hist, &c->b_hist_scan, &c->b_scan_tiles, &c->b_jid, &c->b_seg,
-                  &c->b_runfirst, &c->b_runstart, &c->b_frag, &c->b_fragj, &c->b_fragl, &c->b_fragr, &c->b_acc,
-                  &c->b_ancl, &c->b_ancr, &c->b_hasx, &c->b_ent, &c->b_genlist, &c->b_bintotal, &c->b_inf_comp, &c->b_inf_out, &c->b_inf_blocks, &c->b_inf_status, &c->b_inf_scratch, &c->b_bam_seg, &c->b_bam_rec, &c->b_bam_ctl, &c->b_entsum, &c->f_pos, &c->f_cigoff, &c->f_cigar, &c->f_codes, &c->g_rows, &c->g_models, &c->g_refs, &c->g_out, &c->g_bad,
+    Buf *all[] = {&c->b_cursor, &c->b_scan_tiles, &c->b_hasx, &c->b_xtotal, &c->b_inf_comp, &c->b_inf_out, &c->b_inf_blocks, &c->b_inf_status, &c->b_inf_scratch,
+                  &c->b_bam_seg, &c->b_bam_rec, &c->b_bam_ctl, &c->f_pos, &c->f_cigoff, &c->f_cigar, &c->f_codes, &c->g_rows, &c->g_models, &c->g_refs,
+                  &c->g_out, &c->g_bad,
                   &c->x_pos, &c->x_endx, &c->x_q, &c->x_prefq, &c->x_ce, &c->x_bound, &c->x_de, &c->x_dropped, &c->x_zlist, &c->x_cnt,
                   &c->x_tabk, &c->x_tabc, &c->x_rs, &c->x_re, &c->x_rr};
     for (Buf *b : all) release(*b);
     for (auto &pool : c->pools)
         for (auto &ev : pool.ev) (void)hipEventDestroy(ev);
-    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
-    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
-    if (c->ev_fork2) (void)hipEventDestroy(c->ev_fork2);
     if (c->ev_front) (void)hipEventDestroy(c->ev_front);
-    if (c->ev_join2) (void)hipEventDestroy(c->ev_join2);
-    if (c->stream2) (void)hipStreamDestroy(c->stream2);
     if (c->stream3) (void)hipStreamDestroy(c->stream3);
     if (c->stream4) (void)hipStreamDestroy(c->stream4);
-    if (c->stream5) (void)hipStreamDestroy(c->stream5);
     (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -795,6 +798,7 @@ static int extra_contig(pjb_ctx *c, int32_t tid, std::vector<DevBatch> &batches,
     X.n_rows = J;
     X.n_pairs = P;
     int rc;
+    if ((rc = ensure(c, c->b_xtotal, 8))) return rc;
     if ((rc = ensure(c, c->x_pos, N * 4 + 16))) return rc;
     if ((rc = ensure(c, c->x_endx, N * 4 + 16))) return rc;
     if ((rc = ensure(c, c->x_q, N + 16))) return rc;
@@ -830,8 +834,8 @@ static int extra_contig(pjb_ctx *c, int32_t tid, std::vector<DevBatch> &batches,
     for (auto &b : batches)
         LAUNCH(c, "kx_classify", kx_classify, dim3((unsigned)((b.n + 255) / 256)), dim3(256), b, L, x_pos, x_endx, x_q, ce,
                (int32_t *)X.cover, (u32 *)c->x_zlist.p, X_ZCAP, X.spl_codes, d_cnt);
-    if ((rc = run_scan(c, "kx_ends", ArrU32Fn{ce}, ExclusiveU32Sink{ce}, (u64)L + 2, (u64 *)c->b_total.p))) return rc;
-    if ((rc = run_scan(c, "kx_unspl", ArrU8Fn{x_q}, ExclusiveU32Sink{prefq}, (u64)N + 1, (u64 *)c->b_total.p))) return rc;
+    if ((rc = run_scan(c, "kx_ends", ArrU32Fn{ce}, ExclusiveU32Sink{ce}, (u64)L + 2, (u64 *)c->b_xtotal.p))) return rc;
+    if ((rc = run_scan(c, "kx_unspl", ArrU8Fn{x_q}, ExclusiveU32Sink{prefq}, (u64)N + 1, (u64 *)c->b_xtotal.p))) return rc;
     LAUNCH(c, "kx_cap_bound", kx_cap_bound, dim3((unsigned)((N + 255) / 256)), dim3(256), (const int32_t *)x_pos, (const uint8_t *)x_q,
            (const u32 *)prefq, (const u32 *)ce, (u32)N, L, (u32 *)nullptr, d_cnt);
     u32 n_unspl = 0;
@@ -854,7 +858,7 @@ static int extra_contig(pjb_ctx *c, int32_t tid, std::vector<DevBatch> &batches,
             LAUNCH(c, "kx_undo_dropped", kx_undo_dropped, dim3((unsigned)((b.n + 255) / 256)), dim3(256), b, L,
                    (const uint8_t *)c->x_dropped.p, (int32_t *)X.cover);
     }
-    if ((rc = run_scan(c, "kx_depth", ArrI32Fn{(const int32_t *)X.cover}, InclusiveU32Sink{X.cover}, (u64)L + 1, (u64 *)c->b_total.p)))
+    if ((rc = run_scan(c, "kx_depth", ArrI32Fn{(const int32_t *)X.cover}, InclusiveU32Sink{X.cover}, (u64)L + 1, (u64 *)c->b_xtotal.p)))
         return rc;
     X.has_unspliced = n_unspl > 0;
     X.n_spl = hc.n_spliced;
@@ -865,7 +869,7 @@ static int extra_contig(pjb_ctx *c, int32_t tid, std::vector<DevBatch> &batches,
                (u32)N, (const u32 *)prefq, (const u32 *)ce, L, (const u32 *)c->x_zlist.p, (const ExtraCounters *)d_cnt, X_ZCAP, X.xr);
         if (hipMalloc((void **)&X.pair_code, (size_t)P * 8) != hipSuccess || hipMalloc((void **)&X.pair_row, (size_t)P * 4) != hipSuccess)
             return fail(c, PJB_ERR_NOMEM, "extra: pair codes of target %d", tid);
-        LAUNCH(c, "kx_pair_codes", kx_pair_codes, dim3((P + 255) / 256), dim3(256), sidx, (const u32 *)c->b_jid.p, pair_g,
+        LAUNCH(c, "kx_pair_codes", kx_pair_codes, dim3((P + 255) / 256), dim3(256), sidx, (const u32 *)c->sl[c->cur_slot].jid.p, pair_g,
                (const DevBatch *)c->sl[c->cur_slot].batches.p, (int)batches.size(), P, (u32)row_base, X.pair_code, X.pair_row);
     }
     HIP_TRY(c, hipStreamSynchronize(st));
@@ -900,11 +904,23 @@ static size_t rows_upper_bound(const pjb_ctx *c) {
 
 constexpr unsigned K6_BLOCKS = 128;
 static int queue_contig(pjb_ctx *c, Flight &f, std::vector<DevBatch> &batches) {
-    const hipStream_t st = c->stream;
+    CtlSlot &S = c->sl[f.slot];
+    // the contig's chain runs on its slot's streams, beside the chain of the contig in the other slot; everything the
+    // LAUNCH macro and run_scan do follows c->stream / c->scan_tiles until this function returns
+    const hipStream_t service = c->stream, st = c->side_stream ? S.main : c->stream; // ("overlap" off: everything on one stream)
+    struct ChainScope {
+        pjb_ctx *c;
+        hipStream_t service;
+        ~ChainScope() {
+            c->stream = service;
+            c->scan_tiles = &c->b_scan_tiles;
+        }
+    } chain_scope{c, service};
+    c->stream = st;
+    c->scan_tiles = &S.scan_tiles;
     const int32_t tid = f.tid;
     const u32 n_tiles = f.n_tiles;
     const ContigLimits &lim = f.lim;
-    CtlSlot &S = c->sl[f.slot];
     const int32_t ref_len = c->ref_len[(size_t)tid];
     const Contig &G = c->contigs[(size_t)tid];
     const KeyFmt kf = lim.kf;
@@ -938,35 +954,35 @@ static int queue_contig(pjb_ctx *c, Flight &f, std::vector<DevBatch> &batches) {
     if ((rc = ensure(c, S.tile_stats, (size_t)n_tiles * sizeof(TileStats)))) return rc;
     if ((rc = ensure(c, S.splidx, (size_t)n_tiles * K1_TILE * 4))) return rc;
     if ((rc = ensure(c, S.splpoff, (size_t)n_tiles * K1_TILE * 4))) return rc;
-    if ((rc = ensure(c, c->b_total, 8))) return rc;
+    if ((rc = ensure(c, S.total, 8))) return rc;
     // ---- pair-sized buffers (one sort tile of slack: rs_scatter loads whole tiles unguarded)
     if ((rc = ensure(c, S.okey, ((size_t)PL + RS_TILE) * 8))) return rc; // the pairs' keys as emitted (BAM order): kept, the sort works on copies
-    if ((rc = ensure(c, c->b_key[0], ((size_t)PL + RS_TILE) * 8))) return rc;
-    if ((rc = ensure(c, c->b_key[1], ((size_t)PL + RS_TILE) * 8))) return rc;
-    if ((rc = ensure(c, c->b_idx[0], ((size_t)PL + RS_TILE) * 4))) return rc;
-    if ((rc = ensure(c, c->b_idx[1], ((size_t)PL + RS_TILE) * 4))) return rc;
-    Buf *pb[] = {&S.g, &S.lstart, &S.rend, &S.pos, &S.aend, &S.meta, &S.updown, &c->b_jid};
+    if ((rc = ensure(c, S.key[0], ((size_t)PL + RS_TILE) * 8))) return rc;
+    if ((rc = ensure(c, S.key[1], ((size_t)PL + RS_TILE) * 8))) return rc;
+    if ((rc = ensure(c, S.idx[0], ((size_t)PL + RS_TILE) * 4))) return rc;
+    if ((rc = ensure(c, S.idx[1], ((size_t)PL + RS_TILE) * 4))) return rc;
+    Buf *pb[] = {&S.g, &S.lstart, &S.rend, &S.pos, &S.aend, &S.meta, &S.updown, &S.jid};
     for (Buf *b : pb)
         if ((rc = ensure(c, *b, (size_t)PL * 4 + 16))) return rc;
     if ((rc = ensure(c, S.res, (size_t)PL * 8 + 16))) return rc;
     if ((rc = ensure(c, S.seqw, (size_t)PL * 8 + 16))) return rc;
-    if ((rc = ensure(c, c->b_seg, ((size_t)PL + 1) * 4))) return rc;
-    if ((rc = ensure(c, c->b_runfirst, ((size_t)PL + 1) * 4))) return rc;
-    if ((rc = ensure(c, c->b_runstart, ((size_t)PL + 1) * 4))) return rc;
-    if ((rc = ensure(c, c->b_ent, (size_t)PL * 8 + 16))) return rc;
+    if ((rc = ensure(c, S.seg, ((size_t)PL + 1) * 4))) return rc;
+    if ((rc = ensure(c, S.runfirst, ((size_t)PL + 1) * 4))) return rc;
+    if ((rc = ensure(c, S.runstart, ((size_t)PL + 1) * 4))) return rc;
+    if ((rc = ensure(c, S.ent, (size_t)PL * 8 + 16))) return rc;
     const u32 pair_blocks = std::max<u32>(1, (PL + 255) / 256);
     const u32 gen_cap = ((pair_blocks + GEN_SHARDS - 1) / GEN_SHARDS) * 256; // entries per sub-list
-    if ((rc = ensure(c, c->b_genlist, (size_t)gen_cap * GEN_SHARDS * 4))) return rc;
+    if ((rc = ensure(c, S.genlist, (size_t)gen_cap * GEN_SHARDS * 4))) return rc;
     if ((rc = ensure(c, S.gencount, GEN_SHARDS * 4))) return rc;
     // ---- junction-sized buffers
     const u32 slots_lim = JL + (PL + 63) / 64 + 1;
-    if ((rc = ensure(c, c->b_frag, (size_t)slots_lim * F_WORDS * 4))) return rc;
-    if ((rc = ensure(c, c->b_fragj, (size_t)slots_lim * 4))) return rc;
-    if ((rc = ensure(c, c->b_fragl, (size_t)slots_lim * 4))) return rc;
-    if ((rc = ensure(c, c->b_fragr, (size_t)slots_lim * 4))) return rc;
-    if ((rc = ensure(c, c->b_acc, (size_t)JL * F_WORDS * 4 + 16))) return rc;
-    if ((rc = ensure(c, c->b_ancl, (size_t)JL * 4 + 16))) return rc;
-    if ((rc = ensure(c, c->b_ancr, (size_t)JL * 4 + 16))) return rc;
+    if ((rc = ensure(c, S.frag, (size_t)slots_lim * F_WORDS * 4))) return rc;
+    if ((rc = ensure(c, S.fragj, (size_t)slots_lim * 4))) return rc;
+    if ((rc = ensure(c, S.fragl, (size_t)slots_lim * 4))) return rc;
+    if ((rc = ensure(c, S.fragr, (size_t)slots_lim * 4))) return rc;
+    if ((rc = ensure(c, S.acc, (size_t)JL * F_WORDS * 4 + 16))) return rc;
+    if ((rc = ensure(c, S.ancl, (size_t)JL * 4 + 16))) return rc;
+    if ((rc = ensure(c, S.ancr, (size_t)JL * 4 + 16))) return rc;
     if ((rc = ensure(c, S.rows, (size_t)JL * sizeof(pjb_junction_row) + 16))) return rc;
     // The row table lives twice, both grow-only: in HBM, where the rows stream appends each contig's rows (k6_rows_out),
     // and in page-locked host memory, filled by a DMA per contig once its row count is known (pjb_finish_contig_end).
@@ -1004,24 +1020,15 @@ static int queue_contig(pjb_ctx *c, Flight &f, std::vector<DevBatch> &batches) {
         S.pub_dev = (uint8_t *)dp;
     }
 
-    // ---- the contig's first kernels (count, tile scan, emit) go on the FRONT stream: they touch the records and this
-    // slot's arrays only, so they run beside the previous contig's last kernels (anchors, generic pairs, fragments:
-    // latency-bound, most of the chip idle).  The main stream picks up behind them (ev_k1) and behind the previous
-    // contig's chain (stream order).
-    const hipStream_t front = c->side_stream ? c->stream5 : st;
-    struct StreamScope {
-        pjb_ctx *c;
-        hipStream_t main;
-        ~StreamScope() { c->stream = main; }
-    } front_scope{c, st};
-    if (front != st) {
+    // (records still being produced on the service stream -- host copies, BAM ingest -- come first)
+    const hipStream_t front = st;
+    {
         auto oit = c->open.find(tid);
-        if (oit != c->open.end() && oit->second.on_main_stream) { // records still being produced on the main stream
-            HIP_TRY(c, hipEventRecord(c->ev_front, st));
-            HIP_TRY(c, hipStreamWaitEvent(front, c->ev_front, 0));
+        if (st != service && oit != c->open.end() && oit->second.on_main_stream) {
+            HIP_TRY(c, hipEventRecord(c->ev_front, service));
+            HIP_TRY(c, hipStreamWaitEvent(st, c->ev_front, 0));
         }
     }
-    c->stream = front; // LAUNCH (and its event bracket) follow c->stream
     HIP_TRY(c, hipMemcpyAsync(S.batches.p, S.batches_pinned, batches.size() * sizeof(DevBatch), hipMemcpyHostToDevice, front));
     if (!S.at_rest) {
         HIP_TRY(c, hipMemsetAsync(S.err.p, 0xff, 8, front));
@@ -1070,54 +1077,50 @@ static int queue_contig(pjb_ctx *c, Flight &f, std::vector<DevBatch> &batches) {
     if (fast_codes && !c->side_stream) { // (PJB_SIDE_STREAM=0: one kernel at a time, for clean per-kernel timings)
         LAUNCH(c, "k4a_simple", k4a_simple, dim3(pair_blocks), dim3(256), pr, kf, (const u32 *)G.codes, (int32_t)G.len, d_P, (u64 *)S.res.p);
     } else if (fast_codes) {
-        HIP_TRY(c, hipEventRecord(c->ev_fork, front));
-        HIP_TRY(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
-        c->stream = c->stream2;
+        HIP_TRY(c, hipEventRecord(S.ev_fork, front));
+        HIP_TRY(c, hipStreamWaitEvent(S.side, S.ev_fork, 0));
+        c->stream = S.side;
         f.forked = true;
         LAUNCH(c, "k4a_simple", k4a_simple, dim3(pair_blocks), dim3(256), pr, kf, (const u32 *)G.codes, (int32_t)G.len, d_P, (u64 *)S.res.p);
-        HIP_TRY(c, hipEventRecord(c->ev_join, c->stream2));
+        HIP_TRY(c, hipEventRecord(S.ev_join, S.side));
     }
     c->stream = st;
-    if (front != st) {
-        HIP_TRY(c, hipEventRecord(S.ev_k1, front));
-        HIP_TRY(c, hipStreamWaitEvent(st, S.ev_k1, 0));
-    }
     STAGE_EVENT(1);
 
     // ---- K2d: ordered dense junction ids (the sort then works on 15-19 bits instead of 46-48)
     int sort_bits = kf.total_bits;
     if (lim.dense) {
         const size_t n_words = ((size_t)std::max(ref_len, 1) + 63) / 64;
-        const void *was[2] = {c->b_bitmap.p, c->b_ends.p};
-        if ((rc = ensure(c, c->b_bitmap, n_words * 8 + 16))) return rc;
-        if ((rc = ensure(c, c->b_wrank, n_words * 4 + 16))) return rc;
-        if ((rc = ensure(c, c->b_ends, (size_t)JL * DENSE_ENDS * 4 + 32))) return rc;
-        if ((rc = ensure(c, c->b_firstid, (size_t)JL * 4 + 16))) return rc;
-        if (!c->dense_at_rest || was[0] != c->b_bitmap.p || was[1] != c->b_ends.p) { // (first use, new memory, or a chain that broke off)
-            HIP_TRY(c, hipMemsetAsync(c->b_bitmap.p, 0, c->b_bitmap.cap, st));
-            HIP_TRY(c, hipMemsetAsync(c->b_ends.p, 0xff, c->b_ends.cap, st));
+        const void *was[2] = {S.bitmap.p, S.ends.p};
+        if ((rc = ensure(c, S.bitmap, n_words * 8 + 16))) return rc;
+        if ((rc = ensure(c, S.wrank, n_words * 4 + 16))) return rc;
+        if ((rc = ensure(c, S.ends, (size_t)JL * DENSE_ENDS * 4 + 32))) return rc;
+        if ((rc = ensure(c, S.firstid, (size_t)JL * 4 + 16))) return rc;
+        if (!S.dense_at_rest || was[0] != S.bitmap.p || was[1] != S.ends.p) { // (first use, new memory, or a chain that broke off)
+            HIP_TRY(c, hipMemsetAsync(S.bitmap.p, 0, S.bitmap.cap, st));
+            HIP_TRY(c, hipMemsetAsync(S.ends.p, 0xff, S.ends.cap, st));
         }
-        c->dense_at_rest = false; // until kd_reset is queued
+        S.dense_at_rest = false; // until kd_reset is queued
         const u64 *okey = (const u64 *)pr.key;
         const u32 kd_tiles = std::max<u32>(1, (PL + KD_TILE - 1) / KD_TILE);
-        u64 *cand = (u64 *)c->b_key[1].p; // (free until the first scatter; the candidates are used up before it)
+        u64 *cand = (u64 *)S.key[1].p; // (free until the first scatter; the candidates are used up before it)
         LAUNCH(c, "kd_unique", kd_unique, dim3(kd_tiles), dim3(256), okey, d_P, cand, d_cs);
-        LAUNCH(c, "kd_mark", kd_mark, dim3(pair_blocks), dim3(256), (const u64 *)cand, (const ContigStats *)d_cs, kf, (u64 *)c->b_bitmap.p);
-        if ((rc = run_scan(c, "kd_rank", PopcFn{(const u64 *)c->b_bitmap.p}, ExclusiveU32Sink{(u32 *)c->b_wrank.p}, (u64)n_words,
-                           (u64 *)c->b_total.p)))
+        LAUNCH(c, "kd_mark", kd_mark, dim3(pair_blocks), dim3(256), (const u64 *)cand, (const ContigStats *)d_cs, kf, (u64 *)S.bitmap.p);
+        if ((rc = run_scan(c, "kd_rank", PopcFn{(const u64 *)S.bitmap.p}, ExclusiveU32Sink{(u32 *)S.wrank.p}, (u64)n_words,
+                           (u64 *)S.total.p)))
             return rc;
-        u32 *cand_rank = (u32 *)c->b_idx[1].p; // (free until the first scatter as well)
-        LAUNCH(c, "kd_ends", kd_ends, dim3(pair_blocks), dim3(256), (const u64 *)cand, kf, (const u64 *)c->b_bitmap.p, (const u32 *)c->b_wrank.p, JL,
-               (u32 *)c->b_ends.p, cand_rank, d_cs);
-        if ((rc = run_scan(c, "kd_first", EndsCountFn{(const u32 *)c->b_ends.p}, ExclusiveU32Sink{(u32 *)c->b_firstid.p}, (u64)JL,
-                           (u64 *)c->b_total.p)))
+        u32 *cand_rank = (u32 *)S.idx[1].p; // (free until the first scatter as well)
+        LAUNCH(c, "kd_ends", kd_ends, dim3(pair_blocks), dim3(256), (const u64 *)cand, kf, (const u64 *)S.bitmap.p, (const u32 *)S.wrank.p, JL,
+               (u32 *)S.ends.p, cand_rank, d_cs);
+        if ((rc = run_scan(c, "kd_first", EndsCountFn{(const u32 *)S.ends.p}, ExclusiveU32Sink{(u32 *)S.firstid.p}, (u64)JL,
+                           (u64 *)S.total.p)))
             return rc;
         LAUNCH(c, "kd_close", kd_close, dim3(1), dim3(1), d_cs);
-        LAUNCH(c, "kd_assign", kd_assign, dim3(pair_blocks), dim3(256), okey, d_P, kf, (const u64 *)c->b_bitmap.p, (const u32 *)c->b_wrank.p,
-               (const u32 *)c->b_ends.p, (const u32 *)c->b_firstid.p, (u64 *)c->b_key[0].p);
+        LAUNCH(c, "kd_assign", kd_assign, dim3(pair_blocks), dim3(256), okey, d_P, kf, (const u64 *)S.bitmap.p, (const u32 *)S.wrank.p,
+               (const u32 *)S.ends.p, (const u32 *)S.firstid.p, (u64 *)S.key[0].p);
         LAUNCH(c, "kd_reset", kd_reset, dim3(pair_blocks), dim3(256), (const u64 *)cand, (const u32 *)cand_rank, kf, JL, (const ContigStats *)d_cs,
-               (u64 *)c->b_bitmap.p, (u32 *)c->b_ends.p);
-        c->dense_at_rest = true;
+               (u64 *)S.bitmap.p, (u32 *)S.ends.p);
+        S.dense_at_rest = true;
         sort_bits = std::max(1, bits_of((uint64_t)JL));
     }
     // ---- K2: radix sort (key, pair index); digits: as few passes as the widest digit allows, bits spread evenly
@@ -1127,23 +1130,23 @@ static int queue_contig(pjb_ctx *c, Flight &f, std::vector<DevBatch> &batches) {
     std::vector<int> pass_bits((size_t)n_pass, sort_bits / n_pass);
     for (int p = 0; p < sort_bits % n_pass; p++) pass_bits[(size_t)p]++;
     const int dbits = pass_bits[0];
-    if ((rc = ensure(c, c->b_hist, (size_t)rs_tiles * (1u << dbits) * 4))) return rc;
-    if ((rc = ensure(c, c->b_hist_scan, (size_t)rs_tiles * (1u << dbits) * 4))) return rc;
-    if ((rc = ensure(c, c->b_bintotal, (size_t)4 << dbits))) return rc;
+    if ((rc = ensure(c, S.hist, (size_t)rs_tiles * (1u << dbits) * 4))) return rc;
+    if ((rc = ensure(c, S.hist_scan, (size_t)rs_tiles * (1u << dbits) * 4))) return rc;
+    if ((rc = ensure(c, S.bintotal, (size_t)4 << dbits))) return rc;
     int cur = 0, shift = 0;
     for (int p = 0; p < n_pass; p++) {
         const int bits = pass_bits[(size_t)p];
         if (bits <= 0) break;
-        const u64 *kin = p == 0 && !lim.dense ? (const u64 *)S.okey.p : (const u64 *)c->b_key[cur].p; // (dense ids were written to b_key[0])
-        u64 *kout = (u64 *)c->b_key[cur ^ 1].p;
-        const u32 *vin = p == 0 ? nullptr : (const u32 *)c->b_idx[cur].p;
-        u32 *vout = (u32 *)c->b_idx[cur ^ 1].p;
-        LAUNCH(c, "rs_hist", rs_hist, dim3(rs_tiles), dim3(256), kin, d_P, shift, bits, (u32 *)c->b_hist.p, rs_tiles);
-        LAUNCH(c, "rs_rowscan", rs_rowscan, dim3(1u << bits), dim3(256), (const u32 *)c->b_hist.p, rs_tiles,
-               (u32 *)c->b_hist_scan.p, (u32 *)c->b_bintotal.p);
+        const u64 *kin = p == 0 && !lim.dense ? (const u64 *)S.okey.p : (const u64 *)S.key[cur].p; // (dense ids were written to b_key[0])
+        u64 *kout = (u64 *)S.key[cur ^ 1].p;
+        const u32 *vin = p == 0 ? nullptr : (const u32 *)S.idx[cur].p;
+        u32 *vout = (u32 *)S.idx[cur ^ 1].p;
+        LAUNCH(c, "rs_hist", rs_hist, dim3(rs_tiles), dim3(256), kin, d_P, shift, bits, (u32 *)S.hist.p, rs_tiles);
+        LAUNCH(c, "rs_rowscan", rs_rowscan, dim3(1u << bits), dim3(256), (const u32 *)S.hist.p, rs_tiles,
+               (u32 *)S.hist_scan.p, (u32 *)S.bintotal.p);
 #define RS_SCATTER(B)                                                                                                     \
     LAUNCH_LDS(c, "rs_scatter", rs_scatter<B>, dim3(rs_tiles), dim3(256), rs_scatter_lds_bytes(bits), kin, vin, kout, vout, d_P, \
-               shift, bits, (const u32 *)c->b_hist_scan.p, (const u32 *)c->b_bintotal.p, rs_tiles)
+               shift, bits, (const u32 *)S.hist_scan.p, (const u32 *)S.bintotal.p, rs_tiles)
         switch (bits) { // the usual digit widths get an unrolled match loop
         case 9: RS_SCATTER(9); break;
         case 10: RS_SCATTER(10); break;
@@ -1155,24 +1158,24 @@ static int queue_contig(pjb_ctx *c, Flight &f, std::vector<DevBatch> &batches) {
         shift += bits;
     }
     f.n_pass = n_pass;
-    const u64 *skey = (const u64 *)c->b_key[cur].p;
-    const u32 *sidx = (const u32 *)c->b_idx[cur].p;
+    const u64 *skey = (const u64 *)S.key[cur].p;
+    const u32 *sidx = (const u32 *)S.idx[cur].p;
     f.sidx = sidx;
     STAGE_EVENT(2);
 
     // ---- K2s: junction ids, position runs
     {
         HeadFn hf{skey, sidx, pr.pos};
-        HeadSink hs{(u32 *)c->b_jid.p, (u32 *)c->b_seg.p, (u32 *)c->b_runfirst.p, (u32 *)c->b_runstart.p};
-        if ((rc = run_scan(c, "k2_heads", hf, hs, (u64)PL, (u64 *)c->b_total.p, d_P))) return rc;
-        LAUNCH(c, "k2_close", k2_close, dim3(1), dim3(1), (u64 *)c->b_total.p, (u32 *)c->b_seg.p, (u32 *)c->b_runfirst.p,
-               (u32 *)c->b_runstart.p, d_cs, JL);
+        HeadSink hs{(u32 *)S.jid.p, (u32 *)S.seg.p, (u32 *)S.runfirst.p, (u32 *)S.runstart.p};
+        if ((rc = run_scan(c, "k2_heads", hf, hs, (u64)PL, (u64 *)S.total.p, d_P))) return rc;
+        LAUNCH(c, "k2_close", k2_close, dim3(1), dim3(1), (u64 *)S.total.p, (u32 *)S.seg.p, (u32 *)S.runfirst.p,
+               (u32 *)S.runstart.p, d_cs, JL);
     }
     STAGE_EVENT(3);
 
     // ---- entropy terms and sums need the position runs only: on the side stream, beside the anchors and the generic
     // pairs (a chain of small and latency-bound kernels that leaves most of the chip idle)
-    if ((rc = ensure(c, c->b_entsum, (size_t)JL * 8 + 16))) return rc;
+    if ((rc = ensure(c, S.entsum, (size_t)JL * 8 + 16))) return rc;
     bool entropy_forked = false;
     {
         hipStream_t main_stream = c->stream;
@@ -1182,50 +1185,50 @@ static int queue_contig(pjb_ctx *c, Flight &f, std::vector<DevBatch> &batches) {
             ~StreamScope() { c->stream = main; }
         } scope{c, main_stream};
         if (c->side_stream) {
-            HIP_TRY(c, hipEventRecord(c->ev_fork2, st));
-            HIP_TRY(c, hipStreamWaitEvent(c->stream2, c->ev_fork2, 0));
-            c->stream = c->stream2;
+            HIP_TRY(c, hipEventRecord(S.ev_fork2, st));
+            HIP_TRY(c, hipStreamWaitEvent(S.side, S.ev_fork2, 0));
+            c->stream = S.side;
             entropy_forked = true;
         }
-        LAUNCH(c, "k5_entropy_terms", k5_entropy_terms, dim3(pair_blocks), dim3(256), (const u32 *)c->b_jid.p,
-               (const u32 *)c->b_seg.p, (const u32 *)c->b_runfirst.p, (const u32 *)c->b_runstart.p, d_R, (double *)c->b_ent.p);
-        LAUNCH(c, "k5_entropy_sum", k5_entropy_sum, dim3(std::max<u32>(1, (JL + 3) / 4)), dim3(256), (const u32 *)c->b_runfirst.p,
-               (const double *)c->b_ent.p, d_J, (double *)c->b_entsum.p);
-        if (entropy_forked) HIP_TRY(c, hipEventRecord(c->ev_join2, c->stream2));
+        LAUNCH(c, "k5_entropy_terms", k5_entropy_terms, dim3(pair_blocks), dim3(256), (const u32 *)S.jid.p,
+               (const u32 *)S.seg.p, (const u32 *)S.runfirst.p, (const u32 *)S.runstart.p, d_R, (double *)S.ent.p);
+        LAUNCH(c, "k5_entropy_sum", k5_entropy_sum, dim3(std::max<u32>(1, (JL + 3) / 4)), dim3(256), (const u32 *)S.runfirst.p,
+               (const double *)S.ent.p, d_J, (double *)S.entsum.p);
+        if (entropy_forked) HIP_TRY(c, hipEventRecord(S.ev_join2, S.side));
     }
     // ---- K3: anchors
     const u32 slot_blocks = (slots_lim + 255) / 256;
     const u32 init_n = std::max<u32>(slots_lim, JL * F_WORDS);
-    LAUNCH(c, "k5_init_acc", k5_init_acc, dim3((init_n + 255) / 256), dim3(256), (u32 *)c->b_acc.p, d_J, (int32_t *)c->b_ancl.p,
-           (int32_t *)c->b_ancr.p, (int32_t *)c->b_fragj.p, d_slots);
-    LAUNCH(c, "k3_anchors_frag", k3_anchors_frag, dim3(pair_blocks), dim3(256), sidx, (const u32 *)c->b_jid.p,
+    LAUNCH(c, "k5_init_acc", k5_init_acc, dim3((init_n + 255) / 256), dim3(256), (u32 *)S.acc.p, d_J, (int32_t *)S.ancl.p,
+           (int32_t *)S.ancr.p, (int32_t *)S.fragj.p, d_slots);
+    LAUNCH(c, "k3_anchors_frag", k3_anchors_frag, dim3(pair_blocks), dim3(256), sidx, (const u32 *)S.jid.p,
            (const int32_t *)pr.lstart, (const int32_t *)pr.rend, (const u32 *)pr.meta, fast_codes ? 0 : 1, d_P,
-           (int32_t *)c->b_fragl.p, (int32_t *)c->b_fragr.p, (int32_t *)c->b_fragj.p, (u32 *)c->b_genlist.p,
+           (int32_t *)S.fragl.p, (int32_t *)S.fragr.p, (int32_t *)S.fragj.p, (u32 *)S.genlist.p,
            (u32 *)S.gencount.p);
-    LAUNCH(c, "k3_anchors_junc", k3_anchors_junc, dim3(slot_blocks), dim3(256), (const int32_t *)c->b_fragl.p,
-           (const int32_t *)c->b_fragr.p, (const int32_t *)c->b_fragj.p, d_slots, (int32_t *)c->b_ancl.p,
-           (int32_t *)c->b_ancr.p);
+    LAUNCH(c, "k3_anchors_junc", k3_anchors_junc, dim3(slot_blocks), dim3(256), (const int32_t *)S.fragl.p,
+           (const int32_t *)S.fragr.p, (const int32_t *)S.fragj.p, d_slots, (int32_t *)S.ancl.p,
+           (int32_t *)S.ancr.p);
     STAGE_EVENT(4);
 
-    if (f.forked) HIP_TRY(c, hipStreamWaitEvent(st, c->ev_join, 0)); // k4a_simple's results (side stream) are needed from here on
+    if (f.forked) HIP_TRY(c, hipStreamWaitEvent(st, S.ev_join, 0)); // k4a_simple's results (side stream) are needed from here on
     // ---- K4b: the pairs that need the generic walks (list length lives on the device; the grid covers the
     // worst case and surplus blocks exit at once), then K4: gather + segmented reduce -> fragments
-    LAUNCH(c, "k4b_generic", k4b_generic, dim3((gen_cap * GEN_SHARDS + 255) / 256), dim3(256), (const u32 *)c->b_genlist.p,
-           (const u32 *)S.gencount.p, pair_blocks, skey, sidx, (const u32 *)c->b_jid.p, pr, kf, (const DevBatch *)S.batches.p,
-           (int)batches.size(), (const int32_t *)c->b_ancl.p, (const int32_t *)c->b_ancr.p, (const uint8_t *)G.d,
+    LAUNCH(c, "k4b_generic", k4b_generic, dim3((gen_cap * GEN_SHARDS + 255) / 256), dim3(256), (const u32 *)S.genlist.p,
+           (const u32 *)S.gencount.p, pair_blocks, skey, sidx, (const u32 *)S.jid.p, pr, kf, (const DevBatch *)S.batches.p,
+           (int)batches.size(), (const int32_t *)S.ancl.p, (const int32_t *)S.ancr.p, (const uint8_t *)G.d,
            (int32_t)G.len, G.has_x ? 1 : 0, (const u32 *)(G.has_x ? nullptr : G.codes), (u64 *)S.res.p, d_err);
-    LAUNCH(c, "k4_pairs", k4_pairs, dim3(pair_blocks), dim3(256), skey, sidx, (const u32 *)c->b_jid.p, pr, kf,
-           (const u64 *)S.res.p, d_P, (u32 *)c->b_frag.p, (int32_t *)c->b_fragj.p);
+    LAUNCH(c, "k4_pairs", k4_pairs, dim3(pair_blocks), dim3(256), skey, sidx, (const u32 *)S.jid.p, pr, kf,
+           (const u64 *)S.res.p, d_P, (u32 *)S.frag.p, (int32_t *)S.fragj.p);
     STAGE_EVENT(5);
 
     // ---- K5: fragments -> junctions -> rows
     LAUNCH(c, "k5_frag_reduce", k5_frag_reduce, dim3((slots_lim + 4 * FRAG_SLOTS_PER_WAVE - 1) / (4 * FRAG_SLOTS_PER_WAVE)), dim3(256),
-           (const u32 *)c->b_frag.p, (const int32_t *)c->b_fragj.p, d_slots, (u32 *)c->b_acc.p);
-    if (entropy_forked) HIP_TRY(c, hipStreamWaitEvent(st, c->ev_join2, 0));
-    LAUNCH(c, "k5_finalize", k5_finalize, dim3(std::max<u32>(1, (JL + 255) / 256)), dim3(256), (const u64 *)pr.key, sidx, (const u32 *)c->b_seg.p,
-           (const u32 *)c->b_runfirst.p, (const u32 *)c->b_runstart.p, (const u32 *)c->b_acc.p,
-           (const int32_t *)c->b_ancl.p, (const int32_t *)c->b_ancr.p, kf, (const uint8_t *)G.d, (int32_t)G.len, tid, d_J,
-           (const double *)c->b_entsum.p, (pjb_junction_row *)S.rows.p, d_err);
+           (const u32 *)S.frag.p, (const int32_t *)S.fragj.p, d_slots, (u32 *)S.acc.p);
+    if (entropy_forked) HIP_TRY(c, hipStreamWaitEvent(st, S.ev_join2, 0));
+    LAUNCH(c, "k5_finalize", k5_finalize, dim3(std::max<u32>(1, (JL + 255) / 256)), dim3(256), (const u64 *)pr.key, sidx, (const u32 *)S.seg.p,
+           (const u32 *)S.runfirst.p, (const u32 *)S.runstart.p, (const u32 *)S.acc.p,
+           (const int32_t *)S.ancl.p, (const int32_t *)S.ancr.p, kf, (const uint8_t *)G.d, (int32_t)G.len, tid, d_J,
+           (const double *)S.entsum.p, (pjb_junction_row *)S.rows.p, d_err);
     STAGE_EVENT(6);
 
     // ---- rows to the host (and into the caller's exchange slot), control block last: on the rows stream, so that the
@@ -1273,7 +1276,7 @@ static void unqueue_followers(pjb_ctx *c) {
         Flight &g = c->fl[k];
         if (!g.queued) continue;
         wait_flight(c, g);
-        if (g.forked) (void)hipStreamSynchronize(c->stream2);
+        if (g.forked) (void)hipStreamSynchronize(c->sl[g.slot].side);
         g.queued = false;
         g.forked = false;
         ev_drop(c, g.slot);
@@ -1420,7 +1423,7 @@ int pjb_finish_contig_end(pjb_ctx *c, int32_t tid, pjb_region_result *res) {
         // a limit was too small: the control block says by how much; everything is queued again (and so is the contig
         // queued behind this one: its rows went where this one's belong)
         unqueue_followers(c);
-        if (f.forked) (void)hipStreamSynchronize(c->stream2);
+        if (f.forked) (void)hipStreamSynchronize(c->sl[f.slot].side);
         f.queued = f.forked = false;
         if (cs.overflow & OVF_PAIRS) {
             if (cs.n_pairs >= 0xfffffff0ull) return fail(c, PJB_ERR_ARG, "finish: more than 2^32 spliced pairs on one target are not supported");
