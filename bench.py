@@ -116,6 +116,8 @@ def main():
     ap.add_argument("--reads", type=int, default=int(os.environ.get("PJB_BENCH_READS", 200_000_000)),
                     help="total reads of the 25-contig set (200 M = BASELINE configs[2]; smaller values are for tests)")
     ap.add_argument("--junctions", type=int, default=int(os.environ.get("PJB_BENCH_JUNCTIONS", 250_000)))
+    ap.add_argument("--queue", type=int, default=int(os.environ.get("PJB_BENCH_QUEUE", 3)),
+                    help="contigs queued at once (pjb_finish_contig_begin / _end; at most PJB_MAX_QUEUED = 4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", default=os.environ.get("PJB_BENCH_E2E", "1") == "0")
     ap.add_argument("--e2e-workdir", default=os.environ.get("PJB_BENCH_WORKDIR", "/tmp/pjb_bench_e2e"))
@@ -196,20 +198,23 @@ def main():
         if xchg is not None:
             ctx.set_row_mirror(*xchg.slot_for_next_finish())  # every finish appends header + rows to the exchange slot
         regs = {}
-        prev = None  # two contigs queued: the device never waits for the host between contigs
+        queued = []  # several contigs queued: their kernel chains run side by side, the device never waits for the host
+
+        def collect_oldest():
+            t = queued.pop(0)
+            regs[t] = ctx.finish_contig_end(t)
+            if state.get("want_timing"):
+                state.setdefault("per_contig", {})[t] = ctx.timing()
+
         for tid in mine:
             c = contigs[tid]
             ctx.submit_batch_device(tid, c["batch"], c["n"])
             ctx.finish_contig_begin(tid)
-            if prev is not None:
-                regs[prev] = ctx.finish_contig_end(prev)
-                if state.get("want_timing"):
-                    state.setdefault("per_contig", {})[prev] = ctx.timing()
-            prev = tid
-        if prev is not None:
-            regs[prev] = ctx.finish_contig_end(prev)
-            if state.get("want_timing"):
-                state.setdefault("per_contig", {})[prev] = ctx.timing()
+            queued.append(tid)
+            if len(queued) >= args.queue:
+                collect_oldest()
+        while queued:
+            collect_oldest()
         if not mine:
             ctx.finish_contig(0)  # a rank without contigs still publishes an (empty) header
         rows = ctx.collect(copy=False)  # view of the pinned row table
@@ -406,7 +411,7 @@ def main():
                        "reads_total": N_total, "junctions_total": J_total, "contigs": len(cfgs),
                        "contigs_per_rank": [len(s) for s in shards], "reads_rank0": N_mine, "pairs_rank0": P_mine,
                        "sharding": "by contig", "input": "device-resident SoA records (pjb_submit_batch_device)",
-                       "queue": "two contigs queued (pjb_finish_contig_begin / _end), kernels on five HIP streams",
+                       "queue": f"{args.queue} contigs queued (pjb_finish_contig_begin / _end), their kernel chains side by side on the device",
                        "hbm_resident_gb_rank0": round(hbm_gb, 2)},
             "junctions_per_sec": J_total * args.steps / elapsed,
             "roofline": roofline,

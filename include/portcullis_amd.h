@@ -216,11 +216,12 @@ int pjb_finish_contig(pjb_ctx *ctx, int32_t tid, pjb_region_result *result);
  * same effect from its thread pool: one findJuncs per target in flight per thread, src/junction_builder.cc:215-247).
  * _begin queues the whole kernel chain of the contig and returns without waiting; _end waits for the contig's rows
  * and control block, repeats the contig if a limit it was queued with turned out too small, and closes it --
- * pjb_finish_contig is _begin followed by _end.  Up to TWO contigs may be queued; they are collected in the order
- * they were queued and their rows land in that order.  Between the two calls the contig's batches (and device
+ * pjb_finish_contig is _begin followed by _end.  Up to PJB_MAX_QUEUED contigs may be queued -- their kernel chains
+ * run side by side on the device --; they are collected in the order they were queued and their rows land in that order.  Between the two calls the contig's batches (and device
  * arrays lent by pjb_submit_batch_device) must stay as they are; batches for OTHER targets may be submitted, genomes
  * uploaded.  pjb_collect covers collected contigs only; pjb_clear_rows / pjb_set_row_mirror need an empty queue.
  * With PJB_FLAG_EXTRA one contig is queued at a time. */
+#define PJB_MAX_QUEUED 4
 int pjb_finish_contig_begin(pjb_ctx *ctx, int32_t tid);
 int pjb_finish_contig_end(pjb_ctx *ctx, int32_t tid, pjb_region_result *result);
 

@@ -111,7 +111,7 @@ struct EvPool {
     size_t used = 0;
     std::vector<int> name; // kernel-name index per event pair
 };
-constexpr int MISC_POOL = 2;
+constexpr int MISC_POOL = PJB_MAX_QUEUED;
 
 // a contig between pjb_finish_contig_begin and pjb_finish_contig_end
 struct Flight {
@@ -136,11 +136,12 @@ struct pjb_ctx {
     hipStream_t stream3 = nullptr; // rows stream: k6_rows_out + k7_publish of a contig, beside the next contig's first kernels
     hipStream_t stream4 = nullptr; // header of the row mirror
     hipEvent_t ev_front = nullptr; // service stream -> chain stream
-    CtlSlot sl[2];
-    Flight fl[2]; // FIFO: fl[0] is the oldest
+    CtlSlot sl[PJB_MAX_QUEUED];
+    bool slot_busy[PJB_MAX_QUEUED] = {};
+    Flight fl[PJB_MAX_QUEUED]; // FIFO: fl[0] is the oldest
     int n_fl = 0;
     int cur_slot = 0; // slot of the contig being queued / collected (extra)
-    EvPool pools[3];
+    EvPool pools[PJB_MAX_QUEUED + 1];
     int cur_pool = MISC_POOL;
     Buf b_cursor;     // RowCursor
     std::string err;
@@ -480,7 +481,7 @@ int pjb_create(pjb_ctx **out, const pjb_config *cfg) {
     (void)hipStreamCreateWithFlags(&c->stream4, hipStreamNonBlocking);
     (void)hipEventCreateWithFlags(&c->ev_front, hipEventDisableTiming);
     c->scan_tiles = &c->b_scan_tiles;
-    for (int k = 0; k < 2; k++) {
+    for (int k = 0; k < PJB_MAX_QUEUED; k++) {
         CtlSlot &S = c->sl[k];
         for (auto &ev : S.ev) (void)hipEventCreate(&ev);
         (void)hipEventCreateWithFlags(&S.ev_rows, hipEventDisableTiming);
@@ -492,7 +493,6 @@ int pjb_create(pjb_ctx **out, const pjb_config *cfg) {
         (void)hipEventCreateWithFlags(&S.ev_join2, hipEventDisableTiming);
         (void)hipStreamCreateWithFlags(&S.main, hipStreamNonBlocking);
         (void)hipStreamCreateWithFlags(&S.side, hipStreamNonBlocking);
-        c->fl[k].slot = k;
     }
     c->ktime = (cfg->flags & PJB_FLAG_KERNEL_TIMING) != 0;
     c->extra = (cfg->flags & PJB_FLAG_EXTRA) != 0;
@@ -524,7 +524,7 @@ void pjb_destroy(pjb_ctx *c) {
         if (sl.p) (void)hipFree(sl.p);
     if (c->rows_pinned) (void)hipHostFree(c->rows_pinned);
     if (c->rows_table) (void)hipFree(c->rows_table);
-    for (int k = 0; k < 2; k++) {
+    for (int k = 0; k < PJB_MAX_QUEUED; k++) {
         CtlSlot &S = c->sl[k];
         if (S.pub) (void)hipHostFree(S.pub);
         if (S.batches_pinned) (void)hipHostFree(S.batches_pinned);
@@ -1285,12 +1285,10 @@ static void unqueue_followers(pjb_ctx *c) {
 
 static void pop_flight(pjb_ctx *c) {
     if (c->n_fl <= 0) return;
-    const int slot0 = c->fl[0].slot;
-    if (c->n_fl == 2) c->fl[0] = c->fl[1];
+    c->slot_busy[c->fl[0].slot] = false;
+    for (int k = 1; k < c->n_fl; k++) c->fl[k - 1] = c->fl[k];
     c->n_fl--;
     c->fl[c->n_fl] = Flight();
-    c->fl[c->n_fl].slot = c->n_fl == 1 ? 1 - c->fl[0].slot : slot0;
-    if (c->n_fl == 0) c->fl[1].slot = 1 - c->fl[0].slot;
 }
 
 static std::vector<DevBatch> g_no_batches;
@@ -1298,16 +1296,21 @@ static std::vector<DevBatch> g_no_batches;
 int pjb_finish_contig_begin(pjb_ctx *c, int32_t tid) {
     if (!c) return PJB_ERR_ARG;
     if (tid < 0 || (size_t)tid >= c->ref_len.size()) return fail(c, PJB_ERR_ARG, "finish: bad tid %d", tid);
-    if (c->n_fl >= 2) return fail(c, PJB_ERR_STATE, "finish: two targets are queued already (%d, %d); collect one first", c->fl[0].tid, c->fl[1].tid);
-    if (c->n_fl == 1 && c->fl[0].tid == tid) return fail(c, PJB_ERR_STATE, "finish: target %d is queued already", tid);
-    if (c->n_fl == 1 && c->extra) return fail(c, PJB_ERR_STATE, "finish: with PJB_FLAG_EXTRA targets are finished one at a time");
+    if (c->n_fl >= PJB_MAX_QUEUED)
+        return fail(c, PJB_ERR_STATE, "finish: %d targets are queued already (oldest: %d); collect one first", c->n_fl, c->fl[0].tid);
+    for (int k = 0; k < c->n_fl; k++)
+        if (c->fl[k].tid == tid) return fail(c, PJB_ERR_STATE, "finish: target %d is queued already", tid);
+    if (c->n_fl >= 1 && c->extra) return fail(c, PJB_ERR_STATE, "finish: with PJB_FLAG_EXTRA targets are finished one at a time");
     c->cur_tid = tid;
     HIP_TRY(c, hipSetDevice(c->cfg.device));
     Flight &f = c->fl[c->n_fl];
-    const int slot = f.slot;
+    int slot = 0;
+    while (slot < PJB_MAX_QUEUED && c->slot_busy[slot]) slot++;
+    if (slot >= PJB_MAX_QUEUED) return fail(c, PJB_ERR_STATE, "finish: no free control slot");
     f = Flight();
     f.slot = slot;
     f.tid = tid;
+    c->slot_busy[slot] = true;
     auto open_it = c->open.find(tid);
     if (open_it == c->open.end() || open_it->second.batches.empty()) {
         f.empty = true;
@@ -1352,15 +1355,15 @@ int pjb_finish_contig_begin(pjb_ctx *c, int32_t tid) {
     }
     c->n_fl++;
     if (c->extra) return PJB_OK; // (queued by pjb_finish_contig_end: the extra metrics need this contig's scratch untouched)
-    // a follower that was taken back goes first (rows are in contig order)
-    if (c->n_fl == 2 && !c->fl[0].queued && !c->fl[0].empty) return PJB_OK; // (both are queued in order by the first one's end)
+    // a contig that was taken back goes first (rows are in contig order): the end of the oldest one queues them all
+    for (int k = 0; k + 1 < c->n_fl; k++)
+        if (!c->fl[k].queued && !c->fl[k].empty) return PJB_OK;
     const int rc = queue_contig(c, f, batches);
     if (rc) { // nothing of this contig stays behind
         (void)hipDeviceSynchronize();
         c->n_fl--;
-        const int sl = c->fl[c->n_fl].slot;
+        c->slot_busy[c->fl[c->n_fl].slot] = false;
         c->fl[c->n_fl] = Flight();
-        c->fl[c->n_fl].slot = sl;
         close_contig(c, tid);
     }
     return rc;
@@ -1487,13 +1490,14 @@ int pjb_finish_contig_end(pjb_ctx *c, int32_t tid, pjb_region_result *res) {
     (void)hipEventElapsedTime(&c->timing.total_ms, S.ev[0], S.ev[7]);
     if (res) *res = R;
     closer.ok = true;
-    // a follower that was taken back (or waited for this one) is queued now, its place known
-    if (c->n_fl == 2 && !c->fl[1].queued && !c->fl[1].empty && !c->extra) {
-        auto it = c->open.find(c->fl[1].tid);
-        if (it != c->open.end()) {
-            // (fl[0] is still this contig: count its rows as collected -- they are -- and skip it as "ahead")
-            f.queued = false;
-            if ((rc = queue_contig(c, c->fl[1], it->second.batches))) return rc;
+    // followers that were taken back (or waited for this one) are queued now, in order, the first one's place known
+    if (!c->extra) {
+        f.queued = false; // (fl[0] is still this contig: its rows are collected, it is not "ahead" of anything)
+        for (int k = 1; k < c->n_fl; k++) {
+            Flight &g = c->fl[k];
+            if (g.queued || g.empty) continue;
+            auto it = c->open.find(g.tid);
+            if (it != c->open.end() && (rc = queue_contig(c, g, it->second.batches))) return rc;
         }
     }
     return PJB_OK;

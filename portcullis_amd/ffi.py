@@ -15,6 +15,7 @@ from .records import ORIENTATION, ReadBatch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libportcullis_amd.so")
 ABI_VERSION = 2
+MAX_QUEUED = 4  # PJB_MAX_QUEUED
 N_STAGES = 8
 STAGE_NAMES = ["scan_emit", "sort", "group", "anchors", "pair_stats", "finalize", "d2h", "spare"]
 
@@ -248,7 +249,7 @@ class Context:
         self._check(self._L.pjb_set_option(self._h, name.encode(), int(value)))
 
     def finish_contig_begin(self, tid):
-        """Queue the contig's kernel chain without waiting (at most two contigs queued; collect in the same order)."""
+        """Queue the contig's kernel chain without waiting (at most MAX_QUEUED contigs queued; collect in the same order)."""
         try:
             self._check(self._L.pjb_finish_contig_begin(self._h, tid))
         except Exception:

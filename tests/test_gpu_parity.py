@@ -242,7 +242,7 @@ def test_two_contigs_queued(ffi, orc):
     contigs = _three_contigs(orc)
     want = np.concatenate([c[2] for c in contigs])
     with ffi.Context(0, "FR") as ctx:
-        for depth in (2, 1, 2):
+        for depth in (2, 1, 3, ffi.MAX_QUEUED):
             rows, regs = _run_queued(ffi, ctx, contigs, depth)
             for tid, c in enumerate(contigs):
                 region_equal(regs[tid], c[3])
@@ -255,7 +255,7 @@ def test_two_contigs_queued(ffi, orc):
         ctx.finish_contig_begin(0)
         ctx.finish_contig_begin(1)
         with pytest.raises(ffi.PjbError):
-            ctx.finish_contig_begin(2)
+            ctx.finish_contig_begin(1)
         with pytest.raises(ffi.PjbError):
             ctx.finish_contig_end(1)
         with pytest.raises(ffi.PjbError):
@@ -265,6 +265,16 @@ def test_two_contigs_queued(ffi, orc):
         ctx.finish_contig_end(1)
         ctx.finish_contig_end(2)
         assert_rows_equal(ctx.collect(), want)
+    with ffi.Context(0, "FR") as ctx:  # more than the queue holds (targets without alignments count as well)
+        ctx.set_refs([1000] * (ffi.MAX_QUEUED + 1))
+        for tid in range(ffi.MAX_QUEUED):
+            ctx.finish_contig_begin(tid)
+        with pytest.raises(ffi.PjbError):
+            ctx.finish_contig_begin(ffi.MAX_QUEUED)
+        for tid in range(ffi.MAX_QUEUED):
+            assert ctx.finish_contig_end(tid)["n_reads"] == 0
+        ctx.finish_contig_begin(ffi.MAX_QUEUED)
+        ctx.finish_contig_end(ffi.MAX_QUEUED)
 
 
 def test_queued_behind_an_overflow(ffi, orc):
