@@ -361,6 +361,12 @@ def main():
             roofline["achieved_alone"] = round(dom["alg_bytes"] / (dom_serial_ms * 1e-3) / 1e9, 1)
             roofline["frac_alone"] = round(roofline["achieved_alone"] / PEAK_HBM_GBPS, 4)
         kernel_ms_per_step = sum(k["total_ms"] for k in kern) / args.steps
+        # the whole step against the roofline: algorithmic bytes of all kernels of a step over the step's wall time (the
+        # per-kernel fraction above says little once several chains share the chip)
+        step_bytes = sum((k["alg_bytes"] or 0) * k["launches"] / args.steps for k in kern)
+        roofline["step_alg_bytes"] = int(step_bytes)
+        roofline["step_achieved"] = round(step_bytes / (elapsed / args.steps) / 1e9, 1)
+        roofline["step_frac"] = round(roofline["step_achieved"] / PEAK_HBM_GBPS, 4)
         # HBM bytes per launch from the PMC counters (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 --pmc passes of
         # this same command: tools/pmc_traffic.sh -> tools/summarize_pmc.py).  Counters cannot be read from inside
         # the process; the committed measurement for this workload is attached with the commit it was taken at.
