@@ -3,7 +3,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 import torch
 from portcullis_amd import ffi, synth
 paired = len(sys.argv) > 1 and sys.argv[1] == "pe"
-for n in (2_000_000, 8_000_000, 16_000_000, 32_000_000, 64_000_000, 128_000_000):
+for n in ((10_000_000,) if len(sys.argv) > 2 else (2_000_000, 8_000_000, 16_000_000, 32_000_000, 64_000_000)):
     cfg = dataclasses.replace(synth.CONFIGS["C2"], n_reads=n, contig_len=10 * n, n_junctions=n // (800 if paired else 200), read_len=150 if paired else 100, paired=paired)
     d = synth.generate(cfg, device="cuda")
     torch.cuda.synchronize()
