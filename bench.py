@@ -550,10 +550,13 @@ def e2e_leg(contigs, cfgs, workdir, orientation, oracle_tab_md5):
     n_reads = sum(c["n"] for c in contigs.values())
     walls = []
     out = os.path.join(workdir, "out", "pc")
-    for _ in range(2):
+    for rep in range(int(os.environ.get("PJB_BENCH_E2E_REPS", 2))):  # first run: HIP module load; then steady state
+        env = dict(os.environ)
+        if os.environ.get("PJB_BENCH_E2E_ALTERNATE"):  # (experiment: odd repeats with one target at a time on the device thread)
+            env["PJB_HOST_QUEUE"] = "3" if rep % 2 == 0 else "1"
         t = time.time()
         p = subprocess.run([cli, "junc", "-t", str(cores), "--orientation", orientation, "-o", out, prep],
-                           capture_output=True, text=True)
+                           capture_output=True, text=True, env=env)
         walls.append(time.time() - t)
         if p.returncode != 0:
             raise RuntimeError("portcullis_amd junc failed: " + (p.stderr or p.stdout)[-400:])

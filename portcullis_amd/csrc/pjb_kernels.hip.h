@@ -1402,7 +1402,7 @@ __device__ __forceinline__ void chunk_cmp(CmpChunk &C, bool active, int32_t qi, 
             const u32 q = __builtin_amdgcn_alignbit(C.qw[c + 1], C.qw[c], shq);
             const u32 g = __builtin_amdgcn_alignbit(C.gg[c + 1], C.gg[c], shg);
             const u32 x = q ^ g;
-            u32 m = (x | (x >> 1) | (x >> 2) | (x >> 3)) & 0x11111111u;
+            u32 m = (((x & 0x77777777u) + 0x77777777u) | x) & 0x88888888u; // top bit of every nibble that differs
             if (rem < 8) m &= (1u << (4 * rem)) - 1u;
             if (m) {
                 mism += __popc(m);

@@ -307,17 +307,56 @@ private:
         } catch (const std::exception& e) {
             fatal = e.what();
         }
-        size_t rowsSoFar = 0;  // --extra keeps every contig's rows in the context until pjb_extra_finish
+        // Targets are QUEUED on the device (pjb_finish_contig_begin) and collected later (_end): the kernel chains of up
+        // to kQueued targets run side by side on the GPU, the device never waits for this thread between targets, and
+        // the next target's upload / ingest overlaps the queued chains.  The rows of every target stay in the context's
+        // table (rows arrive in queue order; rowsSoFar marks where the next target's begin).  --extra finishes one
+        // target at a time (its metrics need the target's scratch untouched).
+        size_t kQueued = extra ? 1 : 3;
+        if (const char* e = getenv("PJB_HOST_QUEUE")) kQueued = extra ? 1 : (size_t)std::max(1, std::min(atoi(e), (int)PJB_MAX_QUEUED));
+        struct Pending {
+            int32_t tid;
+            std::promise<ContigDone>* done; // (the worker thread that owns it waits on its future)
+        };
+        std::deque<Pending> pending;
+        size_t rowsSoFar = 0;
+        auto collectOldest = [&]() {
+            Pending p = std::move(pending.front());
+            pending.pop_front();
+            ContigDone d;
+            memset(&d.rr, 0, sizeof d.rr);
+            std::string err;
+            const pjb_junction_row* rows = nullptr;
+            int64_t n = 0;
+            if (pjb_finish_contig_end(ctx, p.tid, &d.rr) != PJB_OK) err = std::string("pjb_finish_contig: ") + pjb_last_error(ctx);
+            else if (pjb_collect(ctx, &rows, &n) != PJB_OK) err = std::string("pjb_collect: ") + pjb_last_error(ctx);
+            else {
+                d.rows.assign(rows + rowsSoFar, rows + n);
+                d.rowBase = rowsSoFar;
+                rowsSoFar = (size_t)n;
+            }
+            (void)pjb_release_contig(ctx, p.tid);
+            if (err.empty()) p.done->set_value(std::move(d));
+            else p.done->set_exception(std::make_exception_ptr(JunctionBuilderException(err)));
+        };
         for (;;) {
             Cmd c;
             {
                 std::unique_lock<std::mutex> lk(mu);
+                if (q.empty() && !pending.empty()) { // nothing to do for the next target yet: collect the oldest queued one
+                    lk.unlock();
+                    collectOldest();
+                    continue;
+                }
                 cv.wait(lk, [&] { return !q.empty(); });
                 c = std::move(q.front());
                 q.pop_front();
                 cv.notify_all();
             }
-            if (c.kind == Cmd::STOP) break;
+            if (c.kind == Cmd::STOP) {
+                while (!pending.empty()) collectOldest();
+                break;
+            }
             std::string err = fatal;
             if (err.empty() && failed.count(c.tid)) err = failed[c.tid];
             if (c.kind == Cmd::GENOME) {
@@ -342,29 +381,29 @@ private:
                 else bam::bigFree(c.bamBytes);
                 c.bamDone->set_value(n);
             } else if (c.kind == Cmd::FINISH) {
-                ContigDone d;
-                memset(&d.rr, 0, sizeof d.rr);
                 if (err.empty()) {
-                    const pjb_junction_row* rows = nullptr;
-                    int64_t n = 0;
-                    if (pjb_finish_contig(ctx, c.tid, &d.rr) != PJB_OK) err = std::string("pjb_finish_contig: ") + pjb_last_error(ctx);
-                    else if (pjb_collect(ctx, &rows, &n) != PJB_OK) err = std::string("pjb_collect: ") + pjb_last_error(ctx);
-                    else if (extra) {
-                        d.rows.assign(rows + rowsSoFar, rows + n);
-                        d.rowBase = rowsSoFar;
-                        rowsSoFar = (size_t)n;
-                    } else d.rows.assign(rows, rows + n);
-                    if (!extra) (void)pjb_clear_rows(ctx);
-                } else if (ctx) {
-                    pjb_region_result dummy;
-                    (void)pjb_finish_contig(ctx, c.tid, &dummy);  // drop whatever was submitted
-                    if (!extra) (void)pjb_clear_rows(ctx);
+                    while (pending.size() >= kQueued) collectOldest();
+                    if (pjb_finish_contig_begin(ctx, c.tid) != PJB_OK) {
+                        err = std::string("pjb_finish_contig: ") + pjb_last_error(ctx);
+                        (void)pjb_release_contig(ctx, c.tid);
+                        c.done->set_exception(std::make_exception_ptr(JunctionBuilderException(err)));
+                    } else
+                        pending.push_back(Pending{c.tid, c.done});
+                } else {
+                    if (ctx) {
+                        while (!pending.empty()) collectOldest();
+                        pjb_region_result dummy;
+                        (void)pjb_finish_contig(ctx, c.tid, &dummy); // drop whatever was submitted
+                        const pjb_junction_row* rows = nullptr;
+                        int64_t n = 0;
+                        if (pjb_collect(ctx, &rows, &n) == PJB_OK) rowsSoFar = (size_t)n; // (rows of a dropped target are skipped)
+                        (void)pjb_release_contig(ctx, c.tid);
+                    }
+                    c.done->set_exception(std::make_exception_ptr(JunctionBuilderException(err)));
                 }
-                if (ctx) (void)pjb_release_contig(ctx, c.tid);
                 failed.erase(c.tid);
-                if (err.empty()) c.done->set_value(std::move(d));
-                else c.done->set_exception(std::make_exception_ptr(JunctionBuilderException(err)));
             } else if (c.kind == Cmd::EXTRA) {
+                while (!pending.empty()) collectOldest();
                 const pjb_extra_row* xr = nullptr;
                 int64_t n = 0;
                 if (err.empty() && pjb_extra_finish(ctx, &xr, &n) != PJB_OK) err = std::string("pjb_extra_finish: ") + pjb_last_error(ctx);
