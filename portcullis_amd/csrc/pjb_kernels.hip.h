@@ -179,6 +179,36 @@ __device__ __forceinline__ T wave_iscan(T v) {
     return v;
 }
 
+// Whole-wave reductions on the DPP path (no LDS traffic, one VALU instruction per step; __shfl_* goes through
+// ds_bpermute): quads, half rows, rows of 16, then row_bcast:15 / row_bcast:31 carry the row totals up -- the result
+// is in lane 63 and is read back as a scalar.  `IDENT` is what lanes that a step does not write contribute.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ u32 dpp_move(u32 ident, u32 v) {
+    return (u32)__builtin_amdgcn_update_dpp((int)ident, (int)v, CTRL, ROW_MASK, 0xf, false);
+}
+struct DppAdd {
+    static constexpr u32 ident = 0u;
+    __device__ __forceinline__ static u32 op(u32 a, u32 b) { return a + b; }
+};
+struct DppMax {
+    static constexpr u32 ident = 0u;
+    __device__ __forceinline__ static u32 op(u32 a, u32 b) { return a > b ? a : b; }
+};
+struct DppMin {
+    static constexpr u32 ident = 0xffffffffu;
+    __device__ __forceinline__ static u32 op(u32 a, u32 b) { return a < b ? a : b; }
+};
+template <typename Op>
+__device__ __forceinline__ u32 wave_total(u32 v) {
+    v = Op::op(v, dpp_move<0xB1, 0xf>(Op::ident, v));  // quad_perm [1,0,3,2]
+    v = Op::op(v, dpp_move<0x4E, 0xf>(Op::ident, v));  // quad_perm [2,3,0,1]
+    v = Op::op(v, dpp_move<0x141, 0xf>(Op::ident, v)); // row_half_mirror
+    v = Op::op(v, dpp_move<0x140, 0xf>(Op::ident, v)); // row_mirror: every lane of a row holds the row's result
+    v = Op::op(v, dpp_move<0x142, 0xa>(Op::ident, v)); // row_bcast:15 into rows 1 and 3
+    v = Op::op(v, dpp_move<0x143, 0xc>(Op::ident, v)); // row_bcast:31 into rows 2 and 3
+    return (u32)__builtin_amdgcn_readlane((int)v, 63);
+}
+
 // exclusive scan over the 256 threads of a block in thread order; returns exclusive prefix, total in *total.
 // smem: at least 4 elements of T.  Contains __syncthreads (call uniformly).
 template <typename T>
@@ -484,14 +514,18 @@ __global__ __launch_bounds__(256) void k1_count(DevBatch b, u32 *tile_cnt, TileS
         }
     }
     // block reduce
-    u64 packed = ((u64)cnt << 32) | ((u64)spl << 16) | (u64)uns; // per tile: spl,uns <= 1024; cnt <= 1024*65535 < 2^26
-    packed = wave_sum(packed);
-    sum = wave_sum(sum);
-    mn = wave_min(mn);
-    mx = wave_max(mx);
-    max_end = wave_max(max_end);
-    max_nlen = wave_max(max_nlen);
-    min_pos = wave_min(min_pos);
+    // whole-wave reductions on the DPP path (every lane gets the result); per wave: spl, uns <= 256, cnt <= 256 * 65535,
+    // and the length sum goes in two 16-bit halves so that nothing can overflow 32 bits
+    u64 packed = ((u64)wave_total<DppAdd>(cnt) << 32) | (u64)wave_total<DppAdd>((spl << 16) | uns);
+    sum = (u64)wave_total<DppAdd>((u32)(sum & 0xffffu)) + ((u64)wave_total<DppAdd>((u32)((sum >> 16) & 0xffffu)) << 16) +
+          ((u64)wave_total<DppAdd>((u32)(sum >> 32)) << 32);
+    auto smin = [](int32_t v) { return (int32_t)(wave_total<DppMin>((u32)v ^ 0x80000000u) ^ 0x80000000u); };
+    auto smax = [](int32_t v) { return (int32_t)(wave_total<DppMax>((u32)v ^ 0x80000000u) ^ 0x80000000u); };
+    mn = smin(mn);
+    mx = smax(mx);
+    max_end = smax(max_end);
+    max_nlen = smax(max_nlen);
+    min_pos = smin(min_pos);
     int w = threadIdx.x >> 6;
     __shared__ u64 smp[4];
     if (lane_id() == 0) {
@@ -1300,6 +1334,18 @@ __global__ __launch_bounds__(256) void k3_anchors_frag(const u32 *sidx, const u3
     const u32 j = valid ? jid_of[i] : 0xffffffffu;
     int32_t l = valid ? lstart[p] : INT32_MAX;
     int32_t r = valid ? rend[p] : INT32_MIN;
+    const u32 j0 = (u32)__builtin_amdgcn_readfirstlane((int)j);
+    if (__ballot(valid && j != j0) == 0) { // one junction in the wavefront (the usual case): whole-wave min / max on the DPP path
+        l = (int32_t)(wave_total<DppMin>((u32)l ^ 0x80000000u) ^ 0x80000000u); // (signed order through the sign bit)
+        r = (int32_t)(wave_total<DppMax>((u32)r ^ 0x80000000u) ^ 0x80000000u);
+        if (valid && lane_id() == 0) {
+            const u32 slot = j + (i >> 6);
+            frag_l[slot] = l;
+            frag_r[slot] = r;
+            frag_j[slot] = (int32_t)j;
+        }
+        return;
+    }
     l = seg_reduce_to_head(l, j, OpMin());
     r = seg_reduce_to_head(r, j, OpMax());
     const u32 jprev = __shfl_up(j, 1, 64);
@@ -1750,7 +1796,45 @@ __global__ __launch_bounds__(256) void k4_pairs(const u64 *skey, const u32 *sidx
         first_mis = minMatch > 0 ? minMatch : 100000000u;
         mism64 = nbMis;
     }
-    // ---- segmented wave reduce to fragment heads; the "same junction at distance o" tests are done once
+    // ---- a wavefront that holds pairs of ONE junction (the usual case: a junction has a few hundred pairs): plain
+    // whole-wave reductions on the DPP path, 16 x 6 VALU steps instead of 115 ds_bpermute round trips
+    const u32 j0 = (u32)__builtin_amdgcn_readfirstlane((int)j);
+    if (__ballot(valid && j != j0) == 0) {
+#pragma unroll
+        for (int w = 0; w < 4; w++) cnt[w] = wave_total<DppAdd>(cnt[w]);
+#pragma unroll
+        for (int w = 0; w < 5; w++) jadp[w] = wave_total<DppAdd>(jadp[w]);
+#pragma unroll
+        for (int w = 0; w < 5; w++) mx[w] = wave_total<DppMax>(mx[w]);
+        first_mis = wave_total<DppMin>(first_mis);
+        // (a pair has fewer than 2^24 mismatches: 64 of them fit 32 bits)
+        mism64 = (u64)wave_total<DppAdd>((u32)mism64);
+        if (valid && lane == 0) {
+            const u32 slot = j + (i >> 6);
+            u32 vals[F_WORDS];
+#pragma unroll
+            for (int k = 0; k < F_WORDS; k++) vals[k] = 0;
+#pragma unroll
+            for (int k = 0; k < 13; k++) vals[F_N + k] = (cnt[k >> 2] >> (8 * (k & 3))) & 0xffu;
+            vals[F_MAXMINANC] = mx[0];
+            vals[F_UP] = mx[1];
+            vals[F_DOWN] = mx[2];
+            vals[F_MAXMMES] = mx[3];
+            vals[F_MAXMINMATCH] = mx[4];
+            vals[F_FIRSTMIS] = first_mis;
+            vals[F_MISM_LO] = (u32)mism64;
+            vals[F_MISM_HI] = 0;
+#pragma unroll
+            for (int k = 0; k < 20; k++) vals[F_JAD0 + k] = (jadp[k >> 2] >> (8 * (k & 3))) & 0xffu;
+            uint4 *dst = reinterpret_cast<uint4 *>(frag + (size_t)slot * F_WORDS);
+#pragma unroll
+            for (int k = 0; k < F_WORDS / 4; k++) dst[k] = make_uint4(vals[4 * k], vals[4 * k + 1], vals[4 * k + 2], vals[4 * k + 3]);
+            frag_j[slot] = (int32_t)j;
+        }
+        return;
+    }
+    // ---- several junctions in the wavefront: segmented wave reduce to fragment heads; the "same junction at distance
+    // o" tests are done once
     u32 take = 0;
 #pragma unroll
     for (int sft = 0; sft < 6; sft++) {
