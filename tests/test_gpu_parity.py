@@ -328,6 +328,27 @@ def test_long_reads(ffi, orc):
     run_both(ffi, orc, genome, to_batch(reads), "FR")
 
 
+def test_options_do_not_change_rows(ffi, orc):
+    """pjb_set_option: kernels of a chain on one stream instead of several ("overlap" 0), the sort on the full keys
+    instead of the dense ids ("dense_ids" 0) -- the rows stay what they are; options need an empty queue."""
+    contigs = _three_contigs(orc, seeds=(51, 52, 53))
+    want = np.concatenate([c[2] for c in contigs])
+    with ffi.Context(0, "FR") as ctx:
+        for overlap, dense in ((0, 1), (1, 0), (0, 0), (1, 1)):
+            ctx.set_option("overlap", overlap)
+            ctx.set_option("dense_ids", dense)
+            rows, _ = _run_queued(ffi, ctx, contigs, 3)
+            assert_rows_equal(rows, want)
+        with pytest.raises(ffi.PjbError):
+            ctx.set_option("no_such_option", 1)
+        ctx.clear_rows()
+        ctx.submit_batch(0, contigs[0][1])
+        ctx.finish_contig_begin(0)
+        with pytest.raises(ffi.PjbError):
+            ctx.set_option("overlap", 0)
+        ctx.finish_contig_end(0)
+
+
 def test_row_mirror(ffi, orc):
     """pjb_set_row_mirror: finish_contig leaves { n_rows, spliced, unspliced, sum_len, min_len, max_len } and the rows
     in the caller's device buffer -- also for a contig without junctions -- and refuses a buffer that is too small."""
@@ -370,6 +391,22 @@ def test_row_mirror(ffi, orc):
                                               max(ra["max_len"], rb["max_len"])]
         assert len(both) == ra["n_junctions"] + rb["n_junctions"] and set(both["refid"]) == {0, 1}
         assert h[64:64 + both.nbytes].tobytes() == both.tobytes()
+        # the same with both contigs queued (pjb_finish_contig_begin / _end): the second contig's place in the mirror
+        # follows from the device-side cursor
+        ctx.clear_rows()
+        ctx.set_row_mirror(buf.data_ptr(), buf.numel())
+        buf.zero_()
+        torch.cuda.synchronize()
+        ctx.submit_batch(0, batch)
+        ctx.submit_batch(1, batch_b)
+        ctx.finish_contig_begin(0)
+        ctx.finish_contig_begin(1)
+        qa = ctx.finish_contig_end(0)
+        qb = ctx.finish_contig_end(1)
+        assert qa == ra and qb == rb
+        assert ctx.collect().tobytes() == both.tobytes()
+        h2 = buf.cpu().numpy()
+        assert h2[:48].tobytes() == h[:48].tobytes() and h2[64:64 + both.nbytes].tobytes() == both.tobytes()
         ctx.set_refs([len(genome)])
         ctx.upload_contig(0, genome.encode())
         small = torch.zeros(64 + ffi.ROW_DTYPE.itemsize, dtype=torch.uint8, device="cuda")
