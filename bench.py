@@ -193,6 +193,8 @@ def main():
     xchg = None
     row_bytes = ffi.ROW_DTYPE.itemsize
 
+    order = sorted(mine, key=lambda t: -contigs[t]["n"])
+
     def step():
         ctx.clear_rows()
         if xchg is not None:
@@ -206,7 +208,7 @@ def main():
             if state.get("want_timing"):
                 state.setdefault("per_contig", {})[t] = ctx.timing()
 
-        for tid in mine:
+        for tid in order:  # largest first: the queue drains at the end of a step on the small contigs
             c = contigs[tid]
             ctx.submit_batch_device(tid, c["batch"], c["n"])
             ctx.finish_contig_begin(tid)
