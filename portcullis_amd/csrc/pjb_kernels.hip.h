@@ -1317,23 +1317,20 @@ __global__ __launch_bounds__(256) void k3_anchors_frag(const u32 *sidx, const u3
     const u32 i = blockIdx.x * 256 + threadIdx.x;
     const bool valid = i < n;
     const u32 p = valid ? sidx[i] : 0;
-    {   // compact the sorted positions whose pair needs the generic compare (order is irrelevant).
-        // GEN_SHARDS independent sub-lists keep the returning atomics off a single address.
-        const bool gen = valid && (all_generic || !(meta[p] & META_SIMPLE));
-        const u64 m = __ballot(gen);
-        if (m) {
-            const u32 shard = blockIdx.x % GEN_SHARDS;
-            const u32 cap = ((gridDim.x + GEN_SHARDS - 1) / GEN_SHARDS) * 256;
-            u32 base = 0;
-            const int leader = __ffsll((long long)m) - 1;
-            if (lane_id() == leader) base = atomicAdd(&gen_count[shard], (u32)__popcll(m));
-            base = __shfl(base, leader, 64);
-            if (gen) gen_list[(size_t)shard * cap + base + (u32)__popcll(m & ((1ull << lane_id()) - 1))] = i;
-        }
-    }
+    // every load first, then the list's returning atomic, the anchors while it is in flight, the list entry last
     const u32 j = valid ? jid_of[i] : 0xffffffffu;
+    const u32 m_ = valid ? meta[p] : META_SIMPLE;
     int32_t l = valid ? lstart[p] : INT32_MAX;
     int32_t r = valid ? rend[p] : INT32_MIN;
+    // compact the sorted positions whose pair needs the generic compare (order is irrelevant).
+    // GEN_SHARDS independent sub-lists keep the returning atomics off a single address.
+    const bool gen = valid && (all_generic || !(m_ & META_SIMPLE));
+    const u64 gm = __ballot(gen);
+    const u32 shard = blockIdx.x % GEN_SHARDS;
+    const u32 cap = ((gridDim.x + GEN_SHARDS - 1) / GEN_SHARDS) * 256;
+    const int leader = gm ? __ffsll((long long)gm) - 1 : 0;
+    u32 base = 0;
+    if (gm && lane_id() == leader) base = atomicAdd(&gen_count[shard], (u32)__popcll(gm));
     const u32 j0 = (u32)__builtin_amdgcn_readfirstlane((int)j);
     if (__ballot(valid && j != j0) == 0) { // one junction in the wavefront (the usual case): whole-wave min / max on the DPP path
         l = (int32_t)(wave_total<DppMin>((u32)l ^ 0x80000000u) ^ 0x80000000u); // (signed order through the sign bit)
@@ -1344,17 +1341,21 @@ __global__ __launch_bounds__(256) void k3_anchors_frag(const u32 *sidx, const u3
             frag_r[slot] = r;
             frag_j[slot] = (int32_t)j;
         }
-        return;
+    } else {
+        l = seg_reduce_to_head(l, j, OpMin());
+        r = seg_reduce_to_head(r, j, OpMax());
+        const u32 jprev = __shfl_up(j, 1, 64);
+        const bool head = valid && (lane_id() == 0 || jprev != j);
+        if (head) {
+            const u32 slot = j + (i >> 6);
+            frag_l[slot] = l;
+            frag_r[slot] = r;
+            frag_j[slot] = (int32_t)j;
+        }
     }
-    l = seg_reduce_to_head(l, j, OpMin());
-    r = seg_reduce_to_head(r, j, OpMax());
-    const u32 jprev = __shfl_up(j, 1, 64);
-    const bool head = valid && (lane_id() == 0 || jprev != j);
-    if (head) {
-        const u32 slot = j + (i >> 6);
-        frag_l[slot] = l;
-        frag_r[slot] = r;
-        frag_j[slot] = (int32_t)j;
+    if (gm) {
+        base = (u32)__builtin_amdgcn_readlane((int)base, leader);
+        if (gen) gen_list[(size_t)shard * cap + base + (u32)__popcll(gm & ((1ull << lane_id()) - 1))] = i;
     }
 }
 // K3b: fragment slots -> junction anchors (anc_l/anc_r pre-initialised to INT32_MAX / INT32_MIN)
