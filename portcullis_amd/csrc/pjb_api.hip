@@ -197,7 +197,7 @@ struct pjb_ctx {
     std::map<int32_t, std::pair<u64 *, u32>> filter_keys; // bamfilt: passing junctions per target (device, sorted)
     Buf f_pos, f_cigoff, f_cigar, f_codes;
     Buf g_rows, g_models, g_refs, g_out, g_bad; // filt feature rows
-    Buf x_pos, x_endx, x_q, x_prefq, x_ce, x_bound, x_de, x_dropped, x_zlist, x_cnt, x_tabk, x_tabc, x_rs, x_re, x_rr;
+    Buf x_pos, x_endx, x_q, x_prefq, x_ce, x_bound, x_de, x_dropped, x_zlist, x_cnt, x_tabk, x_tabc, x_rs, x_re, x_rr, x_tileoff;
     Buf b_hasx, b_xtotal;
 };
 
@@ -551,7 +551,7 @@ void pjb_destroy(pjb_ctx *c) {
                   &c->b_bam_seg, &c->b_bam_rec, &c->b_bam_ctl, &c->f_pos, &c->f_cigoff, &c->f_cigar, &c->f_codes, &c->g_rows, &c->g_models, &c->g_refs,
                   &c->g_out, &c->g_bad,
                   &c->x_pos, &c->x_endx, &c->x_q, &c->x_prefq, &c->x_ce, &c->x_bound, &c->x_de, &c->x_dropped, &c->x_zlist, &c->x_cnt,
-                  &c->x_tabk, &c->x_tabc, &c->x_rs, &c->x_re, &c->x_rr};
+                  &c->x_tabk, &c->x_tabc, &c->x_rs, &c->x_re, &c->x_rr, &c->x_tileoff};
     for (Buf *b : all) release(*b);
     for (auto &pool : c->pools)
         for (auto &ev : pool.ev) (void)hipEventDestroy(ev);
@@ -833,7 +833,17 @@ static int extra_contig(pjb_ctx *c, int32_t tid, std::vector<DevBatch> &batches,
     u32 *prefq = (u32 *)c->x_prefq.p, *ce = (u32 *)c->x_ce.p;
     for (auto &b : batches)
         LAUNCH(c, "kx_classify", kx_classify, dim3((unsigned)((b.n + 255) / 256)), dim3(256), b, L, x_pos, x_endx, x_q, ce,
-               (int32_t *)X.cover, (u32 *)c->x_zlist.p, X_ZCAP, X.spl_codes, d_cnt);
+               (int32_t *)X.cover, (u32 *)c->x_zlist.p, X_ZCAP, d_cnt);
+    {   // the spliced records' name codes, through the tile lists the contig's first kernels left in its slot
+        CtlSlot &S = c->sl[c->cur_slot];
+        u32 n_tiles = 0;
+        for (auto &b : batches) n_tiles = std::max<u32>(n_tiles, b.tile_base + (u32)((b.n + K1_TILE - 1) / K1_TILE));
+        if ((rc = ensure(c, c->x_tileoff, (size_t)n_tiles * 4 + 16))) return rc;
+        LAUNCH(c, "kx_spliced_offsets", kx_spliced_offsets, dim3(1), dim3(1024), (const TileStats *)S.tile_stats.p, n_tiles, (u32 *)c->x_tileoff.p, d_cnt);
+        for (auto &b : batches)
+            LAUNCH(c, "kx_spliced_codes", kx_spliced_codes, dim3((unsigned)((b.n + K1_TILE - 1) / K1_TILE)), dim3(256), b, (const TileStats *)S.tile_stats.p,
+                   (const u32 *)S.splidx.p, (const u32 *)c->x_tileoff.p, X.spl_codes);
+    }
     if ((rc = run_scan(c, "kx_ends", ArrU32Fn{ce}, ExclusiveU32Sink{ce}, (u64)L + 2, (u64 *)c->b_xtotal.p))) return rc;
     if ((rc = run_scan(c, "kx_unspl", ArrU8Fn{x_q}, ExclusiveU32Sink{prefq}, (u64)N + 1, (u64 *)c->b_xtotal.p))) return rc;
     LAUNCH(c, "kx_cap_bound", kx_cap_bound, dim3((unsigned)((N + 255) / 256)), dim3(256), (const int32_t *)x_pos, (const uint8_t *)x_q,

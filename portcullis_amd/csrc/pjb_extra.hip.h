@@ -70,11 +70,10 @@ struct ExtraCounters { // one per contig, device memory
 // (order is irrelevant: they only feed a multiset).
 __global__ __launch_bounds__(256) void kx_classify(DevBatch b, int32_t ref_len, int32_t *x_pos,
                                                     int32_t *x_endx, uint8_t *q_flag, u32 *ce, int32_t *dd, u32 *zlist,
-                                                    u32 zcap, u64 *spl_codes, ExtraCounters *cnt) {
+                                                    u32 zcap, ExtraCounters *cnt) {
     const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const bool on = r < b.n;
     bool spliced = false;
-    u64 code = 0;
     if (on) {
         const u32 g = b.base + (u32)r;
         const u32 c0 = b.cig_off[r], c1 = b.cig_off[r + 1];
@@ -117,18 +116,45 @@ __global__ __launch_bounds__(256) void kx_classify(DevBatch b, int32_t ref_len, 
                 if (op_consumes_ref(ty)) x += ln;
             }
         }
-        if (spliced) code = b.name_hash[r];
-    }
-    // wave-aggregated append of the spliced records' codes
-    const u64 m = __ballot(spliced);
-    if (m) {
-        const int leader = __ffsll((long long)m) - 1;
-        u32 base = 0;
-        if (lane_id() == leader) base = atomicAdd(&cnt->n_spliced, (u32)__popcll(m));
-        base = __shfl(base, leader, 64);
-        if (spliced) spl_codes[base + (u32)__popcll(m & ((1ull << lane_id()) - 1))] = code;
     }
 }
+
+// The name codes of the spliced records, in BAM order, without a single atomic: k1_count left, per 1024-record tile,
+// the ordered list of its spliced records (spl_idx) and their number (tile_stats); one block scans the tile counts,
+// then a block per tile copies its records' codes to the tile's place.  (A wave-aggregated atomicAdd on one counter
+// per wavefront of records cost 1.1 ms per 10 M records: 156 k returning atomics on ONE address.)
+__global__ __launch_bounds__(1024) void kx_spliced_offsets(const TileStats *ts, u32 n_tiles, u32 *off, ExtraCounters *cnt) {
+    __shared__ u32 wsum[16];
+    __shared__ u32 carry_s;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (u32 base = 0; base < n_tiles; base += 1024) {
+        const u32 i = base + threadIdx.x;
+        const u32 v = i < n_tiles ? ts[i].spliced : 0u;
+        const u32 inc = wave_iscan(v);
+        const int w = threadIdx.x >> 6;
+        if (lane_id() == 63) wsum[w] = inc;
+        __syncthreads();
+        u32 wb = 0, tot = 0;
+        for (int k = 0; k < 16; k++) {
+            const u32 t = wsum[k];
+            if (k < w) wb += t;
+            tot += t;
+        }
+        const u32 carry = carry_s;
+        if (i < n_tiles) off[i] = carry + wb + inc - v;
+        __syncthreads();
+        if (threadIdx.x == 0) carry_s = carry + tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) cnt->n_spliced = carry_s;
+}
+__global__ __launch_bounds__(256) void kx_spliced_codes(DevBatch b, const TileStats *ts, const u32 *spl_idx, const u32 *off, u64 *spl_codes) {
+    const u32 tile = b.tile_base + blockIdx.x;
+    const u32 nspl = ts[tile].spliced, o = off[tile];
+    for (u32 ks = threadIdx.x; ks < nspl; ks += 256) spl_codes[o + ks] = b.name_hash[spl_idx[(size_t)tile * K1_TILE + ks]];
+}
+
 
 // scan functors -----------------------------------------------------------------------------------------------
 struct ArrU32Fn {
@@ -171,8 +197,10 @@ __global__ __launch_bounds__(256) void kx_cap_bound(const int32_t *x_pos, const 
         if (bound) bound[g] = u;
         hot = u + 2 > PLP_MAXCNT;
     }
+    // (one counter for every wavefront of records: look first -- the maximum settles after a few waves, and 156 k
+    // atomics on one address are served one at a time; a stale look only costs an atomic)
     const u32 wm = wave_max(u);
-    if (lane_id() == 0 && wm) atomicMax(&cnt->max_buffered, wm);
+    if (lane_id() == 0 && wm > cnt->max_buffered) atomicMax(&cnt->max_buffered, wm);
     if (hot) {
         atomicMin(&cnt->hot_first, g);
         atomicMax(&cnt->hot_last, g);
