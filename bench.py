@@ -556,12 +556,21 @@ def e2e_leg(contigs, cfgs, workdir, orientation, oracle_tab_md5):
         env = dict(os.environ)
         if os.environ.get("PJB_BENCH_E2E_ALTERNATE"):  # (experiment: odd repeats with one target at a time on the device thread)
             env["PJB_HOST_QUEUE"] = "3" if rep % 2 == 0 else "1"
+        if os.environ.get("PJB_BENCH_E2E_SWEEP"):  # (experiment: "VAR=a,b,c": repeat k runs with VAR = the k-th value)
+            var, vals = os.environ["PJB_BENCH_E2E_SWEEP"].split("=")
+            vals = vals.split(",")
+            env[var] = vals[rep % len(vals)]
         t = time.time()
         p = subprocess.run([cli, "junc", "-t", str(cores), "--orientation", orientation, "-o", out, prep],
                            capture_output=True, text=True, env=env)
         walls.append(time.time() - t)
         if p.returncode != 0:
             raise RuntimeError("portcullis_amd junc failed: " + (p.stderr or p.stdout)[-400:])
+    if os.environ.get("PJB_BENCH_E2E_PROFILE"):  # one more run with the host-side timers on; their report goes to a file
+        env = dict(os.environ, PJB_PROFILE_HOST="1")
+        p = subprocess.run([cli, "junc", "-t", str(cores), "--orientation", orientation, "-o", out, prep], capture_output=True, text=True, env=env)
+        with open(os.environ["PJB_BENCH_E2E_PROFILE"], "w") as f:
+            f.write(p.stderr + "\n---- stdout ----\n" + p.stdout)
     tab = open(out + ".junctions.tab", "rb").read()
     md5 = hashlib.md5(tab).hexdigest()
     res = {"wall_s": round(min(walls), 3), "runs_s": [round(w, 3) for w in walls], "reads_per_sec": n_reads / min(walls),

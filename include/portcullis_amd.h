@@ -317,6 +317,25 @@ int pjb_inflate_bgzf(pjb_ctx* ctx, const uint8_t* comp, int64_t comp_bytes, uint
  * Errors: PJB_ERR_BGZF for corrupt BGZF / DEFLATE / BAM record data. */
 int pjb_submit_bam(pjb_ctx* ctx, int32_t tid, const uint8_t* comp, int64_t comp_bytes, int32_t first_uoffset, int64_t* n_records);
 
+/* The same with the target's bytes arriving in PIECES, in file order, any sizes -- for a reader that fills a small ring
+ * of page-locked buffers instead of one buffer per target (page-locking memory costs ~0.15 s per GB: three 3 GB buffers
+ * were 1.4 s of a 5 s run over a 33 GB file):
+ *   pjb_bam_begin        announces `total_bytes` for target `tid` and reserves device memory for them;
+ *   pjb_bam_piece        queues the copy of the next `bytes` to the device (asynchronous if `piece` is page-locked)
+ *                        and meanwhile hops over the BGZF block headers that this piece completes; *ticket (optional)
+ *                        identifies the copy;
+ *   pjb_bam_pieces_done  *completed_ticket = the highest ticket whose copy has left its host buffer (copies complete
+ *                        in order; never blocks): the buffers of all pieces up to it may be reused;
+ *   pjb_bam_end          inflate + parse + transcode of the staged bytes: from here on exactly pjb_submit_bam
+ *                        (same result, same errors; a BGZF error found while hopping is reported by the piece call;
+ *                        a failing piece call drops the target's staging: begin again).
+ * Several targets may be between _begin and _end at once (each has its own device buffer, taken from a pool the
+ * context keeps). */
+int pjb_bam_begin(pjb_ctx* ctx, int32_t tid, int64_t total_bytes);
+int pjb_bam_piece(pjb_ctx* ctx, int32_t tid, const uint8_t* piece, int64_t bytes, int64_t* ticket);
+int pjb_bam_pieces_done(pjb_ctx* ctx, int64_t* completed_ticket);
+int pjb_bam_end(pjb_ctx* ctx, int32_t tid, int32_t first_uoffset, int64_t* n_records);
+
 /* ---- `portcullis filt` feature rows -------------------------------------------------------
  * ModelFeatures::setRow (lib/src/model_features.cc:161-212) for a list of junctions: the columns of VAR_NAMES +
  * JAD_NAMES (lib/include/portcullis/ml/model_features.hpp:45-60), i.e. the row getters, calcIntronScore

@@ -129,6 +129,7 @@ struct Flight {
     Pairs pr;
 };
 
+constexpr size_t PJB_UP_EVENTS = 64;
 struct pjb_ctx {
     pjb_config cfg;
     hipStream_t stream = nullptr;  // service stream: uploads, host batches, BAM ingest, filters, extra metrics; a contig's chain runs
@@ -144,6 +145,13 @@ struct pjb_ctx {
     EvPool pools[PJB_MAX_QUEUED + 1];
     int cur_pool = MISC_POOL;
     Buf b_cursor;     // RowCursor
+    // device ingest in pieces (pjb_bam_begin / _piece / _end)
+    std::map<int32_t, struct BamStage *> bam_stage;
+    std::vector<Buf> stage_pool;  // device buffers for staged BGZF bytes, reused target after target
+    hipStream_t stream_up = nullptr;
+    hipEvent_t ev_up = nullptr;
+    hipEvent_t up_events[64] = {};
+    int64_t up_ticket = 0, up_done = 0;
     std::string err;
     std::vector<int32_t> ref_len;
     std::vector<Contig> contigs;
@@ -510,6 +518,8 @@ int pjb_create(pjb_ctx **out, const pjb_config *cfg) {
     return PJB_OK;
 }
 
+static void bam_stage_clear(pjb_ctx *c); // (defined with the staged ingest)
+
 void pjb_destroy(pjb_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->cfg.device);
@@ -524,6 +534,7 @@ void pjb_destroy(pjb_ctx *c) {
         if (sl.p) (void)hipFree(sl.p);
     if (c->rows_pinned) (void)hipHostFree(c->rows_pinned);
     if (c->rows_table) (void)hipFree(c->rows_table);
+    bam_stage_clear(c);
     for (int k = 0; k < PJB_MAX_QUEUED; k++) {
         CtlSlot &S = c->sl[k];
         if (S.pub) (void)hipHostFree(S.pub);
@@ -1954,43 +1965,17 @@ extern "C" int pjb_inflate_bgzf(pjb_ctx *c, const uint8_t *comp, int64_t comp_by
     return PJB_OK;
 }
 
-extern "C" int pjb_submit_bam(pjb_ctx *c, int32_t tid, const uint8_t *comp, int64_t comp_bytes, int32_t first_uoffset,
-                              int64_t *n_records) {
-    if (!c) return PJB_ERR_ARG;
-    if (n_records) *n_records = 0;
-    if (comp_bytes < 0 || (comp_bytes && !comp) || first_uoffset < 0) return fail(c, PJB_ERR_ARG, "submit_bam: bad arguments");
-    if (tid < 0 || (size_t)tid >= c->ref_len.size()) return fail(c, PJB_ERR_ARG, "submit_bam: bad tid %d", tid);
-    c->cur_tid = tid;
-    HIP_TRY(c, hipSetDevice(c->cfg.device));
-    OpenContig &oc = c->open[tid];
-    if (!oc.batches.empty()) return fail(c, PJB_ERR_STATE, "submit_bam: target %d already has batches (one call per target)", tid);
+// the part of pjb_submit_bam behind the upload: `d_comp` holds the target's BGZF bytes (padded), `blocks` their layout
+static int ingest_staged(pjb_ctx *c, int32_t tid, OpenContig &oc, const uint8_t *d_comp, const std::vector<InfBlock> &blocks, int64_t comp_bytes,
+                         int64_t total, int32_t first_uoffset, int64_t *n_records, double t_scan, double t_up) {
     const bool prof = getenv("PJB_PROFILE_HOST") != nullptr;
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-    double t0 = now(), t_scan, t_up, t_inf, t_walk;
-    std::vector<InfBlock> blocks;
-    int64_t total = 0;
-    int rc = scan_bgzf(c, comp, comp_bytes, blocks, total);
-    if (rc) return rc;
-    if (total == 0 || (int64_t)first_uoffset >= total) return PJB_OK;
-    t_scan = now() - t0;
-    t0 = now();
+    double t0 = now(), t_inf, t_walk;
     hipStream_t st = c->stream;
-    if ((rc = ensure(c, c->b_inf_comp, (size_t)comp_bytes + INF_PAD))) return rc;
+    int rc;
     if ((rc = ensure(c, c->b_inf_out, (size_t)total + 64))) return rc;
-    {
-        // page-locked input (pjb_host_alloc): one DMA, no staging copy
-        hipPointerAttribute_t at;
-        const bool pinned = hipPointerGetAttributes(&at, comp) == hipSuccess && at.type == hipMemoryTypeHost;
-        if (!pinned) (void)hipGetLastError();
-        if (pinned) HIP_TRY(c, hipMemcpyAsync(c->b_inf_comp.p, comp, (size_t)comp_bytes, hipMemcpyHostToDevice, st));
-        else if ((rc = upload_staged(c, c->b_inf_comp.p, comp, (size_t)comp_bytes))) return rc;
-    }
-    HIP_TRY(c, hipMemsetAsync((uint8_t *)c->b_inf_comp.p + comp_bytes, 0, INF_PAD, st));
     HIP_TRY(c, hipMemsetAsync((uint8_t *)c->b_inf_out.p + total, 0, 64, st));
-    if (prof) (void)hipStreamSynchronize(st);
-    t_up = now() - t0;
-    t0 = now();
-    if ((rc = inflate_on_device(c, (const uint8_t *)c->b_inf_comp.p, blocks, (uint8_t *)c->b_inf_out.p))) return rc;
+    if ((rc = inflate_on_device(c, d_comp, blocks, (uint8_t *)c->b_inf_out.p))) return rc;
 
     t_inf = now() - t0;
     t0 = now();
@@ -2138,4 +2123,248 @@ extern "C" int pjb_submit_bam(pjb_ctx *c, int32_t tid, const uint8_t *comp, int6
     oc.last_pos.push_back(INT32_MIN);
     if (n_records) *n_records = (int64_t)n;
     return PJB_OK;
+}
+
+extern "C" int pjb_submit_bam(pjb_ctx *c, int32_t tid, const uint8_t *comp, int64_t comp_bytes, int32_t first_uoffset,
+                              int64_t *n_records) {
+    if (!c) return PJB_ERR_ARG;
+    if (n_records) *n_records = 0;
+    if (comp_bytes < 0 || (comp_bytes && !comp) || first_uoffset < 0) return fail(c, PJB_ERR_ARG, "submit_bam: bad arguments");
+    if (tid < 0 || (size_t)tid >= c->ref_len.size()) return fail(c, PJB_ERR_ARG, "submit_bam: bad tid %d", tid);
+    c->cur_tid = tid;
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    OpenContig &oc = c->open[tid];
+    if (!oc.batches.empty()) return fail(c, PJB_ERR_STATE, "submit_bam: target %d already has batches (one call per target)", tid);
+    const bool prof = getenv("PJB_PROFILE_HOST") != nullptr;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t0 = now(), t_scan, t_up;
+    std::vector<InfBlock> blocks;
+    int64_t total = 0;
+    int rc = scan_bgzf(c, comp, comp_bytes, blocks, total);
+    if (rc) return rc;
+    if (total == 0 || (int64_t)first_uoffset >= total) return PJB_OK;
+    t_scan = now() - t0;
+    t0 = now();
+    hipStream_t st = c->stream;
+    if ((rc = ensure(c, c->b_inf_comp, (size_t)comp_bytes + INF_PAD))) return rc;
+    {
+        // page-locked input (pjb_host_alloc): one DMA, no staging copy
+        hipPointerAttribute_t at;
+        const bool pinned = hipPointerGetAttributes(&at, comp) == hipSuccess && at.type == hipMemoryTypeHost;
+        if (!pinned) (void)hipGetLastError();
+        if (pinned) HIP_TRY(c, hipMemcpyAsync(c->b_inf_comp.p, comp, (size_t)comp_bytes, hipMemcpyHostToDevice, st));
+        else if ((rc = upload_staged(c, c->b_inf_comp.p, comp, (size_t)comp_bytes))) return rc;
+    }
+    HIP_TRY(c, hipMemsetAsync((uint8_t *)c->b_inf_comp.p + comp_bytes, 0, INF_PAD, st));
+    if (prof) (void)hipStreamSynchronize(st);
+    t_up = now() - t0;
+    return ingest_staged(c, tid, oc, (const uint8_t *)c->b_inf_comp.p, blocks, comp_bytes, total, first_uoffset, n_records, t_scan, t_up);
+}
+
+// ---- the same in pieces -----------------------------------------------------------------------------------------
+// (pjb_bam_begin / pjb_bam_piece / pjb_bam_pieces_done / pjb_bam_end, see the header)
+struct BamStage {
+    Buf dev;                 // the target's BGZF bytes on the device (from the context's pool)
+    int64_t total = 0, got = 0;
+    std::vector<InfBlock> blocks;
+    int64_t total_out = 0;
+    int64_t next = 0;        // file-relative offset of the next block header to look at
+    uint8_t keep[65536 + 64]; // bytes [keep_at, got) of what arrived, for a block whose header or footer straddles two pieces
+    int64_t keep_at = 0, keep_n = 0;
+    double t_scan = 0, t_up = 0;
+};
+
+// block headers that are complete with the bytes received so far (the last `avail` bytes of the stream are at `p`, the
+// first of them is byte `p_at` of the target's bytes); leaves st.next at the first block it cannot finish yet
+static int stage_scan(pjb_ctx *c, BamStage &st, const uint8_t *p, int64_t p_at, int64_t avail) {
+    auto byte_at = [&](int64_t off) -> int { // a byte of the stream that is still in reach (this piece or the kept tail)
+        if (off >= p_at && off < p_at + avail) return p[off - p_at];
+        if (off >= st.keep_at && off < st.keep_at + st.keep_n) return st.keep[off - st.keep_at];
+        return -1;
+    };
+    const int64_t end = p_at + avail;
+    while (st.next < st.total) {
+        const int64_t off = st.next;
+        if (off + 18 > end) break;
+        uint8_t h[18];
+        for (int k = 0; k < 18; k++) {
+            const int v = byte_at(off + k);
+            if (v < 0) return fail(c, PJB_ERR_STATE, "bam_piece: internal: header byte %lld out of reach", (long long)(off + k));
+            h[k] = (uint8_t)v;
+        }
+        if (h[0] != 31 || h[1] != 139 || h[2] != 8 || !(h[3] & 4)) return fail(c, PJB_ERR_BGZF, "not a BGZF block header at byte %lld", (long long)off);
+        const uint32_t xlen = h[10] | (uint32_t)h[11] << 8;
+        if (off + 12 + xlen > end) break;
+        int64_t bsize = -1;
+        for (uint32_t x = 0; x + 4 <= xlen;) {
+            int f[6];
+            for (int k = 0; k < 6; k++) f[k] = x + (uint32_t)k < xlen ? byte_at(off + 12 + x + k) : 0;
+            if (f[0] < 0 || f[1] < 0 || f[2] < 0 || f[3] < 0) return fail(c, PJB_ERR_STATE, "bam_piece: internal: extra field out of reach");
+            const uint32_t slen = (uint32_t)f[2] | (uint32_t)f[3] << 8;
+            if (f[0] == 'B' && f[1] == 'C' && slen == 2 && x + 6 <= xlen) bsize = (int64_t)((uint32_t)f[4] | (uint32_t)f[5] << 8) + 1;
+            x += 4 + slen;
+        }
+        if (bsize < 0) return fail(c, PJB_ERR_BGZF, "BGZF block at byte %lld has no BC field", (long long)off);
+        if (bsize < (int64_t)xlen + 20 || off + bsize > st.total)
+            return fail(c, PJB_ERR_BGZF, "BGZF block at byte %lld has an impossible size %lld", (long long)off, (long long)bsize);
+        if (off + bsize > end) break; // its footer has not arrived
+        uint32_t isize = 0;
+        for (int k = 0; k < 4; k++) {
+            const int v = byte_at(off + bsize - 4 + k);
+            if (v < 0) return fail(c, PJB_ERR_STATE, "bam_piece: internal: footer byte out of reach");
+            isize |= (uint32_t)v << (8 * k);
+        }
+        if (isize > 65536u) return fail(c, PJB_ERR_BGZF, "BGZF block at byte %lld declares %u inflated bytes", (long long)off, isize);
+        InfBlock b;
+        b.in_off = (iu64)(off + 12 + xlen);
+        b.in_len = (iu32)(bsize - xlen - 20);
+        b.out_off = (iu64)st.total_out;
+        b.out_len = isize;
+        st.blocks.push_back(b);
+        st.total_out += isize;
+        st.next = off + bsize;
+    }
+    return PJB_OK;
+}
+
+static void bam_stage_clear(pjb_ctx *c) {
+    for (auto &kv : c->bam_stage) {
+        if (kv.second->dev.p) (void)hipFree(kv.second->dev.p);
+        delete kv.second;
+    }
+    c->bam_stage.clear();
+    for (auto &b : c->stage_pool) release(b);
+    c->stage_pool.clear();
+    for (auto &ev : c->up_events)
+        if (ev) (void)hipEventDestroy(ev);
+    if (c->ev_up) (void)hipEventDestroy(c->ev_up);
+    if (c->stream_up) (void)hipStreamDestroy(c->stream_up);
+}
+
+extern "C" int pjb_bam_begin(pjb_ctx *c, int32_t tid, int64_t total_bytes) {
+    if (!c) return PJB_ERR_ARG;
+    if (tid < 0 || (size_t)tid >= c->ref_len.size() || total_bytes <= 0) return fail(c, PJB_ERR_ARG, "bam_begin: bad arguments (tid %d)", tid);
+    if (c->bam_stage.count(tid)) return fail(c, PJB_ERR_STATE, "bam_begin: target %d is being staged already", tid);
+    auto it = c->open.find(tid);
+    if (it != c->open.end() && !it->second.batches.empty()) return fail(c, PJB_ERR_STATE, "bam_begin: target %d already has batches", tid);
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    std::unique_ptr<BamStage> st(new (std::nothrow) BamStage());
+    if (!st) return fail(c, PJB_ERR_NOMEM, "bam_begin: out of host memory");
+    // device buffer: the smallest free one of the pool that fits, else a new one
+    const size_t need = (size_t)total_bytes + INF_PAD;
+    int best = -1;
+    for (size_t k = 0; k < c->stage_pool.size(); k++)
+        if (c->stage_pool[k].cap >= need && (best < 0 || c->stage_pool[k].cap < c->stage_pool[(size_t)best].cap)) best = (int)k;
+    if (best >= 0) {
+        st->dev = c->stage_pool[(size_t)best];
+        c->stage_pool.erase(c->stage_pool.begin() + best);
+    } else {
+        int rc = ensure(c, st->dev, need);
+        if (rc) return rc;
+    }
+    st->total = total_bytes;
+    if (!c->stream_up) HIP_TRY(c, hipStreamCreateWithFlags(&c->stream_up, hipStreamNonBlocking));
+    HIP_TRY(c, hipMemsetAsync((uint8_t *)st->dev.p + total_bytes, 0, INF_PAD, c->stream_up));
+    c->bam_stage[tid] = st.release();
+    return PJB_OK;
+}
+
+static int bam_piece_body(pjb_ctx *c, int32_t tid, BamStage &st, const uint8_t *piece, int64_t bytes, int64_t *ticket);
+
+extern "C" int pjb_bam_piece(pjb_ctx *c, int32_t tid, const uint8_t *piece, int64_t bytes, int64_t *ticket) {
+    if (!c || !piece || bytes <= 0) return fail(c, PJB_ERR_ARG, "bam_piece: bad arguments");
+    auto it = c->bam_stage.find(tid);
+    if (it == c->bam_stage.end()) return fail(c, PJB_ERR_STATE, "bam_piece: target %d was not begun (pjb_bam_begin)", tid);
+    const int rc = bam_piece_body(c, tid, *it->second, piece, bytes, ticket);
+    if (rc) { // the target's staging is dropped: it has to be begun again
+        (void)hipStreamSynchronize(c->stream_up);
+        if (it->second->dev.p) c->stage_pool.push_back(it->second->dev);
+        delete it->second;
+        c->bam_stage.erase(it);
+    }
+    return rc;
+}
+
+static int bam_piece_body(pjb_ctx *c, int32_t tid, BamStage &st, const uint8_t *piece, int64_t bytes, int64_t *ticket) {
+    if (st.got + bytes > st.total) return fail(c, PJB_ERR_ARG, "bam_piece: target %d: more bytes than announced", tid);
+    c->cur_tid = tid;
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t0 = now();
+    // the copy first (asynchronous, on the upload stream), the header hop meanwhile
+    HIP_TRY(c, hipMemcpyAsync((uint8_t *)st.dev.p + st.got, piece, (size_t)bytes, hipMemcpyHostToDevice, c->stream_up));
+    const int64_t tk = ++c->up_ticket;
+    hipEvent_t &ev = c->up_events[(size_t)(tk % (int64_t)PJB_UP_EVENTS)];
+    if (!ev) HIP_TRY(c, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    else if (tk - c->up_done >= (int64_t)PJB_UP_EVENTS) { // the ring is full: its oldest copy must have completed
+        HIP_TRY(c, hipEventSynchronize(ev));
+        c->up_done = std::max<int64_t>(c->up_done, tk - (int64_t)PJB_UP_EVENTS);
+    }
+    HIP_TRY(c, hipEventRecord(ev, c->stream_up));
+    st.t_up += now() - t0;
+    t0 = now();
+    int rc = stage_scan(c, st, piece, st.got, bytes);
+    if (rc) return rc;
+    st.got += bytes;
+    // keep what the next piece's first block may still need: everything from st.next on, if it is short (a block is
+    // at most 64 KB), else nothing (the block then starts in a later piece)
+    if (st.next < st.got) {
+        const int64_t from = st.next;
+        const int64_t n = st.got - from;
+        if (n > (int64_t)sizeof st.keep) return fail(c, PJB_ERR_BGZF, "BGZF block at byte %lld is longer than 64 KB", (long long)from);
+        uint8_t tmp[sizeof st.keep];
+        for (int64_t k = 0; k < n; k++) {
+            const int64_t off = from + k;
+            tmp[k] = off >= st.got - bytes ? piece[off - (st.got - bytes)] : st.keep[off - st.keep_at];
+        }
+        memcpy(st.keep, tmp, (size_t)n);
+        st.keep_at = from;
+        st.keep_n = n;
+    } else
+        st.keep_n = 0;
+    st.t_scan += now() - t0;
+    if (ticket) *ticket = tk;
+    return PJB_OK;
+}
+
+extern "C" int pjb_bam_pieces_done(pjb_ctx *c, int64_t *completed_ticket) {
+    if (!c || !completed_ticket) return PJB_ERR_ARG;
+    while (c->up_done < c->up_ticket) {
+        hipEvent_t ev = c->up_events[(size_t)((c->up_done + 1) % (int64_t)PJB_UP_EVENTS)];
+        if (!ev || hipEventQuery(ev) != hipSuccess) break;
+        c->up_done++;
+    }
+    (void)hipGetLastError(); // (hipErrorNotReady is not an error here)
+    *completed_ticket = c->up_done;
+    return PJB_OK;
+}
+
+extern "C" int pjb_bam_end(pjb_ctx *c, int32_t tid, int32_t first_uoffset, int64_t *n_records) {
+    if (!c) return PJB_ERR_ARG;
+    if (n_records) *n_records = 0;
+    auto it = c->bam_stage.find(tid);
+    if (it == c->bam_stage.end()) return fail(c, PJB_ERR_STATE, "bam_end: target %d was not begun (pjb_bam_begin)", tid);
+    std::unique_ptr<BamStage> st(it->second);
+    c->bam_stage.erase(it);
+    struct Return { // the device buffer goes back to the pool whatever happens (after the work that reads it)
+        pjb_ctx *c;
+        BamStage *st;
+        ~Return() {
+            (void)hipStreamSynchronize(c->stream);
+            if (st->dev.p) c->stage_pool.push_back(st->dev);
+        }
+    } ret{c, st.get()};
+    c->cur_tid = tid;
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    if (first_uoffset < 0) return fail(c, PJB_ERR_ARG, "bam_end: bad first_uoffset");
+    if (st->got != st->total) return fail(c, PJB_ERR_ARG, "bam_end: target %d: %lld of %lld bytes arrived", tid, (long long)st->got, (long long)st->total);
+    if (st->next != st->total) return fail(c, PJB_ERR_BGZF, "truncated BGZF block at byte %lld", (long long)st->next);
+    OpenContig &oc = c->open[tid];
+    if (!oc.batches.empty()) return fail(c, PJB_ERR_STATE, "bam_end: target %d already has batches (one call per target)", tid);
+    if (st->total_out == 0 || (int64_t)first_uoffset >= st->total_out) return PJB_OK;
+    // the service stream picks up behind the last copy
+    if (!c->ev_up) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_up, hipEventDisableTiming));
+    HIP_TRY(c, hipEventRecord(c->ev_up, c->stream_up));
+    HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_up, 0));
+    return ingest_staged(c, tid, oc, (const uint8_t *)st->dev.p, st->blocks, st->total, st->total_out, first_uoffset, n_records, st->t_scan, st->t_up);
 }

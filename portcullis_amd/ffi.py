@@ -25,7 +25,7 @@ EXPORTS = [
     "pjb_finish_contig_end", "pjb_collect",
     "pjb_clear_rows", "pjb_get_timing", "pjb_device_count", "pjb_get_kernel_timing", "pjb_reset_kernel_timing",
     "pjb_select_timed_kernels", "pjb_host_alloc", "pjb_host_free", "pjb_inflate_bgzf", "pjb_submit_bam", "pjb_collect_device", "pjb_set_row_mirror",
-    "pjb_extra_finish", "pjb_set_option", "pjb_filter_set_junctions", "pjb_filter_batch", "pjb_filt_features",
+    "pjb_extra_finish", "pjb_set_option", "pjb_bam_begin", "pjb_bam_piece", "pjb_bam_pieces_done", "pjb_bam_end", "pjb_filter_set_junctions", "pjb_filter_batch", "pjb_filt_features",
 ]
 N_FEATURES = 34
 KMER_TABLE = 3125 * 5
@@ -119,6 +119,10 @@ def load():
         L.pjb_submit_batch_device.argtypes = [C.c_void_p, C.c_int32, C.POINTER(PjbBatch)]
         L.pjb_finish_contig.argtypes = [C.c_void_p, C.c_int32, C.POINTER(PjbRegionResult)]
         L.pjb_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
+        L.pjb_bam_begin.argtypes = [C.c_void_p, C.c_int32, C.c_int64]
+        L.pjb_bam_piece.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
+        L.pjb_bam_pieces_done.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
+        L.pjb_bam_end.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_int64)]
         L.pjb_finish_contig_begin.argtypes = [C.c_void_p, C.c_int32]
         L.pjb_finish_contig_end.argtypes = [C.c_void_p, C.c_int32, C.POINTER(PjbRegionResult)]
         L.pjb_set_row_mirror.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
@@ -344,6 +348,26 @@ class Context:
 
     def clear_rows(self):
         self._check(self._L.pjb_clear_rows(self._h))
+
+    def submit_bam_pieces(self, tid, comp, first_uoffset, piece_sizes):
+        """submit_bam with the bytes handed over in pieces of the given sizes (cycled; pjb_bam_begin / _piece / _end)."""
+        comp = np.frombuffer(bytes(comp), dtype=np.uint8) if not isinstance(comp, np.ndarray) else comp
+        self._check(self._L.pjb_bam_begin(self._h, tid, len(comp)))
+        at, k, last = 0, 0, C.c_int64()
+        keep = []
+        while at < len(comp):
+            nb = min(int(piece_sizes[k % len(piece_sizes)]), len(comp) - at)
+            piece = np.ascontiguousarray(comp[at:at + nb])
+            keep.append(piece)
+            self._check(self._L.pjb_bam_piece(self._h, tid, piece.ctypes.data_as(C.c_void_p), nb, C.byref(last)))
+            at += nb
+            k += 1
+        n = C.c_int64()
+        self._check(self._L.pjb_bam_end(self._h, tid, first_uoffset, C.byref(n)))
+        done = C.c_int64()
+        self._check(self._L.pjb_bam_pieces_done(self._h, C.byref(done)))
+        assert done.value >= last.value  # (everything was consumed by _end)
+        return n.value
 
     def submit_bam(self, tid, comp, first_uoffset):
         """All alignments of target `tid` from the BGZF bytes `comp` (whole blocks, starting with the block

@@ -339,22 +339,39 @@ private:
             if (err.empty()) p.done->set_value(std::move(d));
             else p.done->set_exception(std::make_exception_ptr(JunctionBuilderException(err)));
         };
+        double tKind[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tIdle = 0, tCollect = 0;  // PJB_PROFILE_HOST: where this thread's time goes
+        const double tStart = HostProfile::now();
         for (;;) {
             Cmd c;
             {
                 std::unique_lock<std::mutex> lk(mu);
                 if (q.empty() && !pending.empty()) { // nothing to do for the next target yet: collect the oldest queued one
                     lk.unlock();
+                    const double t0 = HostProfile::now();
                     collectOldest();
+                    tCollect += HostProfile::now() - t0;
                     continue;
                 }
+                const double t0 = HostProfile::now();
                 cv.wait(lk, [&] { return !q.empty(); });
+                tIdle += HostProfile::now() - t0;
                 c = std::move(q.front());
                 q.pop_front();
                 cv.notify_all();
             }
+            struct KindTimer {
+                double* slot;
+                double t0 = HostProfile::now();
+                ~KindTimer() { *slot += HostProfile::now() - t0; }
+            } kindTimer{&tKind[(int)c.kind & 7]};
             if (c.kind == Cmd::STOP) {
                 while (!pending.empty()) collectOldest();
+                if (g_prof.on) {
+                    std::lock_guard<std::mutex> lk(g_prof.mu);
+                    cerr << "[host profile] device thread: alive " << (HostProfile::now() - tStart) << " s: idle " << tIdle << ", collect " << tCollect
+                         << ", GENOME " << tKind[(int)Cmd::GENOME] << ", BATCH " << tKind[(int)Cmd::BATCH] << ", BAM " << tKind[(int)Cmd::BAM]
+                         << ", FINISH " << tKind[(int)Cmd::FINISH] << ", EXTRA " << tKind[(int)Cmd::EXTRA] << endl;
+                }
                 break;
             }
             std::string err = fatal;
@@ -603,7 +620,11 @@ void JunctionBuilder::findJunctions() {
     pinnedPool.reset();
     if (deviceIngest) {
         struct stat bst;
-        if (stat(prepData.getSortedBamFilePath().c_str(), &bst) == 0 && (uint64_t)bst.st_size >= (8ull << 30)) pinnedPool.reset(new PinnedPool(3));
+        if (stat(prepData.getSortedBamFilePath().c_str(), &bst) == 0 && (uint64_t)bst.st_size >= (8ull << 30)) {
+            size_t nbuf = 3;
+            if (const char* e = getenv("PORTCULLIS_PINNED_BUFFERS")) nbuf = (size_t)std::max(1, atoi(e));
+            pinnedPool.reset(new PinnedPool(nbuf));
+        }
     }
     // one device thread per GPU in use; decode workers are assigned round robin
     const int ndevWanted = devices > 0 ? devices : 0;

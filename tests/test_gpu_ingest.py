@@ -295,7 +295,7 @@ def bam_targets(path):
     return raw, refs, first
 
 
-def run_targets_from_bam(ctx, orc, path, genomes, orientation="UNKNOWN"):
+def run_targets_from_bam(ctx, orc, path, genomes, orientation="UNKNOWN", piece_sizes=None):
     from parity import assert_rows_equal, region_equal
     from util_bam import read_bam, records_to_batch
     raw, refs, first = bam_targets(path)
@@ -308,7 +308,7 @@ def run_targets_from_bam(ctx, orc, path, genomes, orientation="UNKNOWN"):
         orows, oreg = orc.find_juncs(tid, refs[tid][1], genomes[tid], batch, orientation)
         ctx.upload_contig(tid, genomes[tid])
         ctx.clear_rows()
-        n = ctx.submit_bam(tid, raw[coff:], uoff)
+        n = ctx.submit_bam(tid, raw[coff:], uoff) if piece_sizes is None else ctx.submit_bam_pieces(tid, raw[coff:], uoff, piece_sizes)
         assert n == len(mine)
         dreg = ctx.finish_contig(tid)
         drows = ctx.collect()
@@ -353,6 +353,44 @@ def test_submit_bam_matches_oracle(orc, tmp_path, block_size):
     write_bam(path, refs, reads, block_size=block_size)
     with ffi.Context(0, "FR") as ctx:
         assert run_targets_from_bam(ctx, orc, path, genomes, "FR") > 50
+
+
+@pytest.mark.parametrize("block_size,pieces", [(0xFF00, [100000]), (700, [1, 17, 5000, 3]), (4096, [4096]), (0xFF00, [7, 65536 + 300])])
+def test_submit_bam_in_pieces(orc, tmp_path, block_size, pieces):
+    """pjb_bam_begin / _piece / _end: the same bytes in pieces that cut BGZF headers, footers and payloads anywhere
+    (pieces shorter than a header, a piece boundary on every block boundary, ...) give the same rows."""
+    from fuzzgen import make_reads
+    from portcullis_amd import ffi
+    from util_bam import write_bam
+    reads, refs, genomes = [], [], {}
+    for tid in range(2):
+        genome, rs = make_reads(50 + tid, n_reads=1200 + 700 * tid, paired=(tid == 1))
+        refs.append((f"chr{tid + 1}", len(genome)))
+        genomes[tid] = genome.encode() if isinstance(genome, str) else genome
+        for k, r in enumerate(rs):
+            r = dict(r)
+            r["tid"] = tid
+            if r.get("mtid", -1) >= 0:
+                r["mtid"] = tid
+            r["name"] = f"t{tid}r{k}"
+            reads.append(r)
+    path = str(tmp_path / "p.bam")
+    write_bam(path, refs, reads, block_size=block_size)
+    with ffi.Context(0, "FR") as ctx:
+        assert run_targets_from_bam(ctx, orc, path, genomes, "FR", piece_sizes=pieces) > 30
+        # protocol errors: a piece for a target that was not begun, more bytes than announced, an end before all bytes
+        raw = open(path, "rb").read()
+        with pytest.raises(ffi.PjbError):
+            ctx.submit_bam_pieces(0, raw[:100], 0, [40])          # truncated block
+        ctx._check(ctx._L.pjb_bam_begin(ctx._h, 1, 1000))
+        import ctypes as C
+        buf = np.frombuffer(raw[:2000], dtype=np.uint8).copy()
+        assert ctx._L.pjb_bam_piece(ctx._h, 1, buf.ctypes.data_as(C.c_void_p), 2000, None) != 0   # more than announced (drops the staging)
+        assert ctx._L.pjb_bam_piece(ctx._h, 1, buf.ctypes.data_as(C.c_void_p), 10, None) != 0     # ... so: not begun
+        ctx._check(ctx._L.pjb_bam_begin(ctx._h, 1, 1000))
+        assert ctx._L.pjb_bam_end(ctx._h, 1, 0, None) != 0          # 0 of 1000 bytes arrived
+        assert ctx._L.pjb_bam_piece(ctx._h, 0, buf.ctypes.data_as(C.c_void_p), 10, None) != 0      # never begun (the failed run above was dropped)
+        assert run_targets_from_bam(ctx, orc, path, genomes, "FR", piece_sizes=pieces) > 30       # and the context still works
 
 
 def test_submit_bam_reference_fixture(orc, golden_dir):
