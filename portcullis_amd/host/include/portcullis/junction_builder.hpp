@@ -56,7 +56,8 @@ class JunctionBuilder {
     int hostThreads = 0;           // 0 = use `threads`; otherwise total host decode threads
     size_t batchRecords = 1 << 20; // alignments per batch sent to the device
     int innerThreads = 1;          // decode threads inside one target sequence (set by findJunctions)
-    std::shared_ptr<class PinnedPool> pinnedPool;  // page-locked file buffers of large device-ingest runs
+    std::shared_ptr<class PinnedPool> pinnedPool;  // ring of page-locked pieces for the file bytes of large device-ingest runs
+    size_t pieceMinTarget = 0;                     // targets with fewer bytes go over in one (pageable) block
     bool deviceIngest = true;      // BGZF inflate + BAM record parse on the GPU (pjb_submit_bam); false: host threads
 
     std::shared_future<int> deviceCount;  // pjb_device_count() evaluated in the background

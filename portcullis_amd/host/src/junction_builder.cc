@@ -213,8 +213,11 @@ class PinnedPool {
     std::condition_variable cv;
     std::vector<Buf> bufs;
 
+    size_t pieceBytes = 0;  // > 0: every buffer has exactly this size (the ring of pieces of the streaming ingest)
+
 public:
-    explicit PinnedPool(size_t n) : bufs(n) {}
+    explicit PinnedPool(size_t n, size_t piece = 0) : bufs(n), pieceBytes(piece) {}
+    size_t piece() const { return pieceBytes; }
     ~PinnedPool() {
         for (auto& b : bufs) pjb_host_free(b.p);
     }
@@ -263,7 +266,7 @@ struct ContigDone {
 class DeviceThread {
 public:
     struct Cmd {
-        enum Kind { GENOME, BATCH, BAM, FINISH, EXTRA, STOP } kind = STOP;
+        enum Kind { GENOME, BATCH, BAM, FINISH, EXTRA, STOP, BAMBEGIN, BAMPIECE, BAMEND } kind = STOP;
         int32_t tid = -1;
         std::string genome;
         bam::ReadBatch batch;
@@ -339,7 +342,24 @@ private:
             if (err.empty()) p.done->set_value(std::move(d));
             else p.done->set_exception(std::make_exception_ptr(JunctionBuilderException(err)));
         };
-        double tKind[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tIdle = 0, tCollect = 0;  // PJB_PROFILE_HOST: where this thread's time goes
+        double tKind[16] = {0}, tIdle = 0, tCollect = 0;  // PJB_PROFILE_HOST: where this thread's time goes
+        // pieces of file bytes whose copy to the device is in flight: (ticket, buffer, pool); released when pjb_bam_pieces_done
+        // says the copy has left the buffer
+        struct InFlight {
+            int64_t ticket;
+            uint8_t* buf;
+            PinnedPool* pool;
+        };
+        std::deque<InFlight> inflight;
+        auto releaseDone = [&](bool all) {
+            if (inflight.empty() || !ctx) return;
+            int64_t done = 0;
+            if (pjb_bam_pieces_done(ctx, &done) != PJB_OK) done = all ? INT64_MAX : 0;
+            while (!inflight.empty() && (all || inflight.front().ticket <= done)) {
+                inflight.front().pool->release(inflight.front().buf);
+                inflight.pop_front();
+            }
+        };
         const double tStart = HostProfile::now();
         for (;;) {
             Cmd c;
@@ -353,7 +373,15 @@ private:
                     continue;
                 }
                 const double t0 = HostProfile::now();
-                cv.wait(lk, [&] { return !q.empty(); });
+                while (q.empty()) {
+                    if (inflight.empty()) cv.wait(lk, [&] { return !q.empty(); });
+                    else {  // a worker may be waiting for one of the pieces in flight: keep handing them back
+                        cv.wait_for(lk, std::chrono::microseconds(200), [&] { return !q.empty(); });
+                        lk.unlock();
+                        releaseDone(false);
+                        lk.lock();
+                    }
+                }
                 tIdle += HostProfile::now() - t0;
                 c = std::move(q.front());
                 q.pop_front();
@@ -363,14 +391,17 @@ private:
                 double* slot;
                 double t0 = HostProfile::now();
                 ~KindTimer() { *slot += HostProfile::now() - t0; }
-            } kindTimer{&tKind[(int)c.kind & 7]};
+            } kindTimer{&tKind[(int)c.kind & 15]};
+            releaseDone(false);
             if (c.kind == Cmd::STOP) {
                 while (!pending.empty()) collectOldest();
+                releaseDone(true);
                 if (g_prof.on) {
                     std::lock_guard<std::mutex> lk(g_prof.mu);
                     cerr << "[host profile] device thread: alive " << (HostProfile::now() - tStart) << " s: idle " << tIdle << ", collect " << tCollect
                          << ", GENOME " << tKind[(int)Cmd::GENOME] << ", BATCH " << tKind[(int)Cmd::BATCH] << ", BAM " << tKind[(int)Cmd::BAM]
-                         << ", FINISH " << tKind[(int)Cmd::FINISH] << ", EXTRA " << tKind[(int)Cmd::EXTRA] << endl;
+                         << ", BAMPIECE " << tKind[(int)Cmd::BAMPIECE] << ", BAMEND " << tKind[(int)Cmd::BAMEND] << ", FINISH "
+                         << tKind[(int)Cmd::FINISH] << ", EXTRA " << tKind[(int)Cmd::EXTRA] << endl;
                 }
                 break;
             }
@@ -396,6 +427,29 @@ private:
                                     " (--ingest host decodes the file on the host threads and streams batches instead)";
                 if (c.bamPool) c.bamPool->release(c.bamBytes);
                 else bam::bigFree(c.bamBytes);
+                c.bamDone->set_value(n);
+            } else if (c.kind == Cmd::BAMBEGIN) {
+                if (err.empty() && pjb_bam_begin(ctx, c.tid, (int64_t)c.bamSize) != PJB_OK)
+                    failed[c.tid] = std::string("pjb_bam_begin: ") + pjb_last_error(ctx);
+            } else if (c.kind == Cmd::BAMPIECE) {
+                int64_t ticket = 0;
+                bool queued = false;
+                if (err.empty()) {
+                    if (pjb_bam_piece(ctx, c.tid, c.bamBytes, (int64_t)c.bamSize, &ticket) != PJB_OK)
+                        failed[c.tid] = std::string("pjb_bam_piece: ") + pjb_last_error(ctx) +
+                                        " (--ingest host decodes the file on the host threads and streams batches instead)";
+                    else
+                        queued = true;
+                }
+                if (queued) inflight.push_back(InFlight{ticket, c.bamBytes, c.bamPool});
+                else c.bamPool->release(c.bamBytes);  // (a failing piece call has waited for the upload stream)
+            } else if (c.kind == Cmd::BAMEND) {
+                int64_t n = 0;
+                if (!err.empty() && ctx) (void)pjb_bam_end(ctx, c.tid, (int32_t)c.bamFirst, nullptr);  // (drops what was staged)
+                if (err.empty() && pjb_bam_end(ctx, c.tid, (int32_t)c.bamFirst, &n) != PJB_OK)
+                    failed[c.tid] = std::string("pjb_bam_end: ") + pjb_last_error(ctx) +
+                                    " (--ingest host decodes the file on the host threads and streams batches instead)";
+                releaseDone(false);
                 c.bamDone->set_value(n);
             } else if (c.kind == Cmd::FINISH) {
                 if (err.empty()) {
@@ -488,8 +542,52 @@ void JunctionBuilder::findJuncs(DeviceThread& device, BamReader& reader, GenomeM
                 uint64_t fileOff = 0;
                 uint8_t* bytes = nullptr;
                 PinnedPool* pool = nullptr;
-                if (reader.regionSpan(seq, fileOff, nb, firstU)) {
-                    if (pinnedPool && nb >= ((size_t)64 << 20) && (bytes = pinnedPool->acquire(nb + 64)) != nullptr) pool = pinnedPool.get();
+                if (reader.regionSpan(seq, fileOff, nb, firstU) && pinnedPool && pinnedPool->piece() > 0 && nb >= pieceMinTarget) {
+                    // large target of a large file: the bytes go to the device in pieces through a small ring of
+                    // page-locked buffers (page-locking a buffer per target costs ~0.15 s per GB); the device thread
+                    // copies a piece while this thread reads the next one
+                    const size_t piece = pinnedPool->piece();
+                    DeviceThread::Cmd b0;
+                    b0.kind = DeviceThread::Cmd::BAMBEGIN;
+                    b0.tid = seq;
+                    b0.bamSize = nb;
+                    device.push(std::move(b0));
+                    std::string readError;
+                    for (size_t off = 0; off < nb; off += piece) {
+                        const size_t n = std::min(piece, nb - off);
+                        uint8_t* buf = pinnedPool->acquire(piece);
+                        if (!buf) {
+                            readError = "out of page-locked memory for the file pieces";
+                            break;
+                        }
+                        try {
+                            reader.readSpan(fileOff + off, n, buf, innerThreads);
+                        } catch (const std::exception& e) {
+                            pinnedPool->release(buf);
+                            readError = e.what();
+                            break;
+                        }
+                        DeviceThread::Cmd c;
+                        c.kind = DeviceThread::Cmd::BAMPIECE;
+                        c.tid = seq;
+                        c.bamBytes = buf;
+                        c.bamSize = n;
+                        c.bamPool = pinnedPool.get();
+                        device.push(std::move(c));
+                    }
+                    std::promise<int64_t> got;
+                    std::future<int64_t> f = got.get_future();
+                    DeviceThread::Cmd c;
+                    c.kind = DeviceThread::Cmd::BAMEND;  // (after a read error: fails with "n of m bytes arrived" and drops the staging)
+                    c.tid = seq;
+                    c.bamFirst = firstU;
+                    c.bamDone = &got;
+                    device.push(std::move(c));
+                    any = f.get() > 0;
+                    if (!readError.empty()) throw bam::BamException(readError);
+                    nb = 0;  // (handled)
+                }
+                if (nb && reader.regionSpan(seq, fileOff, nb, firstU)) {
                     if (!bytes) bytes = (uint8_t*)bam::bigAlloc(nb + 64);
                     try {
                         reader.readSpan(fileOff, nb, bytes, innerThreads);
@@ -620,10 +718,17 @@ void JunctionBuilder::findJunctions() {
     pinnedPool.reset();
     if (deviceIngest) {
         struct stat bst;
-        if (stat(prepData.getSortedBamFilePath().c_str(), &bst) == 0 && (uint64_t)bst.st_size >= (8ull << 30)) {
-            size_t nbuf = 3;
-            if (const char* e = getenv("PORTCULLIS_PINNED_BUFFERS")) nbuf = (size_t)std::max(1, atoi(e));
-            pinnedPool.reset(new PinnedPool(nbuf));
+        uint64_t minFile = 8ull << 30;
+        pieceMinTarget = (size_t)64 << 20;
+        size_t nbuf = 12, pieceBytes = (size_t)128 << 20;  // 1.5 GB of page-locked memory in all
+        if (const char* e = getenv("PORTCULLIS_PINNED_BUFFERS")) nbuf = (size_t)std::max(2, atoi(e));
+        if (const char* e = getenv("PORTCULLIS_PIECE_BYTES")) {  // (tests: small files in small pieces)
+            pieceBytes = (size_t)std::max(64, atoi(e));
+            minFile = 0;
+            pieceMinTarget = 0;
+        }
+        if (stat(prepData.getSortedBamFilePath().c_str(), &bst) == 0 && (uint64_t)bst.st_size >= minFile) {
+            pinnedPool.reset(new PinnedPool(nbuf, pieceBytes));
         }
     }
     // one device thread per GPU in use; decode workers are assigned round robin

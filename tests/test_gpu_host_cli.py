@@ -214,6 +214,17 @@ def test_device_ingest_multi_contig(tmp_path, orc, block_size, threads):
     check(prep, tmp_path, orc, "FR", threads=threads, extra_opts=("--ingest", "device"))
 
 
+@pytest.mark.parametrize("piece_bytes,threads", [(4096, 3), (70000, 1), (333, 4)])
+def test_device_ingest_in_pieces(tmp_path, orc, monkeypatch, piece_bytes, threads):
+    """The file bytes of a target go to the device in pieces through the ring of page-locked buffers (pjb_bam_begin /
+    _piece / _end; what large files do): same outputs byte for byte, pieces smaller and larger than a BGZF block, more
+    workers than ring buffers."""
+    monkeypatch.setenv("PORTCULLIS_PIECE_BYTES", str(piece_bytes))
+    monkeypatch.setenv("PORTCULLIS_PINNED_BUFFERS", "3")
+    prep = multi_contig(tmp_path, [81, None, 82, 83, 84], block_size=2000)
+    check(prep, tmp_path, orc, "FR", threads=threads, extra_opts=("--ingest", "device"))
+
+
 @pytest.mark.parametrize("ingest", ["device", "host"])
 def test_unmapped_tail(tmp_path, orc, ingest):
     """Thousands of unplaced reads after the last target: the index's last chunk end bounds what is read."""
