@@ -172,6 +172,7 @@ struct pjb_ctx {
     // buffers with a rest state that the kernel chain itself restores (no per-contig memsets): error word / list
     // counters (k7_publish; per slot), start bitmap / end slots (kd_reset).  false: set by a memset before use
     int last_slot = 0; // slot of the contig collected last (pjb_collect_device)
+    int inflate_lanes = 512 * 64;                // lanes of one bgzf_inflate launch (2 workgroups x 256 CUs; set from the device at create)
     bool side_stream = true;                     // k4a_simple beside the sort (PJB_SIDE_STREAM=0: on the main stream)
     bool dense_ids = true;                       // K2d (PJB_DENSE_IDS=0 sorts the full keys as round 1 did)
     u32 junc_seen = 0;                           // most junctions a contig has had so far (junction limit of the next contig)
@@ -474,6 +475,7 @@ int pjb_create(pjb_ctx **out, const pjb_config *cfg) {
     hipDeviceProp_t prop;
     e = hipGetDeviceProperties(&prop, cfg->device);
     if (e != hipSuccess) return fail(nullptr, PJB_ERR_HIP, "hipGetDeviceProperties: %s", hipGetErrorString(e));
+    const int n_cu = prop.multiProcessorCount;
     if (prop.warpSize != 64)
         return fail(nullptr, PJB_ERR_NO_DEVICE, "device %d (%s) is not a wave64 CDNA device", cfg->device, prop.gcnArchName);
     pjb_ctx *c = new (std::nothrow) pjb_ctx();
@@ -502,6 +504,7 @@ int pjb_create(pjb_ctx **out, const pjb_config *cfg) {
         (void)hipStreamCreateWithFlags(&S.main, hipStreamNonBlocking);
         (void)hipStreamCreateWithFlags(&S.side, hipStreamNonBlocking);
     }
+    c->inflate_lanes = std::max(1, n_cu) * (160 * 1024 / I2_LDS_BYTES) * 64;
     c->ktime = (cfg->flags & PJB_FLAG_KERNEL_TIMING) != 0;
     c->extra = (cfg->flags & PJB_FLAG_EXTRA) != 0;
     if (const char *s = getenv("PJB_DENSE_IDS")) c->dense_ids = atoi(s) != 0;
@@ -1905,7 +1908,6 @@ int upload_staged(pjb_ctx *c, void *dst, const uint8_t *src, size_t bytes) {
     return PJB_OK;
 }
 
-constexpr uint32_t INF_BLOCKS_PER_LAUNCH = 1u << 18; // bounds the per-lane scratch (80 MB); two 64-lane workgroups fit a CU's LDS
 
 // comp already on the device (padded); blocks on the host
 int inflate_on_device(pjb_ctx *c, const uint8_t *d_comp, const std::vector<InfBlock> &blocks, uint8_t *d_out) {
@@ -1913,20 +1915,21 @@ int inflate_on_device(pjb_ctx *c, const uint8_t *d_comp, const std::vector<InfBl
     const size_t nb = blocks.size();
     if (nb == 0) return PJB_OK;
     if ((rc = ensure(c, c->b_inf_blocks, nb * sizeof(InfBlock)))) return rc;
-    if ((rc = ensure(c, c->b_inf_status, nb * 4 + 4))) return rc;
-    size_t per_launch = std::min<size_t>(nb, INF_BLOCKS_PER_LAUNCH);
-    if (const char *e = getenv("PJB_INF_BLOCKS_PER_LAUNCH")) per_launch = std::min<size_t>(nb, std::max(64, atoi(e))); // tests: several launches
-    if ((rc = ensure(c, c->b_inf_scratch, ((per_launch + 63) / 64 * 64) * INF_SCRATCH_PER_LANE))) return rc;
+    if ((rc = ensure(c, c->b_inf_status, nb * 4 + 16))) return rc;
+    // one launch: as many lanes as the chip holds at once (two 64-lane workgroups per CU: the tables' LDS), each taking
+    // block after block from a counter
+    size_t lanes = std::min<size_t>((nb + 63) / 64 * 64, (size_t)c->inflate_lanes);
+    if (const char *e = getenv("PJB_INF_BLOCKS_PER_LAUNCH")) lanes = std::min<size_t>((nb + 63) / 64 * 64, (size_t)std::max(64, atoi(e)) / 64 * 64); // tests: few lanes, long lists
+    if ((rc = ensure(c, c->b_inf_scratch, lanes * INF_SCRATCH_PER_LANE))) return rc;
     hipStream_t st = c->stream;
     HIP_TRY(c, hipMemcpyAsync(c->b_inf_blocks.p, blocks.data(), nb * sizeof(InfBlock), hipMemcpyHostToDevice, st));
     int *d_status = (int *)c->b_inf_status.p;
     int *d_any = d_status + nb;
-    HIP_TRY(c, hipMemsetAsync(d_any, 0, 4, st));
-    for (size_t b0 = 0; b0 < nb; b0 += per_launch) {
-        const uint32_t cnt = (uint32_t)std::min(per_launch, nb - b0);
-        LAUNCH_LDS(c, "bgzf_inflate", bgzf_inflate, dim3((cnt + 63) / 64), dim3(64), I2_LDS_BYTES, d_comp,
-                   (const InfBlock *)c->b_inf_blocks.p + b0, cnt, d_out, (uint8_t *)c->b_inf_scratch.p, d_status + b0, d_any);
-    }
+    iu32 *d_next = (iu32 *)(d_any + 1);
+    const iu32 ctl[2] = {0u, (iu32)lanes};
+    HIP_TRY(c, hipMemcpyAsync(d_any, ctl, 8, hipMemcpyHostToDevice, st));
+    LAUNCH_LDS(c, "bgzf_inflate", bgzf_inflate, dim3((unsigned)(lanes / 64)), dim3(64), I2_LDS_BYTES, d_comp, (const InfBlock *)c->b_inf_blocks.p, (iu32)nb,
+               d_out, (uint8_t *)c->b_inf_scratch.p, d_status, d_any, d_next);
     int any = 0;
     HIP_TRY(c, hipMemcpyAsync(&any, d_any, 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(c, hipStreamSynchronize(st));

@@ -273,7 +273,7 @@ struct Ring2 { // 16-word LDS ring + bit buffer
 };
 
 __global__ __launch_bounds__(64) void bgzf_inflate(const uint8_t *comp, const InfBlock *blocks, iu32 n_blocks, uint8_t *out,
-                                                     uint8_t *scratch, int *status, int *any_error) {
+                                                     uint8_t *scratch, int *status, int *any_error, iu32 *next_block) {
     extern __shared__ __attribute__((aligned(16))) unsigned short inf_lds[];
     // shared tables behind the per-lane areas
     iu32 *s_len = (iu32 *)(inf_lds + (size_t)I2_LANE_U16 * 64); // base | extra bits << 16
@@ -281,18 +281,23 @@ __global__ __launch_bounds__(64) void bgzf_inflate(const uint8_t *comp, const In
     if (threadIdx.x < 29) s_len[threadIdx.x] = (iu32)c_len_base[threadIdx.x] | ((iu32)c_len_extra[threadIdx.x] << 16);
     if (threadIdx.x < 30) s_dist[threadIdx.x] = (iu32)c_dist_base[threadIdx.x] | ((iu32)c_dist_extra[threadIdx.x] << 16);
     __syncthreads();
-    const iu32 b = blockIdx.x * 64 + threadIdx.x;
-    const bool have = b < n_blocks;
+    // A lane decodes one BGZF block at a time and takes the next one from a counter when it is done (*next_block starts
+    // at the number of lanes launched): a block is 40 ms of dependent work whatever runs beside it, so the launch is
+    // sized to what the chip holds at once and every lane stays busy until the list is empty, instead of one block per
+    // lane with the wave waiting for its slowest lane and the last round of a target a quarter full.
+    iu32 b = blockIdx.x * 64 + threadIdx.x;
+    bool have = b < n_blocks;
     Lane2 L;
     L.p = inf_lds + threadIdx.x * 2;
-    uint8_t *lens = scratch + (size_t)b * INF_SCRATCH_PER_LANE;
+    uint8_t *lens = scratch + (size_t)(blockIdx.x * 64 + threadIdx.x) * INF_SCRATCH_PER_LANE; // (scratch belongs to the lane, not the block)
     InfBlock B;
     B.in_off = B.out_off = 0;
     B.in_len = B.out_len = 0;
     if (have) B = blocks[b];
     const uint8_t *in0 = comp + B.in_off, *in_end = in0 + B.in_len;
     uint8_t *base = out + B.out_off;
-    const iu32 out_len = B.out_len;
+    iu32 out_len = B.out_len;
+    bool more = true; // the list may still hold blocks
     enum { ST_HEADER, ST_SYMBOLS, ST_DONE };
     int state = have ? ST_HEADER : ST_DONE;
     int err = 0;
@@ -404,7 +409,45 @@ __global__ __launch_bounds__(64) void bgzf_inflate(const uint8_t *comp, const In
         qn = 0;
     };
 
-    while (__any(state != ST_DONE)) {
+    for (;;) {
+        // ---- lanes that finished their block: results out, queue drained (its entries are relative to the old block),
+        // next block in
+        if (__any(state == ST_DONE && more)) {
+            memory_phase(); // (everybody: a phase is a round trip for the whole wave anyway)
+            const bool fin = state == ST_DONE && more;
+            if (fin && have) {
+                if (!err && pos != out_len) err = INF_ERR_SIZE;
+                status[b] = err;
+                if (err) atomicOr(any_error, 1);
+            }
+            const iu64 fm = __ballot(fin);
+            iu32 first_new = 0;
+            const int leader = __ffsll((long long)fm) - 1;
+            if ((int)threadIdx.x == leader) first_new = atomicAdd(next_block, (iu32)__popcll(fm));
+            first_new = __shfl(first_new, leader, 64);
+            if (fin) {
+                b = first_new + (iu32)__popcll(fm & ((1ull << threadIdx.x) - 1ull));
+                have = b < n_blocks;
+                more = have;
+                if (have) {
+                    B = blocks[b];
+                    in0 = comp + B.in_off;
+                    in_end = in0 + B.in_len;
+                    base = out + B.out_off;
+                    out_len = B.out_len;
+                    err = 0;
+                    last = false;
+                    bitpos = 0;
+                    pos = 0;
+                    R.ri = R.rf = 0;
+                    R.gp = in0;
+                    R.bb = 0;
+                    R.nb = 0;
+                    state = ST_HEADER;
+                }
+            }
+        }
+        if (!__any(state != ST_DONE)) break;
         if (state == ST_HEADER) {
             // ---- block header and tables, read straight from the stream
             BitReader br;
@@ -618,12 +661,6 @@ __global__ __launch_bounds__(64) void bgzf_inflate(const uint8_t *comp, const In
             qn++;
             pos += len;
         }
-    }
-    memory_phase(); // what is still queued
-    if (have) {
-        if (!err && pos != out_len) err = INF_ERR_SIZE;
-        status[b] = err;
-        if (err) atomicOr(any_error, 1);
     }
 }
 

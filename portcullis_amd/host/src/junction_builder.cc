@@ -73,6 +73,12 @@ JunctionBuilder::JunctionBuilder(const std::string& prepDir, const std::string& 
 namespace {
 struct HostProfile {  // PJB_PROFILE_HOST=1: where the host side of findJuncs spends its time
     bool on = getenv("PJB_PROFILE_HOST") != nullptr;
+    double t0 = now();  // (static initialisation: about when the process starts)
+    void mark(const char* what) {
+        if (!on) return;
+        std::lock_guard<std::mutex> lk(mu);
+        std::cerr << "[host profile] t=" << (now() - t0) << " s: " << what << std::endl;
+    }
     std::mutex mu;
     double genome = 0, submit = 0, finish = 0, total = 0;
     static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
@@ -130,6 +136,7 @@ void JunctionBuilder::process() {
         WallTimer t;
         junctionSystem.saveAll(outDir + "/" + outputPrefix, source, false, outputExonGFF, outputIntronGFF);
     }
+    g_prof.mark("outputs written");
     if (g_prof.on)
         cerr << "[host profile] process: header+index " << (t_p1 - t_p0) << " s, findJunctions " << (t_p2 - t_p1) << " s, saveAll "
              << (HostProfile::now() - t_p2) << " s" << endl;
@@ -342,6 +349,7 @@ private:
             if (err.empty()) p.done->set_value(std::move(d));
             else p.done->set_exception(std::make_exception_ptr(JunctionBuilderException(err)));
         };
+        g_prof.mark("device thread: context ready");
         double tKind[16] = {0}, tIdle = 0, tCollect = 0;  // PJB_PROFILE_HOST: where this thread's time goes
         // pieces of file bytes whose copy to the device is in flight: (ticket, buffer, pool); released when pjb_bam_pieces_done
         // says the copy has left the buffer
@@ -720,8 +728,9 @@ void JunctionBuilder::findJunctions() {
         struct stat bst;
         uint64_t minFile = 8ull << 30;
         pieceMinTarget = (size_t)64 << 20;
-        size_t nbuf = 12, pieceBytes = (size_t)128 << 20;  // 1.5 GB of page-locked memory in all
+        size_t nbuf = 12, pieceBytes = (size_t)64 << 20;  // 0.75 GB of page-locked memory in all (64 MB pieces measured best of 32 / 64 / 128)
         if (const char* e = getenv("PORTCULLIS_PINNED_BUFFERS")) nbuf = (size_t)std::max(2, atoi(e));
+        if (const char* e = getenv("PORTCULLIS_PIECE_MB")) pieceBytes = (size_t)std::max(1, atoi(e)) << 20;
         if (const char* e = getenv("PORTCULLIS_PIECE_BYTES")) {  // (tests: small files in small pieces)
             pieceBytes = (size_t)std::max(64, atoi(e));
             minFile = 0;
@@ -778,6 +787,7 @@ void JunctionBuilder::findJunctions() {
         }
     };
     const double t_workers0 = HostProfile::now();
+    g_prof.mark("workers start");
     cout << " done." << endl;
     cout << "Finding junctions and calculating basic metrics:" << endl;
     cout << " - Queueing " << refs->size() << " target sequences for processing in the thread pool" << endl;
@@ -813,6 +823,7 @@ void JunctionBuilder::findJunctions() {
     deviceThreads.clear();  // joins the device threads (destroys the contexts)
     if (!firstError.empty()) throw JunctionBuilderException(firstError);
     const double t_workers1 = HostProfile::now();
+    g_prof.mark("workers and device threads done");
     cout << " - All threads completed." << endl << " - Combining results from threads." << endl << endl;
     uint64_t unsplicedCount = 0, splicedCount = 0, sumQueryLengths = 0;
     int32_t minQueryLength = INT32_MAX, maxQueryLength = 0;
