@@ -16,8 +16,6 @@ namespace pjb {
 typedef unsigned long long iu64;
 typedef uint32_t iu32;
 
-constexpr int INF_ROOT_L = 8;        // first-level bits, literal/length code
-constexpr int INF_ROOT_D = 5;        // first-level bits, distance code
 constexpr int INF_PAD = 4096;        // zeroed bytes the compressed buffer carries after its last block
 constexpr int INF_LENS = 320;        // code lengths being read (288 + 32)
 constexpr size_t INF_SCRATCH_PER_LANE = INF_LENS; // global scratch per lane: the code lengths of the block header being read
@@ -144,18 +142,21 @@ constexpr int I2_QUEUE = 16;                    // queued matches per lane
 #define PJB_I2_LITS 3
 #endif
 constexpr int I2_LITS = PJB_I2_LITS;            // literals decoded per iteration before the (one) length/distance pair
-constexpr iu32 I2_LIT = 0;                      // u16 entry offsets inside a lane's LDS area
-constexpr iu32 I2_DIST = 256;                   // 32 entries
-constexpr iu32 I2_LLIM = 288, I2_LADJ = 304;    // literal/length tree: per code length, upper bound and slot adjustment of long codes
-constexpr iu32 I2_DLIM = 320, I2_DADJ = 336;    // distance tree
-constexpr iu32 I2_LLONG = 352;                  // symbols of long literal/length codes: 286 low bytes (143) + 286 high bits (18)
-constexpr iu32 I2_LLONG_HI = I2_LLONG + 143;
-constexpr iu32 I2_DLONG = I2_LLONG + 162;       // symbols of long distance codes: 30 bytes (15)
-constexpr iu32 I2_RING = I2_DLONG + 16;         // 16 words of input
+// u16 entry offsets inside a lane's LDS area.  There is no first-level lookup table: with 64 lanes some lane holds a
+// long code in every step, so the canonical search ran every time anyway -- and the 576 bytes of first-level tables
+// were what limited a CU to two workgroups (one wave on each of two SIMDs of four).  Every code is decoded
+// canonically: limits per code length in registers, symbols in code order in LDS.  612 B per lane: four workgroups
+// per CU, a wave on every SIMD.
+constexpr iu32 I2_LADJ = 0, I2_DADJ = 16;       // per code length: slot of its first code minus that code (mod 2^16)
+constexpr iu32 I2_LLONG = 32;                   // literal/length symbols in code order: 288 low bytes (144; the fixed code has 288) + 288 ninth bits (18)
+constexpr iu32 I2_LLONG_HI = I2_LLONG + 144;
+constexpr iu32 I2_DLONG = I2_LLONG + 162;       // distance symbols in code order: 30 bytes (15)
+constexpr iu32 I2_RING = I2_DLONG + 16;         // 16 words of input; while a block header is read: the table build's scratch
 constexpr iu32 I2_Q = I2_RING + 32;             // I2_QUEUE x 2 words
 constexpr iu32 I2_LANE_U16 = I2_Q + 4 * I2_QUEUE;
 constexpr int I2_LDS_BYTES = (int)I2_LANE_U16 * 2 * 64 + 256; // + the shared length / distance tables (2 x 32 words)
 static_assert(I2_LANE_U16 % 2 == 0 && I2_RING % 2 == 0 && I2_Q % 2 == 0, "word-aligned LDS areas");
+static_assert(4 * I2_LDS_BYTES <= 160 * 1024, "four workgroups per CU");
 
 struct Lane2 {
     unsigned short *p; // &lds[lane * 2]
@@ -168,96 +169,73 @@ struct Lane2 {
     }
 };
 
-// Tables of one tree.  root: first level (2^root_bits entries: symbol << 4 | len, 0x8000 = longer code, 0 = invalid).
-// Longer codes are decoded canonically: with v = the next 15 bits, first bit on top, the code length is the
-// smallest len with v < lim[len] (lim[len] = (first code + count of length len) << (15 - len), a non-decreasing
-// sequence), and the symbol is lng[(v >> (15 - len)) + adj[len]] where lng lists the long symbols in code
-// order (bytes, plus their 9th bit at lng_hi for the literal/length tree) and adj[len] = slot of the first
-// code of that length - that first code (mod 2^16).
+// Tables of one tree, canonical: with v = the next 15 bits, first bit on top, the code length is the smallest len with
+// v < lim[len] (lim[len] = (first code + count of length len) << (15 - len), a non-decreasing sequence: 1 + the
+// number of limits that v reaches), and the symbol is lng[(v >> (15 - len)) + adj[len]] where lng lists the symbols
+// in code order (bytes, plus their 9th bit at lng_hi for the literal/length tree) and adj[len] = slot of the first
+// code of that length - that first code (mod 2^16).  The limits live in registers (Lim), adj and lng in LDS.
 // `codes`: the tree of the code-length alphabet.  Like zlib's inflate_table (inftrees.c), an over-subscribed set is an
 // error and so is an incomplete one, except a literal/length or distance set that consists of a single 1-bit code.
-__device__ int inf2_build(const Lane2 L, iu32 root, int root_bits, iu32 lim, iu32 adj, iu32 lng, iu32 lng_hi, const uint8_t *lens, int n,
-                          bool codes = false) {
-    // lim / adj double as scratch: codes per length in lim, running code / slot in adj
-    for (int i = 0; i < 16; i++) L.h(lim + i) = 0;
-    for (int i = 0; i < n; i++) L.h(lim + lens[i]) = L.h(lim + lens[i]) + 1;
-    const iu32 rsize = 1u << root_bits;
-    for (iu32 e = 0; e < rsize; e++) L.h(root + e) = 0;
-    L.h(lim) = 0; // unused codes do not count
+struct Lim {
+    iu32 v[16]; // [1..15]
+};
+__device__ int inf2_build(const Lane2 L, Lim &lim, iu32 adj, iu32 lng, iu32 lng_hi, const uint8_t *lens, int n, bool codes = false) {
+    const iu32 cnt = I2_RING, run = I2_RING + 16; // scratch (the ring is dead while a header is read): codes per length, running slot
+    for (int i = 0; i < 16; i++) L.h(cnt + i) = 0;
+    for (int i = 0; i < n; i++) L.h(cnt + lens[i]) = L.h(cnt + lens[i]) + 1;
+    L.h(cnt) = 0; // unused codes do not count
     int left = 1, max_len = 0;
     for (int len = 1; len <= 15; len++) {
         left <<= 1;
-        left -= (int)L.h(lim + len);
+        left -= (int)L.h(cnt + len);
         if (left < 0) return INF_ERR_CODELENS;
-        if (L.h(lim + len)) max_len = len;
+        if (L.h(cnt + len)) max_len = len;
     }
     if (max_len > 0 && left > 0 && (codes || max_len != 1)) return INF_ERR_CODELENS; // incomplete set
-    // long symbols in code order
+    // symbols in code order: by length, then by symbol
     iu32 slot = 0;
-    for (int len = root_bits + 1; len <= 15; len++) {
-        L.h(adj + len) = (unsigned short)slot;
-        slot += L.h(lim + len);
-    }
-    for (int s = 0; s < n; s++) {
-        const int len = lens[s];
-        if (len > root_bits) {
-            const iu32 at = L.h(adj + len);
-            L.h(adj + len) = (unsigned short)(at + 1);
-            L.set_byte(lng, at, (iu32)s & 0xffu);
-            if (lng_hi) {
-                unsigned short &m = L.h(lng_hi + (at >> 4));
-                m = (unsigned short)((s & 0x100) ? (m | (1u << (at & 15))) : (m & ~(1u << (at & 15))));
-            }
-        }
-    }
-    // first level, with canonical codes assigned in symbol order
-    iu32 code = 0;
     for (int len = 1; len <= 15; len++) {
-        code = (code + (len > 1 ? L.h(lim + len - 1) : 0)) << 1;
-        L.h(adj + len) = (unsigned short)code;
+        L.h(run + len) = (unsigned short)slot;
+        slot += L.h(cnt + len);
     }
     for (int s = 0; s < n; s++) {
         const int len = lens[s];
         if (len == 0) continue;
-        const iu32 c = L.h(adj + len);
-        L.h(adj + len) = (unsigned short)(c + 1);
-        const iu32 rev = bitrev16(c, len);
-        if (len <= root_bits) {
-            const unsigned short ent = (unsigned short)(((iu32)s << 4) | (iu32)len);
-            for (iu32 e = rev; e < rsize; e += 1u << len) L.h(root + e) = ent;
-        } else {
-            L.h(root + (rev & (rsize - 1))) = 0x8000u;
+        const iu32 at = L.h(run + len);
+        L.h(run + len) = (unsigned short)(at + 1);
+        L.set_byte(lng, at, (iu32)s & 0xffu);
+        if (lng_hi) {
+            unsigned short &m = L.h(lng_hi + (at >> 4));
+            m = (unsigned short)((s & 0x100) ? (m | (1u << (at & 15))) : (m & ~(1u << (at & 15))));
         }
     }
-    // adj[len] holds first code + count now; lim[len] the count
+    // limits and adjustments from the canonical first codes
+    iu32 code = 0;
     slot = 0;
+    lim.v[0] = 0;
+#pragma unroll
     for (int len = 1; len <= 15; len++) {
-        const iu32 cnt = L.h(lim + len), end = L.h(adj + len), first = end - cnt;
-        L.h(lim + len) = (unsigned short)(end << (15 - len)); // <= 2^15
-        L.h(adj + len) = (unsigned short)(slot - first);
-        if (len > root_bits) slot += cnt;
+        const iu32 c = L.h(cnt + len);
+        code = (code + (len > 1 ? (iu32)L.h(cnt + len - 1) : 0u)) << 1; // first code of this length
+        lim.v[len] = (code + c) << (15 - len);                           // <= 2^15
+        L.h(adj + len) = (unsigned short)(slot - code);
+        slot += c;
     }
     return 0;
 }
 
 // symbol << 4 | len of the code at the low end of `bits` (at least 15 valid bits), 0 if invalid
-template <int ROOT_BITS>
-__device__ __forceinline__ iu32 inf2_decode(const Lane2 L, iu32 root, iu32 lim, iu32 adj, iu32 lng, iu32 lng_hi, iu32 bits) {
-    iu32 e = L.h(root + (bits & ((1u << ROOT_BITS) - 1u)));
-    if (e & 0x8000u) {
-        const iu32 v15 = __brev(bits) >> 17; // the next 15 bits, first bit in the top position
-        iu32 len = ROOT_BITS + 1;
+template <bool NINTH_BIT>
+__device__ __forceinline__ iu32 inf2_decode(const Lane2 L, const Lim &lim, iu32 adj, iu32 lng, iu32 lng_hi, iu32 bits) {
+    const iu32 v15 = __brev(bits) >> 17; // the next 15 bits, first bit in the top position
+    iu32 len = 1;
 #pragma unroll
-        for (int l = ROOT_BITS + 1; l <= 15; l++) len += v15 >= (iu32)L.h(lim + l) ? 1u : 0u; // independent reads, no branches
-        e = 0;
-        if (len <= 15) {
-            const iu32 i = ((v15 >> (15 - len)) + L.h(adj + len)) & 0x1ffu; // < 286 for a valid code set
-            iu32 sym = L.byte(lng, i);
-            if (lng_hi) sym |= ((L.h(lng_hi + (i >> 4)) >> (i & 15)) & 1u) << 8;
-            e = (sym << 4) | len;
-        }
-    }
-    return e;
+    for (int l = 1; l <= 15; l++) len += v15 >= lim.v[l] ? 1u : 0u; // registers, no branches
+    if (len > 15) return 0;
+    const iu32 i = ((v15 >> (15 - len)) + L.h(adj + len)) & 0x1ffu; // < 286 for a valid code set
+    iu32 sym = L.byte(lng, i);
+    if (NINTH_BIT) sym |= ((L.h(lng_hi + (i >> 4)) >> (i & 15)) & 1u) << 8;
+    return (sym << 4) | len;
 }
 
 // every vector memory operation of this wave has completed (vmcnt = 0, other counters untouched).  Placed where
@@ -310,6 +288,9 @@ __global__ __launch_bounds__(64) void bgzf_inflate(const uint8_t *comp, const In
     R.gp = in0;
     R.bb = 0;
     R.nb = 0;
+    Lim limL, limD; // code-length limits of the literal/length and the distance tree (registers)
+#pragma unroll
+    for (int k = 0; k < 16; k++) limL.v[k] = limD.v[k] = 0;
 
     // all lanes: top up the input rings and resolve the queued matches
     auto memory_phase = [&]() {
@@ -494,12 +475,12 @@ __global__ __launch_bounds__(64) void bgzf_inflate(const uint8_t *comp, const In
                     if (!err) {
                         for (int i = 0; i < 19; i++) lens[i] = 0;
                         for (int i = 0; i < ncl; i++) lens[c_clen_order[i]] = (uint8_t)take(3);
-                        err = inf2_build(L, I2_LIT, 7, I2_LLIM, I2_LADJ, I2_LLONG, 0, lens, 19, true);
+                        err = inf2_build(L, limL, I2_LADJ, I2_LLONG, 0, lens, 19, true); // (the code-length tree borrows the literal tree's places)
                     }
                     int i = 0;
                     while (!err && i < nlit + ndist) {
                         br.refill();
-                        const iu32 e = inf2_decode<7>(L, I2_LIT, I2_LLIM, I2_LADJ, I2_LLONG, 0, (iu32)br.bb);
+                        const iu32 e = inf2_decode<false>(L, limL, I2_LADJ, I2_LLONG, 0, (iu32)br.bb);
                         if (e == 0) {
                             err = INF_ERR_CODELENS;
                             break;
@@ -532,8 +513,8 @@ __global__ __launch_bounds__(64) void bgzf_inflate(const uint8_t *comp, const In
                     }
                     if (!err && lens[256] == 0) err = INF_ERR_CODELENS;
                 }
-                if (!err) err = inf2_build(L, I2_DIST, INF_ROOT_D, I2_DLIM, I2_DADJ, I2_DLONG, 0, lens + nlit, ndist);
-                if (!err) err = inf2_build(L, I2_LIT, INF_ROOT_L, I2_LLIM, I2_LADJ, I2_LLONG, I2_LLONG_HI, lens, nlit);
+                if (!err) err = inf2_build(L, limD, I2_DADJ, I2_DLONG, 0, lens + nlit, ndist);
+                if (!err) err = inf2_build(L, limL, I2_LADJ, I2_LLONG, I2_LLONG_HI, lens, nlit);
                 if (err) {
                     state = ST_DONE;
                 } else {
@@ -581,7 +562,7 @@ __global__ __launch_bounds__(64) void bgzf_inflate(const uint8_t *comp, const In
                     R.rf--;
                     R.nb += 32;
                 }
-                e = inf2_decode<INF_ROOT_L>(L, I2_LIT, I2_LLIM, I2_LADJ, I2_LLONG, I2_LLONG_HI, (iu32)R.bb);
+                e = inf2_decode<true>(L, limL, I2_LADJ, I2_LLONG, I2_LLONG_HI, (iu32)R.bb);
                 if (e == 0) {
                     err = INF_ERR_CODE;
                     bad = true;
@@ -632,7 +613,7 @@ __global__ __launch_bounds__(64) void bgzf_inflate(const uint8_t *comp, const In
                 R.rf--;
                 R.nb += 32;
             }
-            e = inf2_decode<INF_ROOT_D>(L, I2_DIST, I2_DLIM, I2_DADJ, I2_DLONG, 0, (iu32)R.bb);
+            e = inf2_decode<false>(L, limD, I2_DADJ, I2_DLONG, 0, (iu32)R.bb);
             if (e == 0 || (e >> 4) >= 30) {
                 err = INF_ERR_CODE;
                 state = ST_DONE;

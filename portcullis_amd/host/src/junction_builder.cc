@@ -289,7 +289,15 @@ public:
         std::promise<std::vector<pjb_extra_row>>* extraDone = nullptr;  // EXTRA: calcExtraMetrics for every row so far
     };
 
+    // blocks until this thread's context exists (or failed): page-locking the file pieces and creating contexts at the same
+    // time fight over the runtime's locks (contexts ready at 0.65 s instead of 0.4 s)
+    void waitReady() {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return ready; });
+    }
+
 private:
+    bool ready = false;
     std::thread th;
     std::mutex mu;
     std::condition_variable cv;
@@ -350,6 +358,11 @@ private:
             else p.done->set_exception(std::make_exception_ptr(JunctionBuilderException(err)));
         };
         g_prof.mark("device thread: context ready");
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            ready = true;
+            cv.notify_all();
+        }
         double tKind[16] = {0}, tIdle = 0, tCollect = 0;  // PJB_PROFILE_HOST: where this thread's time goes
         // pieces of file bytes whose copy to the device is in flight: (ticket, buffer, pool); released when pjb_bam_pieces_done
         // says the copy has left the buffer
@@ -772,6 +785,7 @@ void JunctionBuilder::findJunctions() {
             reader.open(useCsi);
             reader.setNameHashes(extra);
             DeviceThread& dev = deviceFor(w);
+            if (pinnedPool) dev.waitReady();
             while (true) {
                 int32_t tid;
                 {
