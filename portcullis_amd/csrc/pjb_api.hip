@@ -1929,7 +1929,7 @@ int inflate_on_device(pjb_ctx *c, const uint8_t *d_comp, const std::vector<InfBl
     const iu32 ctl[2] = {0u, (iu32)lanes};
     HIP_TRY(c, hipMemcpyAsync(d_any, ctl, 8, hipMemcpyHostToDevice, st));
     LAUNCH_LDS(c, "bgzf_inflate", bgzf_inflate, dim3((unsigned)(lanes / 64)), dim3(64), I2_LDS_BYTES, d_comp, (const InfBlock *)c->b_inf_blocks.p, (iu32)nb,
-               d_out, (uint8_t *)c->b_inf_scratch.p, d_status, d_any, d_next);
+               d_out, (uint8_t *)c->b_inf_scratch.p, d_status, d_any, d_next, 8);
     int any = 0;
     HIP_TRY(c, hipMemcpyAsync(&any, d_any, 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(c, hipStreamSynchronize(st));

@@ -251,7 +251,7 @@ struct Ring2 { // 16-word LDS ring + bit buffer
 };
 
 __global__ __launch_bounds__(64) void bgzf_inflate(const uint8_t *comp, const InfBlock *blocks, iu32 n_blocks, uint8_t *out,
-                                                     uint8_t *scratch, int *status, int *any_error, iu32 *next_block) {
+                                                     uint8_t *scratch, int *status, int *any_error, iu32 *next_block, int inf_refill) {
     extern __shared__ __attribute__((aligned(16))) unsigned short inf_lds[];
     // shared tables behind the per-lane areas
     iu32 *s_len = (iu32 *)(inf_lds + (size_t)I2_LANE_U16 * 64); // base | extra bits << 16
@@ -393,7 +393,9 @@ __global__ __launch_bounds__(64) void bgzf_inflate(const uint8_t *comp, const In
     for (;;) {
         // ---- lanes that finished their block: results out, queue drained (its entries are relative to the old block),
         // next block in
-        if (__any(state == ST_DONE && more)) {
+        // (not one by one: a block header and its tables are a long stretch of code that a lane would run alone while 63
+        // wait -- lanes are refilled when INF_REFILL of them are idle, or nobody is busy)
+        if ((int)__popcll(__ballot(state == ST_DONE && more)) >= (__any(state != ST_DONE) ? inf_refill : 1)) {
             memory_phase(); // (everybody: a phase is a round trip for the whole wave anyway)
             const bool fin = state == ST_DONE && more;
             if (fin && have) {

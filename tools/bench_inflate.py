@@ -31,6 +31,7 @@ def main():
     ap.add_argument("--config", default="C2")
     ap.add_argument("--chunk-mb", type=int, default=256)
     ap.add_argument("--workdir", default="/tmp/pjb_inflate")
+    ap.add_argument("--times", type=int, default=1, help="inflate the file's blocks this many times in one call (a larger input: BGZF blocks are independent)")
     args = ap.parse_args()
     e2e = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "e2e_bench.py"), "--config", args.config, "--threads", "16",
                           "--workdir", args.workdir, "--keep", "--no-oracle", "--repeat", "2"], capture_output=True, text=True)
@@ -39,6 +40,7 @@ def main():
         raise SystemExit(1)
     e2e_res = json.loads(e2e.stdout.strip().split("\n")[-1])
     raw = open(os.path.join(args.workdir, "prep", "portcullis.sorted.alignments.bam"), "rb").read()
+    raw = raw * args.times
     offs = block_offsets(raw)
     from portcullis_amd import ffi
     ctx = ffi.Context(0, "UNKNOWN", flags=ffi.FLAG_KERNEL_TIMING)
