@@ -50,6 +50,9 @@ def algorithmic_bytes(name, N, C, S, Cs, P, J, L, Pg=0):
         # spliced reads only: compacted slot (8), cig_off (8), pos/flag/mapq/xs (8), ops fetched once; 44 B written per pair
         # (36 B of pair fields + the address of the read's bases for k4a_simple)
         "k1_emit": S * 24 + Cs * 4 + P * 44,
+        # one pass over the records: cig_off, pos, l_qseq, mtid, mpos, seq_off (4 B each), flag (2), mapq, xs (1 each) and every
+        # cigar op, read once; 44 B written per pair
+        "k1_walk": N * 28 + C * 4 + P * 44,
         # K2d, ordered dense junction ids: keys read three times (8 B), ids written once (8 B); the bitmap / rank / end tables are
         # contig-sized and small beside the pairs
         "kd_unique": P * 8,
@@ -395,7 +398,8 @@ def main():
                 e2e = e2e_leg(contigs, cfgs, args.e2e_workdir, ORI, oracle_tab_md5)
             except Exception as ex:  # the e2e leg must never cost the bench line
                 e2e = {"error": f"{type(ex).__name__}: {ex}"[:500]}
-            shutil.rmtree(args.e2e_workdir, ignore_errors=True)
+            if not os.environ.get("PJB_BENCH_KEEP_WORKDIR"):  # (kept for profiling runs of the program on the same files)
+                shutil.rmtree(args.e2e_workdir, ignore_errors=True)
 
         tot_bytes = sum((k["alg_bytes"] or 0) * k["launches"] / args.steps for k in kern)
         cfg_name = "configs[2]" if world == 1 else "configs[3]"

@@ -231,7 +231,10 @@ int pjb_finish_contig_end(pjb_ctx *ctx, int32_t tid, pjb_region_result *result);
  *                kernel at a time on one stream (clean per-kernel timings; also the environment variable
  *                PJB_SIDE_STREAM=0)
  *   "dense_ids"  1 (default): the sort works on ordered dense junction ids; 0: on the full intron keys
- *                (PJB_DENSE_IDS=0) */
+ *                (PJB_DENSE_IDS=0)
+ *   "fused_k1"   0 (default): a counting pass, a scan and a second pass over the spliced records; 1: one pass over the
+ *                records counts the N operations, places the tile's pairs and writes them (k1_walk; measured slower
+ *                on contig-sized inputs; PJB_FUSED_K1=1) */
 int pjb_set_option(pjb_ctx *ctx, const char *name, int64_t value);
 
 /* All rows built so far, contig by contig in finish order, (start,end)-sorted

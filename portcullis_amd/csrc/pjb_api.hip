@@ -87,6 +87,7 @@ struct CtlSlot {
     // what the first kernels of a contig (k1_count, k1_scan_tiles, k1_emit: the front stream) write and the rest of its
     // chain reads: the next contig's first kernels run beside this contig's last ones
     Buf tile_cnt, tile_stats, splidx, splpoff;
+    Buf k1look; // k1_walk: ticket counter, tile and group descriptors
     Buf okey, g, lstart, rend, pos, aend, meta, updown, seqw; // the pairs (BAM order)
     Buf res;                                                  // k4a_simple / k4b_generic results per pair
     hipEvent_t ev_k1 = nullptr;
@@ -174,6 +175,7 @@ struct pjb_ctx {
     int last_slot = 0; // slot of the contig collected last (pjb_collect_device)
     int inflate_lanes = 512 * 64;                // lanes of one bgzf_inflate launch (2 workgroups x 256 CUs; set from the device at create)
     bool side_stream = true;                     // k4a_simple beside the sort (PJB_SIDE_STREAM=0: on the main stream)
+    bool fused_k1 = false;                       // PJB_FUSED_K1=1: the one-pass k1_walk instead of k1_count + k1_scan_tiles + k1_emit
     bool dense_ids = true;                       // K2d (PJB_DENSE_IDS=0 sorts the full keys as round 1 did)
     u32 junc_seen = 0;                           // most junctions a contig has had so far (junction limit of the next contig)
     int lbits_seen = 18;                         // bits of the longest intron this context has met (key format of the next contig)
@@ -508,6 +510,7 @@ int pjb_create(pjb_ctx **out, const pjb_config *cfg) {
     c->ktime = (cfg->flags & PJB_FLAG_KERNEL_TIMING) != 0;
     c->extra = (cfg->flags & PJB_FLAG_EXTRA) != 0;
     if (const char *s = getenv("PJB_DENSE_IDS")) c->dense_ids = atoi(s) != 0;
+    if (const char *s = getenv("PJB_FUSED_K1")) c->fused_k1 = atoi(s) != 0;
     if (const char *s = getenv("PJB_SIDE_STREAM")) c->side_stream = atoi(s) != 0;
     if (const char *s = getenv("PJB_RADIX_BITS")) {
         int v = atoi(s);
@@ -545,7 +548,7 @@ void pjb_destroy(pjb_ctx *c) {
         for (auto &ev : S.ev) (void)hipEventDestroy(ev);
         if (S.ev_rows) (void)hipEventDestroy(S.ev_rows);
         if (S.ev_done) (void)hipEventDestroy(S.ev_done);
-        Buf *sb[] = {&S.cstats, &S.err, &S.gencount, &S.batches, &S.rows, &S.tile_cnt, &S.tile_stats, &S.splidx, &S.splpoff, &S.okey, &S.g,
+        Buf *sb[] = {&S.cstats, &S.err, &S.gencount, &S.batches, &S.rows, &S.tile_cnt, &S.tile_stats, &S.splidx, &S.splpoff, &S.k1look, &S.okey, &S.g,
                      &S.lstart, &S.rend, &S.pos, &S.aend, &S.meta, &S.updown, &S.seqw, &S.res, &S.total, &S.bitmap, &S.wrank, &S.ends, &S.firstid,
                      &S.key[0], &S.key[1], &S.idx[0], &S.idx[1], &S.hist, &S.hist_scan, &S.bintotal, &S.scan_tiles, &S.jid, &S.seg, &S.runfirst,
                      &S.runstart, &S.ent, &S.entsum, &S.frag, &S.fragj, &S.fragl, &S.fragr, &S.acc, &S.ancl, &S.ancr, &S.genlist};
@@ -976,8 +979,11 @@ static int queue_contig(pjb_ctx *c, Flight &f, std::vector<DevBatch> &batches) {
     if ((rc = ensure(c, c->b_cursor, sizeof(RowCursor)))) return rc;
     if ((rc = ensure(c, S.tile_cnt, (size_t)n_tiles * 4))) return rc;
     if ((rc = ensure(c, S.tile_stats, (size_t)n_tiles * sizeof(TileStats)))) return rc;
-    if ((rc = ensure(c, S.splidx, (size_t)n_tiles * K1_TILE * 4))) return rc;
-    if ((rc = ensure(c, S.splpoff, (size_t)n_tiles * K1_TILE * 4))) return rc;
+    const bool fused_k1 = c->fused_k1;
+    const bool want_splidx = !fused_k1 || c->extra; // (--extra reads the tiles' spliced lists)
+    if (want_splidx && (rc = ensure(c, S.splidx, (size_t)n_tiles * K1_TILE * 4))) return rc;
+    if (!fused_k1 && (rc = ensure(c, S.splpoff, (size_t)n_tiles * K1_TILE * 4))) return rc;
+    if (fused_k1 && (rc = ensure(c, S.k1look, k1look_bytes(n_tiles)))) return rc;
     if ((rc = ensure(c, S.total, 8))) return rc;
     // ---- pair-sized buffers (one sort tile of slack: rs_scatter loads whole tiles unguarded)
     if ((rc = ensure(c, S.okey, ((size_t)PL + RS_TILE) * 8))) return rc; // the pairs' keys as emitted (BAM order): kept, the sort works on copies
@@ -1069,15 +1075,6 @@ static int queue_contig(pjb_ctx *c, Flight &f, std::vector<DevBatch> &batches) {
         if (stage_events) HIP_TRY(c, hipEventRecord(S.ev[k], st));  \
     } while (0)
     HIP_TRY(c, hipEventRecord(S.ev[0], front));
-    // ---- K1a: count
-    for (auto &b : batches) {
-        const u32 nt = (u32)((b.n + K1_TILE - 1) / K1_TILE);
-        LAUNCH(c, "k1_count", k1_count, dim3(nt), dim3(256), b, (u32 *)S.tile_cnt.p, (TileStats *)S.tile_stats.p,
-               (u32 *)S.splidx.p, (u32 *)S.splpoff.p, d_err);
-    }
-    LAUNCH(c, "k1_scan_tiles", k1_scan_tiles, dim3(1), dim3(1024), (u32 *)S.tile_cnt.p, (const TileStats *)S.tile_stats.p, n_tiles, d_cs,
-           PL, kf, ref_len);
-    // ---- K1b: emit
     Pairs pr;
     pr.key = (u64 *)S.okey.p;
     pr.g = (u32 *)S.g.p;
@@ -1089,11 +1086,33 @@ static int queue_contig(pjb_ctx *c, Flight &f, std::vector<DevBatch> &batches) {
     pr.updown = (u32 *)S.updown.p;
     pr.seqw = (u64 *)S.seqw.p;
     f.pr = pr;
-    for (auto &b : batches) {
-        const u32 nt = (u32)((b.n + K1_TILE - 1) / K1_TILE);
-        LAUNCH(c, "k1_emit", k1_emit, dim3(nt), dim3(256), b, (const u32 *)S.tile_cnt.p,
-               (const TileStats *)S.tile_stats.p, (const u32 *)S.splidx.p, (const u32 *)S.splpoff.p, pr, kf, ref_len,
-               tid, (int)c->cfg.orientation, d_err, (const ContigStats *)d_cs);
+    if (fused_k1) {
+        // ---- K1 in one pass: count, place (tile and group descriptors) and emit
+        const K1Look lk = k1look_at(S.k1look.p, n_tiles);
+        HIP_TRY(c, hipMemsetAsync(S.k1look.p, 0, k1look_bytes(n_tiles), front));
+        for (auto &b : batches) {
+            const u32 nt = (u32)((b.n + K1_TILE - 1) / K1_TILE);
+            LAUNCH(c, "k1_walk", k1_walk, dim3(nt), dim3(K1W_THREADS), b, lk, n_tiles, (TileStats *)S.tile_stats.p,
+                   want_splidx ? (u32 *)S.splidx.p : (u32 *)nullptr, pr, kf, ref_len, tid, (int)c->cfg.orientation, PL, d_err);
+        }
+        LAUNCH(c, "k1_scan_tiles", k1_scan_tiles, dim3(1), dim3(1024), (u32 *)nullptr, (const TileStats *)S.tile_stats.p, n_tiles, d_cs, PL, kf,
+               ref_len, (const u64 *)lk.tile_desc);
+    } else {
+        // ---- K1a: count
+        for (auto &b : batches) {
+            const u32 nt = (u32)((b.n + K1_TILE - 1) / K1_TILE);
+            LAUNCH(c, "k1_count", k1_count, dim3(nt), dim3(256), b, (u32 *)S.tile_cnt.p, (TileStats *)S.tile_stats.p,
+                   (u32 *)S.splidx.p, (u32 *)S.splpoff.p, d_err);
+        }
+        LAUNCH(c, "k1_scan_tiles", k1_scan_tiles, dim3(1), dim3(1024), (u32 *)S.tile_cnt.p, (const TileStats *)S.tile_stats.p, n_tiles, d_cs,
+               PL, kf, ref_len, (const u64 *)nullptr);
+        // ---- K1b: emit
+        for (auto &b : batches) {
+            const u32 nt = (u32)((b.n + K1_TILE - 1) / K1_TILE);
+            LAUNCH(c, "k1_emit", k1_emit, dim3(nt), dim3(256), b, (const u32 *)S.tile_cnt.p,
+                   (const TileStats *)S.tile_stats.p, (const u32 *)S.splidx.p, (const u32 *)S.splpoff.p, pr, kf, ref_len,
+                   tid, (int)c->cfg.orientation, d_err, (const ContigStats *)d_cs);
+        }
     }
     // ---- K4a: match statistics of the common [S] M N M [S] shape, in BAM order, while the keys are still unsorted:
     // on the side stream, beside the sort of the main stream (joined before pass 1 overwrites the keys)
@@ -1817,6 +1836,7 @@ int pjb_set_option(pjb_ctx *c, const char *name, int64_t value) {
     const std::string n = name;
     if (n == "overlap") c->side_stream = value != 0;
     else if (n == "dense_ids") c->dense_ids = value != 0;
+    else if (n == "fused_k1") c->fused_k1 = value != 0;
     else return fail(c, PJB_ERR_ARG, "set_option: unknown option '%s'", name);
     return PJB_OK;
 }

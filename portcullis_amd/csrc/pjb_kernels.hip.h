@@ -556,8 +556,10 @@ __global__ __launch_bounds__(256) void k1_count(DevBatch b, u32 *tile_cnt, TileS
 }
 
 // single block: exclusive scan of per-tile pair counts (in place) + reduction of tile stats
+// (tile_desc != nullptr: the tiles of k1_walk placed their pairs themselves -- only the total is taken, from their
+// descriptors, and nothing is written back)
 __global__ __launch_bounds__(1024) void k1_scan_tiles(u32 *tile_cnt, const TileStats *ts, u32 n_tiles, ContigStats *out, u32 pair_limit,
-                                                       KeyFmt kf, int32_t ref_len) {
+                                                       KeyFmt kf, int32_t ref_len, const u64 *tile_desc) {
     __shared__ u64 wsum[16];
     __shared__ u64 carry_s;
     __shared__ u64 r_spl[16], r_uns[16], r_sum[16];
@@ -570,7 +572,7 @@ __global__ __launch_bounds__(1024) void k1_scan_tiles(u32 *tile_cnt, const TileS
         u32 i = base + threadIdx.x;
         u64 v = 0;
         if (i < n_tiles) {
-            v = tile_cnt[i];
+            v = tile_desc ? (tile_desc[i] & ((1ull << 40) - 1)) : (u64)tile_cnt[i];
             TileStats t = ts[i];
             spl += t.spliced;
             uns += t.unspliced;
@@ -593,7 +595,7 @@ __global__ __launch_bounds__(1024) void k1_scan_tiles(u32 *tile_cnt, const TileS
         }
         u64 carry = carry_s;
         // NOTE: exclusive offsets are stored as 32-bit: a contig is limited to < 2^32 pairs
-        if (i < n_tiles) tile_cnt[i] = (u32)(carry + wb + inc - v);
+        if (i < n_tiles && !tile_desc) tile_cnt[i] = (u32)(carry + wb + inc - v);
         __syncthreads();
         if (threadIdx.x == 0) carry_s = carry + tot;
         __syncthreads();
@@ -672,11 +674,13 @@ __global__ __launch_bounds__(1024) void k1_scan_tiles(u32 *tile_cnt, const TileS
 // CIGAR ops of one alignment: the first OPS_LDS ops are staged in LDS (one column per thread), the
 // rest (long reads) are read from global memory
 constexpr int OPS_LDS = 8;
-struct OpsView {
+template <int STRIDE, int NLDS>
+struct OpsViewT {
     const uint32_t *g;
-    const u32 *lds; // &s_ops[0][threadIdx.x], stride 256
-    __device__ __forceinline__ u32 operator[](u32 k) const { return k < (u32)OPS_LDS ? lds[k * 256] : g[k]; }
+    const u32 *lds; // &s_ops[0][column]: NLDS rows of STRIDE columns
+    __device__ __forceinline__ u32 operator[](u32 k) const { return k < (u32)NLDS ? lds[k * STRIDE] : g[k]; }
 };
+typedef OpsViewT<256, OPS_LDS> OpsView;
 
 struct NCursor { // walks the N ops of one CIGAR yielding the unclamped position after each N
     u32 i;
@@ -684,7 +688,8 @@ struct NCursor { // walks the N ops of one CIGAR yielding the unclamped position
     bool has;
     int32_t peek;
 };
-__device__ __forceinline__ void ncursor_advance(NCursor &c, const OpsView cig, u32 n) {
+template <typename Ops>
+__device__ __forceinline__ void ncursor_advance(NCursor &c, const Ops cig, u32 n) {
     c.has = false;
     while (c.i < n) {
         u32 op = cig[c.i++];
@@ -698,6 +703,134 @@ __device__ __forceinline__ void ncursor_advance(NCursor &c, const OpsView cig, u
     }
 }
 
+// One spliced read's pairs (JunctionSystem::addJunctions junction_system.cc:140-210) -- everything that follows from
+// the read's fixed-width fields is in R, the CIGAR behind `cig`.  Shape test, walk with the two monotone cursors for
+// the up/down junction counts (junction.cc:795-812), one store per pair field.
+struct EmitRead {
+    u32 n;        // CIGAR operations
+    int32_t pos;
+    u32 g;        // global read ordinal
+    u32 meta;     // per-read predicates (category, XS, UM, BPP, PPP, REL, MULTI)
+    u32 nN;       // N operations
+    int32_t aend; // pos + aligned length - 1
+    int32_t lq;   // l_qseq
+    bool seq_ok;  // the record carries at least lq bases
+    u64 seq_ptr;  // device address of the read's packed bases
+    u32 off;      // index of the read's first pair
+};
+template <typename Ops>
+__device__ __forceinline__ void emit_read_pairs(const Ops cig, const EmitRead R, const Pairs P, const KeyFmt kf, const int32_t ref_len,
+                                                u64 *err) {
+    const u32 n = R.n, g = R.g, nN = R.nN;
+    const int32_t pos = R.pos, aend = R.aend;
+    u32 meta = R.meta;
+    // ---- shape: [S] M N M [S] with the read length matching the CIGAR
+    if (nN == 1 && n >= 3 && n <= 5) {
+        u32 k0 = 0, k1 = n;
+        u32 dS = 0, dE = 0;
+        const u32 opF = cig[0], opL = cig[n - 1];
+        if ((opF & 15u) == OP_S) { dS = opF >> 4; k0 = 1; }
+        if ((opL & 15u) == OP_S) { dE = opL >> 4; k1 = n - 1; }
+        if (k1 - k0 == 3) {
+            const u32 oa = cig[k0], on = cig[k0 + 1], ob = cig[k0 + 2];
+            if ((oa & 15u) == OP_M && (on & 15u) == OP_N && (ob & 15u) == OP_M) {
+                const u32 a = oa >> 4, b2 = ob >> 4;
+                const int32_t lq = R.lq;
+                if (a > 0 && b2 > 0 && a <= RES_FIELD_MAX && b2 <= RES_FIELD_MAX && dS < 4096u && lq > 1 &&
+                    (u64)lq == (u64)dS + a + b2 + dE && R.seq_ok)
+                    meta |= META_SIMPLE | (dS << META_DS_SHIFT);
+            }
+        }
+    }
+    const u64 seq_addr = (meta & META_SIMPLE) ? R.seq_ptr : 0ull;
+    // ---- walk: pairs (junction_system.cc:140-210) and, with two monotone cursors over the read's own
+    // introns, the up/down junction counts (junction.cc:795-812)
+    NCursor U = {0, pos, false, 0}, D = {0, pos, false, 0};
+    ncursor_advance(U, cig, n);
+    ncursor_advance(D, cig, n);
+    u32 cntU = 0, cntD = 0;
+    int32_t lStart = pos, lEndExc = pos, sumAfter = 0, prevRStartU = 0, prevIend = 0;
+    int64_t prev = -1;
+    u32 k = 0;
+    for (u32 i = 0; i < n; i++) {
+        const u32 op = cig[i];
+        const u32 ty = op & 15u;
+        const int32_t ln = (int32_t)(op >> 4);
+        if (ty == OP_N) {
+            if (prev >= 0) {
+                int32_t rEndExc = prevRStartU + sumAfter;
+                if (rEndExc - 1 >= ref_len) rEndExc = ref_len; // junction_system.cc:172-174
+                P.rend[prev] = rEndExc - 1;
+                if (rEndExc - 1 < prevIend) set_error(err, g, PJB_ERR_MIN_ANCHOR); // intron.cc:76
+            }
+            const int32_t istart = lEndExc;
+            const int32_t rStartU = lEndExc + ln;
+            int32_t rStart = rStartU;
+            if (rStart - 1 >= ref_len) rStart = ref_len - 1; // junction_system.cc:169-171
+            const int32_t iend = rStart - 1;
+            while (U.has && U.peek < istart) {
+                cntU++;
+                ncursor_advance(U, cig, n);
+            }
+            while (D.has && D.peek <= iend + 1) {
+                cntD++;
+                ncursor_advance(D, cig, n);
+            }
+            const int64_t idx = (int64_t)R.off + k;
+            P.key[idx] = make_key(kf, istart, iend);
+            P.g[idx] = g;
+            P.lstart[idx] = lStart;
+            P.pos[idx] = pos;
+            P.meta[idx] = meta;
+            P.aend[idx] = aend;
+            P.updown[idx] = cntU | ((nN - cntD) << 16);
+            P.seqw[idx] = seq_addr;
+            if (lStart > istart) set_error(err, g, PJB_ERR_MIN_ANCHOR); // intron.cc:68
+            prev = idx;
+            prevIend = iend;
+            prevRStartU = rStartU;
+            sumAfter = 0;
+            lStart = rStart;
+            lEndExc = rStart;
+            k++;
+        } else if (op_consumes_ref(ty)) {
+            lEndExc += ln;
+            sumAfter += ln;
+        }
+    }
+    if (prev >= 0) {
+        int32_t rEndExc = prevRStartU + sumAfter;
+        if (rEndExc - 1 >= ref_len) rEndExc = ref_len;
+        P.rend[prev] = rEndExc - 1;
+        if (rEndExc - 1 < prevIend) set_error(err, g, PJB_ERR_MIN_ANCHOR);
+    }
+}
+
+// per-read predicates of a pair's `meta` word (Junction::addJunctionAlignment junction.cc:477-502, calcAlignmentStats
+// junction.cc:755-814, BamAlignment::calcIfProperPair bam_alignment.cc:271-292); MULTI and SIMPLE are added by the caller
+__device__ __forceinline__ u32 read_meta(u32 flag, u32 xs, u32 mapq, int32_t pos, int32_t mtid, int32_t mpos, int32_t tid, int orientation) {
+    const bool pp_check = orientation == PJB_OR_FR || orientation == PJB_OR_RF || orientation == PJB_OR_FF;
+    const bool first = flag & 0x40, rev = flag & 0x10;
+    u32 meta = (first ? 0u : 2u) + (rev ? 1u : 0u);
+    meta |= (xs & 3u) << META_XS_SHIFT;
+    const bool um = mapq >= 30;
+    if (um) meta |= META_UM;
+    if (flag & 0x2) meta |= META_BPP;
+    bool ppp = false;
+    if (pp_check) {
+        const bool paired = flag & 0x1, mate_mapped = !(flag & 0x8);
+        if (paired && mate_mapped && tid == mtid) {
+            const bool mrev = flag & 0x20;
+            const bool diff = rev != mrev;
+            const bool gap = !rev ? pos < mpos : pos > mpos;
+            ppp = orientation == PJB_OR_FR ? (diff && gap) : orientation == PJB_OR_RF ? (diff && !gap) : (!diff && gap);
+        }
+    }
+    if (ppp) meta |= META_PPP;
+    if (um && (!pp_check || ppp)) meta |= META_REL;
+    return meta;
+}
+
 // Thread per spliced read (dense, from the list k1_count compacted).  The read's CIGAR is fetched
 // once (8 independent loads into an LDS column, the walks below then run at LDS latency); one walk
 // writes every field of the read's pairs.
@@ -709,11 +842,9 @@ __global__ __launch_bounds__(256) void k1_emit(DevBatch b, const u32 *tile_off, 
     const u32 tile = b.tile_base + blockIdx.x;
     const u32 nspl = tile_stats[tile].spliced;
     const u32 toff = tile_off[tile];
-    const bool pp_check = orientation == PJB_OR_FR || orientation == PJB_OR_RF || orientation == PJB_OR_FF;
     for (u32 ks = threadIdx.x; ks < nspl; ks += 256) {
         const size_t slot = (size_t)tile * K1_TILE + ks;
         const int64_t r = spl_idx[slot];
-        const u32 off = toff + spl_poff[slot];
         const u32 c0 = b.cig_off[r], c1 = b.cig_off[r + 1];
         const u32 n = c1 - c0;
         OpsView cig;
@@ -721,29 +852,12 @@ __global__ __launch_bounds__(256) void k1_emit(DevBatch b, const u32 *tile_off, 
         cig.lds = &s_ops[0][threadIdx.x];
 #pragma unroll
         for (int k = 0; k < OPS_LDS; k++) s_ops[k][threadIdx.x] = (u32)k < n ? cig.g[k] : 0u;
-        const int32_t pos = b.pos[r];
-        const u32 g = b.base + (u32)r;
-        // ---- per-read predicates
-        const u32 flag = b.flag[r];
-        const bool first = flag & 0x40, rev = flag & 0x10;
-        u32 meta = (first ? 0u : 2u) + (rev ? 1u : 0u);
-        meta |= ((u32)b.xs[r] & 3u) << META_XS_SHIFT;
-        const bool um = b.mapq[r] >= 30;
-        if (um) meta |= META_UM;
-        if (flag & 0x2) meta |= META_BPP;
-        bool ppp = false;
-        if (pp_check) { // BamAlignment::calcIfProperPair, bam_alignment.cc:271-292
-            const bool paired = flag & 0x1, mate_mapped = !(flag & 0x8);
-            if (paired && mate_mapped && tid == b.mtid[r]) {
-                const bool mrev = flag & 0x20;
-                const bool diff = rev != mrev;
-                const int32_t mp = b.mpos[r];
-                const bool gap = !rev ? pos < mp : pos > mp;
-                ppp = orientation == PJB_OR_FR ? (diff && gap) : orientation == PJB_OR_RF ? (diff && !gap) : (!diff && gap);
-            }
-        }
-        if (ppp) meta |= META_PPP;
-        if (um && (!pp_check || ppp)) meta |= META_REL;
+        EmitRead R;
+        R.n = n;
+        R.pos = b.pos[r];
+        R.g = b.base + (u32)r;
+        R.off = toff + spl_poff[slot];
+        R.meta = read_meta(b.flag[r], (u32)b.xs[r], b.mapq[r], R.pos, b.mtid[r], b.mpos[r], tid, orientation);
         u32 nN = 0;
         int32_t aligned = 0;
         for (u32 q = 0; q < n; q++) {
@@ -751,89 +865,323 @@ __global__ __launch_bounds__(256) void k1_emit(DevBatch b, const u32 *tile_off, 
             nN += ((op & 15u) == OP_N);
             if (op_consumes_ref(op & 15u)) aligned += (int32_t)(op >> 4);
         }
-        if (nN > 1) meta |= META_MULTI;
-        // ---- shape: [S] M N M [S] with the read length matching the CIGAR
-        if (nN == 1 && n >= 3 && n <= 5) {
-            u32 k0 = 0, k1 = n;
-            u32 dS = 0, dE = 0;
-            const u32 opF = cig[0], opL = cig[n - 1];
-            if ((opF & 15u) == OP_S) { dS = opF >> 4; k0 = 1; }
-            if ((opL & 15u) == OP_S) { dE = opL >> 4; k1 = n - 1; }
-            if (k1 - k0 == 3) {
-                const u32 oa = cig[k0], on = cig[k0 + 1], ob = cig[k0 + 2];
-                if ((oa & 15u) == OP_M && (on & 15u) == OP_N && (ob & 15u) == OP_M) {
-                    const u32 a = oa >> 4, b2 = ob >> 4;
-                    const int32_t lq = b.l_qseq[r];
-                    const u32 words = b.seq_off[r + 1] - b.seq_off[r];
-                    if (a > 0 && b2 > 0 && a <= RES_FIELD_MAX && b2 <= RES_FIELD_MAX && dS < 4096u && lq > 1 &&
-                        (u64)lq == (u64)dS + a + b2 + dE && (u64)words * 8ull >= (u64)lq)
-                        meta |= META_SIMPLE | (dS << META_DS_SHIFT);
+        if (nN > 1) R.meta |= META_MULTI;
+        R.nN = nN;
+        R.aend = R.pos + aligned - 1;
+        R.lq = b.l_qseq[r];
+        const u32 so = b.seq_off[r];
+        R.seq_ok = (u64)(b.seq_off[r + 1] - so) * 8ull >= (u64)(int64_t)R.lq;
+        R.seq_ptr = (u64)(uintptr_t)(b.seq4 + (size_t)so * 4);
+        emit_read_pairs(cig, R, P, kf, ref_len, err);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K1 in ONE pass (k1_walk): k1_count and k1_emit read every record twice -- the second time as a gather over the
+// spliced third of the reads, three dependent loads deep -- because a tile cannot place its pairs before it knows how
+// many pairs all the tiles before it hold.  Here a tile counts, publishes its pair count, and while the answer to
+// "how many before me" is on its way the tile's spliced reads are staged in LDS; the emit walk then runs dense over the
+// staged columns.  Every record byte is read once, coalesced; nothing is written but the pairs.
+//
+// The offset comes through two levels so that no tile polls more than a few words (a plain decoupled look-back has
+// thousands of resident tiles walking back over each other through the fabric -- measured on the scans, see above):
+//   tile_desc[t]  VALID | pairs of tile t                     written by tile t as soon as it has counted
+//   grp_acc[g]    (tiles arrived << 40) + pairs               one atomic add per tile; K1W_GROUP tiles form a group
+//   grp_desc[g]   VALID | pairs of group g, later             written by the group's last arrival;
+//                 VALID | PREFIX | pairs of groups 0..g       upgraded by the first tile of group g + 1
+//   grp_excl[g]   VALID | pairs before group g                written by the group's first tile
+// The first tile of a group walks the group descriptors back to the nearest PREFIX (64 groups = 4096 tiles per step);
+// every other tile reads grp_excl of its group and the descriptors of the tiles before it in the group: one step.
+// Tile numbers are handed out by a ticket counter, so a tile only ever waits for tiles that are already running.
+// All flags travel inside the 8-byte word they guard: relaxed agent-scope atomics, no fences.
+// ---------------------------------------------------------------------------------------------
+constexpr int K1W_GROUP = 64;
+constexpr int K1W_THREADS = 512, K1W_RPT = K1_TILE / K1W_THREADS, K1W_WAVES = K1W_THREADS / 64; // two reads per thread
+constexpr int K1W_OPS = 6; // CIGAR operations staged per spliced read (longer CIGARs continue in global memory)
+constexpr u64 K1W_VALID = 1ull << 63, K1W_PREFIX = 1ull << 62, K1W_VALUE = (1ull << 40) - 1;
+constexpr u32 K1W_SPIN_LIMIT = 1u << 22;
+struct K1Look {
+    u32 *ticket;
+    u64 *tile_desc, *grp_acc, *grp_desc, *grp_excl;
+};
+__host__ __device__ inline size_t k1look_bytes(u32 n_tiles) {
+    const size_t ng = ((size_t)n_tiles + K1W_GROUP - 1) / K1W_GROUP;
+    return 8 + ((size_t)n_tiles + 3 * ng) * 8;
+}
+__host__ __device__ inline K1Look k1look_at(void *p, u32 n_tiles) {
+    const size_t ng = ((size_t)n_tiles + K1W_GROUP - 1) / K1W_GROUP;
+    K1Look L;
+    L.ticket = (u32 *)p;
+    L.tile_desc = (u64 *)p + 1;
+    L.grp_acc = L.tile_desc + n_tiles;
+    L.grp_desc = L.grp_acc + ng;
+    L.grp_excl = L.grp_desc + ng;
+    return L;
+}
+__device__ __forceinline__ u64 ld_agent(const u64 *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_agent(u64 *p, u64 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// waits until the word carries VALID (a bounded wait: a tile that never arrives is a bug, not a hang)
+__device__ __forceinline__ u64 wait_valid(const u64 *p, u64 *err) {
+    u64 d = ld_agent(p);
+    u32 spins = 0;
+    while (!(d & K1W_VALID)) {
+        __builtin_amdgcn_s_sleep(2);
+        d = ld_agent(p);
+        if (++spins > K1W_SPIN_LIMIT) {
+            set_error(err, 0u, PJB_ERR_HIP);
+            return K1W_VALID;
+        }
+    }
+    return d;
+}
+__device__ __forceinline__ u64 wave_sum_u64(u64 v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__global__ __launch_bounds__(K1W_THREADS) void k1_walk(DevBatch b, K1Look Lk, u32 n_tiles_total, TileStats *tile_stats, u32 *spl_idx, Pairs P,
+                                                        KeyFmt kf, int32_t ref_len, int32_t tid, int orientation, u32 pair_limit, u64 *err) {
+    // staged columns, one per spliced read of the tile (slot = rank among the tile's spliced reads)
+    __shared__ u32 s_ops[K1W_OPS][K1_TILE];
+    __shared__ u32 s_rec[9][K1_TILE]; // pos, meta, n, rl | nN << 10, aend, lq, seq_off, pair offset in the tile, cig_off
+    __shared__ u64 sm64[K1W_WAVES];
+    __shared__ u64 sm_scan[K1W_RPT][K1W_WAVES];
+    __shared__ int32_t smi[K1W_WAVES][6];
+    __shared__ u64 smp[K1W_WAVES];
+    __shared__ u32 s_tile;
+    __shared__ u64 s_excl;
+    if (threadIdx.x == 0) s_tile = atomicAdd(Lk.ticket, 1u);
+    __syncthreads();
+    const u32 tile = s_tile;           // tile of the contig
+    const u32 lt = tile - b.tile_base; // tile of this batch
+    const int64_t base = (int64_t)lt * K1_TILE;
+    u32 cnt = 0, spl = 0, uns = 0;
+    u64 sum = 0;
+    int32_t mn = INT32_MAX, mx = 0, max_end = 0, max_nlen = 0, min_pos = INT32_MAX;
+    // ---- every load of the thread's reads, issued before anything is consumed
+    constexpr int K1_OPS = 4;
+    u32 c0[K1W_RPT], nop[K1W_RPT], ops[K1W_RPT][K1_OPS];
+    int32_t pos4[K1W_RPT], prev4[K1W_RPT], len4[K1W_RPT], mtid4[K1W_RPT], mpos4[K1W_RPT];
+    u32 xs4[K1W_RPT], c4[K1W_RPT], flag4[K1W_RPT], mapq4[K1W_RPT], so4[K1W_RPT], so4n[K1W_RPT];
+#pragma unroll
+    for (int it = 0; it < K1W_RPT; it++) {
+        const int64_t r = base + it * K1W_THREADS + threadIdx.x;
+        const bool on = r < b.n;
+        c0[it] = on ? b.cig_off[r] : 0u;
+        nop[it] = on ? b.cig_off[r + 1] - c0[it] : 0u;
+        pos4[it] = on ? b.pos[r] : 0;
+        prev4[it] = on ? (r > 0 ? b.pos[r - 1] : (b.prev_pos_ptr ? *b.prev_pos_ptr : b.prev_pos)) : 0;
+        xs4[it] = on ? (u32)b.xs[r] : 0u;
+        len4[it] = on ? b.l_qseq[r] : 0;
+        flag4[it] = on ? (u32)b.flag[r] : 0u;
+        mapq4[it] = on ? (u32)b.mapq[r] : 0u;
+        mtid4[it] = on ? b.mtid[r] : 0;
+        mpos4[it] = on ? b.mpos[r] : 0;
+        so4[it] = on ? b.seq_off[r] : 0u;
+        so4n[it] = on ? b.seq_off[r + 1] : 0u;
+    }
+#pragma unroll
+    for (int it = 0; it < K1W_RPT; it++)
+#pragma unroll
+        for (int k = 0; k < K1_OPS; k++) ops[it][k] = (u32)k < nop[it] ? b.cigar[c0[it] + k] : 0u;
+    // ---- count (BamAlignment::init bam_alignment.cc:71-100, findJuncs length stats src/junction_builder.cc:333-343)
+    int32_t aend4[K1W_RPT];
+    u32 meta4[K1W_RPT];
+#pragma unroll
+    for (int it = 0; it < K1W_RPT; it++) {
+        const int64_t r = base + it * K1W_THREADS + threadIdx.x;
+        u32 cthis = 0;
+        int32_t al = 0;
+        if (r < b.n) {
+            const int32_t p = pos4[it];
+            if (p < prev4[it]) set_error(err, b.base + (u32)r, PJB_ERR_UNSORTED);
+            if (xs4[it] > 2) set_error(err, b.base + (u32)r, PJB_ERR_BAD_XS);
+            u32 c = 0;
+            auto count_op = [&](u32 op) {
+                const u32 ty = op & 15u;
+                const int32_t ln = (int32_t)(op >> 4);
+                if (op_consumes_ref(ty)) al += ln;
+                if (ty == OP_N) {
+                    c++;
+                    max_nlen = ln > max_nlen ? ln : max_nlen;
                 }
+            };
+#pragma unroll
+            for (int k = 0; k < K1_OPS; k++) count_op(ops[it][k]); // padding ops are 0M: no effect
+            for (u32 k = K1_OPS; k < nop[it]; k++) count_op(b.cigar[c0[it] + k]);
+            const int32_t len = len4[it];
+            mn = len < mn ? len : mn;
+            mx = len > mx ? len : mx;
+            sum += (u64)(int64_t)len;
+            cnt += c;
+            if (c) {
+                spl++;
+                int32_t e = p + al;
+                max_end = e > max_end ? e : max_end;
+                min_pos = p < min_pos ? p : min_pos;
+            } else
+                uns++;
+            cthis = c;
+        }
+        c4[it] = cthis;
+        // what the staged column keeps of the read: aend, and the per-read predicates (bit 31: the record carries its bases)
+        aend4[it] = pos4[it] + al - 1;
+        u32 meta = read_meta(flag4[it], xs4[it], mapq4[it], pos4[it], mtid4[it], mpos4[it], tid, orientation);
+        if (cthis > 1) meta |= META_MULTI;
+        if ((u64)(so4n[it] - so4[it]) * 8ull >= (u64)(int64_t)len4[it]) meta |= 0x80000000u;
+        meta4[it] = meta;
+    }
+    // ---- ordered compaction: read order is round-major (r = base + it * K1W_THREADS + thread); one wave scan per round
+    u64 inc[K1W_RPT];
+    const int w = threadIdx.x >> 6;
+#pragma unroll
+    for (int it = 0; it < K1W_RPT; it++) {
+        inc[it] = wave_iscan<u64>(((u64)c4[it] << 16) | (u64)(c4[it] ? 1u : 0u));
+        if (lane_id() == 63) sm_scan[it][w] = inc[it];
+    }
+    // block reduce of the length statistics (as k1_count)
+    u64 packed = ((u64)wave_total<DppAdd>(cnt) << 32) | (u64)wave_total<DppAdd>((spl << 16) | uns);
+    sum = (u64)wave_total<DppAdd>((u32)(sum & 0xffffu)) + ((u64)wave_total<DppAdd>((u32)((sum >> 16) & 0xffffu)) << 16) +
+          ((u64)wave_total<DppAdd>((u32)(sum >> 32)) << 32);
+    auto smin = [](int32_t v) { return (int32_t)(wave_total<DppMin>((u32)v ^ 0x80000000u) ^ 0x80000000u); };
+    auto smax = [](int32_t v) { return (int32_t)(wave_total<DppMax>((u32)v ^ 0x80000000u) ^ 0x80000000u); };
+    mn = smin(mn);
+    mx = smax(mx);
+    max_end = smax(max_end);
+    max_nlen = smax(max_nlen);
+    min_pos = smin(min_pos);
+    if (lane_id() == 0) {
+        smp[w] = packed;
+        sm64[w] = sum;
+        smi[w][0] = mn;
+        smi[w][1] = mx;
+        smi[w][2] = max_end;
+        smi[w][3] = max_nlen;
+        smi[w][4] = min_pos;
+    }
+    __syncthreads();
+    u32 slot4[K1W_RPT], poff4[K1W_RPT]; // rank among the tile's spliced reads; pairs before the read, in read order within the tile
+    u64 run = 0;
+#pragma unroll
+    for (int it = 0; it < K1W_RPT; it++) {
+        u64 before = run;
+#pragma unroll
+        for (int i = 0; i < K1W_WAVES; i++) {
+            const u64 t = sm_scan[it][i];
+            if (i < w) before += t;
+            run += t;
+        }
+        const u64 ex = before + inc[it] - (((u64)c4[it] << 16) | (u64)(c4[it] ? 1u : 0u));
+        slot4[it] = (u32)(ex & 0xffffu);
+        poff4[it] = (u32)(ex >> 16);
+    }
+    const u64 tile_pairs = run >> 16;
+    const u32 tile_spl = (u32)(run & 0xffffu);
+    // ---- publish the tile's pair count; tile statistics
+    const u32 grp = tile / K1W_GROUP, gi = tile % K1W_GROUP;
+    if (threadIdx.x == 0) {
+        st_agent(&Lk.tile_desc[tile], K1W_VALID | tile_pairs);
+        const u32 gsize = min((u32)K1W_GROUP, n_tiles_total - grp * K1W_GROUP);
+        const u64 old = atomicAdd(&Lk.grp_acc[grp], (1ull << 40) | tile_pairs);
+        if ((u32)(old >> 40) + 1 == gsize) st_agent(&Lk.grp_desc[grp], K1W_VALID | (grp == 0 ? K1W_PREFIX : 0ull) | ((old & K1W_VALUE) + tile_pairs));
+        u64 p = 0, sl = 0;
+        int32_t a0 = INT32_MAX, a1 = 0, a2 = 0, a3 = 0, a4 = INT32_MAX;
+        for (int i = 0; i < K1W_WAVES; i++) {
+            p += smp[i];
+            sl += sm64[i];
+            a0 = min(a0, smi[i][0]);
+            a1 = max(a1, smi[i][1]);
+            a2 = max(a2, smi[i][2]);
+            a3 = max(a3, smi[i][3]);
+            a4 = min(a4, smi[i][4]);
+        }
+        TileStats t;
+        t.spliced = (u32)((p >> 16) & 0xffff);
+        t.unspliced = (u32)(p & 0xffff);
+        t.sum_len = sl;
+        t.min_len = a0;
+        t.max_len = a1;
+        t.max_end = a2;
+        t.max_nlen = a3;
+        t.min_pos = a4;
+        t._pad = 0;
+        tile_stats[tile] = t;
+    }
+    // ---- the first wave fetches the number of pairs before the tile; the others go on staging
+    if (w == 0) {
+        const int lane = lane_id();
+        u64 excl_g = 0;
+        if (gi == 0) {
+            int64_t gg = (int64_t)grp - 1;
+            while (gg >= 0) {
+                const int64_t my = gg - lane;
+                u64 d = 0;
+                if (my >= 0) d = wait_valid(&Lk.grp_desc[my], err);
+                const u64 pm = __ballot((d & K1W_PREFIX) != 0);
+                const int stop = pm ? __ffsll((unsigned long long)pm) - 1 : 64;
+                excl_g += wave_sum_u64((my >= 0 && lane <= stop) ? (d & K1W_VALUE) : 0ull);
+                if (pm) break;
+                gg -= 64;
             }
-        }
-        const u64 seq_addr = (meta & META_SIMPLE) ? (u64)(uintptr_t)(b.seq4 + (size_t)b.seq_off[r] * 4) : 0ull;
-        // ---- walk: pairs (junction_system.cc:140-210) and, with two monotone cursors over the read's own
-        // introns, the up/down junction counts (junction.cc:795-812)
-        const int32_t aend = pos + aligned - 1;
-        NCursor U = {0, pos, false, 0}, D = {0, pos, false, 0};
-        ncursor_advance(U, cig, n);
-        ncursor_advance(D, cig, n);
-        u32 cntU = 0, cntD = 0;
-        int32_t lStart = pos, lEndExc = pos, sumAfter = 0, prevRStartU = 0, prevIend = 0;
-        int64_t prev = -1;
-        u32 k = 0;
-        for (u32 i = 0; i < n; i++) {
-            const u32 op = cig[i];
-            const u32 ty = op & 15u;
-            const int32_t ln = (int32_t)(op >> 4);
-            if (ty == OP_N) {
-                if (prev >= 0) {
-                    int32_t rEndExc = prevRStartU + sumAfter;
-                    if (rEndExc - 1 >= ref_len) rEndExc = ref_len; // junction_system.cc:172-174
-                    P.rend[prev] = rEndExc - 1;
-                    if (rEndExc - 1 < prevIend) set_error(err, g, PJB_ERR_MIN_ANCHOR); // intron.cc:76
-                }
-                const int32_t istart = lEndExc;
-                const int32_t rStartU = lEndExc + ln;
-                int32_t rStart = rStartU;
-                if (rStart - 1 >= ref_len) rStart = ref_len - 1; // junction_system.cc:169-171
-                const int32_t iend = rStart - 1;
-                while (U.has && U.peek < istart) {
-                    cntU++;
-                    ncursor_advance(U, cig, n);
-                }
-                while (D.has && D.peek <= iend + 1) {
-                    cntD++;
-                    ncursor_advance(D, cig, n);
-                }
-                const int64_t idx = (int64_t)off + k;
-                P.key[idx] = make_key(kf, istart, iend);
-                P.g[idx] = g;
-                P.lstart[idx] = lStart;
-                P.pos[idx] = pos;
-                P.meta[idx] = meta;
-                P.aend[idx] = aend;
-                P.updown[idx] = cntU | ((nN - cntD) << 16);
-                P.seqw[idx] = seq_addr;
-                if (lStart > istart) set_error(err, g, PJB_ERR_MIN_ANCHOR); // intron.cc:68
-                prev = idx;
-                prevIend = iend;
-                prevRStartU = rStartU;
-                sumAfter = 0;
-                lStart = rStart;
-                lEndExc = rStart;
-                k++;
-            } else if (op_consumes_ref(ty)) {
-                lEndExc += ln;
-                sumAfter += ln;
+            if (lane == 0) {
+                st_agent(&Lk.grp_excl[grp], K1W_VALID | excl_g);
+                if (grp > 0) st_agent(&Lk.grp_desc[grp - 1], K1W_VALID | K1W_PREFIX | excl_g);
             }
+        } else {
+            u64 d = 0;
+            if (lane == 0) d = wait_valid(&Lk.grp_excl[grp], err) & K1W_VALUE;
+            excl_g = __shfl(d, 0, 64);
         }
-        {
-            int32_t rEndExc = prevRStartU + sumAfter;
-            if (rEndExc - 1 >= ref_len) rEndExc = ref_len;
-            P.rend[prev] = rEndExc - 1;
-            if (rEndExc - 1 < prevIend) set_error(err, g, PJB_ERR_MIN_ANCHOR);
+        u64 v = 0;
+        if ((u32)lane < gi) v = wait_valid(&Lk.tile_desc[(size_t)grp * K1W_GROUP + lane], err) & K1W_VALUE;
+        const u64 excl = excl_g + wave_sum_u64(v);
+        if (lane == 0) s_excl = excl;
+    }
+    // ---- stage the tile's spliced reads in LDS columns, then one thread per column walks and writes the pairs
+#pragma unroll
+    for (int it = 0; it < K1W_RPT; it++) {
+        if (c4[it]) {
+            const u32 rl = (u32)(it * K1W_THREADS) + threadIdx.x;
+            const u32 sl = slot4[it];
+#pragma unroll
+            for (int k = 0; k < K1_OPS; k++) s_ops[k][sl] = ops[it][k];
+            s_rec[0][sl] = (u32)pos4[it];
+            s_rec[1][sl] = meta4[it];
+            s_rec[2][sl] = nop[it];
+            s_rec[3][sl] = rl | (c4[it] << 10);
+            s_rec[4][sl] = (u32)aend4[it];
+            s_rec[5][sl] = (u32)len4[it];
+            s_rec[6][sl] = so4[it];
+            s_rec[7][sl] = poff4[it];
+            s_rec[8][sl] = c0[it];
+            if (spl_idx) spl_idx[(size_t)tile * K1_TILE + sl] = (u32)base + rl;
         }
+    }
+    __syncthreads();
+    const u64 excl = s_excl;
+    if (excl + tile_pairs > (u64)pair_limit) return; // more pairs than planned: k1_scan_tiles raises OVF_PAIRS, the contig is repeated
+    for (u32 k = threadIdx.x; k < tile_spl; k += K1W_THREADS) {
+        EmitRead R;
+        R.pos = (int32_t)s_rec[0][k];
+        const u32 m = s_rec[1][k];
+        R.meta = m & 0x7fffffffu;
+        R.seq_ok = (m & 0x80000000u) != 0;
+        R.n = s_rec[2][k];
+        const u32 rn = s_rec[3][k];
+        R.nN = rn >> 10;
+        R.g = b.base + (u32)base + (rn & 1023u);
+        R.aend = (int32_t)s_rec[4][k];
+        R.lq = (int32_t)s_rec[5][k];
+        R.seq_ptr = (u64)(uintptr_t)(b.seq4 + (size_t)s_rec[6][k] * 4);
+        R.off = (u32)(excl + s_rec[7][k]);
+        OpsViewT<K1_TILE, K1W_OPS> cig;
+        cig.lds = &s_ops[0][k];
+        cig.g = b.cigar + s_rec[8][k];
+        // (the owner staged ops 0..3 from its registers; the rest of the column comes from lines it fetched a moment ago)
+#pragma unroll
+        for (int q = K1_OPS; q < K1W_OPS; q++) s_ops[q][k] = (u32)q < R.n ? cig.g[q] : 0u;
+        emit_read_pairs(cig, R, P, kf, ref_len, err);
     }
 }
 

@@ -20,7 +20,7 @@ for f in sorted(glob.glob('/tmp/pmcsq_*.csv')):
     for r in csv.DictReader(open(f)):
         n = r['Kernel_Name'].split('(')[0].replace('void ', '').split('<')[0].replace('pjb::', '')
         acc[n][r['Counter_Name']].append(float(r['Counter_Value']))
-names = ['k1_count', 'k1_emit', 'k4a_simple', 'k4b_generic', 'k4_pairs', 'k3_anchors_frag', 'kd_unique', 'rs_scatter', 'rs_hist', 'k5_frag_reduce']
+names = ['k1_walk', 'k1_count', 'k1_emit', 'k4a_simple', 'k4b_generic', 'k4_pairs', 'k3_anchors_frag', 'kd_unique', 'rs_scatter', 'rs_hist', 'k5_frag_reduce']
 ctrs = sorted({c for n in acc for c in acc[n]})
 print('counter'.ljust(32) + ''.join(n[:13].rjust(14) for n in names))
 for c in ctrs:

@@ -15,7 +15,7 @@ with open(sys.argv[1]) as f:
 rows.sort()
 # last step: the last n k1_count launches
 nc = int(sys.argv[2]) if len(sys.argv) > 2 else 25
-starts = [i for i, r in enumerate(rows) if r[2] == "k1_count"]
+starts = [i for i, r in enumerate(rows) if r[2] in ("k1_count", "k1_walk")]
 if len(starts) < nc:
     print("kernel names seen:", sorted(set(r[2] for r in rows))[:40])
     sys.exit(1)
