@@ -196,6 +196,17 @@ int pjb_upload_contig(pjb_ctx *ctx, int32_t tid, const uint8_t *bases, int64_t l
 /* Same, for bases that are ALREADY upper-cased and resident in HBM; borrowed until
  * pjb_release_contig / pjb_destroy. */
 int pjb_upload_contig_device(pjb_ctx *ctx, int32_t tid, const uint8_t *d_bases_upper, int64_t len);
+
+/* The same upload from the FASTA file's own bytes: `raw` holds the record's sequence lines as they are in the file
+ * (from the byte the .fai's OFFSET names, raw_bytes of them), line_blen / line_len are the .fai's LINEBASES / LINEWIDTH
+ * and len its LENGTH.  The device takes the line terminators out (base i is byte (i / line_blen) * line_len + i % line_blen),
+ * so the host neither parses nor copies the 250 MB of a human chromosome -- GenomeMapper::fetchBases's loader
+ * (faidx_fetch_seq, deps/htslib-1.3/faidx.c:439-476, keeps the graphic characters) reduced to a pread.  A record that is
+ * not laid out that way (a base position that holds a non-graphic byte, a graphic byte among the terminators, too few
+ * bytes) is left alone: *well_formed = 0, nothing is uploaded, and the caller filters the characters itself
+ * (pjb_upload_contig).  raw in page-locked memory (pjb_host_alloc) crosses in one DMA. */
+int pjb_upload_contig_fasta(pjb_ctx *ctx, int32_t tid, const uint8_t *raw, int64_t raw_bytes, int32_t line_blen, int32_t line_len,
+                            int64_t len, int *well_formed);
 int pjb_release_contig(pjb_ctx *ctx, int32_t tid);
 
 /* Append a batch to contig `tid` (opens it if it is not open).  The host
@@ -338,6 +349,11 @@ int pjb_bam_begin(pjb_ctx* ctx, int32_t tid, int64_t total_bytes);
 int pjb_bam_piece(pjb_ctx* ctx, int32_t tid, const uint8_t* piece, int64_t bytes, int64_t* ticket);
 int pjb_bam_pieces_done(pjb_ctx* ctx, int64_t* completed_ticket);
 int pjb_bam_end(pjb_ctx* ctx, int32_t tid, int32_t first_uoffset, int64_t* n_records);
+/* The target's bgzf_inflate starts by itself when its last piece has been handed over (on a stream of its own, behind the
+ * copy): 1 if it has finished -- or none is in flight -- i.e. pjb_bam_end will not wait for it, else 0.  A caller that
+ * serves several targets can hand over other targets' pieces meanwhile; their inflates then run side by side (a launch
+ * takes ~50 ms whatever its size, and most targets do not fill the chip). */
+int pjb_bam_inflate_done(pjb_ctx *ctx, int32_t tid);
 
 /* ---- `portcullis filt` feature rows -------------------------------------------------------
  * ModelFeatures::setRow (lib/src/model_features.cc:161-212) for a list of junctions: the columns of VAR_NAMES +

@@ -149,6 +149,12 @@ struct pjb_ctx {
     // device ingest in pieces (pjb_bam_begin / _piece / _end)
     std::map<int32_t, struct BamStage *> bam_stage;
     std::vector<Buf> stage_pool;  // device buffers for staged BGZF bytes, reused target after target
+    // pjb_bam_piece starts a target's bgzf_inflate as soon as its last piece is on its way (own stream, own buffers), so that
+    // the inflates of several targets overlap each other and the copies: a launch takes ~50 ms whatever its size (a lane's
+    // 64 KB block), and most targets fill less than the chip
+    std::vector<Buf> out_pool, misc_pool;  // inflated bytes; block tables / status words / per-lane scratch
+    hipStream_t inf_streams[4] = {};
+    unsigned inf_next = 0;
     hipStream_t stream_up = nullptr;
     hipEvent_t ev_up = nullptr;
     hipEvent_t up_events[64] = {};
@@ -210,6 +216,7 @@ struct pjb_ctx {
     Buf g_rows, g_models, g_refs, g_out, g_bad; // filt feature rows
     Buf x_pos, x_endx, x_q, x_prefq, x_ce, x_bound, x_de, x_dropped, x_zlist, x_cnt, x_tabk, x_tabc, x_rs, x_re, x_rr, x_tileoff;
     Buf b_hasx, b_xtotal;
+    Buf b_fasta_raw; // pjb_upload_contig_fasta: the record's bytes as they are in the file
 };
 
 namespace {
@@ -437,6 +444,7 @@ int close_contig(pjb_ctx *c, int32_t tid) {
     return PJB_OK;
 }
 
+int upload_staged(pjb_ctx *c, void *dst, const uint8_t *src, size_t bytes); // (defined with the ingest code)
 } // namespace
 
 extern "C" {
@@ -564,7 +572,7 @@ void pjb_destroy(pjb_ctx *c) {
         if (c->stage[k]) (void)hipHostFree(c->stage[k]);
         if (c->stage_ev[k]) (void)hipEventDestroy(c->stage_ev[k]);
     }
-    Buf *all[] = {&c->b_cursor, &c->b_scan_tiles, &c->b_hasx, &c->b_xtotal, &c->b_inf_comp, &c->b_inf_out, &c->b_inf_blocks, &c->b_inf_status, &c->b_inf_scratch,
+    Buf *all[] = {&c->b_cursor, &c->b_scan_tiles, &c->b_hasx, &c->b_xtotal, &c->b_fasta_raw, &c->b_inf_comp, &c->b_inf_out, &c->b_inf_blocks, &c->b_inf_status, &c->b_inf_scratch,
                   &c->b_bam_seg, &c->b_bam_rec, &c->b_bam_ctl, &c->f_pos, &c->f_cigoff, &c->f_cigar, &c->f_codes, &c->g_rows, &c->g_models, &c->g_refs,
                   &c->g_out, &c->g_bad,
                   &c->x_pos, &c->x_endx, &c->x_q, &c->x_prefq, &c->x_ce, &c->x_bound, &c->x_de, &c->x_dropped, &c->x_zlist, &c->x_cnt,
@@ -676,6 +684,49 @@ int pjb_upload_contig(pjb_ctx *c, int32_t tid, const uint8_t *bases, int64_t len
     int rc = upload_common(c, tid, d, len, true, true);
     if (rc) (void)hipFree(d);
     return rc;
+}
+
+int pjb_upload_contig_fasta(pjb_ctx *c, int32_t tid, const uint8_t *raw, int64_t raw_bytes, int32_t line_blen, int32_t line_len, int64_t len,
+                            int *well_formed) {
+    if (!c) return PJB_ERR_ARG;
+    if (tid < 0 || (size_t)tid >= c->contigs.size() || len < 0 || raw_bytes < 0 || (raw_bytes > 0 && !raw) || line_blen <= 0 ||
+        line_len < line_blen || !well_formed)
+        return fail(c, PJB_ERR_ARG, "pjb_upload_contig_fasta: bad arguments (tid %d)", tid);
+    *well_formed = 0;
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    int rc;
+    if ((rc = ensure(c, c->b_fasta_raw, (size_t)std::max<int64_t>(raw_bytes, 16)))) return rc;
+    if ((rc = ensure(c, c->b_hasx, sizeof(int)))) return rc;
+    uint8_t *d = nullptr;
+    hipError_t e = hipMalloc((void **)&d, (size_t)std::max<int64_t>(len, 16));
+    if (e != hipSuccess) return fail(c, PJB_ERR_NOMEM, "hipMalloc(genome %lld): %s", (long long)len, hipGetErrorString(e));
+    struct Guard {
+        uint8_t *d;
+        ~Guard() {
+            if (d) (void)hipFree(d);
+        }
+    } guard{d};
+    // page-locked input (pjb_host_alloc): one DMA; otherwise through the staging buffers
+    hipPointerAttribute_t at;
+    const bool pinned = raw_bytes > 0 && hipPointerGetAttributes(&at, raw) == hipSuccess && at.type == hipMemoryTypeHost;
+    if (!pinned) (void)hipGetLastError();
+    if (pinned) HIP_TRY(c, hipMemcpyAsync(c->b_fasta_raw.p, raw, (size_t)raw_bytes, hipMemcpyHostToDevice, c->stream));
+    else if (raw_bytes > 0 && (rc = upload_staged(c, c->b_fasta_raw.p, raw, (size_t)raw_bytes))) return rc;
+    int bad = 0;
+    HIP_TRY(c, hipMemsetAsync(c->b_hasx.p, 0, sizeof(int), c->stream));
+    if (len > 0) {
+        const int64_t nthreads = (len + 15) / 16;
+        hipLaunchKernelGGL(k0_fasta, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, c->stream, (const uint8_t *)c->b_fasta_raw.p, raw_bytes, len,
+                           line_blen, line_len, d, (int *)c->b_hasx.p);
+    }
+    HIP_TRY(c, hipMemcpyAsync(&bad, c->b_hasx.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (bad) return PJB_OK; // (*well_formed stays 0: nothing was uploaded)
+    rc = upload_common(c, tid, d, len, true, true);
+    if (rc) return rc;
+    guard.d = nullptr;
+    *well_formed = 1;
+    return PJB_OK;
 }
 
 int pjb_upload_contig_device(pjb_ctx *c, int32_t tid, const uint8_t *d_bases_upper, int64_t len) {
@@ -1930,6 +1981,20 @@ int upload_staged(pjb_ctx *c, void *dst, const uint8_t *src, size_t bytes) {
 
 
 // comp already on the device (padded); blocks on the host
+// the status words of a finished bgzf_inflate (d_status[nb] = "some block failed")
+int inflate_status(pjb_ctx *c, const std::vector<InfBlock> &blocks, const int *d_status) {
+    const size_t nb = blocks.size();
+    int any = 0;
+    HIP_TRY(c, hipMemcpy(&any, d_status + nb, 4, hipMemcpyDeviceToHost));
+    if (!any) return PJB_OK;
+    std::vector<int> status(nb);
+    HIP_TRY(c, hipMemcpy(status.data(), d_status, nb * 4, hipMemcpyDeviceToHost));
+    for (size_t b = 0; b < nb; b++)
+        if (status[b])
+            return fail(c, PJB_ERR_BGZF, "BGZF block %zu (payload at byte %llu): %s", b, (unsigned long long)blocks[b].in_off, inf_text(status[b]));
+    return fail(c, PJB_ERR_BGZF, "BGZF inflate failed");
+}
+
 int inflate_on_device(pjb_ctx *c, const uint8_t *d_comp, const std::vector<InfBlock> &blocks, uint8_t *d_out) {
     int rc;
     const size_t nb = blocks.size();
@@ -1950,20 +2015,9 @@ int inflate_on_device(pjb_ctx *c, const uint8_t *d_comp, const std::vector<InfBl
     HIP_TRY(c, hipMemcpyAsync(d_any, ctl, 8, hipMemcpyHostToDevice, st));
     LAUNCH_LDS(c, "bgzf_inflate", bgzf_inflate, dim3((unsigned)(lanes / 64)), dim3(64), I2_LDS_BYTES, d_comp, (const InfBlock *)c->b_inf_blocks.p, (iu32)nb,
                d_out, (uint8_t *)c->b_inf_scratch.p, d_status, d_any, d_next, 8);
-    int any = 0;
-    HIP_TRY(c, hipMemcpyAsync(&any, d_any, 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(c, hipStreamSynchronize(st));
     if (c->ktime) ev_collect(c, MISC_POOL);
-    if (any) {
-        std::vector<int> status(nb);
-        HIP_TRY(c, hipMemcpy(status.data(), d_status, nb * 4, hipMemcpyDeviceToHost));
-        for (size_t b = 0; b < nb; b++)
-            if (status[b])
-                return fail(c, PJB_ERR_BGZF, "BGZF block %zu (payload at byte %llu): %s", b, (unsigned long long)blocks[b].in_off,
-                            inf_text(status[b]));
-        return fail(c, PJB_ERR_BGZF, "BGZF inflate failed");
-    }
-    return PJB_OK;
+    return inflate_status(c, blocks, d_status);
 }
 } // namespace
 
@@ -1988,23 +2042,32 @@ extern "C" int pjb_inflate_bgzf(pjb_ctx *c, const uint8_t *comp, int64_t comp_by
     return PJB_OK;
 }
 
+static int ingest_parse(pjb_ctx *c, int32_t tid, OpenContig &oc, const uint8_t *d_out, size_t n_blocks, int64_t comp_bytes, int64_t total,
+                        int32_t first_uoffset, int64_t *n_records, double t_scan, double t_up, double t_inf);
+
 // the part of pjb_submit_bam behind the upload: `d_comp` holds the target's BGZF bytes (padded), `blocks` their layout
 static int ingest_staged(pjb_ctx *c, int32_t tid, OpenContig &oc, const uint8_t *d_comp, const std::vector<InfBlock> &blocks, int64_t comp_bytes,
                          int64_t total, int32_t first_uoffset, int64_t *n_records, double t_scan, double t_up) {
-    const bool prof = getenv("PJB_PROFILE_HOST") != nullptr;
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-    double t0 = now(), t_inf, t_walk;
-    hipStream_t st = c->stream;
+    const double t0 = now();
     int rc;
     if ((rc = ensure(c, c->b_inf_out, (size_t)total + 64))) return rc;
-    HIP_TRY(c, hipMemsetAsync((uint8_t *)c->b_inf_out.p + total, 0, 64, st));
+    HIP_TRY(c, hipMemsetAsync((uint8_t *)c->b_inf_out.p + total, 0, 64, c->stream));
     if ((rc = inflate_on_device(c, d_comp, blocks, (uint8_t *)c->b_inf_out.p))) return rc;
+    return ingest_parse(c, tid, oc, (const uint8_t *)c->b_inf_out.p, blocks.size(), comp_bytes, total, first_uoffset, n_records, t_scan, t_up, now() - t0);
+}
 
-    t_inf = now() - t0;
-    t0 = now();
+// the inflated bytes of one target's region (d_out, `total` of them followed by 64 zero bytes) -> the SoA batch of the target
+static int ingest_parse(pjb_ctx *c, int32_t tid, OpenContig &oc, const uint8_t *d_out, size_t n_blocks, int64_t comp_bytes, int64_t total,
+                        int32_t first_uoffset, int64_t *n_records, double t_scan, double t_up, double t_inf) {
+    const bool prof = getenv("PJB_PROFILE_HOST") != nullptr;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t0 = now(), t_walk;
+    hipStream_t st = c->stream;
+    int rc;
     // ---- record boundaries
     BamRegion R;
-    R.U = (const uint8_t *)c->b_inf_out.p;
+    R.U = d_out;
     R.total = (iu64)total;
     R.first = (iu64)first_uoffset;
     R.tid = tid;
@@ -2132,7 +2195,7 @@ static int ingest_staged(pjb_ctx *c, int32_t tid, OpenContig &oc, const uint8_t 
     if (prof)
         fprintf(stderr, "[host profile] submit_bam tid %d: %zu blocks, %.1f MB -> %.1f MB, %zu records: header scan %.3f, upload %.3f, inflate %.3f, "
                         "boundaries %.3f, fill+sizes+transcode %.3f s\n",
-                tid, blocks.size(), comp_bytes / 1e6, total / 1e6, n, t_scan, t_up, t_inf, t_walk, now() - t0);
+                tid, n_blocks, comp_bytes / 1e6, total / 1e6, n, t_scan, t_up, t_inf, t_walk, now() - t0);
     DevBatch d;
     memset(&d, 0, sizeof d);
     d.n = (int64_t)n;
@@ -2195,7 +2258,75 @@ struct BamStage {
     uint8_t keep[65536 + 64]; // bytes [keep_at, got) of what arrived, for a block whose header or footer straddles two pieces
     int64_t keep_at = 0, keep_n = 0;
     double t_scan = 0, t_up = 0;
+    // the inflate launched at the last piece (launched: ev_inf follows the kernel on its stream)
+    bool launched = false;
+    Buf out, d_blocks, d_status, d_scratch;
+    hipEvent_t ev_inf = nullptr, ev_last = nullptr;
 };
+
+// a buffer of at least `bytes` from a pool (the smallest that fits), else a new one
+static int pool_take(pjb_ctx *c, std::vector<Buf> &pool, Buf &b, size_t bytes) {
+    int best = -1;
+    for (size_t k = 0; k < pool.size(); k++)
+        if (pool[k].cap >= bytes && (best < 0 || pool[k].cap < pool[(size_t)best].cap)) best = (int)k;
+    if (best >= 0) {
+        b = pool[(size_t)best];
+        pool.erase(pool.begin() + best);
+        return PJB_OK;
+    }
+    return ensure(c, b, bytes);
+}
+static void pool_give(std::vector<Buf> &pool, Buf &b) {
+    if (b.p) pool.push_back(b);
+    b.p = nullptr;
+    b.cap = 0;
+}
+static void stage_release(pjb_ctx *c, BamStage &st) { // (after the work that uses the buffers has completed)
+    pool_give(c->stage_pool, st.dev);
+    pool_give(c->out_pool, st.out);
+    pool_give(c->misc_pool, st.d_blocks);
+    pool_give(c->misc_pool, st.d_status);
+    pool_give(c->misc_pool, st.d_scratch);
+    if (st.ev_inf) (void)hipEventDestroy(st.ev_inf);
+    if (st.ev_last) (void)hipEventDestroy(st.ev_last);
+    st.ev_inf = st.ev_last = nullptr;
+}
+
+// every byte of the target has been queued for copying and every block header seen: inflate on a stream of its own, behind
+// the last copy.  Nothing here waits; a failure just leaves the inflate to pjb_bam_end.
+static void inflate_early(pjb_ctx *c, BamStage &st) {
+    const size_t nb = st.blocks.size();
+    if (st.launched || nb == 0 || st.total_out <= 0 || getenv("PJB_NO_EARLY_INFLATE")) return;
+    size_t lanes = std::min<size_t>((nb + 63) / 64 * 64, (size_t)c->inflate_lanes);
+    if (const char *e = getenv("PJB_INF_BLOCKS_PER_LAUNCH")) lanes = std::min<size_t>((nb + 63) / 64 * 64, (size_t)std::max(64, atoi(e)) / 64 * 64);
+    if (pool_take(c, c->out_pool, st.out, (size_t)st.total_out + 64) || pool_take(c, c->misc_pool, st.d_blocks, nb * sizeof(InfBlock)) ||
+        pool_take(c, c->misc_pool, st.d_status, nb * 4 + 16) || pool_take(c, c->misc_pool, st.d_scratch, lanes * INF_SCRATCH_PER_LANE)) {
+        c->err.clear();
+        return;
+    }
+    hipStream_t &is = c->inf_streams[c->inf_next++ & 3u];
+    if (!is && hipStreamCreateWithFlags(&is, hipStreamNonBlocking) != hipSuccess) return;
+    if (hipEventCreateWithFlags(&st.ev_last, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&st.ev_inf, hipEventDisableTiming) != hipSuccess) return;
+    int *d_status = (int *)st.d_status.p;
+    int *d_any = d_status + nb;
+    iu32 *d_next = (iu32 *)(d_any + 1);
+    const iu32 ctl[2] = {0u, (iu32)lanes};
+    bool ok = hipEventRecord(st.ev_last, c->stream_up) == hipSuccess && hipStreamWaitEvent(is, st.ev_last, 0) == hipSuccess &&
+              hipMemsetAsync((uint8_t *)st.out.p + st.total_out, 0, 64, is) == hipSuccess &&
+              hipMemcpyAsync(st.d_blocks.p, st.blocks.data(), nb * sizeof(InfBlock), hipMemcpyHostToDevice, is) == hipSuccess &&
+              hipMemcpyAsync(d_any, ctl, 8, hipMemcpyHostToDevice, is) == hipSuccess;
+    if (ok) {
+        hipLaunchKernelGGL(bgzf_inflate, dim3((unsigned)(lanes / 64)), dim3(64), I2_LDS_BYTES, is, (const uint8_t *)st.dev.p, (const InfBlock *)st.d_blocks.p,
+                           (iu32)nb, (uint8_t *)st.out.p, (uint8_t *)st.d_scratch.p, d_status, d_any, d_next, 8);
+        ok = hipGetLastError() == hipSuccess && hipEventRecord(st.ev_inf, is) == hipSuccess;
+    }
+    if (!ok) { // whatever was queued must be over before the buffers are used again
+        (void)hipStreamSynchronize(is);
+        (void)hipGetLastError();
+        return;
+    }
+    st.launched = true;
+}
 
 // block headers that are complete with the bytes received so far (the last `avail` bytes of the stream are at `p`, the
 // first of them is byte `p_at` of the target's bytes); leaves st.next at the first block it cannot finish yet
@@ -2251,13 +2382,19 @@ static int stage_scan(pjb_ctx *c, BamStage &st, const uint8_t *p, int64_t p_at, 
 }
 
 static void bam_stage_clear(pjb_ctx *c) {
+    for (auto &is : c->inf_streams)
+        if (is) (void)hipStreamSynchronize(is);
     for (auto &kv : c->bam_stage) {
-        if (kv.second->dev.p) (void)hipFree(kv.second->dev.p);
+        stage_release(c, *kv.second);
         delete kv.second;
     }
     c->bam_stage.clear();
-    for (auto &b : c->stage_pool) release(b);
-    c->stage_pool.clear();
+    for (auto *pool : {&c->stage_pool, &c->out_pool, &c->misc_pool}) {
+        for (auto &b : *pool) release(b);
+        pool->clear();
+    }
+    for (auto &is : c->inf_streams)
+        if (is) (void)hipStreamDestroy(is);
     for (auto &ev : c->up_events)
         if (ev) (void)hipEventDestroy(ev);
     if (c->ev_up) (void)hipEventDestroy(c->ev_up);
@@ -2301,7 +2438,9 @@ extern "C" int pjb_bam_piece(pjb_ctx *c, int32_t tid, const uint8_t *piece, int6
     const int rc = bam_piece_body(c, tid, *it->second, piece, bytes, ticket);
     if (rc) { // the target's staging is dropped: it has to be begun again
         (void)hipStreamSynchronize(c->stream_up);
-        if (it->second->dev.p) c->stage_pool.push_back(it->second->dev);
+        for (auto &is : c->inf_streams)
+            if (is) (void)hipStreamSynchronize(is);
+        stage_release(c, *it->second);
         delete it->second;
         c->bam_stage.erase(it);
     }
@@ -2347,7 +2486,17 @@ static int bam_piece_body(pjb_ctx *c, int32_t tid, BamStage &st, const uint8_t *
         st.keep_n = 0;
     st.t_scan += now() - t0;
     if (ticket) *ticket = tk;
+    if (st.got == st.total && st.next == st.total) inflate_early(c, st);
     return PJB_OK;
+}
+
+extern "C" int pjb_bam_inflate_done(pjb_ctx *c, int32_t tid) {
+    if (!c) return 1;
+    auto it = c->bam_stage.find(tid);
+    if (it == c->bam_stage.end() || !it->second->launched) return 1; // (nothing in flight: pjb_bam_end does all the work)
+    const bool done = hipEventQuery(it->second->ev_inf) == hipSuccess;
+    (void)hipGetLastError();
+    return done ? 1 : 0;
 }
 
 extern "C" int pjb_bam_pieces_done(pjb_ctx *c, int64_t *completed_ticket) {
@@ -2374,7 +2523,8 @@ extern "C" int pjb_bam_end(pjb_ctx *c, int32_t tid, int32_t first_uoffset, int64
         BamStage *st;
         ~Return() {
             (void)hipStreamSynchronize(c->stream);
-            if (st->dev.p) c->stage_pool.push_back(st->dev);
+            if (st->launched) (void)hipEventSynchronize(st->ev_inf);
+            stage_release(c, *st);
         }
     } ret{c, st.get()};
     c->cur_tid = tid;
@@ -2385,6 +2535,15 @@ extern "C" int pjb_bam_end(pjb_ctx *c, int32_t tid, int32_t first_uoffset, int64
     OpenContig &oc = c->open[tid];
     if (!oc.batches.empty()) return fail(c, PJB_ERR_STATE, "bam_end: target %d already has batches (one call per target)", tid);
     if (st->total_out == 0 || (int64_t)first_uoffset >= st->total_out) return PJB_OK;
+    if (st->launched) { // the inflate started with the last piece: wait for it, look at its status words, go on with the records
+        auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+        const double t0 = now();
+        HIP_TRY(c, hipEventSynchronize(st->ev_inf));
+        int rc = inflate_status(c, st->blocks, (const int *)st->d_status.p);
+        if (rc) return rc;
+        return ingest_parse(c, tid, oc, (const uint8_t *)st->out.p, st->blocks.size(), st->total, st->total_out, first_uoffset, n_records, st->t_scan, st->t_up,
+                            now() - t0);
+    }
     // the service stream picks up behind the last copy
     if (!c->ev_up) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_up, hipEventDisableTiming));
     HIP_TRY(c, hipEventRecord(c->ev_up, c->stream_up));

@@ -369,6 +369,39 @@ __global__ __launch_bounds__(256) void k0_upper(uint8_t *g, int64_t n, int do_up
     }
 }
 
+// K0f: the sequence lines of one FASTA record, as they are in the file, -> its bases.  With the .fai's geometry (line_blen
+// bases per line, line_len bytes per line) base i sits at byte (i / line_blen) * line_len + i % line_blen; every base must be
+// a graphic character and every line terminator byte not one -- the test faidx's loader implies (deps/htslib-1.3/faidx.c
+// reads with isgraph).  Anything else raises `bad` and the host falls back to filtering the characters itself.
+__global__ __launch_bounds__(256) void k0_fasta(const uint8_t *raw, int64_t raw_bytes, int64_t n, int32_t line_blen, int32_t line_len,
+                                                 uint8_t *out, int *bad) {
+    const int64_t i0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 16;
+    if (i0 >= n) return;
+    int64_t line = i0 / line_blen;
+    int32_t col = (int32_t)(i0 - line * line_blen);
+    int64_t src = line * line_len + col;
+    bool wrong = false;
+    const int64_t i1 = i0 + 16 < n ? i0 + 16 : n;
+    for (int64_t i = i0; i < i1; i++) {
+        uint8_t ch = 0;
+        if (src < raw_bytes) ch = raw[src];
+        else wrong = true;
+        wrong |= ch <= 32 || ch >= 127;
+        out[i] = ch;
+        src++;
+        if (++col == line_blen) { // end of a full line: its terminator bytes follow (if another base does)
+            if (i + 1 < n)
+                for (int32_t k = 0; k < line_len - line_blen; k++) {
+                    const uint8_t t = src + k < raw_bytes ? raw[src + k] : (uint8_t)'?';
+                    wrong |= t > 32 && t < 127;
+                }
+            src += line_len - line_blen;
+            col = 0;
+        }
+    }
+    if (__ballot(wrong) && lane_id() == 0) atomicOr(bad, 1);
+}
+
 // K0b: contig bases -> 4-bit nt16 codes, two per byte, LOW nibble first (base i at bits 4*(i&7) of
 // word i>>3).  A byte outside the 16-letter alphabet "=ACMGRSVTWYHKDBN" has no code: the contig is
 // flagged "exotic" and k4 then uses its byte-wise path, so equality semantics stay exact.

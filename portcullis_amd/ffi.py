@@ -20,12 +20,12 @@ N_STAGES = 8
 STAGE_NAMES = ["scan_emit", "sort", "group", "anchors", "pair_stats", "finalize", "d2h", "spare"]
 
 EXPORTS = [
-    "pjb_create", "pjb_destroy", "pjb_last_error", "pjb_set_refs", "pjb_upload_contig", "pjb_upload_contig_device",
+    "pjb_create", "pjb_destroy", "pjb_last_error", "pjb_set_refs", "pjb_upload_contig", "pjb_upload_contig_device", "pjb_upload_contig_fasta",
     "pjb_release_contig", "pjb_submit_batch", "pjb_submit_batch_device", "pjb_finish_contig", "pjb_finish_contig_begin",
     "pjb_finish_contig_end", "pjb_collect",
     "pjb_clear_rows", "pjb_get_timing", "pjb_device_count", "pjb_get_kernel_timing", "pjb_reset_kernel_timing",
     "pjb_select_timed_kernels", "pjb_host_alloc", "pjb_host_free", "pjb_inflate_bgzf", "pjb_submit_bam", "pjb_collect_device", "pjb_set_row_mirror",
-    "pjb_extra_finish", "pjb_set_option", "pjb_bam_begin", "pjb_bam_piece", "pjb_bam_pieces_done", "pjb_bam_end", "pjb_filter_set_junctions", "pjb_filter_batch", "pjb_filt_features",
+    "pjb_extra_finish", "pjb_set_option", "pjb_bam_begin", "pjb_bam_piece", "pjb_bam_pieces_done", "pjb_bam_end", "pjb_bam_inflate_done", "pjb_filter_set_junctions", "pjb_filter_batch", "pjb_filt_features",
 ]
 N_FEATURES = 34
 KMER_TABLE = 3125 * 5
@@ -114,6 +114,7 @@ def load():
         L.pjb_set_refs.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
         L.pjb_upload_contig.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64]
         L.pjb_upload_contig_device.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64]
+        L.pjb_upload_contig_fasta.argtypes = [C.c_void_p, C.c_int32, C.c_char_p, C.c_int64, C.c_int32, C.c_int32, C.c_int64, C.POINTER(C.c_int)]
         L.pjb_release_contig.argtypes = [C.c_void_p, C.c_int32]
         L.pjb_submit_batch.argtypes = [C.c_void_p, C.c_int32, C.POINTER(PjbBatch)]
         L.pjb_submit_batch_device.argtypes = [C.c_void_p, C.c_int32, C.POINTER(PjbBatch)]
@@ -200,6 +201,12 @@ class Context:
     def upload_contig(self, tid, bases):
         b = bases if isinstance(bases, (bytes, bytearray)) else bytes(bases)
         self._check(self._L.pjb_upload_contig(self._h, tid, b, len(b)))
+
+    def upload_contig_fasta(self, tid, raw, line_bases, line_width, length):
+        """raw: the record's sequence lines as they are in the FASTA file.  False: not laid out as stated, nothing uploaded."""
+        ok = C.c_int(0)
+        self._check(self._L.pjb_upload_contig_fasta(self._h, tid, bytes(raw), len(raw), line_bases, line_width, length, C.byref(ok)))
+        return bool(ok.value)
 
     def upload_contig_device(self, tid, tensor):
         """tensor: torch uint8 CUDA tensor of UPPER-CASE bases; must outlive the context's use of it."""

@@ -3,6 +3,7 @@
 // fetchContig returns a whole target sequence for upload to the GPU.
 #pragma once
 
+#include <cstdint>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -42,6 +43,18 @@ public:
     std::string fetchBases(const char* name, int start, int end) const;
     // every base of the sequence (graphic characters only, case preserved)
     std::string fetchContig(const std::string& name) const;
+
+    // where the sequence lines of a record lie in the file and how they are laid out (the .fai's columns); false if the
+    // record is unknown or has no line geometry
+    struct RawSpan {
+        uint64_t fileOffset = 0;
+        size_t bytes = 0;  // from the first base to the last (line terminators in between included)
+        int32_t lineBases = 0, lineWidth = 0;
+        int64_t length = 0;
+    };
+    bool rawSpan(const std::string& name, RawSpan& out) const;
+    // the bytes of a raw span, read with a few threads (pread on the open file)
+    void readRaw(const RawSpan& span, uint8_t* dst, int nthreads) const;
 };
 
 }  // namespace bam

@@ -57,6 +57,7 @@ class JunctionBuilder {
     size_t batchRecords = 1 << 20; // alignments per batch sent to the device
     int innerThreads = 1;          // decode threads inside one target sequence (set by findJunctions)
     std::shared_ptr<class PinnedPool> pinnedPool;  // ring of page-locked pieces for the file bytes of large device-ingest runs
+    std::shared_ptr<class PinnedPool> genomePool;  // a few page-locked buffers for the FASTA bytes of the target sequences (same runs)
     size_t pieceMinTarget = 0;                     // targets with fewer bytes go over in one (pageable) block
     bool deviceIngest = true;      // BGZF inflate + BAM record parse on the GPU (pjb_submit_bam); false: host threads
 

@@ -1,3 +1,6 @@
+#include <unistd.h>
+#include <thread>
+#include <atomic>
 #include <portcullis/bam/genome_mapper.hpp>
 
 #include <algorithm>
@@ -148,6 +151,45 @@ std::string GenomeMapper::fetchContig(const std::string& name) const {
     if (it == byName.end()) throw BamException("The sequence \"" + name + "\" not found in " + genomeFile);
     const Entry& e = entries[it->second];
     return readSpan(e, 0, e.len);
+}
+
+bool GenomeMapper::rawSpan(const std::string& name, RawSpan& out) const {
+    auto it = byName.find(name);
+    if (it == byName.end()) return false;
+    const Entry& e = entries[it->second];
+    if (e.line_blen <= 0 || e.line_len < e.line_blen || e.len < 0) return false;
+    out.fileOffset = (uint64_t)e.offset;
+    out.lineBases = e.line_blen;
+    out.lineWidth = e.line_len;
+    out.length = e.len;
+    out.bytes = e.len == 0 ? 0 : (size_t)((e.len - 1) / e.line_blen * e.line_len + (e.len - 1) % e.line_blen + 1);
+    return true;
+}
+
+void GenomeMapper::readRaw(const RawSpan& span, uint8_t* dst, int nthreads) const {
+    const int fd = fileno(fp);
+    const size_t want = span.bytes;
+    const size_t nsl = std::max<size_t>(1, std::min<size_t>((size_t)std::max(1, nthreads), want >> 22));
+    std::atomic<bool> bad(false);
+    auto slice = [&](size_t t) {
+        const size_t per = (want + nsl - 1) / nsl, a = std::min(want, per * t), b = std::min(want, a + per);
+        size_t got = 0;
+        while (a + got < b) {
+            const ssize_t r = pread(fd, dst + a + got, b - a - got, (off_t)(span.fileOffset + a + got));
+            if (r <= 0) {
+                bad = true;
+                return;
+            }
+            got += (size_t)r;
+        }
+    };
+    if (nsl == 1) slice(0);
+    else {
+        std::vector<std::thread> th;
+        for (size_t t = 0; t < nsl; t++) th.emplace_back(slice, t);
+        for (auto& x : th) x.join();
+    }
+    if (bad) throw BamException("Short read in genome file: " + genomeFile);
 }
 
 }  // namespace bam

@@ -1,5 +1,7 @@
 // JunctionBuilder: orchestration of the junc stage on top of the device path.
 // Flow and console output follow src/junction_builder.cc:84-291 of the reference.
+#include <atomic>
+#include <set>
 #include <portcullis/junction_builder.hpp>
 #include <portcullis/bam/bam_writer.hpp>
 
@@ -81,6 +83,28 @@ struct HostProfile {  // PJB_PROFILE_HOST=1: where the host side of findJuncs sp
     }
     std::mutex mu;
     double genome = 0, submit = 0, finish = 0, total = 0;
+    // PJB_PROFILE_HOST=2: every command of the device threads and every step of the workers with its start and end
+    struct Event {
+        double a, b;
+        std::string what;
+    };
+    bool events_on = on && atoi(getenv("PJB_PROFILE_HOST")) >= 2;
+    std::vector<Event> events;
+    void event(double a, double b, const std::string& what) {
+        if (!events_on) return;
+        std::lock_guard<std::mutex> lk(mu);
+        events.push_back({a - t0, b - t0, what});
+    }
+    void dumpEvents() {
+        if (!events_on) return;
+        std::lock_guard<std::mutex> lk(mu);
+        std::sort(events.begin(), events.end(), [](const Event& x, const Event& y) { return x.a < y.a; });
+        for (auto& e : events) {
+            char line[256];
+            snprintf(line, sizeof line, "[host event] %8.4f %8.4f %7.1f ms  %s", e.a, e.b, (e.b - e.a) * 1e3, e.what.c_str());
+            std::cerr << line << "\n";
+        }
+    }
     static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 };
 HostProfile g_prof;
@@ -137,6 +161,7 @@ void JunctionBuilder::process() {
         junctionSystem.saveAll(outDir + "/" + outputPrefix, source, false, outputExonGFF, outputIntronGFF);
     }
     g_prof.mark("outputs written");
+    g_prof.dumpEvents();
     if (g_prof.on)
         cerr << "[host profile] process: header+index " << (t_p1 - t_p0) << " s, findJunctions " << (t_p2 - t_p1) << " s, saveAll "
              << (HostProfile::now() - t_p2) << " s" << endl;
@@ -222,9 +247,41 @@ class PinnedPool {
 
     size_t pieceBytes = 0;  // > 0: every buffer has exactly this size (the ring of pieces of the streaming ingest)
 
+    // Targets stream their pieces a few at a time, in the order they asked: with every worker's target on its way at once
+    // all of them arrive at about the same time -- late -- and the device has nothing to inflate until then (measured:
+    // first bgzf_inflate 1.0 s after the contexts were ready, PCIe idle before and after a burst).  A target that has the
+    // ring to itself and three others is complete after a few hundred milliseconds and inflates while the next ones cross.
+    // (One gate per device thread: a target's pieces, its genome and its kernels all go through the context of the worker
+    // that took it, so the targets in transfer must be spread over the contexts.)
+    struct Gate {
+        std::mutex mu;
+        std::condition_variable cv;
+        uint64_t next = 0, serving = 0;
+        int active = 0;
+    };
+    Gate gates[16];
+    int gatePermits = 1 << 30;
+
 public:
     explicit PinnedPool(size_t n, size_t piece = 0) : bufs(n), pieceBytes(piece) {}
     size_t piece() const { return pieceBytes; }
+    int readThreads = 1;  // threads a target in transfer reads its pieces with
+    void setTransferSlots(int perLane) { gatePermits = std::max(1, perLane); }
+    void enterTransfer(int lane) {
+        Gate& g = gates[lane & 15];
+        std::unique_lock<std::mutex> lk(g.mu);
+        const uint64_t t = g.next++;
+        g.cv.wait(lk, [&] { return t == g.serving && g.active < gatePermits; });
+        g.serving++;
+        g.active++;
+        g.cv.notify_all();
+    }
+    void leaveTransfer(int lane) {
+        Gate& g = gates[lane & 15];
+        std::lock_guard<std::mutex> lk(g.mu);
+        g.active--;
+        g.cv.notify_all();
+    }
     ~PinnedPool() {
         for (auto& b : bufs) pjb_host_free(b.p);
     }
@@ -276,6 +333,14 @@ public:
         enum Kind { GENOME, BATCH, BAM, FINISH, EXTRA, STOP, BAMBEGIN, BAMPIECE, BAMEND } kind = STOP;
         int32_t tid = -1;
         std::string genome;
+        // GENOME with the record's bytes as they are in the FASTA file (page-locked, from rawPool; the device takes the line
+        // terminators out): rawBytes > 0
+        uint8_t* raw = nullptr;
+        size_t rawBytes = 0;
+        int32_t lineBases = 0, lineWidth = 0;
+        int64_t genomeLen = 0;
+        PinnedPool* rawPool = nullptr;
+        std::promise<bool>* rawDone = nullptr;  // false: the record is not laid out as its index says (the worker sends the filtered bases)
         bam::ReadBatch batch;
         std::vector<bam::ReadBatch>* spare = nullptr;  // where the batch storage goes back to
         std::mutex* spareMu = nullptr;
@@ -358,6 +423,8 @@ private:
             else p.done->set_exception(std::make_exception_ptr(JunctionBuilderException(err)));
         };
         g_prof.mark("device thread: context ready");
+        static std::atomic<int> profIds{0};
+        const int profId = profIds++;
         {
             std::lock_guard<std::mutex> lk(mu);
             ready = true;
@@ -382,37 +449,94 @@ private:
             }
         };
         const double tStart = HostProfile::now();
+        // BAMEND commands whose inflate (started by the target's last piece) is still running: the thread serves other
+        // targets meanwhile -- pieces, whose last one starts the next inflate beside this one -- instead of waiting
+        std::deque<Cmd> deferred;
+        std::set<int32_t> ended;  // targets whose records are complete (BAMEND / BAM taken from the queue)
+        auto readyDeferred = [&]() -> int {
+            for (size_t k = 0; k < deferred.size(); k++)
+                if (!ctx || pjb_bam_inflate_done(ctx, deferred[k].tid)) return (int)k;
+            return -1;
+        };
         for (;;) {
             Cmd c;
+            bool have = false;
             {
+                const int k = readyDeferred();
+                if (k >= 0) {
+                    c = std::move(deferred[(size_t)k]);
+                    deferred.erase(deferred.begin() + k);
+                    have = true;
+                }
+            }
+            if (!have) {
                 std::unique_lock<std::mutex> lk(mu);
-                if (q.empty() && !pending.empty()) { // nothing to do for the next target yet: collect the oldest queued one
+                if (q.empty() && !pending.empty() && deferred.empty()) { // nothing to do for the next target yet: collect the oldest queued one
                     lk.unlock();
                     const double t0 = HostProfile::now();
+                    const int ptid = pending.front().tid;
                     collectOldest();
                     tCollect += HostProfile::now() - t0;
+                    g_prof.event(t0, HostProfile::now(), "dev" + std::to_string(profId) + " collect tid " + std::to_string(ptid));
                     continue;
                 }
                 const double t0 = HostProfile::now();
+                bool again = false;
                 while (q.empty()) {
-                    if (inflight.empty()) cv.wait(lk, [&] { return !q.empty(); });
+                    if (inflight.empty() && deferred.empty()) cv.wait(lk, [&] { return !q.empty(); });
                     else {  // a worker may be waiting for one of the pieces in flight: keep handing them back
                         cv.wait_for(lk, std::chrono::microseconds(200), [&] { return !q.empty(); });
                         lk.unlock();
                         releaseDone(false);
+                        const bool ready = readyDeferred() >= 0;
                         lk.lock();
+                        if (ready && q.empty()) {
+                            again = true;
+                            break;
+                        }
                     }
                 }
                 tIdle += HostProfile::now() - t0;
-                c = std::move(q.front());
-                q.pop_front();
+                if (again) continue;
+                // a genome is needed when its target is finished, the file pieces are needed now: uploads of genomes whose
+                // target's records are not complete yet let every other command pass (each is 30-70 ms of allocations and
+                // a synchronisation, and pieces stuck behind them left PCIe idle at the start of a run)
+                size_t pick = 0;
+                // (only the uploads a worker waits for before it asks for the finish: the others must keep their place)
+                if (q.front().kind == Cmd::GENOME && q.front().rawDone && !ended.count(q.front().tid)) {
+                    size_t urgent = q.size(), other = q.size();
+                    for (size_t k = 0; k < q.size(); k++) {
+                        if (q[k].kind == Cmd::GENOME && q[k].rawDone) {
+                            if (urgent == q.size() && ended.count(q[k].tid)) urgent = k;
+                        } else if (other == q.size())
+                            other = k;
+                    }
+                    pick = urgent < q.size() ? urgent : other < q.size() ? other : 0;
+                }
+                c = std::move(q[pick]);
+                q.erase(q.begin() + (long)pick);
+                if (c.kind == Cmd::BAMEND || c.kind == Cmd::BAM) ended.insert(c.tid);
                 cv.notify_all();
+                if (c.kind == Cmd::BAMEND && ctx && !pjb_bam_inflate_done(ctx, c.tid)) {
+                    deferred.push_back(std::move(c));
+                    continue;
+                }
+                if (c.kind == Cmd::STOP && !deferred.empty()) { // (cannot happen: a worker waits for its BAMEND; keep the order anyway)
+                    q.push_back(std::move(c));
+                    continue;
+                }
             }
             struct KindTimer {
                 double* slot;
+                int kind, tid, dev;
                 double t0 = HostProfile::now();
-                ~KindTimer() { *slot += HostProfile::now() - t0; }
-            } kindTimer{&tKind[(int)c.kind & 15]};
+                ~KindTimer() {
+                    const double t1 = HostProfile::now();
+                    *slot += t1 - t0;
+                    static const char* names[] = {"GENOME", "BATCH", "BAM", "FINISH", "EXTRA", "STOP", "BAMBEGIN", "BAMPIECE", "BAMEND"};
+                    if (g_prof.events_on) g_prof.event(t0, t1, std::string("dev") + std::to_string(dev) + " " + names[kind] + " tid " + std::to_string(tid));
+                }
+            } kindTimer{&tKind[(int)c.kind & 15], (int)c.kind, (int)c.tid, profId};
             releaseDone(false);
             if (c.kind == Cmd::STOP) {
                 while (!pending.empty()) collectOldest();
@@ -428,7 +552,15 @@ private:
             }
             std::string err = fatal;
             if (err.empty() && failed.count(c.tid)) err = failed[c.tid];
-            if (c.kind == Cmd::GENOME) {
+            if (c.kind == Cmd::GENOME && c.rawDone) {
+                int ok = 0;
+                if (err.empty() && pjb_upload_contig_fasta(ctx, c.tid, c.raw, (int64_t)c.rawBytes, c.lineBases, c.lineWidth, c.genomeLen, &ok) != PJB_OK) {
+                    failed[c.tid] = std::string("pjb_upload_contig_fasta: ") + pjb_last_error(ctx);
+                    ok = 1;  // (an error, not a malformed record: no second attempt)
+                }
+                if (c.rawPool) c.rawPool->release(c.raw);
+                c.rawDone->set_value(ok != 0 || !err.empty());
+            } else if (c.kind == Cmd::GENOME) {
                 if (err.empty() && pjb_upload_contig(ctx, c.tid, (const uint8_t*)c.genome.data(), (int64_t)c.genome.size()) != PJB_OK)
                     failed[c.tid] = std::string("pjb_upload_contig: ") + pjb_last_error(ctx);
             } else if (c.kind == Cmd::BATCH) {
@@ -517,6 +649,7 @@ public:
         push(std::move(c));
         th.join();
     }
+    int lane = 0;  // index among the device threads (the transfer gate of this context)
     void push(Cmd&& c) {
         std::unique_lock<std::mutex> lk(mu);
         cv.wait(lk, [&] { return q.size() < cap; });
@@ -568,6 +701,21 @@ void JunctionBuilder::findJuncs(DeviceThread& device, BamReader& reader, GenomeM
                     // page-locked buffers (page-locking a buffer per target costs ~0.15 s per GB); the device thread
                     // copies a piece while this thread reads the next one
                     const size_t piece = pinnedPool->piece();
+                    const double tg0 = HostProfile::now();
+                    pinnedPool->enterTransfer(device.lane);
+                    g_prof.event(tg0, HostProfile::now(), "worker gate wait tid " + std::to_string(seq));
+                    struct Leave {
+                        PinnedPool* p;
+                        int lane;
+                        ~Leave() {
+                            if (p) p->leaveTransfer(lane);
+                        }
+                        void now() {
+                            if (p) p->leaveTransfer(lane);
+                            p = nullptr;
+                        }
+                    } leave{pinnedPool.get(), device.lane};
+                    const int readThreads = std::max(innerThreads, pinnedPool->readThreads);
                     DeviceThread::Cmd b0;
                     b0.kind = DeviceThread::Cmd::BAMBEGIN;
                     b0.tid = seq;
@@ -576,13 +724,17 @@ void JunctionBuilder::findJuncs(DeviceThread& device, BamReader& reader, GenomeM
                     std::string readError;
                     for (size_t off = 0; off < nb; off += piece) {
                         const size_t n = std::min(piece, nb - off);
+                        const double ta0 = HostProfile::now();
                         uint8_t* buf = pinnedPool->acquire(piece);
+                        const double ta1 = HostProfile::now();
+                        if (ta1 - ta0 > 1e-3) g_prof.event(ta0, ta1, "worker ring wait tid " + std::to_string(seq));
                         if (!buf) {
                             readError = "out of page-locked memory for the file pieces";
                             break;
                         }
                         try {
-                            reader.readSpan(fileOff + off, n, buf, innerThreads);
+                            reader.readSpan(fileOff + off, n, buf, readThreads);
+                            g_prof.event(ta1, HostProfile::now(), "worker read piece tid " + std::to_string(seq) + " " + std::to_string(n >> 20) + " MB");
                         } catch (const std::exception& e) {
                             pinnedPool->release(buf);
                             readError = e.what();
@@ -604,6 +756,7 @@ void JunctionBuilder::findJuncs(DeviceThread& device, BamReader& reader, GenomeM
                     c.bamFirst = firstU;
                     c.bamDone = &got;
                     device.push(std::move(c));
+                    leave.now();  // the next target's pieces cross while this one is inflated and parsed
                     any = f.get() > 0;
                     if (!readError.empty()) throw bam::BamException(readError);
                     nb = 0;  // (handled)
@@ -652,16 +805,53 @@ void JunctionBuilder::findJuncs(DeviceThread& device, BamReader& reader, GenomeM
     double t_genome = 0;
     try {
         const double t0 = HostProfile::now();
-        std::string contig = gmap.fetchContig(name);
-        t_genome = HostProfile::now() - t0;
-        if ((int64_t)contig.size() != refs->at((size_t)seq)->length)
-            throw JunctionBuilderException("Genome sequence " + name + " has " + std::to_string(contig.size()) +
-                                           " bases but the BAM header says " + std::to_string(refs->at((size_t)seq)->length));
-        DeviceThread::Cmd c;
-        c.kind = DeviceThread::Cmd::GENOME;
-        c.tid = seq;
-        c.genome = std::move(contig);
-        device.push(std::move(c));
+        // large runs: the record's bytes go to the device as they are in the file (a pread into a page-locked buffer; the
+        // device takes the line terminators out) -- parsing 3 GB of FASTA on the host was 6 core-seconds at the very moment
+        // the file pieces of the first targets want the cores
+        bool uploaded = false;
+        bam::GenomeMapper::RawSpan span;
+        if (genomePool && gmap.rawSpan(name, span) && span.length == refs->at((size_t)seq)->length && span.bytes > 0) {
+            uint8_t* buf = genomePool->acquire(span.bytes);
+            if (buf) {
+                const double t1 = HostProfile::now();
+                try {
+                    gmap.readRaw(span, buf, std::max(innerThreads, 4));
+                } catch (...) {
+                    genomePool->release(buf);
+                    throw;
+                }
+                g_prof.event(t0, t1, "worker genome buffer wait tid " + std::to_string(seq));
+                g_prof.event(t1, HostProfile::now(), "worker genome raw read tid " + std::to_string(seq));
+                std::promise<bool> ok;
+                std::future<bool> f = ok.get_future();
+                DeviceThread::Cmd c;
+                c.kind = DeviceThread::Cmd::GENOME;
+                c.tid = seq;
+                c.raw = buf;
+                c.rawBytes = span.bytes;
+                c.lineBases = span.lineBases;
+                c.lineWidth = span.lineWidth;
+                c.genomeLen = span.length;
+                c.rawPool = genomePool.get();
+                c.rawDone = &ok;
+                device.push(std::move(c));
+                uploaded = f.get();
+                t_genome = HostProfile::now() - t0;
+            }
+        }
+        if (!uploaded) {
+            std::string contig = gmap.fetchContig(name);
+            t_genome = HostProfile::now() - t0;
+            g_prof.event(t0, t0 + t_genome, "worker genome read tid " + std::to_string(seq));
+            if ((int64_t)contig.size() != refs->at((size_t)seq)->length)
+                throw JunctionBuilderException("Genome sequence " + name + " has " + std::to_string(contig.size()) +
+                                               " bases but the BAM header says " + std::to_string(refs->at((size_t)seq)->length));
+            DeviceThread::Cmd c;
+            c.kind = DeviceThread::Cmd::GENOME;
+            c.tid = seq;
+            c.genome = std::move(contig);
+            device.push(std::move(c));
+        }
     } catch (const std::exception& e) {
         genomeError = e.what();
     }
@@ -704,8 +894,34 @@ void JunctionBuilder::findJuncs(DeviceThread& device, BamReader& reader, GenomeM
     }
 }
 
+// PJB_SELFTEST_PREAD=1 (debugging aid): how fast do 4 groups of 4 threads read 64 MB pieces of the BAM file into
+// page-locked buffers right now, with nothing else going on in this process?
+static void preadSelfTest(const std::string& path, const char* when) {
+    if (!getenv("PJB_SELFTEST_PREAD")) return;
+    const size_t piece = (size_t)64 << 20;
+    const int G = 4, T = 4, N = 8;
+    std::vector<uint8_t*> bufs(G);
+    for (auto& b : bufs) b = (uint8_t*)pjb_host_alloc(piece);
+    const double t0 = HostProfile::now();
+    std::vector<std::thread> groups;
+    std::vector<double> ms(G);
+    for (int g = 0; g < G; g++)
+        groups.emplace_back([&, g] {
+            bam::BamReader r(path);
+            const double a = HostProfile::now();
+            for (int k = 0; k < N; k++) r.readSpan(((uint64_t)g * 64 + (uint64_t)k) * piece + (1 << 20), piece, bufs[(size_t)g], T);
+            ms[(size_t)g] = (HostProfile::now() - a) * 1e3 / N;
+        });
+    for (auto& t : groups) t.join();
+    const double dt = HostProfile::now() - t0;
+    std::cerr << "[pread self-test] " << when << ": " << (G * N * piece / dt / 1e9) << " GB/s, ms per 64 MB piece per group: " << ms[0] << " " << ms[1] << " "
+              << ms[2] << " " << ms[3] << std::endl;
+    for (auto& b : bufs) pjb_host_free(b);
+}
+
 void JunctionBuilder::findJunctions() {
     WallTimer timer;
+    preadSelfTest(prepData.getSortedBamFilePath(), "start of findJunctions");
     results.clear();
     results.resize(refs->size());
     if (!deviceCount.valid()) deviceCount = std::async(std::launch::async, [] { return pjb_device_count(); }).share();
@@ -737,6 +953,8 @@ void JunctionBuilder::findJunctions() {
     // large inputs: page-locked buffers for the file bytes (allocating them costs ~0.15 s per GB once, so small runs
     // keep the pageable path whose staging copy is cheaper than that)
     pinnedPool.reset();
+    genomePool.reset();
+    int transferSlots = 0;
     if (deviceIngest) {
         struct stat bst;
         uint64_t minFile = 8ull << 30;
@@ -751,6 +969,9 @@ void JunctionBuilder::findJunctions() {
         }
         if (stat(prepData.getSortedBamFilePath().c_str(), &bst) == 0 && (uint64_t)bst.st_size >= minFile) {
             pinnedPool.reset(new PinnedPool(nbuf, pieceBytes));
+            if (!getenv("PORTCULLIS_GENOME_PARSE")) genomePool.reset(new PinnedPool(3));  // (PORTCULLIS_GENOME_PARSE=1: the host filters the FASTA characters as before)
+            transferSlots = 3;  // targets whose pieces are on their way at once, over all contexts (PORTCULLIS_TRANSFER_SLOTS; 0: no limit)
+            if (const char* e = getenv("PORTCULLIS_TRANSFER_SLOTS")) transferSlots = atoi(e);
         }
     }
     // one device thread per GPU in use; decode workers are assigned round robin
@@ -767,13 +988,21 @@ void JunctionBuilder::findJunctions() {
             }
             // two contexts (device threads, streams) per GPU: while one target's kernels run, the other target's
             // file bytes and genome cross PCIe
-            int per = 2;
+            // (With the file pieces streaming through one context -- whose inflates run on their own streams beside
+            // everything else -- a second context only adds contention for the runtime's locks: 2.9-3.0 s against 3.2 s.)
+            int per = pinnedPool ? 1 : 2;
             if (const char* e = getenv("PORTCULLIS_CTX_PER_GPU")) per = std::max(1, atoi(e));
             per = std::max(1, std::min(per, nthreads / nd));
             if (extra) nd = per = 1;  // the name multiplicities and the depth hand-over between targets are file-wide: one context
             for (int k = 0; k < per; k++)
                 for (int d = 0; d < nd; d++)
                     deviceThreads.emplace_back(new DeviceThread(d, orientation, strandSpecific, lens, deviceCount, extra));
+            for (size_t k = 0; k < deviceThreads.size(); k++) deviceThreads[k]->lane = (int)k;
+            if (pinnedPool && transferSlots > 0) {
+                const int perLane = std::max(1, transferSlots / (int)deviceThreads.size());
+                pinnedPool->setTransferSlots(perLane);
+                pinnedPool->readThreads = std::max(1, total / (perLane * (int)deviceThreads.size()));
+            }
         }
         return *deviceThreads[(size_t)w % deviceThreads.size()];
     };
@@ -809,6 +1038,7 @@ void JunctionBuilder::findJunctions() {
     std::vector<std::thread> pool;
     for (int w = 0; w < nthreads; w++) pool.emplace_back(worker, w);
     for (auto& t : pool) t.join();
+    preadSelfTest(prepData.getSortedBamFilePath(), "workers done, contexts alive");
     if (extra && firstError.empty() && !deviceThreads.empty()) {
         // calcExtraMetrics (src/junction_builder.cc:293-312): multiple mapping score, flanking alignments, coverage
         cout << "Calculating extra junction metrics:" << endl;
@@ -835,6 +1065,7 @@ void JunctionBuilder::findJunctions() {
         }
     }
     deviceThreads.clear();  // joins the device threads (destroys the contexts)
+    preadSelfTest(prepData.getSortedBamFilePath(), "contexts destroyed");
     if (!firstError.empty()) throw JunctionBuilderException(firstError);
     const double t_workers1 = HostProfile::now();
     g_prof.mark("workers and device threads done");

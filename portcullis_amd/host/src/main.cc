@@ -5,6 +5,9 @@
 
 #include <cstring>
 #include <unistd.h>
+#include <cstdlib>
+#include <cstdio>
+#include <ctime>
 #include <iostream>
 
 #ifndef PORTCULLIS_AMD_VERSION
@@ -14,6 +17,11 @@
 int main(int argc, char* argv[]) {
     // exit codes as in src/portcullis.cc:497-515 of the reference
     int rc = 0;
+    if (getenv("PJB_PROFILE_HOST")) {
+        struct timespec ts;
+        clock_gettime(CLOCK_REALTIME, &ts);
+        fprintf(stderr, "[host profile] main entered at epoch %.6f\n", (double)ts.tv_sec + ts.tv_nsec * 1e-9);
+    }
     try {
         if (argc < 2 || (strcmp(argv[1], "junc") != 0 && strcmp(argv[1], "bamfilt") != 0)) {
             std::cerr << "Usage: portcullis_amd junc [options] <prep_data_dir>" << std::endl
@@ -37,5 +45,11 @@ int main(int argc, char* argv[]) {
     // on its own thread after an early error) and without walking the heap (0.15-0.2 s at process exit)
     std::cout.flush();
     std::cerr.flush();
+    if (getenv("PJB_PROFILE_HOST")) {
+        struct timespec ts;
+        clock_gettime(CLOCK_REALTIME, &ts);
+        fprintf(stderr, "[host profile] leaving main at epoch %.6f\n", (double)ts.tv_sec + ts.tv_nsec * 1e-9);
+    }
+    if (getenv("PJB_NORMAL_EXIT")) return rc;  // (profilers write their traces from exit handlers)
     _exit(rc);
 }

@@ -420,3 +420,40 @@ def test_row_mirror(ffi, orc):
         ctx.set_row_mirror(0, 0)
         rows3, _ = ffi.run_contig(ctx, 0, genome.encode(), [batch])
         assert rows3.tobytes() == rows.tobytes()
+
+
+def _fasta_lines(genome, width, term):
+    return term.join(genome[i:i + width] for i in range(0, len(genome), width))
+
+
+@pytest.mark.gpu
+def test_upload_contig_fasta(ffi, orc):
+    """pjb_upload_contig_fasta: the record's bytes as they are in the file (LF and CRLF line ends, a short last line, a
+    length that is a multiple of the line width, soft-masked bases) give the rows pjb_upload_contig gives; a record that
+    is not laid out as stated is refused without touching the contig."""
+    genome, reads = make_reads(61, n_reads=1500)
+    batch = to_batch(reads)
+    masked = "".join(ch.lower() if (i // 37) % 3 == 0 else ch for i, ch in enumerate(genome))
+    orows, oreg = orc.find_juncs(0, len(genome), genome, batch, "UNKNOWN")
+    with ffi.Context(0, "UNKNOWN") as ctx:
+        ctx.set_refs([len(genome)])
+        for width, term in ((60, "\n"), (70, "\r\n"), (len(genome), "\n"), (61, "\n")):
+            raw = _fasta_lines(masked, width, term).encode()
+            assert ctx.upload_contig_fasta(0, raw, width, width + len(term), len(genome))
+            ctx.clear_rows()
+            ctx.submit_batch(0, batch)
+            reg = ctx.finish_contig(0)
+            region_equal(reg, oreg)
+            assert_rows_equal(ctx.collect(), orows)
+        cut = len(genome) - len(genome) % 50  # a whole number of lines
+        raw = _fasta_lines(masked[:cut], 50, "\n").encode()
+        assert ctx.upload_contig_fasta(0, raw, 50, 51, cut)
+        # malformed: a line one base longer than the index says, a blank inside a line, too few bytes
+        good = _fasta_lines(masked, 60, "\n")
+        ctx.upload_contig(0, genome.encode())
+        for bad in (good[:200] + "A" + good[200:], good[:300] + " " + good[301:], good[:-5]):
+            assert not ctx.upload_contig_fasta(0, bad.encode(), 60, 61, len(genome))
+        ctx.clear_rows()  # the contig uploaded before the refused ones is still the one in use
+        ctx.submit_batch(0, batch)
+        reg = ctx.finish_contig(0)
+        assert_rows_equal(ctx.collect(), orows)

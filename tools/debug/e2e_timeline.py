@@ -9,8 +9,9 @@ def load(pat):
     return rows
 K = load(f"{d}/**/*kernel_trace.csv")
 M = load(f"{d}/**/*memory_copy_trace.csv")
+if M: print("copy columns:", list(M[0].keys()))
 ks = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0].split("::")[-1]) for r in K]
-ms = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r.get("Direction", ""), int(r.get("Size", 0) or 0)) for r in M]
+ms = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r.get("Direction", ""), int(r.get("Size", r.get("Bytes", 0)) or 0)) for r in M]
 t0 = min([a for a, _, _ in ks] + [a for a, _, _, _ in ms])
 t1 = max([b for _, b, _ in ks] + [b for _, b, _, _ in ms])
 print(f"span {(t1 - t0) / 1e9:.3f} s, {len(ks)} kernels, {len(ms)} copies, {sum(m[3] for m in ms) / 1e9:.2f} GB copied")
