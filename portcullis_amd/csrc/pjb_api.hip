@@ -11,6 +11,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <memory>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -148,6 +150,9 @@ struct pjb_ctx {
     Buf b_cursor;     // RowCursor
     // device ingest in pieces (pjb_bam_begin / _piece / _end)
     std::map<int32_t, struct BamStage *> bam_stage;
+    // pjb_bam_begin / _piece / _pieces_done / _inflate_done may come from other threads than the context's other calls (the
+    // threads that read the file hand their pieces over themselves): bam_mu guards the staging state below
+    std::mutex bam_mu, err_mu;
     std::vector<Buf> stage_pool;  // device buffers for staged BGZF bytes, reused target after target
     // pjb_bam_piece starts a target's bgzf_inflate as soon as its last piece is on its way (own stream, own buffers), so that
     // the inflates of several targets overlap each other and the copies: a launch takes ~50 ms whatever its size (a lane's
@@ -227,8 +232,11 @@ int fail(pjb_ctx *c, int code, const char *fmt, ...) {
     va_start(ap, fmt);
     vsnprintf(tmp, sizeof tmp, fmt, ap);
     va_end(ap);
-    if (c) c->err = tmp;
-    else g_create_error = tmp;
+    if (c) {
+        std::lock_guard<std::mutex> lk(c->err_mu);
+        c->err = tmp;
+    } else
+        g_create_error = tmp;
     return code;
 }
 
@@ -2404,9 +2412,9 @@ static void bam_stage_clear(pjb_ctx *c) {
 extern "C" int pjb_bam_begin(pjb_ctx *c, int32_t tid, int64_t total_bytes) {
     if (!c) return PJB_ERR_ARG;
     if (tid < 0 || (size_t)tid >= c->ref_len.size() || total_bytes <= 0) return fail(c, PJB_ERR_ARG, "bam_begin: bad arguments (tid %d)", tid);
+    std::lock_guard<std::mutex> lk(c->bam_mu);
     if (c->bam_stage.count(tid)) return fail(c, PJB_ERR_STATE, "bam_begin: target %d is being staged already", tid);
-    auto it = c->open.find(tid);
-    if (it != c->open.end() && !it->second.batches.empty()) return fail(c, PJB_ERR_STATE, "bam_begin: target %d already has batches", tid);
+    // (that the target has no batches yet is checked by pjb_bam_end, on the thread that owns the open targets)
     HIP_TRY(c, hipSetDevice(c->cfg.device));
     std::unique_ptr<BamStage> st(new (std::nothrow) BamStage());
     if (!st) return fail(c, PJB_ERR_NOMEM, "bam_begin: out of host memory");
@@ -2433,6 +2441,7 @@ static int bam_piece_body(pjb_ctx *c, int32_t tid, BamStage &st, const uint8_t *
 
 extern "C" int pjb_bam_piece(pjb_ctx *c, int32_t tid, const uint8_t *piece, int64_t bytes, int64_t *ticket) {
     if (!c || !piece || bytes <= 0) return fail(c, PJB_ERR_ARG, "bam_piece: bad arguments");
+    std::lock_guard<std::mutex> lk(c->bam_mu);
     auto it = c->bam_stage.find(tid);
     if (it == c->bam_stage.end()) return fail(c, PJB_ERR_STATE, "bam_piece: target %d was not begun (pjb_bam_begin)", tid);
     const int rc = bam_piece_body(c, tid, *it->second, piece, bytes, ticket);
@@ -2492,6 +2501,7 @@ static int bam_piece_body(pjb_ctx *c, int32_t tid, BamStage &st, const uint8_t *
 
 extern "C" int pjb_bam_inflate_done(pjb_ctx *c, int32_t tid) {
     if (!c) return 1;
+    std::lock_guard<std::mutex> lk(c->bam_mu);
     auto it = c->bam_stage.find(tid);
     if (it == c->bam_stage.end() || !it->second->launched) return 1; // (nothing in flight: pjb_bam_end does all the work)
     const bool done = hipEventQuery(it->second->ev_inf) == hipSuccess;
@@ -2501,6 +2511,7 @@ extern "C" int pjb_bam_inflate_done(pjb_ctx *c, int32_t tid) {
 
 extern "C" int pjb_bam_pieces_done(pjb_ctx *c, int64_t *completed_ticket) {
     if (!c || !completed_ticket) return PJB_ERR_ARG;
+    std::lock_guard<std::mutex> lk(c->bam_mu);
     while (c->up_done < c->up_ticket) {
         hipEvent_t ev = c->up_events[(size_t)((c->up_done + 1) % (int64_t)PJB_UP_EVENTS)];
         if (!ev || hipEventQuery(ev) != hipSuccess) break;
@@ -2514,16 +2525,21 @@ extern "C" int pjb_bam_pieces_done(pjb_ctx *c, int64_t *completed_ticket) {
 extern "C" int pjb_bam_end(pjb_ctx *c, int32_t tid, int32_t first_uoffset, int64_t *n_records) {
     if (!c) return PJB_ERR_ARG;
     if (n_records) *n_records = 0;
-    auto it = c->bam_stage.find(tid);
-    if (it == c->bam_stage.end()) return fail(c, PJB_ERR_STATE, "bam_end: target %d was not begun (pjb_bam_begin)", tid);
-    std::unique_ptr<BamStage> st(it->second);
-    c->bam_stage.erase(it);
+    std::unique_ptr<BamStage> st;
+    {
+        std::lock_guard<std::mutex> lk(c->bam_mu);
+        auto it = c->bam_stage.find(tid);
+        if (it == c->bam_stage.end()) return fail(c, PJB_ERR_STATE, "bam_end: target %d was not begun (pjb_bam_begin)", tid);
+        st.reset(it->second);
+        c->bam_stage.erase(it);
+    }
     struct Return { // the device buffer goes back to the pool whatever happens (after the work that reads it)
         pjb_ctx *c;
         BamStage *st;
         ~Return() {
             (void)hipStreamSynchronize(c->stream);
             if (st->launched) (void)hipEventSynchronize(st->ev_inf);
+            std::lock_guard<std::mutex> lk(c->bam_mu);
             stage_release(c, *st);
         }
     } ret{c, st.get()};

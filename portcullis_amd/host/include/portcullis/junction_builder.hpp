@@ -59,6 +59,7 @@ class JunctionBuilder {
     std::shared_ptr<class PinnedPool> pinnedPool;  // ring of page-locked pieces for the file bytes of large device-ingest runs
     std::shared_ptr<class PinnedPool> genomePool;  // a few page-locked buffers for the FASTA bytes of the target sequences (same runs)
     size_t pieceMinTarget = 0;                     // targets with fewer bytes go over in one (pageable) block
+    bool directPieces = true;                      // the threads that read the file hand the pieces to the device themselves (PORTCULLIS_DIRECT_PIECES=0: through the device thread's queue)
     bool deviceIngest = true;      // BGZF inflate + BAM record parse on the GPU (pjb_submit_bam); false: host threads
 
     std::shared_future<int> deviceCount;  // pjb_device_count() evaluated in the background

@@ -668,35 +668,7 @@ void BamReader::readSpan(uint64_t fileOff, size_t want, uint8_t* buf, int nthrea
     nthreads = std::max(1, nthreads);
     const size_t nsl = std::max<size_t>(1, std::min<size_t>((size_t)nthreads, want >> 22));
     std::atomic<bool> bad(false);
-    static const bool debug = getenv("PJB_READSPAN_DEBUG") != nullptr;
-    auto clk = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-    const double tSpawn = clk();
-    double tBegin[64] = {0}, tEnd[64] = {0};
-    long flt[64] = {0};
     auto readSlice = [&](size_t t) {
-        struct rusage ru0;
-        if (debug && t < 64) {
-            tBegin[t] = clk();
-            getrusage(RUSAGE_THREAD, &ru0);
-        }
-        struct Flt {
-            long* p;
-            struct rusage* r0;
-            bool on;
-            ~Flt() {
-                if (!on) return;
-                struct rusage r1;
-                getrusage(RUSAGE_THREAD, &r1);
-                *p = (r1.ru_minflt - r0->ru_minflt) + 1000000 * (r1.ru_nivcsw - r0->ru_nivcsw) + 1000000000L * (r1.ru_nvcsw - r0->ru_nvcsw);
-            }
-        } fltEnd{&flt[t < 64 ? t : 0], &ru0, debug && t < 64};
-        struct End {
-            double* p;
-            bool on;
-            ~End() {
-                if (on) *p = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
-            }
-        } end{&tEnd[t < 64 ? t : 0], debug && t < 64};
         const size_t per = (want + nsl - 1) / nsl, a = std::min(want, per * t), b = std::min(want, a + per);
         size_t got = 0;
         while (a + got < b) {
@@ -714,17 +686,6 @@ void BamReader::readSpan(uint64_t fileOff, size_t want, uint8_t* buf, int nthrea
         std::vector<std::thread> th;
         for (size_t t = 0; t < nsl; t++) th.emplace_back(readSlice, t);
         for (auto& x : th) x.join();
-    }
-    if (debug) {
-        const double tDone = clk();
-        double maxStart = 0, minSlice = 1e9, maxSlice = 0;
-        for (size_t t = 0; t < std::min<size_t>(nsl, 64); t++) {
-            maxStart = std::max(maxStart, tBegin[t] - tSpawn);
-            minSlice = std::min(minSlice, tEnd[t] - tBegin[t]);
-            maxSlice = std::max(maxSlice, tEnd[t] - tBegin[t]);
-        }
-        fprintf(stderr, "[readSpan] %zu MB in %zu slices: %.1f ms; thread start delay max %.2f ms; slice min %.1f max %.1f ms; slice 0: %ld minor faults, %ld involuntary / %ld voluntary switches\n", want >> 20, nsl,
-                (tDone - tSpawn) * 1e3, maxStart * 1e3, minSlice * 1e3, maxSlice * 1e3, flt[0] % 1000000, (flt[0] / 1000000) % 1000, flt[0] / 1000000000L);
     }
     if (bad) throw BamException("Could not read BAM file: " + bamFile);
 }

@@ -285,6 +285,16 @@ public:
     ~PinnedPool() {
         for (auto& b : bufs) pjb_host_free(b.p);
     }
+    // a free buffer of the ring, or nullptr at once (ring pieces only: every buffer has the ring's size once allocated)
+    uint8_t* tryAcquire(size_t bytes) {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            bool any = false;
+            for (auto& b : bufs) any |= !b.busy;
+            if (!any) return nullptr;
+        }
+        return acquire(bytes);
+    }
     uint8_t* acquire(size_t bytes) {
         Buf* mine = nullptr;
         {
@@ -360,9 +370,16 @@ public:
         std::unique_lock<std::mutex> lk(mu);
         cv.wait(lk, [&] { return ready; });
     }
+    // the context, for the calls that may come from other threads (pjb_bam_begin / _piece / _pieces_done); nullptr if its
+    // creation failed (the commands then report why)
+    pjb_ctx* context() {
+        waitReady();
+        return sharedCtx;
+    }
 
 private:
     bool ready = false;
+    pjb_ctx* sharedCtx = nullptr;
     std::thread th;
     std::mutex mu;
     std::condition_variable cv;
@@ -423,6 +440,7 @@ private:
             else p.done->set_exception(std::make_exception_ptr(JunctionBuilderException(err)));
         };
         g_prof.mark("device thread: context ready");
+        sharedCtx = fatal.empty() ? ctx : nullptr;
         static std::atomic<int> profIds{0};
         const int profId = profIds++;
         {
@@ -716,16 +734,52 @@ void JunctionBuilder::findJuncs(DeviceThread& device, BamReader& reader, GenomeM
                         }
                     } leave{pinnedPool.get(), device.lane};
                     const int readThreads = std::max(innerThreads, pinnedPool->readThreads);
-                    DeviceThread::Cmd b0;
-                    b0.kind = DeviceThread::Cmd::BAMBEGIN;
-                    b0.tid = seq;
-                    b0.bamSize = nb;
-                    device.push(std::move(b0));
+                    // This thread hands the pieces to the device itself (pjb_bam_begin / _piece are safe beside the device
+                    // thread's calls): queued behind genome uploads, finishes and record parsing on the device thread the
+                    // copies started late and PCIe idled between them.
+                    pjb_ctx* dctx = directPieces ? device.context() : nullptr;
                     std::string readError;
-                    for (size_t off = 0; off < nb; off += piece) {
+                    struct Mine {
+                        int64_t ticket;
+                        uint8_t* buf;
+                    };
+                    std::deque<Mine> mine;  // pieces of this target whose copy may still read the buffer
+                    auto releaseDone = [&](bool all) {
+                        int64_t done = 0;
+                        if (mine.empty()) return;
+                        if (!dctx || pjb_bam_pieces_done(dctx, &done) != PJB_OK) done = all ? INT64_MAX : 0;
+                        for (int spin = 0; all && dctx && done < mine.back().ticket && spin < 20000; spin++) {  // (at most 2 s: the copies of a failed target)
+                            std::this_thread::sleep_for(std::chrono::microseconds(100));
+                            if (pjb_bam_pieces_done(dctx, &done) != PJB_OK) break;
+                        }
+                        if (all) done = INT64_MAX;
+                        while (!mine.empty() && mine.front().ticket <= done) {
+                            pinnedPool->release(mine.front().buf);
+                            mine.pop_front();
+                        }
+                    };
+                    if (dctx) {
+                        const double tb0 = HostProfile::now();
+                        if (pjb_bam_begin(dctx, seq, (int64_t)nb) != PJB_OK) readError = std::string("pjb_bam_begin: ") + pjb_last_error(dctx);
+                        g_prof.event(tb0, HostProfile::now(), "worker bam_begin tid " + std::to_string(seq));
+                    } else {
+                        DeviceThread::Cmd b0;
+                        b0.kind = DeviceThread::Cmd::BAMBEGIN;
+                        b0.tid = seq;
+                        b0.bamSize = nb;
+                        device.push(std::move(b0));
+                    }
+                    for (size_t off = 0; off < nb && readError.empty(); off += piece) {
                         const size_t n = std::min(piece, nb - off);
                         const double ta0 = HostProfile::now();
-                        uint8_t* buf = pinnedPool->acquire(piece);
+                        uint8_t* buf = nullptr;
+                        if (dctx) {
+                            while (!(buf = pinnedPool->tryAcquire(piece))) {  // (this thread's finished copies may be what the ring waits for)
+                                releaseDone(false);
+                                std::this_thread::sleep_for(std::chrono::microseconds(100));
+                            }
+                        } else
+                            buf = pinnedPool->acquire(piece);
                         const double ta1 = HostProfile::now();
                         if (ta1 - ta0 > 1e-3) g_prof.event(ta0, ta1, "worker ring wait tid " + std::to_string(seq));
                         if (!buf) {
@@ -739,6 +793,18 @@ void JunctionBuilder::findJuncs(DeviceThread& device, BamReader& reader, GenomeM
                             pinnedPool->release(buf);
                             readError = e.what();
                             break;
+                        }
+                        if (dctx) {
+                            int64_t ticket = 0;
+                            if (pjb_bam_piece(dctx, seq, buf, (int64_t)n, &ticket) != PJB_OK) {
+                                readError = std::string("pjb_bam_piece: ") + pjb_last_error(dctx);
+                                releaseDone(true);  // (a failing piece call has waited for the upload stream)
+                                pinnedPool->release(buf);
+                                break;
+                            }
+                            mine.push_back(Mine{ticket, buf});
+                            releaseDone(false);
+                            continue;
                         }
                         DeviceThread::Cmd c;
                         c.kind = DeviceThread::Cmd::BAMPIECE;
@@ -758,6 +824,7 @@ void JunctionBuilder::findJuncs(DeviceThread& device, BamReader& reader, GenomeM
                     device.push(std::move(c));
                     leave.now();  // the next target's pieces cross while this one is inflated and parsed
                     any = f.get() > 0;
+                    releaseDone(true);  // (pjb_bam_end has waited for the copies)
                     if (!readError.empty()) throw bam::BamException(readError);
                     nb = 0;  // (handled)
                 }
@@ -894,34 +961,8 @@ void JunctionBuilder::findJuncs(DeviceThread& device, BamReader& reader, GenomeM
     }
 }
 
-// PJB_SELFTEST_PREAD=1 (debugging aid): how fast do 4 groups of 4 threads read 64 MB pieces of the BAM file into
-// page-locked buffers right now, with nothing else going on in this process?
-static void preadSelfTest(const std::string& path, const char* when) {
-    if (!getenv("PJB_SELFTEST_PREAD")) return;
-    const size_t piece = (size_t)64 << 20;
-    const int G = 4, T = 4, N = 8;
-    std::vector<uint8_t*> bufs(G);
-    for (auto& b : bufs) b = (uint8_t*)pjb_host_alloc(piece);
-    const double t0 = HostProfile::now();
-    std::vector<std::thread> groups;
-    std::vector<double> ms(G);
-    for (int g = 0; g < G; g++)
-        groups.emplace_back([&, g] {
-            bam::BamReader r(path);
-            const double a = HostProfile::now();
-            for (int k = 0; k < N; k++) r.readSpan(((uint64_t)g * 64 + (uint64_t)k) * piece + (1 << 20), piece, bufs[(size_t)g], T);
-            ms[(size_t)g] = (HostProfile::now() - a) * 1e3 / N;
-        });
-    for (auto& t : groups) t.join();
-    const double dt = HostProfile::now() - t0;
-    std::cerr << "[pread self-test] " << when << ": " << (G * N * piece / dt / 1e9) << " GB/s, ms per 64 MB piece per group: " << ms[0] << " " << ms[1] << " "
-              << ms[2] << " " << ms[3] << std::endl;
-    for (auto& b : bufs) pjb_host_free(b);
-}
-
 void JunctionBuilder::findJunctions() {
     WallTimer timer;
-    preadSelfTest(prepData.getSortedBamFilePath(), "start of findJunctions");
     results.clear();
     results.resize(refs->size());
     if (!deviceCount.valid()) deviceCount = std::async(std::launch::async, [] { return pjb_device_count(); }).share();
@@ -954,6 +995,7 @@ void JunctionBuilder::findJunctions() {
     // keep the pageable path whose staging copy is cheaper than that)
     pinnedPool.reset();
     genomePool.reset();
+    directPieces = !(getenv("PORTCULLIS_DIRECT_PIECES") && atoi(getenv("PORTCULLIS_DIRECT_PIECES")) == 0);
     int transferSlots = 0;
     if (deviceIngest) {
         struct stat bst;
@@ -1038,7 +1080,6 @@ void JunctionBuilder::findJunctions() {
     std::vector<std::thread> pool;
     for (int w = 0; w < nthreads; w++) pool.emplace_back(worker, w);
     for (auto& t : pool) t.join();
-    preadSelfTest(prepData.getSortedBamFilePath(), "workers done, contexts alive");
     if (extra && firstError.empty() && !deviceThreads.empty()) {
         // calcExtraMetrics (src/junction_builder.cc:293-312): multiple mapping score, flanking alignments, coverage
         cout << "Calculating extra junction metrics:" << endl;
@@ -1065,7 +1106,6 @@ void JunctionBuilder::findJunctions() {
         }
     }
     deviceThreads.clear();  // joins the device threads (destroys the contexts)
-    preadSelfTest(prepData.getSortedBamFilePath(), "contexts destroyed");
     if (!firstError.empty()) throw JunctionBuilderException(firstError);
     const double t_workers1 = HostProfile::now();
     g_prof.mark("workers and device threads done");
