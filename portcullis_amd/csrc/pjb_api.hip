@@ -35,12 +35,44 @@ struct Contig {
     bool has_x = false;
     bool present = false;
     u32 *codes = nullptr; // packed 4-bit codes (k0_encode); nullptr when the contig is "exotic"
+    size_t d_cap = 0, codes_cap = 0; // sizes of the two allocations (they go back to the context's genome pool)
 };
 
-void free_contig(Contig &g) {
-    if (g.owned && g.d) (void)hipFree(g.d);
-    if (g.codes) (void)hipFree(g.codes);
+// The bases and codes of a released contig are kept for the next upload (targets come longest first, so the next genome
+// fits): a hipMalloc / hipFree pair of 250 MB is ~10 ms on the thread that serves every target.
+void free_contig(Contig &g, std::vector<Buf> *pool = nullptr) {
+    auto give = [&](void *p, size_t cap) {
+        if (!p) return;
+        if (pool && cap > 0 && pool->size() < 8) {
+            Buf b;
+            b.p = p;
+            b.cap = cap;
+            pool->push_back(b);
+        } else
+            (void)hipFree(p);
+    };
+    if (g.owned) give(g.d, g.d_cap);
+    give(g.codes, g.codes_cap);
     g = Contig();
+}
+// device memory for a genome array: the smallest pooled buffer that fits, else a new one
+static void *genome_take(std::vector<Buf> &pool, size_t bytes, size_t &cap) {
+    int best = -1;
+    for (size_t k = 0; k < pool.size(); k++)
+        if (pool[k].cap >= bytes && (best < 0 || pool[k].cap < pool[(size_t)best].cap)) best = (int)k;
+    if (best >= 0) {
+        void *p = pool[(size_t)best].p;
+        cap = pool[(size_t)best].cap;
+        pool.erase(pool.begin() + best);
+        return p;
+    }
+    void *p = nullptr;
+    cap = bytes;
+    if (hipMalloc(&p, bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    return p;
 }
 
 struct Slab { // device memory for the batches copied in by pjb_submit_batch; reused contig after contig
@@ -153,6 +185,7 @@ struct pjb_ctx {
     // pjb_bam_begin / _piece / _pieces_done / _inflate_done may come from other threads than the context's other calls (the
     // threads that read the file hand their pieces over themselves): bam_mu guards the staging state below
     std::mutex bam_mu, err_mu;
+    std::vector<Buf> genome_pool; // bases / codes of released contigs (free_contig, genome_take)
     std::vector<Buf> stage_pool;  // device buffers for staged BGZF bytes, reused target after target
     // pjb_bam_piece starts a target's bgzf_inflate as soon as its last piece is on its way (own stream, own buffers), so that
     // the inflates of several targets overlap each other and the copies: a launch takes ~50 ms whatever its size (a lane's
@@ -523,6 +556,8 @@ int pjb_create(pjb_ctx **out, const pjb_config *cfg) {
         (void)hipStreamCreateWithFlags(&S.side, hipStreamNonBlocking);
     }
     c->inflate_lanes = std::max(1, n_cu) * (160 * 1024 / I2_LDS_BYTES) * 64;
+    if (const char *s = getenv("PJB_INFLATE_WG_PER_CU")) // (experiments: fewer resident inflate workgroups leave LDS and a SIMD to the kernels beside them)
+        c->inflate_lanes = std::max(1, n_cu) * std::max(1, std::min(atoi(s), 160 * 1024 / I2_LDS_BYTES)) * 64;
     c->ktime = (cfg->flags & PJB_FLAG_KERNEL_TIMING) != 0;
     c->extra = (cfg->flags & PJB_FLAG_EXTRA) != 0;
     if (const char *s = getenv("PJB_DENSE_IDS")) c->dense_ids = atoi(s) != 0;
@@ -552,6 +587,8 @@ void pjb_destroy(pjb_ctx *c) {
         if (kv.second.first) (void)hipFree(kv.second.first);
     c->filter_keys.clear();
     for (auto &g : c->contigs) free_contig(g);
+    for (auto &b : c->genome_pool) release(b);
+    c->genome_pool.clear();
     for (auto &sl : c->slab_pool)
         if (sl.p) (void)hipFree(sl.p);
     if (c->rows_pinned) (void)hipHostFree(c->rows_pinned);
@@ -607,7 +644,7 @@ int pjb_set_refs(pjb_ctx *c, int32_t n_refs, const int32_t *ref_len) {
     return PJB_OK;
 }
 
-static int upload_common(pjb_ctx *c, int32_t tid, uint8_t *d, int64_t len, bool owned, bool do_upper) {
+static int upload_common(pjb_ctx *c, int32_t tid, uint8_t *d, int64_t len, bool owned, bool do_upper, size_t d_cap = 0) {
     HIP_TRY(c, hipSetDevice(c->cfg.device));
     int rc = ensure(c, c->b_hasx, sizeof(int));
     if (rc) return rc;
@@ -621,11 +658,12 @@ static int upload_common(pjb_ctx *c, int32_t tid, uint8_t *d, int64_t len, bool 
     HIP_TRY(c, hipMemcpyAsync(&hx, c->b_hasx.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     // 4-bit codes for the word-parallel compare in k4 (after upper-casing)
     u32 *codes = nullptr;
+    size_t codes_cap = 0;
     int exotic = 0;
     const int64_t n_words = (len + 7) / 8;
     if (len > 0) {
-        hipError_t e = hipMalloc((void **)&codes, (size_t)(n_words + 2) * 4);
-        if (e != hipSuccess) return fail(c, PJB_ERR_NOMEM, "hipMalloc(genome codes): %s", hipGetErrorString(e));
+        codes = (u32 *)genome_take(c->genome_pool, (size_t)(n_words + 2) * 4, codes_cap);
+        if (!codes) return fail(c, PJB_ERR_NOMEM, "hipMalloc(genome codes, %zu bytes) failed", (size_t)(n_words + 2) * 4);
         (void)hipMemsetAsync(c->b_hasx.p, 0, sizeof(int), c->stream);
         (void)hipMemsetAsync(codes + n_words, 0, 8, c->stream);
         hipLaunchKernelGGL(k0_encode, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, c->stream, (const uint8_t *)d, len,
@@ -642,13 +680,15 @@ static int upload_common(pjb_ctx *c, int32_t tid, uint8_t *d, int64_t len, bool 
         codes = nullptr;
     }
     Contig &g = c->contigs[(size_t)tid];
-    free_contig(g);
+    free_contig(g, &c->genome_pool);
     g.d = d;
     g.len = len;
     g.owned = owned;
     g.has_x = hx != 0;
     g.present = true;
     g.codes = codes;
+    g.d_cap = owned ? d_cap : 0;
+    g.codes_cap = codes ? codes_cap : 0;
     return PJB_OK;
 }
 
@@ -657,9 +697,10 @@ int pjb_upload_contig(pjb_ctx *c, int32_t tid, const uint8_t *bases, int64_t len
     if (tid < 0 || (size_t)tid >= c->contigs.size() || len < 0 || (len > 0 && !bases))
         return fail(c, PJB_ERR_ARG, "pjb_upload_contig: bad arguments (tid %d)", tid);
     HIP_TRY(c, hipSetDevice(c->cfg.device));
-    uint8_t *d = nullptr;
-    hipError_t e = hipMalloc((void **)&d, (size_t)std::max<int64_t>(len, 16));
-    if (e != hipSuccess) return fail(c, PJB_ERR_NOMEM, "hipMalloc(genome %lld): %s", (long long)len, hipGetErrorString(e));
+    size_t d_cap = 0;
+    uint8_t *d = (uint8_t *)genome_take(c->genome_pool, (size_t)std::max<int64_t>(len, 16), d_cap);
+    if (!d) return fail(c, PJB_ERR_NOMEM, "hipMalloc(genome %lld) failed", (long long)len);
+    hipError_t e = hipSuccess;
     // through the page-locked staging buffers in 32 MiB pieces (a pageable hipMemcpy is several times slower)
     const size_t PIECE = (size_t)32 << 20;
     for (size_t off = 0; off < (size_t)len; off += PIECE) {
@@ -689,7 +730,7 @@ int pjb_upload_contig(pjb_ctx *c, int32_t tid, const uint8_t *bases, int64_t len
         (void)hipEventRecord(c->stage_ev[si], c->stream);
         c->stage_busy[si] = true;
     }
-    int rc = upload_common(c, tid, d, len, true, true);
+    int rc = upload_common(c, tid, d, len, true, true, d_cap);
     if (rc) (void)hipFree(d);
     return rc;
 }
@@ -705,9 +746,9 @@ int pjb_upload_contig_fasta(pjb_ctx *c, int32_t tid, const uint8_t *raw, int64_t
     int rc;
     if ((rc = ensure(c, c->b_fasta_raw, (size_t)std::max<int64_t>(raw_bytes, 16)))) return rc;
     if ((rc = ensure(c, c->b_hasx, sizeof(int)))) return rc;
-    uint8_t *d = nullptr;
-    hipError_t e = hipMalloc((void **)&d, (size_t)std::max<int64_t>(len, 16));
-    if (e != hipSuccess) return fail(c, PJB_ERR_NOMEM, "hipMalloc(genome %lld): %s", (long long)len, hipGetErrorString(e));
+    size_t d_cap = 0;
+    uint8_t *d = (uint8_t *)genome_take(c->genome_pool, (size_t)std::max<int64_t>(len, 16), d_cap);
+    if (!d) return fail(c, PJB_ERR_NOMEM, "hipMalloc(genome %lld) failed", (long long)len);
     struct Guard {
         uint8_t *d;
         ~Guard() {
@@ -730,7 +771,7 @@ int pjb_upload_contig_fasta(pjb_ctx *c, int32_t tid, const uint8_t *raw, int64_t
     HIP_TRY(c, hipMemcpyAsync(&bad, c->b_hasx.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (bad) return PJB_OK; // (*well_formed stays 0: nothing was uploaded)
-    rc = upload_common(c, tid, d, len, true, true);
+    rc = upload_common(c, tid, d, len, true, true, d_cap);
     if (rc) return rc;
     guard.d = nullptr;
     *well_formed = 1;
@@ -749,7 +790,7 @@ int pjb_release_contig(pjb_ctx *c, int32_t tid) {
     if (tid < 0 || (size_t)tid >= c->contigs.size()) return fail(c, PJB_ERR_ARG, "pjb_release_contig: bad tid %d", tid);
     Contig &g = c->contigs[(size_t)tid];
     (void)hipStreamSynchronize(c->stream);
-    free_contig(g);
+    free_contig(g, &c->genome_pool);
     return PJB_OK;
 }
 
@@ -2313,7 +2354,15 @@ static void inflate_early(pjb_ctx *c, BamStage &st) {
         return;
     }
     hipStream_t &is = c->inf_streams[c->inf_next++ & 3u];
-    if (!is && hipStreamCreateWithFlags(&is, hipStreamNonBlocking) != hipSuccess) return;
+    if (!is) {
+        // The inflate streams have the lowest priority: a launch holds every LDS byte of the chip for ~50 ms, and the short
+        // kernels beside it -- record parsing, genome uploads, the junc chains of the targets before it -- are what the one
+        // host thread that serves all targets waits for (end to end 2.73 -> 2.44 s; PJB_INFLATE_NORMAL_PRIORITY=1: as before)
+        int lo = 0, hi = 0; // (least, greatest priority)
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+        const bool low = getenv("PJB_INFLATE_NORMAL_PRIORITY") == nullptr;
+        if ((low ? hipStreamCreateWithPriority(&is, hipStreamNonBlocking, lo) : hipStreamCreateWithFlags(&is, hipStreamNonBlocking)) != hipSuccess) return;
+    }
     if (hipEventCreateWithFlags(&st.ev_last, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&st.ev_inf, hipEventDisableTiming) != hipSuccess) return;
     int *d_status = (int *)st.d_status.p;
     int *d_any = d_status + nb;

@@ -3,7 +3,6 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-timeout 900 python -m pytest tests/test_gpu_host_cli.py tests/test_gpu_ingest.py -m gpu -q -x 2>&1 | tail -3
 PJB_BENCH_KEEP_WORKDIR=1 PJB_BENCH_E2E_REPS=1 timeout 900 python bench.py --no-cpu-baseline --steps 2 --warmup 1 > gpurun_out/e2e_tr_bench.json 2> gpurun_out/e2e_tr_bench.err
 python -c "import json; print(json.load(open('gpurun_out/e2e_tr_bench.json'))['e2e'])"
 W=/tmp/pjb_bench_e2e
@@ -21,7 +20,7 @@ lea = float(re.search(r"leaving main at epoch ([0-9.]+)", err).group(1))
 print(f"{sys.argv[1]}: wall {t1 - t0:.2f} s = {ent - t0:.2f} before main + {lea - ent:.2f} in main + {t1 - lea:.2f} after")
 PY
 }
-for i in 1 2 3 4; do run A=1; done; run PORTCULLIS_DIRECT_PIECES=0; run PORTCULLIS_DIRECT_PIECES=0; run PORTCULLIS_TRANSFER_SLOTS=4; run PORTCULLIS_TRANSFER_SLOTS=2; run PORTCULLIS_CTX_PER_GPU=2 PORTCULLIS_TRANSFER_SLOTS=4; md5sum $W/out/pc2.junctions.tab
+run A=1; for i in 1 2 3 4; do run A=1; run PJB_INFLATE_WG_PER_CU=3; run PJB_INFLATE_LOW_PRIORITY=1; run PJB_INFLATE_WG_PER_CU=3 PJB_INFLATE_LOW_PRIORITY=1; done; md5sum $W/out/pc2.junctions.tab
 PJB_PROFILE_HOST=2 portcullis_amd/host/portcullis_amd junc -t 16 --orientation FR -o $W/out/pc2 $W/prep > /dev/null 2> gpurun_out/e2e_tr_host.txt
 grep -E "device thread|workers|main:|context ready" gpurun_out/e2e_tr_host.txt
 rm -rf /tmp/e2e_prof
