@@ -59,6 +59,7 @@ class JunctionBuilder {
     std::shared_ptr<class PinnedPool> pinnedPool;  // ring of page-locked pieces for the file bytes of large device-ingest runs
     std::shared_ptr<class PinnedPool> genomePool;  // a few page-locked buffers for the FASTA bytes of the target sequences (same runs)
     size_t pieceMinTarget = 0;                     // targets with fewer bytes go over in one (pageable) block
+    bool backgroundTeardown = false;               // contexts and page-locked rings are taken down beside the merge and the writers (the program sets it: it leaves with _exit; a library caller that returns from main must not have a thread inside the runtime then)
     bool directPieces = true;                      // the threads that read the file hand the pieces to the device themselves (PORTCULLIS_DIRECT_PIECES=0: through the device thread's queue)
     bool deviceIngest = true;      // BGZF inflate + BAM record parse on the GPU (pjb_submit_bam); false: host threads
 

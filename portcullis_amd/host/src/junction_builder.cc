@@ -1108,7 +1108,8 @@ void JunctionBuilder::findJunctions() {
     // Everything the device produced is on the host.  Taking the contexts down (every device buffer), and the page-locked
     // rings with them, is 0.1-0.3 s of runtime and driver work that nothing waits for: it runs beside the merge and the
     // writers instead of before them (PORTCULLIS_SYNC_TEARDOWN=1: as before).
-    if (getenv("PORTCULLIS_SYNC_TEARDOWN") || !firstError.empty()) {
+    // (a process that will leave through exit handlers must not have a thread inside the runtime by then)
+    if (!backgroundTeardown || getenv("PORTCULLIS_SYNC_TEARDOWN") || getenv("PJB_NORMAL_EXIT") || !firstError.empty()) {
         deviceThreads.clear();  // joins the device threads (destroys the contexts)
     } else {
         auto dts = std::make_shared<std::vector<std::unique_ptr<DeviceThread>>>(std::move(deviceThreads));
@@ -1241,6 +1242,7 @@ int JunctionBuilder::main(int argc, char* argv[]) {
         if (ingest != "host" && ingest != "device") throw JunctionBuilderException("--ingest takes host or device");
         jb.setDeviceIngest(ingest == "device");
     }
+    jb.backgroundTeardown = true;  // (this program leaves through _exit)
     jb.process();
     if (getenv("PJB_PROFILE_HOST")) cerr << "[host profile] main: " << timer.elapsed() << " s until process() returned" << endl;
     return 0;
