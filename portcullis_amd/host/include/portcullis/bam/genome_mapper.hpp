@@ -53,8 +53,9 @@ public:
         int64_t length = 0;
     };
     bool rawSpan(const std::string& name, RawSpan& out) const;
-    // the bytes of a raw span, read with a few threads (pread on the open file)
-    void readRaw(const RawSpan& span, uint8_t* dst, int nthreads) const;
+    // the bytes of a raw span, read with a few threads (pread on the open file); false if the file ends before the span
+    // does (a record that is not laid out as its index line says: the caller filters the characters instead)
+    bool readRaw(const RawSpan& span, uint8_t* dst, int nthreads) const;
 };
 
 }  // namespace bam

@@ -166,17 +166,21 @@ bool GenomeMapper::rawSpan(const std::string& name, RawSpan& out) const {
     return true;
 }
 
-void GenomeMapper::readRaw(const RawSpan& span, uint8_t* dst, int nthreads) const {
+bool GenomeMapper::readRaw(const RawSpan& span, uint8_t* dst, int nthreads) const {
     const int fd = fileno(fp);
     const size_t want = span.bytes;
     const size_t nsl = std::max<size_t>(1, std::min<size_t>((size_t)std::max(1, nthreads), want >> 22));
-    std::atomic<bool> bad(false);
+    std::atomic<bool> bad(false), eof(false);
     auto slice = [&](size_t t) {
         const size_t per = (want + nsl - 1) / nsl, a = std::min(want, per * t), b = std::min(want, a + per);
         size_t got = 0;
         while (a + got < b) {
             const ssize_t r = pread(fd, dst + a + got, b - a - got, (off_t)(span.fileOffset + a + got));
-            if (r <= 0) {
+            if (r == 0) {
+                eof = true;
+                return;
+            }
+            if (r < 0) {
                 bad = true;
                 return;
             }
@@ -189,7 +193,8 @@ void GenomeMapper::readRaw(const RawSpan& span, uint8_t* dst, int nthreads) cons
         for (size_t t = 0; t < nsl; t++) th.emplace_back(slice, t);
         for (auto& x : th) x.join();
     }
-    if (bad) throw BamException("Short read in genome file: " + genomeFile);
+    if (bad) throw BamException("Could not read genome file: " + genomeFile);
+    return !eof;
 }
 
 }  // namespace bam

@@ -881,29 +881,34 @@ void JunctionBuilder::findJuncs(DeviceThread& device, BamReader& reader, GenomeM
             uint8_t* buf = genomePool->acquire(span.bytes);
             if (buf) {
                 const double t1 = HostProfile::now();
+                bool whole = false;
                 try {
-                    gmap.readRaw(span, buf, std::max(innerThreads, 4));
+                    whole = gmap.readRaw(span, buf, std::max(innerThreads, 4));
                 } catch (...) {
                     genomePool->release(buf);
                     throw;
                 }
                 g_prof.event(t0, t1, "worker genome buffer wait tid " + std::to_string(seq));
                 g_prof.event(t1, HostProfile::now(), "worker genome raw read tid " + std::to_string(seq));
-                std::promise<bool> ok;
-                std::future<bool> f = ok.get_future();
-                DeviceThread::Cmd c;
-                c.kind = DeviceThread::Cmd::GENOME;
-                c.tid = seq;
-                c.raw = buf;
-                c.rawBytes = span.bytes;
-                c.lineBases = span.lineBases;
-                c.lineWidth = span.lineWidth;
-                c.genomeLen = span.length;
-                c.rawPool = genomePool.get();
-                c.rawDone = &ok;
-                device.push(std::move(c));
-                uploaded = f.get();
-                t_genome = HostProfile::now() - t0;
+                if (!whole) {  // the file ends before the span the index describes: the record is not laid out that way
+                    genomePool->release(buf);
+                } else {
+                    std::promise<bool> ok;
+                    std::future<bool> f = ok.get_future();
+                    DeviceThread::Cmd c;
+                    c.kind = DeviceThread::Cmd::GENOME;
+                    c.tid = seq;
+                    c.raw = buf;
+                    c.rawBytes = span.bytes;
+                    c.lineBases = span.lineBases;
+                    c.lineWidth = span.lineWidth;
+                    c.genomeLen = span.length;
+                    c.rawPool = genomePool.get();
+                    c.rawDone = &ok;
+                    device.push(std::move(c));
+                    uploaded = f.get();
+                    t_genome = HostProfile::now() - t0;
+                }
             }
         }
         if (!uploaded) {
