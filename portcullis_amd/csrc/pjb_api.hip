@@ -2309,6 +2309,7 @@ struct BamStage {
     double t_scan = 0, t_up = 0;
     // the inflate launched at the last piece (launched: ev_inf follows the kernel on its stream)
     bool launched = false;
+    iu32 ctl[2] = {0, 0}; // { "some block failed", lanes }: copied to the device asynchronously, so it lives here and not on a stack
     Buf out, d_blocks, d_status, d_scratch;
     hipEvent_t ev_inf = nullptr, ev_last = nullptr;
 };
@@ -2367,11 +2368,12 @@ static void inflate_early(pjb_ctx *c, BamStage &st) {
     int *d_status = (int *)st.d_status.p;
     int *d_any = d_status + nb;
     iu32 *d_next = (iu32 *)(d_any + 1);
-    const iu32 ctl[2] = {0u, (iu32)lanes};
+    st.ctl[0] = 0u;
+    st.ctl[1] = (iu32)lanes;
     bool ok = hipEventRecord(st.ev_last, c->stream_up) == hipSuccess && hipStreamWaitEvent(is, st.ev_last, 0) == hipSuccess &&
               hipMemsetAsync((uint8_t *)st.out.p + st.total_out, 0, 64, is) == hipSuccess &&
               hipMemcpyAsync(st.d_blocks.p, st.blocks.data(), nb * sizeof(InfBlock), hipMemcpyHostToDevice, is) == hipSuccess &&
-              hipMemcpyAsync(d_any, ctl, 8, hipMemcpyHostToDevice, is) == hipSuccess;
+              hipMemcpyAsync(d_any, st.ctl, 8, hipMemcpyHostToDevice, is) == hipSuccess;
     if (ok) {
         hipLaunchKernelGGL(bgzf_inflate, dim3((unsigned)(lanes / 64)), dim3(64), I2_LDS_BYTES, is, (const uint8_t *)st.dev.p, (const InfBlock *)st.d_blocks.p,
                            (iu32)nb, (uint8_t *)st.out.p, (uint8_t *)st.d_scratch.p, d_status, d_any, d_next, 8);
