@@ -823,6 +823,8 @@ void JunctionBuilder::findJuncs(DeviceThread& device, BamReader& reader, GenomeM
                     c.bamDone = &got;
                     device.push(std::move(c));
                     leave.now();  // the next target's pieces cross while this one is inflated and parsed
+                    // (the ring gets this target's buffers back as their copies complete, not when its records are parsed)
+                    while (f.wait_for(std::chrono::microseconds(200)) != std::future_status::ready) releaseDone(false);
                     any = f.get() > 0;
                     releaseDone(true);  // (pjb_bam_end has waited for the copies)
                     if (!readError.empty()) throw bam::BamException(readError);
