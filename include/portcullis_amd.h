@@ -343,8 +343,12 @@ int pjb_submit_bam(pjb_ctx* ctx, int32_t tid, const uint8_t* comp, int64_t comp_
  *   pjb_bam_end          inflate + parse + transcode of the staged bytes: from here on exactly pjb_submit_bam
  *                        (same result, same errors; a BGZF error found while hopping is reported by the piece call;
  *                        a failing piece call drops the target's staging: begin again).
- * Several targets may be between _begin and _end at once (each has its own device buffer, taken from a pool the
- * context keeps). */
+ * Several targets may be between _begin and _end at once (each has its own device buffers, taken from pools the
+ * context keeps).  The call that hands over a target's LAST piece also starts its inflate (own stream, lowest priority,
+ * behind the copy): see pjb_bam_inflate_done.
+ * Threads: pjb_bam_begin, _piece, _pieces_done and _inflate_done may be called from other threads than the one that makes
+ * the context's other calls (a thread that reads the file hands its pieces over itself); pjb_bam_end belongs to that one
+ * thread, like everything else. */
 int pjb_bam_begin(pjb_ctx* ctx, int32_t tid, int64_t total_bytes);
 int pjb_bam_piece(pjb_ctx* ctx, int32_t tid, const uint8_t* piece, int64_t bytes, int64_t* ticket);
 int pjb_bam_pieces_done(pjb_ctx* ctx, int64_t* completed_ticket);
