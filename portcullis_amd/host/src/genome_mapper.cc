@@ -1,3 +1,4 @@
+#include <sys/stat.h>
 #include <unistd.h>
 #include <thread>
 #include <atomic>
@@ -157,12 +158,17 @@ bool GenomeMapper::rawSpan(const std::string& name, RawSpan& out) const {
     auto it = byName.find(name);
     if (it == byName.end()) return false;
     const Entry& e = entries[it->second];
-    if (e.line_blen <= 0 || e.line_len < e.line_blen || e.len < 0) return false;
+    if (e.line_blen <= 0 || e.line_len < e.line_blen || e.len < 0 || e.offset < 0) return false;
+    if (e.line_len - e.line_blen > 8) return false;  // (line ends are one or two bytes; anything odd is left to the character filter)
     out.fileOffset = (uint64_t)e.offset;
     out.lineBases = e.line_blen;
     out.lineWidth = e.line_len;
     out.length = e.len;
     out.bytes = e.len == 0 ? 0 : (size_t)((e.len - 1) / e.line_blen * e.line_len + (e.len - 1) % e.line_blen + 1);
+    // an index line that describes more bytes than the file holds is not a layout to rely on (and nothing that large
+    // should be page-locked on its word)
+    struct stat st;
+    if (!fp || fstat(fileno(fp), &st) != 0 || out.fileOffset + out.bytes > (uint64_t)st.st_size) return false;
     return true;
 }
 

@@ -93,7 +93,7 @@ def test_fasta_records_not_laid_out_as_indexed(tmp_path):
     for line in lines:
         f = line.split()
         seen.add(f[0])
-        if f[1] == "short":  # the span the index implies runs past the end of the file: readRaw says so, the caller parses
+        if f[1] in ("short", "none"):  # the span the index implies runs past the end of the file: no raw span, the caller parses
             assert f[0] == "blank"
             continue
         name, off, nbytes, lb, lw, length = f
@@ -102,3 +102,18 @@ def test_fasta_records_not_laid_out_as_indexed(tmp_path):
         assert not ok
     assert seen == {"ragged", "blank"}
     assert open(out / "ragged.seq", "rb").read() == seq.encode()
+
+
+def test_fasta_odd_line_ends_are_left_to_the_filter(tmp_path):
+    """Line ends longer than a few bytes: no raw span (the device's terminator check is bounded), fetchContig still reads
+    the record."""
+    exe = build(tmp_path)
+    seq = "GATTACA" * 40
+    fa = tmp_path / "o.fa"
+    term = "\r" * 9 + "\n"
+    with open(fa, "w", newline="") as f:
+        f.write(">odd" + "\n" + term.join(seq[k:k + 70] for k in range(0, len(seq), 70)) + term)
+    out = tmp_path / "out"
+    out.mkdir()
+    lines = [l for l in subprocess.check_output([exe, str(fa), str(out), "odd"], text=True).split("\n") if l]
+    assert lines == ["odd none"]
