@@ -742,6 +742,7 @@ int pjb_upload_contig_fasta(pjb_ctx *c, int32_t tid, const uint8_t *raw, int64_t
         line_len < line_blen || !well_formed)
         return fail(c, PJB_ERR_ARG, "pjb_upload_contig_fasta: bad arguments (tid %d)", tid);
     *well_formed = 0;
+    if (line_len - line_blen > 64) return PJB_OK; // (line ends are a byte or two; the kernel's check of them is a loop per line)
     HIP_TRY(c, hipSetDevice(c->cfg.device));
     int rc;
     if ((rc = ensure(c, c->b_fasta_raw, (size_t)std::max<int64_t>(raw_bytes, 16)))) return rc;
