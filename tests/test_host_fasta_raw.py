@@ -1,7 +1,8 @@
 """Host side of pjb_upload_contig_fasta (no GPU needed): GenomeMapper::rawSpan / readRaw hand over exactly the bytes of a
 record's sequence lines, and the rule the device applies to them -- base i is byte (i / LINEBASES) * LINEWIDTH +
 i % LINEBASES; every base a graphic character, every terminator byte not one -- gives GenomeMapper::fetchContig's bases
-for records laid out as their .fai line says and refuses the others (restated here in numpy: what k0_fasta computes)."""
+for records laid out as their .fai line says and refuses the others (restated here in numpy: what k0_fasta computes).
+The C++ side runs under AddressSanitizer + UndefinedBehaviorSanitizer (PJB_TEST_SANITIZE=0: against the built library)."""
 import os
 import subprocess
 
@@ -29,6 +30,17 @@ def delinearize(raw, n, line_bases, line_width):
 
 
 def build(tmp_path):
+    if os.environ.get("PJB_TEST_SANITIZE", "1") != "0":
+        # GenomeMapper has no dependency on the device library: the driver and genome_mapper.cc build on their own, under
+        # AddressSanitizer + UndefinedBehaviorSanitizer (an out-of-bounds pread destination or a bad offset computation
+        # aborts the driver)
+        host = os.path.join(ROOT, "portcullis_amd", "host")
+        exe = str(tmp_path / "fasta_raw_span_asan")
+        subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+                               "-fno-omit-frame-pointer", f"-I{host}/include", f"-I{ROOT}/include", "-o", exe,
+                               os.path.join(ROOT, "tests", "cpp", "fasta_raw_span.cc"),
+                               os.path.join(host, "src", "genome_mapper.cc"), "-lpthread"])
+        return exe
     host = os.path.join(ROOT, "portcullis_amd", "host")
     csrc = os.path.join(ROOT, "portcullis_amd", "csrc")
     if not os.path.exists(os.path.join(host, "libportcullis_host.so")):
