@@ -184,7 +184,8 @@ typedef struct pjb_timing {
 int pjb_create(pjb_ctx **out, const pjb_config *cfg);
 void pjb_destroy(pjb_ctx *ctx);
 
-/* Message for the last failing call on ctx (ctx == NULL: last failing pjb_create on this thread). */
+/* Message of the last failing call the CALLING THREAD made on a context (ctx == NULL: its last failing pjb_create).
+ * Kept per thread: the piece calls below may run beside the context's other calls, and a thread reads its own failure. */
 const char *pjb_last_error(const pjb_ctx *ctx);
 
 /* Reference sequence lengths, indexed by BAM tid. */

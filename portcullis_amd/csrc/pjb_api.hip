@@ -22,6 +22,10 @@ using namespace pjb;
 namespace {
 
 thread_local std::string g_create_error;
+// The message of the last failing call of THIS thread (pjb_last_error returns it): pjb_bam_begin / _piece / _pieces_done /
+// _inflate_done may run on other threads than the context's other calls, and a thread must neither read a string another
+// thread is reassigning nor report another thread's failure.
+thread_local std::string g_thread_error;
 
 struct Buf {
     void *p = nullptr;
@@ -266,6 +270,7 @@ int fail(pjb_ctx *c, int code, const char *fmt, ...) {
     vsnprintf(tmp, sizeof tmp, fmt, ap);
     va_end(ap);
     if (c) {
+        g_thread_error = tmp;
         std::lock_guard<std::mutex> lk(c->err_mu);
         c->err = tmp;
     } else
@@ -632,7 +637,7 @@ void pjb_destroy(pjb_ctx *c) {
     delete c;
 }
 
-const char *pjb_last_error(const pjb_ctx *c) { return c ? c->err.c_str() : g_create_error.c_str(); }
+const char *pjb_last_error(const pjb_ctx *c) { return c ? g_thread_error.c_str() : g_create_error.c_str(); }
 
 int pjb_set_refs(pjb_ctx *c, int32_t n_refs, const int32_t *ref_len) {
     if (!c) return PJB_ERR_ARG;
@@ -1641,7 +1646,9 @@ int pjb_finish_contig_end(pjb_ctx *c, int32_t tid, pjb_region_result *res) {
             Flight &g = c->fl[k];
             if (g.queued || g.empty) continue;
             auto it = c->open.find(g.tid);
-            if (it != c->open.end() && (rc = queue_contig(c, g, it->second.batches))) return rc;
+            // a follower that cannot be queued here is queued again -- and reports its error -- by its own
+            // pjb_finish_contig_end; THIS target is collected and its rows are in the table
+            if (it != c->open.end() && queue_contig(c, g, it->second.batches)) break;
         }
     }
     return PJB_OK;
@@ -2352,6 +2359,7 @@ static void inflate_early(pjb_ctx *c, BamStage &st) {
     if (const char *e = getenv("PJB_INF_BLOCKS_PER_LAUNCH")) lanes = std::min<size_t>((nb + 63) / 64 * 64, (size_t)std::max(64, atoi(e)) / 64 * 64);
     if (pool_take(c, c->out_pool, st.out, (size_t)st.total_out + 64) || pool_take(c, c->misc_pool, st.d_blocks, nb * sizeof(InfBlock)) ||
         pool_take(c, c->misc_pool, st.d_status, nb * 4 + 16) || pool_take(c, c->misc_pool, st.d_scratch, lanes * INF_SCRATCH_PER_LANE)) {
+        std::lock_guard<std::mutex> lk(c->err_mu); // (a failure here just leaves the inflate to pjb_bam_end)
         c->err.clear();
         return;
     }
@@ -2483,8 +2491,13 @@ extern "C" int pjb_bam_begin(pjb_ctx *c, int32_t tid, int64_t total_bytes) {
         if (rc) return rc;
     }
     st->total = total_bytes;
-    if (!c->stream_up) HIP_TRY(c, hipStreamCreateWithFlags(&c->stream_up, hipStreamNonBlocking));
-    HIP_TRY(c, hipMemsetAsync((uint8_t *)st->dev.p + total_bytes, 0, INF_PAD, c->stream_up));
+    hipError_t he = hipSuccess;
+    if (!c->stream_up) he = hipStreamCreateWithFlags(&c->stream_up, hipStreamNonBlocking);
+    if (he == hipSuccess) he = hipMemsetAsync((uint8_t *)st->dev.p + total_bytes, 0, INF_PAD, c->stream_up);
+    if (he != hipSuccess) {
+        pool_give(c->stage_pool, st->dev);
+        return fail(c, PJB_ERR_HIP, "bam_begin: %s", hipGetErrorString(he));
+    }
     c->bam_stage[tid] = st.release();
     return PJB_OK;
 }
@@ -2510,7 +2523,6 @@ extern "C" int pjb_bam_piece(pjb_ctx *c, int32_t tid, const uint8_t *piece, int6
 
 static int bam_piece_body(pjb_ctx *c, int32_t tid, BamStage &st, const uint8_t *piece, int64_t bytes, int64_t *ticket) {
     if (st.got + bytes > st.total) return fail(c, PJB_ERR_ARG, "bam_piece: target %d: more bytes than announced", tid);
-    c->cur_tid = tid;
     HIP_TRY(c, hipSetDevice(c->cfg.device));
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     double t0 = now();
@@ -2590,7 +2602,8 @@ extern "C" int pjb_bam_end(pjb_ctx *c, int32_t tid, int32_t first_uoffset, int64
         BamStage *st;
         ~Return() {
             (void)hipStreamSynchronize(c->stream);
-            if (st->launched) (void)hipEventSynchronize(st->ev_inf);
+            if (st->launched) (void)hipEventSynchronize(st->ev_inf); // (the inflate waited for the target's last copy)
+            else if (c->stream_up) (void)hipStreamSynchronize(c->stream_up); // early returns: the copies may still read the caller's buffers
             std::lock_guard<std::mutex> lk(c->bam_mu);
             stage_release(c, *st);
         }

@@ -286,43 +286,56 @@ public:
         for (auto& b : bufs) pjb_host_free(b.p);
     }
     // a free buffer of the ring, or nullptr at once (ring pieces only: every buffer has the ring's size once allocated)
-    uint8_t* tryAcquire(size_t bytes) {
-        {
-            std::lock_guard<std::mutex> lk(mu);
-            bool any = false;
-            for (auto& b : bufs) any |= !b.busy;
-            if (!any) return nullptr;
-        }
-        return acquire(bytes);
-    }
-    uint8_t* acquire(size_t bytes) {
+    uint8_t* tryAcquire(size_t bytes) { return take(bytes, false); }
+    uint8_t* acquire(size_t bytes) { return take(bytes, true); }
+
+private:
+    // The buffer is picked and marked busy under one lock (a second caller can never be sent to sleep for a buffer the
+    // first one saw); a first-use or growing allocation happens with the slot marked busy and its pointer and size are
+    // published under the lock again (release() compares pointers of every slot).
+    uint8_t* take(size_t bytes, bool wait) {
         Buf* mine = nullptr;
         {
             std::unique_lock<std::mutex> lk(mu);
-            cv.wait(lk, [&] {
+            auto anyFree = [&] {
                 for (auto& b : bufs)
                     if (!b.busy) return true;
                 return false;
-            });
+            };
+            if (!anyFree()) {
+                if (!wait) return nullptr;
+                cv.wait(lk, anyFree);
+            }
             for (auto& b : bufs)  // prefer one that is large enough already
                 if (!b.busy && b.cap >= bytes) mine = &b;
             if (!mine)
                 for (auto& b : bufs)
                     if (!b.busy) mine = &b;
             mine->busy = true;
+            if (mine->cap >= bytes) return mine->p;
         }
-        if (mine->cap < bytes) {
-            pjb_host_free(mine->p);
-            mine->cap = bytes + bytes / 8;
-            mine->p = (uint8_t*)pjb_host_alloc(mine->cap);
-            if (!mine->p) {
-                mine->cap = 0;
-                release(nullptr, mine);
-                return nullptr;
-            }
+        uint8_t* old = nullptr;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            old = mine->p;
+            mine->p = nullptr;
+            mine->cap = 0;
         }
-        return mine->p;
+        pjb_host_free(old);
+        const size_t cap = bytes + bytes / 8;
+        uint8_t* np = (uint8_t*)pjb_host_alloc(cap);
+        std::lock_guard<std::mutex> lk(mu);
+        if (!np) {
+            mine->busy = false;
+            cv.notify_all();
+            return nullptr;
+        }
+        mine->p = np;
+        mine->cap = cap;
+        return np;
     }
+
+public:
     void release(uint8_t* p, void* which = nullptr) {
         std::lock_guard<std::mutex> lk(mu);
         for (auto& b : bufs)
@@ -535,9 +548,16 @@ private:
                 q.erase(q.begin() + (long)pick);
                 if (c.kind == Cmd::BAMEND || c.kind == Cmd::BAM) ended.insert(c.tid);
                 cv.notify_all();
-                if (c.kind == Cmd::BAMEND && ctx && !pjb_bam_inflate_done(ctx, c.tid)) {
-                    deferred.push_back(std::move(c));
-                    continue;
+                if (c.kind == Cmd::BAMEND && ctx) {
+                    // (asked without the queue's lock: pjb_bam_inflate_done takes the context's staging lock, which a worker
+                    // holds for the length of a pjb_bam_piece -- push() must not wait for that)
+                    lk.unlock();
+                    const bool inflated = pjb_bam_inflate_done(ctx, c.tid) != 0;
+                    lk.lock();
+                    if (!inflated) {
+                        deferred.push_back(std::move(c));
+                        continue;
+                    }
                 }
                 if (c.kind == Cmd::STOP && !deferred.empty()) { // (cannot happen: a worker waits for its BAMEND; keep the order anyway)
                     q.push_back(std::move(c));
