@@ -247,7 +247,8 @@ struct pjb_ctx {
     // scratch
     Buf *scan_tiles = nullptr; // run_scan's tile sums: the service buffer, or the slot's while a chain is being queued
     Buf b_scan_tiles;
-    Buf b_inf_comp, b_inf_out, b_inf_blocks, b_inf_status, b_inf_scratch; // device-side BGZF inflate
+    Buf b_inf_comp, b_inf_out, b_inf_blocks, b_inf_status, b_inf_scratch, b_inf_bitmap; // device-side BGZF inflate
+    bool inflate_v1 = false; // PJB_INFLATE_V1=1: round 2's one-kernel bgzf_inflate instead of bgzf_decode + bgzf_resolve
     Buf b_bam_seg, b_bam_rec, b_bam_ctl;                                  // device-side BAM record parse
     // --extra
     bool extra = false;
@@ -560,9 +561,11 @@ int pjb_create(pjb_ctx **out, const pjb_config *cfg) {
         (void)hipStreamCreateWithFlags(&S.main, hipStreamNonBlocking);
         (void)hipStreamCreateWithFlags(&S.side, hipStreamNonBlocking);
     }
-    c->inflate_lanes = std::max(1, n_cu) * (160 * 1024 / I2_LDS_BYTES) * 64;
+    if (const char *s = getenv("PJB_INFLATE_V1")) c->inflate_v1 = atoi(s) != 0;
+    const int inf_lds = c->inflate_v1 ? I2_LDS_BYTES : I3_LDS_BYTES;
+    c->inflate_lanes = std::max(1, n_cu) * (160 * 1024 / inf_lds) * 64;
     if (const char *s = getenv("PJB_INFLATE_WG_PER_CU")) // (experiments: fewer resident inflate workgroups leave LDS and a SIMD to the kernels beside them)
-        c->inflate_lanes = std::max(1, n_cu) * std::max(1, std::min(atoi(s), 160 * 1024 / I2_LDS_BYTES)) * 64;
+        c->inflate_lanes = std::max(1, n_cu) * std::max(1, std::min(atoi(s), 160 * 1024 / inf_lds)) * 64;
     c->ktime = (cfg->flags & PJB_FLAG_KERNEL_TIMING) != 0;
     c->extra = (cfg->flags & PJB_FLAG_EXTRA) != 0;
     if (const char *s = getenv("PJB_DENSE_IDS")) c->dense_ids = atoi(s) != 0;
@@ -572,7 +575,8 @@ int pjb_create(pjb_ctx **out, const pjb_config *cfg) {
         int v = atoi(s);
         if (v >= 4 && v <= RS_MAX_BITS) c->radix_max_bits = v;
     }
-    (void)hipFuncSetAttribute((const void *)bgzf_inflate, hipFuncAttributeMaxDynamicSharedMemorySize, I2_LDS_BYTES); // 80 KB
+    (void)hipFuncSetAttribute((const void *)bgzf_inflate, hipFuncAttributeMaxDynamicSharedMemorySize, I2_LDS_BYTES);
+    (void)hipFuncSetAttribute((const void *)bgzf_decode, hipFuncAttributeMaxDynamicSharedMemorySize, I3_LDS_BYTES);
     // 12-bit digits need more dynamic LDS than the 64 KB a kernel gets without asking
     (void)hipFuncSetAttribute((const void *)rs_scatter<0>, hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)rs_scatter_lds_bytes(RS_MAX_BITS));
@@ -622,7 +626,7 @@ void pjb_destroy(pjb_ctx *c) {
         if (c->stage[k]) (void)hipHostFree(c->stage[k]);
         if (c->stage_ev[k]) (void)hipEventDestroy(c->stage_ev[k]);
     }
-    Buf *all[] = {&c->b_cursor, &c->b_scan_tiles, &c->b_hasx, &c->b_xtotal, &c->b_fasta_raw, &c->b_inf_comp, &c->b_inf_out, &c->b_inf_blocks, &c->b_inf_status, &c->b_inf_scratch,
+    Buf *all[] = {&c->b_cursor, &c->b_scan_tiles, &c->b_hasx, &c->b_xtotal, &c->b_fasta_raw, &c->b_inf_comp, &c->b_inf_out, &c->b_inf_blocks, &c->b_inf_status, &c->b_inf_scratch, &c->b_inf_bitmap,
                   &c->b_bam_seg, &c->b_bam_rec, &c->b_bam_ctl, &c->f_pos, &c->f_cigoff, &c->f_cigar, &c->f_codes, &c->g_rows, &c->g_models, &c->g_refs,
                   &c->g_out, &c->g_bad,
                   &c->x_pos, &c->x_endx, &c->x_q, &c->x_prefq, &c->x_ce, &c->x_bound, &c->x_de, &c->x_dropped, &c->x_zlist, &c->x_cnt,
@@ -2070,8 +2074,18 @@ int inflate_on_device(pjb_ctx *c, const uint8_t *d_comp, const std::vector<InfBl
     iu32 *d_next = (iu32 *)(d_any + 1);
     const iu32 ctl[2] = {0u, (iu32)lanes};
     HIP_TRY(c, hipMemcpyAsync(d_any, ctl, 8, hipMemcpyHostToDevice, st));
-    LAUNCH_LDS(c, "bgzf_inflate", bgzf_inflate, dim3((unsigned)(lanes / 64)), dim3(64), I2_LDS_BYTES, d_comp, (const InfBlock *)c->b_inf_blocks.p, (iu32)nb,
-               d_out, (uint8_t *)c->b_inf_scratch.p, d_status, d_any, d_next, 8);
+    if (c->inflate_v1) {
+        LAUNCH_LDS(c, "bgzf_inflate", bgzf_inflate, dim3((unsigned)(lanes / 64)), dim3(64), I2_LDS_BYTES, d_comp, (const InfBlock *)c->b_inf_blocks.p, (iu32)nb,
+                   d_out, (uint8_t *)c->b_inf_scratch.p, d_status, d_any, d_next, 8);
+    } else {
+        // decode (lane per block: literals in place, a token + a bitmap bit per match), then the copies (wave per block)
+        if ((rc = ensure(c, c->b_inf_bitmap, nb * INF_BITMAP_WORDS * 8))) return rc;
+        HIP_TRY(c, hipMemsetAsync(c->b_inf_bitmap.p, 0, nb * INF_BITMAP_WORDS * 8, st));
+        LAUNCH_LDS(c, "bgzf_decode", bgzf_decode, dim3((unsigned)(lanes / 64)), dim3(64), I3_LDS_BYTES, d_comp, (const InfBlock *)c->b_inf_blocks.p, (iu32)nb,
+                   d_out, (uint8_t *)c->b_inf_scratch.p, d_status, d_any, d_next, (iu64 *)c->b_inf_bitmap.p, 8);
+        LAUNCH(c, "bgzf_resolve", bgzf_resolve, dim3((unsigned)((nb + 3) / 4)), dim3(256), (const InfBlock *)c->b_inf_blocks.p, (iu32)nb, d_out,
+               (const iu64 *)c->b_inf_bitmap.p, (const int *)d_status);
+    }
     HIP_TRY(c, hipStreamSynchronize(st));
     if (c->ktime) ev_collect(c, MISC_POOL);
     return inflate_status(c, blocks, d_status);
@@ -2091,7 +2105,7 @@ extern "C" int pjb_inflate_bgzf(pjb_ctx *c, const uint8_t *comp, int64_t comp_by
     if (total == 0) return PJB_OK;
     if (!out) return fail(c, PJB_ERR_ARG, "inflate_bgzf: no output buffer");
     if ((rc = ensure(c, c->b_inf_comp, (size_t)comp_bytes + INF_PAD))) return rc;
-    if ((rc = ensure(c, c->b_inf_out, (size_t)total + 16))) return rc;
+    if ((rc = ensure(c, c->b_inf_out, (size_t)total + 64))) return rc;
     HIP_TRY(c, hipMemcpyAsync(c->b_inf_comp.p, comp, (size_t)comp_bytes, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipMemsetAsync((uint8_t *)c->b_inf_comp.p + comp_bytes, 0, INF_PAD, c->stream));
     if ((rc = inflate_on_device(c, (const uint8_t *)c->b_inf_comp.p, blocks, (uint8_t *)c->b_inf_out.p))) return rc;
@@ -2318,7 +2332,7 @@ struct BamStage {
     // the inflate launched at the last piece (launched: ev_inf follows the kernel on its stream)
     bool launched = false;
     iu32 ctl[2] = {0, 0}; // { "some block failed", lanes }: copied to the device asynchronously, so it lives here and not on a stack
-    Buf out, d_blocks, d_status, d_scratch;
+    Buf out, d_blocks, d_status, d_scratch, d_bitmap;
     hipEvent_t ev_inf = nullptr, ev_last = nullptr;
 };
 
@@ -2345,6 +2359,7 @@ static void stage_release(pjb_ctx *c, BamStage &st) { // (after the work that us
     pool_give(c->misc_pool, st.d_blocks);
     pool_give(c->misc_pool, st.d_status);
     pool_give(c->misc_pool, st.d_scratch);
+    pool_give(c->out_pool, st.d_bitmap); // (output-sized: an eighth of the inflated bytes)
     if (st.ev_inf) (void)hipEventDestroy(st.ev_inf);
     if (st.ev_last) (void)hipEventDestroy(st.ev_last);
     st.ev_inf = st.ev_last = nullptr;
@@ -2358,7 +2373,8 @@ static void inflate_early(pjb_ctx *c, BamStage &st) {
     size_t lanes = std::min<size_t>((nb + 63) / 64 * 64, (size_t)c->inflate_lanes);
     if (const char *e = getenv("PJB_INF_BLOCKS_PER_LAUNCH")) lanes = std::min<size_t>((nb + 63) / 64 * 64, (size_t)std::max(64, atoi(e)) / 64 * 64);
     if (pool_take(c, c->out_pool, st.out, (size_t)st.total_out + 64) || pool_take(c, c->misc_pool, st.d_blocks, nb * sizeof(InfBlock)) ||
-        pool_take(c, c->misc_pool, st.d_status, nb * 4 + 16) || pool_take(c, c->misc_pool, st.d_scratch, lanes * INF_SCRATCH_PER_LANE)) {
+        pool_take(c, c->misc_pool, st.d_status, nb * 4 + 16) || pool_take(c, c->misc_pool, st.d_scratch, lanes * INF_SCRATCH_PER_LANE) ||
+        (!c->inflate_v1 && pool_take(c, c->out_pool, st.d_bitmap, nb * INF_BITMAP_WORDS * 8))) {
         std::lock_guard<std::mutex> lk(c->err_mu); // (a failure here just leaves the inflate to pjb_bam_end)
         c->err.clear();
         return;
@@ -2383,10 +2399,19 @@ static void inflate_early(pjb_ctx *c, BamStage &st) {
               hipMemsetAsync((uint8_t *)st.out.p + st.total_out, 0, 64, is) == hipSuccess &&
               hipMemcpyAsync(st.d_blocks.p, st.blocks.data(), nb * sizeof(InfBlock), hipMemcpyHostToDevice, is) == hipSuccess &&
               hipMemcpyAsync(d_any, st.ctl, 8, hipMemcpyHostToDevice, is) == hipSuccess;
-    if (ok) {
+    if (ok && c->inflate_v1) {
         hipLaunchKernelGGL(bgzf_inflate, dim3((unsigned)(lanes / 64)), dim3(64), I2_LDS_BYTES, is, (const uint8_t *)st.dev.p, (const InfBlock *)st.d_blocks.p,
                            (iu32)nb, (uint8_t *)st.out.p, (uint8_t *)st.d_scratch.p, d_status, d_any, d_next, 8);
         ok = hipGetLastError() == hipSuccess && hipEventRecord(st.ev_inf, is) == hipSuccess;
+    } else if (ok) {
+        ok = hipMemsetAsync(st.d_bitmap.p, 0, nb * INF_BITMAP_WORDS * 8, is) == hipSuccess;
+        if (ok) {
+            hipLaunchKernelGGL(bgzf_decode, dim3((unsigned)(lanes / 64)), dim3(64), I3_LDS_BYTES, is, (const uint8_t *)st.dev.p, (const InfBlock *)st.d_blocks.p,
+                               (iu32)nb, (uint8_t *)st.out.p, (uint8_t *)st.d_scratch.p, d_status, d_any, d_next, (iu64 *)st.d_bitmap.p, 8);
+            hipLaunchKernelGGL(bgzf_resolve, dim3((unsigned)((nb + 3) / 4)), dim3(256), 0, is, (const InfBlock *)st.d_blocks.p, (iu32)nb, (uint8_t *)st.out.p,
+                               (const iu64 *)st.d_bitmap.p, (const int *)d_status);
+            ok = hipGetLastError() == hipSuccess && hipEventRecord(st.ev_inf, is) == hipSuccess;
+        }
     }
     if (!ok) { // whatever was queued must be over before the buffers are used again
         (void)hipStreamSynchronize(is);

@@ -53,6 +53,11 @@ __device__ __forceinline__ iu64 load64u(const uint8_t *p) {
     return v;
 }
 __device__ __forceinline__ void store64u(uint8_t *p, iu64 v) { __builtin_memcpy(p, &v, 8); }
+__device__ __forceinline__ iu32 load32u(const uint8_t *p) {
+    iu32 v;
+    __builtin_memcpy(&v, p, 4);
+    return v;
+}
 // the low n (0..8) bytes of v in at most three stores (4 + 2 + 1) instead of n byte stores
 __device__ __forceinline__ void store_low(uint8_t *p, iu64 v, iu32 n) {
     if (n >= 8) {
@@ -643,6 +648,469 @@ __global__ __launch_bounds__(64) void bgzf_inflate(const uint8_t *comp, const In
             L.w(I2_Q + 4 * qn + 2) = dist;
             qn++;
             pos += len;
+        }
+    }
+}
+
+// =================================================================================================
+// Round 3: the inflate in two kernels.
+//
+// What bounded bgzf_inflate above (SQ counters, profiles/r02f_inflate_sq_counters.txt): a lane-block moved 64 KB through
+// ~185 000 single-lane memory transactions -- one byte store per literal, 4 + 2 + 1-byte pieces per copy step, the
+// loads of every copy -- and a CU retires those at about one per cycle: ~40 % of the kernel, all of it inside "memory
+// phases" in which the whole wave stood still (50 % of wave cycles waiting).  LZ77 copies are exactly the part of
+// DEFLATE that is NOT serial per block, so they leave the lane-per-block kernel:
+//
+//   bgzf_decode   lane per BGZF block, as before, but the lane only DECODES: literals go to their final place, a
+//                 length/distance pair leaves a 3-byte token (length - 3, distance - 1) in the first bytes of the gap
+//                 it will fill (a match is at least 3 bytes long, so the token always fits and needs no memory of its
+//                 own) and one bit in a per-block bitmap of match starts (8 KB per block, a 64-bit word kept in a
+//                 register and stored when the position leaves it).  No match queue (LDS per lane 612 -> 484 bytes:
+//                 five workgroups per CU), no loads but the input refill, nothing that depends on what a copy yields.
+//   bgzf_resolve  wave per BGZF block, no LDS (so it runs beside resident decode workgroups): walks the bitmap 1024
+//                 positions at a time, deals the matches out 64 at a time in output order (lane = match), and copies
+//                 in rounds: a match is ready when its source lies before the first unfinished match of the batch
+//                 (everything before that is final: literals were in place, earlier matches are done); ready matches
+//                 copy side by side in 16-byte steps, overlapping ones (distance < length) as periodic patterns read
+//                 from their final first period only.  The first unfinished match is always ready, so a batch takes
+//                 at most 64 rounds, typically 2-5.
+// Both kernels keep the block status words of bgzf_inflate; resolve skips blocks that failed.
+// =================================================================================================
+constexpr iu32 I3_RING = I2_DLONG + 16;
+constexpr iu32 I3_LANE_U16 = I3_RING + 32; // no match queue
+constexpr int I3_LDS_BYTES = (int)I3_LANE_U16 * 2 * 64 + 256;
+constexpr size_t INF_BITMAP_WORDS = 1024; // u64 words per block: one bit per output byte
+static_assert(I3_LANE_U16 % 2 == 0 && I3_RING % 2 == 0, "word-aligned LDS areas");
+static_assert(5 * I3_LDS_BYTES <= 160 * 1024, "five workgroups per CU");
+static_assert(I3_RING == I2_RING, "inf2_build's scratch is the ring");
+
+__global__ __launch_bounds__(64) void bgzf_decode(const uint8_t *comp, const InfBlock *blocks, iu32 n_blocks, uint8_t *out, uint8_t *scratch,
+                                                    int *status, int *any_error, iu32 *next_block, iu64 *bitmap, int inf_refill) {
+    extern __shared__ __attribute__((aligned(16))) unsigned short inf_lds[];
+    iu32 *s_len = (iu32 *)(inf_lds + (size_t)I3_LANE_U16 * 64); // base | extra bits << 16
+    iu32 *s_dist = s_len + 32;
+    if (threadIdx.x < 29) s_len[threadIdx.x] = (iu32)c_len_base[threadIdx.x] | ((iu32)c_len_extra[threadIdx.x] << 16);
+    if (threadIdx.x < 30) s_dist[threadIdx.x] = (iu32)c_dist_base[threadIdx.x] | ((iu32)c_dist_extra[threadIdx.x] << 16);
+    __syncthreads();
+    iu32 b = blockIdx.x * 64 + threadIdx.x;
+    bool have = b < n_blocks;
+    Lane2 L;
+    L.p = inf_lds + threadIdx.x * 2;
+    uint8_t *lens = scratch + (size_t)(blockIdx.x * 64 + threadIdx.x) * INF_SCRATCH_PER_LANE;
+    InfBlock B;
+    B.in_off = B.out_off = 0;
+    B.in_len = B.out_len = 0;
+    if (have) B = blocks[b];
+    const uint8_t *in0 = comp + B.in_off, *in_end = in0 + B.in_len;
+    uint8_t *base = out + B.out_off;
+    iu64 *bm = bitmap + (size_t)(have ? b : 0) * INF_BITMAP_WORDS;
+    iu32 out_len = B.out_len;
+    bool more = true;
+    enum { ST_HEADER, ST_SYMBOLS, ST_DONE };
+    int state = have ? ST_HEADER : ST_DONE;
+    int err = 0;
+    bool last = false;
+    iu64 bitpos = 0;
+    iu32 pos = 0;
+    iu64 bmw = 0;          // match-start bits of the bitmap word the position is in
+    iu32 bmi = 0xffffffffu; // index of that word (none yet)
+    Ring2 R;
+    R.ri = R.rf = 0;
+    R.gp = in0;
+    R.bb = 0;
+    R.nb = 0;
+    Lim limL, limD;
+#pragma unroll
+    for (int k = 0; k < 16; k++) limL.v[k] = limD.v[k] = 0;
+
+    // all lanes: top up the input rings (one round trip)
+    auto refill_phase = [&]() {
+        if (state == ST_SYMBOLS && R.gp > in_end + 128) { // (see bgzf_inflate: no lane reads more than 256 bytes past its payload)
+            err = INF_ERR_OVERRUN;
+            state = ST_DONE;
+        }
+        const iu32 pairs = state == ST_SYMBOLS ? (16 - R.rf) >> 1 : 0;
+        iu64 v[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) v[k] = load64u(R.gp + 8 * k); // unconditional: the buffer is padded
+        wait_vm();
+        const iu32 wi = (R.ri + R.rf) & 15u;
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+            if ((iu32)k < pairs) {
+                L.w(I3_RING + 2 * ((wi + 2 * k) & 15u)) = (iu32)v[k];
+                L.w(I3_RING + 2 * ((wi + 2 * k + 1) & 15u)) = (iu32)(v[k] >> 32);
+            }
+        R.rf += 2 * pairs;
+        R.gp += 8 * pairs;
+    };
+
+    for (;;) {
+        if ((int)__popcll(__ballot(state == ST_DONE && more)) >= (__any(state != ST_DONE) ? inf_refill : 1)) {
+            const bool fin = state == ST_DONE && more;
+            if (fin && have) {
+                if (bmi != 0xffffffffu) bm[bmi] = bmw;
+                if (!err && pos != out_len) err = INF_ERR_SIZE;
+                status[b] = err;
+                if (err) atomicOr(any_error, 1);
+            }
+            const iu64 fm = __ballot(fin);
+            iu32 first_new = 0;
+            const int leader = __ffsll((long long)fm) - 1;
+            if ((int)threadIdx.x == leader) first_new = atomicAdd(next_block, (iu32)__popcll(fm));
+            first_new = __shfl(first_new, leader, 64);
+            if (fin) {
+                b = first_new + (iu32)__popcll(fm & ((1ull << threadIdx.x) - 1ull));
+                have = b < n_blocks;
+                more = have;
+                if (have) {
+                    B = blocks[b];
+                    in0 = comp + B.in_off;
+                    in_end = in0 + B.in_len;
+                    base = out + B.out_off;
+                    bm = bitmap + (size_t)b * INF_BITMAP_WORDS;
+                    out_len = B.out_len;
+                    err = 0;
+                    last = false;
+                    bitpos = 0;
+                    pos = 0;
+                    bmw = 0;
+                    bmi = 0xffffffffu;
+                    R.ri = R.rf = 0;
+                    R.gp = in0;
+                    R.bb = 0;
+                    R.nb = 0;
+                    state = ST_HEADER;
+                }
+            }
+        }
+        if (!__any(state != ST_DONE)) break;
+        if (state == ST_HEADER) {
+            // ---- block header and tables, read straight from the stream (as in bgzf_inflate)
+            BitReader br;
+            br.start(in0 + (bitpos >> 3));
+            br.refill();
+            br.drop((int)(bitpos & 7));
+            iu64 used = bitpos & 7;
+            auto take = [&](int n) -> iu32 {
+                br.refill();
+                used += (iu64)n;
+                return br.take(n);
+            };
+            last = take(1);
+            const iu32 type = take(2);
+            if (type == 0) { // stored
+                const int pad = (int)((8 - ((bitpos + 3) & 7)) & 7);
+                (void)take(pad);
+                const iu32 len = take(16), nlen = take(16);
+                const uint8_t *src = in0 + ((bitpos + 3 + (iu64)pad + 32) >> 3);
+                if ((len ^ 0xffffu) != nlen) err = INF_ERR_STORED;
+                else if (src + len > in_end || pos + len > out_len) err = INF_ERR_OVERRUN;
+                else {
+                    for (iu32 i = 0; i < len; i++) base[pos + i] = src[i];
+                    pos += len;
+                    bitpos = (iu64)(src + len - in0) * 8;
+                }
+                if (err || last) state = ST_DONE;
+            } else if (type == 3) {
+                err = INF_ERR_BTYPE;
+                state = ST_DONE;
+            } else {
+                int nlit = 288, ndist = 32;
+                if (type == 1) {
+                    for (int i = 0; i < 144; i++) lens[i] = 8;
+                    for (int i = 144; i < 256; i++) lens[i] = 9;
+                    for (int i = 256; i < 280; i++) lens[i] = 7;
+                    for (int i = 280; i < 288; i++) lens[i] = 8;
+                    for (int i = 288; i < 320; i++) lens[i] = 5;
+                } else {
+                    nlit = (int)take(5) + 257;
+                    ndist = (int)take(5) + 1;
+                    const int ncl = (int)take(4) + 4;
+                    if (nlit > 286 || ndist > 30) err = INF_ERR_CODELENS;
+                    if (!err) {
+                        for (int i = 0; i < 19; i++) lens[i] = 0;
+                        for (int i = 0; i < ncl; i++) lens[c_clen_order[i]] = (uint8_t)take(3);
+                        err = inf2_build(L, limL, I2_LADJ, I2_LLONG, 0, lens, 19, true);
+                    }
+                    int i = 0;
+                    while (!err && i < nlit + ndist) {
+                        br.refill();
+                        const iu32 e = inf2_decode<false>(L, limL, I2_LADJ, I2_LLONG, 0, (iu32)br.bb);
+                        if (e == 0) {
+                            err = INF_ERR_CODELENS;
+                            break;
+                        }
+                        br.drop((int)(e & 15u));
+                        used += e & 15u;
+                        const iu32 sym = e >> 4;
+                        if (sym < 16) {
+                            lens[i++] = (uint8_t)sym;
+                        } else {
+                            iu32 rep, val = 0;
+                            if (sym == 16) {
+                                if (i == 0) {
+                                    err = INF_ERR_CODELENS;
+                                    break;
+                                }
+                                val = lens[i - 1];
+                                rep = 3 + take(2);
+                            } else if (sym == 17) {
+                                rep = 3 + take(3);
+                            } else {
+                                rep = 11 + take(7);
+                            }
+                            if (i + (int)rep > nlit + ndist) {
+                                err = INF_ERR_CODELENS;
+                                break;
+                            }
+                            while (rep--) lens[i++] = (uint8_t)val;
+                        }
+                    }
+                    if (!err && lens[256] == 0) err = INF_ERR_CODELENS;
+                }
+                if (!err) err = inf2_build(L, limD, I2_DADJ, I2_DLONG, 0, lens + nlit, ndist);
+                if (!err) err = inf2_build(L, limL, I2_LADJ, I2_LLONG, I2_LLONG_HI, lens, nlit);
+                if (err) {
+                    state = ST_DONE;
+                } else {
+                    const iu64 sp = (bitpos & ~7ull) + used;
+                    R.gp = in0 + (sp >> 3);
+#pragma unroll
+                    for (int k = 0; k < 8; k++) {
+                        const iu64 v = load64u(R.gp + 8 * k);
+                        L.w(I3_RING + 4 * k) = (iu32)v;
+                        L.w(I3_RING + 4 * k + 2) = (iu32)(v >> 32);
+                    }
+                    R.gp += 64;
+                    R.bb = (iu64)L.w(I3_RING) | ((iu64)L.w(I3_RING + 2) << 32);
+                    R.ri = 2;
+                    R.rf = 14;
+                    R.nb = 64 - (int)(sp & 7);
+                    R.bb >>= (sp & 7);
+                    state = ST_SYMBOLS;
+                }
+            }
+        }
+        wait_vm();
+        // ---- symbols
+        for (;;) {
+            const bool sym_on = state == ST_SYMBOLS;
+            if (!__any(sym_on)) break;
+            if (__any(sym_on && R.rf < I2_LITS + 3)) refill_phase(); // an iteration takes at most I2_LITS + 2 words
+            if (state != ST_SYMBOLS) continue;
+            iu32 e = 0, sym = 0;
+            bool bad = false;
+#pragma unroll
+            for (int rep = 0; rep < I2_LITS; rep++) {
+                if (sym >= 256 || bad) break;
+                if (R.nb <= 32) {
+                    R.bb |= (iu64)L.w(I3_RING + 2 * R.ri) << R.nb;
+                    R.ri = (R.ri + 1) & 15u;
+                    R.rf--;
+                    R.nb += 32;
+                }
+                e = inf2_decode<true>(L, limL, I2_LADJ, I2_LLONG, I2_LLONG_HI, (iu32)R.bb);
+                if (e == 0) {
+                    err = INF_ERR_CODE;
+                    bad = true;
+                    break;
+                }
+                R.bb >>= (e & 15u);
+                R.nb -= (int)(e & 15u);
+                sym = e >> 4;
+                if (sym < 256) {
+                    if (pos >= out_len) {
+                        err = INF_ERR_OVERRUN;
+                        bad = true;
+                        break;
+                    }
+                    base[pos++] = (uint8_t)sym;
+                }
+            }
+            if (bad) {
+                state = ST_DONE;
+                continue;
+            }
+            if (sym < 256) continue;
+            if (sym == 256) {
+                const iu64 consumed = (iu64)(R.gp - in0) * 8 - 32ull * R.rf - (iu64)R.nb;
+                if (consumed > (iu64)B.in_len * 8) {
+                    err = INF_ERR_OVERRUN;
+                    state = ST_DONE;
+                    continue;
+                }
+                bitpos = consumed;
+                state = last ? ST_DONE : ST_HEADER;
+                continue;
+            }
+            sym -= 257;
+            if (sym >= 29) {
+                err = INF_ERR_CODE;
+                state = ST_DONE;
+                continue;
+            }
+            const iu32 lt = s_len[sym];
+            const int xl = (int)(lt >> 16);
+            const iu32 len = (lt & 0xffffu) + ((iu32)R.bb & ((1u << xl) - 1u));
+            R.bb >>= xl;
+            R.nb -= xl;
+            if (R.nb <= 32) {
+                R.bb |= (iu64)L.w(I3_RING + 2 * R.ri) << R.nb;
+                R.ri = (R.ri + 1) & 15u;
+                R.rf--;
+                R.nb += 32;
+            }
+            e = inf2_decode<false>(L, limD, I2_DADJ, I2_DLONG, 0, (iu32)R.bb);
+            if (e == 0 || (e >> 4) >= 30) {
+                err = INF_ERR_CODE;
+                state = ST_DONE;
+                continue;
+            }
+            R.bb >>= (e & 15u);
+            R.nb -= (int)(e & 15u);
+            const iu32 ds = e >> 4;
+            const iu32 dt = s_dist[ds];
+            const int xd = (int)(dt >> 16);
+            const iu32 dist = (dt & 0xffffu) + ((iu32)R.bb & ((1u << xd) - 1u));
+            R.bb >>= xd;
+            R.nb -= xd;
+            if (dist > pos) {
+                err = INF_ERR_DIST;
+                state = ST_DONE;
+                continue;
+            }
+            if (pos + len > out_len) {
+                err = INF_ERR_OVERRUN;
+                state = ST_DONE;
+                continue;
+            }
+            // the match's token in the first three bytes of its own gap, its start in the bitmap
+            {
+                const iu32 tok = (len - 3u) | ((dist - 1u) << 8);
+                const unsigned short lo = (unsigned short)tok;
+                __builtin_memcpy(base + pos, &lo, 2);
+                base[pos + 2] = (uint8_t)(tok >> 16);
+                const iu32 w = pos >> 6;
+                if (w != bmi) {
+                    if (bmi != 0xffffffffu) bm[bmi] = bmw;
+                    bmi = w;
+                    bmw = 0;
+                }
+                bmw |= 1ull << (pos & 63u);
+            }
+            pos += len;
+        }
+    }
+}
+
+// 16 bytes at any address as two 8-byte words
+struct U128 {
+    iu64 lo, hi;
+};
+__device__ __forceinline__ U128 load128u(const uint8_t *p) {
+    U128 v;
+    __builtin_memcpy(&v, p, 16);
+    return v;
+}
+__device__ __forceinline__ void store128u(uint8_t *p, U128 v) { __builtin_memcpy(p, &v, 16); }
+
+__global__ __launch_bounds__(256) void bgzf_resolve(const InfBlock *blocks, iu32 n_blocks, uint8_t *out, const iu64 *bitmap, const int *status) {
+    const iu32 lane = threadIdx.x & 63u;
+    const iu32 b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= n_blocks) return; // (whole waves leave; the kernel has no barrier)
+    if (status[b] != 0) return;
+    const InfBlock B = blocks[b];
+    uint8_t *base = out + B.out_off;
+    const iu64 *bm = bitmap + (size_t)b * INF_BITMAP_WORDS;
+    const iu32 n_words = (B.out_len + 63u) >> 6;
+    for (iu32 w0 = 0; w0 < n_words; w0 += 16) { // 1024 output positions per round, 16 per lane
+        const iu32 wi = w0 + (lane >> 2);
+        const iu64 word = wi < n_words ? bm[wi] : 0ull;
+        const iu32 bits = (iu32)(word >> (16u * (lane & 3u))) & 0xffffu;
+        const iu32 cnt = (iu32)__popc(bits);
+        iu32 inc = cnt; // inclusive scan over the wave
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const iu32 t = __shfl_up(inc, d, 64);
+            if ((int)lane >= d) inc += t;
+        }
+        const iu32 pre = inc - cnt;
+        const iu32 T = __shfl(inc, 63, 64);
+        for (iu32 m0 = 0; m0 < T; m0 += 64) { // 64 matches in output order, lane = match
+            const iu32 m = m0 + lane;
+            const bool have = m < T;
+            // the lane whose 16 positions hold match m: the last one with pre <= m
+            iu32 s = 0;
+#pragma unroll
+            for (int step = 32; step >= 1; step >>= 1) {
+                const iu32 t = s + (iu32)step;
+                const iu32 p = __shfl(pre, (int)(t & 63u), 64);
+                if (t < 64u && p <= m) s = t;
+            }
+            const iu32 k = m - __shfl(pre, (int)s, 64);
+            iu32 bs = __shfl(bits, (int)s, 64);
+#pragma unroll
+            for (int i = 0; i < 5; i++) // (16 positions hold at most 6 match starts: a match is 3 bytes or longer)
+                if ((iu32)i < k) bs &= bs - 1u;
+            const iu32 p = (w0 + (s >> 2)) * 64u + 16u * (s & 3u) + (have && bs ? (iu32)__ffs((int)bs) - 1u : 0u);
+            iu32 len = 0, dist = 1;
+            if (have) {
+                const iu32 tok = load32u(base + p) & 0x7fffffu; // (a byte past the token is read: the buffer is padded)
+                len = (tok & 0xffu) + 3u;
+                dist = (tok >> 8) + 1u;
+            }
+            const iu32 src = p - dist;
+            const iu32 need = len < dist ? len : dist; // source bytes that must be final
+            bool done = !have || dist > p || p + len > B.out_len; // (bgzf_decode has checked both for every token it wrote)
+            for (int round = 0; round < 64; round++) {                // (the first unfinished match is always ready: at most 64 rounds)
+                const iu64 nd = __ballot(!done);
+                if (!nd) break;
+                const int f = __ffsll((long long)nd) - 1;
+                const iu32 hwm = __shfl(p, f, 64); // everything before the first unfinished match is final
+                const bool ready = !done && src + need <= hwm;
+                if (ready) {
+                    uint8_t *d = base + p;
+                    const uint8_t *sp = base + src;
+                    if (dist >= len) { // no overlap: 16 bytes a step
+                        iu32 i = 0;
+                        for (; i + 16 <= len; i += 16) store128u(d + i, load128u(sp + i));
+                        if (i < len) {
+                            const U128 v = load128u(sp + i);
+                            const iu32 r = len - i;
+                            if (r >= 8) {
+                                store64u(d + i, v.lo);
+                                store_low(d + i + 8, v.hi, r - 8);
+                            } else
+                                store_low(d + i, v.lo, r);
+                        }
+                    } else if (dist < 8) { // short period: out of registers
+                        const iu64 pmask = (1ull << (8 * dist)) - 1ull;
+                        const iu64 per = load64u(sp) & pmask;
+                        iu32 ph = 0;
+                        for (iu32 i = 0; i < len; i += 8) {
+                            iu64 y = ph ? ((per >> (8 * ph)) | (per << (8 * (dist - ph)))) & pmask : per; // rotated period
+                            for (iu32 sh = 8 * dist; sh < 64; sh <<= 1) y |= y << sh;
+                            store_low(d + i, y, len - i);
+                            ph = (ph + 8) % dist;
+                        }
+                    } else { // 8 <= distance < length: chunk i is the period from offset i mod distance on, wrapping once at most
+                        iu32 o = 0;
+                        for (iu32 i = 0; i < len; i += 8) {
+                            iu64 y = load64u(sp + o);
+                            if (o + 8 > dist) {
+                                const iu32 kk = dist - o; // 1..7 bytes before the wrap
+                                y = (y & ((1ull << (8 * kk)) - 1ull)) | (load64u(sp) << (8 * kk));
+                            }
+                            store_low(d + i, y, len - i);
+                            o += 8;
+                            if (o >= dist) o -= dist;
+                        }
+                    }
+                    done = true;
+                }
+                wait_vm(); // this round's stores are visible to the next round's (and the next batch's) loads
+            }
         }
     }
 }
