@@ -684,6 +684,17 @@ static_assert(I3_LANE_U16 % 2 == 0 && I3_RING % 2 == 0, "word-aligned LDS areas"
 static_assert(5 * I3_LDS_BYTES <= 160 * 1024, "five workgroups per CU");
 static_assert(I3_RING == I2_RING, "inf2_build's scratch is the ring");
 
+// 16 bytes at any address as two 8-byte words
+struct U128 {
+    iu64 lo, hi;
+};
+__device__ __forceinline__ U128 load128u(const uint8_t *p) {
+    U128 v;
+    __builtin_memcpy(&v, p, 16);
+    return v;
+}
+__device__ __forceinline__ void store128u(uint8_t *p, U128 v) { __builtin_memcpy(p, &v, 16); }
+
 __global__ __launch_bounds__(64) void bgzf_decode(const uint8_t *comp, const InfBlock *blocks, iu32 n_blocks, uint8_t *out, uint8_t *scratch,
                                                     int *status, int *any_error, iu32 *next_block, iu64 *bitmap, int inf_refill) {
     extern __shared__ __attribute__((aligned(16))) unsigned short inf_lds[];
@@ -723,27 +734,38 @@ __global__ __launch_bounds__(64) void bgzf_decode(const uint8_t *comp, const Inf
 #pragma unroll
     for (int k = 0; k < 16; k++) limL.v[k] = limD.v[k] = 0;
 
-    // all lanes: top up the input rings (one round trip)
-    auto refill_phase = [&]() {
+    // The input rings are topped up WITHOUT standing still: when some lane's ring is getting low every lane issues the
+    // loads of its next 32 input bytes (two 16-byte loads) and goes on decoding; the words are moved into the rings at
+    // the top of the next iteration, by which time they have arrived.  A lane takes as many of its 8 words as its ring
+    // has room for (the next fetch starts behind them).  Invariant: after the top of an iteration every lane holds at
+    // least 5 words (one iteration uses at most 4): a lane below I3_LOW words has a fetch on its way that brings it
+    // to 8 or more.
+    U128 pf0, pf1;
+    pf0.lo = pf0.hi = pf1.lo = pf1.hi = 0;
+    bool pending = false; // (wave-uniform)
+    auto refill_issue = [&]() {
+        pf0 = load128u(R.gp); // unconditional: the buffer is padded
+        pf1 = load128u(R.gp + 16);
+        pending = true;
+    };
+    auto refill_commit = [&]() {
+        wait_vm();
+        pending = false;
         if (state == ST_SYMBOLS && R.gp > in_end + 128) { // (see bgzf_inflate: no lane reads more than 256 bytes past its payload)
             err = INF_ERR_OVERRUN;
             state = ST_DONE;
         }
-        const iu32 pairs = state == ST_SYMBOLS ? (16 - R.rf) >> 1 : 0;
-        iu64 v[8];
-#pragma unroll
-        for (int k = 0; k < 8; k++) v[k] = load64u(R.gp + 8 * k); // unconditional: the buffer is padded
-        wait_vm();
-        const iu32 wi = (R.ri + R.rf) & 15u;
+        const iu32 take = state == ST_SYMBOLS ? (16u - R.rf < 8u ? 16u - R.rf : 8u) : 0u;
+        const iu32 wi = R.ri + R.rf;
+        const iu32 w[8] = {(iu32)pf0.lo, (iu32)(pf0.lo >> 32), (iu32)pf0.hi, (iu32)(pf0.hi >> 32),
+                           (iu32)pf1.lo, (iu32)(pf1.lo >> 32), (iu32)pf1.hi, (iu32)(pf1.hi >> 32)};
 #pragma unroll
         for (int k = 0; k < 8; k++)
-            if ((iu32)k < pairs) {
-                L.w(I3_RING + 2 * ((wi + 2 * k) & 15u)) = (iu32)v[k];
-                L.w(I3_RING + 2 * ((wi + 2 * k + 1) & 15u)) = (iu32)(v[k] >> 32);
-            }
-        R.rf += 2 * pairs;
-        R.gp += 8 * pairs;
+            if ((iu32)k < take) L.w(I3_RING + 2 * ((wi + k) & 15u)) = w[k];
+        R.rf += take;
+        R.gp += 4 * take;
     };
+    constexpr iu32 I3_LOW = 10; // a ring below this many words asks for more (an iteration uses at most 4, usually 1 or 2)
 
     for (;;) {
         if ((int)__popcll(__ballot(state == ST_DONE && more)) >= (__any(state != ST_DONE) ? inf_refill : 1)) {
@@ -893,127 +915,158 @@ __global__ __launch_bounds__(64) void bgzf_decode(const uint8_t *comp, const Inf
             }
         }
         wait_vm();
+        pending = false; // (a fetch issued before the last lane left the symbols is dropped: lanes re-enter with primed rings)
         // ---- symbols
         for (;;) {
             const bool sym_on = state == ST_SYMBOLS;
             if (!__any(sym_on)) break;
-            if (__any(sym_on && R.rf < I2_LITS + 3)) refill_phase(); // an iteration takes at most I2_LITS + 2 words
-            if (state != ST_SYMBOLS) continue;
-            iu32 e = 0, sym = 0;
-            bool bad = false;
-#pragma unroll
-            for (int rep = 0; rep < I2_LITS; rep++) {
-                if (sym >= 256 || bad) break;
+            if (pending) refill_commit();
+            if (__any(state == ST_SYMBOLS && R.rf < I3_LOW)) refill_issue();
+            // Invariant at this point: a lane in ST_SYMBOLS holds more than 32 bits in its bit buffer and at least 5 words in
+            // its ring.  The next ring word is fetched ahead, so that topping the buffer up never waits for LDS.
+            iu32 nw = L.w(I3_RING + 2 * R.ri);
+            auto topup = [&]() { // more than 32 bits again (twice only after an iteration that used all of them)
                 if (R.nb <= 32) {
-                    R.bb |= (iu64)L.w(I3_RING + 2 * R.ri) << R.nb;
+                    R.bb |= (iu64)nw << R.nb;
+                    R.nb += 32;
                     R.ri = (R.ri + 1) & 15u;
                     R.rf--;
-                    R.nb += 32;
+                    nw = L.w(I3_RING + 2 * R.ri);
                 }
-                e = inf2_decode<true>(L, limL, I2_LADJ, I2_LLONG, I2_LLONG_HI, (iu32)R.bb);
-                if (e == 0) {
+            };
+            if (state == ST_SYMBOLS) {
+                // ---- up to three literal/length codes at once.  The code LENGTHS come out of registers alone (limits per
+                // length), so the three bit positions are known before anything is looked up; the lookups -- slot adjustment,
+                // then symbol byte and ninth bit -- of all three then travel together: two LDS round trips for three
+                // symbols instead of six.  Symbols after a length code or past the valid bits are thrown away.
+                const iu32 b1 = (iu32)R.bb;
+                const iu32 v1 = __brev(b1) >> 17;
+                iu32 len1 = 1;
+#pragma unroll
+                for (int l = 1; l <= 15; l++) len1 += v1 >= limL.v[l] ? 1u : 0u;
+                const iu32 b2 = (iu32)(R.bb >> (len1 & 31u));
+                const iu32 v2 = __brev(b2) >> 17;
+                iu32 len2 = 1;
+#pragma unroll
+                for (int l = 1; l <= 15; l++) len2 += v2 >= limL.v[l] ? 1u : 0u;
+                const iu32 b3 = (iu32)(R.bb >> ((len1 + len2) & 63u));
+                const iu32 v3 = __brev(b3) >> 17;
+                iu32 len3 = 1;
+#pragma unroll
+                for (int l = 1; l <= 15; l++) len3 += v3 >= limL.v[l] ? 1u : 0u;
+                const iu32 a1 = L.h(I2_LADJ + (len1 & 15u)), a2 = L.h(I2_LADJ + (len2 & 15u)), a3 = L.h(I2_LADJ + (len3 & 15u));
+                const iu32 i1 = ((v1 >> ((15u - len1) & 15u)) + a1) & 0x1ffu, i2 = ((v2 >> ((15u - len2) & 15u)) + a2) & 0x1ffu,
+                           i3 = ((v3 >> ((15u - len3) & 15u)) + a3) & 0x1ffu;
+                const iu32 y1 = L.h(I2_LLONG + (i1 >> 1)), y2 = L.h(I2_LLONG + (i2 >> 1)), y3 = L.h(I2_LLONG + (i3 >> 1));
+                const iu32 h1 = L.h(I2_LLONG_HI + (i1 >> 4)), h2 = L.h(I2_LLONG_HI + (i2 >> 4)), h3 = L.h(I2_LLONG_HI + (i3 >> 4));
+                const iu32 s1 = ((y1 >> ((i1 & 1u) * 8u)) & 0xffu) | (((h1 >> (i1 & 15u)) & 1u) << 8);
+                const iu32 s2 = ((y2 >> ((i2 & 1u) * 8u)) & 0xffu) | (((h2 >> (i2 & 15u)) & 1u) << 8);
+                const iu32 s3 = ((y3 >> ((i3 & 1u) * 8u)) & 0xffu) | (((h3 >> (i3 & 15u)) & 1u) << 8);
+                const iu32 c1 = len1, c2 = len1 + len2, c3 = c2 + len3; // (c2 <= 30 < the bits held)
+                const bool lit1 = len1 <= 15u && s1 < 256u;
+                const bool take2 = lit1, lit2 = take2 && len2 <= 15u && s2 < 256u;
+                const bool take3 = lit2 && c3 <= (iu32)R.nb, lit3 = take3 && len3 <= 15u && s3 < 256u;
+                const bool bad_code = len1 > 15u || (take2 && len2 > 15u) || (take3 && len3 > 15u);
+                const iu32 nlit = (iu32)lit1 + (iu32)lit2 + (iu32)lit3;
+                // the symbol that ends the run of literals (if one was decoded), and the bits used
+                iu32 sym = 0, used = 0;
+                if (!lit1) {
+                    sym = s1;
+                    used = c1;
+                } else if (!lit2) {
+                    sym = s2;
+                    used = c2;
+                } else if (take3 && !lit3) {
+                    sym = s3;
+                    used = c3;
+                } else
+                    used = take3 ? c3 : c2;
+                if (bad_code) {
                     err = INF_ERR_CODE;
-                    bad = true;
-                    break;
-                }
-                R.bb >>= (e & 15u);
-                R.nb -= (int)(e & 15u);
-                sym = e >> 4;
-                if (sym < 256) {
-                    if (pos >= out_len) {
-                        err = INF_ERR_OVERRUN;
-                        bad = true;
-                        break;
-                    }
-                    base[pos++] = (uint8_t)sym;
-                }
-            }
-            if (bad) {
-                state = ST_DONE;
-                continue;
-            }
-            if (sym < 256) continue;
-            if (sym == 256) {
-                const iu64 consumed = (iu64)(R.gp - in0) * 8 - 32ull * R.rf - (iu64)R.nb;
-                if (consumed > (iu64)B.in_len * 8) {
+                    state = ST_DONE;
+                } else if (pos + nlit > out_len) {
                     err = INF_ERR_OVERRUN;
                     state = ST_DONE;
-                    continue;
+                } else {
+                    if (lit1) base[pos] = (uint8_t)s1;
+                    if (lit2) base[pos + 1] = (uint8_t)s2;
+                    if (lit3) base[pos + 2] = (uint8_t)s3;
+                    pos += nlit;
+                    R.bb >>= used;
+                    R.nb -= (int)used;
+                    topup();
+                    topup();
+                    if (sym == 256u) { // end of block: where the next header starts
+                        const iu64 consumed = (iu64)(R.gp - in0) * 8 - 32ull * R.rf - (iu64)R.nb;
+                        if (consumed > (iu64)B.in_len * 8) {
+                            err = INF_ERR_OVERRUN;
+                            state = ST_DONE;
+                        } else {
+                            bitpos = consumed;
+                            state = last ? ST_DONE : ST_HEADER;
+                        }
+                    } else if (sym > 256u) {
+                        // ---- length / distance pair: 5 + 15 + 13 bits at most, all in the buffer; the base / extra-bit tables
+                        // of RFC 1951 3.2.5 in closed form (no lookups)
+                        const iu32 ls = sym - 257u;
+                        const iu32 xl = ls < 8u || ls >= 28u ? 0u : (ls >> 2) - 1u;
+                        const iu32 lbase = ls < 8u ? ls + 3u : ls >= 28u ? 258u : ((4u + (ls & 3u)) << xl) + 3u;
+                        const iu32 len = lbase + ((iu32)R.bb & ((1u << xl) - 1u));
+                        R.bb >>= xl;
+                        R.nb -= (int)xl;
+                        const iu32 vd = __brev((iu32)R.bb) >> 17;
+                        iu32 dl = 1;
+#pragma unroll
+                        for (int l = 1; l <= 15; l++) dl += vd >= limD.v[l] ? 1u : 0u;
+                        const iu32 di = ((vd >> ((15u - dl) & 15u)) + L.h(I2_DADJ + (dl & 15u))) & 0x1ffu;
+                        const iu32 ds = L.byte(I2_DLONG, di & 31u);
+                        if (ls > 28u || dl > 15u || ds >= 30u) {
+                            err = INF_ERR_CODE;
+                            state = ST_DONE;
+                        } else {
+                            R.bb >>= dl;
+                            R.nb -= (int)dl;
+                            const iu32 xd = ds < 4u ? 0u : (ds >> 1) - 1u;
+                            const iu32 dbase = ds < 4u ? ds + 1u : ((2u + (ds & 1u)) << xd) + 1u;
+                            const iu32 dist = dbase + ((iu32)R.bb & ((1u << xd) - 1u));
+                            R.bb >>= xd;
+                            R.nb -= (int)xd;
+                            if (dist > pos) {
+                                err = INF_ERR_DIST;
+                                state = ST_DONE;
+                            } else if (pos + len > out_len) {
+                                err = INF_ERR_OVERRUN;
+                                state = ST_DONE;
+                            } else {
+                                // the match's token in the first three bytes of its own gap, its start in the bitmap
+                                const iu32 tok = (len - 3u) | ((dist - 1u) << 8);
+                                if (pos + 4u <= out_len) {
+                                    // one 4-byte store: its last byte is beyond a 3-byte match and belongs to what this lane writes
+                                    // NEXT (a literal, or the next token) -- a later store of the same lane to the same byte, which wins
+                                    __builtin_memcpy(base + pos, &tok, 4);
+                                } else {
+                                    const unsigned short lo = (unsigned short)tok;
+                                    __builtin_memcpy(base + pos, &lo, 2);
+                                    base[pos + 2] = (uint8_t)(tok >> 16);
+                                }
+                                const iu32 w = pos >> 6;
+                                if (w != bmi) {
+                                    if (bmi != 0xffffffffu) bm[bmi] = bmw;
+                                    bmi = w;
+                                    bmw = 0;
+                                }
+                                bmw |= 1ull << (pos & 63u);
+                                pos += len;
+                            }
+                        }
+                        topup();
+                        topup();
+                    }
                 }
-                bitpos = consumed;
-                state = last ? ST_DONE : ST_HEADER;
-                continue;
             }
-            sym -= 257;
-            if (sym >= 29) {
-                err = INF_ERR_CODE;
-                state = ST_DONE;
-                continue;
-            }
-            const iu32 lt = s_len[sym];
-            const int xl = (int)(lt >> 16);
-            const iu32 len = (lt & 0xffffu) + ((iu32)R.bb & ((1u << xl) - 1u));
-            R.bb >>= xl;
-            R.nb -= xl;
-            if (R.nb <= 32) {
-                R.bb |= (iu64)L.w(I3_RING + 2 * R.ri) << R.nb;
-                R.ri = (R.ri + 1) & 15u;
-                R.rf--;
-                R.nb += 32;
-            }
-            e = inf2_decode<false>(L, limD, I2_DADJ, I2_DLONG, 0, (iu32)R.bb);
-            if (e == 0 || (e >> 4) >= 30) {
-                err = INF_ERR_CODE;
-                state = ST_DONE;
-                continue;
-            }
-            R.bb >>= (e & 15u);
-            R.nb -= (int)(e & 15u);
-            const iu32 ds = e >> 4;
-            const iu32 dt = s_dist[ds];
-            const int xd = (int)(dt >> 16);
-            const iu32 dist = (dt & 0xffffu) + ((iu32)R.bb & ((1u << xd) - 1u));
-            R.bb >>= xd;
-            R.nb -= xd;
-            if (dist > pos) {
-                err = INF_ERR_DIST;
-                state = ST_DONE;
-                continue;
-            }
-            if (pos + len > out_len) {
-                err = INF_ERR_OVERRUN;
-                state = ST_DONE;
-                continue;
-            }
-            // the match's token in the first three bytes of its own gap, its start in the bitmap
-            {
-                const iu32 tok = (len - 3u) | ((dist - 1u) << 8);
-                const unsigned short lo = (unsigned short)tok;
-                __builtin_memcpy(base + pos, &lo, 2);
-                base[pos + 2] = (uint8_t)(tok >> 16);
-                const iu32 w = pos >> 6;
-                if (w != bmi) {
-                    if (bmi != 0xffffffffu) bm[bmi] = bmw;
-                    bmi = w;
-                    bmw = 0;
-                }
-                bmw |= 1ull << (pos & 63u);
-            }
-            pos += len;
         }
     }
 }
-
-// 16 bytes at any address as two 8-byte words
-struct U128 {
-    iu64 lo, hi;
-};
-__device__ __forceinline__ U128 load128u(const uint8_t *p) {
-    U128 v;
-    __builtin_memcpy(&v, p, 16);
-    return v;
-}
-__device__ __forceinline__ void store128u(uint8_t *p, U128 v) { __builtin_memcpy(p, &v, 16); }
 
 __global__ __launch_bounds__(256) void bgzf_resolve(const InfBlock *blocks, iu32 n_blocks, uint8_t *out, const iu64 *bitmap, const int *status) {
     const iu32 lane = threadIdx.x & 63u;
@@ -1063,12 +1116,25 @@ __global__ __launch_bounds__(256) void bgzf_resolve(const InfBlock *blocks, iu32
             const iu32 src = p - dist;
             const iu32 need = len < dist ? len : dist; // source bytes that must be final
             bool done = !have || dist > p || p + len > B.out_len; // (bgzf_decode has checked both for every token it wrote)
-            for (int round = 0; round < 64; round++) {                // (the first unfinished match is always ready: at most 64 rounds)
+            // Which matches of the batch does this one wait for?  Those whose destination overlaps its source bytes: the
+            // matches are in output order and their destinations do not overlap, so they are a run of lanes [i_lo, i_hi)
+            // below this one -- i_lo = matches that end at or before the source, i_hi = matches that start before the
+            // source's end.  Everything else the source touches is final: literals were in place, earlier batches are done.
+            const iu32 kp = have ? p : 0xffffffffu, ke = have ? p + len : 0xffffffffu; // (lanes without a match sort last)
+            const iu32 s_end = src + need;
+            iu32 i_lo = 0, i_hi = 0;
+#pragma unroll
+            for (int step = 32; step >= 1; step >>= 1) {
+                const iu32 tl = i_lo + (iu32)step, th = i_hi + (iu32)step;
+                const iu32 el = __shfl(ke, (int)((tl - 1u) & 63u), 64), ph = __shfl(kp, (int)((th - 1u) & 63u), 64);
+                if (el <= src) i_lo = tl;
+                if (ph < s_end) i_hi = th;
+            }
+            const iu64 deps = i_hi > i_lo ? (((1ull << i_hi) - 1ull) & ~((1ull << i_lo) - 1ull)) : 0ull; // (i_hi <= this lane < 64)
+            for (int round = 0; round < 64; round++) { // (the first unfinished match waits for nobody: at most 64 rounds)
                 const iu64 nd = __ballot(!done);
                 if (!nd) break;
-                const int f = __ffsll((long long)nd) - 1;
-                const iu32 hwm = __shfl(p, f, 64); // everything before the first unfinished match is final
-                const bool ready = !done && src + need <= hwm;
+                const bool ready = !done && !(nd & deps);
                 if (ready) {
                     uint8_t *d = base + p;
                     const uint8_t *sp = base + src;

@@ -6,7 +6,7 @@ rows = []
 for f in glob.glob(f"{d}/**/*kernel_trace.csv", recursive=True):
     rows += list(csv.DictReader(open(f)))
 t0 = min(int(r["Start_Timestamp"]) for r in rows)
-inf = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r.get("Queue_Id", "?"), int(r.get("Grid_Size", r.get("Grid_Size_X", 0)) or 0)) for r in rows if "bgzf_inflate" in r["Kernel_Name"])
+inf = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r.get("Queue_Id", "?"), int(r.get("Grid_Size", r.get("Grid_Size_X", 0)) or 0)) for r in rows if any(k in r["Kernel_Name"] for k in ("bgzf_inflate", "bgzf_decode", "bgzf_resolve")))
 last_end = None
 for a, b, q, g in inf:
     running = sum(1 for x, y, _, _ in inf if x < a < y)

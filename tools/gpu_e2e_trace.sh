@@ -14,3 +14,5 @@ export PJB_NORMAL_EXIT=1
 ( time rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d /tmp/e2e_prof -- portcullis_amd/host/portcullis_amd junc -t 16 --orientation FR -o $W/out/pc3 $W/prep > /dev/null 2> gpurun_out/e2e_tr_rocprof.err ) 2>&1 | tail -3
 python tools/debug/e2e_timeline.py /tmp/e2e_prof > gpurun_out/e2e_timeline.txt 2>&1
 head -70 gpurun_out/e2e_timeline.txt
+python tools/debug/inflate_gantt.py /tmp/e2e_prof > gpurun_out/e2e_inflate_gantt.txt 2>&1
+tail -45 gpurun_out/e2e_inflate_gantt.txt
