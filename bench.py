@@ -121,11 +121,20 @@ def main():
     ap.add_argument("--junctions", type=int, default=int(os.environ.get("PJB_BENCH_JUNCTIONS", 250_000)))
     ap.add_argument("--queue", type=int, default=int(os.environ.get("PJB_BENCH_QUEUE", 3)),
                     help="contigs queued at once (pjb_finish_contig_begin / _end; at most PJB_MAX_QUEUED = 4)")
+    ap.add_argument("--group-bases", type=int, default=int(os.environ.get("PJB_BENCH_GROUP_BASES", 1 << 30)),
+                    help="targets are finished in groups (pjb_finish_group_begin: ONE kernel chain over several targets) of consecutive "
+                         "targets adding up to at most this many bases -- GRCh38: three chains of ~1 Gb; 0: one chain per target")
+    ap.add_argument("--config", default="c3", choices=["c3", "c5"],
+                    help="c3: BASELINE configs[2] (200 M reads; the default and the driver's line).  c5: BASELINE configs[4] WHOLE on one GPU -- "
+                         "1 B paired-end reads, 300 k junctions, Zipf depth, strandedness=firststrand, 73 GB of records resident in HBM; no BAM "
+                         "leg (the file would be 170 GB), the CPU baseline runs on three of the 25 targets")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", default=os.environ.get("PJB_BENCH_E2E", "1") == "0")
     ap.add_argument("--e2e-workdir", default=os.environ.get("PJB_BENCH_WORKDIR", "/tmp/pjb_bench_e2e"))
     ap.add_argument("--no-verify", action="store_true", help="N > 1: skip rank 0's single-GPU re-run of the whole set")
     args = ap.parse_args()
+    if args.config == "c5":
+        args.reads, args.junctions, args.no_e2e = 1_000_000_000, 300_000, True
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         spawn_ranks(args.gpus)
 
@@ -172,7 +181,7 @@ def main():
     L = cfgs[0].read_len
     ORI = "FR"
 
-    ctx = ffi.Context(device=dev_index, orientation=ORI, flags=ffi.FLAG_KERNEL_TIMING)
+    ctx = ffi.Context(device=dev_index, orientation=ORI, flags=ffi.FLAG_KERNEL_TIMING, strandedness=1 if args.config == "c5" else 3)
     ctx.set_refs(lens)
     t_gen = time.time()
     contigs = {}  # tid -> dict(batch, n, P, C, S, Cs)
@@ -196,26 +205,38 @@ def main():
     xchg = None
     row_bytes = ffi.ROW_DTYPE.itemsize
 
-    order = sorted(mine, key=lambda t: -contigs[t]["n"])
+    # the chains of a step: groups of consecutive targets (one kernel chain each), or every target alone
+    if args.group_bases > 0:
+        chains = ffi.plan_groups(lens, sorted(mine), args.group_bases)
+    else:
+        chains = [[t] for t in mine]
+    chains.sort(key=lambda g: -sum(contigs[t]["n"] for t in g))  # largest first: the queue drains at the end of a step on the small ones
 
     def step():
         ctx.clear_rows()
         if xchg is not None:
             ctx.set_row_mirror(*xchg.slot_for_next_finish())  # every finish appends header + rows to the exchange slot
         regs = {}
-        queued = []  # several contigs queued: their kernel chains run side by side, the device never waits for the host
+        queued = []  # several chains queued: they run side by side, the device never waits for the host
 
         def collect_oldest():
-            t = queued.pop(0)
-            regs[t] = ctx.finish_contig_end(t)
+            g = queued.pop(0)
+            if len(g) == 1:
+                regs[g[0]] = ctx.finish_contig_end(g[0])
+            else:
+                regs.update(ctx.finish_group_end(g))
             if state.get("want_timing"):
-                state.setdefault("per_contig", {})[t] = ctx.timing()
+                state.setdefault("per_chain", {})[tuple(g)] = ctx.timing()
 
-        for tid in order:  # largest first: the queue drains at the end of a step on the small contigs
-            c = contigs[tid]
-            ctx.submit_batch_device(tid, c["batch"], c["n"])
-            ctx.finish_contig_begin(tid)
-            queued.append(tid)
+        for g in chains:
+            for tid in g:
+                c = contigs[tid]
+                ctx.submit_batch_device(tid, c["batch"], c["n"])
+            if len(g) == 1:
+                ctx.finish_contig_begin(g[0])
+            else:
+                ctx.finish_group_begin(g)
+            queued.append(g)
             if len(queued) >= args.queue:
                 collect_oldest()
         while queued:
@@ -328,22 +349,26 @@ def main():
         dom_serial_ms = kt[dominant][1] / kt[dominant][0] if dominant and kt[dominant][0] else None
         if dominant:
             kt[dominant] = kt_timed[dominant]  # measured live over the timed region (beside whatever overlapped it)
-        per = state.get("per_contig", {})
+        per = state.get("per_chain", {})
         kern = []
+        per_target_kernels = ("k1_count", "k1_emit", "k1_walk")  # launched once per target; everything else once per chain
         for name, (launches, ms) in kt.items():
             if launches == 0:
                 continue
-            # algorithmic bytes of this kernel over one step = sum over this rank's contigs (x sort passes)
+            # algorithmic bytes of this kernel over one step = sum over this rank's chains (x sort passes); the formulas are
+            # linear in the counts, so a chain's bytes are those of its targets' summed counts
             tot_b = 0.0
             known = True
-            for tid in mine:
-                c = contigs[tid]
-                Jc = int(regs[tid]["n_junctions"])
-                b = algorithmic_bytes(name, c["n"], c["C"], c["S"], c["Cs"], c["P"], Jc, L, int(per[tid].get("generic_pairs", 0)))
+            for g in chains:
+                cs_ = [contigs[t] for t in g]
+                Jc = sum(int(regs[t]["n_junctions"]) for t in g)
+                tm = per.get(tuple(g), {})
+                b = algorithmic_bytes(name, sum(c["n"] for c in cs_), sum(c["C"] for c in cs_), sum(c["S"] for c in cs_),
+                                      sum(c["Cs"] for c in cs_), sum(c["P"] for c in cs_), Jc, L, int(tm.get("generic_pairs", 0)))
                 if b is None:
                     known = False
                     break
-                mult = int(per[tid]["sort_passes"]) if name in ("rs_hist", "rs_scatter") else 1
+                mult = int(tm.get("sort_passes", 1)) if name in ("rs_hist", "rs_scatter") else 1
                 tot_b += b * mult
             per_step = launches / args.steps
             kern.append(dict(name=name, launches=launches, avg_ms=ms / launches, total_ms=ms,
@@ -391,7 +416,8 @@ def main():
         cpu = None
         oracle_tab_md5 = None
         if world == 1 and not args.no_cpu_baseline:
-            cpu, oracle_tab_md5, oracle_tab_len = cpu_baseline(contigs, cfgs, rows, regs, ORI, synth)
+            sample = None if args.config != "c5" else {t: contigs[t] for t in (0, 12, 24) if t in contigs}
+            cpu, oracle_tab_md5, oracle_tab_len = cpu_baseline(sample or contigs, cfgs, rows, regs, ORI, synth, partial=sample is not None)
         e2e = None
         if world == 1 and not args.no_e2e:
             try:
@@ -402,7 +428,7 @@ def main():
                 shutil.rmtree(args.e2e_workdir, ignore_errors=True)
 
         tot_bytes = sum((k["alg_bytes"] or 0) * k["launches"] / args.steps for k in kern)
-        cfg_name = "configs[2]" if world == 1 else "configs[3]"
+        cfg_name = "configs[4] (whole, on one GPU)" if args.config == "c5" else "configs[2]" if world == 1 else "configs[3]"
         result = {
             "metric": "junc_reads_per_sec",
             "value": N_total * args.steps / elapsed,
@@ -423,7 +449,10 @@ def main():
                        "reads_total": N_total, "junctions_total": J_total, "contigs": len(cfgs),
                        "contigs_per_rank": [len(s) for s in shards], "reads_rank0": N_mine, "pairs_rank0": P_mine,
                        "sharding": "by contig", "input": "device-resident SoA records (pjb_submit_batch_device)",
-                       "queue": f"{args.queue} contigs queued (pjb_finish_contig_begin / _end), their kernel chains side by side on the device",
+                       "chains": [len(g) for g in chains],
+                       "queue": (f"{len(chains)} kernel chains per step, each over a group of consecutive targets (pjb_finish_group_begin / _end), "
+                                 if args.group_bases > 0 else "one kernel chain per target (pjb_finish_contig_begin / _end), ")
+                                + f"{args.queue} chains queued at once, side by side on the device",
                        "hbm_resident_gb_rank0": round(hbm_gb, 2)},
             "junctions_per_sec": J_total * args.steps / elapsed,
             "roofline": roofline,
@@ -460,7 +489,7 @@ def host_cores():
     return n
 
 
-def cpu_baseline(contigs, cfgs, dev_rows, dev_regs, orientation, synth):
+def cpu_baseline(contigs, cfgs, dev_rows, dev_regs, orientation, synth, partial=False):
     """The CPU oracle (oracle/portcullis_oracle.c, kind "port") over the WHOLE workload on the box's host cores:
     one thread per contig, longest first, exactly the parallelism the reference has (one thread per target,
     src/junction_builder.cc:241-245).  The sample is bounded by construction (about 25 s of single-core work for
@@ -508,13 +537,30 @@ def cpu_baseline(contigs, cfgs, dev_rows, dev_regs, orientation, synth):
     tab = orc.write_tab(allrows, list(synth.GRCH38_NAMES[: len(cfgs)]), lens)
     longest = max(v[2] for v in out.values())
     return ({"value": n_reads / wall, "unit": "reads/s", "cores": cores, "kind": "port",
-             "sample": f"the whole workload: {n_reads} records of {len(out)} contigs ({len(allrows)} junctions), "
+             "sample": ("a sample of the workload: " if partial else "the whole workload: ") + f"{n_reads} records of {len(out)} contigs ({len(allrows)} junctions), "
                        f"oracle/portcullis_oracle.c on pre-decoded records, one thread per contig on {cores} cores: "
                        f"{wall:.1f} s wall including the records' copy out of HBM, {cpu_s:.1f} s of oracle CPU time, longest contig {longest:.1f} s; "
                        f"every device row of the timed run equals the oracle's (integers bit-exact, max |entropy diff| {worst:.2g})",
              "single_core_reads_per_sec": n_reads / cpu_s,
              "junctions_per_sec": len(allrows) / wall},
-            hashlib.md5(tab).hexdigest(), len(tab))
+            None if partial else hashlib.md5(tab).hexdigest(), len(tab))
+
+
+def warm_file(path, threads, passes=2):
+    """Reads the file `passes` times with `threads` readers (os.pread releases the GIL)."""
+    import concurrent.futures as cf
+
+    size = os.path.getsize(path)
+    chunk = 64 << 20
+    fd = os.open(path, os.O_RDONLY)
+    try:
+        def rd(off):
+            return len(os.pread(fd, chunk, off))
+        for _ in range(max(0, passes)):
+            with cf.ThreadPoolExecutor(max_workers=max(1, threads)) as ex:
+                sum(ex.map(rd, range(0, size, chunk)))
+    finally:
+        os.close(fd)
 
 
 def e2e_leg(contigs, cfgs, workdir, orientation, oracle_tab_md5, reads_arg, junctions_arg):
@@ -578,6 +624,22 @@ def e2e_leg(contigs, cfgs, workdir, orientation, oracle_tab_md5, reads_arg, junc
     walls, md5s = [], []
     out = os.path.join(workdir, "out", "pc")
     n_tab = 0
+    # "Page cache warm" made true before anything is timed.  The runs right after the BAM was written were the outliers of
+    # every bench line so far (driver, round 2: 3.49 / 4.16 / 2.47 s; this round: 2.50 / 3.69 / 2.38 / 2.47 / 2.43, 4.66 / 3.85 /
+    # 2.36 / 3.58 / 2.26 -- and 2.0-2.3 s five times in a row a minute later, same files, same binary): pages that were
+    # written, synced and read once or twice are still moving between the kernel's inactive and active lists, and a 33 GB
+    # pread pays for it.  Two plain passes over the file and one untimed run of the program settle that; a prepared BAM that
+    # a pipeline has just sorted and indexed is in the same state.
+    t0 = time.time()
+    warm_file(bam, cores, passes=int(os.environ.get("PJB_BENCH_E2E_WARM_PASSES", 2)))
+    t_warm = time.time() - t0
+    warmup_run_s = None
+    if not os.environ.get("PJB_BENCH_E2E_NO_WARMUP_RUN"):
+        t = time.time()
+        p = subprocess.run([cli, "junc", "-t", str(cores), "--orientation", orientation, "-o", out, prep], capture_output=True, text=True)
+        warmup_run_s = round(time.time() - t, 3)
+        if p.returncode != 0:
+            raise RuntimeError("portcullis_amd junc failed: " + (p.stderr or p.stdout)[-400:])
     for rep in range(max(1, int(os.environ.get("PJB_BENCH_E2E_REPS", 5)))):
         env = dict(os.environ)
         if os.environ.get("PJB_BENCH_E2E_SWEEP"):  # (experiment: "VAR=a,b,c": repeat k runs with VAR = the k-th value)
@@ -612,7 +674,8 @@ def e2e_leg(contigs, cfgs, workdir, orientation, oracle_tab_md5, reads_arg, junc
            "tab_identical_to_oracle": (all(m == oracle_tab_md5 for m in md5s)) if oracle_tab_md5 else None,
            "tab_md5_checked_runs": len(md5s) if oracle_tab_md5 else 0,
            "path": "BGZF BAM bytes on disk (page cache warm) -> portcullis_amd junc (device ingest: pjb_submit_bam) -> .junctions.tab/.bed",
-           "prep_s": {"dump_soa": round(t_dump, 1), "soa2bam": round(t_bam, 1), "sync": round(t_sync, 1), "cached": cached}}
+           "warmup_run_s": warmup_run_s,
+           "prep_s": {"dump_soa": round(t_dump, 1), "soa2bam": round(t_bam, 1), "sync": round(t_sync, 1), "warm_passes": round(t_warm, 1), "cached": cached}}
     # ---- the CPU neighbour: same files, host cores only
     if not os.environ.get("PJB_BENCH_NO_E2E_CPU"):
         try:

@@ -237,6 +237,23 @@ int pjb_finish_contig(pjb_ctx *ctx, int32_t tid, pjb_region_result *result);
 int pjb_finish_contig_begin(pjb_ctx *ctx, int32_t tid);
 int pjb_finish_contig_end(pjb_ctx *ctx, int32_t tid, pjb_region_result *result);
 
+/* Several targets finished as ONE kernel chain (a "group").  A chain of ~45 kernels over one human chromosome's 8 M
+ * alignments leaves most of the chip idle in most of its kernels; the reference's answer to many small targets is its
+ * thread pool (one findJuncs per target and thread, src/junction_builder.cc:236-247), the device's is to walk several
+ * targets' records in one pass: the group's targets are laid side by side in a virtual sequence, the intron keys carry
+ * the position in it -- which is what the reference's (refId, start, end) key (lib/include/portcullis/intron.hpp:44-149)
+ * amounts to -- and rows come back per target, in the order of `tids`, exactly as n calls of pjb_finish_contig would have
+ * produced them (same rows, same per-target results).  Every target named must have had its batches submitted and its
+ * genome uploaded; targets without alignments may be named.  _begin / _end pair up like pjb_finish_contig_begin / _end
+ * and share their queue (PJB_MAX_QUEUED chains, collected in order; _end names the same targets in the same order).
+ * PJB_ERR_ARG from _begin means "not as a group" (more than PJB_GROUP_MAX targets, 2^31 bases or more in all, a
+ * PJB_FLAG_EXTRA context, a target whose genome holds characters outside the 16-letter nucleotide alphabet): finish the
+ * targets one by one.  A member that turns out to hold alignments outside its own sequence makes _end finish the
+ * members one by one itself. */
+#define PJB_GROUP_MAX 32
+int pjb_finish_group_begin(pjb_ctx *ctx, const int32_t *tids, int32_t n_tids);
+int pjb_finish_group_end(pjb_ctx *ctx, const int32_t *tids, int32_t n_tids, pjb_region_result *results /* n_tids of them */);
+
 /* Tuning switches (queue must be empty).  Results never depend on them.
  *   "overlap"    1 (default): a contig's kernels are spread over several HIP streams -- its first kernels beside the
  *                previous contig's last ones, match statistics and entropy beside the sort and the anchors; 0: one

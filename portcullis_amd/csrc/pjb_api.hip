@@ -126,6 +126,7 @@ struct CtlSlot {
     // chain reads: the next contig's first kernels run beside this contig's last ones
     Buf tile_cnt, tile_stats, splidx, splpoff;
     Buf k1look; // k1_walk: ticket counter, tile and group descriptors
+    Buf members; // groups: MemberStats[GROUP_MAX] | member_junc u32[GROUP_MAX] | tile_lo u32[GROUP_MAX + 1]
     Buf okey, g, lstart, rend, pos, aend, meta, updown, seqw; // the pairs (BAM order)
     Buf res;                                                  // k4a_simple / k4b_generic results per pair
     hipEvent_t ev_k1 = nullptr;
@@ -152,9 +153,16 @@ struct EvPool {
 };
 constexpr int MISC_POOL = PJB_MAX_QUEUED;
 
-// a contig between pjb_finish_contig_begin and pjb_finish_contig_end
+// a target -- or a GROUP of targets finished as one chain (pjb_finish_group_begin) -- between _begin and _end
 struct Flight {
-    int32_t tid = -1;
+    int32_t tid = -1;      // the first member (messages)
+    std::vector<int32_t> tids;   // members, in the order of their virtual offsets (a single target: one entry)
+    std::vector<int32_t> voff;   // offset of each member in the group's virtual sequence (GroupTab)
+    int64_t vlen = 0;            // length of the virtual sequence
+    std::vector<u32> tile_lo;    // first K1 tile of each member, + the total
+    std::vector<int64_t> m_reads; // reads of each member
+    std::vector<DevBatch> batches; // every member's batches, read ordinals and tile numbers running through the group
+    std::vector<int> batch_member; // member of each batch
     int slot = 0;
     bool queued = false;   // its kernels are on the streams
     bool empty = false;    // no batches: nothing to queue
@@ -610,7 +618,7 @@ void pjb_destroy(pjb_ctx *c) {
         for (auto &ev : S.ev) (void)hipEventDestroy(ev);
         if (S.ev_rows) (void)hipEventDestroy(S.ev_rows);
         if (S.ev_done) (void)hipEventDestroy(S.ev_done);
-        Buf *sb[] = {&S.cstats, &S.err, &S.gencount, &S.batches, &S.rows, &S.tile_cnt, &S.tile_stats, &S.splidx, &S.splpoff, &S.k1look, &S.okey, &S.g,
+        Buf *sb[] = {&S.cstats, &S.err, &S.gencount, &S.batches, &S.rows, &S.tile_cnt, &S.tile_stats, &S.splidx, &S.splpoff, &S.k1look, &S.members, &S.okey, &S.g,
                      &S.lstart, &S.rend, &S.pos, &S.aend, &S.meta, &S.updown, &S.seqw, &S.res, &S.total, &S.bitmap, &S.wrank, &S.ends, &S.firstid,
                      &S.key[0], &S.key[1], &S.idx[0], &S.idx[1], &S.hist, &S.hist_scan, &S.bintotal, &S.scan_tiles, &S.jid, &S.seg, &S.runfirst,
                      &S.runstart, &S.ent, &S.entsum, &S.frag, &S.fragj, &S.fragl, &S.fragr, &S.acc, &S.ancl, &S.ancr, &S.genlist};
@@ -1040,7 +1048,8 @@ static size_t rows_upper_bound(const pjb_ctx *c) {
 }
 
 constexpr unsigned K6_BLOCKS = 128;
-static int queue_contig(pjb_ctx *c, Flight &f, std::vector<DevBatch> &batches) {
+static int queue_contig(pjb_ctx *c, Flight &f) {
+    std::vector<DevBatch> &batches = f.batches;
     CtlSlot &S = c->sl[f.slot];
     // the contig's chain runs on its slot's streams, beside the chain of the contig in the other slot; everything the
     // LAUNCH macro and run_scan do follows c->stream / c->scan_tiles until this function returns
@@ -1055,11 +1064,26 @@ static int queue_contig(pjb_ctx *c, Flight &f, std::vector<DevBatch> &batches) {
     } chain_scope{c, service};
     c->stream = st;
     c->scan_tiles = &S.scan_tiles;
-    const int32_t tid = f.tid;
     const u32 n_tiles = f.n_tiles;
     const ContigLimits &lim = f.lim;
-    const int32_t ref_len = c->ref_len[(size_t)tid];
-    const Contig &G = c->contigs[(size_t)tid];
+    const int n_members = (int)f.tids.size();
+    const bool group = n_members > 1;
+    // the sequence the chain works on: the target itself, or the group's virtual sequence (every member at its offset)
+    const int32_t ref_len = group ? (int32_t)f.vlen : c->ref_len[(size_t)f.tid];
+    GroupTab GT;
+    memset(&GT, 0, sizeof GT);
+    GT.n = n_members;
+    bool all_codes = true, any_x = false;
+    for (int m = 0; m < n_members; m++) {
+        const Contig &g = c->contigs[(size_t)f.tids[(size_t)m]];
+        GT.voff[m] = f.voff[(size_t)m];
+        GT.len[m] = (int32_t)g.len;
+        GT.tid[m] = f.tids[(size_t)m];
+        GT.d[m] = g.d;
+        GT.codes[m] = g.codes;
+        all_codes = all_codes && g.codes != nullptr;
+        any_x = any_x || g.has_x;
+    }
     const KeyFmt kf = lim.kf;
     const u32 PL = lim.pair_limit, JL = lim.junc_limit;
     int rc;
@@ -1075,11 +1099,11 @@ static int queue_contig(pjb_ctx *c, Flight &f, std::vector<DevBatch> &batches) {
     c->cur_slot = f.slot;
     ev_drop(c, f.slot);
     if ((rc = ensure(c, S.batches, batches.size() * sizeof(DevBatch)))) return rc;
-    if (batches.size() > S.batches_pinned_cap) {
+    if (batches.size() + 2 > S.batches_pinned_cap) { // (+ 2 descriptors' worth of room for a group's tile ranges: 33 words)
         if (S.batches_pinned) (void)hipHostFree(S.batches_pinned);
         S.batches_pinned = nullptr;
         S.batches_pinned_cap = 0;
-        const size_t cap = std::max<size_t>(batches.size() * 2, 16);
+        const size_t cap = std::max<size_t>(batches.size() * 2 + 2, 16);
         HIP_TRY(c, hipHostMalloc((void **)&S.batches_pinned, cap * sizeof(DevBatch), hipHostMallocDefault));
         S.batches_pinned_cap = cap;
     }
@@ -1089,11 +1113,15 @@ static int queue_contig(pjb_ctx *c, Flight &f, std::vector<DevBatch> &batches) {
     if ((rc = ensure(c, c->b_cursor, sizeof(RowCursor)))) return rc;
     if ((rc = ensure(c, S.tile_cnt, (size_t)n_tiles * 4))) return rc;
     if ((rc = ensure(c, S.tile_stats, (size_t)n_tiles * sizeof(TileStats)))) return rc;
-    const bool fused_k1 = c->fused_k1;
+    const bool fused_k1 = c->fused_k1 && !group; // (the one-pass walk is a single-target experiment)
     const bool want_splidx = !fused_k1 || c->extra; // (--extra reads the tiles' spliced lists)
     if (want_splidx && (rc = ensure(c, S.splidx, (size_t)n_tiles * K1_TILE * 4))) return rc;
     if (!fused_k1 && (rc = ensure(c, S.splpoff, (size_t)n_tiles * K1_TILE * 4))) return rc;
     if (fused_k1 && (rc = ensure(c, S.k1look, k1look_bytes(n_tiles)))) return rc;
+    if ((rc = ensure(c, S.members, GROUP_MAX * sizeof(MemberStats) + GROUP_MAX * 4 + (GROUP_MAX + 1) * 4))) return rc;
+    MemberStats *d_members = (MemberStats *)S.members.p;
+    u32 *d_member_junc = (u32 *)(d_members + GROUP_MAX);
+    u32 *d_tile_lo = d_member_junc + GROUP_MAX;
     if ((rc = ensure(c, S.total, 8))) return rc;
     // ---- pair-sized buffers (one sort tile of slack: rs_scatter loads whole tiles unguarded)
     if ((rc = ensure(c, S.okey, ((size_t)PL + RS_TILE) * 8))) return rc; // the pairs' keys as emitted (BAM order): kept, the sort works on copies
@@ -1163,13 +1191,22 @@ static int queue_contig(pjb_ctx *c, Flight &f, std::vector<DevBatch> &batches) {
     // (records still being produced on the service stream -- host copies, BAM ingest -- come first)
     const hipStream_t front = st;
     {
-        auto oit = c->open.find(tid);
-        if (st != service && oit != c->open.end() && oit->second.on_main_stream) {
+        bool on_service = false;
+        for (int32_t t : f.tids) {
+            auto oit = c->open.find(t);
+            on_service = on_service || (oit != c->open.end() && oit->second.on_main_stream);
+        }
+        if (st != service && on_service) {
             HIP_TRY(c, hipEventRecord(c->ev_front, service));
             HIP_TRY(c, hipStreamWaitEvent(st, c->ev_front, 0));
         }
     }
     HIP_TRY(c, hipMemcpyAsync(S.batches.p, S.batches_pinned, batches.size() * sizeof(DevBatch), hipMemcpyHostToDevice, front));
+    if (group) { // (the tile ranges of the members; lives behind the batch descriptors in the page-locked staging block)
+        u32 *h_lo = (u32 *)(S.batches_pinned + batches.size());
+        for (int m = 0; m <= n_members; m++) h_lo[m] = f.tile_lo[(size_t)m];
+        HIP_TRY(c, hipMemcpyAsync(d_tile_lo, h_lo, (size_t)(n_members + 1) * 4, hipMemcpyHostToDevice, front));
+    }
     if (!S.at_rest) {
         HIP_TRY(c, hipMemsetAsync(S.err.p, 0xff, 8, front));
         HIP_TRY(c, hipMemsetAsync(S.gencount.p, 0, GEN_SHARDS * 4, front));
@@ -1203,38 +1240,46 @@ static int queue_contig(pjb_ctx *c, Flight &f, std::vector<DevBatch> &batches) {
         for (auto &b : batches) {
             const u32 nt = (u32)((b.n + K1_TILE - 1) / K1_TILE);
             LAUNCH(c, "k1_walk", k1_walk, dim3(nt), dim3(K1W_THREADS), b, lk, n_tiles, (TileStats *)S.tile_stats.p,
-                   want_splidx ? (u32 *)S.splidx.p : (u32 *)nullptr, pr, kf, ref_len, tid, (int)c->cfg.orientation, PL, d_err);
+                   want_splidx ? (u32 *)S.splidx.p : (u32 *)nullptr, pr, kf, ref_len, f.tid, (int)c->cfg.orientation, PL, d_err);
         }
         LAUNCH(c, "k1_scan_tiles", k1_scan_tiles, dim3(1), dim3(1024), (u32 *)nullptr, (const TileStats *)S.tile_stats.p, n_tiles, d_cs, PL, kf,
                ref_len, (const u64 *)lk.tile_desc);
     } else {
-        // ---- K1a: count
-        for (auto &b : batches) {
+        // ---- K1a: count (a group's members: a tile whose alignments leave the member's own sequence is flagged)
+        for (size_t bi = 0; bi < batches.size(); bi++) {
+            const DevBatch &b = batches[bi];
+            const int32_t own_len = c->ref_len[(size_t)f.tids[(size_t)f.batch_member[bi]]];
             const u32 nt = (u32)((b.n + K1_TILE - 1) / K1_TILE);
             LAUNCH(c, "k1_count", k1_count, dim3(nt), dim3(256), b, (u32 *)S.tile_cnt.p, (TileStats *)S.tile_stats.p,
-                   (u32 *)S.splidx.p, (u32 *)S.splpoff.p, d_err);
+                   (u32 *)S.splidx.p, (u32 *)S.splpoff.p, d_err, group ? std::max(own_len, 1) : 0);
         }
+        if (group)
+            LAUNCH(c, "kg_member_stats", kg_member_stats, dim3((unsigned)n_members), dim3(256), (const u32 *)S.tile_cnt.p, (const TileStats *)S.tile_stats.p,
+                   (const u32 *)d_tile_lo, n_members, d_members);
         LAUNCH(c, "k1_scan_tiles", k1_scan_tiles, dim3(1), dim3(1024), (u32 *)S.tile_cnt.p, (const TileStats *)S.tile_stats.p, n_tiles, d_cs,
-               PL, kf, ref_len, (const u64 *)nullptr);
-        // ---- K1b: emit
-        for (auto &b : batches) {
+               PL, kf, group ? INT32_MAX - 1 : ref_len, (const u64 *)nullptr);
+        // ---- K1b: emit (coordinates in the group's virtual sequence)
+        for (size_t bi = 0; bi < batches.size(); bi++) {
+            const DevBatch &b = batches[bi];
+            const int m = f.batch_member[bi];
+            const int32_t own_tid = f.tids[(size_t)m], own_len = c->ref_len[(size_t)own_tid];
             const u32 nt = (u32)((b.n + K1_TILE - 1) / K1_TILE);
             LAUNCH(c, "k1_emit", k1_emit, dim3(nt), dim3(256), b, (const u32 *)S.tile_cnt.p,
-                   (const TileStats *)S.tile_stats.p, (const u32 *)S.splidx.p, (const u32 *)S.splpoff.p, pr, kf, ref_len,
-                   tid, (int)c->cfg.orientation, d_err, (const ContigStats *)d_cs);
+                   (const TileStats *)S.tile_stats.p, (const u32 *)S.splidx.p, (const u32 *)S.splpoff.p, pr, kf, own_len,
+                   own_tid, (int)c->cfg.orientation, d_err, (const ContigStats *)d_cs, f.voff[(size_t)m]);
         }
     }
     // ---- K4a: match statistics of the common [S] M N M [S] shape, in BAM order, while the keys are still unsorted:
     // on the side stream, beside the sort of the main stream (joined before pass 1 overwrites the keys)
-    const bool fast_codes = G.codes != nullptr && !G.has_x;
+    const bool fast_codes = all_codes && !any_x;
     if (fast_codes && !c->side_stream) { // (PJB_SIDE_STREAM=0: one kernel at a time, for clean per-kernel timings)
-        LAUNCH(c, "k4a_simple", k4a_simple, dim3(pair_blocks), dim3(256), pr, kf, (const u32 *)G.codes, (int32_t)G.len, d_P, (u64 *)S.res.p);
+        LAUNCH(c, "k4a_simple", k4a_simple, dim3(pair_blocks), dim3(256), pr, kf, GT, d_P, (u64 *)S.res.p);
     } else if (fast_codes) {
         HIP_TRY(c, hipEventRecord(S.ev_fork, front));
         HIP_TRY(c, hipStreamWaitEvent(S.side, S.ev_fork, 0));
         c->stream = S.side;
         f.forked = true;
-        LAUNCH(c, "k4a_simple", k4a_simple, dim3(pair_blocks), dim3(256), pr, kf, (const u32 *)G.codes, (int32_t)G.len, d_P, (u64 *)S.res.p);
+        LAUNCH(c, "k4a_simple", k4a_simple, dim3(pair_blocks), dim3(256), pr, kf, GT, d_P, (u64 *)S.res.p);
         HIP_TRY(c, hipEventRecord(S.ev_join, S.side));
     }
     c->stream = st;
@@ -1353,7 +1398,7 @@ static int queue_contig(pjb_ctx *c, Flight &f, std::vector<DevBatch> &batches) {
     const u32 slot_blocks = (slots_lim + 255) / 256;
     const u32 init_n = std::max<u32>(slots_lim, JL * F_WORDS);
     LAUNCH(c, "k5_init_acc", k5_init_acc, dim3((init_n + 255) / 256), dim3(256), (u32 *)S.acc.p, d_J, (int32_t *)S.ancl.p,
-           (int32_t *)S.ancr.p, (int32_t *)S.fragj.p, d_slots);
+           (int32_t *)S.ancr.p, (int32_t *)S.fragj.p, d_slots, d_member_junc);
     LAUNCH(c, "k3_anchors_frag", k3_anchors_frag, dim3(pair_blocks), dim3(256), sidx, (const u32 *)S.jid.p,
            (const int32_t *)pr.lstart, (const int32_t *)pr.rend, (const u32 *)pr.meta, fast_codes ? 0 : 1, d_P,
            (int32_t *)S.fragl.p, (int32_t *)S.fragr.p, (int32_t *)S.fragj.p, (u32 *)S.genlist.p,
@@ -1368,8 +1413,7 @@ static int queue_contig(pjb_ctx *c, Flight &f, std::vector<DevBatch> &batches) {
     // worst case and surplus blocks exit at once), then K4: gather + segmented reduce -> fragments
     LAUNCH(c, "k4b_generic", k4b_generic, dim3((gen_cap * GEN_SHARDS + 255) / 256), dim3(256), (const u32 *)S.genlist.p,
            (const u32 *)S.gencount.p, pair_blocks, skey, sidx, (const u32 *)S.jid.p, pr, kf, (const DevBatch *)S.batches.p,
-           (int)batches.size(), (const int32_t *)S.ancl.p, (const int32_t *)S.ancr.p, (const uint8_t *)G.d,
-           (int32_t)G.len, G.has_x ? 1 : 0, (const u32 *)(G.has_x ? nullptr : G.codes), (u64 *)S.res.p, d_err);
+           (int)batches.size(), (const int32_t *)S.ancl.p, (const int32_t *)S.ancr.p, GT, any_x ? 1 : 0, any_x ? 0 : 1, (u64 *)S.res.p, d_err);
     LAUNCH(c, "k4_pairs", k4_pairs, dim3(pair_blocks), dim3(256), skey, sidx, (const u32 *)S.jid.p, pr, kf,
            (const u64 *)S.res.p, d_P, (u32 *)S.frag.p, (int32_t *)S.fragj.p);
     STAGE_EVENT(5);
@@ -1380,8 +1424,8 @@ static int queue_contig(pjb_ctx *c, Flight &f, std::vector<DevBatch> &batches) {
     if (entropy_forked) HIP_TRY(c, hipStreamWaitEvent(st, S.ev_join2, 0));
     LAUNCH(c, "k5_finalize", k5_finalize, dim3(std::max<u32>(1, (JL + 255) / 256)), dim3(256), (const u64 *)pr.key, sidx, (const u32 *)S.seg.p,
            (const u32 *)S.runfirst.p, (const u32 *)S.runstart.p, (const u32 *)S.acc.p,
-           (const int32_t *)S.ancl.p, (const int32_t *)S.ancr.p, kf, (const uint8_t *)G.d, (int32_t)G.len, tid, d_J,
-           (const double *)S.entsum.p, (pjb_junction_row *)S.rows.p, d_err);
+           (const int32_t *)S.ancl.p, (const int32_t *)S.ancr.p, kf, GT, d_J, (const double *)S.entsum.p, (pjb_junction_row *)S.rows.p, d_err,
+           d_member_junc);
     STAGE_EVENT(6);
 
     // ---- rows to the host (and into the caller's exchange slot), control block last: on the rows stream, so that the
@@ -1407,7 +1451,7 @@ static int queue_contig(pjb_ctx *c, Flight &f, std::vector<DevBatch> &batches) {
         LAUNCH(c, "k6_rows_out", k6_rows_out, dim3(K6_BLOCKS), dim3(256), (const u64 *)S.rows.p, (const ContigStats *)d_cs,
                (u64 *)c->rows_table, row_base, mirror_base, (const RowCursor *)c->b_cursor.p, mirror_table, mirror_room);
         LAUNCH(c, "k7_publish", k7_publish, dim3(1), dim3(256), (const ContigStats *)d_cs, d_err, (u32 *)S.gencount.p, S.pub_dev, row_base,
-               mirror_base, (RowCursor *)c->b_cursor.p);
+               mirror_base, (RowCursor *)c->b_cursor.p, (const MemberStats *)d_members, (const u32 *)d_member_junc, n_members);
     }
     S.at_rest = true;
     HIP_TRY(c, hipEventRecord(S.ev[7], rows_stream));
@@ -1444,150 +1488,179 @@ static void pop_flight(pjb_ctx *c) {
     c->fl[c->n_fl] = Flight();
 }
 
-static std::vector<DevBatch> g_no_batches;
-
-int pjb_finish_contig_begin(pjb_ctx *c, int32_t tid) {
-    if (!c) return PJB_ERR_ARG;
-    if (tid < 0 || (size_t)tid >= c->ref_len.size()) return fail(c, PJB_ERR_ARG, "finish: bad tid %d", tid);
-    if (c->n_fl >= PJB_MAX_QUEUED)
-        return fail(c, PJB_ERR_STATE, "finish: %d targets are queued already (oldest: %d); collect one first", c->n_fl, c->fl[0].tid);
-    for (int k = 0; k < c->n_fl; k++)
-        if (c->fl[k].tid == tid) return fail(c, PJB_ERR_STATE, "finish: target %d is queued already", tid);
-    if (c->n_fl >= 1 && c->extra) return fail(c, PJB_ERR_STATE, "finish: with PJB_FLAG_EXTRA targets are finished one at a time");
-    c->cur_tid = tid;
-    HIP_TRY(c, hipSetDevice(c->cfg.device));
-    Flight &f = c->fl[c->n_fl];
-    int slot = 0;
-    while (slot < PJB_MAX_QUEUED && c->slot_busy[slot]) slot++;
-    if (slot >= PJB_MAX_QUEUED) return fail(c, PJB_ERR_STATE, "finish: no free control slot");
-    f = Flight();
-    f.slot = slot;
-    f.tid = tid;
-    c->slot_busy[slot] = true;
-    auto open_it = c->open.find(tid);
-    if (open_it == c->open.end() || open_it->second.batches.empty()) {
-        f.empty = true;
-        c->n_fl++;
-        return PJB_OK;
-    }
-    std::vector<DevBatch> &batches = open_it->second.batches;
-    {
+// The flight's batch list, virtual offsets, tile ranges and limits from the open targets named in f.tids.
+static void prepare_flight(pjb_ctx *c, Flight &f) {
+    f.batches.clear();
+    f.batch_member.clear();
+    f.voff.assign(f.tids.size(), 0);
+    f.tile_lo.assign(f.tids.size() + 1, 0);
+    f.m_reads.assign(f.tids.size(), 0);
+    f.n_tiles = 0;
+    f.n_reads = 0;
+    int64_t at = 0;
+    bool genomes_ok = true;
+    for (size_t m = 0; m < f.tids.size(); m++) {
+        const int32_t tid = f.tids[m];
+        const int32_t ref_len = c->ref_len[(size_t)tid];
+        f.voff[m] = (int32_t)at;
+        at += (((int64_t)std::max(ref_len, 1) + GROUP_GAP) + 63) & ~(int64_t)63;
+        f.tile_lo[m] = f.n_tiles;
+        const Contig &G = c->contigs[(size_t)tid];
+        auto open_it = c->open.find(tid);
+        if (open_it == c->open.end() || open_it->second.batches.empty()) continue;
+        // without the target's genome only the counting stage may run: any pair then shows up as an overflow
+        if (!G.present || G.len != ref_len) genomes_ok = false;
+        OpenContig &oc = open_it->second;
         int32_t prev_pos = INT32_MIN;
         const int32_t *prev_ptr = nullptr;
-        OpenContig &oc = open_it->second;
-        for (size_t k = 0; k < batches.size(); k++) {
-            DevBatch &b = batches[k];
+        for (size_t k = 0; k < oc.batches.size(); k++) {
+            DevBatch b = oc.batches[k];
+            b.base = (uint32_t)f.n_reads; // read ordinals and tile numbers run through the whole group
             b.tile_base = f.n_tiles;
             f.n_tiles += (u32)((b.n + K1_TILE - 1) / K1_TILE);
             b.prev_pos = prev_pos;
             b.prev_pos_ptr = prev_ptr; // sortedness across batches: the last position of the previous batch, wherever it is known
             f.n_reads += b.n;
+            f.m_reads[m] += b.n;
             if (oc.last_known[k]) {
                 prev_pos = oc.last_pos[k];
                 prev_ptr = nullptr;
             } else
                 prev_ptr = b.pos + (b.n - 1);
+            f.batches.push_back(b);
+            f.batch_member.push_back((int)m);
         }
     }
-    const int32_t ref_len = c->ref_len[(size_t)tid];
-    const Contig &G = c->contigs[(size_t)tid];
-    // ---- limits.  Pairs: a share of the reads (a contig with more N operations than that is repeated once with the
-    // exact count).  Junctions: a share of the pair limit, at least twice what a contig of this context has had.  Key:
-    // contig coordinates and the longest intron seen by this context so far.
+    f.tile_lo[f.tids.size()] = f.n_tiles;
+    f.vlen = f.tids.size() > 1 ? at : c->ref_len[(size_t)f.tid];
+    f.empty = f.batches.empty();
+    // ---- limits.  Pairs: a share of the reads (a chain with more N operations than that is repeated once with the
+    // exact count).  Junctions: a share of the pair limit, at least twice what a chain of this context has had.  Key:
+    // coordinates of the (virtual) sequence and the longest intron seen by this context so far.
     ContigLimits &lim = f.lim;
-    {
-        const u64 guess = std::min<u64>(0xffffff00ull, (u64)f.n_reads * 5 / 8 + 4096);
-        lim.pair_limit = (u32)std::max<u64>(guess, 4096);
-        lim.junc_limit = std::max<u32>(std::max<u32>(lim.pair_limit / 32, 4096), 2 * c->junc_seen);
-        // without the contig's genome only the counting stage may run: any pair then shows up as an overflow
-        if (!G.present || G.len != ref_len) lim.pair_limit = 0;
-        lim.kf.raw = 0;
-        lim.kf.lbits = std::max(1, c->lbits_seen);
-        lim.kf.total_bits = lim.kf.lbits + std::max(1, bits_of((uint64_t)std::max(ref_len, 1)));
-        lim.dense = c->dense_ids;
+    const u64 guess = std::min<u64>(0xffffff00ull, (u64)f.n_reads * 5 / 8 + 4096);
+    lim.pair_limit = (u32)std::max<u64>(guess, 4096);
+    lim.junc_limit = std::max<u32>(std::max<u32>(lim.pair_limit / 32, 4096), 2 * c->junc_seen * (u32)std::max<size_t>(1, f.tids.size() > 1 ? 2 : 1));
+    if (!genomes_ok) lim.pair_limit = 0;
+    lim.kf.raw = 0;
+    lim.kf.lbits = std::max(1, c->lbits_seen);
+    lim.kf.total_bits = lim.kf.lbits + std::max(1, bits_of((uint64_t)std::max<int64_t>(f.vlen, 1)));
+    lim.dense = c->dense_ids;
+}
+
+static int begin_flight(pjb_ctx *c, const int32_t *tids, int32_t n, const char *who) {
+    if (!c) return PJB_ERR_ARG;
+    if (!tids || n < 1 || n > GROUP_MAX) return fail(c, PJB_ERR_ARG, "%s: 1 to %d targets", who, GROUP_MAX);
+    for (int32_t k = 0; k < n; k++) {
+        if (tids[k] < 0 || (size_t)tids[k] >= c->ref_len.size()) return fail(c, PJB_ERR_ARG, "%s: bad tid %d", who, tids[k]);
+        for (int32_t q = 0; q < k; q++)
+            if (tids[q] == tids[k]) return fail(c, PJB_ERR_ARG, "%s: target %d named twice", who, tids[k]);
     }
+    if (c->n_fl >= PJB_MAX_QUEUED)
+        return fail(c, PJB_ERR_STATE, "%s: %d chains are queued already (oldest: target %d); collect one first", who, c->n_fl, c->fl[0].tid);
+    for (int k = 0; k < c->n_fl; k++)
+        for (int32_t t : c->fl[k].tids)
+            for (int32_t q = 0; q < n; q++)
+                if (t == tids[q]) return fail(c, PJB_ERR_STATE, "%s: target %d is queued already", who, t);
+    if (c->n_fl >= 1 && c->extra) return fail(c, PJB_ERR_STATE, "%s: with PJB_FLAG_EXTRA targets are finished one at a time", who);
+    if (n > 1) {
+        // what a group needs (a caller that gets PJB_ERR_ARG here finishes the targets one by one)
+        if (c->extra) return fail(c, PJB_ERR_ARG, "%s: PJB_FLAG_EXTRA contexts finish one target at a time", who);
+        int64_t vlen = 0;
+        for (int32_t k = 0; k < n; k++) {
+            const Contig &G = c->contigs[(size_t)tids[k]];
+            vlen += (((int64_t)std::max(c->ref_len[(size_t)tids[k]], 1) + GROUP_GAP) + 63) & ~(int64_t)63;
+            auto it = c->open.find(tids[k]);
+            const bool has_reads = it != c->open.end() && !it->second.batches.empty();
+            if (has_reads && (!G.present || G.len != c->ref_len[(size_t)tids[k]]))
+                return fail(c, PJB_ERR_ARG, "%s: the genome of target %d has not been uploaded", who, tids[k]);
+            if (has_reads && (!G.codes || G.has_x))
+                return fail(c, PJB_ERR_ARG, "%s: target %d has characters outside the 16-letter alphabet: finish it alone", who, tids[k]);
+        }
+        if (vlen >= (int64_t)INT32_MAX - (1 << 20)) return fail(c, PJB_ERR_ARG, "%s: the group's targets add up to %lld bases (limit 2^31)", who, (long long)vlen);
+    }
+    c->cur_tid = tids[0];
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    Flight &f = c->fl[c->n_fl];
+    int slot = 0;
+    while (slot < PJB_MAX_QUEUED && c->slot_busy[slot]) slot++;
+    if (slot >= PJB_MAX_QUEUED) return fail(c, PJB_ERR_STATE, "%s: no free control slot", who);
+    f = Flight();
+    f.slot = slot;
+    f.tid = tids[0];
+    f.tids.assign(tids, tids + n);
+    c->slot_busy[slot] = true;
+    prepare_flight(c, f);
     c->n_fl++;
-    if (c->extra) return PJB_OK; // (queued by pjb_finish_contig_end: the extra metrics need this contig's scratch untouched)
-    // a contig that was taken back goes first (rows are in contig order): the end of the oldest one queues them all
+    if (f.empty) return PJB_OK;
+    if (c->extra) return PJB_OK; // (queued by _end: the extra metrics need this contig's scratch untouched)
+    // a chain that was taken back goes first (rows are in queue order): the end of the oldest one queues them all
     for (int k = 0; k + 1 < c->n_fl; k++)
         if (!c->fl[k].queued && !c->fl[k].empty) return PJB_OK;
-    const int rc = queue_contig(c, f, batches);
-    if (rc) { // nothing of this contig stays behind
+    const int rc = queue_contig(c, f);
+    if (rc) { // nothing of this chain stays behind
         (void)hipDeviceSynchronize();
         c->n_fl--;
         c->slot_busy[c->fl[c->n_fl].slot] = false;
+        std::vector<int32_t> members = c->fl[c->n_fl].tids;
         c->fl[c->n_fl] = Flight();
-        close_contig(c, tid);
+        for (int32_t t : members) close_contig(c, t);
     }
     return rc;
 }
 
-int pjb_finish_contig_end(pjb_ctx *c, int32_t tid, pjb_region_result *res) {
-    if (!c) return PJB_ERR_ARG;
-    if (c->n_fl <= 0 || c->fl[0].tid != tid)
-        return fail(c, PJB_ERR_STATE, "finish: target %d is not the oldest queued target (pjb_finish_contig_begin first; collect in the same order)", tid);
-    c->cur_tid = tid;
-    HIP_TRY(c, hipSetDevice(c->cfg.device));
-    struct Closer { // also on every error path: the side stream (k4a_simple) may still read the contig's batches
-        pjb_ctx *c;
-        int32_t tid;
-        bool ok = false;
-        ~Closer() {
-            Flight &f = c->fl[0];
-            if (!ok) { // whatever is queued is in an unknown place now
-                (void)hipDeviceSynchronize();
-                unqueue_followers(c);
-            } else if (f.forked && f.queued)
-                (void)0; // (joined by the main stream before k4b; the chain has completed)
-            pop_flight(c);
-            close_contig(c, tid);
-        }
-    } closer{c, tid};
+int pjb_finish_contig_begin(pjb_ctx *c, int32_t tid) { return begin_flight(c, &tid, 1, "finish"); }
+int pjb_finish_group_begin(pjb_ctx *c, const int32_t *tids, int32_t n_tids) { return begin_flight(c, tids, n_tids, "finish_group"); }
+
+// Collects the chain in fl[0] -- waits for it, repeats it when a limit it was queued with turned out too small -- and
+// fills one result per member.  A group whose members turn out to hold alignments outside their own sequence is taken
+// apart: *redo_single is set and nothing is committed.
+static int collect_flight(pjb_ctx *c, pjb_region_result *res, bool *redo_single) {
     Flight &f = c->fl[0];
-    pjb_region_result R;
-    memset(&R, 0, sizeof R);
-    R.min_len = INT32_MAX;
-    memset(&c->timing, 0, sizeof c->timing);
-    c->last_rows_n = 0;
-    if (res) *res = R;
-    if (f.empty) {
-        const int rc = mirror_header_only(c, R);
-        closer.ok = rc == PJB_OK;
-        return rc;
-    }
-    auto open_it = c->open.find(tid);
-    if (open_it == c->open.end()) return fail(c, PJB_ERR_STATE, "finish: target %d lost its batches", tid);
-    std::vector<DevBatch> &batches = open_it->second.batches;
-    const int32_t ref_len = c->ref_len[(size_t)tid];
-    const Contig &G = c->contigs[(size_t)tid];
+    const int n_members = (int)f.tids.size();
+    const bool group = n_members > 1;
     CtlSlot &S = c->sl[f.slot];
     ContigLimits &lim = f.lim;
+    const int32_t tid = f.tid;
+    const int32_t ref_len = group ? (int32_t)f.vlen : c->ref_len[(size_t)tid];
     int rc;
     ContigStats cs;
     u64 herr = ~0ull;
     for (;; f.attempt++) {
-        if (!f.queued && (rc = queue_contig(c, f, batches))) return rc;
+        if (!f.queued && (rc = queue_contig(c, f))) return rc;
         wait_flight(c, f);
         memcpy(&cs, S.pub, sizeof cs);
         memcpy(&herr, S.pub + PUB_ERR_AT, 8);
         if ((rc = check_device_error(c, herr))) return rc;
-        if (cs.n_pairs > 0 && !G.present) return fail(c, PJB_ERR_STATE, "finish: genome of target %d was not uploaded", tid);
-        if (cs.n_pairs > 0 && G.len != ref_len)
-            return fail(c, PJB_ERR_ARG, "finish: genome of target %d has %lld bases, header says %d", tid, (long long)G.len, ref_len);
+        for (int m = 0; m < n_members && cs.n_pairs > 0; m++) {
+            const Contig &G = c->contigs[(size_t)f.tids[(size_t)m]];
+            if (f.m_reads[(size_t)m] == 0) continue;
+            if (!G.present) return fail(c, PJB_ERR_STATE, "finish: genome of target %d was not uploaded", f.tids[(size_t)m]);
+            if (G.len != c->ref_len[(size_t)f.tids[(size_t)m]])
+                return fail(c, PJB_ERR_ARG, "finish: genome of target %d has %lld bases, header says %d", f.tids[(size_t)m], (long long)G.len,
+                            c->ref_len[(size_t)f.tids[(size_t)m]]);
+        }
         if (!cs.overflow) break;
         if (f.attempt >= 3) return fail(c, PJB_ERR_STATE, "finish: limits of target %d did not settle (overflow bits %u)", tid, cs.overflow);
-        // a limit was too small: the control block says by how much; everything is queued again (and so is the contig
+        // a limit was too small: the control block says by how much; everything is queued again (and so is the chain
         // queued behind this one: its rows went where this one's belong)
         unqueue_followers(c);
         if (f.forked) (void)hipStreamSynchronize(c->sl[f.slot].side);
         f.queued = f.forked = false;
         if (cs.overflow & OVF_PAIRS) {
-            if (cs.n_pairs >= 0xfffffff0ull) return fail(c, PJB_ERR_ARG, "finish: more than 2^32 spliced pairs on one target are not supported");
+            if (cs.n_pairs >= 0xfffffff0ull)
+                return fail(c, PJB_ERR_ARG, group ? "finish_group: more than 2^32 spliced pairs in one group: finish its targets in smaller groups"
+                                                  : "finish: more than 2^32 spliced pairs on one target are not supported");
             lim.pair_limit = (u32)cs.n_pairs + 64;
             lim.junc_limit = std::max<u32>(lim.junc_limit, lim.pair_limit / 8);
         }
         if (cs.overflow & OVF_KEYFMT) {
-            if (cs.min_pos < 0 || cs.max_end > ref_len || cs.max_end < 0) {
+            const bool weird = cs.min_pos < 0 || cs.max_end > ref_len || cs.max_end < 0;
+            if (weird && group) { // (k1_count reports INT32_MAX for a member whose alignments leave it)
+                *redo_single = true;
+                return PJB_OK;
+            }
+            if (weird) {
                 lim.kf.raw = 1;
                 lim.kf.lbits = 32;
                 lim.kf.total_bits = 64;
@@ -1601,16 +1674,51 @@ int pjb_finish_contig_end(pjb_ctx *c, int32_t tid, pjb_region_result *res) {
         if (cs.overflow & OVF_DENSE) lim.dense = false; // a donor with more alternative acceptors than K2d keeps: sort the full keys
     }
     if (!lim.kf.raw) c->lbits_seen = std::max(c->lbits_seen, std::max(1, bits_of((uint64_t)cs.max_nlen)));
-    R.spliced = cs.spliced;
-    R.unspliced = cs.unspliced;
-    R.sum_len = cs.sum_len;
-    R.min_len = cs.min_len;
-    R.max_len = cs.max_len;
-    R.n_reads = f.n_reads;
-    R.n_pairs = (int64_t)cs.n_pairs;
     const u32 P = cs.P, J = cs.J;
-    R.n_junctions = J;
-    c->junc_seen = std::max(c->junc_seen, J);
+    // ---- one result per member
+    pjb_region_result Rsum;
+    memset(&Rsum, 0, sizeof Rsum);
+    Rsum.min_len = INT32_MAX;
+    if (!group) {
+        pjb_region_result &R = res[0];
+        R.spliced = cs.spliced;
+        R.unspliced = cs.unspliced;
+        R.sum_len = cs.sum_len;
+        R.min_len = cs.min_len;
+        R.max_len = cs.max_len;
+        R.n_reads = f.n_reads;
+        R.n_pairs = (int64_t)cs.n_pairs;
+        R.n_junctions = J;
+        Rsum = R;
+    } else {
+        const MemberStats *ms = (const MemberStats *)(S.pub + PUB_MEMBERS_AT);
+        u64 pairs = 0, juncs = 0;
+        for (int m = 0; m < n_members; m++) {
+            pjb_region_result &R = res[m];
+            memset(&R, 0, sizeof R);
+            R.min_len = INT32_MAX;
+            if (f.m_reads[(size_t)m] == 0) continue;
+            R.spliced = ms[m].spliced;
+            R.unspliced = ms[m].unspliced;
+            R.sum_len = ms[m].sum_len;
+            R.min_len = ms[m].min_len;
+            R.max_len = ms[m].max_len;
+            R.n_reads = f.m_reads[(size_t)m];
+            R.n_pairs = (int64_t)ms[m].n_pairs;
+            R.n_junctions = ms[m].n_junc;
+            pairs += ms[m].n_pairs;
+            juncs += ms[m].n_junc;
+        }
+        if (pairs != cs.n_pairs || juncs != J)
+            return fail(c, PJB_ERR_STATE, "finish_group: members hold %llu pairs / %llu junctions, the chain %llu / %u", (unsigned long long)pairs,
+                        (unsigned long long)juncs, (unsigned long long)cs.n_pairs, J);
+        Rsum.spliced = cs.spliced;
+        Rsum.unspliced = cs.unspliced;
+        Rsum.sum_len = cs.sum_len;
+        Rsum.min_len = cs.min_len;
+        Rsum.max_len = cs.max_len;
+    }
+    c->junc_seen = std::max(c->junc_seen, group ? J / (u32)n_members : J);
     c->timing.sort_passes = f.n_pass;
     c->timing.generic_pairs = 0;
     for (u32 k = 0; k < GEN_SHARDS; k++) c->timing.generic_pairs += ((const u32 *)(S.pub + PUB_GEN_AT))[k];
@@ -1624,16 +1732,16 @@ int pjb_finish_contig_end(pjb_ctx *c, int32_t tid, pjb_region_result *res) {
     if (c->mirror) { // the rows are in the exchange slot already (k6_rows_out); the header follows, covered by a small wait
         const size_t need = PJB_MIRROR_HEADER_BYTES + (c->mirror_rows + J) * sizeof(pjb_junction_row);
         if (need > c->mirror_cap) return fail(c, PJB_ERR_ARG, "finish: %zu rows do not fit the row mirror (%zu bytes)", c->mirror_rows + J, c->mirror_cap);
-        mirror_fold(c, R, J);
+        mirror_fold(c, Rsum, J);
         HIP_TRY(c, hipMemcpyAsync(c->mirror, c->mirror_hdr, PJB_MIRROR_HEADER_BYTES, hipMemcpyHostToDevice, c->stream4));
         HIP_TRY(c, hipStreamSynchronize(c->stream4));
     }
-    if (J) { // the contig's rows: HBM table -> host table, by DMA, behind whatever the caller does next
+    if (J) { // the chain's rows: HBM table -> host table, by DMA, behind whatever the caller does next
         HIP_TRY(c, hipMemcpyAsync(c->rows_pinned + old, c->rows_table + old, (size_t)J * sizeof(pjb_junction_row), hipMemcpyDeviceToHost, c->stream4));
         c->rows_copy_pending = true;
     }
     c->cur_slot = f.slot;
-    if (c->extra && (rc = extra_contig(c, tid, batches, f.n_reads, cs.spliced, P, J, f.sidx, f.pr.g, old))) return rc;
+    if (c->extra && (rc = extra_contig(c, tid, f.batches, f.n_reads, cs.spliced, P, J, f.sidx, f.pr.g, old))) return rc;
     c->rows_n = old + J;
     c->last_rows_n = J;
     c->last_slot = f.slot;
@@ -1641,21 +1749,91 @@ int pjb_finish_contig_end(pjb_ctx *c, int32_t tid, pjb_region_result *res) {
     if (c->ktime && c->ktime_only.empty())
         for (int k = 0; k < 7; k++) (void)hipEventElapsedTime(&c->timing.stage_ms[k], S.ev[k], S.ev[k + 1]);
     (void)hipEventElapsedTime(&c->timing.total_ms, S.ev[0], S.ev[7]);
-    if (res) *res = R;
+    return PJB_OK;
+}
+
+static int end_flight(pjb_ctx *c, const int32_t *tids, int32_t n, pjb_region_result *res, const char *who) {
+    if (!c) return PJB_ERR_ARG;
+    if (!tids || n < 1) return fail(c, PJB_ERR_ARG, "%s: no targets", who);
+    bool same = c->n_fl > 0 && (int32_t)c->fl[0].tids.size() == n;
+    for (int32_t k = 0; same && k < n; k++) same = c->fl[0].tids[(size_t)k] == tids[k];
+    if (!same)
+        return fail(c, PJB_ERR_STATE, "%s: target %d (and the %d named with it) is not the oldest queued chain (begin first; collect in the same order, "
+                                      "with the same targets)", who, tids[0], n - 1);
+    c->cur_tid = tids[0];
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    struct Closer { // also on every error path: the side stream (k4a_simple) may still read the contig's batches
+        pjb_ctx *c;
+        bool ok = false;
+        ~Closer() {
+            if (!ok) { // whatever is queued is in an unknown place now
+                (void)hipDeviceSynchronize();
+                unqueue_followers(c);
+            }
+            const std::vector<int32_t> members = c->fl[0].tids;
+            pop_flight(c);
+            for (int32_t t : members) close_contig(c, t);
+        }
+    } closer{c};
+    std::vector<pjb_region_result> tmp((size_t)n);
+    for (auto &R : tmp) {
+        memset(&R, 0, sizeof R);
+        R.min_len = INT32_MAX;
+    }
+    memset(&c->timing, 0, sizeof c->timing);
+    c->last_rows_n = 0;
+    if (res) memcpy(res, tmp.data(), tmp.size() * sizeof(pjb_region_result));
+    int rc;
+    if (c->fl[0].empty) {
+        rc = mirror_header_only(c, tmp[0]);
+        closer.ok = rc == PJB_OK;
+        return rc;
+    }
+    bool redo_single = false;
+    if ((rc = collect_flight(c, tmp.data(), &redo_single))) return rc;
+    if (redo_single) {
+        // a member holds alignments outside its own sequence: the members go through one by one, in this chain's slot
+        const Flight whole = c->fl[0];
+        size_t rows_total = 0;
+        for (int32_t m = 0; m < n; m++) {
+            Flight one = Flight();
+            one.slot = whole.slot;
+            one.tid = whole.tids[(size_t)m];
+            one.tids.assign(1, one.tid);
+            prepare_flight(c, one);
+            c->fl[0] = one;
+            if (one.empty) continue;
+            bool again = false;
+            rc = collect_flight(c, &tmp[(size_t)m], &again);
+            if (rc) {
+                c->fl[0] = whole; // (the closer releases every member)
+                return rc;
+            }
+            rows_total += c->last_rows_n;
+        }
+        c->fl[0] = whole;
+        c->fl[0].queued = c->fl[0].forked = false;
+        c->last_rows_n = rows_total; // (pjb_collect_device covers the last member only: a caller of groups uses pjb_collect)
+    }
+    if (res) memcpy(res, tmp.data(), tmp.size() * sizeof(pjb_region_result));
     closer.ok = true;
     // followers that were taken back (or waited for this one) are queued now, in order, the first one's place known
     if (!c->extra) {
-        f.queued = false; // (fl[0] is still this contig: its rows are collected, it is not "ahead" of anything)
+        c->fl[0].queued = false; // (fl[0] is still this chain: its rows are collected, it is not "ahead" of anything)
         for (int k = 1; k < c->n_fl; k++) {
             Flight &g = c->fl[k];
             if (g.queued || g.empty) continue;
-            auto it = c->open.find(g.tid);
-            // a follower that cannot be queued here is queued again -- and reports its error -- by its own
-            // pjb_finish_contig_end; THIS target is collected and its rows are in the table
-            if (it != c->open.end() && queue_contig(c, g, it->second.batches)) break;
+            // a follower that cannot be queued here is queued again -- and reports its error -- by its own _end; THIS
+            // chain is collected and its rows are in the table
+            if (queue_contig(c, g)) break;
         }
     }
     return PJB_OK;
+}
+
+int pjb_finish_contig_end(pjb_ctx *c, int32_t tid, pjb_region_result *res) { return end_flight(c, &tid, 1, res, "finish"); }
+int pjb_finish_group_end(pjb_ctx *c, const int32_t *tids, int32_t n_tids, pjb_region_result *results) {
+    return end_flight(c, tids, n_tids, results, "finish_group");
 }
 
 int pjb_finish_contig(pjb_ctx *c, int32_t tid, pjb_region_result *res) {

@@ -113,6 +113,53 @@ __device__ __forceinline__ u64 pack_res(u32 minMatch, u32 mmes, u32 mis) {
 }
 constexpr u32 RES_FIELD_MAX = 0xfffffu; // anchors longer than this take the generic path
 
+// ---------------------------------------------------------------------------------------------
+// Target GROUPS ("super-chains").  A chain of 45 kernels over one 8 M-read target leaves most of the chip idle in most of
+// its kernels; several targets finished together are ONE chain over a virtual sequence in which member i occupies
+// [voff_i, voff_i + len_i) (offsets 64-aligned, a gap between members).  k1_emit adds the offset to every coordinate it
+// emits, so keys, sort, grouping, anchors and reductions never see the difference -- an intron key still names one
+// junction of one target, and key order is (member, start, end).  Only what touches a target's OWN data converts back:
+// the genome of a pair / junction (k4a_simple, k4b_generic, k5_finalize look the member up by position) and the rows
+// (refid, local coordinates).  A single target is a group of one with offset 0.
+// ---------------------------------------------------------------------------------------------
+constexpr int GROUP_MAX = 32;
+constexpr int32_t GROUP_GAP = 4096;
+struct GroupTab {
+    int32_t n;
+    int32_t voff[GROUP_MAX]; // ascending
+    int32_t len[GROUP_MAX];
+    int32_t tid[GROUP_MAX];
+    const uint8_t *d[GROUP_MAX];   // upper-cased bases
+    const u32 *codes[GROUP_MAX];   // 4-bit codes (nullptr: exotic member)
+};
+struct Member {
+    int32_t idx, voff, len, tid;
+    const uint8_t *d;
+    const u32 *codes;
+};
+__device__ __forceinline__ Member member_of(const GroupTab &T, int32_t vpos) {
+    int m = 0;
+    if (T.n > 1) {
+#pragma unroll
+        for (int s = GROUP_MAX / 2; s >= 1; s >>= 1)
+            if (m + s < T.n && T.voff[m + s] <= vpos) m += s;
+    }
+    Member M;
+    M.idx = m;
+    M.voff = T.voff[m];
+    M.len = T.len[m];
+    M.tid = T.tid[m];
+    M.d = T.d[m];
+    M.codes = T.codes[m];
+    return M;
+}
+// per-member counters of a group (what pjb_region_result reports per target)
+struct MemberStats {
+    u64 spliced, unspliced, sum_len, n_pairs;
+    int32_t min_len, max_len;
+    u32 n_junc, _pad;
+};
+
 // key packing: normal case (start << lbits) | intron_len, fallback raw (start << 32) | (u32)end
 struct KeyFmt {
     int raw;   // 1 = raw 64-bit (weird coordinates present)
@@ -448,8 +495,11 @@ __global__ __launch_bounds__(256) void k0_encode(const uint8_t *g, int64_t n, u3
 // ---------------------------------------------------------------------------------------------
 constexpr int K1_TILE = 1024;
 
+// chk_ref_len > 0 (members of a group): a tile with an alignment that ends past the target reports max_end = INT32_MAX, so
+// that k1_scan_tiles sees "weird coordinates" whatever the group's virtual length is (the host then finishes the
+// members one by one).
 __global__ __launch_bounds__(256) void k1_count(DevBatch b, u32 *tile_cnt, TileStats *tile_stats, u32 *spl_idx,
-                                                 u32 *spl_poff, u64 *err) {
+                                                 u32 *spl_poff, u64 *err, int32_t chk_ref_len) {
     __shared__ u64 sm64[4];
     __shared__ u64 sm_scan4[4][4];
     __shared__ int32_t smi[4][6];
@@ -582,6 +632,7 @@ __global__ __launch_bounds__(256) void k1_count(DevBatch b, u32 *tile_cnt, TileS
         t.max_end = max(max(smi[0][2], smi[1][2]), max(smi[2][2], smi[3][2]));
         t.max_nlen = max(max(smi[0][3], smi[1][3]), max(smi[2][3], smi[3][3]));
         t.min_pos = min(min(smi[0][4], smi[1][4]), min(smi[2][4], smi[3][4]));
+        if (chk_ref_len > 0 && t.max_end > chk_ref_len) t.max_end = INT32_MAX;
         t._pad = 0;
         tile_stats[b.tile_base + blockIdx.x] = t;
         tile_cnt[b.tile_base + blockIdx.x] = (u32)(p >> 32);
@@ -867,9 +918,11 @@ __device__ __forceinline__ u32 read_meta(u32 flag, u32 xs, u32 mapq, int32_t pos
 // Thread per spliced read (dense, from the list k1_count compacted).  The read's CIGAR is fetched
 // once (8 independent loads into an LDS column, the walks below then run at LDS latency); one walk
 // writes every field of the read's pairs.
+// voff: the target's offset in its group's virtual sequence (0 for a single target); every coordinate a pair carries is
+// virtual, the per-read predicates are evaluated on the record's own coordinates.
 __global__ __launch_bounds__(256) void k1_emit(DevBatch b, const u32 *tile_off, const TileStats *tile_stats,
                                                 const u32 *spl_idx, const u32 *spl_poff, Pairs P, KeyFmt kf, int32_t ref_len,
-                                                int32_t tid, int orientation, u64 *err, const ContigStats *cs) {
+                                                int32_t tid, int orientation, u64 *err, const ContigStats *cs, int32_t voff) {
     __shared__ u32 s_ops[OPS_LDS][256];
     if (cs->P == 0) return; // no pairs, or a limit was exceeded: the contig is repeated with larger buffers
     const u32 tile = b.tile_base + blockIdx.x;
@@ -891,6 +944,7 @@ __global__ __launch_bounds__(256) void k1_emit(DevBatch b, const u32 *tile_off, 
         R.g = b.base + (u32)r;
         R.off = toff + spl_poff[slot];
         R.meta = read_meta(b.flag[r], (u32)b.xs[r], b.mapq[r], R.pos, b.mtid[r], b.mpos[r], tid, orientation);
+        R.pos += voff;
         u32 nN = 0;
         int32_t aligned = 0;
         for (u32 q = 0; q < n; q++) {
@@ -905,7 +959,55 @@ __global__ __launch_bounds__(256) void k1_emit(DevBatch b, const u32 *tile_off, 
         const u32 so = b.seq_off[r];
         R.seq_ok = (u64)(b.seq_off[r + 1] - so) * 8ull >= (u64)(int64_t)R.lq;
         R.seq_ptr = (u64)(uintptr_t)(b.seq4 + (size_t)so * 4);
-        emit_read_pairs(cig, R, P, kf, ref_len, err);
+        emit_read_pairs(cig, R, P, kf, voff + ref_len, err);
+    }
+}
+
+// per-member counters of a group, from the tile statistics of the member's tiles (before k1_scan_tiles turns the tile pair
+// counts into offsets): one block per member
+__global__ __launch_bounds__(256) void kg_member_stats(const u32 *tile_cnt, const TileStats *ts, const u32 *tile_lo, int n_members, MemberStats *out) {
+    __shared__ u64 sm[4][4];
+    __shared__ int32_t smi[4][2];
+    const int m = blockIdx.x;
+    if (m >= n_members) return;
+    u64 spl = 0, uns = 0, sum = 0, pairs = 0;
+    int32_t mn = INT32_MAX, mx = 0;
+    for (u32 t = tile_lo[m] + threadIdx.x; t < tile_lo[m + 1]; t += 256) {
+        const TileStats x = ts[t];
+        spl += x.spliced;
+        uns += x.unspliced;
+        sum += x.sum_len;
+        pairs += tile_cnt[t];
+        mn = min(mn, x.min_len);
+        mx = max(mx, x.max_len);
+    }
+    spl = wave_sum(spl);
+    uns = wave_sum(uns);
+    sum = wave_sum(sum);
+    pairs = wave_sum(pairs);
+    mn = wave_min(mn);
+    mx = wave_max(mx);
+    const int w = threadIdx.x >> 6;
+    if (lane_id() == 0) {
+        sm[w][0] = spl;
+        sm[w][1] = uns;
+        sm[w][2] = sum;
+        sm[w][3] = pairs;
+        smi[w][0] = mn;
+        smi[w][1] = mx;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        MemberStats S;
+        S.spliced = sm[0][0] + sm[1][0] + sm[2][0] + sm[3][0];
+        S.unspliced = sm[0][1] + sm[1][1] + sm[2][1] + sm[3][1];
+        S.sum_len = sm[0][2] + sm[1][2] + sm[2][2] + sm[3][2];
+        S.n_pairs = sm[0][3] + sm[1][3] + sm[2][3] + sm[3][3];
+        S.min_len = min(min(smi[0][0], smi[1][0]), min(smi[2][0], smi[3][0]));
+        S.max_len = max(max(smi[0][1], smi[1][1]), max(smi[2][1], smi[3][1]));
+        S.n_junc = 0; // (counted by k5_finalize)
+        S._pad = 0;
+        out[m] = S;
     }
 }
 
@@ -2047,17 +2149,25 @@ __device__ __forceinline__ const DevBatch &find_batch(const DevBatch *batches, i
 // against genome[iend+1, iend+1+b); neither depends on the junction-level window, the walk rules
 // of bam_alignment.cc:341-462 reduce to exactly this for the shape.  Everything a pair needs is in the pair arrays
 // (k1_emit left the address of the read's bases there): one round of coalesced loads, then the bases.
-__global__ __launch_bounds__(256) void k4a_simple(Pairs P, KeyFmt kf, const u32 *gcodes, int32_t glen, const u32 *np, u64 *res) {
+__global__ __launch_bounds__(256) void k4a_simple(Pairs P, KeyFmt kf, GroupTab G, const u32 *np, u64 *res) {
     const u32 n = *np;
     const u32 p = blockIdx.x * 256 + threadIdx.x;
     if (p >= n) return;
     const u32 meta = P.meta[p];
     const u64 key = P.key[p];
-    const int32_t pos = P.pos[p], rend = P.rend[p];
+    int32_t pos = P.pos[p], rend = P.rend[p];
     const u32 *seqw = reinterpret_cast<const u32 *>((uintptr_t)P.seqw[p]);
     if (!(meta & META_SIMPLE)) return;
     int32_t istart, iend;
     unpack_key(kf, key, istart, iend);
+    // the pair's target: its codes, and the target's own coordinates from here on
+    const Member M = member_of(G, pos);
+    const u32 *gcodes = M.codes;
+    const int32_t glen = M.len;
+    pos -= M.voff;
+    rend -= M.voff;
+    istart -= M.voff;
+    iend -= M.voff;
     const int32_t a = istart - pos, bb = rend - iend;
     const int32_t dS = (int32_t)((meta >> META_DS_SHIFT) & 0xfffu);
     const int32_t g_words = (glen + 7) / 8 + 1;
@@ -2082,8 +2192,8 @@ __global__ __launch_bounds__(256) void k4a_simple(Pairs P, KeyFmt kf, const u32 
 // thread per entry of a compacted list of sorted positions; needs the junction-level anchors.
 __global__ __launch_bounds__(256) void k4b_generic(const u32 *list, const u32 *n_list, u32 pair_blocks, const u64 *skey, const u32 *sidx,
                                                     const u32 *jid_of, Pairs P, KeyFmt kf, const DevBatch *batches, int n_batches,
-                                                    const int32_t *anc_l, const int32_t *anc_r, const uint8_t *genome,
-                                                    int32_t glen, int genome_has_x, const u32 *gcodes, u64 *res, u64 *err) {
+                                                    const int32_t *anc_l, const int32_t *anc_r, GroupTab G, int genome_has_x, int use_codes,
+                                                    u64 *res, u64 *err) {
     __shared__ u32 s_ops[OPS_LDS][256];
     // sub-list `shard` occupies [shard * cap, shard * cap + n_list[shard]); pair_blocks is the K3 grid size
     const u32 cap = ((pair_blocks + GEN_SHARDS - 1) / GEN_SHARDS) * 256;
@@ -2104,7 +2214,9 @@ __global__ __launch_bounds__(256) void k4b_generic(const u32 *list, const u32 *n
     cig.lds = &s_ops[0][threadIdx.x];
 #pragma unroll
     for (int k = 0; k < OPS_LDS; k++) s_ops[k][threadIdx.x] = (u32)k < nc ? cig.g[k] : 0u;
-    const int32_t pos = P.pos[p], aend = P.aend[p];
+    const int32_t vpos = P.pos[p], aend = P.aend[p];
+    const Member M = member_of(G, vpos); // the pair's target: everything below is in the target's own coordinates
+    const int32_t pos = vpos - M.voff;
     const int32_t lq = b.l_qseq[r];
     const u32 words = b.seq_off[r + 1] - b.seq_off[r];
     if (lq > 1 && (u64)words * 8ull < (u64)lq) {
@@ -2113,8 +2225,8 @@ __global__ __launch_bounds__(256) void k4b_generic(const u32 *list, const u32 *n
         return;
     }
     const uint8_t *seq = b.seq4 + (size_t)b.seq_off[r] * 4;
-    res[p] = pair_stats_generic(cig, nc, pos, aend - pos + 1, seq, lq, genome, glen, genome_has_x != 0, gcodes, anc_l[j],
-                                istart, iend, anc_r[j], g, err);
+    res[p] = pair_stats_generic(cig, nc, pos, aend - vpos + 1, seq, lq, M.d, M.len, genome_has_x != 0, use_codes ? M.codes : (const u32 *)nullptr,
+                                anc_l[j] - M.voff, istart - M.voff, iend - M.voff, anc_r[j] - M.voff, g, err);
 }
 
 // fragment record: 48 words
@@ -2332,9 +2444,10 @@ __global__ __launch_bounds__(256) void k5_frag_reduce(const u32 *frag, const int
     flush(cur);
 }
 __global__ __launch_bounds__(256) void k5_init_acc(u32 *acc, const u32 *n_junc_p, int32_t *anc_l, int32_t *anc_r, int32_t *frag_j,
-                                                    const u32 *n_slots_p) {
+                                                    const u32 *n_slots_p, u32 *member_junc) {
     const u32 n_junc = *n_junc_p, n_slots = *n_slots_p;
     const u32 t = blockIdx.x * 256 + threadIdx.x;
+    if (t < (u32)GROUP_MAX) member_junc[t] = 0;
     if (t < n_slots) frag_j[t] = -1; // unused fragment slot
     if (t < n_junc * F_WORDS) acc[t] = (t % F_WORDS) == F_FIRSTMIS ? 100000000u : 0u;
     if (t < n_junc) {
@@ -2424,9 +2537,8 @@ __global__ __launch_bounds__(256) void k5_entropy_sum(const u32 *run_first, cons
 
 __global__ __launch_bounds__(256) void k5_finalize(const u64 *pair_key, const u32 *sidx, const u32 *seg_off, const u32 *run_first,
                                                     const u32 *run_start, const u32 *acc, const int32_t *anc_l,
-                                                    const int32_t *anc_r, KeyFmt kf, const uint8_t *genome, int32_t glen,
-                                                    int32_t tid, const u32 *n_junc_p, const double *ent_sum, pjb_junction_row *rows,
-                                                    u64 *err) {
+                                                    const int32_t *anc_r, KeyFmt kf, GroupTab G, const u32 *n_junc_p, const double *ent_sum,
+                                                    pjb_junction_row *rows, u64 *err, u32 *member_junc) {
     const u32 n_junc = *n_junc_p;
     const u32 j = blockIdx.x * 256 + threadIdx.x;
     if (j >= n_junc) return;
@@ -2436,11 +2548,25 @@ __global__ __launch_bounds__(256) void k5_finalize(const u64 *pair_key, const u3
     int32_t istart, iend;
     const u32 s0 = seg_off[j];
     unpack_key(kf, pair_key[sidx[s0]], istart, iend);
-    R.refid = tid;
+    // the junction's target: rows carry the target's own coordinates
+    const Member M = member_of(G, istart);
+    const uint8_t *genome = M.d;
+    const int32_t glen = M.len;
+    istart -= M.voff;
+    iend -= M.voff;
+    if (G.n > 1) { // junctions per member: neighbouring junctions share their member, so one add per wavefront and member
+        const int m0 = __builtin_amdgcn_readfirstlane(M.idx);
+        const u64 same = __ballot(M.idx == m0);
+        if (M.idx == m0) {
+            if (lane_id() == __ffsll((long long)same) - 1) atomicAdd(&member_junc[m0], (u32)__popcll(same));
+        } else
+            atomicAdd(&member_junc[M.idx], 1u);
+    }
+    R.refid = M.tid;
     R.start = istart;
     R.end = iend;
-    R.left = anc_l[j];
-    R.right = anc_r[j];
+    R.left = anc_l[j] - M.voff;
+    R.right = anc_r[j] - M.voff;
     const u32 n = a[F_N];
     R.nb_raw = n;
     R.nb_dist = a[F_DIST];
@@ -2610,10 +2736,16 @@ __global__ __launch_bounds__(256) void k6_rows_out(const u64 *rows, const Contig
 // The last kernel of a contig: control block, error word and list counters go to page-locked host memory in one go
 // (three small copies otherwise), error word and counters return to their rest state for the contig that uses this
 // control slot next, and the row cursor moves on.
-constexpr int PUB_BASE_AT = 240, PUB_ERR_AT = 256, PUB_GEN_AT = 512, PUB_BYTES = 2048; // byte offsets in the published block
+constexpr int PUB_BASE_AT = 240, PUB_ERR_AT = 256, PUB_GEN_AT = 512, PUB_MEMBERS_AT = 1536, PUB_BYTES = 4096; // byte offsets in the published block
+static_assert(PUB_MEMBERS_AT + GROUP_MAX * sizeof(MemberStats) <= PUB_BYTES && sizeof(MemberStats) % 8 == 0, "control block layout");
 __global__ __launch_bounds__(256) void k7_publish(const ContigStats *cs, u64 *err, u32 *gencount, uint8_t *host, int64_t base, int64_t mirror_base,
-                                                  RowCursor *cur) {
+                                                  RowCursor *cur, const MemberStats *members, const u32 *member_junc, int n_members) {
     const u32 t = threadIdx.x;
+    if (n_members > 1 && t < (u32)n_members) { // a group: the members' own counters
+        MemberStats S = members[t];
+        S.n_junc = member_junc[t];
+        reinterpret_cast<MemberStats *>(host + PUB_MEMBERS_AT)[t] = S;
+    }
     static_assert(sizeof(ContigStats) % 8 == 0 && sizeof(ContigStats) <= PUB_BASE_AT, "control block layout");
     static_assert(PUB_GEN_AT + GEN_SHARDS * 4 <= PUB_BYTES, "control block layout");
     if (t < sizeof(ContigStats) / 8) reinterpret_cast<u64 *>(host)[t] = reinterpret_cast<const u64 *>(cs)[t];

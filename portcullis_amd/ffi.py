@@ -22,7 +22,7 @@ STAGE_NAMES = ["scan_emit", "sort", "group", "anchors", "pair_stats", "finalize"
 EXPORTS = [
     "pjb_create", "pjb_destroy", "pjb_last_error", "pjb_set_refs", "pjb_upload_contig", "pjb_upload_contig_device", "pjb_upload_contig_fasta",
     "pjb_release_contig", "pjb_submit_batch", "pjb_submit_batch_device", "pjb_finish_contig", "pjb_finish_contig_begin",
-    "pjb_finish_contig_end", "pjb_collect",
+    "pjb_finish_contig_end", "pjb_finish_group_begin", "pjb_finish_group_end", "pjb_collect",
     "pjb_clear_rows", "pjb_get_timing", "pjb_device_count", "pjb_get_kernel_timing", "pjb_reset_kernel_timing",
     "pjb_select_timed_kernels", "pjb_host_alloc", "pjb_host_free", "pjb_inflate_bgzf", "pjb_submit_bam", "pjb_collect_device", "pjb_set_row_mirror",
     "pjb_extra_finish", "pjb_set_option", "pjb_bam_begin", "pjb_bam_piece", "pjb_bam_pieces_done", "pjb_bam_end", "pjb_bam_inflate_done", "pjb_filter_set_junctions", "pjb_filter_batch", "pjb_filt_features",
@@ -126,6 +126,8 @@ def load():
         L.pjb_bam_end.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_int64)]
         L.pjb_finish_contig_begin.argtypes = [C.c_void_p, C.c_int32]
         L.pjb_finish_contig_end.argtypes = [C.c_void_p, C.c_int32, C.POINTER(PjbRegionResult)]
+        L.pjb_finish_group_begin.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.c_int32]
+        L.pjb_finish_group_end.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.c_int32, C.POINTER(PjbRegionResult)]
         L.pjb_set_row_mirror.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
         L.pjb_collect_device.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
         L.pjb_inflate_bgzf.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
@@ -274,6 +276,27 @@ class Context:
         finally:
             self._keep_batch.pop(tid, None)
         return {k: getattr(r, k) for k, _ in PjbRegionResult._fields_}
+
+    def finish_group_begin(self, tids):
+        """Queue ONE kernel chain over several targets (pjb_finish_group_begin); collect with finish_group_end(tids)."""
+        arr = (C.c_int32 * len(tids))(*tids)
+        try:
+            self._check(self._L.pjb_finish_group_begin(self._h, arr, len(tids)))
+        except Exception:
+            for t in tids:
+                self._keep_batch.pop(t, None)
+            raise
+
+    def finish_group_end(self, tids):
+        """-> {tid: region result} for the group queued with the same tids."""
+        arr = (C.c_int32 * len(tids))(*tids)
+        res = (PjbRegionResult * len(tids))()
+        try:
+            self._check(self._L.pjb_finish_group_end(self._h, arr, len(tids), res))
+        finally:
+            for t in tids:
+                self._keep_batch.pop(t, None)
+        return {t: {k: getattr(res[i], k) for k, _ in PjbRegionResult._fields_} for i, t in enumerate(tids)}
 
     def collect(self, copy=True):
         """Rows built so far.  copy=False returns a view of the context's pinned buffer that is only
@@ -433,3 +456,24 @@ def run_contig(ctx, tid, genome, batches):
         ctx.submit_batch(tid, b)
     reg = ctx.finish_contig(tid)
     return ctx.collect(), reg
+
+
+GROUP_MAX = 32  # PJB_GROUP_MAX
+GROUP_GAP = 4096
+
+
+def plan_groups(ref_lens, tids, max_bases=1 << 30):
+    """Consecutive runs of `tids` whose sequences (plus the gap pjb_finish_group_begin leaves between members) stay below
+    `max_bases` and PJB_GROUP_MAX members: the groups a caller hands to finish_group_begin.  GRCh38's 25 sequences in
+    index order give three groups of about 1 Gb."""
+    groups, cur, tot = [], [], 0
+    for t in tids:
+        span = ((max(int(ref_lens[t]), 1) + GROUP_GAP) + 63) & ~63
+        if cur and (tot + span > max_bases or len(cur) >= GROUP_MAX):
+            groups.append(cur)
+            cur, tot = [], 0
+        cur.append(t)
+        tot += span
+    if cur:
+        groups.append(cur)
+    return groups

@@ -8,6 +8,7 @@
 #include <chrono>
 #include <condition_variable>
 #include <deque>
+#include <functional>
 #include <future>
 #include <cstdlib>
 #include <cstring>
@@ -410,7 +411,9 @@ private:
             pjb_config cfg;
             memset(&cfg, 0, sizeof cfg);
             cfg.abi_version = PJB_ABI_VERSION;
-            cfg.device = device;
+            // PORTCULLIS_DEVICES_SHARE_GPU=1: every device thread of a --devices N run uses GPU 0 (a one-GPU box walks through
+            // the N-device code path: worker -> device thread assignment, N contexts, the host merge; never a measurement)
+            cfg.device = getenv("PORTCULLIS_DEVICES_SHARE_GPU") ? 0 : device;
             cfg.orientation = (int32_t)orientation;
             cfg.strandedness = (int32_t)strandedness;
             if (extra) cfg.flags |= PJB_FLAG_EXTRA;
@@ -708,7 +711,24 @@ void JunctionBuilder::findJuncs(DeviceThread& device, BamReader& reader, GenomeM
     std::string decodeError;
     bool any = false;
     double t_blocked = 0;
+    // raised by the decoder thread when the target's file pieces are all on their way (or it has stopped): the genome is
+    // needed when the target is finished, the pieces are needed now -- until then this target's genome leaves the cores, the
+    // page-locking calls and PCIe to the pieces (PORTCULLIS_GENOME_EARLY=1: both at once, as before)
+    std::promise<void> piecesGone;
+    std::shared_future<void> piecesGoneF = piecesGone.get_future().share();
+    bool piecesGoneSet = false;
+    auto raisePiecesGone = [&] {
+        if (!piecesGoneSet) {
+            piecesGoneSet = true;
+            piecesGone.set_value();
+        }
+    };
+    const bool genomeLate = deviceIngest && pinnedPool && !getenv("PORTCULLIS_GENOME_EARLY");
     std::thread decoder([&] {
+        struct Raise {
+            std::function<void()> f;
+            ~Raise() { f(); }
+        } raiseAtExit{raisePiecesGone};
         auto send = [&](bam::ReadBatch& b) {
             const double tb0 = HostProfile::now();
             DeviceThread::Cmd c;
@@ -843,6 +863,7 @@ void JunctionBuilder::findJuncs(DeviceThread& device, BamReader& reader, GenomeM
                     c.bamDone = &got;
                     device.push(std::move(c));
                     leave.now();  // the next target's pieces cross while this one is inflated and parsed
+                    raisePiecesGone();
                     // (the ring gets this target's buffers back as their copies complete, not when its records are parsed)
                     while (f.wait_for(std::chrono::microseconds(200)) != std::future_status::ready) releaseDone(false);
                     any = f.get() > 0;
@@ -893,6 +914,7 @@ void JunctionBuilder::findJuncs(DeviceThread& device, BamReader& reader, GenomeM
     std::string genomeError;
     double t_genome = 0;
     try {
+        if (genomeLate) piecesGoneF.wait();
         const double t0 = HostProfile::now();
         // large runs: the record's bytes go to the device as they are in the file (a pread into a page-locked buffer; the
         // device takes the line terminators out) -- parsing 3 GB of FASTA on the host was 6 core-seconds at the very moment
@@ -1052,7 +1074,8 @@ void JunctionBuilder::findJunctions() {
             // the device count is only known once HIP is up; until then assume one GPU per requested device
             int nd = 1;
             if (ndevWanted > 1 || devices == 0) {
-                const int visible = deviceCount.get();
+                int visible = deviceCount.get();
+                if (getenv("PORTCULLIS_DEVICES_SHARE_GPU") && visible > 0 && ndevWanted > 0) visible = ndevWanted;
                 nd = std::max(1, std::min(ndevWanted > 0 ? ndevWanted : visible, std::min(visible, nthreads)));
             }
             // two contexts (device threads, streams) per GPU: while one target's kernels run, the other target's

@@ -260,6 +260,16 @@ def test_contexts_per_gpu(tmp_path, orc, per_gpu, monkeypatch):
     check(prep, tmp_path, orc, "RF", threads=5, extra_opts=("--ingest", "device", "--devices", "1"))
 
 
+@pytest.mark.parametrize("ingest", ["device", "host"])
+def test_two_device_threads_share_one_gpu(tmp_path, orc, ingest, monkeypatch):
+    """`junc --devices 2` on a one-GPU box: PORTCULLIS_DEVICES_SHARE_GPU=1 points both device threads (two contexts, the
+    targets dealt out between them, the host-side merge of their tables: src/junction_builder.cc:258-269) at GPU 0.  Same
+    files as the oracle's -- the multi-GPU path of the program, minus the second GPU."""
+    monkeypatch.setenv("PORTCULLIS_DEVICES_SHARE_GPU", "1")
+    prep = multi_contig(tmp_path, [91, 92, 93, None, 94, 95], block_size=20000)
+    p, _ = check(prep, tmp_path, orc, "FR", threads=6, extra_opts=("--ingest", ingest, "--devices", "2"))
+
+
 @pytest.mark.parametrize("ingest", ["host", "device"])
 def test_extra_metrics_cli(tmp_path, orc, ingest):
     """`junc --extra`: mm_score, coverage, up_aln, down_aln columns of the .tab equal the oracle's, with the records
