@@ -132,7 +132,7 @@ struct CtlSlot {
     hipEvent_t ev_k1 = nullptr;
     // the rest of the chain's scratch, and its streams: the chains of the two slots run side by side (most kernels of a
     // contig-sized chain are latency-bound and leave the chip half idle)
-    Buf total, bitmap, wrank, ends, firstid, key[2], idx[2], hist, hist_scan, bintotal, scan_tiles;
+    Buf total, bitmap, wrank, ends, firstid, key[2], idx[2], hist, hist_scan, hist_part, bintotal, scan_tiles;
     Buf jid, seg, runfirst, runstart, ent, entsum, frag, fragj, fragl, fragr, acc, ancl, ancr, genlist;
     bool dense_at_rest = false;
     hipStream_t main = nullptr, side = nullptr; // chain; match statistics / entropy beside it
@@ -620,7 +620,7 @@ void pjb_destroy(pjb_ctx *c) {
         if (S.ev_done) (void)hipEventDestroy(S.ev_done);
         Buf *sb[] = {&S.cstats, &S.err, &S.gencount, &S.batches, &S.rows, &S.tile_cnt, &S.tile_stats, &S.splidx, &S.splpoff, &S.k1look, &S.members, &S.okey, &S.g,
                      &S.lstart, &S.rend, &S.pos, &S.aend, &S.meta, &S.updown, &S.seqw, &S.res, &S.total, &S.bitmap, &S.wrank, &S.ends, &S.firstid,
-                     &S.key[0], &S.key[1], &S.idx[0], &S.idx[1], &S.hist, &S.hist_scan, &S.bintotal, &S.scan_tiles, &S.jid, &S.seg, &S.runfirst,
+                     &S.key[0], &S.key[1], &S.idx[0], &S.idx[1], &S.hist, &S.hist_scan, &S.hist_part, &S.bintotal, &S.scan_tiles, &S.jid, &S.seg, &S.runfirst,
                      &S.runstart, &S.ent, &S.entsum, &S.frag, &S.fragj, &S.fragl, &S.fragr, &S.acc, &S.ancl, &S.ancr, &S.genlist};
         for (Buf *b : sb) release(*b);
         hipEvent_t evs[] = {S.ev_k1, S.ev_fork, S.ev_join, S.ev_fork2, S.ev_join2};
@@ -1331,6 +1331,7 @@ static int queue_contig(pjb_ctx *c, Flight &f) {
     if ((rc = ensure(c, S.hist, (size_t)rs_tiles * (1u << dbits) * 4))) return rc;
     if ((rc = ensure(c, S.hist_scan, (size_t)rs_tiles * (1u << dbits) * 4))) return rc;
     if ((rc = ensure(c, S.bintotal, (size_t)4 << dbits))) return rc;
+    if ((rc = ensure(c, S.hist_part, (size_t)((rs_tiles + RSP_TILES - 1) / RSP_TILES) * (1u << dbits) * 4))) return rc;
     int cur = 0, shift = 0;
     for (int p = 0; p < n_pass; p++) {
         const int bits = pass_bits[(size_t)p];
@@ -1340,8 +1341,12 @@ static int queue_contig(pjb_ctx *c, Flight &f) {
         const u32 *vin = p == 0 ? nullptr : (const u32 *)S.idx[cur].p;
         u32 *vout = (u32 *)S.idx[cur ^ 1].p;
         LAUNCH(c, "rs_hist", rs_hist, dim3(rs_tiles), dim3(256), kin, d_P, shift, bits, (u32 *)S.hist.p, rs_tiles);
-        LAUNCH(c, "rs_rowscan", rs_rowscan, dim3(1u << bits), dim3(256), (const u32 *)S.hist.p, rs_tiles,
-               (u32 *)S.hist_scan.p, (u32 *)S.bintotal.p);
+        {
+            const u32 nb = 1u << bits, n_panels = (rs_tiles + RSP_TILES - 1) / RSP_TILES;
+            LAUNCH(c, "rs_panel_sums", rs_panel_sums, dim3(n_panels, (nb + 255) / 256), dim3(256), (const u32 *)S.hist.p, rs_tiles, nb, (u32 *)S.hist_part.p);
+            LAUNCH(c, "rs_panel_scan", rs_panel_scan, dim3(n_panels, (nb + 255) / 256), dim3(256), (const u32 *)S.hist.p, (const u32 *)S.hist_part.p, rs_tiles, nb,
+                   (u32 *)S.hist_scan.p, (u32 *)S.bintotal.p);
+        }
 #define RS_SCATTER(B)                                                                                                     \
     LAUNCH_LDS(c, "rs_scatter", rs_scatter<B>, dim3(rs_tiles), dim3(256), rs_scatter_lds_bytes(bits), kin, vin, kout, vout, d_P, \
                shift, bits, (const u32 *)S.hist_scan.p, (const u32 *)S.bintotal.p, rs_tiles)

@@ -1526,28 +1526,57 @@ __global__ __launch_bounds__(256) void rs_hist(const u64 *keys, const u32 *np, i
         wave_hist_add(h, (u32)(kk[k] >> shift) & mask, i < n);
     }
     __syncthreads();
-    for (u32 d = threadIdx.x; d < nb; d += 256) hist[(size_t)d * n_tiles + blockIdx.x] = h[d];
+    // tile-major: a tile's counts are one contiguous run (bin-major, every 4-byte store was a write granule of its own:
+    // twice the algorithmic traffic, PMC round 2), and rs_scatter reads its tile's scanned counts the same way
+    for (u32 d = threadIdx.x; d < nb; d += 256) hist[(size_t)blockIdx.x * nb + d] = h[d];
 }
 
-// One block per digit value: exclusive scan of that digit's row of per-tile counts (tile order) and
-// the row total.  The scatter adds the number of keys with a smaller digit itself (a block scan of
-// the 2^bits totals), so the pass needs neither a scan of the whole matrix nor global atomics.
-__global__ __launch_bounds__(256) void rs_rowscan(const u32 *hist, u32 n_tiles, u32 *hist_scan, u32 *row_total) {
-    __shared__ u32 sm[4];
-    const u32 d = blockIdx.x;
-    u32 run = 0;
-    const u32 *row = hist + (size_t)d * n_tiles;
-    u32 *out = hist_scan + (size_t)d * n_tiles;
-    for (u32 t0 = 0; t0 < n_tiles; t0 += 256) {
-        const u32 t = t0 + threadIdx.x;
-        const u32 v = t < n_tiles ? row[t] : 0u;
-        u32 tot;
-        const u32 ex = block_escan_256<u32>(v, sm, &tot);
-        if (t < n_tiles) out[t] = run + ex;
-        run += tot;
-        __syncthreads();
+// Exclusive scan over the tiles of every digit's counts (tile order) and the digit totals, on the tile-major matrix, in two
+// small kernels over PANELS of RSP_TILES tiles x 64 digits (one wavefront each, lane = digit, so every load is 256
+// contiguous bytes of a tile's row): rs_panel_sums adds up each panel's columns; rs_panel_scan lets every panel add the
+// sums of the panels before it itself (a few hundred at most) and writes its tiles' exclusive counts; the last panel
+// also leaves the digit totals.  (One block per digit walking all tiles -- round 2 -- took 8 us for one chromosome's 650
+// tiles and 144 us for a 0.5 Gb chain's 4 400.)  The scatter adds the number of keys with a smaller digit itself (a
+// block scan of the 2^bits totals), so the pass needs neither a scan of the whole matrix nor global atomics.
+constexpr u32 RSP_TILES = 64;
+__global__ __launch_bounds__(256) void rs_panel_sums(const u32 *hist, u32 n_tiles, u32 nb, u32 *psum) {
+    const u32 d = blockIdx.y * 256 + threadIdx.x;
+    if (d >= nb) return;
+    const u32 t0 = blockIdx.x * RSP_TILES, t1 = t0 + RSP_TILES < n_tiles ? t0 + RSP_TILES : n_tiles;
+    u32 sum = 0;
+    for (u32 t = t0; t < t1; t += 8) { // eight loads in flight per lane
+        u32 v[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) v[k] = t + k < t1 ? hist[(size_t)(t + k) * nb + d] : 0u;
+#pragma unroll
+        for (int k = 0; k < 8; k++) sum += v[k];
     }
-    if (threadIdx.x == 0) row_total[d] = run;
+    psum[(size_t)blockIdx.x * nb + d] = sum;
+}
+__global__ __launch_bounds__(256) void rs_panel_scan(const u32 *hist, const u32 *psum, u32 n_tiles, u32 nb, u32 *hist_scan, u32 *row_total) {
+    const u32 d = blockIdx.y * 256 + threadIdx.x;
+    if (d >= nb) return;
+    const u32 panel = blockIdx.x;
+    u32 run = 0;
+    for (u32 q = 0; q < panel; q += 8) {
+        u32 v[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) v[k] = q + k < panel ? psum[(size_t)(q + k) * nb + d] : 0u;
+#pragma unroll
+        for (int k = 0; k < 8; k++) run += v[k];
+    }
+    const u32 t0 = panel * RSP_TILES, t1 = t0 + RSP_TILES < n_tiles ? t0 + RSP_TILES : n_tiles;
+    for (u32 t = t0; t < t1; t += 8) {
+        u32 v[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) v[k] = t + k < t1 ? hist[(size_t)(t + k) * nb + d] : 0u;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            if (t + k < t1) hist_scan[(size_t)(t + k) * nb + d] = run;
+            run += v[k];
+        }
+    }
+    if (t1 == n_tiles) row_total[d] = run; // (the last panel)
 }
 
 // LDS of one rs_scatter block: the tile's keys in digit order (reused for the pair indices), the offset
@@ -1625,7 +1654,7 @@ __global__ __launch_bounds__(256, 4) void rs_scatter(const u64 *kin, const u32 *
         const u32 d = d0 + k;
         const bool on = (u32)k < per && d < nb;
         pf_rt[k] = on ? row_total[d] : 0u;
-        pf_hs[k] = on ? hist_scan[(size_t)d * n_tiles + tile] : 0u;
+        pf_hs[k] = on ? hist_scan[(size_t)tile * nb + d] : 0u;
     }
 #pragma unroll
     for (int r = 0; r < RS_ITEMS; r++) {
@@ -1670,7 +1699,7 @@ __global__ __launch_bounds__(256, 4) void rs_scatter(const u64 *kin, const u32 *
         if (d >= nb) break;
         const u32 c0 = wcnt[d], c1 = wcnt[nb + d], c2 = wcnt[2 * nb + d], c3 = wcnt[3 * nb + d];
         // first output slot of this tile's keys with digit d
-        const u32 gfirst = dbase + (k < RS_PF ? pf_hs[k < RS_PF ? k : 0] : hist_scan[(size_t)d * n_tiles + tile]);
+        const u32 gfirst = dbase + (k < RS_PF ? pf_hs[k < RS_PF ? k : 0] : hist_scan[(size_t)tile * nb + d]);
         dbase += k < RS_PF ? pf_rt[k < RS_PF ? k : 0] : row_total[d];
         delta[d] = gfirst - tstart;
         wcnt[d] = (unsigned short)tstart;

@@ -118,23 +118,38 @@ def test_group_with_empty_targets_and_order(ffi, orc):
 
 def test_group_member_with_alignments_outside_its_sequence(ffi, orc):
     """An alignment that runs past the end of its own target must not see the next member's bases: the group is taken apart
-    and its members finished one by one (same rows as singles)."""
+    and its members are finished one by one -- which reports exactly what finishing that target alone reports (here the
+    reference's "anchor region ... not the same size" condition, an error in the oracle as well)."""
     contigs = _contigs(orc, (61, 62), "UNKNOWN", paired=False)
-    glen = 3000
-    rng = np.random.default_rng(5)
-    genome = "".join(rng.choice(list("ACGT"), size=glen))
-    reads = [dict(pos=100 + 3 * k, cigar="30M200N30M", seq="A" * 60, xs="+", flag=0) for k in range(40)]
-    reads.append(dict(pos=glen - 40, cigar="30M100N30M", seq="C" * 60, xs="+", flag=0))  # right anchor beyond the end
-    odd = ReadBatch.from_reads(reads)
-    orows, oreg = orc.find_juncs(2, glen, genome, odd, "UNKNOWN")
-    three = [contigs[0], contigs[1], (genome, odd, orows, oreg)]
+    from fixtures_micro import read_from_genome
+    rng = np.random.default_rng(99)
+    genome = "".join(rng.choice(list("ACGT"), size=6000))
+    glen = len(genome)
+    odd = ReadBatch.from_reads([read_from_genome(genome, 5900, "50M100N60M")])  # (test_gpu_edge_cases: read_runs_off_contig_end)
+    with pytest.raises(orc.OracleError):
+        orc.find_juncs(2, glen, genome, odd, "UNKNOWN")
+    three = [contigs[0], contigs[1], (genome, odd, None, None)]
     with ffi.Context(0, "UNKNOWN") as ctx:
-        srows, sregs = _singles(ctx, three)
-        assert_rows_equal(srows[srows["refid"] == 2], orows)
-        rows, regs = _grouped(ctx, three, [[0, 2, 1]])
+        _setup(ctx, three)
+        ctx.submit_batch(2, odd)
+        with pytest.raises(ffi.PjbError) as single:
+            ctx.finish_contig(2)
+    with ffi.Context(0, "UNKNOWN") as ctx:
+        _setup(ctx, three)
         for tid in range(3):
-            assert regs[tid] == sregs[tid]
-            assert rows[rows["refid"] == tid].tobytes() == srows[srows["refid"] == tid].tobytes()
+            ctx.submit_batch(tid, three[tid][1])
+        ctx.finish_group_begin([0, 2, 1])
+        with pytest.raises(ffi.PjbError) as grouped:
+            ctx.finish_group_end([0, 2, 1])
+        assert grouped.value.code == single.value.code, (grouped.value, single.value)
+        # the context goes on: the two healthy targets as a group
+        ctx.clear_rows()
+        ctx.submit_batch(0, three[0][1])
+        ctx.submit_batch(1, three[1][1])
+        ctx.finish_group_begin([0, 1])
+        regs = ctx.finish_group_end([0, 1])
+        region_equal(regs[0], three[0][3])
+        assert_rows_equal(ctx.collect(), np.concatenate([three[0][2], three[1][2]]))
 
 
 def test_group_refusals(ffi, orc):
