@@ -252,9 +252,12 @@ def test_c5_whole_on_one_gpu():
     from oracle import oracle as orc
     from portcullis_amd import ffi, synth
 
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()  # (what earlier tests of this process left in torch's caching allocator)
     free, _ = torch.cuda.mem_get_info()
-    if free < 150e9:
-        pytest.skip("needs ~120 GB of free HBM")
+    if free < 125e9:
+        pytest.skip(f"needs ~120 GB of free HBM, {free / 1e9:.0f} GB are free")
     cfgs = synth.c3_contig_configs(1_000_000_000, 300_000)
     lens = [c.contig_len for c in cfgs]
     with ffi.Context(0, "FR", strandedness=1) as ctx:          # PJB_SS_FIRSTSTRAND: accepted, no effect on junc output
