@@ -195,6 +195,7 @@ def main():
     for tid in mine:
         contigs[tid] = load_contig(tid, ctx)
     torch.cuda.synchronize()
+    torch.cuda.empty_cache()  # the generator's temporaries go back to the driver (the library allocates with hipMalloc, not through torch)
     t_gen = time.time() - t_gen
     hbm_gb = torch.cuda.memory_allocated() / 1e9
     N_mine = sum(c["n"] for c in contigs.values())

@@ -124,7 +124,7 @@ struct CtlSlot {
     Buf cstats, err, gencount, batches, rows;
     // what the first kernels of a contig (k1_count, k1_scan_tiles, k1_emit: the front stream) write and the rest of its
     // chain reads: the next contig's first kernels run beside this contig's last ones
-    Buf tile_cnt, tile_stats, splidx, splpoff;
+    Buf tile_cnt, tile_stats, splidx, splpoff, tile_soff, chunk_tile;
     Buf k1look; // k1_walk: ticket counter, tile and group descriptors
     Buf members; // groups: MemberStats[GROUP_MAX] | member_junc u32[GROUP_MAX] | tile_lo u32[GROUP_MAX + 1]
     Buf okey, g, lstart, rend, pos, aend, meta, updown, seqw; // the pairs (BAM order)
@@ -618,7 +618,7 @@ void pjb_destroy(pjb_ctx *c) {
         for (auto &ev : S.ev) (void)hipEventDestroy(ev);
         if (S.ev_rows) (void)hipEventDestroy(S.ev_rows);
         if (S.ev_done) (void)hipEventDestroy(S.ev_done);
-        Buf *sb[] = {&S.cstats, &S.err, &S.gencount, &S.batches, &S.rows, &S.tile_cnt, &S.tile_stats, &S.splidx, &S.splpoff, &S.k1look, &S.members, &S.okey, &S.g,
+        Buf *sb[] = {&S.cstats, &S.err, &S.gencount, &S.batches, &S.rows, &S.tile_cnt, &S.tile_stats, &S.splidx, &S.splpoff, &S.tile_soff, &S.chunk_tile, &S.k1look, &S.members, &S.okey, &S.g,
                      &S.lstart, &S.rend, &S.pos, &S.aend, &S.meta, &S.updown, &S.seqw, &S.res, &S.total, &S.bitmap, &S.wrank, &S.ends, &S.firstid,
                      &S.key[0], &S.key[1], &S.idx[0], &S.idx[1], &S.hist, &S.hist_scan, &S.hist_part, &S.bintotal, &S.scan_tiles, &S.jid, &S.seg, &S.runfirst,
                      &S.runstart, &S.ent, &S.entsum, &S.frag, &S.fragj, &S.fragl, &S.fragr, &S.acc, &S.ancl, &S.ancr, &S.genlist};
@@ -1113,6 +1113,8 @@ static int queue_contig(pjb_ctx *c, Flight &f) {
     if ((rc = ensure(c, c->b_cursor, sizeof(RowCursor)))) return rc;
     if ((rc = ensure(c, S.tile_cnt, (size_t)n_tiles * 4))) return rc;
     if ((rc = ensure(c, S.tile_stats, (size_t)n_tiles * sizeof(TileStats)))) return rc;
+    if ((rc = ensure(c, S.tile_soff, ((size_t)n_tiles + 1) * 4))) return rc;
+    if ((rc = ensure(c, S.chunk_tile, ((size_t)n_tiles * (K1_TILE / 256) + 4) * 4))) return rc;
     const bool fused_k1 = c->fused_k1 && !group; // (the one-pass walk is a single-target experiment)
     const bool want_splidx = !fused_k1 || c->extra; // (--extra reads the tiles' spliced lists)
     if (want_splidx && (rc = ensure(c, S.splidx, (size_t)n_tiles * K1_TILE * 4))) return rc;
@@ -1243,7 +1245,7 @@ static int queue_contig(pjb_ctx *c, Flight &f) {
                    want_splidx ? (u32 *)S.splidx.p : (u32 *)nullptr, pr, kf, ref_len, f.tid, (int)c->cfg.orientation, PL, d_err);
         }
         LAUNCH(c, "k1_scan_tiles", k1_scan_tiles, dim3(1), dim3(1024), (u32 *)nullptr, (const TileStats *)S.tile_stats.p, n_tiles, d_cs, PL, kf,
-               ref_len, (const u64 *)lk.tile_desc);
+               ref_len, (const u64 *)lk.tile_desc, (u32 *)nullptr, (u32 *)nullptr);
     } else {
         // ---- K1a: count (a group's members: a tile whose alignments leave the member's own sequence is flagged)
         for (size_t bi = 0; bi < batches.size(); bi++) {
@@ -1257,15 +1259,17 @@ static int queue_contig(pjb_ctx *c, Flight &f) {
             LAUNCH(c, "kg_member_stats", kg_member_stats, dim3((unsigned)n_members), dim3(256), (const u32 *)S.tile_cnt.p, (const TileStats *)S.tile_stats.p,
                    (const u32 *)d_tile_lo, n_members, d_members);
         LAUNCH(c, "k1_scan_tiles", k1_scan_tiles, dim3(1), dim3(1024), (u32 *)S.tile_cnt.p, (const TileStats *)S.tile_stats.p, n_tiles, d_cs,
-               PL, kf, group ? INT32_MAX - 1 : ref_len, (const u64 *)nullptr);
+               PL, kf, group ? INT32_MAX - 1 : ref_len, (const u64 *)nullptr, (u32 *)S.tile_soff.p, (u32 *)S.chunk_tile.p);
         // ---- K1b: emit (coordinates in the group's virtual sequence)
         for (size_t bi = 0; bi < batches.size(); bi++) {
             const DevBatch &b = batches[bi];
             const int m = f.batch_member[bi];
             const int32_t own_tid = f.tids[(size_t)m], own_len = c->ref_len[(size_t)own_tid];
             const u32 nt = (u32)((b.n + K1_TILE - 1) / K1_TILE);
-            LAUNCH(c, "k1_emit", k1_emit, dim3(nt), dim3(256), b, (const u32 *)S.tile_cnt.p,
-                   (const TileStats *)S.tile_stats.p, (const u32 *)S.splidx.p, (const u32 *)S.splpoff.p, pr, kf, own_len,
+            // (a tile holds ~300 spliced reads = 1.2 chunks of 256: a grid of half the tiles keeps two or three chunks per block)
+            const u32 grid = std::max<u32>(1, std::min<u32>(nt, std::max<u32>(1024, nt / 2)));
+            LAUNCH(c, "k1_emit", k1_emit, dim3(grid), dim3(256), b, nt, n_tiles, (const u32 *)S.tile_cnt.p, (const u32 *)S.tile_soff.p,
+                   (const u32 *)S.chunk_tile.p, (const u32 *)S.splidx.p, (const u32 *)S.splpoff.p, pr, kf, own_len,
                    own_tid, (int)c->cfg.orientation, d_err, (const ContigStats *)d_cs, f.voff[(size_t)m]);
         }
     }

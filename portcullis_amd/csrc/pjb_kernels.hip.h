@@ -642,10 +642,15 @@ __global__ __launch_bounds__(256) void k1_count(DevBatch b, u32 *tile_cnt, TileS
 // single block: exclusive scan of per-tile pair counts (in place) + reduction of tile stats
 // (tile_desc != nullptr: the tiles of k1_walk placed their pairs themselves -- only the total is taken, from their
 // descriptors, and nothing is written back)
+// tile_soff / chunk_tile (both may be nullptr): the tiles' spliced reads seen as ONE dense list -- tile_soff[t] = spliced reads
+// before tile t (n_tiles + 1 entries), chunk_tile[c] = the tile that holds list entry 256 c -- for k1_emit's dense mapping.
 __global__ __launch_bounds__(1024) void k1_scan_tiles(u32 *tile_cnt, const TileStats *ts, u32 n_tiles, ContigStats *out, u32 pair_limit,
-                                                       KeyFmt kf, int32_t ref_len, const u64 *tile_desc) {
+                                                       KeyFmt kf, int32_t ref_len, const u64 *tile_desc, u32 *tile_soff, u32 *chunk_tile) {
     __shared__ u64 wsum[16];
+    __shared__ u32 wsum2[16];
+    __shared__ u32 carry2_s;
     __shared__ u64 carry_s;
+    if (threadIdx.x == 0) carry2_s = 0;
     __shared__ u64 r_spl[16], r_uns[16], r_sum[16];
     __shared__ int32_t r_i[16][5];
     if (threadIdx.x == 0) carry_s = 0;
@@ -655,9 +660,11 @@ __global__ __launch_bounds__(1024) void k1_scan_tiles(u32 *tile_cnt, const TileS
     for (u32 base = 0; base < n_tiles; base += 1024) {
         u32 i = base + threadIdx.x;
         u64 v = 0;
+        u32 v2 = 0; // spliced reads of the tile
         if (i < n_tiles) {
             v = tile_desc ? (tile_desc[i] & ((1ull << 40) - 1)) : (u64)tile_cnt[i];
             TileStats t = ts[i];
+            v2 = t.spliced;
             spl += t.spliced;
             uns += t.unspliced;
             sum += t.sum_len;
@@ -668,22 +675,42 @@ __global__ __launch_bounds__(1024) void k1_scan_tiles(u32 *tile_cnt, const TileS
             min_pos = min(min_pos, t.min_pos);
         }
         u64 inc = wave_iscan(v);
+        u32 inc2 = wave_iscan(v2);
         int w = threadIdx.x >> 6;
-        if (lane_id() == 63) wsum[w] = inc;
+        if (lane_id() == 63) {
+            wsum[w] = inc;
+            wsum2[w] = inc2;
+        }
         __syncthreads();
         u64 wb = 0, tot = 0;
+        u32 wb2 = 0, tot2 = 0;
         for (int k = 0; k < 16; k++) {
             u64 s = wsum[k];
-            if (k < w) wb += s;
+            u32 s2 = wsum2[k];
+            if (k < w) {
+                wb += s;
+                wb2 += s2;
+            }
             tot += s;
+            tot2 += s2;
         }
         u64 carry = carry_s;
+        const u32 carry2 = carry2_s;
         // NOTE: exclusive offsets are stored as 32-bit: a contig is limited to < 2^32 pairs
         if (i < n_tiles && !tile_desc) tile_cnt[i] = (u32)(carry + wb + inc - v);
+        if (i < n_tiles && tile_soff) {
+            const u32 so = carry2 + wb2 + inc2 - v2;
+            tile_soff[i] = so;
+            for (u32 c = (so + 255u) >> 8; (c << 8) < so + v2; c++) chunk_tile[c] = i; // list entries 256 c that fall into this tile
+        }
         __syncthreads();
-        if (threadIdx.x == 0) carry_s = carry + tot;
+        if (threadIdx.x == 0) {
+            carry_s = carry + tot;
+            carry2_s = carry2 + tot2;
+        }
         __syncthreads();
     }
+    if (threadIdx.x == 0 && tile_soff) tile_soff[n_tiles] = carry2_s;
     spl = wave_sum(spl);
     uns = wave_sum(uns);
     sum = wave_sum(sum);
@@ -918,18 +945,48 @@ __device__ __forceinline__ u32 read_meta(u32 flag, u32 xs, u32 mapq, int32_t pos
 // Thread per spliced read (dense, from the list k1_count compacted).  The read's CIGAR is fetched
 // once (8 independent loads into an LDS column, the walks below then run at LDS latency); one walk
 // writes every field of the read's pairs.
+// Thread per spliced read of the batch, DENSE: the tiles' spliced lists (k1_count compacted them per tile) are walked as one
+// list -- entry s lies in the tile t with tile_soff[t] <= s < tile_soff[t + 1], found from chunk_tile (the tile of entry
+// 256 * chunk) and a short walk -- so every thread of every block has a read.  (Round 2 looped over a tile's list with 256
+// threads: a tile holds ~300 spliced reads, so the second trip ran 44 lanes wide: 58 % of the lanes did anything.)  The grid
+// is fixed; blocks stride over the batch's chunks.
 // voff: the target's offset in its group's virtual sequence (0 for a single target); every coordinate a pair carries is
 // virtual, the per-read predicates are evaluated on the record's own coordinates.
-__global__ __launch_bounds__(256) void k1_emit(DevBatch b, const u32 *tile_off, const TileStats *tile_stats,
-                                                const u32 *spl_idx, const u32 *spl_poff, Pairs P, KeyFmt kf, int32_t ref_len,
+constexpr int K1E_LOOK = 16;
+__global__ __launch_bounds__(256) void k1_emit(DevBatch b, u32 n_tiles_batch, u32 n_tiles_total, const u32 *tile_off, const u32 *tile_soff,
+                                                const u32 *chunk_tile, const u32 *spl_idx, const u32 *spl_poff, Pairs P, KeyFmt kf, int32_t ref_len,
                                                 int32_t tid, int orientation, u64 *err, const ContigStats *cs, int32_t voff) {
     __shared__ u32 s_ops[OPS_LDS][256];
+    __shared__ u32 s_soff[K1E_LOOK];
     if (cs->P == 0) return; // no pairs, or a limit was exceeded: the contig is repeated with larger buffers
-    const u32 tile = b.tile_base + blockIdx.x;
-    const u32 nspl = tile_stats[tile].spliced;
-    const u32 toff = tile_off[tile];
-    for (u32 ks = threadIdx.x; ks < nspl; ks += 256) {
-        const size_t slot = (size_t)tile * K1_TILE + ks;
+    const u32 s_begin = tile_soff[b.tile_base], s_end = tile_soff[b.tile_base + n_tiles_batch];
+    if (s_begin == s_end) return;
+    const u32 c_lo = s_begin >> 8, c_hi = (s_end + 255u) >> 8;
+    for (u32 chunk = c_lo + blockIdx.x; chunk < c_hi; chunk += gridDim.x) {
+        // the tile of the chunk's first entry (for the batch's first chunk: of the batch's first entry)
+        const u32 s0 = (chunk << 8) < s_begin ? s_begin : (chunk << 8);
+        u32 t0 = (chunk << 8) < s_begin ? b.tile_base : chunk_tile[chunk];
+        __syncthreads();
+        if (threadIdx.x < K1E_LOOK) s_soff[threadIdx.x] = t0 + threadIdx.x <= n_tiles_total ? tile_soff[t0 + threadIdx.x] : 0xffffffffu;
+        __syncthreads();
+        (void)s0;
+        const u32 s = (chunk << 8) + threadIdx.x;
+        if (s < s_begin || s >= s_end) continue;
+        u32 k = 0;
+        while (k + 1 < (u32)K1E_LOOK && s >= s_soff[k + 1]) k++;
+        u32 tile = t0 + k, soff = s_soff[k];
+        if (k + 1 == (u32)K1E_LOOK && s >= soff) { // (a run of tiles without spliced reads longer than the window: search)
+            u32 lo = tile, hi = n_tiles_total; // tile_soff[lo] <= s < tile_soff[hi]
+            while (hi - lo > 1) {
+                const u32 mid = (lo + hi) >> 1;
+                if (tile_soff[mid] <= s) lo = mid;
+                else hi = mid;
+            }
+            tile = lo;
+            soff = tile_soff[lo];
+        }
+        const u32 toff = tile_off[tile];
+        const size_t slot = (size_t)tile * K1_TILE + (s - soff);
         const int64_t r = spl_idx[slot];
         const u32 c0 = b.cig_off[r], c1 = b.cig_off[r + 1];
         const u32 n = c1 - c0;
@@ -937,7 +994,7 @@ __global__ __launch_bounds__(256) void k1_emit(DevBatch b, const u32 *tile_off, 
         cig.g = b.cigar + c0;
         cig.lds = &s_ops[0][threadIdx.x];
 #pragma unroll
-        for (int k = 0; k < OPS_LDS; k++) s_ops[k][threadIdx.x] = (u32)k < n ? cig.g[k] : 0u;
+        for (int q = 0; q < OPS_LDS; q++) s_ops[q][threadIdx.x] = (u32)q < n ? cig.g[q] : 0u;
         EmitRead R;
         R.n = n;
         R.pos = b.pos[r];

@@ -17,6 +17,11 @@
 int main(int argc, char* argv[]) {
     // exit codes as in src/portcullis.cc:497-515 of the reference
     int rc = 0;
+    // The program keeps ~15 HIP streams busy at once (file pieces, four inflate streams, the service stream, two per queued
+    // chain, rows); the runtime maps them onto 4 hardware queues unless told otherwise, and streams that share a queue wait
+    // for each other.  8 queues: end to end 2.36 -> 2.18 s median of 7 (profiles/r03o_e2e_hw_queues.txt).  Read by the
+    // runtime when it starts, so it is set before anything touches HIP; a value the user exported wins.
+    setenv("GPU_MAX_HW_QUEUES", "8", 0);
     if (getenv("PJB_PROFILE_HOST")) {
         struct timespec ts;
         clock_gettime(CLOCK_REALTIME, &ts);
