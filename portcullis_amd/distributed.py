@@ -74,164 +74,9 @@ def allgather_rows(rows, device, group=None):
     return np.concatenate(parts) if parts else np.zeros(0, dtype=rows.dtype)
 
 
-def gather_region(region, device, group=None):
-    """The same reduction as allreduce_region with ONE collective and one host sync: every rank's five counters are
-    all-gathered and folded locally."""
-    world = dist.get_world_size(group)
-    mine = torch.tensor([region["spliced"], region["unspliced"], region["sum_len"], region["min_len"], region["max_len"]],
-                        dtype=torch.int64, device=device)
-    out = torch.empty((world, 5), dtype=torch.int64, device=device)
-    dist.all_gather(list(out.unbind(0)), mine, group=group)
-    h = out.cpu()
-    return dict(spliced=int(h[:, 0].sum()), unspliced=int(h[:, 1].sum()), sum_len=int(h[:, 2].sum()),
-                min_len=int(h[:, 3].min()), max_len=int(h[:, 4].max()))
-
-
-class RegionExchange:
-    """The counters of gather_region without a host sync per call: add() launches one small asynchronous
-    all-gather per contig into its own slot, result() folds everything at the end of the run."""
-
-    def __init__(self, slots, device, group=None):
-        self.group, self.device = group, torch.device(device)
-        self.world = dist.get_world_size(group)
-        self.cuda = self.device.type == "cuda"
-        self.mine_host = torch.zeros((slots, 5), dtype=torch.int64, pin_memory=self.cuda)
-        self.mine = torch.zeros((slots, 5), dtype=torch.int64, device=self.device)
-        self.out = torch.zeros((slots, self.world, 5), dtype=torch.int64, device=self.device)
-        self.mine_np = self.mine_host.numpy()  # same memory: filled without creating tensors
-        self.nccl = dist.get_backend(group) == "nccl"
-        self.used = 0
-        self.work = []
-
-    def add(self, region):
-        k = self.used
-        if k >= self.mine.shape[0]:
-            raise ValueError("RegionExchange: more contigs than slots")
-        self.used += 1
-        self.mine_np[k] = (region["spliced"], region["unspliced"], region["sum_len"], region["min_len"], region["max_len"])
-        self.mine[k].copy_(self.mine_host[k], non_blocking=True)
-        if self.nccl:
-            self.work.append(dist.all_gather_into_tensor(self.out[k].view(-1), self.mine[k], group=self.group, async_op=True))
-        else:
-            self.work.append(dist.all_gather(list(self.out[k].unbind(0)), self.mine[k], group=self.group, async_op=True))
-
-    def result(self):
-        for w in self.work:
-            w.wait()
-        self.work = []
-        h = self.out[: self.used].cpu().reshape(-1, 5)
-        if len(h) == 0:
-            return dict(spliced=0, unspliced=0, sum_len=0, min_len=2**31 - 1, max_len=0)
-        return dict(spliced=int(h[:, 0].sum()), unspliced=int(h[:, 1].sum()), sum_len=int(h[:, 2].sum()),
-                    min_len=int(h[:, 3].min()), max_len=int(h[:, 4].max()))
-
-
-class DeviceRows:
-    """A device pointer as a torch tensor source (the rows pjb_collect_device returns)."""
-
-    def __init__(self, ptr, nbytes):
-        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
-
-
-class RowExchange:
-    """All-gather of the per-rank junction tables, device to device, off the critical path.
-
-    Rows are PODs of `row_bytes` bytes.  Every rank owns a send slot of `cap` rows plus a 16-byte header (its row
-    count) and a receive buffer of world x slot.  start() copies the rank's rows (a uint8 tensor on `device`, e.g.
-    the view of pjb_collect_device) into the send slot and launches the collective asynchronously: RCCL moves the
-    slots over xGMI while the next contig's kernels run.  Rank `root` brings the gathered buffer to page-locked host
-    memory: after every exchange on a side stream, or once in finish().  The next start() (or finish()) waits for
-    what is in flight before the buffers are reused.
-    """
-    HDR = 16
-
-    def __init__(self, row_bytes, cap_rows, device, group=None, root=0, host_copy="every"):
-        """host_copy: "every" = the root copies each gathered table to the host (asynchronously), "final" = only
-        finish() does (one copy per job: the tables of earlier exchanges stay in HBM until overwritten)."""
-        self.host_copy = host_copy
-        self.group, self.device, self.row_bytes = group, torch.device(device), row_bytes
-        self.world, self.rank, self.root = dist.get_world_size(group), dist.get_rank(group), root
-        self.cuda = self.device.type == "cuda"
-        self.work = None
-        self.copy_done = None
-        self.counts = None
-        self._alloc(cap_rows)
-        self.side = torch.cuda.Stream(device=self.device) if self.cuda else None
-
-    def _alloc(self, cap_rows):
-        self.cap = int(cap_rows)
-        self.slot = self.HDR + self.cap * self.row_bytes
-        self.send = torch.zeros(self.slot, dtype=torch.uint8, device=self.device)
-        self.recv = torch.zeros(self.world * self.slot, dtype=torch.uint8, device=self.device)
-        self.host = None
-        if self.rank == self.root:
-            self.host = torch.zeros(self.world * self.slot, dtype=torch.uint8, pin_memory=self.cuda)
-        self.count_host = torch.zeros(1, dtype=torch.int64, pin_memory=self.cuda)  # staging for the header
-        self.count_np = self.count_host.numpy()
-        self.count_u8 = self.count_host.view(torch.uint8)
-        self.send_hdr = self.send[:8]
-
-    def _wait(self):
-        if self.work is not None:
-            self.work.wait()  # the current stream waits for the collective (the host does not block on CUDA)
-            self.work = None
-        if self.copy_done is not None:
-            self.copy_done.synchronize()
-            self.copy_done = None
-
-    def start(self, rows_u8, n_rows):
-        """rows_u8: uint8 tensor with at least n_rows * row_bytes bytes on `device`."""
-        self._wait()
-        if n_rows > self.cap:  # every rank must grow together: callers size cap from a maximum agreed up front
-            raise ValueError(f"RowExchange: {n_rows} rows exceed the agreed capacity {self.cap}")
-        nb = n_rows * self.row_bytes
-        self.count_np[0] = n_rows  # (reused safely: the stream is synchronised below before start() returns)
-        self.send_hdr.copy_(self.count_u8, non_blocking=True)
-        if nb:
-            self.send[self.HDR:self.HDR + nb] = rows_u8[:nb]
-        if self.cuda:
-            # rows_u8 usually aliases a buffer its owner rewrites on another stream (pjb_collect_device): the copy
-            # out of it (microseconds) must have happened before this returns
-            torch.cuda.current_stream(self.device).synchronize()
-        else:
-            self.send_hdr.copy_(self.count_u8)  # (CPU tensors: plain copy)
-        if dist.get_backend(self.group) == "nccl":
-            self.work = dist.all_gather_into_tensor(self.recv, self.send, group=self.group, async_op=True)
-        else:
-            self.work = dist.all_gather(list(self.recv.view(self.world, self.slot).unbind(0)), self.send, group=self.group,
-                                        async_op=True)
-        if self.rank == self.root and self.host_copy == "every":
-            if self.cuda:
-                ready = torch.cuda.Event()
-                self.side.wait_stream(torch.cuda.current_stream(self.device))
-                with torch.cuda.stream(self.side):
-                    self.work.wait()  # on the side stream: the copy follows the collective, not the next kernels
-                    self.host.copy_(self.recv, non_blocking=True)
-                    ready.record(self.side)
-                self.copy_done = ready
-                # the main stream must still not overwrite send / recv before the collective is done
-            else:
-                self.work.wait()
-                self.host.copy_(self.recv)
-
-    def finish(self):
-        """Wait for the exchange in flight; on the root returns the merged table (uint8 numpy, rank order)."""
-        self._wait()
-        if self.rank == self.root and self.host_copy != "every":
-            self.host.copy_(self.recv)  # after the wait: ordered behind the collective on the current stream
-        if self.cuda:
-            torch.cuda.current_stream(self.device).synchronize()
-        if self.rank != self.root:
-            return None
-        h = self.host.numpy().reshape(self.world, self.slot)
-        counts = [int(h[r, :8].view(np.int64)[0]) for r in range(self.world)]
-        self.counts = counts
-        parts = [h[r, self.HDR:self.HDR + counts[r] * self.row_bytes] for r in range(self.world) if counts[r]]
-        return np.concatenate(parts) if parts else np.zeros(0, dtype=np.uint8)
-
-
 class MirrorExchange:
-    """RowExchange without a copy or a synchronisation of its own on the sending side: the send slots are handed to
+    """All-gather of the per-rank junction tables, device to device, without a copy or a synchronisation of its own on the
+    sending side: the send slots are handed to
     the library (pjb_set_row_mirror), whose pjb_finish_contig leaves header + rows in them, so that after
     finish_contig returns launch() only starts the asynchronous all-gather.
 

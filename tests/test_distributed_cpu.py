@@ -72,60 +72,6 @@ def test_shard_contigs_lpt():
     assert pd.shard_contigs([], 2) == [[], []]
 
 
-def _worker_exchange(rank, world, port, q):
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    dev = torch.device("cpu")
-    x = pd.RowExchange(ROW_DTYPE.itemsize, cap_rows=8, device=dev, host_copy=["every", "final"][int(os.environ.get("PJB_TEST_HOSTCOPY", "0"))])
-    outs = []
-    for step, n in enumerate([[3, 0], [8, 5], [1, 2]]):  # back-to-back exchanges reuse the slots
-        rows = _rows(rank + 10 * step, n[rank])
-        t = torch.from_numpy(rows.view(np.uint8).copy()) if n[rank] else torch.zeros(0, dtype=torch.uint8)
-        x.start(t, n[rank])
-        merged = x.finish()
-        outs.append(None if merged is None else merged.tobytes())
-    reg = dict(spliced=10 * (rank + 1), unspliced=5, sum_len=1000 * (rank + 1), min_len=50 + rank, max_len=100 + rank)
-    tot = pd.gather_region(reg, dev)
-    rx = pd.RegionExchange(3, dev)
-    for k in range(3):
-        rx.add(dict(spliced=k + rank, unspliced=1, sum_len=100 * (k + 1), min_len=40 + k + rank, max_len=90 + k + 2 * rank))
-    tot2 = rx.result()
-    assert tot2 == dict(spliced=3 + 3 + 3, unspliced=6, sum_len=1200, min_len=40, max_len=94), tot2
-    try:
-        x.start(torch.zeros(9 * ROW_DTYPE.itemsize, dtype=torch.uint8), 9)
-        over = False
-    except ValueError:
-        over = True
-    q.put((rank, outs, tot, over))
-    dist.destroy_process_group()
-
-
-@pytest.mark.parametrize("mode", [0, 1])
-def test_row_exchange_world2(mode, monkeypatch):
-    """The asynchronous device-side exchange used by bench.py --gpus N, on CPU tensors over gloo."""
-    monkeypatch.setenv("PJB_TEST_HOSTCOPY", str(mode))
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_worker_exchange, args=(r, 2, port, q)) for r in range(2)]
-    for p in procs:
-        p.start()
-    got = [q.get(timeout=120) for _ in range(2)]
-    for p in procs:
-        p.join(60)
-        assert p.exitcode == 0
-    for rank, outs, tot, over in got:
-        assert over
-        assert tot == dict(spliced=30, unspliced=10, sum_len=3000, min_len=50, max_len=101)
-        for step, n in enumerate([[3, 0], [8, 5], [1, 2]]):
-            if rank == 0:
-                expect = np.concatenate([_rows(0 + 10 * step, n[0]), _rows(1 + 10 * step, n[1])])
-                assert outs[step] == expect.tobytes()
-            else:
-                assert outs[step] is None
-
-
 def _worker_mirror(rank, world, port, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
