@@ -120,7 +120,7 @@ def main():
                     help="total reads of the 25-contig set (200 M = BASELINE configs[2]; smaller values are for tests)")
     ap.add_argument("--junctions", type=int, default=int(os.environ.get("PJB_BENCH_JUNCTIONS", 250_000)))
     ap.add_argument("--queue", type=int, default=int(os.environ.get("PJB_BENCH_QUEUE", 3)),
-                    help="contigs queued at once (pjb_finish_contig_begin / _end; at most PJB_MAX_QUEUED = 4)")
+                    help="contigs queued at once (pjb_finish_contig_begin / _end; at most PJB_MAX_QUEUED = 8)")
     ap.add_argument("--group-bases", type=int, default=int(os.environ.get("PJB_BENCH_GROUP_BASES", 1 << 29)),
                     help="targets are finished in groups (pjb_finish_group_begin: ONE kernel chain over several targets) of consecutive "
                          "targets adding up to at most this many bases -- GRCh38: seven chains of up to 0.5 Gb (measured best of 25 / 16 / 7 / 3 chains); 0: one chain per target")

@@ -233,9 +233,14 @@ int pjb_finish_contig(pjb_ctx *ctx, int32_t tid, pjb_region_result *result);
  * arrays lent by pjb_submit_batch_device) must stay as they are; batches for OTHER targets may be submitted, genomes
  * uploaded.  pjb_collect covers collected contigs only; pjb_clear_rows / pjb_set_row_mirror need an empty queue.
  * With PJB_FLAG_EXTRA one contig is queued at a time. */
-#define PJB_MAX_QUEUED 4
+#define PJB_MAX_QUEUED 8
 int pjb_finish_contig_begin(pjb_ctx *ctx, int32_t tid);
 int pjb_finish_contig_end(pjb_ctx *ctx, int32_t tid, pjb_region_result *result);
+
+/* 1 if pjb_finish_contig_end / pjb_finish_group_end for the OLDEST queued chain would not wait for the device (its kernels
+ * have completed, or nothing is queued, or the chain has to be queued again first), else 0.  Never blocks: a caller that
+ * serves several targets collects finished chains when they are ready and does something else meanwhile. */
+int pjb_finish_ready(pjb_ctx *ctx);
 
 /* Several targets finished as ONE kernel chain (a "group").  A chain of ~45 kernels over one human chromosome's 8 M
  * alignments leaves most of the chip idle in most of its kernels; the reference's answer to many small targets is its

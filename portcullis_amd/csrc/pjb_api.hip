@@ -501,6 +501,7 @@ int close_contig(pjb_ctx *c, int32_t tid) {
 
 int upload_staged(pjb_ctx *c, void *dst, const uint8_t *src, size_t bytes); // (defined with the ingest code)
 } // namespace
+static int slot_init(pjb_ctx *c, int k);
 
 extern "C" {
 
@@ -556,19 +557,11 @@ int pjb_create(pjb_ctx **out, const pjb_config *cfg) {
     (void)hipStreamCreateWithFlags(&c->stream4, hipStreamNonBlocking);
     (void)hipEventCreateWithFlags(&c->ev_front, hipEventDisableTiming);
     c->scan_tiles = &c->b_scan_tiles;
-    for (int k = 0; k < PJB_MAX_QUEUED; k++) {
-        CtlSlot &S = c->sl[k];
-        for (auto &ev : S.ev) (void)hipEventCreate(&ev);
-        (void)hipEventCreateWithFlags(&S.ev_rows, hipEventDisableTiming);
-        (void)hipEventCreateWithFlags(&S.ev_done, hipEventDisableTiming);
-        (void)hipEventCreateWithFlags(&S.ev_k1, hipEventDisableTiming);
-        (void)hipEventCreateWithFlags(&S.ev_fork, hipEventDisableTiming);
-        (void)hipEventCreateWithFlags(&S.ev_join, hipEventDisableTiming);
-        (void)hipEventCreateWithFlags(&S.ev_fork2, hipEventDisableTiming);
-        (void)hipEventCreateWithFlags(&S.ev_join2, hipEventDisableTiming);
-        (void)hipStreamCreateWithFlags(&S.main, hipStreamNonBlocking);
-        (void)hipStreamCreateWithFlags(&S.side, hipStreamNonBlocking);
-    }
+    // The first four control slots get their streams and events now; the others when they are first used (slot_init).  Creating
+    // a stream is ~10 ms on an idle device -- and blocked for 1.9 s once when it happened in the middle of an end-to-end run
+    // (the runtime creates a hardware queue behind whatever the device is doing): a caller that wants more than four chains in
+    // flight on a busy device queues that deep once, early.
+    for (int k = 0; k < 4 && k < PJB_MAX_QUEUED; k++) (void)slot_init(c, k);
     if (const char *s = getenv("PJB_INFLATE_V1")) c->inflate_v1 = atoi(s) != 0;
     const int inf_lds = c->inflate_v1 ? I2_LDS_BYTES : I3_LDS_BYTES;
     c->inflate_lanes = std::max(1, n_cu) * (160 * 1024 / inf_lds) * 64;
@@ -615,7 +608,8 @@ void pjb_destroy(pjb_ctx *c) {
         CtlSlot &S = c->sl[k];
         if (S.pub) (void)hipHostFree(S.pub);
         if (S.batches_pinned) (void)hipHostFree(S.batches_pinned);
-        for (auto &ev : S.ev) (void)hipEventDestroy(ev);
+        for (auto &ev : S.ev)
+            if (ev) (void)hipEventDestroy(ev);
         if (S.ev_rows) (void)hipEventDestroy(S.ev_rows);
         if (S.ev_done) (void)hipEventDestroy(S.ev_done);
         Buf *sb[] = {&S.cstats, &S.err, &S.gencount, &S.batches, &S.rows, &S.tile_cnt, &S.tile_stats, &S.splidx, &S.splpoff, &S.tile_soff, &S.chunk_tile, &S.k1look, &S.members, &S.okey, &S.g,
@@ -1557,6 +1551,23 @@ static void prepare_flight(pjb_ctx *c, Flight &f) {
     lim.dense = c->dense_ids;
 }
 
+// streams and events of a control slot, at its first use (a context that never queues eight chains never pays for them)
+static int slot_init(pjb_ctx *c, int k) {
+    CtlSlot &S = c->sl[k];
+    if (S.main) return PJB_OK;
+    for (auto &ev : S.ev) HIP_TRY(c, hipEventCreate(&ev));
+    HIP_TRY(c, hipEventCreateWithFlags(&S.ev_rows, hipEventDisableTiming));
+    HIP_TRY(c, hipEventCreateWithFlags(&S.ev_done, hipEventDisableTiming));
+    HIP_TRY(c, hipEventCreateWithFlags(&S.ev_k1, hipEventDisableTiming));
+    HIP_TRY(c, hipEventCreateWithFlags(&S.ev_fork, hipEventDisableTiming));
+    HIP_TRY(c, hipEventCreateWithFlags(&S.ev_join, hipEventDisableTiming));
+    HIP_TRY(c, hipEventCreateWithFlags(&S.ev_fork2, hipEventDisableTiming));
+    HIP_TRY(c, hipEventCreateWithFlags(&S.ev_join2, hipEventDisableTiming));
+    HIP_TRY(c, hipStreamCreateWithFlags(&S.side, hipStreamNonBlocking));
+    HIP_TRY(c, hipStreamCreateWithFlags(&S.main, hipStreamNonBlocking));
+    return PJB_OK;
+}
+
 static int begin_flight(pjb_ctx *c, const int32_t *tids, int32_t n, const char *who) {
     if (!c) return PJB_ERR_ARG;
     if (!tids || n < 1 || n > GROUP_MAX) return fail(c, PJB_ERR_ARG, "%s: 1 to %d targets", who, GROUP_MAX);
@@ -1594,6 +1605,10 @@ static int begin_flight(pjb_ctx *c, const int32_t *tids, int32_t n, const char *
     int slot = 0;
     while (slot < PJB_MAX_QUEUED && c->slot_busy[slot]) slot++;
     if (slot >= PJB_MAX_QUEUED) return fail(c, PJB_ERR_STATE, "%s: no free control slot", who);
+    {
+        const int rc = slot_init(c, slot);
+        if (rc) return rc;
+    }
     f = Flight();
     f.slot = slot;
     f.tid = tids[0];
@@ -1838,6 +1853,15 @@ static int end_flight(pjb_ctx *c, const int32_t *tids, int32_t n, pjb_region_res
         }
     }
     return PJB_OK;
+}
+
+int pjb_finish_ready(pjb_ctx *c) {
+    if (!c || c->n_fl <= 0) return 1;
+    const Flight &f = c->fl[0];
+    if (f.empty || !f.queued) return 1;
+    const bool done = hipEventQuery(c->sl[f.slot].ev_done) == hipSuccess;
+    (void)hipGetLastError(); // (hipErrorNotReady is not an error here)
+    return done ? 1 : 0;
 }
 
 int pjb_finish_contig_end(pjb_ctx *c, int32_t tid, pjb_region_result *res) { return end_flight(c, &tid, 1, res, "finish"); }

@@ -15,14 +15,14 @@ from .records import ORIENTATION, ReadBatch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libportcullis_amd.so")
 ABI_VERSION = 2
-MAX_QUEUED = 4  # PJB_MAX_QUEUED
+MAX_QUEUED = 8  # PJB_MAX_QUEUED
 N_STAGES = 8
 STAGE_NAMES = ["scan_emit", "sort", "group", "anchors", "pair_stats", "finalize", "d2h", "spare"]
 
 EXPORTS = [
     "pjb_create", "pjb_destroy", "pjb_last_error", "pjb_set_refs", "pjb_upload_contig", "pjb_upload_contig_device", "pjb_upload_contig_fasta",
     "pjb_release_contig", "pjb_submit_batch", "pjb_submit_batch_device", "pjb_finish_contig", "pjb_finish_contig_begin",
-    "pjb_finish_contig_end", "pjb_finish_group_begin", "pjb_finish_group_end", "pjb_collect",
+    "pjb_finish_contig_end", "pjb_finish_ready", "pjb_finish_group_begin", "pjb_finish_group_end", "pjb_collect",
     "pjb_clear_rows", "pjb_get_timing", "pjb_device_count", "pjb_get_kernel_timing", "pjb_reset_kernel_timing",
     "pjb_select_timed_kernels", "pjb_host_alloc", "pjb_host_free", "pjb_inflate_bgzf", "pjb_submit_bam", "pjb_collect_device", "pjb_set_row_mirror",
     "pjb_extra_finish", "pjb_set_option", "pjb_bam_begin", "pjb_bam_piece", "pjb_bam_pieces_done", "pjb_bam_end", "pjb_bam_inflate_done", "pjb_filter_set_junctions", "pjb_filter_batch", "pjb_filt_features",
@@ -126,6 +126,7 @@ def load():
         L.pjb_bam_end.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_int64)]
         L.pjb_finish_contig_begin.argtypes = [C.c_void_p, C.c_int32]
         L.pjb_finish_contig_end.argtypes = [C.c_void_p, C.c_int32, C.POINTER(PjbRegionResult)]
+        L.pjb_finish_ready.argtypes = [C.c_void_p]
         L.pjb_finish_group_begin.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.c_int32]
         L.pjb_finish_group_end.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.c_int32, C.POINTER(PjbRegionResult)]
         L.pjb_set_row_mirror.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
@@ -276,6 +277,10 @@ class Context:
         finally:
             self._keep_batch.pop(tid, None)
         return {k: getattr(r, k) for k, _ in PjbRegionResult._fields_}
+
+    def finish_ready(self):
+        """True if collecting the oldest queued chain would not wait for the device."""
+        return bool(self._L.pjb_finish_ready(self._h))
 
     def finish_group_begin(self, tids):
         """Queue ONE kernel chain over several targets (pjb_finish_group_begin); collect with finish_group_end(tids)."""

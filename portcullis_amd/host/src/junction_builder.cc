@@ -398,7 +398,7 @@ private:
     std::mutex mu;
     std::condition_variable cv;
     std::deque<Cmd> q;
-    size_t cap = 6;
+    size_t cap = getenv("PORTCULLIS_CMD_CAP") ? (size_t)std::max(1, atoi(getenv("PORTCULLIS_CMD_CAP"))) : 6;  // (commands waiting for the device thread; workers block when it is full)
     std::map<int32_t, std::string> failed;  // contig -> first error
     std::string fatal;                      // context creation failed
 
@@ -428,7 +428,7 @@ private:
         // the next target's upload / ingest overlaps the queued chains.  The rows of every target stay in the context's
         // table (rows arrive in queue order; rowsSoFar marks where the next target's begin).  --extra finishes one
         // target at a time (its metrics need the target's scratch untouched).
-        size_t kQueued = extra ? 1 : 3;
+        size_t kQueued = extra ? 1 : 3;  // (the library creates the streams of four control slots up front; deeper ones on a busy device cost seconds)
         if (const char* e = getenv("PJB_HOST_QUEUE")) kQueued = extra ? 1 : (size_t)std::max(1, std::min(atoi(e), (int)PJB_MAX_QUEUED));
         struct Pending {
             int32_t tid;
@@ -503,9 +503,21 @@ private:
                     have = true;
                 }
             }
+            // chains that have completed are collected at once, without ever waiting for one that has not: a chain queued beside
+            // the inflates of the next targets can take 100 ms and more (their resident workgroups hold the CUs' LDS), and a
+            // thread that sat in pjb_finish_contig_end for that long held up every other target's commands -- and, through the
+            // bounded command queue, the workers that read the file (the input stood still whenever this thread waited)
+            static const bool pollCollect = getenv("PORTCULLIS_BLOCKING_COLLECT") == nullptr;
+            while (pollCollect && !pending.empty() && ctx && pjb_finish_ready(ctx)) {
+                const double t0 = HostProfile::now();
+                const int ptid = pending.front().tid;
+                collectOldest();
+                tCollect += HostProfile::now() - t0;
+                g_prof.event(t0, HostProfile::now(), "dev" + std::to_string(profId) + " collect tid " + std::to_string(ptid));
+            }
             if (!have) {
                 std::unique_lock<std::mutex> lk(mu);
-                if (q.empty() && !pending.empty() && deferred.empty()) { // nothing to do for the next target yet: collect the oldest queued one
+                if (!pollCollect && q.empty() && !pending.empty() && deferred.empty()) { // (round 2: collect the oldest queued one, waiting for it)
                     lk.unlock();
                     const double t0 = HostProfile::now();
                     const int ptid = pending.front().tid;
@@ -517,12 +529,12 @@ private:
                 const double t0 = HostProfile::now();
                 bool again = false;
                 while (q.empty()) {
-                    if (inflight.empty() && deferred.empty()) cv.wait(lk, [&] { return !q.empty(); });
-                    else {  // a worker may be waiting for one of the pieces in flight: keep handing them back
+                    if (inflight.empty() && deferred.empty() && pending.empty()) cv.wait(lk, [&] { return !q.empty(); });
+                    else {  // a worker may be waiting for one of the pieces in flight: keep handing them back; queued chains complete
                         cv.wait_for(lk, std::chrono::microseconds(200), [&] { return !q.empty(); });
                         lk.unlock();
                         releaseDone(false);
-                        const bool ready = readyDeferred() >= 0;
+                        const bool ready = readyDeferred() >= 0 || (pollCollect && !pending.empty() && ctx && pjb_finish_ready(ctx));
                         lk.lock();
                         if (ready && q.empty()) {
                             again = true;
@@ -861,9 +873,19 @@ void JunctionBuilder::findJuncs(DeviceThread& device, BamReader& reader, GenomeM
                     c.tid = seq;
                     c.bamFirst = firstU;
                     c.bamDone = &got;
+                    const bool leaveFirst = getenv("PORTCULLIS_LEAVE_BEFORE_PUSH") != nullptr;  // (experiment; see below)
+                    if (leaveFirst) {
+                        leave.now();
+                        raisePiecesGone();
+                    }
                     device.push(std::move(c));
-                    leave.now();  // the next target's pieces cross while this one is inflated and parsed
-                    raisePiecesGone();
+                    if (!leaveFirst) {
+                        leave.now();  // the next target's pieces cross while this one is inflated and parsed
+                        raisePiecesGone();
+                    }
+                    // (Releasing the slot before the push, a command queue of 32 and one worker per target -- each harmless
+                    // alone -- together let the file run at 33-42 GB/s for half a second and then stand still for one or two:
+                    // runs of 2.1 or 4 s, profiles/r03v_e2e_scheduling_ab.txt.  More in flight is not more throughput here.)
                     // (the ring gets this target's buffers back as their copies complete, not when its records are parsed)
                     while (f.wait_for(std::chrono::microseconds(200)) != std::future_status::ready) releaseDone(false);
                     any = f.get() > 0;
@@ -1128,7 +1150,11 @@ void JunctionBuilder::findJunctions() {
     cout << " - Queueing " << refs->size() << " target sequences for processing in the thread pool" << endl;
     cout << " - Processing: " << endl;
     std::vector<std::thread> pool;
-    for (int w = 0; w < nthreads; w++) pool.emplace_back(worker, w);
+    // (PORTCULLIS_WORKER_PER_TARGET=1, an experiment: a worker belongs to its target until the target's rows are back and
+    // mostly waits; one worker per target keeps the file moving while every other worker waits for the device.  Not the
+    // default: see the note at the transfer gate.)
+    const int nworkers = pinnedPool && getenv("PORTCULLIS_WORKER_PER_TARGET") ? std::max(nthreads, std::min(withReads, 64)) : nthreads;
+    for (int w = 0; w < nworkers; w++) pool.emplace_back(worker, w);
     for (auto& t : pool) t.join();
     if (extra && firstError.empty() && !deviceThreads.empty()) {
         // calcExtraMetrics (src/junction_builder.cc:293-312): multiple mapping score, flanking alignments, coverage
