@@ -232,7 +232,7 @@ int pjb_finish_contig(pjb_ctx *ctx, int32_t tid, pjb_region_result *result);
  * run side by side on the device --; they are collected in the order they were queued and their rows land in that order.  Between the two calls the contig's batches (and device
  * arrays lent by pjb_submit_batch_device) must stay as they are; batches for OTHER targets may be submitted, genomes
  * uploaded.  pjb_collect covers collected contigs only; pjb_clear_rows / pjb_set_row_mirror need an empty queue.
- * With PJB_FLAG_EXTRA one contig is queued at a time. */
+ * PJB_FLAG_EXTRA contexts queue like any other (the target's extra metrics are queued when its chain is collected). */
 #define PJB_MAX_QUEUED 8
 int pjb_finish_contig_begin(pjb_ctx *ctx, int32_t tid);
 int pjb_finish_contig_end(pjb_ctx *ctx, int32_t tid, pjb_region_result *result);
@@ -268,7 +268,10 @@ int pjb_finish_group_end(pjb_ctx *ctx, const int32_t *tids, int32_t n_tids, pjb_
  *                (PJB_DENSE_IDS=0)
  *   "fused_k1"   0 (default): a counting pass, a scan and a second pass over the spliced records; 1: one pass over the
  *                records counts the N operations, places the tile's pairs and writes them (k1_walk; measured slower
- *                on contig-sized inputs; PJB_FUSED_K1=1) */
+ *                on contig-sized inputs; PJB_FUSED_K1=1)
+ *   "extra_dense" 0 (default): PJB_FLAG_EXTRA answers depth and flanking counts from the unspliced records themselves
+ *                (a few records per junction) and builds a target's per-base depth vector only where htslib's
+ *                8000-record pileup cap may bite; 1: the depth vector for every target (round 2's path) */
 int pjb_set_option(pjb_ctx *ctx, const char *name, int64_t value);
 
 /* All rows built so far, contig by contig in finish order, (start,end)-sorted

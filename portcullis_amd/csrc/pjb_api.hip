@@ -108,6 +108,20 @@ struct ExtraContig {
     u32 n_pairs = 0;
     u64 *spl_codes = nullptr;  // name codes of the contig's spliced records
     u32 n_spl = 0;
+    bool dense = false;        // went through the dense path: `cover` and the other pointers are allocations of their own
+    bool codes_in_table = false; // the spliced records' codes are in the name table already
+    SparseDepth sparse = {nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0}; // else: the records' spans (arena memory)
+};
+
+// what the targets of a PJB_FLAG_EXTRA context keep until pjb_extra_finish comes from a few large allocations that are
+// reused by the next file (pjb_clear_rows): no hipMalloc / hipFree per target
+struct XArena {
+    struct Chunk {
+        uint8_t *p;
+        size_t cap;
+    };
+    std::vector<Chunk> chunks;
+    size_t cur = 0, used = 0; // next byte: chunks[cur].p + used
 };
 
 // limits a contig is queued with (the kernels check them; see pjb_finish_contig_end)
@@ -122,6 +136,7 @@ struct ContigLimits {
 // host, and the timing events.  Everything else is scratch of the main stream and protected by stream order.
 struct CtlSlot {
     Buf cstats, err, gencount, batches, rows;
+    Buf x_q, x_spos, x_send, x_gapoff, x_zlist, x_scnt, x_codes; // --extra: scratch of the target in this slot
     // what the first kernels of a contig (k1_count, k1_scan_tiles, k1_emit: the front stream) write and the rest of its
     // chain reads: the next contig's first kernels run beside this contig's last ones
     Buf tile_cnt, tile_stats, splidx, splpoff, tile_soff, chunk_tile;
@@ -130,6 +145,7 @@ struct CtlSlot {
     Buf okey, g, lstart, rend, pos, aend, meta, updown, seqw; // the pairs (BAM order)
     Buf res;                                                  // k4a_simple / k4b_generic results per pair
     hipEvent_t ev_k1 = nullptr;
+    hipEvent_t ev_xk1 = nullptr; // --extra: k1_count has left the records' spans (XOut) in the slot's scratch
     // the rest of the chain's scratch, and its streams: the chains of the two slots run side by side (most kernels of a
     // contig-sized chain are latency-bound and leave the chip half idle)
     Buf total, bitmap, wrank, ends, firstid, key[2], idx[2], hist, hist_scan, hist_part, bintotal, scan_tiles;
@@ -174,6 +190,13 @@ struct Flight {
     int n_pass = 0;
     const u32 *sidx = nullptr;
     Pairs pr;
+    // --extra: what the part that only needs the records (extra_pre) left for the part that needs the rows (extra_contig)
+    bool x_pre = false;
+    bool x_k1 = false; // k1_count classified the records (else: kx_classify_sparse)
+    int32_t *x_spos = nullptr, *x_send = nullptr;
+    u32 *x_gapoff = nullptr;
+    Gap *x_gaps = nullptr;
+    u32 x_gap_cap = 0;
 };
 
 constexpr size_t PJB_UP_EVENTS = 64;
@@ -261,11 +284,16 @@ struct pjb_ctx {
     // --extra
     bool extra = false;
     std::vector<ExtraContig> xc;
-    std::vector<pjb_extra_row> xrows_host;
     std::map<int32_t, std::pair<u64 *, u32>> filter_keys; // bamfilt: passing junctions per target (device, sorted)
     Buf f_pos, f_cigoff, f_cigar, f_codes;
     Buf g_rows, g_models, g_refs, g_out, g_bad; // filt feature rows
     Buf x_pos, x_endx, x_q, x_prefq, x_ce, x_bound, x_de, x_dropped, x_zlist, x_cnt, x_tabk, x_tabc, x_rs, x_re, x_rr, x_tileoff;
+    Buf x_xrall, x_tab; // x_tab: the name table (NameSlot), x_tab_slots slots, holding the codes of x_tab_n spliced records
+    size_t x_tab_slots = 0, x_tab_n = 0;
+    XArena xarena;
+    pjb_extra_row *xrows_pinned = nullptr;
+    size_t xrows_pinned_cap = 0;
+    bool extra_dense_only = false; // pjb_set_option("extra_dense", 1): the round-2 path for every target
     Buf b_hasx, b_xtotal;
     Buf b_fasta_raw; // pjb_upload_contig_fasta: the record's bytes as they are in the file
 };
@@ -478,6 +506,7 @@ void *slab_alloc(pjb_ctx *c, OpenContig &oc, size_t bytes) {
 
 void extra_clear(pjb_ctx *c) {
     for (auto &x : c->xc) {
+        if (!x.dense) continue; // (everything else is arena memory)
         if (x.cover) (void)hipFree(x.cover);
         if (x.xr) (void)hipFree(x.xr);
         if (x.pair_code) (void)hipFree(x.pair_code);
@@ -485,7 +514,30 @@ void extra_clear(pjb_ctx *c) {
         if (x.spl_codes) (void)hipFree(x.spl_codes);
     }
     c->xc.clear();
-    c->xrows_host.clear();
+    c->xarena.cur = c->xarena.used = 0;
+    c->x_tab_n = 0; // (the table is wiped when the next file's first codes arrive)
+}
+
+// `bytes` of arena memory (256-byte aligned), nullptr when the device is out of memory
+void *xarena_alloc(pjb_ctx *c, size_t bytes) {
+    XArena &A = c->xarena;
+    bytes = (std::max<size_t>(bytes, 16) + 255) & ~(size_t)255;
+    for (; A.cur < A.chunks.size(); A.cur++, A.used = 0)
+        if (A.chunks[A.cur].cap - A.used >= bytes) {
+            void *r = A.chunks[A.cur].p + A.used;
+            A.used += bytes;
+            return r;
+        }
+    XArena::Chunk ch;
+    ch.cap = std::max<size_t>(bytes, (size_t)256 << 20);
+    if (hipMalloc((void **)&ch.p, ch.cap) != hipSuccess) {
+        ch.cap = bytes;
+        if (hipMalloc((void **)&ch.p, ch.cap) != hipSuccess) return nullptr;
+    }
+    A.chunks.push_back(ch);
+    A.cur = A.chunks.size() - 1;
+    A.used = bytes;
+    return ch.p;
 }
 
 int close_contig(pjb_ctx *c, int32_t tid) {
@@ -612,12 +664,12 @@ void pjb_destroy(pjb_ctx *c) {
             if (ev) (void)hipEventDestroy(ev);
         if (S.ev_rows) (void)hipEventDestroy(S.ev_rows);
         if (S.ev_done) (void)hipEventDestroy(S.ev_done);
-        Buf *sb[] = {&S.cstats, &S.err, &S.gencount, &S.batches, &S.rows, &S.tile_cnt, &S.tile_stats, &S.splidx, &S.splpoff, &S.tile_soff, &S.chunk_tile, &S.k1look, &S.members, &S.okey, &S.g,
+        Buf *sb[] = {&S.x_q, &S.x_spos, &S.x_send, &S.x_gapoff, &S.x_zlist, &S.x_scnt, &S.x_codes, &S.cstats, &S.err, &S.gencount, &S.batches, &S.rows, &S.tile_cnt, &S.tile_stats, &S.splidx, &S.splpoff, &S.tile_soff, &S.chunk_tile, &S.k1look, &S.members, &S.okey, &S.g,
                      &S.lstart, &S.rend, &S.pos, &S.aend, &S.meta, &S.updown, &S.seqw, &S.res, &S.total, &S.bitmap, &S.wrank, &S.ends, &S.firstid,
                      &S.key[0], &S.key[1], &S.idx[0], &S.idx[1], &S.hist, &S.hist_scan, &S.hist_part, &S.bintotal, &S.scan_tiles, &S.jid, &S.seg, &S.runfirst,
                      &S.runstart, &S.ent, &S.entsum, &S.frag, &S.fragj, &S.fragl, &S.fragr, &S.acc, &S.ancl, &S.ancr, &S.genlist};
         for (Buf *b : sb) release(*b);
-        hipEvent_t evs[] = {S.ev_k1, S.ev_fork, S.ev_join, S.ev_fork2, S.ev_join2};
+        hipEvent_t evs[] = {S.ev_k1, S.ev_xk1, S.ev_fork, S.ev_join, S.ev_fork2, S.ev_join2};
         for (hipEvent_t e : evs)
             if (e) (void)hipEventDestroy(e);
         if (S.main) (void)hipStreamDestroy(S.main);
@@ -632,8 +684,10 @@ void pjb_destroy(pjb_ctx *c) {
                   &c->b_bam_seg, &c->b_bam_rec, &c->b_bam_ctl, &c->f_pos, &c->f_cigoff, &c->f_cigar, &c->f_codes, &c->g_rows, &c->g_models, &c->g_refs,
                   &c->g_out, &c->g_bad,
                   &c->x_pos, &c->x_endx, &c->x_q, &c->x_prefq, &c->x_ce, &c->x_bound, &c->x_de, &c->x_dropped, &c->x_zlist, &c->x_cnt,
-                  &c->x_tabk, &c->x_tabc, &c->x_rs, &c->x_re, &c->x_rr, &c->x_tileoff};
+                  &c->x_tabk, &c->x_tabc, &c->x_rs, &c->x_re, &c->x_rr, &c->x_tileoff, &c->x_xrall, &c->x_tab};
     for (Buf *b : all) release(*b);
+    for (auto &ch : c->xarena.chunks) (void)hipFree(ch.p);
+    if (c->xrows_pinned) (void)hipHostFree(c->xrows_pinned);
     for (auto &pool : c->pools)
         for (auto &ev : pool.ev) (void)hipEventDestroy(ev);
     if (c->ev_front) (void)hipEventDestroy(c->ev_front);
@@ -915,12 +969,14 @@ static int mirror_header_only(pjb_ctx *c, const pjb_region_result &R) {
 // per-base depth, the junctions' flanking alignment counts, and the name codes phase 2 needs.  Runs after the
 // contig's rows exist (b_rows, sidx, jid are still this contig's).
 constexpr u32 X_ZCAP = 1u << 20;
-static int extra_contig(pjb_ctx *c, int32_t tid, std::vector<DevBatch> &batches, int64_t n_reads, u64 n_spliced, u32 P, u32 J,
-                        const u32 *sidx, const u32 *pair_g, size_t row_base) {
+static int extra_contig_dense(pjb_ctx *c, int32_t tid, std::vector<DevBatch> &batches, int64_t n_reads, u64 n_spliced, u32 P, u32 J,
+                              const u32 *sidx, const u32 *pair_g, size_t row_base, bool codes_in_table) {
     hipStream_t st = c->stream;
     const int32_t L = c->ref_len[(size_t)tid];
     const size_t N = (size_t)n_reads;
     ExtraContig X;
+    X.dense = true;
+    X.codes_in_table = codes_in_table;
     X.tid = tid;
     X.len = L;
     X.row_base = row_base;
@@ -1015,6 +1071,161 @@ static int extra_contig(pjb_ctx *c, int32_t tid, std::vector<DevBatch> &batches,
     if (c->ktime) ev_collect(c, MISC_POOL);
     c->xc.push_back(X);
     guard.x = nullptr;
+    return PJB_OK;
+}
+
+#define XTRACE(what)                                                                                                              \
+    do {                                                                                                                          \
+        if (xtrace) {                                                                                                             \
+            (void)hipStreamSynchronize(st);                                                                                       \
+            const auto now_ = std::chrono::steady_clock::now();                                                                   \
+            fprintf(stderr, "[xtrace] %-28s %.3f ms\n", what, std::chrono::duration<double, std::milli>(now_ - xt0).count());     \
+            xt0 = now_;                                                                                                           \
+        }                                                                                                                         \
+    } while (0)
+// room in the name table for `add` more codes (load <= 1/2): a larger table takes over the old one's names
+static int name_table_reserve(pjb_ctx *c, size_t add) {
+    hipStream_t st = c->stream;
+    const size_t need = (c->x_tab_n + add) + (c->x_tab_n + add) / 2 + 1; // load <= 2/3
+    if (c->x_tab_n == 0 && c->x_tab_slots >= need) { // first codes of a file: wipe
+        if (add) HIP_TRY(c, hipMemsetAsync(c->x_tab.p, 0xff, c->x_tab_slots * sizeof(NameSlot), st));
+        return PJB_OK;
+    }
+    if (c->x_tab_slots >= need) return PJB_OK;
+    if (need > 0xfffffff0ull) return fail(c, PJB_ERR_ARG, "extra: more than 2^31 spliced records");
+    const size_t slots = std::min<size_t>(std::max<size_t>(2 * need + 16, 1024), 0xfffffff0ull); // (twice what is needed now: a file's targets arrive one by one)
+    Buf nb;
+    int rc = ensure(c, nb, slots * sizeof(NameSlot));
+    if (rc) return rc;
+    HIP_TRY(c, hipMemsetAsync(nb.p, 0xff, slots * sizeof(NameSlot), st));
+    if (c->x_tab_n)
+        LAUNCH(c, "kx_name_rehash", kx_name_rehash, dim3((unsigned)((c->x_tab_slots + 255) / 256)), dim3(256), (const NameSlot *)c->x_tab.p,
+               (u32)c->x_tab_slots, (NameSlot *)nb.p, (u32)slots);
+    if (c->x_tab.p) {
+        HIP_TRY(c, hipStreamSynchronize(st));
+        release(c->x_tab);
+    }
+    c->x_tab = nb;
+    c->x_tab_slots = slots;
+    return PJB_OK;
+}
+static int name_table_insert(pjb_ctx *c, const u64 *codes, u32 n) {
+    if (!n) return PJB_OK;
+    int rc = name_table_reserve(c, n);
+    if (rc) return rc;
+    LAUNCH(c, "kx_name_insert", kx_name_insert4, dim3((n + 1023) / 1024), dim3(256), codes, n, (NameSlot *)c->x_tab.p, (u32)c->x_tab_slots);
+    c->x_tab_n += n;
+    return PJB_OK;
+}
+
+// The same per-target work without an array of the target's length (pjb_extra.hip.h, "the sparse path"), in two parts.
+// extra_pre needs the records only: queued on the service stream when the target's chain is queued, it runs beside the
+// chains.  extra_contig needs the chain's rows and sorted pairs: queued when the chain is collected, beside the chains of
+// the targets queued after this one; one wait at its end.  A target where the pileup's cap may bite goes through
+// extra_contig_dense instead.
+static int extra_pre(pjb_ctx *c, Flight &f) {
+    if (f.x_pre || c->extra_dense_only || f.empty) return PJB_OK;
+    hipStream_t st = c->stream;
+    CtlSlot &S = c->sl[f.slot];
+    const size_t N = (size_t)f.n_reads;
+    int rc;
+    f.x_gap_cap = (u32)std::min<size_t>(N / 16 + 1024, 0x7fffffffu);
+    f.x_spos = (int32_t *)xarena_alloc(c, N * 4 + 16); // (compacted: the records with a span)
+    f.x_send = (int32_t *)xarena_alloc(c, N * 4 + 16);
+    f.x_gapoff = (u32 *)xarena_alloc(c, (N / 256 + 2) * 4);
+    f.x_gaps = (Gap *)xarena_alloc(c, (size_t)f.x_gap_cap * sizeof(Gap));
+    if (!f.x_spos || !f.x_send || !f.x_gapoff || !f.x_gaps)
+        return fail(c, PJB_ERR_NOMEM, "extra: no device memory for what target %d keeps (%zu records)", f.tid, N);
+    if ((rc = ensure(c, S.x_q, N + 16)) || (rc = ensure(c, S.x_spos, N * 4 + 16)) || (rc = ensure(c, S.x_send, N * 4 + 16)) ||
+        (rc = ensure(c, S.x_gapoff, (N / 256 + 2) * 4)) || (rc = ensure(c, S.x_zlist, (size_t)X_ZCAP * 4)) ||
+        (rc = ensure(c, S.x_scnt, sizeof(SparseCounters) + sizeof(ExtraCounters))))
+        return rc;
+    uint8_t *q = (uint8_t *)S.x_q.p;
+    SparseCounters *d_cnt = (SparseCounters *)S.x_scnt.p;
+    if (f.x_k1) HIP_TRY(c, hipStreamWaitEvent(st, S.ev_xk1, 0)); // (the chain's k1_count classified the records)
+    else {
+        HIP_TRY(c, hipMemsetAsync(q + N, 0, 1, st));
+        HIP_TRY(c, hipMemsetAsync(d_cnt, 0, sizeof(SparseCounters) + sizeof(ExtraCounters), st));
+        for (auto &b : f.batches)
+            LAUNCH(c, "kx_classify_sparse", kx_classify_sparse, dim3((unsigned)((b.n + 255) / 256)), dim3(256), b, (int32_t *)S.x_spos.p, (int32_t *)S.x_send.p,
+                   q, (u32 *)S.x_zlist.p, X_ZCAP, d_cnt);
+    }
+    if ((rc = run_scan(c, "kx_spans", SparseFn{q},
+                       SparseSink{f.x_spos, f.x_send, (u32 *)S.x_gapoff.p, f.x_gapoff, (const int32_t *)S.x_spos.p, (const int32_t *)S.x_send.p, q}, (u64)N + 1,
+                       &d_cnt->total)))
+        return rc;
+    for (auto &b : f.batches)
+        if (b.n > 0)
+            LAUNCH(c, "kx_gaps", kx_gaps, dim3((unsigned)((((u64)b.base + (u64)b.n + 255) >> 8) - (b.base >> 8))), dim3(256), b, (const uint8_t *)q, (u32)N,
+                   (const u32 *)S.x_gapoff.p, f.x_gaps, f.x_gap_cap, d_cnt);
+    if (N >= PLP_MAXCNT)
+        LAUNCH(c, "kx_cap_check", kx_cap_check, dim3((unsigned)((N + 255) / 256)), dim3(256), (const int32_t *)f.x_spos, d_cnt);
+    f.x_pre = true;
+    return PJB_OK;
+}
+
+static int extra_contig(pjb_ctx *c, Flight &f, int32_t tid, u64 n_spliced, u32 P, u32 J, size_t row_base) {
+    std::vector<DevBatch> &batches = f.batches;
+    if (c->extra_dense_only) return extra_contig_dense(c, tid, batches, f.n_reads, n_spliced, P, J, f.sidx, f.pr.g, row_base, false);
+    int rc;
+    if ((rc = extra_pre(c, f))) return rc;
+    hipStream_t st = c->stream;
+    const int32_t L = c->ref_len[(size_t)tid];
+    CtlSlot &S = c->sl[f.slot];
+    ExtraContig X;
+    X.tid = tid;
+    X.len = L;
+    X.row_base = row_base;
+    X.n_rows = J;
+    X.n_pairs = P;
+    X.xr = J ? (ExtraRow *)xarena_alloc(c, (size_t)J * sizeof(ExtraRow)) : nullptr;
+    X.pair_code = J ? (u64 *)xarena_alloc(c, (size_t)P * 8 + 16) : nullptr;
+    X.pair_row = J ? (u32 *)xarena_alloc(c, (size_t)P * 4 + 16) : nullptr;
+    if (J && (!X.xr || !X.pair_code || !X.pair_row)) return fail(c, PJB_ERR_NOMEM, "extra: no device memory for the pairs of target %d", tid);
+    if ((rc = ensure(c, S.x_codes, std::max<size_t>((size_t)n_spliced, 1) * 8))) return rc;
+    const bool xtrace = getenv("PJB_XTRACE") != nullptr;
+    auto xt0 = std::chrono::steady_clock::now();
+    XTRACE("post: pre-part done");
+    SparseCounters *d_cnt = (SparseCounters *)S.x_scnt.p;
+    ExtraCounters *d_xcnt = (ExtraCounters *)(d_cnt + 1);
+    {   // the spliced records' name codes, through the tile lists the target's first kernels left in its slot -> the name table
+        u32 n_tiles = 0;
+        for (auto &b : batches) n_tiles = std::max<u32>(n_tiles, b.tile_base + (u32)((b.n + K1_TILE - 1) / K1_TILE));
+        if ((rc = ensure(c, c->x_tileoff, (size_t)n_tiles * 4 + 16))) return rc;
+        LAUNCH(c, "kx_spliced_offsets", kx_spliced_offsets, dim3(1), dim3(1024), (const TileStats *)S.tile_stats.p, n_tiles, (u32 *)c->x_tileoff.p, d_xcnt);
+        for (auto &b : batches)
+            LAUNCH(c, "kx_spliced_codes", kx_spliced_codes, dim3((unsigned)((b.n + K1_TILE - 1) / K1_TILE)), dim3(256), b, (const TileStats *)S.tile_stats.p,
+                   (const u32 *)S.splidx.p, (const u32 *)c->x_tileoff.p, (u64 *)S.x_codes.p);
+        XTRACE("post: codes");
+        if ((rc = name_table_insert(c, (const u64 *)S.x_codes.p, (u32)n_spliced))) return rc;
+        X.codes_in_table = true;
+        XTRACE("post: insert");
+    }
+    if (J > 0) {
+        HIP_TRY(c, hipMemsetAsync(X.xr, 0, (size_t)J * sizeof(ExtraRow), st));
+        LAUNCH(c, "kx_flank_sparse", kx_flank_sparse, dim3((J + 255) / 256), dim3(256), (const pjb_junction_row *)S.rows.p, J,
+               (const int32_t *)f.x_spos, (const int32_t *)f.x_send, L, (const u32 *)S.x_zlist.p, (const SparseCounters *)d_cnt, X_ZCAP, X.xr);
+        LAUNCH(c, "kx_pair_codes", kx_pair_codes, dim3((P + 255) / 256), dim3(256), f.sidx, (const u32 *)S.jid.p, f.pr.g, (const DevBatch *)S.batches.p,
+               (int)batches.size(), P, (u32)row_base, X.pair_code, X.pair_row);
+    }
+    // one wait: the counters decide whether the sparse answer stands
+    SparseCounters &hc = *(SparseCounters *)(S.pub + PUB_XCNT_AT);
+    ExtraCounters &hx = *(ExtraCounters *)(S.pub + PUB_XCNT_AT + sizeof(SparseCounters));
+    XTRACE("post: flank + pair codes");
+    HIP_TRY(c, hipMemcpyAsync(&hc, d_cnt, sizeof(SparseCounters) + sizeof(ExtraCounters), hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipStreamSynchronize(st));
+    XTRACE("post: counters");
+    if (c->ktime) ev_collect(c, MISC_POOL);
+    if (hc.n_zero > X_ZCAP)
+        return fail(c, PJB_ERR_ARG, "extra: target %d has %u mapped records without a reference span (limit %u)", tid, hc.n_zero, X_ZCAP);
+    if (hx.n_spliced != (u32)n_spliced)
+        return fail(c, PJB_ERR_STATE, "extra: target %d: %u spliced records in the tile lists, the chain counted %llu", tid, hx.n_spliced, (unsigned long long)n_spliced);
+    if (hc.need_dense) // the pileup's cap may bite (or the gap list is too small): the depth vector, as in round 2
+        return extra_contig_dense(c, tid, batches, f.n_reads, n_spliced, P, J, f.sidx, f.pr.g, row_base, true);
+    X.has_unspliced = (u32)hc.total > 0;
+    X.n_spl = hx.n_spliced;
+    X.sparse = SparseDepth{f.x_spos, f.x_send, f.x_gaps, f.x_gapoff, (u32)hc.total, (u32)(hc.total >> 32), hc.max_span, hc.max_gap};
+    c->xc.push_back(X);
     return PJB_OK;
 }
 
@@ -1241,13 +1452,34 @@ static int queue_contig(pjb_ctx *c, Flight &f) {
         LAUNCH(c, "k1_scan_tiles", k1_scan_tiles, dim3(1), dim3(1024), (u32 *)nullptr, (const TileStats *)S.tile_stats.p, n_tiles, d_cs, PL, kf,
                ref_len, (const u64 *)lk.tile_desc, (u32 *)nullptr, (u32 *)nullptr);
     } else {
-        // ---- K1a: count (a group's members: a tile whose alignments leave the member's own sequence is flagged)
+        // ---- K1a: count (a group's members: a tile whose alignments leave the member's own sequence is flagged); with
+        // PJB_FLAG_EXTRA the first time also what the records span (a chain that is queued again leaves that alone: the
+        // service stream may be reading it)
+        const bool xk1 = c->extra && !c->extra_dense_only && !group && !f.x_k1 && !f.x_pre;
+        XOut xo = {nullptr, nullptr, nullptr, nullptr, 0, nullptr};
+        if (xk1) {
+            const size_t N = (size_t)f.n_reads;
+            if ((rc = ensure(c, S.x_q, N + 16)) || (rc = ensure(c, S.x_spos, N * 4 + 16)) || (rc = ensure(c, S.x_send, N * 4 + 16)) ||
+                (rc = ensure(c, S.x_zlist, (size_t)X_ZCAP * 4)) || (rc = ensure(c, S.x_scnt, sizeof(SparseCounters) + sizeof(ExtraCounters))))
+                return rc;
+            HIP_TRY(c, hipMemsetAsync((uint8_t *)S.x_q.p + N, 0, 1, c->stream));
+            HIP_TRY(c, hipMemsetAsync(S.x_scnt.p, 0, sizeof(SparseCounters) + sizeof(ExtraCounters), c->stream));
+            xo = XOut{(int32_t *)S.x_spos.p, (int32_t *)S.x_send.p, (uint8_t *)S.x_q.p, (u32 *)S.x_zlist.p, X_ZCAP, (SparseCounters *)S.x_scnt.p};
+        }
         for (size_t bi = 0; bi < batches.size(); bi++) {
             const DevBatch &b = batches[bi];
             const int32_t own_len = c->ref_len[(size_t)f.tids[(size_t)f.batch_member[bi]]];
             const u32 nt = (u32)((b.n + K1_TILE - 1) / K1_TILE);
-            LAUNCH(c, "k1_count", k1_count, dim3(nt), dim3(256), b, (u32 *)S.tile_cnt.p, (TileStats *)S.tile_stats.p,
-                   (u32 *)S.splidx.p, (u32 *)S.splpoff.p, d_err, group ? std::max(own_len, 1) : 0);
+            if (xk1)
+                LAUNCH(c, "k1_count", k1_count<true>, dim3(nt), dim3(256), b, (u32 *)S.tile_cnt.p, (TileStats *)S.tile_stats.p, (u32 *)S.splidx.p,
+                       (u32 *)S.splpoff.p, d_err, 0, xo);
+            else
+                LAUNCH(c, "k1_count", k1_count<false>, dim3(nt), dim3(256), b, (u32 *)S.tile_cnt.p, (TileStats *)S.tile_stats.p, (u32 *)S.splidx.p,
+                       (u32 *)S.splpoff.p, d_err, group ? std::max(own_len, 1) : 0, xo);
+        }
+        if (xk1) {
+            HIP_TRY(c, hipEventRecord(S.ev_xk1, c->stream));
+            f.x_k1 = true;
         }
         if (group)
             LAUNCH(c, "kg_member_stats", kg_member_stats, dim3((unsigned)n_members), dim3(256), (const u32 *)S.tile_cnt.p, (const TileStats *)S.tile_stats.p,
@@ -1554,18 +1786,29 @@ static void prepare_flight(pjb_ctx *c, Flight &f) {
 // streams and events of a control slot, at its first use (a context that never queues eight chains never pays for them)
 static int slot_init(pjb_ctx *c, int k) {
     CtlSlot &S = c->sl[k];
-    if (S.main) return PJB_OK;
+    if (S.ev_done) return PJB_OK;
     for (auto &ev : S.ev) HIP_TRY(c, hipEventCreate(&ev));
     HIP_TRY(c, hipEventCreateWithFlags(&S.ev_rows, hipEventDisableTiming));
     HIP_TRY(c, hipEventCreateWithFlags(&S.ev_done, hipEventDisableTiming));
     HIP_TRY(c, hipEventCreateWithFlags(&S.ev_k1, hipEventDisableTiming));
+    HIP_TRY(c, hipEventCreateWithFlags(&S.ev_xk1, hipEventDisableTiming));
     HIP_TRY(c, hipEventCreateWithFlags(&S.ev_fork, hipEventDisableTiming));
     HIP_TRY(c, hipEventCreateWithFlags(&S.ev_join, hipEventDisableTiming));
     HIP_TRY(c, hipEventCreateWithFlags(&S.ev_fork2, hipEventDisableTiming));
     HIP_TRY(c, hipEventCreateWithFlags(&S.ev_join2, hipEventDisableTiming));
-    HIP_TRY(c, hipStreamCreateWithFlags(&S.side, hipStreamNonBlocking));
+    // (main before side, slot after slot: the order in which streams are created decides which hardware queue they share, and
+    // every other order tried -- side first, all mains first, one to three streams created before -- cost the configs[2] step
+    // 5 - 12 %: profiles/r03z_stream_order.txt)
     HIP_TRY(c, hipStreamCreateWithFlags(&S.main, hipStreamNonBlocking));
+    HIP_TRY(c, hipStreamCreateWithFlags(&S.side, hipStreamNonBlocking));
     return PJB_OK;
+}
+
+// the chain and, with PJB_FLAG_EXTRA, the part of the extra metrics that needs the records only (service stream, beside the chain)
+static int queue_chain(pjb_ctx *c, Flight &f) {
+    int rc = queue_contig(c, f);
+    if (!rc && c->extra) rc = extra_pre(c, f);
+    return rc;
 }
 
 static int begin_flight(pjb_ctx *c, const int32_t *tids, int32_t n, const char *who) {
@@ -1582,7 +1825,6 @@ static int begin_flight(pjb_ctx *c, const int32_t *tids, int32_t n, const char *
         for (int32_t t : c->fl[k].tids)
             for (int32_t q = 0; q < n; q++)
                 if (t == tids[q]) return fail(c, PJB_ERR_STATE, "%s: target %d is queued already", who, t);
-    if (c->n_fl >= 1 && c->extra) return fail(c, PJB_ERR_STATE, "%s: with PJB_FLAG_EXTRA targets are finished one at a time", who);
     if (n > 1) {
         // what a group needs (a caller that gets PJB_ERR_ARG here finishes the targets one by one)
         if (c->extra) return fail(c, PJB_ERR_ARG, "%s: PJB_FLAG_EXTRA contexts finish one target at a time", who);
@@ -1617,11 +1859,10 @@ static int begin_flight(pjb_ctx *c, const int32_t *tids, int32_t n, const char *
     prepare_flight(c, f);
     c->n_fl++;
     if (f.empty) return PJB_OK;
-    if (c->extra) return PJB_OK; // (queued by _end: the extra metrics need this contig's scratch untouched)
     // a chain that was taken back goes first (rows are in queue order): the end of the oldest one queues them all
     for (int k = 0; k + 1 < c->n_fl; k++)
         if (!c->fl[k].queued && !c->fl[k].empty) return PJB_OK;
-    const int rc = queue_contig(c, f);
+    const int rc = queue_chain(c, f);
     if (rc) { // nothing of this chain stays behind
         (void)hipDeviceSynchronize();
         c->n_fl--;
@@ -1651,7 +1892,7 @@ static int collect_flight(pjb_ctx *c, pjb_region_result *res, bool *redo_single)
     ContigStats cs;
     u64 herr = ~0ull;
     for (;; f.attempt++) {
-        if (!f.queued && (rc = queue_contig(c, f))) return rc;
+        if (!f.queued && (rc = queue_chain(c, f))) return rc;
         wait_flight(c, f);
         memcpy(&cs, S.pub, sizeof cs);
         memcpy(&herr, S.pub + PUB_ERR_AT, 8);
@@ -1765,7 +2006,7 @@ static int collect_flight(pjb_ctx *c, pjb_region_result *res, bool *redo_single)
         c->rows_copy_pending = true;
     }
     c->cur_slot = f.slot;
-    if (c->extra && (rc = extra_contig(c, tid, f.batches, f.n_reads, cs.spliced, P, J, f.sidx, f.pr.g, old))) return rc;
+    if (c->extra && (rc = extra_contig(c, f, tid, cs.spliced, P, J, old))) return rc;
     c->rows_n = old + J;
     c->last_rows_n = J;
     c->last_slot = f.slot;
@@ -1842,15 +2083,13 @@ static int end_flight(pjb_ctx *c, const int32_t *tids, int32_t n, pjb_region_res
     if (res) memcpy(res, tmp.data(), tmp.size() * sizeof(pjb_region_result));
     closer.ok = true;
     // followers that were taken back (or waited for this one) are queued now, in order, the first one's place known
-    if (!c->extra) {
-        c->fl[0].queued = false; // (fl[0] is still this chain: its rows are collected, it is not "ahead" of anything)
-        for (int k = 1; k < c->n_fl; k++) {
-            Flight &g = c->fl[k];
-            if (g.queued || g.empty) continue;
-            // a follower that cannot be queued here is queued again -- and reports its error -- by its own _end; THIS
-            // chain is collected and its rows are in the table
-            if (queue_contig(c, g)) break;
-        }
+    c->fl[0].queued = false; // (fl[0] is still this chain: its rows are collected, it is not "ahead" of anything)
+    for (int k = 1; k < c->n_fl; k++) {
+        Flight &g = c->fl[k];
+        if (g.queued || g.empty) continue;
+        // a follower that cannot be queued here is queued again -- and reports its error -- by its own _end; THIS
+        // chain is collected and its rows are in the table
+        if (queue_chain(c, g)) break;
     }
     return PJB_OK;
 }
@@ -1921,89 +2160,77 @@ int pjb_clear_rows(pjb_ctx *c) {
 
 int pjb_extra_finish(pjb_ctx *c, const pjb_extra_row **rows_out, int64_t *n_out) {
     if (!c || !rows_out || !n_out) return PJB_ERR_ARG;
+    const bool xtrace = getenv("PJB_XTRACE") != nullptr;
+    auto xt0 = std::chrono::steady_clock::now();
     if (!c->extra) return fail(c, PJB_ERR_STATE, "pjb_extra_finish: the context was not created with PJB_FLAG_EXTRA");
     if (!c->open.empty()) return fail(c, PJB_ERR_STATE, "pjb_extra_finish: target %d is still open", c->open.begin()->first);
+    if (c->n_fl) return fail(c, PJB_ERR_STATE, "pjb_extra_finish: target %d is still queued", c->fl[0].tid);
     HIP_TRY(c, hipSetDevice(c->cfg.device));
     hipStream_t st = c->stream;
     int rc;
     const size_t Jall = c->rows_n;
-    c->xrows_host.assign(Jall, pjb_extra_row{0.0, 0.0, 0u, 0u});
-    *rows_out = c->xrows_host.data();
+    *rows_out = c->xrows_pinned;
     *n_out = (int64_t)Jall;
     if (Jall == 0) return PJB_OK;
-    // ---- splicedAlignmentMap over every spliced record of the file (src/junction_builder.cc:168-176)
-    size_t S = 0;
-    for (auto &x : c->xc) S += x.n_spl;
-    size_t cap = 1024;
-    while (cap < 2 * S + 1) cap <<= 1;
-    if (cap > (1ull << 32)) return fail(c, PJB_ERR_ARG, "pjb_extra_finish: more than 2^31 spliced records");
-    if ((rc = ensure(c, c->x_tabk, cap * 8))) return rc;
-    if ((rc = ensure(c, c->x_tabc, cap * 4))) return rc;
-    HIP_TRY(c, hipMemsetAsync(c->x_tabk.p, 0xff, cap * 8, st));
-    HIP_TRY(c, hipMemsetAsync(c->x_tabc.p, 0, cap * 4, st));
-    const u32 mask = (u32)(cap - 1);
-    for (auto &x : c->xc)
-        if (x.n_spl)
-            LAUNCH(c, "kx_name_insert", kx_name_insert, dim3((x.n_spl + 255) / 256), dim3(256), (const u64 *)x.spl_codes, x.n_spl,
-                   (u64 *)c->x_tabk.p, (u32 *)c->x_tabc.p, mask);
-    for (auto &x : c->xc)
-        if (x.n_pairs && x.xr)
-            LAUNCH(c, "kx_name_sum", kx_name_sum, dim3((x.n_pairs + 255) / 256), dim3(256), (const u64 *)x.pair_code, (const u32 *)x.pair_row,
-                   x.n_pairs, (const u64 *)c->x_tabk.p, (const u32 *)c->x_tabc.p, mask, x.xr - x.row_base);
-    // ---- rows as SoA on the device (start, end, nb_raw)
-    if ((rc = rows_sync(c))) return rc;
-    std::vector<int32_t> hs(Jall), he(Jall);
-    std::vector<uint32_t> hr(Jall);
-    for (size_t j = 0; j < Jall; j++) {
-        hs[j] = c->rows_pinned[j].start;
-        he[j] = c->rows_pinned[j].end;
-        hr[j] = c->rows_pinned[j].nb_raw;
+    if (Jall > c->xrows_pinned_cap) {
+        if (c->xrows_pinned) (void)hipHostFree(c->xrows_pinned);
+        c->xrows_pinned = nullptr;
+        c->xrows_pinned_cap = 0;
+        const size_t cap = Jall + Jall / 4 + 1024;
+        HIP_TRY(c, hipHostMalloc((void **)&c->xrows_pinned, cap * sizeof(pjb_extra_row), hipHostMallocDefault));
+        c->xrows_pinned_cap = cap;
     }
-    if ((rc = ensure(c, c->x_rs, Jall * 4))) return rc;
-    if ((rc = ensure(c, c->x_re, Jall * 4))) return rc;
-    if ((rc = ensure(c, c->x_rr, Jall * 4))) return rc;
-    HIP_TRY(c, hipMemcpyAsync(c->x_rs.p, hs.data(), Jall * 4, hipMemcpyHostToDevice, st));
-    HIP_TRY(c, hipMemcpyAsync(c->x_re.p, he.data(), Jall * 4, hipMemcpyHostToDevice, st));
-    HIP_TRY(c, hipMemcpyAsync(c->x_rr.p, hr.data(), Jall * 4, hipMemcpyHostToDevice, st));
+    *rows_out = c->xrows_pinned;
+    // every target's flanking counts into one table, parallel to the row table in HBM (which the kernels below read)
+    if ((rc = ensure(c, c->x_xrall, Jall * (sizeof(ExtraRow) + sizeof(pjb_extra_row))))) return rc;
+    ExtraRow *xr = (ExtraRow *)c->x_xrall.p;
+    pjb_extra_row *xout = (pjb_extra_row *)(xr + Jall);
+    HIP_TRY(c, hipMemsetAsync(xr, 0, Jall * sizeof(ExtraRow), st));
+    for (auto &x : c->xc)
+        if (x.n_rows) HIP_TRY(c, hipMemcpyAsync(xr + x.row_base, x.xr, x.n_rows * sizeof(ExtraRow), hipMemcpyDeviceToDevice, st));
+    XTRACE("finish: memset + copies");
+    // ---- splicedAlignmentMap over every spliced record of the file (src/junction_builder.cc:168-176): the targets' codes went
+    // into the table as the targets were collected (a target of the dense path: now)
+    for (auto &x : c->xc)
+        if (!x.codes_in_table) {
+            if ((rc = name_table_insert(c, (const u64 *)x.spl_codes, x.n_spl))) return rc;
+            x.codes_in_table = true;
+        }
+    if (c->x_tab_n)
+        for (auto &x : c->xc)
+            if (x.n_pairs && x.n_rows)
+                LAUNCH(c, "kx_name_sum", kx_name_sum, dim3((x.n_pairs + 1023) / 1024), dim3(256), (const u64 *)x.pair_code, (const u32 *)x.pair_row,
+                       x.n_pairs, (const NameSlot *)c->x_tab.p, (u32)c->x_tab_slots, xr);
     // ---- JunctionSystem::calcCoverage (lib/src/junction_system.cc:231-242).  DepthParser::loadNextBatch
     // (lib/src/depth_parser.cc:112-164) returns the vector of the target it started in, but by then `last`
     // names the target the pileup has moved on to, and getCurrentRefIndex() selects THAT target's junctions:
     // every batch is applied to the junctions of the next target that has unspliced records; only the final
     // batch (the pileup ended inside it) meets its own junctions, after they were first given the previous
     // target's.  Targets without unspliced records never appear.
+    XTRACE("finish: name sums");
     std::vector<const ExtraContig *> T;
     for (auto &x : c->xc)
         if (x.has_unspliced) T.push_back(&x);
     std::sort(T.begin(), T.end(), [](const ExtraContig *a, const ExtraContig *b) { return a->tid < b->tid; });
+    const pjb_junction_row *rows = c->rows_table;
     for (size_t k = 0; k < T.size(); k++) {
         const ExtraContig &x = *T[k];
         if (!x.n_rows) continue;
         const ExtraContig *src = (k + 1 == T.size()) ? &x : (k > 0 ? T[k - 1] : nullptr);
         if (!src) continue; // the first target's junctions are never visited (unless it is also the last)
-        LAUNCH(c, "kx_coverage", kx_coverage, dim3((unsigned)((x.n_rows + 255) / 256)), dim3(256), (const int32_t *)c->x_rs.p,
-               (const int32_t *)c->x_re.p, (const uint32_t *)c->x_rr.p, (u32)x.row_base, (u32)x.n_rows, (const u32 *)src->cover, src->len,
-               x.xr - x.row_base);
+        if (src->dense)
+            LAUNCH(c, "kx_coverage", kx_coverage, dim3((unsigned)((x.n_rows + 255) / 256)), dim3(256), rows, (u32)x.row_base, (u32)x.n_rows,
+                   (const u32 *)src->cover, src->len, xr);
+        else
+            LAUNCH(c, "kx_coverage_sparse", kx_coverage_sparse, dim3((unsigned)((x.n_rows + 255) / 256)), dim3(256), rows, (u32)x.row_base,
+                   (u32)x.n_rows, src->sparse, src->len, xr);
     }
-    std::vector<ExtraRow> tmp;
-    for (auto &x : c->xc) {
-        if (!x.n_rows) continue;
-        LAUNCH(c, "kx_mm_score", kx_mm_score, dim3((unsigned)((x.n_rows + 255) / 256)), dim3(256), (const uint32_t *)c->x_rr.p + x.row_base,
-               (u32)x.n_rows, x.xr);
-    }
-    for (auto &x : c->xc) {
-        if (!x.n_rows) continue;
-        tmp.resize(x.n_rows);
-        HIP_TRY(c, hipMemcpyAsync(tmp.data(), x.xr, x.n_rows * sizeof(ExtraRow), hipMemcpyDeviceToHost, st));
-        HIP_TRY(c, hipStreamSynchronize(st));
-        for (size_t j = 0; j < x.n_rows; j++) {
-            pjb_extra_row &o = c->xrows_host[x.row_base + j];
-            o.mm_score = tmp[j].mm_score;
-            o.coverage = tmp[j].coverage;
-            o.up_aln = tmp[j].up_aln;
-            o.down_aln = tmp[j].down_aln;
-        }
-    }
+    XTRACE("finish: coverage");
+    LAUNCH(c, "kx_rows_out", kx_rows_out, dim3((unsigned)((Jall + 255) / 256)), dim3(256), rows, (const ExtraRow *)xr, (u32)Jall, xout);
+    XTRACE("finish: rows_out");
+    HIP_TRY(c, hipMemcpyAsync(c->xrows_pinned, xout, Jall * sizeof(pjb_extra_row), hipMemcpyDeviceToHost, st));
     HIP_TRY(c, hipStreamSynchronize(st));
+    XTRACE("finish: D2H");
     if (c->ktime) ev_collect(c, MISC_POOL);
     return PJB_OK;
 }
@@ -2160,6 +2387,7 @@ int pjb_set_option(pjb_ctx *c, const char *name, int64_t value) {
     if (n == "overlap") c->side_stream = value != 0;
     else if (n == "dense_ids") c->dense_ids = value != 0;
     else if (n == "fused_k1") c->fused_k1 = value != 0;
+    else if (n == "extra_dense") c->extra_dense_only = value != 0;
     else return fail(c, PJB_ERR_ARG, "set_option: unknown option '%s'", name);
     return PJB_OK;
 }

@@ -325,44 +325,372 @@ __global__ __launch_bounds__(256) void kx_pair_codes(const u32 *sidx, const u32 
     pair_row[i] = row_base + jid_of[i];
 }
 
+// ---- the sparse path (round 3): no array of the target's length --------------------------------------------------
+// The depth of the unspliced records is only ever READ at 42 positions per junction (Junction::calcCoverage,
+// junction.cc:935-951) and the ends histogram at one position per junction (processJunctionVicinity) -- while building
+// them costs two memsets, 3 atomics per record and two scans over the target's LENGTH (0.5 ms each per 100 Mb).  The
+// records are sorted by position, and a record that covers x starts within max_span bases before x: so both questions
+// are answered from the records themselves, by a thread per junction that walks the few records starting in
+// (x - max_span, x].  What is kept of a target until pjb_extra_finish: the unspliced records with a span, compacted --
+// pos[k], end[k] (exclusive) in file order -- and the list of their D operations ("gaps": inside the span, not counted by
+// the pileup) with one offset per 256 records.  (The spliced records are left out: a junction's own alignments start
+// right before it, 300 k of them at the deepest junction of configs[1], and would all be walked for nothing.)
+//   htslib's 8000-record cap (kx_cap_*) is only possible where 7999 consecutive unspliced records start within max_span
+// bases (kx_cap_check); such a target -- and one with more gaps than the list holds -- goes through the dense path
+// above instead.
+// (SparseCounters, XOut: pjb_kernels.hip.h -- k1_count writes them when the records go through it; kx_classify_sparse is
+// the same classification for the records of a target that went through k1_walk)
+__global__ __launch_bounds__(256) void kx_classify_sparse(DevBatch b, int32_t *s_pos, int32_t *s_end, uint8_t *q_flag, u32 *zlist, u32 zcap,
+                                                           SparseCounters *cnt) {
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    u32 span = 0, gapmax = 0;
+    bool many = false;
+    if (r < b.n) {
+        const u32 g = b.base + (u32)r;
+        const u32 c0 = b.cig_off[r], c1 = b.cig_off[r + 1];
+        const int32_t pos = b.pos[r];
+        int32_t aligned = 0;
+        u32 ngap = 0;
+        bool spliced = false;
+        for (u32 k = c0; k < c1; k++) {
+            const u32 op = b.cigar[k];
+            const u32 ty = op & 15u;
+            if (ty == OP_N) spliced = true;
+            if (op_consumes_ref(ty)) {
+                aligned += (int32_t)(op >> 4);
+                if (ty == 2u && (op >> 4)) { // D: inside the span, no depth
+                    ngap++;
+                    gapmax = max(gapmax, op >> 4);
+                }
+            }
+        }
+        const bool mapped = !(b.flag[r] & 0x4u);
+        const bool unspliced = !spliced && mapped;
+        const bool spans = unspliced && aligned > 0 && pos >= 0;
+        s_pos[g] = pos;
+        s_end[g] = spans ? pos + aligned : pos;
+        if (!spans) ngap = 0, gapmax = 0;
+        if (ngap > SPARSE_GAP_MAX) many = true, ngap = SPARSE_GAP_MAX;
+        q_flag[g] = (uint8_t)((spans ? 1u : 0u) | (ngap << 1));
+        if (spans) span = (u32)aligned;
+        if (unspliced && aligned == 0) {
+            const u32 z = atomicAdd(&cnt->n_zero, 1u);
+            if (z < zcap) zlist[z] = (u32)pos;
+        }
+    }
+    span = wave_max(span);
+    gapmax = wave_max(gapmax);
+    if (lane_id() == 0) { // (look first: the maxima settle after a few waves)
+        if (span > cnt->max_span) atomicMax(&cnt->max_span, span);
+        if (gapmax > cnt->max_gap) atomicMax(&cnt->max_gap, gapmax);
+    }
+    if (many) atomicOr(&cnt->need_dense, 2u);
+}
+
+// one scan over the records: (records with a span) | (gaps) << 32
+struct SparseFn {
+    const uint8_t *q;
+    __device__ u64 operator()(u64 i) const {
+        const u32 v = q[i];
+        return (u64)(v & 1u) | ((u64)(v >> 1) << 32);
+    }
+};
+struct Gap {
+    int32_t start, end; // [start, end)
+};
+struct SparseSink { // the records with a span, compacted in rank order; gaps before every 256th record and every 256th rank
+    int32_t *comp_pos, *comp_end;
+    u32 *gapoff_rec, *gapoff_rank;
+    const int32_t *s_pos, *s_end;
+    const uint8_t *q;
+    __device__ void operator()(u64 i, u64, u64 ex) const {
+        const u32 rank = (u32)ex, gbefore = (u32)(ex >> 32);
+        if ((i & 255u) == 0) gapoff_rec[i >> 8] = gbefore;
+        if (q[i] & 1u) {
+            comp_pos[rank] = s_pos[i];
+            comp_end[rank] = s_end[i];
+            if ((rank & 255u) == 0) gapoff_rank[rank >> 8] = gbefore;
+        }
+    }
+};
+// the gaps (D operations) of the unspliced records in record order: a block per 256 records (global ordinals, so that
+// gapoff[block] is the block's first entry), an exclusive scan of the records' gap counts inside the block
+__global__ __launch_bounds__(256) void kx_gaps(DevBatch b, const uint8_t *q, u32 n_total, const u32 *gapoff, Gap *gaps, u32 gap_cap, SparseCounters *cnt) {
+    __shared__ u32 wsum[4];
+    if ((cnt->total >> 32) == 0) return; // (no gap in the whole target: the usual case for short reads)
+    const u32 first_block = b.base >> 8;
+    const u64 g = ((u64)(first_block + blockIdx.x) << 8) + threadIdx.x; // global record ordinal
+    const u32 ngap = g < n_total ? (u32)(q[g] >> 1) : 0u;
+    const u32 inc = wave_iscan(ngap);
+    const int w = threadIdx.x >> 6;
+    if (lane_id() == 63) wsum[w] = inc;
+    __syncthreads();
+    u32 before = gapoff[first_block + blockIdx.x] + inc - ngap;
+    for (int k = 0; k < w; k++) before += wsum[k];
+    if (!ngap || g < b.base || g >= (u64)b.base + (u64)b.n) return; // (a neighbouring batch's record: it only counts)
+    if (before + ngap > gap_cap) {
+        atomicOr(&cnt->need_dense, 4u);
+        return;
+    }
+    const u32 r = (u32)g - b.base;
+    int32_t x = b.pos[r];
+    u32 k_out = 0;
+    for (u32 k = b.cig_off[r]; k < b.cig_off[r + 1] && k_out < ngap; k++) {
+        const u32 op = b.cigar[k], ty = op & 15u;
+        const int32_t ln = (int32_t)(op >> 4);
+        if (ty == 2u && ln) gaps[before + k_out++] = Gap{x, x + ln};
+        if (op_consumes_ref(ty)) x += ln;
+    }
+}
+
+// the pileup's cap can only bite where PLP_MAXCNT - 1 records with a span start within max_span bases of each other
+__global__ __launch_bounds__(256) void kx_cap_check(const int32_t *comp_pos, SparseCounters *cnt) {
+    const u32 n = (u32)cnt->total, K = PLP_MAXCNT - 1;
+    const u32 r = blockIdx.x * 256 + threadIdx.x + K;
+    if (r >= n) return;
+    if ((int64_t)comp_pos[r] - (int64_t)comp_pos[r - K] <= (int64_t)cnt->max_span) atomicOr(&cnt->need_dense, 1u);
+}
+
+__device__ __forceinline__ u32 lower_bound_i64(const int32_t *a, u32 n, int64_t v) { // first index with a[i] >= v
+    u32 lo = 0, hi = n;
+    while (lo < hi) {
+        const u32 mid = lo + ((hi - lo) >> 1);
+        if ((int64_t)a[mid] < v) lo = mid + 1;
+        else hi = mid;
+    }
+    return lo;
+}
+
+// Every lane has a range [i0, i1) of its own and wants acc(i, p) summed over it, p being the lane's parameters.  The ranges are
+// a handful of records where coverage is ordinary -- the lane walks them itself -- and thousands in a pile-up: those are taken
+// one after the other by the whole wavefront.  (A wavefront per junction was tried first: its 64-wide searches touched 64 cache
+// lines per probe, 0.8 ms per 50 k junctions; a search per lane shares its upper levels with the neighbouring junctions'.)
+// Every lane of the wavefront must call this.
+constexpr u32 RANGE_SHORT = 48;
+struct Win { // two windows of positions, [p1lo, p1hi] and [p2lo, p2hi] (empty: hi < lo)
+    int32_t p1lo, p1hi, p2lo, p2hi;
+};
+template <class F>
+__device__ __forceinline__ void ranges_sum2(u32 i0, u32 i1, const Win w, F acc, u32 &s1, u32 &s2) {
+    const bool big = i1 > i0 && i1 - i0 > RANGE_SHORT;
+    if (!big)
+        for (u32 i = i0; i < i1; i++) acc(i, w, s1, s2);
+    u64 m = __ballot(big);
+    const int lane = lane_id();
+    while (m) {
+        const int src = __ffsll((unsigned long long)m) - 1;
+        m &= m - 1;
+        const u32 j0 = (u32)__shfl((int)i0, src, 64), j1 = (u32)__shfl((int)i1, src, 64);
+        Win ws;
+        ws.p1lo = __shfl(w.p1lo, src, 64);
+        ws.p1hi = __shfl(w.p1hi, src, 64);
+        ws.p2lo = __shfl(w.p2lo, src, 64);
+        ws.p2hi = __shfl(w.p2hi, src, 64);
+        u32 t1 = 0, t2 = 0;
+        for (u32 i = j0 + (u32)lane; i < j1; i += 64) acc(i, ws, t1, t2);
+        t1 = wave_total<DppAdd>(t1); // (every lane gets the sum)
+        t2 = wave_total<DppAdd>(t2);
+        if (lane == src) {
+            s1 += t1;
+            s2 += t2;
+        }
+    }
+}
+
+// KX4 without the ends histogram: a thread per junction.
+//   #{getEnd() < x} = (records with a span that start before x - max_span: all of them) + (those among the records starting
+//   in [x - max_span, x) whose last base lies before x); a record starting at or after x ends at or after x.
+__global__ __launch_bounds__(256) void kx_flank_sparse(const pjb_junction_row *rows, u32 n_rows, const int32_t *s_pos, const int32_t *s_end,
+                                                        int32_t ref_len, const u32 *zlist, const SparseCounters *cnt, u32 zcap, ExtraRow *out) {
+    const u32 n_reads = (u32)cnt->total; // (s_pos / s_end: the records with a span only, in rank order)
+    const u32 j = blockIdx.x * 256 + threadIdx.x;
+    const bool on = j < n_rows;
+    int32_t s = 0, e = 0, l = 0, r = 0;
+    if (on) s = rows[j].start, e = rows[j].end, l = rows[j].left, r = rows[j].right;
+    auto before = [&](int32_t v) -> u32 { return lower_bound_i32(s_pos, n_reads, v); }; // #{pos < v}
+    const int32_t lc = l < 0 ? 0 : (l > ref_len + 1 ? ref_len + 1 : l);
+    u32 ended = 0, i0 = 0, i1 = 0;
+    if (on) {
+        if (lc == ref_len + 1) ended = n_reads; // (the histogram clamps every end to ref_len)
+        else {
+            i0 = lower_bound_i64(s_pos, n_reads, (int64_t)lc - (int64_t)cnt->max_span);
+            i1 = lower_bound_i32(s_pos, n_reads, lc);
+            ended = i0;
+        }
+    }
+    u32 part = 0, unused = 0;
+    ranges_sum2(i0, i1, Win{lc, 0, 0, 0}, [&](u32 i, const Win w, u32 &a, u32 &) {
+        if (s_end[i] - 1 < w.p1lo) a++;
+    }, part, unused);
+    if (!on) return;
+    u32 up = before(s) - (ended + part);
+    u32 down = before(r == INT32_MAX ? r : r + 1) - before(e == INT32_MAX ? e : e + 1);
+    u32 nz = cnt->n_zero;
+    if (nz > zcap) nz = zcap;
+    for (u32 k = 0; k < nz; k++) {
+        const int32_t pos = (int32_t)zlist[k], end = pos - 1;
+        if (s > pos && l <= end) up++;
+        if (r >= pos && e < pos) down++;
+    }
+    out[j].up_aln = up;
+    out[j].down_aln = down;
+}
+
+// what a target keeps for pjb_extra_finish (device pointers): the records with a span in rank order, their gaps (record
+// order = rank order) and the number of gaps before every 256th of them
+struct SparseDepth {
+    const int32_t *s_pos, *s_end;
+    const Gap *gaps;
+    const u32 *gapoff;
+    u32 n_reads, n_gaps, max_span, max_gap;
+};
+__device__ __forceinline__ u32 span_overlap(int64_t x0, int64_t x1, int32_t plo, int32_t phi) { // |[x0, x1) n [plo, phi]|
+    const int64_t lo = x0 > plo ? x0 : (int64_t)plo, hi = (x1 - 1) < phi ? (x1 - 1) : (int64_t)phi;
+    return hi >= lo ? (u32)(hi - lo + 1) : 0u;
+}
+// sum over i in [a, b], 1 <= i < len, of the depth at position i - 1 -- for two windows [a1, b1], [a2, b2] at once; every lane of
+// the wavefront calls this (`on`: the lane has a junction)
+__device__ __forceinline__ void sparse_cov2(const SparseDepth D, int32_t len, bool on, int32_t a1, int32_t b1, int32_t a2, int32_t b2, u32 &sum1,
+                                            u32 &sum2) {
+    // window [a, b] in i -> positions [max(a, 1) - 1, min(b, len - 1) - 1]
+    auto lo_of = [&](int32_t a) -> int32_t { return (a < 1 ? 1 : a) - 1; };
+    auto hi_of = [&](int32_t b) -> int32_t { return b < 0 ? -1 : (b > len - 1 ? len - 1 : b) - 1; };
+    const Win w{lo_of(a1), hi_of(b1), lo_of(a2), hi_of(b2)};
+    const bool e1 = w.p1hi >= w.p1lo, e2 = w.p2hi >= w.p2lo;
+    int64_t lo = 0, hi = -1;
+    if (e1) lo = w.p1lo, hi = w.p1hi;
+    if (e2) {
+        lo = e1 && lo < w.p2lo ? lo : (int64_t)w.p2lo;
+        hi = e1 && hi > w.p2hi ? hi : (int64_t)w.p2hi;
+    }
+    u32 i0 = 0, i1 = 0, g0 = 0, g1 = 0;
+    if (on && hi >= lo) {
+        i0 = lower_bound_i64(D.s_pos, D.n_reads, lo - (int64_t)D.max_span + 1);
+        i1 = lower_bound_i64(D.s_pos, D.n_reads, hi + 1);
+        if (D.n_gaps && i1 > i0) { // a gap that covers a position of the window belongs to a record starting in (lo - max_span, hi]
+            const u32 k1 = (i1 + 255u) >> 8;
+            g0 = D.gapoff[i0 >> 8];
+            g1 = (u64)k1 * 256u < (u64)D.n_reads ? D.gapoff[k1] : D.n_gaps;
+        }
+    }
+    u32 s1 = 0, s2 = 0, m1 = 0, m2 = 0;
+    ranges_sum2(i0, i1, w, [&](u32 i, const Win ww, u32 &a, u32 &b) {
+        const int64_t x0 = D.s_pos[i], x1 = D.s_end[i];
+        a += span_overlap(x0, x1, ww.p1lo, ww.p1hi);
+        b += span_overlap(x0, x1, ww.p2lo, ww.p2hi);
+    }, s1, s2);
+    ranges_sum2(g0, g1, w, [&](u32 k, const Win ww, u32 &a, u32 &b) {
+        const Gap g = D.gaps[k];
+        a += span_overlap(g.start, g.end, ww.p1lo, ww.p1hi);
+        b += span_overlap(g.start, g.end, ww.p2lo, ww.p2hi);
+    }, m1, m2);
+    sum1 = s1 - m1;
+    sum2 = s2 - m2;
+}
+// Junction::calcCoverage (junction.cc:923-951) from a target's records instead of its depth vector: a thread per junction
+__global__ __launch_bounds__(256) void kx_coverage_sparse(const pjb_junction_row *rows, u32 row0, u32 n, SparseDepth D, int32_t len_src, ExtraRow *out) {
+    const u32 k = blockIdx.x * 256 + threadIdx.x;
+    const bool on = k < n;
+    const u32 j = row0 + (on ? k : 0u);
+    int32_t s = 0, e = 0;
+    if (on) s = rows[j].start, e = rows[j].end;
+    u32 d1, d2, a1, a2;
+    sparse_cov2(D, len_src, on, s - 20, s - 11, s - 10, s, d1, d2);
+    sparse_cov2(D, len_src, on, e + 10, e + 20, e, e + 9, a1, a2);
+    if (!on) return;
+    const double donor = (1.0 / 9.0) * (double)d1 - (1.0 / 10.0) * (double)d2;
+    const double acceptor = (1.0 / 10.0) * (double)a1 - (1.0 / 9.0) * (double)a2;
+    out[j].coverage = donor + acceptor;
+}
+
 // ---- phase 2 (all contigs done) ---------------------------------------------------------------------------
 constexpr u64 NAME_EMPTY = ~0ull;
 __device__ __forceinline__ u64 name_slot_key(u64 code) { return code == NAME_EMPTY ? code - 1 : code; }
-__device__ __forceinline__ u32 name_slot_of(u64 key, u32 mask) { return (u32)((key * 0x9e3779b97f4a7c15ULL) >> 32) & mask; }
+// (any number of slots, not a power of two: the table of a file is sized to its names, and 144 MB stay in the 256 MB of
+// Infinity Cache where 268 MB do not)
+__device__ __forceinline__ u32 name_slot_of(u64 key, u32 slots) { return (u32)((((key * 0x9e3779b97f4a7c15ULL) >> 32) * (u64)slots) >> 32); }
+__device__ __forceinline__ u32 name_next(u32 h, u32 slots) { return h + 1 == slots ? 0u : h + 1; }
 
-// splicedAlignmentMap[code]++ (junction_builder.cc:173-174) for every spliced record of the file
-__global__ __launch_bounds__(256) void kx_name_insert(const u64 *codes, u32 n, u64 *keys, u32 *counts, u32 mask) {
-    const u32 i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const u64 key = name_slot_key(codes[i]);
-    u32 h = name_slot_of(key, mask);
+// splicedAlignmentMap[code]++ (junction_builder.cc:173-174) for every spliced record of the file.  One 16-byte slot per
+// name: key and count share a sector (a lookup is one random access, not two); the table is filled with 0xff, so an empty
+// slot's key is NAME_EMPTY and a slot's count is `count + 1` in 32-bit arithmetic.
+struct NameSlot {
+    u64 key;
+    u32 count, _pad;
+};
+__device__ __forceinline__ void name_add(NameSlot *tab, u32 slots, u64 key, u32 n) {
+    u32 h = name_slot_of(key, slots);
     for (;;) {
-        u64 cur = keys[h];
-        if (cur == NAME_EMPTY) cur = atomicCAS((unsigned long long *)&keys[h], (unsigned long long)NAME_EMPTY, (unsigned long long)key);
+        u64 cur = tab[h].key;
+        if (cur == NAME_EMPTY) cur = atomicCAS((unsigned long long *)&tab[h].key, (unsigned long long)NAME_EMPTY, (unsigned long long)key);
         if (cur == NAME_EMPTY || cur == key) {
-            atomicAdd(&counts[h], 1u);
+            atomicAdd(&tab[h].count, n);
             return;
         }
-        h = (h + 1) & mask;
+        h = name_next(h, slots);
     }
 }
-// M of every junction: sum over its alignments of the map entry of their code (junction.cc:916-919, uint32)
-__global__ __launch_bounds__(256) void kx_name_sum(const u64 *pair_code, const u32 *pair_row, u32 n, const u64 *keys,
-                                                    const u32 *counts, u32 mask, ExtraRow *out) {
+// the table has grown: every name of the old one into the new one
+__global__ __launch_bounds__(256) void kx_name_rehash(const NameSlot *old_tab, u32 old_slots, NameSlot *tab, u32 slots) {
     const u32 i = blockIdx.x * 256 + threadIdx.x;
-    const bool on = i < n;
-    u32 c = 0, row = 0xffffffffu;
-    if (on) {
-        const u64 key = name_slot_key(pair_code[i]);
-        u32 h = name_slot_of(key, mask);
-        while (keys[h] != key && keys[h] != NAME_EMPTY) h = (h + 1) & mask;
-        c = keys[h] == key ? counts[h] : 0u;
-        row = pair_row[i];
+    if (i >= old_slots) return;
+    const NameSlot o = old_tab[i];
+    if (o.key != NAME_EMPTY) name_add(tab, slots, o.key, o.count + 1u);
+}
+// M of every junction: sum over its alignments of the map entry of their code (junction.cc:916-919, uint32).  Four pairs
+// per thread, a wavefront's 256 consecutive pairs in four rounds: the four random probes of a thread are in flight together.
+__global__ __launch_bounds__(256) void kx_name_sum(const u64 *pair_code, const u32 *pair_row, u32 n, const NameSlot *tab, u32 slots, ExtraRow *out) {
+    const u32 base = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 256 + (u32)lane_id();
+    u64 key[4];
+    u32 h[4], row[4], c[4];
+    NameSlot sl[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const u32 i = base + 64 * k;
+        key[k] = i < n ? name_slot_key(pair_code[i]) : 0ull;
+        row[k] = i < n ? pair_row[i] : 0xffffffffu;
+        h[k] = name_slot_of(key[k], slots);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) sl[k] = tab[h[k]];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const u32 i = base + 64 * k;
+        while (i < n && sl[k].key != key[k] && sl[k].key != NAME_EMPTY) {
+            h[k] = name_next(h[k], slots);
+            sl[k] = tab[h[k]];
+        }
+        c[k] = i < n && sl[k].key == key[k] ? sl[k].count + 1u : 0u;
     }
     // pairs are stored junction by junction: fold equal rows inside the wave before the atomic
-    c = seg_reduce_to_head(c, row, OpAdd());
-    const u32 prev = __shfl_up(row, 1, 64);
-    if (on && (lane_id() == 0 || prev != row)) atomicAdd(&out[row].m_sum, c);
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const u32 i = base + 64 * k;
+        const u32 cc = seg_reduce_to_head(c[k], row[k], OpAdd());
+        const u32 prev = __shfl_up(row[k], 1, 64);
+        if (i < n && (lane_id() == 0 || prev != row[k])) atomicAdd(&out[row[k]].m_sum, cc);
+    }
+}
+// four codes per thread into the table (the probes of a thread in flight together)
+__global__ __launch_bounds__(256) void kx_name_insert4(const u64 *codes, u32 n, NameSlot *tab, u32 slots) {
+    const u32 base = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 256 + (u32)lane_id();
+    u64 key[4];
+    u32 h[4];
+    u64 cur[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const u32 i = base + 64 * k;
+        key[k] = i < n ? name_slot_key(codes[i]) : 0ull;
+        h[k] = name_slot_of(key[k], slots);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) cur[k] = tab[h[k]].key; // (a plain look first: most codes of a deep file are in the table already)
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        if (base + 64 * k >= n) continue;
+        if (cur[k] == key[k]) atomicAdd(&tab[h[k]].count, 1u);
+        else name_add(tab, slots, key[k], 1u);
+    }
 }
 
 // Junction::calcCoverage (junction.cc:923-951) for the rows [row0, row0 + n) against the depth vector of one
@@ -375,20 +703,25 @@ __device__ __forceinline__ double cov_window(const u32 *cover, int32_t len, int3
         if (i >= 1 && i < len) readCount += cover[i - 1];
     return multiplier * (double)readCount;
 }
-__global__ __launch_bounds__(256) void kx_coverage(const int32_t *row_start, const int32_t *row_end, const uint32_t *row_raw,
-                                                    u32 row0, u32 n, const u32 *cover, int32_t len_src, ExtraRow *out) {
+__global__ __launch_bounds__(256) void kx_coverage(const pjb_junction_row *rows, u32 row0, u32 n, const u32 *cover, int32_t len_src, ExtraRow *out) {
     const u32 k = blockIdx.x * 256 + threadIdx.x;
     if (k >= n) return;
     const u32 j = row0 + k;
-    const int32_t s = row_start[j], e = row_end[j];
+    const int32_t s = rows[j].start, e = rows[j].end;
     const double donor = cov_window(cover, len_src, s - 20, s - 11) - cov_window(cover, len_src, s - 10, s);
     const double acceptor = cov_window(cover, len_src, e + 10, e + 20) - cov_window(cover, len_src, e, e + 9);
     out[j].coverage = donor + acceptor;
 }
-__global__ __launch_bounds__(256) void kx_mm_score(const uint32_t *row_raw, u32 n, ExtraRow *out) {
+// the finished columns of every junction, in the layout pjb_extra_finish hands out (mm_score = N / M, junction.cc:920)
+__global__ __launch_bounds__(256) void kx_rows_out(const pjb_junction_row *rows, const ExtraRow *x, u32 n, pjb_extra_row *out) {
     const u32 j = blockIdx.x * 256 + threadIdx.x;
     if (j >= n) return;
-    out[j].mm_score = (double)row_raw[j] / (double)out[j].m_sum; // N / M, junction.cc:920
+    pjb_extra_row o;
+    o.mm_score = (double)rows[j].nb_raw / (double)x[j].m_sum;
+    o.coverage = x[j].coverage;
+    o.up_aln = x[j].up_aln;
+    o.down_aln = x[j].down_aln;
+    out[j] = o;
 }
 
 // ---- filt feature rows: ModelFeatures::setRow, lib/src/model_features.cc:161-212 ------------------

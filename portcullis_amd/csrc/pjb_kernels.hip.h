@@ -495,11 +495,30 @@ __global__ __launch_bounds__(256) void k0_encode(const uint8_t *g, int64_t n, u3
 // ---------------------------------------------------------------------------------------------
 constexpr int K1_TILE = 1024;
 
+// --extra by-products of the first pass (pjb_extra.hip.h, "the sparse path"): which records belong to unspliced.bam and what
+// they span -- k1_count has every record's CIGAR in registers anyway
+struct SparseCounters { // one per target, device memory (zeroed)
+    u32 n_zero;       // unspliced mapped records with no reference-consuming op (zlist entries)
+    u32 max_span;     // longest reference span of an unspliced mapped record
+    u32 max_gap;      // longest D operation among them
+    u32 need_dense;   // bit 0: the pileup cap may bite; bit 1: a record with more than 126 gaps; bit 2: gap list full
+    u64 total;        // written by the scan: unspliced records with a span | gaps << 32
+};
+constexpr u32 SPARSE_GAP_MAX = 126;
+struct XOut {
+    int32_t *s_pos, *s_end; // per record (global ordinal): position, exclusive end of the span (= pos: no span / not unspliced.bam)
+    uint8_t *q;             // bit 0: has a span, bits 1-7: D operations
+    u32 *zlist;
+    u32 zcap;
+    SparseCounters *cnt;
+};
+
 // chk_ref_len > 0 (members of a group): a tile with an alignment that ends past the target reports max_end = INT32_MAX, so
 // that k1_scan_tiles sees "weird coordinates" whatever the group's virtual length is (the host then finishes the
 // members one by one).
+template <bool EXTRA>
 __global__ __launch_bounds__(256) void k1_count(DevBatch b, u32 *tile_cnt, TileStats *tile_stats, u32 *spl_idx,
-                                                 u32 *spl_poff, u64 *err, int32_t chk_ref_len) {
+                                                 u32 *spl_poff, u64 *err, int32_t chk_ref_len, XOut X) {
     __shared__ u64 sm64[4];
     __shared__ u64 sm_scan4[4][4];
     __shared__ int32_t smi[4][6];
@@ -513,6 +532,8 @@ __global__ __launch_bounds__(256) void k1_count(DevBatch b, u32 *tile_cnt, TileS
     u32 c0[4], nop[4], ops[4][K1_OPS];
     int32_t pos4[4], prev4[4], len4[4];
     u32 xs4[4], c4[4];
+    u32 xflag4[4] = {0, 0, 0, 0}, xspan = 0, xgapmax = 0; // (EXTRA)
+    bool xmany = false;
 #pragma unroll
     for (int it = 0; it < 4; it++) {
         const int64_t r = base + it * 256 + threadIdx.x;
@@ -523,6 +544,7 @@ __global__ __launch_bounds__(256) void k1_count(DevBatch b, u32 *tile_cnt, TileS
         prev4[it] = on ? (r > 0 ? b.pos[r - 1] : (b.prev_pos_ptr ? *b.prev_pos_ptr : b.prev_pos)) : 0;
         xs4[it] = on ? (u32)b.xs[r] : 0u;
         len4[it] = on ? b.l_qseq[r] : 0;
+        if (EXTRA) xflag4[it] = on ? (u32)b.flag[r] : 0u;
     }
 #pragma unroll
     for (int it = 0; it < 4; it++)
@@ -536,7 +558,7 @@ __global__ __launch_bounds__(256) void k1_count(DevBatch b, u32 *tile_cnt, TileS
             const int32_t p = pos4[it];
             if (p < prev4[it]) set_error(err, b.base + (u32)r, PJB_ERR_UNSORTED);
             if (xs4[it] > 2) set_error(err, b.base + (u32)r, PJB_ERR_BAD_XS);
-            u32 c = 0;
+            u32 c = 0, ngap = 0, gmax = 0;
             int32_t al = 0;
             auto count_op = [&](u32 op) {
                 const u32 ty = op & 15u;
@@ -545,6 +567,10 @@ __global__ __launch_bounds__(256) void k1_count(DevBatch b, u32 *tile_cnt, TileS
                 if (ty == OP_N) {
                     c++;
                     max_nlen = ln > max_nlen ? ln : max_nlen;
+                }
+                if (EXTRA && ty == OP_D && ln) { // inside the span, no depth
+                    ngap++;
+                    gmax = max(gmax, (u32)ln);
                 }
             };
 #pragma unroll
@@ -563,8 +589,33 @@ __global__ __launch_bounds__(256) void k1_count(DevBatch b, u32 *tile_cnt, TileS
             } else
                 uns++;
             cthis = c;
+            if (EXTRA) { // the record's part in unspliced.bam (junction_builder.cc:168-186)
+                const u32 g = b.base + (u32)r;
+                const bool unspliced = c == 0 && !(xflag4[it] & 0x4u);
+                const bool spans = unspliced && al > 0 && p >= 0;
+                X.s_pos[g] = p;
+                X.s_end[g] = spans ? p + al : p;
+                if (!spans) ngap = 0, gmax = 0;
+                if (ngap > SPARSE_GAP_MAX) xmany = true, ngap = SPARSE_GAP_MAX;
+                X.q[g] = (uint8_t)((spans ? 1u : 0u) | (ngap << 1));
+                if (spans) xspan = max(xspan, (u32)al);
+                xgapmax = max(xgapmax, gmax);
+                if (unspliced && al == 0) {
+                    const u32 z = atomicAdd(&X.cnt->n_zero, 1u);
+                    if (z < X.zcap) X.zlist[z] = (u32)p;
+                }
+            }
         }
         c4[it] = cthis;
+    }
+    if (EXTRA) {
+        xspan = wave_max(xspan);
+        xgapmax = wave_max(xgapmax);
+        if (lane_id() == 0) { // (look first: the maxima settle after a few waves)
+            if (xspan > X.cnt->max_span) atomicMax(&X.cnt->max_span, xspan);
+            if (xgapmax > X.cnt->max_gap) atomicMax(&X.cnt->max_gap, xgapmax);
+        }
+        if (xmany) atomicOr(&X.cnt->need_dense, 2u);
     }
     // ordered compaction of the spliced reads of this tile: slot k holds the k-th spliced read
     // (batch-local index) and the tile-local offset of its first pair.  Read order is round-major
@@ -2822,7 +2873,7 @@ __global__ __launch_bounds__(256) void k6_rows_out(const u64 *rows, const Contig
 // The last kernel of a contig: control block, error word and list counters go to page-locked host memory in one go
 // (three small copies otherwise), error word and counters return to their rest state for the contig that uses this
 // control slot next, and the row cursor moves on.
-constexpr int PUB_BASE_AT = 240, PUB_ERR_AT = 256, PUB_GEN_AT = 512, PUB_MEMBERS_AT = 1536, PUB_BYTES = 4096; // byte offsets in the published block
+constexpr int PUB_BASE_AT = 240, PUB_ERR_AT = 256, PUB_XCNT_AT = 320 /* --extra: the target's counters, 64 bytes */, PUB_GEN_AT = 512, PUB_MEMBERS_AT = 1536, PUB_BYTES = 4096; // byte offsets in the published block
 static_assert(PUB_MEMBERS_AT + GROUP_MAX * sizeof(MemberStats) <= PUB_BYTES && sizeof(MemberStats) % 8 == 0, "control block layout");
 __global__ __launch_bounds__(256) void k7_publish(const ContigStats *cs, u64 *err, u32 *gencount, uint8_t *host, int64_t base, int64_t mirror_base,
                                                   RowCursor *cur, const MemberStats *members, const u32 *member_junc, int n_members) {

@@ -327,16 +327,18 @@ class Context:
         self._check(self._L.pjb_collect_device(self._h, C.byref(p), C.byref(n)))
         return (p.value or 0), n.value
 
-    def extra_finish(self):
+    def extra_finish(self, copy=True):
         """calcExtraMetrics once every contig of the file is finished (FLAG_EXTRA contexts): one EXTRA_DTYPE record
-        per row of collect(), same order."""
+        per row of collect(), same order.  copy=False: a view of the context's page-locked table (valid until the next
+        clear_rows / close)."""
         p = C.c_void_p()
         n = C.c_int64()
         self._check(self._L.pjb_extra_finish(self._h, C.byref(p), C.byref(n)))
         if n.value == 0:
             return np.zeros(0, dtype=EXTRA_DTYPE)
         buf = (C.c_char * (n.value * EXTRA_DTYPE.itemsize)).from_address(p.value)
-        return np.frombuffer(buf, dtype=EXTRA_DTYPE, count=n.value).copy()
+        a = np.frombuffer(buf, dtype=EXTRA_DTYPE, count=n.value)
+        return a.copy() if copy else a
 
     def filter_set_junctions(self, tid, starts, ends):
         """bamfilt: the junctions of target `tid` that passed the filter (any order; duplicates are dropped)."""

@@ -55,11 +55,16 @@ def oracle_extra(orc, contigs, orientation="UNKNOWN"):
     return rows, lens
 
 
-def device_extra(ffi, orc, contigs, orientation="UNKNOWN", split=None):
-    """The same contigs through a PJB_FLAG_EXTRA context.  Returns (rows, extra rows)."""
+def device_extra(ffi, orc, contigs, orientation="UNKNOWN", split=None, queue=1, dense=False):
+    """The same contigs through a PJB_FLAG_EXTRA context.  Returns (rows, extra rows).  queue > 1: that many targets'
+    kernel chains queued at once (pjb_finish_contig_begin / _end); dense: the depth-vector path for every target
+    (pjb_set_option "extra_dense")."""
     with ffi.Context(0, orientation, flags=ffi.FLAG_EXTRA) as ctx:
         ctx.set_refs([len(g) for g, _ in contigs])
         ctx.clear_rows()
+        if dense:
+            ctx.set_option("extra_dense", 1)
+        queued = []
         for tid, (genome, reads) in enumerate(contigs):
             ctx.upload_contig(tid, genome.encode())
             if reads:
@@ -70,7 +75,15 @@ def device_extra(ffi, orc, contigs, orientation="UNKNOWN", split=None):
                         ctx.submit_batch(tid, b.slice(lo, hi))
                 else:
                     ctx.submit_batch(tid, b)
-            ctx.finish_contig(tid)
+            if queue <= 1:
+                ctx.finish_contig(tid)
+                continue
+            if len(queued) >= queue:
+                ctx.finish_contig_end(queued.pop(0))
+            ctx.finish_contig_begin(tid)
+            queued.append(tid)
+        for tid in queued:
+            ctx.finish_contig_end(tid)
         rows = ctx.collect()
         extra = ctx.extra_finish()
     return rows, extra

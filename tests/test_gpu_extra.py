@@ -34,11 +34,14 @@ def _contigs(seed, n_contigs=3, n_reads=2500, paired=False, **kw):
     return out
 
 
-@pytest.mark.parametrize("seed,paired", [(1, False), (2, True), (3, False), (4, True)])
-def test_extra_fuzz_multi_contig(ffi, orc, seed, paired):
-    contigs = _contigs(seed, paired=paired)
+@pytest.mark.parametrize("seed,paired,queue,dense", [(1, False, 1, False), (2, True, 3, False), (3, False, 2, True), (4, True, 1, True),
+                                                      (5, False, 4, False), (6, True, 2, False)])
+def test_extra_fuzz_multi_contig(ffi, orc, seed, paired, queue, dense):
+    """mm_score, coverage, up_aln, down_aln of three targets against the oracle: one target at a time and with several
+    chains queued; through the records themselves (the default) and through the depth vector (`dense`)."""
+    contigs = _contigs(seed, paired=paired, n_contigs=3 if seed < 5 else 5)
     orows, _ = oracle_extra(orc, contigs, "FR" if paired else "UNKNOWN")
-    rows, extra = device_extra(ffi, orc, contigs, "FR" if paired else "UNKNOWN")
+    rows, extra = device_extra(ffi, orc, contigs, "FR" if paired else "UNKNOWN", queue=queue, dense=dense)
     assert_rows_equal(rows, orows)
     assert_extra_equal(rows, extra, orows)
     assert (extra["up_aln"] > 0).any() and (extra["down_aln"] > 0).any() and (extra["mm_score"] < 1).any()
@@ -105,6 +108,45 @@ def test_extra_zero_span_and_edges(ffi, orc):
     rows, extra = device_extra(ffi, orc, contigs)
     assert_rows_equal(rows, orows)
     assert_extra_equal(rows, extra, orows)
+
+
+def test_extra_gaps_and_dense_fallbacks(ffi, orc):
+    """Deletions inside unspliced records around a junction (no depth inside a D), and the two ways a target falls back to
+    the depth vector: a record with more than 126 deletions, more deletions than the gap list holds."""
+    genome, reads = make_reads(21, glen=8000, n_reads=900, L=(60, 120))
+    rng = np.random.default_rng(8)
+    spliced = [r for r in reads if "N" in r["cigar"]]
+    assert spliced
+    extra_reads = []
+    for r in spliced[::3]:
+        import re
+        ops = re.findall(r"(\d+)([MIDNSHP=X])", r["cigar"])
+        start = r["pos"]         # intron start: the donor windows are [start - 21, start - 1]
+        for ln, op in ops:
+            if op == "N":
+                break
+            if op in "MD=X":
+                start += int(ln)
+        for k in range(4):
+            p = max(0, start - 30 - 3 * k)
+            extra_reads.append(dict(pos=p, cigar=f"{8 + k}M{2 + k}D{12}M1D{9}M", seq=None, l_qseq=0, flag=0))
+    base = sorted(reads + extra_reads, key=lambda r: r["pos"])
+    variants = {"gaps": base}
+    many = dict(pos=max(0, spliced[0]["pos"] - 50), cigar="".join("1M1D" for _ in range(130)) + "5M", seq=None, l_qseq=0, flag=0)
+    variants["a record with 130 gaps"] = sorted(base + [many], key=lambda r: r["pos"])
+    few = [r for r in base if "N" in r["cigar"]][:40]
+    lots = [dict(pos=max(0, few[k % len(few)]["pos"] - 20), cigar="".join("2M1D" for _ in range(60)) + "3M", seq=None, l_qseq=0, flag=0) for k in range(40)]
+    variants["gap list full"] = sorted(few + lots, key=lambda r: r["pos"])
+    for what, rr in variants.items():
+        rr = [dict(r) for r in rr]
+        add_names(rr, rng, "g", unmapped_frac=0.0)
+        contigs = [(genome, rr)]
+        orows, _ = oracle_extra(orc, contigs)
+        for dense in (False, True):
+            rows, extra = device_extra(ffi, orc, contigs, dense=dense)
+            assert_rows_equal(rows, orows)
+            assert_extra_equal(rows, extra, orows)
+        assert (extra["coverage"] != 0).any(), what
 
 
 def test_extra_needs_name_hash_and_flag(ffi, orc):
