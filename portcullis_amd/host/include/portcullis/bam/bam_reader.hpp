@@ -135,6 +135,20 @@ public:
     // sequence, src/junction_builder.cc:109-112; this is SURVEY row f1, host ingest.)
     void decodeRegionParallel(int32_t tid, int nthreads, size_t maxRecords, const std::function<void(ReadBatch&)>& sink);
 
+    // Every record of the file in file order (unplaced ones included) for callers that keep records as byte spans
+    // (BamFilter): the file is taken in pieces of about `chunkBytes` inflated bytes -- blocks inflated by `nthreads`
+    // workers, record starts found by all of them at once (each walks the block_size chain from a record start the
+    // index names to the next one; the unplaced tail of a file, which no index covers, is one walk) -- and `sink` gets
+    // one FileChunk per piece: whole records only, `slices` = their offsets in `data`, slice after slice in file order.
+    // The chunk's memory is the reader's: it is overwritten by the next piece.
+    struct FileChunk {
+        const uint8_t* data = nullptr;
+        size_t bytes = 0;
+        std::vector<const std::vector<uint64_t>*> slices;  // record offsets (each: 4-byte block_size + body)
+        size_t records = 0;
+    };
+    void scanRecordsParallel(int nthreads, size_t chunkBytes, const std::function<void(const FileChunk&)>& sink);
+
     // The file bytes that hold target `tid`'s records, untouched (whole BGZF blocks: from the block with its
     // first record through the block in which the next target starts, or the end of the file), read with
     // `nthreads` parallel preads into one bigAlloc buffer the caller frees with bigFree.  firstU = offset of

@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "bam_master.hpp"
+#include "phase_pool.hpp"
 
 namespace portcullis {
 namespace bam {
@@ -38,6 +39,10 @@ class BamWriter {
     uint32_t prevBin = 0;
     void flush(bool final);
     void indexRecord(const RecInfo& r, uint64_t vs, uint64_t ve);
+    int32_t cacheTid = -1;             // indexRecord: the bin of the previous record (records come sorted: nearly always the same)
+    uint32_t cacheBin = 0;
+    std::vector<std::pair<uint64_t, uint64_t>>* cacheChunks = nullptr;
+    PhasePool* pool = nullptr;         // writeRecords' workers also compress (else: threads started per flush)
 
 public:
     static constexpr size_t BLOCK = 0xff00;
@@ -48,6 +53,11 @@ public:
     void open(const std::string& headerText, const std::vector<RefSeq>& targets);
     // one alignment record: the 4-byte block_size followed by block_size bytes, exactly as in the input file
     void write(const uint8_t* rec, size_t len);
+    // Many records at once: the records at data + (*slices[s])[k], slice after slice, of which those are written whose code
+    // (codes[flat index]; nullptr: every record) is non-zero -- or equals `only` when `only` is non-zero.  The bytes are
+    // gathered and the blocks compressed by `workers`.
+    void writeRecords(const uint8_t* data, const std::vector<const std::vector<uint64_t>*>& slices, const uint8_t* codes, uint8_t only,
+                      PhasePool& workers);
     void close();
     bool isOpen() const { return fp != nullptr; }
 };

@@ -15,6 +15,7 @@
 
 #include <portcullis/bam/bam_reader.hpp>
 #include <portcullis/bam/bam_writer.hpp>
+#include <portcullis/bam/phase_pool.hpp>
 #include <portcullis/junction_system.hpp>
 
 #include "../../../include/portcullis_amd.h"
@@ -101,71 +102,86 @@ void BamFilter::filter() {
         cout << " - Saving unmodified MSRs to: " << outputBam << ".unmod.bam" << endl;
     }
     nbReadsIn = nbReadsOut = nbReadsModifiedOut = 0;
-    // ---- records in file order; a chunk = consecutive records of one target
-    const size_t CHUNK = 1u << 20;
-    std::vector<uint8_t> raw;          // the chunk's records, back to back
-    std::vector<size_t> recOff;        // start of each record in `raw` (+ end)
-    std::vector<int32_t> pos;
-    std::vector<uint32_t> cigOff, cigar;
-    std::vector<uint8_t> codes;
-    int32_t chunkTid = -2;
+    // ---- the file in pieces of 256 MB of records (src/bam_filter.cc:190-225 visits them one by one).  Everything per
+    // record is done by `threads` workers at once: BGZF inflate and finding the records (BamReader::scanRecordsParallel),
+    // pulling out (target, pos, CIGAR), gathering the kept records and compressing them (BamWriter::writeRecords); the
+    // decision comes from the device, one batch per run of records of a target.
     const int32_t mode = clipMode == ClipMode::HARD ? PJB_CLIP_HARD : clipMode == ClipMode::SOFT ? PJB_CLIP_SOFT : PJB_CLIP_COMPLETE;
-    auto flushChunk = [&]() {
-        const size_t n = pos.size();
-        if (n == 0) return;
+    bam::PhasePool workers(threads > 1 ? threads : 0);
+    std::vector<int32_t> tids, pos;
+    std::vector<uint32_t> cigOff, cigar, runOff;
+    std::vector<uint8_t> codes;
+    auto le32 = [](const uint8_t* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); };
+    reader.scanRecordsParallel(threads, (size_t)256 << 20, [&](const bam::BamReader::FileChunk& fc) {
+        const size_t ns = fc.slices.size(), n = fc.records;
+        std::vector<size_t> base(ns + 1, 0), opBase(ns + 1, 0);
+        for (size_t s = 0; s < ns; s++) base[s + 1] = base[s] + fc.slices[s]->size();
+        tids.resize(n);
+        pos.resize(n);
+        cigOff.resize(n + 1);
         codes.assign(n, 1);
-        if (chunkTid >= 0) {
-            pjb_batch b;
-            memset(&b, 0, sizeof b);
-            b.n_reads = (int64_t)n;
-            b.pos = pos.data();
-            b.cig_off = cigOff.data();
-            b.cigar = cigar.empty() ? cigOff.data() : cigar.data();
-            if (pjb_filter_batch(ctx, chunkTid, &b, mode, codes.data()) != PJB_OK)
-                throw BamFilterException(std::string("pjb_filter_batch: ") + pjb_last_error(ctx));
-        }
-        for (size_t i = 0; i < n; i++) {
-            const uint8_t* r = raw.data() + recOff[i];
-            const size_t len = recOff[i + 1] - recOff[i];
-            if (codes[i] == 0) continue;
-            writer.write(r, len);
-            nbReadsOut++;
-            if (codes[i] == 3) {
-                nbReadsModifiedOut++;
-                if (saveMSRs) {
-                    mod->write(r, len);
-                    unmod->write(r, len);
-                }
+        workers.run(ns, [&](size_t s) {  // (the reader checked that every record's name and CIGAR lie inside it)
+            size_t ops = 0, i = base[s];
+            for (uint64_t off : *fc.slices[s]) {
+                const uint8_t* r = fc.data + off;
+                tids[i] = (int32_t)le32(r + 4);
+                pos[i] = (int32_t)le32(r + 8);
+                ops += (uint32_t)r[16] | ((uint32_t)r[17] << 8);
+                i++;
             }
+            opBase[s + 1] = ops;
+        });
+        for (size_t s = 0; s < ns; s++) opBase[s + 1] += opBase[s];
+        if (opBase[ns] > 0xfffffff0ull) throw BamFilterException("Too many CIGAR operations in one piece of the file");
+        cigar.resize(opBase[ns] + 1);
+        cigOff[n] = (uint32_t)opBase[ns];
+        workers.run(ns, [&](size_t s) {
+            size_t o = opBase[s], i = base[s];
+            for (uint64_t off : *fc.slices[s]) {
+                const uint8_t* r = fc.data + off;
+                const uint32_t l_name = r[12], n_cig = (uint32_t)r[16] | ((uint32_t)r[17] << 8);
+                cigOff[i++] = (uint32_t)o;
+                memcpy(&cigar[o], r + 36 + l_name, 4ull * n_cig);  // (little-endian host, like everything around the C ABI)
+                o += n_cig;
+            }
+        });
+        // runs of one target: the device answers for each
+        for (size_t a = 0; a < n;) {
+            size_t b = a + 1;
+            while (b < n && tids[b] == tids[a]) b++;
+            if (tids[a] >= 0) {
+                const uint32_t o0 = cigOff[a];
+                const uint32_t* co = cigOff.data() + a;
+                if (o0) {  // the batch's offsets start at 0
+                    runOff.resize(b - a + 1);
+                    for (size_t k = 0; k <= b - a; k++) runOff[k] = cigOff[a + k] - o0;
+                    co = runOff.data();
+                }
+                pjb_batch pb;
+                memset(&pb, 0, sizeof pb);
+                pb.n_reads = (int64_t)(b - a);
+                pb.pos = pos.data() + a;
+                pb.cig_off = co;
+                pb.cigar = cigar.data() + o0;
+                if (pjb_filter_batch(ctx, tids[a], &pb, mode, codes.data() + a) != PJB_OK)
+                    throw BamFilterException(std::string("pjb_filter_batch: ") + pjb_last_error(ctx));
+            }
+            a = b;
         }
-        raw.clear();
-        recOff.assign(1, 0);
-        pos.clear();
-        cigOff.assign(1, 0);
-        cigar.clear();
-    };
-    recOff.assign(1, 0);
-    cigOff.assign(1, 0);
-    std::vector<uint8_t> rec;
-    reader.rewind();
-    while (reader.nextRecord(rec)) {
-        nbReadsIn++;
-        const uint8_t* r = rec.data();
-        auto le32 = [](const uint8_t* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); };
-        const int32_t tid = (int32_t)le32(r + 4);
-        const uint32_t l_name = r[12], n_cig = (uint32_t)r[16] | ((uint32_t)r[17] << 8);
-        if (36ull + l_name + 4ull * n_cig > rec.size()) throw BamFilterException("Invalid BAM record layout");
-        if (tid != chunkTid || pos.size() >= CHUNK) {
-            flushChunk();
-            chunkTid = tid;
+        size_t out = 0, modified = 0;
+        for (size_t i = 0; i < n; i++) {
+            out += codes[i] != 0;
+            modified += codes[i] == 3;
         }
-        raw.insert(raw.end(), rec.begin(), rec.end());
-        recOff.push_back(raw.size());
-        pos.push_back((int32_t)le32(r + 8));
-        for (uint32_t k = 0; k < n_cig; k++) cigar.push_back(le32(r + 36 + l_name + 4 * k));
-        cigOff.push_back((uint32_t)cigar.size());
-    }
-    flushChunk();
+        nbReadsIn += n;
+        nbReadsOut += out;
+        nbReadsModifiedOut += modified;
+        writer.writeRecords(fc.data, fc.slices, codes.data(), 0, workers);
+        if (saveMSRs && modified) {
+            mod->writeRecords(fc.data, fc.slices, codes.data(), 3, workers);
+            unmod->writeRecords(fc.data, fc.slices, codes.data(), 3, workers);
+        }
+    });
     reader.close();
     writer.close();
     if (saveMSRs) {

@@ -1,4 +1,5 @@
 #include <portcullis/bam/bam_reader.hpp>
+#include <portcullis/bam/phase_pool.hpp>
 #include <portcullis/bam/name_hash.hpp>
 
 #include <algorithm>
@@ -546,63 +547,6 @@ struct Mapped {
     }
 };
 
-// Fixed set of worker threads for the phases of decodeRegionParallel (inflate / walk / fill): a phase
-// is `n` independent tasks, run(n, fn) returns when all of them are done.
-class PhasePool {
-    std::vector<std::thread> threads;
-    std::mutex mu;
-    std::condition_variable cvWork, cvDone;
-    std::function<void(size_t)> fn;
-    size_t nTasks = 0, nextTask = 0, pending = 0;
-    uint64_t generation = 0;
-    bool stop = false;
-
-    void loop() {
-        uint64_t seen = 0;
-        for (;;) {
-            std::unique_lock<std::mutex> lk(mu);
-            cvWork.wait(lk, [&] { return stop || (generation != seen && nextTask < nTasks); });
-            if (stop) return;
-            seen = generation;
-            while (nextTask < nTasks) {
-                const size_t t = nextTask++;
-                lk.unlock();
-                fn(t);
-                lk.lock();
-                if (--pending == 0) cvDone.notify_all();
-            }
-        }
-    }
-
-public:
-    explicit PhasePool(int n) {
-        for (int i = 0; i < n; i++) threads.emplace_back([this] { loop(); });
-    }
-    ~PhasePool() {
-        {
-            std::lock_guard<std::mutex> lk(mu);
-            stop = true;
-        }
-        cvWork.notify_all();
-        for (auto& t : threads) t.join();
-    }
-    void run(size_t n, std::function<void(size_t)> f) {
-        if (n == 0) return;
-        if (threads.empty() || n == 1) {
-            for (size_t t = 0; t < n; t++) f(t);
-            return;
-        }
-        std::unique_lock<std::mutex> lk(mu);
-        fn = std::move(f);
-        nTasks = n;
-        nextTask = 0;
-        pending = n;
-        generation++;
-        cvWork.notify_all();
-        cvDone.wait(lk, [&] { return pending == 0; });
-    }
-};
-
 template <typename F>
 void parallelFor(int nthreads, size_t n, F f) {  // f(thread, begin, end) over contiguous slices
     if (nthreads <= 1 || n < 2) {
@@ -701,6 +645,208 @@ uint8_t* BamReader::readRegionBytes(int32_t tid, int nthreads, size_t& bytes, ui
         throw;
     }
     return buf;
+}
+
+void BamReader::scanRecordsParallel(int nthreads, size_t chunkBytes, const std::function<void(const FileChunk&)>& sink) {
+    nthreads = std::max(1, nthreads);
+    PhasePool pool(nthreads > 1 ? nthreads : 0);
+    Mapped m;
+    m.fd = ::open(bamFile.c_str(), O_RDONLY);
+    if (m.fd < 0) throw BamException("Could not open BAM file: " + bamFile);
+    struct stat st;
+    if (fstat(m.fd, &st) != 0) throw BamException("Could not stat BAM file: " + bamFile);
+    const uint64_t fileSize = (uint64_t)st.st_size;
+    // every record start the index names, file-wide
+    std::vector<uint64_t> rpts;
+    for (const auto& v : restart) rpts.insert(rpts.end(), v.begin(), v.end());
+    std::sort(rpts.begin(), rpts.end());
+    rpts.erase(std::unique(rpts.begin(), rpts.end()), rpts.end());
+    const uint64_t CHUNK = std::max<uint64_t>(chunkBytes, 1u << 20);
+    struct BigFree {
+        void operator()(uint8_t* p) const { bigFree(p); }
+    };
+    const size_t CREAD = (size_t)std::min<uint64_t>(CHUNK, 96ull << 20) + (128u << 10);
+    std::unique_ptr<uint8_t[], BigFree> cbuf((uint8_t*)bigAlloc(CREAD)), buf;
+    size_t bufCap = 0, carry = 0, cHave = 0;
+    uint64_t cBase = firstRecordVoffset >> 16, fileOff = cBase;
+    bool first = true;
+    std::vector<Block> blocks;
+    std::vector<uint64_t> uoff;
+    std::vector<std::vector<uint64_t>> sl;
+    std::vector<size_t> stop;
+    for (;;) {
+        // ---- refill the compressed window
+        if (fileOff < fileSize && cHave < CREAD) {
+            const size_t want = (size_t)std::min<uint64_t>(CREAD - cHave, fileSize - fileOff);
+            const size_t nsl = std::max<size_t>(1, std::min<size_t>((size_t)nthreads, want >> 20));
+            std::atomic<bool> ioBad(false);
+            pool.run(nsl, [&](size_t t) {
+                const size_t per = (want + nsl - 1) / nsl, a = std::min(want, per * t), b = std::min(want, a + per);
+                size_t got = 0;
+                while (a + got < b) {
+                    const ssize_t r = pread(m.fd, cbuf.get() + cHave + a + got, b - a - got, (off_t)(fileOff + a + got));
+                    if (r <= 0) {
+                        ioBad = true;
+                        return;
+                    }
+                    got += (size_t)r;
+                }
+            });
+            if (ioBad) throw BamException("Could not read BAM file: " + bamFile);
+            cHave += want;
+            fileOff += want;
+        }
+        // ---- the blocks of this piece, from their headers
+        blocks.clear();
+        uoff.clear();
+        uint64_t total = 0;
+        size_t cpos = 0;
+        while (cpos + 18 <= cHave) {
+            const uint8_t* h = cbuf.get() + cpos;
+            if (h[0] != 31 || h[1] != 139 || h[2] != 8 || !(h[3] & 4)) throw BamException("Invalid BGZF block header");
+            const uint32_t xlen = le16(h + 10);
+            if (cpos + 12 + xlen > cHave) break;
+            int bsize = -1;
+            for (uint32_t o = 0; o + 4 <= xlen;) {
+                const uint8_t* x = h + 12 + o;
+                const uint32_t slen = le16(x + 2);
+                if (x[0] == 'B' && x[1] == 'C' && slen == 2 && o + 6 <= xlen) bsize = le16(x + 4);
+                o += 4 + slen;
+            }
+            if (bsize < 0) throw BamException("BGZF block without BC field");
+            const uint32_t tot = (uint32_t)bsize + 1;
+            if (tot < xlen + 20) throw BamException("Invalid BGZF block: BSIZE is smaller than the block's header and footer");
+            if (cpos + tot > cHave) break;
+            const uint32_t isz = le32(h + tot - 4);
+            if (isz > 65536) throw BamException("Invalid BGZF block: ISIZE exceeds 64 KiB");
+            if (total != 0 && total + isz > CHUNK) break;
+            blocks.push_back({(uint64_t)cpos, tot, isz, xlen});
+            uoff.push_back(total);
+            total += isz;
+            cpos += tot;
+        }
+        if (blocks.empty()) {
+            if (fileOff >= fileSize) {
+                if (cHave != 0) throw BamException("Truncated BGZF block at the end of the file");
+                break;
+            }
+            if (cHave >= CREAD) throw BamException("BGZF block larger than the read window");
+            continue;
+        }
+        const size_t nb = blocks.size(), end = carry + (size_t)total;
+        if (end + 8 > bufCap) {
+            const size_t ncap = std::max<size_t>(end + 8, (size_t)CHUNK + (4u << 20));
+            std::unique_ptr<uint8_t[], BigFree> nbuf((uint8_t*)bigAlloc(ncap));
+            if (carry) memcpy(nbuf.get(), buf.get(), carry);
+            buf.swap(nbuf);
+            bufCap = ncap;
+        }
+        {   // ---- inflate
+            std::atomic<size_t> next(0);
+            std::atomic<bool> bad(false);
+            uint8_t* base = buf.get() + carry;
+            pool.run(std::min<size_t>((size_t)nthreads, nb), [&](size_t) {
+                z_stream zs;
+                memset(&zs, 0, sizeof zs);
+                if (inflateInit2(&zs, -15) != Z_OK) {
+                    bad = true;
+                    return;
+                }
+                for (;;) {
+                    const size_t b = next.fetch_add(1);
+                    if (b >= nb) break;
+                    const Block& k = blocks[b];
+                    if (!k.isize) continue;
+                    inflateReset(&zs);
+                    zs.next_in = cbuf.get() + k.coff + 12 + k.xlen;
+                    zs.avail_in = k.csize - 12 - k.xlen - 8;
+                    zs.next_out = base + uoff[b];
+                    zs.avail_out = k.isize;
+                    const int rc = inflate(&zs, Z_FINISH);
+                    if (rc != Z_STREAM_END || zs.avail_out != 0) bad = true;
+                }
+                inflateEnd(&zs);
+            });
+            if (bad) throw BamException("BGZF inflate failed");
+        }
+        // ---- record starts the index names inside this piece
+        const size_t cur0 = first ? (size_t)(firstRecordVoffset & 0xffff) : 0;
+        first = false;
+        std::vector<size_t> pts;
+        pts.push_back(cur0);
+        {
+            const uint64_t vlo = (cBase + blocks[0].coff) << 16, vhi = (cBase + blocks[nb - 1].coff + 1) << 16;
+            auto it = std::lower_bound(rpts.begin(), rpts.end(), vlo);
+            size_t bi = 0;
+            for (; it != rpts.end() && *it < vhi; ++it) {
+                const uint64_t co = *it >> 16;
+                while (bi < nb && cBase + blocks[bi].coff < co) bi++;
+                if (bi >= nb || cBase + blocks[bi].coff != co) continue;
+                const size_t p = carry + (size_t)uoff[bi] + (size_t)(*it & 0xffff);
+                if (p > pts.back() && p + 36 <= end) pts.push_back(p);
+            }
+        }
+        std::vector<size_t> cut;
+        {
+            const int want = std::max(1, std::min<int>(nthreads * 4, (int)pts.size()));  // (more slices than threads: the tail of a file has no points)
+            cut.push_back(pts[0]);
+            for (int k = 1; k < want; k++) {
+                const size_t target = cur0 + (size_t)((double)(end - cur0) * k / want);
+                auto it = std::lower_bound(pts.begin(), pts.end(), target);
+                if (it != pts.end() && *it > cut.back()) cut.push_back(*it);
+            }
+        }
+        const size_t ns = cut.size();
+        if (sl.size() < ns) sl.resize(ns);
+        stop.assign(ns, 0);
+        std::atomic<bool> badWalk(false);
+        pool.run(ns, [&](size_t t) {
+            std::vector<uint64_t>& off = sl[t];
+            off.clear();
+            const size_t limit = t + 1 < ns ? cut[t + 1] : end;
+            off.reserve((limit - cut[t]) / 160 + 16);
+            size_t cur = cut[t];
+            const uint8_t* B = buf.get();
+            while (cur < limit) {
+                if (cur + 4 > end) break;
+                const uint32_t bs = le32(B + cur);
+                if (bs < 32) {
+                    badWalk = true;
+                    break;
+                }
+                if (cur + 4 + (size_t)bs > end) break;  // partial record at the end of the piece
+                const uint8_t* r = B + cur + 4;
+                if (32 + (size_t)r[8] + 4ull * le16(r + 12) > bs) {
+                    badWalk = true;
+                    break;
+                }
+                off.push_back(cur);
+                cur += 4 + (size_t)bs;
+            }
+            if (t + 1 < ns && cur != limit) badWalk = true;  // the index named a non-boundary
+            stop[t] = cur;
+        });
+        if (badWalk) throw BamException("Invalid BAM record (or the index names an offset that is not a record start)");
+        FileChunk fc;
+        fc.data = buf.get();
+        fc.bytes = stop[ns - 1];
+        for (size_t t = 0; t < ns; t++) {
+            fc.slices.push_back(&sl[t]);
+            fc.records += sl[t].size();
+        }
+        if (fc.records) sink(fc);
+        // ---- what is left: the partial record behind the last whole one, the compressed bytes behind the last block
+        const size_t used = stop[ns - 1];
+        carry = end - used;
+        if (carry) memmove(buf.get(), buf.get() + used, carry);
+        memmove(cbuf.get(), cbuf.get() + cpos, cHave - cpos);
+        cHave -= cpos;
+        cBase += cpos;
+        if (fileOff >= fileSize && cHave == 0) {
+            if (carry) throw BamException("Truncated BAM record at the end of the file");
+            break;
+        }
+    }
 }
 
 void BamReader::decodeRegionParallel(int32_t tid, int nthreads, size_t maxRecords, const std::function<void(ReadBatch&)>& sink) {

@@ -29,6 +29,19 @@ static int reg2bin(int64_t beg, int64_t end) {  // SAM specification section 5.3
     return 0;
 }
 
+static inline int32_t recordEnd(const uint8_t* rec, size_t len) {  // pos + reference span (at least 1), like bam_endpos
+    const int32_t pos = (int32_t)rd32(rec + 8);
+    const uint32_t l_name = rec[12], n_cig = rd16(rec + 16);
+    int64_t span = 0;
+    const uint8_t* cg = rec + 36 + l_name;
+    if (36 + (size_t)l_name + 4ull * n_cig <= len)
+        for (uint32_t k = 0; k < n_cig; k++) {
+            const uint32_t op = rd32(cg + 4 * k), ty = op & 15u;
+            if (ty == 0 || ty == 2 || ty == 3 || ty == 7 || ty == 8) span += op >> 4;
+        }
+    return (int32_t)(pos + (span > 0 ? span : 1));
+}
+
 BamWriter::~BamWriter() {
     try {
         if (fp) close();
@@ -43,6 +56,8 @@ void BamWriter::open(const std::string& headerText, const std::vector<RefSeq>& t
     nTargets = targets.size();
     bins.assign(nTargets, {});
     lin.assign(nTargets, {});
+    cacheChunks = nullptr;
+    cacheTid = -1;
     pending.clear();
     pending.insert(pending.end(), {'B', 'A', 'M', 1});
     put32(pending, (uint32_t)headerText.size());
@@ -64,15 +79,7 @@ void BamWriter::write(const uint8_t* rec, size_t len) {
         RecInfo r;
         r.tid = (int32_t)rd32(rec + 4);
         r.pos = (int32_t)rd32(rec + 8);
-        const uint32_t l_name = rec[12], n_cig = rd16(rec + 16);
-        int64_t span = 0;
-        const uint8_t* cg = rec + 36 + l_name;
-        if (36 + (size_t)l_name + 4ull * n_cig <= len)
-            for (uint32_t k = 0; k < n_cig; k++) {
-                const uint32_t op = rd32(cg + 4 * k), ty = op & 15u;
-                if (ty == 0 || ty == 2 || ty == 3 || ty == 7 || ty == 8) span += op >> 4;
-            }
-        r.end = (int32_t)(r.pos + (span > 0 ? span : 1));
+        r.end = recordEnd(rec, len);
         r.ustart = uflushed + pending.size();
         recs.push_back(r);
     }
@@ -80,10 +87,67 @@ void BamWriter::write(const uint8_t* rec, size_t len) {
     if (pending.size() >= BLOCK * 64 * (size_t)threads) flush(false);
 }
 
+void BamWriter::writeRecords(const uint8_t* data, const std::vector<const std::vector<uint64_t>*>& slices, const uint8_t* codes, uint8_t only,
+                             PhasePool& workers) {
+    if (!fp) throw BamException("BamWriter::writeRecords: file is not open");
+    const size_t ns = slices.size();
+    if (ns == 0) return;
+    auto keep = [&](size_t flat) { return !codes || (only ? codes[flat] == only : codes[flat] != 0); };
+    std::vector<size_t> base(ns + 1, 0), kb(ns + 1, 0), kr(ns + 1, 0);
+    for (size_t s = 0; s < ns; s++) base[s + 1] = base[s] + slices[s]->size();
+    workers.run(ns, [&](size_t s) {
+        size_t bytes = 0, n = 0;
+        const std::vector<uint64_t>& off = *slices[s];
+        for (size_t k = 0; k < off.size(); k++)
+            if (keep(base[s] + k)) {
+                bytes += 4 + (size_t)rd32(data + off[k]);
+                n++;
+            }
+        kb[s + 1] = bytes;
+        kr[s + 1] = n;
+    });
+    for (size_t s = 0; s < ns; s++) {
+        kb[s + 1] += kb[s];
+        kr[s + 1] += kr[s];
+    }
+    if (kr[ns] == 0) return;
+    const size_t p0 = pending.size(), r0 = recs.size();
+    pending.resize(p0 + kb[ns]);
+    if (wantIndex) recs.resize(r0 + kr[ns]);
+    workers.run(ns, [&](size_t s) {
+        const std::vector<uint64_t>& off = *slices[s];
+        uint8_t* dst = pending.data() + p0 + kb[s];
+        size_t i = r0 + kr[s];
+        for (size_t k = 0; k < off.size(); k++) {
+            if (!keep(base[s] + k)) continue;
+            const uint8_t* rec = data + off[k];
+            const size_t len = 4 + (size_t)rd32(rec);
+            memcpy(dst, rec, len);
+            if (wantIndex) {
+                RecInfo r;
+                r.tid = (int32_t)rd32(rec + 4);
+                r.pos = (int32_t)rd32(rec + 8);
+                r.end = recordEnd(rec, len);
+                r.ustart = uflushed + (uint64_t)(dst - pending.data());
+                recs[i++] = r;
+            }
+            dst += len;
+        }
+    });
+    pool = &workers;
+    if (pending.size() >= BLOCK * 64) flush(false);
+    pool = nullptr;
+}
+
 void BamWriter::indexRecord(const RecInfo& r, uint64_t vs, uint64_t ve) {
     if (r.tid < 0 || (size_t)r.tid >= nTargets) return;
     const uint32_t bin = (uint32_t)reg2bin(r.pos, r.end);
-    auto& ch = bins[(size_t)r.tid][bin];
+    if (r.tid != cacheTid || bin != cacheBin || !cacheChunks) {
+        cacheChunks = &bins[(size_t)r.tid][bin];  // (std::map: references stay valid while other bins are added)
+        cacheTid = r.tid;
+        cacheBin = bin;
+    }
+    auto& ch = *cacheChunks;
     if (!ch.empty() && ch.back().second == vs) ch.back().second = ve;
     else ch.push_back({vs, ve});
     const size_t w0 = (size_t)(std::max(r.pos, 0) >> 14), w1 = (size_t)(std::max(r.end - 1, 0) >> 14);
@@ -109,21 +173,22 @@ void BamWriter::flush(bool final) {
     std::atomic<size_t> next(0);
     auto work = [&]() {
         std::vector<uint8_t> out(70000);
+        z_stream zs;
+        memset(&zs, 0, sizeof zs);
+        if (deflateInit2(&zs, level, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) return;  // (the blocks stay empty: reported below)
         for (;;) {
             const size_t b = next.fetch_add(1);
             if (b >= nblk) break;
             const size_t off = b * BLOCK, len = std::min(BLOCK, take - off);
-            z_stream zs;
-            memset(&zs, 0, sizeof zs);
-            if (deflateInit2(&zs, level, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) continue;
+            deflateReset(&zs);
             zs.next_in = &pending[off];
             zs.avail_in = (uInt)len;
             zs.next_out = out.data();
             zs.avail_out = (uInt)out.size();
-            deflate(&zs, Z_FINISH);
+            if (deflate(&zs, Z_FINISH) != Z_STREAM_END) continue;
             const size_t clen = out.size() - zs.avail_out;
-            deflateEnd(&zs);
             std::vector<uint8_t>& o = cblk[b];
+            o.reserve(clen + 26);
             const uint8_t hdr[16] = {31, 139, 8, 4, 0, 0, 0, 0, 0, 255, 6, 0, 'B', 'C', 2, 0};
             o.insert(o.end(), hdr, hdr + 16);
             o.push_back((uint8_t)((clen + 25) & 0xff));
@@ -132,8 +197,10 @@ void BamWriter::flush(bool final) {
             put32(o, (uint32_t)crc32(crc32(0L, Z_NULL, 0), &pending[off], (uInt)len));
             put32(o, (uint32_t)len);
         }
+        deflateEnd(&zs);
     };
-    {
+    if (pool) pool->run(std::min<size_t>(pool->size() ? pool->size() : 1, nblk), [&](size_t) { work(); });
+    else {
         const int nt = (int)std::min<size_t>((size_t)threads, nblk);
         std::vector<std::thread> th;
         for (int t = 1; t < nt; t++) th.emplace_back(work);

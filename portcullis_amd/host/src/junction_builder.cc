@@ -426,10 +426,10 @@ private:
         // Targets are QUEUED on the device (pjb_finish_contig_begin) and collected later (_end): the kernel chains of up
         // to kQueued targets run side by side on the GPU, the device never waits for this thread between targets, and
         // the next target's upload / ingest overlaps the queued chains.  The rows of every target stay in the context's
-        // table (rows arrive in queue order; rowsSoFar marks where the next target's begin).  --extra finishes one
-        // target at a time (its metrics need the target's scratch untouched).
-        size_t kQueued = extra ? 1 : 3;  // (the library creates the streams of four control slots up front; deeper ones on a busy device cost seconds)
-        if (const char* e = getenv("PJB_HOST_QUEUE")) kQueued = extra ? 1 : (size_t)std::max(1, std::min(atoi(e), (int)PJB_MAX_QUEUED));
+        // table (rows arrive in queue order; rowsSoFar marks where the next target's begin).  --extra queues the same
+        // way (a target's extra metrics are queued when its chain is collected).
+        size_t kQueued = 3;  // (the library creates the streams of four control slots up front; deeper ones on a busy device cost seconds)
+        if (const char* e = getenv("PJB_HOST_QUEUE")) kQueued = (size_t)std::max(1, std::min(atoi(e), (int)PJB_MAX_QUEUED));
         struct Pending {
             int32_t tid;
             std::promise<ContigDone>* done; // (the worker thread that owns it waits on its future)

@@ -1,11 +1,14 @@
 // Host BAM I/O under AddressSanitizer / UBSan (no GPU): BamReader's record-at-a-time view (next / current), its raw
 // sequential walk (rewind / nextRecord), and BamWriter (parallel BGZF, in-process .bai) -- the file written here is
 // read back through its own index and must hold the same records.
-//   bam_roundtrip <in.bam> <out.bam> <threads>
+//   bam_roundtrip <in.bam> <out.bam> <threads> [bulk <chunk bytes> <drop every k-th record, 0: none>]
+// bulk: the same through the many-records-at-once route of `bamfilt` (BamReader::scanRecordsParallel -> BamWriter::writeRecords).
 #include <portcullis/bam/bam_reader.hpp>
 #include <portcullis/bam/bam_writer.hpp>
 
 #include <cstdio>
+#include <cstdlib>
+#include <string>
 #include <iostream>
 
 using namespace portcullis::bam;
@@ -48,6 +51,22 @@ int main(int argc, char** argv) {
             r.open();
             BamWriter w(argv[2], atoi(argv[3]));
             w.open(r.getHeaderText(), r.getTargets());
+            if (argc >= 7 && std::string(argv[4]) == "bulk") {
+                const int threads = atoi(argv[3]), drop = atoi(argv[6]);
+                PhasePool workers(threads > 1 ? threads : 0);
+                std::vector<uint8_t> codes;
+                r.scanRecordsParallel(threads, (size_t)atoll(argv[5]), [&](const BamReader::FileChunk& fc) {
+                    codes.assign(fc.records, 1);
+                    if (drop)
+                        for (size_t i = 0; i < fc.records; i++)
+                            if ((raw + i) % (size_t)drop == 0) codes[i] = 0;
+                    raw += fc.records;
+                    w.writeRecords(fc.data, fc.slices, codes.data(), 0, workers);
+                });
+                w.close();
+                printf("bulk raw=%llu\n", raw);
+                return 0;
+            }
             std::vector<uint8_t> rec;
             r.rewind();
             while (r.nextRecord(rec)) {

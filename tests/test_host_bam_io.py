@@ -48,3 +48,58 @@ def test_roundtrip_under_sanitizers(tmp_path, exe, block_size, threads):
     assert f"placed={len(reads) - 3} raw={len(reads)}" in p.stdout
     assert gzip.open(dst, "rb").read() == gzip.open(src, "rb").read()   # same header, same records, same order
     assert os.path.exists(dst + ".bai")
+
+
+def _records(data):
+    import struct
+    (l_text,) = struct.unpack_from("<i", data, 4)
+    o = 8 + l_text
+    (n_ref,) = struct.unpack_from("<i", data, o)
+    o += 4
+    for _ in range(n_ref):
+        (l_name,) = struct.unpack_from("<i", data, o)
+        o += 8 + l_name
+    header, recs = data[:o], []
+    while o < len(data):
+        (bs,) = struct.unpack_from("<i", data, o)
+        recs.append(data[o:o + 4 + bs])
+        o += 4 + bs
+    return header, recs
+
+
+@pytest.mark.parametrize("block_size,threads,chunk,drop", [(0xFF00, 1, 1 << 20, 0), (1500, 3, 1 << 20, 3), (700, 4, 70000, 2), (3000, 2, 1 << 30, 5)])
+def test_bulk_route_under_sanitizers(tmp_path, exe, block_size, threads, chunk, drop):
+    """`bamfilt`'s route through the host library: the whole file in pieces (blocks inflated and record starts found by
+    several threads, from the index's record starts; unplaced records at the end, which no index covers), the kept records
+    gathered and compressed by several threads.  Pieces smaller than the file, records straddling pieces and blocks."""
+    reads, refs = [], []
+    for tid, seed in enumerate([93, 94, None, 95]):
+        if seed is None:
+            refs.append((f"empty{tid}", 3000))
+            continue
+        genome, rr = make_reads(seed, n_reads=2500, paired=tid == 1)
+        for k, r in enumerate(rr):
+            r["tid"] = tid
+            r["name"] = f"n{tid}_{k}"
+            if r.get("mtid", -1) >= 0:
+                r["mtid"] = tid
+        refs.append((f"chr{tid + 1}", len(genome)))
+        reads += rr
+    for k in range(40):
+        reads.append(dict(tid=-1, pos=-1, cigar="", seq="ACGT" * 25, flag=4, mapq=0, name=f"unplaced{k}"))
+    src = str(tmp_path / "in.bam")
+    write_bam(src, refs, reads, block_size=block_size)
+    dst = str(tmp_path / "out.bam")
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=1", UBSAN_OPTIONS="print_stacktrace=1")
+    p = subprocess.run([exe, src, dst, str(threads), "bulk", str(chunk), str(drop)], capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode == 0, p.stdout + p.stderr[-3000:]
+    assert f"bulk raw={len(reads)}" in p.stdout
+    header, recs = _records(gzip.open(src, "rb").read())
+    assert len(recs) == len(reads)
+    want = header + b"".join(r for i, r in enumerate(recs) if not drop or i % drop)
+    assert gzip.open(dst, "rb").read() == want
+    # the index written beside it drives a second pass through the same route
+    again = str(tmp_path / "again.bam")
+    p = subprocess.run([exe, dst, again, str(threads), "bulk", str(chunk), "0"], capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode == 0, p.stdout + p.stderr[-3000:]
+    assert gzip.open(again, "rb").read() == want
