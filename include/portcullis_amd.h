@@ -31,6 +31,7 @@
  *                                                            lib/src/bam_reader.cc:78-146,
  *                                                            deps/htslib-1.3/bgzf.c:292-316,421-540
  *   pjb_inflate_bgzf      inflate_block for a run of BGZF blocks
+ *   pjb_deflate_bgzf      deflate_block for a stream of bytes (the BAM files the stages write)
  *                                                            deps/htslib-1.3/bgzf.c:292-316
  *
  * A context is bound to one HIP device and is not thread-safe; use one
@@ -339,6 +340,17 @@ int pjb_device_count(void);
  * field is an error (PJB_ERR_BGZF, message names the block).  An empty block (the BGZF EOF marker)
  * contributes nothing. */
 int pjb_inflate_bgzf(pjb_ctx* ctx, const uint8_t* comp, int64_t comp_bytes, uint8_t* out, int64_t out_cap, int64_t* out_bytes);
+
+/* The other direction: BGZF-compress `n_bytes` at `in` (host memory) on the device, for the BAM files the stages write
+ * (BamWriter::write -> bam_write1 -> bgzf_write -> deflate_block, lib/src/bam_writer.cc:58-60,
+ * deps/htslib-1.3/bgzf.c:216-262,580-613).  The input is cut into blocks of `block_bytes` bytes (a multiple of 4, at most
+ * 0xff00 = BGZF_BLOCK_SIZE; the last block may be shorter); every block becomes one complete BGZF member (gzip header with
+ * the BC field, a dynamic-Huffman or stored deflate block, CRC-32, ISIZE) and the members are written back to back to `out`
+ * (capacity out_cap; n_blocks * 65536 always suffices), their total to *out_bytes, and -- if member_size is not NULL -- each
+ * member's length to member_size[0 .. n_blocks) (a writer needs them for virtual file offsets).  No EOF block is added.
+ * Any inflater reads the result; it is not the byte stream zlib would have produced (a single hash candidate per position). */
+int pjb_deflate_bgzf(pjb_ctx* ctx, const uint8_t* in, int64_t n_bytes, int32_t block_bytes, uint8_t* out, int64_t out_cap, int64_t* out_bytes,
+                     uint32_t* member_size);
 
 /* One target's alignments straight from the file bytes: inflate + BAM record parse + transcode to the
  * pjb_batch layout, all on the device; the records are appended to target `tid` exactly as a

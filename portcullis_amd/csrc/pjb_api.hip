@@ -2,6 +2,7 @@
 // One context = one HIP device + one stream + a grow-only scratch arena.
 #include "pjb_kernels.hip.h"
 #include "pjb_extra.hip.h"
+#include "pjb_deflate.hip.h"
 #include "pjb_ingest.hip.h"
 
 #include <algorithm>
@@ -279,6 +280,7 @@ struct pjb_ctx {
     Buf *scan_tiles = nullptr; // run_scan's tile sums: the service buffer, or the slot's while a chain is being queued
     Buf b_scan_tiles;
     Buf b_inf_comp, b_inf_out, b_inf_blocks, b_inf_status, b_inf_scratch, b_inf_bitmap; // device-side BGZF inflate
+    Buf b_dfl_in, b_dfl_sym, b_dfl_slots, b_dfl_size, b_dfl_off, b_dfl_packed;           // device-side BGZF deflate
     bool inflate_v1 = false; // PJB_INFLATE_V1=1: round 2's one-kernel bgzf_inflate instead of bgzf_decode + bgzf_resolve
     Buf b_bam_seg, b_bam_rec, b_bam_ctl;                                  // device-side BAM record parse
     // --extra
@@ -684,7 +686,8 @@ void pjb_destroy(pjb_ctx *c) {
                   &c->b_bam_seg, &c->b_bam_rec, &c->b_bam_ctl, &c->f_pos, &c->f_cigoff, &c->f_cigar, &c->f_codes, &c->g_rows, &c->g_models, &c->g_refs,
                   &c->g_out, &c->g_bad,
                   &c->x_pos, &c->x_endx, &c->x_q, &c->x_prefq, &c->x_ce, &c->x_bound, &c->x_de, &c->x_dropped, &c->x_zlist, &c->x_cnt,
-                  &c->x_tabk, &c->x_tabc, &c->x_rs, &c->x_re, &c->x_rr, &c->x_tileoff, &c->x_xrall, &c->x_tab};
+                  &c->x_tabk, &c->x_tabc, &c->x_rs, &c->x_re, &c->x_rr, &c->x_tileoff, &c->x_xrall, &c->x_tab,
+                  &c->b_dfl_in, &c->b_dfl_sym, &c->b_dfl_slots, &c->b_dfl_size, &c->b_dfl_off, &c->b_dfl_packed};
     for (Buf *b : all) release(*b);
     for (auto &ch : c->xarena.chunks) (void)hipFree(ch.p);
     if (c->xrows_pinned) (void)hipHostFree(c->xrows_pinned);
@@ -2549,6 +2552,58 @@ extern "C" int pjb_inflate_bgzf(pjb_ctx *c, const uint8_t *comp, int64_t comp_by
     HIP_TRY(c, hipMemsetAsync((uint8_t *)c->b_inf_comp.p + comp_bytes, 0, INF_PAD, c->stream));
     if ((rc = inflate_on_device(c, (const uint8_t *)c->b_inf_comp.p, blocks, (uint8_t *)c->b_inf_out.p))) return rc;
     HIP_TRY(c, hipMemcpy(out, c->b_inf_out.p, (size_t)total, hipMemcpyDeviceToHost));
+    return PJB_OK;
+}
+
+// BGZF deflate on the device (pjb_deflate.hip.h): at most DFL_LAUNCH_BLOCKS blocks per launch (1 GB of symbol scratch)
+constexpr int64_t DFL_LAUNCH_BLOCKS = 4096;
+extern "C" int pjb_deflate_bgzf(pjb_ctx *c, const uint8_t *in, int64_t n_bytes, int32_t block_bytes, uint8_t *out, int64_t out_cap, int64_t *out_bytes,
+                                uint32_t *member_size) {
+    if (!c || !out_bytes || n_bytes < 0 || (n_bytes && (!in || !out))) return fail(c, PJB_ERR_ARG, "deflate_bgzf: bad arguments");
+    if (block_bytes < 4 || block_bytes > (int32_t)DFL_IN_MAX || (block_bytes & 3))
+        return fail(c, PJB_ERR_ARG, "deflate_bgzf: block_bytes must be a multiple of 4 between 4 and %u", DFL_IN_MAX);
+    *out_bytes = 0;
+    if (n_bytes == 0) return PJB_OK;
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    hipStream_t st = c->stream;
+    const int64_t n_blocks = (n_bytes + block_bytes - 1) / block_bytes;
+    int rc;
+    std::vector<u32> sizes;
+    std::vector<iu64> offs;
+    int64_t written = 0;
+    for (int64_t b0 = 0; b0 < n_blocks; b0 += DFL_LAUNCH_BLOCKS) {
+        const int64_t nb = std::min<int64_t>(DFL_LAUNCH_BLOCKS, n_blocks - b0);
+        const int64_t in_off = b0 * block_bytes, in_len = std::min<int64_t>(n_bytes - in_off, nb * block_bytes);
+        if ((rc = ensure(c, c->b_dfl_in, (size_t)in_len + 64)) || (rc = ensure(c, c->b_dfl_sym, (size_t)nb * DFL_SYM_STRIDE * 4)) ||
+            (rc = ensure(c, c->b_dfl_slots, (size_t)nb * DFL_SLOT)) || (rc = ensure(c, c->b_dfl_size, (size_t)nb * 4)) ||
+            (rc = ensure(c, c->b_dfl_off, (size_t)nb * 8)))
+            return rc;
+        HIP_TRY(c, hipMemcpyAsync(c->b_dfl_in.p, in + in_off, (size_t)in_len, hipMemcpyHostToDevice, st));
+        LAUNCH(c, "bgzf_deflate", bgzf_deflate, dim3((unsigned)nb), dim3(64), (const uint8_t *)c->b_dfl_in.p, (iu64)in_len, (u32)block_bytes, (u32)nb,
+               (u32 *)c->b_dfl_sym.p, (uint8_t *)c->b_dfl_slots.p, (u32 *)c->b_dfl_size.p);
+        sizes.resize((size_t)nb);
+        HIP_TRY(c, hipMemcpyAsync(sizes.data(), c->b_dfl_size.p, (size_t)nb * 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(c, hipStreamSynchronize(st));
+        offs.resize((size_t)nb);
+        iu64 total = 0;
+        for (int64_t k = 0; k < nb; k++) {
+            if (sizes[(size_t)k] < 26 || sizes[(size_t)k] > 65536) return fail(c, PJB_ERR_STATE, "deflate_bgzf: block %lld came out with %u bytes", (long long)(b0 + k), sizes[(size_t)k]);
+            offs[(size_t)k] = total;
+            total += sizes[(size_t)k];
+            if (member_size) member_size[b0 + k] = sizes[(size_t)k];
+        }
+        if (written + (int64_t)total > out_cap)
+            return fail(c, PJB_ERR_ARG, "deflate_bgzf: the output needs more than %lld bytes", (long long)out_cap);
+        if ((rc = ensure(c, c->b_dfl_packed, (size_t)total + 64))) return rc;
+        HIP_TRY(c, hipMemcpyAsync(c->b_dfl_off.p, offs.data(), (size_t)nb * 8, hipMemcpyHostToDevice, st));
+        LAUNCH(c, "bgzf_pack", bgzf_pack, dim3((unsigned)nb), dim3(256), (const uint8_t *)c->b_dfl_slots.p, (const u32 *)c->b_dfl_size.p,
+               (const iu64 *)c->b_dfl_off.p, (u32)nb, (uint8_t *)c->b_dfl_packed.p);
+        HIP_TRY(c, hipMemcpyAsync(out + written, c->b_dfl_packed.p, (size_t)total, hipMemcpyDeviceToHost, st));
+        HIP_TRY(c, hipStreamSynchronize(st));
+        written += (int64_t)total;
+    }
+    *out_bytes = written;
+    if (c->ktime) ev_collect(c, MISC_POOL);
     return PJB_OK;
 }
 

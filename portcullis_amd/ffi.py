@@ -24,7 +24,7 @@ EXPORTS = [
     "pjb_release_contig", "pjb_submit_batch", "pjb_submit_batch_device", "pjb_finish_contig", "pjb_finish_contig_begin",
     "pjb_finish_contig_end", "pjb_finish_ready", "pjb_finish_group_begin", "pjb_finish_group_end", "pjb_collect",
     "pjb_clear_rows", "pjb_get_timing", "pjb_device_count", "pjb_get_kernel_timing", "pjb_reset_kernel_timing",
-    "pjb_select_timed_kernels", "pjb_host_alloc", "pjb_host_free", "pjb_inflate_bgzf", "pjb_submit_bam", "pjb_collect_device", "pjb_set_row_mirror",
+    "pjb_select_timed_kernels", "pjb_host_alloc", "pjb_host_free", "pjb_inflate_bgzf", "pjb_deflate_bgzf", "pjb_submit_bam", "pjb_collect_device", "pjb_set_row_mirror",
     "pjb_extra_finish", "pjb_set_option", "pjb_bam_begin", "pjb_bam_piece", "pjb_bam_pieces_done", "pjb_bam_end", "pjb_bam_inflate_done", "pjb_filter_set_junctions", "pjb_filter_batch", "pjb_filt_features",
 ]
 N_FEATURES = 34
@@ -132,6 +132,7 @@ def load():
         L.pjb_set_row_mirror.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
         L.pjb_collect_device.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
         L.pjb_inflate_bgzf.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
+        L.pjb_deflate_bgzf.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int64, C.POINTER(C.c_int64), C.c_void_p]
         L.pjb_submit_bam.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_int32, C.POINTER(C.c_int64)]
         L.pjb_collect.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
         L.pjb_extra_finish.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
@@ -426,6 +427,18 @@ class Context:
         self._check(self._L.pjb_inflate_bgzf(self._h, comp.ctypes.data_as(C.c_void_p), len(comp),
                                              out.ctypes.data_as(C.c_void_p), cap, C.byref(n)))
         return out[:n.value].tobytes()
+
+    def deflate_bgzf(self, data, block_bytes=0xff00):
+        """BGZF-compress bytes on the device: returns (the members back to back -- no EOF block --, their sizes)."""
+        data = np.frombuffer(bytes(data), dtype=np.uint8)
+        n_blocks = (len(data) + block_bytes - 1) // block_bytes
+        cap = max(1, n_blocks) * 65536
+        out = np.empty(cap, dtype=np.uint8)
+        sizes = np.zeros(max(1, n_blocks), dtype=np.uint32)
+        n = C.c_int64()
+        self._check(self._L.pjb_deflate_bgzf(self._h, data.ctypes.data_as(C.c_void_p), len(data), block_bytes, out.ctypes.data_as(C.c_void_p), cap,
+                                             C.byref(n), sizes.ctypes.data_as(C.c_void_p)))
+        return out[:n.value].tobytes(), sizes[:n_blocks]
 
     def timing(self):
         t = PjbTiming()

@@ -6,7 +6,11 @@
 
 #include <cstdint>
 #include <cstdio>
+#include <functional>
+#include <future>
 #include <map>
+#include <new>
+#include <utility>
 #include <string>
 #include <vector>
 
@@ -15,6 +19,37 @@
 
 namespace portcullis {
 namespace bam {
+
+// The writer's large buffers (uncompressed records waiting for their blocks, compressed blocks) come from a pluggable
+// allocator -- BamFilter plugs in page-locked memory (pjb_host_alloc) so that the device reads and writes them by DMA -- and
+// are never filled with zeros when they grow.
+struct BufferHooks {
+    void* (*alloc)(size_t) = nullptr;  // nullptr: malloc / free
+    void (*release)(void*) = nullptr;
+};
+void setBufferHooks(const BufferHooks& h);  // affects buffers allocated afterwards
+void* hookedAlloc(size_t bytes);
+void hookedFree(void* p);
+template <class T>
+struct HookAlloc {
+    typedef T value_type;
+    HookAlloc() = default;
+    template <class U>
+    HookAlloc(const HookAlloc<U>&) {}
+    T* allocate(size_t n) { return static_cast<T*>(hookedAlloc(n * sizeof(T))); }
+    void deallocate(T* p, size_t) { hookedFree(p); }
+    template <class U>
+    void construct(U*) noexcept {}  // (default-initialised: resize() does not touch the new bytes)
+    template <class U, class A0, class... A>
+    void construct(U* p, A0&& a0, A&&... a) {
+        ::new ((void*)p) U(std::forward<A0>(a0), std::forward<A>(a)...);
+    }
+    template <class U>
+    bool operator==(const HookAlloc<U>&) const { return true; }
+    template <class U>
+    bool operator!=(const HookAlloc<U>&) const { return false; }
+};
+typedef std::vector<uint8_t, HookAlloc<uint8_t>> ByteBuf;
 
 class BamWriter {
     struct RecInfo {
@@ -27,7 +62,7 @@ class BamWriter {
     FILE* fp = nullptr;
     int threads = 1, level = 6;
     bool wantIndex = true;
-    std::vector<uint8_t> pending;      // uncompressed bytes not yet flushed
+    ByteBuf pending;                   // uncompressed bytes not yet flushed
     uint64_t uflushed = 0;             // uncompressed bytes already compressed and written
     uint64_t cwritten = 0;             // compressed bytes written
     std::vector<RecInfo> recs;         // records since the last flush
@@ -43,12 +78,24 @@ class BamWriter {
     uint32_t cacheBin = 0;
     std::vector<std::pair<uint64_t, uint64_t>>* cacheChunks = nullptr;
     PhasePool* pool = nullptr;         // writeRecords' workers also compress (else: threads started per flush)
+    // compresses `n` bytes cut into blocks of `block` bytes (the last one shorter) into complete BGZF members, back to back in
+    // `out`, their lengths in `sizes`; false: not available (zlib takes over)
+    std::function<bool(const uint8_t* in, size_t n, size_t block, ByteBuf& out, std::vector<uint32_t>& sizes)> compressor;
+    ByteBuf cout_;                     // the compressor's output, reused
+    bool asyncFlush = false;           // writeRecords returns while the blocks are compressed and written by another thread
+    std::future<void> inflight;
+    void waitFlush() {
+        if (inflight.valid()) inflight.get();  // (rethrows what the flush threw)
+    }
+    std::vector<uint32_t> csizes_;
 
 public:
     static constexpr size_t BLOCK = 0xff00;
     BamWriter(const std::string& path, int threads = 1, int level = 6) : path(path), threads(threads < 1 ? 1 : threads), level(level) {}
     ~BamWriter();
     void setWriteIndex(bool on) { wantIndex = on; }
+    // BGZF blocks compressed somewhere else (BamFilter: on the device, pjb_deflate_bgzf) instead of by zlib in this process
+    void setBlockCompressor(std::function<bool(const uint8_t*, size_t, size_t, ByteBuf&, std::vector<uint32_t>&)> f) { compressor = std::move(f); }
     const std::string& getPath() const { return path; }
     void open(const std::string& headerText, const std::vector<RefSeq>& targets);
     // one alignment record: the 4-byte block_size followed by block_size bytes, exactly as in the input file
@@ -60,6 +107,9 @@ public:
                       PhasePool& workers);
     void close();
     bool isOpen() const { return fp != nullptr; }
+    // With a block compressor set: writeRecords hands the gathered records to a thread of the writer's own and returns; the
+    // next call (and close) waits for it.  The compressor then runs on that thread.
+    void setAsyncFlush(bool on) { asyncFlush = on; }
 };
 
 }  // namespace bam

@@ -10,6 +10,7 @@
 #include <iomanip>
 #include <iostream>
 #include <map>
+#include <future>
 #include <memory>
 #include <sys/stat.h>
 
@@ -47,11 +48,39 @@ BamFilter::BamFilter(const std::string& jf, const std::string& bf, const std::st
 }
 
 void BamFilter::filter() {
+    const bool profTop = getenv("PORTCULLIS_PROFILE") != nullptr;
+    const auto tTop = std::chrono::steady_clock::now();
+    auto mark = [&](const char* what) {
+        if (profTop) fprintf(stderr, "[bamfilt profile] t=%.3f s: %s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - tTop).count(), what);
+    };
+    // (the device context comes up -- 0.2 s of runtime start -- while the junctions are read)
+    pjb_config cfg;
+    memset(&cfg, 0, sizeof cfg);
+    cfg.abi_version = PJB_ABI_VERSION;
+    cfg.device = device;
+    cfg.orientation = PJB_OR_UNKNOWN;
+    cfg.strandedness = PJB_SS_UNKNOWN;
+    std::future<pjb_ctx*> ctxComing = std::async(std::launch::async, [cfg]() -> pjb_ctx* {
+        pjb_ctx* c1 = nullptr;
+        if (pjb_create(&c1, &cfg) != PJB_OK) throw BamFilterException(std::string("pjb_create: ") + pjb_last_error(nullptr));
+        return c1;
+    });
+    struct CtxGuard {  // (an exception before the context is taken over must still wait for it and release it)
+        std::future<pjb_ctx*>* f;
+        ~CtxGuard() {
+            try {
+                if (f->valid()) pjb_destroy(f->get());
+            } catch (...) {
+            }
+        }
+    } ctxGuard{&ctxComing};
     cout << "Loading junctions from: " << junctionFile << endl;
     JunctionSystem js(junctionFile);
     cout << " - Found " << js.size() << " junctions" << endl << endl;
+    mark("junctions loaded");
     bam::BamReader reader(bamFile);
     reader.open(useCsi);
+    mark("BAM header and index read");
     std::shared_ptr<bam::RefSeqPtrList> refs = reader.createRefList();
     js.setRefs(refs);
     {
@@ -61,14 +90,7 @@ void BamFilter::filter() {
             throw BamFilterException("Could not create output directory at: " + outDir);
     }
     // ---- the filter's junction set, per target, as sorted keys on the device
-    pjb_config cfg;
-    memset(&cfg, 0, sizeof cfg);
-    cfg.abi_version = PJB_ABI_VERSION;
-    cfg.device = device;
-    cfg.orientation = PJB_OR_UNKNOWN;
-    cfg.strandedness = PJB_SS_UNKNOWN;
-    pjb_ctx* ctx = nullptr;
-    if (pjb_create(&ctx, &cfg) != PJB_OK) throw BamFilterException(std::string("pjb_create: ") + pjb_last_error(nullptr));
+    pjb_ctx* ctx = ctxComing.get();
     struct Closer {
         pjb_ctx* c;
         ~Closer() { pjb_destroy(c); }
@@ -86,8 +108,56 @@ void BamFilter::filter() {
                 throw BamFilterException(std::string("pjb_filter_set_junctions: ") + pjb_last_error(ctx));
         }
     }
+    mark("context created, junction keys uploaded");
     cout << " - Processing alignments from: " << bamFile << endl;
+    // BGZF blocks are compressed on the device (pjb_deflate_bgzf); PORTCULLIS_HOST_DEFLATE=1: by zlib on the workers.
+    // The filtered file's blocks go through a context of their own: its writer compresses on a thread of its own while
+    // this thread asks the first context for decisions.
+    const bool hostDeflate = getenv("PORTCULLIS_HOST_DEFLATE") != nullptr;
+    std::shared_future<pjb_ctx*> deflateCtx = std::async(std::launch::async, [cfg, hostDeflate]() -> pjb_ctx* {
+        pjb_ctx* c2 = nullptr;
+        if (!hostDeflate && pjb_create(&c2, &cfg) != PJB_OK) throw BamFilterException(std::string("pjb_create: ") + pjb_last_error(nullptr));
+        return c2;
+    }).share();
+    struct Closer2 {
+        std::shared_future<pjb_ctx*> f;
+        ~Closer2() {
+            try {
+                pjb_destroy(f.get());
+            } catch (...) {
+            }
+        }
+    } closer2{deflateCtx};
     bam::BamWriter writer(outputBam, threads);
+    auto deflateOn = [](pjb_ctx* ctx, const uint8_t* in, size_t n, size_t block, bam::ByteBuf& out, std::vector<uint32_t>& sizes) -> bool {
+        const size_t nblk = (n + block - 1) / block;
+        out.resize(nblk * 65536);
+        sizes.resize(nblk);
+        int64_t got = 0;
+        if (pjb_deflate_bgzf(ctx, in, (int64_t)n, (int32_t)block, out.data(), (int64_t)out.size(), &got, sizes.data()) != PJB_OK)
+            throw BamFilterException(std::string("pjb_deflate_bgzf: ") + pjb_last_error(ctx));
+        out.resize((size_t)got);
+        return true;
+    };
+    auto deviceDeflate = [deflateCtx, deflateOn](const uint8_t* in, size_t n, size_t block, bam::ByteBuf& out, std::vector<uint32_t>& sizes) -> bool {
+        return deflateOn(deflateCtx.get(), in, n, block, out, sizes);
+    };
+    auto deviceDeflateHere = [ctx, deflateOn](const uint8_t* in, size_t n, size_t block, bam::ByteBuf& out, std::vector<uint32_t>& sizes) -> bool {
+        return deflateOn(ctx, in, n, block, out, sizes);  // (the two small files of --save_msrs: on this thread, this thread's context)
+    };
+    if (!hostDeflate) {
+        writer.setBlockCompressor(deviceDeflate);
+        writer.setAsyncFlush(getenv("PORTCULLIS_SYNC_WRITER") == nullptr);
+        if (getenv("PORTCULLIS_PINNED_BUFFERS")) {  // (page-locked buffers: measured no faster than pageable ones here, and 0.2 s to allocate)
+            bam::BufferHooks hooks;
+            hooks.alloc = pjb_host_alloc;
+            hooks.release = pjb_host_free;
+            bam::setBufferHooks(hooks);
+        }
+    }
+    struct HooksOff {
+        ~HooksOff() { bam::setBufferHooks(bam::BufferHooks()); }
+    } hooksOff;
     writer.open(reader.getHeaderText(), reader.getTargets());
     cout << " - Saving filtered alignments to: " << outputBam << endl;
     std::unique_ptr<bam::BamWriter> mod, unmod;
@@ -96,6 +166,10 @@ void BamFilter::filter() {
         unmod.reset(new bam::BamWriter(outputBam + ".unmod.bam", threads));
         mod->setWriteIndex(false);
         unmod->setWriteIndex(false);
+        if (!hostDeflate) {
+            mod->setBlockCompressor(deviceDeflateHere);
+            unmod->setBlockCompressor(deviceDeflateHere);
+        }
         mod->open(reader.getHeaderText(), reader.getTargets());
         unmod->open(reader.getHeaderText(), reader.getTargets());
         cout << " - Saving modified MSRs to: " << outputBam << ".mod.bam" << endl;
@@ -112,7 +186,12 @@ void BamFilter::filter() {
     std::vector<uint32_t> cigOff, cigar, runOff;
     std::vector<uint8_t> codes;
     auto le32 = [](const uint8_t* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); };
+    const bool prof = getenv("PORTCULLIS_PROFILE") != nullptr;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double tExtract = 0, tDevice = 0, tWrite = 0, tSink0 = now(), tScan = 0;
     reader.scanRecordsParallel(threads, (size_t)256 << 20, [&](const bam::BamReader::FileChunk& fc) {
+        double t0 = now();
+        tScan += t0 - tSink0;
         const size_t ns = fc.slices.size(), n = fc.records;
         std::vector<size_t> base(ns + 1, 0), opBase(ns + 1, 0);
         for (size_t s = 0; s < ns; s++) base[s + 1] = base[s] + fc.slices[s]->size();
@@ -145,6 +224,8 @@ void BamFilter::filter() {
                 o += n_cig;
             }
         });
+        tExtract += now() - t0;
+        t0 = now();
         // runs of one target: the device answers for each
         for (size_t a = 0; a < n;) {
             size_t b = a + 1;
@@ -176,14 +257,23 @@ void BamFilter::filter() {
         nbReadsIn += n;
         nbReadsOut += out;
         nbReadsModifiedOut += modified;
+        tDevice += now() - t0;
+        t0 = now();
         writer.writeRecords(fc.data, fc.slices, codes.data(), 0, workers);
         if (saveMSRs && modified) {
             mod->writeRecords(fc.data, fc.slices, codes.data(), 3, workers);
             unmod->writeRecords(fc.data, fc.slices, codes.data(), 3, workers);
         }
+        tWrite += now() - t0;
+        tSink0 = now();
     });
+    if (prof)
+        fprintf(stderr, "[bamfilt profile] read + inflate + find records %.3f s, extract %.3f s, device decisions %.3f s, write %.3f s\n", tScan, tExtract,
+                tDevice, tWrite);
+    mark("last piece handed to the writer");
     reader.close();
     writer.close();
+    mark("output closed (last blocks, EOF block, .bai)");
     if (saveMSRs) {
         mod->close();
         unmod->close();

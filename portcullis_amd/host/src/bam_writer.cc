@@ -3,6 +3,8 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
+#include <cstdlib>
 #include <cstring>
 #include <thread>
 #include <zlib.h>
@@ -10,10 +12,52 @@
 namespace portcullis {
 namespace bam {
 
-static void put32(std::vector<uint8_t>& b, uint32_t v) {
+// PORTCULLIS_PROFILE=1: where the writer's time goes (stderr, at close)
+namespace {
+struct WriterProfile {
+    bool on = getenv("PORTCULLIS_PROFILE") != nullptr;
+    double gather = 0, compress = 0, fwrite_ = 0, index = 0, tail = 0;
+    static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+} g_prof;
+}  // namespace
+
+// ---- buffer hooks: every block remembers who releases it (the hooks may change while buffers are alive)
+namespace {
+BufferHooks g_hooks;
+struct BlockHead {
+    void (*release)(void*);
+    void* base;
+    uint64_t pad_[6];  // (the payload stays 64-byte aligned)
+};
+}  // namespace
+void setBufferHooks(const BufferHooks& h) { g_hooks = h; }
+void* hookedAlloc(size_t bytes) {
+    const BufferHooks h = g_hooks;
+    void* base = h.alloc ? h.alloc(bytes + sizeof(BlockHead)) : nullptr;
+    void (*rel)(void*) = h.alloc ? h.release : nullptr;
+    if (!base) {
+        base = malloc(bytes + sizeof(BlockHead));
+        rel = nullptr;
+    }
+    if (!base) throw std::bad_alloc();
+    BlockHead* bh = static_cast<BlockHead*>(base);
+    bh->release = rel;
+    bh->base = base;
+    return bh + 1;
+}
+void hookedFree(void* p) {
+    if (!p) return;
+    BlockHead* bh = static_cast<BlockHead*>(p) - 1;
+    if (bh->release) bh->release(bh->base);
+    else free(bh->base);
+}
+
+template <class B>
+static void put32(B& b, uint32_t v) {
     for (int k = 0; k < 4; k++) b.push_back((uint8_t)(v >> (8 * k)));
 }
-static void put64(std::vector<uint8_t>& b, uint64_t v) {
+template <class B>
+static void put64(B& b, uint64_t v) {
     for (int k = 0; k < 8; k++) b.push_back((uint8_t)(v >> (8 * k)));
 }
 static inline uint32_t rd32(const uint8_t* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
@@ -44,6 +88,7 @@ static inline int32_t recordEnd(const uint8_t* rec, size_t len) {  // pos + refe
 
 BamWriter::~BamWriter() {
     try {
+        if (inflight.valid()) inflight.wait();
         if (fp) close();
     } catch (...) {
     }
@@ -74,6 +119,7 @@ void BamWriter::open(const std::string& headerText, const std::vector<RefSeq>& t
 
 void BamWriter::write(const uint8_t* rec, size_t len) {
     if (!fp) throw BamException("BamWriter::write: file is not open");
+    waitFlush();
     if (len < 36) throw BamException("BamWriter::write: not a BAM record");
     if (wantIndex) {
         RecInfo r;
@@ -90,6 +136,7 @@ void BamWriter::write(const uint8_t* rec, size_t len) {
 void BamWriter::writeRecords(const uint8_t* data, const std::vector<const std::vector<uint64_t>*>& slices, const uint8_t* codes, uint8_t only,
                              PhasePool& workers) {
     if (!fp) throw BamException("BamWriter::writeRecords: file is not open");
+    waitFlush();
     const size_t ns = slices.size();
     if (ns == 0) return;
     auto keep = [&](size_t flat) { return !codes || (only ? codes[flat] == only : codes[flat] != 0); };
@@ -111,7 +158,9 @@ void BamWriter::writeRecords(const uint8_t* data, const std::vector<const std::v
         kr[s + 1] += kr[s];
     }
     if (kr[ns] == 0) return;
+    const double tg0 = WriterProfile::now();
     const size_t p0 = pending.size(), r0 = recs.size();
+    if (pending.capacity() < p0 + kb[ns]) pending.reserve(p0 + kb[ns] + (kb[ns] >> 3) + (1u << 20));  // (one allocation for a file's pieces, not a doubling series)
     pending.resize(p0 + kb[ns]);
     if (wantIndex) recs.resize(r0 + kr[ns]);
     workers.run(ns, [&](size_t s) {
@@ -134,8 +183,14 @@ void BamWriter::writeRecords(const uint8_t* data, const std::vector<const std::v
             dst += len;
         }
     });
+    g_prof.gather += WriterProfile::now() - tg0;
+    if (pending.size() < BLOCK * 64) return;
+    if (asyncFlush && compressor) {
+        inflight = std::async(std::launch::async, [this] { flush(false); });
+        return;
+    }
     pool = &workers;
-    if (pending.size() >= BLOCK * 64) flush(false);
+    flush(false);
     pool = nullptr;
 }
 
@@ -169,7 +224,20 @@ void BamWriter::flush(bool final) {
         return;
     }
     const size_t take = std::min(pending.size(), nblk * BLOCK);
-    std::vector<std::vector<uint8_t>> cblk(nblk);
+    std::vector<uint64_t> coff(nblk + 1, cwritten);
+    bool external = false;
+    double tp0 = WriterProfile::now();
+    if (compressor && compressor(pending.data(), take, BLOCK, cout_, csizes_)) {
+        if (csizes_.size() != nblk) throw BamException("BamWriter: the block compressor returned the wrong number of blocks");
+        for (size_t b = 0; b < nblk; b++) coff[b + 1] = coff[b] + csizes_[b];
+        if (coff[nblk] - cwritten != cout_.size()) throw BamException("BamWriter: the block compressor's sizes do not add up");
+        g_prof.compress += WriterProfile::now() - tp0;
+        tp0 = WriterProfile::now();
+        if (fwrite(cout_.data(), 1, cout_.size(), fp) != cout_.size()) throw BamException("BamWriter: write failed: " + path);
+        g_prof.fwrite_ += WriterProfile::now() - tp0;
+        external = true;
+    }
+    std::vector<std::vector<uint8_t>> cblk(external ? 0 : nblk);
     std::atomic<size_t> next(0);
     auto work = [&]() {
         std::vector<uint8_t> out(70000);
@@ -199,7 +267,8 @@ void BamWriter::flush(bool final) {
         }
         deflateEnd(&zs);
     };
-    if (pool) pool->run(std::min<size_t>(pool->size() ? pool->size() : 1, nblk), [&](size_t) { work(); });
+    if (external) {
+    } else if (pool) pool->run(std::min<size_t>(pool->size() ? pool->size() : 1, nblk), [&](size_t) { work(); });
     else {
         const int nt = (int)std::min<size_t>((size_t)threads, nblk);
         std::vector<std::thread> th;
@@ -207,14 +276,14 @@ void BamWriter::flush(bool final) {
         work();
         for (auto& t : th) t.join();
     }
-    std::vector<uint64_t> coff(nblk + 1, cwritten);
-    for (size_t b = 0; b < nblk; b++) {
+    for (size_t b = 0; b < nblk && !external; b++) {
         if (cblk[b].empty()) throw BamException("BamWriter: deflate failed");
         coff[b + 1] = coff[b] + cblk[b].size();
         if (fwrite(cblk[b].data(), 1, cblk[b].size(), fp) != cblk[b].size()) throw BamException("BamWriter: write failed: " + path);
     }
     // virtual offsets: a record's start is known once the block holding its first byte is written, its end is the
     // start of the record behind it (or of the EOF block)
+    tp0 = WriterProfile::now();
     if (wantIndex) {
         for (auto& r : recs) {
             if (r.vsKnown) continue;
@@ -240,18 +309,25 @@ void BamWriter::flush(bool final) {
         }
         recs.erase(recs.begin(), recs.begin() + (long)done);
     }
+    g_prof.index += WriterProfile::now() - tp0;
+    tp0 = WriterProfile::now();
     cwritten = coff[nblk];
     uflushed += take;
     pending.erase(pending.begin(), pending.begin() + (long)take);
+    g_prof.tail += WriterProfile::now() - tp0;
 }
 
 void BamWriter::close() {
     if (!fp) return;
+    waitFlush();
     flush(true);
     static const uint8_t eof[28] = {0x1f, 0x8b, 0x08, 0x04, 0, 0, 0, 0, 0, 0xff, 0x06, 0, 0x42, 0x43, 0x02, 0, 0x1b, 0, 0x03, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     if (fwrite(eof, 1, 28, fp) != 28) throw BamException("BamWriter: write failed: " + path);
     fclose(fp);
     fp = nullptr;
+    if (g_prof.on)
+        fprintf(stderr, "[writer profile] %s: gather %.3f s, compress %.3f s, fwrite %.3f s, index %.3f s, tail %.3f s\n", path.c_str(), g_prof.gather,
+                g_prof.compress, g_prof.fwrite_, g_prof.index, g_prof.tail);
     if (!wantIndex) return;
     std::vector<uint8_t> o = {'B', 'A', 'I', 1};
     put32(o, (uint32_t)nTargets);
