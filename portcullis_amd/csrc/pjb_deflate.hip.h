@@ -29,9 +29,12 @@ constexpr u32 DFL_SYM_STRIDE = DFL_IN_MAX + 64; // symbols of one block (one per
 constexpr u32 DFL_STAGE_WORDS = 192;
 
 // (the hash table is only needed by the parse, the tree and staging areas only after it: they share their LDS -- 10.6 KB per
-// wavefront, 15 wavefronts per CU.  Measured: 6 or 15 resident wavefronts per CU, 8 K or 4 K table entries make no difference
-// to the kernel's 11 GB/s -- with every block of a launch resident at once it is bound by instruction issue, ~190 cycles per
-// input byte and SIMD, most of it the divergent match extension and the scalar walk of the parse)
+// wavefront, 15 wavefronts per CU.  Measured (rocprofv3: 23.8 ms per launch of 4096 blocks, profiles/r03ai_*): 6 or 15 resident
+// wavefronts per CU, 8 K or 4 K table entries, 8 or 16 bytes per extension step, skipping positions an earlier round's match
+// covers -- none of it moves the kernel's 11 GB/s.  Every block of a launch is resident at once and the parse is bound by
+// instruction issue: ~1 300 instructions per 64-position round, the wavefront pays for its slowest lane in the match
+// extension and for every symbol in the scalar walk.  The next step is a lane per 1 KB segment walking it like zlib does
+// (positions inside a match skipped) against chains built by a first pass; not built.)
 struct DflAfterParse {
     // tree construction
     unsigned short sorted[288], parent[576];
@@ -42,6 +45,7 @@ struct DflAfterParse {
     u32 stage[DFL_STAGE_WORDS];
     u32 crc_tab[256];
     u32 crc_part[64];
+    u32 bl_count[16], next_code[16]; // (indexed by lengths read from memory: LDS, not registers)
 };
 struct DflShared {
     union {
@@ -102,7 +106,7 @@ __device__ void dfl_build_code(DflShared &S, u32 *freq, int n, int max_bits, uin
         }
         // depths from the root down, limited like zlib's gen_bitlen (trees.c): a node below max_bits stays at max_bits and
         // is counted; then leaves move down from shorter lengths until the code is complete again
-        u32 bl_count[16];
+        u32 *bl_count = S.a.bl_count, *next_code = S.a.next_code;
         for (int i = 0; i < 16; i++) bl_count[i] = 0;
         const int root = 2 * m - 2;
         S.a.nodelen[root] = 0;
@@ -129,7 +133,6 @@ __device__ void dfl_build_code(DflShared &S, u32 *freq, int n, int max_bits, uin
         for (int bits = max_bits; bits >= 1; bits--)
             for (u32 c = 0; c < bl_count[bits]; c++) len[S.a.sorted[idx++]] = (uint8_t)bits;
         // canonical codes (RFC 1951 3.2.2)
-        u32 next_code[16];
         u32 c = 0;
         bl_count[0] = 0;
         for (int bits = 1; bits <= max_bits; bits++) {
@@ -230,14 +233,16 @@ __global__ __launch_bounds__(64) void bgzf_deflate(const uint8_t *in, iu64 n_byt
         if (can) S.head[h] = (unsigned short)p;
         u32 mlen = 0, mdist = 0;
         const u32 maxl = can ? (n - p < DFL_MAX_MATCH ? n - p : DFL_MAX_MATCH) : 0u;
-        if (cand != 0xffffu && p - cand <= 32768u && load32u(src + cand) == w) {
+        const bool open = can && p >= cur; // (a position inside a match chosen in an earlier round only feeds the table)
+        if (open && cand != 0xffffu && p - cand <= 32768u && load32u(src + cand) == w) {
             u32 l = 4;
-            while (l + 8 <= maxl && load64u(src + p + l) == load64u(src + cand + l)) l += 8;
+            while (l + 16 <= maxl && load64u(src + p + l) == load64u(src + cand + l) && load64u(src + p + l + 8) == load64u(src + cand + l + 8)) l += 16;
+            if (l + 8 <= maxl && load64u(src + p + l) == load64u(src + cand + l)) l += 8;
             while (l < maxl && src[p + l] == src[cand + l]) l++;
             mlen = l;
             mdist = p - cand;
         }
-        if (can && p >= 1) { // a run of the byte before
+        if (open && p >= 1) { // a run of the byte before
             const u32 b = src[p - 1];
             if (w == b * 0x01010101u) {
                 const iu64 bb = (iu64)b * 0x0101010101010101ull;

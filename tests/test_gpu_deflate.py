@@ -111,3 +111,36 @@ def test_bam_like_ratio(ctx):
     ratio = len(blob) / ref
     print("device / zlib -6:", round(ratio, 3), len(data), len(blob), ref)
     assert ratio < 1.25
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_structured_fuzz(ctx, seed):
+    """mixtures of what a compressor meets: random stretches, copies from near and far (beyond the 32 K window too), runs,
+    small alphabets, text; random block sizes"""
+    rng = np.random.default_rng(1000 + seed)
+    parts, total = [], 0
+    want = int(rng.integers(1, 4 * 0xff00))
+    while total < want:
+        kind = int(rng.integers(0, 6))
+        ln = int(rng.integers(1, 3000))
+        if kind == 0:
+            b = rng.integers(0, 256, ln, dtype=np.uint8).tobytes()
+        elif kind == 1 and total > 0:   # a copy from somewhere before
+            whole = b"".join(parts)
+            back = int(rng.integers(1, min(len(whole), 70000) + 1))
+            b = (whole[-back:] * (ln // back + 1))[:ln]
+        elif kind == 2:
+            b = bytes([int(rng.integers(0, 256))]) * ln
+        elif kind == 3:
+            b = bytes(rng.integers(0, 4, ln, dtype=np.uint8) + 65)
+        elif kind == 4:
+            b = (b"chr%d\t%d\tread_%d\t" % (int(rng.integers(1, 23)), int(rng.integers(0, 10**8)), int(rng.integers(0, 10**6)))) * (ln // 20 + 1)
+            b = b[:ln]
+        else:
+            b = bytes(rng.integers(0, 256, 16, dtype=np.uint8)) * (ln // 16 + 1)
+            b = b[:ln]
+        parts.append(b)
+        total += len(b)
+    data = b"".join(parts)[:want]
+    block = int(rng.choice([0xff00, 0xff00, 4096, 32768, 1000 * 4]))
+    _check(ctx, data, block)
