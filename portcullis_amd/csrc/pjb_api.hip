@@ -1646,7 +1646,9 @@ static int queue_contig(pjb_ctx *c, Flight &f) {
            (int32_t *)S.ancr.p);
     STAGE_EVENT(4);
 
-    if (f.forked) HIP_TRY(c, hipStreamWaitEvent(st, S.ev_join, 0)); // k4a_simple's results (side stream) are needed from here on
+    const hipStream_t tl = st; // (the chain's last kernels on a stream of lowest priority, so that the next chain's first ones go
+                               // ahead of them: 12.9 -> 14.5 ms per step, profiles/r03am_tail_priority.txt; not kept)
+    if (f.forked) HIP_TRY(c, hipStreamWaitEvent(tl, S.ev_join, 0)); // k4a_simple's results (side stream) are needed from here on
     // ---- K4b: the pairs that need the generic walks (list length lives on the device; the grid covers the
     // worst case and surplus blocks exit at once), then K4: gather + segmented reduce -> fragments
     LAUNCH(c, "k4b_generic", k4b_generic, dim3((gen_cap * GEN_SHARDS + 255) / 256), dim3(256), (const u32 *)S.genlist.p,
@@ -1659,7 +1661,7 @@ static int queue_contig(pjb_ctx *c, Flight &f) {
     // ---- K5: fragments -> junctions -> rows
     LAUNCH(c, "k5_frag_reduce", k5_frag_reduce, dim3((slots_lim + 4 * FRAG_SLOTS_PER_WAVE - 1) / (4 * FRAG_SLOTS_PER_WAVE)), dim3(256),
            (const u32 *)S.frag.p, (const int32_t *)S.fragj.p, d_slots, (u32 *)S.acc.p);
-    if (entropy_forked) HIP_TRY(c, hipStreamWaitEvent(st, S.ev_join2, 0));
+    if (entropy_forked) HIP_TRY(c, hipStreamWaitEvent(tl, S.ev_join2, 0));
     LAUNCH(c, "k5_finalize", k5_finalize, dim3(std::max<u32>(1, (JL + 255) / 256)), dim3(256), (const u64 *)pr.key, sidx, (const u32 *)S.seg.p,
            (const u32 *)S.runfirst.p, (const u32 *)S.runstart.p, (const u32 *)S.acc.p,
            (const int32_t *)S.ancl.p, (const int32_t *)S.ancr.p, kf, GT, d_J, (const double *)S.entsum.p, (pjb_junction_row *)S.rows.p, d_err,
@@ -1674,9 +1676,9 @@ static int queue_contig(pjb_ctx *c, Flight &f) {
         mirror_table = (u64 *)(c->mirror + PJB_MIRROR_HEADER_BYTES);
         mirror_room = (u32)std::min<size_t>((c->mirror_cap - PJB_MIRROR_HEADER_BYTES) / sizeof(pjb_junction_row), 0xffffffffu);
     }
-    const hipStream_t rows_stream = c->side_stream ? c->stream3 : st;
-    if (rows_stream != st) {
-        HIP_TRY(c, hipEventRecord(S.ev_rows, st));
+    const hipStream_t rows_stream = c->side_stream ? c->stream3 : tl;
+    if (rows_stream != tl) {
+        HIP_TRY(c, hipEventRecord(S.ev_rows, tl));
         HIP_TRY(c, hipStreamWaitEvent(rows_stream, S.ev_rows, 0));
     }
     {

@@ -190,6 +190,16 @@ enum : u32 { OP_M = 0, OP_I = 1, OP_D = 2, OP_N = 3, OP_S = 4 };
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 
+// A pointer that was READ from memory (a batch descriptor, a pair's sequence address) is a generic pointer to the compiler:
+// its loads are flat_load, which count against the LDS counter too and are waited for one by one.  Everything such pointers
+// name here is device memory: gload reads through a global pointer.
+template <class T>
+__device__ __forceinline__ T gload(const T *p) {
+    T v;
+    __builtin_memcpy(&v, (const __attribute__((address_space(1))) void *)p, sizeof(T));
+    return v;
+}
+
 template <typename T>
 __device__ __forceinline__ T wave_sum(T v) {
 #pragma unroll
@@ -290,7 +300,7 @@ __global__ __launch_bounds__(256) void scan_reduce_kernel(F f, u64 n, u64 *tile_
 #pragma unroll
     for (int k = 0; k < 8; k++) {
         u64 i = base + (u64)k * 256 + threadIdx.x;
-        if (i < n) s += f(i);
+        if (i < n) s += f(i); // (fetching all eight terms first, unconditionally, as k1_count does, changed nothing here: 49 vs 45 us)
     }
     s = wave_sum(s);
     if (lane_id() == 0) sm[threadIdx.x >> 6] = s;
@@ -534,22 +544,37 @@ __global__ __launch_bounds__(256) void k1_count(DevBatch b, u32 *tile_cnt, TileS
     u32 xs4[4], c4[4];
     u32 xflag4[4] = {0, 0, 0, 0}, xspan = 0, xgapmax = 0; // (EXTRA)
     bool xmany = false;
+    // (Every load below is UNCONDITIONAL -- a lane past the batch's end reads the last record, an operation past a CIGAR's end
+    // reads a word that is always there -- and the value is masked afterwards.  Written as `cond ? load : 0` the compiler
+    // may not speculate the load, turns it into a branch and waits for each one before issuing the next: the 16 CIGAR loads
+    // of a thread were 16 round trips in a row.)
 #pragma unroll
     for (int it = 0; it < 4; it++) {
         const int64_t r = base + it * 256 + threadIdx.x;
         const bool on = r < b.n;
-        c0[it] = on ? b.cig_off[r] : 0u;
-        nop[it] = on ? b.cig_off[r + 1] - c0[it] : 0u;
-        pos4[it] = on ? b.pos[r] : 0;
-        prev4[it] = on ? (r > 0 ? b.pos[r - 1] : (b.prev_pos_ptr ? *b.prev_pos_ptr : b.prev_pos)) : 0;
-        xs4[it] = on ? (u32)b.xs[r] : 0u;
-        len4[it] = on ? b.l_qseq[r] : 0;
-        if (EXTRA) xflag4[it] = on ? (u32)b.flag[r] : 0u;
+        const int64_t rr = on ? r : b.n - 1, rp = rr > 0 ? rr - 1 : 0;
+        const u32 c0v = b.cig_off[rr], c1v = b.cig_off[rr + 1];
+        const int32_t posv = b.pos[rr], prevv = b.pos[rp], lenv = b.l_qseq[rr];
+        const u32 xsv = (u32)b.xs[rr];
+        c0[it] = on ? c0v : 0u;
+        nop[it] = on ? c1v - c0v : 0u;
+        pos4[it] = on ? posv : 0;
+        prev4[it] = on ? (r > 0 ? prevv : (b.prev_pos_ptr ? *b.prev_pos_ptr : b.prev_pos)) : 0;
+        xs4[it] = on ? xsv : 0u;
+        len4[it] = on ? lenv : 0;
+        if (EXTRA) {
+            const u32 fv = (u32)b.flag[rr];
+            xflag4[it] = on ? fv : 0u;
+        }
     }
 #pragma unroll
     for (int it = 0; it < 4; it++)
 #pragma unroll
-        for (int k = 0; k < K1_OPS; k++) ops[it][k] = (u32)k < nop[it] ? b.cigar[c0[it] + k] : 0u;
+        for (int k = 0; k < K1_OPS; k++) {
+            const bool has = (u32)k < nop[it];
+            const u32 v = *(has ? b.cigar + c0[it] + k : b.cig_off);
+            ops[it][k] = has ? v : 0u;
+        }
 #pragma unroll
     for (int it = 0; it < 4; it++) {
         const int64_t r = base + it * 256 + threadIdx.x;
@@ -840,7 +865,7 @@ template <int STRIDE, int NLDS>
 struct OpsViewT {
     const uint32_t *g;
     const u32 *lds; // &s_ops[0][column]: NLDS rows of STRIDE columns
-    __device__ __forceinline__ u32 operator[](u32 k) const { return k < (u32)NLDS ? lds[k * STRIDE] : g[k]; }
+    __device__ __forceinline__ u32 operator[](u32 k) const { return k < (u32)NLDS ? lds[k * STRIDE] : gload(g + k); }
 };
 typedef OpsViewT<256, OPS_LDS> OpsView;
 
@@ -1045,7 +1070,11 @@ __global__ __launch_bounds__(256) void k1_emit(DevBatch b, u32 n_tiles_batch, u3
         cig.g = b.cigar + c0;
         cig.lds = &s_ops[0][threadIdx.x];
 #pragma unroll
-        for (int q = 0; q < OPS_LDS; q++) s_ops[q][threadIdx.x] = (u32)q < n ? cig.g[q] : 0u;
+        for (int q = 0; q < OPS_LDS; q++) { // (unconditional loads, masked: see k1_count)
+            const bool has = (u32)q < n;
+            const u32 v = *(has ? cig.g + q : b.cig_off);
+            s_ops[q][threadIdx.x] = has ? v : 0u;
+        }
         EmitRead R;
         R.n = n;
         R.pos = b.pos[r];
@@ -1860,9 +1889,12 @@ struct HeadFn {
     const u32 *sidx;
     const int32_t *ppos;
     __device__ u64 operator()(u64 i) const {
-        if (i == 0) return (1ull << 32) | 1ull;
-        const bool hj = skey[i] != skey[i - 1];
-        const bool hr = hj || ppos[sidx[i]] != ppos[sidx[i - 1]];
+        const u64 im = i ? i - 1 : 0; // (every load unconditional)
+        const u64 ka = skey[i], kb = skey[im];
+        const u32 sa = sidx[i], sb = sidx[im];
+        const int32_t pa = ppos[sa], pb = ppos[sb];
+        const bool hj = i == 0 || ka != kb;
+        const bool hr = hj || pa != pb;
         return ((u64)hj << 32) | (u64)hr;
     }
 };
@@ -2037,13 +2069,13 @@ struct CmpChunk {
 // d[k] = p[first + k] for 0 <= first + k <= last, else 0 (first + 8 <= last: three loads)
 __device__ __forceinline__ void load9(u32 (&d)[9], const u32 *p, int32_t first, int32_t last) {
     if (first >= 0 && first + 8 <= last) {
-        const Words4 a = *reinterpret_cast<const Words4 *>(p + first), b = *reinterpret_cast<const Words4 *>(p + first + 4);
+        const Words4 a = gload(reinterpret_cast<const Words4 *>(p + first)), b = gload(reinterpret_cast<const Words4 *>(p + first + 4));
         d[0] = a.x, d[1] = a.y, d[2] = a.z, d[3] = a.w;
         d[4] = b.x, d[5] = b.y, d[6] = b.z, d[7] = b.w;
-        d[8] = p[first + 8];
+        d[8] = gload(p + first + 8);
     } else {
 #pragma unroll
-        for (int k = 0; k < 9; k++) d[k] = (first + k >= 0 && first + k <= last) ? p[first + k] : 0u;
+        for (int k = 0; k < 9; k++) d[k] = (first + k >= 0 && first + k <= last) ? gload(p + first + k) : 0u;
     }
 }
 // anchor bases [t, t + 64) of an anchor of l bases: read bases from qi (words of the read up to word q_last may be
@@ -2195,10 +2227,10 @@ __device__ Side anchor_side(const OpsView cig, u32 n, int32_t position, int32_t 
                 const int32_t qb = dS + qPos;
                 for (int32_t t = 0; t < qEmit; t++) {
                     const int32_t qi = qb + t;
-                    const u32 byte = seq[qi >> 1];
+                    const u32 byte = gload(seq + (qi >> 1));
                     const u32 code = (qi & 1) ? (byte & 15u) : (byte >> 4);
                     const int32_t gi = rPos + t;
-                    const u32 gc = (gi >= 0 && gi < glen) ? genome[gi] : 0u;
+                    const u32 gc = (gi >= 0 && gi < glen) ? (u32)gload(genome + gi) : 0u;
                     if (nt16_ascii(code) != gc) {
                         mism++;
                         if (first_mis < 0) first_mis = qTot + t;
@@ -2216,7 +2248,7 @@ __device__ Side anchor_side(const OpsView cig, u32 n, int32_t position, int32_t 
             } else { // contig really contains 'X' characters: compare byte by byte
                 for (int32_t t = 0; t < qEmit; t++) {
                     const int32_t gi = rPos + t;
-                    const u32 gc = (gi >= 0 && gi < glen) ? genome[gi] : 0u;
+                    const u32 gc = (gi >= 0 && gi < glen) ? (u32)gload(genome + gi) : 0u;
                     if (gc != (u32)'X') {
                         mism++;
                         if (first_mis < 0) first_mis = qTot + t;
@@ -2344,24 +2376,29 @@ __global__ __launch_bounds__(256) void k4b_generic(const u32 *list, const u32 *n
     const u32 r = g - b.base;
     int32_t istart, iend;
     unpack_key(kf, P.key[p], istart, iend); // (the sorted key array may hold dense junction ids instead of coordinates)
-    const u32 c0 = b.cig_off[r], c1 = b.cig_off[r + 1];
+    const u32 *cig_off = b.cig_off;
+    const u32 c0 = gload(cig_off + r), c1 = gload(cig_off + r + 1);
     const u32 nc = c1 - c0;
     OpsView cig;
     cig.g = b.cigar + c0;
     cig.lds = &s_ops[0][threadIdx.x];
 #pragma unroll
-    for (int k = 0; k < OPS_LDS; k++) s_ops[k][threadIdx.x] = (u32)k < nc ? cig.g[k] : 0u;
+    for (int k = 0; k < OPS_LDS; k++) { // (unconditional loads, masked: see k1_count)
+        const bool has = (u32)k < nc;
+        const u32 v = gload(has ? cig.g + k : cig_off);
+        s_ops[k][threadIdx.x] = has ? v : 0u;
+    }
     const int32_t vpos = P.pos[p], aend = P.aend[p];
     const Member M = member_of(G, vpos); // the pair's target: everything below is in the target's own coordinates
     const int32_t pos = vpos - M.voff;
-    const int32_t lq = b.l_qseq[r];
-    const u32 words = b.seq_off[r + 1] - b.seq_off[r];
+    const int32_t lq = gload(b.l_qseq + r);
+    const u32 so0 = gload(b.seq_off + r), words = gload(b.seq_off + r + 1) - so0;
     if (lq > 1 && (u64)words * 8ull < (u64)lq) {
         set_error(err, g, PJB_ERR_NO_SEQ);
         res[p] = 0;
         return;
     }
-    const uint8_t *seq = b.seq4 + (size_t)b.seq_off[r] * 4;
+    const uint8_t *seq = b.seq4 + (size_t)so0 * 4;
     res[p] = pair_stats_generic(cig, nc, pos, aend - vpos + 1, seq, lq, M.d, M.len, genome_has_x != 0, use_codes ? M.codes : (const u32 *)nullptr,
                                 anc_l[j] - M.voff, istart - M.voff, iend - M.voff, anc_r[j] - M.voff, g, err);
 }
