@@ -1048,8 +1048,9 @@ __global__ __launch_bounds__(256) void k1_emit(DevBatch b, u32 n_tiles_batch, u3
         (void)s0;
         const u32 s = (chunk << 8) + threadIdx.x;
         if (s < s_begin || s >= s_end) continue;
-        u32 k = 0;
-        while (k + 1 < (u32)K1E_LOOK && s >= s_soff[k + 1]) k++;
+        u32 k = 0; // (the offsets ascend: the entry's tile is the number of them it has reached -- 15 independent LDS reads, not a walk)
+#pragma unroll
+        for (int m = 1; m < K1E_LOOK; m++) k += s >= s_soff[m] ? 1u : 0u;
         u32 tile = t0 + k, soff = s_soff[k];
         if (k + 1 == (u32)K1E_LOOK && s >= soff) { // (a run of tiles without spliced reads longer than the window: search)
             u32 lo = tile, hi = n_tiles_total; // tile_soff[lo] <= s < tile_soff[hi]
