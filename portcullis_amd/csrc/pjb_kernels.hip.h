@@ -1504,11 +1504,17 @@ __global__ __launch_bounds__(256) void kd_unique(const u64 *key, const u32 *np, 
     if (tile0 >= n) return;
     for (int i = threadIdx.x; i < KD_SLOTS; i += 256) set[i] = KD_EMPTY;
     __syncthreads();
+    u64 kk[KD_TILE / 256]; // (the tile's keys are fetched together, unconditionally: see k1_count)
+#pragma unroll
+    for (int i = 0; i < KD_TILE / 256; i++) {
+        const u32 p = tile0 + i * 256 + threadIdx.x;
+        kk[i] = key[p < n ? p : n - 1];
+    }
 #pragma unroll
     for (int i = 0; i < KD_TILE / 256; i++) {
         const u32 p = tile0 + i * 256 + threadIdx.x;
         const bool on = p < n;
-        const u64 k = on ? key[p] : 0;
+        const u64 k = on ? kk[i] : 0;
         if (!first_of_key_run(k, on)) continue;
         u32 h = (u32)((k * 0x9E3779B97F4A7C15ull) >> 52) & (KD_SLOTS - 1);
         for (;;) { // look first: after the first round most keys are there already, and a read of one address by many lanes is a broadcast
@@ -1969,12 +1975,15 @@ __global__ __launch_bounds__(256) void k3_anchors_frag(const u32 *sidx, const u3
     if (blockIdx.x * 256u >= n) return;
     const u32 i = blockIdx.x * 256 + threadIdx.x;
     const bool valid = i < n;
-    const u32 p = valid ? sidx[i] : 0;
+    const u32 ic = valid ? i : n - 1; // (loads unconditional, from the last pair for the lanes past the end, masked after: see k1_count)
+    const u32 p = sidx[ic];
     // every load first, then the list's returning atomic, the anchors while it is in flight, the list entry last
-    const u32 j = valid ? jid_of[i] : 0xffffffffu;
-    const u32 m_ = valid ? meta[p] : META_SIMPLE;
-    int32_t l = valid ? lstart[p] : INT32_MAX;
-    int32_t r = valid ? rend[p] : INT32_MIN;
+    const u32 jv = jid_of[ic], mv = meta[p];
+    const int32_t lv = lstart[p], rv = rend[p];
+    const u32 j = valid ? jv : 0xffffffffu;
+    const u32 m_ = valid ? mv : META_SIMPLE;
+    int32_t l = valid ? lv : INT32_MAX;
+    int32_t r = valid ? rv : INT32_MIN;
     // compact the sorted positions whose pair needs the generic compare (order is irrelevant).
     // GEN_SHARDS independent sub-lists keep the returning atomics off a single address.
     const bool gen = valid && (all_generic || !(m_ & META_SIMPLE));
