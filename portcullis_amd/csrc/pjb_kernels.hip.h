@@ -1760,7 +1760,7 @@ __device__ __forceinline__ u64 wave_match_digit(u32 d, bool valid, int bits) {
 // hist + rowscan + scatter: with every tile resident at once the look-back chain costs more than the
 // two small kernels, so it was dropped.
 template <int BITS>
-__global__ __launch_bounds__(256, 4) void rs_scatter(const u64 *kin, const u32 *vin, u64 *kout, u32 *vout, const u32 *np, int shift,
+__global__ __launch_bounds__(256, 3) void rs_scatter(const u64 *kin, const u32 *vin, u64 *kout, u32 *vout, const u32 *np, int shift,
                                                       int bits, const u32 *hist_scan, const u32 *row_total, u32 n_tiles) {
     extern __shared__ __attribute__((aligned(16))) unsigned char rs_smem[];
     __shared__ u64 s_scan[4];
