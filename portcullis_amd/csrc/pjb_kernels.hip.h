@@ -733,25 +733,32 @@ __global__ __launch_bounds__(1024) void k1_scan_tiles(u32 *tile_cnt, const TileS
     __syncthreads();
     u64 spl = 0, uns = 0, sum = 0;
     int32_t mn = INT32_MAX, mx = 0, max_end = 0, max_nlen = 0, min_pos = INT32_MAX;
-    for (u32 base = 0; base < n_tiles; base += 1024) {
-        u32 i = base + threadIdx.x;
-        u64 v = 0;
-        u32 v2 = 0; // spliced reads of the tile
-        if (i < n_tiles) {
-            v = tile_desc ? (tile_desc[i] & ((1ull << 40) - 1)) : (u64)tile_cnt[i];
-            TileStats t = ts[i];
-            v2 = t.spliced;
-            spl += t.spliced;
-            uns += t.unspliced;
-            sum += t.sum_len;
-            mn = min(mn, t.min_len);
-            mx = max(mx, t.max_len);
-            max_end = max(max_end, t.max_end);
-            max_nlen = max(max_nlen, t.max_nlen);
-            min_pos = min(min_pos, t.min_pos);
+    // four consecutive tiles per thread and round (a chain of 30 M reads has 30 k tiles: 8 rounds of three barriers, not 30)
+    for (u32 base = 0; base < n_tiles; base += 4096) {
+        const u32 i0 = base + 4 * threadIdx.x;
+        u64 v[4] = {0, 0, 0, 0};
+        u32 v2[4] = {0, 0, 0, 0}; // spliced reads of the tiles
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const u32 i = i0 + q;
+            if (i < n_tiles) {
+                v[q] = tile_desc ? (tile_desc[i] & ((1ull << 40) - 1)) : (u64)tile_cnt[i];
+                TileStats t = ts[i];
+                v2[q] = t.spliced;
+                spl += t.spliced;
+                uns += t.unspliced;
+                sum += t.sum_len;
+                mn = min(mn, t.min_len);
+                mx = max(mx, t.max_len);
+                max_end = max(max_end, t.max_end);
+                max_nlen = max(max_nlen, t.max_nlen);
+                min_pos = min(min_pos, t.min_pos);
+            }
         }
-        u64 inc = wave_iscan(v);
-        u32 inc2 = wave_iscan(v2);
+        const u64 vs = v[0] + v[1] + v[2] + v[3];
+        const u32 vs2 = v2[0] + v2[1] + v2[2] + v2[3];
+        u64 inc = wave_iscan(vs);
+        u32 inc2 = wave_iscan(vs2);
         int w = threadIdx.x >> 6;
         if (lane_id() == 63) {
             wsum[w] = inc;
@@ -773,11 +780,18 @@ __global__ __launch_bounds__(1024) void k1_scan_tiles(u32 *tile_cnt, const TileS
         u64 carry = carry_s;
         const u32 carry2 = carry2_s;
         // NOTE: exclusive offsets are stored as 32-bit: a contig is limited to < 2^32 pairs
-        if (i < n_tiles && !tile_desc) tile_cnt[i] = (u32)(carry + wb + inc - v);
-        if (i < n_tiles && tile_soff) {
-            const u32 so = carry2 + wb2 + inc2 - v2;
-            tile_soff[i] = so;
-            for (u32 c = (so + 255u) >> 8; (c << 8) < so + v2; c++) chunk_tile[c] = i; // list entries 256 c that fall into this tile
+        u64 ex = carry + wb + inc - vs;
+        u32 so = carry2 + wb2 + inc2 - vs2;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const u32 i = i0 + q;
+            if (i < n_tiles && !tile_desc) tile_cnt[i] = (u32)ex;
+            if (i < n_tiles && tile_soff) {
+                tile_soff[i] = so;
+                for (u32 c = (so + 255u) >> 8; (c << 8) < so + v2[q]; c++) chunk_tile[c] = i; // list entries 256 c that fall into this tile
+            }
+            ex += v[q];
+            so += v2[q];
         }
         __syncthreads();
         if (threadIdx.x == 0) {
