@@ -678,7 +678,7 @@ void BamReader::scanRecordsParallel(int nthreads, size_t chunkBytes, const std::
         // ---- refill the compressed window
         if (fileOff < fileSize && cHave < CREAD) {
             const size_t want = (size_t)std::min<uint64_t>(CREAD - cHave, fileSize - fileOff);
-            const size_t nsl = std::max<size_t>(1, std::min<size_t>((size_t)nthreads, want >> 20));
+            const size_t nsl = std::max<size_t>(1, std::min<size_t>((size_t)std::min(nthreads, 4), want >> 20));  // (four threads read the page cache fastest: profiles/r03ap_register_probe.txt)
             std::atomic<bool> ioBad(false);
             pool.run(nsl, [&](size_t t) {
                 const size_t per = (want + nsl - 1) / nsl, a = std::min(want, per * t), b = std::min(want, a + per);
@@ -904,7 +904,7 @@ void BamReader::decodeRegionParallel(int32_t tid, int nthreads, size_t maxRecord
         nChunks++;
         if (fileOff < fileSize && cHave < CREAD) {
             const size_t want = (size_t)std::min<uint64_t>(CREAD - cHave, fileSize - fileOff);
-            const size_t nsl = std::max<size_t>(1, std::min<size_t>((size_t)nthreads, want >> 20));
+            const size_t nsl = std::max<size_t>(1, std::min<size_t>((size_t)std::min(nthreads, 4), want >> 20));  // (four threads read the page cache fastest: profiles/r03ap_register_probe.txt)
             std::atomic<bool> ioBad(false);
             pool.run(nsl, [&](size_t t) {
                 const size_t per = (want + nsl - 1) / nsl, a = std::min(want, per * t), b = std::min(want, a + per);

@@ -785,7 +785,7 @@ void JunctionBuilder::findJuncs(DeviceThread& device, BamReader& reader, GenomeM
                             p = nullptr;
                         }
                     } leave{pinnedPool.get(), device.lane};
-                    const int readThreads = std::max(innerThreads, pinnedPool->readThreads);
+                    const int readThreads = pinnedPool->readThreads;
                     // This thread hands the pieces to the device itself (pjb_bam_begin / _piece are safe beside the device
                     // thread's calls): queued behind genome uploads, finishes and record parsing on the device thread the
                     // copies started late and PCIe idled between them.
@@ -1083,7 +1083,11 @@ void JunctionBuilder::findJunctions() {
         if (stat(prepData.getSortedBamFilePath().c_str(), &bst) == 0 && (uint64_t)bst.st_size >= minFile) {
             pinnedPool.reset(new PinnedPool(nbuf, pieceBytes));
             if (!getenv("PORTCULLIS_GENOME_PARSE")) genomePool.reset(new PinnedPool(3));  // (PORTCULLIS_GENOME_PARSE=1: the host filters the FASTA characters as before)
-            transferSlots = 3;  // targets whose pieces are on their way at once, over all contexts (PORTCULLIS_TRANSFER_SLOTS; 0: no limit)
+            // Targets whose pieces are on their way at once, over all contexts (PORTCULLIS_TRANSFER_SLOTS; 0: no limit), each read by
+            // PORTCULLIS_READ_THREADS threads.  FEW readers: four threads pread 31.6 GB/s out of the page cache into page-locked
+            // buffers, eight 25.0, fifteen 24.8 (profiles/r03ap_register_probe.txt), and the run with 2 x 2 readers takes 2.03 s
+            // where 3 x 5 took 2.3 - 2.6 (profiles/r03aq_e2e_readers.txt).
+            transferSlots = 2;
             if (const char* e = getenv("PORTCULLIS_TRANSFER_SLOTS")) transferSlots = atoi(e);
         }
     }
@@ -1115,7 +1119,8 @@ void JunctionBuilder::findJunctions() {
             if (pinnedPool && transferSlots > 0) {
                 const int perLane = std::max(1, transferSlots / (int)deviceThreads.size());
                 pinnedPool->setTransferSlots(perLane);
-                pinnedPool->readThreads = std::max(1, total / (perLane * (int)deviceThreads.size()));
+                pinnedPool->readThreads = std::max(1, std::min(2, total / (perLane * (int)deviceThreads.size())));
+                if (const char* e = getenv("PORTCULLIS_READ_THREADS")) pinnedPool->readThreads = std::max(1, atoi(e));  // (threads per target in transfer)
             }
         }
         return *deviceThreads[(size_t)w % deviceThreads.size()];
