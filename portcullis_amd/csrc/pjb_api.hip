@@ -1452,7 +1452,7 @@ static int queue_contig(pjb_ctx *c, Flight &f) {
             LAUNCH(c, "k1_walk", k1_walk, dim3(nt), dim3(K1W_THREADS), b, lk, n_tiles, (TileStats *)S.tile_stats.p,
                    want_splidx ? (u32 *)S.splidx.p : (u32 *)nullptr, pr, kf, ref_len, f.tid, (int)c->cfg.orientation, PL, d_err);
         }
-        LAUNCH(c, "k1_scan_tiles", k1_scan_tiles, dim3(1), dim3(1024), (u32 *)nullptr, (const TileStats *)S.tile_stats.p, n_tiles, d_cs, PL, kf,
+        LAUNCH(c, "k1_scan_tiles", k1_scan_tiles, dim3(1), dim3(K1S_THREADS), (u32 *)nullptr, (const TileStats *)S.tile_stats.p, n_tiles, d_cs, PL, kf,
                ref_len, (const u64 *)lk.tile_desc, (u32 *)nullptr, (u32 *)nullptr);
     } else {
         // ---- K1a: count (a group's members: a tile whose alignments leave the member's own sequence is flagged); with
@@ -1487,7 +1487,7 @@ static int queue_contig(pjb_ctx *c, Flight &f) {
         if (group)
             LAUNCH(c, "kg_member_stats", kg_member_stats, dim3((unsigned)n_members), dim3(256), (const u32 *)S.tile_cnt.p, (const TileStats *)S.tile_stats.p,
                    (const u32 *)d_tile_lo, n_members, d_members);
-        LAUNCH(c, "k1_scan_tiles", k1_scan_tiles, dim3(1), dim3(1024), (u32 *)S.tile_cnt.p, (const TileStats *)S.tile_stats.p, n_tiles, d_cs,
+        LAUNCH(c, "k1_scan_tiles", k1_scan_tiles, dim3(1), dim3(K1S_THREADS), (u32 *)S.tile_cnt.p, (const TileStats *)S.tile_stats.p, n_tiles, d_cs,
                PL, kf, group ? INT32_MAX - 1 : ref_len, (const u64 *)nullptr, (u32 *)S.tile_soff.p, (u32 *)S.chunk_tile.p);
         // ---- K1b: emit (coordinates in the group's virtual sequence)
         for (size_t bi = 0; bi < batches.size(); bi++) {

@@ -720,31 +720,36 @@ __global__ __launch_bounds__(256) void k1_count(DevBatch b, u32 *tile_cnt, TileS
 // descriptors, and nothing is written back)
 // tile_soff / chunk_tile (both may be nullptr): the tiles' spliced reads seen as ONE dense list -- tile_soff[t] = spliced reads
 // before tile t (n_tiles + 1 entries), chunk_tile[c] = the tile that holds list entry 256 c -- for k1_emit's dense mapping.
-__global__ __launch_bounds__(1024) void k1_scan_tiles(u32 *tile_cnt, const TileStats *ts, u32 n_tiles, ContigStats *out, u32 pair_limit,
-                                                       KeyFmt kf, int32_t ref_len, const u64 *tile_desc, u32 *tile_soff, u32 *chunk_tile) {
-    __shared__ u64 wsum[16];
-    __shared__ u32 wsum2[16];
+// (One block of 256 threads, 16 tiles per thread and round.  It was one block of 1024: a workgroup of 16 wavefronts needs 16
+// free wave slots on ONE CU at once, and beside the inflate and other chains' kernels in the end-to-end run it waited for
+// them -- 4 ms per target instead of 60 us.)
+constexpr int K1S_THREADS = 256, K1S_PER = 16;
+__global__ __launch_bounds__(K1S_THREADS) void k1_scan_tiles(u32 *tile_cnt, const TileStats *ts, u32 n_tiles, ContigStats *out, u32 pair_limit,
+                                                              KeyFmt kf, int32_t ref_len, const u64 *tile_desc, u32 *tile_soff, u32 *chunk_tile) {
+    constexpr int NW = K1S_THREADS / 64;
+    __shared__ u64 wsum[NW];
+    __shared__ u32 wsum2[NW];
     __shared__ u32 carry2_s;
     __shared__ u64 carry_s;
-    if (threadIdx.x == 0) carry2_s = 0;
-    __shared__ u64 r_spl[16], r_uns[16], r_sum[16];
-    __shared__ int32_t r_i[16][5];
-    if (threadIdx.x == 0) carry_s = 0;
+    __shared__ u64 r_spl[NW], r_uns[NW], r_sum[NW];
+    __shared__ int32_t r_i[NW][5];
+    if (threadIdx.x == 0) {
+        carry2_s = 0;
+        carry_s = 0;
+    }
     __syncthreads();
     u64 spl = 0, uns = 0, sum = 0;
     int32_t mn = INT32_MAX, mx = 0, max_end = 0, max_nlen = 0, min_pos = INT32_MAX;
-    // four consecutive tiles per thread and round (a chain of 30 M reads has 30 k tiles: 8 rounds of three barriers, not 30)
-    for (u32 base = 0; base < n_tiles; base += 4096) {
-        const u32 i0 = base + 4 * threadIdx.x;
-        u64 v[4] = {0, 0, 0, 0};
-        u32 v2[4] = {0, 0, 0, 0}; // spliced reads of the tiles
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
+    for (u32 base = 0; base < n_tiles; base += K1S_THREADS * K1S_PER) {
+        const u32 i0 = base + K1S_PER * threadIdx.x;
+        u64 vs = 0;
+        u32 vs2 = 0;
+        for (int q = 0; q < K1S_PER; q++) {
             const u32 i = i0 + q;
             if (i < n_tiles) {
-                v[q] = tile_desc ? (tile_desc[i] & ((1ull << 40) - 1)) : (u64)tile_cnt[i];
-                TileStats t = ts[i];
-                v2[q] = t.spliced;
+                vs += tile_desc ? (tile_desc[i] & ((1ull << 40) - 1)) : (u64)tile_cnt[i];
+                const TileStats t = ts[i];
+                vs2 += t.spliced;
                 spl += t.spliced;
                 uns += t.unspliced;
                 sum += t.sum_len;
@@ -755,11 +760,9 @@ __global__ __launch_bounds__(1024) void k1_scan_tiles(u32 *tile_cnt, const TileS
                 min_pos = min(min_pos, t.min_pos);
             }
         }
-        const u64 vs = v[0] + v[1] + v[2] + v[3];
-        const u32 vs2 = v2[0] + v2[1] + v2[2] + v2[3];
-        u64 inc = wave_iscan(vs);
-        u32 inc2 = wave_iscan(vs2);
-        int w = threadIdx.x >> 6;
+        const u64 inc = wave_iscan(vs);
+        const u32 inc2 = wave_iscan(vs2);
+        const int w = threadIdx.x >> 6;
         if (lane_id() == 63) {
             wsum[w] = inc;
             wsum2[w] = inc2;
@@ -767,9 +770,9 @@ __global__ __launch_bounds__(1024) void k1_scan_tiles(u32 *tile_cnt, const TileS
         __syncthreads();
         u64 wb = 0, tot = 0;
         u32 wb2 = 0, tot2 = 0;
-        for (int k = 0; k < 16; k++) {
-            u64 s = wsum[k];
-            u32 s2 = wsum2[k];
+        for (int k = 0; k < NW; k++) {
+            const u64 s = wsum[k];
+            const u32 s2 = wsum2[k];
             if (k < w) {
                 wb += s;
                 wb2 += s2;
@@ -777,21 +780,23 @@ __global__ __launch_bounds__(1024) void k1_scan_tiles(u32 *tile_cnt, const TileS
             tot += s;
             tot2 += s2;
         }
-        u64 carry = carry_s;
+        const u64 carry = carry_s;
         const u32 carry2 = carry2_s;
         // NOTE: exclusive offsets are stored as 32-bit: a contig is limited to < 2^32 pairs
         u64 ex = carry + wb + inc - vs;
         u32 so = carry2 + wb2 + inc2 - vs2;
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
+        for (int q = 0; q < K1S_PER; q++) { // (the tiles' own counts once more: L2 hits)
             const u32 i = i0 + q;
-            if (i < n_tiles && !tile_desc) tile_cnt[i] = (u32)ex;
-            if (i < n_tiles && tile_soff) {
+            if (i >= n_tiles) break;
+            const u64 v = tile_desc ? (tile_desc[i] & ((1ull << 40) - 1)) : (u64)tile_cnt[i];
+            const u32 v2 = ts[i].spliced;
+            if (!tile_desc) tile_cnt[i] = (u32)ex;
+            if (tile_soff) {
                 tile_soff[i] = so;
-                for (u32 c = (so + 255u) >> 8; (c << 8) < so + v2[q]; c++) chunk_tile[c] = i; // list entries 256 c that fall into this tile
+                for (u32 c = (so + 255u) >> 8; (c << 8) < so + v2; c++) chunk_tile[c] = i; // list entries 256 c that fall into this tile
             }
-            ex += v[q];
-            so += v2[q];
+            ex += v;
+            so += v2;
         }
         __syncthreads();
         if (threadIdx.x == 0) {
@@ -809,7 +814,7 @@ __global__ __launch_bounds__(1024) void k1_scan_tiles(u32 *tile_cnt, const TileS
     max_end = wave_max(max_end);
     max_nlen = wave_max(max_nlen);
     min_pos = wave_min(min_pos);
-    int w = threadIdx.x >> 6;
+    const int w = threadIdx.x >> 6;
     if (lane_id() == 0) {
         r_spl[w] = spl;
         r_uns[w] = uns;
@@ -824,7 +829,7 @@ __global__ __launch_bounds__(1024) void k1_scan_tiles(u32 *tile_cnt, const TileS
     if (threadIdx.x == 0) {
         u64 a = 0, b2 = 0, c = 0;
         int32_t m0 = INT32_MAX, m1 = 0, m2 = 0, m3 = 0, m4 = INT32_MAX;
-        for (int k = 0; k < 16; k++) {
+        for (int k = 0; k < NW; k++) {
             a += r_spl[k];
             b2 += r_uns[k];
             c += r_sum[k];

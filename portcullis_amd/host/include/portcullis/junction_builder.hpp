@@ -56,6 +56,8 @@ class JunctionBuilder {
     int hostThreads = 0;           // 0 = use `threads`; otherwise total host decode threads
     size_t batchRecords = 1 << 20; // alignments per batch sent to the device
     int innerThreads = 1;          // decode threads inside one target sequence (set by findJunctions)
+    std::vector<int> transferRanks;  // per target: its place in the order the targets' file bytes should cross (set by findJunctions)
+    int transferRank(int32_t tid) const { return tid >= 0 && (size_t)tid < transferRanks.size() ? transferRanks[(size_t)tid] : 1 << 30; }
     std::shared_ptr<class PinnedPool> pinnedPool;  // ring of page-locked pieces for the file bytes of large device-ingest runs
     std::shared_ptr<class PinnedPool> genomePool;  // a few page-locked buffers for the FASTA bytes of the target sequences (same runs)
     size_t pieceMinTarget = 0;                     // targets with fewer bytes go over in one (pageable) block

@@ -257,7 +257,7 @@ class PinnedPool {
     struct Gate {
         std::mutex mu;
         std::condition_variable cv;
-        uint64_t next = 0, serving = 0;
+        std::vector<int> waiting;  // ranks of the targets that wait (the best rank = the smallest goes first)
         int active = 0;
     };
     Gate gates[16];
@@ -268,12 +268,14 @@ public:
     size_t piece() const { return pieceBytes; }
     int readThreads = 1;  // threads a target in transfer reads its pieces with
     void setTransferSlots(int perLane) { gatePermits = std::max(1, perLane); }
-    void enterTransfer(int lane) {
+    // `rank`: the target's place in the order the run wants its targets to cross (the workers all arrive here in the same
+    // instant, when the context is ready: who gets the lock first must not decide that chr1 crosses sixth)
+    void enterTransfer(int lane, int rank) {
         Gate& g = gates[lane & 15];
         std::unique_lock<std::mutex> lk(g.mu);
-        const uint64_t t = g.next++;
-        g.cv.wait(lk, [&] { return t == g.serving && g.active < gatePermits; });
-        g.serving++;
+        g.waiting.push_back(rank);
+        g.cv.wait(lk, [&] { return g.active < gatePermits && *std::min_element(g.waiting.begin(), g.waiting.end()) == rank; });
+        g.waiting.erase(std::find(g.waiting.begin(), g.waiting.end(), rank));
         g.active++;
         g.cv.notify_all();
     }
@@ -772,7 +774,7 @@ void JunctionBuilder::findJuncs(DeviceThread& device, BamReader& reader, GenomeM
                     // copies a piece while this thread reads the next one
                     const size_t piece = pinnedPool->piece();
                     const double tg0 = HostProfile::now();
-                    pinnedPool->enterTransfer(device.lane);
+                    pinnedPool->enterTransfer(device.lane, transferRank(seq));
                     g_prof.event(tg0, HostProfile::now(), "worker gate wait tid " + std::to_string(seq));
                     struct Leave {
                         PinnedPool* p;
@@ -1057,6 +1059,17 @@ void JunctionBuilder::findJunctions() {
         order.push_back((int32_t)i);
     }
     std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return refs->at((size_t)a)->length > refs->at((size_t)b)->length; });
+    // ... except that a smaller one goes first: the device has nothing to do until a target's last byte has crossed, and the
+    // largest target takes longest to cross (first inflate 0.23 s after the contexts were ready; the smallest ones still end
+    // the run: a short tail)
+    if (order.size() >= 5 && !getenv("PORTCULLIS_LARGEST_FIRST")) {
+        const size_t k = order.size() * 4 / 5;
+        const int32_t small = order[k];
+        order.erase(order.begin() + (long)k);
+        order.insert(order.begin(), small);
+    }
+    transferRanks.assign(refs->size(), 1 << 30);
+    for (size_t k = 0; k < order.size(); k++) transferRanks[(size_t)order[k]] = (int)k;
     std::mutex mu;
     size_t nextTask = 0;
     std::string firstError;
