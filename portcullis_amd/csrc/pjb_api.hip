@@ -6,6 +6,8 @@
 #include "pjb_ingest.hip.h"
 
 #include <algorithm>
+#include <sys/mman.h>
+#include <thread>
 #include <chrono>
 #include <cstdarg>
 #include <cstdio>
@@ -559,14 +561,61 @@ static int slot_init(pjb_ctx *c, int k);
 
 extern "C" {
 
+// Page-locked host memory.  hipHostMalloc zeroes and pins on the calling thread at ~4.6 GB/s (143 ms for the 768 MB ring of
+// the end-to-end program, as much again for its genome buffers); anonymous huge-page memory touched by four threads and then
+// registered is the same memory to a DMA (56.8 GB/s either way) after 23 ms (tools/debug/register_probe.hip,
+// profiles/r03ap2_register_probe.txt).  Blocks below 8 MB, and anything mmap or the registration refuses, take hipHostMalloc.
+namespace {
+std::mutex g_host_mu;
+std::map<void *, size_t> g_host_registered; // blocks of pjb_host_alloc that are mmap + hipHostRegister (value: mapped bytes)
+} // namespace
 void *pjb_host_alloc(size_t bytes) {
+    if (bytes >= ((size_t)8 << 20) && !getenv("PJB_HOST_ALLOC_PLAIN")) {
+        const size_t huge = (size_t)2 << 20, len = (bytes + huge - 1) & ~(huge - 1);
+        void *p = mmap(nullptr, len, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+        if (p != MAP_FAILED) {
+            (void)madvise(p, len, MADV_HUGEPAGE);
+            const size_t nt = std::min<size_t>(4, len >> 24);
+            auto touch = [&](size_t t) {
+                const size_t per = ((len / std::max<size_t>(nt, 1)) + huge - 1) & ~(huge - 1), a = std::min(len, per * t), b = std::min(len, a + per);
+                for (size_t o = a; o < b; o += 4096) ((volatile uint8_t *)p)[o] = 0;
+            };
+            if (nt <= 1) touch(0);
+            else {
+                std::vector<std::thread> th;
+                for (size_t t = 0; t < nt; t++) th.emplace_back(touch, t);
+                for (auto &x : th) x.join();
+            }
+            if (hipHostRegister(p, len, hipHostRegisterDefault) == hipSuccess) {
+                std::lock_guard<std::mutex> lk(g_host_mu);
+                g_host_registered[p] = len;
+                return p;
+            }
+            (void)hipGetLastError();
+            munmap(p, len);
+        }
+    }
     void *p = nullptr;
     if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) return nullptr;
     return p;
 }
 
 void pjb_host_free(void *p) {
-    if (p) (void)hipHostFree(p);
+    if (!p) return;
+    size_t len = 0;
+    {
+        std::lock_guard<std::mutex> lk(g_host_mu);
+        auto it = g_host_registered.find(p);
+        if (it != g_host_registered.end()) {
+            len = it->second;
+            g_host_registered.erase(it);
+        }
+    }
+    if (len) {
+        (void)hipHostUnregister(p);
+        munmap(p, len);
+    } else
+        (void)hipHostFree(p);
 }
 
 int pjb_device_count(void) {

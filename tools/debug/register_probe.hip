@@ -3,6 +3,7 @@
 // buffers + copy (what the program does).  T threads each.   hipcc -O2 --offload-arch=gfx950 -o register_probe register_probe.hip -lpthread
 //   register_probe <file> [threads]
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <cstdio>
@@ -30,6 +31,52 @@ int main(int argc, char **argv) {
     void *dev = nullptr;
     if (hipMalloc(&dev, total) != hipSuccess) return 1;
     const size_t np = total / piece;
+    {   // anonymous memory, registered: what a ring of page-locked buffers costs to set up, and how fast it then crosses
+        const size_t nb = 12;
+        double t0 = now();
+        uint8_t *anon = (uint8_t *)mmap(nullptr, nb * piece, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+        madvise(anon, nb * piece, MADV_HUGEPAGE);
+        const double t_map = now() - t0;
+        t0 = now();
+        {
+            std::vector<std::thread> th;
+            for (int t = 0; t < 4; t++) th.emplace_back([&, t] { for (size_t k = t; k < nb; k += 4) memset(anon + k * piece, 1, piece); });
+            for (auto &x : th) x.join();
+        }
+        const double t_touch = now() - t0;
+        t0 = now();
+        for (size_t k = 0; k < nb; k++)
+            if (hipHostRegister(anon + k * piece, piece, hipHostRegisterDefault) != hipSuccess) printf("register failed\n");
+        const double t_reg = now() - t0;
+        hipStream_t s;
+        (void)hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+        double best = 0;
+        for (int rep = 0; rep < 3; rep++) {
+            t0 = now();
+            for (size_t k = 0; k < 48; k++) (void)hipMemcpyAsync((char *)dev + (k % np) * piece, anon + (k % nb) * piece, piece, hipMemcpyHostToDevice, s);
+            (void)hipStreamSynchronize(s);
+            best = std::max(best, 48.0 * piece / (now() - t0) / 1e9);
+        }
+        printf("anonymous ring of 12 x 64 MB: mmap %.1f ms, first touch by 4 threads %.1f ms, hipHostRegister %.1f ms (all 12); copies from it %.1f GB/s\n", t_map * 1e3,
+               t_touch * 1e3, t_reg * 1e3, best);
+        void *hm = nullptr;
+        t0 = now();
+        (void)hipHostMalloc(&hm, nb * piece, hipHostMallocDefault);
+        const double t_hm = now() - t0;
+        best = 0;
+        for (int rep = 0; rep < 3; rep++) {
+            t0 = now();
+            for (size_t k = 0; k < 48; k++) (void)hipMemcpyAsync((char *)dev + (k % np) * piece, (char *)hm + (k % nb) * piece, piece, hipMemcpyHostToDevice, s);
+            (void)hipStreamSynchronize(s);
+            best = std::max(best, 48.0 * piece / (now() - t0) / 1e9);
+        }
+        printf("hipHostMalloc of the same 768 MB: %.1f ms; copies from it %.1f GB/s\n", t_hm * 1e3, best);
+        for (size_t k = 0; k < nb; k++) (void)hipHostUnregister(anon + k * piece);
+        (void)hipHostFree(hm);
+        munmap(anon, nb * piece);
+        (void)hipStreamDestroy(s);
+        fflush(stdout);
+    }
     for (int mode = 0; mode < 3; mode++) {
         // 0: pread into page-locked buffers + copy; 1: register the mapping's pieces + copy + unregister; 2: copy from the pageable mapping
         std::atomic<size_t> next(0);
