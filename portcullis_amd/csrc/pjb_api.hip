@@ -664,6 +664,7 @@ int pjb_create(pjb_ctx **out, const pjb_config *cfg) {
     // a stream is ~10 ms on an idle device -- and blocked for 1.9 s once when it happened in the middle of an end-to-end run
     // (the runtime creates a hardware queue behind whatever the device is doing): a caller that wants more than four chains in
     // flight on a busy device queues that deep once, early.
+    // (60 ms for four slots' streams and events; from four threads at once it is 70 - 100 ms: the runtime serialises them)
     for (int k = 0; k < 4 && k < PJB_MAX_QUEUED; k++) (void)slot_init(c, k);
     if (const char *s = getenv("PJB_INFLATE_V1")) c->inflate_v1 = atoi(s) != 0;
     const int inf_lds = c->inflate_v1 ? I2_LDS_BYTES : I3_LDS_BYTES;

@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <exception>
 #include <fstream>
 #include <thread>
 #include <iostream>
@@ -339,6 +340,21 @@ void JunctionSystem::saveAll(const std::string& outputPrefix, const std::string&
     const std::string exonGffPath = outputPrefix + ".junctions.exon.gff3";
     const std::string intronGffPath = outputPrefix + ".junctions.intron.gff3";
     const std::string bedPath = outputPrefix + ".junctions.bed";
+    // the .bed is formatted and written beside the .tab (the messages keep the reference's order)
+    std::exception_ptr bedError;
+    std::thread bedThread([&] {
+        try {
+            outputBED(bedPath, CanonicalSS::ALL, source, bedscore);
+        } catch (...) {
+            bedError = std::current_exception();
+        }
+    });
+    struct Join {
+        std::thread& t;
+        ~Join() {
+            if (t.joinable()) t.join();
+        }
+    } joinBed{bedThread};
     cout << " - Saving junction table to: " << tabPath << " ... ";
     cout.flush();
     {
@@ -371,7 +387,8 @@ void JunctionSystem::saveAll(const std::string& outputPrefix, const std::string&
     }
     cout << " - Saving BED file with all junctions to: " << bedPath << " ... ";
     cout.flush();
-    outputBED(bedPath, CanonicalSS::ALL, source, bedscore);
+    bedThread.join();
+    if (bedError) std::rethrow_exception(bedError);
     cout << "done." << endl;
 }
 
