@@ -326,6 +326,11 @@ int pjb_select_timed_kernels(pjb_ctx *ctx, const char *comma_separated_names);
 /* Page-locked host memory for batch arrays (hipHostMalloc); NULL if it cannot be had. */
 void *pjb_host_alloc(size_t bytes);
 void pjb_host_free(void *p);
+/* Page-lock memory the caller already has -- e.g. a read-only mapping of the BAM file: the file's bytes then cross from the
+ * page cache by DMA, without a copy by the CPU (hipHostRegister; `p` and `bytes` multiples of the page size).  The range
+ * must not overlap another registered range; unregister before unmapping. */
+int pjb_host_register(void *p, size_t bytes);
+int pjb_host_unregister(void *p);
 
 /* Number of visible HIP devices (0 if none); does not create a context. */
 int pjb_device_count(void);

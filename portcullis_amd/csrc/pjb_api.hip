@@ -618,6 +618,23 @@ void pjb_host_free(void *p) {
         (void)hipHostFree(p);
 }
 
+int pjb_host_register(void *p, size_t bytes) {
+    if (!p || !bytes) return PJB_ERR_ARG;
+    if (hipHostRegister(p, bytes, hipHostRegisterDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        return PJB_ERR_HIP;
+    }
+    return PJB_OK;
+}
+int pjb_host_unregister(void *p) {
+    if (!p) return PJB_ERR_ARG;
+    if (hipHostUnregister(p) != hipSuccess) {
+        (void)hipGetLastError();
+        return PJB_ERR_HIP;
+    }
+    return PJB_OK;
+}
+
 int pjb_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;

@@ -24,7 +24,7 @@ EXPORTS = [
     "pjb_release_contig", "pjb_submit_batch", "pjb_submit_batch_device", "pjb_finish_contig", "pjb_finish_contig_begin",
     "pjb_finish_contig_end", "pjb_finish_ready", "pjb_finish_group_begin", "pjb_finish_group_end", "pjb_collect",
     "pjb_clear_rows", "pjb_get_timing", "pjb_device_count", "pjb_get_kernel_timing", "pjb_reset_kernel_timing",
-    "pjb_select_timed_kernels", "pjb_host_alloc", "pjb_host_free", "pjb_inflate_bgzf", "pjb_deflate_bgzf", "pjb_submit_bam", "pjb_collect_device", "pjb_set_row_mirror",
+    "pjb_select_timed_kernels", "pjb_host_alloc", "pjb_host_free", "pjb_host_register", "pjb_host_unregister", "pjb_inflate_bgzf", "pjb_deflate_bgzf", "pjb_submit_bam", "pjb_collect_device", "pjb_set_row_mirror",
     "pjb_extra_finish", "pjb_set_option", "pjb_bam_begin", "pjb_bam_piece", "pjb_bam_pieces_done", "pjb_bam_end", "pjb_bam_inflate_done", "pjb_filter_set_junctions", "pjb_filter_batch", "pjb_filt_features",
 ]
 N_FEATURES = 34

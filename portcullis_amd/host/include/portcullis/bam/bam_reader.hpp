@@ -159,6 +159,9 @@ public:
     bool regionSpan(int32_t tid, uint64_t& fileOff, size_t& bytes, uint32_t& firstU);
     // ... and `bytes` bytes from `fileOff` into dst with `nthreads` parallel preads.
     void readSpan(uint64_t fileOff, size_t bytes, uint8_t* dst, int nthreads);
+    // A read-only mapping of the whole file (made once per process and kept; nullptr if it cannot be had): callers that
+    // page-lock pieces of it hand the page cache itself to the device.
+    static const uint8_t* mapFile(const std::string& path, size_t& bytes);
 };
 
 }  // namespace bam

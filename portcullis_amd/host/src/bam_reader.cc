@@ -7,6 +7,7 @@
 #include <chrono>
 #include <sys/resource.h>
 #include <condition_variable>
+#include <map>
 #include <memory>
 #include <mutex>
 #include <cstring>
@@ -600,6 +601,32 @@ bool BamReader::regionSpan(int32_t tid, uint64_t& fileOff, size_t& bytes, uint32
     bytes = (size_t)(end - lo);
     firstU = (uint32_t)(start & 0xffff);
     return true;
+}
+
+const uint8_t* BamReader::mapFile(const std::string& path, size_t& bytes) {
+    static std::mutex mu;
+    static std::map<std::string, std::pair<const uint8_t*, size_t>> maps;
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = maps.find(path);
+    if (it == maps.end()) {
+        const uint8_t* p = nullptr;
+        size_t n = 0;
+        const int fd = ::open(path.c_str(), O_RDONLY);
+        if (fd >= 0) {
+            struct stat st;
+            if (fstat(fd, &st) == 0 && st.st_size > 0) {
+                void* m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+                if (m != MAP_FAILED) {
+                    p = (const uint8_t*)m;
+                    n = (size_t)st.st_size;
+                }
+            }
+            ::close(fd);
+        }
+        it = maps.emplace(path, std::make_pair(p, n)).first;
+    }
+    bytes = it->second.second;
+    return it->second.first;
 }
 
 void BamReader::readSpan(uint64_t fileOff, size_t want, uint8_t* buf, int nthreads) {

@@ -259,6 +259,7 @@ class PinnedPool {
         std::condition_variable cv;
         std::vector<int> waiting;  // ranks of the targets that wait (the best rank = the smallest goes first)
         int active = 0;
+        uint64_t used = 0;  // slots in use (bit k)
     };
     Gate gates[16];
     int gatePermits = 1 << 30;
@@ -270,21 +271,29 @@ public:
     void setTransferSlots(int perLane) { gatePermits = std::max(1, perLane); }
     // `rank`: the target's place in the order the run wants its targets to cross (the workers all arrive here in the same
     // instant, when the context is ready: who gets the lock first must not decide that chr1 crosses sixth)
-    void enterTransfer(int lane, int rank) {
+    // returns the slot taken (0 .. slots - 1): the slots differ in how their target's bytes travel
+    int enterTransfer(int lane, int rank) {
         Gate& g = gates[lane & 15];
         std::unique_lock<std::mutex> lk(g.mu);
         g.waiting.push_back(rank);
         g.cv.wait(lk, [&] { return g.active < gatePermits && *std::min_element(g.waiting.begin(), g.waiting.end()) == rank; });
         g.waiting.erase(std::find(g.waiting.begin(), g.waiting.end(), rank));
         g.active++;
+        int slot = 0;
+        while (slot < 63 && (g.used >> slot) & 1) slot++;
+        g.used |= 1ull << slot;
         g.cv.notify_all();
+        return slot;
     }
-    void leaveTransfer(int lane) {
+    void leaveTransfer(int lane, int slot) {
         Gate& g = gates[lane & 15];
         std::lock_guard<std::mutex> lk(g.mu);
         g.active--;
+        g.used &= ~(1ull << slot);
         g.cv.notify_all();
     }
+    // PORTCULLIS_REGISTER_SLOT=k: the target in slot k sends pieces of the file's own mapping (page-locked for the copy)
+    int registerSlot = -1;
     ~PinnedPool() {
         for (auto& b : bufs) pjb_host_free(b.p);
     }
@@ -774,20 +783,25 @@ void JunctionBuilder::findJuncs(DeviceThread& device, BamReader& reader, GenomeM
                     // copies a piece while this thread reads the next one
                     const size_t piece = pinnedPool->piece();
                     const double tg0 = HostProfile::now();
-                    pinnedPool->enterTransfer(device.lane, transferRank(seq));
+                    const int slot = pinnedPool->enterTransfer(device.lane, transferRank(seq));
                     g_prof.event(tg0, HostProfile::now(), "worker gate wait tid " + std::to_string(seq));
                     struct Leave {
                         PinnedPool* p;
-                        int lane;
+                        int lane, slot;
                         ~Leave() {
-                            if (p) p->leaveTransfer(lane);
+                            if (p) p->leaveTransfer(lane, slot);
                         }
                         void now() {
-                            if (p) p->leaveTransfer(lane);
+                            if (p) p->leaveTransfer(lane, slot);
                             p = nullptr;
                         }
-                    } leave{pinnedPool.get(), device.lane};
-                    const int readThreads = pinnedPool->readThreads;
+                    } leave{pinnedPool.get(), device.lane, slot};
+                    // One slot's target crosses straight out of the page cache: pieces of the file's mapping are page-locked
+                    // for their copy (2.5 ms per 64 MB, one thread; registration does not scale over threads) while the other
+                    // slot's readers copy theirs into the ring -- two different resources.
+                    size_t mapBytes = 0;
+                    const uint8_t* fileMap = slot == pinnedPool->registerSlot ? bam::BamReader::mapFile(prepData.getSortedBamFilePath(), mapBytes) : nullptr;
+                    const int readThreads = fileMap || pinnedPool->registerSlot < 0 ? pinnedPool->readThreads : pinnedPool->readThreads * 2;
                     // This thread hands the pieces to the device itself (pjb_bam_begin / _piece are safe beside the device
                     // thread's calls): queued behind genome uploads, finishes and record parsing on the device thread the
                     // copies started late and PCIe idled between them.
@@ -795,7 +809,9 @@ void JunctionBuilder::findJuncs(DeviceThread& device, BamReader& reader, GenomeM
                     std::string readError;
                     struct Mine {
                         int64_t ticket;
-                        uint8_t* buf;
+                        uint8_t* buf;  // a ring buffer, or
+                        void* reg;     // a registered range of the file's mapping
+                        size_t regBytes;
                     };
                     std::deque<Mine> mine;  // pieces of this target whose copy may still read the buffer
                     auto releaseDone = [&](bool all) {
@@ -808,7 +824,8 @@ void JunctionBuilder::findJuncs(DeviceThread& device, BamReader& reader, GenomeM
                         }
                         if (all) done = INT64_MAX;
                         while (!mine.empty() && mine.front().ticket <= done) {
-                            pinnedPool->release(mine.front().buf);
+                            if (mine.front().reg) (void)pjb_host_unregister(mine.front().reg);
+                            else pinnedPool->release(mine.front().buf);
                             mine.pop_front();
                         }
                     };
@@ -823,9 +840,37 @@ void JunctionBuilder::findJuncs(DeviceThread& device, BamReader& reader, GenomeM
                         b0.bamSize = nb;
                         device.push(std::move(b0));
                     }
-                    for (size_t off = 0; off < nb && readError.empty(); off += piece) {
-                        const size_t n = std::min(piece, nb - off);
+                    // (with the mapping: pieces end on page boundaries of the FILE, so that no two pieces share a page)
+                    const size_t firstPiece = fileMap ? piece - (size_t)(fileOff & 4095) : piece;
+                    for (size_t off = 0, step = firstPiece; off < nb && readError.empty(); off += step, step = piece) {
+                        const size_t n = std::min(step, nb - off);
                         const double ta0 = HostProfile::now();
+                        if (fileMap && dctx && fileOff + off + n <= mapBytes) {
+                            // [a, e): the pages that hold the piece (the first and the last page of a target may still be locked for
+                            // a neighbouring target's copy: then the piece is read like any other)
+                            const uintptr_t lo = (uintptr_t)(fileMap + fileOff + off), hi = lo + n;
+                            const uintptr_t a = lo & ~(uintptr_t)4095, e = (hi + 4095) & ~(uintptr_t)4095;
+                            while (mine.size() >= 6) {  // (at most six pieces' pages locked at a time)
+                                releaseDone(false);
+                                if (mine.size() >= 6) std::this_thread::sleep_for(std::chrono::microseconds(100));
+                            }
+                            bool sent = false;
+                            if (pjb_host_register((void*)a, (size_t)(e - a)) == PJB_OK) {
+                                int64_t ticket = 0;
+                                if (pjb_bam_piece(dctx, seq, (const uint8_t*)lo, (int64_t)n, &ticket) != PJB_OK) {
+                                    readError = std::string("pjb_bam_piece: ") + pjb_last_error(dctx);
+                                    releaseDone(true);
+                                    (void)pjb_host_unregister((void*)a);
+                                    break;
+                                }
+                                mine.push_back(Mine{ticket, nullptr, (void*)a, (size_t)(e - a)});
+                                g_prof.event(ta0, HostProfile::now(), "worker map piece tid " + std::to_string(seq) + " " + std::to_string(n >> 20) + " MB");
+                                releaseDone(false);
+                                sent = true;
+                            }
+                            if (sent) continue;
+                            // (a piece that cannot be registered -- its first page still locked for a copy in flight -- is read)
+                        }
                         uint8_t* buf = nullptr;
                         if (dctx) {
                             while (!(buf = pinnedPool->tryAcquire(piece))) {  // (this thread's finished copies may be what the ring waits for)
@@ -856,7 +901,7 @@ void JunctionBuilder::findJuncs(DeviceThread& device, BamReader& reader, GenomeM
                                 pinnedPool->release(buf);
                                 break;
                             }
-                            mine.push_back(Mine{ticket, buf});
+                            mine.push_back(Mine{ticket, buf, nullptr, 0});
                             releaseDone(false);
                             continue;
                         }
@@ -1134,6 +1179,7 @@ void JunctionBuilder::findJunctions() {
                 pinnedPool->setTransferSlots(perLane);
                 pinnedPool->readThreads = std::max(1, std::min(2, total / (perLane * (int)deviceThreads.size())));
                 if (const char* e = getenv("PORTCULLIS_READ_THREADS")) pinnedPool->readThreads = std::max(1, atoi(e));  // (threads per target in transfer)
+                if (const char* e = getenv("PORTCULLIS_REGISTER_SLOT")) pinnedPool->registerSlot = atoi(e);
             }
         }
         return *deviceThreads[(size_t)w % deviceThreads.size()];
