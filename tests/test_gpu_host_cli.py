@@ -225,6 +225,18 @@ def test_device_ingest_in_pieces(tmp_path, orc, monkeypatch, piece_bytes, thread
     check(prep, tmp_path, orc, "FR", threads=threads, extra_opts=("--ingest", "device"))
 
 
+@pytest.mark.parametrize("piece_bytes,threads,slot", [(8192, 3, 0), (65536, 4, 1)])
+def test_device_ingest_pieces_of_the_mapping(tmp_path, orc, monkeypatch, piece_bytes, threads, slot):
+    """One transfer slot sends pieces of the file's own mapping, page-locked for their copy (pjb_host_register; the other
+    slot's readers copy theirs into the ring): same outputs byte for byte; pieces whose first page is still locked for a
+    neighbour's copy are read instead."""
+    monkeypatch.setenv("PORTCULLIS_PIECE_BYTES", str(piece_bytes))
+    monkeypatch.setenv("PORTCULLIS_PINNED_BUFFERS", "4")
+    monkeypatch.setenv("PORTCULLIS_REGISTER_SLOT", str(slot))
+    prep = multi_contig(tmp_path, [85, 86, None, 87, 88], block_size=3000)
+    check(prep, tmp_path, orc, "FR", threads=threads, extra_opts=("--ingest", "device"))
+
+
 @pytest.mark.parametrize("ingest", ["device", "host"])
 def test_unmapped_tail(tmp_path, orc, ingest):
     """Thousands of unplaced reads after the last target: the index's last chunk end bounds what is read."""
