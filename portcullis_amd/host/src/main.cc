@@ -3,7 +3,10 @@
 #include <portcullis/bam_filter.hpp>
 #include <portcullis/junction_builder.hpp>
 
+#include <cerrno>
+#include <csignal>
 #include <cstring>
+#include <sys/wait.h>
 #include <unistd.h>
 #include <cstdlib>
 #include <cstdio>
@@ -14,9 +17,56 @@
 #define PORTCULLIS_AMD_VERSION "1.2.4"
 #endif
 
+// The work runs in a child process; this one returns as soon as the child says its outputs are written and closed.
+// Why: a process that held 100 GB of device memory takes the driver 0.02 - 0.25 s to tear down after it has nothing left
+// to do (measured around _exit: `real` minus the program's own last timestamp), and whoever waits for the command waits
+// for that too.  The child is forked before anything touches the GPU; it reports its exit code through a pipe, closes
+// its standard streams and leaves; the tear-down finishes behind the prompt.  PORTCULLIS_NO_FORK=1 (and
+// PJB_NORMAL_EXIT=1, which profilers need): one process, as before.
+static pid_t g_child = -1;
+static void forwardSignal(int sig) {
+    if (g_child > 0) kill(g_child, sig);
+}
+static int g_report_fd = -1;  // (child) where the exit code goes
+
 int main(int argc, char* argv[]) {
     // exit codes as in src/portcullis.cc:497-515 of the reference
     int rc = 0;
+    if (argc >= 2 && !getenv("PORTCULLIS_NO_FORK") && !getenv("PJB_NORMAL_EXIT")) {
+        int fds[2];
+        if (pipe(fds) == 0) {
+            std::cout.flush();
+            std::cerr.flush();
+            const pid_t pid = fork();
+            if (pid > 0) {  // the waiting side
+                close(fds[1]);
+                g_child = pid;
+                signal(SIGINT, forwardSignal);
+                signal(SIGTERM, forwardSignal);
+                unsigned char code = 0;
+                ssize_t got;
+                do got = read(fds[0], &code, 1);
+                while (got < 0 && errno == EINTR);
+                if (got == 1) _exit((int)code);
+                int status = 0;  // the child ended without a word: its status is ours
+                while (waitpid(pid, &status, 0) < 0 && errno == EINTR) {
+                }
+                if (WIFEXITED(status)) _exit(WEXITSTATUS(status));
+                if (WIFSIGNALED(status)) {
+                    signal(WTERMSIG(status), SIG_DFL);
+                    raise(WTERMSIG(status));
+                }
+                _exit(8);
+            }
+            if (pid == 0) {
+                close(fds[0]);
+                g_report_fd = fds[1];
+            } else {  // fork failed: one process
+                close(fds[0]);
+                close(fds[1]);
+            }
+        }
+    }
     // The program keeps ~15 HIP streams busy at once (file pieces, four inflate streams, the service stream, two per queued
     // chain, rows); the runtime maps them onto 4 hardware queues unless told otherwise, and streams that share a queue wait
     // for each other.  8 queues: end to end 2.36 -> 2.18 s median of 7 (profiles/r03o_e2e_hw_queues.txt).  Read by the
@@ -56,5 +106,15 @@ int main(int argc, char* argv[]) {
         fprintf(stderr, "[host profile] leaving main at epoch %.6f\n", (double)ts.tv_sec + ts.tv_nsec * 1e-9);
     }
     if (getenv("PJB_NORMAL_EXIT")) return rc;  // (profilers write their traces from exit handlers)
+    if (g_report_fd >= 0) {  // every output is written and closed: tell the waiting side, let go of its terminal, leave
+        const unsigned char code = (unsigned char)rc;
+        ssize_t w;
+        do w = write(g_report_fd, &code, 1);
+        while (w < 0 && errno == EINTR);
+        close(g_report_fd);
+        close(0);
+        close(1);
+        close(2);
+    }
     _exit(rc);
 }
