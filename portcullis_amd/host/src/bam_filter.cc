@@ -90,12 +90,10 @@ void BamFilter::filter() {
             throw BamFilterException("Could not create output directory at: " + outDir);
     }
     // ---- the filter's junction set, per target, as sorted keys on the device
-    pjb_ctx* ctx = ctxComing.get();
-    struct Closer {
-        pjb_ctx* c;
-        ~Closer() { pjb_destroy(c); }
-    } closer{ctx};
-    {
+    // (the context takes 0.2 s to come up: the junction keys follow it on a thread of their own, and the first piece of the
+    // file is read and inflated meanwhile -- whoever needs the context asks ctxReady)
+    std::shared_future<pjb_ctx*> ctxReady = std::async(std::launch::async, [&js, &ctxComing]() -> pjb_ctx* {
+        pjb_ctx* c1 = ctxComing.get();
         std::map<int32_t, std::vector<uint64_t>> keys;
         for (const JunctionPtr& j : js.getJunctions()) {
             const Intron& in = *j->getIntron();
@@ -104,11 +102,24 @@ void BamFilter::filter() {
         for (auto& kv : keys) {
             std::sort(kv.second.begin(), kv.second.end());
             kv.second.erase(std::unique(kv.second.begin(), kv.second.end()), kv.second.end());
-            if (pjb_filter_set_junctions(ctx, kv.first, kv.second.data(), (int64_t)kv.second.size()) != PJB_OK)
-                throw BamFilterException(std::string("pjb_filter_set_junctions: ") + pjb_last_error(ctx));
+            if (pjb_filter_set_junctions(c1, kv.first, kv.second.data(), (int64_t)kv.second.size()) != PJB_OK) {
+                const std::string msg = std::string("pjb_filter_set_junctions: ") + pjb_last_error(c1);
+                pjb_destroy(c1);
+                throw BamFilterException(msg);
+            }
         }
-    }
-    mark("context created, junction keys uploaded");
+        return c1;
+    }).share();
+    struct Closer {
+        std::shared_future<pjb_ctx*> f;
+        ~Closer() {
+            try {
+                pjb_destroy(f.get());
+            } catch (...) {
+            }
+        }
+    } closer{ctxReady};
+    mark("context and junction keys on their way");
     cout << " - Processing alignments from: " << bamFile << endl;
     // BGZF blocks are compressed on the device (pjb_deflate_bgzf); PORTCULLIS_HOST_DEFLATE=1: by zlib on the workers.
     // The filtered file's blocks go through a context of their own: its writer compresses on a thread of its own while
@@ -142,8 +153,8 @@ void BamFilter::filter() {
     auto deviceDeflate = [deflateCtx, deflateOn](const uint8_t* in, size_t n, size_t block, bam::ByteBuf& out, std::vector<uint32_t>& sizes) -> bool {
         return deflateOn(deflateCtx.get(), in, n, block, out, sizes);
     };
-    auto deviceDeflateHere = [ctx, deflateOn](const uint8_t* in, size_t n, size_t block, bam::ByteBuf& out, std::vector<uint32_t>& sizes) -> bool {
-        return deflateOn(ctx, in, n, block, out, sizes);  // (the two small files of --save_msrs: on this thread, this thread's context)
+    auto deviceDeflateHere = [ctxReady, deflateOn](const uint8_t* in, size_t n, size_t block, bam::ByteBuf& out, std::vector<uint32_t>& sizes) -> bool {
+        return deflateOn(ctxReady.get(), in, n, block, out, sizes);  // (the two small files of --save_msrs: on this thread, this thread's context)
     };
     if (!hostDeflate) {
         writer.setBlockCompressor(deviceDeflate);
@@ -244,6 +255,7 @@ void BamFilter::filter() {
                 pb.pos = pos.data() + a;
                 pb.cig_off = co;
                 pb.cigar = cigar.data() + o0;
+                pjb_ctx* ctx = ctxReady.get();
                 if (pjb_filter_batch(ctx, tids[a], &pb, mode, codes.data() + a) != PJB_OK)
                     throw BamFilterException(std::string("pjb_filter_batch: ") + pjb_last_error(ctx));
             }
