@@ -28,11 +28,17 @@ static void forwardSignal(int sig) {
     if (g_child > 0) kill(g_child, sig);
 }
 static int g_report_fd = -1;  // (child) where the exit code goes
+extern char** environ;
 
 int main(int argc, char* argv[]) {
     // exit codes as in src/portcullis.cc:497-515 of the reference
     int rc = 0;
-    if (argc >= 2 && !getenv("PORTCULLIS_NO_FORK") && !getenv("PJB_NORMAL_EXIT")) {
+    // (not under a profiler or any other preloaded library: it may have started the GPU runtime in this process already, and
+    // a forked child must not inherit that)
+    bool plain = !getenv("LD_PRELOAD") && !getenv("HSA_TOOLS_LIB");
+    for (char** e = environ; plain && e && *e; e++)
+        if (strncmp(*e, "ROCP", 4) == 0 || strncmp(*e, "ROCPROFILER", 11) == 0) plain = false;
+    if (argc >= 2 && plain && !getenv("PORTCULLIS_NO_FORK") && !getenv("PJB_NORMAL_EXIT")) {
         int fds[2];
         if (pipe(fds) == 0) {
             std::cout.flush();
