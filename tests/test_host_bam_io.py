@@ -103,3 +103,59 @@ def test_bulk_route_under_sanitizers(tmp_path, exe, block_size, threads, chunk, 
     p = subprocess.run([exe, dst, again, str(threads), "bulk", str(chunk), "0"], capture_output=True, text=True, timeout=600, env=env)
     assert p.returncode == 0, p.stdout + p.stderr[-3000:]
     assert gzip.open(again, "rb").read() == want
+
+
+@pytest.mark.parametrize("how", ["truncate_mid_block", "truncate_mid_record", "flip_header", "flip_payload", "bad_isize", "index_lies"])
+def test_bulk_route_rejects_damaged_files(tmp_path, exe, how):
+    """Damaged input through the bulk route under the sanitizers: an error (exit code 3, a message), never a crash, a hang
+    or a sanitizer report."""
+    import shutil
+    genome, rr = make_reads(96, n_reads=2000)
+    for k, r in enumerate(rr):
+        r["tid"] = 0
+        r["name"] = f"d{k}"
+    src = str(tmp_path / "in.bam")
+    write_bam(src, [("chr1", len(genome))], rr, block_size=1200)
+    raw = bytearray(open(src, "rb").read())
+    bad = str(tmp_path / "bad.bam")
+    shutil.copy(src + ".bai", bad + ".bai")
+    n = len(raw)
+    if how == "truncate_mid_block":
+        raw = raw[:n // 2 + 7]
+    elif how == "truncate_mid_record":
+        # cut at a block boundary in the middle of the file: the last record of what is left is incomplete
+        o, cut = 0, 0
+        while o < n // 2:
+            cut = o
+            o += (raw[o + 16] | raw[o + 17] << 8) + 1
+        raw = raw[:cut]
+    elif how == "flip_header":
+        o = 0
+        for _ in range(5):
+            o += (raw[o + 16] | raw[o + 17] << 8) + 1
+        raw[o + 1] ^= 0xFF
+    elif how == "flip_payload":
+        o = 0
+        for _ in range(7):
+            o += (raw[o + 16] | raw[o + 17] << 8) + 1
+        raw[o + 30] ^= 0x55
+        raw[o + 31] ^= 0xAA
+    elif how == "bad_isize":
+        o = 0
+        for _ in range(3):
+            o += (raw[o + 16] | raw[o + 17] << 8) + 1
+        size = (raw[o + 16] | raw[o + 17] << 8) + 1
+        raw[o + size - 4] ^= 0x10
+    elif how == "index_lies":
+        bai = bytearray(open(bad + ".bai", "rb").read())
+        for k in range(len(bai) - 16, 40, -8):   # nudge a few virtual offsets off their record starts
+            if bai[k] and k % 24 == 0:
+                bai[k] = (bai[k] + 3) & 0xFF
+        open(bad + ".bai", "wb").write(bai)
+    open(bad, "wb").write(raw)
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=1", UBSAN_OPTIONS="print_stacktrace=1")
+    p = subprocess.run([exe, bad, str(tmp_path / "out.bam"), "3", "bulk", str(1 << 16), "0"], capture_output=True, text=True, timeout=300, env=env)
+    assert "AddressSanitizer" not in p.stderr and "runtime error" not in p.stderr, p.stderr[-3000:]
+    assert p.returncode in (0, 3), (p.returncode, p.stderr[-2000:])
+    if how in ("truncate_mid_block", "flip_header", "bad_isize"):
+        assert p.returncode == 3 and "Error:" in p.stderr
