@@ -144,3 +144,23 @@ def test_structured_fuzz(ctx, seed):
     data = b"".join(parts)[:want]
     block = int(rng.choice([0xff00, 0xff00, 4096, 32768, 1000 * 4]))
     _check(ctx, data, block)
+
+
+def test_bad_arguments_are_refused(ctx):
+    import ctypes as C
+    from portcullis_amd import ffi
+    data = np.frombuffer(b"abcd" * 5000, dtype=np.uint8)
+    out = np.empty(1 << 17, dtype=np.uint8)
+    n = C.c_int64()
+    sizes = np.zeros(8, dtype=np.uint32)
+    L = ctx._L
+    def call(block, cap, nbytes=len(data)):
+        return L.pjb_deflate_bgzf(ctx._h, data.ctypes.data_as(C.c_void_p), nbytes, block, out.ctypes.data_as(C.c_void_p), cap, C.byref(n),
+                                  sizes.ctypes.data_as(C.c_void_p))
+    assert call(0xff00 + 4, 1 << 17) != 0          # larger than a BGZF block may be
+    assert call(1002, 1 << 17) != 0                # not a multiple of 4
+    assert call(0, 1 << 17) != 0
+    assert call(0xff00, 64) != 0                   # the output does not fit
+    assert b"more than" in L.pjb_last_error(ctx._h)
+    assert call(0xff00, 1 << 17) == 0 and n.value > 0
+    assert call(0xff00, 1 << 17, 0) == 0 and n.value == 0   # nothing in, nothing out
