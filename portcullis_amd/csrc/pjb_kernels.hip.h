@@ -912,6 +912,7 @@ __device__ __forceinline__ void ncursor_advance(NCursor &c, const Ops cig, u32 n
 // One spliced read's pairs (JunctionSystem::addJunctions junction_system.cc:140-210) -- everything that follows from
 // the read's fixed-width fields is in R, the CIGAR behind `cig`.  Shape test, walk with the two monotone cursors for
 // the up/down junction counts (junction.cc:795-812), one store per pair field.
+constexpr u32 WALK_HINT = 0x80000000u; // in the low word of a generic pair's `seqw`: the other 31 bits are its N operation's index
 struct EmitRead {
     u32 n;        // CIGAR operations
     int32_t pos;
@@ -958,6 +959,7 @@ __device__ __forceinline__ void emit_read_pairs(const Ops cig, const EmitRead R,
     int32_t lStart = pos, lEndExc = pos, sumAfter = 0, prevRStartU = 0, prevIend = 0;
     int64_t prev = -1;
     u32 k = 0;
+    u32 qsum = 0; // query bases before the operation, soft clips not counted (anchor_side's qPos)
     for (u32 i = 0; i < n; i++) {
         const u32 op = cig[i];
         const u32 ty = op & 15u;
@@ -990,7 +992,9 @@ __device__ __forceinline__ void emit_read_pairs(const Ops cig, const EmitRead R,
             P.meta[idx] = meta;
             P.aend[idx] = aend;
             P.updown[idx] = cntU | ((nN - cntD) << 16);
-            P.seqw[idx] = seq_addr;
+            // (a pair of the generic walk: where its N operation stands in the CIGAR and how many query bases precede it --
+            // k4b_generic starts its walks there instead of at the read's first operation)
+            P.seqw[idx] = (meta & META_SIMPLE) ? seq_addr : (((u64)qsum << 32) | (u64)(i | WALK_HINT));
             if (lStart > istart) set_error(err, g, PJB_ERR_MIN_ANCHOR); // intron.cc:68
             prev = idx;
             prevIend = iend;
@@ -1003,6 +1007,7 @@ __device__ __forceinline__ void emit_read_pairs(const Ops cig, const EmitRead R,
             lEndExc += ln;
             sumAfter += ln;
         }
+        if (op_consumes_query(ty) && ty != OP_S) qsum += (u32)ln;
     }
     if (prev >= 0) {
         int32_t rEndExc = prevRStartU + sumAfter;
@@ -2151,9 +2156,11 @@ __device__ __forceinline__ void cmp_words(const u32 *seqw, int32_t qi, int32_t q
 }
 
 
+// (k0, r0, q0): the operation the walks start at and the reference / query position there -- (0, position, 0), or, from the
+// pair's hint, the first operation that starts inside the window: everything before it the walks only step over
 __device__ Side anchor_side(const OpsView cig, u32 n, int32_t position, int32_t aligned, const uint8_t *seq, int32_t lq,
                             const uint8_t *genome, int32_t glen, bool genome_has_x, const u32 *gcodes, int32_t start,
-                            int32_t end) {
+                            int32_t end, u32 k0, int32_t r0, int32_t q0) {
     Side S;
     S.len = 0;
     S.mism = 0;
@@ -2177,8 +2184,8 @@ __device__ Side anchor_side(const OpsView cig, u32 n, int32_t position, int32_t 
     const u64 avail = (u64)(lq - dS);
     const int32_t clen = (int32_t)(cnt < avail ? cnt : avail);
     // ---- pass A: query walk over ops only -> where it stops (actual_start / actual_end)
-    int32_t rPos = position, qPos = 0;
-    for (u32 k = 0; k < n; k++) {
+    int32_t rPos = r0, qPos = q0;
+    for (u32 k = k0; k < n; k++) {
         const u32 op = cig[k], ty = op & 15u;
         const int32_t ln = (int32_t)(op >> 4);
         const bool cRef = op_consumes_ref(ty);
@@ -2211,11 +2218,11 @@ __device__ Side anchor_side(const OpsView cig, u32 n, int32_t position, int32_t 
     }
     const int32_t gsize = end - start + 1; // length of the fetched anchor string
     // ---- pass B: both walks in lock-step, comparing emissions
-    rPos = position;
-    qPos = 0;
+    rPos = r0;
+    qPos = q0;
     bool qDone = false, gDone = false, diverged = false;
     int32_t qTot = 0, gTot = 0, mism = 0, first_mis = -1, last_mis = -1;
-    for (u32 k = 0; k < n; k++) {
+    for (u32 k = k0; k < n; k++) {
         const u32 op = cig[k], ty = op & 15u;
         const int32_t ln = (int32_t)(op >> 4);
         const bool cRef = op_consumes_ref(ty);
@@ -2310,18 +2317,46 @@ __device__ Side anchor_side(const OpsView cig, u32 n, int32_t position, int32_t 
 // per-pair match statistics through the generic lock-step walks (any CIGAR)
 __device__ __forceinline__ u64 pair_stats_generic(const OpsView cig, u32 nc, int32_t pos, int32_t aligned, const uint8_t *seq,
                                                   int32_t lq, const uint8_t *genome, int32_t glen, bool has_x, const u32 *gcodes,
-                                                  int32_t left, int32_t istart, int32_t iend, int32_t right, u32 g, u64 *err) {
+                                                  int32_t left, int32_t istart, int32_t iend, int32_t right, u32 g, u64 *err, u64 hint) {
     if (lq <= 1) { // junction.cc:168-185
         const u32 totUp = (u32)((istart - 1) - left + 1);
         const u32 totDown = (u32)(right - (iend + 1) + 1);
         return pack_res(0, totUp < totDown ? totUp : totDown, 0);
     }
-    const Side L = anchor_side(cig, nc, pos, aligned, seq, lq, genome, glen, has_x, gcodes, left, istart - 1);
+    // Where the walks start.  Without a hint: at the read's first operation.  With it: the left side walks BACK from the pair's
+    // N operation (which starts at istart, qN query bases into the read) to the first operation that starts inside the window
+    // -- an operation that starts before the window is stepped over whole by the walks, and so is everything before it --, the
+    // right side starts at the operation behind the N.  (A read of 95 operations and 15 introns walked all 95 four times per pair.)
+    u32 kL = 0, kR = 0;
+    int32_t rL = pos, qL = 0, rR = pos, qR = 0;
+    const u32 opi = (u32)hint & ~WALK_HINT;
+    if (((u32)hint & WALK_HINT) && opi < nc && (cig[opi] & 15u) == OP_N) {
+        const int32_t qN = (int32_t)(hint >> 32);
+        kL = opi;
+        rL = istart;
+        qL = qN;
+        while (kL > 0) {
+            const u32 op = cig[kL - 1], ty = op & 15u;
+            const int32_t ln = (int32_t)(op >> 4);
+            const int32_t rp = rL - (op_consumes_ref(ty) ? ln : 0);
+            if (rp < left) break; // (it starts before the window: stepped over, like all before it)
+            kL--;
+            rL = rp;
+            if (op_consumes_query(ty) && ty != OP_S) qL -= ln;
+        }
+        const int32_t after = istart + (int32_t)(cig[opi] >> 4); // the walks' position behind the N (iend + 1 unless it was clamped)
+        if (after == iend + 1) {
+            kR = opi + 1;
+            rR = after;
+            qR = qN;
+        }
+    }
+    const Side L = anchor_side(cig, nc, pos, aligned, seq, lq, genome, glen, has_x, gcodes, left, istart - 1, kL, rL, qL);
     if (L.err) {
         set_error(err, g, L.err);
         return 0;
     }
-    const Side R = anchor_side(cig, nc, pos, aligned, seq, lq, genome, glen, has_x, gcodes, iend + 1, right);
+    const Side R = anchor_side(cig, nc, pos, aligned, seq, lq, genome, glen, has_x, gcodes, iend + 1, right, kR, rR, qR);
     if (R.err) {
         set_error(err, g, R.err);
         return 0;
@@ -2429,7 +2464,8 @@ __global__ __launch_bounds__(256) void k4b_generic(const u32 *list, const u32 *n
     }
     const uint8_t *seq = b.seq4 + (size_t)so0 * 4;
     res[p] = pair_stats_generic(cig, nc, pos, aend - vpos + 1, seq, lq, M.d, M.len, genome_has_x != 0, use_codes ? M.codes : (const u32 *)nullptr,
-                                anc_l[j] - M.voff, istart - M.voff, iend - M.voff, anc_r[j] - M.voff, g, err);
+                                anc_l[j] - M.voff, istart - M.voff, iend - M.voff, anc_r[j] - M.voff, g, err,
+                                (P.meta[p] & META_SIMPLE) ? 0ull : P.seqw[p]); // (a simple pair sent here -- exotic genomes -- carries an address there)
 }
 
 // fragment record: 48 words
