@@ -1226,8 +1226,11 @@ static int extra_pre(pjb_ctx *c, Flight &f) {
         return rc;
     for (auto &b : f.batches)
         if (b.n > 0)
-            LAUNCH(c, "kx_gaps", kx_gaps, dim3((unsigned)((((u64)b.base + (u64)b.n + 255) >> 8) - (b.base >> 8))), dim3(256), b, (const uint8_t *)q, (u32)N,
-                   (const u32 *)S.x_gapoff.p, f.x_gaps, f.x_gap_cap, d_cnt);
+        {
+            const u32 nblk = (u32)((((u64)b.base + (u64)b.n + 255) >> 8) - (b.base >> 8));
+            LAUNCH(c, "kx_gaps", kx_gaps, dim3(std::min<u32>(nblk, 2048)), dim3(256), b, (const uint8_t *)q, (u32)N, (const u32 *)S.x_gapoff.p, f.x_gaps,
+                   f.x_gap_cap, d_cnt, nblk);
+        }
     if (N >= PLP_MAXCNT)
         LAUNCH(c, "kx_cap_check", kx_cap_check, dim3((unsigned)((N + 255) / 256)), dim3(256), (const int32_t *)f.x_spos, d_cnt);
     f.x_pre = true;

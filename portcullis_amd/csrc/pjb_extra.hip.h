@@ -415,31 +415,35 @@ struct SparseSink { // the records with a span, compacted in rank order; gaps be
 };
 // the gaps (D operations) of the unspliced records in record order: a block per 256 records (global ordinals, so that
 // gapoff[block] is the block's first entry), an exclusive scan of the records' gap counts inside the block
-__global__ __launch_bounds__(256) void kx_gaps(DevBatch b, const uint8_t *q, u32 n_total, const u32 *gapoff, Gap *gaps, u32 gap_cap, SparseCounters *cnt) {
+__global__ __launch_bounds__(256) void kx_gaps(DevBatch b, const uint8_t *q, u32 n_total, const u32 *gapoff, Gap *gaps, u32 gap_cap, SparseCounters *cnt,
+                                                u32 n_blocks) {
     __shared__ u32 wsum[4];
-    if ((cnt->total >> 32) == 0) return; // (no gap in the whole target: the usual case for short reads)
+    if ((cnt->total >> 32) == 0) return; // (no gap in the whole target: the usual case for short reads; the grid is small for that)
     const u32 first_block = b.base >> 8;
-    const u64 g = ((u64)(first_block + blockIdx.x) << 8) + threadIdx.x; // global record ordinal
-    const u32 ngap = g < n_total ? (u32)(q[g] >> 1) : 0u;
-    const u32 inc = wave_iscan(ngap);
-    const int w = threadIdx.x >> 6;
-    if (lane_id() == 63) wsum[w] = inc;
-    __syncthreads();
-    u32 before = gapoff[first_block + blockIdx.x] + inc - ngap;
-    for (int k = 0; k < w; k++) before += wsum[k];
-    if (!ngap || g < b.base || g >= (u64)b.base + (u64)b.n) return; // (a neighbouring batch's record: it only counts)
-    if (before + ngap > gap_cap) {
-        atomicOr(&cnt->need_dense, 4u);
-        return;
-    }
-    const u32 r = (u32)g - b.base;
-    int32_t x = b.pos[r];
-    u32 k_out = 0;
-    for (u32 k = b.cig_off[r]; k < b.cig_off[r + 1] && k_out < ngap; k++) {
-        const u32 op = b.cigar[k], ty = op & 15u;
-        const int32_t ln = (int32_t)(op >> 4);
-        if (ty == 2u && ln) gaps[before + k_out++] = Gap{x, x + ln};
-        if (op_consumes_ref(ty)) x += ln;
+    for (u32 blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) { // (uniform per block: the barriers are safe)
+        const u64 g = ((u64)(first_block + blk) << 8) + threadIdx.x; // global record ordinal
+        const u32 ngap = g < n_total ? (u32)(q[g] >> 1) : 0u;
+        const u32 inc = wave_iscan(ngap);
+        const int w = threadIdx.x >> 6;
+        __syncthreads();
+        if (lane_id() == 63) wsum[w] = inc;
+        __syncthreads();
+        u32 before = gapoff[first_block + blk] + inc - ngap;
+        for (int k = 0; k < w; k++) before += wsum[k];
+        if (!ngap || g < b.base || g >= (u64)b.base + (u64)b.n) continue; // (a neighbouring batch's record: it only counts)
+        if (before + ngap > gap_cap) {
+            atomicOr(&cnt->need_dense, 4u);
+            continue;
+        }
+        const u32 r = (u32)g - b.base;
+        int32_t x = b.pos[r];
+        u32 k_out = 0;
+        for (u32 k = b.cig_off[r]; k < b.cig_off[r + 1] && k_out < ngap; k++) {
+            const u32 op = b.cigar[k], ty = op & 15u;
+            const int32_t ln = (int32_t)(op >> 4);
+            if (ty == 2u && ln) gaps[before + k_out++] = Gap{x, x + ln};
+            if (op_consumes_ref(ty)) x += ln;
+        }
     }
 }
 
@@ -645,10 +649,12 @@ __global__ __launch_bounds__(256) void kx_name_sum(const u64 *pair_code, const u
     u32 h[4], row[4], c[4];
     NameSlot sl[4];
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const u32 i = base + 64 * k;
-        key[k] = i < n ? name_slot_key(pair_code[i]) : 0ull;
-        row[k] = i < n ? pair_row[i] : 0xffffffffu;
+    for (int k = 0; k < 4; k++) { // (unconditional loads from a clamped index, masked after: they travel together)
+        const u32 i = base + 64 * k, ic = i < n ? i : n - 1;
+        const u64 code = pair_code[ic];
+        const u32 rw = pair_row[ic];
+        key[k] = i < n ? name_slot_key(code) : 0ull;
+        row[k] = i < n ? rw : 0xffffffffu;
         h[k] = name_slot_of(key[k], slots);
     }
 #pragma unroll
@@ -680,7 +686,8 @@ __global__ __launch_bounds__(256) void kx_name_insert4(const u64 *codes, u32 n, 
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const u32 i = base + 64 * k;
-        key[k] = i < n ? name_slot_key(codes[i]) : 0ull;
+        const u64 code = codes[i < n ? i : n - 1];
+        key[k] = i < n ? name_slot_key(code) : 0ull;
         h[k] = name_slot_of(key[k], slots);
     }
 #pragma unroll
