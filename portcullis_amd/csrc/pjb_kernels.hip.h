@@ -744,11 +744,13 @@ __global__ __launch_bounds__(K1S_THREADS) void k1_scan_tiles(u32 *tile_cnt, cons
         const u32 i0 = base + K1S_PER * threadIdx.x;
         u64 vs = 0;
         u32 vs2 = 0;
-        for (int q = 0; q < K1S_PER; q++) {
-            const u32 i = i0 + q;
+#pragma unroll 4
+        for (int q = 0; q < K1S_PER; q++) { // (loads from a clamped index, masked after: they travel together, see k1_count)
+            const u32 i = i0 + q, ic = i < n_tiles ? i : n_tiles - 1;
+            const u64 cnt = tile_desc ? (tile_desc[ic] & ((1ull << 40) - 1)) : (u64)tile_cnt[ic];
+            const TileStats t = ts[ic];
             if (i < n_tiles) {
-                vs += tile_desc ? (tile_desc[i] & ((1ull << 40) - 1)) : (u64)tile_cnt[i];
-                const TileStats t = ts[i];
+                vs += cnt;
                 vs2 += t.spliced;
                 spl += t.spliced;
                 uns += t.unspliced;
