@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--threads", type=int, default=16)
     ap.add_argument("--runs", type=int, default=3)
     ap.add_argument("--workdir", default="/tmp/pjb_bamfilt")
+    ap.add_argument("--exe", default=os.path.join(ROOT, "portcullis_amd", "host", "portcullis_amd"), help="the program to time")
     ap.add_argument("--env", action="append", default=[], help="NAME=VALUE for the program (repeatable)")
     args = ap.parse_args()
     wd = args.workdir
@@ -41,7 +42,7 @@ def main():
     kept = [l for k, l in enumerate(body) if k % 3 != 1]
     passed = os.path.join(wd, "pass.junctions.tab")
     open(passed, "w").write("\n".join([lines[0]] + kept) + "\n\n")
-    exe = os.path.join(ROOT, "portcullis_amd", "host", "portcullis_amd")
+    exe = args.exe
     out = os.path.join(wd, "filt", "filtered.bam")
     env = dict(os.environ)
     for kv in args.env:

@@ -77,7 +77,9 @@ int main(int argc, char **argv) {
         (void)hipStreamDestroy(s);
         fflush(stdout);
     }
-    for (int mode = 0; mode < 3; mode++) {
+    for (int mode = 0; mode < 5; mode++) {
+        if (mode == 1 || mode == 2) continue; // (measured before: profiles/r03ap_register_probe.txt)
+        // 3: memcpy out of the mapping into page-locked buffers + copy; 4: the same with MADV_SEQUENTIAL + MADV_WILLNEED first
         // 0: pread into page-locked buffers + copy; 1: register the mapping's pieces + copy + unregister; 2: copy from the pageable mapping
         std::atomic<size_t> next(0);
         std::atomic<int> bad(0);
@@ -91,7 +93,7 @@ int main(int argc, char **argv) {
                 hipStream_t s;
                 (void)hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
                 void *pin = nullptr;
-                if (mode == 0 && hipHostMalloc(&pin, piece, hipHostMallocDefault) != hipSuccess) bad = 1;
+                if ((mode == 0 || mode >= 3) && hipHostMalloc(&pin, piece, hipHostMallocDefault) != hipSuccess) bad = 1;
                 for (;;) {
                     const size_t k = next.fetch_add(1);
                     if (k >= np || bad) break;
@@ -103,6 +105,11 @@ int main(int argc, char **argv) {
                             if (r <= 0) { bad = 1; break; }
                             got += (size_t)r;
                         }
+                        (void)hipMemcpyAsync((char *)dev + k * piece, pin, piece, hipMemcpyHostToDevice, s);
+                        (void)hipStreamSynchronize(s);
+                    } else if (mode >= 3) {
+                        if (mode == 4) madvise(src, piece, MADV_WILLNEED);
+                        memcpy(pin, src, piece);
                         (void)hipMemcpyAsync((char *)dev + k * piece, pin, piece, hipMemcpyHostToDevice, s);
                         (void)hipStreamSynchronize(s);
                     } else if (mode == 1) {
@@ -123,7 +130,8 @@ int main(int argc, char **argv) {
         for (auto &x : th) x.join();
         const double dt = now() - t0;
         for (double r : regs) t_reg += r;
-        const char *names[] = {"pread into page-locked buffers + copy", "hipHostRegister(mapping) + copy + unregister", "copy from the pageable mapping"};
+        const char *names[] = {"pread into page-locked buffers + copy", "hipHostRegister(mapping) + copy + unregister", "copy from the pageable mapping",
+                               "memcpy from the mapping into page-locked buffers + copy", "the same after MADV_WILLNEED"};
         printf("%-48s %2d threads: %6.1f GB/s%s", names[mode], T, total / dt / 1e9, bad ? "  (FAILED)" : "");
         if (mode == 1) printf("   (register: %.1f ms per 64 MB piece)", t_reg / np * 1e3);
         printf("\n");
