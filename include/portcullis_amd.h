@@ -106,6 +106,9 @@ typedef struct pjb_config {
  * the flanking alignment counts of its junctions and keeps the name codes of its spliced records; pjb_extra_finish
  * then yields mm_score / coverage / up_aln / down_aln for every row.  Batches must carry name_hash. */
 #define PJB_FLAG_EXTRA 2u
+/* a context that will not queue kernel chains (bamfilt: pjb_filter_batch, pjb_deflate_bgzf only): pjb_create leaves the chain
+ * slots' streams and events (60 ms) to their first use */
+#define PJB_FLAG_NO_CHAINS 4u
 
 /* One batch of fixed-width alignment records of ONE contig, in BAM file order
  * (structure of arrays; BAM-native encodings):

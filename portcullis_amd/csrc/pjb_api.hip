@@ -143,6 +143,8 @@ struct CtlSlot {
     // what the first kernels of a contig (k1_count, k1_scan_tiles, k1_emit: the front stream) write and the rest of its
     // chain reads: the next contig's first kernels run beside this contig's last ones
     Buf tile_cnt, tile_stats, splidx, splpoff, tile_soff, chunk_tile;
+    Buf scan_parts;     // k1_scan_tiles: ScanPart[K1S_BLOCKS], zeroed once; scan_epoch tells one launch's parts from the last one's
+    u32 scan_epoch = 0;
     Buf k1look; // k1_walk: ticket counter, tile and group descriptors
     Buf members; // groups: MemberStats[GROUP_MAX] | member_junc u32[GROUP_MAX] | tile_lo u32[GROUP_MAX + 1]
     Buf okey, g, lstart, rend, pos, aend, meta, updown, seqw; // the pairs (BAM order)
@@ -648,8 +650,14 @@ int pjb_create(pjb_ctx **out, const pjb_config *cfg) {
         return fail(nullptr, PJB_ERR_ARG, "pjb_create: ABI version %d, library is %d", cfg->abi_version, PJB_ABI_VERSION);
     if (cfg->orientation < PJB_OR_SE || cfg->orientation > PJB_OR_UNKNOWN)
         return fail(nullptr, PJB_ERR_ARG, "pjb_create: bad orientation %d", cfg->orientation);
+    const bool ctrace = getenv("PJB_CREATE_TRACE") != nullptr; // (stderr: what the context's start is made of)
+    const auto ct0 = std::chrono::steady_clock::now();
+    auto cmark = [&](const char *what) {
+        if (ctrace) fprintf(stderr, "[pjb_create] %7.1f ms: %s\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ct0).count(), what);
+    };
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
+    cmark("hipGetDeviceCount");
     if (e != hipSuccess || n <= 0)
         return fail(nullptr, PJB_ERR_NO_DEVICE,
                     "no HIP device available (%s); the junc hot path has no CPU fallback",
@@ -661,6 +669,7 @@ int pjb_create(pjb_ctx **out, const pjb_config *cfg) {
     hipDeviceProp_t prop;
     e = hipGetDeviceProperties(&prop, cfg->device);
     if (e != hipSuccess) return fail(nullptr, PJB_ERR_HIP, "hipGetDeviceProperties: %s", hipGetErrorString(e));
+    cmark("hipSetDevice, hipGetDeviceProperties");
     const int n_cu = prop.multiProcessorCount;
     if (prop.warpSize != 64)
         return fail(nullptr, PJB_ERR_NO_DEVICE, "device %d (%s) is not a wave64 CDNA device", cfg->device, prop.gcnArchName);
@@ -682,7 +691,10 @@ int pjb_create(pjb_ctx **out, const pjb_config *cfg) {
     // (the runtime creates a hardware queue behind whatever the device is doing): a caller that wants more than four chains in
     // flight on a busy device queues that deep once, early.
     // (60 ms for four slots' streams and events; from four threads at once it is 70 - 100 ms: the runtime serialises them)
-    for (int k = 0; k < 4 && k < PJB_MAX_QUEUED; k++) (void)slot_init(c, k);
+    cmark("main streams");
+    if (!(cfg->flags & PJB_FLAG_NO_CHAINS))
+        for (int k = 0; k < 4 && k < PJB_MAX_QUEUED; k++) (void)slot_init(c, k);
+    cmark("chain slots");
     if (const char *s = getenv("PJB_INFLATE_V1")) c->inflate_v1 = atoi(s) != 0;
     const int inf_lds = c->inflate_v1 ? I2_LDS_BYTES : I3_LDS_BYTES;
     c->inflate_lanes = std::max(1, n_cu) * (160 * 1024 / inf_lds) * 64;
@@ -702,6 +714,7 @@ int pjb_create(pjb_ctx **out, const pjb_config *cfg) {
     // 12-bit digits need more dynamic LDS than the 64 KB a kernel gets without asking
     (void)hipFuncSetAttribute((const void *)rs_scatter<0>, hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)rs_scatter_lds_bytes(RS_MAX_BITS));
+    cmark("kernel attributes");
     *out = c;
     return PJB_OK;
 }
@@ -733,7 +746,7 @@ void pjb_destroy(pjb_ctx *c) {
             if (ev) (void)hipEventDestroy(ev);
         if (S.ev_rows) (void)hipEventDestroy(S.ev_rows);
         if (S.ev_done) (void)hipEventDestroy(S.ev_done);
-        Buf *sb[] = {&S.x_q, &S.x_spos, &S.x_send, &S.x_gapoff, &S.x_zlist, &S.x_scnt, &S.x_codes, &S.cstats, &S.err, &S.gencount, &S.batches, &S.rows, &S.tile_cnt, &S.tile_stats, &S.splidx, &S.splpoff, &S.tile_soff, &S.chunk_tile, &S.k1look, &S.members, &S.okey, &S.g,
+        Buf *sb[] = {&S.x_q, &S.x_spos, &S.x_send, &S.x_gapoff, &S.x_zlist, &S.x_scnt, &S.x_codes, &S.cstats, &S.err, &S.gencount, &S.batches, &S.rows, &S.tile_cnt, &S.tile_stats, &S.splidx, &S.splpoff, &S.tile_soff, &S.chunk_tile, &S.scan_parts, &S.k1look, &S.members, &S.okey, &S.g,
                      &S.lstart, &S.rend, &S.pos, &S.aend, &S.meta, &S.updown, &S.seqw, &S.res, &S.total, &S.bitmap, &S.wrank, &S.ends, &S.firstid,
                      &S.key[0], &S.key[1], &S.idx[0], &S.idx[1], &S.hist, &S.hist_scan, &S.hist_part, &S.bintotal, &S.scan_tiles, &S.jid, &S.seg, &S.runfirst,
                      &S.runstart, &S.ent, &S.entsum, &S.frag, &S.fragj, &S.fragl, &S.fragr, &S.acc, &S.ancl, &S.ancr, &S.genlist};
@@ -1387,6 +1400,11 @@ static int queue_contig(pjb_ctx *c, Flight &f) {
     }
     memcpy(S.batches_pinned, batches.data(), batches.size() * sizeof(DevBatch));
     if ((rc = ensure(c, S.cstats, sizeof(ContigStats)))) return rc;
+    if (!S.scan_parts.p) {
+        if ((rc = ensure(c, S.scan_parts, sizeof(ScanPart) * K1S_BLOCKS))) return rc;
+        HIP_TRY(c, hipMemset(S.scan_parts.p, 0, sizeof(ScanPart) * K1S_BLOCKS)); // (once per slot)
+        HIP_TRY(c, hipStreamSynchronize(nullptr));
+    }
     if ((rc = ensure(c, S.err, 8))) return rc;
     if ((rc = ensure(c, c->b_cursor, sizeof(RowCursor)))) return rc;
     if ((rc = ensure(c, S.tile_cnt, (size_t)n_tiles * 4))) return rc;
@@ -1522,8 +1540,8 @@ static int queue_contig(pjb_ctx *c, Flight &f) {
             LAUNCH(c, "k1_walk", k1_walk, dim3(nt), dim3(K1W_THREADS), b, lk, n_tiles, (TileStats *)S.tile_stats.p,
                    want_splidx ? (u32 *)S.splidx.p : (u32 *)nullptr, pr, kf, ref_len, f.tid, (int)c->cfg.orientation, PL, d_err);
         }
-        LAUNCH(c, "k1_scan_tiles", k1_scan_tiles, dim3(1), dim3(K1S_THREADS), (u32 *)nullptr, (const TileStats *)S.tile_stats.p, n_tiles, d_cs, PL, kf,
-               ref_len, (const u64 *)lk.tile_desc, (u32 *)nullptr, (u32 *)nullptr);
+        LAUNCH(c, "k1_scan_tiles", k1_scan_tiles, dim3(k1s_blocks(n_tiles)), dim3(K1S_THREADS), (u32 *)nullptr, (const TileStats *)S.tile_stats.p, n_tiles,
+               d_cs, PL, kf, ref_len, (const u64 *)lk.tile_desc, (u32 *)nullptr, (u32 *)nullptr, (ScanPart *)S.scan_parts.p, ++S.scan_epoch);
     } else {
         // ---- K1a: count (a group's members: a tile whose alignments leave the member's own sequence is flagged); with
         // PJB_FLAG_EXTRA the first time also what the records span (a chain that is queued again leaves that alone: the
@@ -1557,8 +1575,9 @@ static int queue_contig(pjb_ctx *c, Flight &f) {
         if (group)
             LAUNCH(c, "kg_member_stats", kg_member_stats, dim3((unsigned)n_members), dim3(256), (const u32 *)S.tile_cnt.p, (const TileStats *)S.tile_stats.p,
                    (const u32 *)d_tile_lo, n_members, d_members);
-        LAUNCH(c, "k1_scan_tiles", k1_scan_tiles, dim3(1), dim3(K1S_THREADS), (u32 *)S.tile_cnt.p, (const TileStats *)S.tile_stats.p, n_tiles, d_cs,
-               PL, kf, group ? INT32_MAX - 1 : ref_len, (const u64 *)nullptr, (u32 *)S.tile_soff.p, (u32 *)S.chunk_tile.p);
+        LAUNCH(c, "k1_scan_tiles", k1_scan_tiles, dim3(k1s_blocks(n_tiles)), dim3(K1S_THREADS), (u32 *)S.tile_cnt.p, (const TileStats *)S.tile_stats.p,
+               n_tiles, d_cs, PL, kf, group ? INT32_MAX - 1 : ref_len, (const u64 *)nullptr, (u32 *)S.tile_soff.p, (u32 *)S.chunk_tile.p,
+               (ScanPart *)S.scan_parts.p, ++S.scan_epoch);
         // ---- K1b: emit (coordinates in the group's virtual sequence)
         for (size_t bi = 0; bi < batches.size(); bi++) {
             const DevBatch &b = batches[bi];

@@ -715,43 +715,59 @@ __global__ __launch_bounds__(256) void k1_count(DevBatch b, u32 *tile_cnt, TileS
     }
 }
 
-// single block: exclusive scan of per-tile pair counts (in place) + reduction of tile stats
+// exclusive scan of per-tile pair counts (in place) + reduction of tile stats
 // (tile_desc != nullptr: the tiles of k1_walk placed their pairs themselves -- only the total is taken, from their
 // descriptors, and nothing is written back)
 // tile_soff / chunk_tile (both may be nullptr): the tiles' spliced reads seen as ONE dense list -- tile_soff[t] = spliced reads
 // before tile t (n_tiles + 1 entries), chunk_tile[c] = the tile that holds list entry 256 c -- for k1_emit's dense mapping.
-// (One block of 256 threads, 16 tiles per thread and round.  It was one block of 1024: a workgroup of 16 wavefronts needs 16
-// free wave slots on ONE CU at once, and beside the inflate and other chains' kernels in the end-to-end run it waited for
-// them -- 4 ms per target instead of 60 us.)
-constexpr int K1S_THREADS = 256, K1S_PER = 16;
+// A FEW blocks of 256 threads (at most K1S_BLOCKS), each over a contiguous range of tiles: a block first sums its range and
+// publishes the sums (ScanPart, flag = this launch's epoch: nothing to reset between launches), then adds up what the blocks
+// before it published -- one lane per predecessor, all of them produced at the same time: no chain -- and scans its range
+// from there; the last block reduces the statistics and writes the ContigStats.  (Workgroups start in the order of their
+// index: a block only ever waits for blocks that started before it.)  It was ONE block: 28 k tiles of a chain of configs[2] in
+// seven rounds of dependent loads, 100 us alone and 310 us beside the other chains' kernels, on every chain's critical path.
+// (And one block of 1024 before that: a workgroup of 16 wavefronts needs 16 free wave slots on ONE CU at once, and beside
+// the inflate and other chains' kernels in the end-to-end run it waited for them -- 4 ms per target instead of 60 us.)
+constexpr int K1S_THREADS = 256, K1S_PER = 16, K1S_BLOCKS = 64;
+struct ScanPart { // what one block of k1_scan_tiles found in its range of tiles
+    u64 pairs, spl, uns, sum;
+    int32_t mn, mx, max_end, max_nlen, min_pos;
+    u32 flag; // == the launch's epoch: the part is complete
+    u32 _pad[2];
+};
+static_assert(sizeof(ScanPart) == 64, "ScanPart layout");
+__host__ __device__ inline u32 k1s_blocks(u32 n_tiles) { // ~1024 tiles a block
+    const u32 g = (n_tiles + 1023u) / 1024u;
+    return g < 1u ? 1u : (g > (u32)K1S_BLOCKS ? (u32)K1S_BLOCKS : g);
+}
 __global__ __launch_bounds__(K1S_THREADS) void k1_scan_tiles(u32 *tile_cnt, const TileStats *ts, u32 n_tiles, ContigStats *out, u32 pair_limit,
-                                                              KeyFmt kf, int32_t ref_len, const u64 *tile_desc, u32 *tile_soff, u32 *chunk_tile) {
+                                                              KeyFmt kf, int32_t ref_len, const u64 *tile_desc, u32 *tile_soff, u32 *chunk_tile,
+                                                              ScanPart *parts, u32 epoch) {
     constexpr int NW = K1S_THREADS / 64;
     __shared__ u64 wsum[NW];
     __shared__ u32 wsum2[NW];
     __shared__ u32 carry2_s;
     __shared__ u64 carry_s;
-    __shared__ u64 r_spl[NW], r_uns[NW], r_sum[NW];
+    __shared__ u64 r_pairs[NW], r_spl[NW], r_uns[NW], r_sum[NW];
     __shared__ int32_t r_i[NW][5];
-    if (threadIdx.x == 0) {
-        carry2_s = 0;
-        carry_s = 0;
-    }
-    __syncthreads();
-    u64 spl = 0, uns = 0, sum = 0;
+    __shared__ ScanPart total_s; // (last block: everything before it)
+    const u32 nblk = gridDim.x, blk = blockIdx.x;
+    // the block's range: whole rounds of 16 tiles per thread so that ranges start at multiples of 16
+    const u32 per_blk = ((n_tiles + nblk - 1) / nblk + (u32)K1S_PER - 1) / (u32)K1S_PER * (u32)K1S_PER;
+    const u32 lo = min(n_tiles, blk * per_blk), hi = min(n_tiles, lo + per_blk);
+    const int w = threadIdx.x >> 6;
+    // ---- pass A: the range's sums
+    u64 pairs = 0, spl = 0, uns = 0, sum = 0;
     int32_t mn = INT32_MAX, mx = 0, max_end = 0, max_nlen = 0, min_pos = INT32_MAX;
-    for (u32 base = 0; base < n_tiles; base += K1S_THREADS * K1S_PER) {
+    for (u32 base = lo; base < hi; base += K1S_THREADS * K1S_PER) {
         const u32 i0 = base + K1S_PER * threadIdx.x;
-        u64 vs = 0;
-        u32 vs2 = 0;
 #pragma unroll 4
         for (int q = 0; q < K1S_PER; q++) { // (loads from a clamped index, masked after: they travel together, see k1_count)
-            const u32 i = i0 + q, ic = i < n_tiles ? i : n_tiles - 1;
+            const u32 i = i0 + q, ic = i < hi ? i : hi - 1;
             const u64 cnt = tile_desc ? (tile_desc[ic] & ((1ull << 40) - 1)) : (u64)tile_cnt[ic];
             const TileStats t = ts[ic];
-            if (i < n_tiles) {
-                vs += cnt;
-                vs2 += t.spliced;
+            if (i < hi) {
+                pairs += cnt;
                 spl += t.spliced;
                 uns += t.unspliced;
                 sum += t.sum_len;
@@ -762,9 +778,113 @@ __global__ __launch_bounds__(K1S_THREADS) void k1_scan_tiles(u32 *tile_cnt, cons
                 min_pos = min(min_pos, t.min_pos);
             }
         }
+    }
+    pairs = wave_sum(pairs);
+    spl = wave_sum(spl);
+    uns = wave_sum(uns);
+    sum = wave_sum(sum);
+    mn = wave_min(mn);
+    mx = wave_max(mx);
+    max_end = wave_max(max_end);
+    max_nlen = wave_max(max_nlen);
+    min_pos = wave_min(min_pos);
+    if (lane_id() == 0) {
+        r_pairs[w] = pairs;
+        r_spl[w] = spl;
+        r_uns[w] = uns;
+        r_sum[w] = sum;
+        r_i[w][0] = mn;
+        r_i[w][1] = mx;
+        r_i[w][2] = max_end;
+        r_i[w][3] = max_nlen;
+        r_i[w][4] = min_pos;
+    }
+    __syncthreads();
+    ScanPart mine;
+    mine.pairs = mine.spl = mine.uns = mine.sum = 0;
+    mine.mn = INT32_MAX, mine.mx = 0, mine.max_end = 0, mine.max_nlen = 0, mine.min_pos = INT32_MAX;
+    for (int k = 0; k < NW; k++) {
+        mine.pairs += r_pairs[k];
+        mine.spl += r_spl[k];
+        mine.uns += r_uns[k];
+        mine.sum += r_sum[k];
+        mine.mn = min(mine.mn, r_i[k][0]);
+        mine.mx = max(mine.mx, r_i[k][1]);
+        mine.max_end = max(mine.max_end, r_i[k][2]);
+        mine.max_nlen = max(mine.max_nlen, r_i[k][3]);
+        mine.min_pos = min(mine.min_pos, r_i[k][4]);
+    }
+    if (threadIdx.x == 0 && blk + 1 < nblk) { // (nobody reads the last block's part)
+        ScanPart *o = parts + blk;
+        o->pairs = mine.pairs;
+        o->spl = mine.spl;
+        o->uns = mine.uns;
+        o->sum = mine.sum;
+        o->mn = mine.mn;
+        o->mx = mine.mx;
+        o->max_end = mine.max_end;
+        o->max_nlen = mine.max_nlen;
+        o->min_pos = mine.min_pos;
+        __hip_atomic_store(&o->flag, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // ---- what the blocks before this one hold: lane k of the first wavefront waits for block k
+    if (w == 0) {
+        const u32 l = lane_id();
+        ScanPart b;
+        b.pairs = b.spl = b.uns = b.sum = 0;
+        b.mn = INT32_MAX, b.mx = 0, b.max_end = 0, b.max_nlen = 0, b.min_pos = INT32_MAX;
+        if (l < blk) {
+            const ScanPart *o = parts + l;
+            while (__hip_atomic_load(&o->flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != epoch) __builtin_amdgcn_s_sleep(1);
+            b.pairs = __hip_atomic_load(&o->pairs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            b.spl = __hip_atomic_load(&o->spl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (blk + 1 == nblk) {
+                b.uns = __hip_atomic_load(&o->uns, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                b.sum = __hip_atomic_load(&o->sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                b.mn = __hip_atomic_load(&o->mn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                b.mx = __hip_atomic_load(&o->mx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                b.max_end = __hip_atomic_load(&o->max_end, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                b.max_nlen = __hip_atomic_load(&o->max_nlen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                b.min_pos = __hip_atomic_load(&o->min_pos, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        b.pairs = wave_sum(b.pairs);
+        b.spl = wave_sum(b.spl);
+        if (blk + 1 == nblk) {
+            b.uns = wave_sum(b.uns);
+            b.sum = wave_sum(b.sum);
+            b.mn = wave_min(b.mn);
+            b.mx = wave_max(b.mx);
+            b.max_end = wave_max(b.max_end);
+            b.max_nlen = wave_max(b.max_nlen);
+            b.min_pos = wave_min(b.min_pos);
+        }
+        if (l == 0) {
+            carry_s = b.pairs;
+            carry2_s = (u32)b.spl;
+            total_s = b;
+        }
+    }
+    __syncthreads();
+    // ---- pass B: the scan of the range, from the sums before it (the tiles' counts once more: L2 hits)
+    for (u32 base = lo; base < hi; base += K1S_THREADS * K1S_PER) {
+        const u32 i0 = base + K1S_PER * threadIdx.x;
+        u64 v[K1S_PER];
+        u32 v2[K1S_PER];
+        u64 vs = 0;
+        u32 vs2 = 0;
+#pragma unroll
+        for (int q = 0; q < K1S_PER; q++) {
+            const u32 i = i0 + q, ic = i < hi ? i : hi - 1;
+            const u64 cnt = tile_desc ? (tile_desc[ic] & ((1ull << 40) - 1)) : (u64)tile_cnt[ic];
+            const u32 sp = ts[ic].spliced;
+            v[q] = i < hi ? cnt : 0;
+            v2[q] = i < hi ? sp : 0u;
+            vs += v[q];
+            vs2 += v2[q];
+        }
         const u64 inc = wave_iscan(vs);
         const u32 inc2 = wave_iscan(vs2);
-        const int w = threadIdx.x >> 6;
         if (lane_id() == 63) {
             wsum[w] = inc;
             wsum2[w] = inc2;
@@ -787,18 +907,18 @@ __global__ __launch_bounds__(K1S_THREADS) void k1_scan_tiles(u32 *tile_cnt, cons
         // NOTE: exclusive offsets are stored as 32-bit: a contig is limited to < 2^32 pairs
         u64 ex = carry + wb + inc - vs;
         u32 so = carry2 + wb2 + inc2 - vs2;
-        for (int q = 0; q < K1S_PER; q++) { // (the tiles' own counts once more: L2 hits)
+#pragma unroll
+        for (int q = 0; q < K1S_PER; q++) {
             const u32 i = i0 + q;
-            if (i >= n_tiles) break;
-            const u64 v = tile_desc ? (tile_desc[i] & ((1ull << 40) - 1)) : (u64)tile_cnt[i];
-            const u32 v2 = ts[i].spliced;
-            if (!tile_desc) tile_cnt[i] = (u32)ex;
-            if (tile_soff) {
-                tile_soff[i] = so;
-                for (u32 c = (so + 255u) >> 8; (c << 8) < so + v2; c++) chunk_tile[c] = i; // list entries 256 c that fall into this tile
+            if (i < hi) {
+                if (!tile_desc) tile_cnt[i] = (u32)ex;
+                if (tile_soff) {
+                    tile_soff[i] = so;
+                    for (u32 c = (so + 255u) >> 8; (c << 8) < so + v2[q]; c++) chunk_tile[c] = i; // list entries 256 c that fall into this tile
+                }
             }
-            ex += v;
-            so += v2;
+            ex += v[q];
+            so += v2[q];
         }
         __syncthreads();
         if (threadIdx.x == 0) {
@@ -807,54 +927,27 @@ __global__ __launch_bounds__(K1S_THREADS) void k1_scan_tiles(u32 *tile_cnt, cons
         }
         __syncthreads();
     }
-    if (threadIdx.x == 0 && tile_soff) tile_soff[n_tiles] = carry2_s;
-    spl = wave_sum(spl);
-    uns = wave_sum(uns);
-    sum = wave_sum(sum);
-    mn = wave_min(mn);
-    mx = wave_max(mx);
-    max_end = wave_max(max_end);
-    max_nlen = wave_max(max_nlen);
-    min_pos = wave_min(min_pos);
-    const int w = threadIdx.x >> 6;
-    if (lane_id() == 0) {
-        r_spl[w] = spl;
-        r_uns[w] = uns;
-        r_sum[w] = sum;
-        r_i[w][0] = mn;
-        r_i[w][1] = mx;
-        r_i[w][2] = max_end;
-        r_i[w][3] = max_nlen;
-        r_i[w][4] = min_pos;
-    }
-    __syncthreads();
+    if (blk + 1 != nblk) return;
     if (threadIdx.x == 0) {
-        u64 a = 0, b2 = 0, c = 0;
-        int32_t m0 = INT32_MAX, m1 = 0, m2 = 0, m3 = 0, m4 = INT32_MAX;
-        for (int k = 0; k < NW; k++) {
-            a += r_spl[k];
-            b2 += r_uns[k];
-            c += r_sum[k];
-            m0 = min(m0, r_i[k][0]);
-            m1 = max(m1, r_i[k][1]);
-            m2 = max(m2, r_i[k][2]);
-            m3 = max(m3, r_i[k][3]);
-            m4 = min(m4, r_i[k][4]);
-        }
-        out->spliced = a;
-        out->unspliced = b2;
-        out->sum_len = c;
+        if (tile_soff) tile_soff[n_tiles] = carry2_s;
+        const ScanPart b = total_s;
+        const u64 n_pairs = carry_s;
+        const int32_t m0 = min(b.mn, mine.mn), m1 = max(b.mx, mine.mx), m2 = max(b.max_end, mine.max_end), m3 = max(b.max_nlen, mine.max_nlen),
+                      m4 = min(b.min_pos, mine.min_pos);
+        out->spliced = b.spl + mine.spl;
+        out->unspliced = b.uns + mine.uns;
+        out->sum_len = b.sum + mine.sum;
         out->min_len = m0;
         out->max_len = m1;
         out->max_end = m2;
         out->max_nlen = m3;
         out->min_pos = m4;
         out->n_tiles = n_tiles;
-        out->n_pairs = carry_s;
+        out->n_pairs = n_pairs;
         // limits the host assumed: pair capacity and key format (the keys of k1_emit must fit the digits it planned)
         u32 ovf = 0;
-        if (carry_s > (u64)pair_limit) ovf |= OVF_PAIRS;
-        if (carry_s > 0) {
+        if (n_pairs > (u64)pair_limit) ovf |= OVF_PAIRS;
+        if (n_pairs > 0) {
             const bool weird = m4 < 0 || m2 > ref_len || m2 < 0;
             if (!kf.raw) {
                 int need = 0;
@@ -863,7 +956,7 @@ __global__ __launch_bounds__(K1S_THREADS) void k1_scan_tiles(u32 *tile_cnt, cons
             }
         }
         out->overflow = ovf;
-        out->P = ovf ? 0u : (u32)carry_s;
+        out->P = ovf ? 0u : (u32)n_pairs;
         out->J = out->R = out->n_slots = 0;
         out->n_junc = out->n_runs = 0;
         out->n_cand = 0;

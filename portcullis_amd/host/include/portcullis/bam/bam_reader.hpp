@@ -83,6 +83,7 @@ class BamReader {
     std::vector<uint64_t> lastOffset;   // per target: largest chunk end in the index (just past its last record)
     std::vector<std::vector<uint64_t>> restart;  // per target: sorted virtual offsets the index names (all are record starts)
     bool indexLoaded = false;
+    std::function<bool(const uint8_t*, size_t, uint8_t*, size_t)> blockInflater;
     int32_t regionTid = -1;
     int32_t regionLen = 0;
     bool regionDone = true;
@@ -148,6 +149,12 @@ public:
         size_t records = 0;
     };
     void scanRecordsParallel(int nthreads, size_t chunkBytes, const std::function<void(const FileChunk&)>& sink);
+    // scanRecordsParallel's blocks inflated somewhere else (BamFilter: on the device, pjb_inflate_bgzf) instead of by zlib on
+    // the workers: `comp` holds `n` bytes of whole consecutive BGZF blocks whose inflated bytes (`outBytes` of them, the sum
+    // of their ISIZE fields) go to `out`.  false: not available right now (zlib takes this piece); an error is thrown.
+    // With it set, the scan's two large buffers come from the writer's buffer hooks (page-locked memory: the device reads
+    // and writes them by DMA).
+    void setBlockInflater(std::function<bool(const uint8_t* comp, size_t n, uint8_t* out, size_t outBytes)> f) { blockInflater = std::move(f); }
 
     // The file bytes that hold target `tid`'s records, untouched (whole BGZF blocks: from the block with its
     // first record through the block in which the next target starts, or the end of the file), read with

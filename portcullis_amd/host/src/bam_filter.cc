@@ -60,6 +60,7 @@ void BamFilter::filter() {
     cfg.device = device;
     cfg.orientation = PJB_OR_UNKNOWN;
     cfg.strandedness = PJB_SS_UNKNOWN;
+    cfg.flags = PJB_FLAG_NO_CHAINS;  // (decisions and BGZF blocks only)
     std::future<pjb_ctx*> ctxComing = std::async(std::launch::async, [cfg]() -> pjb_ctx* {
         pjb_ctx* c1 = nullptr;
         if (pjb_create(&c1, &cfg) != PJB_OK) throw BamFilterException(std::string("pjb_create: ") + pjb_last_error(nullptr));
@@ -159,7 +160,7 @@ void BamFilter::filter() {
     if (!hostDeflate) {
         writer.setBlockCompressor(deviceDeflate);
         writer.setAsyncFlush(getenv("PORTCULLIS_SYNC_WRITER") == nullptr);
-        if (getenv("PORTCULLIS_PINNED_BUFFERS")) {  // (page-locked buffers: measured no faster than pageable ones here, and 0.2 s to allocate)
+        if (!getenv("PORTCULLIS_PAGEABLE_BUFFERS")) {  // (page-locked: the device reads and writes the reader's and the writers' buffers by DMA)
             bam::BufferHooks hooks;
             hooks.alloc = pjb_host_alloc;
             hooks.release = pjb_host_free;
@@ -169,6 +170,17 @@ void BamFilter::filter() {
     struct HooksOff {
         ~HooksOff() { bam::setBufferHooks(bam::BufferHooks()); }
     } hooksOff;
+    // The input's blocks are inflated on the device too (pjb_inflate_bgzf, this thread's context); PORTCULLIS_HOST_INFLATE=1:
+    // by zlib on the workers.
+    if (!getenv("PORTCULLIS_HOST_INFLATE"))
+        reader.setBlockInflater([ctxReady](const uint8_t* comp, size_t n, uint8_t* out, size_t outBytes) -> bool {
+            pjb_ctx* ctx = ctxReady.get();
+            int64_t got = 0;
+            if (pjb_inflate_bgzf(ctx, comp, (int64_t)n, out, (int64_t)outBytes, &got) != PJB_OK)
+                throw BamFilterException(std::string("pjb_inflate_bgzf: ") + pjb_last_error(ctx));
+            if ((size_t)got != outBytes) throw BamFilterException("pjb_inflate_bgzf: the blocks' sizes do not add up");
+            return true;
+        });
     writer.open(reader.getHeaderText(), reader.getTargets());
     cout << " - Saving filtered alignments to: " << outputBam << endl;
     std::unique_ptr<bam::BamWriter> mod, unmod;

@@ -1,5 +1,6 @@
 #include <portcullis/bam/bam_reader.hpp>
 #include <portcullis/bam/phase_pool.hpp>
+#include <portcullis/bam/bam_writer.hpp>
 #include <portcullis/bam/name_hash.hpp>
 
 #include <algorithm>
@@ -689,11 +690,17 @@ void BamReader::scanRecordsParallel(int nthreads, size_t chunkBytes, const std::
     std::sort(rpts.begin(), rpts.end());
     rpts.erase(std::unique(rpts.begin(), rpts.end()), rpts.end());
     const uint64_t CHUNK = std::max<uint64_t>(chunkBytes, 1u << 20);
+    const bool hooked = (bool)blockInflater;  // (the device reads cbuf and writes buf)
     struct BigFree {
-        void operator()(uint8_t* p) const { bigFree(p); }
+        bool hooked;
+        void operator()(uint8_t* p) const {
+            if (hooked) hookedFree(p);
+            else bigFree(p);
+        }
     };
+    auto bufAlloc = [hooked](size_t n) { return (uint8_t*)(hooked ? hookedAlloc(n) : bigAlloc(n)); };
     const size_t CREAD = (size_t)std::min<uint64_t>(CHUNK, 96ull << 20) + (128u << 10);
-    std::unique_ptr<uint8_t[], BigFree> cbuf((uint8_t*)bigAlloc(CREAD)), buf;
+    std::unique_ptr<uint8_t[], BigFree> cbuf(bufAlloc(CREAD), BigFree{hooked}), buf(nullptr, BigFree{hooked});
     size_t bufCap = 0, carry = 0, cHave = 0;
     uint64_t cBase = firstRecordVoffset >> 16, fileOff = cBase;
     bool first = true;
@@ -763,12 +770,12 @@ void BamReader::scanRecordsParallel(int nthreads, size_t chunkBytes, const std::
         const size_t nb = blocks.size(), end = carry + (size_t)total;
         if (end + 8 > bufCap) {
             const size_t ncap = std::max<size_t>(end + 8, (size_t)CHUNK + (4u << 20));
-            std::unique_ptr<uint8_t[], BigFree> nbuf((uint8_t*)bigAlloc(ncap));
+            std::unique_ptr<uint8_t[], BigFree> nbuf(bufAlloc(ncap), BigFree{hooked});
             if (carry) memcpy(nbuf.get(), buf.get(), carry);
             buf.swap(nbuf);
             bufCap = ncap;
         }
-        {   // ---- inflate
+        if (!(blockInflater && blockInflater(cbuf.get(), cpos, buf.get() + carry, (size_t)total))) {  // ---- inflate
             std::atomic<size_t> next(0);
             std::atomic<bool> bad(false);
             uint8_t* base = buf.get() + carry;

@@ -86,8 +86,11 @@ def _split_records(data):
     return header, recs
 
 
-@pytest.mark.parametrize("mode,threads", [("HARD", 1), ("COMPLETE", 4)])
-def test_bamfilt_program(tmp_path, orc, mode, threads):
+@pytest.mark.parametrize("mode,threads,route", [("HARD", 1, "device"), ("COMPLETE", 4, "device"), ("HARD", 3, "zlib")])
+def test_bamfilt_program(tmp_path, orc, mode, threads, route, monkeypatch):
+    if route == "zlib":   # blocks inflated and compressed by zlib on the workers, pageable buffers
+        monkeypatch.setenv("PORTCULLIS_HOST_INFLATE", "1")
+        monkeypatch.setenv("PORTCULLIS_HOST_DEFLATE", "1")
     refs, contigs, reads = [], [], []
     for tid, seed in enumerate([51, 52]):
         genome, rr = make_reads(seed, n_reads=2500, paired=True, glen=20000)

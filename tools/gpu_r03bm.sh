@@ -1,0 +1,14 @@
+#!/bin/bash
+# bamfilt: the writer's buffers page-locked (pjb_host_alloc is mmap + touch + register since 10.10) against pageable
+cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+python tools/bench_bamfilt_program.py --runs 5 2>/dev/null | python -c "
+import json,sys; d=json.loads(sys.stdin.read().strip().split('\n')[-1]); print('pageable', sorted(d['wall_s']), d['kept_bytes_md5'])"
+python tools/bench_bamfilt_program.py --runs 5 --env PORTCULLIS_PINNED_BUFFERS=1 2>/dev/null | python -c "
+import json,sys; d=json.loads(sys.stdin.read().strip().split('\n')[-1]); print('pinned  ', sorted(d['wall_s']), d['kept_bytes_md5'])"
+wd=/tmp/pjb_bamfilt
+for k in 1 2; do
+PORTCULLIS_PINNED_BUFFERS=1 PORTCULLIS_PROFILE=1 portcullis_amd/host/portcullis_amd bamfilt -o $wd/filt/filtered.bam -c HARD -t 16 $wd/pass.junctions.tab $wd/prep/portcullis.sorted.alignments.bam > gpurun_out/r03bm_profile_$k.txt 2>&1
+done
+grep "profile\|pjb_create" gpurun_out/r03bm_profile_2.txt
