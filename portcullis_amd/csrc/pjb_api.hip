@@ -560,6 +560,10 @@ int close_contig(pjb_ctx *c, int32_t tid) {
 int upload_staged(pjb_ctx *c, void *dst, const uint8_t *src, size_t bytes); // (defined with the ingest code)
 } // namespace
 static int slot_init(pjb_ctx *c, int k);
+static void aux_streams(pjb_ctx *c) { // the rows stream and the row mirror's (15 - 20 ms each to create)
+    if (!c->stream3) (void)hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking);
+    if (!c->stream4) (void)hipStreamCreateWithFlags(&c->stream4, hipStreamNonBlocking);
+}
 
 extern "C" {
 
@@ -682,8 +686,7 @@ int pjb_create(pjb_ctx **out, const pjb_config *cfg) {
         delete c;
         return fail(nullptr, PJB_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e));
     }
-    (void)hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking);
-    (void)hipStreamCreateWithFlags(&c->stream4, hipStreamNonBlocking);
+    if (!(cfg->flags & PJB_FLAG_NO_CHAINS)) aux_streams(c); // (else: with the first chain)
     (void)hipEventCreateWithFlags(&c->ev_front, hipEventDisableTiming);
     c->scan_tiles = &c->b_scan_tiles;
     // The first four control slots get their streams and events now; the others when they are first used (slot_init).  Creating
@@ -1042,6 +1045,7 @@ static void mirror_reset(pjb_ctx *c) {
 }
 static int mirror_header_only(pjb_ctx *c, const pjb_region_result &R) {
     if (!c->mirror) return PJB_OK;
+    aux_streams(c);
     mirror_fold(c, R, 0);
     HIP_TRY(c, hipMemcpyAsync(c->mirror, c->mirror_hdr, PJB_MIRROR_HEADER_BYTES, hipMemcpyHostToDevice, c->stream4));
     HIP_TRY(c, hipStreamSynchronize(c->stream4));
@@ -1908,6 +1912,7 @@ static int queue_chain(pjb_ctx *c, Flight &f) {
 static int begin_flight(pjb_ctx *c, const int32_t *tids, int32_t n, const char *who) {
     if (!c) return PJB_ERR_ARG;
     if (!tids || n < 1 || n > GROUP_MAX) return fail(c, PJB_ERR_ARG, "%s: 1 to %d targets", who, GROUP_MAX);
+    aux_streams(c);
     for (int32_t k = 0; k < n; k++) {
         if (tids[k] < 0 || (size_t)tids[k] >= c->ref_len.size()) return fail(c, PJB_ERR_ARG, "%s: bad tid %d", who, tids[k]);
         for (int32_t q = 0; q < k; q++)

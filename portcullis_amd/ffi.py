@@ -33,6 +33,7 @@ PW_LEN = 32
 FEATURE_NAMES = ["Genuine", "rna_usrs", "rna_dist", "rna_rel", "rna_entropy", "rna_rel2raw", "rna_maxminanc", "rna_maxmmes",
                  "rna_missmatch", "rna_intron", "dna_minhamm", "dna_coding", "dna_pws", "dna_ss"] + [f"JAD{i:02d}" for i in range(1, 21)]
 FLAG_KERNEL_TIMING = 1
+FLAG_NO_CHAINS = 4  # bamfilt's contexts: the chain slots' and the rows' streams are created with the first chain, not by pjb_create
 FLAG_EXTRA = 2  # junc --extra: batches carry name_hash, extra_finish() yields mm_score / coverage / up_aln / down_aln
 
 

@@ -148,7 +148,9 @@ public:
         std::vector<const std::vector<uint64_t>*> slices;  // record offsets (each: 4-byte block_size + body)
         size_t records = 0;
     };
-    void scanRecordsParallel(int nthreads, size_t chunkBytes, const std::function<void(const FileChunk&)>& sink);
+    // ahead > 0: the scan runs on a thread of its own (with the workers), up to `ahead` pieces before the one `sink` -- still
+    // on the calling thread, one piece at a time, in file order -- is looking at; a piece stays valid until `sink` returns.
+    void scanRecordsParallel(int nthreads, size_t chunkBytes, const std::function<void(const FileChunk&)>& sink, int ahead = 0);
     // scanRecordsParallel's blocks inflated somewhere else (BamFilter: on the device, pjb_inflate_bgzf) instead of by zlib on
     // the workers: `comp` holds `n` bytes of whole consecutive BGZF blocks whose inflated bytes (`outBytes` of them, the sum
     // of their ISIZE fields) go to `out`.  false: not available right now (zlib takes this piece); an error is thrown.

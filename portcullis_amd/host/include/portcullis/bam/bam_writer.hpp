@@ -81,12 +81,25 @@ class BamWriter {
     // compresses `n` bytes cut into blocks of `block` bytes (the last one shorter) into complete BGZF members, back to back in
     // `out`, their lengths in `sizes`; false: not available (zlib takes over)
     std::function<bool(const uint8_t* in, size_t n, size_t block, ByteBuf& out, std::vector<uint32_t>& sizes)> compressor;
-    ByteBuf cout_;                     // the compressor's output, reused
+    ByteBuf cout_[2];                  // the compressor's output: one is written to the file while the other is filled
+    int coutCur = 0;
+    std::future<void> writing;         // the fwrite of the last compressed piece
+    void waitWrite() {
+        if (writing.valid()) writing.get();  // (rethrows a failed write)
+    }
+    size_t flushBlocks = 64;
     bool asyncFlush = false;           // writeRecords returns while the blocks are compressed and written by another thread
     std::future<void> inflight;
     void waitFlush() {
         if (inflight.valid()) inflight.get();  // (rethrows what the flush threw)
     }
+    // With asyncFlush, writeRecords gathers the next piece into `pending` while the flush thread works on `flushing` /
+    // `flushRecs` (whole blocks only; records whose end is not known yet stay in flushRecs for the next flush).
+    ByteBuf flushing;
+    std::vector<RecInfo> flushRecs;
+    uint64_t ubase = 0;                // offset of pending[0] in the uncompressed stream (== uflushed when no flush is in flight)
+    void settle();                     // wait for the flush thread and take its leftover records back
+    void flushBuf(ByteBuf& buf, std::vector<RecInfo>& rs, bool final);
     std::vector<uint32_t> csizes_;
 
 public:
@@ -110,6 +123,8 @@ public:
     // With a block compressor set: writeRecords hands the gathered records to a thread of the writer's own and returns; the
     // next call (and close) waits for it.  The compressor then runs on that thread.
     void setAsyncFlush(bool on) { asyncFlush = on; }
+    // writeRecords compresses once this many blocks are waiting (64: 4 MB; tests: a few, for many hand-overs in a small file)
+    void setFlushBlocks(size_t n) { flushBlocks = n < 1 ? 1 : n; }
 };
 
 }  // namespace bam

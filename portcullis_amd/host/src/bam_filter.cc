@@ -6,6 +6,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <cmath>
 #include <cstring>
 #include <iomanip>
 #include <iostream>
@@ -93,8 +94,9 @@ void BamFilter::filter() {
     // ---- the filter's junction set, per target, as sorted keys on the device
     // (the context takes 0.2 s to come up: the junction keys follow it on a thread of their own, and the first piece of the
     // file is read and inflated meanwhile -- whoever needs the context asks ctxReady)
-    std::shared_future<pjb_ctx*> ctxReady = std::async(std::launch::async, [&js, &ctxComing]() -> pjb_ctx* {
+    std::shared_future<pjb_ctx*> ctxReady = std::async(std::launch::async, [&js, &ctxComing, &mark]() -> pjb_ctx* {
         pjb_ctx* c1 = ctxComing.get();
+        mark("device context is up");
         std::map<int32_t, std::vector<uint64_t>> keys;
         for (const JunctionPtr& j : js.getJunctions()) {
             const Intron& in = *j->getIntron();
@@ -109,6 +111,7 @@ void BamFilter::filter() {
                 throw BamFilterException(msg);
             }
         }
+        mark("junction keys on the device");
         return c1;
     }).share();
     struct Closer {
@@ -143,6 +146,9 @@ void BamFilter::filter() {
     bam::BamWriter writer(outputBam, threads);
     auto deflateOn = [](pjb_ctx* ctx, const uint8_t* in, size_t n, size_t block, bam::ByteBuf& out, std::vector<uint32_t>& sizes) -> bool {
         const size_t nblk = (n + block - 1) / block;
+        // (room for a quarter more: a piece with more blocks than any before it would move the buffer, and a page-locked
+        // buffer of 200 MB takes 30 - 40 ms to make -- as long as compressing the piece)
+        if (out.capacity() < nblk * 65536) out.reserve(nblk * 65536 + nblk * 16384 + (1u << 20));
         out.resize(nblk * 65536);
         sizes.resize(nblk);
         int64_t got = 0;
@@ -162,7 +168,9 @@ void BamFilter::filter() {
         writer.setAsyncFlush(getenv("PORTCULLIS_SYNC_WRITER") == nullptr);
         if (!getenv("PORTCULLIS_PAGEABLE_BUFFERS")) {  // (page-locked: the device reads and writes the reader's and the writers' buffers by DMA)
             bam::BufferHooks hooks;
-            hooks.alloc = pjb_host_alloc;
+            // (small buffers stay on the heap: page-locking means waiting for the runtime to come up, and the output's header
+            // is written while it does)
+            hooks.alloc = [](size_t n) -> void* { return n >= ((size_t)8 << 20) ? pjb_host_alloc(n) : nullptr; };
             hooks.release = pjb_host_free;
             bam::setBufferHooks(hooks);
         }
@@ -170,9 +178,12 @@ void BamFilter::filter() {
     struct HooksOff {
         ~HooksOff() { bam::setBufferHooks(bam::BufferHooks()); }
     } hooksOff;
-    // The input's blocks are inflated on the device too (pjb_inflate_bgzf, this thread's context); PORTCULLIS_HOST_INFLATE=1:
-    // by zlib on the workers.
-    if (!getenv("PORTCULLIS_HOST_INFLATE"))
+    // PORTCULLIS_DEVICE_INFLATE=1: the input's blocks are inflated on the device too (pjb_inflate_bgzf, this thread's context)
+    // instead of by zlib on the workers.  Not the default: bgzf_decode is a lane per block, a piece of 256 MB has 4 k blocks of
+    // the 60 k the chip holds at once, and a lane needs 40 ms for its block -- 0.52 s for the configs[1] file against zlib's
+    // 0.45 s on 16 threads (profiles/r03bn_bamfilt_device_inflate.txt).
+    const bool deviceInflate = getenv("PORTCULLIS_DEVICE_INFLATE") != nullptr;
+    if (deviceInflate)
         reader.setBlockInflater([ctxReady](const uint8_t* comp, size_t n, uint8_t* out, size_t outBytes) -> bool {
             pjb_ctx* ctx = ctxReady.get();
             int64_t got = 0;
@@ -183,6 +194,7 @@ void BamFilter::filter() {
         });
     writer.open(reader.getHeaderText(), reader.getTargets());
     cout << " - Saving filtered alignments to: " << outputBam << endl;
+    mark("output opened, header written");
     std::unique_ptr<bam::BamWriter> mod, unmod;
     if (saveMSRs) {
         mod.reset(new bam::BamWriter(outputBam + ".mod.bam", threads));
@@ -212,9 +224,16 @@ void BamFilter::filter() {
     const bool prof = getenv("PORTCULLIS_PROFILE") != nullptr;
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     double tExtract = 0, tDevice = 0, tWrite = 0, tSink0 = now(), tScan = 0;
+    // The scan runs two pieces ahead of the decisions (PORTCULLIS_SCAN_AHEAD; 0: in turns) on `threads` workers of its own:
+    // the first pieces are read and inflated while the device context is still coming up, the later ones while the
+    // workers here extract and gather.
+    mark("workers started");
+    const int scanAhead = deviceInflate ? 0 /* (one context, one thread) */
+                          : getenv("PORTCULLIS_SCAN_AHEAD") ? std::max(0, atoi(getenv("PORTCULLIS_SCAN_AHEAD"))) : 2;
     reader.scanRecordsParallel(threads, (size_t)256 << 20, [&](const bam::BamReader::FileChunk& fc) {
         double t0 = now();
         tScan += t0 - tSink0;
+        const double tScanLast = t0 - tSink0;
         const size_t ns = fc.slices.size(), n = fc.records;
         std::vector<size_t> base(ns + 1, 0), opBase(ns + 1, 0);
         for (size_t s = 0; s < ns; s++) base[s + 1] = base[s] + fc.slices[s]->size();
@@ -289,10 +308,12 @@ void BamFilter::filter() {
             unmod->writeRecords(fc.data, fc.slices, codes.data(), 3, workers);
         }
         tWrite += now() - t0;
+        if (prof && getenv("PORTCULLIS_PROFILE_PIECES"))
+            fprintf(stderr, "[piece] %zu records: sink %.3f .. %.3f (writer part from %.3f)\n", n, fmod(tSink0 + (tScanLast), 1000.0), fmod(now(), 1000.0), fmod(t0, 1000.0));
         tSink0 = now();
-    });
+    }, scanAhead);
     if (prof)
-        fprintf(stderr, "[bamfilt profile] read + inflate + find records %.3f s, extract %.3f s, device decisions %.3f s, write %.3f s\n", tScan, tExtract,
+        fprintf(stderr, "[bamfilt profile] read + inflate + find records (or waiting for them) %.3f s, extract %.3f s, device decisions %.3f s, write %.3f s\n", tScan, tExtract,
                 tDevice, tWrite);
     mark("last piece handed to the writer");
     reader.close();

@@ -8,9 +8,11 @@
 #include <chrono>
 #include <sys/resource.h>
 #include <condition_variable>
+#include <deque>
 #include <map>
 #include <memory>
 #include <mutex>
+#include <cmath>
 #include <cstring>
 #include <fcntl.h>
 #include <sstream>
@@ -675,8 +677,10 @@ uint8_t* BamReader::readRegionBytes(int32_t tid, int nthreads, size_t& bytes, ui
     return buf;
 }
 
-void BamReader::scanRecordsParallel(int nthreads, size_t chunkBytes, const std::function<void(const FileChunk&)>& sink) {
+void BamReader::scanRecordsParallel(int nthreads, size_t chunkBytes, const std::function<void(const FileChunk&)>& sink, int ahead) {
     nthreads = std::max(1, nthreads);
+    if (getenv("PORTCULLIS_PROFILE_PIECES"))
+        fprintf(stderr, "[scan] called %.3f\n", fmod(std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(), 1000.0));
     PhasePool pool(nthreads > 1 ? nthreads : 0);
     Mapped m;
     m.fd = ::open(bamFile.c_str(), O_RDONLY);
@@ -700,15 +704,49 @@ void BamReader::scanRecordsParallel(int nthreads, size_t chunkBytes, const std::
     };
     auto bufAlloc = [hooked](size_t n) { return (uint8_t*)(hooked ? hookedAlloc(n) : bigAlloc(n)); };
     const size_t CREAD = (size_t)std::min<uint64_t>(CHUNK, 96ull << 20) + (128u << 10);
-    std::unique_ptr<uint8_t[], BigFree> cbuf(bufAlloc(CREAD), BigFree{hooked}), buf(nullptr, BigFree{hooked});
-    size_t bufCap = 0, carry = 0, cHave = 0;
+    std::unique_ptr<uint8_t[], BigFree> cbuf(bufAlloc(CREAD), BigFree{hooked});
+    // A piece lives in a slot (buffer, slices, FileChunk).  ahead == 0: one slot, `sink` is called between two pieces.
+    // ahead > 0: the pieces are made by a thread of this call (with the workers) up to `ahead` pieces before the one `sink`
+    // -- still on the calling thread, still one piece at a time and in file order -- is looking at.
+    struct Slot {
+        std::unique_ptr<uint8_t[], BigFree> buf;
+        size_t cap = 0;
+        std::vector<std::vector<uint64_t>> sl;
+        FileChunk fc;
+        bool full = false;  // delivered, `sink` has not returned yet
+        explicit Slot(bool hooked) : buf(nullptr, BigFree{hooked}) {}
+    };
+    const size_t nslots = (size_t)std::max(0, ahead) + 1;
+    std::vector<Slot> slots;
+    for (size_t k = 0; k < nslots; k++) slots.emplace_back(hooked);
+    std::mutex qmu;
+    std::condition_variable qcv;
+    std::deque<size_t> ready;   // delivered slots, oldest first
+    bool producerDone = false, abortScan = false;
+    std::exception_ptr producerError;
+    auto deliver = [&](size_t k) {
+        if (nslots == 1) {
+            sink(slots[k].fc);
+            return;
+        }
+        std::lock_guard<std::mutex> lk(qmu);
+        slots[k].full = true;
+        ready.push_back(k);
+        qcv.notify_all();
+    };
+    const bool tracePieces = getenv("PORTCULLIS_PROFILE_PIECES") != nullptr;  // (stderr: when each piece was read, inflated, walked)
+    auto tnow = [] { return fmod(std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(), 1000.0); };
+    if (tracePieces) fprintf(stderr, "[scan] buffers and workers ready %.3f\n", tnow());
+    auto produce = [&]() {
+    size_t carry = 0, cHave = 0, iter = 0;
+    const uint8_t* carrySrc = nullptr;  // the partial record behind the last piece's last whole one (in that piece's buffer)
     uint64_t cBase = firstRecordVoffset >> 16, fileOff = cBase;
     bool first = true;
     std::vector<Block> blocks;
     std::vector<uint64_t> uoff;
-    std::vector<std::vector<uint64_t>> sl;
     std::vector<size_t> stop;
     for (;;) {
+        const double tp0 = tnow();
         // ---- refill the compressed window
         if (fileOff < fileSize && cHave < CREAD) {
             const size_t want = (size_t)std::min<uint64_t>(CREAD - cHave, fileSize - fileOff);
@@ -768,13 +806,30 @@ void BamReader::scanRecordsParallel(int nthreads, size_t chunkBytes, const std::
             continue;
         }
         const size_t nb = blocks.size(), end = carry + (size_t)total;
-        if (end + 8 > bufCap) {
-            const size_t ncap = std::max<size_t>(end + 8, (size_t)CHUNK + (4u << 20));
-            std::unique_ptr<uint8_t[], BigFree> nbuf(bufAlloc(ncap), BigFree{hooked});
-            if (carry) memcpy(nbuf.get(), buf.get(), carry);
-            buf.swap(nbuf);
-            bufCap = ncap;
+        const double tp1 = tnow();
+        Slot& S = slots[iter++ % nslots];
+        if (nslots > 1) {  // (the slot's last piece may still be with the sink)
+            std::unique_lock<std::mutex> lk(qmu);
+            qcv.wait(lk, [&] { return !S.full || abortScan; });
+            if (abortScan) return;
         }
+        {
+            std::unique_ptr<uint8_t[], BigFree> fresh(nullptr, BigFree{hooked});
+            size_t ncap = S.cap;
+            if (end + 8 > S.cap) {
+                ncap = std::max<size_t>(end + 8, (size_t)CHUNK + (4u << 20));
+                fresh.reset(bufAlloc(ncap));
+            }
+            uint8_t* to = fresh ? fresh.get() : S.buf.get();
+            if (carry) memmove(to, carrySrc, carry);  // (one slot: within the same buffer)
+            if (fresh) {
+                S.buf.swap(fresh);
+                S.cap = ncap;
+            }
+        }
+        std::unique_ptr<uint8_t[], BigFree>& buf = S.buf;
+        std::vector<std::vector<uint64_t>>& sl = S.sl;
+        const double tp2 = tnow();
         if (!(blockInflater && blockInflater(cbuf.get(), cpos, buf.get() + carry, (size_t)total))) {  // ---- inflate
             std::atomic<size_t> next(0);
             std::atomic<bool> bad(false);
@@ -803,6 +858,7 @@ void BamReader::scanRecordsParallel(int nthreads, size_t chunkBytes, const std::
             });
             if (bad) throw BamException("BGZF inflate failed");
         }
+        const double tp3 = tnow();
         // ---- record starts the index names inside this piece
         const size_t cur0 = first ? (size_t)(firstRecordVoffset & 0xffff) : 0;
         first = false;
@@ -861,18 +917,21 @@ void BamReader::scanRecordsParallel(int nthreads, size_t chunkBytes, const std::
             stop[t] = cur;
         });
         if (badWalk) throw BamException("Invalid BAM record (or the index names an offset that is not a record start)");
-        FileChunk fc;
+        FileChunk& fc = S.fc;
+        fc = FileChunk();
         fc.data = buf.get();
         fc.bytes = stop[ns - 1];
         for (size_t t = 0; t < ns; t++) {
             fc.slices.push_back(&sl[t]);
             fc.records += sl[t].size();
         }
-        if (fc.records) sink(fc);
         // ---- what is left: the partial record behind the last whole one, the compressed bytes behind the last block
         const size_t used = stop[ns - 1];
         carry = end - used;
-        if (carry) memmove(buf.get(), buf.get() + used, carry);
+        carrySrc = buf.get() + used;
+        if (tracePieces)
+            fprintf(stderr, "[scan piece] %zu blocks: read %.3f .. %.3f, slot and carry .. %.3f, inflate .. %.3f, records .. %.3f\n", nb, tp0, tp1, tp2, tp3, tnow());
+        if (fc.records) deliver((size_t)(&S - slots.data()));
         memmove(cbuf.get(), cbuf.get() + cpos, cHave - cpos);
         cHave -= cpos;
         cBase += cpos;
@@ -881,7 +940,55 @@ void BamReader::scanRecordsParallel(int nthreads, size_t chunkBytes, const std::
             break;
         }
     }
+    };  // produce
+    if (nslots == 1) {
+        produce();
+        return;
+    }
+    std::thread producer([&] {
+        try {
+            produce();
+        } catch (...) {
+            std::lock_guard<std::mutex> lk(qmu);
+            producerError = std::current_exception();
+        }
+        std::lock_guard<std::mutex> lk(qmu);
+        producerDone = true;
+        qcv.notify_all();
+    });
+    struct Joiner {  // (also when `sink` throws: the producer is told to stop, then joined)
+        std::thread& t;
+        std::mutex& mu;
+        std::condition_variable& cv;
+        bool& abort;
+        ~Joiner() {
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                abort = true;
+            }
+            cv.notify_all();
+            t.join();
+        }
+    } joiner{producer, qmu, qcv, abortScan};
+    for (;;) {
+        size_t k;
+        {
+            std::unique_lock<std::mutex> lk(qmu);
+            qcv.wait(lk, [&] { return !ready.empty() || producerDone; });
+            if (ready.empty()) {
+                if (producerError) std::rethrow_exception(producerError);
+                break;
+            }
+            k = ready.front();
+            ready.pop_front();
+        }
+        sink(slots[k].fc);
+        std::lock_guard<std::mutex> lk(qmu);
+        slots[k].full = false;
+        qcv.notify_all();
+    }
 }
+
 
 void BamReader::decodeRegionParallel(int32_t tid, int nthreads, size_t maxRecords, const std::function<void(ReadBatch&)>& sink) {
     if (tid < 0 || (size_t)tid >= targets.size()) throw BamException("decodeRegionParallel: target out of range");

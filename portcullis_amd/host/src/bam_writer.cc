@@ -5,6 +5,7 @@
 #include <atomic>
 #include <chrono>
 #include <cstdlib>
+#include <cmath>
 #include <cstring>
 #include <thread>
 #include <zlib.h>
@@ -89,6 +90,7 @@ static inline int32_t recordEnd(const uint8_t* rec, size_t len) {  // pos + refe
 BamWriter::~BamWriter() {
     try {
         if (inflight.valid()) inflight.wait();
+        if (writing.valid()) writing.wait();
         if (fp) close();
     } catch (...) {
     }
@@ -104,6 +106,9 @@ void BamWriter::open(const std::string& headerText, const std::vector<RefSeq>& t
     cacheChunks = nullptr;
     cacheTid = -1;
     pending.clear();
+    flushing.clear();
+    flushRecs.clear();
+    ubase = uflushed;
     pending.insert(pending.end(), {'B', 'A', 'M', 1});
     put32(pending, (uint32_t)headerText.size());
     pending.insert(pending.end(), headerText.begin(), headerText.end());
@@ -119,14 +124,14 @@ void BamWriter::open(const std::string& headerText, const std::vector<RefSeq>& t
 
 void BamWriter::write(const uint8_t* rec, size_t len) {
     if (!fp) throw BamException("BamWriter::write: file is not open");
-    waitFlush();
+    settle();
     if (len < 36) throw BamException("BamWriter::write: not a BAM record");
     if (wantIndex) {
         RecInfo r;
         r.tid = (int32_t)rd32(rec + 4);
         r.pos = (int32_t)rd32(rec + 8);
         r.end = recordEnd(rec, len);
-        r.ustart = uflushed + pending.size();
+        r.ustart = ubase + pending.size();
         recs.push_back(r);
     }
     pending.insert(pending.end(), rec, rec + len);
@@ -136,7 +141,8 @@ void BamWriter::write(const uint8_t* rec, size_t len) {
 void BamWriter::writeRecords(const uint8_t* data, const std::vector<const std::vector<uint64_t>*>& slices, const uint8_t* codes, uint8_t only,
                              PhasePool& workers) {
     if (!fp) throw BamException("BamWriter::writeRecords: file is not open");
-    waitFlush();
+    const bool handOver = asyncFlush && (bool)compressor;  // (the flush thread has buffers of its own: gather beside it)
+    if (!handOver) settle();
     const size_t ns = slices.size();
     if (ns == 0) return;
     auto keep = [&](size_t flat) { return !codes || (only ? codes[flat] == only : codes[flat] != 0); };
@@ -160,7 +166,7 @@ void BamWriter::writeRecords(const uint8_t* data, const std::vector<const std::v
     if (kr[ns] == 0) return;
     const double tg0 = WriterProfile::now();
     const size_t p0 = pending.size(), r0 = recs.size();
-    if (pending.capacity() < p0 + kb[ns]) pending.reserve(p0 + kb[ns] + (kb[ns] >> 3) + (1u << 20));  // (one allocation for a file's pieces, not a doubling series)
+    if (pending.capacity() < p0 + kb[ns]) pending.reserve(p0 + kb[ns] + (kb[ns] >> 2) + (1u << 20));  // (one allocation for a file's pieces, not a doubling series)
     pending.resize(p0 + kb[ns]);
     if (wantIndex) recs.resize(r0 + kr[ns]);
     workers.run(ns, [&](size_t s) {
@@ -177,21 +183,41 @@ void BamWriter::writeRecords(const uint8_t* data, const std::vector<const std::v
                 r.tid = (int32_t)rd32(rec + 4);
                 r.pos = (int32_t)rd32(rec + 8);
                 r.end = recordEnd(rec, len);
-                r.ustart = uflushed + (uint64_t)(dst - pending.data());
+                r.ustart = ubase + (uint64_t)(dst - pending.data());
                 recs[i++] = r;
             }
             dst += len;
         }
     });
     g_prof.gather += WriterProfile::now() - tg0;
-    if (pending.size() < BLOCK * 64) return;
-    if (asyncFlush && compressor) {
-        inflight = std::async(std::launch::async, [this] { flush(false); });
+    if (pending.size() < BLOCK * flushBlocks) return;
+    if (handOver) {
+        waitFlush();  // (the piece before: `flushing` is free again, flushRecs holds the records it could not close)
+        const size_t take = pending.size() / BLOCK * BLOCK, rest = pending.size() - take;
+        flushing.swap(pending);
+        pending.clear();
+        if (pending.capacity() < flushing.capacity()) pending.reserve(flushing.capacity());
+        pending.resize(rest);
+        if (rest) memcpy(pending.data(), flushing.data() + take, rest);
+        flushing.resize(take);
+        flushRecs.insert(flushRecs.end(), recs.begin(), recs.end());
+        recs.clear();
+        ubase += take;
+        inflight = std::async(std::launch::async, [this] { flushBuf(flushing, flushRecs, false); });
         return;
     }
     pool = &workers;
     flush(false);
     pool = nullptr;
+}
+
+void BamWriter::settle() {
+    waitFlush();
+    if (!flushRecs.empty()) {
+        flushRecs.insert(flushRecs.end(), recs.begin(), recs.end());
+        recs.swap(flushRecs);
+        flushRecs.clear();
+    }
 }
 
 void BamWriter::indexRecord(const RecInfo& r, uint64_t vs, uint64_t ve) {
@@ -214,6 +240,11 @@ void BamWriter::indexRecord(const RecInfo& r, uint64_t vs, uint64_t ve) {
 
 // Compresses every complete 0xff00-byte block of `pending` (all of it when final) and writes the blocks in order.
 void BamWriter::flush(bool final) {
+    flushBuf(pending, recs, final);
+    ubase = uflushed;
+}
+
+void BamWriter::flushBuf(ByteBuf& pending, std::vector<RecInfo>& recs, bool final) {
     const size_t nblk = final ? (pending.size() + BLOCK - 1) / BLOCK : pending.size() / BLOCK;
     if (nblk == 0) {
         if (final && wantIndex) {  // nothing left to compress, but the last records' ends are now known: the EOF block
@@ -227,16 +258,26 @@ void BamWriter::flush(bool final) {
     std::vector<uint64_t> coff(nblk + 1, cwritten);
     bool external = false;
     double tp0 = WriterProfile::now();
-    if (compressor && compressor(pending.data(), take, BLOCK, cout_, csizes_)) {
+    ByteBuf& co = cout_[coutCur];
+    // (a few blocks -- the header, the last records of a file -- are zlib's: no reason to wait for a device)
+    if (compressor && nblk >= 4 && compressor(pending.data(), take, BLOCK, co, csizes_)) {
         if (csizes_.size() != nblk) throw BamException("BamWriter: the block compressor returned the wrong number of blocks");
         for (size_t b = 0; b < nblk; b++) coff[b + 1] = coff[b] + csizes_[b];
-        if (coff[nblk] - cwritten != cout_.size()) throw BamException("BamWriter: the block compressor's sizes do not add up");
+        if (coff[nblk] - cwritten != co.size()) throw BamException("BamWriter: the block compressor's sizes do not add up");
         g_prof.compress += WriterProfile::now() - tp0;
-        tp0 = WriterProfile::now();
-        if (fwrite(cout_.data(), 1, cout_.size(), fp) != cout_.size()) throw BamException("BamWriter: write failed: " + path);
-        g_prof.fwrite_ += WriterProfile::now() - tp0;
+        if (g_prof.on && getenv("PORTCULLIS_PROFILE_PIECES"))
+            fprintf(stderr, "[writer piece] %s: compress %.3f .. %.3f (%zu blocks)\n", path.c_str(), fmod(tp0, 1000.0), fmod(WriterProfile::now(), 1000.0), nblk);
+        // the piece goes to the file beside the index work below and the next piece's compression (the other buffer)
+        waitWrite();
+        writing = std::async(std::launch::async, [this, &co] {
+            const double tw0 = WriterProfile::now();
+            if (fwrite(co.data(), 1, co.size(), fp) != co.size()) throw BamException("BamWriter: write failed: " + path);
+            g_prof.fwrite_ += WriterProfile::now() - tw0;
+        });
+        coutCur ^= 1;
         external = true;
     }
+    if (!external) waitWrite();
     std::vector<std::vector<uint8_t>> cblk(external ? 0 : nblk);
     std::atomic<size_t> next(0);
     auto work = [&]() {
@@ -319,8 +360,9 @@ void BamWriter::flush(bool final) {
 
 void BamWriter::close() {
     if (!fp) return;
-    waitFlush();
+    settle();
     flush(true);
+    waitWrite();
     static const uint8_t eof[28] = {0x1f, 0x8b, 0x08, 0x04, 0, 0, 0, 0, 0, 0xff, 0x06, 0, 0x42, 0x43, 0x02, 0, 0x1b, 0, 0x03, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     if (fwrite(eof, 1, 28, fp) != 28) throw BamException("BamWriter: write failed: " + path);
     fclose(fp);

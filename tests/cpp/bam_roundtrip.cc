@@ -1,12 +1,17 @@
 // Host BAM I/O under AddressSanitizer / UBSan (no GPU): BamReader's record-at-a-time view (next / current), its raw
 // sequential walk (rewind / nextRecord), and BamWriter (parallel BGZF, in-process .bai) -- the file written here is
 // read back through its own index and must hold the same records.
-//   bam_roundtrip <in.bam> <out.bam> <threads> [bulk <chunk bytes> <drop every k-th record, 0: none>]
+//   bam_roundtrip <in.bam> <out.bam> <threads> [bulk <chunk bytes> <drop every k-th record, 0: none> [pieces the scan runs ahead [async]]]
+// async: the writer's hand-over route (a block compressor -- zlib here, the device in BamFilter -- on a thread of the writer's).
 // bulk: the same through the many-records-at-once route of `bamfilt` (BamReader::scanRecordsParallel -> BamWriter::writeRecords).
 #include <portcullis/bam/bam_reader.hpp>
 #include <portcullis/bam/bam_writer.hpp>
 
+#include <algorithm>
 #include <cstdio>
+#include <cstring>
+#include <vector>
+#include <zlib.h>
 #include <cstdlib>
 #include <string>
 #include <iostream>
@@ -55,6 +60,41 @@ int main(int argc, char** argv) {
             if (argc >= 7 && std::string(argv[4]) == "bulk") {
                 const int threads = atoi(argv[3]), drop = atoi(argv[6]);
                 PhasePool workers(threads > 1 ? threads : 0);
+                if (argc >= 9 && std::string(argv[8]) == "async") {
+                    w.setBlockCompressor([](const uint8_t* in, size_t n, size_t block, ByteBuf& out, std::vector<uint32_t>& sizes) -> bool {
+                        out.clear();
+                        sizes.clear();
+                        for (size_t off = 0; off < n; off += block) {
+                            const size_t len = std::min(block, n - off);
+                            std::vector<uint8_t> z(len + 1024);
+                            z_stream zs;
+                            memset(&zs, 0, sizeof zs);
+                            if (deflateInit2(&zs, 1, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) return false;
+                            zs.next_in = const_cast<uint8_t*>(in + off);
+                            zs.avail_in = (uInt)len;
+                            zs.next_out = z.data();
+                            zs.avail_out = (uInt)z.size();
+                            const int rc = deflate(&zs, Z_FINISH);
+                            const size_t clen = z.size() - zs.avail_out;
+                            deflateEnd(&zs);
+                            if (rc != Z_STREAM_END) return false;
+                            const uint8_t hdr[16] = {31, 139, 8, 4, 0, 0, 0, 0, 0, 255, 6, 0, 'B', 'C', 2, 0};
+                            const size_t at = out.size();
+                            out.resize(at + 18 + clen + 8);
+                            memcpy(&out[at], hdr, 16);
+                            out[at + 16] = (uint8_t)((clen + 25) & 0xff);
+                            out[at + 17] = (uint8_t)((clen + 25) >> 8);
+                            memcpy(&out[at + 18], z.data(), clen);
+                            const uint32_t crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), in + off, (uInt)len), isz = (uint32_t)len;
+                            memcpy(&out[at + 18 + clen], &crc, 4);
+                            memcpy(&out[at + 22 + clen], &isz, 4);
+                            sizes.push_back((uint32_t)(clen + 26));
+                        }
+                        return true;
+                    });
+                    w.setAsyncFlush(true);
+                    w.setFlushBlocks(2);
+                }
                 std::vector<uint8_t> codes;
                 r.scanRecordsParallel(threads, (size_t)atoll(argv[5]), [&](const BamReader::FileChunk& fc) {
                     codes.assign(fc.records, 1);
@@ -63,7 +103,7 @@ int main(int argc, char** argv) {
                             if ((raw + i) % (size_t)drop == 0) codes[i] = 0;
                     raw += fc.records;
                     w.writeRecords(fc.data, fc.slices, codes.data(), 0, workers);
-                });
+                }, argc >= 8 ? atoi(argv[7]) : 0);
                 w.close();
                 printf("bulk raw=%llu\n", raw);
                 return 0;

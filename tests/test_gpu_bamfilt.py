@@ -86,11 +86,14 @@ def _split_records(data):
     return header, recs
 
 
-@pytest.mark.parametrize("mode,threads,route", [("HARD", 1, "device"), ("COMPLETE", 4, "device"), ("HARD", 3, "zlib")])
+@pytest.mark.parametrize("mode,threads,route", [("HARD", 1, "default"), ("COMPLETE", 4, "default"), ("HARD", 3, "zlib"), ("SOFT", 2, "device")])
 def test_bamfilt_program(tmp_path, orc, mode, threads, route, monkeypatch):
-    if route == "zlib":   # blocks inflated and compressed by zlib on the workers, pageable buffers
-        monkeypatch.setenv("PORTCULLIS_HOST_INFLATE", "1")
+    if route == "zlib":     # output blocks compressed by zlib on the workers too, the scan in turns with the decisions
         monkeypatch.setenv("PORTCULLIS_HOST_DEFLATE", "1")
+        monkeypatch.setenv("PORTCULLIS_SCAN_AHEAD", "0")
+    if route == "device":   # input blocks inflated on the device, pageable buffers
+        monkeypatch.setenv("PORTCULLIS_DEVICE_INFLATE", "1")
+        monkeypatch.setenv("PORTCULLIS_PAGEABLE_BUFFERS", "1")
     refs, contigs, reads = [], [], []
     for tid, seed in enumerate([51, 52]):
         genome, rr = make_reads(seed, n_reads=2500, paired=True, glen=20000)

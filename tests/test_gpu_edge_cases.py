@@ -122,3 +122,17 @@ def test_long_read_many_ops(ffi, orc):
     reads = [read_from_genome(G, 500, cig), read_from_genome(G, 520, "16M60N40M")]
     status, rows = both(ffi, orc, G, reads)
     assert status == "ok" and len(rows) >= 12
+
+
+def test_chain_on_a_context_made_without_chain_slots(ffi, orc):
+    """PJB_FLAG_NO_CHAINS only postpones the chain slots' streams: a chain on such a context gives the same rows."""
+    reads = [read_from_genome(G, 300, "50M100N50M"), read_from_genome(G, 320, "30M100N70M"), read_from_genome(G, 900, "40M200N60M")]
+    b = ReadBatch.from_reads(reads)
+    orows, oreg = orc.find_juncs(0, len(G), G, b, "UNKNOWN")
+    with ffi.Context(0, "UNKNOWN", flags=ffi.FLAG_NO_CHAINS) as ctx:
+        ctx.set_refs([len(G)])
+        for _ in range(2):
+            drows, dreg = ffi.run_contig(ctx, 0, G.encode(), [b])
+            region_equal(dreg, oreg)
+            assert_rows_equal(drows, orows)
+            ctx.clear_rows()

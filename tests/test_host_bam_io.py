@@ -67,8 +67,11 @@ def _records(data):
     return header, recs
 
 
-@pytest.mark.parametrize("block_size,threads,chunk,drop", [(0xFF00, 1, 1 << 20, 0), (1500, 3, 1 << 20, 3), (700, 4, 70000, 2), (3000, 2, 1 << 30, 5)])
-def test_bulk_route_under_sanitizers(tmp_path, exe, block_size, threads, chunk, drop):
+@pytest.mark.parametrize("block_size,threads,chunk,drop,ahead", [(0xFF00, 1, 1 << 20, 0, 0), (1500, 3, 1 << 20, 3, 0), (700, 4, 70000, 2, 0),
+                                                                 (3000, 2, 1 << 30, 5, 0), (700, 4, 70000, 2, 2), (1500, 3, 200000, 3, 1),
+                                                                 (0xFF00, 1, 1 << 20, 0, 3), (700, 4, 70000, 2, "2 async"), (0xFF00, 3, 1 << 20, 0, "0 async"),
+                                                                 (3000, 2, 1 << 30, 5, "1 async")])
+def test_bulk_route_under_sanitizers(tmp_path, exe, block_size, threads, chunk, drop, ahead):
     """`bamfilt`'s route through the host library: the whole file in pieces (blocks inflated and record starts found by
     several threads, from the index's record starts; unplaced records at the end, which no index covers), the kept records
     gathered and compressed by several threads.  Pieces smaller than the file, records straddling pieces and blocks."""
@@ -91,7 +94,7 @@ def test_bulk_route_under_sanitizers(tmp_path, exe, block_size, threads, chunk, 
     write_bam(src, refs, reads, block_size=block_size)
     dst = str(tmp_path / "out.bam")
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=1", UBSAN_OPTIONS="print_stacktrace=1")
-    p = subprocess.run([exe, src, dst, str(threads), "bulk", str(chunk), str(drop)], capture_output=True, text=True, timeout=600, env=env)
+    p = subprocess.run([exe, src, dst, str(threads), "bulk", str(chunk), str(drop)] + str(ahead).split(), capture_output=True, text=True, timeout=600, env=env)
     assert p.returncode == 0, p.stdout + p.stderr[-3000:]
     assert f"bulk raw={len(reads)}" in p.stdout
     header, recs = _records(gzip.open(src, "rb").read())
@@ -100,13 +103,14 @@ def test_bulk_route_under_sanitizers(tmp_path, exe, block_size, threads, chunk, 
     assert gzip.open(dst, "rb").read() == want
     # the index written beside it drives a second pass through the same route
     again = str(tmp_path / "again.bam")
-    p = subprocess.run([exe, dst, again, str(threads), "bulk", str(chunk), "0"], capture_output=True, text=True, timeout=600, env=env)
+    p = subprocess.run([exe, dst, again, str(threads), "bulk", str(chunk), "0"] + str(ahead).split(), capture_output=True, text=True, timeout=600, env=env)
     assert p.returncode == 0, p.stdout + p.stderr[-3000:]
     assert gzip.open(again, "rb").read() == want
 
 
+@pytest.mark.parametrize("ahead", [0, 2])
 @pytest.mark.parametrize("how", ["truncate_mid_block", "truncate_mid_record", "flip_header", "flip_payload", "bad_isize", "index_lies"])
-def test_bulk_route_rejects_damaged_files(tmp_path, exe, how):
+def test_bulk_route_rejects_damaged_files(tmp_path, exe, how, ahead):
     """Damaged input through the bulk route under the sanitizers: an error (exit code 3, a message), never a crash, a hang
     or a sanitizer report."""
     import shutil
@@ -154,7 +158,7 @@ def test_bulk_route_rejects_damaged_files(tmp_path, exe, how):
         open(bad + ".bai", "wb").write(bai)
     open(bad, "wb").write(raw)
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=1", UBSAN_OPTIONS="print_stacktrace=1")
-    p = subprocess.run([exe, bad, str(tmp_path / "out.bam"), "3", "bulk", str(1 << 16), "0"], capture_output=True, text=True, timeout=300, env=env)
+    p = subprocess.run([exe, bad, str(tmp_path / "out.bam"), "3", "bulk", str(1 << 16), "0", str(ahead)], capture_output=True, text=True, timeout=300, env=env)
     assert "AddressSanitizer" not in p.stderr and "runtime error" not in p.stderr, p.stderr[-3000:]
     assert p.returncode in (0, 3), (p.returncode, p.stderr[-2000:])
     if how in ("truncate_mid_block", "flip_header", "bad_isize"):
