@@ -17,12 +17,12 @@ def test_fast_formatters_match_iostream(tmp_path):
 
 
 def test_formatters_under_sanitizers(tmp_path):
-    """The same driver with junction.cc / junction_system.cc / genome_mapper.cc / bam_reader.cc compiled under
+    """The same driver with junction.cc / junction_system.cc / genome_mapper.cc / bam_reader.cc / bam_writer.cc compiled under
     AddressSanitizer + UndefinedBehaviorSanitizer (the device library is only linked: nothing here calls it)."""
     host = os.path.join(ROOT, "portcullis_amd", "host")
     csrc = os.path.join(ROOT, "portcullis_amd", "csrc")
     exe = str(tmp_path / "fmt_asan")
-    src = [os.path.join(host, "src", f) for f in ("junction.cc", "junction_system.cc", "genome_mapper.cc", "bam_reader.cc")]
+    src = [os.path.join(host, "src", f) for f in ("junction.cc", "junction_system.cc", "genome_mapper.cc", "bam_reader.cc", "bam_writer.cc")]
     subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
                            "-fno-omit-frame-pointer", f"-I{host}/include", f"-I{ROOT}/include", "-o", exe,
                            os.path.join(ROOT, "tests", "cpp", "format_equivalence.cc")] + src +
