@@ -1,6 +1,7 @@
 #include <portcullis/bam/bam_reader.hpp>
 #include <portcullis/bam/phase_pool.hpp>
 #include <portcullis/bam/bam_writer.hpp>
+#include <portcullis/bam/fast_inflate.hpp>
 #include <portcullis/bam/name_hash.hpp>
 
 #include <algorithm>
@@ -28,6 +29,9 @@
 
 namespace portcullis {
 namespace bam {
+
+// blocks go through fastInflate first (fast_inflate.hpp); PORTCULLIS_ZLIB_INFLATE=1: zlib only
+static const bool g_fastInflate = getenv("PORTCULLIS_ZLIB_INFLATE") == nullptr;
 
 // ------------------------------------------------------------------ big allocations
 void* bigAlloc(size_t bytes) {
@@ -124,7 +128,7 @@ bool BgzfStream::loadBlock() {
     const uint32_t isize = le32(&comp[cdata + 4]);
     if (isize > 65536) throw BamException("Invalid BGZF block: ISIZE exceeds 64 KiB");
     block.resize(isize);
-    if (isize) {
+    if (isize && !(g_fastInflate && fastInflate(comp.data(), cdata, block.data(), isize))) {  // (declined: zlib has the last word)
         z_stream zs;
         memset(&zs, 0, sizeof zs);
         if (inflateInit2(&zs, -15) != Z_OK) throw BamException("inflateInit2 failed");
@@ -846,6 +850,7 @@ void BamReader::scanRecordsParallel(int nthreads, size_t chunkBytes, const std::
                     if (b >= nb) break;
                     const Block& k = blocks[b];
                     if (!k.isize) continue;
+                    if (g_fastInflate && fastInflate(cbuf.get() + k.coff + 12 + k.xlen, k.csize - 12 - k.xlen - 8, base + uoff[b], k.isize)) continue;
                     inflateReset(&zs);
                     zs.next_in = cbuf.get() + k.coff + 12 + k.xlen;
                     zs.avail_in = k.csize - 12 - k.xlen - 8;
@@ -1121,6 +1126,7 @@ void BamReader::decodeRegionParallel(int32_t tid, int nthreads, size_t maxRecord
                     if (b >= b1) break;
                     const Block& k = blocks[b];
                     if (!k.isize) continue;
+                    if (g_fastInflate && fastInflate(cbuf.get() + k.coff + 12 + k.xlen, k.csize - 12 - k.xlen - 8, base + uoff[b - b0], k.isize)) continue;
                     z_stream zs;
                     memset(&zs, 0, sizeof zs);
                     if (inflateInit2(&zs, -15) != Z_OK) {

@@ -18,7 +18,8 @@ def exe(tmp_path_factory):
     out = str(tmp_path_factory.mktemp("asan") / "bam_roundtrip")
     subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
                            f"-I{host}/include", f"-I{ROOT}/include", "-o", out, os.path.join(ROOT, "tests", "cpp", "bam_roundtrip.cc"),
-                           os.path.join(host, "src", "bam_reader.cc"), os.path.join(host, "src", "bam_writer.cc"), "-lz", "-lpthread"])
+                           os.path.join(host, "src", "bam_reader.cc"), os.path.join(host, "src", "fast_inflate.cc"), os.path.join(host, "src", "bam_writer.cc"),
+                           "-lz", "-lpthread"])
     return out
 
 
