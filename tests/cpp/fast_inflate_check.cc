@@ -1,14 +1,16 @@
 // fastInflate against zlib (no GPU; built with ASan + UBSan by tests/test_host_fast_inflate.py):
 //   fast_inflate_check <seed> <cases>    -- differential cases: zlib's own output at every level / strategy / window, stored
 //                                            blocks, multi-block streams, then damaged copies of each (truncated, bits flipped)
-//   fast_inflate_check speed <MB>        -- MB/s of both decoders on BAM-like data in 64 KB blocks
+//   fast_inflate_check speed <MB> [threads] -- MB/s of both decoders on BAM-like data in 64 KB blocks
 // A case passes if fastInflate either declines (the callers then ask zlib) or returns exactly what zlib's inflate returns
 // for the same input and output size; on undamaged streams it must not decline.
 #include <portcullis/bam/fast_inflate.hpp>
 
 #include <zlib.h>
 
+#include <atomic>
 #include <chrono>
+#include <thread>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -91,6 +93,30 @@ int main(int argc, char** argv) {
         std::vector<std::vector<uint8_t>> comp;
         for (size_t o = 0; o < total; o += blk) comp.push_back(deflateRaw(std::vector<uint8_t>(data.begin() + (long)o, data.begin() + (long)std::min(total, o + blk)), 6, Z_DEFAULT_STRATEGY, 8, false));
         std::vector<uint8_t> out(total);
+        if (argc >= 4) {  // speed <MB> <threads>: the reader's loop -- threads take blocks from a counter, outputs side by side
+            const int nt = atoi(argv[3]);
+            for (int which = 0; which < 2; which++) {
+                const auto t0 = std::chrono::steady_clock::now();
+                for (int rep = 0; rep < 3; rep++) {
+                    std::atomic<size_t> next(0);
+                    std::vector<std::thread> th;
+                    for (int t = 0; t < nt; t++)
+                        th.emplace_back([&] {
+                            for (;;) {
+                                const size_t b = next.fetch_add(1);
+                                if (b >= comp.size()) break;
+                                const size_t o = b * blk, n = std::min(blk, total - o);
+                                if (which) (void)fastInflate(comp[b].data(), comp[b].size(), out.data() + o, n);
+                                else (void)zlibInflate(comp[b].data(), comp[b].size(), out.data() + o, n);
+                            }
+                        });
+                    for (auto& x : th) x.join();
+                }
+                const double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+                printf("%d threads, %s: %.0f MB/s%s\n", nt, which ? "fastInflate" : "zlib       ", 3.0 * (double)total / s / 1e6, out == data ? "" : "  WRONG");
+            }
+            return 0;
+        }
         for (int which = 0; which < 2; which++) {
             const auto t0 = std::chrono::steady_clock::now();
             bool ok = true;
