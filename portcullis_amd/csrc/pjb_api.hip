@@ -679,6 +679,25 @@ int pjb_create(pjb_ctx **out, const pjb_config *cfg) {
         return fail(nullptr, PJB_ERR_NO_DEVICE, "device %d (%s) is not a wave64 CDNA device", cfg->device, prop.gcnArchName);
     pjb_ctx *c = new (std::nothrow) pjb_ctx();
     if (!c) return fail(nullptr, PJB_ERR_NOMEM, "out of host memory");
+    // The kernels' attributes -- the first call loads the code object, 30 - 70 ms -- are set by a thread of their own while
+    // this one creates the streams (PJB_CREATE_SERIAL=1: afterwards, on this thread).
+    const int dev = cfg->device;
+    auto attributes = [dev] {
+        (void)hipSetDevice(dev);
+        (void)hipFuncSetAttribute((const void *)bgzf_inflate, hipFuncAttributeMaxDynamicSharedMemorySize, I2_LDS_BYTES);
+        (void)hipFuncSetAttribute((const void *)bgzf_decode, hipFuncAttributeMaxDynamicSharedMemorySize, I3_LDS_BYTES);
+        // 12-bit digits need more dynamic LDS than the 64 KB a kernel gets without asking
+        (void)hipFuncSetAttribute((const void *)rs_scatter<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rs_scatter_lds_bytes(RS_MAX_BITS));
+    };
+    const bool serial = getenv("PJB_CREATE_SERIAL") != nullptr;
+    std::thread attr_thread;
+    if (!serial) attr_thread = std::thread(attributes);
+    struct JoinAttr {
+        std::thread &t;
+        ~JoinAttr() {
+            if (t.joinable()) t.join();
+        }
+    } join_attr{attr_thread};
     c->cfg = *cfg;
     memset(&c->timing, 0, sizeof c->timing);
     e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
@@ -712,11 +731,9 @@ int pjb_create(pjb_ctx **out, const pjb_config *cfg) {
         int v = atoi(s);
         if (v >= 4 && v <= RS_MAX_BITS) c->radix_max_bits = v;
     }
-    (void)hipFuncSetAttribute((const void *)bgzf_inflate, hipFuncAttributeMaxDynamicSharedMemorySize, I2_LDS_BYTES);
-    (void)hipFuncSetAttribute((const void *)bgzf_decode, hipFuncAttributeMaxDynamicSharedMemorySize, I3_LDS_BYTES);
-    // 12-bit digits need more dynamic LDS than the 64 KB a kernel gets without asking
-    (void)hipFuncSetAttribute((const void *)rs_scatter<0>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)rs_scatter_lds_bytes(RS_MAX_BITS));
+    cmark("options");
+    if (serial) attributes();
+    else attr_thread.join();
     cmark("kernel attributes");
     *out = c;
     return PJB_OK;
