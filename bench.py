@@ -230,6 +230,7 @@ def main():
                 state.setdefault("per_chain", {})[tuple(g)] = ctx.timing()
 
         for g in chains:
+            tq0 = time.perf_counter()
             for tid in g:
                 c = contigs[tid]
                 ctx.submit_batch_device(tid, c["batch"], c["n"])
@@ -237,6 +238,7 @@ def main():
                 ctx.finish_contig_begin(g[0])
             else:
                 ctx.finish_group_begin(g)
+            state["host_queue_s"] = state.get("host_queue_s", 0.0) + time.perf_counter() - tq0  # (the host's share: PJB_BENCH_HOST_SPLIT)
             queued.append(g)
             if len(queued) >= args.queue:
                 collect_oldest()
@@ -289,9 +291,11 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    state["host_queue_s"] = 0.0
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    host_queue_ms = state["host_queue_s"] * 1e3 / max(args.steps, 1)  # the calling thread inside submit + begin, per step
     merged = xchg.finish() if xchg is not None else None  # the last exchange completes inside the timed region
     torch.cuda.synchronize()
     if world > 1:
@@ -463,6 +467,7 @@ def main():
             "device_kernel_ms_per_step": round(kernel_ms_per_step, 4),
             # sum of the kernels' own durations (one at a time) over the step's wall time: > 1 = what the streams overlap
             "overlap_factor": round(kernel_ms_per_step / (elapsed / args.steps * 1e3), 4),
+            "host_queue_ms_per_step": round(host_queue_ms, 3),  # the calling thread inside pjb_submit_batch_device + pjb_finish_*_begin
             "pipeline_gbps": round(tot_bytes / (kernel_ms_per_step * 1e-3) / 1e9, 1) if kernel_ms_per_step else None,
             "kernels": [dict(name=k["name"], launches_per_step=k["launches"] / args.steps, avg_ms=round(k["avg_ms"], 5),
                              ms_per_step=round(k["total_ms"] / args.steps, 4),
