@@ -274,6 +274,7 @@ struct pjb_ctx {
     int64_t mirror_acc[5] = {0, 0, 0, INT32_MAX, 0}; // spliced, unspliced, sum_len, min_len, max_len
     pjb_timing timing;
     int radix_max_bits = 11;
+    int k1s_blocks_forced = 0;                   // PJB_K1S_BLOCKS (tests): k1_scan_tiles on this many blocks -- 1: every tile in one block's rounds
     // optional per-kernel timing (the events live in the control slots)
     bool ktime = false;
     std::vector<std::string> knames;
@@ -727,6 +728,7 @@ int pjb_create(pjb_ctx **out, const pjb_config *cfg) {
     if (const char *s = getenv("PJB_DENSE_IDS")) c->dense_ids = atoi(s) != 0;
     if (const char *s = getenv("PJB_FUSED_K1")) c->fused_k1 = atoi(s) != 0;
     if (const char *s = getenv("PJB_SIDE_STREAM")) c->side_stream = atoi(s) != 0;
+    if (const char *s = getenv("PJB_K1S_BLOCKS")) c->k1s_blocks_forced = std::max(0, std::min(atoi(s), (int)K1S_BLOCKS));
     if (const char *s = getenv("PJB_RADIX_BITS")) {
         int v = atoi(s);
         if (v >= 4 && v <= RS_MAX_BITS) c->radix_max_bits = v;
@@ -1561,7 +1563,7 @@ static int queue_contig(pjb_ctx *c, Flight &f) {
             LAUNCH(c, "k1_walk", k1_walk, dim3(nt), dim3(K1W_THREADS), b, lk, n_tiles, (TileStats *)S.tile_stats.p,
                    want_splidx ? (u32 *)S.splidx.p : (u32 *)nullptr, pr, kf, ref_len, f.tid, (int)c->cfg.orientation, PL, d_err);
         }
-        LAUNCH(c, "k1_scan_tiles", k1_scan_tiles, dim3(k1s_blocks(n_tiles)), dim3(K1S_THREADS), (u32 *)nullptr, (const TileStats *)S.tile_stats.p, n_tiles,
+        LAUNCH(c, "k1_scan_tiles", k1_scan_tiles, dim3(c->k1s_blocks_forced ? (u32)c->k1s_blocks_forced : k1s_blocks(n_tiles)), dim3(K1S_THREADS), (u32 *)nullptr, (const TileStats *)S.tile_stats.p, n_tiles,
                d_cs, PL, kf, ref_len, (const u64 *)lk.tile_desc, (u32 *)nullptr, (u32 *)nullptr, (ScanPart *)S.scan_parts.p, ++S.scan_epoch);
     } else {
         // ---- K1a: count (a group's members: a tile whose alignments leave the member's own sequence is flagged); with
@@ -1596,7 +1598,7 @@ static int queue_contig(pjb_ctx *c, Flight &f) {
         if (group)
             LAUNCH(c, "kg_member_stats", kg_member_stats, dim3((unsigned)n_members), dim3(256), (const u32 *)S.tile_cnt.p, (const TileStats *)S.tile_stats.p,
                    (const u32 *)d_tile_lo, n_members, d_members);
-        LAUNCH(c, "k1_scan_tiles", k1_scan_tiles, dim3(k1s_blocks(n_tiles)), dim3(K1S_THREADS), (u32 *)S.tile_cnt.p, (const TileStats *)S.tile_stats.p,
+        LAUNCH(c, "k1_scan_tiles", k1_scan_tiles, dim3(c->k1s_blocks_forced ? (u32)c->k1s_blocks_forced : k1s_blocks(n_tiles)), dim3(K1S_THREADS), (u32 *)S.tile_cnt.p, (const TileStats *)S.tile_stats.p,
                n_tiles, d_cs, PL, kf, group ? INT32_MAX - 1 : ref_len, (const u64 *)nullptr, (u32 *)S.tile_soff.p, (u32 *)S.chunk_tile.p,
                (ScanPart *)S.scan_parts.p, ++S.scan_epoch);
         // ---- K1b: emit (coordinates in the group's virtual sequence)

@@ -80,10 +80,13 @@ def test_fullsize_matches_oracle(c2):
     assert_rows_equal(rows, orows)
 
 
-@pytest.mark.parametrize("env", [{"PJB_RADIX_BITS": "6"}, {"PJB_RADIX_BITS": "10"}, {"PJB_RADIX_BITS": "12"}])
+@pytest.mark.parametrize("env", [{"PJB_RADIX_BITS": "6"}, {"PJB_RADIX_BITS": "10"}, {"PJB_RADIX_BITS": "12"},
+                                 {"PJB_K1S_BLOCKS": "1"}, {"PJB_K1S_BLOCKS": "3"}, {"PJB_K1S_BLOCKS": "64"}])
 def test_sort_variants_agree(c2, monkeypatch, env):
     """The radix sort's digit width (unrolled 9/10/11-bit and generic match loops, 12-bit digits with
-    more than 64 KB of LDS) must not change a single byte of the row table."""
+    more than 64 KB of LDS) must not change a single byte of the row table.  Neither must the number of blocks
+    k1_scan_tiles scans the 9 766 tiles with: 1 (three rounds in one block, nobody to wait for), 3 (ranges of several
+    rounds behind predecessors), 64 (more blocks than the default's ten: short ranges)."""
     cfg, data, ctx0, reg, rows = c2
     from portcullis_amd import ffi
 
