@@ -164,3 +164,19 @@ def test_bulk_route_rejects_damaged_files(tmp_path, exe, how, ahead):
     assert p.returncode in (0, 3), (p.returncode, p.stderr[-2000:])
     if how in ("truncate_mid_block", "flip_header", "bad_isize"):
         assert p.returncode == 3 and "Error:" in p.stderr
+
+
+@pytest.mark.parametrize("n_reads", [0, 1])
+@pytest.mark.parametrize("route", ["0", "2 async"])
+def test_bulk_route_on_nearly_empty_files(tmp_path, exe, n_reads, route):
+    """A file with a header and no record (or one): nothing for the scan to deliver, nothing for the writer to hand over --
+    the output is the header (and the record), the EOF block and an index."""
+    refs = [("chr1", 5000), ("chr2", 3000)]
+    reads = [dict(tid=0, pos=100, cigar="50M", seq="A" * 50, flag=0, mapq=60, name="r1")][:n_reads]
+    src, dst = str(tmp_path / "in.bam"), str(tmp_path / "out.bam")
+    write_bam(src, refs, reads, block_size=1500)
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=1", UBSAN_OPTIONS="print_stacktrace=1")
+    p = subprocess.run([exe, src, dst, "3", "bulk", "70000", "0"] + route.split(), capture_output=True, text=True, timeout=300, env=env)
+    assert p.returncode == 0 and f"bulk raw={n_reads}" in p.stdout, p.stdout + p.stderr[-3000:]
+    assert gzip.open(dst, "rb").read() == gzip.open(src, "rb").read()
+    assert os.path.exists(dst + ".bai")
