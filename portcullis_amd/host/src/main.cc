@@ -75,9 +75,12 @@ int main(int argc, char* argv[]) {
     }
     // The program keeps ~15 HIP streams busy at once (file pieces, four inflate streams, the service stream, two per queued
     // chain, rows); the runtime maps them onto 4 hardware queues unless told otherwise, and streams that share a queue wait
-    // for each other.  8 queues: end to end 2.36 -> 2.18 s median of 7 (profiles/r03o_e2e_hw_queues.txt).  Read by the
-    // runtime when it starts, so it is set before anything touches HIP; a value the user exported wins.
-    setenv("GPU_MAX_HW_QUEUES", "8", 0);
+    // for each other.  8 queues: end to end 2.36 -> 2.18 s median of 7 (profiles/r03o_e2e_hw_queues.txt); at the round's last
+    // tree 6 is as good or a little better end to end (1.85 against 1.87 - 1.88 s; 4: 1.85 - 1.91, 12: 1.88 - 2.02;
+    // profiles/r03cq_e2e_hw_queues.txt), and the kernel chains alone -- the bench's step -- run 12.5 ms on 4 to 6 queues and
+    // 14.3 on 8 (profiles/r03cp_hw_queues.txt).  Read by the runtime when it starts, so it is set before anything touches
+    // HIP; a value the user exported wins.
+    setenv("GPU_MAX_HW_QUEUES", "6", 0);
     if (getenv("PJB_PROFILE_HOST")) {
         struct timespec ts;
         clock_gettime(CLOCK_REALTIME, &ts);
