@@ -86,11 +86,14 @@ def _split_records(data):
     return header, recs
 
 
-@pytest.mark.parametrize("mode,threads,route", [("HARD", 1, "default"), ("COMPLETE", 4, "default"), ("HARD", 3, "zlib"), ("SOFT", 2, "device")])
+@pytest.mark.parametrize("mode,threads,route", [("HARD", 1, "default"), ("COMPLETE", 4, "default"), ("HARD", 3, "zlib"), ("SOFT", 2, "device"),
+                                                ("HARD", 4, "handover"), ("SOFT", 1, "handover")])
 def test_bamfilt_program(tmp_path, orc, mode, threads, route, monkeypatch):
     if route == "zlib":     # output blocks compressed by zlib on the workers too, the scan in turns with the decisions
         monkeypatch.setenv("PORTCULLIS_HOST_DEFLATE", "1")
         monkeypatch.setenv("PORTCULLIS_SCAN_AHEAD", "0")
+    if route == "handover":  # the writer hands over every four blocks: gather beside the flush thread, device deflate per hand-over
+        monkeypatch.setenv("PORTCULLIS_FLUSH_BLOCKS", "4")
     if route == "device":   # input blocks inflated on the device, pageable buffers
         monkeypatch.setenv("PORTCULLIS_DEVICE_INFLATE", "1")
         monkeypatch.setenv("PORTCULLIS_PAGEABLE_BUFFERS", "1")
