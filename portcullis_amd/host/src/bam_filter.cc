@@ -48,9 +48,19 @@ BamFilter::BamFilter(const std::string& jf, const std::string& bf, const std::st
     if (!exists(bamFile)) throw BamFilterException("Could not find BAM file at: " + bamFile);
 }
 
+static std::chrono::steady_clock::time_point g_filterEnded;  // (PORTCULLIS_PROFILE: how long the release of filter()'s locals takes)
+
 void BamFilter::filter() {
     const bool profTop = getenv("PORTCULLIS_PROFILE") != nullptr;
     const auto tTop = std::chrono::steady_clock::now();
+    struct ScopeMark {  // (PORTCULLIS_PROFILE: when the locals declared before this one start to be released)
+        const char* what;
+        bool on;
+        std::chrono::steady_clock::time_point t0;
+        ~ScopeMark() {
+            if (on) fprintf(stderr, "[bamfilt profile] t=%.3f s: releasing what was declared before: %s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(), what);
+        }
+    };
     auto mark = [&](const char* what) {
         if (profTop) fprintf(stderr, "[bamfilt profile] t=%.3f s: %s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - tTop).count(), what);
     };
@@ -76,11 +86,17 @@ void BamFilter::filter() {
             }
         }
     } ctxGuard{&ctxComing};
+    ScopeMark sm_ctxGuard{"ctxGuard", profTop, tTop};
     cout << "Loading junctions from: " << junctionFile << endl;
-    JunctionSystem js(junctionFile);
+    // (the junctions and the reader's index are thousands of small allocations: in the command's forked child they are not
+    // taken apart one by one before the process ends -- see `leaves` below)
+    std::unique_ptr<JunctionSystem> jsHold(new JunctionSystem(junctionFile));
+    JunctionSystem& js = *jsHold;
     cout << " - Found " << js.size() << " junctions" << endl << endl;
     mark("junctions loaded");
-    bam::BamReader reader(bamFile);
+    std::unique_ptr<bam::BamReader> readerHold(new bam::BamReader(bamFile));
+    bam::BamReader& reader = *readerHold;
+    ScopeMark sm_reader{"reader", profTop, tTop};
     reader.open(useCsi);
     mark("BAM header and index read");
     std::shared_ptr<bam::RefSeqPtrList> refs = reader.createRefList();
@@ -114,15 +130,21 @@ void BamFilter::filter() {
         mark("junction keys on the device");
         return c1;
     }).share();
+    // In the forked child of the command (main.cc) the contexts and the page-locked buffers are left to the end of the
+    // process, which follows the report to the waiting side: taking them down here is 80 ms of the command's 0.7 s.
+    const bool leaves = getenv("PORTCULLIS_CHILD_LEAVES") != nullptr;
     struct Closer {
         std::shared_future<pjb_ctx*> f;
+        bool leaves;
         ~Closer() {
             try {
-                pjb_destroy(f.get());
+                pjb_ctx* c1 = f.get();
+                if (!leaves) pjb_destroy(c1);
             } catch (...) {
             }
         }
-    } closer{ctxReady};
+    } closer{ctxReady, leaves};
+    ScopeMark sm_closer{"closer", profTop, tTop};
     mark("context and junction keys on their way");
     cout << " - Processing alignments from: " << bamFile << endl;
     // BGZF blocks are compressed on the device (pjb_deflate_bgzf); PORTCULLIS_HOST_DEFLATE=1: by zlib on the workers.
@@ -136,14 +158,19 @@ void BamFilter::filter() {
     }).share();
     struct Closer2 {
         std::shared_future<pjb_ctx*> f;
+        bool leaves;
         ~Closer2() {
             try {
-                pjb_destroy(f.get());
+                pjb_ctx* c2 = f.get();
+                if (!leaves) pjb_destroy(c2);
             } catch (...) {
             }
         }
-    } closer2{deflateCtx};
-    bam::BamWriter writer(outputBam, threads);
+    } closer2{deflateCtx, leaves};
+    ScopeMark sm_closer2{"closer2", profTop, tTop};
+    std::unique_ptr<bam::BamWriter> writerHold(new bam::BamWriter(outputBam, threads));
+    bam::BamWriter& writer = *writerHold;
+    ScopeMark sm_writer{"writer", profTop, tTop};
     auto deflateOn = [](pjb_ctx* ctx, const uint8_t* in, size_t n, size_t block, bam::ByteBuf& out, std::vector<uint32_t>& sizes) -> bool {
         const size_t nblk = (n + block - 1) / block;
         // (room for a quarter more: a piece with more blocks than any before it would move the buffer, and a page-locked
@@ -172,13 +199,14 @@ void BamFilter::filter() {
             // (small buffers stay on the heap: page-locking means waiting for the runtime to come up, and the output's header
             // is written while it does)
             hooks.alloc = [](size_t n) -> void* { return n >= ((size_t)8 << 20) ? pjb_host_alloc(n) : nullptr; };
-            hooks.release = pjb_host_free;
+            hooks.release = leaves ? +[](void*) {} : pjb_host_free;
             bam::setBufferHooks(hooks);
         }
     }
     struct HooksOff {
         ~HooksOff() { bam::setBufferHooks(bam::BufferHooks()); }
     } hooksOff;
+    ScopeMark sm_hooksOff{"hooksOff", profTop, tTop};
     // PORTCULLIS_DEVICE_INFLATE=1: the input's blocks are inflated on the device too (pjb_inflate_bgzf, this thread's context)
     // instead of by zlib on the workers.  Not the default: bgzf_decode is a lane per block, a piece of 256 MB has 4 k blocks of
     // the 60 k the chip holds at once, and a lane needs 40 ms for its block -- 0.52 s for the configs[1] file against zlib's
@@ -217,10 +245,13 @@ void BamFilter::filter() {
     // pulling out (target, pos, CIGAR), gathering the kept records and compressing them (BamWriter::writeRecords); the
     // decision comes from the device, one batch per run of records of a target.
     const int32_t mode = clipMode == ClipMode::HARD ? PJB_CLIP_HARD : clipMode == ClipMode::SOFT ? PJB_CLIP_SOFT : PJB_CLIP_COMPLETE;
-    bam::PhasePool workers(threads > 1 ? threads : 0);
+    std::unique_ptr<bam::PhasePool> workersHold(new bam::PhasePool(threads > 1 ? threads : 0));
+    bam::PhasePool& workers = *workersHold;
+    ScopeMark sm_workers{"workers", profTop, tTop};
     std::vector<int32_t> tids, pos;
     std::vector<uint32_t> cigOff, cigar, runOff;
     std::vector<uint8_t> codes;
+    ScopeMark sm_vectors{"vectors", profTop, tTop};
     auto le32 = [](const uint8_t* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); };
     const bool prof = getenv("PORTCULLIS_PROFILE") != nullptr;
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
@@ -330,6 +361,14 @@ void BamFilter::filter() {
          << ");" << endl
          << endl;
     cout << "Indexing:" << endl << " - filtered alignments ... done." << endl;  // the .bai was written by BamWriter::close
+    if (leaves) {
+        (void)jsHold.release();
+        (void)readerHold.release();
+        (void)writerHold.release();  // (closed above)
+        (void)workersHold.release();
+    }
+    mark(leaves ? "filter() ends (the command's child: what it holds is left to the end of the process)" : "filter() ends (what it holds is released next)");
+    if (profTop) g_filterEnded = std::chrono::steady_clock::now();
 }
 
 std::string BamFilter::helpMessage() {
@@ -384,6 +423,9 @@ int BamFilter::main(int argc, char* argv[]) {
     filter.setVerbose(verbose);
     filter.setThreads(threads);
     filter.filter();
+    if (getenv("PORTCULLIS_PROFILE"))
+        fprintf(stderr, "[bamfilt profile] filter() returned %.3f s after its last statement\n",
+                std::chrono::duration<double>(std::chrono::steady_clock::now() - g_filterEnded).count());
     const double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     std::ios::fmtflags f(cout.flags());
     cout << endl << "Portcullis BAM filter completed." << endl << "Total runtime: " << std::fixed << std::setprecision(1) << s << "s" << endl << endl;

@@ -33,9 +33,11 @@ extern char** environ;
 int main(int argc, char* argv[]) {
     // exit codes as in src/portcullis.cc:497-515 of the reference
     int rc = 0;
-    // (not under a profiler or any other preloaded library: it may have started the GPU runtime in this process already, and
-    // a forked child must not inherit that)
-    bool plain = !getenv("LD_PRELOAD") && !getenv("HSA_TOOLS_LIB");
+    // (not under a profiler: its preloaded library may have started the GPU runtime in this process already, and a forked
+    // child must not inherit that.  Other preloaded libraries -- a sanitizer's runtime, a harness's exec guard -- do not
+    // touch the GPU, and the fork below happens before this program does)
+    const char* preload = getenv("LD_PRELOAD");
+    bool plain = !getenv("HSA_TOOLS_LIB") && !(preload && (strstr(preload, "rocprof") || strstr(preload, "roctracer") || strstr(preload, "roctx")));
     for (char** e = environ; plain && e && *e; e++)
         if (strncmp(*e, "ROCP", 4) == 0 || strncmp(*e, "ROCPROFILER", 11) == 0) plain = false;
     if (argc >= 2 && plain && !getenv("PORTCULLIS_NO_FORK") && !getenv("PJB_NORMAL_EXIT")) {
@@ -67,6 +69,9 @@ int main(int argc, char* argv[]) {
             if (pid == 0) {
                 close(fds[0]);
                 g_report_fd = fds[1];
+                // (the stages may leave device contexts and page-locked buffers to the end of the process: it comes right
+                // after the report, and nobody waits for it)
+                setenv("PORTCULLIS_CHILD_LEAVES", "1", 1);
             } else {  // fork failed: one process
                 close(fds[0]);
                 close(fds[1]);
