@@ -552,6 +552,29 @@ def cpu_baseline(contigs, cfgs, dev_rows, dev_regs, orientation, synth, partial=
             None if partial else hashlib.md5(tab).hexdigest(), len(tab))
 
 
+def wait_until_gone(exe, timeout=20.0):
+    """Seconds until no process named like `exe` is left in the process table (the forked child of the last `portcullis_amd`
+    command leaving -- it stays there until the driver has taken its device memory back): looks, never signals."""
+    name = os.path.basename(exe)[:15]  # (what /proc/<pid>/comm holds)
+    t0 = time.time()
+    while time.time() - t0 < timeout:
+        alive = False
+        for pid in os.listdir("/proc"):
+            if not pid.isdigit():
+                continue
+            try:
+                with open(os.path.join("/proc", pid, "comm")) as f:
+                    if f.read().strip() == name:
+                        alive = True
+                        break
+            except OSError:
+                pass
+        if not alive:
+            break
+        time.sleep(0.02)
+    return time.time() - t0
+
+
 def warm_file(path, threads, passes=2):
     """Reads the file `passes` times with `threads` readers (os.pread releases the GIL)."""
     import concurrent.futures as cf
@@ -640,6 +663,7 @@ def e2e_leg(contigs, cfgs, workdir, orientation, oracle_tab_md5, reads_arg, junc
     warm_file(bam, cores, passes=int(os.environ.get("PJB_BENCH_E2E_WARM_PASSES", 2)))
     t_warm = time.time() - t0
     warmup_run_s = None
+    waits = []
     if not os.environ.get("PJB_BENCH_E2E_NO_WARMUP_RUN"):
         t = time.time()
         p = subprocess.run([cli, "junc", "-t", str(cores), "--orientation", orientation, "-o", out, prep], capture_output=True, text=True)
@@ -656,10 +680,15 @@ def e2e_leg(contigs, cfgs, workdir, orientation, oracle_tab_md5, reads_arg, junc
             os.remove(out + ".junctions.tab")
         except OSError:
             pass
+        # The command returns when its outputs are written; the child that did the work is then still giving 100 GB of device
+        # memory back (host/src/main.cc).  A timed run starts when the run before it is gone from the process table, as a
+        # run on an idle box would (back to back they cost each other 0.5 s: profiles/r03cw_bench_C3.json).
+        quiet_s = wait_until_gone(cli)
         t = time.time()
         p = subprocess.run([cli, "junc", "-t", str(cores), "--orientation", orientation, "-o", out, prep],
                            capture_output=True, text=True, env=env)
         walls.append(time.time() - t)
+        waits.append(round(quiet_s, 3))
         if p.returncode != 0:
             raise RuntimeError("portcullis_amd junc failed: " + (p.stderr or p.stdout)[-400:])
         tab = open(out + ".junctions.tab", "rb").read()
@@ -681,6 +710,7 @@ def e2e_leg(contigs, cfgs, workdir, orientation, oracle_tab_md5, reads_arg, junc
            "tab_md5_checked_runs": len(md5s) if oracle_tab_md5 else 0,
            "path": "BGZF BAM bytes on disk (page cache warm) -> portcullis_amd junc (device ingest: pjb_submit_bam) -> .junctions.tab/.bed",
            "warmup_run_s": warmup_run_s,
+           "waited_for_the_previous_runs_child_s": waits,
            "prep_s": {"dump_soa": round(t_dump, 1), "soa2bam": round(t_bam, 1), "sync": round(t_sync, 1), "warm_passes": round(t_warm, 1), "cached": cached}}
     # ---- the CPU neighbour: same files, host cores only
     if not os.environ.get("PJB_BENCH_NO_E2E_CPU"):
