@@ -39,42 +39,49 @@ sys.path.insert(0, ROOT)
 PEAK_HBM_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 
 
-def algorithmic_bytes(name, N, C, S, Cs, P, J, L, Pg=0):
-    """Algorithmic HBM bytes of ONE launch of kernel `name` over one contig (each byte counted once per logical
+def algorithmic_bytes(name, N, C, S, Cs, P, J, L, Pg=0, Rg=0, R=0, cand=0):
+    """Algorithmic HBM bytes of ONE launch of kernel `name` over one chain (each byte counted once per logical
     pass, caches ignored; DESIGN.md section 4 derives these).  N reads, C cigar ops, S spliced reads, Cs cigar ops
-    of spliced reads, P pairs, J junctions, L read length, Pg pairs that take the generic walks."""
+    of spliced reads, P pairs, J junctions, L read length, Pg pairs / Rg reads that take the generic walks, R
+    position runs, cand candidate keys."""
     frags = P / 64.0 + J
+    ops_s = Cs / max(S, 1)  # cigar ops of a spliced read
     table = {
         # pos, cig_off, l_qseq, xs + every cigar op; 8 B written per spliced read (compacted index + pair offset)
         "k1_count": N * 13 + C * 4 + S * 8,
-        # spliced reads only: compacted slot (8), cig_off (8), pos/flag/mapq/xs (8), ops fetched once; 44 B written per pair
-        # (36 B of pair fields + the address of the read's bases for k4a_simple)
-        "k1_emit": S * 24 + Cs * 4 + P * 44,
-        # one pass over the records: cig_off, pos, l_qseq, mtid, mpos, seq_off (4 B each), flag (2), mapq, xs (1 each) and every
-        # cigar op, read once; 44 B written per pair
-        "k1_walk": N * 28 + C * 4 + P * 44,
-        # K2d, ordered dense junction ids: keys read three times (8 B), ids written once (8 B); the bitmap / rank / end tables are
-        # contig-sized and small beside the pairs
-        "kd_unique": P * 8,
-        "kd_assign": P * 16,
+        # spliced reads only: compacted slot + pair offset (8), cig_off, pos, l_qseq, mtid, mpos, seq_off (4 each), flag (2),
+        # mapq, xs (1 each), the ops once; per pair 8 B key + 32 B record written; reads of the simple shape: L/2 B of packed
+        # bases + L/2 B of genome codes; 8 B list entry per generic read; candidate keys
+        "k1_emit": S * 36 + Cs * 4 + P * 40 + (P - Pg) * L + Rg * 8 + cand * 8,
+        # K2d: key (8) + lStart/rEnd half of the record (16) read, id written twice (8 B sort key, 4 B BAM-order id)
+        "kd_assign": P * 36 + J * 192,
+        "kd_mark": cand * 8, "kd_ends": cand * 12, "kd_table": cand * 12 + J * 8, "kd_reset": cand * 12,
         "rs_hist": P * 8,
         "rs_scatter": P * 24,
-        "k2_heads_reduce": P * 20,
-        "k2_heads_apply": P * 20 + P * 4 + (J + J + P / 8) * 4,
-        "k3_anchors_frag": P * 16 + frags * 12,
-        # simple pairs: meta, key, pos, rend, address of the bases (8), packed read bases L/2, 4-bit genome codes L/2,
-        # 8-byte result; other pairs read the same 28 B of pair fields and stop
-        "k4a_simple": (P - Pg) * (4 + 8 + 4 + 4 + 8 + L + 8) + Pg * 28,
-        # generic pairs: list entry, idx, jid, key, ordinal, cig_off (8), ops, pos/aend, l_qseq, seq_off (8), anchors (8),
-        # read bases + genome codes (L), result
-        "k4b_generic": Pg * (4 + 4 + 4 + 8 + 4 + 8 + 4 * (Cs / max(S, 1)) + 8 + 4 + 8 + 8 + L + 8),
-        # key, idx, jid, pos, aend, result, meta, previous pair (16), lstart, rend, updown; one 192-B fragment record
-        "k4_pairs": P * (8 + 4 + 4 + 4 + 4 + 8 + 4 + 16 + 4 + 4 + 4) + frags * 196,
+        # sorted key (8) + index (4) + the position word of the record behind it (4); the apply pass writes the junction id
+        "k2_heads_reduce": P * 16,
+        "k2_heads_apply": P * 16 + P * 4 + (J + J + R) * 4,
+        # generic reads: list entry (8), cig_off (8), ops, pos/aend half of the first record (16), l_qseq, seq_off (12), L/2 B of
+        # bases; per generic pair: id (4), key (8), anchors (8), genome codes of its window (~L/2), result (8)
+        "k4b_generic": Rg * (44 + 4 * ops_s + L / 2) + Pg * (28 + L / 2),
+        # sorted index + id (8), ONE 32-B record, the junction's key (J entries, cached); one 192-B fragment record + its id
+        "k4_pairs": P * 40 + frags * 196,
         "k5_frag_reduce": frags * 196 + J * 164,
-        "k5_finalize": J * (192 + 24 + 48 + 200),
-        "k5_entropy_terms": J * 8,
+        "k5_finalize": J * (192 + 8 + 8 + 8 + 48 + 200),
+        # per run: run_start (two neighbours: 4), id of its first pair (4), 8-B term written; per junction seg_off / run_first
+        "k5_entropy_terms": R * 16 + J * 16,
+        "k5_entropy_sum": R * 8 + J * 16,
+        "k6_rows_out": J * 200 * 2,
     }
     return table.get(name)
+
+
+def survey_bytes(N, C, S, Cs, P, J, L):
+    """SURVEY.md section 8(d)'s formula for the whole path (what a step is priced at whatever the implementation moves):
+    N (18 + 4 c) + P (24 + 128 + 16 + 36 + 1.5 A + 4 c_s + 16 + 32) + 264 J with A = mean anchor span per pair = L."""
+    c_bar = C / max(N, 1)
+    cs_bar = Cs / max(S, 1)
+    return N * (18 + 4 * c_bar) + P * (24 + 128 + 16 + 36 + 1.5 * L + 4 * cs_bar + 16 + 32) + J * 264
 
 
 def free_port():
@@ -356,7 +363,6 @@ def main():
             kt[dominant] = kt_timed[dominant]  # measured live over the timed region (beside whatever overlapped it)
         per = state.get("per_chain", {})
         kern = []
-        per_target_kernels = ("k1_count", "k1_emit", "k1_walk")  # launched once per target; everything else once per chain
         for name, (launches, ms) in kt.items():
             if launches == 0:
                 continue
@@ -369,7 +375,8 @@ def main():
                 Jc = sum(int(regs[t]["n_junctions"]) for t in g)
                 tm = per.get(tuple(g), {})
                 b = algorithmic_bytes(name, sum(c["n"] for c in cs_), sum(c["C"] for c in cs_), sum(c["S"] for c in cs_),
-                                      sum(c["Cs"] for c in cs_), sum(c["P"] for c in cs_), Jc, L, int(tm.get("generic_pairs", 0)))
+                                      sum(c["Cs"] for c in cs_), sum(c["P"] for c in cs_), Jc, L, int(tm.get("generic_pairs", 0)),
+                                      int(tm.get("generic_reads", 0)), int(tm.get("position_runs", 0)), int(tm.get("candidates", 0)))
                 if b is None:
                     known = False
                     break
@@ -402,6 +409,11 @@ def main():
         roofline["step_alg_bytes"] = int(step_bytes)
         roofline["step_achieved"] = round(step_bytes / (elapsed / args.steps) / 1e9, 1)
         roofline["step_frac"] = round(roofline["step_achieved"] / PEAK_HBM_GBPS, 4)
+        # the same step priced by SURVEY.md section 8(d)'s formula (independent of what this implementation moves)
+        sv = sum(survey_bytes(c["n"], c["C"], c["S"], c["Cs"], c["P"], int(regs[t]["n_junctions"]), L) for t, c in contigs.items())
+        roofline["step_alg_bytes_survey"] = int(sv)
+        roofline["step_frac_survey"] = round(sv / (elapsed / args.steps) / 1e9 / PEAK_HBM_GBPS, 4)
+        roofline["kernels_without_formula"] = sorted(k["name"] for k in kern if not k["alg_bytes"])
         # HBM bytes per launch from the PMC counters (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 --pmc passes of
         # this same command: tools/pmc_traffic.sh -> tools/summarize_pmc.py).  Counters cannot be read from inside
         # the process; the committed measurement for this workload is attached with the commit it was taken at.
@@ -465,6 +477,7 @@ def main():
             "e2e": e2e,
             "multi_gpu_check": verify,
             "device_kernel_ms_per_step": round(kernel_ms_per_step, 4),
+            "launches_per_step": round(sum(k["launches"] for k in kern) / args.steps, 1),
             # sum of the kernels' own durations (one at a time) over the step's wall time: > 1 = what the streams overlap
             "overlap_factor": round(kernel_ms_per_step / (elapsed / args.steps * 1e3), 4),
             "host_queue_ms_per_step": round(host_queue_ms, 3),  # the calling thread inside pjb_submit_batch_device + pjb_finish_*_begin

@@ -49,7 +49,10 @@
 extern "C" {
 #endif
 
-#define PJB_ABI_VERSION 2 /* 2: pjb_batch.name_hash, PJB_FLAG_EXTRA, pjb_extra_finish */
+#define PJB_ABI_VERSION 3 /* 2: pjb_batch.name_hash, PJB_FLAG_EXTRA, pjb_extra_finish
+                           * 3: pjb_timing grew (generic_reads, position_runs, candidates); PJB_MAX_QUEUED 8; pjb_last_error is per calling
+                           *    thread; additive since 2: PJB_FLAG_NO_CHAINS, pjb_finish_group_begin/_end, pjb_finish_ready, pjb_deflate_bgzf,
+                           *    pjb_host_register/_unregister; the option "fused_k1" is gone */
 
 /* ---- status codes ------------------------------------------------------ */
 #define PJB_OK 0
@@ -180,7 +183,10 @@ typedef struct pjb_timing {
     float stage_ms[PJB_N_STAGES]; /* scan/emit, sort, group, anchors, pair stats, finalise, d2h, (spare): filled only under
                                      PJB_FLAG_KERNEL_TIMING with no kernel selection (an event between kernels costs a bubble) */
     int64_t sort_passes;
-    int64_t generic_pairs; /* pairs that took the generic CIGAR walks (k4b) instead of the [S]MNM[S] fast path (k4a) */
+    int64_t generic_pairs; /* pairs that took the generic CIGAR walks (k4b_generic) instead of k1_emit's [S]MNM[S] fast path */
+    int64_t generic_reads; /* the reads those pairs belong to */
+    int64_t position_runs; /* runs of equal read position inside the junctions (the units of the entropy kernels) */
+    int64_t candidates;    /* candidate keys the dense junction ids were built from (0: the chain sorted the full keys) */
 } pjb_timing;
 
 /* ---- entry points ------------------------------------------------------ */

@@ -145,16 +145,14 @@ struct CtlSlot {
     Buf tile_cnt, tile_stats, splidx, splpoff, tile_soff, chunk_tile;
     Buf scan_parts;     // k1_scan_tiles: ScanPart[K1S_BLOCKS], zeroed once; scan_epoch tells one launch's parts from the last one's
     u32 scan_epoch = 0;
-    Buf k1look; // k1_walk: ticket counter, tile and group descriptors
     Buf members; // groups: MemberStats[GROUP_MAX] | member_junc u32[GROUP_MAX] | tile_lo u32[GROUP_MAX + 1]
-    Buf okey, g, lstart, rend, pos, aend, meta, updown, seqw; // the pairs (BAM order)
-    Buf res;                                                  // k4a_simple / k4b_generic results per pair
+    Buf okey, rec, g, jidbam; // the pairs (BAM order): intron keys, 32-byte records, [--extra: read ordinals], junction ids
     hipEvent_t ev_k1 = nullptr;
     hipEvent_t ev_xk1 = nullptr; // --extra: k1_count has left the records' spans (XOut) in the slot's scratch
     // the rest of the chain's scratch, and its streams: the chains of the two slots run side by side (most kernels of a
     // contig-sized chain are latency-bound and leave the chip half idle)
     Buf total, bitmap, wrank, ends, firstid, key[2], idx[2], hist, hist_scan, hist_part, bintotal, scan_tiles;
-    Buf jid, seg, runfirst, runstart, ent, entsum, frag, fragj, fragl, fragr, acc, ancl, ancr, genlist;
+    Buf jid, seg, runfirst, runstart, ent, entsum, frag, fragj, acc, ancl, ancr, jkey, genlist;
     bool dense_at_rest = false;
     hipStream_t main = nullptr, side = nullptr; // chain; match statistics / entropy beside it
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_fork2 = nullptr, ev_join2 = nullptr;
@@ -187,7 +185,7 @@ struct Flight {
     int slot = 0;
     bool queued = false;   // its kernels are on the streams
     bool empty = false;    // no batches: nothing to queue
-    bool forked = false;   // k4a_simple went to the side stream (the contig's batches must outlive it)
+    bool forked = false;   // k4b_generic went to the side stream (the contig's batches must outlive it)
     ContigLimits lim;
     int64_t n_reads = 0;
     u32 n_tiles = 0;
@@ -259,7 +257,6 @@ struct pjb_ctx {
     int last_slot = 0; // slot of the contig collected last (pjb_collect_device)
     int inflate_lanes = 512 * 64;                // lanes of one bgzf_inflate launch (2 workgroups x 256 CUs; set from the device at create)
     bool side_stream = true;                     // k4a_simple beside the sort (PJB_SIDE_STREAM=0: on the main stream)
-    bool fused_k1 = false;                       // PJB_FUSED_K1=1: the one-pass k1_walk instead of k1_count + k1_scan_tiles + k1_emit
     bool dense_ids = true;                       // K2d (PJB_DENSE_IDS=0 sorts the full keys as round 1 did)
     u32 junc_seen = 0;                           // most junctions a contig has had so far (junction limit of the next contig)
     int lbits_seen = 18;                         // bits of the longest intron this context has met (key format of the next contig)
@@ -726,7 +723,6 @@ int pjb_create(pjb_ctx **out, const pjb_config *cfg) {
     c->ktime = (cfg->flags & PJB_FLAG_KERNEL_TIMING) != 0;
     c->extra = (cfg->flags & PJB_FLAG_EXTRA) != 0;
     if (const char *s = getenv("PJB_DENSE_IDS")) c->dense_ids = atoi(s) != 0;
-    if (const char *s = getenv("PJB_FUSED_K1")) c->fused_k1 = atoi(s) != 0;
     if (const char *s = getenv("PJB_SIDE_STREAM")) c->side_stream = atoi(s) != 0;
     if (const char *s = getenv("PJB_K1S_BLOCKS")) c->k1s_blocks_forced = std::max(0, std::min(atoi(s), (int)K1S_BLOCKS));
     if (const char *s = getenv("PJB_RADIX_BITS")) {
@@ -768,10 +764,10 @@ void pjb_destroy(pjb_ctx *c) {
             if (ev) (void)hipEventDestroy(ev);
         if (S.ev_rows) (void)hipEventDestroy(S.ev_rows);
         if (S.ev_done) (void)hipEventDestroy(S.ev_done);
-        Buf *sb[] = {&S.x_q, &S.x_spos, &S.x_send, &S.x_gapoff, &S.x_zlist, &S.x_scnt, &S.x_codes, &S.cstats, &S.err, &S.gencount, &S.batches, &S.rows, &S.tile_cnt, &S.tile_stats, &S.splidx, &S.splpoff, &S.tile_soff, &S.chunk_tile, &S.scan_parts, &S.k1look, &S.members, &S.okey, &S.g,
-                     &S.lstart, &S.rend, &S.pos, &S.aend, &S.meta, &S.updown, &S.seqw, &S.res, &S.total, &S.bitmap, &S.wrank, &S.ends, &S.firstid,
+        Buf *sb[] = {&S.x_q, &S.x_spos, &S.x_send, &S.x_gapoff, &S.x_zlist, &S.x_scnt, &S.x_codes, &S.cstats, &S.err, &S.gencount, &S.batches, &S.rows, &S.tile_cnt, &S.tile_stats, &S.splidx, &S.splpoff, &S.tile_soff, &S.chunk_tile, &S.scan_parts, &S.members, &S.okey, &S.g,
+                     &S.rec, &S.jidbam, &S.jkey, &S.total, &S.bitmap, &S.wrank, &S.ends, &S.firstid,
                      &S.key[0], &S.key[1], &S.idx[0], &S.idx[1], &S.hist, &S.hist_scan, &S.hist_part, &S.bintotal, &S.scan_tiles, &S.jid, &S.seg, &S.runfirst,
-                     &S.runstart, &S.ent, &S.entsum, &S.frag, &S.fragj, &S.fragl, &S.fragr, &S.acc, &S.ancl, &S.ancr, &S.genlist};
+                     &S.runstart, &S.ent, &S.entsum, &S.frag, &S.fragj, &S.acc, &S.ancl, &S.ancr, &S.genlist};
         for (Buf *b : sb) release(*b);
         hipEvent_t evs[] = {S.ev_k1, S.ev_xk1, S.ev_fork, S.ev_join, S.ev_fork2, S.ev_join2};
         for (hipEvent_t e : evs)
@@ -1434,12 +1430,13 @@ static int queue_contig(pjb_ctx *c, Flight &f) {
     if ((rc = ensure(c, S.tile_stats, (size_t)n_tiles * sizeof(TileStats)))) return rc;
     if ((rc = ensure(c, S.tile_soff, ((size_t)n_tiles + 1) * 4))) return rc;
     if ((rc = ensure(c, S.chunk_tile, ((size_t)n_tiles * (K1_TILE / 256) + 4) * 4))) return rc;
-    const bool fused_k1 = c->fused_k1 && !group; // (the one-pass walk is a single-target experiment)
-    const bool want_splidx = !fused_k1 || c->extra; // (--extra reads the tiles' spliced lists)
-    if (want_splidx && (rc = ensure(c, S.splidx, (size_t)n_tiles * K1_TILE * 4))) return rc;
-    if (!fused_k1 && (rc = ensure(c, S.splpoff, (size_t)n_tiles * K1_TILE * 4))) return rc;
-    if (fused_k1 && (rc = ensure(c, S.k1look, k1look_bytes(n_tiles)))) return rc;
-    if ((rc = ensure(c, S.members, GROUP_MAX * sizeof(MemberStats) + GROUP_MAX * 4 + (GROUP_MAX + 1) * 4))) return rc;
+    if ((rc = ensure(c, S.splidx, (size_t)n_tiles * K1_TILE * 4))) return rc;
+    if ((rc = ensure(c, S.splpoff, (size_t)n_tiles * K1_TILE * 4))) return rc;
+    if (!S.members.p) {
+        if ((rc = ensure(c, S.members, GROUP_MAX * sizeof(MemberStats) + GROUP_MAX * 4 + (GROUP_MAX + 1) * 4))) return rc;
+        HIP_TRY(c, hipMemset(S.members.p, 0, S.members.cap)); // (member_junc: k7_publish leaves it zeroed for the next chain)
+        HIP_TRY(c, hipStreamSynchronize(nullptr));
+    }
     MemberStats *d_members = (MemberStats *)S.members.p;
     u32 *d_member_junc = (u32 *)(d_members + GROUP_MAX);
     u32 *d_tile_lo = d_member_junc + GROUP_MAX;
@@ -1450,28 +1447,26 @@ static int queue_contig(pjb_ctx *c, Flight &f) {
     if ((rc = ensure(c, S.key[1], ((size_t)PL + RS_TILE) * 8))) return rc;
     if ((rc = ensure(c, S.idx[0], ((size_t)PL + RS_TILE) * 4))) return rc;
     if ((rc = ensure(c, S.idx[1], ((size_t)PL + RS_TILE) * 4))) return rc;
-    Buf *pb[] = {&S.g, &S.lstart, &S.rend, &S.pos, &S.aend, &S.meta, &S.updown, &S.jid};
-    for (Buf *b : pb)
-        if ((rc = ensure(c, *b, (size_t)PL * 4 + 16))) return rc;
-    if ((rc = ensure(c, S.res, (size_t)PL * 8 + 16))) return rc;
-    if ((rc = ensure(c, S.seqw, (size_t)PL * 8 + 16))) return rc;
+    if ((rc = ensure(c, S.rec, ((size_t)PL + 1) * sizeof(PairRec)))) return rc;
+    if ((rc = ensure(c, S.jid, (size_t)PL * 4 + 16))) return rc;
+    if ((rc = ensure(c, S.jidbam, (size_t)PL * 4 + 16))) return rc;
+    if (c->extra && (rc = ensure(c, S.g, (size_t)PL * 4 + 16))) return rc;
     if ((rc = ensure(c, S.seg, ((size_t)PL + 1) * 4))) return rc;
     if ((rc = ensure(c, S.runfirst, ((size_t)PL + 1) * 4))) return rc;
     if ((rc = ensure(c, S.runstart, ((size_t)PL + 1) * 4))) return rc;
     if ((rc = ensure(c, S.ent, (size_t)PL * 8 + 16))) return rc;
     const u32 pair_blocks = std::max<u32>(1, (PL + 255) / 256);
-    const u32 gen_cap = ((pair_blocks + GEN_SHARDS - 1) / GEN_SHARDS) * 256; // entries per sub-list
-    if ((rc = ensure(c, S.genlist, (size_t)gen_cap * GEN_SHARDS * 4))) return rc;
-    if ((rc = ensure(c, S.gencount, GEN_SHARDS * 4))) return rc;
+    const u32 gen_cap = gen_list_cap(PL); // entries per sub-list
+    if ((rc = ensure(c, S.genlist, (size_t)gen_cap * GEN_SHARDS * 8))) return rc;
+    if ((rc = ensure(c, S.gencount, 2 * GEN_SHARDS * 4))) return rc; // reads | pairs of each sub-list
     // ---- junction-sized buffers
     const u32 slots_lim = JL + (PL + 63) / 64 + 1;
     if ((rc = ensure(c, S.frag, (size_t)slots_lim * F_WORDS * 4))) return rc;
     if ((rc = ensure(c, S.fragj, (size_t)slots_lim * 4))) return rc;
-    if ((rc = ensure(c, S.fragl, (size_t)slots_lim * 4))) return rc;
-    if ((rc = ensure(c, S.fragr, (size_t)slots_lim * 4))) return rc;
     if ((rc = ensure(c, S.acc, (size_t)JL * F_WORDS * 4 + 16))) return rc;
     if ((rc = ensure(c, S.ancl, (size_t)JL * 4 + 16))) return rc;
     if ((rc = ensure(c, S.ancr, (size_t)JL * 4 + 16))) return rc;
+    if ((rc = ensure(c, S.jkey, (size_t)JL * 8 + 16))) return rc;
     if ((rc = ensure(c, S.rows, (size_t)JL * sizeof(pjb_junction_row) + 16))) return rc;
     // The row table lives twice, both grow-only: in HBM, where the rows stream appends each contig's rows (k6_rows_out),
     // and in page-locked host memory, filled by a DMA per contig once its row count is known (pjb_finish_contig_end).
@@ -1530,7 +1525,8 @@ static int queue_contig(pjb_ctx *c, Flight &f) {
     }
     if (!S.at_rest) {
         HIP_TRY(c, hipMemsetAsync(S.err.p, 0xff, 8, front));
-        HIP_TRY(c, hipMemsetAsync(S.gencount.p, 0, GEN_SHARDS * 4, front));
+        HIP_TRY(c, hipMemsetAsync(S.gencount.p, 0, 2 * GEN_SHARDS * 4, front));
+        HIP_TRY(c, hipMemsetAsync(d_member_junc, 0, GROUP_MAX * 4, front));
     }
     S.at_rest = false; // until k7_publish is queued
     u64 *d_err = (u64 *)S.err.p;
@@ -1545,27 +1541,12 @@ static int queue_contig(pjb_ctx *c, Flight &f) {
     HIP_TRY(c, hipEventRecord(S.ev[0], front));
     Pairs pr;
     pr.key = (u64 *)S.okey.p;
-    pr.g = (u32 *)S.g.p;
-    pr.lstart = (int32_t *)S.lstart.p;
-    pr.rend = (int32_t *)S.rend.p;
-    pr.pos = (int32_t *)S.pos.p;
-    pr.aend = (int32_t *)S.aend.p;
-    pr.meta = (u32 *)S.meta.p;
-    pr.updown = (u32 *)S.updown.p;
-    pr.seqw = (u64 *)S.seqw.p;
+    pr.rec = (PairRec *)S.rec.p;
+    pr.g = c->extra ? (u32 *)S.g.p : (u32 *)nullptr;
     f.pr = pr;
-    if (fused_k1) {
-        // ---- K1 in one pass: count, place (tile and group descriptors) and emit
-        const K1Look lk = k1look_at(S.k1look.p, n_tiles);
-        HIP_TRY(c, hipMemsetAsync(S.k1look.p, 0, k1look_bytes(n_tiles), front));
-        for (auto &b : batches) {
-            const u32 nt = (u32)((b.n + K1_TILE - 1) / K1_TILE);
-            LAUNCH(c, "k1_walk", k1_walk, dim3(nt), dim3(K1W_THREADS), b, lk, n_tiles, (TileStats *)S.tile_stats.p,
-                   want_splidx ? (u32 *)S.splidx.p : (u32 *)nullptr, pr, kf, ref_len, f.tid, (int)c->cfg.orientation, PL, d_err);
-        }
-        LAUNCH(c, "k1_scan_tiles", k1_scan_tiles, dim3(c->k1s_blocks_forced ? (u32)c->k1s_blocks_forced : k1s_blocks(n_tiles)), dim3(K1S_THREADS), (u32 *)nullptr, (const TileStats *)S.tile_stats.p, n_tiles,
-               d_cs, PL, kf, ref_len, (const u64 *)lk.tile_desc, (u32 *)nullptr, (u32 *)nullptr, (ScanPart *)S.scan_parts.p, ++S.scan_epoch);
-    } else {
+    u32 *d_gen_reads = (u32 *)S.gencount.p, *d_gen_pairs = d_gen_reads + GEN_SHARDS;
+    const bool fast_codes = all_codes && !any_x; // (else: no read is "simple", every pair takes k4b_generic's byte-wise walks)
+    {
         // ---- K1a: count (a group's members: a tile whose alignments leave the member's own sequence is flagged); with
         // PJB_FLAG_EXTRA the first time also what the records span (a chain that is queued again leaves that alone: the
         // service stream may be reading it)
@@ -1601,7 +1582,15 @@ static int queue_contig(pjb_ctx *c, Flight &f) {
         LAUNCH(c, "k1_scan_tiles", k1_scan_tiles, dim3(c->k1s_blocks_forced ? (u32)c->k1s_blocks_forced : k1s_blocks(n_tiles)), dim3(K1S_THREADS), (u32 *)S.tile_cnt.p, (const TileStats *)S.tile_stats.p,
                n_tiles, d_cs, PL, kf, group ? INT32_MAX - 1 : ref_len, (const u64 *)nullptr, (u32 *)S.tile_soff.p, (u32 *)S.chunk_tile.p,
                (ScanPart *)S.scan_parts.p, ++S.scan_epoch);
-        // ---- K1b: emit (coordinates in the group's virtual sequence)
+        // ---- K1b: emit (coordinates in the group's virtual sequence): keys, the pairs' records -- complete for reads of the
+        // simple shape --, K2d's candidate keys (free until the first scatter; they are used up before it), the list of
+        // reads for k4b_generic
+        EmitLists el;
+        el.cand = lim.dense ? (u64 *)S.key[1].p : (u64 *)nullptr;
+        el.gen_list = (u64 *)S.genlist.p;
+        el.gen_reads = d_gen_reads;
+        el.gen_pairs = d_gen_pairs;
+        el.gen_cap = gen_cap;
         for (size_t bi = 0; bi < batches.size(); bi++) {
             const DevBatch &b = batches[bi];
             const int m = f.batch_member[bi];
@@ -1610,25 +1599,32 @@ static int queue_contig(pjb_ctx *c, Flight &f) {
             // (a tile holds ~300 spliced reads = 1.2 chunks of 256: a grid of half the tiles keeps two or three chunks per block)
             const u32 grid = std::max<u32>(1, std::min<u32>(nt, std::max<u32>(1024, nt / 2)));
             LAUNCH(c, "k1_emit", k1_emit, dim3(grid), dim3(256), b, nt, n_tiles, (const u32 *)S.tile_cnt.p, (const u32 *)S.tile_soff.p,
-                   (const u32 *)S.chunk_tile.p, (const u32 *)S.splidx.p, (const u32 *)S.splpoff.p, pr, kf, own_len,
-                   own_tid, (int)c->cfg.orientation, d_err, (const ContigStats *)d_cs, f.voff[(size_t)m]);
+                   (const u32 *)S.chunk_tile.p, (const u32 *)S.splidx.p, (const u32 *)S.splpoff.p, pr, el, kf, own_len,
+                   own_tid, (int)c->cfg.orientation, d_err, d_cs, f.voff[(size_t)m], fast_codes ? (const u32 *)GT.codes[m] : (const u32 *)nullptr);
         }
     }
-    // ---- K4a: match statistics of the common [S] M N M [S] shape, in BAM order, while the keys are still unsorted:
-    // on the side stream, beside the sort of the main stream (joined before pass 1 overwrites the keys)
-    const bool fast_codes = all_codes && !any_x;
-    if (fast_codes && !c->side_stream) { // (PJB_SIDE_STREAM=0: one kernel at a time, for clean per-kernel timings)
-        LAUNCH(c, "k4a_simple", k4a_simple, dim3(pair_blocks), dim3(256), pr, kf, GT, d_P, (u64 *)S.res.p);
-    } else if (fast_codes) {
-        HIP_TRY(c, hipEventRecord(S.ev_fork, front));
+    STAGE_EVENT(1);
+    // k4b_generic: the pairs that need the generic walks, in BAM order, as soon as junction ids and anchors exist -- beside
+    // the sort, on the side stream
+    const u32 gen_grid = (u32)(((u64)gen_cap * GEN_SHARDS + 255) / 256);
+    auto launch_k4b = [&]() -> int {
+        LAUNCH(c, "k4b_generic", k4b_generic, dim3(gen_grid), dim3(256), (const u64 *)S.genlist.p, (const u32 *)d_gen_reads, gen_cap, (const u64 *)pr.key,
+               pr.rec, (const u32 *)S.jidbam.p, kf, (const DevBatch *)S.batches.p, (int)batches.size(), (const int32_t *)S.ancl.p, (const int32_t *)S.ancr.p,
+               GT, any_x ? 1 : 0, any_x ? 0 : 1, d_err);
+        return PJB_OK;
+    };
+    auto fork_k4b = [&]() -> int { // (the main stream has just produced jid_bam and the anchors)
+        if (!c->side_stream) return launch_k4b();
+        HIP_TRY(c, hipEventRecord(S.ev_fork, st));
         HIP_TRY(c, hipStreamWaitEvent(S.side, S.ev_fork, 0));
         c->stream = S.side;
         f.forked = true;
-        LAUNCH(c, "k4a_simple", k4a_simple, dim3(pair_blocks), dim3(256), pr, kf, GT, d_P, (u64 *)S.res.p);
+        const int rc2 = launch_k4b();
+        c->stream = st;
+        if (rc2) return rc2;
         HIP_TRY(c, hipEventRecord(S.ev_join, S.side));
-    }
-    c->stream = st;
-    STAGE_EVENT(1);
+        return PJB_OK;
+    };
 
     // ---- K2d: ordered dense junction ids (the sort then works on 15-19 bits instead of 46-48)
     int sort_bits = kf.total_bits;
@@ -1645,9 +1641,7 @@ static int queue_contig(pjb_ctx *c, Flight &f) {
         }
         S.dense_at_rest = false; // until kd_reset is queued
         const u64 *okey = (const u64 *)pr.key;
-        const u32 kd_tiles = std::max<u32>(1, (PL + KD_TILE - 1) / KD_TILE);
-        u64 *cand = (u64 *)S.key[1].p; // (free until the first scatter; the candidates are used up before it)
-        LAUNCH(c, "kd_unique", kd_unique, dim3(kd_tiles), dim3(256), okey, d_P, cand, d_cs);
+        u64 *cand = (u64 *)S.key[1].p; // (k1_emit left the candidate keys here)
         LAUNCH(c, "kd_mark", kd_mark, dim3(pair_blocks), dim3(256), (const u64 *)cand, (const ContigStats *)d_cs, kf, (u64 *)S.bitmap.p);
         if ((rc = run_scan(c, "kd_rank", PopcFn{(const u64 *)S.bitmap.p}, ExclusiveU32Sink{(u32 *)S.wrank.p}, (u64)n_words,
                            (u64 *)S.total.p)))
@@ -1655,12 +1649,15 @@ static int queue_contig(pjb_ctx *c, Flight &f) {
         u32 *cand_rank = (u32 *)S.idx[1].p; // (free until the first scatter as well)
         LAUNCH(c, "kd_ends", kd_ends, dim3(pair_blocks), dim3(256), (const u64 *)cand, kf, (const u64 *)S.bitmap.p, (const u32 *)S.wrank.p, JL,
                (u32 *)S.ends.p, cand_rank, d_cs);
-        if ((rc = run_scan(c, "kd_first", EndsCountFn{(const u32 *)S.ends.p}, ExclusiveU32Sink{(u32 *)S.firstid.p}, (u64)JL,
-                           (u64 *)S.total.p)))
+        if ((rc = run_scan(c, "kd_first", EndsCountFn{(const u32 *)S.ends.p}, FirstIdSink{(u32 *)S.firstid.p, (int32_t *)S.ancl.p, (int32_t *)S.ancr.p},
+                           (u64)JL, (u64 *)S.total.p)))
             return rc;
-        LAUNCH(c, "kd_close", kd_close, dim3(1), dim3(1), d_cs);
-        LAUNCH(c, "kd_assign", kd_assign, dim3(pair_blocks), dim3(256), okey, d_P, kf, (const u64 *)S.bitmap.p, (const u32 *)S.wrank.p,
-               (const u32 *)S.ends.p, (const u32 *)S.firstid.p, (u64 *)S.key[0].p);
+        LAUNCH(c, "kd_table", kd_table, dim3(pair_blocks), dim3(256), (const u64 *)cand, (const u32 *)cand_rank, kf, JL, (const u32 *)S.ends.p,
+               (const u32 *)S.firstid.p, (const u64 *)S.total.p, (u64 *)S.jkey.p, d_cs);
+        LAUNCH(c, "kd_assign", kd_assign, dim3(pair_blocks), dim3(256), okey, (const PairRec *)pr.rec, d_P, kf, (const u64 *)S.bitmap.p,
+               (const u32 *)S.wrank.p, (const u32 *)S.ends.p, (const u32 *)S.firstid.p, JL, (const u64 *)S.total.p, (u64 *)S.key[0].p, (u32 *)S.jidbam.p,
+               (int32_t *)S.ancl.p, (int32_t *)S.ancr.p, (u32 *)S.acc.p);
+        if ((rc = fork_k4b())) return rc;
         LAUNCH(c, "kd_reset", kd_reset, dim3(pair_blocks), dim3(256), (const u64 *)cand, (const u32 *)cand_rank, kf, JL, (const ContigStats *)d_cs,
                (u64 *)S.bitmap.p, (u32 *)S.ends.p);
         S.dense_at_rest = true;
@@ -1713,8 +1710,8 @@ static int queue_contig(pjb_ctx *c, Flight &f) {
 
     // ---- K2s: junction ids, position runs
     {
-        HeadFn hf{skey, sidx, pr.pos};
-        HeadSink hs{(u32 *)S.jid.p, (u32 *)S.seg.p, (u32 *)S.runfirst.p, (u32 *)S.runstart.p};
+        HeadFn hf{skey, sidx, (const PairRec *)pr.rec};
+        HeadSink hs{(u32 *)S.jid.p, (u32 *)S.seg.p, (u32 *)S.runfirst.p, (u32 *)S.runstart.p, skey, lim.dense ? (u64 *)nullptr : (u64 *)S.jkey.p};
         if ((rc = run_scan(c, "k2_heads", hf, hs, (u64)PL, (u64 *)S.total.p, d_P))) return rc;
         LAUNCH(c, "k2_close", k2_close, dim3(1), dim3(1), (u64 *)S.total.p, (u32 *)S.seg.p, (u32 *)S.runfirst.p,
                (u32 *)S.runstart.p, d_cs, JL);
@@ -1744,37 +1741,29 @@ static int queue_contig(pjb_ctx *c, Flight &f) {
                (const double *)S.ent.p, d_J, (double *)S.entsum.p);
         if (entropy_forked) HIP_TRY(c, hipEventRecord(S.ev_join2, S.side));
     }
-    // ---- K3: anchors
-    const u32 slot_blocks = (slots_lim + 255) / 256;
-    const u32 init_n = std::max<u32>(slots_lim, JL * F_WORDS);
-    LAUNCH(c, "k5_init_acc", k5_init_acc, dim3((init_n + 255) / 256), dim3(256), (u32 *)S.acc.p, d_J, (int32_t *)S.ancl.p,
-           (int32_t *)S.ancr.p, (int32_t *)S.fragj.p, d_slots, d_member_junc);
-    LAUNCH(c, "k3_anchors_frag", k3_anchors_frag, dim3(pair_blocks), dim3(256), sidx, (const u32 *)S.jid.p,
-           (const int32_t *)pr.lstart, (const int32_t *)pr.rend, (const u32 *)pr.meta, fast_codes ? 0 : 1, d_P,
-           (int32_t *)S.fragl.p, (int32_t *)S.fragr.p, (int32_t *)S.fragj.p, (u32 *)S.genlist.p,
-           (u32 *)S.gencount.p);
-    LAUNCH(c, "k3_anchors_junc", k3_anchors_junc, dim3(slot_blocks), dim3(256), (const int32_t *)S.fragl.p,
-           (const int32_t *)S.fragr.p, (const int32_t *)S.fragj.p, d_slots, (int32_t *)S.ancl.p,
-           (int32_t *)S.ancr.p);
+    // ---- a chain that sorted the full keys has its junction ids only now: anchors, ids in BAM order, then the generic pairs
+    if (!lim.dense) {
+        LAUNCH(c, "kf_init", kf_init, dim3(std::max<u32>(1, std::min<u32>((JL * F_WORDS + 255) / 256, 4096))), dim3(256), (u32 *)S.acc.p, d_J, (int32_t *)S.ancl.p,
+               (int32_t *)S.ancr.p);
+        LAUNCH(c, "kf_anchors", kf_anchors, dim3(pair_blocks), dim3(256), sidx, (const u32 *)S.jid.p, (const PairRec *)pr.rec, d_P, (u32 *)S.jidbam.p,
+               (int32_t *)S.ancl.p, (int32_t *)S.ancr.p);
+        if ((rc = launch_k4b())) return rc;
+    }
     STAGE_EVENT(4);
 
     const hipStream_t tl = st; // (the chain's last kernels on a stream of lowest priority, so that the next chain's first ones go
                                // ahead of them: 12.9 -> 14.5 ms per step, profiles/r03am_tail_priority.txt; not kept)
-    if (f.forked) HIP_TRY(c, hipStreamWaitEvent(tl, S.ev_join, 0)); // k4a_simple's results (side stream) are needed from here on
-    // ---- K4b: the pairs that need the generic walks (list length lives on the device; the grid covers the
-    // worst case and surplus blocks exit at once), then K4: gather + segmented reduce -> fragments
-    LAUNCH(c, "k4b_generic", k4b_generic, dim3((gen_cap * GEN_SHARDS + 255) / 256), dim3(256), (const u32 *)S.genlist.p,
-           (const u32 *)S.gencount.p, pair_blocks, skey, sidx, (const u32 *)S.jid.p, pr, kf, (const DevBatch *)S.batches.p,
-           (int)batches.size(), (const int32_t *)S.ancl.p, (const int32_t *)S.ancr.p, GT, any_x ? 1 : 0, any_x ? 0 : 1, (u64 *)S.res.p, d_err);
-    LAUNCH(c, "k4_pairs", k4_pairs, dim3(pair_blocks), dim3(256), skey, sidx, (const u32 *)S.jid.p, pr, kf,
-           (const u64 *)S.res.p, d_P, (u32 *)S.frag.p, (int32_t *)S.fragj.p);
+    if (f.forked) HIP_TRY(c, hipStreamWaitEvent(tl, S.ev_join, 0)); // k4b_generic's results (side stream) are needed from here on
+    // ---- K4: gather + segmented reduce -> fragments
+    LAUNCH(c, "k4_pairs", k4_pairs, dim3(pair_blocks), dim3(256), sidx, (const u32 *)S.jid.p, (const PairRec *)pr.rec, (const u64 *)S.jkey.p, kf, d_P,
+           (u32 *)S.frag.p, (int32_t *)S.fragj.p);
     STAGE_EVENT(5);
 
     // ---- K5: fragments -> junctions -> rows
     LAUNCH(c, "k5_frag_reduce", k5_frag_reduce, dim3((slots_lim + 4 * FRAG_SLOTS_PER_WAVE - 1) / (4 * FRAG_SLOTS_PER_WAVE)), dim3(256),
            (const u32 *)S.frag.p, (const int32_t *)S.fragj.p, d_slots, (u32 *)S.acc.p);
     if (entropy_forked) HIP_TRY(c, hipStreamWaitEvent(tl, S.ev_join2, 0));
-    LAUNCH(c, "k5_finalize", k5_finalize, dim3(std::max<u32>(1, (JL + 255) / 256)), dim3(256), (const u64 *)pr.key, sidx, (const u32 *)S.seg.p,
+    LAUNCH(c, "k5_finalize", k5_finalize, dim3(std::max<u32>(1, (JL + 255) / 256)), dim3(256), (const u64 *)S.jkey.p, (const u32 *)S.seg.p,
            (const u32 *)S.runfirst.p, (const u32 *)S.runstart.p, (const u32 *)S.acc.p,
            (const int32_t *)S.ancl.p, (const int32_t *)S.ancr.p, kf, GT, d_J, (const double *)S.entsum.p, (pjb_junction_row *)S.rows.p, d_err,
            d_member_junc);
@@ -1802,8 +1791,8 @@ static int queue_contig(pjb_ctx *c, Flight &f) {
         c->stream = rows_stream; // LAUNCH (and its event bracket) follow c->stream
         LAUNCH(c, "k6_rows_out", k6_rows_out, dim3(K6_BLOCKS), dim3(256), (const u64 *)S.rows.p, (const ContigStats *)d_cs,
                (u64 *)c->rows_table, row_base, mirror_base, (const RowCursor *)c->b_cursor.p, mirror_table, mirror_room);
-        LAUNCH(c, "k7_publish", k7_publish, dim3(1), dim3(256), (const ContigStats *)d_cs, d_err, (u32 *)S.gencount.p, S.pub_dev, row_base,
-               mirror_base, (RowCursor *)c->b_cursor.p, (const MemberStats *)d_members, (const u32 *)d_member_junc, n_members);
+        LAUNCH(c, "k7_publish", k7_publish, dim3(1), dim3(256), (const ContigStats *)d_cs, d_err, d_gen_reads, d_gen_pairs, S.pub_dev, row_base,
+               mirror_base, (RowCursor *)c->b_cursor.p, (const MemberStats *)d_members, d_member_junc, n_members);
     }
     S.at_rest = true;
     HIP_TRY(c, hipEventRecord(S.ev[7], rows_stream));
@@ -2104,7 +2093,13 @@ static int collect_flight(pjb_ctx *c, pjb_region_result *res, bool *redo_single)
     c->junc_seen = std::max(c->junc_seen, group ? J / (u32)n_members : J);
     c->timing.sort_passes = f.n_pass;
     c->timing.generic_pairs = 0;
-    for (u32 k = 0; k < GEN_SHARDS; k++) c->timing.generic_pairs += ((const u32 *)(S.pub + PUB_GEN_AT))[k];
+    c->timing.generic_reads = 0;
+    for (u32 k = 0; k < GEN_SHARDS; k++) {
+        c->timing.generic_pairs += ((const u32 *)(S.pub + PUB_GEN_AT))[k];
+        c->timing.generic_reads += ((const u32 *)(S.pub + PUB_GREADS_AT))[k];
+    }
+    c->timing.position_runs = cs.R;
+    c->timing.candidates = lim.dense ? cs.n_cand : 0;
     const size_t old = c->rows_n;
     {
         u32 at[2];
@@ -2504,7 +2499,6 @@ int pjb_set_option(pjb_ctx *c, const char *name, int64_t value) {
     const std::string n = name;
     if (n == "overlap") c->side_stream = value != 0;
     else if (n == "dense_ids") c->dense_ids = value != 0;
-    else if (n == "fused_k1") c->fused_k1 = value != 0;
     else if (n == "extra_dense") c->extra_dense_only = value != 0;
     else return fail(c, PJB_ERR_ARG, "set_option: unknown option '%s'", name);
     return PJB_OK;

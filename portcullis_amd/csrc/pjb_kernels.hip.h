@@ -81,19 +81,43 @@ struct ContigStats {
     u32 n_cand;    // K2d: keys in the candidate list (every junction at least once, few of them more often)
 };
 
-// pairs, structure of arrays (one entry per N operation walked)
-struct Pairs {
-    u64 *key;        // packed intron key (see make_key)
-    u32 *g;          // global read ordinal
-    int32_t *lstart; // lStart  (left anchor start of this pair)
-    int32_t *rend;   // rEndExc-1
-    int32_t *pos;    // read position   (entropy / distinct-alignment runs)
-    int32_t *aend;   // read end = pos + alignedLength - 1
-    u32 *meta;       // bit field, see META_*
-    u32 *updown;     // upjuncs | downjuncs << 16
-    u64 *seqw;       // META_SIMPLE pairs: device address of the read's packed bases (k4a_simple then needs no walk
-                     // pair -> read ordinal -> batch -> seq_off -> bases: four dependent loads less)
+// A pair = one N operation walked (JunctionSystem::addJunctions, junction_system.cc:140-210).  k1_emit writes, in BAM order,
+// the pair's intron key (its own array: kd_assign and the sort's first pass stream over the keys alone) and ONE 32-byte record
+// with everything the per-junction reductions need; every later kernel that works in sorted order fetches a pair with one
+// 32-byte gather (two 16-byte loads from one sector).
+struct __attribute__((aligned(16))) PairRec {
+    u64 aux;         // per-pair match statistics (pack_res): written by k1_emit for the [S] M N M [S] shape, by k4b_generic for the rest
+    int32_t lstart;  // lStart  (left anchor start of this pair)
+    int32_t rend;    // rEndExc-1
+    int32_t pos;     // read position   (entropy / distinct-alignment runs)
+    int32_t aend;    // read end = pos + alignedLength - 1
+    u32 meta;        // bit field, see META_*
+    u32 updown;      // upjuncs | downjuncs << 16
 };
+static_assert(sizeof(PairRec) == 32, "PairRec is one 32-byte sector");
+struct Pairs {
+    u64 *key;     // packed intron key (see make_key), BAM order
+    PairRec *rec; // BAM order
+    u32 *g;       // global read ordinal of the pair's record -- written for PJB_FLAG_EXTRA contexts only (nullptr otherwise)
+};
+__device__ __forceinline__ void rec_store(PairRec *dst, const PairRec &r) {
+    uint4 *q = reinterpret_cast<uint4 *>(dst);
+    q[0] = make_uint4((u32)r.aux, (u32)(r.aux >> 32), (u32)r.lstart, (u32)r.rend);
+    q[1] = make_uint4((u32)r.pos, (u32)r.aend, r.meta, r.updown);
+}
+__device__ __forceinline__ PairRec rec_load(const PairRec *src) {
+    const uint4 *q = reinterpret_cast<const uint4 *>(src);
+    const uint4 a = q[0], b = q[1];
+    PairRec r;
+    r.aux = (u64)a.x | ((u64)a.y << 32);
+    r.lstart = (int32_t)a.z;
+    r.rend = (int32_t)a.w;
+    r.pos = (int32_t)b.x;
+    r.aend = (int32_t)b.y;
+    r.meta = b.z;
+    r.updown = b.w;
+    return r;
+}
 
 enum : u32 {
     META_CAT_MASK = 3u,      // 0 r1pos, 1 r1neg, 2 r2pos, 3 r2neg   (junction.cc:483-498)
@@ -103,9 +127,8 @@ enum : u32 {
     META_BPP = 1u << 6,      // BAM proper-pair flag                 (junction.cc:780)
     META_PPP = 1u << 7,      // calcIfProperPair                     (junction.cc:784)
     META_REL = 1u << 8,      // reliable                             (junction.cc:792)
-    META_SIMPLE = 1u << 9,   // CIGAR is [S] M N M [S] and l_qseq matches it: both anchors are single
-                             // contiguous compares that do not depend on the junction-level window
-    META_DS_SHIFT = 16,      // 12 bits: leading soft clip of a simple pair
+    META_SIMPLE = 1u << 9,   // CIGAR is [S] M N M [S] and l_qseq matches it: both anchors are single contiguous compares
+                             // that do not depend on the junction-level window (k1_emit compares them itself)
 };
 // per-pair match statistics packed in 64 bits: minMatch | mmes << 20 | mismatches << 40
 __device__ __forceinline__ u64 pack_res(u32 minMatch, u32 mmes, u32 mis) {
@@ -964,13 +987,106 @@ __global__ __launch_bounds__(K1S_THREADS) void k1_scan_tiles(u32 *tile_cnt, cons
 }
 
 // ---------------------------------------------------------------------------------------------
+// Packed-base compare helpers (used by k1_emit for the simple shape and by the generic walks of k4b_generic)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ u32 nt16_ascii(u32 c) { // seq_nt16_str "=ACMGRSVTWYHKDBN"
+    // bytes: '=' 3D, 'A' 41, 'C' 43, 'M' 4D, 'G' 47, 'R' 52, 'S' 53, 'V' 56 | 'T' 54,'W' 57,'Y' 59,'H' 48,'K' 4B,'D' 44,'B' 42,'N' 4E
+    const u64 t0 = 0x565352474D43413DULL;
+    const u64 t1 = 0x4E42444B48595754ULL;
+    const u64 t = (c & 8u) ? t1 : t0;
+    return (u32)(t >> ((c & 7u) * 8)) & 0xffu;
+}
+
+// Read nibbles [qi, qi+l) (BAM order: high nibble first) against genome codes [gi, gi+l) (low nibble first), 64 bases
+// = 9 words of each per round; mismatch positions are reported relative to `out_base`.
+//   A lane's words are consecutive but the next lane's are somewhere else, so every load instruction of the wave
+// touches 64 cache lines whatever its width, and the number of load INSTRUCTIONS sets the pace (measured in
+// k4a_simple: 19 per-word loads per read cost 80 us per contig, the compare itself nothing).  So the words come as two
+// 16-byte loads and one 4-byte load per stream -- 4-byte aligned (reads start on word boundaries), which
+// global_load_dwordx4 accepts -- guarded so that nothing is read past the read's last word / the contig's last code
+// word; the short tail of a stream takes guarded word loads.
+__device__ __forceinline__ u32 swap_nibbles(u32 x) { return ((x & 0x0F0F0F0Fu) << 4) | ((x >> 4) & 0x0F0F0F0Fu); }
+struct __attribute__((packed, aligned(4))) Words4 {
+    u32 x, y, z, w;
+};
+// A chunk = NW consecutive words of each stream = (NW - 1) * 8 anchor bases per round (the extra word feeds the funnel
+// shift of the last one): NW = 9 -> two 16-byte loads and one word per stream, NW = 5 -> one 16-byte load and one word.
+template <int NW>
+struct CmpChunkT {
+    u32 qw[NW], gg[NW];
+};
+// d[k] = p[first + k] for 0 <= first + k <= last, else 0
+template <int NW>
+__device__ __forceinline__ void load_words(u32 (&d)[NW], const u32 *p, int32_t first, int32_t last) {
+    static_assert(NW == 9 || NW == 5, "chunk width");
+    if (first >= 0 && first + NW - 1 <= last) {
+        const Words4 a = gload(reinterpret_cast<const Words4 *>(p + first));
+        d[0] = a.x, d[1] = a.y, d[2] = a.z, d[3] = a.w;
+        if constexpr (NW == 9) {
+            const Words4 b = gload(reinterpret_cast<const Words4 *>(p + first + 4));
+            d[4] = b.x, d[5] = b.y, d[6] = b.z, d[7] = b.w;
+        }
+        d[NW - 1] = gload(p + first + NW - 1);
+    } else {
+#pragma unroll
+        for (int k = 0; k < NW; k++) d[k] = (first + k >= 0 && first + k <= last) ? gload(p + first + k) : 0u;
+    }
+}
+// anchor bases [t, t + 8 (NW - 1)) of an anchor of l bases: read bases from qi (words of the read up to word q_last may be
+// touched: whatever lies past the anchor only feeds bits that the length mask removes), genome from gi
+template <int NW>
+__device__ __forceinline__ void chunk_load(CmpChunkT<NW> &C, const u32 *seqw, int32_t qi, int32_t q_last, const u32 *gw, int32_t gi, int32_t g_words,
+                                           int32_t l, int32_t t) {
+    const int32_t lastg = (gi + l - 1) >> 3;
+    load_words<NW>(C.qw, seqw, (qi + t) >> 3, q_last);
+    // (genome words outside [0, g_words) and past the anchor's last word read as 0, as they always did)
+    load_words<NW>(C.gg, gw, (gi + t) >> 3, lastg < g_words - 1 ? lastg : g_words - 1);
+}
+template <int NW>
+__device__ __forceinline__ void chunk_cmp(CmpChunkT<NW> &C, int32_t qi, int32_t gi, int32_t l, int32_t t, int32_t out_base, int32_t &mism,
+                                          int32_t &first_mis, int32_t &last_mis) {
+    const u32 shq = (u32)(qi & 7) * 4u, shg = (u32)(gi & 7) * 4u; // (t is a multiple of 8: the shifts do not move)
+#pragma unroll
+    for (int k = 0; k < NW; k++) C.qw[k] = swap_nibbles(C.qw[k]);
+#pragma unroll
+    for (int c = 0; c < NW - 1; c++) {
+        const int32_t rem = l - t - 8 * c;
+        if (rem > 0) {
+            const u32 q = __builtin_amdgcn_alignbit(C.qw[c + 1], C.qw[c], shq);
+            const u32 g = __builtin_amdgcn_alignbit(C.gg[c + 1], C.gg[c], shg);
+            const u32 x = q ^ g;
+            u32 m = (((x & 0x77777777u) + 0x77777777u) | x) & 0x88888888u; // top bit of every nibble that differs
+            if (rem < 8) m &= (1u << (4 * rem)) - 1u;
+            if (m) {
+                mism += __popc(m);
+                if (first_mis < 0) first_mis = out_base + t + 8 * c + ((__ffs((int)m) - 1) >> 2);
+                last_mis = out_base + t + 8 * c + ((31 - __clz((int)m)) >> 2);
+            }
+        }
+    }
+}
+// one stretch of l bases
+template <int NW>
+__device__ __forceinline__ void cmp_words(const u32 *seqw, int32_t qi, int32_t q_last, const u32 *gw, int32_t gi, int32_t g_words, int32_t l,
+                                          int32_t out_base, int32_t &mism, int32_t &first_mis, int32_t &last_mis) {
+    for (int32_t t = 0; t < l; t += 8 * (NW - 1)) {
+        CmpChunkT<NW> C;
+        chunk_load<NW>(C, seqw, qi, q_last, gw, gi, g_words, l, t);
+        chunk_cmp<NW>(C, qi, gi, l, t, out_base, mism, first_mis, last_mis);
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------
 // K1b: per-read CIGAR walk, pass 2: emit one pair per N op in BAM order
 // (JunctionSystem::addJunctions junction_system.cc:140-210 restated iteratively:
 //  after an N op the next left anchor starts at the CLAMPED rStart; rEndExc is the UNCLAMPED
 //  rStart plus the reference-consuming ops up to the next N, then clamped).
 // Per-pair predicates of Junction::addJunctionAlignment (junction.cc:477-502) and
 // calcAlignmentStats (junction.cc:755-814) are evaluated here, where the read's fixed-width
-// fields are read coalesced, and packed into `meta`.
+// fields are read coalesced, and packed into `meta`.  The same thread then compares the anchors
+// of a read of the common [S] M N M [S] shape with the genome (AlignmentInfo::calcMatchStats,
+// junction.cc:147-240): the pair's record leaves this kernel complete.
 // ---------------------------------------------------------------------------------------------
 // CIGAR ops of one alignment: the first OPS_LDS ops are staged in LDS (one column per thread), the
 // rest (long reads) are read from global memory
@@ -1006,8 +1122,7 @@ __device__ __forceinline__ void ncursor_advance(NCursor &c, const Ops cig, u32 n
 
 // One spliced read's pairs (JunctionSystem::addJunctions junction_system.cc:140-210) -- everything that follows from
 // the read's fixed-width fields is in R, the CIGAR behind `cig`.  Shape test, walk with the two monotone cursors for
-// the up/down junction counts (junction.cc:795-812), one store per pair field.
-constexpr u32 WALK_HINT = 0x80000000u; // in the low word of a generic pair's `seqw`: the other 31 bits are its N operation's index
+// the up/down junction counts (junction.cc:795-812), one 32-byte record per pair.
 struct EmitRead {
     u32 n;        // CIGAR operations
     int32_t pos;
@@ -1017,34 +1132,44 @@ struct EmitRead {
     int32_t aend; // pos + aligned length - 1
     int32_t lq;   // l_qseq
     bool seq_ok;  // the record carries at least lq bases
-    u64 seq_ptr;  // device address of the read's packed bases
     u32 off;      // index of the read's first pair
 };
-template <typename Ops>
+// What the walk hands back: the read's LAST pair is complete but not stored -- a read of the simple shape has one
+// pair, and its caller adds the match statistics before the record goes out (one store per pair, ever).
+struct EmitTail {
+    PairRec rec;
+    int64_t idx; // index of that pair (-1: the read emitted nothing)
+    u64 key;
+    bool simple; // [S] M N M [S], bases present: `dS` is the leading soft clip
+    u32 dS;
+};
+template <typename Ops, typename KeyFn>
 __device__ __forceinline__ void emit_read_pairs(const Ops cig, const EmitRead R, const Pairs P, const KeyFmt kf, const int32_t ref_len,
-                                                u64 *err) {
+                                                const bool allow_simple, u64 *err, KeyFn &&on_key, EmitTail &T) {
     const u32 n = R.n, g = R.g, nN = R.nN;
     const int32_t pos = R.pos, aend = R.aend;
     u32 meta = R.meta;
+    u32 dS = 0;
     // ---- shape: [S] M N M [S] with the read length matching the CIGAR
-    if (nN == 1 && n >= 3 && n <= 5) {
+    if (allow_simple && nN == 1 && n >= 3 && n <= 5) {
         u32 k0 = 0, k1 = n;
-        u32 dS = 0, dE = 0;
+        u32 s0 = 0, dE = 0;
         const u32 opF = cig[0], opL = cig[n - 1];
-        if ((opF & 15u) == OP_S) { dS = opF >> 4; k0 = 1; }
+        if ((opF & 15u) == OP_S) { s0 = opF >> 4; k0 = 1; }
         if ((opL & 15u) == OP_S) { dE = opL >> 4; k1 = n - 1; }
         if (k1 - k0 == 3) {
             const u32 oa = cig[k0], on = cig[k0 + 1], ob = cig[k0 + 2];
             if ((oa & 15u) == OP_M && (on & 15u) == OP_N && (ob & 15u) == OP_M) {
                 const u32 a = oa >> 4, b2 = ob >> 4;
                 const int32_t lq = R.lq;
-                if (a > 0 && b2 > 0 && a <= RES_FIELD_MAX && b2 <= RES_FIELD_MAX && dS < 4096u && lq > 1 &&
-                    (u64)lq == (u64)dS + a + b2 + dE && R.seq_ok)
-                    meta |= META_SIMPLE | (dS << META_DS_SHIFT);
+                if (a > 0 && b2 > 0 && a <= RES_FIELD_MAX && b2 <= RES_FIELD_MAX && s0 <= RES_FIELD_MAX && lq > 1 &&
+                    (u64)lq == (u64)s0 + a + b2 + dE && R.seq_ok) {
+                    meta |= META_SIMPLE;
+                    dS = s0;
+                }
             }
         }
     }
-    const u64 seq_addr = (meta & META_SIMPLE) ? R.seq_ptr : 0ull;
     // ---- walk: pairs (junction_system.cc:140-210) and, with two monotone cursors over the read's own
     // introns, the up/down junction counts (junction.cc:795-812)
     NCursor U = {0, pos, false, 0}, D = {0, pos, false, 0};
@@ -1053,8 +1178,15 @@ __device__ __forceinline__ void emit_read_pairs(const Ops cig, const EmitRead R,
     u32 cntU = 0, cntD = 0;
     int32_t lStart = pos, lEndExc = pos, sumAfter = 0, prevRStartU = 0, prevIend = 0;
     int64_t prev = -1;
+    u64 prev_key = 0;
+    PairRec pend;
+    pend.aux = 0;
+    pend.lstart = pend.rend = 0;
+    pend.pos = pos;
+    pend.aend = aend;
+    pend.meta = meta;
+    pend.updown = 0;
     u32 k = 0;
-    u32 qsum = 0; // query bases before the operation, soft clips not counted (anchor_side's qPos)
     for (u32 i = 0; i < n; i++) {
         const u32 op = cig[i];
         const u32 ty = op & 15u;
@@ -1063,7 +1195,8 @@ __device__ __forceinline__ void emit_read_pairs(const Ops cig, const EmitRead R,
             if (prev >= 0) {
                 int32_t rEndExc = prevRStartU + sumAfter;
                 if (rEndExc - 1 >= ref_len) rEndExc = ref_len; // junction_system.cc:172-174
-                P.rend[prev] = rEndExc - 1;
+                pend.rend = rEndExc - 1;
+                rec_store(P.rec + prev, pend);
                 if (rEndExc - 1 < prevIend) set_error(err, g, PJB_ERR_MIN_ANCHOR); // intron.cc:76
             }
             const int32_t istart = lEndExc;
@@ -1080,18 +1213,15 @@ __device__ __forceinline__ void emit_read_pairs(const Ops cig, const EmitRead R,
                 ncursor_advance(D, cig, n);
             }
             const int64_t idx = (int64_t)R.off + k;
-            P.key[idx] = make_key(kf, istart, iend);
-            P.g[idx] = g;
-            P.lstart[idx] = lStart;
-            P.pos[idx] = pos;
-            P.meta[idx] = meta;
-            P.aend[idx] = aend;
-            P.updown[idx] = cntU | ((nN - cntD) << 16);
-            // (a pair of the generic walk: where its N operation stands in the CIGAR and how many query bases precede it --
-            // k4b_generic starts its walks there instead of at the read's first operation)
-            P.seqw[idx] = (meta & META_SIMPLE) ? seq_addr : (((u64)qsum << 32) | (u64)(i | WALK_HINT));
+            const u64 key = make_key(kf, istart, iend);
+            P.key[idx] = key;
+            if (P.g) P.g[idx] = g;
+            on_key(key);
+            pend.lstart = lStart;
+            pend.updown = cntU | ((nN - cntD) << 16);
             if (lStart > istart) set_error(err, g, PJB_ERR_MIN_ANCHOR); // intron.cc:68
             prev = idx;
+            prev_key = key;
             prevIend = iend;
             prevRStartU = rStartU;
             sumAfter = 0;
@@ -1102,14 +1232,18 @@ __device__ __forceinline__ void emit_read_pairs(const Ops cig, const EmitRead R,
             lEndExc += ln;
             sumAfter += ln;
         }
-        if (op_consumes_query(ty) && ty != OP_S) qsum += (u32)ln;
     }
     if (prev >= 0) {
         int32_t rEndExc = prevRStartU + sumAfter;
         if (rEndExc - 1 >= ref_len) rEndExc = ref_len;
-        P.rend[prev] = rEndExc - 1;
+        pend.rend = rEndExc - 1;
         if (rEndExc - 1 < prevIend) set_error(err, g, PJB_ERR_MIN_ANCHOR);
     }
+    T.rec = pend;
+    T.idx = prev;
+    T.key = prev_key;
+    T.simple = (meta & META_SIMPLE) != 0 && prev >= 0;
+    T.dS = dS;
 }
 
 // per-read predicates of a pair's `meta` word (Junction::addJunctionAlignment junction.cc:477-502, calcAlignmentStats
@@ -1137,86 +1271,207 @@ __device__ __forceinline__ u32 read_meta(u32 flag, u32 xs, u32 mapq, int32_t pos
     return meta;
 }
 
-// Thread per spliced read (dense, from the list k1_count compacted).  The read's CIGAR is fetched
-// once (8 independent loads into an LDS column, the walks below then run at LDS latency); one walk
-// writes every field of the read's pairs.
+// The common shape [S] M N M [S] (coordinates of the read's own target): the left anchor is read[dS, dS+a) against
+// genome[pos, pos+a), the right one read[dS+a, dS+a+b) against genome[iend+1, iend+1+b); neither depends on the
+// junction-level window -- the walk rules of bam_alignment.cc:341-462 reduce to exactly this for the shape.
+constexpr int SIMPLE_NW = 5;
+__device__ __forceinline__ u64 simple_pair_stats(const u32 *seqw, const u32 *gcodes, int32_t glen, int32_t pos, int32_t istart, int32_t iend,
+                                                 int32_t rend, int32_t dS) {
+    const int32_t a = istart - pos, bb = rend - iend;
+    const int32_t g_words = (glen + 7) / 8 + 1;
+    const int32_t q_last = (dS + a + bb - 1) >> 3; // last word of the read that holds aligned bases
+    int32_t misL = 0, firstL = -1, lastL = -1, misR = 0, firstR = -1, lastR = -1;
+    // (one side after the other, 32 bases a round: both sides' words in flight together, 64 bases each -- 36 registers --
+    // cost the kernel half its wavefronts; the number of load instructions per read is the same)
+    cmp_words<SIMPLE_NW>(seqw, dS, q_last, gcodes, pos, g_words, a, 0, misL, firstL, lastL);
+    cmp_words<SIMPLE_NW>(seqw, dS + a, q_last, gcodes, iend + 1, g_words, bb, 0, misR, firstR, lastR);
+    const u32 upM = lastL < 0 ? (u32)a : (u32)(a - 1 - lastL);
+    const u32 downM = firstR < 0 ? (u32)bb : (u32)firstR;
+    const u32 tu = (u32)(a - misL), td = (u32)(bb - misR);
+    return pack_res(upM < downM ? upM : downM, tu < td ? tu : td, (u32)(misL + misR));
+}
+
 // Thread per spliced read of the batch, DENSE: the tiles' spliced lists (k1_count compacted them per tile) are walked as one
 // list -- entry s lies in the tile t with tile_soff[t] <= s < tile_soff[t + 1], found from chunk_tile (the tile of entry
-// 256 * chunk) and a short walk -- so every thread of every block has a read.  (Round 2 looped over a tile's list with 256
-// threads: a tile holds ~300 spliced reads, so the second trip ran 44 lanes wide: 58 % of the lanes did anything.)  The grid
-// is fixed; blocks stride over the batch's chunks.
-// voff: the target's offset in its group's virtual sequence (0 for a single target); every coordinate a pair carries is
-// virtual, the per-read predicates are evaluated on the record's own coordinates.
+// 256 * chunk) and a short walk -- so every thread of every block has a read.  The read's CIGAR is fetched once (8
+// independent loads into an LDS column, the walks then run at LDS latency).  The grid is fixed; blocks stride over the
+// batch's chunks of 256 list entries.
+//   voff: the target's offset in its group's virtual sequence (0 for a single target); every coordinate a pair carries is
+// virtual, the per-read predicates and the base compare work on the record's own coordinates.
+//   gcodes: the target's 4-bit codes; nullptr (exotic characters, an 'X' in the sequence): no read is "simple", every
+// pair goes through k4b_generic's byte-wise walks.
+// By-products, so that no later kernel has to stream over the pairs for them:
+//   * K2d's candidate keys: the block keeps the keys it emits in a small hash set in LDS and appends the distinct ones to the
+//     candidate list when the set is a quarter full (and when the block leaves); a junction appears once per residency;
+//   * the list of reads that need the generic walks (k4b_generic), in GEN_SHARDS sub-lists (one returning atomic per
+//     wavefront, spread over 256 addresses).
 constexpr int K1E_LOOK = 16;
+constexpr int KC_SLOTS = 1024;
+constexpr u64 KD_EMPTY = ~0ull; // no key: a packed key has fewer than 64 bits
+constexpr u32 GEN_SHARDS = 256;
+struct EmitLists {
+    u64 *cand;      // candidate keys (nullptr: the chain sorts the full keys and wants none); their count is ContigStats::n_cand
+    u64 *gen_list;  // global read ordinal | index of the read's first pair << 32
+    u32 *gen_reads; // [GEN_SHARDS] entries of each sub-list
+    u32 *gen_pairs; // [GEN_SHARDS] pairs of those reads
+    u32 gen_cap;    // room of one sub-list
+};
+__host__ __device__ inline u32 gen_list_cap(u32 pair_limit) { // chunks of 256 spliced reads dealt round-robin to the sub-lists
+    const u32 chunks = pair_limit / 256u + 2u;
+    return ((chunks + GEN_SHARDS - 1) / GEN_SHARDS) * 256u;
+}
 __global__ __launch_bounds__(256) void k1_emit(DevBatch b, u32 n_tiles_batch, u32 n_tiles_total, const u32 *tile_off, const u32 *tile_soff,
-                                                const u32 *chunk_tile, const u32 *spl_idx, const u32 *spl_poff, Pairs P, KeyFmt kf, int32_t ref_len,
-                                                int32_t tid, int orientation, u64 *err, const ContigStats *cs, int32_t voff) {
+                                                const u32 *chunk_tile, const u32 *spl_idx, const u32 *spl_poff, Pairs P, EmitLists E, KeyFmt kf,
+                                                int32_t ref_len, int32_t tid, int orientation, u64 *err, ContigStats *cs, int32_t voff,
+                                                const u32 *gcodes) {
     __shared__ u32 s_ops[OPS_LDS][256];
     __shared__ u32 s_soff[K1E_LOOK];
+    __shared__ u64 s_set[KC_SLOTS];
+    __shared__ u32 s_set_n, s_base, s_scan[4];
     if (cs->P == 0) return; // no pairs, or a limit was exceeded: the contig is repeated with larger buffers
     const u32 s_begin = tile_soff[b.tile_base], s_end = tile_soff[b.tile_base + n_tiles_batch];
     if (s_begin == s_end) return;
     const u32 c_lo = s_begin >> 8, c_hi = (s_end + 255u) >> 8;
+    const bool want_cand = E.cand != nullptr;
+    if (want_cand) {
+#pragma unroll
+        for (int i = 0; i < KC_SLOTS / 256; i++) s_set[i * 256 + threadIdx.x] = KD_EMPTY;
+        if (threadIdx.x == 0) s_set_n = 0;
+    }
+    auto cand_insert = [&](u64 k) {
+        u32 h = (u32)((k * 0x9E3779B97F4A7C15ull) >> 40) & (KC_SLOTS - 1);
+        for (int probe = 0; probe < 24; probe++) { // look first: most keys are there already, and a read of one address by many lanes is a broadcast
+            u64 old = s_set[h];
+            if (old == k) return;
+            if (old == KD_EMPTY) {
+                old = atomicCAS((unsigned long long *)&s_set[h], (unsigned long long)KD_EMPTY, (unsigned long long)k);
+                if (old == KD_EMPTY) {
+                    atomicAdd(&s_set_n, 1u);
+                    return;
+                }
+                if (old == k) return;
+            }
+            h = (h + 1) & (KC_SLOTS - 1);
+        }
+        E.cand[atomicAdd(&cs->n_cand, 1u)] = k; // a crowded set (reads with hundreds of introns): straight to the list, where duplicates do no harm
+    };
     for (u32 chunk = c_lo + blockIdx.x; chunk < c_hi; chunk += gridDim.x) {
         // the tile of the chunk's first entry (for the batch's first chunk: of the batch's first entry)
-        const u32 s0 = (chunk << 8) < s_begin ? s_begin : (chunk << 8);
         u32 t0 = (chunk << 8) < s_begin ? b.tile_base : chunk_tile[chunk];
         __syncthreads();
         if (threadIdx.x < K1E_LOOK) s_soff[threadIdx.x] = t0 + threadIdx.x <= n_tiles_total ? tile_soff[t0 + threadIdx.x] : 0xffffffffu;
         __syncthreads();
-        (void)s0;
         const u32 s = (chunk << 8) + threadIdx.x;
-        if (s < s_begin || s >= s_end) continue;
-        u32 k = 0; // (the offsets ascend: the entry's tile is the number of them it has reached -- 15 independent LDS reads, not a walk)
+        const bool on = s >= s_begin && s < s_end;
+        bool gen = false;
+        u32 gen_n = 0;
+        u64 gen_entry = 0;
+        if (on) {
+            u32 k = 0; // (the offsets ascend: the entry's tile is the number of them it has reached -- 15 independent LDS reads, not a walk)
 #pragma unroll
-        for (int m = 1; m < K1E_LOOK; m++) k += s >= s_soff[m] ? 1u : 0u;
-        u32 tile = t0 + k, soff = s_soff[k];
-        if (k + 1 == (u32)K1E_LOOK && s >= soff) { // (a run of tiles without spliced reads longer than the window: search)
-            u32 lo = tile, hi = n_tiles_total; // tile_soff[lo] <= s < tile_soff[hi]
-            while (hi - lo > 1) {
-                const u32 mid = (lo + hi) >> 1;
-                if (tile_soff[mid] <= s) lo = mid;
-                else hi = mid;
+            for (int m = 1; m < K1E_LOOK; m++) k += s >= s_soff[m] ? 1u : 0u;
+            u32 tile = t0 + k, soff = s_soff[k];
+            if (k + 1 == (u32)K1E_LOOK && s >= soff) { // (a run of tiles without spliced reads longer than the window: search)
+                u32 lo = tile, hi = n_tiles_total; // tile_soff[lo] <= s < tile_soff[hi]
+                while (hi - lo > 1) {
+                    const u32 mid = (lo + hi) >> 1;
+                    if (tile_soff[mid] <= s) lo = mid;
+                    else hi = mid;
+                }
+                tile = lo;
+                soff = tile_soff[lo];
             }
-            tile = lo;
-            soff = tile_soff[lo];
-        }
-        const u32 toff = tile_off[tile];
-        const size_t slot = (size_t)tile * K1_TILE + (s - soff);
-        const int64_t r = spl_idx[slot];
-        const u32 c0 = b.cig_off[r], c1 = b.cig_off[r + 1];
-        const u32 n = c1 - c0;
-        OpsView cig;
-        cig.g = b.cigar + c0;
-        cig.lds = &s_ops[0][threadIdx.x];
+            const u32 toff = tile_off[tile];
+            const size_t slot = (size_t)tile * K1_TILE + (s - soff);
+            const int64_t r = spl_idx[slot];
+            const u32 c0 = b.cig_off[r], c1 = b.cig_off[r + 1];
+            const u32 n = c1 - c0;
+            OpsView cig;
+            cig.g = b.cigar + c0;
+            cig.lds = &s_ops[0][threadIdx.x];
 #pragma unroll
-        for (int q = 0; q < OPS_LDS; q++) { // (unconditional loads, masked: see k1_count)
-            const bool has = (u32)q < n;
-            const u32 v = *(has ? cig.g + q : b.cig_off);
-            s_ops[q][threadIdx.x] = has ? v : 0u;
+            for (int q = 0; q < OPS_LDS; q++) { // (unconditional loads, masked: see k1_count)
+                const bool has = (u32)q < n;
+                const u32 v = *(has ? cig.g + q : b.cig_off);
+                s_ops[q][threadIdx.x] = has ? v : 0u;
+            }
+            EmitRead R;
+            R.n = n;
+            R.pos = b.pos[r];
+            R.g = b.base + (u32)r;
+            R.off = toff + spl_poff[slot];
+            R.meta = read_meta(b.flag[r], (u32)b.xs[r], b.mapq[r], R.pos, b.mtid[r], b.mpos[r], tid, orientation);
+            R.pos += voff;
+            u32 nN = 0;
+            int32_t aligned = 0;
+            for (u32 q = 0; q < n; q++) {
+                const u32 op = cig[q];
+                nN += ((op & 15u) == OP_N);
+                if (op_consumes_ref(op & 15u)) aligned += (int32_t)(op >> 4);
+            }
+            if (nN > 1) R.meta |= META_MULTI;
+            R.nN = nN;
+            R.aend = R.pos + aligned - 1;
+            R.lq = b.l_qseq[r];
+            const u32 so = b.seq_off[r];
+            R.seq_ok = (u64)(b.seq_off[r + 1] - so) * 8ull >= (u64)(int64_t)R.lq;
+            EmitTail T;
+            emit_read_pairs(cig, R, P, kf, voff + ref_len, gcodes != nullptr, err, [&](u64 key) { if (want_cand) cand_insert(key); }, T);
+            if (T.idx >= 0) {
+                if (T.simple) {
+                    int32_t istart, iend;
+                    unpack_key(kf, T.key, istart, iend);
+                    T.rec.aux = simple_pair_stats(b.seq4 ? reinterpret_cast<const u32 *>(b.seq4) + so : nullptr, gcodes, ref_len, T.rec.pos - voff, istart - voff,
+                                                  iend - voff, T.rec.rend - voff, (int32_t)T.dS);
+                } else {
+                    gen = true;
+                    gen_n = nN;
+                    gen_entry = (u64)R.g | ((u64)R.off << 32);
+                }
+                rec_store(P.rec + T.idx, T.rec);
+            }
         }
-        EmitRead R;
-        R.n = n;
-        R.pos = b.pos[r];
-        R.g = b.base + (u32)r;
-        R.off = toff + spl_poff[slot];
-        R.meta = read_meta(b.flag[r], (u32)b.xs[r], b.mapq[r], R.pos, b.mtid[r], b.mpos[r], tid, orientation);
-        R.pos += voff;
-        u32 nN = 0;
-        int32_t aligned = 0;
-        for (u32 q = 0; q < n; q++) {
-            const u32 op = cig[q];
-            nN += ((op & 15u) == OP_N);
-            if (op_consumes_ref(op & 15u)) aligned += (int32_t)(op >> 4);
+        // ---- the reads whose pairs need the generic walks: one returning atomic per wavefront
+        const u64 gm = __ballot(gen);
+        if (gm) {
+            const u32 shard = chunk % GEN_SHARDS;
+            const int leader = __ffsll((long long)gm) - 1;
+            const u32 pairs_w = wave_total<DppAdd>(gen_n);
+            u32 base = 0;
+            if (lane_id() == leader) {
+                base = atomicAdd(&E.gen_reads[shard], (u32)__popcll(gm));
+                atomicAdd(&E.gen_pairs[shard], pairs_w);
+            }
+            base = (u32)__builtin_amdgcn_readlane((int)base, leader);
+            const u32 at = base + (u32)__popcll(gm & ((1ull << lane_id()) - 1));
+            if (gen && at < E.gen_cap) E.gen_list[(size_t)shard * E.gen_cap + at] = gen_entry;
         }
-        if (nN > 1) R.meta |= META_MULTI;
-        R.nN = nN;
-        R.aend = R.pos + aligned - 1;
-        R.lq = b.l_qseq[r];
-        const u32 so = b.seq_off[r];
-        R.seq_ok = (u64)(b.seq_off[r + 1] - so) * 8ull >= (u64)(int64_t)R.lq;
-        R.seq_ptr = (u64)(uintptr_t)(b.seq4 + (size_t)so * 4);
-        emit_read_pairs(cig, R, P, kf, voff + ref_len, err);
+        // ---- candidate keys: flush the set when it fills up, and before the block leaves
+        if (want_cand) {
+            __syncthreads();
+            const bool last = chunk + gridDim.x >= c_hi;
+            if (s_set_n > (u32)KC_SLOTS / 4 || last) {
+                u64 mine[KC_SLOTS / 256];
+                u32 cnt = 0;
+#pragma unroll
+                for (int i = 0; i < KC_SLOTS / 256; i++) {
+                    mine[i] = s_set[i * 256 + threadIdx.x];
+                    cnt += mine[i] != KD_EMPTY;
+                    s_set[i * 256 + threadIdx.x] = KD_EMPTY;
+                }
+                u32 total;
+                const u32 excl = block_escan_256(cnt, s_scan, &total);
+                if (threadIdx.x == 0) {
+                    s_base = total ? atomicAdd(&cs->n_cand, total) : 0u;
+                    s_set_n = 0;
+                }
+                __syncthreads();
+                u32 o = s_base + excl;
+#pragma unroll
+                for (int i = 0; i < KC_SLOTS / 256; i++)
+                    if (mine[i] != KD_EMPTY) E.cand[o++] = mine[i];
+            }
+        }
     }
 }
 
@@ -1269,326 +1524,19 @@ __global__ __launch_bounds__(256) void kg_member_stats(const u32 *tile_cnt, cons
 }
 
 // ---------------------------------------------------------------------------------------------
-// K1 in ONE pass (k1_walk): k1_count and k1_emit read every record twice -- the second time as a gather over the
-// spliced third of the reads, three dependent loads deep -- because a tile cannot place its pairs before it knows how
-// many pairs all the tiles before it hold.  Here a tile counts, publishes its pair count, and while the answer to
-// "how many before me" is on its way the tile's spliced reads are staged in LDS; the emit walk then runs dense over the
-// staged columns.  Every record byte is read once, coalesced; nothing is written but the pairs.
-//
-// The offset comes through two levels so that no tile polls more than a few words (a plain decoupled look-back has
-// thousands of resident tiles walking back over each other through the fabric -- measured on the scans, see above):
-//   tile_desc[t]  VALID | pairs of tile t                     written by tile t as soon as it has counted
-//   grp_acc[g]    (tiles arrived << 40) + pairs               one atomic add per tile; K1W_GROUP tiles form a group
-//   grp_desc[g]   VALID | pairs of group g, later             written by the group's last arrival;
-//                 VALID | PREFIX | pairs of groups 0..g       upgraded by the first tile of group g + 1
-//   grp_excl[g]   VALID | pairs before group g                written by the group's first tile
-// The first tile of a group walks the group descriptors back to the nearest PREFIX (64 groups = 4096 tiles per step);
-// every other tile reads grp_excl of its group and the descriptors of the tiles before it in the group: one step.
-// Tile numbers are handed out by a ticket counter, so a tile only ever waits for tiles that are already running.
-// All flags travel inside the 8-byte word they guard: relaxed agent-scope atomics, no fences.
-// ---------------------------------------------------------------------------------------------
-constexpr int K1W_GROUP = 64;
-constexpr int K1W_THREADS = 512, K1W_RPT = K1_TILE / K1W_THREADS, K1W_WAVES = K1W_THREADS / 64; // two reads per thread
-constexpr int K1W_OPS = 6; // CIGAR operations staged per spliced read (longer CIGARs continue in global memory)
-constexpr u64 K1W_VALID = 1ull << 63, K1W_PREFIX = 1ull << 62, K1W_VALUE = (1ull << 40) - 1;
-constexpr u32 K1W_SPIN_LIMIT = 1u << 22;
-struct K1Look {
-    u32 *ticket;
-    u64 *tile_desc, *grp_acc, *grp_desc, *grp_excl;
-};
-__host__ __device__ inline size_t k1look_bytes(u32 n_tiles) {
-    const size_t ng = ((size_t)n_tiles + K1W_GROUP - 1) / K1W_GROUP;
-    return 8 + ((size_t)n_tiles + 3 * ng) * 8;
-}
-__host__ __device__ inline K1Look k1look_at(void *p, u32 n_tiles) {
-    const size_t ng = ((size_t)n_tiles + K1W_GROUP - 1) / K1W_GROUP;
-    K1Look L;
-    L.ticket = (u32 *)p;
-    L.tile_desc = (u64 *)p + 1;
-    L.grp_acc = L.tile_desc + n_tiles;
-    L.grp_desc = L.grp_acc + ng;
-    L.grp_excl = L.grp_desc + ng;
-    return L;
-}
-__device__ __forceinline__ u64 ld_agent(const u64 *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void st_agent(u64 *p, u64 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-// waits until the word carries VALID (a bounded wait: a tile that never arrives is a bug, not a hang)
-__device__ __forceinline__ u64 wait_valid(const u64 *p, u64 *err) {
-    u64 d = ld_agent(p);
-    u32 spins = 0;
-    while (!(d & K1W_VALID)) {
-        __builtin_amdgcn_s_sleep(2);
-        d = ld_agent(p);
-        if (++spins > K1W_SPIN_LIMIT) {
-            set_error(err, 0u, PJB_ERR_HIP);
-            return K1W_VALID;
-        }
-    }
-    return d;
-}
-__device__ __forceinline__ u64 wave_sum_u64(u64 v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
-
-__global__ __launch_bounds__(K1W_THREADS) void k1_walk(DevBatch b, K1Look Lk, u32 n_tiles_total, TileStats *tile_stats, u32 *spl_idx, Pairs P,
-                                                        KeyFmt kf, int32_t ref_len, int32_t tid, int orientation, u32 pair_limit, u64 *err) {
-    // staged columns, one per spliced read of the tile (slot = rank among the tile's spliced reads)
-    __shared__ u32 s_ops[K1W_OPS][K1_TILE];
-    __shared__ u32 s_rec[9][K1_TILE]; // pos, meta, n, rl | nN << 10, aend, lq, seq_off, pair offset in the tile, cig_off
-    __shared__ u64 sm64[K1W_WAVES];
-    __shared__ u64 sm_scan[K1W_RPT][K1W_WAVES];
-    __shared__ int32_t smi[K1W_WAVES][6];
-    __shared__ u64 smp[K1W_WAVES];
-    __shared__ u32 s_tile;
-    __shared__ u64 s_excl;
-    if (threadIdx.x == 0) s_tile = atomicAdd(Lk.ticket, 1u);
-    __syncthreads();
-    const u32 tile = s_tile;           // tile of the contig
-    const u32 lt = tile - b.tile_base; // tile of this batch
-    const int64_t base = (int64_t)lt * K1_TILE;
-    u32 cnt = 0, spl = 0, uns = 0;
-    u64 sum = 0;
-    int32_t mn = INT32_MAX, mx = 0, max_end = 0, max_nlen = 0, min_pos = INT32_MAX;
-    // ---- every load of the thread's reads, issued before anything is consumed
-    constexpr int K1_OPS = 4;
-    u32 c0[K1W_RPT], nop[K1W_RPT], ops[K1W_RPT][K1_OPS];
-    int32_t pos4[K1W_RPT], prev4[K1W_RPT], len4[K1W_RPT], mtid4[K1W_RPT], mpos4[K1W_RPT];
-    u32 xs4[K1W_RPT], c4[K1W_RPT], flag4[K1W_RPT], mapq4[K1W_RPT], so4[K1W_RPT], so4n[K1W_RPT];
-#pragma unroll
-    for (int it = 0; it < K1W_RPT; it++) {
-        const int64_t r = base + it * K1W_THREADS + threadIdx.x;
-        const bool on = r < b.n;
-        c0[it] = on ? b.cig_off[r] : 0u;
-        nop[it] = on ? b.cig_off[r + 1] - c0[it] : 0u;
-        pos4[it] = on ? b.pos[r] : 0;
-        prev4[it] = on ? (r > 0 ? b.pos[r - 1] : (b.prev_pos_ptr ? *b.prev_pos_ptr : b.prev_pos)) : 0;
-        xs4[it] = on ? (u32)b.xs[r] : 0u;
-        len4[it] = on ? b.l_qseq[r] : 0;
-        flag4[it] = on ? (u32)b.flag[r] : 0u;
-        mapq4[it] = on ? (u32)b.mapq[r] : 0u;
-        mtid4[it] = on ? b.mtid[r] : 0;
-        mpos4[it] = on ? b.mpos[r] : 0;
-        so4[it] = on ? b.seq_off[r] : 0u;
-        so4n[it] = on ? b.seq_off[r + 1] : 0u;
-    }
-#pragma unroll
-    for (int it = 0; it < K1W_RPT; it++)
-#pragma unroll
-        for (int k = 0; k < K1_OPS; k++) ops[it][k] = (u32)k < nop[it] ? b.cigar[c0[it] + k] : 0u;
-    // ---- count (BamAlignment::init bam_alignment.cc:71-100, findJuncs length stats src/junction_builder.cc:333-343)
-    int32_t aend4[K1W_RPT];
-    u32 meta4[K1W_RPT];
-#pragma unroll
-    for (int it = 0; it < K1W_RPT; it++) {
-        const int64_t r = base + it * K1W_THREADS + threadIdx.x;
-        u32 cthis = 0;
-        int32_t al = 0;
-        if (r < b.n) {
-            const int32_t p = pos4[it];
-            if (p < prev4[it]) set_error(err, b.base + (u32)r, PJB_ERR_UNSORTED);
-            if (xs4[it] > 2) set_error(err, b.base + (u32)r, PJB_ERR_BAD_XS);
-            u32 c = 0;
-            auto count_op = [&](u32 op) {
-                const u32 ty = op & 15u;
-                const int32_t ln = (int32_t)(op >> 4);
-                if (op_consumes_ref(ty)) al += ln;
-                if (ty == OP_N) {
-                    c++;
-                    max_nlen = ln > max_nlen ? ln : max_nlen;
-                }
-            };
-#pragma unroll
-            for (int k = 0; k < K1_OPS; k++) count_op(ops[it][k]); // padding ops are 0M: no effect
-            for (u32 k = K1_OPS; k < nop[it]; k++) count_op(b.cigar[c0[it] + k]);
-            const int32_t len = len4[it];
-            mn = len < mn ? len : mn;
-            mx = len > mx ? len : mx;
-            sum += (u64)(int64_t)len;
-            cnt += c;
-            if (c) {
-                spl++;
-                int32_t e = p + al;
-                max_end = e > max_end ? e : max_end;
-                min_pos = p < min_pos ? p : min_pos;
-            } else
-                uns++;
-            cthis = c;
-        }
-        c4[it] = cthis;
-        // what the staged column keeps of the read: aend, and the per-read predicates (bit 31: the record carries its bases)
-        aend4[it] = pos4[it] + al - 1;
-        u32 meta = read_meta(flag4[it], xs4[it], mapq4[it], pos4[it], mtid4[it], mpos4[it], tid, orientation);
-        if (cthis > 1) meta |= META_MULTI;
-        if ((u64)(so4n[it] - so4[it]) * 8ull >= (u64)(int64_t)len4[it]) meta |= 0x80000000u;
-        meta4[it] = meta;
-    }
-    // ---- ordered compaction: read order is round-major (r = base + it * K1W_THREADS + thread); one wave scan per round
-    u64 inc[K1W_RPT];
-    const int w = threadIdx.x >> 6;
-#pragma unroll
-    for (int it = 0; it < K1W_RPT; it++) {
-        inc[it] = wave_iscan<u64>(((u64)c4[it] << 16) | (u64)(c4[it] ? 1u : 0u));
-        if (lane_id() == 63) sm_scan[it][w] = inc[it];
-    }
-    // block reduce of the length statistics (as k1_count)
-    u64 packed = ((u64)wave_total<DppAdd>(cnt) << 32) | (u64)wave_total<DppAdd>((spl << 16) | uns);
-    sum = (u64)wave_total<DppAdd>((u32)(sum & 0xffffu)) + ((u64)wave_total<DppAdd>((u32)((sum >> 16) & 0xffffu)) << 16) +
-          ((u64)wave_total<DppAdd>((u32)(sum >> 32)) << 32);
-    auto smin = [](int32_t v) { return (int32_t)(wave_total<DppMin>((u32)v ^ 0x80000000u) ^ 0x80000000u); };
-    auto smax = [](int32_t v) { return (int32_t)(wave_total<DppMax>((u32)v ^ 0x80000000u) ^ 0x80000000u); };
-    mn = smin(mn);
-    mx = smax(mx);
-    max_end = smax(max_end);
-    max_nlen = smax(max_nlen);
-    min_pos = smin(min_pos);
-    if (lane_id() == 0) {
-        smp[w] = packed;
-        sm64[w] = sum;
-        smi[w][0] = mn;
-        smi[w][1] = mx;
-        smi[w][2] = max_end;
-        smi[w][3] = max_nlen;
-        smi[w][4] = min_pos;
-    }
-    __syncthreads();
-    u32 slot4[K1W_RPT], poff4[K1W_RPT]; // rank among the tile's spliced reads; pairs before the read, in read order within the tile
-    u64 run = 0;
-#pragma unroll
-    for (int it = 0; it < K1W_RPT; it++) {
-        u64 before = run;
-#pragma unroll
-        for (int i = 0; i < K1W_WAVES; i++) {
-            const u64 t = sm_scan[it][i];
-            if (i < w) before += t;
-            run += t;
-        }
-        const u64 ex = before + inc[it] - (((u64)c4[it] << 16) | (u64)(c4[it] ? 1u : 0u));
-        slot4[it] = (u32)(ex & 0xffffu);
-        poff4[it] = (u32)(ex >> 16);
-    }
-    const u64 tile_pairs = run >> 16;
-    const u32 tile_spl = (u32)(run & 0xffffu);
-    // ---- publish the tile's pair count; tile statistics
-    const u32 grp = tile / K1W_GROUP, gi = tile % K1W_GROUP;
-    if (threadIdx.x == 0) {
-        st_agent(&Lk.tile_desc[tile], K1W_VALID | tile_pairs);
-        const u32 gsize = min((u32)K1W_GROUP, n_tiles_total - grp * K1W_GROUP);
-        const u64 old = atomicAdd(&Lk.grp_acc[grp], (1ull << 40) | tile_pairs);
-        if ((u32)(old >> 40) + 1 == gsize) st_agent(&Lk.grp_desc[grp], K1W_VALID | (grp == 0 ? K1W_PREFIX : 0ull) | ((old & K1W_VALUE) + tile_pairs));
-        u64 p = 0, sl = 0;
-        int32_t a0 = INT32_MAX, a1 = 0, a2 = 0, a3 = 0, a4 = INT32_MAX;
-        for (int i = 0; i < K1W_WAVES; i++) {
-            p += smp[i];
-            sl += sm64[i];
-            a0 = min(a0, smi[i][0]);
-            a1 = max(a1, smi[i][1]);
-            a2 = max(a2, smi[i][2]);
-            a3 = max(a3, smi[i][3]);
-            a4 = min(a4, smi[i][4]);
-        }
-        TileStats t;
-        t.spliced = (u32)((p >> 16) & 0xffff);
-        t.unspliced = (u32)(p & 0xffff);
-        t.sum_len = sl;
-        t.min_len = a0;
-        t.max_len = a1;
-        t.max_end = a2;
-        t.max_nlen = a3;
-        t.min_pos = a4;
-        t._pad = 0;
-        tile_stats[tile] = t;
-    }
-    // ---- the first wave fetches the number of pairs before the tile; the others go on staging
-    if (w == 0) {
-        const int lane = lane_id();
-        u64 excl_g = 0;
-        if (gi == 0) {
-            int64_t gg = (int64_t)grp - 1;
-            while (gg >= 0) {
-                const int64_t my = gg - lane;
-                u64 d = 0;
-                if (my >= 0) d = wait_valid(&Lk.grp_desc[my], err);
-                const u64 pm = __ballot((d & K1W_PREFIX) != 0);
-                const int stop = pm ? __ffsll((unsigned long long)pm) - 1 : 64;
-                excl_g += wave_sum_u64((my >= 0 && lane <= stop) ? (d & K1W_VALUE) : 0ull);
-                if (pm) break;
-                gg -= 64;
-            }
-            if (lane == 0) {
-                st_agent(&Lk.grp_excl[grp], K1W_VALID | excl_g);
-                if (grp > 0) st_agent(&Lk.grp_desc[grp - 1], K1W_VALID | K1W_PREFIX | excl_g);
-            }
-        } else {
-            u64 d = 0;
-            if (lane == 0) d = wait_valid(&Lk.grp_excl[grp], err) & K1W_VALUE;
-            excl_g = __shfl(d, 0, 64);
-        }
-        u64 v = 0;
-        if ((u32)lane < gi) v = wait_valid(&Lk.tile_desc[(size_t)grp * K1W_GROUP + lane], err) & K1W_VALUE;
-        const u64 excl = excl_g + wave_sum_u64(v);
-        if (lane == 0) s_excl = excl;
-    }
-    // ---- stage the tile's spliced reads in LDS columns, then one thread per column walks and writes the pairs
-#pragma unroll
-    for (int it = 0; it < K1W_RPT; it++) {
-        if (c4[it]) {
-            const u32 rl = (u32)(it * K1W_THREADS) + threadIdx.x;
-            const u32 sl = slot4[it];
-#pragma unroll
-            for (int k = 0; k < K1_OPS; k++) s_ops[k][sl] = ops[it][k];
-            s_rec[0][sl] = (u32)pos4[it];
-            s_rec[1][sl] = meta4[it];
-            s_rec[2][sl] = nop[it];
-            s_rec[3][sl] = rl | (c4[it] << 10);
-            s_rec[4][sl] = (u32)aend4[it];
-            s_rec[5][sl] = (u32)len4[it];
-            s_rec[6][sl] = so4[it];
-            s_rec[7][sl] = poff4[it];
-            s_rec[8][sl] = c0[it];
-            if (spl_idx) spl_idx[(size_t)tile * K1_TILE + sl] = (u32)base + rl;
-        }
-    }
-    __syncthreads();
-    const u64 excl = s_excl;
-    if (excl + tile_pairs > (u64)pair_limit) return; // more pairs than planned: k1_scan_tiles raises OVF_PAIRS, the contig is repeated
-    for (u32 k = threadIdx.x; k < tile_spl; k += K1W_THREADS) {
-        EmitRead R;
-        R.pos = (int32_t)s_rec[0][k];
-        const u32 m = s_rec[1][k];
-        R.meta = m & 0x7fffffffu;
-        R.seq_ok = (m & 0x80000000u) != 0;
-        R.n = s_rec[2][k];
-        const u32 rn = s_rec[3][k];
-        R.nN = rn >> 10;
-        R.g = b.base + (u32)base + (rn & 1023u);
-        R.aend = (int32_t)s_rec[4][k];
-        R.lq = (int32_t)s_rec[5][k];
-        R.seq_ptr = (u64)(uintptr_t)(b.seq4 + (size_t)s_rec[6][k] * 4);
-        R.off = (u32)(excl + s_rec[7][k]);
-        OpsViewT<K1_TILE, K1W_OPS> cig;
-        cig.lds = &s_ops[0][k];
-        cig.g = b.cigar + s_rec[8][k];
-        // (the owner staged ops 0..3 from its registers; the rest of the column comes from lines it fetched a moment ago)
-#pragma unroll
-        for (int q = K1_OPS; q < K1W_OPS; q++) s_ops[q][k] = (u32)q < R.n ? cig.g[q] : 0u;
-        emit_read_pairs(cig, R, P, kf, ref_len, err);
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
 // K2d: ordered dense junction ids.  The intron key is 46-48 bits wide (contig coordinate + intron length): five radix
 // passes, the first of them over digits that differ for every junction of a tile.  But a contig has 10^4-10^5
 // distinct introns, and their RANK in (start, end) order needs 15-19 bits: two passes -- and because the ranks of
 // the junctions a tile touches are neighbours (pairs arrive in BAM order, ranks are ordered by start), both passes
 // scatter into a few long runs per tile.  The rank comes without sorting anything:
-//   kd_unique  pairs -> candidate keys (distinct per tile)
+//   k1_emit    pairs -> candidate keys (distinct per block residency; see there)
 //   kd_mark    one bit per contig base: an intron starts here
 //   scan       prefix popcount over the bitmap words  -> rank of a start among the distinct starts
 //   kd_ends    per start rank, the distinct intron ends seen (alternative acceptors: a handful; DENSE_ENDS slots)
-//   scan       number of ends per start rank           -> first junction id of every start
-//   kd_assign  id of a pair = first id of its start + number of that start's ends below its own end
+//   scan       number of ends per start rank           -> first junction id of every start (+ the anchors' rest state)
+//   kd_table   junction id -> intron key, from the candidates; closes the chain if a limit was exceeded
+//   kd_assign  id of a pair = first id of its start + number of that start's ends below its own end; the junction's
+//              anchors (min lStart, max rEnd over its pairs, junction.cc:477-529) while the pair is in registers
 // Grouping by id is grouping by (start, end), id order is (start, end) order, so everything downstream -- segment
 // heads, fragments, row order -- works on the ids as it did on the keys.  A start with more than DENSE_ENDS different
 // ends raises OVF_DENSE and the contig is repeated with the full-key sort.
@@ -1603,66 +1551,7 @@ __device__ __forceinline__ u32 start_rank(const u64 *bitmap, const u32 *wrank, i
 // Pairs arrive in BAM order, so the pairs of a junction sit close together, and a deep junction is one key repeated 10^5
 // times.  Operations on device memory that many waves aim at one address (or one cache line: the bitmap words of
 // neighbouring starts) are served one after the other by a single L2 channel -- measured, 0.5 ns each, 1.4 ms for the
-// pairs of one contig.  So the pairs are first reduced to a CANDIDATE list: every tile of KD_TILE pairs inserts its
-// keys (run heads only) into a hash set in LDS and appends the distinct ones; a junction appears once per tile it
-// touches, the list is 1-2x the number of junctions, and only it touches the bitmap and the end slots.
-constexpr int KD_TILE = 2048;  // pairs per block (256 threads x 8)
-constexpr int KD_SLOTS = 4096; // LDS set: at most half full
-constexpr u64 KD_EMPTY = ~0ull; // no key: a packed key has fewer than 64 bits
-__device__ __forceinline__ bool first_of_key_run(u64 k, bool on) {
-    const u64 prev = __shfl_up(k, 1, 64);
-    const bool prev_on = __shfl_up((int)on, 1, 64) != 0;
-    return on && (lane_id() == 0 || !prev_on || prev != k);
-}
-__global__ __launch_bounds__(256) void kd_unique(const u64 *key, const u32 *np, u64 *cand, ContigStats *cs) {
-    __shared__ u64 set[KD_SLOTS];
-    __shared__ u32 sm[4];
-    __shared__ u32 base_s;
-    const u32 n = *np;
-    const u32 tile0 = blockIdx.x * KD_TILE;
-    if (tile0 >= n) return;
-    for (int i = threadIdx.x; i < KD_SLOTS; i += 256) set[i] = KD_EMPTY;
-    __syncthreads();
-    u64 kk[KD_TILE / 256]; // (the tile's keys are fetched together, unconditionally: see k1_count)
-#pragma unroll
-    for (int i = 0; i < KD_TILE / 256; i++) {
-        const u32 p = tile0 + i * 256 + threadIdx.x;
-        kk[i] = key[p < n ? p : n - 1];
-    }
-#pragma unroll
-    for (int i = 0; i < KD_TILE / 256; i++) {
-        const u32 p = tile0 + i * 256 + threadIdx.x;
-        const bool on = p < n;
-        const u64 k = on ? kk[i] : 0;
-        if (!first_of_key_run(k, on)) continue;
-        u32 h = (u32)((k * 0x9E3779B97F4A7C15ull) >> 52) & (KD_SLOTS - 1);
-        for (;;) { // look first: after the first round most keys are there already, and a read of one address by many lanes is a broadcast
-            u64 old = set[h];
-            if (old == k) break;
-            if (old == KD_EMPTY) {
-                old = atomicCAS((unsigned long long *)&set[h], (unsigned long long)KD_EMPTY, (unsigned long long)k);
-                if (old == KD_EMPTY || old == k) break;
-            }
-            h = (h + 1) & (KD_SLOTS - 1);
-        }
-    }
-    __syncthreads();
-    u64 mine[KD_SLOTS / 256];
-    u32 cnt = 0;
-#pragma unroll
-    for (int i = 0; i < KD_SLOTS / 256; i++) {
-        mine[i] = set[i * 256 + threadIdx.x];
-        cnt += mine[i] != KD_EMPTY;
-    }
-    u32 total;
-    const u32 excl = block_escan_256(cnt, sm, &total);
-    if (threadIdx.x == 0) base_s = atomicAdd(&cs->n_cand, total);
-    __syncthreads();
-    u32 o = base_s + excl;
-#pragma unroll
-    for (int i = 0; i < KD_SLOTS / 256; i++)
-        if (mine[i] != KD_EMPTY) cand[o++] = mine[i];
-}
+// pairs of one contig.  So only the CANDIDATE list (1-3x the number of junctions) touches the bitmap and the end slots.
 // candidates -> one bit per contig base: an intron starts here
 __global__ __launch_bounds__(256) void kd_mark(const u64 *cand, const ContigStats *cs, KeyFmt kf, u64 *bitmap) {
     const u32 p = blockIdx.x * 256 + threadIdx.x;
@@ -1720,22 +1609,127 @@ struct EndsCountFn {
                      (b.y != DENSE_EMPTY) + (b.z != DENSE_EMPTY) + (b.w != DENSE_EMPTY));
     }
 };
-// one thread: a limit was exceeded while the ids were built -> nothing downstream runs (the host repeats the contig)
-__global__ void kd_close(ContigStats *cs) {
-    if (cs->overflow) cs->P = 0;
-}
-__global__ __launch_bounds__(256) void kd_assign(const u64 *key, const u32 *np, KeyFmt kf, const u64 *bitmap, const u32 *wrank, const u32 *ends,
-                                                 const u32 *first_id, u64 *jid_key) {
-    const u32 p = blockIdx.x * 256 + threadIdx.x;
-    if (p >= *np) return;
-    int32_t s, e;
-    unpack_key(kf, key[p], s, e);
-    const u32 rs = start_rank(bitmap, wrank, s);
+// sink of the scan over the start ranks (junc_limit entries): first junction id of the start, and -- entry i of the
+// junction-sized anchor arrays -- the rest state kd_assign's atomics start from
+struct FirstIdSink {
+    u32 *first_id;
+    int32_t *anc_l, *anc_r;
+    __device__ void operator()(u64 i, u64, u64 ex) const {
+        first_id[i] = (u32)ex;
+        anc_l[i] = INT32_MAX;
+        anc_r[i] = INT32_MIN;
+    }
+};
+__device__ __forceinline__ u32 ends_below(const u32 *ends, u32 rs, u32 ue) { // (DENSE_EMPTY slots compare as larger than any end)
     const uint4 *q = reinterpret_cast<const uint4 *>(ends + (size_t)rs * DENSE_ENDS);
     const uint4 a = q[0], b = q[1];
-    const u32 ue = (u32)e; // DENSE_EMPTY slots compare as larger than any end
-    const u32 below = (a.x < ue) + (a.y < ue) + (a.z < ue) + (a.w < ue) + (b.x < ue) + (b.y < ue) + (b.z < ue) + (b.w < ue);
-    jid_key[p] = (u64)(first_id[rs] + below);
+    return (a.x < ue) + (a.y < ue) + (a.z < ue) + (a.w < ue) + (b.x < ue) + (b.y < ue) + (b.z < ue) + (b.w < ue);
+}
+// junction id -> intron key (every candidate writes its junction's entry: duplicates write the same value); thread 0 closes
+// the chain -- P = 0, nothing downstream runs, the host repeats the contig -- if a limit was exceeded while the ids were built
+__global__ __launch_bounds__(256) void kd_table(const u64 *cand, const u32 *cand_rank, KeyFmt kf, u32 junc_limit, const u32 *ends,
+                                                const u32 *first_id, const u64 *total, u64 *jkey, ContigStats *cs) {
+    const u32 p = blockIdx.x * 256 + threadIdx.x;
+    if (p == 0) {
+        const u64 J = *total;
+        u32 ovf = cs->overflow;
+        if (cs->P != 0 && J > (u64)junc_limit) {
+            ovf |= OVF_JUNC;
+            cs->overflow = ovf;
+            cs->n_junc = (u32)(J < 0xffffffffull ? J : 0xffffffffull);
+        }
+        if (ovf) cs->P = 0;
+    }
+    if (p >= cs->n_cand) return;
+    const u32 rs = cand_rank[p];
+    if (rs >= junc_limit) return;
+    int32_t s, e;
+    unpack_key(kf, cand[p], s, e);
+    const u32 id = first_id[rs] + ends_below(ends, rs, (u32)e);
+    if (id < junc_limit) jkey[id] = cand[p];
+}
+
+// Junction anchors from pairs that sit in the lanes of a wavefront (any order): leftAncStart = min lStart, rightAncEnd = max
+// rEnd (junction.cc:477-529).  Lanes that share a junction with their neighbours are folded first; a head lane whose value
+// would not move the junction's current one (a plain read: the arrays only ever move one way, so a stale value errs on the
+// side of one atomic too many) does not touch it -- a deep junction costs a handful of atomics, not one per wavefront.
+template <typename T, typename OP>
+__device__ __forceinline__ T seg_reduce_to_head(T v, u32 segkey, OP op) {
+    const int l = lane_id();
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        T t = __shfl_down(v, o, 64);
+        u32 k = __shfl_down(segkey, o, 64);
+        if (l + o < 64 && k == segkey) v = op(v, t);
+    }
+    return v;
+}
+struct OpMin { template <typename T> __device__ T operator()(T a, T b) const { return a < b ? a : b; } };
+struct OpMax { template <typename T> __device__ T operator()(T a, T b) const { return a > b ? a : b; } };
+struct OpAdd { template <typename T> __device__ T operator()(T a, T b) const { return a + b; } };
+__device__ __forceinline__ void anchors_fold(bool valid, u32 j, int32_t l, int32_t r, int32_t *anc_l, int32_t *anc_r) {
+    if (!valid) {
+        j = 0xffffffffu;
+        l = INT32_MAX;
+        r = INT32_MIN;
+    }
+    const u32 j0 = (u32)__builtin_amdgcn_readfirstlane((int)j);
+    bool head;
+    if (__ballot(j != j0) == 0) { // one junction in the wavefront (the usual case): whole-wave min / max on the DPP path
+        l = (int32_t)(wave_total<DppMin>((u32)l ^ 0x80000000u) ^ 0x80000000u); // (signed order through the sign bit)
+        r = (int32_t)(wave_total<DppMax>((u32)r ^ 0x80000000u) ^ 0x80000000u);
+        head = lane_id() == 0;
+    } else {
+        l = seg_reduce_to_head(l, j, OpMin());
+        r = seg_reduce_to_head(r, j, OpMax());
+        const u32 jprev = __shfl_up(j, 1, 64);
+        head = lane_id() == 0 || jprev != j;
+    }
+    if (head && j != 0xffffffffu) {
+        if (l < anc_l[j]) atomicMin(&anc_l[j], l);
+        if (r > anc_r[j]) atomicMax(&anc_r[j], r);
+    }
+}
+
+// fragment record of the per-junction reductions: 48 words (see k4_pairs)
+enum {
+    F_N = 0, F_R1P, F_R1N, F_R2P, F_R2N, F_MS, F_XSP, F_XSN, F_UM, F_BPP, F_PPP, F_REL, F_DIST, // sums
+    F_MAXMINANC, F_UP, F_DOWN, F_MAXMMES, F_MAXMINMATCH,                                       // max
+    F_FIRSTMIS,                                                                                 // min
+    F_PAD19,                                                                                    // keeps the next pair 8-byte aligned
+    F_MISM_LO, F_MISM_HI,                                                                       // 64-bit sum
+    F_JAD0,                                                                                     // 20 sums
+    F_WORDS = 48
+};
+__device__ __forceinline__ void acc_rest_state(u32 *acc, u64 n_junc) { // what k5_frag_reduce's atomics start from: sums 0, max 0, min 100000000
+    const u64 n = n_junc * F_WORDS, step = (u64)gridDim.x * blockDim.x;
+    for (u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += step) acc[t] = (t % F_WORDS) == F_FIRSTMIS ? 100000000u : 0u;
+}
+
+__global__ __launch_bounds__(256) void kd_assign(const u64 *key, const PairRec *rec, const u32 *np, KeyFmt kf, const u64 *bitmap, const u32 *wrank,
+                                                 const u32 *ends, const u32 *first_id, u32 junc_limit, const u64 *total, u64 *jid_key, u32 *jid_bam,
+                                                 int32_t *anc_l, int32_t *anc_r, u32 *acc) {
+    const u32 n = *np;
+    if (n == 0) return;
+    {
+        const u64 J = *total;
+        acc_rest_state(acc, J < (u64)junc_limit ? J : (u64)junc_limit);
+    }
+    if (blockIdx.x * 256u >= n) return;
+    const u32 p = blockIdx.x * 256 + threadIdx.x;
+    const bool valid = p < n;
+    const u32 pc = valid ? p : n - 1; // (loads unconditional, from the last pair for the lanes past the end, masked after: see k1_count)
+    const u64 k = key[pc];
+    const uint4 ra = *reinterpret_cast<const uint4 *>(rec + pc); // aux | lstart | rend
+    int32_t s, e;
+    unpack_key(kf, k, s, e);
+    const u32 rs = start_rank(bitmap, wrank, s);
+    const u32 id = first_id[rs] + ends_below(ends, rs, (u32)e);
+    if (valid) {
+        jid_key[p] = (u64)id;
+        jid_bam[p] = id;
+    }
+    anchors_fold(valid && id < junc_limit, id, (int32_t)ra.z, (int32_t)ra.w, anc_l, anc_r);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2013,12 +2007,12 @@ __global__ __launch_bounds__(256, 3) void rs_scatter(const u64 *kin, const u32 *
 struct HeadFn {
     const u64 *skey;
     const u32 *sidx;
-    const int32_t *ppos;
+    const PairRec *rec;
     __device__ u64 operator()(u64 i) const {
         const u64 im = i ? i - 1 : 0; // (every load unconditional)
         const u64 ka = skey[i], kb = skey[im];
         const u32 sa = sidx[i], sb = sidx[im];
-        const int32_t pa = ppos[sa], pb = ppos[sb];
+        const int32_t pa = rec[sa].pos, pb = rec[sb].pos;
         const bool hj = i == 0 || ka != kb;
         const bool hr = hj || pa != pb;
         return ((u64)hj << 32) | (u64)hr;
@@ -2029,6 +2023,8 @@ struct HeadSink {
     u32 *seg_off;   // [J+1] first sorted pair of junction
     u32 *run_first; // [J+1] first run of junction
     u32 *run_start; // [R+1] first sorted pair of run
+    const u64 *skey;
+    u64 *jkey;      // [J]   intron key of the junction -- when the sort ran on the full keys (nullptr: K2d left the table)
     __device__ void operator()(u64 i, u64 v, u64 ex) const {
         const u32 j = (u32)(ex >> 32) + (u32)(v >> 32) - 1; // inclusive count - 1
         const u32 r = (u32)ex + (u32)v - 1;
@@ -2036,6 +2032,7 @@ struct HeadSink {
         if (v >> 32) {
             seg_off[j] = (u32)i;
             run_first[j] = r;
+            if (jkey) jkey[j] = skey[i];
         }
         if ((u32)v) run_start[r] = (u32)i;
     }
@@ -2044,9 +2041,6 @@ __global__ void k2_close(u64 *total, u32 *seg_off, u32 *run_first, u32 *run_star
     const u32 n_pairs = cs->P;
     if (n_pairs == 0) return;
     const u32 J = (u32)(*total >> 32), R = (u32)*total;
-    seg_off[J] = n_pairs;
-    run_first[J] = R;
-    run_start[R] = n_pairs;
     cs->n_junc = J;
     cs->n_runs = R;
     if (J > junc_limit) { // the junction-sized buffers are too small: everything downstream stands still
@@ -2054,111 +2048,38 @@ __global__ void k2_close(u64 *total, u32 *seg_off, u32 *run_first, u32 *run_star
         cs->P = 0;
         return;
     }
+    seg_off[J] = n_pairs;
+    run_first[J] = R;
+    run_start[R] = n_pairs;
     cs->J = J;
     cs->R = R;
     cs->n_slots = J + (n_pairs + 63) / 64;
 }
 
 // ---------------------------------------------------------------------------------------------
-// Fragments.  The sorted pair array is processed in fixed 64-pair slices (one wavefront each).
-// A fragment is a maximal run of one junction inside one slice; its slot is jid + slice index,
-// which is unique and increasing along the array (a slot is skipped when a junction starts
-// exactly on a slice boundary).  Kernels reduce pairs -> fragment slots with a segmented wave
-// reduction, a second small kernel reduces slots -> junctions (segmented again, then one atomic
-// per wave and junction), so a junction with 10^6 pairs costs ~250 same-address atomics, not 10^6.
+// The chain that sorted the FULL keys (PJB_DENSE_IDS off, raw keys, or a donor with more acceptors than K2d keeps) has its
+// junction ids only now: two small kernels give it what kd_assign gives the usual chain -- the rest state of anchors and
+// accumulators, the junction id of every pair in BAM order (k4b_generic works in BAM order) and the anchors.
 // ---------------------------------------------------------------------------------------------
-
-// segmented (by key) reduce towards the segment's FIRST lane; keys are sorted across lanes
-template <typename T, typename OP>
-__device__ __forceinline__ T seg_reduce_to_head(T v, u32 segkey, OP op) {
-    const int l = lane_id();
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        T t = __shfl_down(v, o, 64);
-        u32 k = __shfl_down(segkey, o, 64);
-        if (l + o < 64 && k == segkey) v = op(v, t);
+__global__ __launch_bounds__(256) void kf_init(u32 *acc, const u32 *n_junc_p, int32_t *anc_l, int32_t *anc_r) {
+    const u32 n_junc = *n_junc_p;
+    acc_rest_state(acc, n_junc);
+    for (u64 t = (u64)blockIdx.x * 256 + threadIdx.x; t < n_junc; t += (u64)gridDim.x * 256) {
+        anc_l[t] = INT32_MAX;
+        anc_r[t] = INT32_MIN;
     }
-    return v;
 }
-struct OpMin { template <typename T> __device__ T operator()(T a, T b) const { return a < b ? a : b; } };
-struct OpMax { template <typename T> __device__ T operator()(T a, T b) const { return a > b ? a : b; } };
-struct OpAdd { template <typename T> __device__ T operator()(T a, T b) const { return a + b; } };
-
-constexpr u32 GEN_SHARDS = 256;
-// K3: anchors per fragment
-__global__ __launch_bounds__(256) void k3_anchors_frag(const u32 *sidx, const u32 *jid_of, const int32_t *lstart,
-                                                        const int32_t *rend, const u32 *meta, int all_generic, const u32 *np,
-                                                        int32_t *frag_l, int32_t *frag_r, int32_t *frag_j, u32 *gen_list,
-                                                        u32 *gen_count) {
+__global__ __launch_bounds__(256) void kf_anchors(const u32 *sidx, const u32 *jid_of, const PairRec *rec, const u32 *np, u32 *jid_bam, int32_t *anc_l,
+                                                   int32_t *anc_r) {
     const u32 n = *np;
     if (blockIdx.x * 256u >= n) return;
     const u32 i = blockIdx.x * 256 + threadIdx.x;
     const bool valid = i < n;
-    const u32 ic = valid ? i : n - 1; // (loads unconditional, from the last pair for the lanes past the end, masked after: see k1_count)
-    const u32 p = sidx[ic];
-    // every load first, then the list's returning atomic, the anchors while it is in flight, the list entry last
-    const u32 jv = jid_of[ic], mv = meta[p];
-    const int32_t lv = lstart[p], rv = rend[p];
-    const u32 j = valid ? jv : 0xffffffffu;
-    const u32 m_ = valid ? mv : META_SIMPLE;
-    int32_t l = valid ? lv : INT32_MAX;
-    int32_t r = valid ? rv : INT32_MIN;
-    // compact the sorted positions whose pair needs the generic compare (order is irrelevant).
-    // GEN_SHARDS independent sub-lists keep the returning atomics off a single address.
-    const bool gen = valid && (all_generic || !(m_ & META_SIMPLE));
-    const u64 gm = __ballot(gen);
-    const u32 shard = blockIdx.x % GEN_SHARDS;
-    const u32 cap = ((gridDim.x + GEN_SHARDS - 1) / GEN_SHARDS) * 256;
-    const int leader = gm ? __ffsll((long long)gm) - 1 : 0;
-    u32 base = 0;
-    if (gm && lane_id() == leader) base = atomicAdd(&gen_count[shard], (u32)__popcll(gm));
-    const u32 j0 = (u32)__builtin_amdgcn_readfirstlane((int)j);
-    if (__ballot(valid && j != j0) == 0) { // one junction in the wavefront (the usual case): whole-wave min / max on the DPP path
-        l = (int32_t)(wave_total<DppMin>((u32)l ^ 0x80000000u) ^ 0x80000000u); // (signed order through the sign bit)
-        r = (int32_t)(wave_total<DppMax>((u32)r ^ 0x80000000u) ^ 0x80000000u);
-        if (valid && lane_id() == 0) {
-            const u32 slot = j + (i >> 6);
-            frag_l[slot] = l;
-            frag_r[slot] = r;
-            frag_j[slot] = (int32_t)j;
-        }
-    } else {
-        l = seg_reduce_to_head(l, j, OpMin());
-        r = seg_reduce_to_head(r, j, OpMax());
-        const u32 jprev = __shfl_up(j, 1, 64);
-        const bool head = valid && (lane_id() == 0 || jprev != j);
-        if (head) {
-            const u32 slot = j + (i >> 6);
-            frag_l[slot] = l;
-            frag_r[slot] = r;
-            frag_j[slot] = (int32_t)j;
-        }
-    }
-    if (gm) {
-        base = (u32)__builtin_amdgcn_readlane((int)base, leader);
-        if (gen) gen_list[(size_t)shard * cap + base + (u32)__popcll(gm & ((1ull << lane_id()) - 1))] = i;
-    }
-}
-// K3b: fragment slots -> junction anchors (anc_l/anc_r pre-initialised to INT32_MAX / INT32_MIN)
-__global__ __launch_bounds__(256) void k3_anchors_junc(const int32_t *frag_l, const int32_t *frag_r, const int32_t *frag_j,
-                                                        const u32 *n_slots_p, int32_t *anc_l, int32_t *anc_r) {
-    const u32 n_slots = *n_slots_p;
-    if (blockIdx.x * 256u >= n_slots) return;
-    const u32 s = blockIdx.x * 256 + threadIdx.x;
-    const bool in = s < n_slots;
-    const int32_t jj = in ? frag_j[s] : -1;
-    const bool valid = jj >= 0;
-    // unused slots get a key that never equals a neighbour's
-    const u32 key = valid ? (u32)jj : (0x80000000u | s);
-    int32_t l = valid ? frag_l[s] : INT32_MAX;
-    int32_t r = valid ? frag_r[s] : INT32_MIN;
-    l = seg_reduce_to_head(l, key, OpMin());
-    r = seg_reduce_to_head(r, key, OpMax());
-    const u32 kprev = __shfl_up(key, 1, 64);
-    if (valid && (lane_id() == 0 || kprev != key)) {
-        atomicMin(&anc_l[jj], l);
-        atomicMax(&anc_r[jj], r);
-    }
+    const u32 ic = valid ? i : n - 1;
+    const u32 p = sidx[ic], j = jid_of[ic];
+    const uint4 ra = *reinterpret_cast<const uint4 *>(rec + p);
+    if (valid) jid_bam[p] = j;
+    anchors_fold(valid, j, (int32_t)ra.z, (int32_t)ra.w, anc_l, anc_r);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2167,89 +2088,11 @@ __global__ __launch_bounds__(256) void k3_anchors_junc(const int32_t *frag_l, co
 // counting instead of building strings: the query walk and the genome walk are advanced in
 // lock-step over the CIGAR and their emissions compared op by op.
 // ---------------------------------------------------------------------------------------------
+constexpr int GENERIC_NW = 5;
 struct Side {
     int32_t len, mism, first_mis, last_mis;
     int err;
 };
-
-__device__ __forceinline__ u32 nt16_ascii(u32 c) { // seq_nt16_str "=ACMGRSVTWYHKDBN"
-    // bytes: '=' 3D, 'A' 41, 'C' 43, 'M' 4D, 'G' 47, 'R' 52, 'S' 53, 'V' 56 | 'T' 54,'W' 57,'Y' 59,'H' 48,'K' 4B,'D' 44,'B' 42,'N' 4E
-    const u64 t0 = 0x565352474D43413DULL;
-    const u64 t1 = 0x4E42444B48595754ULL;
-    const u64 t = (c & 8u) ? t1 : t0;
-    return (u32)(t >> ((c & 7u) * 8)) & 0xffu;
-}
-
-// Read nibbles [qi, qi+l) (BAM order: high nibble first) against genome codes [gi, gi+l) (low nibble first), 64 bases
-// = 9 words of each per round; mismatch positions are reported relative to `out_base`.
-//   A lane's words are consecutive but the next lane's are somewhere else, so every load instruction of the wave
-// touches 64 cache lines whatever its width, and the number of load INSTRUCTIONS sets the pace (measured in
-// k4a_simple: 19 per-word loads per read cost 80 us per contig, the compare itself nothing).  So the words come as two
-// 16-byte loads and one 4-byte load per stream -- 4-byte aligned (reads start on word boundaries), which
-// global_load_dwordx4 accepts -- guarded so that nothing is read past the read's last word / the contig's last code
-// word; the short tail of a stream takes guarded word loads.
-__device__ __forceinline__ u32 swap_nibbles(u32 x) { return ((x & 0x0F0F0F0Fu) << 4) | ((x >> 4) & 0x0F0F0F0Fu); }
-struct __attribute__((packed, aligned(4))) Words4 {
-    u32 x, y, z, w;
-};
-struct CmpChunk {
-    u32 qw[9], gg[9];
-};
-// d[k] = p[first + k] for 0 <= first + k <= last, else 0 (first + 8 <= last: three loads)
-__device__ __forceinline__ void load9(u32 (&d)[9], const u32 *p, int32_t first, int32_t last) {
-    if (first >= 0 && first + 8 <= last) {
-        const Words4 a = gload(reinterpret_cast<const Words4 *>(p + first)), b = gload(reinterpret_cast<const Words4 *>(p + first + 4));
-        d[0] = a.x, d[1] = a.y, d[2] = a.z, d[3] = a.w;
-        d[4] = b.x, d[5] = b.y, d[6] = b.z, d[7] = b.w;
-        d[8] = gload(p + first + 8);
-    } else {
-#pragma unroll
-        for (int k = 0; k < 9; k++) d[k] = (first + k >= 0 && first + k <= last) ? gload(p + first + k) : 0u;
-    }
-}
-// anchor bases [t, t + 64) of an anchor of l bases: read bases from qi (words of the read up to word q_last may be
-// touched: whatever lies past the anchor only feeds bits that the length mask removes), genome from gi
-__device__ __forceinline__ void chunk_load(CmpChunk &C, bool active, const u32 *seqw, int32_t qi, int32_t q_last, const u32 *gw, int32_t gi,
-                                           int32_t g_words, int32_t l, int32_t t) {
-    if (!active) return;
-    const int32_t lastg = (gi + l - 1) >> 3;
-    load9(C.qw, seqw, (qi + t) >> 3, q_last);
-    // (genome words outside [0, g_words) and past the anchor's last word read as 0, as they always did)
-    load9(C.gg, gw, (gi + t) >> 3, lastg < g_words - 1 ? lastg : g_words - 1);
-}
-__device__ __forceinline__ void chunk_cmp(CmpChunk &C, bool active, int32_t qi, int32_t gi, int32_t l, int32_t t, int32_t out_base,
-                                          int32_t &mism, int32_t &first_mis, int32_t &last_mis) {
-    if (!active) return;
-    const u32 shq = (u32)(qi & 7) * 4u, shg = (u32)(gi & 7) * 4u; // (t is a multiple of 8: the shifts do not move)
-#pragma unroll
-    for (int k = 0; k < 9; k++) C.qw[k] = swap_nibbles(C.qw[k]);
-#pragma unroll
-    for (int c = 0; c < 8; c++) {
-        const int32_t rem = l - t - 8 * c;
-        if (rem > 0) {
-            const u32 q = __builtin_amdgcn_alignbit(C.qw[c + 1], C.qw[c], shq);
-            const u32 g = __builtin_amdgcn_alignbit(C.gg[c + 1], C.gg[c], shg);
-            const u32 x = q ^ g;
-            u32 m = (((x & 0x77777777u) + 0x77777777u) | x) & 0x88888888u; // top bit of every nibble that differs
-            if (rem < 8) m &= (1u << (4 * rem)) - 1u;
-            if (m) {
-                mism += __popc(m);
-                if (first_mis < 0) first_mis = out_base + t + 8 * c + ((__ffs((int)m) - 1) >> 2);
-                last_mis = out_base + t + 8 * c + ((31 - __clz((int)m)) >> 2);
-            }
-        }
-    }
-}
-// one stretch of l bases (the generic walks: one call per CIGAR operation that emits bases on both sides)
-__device__ __forceinline__ void cmp_words(const u32 *seqw, int32_t qi, int32_t q_last, const u32 *gw, int32_t gi, int32_t g_words, int32_t l,
-                                          int32_t out_base, int32_t &mism, int32_t &first_mis, int32_t &last_mis) {
-    for (int32_t t = 0; t < l; t += 64) {
-        CmpChunk C;
-        chunk_load(C, true, seqw, qi, q_last, gw, gi, g_words, l, t);
-        chunk_cmp(C, true, qi, gi, l, t, out_base, mism, first_mis, last_mis);
-    }
-}
-
 
 // (k0, r0, q0): the operation the walks start at and the reference / query position there -- (0, position, 0), or, from the
 // pair's hint, the first operation that starts inside the window: everything before it the walks only step over
@@ -2352,8 +2195,8 @@ __device__ Side anchor_side(const OpsView cig, u32 n, int32_t position, int32_t 
         if (qEmit != gEmit) diverged = true;
         if (!diverged && qEmit > 0) {
             if (qKind == 1 && gKind == 1 && gcodes != nullptr && rPos >= 0 && rPos + qEmit <= glen) {
-                cmp_words(reinterpret_cast<const u32 *>(seq), dS + qPos, ((lq + 7) >> 3) - 1, gcodes, rPos, (glen + 7) / 8 + 1, qEmit, qTot,
-                          mism, first_mis, last_mis);
+                cmp_words<GENERIC_NW>(reinterpret_cast<const u32 *>(seq), dS + qPos, ((lq + 7) >> 3) - 1, gcodes, rPos, (glen + 7) / 8 + 1, qEmit, qTot,
+                                      mism, first_mis, last_mis);
             } else if (qKind == 1 && gKind == 1) {
                 const int32_t qb = dS + qPos;
                 for (int32_t t = 0; t < qEmit; t++) {
@@ -2412,39 +2255,33 @@ __device__ Side anchor_side(const OpsView cig, u32 n, int32_t position, int32_t 
 // per-pair match statistics through the generic lock-step walks (any CIGAR)
 __device__ __forceinline__ u64 pair_stats_generic(const OpsView cig, u32 nc, int32_t pos, int32_t aligned, const uint8_t *seq,
                                                   int32_t lq, const uint8_t *genome, int32_t glen, bool has_x, const u32 *gcodes,
-                                                  int32_t left, int32_t istart, int32_t iend, int32_t right, u32 g, u64 *err, u64 hint) {
+                                                  int32_t left, int32_t istart, int32_t iend, int32_t right, u32 g, u64 *err, u32 opi,
+                                                  int32_t qN) {
     if (lq <= 1) { // junction.cc:168-185
         const u32 totUp = (u32)((istart - 1) - left + 1);
         const u32 totDown = (u32)(right - (iend + 1) + 1);
         return pack_res(0, totUp < totDown ? totUp : totDown, 0);
     }
-    // Where the walks start.  Without a hint: at the read's first operation.  With it: the left side walks BACK from the pair's
-    // N operation (which starts at istart, qN query bases into the read) to the first operation that starts inside the window
-    // -- an operation that starts before the window is stepped over whole by the walks, and so is everything before it --, the
-    // right side starts at the operation behind the N.  (A read of 95 operations and 15 introns walked all 95 four times per pair.)
-    u32 kL = 0, kR = 0;
-    int32_t rL = pos, qL = 0, rR = pos, qR = 0;
-    const u32 opi = (u32)hint & ~WALK_HINT;
-    if (((u32)hint & WALK_HINT) && opi < nc && (cig[opi] & 15u) == OP_N) {
-        const int32_t qN = (int32_t)(hint >> 32);
-        kL = opi;
-        rL = istart;
-        qL = qN;
-        while (kL > 0) {
-            const u32 op = cig[kL - 1], ty = op & 15u;
-            const int32_t ln = (int32_t)(op >> 4);
-            const int32_t rp = rL - (op_consumes_ref(ty) ? ln : 0);
-            if (rp < left) break; // (it starts before the window: stepped over, like all before it)
-            kL--;
-            rL = rp;
-            if (op_consumes_query(ty) && ty != OP_S) qL -= ln;
-        }
-        const int32_t after = istart + (int32_t)(cig[opi] >> 4); // the walks' position behind the N (iend + 1 unless it was clamped)
-        if (after == iend + 1) {
-            kR = opi + 1;
-            rR = after;
-            qR = qN;
-        }
+    // Where the walks start.  The pair's N operation is operation `opi`; it starts at istart, qN query bases into the read.  The
+    // left side walks BACK from it to the first operation that starts inside the window -- an operation that starts before the
+    // window is stepped over whole by the walks, and so is everything before it --, the right side starts at the operation
+    // behind the N.  (A read of 95 operations and 15 introns walked all 95 four times per pair.)
+    u32 kL = opi, kR = 0;
+    int32_t rL = istart, qL = qN, rR = pos, qR = 0;
+    while (kL > 0) {
+        const u32 op = cig[kL - 1], ty = op & 15u;
+        const int32_t ln = (int32_t)(op >> 4);
+        const int32_t rp = rL - (op_consumes_ref(ty) ? ln : 0);
+        if (rp < left) break; // (it starts before the window: stepped over, like all before it)
+        kL--;
+        rL = rp;
+        if (op_consumes_query(ty) && ty != OP_S) qL -= ln;
+    }
+    const int32_t after = istart + (int32_t)(cig[opi] >> 4); // the walks' position behind the N (iend + 1 unless it was clamped)
+    if (after == iend + 1) {
+        kR = opi + 1;
+        rR = after;
+        qR = qN;
     }
     const Side L = anchor_side(cig, nc, pos, aligned, seq, lq, genome, glen, has_x, gcodes, left, istart - 1, kL, rL, qL);
     if (L.err) {
@@ -2472,69 +2309,23 @@ __device__ __forceinline__ const DevBatch &find_batch(const DevBatch *batches, i
     return batches[lo];
 }
 
-// K4a: the common shape [S] M N M [S], one thread per pair IN EMISSION (BAM) ORDER, before the sort:
-// the left anchor is read[dS, dS+a) against genome[pos, pos+a), the right one read[dS+a, dS+a+b)
-// against genome[iend+1, iend+1+b); neither depends on the junction-level window, the walk rules
-// of bam_alignment.cc:341-462 reduce to exactly this for the shape.  Everything a pair needs is in the pair arrays
-// (k1_emit left the address of the read's bases there): one round of coalesced loads, then the bases.
-__global__ __launch_bounds__(256) void k4a_simple(Pairs P, KeyFmt kf, GroupTab G, const u32 *np, u64 *res) {
-    const u32 n = *np;
-    const u32 p = blockIdx.x * 256 + threadIdx.x;
-    if (p >= n) return;
-    const u32 meta = P.meta[p];
-    const u64 key = P.key[p];
-    int32_t pos = P.pos[p], rend = P.rend[p];
-    const u32 *seqw = reinterpret_cast<const u32 *>((uintptr_t)P.seqw[p]);
-    if (!(meta & META_SIMPLE)) return;
-    int32_t istart, iend;
-    unpack_key(kf, key, istart, iend);
-    // the pair's target: its codes, and the target's own coordinates from here on
-    const Member M = member_of(G, pos);
-    const u32 *gcodes = M.codes;
-    const int32_t glen = M.len;
-    pos -= M.voff;
-    rend -= M.voff;
-    istart -= M.voff;
-    iend -= M.voff;
-    const int32_t a = istart - pos, bb = rend - iend;
-    const int32_t dS = (int32_t)((meta >> META_DS_SHIFT) & 0xfffu);
-    const int32_t g_words = (glen + 7) / 8 + 1;
-    const int32_t q_last = (dS + a + bb - 1) >> 3; // last word of the read that holds aligned bases
-    int32_t misL = 0, firstL = -1, lastL = -1, misR = 0, firstR = -1, lastR = -1;
-    const int32_t longest = a > bb ? a : bb;
-    for (int32_t t = 0; t < longest; t += 64) {
-        CmpChunk L, R;
-        const bool onL = t < a, onR = t < bb;
-        chunk_load(L, onL, seqw, dS, q_last, gcodes, pos, g_words, a, t);
-        chunk_load(R, onR, seqw, dS + a, q_last, gcodes, iend + 1, g_words, bb, t);
-        chunk_cmp(L, onL, dS, pos, a, t, 0, misL, firstL, lastL);
-        chunk_cmp(R, onR, dS + a, iend + 1, bb, t, 0, misR, firstR, lastR);
-    }
-    const u32 upM = lastL < 0 ? (u32)a : (u32)(a - 1 - lastL);
-    const u32 downM = firstR < 0 ? (u32)bb : (u32)firstR;
-    const u32 tu = (u32)(a - misL), td = (u32)(bb - misR);
-    res[p] = pack_res(upM < downM ? upM : downM, tu < td ? tu : td, (u32)(misL + misR));
-}
-
-// K4b: every other pair (multi-junction reads, indels, = X P H ops, exotic contigs, SEQ '*'), one
-// thread per entry of a compacted list of sorted positions; needs the junction-level anchors.
-__global__ __launch_bounds__(256) void k4b_generic(const u32 *list, const u32 *n_list, u32 pair_blocks, const u64 *skey, const u32 *sidx,
-                                                    const u32 *jid_of, Pairs P, KeyFmt kf, const DevBatch *batches, int n_batches,
-                                                    const int32_t *anc_l, const int32_t *anc_r, GroupTab G, int genome_has_x, int use_codes,
-                                                    u64 *res, u64 *err) {
+// K4b: every pair that is not of the simple shape (multi-junction reads, indels, = X P H ops, exotic contigs, SEQ '*'), one
+// thread per READ of the list k1_emit compacted, in BAM order: the read's operations are fetched once (LDS column) and
+// walked once; at every N operation the pair's junction-level anchors (kd_assign) are looked up and the two lock-step
+// walks start right there (op index and query offset are at hand: no hint has to travel with the pair).  The result
+// goes into the pair's record.  Runs on the side stream, beside the sort.
+__global__ __launch_bounds__(256) void k4b_generic(const u64 *list, const u32 *n_list, u32 cap, const u64 *key, PairRec *rec, const u32 *jid_bam,
+                                                    KeyFmt kf, const DevBatch *batches, int n_batches, const int32_t *anc_l, const int32_t *anc_r,
+                                                    GroupTab G, int genome_has_x, int use_codes, u64 *err) {
     __shared__ u32 s_ops[OPS_LDS][256];
-    // sub-list `shard` occupies [shard * cap, shard * cap + n_list[shard]); pair_blocks is the K3 grid size
-    const u32 cap = ((pair_blocks + GEN_SHARDS - 1) / GEN_SHARDS) * 256;
+    // sub-list `shard` occupies [shard * cap, shard * cap + n_list[shard])
     const u32 t = blockIdx.x * 256 + threadIdx.x;
     const u32 shard = t / cap, k_in = t % cap;
     if (shard >= GEN_SHARDS || k_in >= n_list[shard]) return;
-    const u32 i = list[t];
-    const u32 p = sidx[i], j = jid_of[i];
-    const u32 g = P.g[p];
+    const u64 entry = list[t];
+    const u32 g = (u32)entry, p0 = (u32)(entry >> 32);
     const DevBatch &b = find_batch(batches, n_batches, g);
     const u32 r = g - b.base;
-    int32_t istart, iend;
-    unpack_key(kf, P.key[p], istart, iend); // (the sorted key array may hold dense junction ids instead of coordinates)
     const u32 *cig_off = b.cig_off;
     const u32 c0 = gload(cig_off + r), c1 = gload(cig_off + r + 1);
     const u32 nc = c1 - c0;
@@ -2547,63 +2338,79 @@ __global__ __launch_bounds__(256) void k4b_generic(const u32 *list, const u32 *n
         const u32 v = gload(has ? cig.g + k : cig_off);
         s_ops[k][threadIdx.x] = has ? v : 0u;
     }
-    const int32_t vpos = P.pos[p], aend = P.aend[p];
-    const Member M = member_of(G, vpos); // the pair's target: everything below is in the target's own coordinates
+    const uint4 rb = reinterpret_cast<const uint4 *>(rec + p0)[1]; // pos | aend | meta | updown of the read's first pair
+    const int32_t vpos = (int32_t)rb.x, aend = (int32_t)rb.y;
+    const Member M = member_of(G, vpos); // the read's target: everything below is in the target's own coordinates
     const int32_t pos = vpos - M.voff;
     const int32_t lq = gload(b.l_qseq + r);
     const u32 so0 = gload(b.seq_off + r), words = gload(b.seq_off + r + 1) - so0;
     if (lq > 1 && (u64)words * 8ull < (u64)lq) {
         set_error(err, g, PJB_ERR_NO_SEQ);
-        res[p] = 0;
-        return;
+        return; // (the records keep aux = 0)
     }
     const uint8_t *seq = b.seq4 + (size_t)so0 * 4;
-    res[p] = pair_stats_generic(cig, nc, pos, aend - vpos + 1, seq, lq, M.d, M.len, genome_has_x != 0, use_codes ? M.codes : (const u32 *)nullptr,
-                                anc_l[j] - M.voff, istart - M.voff, iend - M.voff, anc_r[j] - M.voff, g, err,
-                                (P.meta[p] & META_SIMPLE) ? 0ull : P.seqw[p]); // (a simple pair sent here -- exotic genomes -- carries an address there)
+    u32 k = 0;
+    int32_t qsum = 0; // query bases before the operation, soft clips not counted (anchor_side's qPos)
+    for (u32 i = 0; i < nc; i++) {
+        const u32 op = cig[i], ty = op & 15u;
+        if (ty == OP_N) {
+            const u32 p = p0 + k;
+            const u32 j = jid_bam[p];
+            int32_t istart, iend;
+            unpack_key(kf, key[p], istart, iend);
+            const u64 res = pair_stats_generic(cig, nc, pos, aend - vpos + 1, seq, lq, M.d, M.len, genome_has_x != 0, use_codes ? M.codes : (const u32 *)nullptr,
+                                               anc_l[j] - M.voff, istart - M.voff, iend - M.voff, anc_r[j] - M.voff, g, err, i, qsum);
+            *reinterpret_cast<u64 *>(rec + p) = res; // PairRec::aux
+            k++;
+        }
+        if (op_consumes_query(ty) && ty != OP_S) qsum += (int32_t)(op >> 4);
+    }
 }
 
-// fragment record: 48 words
-enum {
-    F_N = 0, F_R1P, F_R1N, F_R2P, F_R2N, F_MS, F_XSP, F_XSN, F_UM, F_BPP, F_PPP, F_REL, F_DIST, // sums
-    F_MAXMINANC, F_UP, F_DOWN, F_MAXMMES, F_MAXMINMATCH,                                       // max
-    F_FIRSTMIS,                                                                                 // min
-    F_PAD19,                                                                                    // keeps the next pair 8-byte aligned
-    F_MISM_LO, F_MISM_HI,                                                                       // 64-bit sum
-    F_JAD0,                                                                                     // 20 sums
-    F_WORDS = 48
-};
-
-// K4: gather the per-pair predicates and match statistics in sorted order and fold them to fragment
+// K4: gather the pairs in sorted order -- one 32-byte record each -- and fold predicates and match statistics to fragment
 // heads with a segmented wave reduction (junction.cc:862-909 accumulators, :755-814 counters).
-__global__ __launch_bounds__(256) void k4_pairs(const u64 *skey, const u32 *sidx, const u32 *jid_of, Pairs P, KeyFmt kf,
-                                                 const u64 *res, const u32 *np, u32 *frag, int32_t *frag_j) {
+// Fragments.  The sorted pair array is processed in fixed 64-pair slices (one wavefront each).  A fragment is a maximal
+// run of one junction inside one slice; its slot is jid + slice index, which is unique and increasing along the array.
+// A slot is skipped when a junction starts exactly on a slice boundary, and the very last slot is never used: the
+// wavefront that sees either marks the slot unused (frag_j = -1) itself, so nothing has to be initialised.
+// A second small kernel reduces slots -> junctions (segmented again, then one atomic per wave and junction), so a
+// junction with 10^6 pairs costs ~250 same-address atomics, not 10^6.
+__global__ __launch_bounds__(256) void k4_pairs(const u32 *sidx, const u32 *jid_of, const PairRec *rec, const u64 *jkey, KeyFmt kf, const u32 *np,
+                                                 u32 *frag, int32_t *frag_j) {
     const u32 n = *np;
     if (blockIdx.x * 256u >= n) return;
     const u32 i = blockIdx.x * 256 + threadIdx.x;
     const bool valid = i < n;
     const int lane = lane_id();
+    const u32 ic = valid ? i : n - 1; // (loads unconditional, masked after: see k1_count)
+    const u32 p = sidx[ic];
+    const u32 jv = jid_of[ic];
+    const PairRec Rc = rec_load(rec + p);
+    const u64 jk = jkey[jv];
+    // the pair before this one in sorted order: the neighbouring lane's -- lane 0 fetches it
+    u32 jprev_v = __shfl_up(jv, 1, 64);
+    int32_t pos_prev = __shfl_up(Rc.pos, 1, 64), aend_prev = __shfl_up(Rc.aend, 1, 64);
+    if (lane == 0 && i > 0) {
+        jprev_v = jid_of[i - 1];
+        const uint4 q = reinterpret_cast<const uint4 *>(rec + sidx[i - 1])[1];
+        pos_prev = (int32_t)q.x;
+        aend_prev = (int32_t)q.y;
+    }
     u32 j = 0xffffffffu;
     u32 cnt[4] = {0, 0, 0, 0}, jadp[5] = {0, 0, 0, 0, 0}, mx[5] = {0, 0, 0, 0, 0};
     u32 first_mis = 100000000u; // junction.cc:864
     u64 mism64 = 0;
     if (valid) {
-        const u32 p = sidx[i];
-        j = jid_of[i];
+        j = jv;
         int32_t istart, iend;
-        unpack_key(kf, P.key[p], istart, iend);
-        const int32_t pos = P.pos[p], aend = P.aend[p];
-        const u64 rs = res[p];
+        unpack_key(kf, jk, istart, iend);
+        const u64 rs = Rc.aux;
         const u32 minMatch = (u32)(rs & 0xfffffu), mmes = (u32)((rs >> 20) & 0xfffffu), nbMis = (u32)(rs >> 40);
-        const u32 meta = P.meta[p];
+        const u32 meta = Rc.meta;
         const u32 cat = meta & META_CAT_MASK;
         const u32 xs = (meta >> META_XS_SHIFT) & 3u;
         // distinct alignment runs in BAM order (junction.cc:763-771): compare with the previous pair of the junction
-        bool dist_head = true;
-        if (i > 0 && jid_of[i - 1] == j) {
-            const u32 q = sidx[i - 1];
-            dist_head = P.pos[q] != pos || P.aend[q] != aend;
-        }
+        const bool dist_head = i == 0 || jprev_v != j || pos_prev != Rc.pos || aend_prev != Rc.aend;
         // 8-bit lanes: a wavefront adds at most 64 per field
         cnt[0] = 1u | ((u32)(cat == 0) << 8) | ((u32)(cat == 1) << 16) | ((u32)(cat == 2) << 24);
         cnt[1] = (u32)(cat == 3) | ((u32)((meta & META_MULTI) != 0) << 8) | ((u32)(xs == 1) << 16) | ((u32)(xs == 2) << 24);
@@ -2614,16 +2421,41 @@ __global__ __launch_bounds__(256) void k4_pairs(const u64 *skey, const u32 *sidx
         for (int w = 0; w < 5; w++) // junction.cc:875-877: JAD[k]++ for k < min(20, minMatch)
             jadp[w] = (u32)((u32)(4 * w) < minMatch) | ((u32)((u32)(4 * w + 1) < minMatch) << 8) |
                       ((u32)((u32)(4 * w + 2) < minMatch) << 16) | ((u32)((u32)(4 * w + 3) < minMatch) << 24);
-        const int32_t la = istart - P.lstart[p], ra = P.rend[p] - iend; // Intron::minAnchorLength intron.cc:81-83
+        const int32_t la = istart - Rc.lstart, ra = Rc.rend - iend; // Intron::minAnchorLength intron.cc:81-83
         mx[0] = (u32)(la < ra ? la : ra);
-        const u32 ud = P.updown[p];
-        mx[1] = ud & 0xffffu;
-        mx[2] = ud >> 16;
+        mx[1] = Rc.updown & 0xffffu;
+        mx[2] = Rc.updown >> 16;
         mx[3] = mmes;
         mx[4] = minMatch;
         first_mis = minMatch > 0 ? minMatch : 100000000u;
         mism64 = nbMis;
+        // unused fragment slots: the one skipped when a junction starts on a slice boundary, and the last one
+        if (lane == 0 && i > 0 && jprev_v != j) frag_j[j + (i >> 6) - 1] = -1;
+        if (i == n - 1) frag_j[j + (i >> 6) + 1] = -1;
     }
+    auto store_fragment = [&](u32 hi_word) {
+        const u32 slot = j + (i >> 6);
+        u32 vals[F_WORDS];
+#pragma unroll
+        for (int k = 0; k < F_WORDS; k++) vals[k] = 0;
+        // a full wavefront of one junction makes the first field 64: it still fits its byte (max 64 < 256)
+#pragma unroll
+        for (int k = 0; k < 13; k++) vals[F_N + k] = (cnt[k >> 2] >> (8 * (k & 3))) & 0xffu;
+        vals[F_MAXMINANC] = mx[0];
+        vals[F_UP] = mx[1];
+        vals[F_DOWN] = mx[2];
+        vals[F_MAXMMES] = mx[3];
+        vals[F_MAXMINMATCH] = mx[4];
+        vals[F_FIRSTMIS] = first_mis;
+        vals[F_MISM_LO] = (u32)mism64;
+        vals[F_MISM_HI] = hi_word;
+#pragma unroll
+        for (int k = 0; k < 20; k++) vals[F_JAD0 + k] = (jadp[k >> 2] >> (8 * (k & 3))) & 0xffu;
+        uint4 *dst = reinterpret_cast<uint4 *>(frag + (size_t)slot * F_WORDS);
+#pragma unroll
+        for (int k = 0; k < F_WORDS / 4; k++) dst[k] = make_uint4(vals[4 * k], vals[4 * k + 1], vals[4 * k + 2], vals[4 * k + 3]);
+        frag_j[slot] = (int32_t)j;
+    };
     // ---- a wavefront that holds pairs of ONE junction (the usual case: a junction has a few hundred pairs): plain
     // whole-wave reductions on the DPP path, 16 x 6 VALU steps instead of 115 ds_bpermute round trips
     const u32 j0 = (u32)__builtin_amdgcn_readfirstlane((int)j);
@@ -2637,28 +2469,7 @@ __global__ __launch_bounds__(256) void k4_pairs(const u64 *skey, const u32 *sidx
         first_mis = wave_total<DppMin>(first_mis);
         // (a pair has fewer than 2^24 mismatches: 64 of them fit 32 bits)
         mism64 = (u64)wave_total<DppAdd>((u32)mism64);
-        if (valid && lane == 0) {
-            const u32 slot = j + (i >> 6);
-            u32 vals[F_WORDS];
-#pragma unroll
-            for (int k = 0; k < F_WORDS; k++) vals[k] = 0;
-#pragma unroll
-            for (int k = 0; k < 13; k++) vals[F_N + k] = (cnt[k >> 2] >> (8 * (k & 3))) & 0xffu;
-            vals[F_MAXMINANC] = mx[0];
-            vals[F_UP] = mx[1];
-            vals[F_DOWN] = mx[2];
-            vals[F_MAXMMES] = mx[3];
-            vals[F_MAXMINMATCH] = mx[4];
-            vals[F_FIRSTMIS] = first_mis;
-            vals[F_MISM_LO] = (u32)mism64;
-            vals[F_MISM_HI] = 0;
-#pragma unroll
-            for (int k = 0; k < 20; k++) vals[F_JAD0 + k] = (jadp[k >> 2] >> (8 * (k & 3))) & 0xffu;
-            uint4 *dst = reinterpret_cast<uint4 *>(frag + (size_t)slot * F_WORDS);
-#pragma unroll
-            for (int k = 0; k < F_WORDS / 4; k++) dst[k] = make_uint4(vals[4 * k], vals[4 * k + 1], vals[4 * k + 2], vals[4 * k + 3]);
-            frag_j[slot] = (int32_t)j;
-        }
+        if (valid && lane == 0) store_fragment(0u);
         return;
     }
     // ---- several junctions in the wavefront: segmented wave reduce to fragment heads; the "same junction at distance
@@ -2702,29 +2513,7 @@ __global__ __launch_bounds__(256) void k4_pairs(const u64 *skey, const u32 *sidx
         }
     }
     const u32 jprev = __shfl_up(j, 1, 64);
-    if (valid && (lane == 0 || jprev != j)) {
-        const u32 slot = j + (i >> 6);
-        u32 vals[F_WORDS];
-#pragma unroll
-        for (int k = 0; k < F_WORDS; k++) vals[k] = 0;
-        // a full wavefront of one junction makes the first field 64: it still fits its byte (max 64 < 256)
-#pragma unroll
-        for (int k = 0; k < 13; k++) vals[F_N + k] = (cnt[k >> 2] >> (8 * (k & 3))) & 0xffu;
-        vals[F_MAXMINANC] = mx[0];
-        vals[F_UP] = mx[1];
-        vals[F_DOWN] = mx[2];
-        vals[F_MAXMMES] = mx[3];
-        vals[F_MAXMINMATCH] = mx[4];
-        vals[F_FIRSTMIS] = first_mis;
-        vals[F_MISM_LO] = (u32)mism64;
-        vals[F_MISM_HI] = (u32)(mism64 >> 32);
-#pragma unroll
-        for (int k = 0; k < 20; k++) vals[F_JAD0 + k] = (jadp[k >> 2] >> (8 * (k & 3))) & 0xffu;
-        uint4 *dst = reinterpret_cast<uint4 *>(frag + (size_t)slot * F_WORDS);
-#pragma unroll
-        for (int k = 0; k < F_WORDS / 4; k++) dst[k] = make_uint4(vals[4 * k], vals[4 * k + 1], vals[4 * k + 2], vals[4 * k + 3]);
-        frag_j[slot] = (int32_t)j;
-    }
+    if (valid && (lane == 0 || jprev != j)) store_fragment((u32)(mism64 >> 32));
 }
 
 // K5a: fragment slots -> junction accumulators (acc pre-initialised: sums 0, max 0, min 100000000).
@@ -2776,18 +2565,6 @@ __global__ __launch_bounds__(256) void k5_frag_reduce(const u32 *frag, const int
         }
     }
     flush(cur);
-}
-__global__ __launch_bounds__(256) void k5_init_acc(u32 *acc, const u32 *n_junc_p, int32_t *anc_l, int32_t *anc_r, int32_t *frag_j,
-                                                    const u32 *n_slots_p, u32 *member_junc) {
-    const u32 n_junc = *n_junc_p, n_slots = *n_slots_p;
-    const u32 t = blockIdx.x * 256 + threadIdx.x;
-    if (t < (u32)GROUP_MAX) member_junc[t] = 0;
-    if (t < n_slots) frag_j[t] = -1; // unused fragment slot
-    if (t < n_junc * F_WORDS) acc[t] = (t % F_WORDS) == F_FIRSTMIS ? 100000000u : 0u;
-    if (t < n_junc) {
-        anc_l[t] = INT32_MAX;
-        anc_r[t] = INT32_MIN;
-    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2869,7 +2646,7 @@ __global__ __launch_bounds__(256) void k5_entropy_sum(const u32 *run_first, cons
     if (lane == 0) ent_sum[j] = sum;
 }
 
-__global__ __launch_bounds__(256) void k5_finalize(const u64 *pair_key, const u32 *sidx, const u32 *seg_off, const u32 *run_first,
+__global__ __launch_bounds__(256) void k5_finalize(const u64 *jkey, const u32 *seg_off, const u32 *run_first,
                                                     const u32 *run_start, const u32 *acc, const int32_t *anc_l,
                                                     const int32_t *anc_r, KeyFmt kf, GroupTab G, const u32 *n_junc_p, const double *ent_sum,
                                                     pjb_junction_row *rows, u64 *err, u32 *member_junc) {
@@ -2880,8 +2657,7 @@ __global__ __launch_bounds__(256) void k5_finalize(const u64 *pair_key, const u3
     pjb_junction_row R;
     memset(&R, 0, sizeof R);
     int32_t istart, iend;
-    const u32 s0 = seg_off[j];
-    unpack_key(kf, pair_key[sidx[s0]], istart, iend);
+    unpack_key(kf, jkey[j], istart, iend);
     // the junction's target: rows carry the target's own coordinates
     const Member M = member_of(G, istart);
     const uint8_t *genome = M.d;
@@ -3070,10 +2846,10 @@ __global__ __launch_bounds__(256) void k6_rows_out(const u64 *rows, const Contig
 // The last kernel of a contig: control block, error word and list counters go to page-locked host memory in one go
 // (three small copies otherwise), error word and counters return to their rest state for the contig that uses this
 // control slot next, and the row cursor moves on.
-constexpr int PUB_BASE_AT = 240, PUB_ERR_AT = 256, PUB_XCNT_AT = 320 /* --extra: the target's counters, 64 bytes */, PUB_GEN_AT = 512, PUB_MEMBERS_AT = 1536, PUB_BYTES = 4096; // byte offsets in the published block
+constexpr int PUB_BASE_AT = 240, PUB_ERR_AT = 256, PUB_XCNT_AT = 320 /* --extra: the target's counters, 64 bytes */, PUB_GEN_AT = 512, PUB_MEMBERS_AT = 1536, PUB_GREADS_AT = 3072, PUB_BYTES = 4096; // byte offsets in the published block
 static_assert(PUB_MEMBERS_AT + GROUP_MAX * sizeof(MemberStats) <= PUB_BYTES && sizeof(MemberStats) % 8 == 0, "control block layout");
-__global__ __launch_bounds__(256) void k7_publish(const ContigStats *cs, u64 *err, u32 *gencount, uint8_t *host, int64_t base, int64_t mirror_base,
-                                                  RowCursor *cur, const MemberStats *members, const u32 *member_junc, int n_members) {
+__global__ __launch_bounds__(256) void k7_publish(const ContigStats *cs, u64 *err, u32 *gen_reads, u32 *gen_pairs, uint8_t *host, int64_t base,
+                                                  int64_t mirror_base, RowCursor *cur, const MemberStats *members, u32 *member_junc, int n_members) {
     const u32 t = threadIdx.x;
     if (n_members > 1 && t < (u32)n_members) { // a group: the members' own counters
         MemberStats S = members[t];
@@ -3081,11 +2857,15 @@ __global__ __launch_bounds__(256) void k7_publish(const ContigStats *cs, u64 *er
         reinterpret_cast<MemberStats *>(host + PUB_MEMBERS_AT)[t] = S;
     }
     static_assert(sizeof(ContigStats) % 8 == 0 && sizeof(ContigStats) <= PUB_BASE_AT, "control block layout");
-    static_assert(PUB_GEN_AT + GEN_SHARDS * 4 <= PUB_BYTES, "control block layout");
+    static_assert(PUB_GEN_AT + GEN_SHARDS * 4 <= PUB_MEMBERS_AT && PUB_MEMBERS_AT + GROUP_MAX * sizeof(MemberStats) <= PUB_GREADS_AT &&
+                      PUB_GREADS_AT + GEN_SHARDS * 4 <= PUB_BYTES,
+                  "control block layout");
     if (t < sizeof(ContigStats) / 8) reinterpret_cast<u64 *>(host)[t] = reinterpret_cast<const u64 *>(cs)[t];
-    if (t < GEN_SHARDS) {
-        reinterpret_cast<u32 *>(host + PUB_GEN_AT)[t] = gencount[t];
-        gencount[t] = 0;
+    if (t < GEN_SHARDS) { // pairs that took the generic walks, per sub-list; both counters back to their rest state
+        reinterpret_cast<u32 *>(host + PUB_GEN_AT)[t] = gen_pairs[t];
+        reinterpret_cast<u32 *>(host + PUB_GREADS_AT)[t] = gen_reads[t];
+        gen_pairs[t] = 0;
+        gen_reads[t] = 0;
     }
     if (t == 0) {
         *reinterpret_cast<u64 *>(host + PUB_ERR_AT) = *err;
@@ -3096,6 +2876,8 @@ __global__ __launch_bounds__(256) void k7_publish(const ContigStats *cs, u64 *er
         cur->rows = at + cs->J;
         cur->mirror_rows = mat + cs->J;
     }
+    __syncthreads();
+    if (t < (u32)GROUP_MAX) member_junc[t] = 0; // (k5_finalize counts into it; rest state for the chain that uses the slot next)
 }
 
 } // namespace pjb

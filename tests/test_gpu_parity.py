@@ -330,15 +330,13 @@ def test_long_reads(ffi, orc):
 
 def test_options_do_not_change_rows(ffi, orc):
     """pjb_set_option: kernels of a chain on one stream instead of several ("overlap" 0), the sort on the full keys
-    instead of the dense ids ("dense_ids" 0), k1_count + k1_emit instead of the one-pass k1_walk ("fused_k1" 0) -- the rows
-    stay what they are; options need an empty queue."""
+    instead of the dense ids ("dense_ids" 0) -- the rows stay what they are; options need an empty queue."""
     contigs = _three_contigs(orc, seeds=(51, 52, 53))
     want = np.concatenate([c[2] for c in contigs])
     with ffi.Context(0, "FR") as ctx:
-        for overlap, dense, fused in ((0, 1, 1), (1, 0, 0), (0, 0, 1), (1, 1, 0), (1, 1, 1)):
+        for overlap, dense in ((0, 1), (1, 0), (0, 0), (1, 1)):
             ctx.set_option("overlap", overlap)
             ctx.set_option("dense_ids", dense)
-            ctx.set_option("fused_k1", fused)
             rows, _ = _run_queued(ffi, ctx, contigs, 3)
             assert_rows_equal(rows, want)
         with pytest.raises(ffi.PjbError):

@@ -1,0 +1,33 @@
+#!/bin/bash
+# One parametrised GPU-box script (run as: gpurun -- 'bash tools/gpu_run.sh <step> [<step> ...]').  Steps:
+#   tests            the whole GPU suite (pytest -m gpu -x)
+#   tests:<expr>     pytest -m gpu -k <expr>
+#   smoke            __graft_entry__.smoke()
+#   quick            bench.py without the BAM leg and the CPU baseline (10 steps)            -> gpurun_out/<TAG>_quick.json
+#   bench            bench.py with default flags, as the driver runs it                       -> gpurun_out/<TAG>_bench_C3.json
+#   prof             tools/profile_round.sh: rocprofv3 kernel stats + FETCH/WRITE PMC passes + the bench line
+#   fuzz             the three fuzz campaigns (tests/fuzz_campaign.py, fuzz_groups.py, fuzz_extra.py)
+#   cmd:<shell>      anything else
+# TAG (environment, default r04) names the outputs; COMMIT is recorded in the PMC summary.
+cd "$GRAFT_REPO_ROOT" || exit 1
+TAG=${TAG:-r04}
+OUT=gpurun_out
+mkdir -p $OUT
+rc=0
+for step in "$@"; do
+  echo "=== $step"
+  case "$step" in
+    tests) ( time timeout 2400 python -m pytest tests -m gpu -q -x 2>&1 | tail -25 ) 2>&1 | tee $OUT/${TAG}_pytest.log ;;
+    tests:*) ( time timeout 2400 python -m pytest tests -m gpu -q -x -k "${step#tests:}" 2>&1 | tail -40 ) 2>&1 | tee $OUT/${TAG}_pytest_k.log ;;
+    smoke) python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -5 ;;
+    quick) timeout 900 python bench.py --steps 10 --warmup 3 --no-e2e --no-cpu-baseline > $OUT/${TAG}_quick.json 2> $OUT/${TAG}_quick.err; tail -c 400 $OUT/${TAG}_quick.err
+           python3 tools/show_bench.py $OUT/${TAG}_quick.json ;;
+    bench) ( time python bench.py > $OUT/${TAG}_bench_C3.json 2> $OUT/${TAG}_bench.err ) 2>&1 | tail -4; tail -c 400 $OUT/${TAG}_bench.err
+           python3 tools/show_bench.py $OUT/${TAG}_bench_C3.json ;;
+    prof) bash tools/profile_round.sh $TAG ${COMMIT:-unknown}; python3 tools/show_bench.py $OUT/${TAG}_bench_C3.json ;;
+    fuzz) ( timeout 1500 python tests/fuzz_campaign.py; timeout 900 python tests/fuzz_groups.py; timeout 900 python tests/fuzz_extra.py ) 2>&1 | tail -30 | tee $OUT/${TAG}_fuzz.txt ;;
+    cmd:*) bash -c "${step#cmd:}" ;;
+    *) echo "unknown step $step"; rc=2 ;;
+  esac
+done
+exit $rc
