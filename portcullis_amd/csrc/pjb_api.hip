@@ -1587,6 +1587,7 @@ static int queue_contig(pjb_ctx *c, Flight &f) {
         // reads for k4b_generic
         EmitLists el;
         el.cand = lim.dense ? (u64 *)S.key[1].p : (u64 *)nullptr;
+        el.cand_anc = (u64 *)S.ent.p; // (the entropy terms' buffer: free until the position runs exist)
         el.gen_list = (u64 *)S.genlist.p;
         el.gen_reads = d_gen_reads;
         el.gen_pairs = d_gen_pairs;
@@ -1597,8 +1598,8 @@ static int queue_contig(pjb_ctx *c, Flight &f) {
             const int32_t own_tid = f.tids[(size_t)m], own_len = c->ref_len[(size_t)own_tid];
             const u32 nt = (u32)((b.n + K1_TILE - 1) / K1_TILE);
             // (a tile holds ~300 spliced reads = 1.2 chunks of 256: a grid of half the tiles keeps two or three chunks per block)
-            const u32 grid = std::max<u32>(1, std::min<u32>(nt, std::max<u32>(1024, nt / 2)));
-            LAUNCH(c, "k1_emit", k1_emit, dim3(grid), dim3(256), b, nt, n_tiles, (const u32 *)S.tile_cnt.p, (const u32 *)S.tile_soff.p,
+            const u32 grid = std::max<u32>(1, std::min<u32>(nt, std::max<u32>(1024, nt / 2))) * (256 / K1E_T);
+            LAUNCH(c, "k1_emit", k1_emit, dim3(grid), dim3(K1E_T), b, nt, n_tiles, (const u32 *)S.tile_cnt.p, (const u32 *)S.tile_soff.p,
                    (const u32 *)S.chunk_tile.p, (const u32 *)S.splidx.p, (const u32 *)S.splpoff.p, pr, el, kf, own_len,
                    own_tid, (int)c->cfg.orientation, d_err, d_cs, f.voff[(size_t)m], fast_codes ? (const u32 *)GT.codes[m] : (const u32 *)nullptr);
         }
@@ -1652,11 +1653,10 @@ static int queue_contig(pjb_ctx *c, Flight &f) {
         if ((rc = run_scan(c, "kd_first", EndsCountFn{(const u32 *)S.ends.p}, FirstIdSink{(u32 *)S.firstid.p, (int32_t *)S.ancl.p, (int32_t *)S.ancr.p},
                            (u64)JL, (u64 *)S.total.p)))
             return rc;
-        LAUNCH(c, "kd_table", kd_table, dim3(pair_blocks), dim3(256), (const u64 *)cand, (const u32 *)cand_rank, kf, JL, (const u32 *)S.ends.p,
-               (const u32 *)S.firstid.p, (const u64 *)S.total.p, (u64 *)S.jkey.p, d_cs);
-        LAUNCH(c, "kd_assign", kd_assign, dim3(pair_blocks), dim3(256), okey, (const PairRec *)pr.rec, d_P, kf, (const u64 *)S.bitmap.p,
-               (const u32 *)S.wrank.p, (const u32 *)S.ends.p, (const u32 *)S.firstid.p, JL, (const u64 *)S.total.p, (u64 *)S.key[0].p, (u32 *)S.jidbam.p,
-               (int32_t *)S.ancl.p, (int32_t *)S.ancr.p, (u32 *)S.acc.p);
+        LAUNCH(c, "kd_table", kd_table, dim3(pair_blocks), dim3(256), (const u64 *)cand, (const u64 *)S.ent.p, (const u32 *)cand_rank, kf, JL,
+               (const u32 *)S.ends.p, (const u32 *)S.firstid.p, (const u64 *)S.total.p, (u64 *)S.jkey.p, (int32_t *)S.ancl.p, (int32_t *)S.ancr.p, d_cs);
+        LAUNCH(c, "kd_assign", kd_assign, dim3(pair_blocks), dim3(256), okey, d_P, kf, (const u64 *)S.bitmap.p, (const u32 *)S.wrank.p,
+               (const u32 *)S.ends.p, (const u32 *)S.firstid.p, JL, (const u64 *)S.total.p, (u64 *)S.key[0].p, (u32 *)S.jidbam.p, (u32 *)S.acc.p);
         if ((rc = fork_k4b())) return rc;
         LAUNCH(c, "kd_reset", kd_reset, dim3(pair_blocks), dim3(256), (const u64 *)cand, (const u32 *)cand_rank, kf, JL, (const ContigStats *)d_cs,
                (u64 *)S.bitmap.p, (u32 *)S.ends.p);

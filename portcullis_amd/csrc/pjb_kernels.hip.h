@@ -309,6 +309,30 @@ __device__ __forceinline__ T block_escan_256(T v, T *smem, T *total) {
     return base + inc - v;
 }
 
+// the same over NW wavefronts (NW = 1: no barrier, no shared memory traffic)
+template <int NW, typename T>
+__device__ __forceinline__ T block_escan(T v, T *smem, T *total) {
+    T inc = wave_iscan(v);
+    if constexpr (NW == 1) {
+        *total = __shfl(inc, 63, 64);
+        return inc - v;
+    } else {
+        int w = threadIdx.x >> 6, l = lane_id();
+        __syncthreads();
+        if (l == 63) smem[w] = inc;
+        __syncthreads();
+        T base = 0, tot = 0;
+#pragma unroll
+        for (int i = 0; i < NW; i++) {
+            T s = smem[i];
+            if (i < w) base += s;
+            tot += s;
+        }
+        *total = tot;
+        return base + inc - v;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // generic multi-block exclusive scan of u64 values produced by a functor (3 kernels)
 // ---------------------------------------------------------------------------------------------
@@ -1143,9 +1167,10 @@ struct EmitTail {
     bool simple; // [S] M N M [S], bases present: `dS` is the leading soft clip
     u32 dS;
 };
-template <typename Ops, typename KeyFn>
+// on_pair(key, lStart, rEnd) is called for every pair but the read's last one (its caller has that one in T)
+template <typename Ops, typename PairFn>
 __device__ __forceinline__ void emit_read_pairs(const Ops cig, const EmitRead R, const Pairs P, const KeyFmt kf, const int32_t ref_len,
-                                                const bool allow_simple, u64 *err, KeyFn &&on_key, EmitTail &T) {
+                                                const bool allow_simple, u64 *err, PairFn &&on_pair, EmitTail &T) {
     const u32 n = R.n, g = R.g, nN = R.nN;
     const int32_t pos = R.pos, aend = R.aend;
     u32 meta = R.meta;
@@ -1197,6 +1222,7 @@ __device__ __forceinline__ void emit_read_pairs(const Ops cig, const EmitRead R,
                 if (rEndExc - 1 >= ref_len) rEndExc = ref_len; // junction_system.cc:172-174
                 pend.rend = rEndExc - 1;
                 rec_store(P.rec + prev, pend);
+                on_pair(prev_key, pend.lstart, pend.rend);
                 if (rEndExc - 1 < prevIend) set_error(err, g, PJB_ERR_MIN_ANCHOR); // intron.cc:76
             }
             const int32_t istart = lEndExc;
@@ -1216,7 +1242,6 @@ __device__ __forceinline__ void emit_read_pairs(const Ops cig, const EmitRead R,
             const u64 key = make_key(kf, istart, iend);
             P.key[idx] = key;
             if (P.g) P.g[idx] = g;
-            on_key(key);
             pend.lstart = lStart;
             pend.updown = cntU | ((nN - cntD) << 16);
             if (lStart > istart) set_error(err, g, PJB_ERR_MIN_ANCHOR); // intron.cc:68
@@ -1281,10 +1306,17 @@ __device__ __forceinline__ u64 simple_pair_stats(const u32 *seqw, const u32 *gco
     const int32_t g_words = (glen + 7) / 8 + 1;
     const int32_t q_last = (dS + a + bb - 1) >> 3; // last word of the read that holds aligned bases
     int32_t misL = 0, firstL = -1, lastL = -1, misR = 0, firstR = -1, lastR = -1;
-    // (one side after the other, 32 bases a round: both sides' words in flight together, 64 bases each -- 36 registers --
-    // cost the kernel half its wavefronts; the number of load instructions per read is the same)
-    cmp_words<SIMPLE_NW>(seqw, dS, q_last, gcodes, pos, g_words, a, 0, misL, firstL, lastL);
-    cmp_words<SIMPLE_NW>(seqw, dS + a, q_last, gcodes, iend + 1, g_words, bb, 0, misR, firstR, lastR);
+    // (both sides' words of a round in flight together -- a round is one trip to memory, and the trips set the pace --, 32 bases
+    // a side: 64 a side held 36 registers and cost the kernel a third of its wavefronts)
+    const int32_t longest = a > bb ? a : bb;
+    for (int32_t t = 0; t < longest; t += 8 * (SIMPLE_NW - 1)) {
+        CmpChunkT<SIMPLE_NW> L, R;
+        const bool onL = t < a, onR = t < bb;
+        if (onL) chunk_load<SIMPLE_NW>(L, seqw, dS, q_last, gcodes, pos, g_words, a, t);
+        if (onR) chunk_load<SIMPLE_NW>(R, seqw, dS + a, q_last, gcodes, iend + 1, g_words, bb, t);
+        if (onL) chunk_cmp<SIMPLE_NW>(L, dS, pos, a, t, 0, misL, firstL, lastL);
+        if (onR) chunk_cmp<SIMPLE_NW>(R, dS + a, iend + 1, bb, t, 0, misR, firstR, lastR);
+    }
     const u32 upM = lastL < 0 ? (u32)a : (u32)(a - 1 - lastL);
     const u32 downM = firstR < 0 ? (u32)bb : (u32)firstR;
     const u32 tu = (u32)(a - misL), td = (u32)(bb - misR);
@@ -1301,16 +1333,27 @@ __device__ __forceinline__ u64 simple_pair_stats(const u32 *seqw, const u32 *gco
 //   gcodes: the target's 4-bit codes; nullptr (exotic characters, an 'X' in the sequence): no read is "simple", every
 // pair goes through k4b_generic's byte-wise walks.
 // By-products, so that no later kernel has to stream over the pairs for them:
-//   * K2d's candidate keys: the block keeps the keys it emits in a small hash set in LDS and appends the distinct ones to the
-//     candidate list when the set is a quarter full (and when the block leaves); a junction appears once per residency;
+//   * K2d's candidate keys: the block keeps the keys it emits in a small hash set in LDS -- with the smallest lStart and the
+//     largest rEnd of the pairs behind each key (junction.cc:477-529: the junction anchors' first level of reduction) -- and
+//     appends the distinct ones to the candidate list when the set is a quarter full (and when the block leaves); a
+//     junction appears once per residency;
 //   * the list of reads that need the generic walks (k4b_generic), in GEN_SHARDS sub-lists (one returning atomic per
 //     wavefront, spread over 256 addresses).
 constexpr int K1E_LOOK = 16;
-constexpr int KC_SLOTS = 1024;
+#ifndef K1E_WAVES
+#define K1E_WAVES 6 // wavefronts per SIMD the register allocation aims at (tools/build_variants.sh builds the others for A/B runs)
+#endif
+#ifndef K1E_THREADS
+#define K1E_THREADS 256 // threads of a block = list entries of one trip
+#endif
+constexpr int K1E_T = K1E_THREADS, K1E_SHIFT = K1E_T == 256 ? 8 : K1E_T == 128 ? 7 : 6;
+static_assert((1 << K1E_SHIFT) == K1E_T, "k1_emit block size");
+constexpr int KC_SLOTS = K1E_T * 2;
 constexpr u64 KD_EMPTY = ~0ull; // no key: a packed key has fewer than 64 bits
 constexpr u32 GEN_SHARDS = 256;
 struct EmitLists {
     u64 *cand;      // candidate keys (nullptr: the chain sorts the full keys and wants none); their count is ContigStats::n_cand
+    u64 *cand_anc;  // per candidate: min lStart | max rEnd << 32 over the pairs it stands for (the junction anchors' first level)
     u64 *gen_list;  // global read ordinal | index of the read's first pair << 32
     u32 *gen_reads; // [GEN_SHARDS] entries of each sub-list
     u32 *gen_pairs; // [GEN_SHARDS] pairs of those reads
@@ -1320,48 +1363,59 @@ __host__ __device__ inline u32 gen_list_cap(u32 pair_limit) { // chunks of 256 s
     const u32 chunks = pair_limit / 256u + 2u;
     return ((chunks + GEN_SHARDS - 1) / GEN_SHARDS) * 256u;
 }
-__global__ __launch_bounds__(256) void k1_emit(DevBatch b, u32 n_tiles_batch, u32 n_tiles_total, const u32 *tile_off, const u32 *tile_soff,
+__global__ __launch_bounds__(K1E_T) __attribute__((amdgpu_waves_per_eu(K1E_WAVES, K1E_WAVES))) void k1_emit(DevBatch b, u32 n_tiles_batch, u32 n_tiles_total, const u32 *tile_off, const u32 *tile_soff,
                                                 const u32 *chunk_tile, const u32 *spl_idx, const u32 *spl_poff, Pairs P, EmitLists E, KeyFmt kf,
                                                 int32_t ref_len, int32_t tid, int orientation, u64 *err, ContigStats *cs, int32_t voff,
                                                 const u32 *gcodes) {
-    __shared__ u32 s_ops[OPS_LDS][256];
+    __shared__ u32 s_ops[OPS_LDS][K1E_T];
     __shared__ u32 s_soff[K1E_LOOK];
     __shared__ u64 s_set[KC_SLOTS];
+    __shared__ int32_t s_lo[KC_SLOTS], s_hi[KC_SLOTS];
     __shared__ u32 s_set_n, s_base, s_scan[4];
     if (cs->P == 0) return; // no pairs, or a limit was exceeded: the contig is repeated with larger buffers
     const u32 s_begin = tile_soff[b.tile_base], s_end = tile_soff[b.tile_base + n_tiles_batch];
     if (s_begin == s_end) return;
-    const u32 c_lo = s_begin >> 8, c_hi = (s_end + 255u) >> 8;
+    const u32 c_lo = s_begin >> K1E_SHIFT, c_hi = (s_end + (u32)K1E_T - 1u) >> K1E_SHIFT; // trips of K1E_T list entries
     const bool want_cand = E.cand != nullptr;
     if (want_cand) {
 #pragma unroll
-        for (int i = 0; i < KC_SLOTS / 256; i++) s_set[i * 256 + threadIdx.x] = KD_EMPTY;
+        for (int i = 0; i < KC_SLOTS / K1E_T; i++) {
+            s_set[i * K1E_T + threadIdx.x] = KD_EMPTY;
+            s_lo[i * K1E_T + threadIdx.x] = INT32_MAX;
+            s_hi[i * K1E_T + threadIdx.x] = INT32_MIN;
+        }
         if (threadIdx.x == 0) s_set_n = 0;
     }
-    auto cand_insert = [&](u64 k) {
+    auto cand_insert = [&](u64 k, int32_t lstart, int32_t rend) {
         u32 h = (u32)((k * 0x9E3779B97F4A7C15ull) >> 40) & (KC_SLOTS - 1);
         for (int probe = 0; probe < 24; probe++) { // look first: most keys are there already, and a read of one address by many lanes is a broadcast
             u64 old = s_set[h];
-            if (old == k) return;
             if (old == KD_EMPTY) {
                 old = atomicCAS((unsigned long long *)&s_set[h], (unsigned long long)KD_EMPTY, (unsigned long long)k);
                 if (old == KD_EMPTY) {
                     atomicAdd(&s_set_n, 1u);
-                    return;
+                    old = k;
                 }
-                if (old == k) return;
+            }
+            if (old == k) {
+                if (lstart < s_lo[h]) atomicMin(&s_lo[h], lstart);
+                if (rend > s_hi[h]) atomicMax(&s_hi[h], rend);
+                return;
             }
             h = (h + 1) & (KC_SLOTS - 1);
         }
-        E.cand[atomicAdd(&cs->n_cand, 1u)] = k; // a crowded set (reads with hundreds of introns): straight to the list, where duplicates do no harm
+        // a crowded set (reads with hundreds of introns): straight to the list, where duplicates do no harm
+        const u32 at = atomicAdd(&cs->n_cand, 1u);
+        E.cand[at] = k;
+        E.cand_anc[at] = (u64)(u32)lstart | ((u64)(u32)rend << 32);
     };
     for (u32 chunk = c_lo + blockIdx.x; chunk < c_hi; chunk += gridDim.x) {
         // the tile of the chunk's first entry (for the batch's first chunk: of the batch's first entry)
-        u32 t0 = (chunk << 8) < s_begin ? b.tile_base : chunk_tile[chunk];
+        u32 t0 = (chunk << K1E_SHIFT) < s_begin ? b.tile_base : chunk_tile[chunk >> (8 - K1E_SHIFT)]; // (chunk_tile: the tile of entry 256 c)
         __syncthreads();
         if (threadIdx.x < K1E_LOOK) s_soff[threadIdx.x] = t0 + threadIdx.x <= n_tiles_total ? tile_soff[t0 + threadIdx.x] : 0xffffffffu;
         __syncthreads();
-        const u32 s = (chunk << 8) + threadIdx.x;
+        const u32 s = (chunk << K1E_SHIFT) + threadIdx.x;
         const bool on = s >= s_begin && s < s_end;
         bool gen = false;
         u32 gen_n = 0;
@@ -1386,7 +1440,7 @@ __global__ __launch_bounds__(256) void k1_emit(DevBatch b, u32 n_tiles_batch, u3
             const int64_t r = spl_idx[slot];
             const u32 c0 = b.cig_off[r], c1 = b.cig_off[r + 1];
             const u32 n = c1 - c0;
-            OpsView cig;
+            OpsViewT<K1E_T, OPS_LDS> cig;
             cig.g = b.cigar + c0;
             cig.lds = &s_ops[0][threadIdx.x];
 #pragma unroll
@@ -1416,8 +1470,10 @@ __global__ __launch_bounds__(256) void k1_emit(DevBatch b, u32 n_tiles_batch, u3
             const u32 so = b.seq_off[r];
             R.seq_ok = (u64)(b.seq_off[r + 1] - so) * 8ull >= (u64)(int64_t)R.lq;
             EmitTail T;
-            emit_read_pairs(cig, R, P, kf, voff + ref_len, gcodes != nullptr, err, [&](u64 key) { if (want_cand) cand_insert(key); }, T);
+            emit_read_pairs(cig, R, P, kf, voff + ref_len, gcodes != nullptr, err,
+                            [&](u64 key, int32_t lstart, int32_t rend) { if (want_cand) cand_insert(key, lstart, rend); }, T);
             if (T.idx >= 0) {
+                if (want_cand) cand_insert(T.key, T.rec.lstart, T.rec.rend);
                 if (T.simple) {
                     int32_t istart, iend;
                     unpack_key(kf, T.key, istart, iend);
@@ -1434,7 +1490,7 @@ __global__ __launch_bounds__(256) void k1_emit(DevBatch b, u32 n_tiles_batch, u3
         // ---- the reads whose pairs need the generic walks: one returning atomic per wavefront
         const u64 gm = __ballot(gen);
         if (gm) {
-            const u32 shard = chunk % GEN_SHARDS;
+            const u32 shard = (chunk >> (8 - K1E_SHIFT)) % GEN_SHARDS; // (by 256-entry chunk: gen_list_cap)
             const int leader = __ffsll((long long)gm) - 1;
             const u32 pairs_w = wave_total<DppAdd>(gen_n);
             u32 base = 0;
@@ -1451,16 +1507,20 @@ __global__ __launch_bounds__(256) void k1_emit(DevBatch b, u32 n_tiles_batch, u3
             __syncthreads();
             const bool last = chunk + gridDim.x >= c_hi;
             if (s_set_n > (u32)KC_SLOTS / 4 || last) {
-                u64 mine[KC_SLOTS / 256];
+                u64 mine[KC_SLOTS / K1E_T], anc[KC_SLOTS / K1E_T];
                 u32 cnt = 0;
 #pragma unroll
-                for (int i = 0; i < KC_SLOTS / 256; i++) {
-                    mine[i] = s_set[i * 256 + threadIdx.x];
+                for (int i = 0; i < KC_SLOTS / K1E_T; i++) {
+                    const int at = i * K1E_T + threadIdx.x;
+                    mine[i] = s_set[at];
+                    anc[i] = (u64)(u32)s_lo[at] | ((u64)(u32)s_hi[at] << 32);
                     cnt += mine[i] != KD_EMPTY;
-                    s_set[i * 256 + threadIdx.x] = KD_EMPTY;
+                    s_set[at] = KD_EMPTY;
+                    s_lo[at] = INT32_MAX;
+                    s_hi[at] = INT32_MIN;
                 }
                 u32 total;
-                const u32 excl = block_escan_256(cnt, s_scan, &total);
+                const u32 excl = block_escan<K1E_T / 64>(cnt, s_scan, &total);
                 if (threadIdx.x == 0) {
                     s_base = total ? atomicAdd(&cs->n_cand, total) : 0u;
                     s_set_n = 0;
@@ -1468,8 +1528,11 @@ __global__ __launch_bounds__(256) void k1_emit(DevBatch b, u32 n_tiles_batch, u3
                 __syncthreads();
                 u32 o = s_base + excl;
 #pragma unroll
-                for (int i = 0; i < KC_SLOTS / 256; i++)
-                    if (mine[i] != KD_EMPTY) E.cand[o++] = mine[i];
+                for (int i = 0; i < KC_SLOTS / K1E_T; i++)
+                    if (mine[i] != KD_EMPTY) {
+                        E.cand[o] = mine[i];
+                        E.cand_anc[o++] = anc[i];
+                    }
             }
         }
     }
@@ -1534,9 +1597,9 @@ __global__ __launch_bounds__(256) void kg_member_stats(const u32 *tile_cnt, cons
 //   scan       prefix popcount over the bitmap words  -> rank of a start among the distinct starts
 //   kd_ends    per start rank, the distinct intron ends seen (alternative acceptors: a handful; DENSE_ENDS slots)
 //   scan       number of ends per start rank           -> first junction id of every start (+ the anchors' rest state)
-//   kd_table   junction id -> intron key, from the candidates; closes the chain if a limit was exceeded
-//   kd_assign  id of a pair = first id of its start + number of that start's ends below its own end; the junction's
-//              anchors (min lStart, max rEnd over its pairs, junction.cc:477-529) while the pair is in registers
+//   kd_table   junction id -> intron key and the junction's anchors (min lStart, max rEnd over its pairs, junction.cc:477-529),
+//              from the candidates; closes the chain if a limit was exceeded
+//   kd_assign  id of a pair = first id of its start + number of that start's ends below its own end
 // Grouping by id is grouping by (start, end), id order is (start, end) order, so everything downstream -- segment
 // heads, fragments, row order -- works on the ids as it did on the keys.  A start with more than DENSE_ENDS different
 // ends raises OVF_DENSE and the contig is repeated with the full-key sort.
@@ -1625,34 +1688,13 @@ __device__ __forceinline__ u32 ends_below(const u32 *ends, u32 rs, u32 ue) { // 
     const uint4 a = q[0], b = q[1];
     return (a.x < ue) + (a.y < ue) + (a.z < ue) + (a.w < ue) + (b.x < ue) + (b.y < ue) + (b.z < ue) + (b.w < ue);
 }
-// junction id -> intron key (every candidate writes its junction's entry: duplicates write the same value); thread 0 closes
-// the chain -- P = 0, nothing downstream runs, the host repeats the contig -- if a limit was exceeded while the ids were built
-__global__ __launch_bounds__(256) void kd_table(const u64 *cand, const u32 *cand_rank, KeyFmt kf, u32 junc_limit, const u32 *ends,
-                                                const u32 *first_id, const u64 *total, u64 *jkey, ContigStats *cs) {
-    const u32 p = blockIdx.x * 256 + threadIdx.x;
-    if (p == 0) {
-        const u64 J = *total;
-        u32 ovf = cs->overflow;
-        if (cs->P != 0 && J > (u64)junc_limit) {
-            ovf |= OVF_JUNC;
-            cs->overflow = ovf;
-            cs->n_junc = (u32)(J < 0xffffffffull ? J : 0xffffffffull);
-        }
-        if (ovf) cs->P = 0;
-    }
-    if (p >= cs->n_cand) return;
-    const u32 rs = cand_rank[p];
-    if (rs >= junc_limit) return;
-    int32_t s, e;
-    unpack_key(kf, cand[p], s, e);
-    const u32 id = first_id[rs] + ends_below(ends, rs, (u32)e);
-    if (id < junc_limit) jkey[id] = cand[p];
-}
-
 // Junction anchors from pairs that sit in the lanes of a wavefront (any order): leftAncStart = min lStart, rightAncEnd = max
-// rEnd (junction.cc:477-529).  Lanes that share a junction with their neighbours are folded first; a head lane whose value
-// would not move the junction's current one (a plain read: the arrays only ever move one way, so a stale value errs on the
-// side of one atomic too many) does not touch it -- a deep junction costs a handful of atomics, not one per wavefront.
+// rEnd (junction.cc:477-529).  In BAM order the pairs of the two or three junctions of a locus alternate from lane to lane, so
+// the wavefront takes its DISTINCT junctions one after the other -- all lanes of one junction are folded on the DPP path,
+// whatever lies between them -- and one lane per junction touches the arrays, and only if the value would move them (a
+// read at L2 first: the arrays only ever move one way, so an older value errs on the side of one atomic too many).  (Folding
+// neighbouring lanes only left one atomic per lane wherever junctions alternate: 1.4 ms per chain on one L2 channel.)
+// segmented (by key) reduce towards the segment's FIRST lane; equal keys are contiguous across the lanes
 template <typename T, typename OP>
 __device__ __forceinline__ T seg_reduce_to_head(T v, u32 segkey, OP op) {
     const int l = lane_id();
@@ -1668,27 +1710,55 @@ struct OpMin { template <typename T> __device__ T operator()(T a, T b) const { r
 struct OpMax { template <typename T> __device__ T operator()(T a, T b) const { return a > b ? a : b; } };
 struct OpAdd { template <typename T> __device__ T operator()(T a, T b) const { return a + b; } };
 __device__ __forceinline__ void anchors_fold(bool valid, u32 j, int32_t l, int32_t r, int32_t *anc_l, int32_t *anc_r) {
-    if (!valid) {
-        j = 0xffffffffu;
-        l = INT32_MAX;
-        r = INT32_MIN;
+    const u32 lk = (u32)l ^ 0x80000000u, rk = (u32)r ^ 0x80000000u; // (signed order through the sign bit)
+    u64 todo = __ballot(valid);
+    while (todo) {
+        const int first = __ffsll((long long)todo) - 1;
+        const u32 jc = (u32)__builtin_amdgcn_readlane((int)j, first);
+        const bool mine = valid && j == jc;
+        const u64 m = __ballot(mine);
+        const int32_t lo = (int32_t)(wave_total<DppMin>(mine ? lk : 0xffffffffu) ^ 0x80000000u);
+        const int32_t hi = (int32_t)(wave_total<DppMax>(mine ? rk : 0u) ^ 0x80000000u);
+        if (lane_id() == first) { // (the look goes to L2, where the atomics are done: a CU's L1 would keep showing it the line it fetched first)
+            if (lo < __hip_atomic_load(&anc_l[jc], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(&anc_l[jc], lo);
+            if (hi > __hip_atomic_load(&anc_r[jc], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&anc_r[jc], hi);
+        }
+        todo &= ~m;
     }
-    const u32 j0 = (u32)__builtin_amdgcn_readfirstlane((int)j);
-    bool head;
-    if (__ballot(j != j0) == 0) { // one junction in the wavefront (the usual case): whole-wave min / max on the DPP path
-        l = (int32_t)(wave_total<DppMin>((u32)l ^ 0x80000000u) ^ 0x80000000u); // (signed order through the sign bit)
-        r = (int32_t)(wave_total<DppMax>((u32)r ^ 0x80000000u) ^ 0x80000000u);
-        head = lane_id() == 0;
-    } else {
-        l = seg_reduce_to_head(l, j, OpMin());
-        r = seg_reduce_to_head(r, j, OpMax());
-        const u32 jprev = __shfl_up(j, 1, 64);
-        head = lane_id() == 0 || jprev != j;
+}
+
+// junction id -> intron key (every candidate writes its junction's entry: duplicates write the same value) and the junction's
+// anchors from the candidates' partial ones; thread 0 closes the chain -- P = 0, nothing downstream runs, the host repeats the
+// contig -- if a limit was exceeded while the ids were built
+__global__ __launch_bounds__(256) void kd_table(const u64 *cand, const u64 *cand_anc, const u32 *cand_rank, KeyFmt kf, u32 junc_limit, const u32 *ends,
+                                                const u32 *first_id, const u64 *total, u64 *jkey, int32_t *anc_l, int32_t *anc_r, ContigStats *cs) {
+    const u32 p = blockIdx.x * 256 + threadIdx.x;
+    if (p == 0) {
+        const u64 J = *total;
+        u32 ovf = cs->overflow;
+        if (cs->P != 0 && J > (u64)junc_limit) {
+            ovf |= OVF_JUNC;
+            cs->overflow = ovf;
+            cs->n_junc = (u32)(J < 0xffffffffull ? J : 0xffffffffull);
+        }
+        if (ovf) cs->P = 0;
     }
-    if (head && j != 0xffffffffu) {
-        if (l < anc_l[j]) atomicMin(&anc_l[j], l);
-        if (r > anc_r[j]) atomicMax(&anc_r[j], r);
+    const u32 n = cs->n_cand;
+    if (blockIdx.x * 256u >= n) return;
+    const bool on = p < n;
+    const u32 pc = on ? p : n - 1;
+    const u32 rs = cand_rank[pc];
+    const u64 k = cand[pc], a = cand_anc[pc];
+    bool valid = on && rs < junc_limit;
+    u32 id = 0xffffffffu;
+    if (valid) {
+        int32_t s, e;
+        unpack_key(kf, k, s, e);
+        id = first_id[rs] + ends_below(ends, rs, (u32)e);
+        valid = id < junc_limit;
+        if (valid) jkey[id] = k;
     }
+    anchors_fold(valid, id, (int32_t)(u32)a, (int32_t)(u32)(a >> 32), anc_l, anc_r);
 }
 
 // fragment record of the per-junction reductions: 48 words (see k4_pairs)
@@ -1706,30 +1776,22 @@ __device__ __forceinline__ void acc_rest_state(u32 *acc, u64 n_junc) { // what k
     for (u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += step) acc[t] = (t % F_WORDS) == F_FIRSTMIS ? 100000000u : 0u;
 }
 
-__global__ __launch_bounds__(256) void kd_assign(const u64 *key, const PairRec *rec, const u32 *np, KeyFmt kf, const u64 *bitmap, const u32 *wrank,
-                                                 const u32 *ends, const u32 *first_id, u32 junc_limit, const u64 *total, u64 *jid_key, u32 *jid_bam,
-                                                 int32_t *anc_l, int32_t *anc_r, u32 *acc) {
+__global__ __launch_bounds__(256) void kd_assign(const u64 *key, const u32 *np, KeyFmt kf, const u64 *bitmap, const u32 *wrank, const u32 *ends,
+                                                 const u32 *first_id, u32 junc_limit, const u64 *total, u64 *jid_key, u32 *jid_bam, u32 *acc) {
     const u32 n = *np;
     if (n == 0) return;
     {
         const u64 J = *total;
         acc_rest_state(acc, J < (u64)junc_limit ? J : (u64)junc_limit);
     }
-    if (blockIdx.x * 256u >= n) return;
     const u32 p = blockIdx.x * 256 + threadIdx.x;
-    const bool valid = p < n;
-    const u32 pc = valid ? p : n - 1; // (loads unconditional, from the last pair for the lanes past the end, masked after: see k1_count)
-    const u64 k = key[pc];
-    const uint4 ra = *reinterpret_cast<const uint4 *>(rec + pc); // aux | lstart | rend
+    if (p >= n) return;
     int32_t s, e;
-    unpack_key(kf, k, s, e);
+    unpack_key(kf, key[p], s, e);
     const u32 rs = start_rank(bitmap, wrank, s);
     const u32 id = first_id[rs] + ends_below(ends, rs, (u32)e);
-    if (valid) {
-        jid_key[p] = (u64)id;
-        jid_bam[p] = id;
-    }
-    anchors_fold(valid && id < junc_limit, id, (int32_t)ra.z, (int32_t)ra.w, anc_l, anc_r);
+    jid_key[p] = (u64)id;
+    jid_bam[p] = id;
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -99,8 +99,10 @@ def load():
 
     In a process that also uses torch on the GPU, import torch first: torch ships its own libamdhip64 and the copy
     that is loaded first serves both libraries (torch does not find its devices through the system one)."""
-    global _LIB
+    global _LIB, LIB_PATH
     if _LIB is None:
+        # PJB_LIB_PATH: another build of the same library (kernel A/B runs: tools/build_variants.sh); never a different backend
+        LIB_PATH = os.environ.get("PJB_LIB_PATH", LIB_PATH)
         if not os.path.exists(LIB_PATH):
             raise ImportError(
                 f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "

@@ -4,8 +4,10 @@
 #   tests:<expr>     pytest -m gpu -k <expr>
 #   smoke            __graft_entry__.smoke()
 #   quick            bench.py without the BAM leg and the CPU baseline (10 steps)            -> gpurun_out/<TAG>_quick.json
+#   quick:<variant>  the same with tools/variants/libpjb_<variant>.so (tools/build_variants.sh)
 #   bench            bench.py with default flags, as the driver runs it                       -> gpurun_out/<TAG>_bench_C3.json
 #   prof             tools/profile_round.sh: rocprofv3 kernel stats + FETCH/WRITE PMC passes + the bench line
+#   sq               SQ issue / stall counters per kernel (tools/pmc_sq.sh), condensed by tools/show_sq.py
 #   fuzz             the three fuzz campaigns (tests/fuzz_campaign.py, fuzz_groups.py, fuzz_extra.py)
 #   cmd:<shell>      anything else
 # TAG (environment, default r04) names the outputs; COMMIT is recorded in the PMC summary.
@@ -22,9 +24,12 @@ for step in "$@"; do
     smoke) python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -5 ;;
     quick) timeout 900 python bench.py --steps 10 --warmup 3 --no-e2e --no-cpu-baseline > $OUT/${TAG}_quick.json 2> $OUT/${TAG}_quick.err; tail -c 400 $OUT/${TAG}_quick.err
            python3 tools/show_bench.py $OUT/${TAG}_quick.json ;;
+    quick:*) v=${step#quick:}; PJB_LIB_PATH=$PWD/tools/variants/libpjb_$v.so timeout 900 python bench.py --steps 10 --warmup 3 --no-e2e --no-cpu-baseline > $OUT/${TAG}_quick_$v.json 2> $OUT/${TAG}_quick_$v.err; tail -c 300 $OUT/${TAG}_quick_$v.err
+           python3 tools/show_bench.py $OUT/${TAG}_quick_$v.json | head -12 ;;
     bench) ( time python bench.py > $OUT/${TAG}_bench_C3.json 2> $OUT/${TAG}_bench.err ) 2>&1 | tail -4; tail -c 400 $OUT/${TAG}_bench.err
            python3 tools/show_bench.py $OUT/${TAG}_bench_C3.json ;;
     prof) bash tools/profile_round.sh $TAG ${COMMIT:-unknown}; python3 tools/show_bench.py $OUT/${TAG}_bench_C3.json ;;
+    sq) bash tools/pmc_sq.sh $TAG > $OUT/${TAG}_sq_summary.csv 2>&1; python3 tools/show_sq.py $OUT/sq_$TAG/summary.csv | tee $OUT/${TAG}_sq.txt ;;
     fuzz) ( timeout 1500 python tests/fuzz_campaign.py; timeout 900 python tests/fuzz_groups.py; timeout 900 python tests/fuzz_extra.py ) 2>&1 | tail -30 | tee $OUT/${TAG}_fuzz.txt ;;
     cmd:*) bash -c "${step#cmd:}" ;;
     *) echo "unknown step $step"; rc=2 ;;
