@@ -1158,43 +1158,14 @@ struct EmitRead {
     bool seq_ok;  // the record carries at least lq bases
     u32 off;      // index of the read's first pair
 };
-// What the walk hands back: the read's LAST pair is complete but not stored -- a read of the simple shape has one
-// pair, and its caller adds the match statistics before the record goes out (one store per pair, ever).
-struct EmitTail {
-    PairRec rec;
-    int64_t idx; // index of that pair (-1: the read emitted nothing)
-    u64 key;
-    bool simple; // [S] M N M [S], bases present: `dS` is the leading soft clip
-    u32 dS;
-};
-// on_pair(key, lStart, rEnd) is called for every pair but the read's last one (its caller has that one in T)
+// (reads of the simple shape never come here: k1_emit finishes them in closed form.)  on_pair(key, lStart, rEnd) is called
+// for every pair once its record is complete; the match statistics (PairRec::aux) are k4b_generic's to fill in.
 template <typename Ops, typename PairFn>
 __device__ __forceinline__ void emit_read_pairs(const Ops cig, const EmitRead R, const Pairs P, const KeyFmt kf, const int32_t ref_len,
-                                                const bool allow_simple, u64 *err, PairFn &&on_pair, EmitTail &T) {
+                                                u64 *err, PairFn &&on_pair) {
     const u32 n = R.n, g = R.g, nN = R.nN;
     const int32_t pos = R.pos, aend = R.aend;
     u32 meta = R.meta;
-    u32 dS = 0;
-    // ---- shape: [S] M N M [S] with the read length matching the CIGAR
-    if (allow_simple && nN == 1 && n >= 3 && n <= 5) {
-        u32 k0 = 0, k1 = n;
-        u32 s0 = 0, dE = 0;
-        const u32 opF = cig[0], opL = cig[n - 1];
-        if ((opF & 15u) == OP_S) { s0 = opF >> 4; k0 = 1; }
-        if ((opL & 15u) == OP_S) { dE = opL >> 4; k1 = n - 1; }
-        if (k1 - k0 == 3) {
-            const u32 oa = cig[k0], on = cig[k0 + 1], ob = cig[k0 + 2];
-            if ((oa & 15u) == OP_M && (on & 15u) == OP_N && (ob & 15u) == OP_M) {
-                const u32 a = oa >> 4, b2 = ob >> 4;
-                const int32_t lq = R.lq;
-                if (a > 0 && b2 > 0 && a <= RES_FIELD_MAX && b2 <= RES_FIELD_MAX && s0 <= RES_FIELD_MAX && lq > 1 &&
-                    (u64)lq == (u64)s0 + a + b2 + dE && R.seq_ok) {
-                    meta |= META_SIMPLE;
-                    dS = s0;
-                }
-            }
-        }
-    }
     // ---- walk: pairs (junction_system.cc:140-210) and, with two monotone cursors over the read's own
     // introns, the up/down junction counts (junction.cc:795-812)
     NCursor U = {0, pos, false, 0}, D = {0, pos, false, 0};
@@ -1262,13 +1233,10 @@ __device__ __forceinline__ void emit_read_pairs(const Ops cig, const EmitRead R,
         int32_t rEndExc = prevRStartU + sumAfter;
         if (rEndExc - 1 >= ref_len) rEndExc = ref_len;
         pend.rend = rEndExc - 1;
+        rec_store(P.rec + prev, pend);
+        on_pair(prev_key, pend.lstart, pend.rend);
         if (rEndExc - 1 < prevIend) set_error(err, g, PJB_ERR_MIN_ANCHOR);
     }
-    T.rec = pend;
-    T.idx = prev;
-    T.key = prev_key;
-    T.simple = (meta & META_SIMPLE) != 0 && prev >= 0;
-    T.dS = dS;
 }
 
 // per-read predicates of a pair's `meta` word (Junction::addJunctionAlignment junction.cc:477-502, calcAlignmentStats
@@ -1372,11 +1340,16 @@ __global__ __launch_bounds__(K1E_T) __attribute__((amdgpu_waves_per_eu(K1E_WAVES
     __shared__ u64 s_set[KC_SLOTS];
     __shared__ int32_t s_lo[KC_SLOTS], s_hi[KC_SLOTS];
     __shared__ u32 s_set_n, s_base, s_scan[4];
+    // the trip's reads that are not of the simple shape, compacted: what their walk needs (phase 2)
+    enum { GQ_N = 0, GQ_POS, GQ_G, GQ_META, GQ_LQ, GQ_OFF, GQ_C0, GQ_WORDS };
+    __shared__ u32 s_gq[GQ_WORDS][K1E_T];
+    __shared__ u32 s_gq_n;
     if (cs->P == 0) return; // no pairs, or a limit was exceeded: the contig is repeated with larger buffers
     const u32 s_begin = tile_soff[b.tile_base], s_end = tile_soff[b.tile_base + n_tiles_batch];
     if (s_begin == s_end) return;
     const u32 c_lo = s_begin >> K1E_SHIFT, c_hi = (s_end + (u32)K1E_T - 1u) >> K1E_SHIFT; // trips of K1E_T list entries
     const bool want_cand = E.cand != nullptr;
+    const int32_t vlen = voff + ref_len; // the target's end in the group's virtual sequence
     if (want_cand) {
 #pragma unroll
         for (int i = 0; i < KC_SLOTS / K1E_T; i++) {
@@ -1414,12 +1387,14 @@ __global__ __launch_bounds__(K1E_T) __attribute__((amdgpu_waves_per_eu(K1E_WAVES
         u32 t0 = (chunk << K1E_SHIFT) < s_begin ? b.tile_base : chunk_tile[chunk >> (8 - K1E_SHIFT)]; // (chunk_tile: the tile of entry 256 c)
         __syncthreads();
         if (threadIdx.x < K1E_LOOK) s_soff[threadIdx.x] = t0 + threadIdx.x <= n_tiles_total ? tile_soff[t0 + threadIdx.x] : 0xffffffffu;
+        if (threadIdx.x == 0) s_gq_n = 0;
         __syncthreads();
         const u32 s = (chunk << K1E_SHIFT) + threadIdx.x;
         const bool on = s >= s_begin && s < s_end;
-        bool gen = false;
-        u32 gen_n = 0;
-        u64 gen_entry = 0;
+        // ---- phase 1: every read's fixed-width fields and first operations; a read of the shape [S] M N M [S] (l_qseq matching, bases
+        // present) is finished here, in closed form: one pair, no walk (junction_system.cc:140-210 for one N operation)
+        bool generic = false;
+        u32 q_n = 0, q_pos = 0, q_g = 0, q_meta = 0, q_lq = 0, q_off = 0, q_c0 = 0;
         if (on) {
             u32 k = 0; // (the offsets ascend: the entry's tile is the number of them it has reached -- 15 independent LDS reads, not a walk)
 #pragma unroll
@@ -1440,66 +1415,141 @@ __global__ __launch_bounds__(K1E_T) __attribute__((amdgpu_waves_per_eu(K1E_WAVES
             const int64_t r = spl_idx[slot];
             const u32 c0 = b.cig_off[r], c1 = b.cig_off[r + 1];
             const u32 n = c1 - c0;
-            OpsViewT<K1E_T, OPS_LDS> cig;
-            cig.g = b.cigar + c0;
-            cig.lds = &s_ops[0][threadIdx.x];
+            u32 op[OPS_LDS];
 #pragma unroll
             for (int q = 0; q < OPS_LDS; q++) { // (unconditional loads, masked: see k1_count)
                 const bool has = (u32)q < n;
-                const u32 v = *(has ? cig.g + q : b.cig_off);
-                s_ops[q][threadIdx.x] = has ? v : 0u;
+                const u32 v = *(has ? b.cigar + c0 + q : b.cig_off);
+                op[q] = has ? v : 0u;
+                s_ops[q][threadIdx.x] = op[q];
             }
+            const int32_t pos = b.pos[r];
+            const u32 g = b.base + (u32)r;
+            const u32 off = toff + spl_poff[slot];
+            u32 meta = read_meta(b.flag[r], (u32)b.xs[r], b.mapq[r], pos, b.mtid[r], b.mpos[r], tid, orientation);
+            const int32_t lq = b.l_qseq[r];
+            const u32 so = b.seq_off[r];
+            const bool seq_ok = (u64)(b.seq_off[r + 1] - so) * 8ull >= (u64)(int64_t)lq;
+            // ---- shape
+            bool simple = false;
+            u32 dS = 0, a = 0, nl = 0, b2 = 0;
+            if (gcodes != nullptr && n >= 3 && n <= 5) {
+                const bool clipF = (op[0] & 15u) == OP_S;
+                const u32 opL = n == 3 ? op[2] : n == 4 ? op[3] : op[4];
+                const bool clipL = (opL & 15u) == OP_S;
+                if (n == 3u + (clipF ? 1u : 0u) + (clipL ? 1u : 0u)) {
+                    const u32 oa = clipF ? op[1] : op[0], on_ = clipF ? op[2] : op[1], ob = clipF ? op[3] : op[2];
+                    dS = clipF ? op[0] >> 4 : 0u;
+                    const u32 dE = clipL ? opL >> 4 : 0u;
+                    a = oa >> 4;
+                    nl = on_ >> 4;
+                    b2 = ob >> 4;
+                    simple = (oa & 15u) == OP_M && (on_ & 15u) == OP_N && (ob & 15u) == OP_M && a > 0 && b2 > 0 && a <= RES_FIELD_MAX && b2 <= RES_FIELD_MAX &&
+                             dS <= RES_FIELD_MAX && lq > 1 && (u64)lq == (u64)dS + a + b2 + dE && seq_ok;
+                }
+            }
+            if (simple) {
+                const int32_t vpos = pos + voff;
+                const int32_t istart = vpos + (int32_t)a;
+                const int32_t rStartU = istart + (int32_t)nl;
+                int32_t rStart = rStartU;
+                if (rStart - 1 >= vlen) rStart = vlen - 1; // junction_system.cc:169-171
+                const int32_t iend = rStart - 1;
+                int32_t rEndExc = rStartU + (int32_t)b2;
+                if (rEndExc - 1 >= vlen) rEndExc = vlen; // junction_system.cc:172-174
+                if (rEndExc - 1 < iend) set_error(err, g, PJB_ERR_MIN_ANCHOR); // intron.cc:76
+                const u64 key = make_key(kf, istart, iend);
+                PairRec R;
+                R.lstart = vpos;
+                R.rend = rEndExc - 1;
+                R.pos = vpos;
+                R.aend = vpos + (int32_t)(a + nl + b2) - 1;
+                R.meta = meta | META_SIMPLE;
+                // junction.cc:795-812 for one N operation: nothing upstream; "downstream" counts the operation itself unless its end was clamped
+                R.updown = rStartU <= iend + 1 ? 0u : (1u << 16);
+                R.aux = simple_pair_stats(reinterpret_cast<const u32 *>(b.seq4) + so, gcodes, ref_len, pos, istart - voff, iend - voff, R.rend - voff, (int32_t)dS);
+                P.key[off] = key;
+                if (P.g) P.g[off] = g;
+                rec_store(P.rec + off, R);
+                if (want_cand) cand_insert(key, R.lstart, R.rend);
+            } else {
+                generic = true;
+                q_n = n;
+                q_pos = (u32)pos;
+                q_g = g;
+                q_meta = meta | ((u32)threadIdx.x << 16) | (seq_ok ? 0x80000000u : 0u); // (bits 0-8: predicates; 16-23: the thread that holds the operations; 31: bases present)
+                q_lq = (u32)lq;
+                q_off = off;
+                q_c0 = c0;
+            }
+        }
+        // ---- the other reads are compacted (LDS) ...
+        {
+            const u64 gm = __ballot(generic);
+            if (gm) {
+                const int leader = __ffsll((long long)gm) - 1;
+                u32 base = 0;
+                if (lane_id() == leader) base = atomicAdd(&s_gq_n, (u32)__popcll(gm));
+                base = (u32)__builtin_amdgcn_readlane((int)base, leader);
+                if (generic) {
+                    const u32 at = base + (u32)__popcll(gm & ((1ull << lane_id()) - 1));
+                    s_gq[GQ_N][at] = q_n;
+                    s_gq[GQ_POS][at] = q_pos;
+                    s_gq[GQ_G][at] = q_g;
+                    s_gq[GQ_META][at] = q_meta;
+                    s_gq[GQ_LQ][at] = q_lq;
+                    s_gq[GQ_OFF][at] = q_off;
+                    s_gq[GQ_C0][at] = q_c0;
+                }
+            }
+        }
+        __syncthreads();
+        // ---- ... and walked by the block's first threads (phase 2): a read in five takes this path, and lanes that sat between
+        // the other four would have kept every wavefront in the walk's loops for nothing.  Each of these reads goes on
+        // k4b_generic's list.
+        const u32 n_gen = s_gq_n;
+        const bool gen = threadIdx.x < n_gen;
+        u32 gen_pairs = 0;
+        u64 gen_entry = 0;
+        if (gen) {
+            const u32 at = threadIdx.x;
+            const u32 qm = s_gq[GQ_META][at];
             EmitRead R;
-            R.n = n;
-            R.pos = b.pos[r];
-            R.g = b.base + (u32)r;
-            R.off = toff + spl_poff[slot];
-            R.meta = read_meta(b.flag[r], (u32)b.xs[r], b.mapq[r], R.pos, b.mtid[r], b.mpos[r], tid, orientation);
-            R.pos += voff;
+            R.n = s_gq[GQ_N][at];
+            R.pos = (int32_t)s_gq[GQ_POS][at] + voff;
+            R.g = s_gq[GQ_G][at];
+            R.meta = qm & 0xffffu;
+            R.lq = (int32_t)s_gq[GQ_LQ][at];
+            R.seq_ok = (qm & 0x80000000u) != 0;
+            R.off = s_gq[GQ_OFF][at];
+            OpsViewT<K1E_T, OPS_LDS> cig;
+            cig.g = b.cigar + s_gq[GQ_C0][at];
+            cig.lds = &s_ops[0][(qm >> 16) & 0xffu];
             u32 nN = 0;
             int32_t aligned = 0;
-            for (u32 q = 0; q < n; q++) {
-                const u32 op = cig[q];
-                nN += ((op & 15u) == OP_N);
-                if (op_consumes_ref(op & 15u)) aligned += (int32_t)(op >> 4);
+            for (u32 q = 0; q < R.n; q++) {
+                const u32 o = cig[q];
+                nN += ((o & 15u) == OP_N);
+                if (op_consumes_ref(o & 15u)) aligned += (int32_t)(o >> 4);
             }
             if (nN > 1) R.meta |= META_MULTI;
             R.nN = nN;
             R.aend = R.pos + aligned - 1;
-            R.lq = b.l_qseq[r];
-            const u32 so = b.seq_off[r];
-            R.seq_ok = (u64)(b.seq_off[r + 1] - so) * 8ull >= (u64)(int64_t)R.lq;
-            EmitTail T;
-            emit_read_pairs(cig, R, P, kf, voff + ref_len, gcodes != nullptr, err,
-                            [&](u64 key, int32_t lstart, int32_t rend) { if (want_cand) cand_insert(key, lstart, rend); }, T);
-            if (T.idx >= 0) {
-                if (want_cand) cand_insert(T.key, T.rec.lstart, T.rec.rend);
-                if (T.simple) {
-                    int32_t istart, iend;
-                    unpack_key(kf, T.key, istart, iend);
-                    T.rec.aux = simple_pair_stats(b.seq4 ? reinterpret_cast<const u32 *>(b.seq4) + so : nullptr, gcodes, ref_len, T.rec.pos - voff, istart - voff,
-                                                  iend - voff, T.rec.rend - voff, (int32_t)T.dS);
-                } else {
-                    gen = true;
-                    gen_n = nN;
-                    gen_entry = (u64)R.g | ((u64)R.off << 32);
-                }
-                rec_store(P.rec + T.idx, T.rec);
-            }
+            emit_read_pairs(cig, R, P, kf, vlen, err, [&](u64 key, int32_t lstart, int32_t rend) { if (want_cand) cand_insert(key, lstart, rend); });
+            gen_pairs = nN;
+            gen_entry = (u64)R.g | ((u64)R.off << 32);
         }
-        // ---- the reads whose pairs need the generic walks: one returning atomic per wavefront
-        const u64 gm = __ballot(gen);
-        if (gm) {
+        const u64 gm2 = __ballot(gen);
+        if (gm2) { // one returning atomic per wavefront
             const u32 shard = (chunk >> (8 - K1E_SHIFT)) % GEN_SHARDS; // (by 256-entry chunk: gen_list_cap)
-            const int leader = __ffsll((long long)gm) - 1;
-            const u32 pairs_w = wave_total<DppAdd>(gen_n);
+            const u32 pairs_w = wave_total<DppAdd>(gen_pairs);
             u32 base = 0;
-            if (lane_id() == leader) {
-                base = atomicAdd(&E.gen_reads[shard], (u32)__popcll(gm));
+            if (lane_id() == 0) { // (the block's first threads: lane 0 of a wavefront with any such read has one)
+                base = atomicAdd(&E.gen_reads[shard], (u32)__popcll(gm2));
                 atomicAdd(&E.gen_pairs[shard], pairs_w);
             }
-            base = (u32)__builtin_amdgcn_readlane((int)base, leader);
-            const u32 at = base + (u32)__popcll(gm & ((1ull << lane_id()) - 1));
+            base = (u32)__builtin_amdgcn_readfirstlane((int)base);
+            const u32 at = base + (u32)lane_id();
             if (gen && at < E.gen_cap) E.gen_list[(size_t)shard * E.gen_cap + at] = gen_entry;
         }
         // ---- candidate keys: flush the set when it fills up, and before the block leaves

@@ -27,3 +27,4 @@ with open(out + '/summary.csv', 'w') as fo:
         fo.write(k + ',' + ','.join('%.0f' % (acc[k][c] / max(cnt[k][c], 1)) for c in names) + '\n')
 print(open(out + '/summary.csv').read())
 PY
+rm -rf $OUT/g*   # (the raw counter tables stay on the box: gpurun copies back 64 MiB at most)
