@@ -3259,3 +3259,15 @@ extern "C" int pjb_bam_end(pjb_ctx *c, int32_t tid, int32_t first_uoffset, int64
     HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_up, 0));
     return ingest_staged(c, tid, oc, (const uint8_t *)st->dev.p, st->blocks, st->total, st->total_out, first_uoffset, n_records, st->t_scan, st->t_up);
 }
+
+#ifdef K1E_PROF
+// (profiling builds only: tools/debug/k1e_prof.py)
+extern "C" int pjb_debug_k1e_prof(unsigned long long *out16, int reset) {
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(pjb::k1e_prof), 16 * 8) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[16] = {};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(pjb::k1e_prof), z, sizeof z) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif

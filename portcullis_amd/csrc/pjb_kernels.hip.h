@@ -1308,6 +1308,20 @@ __device__ __forceinline__ u64 simple_pair_stats(const u32 *seqw, const u32 *gco
 //   * the list of reads that need the generic walks (k4b_generic), in GEN_SHARDS sub-lists (one returning atomic per
 //     wavefront, spread over 256 addresses).
 constexpr int K1E_LOOK = 16;
+// K1E_PROF (tools/build_variants.sh, tools/debug/k1e_prof.py): where the wavefronts of k1_emit spend their cycles -- every probe
+// waits for the memory operations issued so far, reads the shader clock and adds the time since the last probe to its slot
+#ifdef K1E_PROF
+__device__ unsigned long long k1e_prof[16];
+#define K1E_PROBE(i)                                                   \
+    do {                                                               \
+        __builtin_amdgcn_s_waitcnt(0);                                 \
+        const unsigned long long t_ = __builtin_readcyclecounter();    \
+        prof_acc[i] += t_ - prof_t;                                    \
+        prof_t = t_;                                                   \
+    } while (0)
+#else
+#define K1E_PROBE(i) do { } while (0)
+#endif
 #ifndef K1E_WAVES
 #define K1E_WAVES 6 // wavefronts per SIMD the register allocation aims at (tools/build_variants.sh builds the others for A/B runs)
 #endif
@@ -1382,13 +1396,18 @@ __global__ __launch_bounds__(K1E_T) __attribute__((amdgpu_waves_per_eu(K1E_WAVES
         E.cand[at] = k;
         E.cand_anc[at] = (u64)(u32)lstart | ((u64)(u32)rend << 32);
     };
+#ifdef K1E_PROF
+    unsigned long long prof_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, prof_t = __builtin_readcyclecounter();
+#endif
     for (u32 chunk = c_lo + blockIdx.x; chunk < c_hi; chunk += gridDim.x) {
         // the tile of the chunk's first entry (for the batch's first chunk: of the batch's first entry)
         u32 t0 = (chunk << K1E_SHIFT) < s_begin ? b.tile_base : chunk_tile[chunk >> (8 - K1E_SHIFT)]; // (chunk_tile: the tile of entry 256 c)
         __syncthreads();
+        K1E_PROBE(0);
         if (threadIdx.x < K1E_LOOK) s_soff[threadIdx.x] = t0 + threadIdx.x <= n_tiles_total ? tile_soff[t0 + threadIdx.x] : 0xffffffffu;
         if (threadIdx.x == 0) s_gq_n = 0;
         __syncthreads();
+        K1E_PROBE(1);
         const u32 s = (chunk << K1E_SHIFT) + threadIdx.x;
         const bool on = s >= s_begin && s < s_end;
         // ---- phase 1: every read's fixed-width fields and first operations; a read of the shape [S] M N M [S] (l_qseq matching, bases
@@ -1413,8 +1432,10 @@ __global__ __launch_bounds__(K1E_T) __attribute__((amdgpu_waves_per_eu(K1E_WAVES
             const u32 toff = tile_off[tile];
             const size_t slot = (size_t)tile * K1_TILE + (s - soff);
             const int64_t r = spl_idx[slot];
+            K1E_PROBE(2);
             const u32 c0 = b.cig_off[r], c1 = b.cig_off[r + 1];
             const u32 n = c1 - c0;
+            K1E_PROBE(3);
             u32 op[OPS_LDS];
 #pragma unroll
             for (int q = 0; q < OPS_LDS; q++) { // (unconditional loads, masked: see k1_count)
@@ -1430,6 +1451,7 @@ __global__ __launch_bounds__(K1E_T) __attribute__((amdgpu_waves_per_eu(K1E_WAVES
             const int32_t lq = b.l_qseq[r];
             const u32 so = b.seq_off[r];
             const bool seq_ok = (u64)(b.seq_off[r + 1] - so) * 8ull >= (u64)(int64_t)lq;
+            K1E_PROBE(4);
             // ---- shape
             bool simple = false;
             u32 dS = 0, a = 0, nl = 0, b2 = 0;
@@ -1468,6 +1490,7 @@ __global__ __launch_bounds__(K1E_T) __attribute__((amdgpu_waves_per_eu(K1E_WAVES
                 // junction.cc:795-812 for one N operation: nothing upstream; "downstream" counts the operation itself unless its end was clamped
                 R.updown = rStartU <= iend + 1 ? 0u : (1u << 16);
                 R.aux = simple_pair_stats(reinterpret_cast<const u32 *>(b.seq4) + so, gcodes, ref_len, pos, istart - voff, iend - voff, R.rend - voff, (int32_t)dS);
+                K1E_PROBE(5);
                 P.key[off] = key;
                 if (P.g) P.g[off] = g;
                 rec_store(P.rec + off, R);
@@ -1483,6 +1506,7 @@ __global__ __launch_bounds__(K1E_T) __attribute__((amdgpu_waves_per_eu(K1E_WAVES
                 q_c0 = c0;
             }
         }
+        K1E_PROBE(6);
         // ---- the other reads are compacted (LDS) ...
         {
             const u64 gm = __ballot(generic);
@@ -1507,6 +1531,7 @@ __global__ __launch_bounds__(K1E_T) __attribute__((amdgpu_waves_per_eu(K1E_WAVES
         // ---- ... and walked by the block's first threads (phase 2): a read in five takes this path, and lanes that sat between
         // the other four would have kept every wavefront in the walk's loops for nothing.  Each of these reads goes on
         // k4b_generic's list.
+        K1E_PROBE(7);
         const u32 n_gen = s_gq_n;
         const bool gen = threadIdx.x < n_gen;
         u32 gen_pairs = 0;
@@ -1552,6 +1577,7 @@ __global__ __launch_bounds__(K1E_T) __attribute__((amdgpu_waves_per_eu(K1E_WAVES
             const u32 at = base + (u32)lane_id();
             if (gen && at < E.gen_cap) E.gen_list[(size_t)shard * E.gen_cap + at] = gen_entry;
         }
+        K1E_PROBE(8);
         // ---- candidate keys: flush the set when it fills up, and before the block leaves
         if (want_cand) {
             __syncthreads();
@@ -1585,7 +1611,13 @@ __global__ __launch_bounds__(K1E_T) __attribute__((amdgpu_waves_per_eu(K1E_WAVES
                     }
             }
         }
+        K1E_PROBE(9);
     }
+#ifdef K1E_PROF
+    if (lane_id() == 0)
+        for (int i = 0; i < 10; i++) atomicAdd(&k1e_prof[i], prof_acc[i]);
+    if (lane_id() == 0) atomicAdd(&k1e_prof[15], 1ull);
+#endif
 }
 
 // per-member counters of a group, from the tile statistics of the member's tiles (before k1_scan_tiles turns the tile pair

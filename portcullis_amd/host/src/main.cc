@@ -17,30 +17,39 @@
 #define PORTCULLIS_AMD_VERSION "1.2.4"
 #endif
 
-// The work runs in a child process; this one returns as soon as the child says its outputs are written and closed.
-// Why: a process that held 100 GB of device memory takes the driver 0.02 - 0.25 s to tear down after it has nothing left
-// to do (measured around _exit: `real` minus the program's own last timestamp), and whoever waits for the command waits
-// for that too.  The child is forked before anything touches the GPU; it reports its exit code through a pipe, closes
-// its standard streams and leaves; the tear-down finishes behind the prompt.  PORTCULLIS_NO_FORK=1 (and
-// PJB_NORMAL_EXIT=1, which profilers need): one process, as before.
+// PORTCULLIS_EARLY_RETURN=1 (opt-in): the work runs in a child process and this one returns as soon as the child says its
+// outputs are written and closed.  Why one may want it: a process that held 100 GB of device memory takes the driver up
+// to a second to tear down after it has nothing left to do, and whoever waits for the command waits for that too.  Why
+// it is not the default: the child still holds its device memory while the driver tears it down, so a command started
+// right behind this one shares the GPU with that for a moment -- `junc A && junc B` would overlap two working sets.
+// The child is forked before anything touches the GPU (never if /dev/kfd is open already or a profiler is preloaded: a
+// forked child must not inherit a started runtime); it reports its exit code through a pipe, closes its standard
+// streams and leaves.
 static pid_t g_child = -1;
 static void forwardSignal(int sig) {
     if (g_child > 0) kill(g_child, sig);
 }
 static int g_report_fd = -1;  // (child) where the exit code goes
-extern char** environ;
 
 int main(int argc, char* argv[]) {
     // exit codes as in src/portcullis.cc:497-515 of the reference
     int rc = 0;
-    // (not under a profiler: its preloaded library may have started the GPU runtime in this process already, and a forked
-    // child must not inherit that.  Other preloaded libraries -- a sanitizer's runtime, a harness's exec guard -- do not
-    // touch the GPU, and the fork below happens before this program does)
-    const char* preload = getenv("LD_PRELOAD");
-    bool plain = !getenv("HSA_TOOLS_LIB") && !(preload && (strstr(preload, "rocprof") || strstr(preload, "roctracer") || strstr(preload, "roctx")));
-    for (char** e = environ; plain && e && *e; e++)
-        if (strncmp(*e, "ROCP", 4) == 0 || strncmp(*e, "ROCPROFILER", 11) == 0) plain = false;
-    if (argc >= 2 && plain && !getenv("PORTCULLIS_NO_FORK") && !getenv("PJB_NORMAL_EXIT")) {
+    // (never with the GPU runtime started in this process already -- a profiler's or any other tool's preloaded library may have
+    // done that before main: decided from the process state, an open /dev/kfd, not from the tool's name)
+    bool kfd_open = false;
+    {
+        char link[64], target[256];
+        for (int fd = 0; fd < 256 && !kfd_open; fd++) {
+            snprintf(link, sizeof link, "/proc/self/fd/%d", fd);
+            const ssize_t n = readlink(link, target, sizeof target - 1);
+            if (n > 0) {
+                target[n] = 0;
+                kfd_open = strstr(target, "/dev/kfd") != nullptr || strstr(target, "/dev/dri/render") != nullptr;
+            }
+        }
+    }
+    const char* early = getenv("PORTCULLIS_EARLY_RETURN");
+    if (argc >= 2 && early && atoi(early) != 0 && !kfd_open && !getenv("HSA_TOOLS_LIB") && !getenv("PJB_NORMAL_EXIT")) {
         int fds[2];
         if (pipe(fds) == 0) {
             std::cout.flush();
