@@ -1460,7 +1460,7 @@ static int queue_contig(pjb_ctx *c, Flight &f) {
     const u32 pair_blocks = std::max<u32>(1, (PL + 255) / 256);
     const u32 gen_cap = gen_list_cap(PL); // entries per sub-list
     if ((rc = ensure(c, S.genlist, (size_t)gen_cap * GEN_SHARDS * 8))) return rc;
-    if ((rc = ensure(c, S.gencount, 2 * GEN_SHARDS * 4))) return rc; // reads | pairs of each sub-list
+    if ((rc = ensure(c, S.gencount, GEN_SHARDS * GEN_CNT_STRIDE * 4))) return rc; // a line per sub-list: reads, pairs
     // ---- junction-sized buffers
     const u32 slots_lim = JL + (PL + 63) / 64 + 1;
     if ((rc = ensure(c, S.frag, (size_t)slots_lim * F_WORDS * 4))) return rc;
@@ -1527,7 +1527,7 @@ static int queue_contig(pjb_ctx *c, Flight &f) {
     }
     if (!S.at_rest) {
         HIP_TRY(c, hipMemsetAsync(S.err.p, 0xff, 8, front));
-        HIP_TRY(c, hipMemsetAsync(S.gencount.p, 0, 2 * GEN_SHARDS * 4, front));
+        HIP_TRY(c, hipMemsetAsync(S.gencount.p, 0, GEN_SHARDS * GEN_CNT_STRIDE * 4, front));
         HIP_TRY(c, hipMemsetAsync(d_member_junc, 0, GROUP_MAX * 4, front));
     }
     S.at_rest = false; // until k7_publish is queued
@@ -1546,7 +1546,7 @@ static int queue_contig(pjb_ctx *c, Flight &f) {
     pr.rec = (PairRec *)S.rec.p;
     pr.g = c->extra ? (u32 *)S.g.p : (u32 *)nullptr;
     f.pr = pr;
-    u32 *d_gen_reads = (u32 *)S.gencount.p, *d_gen_pairs = d_gen_reads + GEN_SHARDS;
+    u32 *d_gen_cnt = (u32 *)S.gencount.p;
     const bool fast_codes = all_codes && !any_x; // (else: no read is "simple", every pair takes k4b_generic's byte-wise walks)
     {
         // ---- K1a: count (a group's members: a tile whose alignments leave the member's own sequence is flagged); with
@@ -1591,8 +1591,7 @@ static int queue_contig(pjb_ctx *c, Flight &f) {
         el.cand = lim.dense ? (u64 *)S.key[1].p : (u64 *)nullptr;
         el.cand_anc = (u64 *)S.ent.p; // (the entropy terms' buffer: free until the position runs exist)
         el.gen_list = (u64 *)S.genlist.p;
-        el.gen_reads = d_gen_reads;
-        el.gen_pairs = d_gen_pairs;
+        el.gen_cnt = d_gen_cnt;
         el.gen_cap = gen_cap;
         for (size_t bi = 0; bi < batches.size(); bi++) {
             const DevBatch &b = batches[bi];
@@ -1611,7 +1610,7 @@ static int queue_contig(pjb_ctx *c, Flight &f) {
     // the sort, on the side stream
     const u32 gen_grid = (u32)(((u64)gen_cap * GEN_SHARDS + 255) / 256);
     auto launch_k4b = [&]() -> int {
-        LAUNCH(c, "k4b_generic", k4b_generic, dim3(gen_grid), dim3(256), (const u64 *)S.genlist.p, (const u32 *)d_gen_reads, gen_cap, (const u64 *)pr.key,
+        LAUNCH(c, "k4b_generic", k4b_generic, dim3(gen_grid), dim3(256), (const u64 *)S.genlist.p, (const u32 *)d_gen_cnt, gen_cap, (const u64 *)pr.key,
                pr.rec, (const u32 *)S.jidbam.p, kf, (const DevBatch *)S.batches.p, (int)batches.size(), (const int32_t *)S.ancl.p, (const int32_t *)S.ancr.p,
                GT, any_x ? 1 : 0, any_x ? 0 : 1, d_err);
         return PJB_OK;
@@ -1793,7 +1792,7 @@ static int queue_contig(pjb_ctx *c, Flight &f) {
         c->stream = rows_stream; // LAUNCH (and its event bracket) follow c->stream
         LAUNCH(c, "k6_rows_out", k6_rows_out, dim3(K6_BLOCKS), dim3(256), (const u64 *)S.rows.p, (const ContigStats *)d_cs,
                (u64 *)c->rows_table, row_base, mirror_base, (const RowCursor *)c->b_cursor.p, mirror_table, mirror_room);
-        LAUNCH(c, "k7_publish", k7_publish, dim3(1), dim3(256), (const ContigStats *)d_cs, d_err, d_gen_reads, d_gen_pairs, S.pub_dev, row_base,
+        LAUNCH(c, "k7_publish", k7_publish, dim3(1), dim3(256), (const ContigStats *)d_cs, d_err, d_gen_cnt, S.pub_dev, row_base,
                mirror_base, (RowCursor *)c->b_cursor.p, (const MemberStats *)d_members, d_member_junc, n_members);
     }
     S.at_rest = true;

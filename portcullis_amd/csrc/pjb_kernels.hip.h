@@ -1331,13 +1331,13 @@ __device__ unsigned long long k1e_prof[16];
 #endif
 constexpr int K1E_T = 256, K1E_SHIFT = 8; // threads of a block = list entries of one trip = one chunk
 constexpr u64 KD_EMPTY = ~0ull; // no key: a packed key has fewer than 64 bits
-constexpr u32 GEN_SHARDS = 256;
+constexpr u32 GEN_SHARDS = 256, GEN_CNT_STRIDE = 32;
 struct EmitLists {
     u64 *cand;      // candidate keys (nullptr: the chain sorts the full keys and wants none); their count is ContigStats::n_cand
     u64 *cand_anc;  // per candidate: min lStart | max rEnd << 32 over the pairs it stands for (the junction anchors' first level)
     u64 *gen_list;  // global read ordinal | index of the read's first pair << 32
-    u32 *gen_reads; // [GEN_SHARDS] entries of each sub-list
-    u32 *gen_pairs; // [GEN_SHARDS] pairs of those reads
+    u32 *gen_cnt;   // [GEN_SHARDS][GEN_CNT_STRIDE]: word 0 entries of the sub-list, word 1 pairs of those reads -- a cache line per
+                    // sub-list: atomics on one line are served one after the other, whatever the address in it
     u32 gen_cap;    // room of one sub-list
 };
 __host__ __device__ inline u32 gen_list_cap(u32 pair_limit) { // chunks of 256 spliced reads dealt round-robin to the sub-lists
@@ -1585,8 +1585,8 @@ __global__ __launch_bounds__(K1E_T) __attribute__((amdgpu_waves_per_eu(K1E_WAVES
             const u32 pairs_w = wave_total<DppAdd>(gen_pairs);
             u32 base = 0;
             if (lane_id() == 0) { // (the block's first threads: lane 0 of a wavefront with any such read has one)
-                base = atomicAdd(&E.gen_reads[shard], (u32)__popcll(gm2));
-                atomicAdd(&E.gen_pairs[shard], pairs_w);
+                base = atomicAdd(&E.gen_cnt[shard * GEN_CNT_STRIDE], (u32)__popcll(gm2));
+                atomicAdd(&E.gen_cnt[shard * GEN_CNT_STRIDE + 1], pairs_w);
             }
             base = (u32)__builtin_amdgcn_readfirstlane((int)base);
             const u32 at = base + (u32)lane_id();
@@ -2464,14 +2464,14 @@ __device__ __forceinline__ const DevBatch &find_batch(const DevBatch *batches, i
 // walked once; at every N operation the pair's junction-level anchors (kd_assign) are looked up and the two lock-step
 // walks start right there (op index and query offset are at hand: no hint has to travel with the pair).  The result
 // goes into the pair's record.  Runs on the side stream, beside the sort.
-__global__ __launch_bounds__(256) void k4b_generic(const u64 *list, const u32 *n_list, u32 cap, const u64 *key, PairRec *rec, const u32 *jid_bam,
+__global__ __launch_bounds__(256) void k4b_generic(const u64 *list, const u32 *gen_cnt, u32 cap, const u64 *key, PairRec *rec, const u32 *jid_bam,
                                                     KeyFmt kf, const DevBatch *batches, int n_batches, const int32_t *anc_l, const int32_t *anc_r,
                                                     GroupTab G, int genome_has_x, int use_codes, u64 *err) {
     __shared__ u32 s_ops[OPS_LDS][256];
     // sub-list `shard` occupies [shard * cap, shard * cap + n_list[shard])
     const u32 t = blockIdx.x * 256 + threadIdx.x;
     const u32 shard = t / cap, k_in = t % cap;
-    if (shard >= GEN_SHARDS || k_in >= n_list[shard]) return;
+    if (shard >= GEN_SHARDS || k_in >= gen_cnt[shard * GEN_CNT_STRIDE]) return;
     const u64 entry = list[t];
     const u32 g = (u32)entry, p0 = (u32)(entry >> 32);
     const DevBatch &b = find_batch(batches, n_batches, g);
@@ -2998,7 +2998,7 @@ __global__ __launch_bounds__(256) void k6_rows_out(const u64 *rows, const Contig
 // control slot next, and the row cursor moves on.
 constexpr int PUB_BASE_AT = 240, PUB_ERR_AT = 256, PUB_XCNT_AT = 320 /* --extra: the target's counters, 64 bytes */, PUB_GEN_AT = 512, PUB_MEMBERS_AT = 1536, PUB_GREADS_AT = 3072, PUB_BYTES = 4096; // byte offsets in the published block
 static_assert(PUB_MEMBERS_AT + GROUP_MAX * sizeof(MemberStats) <= PUB_BYTES && sizeof(MemberStats) % 8 == 0, "control block layout");
-__global__ __launch_bounds__(256) void k7_publish(const ContigStats *cs, u64 *err, u32 *gen_reads, u32 *gen_pairs, uint8_t *host, int64_t base,
+__global__ __launch_bounds__(256) void k7_publish(const ContigStats *cs, u64 *err, u32 *gen_cnt, uint8_t *host, int64_t base,
                                                   int64_t mirror_base, RowCursor *cur, const MemberStats *members, u32 *member_junc, int n_members) {
     const u32 t = threadIdx.x;
     if (n_members > 1 && t < (u32)n_members) { // a group: the members' own counters
@@ -3012,10 +3012,10 @@ __global__ __launch_bounds__(256) void k7_publish(const ContigStats *cs, u64 *er
                   "control block layout");
     if (t < sizeof(ContigStats) / 8) reinterpret_cast<u64 *>(host)[t] = reinterpret_cast<const u64 *>(cs)[t];
     if (t < GEN_SHARDS) { // pairs that took the generic walks, per sub-list; both counters back to their rest state
-        reinterpret_cast<u32 *>(host + PUB_GEN_AT)[t] = gen_pairs[t];
-        reinterpret_cast<u32 *>(host + PUB_GREADS_AT)[t] = gen_reads[t];
-        gen_pairs[t] = 0;
-        gen_reads[t] = 0;
+        reinterpret_cast<u32 *>(host + PUB_GEN_AT)[t] = gen_cnt[t * GEN_CNT_STRIDE + 1];
+        reinterpret_cast<u32 *>(host + PUB_GREADS_AT)[t] = gen_cnt[t * GEN_CNT_STRIDE];
+        gen_cnt[t * GEN_CNT_STRIDE] = 0;
+        gen_cnt[t * GEN_CNT_STRIDE + 1] = 0;
     }
     if (t == 0) {
         *reinterpret_cast<u64 *>(host + PUB_ERR_AT) = *err;
