@@ -283,7 +283,6 @@ struct pjb_ctx {
     Buf b_scan_tiles;
     Buf b_inf_comp, b_inf_out, b_inf_blocks, b_inf_status, b_inf_scratch, b_inf_bitmap; // device-side BGZF inflate
     Buf b_dfl_in, b_dfl_sym, b_dfl_slots, b_dfl_size, b_dfl_off, b_dfl_packed;           // device-side BGZF deflate
-    bool inflate_v1 = false; // PJB_INFLATE_V1=1: round 2's one-kernel bgzf_inflate instead of bgzf_decode + bgzf_resolve
     Buf b_bam_seg, b_bam_rec, b_bam_ctl;                                  // device-side BAM record parse
     // --extra
     bool extra = false;
@@ -574,7 +573,7 @@ std::mutex g_host_mu;
 std::map<void *, size_t> g_host_registered; // blocks of pjb_host_alloc that are mmap + hipHostRegister (value: mapped bytes)
 } // namespace
 void *pjb_host_alloc(size_t bytes) {
-    if (bytes >= ((size_t)8 << 20) && !getenv("PJB_HOST_ALLOC_PLAIN")) {
+    if (bytes >= ((size_t)8 << 20)) {
         const size_t huge = (size_t)2 << 20, len = (bytes + huge - 1) & ~(huge - 1);
         void *p = mmap(nullptr, len, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
         if (p != MAP_FAILED) {
@@ -682,14 +681,11 @@ int pjb_create(pjb_ctx **out, const pjb_config *cfg) {
     const int dev = cfg->device;
     auto attributes = [dev] {
         (void)hipSetDevice(dev);
-        (void)hipFuncSetAttribute((const void *)bgzf_inflate, hipFuncAttributeMaxDynamicSharedMemorySize, I2_LDS_BYTES);
         (void)hipFuncSetAttribute((const void *)bgzf_decode, hipFuncAttributeMaxDynamicSharedMemorySize, I3_LDS_BYTES);
         // 12-bit digits need more dynamic LDS than the 64 KB a kernel gets without asking
         (void)hipFuncSetAttribute((const void *)rs_scatter<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rs_scatter_lds_bytes(RS_MAX_BITS));
     };
-    const bool serial = getenv("PJB_CREATE_SERIAL") != nullptr;
-    std::thread attr_thread;
-    if (!serial) attr_thread = std::thread(attributes);
+    std::thread attr_thread(attributes);
     struct JoinAttr {
         std::thread &t;
         ~JoinAttr() {
@@ -715,23 +711,16 @@ int pjb_create(pjb_ctx **out, const pjb_config *cfg) {
     if (!(cfg->flags & PJB_FLAG_NO_CHAINS))
         for (int k = 0; k < 4 && k < PJB_MAX_QUEUED; k++) (void)slot_init(c, k);
     cmark("chain slots");
-    if (const char *s = getenv("PJB_INFLATE_V1")) c->inflate_v1 = atoi(s) != 0;
-    const int inf_lds = c->inflate_v1 ? I2_LDS_BYTES : I3_LDS_BYTES;
-    c->inflate_lanes = std::max(1, n_cu) * (160 * 1024 / inf_lds) * 64;
-    if (const char *s = getenv("PJB_INFLATE_WG_PER_CU")) // (experiments: fewer resident inflate workgroups leave LDS and a SIMD to the kernels beside them)
-        c->inflate_lanes = std::max(1, n_cu) * std::max(1, std::min(atoi(s), 160 * 1024 / inf_lds)) * 64;
+    c->inflate_lanes = std::max(1, n_cu) * (160 * 1024 / I3_LDS_BYTES) * 64;
     c->ktime = (cfg->flags & PJB_FLAG_KERNEL_TIMING) != 0;
     c->extra = (cfg->flags & PJB_FLAG_EXTRA) != 0;
-    if (const char *s = getenv("PJB_DENSE_IDS")) c->dense_ids = atoi(s) != 0;
-    if (const char *s = getenv("PJB_SIDE_STREAM")) c->side_stream = atoi(s) != 0;
     if (const char *s = getenv("PJB_K1S_BLOCKS")) c->k1s_blocks_forced = std::max(0, std::min(atoi(s), (int)K1S_BLOCKS));
     if (const char *s = getenv("PJB_RADIX_BITS")) {
         int v = atoi(s);
         if (v >= 4 && v <= RS_MAX_BITS) c->radix_max_bits = v;
     }
     cmark("options");
-    if (serial) attributes();
-    else attr_thread.join();
+    attr_thread.join();
     cmark("kernel attributes");
     *out = c;
     return PJB_OK;
@@ -2626,10 +2615,7 @@ int inflate_on_device(pjb_ctx *c, const uint8_t *d_comp, const std::vector<InfBl
     iu32 *d_next = (iu32 *)(d_any + 1);
     const iu32 ctl[2] = {0u, (iu32)lanes};
     HIP_TRY(c, hipMemcpyAsync(d_any, ctl, 8, hipMemcpyHostToDevice, st));
-    if (c->inflate_v1) {
-        LAUNCH_LDS(c, "bgzf_inflate", bgzf_inflate, dim3((unsigned)(lanes / 64)), dim3(64), I2_LDS_BYTES, d_comp, (const InfBlock *)c->b_inf_blocks.p, (iu32)nb,
-                   d_out, (uint8_t *)c->b_inf_scratch.p, d_status, d_any, d_next, 8);
-    } else {
+    {
         // decode (lane per block: literals in place, a token + a bitmap bit per match), then the copies (wave per block)
         if ((rc = ensure(c, c->b_inf_bitmap, nb * INF_BITMAP_WORDS * 8))) return rc;
         HIP_TRY(c, hipMemsetAsync(c->b_inf_bitmap.p, 0, nb * INF_BITMAP_WORDS * 8, st));
@@ -2973,12 +2959,12 @@ static void stage_release(pjb_ctx *c, BamStage &st) { // (after the work that us
 // the last copy.  Nothing here waits; a failure just leaves the inflate to pjb_bam_end.
 static void inflate_early(pjb_ctx *c, BamStage &st) {
     const size_t nb = st.blocks.size();
-    if (st.launched || nb == 0 || st.total_out <= 0 || getenv("PJB_NO_EARLY_INFLATE")) return;
+    if (st.launched || nb == 0 || st.total_out <= 0) return;
     size_t lanes = std::min<size_t>((nb + 63) / 64 * 64, (size_t)c->inflate_lanes);
     if (const char *e = getenv("PJB_INF_BLOCKS_PER_LAUNCH")) lanes = std::min<size_t>((nb + 63) / 64 * 64, (size_t)std::max(64, atoi(e)) / 64 * 64);
     if (pool_take(c, c->out_pool, st.out, (size_t)st.total_out + 64) || pool_take(c, c->misc_pool, st.d_blocks, nb * sizeof(InfBlock)) ||
         pool_take(c, c->misc_pool, st.d_status, nb * 4 + 16) || pool_take(c, c->misc_pool, st.d_scratch, lanes * INF_SCRATCH_PER_LANE) ||
-        (!c->inflate_v1 && pool_take(c, c->out_pool, st.d_bitmap, nb * INF_BITMAP_WORDS * 8))) {
+        pool_take(c, c->out_pool, st.d_bitmap, nb * INF_BITMAP_WORDS * 8)) {
         std::lock_guard<std::mutex> lk(c->err_mu); // (a failure here just leaves the inflate to pjb_bam_end)
         c->err.clear();
         return;
@@ -2987,11 +2973,10 @@ static void inflate_early(pjb_ctx *c, BamStage &st) {
     if (!is) {
         // The inflate streams have the lowest priority: a launch holds every LDS byte of the chip for ~50 ms, and the short
         // kernels beside it -- record parsing, genome uploads, the junc chains of the targets before it -- are what the one
-        // host thread that serves all targets waits for (end to end 2.73 -> 2.44 s; PJB_INFLATE_NORMAL_PRIORITY=1: as before)
+        // host thread that serves all targets waits for (end to end 2.73 -> 2.44 s)
         int lo = 0, hi = 0; // (least, greatest priority)
         (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-        const bool low = getenv("PJB_INFLATE_NORMAL_PRIORITY") == nullptr;
-        if ((low ? hipStreamCreateWithPriority(&is, hipStreamNonBlocking, lo) : hipStreamCreateWithFlags(&is, hipStreamNonBlocking)) != hipSuccess) return;
+        if (hipStreamCreateWithPriority(&is, hipStreamNonBlocking, lo) != hipSuccess) return;
     }
     if (hipEventCreateWithFlags(&st.ev_last, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&st.ev_inf, hipEventDisableTiming) != hipSuccess) return;
     int *d_status = (int *)st.d_status.p;
@@ -3003,11 +2988,7 @@ static void inflate_early(pjb_ctx *c, BamStage &st) {
               hipMemsetAsync((uint8_t *)st.out.p + st.total_out, 0, 64, is) == hipSuccess &&
               hipMemcpyAsync(st.d_blocks.p, st.blocks.data(), nb * sizeof(InfBlock), hipMemcpyHostToDevice, is) == hipSuccess &&
               hipMemcpyAsync(d_any, st.ctl, 8, hipMemcpyHostToDevice, is) == hipSuccess;
-    if (ok && c->inflate_v1) {
-        hipLaunchKernelGGL(bgzf_inflate, dim3((unsigned)(lanes / 64)), dim3(64), I2_LDS_BYTES, is, (const uint8_t *)st.dev.p, (const InfBlock *)st.d_blocks.p,
-                           (iu32)nb, (uint8_t *)st.out.p, (uint8_t *)st.d_scratch.p, d_status, d_any, d_next, 8);
-        ok = hipGetLastError() == hipSuccess && hipEventRecord(st.ev_inf, is) == hipSuccess;
-    } else if (ok) {
+    if (ok) {
         ok = hipMemsetAsync(st.d_bitmap.p, 0, nb * INF_BITMAP_WORDS * 8, is) == hipSuccess;
         if (ok) {
             hipLaunchKernelGGL(bgzf_decode, dim3((unsigned)(lanes / 64)), dim3(64), I3_LDS_BYTES, is, (const uint8_t *)st.dev.p, (const InfBlock *)st.d_blocks.p,

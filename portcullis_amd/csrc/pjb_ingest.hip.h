@@ -255,402 +255,8 @@ struct Ring2 { // 16-word LDS ring + bit buffer
     int nb;
 };
 
-__global__ __launch_bounds__(64) void bgzf_inflate(const uint8_t *comp, const InfBlock *blocks, iu32 n_blocks, uint8_t *out,
-                                                     uint8_t *scratch, int *status, int *any_error, iu32 *next_block, int inf_refill) {
-    extern __shared__ __attribute__((aligned(16))) unsigned short inf_lds[];
-    // shared tables behind the per-lane areas
-    iu32 *s_len = (iu32 *)(inf_lds + (size_t)I2_LANE_U16 * 64); // base | extra bits << 16
-    iu32 *s_dist = s_len + 32;
-    if (threadIdx.x < 29) s_len[threadIdx.x] = (iu32)c_len_base[threadIdx.x] | ((iu32)c_len_extra[threadIdx.x] << 16);
-    if (threadIdx.x < 30) s_dist[threadIdx.x] = (iu32)c_dist_base[threadIdx.x] | ((iu32)c_dist_extra[threadIdx.x] << 16);
-    __syncthreads();
-    // A lane decodes one BGZF block at a time and takes the next one from a counter when it is done (*next_block starts
-    // at the number of lanes launched): a block is 40 ms of dependent work whatever runs beside it, so the launch is
-    // sized to what the chip holds at once and every lane stays busy until the list is empty, instead of one block per
-    // lane with the wave waiting for its slowest lane and the last round of a target a quarter full.
-    iu32 b = blockIdx.x * 64 + threadIdx.x;
-    bool have = b < n_blocks;
-    Lane2 L;
-    L.p = inf_lds + threadIdx.x * 2;
-    uint8_t *lens = scratch + (size_t)(blockIdx.x * 64 + threadIdx.x) * INF_SCRATCH_PER_LANE; // (scratch belongs to the lane, not the block)
-    InfBlock B;
-    B.in_off = B.out_off = 0;
-    B.in_len = B.out_len = 0;
-    if (have) B = blocks[b];
-    const uint8_t *in0 = comp + B.in_off, *in_end = in0 + B.in_len;
-    uint8_t *base = out + B.out_off;
-    iu32 out_len = B.out_len;
-    bool more = true; // the list may still hold blocks
-    enum { ST_HEADER, ST_SYMBOLS, ST_DONE };
-    int state = have ? ST_HEADER : ST_DONE;
-    int err = 0;
-    bool last = false;
-    iu64 bitpos = 0; // stream position (bits from in0) where the next header starts
-    iu32 pos = 0;    // bytes produced
-    iu32 qn = 0;     // queued matches
-    Ring2 R;
-    R.ri = R.rf = 0;
-    R.gp = in0;
-    R.bb = 0;
-    R.nb = 0;
-    Lim limL, limD; // code-length limits of the literal/length and the distance tree (registers)
-#pragma unroll
-    for (int k = 0; k < 16; k++) limL.v[k] = limD.v[k] = 0;
-
-    // all lanes: top up the input rings and resolve the queued matches
-    auto memory_phase = [&]() {
-        // A lane whose ring has run further than its block's payload plus what a ring can hold ahead is decoding bytes
-        // that are not its own (a stream without an end-of-block code in reach): stop it here, so that no lane ever
-        // reads more than 256 bytes past its payload -- the compressed buffer carries INF_PAD zero bytes behind its
-        // last block for exactly that.
-        if (state == ST_SYMBOLS && R.gp > in_end + 128) {
-            err = INF_ERR_OVERRUN;
-            state = ST_DONE;
-        }
-        // one round trip for the ring refill and for the first (up to) 16 bytes of every queued match whose source
-        // lies entirely before the first queued destination (nothing in the queue can have written it)
-        const iu32 pairs = state == ST_SYMBOLS ? (16 - R.rf) >> 1 : 0;
-        iu64 v[8];
-#pragma unroll
-        for (int k = 0; k < 8; k++) v[k] = load64u(R.gp + 8 * k); // unconditional: the buffer is padded
-        const iu32 g_first = qn ? (L.w(I2_Q) & 0xffffu) : 0u;
-        iu64 va[I2_QUEUE], vb[I2_QUEUE];
-        iu32 tk[I2_QUEUE];
-#pragma unroll
-        for (int q = 0; q < I2_QUEUE; q++) {
-            tk[q] = 0;
-            va[q] = vb[q] = 0;
-            if ((iu32)q < qn) {
-                const iu32 w0 = L.w(I2_Q + 4 * q), dist = L.w(I2_Q + 4 * q + 2);
-                const iu32 dst = w0 & 0xffffu, len = w0 >> 16;
-                const iu32 take = len < 16 ? len : 16;
-                if (dist >= 16 && dst - dist + ((take + 7) & ~7u) <= g_first) {
-                    va[q] = load64u(base + dst - dist);
-                    if (take > 8) vb[q] = load64u(base + dst - dist + 8);
-                    tk[q] = take;
-                }
-            }
-        }
-        wait_vm();
-        {
-            const iu32 wi = (R.ri + R.rf) & 15u;
-#pragma unroll
-            for (int k = 0; k < 8; k++)
-                if ((iu32)k < pairs) {
-                    L.w(I2_RING + 2 * ((wi + 2 * k) & 15u)) = (iu32)v[k];
-                    L.w(I2_RING + 2 * ((wi + 2 * k + 1) & 15u)) = (iu32)(v[k] >> 32);
-                }
-            R.rf += 2 * pairs;
-            R.gp += 8 * pairs;
-        }
-#pragma unroll
-        for (int q = 0; q < I2_QUEUE; q++) {
-            const iu32 n = tk[q];
-            if (n) {
-                const iu32 w0 = L.w(I2_Q + 4 * q);
-                const iu32 dst = w0 & 0xffffu, len = w0 >> 16;
-                store_low(base + dst, va[q], n);
-                if (n > 8) store_low(base + dst + 8, vb[q], n - 8);
-                L.w(I2_Q + 4 * q) = ((dst + n) & 0xffffu) | ((len - n) << 16); // what is left of it (usually nothing;
-                                                                                // a copy may end at byte 65536)
-            }
-        }
-        // The rest in order -- sources inside the queue, copies longer than 16 bytes, short periods -- one 8-byte
-        // step of every lane's first unfinished entry per round trip.
-        iu32 qi = 0;
-        for (;;) {
-            iu32 w0 = 0;
-            while (qi < qn) {
-                w0 = L.w(I2_Q + 4 * qi);
-                if (w0 >> 16) break;
-                qi++;
-            }
-            const bool on = qi < qn;
-            if (!__any(on)) break;
-            if (on) {
-                const iu32 dst = w0 & 0xffffu, len = w0 >> 16;
-                const iu32 dist = L.w(I2_Q + 4 * qi + 2);
-                iu64 x = load64u(base + dst - dist);
-                wait_vm();
-                if (dist <= 8) {
-                    // a period of at most 8 bytes (runs of one byte above all: the 0xff qualities of every read):
-                    // the whole copy comes out of registers, chunk k starting at phase 8k mod dist of the period
-                    const iu64 pmask = dist == 8 ? ~0ull : (1ull << (8 * dist)) - 1ull;
-                    const iu64 per = x & pmask;
-                    iu32 ph = 0;
-                    for (iu32 done = 0; done < len; done += 8) {
-                        iu64 y = ph ? ((per >> (8 * ph)) | (per << (8 * (dist - ph)))) & pmask : per; // rotated period
-                        for (iu32 sh = 8 * dist; sh < 64; sh <<= 1) y |= y << sh;
-                        store_low(base + dst + done, y, len - done);
-                        ph = (ph + 8) % dist;
-                    }
-                    L.w(I2_Q + 4 * qi) = (dst + len) & 0xffffu;
-                } else {
-                    const iu32 n = len < 8 ? len : 8;
-                    store_low(base + dst, x, n);
-                    L.w(I2_Q + 4 * qi) = ((dst + n) & 0xffffu) | ((len - n) << 16);
-                }
-            }
-        }
-        qn = 0;
-    };
-
-    for (;;) {
-        // ---- lanes that finished their block: results out, queue drained (its entries are relative to the old block),
-        // next block in
-        // (not one by one: a block header and its tables are a long stretch of code that a lane would run alone while 63
-        // wait -- lanes are refilled when INF_REFILL of them are idle, or nobody is busy)
-        if ((int)__popcll(__ballot(state == ST_DONE && more)) >= (__any(state != ST_DONE) ? inf_refill : 1)) {
-            memory_phase(); // (everybody: a phase is a round trip for the whole wave anyway)
-            const bool fin = state == ST_DONE && more;
-            if (fin && have) {
-                if (!err && pos != out_len) err = INF_ERR_SIZE;
-                status[b] = err;
-                if (err) atomicOr(any_error, 1);
-            }
-            const iu64 fm = __ballot(fin);
-            iu32 first_new = 0;
-            const int leader = __ffsll((long long)fm) - 1;
-            if ((int)threadIdx.x == leader) first_new = atomicAdd(next_block, (iu32)__popcll(fm));
-            first_new = __shfl(first_new, leader, 64);
-            if (fin) {
-                b = first_new + (iu32)__popcll(fm & ((1ull << threadIdx.x) - 1ull));
-                have = b < n_blocks;
-                more = have;
-                if (have) {
-                    B = blocks[b];
-                    in0 = comp + B.in_off;
-                    in_end = in0 + B.in_len;
-                    base = out + B.out_off;
-                    out_len = B.out_len;
-                    err = 0;
-                    last = false;
-                    bitpos = 0;
-                    pos = 0;
-                    R.ri = R.rf = 0;
-                    R.gp = in0;
-                    R.bb = 0;
-                    R.nb = 0;
-                    state = ST_HEADER;
-                }
-            }
-        }
-        if (!__any(state != ST_DONE)) break;
-        if (state == ST_HEADER) {
-            // ---- block header and tables, read straight from the stream
-            BitReader br;
-            br.start(in0 + (bitpos >> 3));
-            br.refill();
-            br.drop((int)(bitpos & 7));
-            iu64 used = bitpos & 7; // bits taken from in0 + (bitpos >> 3)
-            auto take = [&](int n) -> iu32 {
-                br.refill();
-                used += (iu64)n;
-                return br.take(n);
-            };
-            last = take(1);
-            const iu32 type = take(2);
-            if (type == 0) { // stored
-                const int pad = (int)((8 - ((bitpos + 3) & 7)) & 7);
-                (void)take(pad);
-                const iu32 len = take(16), nlen = take(16);
-                const uint8_t *src = in0 + ((bitpos + 3 + (iu64)pad + 32) >> 3);
-                if ((len ^ 0xffffu) != nlen) err = INF_ERR_STORED;
-                else if (src + len > in_end || pos + len > out_len) err = INF_ERR_OVERRUN;
-                else {
-                    for (iu32 i = 0; i < len; i++) base[pos + i] = src[i];
-                    pos += len;
-                    bitpos = (iu64)(src + len - in0) * 8;
-                }
-                if (err || last) state = ST_DONE; // else: next header
-            } else if (type == 3) {
-                err = INF_ERR_BTYPE;
-                state = ST_DONE;
-            } else {
-                int nlit = 288, ndist = 32;
-                if (type == 1) {
-                    for (int i = 0; i < 144; i++) lens[i] = 8;
-                    for (int i = 144; i < 256; i++) lens[i] = 9;
-                    for (int i = 256; i < 280; i++) lens[i] = 7;
-                    for (int i = 280; i < 288; i++) lens[i] = 8;
-                    for (int i = 288; i < 320; i++) lens[i] = 5;
-                } else {
-                    nlit = (int)take(5) + 257;
-                    ndist = (int)take(5) + 1;
-                    const int ncl = (int)take(4) + 4;
-                    if (nlit > 286 || ndist > 30) err = INF_ERR_CODELENS;
-                    if (!err) {
-                        for (int i = 0; i < 19; i++) lens[i] = 0;
-                        for (int i = 0; i < ncl; i++) lens[c_clen_order[i]] = (uint8_t)take(3);
-                        err = inf2_build(L, limL, I2_LADJ, I2_LLONG, 0, lens, 19, true); // (the code-length tree borrows the literal tree's places)
-                    }
-                    int i = 0;
-                    while (!err && i < nlit + ndist) {
-                        br.refill();
-                        const iu32 e = inf2_decode<false>(L, limL, I2_LADJ, I2_LLONG, 0, (iu32)br.bb);
-                        if (e == 0) {
-                            err = INF_ERR_CODELENS;
-                            break;
-                        }
-                        br.drop((int)(e & 15u));
-                        used += e & 15u;
-                        const iu32 sym = e >> 4;
-                        if (sym < 16) {
-                            lens[i++] = (uint8_t)sym;
-                        } else {
-                            iu32 rep, val = 0;
-                            if (sym == 16) {
-                                if (i == 0) {
-                                    err = INF_ERR_CODELENS;
-                                    break;
-                                }
-                                val = lens[i - 1];
-                                rep = 3 + take(2);
-                            } else if (sym == 17) {
-                                rep = 3 + take(3);
-                            } else {
-                                rep = 11 + take(7);
-                            }
-                            if (i + (int)rep > nlit + ndist) {
-                                err = INF_ERR_CODELENS;
-                                break;
-                            }
-                            while (rep--) lens[i++] = (uint8_t)val;
-                        }
-                    }
-                    if (!err && lens[256] == 0) err = INF_ERR_CODELENS;
-                }
-                if (!err) err = inf2_build(L, limD, I2_DADJ, I2_DLONG, 0, lens + nlit, ndist);
-                if (!err) err = inf2_build(L, limL, I2_LADJ, I2_LLONG, I2_LLONG_HI, lens, nlit);
-                if (err) {
-                    state = ST_DONE;
-                } else {
-                    // the symbols start at bitpos + used: prime the ring from there
-                    const iu64 sp = (bitpos & ~7ull) + used;
-                    R.gp = in0 + (sp >> 3);
-                    R.ri = 0;
-#pragma unroll
-                    for (int k = 0; k < 8; k++) {
-                        const iu64 v = load64u(R.gp + 8 * k);
-                        L.w(I2_RING + 4 * k) = (iu32)v;
-                        L.w(I2_RING + 4 * k + 2) = (iu32)(v >> 32);
-                    }
-                    R.gp += 64;
-                    R.rf = 16;
-                    R.bb = 0;
-                    R.nb = 0;
-                    // first word, minus the bits before sp inside its first byte
-                    R.bb = (iu64)L.w(I2_RING) | ((iu64)L.w(I2_RING + 2) << 32);
-                    R.ri = 2;
-                    R.rf = 14;
-                    R.nb = 64 - (int)(sp & 7);
-                    R.bb >>= (sp & 7);
-                    state = ST_SYMBOLS;
-                }
-            }
-        }
-        wait_vm(); // nothing of the header's direct reads is in flight when the decode loop starts
-        // ---- symbols
-        for (;;) {
-            const bool sym_on = state == ST_SYMBOLS;
-            if (!__any(sym_on)) break;
-            if (__any(sym_on && (R.rf < I2_LITS + 3 || qn == I2_QUEUE))) memory_phase(); // an iteration takes at most I2_LITS + 2 words
-            if (state != ST_SYMBOLS) continue; // (the memory phase may have stopped this lane)
-            // up to I2_LITS literals, then at most one end-of-block or length/distance pair: the literal step is short
-            // and most symbols are literals, the pair step is long and some lane needs it in every iteration anyway
-            iu32 e = 0, sym = 0;
-            bool bad = false;
-#pragma unroll
-            for (int rep = 0; rep < I2_LITS; rep++) {
-                if (sym >= 256 || bad) break;
-                if (R.nb <= 32) { // one more word from the ring (never empty here: the top of the iteration saw enough)
-                    R.bb |= (iu64)L.w(I2_RING + 2 * R.ri) << R.nb;
-                    R.ri = (R.ri + 1) & 15u;
-                    R.rf--;
-                    R.nb += 32;
-                }
-                e = inf2_decode<true>(L, limL, I2_LADJ, I2_LLONG, I2_LLONG_HI, (iu32)R.bb);
-                if (e == 0) {
-                    err = INF_ERR_CODE;
-                    bad = true;
-                    break;
-                }
-                R.bb >>= (e & 15u);
-                R.nb -= (int)(e & 15u);
-                sym = e >> 4;
-                if (sym < 256) {
-                    if (pos >= out_len) {
-                        err = INF_ERR_OVERRUN;
-                        bad = true;
-                        break;
-                    }
-                    base[pos++] = (uint8_t)sym;
-                }
-            }
-            if (bad) {
-                state = ST_DONE;
-                continue;
-            }
-            if (sym < 256) continue;
-            if (sym == 256) { // end of block: where the next header starts
-                const iu64 consumed = (iu64)(R.gp - in0) * 8 - 32ull * R.rf - (iu64)R.nb;
-                if (consumed > (iu64)B.in_len * 8) {
-                    err = INF_ERR_OVERRUN;
-                    state = ST_DONE;
-                    continue;
-                }
-                bitpos = consumed;
-                state = last ? ST_DONE : ST_HEADER;
-                continue;
-            }
-            sym -= 257;
-            if (sym >= 29) {
-                err = INF_ERR_CODE;
-                state = ST_DONE;
-                continue;
-            }
-            const iu32 lt = s_len[sym];
-            const int xl = (int)(lt >> 16);
-            const iu32 len = (lt & 0xffffu) + ((iu32)R.bb & ((1u << xl) - 1u));
-            R.bb >>= xl;
-            R.nb -= xl;
-            if (R.nb <= 32) {
-                R.bb |= (iu64)L.w(I2_RING + 2 * R.ri) << R.nb;
-                R.ri = (R.ri + 1) & 15u;
-                R.rf--;
-                R.nb += 32;
-            }
-            e = inf2_decode<false>(L, limD, I2_DADJ, I2_DLONG, 0, (iu32)R.bb);
-            if (e == 0 || (e >> 4) >= 30) {
-                err = INF_ERR_CODE;
-                state = ST_DONE;
-                continue;
-            }
-            R.bb >>= (e & 15u);
-            R.nb -= (int)(e & 15u);
-            const iu32 ds = e >> 4;
-            const iu32 dt = s_dist[ds];
-            const int xd = (int)(dt >> 16);
-            const iu32 dist = (dt & 0xffffu) + ((iu32)R.bb & ((1u << xd) - 1u));
-            R.bb >>= xd;
-            R.nb -= xd;
-            if (dist > pos) {
-                err = INF_ERR_DIST;
-                state = ST_DONE;
-                continue;
-            }
-            if (pos + len > out_len) {
-                err = INF_ERR_OVERRUN;
-                state = ST_DONE;
-                continue;
-            }
-            L.w(I2_Q + 4 * qn) = pos | (len << 16);
-            L.w(I2_Q + 4 * qn + 2) = dist;
-            qn++;
-            pos += len;
-        }
-    }
-}
+// (the one-kernel bgzf_inflate of round 2 -- decode and copies in one lane-per-block kernel, 52 GB/s -- lived here until round 4;
+// what follows replaced it.  The LDS layout above and the table builders are shared.)
 
 // =================================================================================================
 // Round 3: the inflate in two kernels.

@@ -192,7 +192,7 @@ void BamFilter::filter() {
     };
     if (!hostDeflate) {
         writer.setBlockCompressor(deviceDeflate);
-        writer.setAsyncFlush(getenv("PORTCULLIS_SYNC_WRITER") == nullptr);
+        writer.setAsyncFlush(true);
         if (const char* e = getenv("PORTCULLIS_FLUSH_BLOCKS")) writer.setFlushBlocks((size_t)std::max(1, atoi(e)));  // (tests: many hand-overs in a small file)
         if (!getenv("PORTCULLIS_PAGEABLE_BUFFERS")) {  // (page-locked: the device reads and writes the reader's and the writers' buffers by DMA)
             bam::BufferHooks hooks;

@@ -409,7 +409,7 @@ private:
     std::mutex mu;
     std::condition_variable cv;
     std::deque<Cmd> q;
-    size_t cap = getenv("PORTCULLIS_CMD_CAP") ? (size_t)std::max(1, atoi(getenv("PORTCULLIS_CMD_CAP"))) : 6;  // (commands waiting for the device thread; workers block when it is full)
+    size_t cap = 6;  // (commands waiting for the device thread; workers block when it is full)
     std::map<int32_t, std::string> failed;  // contig -> first error
     std::string fatal;                      // context creation failed
 
@@ -440,7 +440,6 @@ private:
         // table (rows arrive in queue order; rowsSoFar marks where the next target's begin).  --extra queues the same
         // way (a target's extra metrics are queued when its chain is collected).
         size_t kQueued = 3;  // (the library creates the streams of four control slots up front; deeper ones on a busy device cost seconds)
-        if (const char* e = getenv("PJB_HOST_QUEUE")) kQueued = (size_t)std::max(1, std::min(atoi(e), (int)PJB_MAX_QUEUED));
         struct Pending {
             int32_t tid;
             std::promise<ContigDone>* done; // (the worker thread that owns it waits on its future)
@@ -518,8 +517,7 @@ private:
             // the inflates of the next targets can take 100 ms and more (their resident workgroups hold the CUs' LDS), and a
             // thread that sat in pjb_finish_contig_end for that long held up every other target's commands -- and, through the
             // bounded command queue, the workers that read the file (the input stood still whenever this thread waited)
-            static const bool pollCollect = getenv("PORTCULLIS_BLOCKING_COLLECT") == nullptr;
-            while (pollCollect && !pending.empty() && ctx && pjb_finish_ready(ctx)) {
+            while (!pending.empty() && ctx && pjb_finish_ready(ctx)) {
                 const double t0 = HostProfile::now();
                 const int ptid = pending.front().tid;
                 collectOldest();
@@ -528,15 +526,6 @@ private:
             }
             if (!have) {
                 std::unique_lock<std::mutex> lk(mu);
-                if (!pollCollect && q.empty() && !pending.empty() && deferred.empty()) { // (round 2: collect the oldest queued one, waiting for it)
-                    lk.unlock();
-                    const double t0 = HostProfile::now();
-                    const int ptid = pending.front().tid;
-                    collectOldest();
-                    tCollect += HostProfile::now() - t0;
-                    g_prof.event(t0, HostProfile::now(), "dev" + std::to_string(profId) + " collect tid " + std::to_string(ptid));
-                    continue;
-                }
                 const double t0 = HostProfile::now();
                 bool again = false;
                 while (q.empty()) {
@@ -545,7 +534,7 @@ private:
                         cv.wait_for(lk, std::chrono::microseconds(200), [&] { return !q.empty(); });
                         lk.unlock();
                         releaseDone(false);
-                        const bool ready = readyDeferred() >= 0 || (pollCollect && !pending.empty() && ctx && pjb_finish_ready(ctx));
+                        const bool ready = readyDeferred() >= 0 || (!pending.empty() && ctx && pjb_finish_ready(ctx));
                         lk.lock();
                         if (ready && q.empty()) {
                             again = true;
@@ -746,7 +735,7 @@ void JunctionBuilder::findJuncs(DeviceThread& device, BamReader& reader, GenomeM
             piecesGone.set_value();
         }
     };
-    const bool genomeLate = deviceIngest && pinnedPool && !getenv("PORTCULLIS_GENOME_EARLY");
+    const bool genomeLate = deviceIngest && pinnedPool;
     std::thread decoder([&] {
         struct Raise {
             std::function<void()> f;
@@ -920,16 +909,9 @@ void JunctionBuilder::findJuncs(DeviceThread& device, BamReader& reader, GenomeM
                     c.tid = seq;
                     c.bamFirst = firstU;
                     c.bamDone = &got;
-                    const bool leaveFirst = getenv("PORTCULLIS_LEAVE_BEFORE_PUSH") != nullptr;  // (experiment; see below)
-                    if (leaveFirst) {
-                        leave.now();
-                        raisePiecesGone();
-                    }
                     device.push(std::move(c));
-                    if (!leaveFirst) {
-                        leave.now();  // the next target's pieces cross while this one is inflated and parsed
-                        raisePiecesGone();
-                    }
+                    leave.now();  // the next target's pieces cross while this one is inflated and parsed
+                    raisePiecesGone();
                     // (Releasing the slot before the push, a command queue of 32 and one worker per target -- each harmless
                     // alone -- together let the file run at 33-42 GB/s for half a second and then stand still for one or two:
                     // runs of 2.1 or 4 s, profiles/r03v_e2e_scheduling_ab.txt.  More in flight is not more throughput here.)
@@ -1107,7 +1089,7 @@ void JunctionBuilder::findJunctions() {
     // ... except that a smaller one goes first: the device has nothing to do until a target's last byte has crossed, and the
     // largest target takes longest to cross (first inflate 0.23 s after the contexts were ready; the smallest ones still end
     // the run: a short tail)
-    if (order.size() >= 5 && !getenv("PORTCULLIS_LARGEST_FIRST")) {
+    if (order.size() >= 5) {
         const size_t k = order.size() * 4 / 5;
         const int32_t small = order[k];
         order.erase(order.begin() + (long)k);
@@ -1124,7 +1106,7 @@ void JunctionBuilder::findJunctions() {
     // keep the pageable path whose staging copy is cheaper than that)
     pinnedPool.reset();
     genomePool.reset();
-    directPieces = !(getenv("PORTCULLIS_DIRECT_PIECES") && atoi(getenv("PORTCULLIS_DIRECT_PIECES")) == 0);
+    directPieces = true;
     int transferSlots = 0;
     if (deviceIngest) {
         struct stat bst;
@@ -1140,7 +1122,7 @@ void JunctionBuilder::findJunctions() {
         }
         if (stat(prepData.getSortedBamFilePath().c_str(), &bst) == 0 && (uint64_t)bst.st_size >= minFile) {
             pinnedPool.reset(new PinnedPool(nbuf, pieceBytes));
-            if (!getenv("PORTCULLIS_GENOME_PARSE")) genomePool.reset(new PinnedPool(3));  // (PORTCULLIS_GENOME_PARSE=1: the host filters the FASTA characters as before)
+            genomePool.reset(new PinnedPool(3));  // (the FASTA records' bytes go up as they are: pjb_upload_contig_fasta)
             // Targets whose pieces are on their way at once, over all contexts (PORTCULLIS_TRANSFER_SLOTS; 0: no limit), each read by
             // PORTCULLIS_READ_THREADS threads.  FEW readers: four threads pread 31.6 GB/s out of the page cache into page-locked
             // buffers, eight 25.0, fifteen 24.8 (profiles/r03ap_register_probe.txt), and the run with 2 x 2 readers takes 2.03 s
@@ -1217,7 +1199,7 @@ void JunctionBuilder::findJunctions() {
     // (PORTCULLIS_WORKER_PER_TARGET=1, an experiment: a worker belongs to its target until the target's rows are back and
     // mostly waits; one worker per target keeps the file moving while every other worker waits for the device.  Not the
     // default: see the note at the transfer gate.)
-    const int nworkers = pinnedPool && getenv("PORTCULLIS_WORKER_PER_TARGET") ? std::max(nthreads, std::min(withReads, 64)) : nthreads;
+    const int nworkers = nthreads;
     for (int w = 0; w < nworkers; w++) pool.emplace_back(worker, w);
     for (auto& t : pool) t.join();
     if (extra && firstError.empty() && !deviceThreads.empty()) {
@@ -1249,7 +1231,7 @@ void JunctionBuilder::findJunctions() {
     // rings with them, is 0.1-0.3 s of runtime and driver work that nothing waits for: it runs beside the merge and the
     // writers instead of before them (PORTCULLIS_SYNC_TEARDOWN=1: as before).
     // (a process that will leave through exit handlers must not have a thread inside the runtime by then)
-    if (!backgroundTeardown || getenv("PORTCULLIS_SYNC_TEARDOWN") || getenv("PJB_NORMAL_EXIT") || !firstError.empty()) {
+    if (!backgroundTeardown || getenv("PJB_NORMAL_EXIT") || !firstError.empty()) {
         deviceThreads.clear();  // joins the device threads (destroys the contexts)
     } else {
         auto dts = std::make_shared<std::vector<std::unique_ptr<DeviceThread>>>(std::move(deviceThreads));

@@ -172,13 +172,13 @@ def test_dense_ids_many_acceptors(ffi, orc, n_acc):
     assert (passes <= 2) == (n_acc <= 8), passes  # ids: 12 bits; keys: 15 + 18 bits
 
 
-def test_dense_ids_off(ffi, orc, monkeypatch):
-    """PJB_DENSE_IDS=0: the round-1 sort of the full intron keys."""
-    monkeypatch.setenv("PJB_DENSE_IDS", "0")
+def test_dense_ids_off(ffi, orc):
+    """pjb_set_option("dense_ids", 0): the round-1 sort of the full intron keys."""
     genome, reads = make_reads(5, n_reads=2500, paired=True)
     batch = to_batch(reads)
     orows, oreg = orc.find_juncs(0, len(genome), genome, batch, "FR")
     with ffi.Context(0, "FR") as ctx:
+        ctx.set_option("dense_ids", 0)
         ctx.set_refs([len(genome)])
         drows, dreg = ffi.run_contig(ctx, 0, genome.encode(), [batch])
         assert ctx.timing()["sort_passes"] >= 3
