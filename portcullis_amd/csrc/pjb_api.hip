@@ -1588,7 +1588,11 @@ static int queue_contig(pjb_ctx *c, Flight &f) {
             const int32_t own_tid = f.tids[(size_t)m], own_len = c->ref_len[(size_t)own_tid];
             const u32 nt = (u32)((b.n + K1_TILE - 1) / K1_TILE);
             // (a tile holds ~300 spliced reads = 1.2 chunks of 256: a grid of half the tiles keeps two or three chunks per block)
-            const u32 grid = std::max<u32>(1, std::min<u32>(nt, std::max<u32>(1024, nt / 2)));
+#ifndef K1E_GRID_MODE
+#define K1E_GRID_MODE 0
+#endif
+            const u32 grid = K1E_GRID_MODE == 1 ? std::max<u32>(1, nt) : K1E_GRID_MODE == 2 ? std::max<u32>(1, std::min<u32>(nt, 1536u)) : K1E_GRID_MODE == 3 ? std::max<u32>(1, std::min<u32>(nt, 3072u))
+                                                : std::max<u32>(1, std::min<u32>(nt, std::max<u32>(1024, nt / 2)));
             LAUNCH(c, "k1_emit", k1_emit, dim3(grid), dim3(256), b, nt, n_tiles, (const u32 *)S.tile_cnt.p, (const u32 *)S.tile_soff.p,
                    (const u32 *)S.chunk_tile.p, (const u32 *)S.splidx.p, (const u32 *)S.splpoff.p, pr, el, kf, own_len,
                    own_tid, (int)c->cfg.orientation, d_err, d_cs, f.voff[(size_t)m], fast_codes ? (const u32 *)GT.codes[m] : (const u32 *)nullptr);
