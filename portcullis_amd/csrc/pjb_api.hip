@@ -152,7 +152,7 @@ struct CtlSlot {
     // the rest of the chain's scratch, and its streams: the chains of the two slots run side by side (most kernels of a
     // contig-sized chain are latency-bound and leave the chip half idle)
     Buf total, bitmap, wrank, ends, firstid, key[2], idx[2], hist, hist_scan, hist_part, bintotal, scan_tiles;
-    Buf jid, seg, runfirst, runstart, ent, entsum, frag, fragj, acc, ancl, ancr, jkey, genlist;
+    Buf jid, seg, runfirst, runstart, ent, entsum, frag, fragj, acc, ancl, ancr, jkey, genlist, masks;
     bool dense_at_rest = false;
     hipStream_t main = nullptr, side = nullptr; // chain; match statistics / entropy beside it
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_fork2 = nullptr, ev_join2 = nullptr;
@@ -192,6 +192,7 @@ struct Flight {
     int attempt = 0;
     int n_pass = 0;
     const u32 *sidx = nullptr;
+    const u32 *jid_sorted = nullptr; // junction id of every sorted pair
     Pairs pr;
     // --extra: what the part that only needs the records (extra_pre) left for the part that needs the rows (extra_contig)
     bool x_pre = false;
@@ -683,7 +684,8 @@ int pjb_create(pjb_ctx **out, const pjb_config *cfg) {
         (void)hipSetDevice(dev);
         (void)hipFuncSetAttribute((const void *)bgzf_decode, hipFuncAttributeMaxDynamicSharedMemorySize, I3_LDS_BYTES);
         // 12-bit digits need more dynamic LDS than the 64 KB a kernel gets without asking
-        (void)hipFuncSetAttribute((const void *)rs_scatter<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rs_scatter_lds_bytes(RS_MAX_BITS));
+        (void)hipFuncSetAttribute((const void *)rs_scatter<0, u64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rs_scatter_lds_bytes(RS_MAX_BITS));
+        (void)hipFuncSetAttribute((const void *)rs_scatter<0, u32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rs_scatter_lds_bytes(RS_MAX_BITS, 4));
     };
     std::thread attr_thread(attributes);
     struct JoinAttr {
@@ -756,7 +758,7 @@ void pjb_destroy(pjb_ctx *c) {
         Buf *sb[] = {&S.x_q, &S.x_spos, &S.x_send, &S.x_gapoff, &S.x_zlist, &S.x_scnt, &S.x_codes, &S.cstats, &S.err, &S.gencount, &S.batches, &S.rows, &S.tile_cnt, &S.tile_stats, &S.splidx, &S.splpoff, &S.tile_soff, &S.chunk_tile, &S.scan_parts, &S.members, &S.okey, &S.g,
                      &S.rec, &S.jidbam, &S.jkey, &S.total, &S.bitmap, &S.wrank, &S.ends, &S.firstid,
                      &S.key[0], &S.key[1], &S.idx[0], &S.idx[1], &S.hist, &S.hist_scan, &S.hist_part, &S.bintotal, &S.scan_tiles, &S.jid, &S.seg, &S.runfirst,
-                     &S.runstart, &S.ent, &S.entsum, &S.frag, &S.fragj, &S.acc, &S.ancl, &S.ancr, &S.genlist};
+                     &S.runstart, &S.ent, &S.entsum, &S.frag, &S.fragj, &S.masks, &S.acc, &S.ancl, &S.ancr, &S.genlist};
         for (Buf *b : sb) release(*b);
         hipEvent_t evs[] = {S.ev_k1, S.ev_xk1, S.ev_fork, S.ev_join, S.ev_fork2, S.ev_join2};
         for (hipEvent_t e : evs)
@@ -1299,7 +1301,7 @@ static int extra_contig(pjb_ctx *c, Flight &f, int32_t tid, u64 n_spliced, u32 P
         HIP_TRY(c, hipMemsetAsync(X.xr, 0, (size_t)J * sizeof(ExtraRow), st));
         LAUNCH(c, "kx_flank_sparse", kx_flank_sparse, dim3((J + 255) / 256), dim3(256), (const pjb_junction_row *)S.rows.p, J,
                (const int32_t *)f.x_spos, (const int32_t *)f.x_send, L, (const u32 *)S.x_zlist.p, (const SparseCounters *)d_cnt, X_ZCAP, X.xr);
-        LAUNCH(c, "kx_pair_codes", kx_pair_codes, dim3((P + 255) / 256), dim3(256), f.sidx, (const u32 *)S.jid.p, f.pr.g, (const DevBatch *)S.batches.p,
+        LAUNCH(c, "kx_pair_codes", kx_pair_codes, dim3((P + 255) / 256), dim3(256), f.sidx, f.jid_sorted, f.pr.g, (const DevBatch *)S.batches.p,
                (int)batches.size(), P, (u32)row_base, X.pair_code, X.pair_row);
     }
     // one wait: the counters decide whether the sparse answer stands
@@ -1440,7 +1442,7 @@ static int queue_contig(pjb_ctx *c, Flight &f) {
     if ((rc = ensure(c, S.idx[1], cand_room * 4))) return rc;
     if ((rc = ensure(c, S.rec, ((size_t)PL + 1) * sizeof(PairRec)))) return rc;
     if ((rc = ensure(c, S.jid, (size_t)PL * 4 + 16))) return rc;
-    if ((rc = ensure(c, S.jidbam, (size_t)PL * 4 + 16))) return rc;
+    if ((rc = ensure(c, S.jidbam, ((size_t)PL + RS_TILE) * 4))) return rc; // (the sort's first pass loads whole tiles)
     if (c->extra && (rc = ensure(c, S.g, (size_t)PL * 4 + 16))) return rc;
     if ((rc = ensure(c, S.seg, ((size_t)PL + 1) * 4))) return rc;
     if ((rc = ensure(c, S.runfirst, ((size_t)PL + 1) * 4))) return rc;
@@ -1650,7 +1652,7 @@ static int queue_contig(pjb_ctx *c, Flight &f) {
         LAUNCH(c, "kd_table", kd_table, dim3(KD_GRID), dim3(256), (const u64 *)cand, (const u64 *)S.ent.p, (const u32 *)cand_rank, kf, JL,
                (const u32 *)S.ends.p, (const u32 *)S.firstid.p, (const u64 *)S.total.p, (u64 *)S.jkey.p, (int32_t *)S.ancl.p, (int32_t *)S.ancr.p, d_cs);
         LAUNCH(c, "kd_assign", kd_assign, dim3(pair_blocks), dim3(256), okey, d_P, kf, (const u64 *)S.bitmap.p, (const u32 *)S.wrank.p,
-               (const u32 *)S.ends.p, (const u32 *)S.firstid.p, JL, (const u64 *)S.total.p, (u64 *)S.key[0].p, (u32 *)S.jidbam.p, (u32 *)S.acc.p);
+               (const u32 *)S.ends.p, (const u32 *)S.firstid.p, JL, (const u64 *)S.total.p, (u32 *)S.jidbam.p, (u32 *)S.acc.p);
         if ((rc = fork_k4b())) return rc;
         LAUNCH(c, "kd_reset", kd_reset, dim3(KD_GRID), dim3(256), (const u64 *)cand, (const u32 *)cand_rank, kf, JL, (const ContigStats *)d_cs,
                (u64 *)S.bitmap.p, (u32 *)S.ends.p);
@@ -1669,22 +1671,21 @@ static int queue_contig(pjb_ctx *c, Flight &f) {
     if ((rc = ensure(c, S.bintotal, (size_t)4 << dbits))) return rc;
     if ((rc = ensure(c, S.hist_part, (size_t)((rs_tiles + RSP_TILES - 1) / RSP_TILES) * (1u << dbits) * 4))) return rc;
     int cur = 0, shift = 0;
-    for (int p = 0; p < n_pass; p++) {
-        const int bits = pass_bits[(size_t)p];
-        if (bits <= 0) break;
-        const u64 *kin = p == 0 && !lim.dense ? (const u64 *)S.okey.p : (const u64 *)S.key[cur].p; // (dense ids were written to b_key[0])
-        u64 *kout = (u64 *)S.key[cur ^ 1].p;
-        const u32 *vin = p == 0 ? nullptr : (const u32 *)S.idx[cur].p;
-        u32 *vout = (u32 *)S.idx[cur ^ 1].p;
-        LAUNCH(c, "rs_hist", rs_hist, dim3(rs_tiles), dim3(256), kin, d_P, shift, bits, (u32 *)S.hist.p, rs_tiles);
+    // digit passes.  Dense ids are 32-bit keys: pass 0 reads them where kd_assign left them (BAM order; k4b_generic reads that array
+    // beside the sort, so no pass writes to it), the ping-pong buffers are the first halves of the 64-bit key buffers.
+    auto sort_pass = [&](auto key_tag, const void *kin_v, void *kout_v, const u32 *vin, u32 *vout, int bits) -> int {
+        using K = decltype(key_tag);
+        const K *kin = (const K *)kin_v;
+        K *kout = (K *)kout_v;
+        LAUNCH(c, "rs_hist", rs_hist<K>, dim3(rs_tiles), dim3(256), kin, d_P, shift, bits, (u32 *)S.hist.p, rs_tiles);
         {
             const u32 nb = 1u << bits, n_panels = (rs_tiles + RSP_TILES - 1) / RSP_TILES;
             LAUNCH(c, "rs_panel_sums", rs_panel_sums, dim3(n_panels, (nb + 255) / 256), dim3(256), (const u32 *)S.hist.p, rs_tiles, nb, (u32 *)S.hist_part.p);
             LAUNCH(c, "rs_panel_scan", rs_panel_scan, dim3(n_panels, (nb + 255) / 256), dim3(256), (const u32 *)S.hist.p, (const u32 *)S.hist_part.p, rs_tiles, nb,
                    (u32 *)S.hist_scan.p, (u32 *)S.bintotal.p);
         }
-#define RS_SCATTER(B)                                                                                                     \
-    LAUNCH_LDS(c, "rs_scatter", rs_scatter<B>, dim3(rs_tiles), dim3(256), rs_scatter_lds_bytes(bits), kin, vin, kout, vout, d_P, \
+#define RS_SCATTER(B)                                                                                                                          \
+    LAUNCH_LDS(c, "rs_scatter", (rs_scatter<B, K>), dim3(rs_tiles), dim3(256), rs_scatter_lds_bytes(bits, sizeof(K)), kin, vin, kout, vout, d_P, \
                shift, bits, (const u32 *)S.hist_scan.p, (const u32 *)S.bintotal.p, rs_tiles)
         switch (bits) { // the usual digit widths get an unrolled match loop
         case 9: RS_SCATTER(9); break;
@@ -1693,65 +1694,87 @@ static int queue_contig(pjb_ctx *c, Flight &f) {
         default: RS_SCATTER(0); break;
         }
 #undef RS_SCATTER
+        return PJB_OK;
+    };
+    for (int p = 0; p < n_pass; p++) {
+        const int bits = pass_bits[(size_t)p];
+        if (bits <= 0) break;
+        const u32 *vin = p == 0 ? nullptr : (const u32 *)S.idx[cur].p;
+        u32 *vout = (u32 *)S.idx[cur ^ 1].p;
+        if (lim.dense) rc = sort_pass((u32)0, p == 0 ? S.jidbam.p : S.key[cur].p, S.key[cur ^ 1].p, vin, vout, bits);
+        else rc = sort_pass((u64)0, p == 0 ? S.okey.p : S.key[cur].p, S.key[cur ^ 1].p, vin, vout, bits);
+        if (rc) return rc;
         cur ^= 1;
         shift += bits;
     }
     f.n_pass = n_pass;
-    const u64 *skey = (const u64 *)S.key[cur].p;
     const u32 *sidx = (const u32 *)S.idx[cur].p;
     f.sidx = sidx;
+    const u32 *jid_sorted = lim.dense ? (const u32 *)S.key[cur].p : (const u32 *)S.jid.p; // junction id of every sorted pair
+    f.jid_sorted = jid_sorted;
     STAGE_EVENT(2);
-
-    // ---- K2s: junction ids, position runs
-    {
+    if ((rc = ensure(c, S.entsum, (size_t)JL * 8 + 16))) return rc;
+    const u32 n_slices_lim = (PL + 63) / 64 + 1;
+    const hipStream_t tl = st;
+    auto entropy_kernels = [&]() -> int {
+        LAUNCH(c, "k5_entropy_terms", k5_entropy_terms, dim3(pair_blocks), dim3(256), jid_sorted, (const u32 *)S.seg.p, (const u32 *)S.runfirst.p,
+               (const u32 *)S.runstart.p, d_R, (double *)S.ent.p);
+        LAUNCH(c, "k5_entropy_sum", k5_entropy_sum, dim3(std::max<u32>(1, (JL + 3) / 4)), dim3(256), (const u32 *)S.runfirst.p,
+               (const double *)S.ent.p, d_J, (double *)S.entsum.p);
+        return PJB_OK;
+    };
+    bool entropy_forked = false;
+    auto fork_entropy = [&]() -> int { // the entropy kernels beside what follows on the main stream (small and latency-bound, both)
+        if (!c->side_stream) return entropy_kernels();
+        HIP_TRY(c, hipEventRecord(S.ev_fork2, st));
+        HIP_TRY(c, hipStreamWaitEvent(S.side, S.ev_fork2, 0));
+        c->stream = S.side;
+        entropy_forked = true;
+        const int rc2 = entropy_kernels();
+        c->stream = st;
+        if (rc2) return rc2;
+        HIP_TRY(c, hipEventRecord(S.ev_join2, S.side));
+        return PJB_OK;
+    };
+    if (lim.dense) {
+        // ---- the usual chain: the sorted ids are the junction ids; K4 gathers the pairs -- one 32-byte record each -- folds them
+        // to fragments and leaves the junction / run boundaries as bit masks; two small kernels turn the masks into
+        // seg_off / run_first / run_start (no second pass over the pairs), then the entropy beside the fragment reduce
+        if ((rc = ensure(c, S.masks, (size_t)n_slices_lim * 8 * 2 + (size_t)n_slices_lim * 4))) return rc;
+        u64 *head_mask = (u64 *)S.masks.p, *run_mask = head_mask + n_slices_lim;
+        u32 *run_base = (u32 *)(run_mask + n_slices_lim);
+        STAGE_EVENT(3);
+        STAGE_EVENT(4);
+        if (f.forked) HIP_TRY(c, hipStreamWaitEvent(tl, S.ev_join, 0)); // k4b_generic's results (side stream) are needed from here on
+        LAUNCH(c, "k4_pairs", k4_pairs, dim3(pair_blocks), dim3(256), sidx, jid_sorted, (const PairRec *)pr.rec, (const u64 *)S.jkey.p, kf, d_P,
+               (u32 *)S.frag.p, (int32_t *)S.fragj.p, head_mask, run_mask);
+        if ((rc = run_scan(c, "k2_runs", Popc64Fn{(const u64 *)run_mask}, ExclusiveU32Sink{run_base}, (u64)n_slices_lim, (u64 *)S.total.p, &d_cs->n_slices)))
+            return rc;
+        LAUNCH(c, "k2_expand", k2_expand, dim3(pair_blocks), dim3(256), jid_sorted, (const u64 *)head_mask, (const u64 *)run_mask, (const u32 *)run_base,
+               (const u64 *)S.total.p, (u32 *)S.seg.p, (u32 *)S.runfirst.p, (u32 *)S.runstart.p, d_cs);
+        STAGE_EVENT(5);
+        if ((rc = fork_entropy())) return rc;
+    } else {
+        // ---- a chain that sorted the full keys: junction ids and position runs from a scan over the sorted pairs (it fetches
+        // every pair's read position), the junctions' keys, anchors, ids in BAM order -- then the generic pairs and K4
+        const u64 *skey = (const u64 *)S.key[cur].p;
         HeadFn hf{skey, sidx, (const PairRec *)pr.rec};
-        HeadSink hs{(u32 *)S.jid.p, (u32 *)S.seg.p, (u32 *)S.runfirst.p, (u32 *)S.runstart.p, skey, lim.dense ? (u64 *)nullptr : (u64 *)S.jkey.p};
+        HeadSink hs{(u32 *)S.jid.p, (u32 *)S.seg.p, (u32 *)S.runfirst.p, (u32 *)S.runstart.p, skey, (u64 *)S.jkey.p};
         if ((rc = run_scan(c, "k2_heads", hf, hs, (u64)PL, (u64 *)S.total.p, d_P))) return rc;
         LAUNCH(c, "k2_close", k2_close, dim3(1), dim3(1), (u64 *)S.total.p, (u32 *)S.seg.p, (u32 *)S.runfirst.p,
                (u32 *)S.runstart.p, d_cs, JL);
-    }
-    STAGE_EVENT(3);
-
-    // ---- entropy terms and sums need the position runs only: on the side stream, beside the anchors and the generic
-    // pairs (a chain of small and latency-bound kernels that leaves most of the chip idle)
-    if ((rc = ensure(c, S.entsum, (size_t)JL * 8 + 16))) return rc;
-    bool entropy_forked = false;
-    {
-        hipStream_t main_stream = c->stream;
-        struct StreamScope {
-            pjb_ctx *c;
-            hipStream_t main;
-            ~StreamScope() { c->stream = main; }
-        } scope{c, main_stream};
-        if (c->side_stream) {
-            HIP_TRY(c, hipEventRecord(S.ev_fork2, st));
-            HIP_TRY(c, hipStreamWaitEvent(S.side, S.ev_fork2, 0));
-            c->stream = S.side;
-            entropy_forked = true;
-        }
-        LAUNCH(c, "k5_entropy_terms", k5_entropy_terms, dim3(pair_blocks), dim3(256), (const u32 *)S.jid.p,
-               (const u32 *)S.seg.p, (const u32 *)S.runfirst.p, (const u32 *)S.runstart.p, d_R, (double *)S.ent.p);
-        LAUNCH(c, "k5_entropy_sum", k5_entropy_sum, dim3(std::max<u32>(1, (JL + 3) / 4)), dim3(256), (const u32 *)S.runfirst.p,
-               (const double *)S.ent.p, d_J, (double *)S.entsum.p);
-        if (entropy_forked) HIP_TRY(c, hipEventRecord(S.ev_join2, S.side));
-    }
-    // ---- a chain that sorted the full keys has its junction ids only now: anchors, ids in BAM order, then the generic pairs
-    if (!lim.dense) {
+        STAGE_EVENT(3);
+        if ((rc = fork_entropy())) return rc;
         LAUNCH(c, "kf_init", kf_init, dim3(std::max<u32>(1, std::min<u32>((JL * F_WORDS + 255) / 256, 4096))), dim3(256), (u32 *)S.acc.p, d_J, (int32_t *)S.ancl.p,
                (int32_t *)S.ancr.p);
         LAUNCH(c, "kf_anchors", kf_anchors, dim3(pair_blocks), dim3(256), sidx, (const u32 *)S.jid.p, (const PairRec *)pr.rec, d_P, (u32 *)S.jidbam.p,
                (int32_t *)S.ancl.p, (int32_t *)S.ancr.p);
         if ((rc = launch_k4b())) return rc;
+        STAGE_EVENT(4);
+        LAUNCH(c, "k4_pairs", k4_pairs, dim3(pair_blocks), dim3(256), sidx, jid_sorted, (const PairRec *)pr.rec, (const u64 *)S.jkey.p, kf, d_P,
+               (u32 *)S.frag.p, (int32_t *)S.fragj.p, (u64 *)nullptr, (u64 *)nullptr);
+        STAGE_EVENT(5);
     }
-    STAGE_EVENT(4);
-
-    const hipStream_t tl = st; // (the chain's last kernels on a stream of lowest priority, so that the next chain's first ones go
-                               // ahead of them: 12.9 -> 14.5 ms per step, profiles/r03am_tail_priority.txt; not kept)
-    if (f.forked) HIP_TRY(c, hipStreamWaitEvent(tl, S.ev_join, 0)); // k4b_generic's results (side stream) are needed from here on
-    // ---- K4: gather + segmented reduce -> fragments
-    LAUNCH(c, "k4_pairs", k4_pairs, dim3(pair_blocks), dim3(256), sidx, (const u32 *)S.jid.p, (const PairRec *)pr.rec, (const u64 *)S.jkey.p, kf, d_P,
-           (u32 *)S.frag.p, (int32_t *)S.fragj.p);
-    STAGE_EVENT(5);
 
     // ---- K5: fragments -> junctions -> rows
     LAUNCH(c, "k5_frag_reduce", k5_frag_reduce, dim3((slots_lim + 4 * FRAG_SLOTS_PER_WAVE - 1) / (4 * FRAG_SLOTS_PER_WAVE)), dim3(256),

@@ -79,6 +79,8 @@ struct ContigStats {
     u32 n_slots;   // J + ceil(P / 64) fragment slots
     u32 overflow;  // OVF_*
     u32 n_cand;    // K2d: keys in the candidate list (every junction at least once, few of them more often)
+    u32 n_slices;  // ceil(P / 64): 64-pair slices of the sorted pair array (fragments, run masks)
+    u32 _pad;
 };
 
 // A pair = one N operation walked (JunctionSystem::addJunctions, junction_system.cc:140-210).  k1_emit writes, in BAM order,
@@ -1828,6 +1830,12 @@ __global__ __launch_bounds__(256) void kd_table(const u64 *cand, const u64 *cand
             cs->n_junc = (u32)(J < 0xffffffffull ? J : 0xffffffffull);
         }
         if (ovf) cs->P = 0;
+        else if (cs->P) { // the ids ARE the junctions: their number and the fragment slots are known from here on
+            const u32 n_pairs = cs->P;
+            cs->n_junc = cs->J = (u32)J;
+            cs->n_slices = (n_pairs + 63) / 64;
+            cs->n_slots = (u32)J + (n_pairs + 63) / 64;
+        }
     }
     const u32 n = cs->P ? cs->n_cand : 0u; // (P = 0: a limit was exceeded, k1_emit wrote nothing)
     for (u32 base = blockIdx.x * 256; base < n; base += gridDim.x * 256) { // (whole wavefronts: anchors_fold works across the lanes)
@@ -1865,7 +1873,7 @@ __device__ __forceinline__ void acc_rest_state(u32 *acc, u64 n_junc) { // what k
 }
 
 __global__ __launch_bounds__(256) void kd_assign(const u64 *key, const u32 *np, KeyFmt kf, const u64 *bitmap, const u32 *wrank, const u32 *ends,
-                                                 const u32 *first_id, u32 junc_limit, const u64 *total, u64 *jid_key, u32 *jid_bam, u32 *acc) {
+                                                 const u32 *first_id, u32 junc_limit, const u64 *total, u32 *jid_bam, u32 *acc) {
     const u32 n = *np;
     if (n == 0) return;
     {
@@ -1877,9 +1885,7 @@ __global__ __launch_bounds__(256) void kd_assign(const u64 *key, const u32 *np, 
     int32_t s, e;
     unpack_key(kf, key[p], s, e);
     const u32 rs = start_rank(bitmap, wrank, s);
-    const u32 id = first_id[rs] + ends_below(ends, rs, (u32)e);
-    jid_key[p] = (u64)id;
-    jid_bam[p] = id;
+    jid_bam[p] = first_id[rs] + ends_below(ends, rs, (u32)e); // (the sort's first pass reads the ids from here; k4b_generic looks its pairs' junctions up)
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1913,7 +1919,8 @@ __device__ __forceinline__ void wave_hist_add(u32 *h, u32 d, bool valid) {
     if ((rem >> lane) & 1ull) atomicAdd(&h[d], 1u);
 }
 
-__global__ __launch_bounds__(256) void rs_hist(const u64 *keys, const u32 *np, int shift, int bits, u32 *hist, u32 n_tiles) {
+template <typename K>
+__global__ __launch_bounds__(256) void rs_hist(const K *keys, const u32 *np, int shift, int bits, u32 *hist, u32 n_tiles) {
     __shared__ u32 h[RS_MAX_BINS];
     const u32 n = *np; // the grid covers the host's limit; tiles past the data count nothing
     const u32 nb = 1u << bits;
@@ -1921,11 +1928,11 @@ __global__ __launch_bounds__(256) void rs_hist(const u64 *keys, const u32 *np, i
     __syncthreads();
     const u32 base = blockIdx.x * RS_TILE;
     const u32 mask = nb - 1;
-    u64 kk[RS_ITEMS];
+    K kk[RS_ITEMS];
 #pragma unroll
     for (int k = 0; k < RS_ITEMS; k++) {
         const u32 i = base + k * 256 + threadIdx.x;
-        kk[k] = i < n ? keys[i] : 0;
+        kk[k] = i < n ? keys[i] : (K)0;
     }
 #pragma unroll
     for (int k = 0; k < RS_ITEMS; k++) {
@@ -1989,7 +1996,9 @@ __global__ __launch_bounds__(256) void rs_panel_scan(const u32 *hist, const u32 
 // LDS of one rs_scatter block: the tile's keys in digit order (reused for the pair indices), the offset
 // "global position - tile-local position" of every digit, and the digit counters of the 4 waves
 // (16 bit: a wave owns 1024 keys, a tile 4096).
-__host__ __device__ constexpr size_t rs_scatter_lds_bytes(int bits) { return (size_t)RS_TILE * 8 + ((size_t)4 << bits) + ((size_t)8 << bits); }
+__host__ __device__ constexpr size_t rs_scatter_lds_bytes(int bits, size_t key_bytes = 8) {
+    return (size_t)RS_TILE * key_bytes + ((size_t)4 << bits) + ((size_t)8 << bits);
+}
 constexpr int RS_PF = 2; // digits per thread whose scan entries are prefetched (9-bit digits: all of them)
 
 // Lanes of the wave holding the same digit as this lane ("match any"), one ballot per digit bit:
@@ -2022,8 +2031,9 @@ __device__ __forceinline__ u64 wave_match_digit(u32 d, bool valid, int bits) {
 // 8-byte {epoch, count} granules) was measured at 0.064 ms per pass against 0.058 ms for
 // hist + rowscan + scatter: with every tile resident at once the look-back chain costs more than the
 // two small kernels, so it was dropped.
-template <int BITS>
-__global__ __launch_bounds__(256, 3) void rs_scatter(const u64 *kin, const u32 *vin, u64 *kout, u32 *vout, const u32 *np, int shift,
+// K: u64 (full intron keys) or u32 (dense junction ids: half the key traffic, half the key registers)
+template <int BITS, typename K>
+__global__ __launch_bounds__(256, 3) void rs_scatter(const K *kin, const u32 *vin, K *kout, u32 *vout, const u32 *np, int shift,
                                                       int bits, const u32 *hist_scan, const u32 *row_total, u32 n_tiles) {
     extern __shared__ __attribute__((aligned(16))) unsigned char rs_smem[];
     __shared__ u64 s_scan[4];
@@ -2032,9 +2042,9 @@ __global__ __launch_bounds__(256, 3) void rs_scatter(const u64 *kin, const u32 *
     if (BITS > 0) bits = BITS;
     const u32 nb = 1u << bits;
     const u32 mask = nb - 1;
-    u64 *kbuf = (u64 *)rs_smem;
+    K *kbuf = (K *)rs_smem;
     u32 *ibuf = (u32 *)rs_smem;
-    u32 *delta = (u32 *)(rs_smem + (size_t)RS_TILE * 8);
+    u32 *delta = (u32 *)(rs_smem + (size_t)RS_TILE * sizeof(K));
     unsigned short *wcnt = (unsigned short *)(delta + nb); // [4][nb]
     for (u32 d = threadIdx.x; d < 2 * nb; d += 256) ((u32 *)wcnt)[d] = 0;
     __syncthreads();
@@ -2043,12 +2053,12 @@ __global__ __launch_bounds__(256, 3) void rs_scatter(const u64 *kin, const u32 *
     unsigned short *wc = wcnt + (size_t)w * nb;
     const u32 base = tile * RS_TILE + w * (RS_TILE / 4);
     const u64 lt = (1ull << lane) - 1;
-    u64 key[RS_ITEMS];
+    K key[RS_ITEMS];
     u32 val[RS_ITEMS];
     u32 rkp[RS_ITEMS / 2]; // tile-local ranks (< 4096), two per register: the kernel must stay under 128 VGPRs
     // the key / index buffers are allocated with one tile of slack, so the last tile loads unguarded too
     // (lanes past n are masked below): 16 independent loads from one scalar base
-    const u64 *kp = kin + base;
+    const K *kp = kin + base;
 #pragma unroll
     for (int r = 0; r < RS_ITEMS; r++) key[r] = kp[r * 64 + lane];
     // digits [d0, d0 + per) belong to this thread in the digit phase (consecutive, so that one block
@@ -2130,7 +2140,7 @@ __global__ __launch_bounds__(256, 3) void rs_scatter(const u64 *kin, const u32 *
 #pragma unroll
     for (int r = 0; r < RS_ITEMS; r++) {
         const u32 j = r * 256 + threadIdx.x;
-        const u64 kk = j < cnt ? kbuf[j] : 0;
+        const K kk = j < cnt ? kbuf[j] : (K)0;
         const u32 d = (u32)(kk >> shift) & mask;
         digp[r >> 1] = (r & 1) ? (digp[r >> 1] | (d << 16)) : d;
         if (j < cnt) kout[delta[d] + j] = kk;
@@ -2204,6 +2214,37 @@ __global__ void k2_close(u64 *total, u32 *seg_off, u32 *run_first, u32 *run_star
     cs->J = J;
     cs->R = R;
     cs->n_slots = J + (n_pairs + 63) / 64;
+}
+
+// K2s for the chain on dense ids: k4_pairs left two bits per sorted pair (junction starts / position run starts), a scan over the
+// slices' popcounts numbers the runs, and this kernel writes what HeadSink writes -- from the masks and the sorted ids alone.
+struct Popc64Fn {
+    const u64 *words;
+    __device__ u64 operator()(u64 i) const { return (u64)__popcll(words[i]); }
+};
+__global__ __launch_bounds__(256) void k2_expand(const u32 *sid, const u64 *head_mask, const u64 *run_mask, const u32 *run_base, const u64 *total,
+                                                 u32 *seg_off, u32 *run_first, u32 *run_start, ContigStats *cs) {
+    const u32 n = cs->P;
+    const u32 i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const u32 sl = i >> 6, bit = i & 63u;
+    const u64 mr = run_mask[sl], mj = head_mask[sl];
+    if ((mr >> bit) & 1ull) {
+        const u32 r = run_base[sl] + (u32)__popcll(mr & ((1ull << bit) - 1ull));
+        run_start[r] = i;
+        if ((mj >> bit) & 1ull) {
+            const u32 j = sid[i];
+            seg_off[j] = i;
+            run_first[j] = r;
+        }
+    }
+    if (i == n - 1) { // (k2_close's part)
+        const u32 R = (u32)*total, J = cs->J;
+        seg_off[J] = n;
+        run_first[J] = R;
+        run_start[R] = n;
+        cs->n_runs = cs->R = R;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2525,8 +2566,11 @@ __global__ __launch_bounds__(256) void k4b_generic(const u64 *list, const u32 *g
 // wavefront that sees either marks the slot unused (frag_j = -1) itself, so nothing has to be initialised.
 // A second small kernel reduces slots -> junctions (segmented again, then one atomic per wave and junction), so a
 // junction with 10^6 pairs costs ~250 same-address atomics, not 10^6.
+// masks (nullptr: the chain that sorted the full keys has its runs from the head scan): per 64-pair slice, the lanes where a
+// junction starts and the lanes where a run of equal read positions starts (entropy, junction.cc:730-749) -- this kernel holds
+// every pair's record anyway, k2_expand turns the bits into seg_off / run_first / run_start without touching a pair.
 __global__ __launch_bounds__(256) void k4_pairs(const u32 *sidx, const u32 *jid_of, const PairRec *rec, const u64 *jkey, KeyFmt kf, const u32 *np,
-                                                 u32 *frag, int32_t *frag_j) {
+                                                 u32 *frag, int32_t *frag_j, u64 *head_mask, u64 *run_mask) {
     const u32 n = *np;
     if (blockIdx.x * 256u >= n) return;
     const u32 i = blockIdx.x * 256 + threadIdx.x;
@@ -2582,6 +2626,15 @@ __global__ __launch_bounds__(256) void k4_pairs(const u32 *sidx, const u32 *jid_
         // unused fragment slots: the one skipped when a junction starts on a slice boundary, and the last one
         if (lane == 0 && i > 0 && jprev_v != j) frag_j[j + (i >> 6) - 1] = -1;
         if (i == n - 1) frag_j[j + (i >> 6) + 1] = -1;
+    }
+    if (head_mask) {
+        const bool hj = valid && (i == 0 || jprev_v != j);
+        const bool hr = valid && (hj || pos_prev != Rc.pos);
+        const u64 mj = __ballot(hj), mr = __ballot(hr);
+        if (lane == 0) {
+            head_mask[i >> 6] = mj;
+            run_mask[i >> 6] = mr;
+        }
     }
     auto store_fragment = [&](u32 hi_word) {
         const u32 slot = j + (i >> 6);
