@@ -1063,7 +1063,7 @@ static int mirror_header_only(pjb_ctx *c, const pjb_region_result &R) {
 // contig's rows exist (b_rows, sidx, jid are still this contig's).
 constexpr u32 X_ZCAP = 1u << 20;
 static int extra_contig_dense(pjb_ctx *c, int32_t tid, std::vector<DevBatch> &batches, int64_t n_reads, u64 n_spliced, u32 P, u32 J,
-                              const u32 *sidx, const u32 *pair_g, size_t row_base, bool codes_in_table) {
+                              const u32 *sidx, const u32 *jid_sorted, const u32 *pair_g, size_t row_base, bool codes_in_table) {
     hipStream_t st = c->stream;
     const int32_t L = c->ref_len[(size_t)tid];
     const size_t N = (size_t)n_reads;
@@ -1157,7 +1157,7 @@ static int extra_contig_dense(pjb_ctx *c, int32_t tid, std::vector<DevBatch> &ba
                (u32)N, (const u32 *)prefq, (const u32 *)ce, L, (const u32 *)c->x_zlist.p, (const ExtraCounters *)d_cnt, X_ZCAP, X.xr);
         if (hipMalloc((void **)&X.pair_code, (size_t)P * 8) != hipSuccess || hipMalloc((void **)&X.pair_row, (size_t)P * 4) != hipSuccess)
             return fail(c, PJB_ERR_NOMEM, "extra: pair codes of target %d", tid);
-        LAUNCH(c, "kx_pair_codes", kx_pair_codes, dim3((P + 255) / 256), dim3(256), sidx, (const u32 *)c->sl[c->cur_slot].jid.p, pair_g,
+        LAUNCH(c, "kx_pair_codes", kx_pair_codes, dim3((P + 255) / 256), dim3(256), sidx, jid_sorted, pair_g,
                (const DevBatch *)c->sl[c->cur_slot].batches.p, (int)batches.size(), P, (u32)row_base, X.pair_code, X.pair_row);
     }
     HIP_TRY(c, hipStreamSynchronize(st));
@@ -1262,7 +1262,7 @@ static int extra_pre(pjb_ctx *c, Flight &f) {
 
 static int extra_contig(pjb_ctx *c, Flight &f, int32_t tid, u64 n_spliced, u32 P, u32 J, size_t row_base) {
     std::vector<DevBatch> &batches = f.batches;
-    if (c->extra_dense_only) return extra_contig_dense(c, tid, batches, f.n_reads, n_spliced, P, J, f.sidx, f.pr.g, row_base, false);
+    if (c->extra_dense_only) return extra_contig_dense(c, tid, batches, f.n_reads, n_spliced, P, J, f.sidx, f.jid_sorted, f.pr.g, row_base, false);
     int rc;
     if ((rc = extra_pre(c, f))) return rc;
     hipStream_t st = c->stream;
@@ -1317,7 +1317,7 @@ static int extra_contig(pjb_ctx *c, Flight &f, int32_t tid, u64 n_spliced, u32 P
     if (hx.n_spliced != (u32)n_spliced)
         return fail(c, PJB_ERR_STATE, "extra: target %d: %u spliced records in the tile lists, the chain counted %llu", tid, hx.n_spliced, (unsigned long long)n_spliced);
     if (hc.need_dense) // the pileup's cap may bite (or the gap list is too small): the depth vector, as in round 2
-        return extra_contig_dense(c, tid, batches, f.n_reads, n_spliced, P, J, f.sidx, f.pr.g, row_base, true);
+        return extra_contig_dense(c, tid, batches, f.n_reads, n_spliced, P, J, f.sidx, f.jid_sorted, f.pr.g, row_base, true);
     X.has_unspliced = (u32)hc.total > 0;
     X.n_spl = hx.n_spliced;
     X.sparse = SparseDepth{f.x_spos, f.x_send, f.x_gaps, f.x_gapoff, (u32)hc.total, (u32)(hc.total >> 32), hc.max_span, hc.max_gap};
