@@ -817,7 +817,8 @@ def e2e_leg_once(contigs, cfgs, workdir, orientation, oracle_tab_md5, reads_arg,
                                   "zlib, parses the records and runs the oracle port of findJuncs; merge, calcJunctionStats and "
                                   ".tab writer.  The port is several times faster per thread than the reference binary, so "
                                   "this is a lower bound on the reference's wall clock on these cores"}
-            res["speedup_vs_cpu"] = round(wall / slowest, 1)  # (against the slowest of: one process, early return until closed, early return until gone)
+            res["speedup_vs_cpu"] = round(wall / med, 1)  # (against the command as it is by default: one process, timed until it is gone)
+            res["speedup_vs_cpu_slowest"] = round(wall / slowest, 1)  # (against the slowest of: one process, early return until closed / until its child is gone)
         except Exception as ex:
             res["cpu"] = {"error": f"{type(ex).__name__}: {ex}"[:300]}
     res["leg_s"] = round(time.time() - t_all, 1)

@@ -141,7 +141,10 @@ def test_bench_line_small_workload(tmp_path):
     d = _run_bench(["--e2e-workdir", str(tmp_path / "e2e")], {})
     assert d["roofline"]["frac"] > 0 and d["roofline"]["alg_bytes_per_launch"] > 0
     assert d["cpu_baseline"]["value"] > 0 and "every device row" in d["cpu_baseline"]["sample"]
+    assert "error" not in d["e2e"], d["e2e"]
     assert d["e2e"]["tab_identical_to_oracle"] is True and d["e2e"]["reads"] == d["config"]["reads_total"]
+    er = d["e2e"]["early_return"]  # the opt-in early return is timed beside the default (one process): closed before the tree is gone
+    assert er["wall_s_outputs_closed"] <= er["wall_s_process_tree"]
 
 
 # ---- BASELINE configs[2] at full size: 200 M paired-end reads over 25 GRCh38-sized contigs, one context
