@@ -343,7 +343,10 @@ constexpr int SCAN_TILE = 2048; // 256 threads x 8
 template <typename F>
 __global__ __launch_bounds__(256) void scan_reduce_kernel(F f, u64 n, u64 *tile_sums, const u32 *np) {
     __shared__ u64 sm[4];
-    if (np) n = *np; // length known on the device only: the grid covers the host's limit
+    if (np) { // length known on the device only: the grid covers the host's limit, and a count beyond it (there is none) must not reach past the buffers
+        const u64 d = *np;
+        n = d < n ? d : n;
+    }
     u64 base = (u64)blockIdx.x * SCAN_TILE;
     u64 s = 0;
 #pragma unroll
@@ -389,7 +392,10 @@ __global__ __launch_bounds__(1024) void scan_tiles_kernel(u64 *tile_sums, u32 n_
 template <typename F, typename G>
 __global__ __launch_bounds__(256) void scan_apply_kernel(F f, G g, u64 n, const u64 *tile_sums, const u32 *np) {
     __shared__ u64 sm[4];
-    if (np) n = *np;
+    if (np) {
+        const u64 d = *np;
+        n = d < n ? d : n;
+    }
     if ((u64)blockIdx.x * SCAN_TILE >= n) return;
     u64 base = (u64)blockIdx.x * SCAN_TILE;
     u64 run = tile_sums[blockIdx.x];
@@ -417,7 +423,10 @@ template <typename F, typename G>
 __global__ __launch_bounds__(256) void scan_apply2_kernel(F f, G g, u64 n, const u64 *tile_sums, const u32 *np, u64 *total) {
     __shared__ u64 sm[4];
     __shared__ u64 s_pref[4];
-    if (np) n = *np;
+    if (np) {
+        const u64 d = *np;
+        n = d < n ? d : n;
+    }
     const u64 n_tiles = n == 0 ? 1 : (n + SCAN_TILE - 1) / SCAN_TILE; // (an empty input still gets its total written)
     if (blockIdx.x >= n_tiles) return;
     u64 acc = 0;
@@ -1007,7 +1016,7 @@ __global__ __launch_bounds__(K1S_THREADS) void k1_scan_tiles(u32 *tile_cnt, cons
         }
         out->overflow = ovf;
         out->P = ovf ? 0u : (u32)n_pairs;
-        out->J = out->R = out->n_slots = 0;
+        out->J = out->R = out->n_slots = out->n_slices = 0;
         out->n_junc = out->n_runs = 0;
         out->n_cand = ((carry2_s + 255u) >> 8) * (u32)CAND_PER_CHUNK; // K2d: every chunk of 256 spliced reads owns CAND_PER_CHUNK candidate slots (k1_emit); the overflow list grows behind them
     }

@@ -19,7 +19,7 @@ rc=0
 for step in "$@"; do
   echo "=== $step"
   case "$step" in
-    tests) ( time timeout 2400 python -m pytest tests -m gpu -q -x 2>&1 | tail -25 ) 2>&1 | tee $OUT/${TAG}_pytest.log ;;
+    tests) ( time timeout 2400 python -m pytest tests -m gpu -q -x > $OUT/${TAG}_pytest_full.log 2>&1 ); grep -v "^  File \"/usr/local/lib" $OUT/${TAG}_pytest_full.log | tail -60 | tee $OUT/${TAG}_pytest.log ;;
     tests:*) ( time timeout 2400 python -m pytest tests -m gpu -q -x -k "${step#tests:}" 2>&1 | tail -40 ) 2>&1 | tee $OUT/${TAG}_pytest_k.log ;;
     smoke) python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -5 ;;
     quick) timeout 900 python bench.py --steps 10 --warmup 3 --no-e2e --no-cpu-baseline > $OUT/${TAG}_quick.json 2> $OUT/${TAG}_quick.err; tail -c 400 $OUT/${TAG}_quick.err
