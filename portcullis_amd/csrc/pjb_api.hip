@@ -452,6 +452,17 @@ bool ktime_wanted(pjb_ctx *c, const char *name) {
         if (n == name) return true;
     return false;
 }
+// PJB_DEBUG_LAUNCH (a build flag, tools/build_variants.sh): every chain kernel is announced on stderr and waited for, so that the
+// last name before a "Memory access fault" is the kernel that faulted
+#ifdef PJB_DEBUG_LAUNCH
+#define PJB_LAUNCH_TRACE(c, name)                                   \
+    do {                                                            \
+        (void)hipStreamSynchronize((c)->stream);                    \
+        fprintf(stderr, "[launch] %s done\n", name);                \
+    } while (0)
+#else
+#define PJB_LAUNCH_TRACE(c, name) do { } while (0)
+#endif
 #define LAUNCH_LDS(c, name, kern, grid, block, lds_bytes, ...)                       \
     do {                                                                            \
         const bool timed_ = ktime_wanted((c), name);                                \
@@ -459,6 +470,7 @@ bool ktime_wanted(pjb_ctx *c, const char *name) {
         hipLaunchKernelGGL(kern, grid, block, lds_bytes, (c)->stream, __VA_ARGS__); \
         if (timed_) ev_end((c));                                                    \
         HIP_TRY((c), hipGetLastError());                                            \
+        PJB_LAUNCH_TRACE(c, name);                                                  \
     } while (0)
 #define LAUNCH(c, name, kern, grid, block, ...) LAUNCH_LDS(c, name, kern, grid, block, 0, __VA_ARGS__)
 

@@ -2640,7 +2640,7 @@ __global__ __launch_bounds__(256) void k4_pairs(const u32 *sidx, const u32 *jid_
         const bool hj = valid && (i == 0 || jprev_v != j);
         const bool hr = valid && (hj || pos_prev != Rc.pos);
         const u64 mj = __ballot(hj), mr = __ballot(hr);
-        if (lane == 0) {
+        if (lane == 0 && i < n) { // (a wavefront wholly past the end has no slice: the arrays hold ceil(n / 64) words)
             head_mask[i >> 6] = mj;
             run_mask[i >> 6] = mr;
         }
