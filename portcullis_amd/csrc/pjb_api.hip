@@ -79,6 +79,9 @@ static void *genome_take(std::vector<Buf> &pool, size_t bytes, size_t &cap) {
         (void)hipGetLastError();
         return nullptr;
     }
+#ifdef PJB_DEBUG_ALLOC
+    fprintf(stderr, "[alloc] genome: %p .. %p (%zu bytes)\n", p, (void *)((char *)p + bytes), bytes);
+#endif
     return p;
 }
 
@@ -257,7 +260,12 @@ struct pjb_ctx {
     // counters (k7_publish; per slot), start bitmap / end slots (kd_reset).  false: set by a memset before use
     int last_slot = 0; // slot of the contig collected last (pjb_collect_device)
     int inflate_lanes = 512 * 64;                // lanes of one bgzf_inflate launch (2 workgroups x 256 CUs; set from the device at create)
-    bool side_stream = true;                     // k4a_simple beside the sort (PJB_SIDE_STREAM=0: on the main stream)
+#ifdef DBG_NO_SIDE
+    bool side_stream = false;
+#else
+    bool side_stream = true;
+#endif
+    bool _side_stream_doc_;                     // k4a_simple beside the sort (PJB_SIDE_STREAM=0: on the main stream)
     bool dense_ids = true;                       // K2d (PJB_DENSE_IDS=0 sorts the full keys as round 1 did)
     u32 junc_seen = 0;                           // most junctions a contig has had so far (junction limit of the next contig)
     int lbits_seen = 18;                         // bits of the longest intron this context has met (key format of the next contig)
@@ -327,7 +335,20 @@ int fail(pjb_ctx *c, int code, const char *fmt, ...) {
                         __LINE__);                                                                         \
     } while (0)
 
+#ifdef PJB_DEBUG_ALLOC // (debug builds: every device buffer with its range on stderr, so that a "Memory access fault ... on address" can be placed)
+#define ensure(c, b, bytes) ensure_named((c), (b), (bytes), #b, __LINE__)
+int ensure_named(pjb_ctx *c, Buf &b, size_t bytes, const char *what, int line);
+int ensure_impl(pjb_ctx *c, Buf &b, size_t bytes);
+int ensure_named(pjb_ctx *c, Buf &b, size_t bytes, const char *what, int line) {
+    const void *was = b.p;
+    const int rc = ensure_impl(c, b, bytes);
+    if (b.p != was) fprintf(stderr, "[alloc] %s (line %d): %p .. %p (%zu bytes, asked %zu)\n", what, line, b.p, (void *)((char *)b.p + b.cap), b.cap, bytes);
+    return rc;
+}
+int ensure_impl(pjb_ctx *c, Buf &b, size_t bytes) {
+#else
 int ensure(pjb_ctx *c, Buf &b, size_t bytes) {
+#endif
     if (bytes <= b.cap && b.p) return PJB_OK;
     if (b.p) HIP_TRY(c, hipFree(b.p));
     b.p = nullptr;
@@ -517,6 +538,9 @@ void *slab_alloc(pjb_ctx *c, OpenContig &oc, size_t bytes) {
     }
     s.used = bytes;
     oc.slabs.push_back(s);
+#ifdef PJB_DEBUG_ALLOC
+    fprintf(stderr, "[alloc] slab: %p .. %p (%zu bytes)\n", (void *)s.p, (void *)(s.p + s.cap), s.cap);
+#endif
     return s.p;
 }
 
@@ -1623,6 +1647,9 @@ static int queue_contig(pjb_ctx *c, Flight &f) {
         return PJB_OK;
     };
     auto fork_k4b = [&]() -> int { // (the main stream has just produced jid_bam and the anchors)
+#ifdef DBG_K4B_INLINE
+        return launch_k4b();
+#endif
         if (!c->side_stream) return launch_k4b();
         HIP_TRY(c, hipEventRecord(S.ev_fork, st));
         HIP_TRY(c, hipStreamWaitEvent(S.side, S.ev_fork, 0));
@@ -1651,22 +1678,28 @@ static int queue_contig(pjb_ctx *c, Flight &f) {
         S.dense_at_rest = false; // until kd_reset is queued
         const u64 *okey = (const u64 *)pr.key;
         u64 *cand = (u64 *)S.key[1].p; // (k1_emit left the candidate keys here)
-        LAUNCH(c, "kd_mark", kd_mark, dim3(KD_GRID), dim3(256), (const u64 *)cand, (const ContigStats *)d_cs, kf, (u64 *)S.bitmap.p);
+#ifdef DBG_KD_BIG_GRID
+        const u32 kd_grid = (u32)((cand_room + 255) / 256);
+#else
+        const u32 kd_grid = KD_GRID;
+#endif
+        LAUNCH(c, "kd_mark", kd_mark, dim3(kd_grid), dim3(256), (const u64 *)cand, (const ContigStats *)d_cs, kf, (u64 *)S.bitmap.p);
         if ((rc = run_scan(c, "kd_rank", PopcFn{(const u64 *)S.bitmap.p}, ExclusiveU32Sink{(u32 *)S.wrank.p}, (u64)n_words,
                            (u64 *)S.total.p)))
             return rc;
         u32 *cand_rank = (u32 *)S.idx[1].p; // (free until the first scatter as well)
-        LAUNCH(c, "kd_ends", kd_ends, dim3(KD_GRID), dim3(256), (const u64 *)cand, kf, (const u64 *)S.bitmap.p, (const u32 *)S.wrank.p, JL,
+        LAUNCH(c, "kd_ends", kd_ends, dim3(kd_grid), dim3(256), (const u64 *)cand, kf, (const u64 *)S.bitmap.p, (const u32 *)S.wrank.p, JL,
                (u32 *)S.ends.p, cand_rank, d_cs);
         if ((rc = run_scan(c, "kd_first", EndsCountFn{(const u32 *)S.ends.p}, FirstIdSink{(u32 *)S.firstid.p, (int32_t *)S.ancl.p, (int32_t *)S.ancr.p},
                            (u64)JL, (u64 *)S.total.p)))
             return rc;
-        LAUNCH(c, "kd_table", kd_table, dim3(KD_GRID), dim3(256), (const u64 *)cand, (const u64 *)S.ent.p, (const u32 *)cand_rank, kf, JL,
+        LAUNCH(c, "kd_table", kd_table, dim3(kd_grid), dim3(256), (const u64 *)cand, (const u64 *)S.ent.p, (const u32 *)cand_rank, kf, JL,
                (const u32 *)S.ends.p, (const u32 *)S.firstid.p, (const u64 *)S.total.p, (u64 *)S.jkey.p, (int32_t *)S.ancl.p, (int32_t *)S.ancr.p, d_cs);
         LAUNCH(c, "kd_assign", kd_assign, dim3(pair_blocks), dim3(256), okey, d_P, kf, (const u64 *)S.bitmap.p, (const u32 *)S.wrank.p,
-               (const u32 *)S.ends.p, (const u32 *)S.firstid.p, JL, (const u64 *)S.total.p, (u32 *)S.jidbam.p, (u32 *)S.acc.p);
+               (const u32 *)S.ends.p, (const u32 *)S.firstid.p, JL, (const u64 *)S.total.p, (u32 *)S.jidbam.p, (u32 *)S.acc.p, (const u64 *)S.jkey.p,
+               (const int32_t *)S.ancl.p, (const int32_t *)S.ancr.p, d_err, d_cs);
         if ((rc = fork_k4b())) return rc;
-        LAUNCH(c, "kd_reset", kd_reset, dim3(KD_GRID), dim3(256), (const u64 *)cand, (const u32 *)cand_rank, kf, JL, (const ContigStats *)d_cs,
+        LAUNCH(c, "kd_reset", kd_reset, dim3(kd_grid), dim3(256), (const u64 *)cand, (const u32 *)cand_rank, kf, JL, (const ContigStats *)d_cs,
                (u64 *)S.bitmap.p, (u32 *)S.ends.p);
         S.dense_at_rest = true;
         sort_bits = std::max(1, bits_of((uint64_t)JL));
@@ -1737,6 +1770,9 @@ static int queue_contig(pjb_ctx *c, Flight &f) {
     };
     bool entropy_forked = false;
     auto fork_entropy = [&]() -> int { // the entropy kernels beside what follows on the main stream (small and latency-bound, both)
+#ifdef DBG_ENT_INLINE
+        return entropy_kernels();
+#endif
         if (!c->side_stream) return entropy_kernels();
         HIP_TRY(c, hipEventRecord(S.ev_fork2, st));
         HIP_TRY(c, hipStreamWaitEvent(S.side, S.ev_fork2, 0));
@@ -1759,7 +1795,7 @@ static int queue_contig(pjb_ctx *c, Flight &f) {
         STAGE_EVENT(4);
         if (f.forked) HIP_TRY(c, hipStreamWaitEvent(tl, S.ev_join, 0)); // k4b_generic's results (side stream) are needed from here on
         LAUNCH(c, "k4_pairs", k4_pairs, dim3(pair_blocks), dim3(256), sidx, jid_sorted, (const PairRec *)pr.rec, (const u64 *)S.jkey.p, kf, d_P,
-               (u32 *)S.frag.p, (int32_t *)S.fragj.p, head_mask, run_mask);
+               (u32 *)S.frag.p, (int32_t *)S.fragj.p, head_mask, run_mask, (const ContigStats *)d_cs, d_err);
         if ((rc = run_scan(c, "k2_runs", Popc64Fn{(const u64 *)run_mask}, ExclusiveU32Sink{run_base}, (u64)n_slices_lim, (u64 *)S.total.p, &d_cs->n_slices)))
             return rc;
         LAUNCH(c, "k2_expand", k2_expand, dim3(pair_blocks), dim3(256), jid_sorted, (const u64 *)head_mask, (const u64 *)run_mask, (const u32 *)run_base,
@@ -1784,7 +1820,7 @@ static int queue_contig(pjb_ctx *c, Flight &f) {
         if ((rc = launch_k4b())) return rc;
         STAGE_EVENT(4);
         LAUNCH(c, "k4_pairs", k4_pairs, dim3(pair_blocks), dim3(256), sidx, jid_sorted, (const PairRec *)pr.rec, (const u64 *)S.jkey.p, kf, d_P,
-               (u32 *)S.frag.p, (int32_t *)S.fragj.p, (u64 *)nullptr, (u64 *)nullptr);
+               (u32 *)S.frag.p, (int32_t *)S.fragj.p, (u64 *)nullptr, (u64 *)nullptr, (const ContigStats *)d_cs, d_err);
         STAGE_EVENT(5);
     }
 

@@ -1531,7 +1531,11 @@ __global__ __launch_bounds__(K1E_T) __attribute__((amdgpu_waves_per_eu(K1E_WAVES
                 q_c0 = c0;
             }
         }
+#ifdef DBG_LANE_INSERT
+        if (want_cand && simple_done) cand_insert(c_key, ca_lo, ca_hi);
+#else
         if (want_cand) cand_add_wave(simple_done, c_key, ca_lo, ca_hi);
+#endif
         K1E_PROBE(6);
         // ---- the other reads are compacted (LDS) ...
         {
@@ -1605,6 +1609,9 @@ __global__ __launch_bounds__(K1E_T) __attribute__((amdgpu_waves_per_eu(K1E_WAVES
         }
         K1E_PROBE(8);
         // ---- the chunk's candidate keys go to its slots
+#ifdef DBG_BARRIER_D
+        __syncthreads();
+#endif
         if (want_cand && own_slots) {
             __syncthreads();
             if (threadIdx.x < CAND_PER_CHUNK) {
@@ -1882,7 +1889,8 @@ __device__ __forceinline__ void acc_rest_state(u32 *acc, u64 n_junc) { // what k
 }
 
 __global__ __launch_bounds__(256) void kd_assign(const u64 *key, const u32 *np, KeyFmt kf, const u64 *bitmap, const u32 *wrank, const u32 *ends,
-                                                 const u32 *first_id, u32 junc_limit, const u64 *total, u32 *jid_bam, u32 *acc) {
+                                                 const u32 *first_id, u32 junc_limit, const u64 *total, u32 *jid_bam, u32 *acc, const u64 *jkey,
+                                                 const int32_t *anc_l, const int32_t *anc_r, u64 *err, ContigStats *cs_chk) {
     const u32 n = *np;
     if (n == 0) return;
     {
@@ -1894,7 +1902,26 @@ __global__ __launch_bounds__(256) void kd_assign(const u64 *key, const u32 *np, 
     int32_t s, e;
     unpack_key(kf, key[p], s, e);
     const u32 rs = start_rank(bitmap, wrank, s);
-    jid_bam[p] = first_id[rs] + ends_below(ends, rs, (u32)e); // (the sort's first pass reads the ids from here; k4b_generic looks its pairs' junctions up)
+    const u32 id = first_id[rs] + ends_below(ends, rs, (u32)e);
+    jid_bam[p] = id; // (the sort's first pass reads the ids from here; k4b_generic looks its pairs' junctions up)
+#ifdef PJB_SELFCHECK // (debug builds: the junction table kd_table made must know this pair's junction -- its start bit, its end slot, its key,
+                     // anchors that enclose the intron; a failure stops the chain (P = 0) so that the report gets out)
+    {
+        int bad = 0;
+        const uint4 *q = reinterpret_cast<const uint4 *>(ends + (size_t)rs * DENSE_ENDS);
+        const uint4 a = q[0], b = q[1];
+        const u32 ue = (u32)e;
+        if (!((bitmap[(u32)s >> 6] >> (s & 63)) & 1ull)) bad = 6;
+        else if (!(a.x == ue || a.y == ue || a.z == ue || a.w == ue || b.x == ue || b.y == ue || b.z == ue || b.w == ue)) bad = 7;
+        else if (id >= junc_limit || id >= (u32)*total) bad = 1;
+        else if (jkey[id] != key[p]) bad = 2;
+        else if (anc_l[id] > s || anc_r[id] < e) bad = 3;
+        if (bad) {
+            set_error(err, 0xfffff000u + (u32)bad, PJB_ERR_HIP);
+            cs_chk->P = 0;
+        }
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2579,7 +2606,7 @@ __global__ __launch_bounds__(256) void k4b_generic(const u64 *list, const u32 *g
 // junction starts and the lanes where a run of equal read positions starts (entropy, junction.cc:730-749) -- this kernel holds
 // every pair's record anyway, k2_expand turns the bits into seg_off / run_first / run_start without touching a pair.
 __global__ __launch_bounds__(256) void k4_pairs(const u32 *sidx, const u32 *jid_of, const PairRec *rec, const u64 *jkey, KeyFmt kf, const u32 *np,
-                                                 u32 *frag, int32_t *frag_j, u64 *head_mask, u64 *run_mask) {
+                                                 u32 *frag, int32_t *frag_j, u64 *head_mask, u64 *run_mask, const ContigStats *cs_chk, u64 *err_chk) {
     const u32 n = *np;
     if (blockIdx.x * 256u >= n) return;
     const u32 i = blockIdx.x * 256 + threadIdx.x;
@@ -2588,6 +2615,22 @@ __global__ __launch_bounds__(256) void k4_pairs(const u32 *sidx, const u32 *jid_
     const u32 ic = valid ? i : n - 1; // (loads unconditional, masked after: see k1_count)
     const u32 p = sidx[ic];
     const u32 jv = jid_of[ic];
+#ifdef PJB_SELFCHECK // (debug builds: what the sort hands over must be a permutation of the pairs with ids below J that ascend in steps of 0 or 1)
+    {
+        const u32 Jc = cs_chk->J;
+        const u32 jb = ic ? jid_of[ic - 1] : jv;
+        int bad = 0;
+        if (p >= n) bad = 1;
+        else if (jv >= Jc) bad = 2;
+        else if (jv != jb && jv != jb + 1) bad = 3;
+        else if (ic == 0 && jv != 0) bad = 4;
+        else if (ic == n - 1 && jv != Jc - 1) bad = 5;
+        if (__ballot(bad != 0)) {
+            if (bad) set_error(err_chk, 0xffffe000u + (u32)bad, PJB_ERR_HIP);
+            return;
+        }
+    }
+#endif
     const PairRec Rc = rec_load(rec + p);
     const u64 jk = jkey[jv];
     // the pair before this one in sorted order: the neighbouring lane's -- lane 0 fetches it
