@@ -1471,11 +1471,9 @@ static int queue_contig(pjb_ctx *c, Flight &f) {
     // ---- pair-sized buffers (one sort tile of slack: rs_scatter loads whole tiles unguarded)
     if ((rc = ensure(c, S.okey, ((size_t)PL + RS_TILE) * 8))) return rc; // the pairs' keys as emitted (BAM order): kept, the sort works on copies
     if ((rc = ensure(c, S.key[0], ((size_t)PL + RS_TILE) * 8))) return rc;
-    // (key[1], idx[1] and ent hold K2d's candidates before the sort needs them: the chunks' own slots plus, at worst, one overflow entry per pair)
-    const size_t cand_room = (size_t)PL + ((size_t)PL / 256 + 2) * CAND_PER_CHUNK + RS_TILE;
-    if ((rc = ensure(c, S.key[1], cand_room * 8))) return rc;
+    if ((rc = ensure(c, S.key[1], ((size_t)PL + RS_TILE) * 8))) return rc;
     if ((rc = ensure(c, S.idx[0], ((size_t)PL + RS_TILE) * 4))) return rc;
-    if ((rc = ensure(c, S.idx[1], cand_room * 4))) return rc;
+    if ((rc = ensure(c, S.idx[1], ((size_t)PL + RS_TILE) * 4))) return rc;
     if ((rc = ensure(c, S.rec, ((size_t)PL + 1) * sizeof(PairRec)))) return rc;
     if ((rc = ensure(c, S.jid, (size_t)PL * 4 + 16))) return rc;
     if ((rc = ensure(c, S.jidbam, ((size_t)PL + RS_TILE) * 4))) return rc; // (the sort's first pass loads whole tiles)
@@ -1483,7 +1481,7 @@ static int queue_contig(pjb_ctx *c, Flight &f) {
     if ((rc = ensure(c, S.seg, ((size_t)PL + 1) * 4))) return rc;
     if ((rc = ensure(c, S.runfirst, ((size_t)PL + 1) * 4))) return rc;
     if ((rc = ensure(c, S.runstart, ((size_t)PL + 1) * 4))) return rc;
-    if ((rc = ensure(c, S.ent, cand_room * 8))) return rc;
+    if ((rc = ensure(c, S.ent, (size_t)PL * 8 + 16))) return rc;
     const u32 pair_blocks = std::max<u32>(1, (PL + 255) / 256);
     const u32 gen_cap = gen_list_cap(PL); // entries per sub-list
     if ((rc = ensure(c, S.genlist, (size_t)gen_cap * GEN_SHARDS * 8))) return rc;
@@ -1626,11 +1624,7 @@ static int queue_contig(pjb_ctx *c, Flight &f) {
             const int32_t own_tid = f.tids[(size_t)m], own_len = c->ref_len[(size_t)own_tid];
             const u32 nt = (u32)((b.n + K1_TILE - 1) / K1_TILE);
             // (a tile holds ~300 spliced reads = 1.2 chunks of 256: a grid of half the tiles keeps two or three chunks per block)
-#ifndef K1E_GRID_MODE
-#define K1E_GRID_MODE 0
-#endif
-            const u32 grid = K1E_GRID_MODE == 1 ? std::max<u32>(1, nt) : K1E_GRID_MODE == 2 ? std::max<u32>(1, std::min<u32>(nt, 1536u)) : K1E_GRID_MODE == 3 ? std::max<u32>(1, std::min<u32>(nt, 3072u))
-                                                : std::max<u32>(1, std::min<u32>(nt, std::max<u32>(1024, nt / 2)));
+            const u32 grid = std::max<u32>(1, std::min<u32>(nt, std::max<u32>(1024, nt / 2)));
             LAUNCH(c, "k1_emit", k1_emit, dim3(grid), dim3(256), b, nt, n_tiles, (const u32 *)S.tile_cnt.p, (const u32 *)S.tile_soff.p,
                    (const u32 *)S.chunk_tile.p, (const u32 *)S.splidx.p, (const u32 *)S.splpoff.p, pr, el, kf, own_len,
                    own_tid, (int)c->cfg.orientation, d_err, d_cs, f.voff[(size_t)m], fast_codes ? (const u32 *)GT.codes[m] : (const u32 *)nullptr);
@@ -1678,28 +1672,23 @@ static int queue_contig(pjb_ctx *c, Flight &f) {
         S.dense_at_rest = false; // until kd_reset is queued
         const u64 *okey = (const u64 *)pr.key;
         u64 *cand = (u64 *)S.key[1].p; // (k1_emit left the candidate keys here)
-#ifdef DBG_KD_BIG_GRID
-        const u32 kd_grid = (u32)((cand_room + 255) / 256);
-#else
-        const u32 kd_grid = KD_GRID;
-#endif
-        LAUNCH(c, "kd_mark", kd_mark, dim3(kd_grid), dim3(256), (const u64 *)cand, (const ContigStats *)d_cs, kf, (u64 *)S.bitmap.p);
+        LAUNCH(c, "kd_mark", kd_mark, dim3(pair_blocks), dim3(256), (const u64 *)cand, (const ContigStats *)d_cs, kf, (u64 *)S.bitmap.p);
         if ((rc = run_scan(c, "kd_rank", PopcFn{(const u64 *)S.bitmap.p}, ExclusiveU32Sink{(u32 *)S.wrank.p}, (u64)n_words,
                            (u64 *)S.total.p)))
             return rc;
         u32 *cand_rank = (u32 *)S.idx[1].p; // (free until the first scatter as well)
-        LAUNCH(c, "kd_ends", kd_ends, dim3(kd_grid), dim3(256), (const u64 *)cand, kf, (const u64 *)S.bitmap.p, (const u32 *)S.wrank.p, JL,
+        LAUNCH(c, "kd_ends", kd_ends, dim3(pair_blocks), dim3(256), (const u64 *)cand, kf, (const u64 *)S.bitmap.p, (const u32 *)S.wrank.p, JL,
                (u32 *)S.ends.p, cand_rank, d_cs);
         if ((rc = run_scan(c, "kd_first", EndsCountFn{(const u32 *)S.ends.p}, FirstIdSink{(u32 *)S.firstid.p, (int32_t *)S.ancl.p, (int32_t *)S.ancr.p},
                            (u64)JL, (u64 *)S.total.p)))
             return rc;
-        LAUNCH(c, "kd_table", kd_table, dim3(kd_grid), dim3(256), (const u64 *)cand, (const u64 *)S.ent.p, (const u32 *)cand_rank, kf, JL,
+        LAUNCH(c, "kd_table", kd_table, dim3(pair_blocks), dim3(256), (const u64 *)cand, (const u64 *)S.ent.p, (const u32 *)cand_rank, kf, JL,
                (const u32 *)S.ends.p, (const u32 *)S.firstid.p, (const u64 *)S.total.p, (u64 *)S.jkey.p, (int32_t *)S.ancl.p, (int32_t *)S.ancr.p, d_cs);
         LAUNCH(c, "kd_assign", kd_assign, dim3(pair_blocks), dim3(256), okey, d_P, kf, (const u64 *)S.bitmap.p, (const u32 *)S.wrank.p,
                (const u32 *)S.ends.p, (const u32 *)S.firstid.p, JL, (const u64 *)S.total.p, (u32 *)S.jidbam.p, (u32 *)S.acc.p, (const u64 *)S.jkey.p,
                (const int32_t *)S.ancl.p, (const int32_t *)S.ancr.p, d_err, d_cs);
         if ((rc = fork_k4b())) return rc;
-        LAUNCH(c, "kd_reset", kd_reset, dim3(kd_grid), dim3(256), (const u64 *)cand, (const u32 *)cand_rank, kf, JL, (const ContigStats *)d_cs,
+        LAUNCH(c, "kd_reset", kd_reset, dim3(pair_blocks), dim3(256), (const u64 *)cand, (const u32 *)cand_rank, kf, JL, (const ContigStats *)d_cs,
                (u64 *)S.bitmap.p, (u32 *)S.ends.p);
         S.dense_at_rest = true;
         sort_bits = std::max(1, bits_of((uint64_t)JL));
@@ -3316,15 +3305,3 @@ extern "C" int pjb_bam_end(pjb_ctx *c, int32_t tid, int32_t first_uoffset, int64
     HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_up, 0));
     return ingest_staged(c, tid, oc, (const uint8_t *)st->dev.p, st->blocks, st->total, st->total_out, first_uoffset, n_records, st->t_scan, st->t_up);
 }
-
-#ifdef K1E_PROF
-// (profiling builds only: tools/debug/k1e_prof.py)
-extern "C" int pjb_debug_k1e_prof(unsigned long long *out16, int reset) {
-    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(pjb::k1e_prof), 16 * 8) != hipSuccess) return -1;
-    if (reset) {
-        unsigned long long z[16] = {};
-        if (hipMemcpyToSymbol(HIP_SYMBOL(pjb::k1e_prof), z, sizeof z) != hipSuccess) return -1;
-    }
-    return 0;
-}
-#endif

@@ -786,7 +786,6 @@ __global__ __launch_bounds__(256) void k1_count(DevBatch b, u32 *tile_cnt, TileS
 // seven rounds of dependent loads, 100 us alone and 310 us beside the other chains' kernels, on every chain's critical path.
 // (And one block of 1024 before that: a workgroup of 16 wavefronts needs 16 free wave slots on ONE CU at once, and beside
 // the inflate and other chains' kernels in the end-to-end run it waited for them -- 4 ms per target instead of 60 us.)
-constexpr int CAND_PER_CHUNK = 8; // candidate keys a chunk of 256 spliced reads can leave in its own slots (see k1_emit)
 constexpr int K1S_THREADS = 256, K1S_PER = 16, K1S_BLOCKS = 64;
 struct ScanPart { // what one block of k1_scan_tiles found in its range of tiles
     u64 pairs, spl, uns, sum;
@@ -1018,7 +1017,7 @@ __global__ __launch_bounds__(K1S_THREADS) void k1_scan_tiles(u32 *tile_cnt, cons
         out->P = ovf ? 0u : (u32)n_pairs;
         out->J = out->R = out->n_slots = out->n_slices = 0;
         out->n_junc = out->n_runs = 0;
-        out->n_cand = ((carry2_s + 255u) >> 8) * (u32)CAND_PER_CHUNK; // K2d: every chunk of 256 spliced reads owns CAND_PER_CHUNK candidate slots (k1_emit); the overflow list grows behind them
+        out->n_cand = 0;
     }
 }
 
@@ -1313,34 +1312,18 @@ __device__ __forceinline__ u64 simple_pair_stats(const u32 *seqw, const u32 *gco
 //   gcodes: the target's 4-bit codes; nullptr (exotic characters, an 'X' in the sequence): no read is "simple", every
 // pair goes through k4b_generic's byte-wise walks.
 // By-products, so that no later kernel has to stream over the pairs for them:
-//   * K2d's candidate keys: a chunk of 256 spliced reads touches two or three junctions; the block keeps the distinct keys of
-//     the chunk in CAND_PER_CHUNK LDS entries -- with the smallest lStart and the largest rEnd of the pairs behind each key
-//     (junction.cc:477-529: the junction anchors' first level of reduction) -- and writes them to the chunk's OWN slots
-//     of the candidate list (unused slots: KD_EMPTY).  No counter is involved: a list that every block appended to through
-//     one atomic cost a launch 200 us whatever else it did -- 4 000 returning atomics on one address, one after the
-//     other.  Only a chunk with more distinct keys than entries (long reads), and the chunk a batch shares with the batch
-//     before it, append to the overflow list behind the slots;
+//   * K2d's candidate keys: the block keeps the keys it emits in a small hash set in LDS -- with the smallest lStart and the
+//     largest rEnd of the pairs behind each key (junction.cc:477-529: the junction anchors' first level of reduction) -- and
+//     appends the distinct ones to the candidate list when the set is a quarter full (and when the block leaves); a
+//     junction appears once per residency;
 //   * the list of reads that need the generic walks (k4b_generic), in GEN_SHARDS sub-lists (one returning atomic per
 //     wavefront, spread over 256 addresses).
 constexpr int K1E_LOOK = 16;
-// K1E_PROF (tools/build_variants.sh, tools/debug/k1e_prof.py): where the wavefronts of k1_emit spend their cycles -- every probe
-// waits for the memory operations issued so far, reads the shader clock and adds the time since the last probe to its slot
-#ifdef K1E_PROF
-__device__ unsigned long long k1e_prof[16];
-#define K1E_PROBE(i)                                                   \
-    do {                                                               \
-        __builtin_amdgcn_s_waitcnt(0);                                 \
-        const unsigned long long t_ = __builtin_readcyclecounter();    \
-        prof_acc[i] += t_ - prof_t;                                    \
-        prof_t = t_;                                                   \
-    } while (0)
-#else
-#define K1E_PROBE(i) do { } while (0)
-#endif
 #ifndef K1E_WAVES
 #define K1E_WAVES 6 // wavefronts per SIMD the register allocation aims at (tools/build_variants.sh builds the others for A/B runs)
 #endif
-constexpr int K1E_T = 256, K1E_SHIFT = 8; // threads of a block = list entries of one trip = one chunk
+constexpr int K1E_T = 256, K1E_SHIFT = 8; // threads of a block = list entries of one trip
+constexpr int KC_SLOTS = K1E_T * 2;     // the block's candidate set (LDS), flushed when a quarter full
 constexpr u64 KD_EMPTY = ~0ull; // no key: a packed key has fewer than 64 bits
 constexpr u32 GEN_SHARDS = 256, GEN_CNT_STRIDE = 32;
 struct EmitLists {
@@ -1361,8 +1344,9 @@ __global__ __launch_bounds__(K1E_T) __attribute__((amdgpu_waves_per_eu(K1E_WAVES
                                                 const u32 *gcodes) {
     __shared__ u32 s_ops[OPS_LDS][K1E_T];
     __shared__ u32 s_soff[K1E_LOOK];
-    __shared__ u64 s_ck[CAND_PER_CHUNK];
-    __shared__ int32_t s_clo[CAND_PER_CHUNK], s_chi[CAND_PER_CHUNK];
+    __shared__ u64 s_set[KC_SLOTS];
+    __shared__ int32_t s_lo[KC_SLOTS], s_hi[KC_SLOTS];
+    __shared__ u32 s_set_n, s_base, s_scan[4];
     // the trip's reads that are not of the simple shape, compacted: what their walk needs (phase 2)
     enum { GQ_N = 0, GQ_POS, GQ_G, GQ_META, GQ_LQ, GQ_OFF, GQ_C0, GQ_WORDS };
     __shared__ u32 s_gq[GQ_WORDS][K1E_T];
@@ -1373,68 +1357,50 @@ __global__ __launch_bounds__(K1E_T) __attribute__((amdgpu_waves_per_eu(K1E_WAVES
     const u32 c_lo = s_begin >> K1E_SHIFT, c_hi = (s_end + (u32)K1E_T - 1u) >> K1E_SHIFT; // trips of K1E_T list entries
     const bool want_cand = E.cand != nullptr;
     const int32_t vlen = voff + ref_len; // the target's end in the group's virtual sequence
-    bool own_slots = false; // this trip's chunk has its own candidate slots (set per trip)
-    // one lane: a key with the anchors of the pairs behind it -> the chunk's entries, else the overflow list
+    if (want_cand) {
+#pragma unroll
+        for (int i = 0; i < KC_SLOTS / K1E_T; i++) {
+            s_set[i * K1E_T + threadIdx.x] = KD_EMPTY;
+            s_lo[i * K1E_T + threadIdx.x] = INT32_MAX;
+            s_hi[i * K1E_T + threadIdx.x] = INT32_MIN;
+        }
+        if (threadIdx.x == 0) s_set_n = 0;
+    }
     auto cand_insert = [&](u64 k, int32_t lstart, int32_t rend) {
-        if (own_slots) {
-#pragma unroll 1
-            for (int i = 0; i < CAND_PER_CHUNK; i++) {
-                u64 cur = s_ck[i];
-                if (cur == KD_EMPTY) {
-                    cur = atomicCAS((unsigned long long *)&s_ck[i], (unsigned long long)KD_EMPTY, (unsigned long long)k);
-                    if (cur == KD_EMPTY) cur = k;
-                }
-                if (cur == k) {
-                    atomicMin(&s_clo[i], lstart);
-                    atomicMax(&s_chi[i], rend);
-                    return;
+        u32 h = (u32)((k * 0x9E3779B97F4A7C15ull) >> 40) & (KC_SLOTS - 1);
+        for (int probe = 0; probe < 24; probe++) { // look first: most keys are there already, and a read of one address by many lanes is a broadcast
+            u64 old = s_set[h];
+            if (old == KD_EMPTY) {
+                old = atomicCAS((unsigned long long *)&s_set[h], (unsigned long long)KD_EMPTY, (unsigned long long)k);
+                if (old == KD_EMPTY) {
+                    atomicAdd(&s_set_n, 1u);
+                    old = k;
                 }
             }
+            if (old == k) {
+                if (lstart < s_lo[h]) atomicMin(&s_lo[h], lstart);
+                if (rend > s_hi[h]) atomicMax(&s_hi[h], rend);
+                return;
+            }
+            h = (h + 1) & (KC_SLOTS - 1);
         }
+        // a crowded set (reads with hundreds of introns): straight to the list, where duplicates do no harm
         const u32 at = atomicAdd(&cs->n_cand, 1u);
         E.cand[at] = k;
         E.cand_anc[at] = (u64)(u32)lstart | ((u64)(u32)rend << 32);
     };
-    // a whole wavefront: its distinct keys one after the other, the lanes of a key folded on the DPP path, one insert per key
-    auto cand_add_wave = [&](bool has, u64 k, int32_t lstart, int32_t rend) {
-        const u32 lk = (u32)lstart ^ 0x80000000u, rk = (u32)rend ^ 0x80000000u; // (signed order through the sign bit)
-        u64 todo = __ballot(has);
-        while (todo) {
-            const int first = __ffsll((long long)todo) - 1;
-            const u64 kc = (u64)(u32)__builtin_amdgcn_readlane((int)(u32)k, first) | ((u64)(u32)__builtin_amdgcn_readlane((int)(u32)(k >> 32), first) << 32);
-            const bool mine = has && k == kc;
-            const u64 m = __ballot(mine);
-            const int32_t lo = (int32_t)(wave_total<DppMin>(mine ? lk : 0xffffffffu) ^ 0x80000000u);
-            const int32_t hi = (int32_t)(wave_total<DppMax>(mine ? rk : 0u) ^ 0x80000000u);
-            if (lane_id() == first) cand_insert(kc, lo, hi);
-            todo &= ~m;
-        }
-    };
-#ifdef K1E_PROF
-    unsigned long long prof_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, prof_t = __builtin_readcyclecounter();
-#endif
     for (u32 chunk = c_lo + blockIdx.x; chunk < c_hi; chunk += gridDim.x) {
         // the tile of the chunk's first entry (for the batch's first chunk: of the batch's first entry)
         u32 t0 = (chunk << K1E_SHIFT) < s_begin ? b.tile_base : chunk_tile[chunk >> (8 - K1E_SHIFT)]; // (chunk_tile: the tile of entry 256 c)
         __syncthreads();
-        K1E_PROBE(0);
         if (threadIdx.x < K1E_LOOK) s_soff[threadIdx.x] = t0 + threadIdx.x <= n_tiles_total ? tile_soff[t0 + threadIdx.x] : 0xffffffffu;
         if (threadIdx.x == 0) s_gq_n = 0;
-        if (threadIdx.x < CAND_PER_CHUNK) {
-            s_ck[threadIdx.x] = KD_EMPTY;
-            s_clo[threadIdx.x] = INT32_MAX;
-            s_chi[threadIdx.x] = INT32_MIN;
-        }
-        own_slots = (chunk << K1E_SHIFT) >= s_begin; // (the chunk a batch shares with the batch before it belongs to that one)
         __syncthreads();
-        K1E_PROBE(1);
         const u32 s = (chunk << K1E_SHIFT) + threadIdx.x;
         const bool on = s >= s_begin && s < s_end;
         // ---- phase 1: every read's fixed-width fields and first operations; a read of the shape [S] M N M [S] (l_qseq matching, bases
         // present) is finished here, in closed form: one pair, no walk (junction_system.cc:140-210 for one N operation)
-        bool generic = false, simple_done = false;
-        u64 c_key = 0;
-        int32_t ca_lo = 0, ca_hi = 0;
+        bool generic = false;
         u32 q_n = 0, q_pos = 0, q_g = 0, q_meta = 0, q_lq = 0, q_off = 0, q_c0 = 0;
         if (on) {
             u32 k = 0; // (the offsets ascend: the entry's tile is the number of them it has reached -- 15 independent LDS reads, not a walk)
@@ -1454,10 +1420,8 @@ __global__ __launch_bounds__(K1E_T) __attribute__((amdgpu_waves_per_eu(K1E_WAVES
             const u32 toff = tile_off[tile];
             const size_t slot = (size_t)tile * K1_TILE + (s - soff);
             const int64_t r = spl_idx[slot];
-            K1E_PROBE(2);
             const u32 c0 = b.cig_off[r], c1 = b.cig_off[r + 1];
             const u32 n = c1 - c0;
-            K1E_PROBE(3);
             u32 op[OPS_LDS];
 #pragma unroll
             for (int q = 0; q < OPS_LDS; q++) { // (unconditional loads, masked: see k1_count)
@@ -1473,7 +1437,6 @@ __global__ __launch_bounds__(K1E_T) __attribute__((amdgpu_waves_per_eu(K1E_WAVES
             const int32_t lq = b.l_qseq[r];
             const u32 so = b.seq_off[r];
             const bool seq_ok = (u64)(b.seq_off[r + 1] - so) * 8ull >= (u64)(int64_t)lq;
-            K1E_PROBE(4);
             // ---- shape
             bool simple = false;
             u32 dS = 0, a = 0, nl = 0, b2 = 0;
@@ -1512,14 +1475,10 @@ __global__ __launch_bounds__(K1E_T) __attribute__((amdgpu_waves_per_eu(K1E_WAVES
                 // junction.cc:795-812 for one N operation: nothing upstream; "downstream" counts the operation itself unless its end was clamped
                 R.updown = rStartU <= iend + 1 ? 0u : (1u << 16);
                 R.aux = simple_pair_stats(reinterpret_cast<const u32 *>(b.seq4) + so, gcodes, ref_len, pos, istart - voff, iend - voff, R.rend - voff, (int32_t)dS);
-                K1E_PROBE(5);
                 P.key[off] = key;
                 if (P.g) P.g[off] = g;
                 rec_store(P.rec + off, R);
-                simple_done = true;
-                c_key = key;
-                ca_lo = R.lstart;
-                ca_hi = R.rend;
+                if (want_cand) cand_insert(key, R.lstart, R.rend);
             } else {
                 generic = true;
                 q_n = n;
@@ -1531,12 +1490,6 @@ __global__ __launch_bounds__(K1E_T) __attribute__((amdgpu_waves_per_eu(K1E_WAVES
                 q_c0 = c0;
             }
         }
-#ifdef DBG_LANE_INSERT
-        if (want_cand && simple_done) cand_insert(c_key, ca_lo, ca_hi);
-#else
-        if (want_cand) cand_add_wave(simple_done, c_key, ca_lo, ca_hi);
-#endif
-        K1E_PROBE(6);
         // ---- the other reads are compacted (LDS) ...
         {
             const u64 gm = __ballot(generic);
@@ -1561,7 +1514,6 @@ __global__ __launch_bounds__(K1E_T) __attribute__((amdgpu_waves_per_eu(K1E_WAVES
         // ---- ... and walked by the block's first threads (phase 2): a read in five takes this path, and lanes that sat between
         // the other four would have kept every wavefront in the walk's loops for nothing.  Each of these reads goes on
         // k4b_generic's list.
-        K1E_PROBE(7);
         const u32 n_gen = s_gq_n;
         const bool gen = threadIdx.x < n_gen;
         u32 gen_pairs = 0;
@@ -1607,26 +1559,40 @@ __global__ __launch_bounds__(K1E_T) __attribute__((amdgpu_waves_per_eu(K1E_WAVES
             const u32 at = base + (u32)lane_id();
             if (gen && at < E.gen_cap) E.gen_list[(size_t)shard * E.gen_cap + at] = gen_entry;
         }
-        K1E_PROBE(8);
-        // ---- the chunk's candidate keys go to its slots
-#ifdef DBG_BARRIER_D
-        __syncthreads();
-#endif
-        if (want_cand && own_slots) {
+        // ---- candidate keys: flush the set when it fills up, and before the block leaves
+        if (want_cand) {
             __syncthreads();
-            if (threadIdx.x < CAND_PER_CHUNK) {
-                const size_t at = (size_t)chunk * CAND_PER_CHUNK + threadIdx.x;
-                E.cand[at] = s_ck[threadIdx.x];
-                E.cand_anc[at] = (u64)(u32)s_clo[threadIdx.x] | ((u64)(u32)s_chi[threadIdx.x] << 32);
+            const bool last = chunk + gridDim.x >= c_hi;
+            if (s_set_n > (u32)KC_SLOTS / 4 || last) {
+                u64 mine[KC_SLOTS / K1E_T], anc[KC_SLOTS / K1E_T];
+                u32 cnt = 0;
+#pragma unroll
+                for (int i = 0; i < KC_SLOTS / K1E_T; i++) {
+                    const int at = i * K1E_T + threadIdx.x;
+                    mine[i] = s_set[at];
+                    anc[i] = (u64)(u32)s_lo[at] | ((u64)(u32)s_hi[at] << 32);
+                    cnt += mine[i] != KD_EMPTY;
+                    s_set[at] = KD_EMPTY;
+                    s_lo[at] = INT32_MAX;
+                    s_hi[at] = INT32_MIN;
+                }
+                u32 total;
+                const u32 excl = block_escan<K1E_T / 64>(cnt, s_scan, &total);
+                if (threadIdx.x == 0) {
+                    s_base = total ? atomicAdd(&cs->n_cand, total) : 0u;
+                    s_set_n = 0;
+                }
+                __syncthreads();
+                u32 o = s_base + excl;
+#pragma unroll
+                for (int i = 0; i < KC_SLOTS / K1E_T; i++)
+                    if (mine[i] != KD_EMPTY) {
+                        E.cand[o] = mine[i];
+                        E.cand_anc[o++] = anc[i];
+                    }
             }
         }
-        K1E_PROBE(9);
     }
-#ifdef K1E_PROF
-    if (lane_id() == 0)
-        for (int i = 0; i < 10; i++) atomicAdd(&k1e_prof[i], prof_acc[i]);
-    if (lane_id() == 0) atomicAdd(&k1e_prof[15], 1ull);
-#endif
 }
 
 // per-member counters of a group, from the tile statistics of the member's tiles (before k1_scan_tiles turns the tile pair
@@ -1707,18 +1673,12 @@ __device__ __forceinline__ u32 start_rank(const u64 *bitmap, const u32 *wrank, i
 // neighbouring starts) are served one after the other by a single L2 channel -- measured, 0.5 ns each, 1.4 ms for the
 // pairs of one contig.  So only the CANDIDATE list (1-3x the number of junctions) touches the bitmap and the end slots.
 // candidates -> one bit per contig base: an intron starts here
-// (the kernels over the candidate list run on a fixed grid and stride over it: the list's length is known on the device only, and
-// its capacity -- one entry per pair at worst -- is thirty times what it usually holds)
-constexpr u32 KD_GRID = 512;
 __global__ __launch_bounds__(256) void kd_mark(const u64 *cand, const ContigStats *cs, KeyFmt kf, u64 *bitmap) {
-    const u32 n = cs->P ? cs->n_cand : 0u; // (P = 0: a limit was exceeded, k1_emit wrote nothing)
-    for (u32 p = blockIdx.x * 256 + threadIdx.x; p < n; p += gridDim.x * 256) {
-        const u64 k = cand[p];
-        if (k == KD_EMPTY) continue;
-        int32_t s, e;
-        unpack_key(kf, k, s, e);
-        atomicOr((unsigned long long *)(bitmap + ((u32)s >> 6)), 1ull << (s & 63));
-    }
+    const u32 p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= cs->n_cand) return;
+    int32_t s, e;
+    unpack_key(kf, cand[p], s, e);
+    atomicOr((unsigned long long *)(bitmap + ((u32)s >> 6)), 1ull << (s & 63));
 }
 struct PopcFn {
     const u64 *words;
@@ -1726,45 +1686,38 @@ struct PopcFn {
 };
 __global__ __launch_bounds__(256) void kd_ends(const u64 *cand, KeyFmt kf, const u64 *bitmap, const u32 *wrank, u32 junc_limit, u32 *ends,
                                                u32 *cand_rank, ContigStats *cs) {
-    const u32 n = cs->P ? cs->n_cand : 0u; // (P = 0: a limit was exceeded, k1_emit wrote nothing)
-    for (u32 p = blockIdx.x * 256 + threadIdx.x; p < n; p += gridDim.x * 256) {
-        const u64 key = cand[p];
-        if (key == KD_EMPTY) continue;
-        int32_t s, e;
-        unpack_key(kf, key, s, e);
-        const u32 rs = start_rank(bitmap, wrank, s);
-        cand_rank[p] = rs;
-        if (rs >= junc_limit) {
-            atomicOr(&cs->overflow, OVF_JUNC);
-            continue;
-        }
-        u32 *slot = ends + (size_t)rs * DENSE_ENDS;
-        const u32 ue = (u32)e;
-        bool placed = false;
-        for (int k = 0; k < DENSE_ENDS && !placed; k++) {
-            const u32 cur = atomicCAS(&slot[k], DENSE_EMPTY, ue);
-            placed = cur == DENSE_EMPTY || cur == ue;
-            // else: the slot holds another end (slots never change once set)
-        }
-        if (!placed) atomicOr(&cs->overflow, OVF_DENSE);
+    const u32 p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= cs->n_cand) return;
+    int32_t s, e;
+    unpack_key(kf, cand[p], s, e);
+    const u32 rs = start_rank(bitmap, wrank, s);
+    cand_rank[p] = rs;
+    if (rs >= junc_limit) {
+        atomicOr(&cs->overflow, OVF_JUNC);
+        return;
     }
+    u32 *slot = ends + (size_t)rs * DENSE_ENDS;
+    const u32 ue = (u32)e;
+    for (int k = 0; k < DENSE_ENDS; k++) {
+        const u32 cur = atomicCAS(&slot[k], DENSE_EMPTY, ue);
+        if (cur == DENSE_EMPTY || cur == ue) return;
+        // else: the slot holds another end (slots never change once set)
+    }
+    atomicOr(&cs->overflow, OVF_DENSE);
 }
 // Bitmap and end slots are all-clear at rest: instead of two memsets over contig-sized buffers per contig, the
 // candidates wipe exactly what they set (after kd_assign has read it).
 __global__ __launch_bounds__(256) void kd_reset(const u64 *cand, const u32 *cand_rank, KeyFmt kf, u32 junc_limit, const ContigStats *cs,
                                                 u64 *bitmap, u32 *ends) {
-    const u32 n = cs->P ? cs->n_cand : 0u; // (P = 0: a limit was exceeded, k1_emit wrote nothing)
-    for (u32 p = blockIdx.x * 256 + threadIdx.x; p < n; p += gridDim.x * 256) {
-        const u64 key = cand[p];
-        if (key == KD_EMPTY) continue;
-        int32_t s, e;
-        unpack_key(kf, key, s, e);
-        bitmap[(u32)s >> 6] = 0;
-        const u32 rs = cand_rank[p];
-        if (rs < junc_limit) {
-            uint4 *q = reinterpret_cast<uint4 *>(ends + (size_t)rs * DENSE_ENDS);
-            q[0] = q[1] = make_uint4(DENSE_EMPTY, DENSE_EMPTY, DENSE_EMPTY, DENSE_EMPTY);
-        }
+    const u32 p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= cs->n_cand) return;
+    int32_t s, e;
+    unpack_key(kf, cand[p], s, e);
+    bitmap[(u32)s >> 6] = 0;
+    const u32 rs = cand_rank[p];
+    if (rs < junc_limit) {
+        uint4 *q = reinterpret_cast<uint4 *>(ends + (size_t)rs * DENSE_ENDS);
+        q[0] = q[1] = make_uint4(DENSE_EMPTY, DENSE_EMPTY, DENSE_EMPTY, DENSE_EMPTY);
     }
 }
 struct EndsCountFn {
@@ -1853,24 +1806,22 @@ __global__ __launch_bounds__(256) void kd_table(const u64 *cand, const u64 *cand
             cs->n_slots = (u32)J + (n_pairs + 63) / 64;
         }
     }
-    const u32 n = cs->P ? cs->n_cand : 0u; // (P = 0: a limit was exceeded, k1_emit wrote nothing)
-    for (u32 base = blockIdx.x * 256; base < n; base += gridDim.x * 256) { // (whole wavefronts: anchors_fold works across the lanes)
-        const u32 q = base + threadIdx.x;
-        const bool on = q < n;
-        const u32 pc = on ? q : n - 1;
-        const u32 rs = cand_rank[pc];
-        const u64 k = cand[pc], a = cand_anc[pc];
-        bool valid = on && k != KD_EMPTY && rs < junc_limit;
-        u32 id = 0xffffffffu;
-        if (valid) {
-            int32_t s, e;
-            unpack_key(kf, k, s, e);
-            id = first_id[rs] + ends_below(ends, rs, (u32)e);
-            valid = id < junc_limit;
-            if (valid) jkey[id] = k;
-        }
-        anchors_fold(valid, id, (int32_t)(u32)a, (int32_t)(u32)(a >> 32), anc_l, anc_r);
+    const u32 n = cs->n_cand;
+    if (blockIdx.x * 256u >= n) return;
+    const bool on = p < n;
+    const u32 pc = on ? p : n - 1;
+    const u32 rs = cand_rank[pc];
+    const u64 k = cand[pc], a = cand_anc[pc];
+    bool valid = on && rs < junc_limit;
+    u32 id = 0xffffffffu;
+    if (valid) {
+        int32_t s, e;
+        unpack_key(kf, k, s, e);
+        id = first_id[rs] + ends_below(ends, rs, (u32)e);
+        valid = id < junc_limit;
+        if (valid) jkey[id] = k;
     }
+    anchors_fold(valid, id, (int32_t)(u32)a, (int32_t)(u32)(a >> 32), anc_l, anc_r);
 }
 
 // fragment record of the per-junction reductions: 48 words (see k4_pairs)
