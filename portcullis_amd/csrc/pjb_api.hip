@@ -361,6 +361,14 @@ int ensure(pjb_ctx *c, Buf &b, size_t bytes) {
         if (e != hipSuccess) return fail(c, PJB_ERR_NOMEM, "hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
     }
     b.cap = want;
+    // test hook (tests/test_gpu_poison.py): PJB_POISON=1 fills every new device buffer with a pattern.  Fresh device memory is
+    // usually zero, and a kernel that reads what nobody wrote gets away with it until the allocator hands out a used page
+    // (round 4: one run of `junc` in thirty died of it); with the pattern it fails every time.
+    static const bool poison = getenv("PJB_POISON") != nullptr && strcmp(getenv("PJB_POISON"), "0") != 0;
+    if (poison) {
+        (void)hipMemset(b.p, 0xCD, want);
+        (void)hipDeviceSynchronize();
+    }
     return PJB_OK;
 }
 
@@ -481,13 +489,16 @@ bool ktime_wanted(pjb_ctx *c, const char *name) {
         (void)hipStreamSynchronize((c)->stream);                    \
         fprintf(stderr, "[launch] %s done\n", name);                \
     } while (0)
+#define PJB_LAUNCH_ANNOUNCE(name) fprintf(stderr, "[launch] %s ...\n", name)
 #else
 #define PJB_LAUNCH_TRACE(c, name) do { } while (0)
+#define PJB_LAUNCH_ANNOUNCE(name) do { } while (0)
 #endif
 #define LAUNCH_LDS(c, name, kern, grid, block, lds_bytes, ...)                       \
     do {                                                                            \
         const bool timed_ = ktime_wanted((c), name);                                \
         if (timed_) ev_begin((c), name);                                            \
+        PJB_LAUNCH_ANNOUNCE(name);                                                  \
         hipLaunchKernelGGL(kern, grid, block, lds_bytes, (c)->stream, __VA_ARGS__); \
         if (timed_) ev_end((c));                                                    \
         HIP_TRY((c), hipGetLastError());                                            \
@@ -1783,6 +1794,44 @@ static int queue_contig(pjb_ctx *c, Flight &f) {
         STAGE_EVENT(3);
         STAGE_EVENT(4);
         if (f.forked) HIP_TRY(c, hipStreamWaitEvent(tl, S.ev_join, 0)); // k4b_generic's results (side stream) are needed from here on
+#ifdef DBG_FRAGJ_MEMSET
+        HIP_TRY(c, hipMemsetAsync(S.fragj.p, 0xff, (size_t)slots_lim * 4, tl));
+#endif
+#ifdef PJB_DEBUG_LAUNCH
+        fprintf(stderr, "[k4_pairs] tid %d PL %u JL %u slots_lim %u n_slices_lim %u frag cap %zu fragj cap %zu masks cap %zu rec cap %zu idx cap %zu key cap %zu jkey cap %zu cur %d n_pass %d\n",
+                f.tid, PL, JL, slots_lim, n_slices_lim, S.frag.cap, S.fragj.cap, S.masks.cap, S.rec.cap, S.idx[cur].cap, S.key[cur].cap, S.jkey.cap, cur, n_pass);
+        {
+            ContigStats hcs;
+            (void)hipDeviceSynchronize();
+            (void)hipMemcpy(&hcs, d_cs, sizeof hcs, hipMemcpyDeviceToHost);
+            u64 htot = 0;
+            (void)hipMemcpy(&htot, S.total.p, 8, hipMemcpyDeviceToHost);
+            fprintf(stderr, "[k4_pairs] cs: P %u n_pairs %llu J %u n_junc %u n_slots %u n_slices %u n_cand %u overflow %u R %u total %llu slot %d attempt %d\n", hcs.P,
+                    (unsigned long long)hcs.n_pairs, hcs.J, hcs.n_junc, hcs.n_slots, hcs.n_slices, hcs.n_cand, hcs.overflow, hcs.R, (unsigned long long)htot, f.slot, f.attempt);
+            // is the sort's output a permutation with ascending ids?  is its input what kd_assign wrote?
+            std::vector<u32> hs(hcs.P), hj(hcs.P), hb(hcs.P);
+            (void)hipMemcpy(hs.data(), sidx, (size_t)hcs.P * 4, hipMemcpyDeviceToHost);
+            (void)hipMemcpy(hj.data(), jid_sorted, (size_t)hcs.P * 4, hipMemcpyDeviceToHost);
+            (void)hipMemcpy(hb.data(), S.jidbam.p, (size_t)hcs.P * 4, hipMemcpyDeviceToHost);
+            std::vector<char> seen(hcs.P, 0);
+            size_t bad_idx = 0, dup = 0, bad_order = 0, bad_in = 0, mism = 0;
+            long first_bad = -1;
+            for (size_t i = 0; i < hcs.P; i++) {
+                if (hb[i] >= hcs.J) bad_in++;
+                if (hs[i] >= hcs.P) {
+                    bad_idx++;
+                    if (first_bad < 0) first_bad = (long)i;
+                    continue;
+                }
+                if (seen[hs[i]]) dup++;
+                seen[hs[i]] = 1;
+                if (hj[i] != hb[hs[i]]) mism++;
+                if (i && hj[i] < hj[i - 1]) bad_order++;
+            }
+            fprintf(stderr, "[k4_pairs] sort check: %zu indices out of range (first at %ld), %zu duplicates, %zu order breaks, %zu key/index mismatches, %zu input ids >= J\n", bad_idx,
+                    first_bad, dup, bad_order, mism, bad_in);
+        }
+#endif
         LAUNCH(c, "k4_pairs", k4_pairs, dim3(pair_blocks), dim3(256), sidx, jid_sorted, (const PairRec *)pr.rec, (const u64 *)S.jkey.p, kf, d_P,
                (u32 *)S.frag.p, (int32_t *)S.fragj.p, head_mask, run_mask, (const ContigStats *)d_cs, d_err);
         if ((rc = run_scan(c, "k2_runs", Popc64Fn{(const u64 *)run_mask}, ExclusiveU32Sink{run_base}, (u64)n_slices_lim, (u64 *)S.total.p, &d_cs->n_slices)))

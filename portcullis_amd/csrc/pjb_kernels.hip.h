@@ -2576,6 +2576,9 @@ __global__ __launch_bounds__(256) void k4_pairs(const u32 *sidx, const u32 *jid_
         else if (jv != jb && jv != jb + 1) bad = 3;
         else if (ic == 0 && jv != 0) bad = 4;
         else if (ic == n - 1 && jv != Jc - 1) bad = 5;
+        else if (jv + (ic >> 6) + 1 >= cs_chk->n_slots) bad = 6;
+        else if ((ic >> 6) >= cs_chk->n_slices) bad = 7;
+        else if (cs_chk->n_slots != Jc + (n + 63) / 64) bad = 8;
         if (__ballot(bad != 0)) {
             if (bad) set_error(err_chk, 0xffffe000u + (u32)bad, PJB_ERR_HIP);
             return;
@@ -2587,7 +2590,7 @@ __global__ __launch_bounds__(256) void k4_pairs(const u32 *sidx, const u32 *jid_
     // the pair before this one in sorted order: the neighbouring lane's -- lane 0 fetches it
     u32 jprev_v = __shfl_up(jv, 1, 64);
     int32_t pos_prev = __shfl_up(Rc.pos, 1, 64), aend_prev = __shfl_up(Rc.aend, 1, 64);
-    if (lane == 0 && i > 0) {
+    if (lane == 0 && valid && i > 0) { // (valid: a wavefront past the end must not follow whatever lies behind the sorted indices)
         jprev_v = jid_of[i - 1];
         const uint4 q = reinterpret_cast<const uint4 *>(rec + sidx[i - 1])[1];
         pos_prev = (int32_t)q.x;
