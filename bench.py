@@ -491,16 +491,6 @@ def main():
             "datagen_s": round(t_gen, 2),
         }
         os.write(real_stdout, (json.dumps(result) + "\n").encode())
-    if os.environ.get("PJB_BENCH_K1E_PROF"):  # (profiling build of the library, tools/build_variants.sh prof=-DK1E_PROF: cycles per phase of k1_emit)
-        import ctypes
-        arr = (ctypes.c_ulonglong * 16)()
-        ffi.load().pjb_debug_k1e_prof(arr, 1)
-        tot = sum(arr[:10]) or 1
-        names = ["loop top + barrier", "tile offsets -> LDS + barrier", "tile_off / spl_idx / spl_poff", "cig_off", "ops + fields", "simple: closed form + compare",
-                 "stores + candidate insert (+ waiting lanes)", "compaction + barrier", "phase 2 (walk) + list", "flush"]
-        sys.stderr.write("k1_emit cycles per phase (share of wave time), waves %d:\n" % arr[15])
-        for i in range(10):
-            sys.stderr.write("  %-46s %6.2f %%  %10.0f cycles/wave\n" % (names[i], 100.0 * arr[i] / tot, arr[i] / max(arr[15], 1)))
     ctx.set_row_mirror(0, 0)
     ctx.close()
     if multi:

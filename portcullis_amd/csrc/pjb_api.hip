@@ -260,12 +260,7 @@ struct pjb_ctx {
     // counters (k7_publish; per slot), start bitmap / end slots (kd_reset).  false: set by a memset before use
     int last_slot = 0; // slot of the contig collected last (pjb_collect_device)
     int inflate_lanes = 512 * 64;                // lanes of one bgzf_inflate launch (2 workgroups x 256 CUs; set from the device at create)
-#ifdef DBG_NO_SIDE
-    bool side_stream = false;
-#else
-    bool side_stream = true;
-#endif
-    bool _side_stream_doc_;                     // k4a_simple beside the sort (PJB_SIDE_STREAM=0: on the main stream)
+    bool side_stream = true;                     // k4b_generic / entropy beside the main stream (pjb_set_option("overlap", 0): everything on one stream)
     bool dense_ids = true;                       // K2d (PJB_DENSE_IDS=0 sorts the full keys as round 1 did)
     u32 junc_seen = 0;                           // most junctions a contig has had so far (junction limit of the next contig)
     int lbits_seen = 18;                         // bits of the longest intron this context has met (key format of the next contig)
@@ -1652,9 +1647,6 @@ static int queue_contig(pjb_ctx *c, Flight &f) {
         return PJB_OK;
     };
     auto fork_k4b = [&]() -> int { // (the main stream has just produced jid_bam and the anchors)
-#ifdef DBG_K4B_INLINE
-        return launch_k4b();
-#endif
         if (!c->side_stream) return launch_k4b();
         HIP_TRY(c, hipEventRecord(S.ev_fork, st));
         HIP_TRY(c, hipStreamWaitEvent(S.side, S.ev_fork, 0));
@@ -1770,9 +1762,6 @@ static int queue_contig(pjb_ctx *c, Flight &f) {
     };
     bool entropy_forked = false;
     auto fork_entropy = [&]() -> int { // the entropy kernels beside what follows on the main stream (small and latency-bound, both)
-#ifdef DBG_ENT_INLINE
-        return entropy_kernels();
-#endif
         if (!c->side_stream) return entropy_kernels();
         HIP_TRY(c, hipEventRecord(S.ev_fork2, st));
         HIP_TRY(c, hipStreamWaitEvent(S.side, S.ev_fork2, 0));
@@ -1794,9 +1783,6 @@ static int queue_contig(pjb_ctx *c, Flight &f) {
         STAGE_EVENT(3);
         STAGE_EVENT(4);
         if (f.forked) HIP_TRY(c, hipStreamWaitEvent(tl, S.ev_join, 0)); // k4b_generic's results (side stream) are needed from here on
-#ifdef DBG_FRAGJ_MEMSET
-        HIP_TRY(c, hipMemsetAsync(S.fragj.p, 0xff, (size_t)slots_lim * 4, tl));
-#endif
 #ifdef PJB_DEBUG_LAUNCH
         fprintf(stderr, "[k4_pairs] tid %d PL %u JL %u slots_lim %u n_slices_lim %u frag cap %zu fragj cap %zu masks cap %zu rec cap %zu idx cap %zu key cap %zu jkey cap %zu cur %d n_pass %d\n",
                 f.tid, PL, JL, slots_lim, n_slices_lim, S.frag.cap, S.fragj.cap, S.masks.cap, S.rec.cap, S.idx[cur].cap, S.key[cur].cap, S.jkey.cap, cur, n_pass);

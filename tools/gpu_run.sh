@@ -26,7 +26,6 @@ for step in "$@"; do
            python3 tools/show_bench.py $OUT/${TAG}_quick.json ;;
     quick:*) v=${step#quick:}; PJB_BENCH_ABLATION=1 PJB_LIB_PATH=$PWD/tools/variants/libpjb_$v.so timeout 900 python bench.py --steps 10 --warmup 3 --no-e2e --no-cpu-baseline > $OUT/${TAG}_quick_$v.json 2> $OUT/${TAG}_quick_$v.err; tail -c 300 $OUT/${TAG}_quick_$v.err
            python3 tools/show_bench.py $OUT/${TAG}_quick_$v.json | head -12 ;;
-    k1eprof) PJB_BENCH_K1E_PROF=1 PJB_LIB_PATH=$PWD/tools/variants/libpjb_prof.so timeout 900 python bench.py --steps 5 --warmup 2 --no-e2e --no-cpu-baseline 2>&1 >/dev/null | grep -A12 "k1_emit cycles" | tee $OUT/${TAG}_k1e_prof.txt ;;
     bench) ( time python bench.py > $OUT/${TAG}_bench_C3.json 2> $OUT/${TAG}_bench.err ) 2>&1 | tail -4; tail -c 400 $OUT/${TAG}_bench.err
            python3 tools/show_bench.py $OUT/${TAG}_bench_C3.json ;;
     prof) bash tools/profile_round.sh $TAG ${COMMIT:-unknown}; python3 tools/show_bench.py $OUT/${TAG}_bench_C3.json ;;
