@@ -1643,7 +1643,7 @@ static int queue_contig(pjb_ctx *c, Flight &f) {
     auto launch_k4b = [&]() -> int {
         LAUNCH(c, "k4b_generic", k4b_generic, dim3(gen_grid), dim3(256), (const u64 *)S.genlist.p, (const u32 *)d_gen_cnt, gen_cap, (const u64 *)pr.key,
                pr.rec, (const u32 *)S.jidbam.p, kf, (const DevBatch *)S.batches.p, (int)batches.size(), (const int32_t *)S.ancl.p, (const int32_t *)S.ancr.p,
-               GT, any_x ? 1 : 0, any_x ? 0 : 1, d_err);
+               GT, any_x ? 1 : 0, any_x ? 0 : 1, d_err, (const ContigStats *)d_cs);
         return PJB_OK;
     };
     auto fork_k4b = [&]() -> int { // (the main stream has just produced jid_bam and the anchors)

@@ -2494,8 +2494,9 @@ __device__ __forceinline__ const DevBatch &find_batch(const DevBatch *batches, i
 // goes into the pair's record.  Runs on the side stream, beside the sort.
 __global__ __launch_bounds__(256) void k4b_generic(const u64 *list, const u32 *gen_cnt, u32 cap, const u64 *key, PairRec *rec, const u32 *jid_bam,
                                                     KeyFmt kf, const DevBatch *batches, int n_batches, const int32_t *anc_l, const int32_t *anc_r,
-                                                    GroupTab G, int genome_has_x, int use_codes, u64 *err) {
+                                                    GroupTab G, int genome_has_x, int use_codes, u64 *err, const ContigStats *cs) {
     __shared__ u32 s_ops[OPS_LDS][256];
+    if (cs->P == 0) return; // (a limit was exceeded while the junction ids were built: there are no ids, the chain is repeated)
     // sub-list `shard` occupies [shard * cap, shard * cap + n_list[shard])
     const u32 t = blockIdx.x * 256 + threadIdx.x;
     const u32 shard = t / cap, k_in = t % cap;
