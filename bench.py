@@ -466,6 +466,10 @@ def main():
                                       "one RCCL all-gather of rows + counters per step"),
                        "reads_total": N_total, "junctions_total": J_total, "contigs": len(cfgs),
                        "contigs_per_rank": [len(s) for s in shards], "reads_rank0": N_mine, "pairs_rank0": P_mine,
+                       # the deal of targets to ranks (longest-processing-time by read count, distributed.shard_contigs): what an N-GPU run of
+                       # this workload can be at best -- step time ~ max shard, so speed-up <= N / max_over_mean -- for 1, 2, 4 and 8 ranks
+                       "lpt_balance": lpt_balance([c.n_reads for c in cfgs], world, pd),
+                       "lpt_balance_by_ranks": {str(k): lpt_balance([c.n_reads for c in cfgs], k, pd)["max_over_mean_reads"] for k in (1, 2, 4, 8)},
                        "sharding": "by contig", "input": "device-resident SoA records (pjb_submit_batch_device)",
                        "chains": [len(g) for g in chains],
                        "queue": (f"{len(chains)} kernel chains per step, each over a group of consecutive targets (pjb_finish_group_begin / _end), "
@@ -495,6 +499,13 @@ def main():
     ctx.close()
     if multi:
         dist.destroy_process_group()
+
+
+def lpt_balance(reads, ranks, pd):
+    sh = pd.shard_contigs(reads, ranks)
+    per = [sum(reads[t] for t in s_) for s_ in sh]
+    mean = sum(per) / max(len(per), 1)
+    return {"ranks": ranks, "reads_per_rank": per, "max_over_mean_reads": round(max(per) / mean, 4) if mean else None}
 
 
 def host_cores():

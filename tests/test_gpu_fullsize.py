@@ -135,6 +135,19 @@ def test_bench_two_ranks_share_one_gpu():
     assert sorted(d["config"]["contigs_per_rank"]) == [12, 13] and d["config"]["junctions_total"] == d["multi_gpu_check"]["rows"]
 
 
+def test_bench_eight_ranks_share_one_gpu():
+    """BASELINE configs[3] / [4] in miniature: `bench.py --gpus 8`, eight ranks on one GPU (gloo exchange), the 25 targets dealt out
+    by read count; rank 0's merged table equals the single-context table byte for byte, every rank got targets, and the line
+    carries the balance of the deal (max shard / mean shard) that a real 8-GPU run can be held against."""
+    d = _run_bench(["--gpus", "8"], {"PJB_BENCH_SHARE_GPU": "1"}, timeout=1500)
+    assert d["n_gpus"] == 8 and d["scaling"] == "strong"
+    assert d["multi_gpu_check"]["merged_equals_single_gpu_table"] is True
+    per = d["config"]["contigs_per_rank"]
+    assert len(per) == 8 and sum(per) == 25 and min(per) >= 1
+    bal = d["config"]["lpt_balance"]
+    assert bal["ranks"] == 8 and 1.0 <= bal["max_over_mean_reads"] < 1.25 and len(bal["reads_per_rank"]) == 8
+
+
 def test_bench_line_small_workload(tmp_path):
     """The whole bench line (roofline, cpu_baseline over every contig with parity, e2e through BAM bytes) on a
     scaled-down 25-contig set."""
@@ -171,8 +184,35 @@ def c3_full():
             regs.append(ctx.finish_contig(tid))
         return ctx.collect(), regs
 
+    def run_groups(queue=3, group_bases=1 << 29):
+        """the bench's step: chains over groups of consecutive targets (pjb_finish_group_begin / _end), `queue` of them in flight"""
+        ctx.clear_rows()
+        chains = ffi.plan_groups([c.contig_len for c in cfgs], list(range(len(cfgs))), group_bases)
+        regs, queued = {}, []
+
+        def collect():
+            g = queued.pop(0)
+            if len(g) == 1:
+                regs[g[0]] = ctx.finish_contig_end(g[0])
+            else:
+                regs.update(ctx.finish_group_end(g))
+
+        for g in chains:
+            for tid in g:
+                ctx.submit_batch_device(tid, data[tid]["batch"], data[tid]["n_reads"])
+            if len(g) == 1:
+                ctx.finish_contig_begin(g[0])
+            else:
+                ctx.finish_group_begin(g)
+            queued.append(g)
+            if len(queued) >= queue:
+                collect()
+        while queued:
+            collect()
+        return ctx.collect(), [regs[t] for t in range(len(cfgs))], chains
+
     rows, regs = run()
-    yield cfgs, data, rows, regs, run
+    yield cfgs, data, rows, regs, run, run_groups
     ctx.close()
 
 
@@ -180,7 +220,7 @@ def test_c3_fullsize_properties_and_oracle(c3_full):
     from oracle import oracle as orc
     from portcullis_amd import synth
 
-    cfgs, data, rows, regs, run = c3_full
+    cfgs, data, rows, regs, run, run_groups = c3_full
     n_reads = sum(c.n_reads for c in cfgs)
     n_pairs = sum(d["n_pairs"] for d in data)
     assert n_reads >= 199_999_000 and len(cfgs) == 25
@@ -201,6 +241,20 @@ def test_c3_fullsize_properties_and_oracle(c3_full):
         region_equal(regs[tid], oreg)
         worst = max(worst, assert_rows_equal(rows[rows["refid"] == tid], orows))
     assert worst <= 1e-6
+
+
+def test_c3_fullsize_group_chains_equal_per_target_chains(c3_full):
+    """The bench's step at full size -- seven chains over groups of consecutive targets, three in flight -- must give, byte for
+    byte, the row table of the per-target chains (which the test above holds against the oracle), and every target's counters."""
+    cfgs, data, rows, regs, run, run_groups = c3_full
+    grows, gregs, chains = run_groups()
+    assert len(chains) == 7 and sorted(t for g in chains for t in g) == list(range(25))
+    assert hashlib.md5(grows.tobytes()).hexdigest() == hashlib.md5(rows.tobytes()).hexdigest()
+    for a, b in zip(gregs, regs):
+        region_equal(a, b)
+        assert a["n_pairs"] == b["n_pairs"] and a["n_junctions"] == b["n_junctions"]
+    g2, _, _ = run_groups(queue=1, group_bases=1 << 30)   # other group sizes, one chain at a time: the same table
+    assert hashlib.md5(g2.tobytes()).hexdigest() == hashlib.md5(rows.tobytes()).hexdigest()
 
 
 # ---- BASELINE configs[4], one rank's share: 125 M reads of a 1 B-read run on one 248 Mb contig, 300 k junctions,

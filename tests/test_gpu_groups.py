@@ -184,3 +184,116 @@ def test_group_refusals(ffi, orc):
             ctx.finish_group_begin([0, 1])
         ctx.finish_contig(0)
         ctx.finish_contig(1)
+
+
+# ---- the limits (include/portcullis_amd.h: PJB_GROUP_MAX members, a virtual sequence below 2^31 bases, pair limit of a chain)
+def test_group_of_the_maximum_number_of_members(ffi, orc):
+    """PJB_GROUP_MAX (32) targets in one chain -- some of them without a single alignment -- and one more is refused."""
+    seeds = list(range(300, 300 + ffi.GROUP_MAX + 1))
+    contigs = _contigs(orc, seeds, n_reads=300)
+    for k in (3, 17, ffi.GROUP_MAX - 1):  # members without reads
+        g, b, _, _ = contigs[k]
+        contigs[k] = (g, None, np.zeros(0, dtype=ffi.ROW_DTYPE), None)
+    with ffi.Context(0, "FR") as ctx:
+        _setup(ctx, contigs)
+        for tid, (_, b, _, _) in enumerate(contigs):
+            if b is not None:
+                ctx.submit_batch(tid, b)
+        with pytest.raises(ffi.PjbError):
+            ctx.finish_group_begin(list(range(ffi.GROUP_MAX + 1)))
+        members = list(range(ffi.GROUP_MAX))
+        ctx.finish_group_begin(members)
+        regs = ctx.finish_group_end(members)
+        last = ctx.finish_contig(ffi.GROUP_MAX)
+        rows = ctx.collect()
+    want = np.concatenate([c[2] for c in contigs])
+    assert_rows_equal(rows, want)
+    for tid in members:
+        if contigs[tid][3] is not None:
+            region_equal(regs[tid], contigs[tid][3])
+        else:
+            assert regs[tid]["n_reads"] == 0 and regs[tid]["n_junctions"] == 0
+    region_equal(last, contigs[ffi.GROUP_MAX][3])
+
+
+def test_group_just_under_two_to_the_31_bases(ffi, orc):
+    """A group's virtual sequence must stay below 2^31 bases: three targets declared 700 Mb long (their alignments sit in the first
+    30 kb; the genome a chain reads is the uploaded one, so the upload is a device buffer of zeros with the real bases in front)
+    make a group of 2.1 G -- refused -- while two of them plus a small one (1.4 G: virtual offsets far beyond 2^30) work."""
+    import torch
+    contigs = _contigs(orc, (411, 412, 413, 414), n_reads=1500)
+    big = 700_000_000
+    lens = [big, big, big, len(contigs[3][0])]
+    with ffi.Context(0, "FR") as ctx:
+        ctx.set_refs(lens)
+        keep = []
+        for tid in range(3):
+            g = contigs[tid][0].encode()
+            d = torch.full((big,), ord("N"), dtype=torch.uint8, device="cuda")
+            d[: len(g)] = torch.frombuffer(bytearray(g), dtype=torch.uint8).cuda()
+            ctx.upload_contig_device(tid, d)
+            keep.append(d)
+        ctx.upload_contig(3, contigs[3][0].encode())
+        # the oracle saw targets of 30 kb; rows depend on the target's length only through clamps at its end, which these reads never reach
+        ctx.clear_rows()
+        for tid in range(4):
+            ctx.submit_batch(tid, contigs[tid][1])
+        with pytest.raises(ffi.PjbError):
+            ctx.finish_group_begin([0, 1, 2])          # 2.1 G bases
+        ctx.finish_group_begin([0, 1, 3])              # 1.4 G: member 3 starts beyond 2^30
+        regs = ctx.finish_group_end([0, 1, 3])
+        r2 = ctx.finish_contig(2)
+        rows = ctx.collect()
+        for tid in (0, 1, 3):
+            region_equal(regs[tid], contigs[tid][3])
+        region_equal(r2, contigs[2][3])
+        want = np.concatenate([contigs[t][2] for t in (0, 1, 3, 2)])
+        assert_rows_equal(rows, want)
+        del keep
+
+
+def test_pair_limit_overflow_inside_a_group(ffi, orc):
+    """A chain is queued with room for 5/8 pairs per alignment (+ 4096); reads with many introns each exceed that: the control block
+    reports the overflow, the group is repeated once with the exact count -- and the chain queued behind it with it."""
+    def many_intron_reads(seed, n):
+        rng = np.random.default_rng(seed)
+        genome = "".join(rng.choice(list("ACGT"), size=60000))
+        reads = []
+        for k in range(n):
+            pos = int(rng.integers(0, 2000))
+            segs = int(rng.integers(6, 10))
+            cigar, seq, r = "", [], pos
+            for s in range(segs):
+                m = int(rng.integers(8, 20))
+                cigar += f"{m}M"
+                seq.append(genome[r:r + m])
+                r += m
+                if s + 1 < segs:
+                    nl = int(rng.integers(50, 300))
+                    cigar += f"{nl}N"
+                    r += nl
+            reads.append(dict(pos=pos, cigar=cigar, seq="".join(seq), flag=0, mapq=60, xs="+", mtid=-1, mpos=-1))
+        reads.sort(key=lambda x: x["pos"])
+        return genome, reads
+
+    contigs = []
+    for tid, (seed, n) in enumerate(((901, 9000), (902, 7000), (903, 2500))):
+        genome, reads = many_intron_reads(seed, n)
+        batch = to_batch(reads)
+        orows, oreg = orc.find_juncs(tid, len(genome), genome, batch, "UNKNOWN")
+        assert oreg["spliced"] == n and len(orows) > 100
+        contigs.append((genome, batch, orows, oreg))
+    with ffi.Context(0, "UNKNOWN") as ctx:
+        _setup(ctx, contigs)
+        for tid, (_, b, _, _) in enumerate(contigs):
+            ctx.submit_batch(tid, b)
+        ctx.finish_group_begin([0, 1])     # ~100 k pairs from 16 k alignments: over the limit
+        ctx.finish_contig_begin(2)         # queued behind it
+        regs = ctx.finish_group_end([0, 1])
+        r2 = ctx.finish_contig_end(2)
+        rows = ctx.collect()
+    for tid in (0, 1):
+        region_equal(regs[tid], contigs[tid][3])
+        assert regs[tid]["n_pairs"] > 5 * regs[tid]["n_reads"]
+    region_equal(r2, contigs[2][3])
+    assert_rows_equal(rows, np.concatenate([c[2] for c in contigs]))
