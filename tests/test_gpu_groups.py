@@ -192,8 +192,8 @@ def test_group_of_the_maximum_number_of_members(ffi, orc):
     seeds = list(range(300, 300 + ffi.GROUP_MAX + 1))
     contigs = _contigs(orc, seeds, n_reads=300)
     for k in (3, 17, ffi.GROUP_MAX - 1):  # members without reads
-        g, b, _, _ = contigs[k]
-        contigs[k] = (g, None, np.zeros(0, dtype=ffi.ROW_DTYPE), None)
+        g, b, orows, _ = contigs[k]
+        contigs[k] = (g, None, orows[:0], None)
     with ffi.Context(0, "FR") as ctx:
         _setup(ctx, contigs)
         for tid, (_, b, _, _) in enumerate(contigs):
