@@ -228,7 +228,7 @@ def test_group_just_under_two_to_the_31_bases(ffi, orc):
         ctx.set_refs(lens)
         keep = []
         for tid in range(3):
-            g = contigs[tid][0].encode()
+            g = contigs[tid][0].upper().encode()   # (pjb_upload_contig_device takes upper-cased bases)
             d = torch.full((big,), ord("N"), dtype=torch.uint8, device="cuda")
             d[: len(g)] = torch.frombuffer(bytearray(g), dtype=torch.uint8).cuda()
             ctx.upload_contig_device(tid, d)
