@@ -217,12 +217,12 @@ def test_group_of_the_maximum_number_of_members(ffi, orc):
 
 
 def test_group_just_under_two_to_the_31_bases(ffi, orc):
-    """A group's virtual sequence must stay below 2^31 bases: three targets declared 700 Mb long (their alignments sit in the first
+    """A group's virtual sequence must stay below 2^31 bases: three targets declared 720 Mb long (their alignments sit in the first
     30 kb; the genome a chain reads is the uploaded one, so the upload is a device buffer of zeros with the real bases in front)
-    make a group of 2.1 G -- refused -- while two of them plus a small one (1.4 G: virtual offsets far beyond 2^30) work."""
+    make a group of 2.16 G (2^31 = 2.147 G) -- refused -- while two of them plus a small one (1.44 G: virtual offsets far beyond 2^30) work."""
     import torch
     contigs = _contigs(orc, (411, 412, 413, 414), n_reads=1500)
-    big = 700_000_000
+    big = 720_000_000
     lens = [big, big, big, len(contigs[3][0])]
     with ffi.Context(0, "FR") as ctx:
         ctx.set_refs(lens)
@@ -239,8 +239,8 @@ def test_group_just_under_two_to_the_31_bases(ffi, orc):
         for tid in range(4):
             ctx.submit_batch(tid, contigs[tid][1])
         with pytest.raises(ffi.PjbError):
-            ctx.finish_group_begin([0, 1, 2])          # 2.1 G bases
-        ctx.finish_group_begin([0, 1, 3])              # 1.4 G: member 3 starts beyond 2^30
+            ctx.finish_group_begin([0, 1, 2])          # 2.16 G bases
+        ctx.finish_group_begin([0, 1, 3])              # 1.44 G: member 3 starts beyond 2^30
         regs = ctx.finish_group_end([0, 1, 3])
         r2 = ctx.finish_contig(2)
         rows = ctx.collect()
