@@ -1831,7 +1831,7 @@ static int queue_contig(pjb_ctx *c, Flight &f) {
         // every pair's read position), the junctions' keys, anchors, ids in BAM order -- then the generic pairs and K4
         const u64 *skey = (const u64 *)S.key[cur].p;
         HeadFn hf{skey, sidx, (const PairRec *)pr.rec};
-        HeadSink hs{(u32 *)S.jid.p, (u32 *)S.seg.p, (u32 *)S.runfirst.p, (u32 *)S.runstart.p, skey, (u64 *)S.jkey.p};
+        HeadSink hs{(u32 *)S.jid.p, (u32 *)S.seg.p, (u32 *)S.runfirst.p, (u32 *)S.runstart.p, skey, (u64 *)S.jkey.p, JL};
         if ((rc = run_scan(c, "k2_heads", hf, hs, (u64)PL, (u64 *)S.total.p, d_P))) return rc;
         LAUNCH(c, "k2_close", k2_close, dim3(1), dim3(1), (u64 *)S.total.p, (u32 *)S.seg.p, (u32 *)S.runfirst.p,
                (u32 *)S.runstart.p, d_cs, JL);

@@ -2172,6 +2172,7 @@ struct HeadSink {
     u32 *run_start; // [R+1] first sorted pair of run
     const u64 *skey;
     u64 *jkey;      // [J]   intron key of the junction -- when the sort ran on the full keys (nullptr: K2d left the table)
+    u32 junc_limit; //       entries jkey has (the other arrays are pair-sized; k2_close stops the chain when there are more heads)
     __device__ void operator()(u64 i, u64 v, u64 ex) const {
         const u32 j = (u32)(ex >> 32) + (u32)(v >> 32) - 1; // inclusive count - 1
         const u32 r = (u32)ex + (u32)v - 1;
@@ -2179,7 +2180,7 @@ struct HeadSink {
         if (v >> 32) {
             seg_off[j] = (u32)i;
             run_first[j] = r;
-            if (jkey) jkey[j] = skey[i];
+            if (jkey && j < junc_limit) jkey[j] = skey[i];
         }
         if ((u32)v) run_start[r] = (u32)i;
     }
