@@ -1490,7 +1490,7 @@ static int queue_contig(pjb_ctx *c, Flight &f) {
     if ((rc = ensure(c, S.ent, (size_t)PL * 8 + 16))) return rc;
     const u32 pair_blocks = std::max<u32>(1, (PL + 255) / 256);
     const u32 gen_cap = gen_list_cap(PL); // entries per sub-list
-    if ((rc = ensure(c, S.genlist, (size_t)gen_cap * GEN_SHARDS * 8))) return rc;
+    if ((rc = ensure(c, S.genlist, (size_t)gen_cap * GEN_SHARDS * 8 * 2))) return rc; // (two lists: EmitLists)
     if ((rc = ensure(c, S.gencount, GEN_SHARDS * GEN_CNT_STRIDE * 4))) return rc; // a line per sub-list: reads, pairs
     // ---- junction-sized buffers
     const u32 slots_lim = JL + (PL + 63) / 64 + 1;
@@ -1639,7 +1639,7 @@ static int queue_contig(pjb_ctx *c, Flight &f) {
     STAGE_EVENT(1);
     // k4b_generic: the pairs that need the generic walks, in BAM order, as soon as junction ids and anchors exist -- beside
     // the sort, on the side stream
-    const u32 gen_grid = (u32)(((u64)gen_cap * GEN_SHARDS + 255) / 256);
+    const u32 gen_grid = std::min<u32>(2 * (u32)(((u64)gen_cap * GEN_SHARDS + 255) / 256), 2560u); // (the blocks stride over the lists' entries)
     auto launch_k4b = [&]() -> int {
         LAUNCH(c, "k4b_generic", k4b_generic, dim3(gen_grid), dim3(256), (const u64 *)S.genlist.p, (const u32 *)d_gen_cnt, gen_cap, (const u64 *)pr.key,
                pr.rec, (const u32 *)S.jidbam.p, kf, (const DevBatch *)S.batches.p, (int)batches.size(), (const int32_t *)S.ancl.p, (const int32_t *)S.ancr.p,

@@ -1168,9 +1168,20 @@ struct EmitRead {
     int32_t lq;   // l_qseq
     bool seq_ok;  // the record carries at least lq bases
     u32 off;      // index of the read's first pair
+    // A read of the shape [S] M (N M)+ [S] (l_qseq matching, bases present, nothing clamped): the anchors of pair k are the M
+    // blocks either side of its N operation -- UNLESS another read's alignment makes the junction's anchor window reach over
+    // a neighbouring intron of this read (bam_alignment.cc:359: the walks only stop at an N operation that leaves the
+    // window).  The window is known after K2d; the block compares are done here, where the read's operations and bases are
+    // at hand (closed != nullptr), and k4b_generic checks the window for the reads on its second list.
+    const u32 *closed_seqw; // the read's packed bases (nullptr: not of that shape -- the generic walks fill PairRec::aux in)
+    const u32 *gcodes;      // the target's 4-bit codes
+    int32_t glen, voff;     // the target's length and its offset in the group's virtual sequence
 };
+__device__ __forceinline__ u64 simple_pair_stats(const u32 *seqw, const u32 *gcodes, int32_t glen, int32_t pos, int32_t istart, int32_t iend,
+                                                 int32_t rend, int32_t dS);
 // (reads of the simple shape never come here: k1_emit finishes them in closed form.)  on_pair(key, lStart, rEnd) is called
-// for every pair once its record is complete; the match statistics (PairRec::aux) are k4b_generic's to fill in.
+// for every pair once its record is complete; the match statistics (PairRec::aux) of a read that is not `closed` are
+// k4b_generic's to fill in.
 template <typename Ops, typename PairFn>
 __device__ __forceinline__ void emit_read_pairs(const Ops cig, const EmitRead R, const Pairs P, const KeyFmt kf, const int32_t ref_len,
                                                 u64 *err, PairFn &&on_pair) {
@@ -1183,16 +1194,22 @@ __device__ __forceinline__ void emit_read_pairs(const Ops cig, const EmitRead R,
     ncursor_advance(U, cig, n);
     ncursor_advance(D, cig, n);
     u32 cntU = 0, cntD = 0;
-    int32_t lStart = pos, lEndExc = pos, sumAfter = 0, prevRStartU = 0, prevIend = 0;
+    int32_t lStart = pos, lEndExc = pos, sumAfter = 0, prevRStartU = 0, prevIend = 0, prevIstart = 0;
+    int32_t qAcc = 0, prevQ = 0; // query bases (soft clips included) before the operation / before the pending pair's N
     int64_t prev = -1;
     u64 prev_key = 0;
+    const bool closed = R.closed_seqw != nullptr;
     PairRec pend;
     pend.aux = 0;
     pend.lstart = pend.rend = 0;
     pend.pos = pos;
     pend.aend = aend;
-    pend.meta = meta;
+    pend.meta = closed ? meta | META_SIMPLE : meta;
     pend.updown = 0;
+    auto closed_stats = [&]() { // left block read[prevQ - a, prevQ) at lstart, right block read[prevQ, ...) behind the intron
+        const int32_t a = prevIstart - pend.lstart;
+        return simple_pair_stats(R.closed_seqw, R.gcodes, R.glen, pend.lstart - R.voff, prevIstart - R.voff, prevIend - R.voff, pend.rend - R.voff, prevQ - a);
+    };
     u32 k = 0;
     for (u32 i = 0; i < n; i++) {
         const u32 op = cig[i];
@@ -1203,6 +1220,7 @@ __device__ __forceinline__ void emit_read_pairs(const Ops cig, const EmitRead R,
                 int32_t rEndExc = prevRStartU + sumAfter;
                 if (rEndExc - 1 >= ref_len) rEndExc = ref_len; // junction_system.cc:172-174
                 pend.rend = rEndExc - 1;
+                if (closed) pend.aux = closed_stats();
                 rec_store(P.rec + prev, pend);
                 on_pair(prev_key, pend.lstart, pend.rend);
                 if (rEndExc - 1 < prevIend) set_error(err, g, PJB_ERR_MIN_ANCHOR); // intron.cc:76
@@ -1229,6 +1247,8 @@ __device__ __forceinline__ void emit_read_pairs(const Ops cig, const EmitRead R,
             if (lStart > istart) set_error(err, g, PJB_ERR_MIN_ANCHOR); // intron.cc:68
             prev = idx;
             prev_key = key;
+            prevIstart = istart;
+            prevQ = qAcc;
             prevIend = iend;
             prevRStartU = rStartU;
             sumAfter = 0;
@@ -1239,11 +1259,13 @@ __device__ __forceinline__ void emit_read_pairs(const Ops cig, const EmitRead R,
             lEndExc += ln;
             sumAfter += ln;
         }
+        if (op_consumes_query(ty)) qAcc += ln;
     }
     if (prev >= 0) {
         int32_t rEndExc = prevRStartU + sumAfter;
         if (rEndExc - 1 >= ref_len) rEndExc = ref_len;
         pend.rend = rEndExc - 1;
+        if (closed) pend.aux = closed_stats();
         rec_store(P.rec + prev, pend);
         on_pair(prev_key, pend.lstart, pend.rend);
         if (rEndExc - 1 < prevIend) set_error(err, g, PJB_ERR_MIN_ANCHOR);
@@ -1329,9 +1351,11 @@ constexpr u32 GEN_SHARDS = 256, GEN_CNT_STRIDE = 32;
 struct EmitLists {
     u64 *cand;      // candidate keys (nullptr: the chain sorts the full keys and wants none); their count is ContigStats::n_cand
     u64 *cand_anc;  // per candidate: min lStart | max rEnd << 32 over the pairs it stands for (the junction anchors' first level)
-    u64 *gen_list;  // global read ordinal | index of the read's first pair << 32
-    u32 *gen_cnt;   // [GEN_SHARDS][GEN_CNT_STRIDE]: word 0 entries of the sub-list, word 1 pairs of those reads -- a cache line per
-                    // sub-list: atomics on one line are served one after the other, whatever the address in it
+    u64 *gen_list;  // global read ordinal | index of the read's first pair << 32: [2][GEN_SHARDS][gen_cap] -- the reads whose
+                    // pairs need the generic walks, then the reads whose closed form waits for the window check (k4b_generic)
+    u32 *gen_cnt;   // [GEN_SHARDS][GEN_CNT_STRIDE]: word 0 entries of the first sub-list, word 1 pairs of those reads, words 2 and 3
+                    // the same for the second -- a cache line per shard: atomics on one line are served one after the other,
+                    // whatever the address in it
     u32 gen_cap;    // room of one sub-list
 };
 __host__ __device__ inline u32 gen_list_cap(u32 pair_limit) { // chunks of 256 spliced reads dealt round-robin to the sub-lists
@@ -1348,7 +1372,7 @@ __global__ __launch_bounds__(K1E_T) __attribute__((amdgpu_waves_per_eu(K1E_WAVES
     __shared__ int32_t s_lo[KC_SLOTS], s_hi[KC_SLOTS];
     __shared__ u32 s_set_n, s_base, s_scan[4];
     // the trip's reads that are not of the simple shape, compacted: what their walk needs (phase 2)
-    enum { GQ_N = 0, GQ_POS, GQ_G, GQ_META, GQ_LQ, GQ_OFF, GQ_C0, GQ_WORDS };
+    enum { GQ_N = 0, GQ_POS, GQ_G, GQ_META, GQ_LQ, GQ_OFF, GQ_C0, GQ_SO, GQ_WORDS };
     __shared__ u32 s_gq[GQ_WORDS][K1E_T];
     __shared__ u32 s_gq_n;
     if (cs->P == 0) return; // no pairs, or a limit was exceeded: the contig is repeated with larger buffers
@@ -1389,6 +1413,24 @@ __global__ __launch_bounds__(K1E_T) __attribute__((amdgpu_waves_per_eu(K1E_WAVES
         E.cand[at] = k;
         E.cand_anc[at] = (u64)(u32)lstart | ((u64)(u32)rend << 32);
     };
+    // appends the wavefront's reads of one kind to k4b_generic's list `kind` (1: the walks, 2: window check): one returning
+    // atomic per wavefront; sub-list by 256-entry chunk (gen_list_cap)
+    auto list_append = [&](u32 kind, bool mine, u32 pairs, u64 entry, u32 chunk) {
+        const u64 gm2 = __ballot(mine);
+        if (!gm2) return;
+        const u32 shard = (chunk >> (8 - K1E_SHIFT)) % GEN_SHARDS;
+        const u32 pairs_w = wave_total<DppAdd>(mine ? pairs : 0u);
+        const int leader = __ffsll((long long)gm2) - 1;
+        const u32 w0 = shard * GEN_CNT_STRIDE + (kind - 1) * 2;
+        u32 base = 0;
+        if (lane_id() == leader) {
+            base = atomicAdd(&E.gen_cnt[w0], (u32)__popcll(gm2));
+            atomicAdd(&E.gen_cnt[w0 + 1], pairs_w);
+        }
+        base = (u32)__builtin_amdgcn_readlane((int)base, leader);
+        const u32 at = base + (u32)__popcll(gm2 & ((1ull << lane_id()) - 1));
+        if (mine && at < E.gen_cap) E.gen_list[((size_t)(kind - 1) * GEN_SHARDS + shard) * E.gen_cap + at] = entry;
+    };
     for (u32 chunk = c_lo + blockIdx.x; chunk < c_hi; chunk += gridDim.x) {
         // the tile of the chunk's first entry (for the batch's first chunk: of the batch's first entry)
         u32 t0 = (chunk << K1E_SHIFT) < s_begin ? b.tile_base : chunk_tile[chunk >> (8 - K1E_SHIFT)]; // (chunk_tile: the tile of entry 256 c)
@@ -1401,7 +1443,9 @@ __global__ __launch_bounds__(K1E_T) __attribute__((amdgpu_waves_per_eu(K1E_WAVES
         // ---- phase 1: every read's fixed-width fields and first operations; a read of the shape [S] M N M [S] (l_qseq matching, bases
         // present) is finished here, in closed form: one pair, no walk (junction_system.cc:140-210 for one N operation)
         bool generic = false;
-        u32 q_n = 0, q_pos = 0, q_g = 0, q_meta = 0, q_lq = 0, q_off = 0, q_c0 = 0;
+        bool p1_two = false; // a read of two introns finished in closed form: k4b_generic checks the junctions' windows (second list)
+        u64 p1_entry = 0;
+        u32 q_n = 0, q_pos = 0, q_g = 0, q_meta = 0, q_lq = 0, q_off = 0, q_c0 = 0, q_so = 0;
         if (on) {
             u32 k = 0; // (the offsets ascend: the entry's tile is the number of them it has reached -- 15 independent LDS reads, not a walk)
 #pragma unroll
@@ -1437,48 +1481,72 @@ __global__ __launch_bounds__(K1E_T) __attribute__((amdgpu_waves_per_eu(K1E_WAVES
             const int32_t lq = b.l_qseq[r];
             const u32 so = b.seq_off[r];
             const bool seq_ok = (u64)(b.seq_off[r + 1] - so) * 8ull >= (u64)(int64_t)lq;
-            // ---- shape
-            bool simple = false;
-            u32 dS = 0, a = 0, nl = 0, b2 = 0;
-            if (gcodes != nullptr && n >= 3 && n <= 5) {
+            // ---- shape: [S] M N M [S], or -- two introns, nothing clamped -- [S] M N M N M [S]
+            bool simple = false, two = false;
+            u32 dS = 0, a = 0, nl = 0, b2 = 0, nl2 = 0, b3 = 0;
+            if (gcodes != nullptr && n >= 3 && n <= 7) {
                 const bool clipF = (op[0] & 15u) == OP_S;
-                const u32 opL = n == 3 ? op[2] : n == 4 ? op[3] : op[4];
-                const bool clipL = (opL & 15u) == OP_S;
-                if (n == 3u + (clipF ? 1u : 0u) + (clipL ? 1u : 0u)) {
-                    const u32 oa = clipF ? op[1] : op[0], on_ = clipF ? op[2] : op[1], ob = clipF ? op[3] : op[2];
+                const u32 i0 = clipF ? 1u : 0u;
+                const u32 oa = clipF ? op[1] : op[0], on_ = clipF ? op[2] : op[1], ob = clipF ? op[3] : op[2];
+                const u32 o3 = clipF ? op[4] : op[3], o4 = clipF ? op[5] : op[4], o5 = clipF ? op[6] : op[5]; // (0 past the last operation)
+                two = n >= i0 + 5u && (o3 & 15u) == OP_N;
+                const u32 body = i0 + (two ? 5u : 3u);
+                const u32 oL = two ? o5 : o3;
+                const bool clipL = n == body + 1u && (oL & 15u) == OP_S;
+                if (n == body || clipL) {
                     dS = clipF ? op[0] >> 4 : 0u;
-                    const u32 dE = clipL ? opL >> 4 : 0u;
+                    const u32 dE = clipL ? oL >> 4 : 0u;
                     a = oa >> 4;
                     nl = on_ >> 4;
                     b2 = ob >> 4;
+                    nl2 = two ? o3 >> 4 : 0u;
+                    b3 = two ? o4 >> 4 : 0u;
                     simple = (oa & 15u) == OP_M && (on_ & 15u) == OP_N && (ob & 15u) == OP_M && a > 0 && b2 > 0 && a <= RES_FIELD_MAX && b2 <= RES_FIELD_MAX &&
-                             dS <= RES_FIELD_MAX && lq > 1 && (u64)lq == (u64)dS + a + b2 + dE && seq_ok;
+                             dS <= RES_FIELD_MAX && lq > 1 && (u64)lq == (u64)dS + a + b2 + b3 + dE && seq_ok;
+                    if (two) // (the clamps of junction_system.cc:169-174 are written out for one intron only: an alignment that leaves its target walks)
+                        simple = simple && (o4 & 15u) == OP_M && b3 > 0 && b3 <= RES_FIELD_MAX && nl > 0 && nl2 > 0 && pos >= 0 &&
+                                 (int64_t)pos + a + nl + b2 + nl2 + b3 <= (int64_t)ref_len;
                 }
             }
             if (simple) {
                 const int32_t vpos = pos + voff;
-                const int32_t istart = vpos + (int32_t)a;
-                const int32_t rStartU = istart + (int32_t)nl;
-                int32_t rStart = rStartU;
-                if (rStart - 1 >= vlen) rStart = vlen - 1; // junction_system.cc:169-171
-                const int32_t iend = rStart - 1;
-                int32_t rEndExc = rStartU + (int32_t)b2;
-                if (rEndExc - 1 >= vlen) rEndExc = vlen; // junction_system.cc:172-174
-                if (rEndExc - 1 < iend) set_error(err, g, PJB_ERR_MIN_ANCHOR); // intron.cc:76
-                const u64 key = make_key(kf, istart, iend);
-                PairRec R;
-                R.lstart = vpos;
-                R.rend = rEndExc - 1;
-                R.pos = vpos;
-                R.aend = vpos + (int32_t)(a + nl + b2) - 1;
-                R.meta = meta | META_SIMPLE;
-                // junction.cc:795-812 for one N operation: nothing upstream; "downstream" counts the operation itself unless its end was clamped
-                R.updown = rStartU <= iend + 1 ? 0u : (1u << 16);
-                R.aux = simple_pair_stats(reinterpret_cast<const u32 *>(b.seq4) + so, gcodes, ref_len, pos, istart - voff, iend - voff, R.rend - voff, (int32_t)dS);
-                P.key[off] = key;
-                if (P.g) P.g[off] = g;
-                rec_store(P.rec + off, R);
-                if (want_cand) cand_insert(key, R.lstart, R.rend);
+                const int32_t aend_all = vpos + (int32_t)(a + nl + b2 + nl2 + b3) - 1;
+                const u32 *seqw = reinterpret_cast<const u32 *>(b.seq4) + so;
+                int32_t lst = vpos;  // the left block of the pair: where it starts, its query offset, its length; intron; right block
+                int32_t qoff = (int32_t)dS;
+                u32 la = a, ln_ = nl, lb = b2;
+                for (u32 pr = 0; pr < (two ? 2u : 1u); pr++) {
+                    const int32_t istart = lst + (int32_t)la;
+                    const int32_t rStartU = istart + (int32_t)ln_;
+                    int32_t rStart = rStartU;
+                    if (rStart - 1 >= vlen) rStart = vlen - 1; // junction_system.cc:169-171
+                    const int32_t iend = rStart - 1;
+                    int32_t rEndExc = rStartU + (int32_t)lb;
+                    if (rEndExc - 1 >= vlen) rEndExc = vlen; // junction_system.cc:172-174
+                    if (rEndExc - 1 < iend) set_error(err, g, PJB_ERR_MIN_ANCHOR); // intron.cc:76
+                    const u64 key = make_key(kf, istart, iend);
+                    PairRec R;
+                    R.lstart = lst;
+                    R.rend = rEndExc - 1;
+                    R.pos = vpos;
+                    R.aend = aend_all;
+                    R.meta = meta | META_SIMPLE | (two ? META_MULTI : 0u);
+                    // junction.cc:795-812.  One N operation: nothing upstream; "downstream" counts the operation itself unless its end was
+                    // clamped.  Two: the first has the second downstream, the second the first upstream.
+                    R.updown = two ? (pr == 0 ? (1u << 16) : 1u) : (rStartU <= iend + 1 ? 0u : (1u << 16));
+                    R.aux = simple_pair_stats(seqw, gcodes, ref_len, lst - voff, istart - voff, iend - voff, R.rend - voff, qoff);
+                    P.key[off + pr] = key;
+                    if (P.g) P.g[off + pr] = g;
+                    rec_store(P.rec + off + pr, R);
+                    if (want_cand) cand_insert(key, R.lstart, R.rend);
+                    lst = rStart;
+                    qoff += (int32_t)la;
+                    la = lb;
+                    ln_ = nl2;
+                    lb = b3;
+                }
+                p1_two = two;
+                p1_entry = (u64)g | ((u64)off << 32);
             } else {
                 generic = true;
                 q_n = n;
@@ -1488,8 +1556,10 @@ __global__ __launch_bounds__(K1E_T) __attribute__((amdgpu_waves_per_eu(K1E_WAVES
                 q_lq = (u32)lq;
                 q_off = off;
                 q_c0 = c0;
+                q_so = so;
             }
         }
+        list_append(2, p1_two, 2u, p1_entry, chunk);
         // ---- the other reads are compacted (LDS) ...
         {
             const u64 gm = __ballot(generic);
@@ -1507,6 +1577,7 @@ __global__ __launch_bounds__(K1E_T) __attribute__((amdgpu_waves_per_eu(K1E_WAVES
                     s_gq[GQ_LQ][at] = q_lq;
                     s_gq[GQ_OFF][at] = q_off;
                     s_gq[GQ_C0][at] = q_c0;
+                    s_gq[GQ_SO][at] = q_so;
                 }
             }
         }
@@ -1516,7 +1587,7 @@ __global__ __launch_bounds__(K1E_T) __attribute__((amdgpu_waves_per_eu(K1E_WAVES
         // k4b_generic's list.
         const u32 n_gen = s_gq_n;
         const bool gen = threadIdx.x < n_gen;
-        u32 gen_pairs = 0;
+        u32 gen_pairs = 0, gen_kind = 0;
         u64 gen_entry = 0;
         if (gen) {
             const u32 at = threadIdx.x;
@@ -1532,33 +1603,40 @@ __global__ __launch_bounds__(K1E_T) __attribute__((amdgpu_waves_per_eu(K1E_WAVES
             OpsViewT<K1E_T, OPS_LDS> cig;
             cig.g = b.cigar + s_gq[GQ_C0][at];
             cig.lds = &s_ops[0][(qm >> 16) & 0xffu];
-            u32 nN = 0;
+            // operations counted, and the shape [S] M (N M)+ [S] recognised: state 0 at the first operation, 5 after a leading S, 1
+            // after an M, 2 after an N, 3 after the closing S, 4 any other shape
+            u32 nN = 0, shape = 0;
             int32_t aligned = 0;
+            int64_t qsum = 0;
             for (u32 q = 0; q < R.n; q++) {
-                const u32 o = cig[q];
-                nN += ((o & 15u) == OP_N);
-                if (op_consumes_ref(o & 15u)) aligned += (int32_t)(o >> 4);
+                const u32 o = cig[q], ty = o & 15u, ln = o >> 4;
+                nN += (ty == OP_N);
+                if (op_consumes_ref(ty)) aligned += (int32_t)ln;
+                if (op_consumes_query(ty)) qsum += ln;
+                const bool len_ok = ln > 0 && ln <= RES_FIELD_MAX;
+                if (ty == OP_M) shape = (shape == 0 || shape == 5 || shape == 2) && len_ok ? 1u : 4u;
+                else if (ty == OP_N) shape = shape == 1 && ln > 0 ? 2u : 4u;
+                else if (ty == OP_S) shape = shape == 0 && len_ok ? 5u : shape == 1 && q + 1 == R.n ? 3u : 4u;
+                else shape = 4;
             }
             if (nN > 1) R.meta |= META_MULTI;
             R.nN = nN;
             R.aend = R.pos + aligned - 1;
+            // (nothing clamped: the alignment lies inside its target -- junction_system.cc:169-174)
+            const bool closed = gcodes != nullptr && (shape == 1 || shape == 3) && nN > 0 && R.seq_ok && R.lq > 1 && qsum == (int64_t)R.lq &&
+                                R.pos >= voff && R.aend < vlen;
+            R.closed_seqw = closed ? reinterpret_cast<const u32 *>(b.seq4) + s_gq[GQ_SO][at] : nullptr;
+            R.gcodes = gcodes;
+            R.glen = ref_len;
+            R.voff = voff;
             emit_read_pairs(cig, R, P, kf, vlen, err, [&](u64 key, int32_t lstart, int32_t rend) { if (want_cand) cand_insert(key, lstart, rend); });
             gen_pairs = nN;
+            gen_kind = closed ? 2u : 1u;
             gen_entry = (u64)R.g | ((u64)R.off << 32);
         }
-        const u64 gm2 = __ballot(gen);
-        if (gm2) { // one returning atomic per wavefront
-            const u32 shard = (chunk >> (8 - K1E_SHIFT)) % GEN_SHARDS; // (by 256-entry chunk: gen_list_cap)
-            const u32 pairs_w = wave_total<DppAdd>(gen_pairs);
-            u32 base = 0;
-            if (lane_id() == 0) { // (the block's first threads: lane 0 of a wavefront with any such read has one)
-                base = atomicAdd(&E.gen_cnt[shard * GEN_CNT_STRIDE], (u32)__popcll(gm2));
-                atomicAdd(&E.gen_cnt[shard * GEN_CNT_STRIDE + 1], pairs_w);
-            }
-            base = (u32)__builtin_amdgcn_readfirstlane((int)base);
-            const u32 at = base + (u32)lane_id();
-            if (gen && at < E.gen_cap) E.gen_list[(size_t)shard * E.gen_cap + at] = gen_entry;
-        }
+        // the read goes on k4b_generic's first list (the walks) or on its second (closed form done, window to be checked)
+        list_append(1, gen_kind == 1, gen_pairs, gen_entry, chunk);
+        list_append(2, gen_kind == 2, gen_pairs, gen_entry, chunk);
         // ---- candidate keys: flush the set when it fills up, and before the block leaves
         if (want_cand) {
             __syncthreads();
@@ -2497,13 +2575,56 @@ __global__ __launch_bounds__(256) void k4b_generic(const u64 *list, const u32 *g
                                                     KeyFmt kf, const DevBatch *batches, int n_batches, const int32_t *anc_l, const int32_t *anc_r,
                                                     GroupTab G, int genome_has_x, int use_codes, u64 *err, const ContigStats *cs) {
     __shared__ u32 s_ops[OPS_LDS][256];
+    __shared__ u32 s_first[2 * GEN_SHARDS + 1]; // item index of every sub-list's first entry (both lists, one index space)
+    __shared__ u32 s_wsum[4];
     if (cs->P == 0) return; // (a limit was exceeded while the junction ids were built: there are no ids, the chain is repeated)
-    // sub-list `shard` occupies [shard * cap, shard * cap + n_list[shard])
-    const u32 t = blockIdx.x * 256 + threadIdx.x;
-    const u32 shard = t / cap, k_in = t % cap;
-    if (shard >= GEN_SHARDS || k_in >= gen_cnt[shard * GEN_CNT_STRIDE]) return;
-    const u64 entry = list[t];
+    // The sub-lists are filled to different heights (sub-list `shard` of list `l` occupies [(l GEN_SHARDS + shard) cap, ... + its
+    // count)): every block numbers their entries -- an exclusive scan over the 512 counts -- and the grid strides over the items.
+    {
+        const u32 i0 = threadIdx.x * 2;
+        const u32 c0 = gen_cnt[(i0 % GEN_SHARDS) * GEN_CNT_STRIDE + (i0 / GEN_SHARDS) * 2];
+        const u32 c1 = gen_cnt[((i0 + 1) % GEN_SHARDS) * GEN_CNT_STRIDE + ((i0 + 1) / GEN_SHARDS) * 2];
+        const u32 n0 = c0 < cap ? c0 : cap, n1 = c1 < cap ? c1 : cap;
+        u32 total;
+        const u32 ex = block_escan<4>(n0 + n1, s_wsum, &total);
+        s_first[i0] = ex;
+        s_first[i0 + 1] = ex + n0;
+        if (threadIdx.x == 255) s_first[2 * GEN_SHARDS] = total;
+        __syncthreads();
+    }
+    static_assert(GEN_SHARDS == 256, "two sub-lists per thread of the block");
+    const u32 n_items = s_first[2 * GEN_SHARDS];
+    for (u32 item0 = blockIdx.x * 256; item0 < n_items; item0 += gridDim.x * 256) {
+    const u32 item = item0 + threadIdx.x;
+    if (item >= n_items) continue; // (no barrier below)
+    u32 sub = 0; // the last sub-list with s_first[sub] <= item
+#pragma unroll
+    for (u32 step = GEN_SHARDS; step > 0; step >>= 1)
+        if (sub + step < 2 * GEN_SHARDS && s_first[sub + step] <= item) sub += step;
+    const bool check_only = sub >= GEN_SHARDS;
+    const u64 entry = list[(size_t)sub * cap + (item - s_first[sub])];
     const u32 g = (u32)entry, p0 = (u32)(entry >> 32);
+    if (check_only) {
+        // A read [S] M (N M)+ [S] whose pairs k1_emit finished with the M blocks as anchors.  That is what the walks produce
+        // unless the junction's window reaches over a neighbouring intron of the read: on the left the walk starts at the
+        // first operation that begins inside the window (the previous N begins at its istart), on the right it stops at an N
+        // that ends outside it (bam_alignment.cc:359).  A read that fails the test takes the walks below -- all its pairs.
+        const u32 nN = (reinterpret_cast<const uint4 *>(rec + p0)[1].w >> 16) + 1u; // (first pair: no junction of the read ends before it, one is its own)
+        bool ok = true;
+        int32_t prev_istart = 0, is, ie;
+        unpack_key(kf, key[p0], is, ie);
+        for (u32 k = 0; k < nN; k++) {
+            const u32 j = jid_bam[p0 + k];
+            int32_t nis = 0, nie = 0;
+            if (k + 1 < nN) unpack_key(kf, key[p0 + k + 1], nis, nie);
+            if (k > 0 && prev_istart >= anc_l[j]) ok = false;
+            if (k + 1 < nN && nie + 1 <= anc_r[j]) ok = false;
+            prev_istart = is;
+            is = nis;
+            ie = nie;
+        }
+        if (ok) continue;
+    }
     const DevBatch &b = find_batch(batches, n_batches, g);
     const u32 r = g - b.base;
     const u32 *cig_off = b.cig_off;
@@ -2526,7 +2647,7 @@ __global__ __launch_bounds__(256) void k4b_generic(const u64 *list, const u32 *g
     const u32 so0 = gload(b.seq_off + r), words = gload(b.seq_off + r + 1) - so0;
     if (lq > 1 && (u64)words * 8ull < (u64)lq) {
         set_error(err, g, PJB_ERR_NO_SEQ);
-        return; // (the records keep aux = 0)
+        continue; // (the records keep aux = 0)
     }
     const uint8_t *seq = b.seq4 + (size_t)so0 * 4;
     u32 k = 0;
@@ -2545,6 +2666,7 @@ __global__ __launch_bounds__(256) void k4b_generic(const u64 *list, const u32 *g
         }
         if (op_consumes_query(ty) && ty != OP_S) qsum += (int32_t)(op >> 4);
     }
+    } // items
 }
 
 // K4: gather the pairs in sorted order -- one 32-byte record each -- and fold predicates and match statistics to fragment
@@ -3075,8 +3197,7 @@ __global__ __launch_bounds__(256) void k7_publish(const ContigStats *cs, u64 *er
     if (t < GEN_SHARDS) { // pairs that took the generic walks, per sub-list; both counters back to their rest state
         reinterpret_cast<u32 *>(host + PUB_GEN_AT)[t] = gen_cnt[t * GEN_CNT_STRIDE + 1];
         reinterpret_cast<u32 *>(host + PUB_GREADS_AT)[t] = gen_cnt[t * GEN_CNT_STRIDE];
-        gen_cnt[t * GEN_CNT_STRIDE] = 0;
-        gen_cnt[t * GEN_CNT_STRIDE + 1] = 0;
+        reinterpret_cast<uint4 *>(gen_cnt + t * GEN_CNT_STRIDE)[0] = make_uint4(0, 0, 0, 0);
     }
     if (t == 0) {
         *reinterpret_cast<u64 *>(host + PUB_ERR_AT) = *err;
