@@ -1474,7 +1474,11 @@ static int queue_contig(pjb_ctx *c, Flight &f) {
             HIP_TRY(c, hipMemset(S.tile_state.p, 0, S.tile_state.cap));
             HIP_TRY(c, hipStreamSynchronize(nullptr));
         }
-        if ((rc = ensure(c, S.k1_ticket, batches.size() * 4 + 64))) return rc; // (a counter per launch, zeroed when the chain is queued)
+        if (!S.k1_ticket.p) {
+            if ((rc = ensure(c, S.k1_ticket, 64))) return rc;
+            HIP_TRY(c, hipMemset(S.k1_ticket.p, 0, 64));
+            HIP_TRY(c, hipStreamSynchronize(nullptr));
+        }
     } else {
         if ((rc = ensure(c, S.tile_soff, ((size_t)n_tiles + 1) * 4))) return rc;
         if ((rc = ensure(c, S.chunk_tile, ((size_t)n_tiles * (K1_TILE / 256) + 4) * 4))) return rc;
@@ -1577,6 +1581,7 @@ static int queue_contig(pjb_ctx *c, Flight &f) {
         HIP_TRY(c, hipMemsetAsync(S.gencount.p, 0, GEN_SHARDS * GEN_CNT_STRIDE * 4, front));
         HIP_TRY(c, hipMemsetAsync(d_member_junc, 0, GROUP_MAX * 4, front));
         HIP_TRY(c, hipMemsetAsync(S.cstats.p, 0, sizeof(ContigStats), front)); // (n_cand)
+        if (S.k1_ticket.p) HIP_TRY(c, hipMemsetAsync(S.k1_ticket.p, 0, 64, front));
     }
     S.at_rest = false; // until k7_publish is queued
     u64 *d_err = (u64 *)S.err.p;
@@ -1609,7 +1614,7 @@ static int queue_contig(pjb_ctx *c, Flight &f) {
         fa.tile_cnt = (u32 *)S.tile_cnt.p;
         fa.tile_stats = (TileStats *)S.tile_stats.p;
         fa.tile_state = (u64 *)S.tile_state.p;
-        HIP_TRY(c, hipMemsetAsync(S.k1_ticket.p, 0, batches.size() * 4, front));
+        fa.ticket = (u32 *)S.k1_ticket.p;
         fa.epoch = ++S.scan_epoch;
         fa.pair_limit = PL;
         for (size_t bi = 0; bi < batches.size(); bi++) {
@@ -1618,8 +1623,7 @@ static int queue_contig(pjb_ctx *c, Flight &f) {
             const int32_t own_tid = f.tids[(size_t)m], own_len = c->ref_len[(size_t)own_tid];
             const u32 nt = (u32)((b.n + K1_TILE - 1) / K1_TILE) * (u32)(K1_TILE / KF_TILE); // (every tile slot of the batch is taken: the look-back has no holes)
             fa.chk_ref_len = group ? std::max(own_len, 1) : 0;
-            fa.ticket = (u32 *)S.k1_ticket.p + bi;
-            LAUNCH(c, "k1_fused", k1_fused, dim3(std::min<u32>(nt, 6u * 256u)), dim3(K1E_T), b, nt, pr, el, kf, own_len, own_tid, (int)c->cfg.orientation, d_err, d_cs, f.voff[(size_t)m],
+            LAUNCH(c, "k1_fused", k1_fused, dim3(nt), dim3(K1E_T), b, pr, el, kf, own_len, own_tid, (int)c->cfg.orientation, d_err, d_cs, f.voff[(size_t)m],
                    fast_codes ? (const u32 *)GT.codes[m] : (const u32 *)nullptr, fa);
         }
         if (group)

@@ -991,6 +991,7 @@ __global__ __launch_bounds__(K1S_THREADS) void k1_scan_tiles(u32 *tile_cnt, cons
         if (tile_soff) tile_soff[n_tiles] = carry2_s;
         const ScanPart b = total_s;
         const u64 n_pairs = fused_ticket ? b.pairs + mine.pairs : carry_s;
+        if (fused_ticket) *fused_ticket = 0; // (rest state: the next chain's tiles are numbered from 0)
         const int32_t m0 = min(b.mn, mine.mn), m1 = max(b.mx, mine.mx), m2 = max(b.max_end, mine.max_end), m3 = max(b.max_nlen, mine.max_nlen),
                       m4 = min(b.min_pos, mine.min_pos);
         out->spliced = b.spl + mine.spl;
@@ -1376,12 +1377,12 @@ __host__ __device__ inline u32 gen_list_cap(u32 pair_limit) {
 // fields, no per-tile spliced lists in memory, no scan kernel between two passes; k1_scan_tiles (fused mode) only adds
 // the tiles' statistics up and checks the limits.  A tile whose pairs do not fit the limits the host assumed (pair
 // capacity, key format) emits nothing; the chain is repeated.
-constexpr int KF_TILE = 256;
+constexpr int KF_TILE = 512;
 struct FusedArgs {
     u32 *tile_cnt;         // [tiles] pairs of the tile (kg_member_stats and k1_scan_tiles add them up)
     TileStats *tile_stats; // [tiles]
     u64 *tile_state;       // [tiles] status << 62 | epoch << 32 | value: status 1 = the tile's pairs, 2 = pairs up to and including the tile
-    u32 *ticket;           // the launch's next tile (0 when the launch starts)
+    u32 *ticket;           // the chain's next tile (rest state 0: k1_scan_tiles puts it back)
     u32 epoch;             // 30 bits, one per queued chain: words of earlier chains read as "not there yet"
     u32 pair_limit;
     int32_t chk_ref_len;   // > 0 (members of a group): see k1_count
@@ -1425,29 +1426,195 @@ __device__ __forceinline__ void k1_emit_body(DevBatch b, u32 n_tiles_batch, u32 
                                                 const u32 *chunk_tile, const u32 *spl_idx, const u32 *spl_poff, Pairs P, EmitLists E, KeyFmt kf,
                                                 int32_t ref_len, int32_t tid, int orientation, u64 *err, ContigStats *cs, int32_t voff,
                                                 const u32 *gcodes, FusedArgs F) {
-    __shared__ u32 s_ops[FUSED ? 1 : OPS_LDS][K1E_T]; // (FUSED: the few reads that walk read their operations from memory)
+    __shared__ u32 s_ops[OPS_LDS][K1E_T];
     __shared__ u32 s_soff[K1E_LOOK];
     __shared__ u64 s_set[KC_SLOTS];
     __shared__ int32_t s_lo[KC_SLOTS], s_hi[KC_SLOTS];
     __shared__ u32 s_set_n, s_base, s_scan[4];
     // the trip's reads that are not of the simple shape, compacted: what their walk needs (phase 2)
     enum { GQ_N = 0, GQ_POS, GQ_G, GQ_META, GQ_LQ, GQ_OFF, GQ_C0, GQ_SO, GQ_WORDS };
-    __shared__ u32 s_gq[FUSED ? 1 : GQ_WORDS][K1E_T]; // (FUSED: the read's place in the block's queue)
+    __shared__ u32 s_gq[GQ_WORDS][K1E_T];
     __shared__ u32 s_gq_n;
     const bool want_cand = E.cand != nullptr;
     const int32_t vlen = voff + ref_len; // the target's end in the group's virtual sequence
     u32 s_begin = 0, s_end = 0, c_lo = 0, c_hi = 0;
-    // (FUSED) the block's queue of spliced records, in BAM order, a ring: what their emission needs.  A tile adds up to KF_TILE
-    // entries; a trip takes K1E_T of them -- every lane of a trip has a record, whatever share of the tiles' records is spliced.
-    enum { Q_C0 = 0, Q_POS, Q_SO, Q_OFF, Q_R, Q_NLQ, Q_META, Q_WORDS };
-    constexpr u32 QCAP = K1E_T + KF_TILE;
-    __shared__ u32 s_q[FUSED ? Q_WORDS : 1][FUSED ? QCAP : 1];
-    u32 q_head = 0, q_count = 0;
+    // (FUSED) the tile's spliced records, in BAM order: what their emission needs
+    enum { Q_C0 = 0, Q_N, Q_POS, Q_SO, Q_LQ, Q_POFF, Q_RMETA, Q_WORDS };
+    __shared__ u32 s_q[FUSED ? Q_WORDS : 1][FUSED ? KF_TILE : 1];
+    u32 n_spl = 0, pair_base = 0, fused_read_base = 0;
     if constexpr (!FUSED) {
         if (cs->P == 0) return; // no pairs, or a limit was exceeded: the contig is repeated with larger buffers
         s_begin = tile_soff[b.tile_base], s_end = tile_soff[b.tile_base + n_tiles_batch];
         if (s_begin == s_end) return;
         c_lo = s_begin >> K1E_SHIFT, c_hi = (s_end + (u32)K1E_T - 1u) >> K1E_SHIFT; // trips of K1E_T list entries
+    } else {
+        constexpr int RNDS = KF_TILE / K1E_T, K1_OPS = 4;
+        __shared__ u32 s_tile, s_pair_base;
+        __shared__ u64 s_scanw[RNDS][K1E_T / 64], s_sum[K1E_T / 64], s_packed[K1E_T / 64];
+        __shared__ int32_t s_mm[K1E_T / 64][5];
+        if (threadIdx.x == 0) s_tile = atomicAdd(F.ticket, 1u);
+        __syncthreads();
+        const u32 tile_id = s_tile; // (chain-wide; a batch's tiles start at 2 b.tile_base: tile_base counts tiles of K1_TILE records)
+        const int64_t base = (int64_t)(tile_id - 2u * b.tile_base) * KF_TILE;
+        fused_read_base = (u32)base;
+        u32 cnt = 0, spl = 0, uns = 0;
+        u64 sum = 0;
+        int32_t mn = INT32_MAX, mx = 0, max_end = 0, max_nlen = 0, min_pos = INT32_MAX;
+        u32 c0a[RNDS], nop[RNDS], ops[RNDS][K1_OPS], xsa[RNDS], c4[RNDS], soa[RNDS], so1a[RNDS], fla[RNDS], mqa[RNDS];
+        int32_t posa[RNDS], prva[RNDS], lena[RNDS], mtida[RNDS], mposa[RNDS];
+        // (every load unconditional, from a clamped index, masked afterwards: see k1_count)
+#pragma unroll
+        for (int it = 0; it < RNDS; it++) {
+            const int64_t r = base + it * K1E_T + threadIdx.x;
+            const bool on = r < b.n;
+            const int64_t rr = on ? r : (b.n > 0 ? b.n - 1 : 0), rp = rr > 0 ? rr - 1 : 0;
+            const u32 c0v = b.cig_off[rr], c1v = b.cig_off[rr + 1];
+            const int32_t posv = b.pos[rr], prevv = b.pos[rp], lenv = b.l_qseq[rr], mtv = b.mtid[rr], mpv = b.mpos[rr];
+            const u32 xsv = (u32)b.xs[rr], flv = (u32)b.flag[rr], mqv = (u32)b.mapq[rr], sov = b.seq_off[rr], so1v = b.seq_off[rr + 1];
+            c0a[it] = on ? c0v : 0u;
+            nop[it] = on ? c1v - c0v : 0u;
+            posa[it] = on ? posv : 0;
+            prva[it] = on ? (r > 0 ? prevv : (b.prev_pos_ptr ? *b.prev_pos_ptr : b.prev_pos)) : 0;
+            xsa[it] = on ? xsv : 0u;
+            lena[it] = on ? lenv : 0;
+            fla[it] = flv, mqa[it] = mqv, mtida[it] = mtv, mposa[it] = mpv, soa[it] = sov, so1a[it] = so1v;
+        }
+#pragma unroll
+        for (int it = 0; it < RNDS; it++)
+#pragma unroll
+            for (int k = 0; k < K1_OPS; k++) {
+                const bool has = (u32)k < nop[it];
+                const u32 v = *(has ? b.cigar + c0a[it] + k : b.cig_off);
+                ops[it][k] = has ? v : 0u;
+            }
+#pragma unroll
+        for (int it = 0; it < RNDS; it++) {
+            const int64_t r = base + it * K1E_T + threadIdx.x;
+            u32 c = 0;
+            if (r < b.n) {
+                const int32_t p = posa[it];
+                if (p < prva[it]) set_error(err, b.base + (u32)r, PJB_ERR_UNSORTED);
+                if (xsa[it] > 2) set_error(err, b.base + (u32)r, PJB_ERR_BAD_XS);
+                int32_t al = 0;
+                auto count_op = [&](u32 op) {
+                    const u32 ty = op & 15u;
+                    const int32_t ln = (int32_t)(op >> 4);
+                    if (op_consumes_ref(ty)) al += ln;
+                    if (ty == OP_N) {
+                        c++;
+                        max_nlen = ln > max_nlen ? ln : max_nlen;
+                    }
+                };
+#pragma unroll
+                for (int k = 0; k < K1_OPS; k++) count_op(ops[it][k]); // padding ops are 0M: no effect
+                for (u32 k = K1_OPS; k < nop[it]; k++) count_op(b.cigar[c0a[it] + k]);
+                const int32_t len = lena[it];
+                mn = len < mn ? len : mn;
+                mx = len > mx ? len : mx;
+                sum += (u64)(int64_t)len;
+                cnt += c;
+                if (c) {
+                    spl++;
+                    const int32_t e = p + al;
+                    max_end = e > max_end ? e : max_end;
+                    min_pos = p < min_pos ? p : min_pos;
+                } else
+                    uns++;
+            }
+            c4[it] = c;
+        }
+        // ordered compaction of the tile's spliced records (record order is round-major, as in k1_count): slot, first pair
+        u64 inc[RNDS];
+        const int w = threadIdx.x >> 6;
+#pragma unroll
+        for (int it = 0; it < RNDS; it++) {
+            inc[it] = wave_iscan<u64>(((u64)c4[it] << 16) | (u64)(c4[it] ? 1u : 0u));
+            if (lane_id() == 63) s_scanw[it][w] = inc[it];
+        }
+        __syncthreads();
+        u64 run = 0; // (pairs << 16 | spliced records) of everything before, in record order
+#pragma unroll
+        for (int it = 0; it < RNDS; it++) {
+            u64 before = run;
+#pragma unroll
+            for (int i = 0; i < K1E_T / 64; i++) {
+                const u64 t = s_scanw[it][i];
+                if (i < w) before += t;
+                run += t;
+            }
+            if (c4[it]) {
+                const u64 ex = before + inc[it] - (((u64)c4[it] << 16) | 1u);
+                const u32 slot = (u32)(ex & 0xffffu);
+                const u32 meta = read_meta(fla[it], xsa[it], mqa[it], posa[it], mtida[it], mposa[it], tid, orientation);
+                const bool seq_ok = (u64)(so1a[it] - soa[it]) * 8ull >= (u64)(int64_t)lena[it];
+                s_q[Q_C0][slot] = c0a[it];
+                s_q[Q_N][slot] = nop[it];
+                s_q[Q_POS][slot] = (u32)posa[it];
+                s_q[Q_SO][slot] = soa[it];
+                s_q[Q_LQ][slot] = (u32)lena[it];
+                s_q[Q_POFF][slot] = (u32)(ex >> 16);
+                s_q[Q_RMETA][slot] = (u32)(it * K1E_T + threadIdx.x) | (meta << 10) | (seq_ok ? 0x80000000u : 0u);
+            }
+        }
+        n_spl = (u32)(run & 0xffffu);
+        const u32 tile_pairs = (u32)(run >> 16);
+        if (threadIdx.x == 0 && tile_id != 0) // (as early as possible: the tiles behind this one wait for it)
+            __hip_atomic_store(&F.tile_state[tile_id], ts_word(1, F.epoch, tile_pairs), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // the tile's statistics (k1_count's block reduction)
+        {
+            const u64 packed = ((u64)wave_total<DppAdd>(cnt) << 32) | (u64)wave_total<DppAdd>((spl << 16) | uns);
+            sum = (u64)wave_total<DppAdd>((u32)(sum & 0xffffu)) + ((u64)wave_total<DppAdd>((u32)((sum >> 16) & 0xffffu)) << 16) +
+                  ((u64)wave_total<DppAdd>((u32)(sum >> 32)) << 32);
+            auto smin = [](int32_t v) { return (int32_t)(wave_total<DppMin>((u32)v ^ 0x80000000u) ^ 0x80000000u); };
+            auto smax = [](int32_t v) { return (int32_t)(wave_total<DppMax>((u32)v ^ 0x80000000u) ^ 0x80000000u); };
+            mn = smin(mn), mx = smax(mx), max_end = smax(max_end), max_nlen = smax(max_nlen), min_pos = smin(min_pos);
+            if (lane_id() == 0) {
+                s_packed[w] = packed;
+                s_sum[w] = sum;
+                s_mm[w][0] = mn, s_mm[w][1] = mx, s_mm[w][2] = max_end, s_mm[w][3] = max_nlen, s_mm[w][4] = min_pos;
+            }
+        }
+        __syncthreads();
+        TileStats t;
+        {
+            u64 pk = 0;
+            t.sum_len = 0;
+            t.min_len = INT32_MAX, t.max_len = 0, t.max_end = 0, t.max_nlen = 0, t.min_pos = INT32_MAX;
+#pragma unroll
+            for (int i = 0; i < K1E_T / 64; i++) {
+                pk += s_packed[i];
+                t.sum_len += s_sum[i];
+                t.min_len = min(t.min_len, s_mm[i][0]);
+                t.max_len = max(t.max_len, s_mm[i][1]);
+                t.max_end = max(t.max_end, s_mm[i][2]);
+                t.max_nlen = max(t.max_nlen, s_mm[i][3]);
+                t.min_pos = min(t.min_pos, s_mm[i][4]);
+            }
+            t.spliced = (u32)((pk >> 16) & 0xffff);
+            t.unspliced = (u32)(pk & 0xffff);
+            t._pad = 0;
+        }
+        // may this tile emit?  Its pairs must fit the key format the host planned (k1_scan_tiles comes to the same verdict for the chain)
+        bool emit_ok = true;
+        if (!kf.raw) {
+            int need = 0;
+            for (u32 v = (u32)t.max_nlen; v; v >>= 1) need++;
+            if (t.spliced && (need > kf.lbits || t.min_pos < 0 || t.max_end > ref_len || t.max_end < 0)) emit_ok = false;
+        }
+        if (threadIdx.x == 0) {
+            TileStats o = t;
+            if (F.chk_ref_len > 0 && o.max_end > F.chk_ref_len) o.max_end = INT32_MAX;
+            F.tile_stats[tile_id] = o;
+            F.tile_cnt[tile_id] = tile_pairs;
+        }
+        if (threadIdx.x < 64) {
+            const u32 ex = tile_lookback(F.tile_state, tile_id, tile_pairs, F.epoch);
+            if (threadIdx.x == 0) s_pair_base = ex;
+        }
+        __syncthreads();
+        pair_base = s_pair_base;
+        if (!emit_ok || (u64)pair_base + tile_pairs > (u64)F.pair_limit) n_spl = 0;
+        if (n_spl == 0) return;
     }
     if (want_cand) {
 #pragma unroll
@@ -1482,64 +1649,25 @@ __device__ __forceinline__ void k1_emit_body(DevBatch b, u32 n_tiles_batch, u32 
         E.cand_anc[at] = (u64)(u32)lstart | ((u64)(u32)rend << 32);
     };
     // appends the wavefront's reads of one kind to k4b_generic's list `kind` (1: the walks, 2: window check): one returning
-    // atomic per wavefront and sub-list.  Sub-list: by 256-entry chunk of the spliced lists (two-pass), by the 512-pair chunk the
-    // read's first pair falls into (FUSED: a trip's reads lie in one or two of them) -- gen_list_cap.
+    // atomic per wavefront; sub-list by 256-entry chunk (gen_list_cap)
     auto list_append = [&](u32 kind, bool mine, u32 pairs, u64 entry, u32 chunk) {
-        u64 todo = __ballot(mine);
-        while (todo) {
-            const int leader = __ffsll((long long)todo) - 1;
-            const u32 my_shard = FUSED ? ((u32)(entry >> 32) >> 9) % GEN_SHARDS : (chunk >> (8 - K1E_SHIFT)) % GEN_SHARDS;
-            const u32 shard = (u32)__builtin_amdgcn_readlane((int)my_shard, leader);
-            const bool now = mine && my_shard == shard;
-            const u64 gm2 = __ballot(now) & todo;
-            const u32 pairs_w = wave_total<DppAdd>(now ? pairs : 0u);
-            const u32 w0 = shard * GEN_CNT_STRIDE + (kind - 1) * 2;
-            u32 base = 0;
-            if (lane_id() == leader) {
-                base = atomicAdd(&E.gen_cnt[w0], (u32)__popcll(gm2));
-                atomicAdd(&E.gen_cnt[w0 + 1], pairs_w);
-            }
-            base = (u32)__builtin_amdgcn_readlane((int)base, leader);
-            const u32 at = base + (u32)__popcll(gm2 & ((1ull << lane_id()) - 1));
-            if (now && at < E.gen_cap) E.gen_list[((size_t)(kind - 1) * GEN_SHARDS + shard) * E.gen_cap + at] = entry;
-            todo &= ~gm2;
+        const u64 gm2 = __ballot(mine);
+        if (!gm2) return;
+        const u32 shard = FUSED ? (pair_base >> 9) % GEN_SHARDS : (chunk >> (8 - K1E_SHIFT)) % GEN_SHARDS; // (gen_list_cap)
+        const u32 pairs_w = wave_total<DppAdd>(mine ? pairs : 0u);
+        const int leader = __ffsll((long long)gm2) - 1;
+        const u32 w0 = shard * GEN_CNT_STRIDE + (kind - 1) * 2;
+        u32 base = 0;
+        if (lane_id() == leader) {
+            base = atomicAdd(&E.gen_cnt[w0], (u32)__popcll(gm2));
+            atomicAdd(&E.gen_cnt[w0 + 1], pairs_w);
         }
+        base = (u32)__builtin_amdgcn_readlane((int)base, leader);
+        const u32 at = base + (u32)__popcll(gm2 & ((1ull << lane_id()) - 1));
+        if (mine && at < E.gen_cap) E.gen_list[((size_t)(kind - 1) * GEN_SHARDS + shard) * E.gen_cap + at] = entry;
     };
-    // candidate keys: the set is flushed when it fills up, and before the block leaves
-    auto cand_flush = [&](bool force) {
-        if (!want_cand) return;
-        __syncthreads();
-        if (s_set_n > (u32)KC_SLOTS / 4 || force) {
-            u64 mine[KC_SLOTS / K1E_T], anc[KC_SLOTS / K1E_T];
-            u32 cnt = 0;
-#pragma unroll
-            for (int i = 0; i < KC_SLOTS / K1E_T; i++) {
-                const int at = i * K1E_T + threadIdx.x;
-                mine[i] = s_set[at];
-                anc[i] = (u64)(u32)s_lo[at] | ((u64)(u32)s_hi[at] << 32);
-                cnt += mine[i] != KD_EMPTY;
-                s_set[at] = KD_EMPTY;
-                s_lo[at] = INT32_MAX;
-                s_hi[at] = INT32_MIN;
-            }
-            u32 total;
-            const u32 excl = block_escan<K1E_T / 64>(cnt, s_scan, &total);
-            if (threadIdx.x == 0) {
-                s_base = total ? atomicAdd(&cs->n_cand, total) : 0u;
-                s_set_n = 0;
-            }
-            __syncthreads();
-            u32 o = s_base + excl;
-#pragma unroll
-            for (int i = 0; i < KC_SLOTS / K1E_T; i++)
-                if (mine[i] != KD_EMPTY) {
-                    E.cand[o] = mine[i];
-                    E.cand_anc[o++] = anc[i];
-                }
-        }
-    };
-    // one trip: K1E_T list entries (two-pass: chunk `chunk` of the batch's spliced lists; FUSED: the first n_on entries of the queue)
-    auto trip = [&](const u32 chunk, const u32 n_on, const bool last) {
+    const u32 trip_lo = FUSED ? 0u : c_lo + blockIdx.x, trip_hi = FUSED ? (n_spl + (u32)K1E_T - 1u) >> K1E_SHIFT : c_hi, trip_step = FUSED ? 1u : gridDim.x;
+    for (u32 chunk = trip_lo; chunk < trip_hi; chunk += trip_step) {
         u32 t0 = 0;
         if constexpr (!FUSED) // the tile of the chunk's first entry (for the batch's first chunk: of the batch's first entry)
             t0 = (chunk << K1E_SHIFT) < s_begin ? b.tile_base : chunk_tile[chunk >> (8 - K1E_SHIFT)]; // (chunk_tile: the tile of entry 256 c)
@@ -1549,8 +1677,7 @@ __device__ __forceinline__ void k1_emit_body(DevBatch b, u32 n_tiles_batch, u32 
         if (threadIdx.x == 0) s_gq_n = 0;
         __syncthreads();
         const u32 s = (chunk << K1E_SHIFT) + threadIdx.x;
-        const bool on = FUSED ? threadIdx.x < n_on : (s >= s_begin && s < s_end);
-        const u32 qe = (q_head + threadIdx.x) % QCAP; // (FUSED) this lane's queue entry
+        const bool on = FUSED ? s < n_spl : (s >= s_begin && s < s_end);
         // ---- phase 1: every read's fixed-width fields and first operations; a read of the shape [S] M N M [S] (l_qseq matching, bases
         // present) is finished here, in closed form: one pair, no walk (junction_system.cc:140-210 for one N operation)
         bool generic = false;
@@ -1563,18 +1690,16 @@ __device__ __forceinline__ void k1_emit_body(DevBatch b, u32 n_tiles_batch, u32 
             int32_t pos, lq;
             bool seq_ok;
             if constexpr (FUSED) {
-                const u32 nlq = s_q[Q_NLQ][qe], mw = s_q[Q_META][qe];
-                r = (int64_t)s_q[Q_R][qe];
-                c0 = s_q[Q_C0][qe];
-                pos = (int32_t)s_q[Q_POS][qe];
-                so = s_q[Q_SO][qe];
-                off = s_q[Q_OFF][qe];
-                n = nlq & 0xffffu;
-                lq = (int32_t)(nlq >> 16);
-                if (n == 0xffffu) n = b.cig_off[r + 1] - c0; // (did not fit 16 bits: from memory)
-                if (lq == 0xffff) lq = b.l_qseq[r];
-                meta = mw & 0x7fffffffu;
-                seq_ok = (mw >> 31) != 0;
+                const u32 rm = s_q[Q_RMETA][s];
+                r = (int64_t)fused_read_base + (int64_t)(rm & 0x3ffu);
+                c0 = s_q[Q_C0][s];
+                n = s_q[Q_N][s];
+                pos = (int32_t)s_q[Q_POS][s];
+                so = s_q[Q_SO][s];
+                lq = (int32_t)s_q[Q_LQ][s];
+                off = pair_base + s_q[Q_POFF][s];
+                meta = (rm >> 10) & 0x1fffffu;
+                seq_ok = (rm >> 31) != 0;
             } else {
                 u32 k = 0; // (the offsets ascend: the entry's tile is the number of them it has reached -- 15 independent LDS reads, not a walk)
 #pragma unroll
@@ -1608,7 +1733,7 @@ __device__ __forceinline__ void k1_emit_body(DevBatch b, u32 n_tiles_batch, u32 
                 const bool has = (u32)q < n;
                 const u32 v = *(has ? b.cigar + c0 + q : b.cig_off);
                 op[q] = has ? v : 0u;
-                if constexpr (!FUSED) s_ops[q][threadIdx.x] = op[q];
+                s_ops[q][threadIdx.x] = op[q];
             }
             const u32 g = b.base + (u32)r;
             // ---- shape: [S] M N M [S], or -- two introns, nothing clamped -- [S] M N M N M [S]
@@ -1700,18 +1825,14 @@ __device__ __forceinline__ void k1_emit_body(DevBatch b, u32 n_tiles_batch, u32 
                 base = (u32)__builtin_amdgcn_readlane((int)base, leader);
                 if (generic) {
                     const u32 at = base + (u32)__popcll(gm & ((1ull << lane_id()) - 1));
-                    if constexpr (FUSED) {
-                        s_gq[0][at] = qe;
-                    } else {
-                        s_gq[GQ_N][at] = q_n;
-                        s_gq[GQ_POS][at] = q_pos;
-                        s_gq[GQ_G][at] = q_g;
-                        s_gq[GQ_META][at] = q_meta;
-                        s_gq[GQ_LQ][at] = q_lq;
-                        s_gq[GQ_OFF][at] = q_off;
-                        s_gq[GQ_C0][at] = q_c0;
-                        s_gq[GQ_SO][at] = q_so;
-                    }
+                    s_gq[GQ_N][at] = q_n;
+                    s_gq[GQ_POS][at] = q_pos;
+                    s_gq[GQ_G][at] = q_g;
+                    s_gq[GQ_META][at] = q_meta;
+                    s_gq[GQ_LQ][at] = q_lq;
+                    s_gq[GQ_OFF][at] = q_off;
+                    s_gq[GQ_C0][at] = q_c0;
+                    s_gq[GQ_SO][at] = q_so;
                 }
             }
         }
@@ -1725,37 +1846,18 @@ __device__ __forceinline__ void k1_emit_body(DevBatch b, u32 n_tiles_batch, u32 
         u64 gen_entry = 0;
         if (gen) {
             const u32 at = threadIdx.x;
-            u32 gq_so;
+            const u32 qm = s_gq[GQ_META][at];
             EmitRead R;
-            OpsViewT<K1E_T, FUSED ? 0 : OPS_LDS> cig;
-            if constexpr (FUSED) {
-                const u32 e = s_gq[0][at];
-                const u32 nlq = s_q[Q_NLQ][e], mw = s_q[Q_META][e], rr = s_q[Q_R][e], cc0 = s_q[Q_C0][e];
-                R.n = nlq & 0xffffu;
-                R.lq = (int32_t)(nlq >> 16);
-                if (R.n == 0xffffu) R.n = b.cig_off[(size_t)rr + 1] - cc0;
-                if (R.lq == 0xffff) R.lq = b.l_qseq[rr];
-                R.pos = (int32_t)s_q[Q_POS][e] + voff;
-                R.g = b.base + rr;
-                R.meta = mw & 0xffffu;
-                R.seq_ok = (mw >> 31) != 0;
-                R.off = s_q[Q_OFF][e];
-                gq_so = s_q[Q_SO][e];
-                cig.g = b.cigar + cc0;
-                cig.lds = nullptr;
-            } else {
-                const u32 qm = s_gq[GQ_META][at];
-                R.n = s_gq[GQ_N][at];
-                R.pos = (int32_t)s_gq[GQ_POS][at] + voff;
-                R.g = s_gq[GQ_G][at];
-                R.meta = qm & 0xffffu;
-                R.lq = (int32_t)s_gq[GQ_LQ][at];
-                R.seq_ok = (qm & 0x80000000u) != 0;
-                R.off = s_gq[GQ_OFF][at];
-                gq_so = s_gq[GQ_SO][at];
-                cig.g = b.cigar + s_gq[GQ_C0][at];
-                cig.lds = &s_ops[0][(qm >> 16) & 0xffu];
-            }
+            R.n = s_gq[GQ_N][at];
+            R.pos = (int32_t)s_gq[GQ_POS][at] + voff;
+            R.g = s_gq[GQ_G][at];
+            R.meta = qm & 0xffffu;
+            R.lq = (int32_t)s_gq[GQ_LQ][at];
+            R.seq_ok = (qm & 0x80000000u) != 0;
+            R.off = s_gq[GQ_OFF][at];
+            OpsViewT<K1E_T, OPS_LDS> cig;
+            cig.g = b.cigar + s_gq[GQ_C0][at];
+            cig.lds = &s_ops[0][(qm >> 16) & 0xffu];
             // operations counted, and the shape [S] M (N M)+ [S] recognised: state 0 at the first operation, 5 after a leading S, 1
             // after an M, 2 after an N, 3 after the closing S, 4 any other shape
             u32 nN = 0, shape = 0;
@@ -1778,7 +1880,7 @@ __device__ __forceinline__ void k1_emit_body(DevBatch b, u32 n_tiles_batch, u32 
             // (nothing clamped: the alignment lies inside its target -- junction_system.cc:169-174)
             const bool closed = gcodes != nullptr && (shape == 1 || shape == 3) && nN > 0 && R.seq_ok && R.lq > 1 && qsum == (int64_t)R.lq &&
                                 R.pos >= voff && R.aend < vlen;
-            R.closed_seqw = closed ? reinterpret_cast<const u32 *>(b.seq4) + gq_so : nullptr;
+            R.closed_seqw = closed ? reinterpret_cast<const u32 *>(b.seq4) + s_gq[GQ_SO][at] : nullptr;
             R.gcodes = gcodes;
             R.glen = ref_len;
             R.voff = voff;
@@ -1790,150 +1892,39 @@ __device__ __forceinline__ void k1_emit_body(DevBatch b, u32 n_tiles_batch, u32 
         // the read goes on k4b_generic's first list (the walks) or on its second (closed form done, window to be checked)
         list_append(1, gen_kind == 1, gen_pairs, gen_entry, chunk);
         list_append(2, gen_kind == 2, gen_pairs, gen_entry, chunk);
-        cand_flush(last);
-    };
-    if constexpr (!FUSED) {
-        for (u32 chunk = c_lo + blockIdx.x; chunk < c_hi; chunk += gridDim.x) trip(chunk, 0u, chunk + gridDim.x >= c_hi);
-    } else {
-        __shared__ u32 s_tile, s_pair_base;
-        __shared__ u64 s_scanw[K1E_T / 64], s_sum[K1E_T / 64], s_packed[K1E_T / 64];
-        __shared__ int32_t s_mm[K1E_T / 64][5];
-        static_assert(KF_TILE == K1E_T, "a record per thread");
-        constexpr int K1_OPS = 4;
-        for (;;) {
+        // ---- candidate keys: flush the set when it fills up, and before the block leaves
+        if (want_cand) {
             __syncthreads();
-            if (threadIdx.x == 0) s_tile = atomicAdd(F.ticket, 1u);
-            __syncthreads();
-            const u32 tile_local = s_tile; // (of this launch; the chain numbers its tiles through: a batch's start at KSCALE b.tile_base)
-            if (tile_local >= n_tiles_batch) break;
-            const u32 tile_id = (u32)(K1_TILE / KF_TILE) * b.tile_base + tile_local;
-            const int64_t r = (int64_t)tile_local * KF_TILE + threadIdx.x;
-            const bool live = r < b.n;
-            // (every load unconditional, from a clamped index, masked afterwards: see k1_count)
-            const int64_t rr = live ? r : (b.n > 0 ? b.n - 1 : 0), rp = rr > 0 ? rr - 1 : 0;
-            const u32 c0v = b.cig_off[rr], c1v = b.cig_off[rr + 1];
-            const int32_t posv = b.pos[rr], prevv = b.pos[rp], lenv = b.l_qseq[rr], mtv = b.mtid[rr], mpv = b.mpos[rr];
-            const u32 xsv = (u32)b.xs[rr], flv = (u32)b.flag[rr], mqv = (u32)b.mapq[rr], sov = b.seq_off[rr], so1v = b.seq_off[rr + 1];
-            const u32 c0 = live ? c0v : 0u, nop = live ? c1v - c0v : 0u;
-            const int32_t prv = r > 0 ? prevv : (b.prev_pos_ptr ? *b.prev_pos_ptr : b.prev_pos);
-            u32 ops[K1_OPS];
+            const bool last = chunk + trip_step >= trip_hi;
+            if (s_set_n > (u32)KC_SLOTS / 4 || last) {
+                u64 mine[KC_SLOTS / K1E_T], anc[KC_SLOTS / K1E_T];
+                u32 cnt = 0;
 #pragma unroll
-            for (int k = 0; k < K1_OPS; k++) {
-                const bool has = (u32)k < nop;
-                const u32 v = *(has ? b.cigar + c0 + k : b.cig_off);
-                ops[k] = has ? v : 0u;
-            }
-            u32 c = 0;
-            int32_t al = 0, max_nlen = 0;
-            if (live) {
-                if (posv < prv) set_error(err, b.base + (u32)r, PJB_ERR_UNSORTED);
-                if (xsv > 2) set_error(err, b.base + (u32)r, PJB_ERR_BAD_XS);
-                auto count_op = [&](u32 op) {
-                    const u32 ty = op & 15u;
-                    const int32_t ln = (int32_t)(op >> 4);
-                    if (op_consumes_ref(ty)) al += ln;
-                    if (ty == OP_N) {
-                        c++;
-                        max_nlen = ln > max_nlen ? ln : max_nlen;
+                for (int i = 0; i < KC_SLOTS / K1E_T; i++) {
+                    const int at = i * K1E_T + threadIdx.x;
+                    mine[i] = s_set[at];
+                    anc[i] = (u64)(u32)s_lo[at] | ((u64)(u32)s_hi[at] << 32);
+                    cnt += mine[i] != KD_EMPTY;
+                    s_set[at] = KD_EMPTY;
+                    s_lo[at] = INT32_MAX;
+                    s_hi[at] = INT32_MIN;
+                }
+                u32 total;
+                const u32 excl = block_escan<K1E_T / 64>(cnt, s_scan, &total);
+                if (threadIdx.x == 0) {
+                    s_base = total ? atomicAdd(&cs->n_cand, total) : 0u;
+                    s_set_n = 0;
+                }
+                __syncthreads();
+                u32 o = s_base + excl;
+#pragma unroll
+                for (int i = 0; i < KC_SLOTS / K1E_T; i++)
+                    if (mine[i] != KD_EMPTY) {
+                        E.cand[o] = mine[i];
+                        E.cand_anc[o++] = anc[i];
                     }
-                };
-#pragma unroll
-                for (int k = 0; k < K1_OPS; k++) count_op(ops[k]); // padding ops are 0M: no effect
-                for (u32 k = K1_OPS; k < nop; k++) count_op(b.cigar[c0 + k]);
-            }
-            // ordered compaction of the tile's spliced records: slot, first pair
-            const int w = threadIdx.x >> 6;
-            const u64 inc = wave_iscan<u64>(((u64)c << 16) | (u64)(c ? 1u : 0u));
-            if (lane_id() == 63) s_scanw[w] = inc;
-            // the tile's statistics (k1_count's block reduction)
-            {
-                const u32 spl = c ? 1u : 0u, uns = live && !c ? 1u : 0u;
-                const u64 packed = ((u64)wave_total<DppAdd>(c) << 32) | (u64)wave_total<DppAdd>((spl << 16) | uns);
-                const u32 len = live ? (u32)lenv : 0u; // (l_qseq >= 0)
-                const u64 sum = (u64)wave_total<DppAdd>(len & 0xffffu) + ((u64)wave_total<DppAdd>(len >> 16) << 16);
-                auto smin = [](int32_t v) { return (int32_t)(wave_total<DppMin>((u32)v ^ 0x80000000u) ^ 0x80000000u); };
-                auto smax = [](int32_t v) { return (int32_t)(wave_total<DppMax>((u32)v ^ 0x80000000u) ^ 0x80000000u); };
-                const int32_t mn = smin(live ? lenv : INT32_MAX), mx = smax(live ? lenv : 0), me = smax(c ? posv + al : 0), mnl = smax(max_nlen),
-                              mp = smin(c ? posv : INT32_MAX);
-                if (lane_id() == 0) {
-                    s_packed[w] = packed;
-                    s_sum[w] = sum;
-                    s_mm[w][0] = mn, s_mm[w][1] = mx, s_mm[w][2] = me, s_mm[w][3] = mnl, s_mm[w][4] = mp;
-                }
-            }
-            __syncthreads();
-            u64 before = 0, run = 0; // (pairs << 16 | spliced records) before this wavefront / of the tile
-#pragma unroll
-            for (int i = 0; i < K1E_T / 64; i++) {
-                const u64 t = s_scanw[i];
-                if (i < w) before += t;
-                run += t;
-            }
-            const u32 n_spl = (u32)(run & 0xffffu), tile_pairs = (u32)(run >> 16);
-            if (threadIdx.x == 0 && tile_id != 0) // (as early as possible: the tiles behind this one wait for it)
-                __hip_atomic_store(&F.tile_state[tile_id], ts_word(1, F.epoch, tile_pairs), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            TileStats t;
-            {
-                u64 pk = 0;
-                t.sum_len = 0;
-                t.min_len = INT32_MAX, t.max_len = 0, t.max_end = 0, t.max_nlen = 0, t.min_pos = INT32_MAX;
-#pragma unroll
-                for (int i = 0; i < K1E_T / 64; i++) {
-                    pk += s_packed[i];
-                    t.sum_len += s_sum[i];
-                    t.min_len = min(t.min_len, s_mm[i][0]);
-                    t.max_len = max(t.max_len, s_mm[i][1]);
-                    t.max_end = max(t.max_end, s_mm[i][2]);
-                    t.max_nlen = max(t.max_nlen, s_mm[i][3]);
-                    t.min_pos = min(t.min_pos, s_mm[i][4]);
-                }
-                t.spliced = (u32)((pk >> 16) & 0xffff);
-                t.unspliced = (u32)(pk & 0xffff);
-                t._pad = 0;
-            }
-            // may this tile emit?  Its pairs must fit the key format the host planned (k1_scan_tiles comes to the same verdict for the chain)
-            bool emit_ok = true;
-            if (!kf.raw) {
-                int need = 0;
-                for (u32 v = (u32)t.max_nlen; v; v >>= 1) need++;
-                if (t.spliced && (need > kf.lbits || t.min_pos < 0 || t.max_end > ref_len || t.max_end < 0)) emit_ok = false;
-            }
-            if (threadIdx.x == 0) {
-                TileStats o = t;
-                if (F.chk_ref_len > 0 && o.max_end > F.chk_ref_len) o.max_end = INT32_MAX;
-                F.tile_stats[tile_id] = o;
-                F.tile_cnt[tile_id] = tile_pairs;
-            }
-            if (threadIdx.x < 64) {
-                const u32 ex = tile_lookback(F.tile_state, tile_id, tile_pairs, F.epoch);
-                if (threadIdx.x == 0) s_pair_base = ex;
-            }
-            __syncthreads();
-            const u32 pair_base = s_pair_base;
-            if (emit_ok && n_spl && (u64)pair_base + tile_pairs <= (u64)F.pair_limit) {
-                if (c) {
-                    const u64 ex = before + inc - (((u64)c << 16) | 1u);
-                    const u32 e = (q_head + q_count + (u32)(ex & 0xffffu)) % QCAP;
-                    const u32 meta = read_meta(flv, xsv, mqv, posv, mtv, mpv, tid, orientation);
-                    const bool seq_ok = (u64)(so1v - sov) * 8ull >= (u64)(int64_t)lenv;
-                    s_q[Q_C0][e] = c0;
-                    s_q[Q_POS][e] = (u32)posv;
-                    s_q[Q_SO][e] = sov;
-                    s_q[Q_OFF][e] = pair_base + (u32)(ex >> 16);
-                    s_q[Q_R][e] = (u32)r;
-                    s_q[Q_NLQ][e] = (nop < 0xffffu ? nop : 0xffffu) | ((u32)lenv < 0xffffu ? (u32)lenv << 16 : 0xffff0000u);
-                    s_q[Q_META][e] = meta | (seq_ok ? 0x80000000u : 0u);
-                }
-                q_count += n_spl;
-            }
-            while (q_count >= (u32)K1E_T) { // (the trip starts with a barrier: the entries are in place)
-                trip(0u, (u32)K1E_T, false);
-                q_head = (q_head + (u32)K1E_T) % QCAP;
-                q_count -= (u32)K1E_T;
             }
         }
-        if (q_count) trip(0u, q_count, false);
-        cand_flush(true);
     }
 }
 
@@ -1944,14 +1935,11 @@ __global__ __launch_bounds__(K1E_T) __attribute__((amdgpu_waves_per_eu(K1E_WAVES
     k1_emit_body<false>(b, n_tiles_batch, n_tiles_total, tile_off, tile_soff, chunk_tile, spl_idx, spl_poff, P, E, kf, ref_len, tid, orientation, err, cs, voff,
                         gcodes, FusedArgs{});
 }
-#ifndef K1F_WAVES
-#define K1F_WAVES 6
-#endif
-// (grid: a few blocks per CU, each taking tiles until the launch's n_tiles are gone)
-__global__ __launch_bounds__(K1E_T) __attribute__((amdgpu_waves_per_eu(K1F_WAVES, K1F_WAVES))) void k1_fused(DevBatch b, u32 n_tiles, Pairs P, EmitLists E, KeyFmt kf, int32_t ref_len,
-                                                                                                  int32_t tid, int orientation, u64 *err, ContigStats *cs,
-                                                                                                  int32_t voff, const u32 *gcodes, FusedArgs F) {
-    k1_emit_body<true>(b, n_tiles, 0, nullptr, nullptr, nullptr, nullptr, nullptr, P, E, kf, ref_len, tid, orientation, err, cs, voff, gcodes, F);
+// (38 KB of LDS a block: four blocks -- 16 wavefronts -- a CU, 128 registers a lane)
+__global__ __launch_bounds__(K1E_T) __attribute__((amdgpu_waves_per_eu(4, 4))) void k1_fused(DevBatch b, Pairs P, EmitLists E, KeyFmt kf, int32_t ref_len, int32_t tid,
+                                                                                          int orientation, u64 *err, ContigStats *cs, int32_t voff,
+                                                                                          const u32 *gcodes, FusedArgs F) {
+    k1_emit_body<true>(b, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, P, E, kf, ref_len, tid, orientation, err, cs, voff, gcodes, F);
 }
 
 // per-member counters of a group, from the tile statistics of the member's tiles (before k1_scan_tiles turns the tile pair
