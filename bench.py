@@ -52,12 +52,7 @@ def algorithmic_bytes(name, N, C, S, Cs, P, J, L, Pg=0, Rg=0, R=0, cand=0):
         # spliced reads only: compacted slot + pair offset (8), cig_off, pos, l_qseq, mtid, mpos, seq_off (4 each), flag (2),
         # mapq, xs (1 each), the ops once; per pair 8 B key + 32 B record written; reads of the simple shape: L/2 B of packed
         # bases + L/2 B of genome codes; 8 B list entry per generic read; candidate keys
-        "k1_emit": S * 36 + Cs * 4 + P * 40 + (P - Pg) * L + Rg * 8 + cand * 16,
-        # K1 in one pass: every read's fixed-width fields once (pos, cig_off, l_qseq, mtid, mpos, seq_off: 4 each; flag 2; mapq, xs: 1
-        # each = 28) and every cigar op once (the spliced reads' ops come back from L2); per pair 8 B key + 32 B record written;
-        # pairs finished in closed form: L/2 B of packed bases + L/2 B of genome codes; 8 B list entry per read on k4b_generic's
-        # lists; candidate key + anchors (16); per tile of 512 reads 32 B of statistics, 4 B count, 8 B look-back word
-        "k1_fused": N * 28 + C * 4 + P * 40 + (P - Pg) * L + Rg * 8 + cand * 16 + (N / 512.0) * 44,
+        "k1_emit": S * 36 + Cs * 4 + P * 40 + (P - Pg) * L + Rg * 8 + cand * 8,
         # K2d: key (8) + lStart/rEnd half of the record (16) read, id written twice (8 B sort key, 4 B BAM-order id)
         "kd_assign": P * 36 + J * 192,
         "kd_mark": cand * 8, "kd_ends": cand * 12, "kd_table": cand * 12 + J * 8, "kd_reset": cand * 12,

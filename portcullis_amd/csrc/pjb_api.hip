@@ -146,8 +146,6 @@ struct CtlSlot {
     // what the first kernels of a contig (k1_count, k1_scan_tiles, k1_emit: the front stream) write and the rest of its
     // chain reads: the next contig's first kernels run beside this contig's last ones
     Buf tile_cnt, tile_stats, splidx, splpoff, tile_soff, chunk_tile;
-    Buf tile_state;     // k1_fused: a look-back word per tile of KF_TILE records (epoch-tagged: never reset)
-    Buf k1_ticket;      // k1_fused: the chain's next tile (u32; 0 at rest)
     Buf scan_parts;     // k1_scan_tiles: ScanPart[K1S_BLOCKS], zeroed once; scan_epoch tells one launch's parts from the last one's
     u32 scan_epoch = 0;
     Buf members; // groups: MemberStats[GROUP_MAX] | member_junc u32[GROUP_MAX] | tile_lo u32[GROUP_MAX + 1]
@@ -799,7 +797,7 @@ void pjb_destroy(pjb_ctx *c) {
             if (ev) (void)hipEventDestroy(ev);
         if (S.ev_rows) (void)hipEventDestroy(S.ev_rows);
         if (S.ev_done) (void)hipEventDestroy(S.ev_done);
-        Buf *sb[] = {&S.x_q, &S.x_spos, &S.x_send, &S.x_gapoff, &S.x_zlist, &S.x_scnt, &S.x_codes, &S.cstats, &S.err, &S.gencount, &S.batches, &S.rows, &S.tile_cnt, &S.tile_stats, &S.splidx, &S.splpoff, &S.tile_soff, &S.chunk_tile, &S.tile_state, &S.k1_ticket, &S.scan_parts, &S.members, &S.okey, &S.g,
+        Buf *sb[] = {&S.x_q, &S.x_spos, &S.x_send, &S.x_gapoff, &S.x_zlist, &S.x_scnt, &S.x_codes, &S.cstats, &S.err, &S.gencount, &S.batches, &S.rows, &S.tile_cnt, &S.tile_stats, &S.splidx, &S.splpoff, &S.tile_soff, &S.chunk_tile, &S.scan_parts, &S.members, &S.okey, &S.g,
                      &S.rec, &S.jidbam, &S.jkey, &S.total, &S.bitmap, &S.wrank, &S.ends, &S.firstid,
                      &S.key[0], &S.key[1], &S.idx[0], &S.idx[1], &S.hist, &S.hist_scan, &S.hist_part, &S.bintotal, &S.scan_tiles, &S.jid, &S.seg, &S.runfirst,
                      &S.runstart, &S.ent, &S.entsum, &S.frag, &S.fragj, &S.masks, &S.acc, &S.ancl, &S.ancr, &S.genlist};
@@ -1461,30 +1459,12 @@ static int queue_contig(pjb_ctx *c, Flight &f) {
     }
     if ((rc = ensure(c, S.err, 8))) return rc;
     if ((rc = ensure(c, c->b_cursor, sizeof(RowCursor)))) return rc;
-    // K1 in one pass (k1_fused: tiles of KF_TILE records, two per tile of K1_TILE) -- but for PJB_FLAG_EXTRA contexts, whose --extra
-    // kernels read the per-tile spliced lists the two-pass K1 (k1_count, k1_scan_tiles, k1_emit) leaves
-    const bool fused = !c->extra;
-    const u32 n_tiles_k1 = fused ? n_tiles * (K1_TILE / KF_TILE) : n_tiles;
-    if ((rc = ensure(c, S.tile_cnt, (size_t)n_tiles_k1 * 4))) return rc;
-    if ((rc = ensure(c, S.tile_stats, (size_t)n_tiles_k1 * sizeof(TileStats)))) return rc;
-    if (fused) {
-        const size_t want = (size_t)n_tiles_k1 * 8 + 64;
-        if (S.tile_state.cap < want) { // (fresh words must not look like this chain's: zero is no epoch)
-            if ((rc = ensure(c, S.tile_state, want * 2))) return rc;
-            HIP_TRY(c, hipMemset(S.tile_state.p, 0, S.tile_state.cap));
-            HIP_TRY(c, hipStreamSynchronize(nullptr));
-        }
-        if (!S.k1_ticket.p) {
-            if ((rc = ensure(c, S.k1_ticket, 64))) return rc;
-            HIP_TRY(c, hipMemset(S.k1_ticket.p, 0, 64));
-            HIP_TRY(c, hipStreamSynchronize(nullptr));
-        }
-    } else {
-        if ((rc = ensure(c, S.tile_soff, ((size_t)n_tiles + 1) * 4))) return rc;
-        if ((rc = ensure(c, S.chunk_tile, ((size_t)n_tiles * (K1_TILE / 256) + 4) * 4))) return rc;
-        if ((rc = ensure(c, S.splidx, (size_t)n_tiles * K1_TILE * 4))) return rc;
-        if ((rc = ensure(c, S.splpoff, (size_t)n_tiles * K1_TILE * 4))) return rc;
-    }
+    if ((rc = ensure(c, S.tile_cnt, (size_t)n_tiles * 4))) return rc;
+    if ((rc = ensure(c, S.tile_stats, (size_t)n_tiles * sizeof(TileStats)))) return rc;
+    if ((rc = ensure(c, S.tile_soff, ((size_t)n_tiles + 1) * 4))) return rc;
+    if ((rc = ensure(c, S.chunk_tile, ((size_t)n_tiles * (K1_TILE / 256) + 4) * 4))) return rc;
+    if ((rc = ensure(c, S.splidx, (size_t)n_tiles * K1_TILE * 4))) return rc;
+    if ((rc = ensure(c, S.splpoff, (size_t)n_tiles * K1_TILE * 4))) return rc;
     if (!S.members.p) {
         if ((rc = ensure(c, S.members, GROUP_MAX * sizeof(MemberStats) + GROUP_MAX * 4 + (GROUP_MAX + 1) * 4))) return rc;
         HIP_TRY(c, hipMemset(S.members.p, 0, S.members.cap)); // (member_junc: k7_publish leaves it zeroed for the next chain)
@@ -1573,15 +1553,13 @@ static int queue_contig(pjb_ctx *c, Flight &f) {
     HIP_TRY(c, hipMemcpyAsync(S.batches.p, S.batches_pinned, batches.size() * sizeof(DevBatch), hipMemcpyHostToDevice, front));
     if (group) { // (the tile ranges of the members; lives behind the batch descriptors in the page-locked staging block)
         u32 *h_lo = (u32 *)(S.batches_pinned + batches.size());
-        for (int m = 0; m <= n_members; m++) h_lo[m] = f.tile_lo[(size_t)m] * (fused ? (u32)(K1_TILE / KF_TILE) : 1u);
+        for (int m = 0; m <= n_members; m++) h_lo[m] = f.tile_lo[(size_t)m];
         HIP_TRY(c, hipMemcpyAsync(d_tile_lo, h_lo, (size_t)(n_members + 1) * 4, hipMemcpyHostToDevice, front));
     }
     if (!S.at_rest) {
         HIP_TRY(c, hipMemsetAsync(S.err.p, 0xff, 8, front));
         HIP_TRY(c, hipMemsetAsync(S.gencount.p, 0, GEN_SHARDS * GEN_CNT_STRIDE * 4, front));
         HIP_TRY(c, hipMemsetAsync(d_member_junc, 0, GROUP_MAX * 4, front));
-        HIP_TRY(c, hipMemsetAsync(S.cstats.p, 0, sizeof(ContigStats), front)); // (n_cand)
-        if (S.k1_ticket.p) HIP_TRY(c, hipMemsetAsync(S.k1_ticket.p, 0, 64, front));
     }
     S.at_rest = false; // until k7_publish is queued
     u64 *d_err = (u64 *)S.err.p;
@@ -1601,38 +1579,7 @@ static int queue_contig(pjb_ctx *c, Flight &f) {
     f.pr = pr;
     u32 *d_gen_cnt = (u32 *)S.gencount.p;
     const bool fast_codes = all_codes && !any_x; // (else: no read is "simple", every pair takes k4b_generic's byte-wise walks)
-    EmitLists el; // K2d's candidate keys (free until the first scatter; they are used up before it), the lists of reads for k4b_generic
-    el.cand = lim.dense ? (u64 *)S.key[1].p : (u64 *)nullptr;
-    el.cand_anc = (u64 *)S.ent.p; // (the entropy terms' buffer: free until the position runs exist)
-    el.gen_list = (u64 *)S.genlist.p;
-    el.gen_cnt = d_gen_cnt;
-    el.gen_cap = gen_cap;
-    if (fused) {
-        // ---- K1, one pass: per tile of KF_TILE records the statistics, the pairs' place (look-back), keys and records -- complete
-        // for reads of the closed-form shapes --, candidate keys, k4b_generic's lists; then the chain's totals and the limits
-        FusedArgs fa;
-        fa.tile_cnt = (u32 *)S.tile_cnt.p;
-        fa.tile_stats = (TileStats *)S.tile_stats.p;
-        fa.tile_state = (u64 *)S.tile_state.p;
-        fa.ticket = (u32 *)S.k1_ticket.p;
-        fa.epoch = ++S.scan_epoch;
-        fa.pair_limit = PL;
-        for (size_t bi = 0; bi < batches.size(); bi++) {
-            const DevBatch &b = batches[bi];
-            const int m = f.batch_member[bi];
-            const int32_t own_tid = f.tids[(size_t)m], own_len = c->ref_len[(size_t)own_tid];
-            const u32 nt = (u32)((b.n + K1_TILE - 1) / K1_TILE) * (u32)(K1_TILE / KF_TILE); // (every tile slot of the batch is taken: the look-back has no holes)
-            fa.chk_ref_len = group ? std::max(own_len, 1) : 0;
-            LAUNCH(c, "k1_fused", k1_fused, dim3(nt), dim3(K1E_T), b, pr, el, kf, own_len, own_tid, (int)c->cfg.orientation, d_err, d_cs, f.voff[(size_t)m],
-                   fast_codes ? (const u32 *)GT.codes[m] : (const u32 *)nullptr, fa);
-        }
-        if (group)
-            LAUNCH(c, "kg_member_stats", kg_member_stats, dim3((unsigned)n_members), dim3(256), (const u32 *)S.tile_cnt.p, (const TileStats *)S.tile_stats.p,
-                   (const u32 *)d_tile_lo, n_members, d_members);
-        LAUNCH(c, "k1_scan_tiles", k1_scan_tiles, dim3(c->k1s_blocks_forced ? (u32)c->k1s_blocks_forced : k1s_blocks(n_tiles_k1)), dim3(K1S_THREADS), (u32 *)S.tile_cnt.p,
-               (const TileStats *)S.tile_stats.p, n_tiles_k1, d_cs, PL, kf, group ? INT32_MAX - 1 : ref_len, (const u64 *)nullptr, (u32 *)nullptr, (u32 *)nullptr,
-               (ScanPart *)S.scan_parts.p, fa.epoch, (u32 *)S.k1_ticket.p);
-    } else {
+    {
         // ---- K1a: count (a group's members: a tile whose alignments leave the member's own sequence is flagged); with
         // PJB_FLAG_EXTRA the first time also what the records span (a chain that is queued again leaves that alone: the
         // service stream may be reading it)
@@ -1667,10 +1614,16 @@ static int queue_contig(pjb_ctx *c, Flight &f) {
                    (const u32 *)d_tile_lo, n_members, d_members);
         LAUNCH(c, "k1_scan_tiles", k1_scan_tiles, dim3(c->k1s_blocks_forced ? (u32)c->k1s_blocks_forced : k1s_blocks(n_tiles)), dim3(K1S_THREADS), (u32 *)S.tile_cnt.p, (const TileStats *)S.tile_stats.p,
                n_tiles, d_cs, PL, kf, group ? INT32_MAX - 1 : ref_len, (const u64 *)nullptr, (u32 *)S.tile_soff.p, (u32 *)S.chunk_tile.p,
-               (ScanPart *)S.scan_parts.p, ++S.scan_epoch, (u32 *)nullptr);
+               (ScanPart *)S.scan_parts.p, ++S.scan_epoch);
         // ---- K1b: emit (coordinates in the group's virtual sequence): keys, the pairs' records -- complete for reads of the
         // simple shape --, K2d's candidate keys (free until the first scatter; they are used up before it), the list of
         // reads for k4b_generic
+        EmitLists el;
+        el.cand = lim.dense ? (u64 *)S.key[1].p : (u64 *)nullptr;
+        el.cand_anc = (u64 *)S.ent.p; // (the entropy terms' buffer: free until the position runs exist)
+        el.gen_list = (u64 *)S.genlist.p;
+        el.gen_cnt = d_gen_cnt;
+        el.gen_cap = gen_cap;
         for (size_t bi = 0; bi < batches.size(); bi++) {
             const DevBatch &b = batches[bi];
             const int m = f.batch_member[bi];
@@ -1927,7 +1880,7 @@ static int queue_contig(pjb_ctx *c, Flight &f) {
         c->stream = rows_stream; // LAUNCH (and its event bracket) follow c->stream
         LAUNCH(c, "k6_rows_out", k6_rows_out, dim3(K6_BLOCKS), dim3(256), (const u64 *)S.rows.p, (const ContigStats *)d_cs,
                (u64 *)c->rows_table, row_base, mirror_base, (const RowCursor *)c->b_cursor.p, mirror_table, mirror_room);
-        LAUNCH(c, "k7_publish", k7_publish, dim3(1), dim3(256), d_cs, d_err, d_gen_cnt, S.pub_dev, row_base,
+        LAUNCH(c, "k7_publish", k7_publish, dim3(1), dim3(256), (const ContigStats *)d_cs, d_err, d_gen_cnt, S.pub_dev, row_base,
                mirror_base, (RowCursor *)c->b_cursor.p, (const MemberStats *)d_members, d_member_junc, n_members);
     }
     S.at_rest = true;

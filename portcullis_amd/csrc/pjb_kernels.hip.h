@@ -800,7 +800,7 @@ __host__ __device__ inline u32 k1s_blocks(u32 n_tiles) { // ~1024 tiles a block
 }
 __global__ __launch_bounds__(K1S_THREADS) void k1_scan_tiles(u32 *tile_cnt, const TileStats *ts, u32 n_tiles, ContigStats *out, u32 pair_limit,
                                                               KeyFmt kf, int32_t ref_len, const u64 *tile_desc, u32 *tile_soff, u32 *chunk_tile,
-                                                              ScanPart *parts, u32 epoch, u32 *fused_ticket) {
+                                                              ScanPart *parts, u32 epoch) {
     constexpr int NW = K1S_THREADS / 64;
     __shared__ u64 wsum[NW];
     __shared__ u32 wsum2[NW];
@@ -924,9 +924,8 @@ __global__ __launch_bounds__(K1S_THREADS) void k1_scan_tiles(u32 *tile_cnt, cons
         }
     }
     __syncthreads();
-    // ---- pass B: the scan of the range, from the sums before it (the tiles' counts once more: L2 hits).  (Not after k1_fused -- fused_ticket
-    // != nullptr --: its tiles placed their pairs themselves and the counts stay counts; only the sums above are wanted.)
-    for (u32 base = lo; base < hi && !fused_ticket; base += K1S_THREADS * K1S_PER) {
+    // ---- pass B: the scan of the range, from the sums before it (the tiles' counts once more: L2 hits)
+    for (u32 base = lo; base < hi; base += K1S_THREADS * K1S_PER) {
         const u32 i0 = base + K1S_PER * threadIdx.x;
         u64 v[K1S_PER];
         u32 v2[K1S_PER];
@@ -990,8 +989,7 @@ __global__ __launch_bounds__(K1S_THREADS) void k1_scan_tiles(u32 *tile_cnt, cons
     if (threadIdx.x == 0) {
         if (tile_soff) tile_soff[n_tiles] = carry2_s;
         const ScanPart b = total_s;
-        const u64 n_pairs = fused_ticket ? b.pairs + mine.pairs : carry_s;
-        if (fused_ticket) *fused_ticket = 0; // (rest state: the next chain's tiles are numbered from 0)
+        const u64 n_pairs = carry_s;
         const int32_t m0 = min(b.mn, mine.mn), m1 = max(b.mx, mine.mx), m2 = max(b.max_end, mine.max_end), m3 = max(b.max_nlen, mine.max_nlen),
                       m4 = min(b.min_pos, mine.min_pos);
         out->spliced = b.spl + mine.spl;
@@ -1019,7 +1017,7 @@ __global__ __launch_bounds__(K1S_THREADS) void k1_scan_tiles(u32 *tile_cnt, cons
         out->P = ovf ? 0u : (u32)n_pairs;
         out->J = out->R = out->n_slots = out->n_slices = 0;
         out->n_junc = out->n_runs = 0;
-        if (!fused_ticket || ovf) out->n_cand = 0; // (k1_fused has filled the candidate list already; k7_publish puts the count back to 0)
+        out->n_cand = 0;
     }
 }
 
@@ -1360,72 +1358,14 @@ struct EmitLists {
                     // whatever the address in it
     u32 gen_cap;    // room of one sub-list
 };
-__host__ __device__ inline u32 gen_list_cap(u32 pair_limit) {
-    // k1_fused deals its tiles to the sub-lists by the 512-pair chunk their first pair falls into: the tiles that start in one
-    // chunk hold fewer than 512 pairs together but for the last one, which adds at most its 512 records -- 1024 entries a chunk.
-    // (k1_emit, two-pass: chunks of 256 spliced reads dealt round-robin, 256 entries each -- covered.)
-    const u32 chunks = pair_limit / 512u + 2u;
-    return ((chunks + GEN_SHARDS - 1) / GEN_SHARDS) * 1024u;
+__host__ __device__ inline u32 gen_list_cap(u32 pair_limit) { // chunks of 256 spliced reads dealt round-robin to the sub-lists
+    const u32 chunks = pair_limit / 256u + 2u;
+    return ((chunks + GEN_SHARDS - 1) / GEN_SHARDS) * 256u;
 }
-// FUSED (every chain but those of PJB_FLAG_EXTRA contexts): ONE pass over the records.  A block takes the chain's next tile of
-// KF_TILE records (a ticket: tiles are taken in order), does what k1_count does for it -- coalesced loads of every record's
-// fixed-width fields and first operations, the statistics, the number of pairs --, publishes the number and learns where the
-// tile's pairs start from the tiles before it (a decoupled look-back over F.tile_state: a word per tile holds "the tile's
-// count" or "the count of everything up to and including the tile" under the chain's epoch; tiles of earlier batches of the
-// chain are complete, tiles of this launch publish their count as soon as they have it), keeps what the spliced records'
-// emission needs in LDS, and emits -- the trips below, over the block's own list.  No second read of the fixed-width
-// fields, no per-tile spliced lists in memory, no scan kernel between two passes; k1_scan_tiles (fused mode) only adds
-// the tiles' statistics up and checks the limits.  A tile whose pairs do not fit the limits the host assumed (pair
-// capacity, key format) emits nothing; the chain is repeated.
-constexpr int KF_TILE = 512;
-struct FusedArgs {
-    u32 *tile_cnt;         // [tiles] pairs of the tile (kg_member_stats and k1_scan_tiles add them up)
-    TileStats *tile_stats; // [tiles]
-    u64 *tile_state;       // [tiles] status << 62 | epoch << 32 | value: status 1 = the tile's pairs, 2 = pairs up to and including the tile
-    u32 *ticket;           // the chain's next tile (rest state 0: k1_scan_tiles puts it back)
-    u32 epoch;             // 30 bits, one per queued chain: words of earlier chains read as "not there yet"
-    u32 pair_limit;
-    int32_t chk_ref_len;   // > 0 (members of a group): see k1_count
-};
-__device__ __forceinline__ u64 ts_word(u32 status, u32 epoch, u64 value) {
-    return ((u64)status << 62) | ((u64)(epoch & 0x3fffffffu) << 32) | (value > 0xffffffffull ? 0xffffffffull : value);
-}
-// pairs of all tiles before `tile` (saturating at 2^32 - 1: such a chain is refused); called by one whole wavefront
-__device__ __forceinline__ u32 tile_lookback(u64 *state, u32 tile, u32 cnt, u32 epoch) {
-    const u32 lane = (u32)lane_id();
-    if (tile == 0) {
-        if (lane == 0) __hip_atomic_store(&state[0], ts_word(2, epoch, cnt), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        return 0;
-    }
-    u64 excl = 0;
-    int64_t idx = (int64_t)tile - 1;
-    while (idx >= 0) {
-        const int64_t my = idx - (int64_t)lane;
-        u64 v = ts_word(2, epoch, 0); // (before the chain's first tile: nothing)
-        if (my >= 0) {
-            for (;;) {
-                v = __hip_atomic_load(&state[my], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (((u32)(v >> 32) & 0x3fffffffu) == (epoch & 0x3fffffffu) && (v >> 62) != 0) break;
-                __builtin_amdgcn_s_sleep(2);
-            }
-        }
-        const u64 full = __ballot((v >> 62) == 2);
-        if (full) { // the nearest tile that knows its prefix ends the walk
-            const u32 first = (u32)__ffsll((long long)full) - 1u;
-            excl += wave_sum(lane <= first ? (v & 0xffffffffull) : 0ull);
-            break;
-        }
-        excl += wave_sum(v & 0xffffffffull);
-        idx -= 64;
-    }
-    if (lane == 0) __hip_atomic_store(&state[tile], ts_word(2, epoch, excl + cnt), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return excl > 0xffffffffull ? 0xffffffffu : (u32)excl;
-}
-template <bool FUSED>
-__device__ __forceinline__ void k1_emit_body(DevBatch b, u32 n_tiles_batch, u32 n_tiles_total, const u32 *tile_off, const u32 *tile_soff,
+__global__ __launch_bounds__(K1E_T) __attribute__((amdgpu_waves_per_eu(K1E_WAVES, K1E_WAVES))) void k1_emit(DevBatch b, u32 n_tiles_batch, u32 n_tiles_total, const u32 *tile_off, const u32 *tile_soff,
                                                 const u32 *chunk_tile, const u32 *spl_idx, const u32 *spl_poff, Pairs P, EmitLists E, KeyFmt kf,
                                                 int32_t ref_len, int32_t tid, int orientation, u64 *err, ContigStats *cs, int32_t voff,
-                                                const u32 *gcodes, FusedArgs F) {
+                                                const u32 *gcodes) {
     __shared__ u32 s_ops[OPS_LDS][K1E_T];
     __shared__ u32 s_soff[K1E_LOOK];
     __shared__ u64 s_set[KC_SLOTS];
@@ -1435,187 +1375,12 @@ __device__ __forceinline__ void k1_emit_body(DevBatch b, u32 n_tiles_batch, u32 
     enum { GQ_N = 0, GQ_POS, GQ_G, GQ_META, GQ_LQ, GQ_OFF, GQ_C0, GQ_SO, GQ_WORDS };
     __shared__ u32 s_gq[GQ_WORDS][K1E_T];
     __shared__ u32 s_gq_n;
+    if (cs->P == 0) return; // no pairs, or a limit was exceeded: the contig is repeated with larger buffers
+    const u32 s_begin = tile_soff[b.tile_base], s_end = tile_soff[b.tile_base + n_tiles_batch];
+    if (s_begin == s_end) return;
+    const u32 c_lo = s_begin >> K1E_SHIFT, c_hi = (s_end + (u32)K1E_T - 1u) >> K1E_SHIFT; // trips of K1E_T list entries
     const bool want_cand = E.cand != nullptr;
     const int32_t vlen = voff + ref_len; // the target's end in the group's virtual sequence
-    u32 s_begin = 0, s_end = 0, c_lo = 0, c_hi = 0;
-    // (FUSED) the tile's spliced records, in BAM order: what their emission needs
-    enum { Q_C0 = 0, Q_N, Q_POS, Q_SO, Q_LQ, Q_POFF, Q_RMETA, Q_WORDS };
-    __shared__ u32 s_q[FUSED ? Q_WORDS : 1][FUSED ? KF_TILE : 1];
-    u32 n_spl = 0, pair_base = 0, fused_read_base = 0;
-    if constexpr (!FUSED) {
-        if (cs->P == 0) return; // no pairs, or a limit was exceeded: the contig is repeated with larger buffers
-        s_begin = tile_soff[b.tile_base], s_end = tile_soff[b.tile_base + n_tiles_batch];
-        if (s_begin == s_end) return;
-        c_lo = s_begin >> K1E_SHIFT, c_hi = (s_end + (u32)K1E_T - 1u) >> K1E_SHIFT; // trips of K1E_T list entries
-    } else {
-        constexpr int RNDS = KF_TILE / K1E_T, K1_OPS = 4;
-        __shared__ u32 s_tile, s_pair_base;
-        __shared__ u64 s_scanw[RNDS][K1E_T / 64], s_sum[K1E_T / 64], s_packed[K1E_T / 64];
-        __shared__ int32_t s_mm[K1E_T / 64][5];
-        if (threadIdx.x == 0) s_tile = atomicAdd(F.ticket, 1u);
-        __syncthreads();
-        const u32 tile_id = s_tile; // (chain-wide; a batch's tiles start at 2 b.tile_base: tile_base counts tiles of K1_TILE records)
-        const int64_t base = (int64_t)(tile_id - 2u * b.tile_base) * KF_TILE;
-        fused_read_base = (u32)base;
-        u32 cnt = 0, spl = 0, uns = 0;
-        u64 sum = 0;
-        int32_t mn = INT32_MAX, mx = 0, max_end = 0, max_nlen = 0, min_pos = INT32_MAX;
-        u32 c0a[RNDS], nop[RNDS], ops[RNDS][K1_OPS], xsa[RNDS], c4[RNDS], soa[RNDS], so1a[RNDS], fla[RNDS], mqa[RNDS];
-        int32_t posa[RNDS], prva[RNDS], lena[RNDS], mtida[RNDS], mposa[RNDS];
-        // (every load unconditional, from a clamped index, masked afterwards: see k1_count)
-#pragma unroll
-        for (int it = 0; it < RNDS; it++) {
-            const int64_t r = base + it * K1E_T + threadIdx.x;
-            const bool on = r < b.n;
-            const int64_t rr = on ? r : (b.n > 0 ? b.n - 1 : 0), rp = rr > 0 ? rr - 1 : 0;
-            const u32 c0v = b.cig_off[rr], c1v = b.cig_off[rr + 1];
-            const int32_t posv = b.pos[rr], prevv = b.pos[rp], lenv = b.l_qseq[rr], mtv = b.mtid[rr], mpv = b.mpos[rr];
-            const u32 xsv = (u32)b.xs[rr], flv = (u32)b.flag[rr], mqv = (u32)b.mapq[rr], sov = b.seq_off[rr], so1v = b.seq_off[rr + 1];
-            c0a[it] = on ? c0v : 0u;
-            nop[it] = on ? c1v - c0v : 0u;
-            posa[it] = on ? posv : 0;
-            prva[it] = on ? (r > 0 ? prevv : (b.prev_pos_ptr ? *b.prev_pos_ptr : b.prev_pos)) : 0;
-            xsa[it] = on ? xsv : 0u;
-            lena[it] = on ? lenv : 0;
-            fla[it] = flv, mqa[it] = mqv, mtida[it] = mtv, mposa[it] = mpv, soa[it] = sov, so1a[it] = so1v;
-        }
-#pragma unroll
-        for (int it = 0; it < RNDS; it++)
-#pragma unroll
-            for (int k = 0; k < K1_OPS; k++) {
-                const bool has = (u32)k < nop[it];
-                const u32 v = *(has ? b.cigar + c0a[it] + k : b.cig_off);
-                ops[it][k] = has ? v : 0u;
-            }
-#pragma unroll
-        for (int it = 0; it < RNDS; it++) {
-            const int64_t r = base + it * K1E_T + threadIdx.x;
-            u32 c = 0;
-            if (r < b.n) {
-                const int32_t p = posa[it];
-                if (p < prva[it]) set_error(err, b.base + (u32)r, PJB_ERR_UNSORTED);
-                if (xsa[it] > 2) set_error(err, b.base + (u32)r, PJB_ERR_BAD_XS);
-                int32_t al = 0;
-                auto count_op = [&](u32 op) {
-                    const u32 ty = op & 15u;
-                    const int32_t ln = (int32_t)(op >> 4);
-                    if (op_consumes_ref(ty)) al += ln;
-                    if (ty == OP_N) {
-                        c++;
-                        max_nlen = ln > max_nlen ? ln : max_nlen;
-                    }
-                };
-#pragma unroll
-                for (int k = 0; k < K1_OPS; k++) count_op(ops[it][k]); // padding ops are 0M: no effect
-                for (u32 k = K1_OPS; k < nop[it]; k++) count_op(b.cigar[c0a[it] + k]);
-                const int32_t len = lena[it];
-                mn = len < mn ? len : mn;
-                mx = len > mx ? len : mx;
-                sum += (u64)(int64_t)len;
-                cnt += c;
-                if (c) {
-                    spl++;
-                    const int32_t e = p + al;
-                    max_end = e > max_end ? e : max_end;
-                    min_pos = p < min_pos ? p : min_pos;
-                } else
-                    uns++;
-            }
-            c4[it] = c;
-        }
-        // ordered compaction of the tile's spliced records (record order is round-major, as in k1_count): slot, first pair
-        u64 inc[RNDS];
-        const int w = threadIdx.x >> 6;
-#pragma unroll
-        for (int it = 0; it < RNDS; it++) {
-            inc[it] = wave_iscan<u64>(((u64)c4[it] << 16) | (u64)(c4[it] ? 1u : 0u));
-            if (lane_id() == 63) s_scanw[it][w] = inc[it];
-        }
-        __syncthreads();
-        u64 run = 0; // (pairs << 16 | spliced records) of everything before, in record order
-#pragma unroll
-        for (int it = 0; it < RNDS; it++) {
-            u64 before = run;
-#pragma unroll
-            for (int i = 0; i < K1E_T / 64; i++) {
-                const u64 t = s_scanw[it][i];
-                if (i < w) before += t;
-                run += t;
-            }
-            if (c4[it]) {
-                const u64 ex = before + inc[it] - (((u64)c4[it] << 16) | 1u);
-                const u32 slot = (u32)(ex & 0xffffu);
-                const u32 meta = read_meta(fla[it], xsa[it], mqa[it], posa[it], mtida[it], mposa[it], tid, orientation);
-                const bool seq_ok = (u64)(so1a[it] - soa[it]) * 8ull >= (u64)(int64_t)lena[it];
-                s_q[Q_C0][slot] = c0a[it];
-                s_q[Q_N][slot] = nop[it];
-                s_q[Q_POS][slot] = (u32)posa[it];
-                s_q[Q_SO][slot] = soa[it];
-                s_q[Q_LQ][slot] = (u32)lena[it];
-                s_q[Q_POFF][slot] = (u32)(ex >> 16);
-                s_q[Q_RMETA][slot] = (u32)(it * K1E_T + threadIdx.x) | (meta << 10) | (seq_ok ? 0x80000000u : 0u);
-            }
-        }
-        n_spl = (u32)(run & 0xffffu);
-        const u32 tile_pairs = (u32)(run >> 16);
-        if (threadIdx.x == 0 && tile_id != 0) // (as early as possible: the tiles behind this one wait for it)
-            __hip_atomic_store(&F.tile_state[tile_id], ts_word(1, F.epoch, tile_pairs), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        // the tile's statistics (k1_count's block reduction)
-        {
-            const u64 packed = ((u64)wave_total<DppAdd>(cnt) << 32) | (u64)wave_total<DppAdd>((spl << 16) | uns);
-            sum = (u64)wave_total<DppAdd>((u32)(sum & 0xffffu)) + ((u64)wave_total<DppAdd>((u32)((sum >> 16) & 0xffffu)) << 16) +
-                  ((u64)wave_total<DppAdd>((u32)(sum >> 32)) << 32);
-            auto smin = [](int32_t v) { return (int32_t)(wave_total<DppMin>((u32)v ^ 0x80000000u) ^ 0x80000000u); };
-            auto smax = [](int32_t v) { return (int32_t)(wave_total<DppMax>((u32)v ^ 0x80000000u) ^ 0x80000000u); };
-            mn = smin(mn), mx = smax(mx), max_end = smax(max_end), max_nlen = smax(max_nlen), min_pos = smin(min_pos);
-            if (lane_id() == 0) {
-                s_packed[w] = packed;
-                s_sum[w] = sum;
-                s_mm[w][0] = mn, s_mm[w][1] = mx, s_mm[w][2] = max_end, s_mm[w][3] = max_nlen, s_mm[w][4] = min_pos;
-            }
-        }
-        __syncthreads();
-        TileStats t;
-        {
-            u64 pk = 0;
-            t.sum_len = 0;
-            t.min_len = INT32_MAX, t.max_len = 0, t.max_end = 0, t.max_nlen = 0, t.min_pos = INT32_MAX;
-#pragma unroll
-            for (int i = 0; i < K1E_T / 64; i++) {
-                pk += s_packed[i];
-                t.sum_len += s_sum[i];
-                t.min_len = min(t.min_len, s_mm[i][0]);
-                t.max_len = max(t.max_len, s_mm[i][1]);
-                t.max_end = max(t.max_end, s_mm[i][2]);
-                t.max_nlen = max(t.max_nlen, s_mm[i][3]);
-                t.min_pos = min(t.min_pos, s_mm[i][4]);
-            }
-            t.spliced = (u32)((pk >> 16) & 0xffff);
-            t.unspliced = (u32)(pk & 0xffff);
-            t._pad = 0;
-        }
-        // may this tile emit?  Its pairs must fit the key format the host planned (k1_scan_tiles comes to the same verdict for the chain)
-        bool emit_ok = true;
-        if (!kf.raw) {
-            int need = 0;
-            for (u32 v = (u32)t.max_nlen; v; v >>= 1) need++;
-            if (t.spliced && (need > kf.lbits || t.min_pos < 0 || t.max_end > ref_len || t.max_end < 0)) emit_ok = false;
-        }
-        if (threadIdx.x == 0) {
-            TileStats o = t;
-            if (F.chk_ref_len > 0 && o.max_end > F.chk_ref_len) o.max_end = INT32_MAX;
-            F.tile_stats[tile_id] = o;
-            F.tile_cnt[tile_id] = tile_pairs;
-        }
-        if (threadIdx.x < 64) {
-            const u32 ex = tile_lookback(F.tile_state, tile_id, tile_pairs, F.epoch);
-            if (threadIdx.x == 0) s_pair_base = ex;
-        }
-        __syncthreads();
-        pair_base = s_pair_base;
-        if (!emit_ok || (u64)pair_base + tile_pairs > (u64)F.pair_limit) n_spl = 0;
-        if (n_spl == 0) return;
-    }
     if (want_cand) {
 #pragma unroll
         for (int i = 0; i < KC_SLOTS / K1E_T; i++) {
@@ -1653,7 +1418,7 @@ __device__ __forceinline__ void k1_emit_body(DevBatch b, u32 n_tiles_batch, u32 
     auto list_append = [&](u32 kind, bool mine, u32 pairs, u64 entry, u32 chunk) {
         const u64 gm2 = __ballot(mine);
         if (!gm2) return;
-        const u32 shard = FUSED ? (pair_base >> 9) % GEN_SHARDS : (chunk >> (8 - K1E_SHIFT)) % GEN_SHARDS; // (gen_list_cap)
+        const u32 shard = (chunk >> (8 - K1E_SHIFT)) % GEN_SHARDS;
         const u32 pairs_w = wave_total<DppAdd>(mine ? pairs : 0u);
         const int leader = __ffsll((long long)gm2) - 1;
         const u32 w0 = shard * GEN_CNT_STRIDE + (kind - 1) * 2;
@@ -1666,18 +1431,15 @@ __device__ __forceinline__ void k1_emit_body(DevBatch b, u32 n_tiles_batch, u32 
         const u32 at = base + (u32)__popcll(gm2 & ((1ull << lane_id()) - 1));
         if (mine && at < E.gen_cap) E.gen_list[((size_t)(kind - 1) * GEN_SHARDS + shard) * E.gen_cap + at] = entry;
     };
-    const u32 trip_lo = FUSED ? 0u : c_lo + blockIdx.x, trip_hi = FUSED ? (n_spl + (u32)K1E_T - 1u) >> K1E_SHIFT : c_hi, trip_step = FUSED ? 1u : gridDim.x;
-    for (u32 chunk = trip_lo; chunk < trip_hi; chunk += trip_step) {
-        u32 t0 = 0;
-        if constexpr (!FUSED) // the tile of the chunk's first entry (for the batch's first chunk: of the batch's first entry)
-            t0 = (chunk << K1E_SHIFT) < s_begin ? b.tile_base : chunk_tile[chunk >> (8 - K1E_SHIFT)]; // (chunk_tile: the tile of entry 256 c)
+    for (u32 chunk = c_lo + blockIdx.x; chunk < c_hi; chunk += gridDim.x) {
+        // the tile of the chunk's first entry (for the batch's first chunk: of the batch's first entry)
+        u32 t0 = (chunk << K1E_SHIFT) < s_begin ? b.tile_base : chunk_tile[chunk >> (8 - K1E_SHIFT)]; // (chunk_tile: the tile of entry 256 c)
         __syncthreads();
-        if constexpr (!FUSED)
-            if (threadIdx.x < K1E_LOOK) s_soff[threadIdx.x] = t0 + threadIdx.x <= n_tiles_total ? tile_soff[t0 + threadIdx.x] : 0xffffffffu;
+        if (threadIdx.x < K1E_LOOK) s_soff[threadIdx.x] = t0 + threadIdx.x <= n_tiles_total ? tile_soff[t0 + threadIdx.x] : 0xffffffffu;
         if (threadIdx.x == 0) s_gq_n = 0;
         __syncthreads();
         const u32 s = (chunk << K1E_SHIFT) + threadIdx.x;
-        const bool on = FUSED ? s < n_spl : (s >= s_begin && s < s_end);
+        const bool on = s >= s_begin && s < s_end;
         // ---- phase 1: every read's fixed-width fields and first operations; a read of the shape [S] M N M [S] (l_qseq matching, bases
         // present) is finished here, in closed form: one pair, no walk (junction_system.cc:140-210 for one N operation)
         bool generic = false;
@@ -1685,48 +1447,25 @@ __device__ __forceinline__ void k1_emit_body(DevBatch b, u32 n_tiles_batch, u32 
         u64 p1_entry = 0;
         u32 q_n = 0, q_pos = 0, q_g = 0, q_meta = 0, q_lq = 0, q_off = 0, q_c0 = 0, q_so = 0;
         if (on) {
-            int64_t r;
-            u32 c0, n, off, meta, so;
-            int32_t pos, lq;
-            bool seq_ok;
-            if constexpr (FUSED) {
-                const u32 rm = s_q[Q_RMETA][s];
-                r = (int64_t)fused_read_base + (int64_t)(rm & 0x3ffu);
-                c0 = s_q[Q_C0][s];
-                n = s_q[Q_N][s];
-                pos = (int32_t)s_q[Q_POS][s];
-                so = s_q[Q_SO][s];
-                lq = (int32_t)s_q[Q_LQ][s];
-                off = pair_base + s_q[Q_POFF][s];
-                meta = (rm >> 10) & 0x1fffffu;
-                seq_ok = (rm >> 31) != 0;
-            } else {
-                u32 k = 0; // (the offsets ascend: the entry's tile is the number of them it has reached -- 15 independent LDS reads, not a walk)
+            u32 k = 0; // (the offsets ascend: the entry's tile is the number of them it has reached -- 15 independent LDS reads, not a walk)
 #pragma unroll
-                for (int m = 1; m < K1E_LOOK; m++) k += s >= s_soff[m] ? 1u : 0u;
-                u32 tile = t0 + k, soff = s_soff[k];
-                if (k + 1 == (u32)K1E_LOOK && s >= soff) { // (a run of tiles without spliced reads longer than the window: search)
-                    u32 lo = tile, hi = n_tiles_total; // tile_soff[lo] <= s < tile_soff[hi]
-                    while (hi - lo > 1) {
-                        const u32 mid = (lo + hi) >> 1;
-                        if (tile_soff[mid] <= s) lo = mid;
-                        else hi = mid;
-                    }
-                    tile = lo;
-                    soff = tile_soff[lo];
+            for (int m = 1; m < K1E_LOOK; m++) k += s >= s_soff[m] ? 1u : 0u;
+            u32 tile = t0 + k, soff = s_soff[k];
+            if (k + 1 == (u32)K1E_LOOK && s >= soff) { // (a run of tiles without spliced reads longer than the window: search)
+                u32 lo = tile, hi = n_tiles_total; // tile_soff[lo] <= s < tile_soff[hi]
+                while (hi - lo > 1) {
+                    const u32 mid = (lo + hi) >> 1;
+                    if (tile_soff[mid] <= s) lo = mid;
+                    else hi = mid;
                 }
-                const u32 toff = tile_off[tile];
-                const size_t slot = (size_t)tile * K1_TILE + (s - soff);
-                r = spl_idx[slot];
-                c0 = b.cig_off[r];
-                n = b.cig_off[r + 1] - c0;
-                pos = b.pos[r];
-                off = toff + spl_poff[slot];
-                meta = read_meta(b.flag[r], (u32)b.xs[r], b.mapq[r], pos, b.mtid[r], b.mpos[r], tid, orientation);
-                lq = b.l_qseq[r];
-                so = b.seq_off[r];
-                seq_ok = (u64)(b.seq_off[r + 1] - so) * 8ull >= (u64)(int64_t)lq;
+                tile = lo;
+                soff = tile_soff[lo];
             }
+            const u32 toff = tile_off[tile];
+            const size_t slot = (size_t)tile * K1_TILE + (s - soff);
+            const int64_t r = spl_idx[slot];
+            const u32 c0 = b.cig_off[r], c1 = b.cig_off[r + 1];
+            const u32 n = c1 - c0;
             u32 op[OPS_LDS];
 #pragma unroll
             for (int q = 0; q < OPS_LDS; q++) { // (unconditional loads, masked: see k1_count)
@@ -1735,7 +1474,13 @@ __device__ __forceinline__ void k1_emit_body(DevBatch b, u32 n_tiles_batch, u32 
                 op[q] = has ? v : 0u;
                 s_ops[q][threadIdx.x] = op[q];
             }
+            const int32_t pos = b.pos[r];
             const u32 g = b.base + (u32)r;
+            const u32 off = toff + spl_poff[slot];
+            u32 meta = read_meta(b.flag[r], (u32)b.xs[r], b.mapq[r], pos, b.mtid[r], b.mpos[r], tid, orientation);
+            const int32_t lq = b.l_qseq[r];
+            const u32 so = b.seq_off[r];
+            const bool seq_ok = (u64)(b.seq_off[r + 1] - so) * 8ull >= (u64)(int64_t)lq;
             // ---- shape: [S] M N M [S], or -- two introns, nothing clamped -- [S] M N M N M [S]
             bool simple = false, two = false;
             u32 dS = 0, a = 0, nl = 0, b2 = 0, nl2 = 0, b3 = 0;
@@ -1895,7 +1640,7 @@ __device__ __forceinline__ void k1_emit_body(DevBatch b, u32 n_tiles_batch, u32 
         // ---- candidate keys: flush the set when it fills up, and before the block leaves
         if (want_cand) {
             __syncthreads();
-            const bool last = chunk + trip_step >= trip_hi;
+            const bool last = chunk + gridDim.x >= c_hi;
             if (s_set_n > (u32)KC_SLOTS / 4 || last) {
                 u64 mine[KC_SLOTS / K1E_T], anc[KC_SLOTS / K1E_T];
                 u32 cnt = 0;
@@ -1926,20 +1671,6 @@ __device__ __forceinline__ void k1_emit_body(DevBatch b, u32 n_tiles_batch, u32 
             }
         }
     }
-}
-
-__global__ __launch_bounds__(K1E_T) __attribute__((amdgpu_waves_per_eu(K1E_WAVES, K1E_WAVES))) void k1_emit(DevBatch b, u32 n_tiles_batch, u32 n_tiles_total, const u32 *tile_off, const u32 *tile_soff,
-                                                const u32 *chunk_tile, const u32 *spl_idx, const u32 *spl_poff, Pairs P, EmitLists E, KeyFmt kf,
-                                                int32_t ref_len, int32_t tid, int orientation, u64 *err, ContigStats *cs, int32_t voff,
-                                                const u32 *gcodes) {
-    k1_emit_body<false>(b, n_tiles_batch, n_tiles_total, tile_off, tile_soff, chunk_tile, spl_idx, spl_poff, P, E, kf, ref_len, tid, orientation, err, cs, voff,
-                        gcodes, FusedArgs{});
-}
-// (38 KB of LDS a block: four blocks -- 16 wavefronts -- a CU, 128 registers a lane)
-__global__ __launch_bounds__(K1E_T) __attribute__((amdgpu_waves_per_eu(4, 4))) void k1_fused(DevBatch b, Pairs P, EmitLists E, KeyFmt kf, int32_t ref_len, int32_t tid,
-                                                                                          int orientation, u64 *err, ContigStats *cs, int32_t voff,
-                                                                                          const u32 *gcodes, FusedArgs F) {
-    k1_emit_body<true>(b, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, P, E, kf, ref_len, tid, orientation, err, cs, voff, gcodes, F);
 }
 
 // per-member counters of a group, from the tile statistics of the member's tiles (before k1_scan_tiles turns the tile pair
@@ -3450,7 +3181,7 @@ __global__ __launch_bounds__(256) void k6_rows_out(const u64 *rows, const Contig
 // control slot next, and the row cursor moves on.
 constexpr int PUB_BASE_AT = 240, PUB_ERR_AT = 256, PUB_XCNT_AT = 320 /* --extra: the target's counters, 64 bytes */, PUB_GEN_AT = 512, PUB_MEMBERS_AT = 1536, PUB_GREADS_AT = 3072, PUB_BYTES = 4096; // byte offsets in the published block
 static_assert(PUB_MEMBERS_AT + GROUP_MAX * sizeof(MemberStats) <= PUB_BYTES && sizeof(MemberStats) % 8 == 0, "control block layout");
-__global__ __launch_bounds__(256) void k7_publish(ContigStats *cs, u64 *err, u32 *gen_cnt, uint8_t *host, int64_t base,
+__global__ __launch_bounds__(256) void k7_publish(const ContigStats *cs, u64 *err, u32 *gen_cnt, uint8_t *host, int64_t base,
                                                   int64_t mirror_base, RowCursor *cur, const MemberStats *members, u32 *member_junc, int n_members) {
     const u32 t = threadIdx.x;
     if (n_members > 1 && t < (u32)n_members) { // a group: the members' own counters
@@ -3479,7 +3210,6 @@ __global__ __launch_bounds__(256) void k7_publish(ContigStats *cs, u64 *err, u32
     }
     __syncthreads();
     if (t < (u32)GROUP_MAX) member_junc[t] = 0; // (k5_finalize counts into it; rest state for the chain that uses the slot next)
-    if (t == 0) cs->n_cand = 0;                 // (k1_fused appends candidates from the chain's first tile on)
 }
 
 } // namespace pjb
