@@ -39,11 +39,12 @@ sys.path.insert(0, ROOT)
 PEAK_HBM_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 
 
-def algorithmic_bytes(name, N, C, S, Cs, P, J, L, Pg=0, Rg=0, R=0, cand=0):
+def algorithmic_bytes(name, N, C, S, Cs, P, J, L, Pg=0, Rg=0, R=0, cand=0, Rv=0, sort_u32=True, G=0):
     """Algorithmic HBM bytes of ONE launch of kernel `name` over one chain (each byte counted once per logical
     pass, caches ignored; DESIGN.md section 4 derives these).  N reads, C cigar ops, S spliced reads, Cs cigar ops
     of spliced reads, P pairs, J junctions, L read length, Pg pairs / Rg reads that take the generic walks, R
-    position runs, cand candidate keys."""
+    position runs, cand candidate keys, Rv reads whose closed form k4b_generic only checks, sort_u32: the sort ran on
+    dense 32-bit ids (else on the 64-bit keys), G bases of the chain's targets."""
     frags = P / 64.0 + J
     ops_s = Cs / max(S, 1)  # cigar ops of a spliced read
     table = {
@@ -53,19 +54,30 @@ def algorithmic_bytes(name, N, C, S, Cs, P, J, L, Pg=0, Rg=0, R=0, cand=0):
         # mapq, xs (1 each), the ops once; per pair 8 B key + 32 B record written; reads of the simple shape: L/2 B of packed
         # bases + L/2 B of genome codes; 8 B list entry per generic read; candidate keys
         "k1_emit": S * 36 + Cs * 4 + P * 40 + (P - Pg) * L + Rg * 8 + cand * 8,
-        # K2d: key (8) + lStart/rEnd half of the record (16) read, id written twice (8 B sort key, 4 B BAM-order id)
-        "kd_assign": P * 36 + J * 192,
-        "kd_mark": cand * 8, "kd_ends": cand * 12, "kd_table": cand * 12 + J * 8, "kd_reset": cand * 12,
-        "rs_hist": P * 8,
-        "rs_scatter": P * 24,
+        # K2d.  kd_assign: the pair's key read (8), its junction id written (4); the accumulators' rest state (192 B per junction)
+        "kd_assign": P * 12 + J * 192,
+        # candidates: key (8), anchors (8), rank (4); bitmap words / end slots they touch; kd_table writes key + anchors per junction
+        "kd_mark": cand * 16, "kd_ends": cand * 12 + cand * 4, "kd_table": cand * 20 + J * 16, "kd_reset": cand * 12 + cand * 40,
+        # prefix popcount over the start bitmap (a bit per base of the chain's targets): words read twice, a 4-B rank per word
+        # written; the scan over the start ranks' end slots (32 B per start, J starts at most) gives the first ids
+        "kd_rank_reduce": G / 64.0 * 8, "kd_rank_apply": G / 64.0 * 12, "kd_first_reduce": J * 32.0, "kd_first_apply": J * 44.0,
+        # the sort: key in (4 or 8), index in (4, but for the first pass), both out
+        "rs_hist": P * (4 if sort_u32 else 8),
+        "rs_scatter": P * (16 if sort_u32 else 24),
+        "rs_panel_sums": P / 4096.0 * 4096, "rs_panel_scan": P / 4096.0 * 8192,  # the tiles' digit counts (1024 x 4 B a tile): read; read + written
         # sorted key (8) + index (4) + the position word of the record behind it (4); the apply pass writes the junction id
         "k2_heads_reduce": P * 16,
         "k2_heads_apply": P * 16 + P * 4 + (J + J + R) * 4,
         # generic reads: list entry (8), cig_off (8), ops, pos/aend half of the first record (16), l_qseq, seq_off (12), L/2 B of
         # bases; per generic pair: id (4), key (8), anchors (8), genome codes of its window (~L/2), result (8)
-        "k4b_generic": Rg * (44 + 4 * ops_s + L / 2) + Pg * (28 + L / 2),
+        "k4b_generic": Rg * (44 + 4 * ops_s + L / 2) + Pg * (28 + L / 2) + Rv * (8 + 16 + 2 * 28),
+        # dense chains: a popcount scan over the slices' two mask words, then seg_off / run_first per junction, run_start per run, from
+        # the sorted ids (4 B per pair) and the masks
+        "k2_runs_reduce": P / 64.0 * 8, "k2_runs_apply": P / 64.0 * 12,
+        "k2_expand": P * 4 + P / 64.0 * 20 + (2 * J + R) * 4,
+        "k1_scan_tiles": N / 1024.0 * 48, "kg_member_stats": N / 1024.0 * 36, "k7_publish": 4096.0,
         # sorted index + id (8), ONE 32-B record, the junction's key (J entries, cached); one 192-B fragment record + its id
-        "k4_pairs": P * 40 + frags * 196,
+        "k4_pairs": P * 40 + frags * 196 + P / 64.0 * 16,
         "k5_frag_reduce": frags * 196 + J * 164,
         "k5_finalize": J * (192 + 8 + 8 + 8 + 48 + 200),
         # per run: run_start (two neighbours: 4), id of its first pair (4), 8-B term written; per junction seg_off / run_first
@@ -377,11 +389,13 @@ def main():
                 tm = per.get(tuple(g), {})
                 b = algorithmic_bytes(name, sum(c["n"] for c in cs_), sum(c["C"] for c in cs_), sum(c["S"] for c in cs_),
                                       sum(c["Cs"] for c in cs_), sum(c["P"] for c in cs_), Jc, L, int(tm.get("generic_pairs", 0)),
-                                      int(tm.get("generic_reads", 0)), int(tm.get("position_runs", 0)), int(tm.get("candidates", 0)))
+                                      int(tm.get("generic_reads", 0)), int(tm.get("position_runs", 0)), int(tm.get("candidates", 0)),
+                                      int(tm.get("checked_reads", 0)), int(tm.get("candidates", 0)) > 0,
+                                      sum(int(c["genome"].numel()) for c in cs_))
                 if b is None:
                     known = False
                     break
-                mult = int(tm.get("sort_passes", 1)) if name in ("rs_hist", "rs_scatter") else 1
+                mult = int(tm.get("sort_passes", 1)) if name in ("rs_hist", "rs_scatter", "rs_panel_sums", "rs_panel_scan") else 1
                 tot_b += b * mult
             per_step = launches / args.steps
             kern.append(dict(name=name, launches=launches, avg_ms=ms / launches, total_ms=ms,

@@ -50,7 +50,7 @@ extern "C" {
 #endif
 
 #define PJB_ABI_VERSION 3 /* 2: pjb_batch.name_hash, PJB_FLAG_EXTRA, pjb_extra_finish
-                           * 3: pjb_timing grew (generic_reads, position_runs, candidates); PJB_MAX_QUEUED 8; pjb_last_error is per calling
+                           * 3: pjb_timing grew (generic_reads, position_runs, candidates, checked_reads); PJB_MAX_QUEUED 8; pjb_last_error is per calling
                            *    thread; additive since 2: PJB_FLAG_NO_CHAINS, pjb_finish_group_begin/_end, pjb_finish_ready, pjb_deflate_bgzf,
                            *    pjb_host_register/_unregister; the option "fused_k1" is gone */
 
@@ -187,6 +187,9 @@ typedef struct pjb_timing {
     int64_t generic_reads; /* the reads those pairs belong to */
     int64_t position_runs; /* runs of equal read position inside the junctions (the units of the entropy kernels) */
     int64_t candidates;    /* candidate keys the dense junction ids were built from (0: the chain sorted the full keys) */
+    int64_t checked_reads; /* reads of the shape [S] M (N M)+ [S] with two or more introns: finished in closed form by k1_emit, their junctions'
+                              anchor windows checked by k4b_generic (not counted in generic_reads unless the check failed... they never are: a
+                              failed check walks the read without moving it to the other list) */
 } pjb_timing;
 
 /* ---- entry points ------------------------------------------------------ */

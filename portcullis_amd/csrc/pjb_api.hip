@@ -2183,6 +2183,7 @@ static int collect_flight(pjb_ctx *c, pjb_region_result *res, bool *redo_single)
     c->timing.sort_passes = f.n_pass;
     c->timing.generic_pairs = 0;
     c->timing.generic_reads = 0;
+    c->timing.checked_reads = *(const u32 *)(S.pub + PUB_CHECKED_AT);
     for (u32 k = 0; k < GEN_SHARDS; k++) {
         c->timing.generic_pairs += ((const u32 *)(S.pub + PUB_GEN_AT))[k];
         c->timing.generic_reads += ((const u32 *)(S.pub + PUB_GREADS_AT))[k];

@@ -3179,7 +3179,7 @@ __global__ __launch_bounds__(256) void k6_rows_out(const u64 *rows, const Contig
 // The last kernel of a contig: control block, error word and list counters go to page-locked host memory in one go
 // (three small copies otherwise), error word and counters return to their rest state for the contig that uses this
 // control slot next, and the row cursor moves on.
-constexpr int PUB_BASE_AT = 240, PUB_ERR_AT = 256, PUB_XCNT_AT = 320 /* --extra: the target's counters, 64 bytes */, PUB_GEN_AT = 512, PUB_MEMBERS_AT = 1536, PUB_GREADS_AT = 3072, PUB_BYTES = 4096; // byte offsets in the published block
+constexpr int PUB_BASE_AT = 240, PUB_ERR_AT = 256, PUB_XCNT_AT = 320 /* --extra: the target's counters, 64 bytes */, PUB_CHECKED_AT = 384 /* reads on k4b_generic's second list */, PUB_GEN_AT = 512, PUB_MEMBERS_AT = 1536, PUB_GREADS_AT = 3072, PUB_BYTES = 4096; // byte offsets in the published block
 static_assert(PUB_MEMBERS_AT + GROUP_MAX * sizeof(MemberStats) <= PUB_BYTES && sizeof(MemberStats) % 8 == 0, "control block layout");
 __global__ __launch_bounds__(256) void k7_publish(const ContigStats *cs, u64 *err, u32 *gen_cnt, uint8_t *host, int64_t base,
                                                   int64_t mirror_base, RowCursor *cur, const MemberStats *members, u32 *member_junc, int n_members) {
@@ -3194,6 +3194,11 @@ __global__ __launch_bounds__(256) void k7_publish(const ContigStats *cs, u64 *er
                       PUB_GREADS_AT + GEN_SHARDS * 4 <= PUB_BYTES,
                   "control block layout");
     if (t < sizeof(ContigStats) / 8) reinterpret_cast<u64 *>(host)[t] = reinterpret_cast<const u64 *>(cs)[t];
+    __shared__ u32 s_chk[4];
+    {
+        const u32 chk = wave_total<DppAdd>(t < GEN_SHARDS ? gen_cnt[t * GEN_CNT_STRIDE + 2] : 0u);
+        if (lane_id() == 0) s_chk[t >> 6] = chk;
+    }
     if (t < GEN_SHARDS) { // pairs that took the generic walks, per sub-list; both counters back to their rest state
         reinterpret_cast<u32 *>(host + PUB_GEN_AT)[t] = gen_cnt[t * GEN_CNT_STRIDE + 1];
         reinterpret_cast<u32 *>(host + PUB_GREADS_AT)[t] = gen_cnt[t * GEN_CNT_STRIDE];
@@ -3210,6 +3215,7 @@ __global__ __launch_bounds__(256) void k7_publish(const ContigStats *cs, u64 *er
     }
     __syncthreads();
     if (t < (u32)GROUP_MAX) member_junc[t] = 0; // (k5_finalize counts into it; rest state for the chain that uses the slot next)
+    if (t == 0) *reinterpret_cast<u32 *>(host + PUB_CHECKED_AT) = s_chk[0] + s_chk[1] + s_chk[2] + s_chk[3];
 }
 
 } // namespace pjb
