@@ -275,13 +275,8 @@ int pjb_finish_group_end(pjb_ctx *ctx, const int32_t *tids, int32_t n_tids, pjb_
 /* Tuning switches (queue must be empty).  Results never depend on them.
  *   "overlap"    1 (default): a contig's kernels are spread over several HIP streams -- its first kernels beside the
  *                previous contig's last ones, match statistics and entropy beside the sort and the anchors; 0: one
- *                kernel at a time on one stream (clean per-kernel timings; also the environment variable
- *                PJB_SIDE_STREAM=0)
+ *                kernel at a time on one stream (clean per-kernel timings)
  *   "dense_ids"  1 (default): the sort works on ordered dense junction ids; 0: on the full intron keys
- *                (PJB_DENSE_IDS=0)
- *   "fused_k1"   0 (default): a counting pass, a scan and a second pass over the spliced records; 1: one pass over the
- *                records counts the N operations, places the tile's pairs and writes them (k1_walk; measured slower
- *                on contig-sized inputs; PJB_FUSED_K1=1)
  *   "extra_dense" 0 (default): PJB_FLAG_EXTRA answers depth and flanking counts from the unspliced records themselves
  *                (a few records per junction) and builds a target's per-base depth vector only where htslib's
  *                8000-record pileup cap may bite; 1: the depth vector for every target (round 2's path) */
