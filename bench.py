@@ -75,15 +75,14 @@ def algorithmic_bytes(name, N, C, S, Cs, P, J, L, Pg=0, Rg=0, R=0, cand=0, Rv=0,
         # the sorted ids (4 B per pair) and the masks
         "k2_runs_reduce": P / 64.0 * 8, "k2_runs_apply": P / 64.0 * 12,
         "k2_expand": P * 4 + P / 64.0 * 20 + (2 * J + R) * 4,
-        "k1_scan_tiles": N / 1024.0 * 48, "kg_member_stats": N / 1024.0 * 36, "k7_publish": 4096.0,
+        "k1_scan_tiles": N / 1024.0 * 48, "kg_member_stats": N / 1024.0 * 36,
         # sorted index + id (8), ONE 32-B record, the junction's key (J entries, cached); one 192-B fragment record + its id
         "k4_pairs": P * 40 + frags * 196 + P / 64.0 * 16,
         "k5_frag_reduce": frags * 196 + J * 164,
         "k5_finalize": J * (192 + 8 + 8 + 8 + 48 + 200),
-        # per run: run_start (two neighbours: 4), id of its first pair (4), 8-B term written; per junction seg_off / run_first
-        "k5_entropy_terms": R * 16 + J * 16,
-        "k5_entropy_sum": R * 8 + J * 16,
-        "k6_rows_out": J * 200 * 2,
+        # per run: its start (4; the next run's start is the neighbour's); per junction seg_off, run_first, the 8-B sum
+        "k5_entropy_sum": R * 4 + J * 20,
+        "k6_rows_out": J * 200 * 2 + 4096,
     }
     return table.get(name)
 

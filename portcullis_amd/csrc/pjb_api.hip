@@ -159,10 +159,10 @@ struct CtlSlot {
     bool dense_at_rest = false;
     hipStream_t main = nullptr, side = nullptr; // chain; match statistics / entropy beside it
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_fork2 = nullptr, ev_join2 = nullptr;
-    uint8_t *pub = nullptr, *pub_dev = nullptr; // page-locked: what k7_publish writes (host view, device view)
+    uint8_t *pub = nullptr, *pub_dev = nullptr; // page-locked: what k6_rows_out (publish_chain) writes (host view, device view)
     DevBatch *batches_pinned = nullptr;         // page-locked staging of the batch descriptors
     size_t batches_pinned_cap = 0;
-    bool at_rest = false;                       // error word / list counters are in their rest state (k7_publish restores it)
+    bool at_rest = false;                       // error word / list counters are in their rest state (k6_rows_out (publish_chain) restores it)
     hipEvent_t ev[PJB_N_STAGES + 2] = {};
     hipEvent_t ev_rows = nullptr, ev_done = nullptr;
 };
@@ -211,7 +211,7 @@ struct pjb_ctx {
     pjb_config cfg;
     hipStream_t stream = nullptr;  // service stream: uploads, host batches, BAM ingest, filters, extra metrics; a contig's chain runs
                                    // on its slot's streams (CtlSlot::main / side)
-    hipStream_t stream3 = nullptr; // rows stream: k6_rows_out + k7_publish of a contig, beside the next contig's first kernels
+    hipStream_t stream3 = nullptr; // rows stream: k6_rows_out + k6_rows_out (publish_chain) of a contig, beside the next contig's first kernels
     hipStream_t stream4 = nullptr; // header of the row mirror
     hipEvent_t ev_front = nullptr; // service stream -> chain stream
     CtlSlot sl[PJB_MAX_QUEUED];
@@ -257,7 +257,7 @@ struct pjb_ctx {
     pjb_junction_row *rows_table = nullptr;      // the same table in HBM (k6_rows_out appends; a DMA per contig fills rows_pinned)
     bool rows_copy_pending = false;              // a DMA into rows_pinned is on stream4
     // buffers with a rest state that the kernel chain itself restores (no per-contig memsets): error word / list
-    // counters (k7_publish; per slot), start bitmap / end slots (kd_reset).  false: set by a memset before use
+    // counters (k6_rows_out (publish_chain); per slot), start bitmap / end slots (kd_reset).  false: set by a memset before use
     int last_slot = 0; // slot of the contig collected last (pjb_collect_device)
     int inflate_lanes = 512 * 64;                // lanes of one bgzf_inflate launch (2 workgroups x 256 CUs; set from the device at create)
     bool side_stream = true;                     // k4b_generic / entropy beside the main stream (pjb_set_option("overlap", 0): everything on one stream)
@@ -1458,7 +1458,11 @@ static int queue_contig(pjb_ctx *c, Flight &f) {
         HIP_TRY(c, hipStreamSynchronize(nullptr));
     }
     if ((rc = ensure(c, S.err, 8))) return rc;
-    if ((rc = ensure(c, c->b_cursor, sizeof(RowCursor)))) return rc;
+    if (!c->b_cursor.p) {
+        if ((rc = ensure(c, c->b_cursor, sizeof(RowCursor)))) return rc;
+        HIP_TRY(c, hipMemset(c->b_cursor.p, 0, sizeof(RowCursor))); // (blocks_done)
+        HIP_TRY(c, hipStreamSynchronize(nullptr));
+    }
     if ((rc = ensure(c, S.tile_cnt, (size_t)n_tiles * 4))) return rc;
     if ((rc = ensure(c, S.tile_stats, (size_t)n_tiles * sizeof(TileStats)))) return rc;
     if ((rc = ensure(c, S.tile_soff, ((size_t)n_tiles + 1) * 4))) return rc;
@@ -1467,7 +1471,7 @@ static int queue_contig(pjb_ctx *c, Flight &f) {
     if ((rc = ensure(c, S.splpoff, (size_t)n_tiles * K1_TILE * 4))) return rc;
     if (!S.members.p) {
         if ((rc = ensure(c, S.members, GROUP_MAX * sizeof(MemberStats) + GROUP_MAX * 4 + (GROUP_MAX + 1) * 4))) return rc;
-        HIP_TRY(c, hipMemset(S.members.p, 0, S.members.cap)); // (member_junc: k7_publish leaves it zeroed for the next chain)
+        HIP_TRY(c, hipMemset(S.members.p, 0, S.members.cap)); // (member_junc: k6_rows_out (publish_chain) leaves it zeroed for the next chain)
         HIP_TRY(c, hipStreamSynchronize(nullptr));
     }
     MemberStats *d_members = (MemberStats *)S.members.p;
@@ -1561,10 +1565,10 @@ static int queue_contig(pjb_ctx *c, Flight &f) {
         HIP_TRY(c, hipMemsetAsync(S.gencount.p, 0, GEN_SHARDS * GEN_CNT_STRIDE * 4, front));
         HIP_TRY(c, hipMemsetAsync(d_member_junc, 0, GROUP_MAX * 4, front));
     }
-    S.at_rest = false; // until k7_publish is queued
+    S.at_rest = false; // until k6_rows_out (publish_chain) is queued
     u64 *d_err = (u64 *)S.err.p;
     ContigStats *d_cs = (ContigStats *)S.cstats.p;
-    const u32 *d_P = &d_cs->P, *d_J = &d_cs->J, *d_R = &d_cs->R, *d_slots = &d_cs->n_slots;
+    const u32 *d_P = &d_cs->P, *d_J = &d_cs->J, *d_slots = &d_cs->n_slots;
     // stage boundaries are timed only under full instrumentation: an event between two kernels costs a ~6 us bubble
     const bool stage_events = c->ktime && c->ktime_only.empty();
 #define STAGE_EVENT(k)                                            \
@@ -1572,6 +1576,20 @@ static int queue_contig(pjb_ctx *c, Flight &f) {
         if (stage_events) HIP_TRY(c, hipEventRecord(S.ev[k], st));  \
     } while (0)
     HIP_TRY(c, hipEventRecord(S.ev[0], front));
+    // K2d's bitmap and end slots (all-clear at rest): k1_emit sets the bits
+    const size_t n_words = ((size_t)std::max(ref_len, 1) + 63) / 64;
+    if (lim.dense) {
+        const void *was[2] = {S.bitmap.p, S.ends.p};
+        if ((rc = ensure(c, S.bitmap, n_words * 8 + 16))) return rc;
+        if ((rc = ensure(c, S.wrank, n_words * 4 + 16))) return rc;
+        if ((rc = ensure(c, S.ends, (size_t)JL * DENSE_ENDS * 4 + 32))) return rc;
+        if ((rc = ensure(c, S.firstid, (size_t)JL * 4 + 16))) return rc;
+        if (!S.dense_at_rest || was[0] != S.bitmap.p || was[1] != S.ends.p) { // (first use, new memory, or a chain that broke off)
+            HIP_TRY(c, hipMemsetAsync(S.bitmap.p, 0, S.bitmap.cap, front));
+            HIP_TRY(c, hipMemsetAsync(S.ends.p, 0xff, S.ends.cap, front));
+        }
+        S.dense_at_rest = false; // until kd_reset is queued
+    }
     Pairs pr;
     pr.key = (u64 *)S.okey.p;
     pr.rec = (PairRec *)S.rec.p;
@@ -1620,7 +1638,8 @@ static int queue_contig(pjb_ctx *c, Flight &f) {
         // reads for k4b_generic
         EmitLists el;
         el.cand = lim.dense ? (u64 *)S.key[1].p : (u64 *)nullptr;
-        el.cand_anc = (u64 *)S.ent.p; // (the entropy terms' buffer: free until the position runs exist)
+        el.bitmap = lim.dense ? (u64 *)S.bitmap.p : (u64 *)nullptr;
+        el.cand_anc = (u64 *)S.ent.p; // (a pair-sized scratch buffer nothing else uses at this point)
         el.gen_list = (u64 *)S.genlist.p;
         el.gen_cnt = d_gen_cnt;
         el.gen_cap = gen_cap;
@@ -1662,36 +1681,25 @@ static int queue_contig(pjb_ctx *c, Flight &f) {
     // ---- K2d: ordered dense junction ids (the sort then works on 15-19 bits instead of 46-48)
     int sort_bits = kf.total_bits;
     if (lim.dense) {
-        const size_t n_words = ((size_t)std::max(ref_len, 1) + 63) / 64;
-        const void *was[2] = {S.bitmap.p, S.ends.p};
-        if ((rc = ensure(c, S.bitmap, n_words * 8 + 16))) return rc;
-        if ((rc = ensure(c, S.wrank, n_words * 4 + 16))) return rc;
-        if ((rc = ensure(c, S.ends, (size_t)JL * DENSE_ENDS * 4 + 32))) return rc;
-        if ((rc = ensure(c, S.firstid, (size_t)JL * 4 + 16))) return rc;
-        if (!S.dense_at_rest || was[0] != S.bitmap.p || was[1] != S.ends.p) { // (first use, new memory, or a chain that broke off)
-            HIP_TRY(c, hipMemsetAsync(S.bitmap.p, 0, S.bitmap.cap, st));
-            HIP_TRY(c, hipMemsetAsync(S.ends.p, 0xff, S.ends.cap, st));
-        }
-        S.dense_at_rest = false; // until kd_reset is queued
+        const u32 cand_blocks = std::min<u32>(pair_blocks, 1024u); // (a few candidates per junction: these kernels stride)
         const u64 *okey = (const u64 *)pr.key;
-        u64 *cand = (u64 *)S.key[1].p; // (k1_emit left the candidate keys here)
-        LAUNCH(c, "kd_mark", kd_mark, dim3(pair_blocks), dim3(256), (const u64 *)cand, (const ContigStats *)d_cs, kf, (u64 *)S.bitmap.p);
+        u64 *cand = (u64 *)S.key[1].p; // (k1_emit left the candidate keys here, and their starts' bits in the bitmap)
         if ((rc = run_scan(c, "kd_rank", PopcFn{(const u64 *)S.bitmap.p}, ExclusiveU32Sink{(u32 *)S.wrank.p}, (u64)n_words,
                            (u64 *)S.total.p)))
             return rc;
         u32 *cand_rank = (u32 *)S.idx[1].p; // (free until the first scatter as well)
-        LAUNCH(c, "kd_ends", kd_ends, dim3(pair_blocks), dim3(256), (const u64 *)cand, kf, (const u64 *)S.bitmap.p, (const u32 *)S.wrank.p, JL,
+        LAUNCH(c, "kd_ends", kd_ends, dim3(cand_blocks), dim3(256), (const u64 *)cand, kf, (const u64 *)S.bitmap.p, (const u32 *)S.wrank.p, JL,
                (u32 *)S.ends.p, cand_rank, d_cs);
         if ((rc = run_scan(c, "kd_first", EndsCountFn{(const u32 *)S.ends.p}, FirstIdSink{(u32 *)S.firstid.p, (int32_t *)S.ancl.p, (int32_t *)S.ancr.p},
                            (u64)JL, (u64 *)S.total.p)))
             return rc;
-        LAUNCH(c, "kd_table", kd_table, dim3(pair_blocks), dim3(256), (const u64 *)cand, (const u64 *)S.ent.p, (const u32 *)cand_rank, kf, JL,
+        LAUNCH(c, "kd_table", kd_table, dim3(cand_blocks), dim3(256), (const u64 *)cand, (const u64 *)S.ent.p, (const u32 *)cand_rank, kf, JL,
                (const u32 *)S.ends.p, (const u32 *)S.firstid.p, (const u64 *)S.total.p, (u64 *)S.jkey.p, (int32_t *)S.ancl.p, (int32_t *)S.ancr.p, d_cs);
         LAUNCH(c, "kd_assign", kd_assign, dim3(pair_blocks), dim3(256), okey, d_P, kf, (const u64 *)S.bitmap.p, (const u32 *)S.wrank.p,
                (const u32 *)S.ends.p, (const u32 *)S.firstid.p, JL, (const u64 *)S.total.p, (u32 *)S.jidbam.p, (u32 *)S.acc.p, (const u64 *)S.jkey.p,
                (const int32_t *)S.ancl.p, (const int32_t *)S.ancr.p, d_err, d_cs);
         if ((rc = fork_k4b())) return rc;
-        LAUNCH(c, "kd_reset", kd_reset, dim3(pair_blocks), dim3(256), (const u64 *)cand, (const u32 *)cand_rank, kf, JL, (const ContigStats *)d_cs,
+        LAUNCH(c, "kd_reset", kd_reset, dim3(cand_blocks), dim3(256), (const u64 *)cand, (const u32 *)cand_rank, kf, JL, (const ContigStats *)d_cs,
                (u64 *)S.bitmap.p, (u32 *)S.ends.p);
         S.dense_at_rest = true;
         sort_bits = std::max(1, bits_of((uint64_t)JL));
@@ -1754,10 +1762,8 @@ static int queue_contig(pjb_ctx *c, Flight &f) {
     const u32 n_slices_lim = (PL + 63) / 64 + 1;
     const hipStream_t tl = st;
     auto entropy_kernels = [&]() -> int {
-        LAUNCH(c, "k5_entropy_terms", k5_entropy_terms, dim3(pair_blocks), dim3(256), jid_sorted, (const u32 *)S.seg.p, (const u32 *)S.runfirst.p,
-               (const u32 *)S.runstart.p, d_R, (double *)S.ent.p);
-        LAUNCH(c, "k5_entropy_sum", k5_entropy_sum, dim3(std::max<u32>(1, (JL + 3) / 4)), dim3(256), (const u32 *)S.runfirst.p,
-               (const double *)S.ent.p, d_J, (double *)S.entsum.p);
+        LAUNCH(c, "k5_entropy_sum", k5_entropy_sum, dim3(std::max<u32>(1, (JL + 3) / 4)), dim3(256), (const u32 *)S.seg.p, (const u32 *)S.runfirst.p,
+               (const u32 *)S.runstart.p, d_J, (double *)S.entsum.p);
         return PJB_OK;
     };
     bool entropy_forked = false;
@@ -1879,9 +1885,8 @@ static int queue_contig(pjb_ctx *c, Flight &f) {
         } scope{c, c->stream};
         c->stream = rows_stream; // LAUNCH (and its event bracket) follow c->stream
         LAUNCH(c, "k6_rows_out", k6_rows_out, dim3(K6_BLOCKS), dim3(256), (const u64 *)S.rows.p, (const ContigStats *)d_cs,
-               (u64 *)c->rows_table, row_base, mirror_base, (const RowCursor *)c->b_cursor.p, mirror_table, mirror_room);
-        LAUNCH(c, "k7_publish", k7_publish, dim3(1), dim3(256), (const ContigStats *)d_cs, d_err, d_gen_cnt, S.pub_dev, row_base,
-               mirror_base, (RowCursor *)c->b_cursor.p, (const MemberStats *)d_members, d_member_junc, n_members);
+               (u64 *)c->rows_table, row_base, mirror_base, (RowCursor *)c->b_cursor.p, mirror_table, mirror_room, d_err, d_gen_cnt, S.pub_dev,
+               (const MemberStats *)d_members, d_member_junc, n_members);
     }
     S.at_rest = true;
     HIP_TRY(c, hipEventRecord(S.ev[7], rows_stream));

@@ -1350,6 +1350,7 @@ constexpr u64 KD_EMPTY = ~0ull; // no key: a packed key has fewer than 64 bits
 constexpr u32 GEN_SHARDS = 256, GEN_CNT_STRIDE = 32;
 struct EmitLists {
     u64 *cand;      // candidate keys (nullptr: the chain sorts the full keys and wants none); their count is ContigStats::n_cand
+    u64 *bitmap;    // K2d's bitmap of intron starts (all-clear at rest): every candidate sets its start's bit as it is listed
     u64 *cand_anc;  // per candidate: min lStart | max rEnd << 32 over the pairs it stands for (the junction anchors' first level)
     u64 *gen_list;  // global read ordinal | index of the read's first pair << 32: [2][GEN_SHARDS][gen_cap] -- the reads whose
                     // pairs need the generic walks, then the reads whose closed form waits for the window check (k4b_generic)
@@ -1390,6 +1391,11 @@ __global__ __launch_bounds__(K1E_T) __attribute__((amdgpu_waves_per_eu(K1E_WAVES
         }
         if (threadIdx.x == 0) s_set_n = 0;
     }
+    auto cand_mark = [&](u64 k) { // (what kd_mark did in a launch of its own)
+        int32_t ms, me;
+        unpack_key(kf, k, ms, me);
+        atomicOr((unsigned long long *)(E.bitmap + ((u32)ms >> 6)), 1ull << (ms & 63));
+    };
     auto cand_insert = [&](u64 k, int32_t lstart, int32_t rend) {
         u32 h = (u32)((k * 0x9E3779B97F4A7C15ull) >> 40) & (KC_SLOTS - 1);
         for (int probe = 0; probe < 24; probe++) { // look first: most keys are there already, and a read of one address by many lanes is a broadcast
@@ -1412,6 +1418,7 @@ __global__ __launch_bounds__(K1E_T) __attribute__((amdgpu_waves_per_eu(K1E_WAVES
         const u32 at = atomicAdd(&cs->n_cand, 1u);
         E.cand[at] = k;
         E.cand_anc[at] = (u64)(u32)lstart | ((u64)(u32)rend << 32);
+        cand_mark(k);
     };
     // appends the wavefront's reads of one kind to k4b_generic's list `kind` (1: the walks, 2: window check): one returning
     // atomic per wavefront; sub-list by 256-entry chunk (gen_list_cap)
@@ -1667,6 +1674,7 @@ __global__ __launch_bounds__(K1E_T) __attribute__((amdgpu_waves_per_eu(K1E_WAVES
                     if (mine[i] != KD_EMPTY) {
                         E.cand[o] = mine[i];
                         E.cand_anc[o++] = anc[i];
+                        cand_mark(mine[i]);
                     }
             }
         }
@@ -1751,51 +1759,46 @@ __device__ __forceinline__ u32 start_rank(const u64 *bitmap, const u32 *wrank, i
 // neighbouring starts) are served one after the other by a single L2 channel -- measured, 0.5 ns each, 1.4 ms for the
 // pairs of one contig.  So only the CANDIDATE list (1-3x the number of junctions) touches the bitmap and the end slots.
 // candidates -> one bit per contig base: an intron starts here
-__global__ __launch_bounds__(256) void kd_mark(const u64 *cand, const ContigStats *cs, KeyFmt kf, u64 *bitmap) {
-    const u32 p = blockIdx.x * 256 + threadIdx.x;
-    if (p >= cs->n_cand) return;
-    int32_t s, e;
-    unpack_key(kf, cand[p], s, e);
-    atomicOr((unsigned long long *)(bitmap + ((u32)s >> 6)), 1ull << (s & 63));
-}
 struct PopcFn {
     const u64 *words;
     __device__ u64 operator()(u64 i) const { return (u64)__popcll(words[i]); }
 };
 __global__ __launch_bounds__(256) void kd_ends(const u64 *cand, KeyFmt kf, const u64 *bitmap, const u32 *wrank, u32 junc_limit, u32 *ends,
                                                u32 *cand_rank, ContigStats *cs) {
-    const u32 p = blockIdx.x * 256 + threadIdx.x;
-    if (p >= cs->n_cand) return;
-    int32_t s, e;
-    unpack_key(kf, cand[p], s, e);
-    const u32 rs = start_rank(bitmap, wrank, s);
-    cand_rank[p] = rs;
-    if (rs >= junc_limit) {
-        atomicOr(&cs->overflow, OVF_JUNC);
-        return;
+    const u32 n = cs->n_cand; // (a few candidates per junction: the grid is small and strides)
+    for (u32 p = blockIdx.x * 256 + threadIdx.x; p < n; p += gridDim.x * 256) {
+        int32_t s, e;
+        unpack_key(kf, cand[p], s, e);
+        const u32 rs = start_rank(bitmap, wrank, s);
+        cand_rank[p] = rs;
+        if (rs >= junc_limit) {
+            atomicOr(&cs->overflow, OVF_JUNC);
+            continue;
+        }
+        u32 *slot = ends + (size_t)rs * DENSE_ENDS;
+        const u32 ue = (u32)e;
+        bool placed = false;
+        for (int k = 0; k < DENSE_ENDS && !placed; k++) {
+            const u32 cur = atomicCAS(&slot[k], DENSE_EMPTY, ue);
+            placed = cur == DENSE_EMPTY || cur == ue; // else: the slot holds another end (slots never change once set)
+        }
+        if (!placed) atomicOr(&cs->overflow, OVF_DENSE);
     }
-    u32 *slot = ends + (size_t)rs * DENSE_ENDS;
-    const u32 ue = (u32)e;
-    for (int k = 0; k < DENSE_ENDS; k++) {
-        const u32 cur = atomicCAS(&slot[k], DENSE_EMPTY, ue);
-        if (cur == DENSE_EMPTY || cur == ue) return;
-        // else: the slot holds another end (slots never change once set)
-    }
-    atomicOr(&cs->overflow, OVF_DENSE);
 }
 // Bitmap and end slots are all-clear at rest: instead of two memsets over contig-sized buffers per contig, the
 // candidates wipe exactly what they set (after kd_assign has read it).
 __global__ __launch_bounds__(256) void kd_reset(const u64 *cand, const u32 *cand_rank, KeyFmt kf, u32 junc_limit, const ContigStats *cs,
                                                 u64 *bitmap, u32 *ends) {
-    const u32 p = blockIdx.x * 256 + threadIdx.x;
-    if (p >= cs->n_cand) return;
-    int32_t s, e;
-    unpack_key(kf, cand[p], s, e);
-    bitmap[(u32)s >> 6] = 0;
-    const u32 rs = cand_rank[p];
-    if (rs < junc_limit) {
-        uint4 *q = reinterpret_cast<uint4 *>(ends + (size_t)rs * DENSE_ENDS);
-        q[0] = q[1] = make_uint4(DENSE_EMPTY, DENSE_EMPTY, DENSE_EMPTY, DENSE_EMPTY);
+    const u32 n = cs->n_cand;
+    for (u32 p = blockIdx.x * 256 + threadIdx.x; p < n; p += gridDim.x * 256) {
+        int32_t s, e;
+        unpack_key(kf, cand[p], s, e);
+        bitmap[(u32)s >> 6] = 0;
+        const u32 rs = cand_rank[p];
+        if (rs < junc_limit) {
+            uint4 *q = reinterpret_cast<uint4 *>(ends + (size_t)rs * DENSE_ENDS);
+            q[0] = q[1] = make_uint4(DENSE_EMPTY, DENSE_EMPTY, DENSE_EMPTY, DENSE_EMPTY);
+        }
     }
 }
 struct EndsCountFn {
@@ -1885,21 +1888,23 @@ __global__ __launch_bounds__(256) void kd_table(const u64 *cand, const u64 *cand
         }
     }
     const u32 n = cs->n_cand;
-    if (blockIdx.x * 256u >= n) return;
-    const bool on = p < n;
-    const u32 pc = on ? p : n - 1;
-    const u32 rs = cand_rank[pc];
-    const u64 k = cand[pc], a = cand_anc[pc];
-    bool valid = on && rs < junc_limit;
-    u32 id = 0xffffffffu;
-    if (valid) {
-        int32_t s, e;
-        unpack_key(kf, k, s, e);
-        id = first_id[rs] + ends_below(ends, rs, (u32)e);
-        valid = id < junc_limit;
-        if (valid) jkey[id] = k;
+    for (u32 base = blockIdx.x * 256u; base < n; base += gridDim.x * 256u) { // (whole wavefronts: anchors_fold)
+        const u32 q = base + threadIdx.x;
+        const bool on = q < n;
+        const u32 pc = on ? q : n - 1;
+        const u32 rs = cand_rank[pc];
+        const u64 k = cand[pc], a = cand_anc[pc];
+        bool valid = on && rs < junc_limit;
+        u32 id = 0xffffffffu;
+        if (valid) {
+            int32_t s, e;
+            unpack_key(kf, k, s, e);
+            id = first_id[rs] + ends_below(ends, rs, (u32)e);
+            valid = id < junc_limit;
+            if (valid) jkey[id] = k;
+        }
+        anchors_fold(valid, id, (int32_t)(u32)a, (int32_t)(u32)(a >> 32), anc_l, anc_r);
     }
-    anchors_fold(valid, id, (int32_t)(u32)a, (int32_t)(u32)(a >> 32), anc_l, anc_r);
 }
 
 // fragment record of the per-junction reductions: 48 words (see k4_pairs)
@@ -2938,41 +2943,34 @@ __device__ __forceinline__ void fetch_clamp(int32_t glen, int32_t &b, int32_t &e
 // (junction.cc:730-749): with runs r_0..r_m of equal read position the flush rule yields the counts
 // (r_0+1, r_1, ..., r_{m-1}, r_m-1); a zero count contributes nothing.  k5_finalize adds the terms
 // of a junction sequentially, in run order, so the sum rounds like the reference's loop.
-__global__ __launch_bounds__(256) void k5_entropy_terms(const u32 *jid_of, const u32 *seg_off, const u32 *run_first,
-                                                         const u32 *run_start, const u32 *n_runs_p, double *term) {
-    const u32 n_runs = *n_runs_p;
-    const u32 r = blockIdx.x * 256 + threadIdx.x;
-    if (r >= n_runs) return;
-    const u32 s = run_start[r];
-    const u32 j = jid_of[s];
-    const u32 n = seg_off[j + 1] - seg_off[j];
-    const u32 rf = run_first[j], rl = run_first[j + 1];
-    u32 c = run_start[r + 1] - s;
-    if (rl - rf > 1) {
-        if (r == rf) c += 1;
-        else if (r == rl - 1) c -= 1;
-    }
-    double t = 0.0;
-    if (c != 0 && n > 1) {
-        const double pI = (double)c / (double)n;
-        t = __dmul_rn(pI, log2(pI));
-    }
-    term[r] = t;
-}
-
-// Entropy of a junction = |sum of its runs' terms|, added one after the other in run order so that the sum rounds like
-// the reference's loop (junction.cc:742-748).  One wavefront per junction: the terms arrive 64 at a time with one
-// coalesced load and are folded in lane order through scalar reads (the chain of dependent adds is the same, the chain
-// of dependent memory loads is gone).
-__global__ __launch_bounds__(256) void k5_entropy_sum(const u32 *run_first, const double *term, const u32 *n_junc_p, double *ent_sum) {
+// Entropy of a junction (junction.cc:730-749) = |sum over its position runs of p log2 p|, p = run length / pairs of the junction
+// with the reference's grouping (first run + 1, last run - 1 when there are several), added one after the other in run
+// order so that the sum rounds like the reference's loop (:742-748).  One wavefront per junction: 64 runs at a time -- each
+// lane its run's term from two neighbouring run starts -- folded in lane order through scalar reads (the chain of dependent
+// adds is the reference's, there is no chain of dependent loads).  (The terms had a kernel and an array of their own until
+// round 4.)
+__global__ __launch_bounds__(256) void k5_entropy_sum(const u32 *seg_off, const u32 *run_first, const u32 *run_start, const u32 *n_junc_p,
+                                                       double *ent_sum) {
     const u32 j = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (j >= *n_junc_p) return;
     const int lane = lane_id();
     const u32 rf = run_first[j], rl = run_first[j + 1];
+    const u32 n = seg_off[j + 1] - seg_off[j];
     double sum = 0.0;
     for (u32 r0 = rf; r0 < rl; r0 += 64) {
         const u32 r = r0 + (u32)lane;
-        const double t = r < rl ? term[r] : 0.0;
+        double t = 0.0;
+        if (r < rl) {
+            u32 c = run_start[r + 1] - run_start[r];
+            if (rl - rf > 1) {
+                if (r == rf) c += 1;
+                else if (r == rl - 1) c -= 1;
+            }
+            if (c != 0 && n > 1) {
+                const double pI = (double)c / (double)n;
+                t = __dmul_rn(pI, log2(pI));
+            }
+        }
         const u32 cnt = rl - r0 < 64u ? rl - r0 : 64u;
         for (u32 k = 0; k < cnt; k++) sum = __dadd_rn(sum, __shfl(t, (int)k, 64));
     }
@@ -3156,12 +3154,20 @@ static_assert(sizeof(pjb_junction_row) % 8 == 0, "rows are copied in 8-byte unit
 // Where a contig's rows go is known to the host only when the contigs before it have been collected.  With two contigs
 // queued (pjb_finish_contig_begin) the second one's place follows from the first one's junction count, which lives on
 // the device: a cursor (rows written so far: host table, exchange slot), read by k6_rows_out and advanced by
-// k7_publish, both on the rows stream and so in contig order.  base < 0: take the cursor.
+// publish_chain (the last block of k6_rows_out), on the rows stream and so in contig order.  base < 0: take the cursor.
 struct RowCursor {
     u32 rows, mirror_rows;
+    u32 blocks_done; // k6_rows_out: blocks of the running launch that have written their rows (0 at rest)
+    u32 _pad;
 };
+__device__ __forceinline__ void publish_chain(const ContigStats *cs, u64 *err, u32 *gen_cnt, uint8_t *host, int64_t base, int64_t mirror_base,
+                                              RowCursor *cur, const MemberStats *members, u32 *member_junc, int n_members);
+// Rows -> the row table, then -- the block that finishes last -- the chain's control block -> page-locked host memory, rest
+// states restored, the cursor advanced (publish_chain; a launch of its own until round 4).  The rows stream runs these
+// launches one after the other, so one counter in the cursor serves every slot.
 __global__ __launch_bounds__(256) void k6_rows_out(const u64 *rows, const ContigStats *cs, u64 *host_table, int64_t base, int64_t mirror_base,
-                                                   const RowCursor *cur, u64 *mirror_table, u32 mirror_room) {
+                                                   RowCursor *cur, u64 *mirror_table, u32 mirror_room, u64 *err, u32 *gen_cnt, uint8_t *host_pub,
+                                                   const MemberStats *members, u32 *member_junc, int n_members) {
     // a grid of a few dozen blocks walks the rows: the kernel runs beside the next contig's first kernels, its stores
     // wait on PCIe, and it should not sit on their wave slots meanwhile
     const u32 nj = cs->J;
@@ -3174,6 +3180,13 @@ __global__ __launch_bounds__(256) void k6_rows_out(const u64 *rows, const Contig
         host_table[at * ROW_U64 + i] = v;
         if (to_mirror) mirror_table[mat * ROW_U64 + i] = v;
     }
+    __shared__ u32 s_last;
+    __syncthreads(); // (every thread of the block has read the cursor)
+    if (threadIdx.x == 0) s_last = atomicAdd(&cur->blocks_done, 1u) + 1u == gridDim.x ? 1u : 0u;
+    __syncthreads();
+    if (!s_last) return;
+    if (threadIdx.x == 0) cur->blocks_done = 0;
+    publish_chain(cs, err, gen_cnt, host_pub, base, mirror_base, cur, members, member_junc, n_members);
 }
 
 // The last kernel of a contig: control block, error word and list counters go to page-locked host memory in one go
@@ -3181,8 +3194,8 @@ __global__ __launch_bounds__(256) void k6_rows_out(const u64 *rows, const Contig
 // control slot next, and the row cursor moves on.
 constexpr int PUB_BASE_AT = 240, PUB_ERR_AT = 256, PUB_XCNT_AT = 320 /* --extra: the target's counters, 64 bytes */, PUB_CHECKED_AT = 384 /* reads on k4b_generic's second list */, PUB_GEN_AT = 512, PUB_MEMBERS_AT = 1536, PUB_GREADS_AT = 3072, PUB_BYTES = 4096; // byte offsets in the published block
 static_assert(PUB_MEMBERS_AT + GROUP_MAX * sizeof(MemberStats) <= PUB_BYTES && sizeof(MemberStats) % 8 == 0, "control block layout");
-__global__ __launch_bounds__(256) void k7_publish(const ContigStats *cs, u64 *err, u32 *gen_cnt, uint8_t *host, int64_t base,
-                                                  int64_t mirror_base, RowCursor *cur, const MemberStats *members, u32 *member_junc, int n_members) {
+__device__ __forceinline__ void publish_chain(const ContigStats *cs, u64 *err, u32 *gen_cnt, uint8_t *host, int64_t base, int64_t mirror_base,
+                                              RowCursor *cur, const MemberStats *members, u32 *member_junc, int n_members) {
     const u32 t = threadIdx.x;
     if (n_members > 1 && t < (u32)n_members) { // a group: the members' own counters
         MemberStats S = members[t];
