@@ -1888,7 +1888,7 @@ __global__ __launch_bounds__(256) void kd_table(const u64 *cand, const u64 *cand
         }
     }
     const u32 n = cs->n_cand;
-    for (u32 base = blockIdx.x * 256u; base < n; base += gridDim.x * 256u) { // (whole wavefronts: anchors_fold)
+    for (u32 base = blockIdx.x * 256u; base < n; base += gridDim.x * 256u) {
         const u32 q = base + threadIdx.x;
         const bool on = q < n;
         const u32 pc = on ? q : n - 1;
@@ -1903,7 +1903,13 @@ __global__ __launch_bounds__(256) void kd_table(const u64 *cand, const u64 *cand
             valid = id < junc_limit;
             if (valid) jkey[id] = k;
         }
-        anchors_fold(valid, id, (int32_t)(u32)a, (int32_t)(u32)(a >> 32), anc_l, anc_r);
+        // (a junction has a candidate or two: the lanes of a wavefront hold different junctions, there is nothing to fold -- each lane
+        // moves its junction's anchors itself, and only if its value would move them)
+        if (valid) {
+            const int32_t lo = (int32_t)(u32)a, hi = (int32_t)(u32)(a >> 32);
+            if (lo < __hip_atomic_load(&anc_l[id], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(&anc_l[id], lo);
+            if (hi > __hip_atomic_load(&anc_r[id], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&anc_r[id], hi);
+        }
     }
 }
 
