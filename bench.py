@@ -139,9 +139,9 @@ def main():
     ap.add_argument("--junctions", type=int, default=int(os.environ.get("PJB_BENCH_JUNCTIONS", 250_000)))
     ap.add_argument("--queue", type=int, default=int(os.environ.get("PJB_BENCH_QUEUE", 3)),
                     help="contigs queued at once (pjb_finish_contig_begin / _end; at most PJB_MAX_QUEUED = 8)")
-    ap.add_argument("--group-bases", type=int, default=int(os.environ.get("PJB_BENCH_GROUP_BASES", 1 << 29)),
+    ap.add_argument("--group-bases", type=int, default=int(os.environ.get("PJB_BENCH_GROUP_BASES", 1 << 30)),
                     help="targets are finished in groups (pjb_finish_group_begin: ONE kernel chain over several targets) of consecutive "
-                         "targets adding up to at most this many bases -- GRCh38: seven chains of up to 0.5 Gb (measured best of 25 / 16 / 7 / 3 chains); 0: one chain per target")
+                         "targets adding up to at most this many bases -- GRCh38: three chains of up to 1 Gb (round 4, measured: 16 / 7 / 5 / 3 / 2 chains = 11.8 / 11.1 / 10.9 / 10.6 / 11.2 ms a step -- profiles/r04d_grouping_sweep.txt; round 3's longer chains favoured 7); 0: one chain per target")
     ap.add_argument("--config", default="c3", choices=["c3", "c5"],
                     help="c3: BASELINE configs[2] (200 M reads; the default and the driver's line).  c5: BASELINE configs[4] WHOLE on one GPU -- "
                          "1 B paired-end reads, 300 k junctions, Zipf depth, strandedness=firststrand, 73 GB of records resident in HBM; no BAM "

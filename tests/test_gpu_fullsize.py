@@ -184,7 +184,7 @@ def c3_full():
             regs.append(ctx.finish_contig(tid))
         return ctx.collect(), regs
 
-    def run_groups(queue=3, group_bases=1 << 29):
+    def run_groups(queue=3, group_bases=1 << 30):
         """the bench's step: chains over groups of consecutive targets (pjb_finish_group_begin / _end), `queue` of them in flight"""
         ctx.clear_rows()
         chains = ffi.plan_groups([c.contig_len for c in cfgs], list(range(len(cfgs))), group_bases)
@@ -244,7 +244,7 @@ def test_c3_fullsize_properties_and_oracle(c3_full):
 
 
 def test_c3_fullsize_group_chains_equal_per_target_chains(c3_full):
-    """The bench's step at full size -- seven chains over groups of consecutive targets, three in flight -- must give, byte for
+    """The bench's step at full size -- three chains over groups of consecutive targets (1 Gb each), all in flight -- must give, byte for
     byte, the row table of the per-target chains (which the test above holds against the oracle), and every target's counters."""
     cfgs, data, rows, regs, run, run_groups = c3_full
     grows, gregs, chains = run_groups()
