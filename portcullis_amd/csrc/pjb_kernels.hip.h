@@ -1053,15 +1053,15 @@ struct CmpChunkT {
 // d[k] = p[first + k] for 0 <= first + k <= last, else 0
 template <int NW>
 __device__ __forceinline__ void load_words(u32 (&d)[NW], const u32 *p, int32_t first, int32_t last) {
-    static_assert(NW == 9 || NW == 5, "chunk width");
+    static_assert(NW == 9 || NW == 8 || NW == 5, "chunk width");
     if (first >= 0 && first + NW - 1 <= last) {
         const Words4 a = gload(reinterpret_cast<const Words4 *>(p + first));
         d[0] = a.x, d[1] = a.y, d[2] = a.z, d[3] = a.w;
-        if constexpr (NW == 9) {
+        if constexpr (NW >= 8) {
             const Words4 b = gload(reinterpret_cast<const Words4 *>(p + first + 4));
             d[4] = b.x, d[5] = b.y, d[6] = b.z, d[7] = b.w;
         }
-        d[NW - 1] = gload(p + first + NW - 1);
+        if constexpr (NW != 8) d[NW - 1] = gload(p + first + NW - 1); // (NW = 8: two 16-byte loads and nothing else -- 56 bases a round)
     } else {
 #pragma unroll
         for (int k = 0; k < NW; k++) d[k] = (first + k >= 0 && first + k <= last) ? gload(p + first + k) : 0u;
@@ -1069,13 +1069,16 @@ __device__ __forceinline__ void load_words(u32 (&d)[NW], const u32 *p, int32_t f
 }
 // anchor bases [t, t + 8 (NW - 1)) of an anchor of l bases: read bases from qi (words of the read up to word q_last may be
 // touched: whatever lies past the anchor only feeds bits that the length mask removes), genome from gi
-template <int NW>
+// TO_BUFFER_END: q_last is the last word of the batch's bases (relative to the read) and the genome may be read up to its last
+// code word, not only to the anchor's: the last round of an anchor then takes the 16-byte loads too instead of one guarded
+// load per word (what lies past the anchor is masked either way).
+template <int NW, bool TO_BUFFER_END = false>
 __device__ __forceinline__ void chunk_load(CmpChunkT<NW> &C, const u32 *seqw, int32_t qi, int32_t q_last, const u32 *gw, int32_t gi, int32_t g_words,
                                            int32_t l, int32_t t) {
     const int32_t lastg = (gi + l - 1) >> 3;
     load_words<NW>(C.qw, seqw, (qi + t) >> 3, q_last);
-    // (genome words outside [0, g_words) and past the anchor's last word read as 0, as they always did)
-    load_words<NW>(C.gg, gw, (gi + t) >> 3, lastg < g_words - 1 ? lastg : g_words - 1);
+    // (genome words outside [0, g_words) and -- but for TO_BUFFER_END -- past the anchor's last word read as 0, as they always did)
+    load_words<NW>(C.gg, gw, (gi + t) >> 3, !TO_BUFFER_END && lastg < g_words - 1 ? lastg : g_words - 1);
 }
 template <int NW>
 __device__ __forceinline__ void chunk_cmp(CmpChunkT<NW> &C, int32_t qi, int32_t gi, int32_t l, int32_t t, int32_t out_base, int32_t &mism,
@@ -1174,11 +1177,12 @@ struct EmitRead {
     // window).  The window is known after K2d; the block compares are done here, where the read's operations and bases are
     // at hand (closed != nullptr), and k4b_generic checks the window for the reads on its second list.
     const u32 *closed_seqw; // the read's packed bases (nullptr: not of that shape -- the generic walks fill PairRec::aux in)
+    int32_t q_limit;        // last word behind closed_seqw that may be read (simple_pair_stats)
     const u32 *gcodes;      // the target's 4-bit codes
     int32_t glen, voff;     // the target's length and its offset in the group's virtual sequence
 };
 __device__ __forceinline__ u64 simple_pair_stats(const u32 *seqw, const u32 *gcodes, int32_t glen, int32_t pos, int32_t istart, int32_t iend,
-                                                 int32_t rend, int32_t dS);
+                                                 int32_t rend, int32_t dS, int32_t q_limit);
 // (reads of the simple shape never come here: k1_emit finishes them in closed form.)  on_pair(key, lStart, rEnd) is called
 // for every pair once its record is complete; the match statistics (PairRec::aux) of a read that is not `closed` are
 // k4b_generic's to fill in.
@@ -1208,7 +1212,7 @@ __device__ __forceinline__ void emit_read_pairs(const Ops cig, const EmitRead R,
     pend.updown = 0;
     auto closed_stats = [&]() { // left block read[prevQ - a, prevQ) at lstart, right block read[prevQ, ...) behind the intron
         const int32_t a = prevIstart - pend.lstart;
-        return simple_pair_stats(R.closed_seqw, R.gcodes, R.glen, pend.lstart - R.voff, prevIstart - R.voff, prevIend - R.voff, pend.rend - R.voff, prevQ - a);
+        return simple_pair_stats(R.closed_seqw, R.gcodes, R.glen, pend.lstart - R.voff, prevIstart - R.voff, prevIend - R.voff, pend.rend - R.voff, prevQ - a, R.q_limit);
     };
     u32 k = 0;
     for (u32 i = 0; i < n; i++) {
@@ -1300,21 +1304,40 @@ __device__ __forceinline__ u32 read_meta(u32 flag, u32 xs, u32 mapq, int32_t pos
 // The common shape [S] M N M [S] (coordinates of the read's own target): the left anchor is read[dS, dS+a) against
 // genome[pos, pos+a), the right one read[dS+a, dS+a+b) against genome[iend+1, iend+1+b); neither depends on the
 // junction-level window -- the walk rules of bam_alignment.cc:341-462 reduce to exactly this for the shape.
-constexpr int SIMPLE_NW = 5;
+#ifndef PJB_SIMPLE_NW
+#define PJB_SIMPLE_NW 5
+#endif
+#ifndef PJB_SIMPLE_SEQ
+#define PJB_SIMPLE_SEQ 0 // 1: the two sides one after the other (half the registers, one more round trip)
+#endif
+constexpr int SIMPLE_NW = PJB_SIMPLE_NW;
+// q_limit: the last word after seqw that may be read (the batch's last word of bases: what a load brings in past the anchors is masked)
 __device__ __forceinline__ u64 simple_pair_stats(const u32 *seqw, const u32 *gcodes, int32_t glen, int32_t pos, int32_t istart, int32_t iend,
-                                                 int32_t rend, int32_t dS) {
+                                                 int32_t rend, int32_t dS, int32_t q_limit) {
     const int32_t a = istart - pos, bb = rend - iend;
     const int32_t g_words = (glen + 7) / 8 + 1;
-    const int32_t q_last = (dS + a + bb - 1) >> 3; // last word of the read that holds aligned bases
+    const int32_t q_last = q_limit;
     int32_t misL = 0, firstL = -1, lastL = -1, misR = 0, firstR = -1, lastR = -1;
     // (both sides' words of a round in flight together -- a round is one trip to memory, and the trips set the pace --, 32 bases
     // a side: 64 a side held 36 registers and cost the kernel a third of its wavefronts)
-    const int32_t longest = a > bb ? a : bb;
+#if PJB_SIMPLE_SEQ
+    for (int32_t t = 0; t < a; t += 8 * (SIMPLE_NW - 1)) {
+        CmpChunkT<SIMPLE_NW> L;
+        chunk_load<SIMPLE_NW, true>(L, seqw, dS, q_last, gcodes, pos, g_words, a, t);
+        chunk_cmp<SIMPLE_NW>(L, dS, pos, a, t, 0, misL, firstL, lastL);
+    }
+    for (int32_t t = 0; t < bb; t += 8 * (SIMPLE_NW - 1)) {
+        CmpChunkT<SIMPLE_NW> R;
+        chunk_load<SIMPLE_NW, true>(R, seqw, dS + a, q_last, gcodes, iend + 1, g_words, bb, t);
+        chunk_cmp<SIMPLE_NW>(R, dS + a, iend + 1, bb, t, 0, misR, firstR, lastR);
+    }
+#endif
+    const int32_t longest = PJB_SIMPLE_SEQ ? 0 : (a > bb ? a : bb);
     for (int32_t t = 0; t < longest; t += 8 * (SIMPLE_NW - 1)) {
         CmpChunkT<SIMPLE_NW> L, R;
         const bool onL = t < a, onR = t < bb;
-        if (onL) chunk_load<SIMPLE_NW>(L, seqw, dS, q_last, gcodes, pos, g_words, a, t);
-        if (onR) chunk_load<SIMPLE_NW>(R, seqw, dS + a, q_last, gcodes, iend + 1, g_words, bb, t);
+        if (onL) chunk_load<SIMPLE_NW, true>(L, seqw, dS, q_last, gcodes, pos, g_words, a, t);
+        if (onR) chunk_load<SIMPLE_NW, true>(R, seqw, dS + a, q_last, gcodes, iend + 1, g_words, bb, t);
         if (onL) chunk_cmp<SIMPLE_NW>(L, dS, pos, a, t, 0, misL, firstL, lastL);
         if (onR) chunk_cmp<SIMPLE_NW>(R, dS + a, iend + 1, bb, t, 0, misR, firstR, lastR);
     }
@@ -1382,6 +1405,7 @@ __global__ __launch_bounds__(K1E_T) __attribute__((amdgpu_waves_per_eu(K1E_WAVES
     const u32 c_lo = s_begin >> K1E_SHIFT, c_hi = (s_end + (u32)K1E_T - 1u) >> K1E_SHIFT; // trips of K1E_T list entries
     const bool want_cand = E.cand != nullptr;
     const int32_t vlen = voff + ref_len; // the target's end in the group's virtual sequence
+    const u32 seq_words = b.seq_off[b.n]; // words of packed bases in the batch: no compare reads past them
     if (want_cand) {
 #pragma unroll
         for (int i = 0; i < KC_SLOTS / K1E_T; i++) {
@@ -1541,7 +1565,7 @@ __global__ __launch_bounds__(K1E_T) __attribute__((amdgpu_waves_per_eu(K1E_WAVES
                     // junction.cc:795-812.  One N operation: nothing upstream; "downstream" counts the operation itself unless its end was
                     // clamped.  Two: the first has the second downstream, the second the first upstream.
                     R.updown = two ? (pr == 0 ? (1u << 16) : 1u) : (rStartU <= iend + 1 ? 0u : (1u << 16));
-                    R.aux = simple_pair_stats(seqw, gcodes, ref_len, lst - voff, istart - voff, iend - voff, R.rend - voff, qoff);
+                    R.aux = simple_pair_stats(seqw, gcodes, ref_len, lst - voff, istart - voff, iend - voff, R.rend - voff, qoff, (int32_t)min(seq_words - 1u - so, 0x7fffffffu));
                     P.key[off + pr] = key;
                     if (P.g) P.g[off + pr] = g;
                     rec_store(P.rec + off + pr, R);
@@ -1633,6 +1657,7 @@ __global__ __launch_bounds__(K1E_T) __attribute__((amdgpu_waves_per_eu(K1E_WAVES
             const bool closed = gcodes != nullptr && (shape == 1 || shape == 3) && nN > 0 && R.seq_ok && R.lq > 1 && qsum == (int64_t)R.lq &&
                                 R.pos >= voff && R.aend < vlen;
             R.closed_seqw = closed ? reinterpret_cast<const u32 *>(b.seq4) + s_gq[GQ_SO][at] : nullptr;
+            R.q_limit = (int32_t)min(seq_words - 1u - s_gq[GQ_SO][at], 0x7fffffffu);
             R.gcodes = gcodes;
             R.glen = ref_len;
             R.voff = voff;
