@@ -224,6 +224,10 @@ __device__ __forceinline__ T gload(const T *p) {
     __builtin_memcpy(&v, (const __attribute__((address_space(1))) void *)p, sizeof(T));
     return v;
 }
+// four consecutive words at a 4-byte aligned address (global_load_dwordx4 accepts that)
+struct __attribute__((packed, aligned(4))) Words4 {
+    u32 x, y, z, w;
+};
 
 template <typename T>
 __device__ __forceinline__ T wave_sum(T v) {
@@ -625,14 +629,24 @@ __global__ __launch_bounds__(256) void k1_count(DevBatch b, u32 *tile_cnt, TileS
             xflag4[it] = on ? fv : 0u;
         }
     }
+    static_assert(K1_OPS == 4, "one 16-byte load");
+    const u32 cig_words = b.cig_off[b.n];
 #pragma unroll
-    for (int it = 0; it < 4; it++)
+    for (int it = 0; it < 4; it++) {
+        if (c0[it] + (u32)K1_OPS <= cig_words) { // (one 16-byte load; what lies behind the read's last operation is masked)
+            const Words4 w = gload(reinterpret_cast<const Words4 *>(b.cigar + c0[it]));
+            ops[it][0] = w.x, ops[it][1] = w.y, ops[it][2] = w.z, ops[it][3] = w.w;
 #pragma unroll
-        for (int k = 0; k < K1_OPS; k++) {
-            const bool has = (u32)k < nop[it];
-            const u32 v = *(has ? b.cigar + c0[it] + k : b.cig_off);
-            ops[it][k] = has ? v : 0u;
+            for (int k = 0; k < K1_OPS; k++) ops[it][k] = (u32)k < nop[it] ? ops[it][k] : 0u;
+        } else {
+#pragma unroll
+            for (int k = 0; k < K1_OPS; k++) {
+                const bool has = (u32)k < nop[it];
+                const u32 v = *(has ? b.cigar + c0[it] + k : b.cig_off);
+                ops[it][k] = has ? v : 0u;
+            }
         }
+    }
 #pragma unroll
     for (int it = 0; it < 4; it++) {
         const int64_t r = base + it * 256 + threadIdx.x;
@@ -1041,9 +1055,6 @@ __device__ __forceinline__ u32 nt16_ascii(u32 c) { // seq_nt16_str "=ACMGRSVTWYH
 // global_load_dwordx4 accepts -- guarded so that nothing is read past the read's last word / the contig's last code
 // word; the short tail of a stream takes guarded word loads.
 __device__ __forceinline__ u32 swap_nibbles(u32 x) { return ((x & 0x0F0F0F0Fu) << 4) | ((x >> 4) & 0x0F0F0F0Fu); }
-struct __attribute__((packed, aligned(4))) Words4 {
-    u32 x, y, z, w;
-};
 // A chunk = NW consecutive words of each stream = (NW - 1) * 8 anchor bases per round (the extra word feeds the funnel
 // shift of the last one): NW = 9 -> two 16-byte loads and one word per stream, NW = 5 -> one 16-byte load and one word.
 template <int NW>
@@ -1305,10 +1316,11 @@ __device__ __forceinline__ u32 read_meta(u32 flag, u32 xs, u32 mapq, int32_t pos
 // genome[pos, pos+a), the right one read[dS+a, dS+a+b) against genome[iend+1, iend+1+b); neither depends on the
 // junction-level window -- the walk rules of bam_alignment.cc:341-462 reduce to exactly this for the shape.
 #ifndef PJB_SIMPLE_NW
-#define PJB_SIMPLE_NW 5
+#define PJB_SIMPLE_NW 8 // two 16-byte loads per stream and round, 56 bases a round (5: one 16-byte load and a word, 32 bases)
 #endif
 #ifndef PJB_SIMPLE_SEQ
-#define PJB_SIMPLE_SEQ 0 // 1: the two sides one after the other (half the registers, one more round trip)
+#define PJB_SIMPLE_SEQ 1 // 1: the two sides one after the other (half the registers, one more round trip); 0: both sides' words of a round in flight together
+// (profiles/r04e_compare_variants.txt: NW 5 both / 8 both / 5 sequential / 8 sequential = 10.56 / 11.56 / 10.07 / 9.97 ms a step)
 #endif
 constexpr int SIMPLE_NW = PJB_SIMPLE_NW;
 // q_limit: the last word after seqw that may be read (the batch's last word of bases: what a load brings in past the anchors is masked)
@@ -1406,6 +1418,7 @@ __global__ __launch_bounds__(K1E_T) __attribute__((amdgpu_waves_per_eu(K1E_WAVES
     const bool want_cand = E.cand != nullptr;
     const int32_t vlen = voff + ref_len; // the target's end in the group's virtual sequence
     const u32 seq_words = b.seq_off[b.n]; // words of packed bases in the batch: no compare reads past them
+    const u32 cig_words = b.cig_off[b.n]; // operations in the batch
     if (want_cand) {
 #pragma unroll
         for (int i = 0; i < KC_SLOTS / K1E_T; i++) {
@@ -1498,13 +1511,22 @@ __global__ __launch_bounds__(K1E_T) __attribute__((amdgpu_waves_per_eu(K1E_WAVES
             const u32 c0 = b.cig_off[r], c1 = b.cig_off[r + 1];
             const u32 n = c1 - c0;
             u32 op[OPS_LDS];
+            static_assert(OPS_LDS == 8, "two 16-byte loads");
+            if (c0 + (u32)OPS_LDS <= cig_words) { // the read's first eight operations: two 16-byte loads (whatever lies behind its last one is masked)
+                const Words4 lo4 = gload(reinterpret_cast<const Words4 *>(b.cigar + c0)), hi4 = gload(reinterpret_cast<const Words4 *>(b.cigar + c0 + 4));
+                op[0] = lo4.x, op[1] = lo4.y, op[2] = lo4.z, op[3] = lo4.w, op[4] = hi4.x, op[5] = hi4.y, op[6] = hi4.z, op[7] = hi4.w;
 #pragma unroll
-            for (int q = 0; q < OPS_LDS; q++) { // (unconditional loads, masked: see k1_count)
-                const bool has = (u32)q < n;
-                const u32 v = *(has ? b.cigar + c0 + q : b.cig_off);
-                op[q] = has ? v : 0u;
-                s_ops[q][threadIdx.x] = op[q];
+                for (int q = 0; q < OPS_LDS; q++) op[q] = (u32)q < n ? op[q] : 0u;
+            } else { // (the batch's last operations: word by word -- unconditional loads, masked: see k1_count)
+#pragma unroll
+                for (int q = 0; q < OPS_LDS; q++) {
+                    const bool has = (u32)q < n;
+                    const u32 v = *(has ? b.cigar + c0 + q : b.cig_off);
+                    op[q] = has ? v : 0u;
+                }
             }
+#pragma unroll
+            for (int q = 0; q < OPS_LDS; q++) s_ops[q][threadIdx.x] = op[q];
             const int32_t pos = b.pos[r];
             const u32 g = b.base + (u32)r;
             const u32 off = toff + spl_poff[slot];
