@@ -629,24 +629,16 @@ __global__ __launch_bounds__(256) void k1_count(DevBatch b, u32 *tile_cnt, TileS
             xflag4[it] = on ? fv : 0u;
         }
     }
-    static_assert(K1_OPS == 4, "one 16-byte load");
-    const u32 cig_words = b.cig_off[b.n];
+    // (one 16-byte load per read instead of four words was measured: 55 against 52 us a launch -- consecutive reads' operations
+    // are neighbours, the word loads coalesce)
 #pragma unroll
-    for (int it = 0; it < 4; it++) {
-        if (c0[it] + (u32)K1_OPS <= cig_words) { // (one 16-byte load; what lies behind the read's last operation is masked)
-            const Words4 w = gload(reinterpret_cast<const Words4 *>(b.cigar + c0[it]));
-            ops[it][0] = w.x, ops[it][1] = w.y, ops[it][2] = w.z, ops[it][3] = w.w;
+    for (int it = 0; it < 4; it++)
 #pragma unroll
-            for (int k = 0; k < K1_OPS; k++) ops[it][k] = (u32)k < nop[it] ? ops[it][k] : 0u;
-        } else {
-#pragma unroll
-            for (int k = 0; k < K1_OPS; k++) {
-                const bool has = (u32)k < nop[it];
-                const u32 v = *(has ? b.cigar + c0[it] + k : b.cig_off);
-                ops[it][k] = has ? v : 0u;
-            }
+        for (int k = 0; k < K1_OPS; k++) {
+            const bool has = (u32)k < nop[it];
+            const u32 v = *(has ? b.cigar + c0[it] + k : b.cig_off);
+            ops[it][k] = has ? v : 0u;
         }
-    }
 #pragma unroll
     for (int it = 0; it < 4; it++) {
         const int64_t r = base + it * 256 + threadIdx.x;
