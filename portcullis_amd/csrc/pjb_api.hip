@@ -145,7 +145,7 @@ struct CtlSlot {
     Buf x_q, x_spos, x_send, x_gapoff, x_zlist, x_scnt, x_codes; // --extra: scratch of the target in this slot
     // what the first kernels of a contig (k1_count, k1_scan_tiles, k1_emit: the front stream) write and the rest of its
     // chain reads: the next contig's first kernels run beside this contig's last ones
-    Buf tile_cnt, tile_stats, splidx, splpoff, tile_soff, chunk_tile;
+    Buf tile_cnt, tile_stats, splidx, splpoff, splrec, tile_soff, chunk_tile;
     Buf scan_parts;     // k1_scan_tiles: ScanPart[K1S_BLOCKS], zeroed once; scan_epoch tells one launch's parts from the last one's
     u32 scan_epoch = 0;
     Buf members; // groups: MemberStats[GROUP_MAX] | member_junc u32[GROUP_MAX] | tile_lo u32[GROUP_MAX + 1]
@@ -797,7 +797,7 @@ void pjb_destroy(pjb_ctx *c) {
             if (ev) (void)hipEventDestroy(ev);
         if (S.ev_rows) (void)hipEventDestroy(S.ev_rows);
         if (S.ev_done) (void)hipEventDestroy(S.ev_done);
-        Buf *sb[] = {&S.x_q, &S.x_spos, &S.x_send, &S.x_gapoff, &S.x_zlist, &S.x_scnt, &S.x_codes, &S.cstats, &S.err, &S.gencount, &S.batches, &S.rows, &S.tile_cnt, &S.tile_stats, &S.splidx, &S.splpoff, &S.tile_soff, &S.chunk_tile, &S.scan_parts, &S.members, &S.okey, &S.g,
+        Buf *sb[] = {&S.x_q, &S.x_spos, &S.x_send, &S.x_gapoff, &S.x_zlist, &S.x_scnt, &S.x_codes, &S.cstats, &S.err, &S.gencount, &S.batches, &S.rows, &S.tile_cnt, &S.tile_stats, &S.splidx, &S.splpoff, &S.splrec, &S.tile_soff, &S.chunk_tile, &S.scan_parts, &S.members, &S.okey, &S.g,
                      &S.rec, &S.jidbam, &S.jkey, &S.total, &S.bitmap, &S.wrank, &S.ends, &S.firstid,
                      &S.key[0], &S.key[1], &S.idx[0], &S.idx[1], &S.hist, &S.hist_scan, &S.hist_part, &S.bintotal, &S.scan_tiles, &S.jid, &S.seg, &S.runfirst,
                      &S.runstart, &S.ent, &S.entsum, &S.frag, &S.fragj, &S.masks, &S.acc, &S.ancl, &S.ancr, &S.genlist};
@@ -1469,6 +1469,7 @@ static int queue_contig(pjb_ctx *c, Flight &f) {
     if ((rc = ensure(c, S.chunk_tile, ((size_t)n_tiles * (K1_TILE / 256) + 4) * 4))) return rc;
     if ((rc = ensure(c, S.splidx, (size_t)n_tiles * K1_TILE * 4))) return rc;
     if ((rc = ensure(c, S.splpoff, (size_t)n_tiles * K1_TILE * 4))) return rc;
+    if ((rc = ensure(c, S.splrec, (size_t)n_tiles * K1_TILE * 16))) return rc;
     if (!S.members.p) {
         if ((rc = ensure(c, S.members, GROUP_MAX * sizeof(MemberStats) + GROUP_MAX * 4 + (GROUP_MAX + 1) * 4))) return rc;
         HIP_TRY(c, hipMemset(S.members.p, 0, S.members.cap)); // (member_junc: k6_rows_out (publish_chain) leaves it zeroed for the next chain)
@@ -1618,10 +1619,10 @@ static int queue_contig(pjb_ctx *c, Flight &f) {
             const u32 nt = (u32)((b.n + K1_TILE - 1) / K1_TILE);
             if (xk1)
                 LAUNCH(c, "k1_count", k1_count<true>, dim3(nt), dim3(256), b, (u32 *)S.tile_cnt.p, (TileStats *)S.tile_stats.p, (u32 *)S.splidx.p,
-                       (u32 *)S.splpoff.p, d_err, 0, xo);
+                       (u32 *)S.splpoff.p, (uint4 *)S.splrec.p, d_err, 0, xo);
             else
                 LAUNCH(c, "k1_count", k1_count<false>, dim3(nt), dim3(256), b, (u32 *)S.tile_cnt.p, (TileStats *)S.tile_stats.p, (u32 *)S.splidx.p,
-                       (u32 *)S.splpoff.p, d_err, group ? std::max(own_len, 1) : 0, xo);
+                       (u32 *)S.splpoff.p, (uint4 *)S.splrec.p, d_err, group ? std::max(own_len, 1) : 0, xo);
         }
         if (xk1) {
             HIP_TRY(c, hipEventRecord(S.ev_xk1, c->stream));
@@ -1651,7 +1652,7 @@ static int queue_contig(pjb_ctx *c, Flight &f) {
             // (a tile holds ~300 spliced reads = 1.2 chunks of 256: a grid of half the tiles keeps two or three chunks per block)
             const u32 grid = std::max<u32>(1, std::min<u32>(nt, std::max<u32>(1024, nt / 2)));
             LAUNCH(c, "k1_emit", k1_emit, dim3(grid), dim3(256), b, nt, n_tiles, (const u32 *)S.tile_cnt.p, (const u32 *)S.tile_soff.p,
-                   (const u32 *)S.chunk_tile.p, (const u32 *)S.splidx.p, (const u32 *)S.splpoff.p, pr, el, kf, own_len,
+                   (const u32 *)S.chunk_tile.p, (const u32 *)S.splidx.p, (const u32 *)S.splpoff.p, (const uint4 *)S.splrec.p, pr, el, kf, own_len,
                    own_tid, (int)c->cfg.orientation, d_err, d_cs, f.voff[(size_t)m], fast_codes ? (const u32 *)GT.codes[m] : (const u32 *)nullptr);
         }
     }

@@ -588,9 +588,18 @@ struct XOut {
 // chk_ref_len > 0 (members of a group): a tile with an alignment that ends past the target reports max_end = INT32_MAX, so
 // that k1_scan_tiles sees "weird coordinates" whatever the group's virtual length is (the host then finishes the
 // members one by one).
+// spl_rec: per spliced read of the tile's list, what this pass holds in registers anyway and k1_emit would have to gather again --
+// {first operation's index, position, first word of the bases, operations (15 bits) | bases present (bit 15) | l_qseq (16 bits)};
+// an operation count or l_qseq that does not fit is stored as all-ones and fetched by k1_emit.
+__device__ __forceinline__ u32 spl_nlq(u32 n, bool seq_ok, int32_t lq) {
+    return (n < 0x7fffu ? n : 0x7fffu) | (seq_ok ? 0x8000u : 0u) | ((u32)lq < 0xffffu ? (u32)lq << 16 : 0xffff0000u);
+}
+#ifndef K1C_WAVES
+#define K1C_WAVES 5 // (84 registers as the compiler wants them; forced to 64: 31 spills, 99 against 61 us a launch)
+#endif
 template <bool EXTRA>
-__global__ __launch_bounds__(256) void k1_count(DevBatch b, u32 *tile_cnt, TileStats *tile_stats, u32 *spl_idx,
-                                                 u32 *spl_poff, u64 *err, int32_t chk_ref_len, XOut X) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(K1C_WAVES, K1C_WAVES))) void k1_count(DevBatch b, u32 *tile_cnt, TileStats *tile_stats, u32 *spl_idx,
+                                                 u32 *spl_poff, uint4 *spl_rec, u64 *err, int32_t chk_ref_len, XOut X) {
     __shared__ u64 sm64[4];
     __shared__ u64 sm_scan4[4][4];
     __shared__ int32_t smi[4][6];
@@ -602,8 +611,9 @@ __global__ __launch_bounds__(256) void k1_count(DevBatch b, u32 *tile_cnt, TileS
     // K1_OPS ops of every CIGAR (longer CIGARs continue from global memory), then the per-read scalars
     constexpr int K1_OPS = 4;
     u32 c0[4], nop[4], ops[4][K1_OPS];
-    int32_t pos4[4], prev4[4], len4[4];
-    u32 xs4[4], c4[4];
+    int32_t pos4[4];
+    u32 c4[4], so4[4], nlq4[4]; // (nlq4: spl_nlq -- what the spliced list keeps of operations count, l_qseq and the presence of bases)
+    u32 bad = 0;                // bit it: read `it` lies before its predecessor; bit 4 + it: its XS code is not one
     u32 xflag4[4] = {0, 0, 0, 0}, xspan = 0, xgapmax = 0; // (EXTRA)
     bool xmany = false;
     // (Every load below is UNCONDITIONAL -- a lane past the batch's end reads the last record, an operation past a CIGAR's end
@@ -617,13 +627,22 @@ __global__ __launch_bounds__(256) void k1_count(DevBatch b, u32 *tile_cnt, TileS
         const int64_t rr = on ? r : b.n - 1, rp = rr > 0 ? rr - 1 : 0;
         const u32 c0v = b.cig_off[rr], c1v = b.cig_off[rr + 1];
         const int32_t posv = b.pos[rr], prevv = b.pos[rp], lenv = b.l_qseq[rr];
-        const u32 xsv = (u32)b.xs[rr];
+        const u32 xsv = (u32)b.xs[rr], sov = b.seq_off[rr], so1v = b.seq_off[rr + 1];
+        // (the scalars are folded as they arrive -- the operations' loads below need the offsets of this same batch of loads anyway --
+        // so that only what the list and the walk need stays in registers: 58 of them, eight tiles a CU)
+        so4[it] = sov;
         c0[it] = on ? c0v : 0u;
         nop[it] = on ? c1v - c0v : 0u;
         pos4[it] = on ? posv : 0;
-        prev4[it] = on ? (r > 0 ? prevv : (b.prev_pos_ptr ? *b.prev_pos_ptr : b.prev_pos)) : 0;
-        xs4[it] = on ? xsv : 0u;
-        len4[it] = on ? lenv : 0;
+        const int32_t prv = r > 0 ? prevv : (b.prev_pos_ptr ? *b.prev_pos_ptr : b.prev_pos);
+        if (on && posv < prv) bad |= 1u << it;
+        if (on && xsv > 2) bad |= 16u << it;
+        if (on) {
+            mn = lenv < mn ? lenv : mn;
+            mx = lenv > mx ? lenv : mx;
+            sum += (u64)(int64_t)lenv;
+        }
+        nlq4[it] = spl_nlq(c1v - c0v, (u64)(so1v - sov) * 8ull >= (u64)(int64_t)lenv, lenv);
         if (EXTRA) {
             const u32 fv = (u32)b.flag[rr];
             xflag4[it] = on ? fv : 0u;
@@ -645,8 +664,8 @@ __global__ __launch_bounds__(256) void k1_count(DevBatch b, u32 *tile_cnt, TileS
         u32 cthis = 0;
         if (r < b.n) {
             const int32_t p = pos4[it];
-            if (p < prev4[it]) set_error(err, b.base + (u32)r, PJB_ERR_UNSORTED);
-            if (xs4[it] > 2) set_error(err, b.base + (u32)r, PJB_ERR_BAD_XS);
+            if (bad & (1u << it)) set_error(err, b.base + (u32)r, PJB_ERR_UNSORTED);
+            if (bad & (16u << it)) set_error(err, b.base + (u32)r, PJB_ERR_BAD_XS);
             u32 c = 0, ngap = 0, gmax = 0;
             int32_t al = 0;
             auto count_op = [&](u32 op) {
@@ -665,10 +684,6 @@ __global__ __launch_bounds__(256) void k1_count(DevBatch b, u32 *tile_cnt, TileS
 #pragma unroll
             for (int k = 0; k < K1_OPS; k++) count_op(ops[it][k]); // padding ops are 0M: no effect
             for (u32 k = K1_OPS; k < nop[it]; k++) count_op(b.cigar[c0[it] + k]);
-            const int32_t len = len4[it];
-            mn = len < mn ? len : mn;
-            mx = len > mx ? len : mx;
-            sum += (u64)(int64_t)len;
             cnt += c;
             if (c) {
                 spl++;
@@ -733,6 +748,7 @@ __global__ __launch_bounds__(256) void k1_count(DevBatch b, u32 *tile_cnt, TileS
                 const size_t slot = (size_t)(b.tile_base + blockIdx.x) * K1_TILE + (u32)(ex & 0xffffu);
                 spl_idx[slot] = (u32)(base + it * 256 + threadIdx.x);
                 spl_poff[slot] = (u32)(ex >> 16);
+                spl_rec[slot] = make_uint4(c0[it], (u32)pos4[it], so4[it], nlq4[it]);
             }
         }
     }
@@ -1391,7 +1407,7 @@ __host__ __device__ inline u32 gen_list_cap(u32 pair_limit) { // chunks of 256 s
     return ((chunks + GEN_SHARDS - 1) / GEN_SHARDS) * 256u;
 }
 __global__ __launch_bounds__(K1E_T) __attribute__((amdgpu_waves_per_eu(K1E_WAVES, K1E_WAVES))) void k1_emit(DevBatch b, u32 n_tiles_batch, u32 n_tiles_total, const u32 *tile_off, const u32 *tile_soff,
-                                                const u32 *chunk_tile, const u32 *spl_idx, const u32 *spl_poff, Pairs P, EmitLists E, KeyFmt kf,
+                                                const u32 *chunk_tile, const u32 *spl_idx, const u32 *spl_poff, const uint4 *spl_rec, Pairs P, EmitLists E, KeyFmt kf,
                                                 int32_t ref_len, int32_t tid, int orientation, u64 *err, ContigStats *cs, int32_t voff,
                                                 const u32 *gcodes) {
     __shared__ u32 s_ops[OPS_LDS][K1E_T];
@@ -1500,8 +1516,10 @@ __global__ __launch_bounds__(K1E_T) __attribute__((amdgpu_waves_per_eu(K1E_WAVES
             const u32 toff = tile_off[tile];
             const size_t slot = (size_t)tile * K1_TILE + (s - soff);
             const int64_t r = spl_idx[slot];
-            const u32 c0 = b.cig_off[r], c1 = b.cig_off[r + 1];
-            const u32 n = c1 - c0;
+            const uint4 sr = spl_rec[slot]; // (k1_count's by-product: no gathers of cig_off, pos, l_qseq, seq_off)
+            const u32 c0 = sr.x;
+            u32 n = sr.w & 0x7fffu;
+            if (n == 0x7fffu) n = b.cig_off[r + 1] - c0;
             u32 op[OPS_LDS];
             static_assert(OPS_LDS == 8, "two 16-byte loads");
             if (c0 + (u32)OPS_LDS <= cig_words) { // the read's first eight operations: two 16-byte loads (whatever lies behind its last one is masked)
@@ -1519,13 +1537,14 @@ __global__ __launch_bounds__(K1E_T) __attribute__((amdgpu_waves_per_eu(K1E_WAVES
             }
 #pragma unroll
             for (int q = 0; q < OPS_LDS; q++) s_ops[q][threadIdx.x] = op[q];
-            const int32_t pos = b.pos[r];
+            const int32_t pos = (int32_t)sr.y;
             const u32 g = b.base + (u32)r;
             const u32 off = toff + spl_poff[slot];
             u32 meta = read_meta(b.flag[r], (u32)b.xs[r], b.mapq[r], pos, b.mtid[r], b.mpos[r], tid, orientation);
-            const int32_t lq = b.l_qseq[r];
-            const u32 so = b.seq_off[r];
-            const bool seq_ok = (u64)(b.seq_off[r + 1] - so) * 8ull >= (u64)(int64_t)lq;
+            int32_t lq = (int32_t)(sr.w >> 16);
+            if (lq == 0xffff) lq = b.l_qseq[r];
+            const u32 so = sr.z;
+            const bool seq_ok = (sr.w & 0x8000u) != 0;
             // ---- shape: [S] M N M [S], or -- two introns, nothing clamped -- [S] M N M N M [S]
             bool simple = false, two = false;
             u32 dS = 0, a = 0, nl = 0, b2 = 0, nl2 = 0, b3 = 0;
