@@ -48,11 +48,12 @@ def algorithmic_bytes(name, N, C, S, Cs, P, J, L, Pg=0, Rg=0, R=0, cand=0, Rv=0,
     frags = P / 64.0 + J
     ops_s = Cs / max(S, 1)  # cigar ops of a spliced read
     table = {
-        # pos, cig_off, l_qseq, xs + every cigar op; 8 B written per spliced read (compacted index + pair offset)
-        "k1_count": N * 13 + C * 4 + S * 8,
-        # spliced reads only: compacted slot + pair offset (8), cig_off, pos, l_qseq, mtid, mpos, seq_off (4 each), flag (2),
-        # mapq, xs (1 each), the ops once; per pair 8 B key + 32 B record written; reads of the simple shape: L/2 B of packed
-        # bases + L/2 B of genome codes; 8 B list entry per generic read; candidate keys
+        # pos, cig_off, l_qseq, seq_off (4 each), xs (1) + every cigar op; 24 B written per spliced read (index, pair offset, and the
+        # 16-B record of what this pass holds of the read: operations index / count, position, bases offset, l_qseq)
+        "k1_count": N * 17 + C * 4 + S * 24,
+        # spliced reads only: the list's 24 B, mtid, mpos (4 each), flag (2), mapq, xs (1 each), the ops once; per pair 8 B key +
+        # 32 B record written; pairs finished in closed form: L/2 B of packed bases + L/2 B of genome codes; 8 B list entry per
+        # read on k4b_generic's lists; candidate key + anchors (16)
         "k1_emit": S * 36 + Cs * 4 + P * 40 + (P - Pg) * L + Rg * 8 + cand * 8,
         # K2d.  kd_assign: the pair's key read (8), its junction id written (4); the accumulators' rest state (192 B per junction)
         "kd_assign": P * 12 + J * 192,
