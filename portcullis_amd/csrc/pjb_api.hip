@@ -1495,6 +1495,7 @@ static int queue_contig(pjb_ctx *c, Flight &f) {
     if ((rc = ensure(c, S.ent, (size_t)PL * 8 + 16))) return rc;
     const u32 pair_blocks = std::max<u32>(1, (PL + 255) / 256);
     const u32 gen_cap = gen_list_cap(PL); // entries per sub-list
+    const u32 pack_nn = (u64)f.n_reads < (1ull << 28) ? 1u : 0u; // (EmitLists::pack_nn)
     if ((rc = ensure(c, S.genlist, (size_t)gen_cap * GEN_SHARDS * 8 * 2))) return rc; // (two lists: EmitLists)
     if ((rc = ensure(c, S.gencount, GEN_SHARDS * GEN_CNT_STRIDE * 4))) return rc; // a line per sub-list: reads, pairs
     // ---- junction-sized buffers
@@ -1644,6 +1645,7 @@ static int queue_contig(pjb_ctx *c, Flight &f) {
         el.gen_list = (u64 *)S.genlist.p;
         el.gen_cnt = d_gen_cnt;
         el.gen_cap = gen_cap;
+        el.pack_nn = pack_nn;
         for (size_t bi = 0; bi < batches.size(); bi++) {
             const DevBatch &b = batches[bi];
             const int m = f.batch_member[bi];
@@ -1663,7 +1665,7 @@ static int queue_contig(pjb_ctx *c, Flight &f) {
     auto launch_k4b = [&]() -> int {
         LAUNCH(c, "k4b_generic", k4b_generic, dim3(gen_grid), dim3(256), (const u64 *)S.genlist.p, (const u32 *)d_gen_cnt, gen_cap, (const u64 *)pr.key,
                pr.rec, (const u32 *)S.jidbam.p, kf, (const DevBatch *)S.batches.p, (int)batches.size(), (const int32_t *)S.ancl.p, (const int32_t *)S.ancr.p,
-               GT, any_x ? 1 : 0, any_x ? 0 : 1, d_err, (const ContigStats *)d_cs);
+               GT, any_x ? 1 : 0, any_x ? 0 : 1, d_err, (const ContigStats *)d_cs, pack_nn);
         return PJB_OK;
     };
     auto fork_k4b = [&]() -> int { // (the main stream has just produced jid_bam and the anchors)
@@ -1763,7 +1765,7 @@ static int queue_contig(pjb_ctx *c, Flight &f) {
     const u32 n_slices_lim = (PL + 63) / 64 + 1;
     const hipStream_t tl = st;
     auto entropy_kernels = [&]() -> int {
-        LAUNCH(c, "k5_entropy_sum", k5_entropy_sum, dim3(std::max<u32>(1, (JL + 3) / 4)), dim3(256), (const u32 *)S.seg.p, (const u32 *)S.runfirst.p,
+        LAUNCH(c, "k5_entropy_sum", k5_entropy_sum, dim3(std::max<u32>(1, (JL + 15) / 16)), dim3(256), (const u32 *)S.seg.p, (const u32 *)S.runfirst.p,
                (const u32 *)S.runstart.p, d_J, (double *)S.entsum.p);
         return PJB_OK;
     };

@@ -1401,6 +1401,7 @@ struct EmitLists {
                     // the same for the second -- a cache line per shard: atomics on one line are served one after the other,
                     // whatever the address in it
     u32 gen_cap;    // room of one sub-list
+    u32 pack_nn;    // 1 (chains of fewer than 2^28 reads): entries of the second list carry min(N operations, 15) in bits 28-31 of the read ordinal
 };
 __host__ __device__ inline u32 gen_list_cap(u32 pair_limit) { // chunks of 256 spliced reads dealt round-robin to the sub-lists
     const u32 chunks = pair_limit / 256u + 2u;
@@ -1610,7 +1611,7 @@ __global__ __launch_bounds__(K1E_T) __attribute__((amdgpu_waves_per_eu(K1E_WAVES
                     lb = b3;
                 }
                 p1_two = two;
-                p1_entry = (u64)g | ((u64)off << 32);
+                p1_entry = (u64)(E.pack_nn ? g | (2u << 28) : g) | ((u64)off << 32);
             } else {
                 generic = true;
                 q_n = n;
@@ -1697,7 +1698,7 @@ __global__ __launch_bounds__(K1E_T) __attribute__((amdgpu_waves_per_eu(K1E_WAVES
             emit_read_pairs(cig, R, P, kf, vlen, err, [&](u64 key, int32_t lstart, int32_t rend) { if (want_cand) cand_insert(key, lstart, rend); });
             gen_pairs = nN;
             gen_kind = closed ? 2u : 1u;
-            gen_entry = (u64)R.g | ((u64)R.off << 32);
+            gen_entry = (u64)(closed && E.pack_nn ? R.g | ((nN < 15u ? nN : 15u) << 28) : R.g) | ((u64)R.off << 32);
         }
         // the read goes on k4b_generic's first list (the walks) or on its second (closed form done, window to be checked)
         list_append(1, gen_kind == 1, gen_pairs, gen_entry, chunk);
@@ -2642,7 +2643,7 @@ __device__ __forceinline__ const DevBatch &find_batch(const DevBatch *batches, i
 // goes into the pair's record.  Runs on the side stream, beside the sort.
 __global__ __launch_bounds__(256) void k4b_generic(const u64 *list, const u32 *gen_cnt, u32 cap, const u64 *key, PairRec *rec, const u32 *jid_bam,
                                                     KeyFmt kf, const DevBatch *batches, int n_batches, const int32_t *anc_l, const int32_t *anc_r,
-                                                    GroupTab G, int genome_has_x, int use_codes, u64 *err, const ContigStats *cs) {
+                                                    GroupTab G, int genome_has_x, int use_codes, u64 *err, const ContigStats *cs, u32 pack_nn) {
     __shared__ u32 s_ops[OPS_LDS][256];
     __shared__ u32 s_first[2 * GEN_SHARDS + 1]; // item index of every sub-list's first entry (both lists, one index space)
     __shared__ u32 s_wsum[4];
@@ -2672,13 +2673,16 @@ __global__ __launch_bounds__(256) void k4b_generic(const u64 *list, const u32 *g
         if (sub + step < 2 * GEN_SHARDS && s_first[sub + step] <= item) sub += step;
     const bool check_only = sub >= GEN_SHARDS;
     const u64 entry = list[(size_t)sub * cap + (item - s_first[sub])];
-    const u32 g = (u32)entry, p0 = (u32)(entry >> 32);
+    const u32 p0 = (u32)(entry >> 32);
+    const u32 g = check_only && pack_nn ? (u32)entry & 0x0fffffffu : (u32)entry;
     if (check_only) {
         // A read [S] M (N M)+ [S] whose pairs k1_emit finished with the M blocks as anchors.  That is what the walks produce
         // unless the junction's window reaches over a neighbouring intron of the read: on the left the walk starts at the
         // first operation that begins inside the window (the previous N begins at its istart), on the right it stops at an N
         // that ends outside it (bam_alignment.cc:359).  A read that fails the test takes the walks below -- all its pairs.
-        const u32 nN = (reinterpret_cast<const uint4 *>(rec + p0)[1].w >> 16) + 1u; // (first pair: no junction of the read ends before it, one is its own)
+        // N operations of the read: in the entry, or from its first pair's record (no junction of the read ends before that pair, one is its own)
+        const u32 code = pack_nn ? (u32)entry >> 28 : 15u;
+        const u32 nN = code < 15u ? code : (reinterpret_cast<const uint4 *>(rec + p0)[1].w >> 16) + 1u;
         bool ok = true;
         int32_t prev_istart = 0, is, ie;
         unpack_key(kf, key[p0], is, ie);
@@ -3009,20 +3013,22 @@ __device__ __forceinline__ void fetch_clamp(int32_t glen, int32_t &b, int32_t &e
 // of a junction sequentially, in run order, so the sum rounds like the reference's loop.
 // Entropy of a junction (junction.cc:730-749) = |sum over its position runs of p log2 p|, p = run length / pairs of the junction
 // with the reference's grouping (first run + 1, last run - 1 when there are several), added one after the other in run
-// order so that the sum rounds like the reference's loop (:742-748).  One wavefront per junction: 64 runs at a time -- each
-// lane its run's term from two neighbouring run starts -- folded in lane order through scalar reads (the chain of dependent
-// adds is the reference's, there is no chain of dependent loads).  (The terms had a kernel and an array of their own until
+// order so that the sum rounds like the reference's loop (:742-748).  Sixteen lanes per junction: 16 runs at a time -- each
+// lane its run's term from two neighbouring run starts -- folded in lane order (the chain of dependent adds is the
+// reference's, there is no chain of dependent loads).  (The terms had a kernel and an array of their own until
 // round 4.)
 __global__ __launch_bounds__(256) void k5_entropy_sum(const u32 *seg_off, const u32 *run_first, const u32 *run_start, const u32 *n_junc_p,
                                                        double *ent_sum) {
-    const u32 j = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (j >= *n_junc_p) return;
-    const int lane = lane_id();
-    const u32 rf = run_first[j], rl = run_first[j + 1];
-    const u32 n = seg_off[j + 1] - seg_off[j];
+    // sixteen lanes per junction, four junctions per wavefront: most junctions have a handful of runs (a whole wavefront each spent
+    // its time on 60 idle lanes), the deep ones a hundred or two (read positions within a read length of the intron)
+    const int lane = lane_id(), sl = lane & 15;
+    const u32 j = ((blockIdx.x * 4 + (threadIdx.x >> 6)) << 2) + (u32)(lane >> 4);
+    const bool valid = j < *n_junc_p;
+    const u32 rf = valid ? run_first[j] : 0u, rl = valid ? run_first[j + 1] : 0u;
+    const u32 n = valid ? seg_off[j + 1] - seg_off[j] : 0u;
     double sum = 0.0;
-    for (u32 r0 = rf; r0 < rl; r0 += 64) {
-        const u32 r = r0 + (u32)lane;
+    for (u32 r0 = rf; __any(r0 < rl); r0 += 16) {
+        const u32 r = r0 + (u32)sl;
         double t = 0.0;
         if (r < rl) {
             u32 c = run_start[r + 1] - run_start[r];
@@ -3035,10 +3041,14 @@ __global__ __launch_bounds__(256) void k5_entropy_sum(const u32 *seg_off, const 
                 t = __dmul_rn(pI, log2(pI));
             }
         }
-        const u32 cnt = rl - r0 < 64u ? rl - r0 : 64u;
-        for (u32 k = 0; k < cnt; k++) sum = __dadd_rn(sum, __shfl(t, (int)k, 64));
+        const u32 cnt = r0 < rl ? (rl - r0 < 16u ? rl - r0 : 16u) : 0u;
+#pragma unroll
+        for (u32 k = 0; k < 16; k++) { // (in run order: the sum rounds like the reference's loop)
+            const double v = __shfl(t, (int)k, 16);
+            if (k < cnt) sum = __dadd_rn(sum, v);
+        }
     }
-    if (lane == 0) ent_sum[j] = sum;
+    if (valid && sl == 0) ent_sum[j] = sum;
 }
 
 __global__ __launch_bounds__(256) void k5_finalize(const u64 *jkey, const u32 *seg_off, const u32 *run_first,
