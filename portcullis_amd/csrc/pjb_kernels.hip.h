@@ -1123,12 +1123,12 @@ __device__ __forceinline__ void chunk_cmp(CmpChunkT<NW> &C, int32_t qi, int32_t 
     }
 }
 // one stretch of l bases
-template <int NW>
+template <int NW, bool TO_BUFFER_END = false>
 __device__ __forceinline__ void cmp_words(const u32 *seqw, int32_t qi, int32_t q_last, const u32 *gw, int32_t gi, int32_t g_words, int32_t l,
                                           int32_t out_base, int32_t &mism, int32_t &first_mis, int32_t &last_mis) {
     for (int32_t t = 0; t < l; t += 8 * (NW - 1)) {
         CmpChunkT<NW> C;
-        chunk_load<NW>(C, seqw, qi, q_last, gw, gi, g_words, l, t);
+        chunk_load<NW, TO_BUFFER_END>(C, seqw, qi, q_last, gw, gi, g_words, l, t);
         chunk_cmp<NW>(C, qi, gi, l, t, out_base, mism, first_mis, last_mis);
     }
 }
@@ -2415,7 +2415,7 @@ __global__ __launch_bounds__(256) void kf_anchors(const u32 *sidx, const u32 *ji
 // counting instead of building strings: the query walk and the genome walk are advanced in
 // lock-step over the CIGAR and their emissions compared op by op.
 // ---------------------------------------------------------------------------------------------
-constexpr int GENERIC_NW = 5;
+constexpr int GENERIC_NW = 8; // (as the closed form: two 16-byte loads per stream and round, loads may run to the buffers' ends)
 struct Side {
     int32_t len, mism, first_mis, last_mis;
     int err;
@@ -2425,7 +2425,7 @@ struct Side {
 // pair's hint, the first operation that starts inside the window: everything before it the walks only step over
 __device__ Side anchor_side(const OpsView cig, u32 n, int32_t position, int32_t aligned, const uint8_t *seq, int32_t lq,
                             const uint8_t *genome, int32_t glen, bool genome_has_x, const u32 *gcodes, int32_t start,
-                            int32_t end, u32 k0, int32_t r0, int32_t q0) {
+                            int32_t end, u32 k0, int32_t r0, int32_t q0, int32_t q_limit /* last word behind seq that may be read */) {
     Side S;
     S.len = 0;
     S.mism = 0;
@@ -2522,7 +2522,7 @@ __device__ Side anchor_side(const OpsView cig, u32 n, int32_t position, int32_t 
         if (qEmit != gEmit) diverged = true;
         if (!diverged && qEmit > 0) {
             if (qKind == 1 && gKind == 1 && gcodes != nullptr && rPos >= 0 && rPos + qEmit <= glen) {
-                cmp_words<GENERIC_NW>(reinterpret_cast<const u32 *>(seq), dS + qPos, ((lq + 7) >> 3) - 1, gcodes, rPos, (glen + 7) / 8 + 1, qEmit, qTot,
+                cmp_words<GENERIC_NW, true>(reinterpret_cast<const u32 *>(seq), dS + qPos, q_limit, gcodes, rPos, (glen + 7) / 8 + 1, qEmit, qTot,
                                       mism, first_mis, last_mis);
             } else if (qKind == 1 && gKind == 1) {
                 const int32_t qb = dS + qPos;
@@ -2583,7 +2583,7 @@ __device__ Side anchor_side(const OpsView cig, u32 n, int32_t position, int32_t 
 __device__ __forceinline__ u64 pair_stats_generic(const OpsView cig, u32 nc, int32_t pos, int32_t aligned, const uint8_t *seq,
                                                   int32_t lq, const uint8_t *genome, int32_t glen, bool has_x, const u32 *gcodes,
                                                   int32_t left, int32_t istart, int32_t iend, int32_t right, u32 g, u64 *err, u32 opi,
-                                                  int32_t qN) {
+                                                  int32_t qN, int32_t q_limit) {
     if (lq <= 1) { // junction.cc:168-185
         const u32 totUp = (u32)((istart - 1) - left + 1);
         const u32 totDown = (u32)(right - (iend + 1) + 1);
@@ -2610,12 +2610,12 @@ __device__ __forceinline__ u64 pair_stats_generic(const OpsView cig, u32 nc, int
         rR = after;
         qR = qN;
     }
-    const Side L = anchor_side(cig, nc, pos, aligned, seq, lq, genome, glen, has_x, gcodes, left, istart - 1, kL, rL, qL);
+    const Side L = anchor_side(cig, nc, pos, aligned, seq, lq, genome, glen, has_x, gcodes, left, istart - 1, kL, rL, qL, q_limit);
     if (L.err) {
         set_error(err, g, L.err);
         return 0;
     }
-    const Side R = anchor_side(cig, nc, pos, aligned, seq, lq, genome, glen, has_x, gcodes, iend + 1, right, kR, rR, qR);
+    const Side R = anchor_side(cig, nc, pos, aligned, seq, lq, genome, glen, has_x, gcodes, iend + 1, right, kR, rR, qR, q_limit);
     if (R.err) {
         set_error(err, g, R.err);
         return 0;
@@ -2673,6 +2673,12 @@ __global__ __launch_bounds__(256) void k4b_generic(const u64 *list, const u32 *g
         if (sub + step < 2 * GEN_SHARDS && s_first[sub + step] <= item) sub += step;
     const bool check_only = sub >= GEN_SHARDS;
     const u64 entry = list[(size_t)sub * cap + (item - s_first[sub])];
+#ifdef PJB_K4B_SKIP_CHECK // (timing experiments only)
+    if (check_only) continue;
+#endif
+#ifdef PJB_K4B_SKIP_WALK
+    if (!check_only) continue;
+#endif
     const u32 p0 = (u32)(entry >> 32);
     const u32 g = check_only && pack_nn ? (u32)entry & 0x0fffffffu : (u32)entry;
     if (check_only) {
@@ -2723,6 +2729,7 @@ __global__ __launch_bounds__(256) void k4b_generic(const u64 *list, const u32 *g
         continue; // (the records keep aux = 0)
     }
     const uint8_t *seq = b.seq4 + (size_t)so0 * 4;
+    const int32_t q_limit = (int32_t)min(gload(b.seq_off + b.n) - 1u - so0, 0x7fffffffu); // (to the end of the batch's bases: chunk_load)
     u32 k = 0;
     int32_t qsum = 0; // query bases before the operation, soft clips not counted (anchor_side's qPos)
     for (u32 i = 0; i < nc; i++) {
@@ -2733,7 +2740,7 @@ __global__ __launch_bounds__(256) void k4b_generic(const u64 *list, const u32 *g
             int32_t istart, iend;
             unpack_key(kf, key[p], istart, iend);
             const u64 res = pair_stats_generic(cig, nc, pos, aend - vpos + 1, seq, lq, M.d, M.len, genome_has_x != 0, use_codes ? M.codes : (const u32 *)nullptr,
-                                               anc_l[j] - M.voff, istart - M.voff, iend - M.voff, anc_r[j] - M.voff, g, err, i, qsum);
+                                               anc_l[j] - M.voff, istart - M.voff, iend - M.voff, anc_r[j] - M.voff, g, err, i, qsum, q_limit);
             *reinterpret_cast<u64 *>(rec + p) = res; // PairRec::aux
             k++;
         }
