@@ -61,7 +61,7 @@ def algorithmic_bytes(name, N, C, S, Cs, P, J, L, Pg=0, Rg=0, R=0, cand=0, Rv=0,
         "kd_mark": cand * 16, "kd_ends": cand * 12 + cand * 4, "kd_table": cand * 20 + J * 16, "kd_reset": cand * 12 + cand * 40,
         # prefix popcount over the start bitmap (a bit per base of the chain's targets): words read twice, a 4-B rank per word
         # written; the scan over the start ranks' end slots (32 B per start, J starts at most) gives the first ids
-        "kd_rank_reduce": G / 64.0 * 8, "kd_rank_apply": G / 64.0 * 12, "kd_first_reduce": J * 32.0, "kd_first_apply": J * 44.0,
+        "kd_rank_reduce": G / 64.0 * 8, "kd_rank_apply": G / 64.0 * 12, "kd_rank_tiles": G / 64.0 / 2048 * 16 + 64, "kd_first_reduce": J * 32.0, "kd_first_apply": J * 44.0,
         # the sort: key in (4 or 8), index in (4, but for the first pass), both out
         "rs_hist": P * (4 if sort_u32 else 8),
         "rs_scatter": P * (16 if sort_u32 else 24),
