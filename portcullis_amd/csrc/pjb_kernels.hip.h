@@ -208,7 +208,7 @@ __device__ __host__ inline void unpack_key(const KeyFmt &f, u64 k, int32_t &ista
 // CIGAR op classes by BAM op code "MIDNSHP=XB" (bam_alignment.hpp:75-99)
 __device__ __forceinline__ bool op_consumes_ref(u32 op) { return (0x18Du >> op) & 1u; }   // M D N = X
 __device__ __forceinline__ bool op_consumes_query(u32 op) { return (0x193u >> op) & 1u; } // M I S = X
-enum : u32 { OP_M = 0, OP_I = 1, OP_D = 2, OP_N = 3, OP_S = 4 };
+enum : u32 { OP_M = 0, OP_I = 1, OP_D = 2, OP_N = 3, OP_S = 4, OP_H = 5, OP_P = 6, OP_EQ = 7, OP_X = 8 };
 
 // ---------------------------------------------------------------------------------------------
 // wave / block primitives (wave = 64 lanes)
@@ -1177,6 +1177,19 @@ __device__ __forceinline__ void ncursor_advance(NCursor &c, const Ops cig, u32 n
     }
 }
 
+#ifndef PJB_CLOSED_INDELS
+#define PJB_CLOSED_INDELS 0 // 1: blocks with I / D operations in closed form too (emit_read_pairs can; measured: the walk list all but
+                            // empties -- k4b_generic 224 -> 136 us a chain -- but k1_emit's second phase, a few lanes per block, pays
+                            // 60 us a launch for it: 9.75 against 9.1 ms a step.  k4b_generic runs beside the sort, k1_emit beside nothing.)
+#endif
+#ifndef PJB_SIMPLE_NW
+#define PJB_SIMPLE_NW 8 // two 16-byte loads per stream and round, 56 bases a round (5: one 16-byte load and a word, 32 bases)
+#endif
+#ifndef PJB_SIMPLE_SEQ
+#define PJB_SIMPLE_SEQ 1 // 1: the two sides one after the other (half the registers, one more round trip); 0: both sides' words of a round in flight together
+// (profiles/r04e_compare_variants.txt: NW 5 both / 8 both / 5 sequential / 8 sequential = 10.56 / 11.56 / 10.07 / 9.97 ms a step)
+#endif
+constexpr int SIMPLE_NW = PJB_SIMPLE_NW;
 // One spliced read's pairs (JunctionSystem::addJunctions junction_system.cc:140-210) -- everything that follows from
 // the read's fixed-width fields is in R, the CIGAR behind `cig`.  Shape test, walk with the two monotone cursors for
 // the up/down junction counts (junction.cc:795-812), one 32-byte record per pair.
@@ -1229,10 +1242,23 @@ __device__ __forceinline__ void emit_read_pairs(const Ops cig, const EmitRead R,
     pend.aend = aend;
     pend.meta = closed ? meta | META_SIMPLE : meta;
     pend.updown = 0;
-    auto closed_stats = [&]() { // left block read[prevQ - a, prevQ) at lstart, right block read[prevQ, ...) behind the intron
-        const int32_t a = prevIstart - pend.lstart;
-        return simple_pair_stats(R.closed_seqw, R.gcodes, R.glen, pend.lstart - R.voff, prevIstart - R.voff, prevIend - R.voff, pend.rend - R.voff, prevQ - a, R.q_limit);
+    // closed: the read is [S] B (N B)+ [S], every block B a run of M = X I D operations that starts and ends with bases on both
+    // sides.  What the walks emit for a block -- compared bases for M = X, read letters against 'X' padding for I, 'X' padding
+    // against genome bases for D (never equal: such targets hold no 'X') -- is accumulated ONCE per block as the operations go
+    // by: a block is the right anchor of the pair before it and the left anchor of the pair behind it (bam_alignment.cc:341-462
+    // with the whole block inside the window, which k4b_generic checks).
+    struct Block {
+        int32_t len, mism, first, last;
     };
+    Block blkL = {0, 0, -1, -1}, blk = {0, 0, -1, -1}; // the pending pair's left block; the block being walked
+    auto closed_stats = [&]() { // junction.cc:263-272: matches from the left block's end / the right block's start; mmes; mismatches
+        const u32 upM = blkL.last < 0 ? (u32)blkL.len : (u32)(blkL.len - 1 - blkL.last);
+        const u32 downM = blk.first < 0 ? (u32)blk.len : (u32)blk.first;
+        const u32 tu = (u32)(blkL.len - blkL.mism), td = (u32)(blk.len - blk.mism);
+        return pack_res(upM < downM ? upM : downM, tu < td ? tu : td, (u32)(blkL.mism + blk.mism));
+    };
+    (void)prevIstart;
+    (void)prevQ;
     u32 k = 0;
     for (u32 i = 0; i < n; i++) {
         const u32 op = cig[i];
@@ -1270,6 +1296,8 @@ __device__ __forceinline__ void emit_read_pairs(const Ops cig, const EmitRead R,
             if (lStart > istart) set_error(err, g, PJB_ERR_MIN_ANCHOR); // intron.cc:68
             prev = idx;
             prev_key = key;
+            blkL = blk; // (the block that ends here is this pair's left anchor)
+            blk = Block{0, 0, -1, -1};
             prevIstart = istart;
             prevQ = qAcc;
             prevIend = iend;
@@ -1278,9 +1306,22 @@ __device__ __forceinline__ void emit_read_pairs(const Ops cig, const EmitRead R,
             lStart = rStart;
             lEndExc = rStart;
             k++;
-        } else if (op_consumes_ref(ty)) {
-            lEndExc += ln;
-            sumAfter += ln;
+        } else {
+            if (closed && ty != OP_S) {
+                const bool cq = op_consumes_query(ty), cr = op_consumes_ref(ty);
+                if (cq && cr) // M = X: bases against bases
+                    cmp_words<SIMPLE_NW, true>(R.closed_seqw, qAcc, R.q_limit, R.gcodes, lEndExc - R.voff, (R.glen + 7) / 8 + 1, ln, blk.len, blk.mism, blk.first, blk.last);
+                else { // I / D: ln positions that never match
+                    blk.mism += ln;
+                    if (blk.first < 0) blk.first = blk.len;
+                    blk.last = blk.len + ln - 1;
+                }
+                blk.len += ln;
+            }
+            if (op_consumes_ref(ty)) {
+                lEndExc += ln;
+                sumAfter += ln;
+            }
         }
         if (op_consumes_query(ty)) qAcc += ln;
     }
@@ -1323,14 +1364,6 @@ __device__ __forceinline__ u32 read_meta(u32 flag, u32 xs, u32 mapq, int32_t pos
 // The common shape [S] M N M [S] (coordinates of the read's own target): the left anchor is read[dS, dS+a) against
 // genome[pos, pos+a), the right one read[dS+a, dS+a+b) against genome[iend+1, iend+1+b); neither depends on the
 // junction-level window -- the walk rules of bam_alignment.cc:341-462 reduce to exactly this for the shape.
-#ifndef PJB_SIMPLE_NW
-#define PJB_SIMPLE_NW 8 // two 16-byte loads per stream and round, 56 bases a round (5: one 16-byte load and a word, 32 bases)
-#endif
-#ifndef PJB_SIMPLE_SEQ
-#define PJB_SIMPLE_SEQ 1 // 1: the two sides one after the other (half the registers, one more round trip); 0: both sides' words of a round in flight together
-// (profiles/r04e_compare_variants.txt: NW 5 both / 8 both / 5 sequential / 8 sequential = 10.56 / 11.56 / 10.07 / 9.97 ms a step)
-#endif
-constexpr int SIMPLE_NW = PJB_SIMPLE_NW;
 // q_limit: the last word after seqw that may be read (the batch's last word of bases: what a load brings in past the anchors is masked)
 __device__ __forceinline__ u64 simple_pair_stats(const u32 *seqw, const u32 *gcodes, int32_t glen, int32_t pos, int32_t istart, int32_t iend,
                                                  int32_t rend, int32_t dS, int32_t q_limit) {
@@ -1668,21 +1701,25 @@ __global__ __launch_bounds__(K1E_T) __attribute__((amdgpu_waves_per_eu(K1E_WAVES
             OpsViewT<K1E_T, OPS_LDS> cig;
             cig.g = b.cigar + s_gq[GQ_C0][at];
             cig.lds = &s_ops[0][(qm >> 16) & 0xffu];
-            // operations counted, and the shape [S] M (N M)+ [S] recognised: state 0 at the first operation, 5 after a leading S, 1
-            // after an M, 2 after an N, 3 after the closing S, 4 any other shape
+            // operations counted, and the shape [S] B (N B)+ [S] recognised, B = M = X I D operations that begin and end with bases on
+            // both sides: state 0 at the first operation, 5 after a leading S, 1 after M = X, 6 after I or D, 2 after an N, 3 after the
+            // closing S, 4 any other shape
             u32 nN = 0, shape = 0;
             int32_t aligned = 0;
-            int64_t qsum = 0;
+            int64_t qsum = 0, bsum = 0; // query bases; positions the walks emit for the current block
             for (u32 q = 0; q < R.n; q++) {
                 const u32 o = cig[q], ty = o & 15u, ln = o >> 4;
                 nN += (ty == OP_N);
                 if (op_consumes_ref(ty)) aligned += (int32_t)ln;
                 if (op_consumes_query(ty)) qsum += ln;
                 const bool len_ok = ln > 0 && ln <= RES_FIELD_MAX;
-                if (ty == OP_M) shape = (shape == 0 || shape == 5 || shape == 2) && len_ok ? 1u : 4u;
+                if (ty == OP_M || ty == OP_EQ || ty == OP_X) shape = (shape == 0 || shape == 5 || shape == 2 || shape == 1 || shape == 6) && len_ok ? 1u : 4u;
+                else if (ty == OP_I || ty == OP_D) shape = PJB_CLOSED_INDELS && shape == 1 && len_ok ? 6u : 4u;
                 else if (ty == OP_N) shape = shape == 1 && ln > 0 ? 2u : 4u;
                 else if (ty == OP_S) shape = shape == 0 && len_ok ? 5u : shape == 1 && q + 1 == R.n ? 3u : 4u;
                 else shape = 4;
+                bsum = ty == OP_N ? 0 : ty == OP_S ? bsum : bsum + ln;
+                if (bsum > (int64_t)RES_FIELD_MAX) shape = 4;
             }
             if (nN > 1) R.meta |= META_MULTI;
             R.nN = nN;
