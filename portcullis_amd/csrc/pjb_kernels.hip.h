@@ -2710,12 +2710,6 @@ __global__ __launch_bounds__(256) void k4b_generic(const u64 *list, const u32 *g
         if (sub + step < 2 * GEN_SHARDS && s_first[sub + step] <= item) sub += step;
     const bool check_only = sub >= GEN_SHARDS;
     const u64 entry = list[(size_t)sub * cap + (item - s_first[sub])];
-#ifdef PJB_K4B_SKIP_CHECK // (timing experiments only)
-    if (check_only) continue;
-#endif
-#ifdef PJB_K4B_SKIP_WALK
-    if (!check_only) continue;
-#endif
     const u32 p0 = (u32)(entry >> 32);
     const u32 g = check_only && pack_nn ? (u32)entry & 0x0fffffffu : (u32)entry;
     if (check_only) {
