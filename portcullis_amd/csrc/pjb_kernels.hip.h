@@ -1185,11 +1185,22 @@ __device__ __forceinline__ void ncursor_advance(NCursor &c, const Ops cig, u32 n
 #ifndef PJB_SIMPLE_NW
 #define PJB_SIMPLE_NW 8 // two 16-byte loads per stream and round, 56 bases a round (5: one 16-byte load and a word, 32 bases)
 #endif
-#ifndef PJB_SIMPLE_SEQ
-#define PJB_SIMPLE_SEQ 1 // 1: the two sides one after the other (half the registers, one more round trip); 0: both sides' words of a round in flight together
-// (profiles/r04e_compare_variants.txt: NW 5 both / 8 both / 5 sequential / 8 sequential = 10.56 / 11.56 / 10.07 / 9.97 ms a step)
-#endif
+// (profiles/r04e_compare_variants.txt: 32 bases a round with both anchors' words in flight together / 56 together / 32 one anchor
+// after the other / 56 one after the other = 10.56 / 11.56 / 10.07 / 9.97 ms a step; since then an anchor is a block compared on
+// its own, one after the other)
 constexpr int SIMPLE_NW = PJB_SIMPLE_NW;
+// what the walks find comparing one anchor (a block of emitted positions): its length, mismatches, first and last mismatch
+struct CmpBlock {
+    int32_t len, mism, first, last;
+};
+// a pair's packed statistics from its left and right anchor (junction.cc:263-272: matches from the left anchor's end / the right
+// anchor's start; mmes; mismatches)
+__device__ __forceinline__ u64 cmp_blocks_res(const CmpBlock &L, const CmpBlock &R) {
+    const u32 upM = L.last < 0 ? (u32)L.len : (u32)(L.len - 1 - L.last);
+    const u32 downM = R.first < 0 ? (u32)R.len : (u32)R.first;
+    const u32 tu = (u32)(L.len - L.mism), td = (u32)(R.len - R.mism);
+    return pack_res(upM < downM ? upM : downM, tu < td ? tu : td, (u32)(L.mism + R.mism));
+}
 // One spliced read's pairs (JunctionSystem::addJunctions junction_system.cc:140-210) -- everything that follows from
 // the read's fixed-width fields is in R, the CIGAR behind `cig`.  Shape test, walk with the two monotone cursors for
 // the up/down junction counts (junction.cc:795-812), one 32-byte record per pair.
@@ -1209,12 +1220,10 @@ struct EmitRead {
     // window).  The window is known after K2d; the block compares are done here, where the read's operations and bases are
     // at hand (closed != nullptr), and k4b_generic checks the window for the reads on its second list.
     const u32 *closed_seqw; // the read's packed bases (nullptr: not of that shape -- the generic walks fill PairRec::aux in)
-    int32_t q_limit;        // last word behind closed_seqw that may be read (simple_pair_stats)
+    int32_t q_limit;        // last word behind closed_seqw that may be read (cmp_words)
     const u32 *gcodes;      // the target's 4-bit codes
     int32_t glen, voff;     // the target's length and its offset in the group's virtual sequence
 };
-__device__ __forceinline__ u64 simple_pair_stats(const u32 *seqw, const u32 *gcodes, int32_t glen, int32_t pos, int32_t istart, int32_t iend,
-                                                 int32_t rend, int32_t dS, int32_t q_limit);
 // (reads of the simple shape never come here: k1_emit finishes them in closed form.)  on_pair(key, lStart, rEnd) is called
 // for every pair once its record is complete; the match statistics (PairRec::aux) of a read that is not `closed` are
 // k4b_generic's to fill in.
@@ -1247,16 +1256,9 @@ __device__ __forceinline__ void emit_read_pairs(const Ops cig, const EmitRead R,
     // against genome bases for D (never equal: such targets hold no 'X') -- is accumulated ONCE per block as the operations go
     // by: a block is the right anchor of the pair before it and the left anchor of the pair behind it (bam_alignment.cc:341-462
     // with the whole block inside the window, which k4b_generic checks).
-    struct Block {
-        int32_t len, mism, first, last;
-    };
+    typedef CmpBlock Block;
     Block blkL = {0, 0, -1, -1}, blk = {0, 0, -1, -1}; // the pending pair's left block; the block being walked
-    auto closed_stats = [&]() { // junction.cc:263-272: matches from the left block's end / the right block's start; mmes; mismatches
-        const u32 upM = blkL.last < 0 ? (u32)blkL.len : (u32)(blkL.len - 1 - blkL.last);
-        const u32 downM = blk.first < 0 ? (u32)blk.len : (u32)blk.first;
-        const u32 tu = (u32)(blkL.len - blkL.mism), td = (u32)(blk.len - blk.mism);
-        return pack_res(upM < downM ? upM : downM, tu < td ? tu : td, (u32)(blkL.mism + blk.mism));
-    };
+    auto closed_stats = [&]() { return cmp_blocks_res(blkL, blk); };
     (void)prevIstart;
     (void)prevQ;
     u32 k = 0;
@@ -1361,45 +1363,10 @@ __device__ __forceinline__ u32 read_meta(u32 flag, u32 xs, u32 mapq, int32_t pos
     return meta;
 }
 
-// The common shape [S] M N M [S] (coordinates of the read's own target): the left anchor is read[dS, dS+a) against
-// genome[pos, pos+a), the right one read[dS+a, dS+a+b) against genome[iend+1, iend+1+b); neither depends on the
-// junction-level window -- the walk rules of bam_alignment.cc:341-462 reduce to exactly this for the shape.
-// q_limit: the last word after seqw that may be read (the batch's last word of bases: what a load brings in past the anchors is masked)
-__device__ __forceinline__ u64 simple_pair_stats(const u32 *seqw, const u32 *gcodes, int32_t glen, int32_t pos, int32_t istart, int32_t iend,
-                                                 int32_t rend, int32_t dS, int32_t q_limit) {
-    const int32_t a = istart - pos, bb = rend - iend;
-    const int32_t g_words = (glen + 7) / 8 + 1;
-    const int32_t q_last = q_limit;
-    int32_t misL = 0, firstL = -1, lastL = -1, misR = 0, firstR = -1, lastR = -1;
-    // (both sides' words of a round in flight together -- a round is one trip to memory, and the trips set the pace --, 32 bases
-    // a side: 64 a side held 36 registers and cost the kernel a third of its wavefronts)
-#if PJB_SIMPLE_SEQ
-    for (int32_t t = 0; t < a; t += 8 * (SIMPLE_NW - 1)) {
-        CmpChunkT<SIMPLE_NW> L;
-        chunk_load<SIMPLE_NW, true>(L, seqw, dS, q_last, gcodes, pos, g_words, a, t);
-        chunk_cmp<SIMPLE_NW>(L, dS, pos, a, t, 0, misL, firstL, lastL);
-    }
-    for (int32_t t = 0; t < bb; t += 8 * (SIMPLE_NW - 1)) {
-        CmpChunkT<SIMPLE_NW> R;
-        chunk_load<SIMPLE_NW, true>(R, seqw, dS + a, q_last, gcodes, iend + 1, g_words, bb, t);
-        chunk_cmp<SIMPLE_NW>(R, dS + a, iend + 1, bb, t, 0, misR, firstR, lastR);
-    }
-#endif
-    const int32_t longest = PJB_SIMPLE_SEQ ? 0 : (a > bb ? a : bb);
-    for (int32_t t = 0; t < longest; t += 8 * (SIMPLE_NW - 1)) {
-        CmpChunkT<SIMPLE_NW> L, R;
-        const bool onL = t < a, onR = t < bb;
-        if (onL) chunk_load<SIMPLE_NW, true>(L, seqw, dS, q_last, gcodes, pos, g_words, a, t);
-        if (onR) chunk_load<SIMPLE_NW, true>(R, seqw, dS + a, q_last, gcodes, iend + 1, g_words, bb, t);
-        if (onL) chunk_cmp<SIMPLE_NW>(L, dS, pos, a, t, 0, misL, firstL, lastL);
-        if (onR) chunk_cmp<SIMPLE_NW>(R, dS + a, iend + 1, bb, t, 0, misR, firstR, lastR);
-    }
-    const u32 upM = lastL < 0 ? (u32)a : (u32)(a - 1 - lastL);
-    const u32 downM = firstR < 0 ? (u32)bb : (u32)firstR;
-    const u32 tu = (u32)(a - misL), td = (u32)(bb - misR);
-    return pack_res(upM < downM ? upM : downM, tu < td ? tu : td, (u32)(misL + misR));
-}
-
+// The common shapes [S] M N M [S] and [S] M N M N M [S] (coordinates of the read's own target): an anchor is one block of bases,
+// read[q, q + len) against genome[g, g + len) (cmp_words); neither depends on the junction-level window -- the walk rules of
+// bam_alignment.cc:341-462 reduce to exactly this for the shapes (for two introns: unless a window reaches over the other
+// intron, which k4b_generic checks).
 // Thread per spliced read of the batch, DENSE: the tiles' spliced lists (k1_count compacted them per tile) are walked as one
 // list -- entry s lies in the tile t with tile_soff[t] <= s < tile_soff[t + 1], found from chunk_tile (the tile of entry
 // 256 * chunk) and a short walk -- so every thread of every block has a read.  The read's CIGAR is fetched once (8
@@ -1613,6 +1580,7 @@ __global__ __launch_bounds__(K1E_T) __attribute__((amdgpu_waves_per_eu(K1E_WAVES
                 int32_t lst = vpos;  // the left block of the pair: where it starts, its query offset, its length; intron; right block
                 int32_t qoff = (int32_t)dS;
                 u32 la = a, ln_ = nl, lb = b2;
+                CmpBlock blkL = {0, 0, -1, -1};
                 for (u32 pr = 0; pr < (two ? 2u : 1u); pr++) {
                     const int32_t istart = lst + (int32_t)la;
                     const int32_t rStartU = istart + (int32_t)ln_;
@@ -1632,7 +1600,19 @@ __global__ __launch_bounds__(K1E_T) __attribute__((amdgpu_waves_per_eu(K1E_WAVES
                     // junction.cc:795-812.  One N operation: nothing upstream; "downstream" counts the operation itself unless its end was
                     // clamped.  Two: the first has the second downstream, the second the first upstream.
                     R.updown = two ? (pr == 0 ? (1u << 16) : 1u) : (rStartU <= iend + 1 ? 0u : (1u << 16));
-                    R.aux = simple_pair_stats(seqw, gcodes, ref_len, lst - voff, istart - voff, iend - voff, R.rend - voff, qoff, (int32_t)min(seq_words - 1u - so, 0x7fffffffu));
+                    // the anchors' match statistics: every block of bases is compared once -- the block between two introns is the first
+                    // pair's right anchor and the second pair's left one
+                    {
+                        const int32_t q_limit = (int32_t)min(seq_words - 1u - so, 0x7fffffffu), g_words = (ref_len + 7) / 8 + 1;
+                        if (pr == 0) {
+                            blkL = CmpBlock{(int32_t)la, 0, -1, -1};
+                            cmp_words<SIMPLE_NW, true>(seqw, qoff, q_limit, gcodes, lst - voff, g_words, (int32_t)la, 0, blkL.mism, blkL.first, blkL.last);
+                        }
+                        CmpBlock blkR = {R.rend - iend, 0, -1, -1};
+                        cmp_words<SIMPLE_NW, true>(seqw, qoff + (int32_t)la, q_limit, gcodes, iend + 1 - voff, g_words, blkR.len, 0, blkR.mism, blkR.first, blkR.last);
+                        R.aux = cmp_blocks_res(blkL, blkR);
+                        blkL = blkR;
+                    }
                     P.key[off + pr] = key;
                     if (P.g) P.g[off + pr] = g;
                     rec_store(P.rec + off + pr, R);
