@@ -1496,7 +1496,7 @@ static int queue_contig(pjb_ctx *c, Flight &f) {
     const u32 pair_blocks = std::max<u32>(1, (PL + 255) / 256);
     const u32 gen_cap = gen_list_cap(PL); // entries per sub-list
     const u32 pack_nn = (u64)f.n_reads < (1ull << 28) ? 1u : 0u; // (EmitLists::pack_nn)
-    if ((rc = ensure(c, S.genlist, (size_t)gen_cap * GEN_SHARDS * 8 * 2))) return rc; // (two lists: EmitLists)
+    if ((rc = ensure(c, S.genlist, (size_t)gen_cap * GEN_SHARDS * 8 * 3))) return rc; // (three lists: EmitLists)
     if ((rc = ensure(c, S.gencount, GEN_SHARDS * GEN_CNT_STRIDE * 4))) return rc; // a line per sub-list: reads, pairs
     // ---- junction-sized buffers
     const u32 slots_lim = JL + (PL + 63) / 64 + 1;
@@ -1657,6 +1657,10 @@ static int queue_contig(pjb_ctx *c, Flight &f) {
                    (const u32 *)S.chunk_tile.p, (const u32 *)S.splidx.p, (const u32 *)S.splpoff.p, (const uint4 *)S.splrec.p, pr, el, kf, own_len,
                    own_tid, (int)c->cfg.orientation, d_err, d_cs, f.voff[(size_t)m], fast_codes ? (const u32 *)GT.codes[m] : (const u32 *)nullptr);
         }
+        // the reads k1_emit left: one launch over the chain's third list (the blocks stride over it)
+        LAUNCH(c, "k1_generic", k1_generic, dim3(std::min<u32>(std::max<u32>(1, (u32)(((u64)gen_cap * GEN_SHARDS + K1E_T - 1) / K1E_T)), 1536u)), dim3(K1E_T),
+               (const DevBatch *)S.batches.p, (int)batches.size(), (const u32 *)S.splidx.p, (const uint4 *)S.splrec.p, pr, el, kf, GT, fast_codes ? 1 : 0,
+               (int)c->cfg.orientation, d_err, d_cs);
     }
     STAGE_EVENT(1);
     // k4b_generic: the pairs that need the generic walks, in BAM order, as soon as junction ids and anchors exist -- beside
@@ -1965,6 +1969,7 @@ static void prepare_flight(pjb_ctx *c, Flight &f) {
                 prev_ptr = nullptr;
             } else
                 prev_ptr = b.pos + (b.n - 1);
+            b.member = (int32_t)m;
             f.batches.push_back(b);
             f.batch_member.push_back((int)m);
         }

@@ -42,7 +42,7 @@ struct DevBatch {
     uint32_t base;      // global read ordinal of record 0 within the contig
     uint32_t tile_base; // first K1 tile index of this batch
     int32_t prev_pos;   // pos of the last record of the previous batch (sortedness across batches)
-    int32_t _pad;
+    int32_t member;     // the batch's target: its index among the chain's members (GroupTab)
     const int32_t *prev_pos_ptr; // where that position is, when only the device knows it (nullptr: prev_pos holds it)
 };
 
@@ -1395,11 +1395,11 @@ struct EmitLists {
     u64 *cand;      // candidate keys (nullptr: the chain sorts the full keys and wants none); their count is ContigStats::n_cand
     u64 *bitmap;    // K2d's bitmap of intron starts (all-clear at rest): every candidate sets its start's bit as it is listed
     u64 *cand_anc;  // per candidate: min lStart | max rEnd << 32 over the pairs it stands for (the junction anchors' first level)
-    u64 *gen_list;  // global read ordinal | index of the read's first pair << 32: [2][GEN_SHARDS][gen_cap] -- the reads whose
-                    // pairs need the generic walks, then the reads whose closed form waits for the window check (k4b_generic)
-    u32 *gen_cnt;   // [GEN_SHARDS][GEN_CNT_STRIDE]: word 0 entries of the first sub-list, word 1 pairs of those reads, words 2 and 3
-                    // the same for the second -- a cache line per shard: atomics on one line are served one after the other,
-                    // whatever the address in it
+    u64 *gen_list;  // [3][GEN_SHARDS][gen_cap].  Lists 1 and 2, for k4b_generic: global read ordinal | index of the read's first pair
+                    // << 32 -- the reads whose pairs need the generic walks; the reads whose closed form waits for the window check.
+                    // List 3, for k1_generic: the read's slot in the tiles' spliced lists | index of its first pair << 32.
+    u32 *gen_cnt;   // [GEN_SHARDS][GEN_CNT_STRIDE]: words 2 l - 2, 2 l - 1 = entries of list l's sub-list, pairs of those reads -- a cache
+                    // line per shard: atomics on one line are served one after the other, whatever the address in it
     u32 gen_cap;    // room of one sub-list
     u32 pack_nn;    // 1 (chains of fewer than 2^28 reads): entries of the second list carry min(N operations, 15) in bits 28-31 of the read ordinal
 };
@@ -1407,55 +1407,48 @@ __host__ __device__ inline u32 gen_list_cap(u32 pair_limit) { // chunks of 256 s
     const u32 chunks = pair_limit / 256u + 2u;
     return ((chunks + GEN_SHARDS - 1) / GEN_SHARDS) * 256u;
 }
-__global__ __launch_bounds__(K1E_T) __attribute__((amdgpu_waves_per_eu(K1E_WAVES, K1E_WAVES))) void k1_emit(DevBatch b, u32 n_tiles_batch, u32 n_tiles_total, const u32 *tile_off, const u32 *tile_soff,
-                                                const u32 *chunk_tile, const u32 *spl_idx, const u32 *spl_poff, const uint4 *spl_rec, Pairs P, EmitLists E, KeyFmt kf,
-                                                int32_t ref_len, int32_t tid, int orientation, u64 *err, ContigStats *cs, int32_t voff,
-                                                const u32 *gcodes) {
-    __shared__ u32 s_ops[OPS_LDS][K1E_T];
-    __shared__ u32 s_soff[K1E_LOOK];
-    __shared__ u64 s_set[KC_SLOTS];
-    __shared__ int32_t s_lo[KC_SLOTS], s_hi[KC_SLOTS];
-    __shared__ u32 s_set_n, s_base, s_scan[4];
-    // the trip's reads that are not of the simple shape, compacted: what their walk needs (phase 2)
-    enum { GQ_N = 0, GQ_POS, GQ_G, GQ_META, GQ_LQ, GQ_OFF, GQ_C0, GQ_SO, GQ_WORDS };
-    __shared__ u32 s_gq[GQ_WORDS][K1E_T];
-    __shared__ u32 s_gq_n;
-    if (cs->P == 0) return; // no pairs, or a limit was exceeded: the contig is repeated with larger buffers
-    const u32 s_begin = tile_soff[b.tile_base], s_end = tile_soff[b.tile_base + n_tiles_batch];
-    if (s_begin == s_end) return;
-    const u32 c_lo = s_begin >> K1E_SHIFT, c_hi = (s_end + (u32)K1E_T - 1u) >> K1E_SHIFT; // trips of K1E_T list entries
-    const bool want_cand = E.cand != nullptr;
-    const int32_t vlen = voff + ref_len; // the target's end in the group's virtual sequence
-    const u32 seq_words = b.seq_off[b.n]; // words of packed bases in the batch: no compare reads past them
-    const u32 cig_words = b.cig_off[b.n]; // operations in the batch
-    if (want_cand) {
+// What k1_emit and k1_generic share: the block's candidate set (LDS) and the appends to k4b_generic's / k1_generic's lists.
+struct EmitShared {
+    u64 set[KC_SLOTS];
+    int32_t lo[KC_SLOTS], hi[KC_SLOTS];
+    u32 set_n, base, scan[4];
+};
+struct EmitCtx {
+    EmitShared &sh;
+    const EmitLists &E;
+    const KeyFmt kf;
+    ContigStats *cs;
+    const bool want_cand;
+    __device__ __forceinline__ void init() {
+        if (!want_cand) return;
 #pragma unroll
         for (int i = 0; i < KC_SLOTS / K1E_T; i++) {
-            s_set[i * K1E_T + threadIdx.x] = KD_EMPTY;
-            s_lo[i * K1E_T + threadIdx.x] = INT32_MAX;
-            s_hi[i * K1E_T + threadIdx.x] = INT32_MIN;
+            sh.set[i * K1E_T + threadIdx.x] = KD_EMPTY;
+            sh.lo[i * K1E_T + threadIdx.x] = INT32_MAX;
+            sh.hi[i * K1E_T + threadIdx.x] = INT32_MIN;
         }
-        if (threadIdx.x == 0) s_set_n = 0;
+        if (threadIdx.x == 0) sh.set_n = 0;
     }
-    auto cand_mark = [&](u64 k) { // (what kd_mark did in a launch of its own)
+    __device__ __forceinline__ void cand_mark(u64 k) const { // (what kd_mark did in a launch of its own)
         int32_t ms, me;
         unpack_key(kf, k, ms, me);
         atomicOr((unsigned long long *)(E.bitmap + ((u32)ms >> 6)), 1ull << (ms & 63));
-    };
-    auto cand_insert = [&](u64 k, int32_t lstart, int32_t rend) {
+    }
+    __device__ __forceinline__ void cand_insert(u64 k, int32_t lstart, int32_t rend) const {
+        if (!want_cand) return;
         u32 h = (u32)((k * 0x9E3779B97F4A7C15ull) >> 40) & (KC_SLOTS - 1);
         for (int probe = 0; probe < 24; probe++) { // look first: most keys are there already, and a read of one address by many lanes is a broadcast
-            u64 old = s_set[h];
+            u64 old = sh.set[h];
             if (old == KD_EMPTY) {
-                old = atomicCAS((unsigned long long *)&s_set[h], (unsigned long long)KD_EMPTY, (unsigned long long)k);
+                old = atomicCAS((unsigned long long *)&sh.set[h], (unsigned long long)KD_EMPTY, (unsigned long long)k);
                 if (old == KD_EMPTY) {
-                    atomicAdd(&s_set_n, 1u);
+                    atomicAdd(&sh.set_n, 1u);
                     old = k;
                 }
             }
             if (old == k) {
-                if (lstart < s_lo[h]) atomicMin(&s_lo[h], lstart);
-                if (rend > s_hi[h]) atomicMax(&s_hi[h], rend);
+                if (lstart < sh.lo[h]) atomicMin(&sh.lo[h], lstart);
+                if (rend > sh.hi[h]) atomicMax(&sh.hi[h], rend);
                 return;
             }
             h = (h + 1) & (KC_SLOTS - 1);
@@ -1465,13 +1458,12 @@ __global__ __launch_bounds__(K1E_T) __attribute__((amdgpu_waves_per_eu(K1E_WAVES
         E.cand[at] = k;
         E.cand_anc[at] = (u64)(u32)lstart | ((u64)(u32)rend << 32);
         cand_mark(k);
-    };
-    // appends the wavefront's reads of one kind to k4b_generic's list `kind` (1: the walks, 2: window check): one returning
-    // atomic per wavefront; sub-list by 256-entry chunk (gen_list_cap)
-    auto list_append = [&](u32 kind, bool mine, u32 pairs, u64 entry, u32 chunk) {
+    }
+    // appends the wavefront's entries to list `kind` (1: reads for k4b_generic's walks, 2: for its window check, 3: reads for
+    // k1_generic): one returning atomic per wavefront; sub-list `shard` (callers deal 256-entry chunks round-robin: gen_list_cap)
+    __device__ __forceinline__ void list_append(u32 kind, bool mine, u32 pairs, u64 entry, u32 shard) const {
         const u64 gm2 = __ballot(mine);
         if (!gm2) return;
-        const u32 shard = (chunk >> (8 - K1E_SHIFT)) % GEN_SHARDS;
         const u32 pairs_w = wave_total<DppAdd>(mine ? pairs : 0u);
         const int leader = __ffsll((long long)gm2) - 1;
         const u32 w0 = shard * GEN_CNT_STRIDE + (kind - 1) * 2;
@@ -1483,22 +1475,75 @@ __global__ __launch_bounds__(K1E_T) __attribute__((amdgpu_waves_per_eu(K1E_WAVES
         base = (u32)__builtin_amdgcn_readlane((int)base, leader);
         const u32 at = base + (u32)__popcll(gm2 & ((1ull << lane_id()) - 1));
         if (mine && at < E.gen_cap) E.gen_list[((size_t)(kind - 1) * GEN_SHARDS + shard) * E.gen_cap + at] = entry;
-    };
+    }
+    // candidate keys: the set is flushed when it fills up, and before the block leaves (every thread of the block calls)
+    __device__ __forceinline__ void cand_flush(bool force) const {
+        if (!want_cand) return;
+        __syncthreads();
+        if (sh.set_n > (u32)KC_SLOTS / 4 || force) {
+            u64 mine[KC_SLOTS / K1E_T], anc[KC_SLOTS / K1E_T];
+            u32 cnt = 0;
+#pragma unroll
+            for (int i = 0; i < KC_SLOTS / K1E_T; i++) {
+                const int at = i * K1E_T + threadIdx.x;
+                mine[i] = sh.set[at];
+                anc[i] = (u64)(u32)sh.lo[at] | ((u64)(u32)sh.hi[at] << 32);
+                cnt += mine[i] != KD_EMPTY;
+                sh.set[at] = KD_EMPTY;
+                sh.lo[at] = INT32_MAX;
+                sh.hi[at] = INT32_MIN;
+            }
+            u32 total;
+            const u32 excl = block_escan<K1E_T / 64>(cnt, sh.scan, &total);
+            if (threadIdx.x == 0) {
+                sh.base = total ? atomicAdd(&cs->n_cand, total) : 0u;
+                sh.set_n = 0;
+            }
+            __syncthreads();
+            u32 o = sh.base + excl;
+#pragma unroll
+            for (int i = 0; i < KC_SLOTS / K1E_T; i++)
+                if (mine[i] != KD_EMPTY) {
+                    E.cand[o] = mine[i];
+                    E.cand_anc[o++] = anc[i];
+                    cand_mark(mine[i]);
+                }
+        }
+    }
+};
+
+__global__ __launch_bounds__(K1E_T) __attribute__((amdgpu_waves_per_eu(K1E_WAVES, K1E_WAVES))) void k1_emit(DevBatch b, u32 n_tiles_batch, u32 n_tiles_total, const u32 *tile_off, const u32 *tile_soff,
+                                                const u32 *chunk_tile, const u32 *spl_idx, const u32 *spl_poff, const uint4 *spl_rec, Pairs P, EmitLists E, KeyFmt kf,
+                                                int32_t ref_len, int32_t tid, int orientation, u64 *err, ContigStats *cs, int32_t voff,
+                                                const u32 *gcodes) {
+    __shared__ u32 s_soff[K1E_LOOK];
+    __shared__ EmitShared sh;
+    if (cs->P == 0) return; // no pairs, or a limit was exceeded: the contig is repeated with larger buffers
+    const u32 s_begin = tile_soff[b.tile_base], s_end = tile_soff[b.tile_base + n_tiles_batch];
+    if (s_begin == s_end) return;
+    const u32 c_lo = s_begin >> K1E_SHIFT, c_hi = (s_end + (u32)K1E_T - 1u) >> K1E_SHIFT; // trips of K1E_T list entries
+    const bool want_cand = E.cand != nullptr;
+    const int32_t vlen = voff + ref_len; // the target's end in the group's virtual sequence
+    const u32 seq_words = b.seq_off[b.n]; // words of packed bases in the batch: no compare reads past them
+    const u32 cig_words = b.cig_off[b.n]; // operations in the batch
+    EmitCtx ctx{sh, E, kf, cs, want_cand};
+    ctx.init();
+    auto cand_insert = [&](u64 k, int32_t lstart, int32_t rend) { ctx.cand_insert(k, lstart, rend); };
     for (u32 chunk = c_lo + blockIdx.x; chunk < c_hi; chunk += gridDim.x) {
         // the tile of the chunk's first entry (for the batch's first chunk: of the batch's first entry)
         u32 t0 = (chunk << K1E_SHIFT) < s_begin ? b.tile_base : chunk_tile[chunk >> (8 - K1E_SHIFT)]; // (chunk_tile: the tile of entry 256 c)
         __syncthreads();
         if (threadIdx.x < K1E_LOOK) s_soff[threadIdx.x] = t0 + threadIdx.x <= n_tiles_total ? tile_soff[t0 + threadIdx.x] : 0xffffffffu;
-        if (threadIdx.x == 0) s_gq_n = 0;
         __syncthreads();
         const u32 s = (chunk << K1E_SHIFT) + threadIdx.x;
         const bool on = s >= s_begin && s < s_end;
-        // ---- phase 1: every read's fixed-width fields and first operations; a read of the shape [S] M N M [S] (l_qseq matching, bases
-        // present) is finished here, in closed form: one pair, no walk (junction_system.cc:140-210 for one N operation)
+        // Every read's list record, five gathers and first operations.  A read of the shape [S] M N M [S] or [S] M N M N M [S]
+        // (l_qseq matching, bases present) is finished here, in closed form (junction_system.cc:140-210 for one or two N
+        // operations); any other read goes on k1_generic's list: a few lanes of every wavefront walking their reads kept the
+        // whole block waiting (84 of 307 us a launch for one read in twenty).
         bool generic = false;
         bool p1_two = false; // a read of two introns finished in closed form: k4b_generic checks the junctions' windows (second list)
-        u64 p1_entry = 0;
-        u32 q_n = 0, q_pos = 0, q_g = 0, q_meta = 0, q_lq = 0, q_off = 0, q_c0 = 0, q_so = 0;
+        u64 p1_entry = 0, g3_entry = 0;
         if (on) {
             u32 k = 0; // (the offsets ascend: the entry's tile is the number of them it has reached -- 15 independent LDS reads, not a walk)
 #pragma unroll
@@ -1536,8 +1581,6 @@ __global__ __launch_bounds__(K1E_T) __attribute__((amdgpu_waves_per_eu(K1E_WAVES
                     op[q] = has ? v : 0u;
                 }
             }
-#pragma unroll
-            for (int q = 0; q < OPS_LDS; q++) s_ops[q][threadIdx.x] = op[q];
             const int32_t pos = (int32_t)sr.y;
             const u32 g = b.base + (u32)r;
             const u32 off = toff + spl_poff[slot];
@@ -1627,60 +1670,86 @@ __global__ __launch_bounds__(K1E_T) __attribute__((amdgpu_waves_per_eu(K1E_WAVES
                 p1_entry = (u64)(E.pack_nn ? g | (2u << 28) : g) | ((u64)off << 32);
             } else {
                 generic = true;
-                q_n = n;
-                q_pos = (u32)pos;
-                q_g = g;
-                q_meta = meta | ((u32)threadIdx.x << 16) | (seq_ok ? 0x80000000u : 0u); // (bits 0-8: predicates; 16-23: the thread that holds the operations; 31: bases present)
-                q_lq = (u32)lq;
-                q_off = off;
-                q_c0 = c0;
-                q_so = so;
+                g3_entry = (u64)(u32)slot | ((u64)off << 32); // (the read's place in the tiles' lists, its first pair)
             }
         }
-        list_append(2, p1_two, 2u, p1_entry, chunk);
-        // ---- the other reads are compacted (LDS) ...
-        {
-            const u64 gm = __ballot(generic);
-            if (gm) {
-                const int leader = __ffsll((long long)gm) - 1;
-                u32 base = 0;
-                if (lane_id() == leader) base = atomicAdd(&s_gq_n, (u32)__popcll(gm));
-                base = (u32)__builtin_amdgcn_readlane((int)base, leader);
-                if (generic) {
-                    const u32 at = base + (u32)__popcll(gm & ((1ull << lane_id()) - 1));
-                    s_gq[GQ_N][at] = q_n;
-                    s_gq[GQ_POS][at] = q_pos;
-                    s_gq[GQ_G][at] = q_g;
-                    s_gq[GQ_META][at] = q_meta;
-                    s_gq[GQ_LQ][at] = q_lq;
-                    s_gq[GQ_OFF][at] = q_off;
-                    s_gq[GQ_C0][at] = q_c0;
-                    s_gq[GQ_SO][at] = q_so;
-                }
-            }
-        }
+        const u32 shard = (chunk >> (8 - K1E_SHIFT)) % GEN_SHARDS;
+        ctx.list_append(2, p1_two, 2u, p1_entry, shard);
+        ctx.list_append(3, generic, 0u, g3_entry, shard);
+        ctx.cand_flush(chunk + gridDim.x >= c_hi);
+    }
+}
+
+// The reads k1_emit did not finish (three and more introns, indels, = X P H operations, clamped ends, exotic targets, SEQ '*'):
+// a thread per read of the chain's third list, dense.  The read's operations are walked (emit_read_pairs): keys and records
+// of its pairs, candidates, and -- for [S] B (N B)+ [S] -- the blocks' compares; then the read goes on one of k4b_generic's
+// lists.  One launch per chain, behind the chain's k1_emit launches.
+__device__ __forceinline__ const DevBatch &find_batch_by_tile(const DevBatch *batches, int n_batches, u32 tile) {
+    int lo = 0, hi = n_batches - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (batches[mid].tile_base <= tile) lo = mid;
+        else hi = mid - 1;
+    }
+    return batches[lo];
+}
+__global__ __launch_bounds__(K1E_T) void k1_generic(const DevBatch *batches, int n_batches, const u32 *spl_idx, const uint4 *spl_rec, Pairs P, EmitLists E, KeyFmt kf,
+                                                    GroupTab G, int use_codes, int orientation, u64 *err, ContigStats *cs) {
+    __shared__ EmitShared sh;
+    __shared__ u32 s_ops[OPS_LDS][K1E_T];
+    __shared__ u32 s_first[GEN_SHARDS + 1];
+    __shared__ u32 s_wsum[4];
+    if (cs->P == 0) return;
+    const bool want_cand = E.cand != nullptr;
+    EmitCtx ctx{sh, E, kf, cs, want_cand};
+    ctx.init();
+    static_assert(GEN_SHARDS == K1E_T, "a sub-list per thread");
+    {
+        const u32 c = E.gen_cnt[threadIdx.x * GEN_CNT_STRIDE + 4];
+        u32 total;
+        const u32 ex = block_escan<K1E_T / 64>(c < E.gen_cap ? c : E.gen_cap, s_wsum, &total);
+        s_first[threadIdx.x] = ex;
+        if (threadIdx.x == K1E_T - 1) s_first[GEN_SHARDS] = total;
         __syncthreads();
-        // ---- ... and walked by the block's first threads (phase 2): a read in five takes this path, and lanes that sat between
-        // the other four would have kept every wavefront in the walk's loops for nothing.  Each of these reads goes on
-        // k4b_generic's list.
-        const u32 n_gen = s_gq_n;
-        const bool gen = threadIdx.x < n_gen;
+    }
+    const u32 n_items = s_first[GEN_SHARDS];
+    for (u32 item0 = blockIdx.x * K1E_T; item0 < n_items; item0 += gridDim.x * K1E_T) {
+        const u32 item = item0 + threadIdx.x;
         u32 gen_pairs = 0, gen_kind = 0;
         u64 gen_entry = 0;
-        if (gen) {
-            const u32 at = threadIdx.x;
-            const u32 qm = s_gq[GQ_META][at];
+        if (item < n_items) {
+            u32 sub = 0; // the last sub-list with s_first[sub] <= item
+#pragma unroll
+            for (u32 step = GEN_SHARDS / 2; step > 0; step >>= 1)
+                if (sub + step < GEN_SHARDS && s_first[sub + step] <= item) sub += step;
+            const u64 e3 = E.gen_list[((size_t)2 * GEN_SHARDS + sub) * E.gen_cap + (item - s_first[sub])];
+            const u32 slot = (u32)e3;
+            const DevBatch &b = find_batch_by_tile(batches, n_batches, slot / (u32)K1_TILE);
+            const u32 r = spl_idx[slot];
+            const uint4 sr = spl_rec[slot];
+            const int m = b.member;
+            const int32_t voff = G.voff[m], ref_len = G.len[m], vlen = voff + ref_len;
+            const u32 *gcodes = use_codes ? G.codes[m] : (const u32 *)nullptr;
             EmitRead R;
-            R.n = s_gq[GQ_N][at];
-            R.pos = (int32_t)s_gq[GQ_POS][at] + voff;
-            R.g = s_gq[GQ_G][at];
-            R.meta = qm & 0xffffu;
-            R.lq = (int32_t)s_gq[GQ_LQ][at];
-            R.seq_ok = (qm & 0x80000000u) != 0;
-            R.off = s_gq[GQ_OFF][at];
+            R.n = sr.w & 0x7fffu;
+            if (R.n == 0x7fffu) R.n = gload(b.cig_off + r + 1) - sr.x;
+            R.lq = (int32_t)(sr.w >> 16);
+            if (R.lq == 0xffff) R.lq = gload(b.l_qseq + r);
+            const int32_t pos = (int32_t)sr.y;
+            R.pos = pos + voff;
+            R.g = b.base + r;
+            R.meta = read_meta(gload(b.flag + r), (u32)gload(b.xs + r), gload(b.mapq + r), pos, gload(b.mtid + r), gload(b.mpos + r), G.tid[m], orientation);
+            R.seq_ok = (sr.w & 0x8000u) != 0;
+            R.off = (u32)(e3 >> 32);
             OpsViewT<K1E_T, OPS_LDS> cig;
-            cig.g = b.cigar + s_gq[GQ_C0][at];
-            cig.lds = &s_ops[0][(qm >> 16) & 0xffu];
+            cig.g = b.cigar + sr.x;
+            cig.lds = &s_ops[0][threadIdx.x];
+#pragma unroll
+            for (int q = 0; q < OPS_LDS; q++) { // (unconditional loads, masked: see k1_count)
+                const bool has = (u32)q < R.n;
+                const u32 v = gload(has ? cig.g + q : b.cig_off);
+                s_ops[q][threadIdx.x] = has ? v : 0u;
+            }
             // operations counted, and the shape [S] B (N B)+ [S] recognised, B = M = X I D operations that begin and end with bases on
             // both sides: state 0 at the first operation, 5 after a leading S, 1 after M = X, 6 after I or D, 2 after an N, 3 after the
             // closing S, 4 any other shape
@@ -1707,53 +1776,21 @@ __global__ __launch_bounds__(K1E_T) __attribute__((amdgpu_waves_per_eu(K1E_WAVES
             // (nothing clamped: the alignment lies inside its target -- junction_system.cc:169-174)
             const bool closed = gcodes != nullptr && (shape == 1 || shape == 3) && nN > 0 && R.seq_ok && R.lq > 1 && qsum == (int64_t)R.lq &&
                                 R.pos >= voff && R.aend < vlen;
-            R.closed_seqw = closed ? reinterpret_cast<const u32 *>(b.seq4) + s_gq[GQ_SO][at] : nullptr;
-            R.q_limit = (int32_t)min(seq_words - 1u - s_gq[GQ_SO][at], 0x7fffffffu);
+            R.closed_seqw = closed ? reinterpret_cast<const u32 *>(b.seq4) + sr.z : nullptr;
+            R.q_limit = (int32_t)min(gload(b.seq_off + b.n) - 1u - sr.z, 0x7fffffffu);
             R.gcodes = gcodes;
             R.glen = ref_len;
             R.voff = voff;
-            emit_read_pairs(cig, R, P, kf, vlen, err, [&](u64 key, int32_t lstart, int32_t rend) { if (want_cand) cand_insert(key, lstart, rend); });
+            emit_read_pairs(cig, R, P, kf, vlen, err, [&](u64 key, int32_t lstart, int32_t rend) { ctx.cand_insert(key, lstart, rend); });
             gen_pairs = nN;
             gen_kind = closed ? 2u : 1u;
             gen_entry = (u64)(closed && E.pack_nn ? R.g | ((nN < 15u ? nN : 15u) << 28) : R.g) | ((u64)R.off << 32);
         }
         // the read goes on k4b_generic's first list (the walks) or on its second (closed form done, window to be checked)
-        list_append(1, gen_kind == 1, gen_pairs, gen_entry, chunk);
-        list_append(2, gen_kind == 2, gen_pairs, gen_entry, chunk);
-        // ---- candidate keys: flush the set when it fills up, and before the block leaves
-        if (want_cand) {
-            __syncthreads();
-            const bool last = chunk + gridDim.x >= c_hi;
-            if (s_set_n > (u32)KC_SLOTS / 4 || last) {
-                u64 mine[KC_SLOTS / K1E_T], anc[KC_SLOTS / K1E_T];
-                u32 cnt = 0;
-#pragma unroll
-                for (int i = 0; i < KC_SLOTS / K1E_T; i++) {
-                    const int at = i * K1E_T + threadIdx.x;
-                    mine[i] = s_set[at];
-                    anc[i] = (u64)(u32)s_lo[at] | ((u64)(u32)s_hi[at] << 32);
-                    cnt += mine[i] != KD_EMPTY;
-                    s_set[at] = KD_EMPTY;
-                    s_lo[at] = INT32_MAX;
-                    s_hi[at] = INT32_MIN;
-                }
-                u32 total;
-                const u32 excl = block_escan<K1E_T / 64>(cnt, s_scan, &total);
-                if (threadIdx.x == 0) {
-                    s_base = total ? atomicAdd(&cs->n_cand, total) : 0u;
-                    s_set_n = 0;
-                }
-                __syncthreads();
-                u32 o = s_base + excl;
-#pragma unroll
-                for (int i = 0; i < KC_SLOTS / K1E_T; i++)
-                    if (mine[i] != KD_EMPTY) {
-                        E.cand[o] = mine[i];
-                        E.cand_anc[o++] = anc[i];
-                        cand_mark(mine[i]);
-                    }
-            }
-        }
+        const u32 shard = (item0 >> K1E_SHIFT) % GEN_SHARDS;
+        ctx.list_append(1, gen_kind == 1, gen_pairs, gen_entry, shard);
+        ctx.list_append(2, gen_kind == 2, gen_pairs, gen_entry, shard);
+        ctx.cand_flush(item0 + gridDim.x * K1E_T >= n_items);
     }
 }
 
@@ -3308,6 +3345,7 @@ __device__ __forceinline__ void publish_chain(const ContigStats *cs, u64 *err, u
         reinterpret_cast<u32 *>(host + PUB_GEN_AT)[t] = gen_cnt[t * GEN_CNT_STRIDE + 1];
         reinterpret_cast<u32 *>(host + PUB_GREADS_AT)[t] = gen_cnt[t * GEN_CNT_STRIDE];
         reinterpret_cast<uint4 *>(gen_cnt + t * GEN_CNT_STRIDE)[0] = make_uint4(0, 0, 0, 0);
+        reinterpret_cast<uint4 *>(gen_cnt + t * GEN_CNT_STRIDE)[1] = make_uint4(0, 0, 0, 0); // (the third list's)
     }
     if (t == 0) {
         *reinterpret_cast<u64 *>(host + PUB_ERR_AT) = *err;
