@@ -1403,9 +1403,12 @@ struct EmitLists {
     u32 gen_cap;    // room of one sub-list
     u32 pack_nn;    // 1 (chains of fewer than 2^28 reads): entries of the second list carry min(N operations, 15) in bits 28-31 of the read ordinal
 };
-__host__ __device__ inline u32 gen_list_cap(u32 pair_limit) { // chunks of 256 spliced reads dealt round-robin to the sub-lists
+// Room of a sub-list.  k1_emit deals its chunks of 256 spliced reads round-robin to the sub-lists (up to 256 entries a chunk on list
+// 2 and on list 3); k1_generic does the same with its chunks of 256 items of list 3 (up to 256 entries a chunk on list 1 or 2),
+// and it has at most as many chunks as k1_emit: a sub-list of lists 1 and 2 may receive 512 entries per round.
+__host__ __device__ inline u32 gen_list_cap(u32 pair_limit) {
     const u32 chunks = pair_limit / 256u + 2u;
-    return ((chunks + GEN_SHARDS - 1) / GEN_SHARDS) * 256u;
+    return ((chunks + GEN_SHARDS - 1) / GEN_SHARDS) * 512u;
 }
 // What k1_emit and k1_generic share: the block's candidate set (LDS) and the appends to k4b_generic's / k1_generic's lists.
 struct EmitShared {
