@@ -1709,6 +1709,7 @@ __global__ __launch_bounds__(K1E_T) void k1_generic(const DevBatch *batches, int
     static_assert(GEN_SHARDS == K1E_T, "a sub-list per thread");
     {
         const u32 c = E.gen_cnt[threadIdx.x * GEN_CNT_STRIDE + 4];
+        if (c > E.gen_cap) set_error(err, 0xfffffe01u, PJB_ERR_HIP); // (a sub-list overflowed: gen_list_cap is wrong -- entries were dropped)
         u32 total;
         const u32 ex = block_escan<K1E_T / 64>(c < E.gen_cap ? c : E.gen_cap, s_wsum, &total);
         s_first[threadIdx.x] = ex;
@@ -2711,6 +2712,7 @@ __global__ __launch_bounds__(256) void k4b_generic(const u64 *list, const u32 *g
         const u32 i0 = threadIdx.x * 2;
         const u32 c0 = gen_cnt[(i0 % GEN_SHARDS) * GEN_CNT_STRIDE + (i0 / GEN_SHARDS) * 2];
         const u32 c1 = gen_cnt[((i0 + 1) % GEN_SHARDS) * GEN_CNT_STRIDE + ((i0 + 1) / GEN_SHARDS) * 2];
+        if (c0 > cap || c1 > cap) set_error(err, 0xfffffe00u, PJB_ERR_HIP); // (a sub-list overflowed: gen_list_cap is wrong -- entries were dropped)
         const u32 n0 = c0 < cap ? c0 : cap, n1 = c1 < cap ? c1 : cap;
         u32 total;
         const u32 ex = block_escan<4>(n0 + n1, s_wsum, &total);
