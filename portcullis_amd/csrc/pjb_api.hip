@@ -133,6 +133,7 @@ struct XArena {
 // limits a contig is queued with (the kernels check them; see pjb_finish_contig_end)
 struct ContigLimits {
     u32 pair_limit = 0, junc_limit = 0;
+    u32 list_cap = 0; // room of a sub-list of the read lists (0: gen_list_cap(pair_limit))
     KeyFmt kf;
     bool dense = false; // sort ordered dense junction ids (K2d) instead of the full keys
 };
@@ -1494,7 +1495,7 @@ static int queue_contig(pjb_ctx *c, Flight &f) {
     if ((rc = ensure(c, S.runstart, ((size_t)PL + 1) * 4))) return rc;
     if ((rc = ensure(c, S.ent, (size_t)PL * 8 + 16))) return rc;
     const u32 pair_blocks = std::max<u32>(1, (PL + 255) / 256);
-    const u32 gen_cap = gen_list_cap(PL); // entries per sub-list
+    const u32 gen_cap = std::max(gen_list_cap(PL), lim.list_cap); // entries per sub-list
     const u32 pack_nn = (u64)f.n_reads < (1ull << 28) ? 1u : 0u; // (EmitLists::pack_nn)
     if ((rc = ensure(c, S.genlist, (size_t)gen_cap * GEN_SHARDS * 8 * 3))) return rc; // (three lists: EmitLists)
     if ((rc = ensure(c, S.gencount, GEN_SHARDS * GEN_CNT_STRIDE * 4))) return rc; // a line per sub-list: reads, pairs
@@ -1701,7 +1702,8 @@ static int queue_contig(pjb_ctx *c, Flight &f) {
                            (u64)JL, (u64 *)S.total.p)))
             return rc;
         LAUNCH(c, "kd_table", kd_table, dim3(cand_blocks), dim3(256), (const u64 *)cand, (const u64 *)S.ent.p, (const u32 *)cand_rank, kf, JL,
-               (const u32 *)S.ends.p, (const u32 *)S.firstid.p, (const u64 *)S.total.p, (u64 *)S.jkey.p, (int32_t *)S.ancl.p, (int32_t *)S.ancr.p, d_cs);
+               (const u32 *)S.ends.p, (const u32 *)S.firstid.p, (const u64 *)S.total.p, (u64 *)S.jkey.p, (int32_t *)S.ancl.p, (int32_t *)S.ancr.p, d_cs,
+               (const u32 *)d_gen_cnt, gen_cap);
         LAUNCH(c, "kd_assign", kd_assign, dim3(pair_blocks), dim3(256), okey, d_P, kf, (const u64 *)S.bitmap.p, (const u32 *)S.wrank.p,
                (const u32 *)S.ends.p, (const u32 *)S.firstid.p, JL, (const u64 *)S.total.p, (u32 *)S.jidbam.p, (u32 *)S.acc.p, (const u64 *)S.jkey.p,
                (const int32_t *)S.ancl.p, (const int32_t *)S.ancr.p, d_err, d_cs);
@@ -1847,7 +1849,7 @@ static int queue_contig(pjb_ctx *c, Flight &f) {
         HeadSink hs{(u32 *)S.jid.p, (u32 *)S.seg.p, (u32 *)S.runfirst.p, (u32 *)S.runstart.p, skey, (u64 *)S.jkey.p, JL};
         if ((rc = run_scan(c, "k2_heads", hf, hs, (u64)PL, (u64 *)S.total.p, d_P))) return rc;
         LAUNCH(c, "k2_close", k2_close, dim3(1), dim3(1), (u64 *)S.total.p, (u32 *)S.seg.p, (u32 *)S.runfirst.p,
-               (u32 *)S.runstart.p, d_cs, JL);
+               (u32 *)S.runstart.p, d_cs, JL, (const u32 *)d_gen_cnt, gen_cap);
         STAGE_EVENT(3);
         if ((rc = fork_entropy())) return rc;
         LAUNCH(c, "kf_init", kf_init, dim3(std::max<u32>(1, std::min<u32>((JL * F_WORDS + 255) / 256, 4096))), dim3(256), (u32 *)S.acc.p, d_J, (int32_t *)S.ancl.p,
@@ -2146,6 +2148,7 @@ static int collect_flight(pjb_ctx *c, pjb_region_result *res, bool *redo_single)
         }
         if (cs.overflow & OVF_JUNC) lim.junc_limit = std::max<u32>(cs.n_junc + 64, (cs.overflow & OVF_DENSE) || !lim.dense ? 0u : lim.junc_limit * 4);
         if (cs.overflow & OVF_DENSE) lim.dense = false; // a donor with more alternative acceptors than K2d keeps: sort the full keys
+        if (cs.overflow & OVF_LISTS) lim.list_cap = (cs.list_need + cs.list_need / 4 + 511u) & ~255u; // (k1_generic's entries depend on the appends' order: some slack)
     }
     if (!lim.kf.raw) c->lbits_seen = std::max(c->lbits_seen, std::max(1, bits_of((uint64_t)cs.max_nlen)));
     const u32 P = cs.P, J = cs.J;

@@ -65,7 +65,7 @@ struct TileStats { // per K1 tile
 // runs (pairs, junctions, key format); the kernels read the actual counts from here, and a count that exceeds its limit
 // raises an overflow bit and zeroes the count so that everything downstream does nothing.  pjb_finish_contig reads the
 // block back once, at the end, and repeats the contig with larger limits if a bit is set.
-enum : u32 { OVF_PAIRS = 1u, OVF_KEYFMT = 2u, OVF_JUNC = 4u, OVF_DENSE = 8u };
+enum : u32 { OVF_PAIRS = 1u, OVF_KEYFMT = 2u, OVF_JUNC = 4u, OVF_DENSE = 8u, OVF_LISTS = 16u };
 struct ContigStats {
     u64 spliced, unspliced, sum_len;
     int32_t min_len, max_len;
@@ -80,7 +80,7 @@ struct ContigStats {
     u32 overflow;  // OVF_*
     u32 n_cand;    // K2d: keys in the candidate list (every junction at least once, few of them more often)
     u32 n_slices;  // ceil(P / 64): 64-pair slices of the sorted pair array (fragments, run masks)
-    u32 _pad;
+    u32 list_need; // OVF_LISTS: the fullest sub-list of the read lists (EmitLists) wanted this many entries
 };
 
 // A pair = one N operation walked (JunctionSystem::addJunctions, junction_system.cc:140-210).  k1_emit writes, in BAM order,
@@ -1039,6 +1039,7 @@ __global__ __launch_bounds__(K1S_THREADS) void k1_scan_tiles(u32 *tile_cnt, cons
         out->P = ovf ? 0u : (u32)n_pairs;
         out->J = out->R = out->n_slots = out->n_slices = 0;
         out->n_junc = out->n_runs = 0;
+        out->list_need = 0;
         out->n_cand = 0;
     }
 }
@@ -1403,12 +1404,19 @@ struct EmitLists {
     u32 gen_cap;    // room of one sub-list
     u32 pack_nn;    // 1 (chains of fewer than 2^28 reads): entries of the second list carry min(N operations, 15) in bits 28-31 of the read ordinal
 };
-// Room of a sub-list.  k1_emit deals its chunks of 256 spliced reads round-robin to the sub-lists (up to 256 entries a chunk on list
-// 2 and on list 3); k1_generic does the same with its chunks of 256 items of list 3 (up to 256 entries a chunk on list 1 or 2),
-// and it has at most as many chunks as k1_emit: a sub-list of lists 1 and 2 may receive 512 entries per round.
+// Room of a sub-list (before anything says otherwise): k1_emit deals its chunks of 256 spliced reads round-robin to the sub-lists
+// (up to 256 entries a chunk on list 2 and on list 3), k1_generic its chunks of 256 items of list 3 (up to 256 entries on list 1
+// or 2).  A sub-list that several full chunks of both kernels hit can want more than this: the appends count on, nothing is
+// written past the room, the chain is closed (OVF_LISTS, ContigStats::list_need) and repeated with the room it asked for.
 __host__ __device__ inline u32 gen_list_cap(u32 pair_limit) {
     const u32 chunks = pair_limit / 256u + 2u;
-    return ((chunks + GEN_SHARDS - 1) / GEN_SHARDS) * 512u;
+    return ((chunks + GEN_SHARDS - 1) / GEN_SHARDS) * 256u;
+}
+// the fullest sub-list of the three lists' sub-lists `shard` (0: all within their room)
+__device__ __forceinline__ u32 lists_over(const u32 *gen_cnt, u32 shard, u32 cap) {
+    const u32 a = gen_cnt[shard * GEN_CNT_STRIDE], b = gen_cnt[shard * GEN_CNT_STRIDE + 2], c = gen_cnt[shard * GEN_CNT_STRIDE + 4];
+    const u32 m = a > b ? (a > c ? a : c) : (b > c ? b : c);
+    return m > cap ? m : 0u;
 }
 // What k1_emit and k1_generic share: the block's candidate set (LDS) and the appends to k4b_generic's / k1_generic's lists.
 struct EmitShared {
@@ -1709,7 +1717,6 @@ __global__ __launch_bounds__(K1E_T) void k1_generic(const DevBatch *batches, int
     static_assert(GEN_SHARDS == K1E_T, "a sub-list per thread");
     {
         const u32 c = E.gen_cnt[threadIdx.x * GEN_CNT_STRIDE + 4];
-        if (c > E.gen_cap) set_error(err, 0xfffffe01u, PJB_ERR_HIP); // (a sub-list overflowed: gen_list_cap is wrong -- entries were dropped)
         u32 total;
         const u32 ex = block_escan<K1E_T / 64>(c < E.gen_cap ? c : E.gen_cap, s_wsum, &total);
         s_first[threadIdx.x] = ex;
@@ -1986,8 +1993,15 @@ __device__ __forceinline__ void anchors_fold(bool valid, u32 j, int32_t l, int32
 // anchors from the candidates' partial ones; thread 0 closes the chain -- P = 0, nothing downstream runs, the host repeats the
 // contig -- if a limit was exceeded while the ids were built
 __global__ __launch_bounds__(256) void kd_table(const u64 *cand, const u64 *cand_anc, const u32 *cand_rank, KeyFmt kf, u32 junc_limit, const u32 *ends,
-                                                const u32 *first_id, const u64 *total, u64 *jkey, int32_t *anc_l, int32_t *anc_r, ContigStats *cs) {
+                                                const u32 *first_id, const u64 *total, u64 *jkey, int32_t *anc_l, int32_t *anc_r, ContigStats *cs,
+                                                const u32 *gen_cnt, u32 gen_cap) {
     const u32 p = blockIdx.x * 256 + threadIdx.x;
+    if (blockIdx.x == 0) { // (the read lists: every sub-list within its room?)
+        static_assert(GEN_SHARDS == 256, "a shard per thread of the first block");
+        const u32 over = lists_over(gen_cnt, threadIdx.x, gen_cap);
+        if (over) atomicMax(&cs->list_need, over);
+        if (__syncthreads_or((int)over) && threadIdx.x == 0) cs->overflow |= OVF_LISTS;
+    }
     if (p == 0) {
         const u64 J = *total;
         u32 ovf = cs->overflow;
@@ -2391,9 +2405,19 @@ struct HeadSink {
         if ((u32)v) run_start[r] = (u32)i;
     }
 };
-__global__ void k2_close(u64 *total, u32 *seg_off, u32 *run_first, u32 *run_start, ContigStats *cs, u32 junc_limit) {
+__global__ void k2_close(u64 *total, u32 *seg_off, u32 *run_first, u32 *run_start, ContigStats *cs, u32 junc_limit, const u32 *gen_cnt, u32 gen_cap) {
     const u32 n_pairs = cs->P;
     if (n_pairs == 0) return;
+    {
+        u32 need = 0;
+        for (u32 sh = 0; sh < GEN_SHARDS; sh++) need = max(need, lists_over(gen_cnt, sh, gen_cap));
+        if (need) { // a read list overflowed: the chain is repeated with more room
+            cs->list_need = need;
+            cs->overflow |= OVF_LISTS;
+            cs->P = 0;
+            return;
+        }
+    }
     const u32 J = (u32)(*total >> 32), R = (u32)*total;
     cs->n_junc = J;
     cs->n_runs = R;
@@ -2712,7 +2736,6 @@ __global__ __launch_bounds__(256) void k4b_generic(const u64 *list, const u32 *g
         const u32 i0 = threadIdx.x * 2;
         const u32 c0 = gen_cnt[(i0 % GEN_SHARDS) * GEN_CNT_STRIDE + (i0 / GEN_SHARDS) * 2];
         const u32 c1 = gen_cnt[((i0 + 1) % GEN_SHARDS) * GEN_CNT_STRIDE + ((i0 + 1) / GEN_SHARDS) * 2];
-        if (c0 > cap || c1 > cap) set_error(err, 0xfffffe00u, PJB_ERR_HIP); // (a sub-list overflowed: gen_list_cap is wrong -- entries were dropped)
         const u32 n0 = c0 < cap ? c0 : cap, n1 = c1 < cap ? c1 : cap;
         u32 total;
         const u32 ex = block_escan<4>(n0 + n1, s_wsum, &total);
