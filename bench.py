@@ -57,7 +57,7 @@ def algorithmic_bytes(name, N, C, S, Cs, P, J, L, Pg=0, Rg=0, R=0, cand=0, Rv=0,
         "k1_emit": S * 36 + Cs * 4 + P * 40 + (P - Pg) * L + Rg * 8 + cand * 8,
         # the reads k1_emit leaves to a walk of their operations (those on k4b_generic's first list and the multi-intron reads beyond
         # two introns, about as many again): list entry (8), list record (16), five gathers (12), operations, bases + codes, the pairs
-        "k1_generic": 2 * Rg * (36 + 4 * ops_s + L) + 2 * Pg * 40,
+        "k1_generic": (Rg + Rv / 2.0) * (36 + 4 * ops_s + L) + (Pg + Rv) * 40,  # (about half of the checked reads come from here)
         # K2d.  kd_assign: the pair's key read (8), its junction id written (4); the accumulators' rest state (192 B per junction)
         "kd_assign": P * 12 + J * 192,
         # candidates: key (8), anchors (8), rank (4); bitmap words / end slots they touch; kd_table writes key + anchors per junction

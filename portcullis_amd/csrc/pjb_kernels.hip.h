@@ -1179,9 +1179,9 @@ __device__ __forceinline__ void ncursor_advance(NCursor &c, const Ops cig, u32 n
 }
 
 #ifndef PJB_CLOSED_INDELS
-#define PJB_CLOSED_INDELS 0 // 1: blocks with I / D operations in closed form too (emit_read_pairs can; measured: the walk list all but
-                            // empties -- k4b_generic 224 -> 136 us a chain -- but k1_emit's second phase, a few lanes per block, pays
-                            // 60 us a launch for it: 9.75 against 9.1 ms a step.  k4b_generic runs beside the sort, k1_emit beside nothing.)
+#define PJB_CLOSED_INDELS 1 // blocks with I / D operations in closed form too (emit_read_pairs): the walk list all but empties -- k4b_generic
+                            // 224 -> 140 us a chain, k1_generic 122 -> 162 -- 8.82 -> 8.64 ms a step.  (While these reads were walked by a few
+                            // lanes of k1_emit's blocks the same switch cost 60 us a k1_emit launch: 9.75 against 9.1 ms.)
 #endif
 #ifndef PJB_SIMPLE_NW
 #define PJB_SIMPLE_NW 8 // two 16-byte loads per stream and round, 56 bases a round (5: one 16-byte load and a word, 32 bases)
