@@ -1620,10 +1620,10 @@ static int queue_contig(pjb_ctx *c, Flight &f) {
             const int32_t own_len = c->ref_len[(size_t)f.tids[(size_t)f.batch_member[bi]]];
             const u32 nt = (u32)((b.n + K1_TILE - 1) / K1_TILE);
             if (xk1)
-                LAUNCH(c, "k1_count", k1_count<true>, dim3(nt), dim3(256), b, (u32 *)S.tile_cnt.p, (TileStats *)S.tile_stats.p, (u32 *)S.splidx.p,
+                LAUNCH(c, "k1_count", k1_count<true>, dim3(nt), dim3(K1C_T), b, (u32 *)S.tile_cnt.p, (TileStats *)S.tile_stats.p, (u32 *)S.splidx.p,
                        (u32 *)S.splpoff.p, (uint4 *)S.splrec.p, d_err, 0, xo);
             else
-                LAUNCH(c, "k1_count", k1_count<false>, dim3(nt), dim3(256), b, (u32 *)S.tile_cnt.p, (TileStats *)S.tile_stats.p, (u32 *)S.splidx.p,
+                LAUNCH(c, "k1_count", k1_count<false>, dim3(nt), dim3(K1C_T), b, (u32 *)S.tile_cnt.p, (TileStats *)S.tile_stats.p, (u32 *)S.splidx.p,
                        (u32 *)S.splpoff.p, (uint4 *)S.splrec.p, d_err, group ? std::max(own_len, 1) : 0, xo);
         }
         if (xk1) {

@@ -594,15 +594,20 @@ struct XOut {
 __device__ __forceinline__ u32 spl_nlq(u32 n, bool seq_ok, int32_t lq) {
     return (n < 0x7fffu ? n : 0x7fffu) | (seq_ok ? 0x8000u : 0u) | ((u32)lq < 0xffffu ? (u32)lq << 16 : 0xffff0000u);
 }
+#ifndef K1C_T
+#define K1C_T 256 // threads of a k1_count block (a tile is K1_TILE reads: 4 per thread).  512 threads x 2 reads need 64 registers instead of
+                  // 84 but took 88 against 63 us a launch beside the other chains' kernels: a block of 8 wavefronts waits for 8 free slots on ONE CU
+#endif
 #ifndef K1C_WAVES
 #define K1C_WAVES 5 // (84 registers as the compiler wants them; forced to 64: 31 spills, 99 against 61 us a launch)
 #endif
 template <bool EXTRA>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(K1C_WAVES, K1C_WAVES))) void k1_count(DevBatch b, u32 *tile_cnt, TileStats *tile_stats, u32 *spl_idx,
+__global__ __launch_bounds__(K1C_T) __attribute__((amdgpu_waves_per_eu(K1C_WAVES, K1C_WAVES))) void k1_count(DevBatch b, u32 *tile_cnt, TileStats *tile_stats, u32 *spl_idx,
                                                  u32 *spl_poff, uint4 *spl_rec, u64 *err, int32_t chk_ref_len, XOut X) {
-    __shared__ u64 sm64[4];
-    __shared__ u64 sm_scan4[4][4];
-    __shared__ int32_t smi[4][6];
+    constexpr int NW = K1C_T / 64, RPT = K1_TILE / K1C_T; // wavefronts of the block; reads per thread
+    __shared__ u64 sm64[NW];
+    __shared__ u64 sm_scan4[RPT][NW];
+    __shared__ int32_t smi[NW][6];
     int64_t base = (int64_t)blockIdx.x * K1_TILE;
     u32 cnt = 0, spl = 0, uns = 0;
     u64 sum = 0;
@@ -610,19 +615,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(K1C_WAVES, 
     // all loads of the thread's 4 reads are issued before anything is consumed: offsets, then the first
     // K1_OPS ops of every CIGAR (longer CIGARs continue from global memory), then the per-read scalars
     constexpr int K1_OPS = 4;
-    u32 c0[4], nop[4], ops[4][K1_OPS];
-    int32_t pos4[4];
-    u32 c4[4], so4[4], nlq4[4]; // (nlq4: spl_nlq -- what the spliced list keeps of operations count, l_qseq and the presence of bases)
+    u32 c0[RPT], nop[RPT], ops[RPT][K1_OPS];
+    int32_t pos4[RPT];
+    u32 c4[RPT], so4[RPT], nlq4[RPT]; // (nlq4: spl_nlq -- what the spliced list keeps of operations count, l_qseq and the presence of bases)
     u32 bad = 0;                // bit it: read `it` lies before its predecessor; bit 4 + it: its XS code is not one
-    u32 xflag4[4] = {0, 0, 0, 0}, xspan = 0, xgapmax = 0; // (EXTRA)
+    u32 xflag4[RPT] = {}, xspan = 0, xgapmax = 0; // (EXTRA)
     bool xmany = false;
     // (Every load below is UNCONDITIONAL -- a lane past the batch's end reads the last record, an operation past a CIGAR's end
     // reads a word that is always there -- and the value is masked afterwards.  Written as `cond ? load : 0` the compiler
     // may not speculate the load, turns it into a branch and waits for each one before issuing the next: the 16 CIGAR loads
     // of a thread were 16 round trips in a row.)
 #pragma unroll
-    for (int it = 0; it < 4; it++) {
-        const int64_t r = base + it * 256 + threadIdx.x;
+    for (int it = 0; it < RPT; it++) {
+        const int64_t r = base + it * K1C_T + threadIdx.x;
         const bool on = r < b.n;
         const int64_t rr = on ? r : b.n - 1, rp = rr > 0 ? rr - 1 : 0;
         const u32 c0v = b.cig_off[rr], c1v = b.cig_off[rr + 1];
@@ -651,7 +656,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(K1C_WAVES, 
     // (one 16-byte load per read instead of four words was measured: 55 against 52 us a launch -- consecutive reads' operations
     // are neighbours, the word loads coalesce)
 #pragma unroll
-    for (int it = 0; it < 4; it++)
+    for (int it = 0; it < RPT; it++)
 #pragma unroll
         for (int k = 0; k < K1_OPS; k++) {
             const bool has = (u32)k < nop[it];
@@ -659,8 +664,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(K1C_WAVES, 
             ops[it][k] = has ? v : 0u;
         }
 #pragma unroll
-    for (int it = 0; it < 4; it++) {
-        const int64_t r = base + it * 256 + threadIdx.x;
+    for (int it = 0; it < RPT; it++) {
+        const int64_t r = base + it * K1C_T + threadIdx.x;
         u32 cthis = 0;
         if (r < b.n) {
             const int32_t p = pos4[it];
@@ -725,20 +730,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(K1C_WAVES, 
     // (batch-local index) and the tile-local offset of its first pair.  Read order is round-major
     // (r = base + it * 256 + thread): one wave scan per round, one barrier for all four.
     {
-        u64 inc[4];
+        u64 inc[RPT];
         const int w = threadIdx.x >> 6;
 #pragma unroll
-        for (int it = 0; it < 4; it++) {
+        for (int it = 0; it < RPT; it++) {
             inc[it] = wave_iscan<u64>(((u64)c4[it] << 16) | (u64)(c4[it] ? 1u : 0u));
             if (lane_id() == 63) sm_scan4[it][w] = inc[it];
         }
         __syncthreads();
         u64 run = 0; // (pairs << 16 | spliced reads) of everything before, in read order
 #pragma unroll
-        for (int it = 0; it < 4; it++) {
+        for (int it = 0; it < RPT; it++) {
             u64 before = run;
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
+            for (int i = 0; i < NW; i++) {
                 const u64 t = sm_scan4[it][i];
                 if (i < w) before += t;
                 run += t;
@@ -746,7 +751,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(K1C_WAVES, 
             if (c4[it]) {
                 const u64 ex = before + inc[it] - (((u64)c4[it] << 16) | 1u);
                 const size_t slot = (size_t)(b.tile_base + blockIdx.x) * K1_TILE + (u32)(ex & 0xffffu);
-                spl_idx[slot] = (u32)(base + it * 256 + threadIdx.x);
+                spl_idx[slot] = (u32)(base + it * K1C_T + threadIdx.x);
                 spl_poff[slot] = (u32)(ex >> 16);
                 spl_rec[slot] = make_uint4(c0[it], (u32)pos4[it], so4[it], nlq4[it]);
             }
@@ -766,7 +771,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(K1C_WAVES, 
     max_nlen = smax(max_nlen);
     min_pos = smin(min_pos);
     int w = threadIdx.x >> 6;
-    __shared__ u64 smp[4];
+    __shared__ u64 smp[NW];
     if (lane_id() == 0) {
         smp[w] = packed;
         sm64[w] = sum;
@@ -778,16 +783,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(K1C_WAVES, 
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        u64 p = smp[0] + smp[1] + smp[2] + smp[3];
+        u64 p = 0;
         TileStats t;
+        t.sum_len = 0;
+        t.min_len = INT32_MAX, t.max_len = 0, t.max_end = 0, t.max_nlen = 0, t.min_pos = INT32_MAX;
+        for (int i = 0; i < NW; i++) {
+            p += smp[i];
+            t.sum_len += sm64[i];
+            t.min_len = min(t.min_len, smi[i][0]);
+            t.max_len = max(t.max_len, smi[i][1]);
+            t.max_end = max(t.max_end, smi[i][2]);
+            t.max_nlen = max(t.max_nlen, smi[i][3]);
+            t.min_pos = min(t.min_pos, smi[i][4]);
+        }
         t.spliced = (u32)((p >> 16) & 0xffff);
         t.unspliced = (u32)(p & 0xffff);
-        t.sum_len = sm64[0] + sm64[1] + sm64[2] + sm64[3];
-        t.min_len = min(min(smi[0][0], smi[1][0]), min(smi[2][0], smi[3][0]));
-        t.max_len = max(max(smi[0][1], smi[1][1]), max(smi[2][1], smi[3][1]));
-        t.max_end = max(max(smi[0][2], smi[1][2]), max(smi[2][2], smi[3][2]));
-        t.max_nlen = max(max(smi[0][3], smi[1][3]), max(smi[2][3], smi[3][3]));
-        t.min_pos = min(min(smi[0][4], smi[1][4]), min(smi[2][4], smi[3][4]));
         if (chk_ref_len > 0 && t.max_end > chk_ref_len) t.max_end = INT32_MAX;
         t._pad = 0;
         tile_stats[b.tile_base + blockIdx.x] = t;
