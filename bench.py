@@ -157,6 +157,7 @@ def main():
     args = ap.parse_args()
     if args.config == "c5":
         args.reads, args.junctions, args.no_e2e = 1_000_000_000, 300_000, True
+        args.queue = min(args.queue, 2)  # (a 335 M-read chain's scratch is ~45 GB: two of the three chains in flight beside the 73 GB of records)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         spawn_ranks(args.gpus)
 
