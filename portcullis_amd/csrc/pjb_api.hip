@@ -1659,7 +1659,7 @@ static int queue_contig(pjb_ctx *c, Flight &f) {
                    own_tid, (int)c->cfg.orientation, d_err, d_cs, f.voff[(size_t)m], fast_codes ? (const u32 *)GT.codes[m] : (const u32 *)nullptr);
         }
         // the reads k1_emit left: one launch over the chain's third list (the blocks stride over it)
-        LAUNCH(c, "k1_generic", k1_generic, dim3(std::min<u32>(std::max<u32>(1, (u32)(((u64)gen_cap * GEN_SHARDS + K1E_T - 1) / K1E_T)), 1536u)), dim3(K1E_T),
+        LAUNCH(c, "k1_generic", k1_generic, dim3(std::min<u32>(std::max<u32>(1, (u32)(((u64)gen_cap * GEN_SHARDS + K1E_T - 1) / K1E_T)), 1536u /* six blocks a CU; 512 .. 3072 measured: no difference */)), dim3(K1E_T),
                (const DevBatch *)S.batches.p, (int)batches.size(), (const u32 *)S.splidx.p, (const uint4 *)S.splrec.p, pr, el, kf, GT, fast_codes ? 1 : 0,
                (int)c->cfg.orientation, d_err, d_cs);
     }
