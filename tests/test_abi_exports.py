@@ -30,6 +30,23 @@ def test_struct_sizes():
     assert ctypes.sizeof(ffi.PjbConfig) == 20
 
 
+def test_struct_sizes_match_the_header_compiled(tmp_path):
+    """sizeof of every struct the stub mirrors, as gcc sees it in include/portcullis_amd.h (pjb_timing grew in ABI 3)."""
+    import subprocess
+    from portcullis_amd import ffi
+
+    src = tmp_path / "sz.c"
+    src.write_text('#include <stdio.h>\n#include "portcullis_amd.h"\nint main(void) { printf("%zu %zu %zu %zu %zu %d\\n", sizeof(pjb_timing), '
+                   'sizeof(pjb_batch), sizeof(pjb_region_result), sizeof(pjb_config), sizeof(pjb_junction_row), PJB_ABI_VERSION); return 0; }\n')
+    exe = tmp_path / "sz"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), "-o", str(exe), str(src)], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()
+    timing, batch, region, config, row, abi = (int(x) for x in out)
+    assert timing == ctypes.sizeof(ffi.PjbTiming)
+    assert batch == ctypes.sizeof(ffi.PjbBatch) and region == ctypes.sizeof(ffi.PjbRegionResult) and config == ctypes.sizeof(ffi.PjbConfig)
+    assert row == ffi.ROW_DTYPE.itemsize and abi == ffi.ABI_VERSION
+
+
 def test_no_device_is_a_loud_error():
     """Without a GPU pjb_create must fail with PJB_ERR_NO_DEVICE -- there is no CPU fallback."""
     from portcullis_amd import ffi
