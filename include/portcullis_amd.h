@@ -403,7 +403,7 @@ int pjb_bam_begin(pjb_ctx* ctx, int32_t tid, int64_t total_bytes);
 int pjb_bam_piece(pjb_ctx* ctx, int32_t tid, const uint8_t* piece, int64_t bytes, int64_t* ticket);
 int pjb_bam_pieces_done(pjb_ctx* ctx, int64_t* completed_ticket);
 int pjb_bam_end(pjb_ctx* ctx, int32_t tid, int32_t first_uoffset, int64_t* n_records);
-/* The target's bgzf_inflate starts by itself when its last piece has been handed over (on a stream of its own, behind the
+/* The target's inflate (bgzf_decode + bgzf_resolve) starts by itself when its last piece has been handed over (on a stream of its own, behind the
  * copy): 1 if it has finished -- or none is in flight -- i.e. pjb_bam_end will not wait for it, else 0.  A caller that
  * serves several targets can hand over other targets' pieces meanwhile; their inflates then run side by side (a launch
  * takes ~50 ms whatever its size, and most targets do not fill the chip). */

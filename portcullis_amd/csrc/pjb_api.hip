@@ -2246,7 +2246,7 @@ static int end_flight(pjb_ctx *c, const int32_t *tids, int32_t n, pjb_region_res
                                       "with the same targets)", who, tids[0], n - 1);
     c->cur_tid = tids[0];
     HIP_TRY(c, hipSetDevice(c->cfg.device));
-    struct Closer { // also on every error path: the side stream (k4a_simple) may still read the contig's batches
+    struct Closer { // also on every error path: the side stream (k4b_generic) may still read the contig's batches
         pjb_ctx *c;
         bool ok = false;
         ~Closer() {

@@ -1,14 +1,17 @@
 // pjb_kernels.hip.h -- hand-written HIP kernels (gfx950 / CDNA4, wave64) for the
 // Portcullis `junc` hot path.  Integer / byte work bounded by HBM bandwidth; no MFMA.
 //
-// Pipeline per contig (DESIGN.md has the data layout and byte counts):
-//   K1a k1_count        per-read CIGAR walk: N-op count, length stats, sortedness    (a1,a2)
-//   K1b k1_emit         per-read CIGAR walk: emit (intron key, anchors, flags) pairs (a3,a5,a8)
-//   K2  radix sort      stable LSD sort of pairs by intron key (start,end)           (a3 grouping)
-//   K2s k2_* scans      segment heads -> junction ids, position runs                 (a3,a7)
-//   K3  k3_anchors      per-junction leftAncStart / rightAncEnd                      (a5)
-//   K4  k4_pairs        per-pair padded query/genome comparison + fragment reduce    (a12,a13,a8)
-//   K5  k5_*            fragment -> junction reduce, entropy, splice motif, hamming  (a6,a7,a9-a11,a13)
+// The chain of one target or group of targets (DESIGN.md section 4 has the table, the data layout and the byte counts):
+//   K1   k1_count, k1_scan_tiles   per-read CIGAR walk: N-op count, length stats, sortedness; the tiles' spliced lists     (a1,a2)
+//        k1_emit                   the spliced reads of the closed-form shapes: pairs (key, 32-byte record) complete       (a3,a5,a8,a12)
+//        k1_generic                every other spliced read: its operations walked, pairs, closed form where possible      (a3,a5,a8,a12)
+//   K2d  kd_*                      ordered dense junction ids from candidate keys; junction keys and anchors               (a3,a5)
+//   K4b  k4b_generic               window check of the closed forms / the padded query-genome walks (side stream)          (a12,a13)
+//   K2   rs_*                      stable LSD radix sort of (junction id, pair index)                                       (a3 grouping)
+//   K4   k4_pairs                  sorted pairs -> fragment heads; head / run masks                                         (a8,a13)
+//   K2s  k2_runs, k2_expand        position runs per junction (or k2_heads + kf_* on full keys)                             (a3,a7)
+//   K5   k5_*                      fragment -> junction reduce, entropy, splice motif, hamming -> rows                      (a6,a7,a9-a11,a13)
+//   K6   k6_rows_out               rows to the table; control block to the host
 // References in comments are file:line in the reference checkout.
 #pragma once
 
@@ -144,7 +147,7 @@ constexpr u32 RES_FIELD_MAX = 0xfffffu; // anchors longer than this take the gen
 // [voff_i, voff_i + len_i) (offsets 64-aligned, a gap between members).  k1_emit adds the offset to every coordinate it
 // emits, so keys, sort, grouping, anchors and reductions never see the difference -- an intron key still names one
 // junction of one target, and key order is (member, start, end).  Only what touches a target's OWN data converts back:
-// the genome of a pair / junction (k4a_simple, k4b_generic, k5_finalize look the member up by position) and the rows
+// the genome of a pair / junction (k1_generic, k4b_generic, k5_finalize look the member up by index / position) and the rows
 // (refid, local coordinates).  A single target is a group of one with offset 0.
 // ---------------------------------------------------------------------------------------------
 constexpr int GROUP_MAX = 32;
@@ -1870,7 +1873,7 @@ __global__ __launch_bounds__(256) void kg_member_stats(const u32 *tile_cnt, cons
 // the junctions a tile touches are neighbours (pairs arrive in BAM order, ranks are ordered by start), both passes
 // scatter into a few long runs per tile.  The rank comes without sorting anything:
 //   k1_emit    pairs -> candidate keys (distinct per block residency; see there)
-//   kd_mark    one bit per contig base: an intron starts here
+//   (k1_emit / k1_generic also set one bit per contig base where an intron of a listed candidate starts)
 //   scan       prefix popcount over the bitmap words  -> rank of a start among the distinct starts
 //   kd_ends    per start rank, the distinct intron ends seen (alternative acceptors: a handful; DENSE_ENDS slots)
 //   scan       number of ends per start rank           -> first junction id of every start (+ the anchors' rest state)
@@ -3207,7 +3210,7 @@ __global__ __launch_bounds__(256) void k5_finalize(const u64 *jkey, const u32 *s
         else if ((double)nn / tot >= 0.95) R.read_strand = PJB_STRAND_NEG;
         else R.read_strand = PJB_STRAND_UNK;
     }
-    // calcEntropy, junction.cc:730-749: the per-run terms (k5_entropy_terms) summed in run order (k5_entropy_sum), then fabs
+    // calcEntropy, junction.cc:730-749: the per-run terms summed in run order (k5_entropy_sum), then fabs
     R.entropy = n > 1 ? fabs(ent_sum[j]) : 0.0;
     // processJunctionWindow, junction.cc:561-649
     {
