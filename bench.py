@@ -70,6 +70,9 @@ def algorithmic_bytes(name, N, C, S, Cs, P, J, L, Pg=0, Rg=0, R=0, cand=0, Rv=0,
         "rs_scatter": P * (16 if sort_u32 else 24),
         "rs_panel_sums": P / 4096.0 * 4096, "rs_panel_scan": P / 4096.0 * 8192,  # the tiles' digit counts (1024 x 4 B a tile): read; read + written
         # sorted key (8) + index (4) + the position word of the record behind it (4); the apply pass writes the junction id
+        # (chains that sort the full keys) the scan's closing kernel; rest state of accumulators and anchors; anchors from the sorted
+        # pairs (index, id, lStart / rEnd half of the record) and the BAM-order ids
+        "k2_close": 64.0, "kf_init": J * 200, "kf_anchors": P * 28 + J * 8,
         "k2_heads_reduce": P * 16,
         "k2_heads_apply": P * 16 + P * 4 + (J + J + R) * 4,
         # generic reads: list entry (8), cig_off (8), ops, pos/aend half of the first record (16), l_qseq, seq_off (12), L/2 B of
