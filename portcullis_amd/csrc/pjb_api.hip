@@ -276,6 +276,8 @@ struct pjb_ctx {
     int64_t mirror_acc[5] = {0, 0, 0, INT32_MAX, 0}; // spliced, unspliced, sum_len, min_len, max_len
     pjb_timing timing;
     int radix_max_bits = 11;
+    bool k1_serial = true;            // PJB_K1_SERIAL=0: the chains' K1 stages side by side
+    hipEvent_t last_k1_ev = nullptr;  // the K1 stage of the chain queued last
     int k1s_blocks_forced = 0;                   // PJB_K1S_BLOCKS (tests): k1_scan_tiles on this many blocks -- 1: every tile in one block's rounds
     // optional per-kernel timing (the events live in the control slots)
     bool ktime = false;
@@ -759,6 +761,7 @@ int pjb_create(pjb_ctx **out, const pjb_config *cfg) {
     c->inflate_lanes = std::max(1, n_cu) * (160 * 1024 / I3_LDS_BYTES) * 64;
     c->ktime = (cfg->flags & PJB_FLAG_KERNEL_TIMING) != 0;
     c->extra = (cfg->flags & PJB_FLAG_EXTRA) != 0;
+    if (const char *s = getenv("PJB_K1_SERIAL")) c->k1_serial = atoi(s) != 0;
     if (const char *s = getenv("PJB_K1S_BLOCKS")) c->k1s_blocks_forced = std::max(0, std::min(atoi(s), (int)K1S_BLOCKS));
     if (const char *s = getenv("PJB_RADIX_BITS")) {
         int v = atoi(s);
@@ -774,6 +777,18 @@ int pjb_create(pjb_ctx **out, const pjb_config *cfg) {
 static void bam_stage_clear(pjb_ctx *c); // (defined with the staged ingest)
 
 void pjb_destroy(pjb_ctx *c) {
+#ifdef K1E_PROF
+    {
+        unsigned long long h[16] = {0};
+        (void)hipDeviceSynchronize();
+        if (hipMemcpyFromSymbol(h, HIP_SYMBOL(pjb::g_k1e_prof), sizeof h) == hipSuccess) {
+            unsigned long long tot = 0;
+            for (int i = 0; i < 12; i++) tot += h[i];
+            static const char *nm[12] = {"block start", "prologue", "shapes (wait ops)", "windows issue", "next records issue", "stage wait", "next ops issue", "compare+emit", "lists", "cand flush", "span of bases", "bases issue"};
+            for (int i = 0; i < 12; i++) fprintf(stderr, "[k1e_prof] %-20s %6.2f %%  %llu\n", nm[i], tot ? 100.0 * (double)h[i] / (double)tot : 0.0, h[i]);
+        }
+    }
+#endif
     if (!c) return;
     (void)hipSetDevice(c->cfg.device);
     (void)hipDeviceSynchronize(); // (contigs may still be queued)
@@ -1615,17 +1630,16 @@ static int queue_contig(pjb_ctx *c, Flight &f) {
             HIP_TRY(c, hipMemsetAsync(S.x_scnt.p, 0, sizeof(SparseCounters) + sizeof(ExtraCounters), c->stream));
             xo = XOut{(int32_t *)S.x_spos.p, (int32_t *)S.x_send.p, (uint8_t *)S.x_q.p, (u32 *)S.x_zlist.p, X_ZCAP, (SparseCounters *)S.x_scnt.p};
         }
-        for (size_t bi = 0; bi < batches.size(); bi++) {
-            const DevBatch &b = batches[bi];
-            const int32_t own_len = c->ref_len[(size_t)f.tids[(size_t)f.batch_member[bi]]];
-            const u32 nt = (u32)((b.n + K1_TILE - 1) / K1_TILE);
-            if (xk1)
-                LAUNCH(c, "k1_count", k1_count<true>, dim3(nt), dim3(K1C_T), b, (u32 *)S.tile_cnt.p, (TileStats *)S.tile_stats.p, (u32 *)S.splidx.p,
-                       (u32 *)S.splpoff.p, (uint4 *)S.splrec.p, d_err, 0, xo);
-            else
-                LAUNCH(c, "k1_count", k1_count<false>, dim3(nt), dim3(K1C_T), b, (u32 *)S.tile_cnt.p, (TileStats *)S.tile_stats.p, (u32 *)S.splidx.p,
-                       (u32 *)S.splpoff.p, (uint4 *)S.splrec.p, d_err, group ? std::max(own_len, 1) : 0, xo);
-        }
+        // K1 of one chain fills the chip: the chains' K1 stages follow each other (this chain's waits for the last queued chain's),
+        // and what comes behind a chain's K1 -- many small kernels -- runs beside the NEXT chain's K1 instead of beside its own twin
+        if (c->k1_serial && c->last_k1_ev) HIP_TRY(c, hipStreamWaitEvent(st, c->last_k1_ev, 0));
+        // (one launch over the chain's tiles: a block finds its batch from the tile index)
+        if (xk1)
+            LAUNCH(c, "k1_count", k1_count<true>, dim3(n_tiles), dim3(K1C_T), (const DevBatch *)S.batches.p, (int)batches.size(), (u32 *)S.tile_cnt.p, (TileStats *)S.tile_stats.p,
+                   (u32 *)S.splidx.p, (u32 *)S.splpoff.p, (uint4 *)S.splrec.p, d_err, GT, 0, xo);
+        else
+            LAUNCH(c, "k1_count", k1_count<false>, dim3(n_tiles), dim3(K1C_T), (const DevBatch *)S.batches.p, (int)batches.size(), (u32 *)S.tile_cnt.p, (TileStats *)S.tile_stats.p,
+                   (u32 *)S.splidx.p, (u32 *)S.splpoff.p, (uint4 *)S.splrec.p, d_err, GT, group ? 1 : 0, xo);
         if (xk1) {
             HIP_TRY(c, hipEventRecord(S.ev_xk1, c->stream));
             f.x_k1 = true;
@@ -1647,21 +1661,28 @@ static int queue_contig(pjb_ctx *c, Flight &f) {
         el.gen_cnt = d_gen_cnt;
         el.gen_cap = gen_cap;
         el.pack_nn = pack_nn;
-        for (size_t bi = 0; bi < batches.size(); bi++) {
-            const DevBatch &b = batches[bi];
-            const int m = f.batch_member[bi];
-            const int32_t own_tid = f.tids[(size_t)m], own_len = c->ref_len[(size_t)own_tid];
-            const u32 nt = (u32)((b.n + K1_TILE - 1) / K1_TILE);
-            // (a tile holds ~300 spliced reads = 1.2 chunks of 256: a grid of half the tiles keeps two or three chunks per block)
-            const u32 grid = std::max<u32>(1, std::min<u32>(nt, std::max<u32>(1024, nt / 2)));
-            LAUNCH(c, "k1_emit", k1_emit, dim3(grid), dim3(256), b, nt, n_tiles, (const u32 *)S.tile_cnt.p, (const u32 *)S.tile_soff.p,
-                   (const u32 *)S.chunk_tile.p, (const u32 *)S.splidx.p, (const u32 *)S.splpoff.p, (const uint4 *)S.splrec.p, pr, el, kf, own_len,
-                   own_tid, (int)c->cfg.orientation, d_err, d_cs, f.voff[(size_t)m], fast_codes ? (const u32 *)GT.codes[m] : (const u32 *)nullptr);
+        // (one launch per chain -- per K1E_MAXB batches --: the blocks stride over the batches' trips of 256 spliced reads; a tile holds
+        // ~300 spliced reads = 1.2 trips: a grid of half the tiles keeps two or three trips per block)
+        for (size_t b0 = 0; b0 < batches.size(); b0 += K1E_MAXB) {
+            const size_t nb = std::min<size_t>(K1E_MAXB, batches.size() - b0);
+            u64 reads = 0;
+            for (size_t bi = b0; bi < b0 + nb; bi++) reads += (u64)batches[bi].n;
+            const u32 nt = (u32)std::min<u64>((reads + K1_TILE - 1) / K1_TILE + nb, 0x7fffffffu);
+            // (tiles of reads per block: 2 / 4 / 8 / 16 = 9.17 / 8.96 / 8.94 / 9.05 ms a step, profiles/r05q_*)
+            static const u32 tiles_per_block = getenv("PJB_K1E_TILES") ? (u32)std::max(1, atoi(getenv("PJB_K1E_TILES"))) : 4u;
+            const u32 grid = std::max<u32>(1, std::min<u32>(nt, std::max<u32>(1024, nt / tiles_per_block)));
+            LAUNCH(c, "k1_emit", k1_emit, dim3(grid), dim3(256), (const DevBatch *)S.batches.p + b0, (int)nb, n_tiles, (const u32 *)S.tile_cnt.p,
+                   (const u32 *)S.tile_soff.p, (const u32 *)S.chunk_tile.p, (const u32 *)S.splidx.p, (const u32 *)S.splpoff.p, (const uint4 *)S.splrec.p, pr, el, kf,
+                   GT, fast_codes ? 1 : 0, (int)c->cfg.orientation, d_err, d_cs);
         }
         // the reads k1_emit left: one launch over the chain's third list (the blocks stride over it)
         LAUNCH(c, "k1_generic", k1_generic, dim3(std::min<u32>(std::max<u32>(1, (u32)(((u64)gen_cap * GEN_SHARDS + K1E_T - 1) / K1E_T)), 1536u /* six blocks a CU; 512 .. 3072 measured: no difference */)), dim3(K1E_T),
                (const DevBatch *)S.batches.p, (int)batches.size(), (const u32 *)S.splidx.p, (const uint4 *)S.splrec.p, pr, el, kf, GT, fast_codes ? 1 : 0,
                (int)c->cfg.orientation, d_err, d_cs);
+    }
+    if (c->k1_serial) {
+        HIP_TRY(c, hipEventRecord(S.ev_k1, st));
+        c->last_k1_ev = S.ev_k1;
     }
     STAGE_EVENT(1);
     // k4b_generic: the pairs that need the generic walks, in BAM order, as soon as junction ids and anchors exist -- beside

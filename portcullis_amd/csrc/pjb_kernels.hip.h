@@ -217,6 +217,14 @@ enum : u32 { OP_M = 0, OP_I = 1, OP_D = 2, OP_N = 3, OP_S = 4, OP_H = 5, OP_P = 
 // wave / block primitives (wave = 64 lanes)
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+// A barrier that orders LDS traffic only.  __syncthreads() is a workgroup-scope fence as well: hipcc drains vmcnt before it, which
+// makes a wave wait for every load it has in flight and for its STORES to be acknowledged -- k1_emit keeps the next trip's loads in
+// flight across its barriers on purpose.  Nothing that other waves of the block read from global memory may depend on this.
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
 
 // A pointer that was READ from memory (a batch descriptor, a pair's sequence address) is a generic pointer to the compiler:
 // its loads are flat_load, which count against the LDS counter too and are waited for one by one.  Everything such pointers
@@ -226,6 +234,59 @@ __device__ __forceinline__ T gload(const T *p) {
     T v;
     __builtin_memcpy(&v, (const __attribute__((address_space(1))) void *)p, sizeof(T));
     return v;
+}
+// A batch descriptor fetched from device memory (one launch per chain: the block looks its batch up): the same fields as
+// pointers into GLOBAL memory, so that what is read through them are global_load / s_load instructions.
+#define PJB_GLOBAL __attribute__((address_space(1)))
+template <class T>
+__device__ __forceinline__ const PJB_GLOBAL T *as_global(const T *p) {
+    return (const PJB_GLOBAL T *)p;
+}
+template <class T, class U>
+__device__ __forceinline__ T gload_as(const PJB_GLOBAL U *p) { // a T at a global address
+    T v;
+    __builtin_memcpy(&v, (const PJB_GLOBAL void *)p, sizeof(T));
+    return v;
+}
+struct GBatch {
+    const PJB_GLOBAL int32_t *pos;
+    const PJB_GLOBAL uint16_t *flag;
+    const PJB_GLOBAL uint8_t *mapq;
+    const PJB_GLOBAL uint8_t *xs;
+    const PJB_GLOBAL int32_t *l_qseq;
+    const PJB_GLOBAL int32_t *mtid;
+    const PJB_GLOBAL int32_t *mpos;
+    const PJB_GLOBAL uint32_t *cig_off;
+    const PJB_GLOBAL uint32_t *cigar;
+    const PJB_GLOBAL uint32_t *seq_off;
+    const PJB_GLOBAL uint8_t *seq4;
+    int64_t n;
+    uint32_t base, tile_base;
+    int32_t prev_pos, member;
+    const PJB_GLOBAL int32_t *prev_pos_ptr;
+};
+#define PJB_CONSTANT __attribute__((address_space(4)))
+__device__ __forceinline__ GBatch load_batch(const DevBatch *d) { // (through the constant address space: a uniform index gives scalar loads)
+    const PJB_CONSTANT DevBatch *g = (const PJB_CONSTANT DevBatch *)d;
+    GBatch b;
+    b.pos = as_global(g->pos);
+    b.flag = as_global(g->flag);
+    b.mapq = as_global(g->mapq);
+    b.xs = as_global(g->xs);
+    b.l_qseq = as_global(g->l_qseq);
+    b.mtid = as_global(g->mtid);
+    b.mpos = as_global(g->mpos);
+    b.cig_off = as_global(g->cig_off);
+    b.cigar = as_global(g->cigar);
+    b.seq_off = as_global(g->seq_off);
+    b.seq4 = as_global(g->seq4);
+    b.n = g->n;
+    b.base = g->base;
+    b.tile_base = g->tile_base;
+    b.prev_pos = g->prev_pos;
+    b.member = g->member;
+    b.prev_pos_ptr = as_global(g->prev_pos_ptr);
+    return b;
 }
 // four consecutive words at a 4-byte aligned address (global_load_dwordx4 accepts that)
 struct __attribute__((packed, aligned(4))) Words4 {
@@ -319,7 +380,7 @@ __device__ __forceinline__ T block_escan_256(T v, T *smem, T *total) {
 }
 
 // the same over NW wavefronts (NW = 1: no barrier, no shared memory traffic)
-template <int NW, typename T>
+template <int NW, typename T, bool LDS_ONLY = false>
 __device__ __forceinline__ T block_escan(T v, T *smem, T *total) {
     T inc = wave_iscan(v);
     if constexpr (NW == 1) {
@@ -327,9 +388,11 @@ __device__ __forceinline__ T block_escan(T v, T *smem, T *total) {
         return inc - v;
     } else {
         int w = threadIdx.x >> 6, l = lane_id();
-        __syncthreads();
+        if constexpr (LDS_ONLY) lds_barrier();
+        else __syncthreads();
         if (l == 63) smem[w] = inc;
-        __syncthreads();
+        if constexpr (LDS_ONLY) lds_barrier();
+        else __syncthreads();
         T base = 0, tot = 0;
 #pragma unroll
         for (int i = 0; i < NW; i++) {
@@ -601,17 +664,261 @@ __device__ __forceinline__ u32 spl_nlq(u32 n, bool seq_ok, int32_t lq) {
 #define K1C_T 256 // threads of a k1_count block (a tile is K1_TILE reads: 4 per thread).  512 threads x 2 reads need 64 registers instead of
                   // 84 but took 88 against 63 us a launch beside the other chains' kernels: a block of 8 wavefronts waits for 8 free slots on ONE CU
 #endif
+#ifndef K1C_NO_ROWS
+#define K1C_NO_ROWS 0 // 1: every tile takes the rounds (A/B builds)
+#endif
 #ifndef K1C_WAVES
 #define K1C_WAVES 5 // (84 registers as the compiler wants them; forced to 64: 31 spills, 99 against 61 us a launch)
 #endif
+// ONE launch per chain: block = one tile of the chain's tile space; its batch is the last one whose tile_base it has reached
+// (the descriptors live in device memory, the index is uniform: scalar loads).  chk_members (groups): see chk_ref_len below.
+__device__ __forceinline__ int batch_of_tile(const DevBatch *batches, int n_batches, u32 tile) {
+    // lane k looks at batch base + k: one load and one ballot per 64 batches
+    int found = 0;
+    for (int base = 0; base < n_batches; base += 64) {
+        const int k = base + lane_id();
+        const u32 tb = k < n_batches ? gload(&batches[k].tile_base) : 0xffffffffu;
+        const u64 m = __ballot(tb <= tile);
+        if (m == 0) break;
+        found = base + 63 - __clzll((long long)m);
+    }
+    return __builtin_amdgcn_readfirstlane(found);
+}
+// inclusive scan across the wave on the DPP path (row shifts, then the row totals carried up: no LDS traffic, ~14 instructions)
+template <int CTRL, int ROW_MASK, int BANK_MASK>
+__device__ __forceinline__ u32 dpp_shift0(u32 v) { // the source lane's value, 0 where there is none
+    return (u32)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, BANK_MASK, false);
+}
+__device__ __forceinline__ u32 wave_iscan_dpp(u32 v) {
+    u32 o = v + dpp_shift0<0x111, 0xf, 0xf>(v) + dpp_shift0<0x112, 0xf, 0xf>(v) + dpp_shift0<0x113, 0xf, 0xf>(v); // row_shr:1..3
+    o += dpp_shift0<0x114, 0xf, 0xe>(o); // row_shr:4
+    o += dpp_shift0<0x118, 0xf, 0xc>(o); // row_shr:8
+    o += dpp_shift0<0x142, 0xa, 0xf>(o); // row_bcast:15
+    o += dpp_shift0<0x143, 0xc, 0xf>(o); // row_bcast:31
+    return o;
+}
+#define PJB_LDS __attribute__((address_space(3)))
+#ifndef K1C_OPSW
+#define K1C_OPSW 3072 // operations of a tile that the fast path of k1_count keeps in LDS (a tile of 1024 reads has ~1 700)
+#endif
+// The FAST path of a tile (all 1024 reads there, its operations fit in LDS): a thread owns four CONSECUTIVE reads, so every
+// fixed-width field is one 16-byte load (the kernel was bound by VALU issue -- 83 % busy, round 5's SQ counters: 16 address
+// computations and word loads for the operations, four 64-bit shuffle scans), the tile's operations come with coalesced loads
+// straight to LDS and are read from there, and ONE scan per wavefront orders the spliced reads.
 template <bool EXTRA>
-__global__ __launch_bounds__(K1C_T) __attribute__((amdgpu_waves_per_eu(K1C_WAVES, K1C_WAVES))) void k1_count(DevBatch b, u32 *tile_cnt, TileStats *tile_stats, u32 *spl_idx,
-                                                 u32 *spl_poff, uint4 *spl_rec, u64 *err, int32_t chk_ref_len, XOut X) {
+__device__ __forceinline__ void k1_count_rows(const GBatch &b, const u32 tile_local, const u32 cA, const u32 n_ops, u32 *tile_cnt, TileStats *tile_stats, u32 *spl_idx,
+                                              u32 *spl_poff, uint4 *spl_rec, u64 *err, const int32_t chk_ref_len, const XOut &X) {
+    constexpr int NW = K1C_T / 64;
+    static_assert(K1C_T * 4 == K1_TILE, "four reads a thread");
+    __shared__ __attribute__((aligned(16))) u32 s_ops[K1C_OPSW + 8];
+    __shared__ u32 s_scan[2][NW];
+    __shared__ u64 r64[NW][2];
+    __shared__ int32_t r32[NW][6];
+    const int t = threadIdx.x, w = t >> 6;
+    const int64_t r0 = (int64_t)tile_local * K1_TILE + 4 * t; // the thread's first read
+    // ---- the tile's operations -> LDS (16 bytes a lane straight to LDS; the span starts at the 16-byte boundary below its first word)
+    const uintptr_t a0 = (uintptr_t)(b.cigar + cA);
+    const u32 shift = (u32)(a0 >> 2) & 3u;
+    {
+        const PJB_GLOBAL uint4 *p = (const PJB_GLOBAL uint4 *)(a0 - 4u * shift);
+        const u32 total = n_ops + shift; // words from the aligned start; they all exist but for the last 16 bytes' tail: the array ends at cig_off[n]
+        const u32 exist = b.cig_off[b.n] - cA + shift;
+#pragma unroll
+        for (int it = 0; it < (K1C_OPSW + 3 + K1C_T * 4 - 1) / (K1C_T * 4); it++) {
+            if ((u32)it * (K1C_T * 4) < total) {
+                const u32 i = (u32)it * (K1C_T * 4) + (u32)t * 4u;
+                if (i + 4u <= exist) {
+                    if (i < total) __builtin_amdgcn_global_load_lds(p + (i >> 2), (PJB_LDS void *)(s_ops + it * (K1C_T * 4) + w * 256), 16, 0, 0);
+                } else if (i < exist) {
+                    const PJB_GLOBAL u32 *q = (const PJB_GLOBAL u32 *)p + i;
+                    s_ops[i] = q[0];
+                    if (i + 1u < exist) s_ops[i + 1] = q[1];
+                    if (i + 2u < exist) s_ops[i + 2] = q[2];
+                }
+            }
+        }
+    }
+    // ---- the four reads' fields: one 16-byte load each
+    const Words4 co = gload_as<Words4>(b.cig_off + r0);
+    const u32 co4 = b.cig_off[r0 + 4];
+    const Words4 po = gload_as<Words4>(b.pos + r0);
+    const int32_t pprev = r0 > 0 ? b.pos[r0 - 1] : (b.prev_pos_ptr ? *b.prev_pos_ptr : b.prev_pos);
+    const Words4 lqv = gload_as<Words4>(b.l_qseq + r0);
+    const Words4 sov = gload_as<Words4>(b.seq_off + r0);
+    const u32 so4 = b.seq_off[r0 + 4];
+    const u32 xs4 = gload_as<u32>(b.xs + r0);
+    u64 fl4 = 0;
+    if (EXTRA) fl4 = gload_as<u64>(b.flag + r0);
+    const u32 c[5] = {co.x, co.y, co.z, co.w, co4}, so[5] = {sov.x, sov.y, sov.z, sov.w, so4};
+    const int32_t pos[4] = {(int32_t)po.x, (int32_t)po.y, (int32_t)po.z, (int32_t)po.w}, lq[4] = {(int32_t)lqv.x, (int32_t)lqv.y, (int32_t)lqv.z, (int32_t)lqv.w};
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // (the LDS-DMA: hipcc does not wait for it before a ds_read of its own accord)
+    __syncthreads();
+    u32 cnt = 0, spl = 0, uns = 0;
+    u64 sum = 0;
+    int32_t mn = INT32_MAX, mx = 0, max_end = 0, max_nlen = 0, min_pos = INT32_MAX;
+    u32 cN[4], nlq[4];
+    u32 xspan = 0, xgapmax = 0;
+    bool xmany = false;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int64_t r = r0 + i;
+        const int32_t p = pos[i], lenv = lq[i];
+        const int32_t prv = i == 0 ? pprev : pos[i > 0 ? i - 1 : 0];
+        if (p < prv) set_error(err, b.base + (u32)r, PJB_ERR_UNSORTED);
+        if (((xs4 >> (8 * i)) & 0xffu) > 2u) set_error(err, b.base + (u32)r, PJB_ERR_BAD_XS);
+        mn = lenv < mn ? lenv : mn;
+        mx = lenv > mx ? lenv : mx;
+        sum += (u64)(int64_t)lenv;
+        const u32 n = c[i + 1] - c[i];
+        nlq[i] = spl_nlq(n, (u64)(so[i + 1] - so[i]) * 8ull >= (u64)(int64_t)lenv, lenv);
+        const u32 *ops = s_ops + (c[i] - cA + shift);
+        u32 cc = 0, ngap = 0, gmax = 0;
+        int32_t al = 0;
+        auto count_op = [&](u32 op) {
+            const u32 ty = op & 15u;
+            const int32_t ln = (int32_t)(op >> 4);
+            if (op_consumes_ref(ty)) al += ln;
+            if (ty == OP_N) {
+                cc++;
+                max_nlen = ln > max_nlen ? ln : max_nlen;
+            }
+            if (EXTRA && ty == OP_D && ln) { // inside the span, no depth
+                ngap++;
+                gmax = max(gmax, (u32)ln);
+            }
+        };
+        const u32 o0 = ops[0], o1 = ops[1], o2 = ops[2], o3 = ops[3]; // (what lies behind the read's last operation is masked: 0M has no effect)
+        count_op(0u < n ? o0 : 0u);
+        count_op(1u < n ? o1 : 0u);
+        count_op(2u < n ? o2 : 0u);
+        count_op(3u < n ? o3 : 0u);
+        for (u32 k = 4; k < n; k++) count_op(ops[k]);
+        cnt += cc;
+        if (cc) {
+            spl++;
+            const int32_t e = p + al;
+            max_end = e > max_end ? e : max_end;
+            min_pos = p < min_pos ? p : min_pos;
+        } else
+            uns++;
+        cN[i] = cc;
+        if (EXTRA) { // the record's part in unspliced.bam (junction_builder.cc:168-186)
+            const u32 g = b.base + (u32)r;
+            const u32 fv = (u32)(fl4 >> (16 * i)) & 0xffffu;
+            const bool unspliced = cc == 0 && !(fv & 0x4u);
+            const bool spans = unspliced && al > 0 && p >= 0;
+            X.s_pos[g] = p;
+            X.s_end[g] = spans ? p + al : p;
+            if (!spans) ngap = 0, gmax = 0;
+            if (ngap > SPARSE_GAP_MAX) xmany = true, ngap = SPARSE_GAP_MAX;
+            X.q[g] = (uint8_t)((spans ? 1u : 0u) | (ngap << 1));
+            if (spans) xspan = max(xspan, (u32)al);
+            xgapmax = max(xgapmax, gmax);
+            if (unspliced && al == 0) {
+                const u32 z = atomicAdd(&X.cnt->n_zero, 1u);
+                if (z < X.zcap) X.zlist[z] = (u32)p;
+            }
+        }
+    }
+    if (EXTRA) {
+        xspan = wave_max(xspan);
+        xgapmax = wave_max(xgapmax);
+        if (lane_id() == 0) { // (look first: the maxima settle after a few waves)
+            if (xspan > X.cnt->max_span) atomicMax(&X.cnt->max_span, xspan);
+            if (xgapmax > X.cnt->max_gap) atomicMax(&X.cnt->max_gap, xgapmax);
+        }
+        if (xmany) atomicOr(&X.cnt->need_dense, 2u);
+    }
+    // ---- ordered compaction of the tile's spliced reads: slot k holds the k-th of them (batch-local index) and the tile-local offset
+    // of its first pair.  Thread order is read order: one scan of the threads' counts.
+    {
+        const u32 inc_s = wave_iscan_dpp(spl), inc_p = wave_iscan_dpp(cnt);
+        if (lane_id() == 63) {
+            s_scan[0][w] = inc_s;
+            s_scan[1][w] = inc_p;
+        }
+        __syncthreads();
+        u32 ex_s = inc_s - spl, ex_p = inc_p - cnt;
+#pragma unroll
+        for (int k = 0; k < NW; k++)
+            if (k < w) {
+                ex_s += s_scan[0][k];
+                ex_p += s_scan[1][k];
+            }
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+            if (cN[i]) {
+                const size_t slot = (size_t)blockIdx.x * K1_TILE + ex_s;
+                spl_idx[slot] = (u32)(r0 + i);
+                spl_poff[slot] = ex_p;
+                spl_rec[slot] = make_uint4(c[i], (u32)pos[i], so[i], nlq[i]);
+                ex_s++;
+                ex_p += cN[i];
+            }
+    }
+    // ---- the tile's statistics (whole-wave reductions on the DPP path; the length sum in 16-bit halves: nothing overflows 32 bits)
+    const u32 w_cnt = wave_total<DppAdd>(cnt), w_su = wave_total<DppAdd>((spl << 16) | uns);
+    sum = (u64)wave_total<DppAdd>((u32)(sum & 0xffffu)) + ((u64)wave_total<DppAdd>((u32)((sum >> 16) & 0xffffu)) << 16) +
+          ((u64)wave_total<DppAdd>((u32)(sum >> 32)) << 32);
+    auto smin = [](int32_t v) { return (int32_t)(wave_total<DppMin>((u32)v ^ 0x80000000u) ^ 0x80000000u); };
+    auto smax = [](int32_t v) { return (int32_t)(wave_total<DppMax>((u32)v ^ 0x80000000u) ^ 0x80000000u); };
+    mn = smin(mn);
+    mx = smax(mx);
+    max_end = smax(max_end);
+    max_nlen = smax(max_nlen);
+    min_pos = smin(min_pos);
+    if (lane_id() == 0) {
+        r64[w][0] = ((u64)w_cnt << 32) | w_su;
+        r64[w][1] = sum;
+        r32[w][0] = mn;
+        r32[w][1] = mx;
+        r32[w][2] = max_end;
+        r32[w][3] = max_nlen;
+        r32[w][4] = min_pos;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        u64 pk = 0;
+        TileStats ts;
+        ts.sum_len = 0;
+        ts.min_len = INT32_MAX, ts.max_len = 0, ts.max_end = 0, ts.max_nlen = 0, ts.min_pos = INT32_MAX;
+        for (int i = 0; i < NW; i++) {
+            pk += r64[i][0];
+            ts.sum_len += r64[i][1];
+            ts.min_len = min(ts.min_len, r32[i][0]);
+            ts.max_len = max(ts.max_len, r32[i][1]);
+            ts.max_end = max(ts.max_end, r32[i][2]);
+            ts.max_nlen = max(ts.max_nlen, r32[i][3]);
+            ts.min_pos = min(ts.min_pos, r32[i][4]);
+        }
+        ts.spliced = (u32)((pk >> 16) & 0xffff);
+        ts.unspliced = (u32)(pk & 0xffff);
+        if (chk_ref_len > 0 && ts.max_end > chk_ref_len) ts.max_end = INT32_MAX;
+        ts._pad = 0;
+        tile_stats[blockIdx.x] = ts;
+        tile_cnt[blockIdx.x] = (u32)(pk >> 32);
+    }
+}
+template <bool EXTRA>
+__global__ __launch_bounds__(K1C_T) __attribute__((amdgpu_waves_per_eu(K1C_WAVES, K1C_WAVES))) void k1_count(const DevBatch *batches, int n_batches, u32 *tile_cnt, TileStats *tile_stats, u32 *spl_idx,
+                                                 u32 *spl_poff, uint4 *spl_rec, u64 *err, GroupTab G, int chk_members, XOut X) {
     constexpr int NW = K1C_T / 64, RPT = K1_TILE / K1C_T; // wavefronts of the block; reads per thread
     __shared__ u64 sm64[NW];
     __shared__ u64 sm_scan4[RPT][NW];
     __shared__ int32_t smi[NW][6];
-    int64_t base = (int64_t)blockIdx.x * K1_TILE;
+    const GBatch b = load_batch(batches + batch_of_tile(batches, n_batches, blockIdx.x));
+    const u32 tile_local = blockIdx.x - b.tile_base;
+    const int32_t chk_ref_len = chk_members ? max(G.len[b.member], 1) : 0;
+    int64_t base = (int64_t)tile_local * K1_TILE;
+#if !K1C_NO_ROWS
+    if (base + K1_TILE <= b.n) { // (a whole tile whose operations fit in LDS: the fast path; else the rounds below)
+        const u32 cA = b.cig_off[base], cB = b.cig_off[base + K1_TILE];
+        if (cB - cA + 3u <= (u32)K1C_OPSW) {
+            k1_count_rows<EXTRA>(b, tile_local, cA, cB - cA, tile_cnt, tile_stats, spl_idx, spl_poff, spl_rec, err, chk_ref_len, X);
+            return;
+        }
+    }
+#endif
     u32 cnt = 0, spl = 0, uns = 0;
     u64 sum = 0;
     int32_t mn = INT32_MAX, mx = 0, max_end = 0, max_nlen = 0, min_pos = INT32_MAX;
@@ -753,7 +1060,7 @@ __global__ __launch_bounds__(K1C_T) __attribute__((amdgpu_waves_per_eu(K1C_WAVES
             }
             if (c4[it]) {
                 const u64 ex = before + inc[it] - (((u64)c4[it] << 16) | 1u);
-                const size_t slot = (size_t)(b.tile_base + blockIdx.x) * K1_TILE + (u32)(ex & 0xffffu);
+                const size_t slot = (size_t)blockIdx.x * K1_TILE + (u32)(ex & 0xffffu);
                 spl_idx[slot] = (u32)(base + it * K1C_T + threadIdx.x);
                 spl_poff[slot] = (u32)(ex >> 16);
                 spl_rec[slot] = make_uint4(c0[it], (u32)pos4[it], so4[it], nlq4[it]);
@@ -803,8 +1110,8 @@ __global__ __launch_bounds__(K1C_T) __attribute__((amdgpu_waves_per_eu(K1C_WAVES
         t.unspliced = (u32)(p & 0xffff);
         if (chk_ref_len > 0 && t.max_end > chk_ref_len) t.max_end = INT32_MAX;
         t._pad = 0;
-        tile_stats[b.tile_base + blockIdx.x] = t;
-        tile_cnt[b.tile_base + blockIdx.x] = (u32)(p >> 32);
+        tile_stats[blockIdx.x] = t;
+        tile_cnt[blockIdx.x] = (u32)(p >> 32);
     }
 }
 
@@ -1399,7 +1706,7 @@ __device__ __forceinline__ u32 read_meta(u32 flag, u32 xs, u32 mapq, int32_t pos
 //     wavefront, spread over 256 addresses).
 constexpr int K1E_LOOK = 16;
 #ifndef K1E_WAVES
-#define K1E_WAVES 6 // wavefronts per SIMD the register allocation aims at (tools/build_variants.sh builds the others for A/B runs)
+#define K1E_WAVES 4 // wavefronts per SIMD the register allocation aims at (tools/build_variants.sh builds the others for A/B runs)
 #endif
 constexpr int K1E_T = 256, K1E_SHIFT = 8; // threads of a block = list entries of one trip
 constexpr int KC_SLOTS = K1E_T * 2;     // the block's candidate set (LDS), flushed when a quarter full
@@ -1485,6 +1792,28 @@ struct EmitCtx {
     }
     // appends the wavefront's entries to list `kind` (1: reads for k4b_generic's walks, 2: for its window check, 3: reads for
     // k1_generic): one returning atomic per wavefront; sub-list `shard` (callers deal 256-entry chunks round-robin: gen_list_cap)
+    // the same in two halves: the returning atomic early (list_reserve), the stores once its answer is there (list_write) -- a wavefront
+    // that appends and stores at once waits a memory round trip for the atomic
+    __device__ __forceinline__ u32 list_reserve(u32 kind, bool mine, u32 pairs, u32 shard) const {
+        const u64 gm2 = __ballot(mine);
+        if (!gm2) return 0u;
+        const u32 pairs_w = wave_total<DppAdd>(mine ? pairs : 0u);
+        const int leader = __ffsll((long long)gm2) - 1;
+        const u32 w0 = shard * GEN_CNT_STRIDE + (kind - 1) * 2;
+        u32 base = 0;
+        if (lane_id() == leader) {
+            base = atomicAdd(&E.gen_cnt[w0], (u32)__popcll(gm2));
+            if (pairs_w) atomicAdd(&E.gen_cnt[w0 + 1], pairs_w);
+        }
+        return base; // (in the leader's lane)
+    }
+    __device__ __forceinline__ void list_write(u32 kind, bool mine, u32 base, u64 entry, u32 shard) const {
+        const u64 gm2 = __ballot(mine);
+        if (!gm2) return;
+        base = (u32)__builtin_amdgcn_readlane((int)base, __ffsll((long long)gm2) - 1);
+        const u32 at = base + (u32)__popcll(gm2 & ((1ull << lane_id()) - 1));
+        if (mine && at < E.gen_cap) E.gen_list[((size_t)(kind - 1) * GEN_SHARDS + shard) * E.gen_cap + at] = entry;
+    }
     __device__ __forceinline__ void list_append(u32 kind, bool mine, u32 pairs, u64 entry, u32 shard) const {
         const u64 gm2 = __ballot(mine);
         if (!gm2) return;
@@ -1503,7 +1832,7 @@ struct EmitCtx {
     // candidate keys: the set is flushed when it fills up, and before the block leaves (every thread of the block calls)
     __device__ __forceinline__ void cand_flush(bool force) const {
         if (!want_cand) return;
-        __syncthreads();
+        lds_barrier();
         if (sh.set_n > (u32)KC_SLOTS / 4 || force) {
             u64 mine[KC_SLOTS / K1E_T], anc[KC_SLOTS / K1E_T];
             u32 cnt = 0;
@@ -1518,12 +1847,12 @@ struct EmitCtx {
                 sh.hi[at] = INT32_MIN;
             }
             u32 total;
-            const u32 excl = block_escan<K1E_T / 64>(cnt, sh.scan, &total);
+            const u32 excl = block_escan<K1E_T / 64, u32, true>(cnt, sh.scan, &total);
             if (threadIdx.x == 0) {
                 sh.base = total ? atomicAdd(&cs->n_cand, total) : 0u;
                 sh.set_n = 0;
             }
-            __syncthreads();
+            lds_barrier();
             u32 o = sh.base + excl;
 #pragma unroll
             for (int i = 0; i < KC_SLOTS / K1E_T; i++)
@@ -1536,43 +1865,281 @@ struct EmitCtx {
     }
 };
 
-__global__ __launch_bounds__(K1E_T) __attribute__((amdgpu_waves_per_eu(K1E_WAVES, K1E_WAVES))) void k1_emit(DevBatch b, u32 n_tiles_batch, u32 n_tiles_total, const u32 *tile_off, const u32 *tile_soff,
+// ---- the wavefront's reads through LDS.  A lane's bases are its own ~76 bytes, so a 16-byte load of them by all lanes touched
+// 64 cache lines and fetched 8 KB for 1 KB (SQ counters, round 4: ~100 such loads per wavefront, the kernel bound by their
+// NUMBER); but the spliced reads' bases lie back to back in seq4 in list order -- the 64 reads of a wavefront are ONE span of
+// ~5 KB -- and position-sorted reads compare against a few hundred bases of genome: both are staged with coalesced 16-byte loads
+// (five for the bases, one per genome window) and every lane then reads its words from LDS.  A window holds K1E_GENW words from
+// the smallest block start of the wavefront's lanes: window 0 = the reads' first blocks of bases (left anchors), 1 = their second
+// (right anchor / the block between two introns), 2 = their third; a lane whose block leaves its window (another acceptor far
+// away) or whose wavefront's reads span more than K1E_SEQW words (long reads) takes the gathers (cmp_words) as before.
+#ifndef K1E_SEQW
+#define K1E_SEQW 1280 // words of packed bases per wavefront: 64 reads of up to 160 bases
+#endif
+#ifndef K1E_GENW
+#define K1E_GENW 64   // words of genome codes per window: 512 bases
+#endif
+#ifndef K1E_PASSES
+#define K1E_PASSES 1 // passes over the wavefront's loci (two windows each) before the gathers take what is left.  (More passes were
+                     // measured: a second pass costs another round trip of staging loads -- frac_alone 0.56 against 0.61.)
+#endif
+#ifndef K1E_SEQ_LAST
+#define K1E_SEQ_LAST 0
+#endif
+#ifndef K1E_REGSTAGE
+#define K1E_REGSTAGE 0
+#endif
+#ifndef K1E_LDS_NW
+#define K1E_LDS_NW 5  // words per stream and round of the LDS compare (32 bases a round)
+#endif
+constexpr int K1E_SLACK = 8; // a round may read this many words past what its block needs (masked)
+struct __attribute__((aligned(16))) EmitStage { // one per wavefront
+    u32 seq[K1E_SEQW + K1E_SLACK];
+    u32 gen[3][2][K1E_GENW + K1E_SLACK]; // two windows per block of bases: a wavefront often holds the reads of two loci
+};
+// words [first, first + count) of `src` to dst[shift ...], shift (returned) = words between the 16-byte boundary at or below
+// src + first and it; `exist` = words of src there are (nothing is read past them).  The whole wavefront calls.  The loads go
+// straight to LDS (global_load_lds_dwordx4: lane l's 16 bytes land at the wave-uniform base + 16 l) and are NOT waited for:
+// stage_wait() before the first read.  MAXW: the most words a call may ask for (the loop unrolls: every load is issued at once).
+template <int MAXW>
+__device__ __forceinline__ u32 stage_span(u32 *dst, const PJB_GLOBAL u32 *src, u32 first, u32 count, u32 exist) {
+    const uintptr_t a = (uintptr_t)(src + first);
+    const u32 shift = (u32)(a >> 2) & 3u;
+    const PJB_GLOBAL uint4 *p = (const PJB_GLOBAL uint4 *)(a - 4u * shift);
+    const u32 total = count + shift;         // words from the aligned start
+    const u32 avail = exist - first + shift; // words that exist from there
+    constexpr int ITERS = (MAXW + 3 + 255) / 256;
+#if K1E_REGSTAGE // (experiment: through registers)
+    uint4 v[ITERS];
+#pragma unroll
+    for (int it = 0; it < ITERS; it++) {
+        const u32 i = (u32)it * 256u + (u32)lane_id() * 4u;
+        const u32 ic = i + 4u <= avail && i < total ? i : 0u;
+        v[it] = gload_as<uint4>(p + (ic >> 2));
+    }
+#pragma unroll
+    for (int it = 0; it < ITERS; it++) {
+        const u32 i = (u32)it * 256u + (u32)lane_id() * 4u;
+        if (i + 4u <= avail && i < total) *reinterpret_cast<uint4 *>(dst + i) = v[it];
+        else if (i < avail && i < total) {
+            const PJB_GLOBAL u32 *w = (const PJB_GLOBAL u32 *)p + i;
+            dst[i] = w[0];
+            if (i + 1u < avail) dst[i + 1] = w[1];
+            if (i + 2u < avail) dst[i + 2] = w[2];
+        }
+    }
+    return shift;
+#endif
+#pragma unroll
+    for (int it = 0; it < ITERS; it++) {
+        if ((u32)it * 256u < total) { // (uniform)
+            const u32 i = (u32)it * 256u + (u32)lane_id() * 4u;
+            if (i + 4u <= avail) {
+                if (i < total) __builtin_amdgcn_global_load_lds(p + (i >> 2), (PJB_LDS void *)(dst + it * 256), 16, 0, 0);
+            } else if (i < avail) { // (the last words of the array)
+                const PJB_GLOBAL u32 *w = (const PJB_GLOBAL u32 *)p + i;
+                dst[i] = w[0];
+                if (i + 1u < avail) dst[i + 1] = w[1];
+                if (i + 2u < avail) dst[i + 2] = w[2];
+            }
+        }
+    }
+    return shift;
+}
+__device__ __forceinline__ void stage_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); } // (hipcc does not wait for an LDS-DMA before a ds_read of its own accord)
+// One block of l bases, both streams in LDS: read words from qs[qw0 ...] (word 0 of the read at qs[qw0]), genome codes from
+// gs[gofs + word index].  The kernel is bound by VALU issue (round 5's SQ counters: the compares were 62 % of its vector instructions,
+// ~830 per read), so this is written for instruction count: GROUPS of 32 bases, no branch inside a group --
+//   * four words per stream (a fifth carried over), funnel-shifted into place, XOR;
+//   * "nibble differs" as the top bit of the nibble (3 operations a word), the four words' flags packed into ONE word M (bit 4 n + k
+//     = base 8 k + n of the group: v_bfi), so that a group costs one popcount and one update of the trackers;
+//   * the group that holds the block's end is masked with a table word (k1e_tail_mask: bit 4 n + k set iff 8 k + n < r);
+//   * first / last mismatch: the first / last group with a flag is kept as it is (its M and its number) and decoded once, behind the
+//     loop.  WF / WL: which of the two the caller needs (a left anchor only its last mismatch, a right anchor only its first).
+__device__ __forceinline__ u32 k1e_tail_mask_word(u32 r) { // r = 0 .. 32 bases of a group that are part of the block
+    u32 m = 0;
+    for (u32 k = 0; k < 4; k++)
+        for (u32 n = 0; n < 8; n++)
+            if (8 * k + n < r) m |= 1u << (4 * n + k);
+    return m;
+}
+__device__ __forceinline__ u32 nibble_flags_top(u32 x) { return ((x & 0x77777777u) + 0x77777777u) | x; } // bit 4 n + 3: nibble n of x is not 0 (other bits: anything)
+__device__ __forceinline__ u32 bfi(u32 mask, u32 a, u32 b) { return (a & mask) | (b & ~mask); }          // (v_bfi_b32)
+// base index (within the group) of the lowest / highest base flagged in a packed group word
+__device__ __forceinline__ int32_t packed_first(u32 M) {
+    const u32 m0 = M & 0x11111111u, m1 = M & 0x22222222u, m2 = M & 0x44444444u, m3 = M & 0x88888888u;
+    const u32 sel = m0 ? m0 : m1 ? m1 : m2 ? m2 : m3;
+    const int32_t k = m0 ? 0 : m1 ? 1 : m2 ? 2 : 3;
+    return 8 * k + ((__ffs((int)sel) - 1) >> 2);
+}
+__device__ __forceinline__ int32_t packed_last(u32 M) {
+    const u32 m0 = M & 0x11111111u, m1 = M & 0x22222222u, m2 = M & 0x44444444u, m3 = M & 0x88888888u;
+    const u32 sel = m3 ? m3 : m2 ? m2 : m1 ? m1 : m0;
+    const int32_t k = m3 ? 3 : m2 ? 2 : m1 ? 1 : 0;
+    return 8 * k + ((31 - __clz((int)sel)) >> 2);
+}
+template <bool WF, bool WL>
+__device__ __forceinline__ void cmp_block_lds(const u32 *qs, int32_t qw0, int32_t qi, const u32 *gs, int32_t gofs, int32_t gi, int32_t l, const u32 *tail_mask,
+                                              CmpBlock &B) {
+    const u32 shq = (u32)(qi & 7) * 4u, shg = (u32)(gi & 7) * 4u;
+    const u32 *qp = qs + qw0 + (qi >> 3), *gp = gs + gofs + (gi >> 3);
+    u32 qa = swap_nibbles(qp[0]), ga = gp[0];
+    u32 cnt = 0, mF = 0, mL = 0;
+    int32_t gF = 0, gL = 0;
+    for (int32_t grp = 0; 32 * grp < l; grp++) {
+        const u32 q1 = swap_nibbles(qp[1]), q2 = swap_nibbles(qp[2]), q3 = swap_nibbles(qp[3]), q4 = swap_nibbles(qp[4]);
+        const u32 g1 = gp[1], g2 = gp[2], g3 = gp[3], g4 = gp[4];
+        const u32 x0 = __builtin_amdgcn_alignbit(q1, qa, shq) ^ __builtin_amdgcn_alignbit(g1, ga, shg);
+        const u32 x1 = __builtin_amdgcn_alignbit(q2, q1, shq) ^ __builtin_amdgcn_alignbit(g2, g1, shg);
+        const u32 x2 = __builtin_amdgcn_alignbit(q3, q2, shq) ^ __builtin_amdgcn_alignbit(g3, g2, shg);
+        const u32 x3 = __builtin_amdgcn_alignbit(q4, q3, shq) ^ __builtin_amdgcn_alignbit(g4, g3, shg);
+        qa = q4;
+        ga = g4;
+        qp += 4;
+        gp += 4;
+        u32 M = (nibble_flags_top(x0) >> 3) & 0x11111111u;
+        M = bfi(0x22222222u, nibble_flags_top(x1) >> 2, M);
+        M = bfi(0x44444444u, nibble_flags_top(x2) >> 1, M);
+        M = bfi(0x88888888u, nibble_flags_top(x3), M);
+        const int32_t r = l - 32 * grp;
+        M &= tail_mask[r < 32 ? r : 32];
+        cnt += (u32)__popc(M);
+        const bool nz = M != 0;
+        if (WL) {
+            mL = nz ? M : mL;
+            gL = nz ? grp : gL;
+        }
+        if (WF) {
+            const bool take = nz && mF == 0;
+            mF = take ? M : mF;
+            gF = take ? grp : gF;
+        }
+    }
+    B.mism = (int32_t)cnt;
+    B.first = WF && mF ? 32 * gF + packed_first(mF) : -1;
+    B.last = WL && mL ? 32 * gL + packed_last(mL) : -1;
+}
+
+// ONE launch per chain (25 launches of 13 - 690 us became 3): a block takes a range of the chain's consecutive trips -- (batch, chunk
+// of 256 list entries), a batch after the other; a chunk that two batches share is visited once for each, its lanes masked.  The
+// batch descriptors and the members' table are read through uniform indices (scalar loads).
+//   The kernel waits for memory, not for bandwidth (round 4's SQ counters: three quarters of the wave-cycles parked on s_waitcnt),
+// and a trip is a chain of dependent round trips: tile offsets -> list record -> operations and per-read fields -> bases -> stores.
+// So the trips are software-pipelined: while trip v is compared out of LDS, the list records and then the operations / fields
+// of trip v + 1 are already on their way (in registers), and ALL of a trip's staging loads (bases, three genome windows) are
+// issued together, behind one wait.
+#ifndef K1E_ABL
+#define K1E_ABL 0 // timing experiments only (tools/build_variants.sh): 1 no compares, 2 no candidates, 4 no staging (every compare gathers), 8 no list appends, 16 no gathering compares
+#endif
+#ifdef K1E_PROF // (debug builds: wave-cycles per section of k1_emit, summed over every wavefront; printed by pjb_destroy)
+__device__ unsigned long long g_k1e_prof[16];
+#define K1E_T0() unsigned long long prof_t = __builtin_amdgcn_s_memtime()
+#define K1E_MARK(i)                                                                  \
+    do {                                                                             \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime();                \
+        if (lane_id() == 0) atomicAdd(&g_k1e_prof[i], now_ - prof_t);                \
+        prof_t = now_;                                                               \
+    } while (0)
+#else
+#define K1E_T0() do {} while (0)
+#define K1E_MARK(i) do {} while (0)
+#endif
+constexpr int K1E_MAXB = 64; // batches one launch takes (the host splits longer lists)
+struct EmitRec { // a trip's list records (per lane)
+    bool on;
+    u32 slot, r, toff, poff;
+    uint4 sr;
+};
+struct EmitOps { // and what the records lead to: the read's first operations and its fixed-width fields
+    u32 op[OPS_LDS];
+    u32 n, flag, xs, mapq;
+    int32_t mtid, mpos, lq;
+};
+struct EmitTrip { // (uniform)
+    int bi;
+    u32 chunk, s_begin, s_end;
+};
+__global__ __launch_bounds__(K1E_T) __attribute__((amdgpu_waves_per_eu(K1E_WAVES, K1E_WAVES))) void k1_emit(const DevBatch *batches, int n_batches, u32 n_tiles_total, const u32 *tile_off, const u32 *tile_soff,
                                                 const u32 *chunk_tile, const u32 *spl_idx, const u32 *spl_poff, const uint4 *spl_rec, Pairs P, EmitLists E, KeyFmt kf,
-                                                int32_t ref_len, int32_t tid, int orientation, u64 *err, ContigStats *cs, int32_t voff,
-                                                const u32 *gcodes) {
+                                                GroupTab G, int use_codes, int orientation, u64 *err, ContigStats *cs) {
     __shared__ u32 s_soff[K1E_LOOK];
     __shared__ EmitShared sh;
+    __shared__ EmitStage s_stage[K1E_T / 64];
+    __shared__ u32 s_cfirst[K1E_MAXB + 1]; // trips before batch i
+    __shared__ u32 s_sbegin[K1E_MAXB + 1]; // list entries before batch i (batches follow each other in the tiles' space)
+    __shared__ u32 s_seqw[K1E_MAXB], s_cigw[K1E_MAXB], s_tbase[K1E_MAXB]; // words of packed bases / operations in batch i; its first tile
+    __shared__ u32 s_wsum[4];
+    __shared__ u32 s_tail[33]; // cmp_block_lds's masks of a block's last group
     if (cs->P == 0) return; // no pairs, or a limit was exceeded: the contig is repeated with larger buffers
-    const u32 s_begin = tile_soff[b.tile_base], s_end = tile_soff[b.tile_base + n_tiles_batch];
-    if (s_begin == s_end) return;
-    const u32 c_lo = s_begin >> K1E_SHIFT, c_hi = (s_end + (u32)K1E_T - 1u) >> K1E_SHIFT; // trips of K1E_T list entries
+    K1E_T0();
     const bool want_cand = E.cand != nullptr;
-    const int32_t vlen = voff + ref_len; // the target's end in the group's virtual sequence
-    const u32 seq_words = b.seq_off[b.n]; // words of packed bases in the batch: no compare reads past them
-    const u32 cig_words = b.cig_off[b.n]; // operations in the batch
     EmitCtx ctx{sh, E, kf, cs, want_cand};
     ctx.init();
+    if (threadIdx.x < 33) s_tail[threadIdx.x] = k1e_tail_mask_word(threadIdx.x);
     auto cand_insert = [&](u64 k, int32_t lstart, int32_t rend) { ctx.cand_insert(k, lstart, rend); };
-    for (u32 chunk = c_lo + blockIdx.x; chunk < c_hi; chunk += gridDim.x) {
-        // the tile of the chunk's first entry (for the batch's first chunk: of the batch's first entry)
-        u32 t0 = (chunk << K1E_SHIFT) < s_begin ? b.tile_base : chunk_tile[chunk >> (8 - K1E_SHIFT)]; // (chunk_tile: the tile of entry 256 c)
+    {
+        u32 trips = 0;
+        if ((int)threadIdx.x < n_batches) {
+            const PJB_GLOBAL DevBatch *d = as_global(batches + threadIdx.x);
+            const u32 tb = d->tile_base, nt = (u32)((d->n + K1_TILE - 1) / K1_TILE);
+            const u32 sb = tile_soff[tb], se = tile_soff[tb + nt];
+            trips = sb == se ? 0u : ((se + (u32)K1E_T - 1u) >> K1E_SHIFT) - (sb >> K1E_SHIFT);
+            s_sbegin[threadIdx.x] = sb;
+            if ((int)threadIdx.x == n_batches - 1) s_sbegin[n_batches] = se;
+            s_seqw[threadIdx.x] = as_global(d->seq_off)[d->n];
+            s_cigw[threadIdx.x] = as_global(d->cig_off)[d->n];
+            s_tbase[threadIdx.x] = tb;
+        }
+        u32 total;
+        const u32 ex = block_escan<K1E_T / 64>(trips, s_wsum, &total);
+        if (threadIdx.x < (u32)K1E_MAXB) s_cfirst[threadIdx.x] = ex;
+        if (threadIdx.x == K1E_T - 1) s_cfirst[K1E_MAXB] = total;
         __syncthreads();
-        if (threadIdx.x < K1E_LOOK) s_soff[threadIdx.x] = t0 + threadIdx.x <= n_tiles_total ? tile_soff[t0 + threadIdx.x] : 0xffffffffu;
-        __syncthreads();
-        const u32 s = (chunk << K1E_SHIFT) + threadIdx.x;
-        const bool on = s >= s_begin && s < s_end;
-        // Every read's list record, five gathers and first operations.  A read of the shape [S] M N M [S] or [S] M N M N M [S]
-        // (l_qseq matching, bases present) is finished here, in closed form (junction_system.cc:140-210 for one or two N
-        // operations); any other read goes on k1_generic's list: a few lanes of every wavefront walking their reads kept the
-        // whole block waiting (84 of 307 us a launch for one read in twenty).
-        bool generic = false;
-        bool p1_two = false; // a read of two introns finished in closed form: k4b_generic checks the junctions' windows (second list)
-        u64 p1_entry = 0, g3_entry = 0;
-        if (on) {
+    }
+    const u32 n_trips = s_cfirst[K1E_MAXB];
+    EmitStage &stg = s_stage[threadIdx.x >> 6];
+    // a block's trips are consecutive: the window of tile offsets (s_soff: 16 tiles ~ 18 trips) is fetched once and serves the trips
+    // behind it; consecutive trips share junctions, so the block's candidate set lists each of them once
+    const u32 per_block = (n_trips + gridDim.x - 1) / gridDim.x;
+    const u32 v_lo = min(n_trips, blockIdx.x * per_block), v_hi = min(n_trips, v_lo + per_block);
+    if (v_lo >= v_hi) return;
+    u32 win_t0 = 0xffffffffu; // the tile of s_soff[0] (none yet)
+    int win_bi = -1;
+    // ---- the trip's batch: the last one with s_cfirst <= v (uniform)
+    auto locate = [&](u32 v) {
+        static_assert(K1E_MAXB <= 64, "one ballot");
+        const int k = lane_id();
+        const u64 m = __ballot(k < n_batches && s_cfirst[k] <= v);
+        EmitTrip T;
+        T.bi = __builtin_amdgcn_readfirstlane(63 - __clzll((long long)m));
+        T.s_begin = s_sbegin[T.bi];
+        T.s_end = s_sbegin[T.bi + 1];
+        T.chunk = (T.s_begin >> K1E_SHIFT) + (v - s_cfirst[T.bi]);
+        return T;
+    };
+    // ---- a trip's list records (k1_count's by-product: no gathers of cig_off, pos, l_qseq, seq_off); every thread of the block calls
+    auto fetch_rec = [&](const EmitTrip &T) {
+        const u32 s_last = min((T.chunk + 1u) << K1E_SHIFT, T.s_end) - 1u;
+        // (the window is only written between two barriers below: reading it here needs none)
+        const bool reload = win_bi != T.bi || win_t0 == 0xffffffffu || s_last >= s_soff[K1E_LOOK - 1];
+        if (reload) { // the window of tile offsets: from the tile of the trip's first entry (for a batch's first chunk: of the batch's first entry)
+            win_t0 = (T.chunk << K1E_SHIFT) < T.s_begin ? s_tbase[T.bi] : chunk_tile[T.chunk >> (8 - K1E_SHIFT)]; // (chunk_tile: the tile of entry 256 c)
+            win_bi = T.bi;
+            const u32 mine = threadIdx.x < K1E_LOOK && win_t0 + threadIdx.x <= n_tiles_total ? tile_soff[win_t0 + threadIdx.x] : 0xffffffffu;
+            lds_barrier(); // (everybody is done with the old window)
+            if (threadIdx.x < K1E_LOOK) s_soff[threadIdx.x] = mine;
+            lds_barrier();
+        }
+        const u32 s = (T.chunk << K1E_SHIFT) + threadIdx.x;
+        EmitRec R;
+        R.on = s >= T.s_begin && s < T.s_end;
+        R.slot = R.r = R.toff = R.poff = 0;
+        R.sr = make_uint4(0, 0, 0, 0);
+        if (R.on) {
             u32 k = 0; // (the offsets ascend: the entry's tile is the number of them it has reached -- 15 independent LDS reads, not a walk)
 #pragma unroll
             for (int m = 1; m < K1E_LOOK; m++) k += s >= s_soff[m] ? 1u : 0u;
-            u32 tile = t0 + k, soff = s_soff[k];
+            u32 tile = win_t0 + k, soff = s_soff[k];
             if (k + 1 == (u32)K1E_LOOK && s >= soff) { // (a run of tiles without spliced reads longer than the window: search)
                 u32 lo = tile, hi = n_tiles_total; // tile_soff[lo] <= s < tile_soff[hi]
                 while (hi - lo > 1) {
@@ -1583,39 +2150,89 @@ __global__ __launch_bounds__(K1E_T) __attribute__((amdgpu_waves_per_eu(K1E_WAVES
                 tile = lo;
                 soff = tile_soff[lo];
             }
-            const u32 toff = tile_off[tile];
-            const size_t slot = (size_t)tile * K1_TILE + (s - soff);
-            const int64_t r = spl_idx[slot];
-            const uint4 sr = spl_rec[slot]; // (k1_count's by-product: no gathers of cig_off, pos, l_qseq, seq_off)
-            const u32 c0 = sr.x;
-            u32 n = sr.w & 0x7fffu;
-            if (n == 0x7fffu) n = b.cig_off[r + 1] - c0;
-            u32 op[OPS_LDS];
-            static_assert(OPS_LDS == 8, "two 16-byte loads");
-            if (c0 + (u32)OPS_LDS <= cig_words) { // the read's first eight operations: two 16-byte loads (whatever lies behind its last one is masked)
-                const Words4 lo4 = gload(reinterpret_cast<const Words4 *>(b.cigar + c0)), hi4 = gload(reinterpret_cast<const Words4 *>(b.cigar + c0 + 4));
-                op[0] = lo4.x, op[1] = lo4.y, op[2] = lo4.z, op[3] = lo4.w, op[4] = hi4.x, op[5] = hi4.y, op[6] = hi4.z, op[7] = hi4.w;
+            R.slot = tile * (u32)K1_TILE + (s - soff);
+            R.sr = spl_rec[R.slot];
+            R.r = spl_idx[R.slot];
+            R.toff = tile_off[tile];
+            R.poff = spl_poff[R.slot];
+        }
+        return R;
+    };
+    // ---- and what they lead to: the read's first eight operations (two 16-byte loads; whatever lies behind its last one is masked
+    // by the consumer) and its five fields
+    auto fetch_ops = [&](const EmitTrip &T, const EmitRec &R) {
+        EmitOps O;
 #pragma unroll
-                for (int q = 0; q < OPS_LDS; q++) op[q] = (u32)q < n ? op[q] : 0u;
-            } else { // (the batch's last operations: word by word -- unconditional loads, masked: see k1_count)
+        for (int q = 0; q < OPS_LDS; q++) O.op[q] = 0;
+        O.n = O.flag = O.xs = O.mapq = 0;
+        O.mtid = O.mpos = O.lq = 0;
+        if (R.on) {
+            const GBatch b = load_batch(batches + T.bi);
+            const u32 c0 = R.sr.x, cig_words = s_cigw[T.bi];
+            const int64_t r = R.r;
+            u32 n = R.sr.w & 0x7fffu;
+            if (n == 0x7fffu) n = b.cig_off[r + 1] - c0;
+            O.n = n;
+            O.flag = b.flag[r];
+            O.xs = b.xs[r];
+            O.mapq = b.mapq[r];
+            O.mtid = b.mtid[r];
+            O.mpos = b.mpos[r];
+            O.lq = (int32_t)(R.sr.w >> 16);
+            if (O.lq == 0xffff) O.lq = b.l_qseq[r];
+            static_assert(OPS_LDS == 8, "two 16-byte loads");
+            // (the batch's last operations are read from the first word on: the loads never leave the array)
+            const u32 c0c = c0 + (u32)OPS_LDS <= cig_words ? c0 : (cig_words >= (u32)OPS_LDS ? cig_words - (u32)OPS_LDS : 0u);
+            const Words4 lo4 = gload_as<Words4>(b.cigar + c0c), hi4 = gload_as<Words4>(b.cigar + c0c + 4);
+            u32 w[OPS_LDS] = {lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z, hi4.w};
+            if (c0c != c0) { // (shifted: at most seven words)
+                const u32 sh = c0 - c0c;
 #pragma unroll
                 for (int q = 0; q < OPS_LDS; q++) {
-                    const bool has = (u32)q < n;
-                    const u32 v = *(has ? b.cigar + c0 + q : b.cig_off);
-                    op[q] = has ? v : 0u;
+                    u32 v = 0;
+#pragma unroll
+                    for (int j = q; j < OPS_LDS; j++) v = (u32)(j - q) == sh ? w[j] : v;
+                    w[q] = v;
                 }
             }
-            const int32_t pos = (int32_t)sr.y;
-            const u32 g = b.base + (u32)r;
-            const u32 off = toff + spl_poff[slot];
-            u32 meta = read_meta(b.flag[r], (u32)b.xs[r], b.mapq[r], pos, b.mtid[r], b.mpos[r], tid, orientation);
-            int32_t lq = (int32_t)(sr.w >> 16);
-            if (lq == 0xffff) lq = b.l_qseq[r];
-            const u32 so = sr.z;
-            const bool seq_ok = (sr.w & 0x8000u) != 0;
+#pragma unroll
+            for (int q = 0; q < OPS_LDS; q++) O.op[q] = w[q];
+        }
+        return O;
+    };
+    K1E_MARK(0); // block start: tables
+    EmitTrip T = locate(v_lo);
+    EmitRec R = fetch_rec(T);
+    EmitOps O = fetch_ops(T, R);
+    K1E_MARK(1); // prologue: first trip's records and operations issued
+    for (u32 v = v_lo; v < v_hi; v++) {
+        const GBatch b = load_batch(batches + T.bi);
+        const int mem = b.member;
+        const int32_t voff = G.voff[mem], ref_len = G.len[mem], tid = G.tid[mem];
+        const PJB_GLOBAL u32 *gcodes = use_codes ? as_global(G.codes[mem]) : (const PJB_GLOBAL u32 *)nullptr;
+        const int32_t vlen = voff + ref_len; // the target's end in the group's virtual sequence
+        const u32 seq_words = s_seqw[T.bi];  // words of packed bases in the batch: nothing reads past them
+        const int32_t g_words = (ref_len + 7) / 8 + 1;
+        const u32 chunk = T.chunk;
+        const bool on = R.on;
+        const u32 so = R.sr.z;
+        const int32_t pos = (int32_t)R.sr.y, lq = O.lq;
+        // A read of the shape [S] M N M [S] or [S] M N M N M [S] (l_qseq matching, bases present) is finished here, in closed form
+        // (junction_system.cc:140-210 for one or two N operations); any other read goes on k1_generic's list: a few lanes of every
+        // wavefront walking their reads kept the whole block waiting (84 of 307 us a launch for one read in twenty).
+        bool generic = false, simple = false, two = false;
+        u64 g3_entry = 0;
+        u32 dS = 0, a = 0, nl = 0, b2 = 0, nl2 = 0, b3 = 0, meta = 0, off = 0, g = 0;
+        if (on) {
+            const u32 n = O.n;
+            u32 op[OPS_LDS];
+#pragma unroll
+            for (int q = 0; q < OPS_LDS; q++) op[q] = (u32)q < n ? O.op[q] : 0u;
+            g = b.base + R.r;
+            off = R.toff + R.poff;
+            meta = read_meta(O.flag, O.xs, O.mapq, pos, O.mtid, O.mpos, tid, orientation);
+            const bool seq_ok = (R.sr.w & 0x8000u) != 0;
             // ---- shape: [S] M N M [S], or -- two introns, nothing clamped -- [S] M N M N M [S]
-            bool simple = false, two = false;
-            u32 dS = 0, a = 0, nl = 0, b2 = 0, nl2 = 0, b3 = 0;
             if (gcodes != nullptr && n >= 3 && n <= 7) {
                 const bool clipF = (op[0] & 15u) == OP_S;
                 const u32 i0 = clipF ? 1u : 0u;
@@ -1640,67 +2257,170 @@ __global__ __launch_bounds__(K1E_T) __attribute__((amdgpu_waves_per_eu(K1E_WAVES
                                  (int64_t)pos + a + nl + b2 + nl2 + b3 <= (int64_t)ref_len;
                 }
             }
-            if (simple) {
-                const int32_t vpos = pos + voff;
-                const int32_t aend_all = vpos + (int32_t)(a + nl + b2 + nl2 + b3) - 1;
-                const u32 *seqw = reinterpret_cast<const u32 *>(b.seq4) + so;
-                int32_t lst = vpos;  // the left block of the pair: where it starts, its query offset, its length; intron; right block
-                int32_t qoff = (int32_t)dS;
-                u32 la = a, ln_ = nl, lb = b2;
-                CmpBlock blkL = {0, 0, -1, -1};
-                for (u32 pr = 0; pr < (two ? 2u : 1u); pr++) {
-                    const int32_t istart = lst + (int32_t)la;
-                    const int32_t rStartU = istart + (int32_t)ln_;
-                    int32_t rStart = rStartU;
-                    if (rStart - 1 >= vlen) rStart = vlen - 1; // junction_system.cc:169-171
-                    const int32_t iend = rStart - 1;
-                    int32_t rEndExc = rStartU + (int32_t)lb;
-                    if (rEndExc - 1 >= vlen) rEndExc = vlen; // junction_system.cc:172-174
-                    if (rEndExc - 1 < iend) set_error(err, g, PJB_ERR_MIN_ANCHOR); // intron.cc:76
-                    const u64 key = make_key(kf, istart, iend);
-                    PairRec R;
-                    R.lstart = lst;
-                    R.rend = rEndExc - 1;
-                    R.pos = vpos;
-                    R.aend = aend_all;
-                    R.meta = meta | META_SIMPLE | (two ? META_MULTI : 0u);
-                    // junction.cc:795-812.  One N operation: nothing upstream; "downstream" counts the operation itself unless its end was
-                    // clamped.  Two: the first has the second downstream, the second the first upstream.
-                    R.updown = two ? (pr == 0 ? (1u << 16) : 1u) : (rStartU <= iend + 1 ? 0u : (1u << 16));
-                    // the anchors' match statistics: every block of bases is compared once -- the block between two introns is the first
-                    // pair's right anchor and the second pair's left one
-                    {
-                        const int32_t q_limit = (int32_t)min(seq_words - 1u - so, 0x7fffffffu), g_words = (ref_len + 7) / 8 + 1;
-                        if (pr == 0) {
-                            blkL = CmpBlock{(int32_t)la, 0, -1, -1};
-                            cmp_words<SIMPLE_NW, true>(seqw, qoff, q_limit, gcodes, lst - voff, g_words, (int32_t)la, 0, blkL.mism, blkL.first, blkL.last);
-                        }
-                        CmpBlock blkR = {R.rend - iend, 0, -1, -1};
-                        cmp_words<SIMPLE_NW, true>(seqw, qoff + (int32_t)la, q_limit, gcodes, iend + 1 - voff, g_words, blkR.len, 0, blkR.mism, blkR.first, blkR.last);
-                        R.aux = cmp_blocks_res(blkL, blkR);
-                        blkL = blkR;
-                    }
-                    P.key[off + pr] = key;
-                    if (P.g) P.g[off + pr] = g;
-                    rec_store(P.rec + off + pr, R);
-                    if (want_cand) cand_insert(key, R.lstart, R.rend);
-                    lst = rStart;
-                    qoff += (int32_t)la;
-                    la = lb;
-                    ln_ = nl2;
-                    lb = b3;
-                }
-                p1_two = two;
-                p1_entry = (u64)(E.pack_nn ? g | (2u << 28) : g) | ((u64)off << 32);
-            } else {
+            two = two && simple;
+            if (!simple) {
                 generic = true;
-                g3_entry = (u64)(u32)slot | ((u64)off << 32); // (the read's place in the tiles' lists, its first pair)
+                g3_entry = (u64)R.slot | ((u64)off << 32); // (the read's place in the tiles' lists, its first pair)
             }
         }
         const u32 shard = (chunk >> (8 - K1E_SHIFT)) % GEN_SHARDS;
-        ctx.list_append(2, p1_two, 2u, p1_entry, shard);
-        ctx.list_append(3, generic, 0u, g3_entry, shard);
-        ctx.cand_flush(chunk + gridDim.x >= c_hi);
+        const u32 base2 = ctx.list_reserve(2, two, 2u, shard), base3 = ctx.list_reserve(3, generic, 0u, shard);
+        K1E_MARK(2); // shapes (waits for the operations)
+        // ---- staging (the whole wavefront): the reads' bases and the genome under their blocks of bases, all on their way at once.  A
+        // lane takes part if its alignment lies inside its target (nothing clamped) and none of its blocks is longer than a window.
+        constexpr u32 WIN_BASES = ((u32)K1E_GENW - 8u) * 8u;
+        const bool lds_ok = simple && pos >= 0 && (int64_t)pos + a + nl + b2 + nl2 + b3 <= (int64_t)ref_len && a <= WIN_BASES && b2 <= WIN_BASES && b3 <= WIN_BASES;
+        int32_t q_w0 = 0;
+        bool staged = false;
+        {
+            const u32 nwq = ((u32)lq + 7u) >> 3;
+            const u32 q_lo = wave_total<DppMin>(lds_ok ? so : 0xffffffffu), q_hi = wave_total<DppMax>(lds_ok ? so + nwq : 0u);
+            K1E_MARK(10); // (span of the bases)
+            if (!(K1E_ABL & 4) && q_lo < q_hi && q_hi - q_lo <= (u32)K1E_SEQW - 3u && q_hi <= seq_words) {
+                staged = true;
+                const u32 shq = stage_span<K1E_SEQW>(stg.seq, (const PJB_GLOBAL u32 *)b.seq4, q_lo, q_hi - q_lo, seq_words);
+                q_w0 = (int32_t)(so - q_lo + shq);
+                K1E_MARK(11); // (bases issued)
+            }
+        }
+        // One read's pairs in closed form (junction_system.cc:140-210 for one or two N operations).  LDS: its blocks of bases are
+        // compared out of the staged windows (g_ofs*); else with the gathers of cmp_words.
+        const u32 *seqw = (const u32 *)b.seq4 + so;
+        const int32_t q_limit = (int32_t)min(seq_words - 1u - so, 0x7fffffffu);
+        auto emit_simple = [&](auto lds_tag, int32_t g_ofs0, int32_t g_ofs1, int32_t g_ofs2) {
+            constexpr bool LDS = decltype(lds_tag)::value;
+            const int32_t vpos = pos + voff;
+            const int32_t aend_all = vpos + (int32_t)(a + nl + b2 + nl2 + b3) - 1;
+            // one block of bases: read [q, q + len) against the target's [gl, gl + len)
+            auto cmp_block = [&](int k, int32_t q, int32_t gl, CmpBlock &B) {
+#if K1E_ABL & 1
+                return;
+#endif
+                if constexpr (LDS)
+                    cmp_block_lds<true, true>(stg.seq, q_w0, q, stg.gen[k][0], k == 0 ? g_ofs0 : k == 1 ? g_ofs1 : g_ofs2, gl, B.len, s_tail, B);
+                else if (!(K1E_ABL & 16))
+                    cmp_words<SIMPLE_NW, true>(seqw, q, q_limit, (const u32 *)gcodes, gl, g_words, B.len, 0, B.mism, B.first, B.last);
+            };
+            int32_t lst = vpos;  // the left block of the pair: where it starts, its query offset, its length; intron; right block
+            int32_t qoff = (int32_t)dS;
+            u32 la = a, ln_ = nl, lb = b2;
+            CmpBlock blkL = {0, 0, -1, -1};
+            for (u32 pr = 0; pr < (two ? 2u : 1u); pr++) {
+                const int32_t istart = lst + (int32_t)la;
+                const int32_t rStartU = istart + (int32_t)ln_;
+                int32_t rStart = rStartU;
+                if (rStart - 1 >= vlen) rStart = vlen - 1; // junction_system.cc:169-171
+                const int32_t iend = rStart - 1;
+                int32_t rEndExc = rStartU + (int32_t)lb;
+                if (rEndExc - 1 >= vlen) rEndExc = vlen; // junction_system.cc:172-174
+                if (rEndExc - 1 < iend) set_error(err, g, PJB_ERR_MIN_ANCHOR); // intron.cc:76
+                const u64 key = make_key(kf, istart, iend);
+                PairRec Q;
+                Q.lstart = lst;
+                Q.rend = rEndExc - 1;
+                Q.pos = vpos;
+                Q.aend = aend_all;
+                Q.meta = meta | META_SIMPLE | (two ? META_MULTI : 0u);
+                // junction.cc:795-812.  One N operation: nothing upstream; "downstream" counts the operation itself unless its end was
+                // clamped.  Two: the first has the second downstream, the second the first upstream.
+                Q.updown = two ? (pr == 0 ? (1u << 16) : 1u) : (rStartU <= iend + 1 ? 0u : (1u << 16));
+                // the anchors' match statistics: every block of bases is compared once -- the block between two introns is the first
+                // pair's right anchor and the second pair's left one
+                {
+                    if (pr == 0) {
+                        blkL = CmpBlock{(int32_t)la, 0, -1, -1};
+                        cmp_block(0, qoff, lst - voff, blkL);
+                    }
+                    CmpBlock blkR = {Q.rend - iend, 0, -1, -1};
+                    cmp_block((int)pr + 1, qoff + (int32_t)la, iend + 1 - voff, blkR);
+                    Q.aux = cmp_blocks_res(blkL, blkR);
+                    blkL = blkR;
+                }
+                P.key[off + pr] = key;
+                if (P.g) P.g[off + pr] = g;
+                rec_store(P.rec + off + pr, Q);
+#if !(K1E_ABL & 2)
+                if (want_cand) cand_insert(key, Q.lstart, Q.rend);
+#endif
+                lst = rStart;
+                qoff += (int32_t)la;
+                la = lb;
+                ln_ = nl2;
+                lb = b3;
+            }
+        };
+        // ---- passes over the wavefront's loci.  Window A of a block of bases starts at the block of the first lane that is still to
+        // do, window B at the block of the first lane A does not hold (the reads of a wavefront are position-sorted: mostly one
+        // locus, often two, seldom more -- the lanes of each next to each other); a lane is done in the pass that holds all of its
+        // blocks, and the first lane to do always is: the passes end.  The next trip's list records go out behind the first pass's
+        // staging loads, its operations and fields behind the first wait: they are in flight while this trip is compared.
+        const bool more = v + 1 < v_hi;
+        EmitTrip Tn = T;
+        EmitRec Rn = R;
+        EmitOps On = O;
+        bool todo = staged && lds_ok;
+        for (int pass = 0;; pass++) {
+            u32 in_win = 0; // bit k: the lane's block k is in a window
+            int32_t g_ofs0 = 0, g_ofs1 = 0, g_ofs2 = 0;
+            if (staged) {
+                const u32 gs0 = (u32)pos, gs1 = (u32)pos + a + nl, gs2 = gs1 + b2 + nl2; // the blocks' first bases (target coordinates)
+                auto window = [&](int k, bool has, u32 gstart, u32 len, int32_t &g_ofs) {
+                    const u64 bal = __ballot(has);
+                    if (bal == 0) return;
+                    const u32 w0 = gstart >> 3, w1 = ((gstart + len - 1u) >> 3) + 1u; // (the word behind the block's last feeds the funnel shift)
+                    const u32 loA = (u32)__builtin_amdgcn_readlane((int)w0, __ffsll((long long)bal) - 1);
+                    const int32_t ofsA = (int32_t)stage_span<K1E_GENW>(stg.gen[k][0], gcodes, loA, min((u32)K1E_GENW, (u32)g_words - loA), (u32)g_words) - (int32_t)loA;
+                    const bool inA = has && w0 >= loA && w1 < loA + (u32)K1E_GENW - 3u;
+                    const u64 rest = bal & ~__ballot(inA);
+                    bool inB = false;
+                    int32_t ofsB = 0;
+                    if (rest) {
+                        const u32 loB = (u32)__builtin_amdgcn_readlane((int)w0, __ffsll((long long)rest) - 1);
+                        ofsB = (int32_t)stage_span<K1E_GENW>(stg.gen[k][1], gcodes, loB, min((u32)K1E_GENW, (u32)g_words - loB), (u32)g_words) - (int32_t)loB +
+                               (int32_t)(K1E_GENW + K1E_SLACK);
+                        inB = has && !inA && w0 >= loB && w1 < loB + (u32)K1E_GENW - 3u;
+                    }
+                    g_ofs = inA ? ofsA : ofsB; // (word index from stg.gen[k][0])
+                    if (inA || inB) in_win |= 1u << k;
+                };
+                window(0, todo, gs0, a, g_ofs0);
+                window(1, todo, gs1, b2, g_ofs1);
+                window(2, todo && two, gs2, b3, g_ofs2);
+            }
+            if (pass == 0) {
+                K1E_MARK(3); // staging issued
+                if (more) {
+                    Tn = locate(v + 1);
+                    Rn = fetch_rec(Tn);
+                }
+                K1E_MARK(4); // next records issued
+            }
+            if (staged || (pass == 0 && more)) stage_wait();
+            if (pass == 0) {
+                K1E_MARK(5); // the wait
+                if (more) On = fetch_ops(Tn, Rn);
+                K1E_MARK(6); // next operations issued
+            }
+            const u32 need = two ? 7u : 3u;
+            const bool now = todo && (in_win & need) == need;
+            if (now) emit_simple(std::true_type{}, g_ofs0, g_ofs1, g_ofs2);
+            todo = todo && !now;
+            if (pass + 1 >= K1E_PASSES || !__ballot(todo)) break;
+        }
+        // (what the windows did not hold -- a third locus in the wavefront, clamped ends, long blocks, long reads: the gathers)
+        if (simple && (todo || !(staged && lds_ok))) emit_simple(std::false_type{}, 0, 0, 0);
+        const u64 p1_entry = (u64)(E.pack_nn ? g | (2u << 28) : g) | ((u64)off << 32);
+        K1E_MARK(7); // compares, records, candidates
+        ctx.list_write(2, two, base2, p1_entry, shard);
+        ctx.list_write(3, generic, base3, g3_entry, shard);
+        K1E_MARK(8); // list entries
+        // (the candidate set is flushed when the block leaves: a set that fills up before that sends its keys straight to the list --
+        // cand_insert -- and no barrier ties the block's wavefronts together trip by trip)
+        if (!more) ctx.cand_flush(true);
+        K1E_MARK(9); // candidate flush (barrier)
+        T = Tn;
+        R = Rn;
+        O = On;
     }
 }
 

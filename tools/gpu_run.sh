@@ -8,6 +8,7 @@
 #   bench            bench.py with default flags, as the driver runs it                       -> gpurun_out/<TAG>_bench_C3.json
 #   prof             tools/profile_round.sh: rocprofv3 kernel stats + FETCH/WRITE PMC passes + the bench line
 #   sq               SQ issue / stall counters per kernel (tools/pmc_sq.sh), condensed by tools/show_sq.py
+#   sqv:<variant>    instruction counts per kernel (the first two counter groups of pmc_sq.sh) of tools/variants/libpjb_<variant>.so
 #   fuzz             the three fuzz campaigns (tests/fuzz_campaign.py, fuzz_groups.py, fuzz_extra.py)
 #   cmd:<shell>      anything else
 # TAG (environment, default r04) names the outputs; COMMIT is recorded in the PMC summary.
@@ -30,6 +31,7 @@ for step in "$@"; do
            python3 tools/show_bench.py $OUT/${TAG}_bench_C3.json ;;
     prof) bash tools/profile_round.sh $TAG ${COMMIT:-unknown}; python3 tools/show_bench.py $OUT/${TAG}_bench_C3.json ;;
     sq) bash tools/pmc_sq.sh $TAG > $OUT/${TAG}_sq_summary.csv 2>&1; python3 tools/show_sq.py $OUT/sq_$TAG/summary.csv | tee $OUT/${TAG}_sq.txt ;;
+    sqv:*) v=${step#sqv:}; PJB_BENCH_ABLATION=1 PJB_LIB_PATH=$PWD/tools/variants/libpjb_$v.so SQ_GROUPS=2 bash tools/pmc_sq.sh ${TAG}_$v > $OUT/${TAG}_sq_${v}_summary.csv 2>&1; python3 tools/show_sq.py $OUT/sq_${TAG}_$v/summary.csv | head -4 | tee $OUT/${TAG}_sq_$v.txt ;;
     fuzz) ( timeout 1500 python tests/fuzz_campaign.py; timeout 900 python tests/fuzz_groups.py; timeout 900 python tests/fuzz_extra.py ) 2>&1 | tail -30 | tee $OUT/${TAG}_fuzz.txt ;;
     cmd:*) bash -c "${step#cmd:}" ;;
     *) echo "unknown step $step"; rc=2 ;;
