@@ -439,16 +439,35 @@ def main():
         # HBM bytes per launch from the PMC counters (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 --pmc passes of
         # this same command: tools/pmc_traffic.sh -> tools/summarize_pmc.py).  Counters cannot be read from inside
         # the process; the committed measurement for this workload is attached with the commit it was taken at.
+        # A committed figure describes the kernels it was measured on: it carries the hash of portcullis_amd/csrc/ at that time
+        # (tools/csrc_hash.py) and is dropped when the working tree's kernels differ.
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic_latest.json")
+        here_hash = csrc_hash()
         if world == 1 and args.reads == 200_000_000 and os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
                 if tj.get("_workload") == "C3":
                     tr = tj.get("pjb::" + dom["name"])
-                    if tr:
+                    if tr and tj.get("_csrc_hash") == here_hash:
                         roofline["traffic"] = tr["hbm_bytes_per_launch"]
                         roofline["traffic_source"] = ("profiles/pmc_traffic_latest.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
-                                                      f"passes of this command at commit {tj.get('_commit', '?')})")
+                                                      f"passes of this command at commit {tj.get('_commit', '?')}, csrc hash {here_hash})")
+                    elif tr:
+                        roofline["traffic_source"] = (f"none: profiles/pmc_traffic_latest.json was measured on other kernels (csrc hash "
+                                                      f"{tj.get('_csrc_hash', 'unrecorded')}, this tree {here_hash})")
+            except Exception:
+                pass
+        # the third reading of the same kernel: algorithmic bytes over the rocprofv3 --kernel-trace --stats average of the committed
+        # summary (profiles/rocprof_latest.json, tools/profile_round.sh), if it was taken on these kernels
+        rpath = os.path.join(ROOT, "profiles", "rocprof_latest.json")
+        if world == 1 and args.reads == 200_000_000 and os.path.exists(rpath) and dom["alg_bytes"]:
+            try:
+                rj = json.load(open(rpath))
+                avg_ns = rj.get("kernels", {}).get("pjb::" + dom["name"], {}).get("avg_ns")
+                if rj.get("_workload") == "C3" and rj.get("_csrc_hash") == here_hash and avg_ns:
+                    roofline["avg_kernel_ms_rocprof"] = round(avg_ns * 1e-6, 5)
+                    roofline["frac_rocprof"] = round(dom["alg_bytes"] / (avg_ns * 1e-9) / 1e9 / PEAK_HBM_GBPS, 4)
+                    roofline["rocprof_source"] = f"profiles/rocprof_latest.json ({rj.get('_source', '?')}, commit {rj.get('_commit', '?')})"
             except Exception:
                 pass
 
@@ -515,11 +534,23 @@ def main():
                             "the roofline kernel's row is the one measured inside the timed region",
             "datagen_s": round(t_gen, 2),
         }
+        # a line from an ablation build or another library build says so: its results were not checked
+        if os.environ.get("PJB_BENCH_ABLATION") or os.environ.get("PJB_LIB_PATH"):
+            result["ablation"] = bool(os.environ.get("PJB_BENCH_ABLATION"))
+            result["lib_path"] = os.environ.get("PJB_LIB_PATH")
+            result["checked"] = not os.environ.get("PJB_BENCH_ABLATION")
         os.write(real_stdout, (json.dumps(result) + "\n").encode())
     ctx.set_row_mirror(0, 0)
     ctx.close()
     if multi:
         dist.destroy_process_group()
+
+
+def csrc_hash():
+    """sha256 (16 hex digits) over the kernel sources: what a committed PMC / rocprof figure must match to be quoted."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from csrc_hash import csrc_hash as h
+    return h(ROOT)
 
 
 def lpt_balance(reads, ranks, pd):

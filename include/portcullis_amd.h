@@ -197,8 +197,9 @@ typedef struct pjb_timing {
 int pjb_create(pjb_ctx **out, const pjb_config *cfg);
 void pjb_destroy(pjb_ctx *ctx);
 
-/* Message of the last failing call the CALLING THREAD made on a context (ctx == NULL: its last failing pjb_create).
- * Kept per thread: the piece calls below may run beside the context's other calls, and a thread reads its own failure. */
+/* Message of the last failing call the CALLING THREAD made on THIS context (ctx == NULL: its last failing pjb_create); the empty
+ * string if that thread's last failure was on another context or it has had none.  Kept per thread: the piece calls below may run
+ * beside the context's other calls, and a thread reads its own failure.  A successful call does not clear it. */
 const char *pjb_last_error(const pjb_ctx *ctx);
 
 /* Reference sequence lengths, indexed by BAM tid. */
@@ -279,7 +280,9 @@ int pjb_finish_group_end(pjb_ctx *ctx, const int32_t *tids, int32_t n_tids, pjb_
  *   "dense_ids"  1 (default): the sort works on ordered dense junction ids; 0: on the full intron keys
  *   "extra_dense" 0 (default): PJB_FLAG_EXTRA answers depth and flanking counts from the unspliced records themselves
  *                (a few records per junction) and builds a target's per-base depth vector only where htslib's
- *                8000-record pileup cap may bite; 1: the depth vector for every target (round 2's path) */
+ *                8000-record pileup cap may bite; 1: the depth vector for every target (round 2's path)
+ *   "list_cap"   0 (default): the kernels' read lists get the room the pair limit implies; n > 0 (test hook): the first attempt
+ *                of every chain gets room for n entries per sub-list, so that the overflow-and-repeat path runs */
 int pjb_set_option(pjb_ctx *ctx, const char *name, int64_t value);
 
 /* All rows built so far, contig by contig in finish order, (start,end)-sorted

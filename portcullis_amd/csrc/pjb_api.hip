@@ -29,6 +29,7 @@ thread_local std::string g_create_error;
 // _inflate_done may run on other threads than the context's other calls, and a thread must neither read a string another
 // thread is reassigning nor report another thread's failure.
 thread_local std::string g_thread_error;
+thread_local const void *g_thread_error_ctx = nullptr; // the context the message belongs to (a thread may drive several)
 
 struct Buf {
     void *p = nullptr;
@@ -193,7 +194,7 @@ struct Flight {
     ContigLimits lim;
     int64_t n_reads = 0;
     u32 n_tiles = 0;
-    int attempt = 0;
+    int attempt = 0, list_attempt = 0;
     int n_pass = 0;
     const u32 *sidx = nullptr;
     const u32 *jid_sorted = nullptr; // junction id of every sorted pair
@@ -276,6 +277,7 @@ struct pjb_ctx {
     int64_t mirror_acc[5] = {0, 0, 0, INT32_MAX, 0}; // spliced, unspliced, sum_len, min_len, max_len
     pjb_timing timing;
     int radix_max_bits = 11;
+    u32 list_cap_forced = 0;          // pjb_set_option("list_cap", n): the read lists' first room (tests of the OVF_LISTS repeat)
     bool k1_serial = true;            // PJB_K1_SERIAL=0: the chains' K1 stages side by side
     hipEvent_t last_k1_ev = nullptr;  // the K1 stage of the chain queued last
     int k1s_blocks_forced = 0;                   // PJB_K1S_BLOCKS (tests): k1_scan_tiles on this many blocks -- 1: every tile in one block's rounds
@@ -318,6 +320,7 @@ int fail(pjb_ctx *c, int code, const char *fmt, ...) {
     va_end(ap);
     if (c) {
         g_thread_error = tmp;
+        g_thread_error_ctx = c;
         std::lock_guard<std::mutex> lk(c->err_mu);
         c->err = tmp;
     } else
@@ -847,7 +850,10 @@ void pjb_destroy(pjb_ctx *c) {
     delete c;
 }
 
-const char *pjb_last_error(const pjb_ctx *c) { return c ? g_thread_error.c_str() : g_create_error.c_str(); }
+const char *pjb_last_error(const pjb_ctx *c) {
+    if (!c) return g_create_error.c_str();
+    return g_thread_error_ctx == c ? g_thread_error.c_str() : ""; // (this thread's last failure on THIS context; none: the empty string)
+}
 
 int pjb_set_refs(pjb_ctx *c, int32_t n_refs, const int32_t *ref_len) {
     if (!c) return PJB_ERR_ARG;
@@ -1510,7 +1516,8 @@ static int queue_contig(pjb_ctx *c, Flight &f) {
     if ((rc = ensure(c, S.runstart, ((size_t)PL + 1) * 4))) return rc;
     if ((rc = ensure(c, S.ent, (size_t)PL * 8 + 16))) return rc;
     const u32 pair_blocks = std::max<u32>(1, (PL + 255) / 256);
-    const u32 gen_cap = std::max(gen_list_cap(PL), lim.list_cap); // entries per sub-list
+    // entries per sub-list (list_cap_forced: the test hook pjb_set_option("list_cap", n) -- a first attempt with a room that overflows)
+    const u32 gen_cap = lim.list_cap ? lim.list_cap : (c->list_cap_forced ? c->list_cap_forced : gen_list_cap(PL));
     const u32 pack_nn = (u64)f.n_reads < (1ull << 28) ? 1u : 0u; // (EmitLists::pack_nn)
     if ((rc = ensure(c, S.genlist, (size_t)gen_cap * GEN_SHARDS * 8 * 3))) return rc; // (three lists: EmitLists)
     if ((rc = ensure(c, S.gencount, GEN_SHARDS * GEN_CNT_STRIDE * 4))) return rc; // a line per sub-list: reads, pairs
@@ -1725,7 +1732,7 @@ static int queue_contig(pjb_ctx *c, Flight &f) {
         LAUNCH(c, "kd_table", kd_table, dim3(cand_blocks), dim3(256), (const u64 *)cand, (const u64 *)S.ent.p, (const u32 *)cand_rank, kf, JL,
                (const u32 *)S.ends.p, (const u32 *)S.firstid.p, (const u64 *)S.total.p, (u64 *)S.jkey.p, (int32_t *)S.ancl.p, (int32_t *)S.ancr.p, d_cs,
                (const u32 *)d_gen_cnt, gen_cap);
-        LAUNCH(c, "kd_assign", kd_assign, dim3(pair_blocks), dim3(256), okey, d_P, kf, (const u64 *)S.bitmap.p, (const u32 *)S.wrank.p,
+        LAUNCH(c, "kd_assign", kd_assign, dim3((pair_blocks + KDA_PER - 1) / KDA_PER), dim3(256), okey, d_P, kf, (const u64 *)S.bitmap.p, (const u32 *)S.wrank.p,
                (const u32 *)S.ends.p, (const u32 *)S.firstid.p, JL, (const u64 *)S.total.p, (u32 *)S.jidbam.p, (u32 *)S.acc.p, (const u64 *)S.jkey.p,
                (const int32_t *)S.ancl.p, (const int32_t *)S.ancr.p, d_err, d_cs);
         if ((rc = fork_k4b())) return rc;
@@ -1858,7 +1865,7 @@ static int queue_contig(pjb_ctx *c, Flight &f) {
                (u32 *)S.frag.p, (int32_t *)S.fragj.p, head_mask, run_mask, (const ContigStats *)d_cs, d_err);
         if ((rc = run_scan(c, "k2_runs", Popc64Fn{(const u64 *)run_mask}, ExclusiveU32Sink{run_base}, (u64)n_slices_lim, (u64 *)S.total.p, &d_cs->n_slices)))
             return rc;
-        LAUNCH(c, "k2_expand", k2_expand, dim3(pair_blocks), dim3(256), jid_sorted, (const u64 *)head_mask, (const u64 *)run_mask, (const u32 *)run_base,
+        LAUNCH(c, "k2_expand", k2_expand, dim3((pair_blocks + K2E_PER - 1) / K2E_PER), dim3(256), jid_sorted, (const u64 *)head_mask, (const u64 *)run_mask, (const u32 *)run_base,
                (const u64 *)S.total.p, (u32 *)S.seg.p, (u32 *)S.runfirst.p, (u32 *)S.runstart.p, d_cs);
         STAGE_EVENT(5);
         if ((rc = fork_entropy())) return rc;
@@ -2138,7 +2145,12 @@ static int collect_flight(pjb_ctx *c, pjb_region_result *res, bool *redo_single)
                             c->ref_len[(size_t)f.tids[(size_t)m]]);
         }
         if (!cs.overflow) break;
-        if (f.attempt >= 3) return fail(c, PJB_ERR_STATE, "finish: limits of target %d did not settle (overflow bits %u)", tid, cs.overflow);
+        // (a repeat for the read lists' room alone has a budget of its own: it must not use up the attempts the other limits may need)
+        if (cs.overflow == OVF_LISTS && f.list_attempt < 3) {
+            f.list_attempt++;
+            f.attempt--;
+        } else if (f.attempt >= 3)
+            return fail(c, PJB_ERR_STATE, "finish: limits of target %d did not settle (overflow bits %u)", tid, cs.overflow);
         // a limit was too small: the control block says by how much; everything is queued again (and so is the chain
         // queued behind this one: its rows went where this one's belong)
         unqueue_followers(c);
@@ -2169,7 +2181,7 @@ static int collect_flight(pjb_ctx *c, pjb_region_result *res, bool *redo_single)
         }
         if (cs.overflow & OVF_JUNC) lim.junc_limit = std::max<u32>(cs.n_junc + 64, (cs.overflow & OVF_DENSE) || !lim.dense ? 0u : lim.junc_limit * 4);
         if (cs.overflow & OVF_DENSE) lim.dense = false; // a donor with more alternative acceptors than K2d keeps: sort the full keys
-        if (cs.overflow & OVF_LISTS) lim.list_cap = (cs.list_need + cs.list_need / 4 + 511u) & ~255u; // (k1_generic's entries depend on the appends' order: some slack)
+        if (cs.overflow & OVF_LISTS) lim.list_cap = std::max(gen_list_cap(lim.pair_limit), (cs.list_need + cs.list_need / 4 + 511u) & ~255u); // (k1_generic's entries depend on the appends' order: some slack)
     }
     if (!lim.kf.raw) c->lbits_seen = std::max(c->lbits_seen, std::max(1, bits_of((uint64_t)cs.max_nlen)));
     const u32 P = cs.P, J = cs.J;
@@ -2627,6 +2639,7 @@ int pjb_set_option(pjb_ctx *c, const char *name, int64_t value) {
     if (n == "overlap") c->side_stream = value != 0;
     else if (n == "dense_ids") c->dense_ids = value != 0;
     else if (n == "extra_dense") c->extra_dense_only = value != 0;
+    else if (n == "list_cap") c->list_cap_forced = (u32)std::max<int64_t>(0, std::min<int64_t>(value, 1 << 30));
     else return fail(c, PJB_ERR_ARG, "set_option: unknown option '%s'", name);
     return PJB_OK;
 }

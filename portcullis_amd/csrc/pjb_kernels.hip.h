@@ -1708,8 +1708,11 @@ constexpr int K1E_LOOK = 16;
 #ifndef K1E_WAVES
 #define K1E_WAVES 4 // wavefronts per SIMD the register allocation aims at (tools/build_variants.sh builds the others for A/B runs)
 #endif
+#ifndef K1E_SET
+#define K1E_SET 1 // slots of the block's candidate set per thread (2: 8.82 against 8.75 ms a step)
+#endif
 constexpr int K1E_T = 256, K1E_SHIFT = 8; // threads of a block = list entries of one trip
-constexpr int KC_SLOTS = K1E_T * 2;     // the block's candidate set (LDS), flushed when a quarter full
+constexpr int KC_SLOTS = K1E_T * K1E_SET;     // the block's candidate set (LDS), flushed when a quarter full
 constexpr u64 KD_EMPTY = ~0ull; // no key: a packed key has fewer than 64 bits
 constexpr u32 GEN_SHARDS = 256, GEN_CNT_STRIDE = 32;
 struct EmitLists {
@@ -1735,7 +1738,11 @@ __host__ __device__ inline u32 gen_list_cap(u32 pair_limit) {
 // the fullest sub-list of the three lists' sub-lists `shard` (0: all within their room)
 __device__ __forceinline__ u32 lists_over(const u32 *gen_cnt, u32 shard, u32 cap) {
     const u32 a = gen_cnt[shard * GEN_CNT_STRIDE], b = gen_cnt[shard * GEN_CNT_STRIDE + 2], c = gen_cnt[shard * GEN_CNT_STRIDE + 4];
-    const u32 m = a > b ? (a > c ? a : c) : (b > c ? b : c);
+    // (the entries of list 3 that found no room were not walked by k1_generic: each of them would have gone on list 1 or 2 -- an
+    // upper bound, so that ONE repeat settles the lists)
+    const u32 dropped = c > cap ? c - cap : 0u;
+    const u32 ab = (a > b ? a : b) + dropped;
+    const u32 m = ab > c ? ab : c;
     return m > cap ? m : 0u;
 }
 // What k1_emit and k1_generic share: the block's candidate set (LDS) and the appends to k4b_generic's / k1_generic's lists.
@@ -1883,19 +1890,21 @@ struct EmitCtx {
 #define K1E_PASSES 1 // passes over the wavefront's loci (two windows each) before the gathers take what is left.  (More passes were
                      // measured: a second pass costs another round trip of staging loads -- frac_alone 0.56 against 0.61.)
 #endif
-#ifndef K1E_SEQ_LAST
-#define K1E_SEQ_LAST 0
-#endif
-#ifndef K1E_REGSTAGE
-#define K1E_REGSTAGE 0
-#endif
 #ifndef K1E_LDS_NW
 #define K1E_LDS_NW 5  // words per stream and round of the LDS compare (32 bases a round)
 #endif
 constexpr int K1E_SLACK = 8; // a round may read this many words past what its block needs (masked)
+#ifndef K1E_STAGE
+#define K1E_STAGE 0 // 1: the wavefront's bases and genome windows through LDS (measured, round 5: 8.82 ms a step against 8.33 for the
+                    // gathers -- the kernel waits for memory round trips and for VALU issue, not for the bytes of its gathers; kept for the record)
+#endif
 struct __attribute__((aligned(16))) EmitStage { // one per wavefront
+#if K1E_STAGE
     u32 seq[K1E_SEQW + K1E_SLACK];
     u32 gen[3][2][K1E_GENW + K1E_SLACK]; // two windows per block of bases: a wavefront often holds the reads of two loci
+#else
+    u32 seq[4], gen[3][2][4];
+#endif
 };
 // words [first, first + count) of `src` to dst[shift ...], shift (returned) = words between the 16-byte boundary at or below
 // src + first and it; `exist` = words of src there are (nothing is read past them).  The whole wavefront calls.  The loads go
@@ -1909,27 +1918,6 @@ __device__ __forceinline__ u32 stage_span(u32 *dst, const PJB_GLOBAL u32 *src, u
     const u32 total = count + shift;         // words from the aligned start
     const u32 avail = exist - first + shift; // words that exist from there
     constexpr int ITERS = (MAXW + 3 + 255) / 256;
-#if K1E_REGSTAGE // (experiment: through registers)
-    uint4 v[ITERS];
-#pragma unroll
-    for (int it = 0; it < ITERS; it++) {
-        const u32 i = (u32)it * 256u + (u32)lane_id() * 4u;
-        const u32 ic = i + 4u <= avail && i < total ? i : 0u;
-        v[it] = gload_as<uint4>(p + (ic >> 2));
-    }
-#pragma unroll
-    for (int it = 0; it < ITERS; it++) {
-        const u32 i = (u32)it * 256u + (u32)lane_id() * 4u;
-        if (i + 4u <= avail && i < total) *reinterpret_cast<uint4 *>(dst + i) = v[it];
-        else if (i < avail && i < total) {
-            const PJB_GLOBAL u32 *w = (const PJB_GLOBAL u32 *)p + i;
-            dst[i] = w[0];
-            if (i + 1u < avail) dst[i + 1] = w[1];
-            if (i + 2u < avail) dst[i + 2] = w[2];
-        }
-    }
-    return shift;
-#endif
 #pragma unroll
     for (int it = 0; it < ITERS; it++) {
         if ((u32)it * 256u < total) { // (uniform)
@@ -2276,7 +2264,7 @@ __global__ __launch_bounds__(K1E_T) __attribute__((amdgpu_waves_per_eu(K1E_WAVES
             const u32 nwq = ((u32)lq + 7u) >> 3;
             const u32 q_lo = wave_total<DppMin>(lds_ok ? so : 0xffffffffu), q_hi = wave_total<DppMax>(lds_ok ? so + nwq : 0u);
             K1E_MARK(10); // (span of the bases)
-            if (!(K1E_ABL & 4) && q_lo < q_hi && q_hi - q_lo <= (u32)K1E_SEQW - 3u && q_hi <= seq_words) {
+            if (K1E_STAGE && !(K1E_ABL & 4) && q_lo < q_hi && q_hi - q_lo <= (u32)K1E_SEQW - 3u && q_hi <= seq_words) {
                 staged = true;
                 const u32 shq = stage_span<K1E_SEQW>(stg.seq, (const PJB_GLOBAL u32 *)b.seq4, q_lo, q_hi - q_lo, seq_words);
                 q_w0 = (int32_t)(so - q_lo + shq);
@@ -2792,6 +2780,7 @@ __device__ __forceinline__ void acc_rest_state(u32 *acc, u64 n_junc) { // what k
     for (u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += step) acc[t] = (t % F_WORDS) == F_FIRSTMIS ? 100000000u : 0u;
 }
 
+constexpr int KDA_PER = 4;
 __global__ __launch_bounds__(256) void kd_assign(const u64 *key, const u32 *np, KeyFmt kf, const u64 *bitmap, const u32 *wrank, const u32 *ends,
                                                  const u32 *first_id, u32 junc_limit, const u64 *total, u32 *jid_bam, u32 *acc, const u64 *jkey,
                                                  const int32_t *anc_l, const int32_t *anc_r, u64 *err, ContigStats *cs_chk) {
@@ -2801,14 +2790,59 @@ __global__ __launch_bounds__(256) void kd_assign(const u64 *key, const u32 *np, 
         const u64 J = *total;
         acc_rest_state(acc, J < (u64)junc_limit ? J : (u64)junc_limit);
     }
-    const u32 p = blockIdx.x * 256 + threadIdx.x;
+    // KDA_PER pairs a thread, their loads side by side: a pair is a chain of three dependent look-ups (key -> bitmap word and rank ->
+    // end slots and first id), and a wavefront with one pair per lane (651 k of them a chain) spent its life waiting for them one
+    // after the other -- 134 us a chain (round 4) for 267 MB
+    // Pairs arrive in BAM order: the lanes of a wavefront mostly hold the pairs of one or two junctions.  Only the first lane of a run
+    // of equal keys (a "leader") looks its junction up -- the look-ups are gathers of 56 bytes a pair, and their cost follows the
+    // lanes that take part -- the others take the leader's answer (one ds_bpermute).
+    u64 kk[KDA_PER];
+    u32 pp[KDA_PER];
+#pragma unroll
+    for (int q = 0; q < KDA_PER; q++) {
+        pp[q] = (blockIdx.x * KDA_PER + q) * 256 + threadIdx.x;
+        kk[q] = key[pp[q] < n ? pp[q] : n - 1];
+    }
+    bool lead[KDA_PER];
+    int32_t ss[KDA_PER], ee[KDA_PER];
+    u64 bw[KDA_PER];
+    u32 wr[KDA_PER];
+#pragma unroll
+    for (int q = 0; q < KDA_PER; q++) {
+        const u32 plo = (u32)__builtin_amdgcn_update_dpp(0, (int)(u32)kk[q], 0x138, 0xf, 0xf, false);         // wave_shr:1
+        const u32 phi = (u32)__builtin_amdgcn_update_dpp(0, (int)(u32)(kk[q] >> 32), 0x138, 0xf, 0xf, false);
+        lead[q] = lane_id() == 0 || plo != (u32)kk[q] || phi != (u32)(kk[q] >> 32);
+        unpack_key(kf, kk[q], ss[q], ee[q]);
+        bw[q] = 0;
+        wr[q] = 0;
+        if (lead[q]) {
+            bw[q] = bitmap[(u32)ss[q] >> 6];
+            wr[q] = wrank[(u32)ss[q] >> 6];
+        }
+    }
+    u32 rs_[KDA_PER], fi[KDA_PER], eb[KDA_PER];
+#pragma unroll
+    for (int q = 0; q < KDA_PER; q++) {
+        rs_[q] = wr[q] + (u32)__popcll(bw[q] & ((1ull << (ss[q] & 63)) - 1ull));
+        fi[q] = eb[q] = 0;
+        if (lead[q]) {
+            fi[q] = first_id[rs_[q]];
+            eb[q] = ends_below(ends, rs_[q], (u32)ee[q]);
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < KDA_PER; q++) {
+        const u64 lm = __ballot(lead[q]) & ((2ull << lane_id()) - 1ull); // (lane 0 always leads)
+        const u32 id = (u32)__shfl((int)(fi[q] + eb[q]), 63 - __clzll((long long)lm), 64);
+        fi[q] = id;
+        eb[q] = 0;
+        if (pp[q] < n) jid_bam[pp[q]] = id; // (the sort's first pass reads the ids from here; k4b_generic looks its pairs' junctions up)
+    }
+#ifdef PJB_SELFCHECK
+    const u32 p = pp[0];
     if (p >= n) return;
-    int32_t s, e;
-    unpack_key(kf, key[p], s, e);
-    const u32 rs = start_rank(bitmap, wrank, s);
-    const u32 id = first_id[rs] + ends_below(ends, rs, (u32)e);
-    jid_bam[p] = id; // (the sort's first pass reads the ids from here; k4b_generic looks its pairs' junctions up)
-#ifdef PJB_SELFCHECK // (debug builds: the junction table kd_table made must know this pair's junction -- its start bit, its end slot, its key,
+    const int32_t s = ss[0], e = ee[0];
+    const u32 rs = rs_[0], id = fi[0] + eb[0]; // (debug builds: the junction table kd_table made must know this pair's junction -- its start bit, its end slot, its key,
                      // anchors that enclose the intron; a failure stops the chain (P = 0) so that the report gets out)
     {
         int bad = 0;
@@ -3173,23 +3207,27 @@ struct Popc64Fn {
     const u64 *words;
     __device__ u64 operator()(u64 i) const { return (u64)__popcll(words[i]); }
 };
+constexpr int K2E_PER = 4;
 __global__ __launch_bounds__(256) void k2_expand(const u32 *sid, const u64 *head_mask, const u64 *run_mask, const u32 *run_base, const u64 *total,
                                                  u32 *seg_off, u32 *run_first, u32 *run_start, ContigStats *cs) {
     const u32 n = cs->P;
-    const u32 i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const u32 sl = i >> 6, bit = i & 63u;
-    const u64 mr = run_mask[sl], mj = head_mask[sl];
-    if ((mr >> bit) & 1ull) {
-        const u32 r = run_base[sl] + (u32)__popcll(mr & ((1ull << bit) - 1ull));
-        run_start[r] = i;
-        if ((mj >> bit) & 1ull) {
-            const u32 j = sid[i];
-            seg_off[j] = i;
-            run_first[j] = r;
+#pragma unroll
+    for (int q = 0; q < K2E_PER; q++) { // (a wavefront takes K2E_PER slices: their mask words' loads travel together)
+        const u32 i = (blockIdx.x * K2E_PER + q) * 256 + threadIdx.x;
+        if (i >= n) continue;
+        const u32 sl = i >> 6, bit = i & 63u;
+        const u64 mr = run_mask[sl], mj = head_mask[sl];
+        if ((mr >> bit) & 1ull) {
+            const u32 r = run_base[sl] + (u32)__popcll(mr & ((1ull << bit) - 1ull));
+            run_start[r] = i;
+            if ((mj >> bit) & 1ull) {
+                const u32 j = sid[i];
+                seg_off[j] = i;
+                run_first[j] = r;
+            }
         }
     }
-    if (i == n - 1) { // (k2_close's part)
+    if (n > 0 && (n - 1) / (256u * K2E_PER) == blockIdx.x && threadIdx.x == 0) { // (k2_close's part: once, by the block that holds the last pair)
         const u32 R = (u32)*total, J = cs->J;
         seg_off[J] = n;
         run_first[J] = R;
@@ -4071,10 +4109,16 @@ __global__ __launch_bounds__(256) void k6_rows_out(const u64 *rows, const Contig
         if (to_mirror) mirror_table[mat * ROW_U64 + i] = v;
     }
     __shared__ u32 s_last;
+    // (The rows -- host memory, and a mirror that may be a peer's -- must be out before the control block that announces them: a
+    // system-scope fence in every block before it counts itself done, and once more in the last block before it publishes.  Today
+    // every consumer waits for the stream's event; a consumer that polls the control block would see the rows too.  The one
+    // blocks_done counter serves every slot because the rows stream runs these launches one after the other.)
+    __threadfence_system();
     __syncthreads(); // (every thread of the block has read the cursor)
     if (threadIdx.x == 0) s_last = atomicAdd(&cur->blocks_done, 1u) + 1u == gridDim.x ? 1u : 0u;
     __syncthreads();
     if (!s_last) return;
+    __threadfence_system();
     if (threadIdx.x == 0) cur->blocks_done = 0;
     publish_chain(cs, err, gen_cnt, host_pub, base, mirror_base, cur, members, member_junc, n_members);
 }

@@ -1,5 +1,6 @@
 // portcullis_amd: command line entry: the `junc` mode and `bamfilt`; prep / filt remain the
 // reference's programs and interoperate through the prep directory and the .tab file.
+#include <dirent.h>
 #include <portcullis/bam_filter.hpp>
 #include <portcullis/junction_builder.hpp>
 
@@ -38,14 +39,21 @@ int main(int argc, char* argv[]) {
     // done that before main: decided from the process state, an open /dev/kfd, not from the tool's name)
     bool kfd_open = false;
     {
-        char link[64], target[256];
-        for (int fd = 0; fd < 256 && !kfd_open; fd++) {
-            snprintf(link, sizeof link, "/proc/self/fd/%d", fd);
-            const ssize_t n = readlink(link, target, sizeof target - 1);
-            if (n > 0) {
-                target[n] = 0;
-                kfd_open = strstr(target, "/dev/kfd") != nullptr || strstr(target, "/dev/dri/render") != nullptr;
+        // (every entry of /proc/self/fd, whatever its number; a /proc that cannot be read counts as "started": no fork then)
+        DIR* d = opendir("/proc/self/fd");
+        if (!d) kfd_open = true;
+        else {
+            char link[300], target[256];
+            while (const dirent* e = readdir(d)) {
+                if (e->d_name[0] == '.') continue;
+                snprintf(link, sizeof link, "/proc/self/fd/%s", e->d_name);
+                const ssize_t n = readlink(link, target, sizeof target - 1);
+                if (n > 0) {
+                    target[n] = 0;
+                    if (strstr(target, "/dev/kfd") != nullptr || strstr(target, "/dev/dri/render") != nullptr) kfd_open = true;
+                }
             }
+            closedir(d);
         }
     }
     const char* early = getenv("PORTCULLIS_EARLY_RETURN");

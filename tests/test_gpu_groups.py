@@ -297,3 +297,22 @@ def test_pair_limit_overflow_inside_a_group(ffi, orc):
         assert regs[tid]["n_pairs"] > 5 * regs[tid]["n_reads"]
     region_equal(r2, contigs[2][3])
     assert_rows_equal(rows, np.concatenate([c[2] for c in contigs]))
+
+
+@pytest.mark.parametrize("dense", [1, 0])
+def test_read_list_room_overflow_is_repeated(ffi, orc, dense):
+    """nothing reached the OVF_LISTS path (a read sub-list that overflows closes the chain, which is queued again
+    with the room it asked for).  pjb_set_option("list_cap", 8) makes every chain's first attempt overflow: groups == singles ==
+    oracle after the repeat, on the dense-id chain and on the full-key chain."""
+    contigs = _contigs(orc, [501, 502, 503], n_reads=3000)
+    with ffi.Context(0, "FR") as ctx:
+        ctx.set_option("dense_ids", dense)
+        ctx.set_option("list_cap", 8)
+        rows_s, regs_s = _singles(ctx, contigs)
+        rows_g, regs_g = _grouped(ctx, contigs, [[0, 1, 2]])
+    want = np.concatenate([c[2] for c in contigs])
+    assert_rows_equal(rows_s, want)
+    assert rows_g.tobytes() == rows_s.tobytes()
+    for tid, c in enumerate(contigs):
+        region_equal(regs_s[tid], c[3])
+        region_equal(regs_g[tid], c[3])

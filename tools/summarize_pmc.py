@@ -30,6 +30,10 @@ if workload:
     meta["_workload"] = workload  # bench.py attaches the traffic figure only to a run of the same workload
 if commit:
     meta["_commit"] = commit
+import os
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from csrc_hash import csrc_hash
+meta["_csrc_hash"] = csrc_hash(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 json.dump({**meta, **summary}, open(out, "w"), indent=1)
 for k, v in summary.items():
     print(f"{k:45s} fetch_raw {v['fetch_kib_raw'] / 1024:9.1f} MiB  write {v['write_kib'] / 1024:9.1f} MiB  corrected {v['hbm_bytes_per_launch'] / 1e6:9.1f} MB")
