@@ -2192,6 +2192,13 @@ __global__ __launch_bounds__(K1E_T) __attribute__((amdgpu_waves_per_eu(K1E_WAVES
     EmitTrip T = locate(v_lo);
     EmitRec R = fetch_rec(T);
     EmitOps O = fetch_ops(T, R);
+    // (the list records run TWO trips ahead, the operations and fields one: what a trip asks for has had a whole trip to arrive)
+    EmitTrip T1 = T;
+    EmitRec R1 = R;
+    if (v_lo + 1 < v_hi) {
+        T1 = locate(v_lo + 1);
+        R1 = fetch_rec(T1);
+    }
     K1E_MARK(1); // prologue: first trip's records and operations issued
     for (u32 v = v_lo; v < v_hi; v++) {
         const GBatch b = load_batch(batches + T.bi);
@@ -2284,57 +2291,95 @@ __global__ __launch_bounds__(K1E_T) __attribute__((amdgpu_waves_per_eu(K1E_WAVES
 #if K1E_ABL & 1
                 return;
 #endif
-                if constexpr (LDS)
-                    cmp_block_lds<true, true>(stg.seq, q_w0, q, stg.gen[k][0], k == 0 ? g_ofs0 : k == 1 ? g_ofs1 : g_ofs2, gl, B.len, s_tail, B);
-                else if (!(K1E_ABL & 16))
-                    cmp_words<SIMPLE_NW, true>(seqw, q, q_limit, (const u32 *)gcodes, gl, g_words, B.len, 0, B.mism, B.first, B.last);
+                if constexpr (LDS) cmp_block_lds<true, true>(stg.seq, q_w0, q, stg.gen[k][0], k == 0 ? g_ofs0 : k == 1 ? g_ofs1 : g_ofs2, gl, B.len, s_tail, B);
             };
-            int32_t lst = vpos;  // the left block of the pair: where it starts, its query offset, its length; intron; right block
-            int32_t qoff = (int32_t)dS;
-            u32 la = a, ln_ = nl, lb = b2;
-            CmpBlock blkL = {0, 0, -1, -1};
-            for (u32 pr = 0; pr < (two ? 2u : 1u); pr++) {
-                const int32_t istart = lst + (int32_t)la;
-                const int32_t rStartU = istart + (int32_t)ln_;
-                int32_t rStart = rStartU;
-                if (rStart - 1 >= vlen) rStart = vlen - 1; // junction_system.cc:169-171
-                const int32_t iend = rStart - 1;
-                int32_t rEndExc = rStartU + (int32_t)lb;
-                if (rEndExc - 1 >= vlen) rEndExc = vlen; // junction_system.cc:172-174
-                if (rEndExc - 1 < iend) set_error(err, g, PJB_ERR_MIN_ANCHOR); // intron.cc:76
-                const u64 key = make_key(kf, istart, iend);
+            // ---- the pairs' geometry (junction_system.cc:140-210 for one or two N operations)
+            const u32 npairs = two ? 2u : 1u;
+            u64 key_[2];
+            int32_t lst_[2], rend_[2], iend_[2];
+            u32 ud_[2];
+            {
+                int32_t lst = vpos; // the left block of the pair: where it starts, its length; intron; right block
+                u32 la = a, ln_ = nl, lb = b2;
+#pragma unroll
+                for (u32 pr = 0; pr < 2; pr++) {
+                    const int32_t istart = lst + (int32_t)la;
+                    const int32_t rStartU = istart + (int32_t)ln_;
+                    int32_t rStart = rStartU;
+                    if (rStart - 1 >= vlen) rStart = vlen - 1; // junction_system.cc:169-171
+                    const int32_t iend = rStart - 1;
+                    int32_t rEndExc = rStartU + (int32_t)lb;
+                    if (rEndExc - 1 >= vlen) rEndExc = vlen; // junction_system.cc:172-174
+                    if (pr < npairs && rEndExc - 1 < iend) set_error(err, g, PJB_ERR_MIN_ANCHOR); // intron.cc:76
+                    key_[pr] = make_key(kf, istart, iend);
+                    lst_[pr] = lst;
+                    rend_[pr] = rEndExc - 1;
+                    iend_[pr] = iend;
+                    // junction.cc:795-812.  One N operation: nothing upstream; "downstream" counts the operation itself unless its end was
+                    // clamped.  Two: the first has the second downstream, the second the first upstream.
+                    ud_[pr] = two ? (pr == 0 ? (1u << 16) : 1u) : (rStartU <= iend + 1 ? 0u : (1u << 16));
+                    lst = rStart;
+                    la = lb;
+                    ln_ = nl2;
+                    lb = b3;
+                }
+            }
+            // ---- the anchors' match statistics: every block of bases is compared once -- the block between two introns is the first
+            // pair's right anchor and the second pair's left one.  Block k: read [bq, bq + bl) against the target's [bg, bg + bl).
+            const int32_t bq[3] = {(int32_t)dS, (int32_t)(dS + a), (int32_t)(dS + a + b2)};
+            const int32_t bg[3] = {lst_[0] - voff, iend_[0] + 1 - voff, iend_[1] + 1 - voff};
+            const int32_t bl[3] = {(int32_t)a, rend_[0] - iend_[0], rend_[1] - iend_[1]};
+            CmpBlock res[3] = {{bl[0], 0, -1, -1}, {bl[1], 0, -1, -1}, {bl[2], 0, -1, -1}};
+            if constexpr (LDS) {
+                cmp_block(0, bq[0], bg[0], res[0]);
+                cmp_block(1, bq[1], bg[1], res[1]);
+                if (two) cmp_block(2, bq[2], bg[2], res[2]);
+            } else if (!(K1E_ABL & 17)) {
+                // The gathers, a ROUND of 56 bases at a time, every lane through its own blocks one after the other: a lane with a long
+                // left anchor has a short right one, so the wavefront needs max (rounds of all blocks of a lane) iterations -- four
+                // for 150 bases -- where block after block it needed max (rounds of block 0) + max (rounds of block 1) + ... -- six or
+                // more; each iteration is a memory round trip as well.
+                const int nb = two ? 3 : 2;
+                int k = 0;
+                int32_t t = 0, mism = 0, first = -1, last = -1;
+                for (;;) {
+                    // (blocks without bases -- a clamped end -- are stepped over)
+                    int32_t l = k == 0 ? bl[0] : k == 1 ? bl[1] : bl[2];
+                    const bool act = k < nb && t < l;
+                    if (act) {
+                        const int32_t qi = k == 0 ? bq[0] : k == 1 ? bq[1] : bq[2], gi = k == 0 ? bg[0] : k == 1 ? bg[1] : bg[2];
+                        CmpChunkT<SIMPLE_NW> C;
+                        chunk_load<SIMPLE_NW, true>(C, seqw, qi, q_limit, (const u32 *)gcodes, gi, g_words, l, t);
+                        chunk_cmp<SIMPLE_NW>(C, qi, gi, l, t, 0, mism, first, last);
+                        t += 8 * (SIMPLE_NW - 1);
+                    }
+                    if (k < nb && t >= l) { // the lane's block is finished (or empty): its results, the next block
+                        if (k == 0) res[0].mism = mism, res[0].first = first, res[0].last = last;
+                        if (k == 1) res[1].mism = mism, res[1].first = first, res[1].last = last;
+                        if (k == 2) res[2].mism = mism, res[2].first = first, res[2].last = last;
+                        k++;
+                        t = 0, mism = 0, first = -1, last = -1;
+                    }
+                    if (!__ballot(k < nb)) break;
+                }
+            }
+#pragma unroll
+            for (u32 pr = 0; pr < 2; pr++) {
+                if (pr >= npairs) break;
                 PairRec Q;
-                Q.lstart = lst;
-                Q.rend = rEndExc - 1;
+                Q.lstart = lst_[pr];
+                Q.rend = rend_[pr];
                 Q.pos = vpos;
                 Q.aend = aend_all;
                 Q.meta = meta | META_SIMPLE | (two ? META_MULTI : 0u);
-                // junction.cc:795-812.  One N operation: nothing upstream; "downstream" counts the operation itself unless its end was
-                // clamped.  Two: the first has the second downstream, the second the first upstream.
-                Q.updown = two ? (pr == 0 ? (1u << 16) : 1u) : (rStartU <= iend + 1 ? 0u : (1u << 16));
-                // the anchors' match statistics: every block of bases is compared once -- the block between two introns is the first
-                // pair's right anchor and the second pair's left one
-                {
-                    if (pr == 0) {
-                        blkL = CmpBlock{(int32_t)la, 0, -1, -1};
-                        cmp_block(0, qoff, lst - voff, blkL);
-                    }
-                    CmpBlock blkR = {Q.rend - iend, 0, -1, -1};
-                    cmp_block((int)pr + 1, qoff + (int32_t)la, iend + 1 - voff, blkR);
-                    Q.aux = cmp_blocks_res(blkL, blkR);
-                    blkL = blkR;
-                }
-                P.key[off + pr] = key;
+                Q.updown = ud_[pr];
+                Q.aux = cmp_blocks_res(res[pr], res[pr + 1]);
+                P.key[off + pr] = key_[pr];
                 if (P.g) P.g[off + pr] = g;
                 rec_store(P.rec + off + pr, Q);
 #if !(K1E_ABL & 2)
-                if (want_cand) cand_insert(key, Q.lstart, Q.rend);
+                if (want_cand) cand_insert(key_[pr], Q.lstart, Q.rend);
 #endif
-                lst = rStart;
-                qoff += (int32_t)la;
-                la = lb;
-                ln_ = nl2;
-                lb = b3;
             }
         };
         // ---- passes over the wavefront's loci.  Window A of a block of bases starts at the block of the first lane that is still to
@@ -2342,9 +2387,9 @@ __global__ __launch_bounds__(K1E_T) __attribute__((amdgpu_waves_per_eu(K1E_WAVES
         // locus, often two, seldom more -- the lanes of each next to each other); a lane is done in the pass that holds all of its
         // blocks, and the first lane to do always is: the passes end.  The next trip's list records go out behind the first pass's
         // staging loads, its operations and fields behind the first wait: they are in flight while this trip is compared.
-        const bool more = v + 1 < v_hi;
-        EmitTrip Tn = T;
-        EmitRec Rn = R;
+        const bool more = v + 1 < v_hi, more2 = v + 2 < v_hi;
+        EmitTrip T2 = T1;
+        EmitRec R2 = R1;
         EmitOps On = O;
         bool todo = staged && lds_ok;
         for (int pass = 0;; pass++) {
@@ -2377,16 +2422,16 @@ __global__ __launch_bounds__(K1E_T) __attribute__((amdgpu_waves_per_eu(K1E_WAVES
             }
             if (pass == 0) {
                 K1E_MARK(3); // staging issued
-                if (more) {
-                    Tn = locate(v + 1);
-                    Rn = fetch_rec(Tn);
+                if (more2) {
+                    T2 = locate(v + 2);
+                    R2 = fetch_rec(T2);
                 }
-                K1E_MARK(4); // next records issued
+                K1E_MARK(4); // records of the trip after the next issued
             }
-            if (staged || (pass == 0 && more)) stage_wait();
+            if (staged) stage_wait();
             if (pass == 0) {
                 K1E_MARK(5); // the wait
-                if (more) On = fetch_ops(Tn, Rn);
+                if (more) On = fetch_ops(T1, R1);
                 K1E_MARK(6); // next operations issued
             }
             const u32 need = two ? 7u : 3u;
@@ -2406,9 +2451,11 @@ __global__ __launch_bounds__(K1E_T) __attribute__((amdgpu_waves_per_eu(K1E_WAVES
         // cand_insert -- and no barrier ties the block's wavefronts together trip by trip)
         if (!more) ctx.cand_flush(true);
         K1E_MARK(9); // candidate flush (barrier)
-        T = Tn;
-        R = Rn;
+        T = T1;
+        R = R1;
         O = On;
+        T1 = T2;
+        R1 = R2;
     }
 }
 
