@@ -281,6 +281,8 @@ int pjb_finish_group_end(pjb_ctx *ctx, const int32_t *tids, int32_t n_tids, pjb_
  *   "extra_dense" 0 (default): PJB_FLAG_EXTRA answers depth and flanking counts from the unspliced records themselves
  *                (a few records per junction) and builds a target's per-base depth vector only where htslib's
  *                8000-record pileup cap may bite; 1: the depth vector for every target (round 2's path)
+ *   "sort_floor" 65536 (default): the sort's digits cover at least this many junction ids (and twice what the context's chains have
+ *                had); n (test hook): a small floor, so that a chain with more junctions than planned for is repeated
  *   "list_cap"   0 (default): the kernels' read lists get the room the pair limit implies; n > 0 (test hook): the first attempt
  *                of every chain gets room for n entries per sub-list, so that the overflow-and-repeat path runs */
 int pjb_set_option(pjb_ctx *ctx, const char *name, int64_t value);

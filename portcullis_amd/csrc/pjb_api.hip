@@ -135,6 +135,9 @@ struct XArena {
 struct ContigLimits {
     u32 pair_limit = 0, junc_limit = 0;
     u32 list_cap = 0; // room of a sub-list of the read lists (0: gen_list_cap(pair_limit))
+    u32 sort_limit = 0; // junction ids the sort's digits are planned for (0: junc_limit).  The buffers hold junc_limit junctions -- a share of
+                        // the pair limit, generous --, but digits planned for it made the sort count and scan 2048-entry tables per tile
+                        // of 4096 pairs (61 MB a launch, round 4's PMC pass) where a chain has 2^17 junctions
     KeyFmt kf;
     bool dense = false; // sort ordered dense junction ids (K2d) instead of the full keys
 };
@@ -277,6 +280,7 @@ struct pjb_ctx {
     int64_t mirror_acc[5] = {0, 0, 0, INT32_MAX, 0}; // spliced, unspliced, sum_len, min_len, max_len
     pjb_timing timing;
     int radix_max_bits = 11;
+    u32 sort_floor = 1u << 16;        // pjb_set_option("sort_floor", n): the least number of junction ids the sort's digits are planned for (tests: small)
     u32 list_cap_forced = 0;          // pjb_set_option("list_cap", n): the read lists' first room (tests of the OVF_LISTS repeat)
     bool k1_serial = true;            // PJB_K1_SERIAL=0: the chains' K1 stages side by side
     hipEvent_t last_k1_ev = nullptr;  // the K1 stage of the chain queued last
@@ -1451,6 +1455,7 @@ static int queue_contig(pjb_ctx *c, Flight &f) {
     }
     const KeyFmt kf = lim.kf;
     const u32 PL = lim.pair_limit, JL = lim.junc_limit;
+    const u32 SL = lim.sort_limit && lim.sort_limit < JL ? lim.sort_limit : JL; // (ids the sort's digits cover)
     int rc;
     // the place of this contig's rows: known here if nothing is queued ahead of it, else it follows on the device
     bool ahead = false;
@@ -1682,12 +1687,18 @@ static int queue_contig(pjb_ctx *c, Flight &f) {
                    (const u32 *)S.tile_soff.p, (const u32 *)S.chunk_tile.p, (const u32 *)S.splidx.p, (const u32 *)S.splpoff.p, (const uint4 *)S.splrec.p, pr, el, kf,
                    GT, fast_codes ? 1 : 0, (int)c->cfg.orientation, d_err, d_cs);
         }
+        // (the next chain's K1 may start here: k1_generic -- a few reads walked by a few wavefronts, waiting for their loads -- runs beside
+        // its k1_count, which is a stream)
+        if (c->k1_serial && !getenv("PJB_K1_SERIAL_LATE")) {
+            HIP_TRY(c, hipEventRecord(S.ev_k1, st));
+            c->last_k1_ev = S.ev_k1;
+        }
         // the reads k1_emit left: one launch over the chain's third list (the blocks stride over it)
         LAUNCH(c, "k1_generic", k1_generic, dim3(std::min<u32>(std::max<u32>(1, (u32)(((u64)gen_cap * GEN_SHARDS + K1E_T - 1) / K1E_T)), 1536u /* six blocks a CU; 512 .. 3072 measured: no difference */)), dim3(K1E_T),
                (const DevBatch *)S.batches.p, (int)batches.size(), (const u32 *)S.splidx.p, (const uint4 *)S.splrec.p, pr, el, kf, GT, fast_codes ? 1 : 0,
                (int)c->cfg.orientation, d_err, d_cs);
     }
-    if (c->k1_serial) {
+    if (c->k1_serial && getenv("PJB_K1_SERIAL_LATE")) { // (experiment: behind k1_generic)
         HIP_TRY(c, hipEventRecord(S.ev_k1, st));
         c->last_k1_ev = S.ev_k1;
     }
@@ -1731,7 +1742,7 @@ static int queue_contig(pjb_ctx *c, Flight &f) {
             return rc;
         LAUNCH(c, "kd_table", kd_table, dim3(cand_blocks), dim3(256), (const u64 *)cand, (const u64 *)S.ent.p, (const u32 *)cand_rank, kf, JL,
                (const u32 *)S.ends.p, (const u32 *)S.firstid.p, (const u64 *)S.total.p, (u64 *)S.jkey.p, (int32_t *)S.ancl.p, (int32_t *)S.ancr.p, d_cs,
-               (const u32 *)d_gen_cnt, gen_cap);
+               (const u32 *)d_gen_cnt, gen_cap, SL);
         LAUNCH(c, "kd_assign", kd_assign, dim3((pair_blocks + KDA_PER - 1) / KDA_PER), dim3(256), okey, d_P, kf, (const u64 *)S.bitmap.p, (const u32 *)S.wrank.p,
                (const u32 *)S.ends.p, (const u32 *)S.firstid.p, JL, (const u64 *)S.total.p, (u32 *)S.jidbam.p, (u32 *)S.acc.p, (const u64 *)S.jkey.p,
                (const int32_t *)S.ancl.p, (const int32_t *)S.ancr.p, d_err, d_cs);
@@ -1739,7 +1750,7 @@ static int queue_contig(pjb_ctx *c, Flight &f) {
         LAUNCH(c, "kd_reset", kd_reset, dim3(cand_blocks), dim3(256), (const u64 *)cand, (const u32 *)cand_rank, kf, JL, (const ContigStats *)d_cs,
                (u64 *)S.bitmap.p, (u32 *)S.ends.p);
         S.dense_at_rest = true;
-        sort_bits = std::max(1, bits_of((uint64_t)JL));
+        sort_bits = std::max(1, bits_of((uint64_t)SL));
     }
     // ---- K2: radix sort (key, pair index); digits: as few passes as the widest digit allows, bits spread evenly
     const u32 rs_tiles = std::max<u32>(1, (PL + RS_TILE - 1) / RS_TILE);
@@ -2019,6 +2030,8 @@ static void prepare_flight(pjb_ctx *c, Flight &f) {
     lim.kf.lbits = std::max(1, c->lbits_seen);
     lim.kf.total_bits = lim.kf.lbits + std::max(1, bits_of((uint64_t)std::max<int64_t>(f.vlen, 1)));
     lim.dense = c->dense_ids;
+    // (twice what a chain of this context's targets has had, per member; a chain with more is repeated with digits for junc_limit)
+    lim.sort_limit = c->junc_seen ? std::min<u32>(lim.junc_limit, std::max<u32>(c->sort_floor, 2 * c->junc_seen * (u32)std::max<size_t>(1, f.tids.size()))) : 0u;
 }
 
 // streams and events of a control slot, at its first use (a context that never queues eight chains never pays for them)
@@ -2179,7 +2192,9 @@ static int collect_flight(pjb_ctx *c, pjb_region_result *res, bool *redo_single)
                 lim.kf.total_bits = lim.kf.lbits + std::max(1, bits_of((uint64_t)std::max(ref_len, 1)));
             }
         }
-        if (cs.overflow & OVF_JUNC) lim.junc_limit = std::max<u32>(cs.n_junc + 64, (cs.overflow & OVF_DENSE) || !lim.dense ? 0u : lim.junc_limit * 4);
+        const bool sort_only = (cs.overflow & OVF_JUNC) && lim.sort_limit && cs.n_junc <= lim.junc_limit; // (the buffers were large enough)
+        if (cs.overflow & OVF_JUNC) lim.sort_limit = 0;
+        if ((cs.overflow & OVF_JUNC) && !sort_only) lim.junc_limit = std::max<u32>(cs.n_junc + 64, (cs.overflow & OVF_DENSE) || !lim.dense ? 0u : lim.junc_limit * 4);
         if (cs.overflow & OVF_DENSE) lim.dense = false; // a donor with more alternative acceptors than K2d keeps: sort the full keys
         if (cs.overflow & OVF_LISTS) lim.list_cap = std::max(gen_list_cap(lim.pair_limit), (cs.list_need + cs.list_need / 4 + 511u) & ~255u); // (k1_generic's entries depend on the appends' order: some slack)
     }
@@ -2639,6 +2654,7 @@ int pjb_set_option(pjb_ctx *c, const char *name, int64_t value) {
     if (n == "overlap") c->side_stream = value != 0;
     else if (n == "dense_ids") c->dense_ids = value != 0;
     else if (n == "extra_dense") c->extra_dense_only = value != 0;
+    else if (n == "sort_floor") c->sort_floor = (u32)std::max<int64_t>(1, std::min<int64_t>(value, 1 << 30));
     else if (n == "list_cap") c->list_cap_forced = (u32)std::max<int64_t>(0, std::min<int64_t>(value, 1 << 30));
     else return fail(c, PJB_ERR_ARG, "set_option: unknown option '%s'", name);
     return PJB_OK;

@@ -2762,7 +2762,7 @@ __device__ __forceinline__ void anchors_fold(bool valid, u32 j, int32_t l, int32
 // contig -- if a limit was exceeded while the ids were built
 __global__ __launch_bounds__(256) void kd_table(const u64 *cand, const u64 *cand_anc, const u32 *cand_rank, KeyFmt kf, u32 junc_limit, const u32 *ends,
                                                 const u32 *first_id, const u64 *total, u64 *jkey, int32_t *anc_l, int32_t *anc_r, ContigStats *cs,
-                                                const u32 *gen_cnt, u32 gen_cap) {
+                                                const u32 *gen_cnt, u32 gen_cap, u32 sort_limit) {
     const u32 p = blockIdx.x * 256 + threadIdx.x;
     if (blockIdx.x == 0) { // (the read lists: every sub-list within its room?)
         static_assert(GEN_SHARDS == 256, "a shard per thread of the first block");
@@ -2773,7 +2773,9 @@ __global__ __launch_bounds__(256) void kd_table(const u64 *cand, const u64 *cand
     if (p == 0) {
         const u64 J = *total;
         u32 ovf = cs->overflow;
-        if (cs->P != 0 && J > (u64)junc_limit) {
+        // (sort_limit: the ids the sort's digits were planned for -- what chains of this context have had so far, with room; junc_limit:
+        // what the buffers hold)
+        if (cs->P != 0 && (J > (u64)junc_limit || J > (u64)sort_limit)) {
             ovf |= OVF_JUNC;
             cs->overflow = ovf;
             cs->n_junc = (u32)(J < 0xffffffffull ? J : 0xffffffffull);

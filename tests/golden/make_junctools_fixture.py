@@ -10,7 +10,8 @@ the reference's TabJunction, as imported from /root/reference, and records what 
   * parse_line(line)                       -- must accept the column count; int() conversions of the coordinate columns
   * the parsed attributes and str(junction) -- junctools' re-serialisation of the row
 
-into tests/golden/junctools_tab.json.  tests/test_oracle_junctools.py re-derives the same .tab text from the oracle (CPU) and
+into tests/golden/junctools_tab.json; and, for the same inputs, what the reference's BedJunction.parse_line makes of every line of the
+oracle's .junctions.bed and its GFFJunction.parse_line of every line of the .introns.gff3 (tests/golden/junctools_bed_gff.json).  tests/test_oracle_junctools.py re-derives the same .tab text from the oracle (CPU) and
 tests/test_gpu_junctools.py from the device rows through the C++ writer, and both compare with these vectors.  Nothing of
 junctools travels: the fixture holds inputs' names and expected outputs only.
 
@@ -47,6 +48,8 @@ def main():
     header = ref.TabJunction().file_header()
     out = {"_made_by": "tests/golden/make_junctools_fixture.py", "_reference_parser": "scripts/junctools/junctools/junction.py:579-799 (TabJunction)",
            "header": header, "n_columns": len(header.split("\t")), "cases": {}}
+    out2 = {"_made_by": "tests/golden/make_junctools_fixture.py",
+            "_reference_parsers": "scripts/junctools/junctools/junction.py:414-456 (BedJunction.parse_line), :531-577 (GFFJunction.parse_line)", "cases": {}}
     for name, (refs, genomes, batches, orientation) in cases().items():
         rows, _tot = orc.run_prep_like(refs, genomes, batches, orientation)
         tab = orc.write_tab(rows, [n for n, _ in refs], [l for _, l in refs]).decode()
@@ -67,8 +70,42 @@ def main():
                 "min_hamming": tj.getMinHamming(), "nb_samples": tj.getNbSamples(), "ss_type": tj.getSSType(), "str": str(tj)})
         out["cases"][name] = {"orientation": orientation, "n_rows": len(parsed), "rows": parsed}
         print(f"{name}: {len(parsed)} rows parsed and re-serialised by the reference's TabJunction")
+        # ---- the other two writers' witnesses: BedJunction.parse_line (junction.py:414-456) on the oracle's .junctions.bed,
+        # GFFJunction.parse_line (junction.py:531-577) on its .introns.gff3 -- what the reference's readers make of every line
+        names = [n for n, _ in refs]
+        bed_lines = orc.write_bed(rows, names, version="1.2.4").decode().split("\n")
+        bed = []
+        for line in bed_lines:
+            bj = ref.BedJunction()
+            if bj.parse_line(line) is None:  # (the track line, the empty end)
+                bed.append({"line": line, "parsed": None})
+                continue
+            bed.append({"line": line, "parsed": {"refseq": bj.refseq, "start": bj.start, "end": bj.end, "left": bj.left, "right": bj.right,
+                                                  "strand": bj.strand, "id": bj.id, "score": bj.score, "style": str(bj.style),
+                                                  "rgb": [bj.red, bj.green, bj.blue]}})
+        gff_lines = orc.write_intron_gff(rows, names).decode().split("\n")
+        gff = []
+        for line in gff_lines:
+            gj = ref.GFFJunction()
+            if gj.parse_line(line) is None:  # (comment lines, the empty end)
+                gff.append({"line": line, "parsed": None})
+                continue
+            gff.append({"line": line, "parsed": {"refseq": gj.refseq, "start": gj.start, "end": gj.end, "strand": gj.strand, "source": gj.source,
+                                                  "feature": gj.feature, "score": gj.score, "frame": gj.frame, "raw": gj.raw, "attrs": list(gj.attrs)}})
+        n_bed = sum(1 for e in bed if e["parsed"])
+        n_gff = sum(1 for e in gff if e["parsed"])
+        assert n_bed == len(parsed) == n_gff, (n_bed, len(parsed), n_gff)
+        for e, g_, t in zip([e for e in bed if e["parsed"]], [e for e in gff if e["parsed"]], parsed):  # the three files name the same introns
+            assert (e["parsed"]["refseq"], e["parsed"]["start"], e["parsed"]["end"]) == (t["refseq"], t["start"], t["end"]) == \
+                   (g_["parsed"]["refseq"], g_["parsed"]["start"], g_["parsed"]["end"])
+            assert (e["parsed"]["left"], e["parsed"]["right"]) == (t["left"], t["right"])
+        out2["cases"][name] = {"bed": bed, "intron_gff": gff}
+        print(f"{name}: {n_bed} .bed lines parsed by BedJunction, {n_gff} .gff3 lines by GFFJunction")
     with open(os.path.join(HERE, "junctools_tab.json"), "w") as f:
         json.dump(out, f, indent=0, sort_keys=True)
+        f.write("\n")
+    with open(os.path.join(HERE, "junctools_bed_gff.json"), "w") as f:
+        json.dump(out2, f, indent=0, sort_keys=True)
         f.write("\n")
 
 

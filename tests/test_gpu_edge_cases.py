@@ -136,3 +136,18 @@ def test_chain_on_a_context_made_without_chain_slots(ffi, orc):
             region_equal(dreg, oreg)
             assert_rows_equal(drows, orows)
             ctx.clear_rows()
+
+
+@pytest.mark.parametrize("seed", [7002, 7003, 7006, 7009])
+def test_fuzz_family_many_ops(ffi, orc, seed):
+    """Round 4's verdict: a fuzz family of long CIGARs (reads of hundreds of bases over several introns, an indel / = / X / P run every
+    few bases, clips): tens of operations a read, up to ~70 -- far past the eight operations the kernels keep close at hand."""
+    import re
+
+    from fuzzgen import make_reads
+    genome, reads = make_reads(seed, glen=200000, n_reads=300, paired=True, opts=dict(indel=0.92, eqx=0.05, pad=0.02, sub=0.01, clip=0.3, hard=0.05),
+                               L=(1500, 4000), n_tx=8, noseq_frac=0.0)
+    n_ops = sorted(len(re.findall(r"\d+[MIDNSHP=X]", r["cigar"])) for r in reads)
+    assert n_ops[len(n_ops) // 2] >= 25 and n_ops[-1] >= 50, (n_ops[len(n_ops) // 2], n_ops[-1])
+    status, rows = both(ffi, orc, genome, reads, "FR")
+    assert status == "ok" and len(rows) > 0

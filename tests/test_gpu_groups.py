@@ -316,3 +316,25 @@ def test_read_list_room_overflow_is_repeated(ffi, orc, dense):
     for tid, c in enumerate(contigs):
         region_equal(regs_s[tid], c[3])
         region_equal(regs_g[tid], c[3])
+
+
+def test_sort_digits_planned_too_small_are_repeated(ffi, orc):
+    """The sort's digits are planned from the junctions the context's chains have had (twice that, at least "sort_floor"), not from
+    the buffers' limit; a chain with more junctions than that closes and is repeated with digits for the limit.  A floor of 2 makes
+    it happen: a small target first, then larger ones -- singles, and a group -- against the oracle."""
+    contigs = _contigs(orc, [611], n_reads=60) + _contigs(orc, [612, 613], n_reads=3000)
+    # (the oracle rows carry the target index they were made with: rebuild them with this test's indices)
+    fixed = []
+    for tid, (g, b, _, _) in enumerate(contigs):
+        orows, oreg = orc.find_juncs(tid, len(g), g, b, "FR")
+        fixed.append((g, b, orows, oreg))
+    want = np.concatenate([c[2] for c in fixed])
+    with ffi.Context(0, "FR") as ctx:
+        ctx.set_option("sort_floor", 2)
+        rows_s, regs_s = _singles(ctx, fixed)
+        assert_rows_equal(rows_s, want)
+        rows_g, regs_g = _grouped(ctx, fixed, [[0], [1, 2]])
+        assert rows_g.tobytes() == rows_s.tobytes()
+        for tid, c in enumerate(fixed):
+            region_equal(regs_s[tid], c[3])
+            region_equal(regs_g[tid], c[3])

@@ -7,7 +7,7 @@ import subprocess
 import pytest
 
 from junctools_cases import fuzz_contigs, micro_reads
-from test_oracle_junctools import FIX, check_tab_against_fixture
+from test_oracle_junctools import FIX, FIX2, check_bed_against_fixture, check_gff_against_fixture, check_tab_against_fixture
 from util_bam import make_prep_dir
 
 pytestmark = pytest.mark.gpu
@@ -27,8 +27,11 @@ def run_junc(prep, out, orientation, *opts):
 def test_micro_fixtures_tab_is_what_junctools_parsed(tmp_path, ingest):
     name, genome, reads = micro_reads()
     prep = make_prep_dir(str(tmp_path / "prep"), [(name, len(genome))], [(name, genome)], reads)
-    tab = run_junc(prep, str(tmp_path / "out" / "pc"), "FR", "--ingest", ingest)
+    tab = run_junc(prep, str(tmp_path / "out" / "pc"), "FR", "--ingest", ingest, "--intron_gff")
     check_tab_against_fixture(tab, FIX["cases"]["micro_FR"])
+    # the program's .bed and intron .gff3: line for line what the reference's BedJunction / GFFJunction parsed
+    check_bed_against_fixture(open(str(tmp_path / "out" / "pc") + ".junctions.bed").read(), FIX2["cases"]["micro_FR"])
+    check_gff_against_fixture(open(str(tmp_path / "out" / "pc") + ".junctions.intron.gff3").read(), FIX2["cases"]["micro_FR"])
 
 
 @pytest.mark.parametrize("ingest", ["host", "device"])
@@ -36,5 +39,7 @@ def test_fuzz_targets_tab_is_what_junctools_parsed(tmp_path, ingest):
     contigs = fuzz_contigs()
     reads = [r for _, _, rr in contigs for r in rr]
     prep = make_prep_dir(str(tmp_path / "prep"), [(n, len(g)) for n, g, _ in contigs], [(n, g) for n, g, _ in contigs], reads)
-    tab = run_junc(prep, str(tmp_path / "out" / "pc"), "FR", "--ingest", ingest)
+    tab = run_junc(prep, str(tmp_path / "out" / "pc"), "FR", "--ingest", ingest, "--intron_gff")
     check_tab_against_fixture(tab, FIX["cases"]["fuzz3_FR"])
+    check_bed_against_fixture(open(str(tmp_path / "out" / "pc") + ".junctions.bed").read(), FIX2["cases"]["fuzz3_FR"])
+    check_gff_against_fixture(open(str(tmp_path / "out" / "pc") + ".junctions.intron.gff3").read(), FIX2["cases"]["fuzz3_FR"])

@@ -61,3 +61,57 @@ def test_fixture_covers_the_format():
     assert any("4294967295" in (r["metrics"]["dist_2_up_junc"], r["metrics"]["dist_2_down_junc"]) for r in rows)
     assert any("." in r["metrics"]["entropy"] for r in rows) and any("." in r["metrics"]["mean_mismatches"] for r in rows)
     assert any(r["metrics"]["suspicious"] == "1" for r in rows)
+
+
+# ---- the .junctions.bed and .junctions.intron.gff3 witnesses (tests/golden/junctools_bed_gff.json): what the reference's own
+# BedJunction.parse_line (scripts/junctools/junctools/junction.py:414-456) and GFFJunction.parse_line (:531-577) made of every line
+FIX2 = json.load(open(os.path.join(HERE, "golden", "junctools_bed_gff.json")))
+
+
+def check_bed_against_fixture(bed_text, case):
+    lines = bed_text.split("\n")
+    assert lines == [e["line"] for e in case["bed"]]
+    for line, e in zip(lines, case["bed"]):
+        c = line.split("\t")
+        p = e["parsed"]
+        if p is None:  # the track line / the empty end: junctools skips anything that has not 6 or 12 columns
+            assert len(c) not in (6, 12)
+            continue
+        # junctools' reading of the 12 columns: thickStart / thickEnd are the intron, chromStart / chromEnd the anchors' outer ends
+        assert len(c) == 12 and (c[0], int(c[6]), int(c[7]) - 1, int(c[1]), int(c[2]) - 1, c[5], c[3], float(c[4])) == (
+            p["refseq"], p["start"], p["end"], p["left"], p["right"], p["strand"], p["id"], p["score"])
+        assert [int(x) for x in c[8].split(",")] == p["rgb"]
+        assert p["start"] != p["left"], "portcullis writes the exon-anchored style (junctools: EBED), not tophat's"
+
+
+def check_gff_against_fixture(gff_text, case):
+    lines = gff_text.split("\n")
+    assert lines == [e["line"] for e in case["intron_gff"]]
+    for line, e in zip(lines, case["intron_gff"]):
+        p = e["parsed"]
+        if p is None:
+            assert line.startswith("#") or len(line.split("\t")) <= 1
+            continue
+        c = line.split("\t")
+        assert len(c) == 9 and c[2] == "intron"
+        assert (c[0], int(c[3]) - 1, int(c[4]) - 1, c[6], c[1], c[7]) == (p["refseq"], p["start"], p["end"], p["strand"], p["source"], p["frame"])
+        assert (float(c[5]) if c[5] != "." else 0.0) == p["score"] and c[8].split(";") == p["attrs"]
+        mult = [a.split("=")[1] for a in p["attrs"] if a.startswith("mult")]
+        assert not mult or int(mult[0]) == p["raw"]
+
+
+@pytest.mark.parametrize("name", sorted(FIX2["cases"]))
+def test_oracle_bed_and_gff_are_what_junctools_parsed(orc, name):
+    refs, genomes, batches, orientation = build_cases()[name]
+    rows, _ = orc.run_prep_like(refs, genomes, batches, orientation)
+    names = [n for n, _ in refs]
+    check_bed_against_fixture(orc.write_bed(rows, names, version="1.2.4").decode(), FIX2["cases"][name])
+    check_gff_against_fixture(orc.write_intron_gff(rows, names).decode(), FIX2["cases"][name])
+    # the three files name the same introns: junctools' three parsers agree line by line
+    tab = FIX["cases"][name]["rows"]
+    bed = [e["parsed"] for e in FIX2["cases"][name]["bed"] if e["parsed"]]
+    gff = [e["parsed"] for e in FIX2["cases"][name]["intron_gff"] if e["parsed"]]
+    assert len(tab) == len(bed) == len(gff)
+    for t, b, g in zip(tab, bed, gff):
+        assert (t["refseq"], t["start"], t["end"]) == (b["refseq"], b["start"], b["end"]) == (g["refseq"], g["start"], g["end"])
+        assert (t["left"], t["right"]) == (b["left"], b["right"])

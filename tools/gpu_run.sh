@@ -9,6 +9,7 @@
 #   prof             tools/profile_round.sh: rocprofv3 kernel stats + FETCH/WRITE PMC passes + the bench line
 #   sq               SQ issue / stall counters per kernel (tools/pmc_sq.sh), condensed by tools/show_sq.py
 #   sqv:<variant>    instruction counts per kernel (the first two counter groups of pmc_sq.sh) of tools/variants/libpjb_<variant>.so
+#   e2eprof          (behind `bench`) the program on the bench's prepared BAM with PJB_PROFILE_HOST=1, three runs -> gpurun_out/<TAG>_e2e_host_profile_k.txt
 #   fuzz             the three fuzz campaigns (tests/fuzz_campaign.py, fuzz_groups.py, fuzz_extra.py)
 #   cmd:<shell>      anything else
 # TAG (environment, default r04) names the outputs; COMMIT is recorded in the PMC summary.
@@ -32,6 +33,9 @@ for step in "$@"; do
     prof) bash tools/profile_round.sh $TAG ${COMMIT:-unknown}; python3 tools/show_bench.py $OUT/${TAG}_bench_C3.json ;;
     sq) bash tools/pmc_sq.sh $TAG > $OUT/${TAG}_sq_summary.csv 2>&1; python3 tools/show_sq.py $OUT/sq_$TAG/summary.csv | tee $OUT/${TAG}_sq.txt ;;
     sqv:*) v=${step#sqv:}; PJB_BENCH_ABLATION=1 PJB_LIB_PATH=$PWD/tools/variants/libpjb_$v.so SQ_GROUPS=2 bash tools/pmc_sq.sh ${TAG}_$v > $OUT/${TAG}_sq_${v}_summary.csv 2>&1; python3 tools/show_sq.py $OUT/sq_${TAG}_$v/summary.csv | head -4 | tee $OUT/${TAG}_sq_$v.txt ;;
+    e2eprof) # after a `bench` step in the same call (the prepared directory is kept in /tmp/pjb_bench_e2e): the program's own host profile, three runs
+           for k in 1 2 3; do ( time PJB_PROFILE_HOST=1 portcullis_amd/host/portcullis_amd junc -t $(nproc) --orientation FR -o /tmp/pjb_bench_e2e/prof/pc /tmp/pjb_bench_e2e/prep ) > $OUT/${TAG}_e2e_host_profile_$k.txt 2>&1; grep -E "real|Wall" $OUT/${TAG}_e2e_host_profile_$k.txt | head -3; done
+           grep -E "host profile" $OUT/${TAG}_e2e_host_profile_2.txt | tail -40 ;;
     fuzz) ( timeout 1500 python tests/fuzz_campaign.py; timeout 900 python tests/fuzz_groups.py; timeout 900 python tests/fuzz_extra.py ) 2>&1 | tail -30 | tee $OUT/${TAG}_fuzz.txt ;;
     cmd:*) bash -c "${step#cmd:}" ;;
     *) echo "unknown step $step"; rc=2 ;;
