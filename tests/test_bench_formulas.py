@@ -1,6 +1,7 @@
 """bench.py's byte formulas: every kernel the chain launches (pjb_api.hip) has one, so that `roofline.step_alg_bytes` prices the whole step."""
 import os
 import re
+import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -33,3 +34,28 @@ def test_survey_formula_is_the_one_of_section_8d():
     # N (18 + 4 c) + P (24 + 128 + 16 + 36 + 1.5 A + 4 c_s + 16 + 32) + 264 J with A = L
     got = bench.survey_bytes(10, 30, 4, 16, 5, 2, 100)
     assert got == 10 * (18 + 4 * 3.0) + 5 * (24 + 128 + 16 + 36 + 150.0 + 4 * 4.0 + 16 + 32) + 2 * 264
+
+
+def test_committed_counter_figures_carry_the_kernel_sources_hash(tmp_path):
+    """Round 4's verdict: roofline.traffic came from a committed file whatever the kernels had become since.  The committed PMC /
+    rocprof summaries now carry the hash of portcullis_amd/csrc/ they were measured on (tools/csrc_hash.py) and bench.py quotes
+    them only on a match.  Here: the hash is stable, follows the sources, and the committed files that exist have one."""
+    import json
+    import shutil
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from csrc_hash import csrc_hash
+    h = csrc_hash(ROOT)
+    assert len(h) == 16 and h == csrc_hash(ROOT) and int(h, 16) >= 0
+    # a copy with one byte more in a kernel file hashes differently
+    dst = tmp_path / "portcullis_amd" / "csrc"
+    shutil.copytree(os.path.join(ROOT, "portcullis_amd", "csrc"), dst, ignore=shutil.ignore_patterns("*.so"))
+    assert csrc_hash(str(tmp_path)) == h
+    with open(dst / "pjb_kernels.hip.h", "a") as f:
+        f.write("\n")
+    assert csrc_hash(str(tmp_path)) != h
+    for name in ("pmc_traffic_latest.json", "rocprof_latest.json"):
+        p = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(p):
+            j = json.load(open(p))
+            if "_csrc_hash" in j:  # (files of round 4 have none: bench.py drops their figures)
+                assert len(j["_csrc_hash"]) == 16
