@@ -39,7 +39,7 @@ sys.path.insert(0, ROOT)
 PEAK_HBM_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 
 
-def algorithmic_bytes(name, N, C, S, Cs, P, J, L, Pg=0, Rg=0, R=0, cand=0, Rv=0, sort_u32=True, G=0):
+def algorithmic_bytes(name, N, C, S, Cs, P, J, L, Pg=0, Rg=0, R=0, cand=0, Rv=0, sort_u32=True, G=0, sort_ids=None):
     """Algorithmic HBM bytes of ONE launch of kernel `name` over one chain (each byte counted once per logical
     pass, caches ignored; DESIGN.md section 4 derives these).  N reads, C cigar ops, S spliced reads, Cs cigar ops
     of spliced reads, P pairs, J junctions, L read length, Pg pairs / Rg reads that take the generic walks, R
@@ -47,6 +47,16 @@ def algorithmic_bytes(name, N, C, S, Cs, P, J, L, Pg=0, Rg=0, R=0, cand=0, Rv=0,
     dense 32-bit ids (else on the 64-bit keys), G bases of the chain's targets."""
     frags = P / 64.0 + J
     ops_s = Cs / max(S, 1)  # cigar ops of a spliced read
+    # the sort's digit tables: one count per digit value and tile of 4096 pairs.  Dense ids: digits planned for twice the junctions
+    # the context's chains have had, at least 2^16 (pjb_api.hip: prepare_flight), in passes of at most 11 bits
+    rs_tiles = P / 4096.0
+    if sort_u32:
+        id_bits = int(sort_ids if sort_ids else max(1 << 16, 2 * max(int(J), 1))).bit_length()  # (sort_ids: what the library planned for)
+        n_pass = -(-id_bits // 11)
+        rs_nb = 1 << -(-id_bits // n_pass)
+    else:
+        rs_nb = 1 << 11
+    rs_table = rs_tiles * rs_nb * 4
     table = {
         # pos, cig_off, l_qseq, seq_off (4 each), xs (1) + every cigar op; 24 B written per spliced read (index, pair offset, and the
         # 16-B record of what this pass holds of the read: operations index / count, position, bases offset, l_qseq)
@@ -66,9 +76,11 @@ def algorithmic_bytes(name, N, C, S, Cs, P, J, L, Pg=0, Rg=0, R=0, cand=0, Rv=0,
         # written; the scan over the start ranks' end slots (32 B per start, J starts at most) gives the first ids
         "kd_rank_reduce": G / 64.0 * 8, "kd_rank_apply": G / 64.0 * 12, "kd_rank_tiles": G / 64.0 / 2048 * 16 + 64, "kd_first_reduce": J * 32.0, "kd_first_apply": J * 44.0,
         # the sort: key in (4 or 8), index in (4, but for the first pass), both out
-        "rs_hist": P * (4 if sort_u32 else 8),
-        "rs_scatter": P * (16 if sort_u32 else 24),
-        "rs_panel_sums": P / 4096.0 * 4096, "rs_panel_scan": P / 4096.0 * 8192,  # the tiles' digit counts (1024 x 4 B a tile): read; read + written
+        # ... and the tiles' digit counts (rs_table: written by rs_hist, read by rs_panel_sums, read and written as offsets by
+        # rs_panel_scan, read by rs_scatter -- round 4's PMC pass: a third of the sort's traffic, not in the formulas then)
+        "rs_hist": P * (4 if sort_u32 else 8) + rs_table,
+        "rs_scatter": P * (16 if sort_u32 else 24) + rs_table,
+        "rs_panel_sums": rs_table + rs_table / 64.0, "rs_panel_scan": 2 * rs_table + rs_table / 64.0,
         # sorted key (8) + index (4) + the position word of the record behind it (4); the apply pass writes the junction id
         # (chains that sort the full keys) the scan's closing kernel; rest state of accumulators and anchors; anchors from the sorted
         # pairs (index, id, lStart / rEnd half of the record) and the BAM-order ids
@@ -383,6 +395,8 @@ def main():
             kt[dominant] = kt_timed[dominant]  # measured live over the timed region (beside whatever overlapped it)
         per = state.get("per_chain", {})
         kern = []
+        # (what the library plans the sort's digits from: the most junctions per read a chain of this context has had -- pjb_api.hip: junc_per_read)
+        junc_per_read = max([sum(int(regs[t]["n_junctions"]) for t in g) / max(sum(contigs[t]["n"] for t in g), 1) for g in chains] + [0.0])
         for name, (launches, ms) in kt.items():
             if launches == 0:
                 continue
@@ -398,7 +412,8 @@ def main():
                                       sum(c["Cs"] for c in cs_), sum(c["P"] for c in cs_), Jc, L, int(tm.get("generic_pairs", 0)),
                                       int(tm.get("generic_reads", 0)), int(tm.get("position_runs", 0)), int(tm.get("candidates", 0)),
                                       int(tm.get("checked_reads", 0)), int(tm.get("candidates", 0)) > 0,
-                                      sum(int(c["genome"].numel()) for c in cs_))
+                                      sum(int(c["genome"].numel()) for c in cs_),
+                                      sort_ids=max(1 << 16, int(2.0 * junc_per_read * sum(c["n"] for c in cs_) + 64.0)))
                 if b is None:
                     known = False
                     break

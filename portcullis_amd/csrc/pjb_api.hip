@@ -280,6 +280,7 @@ struct pjb_ctx {
     int64_t mirror_acc[5] = {0, 0, 0, INT32_MAX, 0}; // spliced, unspliced, sum_len, min_len, max_len
     pjb_timing timing;
     int radix_max_bits = 11;
+    double junc_per_read = 0;         // most junctions per read a chain of this context has had (the sort's digits of the next chain)
     u32 sort_floor = 1u << 16;        // pjb_set_option("sort_floor", n): the least number of junction ids the sort's digits are planned for (tests: small)
     u32 list_cap_forced = 0;          // pjb_set_option("list_cap", n): the read lists' first room (tests of the OVF_LISTS repeat)
     bool k1_serial = true;            // PJB_K1_SERIAL=0: the chains' K1 stages side by side
@@ -2031,7 +2032,8 @@ static void prepare_flight(pjb_ctx *c, Flight &f) {
     lim.kf.total_bits = lim.kf.lbits + std::max(1, bits_of((uint64_t)std::max<int64_t>(f.vlen, 1)));
     lim.dense = c->dense_ids;
     // (twice what a chain of this context's targets has had, per member; a chain with more is repeated with digits for junc_limit)
-    lim.sort_limit = c->junc_seen ? std::min<u32>(lim.junc_limit, std::max<u32>(c->sort_floor, 2 * c->junc_seen * (u32)std::max<size_t>(1, f.tids.size()))) : 0u;
+    // (junctions per read: chains of one file have about the same, whatever their targets' number and size)
+    lim.sort_limit = c->junc_per_read > 0 ? std::min<u32>(lim.junc_limit, std::max<u32>(c->sort_floor, (u32)std::min<double>(4.0e9, 2.0 * c->junc_per_read * (double)f.n_reads + 64.0))) : 0u;
 }
 
 // streams and events of a control slot, at its first use (a context that never queues eight chains never pays for them)
@@ -2244,6 +2246,7 @@ static int collect_flight(pjb_ctx *c, pjb_region_result *res, bool *redo_single)
         Rsum.max_len = cs.max_len;
     }
     c->junc_seen = std::max(c->junc_seen, group ? J / (u32)n_members : J);
+    if (f.n_reads > 0) c->junc_per_read = std::max(c->junc_per_read, (double)J / (double)f.n_reads);
     c->timing.sort_passes = f.n_pass;
     c->timing.generic_pairs = 0;
     c->timing.generic_reads = 0;
