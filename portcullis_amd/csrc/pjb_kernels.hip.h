@@ -668,7 +668,7 @@ __device__ __forceinline__ u32 spl_nlq(u32 n, bool seq_ok, int32_t lq) {
 #define K1C_NO_ROWS 0 // 1: every tile takes the rounds (A/B builds)
 #endif
 #ifndef K1C_WAVES
-#define K1C_WAVES 5 // (84 registers as the compiler wants them; forced to 64: 31 spills, 99 against 61 us a launch)
+#define K1C_WAVES 7 // waves per SIMD the register allocation aims at: 5 / 6 / 7 / 8 = 423 / 412 / 408 / 490 us a chain (8: 27 registers spilled)
 #endif
 // ONE launch per chain: block = one tile of the chain's tile space; its batch is the last one whose tile_base it has reached
 // (the descriptors live in device memory, the index is uniform: scalar loads).  chk_members (groups): see chk_ref_len below.
