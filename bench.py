@@ -80,7 +80,8 @@ def algorithmic_bytes(name, N, C, S, Cs, P, J, L, Pg=0, Rg=0, R=0, cand=0, Rv=0,
         # rs_panel_scan, read by rs_scatter -- round 4's PMC pass: a third of the sort's traffic, not in the formulas then)
         "rs_hist": P * (4 if sort_u32 else 8) + rs_table,
         "rs_scatter": P * (16 if sort_u32 else 24) + rs_table,
-        "rs_panel_sums": rs_table + rs_table / 64.0, "rs_panel_scan": 2 * rs_table + rs_table / 64.0,
+        # (a panel = 64 tiles; rs_panel_scan lets every panel add up the sums of the panels before it: panels^2 / 2 rows of rs_nb counts)
+        "rs_panel_sums": rs_table + rs_table / 64.0, "rs_panel_scan": 2 * rs_table + (rs_tiles / 64.0) ** 2 / 2.0 * rs_nb * 4,
         # sorted key (8) + index (4) + the position word of the record behind it (4); the apply pass writes the junction id
         # (chains that sort the full keys) the scan's closing kernel; rest state of accumulators and anchors; anchors from the sorted
         # pairs (index, id, lStart / rEnd half of the record) and the BAM-order ids
