@@ -12,9 +12,9 @@
 #   e2eprof          (behind `bench`) the program on the bench's prepared BAM with PJB_PROFILE_HOST=1, three runs -> gpurun_out/<TAG>_e2e_host_profile_k.txt
 #   fuzz             the three fuzz campaigns (tests/fuzz_campaign.py, fuzz_groups.py, fuzz_extra.py)
 #   cmd:<shell>      anything else
-# TAG (environment, default r04) names the outputs; COMMIT is recorded in the PMC summary.
+# TAG (environment, default r05) names the outputs; COMMIT is recorded in the PMC summary.
 cd "$GRAFT_REPO_ROOT" || exit 1
-TAG=${TAG:-r04}
+TAG=${TAG:-r05}
 OUT=gpurun_out
 mkdir -p $OUT
 rc=0
