@@ -2017,7 +2017,7 @@ __device__ __forceinline__ void cmp_block_lds(const u32 *qs, int32_t qw0, int32_
 // of trip v + 1 are already on their way (in registers), and ALL of a trip's staging loads (bases, three genome windows) are
 // issued together, behind one wait.
 #ifndef K1E_ABL
-#define K1E_ABL 0 // timing experiments only (tools/build_variants.sh): 1 no compares, 2 no candidates, 4 no staging (every compare gathers), 8 no list appends, 16 no gathering compares
+#define K1E_ABL 0 // timing experiments only (tools/build_variants.sh): 1 no compares, 2 no candidates, 4 no staging (every compare gathers), 8 no list appends, 16 no gathering compares, 32 / 64 the gathers of a lane pair / quad next to each other (results wrong)
 #endif
 #ifdef K1E_PROF // (debug builds: wave-cycles per section of k1_emit, summed over every wavefront; printed by pjb_destroy)
 __device__ unsigned long long g_k1e_prof[16];
@@ -2349,7 +2349,16 @@ __global__ __launch_bounds__(K1E_T) __attribute__((amdgpu_waves_per_eu(K1E_WAVES
                     if (act) {
                         const int32_t qi = k == 0 ? bq[0] : k == 1 ? bq[1] : bq[2], gi = k == 0 ? bg[0] : k == 1 ? bg[1] : bg[2];
                         CmpChunkT<SIMPLE_NW> C;
+#if K1E_ABL & 96
+                        { // (timing only, results wrong: the lanes of a pair / a quad load from the first one's addresses)
+                            const int src = lane_id() & ((K1E_ABL & 64) ? ~3 : ~1);
+                            const u32 so_ = (u32)__shfl((int)so, src, 64);
+                            const int32_t qi_ = __shfl(qi, src, 64) + ((lane_id() - src) * 32), gi_ = __shfl(gi, src, 64) + ((lane_id() - src) * 32);
+                            chunk_load<SIMPLE_NW, true>(C, (const u32 *)b.seq4 + so_, qi_, (int32_t)min(seq_words - 1u - so_, 0x7fffffffu), (const u32 *)gcodes, gi_, g_words, l, t);
+                        }
+#else
                         chunk_load<SIMPLE_NW, true>(C, seqw, qi, q_limit, (const u32 *)gcodes, gi, g_words, l, t);
+#endif
                         chunk_cmp<SIMPLE_NW>(C, qi, gi, l, t, 0, mism, first, last);
                         t += 8 * (SIMPLE_NW - 1);
                     }
