@@ -1443,6 +1443,46 @@ __device__ __forceinline__ void chunk_cmp(CmpChunkT<NW> &C, int32_t qi, int32_t 
         }
     }
 }
+// v_ffbl_b32 / v_ffbh_u32 as the hardware defines them: 0xffffffff for 0 (the language's count-zeros builtins leave 0 undefined or
+// cost a second instruction)
+__device__ __forceinline__ u32 ffbl_hw(u32 x) {
+    u32 r;
+    asm("v_ffbl_b32 %0, %1" : "=v"(r) : "v"(x));
+    return r;
+}
+__device__ __forceinline__ u32 ffbh_hw(u32 x) {
+    u32 r;
+    asm("v_ffbh_u32 %0, %1" : "=v"(r) : "v"(x));
+    return r;
+}
+// chunk_cmp without a branch: the words' flags (top bit of every nibble that differs) are cut to the anchor's length by a shift pair
+// (no compare / select, nothing skipped), and the first / last mismatch are kept as BIT positions 4 * base + 3 from the anchor's
+// start -- fbit: the lowest (0xffffffff: none), lbit1: the highest + 1 (0: none) -- folded with saturating adds and min / max, which
+// make a word without mismatches neutral (v_ffbl / v_ffbh return 0xffffffff for it).  base = (int32_t)fbit >> 2 and
+// ((int32_t)lbit1 - 1) >> 2, -1 for none.  20 vector instructions a word where chunk_cmp takes 26 and seven scalar ones.
+template <int NW>
+__device__ __forceinline__ void chunk_cmp_bits(CmpChunkT<NW> &C, int32_t qi, int32_t gi, int32_t l, int32_t t, u32 &mism, u32 &fbit, u32 &lbit1) {
+    const u32 shq = (u32)(qi & 7) * 4u, shg = (u32)(gi & 7) * 4u;
+#pragma unroll
+    for (int k = 0; k < NW; k++) C.qw[k] = swap_nibbles(C.qw[k]);
+    const int32_t rem2 = 2 * (l - t); // twice the bases left from the chunk's first
+    u32 fw = 0xffffffffu, lw = 0;
+#pragma unroll
+    for (int c = 0; c < NW - 1; c++) {
+        int32_t w2 = rem2 - 16 * c; // twice the word's valid bases, 0 .. 16
+        w2 = w2 < 0 ? 0 : (w2 > 16 ? 16 : w2);
+        const u32 inval = (0xffffffffu << (u32)w2) << (u32)w2; // (two shifts: a shift by 32 would not move)
+        const u32 q = __builtin_amdgcn_alignbit(C.qw[c + 1], C.qw[c], shq);
+        const u32 g = __builtin_amdgcn_alignbit(C.gg[c + 1], C.gg[c], shg);
+        const u32 x = q ^ g;
+        const u32 m = (((x & 0x77777777u) + 0x77777777u) | x) & (0x88888888u & ~inval);
+        mism += (u32)__popc(m);
+        fw = min(fw, __builtin_elementwise_add_sat(ffbl_hw(m), 32u * (u32)c));
+        lw = max(lw, __builtin_elementwise_sub_sat(32u * (u32)c + 32u, ffbh_hw(m)));
+    }
+    fbit = min(fbit, __builtin_elementwise_add_sat(fw, 4u * (u32)t));
+    lbit1 = lw ? lw + 4u * (u32)t : lbit1; // (rounds ascend)
+}
 // one stretch of l bases
 template <int NW, bool TO_BUFFER_END = false>
 __device__ __forceinline__ void cmp_words(const u32 *seqw, int32_t qi, int32_t q_last, const u32 *gw, int32_t gi, int32_t g_words, int32_t l,
@@ -2017,7 +2057,7 @@ __device__ __forceinline__ void cmp_block_lds(const u32 *qs, int32_t qw0, int32_
 // of trip v + 1 are already on their way (in registers), and ALL of a trip's staging loads (bases, three genome windows) are
 // issued together, behind one wait.
 #ifndef K1E_ABL
-#define K1E_ABL 0 // timing experiments only (tools/build_variants.sh): 1 no compares, 2 no candidates, 4 no staging (every compare gathers), 8 no list appends, 16 no gathering compares, 32 / 64 the gathers of a lane pair / quad next to each other (results wrong)
+#define K1E_ABL 0 // timing experiments only (tools/build_variants.sh): 1 no compares, 2 no candidates, 4 no staging (every compare gathers), 8 no list appends, 16 no gathering compares, 32 / 64 the gathers of a lane pair / quad next to each other, 128 no genome gathers, 256 no gathers (the compare runs on made-up words), 512 gathers without the compare (results wrong)
 #endif
 #ifdef K1E_PROF // (debug builds: wave-cycles per section of k1_emit, summed over every wavefront; printed by pjb_destroy)
 __device__ unsigned long long g_k1e_prof[16];
@@ -2341,7 +2381,8 @@ __global__ __launch_bounds__(K1E_T) __attribute__((amdgpu_waves_per_eu(K1E_WAVES
                 // more; each iteration is a memory round trip as well.
                 const int nb = two ? 3 : 2;
                 int k = 0;
-                int32_t t = 0, mism = 0, first = -1, last = -1;
+                int32_t t = 0;
+                u32 mism = 0, fbit = 0xffffffffu, lbit1 = 0;
                 for (;;) {
                     // (blocks without bases -- a clamped end -- are stepped over)
                     int32_t l = k == 0 ? bl[0] : k == 1 ? bl[1] : bl[2];
@@ -2356,18 +2397,39 @@ __global__ __launch_bounds__(K1E_T) __attribute__((amdgpu_waves_per_eu(K1E_WAVES
                             const int32_t qi_ = __shfl(qi, src, 64) + ((lane_id() - src) * 32), gi_ = __shfl(gi, src, 64) + ((lane_id() - src) * 32);
                             chunk_load<SIMPLE_NW, true>(C, (const u32 *)b.seq4 + so_, qi_, (int32_t)min(seq_words - 1u - so_, 0x7fffffffu), (const u32 *)gcodes, gi_, g_words, l, t);
                         }
+#elif K1E_ABL & 128
+                        { // (timing only, results wrong: the genome's words are not loaded)
+                            load_words<SIMPLE_NW>(C.qw, seqw, (qi + t) >> 3, q_limit);
+#pragma unroll
+                            for (int w = 0; w < SIMPLE_NW; w++) C.gg[w] = C.qw[w] ^ (u32)gi;
+                        }
+#elif K1E_ABL & 256
+                        { // (timing only, results wrong: nothing is loaded, the compare runs on made-up words)
+#pragma unroll
+                            for (int w = 0; w < SIMPLE_NW; w++) C.qw[w] = (u32)qi * (u32)(w + 3) + (u32)t, C.gg[w] = (u32)gi * (u32)(w + 5) + (u32)t;
+                        }
 #else
                         chunk_load<SIMPLE_NW, true>(C, seqw, qi, q_limit, (const u32 *)gcodes, gi, g_words, l, t);
 #endif
-                        chunk_cmp<SIMPLE_NW>(C, qi, gi, l, t, 0, mism, first, last);
+#if K1E_ABL & 512
+                        { // (timing only, results wrong: the words are loaded and folded, not compared)
+                            u32 acc = 0;
+#pragma unroll
+                            for (int w = 0; w < SIMPLE_NW; w++) acc ^= C.qw[w] ^ C.gg[w];
+                            mism += acc & 1u;
+                        }
+#else
+                        chunk_cmp_bits<SIMPLE_NW>(C, qi, gi, l, t, mism, fbit, lbit1);
+#endif
                         t += 8 * (SIMPLE_NW - 1);
                     }
                     if (k < nb && t >= l) { // the lane's block is finished (or empty): its results, the next block
-                        if (k == 0) res[0].mism = mism, res[0].first = first, res[0].last = last;
-                        if (k == 1) res[1].mism = mism, res[1].first = first, res[1].last = last;
-                        if (k == 2) res[2].mism = mism, res[2].first = first, res[2].last = last;
+                        const int32_t first = (int32_t)fbit >> 2, last = ((int32_t)lbit1 - 1) >> 2; // (-1: no mismatch)
+                        if (k == 0) res[0].mism = (int32_t)mism, res[0].first = first, res[0].last = last;
+                        if (k == 1) res[1].mism = (int32_t)mism, res[1].first = first, res[1].last = last;
+                        if (k == 2) res[2].mism = (int32_t)mism, res[2].first = first, res[2].last = last;
                         k++;
-                        t = 0, mism = 0, first = -1, last = -1;
+                        t = 0, mism = 0, fbit = 0xffffffffu, lbit1 = 0;
                     }
                     if (!__ballot(k < nb)) break;
                 }
