@@ -3926,10 +3926,20 @@ __global__ __launch_bounds__(256) void k5_frag_reduce(const u32 *frag, const int
         else if (k == F_FIRSTMIS) atomicMin(dst, v);
         else if (v) atomicAdd(dst, v);
     };
-    for (u32 s = s0; s < s1; s++) {
-        const int32_t j = __shfl(myj, (int)(s - s0), 64);
+    // (the rows of all sixteen slots are asked for before the first is folded: sixteen loads on their way at once, not a chain of
+    // sixteen round trips)
+    u32 row[FRAG_SLOTS_PER_WAVE];
+#pragma unroll
+    for (int q = 0; q < FRAG_SLOTS_PER_WAVE; q++) {
+        const int32_t jq = __shfl(myj, q, 64);
+        row[q] = (jq >= 0 && k < F_WORDS) ? frag[(size_t)(s0 + (u32)q) * F_WORDS + k] : 0u;
+    }
+#pragma unroll
+    for (int q = 0; q < FRAG_SLOTS_PER_WAVE; q++) {
+        if (s0 + (u32)q >= s1) break;
+        const int32_t j = __shfl(myj, q, 64);
         if (j < 0) continue; // unused slot
-        const u32 w = k < F_WORDS ? frag[(size_t)s * F_WORDS + k] : 0u;
+        const u32 w = row[q];
         const u32 wlo = __shfl(w, F_MISM_LO, 64);
         if (j != cur) {
             flush(cur);
