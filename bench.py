@@ -251,6 +251,10 @@ def main():
     else:
         chains = [[t] for t in mine]
     chains.sort(key=lambda g: -sum(contigs[t]["n"] for t in g))  # largest first: the queue drains at the end of a step on the small ones
+    if os.environ.get("PJB_BENCH_CHAINS"):  # (experiment: "0-3;4-9;10-24": the chains and their order as given)
+        chains = [list(range(int(a.split("-")[0]), int(a.split("-")[-1]) + 1)) for a in os.environ["PJB_BENCH_CHAINS"].split(";")]
+        chains = [[t for t in g if t in mine] for g in chains]
+        assert sorted(t for g in chains for t in g) == sorted(mine)
 
     def step():
         ctx.clear_rows()
