@@ -68,8 +68,9 @@ def algorithmic_bytes(name, N, C, S, Cs, P, J, L, Pg=0, Rg=0, R=0, cand=0, Rv=0,
         # the reads k1_emit leaves to a walk of their operations (those on k4b_generic's first list and the multi-intron reads beyond
         # two introns, about as many again): list entry (8), list record (16), five gathers (12), operations, bases + codes, the pairs
         "k1_generic": (Rg + Rv / 2.0) * (36 + 4 * ops_s + L) + (Pg + Rv) * 40,  # (about half of the checked reads come from here)
-        # K2d.  kd_assign: the pair's key read (8), its junction id written (4); the accumulators' rest state (192 B per junction)
-        "kd_assign": P * 12 + J * 192,
+        # K2d.  kd_assign: the pair's key read (8), its junction id written (4); the accumulators' rest state (192 B per junction);
+        # the tiles' counts of the ids' first digit (the sort's first pass has no rs_hist)
+        "kd_assign": P * 12 + J * 192 + rs_table,
         # candidates: key (8), anchors (8), rank (4); bitmap words / end slots they touch; kd_table writes key + anchors per junction
         "kd_mark": cand * 16, "kd_ends": cand * 12 + cand * 4, "kd_table": cand * 20 + J * 16, "kd_reset": cand * 12 + cand * 40,
         # prefix popcount over the start bitmap (a bit per base of the chain's targets): words read twice, a 4-B rank per word
@@ -423,6 +424,8 @@ def main():
                     known = False
                     break
                 mult = int(tm.get("sort_passes", 1)) if name in ("rs_hist", "rs_scatter", "rs_panel_sums", "rs_panel_scan") else 1
+                if name == "rs_hist" and int(tm.get("candidates", 0)) > 0:
+                    mult -= 1  # (dense ids: kd_assign counts the first digit)
                 tot_b += b * mult
             per_step = launches / args.steps
             kern.append(dict(name=name, launches=launches, avg_ms=ms / launches, total_ms=ms,

@@ -1728,6 +1728,24 @@ static int queue_contig(pjb_ctx *c, Flight &f) {
 
     // ---- K2d: ordered dense junction ids (the sort then works on 15-19 bits instead of 46-48)
     int sort_bits = kf.total_bits;
+    // the sort's passes: as few as the widest digit allows, bits spread evenly (planned before kd_assign, which counts the first digit)
+    const u32 rs_tiles = std::max<u32>(1, (PL + RS_TILE - 1) / RS_TILE);
+    int n_pass = 1;
+    std::vector<int> pass_bits;
+    bool first_hist_done = false;
+    auto plan_passes = [&]() -> int {
+        n_pass = (sort_bits + c->radix_max_bits - 1) / c->radix_max_bits;
+        if (n_pass < 1) n_pass = 1;
+        pass_bits.assign((size_t)n_pass, sort_bits / n_pass);
+        for (int p = 0; p < sort_bits % n_pass; p++) pass_bits[(size_t)p]++;
+        const int dbits = pass_bits[0];
+        int rc2;
+        if ((rc2 = ensure(c, S.hist, (size_t)rs_tiles * (1u << dbits) * 4))) return rc2;
+        if ((rc2 = ensure(c, S.hist_scan, (size_t)rs_tiles * (1u << dbits) * 4))) return rc2;
+        if ((rc2 = ensure(c, S.bintotal, (size_t)4 << dbits))) return rc2;
+        if ((rc2 = ensure(c, S.hist_part, (size_t)((rs_tiles + RSP_TILES - 1) / RSP_TILES) * (1u << dbits) * 4))) return rc2;
+        return PJB_OK;
+    };
     if (lim.dense) {
         const u32 cand_blocks = std::min<u32>(pair_blocks, 1024u); // (a few candidates per junction: these kernels stride)
         const u64 *okey = (const u64 *)pr.key;
@@ -1744,26 +1762,20 @@ static int queue_contig(pjb_ctx *c, Flight &f) {
         LAUNCH(c, "kd_table", kd_table, dim3(cand_blocks), dim3(256), (const u64 *)cand, (const u64 *)S.ent.p, (const u32 *)cand_rank, kf, JL,
                (const u32 *)S.ends.p, (const u32 *)S.firstid.p, (const u64 *)S.total.p, (u64 *)S.jkey.p, (int32_t *)S.ancl.p, (int32_t *)S.ancr.p, d_cs,
                (const u32 *)d_gen_cnt, gen_cap, SL);
-        LAUNCH(c, "kd_assign", kd_assign, dim3((pair_blocks + KDA_PER - 1) / KDA_PER), dim3(256), okey, d_P, kf, (const u64 *)S.bitmap.p, (const u32 *)S.wrank.p,
+        // (a block per tile of the sort: it leaves the tile's counts of the ids' first digit -- the first pass below has no rs_hist)
+        sort_bits = std::max(1, bits_of((uint64_t)SL));
+        if ((rc = plan_passes())) return rc;
+        LAUNCH(c, "kd_assign", kd_assign, dim3(rs_tiles), dim3(256), okey, d_P, kf, (const u64 *)S.bitmap.p, (const u32 *)S.wrank.p,
                (const u32 *)S.ends.p, (const u32 *)S.firstid.p, JL, (const u64 *)S.total.p, (u32 *)S.jidbam.p, (u32 *)S.acc.p, (const u64 *)S.jkey.p,
-               (const int32_t *)S.ancl.p, (const int32_t *)S.ancr.p, d_err, d_cs);
+               (const int32_t *)S.ancl.p, (const int32_t *)S.ancr.p, d_err, d_cs, pass_bits[0], (u32 *)S.hist.p);
+        first_hist_done = true;
         if ((rc = fork_k4b())) return rc;
         LAUNCH(c, "kd_reset", kd_reset, dim3(cand_blocks), dim3(256), (const u64 *)cand, (const u32 *)cand_rank, kf, JL, (const ContigStats *)d_cs,
                (u64 *)S.bitmap.p, (u32 *)S.ends.p);
         S.dense_at_rest = true;
-        sort_bits = std::max(1, bits_of((uint64_t)SL));
-    }
-    // ---- K2: radix sort (key, pair index); digits: as few passes as the widest digit allows, bits spread evenly
-    const u32 rs_tiles = std::max<u32>(1, (PL + RS_TILE - 1) / RS_TILE);
-    int n_pass = (sort_bits + c->radix_max_bits - 1) / c->radix_max_bits;
-    if (n_pass < 1) n_pass = 1;
-    std::vector<int> pass_bits((size_t)n_pass, sort_bits / n_pass);
-    for (int p = 0; p < sort_bits % n_pass; p++) pass_bits[(size_t)p]++;
-    const int dbits = pass_bits[0];
-    if ((rc = ensure(c, S.hist, (size_t)rs_tiles * (1u << dbits) * 4))) return rc;
-    if ((rc = ensure(c, S.hist_scan, (size_t)rs_tiles * (1u << dbits) * 4))) return rc;
-    if ((rc = ensure(c, S.bintotal, (size_t)4 << dbits))) return rc;
-    if ((rc = ensure(c, S.hist_part, (size_t)((rs_tiles + RSP_TILES - 1) / RSP_TILES) * (1u << dbits) * 4))) return rc;
+    } else if ((rc = plan_passes()))
+        return rc;
+    // ---- K2: radix sort (key, pair index)
     int cur = 0, shift = 0;
     // digit passes.  Dense ids are 32-bit keys: pass 0 reads them where kd_assign left them (BAM order; k4b_generic reads that array
     // beside the sort, so no pass writes to it), the ping-pong buffers are the first halves of the 64-bit key buffers.
@@ -1771,7 +1783,8 @@ static int queue_contig(pjb_ctx *c, Flight &f) {
         using K = decltype(key_tag);
         const K *kin = (const K *)kin_v;
         K *kout = (K *)kout_v;
-        LAUNCH(c, "rs_hist", rs_hist<K>, dim3(rs_tiles), dim3(256), kin, d_P, shift, bits, (u32 *)S.hist.p, rs_tiles);
+        if (!(shift == 0 && first_hist_done)) // (dense ids: kd_assign counted the first digit)
+            LAUNCH(c, "rs_hist", rs_hist<K>, dim3(rs_tiles), dim3(256), kin, d_P, shift, bits, (u32 *)S.hist.p, rs_tiles);
         {
             const u32 nb = 1u << bits, n_panels = (rs_tiles + RSP_TILES - 1) / RSP_TILES;
             LAUNCH(c, "rs_panel_sums", rs_panel_sums, dim3(n_panels, (nb + 255) / 256), dim3(256), (const u32 *)S.hist.p, rs_tiles, nb, (u32 *)S.hist_part.p);

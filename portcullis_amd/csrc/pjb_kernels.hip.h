@@ -2900,16 +2900,28 @@ __device__ __forceinline__ void acc_rest_state(u32 *acc, u64 n_junc) { // what k
     for (u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += step) acc[t] = (t % F_WORDS) == F_FIRSTMIS ? 100000000u : 0u;
 }
 
+// (the sort's tile and its digit counter, defined with the sort below: kd_assign counts the first digit of the ids it hands out)
+constexpr int KDA_TILE = 4096; // = RS_TILE
+__device__ __forceinline__ void wave_hist_add(u32 *h, u32 d, bool valid);
 constexpr int KDA_PER = 4;
 __global__ __launch_bounds__(256) void kd_assign(const u64 *key, const u32 *np, KeyFmt kf, const u64 *bitmap, const u32 *wrank, const u32 *ends,
                                                  const u32 *first_id, u32 junc_limit, const u64 *total, u32 *jid_bam, u32 *acc, const u64 *jkey,
-                                                 const int32_t *anc_l, const int32_t *anc_r, u64 *err, ContigStats *cs_chk) {
+                                                 const int32_t *anc_l, const int32_t *anc_r, u64 *err, ContigStats *cs_chk, int hist_bits, u32 *hist) {
+    // A block takes one TILE of the sort (4 096 pairs, four chunks of 1 024) and leaves the tile's counts of the ids' first digit
+    // where rs_hist would have put them (hist_bits > 0): the sort's first pass starts at its scan -- the ids are not read a second
+    // time to be counted.
+    __shared__ u32 s_h[4096]; // (RS_MAX_BINS)
     const u32 n = *np;
     if (n == 0) return;
     {
         const u64 J = *total;
         acc_rest_state(acc, J < (u64)junc_limit ? J : (u64)junc_limit);
     }
+    const u32 nb = hist_bits > 0 ? 1u << hist_bits : 0u;
+    for (u32 d = threadIdx.x; d < nb; d += 256) s_h[d] = 0;
+    if (nb) __syncthreads();
+    for (u32 chunk = blockIdx.x * (KDA_TILE / (KDA_PER * 256)); chunk < (blockIdx.x + 1) * (KDA_TILE / (KDA_PER * 256)); chunk++) {
+    if (chunk * (KDA_PER * 256) >= n) break;
     // KDA_PER pairs a thread, their loads side by side: a pair is a chain of three dependent look-ups (key -> bitmap word and rank ->
     // end slots and first id), and a wavefront with one pair per lane (651 k of them a chain) spent its life waiting for them one
     // after the other -- 134 us a chain (round 4) for 267 MB
@@ -2920,7 +2932,7 @@ __global__ __launch_bounds__(256) void kd_assign(const u64 *key, const u32 *np, 
     u32 pp[KDA_PER];
 #pragma unroll
     for (int q = 0; q < KDA_PER; q++) {
-        pp[q] = (blockIdx.x * KDA_PER + q) * 256 + threadIdx.x;
+        pp[q] = (chunk * KDA_PER + q) * 256 + threadIdx.x;
         kk[q] = key[pp[q] < n ? pp[q] : n - 1];
     }
     bool lead[KDA_PER];
@@ -2957,10 +2969,11 @@ __global__ __launch_bounds__(256) void kd_assign(const u64 *key, const u32 *np, 
         fi[q] = id;
         eb[q] = 0;
         if (pp[q] < n) jid_bam[pp[q]] = id; // (the sort's first pass reads the ids from here; k4b_generic looks its pairs' junctions up)
+        if (nb) wave_hist_add(s_h, id & (nb - 1u), pp[q] < n);
     }
 #ifdef PJB_SELFCHECK
     const u32 p = pp[0];
-    if (p >= n) return;
+    if (p < n) {
     const int32_t s = ss[0], e = ee[0];
     const u32 rs = rs_[0], id = fi[0] + eb[0]; // (debug builds: the junction table kd_table made must know this pair's junction -- its start bit, its end slot, its key,
                      // anchors that enclose the intron; a failure stops the chain (P = 0) so that the report gets out)
@@ -2979,7 +2992,13 @@ __global__ __launch_bounds__(256) void kd_assign(const u64 *key, const u32 *np, 
             cs_chk->P = 0;
         }
     }
+    }
 #endif
+    } // chunks
+    if (nb) {
+        __syncthreads();
+        for (u32 d = threadIdx.x; d < nb; d += 256) hist[(size_t)blockIdx.x * nb + d] = s_h[d];
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2993,6 +3012,7 @@ constexpr int RS_ITEMS = 16;
 constexpr int RS_TILE = 256 * RS_ITEMS; // 4096 keys per block
 constexpr int RS_MAX_BITS = 12;
 constexpr int RS_MAX_BINS = 1 << RS_MAX_BITS;
+static_assert(KDA_TILE == RS_TILE && RS_MAX_BINS <= 4096, "kd_assign counts the sort's first digit tile by tile");
 
 // Histogram add of one digit per lane.  Keys arrive nearly sorted and deep junctions repeat one key
 // thousands of times, so most lanes of a wave often hold the same digit: the two most common
@@ -3912,7 +3932,6 @@ __global__ __launch_bounds__(256) void k5_frag_reduce(const u32 *frag, const int
     const int k = lane_id();
     const u32 s0 = wave * FRAG_SLOTS_PER_WAVE;
     if (s0 >= n_slots) return;
-    const u32 s1 = min(s0 + FRAG_SLOTS_PER_WAVE, n_slots);
     const int32_t myj = (k < FRAG_SLOTS_PER_WAVE && s0 + k < n_slots) ? frag_j[s0 + k] : -1;
     int32_t cur = -1;
     u32 v = 0, carry_lo = 0; // lane F_MISM_HI also keeps the low word to do the 64-bit add
@@ -3935,23 +3954,23 @@ __global__ __launch_bounds__(256) void k5_frag_reduce(const u32 *frag, const int
         row[q] = (jq >= 0 && k < F_WORDS) ? frag[(size_t)(s0 + (u32)q) * F_WORDS + k] : 0u;
     }
 #pragma unroll
-    for (int q = 0; q < FRAG_SLOTS_PER_WAVE; q++) {
-        if (s0 + (u32)q >= s1) break;
+    for (int q = 0; q < FRAG_SLOTS_PER_WAVE; q++) { // (no break / continue: the loop unrolls and row[] stays in registers)
         const int32_t j = __shfl(myj, q, 64);
-        if (j < 0) continue; // unused slot
-        const u32 w = row[q];
-        const u32 wlo = __shfl(w, F_MISM_LO, 64);
-        if (j != cur) {
-            flush(cur);
-            cur = j;
-            v = w;
-            carry_lo = wlo;
-        } else if (k == F_MISM_HI) {
-            const u64 sum = (((u64)v << 32) | carry_lo) + (((u64)w << 32) | wlo);
-            v = (u32)(sum >> 32);
-            carry_lo = (u32)sum;
-        } else {
-            v = frag_combine(k, v, w);
+        if (j >= 0) { // (unused slots and those past the last have -1)
+            const u32 w = row[q];
+            const u32 wlo = __shfl(w, F_MISM_LO, 64);
+            if (j != cur) {
+                flush(cur);
+                cur = j;
+                v = w;
+                carry_lo = wlo;
+            } else if (k == F_MISM_HI) {
+                const u64 sum = (((u64)v << 32) | carry_lo) + (((u64)w << 32) | wlo);
+                v = (u32)(sum >> 32);
+                carry_lo = (u32)sum;
+            } else {
+                v = frag_combine(k, v, w);
+            }
         }
     }
     flush(cur);
