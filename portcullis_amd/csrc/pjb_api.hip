@@ -1657,9 +1657,6 @@ static int queue_contig(pjb_ctx *c, Flight &f) {
             HIP_TRY(c, hipEventRecord(S.ev_xk1, c->stream));
             f.x_k1 = true;
         }
-        if (group)
-            LAUNCH(c, "kg_member_stats", kg_member_stats, dim3((unsigned)n_members), dim3(256), (const u32 *)S.tile_cnt.p, (const TileStats *)S.tile_stats.p,
-                   (const u32 *)d_tile_lo, n_members, d_members);
         LAUNCH(c, "k1_scan_tiles", k1_scan_tiles, dim3(c->k1s_blocks_forced ? (u32)c->k1s_blocks_forced : k1s_blocks(n_tiles)), dim3(K1S_THREADS), (u32 *)S.tile_cnt.p, (const TileStats *)S.tile_stats.p,
                n_tiles, d_cs, PL, kf, group ? INT32_MAX - 1 : ref_len, (const u64 *)nullptr, (u32 *)S.tile_soff.p, (u32 *)S.chunk_tile.p,
                (ScanPart *)S.scan_parts.p, ++S.scan_epoch);
@@ -1694,6 +1691,11 @@ static int queue_contig(pjb_ctx *c, Flight &f) {
             HIP_TRY(c, hipEventRecord(S.ev_k1, st));
             c->last_k1_ev = S.ev_k1;
         }
+        // (per-member counters of a group: off the K1 stage -- beside the next chain's k1_count -- and before k5_finalize counts the
+        // members' junctions into them)
+        if (group)
+            LAUNCH(c, "kg_member_stats", kg_member_stats, dim3((unsigned)n_members), dim3(256), (const u32 *)S.tile_cnt.p, (const TileStats *)S.tile_stats.p,
+                   (const u32 *)d_tile_lo, n_members, d_members, n_tiles, (const ContigStats *)d_cs);
         // the reads k1_emit left: one launch over the chain's third list (the blocks stride over it)
         LAUNCH(c, "k1_generic", k1_generic, dim3(std::min<u32>(std::max<u32>(1, (u32)(((u64)gen_cap * GEN_SHARDS + K1E_T - 1) / K1E_T)), 1536u /* six blocks a CU; 512 .. 3072 measured: no difference */)), dim3(K1E_T),
                (const DevBatch *)S.batches.p, (int)batches.size(), (const u32 *)S.splidx.p, (const uint4 *)S.splrec.p, pr, el, kf, GT, fast_codes ? 1 : 0,

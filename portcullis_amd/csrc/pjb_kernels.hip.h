@@ -2646,7 +2646,10 @@ __global__ __launch_bounds__(K1E_T) void k1_generic(const DevBatch *batches, int
 
 // per-member counters of a group, from the tile statistics of the member's tiles (before k1_scan_tiles turns the tile pair
 // counts into offsets): one block per member
-__global__ __launch_bounds__(256) void kg_member_stats(const u32 *tile_cnt, const TileStats *ts, const u32 *tile_lo, int n_members, MemberStats *out) {
+// (behind k1_scan_tiles and off the chain's K1 stage: a member's pairs are the difference of the scanned counts at its first tile and
+// the next member's)
+__global__ __launch_bounds__(256) void kg_member_stats(const u32 *tile_off, const TileStats *ts, const u32 *tile_lo, int n_members, MemberStats *out, u32 n_tiles,
+                                                       const ContigStats *cs) {
     __shared__ u64 sm[4][4];
     __shared__ int32_t smi[4][2];
     const int m = blockIdx.x;
@@ -2658,14 +2661,16 @@ __global__ __launch_bounds__(256) void kg_member_stats(const u32 *tile_cnt, cons
         spl += x.spliced;
         uns += x.unspliced;
         sum += x.sum_len;
-        pairs += tile_cnt[t];
         mn = min(mn, x.min_len);
         mx = max(mx, x.max_len);
     }
     spl = wave_sum(spl);
     uns = wave_sum(uns);
     sum = wave_sum(sum);
-    pairs = wave_sum(pairs);
+    {
+        const u32 t0 = tile_lo[m], t1 = tile_lo[m + 1], total = (u32)cs->n_pairs;
+        pairs = threadIdx.x == 0 ? (u64)((t1 < n_tiles ? tile_off[t1] : total) - (t0 < n_tiles ? tile_off[t0] : total)) : 0ull;
+    }
     mn = wave_min(mn);
     mx = wave_max(mx);
     const int w = threadIdx.x >> 6;
