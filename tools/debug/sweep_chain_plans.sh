@@ -1,5 +1,5 @@
-# (experiment) the step under different chain plans: a small last chain leaves less of its tail without a K1 stage beside it
-for plan in "" "0-3;4-9;10-18;19-24" "0-3;4-9;10-21;22-24" "0-3;4-9;10-16;17-24" "19-24;0-3;4-9;10-18" "0-4;5-11;12-21;22-24"; do
+# (experiment) the step under different chain plans (PJB_BENCH_CHAINS: the chains and their order as given)
+for plan in "" "0-5;6-13;14-24" "0-6;7-15;16-24" "0-7;8-17;18-24" "" "0-5;6-13;14-24" "0-6;7-15;16-24" "0-14;15-24"; do
   echo "== plan '$plan'"
   PJB_BENCH_CHAINS="$plan" python bench.py --steps 10 --warmup 3 --no-e2e --no-cpu-baseline 2>/dev/null | python3 -c "
 import json,sys
