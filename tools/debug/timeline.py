@@ -61,3 +61,8 @@ for s, e, n, q in sorted(seg):
 print("idle before kernel     count  total_ms  avg_us")
 for n, (k, t) in sorted(after.items(), key=lambda kv: -kv[1][1])[:15]:
     print(f"{n:24s} {k:6d} {t / 1e6:9.3f} {t / k / 1e3:8.1f}")
+import os
+if os.environ.get("TIMELINE_LIST"):  # every launch of the step in start order: start, end, duration (us from the step's start), stream
+    print("start_us   end_us   dur_us  kernel (stream)")
+    for s, e, n, q in sorted(seg):
+        print(f"{(s - t0) / 1e3:8.1f} {(e - t0) / 1e3:8.1f} {(e - s) / 1e3:7.1f}  {n} ({q})")
