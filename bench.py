@@ -549,6 +549,10 @@ def main():
             # sum of the kernels' own durations (one at a time) over the step's wall time: > 1 = what the streams overlap
             "overlap_factor": round(kernel_ms_per_step / (elapsed / args.steps * 1e3), 4),
             "host_queue_ms_per_step": round(host_queue_ms, 3),  # the calling thread inside pjb_submit_batch_device + pjb_finish_*_begin
+            # a chain's stages on their own (the instrumented steps: one chain at a time, one kernel at a time, gaps included): what the
+            # LAST chain of a step costs behind its K1 stage, where no other chain runs beside it
+            "chain_stages_ms_alone": [dict(targets=len(g), **{k: round(float(v), 3) for k, v in state["per_chain"][tuple(g)]["stage_ms"].items()})
+                                      for g in chains if tuple(g) in state.get("per_chain", {})],
             "pipeline_gbps": round(tot_bytes / (kernel_ms_per_step * 1e-3) / 1e9, 1) if kernel_ms_per_step else None,
             "kernels": [dict(name=k["name"], launches_per_step=k["launches"] / args.steps, avg_ms=round(k["avg_ms"], 5),
                              ms_per_step=round(k["total_ms"] / args.steps, 4),
