@@ -75,7 +75,10 @@ def algorithmic_bytes(name, N, C, S, Cs, P, J, L, Pg=0, Rg=0, R=0, cand=0, Rv=0,
         "kd_mark": cand * 16, "kd_ends": cand * 12 + cand * 4, "kd_table": cand * 20 + J * 16, "kd_reset": cand * 12 + cand * 40,
         # prefix popcount over the start bitmap (a bit per base of the chain's targets): words read twice, a 4-B rank per word
         # written; the scan over the start ranks' end slots (32 B per start, J starts at most) gives the first ids
-        "kd_rank_reduce": G / 64.0 * 8, "kd_rank_apply": G / 64.0 * 12, "kd_rank_tiles": G / 64.0 / 2048 * 16 + 64, "kd_first_reduce": J * 32.0, "kd_first_apply": J * 44.0,
+        # (round 5: the prefix sum runs over the counts of starts per PAGE of the bitmap -- 64 words = 4 096 bases --, and kd_rank_pages
+        # reads the words and writes the ranks of the pages that hold a start only: at most J of them)
+        "kd_rank_reduce": G / 4096.0 * 4, "kd_rank_apply": G / 4096.0 * 8, "kd_rank_tiles": G / 4096.0 / 2048 * 16 + 64,
+        "kd_rank_pages": G / 4096.0 * 8 + min(J, G / 4096.0) * (512 + 256), "kd_first_reduce": J * 32.0, "kd_first_apply": J * 44.0,
         # the sort: key in (4 or 8), index in (4, but for the first pass), both out
         # ... and the tiles' digit counts (rs_table: written by rs_hist, read by rs_panel_sums, read and written as offsets by
         # rs_panel_scan, read by rs_scatter -- round 4's PMC pass: a third of the sort's traffic, not in the formulas then)

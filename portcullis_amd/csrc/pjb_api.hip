@@ -160,6 +160,7 @@ struct CtlSlot {
     // the rest of the chain's scratch, and its streams: the chains of the two slots run side by side (most kernels of a
     // contig-sized chain are latency-bound and leave the chip half idle)
     Buf total, bitmap, wrank, ends, firstid, key[2], idx[2], hist, hist_scan, hist_part, bintotal, scan_tiles;
+    Buf pagecnt, pagerank; // K2d: starts per page of the bitmap (all-zero at rest), their exclusive prefix
     Buf jid, seg, runfirst, runstart, ent, entsum, frag, fragj, acc, ancl, ancr, jkey, genlist, masks;
     bool dense_at_rest = false;
     hipStream_t main = nullptr, side = nullptr; // chain; match statistics / entropy beside it
@@ -822,7 +823,7 @@ void pjb_destroy(pjb_ctx *c) {
         if (S.ev_rows) (void)hipEventDestroy(S.ev_rows);
         if (S.ev_done) (void)hipEventDestroy(S.ev_done);
         Buf *sb[] = {&S.x_q, &S.x_spos, &S.x_send, &S.x_gapoff, &S.x_zlist, &S.x_scnt, &S.x_codes, &S.cstats, &S.err, &S.gencount, &S.batches, &S.rows, &S.tile_cnt, &S.tile_stats, &S.splidx, &S.splpoff, &S.splrec, &S.tile_soff, &S.chunk_tile, &S.scan_parts, &S.members, &S.okey, &S.g,
-                     &S.rec, &S.jidbam, &S.jkey, &S.total, &S.bitmap, &S.wrank, &S.ends, &S.firstid,
+                     &S.rec, &S.jidbam, &S.jkey, &S.total, &S.bitmap, &S.wrank, &S.pagecnt, &S.pagerank, &S.ends, &S.firstid,
                      &S.key[0], &S.key[1], &S.idx[0], &S.idx[1], &S.hist, &S.hist_scan, &S.hist_part, &S.bintotal, &S.scan_tiles, &S.jid, &S.seg, &S.runfirst,
                      &S.runstart, &S.ent, &S.entsum, &S.frag, &S.fragj, &S.masks, &S.acc, &S.ancl, &S.ancr, &S.genlist};
         for (Buf *b : sb) release(*b);
@@ -1613,10 +1614,14 @@ static int queue_contig(pjb_ctx *c, Flight &f) {
         const void *was[2] = {S.bitmap.p, S.ends.p};
         if ((rc = ensure(c, S.bitmap, n_words * 8 + 16))) return rc;
         if ((rc = ensure(c, S.wrank, n_words * 4 + 16))) return rc;
+        const void *was_pc = S.pagecnt.p;
+        if ((rc = ensure(c, S.pagecnt, ((n_words >> KD_PAGE_SHIFT) + 1) * 4 + 16))) return rc;
+        if ((rc = ensure(c, S.pagerank, ((n_words >> KD_PAGE_SHIFT) + 1) * 4 + 16))) return rc;
         if ((rc = ensure(c, S.ends, (size_t)JL * DENSE_ENDS * 4 + 32))) return rc;
         if ((rc = ensure(c, S.firstid, (size_t)JL * 4 + 16))) return rc;
-        if (!S.dense_at_rest || was[0] != S.bitmap.p || was[1] != S.ends.p) { // (first use, new memory, or a chain that broke off)
+        if (!S.dense_at_rest || was[0] != S.bitmap.p || was[1] != S.ends.p || was_pc != S.pagecnt.p) { // (first use, new memory, or a chain that broke off)
             HIP_TRY(c, hipMemsetAsync(S.bitmap.p, 0, S.bitmap.cap, front));
+            HIP_TRY(c, hipMemsetAsync(S.pagecnt.p, 0, S.pagecnt.cap, front));
             HIP_TRY(c, hipMemsetAsync(S.ends.p, 0xff, S.ends.cap, front));
         }
         S.dense_at_rest = false; // until kd_reset is queued
@@ -1666,6 +1671,7 @@ static int queue_contig(pjb_ctx *c, Flight &f) {
         EmitLists el;
         el.cand = lim.dense ? (u64 *)S.key[1].p : (u64 *)nullptr;
         el.bitmap = lim.dense ? (u64 *)S.bitmap.p : (u64 *)nullptr;
+        el.page_cnt = lim.dense ? (u32 *)S.pagecnt.p : (u32 *)nullptr;
         el.cand_anc = (u64 *)S.ent.p; // (a pair-sized scratch buffer nothing else uses at this point)
         el.gen_list = (u64 *)S.genlist.p;
         el.gen_cnt = d_gen_cnt;
@@ -1752,9 +1758,12 @@ static int queue_contig(pjb_ctx *c, Flight &f) {
         const u32 cand_blocks = std::min<u32>(pair_blocks, 1024u); // (a few candidates per junction: these kernels stride)
         const u64 *okey = (const u64 *)pr.key;
         u64 *cand = (u64 *)S.key[1].p; // (k1_emit left the candidate keys here, and their starts' bits in the bitmap)
-        if ((rc = run_scan(c, "kd_rank", PopcFn{(const u64 *)S.bitmap.p}, ExclusiveU32Sink{(u32 *)S.wrank.p}, (u64)n_words,
-                           (u64 *)S.total.p)))
+        // (ranks of the bitmap's words: a prefix sum over the pages' counts of starts, then the words of the pages that hold one)
+        const u32 n_pages = (u32)((n_words + ((size_t)1 << KD_PAGE_SHIFT) - 1) >> KD_PAGE_SHIFT);
+        if ((rc = run_scan(c, "kd_rank", ArrU32Fn{(const u32 *)S.pagecnt.p}, ExclusiveU32Sink{(u32 *)S.pagerank.p}, (u64)n_pages, (u64 *)S.total.p)))
             return rc;
+        LAUNCH(c, "kd_rank_pages", kd_rank_pages, dim3((n_pages + 3) / 4), dim3(256), (const u64 *)S.bitmap.p, (const u32 *)S.pagecnt.p, (const u32 *)S.pagerank.p,
+               (u32 *)S.wrank.p, n_pages, (u32)n_words);
         u32 *cand_rank = (u32 *)S.idx[1].p; // (free until the first scatter as well)
         LAUNCH(c, "kd_ends", kd_ends, dim3(cand_blocks), dim3(256), (const u64 *)cand, kf, (const u64 *)S.bitmap.p, (const u32 *)S.wrank.p, JL,
                (u32 *)S.ends.p, cand_rank, d_cs);
@@ -1773,7 +1782,7 @@ static int queue_contig(pjb_ctx *c, Flight &f) {
         first_hist_done = true;
         if ((rc = fork_k4b())) return rc;
         LAUNCH(c, "kd_reset", kd_reset, dim3(cand_blocks), dim3(256), (const u64 *)cand, (const u32 *)cand_rank, kf, JL, (const ContigStats *)d_cs,
-               (u64 *)S.bitmap.p, (u32 *)S.ends.p);
+               (u64 *)S.bitmap.p, (u32 *)S.ends.p, (u32 *)S.pagecnt.p);
         S.dense_at_rest = true;
     } else if ((rc = plan_passes()))
         return rc;

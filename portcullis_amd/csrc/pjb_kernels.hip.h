@@ -1755,9 +1755,11 @@ constexpr int K1E_T = 256, K1E_SHIFT = 8; // threads of a block = list entries o
 constexpr int KC_SLOTS = K1E_T * K1E_SET;     // the block's candidate set (LDS), flushed when a quarter full
 constexpr u64 KD_EMPTY = ~0ull; // no key: a packed key has fewer than 64 bits
 constexpr u32 GEN_SHARDS = 256, GEN_CNT_STRIDE = 32;
+constexpr int KD_PAGE_SHIFT = 6; // a page of the start bitmap: 64 words, one wavefront
 struct EmitLists {
     u64 *cand;      // candidate keys (nullptr: the chain sorts the full keys and wants none); their count is ContigStats::n_cand
     u64 *bitmap;    // K2d's bitmap of intron starts (all-clear at rest): every candidate sets its start's bit as it is listed
+    u32 *page_cnt;  // starts per PAGE of the bitmap (64 words = 4 096 bases; all-zero at rest): counted as their bits are set for the first time
     u64 *cand_anc;  // per candidate: min lStart | max rEnd << 32 over the pairs it stands for (the junction anchors' first level)
     u64 *gen_list;  // [3][GEN_SHARDS][gen_cap].  Lists 1 and 2, for k4b_generic: global read ordinal | index of the read's first pair
                     // << 32 -- the reads whose pairs need the generic walks; the reads whose closed form waits for the window check.
@@ -1810,7 +1812,10 @@ struct EmitCtx {
     __device__ __forceinline__ void cand_mark(u64 k) const { // (what kd_mark did in a launch of its own)
         int32_t ms, me;
         unpack_key(kf, k, ms, me);
-        atomicOr((unsigned long long *)(E.bitmap + ((u32)ms >> 6)), 1ull << (ms & 63));
+        const u32 w = (u32)ms >> 6;
+        const u64 bit = 1ull << (ms & 63);
+        const u64 old = atomicOr((unsigned long long *)(E.bitmap + w), (unsigned long long)bit);
+        if (!(old & bit)) atomicAdd(&E.page_cnt[w >> KD_PAGE_SHIFT], 1u); // (the ranks below are scanned over the pages, not over the words)
     }
     __device__ __forceinline__ void cand_insert(u64 k, int32_t lstart, int32_t rend) const {
         if (!want_cand) return;
@@ -2753,15 +2758,31 @@ __global__ __launch_bounds__(256) void kd_ends(const u64 *cand, KeyFmt kf, const
         if (!placed) atomicOr(&cs->overflow, OVF_DENSE);
     }
 }
-// Bitmap and end slots are all-clear at rest: instead of two memsets over contig-sized buffers per contig, the
+// The ranks of the bitmap's words, page by page: the starts are few (a third of the pages of a human-sized chain hold one, fewer
+// where genes cluster), so the prefix sum runs over the PAGES' counts (k1_emit / k1_generic count a start when its bit is set for
+// the first time) and only the pages that hold a start are read: a wavefront per page, lane = word, the word's rank = the page's
+// rank + the popcounts of the page's words before it.  Words of pages without a start keep whatever rank they had: nobody asks
+// for it (kd_ends, kd_assign look up the words of their own starts).  (Until round 5 a three-kernel scan read all of the bitmap
+// twice and wrote every word's rank: 320 MB and 90 us a 1-Gb chain.)
+__global__ __launch_bounds__(256) void kd_rank_pages(const u64 *bitmap, const u32 *page_cnt, const u32 *page_rank, u32 *wrank, u32 n_pages, u32 n_words) {
+    const u32 page = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (page >= n_pages) return;
+    if (page_cnt[page] == 0) return; // (uniform per wavefront)
+    const u32 w = (page << KD_PAGE_SHIFT) + (u32)lane_id();
+    const u32 c = w < n_words ? (u32)__popcll(bitmap[w]) : 0u;
+    const u32 inc = wave_iscan(c);
+    if (w < n_words) wrank[w] = page_rank[page] + inc - c;
+}
+// Bitmap, page counts and end slots are all-clear at rest: instead of memsets over contig-sized buffers per contig, the
 // candidates wipe exactly what they set (after kd_assign has read it).
 __global__ __launch_bounds__(256) void kd_reset(const u64 *cand, const u32 *cand_rank, KeyFmt kf, u32 junc_limit, const ContigStats *cs,
-                                                u64 *bitmap, u32 *ends) {
+                                                u64 *bitmap, u32 *ends, u32 *page_cnt) {
     const u32 n = cs->n_cand;
     for (u32 p = blockIdx.x * 256 + threadIdx.x; p < n; p += gridDim.x * 256) {
         int32_t s, e;
         unpack_key(kf, cand[p], s, e);
         bitmap[(u32)s >> 6] = 0;
+        page_cnt[(u32)s >> (6 + KD_PAGE_SHIFT)] = 0;
         const u32 rs = cand_rank[p];
         if (rs < junc_limit) {
             uint4 *q = reinterpret_cast<uint4 *>(ends + (size_t)rs * DENSE_ENDS);
