@@ -359,7 +359,7 @@ def main():
     # timed region above ends with its last chain's tail (junction ids, sort, reductions, rows over PCIe) alone on the chip; a queue
     # of samples hides it behind the next sample's K1 stage.  Rows of all passes stay in the table: each pass's must equal the step's.
     back_to_back = None
-    if world == 1 and not os.environ.get("PJB_BENCH_ABLATION") and not args.no_back_to_back and args.steps > 1:
+    if not multi and not os.environ.get("PJB_BENCH_ABLATION") and not args.no_back_to_back and args.steps > 1:  # (no row exchange: its slot holds one pass)
         def passes_back_to_back(k):
             ctx.clear_rows()
             inflight = []
