@@ -6,6 +6,6 @@ OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_$1
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 for ctr in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $OUT/$ctr -o pmc -- python3 $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-e2e > $OUT/bench_$ctr.log 2>&1 || true
+  rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $OUT/$ctr -o pmc -- python3 $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-e2e --no-back-to-back > $OUT/bench_$ctr.log 2>&1 || true
   ls $OUT/$ctr | head
 done

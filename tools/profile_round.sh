@@ -6,7 +6,7 @@ COMMIT=${2:-unknown}
 OUT=$GRAFT_REPO_ROOT/gpurun_out
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$TAG -o $TAG -- python3 $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-e2e > $OUT/bench_prof_$TAG.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$TAG -o $TAG -- python3 $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-e2e --no-back-to-back > $OUT/bench_prof_$TAG.log 2>&1
 cd $GRAFT_REPO_ROOT
 python3 tools/summarize_rocprof.py $(find $OUT/prof_$TAG -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_bench_C3_kernel_stats.csv $OUT/${TAG}_rocprof.json C3 $COMMIT
 bash tools/pmc_traffic.sh $TAG
