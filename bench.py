@@ -222,6 +222,9 @@ def main():
     lens = [c.contig_len for c in cfgs]
     shards = pd.shard_contigs([c.n_reads for c in cfgs], world)
     mine = shards[rank]
+    if world == 1 and os.environ.get("PJB_BENCH_AS_RANK"):  # (experiment: "r/N": one GPU with the targets rank r of N would get; never a measurement of N GPUs)
+        r_, n_ = (int(x) for x in os.environ["PJB_BENCH_AS_RANK"].split("/"))
+        mine = pd.shard_contigs([c.n_reads for c in cfgs], n_)[r_]
     L = cfgs[0].read_len
     ORI = "FR"
 
@@ -252,7 +255,13 @@ def main():
 
     # the chains of a step: groups of consecutive targets (one kernel chain each), or every target alone
     if args.group_bases > 0:
-        chains = ffi.plan_groups(lens, sorted(mine), args.group_bases)
+        gb = args.group_bases
+        share = sum(lens[t] for t in mine)
+        if len(mine) > 1 and 600_000_000 < share <= gb:
+            # a share that would be ONE chain (3 or 4 ranks) goes as two: the first one's tail runs beside the second one's K1 stage
+            # (one GPU with rank 0's share of 3 / 4 ranks: 3.10 against 3.26 ms, 2.52 against 2.58; tools/debug/sweep_rank_share.sh)
+            gb = int(share * 0.55)
+        chains = ffi.plan_groups(lens, sorted(mine), gb)
     else:
         chains = [[t] for t in mine]
     chains.sort(key=lambda g: -sum(contigs[t]["n"] for t in g))  # largest first: the queue drains at the end of a step on the small ones
