@@ -256,11 +256,11 @@ def main():
     # the chains of a step: groups of consecutive targets (one kernel chain each), or every target alone
     if args.group_bases > 0:
         gb = args.group_bases
-        share = sum(lens[t] for t in mine)
-        if len(mine) > 1 and 600_000_000 < share <= gb:
+        share_bases = sum(lens[t] for t in mine)
+        if len(mine) > 1 and 600_000_000 < share_bases <= gb:
             # a share that would be ONE chain (3 or 4 ranks) goes as two: the first one's tail runs beside the second one's K1 stage
             # (one GPU with rank 0's share of 3 / 4 ranks: 3.10 against 3.26 ms, 2.52 against 2.58; tools/debug/sweep_rank_share.sh)
-            gb = int(share * 0.55)
+            gb = int(share_bases * 0.55)
         chains = ffi.plan_groups(lens, sorted(mine), gb)
     else:
         chains = [[t] for t in mine]
