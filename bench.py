@@ -622,6 +622,12 @@ def main():
             "datagen_s": round(t_gen, 2),
         }
         # a line from an ablation build or another library build says so: its results were not checked
+        if world == 1 and os.environ.get("PJB_BENCH_AS_RANK"):
+            # (experiment: this GPU held the targets ONE rank of an N-rank run would get -- no exchange, never a measurement of N GPUs;
+            # `value` counts the share's own reads, not the set's)
+            result["as_rank"] = os.environ["PJB_BENCH_AS_RANK"]
+            result["value"] = N_mine * args.steps / elapsed
+            result["config"]["targets_rank"] = sorted(mine)
         if os.environ.get("PJB_BENCH_ABLATION") or os.environ.get("PJB_LIB_PATH"):
             result["ablation"] = bool(os.environ.get("PJB_BENCH_ABLATION"))
             result["lib_path"] = os.environ.get("PJB_LIB_PATH")

@@ -49,7 +49,9 @@
 extern "C" {
 #endif
 
-#define PJB_ABI_VERSION 3 /* 2: pjb_batch.name_hash, PJB_FLAG_EXTRA, pjb_extra_finish
+#define PJB_ABI_VERSION 4 /* 4: pjb_batch.seq2 / .seq_exc (2-bit bases with their exception bitmap; a context created with abi_version 3 is
+                           *    served as before: the two members are not read), pjb_merge_rows
+                           * 2: pjb_batch.name_hash, PJB_FLAG_EXTRA, pjb_extra_finish
                            * 3: pjb_timing grew (generic_reads, position_runs, candidates, checked_reads); PJB_MAX_QUEUED 8; pjb_last_error is per calling
                            *    thread; additive since 2: PJB_FLAG_NO_CHAINS, pjb_finish_group_begin/_end, pjb_finish_ready, pjb_deflate_bgzf,
                            *    pjb_host_register/_unregister; the option "fused_k1" is gone */
@@ -140,6 +142,17 @@ typedef struct pjb_batch {
      * lib/src/bam_alignment.cc:233-242: QNAME, plus "_R1" / "_R2" / "_R?" for paired reads); only read by
      * contexts created with PJB_FLAG_EXTRA, may be NULL otherwise. */
     const uint64_t *name_hash;
+    /* ---- ABI 4 (read only when pjb_config.abi_version >= 4; both NULL: the compares run on seq4 as before) ----
+     * seq2     the same bases in 2 bits (A 0, C 1, G 2, T 3), one uint16 per seq4 WORD: element seq_off[r] + k holds bases 8k .. 8k+7 of
+     *          read r, base j at bits 2j, 2j+1 (what is stored for a base outside ACGT, or behind the read's last base, does not matter).
+     *          As many elements as seq4 has words; the array starts on a 4-byte boundary.
+     * seq_exc  bit r (bit r & 31 of word r >> 5) set: read r is NOT to be compared in 2 bits -- one of its l_qseq bases is not A, C, G or
+     *          T (BAM codes 1, 2, 4, 8), or it carries fewer than l_qseq bases.  (n_reads + 31) / 32 words.
+     * Who fills them: the device ingest (pjb_submit_bam / pjb_bam_*) as it transcodes the records; a caller that decodes BAM itself
+     * packs them where it copies SEQ (AlignmentInfo::calcMatchStats compares characters, lib/src/junction.cc:147-240, and a read of
+     * pure ACGT against a stretch of pure ACGT compares the same in 2 bits -- k1_emit takes the 4-bit codes for everything else). */
+    const uint16_t *seq2;
+    const uint32_t *seq_exc;
 } pjb_batch;
 
 /* RegionResult (src/junction_builder.hpp:62-76) plus sizes of what was built */

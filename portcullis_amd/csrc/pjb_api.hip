@@ -43,7 +43,8 @@ struct Contig {
     bool has_x = false;
     bool present = false;
     u32 *codes = nullptr; // packed 4-bit codes (k0_encode); nullptr when the contig is "exotic"
-    size_t d_cap = 0, codes_cap = 0; // sizes of the two allocations (they go back to the context's genome pool)
+    u32 *codes2 = nullptr; // 2-bit codes | exception bitmap (k0_encode2); with codes
+    size_t d_cap = 0, codes_cap = 0, codes2_cap = 0; // sizes of the allocations (they go back to the context's genome pool)
 };
 
 // The bases and codes of a released contig are kept for the next upload (targets come longest first, so the next genome
@@ -51,7 +52,7 @@ struct Contig {
 void free_contig(Contig &g, std::vector<Buf> *pool = nullptr) {
     auto give = [&](void *p, size_t cap) {
         if (!p) return;
-        if (pool && cap > 0 && pool->size() < 8) {
+        if (pool && cap > 0 && pool->size() < 12) {
             Buf b;
             b.p = p;
             b.cap = cap;
@@ -61,6 +62,7 @@ void free_contig(Contig &g, std::vector<Buf> *pool = nullptr) {
     };
     if (g.owned) give(g.d, g.d_cap);
     give(g.codes, g.codes_cap);
+    give(g.codes2, g.codes2_cap);
     g = Contig();
 }
 // device memory for a genome array: the smallest pooled buffer that fits, else a new one
@@ -702,7 +704,7 @@ int pjb_device_count(void) {
 int pjb_create(pjb_ctx **out, const pjb_config *cfg) {
     if (!out || !cfg) return fail(nullptr, PJB_ERR_ARG, "pjb_create: null argument");
     *out = nullptr;
-    if (cfg->abi_version != PJB_ABI_VERSION)
+    if (cfg->abi_version != PJB_ABI_VERSION && cfg->abi_version != 3) // (3: the same entry points; pjb_batch ends at name_hash)
         return fail(nullptr, PJB_ERR_ARG, "pjb_create: ABI version %d, library is %d", cfg->abi_version, PJB_ABI_VERSION);
     if (cfg->orientation < PJB_OR_SE || cfg->orientation > PJB_OR_UNKNOWN)
         return fail(nullptr, PJB_ERR_ARG, "pjb_create: bad orientation %d", cfg->orientation);
@@ -786,6 +788,9 @@ int pjb_create(pjb_ctx **out, const pjb_config *cfg) {
 static void bam_stage_clear(pjb_ctx *c); // (defined with the staged ingest)
 
 void pjb_destroy(pjb_ctx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->cfg.device);
+    (void)hipDeviceSynchronize(); // (contigs may still be queued)
 #ifdef K1E_PROF
     {
         unsigned long long h[16] = {0};
@@ -798,9 +803,21 @@ void pjb_destroy(pjb_ctx *c) {
         }
     }
 #endif
-    if (!c) return;
-    (void)hipSetDevice(c->cfg.device);
-    (void)hipDeviceSynchronize(); // (contigs may still be queued)
+#ifdef K1E_HIST
+    { // compare rounds per wavefront and trip of k1_emit: what ran (the longest lane's) against what the lanes needed
+        unsigned long long h[4][32] = {{0}};
+        if (hipMemcpyFromSymbol(h, HIP_SYMBOL(pjb::g_k1e_hist), sizeof h) == hipSuccess) {
+            unsigned long long trips = 0, run = 0, need = 0, lanes = 0;
+            for (int r = 0; r < 32; r++) trips += h[0][r], run += h[0][r] * (unsigned long long)r, need += h[1][r], lanes += h[2][r];
+            fprintf(stderr, "[k1e_hist] 2-bit rounds: %llu wavefront-trips, %.3f rounds run a trip, %.3f rounds a lane needs (max / mean %.3f)\n", trips,
+                    trips ? (double)run / (double)trips : 0.0, lanes ? (double)need / (double)lanes : 0.0,
+                    need ? ((double)run / (double)trips) / ((double)need / (double)lanes) : 0.0);
+            for (int r = 0; r < 32; r++)
+                if (h[0][r] || h[3][r])
+                    fprintf(stderr, "[k1e_hist]   %2d rounds: %10llu trips (2-bit)  %10llu trips (4-bit)\n", r, h[0][r], h[3][r]);
+        }
+    }
+#endif
     while (!c->open.empty()) close_contig(c, c->open.begin()->first);
     extra_clear(c);
     for (auto &kv : c->filter_keys)
@@ -897,14 +914,36 @@ static int upload_common(pjb_ctx *c, int32_t tid, uint8_t *d, int64_t len, bool 
                            codes, n_words, (int *)c->b_hasx.p);
         (void)hipMemcpyAsync(&exotic, c->b_hasx.p, sizeof(int), hipMemcpyDeviceToHost, c->stream);
     }
+    // 2-bit codes and their exception bitmap for k1_emit's compares (PJB_NO_SEQ2=1: not built -- A/B runs)
+    u32 *codes2 = nullptr;
+    size_t codes2_cap = 0;
+    static const bool no_seq2 = getenv("PJB_NO_SEQ2") && atoi(getenv("PJB_NO_SEQ2")) != 0;
+    if (len > 0 && !no_seq2) {
+        const size_t words = (size_t)codes2_alloc_words(len);
+        codes2 = (u32 *)genome_take(c->genome_pool, words * 4, codes2_cap);
+        if (!codes2) {
+            if (codes) (void)hipFree(codes);
+            return fail(c, PJB_ERR_NOMEM, "hipMalloc(genome 2-bit codes, %zu bytes) failed", words * 4);
+        }
+        const int64_t n2w = codes2_words(len), nxw = gexc_words(len);
+        (void)hipMemsetAsync(codes2 + n2w, 0, (size_t)K0_CODES2_PAD * 4, c->stream);
+        (void)hipMemsetAsync(codes2 + n2w + K0_CODES2_PAD + nxw, 0, (size_t)K0_GEXC_PAD * 4, c->stream);
+        hipLaunchKernelGGL(k0_encode2, dim3((unsigned)(((len + 63) / 64 + 255) / 256)), dim3(256), 0, c->stream, (const uint8_t *)d, len, codes2,
+                           codes2 + n2w + K0_CODES2_PAD);
+    }
     hipError_t se = hipStreamSynchronize(c->stream);
     if (se != hipSuccess) {
         if (codes) (void)hipFree(codes);
+        if (codes2) (void)hipFree(codes2);
         return fail(c, PJB_ERR_HIP, "upload: %s", hipGetErrorString(se));
     }
     if (exotic && codes) {
         (void)hipFree(codes);
         codes = nullptr;
+    }
+    if (!codes && codes2) {
+        (void)hipFree(codes2);
+        codes2 = nullptr;
     }
     Contig &g = c->contigs[(size_t)tid];
     free_contig(g, &c->genome_pool);
@@ -914,8 +953,10 @@ static int upload_common(pjb_ctx *c, int32_t tid, uint8_t *d, int64_t len, bool 
     g.has_x = hx != 0;
     g.present = true;
     g.codes = codes;
+    g.codes2 = codes2;
     g.d_cap = owned ? d_cap : 0;
     g.codes_cap = codes ? codes_cap : 0;
+    g.codes2_cap = codes2 ? codes2_cap : 0;
     return PJB_OK;
 }
 
@@ -1046,16 +1087,23 @@ static int add_batch(pjb_ctx *c, int32_t tid, const pjb_batch *b, bool device) {
         d.pos = b->pos; d.flag = b->flag; d.mapq = b->mapq; d.xs = b->xs; d.l_qseq = b->l_qseq; d.mtid = b->mtid;
         d.mpos = b->mpos; d.cig_off = b->cig_off; d.cigar = b->cigar; d.seq_off = b->seq_off; d.seq4 = b->seq4;
         d.name_hash = c->extra ? (const u64 *)b->name_hash : nullptr;
+        if (c->cfg.abi_version >= 4 && b->seq2 && b->seq_exc) {
+            if ((uintptr_t)b->seq2 & 3u) return fail(c, PJB_ERR_ARG, "submit: pjb_batch.seq2 must start on a 4-byte boundary");
+            d.seq2 = (const uint32_t *)b->seq2;
+            d.seq_exc = b->seq_exc;
+        }
     } else {
         const size_t n = (size_t)b->n_reads;
         const size_t n_ops = b->cig_off[n], n_words = b->seq_off[n];
-        const void *src[12] = {b->pos, b->flag, b->mapq, b->xs, b->l_qseq, b->mtid, b->mpos, b->cig_off, b->cigar, b->seq_off, b->seq4,
-                               c->extra ? b->name_hash : nullptr};
-        const size_t bytes[12] = {n * 4, n * 2, n, n, n * 4, n * 4, n * 4, (n + 1) * 4, n_ops * 4, (n + 1) * 4, n_words * 4,
-                                  c->extra ? n * 8 : 0};
+        const void *src[14] = {b->pos, b->flag, b->mapq, b->xs, b->l_qseq, b->mtid, b->mpos, b->cig_off, b->cigar, b->seq_off, b->seq4,
+                               c->extra ? b->name_hash : nullptr, nullptr, nullptr};
+        const bool two = c->cfg.abi_version >= 4 && b->seq2 && b->seq_exc;
+        if (two) src[12] = b->seq2, src[13] = b->seq_exc;
+        const size_t bytes[14] = {n * 4, n * 2, n, n, n * 4, n * 4, n * 4, (n + 1) * 4, n_ops * 4, (n + 1) * 4, n_words * 4,
+                                  c->extra ? n * 8 : 0, two ? n_words * 2 : 0, two ? ((n + 31) / 32) * 4 : 0};
         // pack into a staging buffer, one DMA to a device slab region with the same packing
-        size_t offs[12], total_b = 0;
-        for (int k = 0; k < 12; k++) {
+        size_t offs[14], total_b = 0;
+        for (int k = 0; k < 14; k++) {
             offs[k] = total_b;
             total_b += (std::max<size_t>(bytes[k], 16) + 255) & ~(size_t)255;
         }
@@ -1076,8 +1124,8 @@ static int add_batch(pjb_ctx *c, int32_t tid, const pjb_batch *b, bool device) {
         if (!c->stage_ev[si]) HIP_TRY(c, hipEventCreateWithFlags(&c->stage_ev[si], hipEventDisableTiming));
         uint8_t *dev = (uint8_t *)slab_alloc(c, oc, total_b);
         if (!dev) return fail(c, PJB_ERR_NOMEM, "submit: out of device memory for a batch of %zu bytes", total_b);
-        void *ptrs[12];
-        for (int k = 0; k < 12; k++) {
+        void *ptrs[14];
+        for (int k = 0; k < 14; k++) {
             if (bytes[k] && src[k]) parallel_copy(c->stage[si] + offs[k], src[k], bytes[k]);
             ptrs[k] = dev + offs[k];
         }
@@ -1089,6 +1137,7 @@ static int add_batch(pjb_ctx *c, int32_t tid, const pjb_batch *b, bool device) {
         d.mpos = (const int32_t *)ptrs[6]; d.cig_off = (const uint32_t *)ptrs[7]; d.cigar = (const uint32_t *)ptrs[8];
         d.seq_off = (const uint32_t *)ptrs[9]; d.seq4 = (const uint8_t *)ptrs[10];
         d.name_hash = c->extra ? (const u64 *)ptrs[11] : nullptr;
+        if (two) d.seq2 = (const uint32_t *)ptrs[12], d.seq_exc = (const uint32_t *)ptrs[13];
     }
     oc.batches.push_back(d);
     if (!device) oc.on_main_stream = true;
@@ -1452,6 +1501,7 @@ static int queue_contig(pjb_ctx *c, Flight &f) {
         GT.tid[m] = f.tids[(size_t)m];
         GT.d[m] = g.d;
         GT.codes[m] = g.codes;
+        GT.codes2[m] = g.codes2;
         all_codes = all_codes && g.codes != nullptr;
         any_x = any_x || g.has_x;
     }
@@ -3026,6 +3076,8 @@ static int ingest_parse(pjb_ctx *c, int32_t tid, OpenContig &oc, const uint8_t *
     B.cigar = nullptr;
     B.seq4 = nullptr;
     B.name_hash = nullptr;
+    B.seq2 = nullptr;
+    B.seq_exc = nullptr;
     if (c->extra) {
         B.name_hash = (iu64 *)slab_alloc(c, oc, n * 8 + 16);
         if (!B.name_hash) return fail(c, PJB_ERR_NOMEM, "submit_bam: out of device memory for name codes");
@@ -3043,6 +3095,12 @@ static int ingest_parse(pjb_ctx *c, int32_t tid, OpenContig &oc, const uint8_t *
     B.cigar = (iu32 *)slab_alloc(c, oc, (size_t)n_ops * 4 + 16);
     B.seq4 = (uint8_t *)slab_alloc(c, oc, (size_t)n_words * 4 + 16);
     if (!B.cigar || !B.seq4) return fail(c, PJB_ERR_NOMEM, "submit_bam: out of device memory for CIGARs / bases");
+    static const bool no_seq2 = getenv("PJB_NO_SEQ2") && atoi(getenv("PJB_NO_SEQ2")) != 0;
+    if (!no_seq2) { // the bases in 2 bits as well (what pjb_batch.seq2 / .seq_exc hold): written where the 4-bit bases are
+        B.seq2 = (unsigned short *)slab_alloc(c, oc, ((size_t)n_words + 2) * 2 + 16);
+        B.seq_exc = (iu32 *)slab_alloc(c, oc, ((n + 31) / 32) * 4 + 16);
+        if (!B.seq2 || !B.seq_exc) return fail(c, PJB_ERR_NOMEM, "submit_bam: out of device memory for the 2-bit bases");
+    }
     LAUNCH(c, "bam_transcode", bam_transcode, dim3((unsigned)((n + 255) / 256)), dim3(256), R.U, (const iu64 *)c->b_bam_rec.p, (iu64)n, B);
     HIP_TRY(c, hipStreamSynchronize(st)); // `tails` is on this stack frame
     if (c->ktime) ev_collect(c, MISC_POOL);
@@ -3057,6 +3115,8 @@ static int ingest_parse(pjb_ctx *c, int32_t tid, OpenContig &oc, const uint8_t *
     d.pos = B.pos; d.flag = B.flag; d.mapq = B.mapq; d.xs = B.xs; d.l_qseq = B.l_qseq; d.mtid = B.mtid; d.mpos = B.mpos;
     d.cig_off = B.cig_off; d.cigar = B.cigar; d.seq_off = B.seq_off; d.seq4 = B.seq4;
     d.name_hash = (const u64 *)B.name_hash;
+    d.seq2 = (const uint32_t *)B.seq2;
+    d.seq_exc = B.seq_exc;
     oc.on_main_stream = true;
     oc.batches.push_back(d);
     oc.last_known.push_back(0);

@@ -1032,6 +1032,8 @@ struct BamSoA {
     iu32 *cig_off, *cigar, *seq_off;
     uint8_t *seq4;
     iu64 *name_hash; // junc --extra only (nullptr otherwise): std::hash of deriveName(), see pjb_extra.hip.h
+    unsigned short *seq2; // the bases in 2 bits, a 16-bit granule per seq4 word, and the reads' exception bitmap (pjb_batch.seq2 / .seq_exc;
+    iu32 *seq_exc;        // nullptr: not written)
 };
 
 // XS:A aux tag -> 0 absent / '?' / '.', 1 '+', 2 '-', 3 anything else (same rules as the host transcoder)
@@ -1073,36 +1075,67 @@ __device__ uint8_t bam_xs_code(const uint8_t *p, const uint8_t *end) {
     return 0;
 }
 
+// one seq4 word (eight bases, BAM order: high nibble first) -> its 16-bit granule of 2-bit codes (A 0, C 1, G 2, T 3, base j at bits 2j) and,
+// in `bad`, bit 4 j + 3 for every base j that is none of the four
+__device__ __forceinline__ iu32 seq4_word_to2(iu32 v, iu32 &bad) {
+    const iu32 sw = ((v & 0x0F0F0F0Fu) << 4) | ((v >> 4) & 0x0F0F0F0Fu);                      // nibble j = base j
+    const iu32 code = (((sw >> 1) & 0x77777777u) - ((sw >> 3) & 0x11111111u)) & 0x33333333u;  // 1 2 4 8 -> 0 1 2 3
+    const iu32 pc = sw - ((sw >> 1) & 0x77777777u) - ((sw >> 2) & 0x33333333u) - ((sw >> 3) & 0x11111111u); // bits set per nibble
+    const iu32 x = pc ^ 0x11111111u;                                                           // 0 where exactly one is
+    bad = (((x & 0x77777777u) + 0x77777777u) | x) & 0x88888888u;
+    iu32 y = (code | (code >> 2)) & 0x0F0F0F0Fu;
+    y = (y | (y >> 4)) & 0x00FF00FFu;
+    return (y | (y >> 8)) & 0xFFFFu;
+}
 __global__ __launch_bounds__(256) void bam_transcode(const uint8_t *U, const iu64 *rec_off, iu64 n, BamSoA B) {
     const iu64 i = (iu64)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const iu64 off = rec_off[i];
-    const iu32 bs = ld32u(U + off);
-    const uint8_t *r = U + off + 4;
-    const iu32 l_name = r[8], n_cig = ld16u(r + 12);
-    const int32_t l_seq = (int32_t)ld32u(r + 16);
-    const iu64 cig_at = 32 + l_name, seq_at = cig_at + 4ull * n_cig;
-    const iu64 seq_bytes = (iu64)((l_seq + 1) / 2);
-    const iu64 aux_at = seq_at + seq_bytes + (iu64)l_seq;
-    B.pos[i] = (int32_t)ld32u(r + 4);
-    B.mapq[i] = r[9];
-    B.flag[i] = (uint16_t)ld16u(r + 14);
-    B.l_qseq[i] = l_seq;
-    B.mtid[i] = (int32_t)ld32u(r + 20);
-    B.mpos[i] = (int32_t)ld32u(r + 24);
-    B.xs[i] = bam_xs_code(r + aux_at, r + bs);
-    if (B.name_hash) B.name_hash[i] = derive_name_hash(r + 32, l_name ? l_name - 1 : 0, ld16u(r + 14));
-    const iu32 co = B.cig_off[i];
-    for (iu32 k = 0; k < n_cig; k++) B.cigar[co + k] = ld32u(r + cig_at + 4 * k);
-    const iu32 so = B.seq_off[i], words = B.seq_off[i + 1] - so;
-    if (words) {
-        iu32 *dst = (iu32 *)B.seq4 + so;
-        const uint8_t *src = r + seq_at;
-        for (iu32 w = 0; w < words; w++) {
-            iu32 v = ld32u(src + 4 * w); // may read up to 3 bytes past the bases: still inside the record (qualities follow)
-            const iu64 have = seq_bytes - 4ull * w;
-            if (have < 4) v &= (1u << (8 * (iu32)have)) - 1u; // zero the padding of the last word
-            dst[w] = v;
+    bool exc = true; // (a record without bases, or past the last one)
+    if (i < n) {
+        const iu64 off = rec_off[i];
+        const iu32 bs = ld32u(U + off);
+        const uint8_t *r = U + off + 4;
+        const iu32 l_name = r[8], n_cig = ld16u(r + 12);
+        const int32_t l_seq = (int32_t)ld32u(r + 16);
+        const iu64 cig_at = 32 + l_name, seq_at = cig_at + 4ull * n_cig;
+        const iu64 seq_bytes = (iu64)((l_seq + 1) / 2);
+        const iu64 aux_at = seq_at + seq_bytes + (iu64)l_seq;
+        B.pos[i] = (int32_t)ld32u(r + 4);
+        B.mapq[i] = r[9];
+        B.flag[i] = (uint16_t)ld16u(r + 14);
+        B.l_qseq[i] = l_seq;
+        B.mtid[i] = (int32_t)ld32u(r + 20);
+        B.mpos[i] = (int32_t)ld32u(r + 24);
+        B.xs[i] = bam_xs_code(r + aux_at, r + bs);
+        if (B.name_hash) B.name_hash[i] = derive_name_hash(r + 32, l_name ? l_name - 1 : 0, ld16u(r + 14));
+        const iu32 co = B.cig_off[i];
+        for (iu32 k = 0; k < n_cig; k++) B.cigar[co + k] = ld32u(r + cig_at + 4 * k);
+        const iu32 so = B.seq_off[i], words = B.seq_off[i + 1] - so;
+        if (words) {
+            iu32 *dst = (iu32 *)B.seq4 + so;
+            const uint8_t *src = r + seq_at;
+            iu32 any_bad = 0;
+            for (iu32 w = 0; w < words; w++) {
+                iu32 v = ld32u(src + 4 * w); // may read up to 3 bytes past the bases: still inside the record (qualities follow)
+                const iu64 have = seq_bytes - 4ull * w;
+                if (have < 4) v &= (1u << (8 * (iu32)have)) - 1u; // zero the padding of the last word
+                dst[w] = v;
+                if (B.seq2) {
+                    iu32 bad;
+                    B.seq2[so + w] = (unsigned short)seq4_word_to2(v, bad);
+                    const int64_t left = (int64_t)l_seq - 8 * (int64_t)w; // bases of the read from this word on
+                    if (left < 8) bad &= left > 0 ? (1u << (4 * (iu32)left)) - 1u : 0u;
+                    any_bad |= bad;
+                }
+            }
+            exc = any_bad != 0 || (iu64)words * 8 < (iu64)l_seq || l_seq <= 0;
+        }
+    }
+    if (B.seq_exc) { // the wavefront's 64 records are two words of the bitmap
+        const iu64 m = __ballot(exc);
+        const iu64 i0 = (iu64)blockIdx.x * 256 + (threadIdx.x & ~63u);
+        if ((threadIdx.x & 63u) == 0 && i0 < n) {
+            B.seq_exc[i0 >> 5] = (iu32)m;
+            if (i0 + 32 < n) B.seq_exc[(i0 >> 5) + 1] = (iu32)(m >> 32);
         }
     }
 }

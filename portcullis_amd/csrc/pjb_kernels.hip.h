@@ -47,6 +47,8 @@ struct DevBatch {
     int32_t prev_pos;   // pos of the last record of the previous batch (sortedness across batches)
     int32_t member;     // the batch's target: its index among the chain's members (GroupTab)
     const int32_t *prev_pos_ptr; // where that position is, when only the device knows it (nullptr: prev_pos holds it)
+    const uint32_t *seq2;        // pjb_batch.seq2 seen as words (two 16-bit granules each; nullptr: the batch has 4-bit bases only)
+    const uint32_t *seq_exc;     // pjb_batch.seq_exc
 };
 
 // error word: min over (ordinal << 8 | -code); ~0 = no error
@@ -159,6 +161,8 @@ struct GroupTab {
     int32_t tid[GROUP_MAX];
     const uint8_t *d[GROUP_MAX];   // upper-cased bases
     const u32 *codes[GROUP_MAX];   // 4-bit codes (nullptr: exotic member)
+    const u32 *codes2[GROUP_MAX];  // 2-bit codes and, behind them, the bitmap of the 64-base stretches that hold a character outside ACGT
+                                   // (k0_encode2; nullptr with codes)
 };
 struct Member {
     int32_t idx, voff, len, tid;
@@ -264,6 +268,7 @@ struct GBatch {
     uint32_t base, tile_base;
     int32_t prev_pos, member;
     const PJB_GLOBAL int32_t *prev_pos_ptr;
+    const PJB_GLOBAL uint32_t *seq2, *seq_exc;
 };
 #define PJB_CONSTANT __attribute__((address_space(4)))
 __device__ __forceinline__ GBatch load_batch(const DevBatch *d) { // (through the constant address space: a uniform index gives scalar loads)
@@ -286,6 +291,8 @@ __device__ __forceinline__ GBatch load_batch(const DevBatch *d) { // (through th
     b.prev_pos = g->prev_pos;
     b.member = g->member;
     b.prev_pos_ptr = as_global(g->prev_pos_ptr);
+    b.seq2 = as_global(g->seq2);
+    b.seq_exc = as_global(g->seq_exc);
     return b;
 }
 // four consecutive words at a 4-byte aligned address (global_load_dwordx4 accepts that)
@@ -625,6 +632,53 @@ __global__ __launch_bounds__(256) void k0_encode(const uint8_t *g, int64_t n, u3
         codes[w] = out;
     }
     if (__ballot(exotic) && lane_id() == 0) atomicOr(exotic_flag, 1);
+}
+
+// K0c: the same bases in TWO bits (A 0, C 1, G 2, T 3; base i at bits 2 (i & 15) of word i >> 4; anything else is stored as 0) and
+// the exceptions: bit i >> 6 of the bitmap is set when one of the bases 64 (i >> 6) .. 64 (i >> 6) + 63 is not A, C, G or T.  k1_emit
+// compares a block of read bases in 2 bits only where the bitmap is clear under it (a read of pure ACGT against a stretch of pure
+// ACGT: characters are equal exactly where the 2-bit codes are) and takes the 4-bit codes for every other block.  A thread owns one
+// 64-base stretch: four words of codes (one 16-byte store), one bit; a wavefront's bits are one u64 of the bitmap.
+//   Layout of the allocation: codes2[0 .. n2w) | K0_CODES2_PAD zero words | bitmap u32[(n + 2047) / 2048] | K0_GEXC_PAD zero words.
+constexpr int K0_CODES2_PAD = 8, K0_GEXC_PAD = 4;
+__host__ __device__ inline int64_t codes2_words(int64_t n) { return ((n + 63) / 64) * 4; }          // (whole stretches)
+__host__ __device__ inline int64_t gexc_words(int64_t n) { return (((n + 63) / 64 + 63) / 64) * 2; } // (whole u64s)
+__host__ __device__ inline int64_t codes2_alloc_words(int64_t n) { return codes2_words(n) + K0_CODES2_PAD + gexc_words(n) + K0_GEXC_PAD; }
+__global__ __launch_bounds__(256) void k0_encode2(const uint8_t *g, int64_t n, u32 *codes2, u32 *gexc) {
+    const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x; // stretch
+    const int64_t n_str = (n + 63) / 64;
+    bool exc = false;
+    if (s < n_str) {
+        u32 w[4] = {0, 0, 0, 0};
+        const int64_t b0 = s * 64;
+        if (b0 + 64 <= n && ((uintptr_t)(g + b0) & 15) == 0) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const uint4 v = *reinterpret_cast<const uint4 *>(g + b0 + 16 * q);
+                const u32 x[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int k = 0; k < 16; k++) {
+                    const u32 c = (x[k >> 2] >> (8 * (k & 3))) & 0xffu;
+                    const u32 code = c == 'C' ? 1u : c == 'G' ? 2u : c == 'T' ? 3u : 0u;
+                    exc |= !(c == 'A' || c == 'C' || c == 'G' || c == 'T');
+                    w[q] |= code << (2 * k);
+                }
+            }
+        } else {
+            for (int k = 0; k < 64; k++) {
+                const int64_t i = b0 + k;
+                if (i < n) {
+                    const u32 c = g[i];
+                    const u32 code = c == 'C' ? 1u : c == 'G' ? 2u : c == 'T' ? 3u : 0u;
+                    exc |= !(c == 'A' || c == 'C' || c == 'G' || c == 'T');
+                    w[k >> 4] |= code << (2 * (k & 15));
+                }
+            }
+        }
+        *reinterpret_cast<uint4 *>(codes2 + 4 * s) = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+    const u64 m = __ballot(exc);
+    if (lane_id() == 0 && s < ((n_str + 63) / 64) * 64) reinterpret_cast<u64 *>(gexc)[s >> 6] = m;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1917,140 +1971,38 @@ struct EmitCtx {
     }
 };
 
-// ---- the wavefront's reads through LDS.  A lane's bases are its own ~76 bytes, so a 16-byte load of them by all lanes touched
-// 64 cache lines and fetched 8 KB for 1 KB (SQ counters, round 4: ~100 such loads per wavefront, the kernel bound by their
-// NUMBER); but the spliced reads' bases lie back to back in seq4 in list order -- the 64 reads of a wavefront are ONE span of
-// ~5 KB -- and position-sorted reads compare against a few hundred bases of genome: both are staged with coalesced 16-byte loads
-// (five for the bases, one per genome window) and every lane then reads its words from LDS.  A window holds K1E_GENW words from
-// the smallest block start of the wavefront's lanes: window 0 = the reads' first blocks of bases (left anchors), 1 = their second
-// (right anchor / the block between two introns), 2 = their third; a lane whose block leaves its window (another acceptor far
-// away) or whose wavefront's reads span more than K1E_SEQW words (long reads) takes the gathers (cmp_words) as before.
-#ifndef K1E_SEQW
-#define K1E_SEQW 1280 // words of packed bases per wavefront: 64 reads of up to 160 bases
-#endif
-#ifndef K1E_GENW
-#define K1E_GENW 64   // words of genome codes per window: 512 bases
-#endif
-#ifndef K1E_PASSES
-#define K1E_PASSES 1 // passes over the wavefront's loci (two windows each) before the gathers take what is left.  (More passes were
-                     // measured: a second pass costs another round trip of staging loads -- frac_alone 0.56 against 0.61.)
-#endif
-#ifndef K1E_LDS_NW
-#define K1E_LDS_NW 5  // words per stream and round of the LDS compare (32 bases a round)
-#endif
-constexpr int K1E_SLACK = 8; // a round may read this many words past what its block needs (masked)
-#ifndef K1E_STAGE
-#define K1E_STAGE 0 // 1: the wavefront's bases and genome windows through LDS (measured, round 5: 8.82 ms a step against 8.33 for the
-                    // gathers -- the kernel waits for memory round trips and for VALU issue, not for the bytes of its gathers; kept for the record)
-#endif
-struct __attribute__((aligned(16))) EmitStage { // one per wavefront
-#if K1E_STAGE
-    u32 seq[K1E_SEQW + K1E_SLACK];
-    u32 gen[3][2][K1E_GENW + K1E_SLACK]; // two windows per block of bases: a wavefront often holds the reads of two loci
-#else
-    u32 seq[4], gen[3][2][4];
-#endif
+// ---- bases in TWO bits (pjb_batch.seq2 / GroupTab::codes2).  Round 5 took the compares apart (profiles/r05_k1_experiments.txt sections
+// 9, 10, 13): they are bound twice -- by the texture addresser, which takes a 4-byte-aligned 16-byte gather one LANE a cycle (16 gathers a
+// read), and by ~20 vector instructions per 8 bases.  In 2 bits a 16-byte gather holds 64 bases and a word 16: a round of two gathers per
+// stream covers 112 bases where the 4-bit round covers 56, and a word costs 13 instructions.  A lane compares in 2 bits when its read
+// is pure ACGT (seq_exc clear), lies inside its target, and the target's exception bitmap is clear under every block of its bases
+// (checked behind the compare: the bitmap words are asked for before the first round and looked at after the last); every other lane
+// takes the 4-bit rounds as before -- characters are equal exactly where 2-bit codes are when both sides are pure ACGT.
+//   Read base i of a read whose seq4 words start at so: bit 16 (so & 1) + 2 i from word so >> 1 of seq2 (a 16-bit granule per seq4 word).
+struct __attribute__((packed, aligned(4))) Words2 {
+    u32 x, y;
 };
-// words [first, first + count) of `src` to dst[shift ...], shift (returned) = words between the 16-byte boundary at or below
-// src + first and it; `exist` = words of src there are (nothing is read past them).  The whole wavefront calls.  The loads go
-// straight to LDS (global_load_lds_dwordx4: lane l's 16 bytes land at the wave-uniform base + 16 l) and are NOT waited for:
-// stage_wait() before the first read.  MAXW: the most words a call may ask for (the loop unrolls: every load is issued at once).
-template <int MAXW>
-__device__ __forceinline__ u32 stage_span(u32 *dst, const PJB_GLOBAL u32 *src, u32 first, u32 count, u32 exist) {
-    const uintptr_t a = (uintptr_t)(src + first);
-    const u32 shift = (u32)(a >> 2) & 3u;
-    const PJB_GLOBAL uint4 *p = (const PJB_GLOBAL uint4 *)(a - 4u * shift);
-    const u32 total = count + shift;         // words from the aligned start
-    const u32 avail = exist - first + shift; // words that exist from there
-    constexpr int ITERS = (MAXW + 3 + 255) / 256;
+constexpr int C2_NW = 8;                      // words per stream and round: two 16-byte gathers, 7 words = 112 bases compared
+constexpr int32_t C2_ROUND = 16 * (C2_NW - 1);
+constexpr int32_t C2_MAX_BLOCK = 1900;        // a longer block of bases (31 stretches of the bitmap: one 8-byte load) takes the 4-bit rounds
+template <int NW>
+__device__ __forceinline__ void chunk2_cmp_bits(const u32 (&qw)[NW], const u32 (&gw)[NW], u32 shq, u32 shg, int32_t l, int32_t t, u32 &mism, u32 &fbit,
+                                                u32 &lbit1) {
+    const int32_t rem = l - t; // bases left from the chunk's first
+    u32 fw = 0xffffffffu, lw = 0;
 #pragma unroll
-    for (int it = 0; it < ITERS; it++) {
-        if ((u32)it * 256u < total) { // (uniform)
-            const u32 i = (u32)it * 256u + (u32)lane_id() * 4u;
-            if (i + 4u <= avail) {
-                if (i < total) __builtin_amdgcn_global_load_lds(p + (i >> 2), (PJB_LDS void *)(dst + it * 256), 16, 0, 0);
-            } else if (i < avail) { // (the last words of the array)
-                const PJB_GLOBAL u32 *w = (const PJB_GLOBAL u32 *)p + i;
-                dst[i] = w[0];
-                if (i + 1u < avail) dst[i + 1] = w[1];
-                if (i + 2u < avail) dst[i + 2] = w[2];
-            }
-        }
+    for (int c = 0; c < NW - 1; c++) {
+        int32_t v = rem - 16 * c; // the word's valid bases, 0 .. 16
+        v = v < 0 ? 0 : (v > 16 ? 16 : v);
+        const u32 inval = (0xffffffffu << (u32)v) << (u32)v; // (two shifts: a shift by 32 would not move)
+        const u32 x = __builtin_amdgcn_alignbit(qw[c + 1], qw[c], shq) ^ __builtin_amdgcn_alignbit(gw[c + 1], gw[c], shg);
+        const u32 m = (x | (x >> 1)) & (0x55555555u & ~inval); // bit 2 j: base j differs
+        mism += (u32)__popc(m);
+        fw = min(fw, __builtin_elementwise_add_sat(ffbl_hw(m), 32u * (u32)c));
+        lw = max(lw, __builtin_elementwise_sub_sat(32u * (u32)c + 32u, ffbh_hw(m)));
     }
-    return shift;
-}
-__device__ __forceinline__ void stage_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); } // (hipcc does not wait for an LDS-DMA before a ds_read of its own accord)
-// One block of l bases, both streams in LDS: read words from qs[qw0 ...] (word 0 of the read at qs[qw0]), genome codes from
-// gs[gofs + word index].  The kernel is bound by VALU issue (round 5's SQ counters: the compares were 62 % of its vector instructions,
-// ~830 per read), so this is written for instruction count: GROUPS of 32 bases, no branch inside a group --
-//   * four words per stream (a fifth carried over), funnel-shifted into place, XOR;
-//   * "nibble differs" as the top bit of the nibble (3 operations a word), the four words' flags packed into ONE word M (bit 4 n + k
-//     = base 8 k + n of the group: v_bfi), so that a group costs one popcount and one update of the trackers;
-//   * the group that holds the block's end is masked with a table word (k1e_tail_mask: bit 4 n + k set iff 8 k + n < r);
-//   * first / last mismatch: the first / last group with a flag is kept as it is (its M and its number) and decoded once, behind the
-//     loop.  WF / WL: which of the two the caller needs (a left anchor only its last mismatch, a right anchor only its first).
-__device__ __forceinline__ u32 k1e_tail_mask_word(u32 r) { // r = 0 .. 32 bases of a group that are part of the block
-    u32 m = 0;
-    for (u32 k = 0; k < 4; k++)
-        for (u32 n = 0; n < 8; n++)
-            if (8 * k + n < r) m |= 1u << (4 * n + k);
-    return m;
-}
-__device__ __forceinline__ u32 nibble_flags_top(u32 x) { return ((x & 0x77777777u) + 0x77777777u) | x; } // bit 4 n + 3: nibble n of x is not 0 (other bits: anything)
-__device__ __forceinline__ u32 bfi(u32 mask, u32 a, u32 b) { return (a & mask) | (b & ~mask); }          // (v_bfi_b32)
-// base index (within the group) of the lowest / highest base flagged in a packed group word
-__device__ __forceinline__ int32_t packed_first(u32 M) {
-    const u32 m0 = M & 0x11111111u, m1 = M & 0x22222222u, m2 = M & 0x44444444u, m3 = M & 0x88888888u;
-    const u32 sel = m0 ? m0 : m1 ? m1 : m2 ? m2 : m3;
-    const int32_t k = m0 ? 0 : m1 ? 1 : m2 ? 2 : 3;
-    return 8 * k + ((__ffs((int)sel) - 1) >> 2);
-}
-__device__ __forceinline__ int32_t packed_last(u32 M) {
-    const u32 m0 = M & 0x11111111u, m1 = M & 0x22222222u, m2 = M & 0x44444444u, m3 = M & 0x88888888u;
-    const u32 sel = m3 ? m3 : m2 ? m2 : m1 ? m1 : m0;
-    const int32_t k = m3 ? 3 : m2 ? 2 : m1 ? 1 : 0;
-    return 8 * k + ((31 - __clz((int)sel)) >> 2);
-}
-template <bool WF, bool WL>
-__device__ __forceinline__ void cmp_block_lds(const u32 *qs, int32_t qw0, int32_t qi, const u32 *gs, int32_t gofs, int32_t gi, int32_t l, const u32 *tail_mask,
-                                              CmpBlock &B) {
-    const u32 shq = (u32)(qi & 7) * 4u, shg = (u32)(gi & 7) * 4u;
-    const u32 *qp = qs + qw0 + (qi >> 3), *gp = gs + gofs + (gi >> 3);
-    u32 qa = swap_nibbles(qp[0]), ga = gp[0];
-    u32 cnt = 0, mF = 0, mL = 0;
-    int32_t gF = 0, gL = 0;
-    for (int32_t grp = 0; 32 * grp < l; grp++) {
-        const u32 q1 = swap_nibbles(qp[1]), q2 = swap_nibbles(qp[2]), q3 = swap_nibbles(qp[3]), q4 = swap_nibbles(qp[4]);
-        const u32 g1 = gp[1], g2 = gp[2], g3 = gp[3], g4 = gp[4];
-        const u32 x0 = __builtin_amdgcn_alignbit(q1, qa, shq) ^ __builtin_amdgcn_alignbit(g1, ga, shg);
-        const u32 x1 = __builtin_amdgcn_alignbit(q2, q1, shq) ^ __builtin_amdgcn_alignbit(g2, g1, shg);
-        const u32 x2 = __builtin_amdgcn_alignbit(q3, q2, shq) ^ __builtin_amdgcn_alignbit(g3, g2, shg);
-        const u32 x3 = __builtin_amdgcn_alignbit(q4, q3, shq) ^ __builtin_amdgcn_alignbit(g4, g3, shg);
-        qa = q4;
-        ga = g4;
-        qp += 4;
-        gp += 4;
-        u32 M = (nibble_flags_top(x0) >> 3) & 0x11111111u;
-        M = bfi(0x22222222u, nibble_flags_top(x1) >> 2, M);
-        M = bfi(0x44444444u, nibble_flags_top(x2) >> 1, M);
-        M = bfi(0x88888888u, nibble_flags_top(x3), M);
-        const int32_t r = l - 32 * grp;
-        M &= tail_mask[r < 32 ? r : 32];
-        cnt += (u32)__popc(M);
-        const bool nz = M != 0;
-        if (WL) {
-            mL = nz ? M : mL;
-            gL = nz ? grp : gL;
-        }
-        if (WF) {
-            const bool take = nz && mF == 0;
-            mF = take ? M : mF;
-            gF = take ? grp : gF;
-        }
-    }
-    B.mism = (int32_t)cnt;
-    B.first = WF && mF ? 32 * gF + packed_first(mF) : -1;
-    B.last = WL && mL ? 32 * gL + packed_last(mL) : -1;
+    fbit = min(fbit, __builtin_elementwise_add_sat(fw, 2u * (u32)t));
+    lbit1 = lw ? lw + 2u * (u32)t : lbit1; // (rounds ascend)
 }
 
 // ONE launch per chain (25 launches of 13 - 690 us became 3): a block takes a range of the chain's consecutive trips -- (batch, chunk
@@ -2058,12 +2010,10 @@ __device__ __forceinline__ void cmp_block_lds(const u32 *qs, int32_t qw0, int32_
 // batch descriptors and the members' table are read through uniform indices (scalar loads).
 //   The kernel waits for memory, not for bandwidth (round 4's SQ counters: three quarters of the wave-cycles parked on s_waitcnt),
 // and a trip is a chain of dependent round trips: tile offsets -> list record -> operations and per-read fields -> bases -> stores.
-// So the trips are software-pipelined: while trip v is compared out of LDS, the list records and then the operations / fields
-// of trip v + 1 are already on their way (in registers), and ALL of a trip's staging loads (bases, three genome windows) are
-// issued together, behind one wait.
-#ifndef K1E_ABL
-#define K1E_ABL 0 // timing experiments only (tools/build_variants.sh): 1 no compares, 2 no candidates, 4 no staging (every compare gathers), 8 no list appends, 16 no gathering compares, 32 / 64 the gathers of a lane pair / quad next to each other, 128 no genome gathers, 256 no gathers (the compare runs on made-up words), 512 gathers without the compare (results wrong)
-#endif
+// So the trips are software-pipelined: while trip v is compared, the list records of trip v + 2 and the operations / fields of
+// trip v + 1 are already on their way (in registers).
+//   (Round 5 also built the version that stages the wavefront's bases and genome windows through LDS with coalesced loads: 2.4 x fewer
+// vector-memory instructions, the same time -- profiles/r05_k1_experiments.txt section 1; it left the tree with round 6, git has it.)
 #ifdef K1E_PROF // (debug builds: wave-cycles per section of k1_emit, summed over every wavefront; printed by pjb_destroy)
 __device__ unsigned long long g_k1e_prof[16];
 #define K1E_T0() unsigned long long prof_t = __builtin_amdgcn_s_memtime()
@@ -2077,6 +2027,9 @@ __device__ unsigned long long g_k1e_prof[16];
 #define K1E_T0() do {} while (0)
 #define K1E_MARK(i) do {} while (0)
 #endif
+#ifdef K1E_HIST // (debug builds: per wavefront and trip, compare rounds run (the longest lane's) against the lanes' mean -- pjb_destroy prints the table)
+__device__ unsigned long long g_k1e_hist[4][32]; // [0]: trips by rounds run, [1]: sum of active lanes' rounds by rounds run, [2]: active lanes, [3]: 4-bit rounds run
+#endif
 constexpr int K1E_MAXB = 64; // batches one launch takes (the host splits longer lists)
 struct EmitRec { // a trip's list records (per lane)
     bool on;
@@ -2085,7 +2038,7 @@ struct EmitRec { // a trip's list records (per lane)
 };
 struct EmitOps { // and what the records lead to: the read's first operations and its fixed-width fields
     u32 op[OPS_LDS];
-    u32 n, flag, xs, mapq;
+    u32 n, flag, xs, mapq; // (xs: bit 8 = the read is not to be compared in 2 bits -- its bit of seq_exc, or no 2-bit bases in the batch)
     int32_t mtid, mpos, lq;
 };
 struct EmitTrip { // (uniform)
@@ -2097,18 +2050,15 @@ __global__ __launch_bounds__(K1E_T) __attribute__((amdgpu_waves_per_eu(K1E_WAVES
                                                 GroupTab G, int use_codes, int orientation, u64 *err, ContigStats *cs) {
     __shared__ u32 s_soff[K1E_LOOK];
     __shared__ EmitShared sh;
-    __shared__ EmitStage s_stage[K1E_T / 64];
     __shared__ u32 s_cfirst[K1E_MAXB + 1]; // trips before batch i
     __shared__ u32 s_sbegin[K1E_MAXB + 1]; // list entries before batch i (batches follow each other in the tiles' space)
     __shared__ u32 s_seqw[K1E_MAXB], s_cigw[K1E_MAXB], s_tbase[K1E_MAXB]; // words of packed bases / operations in batch i; its first tile
     __shared__ u32 s_wsum[4];
-    __shared__ u32 s_tail[33]; // cmp_block_lds's masks of a block's last group
     if (cs->P == 0) return; // no pairs, or a limit was exceeded: the contig is repeated with larger buffers
     K1E_T0();
     const bool want_cand = E.cand != nullptr;
     EmitCtx ctx{sh, E, kf, cs, want_cand};
     ctx.init();
-    if (threadIdx.x < 33) s_tail[threadIdx.x] = k1e_tail_mask_word(threadIdx.x);
     auto cand_insert = [&](u64 k, int32_t lstart, int32_t rend) { ctx.cand_insert(k, lstart, rend); };
     {
         u32 trips = 0;
@@ -2130,7 +2080,6 @@ __global__ __launch_bounds__(K1E_T) __attribute__((amdgpu_waves_per_eu(K1E_WAVES
         __syncthreads();
     }
     const u32 n_trips = s_cfirst[K1E_MAXB];
-    EmitStage &stg = s_stage[threadIdx.x >> 6];
     // a block's trips are consecutive: the window of tile offsets (s_soff: 16 tiles ~ 18 trips) is fetched once and serves the trips
     // behind it; consecutive trips share junctions, so the block's candidate set lists each of them once
     const u32 per_block = (n_trips + gridDim.x - 1) / gridDim.x;
@@ -2192,7 +2141,7 @@ __global__ __launch_bounds__(K1E_T) __attribute__((amdgpu_waves_per_eu(K1E_WAVES
         return R;
     };
     // ---- and what they lead to: the read's first eight operations (two 16-byte loads; whatever lies behind its last one is masked
-    // by the consumer) and its five fields
+    // by the consumer), its five fields and its bit of the batch's exception bitmap
     auto fetch_ops = [&](const EmitTrip &T, const EmitRec &R) {
         EmitOps O;
 #pragma unroll
@@ -2207,29 +2156,35 @@ __global__ __launch_bounds__(K1E_T) __attribute__((amdgpu_waves_per_eu(K1E_WAVES
             if (n == 0x7fffu) n = b.cig_off[r + 1] - c0;
             O.n = n;
             O.flag = b.flag[r];
-            O.xs = b.xs[r];
+            O.xs = (u32)b.xs[r] | 0x100u;
             O.mapq = b.mapq[r];
             O.mtid = b.mtid[r];
             O.mpos = b.mpos[r];
+            if (b.seq2 != nullptr) O.xs = (O.xs & 0xffu) | (((b.seq_exc[r >> 5] >> (u32)(r & 31)) & 1u) << 8); // (uniform test: the batch either has 2-bit bases or not)
             O.lq = (int32_t)(R.sr.w >> 16);
             if (O.lq == 0xffff) O.lq = b.l_qseq[r];
             static_assert(OPS_LDS == 8, "two 16-byte loads");
-            // (the batch's last operations are read from the first word on: the loads never leave the array)
-            const u32 c0c = c0 + (u32)OPS_LDS <= cig_words ? c0 : (cig_words >= (u32)OPS_LDS ? cig_words - (u32)OPS_LDS : 0u);
-            const Words4 lo4 = gload_as<Words4>(b.cigar + c0c), hi4 = gload_as<Words4>(b.cigar + c0c + 4);
-            u32 w[OPS_LDS] = {lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z, hi4.w};
-            if (c0c != c0) { // (shifted: at most seven words)
-                const u32 sh = c0 - c0c;
+            if (cig_words >= (u32)OPS_LDS) {
+                // (the batch's last operations are read from eight words before its end: the loads never leave the array)
+                const u32 c0c = c0 + (u32)OPS_LDS <= cig_words ? c0 : cig_words - (u32)OPS_LDS;
+                const Words4 lo4 = gload_as<Words4>(b.cigar + c0c), hi4 = gload_as<Words4>(b.cigar + c0c + 4);
+                u32 w[OPS_LDS] = {lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z, hi4.w};
+                if (c0c != c0) { // (shifted: at most seven words)
+                    const u32 sh = c0 - c0c;
 #pragma unroll
-                for (int q = 0; q < OPS_LDS; q++) {
-                    u32 v = 0;
+                    for (int q = 0; q < OPS_LDS; q++) {
+                        u32 v = 0;
 #pragma unroll
-                    for (int j = q; j < OPS_LDS; j++) v = (u32)(j - q) == sh ? w[j] : v;
-                    w[q] = v;
+                        for (int j = q; j < OPS_LDS; j++) v = (u32)(j - q) == sh ? w[j] : v;
+                        w[q] = v;
+                    }
                 }
-            }
 #pragma unroll
-            for (int q = 0; q < OPS_LDS; q++) O.op[q] = w[q];
+                for (int q = 0; q < OPS_LDS; q++) O.op[q] = w[q];
+            } else { // (a batch of fewer than eight operations: word by word, guarded)
+#pragma unroll
+                for (int q = 0; q < OPS_LDS; q++) O.op[q] = c0 + (u32)q < cig_words ? b.cigar[c0 + (u32)q] : 0u;
+            }
         }
         return O;
     };
@@ -2250,6 +2205,7 @@ __global__ __launch_bounds__(K1E_T) __attribute__((amdgpu_waves_per_eu(K1E_WAVES
         const int mem = b.member;
         const int32_t voff = G.voff[mem], ref_len = G.len[mem], tid = G.tid[mem];
         const PJB_GLOBAL u32 *gcodes = use_codes ? as_global(G.codes[mem]) : (const PJB_GLOBAL u32 *)nullptr;
+        const PJB_GLOBAL u32 *gcodes2 = use_codes && b.seq2 != nullptr ? as_global(G.codes2[mem]) : (const PJB_GLOBAL u32 *)nullptr;
         const int32_t vlen = voff + ref_len; // the target's end in the group's virtual sequence
         const u32 seq_words = s_seqw[T.bi];  // words of packed bases in the batch: nothing reads past them
         const int32_t g_words = (ref_len + 7) / 8 + 1;
@@ -2270,7 +2226,7 @@ __global__ __launch_bounds__(K1E_T) __attribute__((amdgpu_waves_per_eu(K1E_WAVES
             for (int q = 0; q < OPS_LDS; q++) op[q] = (u32)q < n ? O.op[q] : 0u;
             g = b.base + R.r;
             off = R.toff + R.poff;
-            meta = read_meta(O.flag, O.xs, O.mapq, pos, O.mtid, O.mpos, tid, orientation);
+            meta = read_meta(O.flag, O.xs & 0xffu, O.mapq, pos, O.mtid, O.mpos, tid, orientation);
             const bool seq_ok = (R.sr.w & 0x8000u) != 0;
             // ---- shape: [S] M N M [S], or -- two introns, nothing clamped -- [S] M N M N M [S]
             if (gcodes != nullptr && n >= 3 && n <= 7) {
@@ -2306,38 +2262,40 @@ __global__ __launch_bounds__(K1E_T) __attribute__((amdgpu_waves_per_eu(K1E_WAVES
         const u32 shard = (chunk >> (8 - K1E_SHIFT)) % GEN_SHARDS;
         const u32 base2 = ctx.list_reserve(2, two, 2u, shard), base3 = ctx.list_reserve(3, generic, 0u, shard);
         K1E_MARK(2); // shapes (waits for the operations)
-        // ---- staging (the whole wavefront): the reads' bases and the genome under their blocks of bases, all on their way at once.  A
-        // lane takes part if its alignment lies inside its target (nothing clamped) and none of its blocks is longer than a window.
-        constexpr u32 WIN_BASES = ((u32)K1E_GENW - 8u) * 8u;
-        const bool lds_ok = simple && pos >= 0 && (int64_t)pos + a + nl + b2 + nl2 + b3 <= (int64_t)ref_len && a <= WIN_BASES && b2 <= WIN_BASES && b3 <= WIN_BASES;
-        int32_t q_w0 = 0;
-        bool staged = false;
-        {
-            const u32 nwq = ((u32)lq + 7u) >> 3;
-            const u32 q_lo = wave_total<DppMin>(lds_ok ? so : 0xffffffffu), q_hi = wave_total<DppMax>(lds_ok ? so + nwq : 0u);
-            K1E_MARK(10); // (span of the bases)
-            if (K1E_STAGE && !(K1E_ABL & 4) && q_lo < q_hi && q_hi - q_lo <= (u32)K1E_SEQW - 3u && q_hi <= seq_words) {
-                staged = true;
-                const u32 shq = stage_span<K1E_SEQW>(stg.seq, (const PJB_GLOBAL u32 *)b.seq4, q_lo, q_hi - q_lo, seq_words);
-                q_w0 = (int32_t)(so - q_lo + shq);
-                K1E_MARK(11); // (bases issued)
-            }
+        // ---- in 2 bits: the read is pure ACGT, lies inside its target (nothing clamped: block k of its bases starts at g2s[k]), no block
+        // longer than the bitmap load covers.  The exception bitmap under the blocks -- bits g2s >> 6 .. (g2s + len - 1) >> 6, at most 31 of
+        // them, in the two words from word g2s >> 11 -- is asked for here and looked at just before the rounds.
+        bool use2 = simple && gcodes2 != nullptr && !(O.xs & 0x100u) && pos >= 0 && (int64_t)pos + a + nl + b2 + nl2 + b3 <= (int64_t)ref_len &&
+                    a <= (u32)C2_MAX_BLOCK && b2 <= (u32)C2_MAX_BLOCK && b3 <= (u32)C2_MAX_BLOCK;
+        const int64_t n2w = codes2_words(ref_len);
+        Words2 x0 = {0, 0}, x1 = {0, 0}, x2 = {0, 0};
+        if (use2) {
+            const PJB_GLOBAL u32 *gexc = gcodes2 + n2w + K0_CODES2_PAD;
+            const u32 g1 = (u32)pos + a + nl;
+            x0 = gload_as<Words2>(gexc + ((u32)pos >> 11));
+            x1 = gload_as<Words2>(gexc + (g1 >> 11));
+            if (two) x2 = gload_as<Words2>(gexc + ((g1 + b2 + nl2) >> 11));
         }
-        // One read's pairs in closed form (junction_system.cc:140-210 for one or two N operations).  LDS: its blocks of bases are
-        // compared out of the staged windows (g_ofs*); else with the gathers of cmp_words.
+        // the next trips' loads go out before this trip's compares: its list records (two ahead), then the operations and fields (one
+        // ahead) -- they are in flight while this trip is compared
+        const bool more = v + 1 < v_hi, more2 = v + 2 < v_hi;
+        EmitTrip T2 = T1;
+        EmitRec R2 = R1;
+        EmitOps On = O;
+        if (more2) {
+            T2 = locate(v + 2);
+            R2 = fetch_rec(T2);
+        }
+        K1E_MARK(4); // records of the trip after the next issued
+        if (more) On = fetch_ops(T1, R1);
+        K1E_MARK(6); // next operations issued
+        // One read's pairs in closed form (junction_system.cc:140-210 for one or two N operations): its blocks of bases compared with
+        // gathers, in 2 bits where that is exact and on the 4-bit codes elsewhere.
         const u32 *seqw = (const u32 *)b.seq4 + so;
         const int32_t q_limit = (int32_t)min(seq_words - 1u - so, 0x7fffffffu);
-        auto emit_simple = [&](auto lds_tag, int32_t g_ofs0, int32_t g_ofs1, int32_t g_ofs2) {
-            constexpr bool LDS = decltype(lds_tag)::value;
+        if (simple) {
             const int32_t vpos = pos + voff;
             const int32_t aend_all = vpos + (int32_t)(a + nl + b2 + nl2 + b3) - 1;
-            // one block of bases: read [q, q + len) against the target's [gl, gl + len)
-            auto cmp_block = [&](int k, int32_t q, int32_t gl, CmpBlock &B) {
-#if K1E_ABL & 1
-                return;
-#endif
-                if constexpr (LDS) cmp_block_lds<true, true>(stg.seq, q_w0, q, stg.gen[k][0], k == 0 ? g_ofs0 : k == 1 ? g_ofs1 : g_ofs2, gl, B.len, s_tail, B);
-            };
             // ---- the pairs' geometry (junction_system.cc:140-210 for one or two N operations)
             const u32 npairs = two ? 2u : 1u;
             u64 key_[2];
@@ -2375,57 +2333,71 @@ __global__ __launch_bounds__(K1E_T) __attribute__((amdgpu_waves_per_eu(K1E_WAVES
             const int32_t bg[3] = {lst_[0] - voff, iend_[0] + 1 - voff, iend_[1] + 1 - voff};
             const int32_t bl[3] = {(int32_t)a, rend_[0] - iend_[0], rend_[1] - iend_[1]};
             CmpBlock res[3] = {{bl[0], 0, -1, -1}, {bl[1], 0, -1, -1}, {bl[2], 0, -1, -1}};
-            if constexpr (LDS) {
-                cmp_block(0, bq[0], bg[0], res[0]);
-                cmp_block(1, bq[1], bg[1], res[1]);
-                if (two) cmp_block(2, bq[2], bg[2], res[2]);
-            } else if (!(K1E_ABL & 17)) {
-                // The gathers, a ROUND of 56 bases at a time, every lane through its own blocks one after the other: a lane with a long
-                // left anchor has a short right one, so the wavefront needs max (rounds of all blocks of a lane) iterations -- four
-                // for 150 bases -- where block after block it needed max (rounds of block 0) + max (rounds of block 1) + ... -- six or
-                // more; each iteration is a memory round trip as well.
-                const int nb = two ? 3 : 2;
-                int k = 0;
+            // The gathers, a ROUND at a time, every lane through its own blocks one after the other: a lane with a long left anchor
+            // has a short right one, so the wavefront needs max (rounds of all blocks of a lane) iterations where block after block it
+            // needed max (rounds of block 0) + max (rounds of block 1) + ...; each iteration is a memory round trip as well.
+            const int nb = two ? 3 : 2;
+            { // a stretch with a character outside ACGT under one of the blocks: the lane compares on the 4-bit codes
+                auto hit = [&](const Words2 &w, int32_t gi, int32_t l) {
+                    const u32 b0 = (u32)gi >> 6, cnt = (((u32)(gi + l - 1)) >> 6) - b0 + 1u; // 1 .. 31 stretches
+                    const u64 bits = (((u64)1 << cnt) - 1u) << (b0 & 31u);
+                    return (((u64)w.x | ((u64)w.y << 32)) & bits) != 0;
+                };
+                if (use2 && (hit(x0, bg[0], bl[0]) || hit(x1, bg[1], bl[1]) || (two && hit(x2, bg[2], bl[2])))) use2 = false;
+            }
+#ifdef K1E_HIST
+            u32 h_rounds = 0, h_mine = 0, h_rounds4 = 0;
+#endif
+            if (__ballot(use2)) {
+                const u32 *seq2w = (const u32 *)b.seq2 + (so >> 1);
+                const int32_t q2_last = (int32_t)min(((seq_words + 1u) >> 1) - 1u - (so >> 1), 0x7fffffffu); // the batch's last word of 2-bit bases, from the read's first
+                const int32_t g2_last = (int32_t)(n2w + K0_CODES2_PAD - 1);
+                const u32 qodd = (so & 1u) * 16u;
+                int k = use2 ? 0 : nb;
+                int32_t t = 0;
+                u32 mism = 0, fbit = 0xffffffffu, lbit1 = 0;
+                for (;;) {
+                    const int32_t l = k == 0 ? bl[0] : k == 1 ? bl[1] : bl[2];
+                    const bool act = k < nb && t < l;
+                    if (act) {
+                        const int32_t qi = k == 0 ? bq[0] : k == 1 ? bq[1] : bq[2], gi = k == 0 ? bg[0] : k == 1 ? bg[1] : bg[2];
+                        const u32 qbit = qodd + 2u * (u32)(qi + t), gbit = 2u * (u32)(gi + t);
+                        u32 qw[C2_NW], gw[C2_NW];
+                        load_words<C2_NW>(qw, seq2w, (int32_t)(qbit >> 5), q2_last);
+                        load_words<C2_NW>(gw, (const u32 *)gcodes2, (int32_t)(gbit >> 5), g2_last);
+                        chunk2_cmp_bits<C2_NW>(qw, gw, qbit & 31u, gbit & 31u, l, t, mism, fbit, lbit1);
+                        t += C2_ROUND;
+#ifdef K1E_HIST
+                        h_mine++;
+#endif
+                    }
+                    if (k < nb && t >= l) { // the lane's block is finished: its results, the next block
+                        const int32_t first = (int32_t)fbit >> 1, last = ((int32_t)lbit1 - 1) >> 1; // (-1: no mismatch)
+                        if (k == 0) res[0].mism = (int32_t)mism, res[0].first = first, res[0].last = last;
+                        if (k == 1) res[1].mism = (int32_t)mism, res[1].first = first, res[1].last = last;
+                        if (k == 2) res[2].mism = (int32_t)mism, res[2].first = first, res[2].last = last;
+                        k++;
+                        t = 0, mism = 0, fbit = 0xffffffffu, lbit1 = 0;
+                    }
+#ifdef K1E_HIST
+                    h_rounds++;
+#endif
+                    if (!__ballot(k < nb)) break;
+                }
+            }
+            if (__ballot(!use2)) { // ---- on the 4-bit codes (rounds of 56 bases)
+                int k = use2 ? nb : 0;
                 int32_t t = 0;
                 u32 mism = 0, fbit = 0xffffffffu, lbit1 = 0;
                 for (;;) {
                     // (blocks without bases -- a clamped end -- are stepped over)
-                    int32_t l = k == 0 ? bl[0] : k == 1 ? bl[1] : bl[2];
+                    const int32_t l = k == 0 ? bl[0] : k == 1 ? bl[1] : bl[2];
                     const bool act = k < nb && t < l;
                     if (act) {
                         const int32_t qi = k == 0 ? bq[0] : k == 1 ? bq[1] : bq[2], gi = k == 0 ? bg[0] : k == 1 ? bg[1] : bg[2];
                         CmpChunkT<SIMPLE_NW> C;
-#if K1E_ABL & 96
-                        { // (timing only, results wrong: the lanes of a pair / a quad load from the first one's addresses)
-                            const int src = lane_id() & ((K1E_ABL & 64) ? ~3 : ~1);
-                            const u32 so_ = (u32)__shfl((int)so, src, 64);
-                            const int32_t qi_ = __shfl(qi, src, 64) + ((lane_id() - src) * 32), gi_ = __shfl(gi, src, 64) + ((lane_id() - src) * 32);
-                            chunk_load<SIMPLE_NW, true>(C, (const u32 *)b.seq4 + so_, qi_, (int32_t)min(seq_words - 1u - so_, 0x7fffffffu), (const u32 *)gcodes, gi_, g_words, l, t);
-                        }
-#elif K1E_ABL & 128
-                        { // (timing only, results wrong: the genome's words are not loaded)
-                            load_words<SIMPLE_NW>(C.qw, seqw, (qi + t) >> 3, q_limit);
-#pragma unroll
-                            for (int w = 0; w < SIMPLE_NW; w++) C.gg[w] = C.qw[w] ^ (u32)gi;
-                        }
-#elif K1E_ABL & 256
-                        { // (timing only, results wrong: nothing is loaded, the compare runs on made-up words)
-#pragma unroll
-                            for (int w = 0; w < SIMPLE_NW; w++) C.qw[w] = (u32)qi * (u32)(w + 3) + (u32)t, C.gg[w] = (u32)gi * (u32)(w + 5) + (u32)t;
-                        }
-#else
                         chunk_load<SIMPLE_NW, true>(C, seqw, qi, q_limit, (const u32 *)gcodes, gi, g_words, l, t);
-#endif
-#if K1E_ABL & 512
-                        { // (timing only, results wrong: the words are loaded and folded, not compared)
-                            u32 acc = 0;
-#pragma unroll
-                            for (int w = 0; w < SIMPLE_NW; w++) acc ^= C.qw[w] ^ C.gg[w];
-                            mism += acc & 1u;
-                        }
-#else
                         chunk_cmp_bits<SIMPLE_NW>(C, qi, gi, l, t, mism, fbit, lbit1);
-#endif
                         t += 8 * (SIMPLE_NW - 1);
                     }
                     if (k < nb && t >= l) { // the lane's block is finished (or empty): its results, the next block
@@ -2436,9 +2408,24 @@ __global__ __launch_bounds__(K1E_T) __attribute__((amdgpu_waves_per_eu(K1E_WAVES
                         k++;
                         t = 0, mism = 0, fbit = 0xffffffffu, lbit1 = 0;
                     }
+#ifdef K1E_HIST
+                    h_rounds4++;
+#endif
                     if (!__ballot(k < nb)) break;
                 }
             }
+#ifdef K1E_HIST
+            {
+                const u32 lanes = (u32)__popcll(__ballot(true)), sum = wave_total<DppAdd>(h_mine);
+                const u32 r_ = min(h_rounds, 31u), r4 = min(wave_total<DppMax>(h_rounds4), 31u);
+                if (lane_id() == (int)(__ffsll((long long)__ballot(true)) - 1)) {
+                    atomicAdd(&g_k1e_hist[0][r_], 1ull);
+                    atomicAdd(&g_k1e_hist[1][r_], (unsigned long long)sum);
+                    atomicAdd(&g_k1e_hist[2][r_], (unsigned long long)lanes);
+                    atomicAdd(&g_k1e_hist[3][r4], 1ull);
+                }
+            }
+#endif
 #pragma unroll
             for (u32 pr = 0; pr < 2; pr++) {
                 if (pr >= npairs) break;
@@ -2453,71 +2440,9 @@ __global__ __launch_bounds__(K1E_T) __attribute__((amdgpu_waves_per_eu(K1E_WAVES
                 P.key[off + pr] = key_[pr];
                 if (P.g) P.g[off + pr] = g;
                 rec_store(P.rec + off + pr, Q);
-#if !(K1E_ABL & 2)
                 if (want_cand) cand_insert(key_[pr], Q.lstart, Q.rend);
-#endif
             }
-        };
-        // ---- passes over the wavefront's loci.  Window A of a block of bases starts at the block of the first lane that is still to
-        // do, window B at the block of the first lane A does not hold (the reads of a wavefront are position-sorted: mostly one
-        // locus, often two, seldom more -- the lanes of each next to each other); a lane is done in the pass that holds all of its
-        // blocks, and the first lane to do always is: the passes end.  The next trip's list records go out behind the first pass's
-        // staging loads, its operations and fields behind the first wait: they are in flight while this trip is compared.
-        const bool more = v + 1 < v_hi, more2 = v + 2 < v_hi;
-        EmitTrip T2 = T1;
-        EmitRec R2 = R1;
-        EmitOps On = O;
-        bool todo = staged && lds_ok;
-        for (int pass = 0;; pass++) {
-            u32 in_win = 0; // bit k: the lane's block k is in a window
-            int32_t g_ofs0 = 0, g_ofs1 = 0, g_ofs2 = 0;
-            if (staged) {
-                const u32 gs0 = (u32)pos, gs1 = (u32)pos + a + nl, gs2 = gs1 + b2 + nl2; // the blocks' first bases (target coordinates)
-                auto window = [&](int k, bool has, u32 gstart, u32 len, int32_t &g_ofs) {
-                    const u64 bal = __ballot(has);
-                    if (bal == 0) return;
-                    const u32 w0 = gstart >> 3, w1 = ((gstart + len - 1u) >> 3) + 1u; // (the word behind the block's last feeds the funnel shift)
-                    const u32 loA = (u32)__builtin_amdgcn_readlane((int)w0, __ffsll((long long)bal) - 1);
-                    const int32_t ofsA = (int32_t)stage_span<K1E_GENW>(stg.gen[k][0], gcodes, loA, min((u32)K1E_GENW, (u32)g_words - loA), (u32)g_words) - (int32_t)loA;
-                    const bool inA = has && w0 >= loA && w1 < loA + (u32)K1E_GENW - 3u;
-                    const u64 rest = bal & ~__ballot(inA);
-                    bool inB = false;
-                    int32_t ofsB = 0;
-                    if (rest) {
-                        const u32 loB = (u32)__builtin_amdgcn_readlane((int)w0, __ffsll((long long)rest) - 1);
-                        ofsB = (int32_t)stage_span<K1E_GENW>(stg.gen[k][1], gcodes, loB, min((u32)K1E_GENW, (u32)g_words - loB), (u32)g_words) - (int32_t)loB +
-                               (int32_t)(K1E_GENW + K1E_SLACK);
-                        inB = has && !inA && w0 >= loB && w1 < loB + (u32)K1E_GENW - 3u;
-                    }
-                    g_ofs = inA ? ofsA : ofsB; // (word index from stg.gen[k][0])
-                    if (inA || inB) in_win |= 1u << k;
-                };
-                window(0, todo, gs0, a, g_ofs0);
-                window(1, todo, gs1, b2, g_ofs1);
-                window(2, todo && two, gs2, b3, g_ofs2);
-            }
-            if (pass == 0) {
-                K1E_MARK(3); // staging issued
-                if (more2) {
-                    T2 = locate(v + 2);
-                    R2 = fetch_rec(T2);
-                }
-                K1E_MARK(4); // records of the trip after the next issued
-            }
-            if (staged) stage_wait();
-            if (pass == 0) {
-                K1E_MARK(5); // the wait
-                if (more) On = fetch_ops(T1, R1);
-                K1E_MARK(6); // next operations issued
-            }
-            const u32 need = two ? 7u : 3u;
-            const bool now = todo && (in_win & need) == need;
-            if (now) emit_simple(std::true_type{}, g_ofs0, g_ofs1, g_ofs2);
-            todo = todo && !now;
-            if (pass + 1 >= K1E_PASSES || !__ballot(todo)) break;
         }
-        // (what the windows did not hold -- a third locus in the wavefront, clamped ends, long blocks, long reads: the gathers)
-        if (simple && (todo || !(staged && lds_ok))) emit_simple(std::false_type{}, 0, 0, 0);
         const u64 p1_entry = (u64)(E.pack_nn ? g | (2u << 28) : g) | ((u64)off << 32);
         K1E_MARK(7); // compares, records, candidates
         ctx.list_write(2, two, base2, p1_entry, shard);

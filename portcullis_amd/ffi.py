@@ -10,11 +10,11 @@ import os
 
 import numpy as np
 
-from .records import ORIENTATION, ReadBatch
+from .records import ORIENTATION, ReadBatch, pack_seq2
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libportcullis_amd.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 MAX_QUEUED = 8  # PJB_MAX_QUEUED
 N_STAGES = 8
 STAGE_NAMES = ["scan_emit", "sort", "group", "anchors", "pair_stats", "finalize", "d2h", "spare"]
@@ -45,7 +45,7 @@ class PjbConfig(C.Structure):
 class PjbBatch(C.Structure):
     _fields_ = [("n_reads", C.c_int64)] + [
         (n, C.c_void_p) for n in ("pos", "flag", "mapq", "xs", "l_qseq", "mtid", "mpos", "cig_off", "cigar", "seq_off", "seq4",
-                                  "name_hash")
+                                  "name_hash", "seq2", "seq_exc")
     ]
 
 
@@ -223,7 +223,11 @@ class Context:
     def release_contig(self, tid):
         self._check(self._L.pjb_release_contig(self._h, tid))
 
-    def submit_batch(self, tid, batch: ReadBatch):
+    def submit_batch(self, tid, batch: ReadBatch, seq2=None):
+        """seq2: None = as PJB_FFI_SEQ2 says (default 1): the batch goes over with its bases in 2 bits as well (records.pack_seq2, what an
+        ABI-4 decoder does); False = seq4 only (the compares then run on the 4-bit codes)."""
+        if seq2 is None:
+            seq2 = os.environ.get("PJB_FFI_SEQ2", "1") != "0"
         pb = PjbBatch()
         pb.n_reads = batch.n
         keep = []
@@ -240,6 +244,12 @@ class Context:
                 nh = np.zeros(2, dtype=np.uint64)
             keep.append(nh)
             pb.name_hash = nh.ctypes.data
+        if seq2 and batch.n:
+            s2, sx = pack_seq2(batch.seq4, batch.seq_off, batch.l_qseq)
+            s2 = np.ascontiguousarray(np.concatenate([s2, np.zeros(2, dtype=np.uint16)]))  # (read as words: an even number of granules)
+            sx = np.ascontiguousarray(sx) if sx.size else np.zeros(1, dtype=np.uint32)
+            keep += [s2, sx]
+            pb.seq2, pb.seq_exc = s2.ctypes.data, sx.ctypes.data
         self._check(self._L.pjb_submit_batch(self._h, tid, C.byref(pb)))
 
     def submit_batch_device(self, tid, tensors, n_reads):
@@ -253,6 +263,9 @@ class Context:
         if tensors.get("name_hash") is not None:
             self._keep_batch.setdefault(tid, []).append(tensors["name_hash"])
             pb.name_hash = tensors["name_hash"].data_ptr()
+        if tensors.get("seq2") is not None and tensors.get("seq_exc") is not None and os.environ.get("PJB_FFI_SEQ2", "1") != "0":
+            self._keep_batch.setdefault(tid, []) .extend([tensors["seq2"], tensors["seq_exc"]])
+            pb.seq2, pb.seq_exc = tensors["seq2"].data_ptr(), tensors["seq_exc"].data_ptr()
         self._check(self._L.pjb_submit_batch_device(self._h, tid, C.byref(pb)))
 
     def finish_contig(self, tid):

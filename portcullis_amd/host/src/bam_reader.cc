@@ -73,6 +73,8 @@ void ReadBatch::view(pjb_batch& b) const {
     b.mtid = mtid.data(); b.mpos = mpos.data(); b.cig_off = cig_off.data(); b.cigar = cigar.data();
     b.seq_off = seq_off.data(); b.seq4 = seq4.data();
     b.name_hash = name_hash.size() == pos.size() && !pos.empty() ? name_hash.data() : nullptr;
+    b.seq2 = nullptr; // (the host decoder hands over BAM's 4-bit bases only: the device ingest, which is the default, writes both)
+    b.seq_exc = nullptr;
 }
 
 // ------------------------------------------------------------------ BGZF

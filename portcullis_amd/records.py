@@ -50,6 +50,47 @@ def encode_seq(s):
     return ((codes[0::2] << 4) | codes[1::2]).astype(np.uint8)
 
 
+# 2-bit bases (pjb_batch.seq2 / .seq_exc, ABI 4): per seq4 byte the two bases' codes (A 0, C 1, G 2, T 3; anything else 0) in four
+# bits, low base first; per BAM code whether it is one of A, C, G, T
+_CODE2 = np.zeros(16, dtype=np.uint8)
+_CODE2[[1, 2, 4, 8]] = [0, 1, 2, 3]
+_VALID2 = np.zeros(16, dtype=bool)
+_VALID2[[1, 2, 4, 8]] = True
+_b = np.arange(256)
+_V2 = (_CODE2[_b >> 4] | (_CODE2[_b & 15] << 2)).astype(np.uint8)       # (BAM: high nibble = the first base of the byte)
+_BAD2 = ((~_VALID2[_b >> 4]).astype(np.uint8) + (~_VALID2[_b & 15]).astype(np.uint8)).astype(np.uint8)
+del _b
+
+
+def pack_seq2(seq4, seq_off, l_qseq):
+    """What a decoder writes beside seq4 for ABI 4: (seq2 uint16[words of seq4], seq_exc uint32[(n + 31) // 32]) -- the same bases in
+    2 bits, a 16-bit granule per seq4 word, and per read whether it must NOT be compared in 2 bits (a base outside ACGT among its
+    l_qseq bases, or fewer bases than l_qseq).  A format conversion: nothing of the path's arithmetic."""
+    seq4 = np.ascontiguousarray(seq4, dtype=np.uint8)
+    seq_off = np.asarray(seq_off, dtype=np.int64)
+    lq = np.asarray(l_qseq, dtype=np.int64)
+    n = len(lq)
+    n_words = int(seq_off[n]) if n else 0
+    b = seq4[: 4 * n_words]
+    v = _V2[b]
+    seq2 = (v[0::2] | (v[1::2] << 4)).astype(np.uint8).view(np.uint16) if n_words else np.zeros(0, dtype=np.uint16)
+    # per read: characters outside ACGT among its first l_qseq bases = those of its whole bytes + the high nibble of an odd last one
+    bad_cum = np.concatenate([[0], np.cumsum(_BAD2[b], dtype=np.int64)])
+    first = 4 * seq_off[:n]
+    have = (seq_off[1 : n + 1] - seq_off[:n]) * 8
+    full = np.minimum(lq, have).clip(min=0)
+    cnt = bad_cum[first + full // 2] - bad_cum[first]
+    odd = (full % 2 == 1) & (full > 0)
+    idx = np.minimum(first + full // 2, max(len(b) - 1, 0))
+    last_hi = (b[idx] >> 4) if len(b) else np.zeros(n, dtype=np.uint8)
+    cnt = cnt + (odd & ~_VALID2[last_hi])
+    exc = (cnt > 0) | (have < lq) | (lq <= 0)
+    bits = np.zeros(((n + 31) // 32) * 32, dtype=np.uint8)
+    bits[:n] = exc
+    seq_exc = np.packbits(bits, bitorder="little").view(np.uint32) if n else np.zeros(0, dtype=np.uint32)
+    return seq2, seq_exc
+
+
 @dataclass
 class ReadBatch:
     """Alignment records of one contig, in BAM file order."""

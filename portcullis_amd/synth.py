@@ -307,6 +307,10 @@ def generate(cfg: SynthConfig, device="cpu", seed=None, tid=0):
     seq_off = torch.zeros(N + 1, dtype=torch.int64, device=dev)
     seq_off[1:] = torch.cumsum(seq_words, 0)
     seq4 = packed[o_s].reshape(-1).contiguous()
+    # the same bases in 2 bits and the reads' exception bitmap (pjb_batch.seq2 / .seq_exc, ABI 4: what a decoder writes beside seq4; every
+    # generated base is one of ACGT and every spliced read carries its L bases)
+    seq2 = pack_seq2_torch(seq4)
+    seq_exc = bits_to_words(~o_spl)
     n_pairs = int(((op_all == OP_N) & present).sum())
     mtid_t = torch.full((N,), -1, dtype=torch.int64, device=dev)
     mpos_t = torch.full((N,), -1, dtype=torch.int64, device=dev)
@@ -340,9 +344,36 @@ def generate(cfg: SynthConfig, device="cpu", seed=None, tid=0):
         cigar=cigar,
         seq_off=seq_off.to(torch.int32),
         seq4=seq4,
+        seq2=seq2,
+        seq_exc=seq_exc,
     )
     return dict(genome=genome, batch=batch, n_reads=N, n_pairs=n_pairs, n_cigar_ops=int(cig_off[-1]),
                 n_spliced=S, seq_words_per_read=W, config=cfg)
+
+
+def pack_seq2_torch(seq4):
+    """uint8 tensor of 4-bit packed bases (whole 4-byte words) -> int16 tensor, one 16-bit granule per word (records.pack_seq2's layout), padded
+    to an even number of granules."""
+    code = torch.zeros(16, dtype=torch.uint8, device=seq4.device)
+    code[torch.tensor([1, 2, 4, 8], device=seq4.device)] = torch.tensor([0, 1, 2, 3], dtype=torch.uint8, device=seq4.device)
+    b = torch.arange(256, device=seq4.device)
+    v2 = (code[b >> 4] | (code[b & 15] << 2)).to(torch.uint8)
+    n = seq4.numel()
+    out = torch.zeros(((n // 4 + 1) // 2) * 4, dtype=torch.uint8, device=seq4.device)
+    STEP = 1 << 27
+    for lo in range(0, n, STEP):
+        v = v2[seq4[lo:lo + STEP].long()]
+        out[lo // 2:(lo + v.numel()) // 2] = v[0::2] | (v[1::2] << 4)
+    return out.view(torch.int16)
+
+
+def bits_to_words(mask):
+    """bool tensor -> int32 tensor of its bits, bit r & 31 of word r >> 5 (the bit pattern of uint32)."""
+    n = mask.numel()
+    m = torch.zeros(((n + 31) // 32) * 32, dtype=torch.int64, device=mask.device)
+    m[:n] = mask.long()
+    w = (m.view(-1, 32) << torch.arange(32, device=mask.device)).sum(1)
+    return torch.where(w >= (1 << 31), w - (1 << 32), w).to(torch.int32)
 
 
 def batch_to_numpy(batch, lo=0, hi=None):

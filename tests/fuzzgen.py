@@ -166,6 +166,45 @@ def _tx_read(rng, genome, exons, L, opts):
 
 
 DEFAULT_OPTS = dict(indel=0.06, eqx=0.04, pad=0.01, sub=0.01, clip=0.1, hard=0.03)
+# The "exception channel" family (round 6: k1_emit compares in 2 bits where reads and genome are pure ACGT): a CLEAN genome
+# (genome_n = genome_iupac = 0) with characters outside ACGT -- N, IUPAC codes, lower-case letters -- planted at the anchors' edges
+# (the first / last base of an exon, the bases either side of it, the boundaries of the exception bitmap's 64-base stretches), and
+# reads that carry N / IUPAC codes / '=' of their own, at their anchors' first and last bases among others.  edge_exc plants before
+# the reads are drawn (they copy the letters), late_exc afterwards (a pure-ACGT read over a letter that is not).
+EXC_OPTS = dict(genome_n=0.0, genome_iupac=0.0, genome_lower=0.02, edge_exc=0.04, late_exc=0.08, read_exc=0.08)
+_NON_ACGT = list("NNNNRYSWKMBDHVacgtn")
+
+
+def plant_edge_exceptions(rng, genome, txs, p):
+    g = list(genome)
+    for ex in txs:
+        for s, e in ex:
+            for at in (s - 1, s, s + 1, e - 2, e - 1, e, (s // 64) * 64 + 63, (s // 64) * 64 + 64, (e // 64) * 64 - 1, (e // 64) * 64):
+                if 0 <= at < len(g) and rng.random() < p / 3:
+                    g[at] = str(rng.choice(_NON_ACGT))
+    return "".join(g)
+
+
+def read_exceptions(rng, r, p):
+    """With probability p the read gets one to three letters outside ACGT ('=' among them): at the first / last base of one of
+    its M blocks, or anywhere."""
+    import re
+    if r["seq"] is None or not r["seq"] or rng.random() >= p:
+        return
+    ops = [(int(n), o) for n, o in re.findall(r"(\d+)([MIDNSHP=X])", r["cigar"])]
+    edges = []
+    q = 0
+    for n, o in ops:
+        if o in "M=X":
+            edges += [q, q + n - 1]
+        if o in "MIS=X":
+            q += n
+    arr = list(r["seq"])
+    for _ in range(int(rng.integers(1, 4))):
+        at = int(rng.choice(edges)) if edges and rng.random() < 0.6 else int(rng.integers(0, len(arr)))
+        if 0 <= at < len(arr):
+            arr[at] = str(rng.choice(list("NNNRYSWKMBDHV=")))
+    r["seq"] = "".join(arr)
 
 
 def make_reads(seed, glen=30000, n_reads=3000, paired=False, opts=None, L=(30, 150), n_tx=12, no_xs_frac=0.1,
@@ -174,8 +213,10 @@ def make_reads(seed, glen=30000, n_reads=3000, paired=False, opts=None, L=(30, 1
     o = dict(DEFAULT_OPTS)
     if opts:
         o.update(opts)
-    genome = random_genome(rng, glen)
+    genome = random_genome(rng, glen, lower_frac=o.get("genome_lower", 0.1), n_frac=o.get("genome_n", 0.002), iupac_frac=o.get("genome_iupac", 0.001))
     txs, genome = make_transcripts(rng, glen, n_tx=n_tx, genome=genome)
+    if o.get("edge_exc"):
+        genome = plant_edge_exceptions(rng, genome, txs, o["edge_exc"])
     strands = [("+" if rng.random() < 0.5 else "-") for _ in txs]
     # zipf-ish transcript popularity
     w = 1.0 / np.arange(1, len(txs) + 1) ** 1.1
@@ -206,9 +247,13 @@ def make_reads(seed, glen=30000, n_reads=3000, paired=False, opts=None, L=(30, 1
         r["mapq"] = int(rng.choice([60, 60, 60, 60, 30, 29, 3, 0]))
         x = rng.random()
         r["xs"] = None if x < no_xs_frac else (strands[t] if x < 0.97 else ("-" if strands[t] == "+" else "+"))
+        if o.get("read_exc"):
+            read_exceptions(rng, r, o["read_exc"])
         if rng.random() < noseq_frac:
             r["seq"] = None
         reads.append(r)
+    if o.get("late_exc"):
+        genome = plant_edge_exceptions(rng, genome, txs, o["late_exc"])
     reads.sort(key=lambda r: r["pos"])
     return genome, reads
 

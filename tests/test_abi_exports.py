@@ -24,7 +24,7 @@ def test_struct_sizes():
     from portcullis_amd import ffi
 
     assert ffi.ROW_DTYPE.itemsize == 200
-    assert ctypes.sizeof(ffi.PjbBatch) == 8 + 12 * 8
+    assert ctypes.sizeof(ffi.PjbBatch) == 8 + 14 * 8  # (ABI 4: + seq2, seq_exc)
     assert ffi.EXTRA_DTYPE.itemsize == 24
     assert ctypes.sizeof(ffi.PjbRegionResult) == 56
     assert ctypes.sizeof(ffi.PjbConfig) == 20

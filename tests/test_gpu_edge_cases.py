@@ -151,3 +151,42 @@ def test_fuzz_family_many_ops(ffi, orc, seed):
     assert n_ops[len(n_ops) // 2] >= 25 and n_ops[-1] >= 50, (n_ops[len(n_ops) // 2], n_ops[-1])
     status, rows = both(ffi, orc, genome, reads, "FR")
     assert status == "ok" and len(rows) > 0
+
+
+@pytest.mark.parametrize("seed,ori", [(9001, "FR"), (9002, "UNKNOWN"), (9003, "RF"), (9004, "FF"), (9005, "SE"), (9006, "FR"), (9007, "UNKNOWN"), (9008, "FR")])
+def test_fuzz_family_exception_channel(ffi, orc, seed, ori):
+    """Round 5's verdict: the inputs of the 2-bit compare's exception channel.  A genome that is pure ACGT but for letters planted at
+    the anchors' edges and at the boundaries of the exception bitmap's 64-base stretches (N, IUPAC codes, lower case), reads with N /
+    IUPAC codes / '=' of their own at their anchors' first and last bases: the lanes of one wavefront take the 2-bit rounds, fall back
+    to the 4-bit codes under a flagged stretch, or never leave them -- and every row must equal the oracle's.  Then the same records
+    with 4-bit bases only (pjb_batch.seq2 = NULL): the same rows."""
+    from fuzzgen import EXC_OPTS, make_reads
+    from portcullis_amd.records import pack_seq2
+    genome, reads = make_reads(seed, glen=30000 + 997 * (seed % 7), n_reads=2500, paired=ori != "SE", opts=EXC_OPTS, L=(40, 260))
+    b = ReadBatch.from_reads(reads)
+    _, sx = pack_seq2(b.seq4, b.seq_off, b.l_qseq)
+    spliced = np.array(["N" in r["cigar"] for r in reads])
+    marked = np.unpackbits(sx.view(np.uint8), bitorder="little")[: b.n].astype(bool) & spliced
+    assert 0.05 < marked.sum() / spliced.sum() < 0.8 and sum(c.upper() not in "ACGT" for c in genome) >= 5  # both kinds of lanes side by side
+    status, orows = both(ffi, orc, genome, reads, ori)
+    assert status == "ok" and len(orows) > 10
+    with ffi.Context(0, ori) as ctx:
+        ctx.set_refs([len(genome)])
+        ctx.upload_contig(0, genome.encode())
+        ctx.submit_batch(0, b, seq2=False)
+        ctx.finish_contig(0)
+        assert_rows_equal(ctx.collect(), orows)
+
+
+def test_exception_bitmap_at_stretch_and_word_boundaries(ffi, orc):
+    """One letter outside ACGT moved base by base across a read's anchors, over the boundaries of the genome's 64-base stretches and
+    of the bitmap's 32-stretch words: under an anchor it is a mismatch (the lane falls back to the 4-bit codes), next to it nothing."""
+    rng = np.random.default_rng(77)
+    g0 = "".join(rng.choice(list("ACGT"), size=9000))
+    for pos in (2048 - 40, 4096 - 75, 64 * 31 - 10, 2048 * 2 + 3):
+        for at in list(range(pos - 2, pos + 3)) + list(range(pos + 38, pos + 43)) + list(range(pos + 138, pos + 143)) + [pos + 140 + 59, pos + 140 + 60]:
+            for ch in ("NRnc"[at % 4],):  # ('c': lower case only -- upper-cased it is no exception)
+                g = g0[:at] + ch + g0[at + 1:]
+                reads = [read_from_genome(g0, pos, "40M100N60M"), read_from_genome(g0, pos + 1, "39M100N61M"), read_from_genome(g0, pos - 3, "5S43M100N20M50N37M4S")]
+                status, _ = both(ffi, orc, g, reads)
+                assert status == "ok"

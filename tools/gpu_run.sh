@@ -11,10 +11,11 @@
 #   sqv:<variant>    instruction counts per kernel (the first two counter groups of pmc_sq.sh) of tools/variants/libpjb_<variant>.so
 #   e2eprof          (behind `bench`) the program on the bench's prepared BAM with PJB_PROFILE_HOST=1, three runs -> gpurun_out/<TAG>_e2e_host_profile_k.txt
 #   fuzz             the three fuzz campaigns (tests/fuzz_campaign.py, fuzz_groups.py, fuzz_extra.py)
+#   rankshare[:N,N]  tools/rank_share.py: every rank's share of configs[2] on this one GPU (PJB_BENCH_AS_RANK)  -> gpurun_out/<TAG>_rank_share.json
 #   cmd:<shell>      anything else
 # TAG (environment, default r05) names the outputs; COMMIT is recorded in the PMC summary.
 cd "$GRAFT_REPO_ROOT" || exit 1
-TAG=${TAG:-r05}
+TAG=${TAG:-r06}
 OUT=gpurun_out
 mkdir -p $OUT
 rc=0
@@ -37,6 +38,8 @@ for step in "$@"; do
            for k in 1 2 3; do ( time PJB_PROFILE_HOST=1 portcullis_amd/host/portcullis_amd junc -t $(nproc) --orientation FR -o /tmp/pjb_bench_e2e/prof/pc /tmp/pjb_bench_e2e/prep ) > $OUT/${TAG}_e2e_host_profile_$k.txt 2>&1; grep -E "real|Wall" $OUT/${TAG}_e2e_host_profile_$k.txt | head -3; done
            grep -E "host profile" $OUT/${TAG}_e2e_host_profile_2.txt | tail -40 ;;
     fuzz) ( timeout 1500 python tests/fuzz_campaign.py; timeout 900 python tests/fuzz_groups.py; timeout 900 python tests/fuzz_extra.py ) 2>&1 | tail -30 | tee $OUT/${TAG}_fuzz.txt ;;
+    rankshare) timeout 3000 python tools/rank_share.py $TAG 2>&1 | tail -30 ;;
+    rankshare:*) timeout 3000 python tools/rank_share.py $TAG "${step#rankshare:}" 2>&1 | tail -30 ;;
     cmd:*) bash -c "${step#cmd:}" ;;
     *) echo "unknown step $step"; rc=2 ;;
   esac
