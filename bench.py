@@ -39,12 +39,13 @@ sys.path.insert(0, ROOT)
 PEAK_HBM_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 
 
-def algorithmic_bytes(name, N, C, S, Cs, P, J, L, Pg=0, Rg=0, R=0, cand=0, Rv=0, sort_u32=True, G=0, sort_ids=None):
+def algorithmic_bytes(name, N, C, S, Cs, P, J, L, Pg=0, Rg=0, R=0, cand=0, Rv=0, sort_u32=True, G=0, sort_ids=None, two_bit=True):
     """Algorithmic HBM bytes of ONE launch of kernel `name` over one chain (each byte counted once per logical
     pass, caches ignored; DESIGN.md section 4 derives these).  N reads, C cigar ops, S spliced reads, Cs cigar ops
     of spliced reads, P pairs, J junctions, L read length, Pg pairs / Rg reads that take the generic walks, R
     position runs, cand candidate keys, Rv reads whose closed form k4b_generic only checks, sort_u32: the sort ran on
-    dense 32-bit ids (else on the 64-bit keys), G bases of the chain's targets."""
+    dense 32-bit ids (else on the 64-bit keys), G bases of the chain's targets, two_bit: the batches carry their bases in 2 bits as well
+    (pjb_batch.seq2, ABI 4) and k1_emit compares those -- a base of read and genome then costs 2 + 2 bits, not 4 + 4."""
     frags = P / 64.0 + J
     ops_s = Cs / max(S, 1)  # cigar ops of a spliced read
     # the sort's digit tables: one count per digit value and tile of 4096 pairs.  Dense ids: digits planned for twice the junctions
@@ -62,9 +63,10 @@ def algorithmic_bytes(name, N, C, S, Cs, P, J, L, Pg=0, Rg=0, R=0, cand=0, Rv=0,
         # 16-B record of what this pass holds of the read: operations index / count, position, bases offset, l_qseq)
         "k1_count": N * 17 + C * 4 + S * 24,
         # spliced reads only: the list's 24 B, mtid, mpos (4 each), flag (2), mapq, xs (1 each), the ops once; per pair 8 B key +
-        # 32 B record written; pairs finished in closed form: L/2 B of packed bases + L/2 B of genome codes; 8 B list entry per
-        # read on k4b_generic's lists; candidate key + anchors (16)
-        "k1_emit": S * 36 + Cs * 4 + P * 40 + (P - Pg) * L + Rg * 8 + cand * 8,
+        # 32 B record written; pairs finished in closed form: L/2 B of packed bases + L/2 B of genome codes -- L/4 + L/4 in 2 bits, plus
+        # the read's bit of seq_exc and the genome's exception bitmap (a bit per 64 bases) --; 8 B list entry per read on k4b_generic's
+        # lists; candidate key + anchors (16)
+        "k1_emit": S * 36 + Cs * 4 + P * 40 + (P - Pg) * L * (0.5 if two_bit else 1.0) + (S / 8.0 + G / 512.0 if two_bit else 0.0) + Rg * 8 + cand * 8,
         # the reads k1_emit leaves to a walk of their operations (those on k4b_generic's first list and the multi-intron reads beyond
         # two introns, about as many again): list entry (8), list record (16), five gathers (12), operations, bases + codes, the pairs
         "k1_generic": (Rg + Rv / 2.0) * (36 + 4 * ops_s + L) + (Pg + Rv) * 40,  # (about half of the checked reads come from here)
@@ -421,7 +423,11 @@ def main():
         mt = merged.view(ffi.ROW_DTYPE)
         assert len(mt) == sum(xchg.counts) and xchg.counts[0] == len(rows)
         assert mt[: len(rows)].tobytes() == rows.tobytes()
-        merged_rows, totals = pd.merge_rank_tables(merged, ffi.ROW_DTYPE, xchg.regions)
+        # the merge itself is the library's (pjb_merge_rows, the receive side of the C ABI: what a C++ caller runs behind its all-gather);
+        # the numpy restatement checks it
+        merged_rows, totals = ffi.merge_rows(xchg.host.numpy(), n_ranks_seen, xchg.slot)
+        chk_rows, chk_tot = pd.merge_rank_tables(merged, ffi.ROW_DTYPE, xchg.regions)
+        assert merged_rows.tobytes() == chk_rows.tobytes() and all(totals[k] == v for k, v in chk_tot.items())
         assert totals["spliced"] + totals["unspliced"] == N_total, (totals, N_total)
         assert totals["sum_len"] == N_total * L
     J_total = len(merged_rows) if rank == 0 else 0
@@ -460,6 +466,8 @@ def main():
             kt[dominant] = kt_timed[dominant]  # measured live over the timed region (beside whatever overlapped it)
         per = state.get("per_chain", {})
         kern = []
+        # the batches carry their bases in 2 bits as well (synth; PJB_FFI_SEQ2=0 submits them without: A/B runs of the 4-bit compare)
+        two_bit = os.environ.get("PJB_FFI_SEQ2", "1") != "0" and os.environ.get("PJB_NO_SEQ2", "0") == "0"
         # (what the library plans the sort's digits from: the most junctions per read a chain of this context has had -- pjb_api.hip: junc_per_read)
         junc_per_read = max([sum(int(regs[t]["n_junctions"]) for t in g) / max(sum(contigs[t]["n"] for t in g), 1) for g in chains] + [0.0])
         for name, (launches, ms) in kt.items():
@@ -478,7 +486,7 @@ def main():
                                       int(tm.get("generic_reads", 0)), int(tm.get("position_runs", 0)), int(tm.get("candidates", 0)),
                                       int(tm.get("checked_reads", 0)), int(tm.get("candidates", 0)) > 0,
                                       sum(int(c["genome"].numel()) for c in cs_),
-                                      sort_ids=max(1 << 16, int(2.0 * junc_per_read * sum(c["n"] for c in cs_) + 64.0)))
+                                      sort_ids=max(1 << 16, int(2.0 * junc_per_read * sum(c["n"] for c in cs_) + 64.0)), two_bit=two_bit)
                 if b is None:
                     known = False
                     break
@@ -502,6 +510,16 @@ def main():
                              "contigs differ in size) / average launch duration, HIP events on the kernel's stream inside the timed "
                              "region, where kernels of two contigs and of the side streams run beside it; *_alone: the same kernel "
                              "in the instrumented steps before the timed region, one kernel at a time (overlap off)")
+        if two_bit and dom["name"] == "k1_emit" and dom["alg_bytes"]:
+            # the same launches priced as rounds 1 - 5 priced them (bases at 4 + 4 bits): NOT this kernel's bytes any more -- kept so
+            # that the fraction can be read against the earlier rounds' lines
+            b4 = sum(algorithmic_bytes("k1_emit", sum(contigs[t]["n"] for t in g), sum(contigs[t]["C"] for t in g), sum(contigs[t]["S"] for t in g),
+                                       sum(contigs[t]["Cs"] for t in g), sum(contigs[t]["P"] for t in g), 0, L, int(per.get(tuple(g), {}).get("generic_pairs", 0)),
+                                       int(per.get(tuple(g), {}).get("generic_reads", 0)), 0, int(per.get(tuple(g), {}).get("candidates", 0)), two_bit=False)
+                     for g in chains) / max(dom["launches"] / args.steps, 1)
+            roofline["frac_at_4bit_prices"] = round(b4 / (dom["avg_ms"] * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4)
+            roofline["frac_at_4bit_prices_note"] = ("the same launches with every compared base priced at 4 + 4 bits as in rounds 1 - 5 (the kernel reads 2 + 2): "
+                                                    "for comparison across rounds only")
         if dom_serial_ms and dom["alg_bytes"]:
             roofline["avg_kernel_ms_alone"] = round(dom_serial_ms, 5)
             roofline["achieved_alone"] = round(dom["alg_bytes"] / (dom_serial_ms * 1e-3) / 1e9, 1)
@@ -592,7 +610,7 @@ def main():
                        # this workload can be at best -- step time ~ max shard, so speed-up <= N / max_over_mean -- for 1, 2, 4 and 8 ranks
                        "lpt_balance": lpt_balance([c.n_reads for c in cfgs], world, pd),
                        "lpt_balance_by_ranks": {str(k): lpt_balance([c.n_reads for c in cfgs], k, pd)["max_over_mean_reads"] for k in (1, 2, 4, 8)},
-                       "sharding": "by contig", "input": "device-resident SoA records (pjb_submit_batch_device)",
+                       "sharding": "by contig", "input": "device-resident SoA records (pjb_submit_batch_device)" + (", bases in 4 and in 2 bits (pjb_batch.seq2 / .seq_exc, ABI 4)" if two_bit else ", bases in 4 bits only"),
                        "chains": [len(g) for g in chains],
                        "queue": (f"{len(chains)} kernel chains per step, each over a group of consecutive targets (pjb_finish_group_begin / _end), "
                                  if args.group_bases > 0 else "one kernel chain per target (pjb_finish_contig_begin / _end), ")

@@ -317,6 +317,17 @@ int pjb_collect_device(pjb_ctx *ctx, const pjb_junction_row **device_rows, int64
  * synchronisation on the caller's side.  Rows that do not fit fail with PJB_ERR_ARG. */
 #define PJB_MIRROR_HEADER_BYTES 64
 int pjb_set_row_mirror(pjb_ctx *ctx, void *device_buffer, int64_t cap_bytes);
+/* The RECEIVE side of that merge, for a caller that runs one process per GPU: `gathered` (HOST memory) holds n_ranks send slots as
+ * pjb_set_row_mirror leaves them -- slot r at gathered + r * slot_stride_bytes: the 64-byte header, then its rows -- i.e. what an
+ * all-gather of the ranks' slots (ncclAllGather over xGMI, MPI_Allgather, ...) followed by one copy to the host delivers.  Writes ONE
+ * table to rows_out: every rank's rows, stably ordered by refid -- a target's rows are contiguous in its rank's slot and already
+ * (start, end)-sorted, so this is JunctionSystem::sort's order (lib/src/junction_system.cc:322-330) over the appended systems
+ * (src/junction_builder.cc:258-269) -- and folds the ranks' read-length counters into *totals (sums, min, max: src/junction_builder.cc:
+ * 270-278; n_reads = spliced + unspliced, n_junctions = rows written, n_pairs = 0: the header does not carry it).  Host arithmetic
+ * only: no context, no device, no collective library inside -- INTEGRATION.md section "multi-GPU" shows the lines around it.
+ * PJB_ERR_ARG: a header with a negative count or more rows than the slot holds, or cap_rows too small (*n_rows then says how many). */
+int pjb_merge_rows(const void *gathered, int32_t n_ranks, int64_t slot_stride_bytes, pjb_junction_row *rows_out, int64_t cap_rows,
+                   int64_t *n_rows, pjb_region_result *totals);
 int pjb_clear_rows(pjb_ctx *ctx);
 
 /* The --extra columns of one junction (lib/include/portcullis/junction.hpp:240-243). */

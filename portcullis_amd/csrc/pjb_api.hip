@@ -2488,6 +2488,54 @@ int pjb_set_row_mirror(pjb_ctx *c, void *device_buffer, int64_t cap_bytes) {
     return PJB_OK;
 }
 
+int pjb_merge_rows(const void *gathered, int32_t n_ranks, int64_t slot_stride_bytes, pjb_junction_row *rows_out, int64_t cap_rows, int64_t *n_rows,
+                   pjb_region_result *totals) {
+    if (n_rows) *n_rows = 0;
+    if (!gathered || n_ranks < 1 || slot_stride_bytes < PJB_MIRROR_HEADER_BYTES || !n_rows || !totals || cap_rows < 0 || (cap_rows > 0 && !rows_out))
+        return PJB_ERR_ARG;
+    struct Run { // rows of one target in one rank's slot
+        int32_t refid;
+        const pjb_junction_row *first;
+        int64_t n;
+    };
+    std::vector<Run> runs;
+    pjb_region_result T;
+    memset(&T, 0, sizeof T);
+    T.min_len = INT32_MAX;
+    int64_t total = 0;
+    for (int32_t r = 0; r < n_ranks; r++) {
+        const uint8_t *slot = (const uint8_t *)gathered + (size_t)r * (size_t)slot_stride_bytes;
+        int64_t h[6];
+        memcpy(h, slot, sizeof h); // n_rows, spliced, unspliced, sum_len, min_len, max_len
+        if (h[0] < 0 || h[0] > (slot_stride_bytes - PJB_MIRROR_HEADER_BYTES) / (int64_t)sizeof(pjb_junction_row)) return PJB_ERR_ARG;
+        T.spliced += (uint64_t)h[1];
+        T.unspliced += (uint64_t)h[2];
+        T.sum_len += (uint64_t)h[3];
+        T.min_len = std::min<int32_t>(T.min_len, (int32_t)std::min<int64_t>(h[4], INT32_MAX));
+        T.max_len = std::max<int32_t>(T.max_len, (int32_t)h[5]);
+        const pjb_junction_row *rows = (const pjb_junction_row *)(slot + PJB_MIRROR_HEADER_BYTES);
+        for (int64_t i = 0; i < h[0];) {
+            int64_t j = i + 1;
+            while (j < h[0] && rows[j].refid == rows[i].refid) j++;
+            runs.push_back(Run{rows[i].refid, rows + i, j - i});
+            i = j;
+        }
+        total += h[0];
+    }
+    T.n_reads = (int64_t)(T.spliced + T.unspliced);
+    T.n_junctions = total;
+    *totals = T;
+    *n_rows = total;
+    if (total > cap_rows) return PJB_ERR_ARG;
+    std::stable_sort(runs.begin(), runs.end(), [](const Run &a, const Run &b) { return a.refid < b.refid; });
+    pjb_junction_row *out = rows_out;
+    for (const Run &u : runs) {
+        memcpy(out, u.first, (size_t)u.n * sizeof(pjb_junction_row));
+        out += u.n;
+    }
+    return PJB_OK;
+}
+
 int pjb_clear_rows(pjb_ctx *c) {
     if (!c) return PJB_ERR_ARG;
     if (c->n_fl) return fail(c, PJB_ERR_STATE, "clear_rows: target %d is still queued", c->fl[0].tid);

@@ -1982,6 +1982,9 @@ struct EmitCtx {
 struct __attribute__((packed, aligned(4))) Words2 {
     u32 x, y;
 };
+#ifndef C2_SKIP_HI
+#define C2_SKIP_HI 1 // a round whose block has 48 bases or fewer left asks for ONE 16-byte gather per stream (the addresser takes a gather a LANE a cycle: lanes that do not ask cost nothing)
+#endif
 constexpr int C2_NW = 8;                      // words per stream and round: two 16-byte gathers, 7 words = 112 bases compared
 constexpr int32_t C2_ROUND = 16 * (C2_NW - 1);
 constexpr int32_t C2_MAX_BLOCK = 1900;        // a longer block of bases (31 stretches of the bitmap: one 8-byte load) takes the 4-bit rounds
@@ -2217,7 +2220,6 @@ __global__ __launch_bounds__(K1E_T) __attribute__((amdgpu_waves_per_eu(K1E_WAVES
         // (junction_system.cc:140-210 for one or two N operations); any other read goes on k1_generic's list: a few lanes of every
         // wavefront walking their reads kept the whole block waiting (84 of 307 us a launch for one read in twenty).
         bool generic = false, simple = false, two = false;
-        u64 g3_entry = 0;
         u32 dS = 0, a = 0, nl = 0, b2 = 0, nl2 = 0, b3 = 0, meta = 0, off = 0, g = 0;
         if (on) {
             const u32 n = O.n;
@@ -2254,10 +2256,7 @@ __global__ __launch_bounds__(K1E_T) __attribute__((amdgpu_waves_per_eu(K1E_WAVES
                 }
             }
             two = two && simple;
-            if (!simple) {
-                generic = true;
-                g3_entry = (u64)R.slot | ((u64)off << 32); // (the read's place in the tiles' lists, its first pair)
-            }
+            generic = !simple;
         }
         const u32 shard = (chunk >> (8 - K1E_SHIFT)) % GEN_SHARDS;
         const u32 base2 = ctx.list_reserve(2, two, 2u, shard), base3 = ctx.list_reserve(3, generic, 0u, shard);
@@ -2298,8 +2297,7 @@ __global__ __launch_bounds__(K1E_T) __attribute__((amdgpu_waves_per_eu(K1E_WAVES
             const int32_t aend_all = vpos + (int32_t)(a + nl + b2 + nl2 + b3) - 1;
             // ---- the pairs' geometry (junction_system.cc:140-210 for one or two N operations)
             const u32 npairs = two ? 2u : 1u;
-            u64 key_[2];
-            int32_t lst_[2], rend_[2], iend_[2];
+            int32_t ist_[2], lst_[2], rend_[2], iend_[2];
             u32 ud_[2];
             {
                 int32_t lst = vpos; // the left block of the pair: where it starts, its length; intron; right block
@@ -2314,7 +2312,7 @@ __global__ __launch_bounds__(K1E_T) __attribute__((amdgpu_waves_per_eu(K1E_WAVES
                     int32_t rEndExc = rStartU + (int32_t)lb;
                     if (rEndExc - 1 >= vlen) rEndExc = vlen; // junction_system.cc:172-174
                     if (pr < npairs && rEndExc - 1 < iend) set_error(err, g, PJB_ERR_MIN_ANCHOR); // intron.cc:76
-                    key_[pr] = make_key(kf, istart, iend);
+                    ist_[pr] = istart;
                     lst_[pr] = lst;
                     rend_[pr] = rEndExc - 1;
                     iend_[pr] = iend;
@@ -2363,8 +2361,20 @@ __global__ __launch_bounds__(K1E_T) __attribute__((amdgpu_waves_per_eu(K1E_WAVES
                         const int32_t qi = k == 0 ? bq[0] : k == 1 ? bq[1] : bq[2], gi = k == 0 ? bg[0] : k == 1 ? bg[1] : bg[2];
                         const u32 qbit = qodd + 2u * (u32)(qi + t), gbit = 2u * (u32)(gi + t);
                         u32 qw[C2_NW], gw[C2_NW];
-                        load_words<C2_NW>(qw, seq2w, (int32_t)(qbit >> 5), q2_last);
-                        load_words<C2_NW>(gw, (const u32 *)gcodes2, (int32_t)(gbit >> 5), g2_last);
+                        const int32_t qf = (int32_t)(qbit >> 5), gf = (int32_t)(gbit >> 5);
+                        if (C2_SKIP_HI && qf + C2_NW - 1 <= q2_last) { // (the genome's words are always there: K0_CODES2_PAD)
+                            const Words4 qa = gload(reinterpret_cast<const Words4 *>(seq2w + qf)), ga = gload_as<Words4>(gcodes2 + gf);
+                            Words4 qb = {0, 0, 0, 0}, gb = {0, 0, 0, 0};
+                            if (l - t > 48) { // (words 4 .. 7 feed the bases from the 49th on)
+                                qb = gload(reinterpret_cast<const Words4 *>(seq2w + qf + 4));
+                                gb = gload_as<Words4>(gcodes2 + gf + 4);
+                            }
+                            qw[0] = qa.x, qw[1] = qa.y, qw[2] = qa.z, qw[3] = qa.w, qw[4] = qb.x, qw[5] = qb.y, qw[6] = qb.z, qw[7] = qb.w;
+                            gw[0] = ga.x, gw[1] = ga.y, gw[2] = ga.z, gw[3] = ga.w, gw[4] = gb.x, gw[5] = gb.y, gw[6] = gb.z, gw[7] = gb.w;
+                        } else {
+                            load_words<C2_NW>(qw, seq2w, qf, q2_last);
+                            load_words<C2_NW>(gw, (const u32 *)gcodes2, gf, g2_last);
+                        }
                         chunk2_cmp_bits<C2_NW>(qw, gw, qbit & 31u, gbit & 31u, l, t, mism, fbit, lbit1);
                         t += C2_ROUND;
 #ifdef K1E_HIST
@@ -2437,16 +2447,17 @@ __global__ __launch_bounds__(K1E_T) __attribute__((amdgpu_waves_per_eu(K1E_WAVES
                 Q.meta = meta | META_SIMPLE | (two ? META_MULTI : 0u);
                 Q.updown = ud_[pr];
                 Q.aux = cmp_blocks_res(res[pr], res[pr + 1]);
-                P.key[off + pr] = key_[pr];
+                const u64 key = make_key(kf, ist_[pr], iend_[pr]);
+                P.key[off + pr] = key;
                 if (P.g) P.g[off + pr] = g;
                 rec_store(P.rec + off + pr, Q);
-                if (want_cand) cand_insert(key_[pr], Q.lstart, Q.rend);
+                if (want_cand) cand_insert(key, Q.lstart, Q.rend);
             }
         }
         const u64 p1_entry = (u64)(E.pack_nn ? g | (2u << 28) : g) | ((u64)off << 32);
         K1E_MARK(7); // compares, records, candidates
         ctx.list_write(2, two, base2, p1_entry, shard);
-        ctx.list_write(3, generic, base3, g3_entry, shard);
+        ctx.list_write(3, generic, base3, (u64)R.slot | ((u64)off << 32), shard); // (the read's place in the tiles' lists, its first pair)
         K1E_MARK(8); // list entries
         // (the candidate set is flushed when the block leaves: a set that fills up before that sends its keys straight to the list --
         // cand_insert -- and no barrier ties the block's wavefronts together trip by trip)

@@ -25,7 +25,7 @@ EXPORTS = [
     "pjb_finish_contig_end", "pjb_finish_ready", "pjb_finish_group_begin", "pjb_finish_group_end", "pjb_collect",
     "pjb_clear_rows", "pjb_get_timing", "pjb_device_count", "pjb_get_kernel_timing", "pjb_reset_kernel_timing",
     "pjb_select_timed_kernels", "pjb_host_alloc", "pjb_host_free", "pjb_host_register", "pjb_host_unregister", "pjb_inflate_bgzf", "pjb_deflate_bgzf", "pjb_submit_bam", "pjb_collect_device", "pjb_set_row_mirror",
-    "pjb_extra_finish", "pjb_set_option", "pjb_bam_begin", "pjb_bam_piece", "pjb_bam_pieces_done", "pjb_bam_end", "pjb_bam_inflate_done", "pjb_filter_set_junctions", "pjb_filter_batch", "pjb_filt_features",
+    "pjb_extra_finish", "pjb_set_option", "pjb_merge_rows", "pjb_bam_begin", "pjb_bam_piece", "pjb_bam_pieces_done", "pjb_bam_end", "pjb_bam_inflate_done", "pjb_filter_set_junctions", "pjb_filter_batch", "pjb_filt_features",
 ]
 N_FEATURES = 34
 KMER_TABLE = 3125 * 5
@@ -149,6 +149,7 @@ def load():
         L.pjb_device_count.restype = C.c_int
         L.pjb_device_count.argtypes = []
         L.pjb_clear_rows.argtypes = [C.c_void_p]
+        L.pjb_merge_rows.argtypes = [C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_int64, C.POINTER(C.c_int64), C.POINTER(PjbRegionResult)]
         L.pjb_get_timing.argtypes = [C.c_void_p, C.POINTER(PjbTiming)]
         L.pjb_get_kernel_timing.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]
         L.pjb_reset_kernel_timing.argtypes = [C.c_void_p]
@@ -159,6 +160,22 @@ def load():
 
 def device_count():
     return load().pjb_device_count()
+
+
+def merge_rows(gathered, n_ranks, slot_stride_bytes):
+    """pjb_merge_rows: the gathered send slots (uint8 numpy, n_ranks * slot_stride_bytes) -> (rows in refid order, folded counters).
+    Host arithmetic of the library; needs no context and no device."""
+    L = load()
+    g = np.ascontiguousarray(gathered, dtype=np.uint8)
+    assert g.size >= n_ranks * slot_stride_bytes
+    cap = max((int(slot_stride_bytes) - 64) // ROW_DTYPE.itemsize, 0) * int(n_ranks)
+    out = np.zeros(max(cap, 1), dtype=ROW_DTYPE)
+    n = C.c_int64()
+    tot = PjbRegionResult()
+    rc = L.pjb_merge_rows(g.ctypes.data, n_ranks, slot_stride_bytes, out.ctypes.data, cap, C.byref(n), C.byref(tot))
+    if rc:
+        raise PjbError(rc, "pjb_merge_rows: malformed slot header or too many rows")
+    return out[: n.value].copy(), {k: getattr(tot, k) for k, _ in PjbRegionResult._fields_}
 
 
 _FIELDS = [("pos", np.int32), ("flag", np.uint16), ("mapq", np.uint8), ("xs", np.uint8), ("l_qseq", np.int32),

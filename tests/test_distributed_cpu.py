@@ -165,6 +165,11 @@ def _worker_sharded(rank, world, port, q):
     out = None
     if rank == 0:
         rows, totals = pd.merge_rank_tables(merged, ROW_DTYPE, x.regions)
+        # the same merge through the C ABI's receive side (pjb_merge_rows: what a C++ caller runs behind its ncclAllGather)
+        from portcullis_amd import ffi
+        nrows, ntot = ffi.merge_rows(x.host.numpy(), world, x.slot)
+        assert nrows.tobytes() == rows.tobytes() and {k: ntot[k] for k in totals} == totals
+        assert ntot["n_junctions"] == len(rows) and ntot["n_reads"] == totals["spliced"] + totals["unspliced"]
         out = (rows.tobytes(), totals, x.counts)
     q.put((rank, mine, out))
     dist.destroy_process_group()
@@ -194,3 +199,35 @@ def test_sharded_contig_set_merges_to_single_table_world2():
                           sum_len=sum(r["sum_len"] for r in regs), min_len=min(r["min_len"] for r in regs),
                           max_len=max(r["max_len"] for r in regs))
     assert out1 is None
+
+
+def test_merge_rows_edge_cases():
+    """pjb_merge_rows alone (host arithmetic of the library, no device): empty ranks, a target's rows staying in their order, interleaved
+    targets across ranks, malformed headers."""
+    from portcullis_amd import ffi
+
+    stride = 64 + 6 * ROW_DTYPE.itemsize
+
+    def slot(rows, reg):
+        b = np.zeros(stride, dtype=np.uint8)
+        b[:48] = np.array([len(rows), reg[0], reg[1], reg[2], reg[3], reg[4]], dtype=np.int64).view(np.uint8)
+        if len(rows):
+            b[64:64 + rows.nbytes] = rows.view(np.uint8)
+        return b
+
+    def rows_of(tids):
+        return np.concatenate([_contig_rows(t)[:2] for t in tids]) if tids else np.zeros(0, dtype=ROW_DTYPE)
+
+    a, b, c = rows_of([5, 2, 9]), rows_of([]), rows_of([7, 0, 3])  # ranks finish their targets in any order
+    g = np.concatenate([slot(a, (10, 1, 1500, 149, 151)), slot(b, (0, 0, 0, 2**31 - 1, 0)), slot(c, (4, 2, 900, 150, 153))])
+    rows, tot = ffi.merge_rows(g, 3, stride)
+    want = np.concatenate([_contig_rows(t)[:2] for t in (0, 2, 3, 5, 7, 9)])
+    assert rows.tobytes() == want.tobytes()
+    assert (tot["spliced"], tot["unspliced"], tot["sum_len"], tot["min_len"], tot["max_len"], tot["n_reads"], tot["n_junctions"]) == (14, 3, 2400, 149, 153, 17, len(want))
+    bad = g.copy()
+    bad[:8] = np.array([7], dtype=np.int64).view(np.uint8)  # more rows than a slot holds
+    with pytest.raises(ffi.PjbError):
+        ffi.merge_rows(bad, 3, stride)
+    bad[:8] = np.array([-1], dtype=np.int64).view(np.uint8)
+    with pytest.raises(ffi.PjbError):
+        ffi.merge_rows(bad, 3, stride)

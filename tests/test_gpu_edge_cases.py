@@ -187,6 +187,6 @@ def test_exception_bitmap_at_stretch_and_word_boundaries(ffi, orc):
         for at in list(range(pos - 2, pos + 3)) + list(range(pos + 38, pos + 43)) + list(range(pos + 138, pos + 143)) + [pos + 140 + 59, pos + 140 + 60]:
             for ch in ("NRnc"[at % 4],):  # ('c': lower case only -- upper-cased it is no exception)
                 g = g0[:at] + ch + g0[at + 1:]
-                reads = [read_from_genome(g0, pos, "40M100N60M"), read_from_genome(g0, pos + 1, "39M100N61M"), read_from_genome(g0, pos - 3, "5S43M100N20M50N37M4S")]
+                reads = [read_from_genome(g0, pos - 3, "5S43M100N20M50N37M4S"), read_from_genome(g0, pos, "40M100N60M"), read_from_genome(g0, pos + 1, "39M100N61M")]
                 status, _ = both(ffi, orc, g, reads)
                 assert status == "ok"
