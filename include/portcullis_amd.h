@@ -203,6 +203,9 @@ typedef struct pjb_timing {
     int64_t checked_reads; /* reads of the shape [S] M (N M)+ [S] with two or more introns: finished in closed form by k1_emit, their junctions'
                               anchor windows checked by k4b_generic (not counted in generic_reads unless the check failed... they never are: a
                               failed check walks the read without moving it to the other list) */
+    /* ---- ABI 4 (not written for a context created with abi_version 3) ---- */
+    int64_t repeats;        /* times the chain collected last was queued AGAIN because a limit it had been queued with turned out too small */
+    int64_t repeat_reasons; /* which limits, OR-ed over those repeats: 1 pairs, 2 key format, 4 junctions (or the sort's digits), 8 dense ids, 16 read lists */
 } pjb_timing;
 
 /* ---- entry points ------------------------------------------------------ */

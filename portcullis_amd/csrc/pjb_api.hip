@@ -2219,6 +2219,7 @@ static int collect_flight(pjb_ctx *c, pjb_region_result *res, bool *redo_single)
     int rc;
     ContigStats cs;
     u64 herr = ~0ull;
+    int64_t repeats = 0, repeat_reasons = 0;
     for (;; f.attempt++) {
         if (!f.queued && (rc = queue_chain(c, f))) return rc;
         wait_flight(c, f);
@@ -2242,6 +2243,8 @@ static int collect_flight(pjb_ctx *c, pjb_region_result *res, bool *redo_single)
             return fail(c, PJB_ERR_STATE, "finish: limits of target %d did not settle (overflow bits %u)", tid, cs.overflow);
         // a limit was too small: the control block says by how much; everything is queued again (and so is the chain
         // queued behind this one: its rows went where this one's belong)
+        repeats++;
+        repeat_reasons |= (int64_t)cs.overflow;
         unqueue_followers(c);
         if (f.forked) (void)hipStreamSynchronize(c->sl[f.slot].side);
         f.queued = f.forked = false;
@@ -2322,6 +2325,8 @@ static int collect_flight(pjb_ctx *c, pjb_region_result *res, bool *redo_single)
     c->junc_seen = std::max(c->junc_seen, group ? J / (u32)n_members : J);
     if (f.n_reads > 0) c->junc_per_read = std::max(c->junc_per_read, (double)J / (double)f.n_reads);
     c->timing.sort_passes = f.n_pass;
+    c->timing.repeats = repeats;
+    c->timing.repeat_reasons = repeat_reasons;
     c->timing.generic_pairs = 0;
     c->timing.generic_reads = 0;
     c->timing.checked_reads = *(const u32 *)(S.pub + PUB_CHECKED_AT);
@@ -2787,7 +2792,8 @@ int pjb_set_option(pjb_ctx *c, const char *name, int64_t value) {
 
 int pjb_get_timing(const pjb_ctx *c, pjb_timing *out) {
     if (!c || !out) return PJB_ERR_ARG;
-    *out = c->timing;
+    if (c->cfg.abi_version >= 4) *out = c->timing;
+    else memcpy(out, &c->timing, offsetof(pjb_timing, repeats)); // (ABI 3's pjb_timing ended at checked_reads)
     return PJB_OK;
 }
 

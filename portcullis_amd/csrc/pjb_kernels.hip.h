@@ -2874,7 +2874,12 @@ __global__ __launch_bounds__(256) void kd_assign(const u64 *key, const u32 *np, 
     // time to be counted.
     __shared__ u32 s_h[4096]; // (RS_MAX_BINS)
     const u32 n = *np;
-    if (n == 0) return;
+    if (n == 0) { // (a chain without pairs, or closed by an overflow: the tile's counts are still this kernel's to write -- zeros --, the
+                  // panel kernels behind it read them)
+        if (hist_bits > 0)
+            for (u32 d = threadIdx.x; d < (1u << hist_bits); d += 256) hist[(size_t)blockIdx.x * (1u << hist_bits) + d] = 0;
+        return;
+    }
     {
         const u64 J = *total;
         acc_rest_state(acc, J < (u64)junc_limit ? J : (u64)junc_limit);

@@ -61,7 +61,7 @@ class PjbRegionResult(C.Structure):
 
 class PjbTiming(C.Structure):
     _fields_ = [("total_ms", C.c_float), ("stage_ms", C.c_float * N_STAGES), ("sort_passes", C.c_int64),
-                ("generic_pairs", C.c_int64), ("generic_reads", C.c_int64), ("position_runs", C.c_int64), ("candidates", C.c_int64), ("checked_reads", C.c_int64)]
+                ("generic_pairs", C.c_int64), ("generic_reads", C.c_int64), ("position_runs", C.c_int64), ("candidates", C.c_int64), ("checked_reads", C.c_int64), ("repeats", C.c_int64), ("repeat_reasons", C.c_int64)]
 
 
 class PjbKernelTime(C.Structure):
@@ -478,7 +478,7 @@ class Context:
         self._check(self._L.pjb_get_timing(self._h, C.byref(t)))
         return dict(total_ms=t.total_ms, stage_ms={STAGE_NAMES[i]: t.stage_ms[i] for i in range(N_STAGES)},
                     sort_passes=t.sort_passes, generic_pairs=t.generic_pairs, generic_reads=t.generic_reads, checked_reads=t.checked_reads,
-                    position_runs=t.position_runs, candidates=t.candidates)
+                    position_runs=t.position_runs, candidates=t.candidates, repeats=t.repeats, repeat_reasons=t.repeat_reasons)
 
 
 def _kernel_timing(self):

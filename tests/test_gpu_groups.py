@@ -309,7 +309,11 @@ def test_read_list_room_overflow_is_repeated(ffi, orc, dense):
         ctx.set_option("dense_ids", dense)
         ctx.set_option("list_cap", 8)
         rows_s, regs_s = _singles(ctx, contigs)
+        t = ctx.timing()
+        assert t["repeats"] >= 1 and t["repeat_reasons"] & 16, t  # (the last single chain: queued again for the read lists' room)
         rows_g, regs_g = _grouped(ctx, contigs, [[0, 1, 2]])
+        t = ctx.timing()
+        assert t["repeats"] >= 1 and t["repeat_reasons"] & 16, t
     want = np.concatenate([c[2] for c in contigs])
     assert_rows_equal(rows_s, want)
     assert rows_g.tobytes() == rows_s.tobytes()
@@ -319,22 +323,44 @@ def test_read_list_room_overflow_is_repeated(ffi, orc, dense):
 
 
 def test_sort_digits_planned_too_small_are_repeated(ffi, orc):
-    """The sort's digits are planned from the junctions the context's chains have had (twice that, at least "sort_floor"), not from
-    the buffers' limit; a chain with more junctions than that closes and is repeated with digits for the limit.  A floor of 2 makes
-    it happen: a small target first, then larger ones -- singles, and a group -- against the oracle."""
-    contigs = _contigs(orc, [611], n_reads=60) + _contigs(orc, [612, 613], n_reads=3000)
-    # (the oracle rows carry the target index they were made with: rebuild them with this test's indices)
+    """The sort's digits are planned from the junctions per read the context's chains have had (twice that, + 64, at least
+    "sort_floor"), not from the buffers' limit; a chain with more junctions than that closes (OVF_JUNC from kd_table) and is repeated
+    with digits for the limit.  A first target with thousands of reads on a handful of junctions makes the plan small, the targets
+    behind it hold ~90 junctions in under a thousand reads: their chains MUST repeat -- pjb_timing.repeats says so -- singly and as a
+    group, and still give the oracle's rows (a sort with too few digit bits would misorder them)."""
+    from fuzzgen import make_reads, to_batch
     fixed = []
-    for tid, (g, b, _, _) in enumerate(contigs):
+    for tid, (seed, n_reads, n_tx) in enumerate([(611, 4000, 1), (612, 800, 40), (613, 900, 40)]):
+        g, reads = make_reads(seed, glen=40000, n_reads=n_reads, paired=True, n_tx=n_tx)
+        b = to_batch(reads)
         orows, oreg = orc.find_juncs(tid, len(g), g, b, "FR")
         fixed.append((g, b, orows, oreg))
+    assert len(fixed[0][2]) < 10 and len(fixed[1][2]) > 80 and len(fixed[2][2]) > 80
     want = np.concatenate([c[2] for c in fixed])
-    with ffi.Context(0, "FR") as ctx:
-        ctx.set_option("sort_floor", 2)
-        rows_s, regs_s = _singles(ctx, fixed)
-        assert_rows_equal(rows_s, want)
-        rows_g, regs_g = _grouped(ctx, fixed, [[0], [1, 2]])
-        assert rows_g.tobytes() == rows_s.tobytes()
-        for tid, c in enumerate(fixed):
-            region_equal(regs_s[tid], c[3])
-            region_equal(regs_g[tid], c[3])
+
+    def run(groups):
+        with ffi.Context(0, "FR") as ctx:
+            ctx.set_option("sort_floor", 2)
+            _setup(ctx, fixed)
+            regs, repeats = {}, []
+            for g in groups:
+                for tid in g:
+                    ctx.submit_batch(tid, fixed[tid][1])
+                if len(g) == 1:
+                    regs[g[0]] = ctx.finish_contig(g[0])
+                else:
+                    ctx.finish_group_begin(g)
+                    regs.update(ctx.finish_group_end(g))
+                t = ctx.timing()
+                repeats.append((t["repeats"], t["repeat_reasons"]))
+            return ctx.collect(), regs, repeats
+
+    rows_s, regs_s, rep_s = run([[0], [1], [2]])
+    assert rep_s[0] == (0, 0) and rep_s[1][0] >= 1 and rep_s[1][1] & 4, rep_s  # the second chain was queued again for its junctions
+    assert_rows_equal(rows_s, want)
+    rows_g, regs_g, rep_g = run([[0], [1, 2]])
+    assert rep_g[1][0] >= 1 and rep_g[1][1] & 4, rep_g
+    assert rows_g.tobytes() == rows_s.tobytes()
+    for tid, c in enumerate(fixed):
+        region_equal(regs_s[tid], c[3])
+        region_equal(regs_g[tid], c[3])
