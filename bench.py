@@ -36,6 +36,10 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# (torch's caching allocator keeps blocks above 256 MB whole: the generator's multi-GB temporaries then go back to the driver with
+# empty_cache() instead of being pinned by small tensors carved out of them -- the library allocates with hipMalloc, not through torch)
+for _v in ("PYTORCH_HIP_ALLOC_CONF", "PYTORCH_CUDA_ALLOC_CONF"):
+    os.environ.setdefault(_v, "max_split_size_mb:256")
 PEAK_HBM_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 
 
@@ -257,12 +261,7 @@ def main():
 
     # the chains of a step: groups of consecutive targets (one kernel chain each), or every target alone
     if args.group_bases > 0:
-        gb = args.group_bases
-        share_bases = sum(lens[t] for t in mine)
-        if len(mine) > 1 and 600_000_000 < share_bases <= gb:
-            # a share that would be ONE chain (3 or 4 ranks) goes as two: the first one's tail runs beside the second one's K1 stage
-            # (one GPU with rank 0's share of 3 / 4 ranks: 3.10 against 3.26 ms, 2.52 against 2.58; tools/debug/sweep_rank_share.sh)
-            gb = int(share_bases * 0.55)
+        gb = args.group_bases  # (a share that would be ONE chain of more than 0.6 Gb -- 3 or 4 ranks -- goes as two: the library's rule, pjb_plan_groups)
         chains = ffi.plan_groups(lens, sorted(mine), gb)
     else:
         chains = [[t] for t in mine]

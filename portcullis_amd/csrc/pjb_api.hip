@@ -2493,6 +2493,33 @@ int pjb_set_row_mirror(pjb_ctx *c, void *device_buffer, int64_t cap_bytes) {
     return PJB_OK;
 }
 
+int pjb_plan_groups(const int32_t *ref_len, const int32_t *tids, int32_t n_tids, int64_t max_bases, int32_t *group_of) {
+    if (n_tids < 0 || (n_tids > 0 && (!ref_len || !tids || !group_of))) return PJB_ERR_ARG;
+    if (max_bases <= 0) max_bases = (int64_t)1 << 30;
+    auto span = [&](int32_t k) { return (((int64_t)std::max(ref_len[tids[k]], 1) + GROUP_GAP) + 63) & ~(int64_t)63; };
+    auto plan = [&](int64_t cap) {
+        int32_t g = 0, members = 0;
+        int64_t tot = 0;
+        for (int32_t k = 0; k < n_tids; k++) {
+            const int64_t s = span(k);
+            if (members && (tot + s > cap || members >= GROUP_MAX)) g++, members = 0, tot = 0;
+            group_of[k] = g;
+            members++;
+            tot += s;
+        }
+        return n_tids ? g + 1 : 0;
+    };
+    for (int32_t k = 0; k < n_tids; k++)
+        if (tids[k] < 0) return PJB_ERR_ARG;
+    int32_t n = plan(max_bases);
+    if (n == 1 && n_tids > 1) { // ONE chain of more than 0.6 Gb: two, so that the first one's tail has the second one's K1 stage beside it
+        int64_t total = 0;
+        for (int32_t k = 0; k < n_tids; k++) total += span(k);
+        if (total > 600000000) n = plan((int64_t)((double)total * 0.55));
+    }
+    return n;
+}
+
 int pjb_merge_rows(const void *gathered, int32_t n_ranks, int64_t slot_stride_bytes, pjb_junction_row *rows_out, int64_t cap_rows, int64_t *n_rows,
                    pjb_region_result *totals) {
     if (n_rows) *n_rows = 0;

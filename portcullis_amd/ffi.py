@@ -25,7 +25,7 @@ EXPORTS = [
     "pjb_finish_contig_end", "pjb_finish_ready", "pjb_finish_group_begin", "pjb_finish_group_end", "pjb_collect",
     "pjb_clear_rows", "pjb_get_timing", "pjb_device_count", "pjb_get_kernel_timing", "pjb_reset_kernel_timing",
     "pjb_select_timed_kernels", "pjb_host_alloc", "pjb_host_free", "pjb_host_register", "pjb_host_unregister", "pjb_inflate_bgzf", "pjb_deflate_bgzf", "pjb_submit_bam", "pjb_collect_device", "pjb_set_row_mirror",
-    "pjb_extra_finish", "pjb_set_option", "pjb_merge_rows", "pjb_bam_begin", "pjb_bam_piece", "pjb_bam_pieces_done", "pjb_bam_end", "pjb_bam_inflate_done", "pjb_filter_set_junctions", "pjb_filter_batch", "pjb_filt_features",
+    "pjb_extra_finish", "pjb_set_option", "pjb_merge_rows", "pjb_plan_groups", "pjb_bam_begin", "pjb_bam_piece", "pjb_bam_pieces_done", "pjb_bam_end", "pjb_bam_inflate_done", "pjb_filter_set_junctions", "pjb_filter_batch", "pjb_filt_features",
 ]
 N_FEATURES = 34
 KMER_TABLE = 3125 * 5
@@ -149,6 +149,7 @@ def load():
         L.pjb_device_count.restype = C.c_int
         L.pjb_device_count.argtypes = []
         L.pjb_clear_rows.argtypes = [C.c_void_p]
+        L.pjb_plan_groups.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_void_p]
         L.pjb_merge_rows.argtypes = [C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_int64, C.POINTER(C.c_int64), C.POINTER(PjbRegionResult)]
         L.pjb_get_timing.argtypes = [C.c_void_p, C.POINTER(PjbTiming)]
         L.pjb_get_kernel_timing.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]
@@ -517,17 +518,18 @@ GROUP_GAP = 4096
 
 
 def plan_groups(ref_lens, tids, max_bases=1 << 30):
-    """Consecutive runs of `tids` whose sequences (plus the gap pjb_finish_group_begin leaves between members) stay below
-    `max_bases` and PJB_GROUP_MAX members: the groups a caller hands to finish_group_begin.  GRCh38's 25 sequences in
-    index order give three groups of about 1 Gb."""
-    groups, cur, tot = [], [], 0
-    for t in tids:
-        span = ((max(int(ref_lens[t]), 1) + GROUP_GAP) + 63) & ~63
-        if cur and (tot + span > max_bases or len(cur) >= GROUP_MAX):
-            groups.append(cur)
-            cur, tot = [], 0
-        cur.append(t)
-        tot += span
-    if cur:
-        groups.append(cur)
-    return groups
+    """pjb_plan_groups: the chains `tids` (in this order) are finished as -- consecutive runs whose sequences (plus the gap
+    pjb_finish_group_begin leaves between members) stay below `max_bases` and PJB_GROUP_MAX members; a set that would be one chain of
+    more than 0.6 Gb goes as two.  GRCh38's 25 sequences in index order give three groups of about 1 Gb.  The program, bench.py and the
+    ranks of a multi-GPU run all plan with this function of the library."""
+    tids = [int(t) for t in tids]
+    if not tids:
+        return []
+    lens = np.ascontiguousarray(ref_lens, dtype=np.int32)
+    t = np.ascontiguousarray(tids, dtype=np.int32)
+    assert t.min() >= 0 and t.max() < len(lens)
+    g = np.zeros(len(t), dtype=np.int32)
+    n = load().pjb_plan_groups(lens.ctypes.data, t.ctypes.data, len(t), int(max_bases), g.ctypes.data)
+    if n < 0:
+        raise PjbError(n, "pjb_plan_groups: bad arguments")
+    return [[tids[k] for k in range(len(tids)) if g[k] == i] for i in range(n)]

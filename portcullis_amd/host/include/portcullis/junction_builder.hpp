@@ -76,6 +76,11 @@ protected:
     void findJunctions();
     // decode one target sequence (worker body) and feed it to the thread that owns the GPU context
     void findJuncs(class DeviceThread& device, bam::BamReader& reader, bam::GenomeMapper& gmap, int32_t seq);
+    // group chains (the program's default for large inputs): a worker does not wait for its target's chain -- the group is queued when its
+    // last member has been asked for -- and findJunctions completes the targets once every one of them has been asked for
+    void completeTarget(int32_t seq, struct DeferredTarget& dt);
+    std::vector<std::shared_ptr<struct DeferredTarget>> deferredTargets;
+    std::mutex deferredMu;
 
 public:
     JunctionBuilder(const std::string& prepDir, const std::string& output);

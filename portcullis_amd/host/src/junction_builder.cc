@@ -362,10 +362,19 @@ struct ContigDone {
     size_t rowBase = 0;  // --extra: index of rows[0] in the context's row table (pjb_extra_finish's order)
 };
 
+// a target between "asked to be finished" and "its chain has been collected"
+struct DeferredTarget {
+    std::promise<ContigDone> done;
+    std::future<ContigDone> fut;
+    std::string decodeError, genomeError, name;
+    bool any = false;
+    double t_begin = 0, t_decoded = 0, t_blocked = 0, t_genome = 0;
+};
+
 class DeviceThread {
 public:
     struct Cmd {
-        enum Kind { GENOME, BATCH, BAM, FINISH, EXTRA, STOP, BAMBEGIN, BAMPIECE, BAMEND } kind = STOP;
+        enum Kind { GENOME, BATCH, BAM, FINISH, EXTRA, STOP, BAMBEGIN, BAMPIECE, BAMEND, FLUSH } kind = STOP;
         int32_t tid = -1;
         std::string genome;
         // GENOME with the record's bytes as they are in the FASTA file (page-locked, from rawPool; the device takes the line
@@ -413,6 +422,11 @@ private:
     std::map<int32_t, std::string> failed;  // contig -> first error
     std::string fatal;                      // context creation failed
 
+    // The chain plan (pjb_plan_groups over the targets this thread will be asked to finish, in index order): a FINISH of a target that
+    // belongs to a group of several waits here until the group's last member has been asked for, then the group is queued as ONE
+    // kernel chain (pjb_finish_group_begin) -- three chains for a human genome instead of twenty-five, which is what bench.py measures.
+    // Empty: every target is a chain of its own (several contexts share the targets, --extra, PORTCULLIS_CHAIN_PLAN=targets).
+    std::vector<std::vector<int32_t>> plan;
     void run(int device, bam::Orientation orientation, bam::Strandedness strandedness, std::vector<int32_t> lens,
              std::shared_future<int> deviceCount, bool extra) {
         pjb_ctx* ctx = nullptr;
@@ -443,17 +457,44 @@ private:
         struct Pending {
             int32_t tid;
             std::promise<ContigDone>* done; // (the worker thread that owns it waits on its future)
+            std::vector<int32_t> tids;      // a group chain: its members, in the order they were named to pjb_finish_group_begin
+            std::vector<std::promise<ContigDone>*> dones;
         };
         std::deque<Pending> pending;
         size_t rowsSoFar = 0;
+        const bool printPlan = getenv("PJB_PRINT_CHAIN_PLAN") != nullptr;
         auto collectOldest = [&]() {
             Pending p = std::move(pending.front());
             pending.pop_front();
-            ContigDone d;
-            memset(&d.rr, 0, sizeof d.rr);
             std::string err;
             const pjb_junction_row* rows = nullptr;
             int64_t n = 0;
+            if (!p.tids.empty()) { // a group: one result per member, the rows member after member in the order of `tids`
+                std::vector<pjb_region_result> rr(p.tids.size());
+                for (auto& r : rr) memset(&r, 0, sizeof r);
+                if (pjb_finish_group_end(ctx, p.tids.data(), (int32_t)p.tids.size(), rr.data()) != PJB_OK) err = std::string("pjb_finish_group: ") + pjb_last_error(ctx);
+                else if (pjb_collect(ctx, &rows, &n) != PJB_OK) err = std::string("pjb_collect: ") + pjb_last_error(ctx);
+                size_t at = rowsSoFar;
+                for (size_t m = 0; m < p.tids.size(); m++) {
+                    (void)pjb_release_contig(ctx, p.tids[m]);
+                    if (!err.empty()) {
+                        p.dones[m]->set_exception(std::make_exception_ptr(JunctionBuilderException(err)));
+                        continue;
+                    }
+                    ContigDone d;
+                    d.rr = rr[m];
+                    size_t e = at;
+                    while (e < (size_t)n && rows[e].refid == p.tids[m]) e++;
+                    d.rows.assign(rows + at, rows + e);
+                    d.rowBase = at;
+                    at = e;
+                    p.dones[m]->set_value(std::move(d));
+                }
+                if (err.empty()) rowsSoFar = (size_t)n;
+                return;
+            }
+            ContigDone d;
+            memset(&d.rr, 0, sizeof d.rr);
             if (pjb_finish_contig_end(ctx, p.tid, &d.rr) != PJB_OK) err = std::string("pjb_finish_contig: ") + pjb_last_error(ctx);
             else if (pjb_collect(ctx, &rows, &n) != PJB_OK) err = std::string("pjb_collect: ") + pjb_last_error(ctx);
             else {
@@ -464,6 +505,54 @@ private:
             (void)pjb_release_contig(ctx, p.tid);
             if (err.empty()) p.done->set_value(std::move(d));
             else p.done->set_exception(std::make_exception_ptr(JunctionBuilderException(err)));
+        };
+        // ---- the plan's book-keeping: group of a target, the members that have been asked for so far
+        std::map<int32_t, size_t> groupOf;
+        for (size_t g = 0; g < plan.size(); g++)
+            for (int32_t t : plan[g]) groupOf[t] = g;
+        struct Waiting {
+            std::vector<std::pair<int32_t, std::promise<ContigDone>*>> got;
+            bool single = false; // a member failed, or the library said "not as a group": the members go one by one
+        };
+        std::vector<Waiting> waiting(plan.size());
+        if (printPlan && !plan.empty()) {
+            std::string txt;
+            for (auto& g : plan) {
+                txt += txt.empty() ? "" : " | ";
+                for (size_t k = 0; k < g.size(); k++) txt += (k ? "," : "") + std::to_string(g[k]);
+            }
+            cerr << "[chain plan] " << plan.size() << " chains: " << txt << endl;
+        }
+        auto beginSingle = [&](int32_t tid, std::promise<ContigDone>* done) {
+            while (pending.size() >= kQueued) collectOldest();
+            if (pjb_finish_contig_begin(ctx, tid) != PJB_OK) {
+                const std::string err = std::string("pjb_finish_contig: ") + pjb_last_error(ctx);
+                (void)pjb_release_contig(ctx, tid);
+                done->set_exception(std::make_exception_ptr(JunctionBuilderException(err)));
+            } else {
+                if (printPlan) cerr << "[chain] target " << tid << endl;
+                pending.push_back(Pending{tid, done, {}, {}});
+            }
+        };
+        auto beginGroup = [&](Waiting& w) {
+            std::sort(w.got.begin(), w.got.end());
+            std::vector<int32_t> tids;
+            std::vector<std::promise<ContigDone>*> dones;
+            for (auto& x : w.got) tids.push_back(x.first), dones.push_back(x.second);
+            w.got.clear();
+            if (tids.empty()) return;
+            while (pending.size() >= kQueued) collectOldest();
+            if (tids.size() > 1 && !w.single && pjb_finish_group_begin(ctx, tids.data(), (int32_t)tids.size()) == PJB_OK) {
+                if (printPlan) {
+                    std::string txt;
+                    for (size_t k = 0; k < tids.size(); k++) txt += (k ? "," : "") + std::to_string(tids[k]);
+                    cerr << "[chain] group " << txt << endl;
+                }
+                pending.push_back(Pending{tids[0], nullptr, tids, dones});
+                return;
+            }
+            // (PJB_ERR_ARG: "not as a group" -- a target with characters outside the nucleotide alphabet, ...: one by one)
+            for (size_t k = 0; k < tids.size(); k++) beginSingle(tids[k], dones[k]);
         };
         g_prof.mark("device thread: context ready");
         sharedCtx = fatal.empty() ? ctx : nullptr;
@@ -586,12 +675,13 @@ private:
                 ~KindTimer() {
                     const double t1 = HostProfile::now();
                     *slot += t1 - t0;
-                    static const char* names[] = {"GENOME", "BATCH", "BAM", "FINISH", "EXTRA", "STOP", "BAMBEGIN", "BAMPIECE", "BAMEND"};
+                    static const char* names[] = {"GENOME", "BATCH", "BAM", "FINISH", "EXTRA", "STOP", "BAMBEGIN", "BAMPIECE", "BAMEND", "FLUSH"};
                     if (g_prof.events_on) g_prof.event(t0, t1, std::string("dev") + std::to_string(dev) + " " + names[kind] + " tid " + std::to_string(tid));
                 }
             } kindTimer{&tKind[(int)c.kind & 15], (int)c.kind, (int)c.tid, profId};
             releaseDone(false);
             if (c.kind == Cmd::STOP) {
+                for (auto& w : waiting) beginGroup(w);
                 while (!pending.empty()) collectOldest();
                 releaseDone(true);
                 if (g_prof.on) {
@@ -657,16 +747,23 @@ private:
                                     " (--ingest host decodes the file on the host threads and streams batches instead)";
                 releaseDone(false);
                 c.bamDone->set_value(n);
+            } else if (c.kind == Cmd::FLUSH) { // (no more targets will come: what still waits for the rest of its group goes now)
+                for (auto& w : waiting) beginGroup(w);
+                while (!pending.empty()) collectOldest();
             } else if (c.kind == Cmd::FINISH) {
-                if (err.empty()) {
-                    while (pending.size() >= kQueued) collectOldest();
-                    if (pjb_finish_contig_begin(ctx, c.tid) != PJB_OK) {
-                        err = std::string("pjb_finish_contig: ") + pjb_last_error(ctx);
-                        (void)pjb_release_contig(ctx, c.tid);
-                        c.done->set_exception(std::make_exception_ptr(JunctionBuilderException(err)));
-                    } else
-                        pending.push_back(Pending{c.tid, c.done});
+                auto git = groupOf.find(c.tid);
+                if (err.empty() && git != groupOf.end() && plan[git->second].size() > 1 && !waiting[git->second].single) {
+                    Waiting& w = waiting[git->second];
+                    w.got.emplace_back(c.tid, c.done);
+                    if (w.got.size() == plan[git->second].size()) beginGroup(w);
+                } else if (err.empty()) {
+                    beginSingle(c.tid, c.done);
                 } else {
+                    if (git != groupOf.end()) { // the group is not complete any more: its members go one by one
+                        Waiting& w = waiting[git->second];
+                        w.single = true;
+                        beginGroup(w);
+                    }
                     if (ctx) {
                         while (!pending.empty()) collectOldest();
                         pjb_region_result dummy;
@@ -693,9 +790,11 @@ private:
 
 public:
     DeviceThread(int device, bam::Orientation o, bam::Strandedness s, const std::vector<int32_t>& lens, std::shared_future<int> dc,
-                 bool extra = false) {
+                 bool extra = false, std::vector<std::vector<int32_t>> chainPlan = {}) {
+        plan = std::move(chainPlan);
         th = std::thread([=] { run(device, o, s, lens, dc, extra); });
     }
+    bool grouped() const { return !plan.empty(); }
     ~DeviceThread() {
         Cmd c;
         c.kind = Cmd::STOP;
@@ -1025,26 +1124,47 @@ void JunctionBuilder::findJuncs(DeviceThread& device, BamReader& reader, GenomeM
     decoder.join();
     const double t_decoded = HostProfile::now();
     // always close the contig on the device, also after a host-side error
-    std::promise<ContigDone> done;
-    std::future<ContigDone> fut = done.get_future();
+    auto dt = std::make_shared<DeferredTarget>();
+    dt->fut = dt->done.get_future();
+    dt->decodeError = decodeError;
+    dt->genomeError = genomeError;
+    dt->any = any;
+    dt->name = name;
+    dt->t_begin = t_begin;
+    dt->t_decoded = t_decoded;
+    dt->t_blocked = t_blocked;
+    dt->t_genome = t_genome;
     {
         DeviceThread::Cmd c;
         c.kind = DeviceThread::Cmd::FINISH;
         c.tid = seq;
-        c.done = &done;
+        c.done = &dt->done;
         device.push(std::move(c));
     }
+    if (device.grouped()) {
+        // the target's chain is queued when the last member of its group has been asked for: this worker goes on to its next target
+        // (waiting here, a worker would hold the thread the group's other members need) and findJunctions takes the result later
+        std::lock_guard<std::mutex> lk(deferredMu);
+        deferredTargets[(size_t)seq] = dt;
+        return;
+    }
+    completeTarget(seq, *dt);
+}
+
+// what a worker does once its target's chain has been collected (or failed)
+void JunctionBuilder::completeTarget(int32_t seq, DeferredTarget& dt) {
+    RegionResult& res = results[(size_t)seq];
     ContigDone d;
     std::string finishError;
     try {
-        d = fut.get();
+        d = dt.fut.get();
     } catch (const std::exception& e) {
         finishError = e.what();
     }
-    if (!decodeError.empty()) throw JunctionBuilderException(decodeError);
-    if (!genomeError.empty()) throw JunctionBuilderException(genomeError);
+    if (!dt.decodeError.empty()) throw JunctionBuilderException(dt.decodeError);
+    if (!dt.genomeError.empty()) throw JunctionBuilderException(dt.genomeError);
     if (!finishError.empty()) throw JunctionBuilderException(finishError);
-    if (!any) return;
+    if (!dt.any) return;
     res.js.appendRows(d.rows.data(), d.rows.size());
     res.rowBase = d.rowBase;
     res.splicedCount = d.rr.spliced;
@@ -1055,9 +1175,9 @@ void JunctionBuilder::findJuncs(DeviceThread& device, BamReader& reader, GenomeM
     if (g_prof.on) {
         const double t_end = HostProfile::now();
         std::lock_guard<std::mutex> lk(g_prof.mu);
-        cerr << "[host profile] " << name << ": total " << (t_end - t_begin) << " s = decode (incl. queueing) " << (t_decoded - t_begin)
-             << " (of which blocked on the device queue " << t_blocked << ") + finish/rows " << (t_end - t_decoded)
-             << "; genome read " << t_genome << endl;
+        cerr << "[host profile] " << dt.name << ": total " << (t_end - dt.t_begin) << " s = decode (incl. queueing) " << (dt.t_decoded - dt.t_begin)
+             << " (of which blocked on the device queue " << dt.t_blocked << ") + finish/rows " << (t_end - dt.t_decoded)
+             << "; genome read " << dt.t_genome << endl;
     }
 }
 
@@ -1152,9 +1272,34 @@ void JunctionBuilder::findJunctions() {
             if (const char* e = getenv("PORTCULLIS_CTX_PER_GPU")) per = std::max(1, atoi(e));
             per = std::max(1, std::min(per, nthreads / nd));
             if (extra) nd = per = 1;  // the name multiplicities and the depth hand-over between targets are file-wide: one context
+            // The chain plan.  ONE context serves every target (the default for large inputs): the targets that hold alignments, in index
+            // order, are finished in the groups pjb_plan_groups makes of them -- what bench.py's step does.  Several contexts take their
+            // targets as the workers come (no telling which context a target goes to), and --extra contexts do not take groups: a
+            // chain per target.  PORTCULLIS_CHAIN_PLAN=targets | groups overrides (groups: only with one context); PORTCULLIS_GROUP_BASES
+            // sets the bases of a group (tests: small genomes in several groups).
+            std::vector<std::vector<int32_t>> chainPlan;
+            const char* planEnv = getenv("PORTCULLIS_CHAIN_PLAN");
+            const bool wantGroups = planEnv ? std::string(planEnv) == "groups" : (pinnedPool != nullptr);
+            if (wantGroups && nd * per == 1 && !extra) {
+                std::vector<int32_t> with;
+                {
+                    BamReader probe(prepData.getSortedBamFilePath());
+                    probe.open(useCsi);
+                    for (size_t i = 0; i < refs->size(); i++)
+                        if (probe.hasAlignments((int32_t)i)) with.push_back((int32_t)i);
+                }
+                std::vector<int32_t> groupOf(with.size(), 0);
+                int64_t gb = 0;
+                if (const char* e = getenv("PORTCULLIS_GROUP_BASES")) gb = atoll(e);
+                const int ng = pjb_plan_groups(lens.data(), with.data(), (int32_t)with.size(), gb, groupOf.data());
+                if (ng > 0) {
+                    chainPlan.resize((size_t)ng);
+                    for (size_t k = 0; k < with.size(); k++) chainPlan[(size_t)groupOf[k]].push_back(with[k]);
+                }
+            }
             for (int k = 0; k < per; k++)
                 for (int d = 0; d < nd; d++)
-                    deviceThreads.emplace_back(new DeviceThread(d, orientation, strandSpecific, lens, deviceCount, extra));
+                    deviceThreads.emplace_back(new DeviceThread(d, orientation, strandSpecific, lens, deviceCount, extra, chainPlan));
             for (size_t k = 0; k < deviceThreads.size(); k++) deviceThreads[k]->lane = (int)k;
             if (pinnedPool && transferSlots > 0) {
                 const int perLane = std::max(1, transferSlots / (int)deviceThreads.size());
@@ -1200,8 +1345,25 @@ void JunctionBuilder::findJunctions() {
     // mostly waits; one worker per target keeps the file moving while every other worker waits for the device.  Not the
     // default: see the note at the transfer gate.)
     const int nworkers = nthreads;
+    deferredTargets.assign(refs->size(), nullptr);
     for (int w = 0; w < nworkers; w++) pool.emplace_back(worker, w);
     for (auto& t : pool) t.join();
+    // group chains: every target has been asked for -- what still waits for the rest of its group goes now, then the results are taken
+    for (auto& dth : deviceThreads)
+        if (dth->grouped()) {
+            DeviceThread::Cmd c;
+            c.kind = DeviceThread::Cmd::FLUSH;
+            dth->push(std::move(c));
+        }
+    for (size_t i = 0; i < deferredTargets.size(); i++)
+        if (deferredTargets[i]) {
+            try {
+                completeTarget((int32_t)i, *deferredTargets[i]);
+            } catch (const std::exception& e) {
+                if (firstError.empty()) firstError = e.what();
+            }
+            deferredTargets[i].reset();
+        }
     if (extra && firstError.empty() && !deviceThreads.empty()) {
         // calcExtraMetrics (src/junction_builder.cc:293-312): multiple mapping score, flanking alignments, coverage
         cout << "Calculating extra junction metrics:" << endl;

@@ -347,8 +347,14 @@ def generate(cfg: SynthConfig, device="cpu", seed=None, tid=0):
         seq2=seq2,
         seq_exc=seq_exc,
     )
-    return dict(genome=genome, batch=batch, n_reads=N, n_pairs=n_pairs, n_cigar_ops=int(cig_off[-1]),
-                n_spliced=S, seq_words_per_read=W, config=cfg)
+    out = dict(genome=genome, batch=batch, n_reads=N, n_pairs=n_pairs, n_cigar_ops=int(cig_off[-1]),
+               n_spliced=S, seq_words_per_read=W, config=cfg)
+    if dev.type == "cuda":
+        # the temporaries go back to the driver now: the library allocates with hipMalloc, not through torch's cache (with
+        # max_split_size_mb set -- tests/conftest.py, bench.py -- the cache holds them as whole blocks that nothing pins)
+        del pos, order, len_all, op_all, present, flag, mapq, xs, lq, seq_words, seq_off, cig_off, cigar, seq4, seq2, seq_exc, mtid_t, mpos_t, tmp
+        torch.cuda.empty_cache()
+    return out
 
 
 def pack_seq2_torch(seq4):

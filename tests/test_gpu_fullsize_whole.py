@@ -25,6 +25,7 @@ def test_c5_whole_on_one_gpu():
     gc.collect()
     torch.cuda.empty_cache()  # (what earlier tests of this process left in torch's caching allocator)
     free, _ = torch.cuda.mem_get_info()
+    print(f"free HBM at the start: {free / 1e9:.1f} GB")
     if free < 125e9:
         pytest.skip(f"needs ~120 GB of free HBM, {free / 1e9:.0f} GB are free")
     cfgs = synth.c3_contig_configs(1_000_000_000, 300_000)
@@ -40,6 +41,8 @@ def test_c5_whole_on_one_gpu():
         torch.cuda.empty_cache()  # the generator's temporaries go back to the driver: the library allocates with hipMalloc, not through torch
         n_reads = sum(d["n_reads"] for d in data)
         n_pairs = sum(d["n_pairs"] for d in data)
+        print(f"records resident: torch allocated {torch.cuda.memory_allocated() / 1e9:.1f} GB, reserved {torch.cuda.memory_reserved() / 1e9:.1f} GB, "
+              f"free on the device {torch.cuda.mem_get_info()[0] / 1e9:.1f} GB")
         assert n_reads >= 999_000_000
         groups = ffi.plan_groups(lens, list(range(len(cfgs))))
         assert len(groups) == 3
