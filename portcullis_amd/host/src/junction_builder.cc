@@ -364,6 +364,7 @@ struct ContigDone {
 
 // a target between "asked to be finished" and "its chain has been collected"
 struct DeferredTarget {
+    std::promise<void> seen;
     std::promise<ContigDone> done;
     std::future<ContigDone> fut;
     std::string decodeError, genomeError, name;
@@ -389,6 +390,7 @@ public:
         std::vector<bam::ReadBatch>* spare = nullptr;  // where the batch storage goes back to
         std::mutex* spareMu = nullptr;
         std::promise<ContigDone>* done = nullptr;
+        std::promise<void>* seen = nullptr;  // FINISH: fulfilled when the device thread takes the command (everything the worker queued before it -- batches that point at the worker's stack -- has been served)
         // BAM: the target's file bytes for the device-side ingest (freed by the device thread)
         uint8_t* bamBytes = nullptr;
         size_t bamSize = 0;
@@ -751,6 +753,7 @@ private:
                 for (auto& w : waiting) beginGroup(w);
                 while (!pending.empty()) collectOldest();
             } else if (c.kind == Cmd::FINISH) {
+                if (c.seen) c.seen->set_value();
                 auto git = groupOf.find(c.tid);
                 if (err.empty() && git != groupOf.end() && plan[git->second].size() > 1 && !waiting[git->second].single) {
                     Waiting& w = waiting[git->second];
@@ -1139,9 +1142,11 @@ void JunctionBuilder::findJuncs(DeviceThread& device, BamReader& reader, GenomeM
         c.kind = DeviceThread::Cmd::FINISH;
         c.tid = seq;
         c.done = &dt->done;
+        if (device.grouped()) c.seen = &dt->seen;
         device.push(std::move(c));
     }
     if (device.grouped()) {
+        dt->seen.get_future().wait();  // (the batches queued before the FINISH name this frame's buffers)
         // the target's chain is queued when the last member of its group has been asked for: this worker goes on to its next target
         // (waiting here, a worker would hold the thread the group's other members need) and findJunctions takes the result later
         std::lock_guard<std::mutex> lk(deferredMu);

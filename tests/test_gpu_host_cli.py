@@ -416,7 +416,7 @@ def test_separate_bams(tmp_path, orc):
 # ---- the program's chain plan (round 5's verdict: "the product program still finishes one target per chain")
 def _plan_from_stderr(stderr):
     plan = [ln for ln in stderr.splitlines() if ln.startswith("[chain plan] ")]
-    chains = [ln.split(" ", 2)[2] for ln in stderr.splitlines() if ln.startswith("[chain] ")]
+    chains = [ln.split(" ", 1)[1] for ln in stderr.splitlines() if ln.startswith("[chain] ")]
     groups = []
     if plan:
         groups = [[int(t) for t in g.split(",")] for g in plan[0].split(": ", 1)[1].split(" | ")]
