@@ -43,8 +43,8 @@ struct Contig {
     bool has_x = false;
     bool present = false;
     u32 *codes = nullptr; // packed 4-bit codes (k0_encode); nullptr when the contig is "exotic"
-    u32 *codes2 = nullptr; // 2-bit codes | exception bitmap (k0_encode2); with codes
-    size_t d_cap = 0, codes_cap = 0, codes2_cap = 0; // sizes of the allocations (they go back to the context's genome pool)
+    u32 *codes2 = nullptr; // 2-bit codes | exception bitmap (k0_encode2): behind the 4-bit codes, in their allocation
+    size_t d_cap = 0, codes_cap = 0; // sizes of the allocations (they go back to the context's genome pool)
 };
 
 // The bases and codes of a released contig are kept for the next upload (targets come longest first, so the next genome
@@ -61,8 +61,7 @@ void free_contig(Contig &g, std::vector<Buf> *pool = nullptr) {
             (void)hipFree(p);
     };
     if (g.owned) give(g.d, g.d_cap);
-    give(g.codes, g.codes_cap);
-    give(g.codes2, g.codes2_cap);
+    give(g.codes, g.codes_cap); // (codes2 lies in the same allocation)
     g = Contig();
 }
 // device memory for a genome array: the smallest pooled buffer that fits, else a new one
@@ -100,6 +99,9 @@ struct OpenContig {
     std::vector<char> last_known;   // 0 = must be read back from the device (device-resident batch)
     std::vector<Slab> slabs;        // device memory holding this contig's host-submitted batches
     bool on_main_stream = false;    // some batch was produced by work queued on the main stream (host copies, BAM ingest)
+    size_t slab_hint = 0;           // what the target's records will take in all, roughly (device ingest: from the inflated bytes): its first slab
+                                    // is this large -- ONE hipMalloc per target instead of one per 128 MB (targets finished as groups keep their
+                                    // slabs until the group is collected: nothing comes back to the pool in between)
 };
 
 } // namespace
@@ -542,16 +544,22 @@ void *slab_alloc(pjb_ctx *c, OpenContig &oc, size_t bytes) {
             s.used += bytes;
             return r;
         }
-    for (size_t k = 0; k < c->slab_pool.size(); k++)
-        if (c->slab_pool[k].cap >= bytes) {
-            Slab s = c->slab_pool[k];
-            c->slab_pool.erase(c->slab_pool.begin() + (long)k);
+    {
+        // (a target's first slab: the smallest pooled one that holds what the target is expected to take in all, else a new one of that size)
+        const size_t want = oc.slabs.empty() ? std::max(bytes, oc.slab_hint) : bytes;
+        long best = -1;
+        for (size_t k = 0; k < c->slab_pool.size(); k++)
+            if (c->slab_pool[k].cap >= want && (best < 0 || c->slab_pool[k].cap < c->slab_pool[(size_t)best].cap)) best = (long)k;
+        if (best >= 0) {
+            Slab s = c->slab_pool[(size_t)best];
+            c->slab_pool.erase(c->slab_pool.begin() + best);
             s.used = bytes;
             oc.slabs.push_back(s);
             return s.p;
         }
+    }
     Slab s;
-    s.cap = std::max<size_t>(bytes, (size_t)128 << 20);
+    s.cap = std::max<size_t>(bytes, std::max<size_t>((size_t)128 << 20, oc.slabs.empty() ? oc.slab_hint : 0));
     if (hipMalloc((void **)&s.p, s.cap) != hipSuccess) {
         s.cap = bytes;
         if (hipMalloc((void **)&s.p, s.cap) != hipSuccess) return nullptr;
@@ -905,26 +913,23 @@ static int upload_common(pjb_ctx *c, int32_t tid, uint8_t *d, int64_t len, bool 
     size_t codes_cap = 0;
     int exotic = 0;
     const int64_t n_words = (len + 7) / 8;
+    static const bool no_seq2 = getenv("PJB_NO_SEQ2") && atoi(getenv("PJB_NO_SEQ2")) != 0;
+    const size_t c2_at = ((size_t)(n_words + 2) + 3) & ~(size_t)3;                       // (the 2-bit codes start on a 16-byte boundary)
+    const size_t c2_words = len > 0 && !no_seq2 ? (size_t)codes2_alloc_words(len) : 0;
     if (len > 0) {
-        codes = (u32 *)genome_take(c->genome_pool, (size_t)(n_words + 2) * 4, codes_cap);
-        if (!codes) return fail(c, PJB_ERR_NOMEM, "hipMalloc(genome codes, %zu bytes) failed", (size_t)(n_words + 2) * 4);
+        codes = (u32 *)genome_take(c->genome_pool, (c2_at + c2_words) * 4, codes_cap);
+        if (!codes) return fail(c, PJB_ERR_NOMEM, "hipMalloc(genome codes, %zu bytes) failed", (c2_at + c2_words) * 4);
         (void)hipMemsetAsync(c->b_hasx.p, 0, sizeof(int), c->stream);
         (void)hipMemsetAsync(codes + n_words, 0, 8, c->stream);
         hipLaunchKernelGGL(k0_encode, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, c->stream, (const uint8_t *)d, len,
                            codes, n_words, (int *)c->b_hasx.p);
         (void)hipMemcpyAsync(&exotic, c->b_hasx.p, sizeof(int), hipMemcpyDeviceToHost, c->stream);
     }
-    // 2-bit codes and their exception bitmap for k1_emit's compares (PJB_NO_SEQ2=1: not built -- A/B runs)
+    // 2-bit codes and their exception bitmap for k1_emit's compares (PJB_NO_SEQ2=1: not built -- A/B runs): behind the 4-bit codes, in
+    // the same allocation (a hipMalloc is milliseconds on the thread that serves every target)
     u32 *codes2 = nullptr;
-    size_t codes2_cap = 0;
-    static const bool no_seq2 = getenv("PJB_NO_SEQ2") && atoi(getenv("PJB_NO_SEQ2")) != 0;
-    if (len > 0 && !no_seq2) {
-        const size_t words = (size_t)codes2_alloc_words(len);
-        codes2 = (u32 *)genome_take(c->genome_pool, words * 4, codes2_cap);
-        if (!codes2) {
-            if (codes) (void)hipFree(codes);
-            return fail(c, PJB_ERR_NOMEM, "hipMalloc(genome 2-bit codes, %zu bytes) failed", words * 4);
-        }
+    if (codes && c2_words) {
+        codes2 = codes + c2_at;
         const int64_t n2w = codes2_words(len), nxw = gexc_words(len);
         (void)hipMemsetAsync(codes2 + n2w, 0, (size_t)K0_CODES2_PAD * 4, c->stream);
         (void)hipMemsetAsync(codes2 + n2w + K0_CODES2_PAD + nxw, 0, (size_t)K0_GEXC_PAD * 4, c->stream);
@@ -934,15 +939,11 @@ static int upload_common(pjb_ctx *c, int32_t tid, uint8_t *d, int64_t len, bool 
     hipError_t se = hipStreamSynchronize(c->stream);
     if (se != hipSuccess) {
         if (codes) (void)hipFree(codes);
-        if (codes2) (void)hipFree(codes2);
         return fail(c, PJB_ERR_HIP, "upload: %s", hipGetErrorString(se));
     }
     if (exotic && codes) {
         (void)hipFree(codes);
         codes = nullptr;
-    }
-    if (!codes && codes2) {
-        (void)hipFree(codes2);
         codes2 = nullptr;
     }
     Contig &g = c->contigs[(size_t)tid];
@@ -956,7 +957,6 @@ static int upload_common(pjb_ctx *c, int32_t tid, uint8_t *d, int64_t len, bool 
     g.codes2 = codes2;
     g.d_cap = owned ? d_cap : 0;
     g.codes_cap = codes ? codes_cap : 0;
-    g.codes2_cap = codes2 ? codes2_cap : 0;
     return PJB_OK;
 }
 
@@ -3134,6 +3134,8 @@ static int ingest_parse(pjb_ctx *c, int32_t tid, OpenContig &oc, const uint8_t *
     LAUNCH(c, "bam_walk_fill", bam_walk<true>, dim3((n_seg + 255) / 256), dim3(256), R, n_seg, (const iu64 *)seg_start, O);
 
     // ---- SoA arrays in the target's slabs (same packing as a host-submitted batch)
+    // (150-base paired-end records: fields + operations + 4- and 2-bit bases of the spliced third are 0.28 of the inflated bytes)
+    if (oc.slabs.empty()) oc.slab_hint = (((size_t)total / 100 * 32) + ((size_t)32 << 20)) & ~(((size_t)1 << 20) - 1);
     const size_t fixed[8] = {n * 4, n * 2, n, n, n * 4, n * 4, n * 4, (n + 1) * 4}; // pos flag mapq xs l_qseq mtid mpos cig_off
     size_t offs[9], tot_b = 0;
     for (int k = 0; k < 8; k++) {

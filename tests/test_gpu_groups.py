@@ -356,7 +356,9 @@ def test_sort_digits_planned_too_small_are_repeated(ffi, orc):
             return ctx.collect(), regs, repeats
 
     rows_s, regs_s, rep_s = run([[0], [1], [2]])
-    assert rep_s[0] == (0, 0) and rep_s[1][0] >= 1 and rep_s[1][1] & 4, rep_s  # the second chain was queued again for its junctions
+    # the second chain was queued again for its junctions (the first one may repeat for its read lists' room -- thousands of reads of one
+    # transcript on a few sub-lists -- but not for junctions: nothing had been planned yet)
+    assert not rep_s[0][1] & 4 and rep_s[1][0] >= 1 and rep_s[1][1] & 4, rep_s
     assert_rows_equal(rows_s, want)
     rows_g, regs_g, rep_g = run([[0], [1, 2]])
     assert rep_g[1][0] >= 1 and rep_g[1][1] & 4, rep_g
