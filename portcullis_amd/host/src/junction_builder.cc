@@ -493,6 +493,7 @@ private:
                     p.dones[m]->set_value(std::move(d));
                 }
                 if (err.empty()) rowsSoFar = (size_t)n;
+                g_prof.mark(("chain collected: group from target " + std::to_string(p.tids[0])).c_str());
                 return;
             }
             ContigDone d;
@@ -533,6 +534,7 @@ private:
                 done->set_exception(std::make_exception_ptr(JunctionBuilderException(err)));
             } else {
                 if (printPlan) cerr << "[chain] target " << tid << endl;
+                g_prof.mark(("chain queued: target " + std::to_string(tid)).c_str());
                 pending.push_back(Pending{tid, done, {}, {}});
             }
         };
@@ -550,6 +552,7 @@ private:
                     for (size_t k = 0; k < tids.size(); k++) txt += (k ? "," : "") + std::to_string(tids[k]);
                     cerr << "[chain] group " << txt << endl;
                 }
+                g_prof.mark(("chain queued: group of " + std::to_string(tids.size()) + " from target " + std::to_string(tids[0])).c_str());
                 pending.push_back(Pending{tids[0], nullptr, tids, dones});
                 return;
             }
