@@ -38,7 +38,7 @@ for step in "$@"; do
            for k in 1 2 3; do ( time PJB_PROFILE_HOST=1 PJB_CREATE_TRACE=1 portcullis_amd/host/portcullis_amd junc -t $(nproc) --orientation FR -o /tmp/pjb_bench_e2e/prof/pc /tmp/pjb_bench_e2e/prep ) > $OUT/${TAG}_e2e_host_profile_$k.txt 2>&1; grep -E "real|Wall" $OUT/${TAG}_e2e_host_profile_$k.txt | head -3; done
            grep -E "host profile" $OUT/${TAG}_e2e_host_profile_2.txt | grep -v "submit_bam\|\] chr" | tail -40
            # the two chain plans side by side (wall of the command, alternating): groups (the default for this input) / one chain per target
-           for k in 1 2 3 4; do for plan in groups targets; do /usr/bin/time -f "e2e plan $plan: %e s" env PORTCULLIS_CHAIN_PLAN=$plan portcullis_amd/host/portcullis_amd junc -t $(nproc) --orientation FR -o /tmp/pjb_bench_e2e/prof/pc_$plan /tmp/pjb_bench_e2e/prep 2>&1 >/dev/null | grep "e2e plan"; done; done | tee $OUT/${TAG}_e2e_plans.txt
+           for k in 1 2 3 4; do for plan in groups targets; do s=$(date +%s.%N); PORTCULLIS_CHAIN_PLAN=$plan portcullis_amd/host/portcullis_amd junc -t $(nproc) --orientation FR -o /tmp/pjb_bench_e2e/prof/pc_$plan /tmp/pjb_bench_e2e/prep > /dev/null 2>&1; e=$(date +%s.%N); python3 -c "print('e2e plan $plan: %.3f s' % ($e - $s))"; done; done | tee $OUT/${TAG}_e2e_plans.txt
            md5sum /tmp/pjb_bench_e2e/prof/pc_groups.junctions.tab /tmp/pjb_bench_e2e/prof/pc_targets.junctions.tab | tee -a $OUT/${TAG}_e2e_plans.txt ;;
     fuzz) ( timeout 1500 python tests/fuzz_campaign.py; timeout 900 python tests/fuzz_groups.py; timeout 900 python tests/fuzz_extra.py ) 2>&1 | tail -30 | tee $OUT/${TAG}_fuzz.txt ;;
     rankshare) timeout 3000 python tools/rank_share.py $TAG 2>&1 | tail -30 ;;
