@@ -1734,8 +1734,10 @@ static int queue_contig(pjb_ctx *c, Flight &f) {
             u64 reads = 0;
             for (size_t bi = b0; bi < b0 + nb; bi++) reads += (u64)batches[bi].n;
             const u32 nt = (u32)std::min<u64>((reads + K1_TILE - 1) / K1_TILE + nb, 0x7fffffffu);
-            // (tiles of reads per block: 2 / 4 / 8 / 16 = 9.17 / 8.96 / 8.94 / 9.05 ms a step, profiles/r05q_*)
-            static const u32 tiles_per_block = getenv("PJB_K1E_TILES") ? (u32)std::max(1, atoi(getenv("PJB_K1E_TILES"))) : 4u;
+            // (tiles of reads per block: 2 / 4 / 8 / 16 = 9.17 / 8.96 / 8.94 / 9.05 ms a step, profiles/r05q_*; with round 6's 2-bit compare
+            // 4 / 8 / 12 / 16 / 32 / 64 = 7.25 - 7.37 / 7.15 - 7.17 / 7.32 / 7.32 / 7.37 / 8.02: fewer, longer blocks make the kernel itself
+            // faster still -- 970 us a chain in the step at 16 against 1 085 at 8 -- but the step no shorter: profiles/r06_k1_experiments.txt)
+            static const u32 tiles_per_block = getenv("PJB_K1E_TILES") ? (u32)std::max(1, atoi(getenv("PJB_K1E_TILES"))) : 8u;
             const u32 grid = std::max<u32>(1, std::min<u32>(nt, std::max<u32>(1024, nt / tiles_per_block)));
             LAUNCH(c, "k1_emit", k1_emit, dim3(grid), dim3(256), (const DevBatch *)S.batches.p + b0, (int)nb, n_tiles, (const u32 *)S.tile_cnt.p,
                    (const u32 *)S.tile_soff.p, (const u32 *)S.chunk_tile.p, (const u32 *)S.splidx.p, (const u32 *)S.splpoff.p, (const uint4 *)S.splrec.p, pr, el, kf,
