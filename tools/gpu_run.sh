@@ -11,6 +11,7 @@
 #   sqv:<variant>    instruction counts per kernel (the first two counter groups of pmc_sq.sh) of tools/variants/libpjb_<variant>.so
 #   e2eprof          (behind `bench`) the program on the bench's prepared BAM with PJB_PROFILE_HOST=1, three runs -> gpurun_out/<TAG>_e2e_host_profile_k.txt
 #   fuzz             the three fuzz campaigns (tests/fuzz_campaign.py, fuzz_groups.py, fuzz_extra.py)
+#   inflate          tools/bench_inflate.py at ~6 k and at ~130 k blocks a launch                              -> gpurun_out/<TAG>_bench_inflate.json
 #   rankshare[:N,N]  tools/rank_share.py: every rank's share of configs[2] on this one GPU (PJB_BENCH_AS_RANK)  -> gpurun_out/<TAG>_rank_share.json
 #   cmd:<shell>      anything else
 # TAG (environment, default r05) names the outputs; COMMIT is recorded in the PMC summary.
@@ -41,6 +42,21 @@ for step in "$@"; do
            for k in 1 2 3 4; do for plan in groups targets; do s=$(date +%s.%N); PORTCULLIS_CHAIN_PLAN=$plan portcullis_amd/host/portcullis_amd junc -t $(nproc) --orientation FR -o /tmp/pjb_bench_e2e/prof/pc_$plan /tmp/pjb_bench_e2e/prep > /dev/null 2>&1; e=$(date +%s.%N); python3 -c "print('e2e plan $plan: %.3f s' % ($e - $s))"; done; done | tee $OUT/${TAG}_e2e_plans.txt
            md5sum /tmp/pjb_bench_e2e/prof/pc_groups.junctions.tab /tmp/pjb_bench_e2e/prof/pc_targets.junctions.tab | tee -a $OUT/${TAG}_e2e_plans.txt ;;
     fuzz) ( timeout 1500 python tests/fuzz_campaign.py; timeout 900 python tests/fuzz_groups.py; timeout 900 python tests/fuzz_extra.py ) 2>&1 | tail -30 | tee $OUT/${TAG}_fuzz.txt ;;
+    inflate) # bgzf_decode at both launch sizes: ~6 k blocks a launch (the C2 file in 256 MB chunks) and ~130 k (the file four times over, one launch)
+           python tools/bench_inflate.py > $OUT/${TAG}_inflate_small.json 2> $OUT/${TAG}_inflate.err
+           python tools/bench_inflate.py --chunk-mb 8192 --times 4 > $OUT/${TAG}_inflate_large.json 2>> $OUT/${TAG}_inflate.err
+           python3 - "$OUT/${TAG}_inflate_small.json" "$OUT/${TAG}_inflate_large.json" "$OUT/${TAG}_bench_inflate.json" <<'PY'
+import json, sys
+small, large = (json.loads(open(f).read().strip().splitlines()[-1]) for f in sys.argv[1:3])
+out = {"what": "device-side BGZF inflate (pjb_inflate_bgzf: bgzf_decode, a lane per block, + bgzf_resolve) on the configs[1] BAM; kernel time by HIP events; "
+               "the rate depends on the blocks per launch: a launch needs >= 64 k blocks to fill the chip's lanes",
+       "small_launches": {k: small[k] for k in ("blocks", "kernel_launches", "kernel_ms", "kernel_gbps_inflated", "kernel_gbps_compressed", "kernels")},
+       "large_launch": {k: large[k] for k in ("blocks", "kernel_launches", "kernel_ms", "kernel_gbps_inflated", "kernel_gbps_compressed", "kernels")},
+       "zlib_1thread_gbps_inflated": small["zlib_1thread_gbps_inflated"], "e2e": small.get("e2e")}
+json.dump(out, open(sys.argv[3], "w"), indent=1)
+print(json.dumps({k: {"blocks_per_launch": v["blocks"] // max(v["kernel_launches"], 1), "gbps_inflated": v["kernel_gbps_inflated"]} for k, v in out.items() if isinstance(v, dict) and "blocks" in v}))
+PY
+           ;;
     rankshare) timeout 3000 python tools/rank_share.py $TAG 2>&1 | tail -30 ;;
     rankshare:*) timeout 3000 python tools/rank_share.py $TAG "${step#rankshare:}" 2>&1 | tail -30 ;;
     cmd:*) bash -c "${step#cmd:}" ;;

@@ -10,7 +10,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$TAG -o $TAG -
 cd $GRAFT_REPO_ROOT
 python3 tools/summarize_rocprof.py $(find $OUT/prof_$TAG -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_bench_C3_kernel_stats.csv $OUT/${TAG}_rocprof.json C3 $COMMIT
 bash tools/pmc_traffic.sh $TAG
-python3 tools/summarize_pmc.py $OUT/pmc_$TAG $OUT/${TAG}_pmc_traffic.json C3 $COMMIT
+python3 tools/summarize_pmc.py $OUT/pmc_$TAG $OUT/${TAG}_pmc_traffic.json C3 $COMMIT keep_last=2/7
 python3 bench.py --steps 20 --warmup 3 ${BENCH_FLAGS:-} > $OUT/${TAG}_bench_C3.json 2> $OUT/bench_$TAG.err
 tail -c 300 $OUT/bench_$TAG.err
 # keep what travels back small: the raw traces stay on the box

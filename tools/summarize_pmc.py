@@ -10,9 +10,16 @@ from collections import defaultdict
 d, out = sys.argv[1], sys.argv[2]
 workload = sys.argv[3] if len(sys.argv) > 3 else None
 commit = sys.argv[4] if len(sys.argv) > 4 else None
+# "keep_last=a/b": of every kernel's dispatches (in dispatch order) only the last a/b are averaged -- the timed steps of a bench run that
+# did warm-up and instrumented passes first (the first chains of a context still plan the sort's digits for the buffers' limit: their
+# rs_panel_* dispatches move tables four times the size of the timed configuration's)
+keep = next((a.split("=", 1)[1] for a in sys.argv[5:] if a.startswith("keep_last=")), None)
 res = defaultdict(lambda: defaultdict(list))
 for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
-    for r in csv.DictReader(open(f"{d}/{ctr}/pmc_counter_collection.csv")):
+    rows = list(csv.DictReader(open(f"{d}/{ctr}/pmc_counter_collection.csv")))
+    if rows and "Dispatch_Id" in rows[0]:
+        rows.sort(key=lambda r: int(r["Dispatch_Id"]))
+    for r in rows:
         name = r["Kernel_Name"].split("(")[0].replace("void ", "").split("<")[0]  # template arguments dropped
         if "pjb::" not in name or r["Counter_Name"] != ctr:
             continue
@@ -21,6 +28,10 @@ summary = {}
 for name, v in sorted(res.items()):
     f = v.get("FETCH_SIZE", [])
     w = v.get("WRITE_SIZE", [])
+    if keep:
+        a, b = (int(x) for x in keep.split("/"))
+        f = f[len(f) - len(f) * a // b:] if f else f
+        w = w[len(w) - len(w) * a // b:] if w else w
     fk = sum(f) / len(f) if f else 0.0
     wk = sum(w) / len(w) if w else 0.0
     summary[name] = dict(launches=len(f), fetch_kib_raw=round(fk, 1), write_kib=round(wk, 1),
@@ -30,6 +41,8 @@ if workload:
     meta["_workload"] = workload  # bench.py attaches the traffic figure only to a run of the same workload
 if commit:
     meta["_commit"] = commit
+if keep:
+    meta["_dispatches_averaged"] = f"the last {keep} of every kernel's dispatches (the timed steps)"
 import os
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from csrc_hash import csrc_hash
