@@ -293,8 +293,8 @@ int pjb_finish_group_end(pjb_ctx *ctx, const int32_t *tids, int32_t n_tids, pjb_
  * (ascending, groups are runs of consecutive entries); returns the number of groups, a negative status on bad arguments.  No context
  * needed (host arithmetic).  The rule: a group holds consecutive targets whose sequences -- each with the gap the group's virtual
  * sequence leaves behind it, rounded up to 64 -- add up to at most max_bases (<= 0: 2^30, the measured optimum of profiles/
- * r04d_grouping_sweep.txt) and at most PJB_GROUP_MAX members; a set that would be ONE group of more than 0.6 Gb is planned as two (0.55 of
- * its bases each at most: the first chain's tail then runs beside the second one's first kernels -- tools/rank_share.py, profiles/r06_rank_share.json).
+ * r04d_grouping_sweep.txt) and at most PJB_GROUP_MAX members; a set that would be ONE group of more than 0.6 Gb is planned again with 0.55 of its
+ * bases as the limit (two chains, three when the targets do not divide that way: the first chain's tail then runs beside the second one's first kernels -- tools/rank_share.py, profiles/r06_rank_share.json).
  * The program (`portcullis_amd junc`), bench.py and the multi-GPU ranks all plan with this one function: the reference hands every target
  * to its thread pool (src/junction_builder.cc:236-247), the device gets chains that fill it. */
 int pjb_plan_groups(const int32_t *ref_len, const int32_t *tids, int32_t n_tids, int64_t max_bases, int32_t *group_of);

@@ -1,626 +1,8 @@
-// pjb_api.hip -- C ABI (include/portcullis_amd.h) over the HIP kernels.
-// One context = one HIP device + one stream + a grow-only scratch arena.
-#include "pjb_kernels.hip.h"
-#include "pjb_extra.hip.h"
-#include "pjb_deflate.hip.h"
-#include "pjb_ingest.hip.h"
+// pjb_api.hip -- C ABI (include/portcullis_amd.h) over the HIP kernels: contexts, genomes, batches, the kernel chains, rows.
+// One context = one HIP device + its streams + grow-only scratch.  (--extra / bamfilt / filt: pjb_extra_api.hip; BGZF and BAM: pjb_ingest_api.hip.)
+#define PJB_KERNELS_CHAIN 1
+#include "pjb_host.hip.h"
 
-#include <algorithm>
-#include <sys/mman.h>
-#include <thread>
-#include <chrono>
-#include <cstdarg>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <map>
-#include <memory>
-#include <mutex>
-#include <string>
-#include <thread>
-#include <vector>
-
-using namespace pjb;
-
-namespace {
-
-thread_local std::string g_create_error;
-// The message of the last failing call of THIS thread (pjb_last_error returns it): pjb_bam_begin / _piece / _pieces_done /
-// _inflate_done may run on other threads than the context's other calls, and a thread must neither read a string another
-// thread is reassigning nor report another thread's failure.
-thread_local std::string g_thread_error;
-thread_local const void *g_thread_error_ctx = nullptr; // the context the message belongs to (a thread may drive several)
-
-struct Buf {
-    void *p = nullptr;
-    size_t cap = 0;
-};
-
-struct Contig {
-    uint8_t *d = nullptr;
-    int64_t len = 0;
-    bool owned = false;
-    bool has_x = false;
-    bool present = false;
-    u32 *codes = nullptr; // packed 4-bit codes (k0_encode); nullptr when the contig is "exotic"
-    u32 *codes2 = nullptr; // 2-bit codes | exception bitmap (k0_encode2): behind the 4-bit codes, in their allocation
-    size_t d_cap = 0, codes_cap = 0; // sizes of the allocations (they go back to the context's genome pool)
-};
-
-// The bases and codes of a released contig are kept for the next upload (targets come longest first, so the next genome
-// fits): a hipMalloc / hipFree pair of 250 MB is ~10 ms on the thread that serves every target.
-void free_contig(Contig &g, std::vector<Buf> *pool = nullptr) {
-    auto give = [&](void *p, size_t cap) {
-        if (!p) return;
-        if (pool && cap > 0 && pool->size() < 12) {
-            Buf b;
-            b.p = p;
-            b.cap = cap;
-            pool->push_back(b);
-        } else
-            (void)hipFree(p);
-    };
-    if (g.owned) give(g.d, g.d_cap);
-    give(g.codes, g.codes_cap); // (codes2 lies in the same allocation)
-    g = Contig();
-}
-// device memory for a genome array: the smallest pooled buffer that fits, else a new one
-static void *genome_take(std::vector<Buf> &pool, size_t bytes, size_t &cap) {
-    int best = -1;
-    for (size_t k = 0; k < pool.size(); k++)
-        if (pool[k].cap >= bytes && (best < 0 || pool[k].cap < pool[(size_t)best].cap)) best = (int)k;
-    if (best >= 0) {
-        void *p = pool[(size_t)best].p;
-        cap = pool[(size_t)best].cap;
-        pool.erase(pool.begin() + best);
-        return p;
-    }
-    void *p = nullptr;
-    cap = bytes;
-    if (hipMalloc(&p, bytes) != hipSuccess) {
-        (void)hipGetLastError();
-        return nullptr;
-    }
-#ifdef PJB_DEBUG_ALLOC
-    fprintf(stderr, "[alloc] genome: %p .. %p (%zu bytes)\n", p, (void *)((char *)p + bytes), bytes);
-#endif
-    return p;
-}
-
-struct Slab { // device memory for the batches copied in by pjb_submit_batch; reused contig after contig
-    uint8_t *p = nullptr;
-    size_t cap = 0, used = 0;
-};
-
-// a contig that has received batches and is not finished yet; several may be open at once
-struct OpenContig {
-    std::vector<DevBatch> batches;
-    std::vector<int32_t> last_pos;  // pos of the last record of each batch (sortedness across batches)
-    std::vector<char> last_known;   // 0 = must be read back from the device (device-resident batch)
-    std::vector<Slab> slabs;        // device memory holding this contig's host-submitted batches
-    bool on_main_stream = false;    // some batch was produced by work queued on the main stream (host copies, BAM ingest)
-    size_t slab_hint = 0;           // what the target's records will take in all, roughly (device ingest: from the inflated bytes): its first slab
-                                    // is this large -- ONE hipMalloc per target instead of one per 128 MB (targets finished as groups keep their
-                                    // slabs until the group is collected: nothing comes back to the pool in between)
-};
-
-} // namespace
-
-// --extra: what is kept of a finished contig until pjb_extra_finish
-struct ExtraContig {
-    int32_t tid = -1;
-    int32_t len = 0;
-    u32 *cover = nullptr;      // per-base depth of the unspliced records (len + 2 entries), nullptr: none
-    bool has_unspliced = false;
-    size_t row_base = 0, n_rows = 0;
-    ExtraRow *xr = nullptr;    // n_rows entries (flanking counts now; m_sum / mm_score / coverage in phase 2)
-    u64 *pair_code = nullptr;  // per sorted pair: name code of its record
-    u32 *pair_row = nullptr;   //                  row (index into the context's row table)
-    u32 n_pairs = 0;
-    u64 *spl_codes = nullptr;  // name codes of the contig's spliced records
-    u32 n_spl = 0;
-    bool dense = false;        // went through the dense path: `cover` and the other pointers are allocations of their own
-    bool codes_in_table = false; // the spliced records' codes are in the name table already
-    SparseDepth sparse = {nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0}; // else: the records' spans (arena memory)
-};
-
-// what the targets of a PJB_FLAG_EXTRA context keep until pjb_extra_finish comes from a few large allocations that are
-// reused by the next file (pjb_clear_rows): no hipMalloc / hipFree per target
-struct XArena {
-    struct Chunk {
-        uint8_t *p;
-        size_t cap;
-    };
-    std::vector<Chunk> chunks;
-    size_t cur = 0, used = 0; // next byte: chunks[cur].p + used
-};
-
-// limits a contig is queued with (the kernels check them; see pjb_finish_contig_end)
-struct ContigLimits {
-    u32 pair_limit = 0, junc_limit = 0;
-    u32 list_cap = 0; // room of a sub-list of the read lists (0: gen_list_cap(pair_limit))
-    u32 sort_limit = 0; // junction ids the sort's digits are planned for (0: junc_limit).  The buffers hold junc_limit junctions -- a share of
-                        // the pair limit, generous --, but digits planned for it made the sort count and scan 2048-entry tables per tile
-                        // of 4096 pairs (61 MB a launch, round 4's PMC pass) where a chain has 2^17 junctions
-    KeyFmt kf;
-    bool dense = false; // sort ordered dense junction ids (K2d) instead of the full keys
-};
-
-// What two queued contigs must not share: control block, error word, list counters, batch descriptors and the device
-// copy of the rows (the rows stream still reads them while the next contig's kernels run), the published block on the
-// host, and the timing events.  Everything else is scratch of the main stream and protected by stream order.
-struct CtlSlot {
-    Buf cstats, err, gencount, batches, rows;
-    Buf x_q, x_spos, x_send, x_gapoff, x_zlist, x_scnt, x_codes; // --extra: scratch of the target in this slot
-    // what the first kernels of a contig (k1_count, k1_scan_tiles, k1_emit: the front stream) write and the rest of its
-    // chain reads: the next contig's first kernels run beside this contig's last ones
-    Buf tile_cnt, tile_stats, splidx, splpoff, splrec, tile_soff, chunk_tile;
-    Buf scan_parts;     // k1_scan_tiles: ScanPart[K1S_BLOCKS], zeroed once; scan_epoch tells one launch's parts from the last one's
-    u32 scan_epoch = 0;
-    Buf members; // groups: MemberStats[GROUP_MAX] | member_junc u32[GROUP_MAX] | tile_lo u32[GROUP_MAX + 1]
-    Buf okey, rec, g, jidbam; // the pairs (BAM order): intron keys, 32-byte records, [--extra: read ordinals], junction ids
-    hipEvent_t ev_k1 = nullptr;
-    hipEvent_t ev_xk1 = nullptr; // --extra: k1_count has left the records' spans (XOut) in the slot's scratch
-    // the rest of the chain's scratch, and its streams: the chains of the two slots run side by side (most kernels of a
-    // contig-sized chain are latency-bound and leave the chip half idle)
-    Buf total, bitmap, wrank, ends, firstid, key[2], idx[2], hist, hist_scan, hist_part, bintotal, scan_tiles;
-    Buf pagecnt, pagerank; // K2d: starts per page of the bitmap (all-zero at rest), their exclusive prefix
-    Buf jid, seg, runfirst, runstart, ent, entsum, frag, fragj, acc, ancl, ancr, jkey, genlist, masks;
-    bool dense_at_rest = false;
-    hipStream_t main = nullptr, side = nullptr; // chain; match statistics / entropy beside it
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_fork2 = nullptr, ev_join2 = nullptr;
-    uint8_t *pub = nullptr, *pub_dev = nullptr; // page-locked: what k6_rows_out (publish_chain) writes (host view, device view)
-    DevBatch *batches_pinned = nullptr;         // page-locked staging of the batch descriptors
-    size_t batches_pinned_cap = 0;
-    bool at_rest = false;                       // error word / list counters are in their rest state (k6_rows_out (publish_chain) restores it)
-    hipEvent_t ev[PJB_N_STAGES + 2] = {};
-    hipEvent_t ev_rows = nullptr, ev_done = nullptr;
-};
-// optional per-kernel event brackets: one pool per control slot (collected when that contig is), one for everything
-// launched outside a contig's chain (ingest, filters; collected when the timing table is read)
-struct EvPool {
-    std::vector<hipEvent_t> ev;
-    size_t used = 0;
-    std::vector<int> name; // kernel-name index per event pair
-};
-constexpr int MISC_POOL = PJB_MAX_QUEUED;
-
-// a target -- or a GROUP of targets finished as one chain (pjb_finish_group_begin) -- between _begin and _end
-struct Flight {
-    int32_t tid = -1;      // the first member (messages)
-    std::vector<int32_t> tids;   // members, in the order of their virtual offsets (a single target: one entry)
-    std::vector<int32_t> voff;   // offset of each member in the group's virtual sequence (GroupTab)
-    int64_t vlen = 0;            // length of the virtual sequence
-    std::vector<u32> tile_lo;    // first K1 tile of each member, + the total
-    std::vector<int64_t> m_reads; // reads of each member
-    std::vector<DevBatch> batches; // every member's batches, read ordinals and tile numbers running through the group
-    std::vector<int> batch_member; // member of each batch
-    int slot = 0;
-    bool queued = false;   // its kernels are on the streams
-    bool empty = false;    // no batches: nothing to queue
-    bool forked = false;   // k4b_generic went to the side stream (the contig's batches must outlive it)
-    ContigLimits lim;
-    int64_t n_reads = 0;
-    u32 n_tiles = 0;
-    int attempt = 0, list_attempt = 0;
-    int n_pass = 0;
-    const u32 *sidx = nullptr;
-    const u32 *jid_sorted = nullptr; // junction id of every sorted pair
-    Pairs pr;
-    // --extra: what the part that only needs the records (extra_pre) left for the part that needs the rows (extra_contig)
-    bool x_pre = false;
-    bool x_k1 = false; // k1_count classified the records (else: kx_classify_sparse)
-    int32_t *x_spos = nullptr, *x_send = nullptr;
-    u32 *x_gapoff = nullptr;
-    Gap *x_gaps = nullptr;
-    u32 x_gap_cap = 0;
-};
-
-constexpr size_t PJB_UP_EVENTS = 64;
-struct pjb_ctx {
-    pjb_config cfg;
-    hipStream_t stream = nullptr;  // service stream: uploads, host batches, BAM ingest, filters, extra metrics; a contig's chain runs
-                                   // on its slot's streams (CtlSlot::main / side)
-    hipStream_t stream3 = nullptr; // rows stream: k6_rows_out + k6_rows_out (publish_chain) of a contig, beside the next contig's first kernels
-    hipStream_t stream4 = nullptr; // header of the row mirror
-    hipEvent_t ev_front = nullptr; // service stream -> chain stream
-    CtlSlot sl[PJB_MAX_QUEUED];
-    bool slot_busy[PJB_MAX_QUEUED] = {};
-    Flight fl[PJB_MAX_QUEUED]; // FIFO: fl[0] is the oldest
-    int n_fl = 0;
-    int cur_slot = 0; // slot of the contig being queued / collected (extra)
-    EvPool pools[PJB_MAX_QUEUED + 1];
-    int cur_pool = MISC_POOL;
-    Buf b_cursor;     // RowCursor
-    // device ingest in pieces (pjb_bam_begin / _piece / _end)
-    std::map<int32_t, struct BamStage *> bam_stage;
-    // pjb_bam_begin / _piece / _pieces_done / _inflate_done may come from other threads than the context's other calls (the
-    // threads that read the file hand their pieces over themselves): bam_mu guards the staging state below
-    std::mutex bam_mu, err_mu;
-    std::vector<Buf> genome_pool; // bases / codes of released contigs (free_contig, genome_take)
-    std::vector<Buf> stage_pool;  // device buffers for staged BGZF bytes, reused target after target
-    // pjb_bam_piece starts a target's bgzf_inflate as soon as its last piece is on its way (own stream, own buffers), so that
-    // the inflates of several targets overlap each other and the copies: a launch takes ~50 ms whatever its size (a lane's
-    // 64 KB block), and most targets fill less than the chip
-    std::vector<Buf> out_pool, misc_pool;  // inflated bytes; block tables / status words / per-lane scratch
-    hipStream_t inf_streams[4] = {};
-    unsigned inf_next = 0;
-    hipStream_t stream_up = nullptr;
-    hipEvent_t ev_up = nullptr;
-    hipEvent_t up_events[64] = {};
-    int64_t up_ticket = 0, up_done = 0;
-    std::string err;
-    std::vector<int32_t> ref_len;
-    std::vector<Contig> contigs;
-    int32_t cur_tid = -1; // contig of the call in progress (error messages)
-    std::map<int32_t, OpenContig> open;
-    std::vector<Slab> slab_pool; // free slabs, reused contig after contig
-    // two page-locked staging buffers: pjb_submit_batch packs the caller's arrays into one of them
-    // (plain memcpy) and the DMA engine moves it to HBM while the caller decodes the next batch
-    uint8_t *stage[2] = {nullptr, nullptr};
-    size_t stage_cap[2] = {0, 0};
-    hipEvent_t stage_ev[2] = {nullptr, nullptr};
-    bool stage_busy[2] = {false, false};
-    unsigned stage_next = 0;
-    // junction rows live in a grow-only pinned host buffer so the D2H copy is a single DMA
-    pjb_junction_row *rows_pinned = nullptr;
-    pjb_junction_row *rows_table = nullptr;      // the same table in HBM (k6_rows_out appends; a DMA per contig fills rows_pinned)
-    bool rows_copy_pending = false;              // a DMA into rows_pinned is on stream4
-    // buffers with a rest state that the kernel chain itself restores (no per-contig memsets): error word / list
-    // counters (k6_rows_out (publish_chain); per slot), start bitmap / end slots (kd_reset).  false: set by a memset before use
-    int last_slot = 0; // slot of the contig collected last (pjb_collect_device)
-    int inflate_lanes = 512 * 64;                // lanes of one bgzf_inflate launch (2 workgroups x 256 CUs; set from the device at create)
-    bool side_stream = true;                     // k4b_generic / entropy beside the main stream (pjb_set_option("overlap", 0): everything on one stream)
-    bool dense_ids = true;                       // K2d (PJB_DENSE_IDS=0 sorts the full keys as round 1 did)
-    u32 junc_seen = 0;                           // most junctions a contig has had so far (junction limit of the next contig)
-    int lbits_seen = 18;                         // bits of the longest intron this context has met (key format of the next contig)
-    size_t rows_n = 0, rows_cap = 0;
-    size_t last_rows_n = 0; // rows of the contig finished last (still in b_rows)
-    uint8_t *mirror = nullptr; // caller's device buffer filled by every finish (header + rows)
-    size_t mirror_cap = 0;
-    int64_t *mirror_hdr = nullptr; // page-locked staging of the header
-    // the mirror accumulates: rows of every finish since the last pjb_set_row_mirror / pjb_clear_rows are appended and
-    // the header holds the folded counters (a rank that owns several contigs sends ONE slot per merge)
-    size_t mirror_rows = 0;
-    int64_t mirror_acc[5] = {0, 0, 0, INT32_MAX, 0}; // spliced, unspliced, sum_len, min_len, max_len
-    pjb_timing timing;
-    int radix_max_bits = 11;
-    double junc_per_read = 0;         // most junctions per read a chain of this context has had (the sort's digits of the next chain)
-    u32 sort_floor = 1u << 16;        // pjb_set_option("sort_floor", n): the least number of junction ids the sort's digits are planned for (tests: small)
-    u32 list_cap_forced = 0;          // pjb_set_option("list_cap", n): the read lists' first room (tests of the OVF_LISTS repeat)
-    bool k1_serial = true;            // PJB_K1_SERIAL=0: the chains' K1 stages side by side
-    hipEvent_t last_k1_ev = nullptr;  // the K1 stage of the chain queued last
-    int k1s_blocks_forced = 0;                   // PJB_K1S_BLOCKS (tests): k1_scan_tiles on this many blocks -- 1: every tile in one block's rounds
-    // optional per-kernel timing (the events live in the control slots)
-    bool ktime = false;
-    std::vector<std::string> knames;
-    std::vector<int64_t> kcount;
-    std::vector<double> kms;
-    std::vector<std::string> ktime_only; // if non-empty, only these kernel names are bracketed
-    // scratch
-    Buf *scan_tiles = nullptr; // run_scan's tile sums: the service buffer, or the slot's while a chain is being queued
-    Buf b_scan_tiles;
-    Buf b_inf_comp, b_inf_out, b_inf_blocks, b_inf_status, b_inf_scratch, b_inf_bitmap; // device-side BGZF inflate
-    Buf b_dfl_in, b_dfl_sym, b_dfl_slots, b_dfl_size, b_dfl_off, b_dfl_packed;           // device-side BGZF deflate
-    Buf b_bam_seg, b_bam_rec, b_bam_ctl;                                  // device-side BAM record parse
-    // --extra
-    bool extra = false;
-    std::vector<ExtraContig> xc;
-    std::map<int32_t, std::pair<u64 *, u32>> filter_keys; // bamfilt: passing junctions per target (device, sorted)
-    Buf f_pos, f_cigoff, f_cigar, f_codes;
-    Buf g_rows, g_models, g_refs, g_out, g_bad; // filt feature rows
-    Buf x_pos, x_endx, x_q, x_prefq, x_ce, x_bound, x_de, x_dropped, x_zlist, x_cnt, x_tabk, x_tabc, x_rs, x_re, x_rr, x_tileoff;
-    Buf x_xrall, x_tab; // x_tab: the name table (NameSlot), x_tab_slots slots, holding the codes of x_tab_n spliced records
-    size_t x_tab_slots = 0, x_tab_n = 0;
-    XArena xarena;
-    pjb_extra_row *xrows_pinned = nullptr;
-    size_t xrows_pinned_cap = 0;
-    bool extra_dense_only = false; // pjb_set_option("extra_dense", 1): the round-2 path for every target
-    Buf b_hasx, b_xtotal;
-    Buf b_fasta_raw; // pjb_upload_contig_fasta: the record's bytes as they are in the file
-};
-
-namespace {
-
-int fail(pjb_ctx *c, int code, const char *fmt, ...) {
-    char tmp[1024];
-    va_list ap;
-    va_start(ap, fmt);
-    vsnprintf(tmp, sizeof tmp, fmt, ap);
-    va_end(ap);
-    if (c) {
-        g_thread_error = tmp;
-        g_thread_error_ctx = c;
-        std::lock_guard<std::mutex> lk(c->err_mu);
-        c->err = tmp;
-    } else
-        g_create_error = tmp;
-    return code;
-}
-
-#define HIP_TRY(c, call)                                                                                   \
-    do {                                                                                                   \
-        hipError_t e_ = (call);                                                                            \
-        if (e_ != hipSuccess)                                                                              \
-            return fail((c), PJB_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, \
-                        __LINE__);                                                                         \
-    } while (0)
-
-#ifdef PJB_DEBUG_ALLOC // (debug builds: every device buffer with its range on stderr, so that a "Memory access fault ... on address" can be placed)
-#define ensure(c, b, bytes) ensure_named((c), (b), (bytes), #b, __LINE__)
-int ensure_named(pjb_ctx *c, Buf &b, size_t bytes, const char *what, int line);
-int ensure_impl(pjb_ctx *c, Buf &b, size_t bytes);
-int ensure_named(pjb_ctx *c, Buf &b, size_t bytes, const char *what, int line) {
-    const void *was = b.p;
-    const int rc = ensure_impl(c, b, bytes);
-    if (b.p != was) fprintf(stderr, "[alloc] %s (line %d): %p .. %p (%zu bytes, asked %zu)\n", what, line, b.p, (void *)((char *)b.p + b.cap), b.cap, bytes);
-    return rc;
-}
-int ensure_impl(pjb_ctx *c, Buf &b, size_t bytes) {
-#else
-int ensure(pjb_ctx *c, Buf &b, size_t bytes) {
-#endif
-    if (bytes <= b.cap && b.p) return PJB_OK;
-    if (b.p) HIP_TRY(c, hipFree(b.p));
-    b.p = nullptr;
-    b.cap = 0;
-    size_t want = std::max<size_t>(bytes + bytes / 4, 256);
-    hipError_t e = hipMalloc(&b.p, want);
-    if (e != hipSuccess) {
-        want = std::max<size_t>(bytes, 256);
-        e = hipMalloc(&b.p, want);
-        if (e != hipSuccess) return fail(c, PJB_ERR_NOMEM, "hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
-    }
-    b.cap = want;
-    // test hook (tests/test_gpu_poison.py): PJB_POISON=1 fills every new device buffer with a pattern.  Fresh device memory is
-    // usually zero, and a kernel that reads what nobody wrote gets away with it until the allocator hands out a used page
-    // (round 4: one run of `junc` in thirty died of it); with the pattern it fails every time.
-    static const bool poison = getenv("PJB_POISON") != nullptr && strcmp(getenv("PJB_POISON"), "0") != 0;
-    if (poison) {
-        (void)hipMemset(b.p, 0xCD, want);
-        (void)hipDeviceSynchronize();
-    }
-    return PJB_OK;
-}
-
-void release(Buf &b) {
-    if (b.p) (void)hipFree(b.p);
-    b.p = nullptr;
-    b.cap = 0;
-}
-
-const char *err_text(int code) {
-    switch (code) {
-    case PJB_ERR_BAD_XS: return "Unknown strand: XS tag is not one of + - ? .";
-    case PJB_ERR_NO_PRESENCE: return "Found an alignment that does not have a presence in the requested region";
-    case PJB_ERR_ZERO_LEN_OP: return "Can't extract cigar op sequence from query string when length has been calculated as 0";
-    case PJB_ERR_QUERY_RANGE: return "Can't extract cigar op sequence from query string";
-    case PJB_ERR_GENOME_RANGE: return "Can't extract cigar op sequence from extracted genome region";
-    case PJB_ERR_QREGION: return "Query region is outside the genomic region";
-    case PJB_ERR_ANCHOR_MISMATCH: return "Anchor region for query and genome are not the same size";
-    case PJB_ERR_SPLICE_SITE_LEN: return "Retrieved sequence for splice site of junction is not the expected length";
-    case PJB_ERR_ANCHOR_LEN: return "Retrieved sequence for anchor of junction is not the expected length";
-    case PJB_ERR_INTRON_FLANK_LEN: return "Retrieved sequence for intron region of junction is not the expected length";
-    case PJB_ERR_MIN_ANCHOR: return "The intron must lie inside its anchors (Intron::minAnchorLength)";
-    case PJB_ERR_HAMMING_LEN: return "Can't find hamming distance of strings that are not the same length";
-    case PJB_ERR_CLIP_RANGE: return "Soft clip longer than the read (basic_string::substr)";
-    case PJB_ERR_UNSORTED: return "Alignments are not coordinate sorted";
-    case PJB_ERR_DIVERGENT: return "Malformed CIGAR: padded query and genome walks disagree";
-    case PJB_ERR_NO_SEQ: return "A spliced alignment was submitted without its sequence";
-    default: return "unknown error";
-    }
-}
-
-int check_device_error(pjb_ctx *c, u64 e) {
-    if (e == ~0ull) return PJB_OK;
-    const int code = -(int)(e & 0xff);
-    const unsigned long long ord = e >> 8;
-    return fail(c, code, "%s (alignment ordinal %llu on target %d)", err_text(code), ord, c->cur_tid);
-}
-
-// host-side copy into page-locked staging memory, split over a few threads for large blocks
-void parallel_copy(void *dst, const void *src, size_t bytes) {
-    const size_t MIN_SLICE = (size_t)4 << 20;
-    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-    const size_t nthr = std::min<size_t>(std::min<size_t>(8, hw), bytes / MIN_SLICE);
-    if (nthr <= 1) {
-        memcpy(dst, src, bytes);
-        return;
-    }
-    std::vector<std::thread> th;
-    const size_t per = ((bytes + nthr - 1) / nthr + 63) & ~(size_t)63;
-    for (size_t t = 0; t < nthr; t++) {
-        const size_t a = std::min(bytes, per * t), b = std::min(bytes, a + per);
-        if (a < b) th.emplace_back([=] { memcpy((uint8_t *)dst + a, (const uint8_t *)src + a, b - a); });
-    }
-    for (auto &x : th) x.join();
-}
-
-int bits_of(uint64_t v) {
-    int b = 0;
-    while (v) {
-        b++;
-        v >>= 1;
-    }
-    return b;
-}
-
-// kernel launch with optional event bracketing -------------------------------------------------
-int kname_index(pjb_ctx *c, const char *name) {
-    for (size_t i = 0; i < c->knames.size(); i++)
-        if (c->knames[i] == name) return (int)i;
-    c->knames.push_back(name);
-    c->kcount.push_back(0);
-    c->kms.push_back(0.0);
-    return (int)c->knames.size() - 1;
-}
-void ev_begin(pjb_ctx *c, const char *name) {
-    EvPool &S = c->pools[c->cur_pool];
-    if (S.used + 2 > S.ev.size()) {
-        S.ev.resize(S.used + 2);
-        (void)hipEventCreate(&S.ev[S.used]);
-        (void)hipEventCreate(&S.ev[S.used + 1]);
-    }
-    S.name.push_back(kname_index(c, name));
-    (void)hipEventRecord(S.ev[S.used], c->stream);
-}
-void ev_end(pjb_ctx *c) {
-    EvPool &S = c->pools[c->cur_pool];
-    (void)hipEventRecord(S.ev[S.used + 1], c->stream);
-    S.used += 2;
-}
-void ev_collect(pjb_ctx *c, int pool) { // the pool's events must have completed
-    EvPool &S = c->pools[pool];
-    for (size_t k = 0; k < S.name.size(); k++) {
-        float ms = 0.f;
-        if (hipEventElapsedTime(&ms, S.ev[2 * k], S.ev[2 * k + 1]) == hipSuccess) {
-            c->kcount[(size_t)S.name[k]]++;
-            c->kms[(size_t)S.name[k]] += ms;
-        }
-    }
-    S.name.clear();
-    S.used = 0;
-}
-void ev_drop(pjb_ctx *c, int pool) {
-    c->pools[pool].name.clear();
-    c->pools[pool].used = 0;
-}
-bool ktime_wanted(pjb_ctx *c, const char *name) {
-    if (!c->ktime) return false;
-    if (c->ktime_only.empty()) return true;
-    for (auto &n : c->ktime_only)
-        if (n == name) return true;
-    return false;
-}
-// PJB_DEBUG_LAUNCH (a build flag, tools/build_variants.sh): every chain kernel is announced on stderr and waited for, so that the
-// last name before a "Memory access fault" is the kernel that faulted
-#ifdef PJB_DEBUG_LAUNCH
-#define PJB_LAUNCH_TRACE(c, name)                                   \
-    do {                                                            \
-        (void)hipStreamSynchronize((c)->stream);                    \
-        fprintf(stderr, "[launch] %s done\n", name);                \
-    } while (0)
-#define PJB_LAUNCH_ANNOUNCE(name) fprintf(stderr, "[launch] %s ...\n", name)
-#else
-#define PJB_LAUNCH_TRACE(c, name) do { } while (0)
-#define PJB_LAUNCH_ANNOUNCE(name) do { } while (0)
-#endif
-#define LAUNCH_LDS(c, name, kern, grid, block, lds_bytes, ...)                       \
-    do {                                                                            \
-        const bool timed_ = ktime_wanted((c), name);                                \
-        if (timed_) ev_begin((c), name);                                            \
-        PJB_LAUNCH_ANNOUNCE(name);                                                  \
-        hipLaunchKernelGGL(kern, grid, block, lds_bytes, (c)->stream, __VA_ARGS__); \
-        if (timed_) ev_end((c));                                                    \
-        HIP_TRY((c), hipGetLastError());                                            \
-        PJB_LAUNCH_TRACE(c, name);                                                  \
-    } while (0)
-#define LAUNCH(c, name, kern, grid, block, ...) LAUNCH_LDS(c, name, kern, grid, block, 0, __VA_ARGS__)
-
-// generic scan launchers ------------------------------------------------------------------------
-template <typename F, typename G>
-int run_scan(pjb_ctx *c, const char *tag, F f, G g, u64 n, u64 *d_total, const u32 *d_n = nullptr) {
-    const u32 nt = std::max<u32>(1, (u32)((n + SCAN_TILE - 1) / SCAN_TILE)); // (an empty input still gets its total written)
-    Buf &tiles = c->scan_tiles ? *c->scan_tiles : c->b_scan_tiles;
-    int rc = ensure(c, tiles, (size_t)nt * 8);
-    if (rc) return rc;
-    u64 *ts = (u64 *)tiles.p;
-    std::string t = tag;
-    LAUNCH(c, (t + "_reduce").c_str(), (scan_reduce_kernel<F>), dim3(nt), dim3(256), f, n, ts, d_n);
-    if (nt <= SCAN2_MAX_TILES) { // contig-sized: the apply blocks add up the tile sums before them themselves
-        LAUNCH(c, (t + "_apply").c_str(), (scan_apply2_kernel<F, G>), dim3(nt), dim3(256), f, g, n, (const u64 *)ts, d_n, d_total);
-        return PJB_OK;
-    }
-    LAUNCH(c, (t + "_tiles").c_str(), scan_tiles_kernel, dim3(1), dim3(1024), ts, nt, d_total);
-    LAUNCH(c, (t + "_apply").c_str(), (scan_apply_kernel<F, G>), dim3(nt), dim3(256), f, g, n, (const u64 *)ts, d_n);
-    return PJB_OK;
-}
-
-void *slab_alloc(pjb_ctx *c, OpenContig &oc, size_t bytes) {
-    bytes = (std::max<size_t>(bytes, 16) + 255) & ~(size_t)255;
-    for (auto &s : oc.slabs)
-        if (s.cap - s.used >= bytes) {
-            void *r = s.p + s.used;
-            s.used += bytes;
-            return r;
-        }
-    {
-        // (a target's first slab: the smallest pooled one that holds what the target is expected to take in all, else a new one of that size)
-        const size_t want = oc.slabs.empty() ? std::max(bytes, oc.slab_hint) : bytes;
-        long best = -1;
-        for (size_t k = 0; k < c->slab_pool.size(); k++)
-            if (c->slab_pool[k].cap >= want && (best < 0 || c->slab_pool[k].cap < c->slab_pool[(size_t)best].cap)) best = (long)k;
-        if (best >= 0) {
-            Slab s = c->slab_pool[(size_t)best];
-            c->slab_pool.erase(c->slab_pool.begin() + best);
-            s.used = bytes;
-            oc.slabs.push_back(s);
-            return s.p;
-        }
-    }
-    Slab s;
-    s.cap = std::max<size_t>(bytes, std::max<size_t>((size_t)128 << 20, oc.slabs.empty() ? oc.slab_hint : 0));
-    if (hipMalloc((void **)&s.p, s.cap) != hipSuccess) {
-        s.cap = bytes;
-        if (hipMalloc((void **)&s.p, s.cap) != hipSuccess) return nullptr;
-    }
-    s.used = bytes;
-    oc.slabs.push_back(s);
-#ifdef PJB_DEBUG_ALLOC
-    fprintf(stderr, "[alloc] slab: %p .. %p (%zu bytes)\n", (void *)s.p, (void *)(s.p + s.cap), s.cap);
-#endif
-    return s.p;
-}
-
-void extra_clear(pjb_ctx *c) {
-    for (auto &x : c->xc) {
-        if (!x.dense) continue; // (everything else is arena memory)
-        if (x.cover) (void)hipFree(x.cover);
-        if (x.xr) (void)hipFree(x.xr);
-        if (x.pair_code) (void)hipFree(x.pair_code);
-        if (x.pair_row) (void)hipFree(x.pair_row);
-        if (x.spl_codes) (void)hipFree(x.spl_codes);
-    }
-    c->xc.clear();
-    c->xarena.cur = c->xarena.used = 0;
-    c->x_tab_n = 0; // (the table is wiped when the next file's first codes arrive)
-}
-
-// `bytes` of arena memory (256-byte aligned), nullptr when the device is out of memory
-void *xarena_alloc(pjb_ctx *c, size_t bytes) {
-    XArena &A = c->xarena;
-    bytes = (std::max<size_t>(bytes, 16) + 255) & ~(size_t)255;
-    for (; A.cur < A.chunks.size(); A.cur++, A.used = 0)
-        if (A.chunks[A.cur].cap - A.used >= bytes) {
-            void *r = A.chunks[A.cur].p + A.used;
-            A.used += bytes;
-            return r;
-        }
-    XArena::Chunk ch;
-    ch.cap = std::max<size_t>(bytes, (size_t)256 << 20);
-    if (hipMalloc((void **)&ch.p, ch.cap) != hipSuccess) {
-        ch.cap = bytes;
-        if (hipMalloc((void **)&ch.p, ch.cap) != hipSuccess) return nullptr;
-    }
-    A.chunks.push_back(ch);
-    A.cur = A.chunks.size() - 1;
-    A.used = bytes;
-    return ch.p;
-}
-
-int close_contig(pjb_ctx *c, int32_t tid) {
-    auto it = c->open.find(tid);
-    if (it == c->open.end()) return PJB_OK;
-    for (auto &s : it->second.slabs) {
-        s.used = 0;
-        c->slab_pool.push_back(s);
-    }
-    c->open.erase(it);
-    return PJB_OK;
-}
-
-int upload_staged(pjb_ctx *c, void *dst, const uint8_t *src, size_t bytes); // (defined with the ingest code)
-} // namespace
 static int slot_init(pjb_ctx *c, int k);
 static void aux_streams(pjb_ctx *c) { // the rows stream and the row mirror's (15 - 20 ms each to create)
     if (!c->stream3) (void)hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking);
@@ -746,7 +128,7 @@ int pjb_create(pjb_ctx **out, const pjb_config *cfg) {
     const int dev = cfg->device;
     auto attributes = [dev] {
         (void)hipSetDevice(dev);
-        (void)hipFuncSetAttribute((const void *)bgzf_decode, hipFuncAttributeMaxDynamicSharedMemorySize, I3_LDS_BYTES);
+        ingest_kernel_attributes();
         // 12-bit digits need more dynamic LDS than the 64 KB a kernel gets without asking
         (void)hipFuncSetAttribute((const void *)rs_scatter<0, u64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rs_scatter_lds_bytes(RS_MAX_BITS));
         (void)hipFuncSetAttribute((const void *)rs_scatter<0, u32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rs_scatter_lds_bytes(RS_MAX_BITS, 4));
@@ -777,7 +159,7 @@ int pjb_create(pjb_ctx **out, const pjb_config *cfg) {
     if (!(cfg->flags & PJB_FLAG_NO_CHAINS))
         for (int k = 0; k < 4 && k < PJB_MAX_QUEUED; k++) (void)slot_init(c, k);
     cmark("chain slots");
-    c->inflate_lanes = std::max(1, n_cu) * (160 * 1024 / I3_LDS_BYTES) * 64;
+    c->inflate_lanes = std::max(1, n_cu) * (160 * 1024 / ingest_lds_bytes()) * 64;
     c->ktime = (cfg->flags & PJB_FLAG_KERNEL_TIMING) != 0;
     c->extra = (cfg->flags & PJB_FLAG_EXTRA) != 0;
     if (const char *s = getenv("PJB_K1_SERIAL")) c->k1_serial = atoi(s) != 0;
@@ -793,7 +175,6 @@ int pjb_create(pjb_ctx **out, const pjb_config *cfg) {
     return PJB_OK;
 }
 
-static void bam_stage_clear(pjb_ctx *c); // (defined with the staged ingest)
 
 void pjb_destroy(pjb_ctx *c) {
     if (!c) return;
@@ -1180,284 +561,8 @@ static int mirror_header_only(pjb_ctx *c, const pjb_region_result &R) {
 // --extra, per contig (calcExtraMetrics' per-target work, src/junction_builder.cc:293-312): the unspliced records'
 // per-base depth, the junctions' flanking alignment counts, and the name codes phase 2 needs.  Runs after the
 // contig's rows exist (b_rows, sidx, jid are still this contig's).
-constexpr u32 X_ZCAP = 1u << 20;
-static int extra_contig_dense(pjb_ctx *c, int32_t tid, std::vector<DevBatch> &batches, int64_t n_reads, u64 n_spliced, u32 P, u32 J,
-                              const u32 *sidx, const u32 *jid_sorted, const u32 *pair_g, size_t row_base, bool codes_in_table) {
-    hipStream_t st = c->stream;
-    const int32_t L = c->ref_len[(size_t)tid];
-    const size_t N = (size_t)n_reads;
-    ExtraContig X;
-    X.dense = true;
-    X.codes_in_table = codes_in_table;
-    X.tid = tid;
-    X.len = L;
-    X.row_base = row_base;
-    X.n_rows = J;
-    X.n_pairs = P;
-    int rc;
-    if ((rc = ensure(c, c->b_xtotal, 8))) return rc;
-    if ((rc = ensure(c, c->x_pos, N * 4 + 16))) return rc;
-    if ((rc = ensure(c, c->x_endx, N * 4 + 16))) return rc;
-    if ((rc = ensure(c, c->x_q, N + 16))) return rc;
-    if ((rc = ensure(c, c->x_prefq, (N + 1) * 4))) return rc;
-    if ((rc = ensure(c, c->x_ce, ((size_t)L + 2) * 4))) return rc;
-    if ((rc = ensure(c, c->x_zlist, (size_t)X_ZCAP * 4))) return rc;
-    if ((rc = ensure(c, c->x_cnt, sizeof(ExtraCounters)))) return rc;
-    struct Guard { // frees what this contig allocated unless it is handed over to the context
-        ExtraContig *x;
-        ~Guard() {
-            if (!x) return;
-            if (x->cover) (void)hipFree(x->cover);
-            if (x->xr) (void)hipFree(x->xr);
-            if (x->pair_code) (void)hipFree(x->pair_code);
-            if (x->pair_row) (void)hipFree(x->pair_row);
-            if (x->spl_codes) (void)hipFree(x->spl_codes);
-        }
-    } guard{&X};
-    if (hipMalloc((void **)&X.cover, ((size_t)L + 2) * 4) != hipSuccess) return fail(c, PJB_ERR_NOMEM, "extra: depth array of target %d", tid);
-    if (hipMalloc((void **)&X.spl_codes, std::max<size_t>((size_t)n_spliced, 1) * 8) != hipSuccess)
-        return fail(c, PJB_ERR_NOMEM, "extra: name codes of target %d", tid);
-    HIP_TRY(c, hipMemsetAsync(X.cover, 0, ((size_t)L + 2) * 4, st));
-    HIP_TRY(c, hipMemsetAsync(c->x_ce.p, 0, ((size_t)L + 2) * 4, st));
-    HIP_TRY(c, hipMemsetAsync((uint8_t *)c->x_q.p + N, 0, 1, st));
-    ExtraCounters hc;
-    memset(&hc, 0, sizeof hc);
-    hc.hot_first = 0xffffffffu;
-    HIP_TRY(c, hipMemcpyAsync(c->x_cnt.p, &hc, sizeof hc, hipMemcpyHostToDevice, st));
-    ExtraCounters *d_cnt = (ExtraCounters *)c->x_cnt.p;
-    int32_t *x_pos = (int32_t *)c->x_pos.p, *x_endx = (int32_t *)c->x_endx.p;
-    uint8_t *x_q = (uint8_t *)c->x_q.p;
-    u32 *prefq = (u32 *)c->x_prefq.p, *ce = (u32 *)c->x_ce.p;
-    for (auto &b : batches)
-        LAUNCH(c, "kx_classify", kx_classify, dim3((unsigned)((b.n + 255) / 256)), dim3(256), b, L, x_pos, x_endx, x_q, ce,
-               (int32_t *)X.cover, (u32 *)c->x_zlist.p, X_ZCAP, d_cnt);
-    {   // the spliced records' name codes, through the tile lists the contig's first kernels left in its slot
-        CtlSlot &S = c->sl[c->cur_slot];
-        u32 n_tiles = 0;
-        for (auto &b : batches) n_tiles = std::max<u32>(n_tiles, b.tile_base + (u32)((b.n + K1_TILE - 1) / K1_TILE));
-        if ((rc = ensure(c, c->x_tileoff, (size_t)n_tiles * 4 + 16))) return rc;
-        LAUNCH(c, "kx_spliced_offsets", kx_spliced_offsets, dim3(1), dim3(1024), (const TileStats *)S.tile_stats.p, n_tiles, (u32 *)c->x_tileoff.p, d_cnt);
-        for (auto &b : batches)
-            LAUNCH(c, "kx_spliced_codes", kx_spliced_codes, dim3((unsigned)((b.n + K1_TILE - 1) / K1_TILE)), dim3(256), b, (const TileStats *)S.tile_stats.p,
-                   (const u32 *)S.splidx.p, (const u32 *)c->x_tileoff.p, X.spl_codes);
-    }
-    if ((rc = run_scan(c, "kx_ends", ArrU32Fn{ce}, ExclusiveU32Sink{ce}, (u64)L + 2, (u64 *)c->b_xtotal.p))) return rc;
-    if ((rc = run_scan(c, "kx_unspl", ArrU8Fn{x_q}, ExclusiveU32Sink{prefq}, (u64)N + 1, (u64 *)c->b_xtotal.p))) return rc;
-    LAUNCH(c, "kx_cap_bound", kx_cap_bound, dim3((unsigned)((N + 255) / 256)), dim3(256), (const int32_t *)x_pos, (const uint8_t *)x_q,
-           (const u32 *)prefq, (const u32 *)ce, (u32)N, L, (u32 *)nullptr, d_cnt);
-    u32 n_unspl = 0;
-    HIP_TRY(c, hipMemcpyAsync(&hc, d_cnt, sizeof hc, hipMemcpyDeviceToHost, st));
-    HIP_TRY(c, hipMemcpyAsync(&n_unspl, prefq + N, 4, hipMemcpyDeviceToHost, st));
-    HIP_TRY(c, hipStreamSynchronize(st));
-    if (hc.n_zero > X_ZCAP)
-        return fail(c, PJB_ERR_ARG, "extra: target %d has %u mapped records without a reference span (limit %u)", tid, hc.n_zero, X_ZCAP);
-    if (hc.max_buffered + 2 > PLP_MAXCNT) { // the pileup's record cap may bite: replay it over the hot span
-        if ((rc = ensure(c, c->x_bound, N * 4 + 16))) return rc;
-        if ((rc = ensure(c, c->x_de, ((size_t)L + 2) * 4))) return rc;
-        if ((rc = ensure(c, c->x_dropped, N + 16))) return rc;
-        HIP_TRY(c, hipMemsetAsync(c->x_de.p, 0, ((size_t)L + 2) * 4, st));
-        HIP_TRY(c, hipMemsetAsync(c->x_dropped.p, 0, N + 16, st));
-        LAUNCH(c, "kx_cap_bound", kx_cap_bound, dim3((unsigned)((N + 255) / 256)), dim3(256), (const int32_t *)x_pos,
-               (const uint8_t *)x_q, (const u32 *)prefq, (const u32 *)ce, (u32)N, L, (u32 *)c->x_bound.p, d_cnt);
-        LAUNCH(c, "kx_cap_replay", kx_cap_replay, dim3(1), dim3(64), (const int32_t *)x_pos, (const int32_t *)x_endx, (const uint8_t *)x_q,
-               (const u32 *)c->x_bound.p, (u32)N, L, (u32 *)c->x_de.p, (uint8_t *)c->x_dropped.p, d_cnt);
-        for (auto &b : batches)
-            LAUNCH(c, "kx_undo_dropped", kx_undo_dropped, dim3((unsigned)((b.n + 255) / 256)), dim3(256), b, L,
-                   (const uint8_t *)c->x_dropped.p, (int32_t *)X.cover);
-    }
-    if ((rc = run_scan(c, "kx_depth", ArrI32Fn{(const int32_t *)X.cover}, InclusiveU32Sink{X.cover}, (u64)L + 1, (u64 *)c->b_xtotal.p)))
-        return rc;
-    X.has_unspliced = n_unspl > 0;
-    X.n_spl = hc.n_spliced;
-    if (J > 0) {
-        if (hipMalloc((void **)&X.xr, (size_t)J * sizeof(ExtraRow)) != hipSuccess) return fail(c, PJB_ERR_NOMEM, "extra: rows of target %d", tid);
-        HIP_TRY(c, hipMemsetAsync(X.xr, 0, (size_t)J * sizeof(ExtraRow), st));
-        LAUNCH(c, "kx_flank", kx_flank, dim3((J + 255) / 256), dim3(256), (const pjb_junction_row *)c->sl[c->cur_slot].rows.p, J, (const int32_t *)x_pos,
-               (u32)N, (const u32 *)prefq, (const u32 *)ce, L, (const u32 *)c->x_zlist.p, (const ExtraCounters *)d_cnt, X_ZCAP, X.xr);
-        if (hipMalloc((void **)&X.pair_code, (size_t)P * 8) != hipSuccess || hipMalloc((void **)&X.pair_row, (size_t)P * 4) != hipSuccess)
-            return fail(c, PJB_ERR_NOMEM, "extra: pair codes of target %d", tid);
-        LAUNCH(c, "kx_pair_codes", kx_pair_codes, dim3((P + 255) / 256), dim3(256), sidx, jid_sorted, pair_g,
-               (const DevBatch *)c->sl[c->cur_slot].batches.p, (int)batches.size(), P, (u32)row_base, X.pair_code, X.pair_row);
-    }
-    HIP_TRY(c, hipStreamSynchronize(st));
-    if (c->ktime) ev_collect(c, MISC_POOL);
-    c->xc.push_back(X);
-    guard.x = nullptr;
-    return PJB_OK;
-}
-
-#define XTRACE(what)                                                                                                              \
-    do {                                                                                                                          \
-        if (xtrace) {                                                                                                             \
-            (void)hipStreamSynchronize(st);                                                                                       \
-            const auto now_ = std::chrono::steady_clock::now();                                                                   \
-            fprintf(stderr, "[xtrace] %-28s %.3f ms\n", what, std::chrono::duration<double, std::milli>(now_ - xt0).count());     \
-            xt0 = now_;                                                                                                           \
-        }                                                                                                                         \
-    } while (0)
-// room in the name table for `add` more codes (load <= 1/2): a larger table takes over the old one's names
-static int name_table_reserve(pjb_ctx *c, size_t add) {
-    hipStream_t st = c->stream;
-    const size_t need = (c->x_tab_n + add) + (c->x_tab_n + add) / 2 + 1; // load <= 2/3
-    if (c->x_tab_n == 0 && c->x_tab_slots >= need) { // first codes of a file: wipe
-        if (add) HIP_TRY(c, hipMemsetAsync(c->x_tab.p, 0xff, c->x_tab_slots * sizeof(NameSlot), st));
-        return PJB_OK;
-    }
-    if (c->x_tab_slots >= need) return PJB_OK;
-    if (need > 0xfffffff0ull) return fail(c, PJB_ERR_ARG, "extra: more than 2^31 spliced records");
-    const size_t slots = std::min<size_t>(std::max<size_t>(2 * need + 16, 1024), 0xfffffff0ull); // (twice what is needed now: a file's targets arrive one by one)
-    Buf nb;
-    int rc = ensure(c, nb, slots * sizeof(NameSlot));
-    if (rc) return rc;
-    HIP_TRY(c, hipMemsetAsync(nb.p, 0xff, slots * sizeof(NameSlot), st));
-    if (c->x_tab_n)
-        LAUNCH(c, "kx_name_rehash", kx_name_rehash, dim3((unsigned)((c->x_tab_slots + 255) / 256)), dim3(256), (const NameSlot *)c->x_tab.p,
-               (u32)c->x_tab_slots, (NameSlot *)nb.p, (u32)slots);
-    if (c->x_tab.p) {
-        HIP_TRY(c, hipStreamSynchronize(st));
-        release(c->x_tab);
-    }
-    c->x_tab = nb;
-    c->x_tab_slots = slots;
-    return PJB_OK;
-}
-static int name_table_insert(pjb_ctx *c, const u64 *codes, u32 n) {
-    if (!n) return PJB_OK;
-    int rc = name_table_reserve(c, n);
-    if (rc) return rc;
-    LAUNCH(c, "kx_name_insert", kx_name_insert4, dim3((n + 1023) / 1024), dim3(256), codes, n, (NameSlot *)c->x_tab.p, (u32)c->x_tab_slots);
-    c->x_tab_n += n;
-    return PJB_OK;
-}
-
-// The same per-target work without an array of the target's length (pjb_extra.hip.h, "the sparse path"), in two parts.
-// extra_pre needs the records only: queued on the service stream when the target's chain is queued, it runs beside the
-// chains.  extra_contig needs the chain's rows and sorted pairs: queued when the chain is collected, beside the chains of
-// the targets queued after this one; one wait at its end.  A target where the pileup's cap may bite goes through
-// extra_contig_dense instead.
-static int extra_pre(pjb_ctx *c, Flight &f) {
-    if (f.x_pre || c->extra_dense_only || f.empty) return PJB_OK;
-    hipStream_t st = c->stream;
-    CtlSlot &S = c->sl[f.slot];
-    const size_t N = (size_t)f.n_reads;
-    int rc;
-    f.x_gap_cap = (u32)std::min<size_t>(N / 16 + 1024, 0x7fffffffu);
-    f.x_spos = (int32_t *)xarena_alloc(c, N * 4 + 16); // (compacted: the records with a span)
-    f.x_send = (int32_t *)xarena_alloc(c, N * 4 + 16);
-    f.x_gapoff = (u32 *)xarena_alloc(c, (N / 256 + 2) * 4);
-    f.x_gaps = (Gap *)xarena_alloc(c, (size_t)f.x_gap_cap * sizeof(Gap));
-    if (!f.x_spos || !f.x_send || !f.x_gapoff || !f.x_gaps)
-        return fail(c, PJB_ERR_NOMEM, "extra: no device memory for what target %d keeps (%zu records)", f.tid, N);
-    if ((rc = ensure(c, S.x_q, N + 16)) || (rc = ensure(c, S.x_spos, N * 4 + 16)) || (rc = ensure(c, S.x_send, N * 4 + 16)) ||
-        (rc = ensure(c, S.x_gapoff, (N / 256 + 2) * 4)) || (rc = ensure(c, S.x_zlist, (size_t)X_ZCAP * 4)) ||
-        (rc = ensure(c, S.x_scnt, sizeof(SparseCounters) + sizeof(ExtraCounters))))
-        return rc;
-    uint8_t *q = (uint8_t *)S.x_q.p;
-    SparseCounters *d_cnt = (SparseCounters *)S.x_scnt.p;
-    if (f.x_k1) HIP_TRY(c, hipStreamWaitEvent(st, S.ev_xk1, 0)); // (the chain's k1_count classified the records)
-    else {
-        HIP_TRY(c, hipMemsetAsync(q + N, 0, 1, st));
-        HIP_TRY(c, hipMemsetAsync(d_cnt, 0, sizeof(SparseCounters) + sizeof(ExtraCounters), st));
-        for (auto &b : f.batches)
-            LAUNCH(c, "kx_classify_sparse", kx_classify_sparse, dim3((unsigned)((b.n + 255) / 256)), dim3(256), b, (int32_t *)S.x_spos.p, (int32_t *)S.x_send.p,
-                   q, (u32 *)S.x_zlist.p, X_ZCAP, d_cnt);
-    }
-    if ((rc = run_scan(c, "kx_spans", SparseFn{q},
-                       SparseSink{f.x_spos, f.x_send, (u32 *)S.x_gapoff.p, f.x_gapoff, (const int32_t *)S.x_spos.p, (const int32_t *)S.x_send.p, q}, (u64)N + 1,
-                       &d_cnt->total)))
-        return rc;
-    for (auto &b : f.batches)
-        if (b.n > 0)
-        {
-            const u32 nblk = (u32)((((u64)b.base + (u64)b.n + 255) >> 8) - (b.base >> 8));
-            LAUNCH(c, "kx_gaps", kx_gaps, dim3(std::min<u32>(nblk, 2048)), dim3(256), b, (const uint8_t *)q, (u32)N, (const u32 *)S.x_gapoff.p, f.x_gaps,
-                   f.x_gap_cap, d_cnt, nblk);
-        }
-    if (N >= PLP_MAXCNT)
-        LAUNCH(c, "kx_cap_check", kx_cap_check, dim3((unsigned)((N + 255) / 256)), dim3(256), (const int32_t *)f.x_spos, d_cnt);
-    f.x_pre = true;
-    return PJB_OK;
-}
-
-static int extra_contig(pjb_ctx *c, Flight &f, int32_t tid, u64 n_spliced, u32 P, u32 J, size_t row_base) {
-    std::vector<DevBatch> &batches = f.batches;
-    if (c->extra_dense_only) return extra_contig_dense(c, tid, batches, f.n_reads, n_spliced, P, J, f.sidx, f.jid_sorted, f.pr.g, row_base, false);
-    int rc;
-    if ((rc = extra_pre(c, f))) return rc;
-    hipStream_t st = c->stream;
-    const int32_t L = c->ref_len[(size_t)tid];
-    CtlSlot &S = c->sl[f.slot];
-    ExtraContig X;
-    X.tid = tid;
-    X.len = L;
-    X.row_base = row_base;
-    X.n_rows = J;
-    X.n_pairs = P;
-    X.xr = J ? (ExtraRow *)xarena_alloc(c, (size_t)J * sizeof(ExtraRow)) : nullptr;
-    X.pair_code = J ? (u64 *)xarena_alloc(c, (size_t)P * 8 + 16) : nullptr;
-    X.pair_row = J ? (u32 *)xarena_alloc(c, (size_t)P * 4 + 16) : nullptr;
-    if (J && (!X.xr || !X.pair_code || !X.pair_row)) return fail(c, PJB_ERR_NOMEM, "extra: no device memory for the pairs of target %d", tid);
-    if ((rc = ensure(c, S.x_codes, std::max<size_t>((size_t)n_spliced, 1) * 8))) return rc;
-    const bool xtrace = getenv("PJB_XTRACE") != nullptr;
-    auto xt0 = std::chrono::steady_clock::now();
-    XTRACE("post: pre-part done");
-    SparseCounters *d_cnt = (SparseCounters *)S.x_scnt.p;
-    ExtraCounters *d_xcnt = (ExtraCounters *)(d_cnt + 1);
-    {   // the spliced records' name codes, through the tile lists the target's first kernels left in its slot -> the name table
-        u32 n_tiles = 0;
-        for (auto &b : batches) n_tiles = std::max<u32>(n_tiles, b.tile_base + (u32)((b.n + K1_TILE - 1) / K1_TILE));
-        if ((rc = ensure(c, c->x_tileoff, (size_t)n_tiles * 4 + 16))) return rc;
-        LAUNCH(c, "kx_spliced_offsets", kx_spliced_offsets, dim3(1), dim3(1024), (const TileStats *)S.tile_stats.p, n_tiles, (u32 *)c->x_tileoff.p, d_xcnt);
-        for (auto &b : batches)
-            LAUNCH(c, "kx_spliced_codes", kx_spliced_codes, dim3((unsigned)((b.n + K1_TILE - 1) / K1_TILE)), dim3(256), b, (const TileStats *)S.tile_stats.p,
-                   (const u32 *)S.splidx.p, (const u32 *)c->x_tileoff.p, (u64 *)S.x_codes.p);
-        XTRACE("post: codes");
-        if ((rc = name_table_insert(c, (const u64 *)S.x_codes.p, (u32)n_spliced))) return rc;
-        X.codes_in_table = true;
-        XTRACE("post: insert");
-    }
-    if (J > 0) {
-        HIP_TRY(c, hipMemsetAsync(X.xr, 0, (size_t)J * sizeof(ExtraRow), st));
-        LAUNCH(c, "kx_flank_sparse", kx_flank_sparse, dim3((J + 255) / 256), dim3(256), (const pjb_junction_row *)S.rows.p, J,
-               (const int32_t *)f.x_spos, (const int32_t *)f.x_send, L, (const u32 *)S.x_zlist.p, (const SparseCounters *)d_cnt, X_ZCAP, X.xr);
-        LAUNCH(c, "kx_pair_codes", kx_pair_codes, dim3((P + 255) / 256), dim3(256), f.sidx, f.jid_sorted, f.pr.g, (const DevBatch *)S.batches.p,
-               (int)batches.size(), P, (u32)row_base, X.pair_code, X.pair_row);
-    }
-    // one wait: the counters decide whether the sparse answer stands
-    SparseCounters &hc = *(SparseCounters *)(S.pub + PUB_XCNT_AT);
-    ExtraCounters &hx = *(ExtraCounters *)(S.pub + PUB_XCNT_AT + sizeof(SparseCounters));
-    XTRACE("post: flank + pair codes");
-    HIP_TRY(c, hipMemcpyAsync(&hc, d_cnt, sizeof(SparseCounters) + sizeof(ExtraCounters), hipMemcpyDeviceToHost, st));
-    HIP_TRY(c, hipStreamSynchronize(st));
-    XTRACE("post: counters");
-    if (c->ktime) ev_collect(c, MISC_POOL);
-    if (hc.n_zero > X_ZCAP)
-        return fail(c, PJB_ERR_ARG, "extra: target %d has %u mapped records without a reference span (limit %u)", tid, hc.n_zero, X_ZCAP);
-    if (hx.n_spliced != (u32)n_spliced)
-        return fail(c, PJB_ERR_STATE, "extra: target %d: %u spliced records in the tile lists, the chain counted %llu", tid, hx.n_spliced, (unsigned long long)n_spliced);
-    if (hc.need_dense) // the pileup's cap may bite (or the gap list is too small): the depth vector, as in round 2
-        return extra_contig_dense(c, tid, batches, f.n_reads, n_spliced, P, J, f.sidx, f.jid_sorted, f.pr.g, row_base, true);
-    X.has_unspliced = (u32)hc.total > 0;
-    X.n_spl = hx.n_spliced;
-    X.sparse = SparseDepth{f.x_spos, f.x_send, f.x_gaps, f.x_gapoff, (u32)hc.total, (u32)(hc.total >> 32), hc.max_span, hc.max_gap};
-    c->xc.push_back(X);
-    return PJB_OK;
-}
-
-// The device work of one contig, queued in one go.  The host does not learn a single count while the kernels run:
-// buffers and grids are sized from LIMITS (pair_limit, junc_limit, the key format kf), the kernels read the actual
-// counts from the control block in device memory (ContigStats) and stand still when a limit is exceeded.  Nothing
-// here waits for the device: the last kernels (rows stream) write rows and control block into page-locked host memory
-// and pjb_finish_contig_end waits for their event -- by which time the next contig may be queued behind this one.
 static void wait_flight(pjb_ctx *c, Flight &f);
 
-// the host row table is complete up to rows_n
-static int rows_sync(pjb_ctx *c) {
-    if (!c->rows_copy_pending) return PJB_OK;
-    HIP_TRY(c, hipStreamSynchronize(c->stream4));
-    c->rows_copy_pending = false;
-    return PJB_OK;
-}
 
 // rows of the contigs collected so far plus the most the queued ones can add
 static size_t rows_upper_bound(const pjb_ctx *c) {
@@ -2584,195 +1689,6 @@ int pjb_clear_rows(pjb_ctx *c) {
     return PJB_OK;
 }
 
-int pjb_extra_finish(pjb_ctx *c, const pjb_extra_row **rows_out, int64_t *n_out) {
-    if (!c || !rows_out || !n_out) return PJB_ERR_ARG;
-    const bool xtrace = getenv("PJB_XTRACE") != nullptr;
-    auto xt0 = std::chrono::steady_clock::now();
-    if (!c->extra) return fail(c, PJB_ERR_STATE, "pjb_extra_finish: the context was not created with PJB_FLAG_EXTRA");
-    if (!c->open.empty()) return fail(c, PJB_ERR_STATE, "pjb_extra_finish: target %d is still open", c->open.begin()->first);
-    if (c->n_fl) return fail(c, PJB_ERR_STATE, "pjb_extra_finish: target %d is still queued", c->fl[0].tid);
-    HIP_TRY(c, hipSetDevice(c->cfg.device));
-    hipStream_t st = c->stream;
-    int rc;
-    const size_t Jall = c->rows_n;
-    *rows_out = c->xrows_pinned;
-    *n_out = (int64_t)Jall;
-    if (Jall == 0) return PJB_OK;
-    if (Jall > c->xrows_pinned_cap) {
-        if (c->xrows_pinned) (void)hipHostFree(c->xrows_pinned);
-        c->xrows_pinned = nullptr;
-        c->xrows_pinned_cap = 0;
-        const size_t cap = Jall + Jall / 4 + 1024;
-        HIP_TRY(c, hipHostMalloc((void **)&c->xrows_pinned, cap * sizeof(pjb_extra_row), hipHostMallocDefault));
-        c->xrows_pinned_cap = cap;
-    }
-    *rows_out = c->xrows_pinned;
-    // every target's flanking counts into one table, parallel to the row table in HBM (which the kernels below read)
-    if ((rc = ensure(c, c->x_xrall, Jall * (sizeof(ExtraRow) + sizeof(pjb_extra_row))))) return rc;
-    ExtraRow *xr = (ExtraRow *)c->x_xrall.p;
-    pjb_extra_row *xout = (pjb_extra_row *)(xr + Jall);
-    HIP_TRY(c, hipMemsetAsync(xr, 0, Jall * sizeof(ExtraRow), st));
-    for (auto &x : c->xc)
-        if (x.n_rows) HIP_TRY(c, hipMemcpyAsync(xr + x.row_base, x.xr, x.n_rows * sizeof(ExtraRow), hipMemcpyDeviceToDevice, st));
-    XTRACE("finish: memset + copies");
-    // ---- splicedAlignmentMap over every spliced record of the file (src/junction_builder.cc:168-176): the targets' codes went
-    // into the table as the targets were collected (a target of the dense path: now)
-    for (auto &x : c->xc)
-        if (!x.codes_in_table) {
-            if ((rc = name_table_insert(c, (const u64 *)x.spl_codes, x.n_spl))) return rc;
-            x.codes_in_table = true;
-        }
-    if (c->x_tab_n)
-        for (auto &x : c->xc)
-            if (x.n_pairs && x.n_rows)
-                LAUNCH(c, "kx_name_sum", kx_name_sum, dim3((x.n_pairs + 1023) / 1024), dim3(256), (const u64 *)x.pair_code, (const u32 *)x.pair_row,
-                       x.n_pairs, (const NameSlot *)c->x_tab.p, (u32)c->x_tab_slots, xr);
-    // ---- JunctionSystem::calcCoverage (lib/src/junction_system.cc:231-242).  DepthParser::loadNextBatch
-    // (lib/src/depth_parser.cc:112-164) returns the vector of the target it started in, but by then `last`
-    // names the target the pileup has moved on to, and getCurrentRefIndex() selects THAT target's junctions:
-    // every batch is applied to the junctions of the next target that has unspliced records; only the final
-    // batch (the pileup ended inside it) meets its own junctions, after they were first given the previous
-    // target's.  Targets without unspliced records never appear.
-    XTRACE("finish: name sums");
-    std::vector<const ExtraContig *> T;
-    for (auto &x : c->xc)
-        if (x.has_unspliced) T.push_back(&x);
-    std::sort(T.begin(), T.end(), [](const ExtraContig *a, const ExtraContig *b) { return a->tid < b->tid; });
-    const pjb_junction_row *rows = c->rows_table;
-    for (size_t k = 0; k < T.size(); k++) {
-        const ExtraContig &x = *T[k];
-        if (!x.n_rows) continue;
-        const ExtraContig *src = (k + 1 == T.size()) ? &x : (k > 0 ? T[k - 1] : nullptr);
-        if (!src) continue; // the first target's junctions are never visited (unless it is also the last)
-        if (src->dense)
-            LAUNCH(c, "kx_coverage", kx_coverage, dim3((unsigned)((x.n_rows + 255) / 256)), dim3(256), rows, (u32)x.row_base, (u32)x.n_rows,
-                   (const u32 *)src->cover, src->len, xr);
-        else
-            LAUNCH(c, "kx_coverage_sparse", kx_coverage_sparse, dim3((unsigned)((x.n_rows + 255) / 256)), dim3(256), rows, (u32)x.row_base,
-                   (u32)x.n_rows, src->sparse, src->len, xr);
-    }
-    XTRACE("finish: coverage");
-    LAUNCH(c, "kx_rows_out", kx_rows_out, dim3((unsigned)((Jall + 255) / 256)), dim3(256), rows, (const ExtraRow *)xr, (u32)Jall, xout);
-    XTRACE("finish: rows_out");
-    HIP_TRY(c, hipMemcpyAsync(c->xrows_pinned, xout, Jall * sizeof(pjb_extra_row), hipMemcpyDeviceToHost, st));
-    HIP_TRY(c, hipStreamSynchronize(st));
-    XTRACE("finish: D2H");
-    if (c->ktime) ev_collect(c, MISC_POOL);
-    return PJB_OK;
-}
-
-int pjb_filter_set_junctions(pjb_ctx *c, int32_t tid, const uint64_t *sorted_keys, int64_t n_keys) {
-    if (!c) return PJB_ERR_ARG;
-    if (tid < 0 || n_keys < 0 || n_keys > 0xfffffff0ll || (n_keys > 0 && !sorted_keys))
-        return fail(c, PJB_ERR_ARG, "pjb_filter_set_junctions: bad arguments (tid %d)", tid);
-    for (int64_t i = 1; i < n_keys; i++)
-        if (sorted_keys[i - 1] >= sorted_keys[i]) return fail(c, PJB_ERR_ARG, "pjb_filter_set_junctions: keys must be strictly ascending");
-    HIP_TRY(c, hipSetDevice(c->cfg.device));
-    auto it = c->filter_keys.find(tid);
-    if (it != c->filter_keys.end()) {
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
-        if (it->second.first) (void)hipFree(it->second.first);
-        c->filter_keys.erase(it);
-    }
-    u64 *d = nullptr;
-    if (n_keys) {
-        if (hipMalloc((void **)&d, (size_t)n_keys * 8) != hipSuccess) return fail(c, PJB_ERR_NOMEM, "pjb_filter_set_junctions: %lld keys", (long long)n_keys);
-        hipError_t e = hipMemcpy(d, sorted_keys, (size_t)n_keys * 8, hipMemcpyHostToDevice);
-        if (e != hipSuccess) {
-            (void)hipFree(d);
-            return fail(c, PJB_ERR_HIP, "pjb_filter_set_junctions: %s", hipGetErrorString(e));
-        }
-    }
-    c->filter_keys[tid] = std::make_pair(d, (u32)n_keys);
-    return PJB_OK;
-}
-
-int pjb_filter_batch(pjb_ctx *c, int32_t tid, const pjb_batch *b, int32_t clip_mode, uint8_t *codes_out) {
-    if (!c) return PJB_ERR_ARG;
-    if (!b || b->n_reads < 0 || (b->n_reads > 0 && (!b->pos || !b->cig_off || !b->cigar || !codes_out)))
-        return fail(c, PJB_ERR_ARG, "pjb_filter_batch: bad batch");
-    if (clip_mode < PJB_CLIP_HARD || clip_mode > PJB_CLIP_COMPLETE) return fail(c, PJB_ERR_ARG, "pjb_filter_batch: bad clip mode %d", clip_mode);
-    if (b->n_reads == 0) return PJB_OK;
-    if (b->n_reads > 0xfffffff0ll) return fail(c, PJB_ERR_ARG, "pjb_filter_batch: batch too large");
-    HIP_TRY(c, hipSetDevice(c->cfg.device));
-    hipStream_t st = c->stream;
-    const size_t n = (size_t)b->n_reads, n_ops = b->cig_off[n];
-    int rc;
-    if ((rc = ensure(c, c->f_pos, n * 4))) return rc;
-    if ((rc = ensure(c, c->f_cigoff, (n + 1) * 4))) return rc;
-    if ((rc = ensure(c, c->f_cigar, n_ops * 4 + 16))) return rc;
-    if ((rc = ensure(c, c->f_codes, n + 16))) return rc;
-    HIP_TRY(c, hipMemcpyAsync(c->f_pos.p, b->pos, n * 4, hipMemcpyHostToDevice, st));
-    HIP_TRY(c, hipMemcpyAsync(c->f_cigoff.p, b->cig_off, (n + 1) * 4, hipMemcpyHostToDevice, st));
-    if (n_ops) HIP_TRY(c, hipMemcpyAsync(c->f_cigar.p, b->cigar, n_ops * 4, hipMemcpyHostToDevice, st));
-    const u64 *keys = nullptr;
-    u32 n_keys = 0;
-    auto it = c->filter_keys.find(tid);
-    if (it != c->filter_keys.end()) {
-        keys = it->second.first;
-        n_keys = it->second.second;
-    }
-    LAUNCH(c, "kf_filter", kf_filter, dim3((unsigned)((n + 255) / 256)), dim3(256), (const int32_t *)c->f_pos.p, (const u32 *)c->f_cigoff.p,
-           (const u32 *)c->f_cigar.p, (u32)n, keys, n_keys, (int)clip_mode, (uint8_t *)c->f_codes.p);
-    HIP_TRY(c, hipMemcpyAsync(codes_out, c->f_codes.p, n, hipMemcpyDeviceToHost, st));
-    HIP_TRY(c, hipStreamSynchronize(st));
-    if (c->ktime) ev_collect(c, MISC_POOL);
-    return PJB_OK;
-}
-
-int pjb_filt_features(pjb_ctx *c, const pjb_junction_row *rows, int64_t n_rows, double mean_read_length, uint32_t l95,
-                      const pjb_markov_models *models, double *features_out) {
-    if (!c) return PJB_ERR_ARG;
-    if (n_rows < 0 || (n_rows > 0 && (!rows || !features_out)) || !models || n_rows > 0xfffffff0ll)
-        return fail(c, PJB_ERR_ARG, "pjb_filt_features: bad arguments");
-    if (n_rows == 0) return PJB_OK;
-    HIP_TRY(c, hipSetDevice(c->cfg.device));
-    hipStream_t st = c->stream;
-    const size_t n = (size_t)n_rows;
-    int rc;
-    if ((rc = ensure(c, c->g_rows, n * sizeof(pjb_junction_row)))) return rc;
-    if ((rc = ensure(c, c->g_models, ((size_t)6 * PJB_KMER_TABLE + 2 * PJB_PW_LEN * 5) * sizeof(double)))) return rc;
-    if ((rc = ensure(c, c->g_refs, std::max<size_t>(c->contigs.size(), 1) * sizeof(GenomeRef)))) return rc;
-    if ((rc = ensure(c, c->g_out, n * PJB_N_FEATURES * sizeof(double)))) return rc;
-    if ((rc = ensure(c, c->g_bad, sizeof(int)))) return rc;
-    HIP_TRY(c, hipMemcpyAsync(c->g_rows.p, rows, n * sizeof(pjb_junction_row), hipMemcpyHostToDevice, st));
-    DevModels M;
-    memset(&M, 0, sizeof M);
-    double *dm = (double *)c->g_models.p;
-    const double *src[8] = {models->exon, models->intron, models->donor_t, models->donor_f, models->acceptor_t, models->acceptor_f,
-                            models->donor_pw, models->acceptor_pw};
-    const double **dst[8] = {&M.exon, &M.intron, &M.don_t, &M.don_f, &M.acc_t, &M.acc_f, &M.don_pw, &M.acc_pw};
-    size_t at = 0;
-    for (int k = 0; k < 8; k++) {
-        const size_t cnt = k < 6 ? (size_t)PJB_KMER_TABLE : (size_t)PJB_PW_LEN * 5;
-        if (src[k]) {
-            HIP_TRY(c, hipMemcpyAsync(dm + at, src[k], cnt * sizeof(double), hipMemcpyHostToDevice, st));
-            *dst[k] = dm + at;
-        }
-        at += cnt;
-    }
-    M.exon_size = models->exon ? models->exon_size : 0;
-    M.intron_size = models->intron ? models->intron_size : 0;
-    M.don_pw_size = models->donor_pw ? models->donor_pw_size : 0;
-    M.acc_pw_size = models->acceptor_pw ? models->acceptor_pw_size : 0;
-    std::vector<GenomeRef> refs(std::max<size_t>(c->contigs.size(), 1));
-    for (size_t t = 0; t < c->contigs.size(); t++) {
-        refs[t].d = c->contigs[t].present ? c->contigs[t].d : nullptr;
-        refs[t].len = (int32_t)c->contigs[t].len;
-    }
-    HIP_TRY(c, hipMemcpyAsync(c->g_refs.p, refs.data(), refs.size() * sizeof(GenomeRef), hipMemcpyHostToDevice, st));
-    HIP_TRY(c, hipMemsetAsync(c->g_bad.p, 0, sizeof(int), st));
-    LAUNCH(c, "kg_features", kg_features, dim3((unsigned)((n + 255) / 256)), dim3(256), (const pjb_junction_row *)c->g_rows.p, (u32)n,
-           (const GenomeRef *)c->g_refs.p, (int)c->contigs.size(), M, mean_read_length, (u32)l95, (double *)c->g_out.p, (int *)c->g_bad.p);
-    int bad = 0;
-    HIP_TRY(c, hipMemcpyAsync(features_out, c->g_out.p, n * PJB_N_FEATURES * sizeof(double), hipMemcpyDeviceToHost, st));
-    HIP_TRY(c, hipMemcpyAsync(&bad, c->g_bad.p, sizeof(int), hipMemcpyDeviceToHost, st));
-    HIP_TRY(c, hipStreamSynchronize(st));
-    if (c->ktime) ev_collect(c, MISC_POOL);
-    if (bad) return fail(c, PJB_ERR_STATE, "pjb_filt_features: a junction lies on a target whose genome was not uploaded");
-    return PJB_OK;
-}
-
 int pjb_get_kernel_timing(const pjb_ctx *c, pjb_kernel_time *out, int32_t cap, int32_t *n) {
     if (!c || !n) return PJB_ERR_ARG;
     *n = (int32_t)c->knames.size();
@@ -2827,755 +1743,3 @@ int pjb_get_timing(const pjb_ctx *c, pjb_timing *out) {
 }
 
 } // extern "C"
-
-// ---- device-side ingest ---------------------------------------------------------------------------
-namespace {
-const char *inf_text(int code) {
-    switch (code) {
-    case INF_ERR_BTYPE: return "reserved DEFLATE block type";
-    case INF_ERR_STORED: return "stored block length check failed";
-    case INF_ERR_CODELENS: return "invalid code length set";
-    case INF_ERR_CODE: return "invalid Huffman code";
-    case INF_ERR_DIST: return "match distance before the start of the block";
-    case INF_ERR_OVERRUN: return "block inflates or reads past its declared size";
-    case INF_ERR_SIZE: return "block inflates to fewer bytes than its ISIZE";
-    default: return "bad block";
-    }
-}
-
-// hop over the BGZF block headers (bgzf.c:348-356 check_header, BSIZE from the BC extra subfield)
-int scan_bgzf(pjb_ctx *c, const uint8_t *comp, int64_t n, std::vector<InfBlock> &blocks, int64_t &total_out) {
-    int64_t off = 0;
-    total_out = 0;
-    while (off < n) {
-        if (off + 18 > n) return fail(c, PJB_ERR_BGZF, "truncated BGZF block header at byte %lld", (long long)off);
-        const uint8_t *h = comp + off;
-        if (h[0] != 31 || h[1] != 139 || h[2] != 8 || !(h[3] & 4))
-            return fail(c, PJB_ERR_BGZF, "not a BGZF block header at byte %lld", (long long)off);
-        const uint32_t xlen = h[10] | (uint32_t)h[11] << 8;
-        if (off + 12 + xlen > n) return fail(c, PJB_ERR_BGZF, "truncated BGZF extra field at byte %lld", (long long)off);
-        int64_t bsize = -1;
-        for (uint32_t x = 0; x + 4 <= xlen;) {
-            const uint8_t *f = h + 12 + x;
-            const uint32_t slen = f[2] | (uint32_t)f[3] << 8;
-            if (f[0] == 'B' && f[1] == 'C' && slen == 2 && x + 6 <= xlen) bsize = (int64_t)(f[4] | (uint32_t)f[5] << 8) + 1;
-            x += 4 + slen;
-        }
-        if (bsize < 0) return fail(c, PJB_ERR_BGZF, "BGZF block at byte %lld has no BC field", (long long)off);
-        if (bsize < (int64_t)xlen + 20 || off + bsize > n)
-            return fail(c, PJB_ERR_BGZF, "BGZF block at byte %lld has an impossible size %lld", (long long)off, (long long)bsize);
-        const uint8_t *foot = comp + off + bsize - 8;
-        const uint32_t isize = foot[4] | (uint32_t)foot[5] << 8 | (uint32_t)foot[6] << 16 | (uint32_t)foot[7] << 24;
-        if (isize > 65536u) return fail(c, PJB_ERR_BGZF, "BGZF block at byte %lld declares %u inflated bytes", (long long)off, isize);
-        InfBlock b;
-        b.in_off = (iu64)(off + 12 + xlen);
-        b.in_len = (iu32)(bsize - xlen - 20);
-        b.out_off = (iu64)total_out;
-        b.out_len = isize;
-        blocks.push_back(b);
-        total_out += isize;
-        off += bsize;
-    }
-    return PJB_OK;
-}
-
-// pageable host memory -> device through the two page-locked staging buffers: a few threads memcpy a
-// piece into one buffer while the DMA engine drains the other
-int upload_staged(pjb_ctx *c, void *dst, const uint8_t *src, size_t bytes) {
-    const size_t PIECE = (size_t)64 << 20;
-    for (size_t off = 0; off < bytes; off += PIECE) {
-        const size_t nb = std::min(PIECE, bytes - off);
-        const unsigned si = c->stage_next++ & 1u;
-        if (c->stage_busy[si]) {
-            HIP_TRY(c, hipEventSynchronize(c->stage_ev[si]));
-            c->stage_busy[si] = false;
-        }
-        if (c->stage_cap[si] < nb) {
-            if (c->stage[si]) (void)hipHostFree(c->stage[si]);
-            c->stage[si] = nullptr;
-            c->stage_cap[si] = 0;
-            if (hipHostMalloc((void **)&c->stage[si], PIECE, hipHostMallocDefault) != hipSuccess)
-                return fail(c, PJB_ERR_NOMEM, "cannot allocate %zu bytes of page-locked staging memory", PIECE);
-            c->stage_cap[si] = PIECE;
-        }
-        if (!c->stage_ev[si]) HIP_TRY(c, hipEventCreateWithFlags(&c->stage_ev[si], hipEventDisableTiming));
-        parallel_copy(c->stage[si], src + off, nb);
-        HIP_TRY(c, hipMemcpyAsync((uint8_t *)dst + off, c->stage[si], nb, hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(c, hipEventRecord(c->stage_ev[si], c->stream));
-        c->stage_busy[si] = true;
-    }
-    return PJB_OK;
-}
-
-
-// comp already on the device (padded); blocks on the host
-// the status words of a finished bgzf_inflate (d_status[nb] = "some block failed")
-int inflate_status(pjb_ctx *c, const std::vector<InfBlock> &blocks, const int *d_status) {
-    const size_t nb = blocks.size();
-    int any = 0;
-    HIP_TRY(c, hipMemcpy(&any, d_status + nb, 4, hipMemcpyDeviceToHost));
-    if (!any) return PJB_OK;
-    std::vector<int> status(nb);
-    HIP_TRY(c, hipMemcpy(status.data(), d_status, nb * 4, hipMemcpyDeviceToHost));
-    for (size_t b = 0; b < nb; b++)
-        if (status[b])
-            return fail(c, PJB_ERR_BGZF, "BGZF block %zu (payload at byte %llu): %s", b, (unsigned long long)blocks[b].in_off, inf_text(status[b]));
-    return fail(c, PJB_ERR_BGZF, "BGZF inflate failed");
-}
-
-int inflate_on_device(pjb_ctx *c, const uint8_t *d_comp, const std::vector<InfBlock> &blocks, uint8_t *d_out) {
-    int rc;
-    const size_t nb = blocks.size();
-    if (nb == 0) return PJB_OK;
-    if ((rc = ensure(c, c->b_inf_blocks, nb * sizeof(InfBlock)))) return rc;
-    if ((rc = ensure(c, c->b_inf_status, nb * 4 + 16))) return rc;
-    // one launch: as many lanes as the chip holds at once (two 64-lane workgroups per CU: the tables' LDS), each taking
-    // block after block from a counter
-    size_t lanes = std::min<size_t>((nb + 63) / 64 * 64, (size_t)c->inflate_lanes);
-    if (const char *e = getenv("PJB_INF_BLOCKS_PER_LAUNCH")) lanes = std::min<size_t>((nb + 63) / 64 * 64, (size_t)std::max(64, atoi(e)) / 64 * 64); // tests: few lanes, long lists
-    if ((rc = ensure(c, c->b_inf_scratch, lanes * INF_SCRATCH_PER_LANE))) return rc;
-    hipStream_t st = c->stream;
-    HIP_TRY(c, hipMemcpyAsync(c->b_inf_blocks.p, blocks.data(), nb * sizeof(InfBlock), hipMemcpyHostToDevice, st));
-    int *d_status = (int *)c->b_inf_status.p;
-    int *d_any = d_status + nb;
-    iu32 *d_next = (iu32 *)(d_any + 1);
-    const iu32 ctl[2] = {0u, (iu32)lanes};
-    HIP_TRY(c, hipMemcpyAsync(d_any, ctl, 8, hipMemcpyHostToDevice, st));
-    {
-        // decode (lane per block: literals in place, a token + a bitmap bit per match), then the copies (wave per block)
-        if ((rc = ensure(c, c->b_inf_bitmap, nb * INF_BITMAP_WORDS * 8))) return rc;
-        HIP_TRY(c, hipMemsetAsync(c->b_inf_bitmap.p, 0, nb * INF_BITMAP_WORDS * 8, st));
-        LAUNCH_LDS(c, "bgzf_decode", bgzf_decode, dim3((unsigned)(lanes / 64)), dim3(64), I3_LDS_BYTES, d_comp, (const InfBlock *)c->b_inf_blocks.p, (iu32)nb,
-                   d_out, (uint8_t *)c->b_inf_scratch.p, d_status, d_any, d_next, (iu64 *)c->b_inf_bitmap.p, 8);
-        LAUNCH(c, "bgzf_resolve", bgzf_resolve, dim3((unsigned)((nb + 3) / 4)), dim3(256), (const InfBlock *)c->b_inf_blocks.p, (iu32)nb, d_out,
-               (const iu64 *)c->b_inf_bitmap.p, (const int *)d_status);
-    }
-    HIP_TRY(c, hipStreamSynchronize(st));
-    if (c->ktime) ev_collect(c, MISC_POOL);
-    return inflate_status(c, blocks, d_status);
-}
-} // namespace
-
-extern "C" int pjb_inflate_bgzf(pjb_ctx *c, const uint8_t *comp, int64_t comp_bytes, uint8_t *out, int64_t out_cap,
-                                int64_t *out_bytes) {
-    if (!c || !out_bytes || comp_bytes < 0 || (comp_bytes && !comp)) return fail(c, PJB_ERR_ARG, "inflate_bgzf: bad arguments");
-    HIP_TRY(c, hipSetDevice(c->cfg.device));
-    std::vector<InfBlock> blocks;
-    int64_t total = 0;
-    int rc = scan_bgzf(c, comp, comp_bytes, blocks, total);
-    if (rc) return rc;
-    *out_bytes = total;
-    if (total > out_cap) return fail(c, PJB_ERR_ARG, "inflate_bgzf: output needs %lld bytes, capacity is %lld", (long long)total, (long long)out_cap);
-    if (total == 0) return PJB_OK;
-    if (!out) return fail(c, PJB_ERR_ARG, "inflate_bgzf: no output buffer");
-    if ((rc = ensure(c, c->b_inf_comp, (size_t)comp_bytes + INF_PAD))) return rc;
-    if ((rc = ensure(c, c->b_inf_out, (size_t)total + 64))) return rc;
-    HIP_TRY(c, hipMemcpyAsync(c->b_inf_comp.p, comp, (size_t)comp_bytes, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipMemsetAsync((uint8_t *)c->b_inf_comp.p + comp_bytes, 0, INF_PAD, c->stream));
-    if ((rc = inflate_on_device(c, (const uint8_t *)c->b_inf_comp.p, blocks, (uint8_t *)c->b_inf_out.p))) return rc;
-    HIP_TRY(c, hipMemcpy(out, c->b_inf_out.p, (size_t)total, hipMemcpyDeviceToHost));
-    return PJB_OK;
-}
-
-// BGZF deflate on the device (pjb_deflate.hip.h): at most DFL_LAUNCH_BLOCKS blocks per launch (1 GB of symbol scratch)
-constexpr int64_t DFL_LAUNCH_BLOCKS = 4096;
-extern "C" int pjb_deflate_bgzf(pjb_ctx *c, const uint8_t *in, int64_t n_bytes, int32_t block_bytes, uint8_t *out, int64_t out_cap, int64_t *out_bytes,
-                                uint32_t *member_size) {
-    if (!c || !out_bytes || n_bytes < 0 || (n_bytes && (!in || !out))) return fail(c, PJB_ERR_ARG, "deflate_bgzf: bad arguments");
-    if (block_bytes < 4 || block_bytes > (int32_t)DFL_IN_MAX || (block_bytes & 3))
-        return fail(c, PJB_ERR_ARG, "deflate_bgzf: block_bytes must be a multiple of 4 between 4 and %u", DFL_IN_MAX);
-    *out_bytes = 0;
-    if (n_bytes == 0) return PJB_OK;
-    HIP_TRY(c, hipSetDevice(c->cfg.device));
-    hipStream_t st = c->stream;
-    const int64_t n_blocks = (n_bytes + block_bytes - 1) / block_bytes;
-    int rc;
-    std::vector<u32> sizes;
-    std::vector<iu64> offs;
-    int64_t written = 0;
-    for (int64_t b0 = 0; b0 < n_blocks; b0 += DFL_LAUNCH_BLOCKS) {
-        const int64_t nb = std::min<int64_t>(DFL_LAUNCH_BLOCKS, n_blocks - b0);
-        const int64_t in_off = b0 * block_bytes, in_len = std::min<int64_t>(n_bytes - in_off, nb * block_bytes);
-        if ((rc = ensure(c, c->b_dfl_in, (size_t)in_len + 64)) || (rc = ensure(c, c->b_dfl_sym, (size_t)nb * DFL_SYM_STRIDE * 4)) ||
-            (rc = ensure(c, c->b_dfl_slots, (size_t)nb * DFL_SLOT)) || (rc = ensure(c, c->b_dfl_size, (size_t)nb * 4)) ||
-            (rc = ensure(c, c->b_dfl_off, (size_t)nb * 8)))
-            return rc;
-        HIP_TRY(c, hipMemcpyAsync(c->b_dfl_in.p, in + in_off, (size_t)in_len, hipMemcpyHostToDevice, st));
-        LAUNCH(c, "bgzf_deflate", bgzf_deflate, dim3((unsigned)nb), dim3(64), (const uint8_t *)c->b_dfl_in.p, (iu64)in_len, (u32)block_bytes, (u32)nb,
-               (u32 *)c->b_dfl_sym.p, (uint8_t *)c->b_dfl_slots.p, (u32 *)c->b_dfl_size.p);
-        sizes.resize((size_t)nb);
-        HIP_TRY(c, hipMemcpyAsync(sizes.data(), c->b_dfl_size.p, (size_t)nb * 4, hipMemcpyDeviceToHost, st));
-        HIP_TRY(c, hipStreamSynchronize(st));
-        offs.resize((size_t)nb);
-        iu64 total = 0;
-        for (int64_t k = 0; k < nb; k++) {
-            if (sizes[(size_t)k] < 26 || sizes[(size_t)k] > 65536) return fail(c, PJB_ERR_STATE, "deflate_bgzf: block %lld came out with %u bytes", (long long)(b0 + k), sizes[(size_t)k]);
-            offs[(size_t)k] = total;
-            total += sizes[(size_t)k];
-            if (member_size) member_size[b0 + k] = sizes[(size_t)k];
-        }
-        if (written + (int64_t)total > out_cap)
-            return fail(c, PJB_ERR_ARG, "deflate_bgzf: the output needs more than %lld bytes", (long long)out_cap);
-        if ((rc = ensure(c, c->b_dfl_packed, (size_t)total + 64))) return rc;
-        HIP_TRY(c, hipMemcpyAsync(c->b_dfl_off.p, offs.data(), (size_t)nb * 8, hipMemcpyHostToDevice, st));
-        LAUNCH(c, "bgzf_pack", bgzf_pack, dim3((unsigned)nb), dim3(256), (const uint8_t *)c->b_dfl_slots.p, (const u32 *)c->b_dfl_size.p,
-               (const iu64 *)c->b_dfl_off.p, (u32)nb, (uint8_t *)c->b_dfl_packed.p);
-        HIP_TRY(c, hipMemcpyAsync(out + written, c->b_dfl_packed.p, (size_t)total, hipMemcpyDeviceToHost, st));
-        HIP_TRY(c, hipStreamSynchronize(st));
-        written += (int64_t)total;
-    }
-    *out_bytes = written;
-    if (c->ktime) ev_collect(c, MISC_POOL);
-    return PJB_OK;
-}
-
-static int ingest_parse(pjb_ctx *c, int32_t tid, OpenContig &oc, const uint8_t *d_out, size_t n_blocks, int64_t comp_bytes, int64_t total,
-                        int32_t first_uoffset, int64_t *n_records, double t_scan, double t_up, double t_inf);
-
-// the part of pjb_submit_bam behind the upload: `d_comp` holds the target's BGZF bytes (padded), `blocks` their layout
-static int ingest_staged(pjb_ctx *c, int32_t tid, OpenContig &oc, const uint8_t *d_comp, const std::vector<InfBlock> &blocks, int64_t comp_bytes,
-                         int64_t total, int32_t first_uoffset, int64_t *n_records, double t_scan, double t_up) {
-    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-    const double t0 = now();
-    int rc;
-    if ((rc = ensure(c, c->b_inf_out, (size_t)total + 64))) return rc;
-    HIP_TRY(c, hipMemsetAsync((uint8_t *)c->b_inf_out.p + total, 0, 64, c->stream));
-    if ((rc = inflate_on_device(c, d_comp, blocks, (uint8_t *)c->b_inf_out.p))) return rc;
-    return ingest_parse(c, tid, oc, (const uint8_t *)c->b_inf_out.p, blocks.size(), comp_bytes, total, first_uoffset, n_records, t_scan, t_up, now() - t0);
-}
-
-// the inflated bytes of one target's region (d_out, `total` of them followed by 64 zero bytes) -> the SoA batch of the target
-static int ingest_parse(pjb_ctx *c, int32_t tid, OpenContig &oc, const uint8_t *d_out, size_t n_blocks, int64_t comp_bytes, int64_t total,
-                        int32_t first_uoffset, int64_t *n_records, double t_scan, double t_up, double t_inf) {
-    const bool prof = getenv("PJB_PROFILE_HOST") != nullptr;
-    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-    double t0 = now(), t_walk;
-    hipStream_t st = c->stream;
-    int rc;
-    // ---- record boundaries
-    BamRegion R;
-    R.U = d_out;
-    R.total = (iu64)total;
-    R.first = (iu64)first_uoffset;
-    R.tid = tid;
-    R.ref_len = c->ref_len[(size_t)tid];
-    R.n_ref = (int32_t)c->ref_len.size();
-    const uint32_t n_seg = (uint32_t)(((iu64)total + BAM_SEG - 1) / BAM_SEG);
-    // seg_start u64 | seg_base u64 | land u64 | seg_n u32
-    if ((rc = ensure(c, c->b_bam_seg, (size_t)n_seg * 28 + 64))) return rc;
-    if ((rc = ensure(c, c->b_bam_ctl, 64))) return rc;
-    iu64 *seg_start = (iu64 *)c->b_bam_seg.p;
-    iu64 *seg_base = seg_start + n_seg;
-    iu64 *land = seg_base + n_seg;
-    iu32 *seg_n = (iu32 *)(land + n_seg);
-    iu32 *ctl = (iu32 *)c->b_bam_ctl.p; // [0..2] end / mismatch / bad segment, [4..5] u64 total of a scan
-    iu64 *d_total = (iu64 *)(ctl + 4);
-    HIP_TRY(c, hipMemsetAsync(ctl, 0xff, 16, st));
-    BamWalkOut O;
-    O.seg_n = seg_n;
-    O.land = land;
-    O.rec_off = nullptr;
-    O.seg_base = seg_base;
-    O.ctl = ctl;
-    LAUNCH(c, "bam_find_starts", bam_find_starts, dim3(n_seg), dim3(64), R, n_seg, seg_start);
-    if (const char *e = getenv("PJB_TEST_FALSE_START")) { // test hook: damage the guessed start of one segment
-        const uint32_t k = (uint32_t)atoi(e);
-        if (k > 0 && k < n_seg) {
-            iu64 v = 0;
-            HIP_TRY(c, hipMemcpyAsync(&v, seg_start + k, 8, hipMemcpyDeviceToHost, st));
-            HIP_TRY(c, hipStreamSynchronize(st));
-            if (v != BAM_NONE) {
-                v += 1;
-                HIP_TRY(c, hipMemcpyAsync(seg_start + k, &v, 8, hipMemcpyHostToDevice, st));
-                HIP_TRY(c, hipStreamSynchronize(st));
-            }
-        }
-    }
-    uint32_t h_ctl[8];
-    uint32_t end_seg = 0xffffffffu;
-    for (int attempt = 0;; attempt++) {
-        HIP_TRY(c, hipMemsetAsync(ctl, 0xff, 16, st));
-        HIP_TRY(c, hipMemsetAsync(ctl + 6, 0xff, 4, st));
-        LAUNCH(c, "bam_walk_count", bam_walk<false>, dim3((n_seg + 255) / 256), dim3(256), R, n_seg, (const iu64 *)seg_start, O);
-        HIP_TRY(c, hipMemcpyAsync(h_ctl, ctl, 32, hipMemcpyDeviceToHost, st));
-        HIP_TRY(c, hipStreamSynchronize(st));
-        end_seg = h_ctl[0];
-        if (h_ctl[2] != 0xffffffffu && h_ctl[2] <= end_seg && (h_ctl[1] == 0xffffffffu || h_ctl[2] <= h_ctl[1]))
-            return fail(c, PJB_ERR_BGZF, "Invalid BAM record layout on target %d (inflated offset %llu..)", tid,
-                        (unsigned long long)h_ctl[2] * BAM_SEG);
-        if (h_ctl[1] == 0xffffffffu || h_ctl[1] > end_seg) break; // every walk landed on the next start
-        // a guessed start was not a record boundary: replace it by the boundary the verified walk reached, walk again
-        if (attempt >= 16)
-            return fail(c, PJB_ERR_BGZF, "BAM record chain of target %d is inconsistent near inflated offset %llu", tid,
-                        (unsigned long long)h_ctl[1] * BAM_SEG);
-        LAUNCH(c, "bam_repair_start", bam_repair_start, dim3(1), dim3(1), seg_start, n_seg, h_ctl[1], (const iu64 *)land, (iu64)total, ctl);
-        HIP_TRY(c, hipMemcpyAsync(h_ctl, ctl, 16, hipMemcpyDeviceToHost, st));
-        HIP_TRY(c, hipStreamSynchronize(st));
-        if (h_ctl[3] != 0xffffffffu)
-            return fail(c, PJB_ERR_BGZF, "Invalid BAM record on target %d (inflated offset %llu..)", tid, (unsigned long long)h_ctl[3] * BAM_SEG);
-    }
-    // The data ends inside a record of this target and no record of another target (or past the target's end) was seen:
-    // the bytes handed over stop short of the target's last alignment (a stale index, a truncated file).  The reference
-    // fails on a truncated file too (bgzf_read / bam_read1); dropping the tail silently would change counts.
-    if (end_seg == 0xffffffffu && h_ctl[6] != 0xffffffffu)
-        return fail(c, PJB_ERR_BGZF, "the data for target %d ends inside an alignment record (inflated offset %llu..): truncated "
-                                     "file, or the index's span for the target is too short", tid, (unsigned long long)h_ctl[6] * BAM_SEG);
-    LAUNCH(c, "bam_trim_segments", bam_trim_segments, dim3((n_seg + 255) / 256), dim3(256), seg_n, n_seg, (const iu32 *)ctl);
-    if ((rc = run_scan(c, "bam_seg", SegCountFn{seg_n}, SegBaseSink{seg_base}, n_seg, d_total))) return rc;
-    HIP_TRY(c, hipMemcpyAsync(h_ctl, ctl, 24, hipMemcpyDeviceToHost, st));
-    HIP_TRY(c, hipStreamSynchronize(st));
-    t_walk = now() - t0;
-    t0 = now();
-    iu64 n64;
-    memcpy(&n64, &h_ctl[4], 8);
-    if (n64 == 0) return PJB_OK;
-    if (n64 >= 0xffffff00ull) return fail(c, PJB_ERR_ARG, "submit_bam: more than 2^32 alignments on one target are not supported");
-    const size_t n = (size_t)n64;
-    if ((rc = ensure(c, c->b_bam_rec, n * 8))) return rc;
-    O.rec_off = (iu64 *)c->b_bam_rec.p;
-    LAUNCH(c, "bam_walk_fill", bam_walk<true>, dim3((n_seg + 255) / 256), dim3(256), R, n_seg, (const iu64 *)seg_start, O);
-
-    // ---- SoA arrays in the target's slabs (same packing as a host-submitted batch)
-    // (150-base paired-end records: fields + operations + 4- and 2-bit bases of the spliced third are 0.28 of the inflated bytes)
-    if (oc.slabs.empty()) oc.slab_hint = (((size_t)total / 100 * 32) + ((size_t)32 << 20)) & ~(((size_t)1 << 20) - 1);
-    const size_t fixed[8] = {n * 4, n * 2, n, n, n * 4, n * 4, n * 4, (n + 1) * 4}; // pos flag mapq xs l_qseq mtid mpos cig_off
-    size_t offs[9], tot_b = 0;
-    for (int k = 0; k < 8; k++) {
-        offs[k] = tot_b;
-        tot_b += (std::max<size_t>(fixed[k], 16) + 255) & ~(size_t)255;
-    }
-    offs[8] = tot_b; // seq_off
-    tot_b += (((n + 1) * 4) + 255) & ~(size_t)255;
-    uint8_t *dev = (uint8_t *)slab_alloc(c, oc, tot_b);
-    if (!dev) return fail(c, PJB_ERR_NOMEM, "submit_bam: out of device memory for %zu alignments", n);
-    BamSoA B;
-    B.pos = (int32_t *)(dev + offs[0]);
-    B.flag = (uint16_t *)(dev + offs[1]);
-    B.mapq = dev + offs[2];
-    B.xs = dev + offs[3];
-    B.l_qseq = (int32_t *)(dev + offs[4]);
-    B.mtid = (int32_t *)(dev + offs[5]);
-    B.mpos = (int32_t *)(dev + offs[6]);
-    B.cig_off = (iu32 *)(dev + offs[7]);
-    B.seq_off = (iu32 *)(dev + offs[8]);
-    B.cigar = nullptr;
-    B.seq4 = nullptr;
-    B.name_hash = nullptr;
-    B.seq2 = nullptr;
-    B.seq_exc = nullptr;
-    if (c->extra) {
-        B.name_hash = (iu64 *)slab_alloc(c, oc, n * 8 + 16);
-        if (!B.name_hash) return fail(c, PJB_ERR_NOMEM, "submit_bam: out of device memory for name codes");
-    }
-    if ((rc = run_scan(c, "bam_sizes", BamSizesFn{R.U, (const iu64 *)c->b_bam_rec.p}, BamOffsetsSink{B.cig_off, B.seq_off}, n, d_total)))
-        return rc;
-    iu64 tot = 0;
-    HIP_TRY(c, hipMemcpyAsync(&tot, d_total, 8, hipMemcpyDeviceToHost, st));
-    HIP_TRY(c, hipStreamSynchronize(st));
-    const uint32_t n_ops = (uint32_t)(tot >> 32), n_words = (uint32_t)tot;
-    // (a carry out of the low half would mean 2^32 sequence words: 16 GB of bases on one target)
-    const uint32_t tails[2] = {n_ops, n_words};
-    HIP_TRY(c, hipMemcpyAsync(B.cig_off + n, &tails[0], 4, hipMemcpyHostToDevice, st));
-    HIP_TRY(c, hipMemcpyAsync(B.seq_off + n, &tails[1], 4, hipMemcpyHostToDevice, st));
-    B.cigar = (iu32 *)slab_alloc(c, oc, (size_t)n_ops * 4 + 16);
-    B.seq4 = (uint8_t *)slab_alloc(c, oc, (size_t)n_words * 4 + 16);
-    if (!B.cigar || !B.seq4) return fail(c, PJB_ERR_NOMEM, "submit_bam: out of device memory for CIGARs / bases");
-    static const bool no_seq2 = getenv("PJB_NO_SEQ2") && atoi(getenv("PJB_NO_SEQ2")) != 0;
-    if (!no_seq2) { // the bases in 2 bits as well (what pjb_batch.seq2 / .seq_exc hold): written where the 4-bit bases are
-        B.seq2 = (unsigned short *)slab_alloc(c, oc, ((size_t)n_words + 2) * 2 + 16);
-        B.seq_exc = (iu32 *)slab_alloc(c, oc, ((n + 31) / 32) * 4 + 16);
-        if (!B.seq2 || !B.seq_exc) return fail(c, PJB_ERR_NOMEM, "submit_bam: out of device memory for the 2-bit bases");
-    }
-    LAUNCH(c, "bam_transcode", bam_transcode, dim3((unsigned)((n + 255) / 256)), dim3(256), R.U, (const iu64 *)c->b_bam_rec.p, (iu64)n, B);
-    HIP_TRY(c, hipStreamSynchronize(st)); // `tails` is on this stack frame
-    if (c->ktime) ev_collect(c, MISC_POOL);
-    if (prof)
-        fprintf(stderr, "[host profile] submit_bam tid %d: %zu blocks, %.1f MB -> %.1f MB, %zu records: header scan %.3f, upload %.3f, inflate %.3f, "
-                        "boundaries %.3f, fill+sizes+transcode %.3f s\n",
-                tid, n_blocks, comp_bytes / 1e6, total / 1e6, n, t_scan, t_up, t_inf, t_walk, now() - t0);
-    DevBatch d;
-    memset(&d, 0, sizeof d);
-    d.n = (int64_t)n;
-    d.base = 0;
-    d.pos = B.pos; d.flag = B.flag; d.mapq = B.mapq; d.xs = B.xs; d.l_qseq = B.l_qseq; d.mtid = B.mtid; d.mpos = B.mpos;
-    d.cig_off = B.cig_off; d.cigar = B.cigar; d.seq_off = B.seq_off; d.seq4 = B.seq4;
-    d.name_hash = (const u64 *)B.name_hash;
-    d.seq2 = (const uint32_t *)B.seq2;
-    d.seq_exc = B.seq_exc;
-    oc.on_main_stream = true;
-    oc.batches.push_back(d);
-    oc.last_known.push_back(0);
-    oc.last_pos.push_back(INT32_MIN);
-    if (n_records) *n_records = (int64_t)n;
-    return PJB_OK;
-}
-
-extern "C" int pjb_submit_bam(pjb_ctx *c, int32_t tid, const uint8_t *comp, int64_t comp_bytes, int32_t first_uoffset,
-                              int64_t *n_records) {
-    if (!c) return PJB_ERR_ARG;
-    if (n_records) *n_records = 0;
-    if (comp_bytes < 0 || (comp_bytes && !comp) || first_uoffset < 0) return fail(c, PJB_ERR_ARG, "submit_bam: bad arguments");
-    if (tid < 0 || (size_t)tid >= c->ref_len.size()) return fail(c, PJB_ERR_ARG, "submit_bam: bad tid %d", tid);
-    c->cur_tid = tid;
-    HIP_TRY(c, hipSetDevice(c->cfg.device));
-    OpenContig &oc = c->open[tid];
-    if (!oc.batches.empty()) return fail(c, PJB_ERR_STATE, "submit_bam: target %d already has batches (one call per target)", tid);
-    const bool prof = getenv("PJB_PROFILE_HOST") != nullptr;
-    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-    double t0 = now(), t_scan, t_up;
-    std::vector<InfBlock> blocks;
-    int64_t total = 0;
-    int rc = scan_bgzf(c, comp, comp_bytes, blocks, total);
-    if (rc) return rc;
-    if (total == 0 || (int64_t)first_uoffset >= total) return PJB_OK;
-    t_scan = now() - t0;
-    t0 = now();
-    hipStream_t st = c->stream;
-    if ((rc = ensure(c, c->b_inf_comp, (size_t)comp_bytes + INF_PAD))) return rc;
-    {
-        // page-locked input (pjb_host_alloc): one DMA, no staging copy
-        hipPointerAttribute_t at;
-        const bool pinned = hipPointerGetAttributes(&at, comp) == hipSuccess && at.type == hipMemoryTypeHost;
-        if (!pinned) (void)hipGetLastError();
-        if (pinned) HIP_TRY(c, hipMemcpyAsync(c->b_inf_comp.p, comp, (size_t)comp_bytes, hipMemcpyHostToDevice, st));
-        else if ((rc = upload_staged(c, c->b_inf_comp.p, comp, (size_t)comp_bytes))) return rc;
-    }
-    HIP_TRY(c, hipMemsetAsync((uint8_t *)c->b_inf_comp.p + comp_bytes, 0, INF_PAD, st));
-    if (prof) (void)hipStreamSynchronize(st);
-    t_up = now() - t0;
-    return ingest_staged(c, tid, oc, (const uint8_t *)c->b_inf_comp.p, blocks, comp_bytes, total, first_uoffset, n_records, t_scan, t_up);
-}
-
-// ---- the same in pieces -----------------------------------------------------------------------------------------
-// (pjb_bam_begin / pjb_bam_piece / pjb_bam_pieces_done / pjb_bam_end, see the header)
-struct BamStage {
-    Buf dev;                 // the target's BGZF bytes on the device (from the context's pool)
-    int64_t total = 0, got = 0;
-    std::vector<InfBlock> blocks;
-    int64_t total_out = 0;
-    int64_t next = 0;        // file-relative offset of the next block header to look at
-    uint8_t keep[65536 + 64]; // bytes [keep_at, got) of what arrived, for a block whose header or footer straddles two pieces
-    int64_t keep_at = 0, keep_n = 0;
-    double t_scan = 0, t_up = 0;
-    // the inflate launched at the last piece (launched: ev_inf follows the kernel on its stream)
-    bool launched = false;
-    iu32 ctl[2] = {0, 0}; // { "some block failed", lanes }: copied to the device asynchronously, so it lives here and not on a stack
-    Buf out, d_blocks, d_status, d_scratch, d_bitmap;
-    hipEvent_t ev_inf = nullptr, ev_last = nullptr;
-};
-
-// a buffer of at least `bytes` from a pool (the smallest that fits), else a new one
-static int pool_take(pjb_ctx *c, std::vector<Buf> &pool, Buf &b, size_t bytes) {
-    int best = -1;
-    for (size_t k = 0; k < pool.size(); k++)
-        if (pool[k].cap >= bytes && (best < 0 || pool[k].cap < pool[(size_t)best].cap)) best = (int)k;
-    if (best >= 0) {
-        b = pool[(size_t)best];
-        pool.erase(pool.begin() + best);
-        return PJB_OK;
-    }
-    return ensure(c, b, bytes);
-}
-static void pool_give(std::vector<Buf> &pool, Buf &b) {
-    if (b.p) pool.push_back(b);
-    b.p = nullptr;
-    b.cap = 0;
-}
-static void stage_release(pjb_ctx *c, BamStage &st) { // (after the work that uses the buffers has completed)
-    pool_give(c->stage_pool, st.dev);
-    pool_give(c->out_pool, st.out);
-    pool_give(c->misc_pool, st.d_blocks);
-    pool_give(c->misc_pool, st.d_status);
-    pool_give(c->misc_pool, st.d_scratch);
-    pool_give(c->out_pool, st.d_bitmap); // (output-sized: an eighth of the inflated bytes)
-    if (st.ev_inf) (void)hipEventDestroy(st.ev_inf);
-    if (st.ev_last) (void)hipEventDestroy(st.ev_last);
-    st.ev_inf = st.ev_last = nullptr;
-}
-
-// every byte of the target has been queued for copying and every block header seen: inflate on a stream of its own, behind
-// the last copy.  Nothing here waits; a failure just leaves the inflate to pjb_bam_end.
-static void inflate_early(pjb_ctx *c, BamStage &st) {
-    const size_t nb = st.blocks.size();
-    if (st.launched || nb == 0 || st.total_out <= 0) return;
-    size_t lanes = std::min<size_t>((nb + 63) / 64 * 64, (size_t)c->inflate_lanes);
-    if (const char *e = getenv("PJB_INF_BLOCKS_PER_LAUNCH")) lanes = std::min<size_t>((nb + 63) / 64 * 64, (size_t)std::max(64, atoi(e)) / 64 * 64);
-    if (pool_take(c, c->out_pool, st.out, (size_t)st.total_out + 64) || pool_take(c, c->misc_pool, st.d_blocks, nb * sizeof(InfBlock)) ||
-        pool_take(c, c->misc_pool, st.d_status, nb * 4 + 16) || pool_take(c, c->misc_pool, st.d_scratch, lanes * INF_SCRATCH_PER_LANE) ||
-        pool_take(c, c->out_pool, st.d_bitmap, nb * INF_BITMAP_WORDS * 8)) {
-        std::lock_guard<std::mutex> lk(c->err_mu); // (a failure here just leaves the inflate to pjb_bam_end)
-        c->err.clear();
-        return;
-    }
-    hipStream_t &is = c->inf_streams[c->inf_next++ & 3u];
-    if (!is) {
-        // The inflate streams have the lowest priority: a launch holds every LDS byte of the chip for ~50 ms, and the short
-        // kernels beside it -- record parsing, genome uploads, the junc chains of the targets before it -- are what the one
-        // host thread that serves all targets waits for (end to end 2.73 -> 2.44 s)
-        int lo = 0, hi = 0; // (least, greatest priority)
-        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-        if (hipStreamCreateWithPriority(&is, hipStreamNonBlocking, lo) != hipSuccess) return;
-    }
-    if (hipEventCreateWithFlags(&st.ev_last, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&st.ev_inf, hipEventDisableTiming) != hipSuccess) return;
-    int *d_status = (int *)st.d_status.p;
-    int *d_any = d_status + nb;
-    iu32 *d_next = (iu32 *)(d_any + 1);
-    st.ctl[0] = 0u;
-    st.ctl[1] = (iu32)lanes;
-    bool ok = hipEventRecord(st.ev_last, c->stream_up) == hipSuccess && hipStreamWaitEvent(is, st.ev_last, 0) == hipSuccess &&
-              hipMemsetAsync((uint8_t *)st.out.p + st.total_out, 0, 64, is) == hipSuccess &&
-              hipMemcpyAsync(st.d_blocks.p, st.blocks.data(), nb * sizeof(InfBlock), hipMemcpyHostToDevice, is) == hipSuccess &&
-              hipMemcpyAsync(d_any, st.ctl, 8, hipMemcpyHostToDevice, is) == hipSuccess;
-    if (ok) {
-        ok = hipMemsetAsync(st.d_bitmap.p, 0, nb * INF_BITMAP_WORDS * 8, is) == hipSuccess;
-        if (ok) {
-            hipLaunchKernelGGL(bgzf_decode, dim3((unsigned)(lanes / 64)), dim3(64), I3_LDS_BYTES, is, (const uint8_t *)st.dev.p, (const InfBlock *)st.d_blocks.p,
-                               (iu32)nb, (uint8_t *)st.out.p, (uint8_t *)st.d_scratch.p, d_status, d_any, d_next, (iu64 *)st.d_bitmap.p, 8);
-            hipLaunchKernelGGL(bgzf_resolve, dim3((unsigned)((nb + 3) / 4)), dim3(256), 0, is, (const InfBlock *)st.d_blocks.p, (iu32)nb, (uint8_t *)st.out.p,
-                               (const iu64 *)st.d_bitmap.p, (const int *)d_status);
-            ok = hipGetLastError() == hipSuccess && hipEventRecord(st.ev_inf, is) == hipSuccess;
-        }
-    }
-    if (!ok) { // whatever was queued must be over before the buffers are used again
-        (void)hipStreamSynchronize(is);
-        (void)hipGetLastError();
-        return;
-    }
-    st.launched = true;
-}
-
-// block headers that are complete with the bytes received so far (the last `avail` bytes of the stream are at `p`, the
-// first of them is byte `p_at` of the target's bytes); leaves st.next at the first block it cannot finish yet
-static int stage_scan(pjb_ctx *c, BamStage &st, const uint8_t *p, int64_t p_at, int64_t avail) {
-    auto byte_at = [&](int64_t off) -> int { // a byte of the stream that is still in reach (this piece or the kept tail)
-        if (off >= p_at && off < p_at + avail) return p[off - p_at];
-        if (off >= st.keep_at && off < st.keep_at + st.keep_n) return st.keep[off - st.keep_at];
-        return -1;
-    };
-    const int64_t end = p_at + avail;
-    while (st.next < st.total) {
-        const int64_t off = st.next;
-        if (off + 18 > end) break;
-        uint8_t h[18];
-        for (int k = 0; k < 18; k++) {
-            const int v = byte_at(off + k);
-            if (v < 0) return fail(c, PJB_ERR_STATE, "bam_piece: internal: header byte %lld out of reach", (long long)(off + k));
-            h[k] = (uint8_t)v;
-        }
-        if (h[0] != 31 || h[1] != 139 || h[2] != 8 || !(h[3] & 4)) return fail(c, PJB_ERR_BGZF, "not a BGZF block header at byte %lld", (long long)off);
-        const uint32_t xlen = h[10] | (uint32_t)h[11] << 8;
-        if (off + 12 + xlen > end) break;
-        int64_t bsize = -1;
-        for (uint32_t x = 0; x + 4 <= xlen;) {
-            int f[6];
-            for (int k = 0; k < 6; k++) f[k] = x + (uint32_t)k < xlen ? byte_at(off + 12 + x + k) : 0;
-            if (f[0] < 0 || f[1] < 0 || f[2] < 0 || f[3] < 0) return fail(c, PJB_ERR_STATE, "bam_piece: internal: extra field out of reach");
-            const uint32_t slen = (uint32_t)f[2] | (uint32_t)f[3] << 8;
-            if (f[0] == 'B' && f[1] == 'C' && slen == 2 && x + 6 <= xlen) bsize = (int64_t)((uint32_t)f[4] | (uint32_t)f[5] << 8) + 1;
-            x += 4 + slen;
-        }
-        if (bsize < 0) return fail(c, PJB_ERR_BGZF, "BGZF block at byte %lld has no BC field", (long long)off);
-        if (bsize < (int64_t)xlen + 20 || off + bsize > st.total)
-            return fail(c, PJB_ERR_BGZF, "BGZF block at byte %lld has an impossible size %lld", (long long)off, (long long)bsize);
-        if (off + bsize > end) break; // its footer has not arrived
-        uint32_t isize = 0;
-        for (int k = 0; k < 4; k++) {
-            const int v = byte_at(off + bsize - 4 + k);
-            if (v < 0) return fail(c, PJB_ERR_STATE, "bam_piece: internal: footer byte out of reach");
-            isize |= (uint32_t)v << (8 * k);
-        }
-        if (isize > 65536u) return fail(c, PJB_ERR_BGZF, "BGZF block at byte %lld declares %u inflated bytes", (long long)off, isize);
-        InfBlock b;
-        b.in_off = (iu64)(off + 12 + xlen);
-        b.in_len = (iu32)(bsize - xlen - 20);
-        b.out_off = (iu64)st.total_out;
-        b.out_len = isize;
-        st.blocks.push_back(b);
-        st.total_out += isize;
-        st.next = off + bsize;
-    }
-    return PJB_OK;
-}
-
-static void bam_stage_clear(pjb_ctx *c) {
-    for (auto &is : c->inf_streams)
-        if (is) (void)hipStreamSynchronize(is);
-    for (auto &kv : c->bam_stage) {
-        stage_release(c, *kv.second);
-        delete kv.second;
-    }
-    c->bam_stage.clear();
-    for (auto *pool : {&c->stage_pool, &c->out_pool, &c->misc_pool}) {
-        for (auto &b : *pool) release(b);
-        pool->clear();
-    }
-    for (auto &is : c->inf_streams)
-        if (is) (void)hipStreamDestroy(is);
-    for (auto &ev : c->up_events)
-        if (ev) (void)hipEventDestroy(ev);
-    if (c->ev_up) (void)hipEventDestroy(c->ev_up);
-    if (c->stream_up) (void)hipStreamDestroy(c->stream_up);
-}
-
-extern "C" int pjb_bam_begin(pjb_ctx *c, int32_t tid, int64_t total_bytes) {
-    if (!c) return PJB_ERR_ARG;
-    if (tid < 0 || (size_t)tid >= c->ref_len.size() || total_bytes <= 0) return fail(c, PJB_ERR_ARG, "bam_begin: bad arguments (tid %d)", tid);
-    std::lock_guard<std::mutex> lk(c->bam_mu);
-    if (c->bam_stage.count(tid)) return fail(c, PJB_ERR_STATE, "bam_begin: target %d is being staged already", tid);
-    // (that the target has no batches yet is checked by pjb_bam_end, on the thread that owns the open targets)
-    HIP_TRY(c, hipSetDevice(c->cfg.device));
-    std::unique_ptr<BamStage> st(new (std::nothrow) BamStage());
-    if (!st) return fail(c, PJB_ERR_NOMEM, "bam_begin: out of host memory");
-    // device buffer: the smallest free one of the pool that fits, else a new one
-    const size_t need = (size_t)total_bytes + INF_PAD;
-    int best = -1;
-    for (size_t k = 0; k < c->stage_pool.size(); k++)
-        if (c->stage_pool[k].cap >= need && (best < 0 || c->stage_pool[k].cap < c->stage_pool[(size_t)best].cap)) best = (int)k;
-    if (best >= 0) {
-        st->dev = c->stage_pool[(size_t)best];
-        c->stage_pool.erase(c->stage_pool.begin() + best);
-    } else {
-        int rc = ensure(c, st->dev, need);
-        if (rc) return rc;
-    }
-    st->total = total_bytes;
-    hipError_t he = hipSuccess;
-    if (!c->stream_up) he = hipStreamCreateWithFlags(&c->stream_up, hipStreamNonBlocking);
-    if (he == hipSuccess) he = hipMemsetAsync((uint8_t *)st->dev.p + total_bytes, 0, INF_PAD, c->stream_up);
-    if (he != hipSuccess) {
-        pool_give(c->stage_pool, st->dev);
-        return fail(c, PJB_ERR_HIP, "bam_begin: %s", hipGetErrorString(he));
-    }
-    c->bam_stage[tid] = st.release();
-    return PJB_OK;
-}
-
-static int bam_piece_body(pjb_ctx *c, int32_t tid, BamStage &st, const uint8_t *piece, int64_t bytes, int64_t *ticket);
-
-extern "C" int pjb_bam_piece(pjb_ctx *c, int32_t tid, const uint8_t *piece, int64_t bytes, int64_t *ticket) {
-    if (!c || !piece || bytes <= 0) return fail(c, PJB_ERR_ARG, "bam_piece: bad arguments");
-    std::lock_guard<std::mutex> lk(c->bam_mu);
-    auto it = c->bam_stage.find(tid);
-    if (it == c->bam_stage.end()) return fail(c, PJB_ERR_STATE, "bam_piece: target %d was not begun (pjb_bam_begin)", tid);
-    const int rc = bam_piece_body(c, tid, *it->second, piece, bytes, ticket);
-    if (rc) { // the target's staging is dropped: it has to be begun again
-        (void)hipStreamSynchronize(c->stream_up);
-        for (auto &is : c->inf_streams)
-            if (is) (void)hipStreamSynchronize(is);
-        stage_release(c, *it->second);
-        delete it->second;
-        c->bam_stage.erase(it);
-    }
-    return rc;
-}
-
-static int bam_piece_body(pjb_ctx *c, int32_t tid, BamStage &st, const uint8_t *piece, int64_t bytes, int64_t *ticket) {
-    if (st.got + bytes > st.total) return fail(c, PJB_ERR_ARG, "bam_piece: target %d: more bytes than announced", tid);
-    HIP_TRY(c, hipSetDevice(c->cfg.device));
-    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-    double t0 = now();
-    // the copy first (asynchronous, on the upload stream), the header hop meanwhile
-    HIP_TRY(c, hipMemcpyAsync((uint8_t *)st.dev.p + st.got, piece, (size_t)bytes, hipMemcpyHostToDevice, c->stream_up));
-    const int64_t tk = ++c->up_ticket;
-    hipEvent_t &ev = c->up_events[(size_t)(tk % (int64_t)PJB_UP_EVENTS)];
-    if (!ev) HIP_TRY(c, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-    else if (tk - c->up_done >= (int64_t)PJB_UP_EVENTS) { // the ring is full: its oldest copy must have completed
-        HIP_TRY(c, hipEventSynchronize(ev));
-        c->up_done = std::max<int64_t>(c->up_done, tk - (int64_t)PJB_UP_EVENTS);
-    }
-    HIP_TRY(c, hipEventRecord(ev, c->stream_up));
-    st.t_up += now() - t0;
-    t0 = now();
-    int rc = stage_scan(c, st, piece, st.got, bytes);
-    if (rc) return rc;
-    st.got += bytes;
-    // keep what the next piece's first block may still need: everything from st.next on, if it is short (a block is
-    // at most 64 KB), else nothing (the block then starts in a later piece)
-    if (st.next < st.got) {
-        const int64_t from = st.next;
-        const int64_t n = st.got - from;
-        if (n > (int64_t)sizeof st.keep) return fail(c, PJB_ERR_BGZF, "BGZF block at byte %lld is longer than 64 KB", (long long)from);
-        uint8_t tmp[sizeof st.keep];
-        for (int64_t k = 0; k < n; k++) {
-            const int64_t off = from + k;
-            tmp[k] = off >= st.got - bytes ? piece[off - (st.got - bytes)] : st.keep[off - st.keep_at];
-        }
-        memcpy(st.keep, tmp, (size_t)n);
-        st.keep_at = from;
-        st.keep_n = n;
-    } else
-        st.keep_n = 0;
-    st.t_scan += now() - t0;
-    if (ticket) *ticket = tk;
-    if (st.got == st.total && st.next == st.total) inflate_early(c, st);
-    return PJB_OK;
-}
-
-extern "C" int pjb_bam_inflate_done(pjb_ctx *c, int32_t tid) {
-    if (!c) return 1;
-    std::lock_guard<std::mutex> lk(c->bam_mu);
-    auto it = c->bam_stage.find(tid);
-    if (it == c->bam_stage.end() || !it->second->launched) return 1; // (nothing in flight: pjb_bam_end does all the work)
-    const bool done = hipEventQuery(it->second->ev_inf) == hipSuccess;
-    (void)hipGetLastError();
-    return done ? 1 : 0;
-}
-
-extern "C" int pjb_bam_pieces_done(pjb_ctx *c, int64_t *completed_ticket) {
-    if (!c || !completed_ticket) return PJB_ERR_ARG;
-    std::lock_guard<std::mutex> lk(c->bam_mu);
-    while (c->up_done < c->up_ticket) {
-        hipEvent_t ev = c->up_events[(size_t)((c->up_done + 1) % (int64_t)PJB_UP_EVENTS)];
-        if (!ev || hipEventQuery(ev) != hipSuccess) break;
-        c->up_done++;
-    }
-    (void)hipGetLastError(); // (hipErrorNotReady is not an error here)
-    *completed_ticket = c->up_done;
-    return PJB_OK;
-}
-
-extern "C" int pjb_bam_end(pjb_ctx *c, int32_t tid, int32_t first_uoffset, int64_t *n_records) {
-    if (!c) return PJB_ERR_ARG;
-    if (n_records) *n_records = 0;
-    std::unique_ptr<BamStage> st;
-    {
-        std::lock_guard<std::mutex> lk(c->bam_mu);
-        auto it = c->bam_stage.find(tid);
-        if (it == c->bam_stage.end()) return fail(c, PJB_ERR_STATE, "bam_end: target %d was not begun (pjb_bam_begin)", tid);
-        st.reset(it->second);
-        c->bam_stage.erase(it);
-    }
-    struct Return { // the device buffer goes back to the pool whatever happens (after the work that reads it)
-        pjb_ctx *c;
-        BamStage *st;
-        ~Return() {
-            (void)hipStreamSynchronize(c->stream);
-            if (st->launched) (void)hipEventSynchronize(st->ev_inf); // (the inflate waited for the target's last copy)
-            else if (c->stream_up) (void)hipStreamSynchronize(c->stream_up); // early returns: the copies may still read the caller's buffers
-            std::lock_guard<std::mutex> lk(c->bam_mu);
-            stage_release(c, *st);
-        }
-    } ret{c, st.get()};
-    c->cur_tid = tid;
-    HIP_TRY(c, hipSetDevice(c->cfg.device));
-    if (first_uoffset < 0) return fail(c, PJB_ERR_ARG, "bam_end: bad first_uoffset");
-    if (st->got != st->total) return fail(c, PJB_ERR_ARG, "bam_end: target %d: %lld of %lld bytes arrived", tid, (long long)st->got, (long long)st->total);
-    if (st->next != st->total) return fail(c, PJB_ERR_BGZF, "truncated BGZF block at byte %lld", (long long)st->next);
-    OpenContig &oc = c->open[tid];
-    if (!oc.batches.empty()) return fail(c, PJB_ERR_STATE, "bam_end: target %d already has batches (one call per target)", tid);
-    if (st->total_out == 0 || (int64_t)first_uoffset >= st->total_out) return PJB_OK;
-    if (st->launched) { // the inflate started with the last piece: wait for it, look at its status words, go on with the records
-        auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-        const double t0 = now();
-        HIP_TRY(c, hipEventSynchronize(st->ev_inf));
-        int rc = inflate_status(c, st->blocks, (const int *)st->d_status.p);
-        if (rc) return rc;
-        return ingest_parse(c, tid, oc, (const uint8_t *)st->out.p, st->blocks.size(), st->total, st->total_out, first_uoffset, n_records, st->t_scan, st->t_up,
-                            now() - t0);
-    }
-    // the service stream picks up behind the last copy
-    if (!c->ev_up) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_up, hipEventDisableTiming));
-    HIP_TRY(c, hipEventRecord(c->ev_up, c->stream_up));
-    HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_up, 0));
-    return ingest_staged(c, tid, oc, (const uint8_t *)st->dev.p, st->blocks, st->total, st->total_out, first_uoffset, n_records, st->t_scan, st->t_up);
-}

@@ -68,6 +68,7 @@ struct ExtraCounters { // one per contig, device memory
 // separateBams does, records its position / exclusive end for the rank queries, counts its end in `ce`
 // and adds its M / = / X runs to the depth difference array; the name codes of spliced records are appended
 // (order is irrelevant: they only feed a multiset).
+#ifdef PJB_KERNELS_EXTRA
 __global__ __launch_bounds__(256) void kx_classify(DevBatch b, int32_t ref_len, int32_t *x_pos,
                                                     int32_t *x_endx, uint8_t *q_flag, u32 *ce, int32_t *dd, u32 *zlist,
                                                     u32 zcap, ExtraCounters *cnt) {
@@ -118,11 +119,13 @@ __global__ __launch_bounds__(256) void kx_classify(DevBatch b, int32_t ref_len, 
         }
     }
 }
+#endif // PJB_KERNELS_EXTRA
 
 // The name codes of the spliced records, in BAM order, without a single atomic: k1_count left, per 1024-record tile,
 // the ordered list of its spliced records (spl_idx) and their number (tile_stats); one block scans the tile counts,
 // then a block per tile copies its records' codes to the tile's place.  (A wave-aggregated atomicAdd on one counter
 // per wavefront of records cost 1.1 ms per 10 M records: 156 k returning atomics on ONE address.)
+#ifdef PJB_KERNELS_EXTRA
 __global__ __launch_bounds__(1024) void kx_spliced_offsets(const TileStats *ts, u32 n_tiles, u32 *off, ExtraCounters *cnt) {
     __shared__ u32 wsum[16];
     __shared__ u32 carry_s;
@@ -149,11 +152,14 @@ __global__ __launch_bounds__(1024) void kx_spliced_offsets(const TileStats *ts, 
     }
     if (threadIdx.x == 0) cnt->n_spliced = carry_s;
 }
+#endif // PJB_KERNELS_EXTRA
+#ifdef PJB_KERNELS_EXTRA
 __global__ __launch_bounds__(256) void kx_spliced_codes(DevBatch b, const TileStats *ts, const u32 *spl_idx, const u32 *off, u64 *spl_codes) {
     const u32 tile = b.tile_base + blockIdx.x;
     const u32 nspl = ts[tile].spliced, o = off[tile];
     for (u32 ks = threadIdx.x; ks < nspl; ks += 256) spl_codes[o + ks] = b.name_hash[spl_idx[(size_t)tile * K1_TILE + ks]];
 }
+#endif // PJB_KERNELS_EXTRA
 
 
 // scan functors -----------------------------------------------------------------------------------------------
@@ -184,6 +190,7 @@ struct InclusiveU32Sink { // out[i] = sum of the terms up to and including i (ma
 // endpos >= pos_i, kept or not = (unspliced records before i) - (unspliced records with endpos < pos_i).  If
 // the bound stays below maxcnt - 1 everywhere, nothing is dropped and the difference array already holds the
 // reference's depth (the normal case: it takes 8000-fold coverage of unspliced records).
+#ifdef PJB_KERNELS_EXTRA
 __global__ __launch_bounds__(256) void kx_cap_bound(const int32_t *x_pos, const uint8_t *q_flag, const u32 *prefix_q,
                                                      const u32 *pe, u32 n, int32_t ref_len, u32 *bound, ExtraCounters *cnt) {
     const u32 g = blockIdx.x * 256 + threadIdx.x;
@@ -206,11 +213,13 @@ __global__ __launch_bounds__(256) void kx_cap_bound(const int32_t *x_pos, const 
         atomicMax(&cnt->hot_last, g);
     }
 }
+#endif // PJB_KERNELS_EXTRA
 
 // KX3b: exact replay of the cap over the span of records whose bound reaches it (outside the span every record
 // is kept whatever happened before: its list is at most its bound).  Sequential by nature -- whether a record is
 // kept depends on which earlier ones were -- so one lane walks the span; `de` (zeroed, ref_len + 2 entries)
 // counts dropped records by endpos.  Kept records inside the list = bound - dropped records still inside.
+#ifdef PJB_KERNELS_EXTRA
 __global__ void kx_cap_replay(const int32_t *x_pos, const int32_t *x_endx, const uint8_t *q_flag, const u32 *bound, u32 n,
                               int32_t ref_len, u32 *de, uint8_t *dropped, ExtraCounters *cnt) {
     if (blockIdx.x != 0 || threadIdx.x != 0) return;
@@ -242,8 +251,10 @@ __global__ void kx_cap_replay(const int32_t *x_pos, const int32_t *x_endx, const
     }
     cnt->n_dropped = dtotal;
 }
+#endif // PJB_KERNELS_EXTRA
 
 // KX3c: take the dropped records' M / = / X runs back out of the difference array (before the scan).
+#ifdef PJB_KERNELS_EXTRA
 __global__ __launch_bounds__(256) void kx_undo_dropped(DevBatch b, int32_t ref_len, const uint8_t *dropped, int32_t *dd) {
     const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (r >= b.n || !dropped[b.base + (u32)r]) return;
@@ -264,6 +275,7 @@ __global__ __launch_bounds__(256) void kx_undo_dropped(DevBatch b, int32_t ref_l
         if (op_consumes_ref(ty)) x += ln;
     }
 }
+#endif // PJB_KERNELS_EXTRA
 
 __device__ __forceinline__ u32 lower_bound_i32(const int32_t *a, u32 n, int32_t v) { // first index with a[i] >= v
     u32 lo = 0, hi = n;
@@ -291,6 +303,7 @@ struct ExtraRow { // what pjb_extra_finish hands back, parallel to the junction 
 // with getEnd() < x.  The reference's region query (sam_itr_queryi over [left - maxQueryLength - 1, right +
 // maxQueryLength + 1)) cannot exclude a record either test accepts.  Records without a reference span
 // (getEnd() == pos - 1) are tested one by one from `zlist`.
+#ifdef PJB_KERNELS_EXTRA
 __global__ __launch_bounds__(256) void kx_flank(const pjb_junction_row *rows, u32 n_rows, const int32_t *x_pos, u32 n_reads,
                                                  const u32 *prefix_q, const u32 *pe, int32_t ref_len, const u32 *zlist,
                                                  const ExtraCounters *cnt, u32 zcap, ExtraRow *out) {
@@ -311,8 +324,10 @@ __global__ __launch_bounds__(256) void kx_flank(const pjb_junction_row *rows, u3
     out[j].up_aln = up;
     out[j].down_aln = down;
 }
+#endif // PJB_KERNELS_EXTRA
 
 // KX5: per sorted pair, the name code of its record and the global row it belongs to (kept until pjb_extra_finish)
+#ifdef PJB_KERNELS_EXTRA
 __global__ __launch_bounds__(256) void kx_pair_codes(const u32 *sidx, const u32 *jid_of, const u32 *pair_g, const DevBatch *batches,
                                                       int n_batches, u32 n, u32 row_base,
                                                       u64 *pair_code, u32 *pair_row) {
@@ -324,6 +339,7 @@ __global__ __launch_bounds__(256) void kx_pair_codes(const u32 *sidx, const u32 
     pair_code[i] = batches[bi].name_hash[g - batches[bi].base];
     pair_row[i] = row_base + jid_of[i];
 }
+#endif // PJB_KERNELS_EXTRA
 
 // ---- the sparse path (round 3): no array of the target's length --------------------------------------------------
 // The depth of the unspliced records is only ever READ at 42 positions per junction (Junction::calcCoverage,
@@ -340,6 +356,7 @@ __global__ __launch_bounds__(256) void kx_pair_codes(const u32 *sidx, const u32 
 // above instead.
 // (SparseCounters, XOut: pjb_kernels.hip.h -- k1_count writes them when the records go through it; kx_classify_sparse is
 // the same classification for the records of a target that went through k1_walk)
+#ifdef PJB_KERNELS_EXTRA
 __global__ __launch_bounds__(256) void kx_classify_sparse(DevBatch b, int32_t *s_pos, int32_t *s_end, uint8_t *q_flag, u32 *zlist, u32 zcap,
                                                            SparseCounters *cnt) {
     const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -386,6 +403,7 @@ __global__ __launch_bounds__(256) void kx_classify_sparse(DevBatch b, int32_t *s
     }
     if (many) atomicOr(&cnt->need_dense, 2u);
 }
+#endif // PJB_KERNELS_EXTRA
 
 // one scan over the records: (records with a span) | (gaps) << 32
 struct SparseFn {
@@ -415,6 +433,7 @@ struct SparseSink { // the records with a span, compacted in rank order; gaps be
 };
 // the gaps (D operations) of the unspliced records in record order: a block per 256 records (global ordinals, so that
 // gapoff[block] is the block's first entry), an exclusive scan of the records' gap counts inside the block
+#ifdef PJB_KERNELS_EXTRA
 __global__ __launch_bounds__(256) void kx_gaps(DevBatch b, const uint8_t *q, u32 n_total, const u32 *gapoff, Gap *gaps, u32 gap_cap, SparseCounters *cnt,
                                                 u32 n_blocks) {
     __shared__ u32 wsum[4];
@@ -446,14 +465,17 @@ __global__ __launch_bounds__(256) void kx_gaps(DevBatch b, const uint8_t *q, u32
         }
     }
 }
+#endif // PJB_KERNELS_EXTRA
 
 // the pileup's cap can only bite where PLP_MAXCNT - 1 records with a span start within max_span bases of each other
+#ifdef PJB_KERNELS_EXTRA
 __global__ __launch_bounds__(256) void kx_cap_check(const int32_t *comp_pos, SparseCounters *cnt) {
     const u32 n = (u32)cnt->total, K = PLP_MAXCNT - 1;
     const u32 r = blockIdx.x * 256 + threadIdx.x + K;
     if (r >= n) return;
     if ((int64_t)comp_pos[r] - (int64_t)comp_pos[r - K] <= (int64_t)cnt->max_span) atomicOr(&cnt->need_dense, 1u);
 }
+#endif // PJB_KERNELS_EXTRA
 
 __device__ __forceinline__ u32 lower_bound_i64(const int32_t *a, u32 n, int64_t v) { // first index with a[i] >= v
     u32 lo = 0, hi = n;
@@ -504,6 +526,7 @@ __device__ __forceinline__ void ranges_sum2(u32 i0, u32 i1, const Win w, F acc, 
 // KX4 without the ends histogram: a thread per junction.
 //   #{getEnd() < x} = (records with a span that start before x - max_span: all of them) + (those among the records starting
 //   in [x - max_span, x) whose last base lies before x); a record starting at or after x ends at or after x.
+#ifdef PJB_KERNELS_EXTRA
 __global__ __launch_bounds__(256) void kx_flank_sparse(const pjb_junction_row *rows, u32 n_rows, const int32_t *s_pos, const int32_t *s_end,
                                                         int32_t ref_len, const u32 *zlist, const SparseCounters *cnt, u32 zcap, ExtraRow *out) {
     const u32 n_reads = (u32)cnt->total; // (s_pos / s_end: the records with a span only, in rank order)
@@ -539,6 +562,7 @@ __global__ __launch_bounds__(256) void kx_flank_sparse(const pjb_junction_row *r
     out[j].up_aln = up;
     out[j].down_aln = down;
 }
+#endif // PJB_KERNELS_EXTRA
 
 // what a target keeps for pjb_extra_finish (device pointers): the records with a span in rank order, their gaps (record
 // order = rank order) and the number of gaps before every 256th of them
@@ -592,6 +616,7 @@ __device__ __forceinline__ void sparse_cov2(const SparseDepth D, int32_t len, bo
     sum2 = s2 - m2;
 }
 // Junction::calcCoverage (junction.cc:923-951) from a target's records instead of its depth vector: a thread per junction
+#ifdef PJB_KERNELS_EXTRA
 __global__ __launch_bounds__(256) void kx_coverage_sparse(const pjb_junction_row *rows, u32 row0, u32 n, SparseDepth D, int32_t len_src, ExtraRow *out) {
     const u32 k = blockIdx.x * 256 + threadIdx.x;
     const bool on = k < n;
@@ -606,6 +631,7 @@ __global__ __launch_bounds__(256) void kx_coverage_sparse(const pjb_junction_row
     const double acceptor = (1.0 / 10.0) * (double)a1 - (1.0 / 9.0) * (double)a2;
     out[j].coverage = donor + acceptor;
 }
+#endif // PJB_KERNELS_EXTRA
 
 // ---- phase 2 (all contigs done) ---------------------------------------------------------------------------
 constexpr u64 NAME_EMPTY = ~0ull;
@@ -635,14 +661,17 @@ __device__ __forceinline__ void name_add(NameSlot *tab, u32 slots, u64 key, u32 
     }
 }
 // the table has grown: every name of the old one into the new one
+#ifdef PJB_KERNELS_EXTRA
 __global__ __launch_bounds__(256) void kx_name_rehash(const NameSlot *old_tab, u32 old_slots, NameSlot *tab, u32 slots) {
     const u32 i = blockIdx.x * 256 + threadIdx.x;
     if (i >= old_slots) return;
     const NameSlot o = old_tab[i];
     if (o.key != NAME_EMPTY) name_add(tab, slots, o.key, o.count + 1u);
 }
+#endif // PJB_KERNELS_EXTRA
 // M of every junction: sum over its alignments of the map entry of their code (junction.cc:916-919, uint32).  Four pairs
 // per thread, a wavefront's 256 consecutive pairs in four rounds: the four random probes of a thread are in flight together.
+#ifdef PJB_KERNELS_EXTRA
 __global__ __launch_bounds__(256) void kx_name_sum(const u64 *pair_code, const u32 *pair_row, u32 n, const NameSlot *tab, u32 slots, ExtraRow *out) {
     const u32 base = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 256 + (u32)lane_id();
     u64 key[4];
@@ -677,7 +706,9 @@ __global__ __launch_bounds__(256) void kx_name_sum(const u64 *pair_code, const u
         if (i < n && (lane_id() == 0 || prev != row[k])) atomicAdd(&out[row[k]].m_sum, cc);
     }
 }
+#endif // PJB_KERNELS_EXTRA
 // four codes per thread into the table (the probes of a thread in flight together)
+#ifdef PJB_KERNELS_EXTRA
 __global__ __launch_bounds__(256) void kx_name_insert4(const u64 *codes, u32 n, NameSlot *tab, u32 slots) {
     const u32 base = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 256 + (u32)lane_id();
     u64 key[4];
@@ -699,6 +730,7 @@ __global__ __launch_bounds__(256) void kx_name_insert4(const u64 *codes, u32 n, 
         else name_add(tab, slots, key[k], 1u);
     }
 }
+#endif // PJB_KERNELS_EXTRA
 
 // Junction::calcCoverage (junction.cc:923-951) for the rows [row0, row0 + n) against the depth vector of one
 // target: levels[i] = cover[i - 1] (DepthParser stores a position's depth at pos + 1, depth_parser.cc:127,147),
@@ -710,6 +742,7 @@ __device__ __forceinline__ double cov_window(const u32 *cover, int32_t len, int3
         if (i >= 1 && i < len) readCount += cover[i - 1];
     return multiplier * (double)readCount;
 }
+#ifdef PJB_KERNELS_EXTRA
 __global__ __launch_bounds__(256) void kx_coverage(const pjb_junction_row *rows, u32 row0, u32 n, const u32 *cover, int32_t len_src, ExtraRow *out) {
     const u32 k = blockIdx.x * 256 + threadIdx.x;
     if (k >= n) return;
@@ -719,7 +752,9 @@ __global__ __launch_bounds__(256) void kx_coverage(const pjb_junction_row *rows,
     const double acceptor = cov_window(cover, len_src, e + 10, e + 20) - cov_window(cover, len_src, e, e + 9);
     out[j].coverage = donor + acceptor;
 }
+#endif // PJB_KERNELS_EXTRA
 // the finished columns of every junction, in the layout pjb_extra_finish hands out (mm_score = N / M, junction.cc:920)
+#ifdef PJB_KERNELS_EXTRA
 __global__ __launch_bounds__(256) void kx_rows_out(const pjb_junction_row *rows, const ExtraRow *x, u32 n, pjb_extra_row *out) {
     const u32 j = blockIdx.x * 256 + threadIdx.x;
     if (j >= n) return;
@@ -730,6 +765,7 @@ __global__ __launch_bounds__(256) void kx_rows_out(const pjb_junction_row *rows,
     o.down_aln = x[j].down_aln;
     out[j] = o;
 }
+#endif // PJB_KERNELS_EXTRA
 
 // ---- filt feature rows: ModelFeatures::setRow, lib/src/model_features.cc:161-212 ------------------
 struct DevModels {
@@ -781,6 +817,7 @@ __device__ double pos_score(const double *tab, const uint8_t *g, int32_t glen, i
     if (score == 0.0) return -300.0;
     return log(score);
 }
+#ifdef PJB_KERNELS_EXTRA
 __global__ __launch_bounds__(256) void kg_features(const pjb_junction_row *rows, u32 n, const GenomeRef *genomes, int n_refs, DevModels M,
                                                     double mean_read_length, u32 l95, double *out, int *bad) {
     const u32 r = blockIdx.x * 256 + threadIdx.x;
@@ -837,10 +874,12 @@ __global__ __launch_bounds__(256) void kg_features(const pjb_junction_row *rows,
         f[14 + i] = log2(Ni / Ei);
     }
 }
+#endif // PJB_KERNELS_EXTRA
 
 // ---- bamfilt: BamFilter::filter's decision per alignment, src/bam_filter.cc:75-150,190-225.
 // The walk is the reference's, including that it does not advance over an N operation (only the else-branch of
 // :86-96 adds to lEnd): the introns after a read's first one are looked up short of the earlier introns' lengths.
+#ifdef PJB_KERNELS_EXTRA
 __global__ __launch_bounds__(256) void kf_filter(const int32_t *pos, const u32 *cig_off, const u32 *cigar, u32 n, const u64 *keys, u32 n_keys,
                                                   int clip_mode, uint8_t *codes) {
     const u32 i = blockIdx.x * 256 + threadIdx.x;
@@ -873,5 +912,6 @@ __global__ __launch_bounds__(256) void kf_filter(const int32_t *pos, const u32 *
     }
     codes[i] = code;
 }
+#endif // PJB_KERNELS_EXTRA
 
 } // namespace pjb

@@ -438,6 +438,8 @@ __global__ __launch_bounds__(256) void scan_reduce_kernel(F f, u64 n, u64 *tile_
 }
 
 // single block: in-place exclusive scan of tile sums; writes grand total to *total
+// (a template only so that every translation unit that scans -- chain, extra, ingest -- instantiates it for itself)
+template <int UNUSED = 0>
 __global__ __launch_bounds__(1024) void scan_tiles_kernel(u64 *tile_sums, u32 n_tiles, u64 *total) {
     __shared__ u64 wsum[16];
     __shared__ u64 carry_s;
@@ -529,6 +531,7 @@ __global__ __launch_bounds__(256) void scan_apply2_kernel(F f, G g, u64 n, const
 // ---------------------------------------------------------------------------------------------
 // K0: upper-case contig bases in place (boost::to_upper on fetched strings, junction.cc:586-587,635-638)
 // ---------------------------------------------------------------------------------------------
+#ifdef PJB_KERNELS_CHAIN
 __global__ __launch_bounds__(256) void k0_upper(uint8_t *g, int64_t n, int do_upper, int *has_x) {
     int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 16;
     bool x = false;
@@ -560,11 +563,13 @@ __global__ __launch_bounds__(256) void k0_upper(uint8_t *g, int64_t n, int do_up
         }
     }
 }
+#endif // PJB_KERNELS_CHAIN
 
 // K0f: the sequence lines of one FASTA record, as they are in the file, -> its bases.  With the .fai's geometry (line_blen
 // bases per line, line_len bytes per line) base i sits at byte (i / line_blen) * line_len + i % line_blen; every base must be
 // a graphic character and every line terminator byte not one -- the test faidx's loader implies (deps/htslib-1.3/faidx.c
 // reads with isgraph).  Anything else raises `bad` and the host falls back to filtering the characters itself.
+#ifdef PJB_KERNELS_CHAIN
 __global__ __launch_bounds__(256) void k0_fasta(const uint8_t *raw, int64_t raw_bytes, int64_t n, int32_t line_blen, int32_t line_len,
                                                  uint8_t *out, int *bad) {
     const int64_t i0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 16;
@@ -593,6 +598,7 @@ __global__ __launch_bounds__(256) void k0_fasta(const uint8_t *raw, int64_t raw_
     }
     if (__ballot(wrong) && lane_id() == 0) atomicOr(bad, 1);
 }
+#endif // PJB_KERNELS_CHAIN
 
 // K0b: contig bases -> 4-bit nt16 codes, two per byte, LOW nibble first (base i at bits 4*(i&7) of
 // word i>>3).  A byte outside the 16-letter alphabet "=ACMGRSVTWYHKDBN" has no code: the contig is
@@ -618,6 +624,7 @@ __device__ __forceinline__ u32 nt16_code(u32 c, bool &exotic) {
     default: exotic = true; return 0;
     }
 }
+#ifdef PJB_KERNELS_CHAIN
 __global__ __launch_bounds__(256) void k0_encode(const uint8_t *g, int64_t n, u32 *codes, int64_t n_words, int *exotic_flag) {
     const int64_t w = (int64_t)blockIdx.x * 256 + threadIdx.x;
     bool exotic = false;
@@ -633,6 +640,7 @@ __global__ __launch_bounds__(256) void k0_encode(const uint8_t *g, int64_t n, u3
     }
     if (__ballot(exotic) && lane_id() == 0) atomicOr(exotic_flag, 1);
 }
+#endif // PJB_KERNELS_CHAIN
 
 // K0c: the same bases in TWO bits (A 0, C 1, G 2, T 3; base i at bits 2 (i & 15) of word i >> 4; anything else is stored as 0) and
 // the exceptions: bit i >> 6 of the bitmap is set when one of the bases 64 (i >> 6) .. 64 (i >> 6) + 63 is not A, C, G or T.  k1_emit
@@ -644,6 +652,7 @@ constexpr int K0_CODES2_PAD = 8, K0_GEXC_PAD = 4;
 __host__ __device__ inline int64_t codes2_words(int64_t n) { return ((n + 63) / 64) * 4; }          // (whole stretches)
 __host__ __device__ inline int64_t gexc_words(int64_t n) { return (((n + 63) / 64 + 63) / 64) * 2; } // (whole u64s)
 __host__ __device__ inline int64_t codes2_alloc_words(int64_t n) { return codes2_words(n) + K0_CODES2_PAD + gexc_words(n) + K0_GEXC_PAD; }
+#ifdef PJB_KERNELS_CHAIN
 __global__ __launch_bounds__(256) void k0_encode2(const uint8_t *g, int64_t n, u32 *codes2, u32 *gexc) {
     const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x; // stretch
     const int64_t n_str = (n + 63) / 64;
@@ -680,6 +689,7 @@ __global__ __launch_bounds__(256) void k0_encode2(const uint8_t *g, int64_t n, u
     const u64 m = __ballot(exc);
     if (lane_id() == 0 && s < ((n_str + 63) / 64) * 64) reinterpret_cast<u64 *>(gexc)[s >> 6] = m;
 }
+#endif // PJB_KERNELS_CHAIN
 
 // ---------------------------------------------------------------------------------------------
 // K1a: per-read CIGAR walk, pass 1 (BamAlignment::init bam_alignment.cc:71-100, findJuncs length
@@ -1194,6 +1204,7 @@ __host__ __device__ inline u32 k1s_blocks(u32 n_tiles) { // ~1024 tiles a block
     const u32 g = (n_tiles + 1023u) / 1024u;
     return g < 1u ? 1u : (g > (u32)K1S_BLOCKS ? (u32)K1S_BLOCKS : g);
 }
+#ifdef PJB_KERNELS_CHAIN
 __global__ __launch_bounds__(K1S_THREADS) void k1_scan_tiles(u32 *tile_cnt, const TileStats *ts, u32 n_tiles, ContigStats *out, u32 pair_limit,
                                                               KeyFmt kf, int32_t ref_len, const u64 *tile_desc, u32 *tile_soff, u32 *chunk_tile,
                                                               ScanPart *parts, u32 epoch) {
@@ -1417,6 +1428,7 @@ __global__ __launch_bounds__(K1S_THREADS) void k1_scan_tiles(u32 *tile_cnt, cons
         out->n_cand = 0;
     }
 }
+#endif // PJB_KERNELS_CHAIN
 
 // ---------------------------------------------------------------------------------------------
 // Packed-base compare helpers (used by k1_emit for the simple shape and by the generic walks of k4b_generic)
@@ -2017,7 +2029,7 @@ __device__ __forceinline__ void chunk2_cmp_bits(const u32 (&qw)[NW], const u32 (
 // trip v + 1 are already on their way (in registers).
 //   (Round 5 also built the version that stages the wavefront's bases and genome windows through LDS with coalesced loads: 2.4 x fewer
 // vector-memory instructions, the same time -- profiles/r05_k1_experiments.txt section 1; it left the tree with round 6, git has it.)
-#ifdef K1E_PROF // (debug builds: wave-cycles per section of k1_emit, summed over every wavefront; printed by pjb_destroy)
+#if defined(K1E_PROF) && defined(PJB_KERNELS_CHAIN) // (debug builds: wave-cycles per section of k1_emit, summed over every wavefront; printed by pjb_destroy)
 __device__ unsigned long long g_k1e_prof[16];
 #define K1E_T0() unsigned long long prof_t = __builtin_amdgcn_s_memtime()
 #define K1E_MARK(i)                                                                  \
@@ -2030,7 +2042,7 @@ __device__ unsigned long long g_k1e_prof[16];
 #define K1E_T0() do {} while (0)
 #define K1E_MARK(i) do {} while (0)
 #endif
-#ifdef K1E_HIST // (debug builds: per wavefront and trip, compare rounds run (the longest lane's) against the lanes' mean -- pjb_destroy prints the table)
+#if defined(K1E_HIST) && defined(PJB_KERNELS_CHAIN) // (debug builds: per wavefront and trip, compare rounds run (the longest lane's) against the lanes' mean -- pjb_destroy prints the table)
 __device__ unsigned long long g_k1e_hist[4][32]; // [0]: trips by rounds run, [1]: sum of active lanes' rounds by rounds run, [2]: active lanes, [3]: 4-bit rounds run
 #endif
 constexpr int K1E_MAXB = 64; // batches one launch takes (the host splits longer lists)
@@ -2048,6 +2060,7 @@ struct EmitTrip { // (uniform)
     int bi;
     u32 chunk, s_begin, s_end;
 };
+#ifdef PJB_KERNELS_CHAIN
 __global__ __launch_bounds__(K1E_T) __attribute__((amdgpu_waves_per_eu(K1E_WAVES, K1E_WAVES))) void k1_emit(const DevBatch *batches, int n_batches, u32 n_tiles_total, const u32 *tile_off, const u32 *tile_soff,
                                                 const u32 *chunk_tile, const u32 *spl_idx, const u32 *spl_poff, const uint4 *spl_rec, Pairs P, EmitLists E, KeyFmt kf,
                                                 GroupTab G, int use_codes, int orientation, u64 *err, ContigStats *cs) {
@@ -2470,6 +2483,7 @@ __global__ __launch_bounds__(K1E_T) __attribute__((amdgpu_waves_per_eu(K1E_WAVES
         R1 = R2;
     }
 }
+#endif // PJB_KERNELS_CHAIN
 
 // The reads k1_emit did not finish (three and more introns, indels, = X P H operations, clamped ends, exotic targets, SEQ '*'):
 // a thread per read of the chain's third list, dense.  The read's operations are walked (emit_read_pairs): keys and records
@@ -2484,6 +2498,7 @@ __device__ __forceinline__ const DevBatch &find_batch_by_tile(const DevBatch *ba
     }
     return batches[lo];
 }
+#ifdef PJB_KERNELS_CHAIN
 __global__ __launch_bounds__(K1E_T) void k1_generic(const DevBatch *batches, int n_batches, const u32 *spl_idx, const uint4 *spl_rec, Pairs P, EmitLists E, KeyFmt kf,
                                                     GroupTab G, int use_codes, int orientation, u64 *err, ContigStats *cs) {
     __shared__ EmitShared sh;
@@ -2584,11 +2599,13 @@ __global__ __launch_bounds__(K1E_T) void k1_generic(const DevBatch *batches, int
         ctx.cand_flush(item0 + gridDim.x * K1E_T >= n_items);
     }
 }
+#endif // PJB_KERNELS_CHAIN
 
 // per-member counters of a group, from the tile statistics of the member's tiles (before k1_scan_tiles turns the tile pair
 // counts into offsets): one block per member
 // (behind k1_scan_tiles and off the chain's K1 stage: a member's pairs are the difference of the scanned counts at its first tile and
 // the next member's)
+#ifdef PJB_KERNELS_CHAIN
 __global__ __launch_bounds__(256) void kg_member_stats(const u32 *tile_off, const TileStats *ts, const u32 *tile_lo, int n_members, MemberStats *out, u32 n_tiles,
                                                        const ContigStats *cs) {
     __shared__ u64 sm[4][4];
@@ -2637,6 +2654,7 @@ __global__ __launch_bounds__(256) void kg_member_stats(const u32 *tile_off, cons
         out[m] = S;
     }
 }
+#endif // PJB_KERNELS_CHAIN
 
 // ---------------------------------------------------------------------------------------------
 // K2d: ordered dense junction ids.  The intron key is 46-48 bits wide (contig coordinate + intron length): five radix
@@ -2672,6 +2690,7 @@ struct PopcFn {
     const u64 *words;
     __device__ u64 operator()(u64 i) const { return (u64)__popcll(words[i]); }
 };
+#ifdef PJB_KERNELS_CHAIN
 __global__ __launch_bounds__(256) void kd_ends(const u64 *cand, KeyFmt kf, const u64 *bitmap, const u32 *wrank, u32 junc_limit, u32 *ends,
                                                u32 *cand_rank, ContigStats *cs) {
     const u32 n = cs->n_cand; // (a few candidates per junction: the grid is small and strides)
@@ -2694,12 +2713,14 @@ __global__ __launch_bounds__(256) void kd_ends(const u64 *cand, KeyFmt kf, const
         if (!placed) atomicOr(&cs->overflow, OVF_DENSE);
     }
 }
+#endif // PJB_KERNELS_CHAIN
 // The ranks of the bitmap's words, page by page: the starts are few (a third of the pages of a human-sized chain hold one, fewer
 // where genes cluster), so the prefix sum runs over the PAGES' counts (k1_emit / k1_generic count a start when its bit is set for
 // the first time) and only the pages that hold a start are read: a wavefront per page, lane = word, the word's rank = the page's
 // rank + the popcounts of the page's words before it.  Words of pages without a start keep whatever rank they had: nobody asks
 // for it (kd_ends, kd_assign look up the words of their own starts).  (Until round 5 a three-kernel scan read all of the bitmap
 // twice and wrote every word's rank: 320 MB and 90 us a 1-Gb chain.)
+#ifdef PJB_KERNELS_CHAIN
 __global__ __launch_bounds__(256) void kd_rank_pages(const u64 *bitmap, const u32 *page_cnt, const u32 *page_rank, u32 *wrank, u32 n_pages, u32 n_words) {
     const u32 page = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (page >= n_pages) return;
@@ -2709,8 +2730,10 @@ __global__ __launch_bounds__(256) void kd_rank_pages(const u64 *bitmap, const u3
     const u32 inc = wave_iscan(c);
     if (w < n_words) wrank[w] = page_rank[page] + inc - c;
 }
+#endif // PJB_KERNELS_CHAIN
 // Bitmap, page counts and end slots are all-clear at rest: instead of memsets over contig-sized buffers per contig, the
 // candidates wipe exactly what they set (after kd_assign has read it).
+#ifdef PJB_KERNELS_CHAIN
 __global__ __launch_bounds__(256) void kd_reset(const u64 *cand, const u32 *cand_rank, KeyFmt kf, u32 junc_limit, const ContigStats *cs,
                                                 u64 *bitmap, u32 *ends, u32 *page_cnt) {
     const u32 n = cs->n_cand;
@@ -2726,6 +2749,7 @@ __global__ __launch_bounds__(256) void kd_reset(const u64 *cand, const u32 *cand
         }
     }
 }
+#endif // PJB_KERNELS_CHAIN
 struct EndsCountFn {
     const u32 *ends;
     __device__ u64 operator()(u64 rs) const {
@@ -2793,6 +2817,7 @@ __device__ __forceinline__ void anchors_fold(bool valid, u32 j, int32_t l, int32
 // junction id -> intron key (every candidate writes its junction's entry: duplicates write the same value) and the junction's
 // anchors from the candidates' partial ones; thread 0 closes the chain -- P = 0, nothing downstream runs, the host repeats the
 // contig -- if a limit was exceeded while the ids were built
+#ifdef PJB_KERNELS_CHAIN
 __global__ __launch_bounds__(256) void kd_table(const u64 *cand, const u64 *cand_anc, const u32 *cand_rank, KeyFmt kf, u32 junc_limit, const u32 *ends,
                                                 const u32 *first_id, const u64 *total, u64 *jkey, int32_t *anc_l, int32_t *anc_r, ContigStats *cs,
                                                 const u32 *gen_cnt, u32 gen_cap, u32 sort_limit) {
@@ -2846,6 +2871,7 @@ __global__ __launch_bounds__(256) void kd_table(const u64 *cand, const u64 *cand
         }
     }
 }
+#endif // PJB_KERNELS_CHAIN
 
 // fragment record of the per-junction reductions: 48 words (see k4_pairs)
 enum {
@@ -2866,6 +2892,7 @@ __device__ __forceinline__ void acc_rest_state(u32 *acc, u64 n_junc) { // what k
 constexpr int KDA_TILE = 4096; // = RS_TILE
 __device__ __forceinline__ void wave_hist_add(u32 *h, u32 d, bool valid);
 constexpr int KDA_PER = 4;
+#ifdef PJB_KERNELS_CHAIN
 __global__ __launch_bounds__(256) void kd_assign(const u64 *key, const u32 *np, KeyFmt kf, const u64 *bitmap, const u32 *wrank, const u32 *ends,
                                                  const u32 *first_id, u32 junc_limit, const u64 *total, u32 *jid_bam, u32 *acc, const u64 *jkey,
                                                  const int32_t *anc_l, const int32_t *anc_r, u64 *err, ContigStats *cs_chk, int hist_bits, u32 *hist) {
@@ -2967,6 +2994,7 @@ __global__ __launch_bounds__(256) void kd_assign(const u64 *key, const u32 *np, 
         for (u32 d = threadIdx.x; d < nb; d += 256) hist[(size_t)blockIdx.x * nb + d] = s_h[d];
     }
 }
+#endif // PJB_KERNELS_CHAIN
 
 // ---------------------------------------------------------------------------------------------
 // K2: stable LSD radix sort of (key, pair index).  Classic 3-step passes: per-tile digit
@@ -3034,6 +3062,7 @@ __global__ __launch_bounds__(256) void rs_hist(const K *keys, const u32 *np, int
 // tiles and 144 us for a 0.5 Gb chain's 4 400.)  The scatter adds the number of keys with a smaller digit itself (a
 // block scan of the 2^bits totals), so the pass needs neither a scan of the whole matrix nor global atomics.
 constexpr u32 RSP_TILES = 64;
+#ifdef PJB_KERNELS_CHAIN
 __global__ __launch_bounds__(256) void rs_panel_sums(const u32 *hist, u32 n_tiles, u32 nb, u32 *psum) {
     const u32 d = blockIdx.y * 256 + threadIdx.x;
     if (d >= nb) return;
@@ -3048,6 +3077,8 @@ __global__ __launch_bounds__(256) void rs_panel_sums(const u32 *hist, u32 n_tile
     }
     psum[(size_t)blockIdx.x * nb + d] = sum;
 }
+#endif // PJB_KERNELS_CHAIN
+#ifdef PJB_KERNELS_CHAIN
 __global__ __launch_bounds__(256) void rs_panel_scan(const u32 *hist, const u32 *psum, u32 n_tiles, u32 nb, u32 *hist_scan, u32 *row_total) {
     const u32 d = blockIdx.y * 256 + threadIdx.x;
     if (d >= nb) return;
@@ -3073,6 +3104,7 @@ __global__ __launch_bounds__(256) void rs_panel_scan(const u32 *hist, const u32 
     }
     if (t1 == n_tiles) row_total[d] = run; // (the last panel)
 }
+#endif // PJB_KERNELS_CHAIN
 
 // LDS of one rs_scatter block: the tile's keys in digit order (reused for the pair indices), the offset
 // "global position - tile-local position" of every digit, and the digit counters of the 4 waves
@@ -3279,6 +3311,7 @@ struct HeadSink {
         if ((u32)v) run_start[r] = (u32)i;
     }
 };
+#ifdef PJB_KERNELS_CHAIN
 __global__ void k2_close(u64 *total, u32 *seg_off, u32 *run_first, u32 *run_start, ContigStats *cs, u32 junc_limit, const u32 *gen_cnt, u32 gen_cap) {
     const u32 n_pairs = cs->P;
     if (n_pairs == 0) return;
@@ -3307,6 +3340,7 @@ __global__ void k2_close(u64 *total, u32 *seg_off, u32 *run_first, u32 *run_star
     cs->R = R;
     cs->n_slots = J + (n_pairs + 63) / 64;
 }
+#endif // PJB_KERNELS_CHAIN
 
 // K2s for the chain on dense ids: k4_pairs left two bits per sorted pair (junction starts / position run starts), a scan over the
 // slices' popcounts numbers the runs, and this kernel writes what HeadSink writes -- from the masks and the sorted ids alone.
@@ -3315,6 +3349,7 @@ struct Popc64Fn {
     __device__ u64 operator()(u64 i) const { return (u64)__popcll(words[i]); }
 };
 constexpr int K2E_PER = 4;
+#ifdef PJB_KERNELS_CHAIN
 __global__ __launch_bounds__(256) void k2_expand(const u32 *sid, const u64 *head_mask, const u64 *run_mask, const u32 *run_base, const u64 *total,
                                                  u32 *seg_off, u32 *run_first, u32 *run_start, ContigStats *cs) {
     const u32 n = cs->P;
@@ -3342,12 +3377,14 @@ __global__ __launch_bounds__(256) void k2_expand(const u32 *sid, const u64 *head
         cs->n_runs = cs->R = R;
     }
 }
+#endif // PJB_KERNELS_CHAIN
 
 // ---------------------------------------------------------------------------------------------
 // The chain that sorted the FULL keys (PJB_DENSE_IDS off, raw keys, or a donor with more acceptors than K2d keeps) has its
 // junction ids only now: two small kernels give it what kd_assign gives the usual chain -- the rest state of anchors and
 // accumulators, the junction id of every pair in BAM order (k4b_generic works in BAM order) and the anchors.
 // ---------------------------------------------------------------------------------------------
+#ifdef PJB_KERNELS_CHAIN
 __global__ __launch_bounds__(256) void kf_init(u32 *acc, const u32 *n_junc_p, int32_t *anc_l, int32_t *anc_r) {
     const u32 n_junc = *n_junc_p;
     acc_rest_state(acc, n_junc);
@@ -3356,6 +3393,8 @@ __global__ __launch_bounds__(256) void kf_init(u32 *acc, const u32 *n_junc_p, in
         anc_r[t] = INT32_MIN;
     }
 }
+#endif // PJB_KERNELS_CHAIN
+#ifdef PJB_KERNELS_CHAIN
 __global__ __launch_bounds__(256) void kf_anchors(const u32 *sidx, const u32 *jid_of, const PairRec *rec, const u32 *np, u32 *jid_bam, int32_t *anc_l,
                                                    int32_t *anc_r) {
     const u32 n = *np;
@@ -3368,6 +3407,7 @@ __global__ __launch_bounds__(256) void kf_anchors(const u32 *sidx, const u32 *ji
     if (valid) jid_bam[p] = j;
     anchors_fold(valid, j, (int32_t)ra.z, (int32_t)ra.w, anc_l, anc_r);
 }
+#endif // PJB_KERNELS_CHAIN
 
 // ---------------------------------------------------------------------------------------------
 // K4: per-pair match statistics (AlignmentInfo::calcMatchStats junction.cc:147-240 on top of
@@ -3601,6 +3641,7 @@ __device__ __forceinline__ const DevBatch &find_batch(const DevBatch *batches, i
 // walked once; at every N operation the pair's junction-level anchors (kd_assign) are looked up and the two lock-step
 // walks start right there (op index and query offset are at hand: no hint has to travel with the pair).  The result
 // goes into the pair's record.  Runs on the side stream, beside the sort.
+#ifdef PJB_KERNELS_CHAIN
 __global__ __launch_bounds__(256) void k4b_generic(const u64 *list, const u32 *gen_cnt, u32 cap, const u64 *key, PairRec *rec, const u32 *jid_bam,
                                                     KeyFmt kf, const DevBatch *batches, int n_batches, const int32_t *anc_l, const int32_t *anc_r,
                                                     GroupTab G, int genome_has_x, int use_codes, u64 *err, const ContigStats *cs, u32 pack_nn) {
@@ -3702,6 +3743,7 @@ __global__ __launch_bounds__(256) void k4b_generic(const u64 *list, const u32 *g
     }
     } // items
 }
+#endif // PJB_KERNELS_CHAIN
 
 // K4: gather the pairs in sorted order -- one 32-byte record each -- and fold predicates and match statistics to fragment
 // heads with a segmented wave reduction (junction.cc:862-909 accumulators, :755-814 counters).
@@ -3714,6 +3756,7 @@ __global__ __launch_bounds__(256) void k4b_generic(const u64 *list, const u32 *g
 // masks (nullptr: the chain that sorted the full keys has its runs from the head scan): per 64-pair slice, the lanes where a
 // junction starts and the lanes where a run of equal read positions starts (entropy, junction.cc:730-749) -- this kernel holds
 // every pair's record anyway, k2_expand turns the bits into seg_off / run_first / run_start without touching a pair.
+#ifdef PJB_KERNELS_CHAIN
 __global__ __launch_bounds__(256) void k4_pairs(const u32 *sidx, const u32 *jid_of, const PairRec *rec, const u64 *jkey, KeyFmt kf, const u32 *np,
                                                  u32 *frag, int32_t *frag_j, u64 *head_mask, u64 *run_mask, const ContigStats *cs_chk, u64 *err_chk) {
     const u32 n = *np;
@@ -3882,6 +3925,7 @@ __global__ __launch_bounds__(256) void k4_pairs(const u32 *sidx, const u32 *jid_
     const u32 jprev = __shfl_up(j, 1, 64);
     if (valid && (lane == 0 || jprev != j)) store_fragment((u32)(mism64 >> 32));
 }
+#endif // PJB_KERNELS_CHAIN
 
 // K5a: fragment slots -> junction accumulators (acc pre-initialised: sums 0, max 0, min 100000000).
 // One wavefront walks 64 consecutive slots; lane k owns word k of the 48-word record, so every
@@ -3893,6 +3937,7 @@ __device__ __forceinline__ u32 frag_combine(int k, u32 a, u32 b) {
     return a + b; // sums; F_MISM_LO/HI are handled as one 64-bit add by the caller
 }
 constexpr int FRAG_SLOTS_PER_WAVE = 16; // short per-wave chains keep enough wavefronts in flight
+#ifdef PJB_KERNELS_CHAIN
 __global__ __launch_bounds__(256) void k5_frag_reduce(const u32 *frag, const int32_t *frag_j, const u32 *n_slots_p, u32 *acc) {
     const u32 n_slots = *n_slots_p;
     const u32 wave = (blockIdx.x * 256 + threadIdx.x) >> 6;
@@ -3942,6 +3987,7 @@ __global__ __launch_bounds__(256) void k5_frag_reduce(const u32 *frag, const int
     }
     flush(cur);
 }
+#endif // PJB_KERNELS_CHAIN
 
 // ---------------------------------------------------------------------------------------------
 // K5b: one thread per junction: strand from reads, entropy over position runs, splice motif,
@@ -3987,6 +4033,7 @@ __device__ __forceinline__ void fetch_clamp(int32_t glen, int32_t &b, int32_t &e
 // lane its run's term from two neighbouring run starts -- folded in lane order (the chain of dependent adds is the
 // reference's, there is no chain of dependent loads).  (The terms had a kernel and an array of their own until
 // round 4.)
+#ifdef PJB_KERNELS_CHAIN
 __global__ __launch_bounds__(256) void k5_entropy_sum(const u32 *seg_off, const u32 *run_first, const u32 *run_start, const u32 *n_junc_p,
                                                        double *ent_sum) {
     // sixteen lanes per junction, four junctions per wavefront: most junctions have a handful of runs (a whole wavefront each spent
@@ -4020,7 +4067,9 @@ __global__ __launch_bounds__(256) void k5_entropy_sum(const u32 *seg_off, const 
     }
     if (valid && sl == 0) ent_sum[j] = sum;
 }
+#endif // PJB_KERNELS_CHAIN
 
+#ifdef PJB_KERNELS_CHAIN
 __global__ __launch_bounds__(256) void k5_finalize(const u64 *jkey, const u32 *seg_off, const u32 *run_first,
                                                     const u32 *run_start, const u32 *acc, const int32_t *anc_l,
                                                     const int32_t *anc_r, KeyFmt kf, GroupTab G, const u32 *n_junc_p, const double *ent_sum,
@@ -4188,6 +4237,7 @@ __global__ __launch_bounds__(256) void k5_finalize(const u64 *jkey, const u32 *s
     }
     rows[j] = R;
 }
+#endif // PJB_KERNELS_CHAIN
 
 // K6: the contig's rows leave the device inside the kernel chain -- the host does not know the row count when it
 // queues the work, so it cannot size a copy: 8-byte units go straight into page-locked host memory (mapped into the
@@ -4209,6 +4259,7 @@ __device__ __forceinline__ void publish_chain(const ContigStats *cs, u64 *err, u
 // Rows -> the row table, then -- the block that finishes last -- the chain's control block -> page-locked host memory, rest
 // states restored, the cursor advanced (publish_chain; a launch of its own until round 4).  The rows stream runs these
 // launches one after the other, so one counter in the cursor serves every slot.
+#ifdef PJB_KERNELS_CHAIN
 __global__ __launch_bounds__(256) void k6_rows_out(const u64 *rows, const ContigStats *cs, u64 *host_table, int64_t base, int64_t mirror_base,
                                                    RowCursor *cur, u64 *mirror_table, u32 mirror_room, u64 *err, u32 *gen_cnt, uint8_t *host_pub,
                                                    const MemberStats *members, u32 *member_junc, int n_members) {
@@ -4238,6 +4289,7 @@ __global__ __launch_bounds__(256) void k6_rows_out(const u64 *rows, const Contig
     if (threadIdx.x == 0) cur->blocks_done = 0;
     publish_chain(cs, err, gen_cnt, host_pub, base, mirror_base, cur, members, member_junc, n_members);
 }
+#endif // PJB_KERNELS_CHAIN
 
 // The last kernel of a contig: control block, error word and list counters go to page-locked host memory in one go
 // (three small copies otherwise), error word and counters return to their rest state for the contig that uses this

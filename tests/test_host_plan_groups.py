@@ -1,4 +1,5 @@
-"""plan_groups (portcullis_amd/ffi.py): the groups a caller hands to pjb_finish_group_begin -- host logic, no GPU."""
+"""plan_groups (pjb_plan_groups through portcullis_amd/ffi.py): the chain plan of the program, of bench.py and of a multi-GPU rank -- host
+arithmetic of the library, no GPU."""
 import pytest
 
 
@@ -19,9 +20,15 @@ def test_grch38_gives_three_chains_of_about_a_gigabase():
     ([100] * 5, [0, 1, 2, 3, 4], 1 << 30, [[0, 1, 2, 3, 4]]),
     ([100] * 40, list(range(40)), 1 << 30, [list(range(32)), list(range(32, 40))]),        # PJB_GROUP_MAX members at most
     ([1 << 29, 1 << 29, 1 << 29], [0, 1, 2], 1 << 30, [[0], [1], [2]]),                      # the gap between members counts
-    ([10, 1 << 31, 10], [0, 1, 2], 1 << 30, [[0], [1], [2]]),                               # a target longer than the limit stands alone
+    ([10, (1 << 31) - 1, 10], [0, 1, 2], 1 << 30, [[0], [1], [2]]),                         # a target longer than the limit stands alone
     ([5, 5, 5], [2, 0], 1 << 30, [[2, 0]]),                                                 # only the targets named, in the order given
     ([0, 0], [0, 1], 1 << 30, [[0, 1]]),                                                    # empty targets count one base
+    # a set that would be ONE chain of more than 0.6 Gb goes as chains of at most 0.55 of its bases (two, or three when the targets do not
+    # divide that way): the share of a rank of three or four
+    ([300_000_000, 200_000_000, 150_000_000, 100_000_000], [0, 1, 2, 3], 1 << 30, [[0], [1, 2], [3]]),
+    ([300_000_000, 200_000_000], [0, 1], 1 << 30, [[0, 1]]),                                # 0.5 Gb: one chain
+    ([700_000_000], [0], 1 << 30, [[0]]),                                                   # a single target is never split
+    ([], [], 1 << 30, []),
 ])
 def test_edge_cases(lens, tids, max_bases, want):
     from portcullis_amd import ffi

@@ -8,8 +8,10 @@ mkdir -p tools/variants
 for spec in "$@"; do
   name=${spec%%=*}; flags=${spec#*=}
   echo "building $name: $flags"
-  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -Wall -Wno-unused-function $flags -shared \
-      -o tools/variants/libpjb_$name.so portcullis_amd/csrc/pjb_api.hip &
+  ( F="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -Wall -Wno-unused-function $flags"
+    for u in pjb_api pjb_extra_api pjb_ingest_api; do /opt/rocm/bin/hipcc $F -c -o tools/variants/${name}_$u.o portcullis_amd/csrc/$u.hip & done; wait
+    /opt/rocm/bin/hipcc $F -shared -o tools/variants/libpjb_$name.so tools/variants/${name}_pjb_api.o tools/variants/${name}_pjb_extra_api.o tools/variants/${name}_pjb_ingest_api.o
+    rm -f tools/variants/${name}_*.o ) &
 done
 wait
 ls -la tools/variants/

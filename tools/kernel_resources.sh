@@ -2,7 +2,12 @@
 # Register / LDS / occupancy table of every kernel of libportcullis_amd.so (no GPU needed: hipcc's resource-usage remarks).
 #   bash tools/kernel_resources.sh [name-filter]
 cd "$(dirname "$0")/../portcullis_amd/csrc"
-/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -Wno-unused-function -Rpass-analysis=kernel-resource-usage -c -o /tmp/pjb_api_res.o pjb_api.hip 2> /tmp/pjb_resource.txt
+#   UNITS="pjb_api" bash tools/kernel_resources.sh k1_   (one translation unit only: pjb_api | pjb_extra_api | pjb_ingest_api)
+: > /tmp/pjb_resource.txt
+for u in ${UNITS:-pjb_api pjb_extra_api pjb_ingest_api}; do
+  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -Wno-unused-function -Rpass-analysis=kernel-resource-usage -c -o /tmp/${u}_res.o $u.hip 2>> /tmp/pjb_resource.txt &
+done
+wait
 python3 - "$1" <<'PY'
 import re, sys
 flt = sys.argv[1] if len(sys.argv) > 1 else ""
