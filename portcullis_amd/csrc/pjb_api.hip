@@ -278,6 +278,10 @@ int pjb_set_refs(pjb_ctx *c, int32_t n_refs, const int32_t *ref_len) {
 }
 
 static int upload_common(pjb_ctx *c, int32_t tid, uint8_t *d, int64_t len, bool owned, bool do_upper, size_t d_cap = 0) {
+    static const bool prof = getenv("PJB_PROFILE_HOST") != nullptr;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_up0 = now();
+    double t_alloc = 0;
     HIP_TRY(c, hipSetDevice(c->cfg.device));
     int rc = ensure(c, c->b_hasx, sizeof(int));
     if (rc) return rc;
@@ -298,7 +302,9 @@ static int upload_common(pjb_ctx *c, int32_t tid, uint8_t *d, int64_t len, bool 
     const size_t c2_at = ((size_t)(n_words + 2) + 3) & ~(size_t)3;                       // (the 2-bit codes start on a 16-byte boundary)
     const size_t c2_words = len > 0 && !no_seq2 ? (size_t)codes2_alloc_words(len) : 0;
     if (len > 0) {
+        const double ta = now();
         codes = (u32 *)genome_take(c->genome_pool, (c2_at + c2_words) * 4, codes_cap);
+        t_alloc = now() - ta;
         if (!codes) return fail(c, PJB_ERR_NOMEM, "hipMalloc(genome codes, %zu bytes) failed", (c2_at + c2_words) * 4);
         (void)hipMemsetAsync(c->b_hasx.p, 0, sizeof(int), c->stream);
         (void)hipMemsetAsync(codes + n_words, 0, 8, c->stream);
@@ -317,11 +323,15 @@ static int upload_common(pjb_ctx *c, int32_t tid, uint8_t *d, int64_t len, bool 
         hipLaunchKernelGGL(k0_encode2, dim3((unsigned)(((len + 63) / 64 + 255) / 256)), dim3(256), 0, c->stream, (const uint8_t *)d, len, codes2,
                            codes2 + n2w + K0_CODES2_PAD);
     }
+    const double t_sync0 = now();
     hipError_t se = hipStreamSynchronize(c->stream);
     if (se != hipSuccess) {
         if (codes) (void)hipFree(codes);
         return fail(c, PJB_ERR_HIP, "upload: %s", hipGetErrorString(se));
     }
+    if (prof)
+        fprintf(stderr, "[host profile] genome tid %d (%lld bases): codes allocation %.4f, launches %.4f, wait for the stream %.4f s\n", tid, (long long)len, t_alloc,
+                t_sync0 - t_up0 - t_alloc, now() - t_sync0);
     if (exotic && codes) {
         (void)hipFree(codes);
         codes = nullptr;
@@ -397,8 +407,11 @@ int pjb_upload_contig_fasta(pjb_ctx *c, int32_t tid, const uint8_t *raw, int64_t
     if ((rc = ensure(c, c->b_fasta_raw, (size_t)std::max<int64_t>(raw_bytes, 16)))) return rc;
     if ((rc = ensure(c, c->b_hasx, sizeof(int)))) return rc;
     size_t d_cap = 0;
+    const double t_a0 = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
     uint8_t *d = (uint8_t *)genome_take(c->genome_pool, (size_t)std::max<int64_t>(len, 16), d_cap);
     if (!d) return fail(c, PJB_ERR_NOMEM, "hipMalloc(genome %lld) failed", (long long)len);
+    if (getenv("PJB_PROFILE_HOST"))
+        fprintf(stderr, "[host profile] genome tid %d: bases allocation %.4f s\n", tid, std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count() - t_a0);
     struct Guard {
         uint8_t *d;
         ~Guard() {
