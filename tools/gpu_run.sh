@@ -39,7 +39,17 @@ for step in "$@"; do
            for k in 1 2 3; do ( time PJB_PROFILE_HOST=1 PJB_CREATE_TRACE=1 portcullis_amd/host/portcullis_amd junc -t $(nproc) --orientation FR -o /tmp/pjb_bench_e2e/prof/pc /tmp/pjb_bench_e2e/prep ) > $OUT/${TAG}_e2e_host_profile_$k.txt 2>&1; grep -E "real|Wall" $OUT/${TAG}_e2e_host_profile_$k.txt | head -3; done
            grep -E "host profile" $OUT/${TAG}_e2e_host_profile_2.txt | grep -v "submit_bam\|\] chr" | tail -40
            # the two chain plans side by side (wall of the command, alternating): groups (the default for this input) / one chain per target
-           for k in 1 2 3 4; do for plan in groups targets; do s=$(date +%s.%N); PORTCULLIS_CHAIN_PLAN=$plan portcullis_amd/host/portcullis_amd junc -t $(nproc) --orientation FR -o /tmp/pjb_bench_e2e/prof/pc_$plan /tmp/pjb_bench_e2e/prep > /dev/null 2>&1; e=$(date +%s.%N); python3 -c "print('e2e plan $plan: %.3f s' % ($e - $s))"; done; done | tee $OUT/${TAG}_e2e_plans.txt
+           for k in 1 2 3 4 5 6; do for plan in groups:0 targets:0 groups:536870912 groups:268435456; do p=${plan%%:*}; gb=${plan##*:}; s=$(date +%s.%N); PORTCULLIS_CHAIN_PLAN=$p PORTCULLIS_GROUP_BASES=$gb portcullis_amd/host/portcullis_amd junc -t $(nproc) --orientation FR -o /tmp/pjb_bench_e2e/prof/pc_$p /tmp/pjb_bench_e2e/prep > /dev/null 2>&1; e=$(date +%s.%N); python3 -c "print('e2e plan $plan: %.3f s' % ($e - $s))"; done; done | tee $OUT/${TAG}_e2e_plans.txt
+           python3 - $OUT/${TAG}_e2e_plans.txt <<'PY' | tee -a $OUT/${TAG}_e2e_plans.txt
+import sys, collections, statistics
+d = collections.defaultdict(list)
+for ln in open(sys.argv[1]):
+    if ln.startswith("e2e plan "):
+        k, v = ln[9:].split(": ")
+        d[k].append(float(v.split()[0]))
+for k, v in d.items():
+    print(f"median {k}: {statistics.median(v):.3f} s  (min {min(v):.3f}, max {max(v):.3f}, {len(v)} runs)")
+PY
            md5sum /tmp/pjb_bench_e2e/prof/pc_groups.junctions.tab /tmp/pjb_bench_e2e/prof/pc_targets.junctions.tab | tee -a $OUT/${TAG}_e2e_plans.txt ;;
     fuzz) ( timeout 1500 python tests/fuzz_campaign.py; timeout 900 python tests/fuzz_groups.py; timeout 900 python tests/fuzz_extra.py ) 2>&1 | tail -30 | tee $OUT/${TAG}_fuzz.txt ;;
     inflate) # bgzf_decode at both launch sizes: ~6 k blocks a launch (the C2 file in 256 MB chunks) and ~130 k (the file four times over, one launch)
