@@ -23,7 +23,7 @@ def main():
     ap.add_argument("--start", type=int, default=1000)
     ap.add_argument("--max-reads", type=int, default=6000)
     args = ap.parse_args()
-    from fuzzgen import make_reads, to_batch
+    from fuzzgen import EXC_OPTS, make_reads, to_batch
     from oracle import oracle as orc
     from parity import assert_rows_equal, region_equal
     from portcullis_amd import ffi
@@ -31,7 +31,10 @@ def main():
     from util_bam import write_bam
 
     oris = ["UNKNOWN", "FR", "RF", "FF", "SE"]
-    opt_sets = [None, dict(indel=0.3, clip=0.4, hard=0.1), dict(eqx=0.5, pad=0.1, sub=0.05), dict(indel=0.0, clip=0.0, hard=0.0, sub=0.0)]
+    # (the last two: round 6's "exception channel" family -- a genome of pure ACGT but for letters planted at the anchors' edges, reads with
+    # N / IUPAC codes / '=' of their own -- alone and with many indels: the 2-bit and the 4-bit compare side by side in one wavefront)
+    opt_sets = [None, dict(indel=0.3, clip=0.4, hard=0.1), dict(eqx=0.5, pad=0.1, sub=0.05), dict(indel=0.0, clip=0.0, hard=0.0, sub=0.0),
+                dict(EXC_OPTS), dict(EXC_OPTS, indel=0.3, clip=0.4)]
     t0 = time.time()
     n_j = 0
     fails = []
@@ -53,6 +56,13 @@ def main():
                 drows, dreg = ffi.run_contig(ctx, 0, genome.encode(), [batch])
                 region_equal(dreg, oreg)
                 assert_rows_equal(drows, orows)
+                # 1b. the same batch with 4-bit bases only (pjb_batch.seq2 = NULL: round 5's compare)
+                if seed % 3 == 0:
+                    ctx.clear_rows()
+                    ctx.submit_batch(0, batch, seq2=False)
+                    dreg = ctx.finish_contig(0)
+                    region_equal(dreg, oreg)
+                    assert_rows_equal(ctx.collect(), orows)
                 # 2. ragged batches
                 cuts = sorted(set(int(x) for x in rng.integers(1, max(2, batch.n), size=int(rng.integers(1, 6)))))
                 cuts = [0] + [c for c in cuts if 0 < c < batch.n] + [batch.n]
@@ -82,7 +92,7 @@ def main():
             n_j += len(orows)
         except Exception as e:  # keep going: report every failing seed
             fails.append((seed, ori, repr(e)[:300]))
-    print(f"{args.seeds} seeds from {args.start}: {n_j} junctions compared three ways each, {len(fails)} failures, {time.time() - t0:.0f} s")
+    print(f"{args.seeds} seeds from {args.start}: {n_j} junctions compared three ways each (a third of the seeds a fourth way: 4-bit bases only), {len(fails)} failures, {time.time() - t0:.0f} s")
     for f in fails[:20]:
         print("FAIL", f)
     sys.exit(1 if fails else 0)

@@ -51,7 +51,11 @@ for k, v in d.items():
     print(f"median {k}: {statistics.median(v):.3f} s  (min {min(v):.3f}, max {max(v):.3f}, {len(v)} runs)")
 PY
            md5sum /tmp/pjb_bench_e2e/prof/pc_groups.junctions.tab /tmp/pjb_bench_e2e/prof/pc_targets.junctions.tab | tee -a $OUT/${TAG}_e2e_plans.txt ;;
-    fuzz) ( timeout 1500 python tests/fuzz_campaign.py; timeout 900 python tests/fuzz_groups.py; timeout 900 python tests/fuzz_extra.py ) 2>&1 | tail -30 | tee $OUT/${TAG}_fuzz.txt ;;
+    fuzz) ( timeout 1500 python tests/fuzz_campaign.py --seeds ${FUZZ_SEEDS:-100} --start ${FUZZ_START:-1000}; timeout 900 python tests/fuzz_groups.py --seeds ${FUZZ_GROUP_SEEDS:-100}; timeout 900 python tests/fuzz_extra.py ) 2>&1 | tail -30 | tee $OUT/${TAG}_fuzz.txt ;;
+    fuzzbig) # the round's campaign: FUZZ_SEEDS seeds of fuzz_campaign.py in four processes side by side, then the group and the --extra campaigns
+           n=${FUZZ_SEEDS:-1200}; q=$((n / 4))
+           for k in 0 1 2 3; do ( timeout 3000 python tests/fuzz_campaign.py --seeds $q --start $((${FUZZ_START:-20000} + k * q)) 2>&1 | tail -8 > $OUT/${TAG}_fuzz_part$k.txt ) & done; wait
+           ( cat $OUT/${TAG}_fuzz_part?.txt; timeout 1500 python tests/fuzz_groups.py --seeds ${FUZZ_GROUP_SEEDS:-300} --start 9000; timeout 1500 python tests/fuzz_extra.py ) 2>&1 | tail -40 | tee $OUT/${TAG}_fuzz.txt ;;
     inflate) # bgzf_decode at both launch sizes: ~6 k blocks a launch (the C2 file in 256 MB chunks) and ~130 k (the file four times over, one launch)
            python tools/bench_inflate.py > $OUT/${TAG}_inflate_small.json 2> $OUT/${TAG}_inflate.err
            python tools/bench_inflate.py --chunk-mb 8192 --times 4 > $OUT/${TAG}_inflate_large.json 2>> $OUT/${TAG}_inflate.err
