@@ -145,7 +145,8 @@ typedef struct pjb_batch {
     /* ---- ABI 4 (read only when pjb_config.abi_version >= 4; both NULL: the compares run on seq4 as before) ----
      * seq2     the same bases in 2 bits (A 0, C 1, G 2, T 3), one uint16 per seq4 WORD: element seq_off[r] + k holds bases 8k .. 8k+7 of
      *          read r, base j at bits 2j, 2j+1 (what is stored for a base outside ACGT, or behind the read's last base, does not matter).
-     *          As many elements as seq4 has words; the array starts on a 4-byte boundary.
+     *          As many elements as seq4 has words, rounded up to an even number (the device reads the array as 32-bit words); the array
+     *          starts on a 4-byte boundary.
      * seq_exc  bit r (bit r & 31 of word r >> 5) set: read r is NOT to be compared in 2 bits -- one of its l_qseq bases is not A, C, G or
      *          T (BAM codes 1, 2, 4, 8), or it carries fewer than l_qseq bases.  (n_reads + 31) / 32 words.
      * Who fills them: the device ingest (pjb_submit_bam / pjb_bam_*) as it transcodes the records; a caller that decodes BAM itself
