@@ -2133,10 +2133,17 @@ __global__ __launch_bounds__(K1E_T) __attribute__((amdgpu_waves_per_eu(K1E_WAVES
         R.on = s >= T.s_begin && s < T.s_end;
         R.slot = R.r = R.toff = R.poff = 0;
         R.sr = make_uint4(0, 0, 0, 0);
+        // The entry's tile = the number of the window's offsets it has reached (they ascend).  A wavefront's 64 entries are consecutive: they
+        // lie in one tile, seldom in two or three -- so lane m holds offset m, two ballots say how many offsets the wavefront's first and last
+        // entry have reached, and only the offsets in between (none, mostly) are compared lane by lane.  (It was fifteen LDS reads and
+        // compares a lane: the kernel is bound by instruction issue -- round 6's SQ counters: its four wavefronts keep a SIMD's issue port
+        // busy 104 % of the time between them --, so every instruction of a trip counts.)
+        const u32 w_first = (T.chunk << K1E_SHIFT) + (threadIdx.x & ~63u);
+        const u32 off_m = lane_id() < K1E_LOOK ? s_soff[lane_id() & (K1E_LOOK - 1)] : 0xffffffffu;
+        const u32 m_lo = (u32)__popcll(__ballot(off_m <= w_first)), m_hi = (u32)__popcll(__ballot(off_m <= w_first + 63u));
         if (R.on) {
-            u32 k = 0; // (the offsets ascend: the entry's tile is the number of them it has reached -- 15 independent LDS reads, not a walk)
-#pragma unroll
-            for (int m = 1; m < K1E_LOOK; m++) k += s >= s_soff[m] ? 1u : 0u;
+            u32 k = m_lo ? m_lo - 1u : 0u; // (m_lo >= 1: offset 0 belongs to the tile of the trip's first entry or an earlier one)
+            for (u32 m = m_lo ? m_lo : 1u; m < m_hi; m++) k += s >= (u32)__builtin_amdgcn_readlane((int)off_m, (int)m) ? 1u : 0u;
             u32 tile = win_t0 + k, soff = s_soff[k];
             if (k + 1 == (u32)K1E_LOOK && s >= soff) { // (a run of tiles without spliced reads longer than the window: search)
                 u32 lo = tile, hi = n_tiles_total; // tile_soff[lo] <= s < tile_soff[hi]
@@ -2236,9 +2243,9 @@ __global__ __launch_bounds__(K1E_T) __attribute__((amdgpu_waves_per_eu(K1E_WAVES
         u32 dS = 0, a = 0, nl = 0, b2 = 0, nl2 = 0, b3 = 0, meta = 0, off = 0, g = 0;
         if (on) {
             const u32 n = O.n;
-            u32 op[OPS_LDS];
-#pragma unroll
-            for (int q = 0; q < OPS_LDS; q++) op[q] = (u32)q < n ? O.op[q] : 0u;
+            // (what lies behind the read's last operation -- the next read's operations -- is never looked at: every use below is behind a
+            // test of n)
+            const u32 (&op)[OPS_LDS] = O.op;
             g = b.base + R.r;
             off = R.toff + R.poff;
             meta = read_meta(O.flag, O.xs & 0xffu, O.mapq, pos, O.mtid, O.mpos, tid, orientation);
