@@ -100,10 +100,7 @@ def algorithmic_bytes(name, N, C, S, Cs, P, J, L, Pg=0, Rg=0, R=0, cand=0, Rv=0,
         "k2_heads_apply": P * 16 + P * 4 + (J + J + R) * 4,
         # generic reads: list entry (8), cig_off (8), ops, pos/aend half of the first record (16), l_qseq, seq_off (12), L/2 B of
         # bases; per generic pair: id (4), key (8), anchors (8), genome codes of its window (~L/2), result (8)
-        "k4b_generic": Rg * (44 + 4 * ops_s + L / 2) + Pg * (28 + L / 2),
-        # the window check of the closed forms (round 6: a kernel of its own): list entry (8), per pair of the read its key, junction id and
-        # the junction's two anchors (2 x 28), the N count from the entry
-        "k4b_check": Rv * (8 + 16 + 2 * 28),
+        "k4b_generic": Rg * (44 + 4 * ops_s + L / 2) + Pg * (28 + L / 2) + Rv * (8 + 16 + 2 * 28),
         # dense chains: a popcount scan over the slices' two mask words, then seg_off / run_first per junction, run_start per run, from
         # the sorted ids (4 B per pair) and the masks
         "k2_runs_reduce": P / 64.0 * 8, "k2_runs_apply": P / 64.0 * 12,

@@ -694,7 +694,7 @@ static int queue_contig(pjb_ctx *c, Flight &f) {
     // entries per sub-list (list_cap_forced: the test hook pjb_set_option("list_cap", n) -- a first attempt with a room that overflows)
     const u32 gen_cap = lim.list_cap ? lim.list_cap : (c->list_cap_forced ? c->list_cap_forced : gen_list_cap(PL));
     const u32 pack_nn = (u64)f.n_reads < (1ull << 28) ? 1u : 0u; // (EmitLists::pack_nn)
-    if ((rc = ensure(c, S.genlist, (size_t)gen_cap * GEN_SHARDS * 8 * 4))) return rc; // (three lists: EmitLists; the fourth: the reads that fail k4b_check)
+    if ((rc = ensure(c, S.genlist, (size_t)gen_cap * GEN_SHARDS * 8 * 3))) return rc; // (three lists: EmitLists)
     if ((rc = ensure(c, S.gencount, GEN_SHARDS * GEN_CNT_STRIDE * 4))) return rc; // a line per sub-list: reads, pairs
     // ---- junction-sized buffers
     const u32 slots_lim = JL + (PL + 63) / 64 + 1;
@@ -886,8 +886,6 @@ static int queue_contig(pjb_ctx *c, Flight &f) {
     // the sort, on the side stream
     const u32 gen_grid = std::min<u32>(2 * (u32)(((u64)gen_cap * GEN_SHARDS + 255) / 256), 2560u); // (the blocks stride over the lists' entries)
     auto launch_k4b = [&]() -> int {
-        LAUNCH(c, "k4b_check", k4b_check, dim3(gen_grid), dim3(256), (u64 *)S.genlist.p, d_gen_cnt, gen_cap, (const u64 *)pr.key, (const PairRec *)pr.rec,
-               (const u32 *)S.jidbam.p, kf, (const int32_t *)S.ancl.p, (const int32_t *)S.ancr.p, (const ContigStats *)d_cs, pack_nn);
         LAUNCH(c, "k4b_generic", k4b_generic, dim3(gen_grid), dim3(256), (const u64 *)S.genlist.p, (const u32 *)d_gen_cnt, gen_cap, (const u64 *)pr.key,
                pr.rec, (const u32 *)S.jidbam.p, kf, (const DevBatch *)S.batches.p, (int)batches.size(), (const int32_t *)S.ancl.p, (const int32_t *)S.ancr.p,
                GT, any_x ? 1 : 0, any_x ? 0 : 1, d_err, (const ContigStats *)d_cs, pack_nn);

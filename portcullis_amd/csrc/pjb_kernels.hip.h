@@ -3152,11 +3152,8 @@ __device__ __forceinline__ u64 wave_match_digit(u32 d, bool valid, int bits) {
 // hist + rowscan + scatter: with every tile resident at once the look-back chain costs more than the
 // two small kernels, so it was dropped.
 // K: u64 (full intron keys) or u32 (dense junction ids: half the key traffic, half the key registers)
-#ifndef RS_SCATTER_WAVES
-#define RS_SCATTER_WAVES 3 // wavefronts per SIMD the register allocation must allow (tools/build_variants.sh builds 4 and 5 for A/B runs)
-#endif
 template <int BITS, typename K>
-__global__ __launch_bounds__(256, RS_SCATTER_WAVES) void rs_scatter(const K *kin, const u32 *vin, K *kout, u32 *vout, const u32 *np, int shift,
+__global__ __launch_bounds__(256, 3) void rs_scatter(const K *kin, const u32 *vin, K *kout, u32 *vout, const u32 *np, int shift,
                                                       int bits, const u32 *hist_scan, const u32 *row_total, u32 n_tiles) {
     extern __shared__ __attribute__((aligned(16))) unsigned char rs_smem[];
     __shared__ u64 s_scan[4];
@@ -3651,42 +3648,46 @@ __device__ __forceinline__ const DevBatch &find_batch(const DevBatch *batches, i
 // walked once; at every N operation the pair's junction-level anchors (kd_assign) are looked up and the two lock-step
 // walks start right there (op index and query offset are at hand: no hint has to travel with the pair).  The result
 // goes into the pair's record.  Runs on the side stream, beside the sort.
-// The window check of the closed forms as a kernel of its own (round 6): a thread per read of the chain's SECOND list -- the reads of the shape
-// [S] M (N M)+ [S] with two and more introns whose pairs k1_emit / k1_generic finished with the M blocks as anchors.  That is what the walks
-// produce unless the junction's window reaches over a neighbouring intron of the read: on the left the walk starts at the first operation
-// that begins inside the window (the previous N begins at its istart), on the right it stops at an N that ends outside it
-// (bam_alignment.cc:359).  All but a handful pass; a read that fails goes on the FOURTH list -- dense, `fail_cnt` entries -- and
-// k4b_generic walks all its pairs.  (As one kernel with the walks the check ran at the walks' 101 registers, four wavefronts a SIMD: three
-// dependent gathers a read with nothing to hide them behind.)
-constexpr u32 GEN_FAIL_WORD = 6; // word of the first shard's counter line that counts the fourth list's entries (publish_chain clears the line)
 #ifdef PJB_KERNELS_CHAIN
-__global__ __launch_bounds__(256) void k4b_check(u64 *list, u32 *gen_cnt, u32 cap, const u64 *key, const PairRec *rec, const u32 *jid_bam, KeyFmt kf,
-                                                  const int32_t *anc_l, const int32_t *anc_r, const ContigStats *cs, u32 pack_nn) {
-    __shared__ u32 s_first[GEN_SHARDS + 1]; // item index of every sub-list's first entry
+__global__ __launch_bounds__(256) void k4b_generic(const u64 *list, const u32 *gen_cnt, u32 cap, const u64 *key, PairRec *rec, const u32 *jid_bam,
+                                                    KeyFmt kf, const DevBatch *batches, int n_batches, const int32_t *anc_l, const int32_t *anc_r,
+                                                    GroupTab G, int genome_has_x, int use_codes, u64 *err, const ContigStats *cs, u32 pack_nn) {
+    __shared__ u32 s_ops[OPS_LDS][256];
+    __shared__ u32 s_first[2 * GEN_SHARDS + 1]; // item index of every sub-list's first entry (both lists, one index space)
     __shared__ u32 s_wsum[4];
     if (cs->P == 0) return; // (a limit was exceeded while the junction ids were built: there are no ids, the chain is repeated)
+    // The sub-lists are filled to different heights (sub-list `shard` of list `l` occupies [(l GEN_SHARDS + shard) cap, ... + its
+    // count)): every block numbers their entries -- an exclusive scan over the 512 counts -- and the grid strides over the items.
     {
-        const u32 c0 = gen_cnt[threadIdx.x * GEN_CNT_STRIDE + 2];
-        const u32 n0 = c0 < cap ? c0 : cap;
+        const u32 i0 = threadIdx.x * 2;
+        const u32 c0 = gen_cnt[(i0 % GEN_SHARDS) * GEN_CNT_STRIDE + (i0 / GEN_SHARDS) * 2];
+        const u32 c1 = gen_cnt[((i0 + 1) % GEN_SHARDS) * GEN_CNT_STRIDE + ((i0 + 1) / GEN_SHARDS) * 2];
+        const u32 n0 = c0 < cap ? c0 : cap, n1 = c1 < cap ? c1 : cap;
         u32 total;
-        const u32 ex = block_escan<4>(n0, s_wsum, &total);
-        s_first[threadIdx.x] = ex;
-        if (threadIdx.x == 255) s_first[GEN_SHARDS] = total;
+        const u32 ex = block_escan<4>(n0 + n1, s_wsum, &total);
+        s_first[i0] = ex;
+        s_first[i0 + 1] = ex + n0;
+        if (threadIdx.x == 255) s_first[2 * GEN_SHARDS] = total;
         __syncthreads();
     }
-    static_assert(GEN_SHARDS == 256, "a sub-list per thread of the block");
-    const u32 n_items = s_first[GEN_SHARDS];
-    const u64 *list2 = list + (size_t)GEN_SHARDS * cap;
-    u64 *list4 = list + (size_t)3 * GEN_SHARDS * cap;
+    static_assert(GEN_SHARDS == 256, "two sub-lists per thread of the block");
+    const u32 n_items = s_first[2 * GEN_SHARDS];
     for (u32 item0 = blockIdx.x * 256; item0 < n_items; item0 += gridDim.x * 256) {
-        const u32 item = item0 + threadIdx.x;
-        if (item >= n_items) continue; // (no barrier below)
-        u32 sub = 0; // the last sub-list with s_first[sub] <= item
+    const u32 item = item0 + threadIdx.x;
+    if (item >= n_items) continue; // (no barrier below)
+    u32 sub = 0; // the last sub-list with s_first[sub] <= item
 #pragma unroll
-        for (u32 step = GEN_SHARDS / 2; step > 0; step >>= 1)
-            if (s_first[sub + step] <= item) sub += step;
-        const u64 entry = list2[(size_t)sub * cap + (item - s_first[sub])];
-        const u32 p0 = (u32)(entry >> 32);
+    for (u32 step = GEN_SHARDS; step > 0; step >>= 1)
+        if (sub + step < 2 * GEN_SHARDS && s_first[sub + step] <= item) sub += step;
+    const bool check_only = sub >= GEN_SHARDS;
+    const u64 entry = list[(size_t)sub * cap + (item - s_first[sub])];
+    const u32 p0 = (u32)(entry >> 32);
+    const u32 g = check_only && pack_nn ? (u32)entry & 0x0fffffffu : (u32)entry;
+    if (check_only) {
+        // A read [S] M (N M)+ [S] whose pairs k1_emit finished with the M blocks as anchors.  That is what the walks produce
+        // unless the junction's window reaches over a neighbouring intron of the read: on the left the walk starts at the
+        // first operation that begins inside the window (the previous N begins at its istart), on the right it stops at an N
+        // that ends outside it (bam_alignment.cc:359).  A read that fails the test takes the walks below -- all its pairs.
         // N operations of the read: in the entry, or from its first pair's record (no junction of the read ends before that pair, one is its own)
         const u32 code = pack_nn ? (u32)entry >> 28 : 15u;
         const u32 nN = code < 15u ? code : (reinterpret_cast<const uint4 *>(rec + p0)[1].w >> 16) + 1u;
@@ -3703,53 +3704,8 @@ __global__ __launch_bounds__(256) void k4b_check(u64 *list, u32 *gen_cnt, u32 ca
             is = nis;
             ie = nie;
         }
-        (void)ie;
-        if (!ok) list4[atomicAdd(&gen_cnt[GEN_FAIL_WORD], 1u)] = entry; // (at most as many as the second list holds: the fourth has its room)
+        if (ok) continue;
     }
-}
-#endif // PJB_KERNELS_CHAIN
-
-// The walks: a thread per read of the chain's FIRST list (the reads whose pairs need the lock-step padded query / genome walks) and of the
-// fourth (the reads whose closed form failed k4b_check's window test).
-#ifdef PJB_KERNELS_CHAIN
-__global__ __launch_bounds__(256) void k4b_generic(const u64 *list, const u32 *gen_cnt, u32 cap, const u64 *key, PairRec *rec, const u32 *jid_bam,
-                                                    KeyFmt kf, const DevBatch *batches, int n_batches, const int32_t *anc_l, const int32_t *anc_r,
-                                                    GroupTab G, int genome_has_x, int use_codes, u64 *err, const ContigStats *cs, u32 pack_nn) {
-    __shared__ u32 s_ops[OPS_LDS][256];
-    __shared__ u32 s_first[GEN_SHARDS + 2]; // item index of every sub-list's first entry (the first list's sub-lists, then the fourth list)
-    __shared__ u32 s_wsum[4];
-    if (cs->P == 0) return; // (a limit was exceeded while the junction ids were built: there are no ids, the chain is repeated)
-    // The sub-lists are filled to different heights (sub-list `shard` of list `l` occupies [(l GEN_SHARDS + shard) cap, ... + its
-    // count)): every block numbers their entries -- an exclusive scan over the counts -- and the grid strides over the items.
-    {
-        const u32 c0 = gen_cnt[threadIdx.x * GEN_CNT_STRIDE];
-        const u32 n0 = c0 < cap ? c0 : cap;
-        u32 total;
-        const u32 ex = block_escan<4>(n0, s_wsum, &total);
-        s_first[threadIdx.x] = ex;
-        if (threadIdx.x == 255) {
-            s_first[GEN_SHARDS] = total;
-            s_first[GEN_SHARDS + 1] = total + gen_cnt[GEN_FAIL_WORD];
-        }
-        __syncthreads();
-    }
-    static_assert(GEN_SHARDS == 256, "a sub-list per thread of the block");
-    const u32 n_walk = s_first[GEN_SHARDS], n_items = s_first[GEN_SHARDS + 1];
-    for (u32 item0 = blockIdx.x * 256; item0 < n_items; item0 += gridDim.x * 256) {
-    const u32 item = item0 + threadIdx.x;
-    if (item >= n_items) continue; // (no barrier below)
-    const bool failed_check = item >= n_walk;
-    u64 entry;
-    if (failed_check) entry = list[(size_t)3 * GEN_SHARDS * cap + (item - n_walk)];
-    else {
-        u32 sub = 0; // the last sub-list with s_first[sub] <= item
-#pragma unroll
-        for (u32 step = GEN_SHARDS / 2; step > 0; step >>= 1)
-            if (s_first[sub + step] <= item) sub += step;
-        entry = list[(size_t)sub * cap + (item - s_first[sub])];
-    }
-    const u32 p0 = (u32)(entry >> 32);
-    const u32 g = failed_check && pack_nn ? (u32)entry & 0x0fffffffu : (u32)entry;
     const DevBatch &b = find_batch(batches, n_batches, g);
     const u32 r = g - b.base;
     const u32 *cig_off = b.cig_off;
