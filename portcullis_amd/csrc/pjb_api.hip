@@ -315,13 +315,16 @@ static int upload_common(pjb_ctx *c, int32_t tid, uint8_t *d, int64_t len, bool 
     // 2-bit codes and their exception bitmap for k1_emit's compares (PJB_NO_SEQ2=1: not built -- A/B runs): behind the 4-bit codes, in
     // the same allocation (a hipMalloc is milliseconds on the thread that serves every target)
     u32 *codes2 = nullptr;
+    int any_exc = 1;
     if (codes && c2_words) {
         codes2 = codes + c2_at;
+        (void)hipMemsetAsync(c->b_hasx.p, 0, sizeof(int), c->stream);
         const int64_t n2w = codes2_words(len), nxw = gexc_words(len);
         (void)hipMemsetAsync(codes2 + n2w, 0, (size_t)K0_CODES2_PAD * 4, c->stream);
         (void)hipMemsetAsync(codes2 + n2w + K0_CODES2_PAD + nxw, 0, (size_t)K0_GEXC_PAD * 4, c->stream);
         hipLaunchKernelGGL(k0_encode2, dim3((unsigned)(((len + 63) / 64 + 255) / 256)), dim3(256), 0, c->stream, (const uint8_t *)d, len, codes2,
-                           codes2 + n2w + K0_CODES2_PAD);
+                           codes2 + n2w + K0_CODES2_PAD, (int *)c->b_hasx.p);
+        (void)hipMemcpyAsync(&any_exc, c->b_hasx.p, sizeof(int), hipMemcpyDeviceToHost, c->stream);
     }
     const double t_sync0 = now();
     hipError_t se = hipStreamSynchronize(c->stream);
@@ -346,6 +349,7 @@ static int upload_common(pjb_ctx *c, int32_t tid, uint8_t *d, int64_t len, bool 
     g.present = true;
     g.codes = codes;
     g.codes2 = codes2;
+    g.any_exc = any_exc != 0;
     g.d_cap = owned ? d_cap : 0;
     g.codes_cap = codes ? codes_cap : 0;
     return PJB_OK;
@@ -620,6 +624,7 @@ static int queue_contig(pjb_ctx *c, Flight &f) {
         GT.d[m] = g.d;
         GT.codes[m] = g.codes;
         GT.codes2[m] = g.codes2;
+        if (g.any_exc) GT.exc_members |= 1u << m;
         all_codes = all_codes && g.codes != nullptr;
         any_x = any_x || g.has_x;
     }

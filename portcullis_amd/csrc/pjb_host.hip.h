@@ -45,6 +45,7 @@ struct Contig {
     bool present = false;
     u32 *codes = nullptr; // packed 4-bit codes (k0_encode); nullptr when the contig is "exotic"
     u32 *codes2 = nullptr; // 2-bit codes | exception bitmap (k0_encode2): behind the 4-bit codes, in their allocation
+    bool any_exc = true;   // the bitmap has a bit set (false: k1_emit never looks at it)
     size_t d_cap = 0, codes_cap = 0; // sizes of the allocations (they go back to the context's genome pool)
 };
 

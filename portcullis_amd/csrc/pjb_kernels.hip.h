@@ -163,6 +163,7 @@ struct GroupTab {
     const u32 *codes[GROUP_MAX];   // 4-bit codes (nullptr: exotic member)
     const u32 *codes2[GROUP_MAX];  // 2-bit codes and, behind them, the bitmap of the 64-base stretches that hold a character outside ACGT
                                    // (k0_encode2; nullptr with codes)
+    u32 exc_members;               // bit m: member m's bitmap has a bit set at all (else k1_emit does not look at it)
 };
 struct Member {
     int32_t idx, voff, len, tid;
@@ -653,7 +654,7 @@ __host__ __device__ inline int64_t codes2_words(int64_t n) { return ((n + 63) / 
 __host__ __device__ inline int64_t gexc_words(int64_t n) { return (((n + 63) / 64 + 63) / 64) * 2; } // (whole u64s)
 __host__ __device__ inline int64_t codes2_alloc_words(int64_t n) { return codes2_words(n) + K0_CODES2_PAD + gexc_words(n) + K0_GEXC_PAD; }
 #ifdef PJB_KERNELS_CHAIN
-__global__ __launch_bounds__(256) void k0_encode2(const uint8_t *g, int64_t n, u32 *codes2, u32 *gexc) {
+__global__ __launch_bounds__(256) void k0_encode2(const uint8_t *g, int64_t n, u32 *codes2, u32 *gexc, int *any_exc) {
     const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x; // stretch
     const int64_t n_str = (n + 63) / 64;
     bool exc = false;
@@ -688,6 +689,7 @@ __global__ __launch_bounds__(256) void k0_encode2(const uint8_t *g, int64_t n, u
     }
     const u64 m = __ballot(exc);
     if (lane_id() == 0 && s < ((n_str + 63) / 64) * 64) reinterpret_cast<u64 *>(gexc)[s >> 6] = m;
+    if (m && lane_id() == 0) atomicOr(any_exc, 1); // (a target without a single exception -- a telomere-to-telomere assembly, a bacterium -- is never asked)
 }
 #endif // PJB_KERNELS_CHAIN
 
@@ -1912,10 +1914,11 @@ struct EmitCtx {
     // k1_generic): one returning atomic per wavefront; sub-list `shard` (callers deal 256-entry chunks round-robin: gen_list_cap)
     // the same in two halves: the returning atomic early (list_reserve), the stores once its answer is there (list_write) -- a wavefront
     // that appends and stores at once waits a memory round trip for the atomic
+    // (`pairs`: the same for every entry of the call -- k1_emit's lists hold reads of two pairs, or count none)
     __device__ __forceinline__ u32 list_reserve(u32 kind, bool mine, u32 pairs, u32 shard) const {
         const u64 gm2 = __ballot(mine);
         if (!gm2) return 0u;
-        const u32 pairs_w = wave_total<DppAdd>(mine ? pairs : 0u);
+        const u32 pairs_w = pairs * (u32)__popcll(gm2);
         const int leader = __ffsll((long long)gm2) - 1;
         const u32 w0 = shard * GEN_CNT_STRIDE + (kind - 1) * 2;
         u32 base = 0;
@@ -2287,8 +2290,9 @@ __global__ __launch_bounds__(K1E_T) __attribute__((amdgpu_waves_per_eu(K1E_WAVES
         bool use2 = simple && gcodes2 != nullptr && !(O.xs & 0x100u) && pos >= 0 && (int64_t)pos + a + nl + b2 + nl2 + b3 <= (int64_t)ref_len &&
                     a <= (u32)C2_MAX_BLOCK && b2 <= (u32)C2_MAX_BLOCK && b3 <= (u32)C2_MAX_BLOCK;
         const int64_t n2w = codes2_words(ref_len);
+        const bool any_exc = (G.exc_members >> mem) & 1u; // (uniform)
         Words2 x0 = {0, 0}, x1 = {0, 0}, x2 = {0, 0};
-        if (use2) {
+        if (use2 && any_exc) {
             const PJB_GLOBAL u32 *gexc = gcodes2 + n2w + K0_CODES2_PAD;
             const u32 g1 = (u32)pos + a + nl;
             x0 = gload_as<Words2>(gexc + ((u32)pos >> 11));
@@ -2361,7 +2365,7 @@ __global__ __launch_bounds__(K1E_T) __attribute__((amdgpu_waves_per_eu(K1E_WAVES
                     const u64 bits = (((u64)1 << cnt) - 1u) << (b0 & 31u);
                     return (((u64)w.x | ((u64)w.y << 32)) & bits) != 0;
                 };
-                if (use2 && (hit(x0, bg[0], bl[0]) || hit(x1, bg[1], bl[1]) || (two && hit(x2, bg[2], bl[2])))) use2 = false;
+                if (any_exc && use2 && (hit(x0, bg[0], bl[0]) || hit(x1, bg[1], bl[1]) || (two && hit(x2, bg[2], bl[2])))) use2 = false;
             }
 #ifdef K1E_HIST
             u32 h_rounds = 0, h_mine = 0, h_rounds4 = 0;

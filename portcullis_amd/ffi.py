@@ -187,11 +187,13 @@ _FIELDS = [("pos", np.int32), ("flag", np.uint16), ("mapq", np.uint8), ("xs", np
 class Context:
     """One device context (pjb_ctx).  Mirrors the calls JunctionBuilder::findJunctions makes."""
 
-    def __init__(self, device=0, orientation="UNKNOWN", strandedness=3, flags=0):
+    def __init__(self, device=0, orientation="UNKNOWN", strandedness=3, flags=0, abi_version=ABI_VERSION):
+        """abi_version: what the caller was compiled against (3: a caller that knows nothing of pjb_batch.seq2 / pjb_timing.repeats)."""
         self._L = load()
         self._h = C.c_void_p()
+        self._abi = int(abi_version)
         ori = ORIENTATION[orientation] if isinstance(orientation, str) else int(orientation)
-        cfg = PjbConfig(ABI_VERSION, device, ori, strandedness, flags)
+        cfg = PjbConfig(self._abi, device, ori, strandedness, flags)
         rc = self._L.pjb_create(C.byref(self._h), C.byref(cfg))
         if rc:
             raise PjbError(rc, self._L.pjb_last_error(None).decode())
@@ -247,6 +249,9 @@ class Context:
         if seq2 is None:
             seq2 = os.environ.get("PJB_FFI_SEQ2", "1") != "0"
         pb = PjbBatch()
+        if self._abi < 4:  # (an ABI-3 caller's struct ends at name_hash: whatever lies behind it is not the library's to read)
+            seq2 = False
+            pb.seq2 = pb.seq_exc = 0xDEADBEEF0
         pb.n_reads = batch.n
         keep = []
         for name, dt in _FIELDS:
@@ -476,6 +481,7 @@ class Context:
 
     def timing(self):
         t = PjbTiming()
+        t.repeats = t.repeat_reasons = -77  # (an ABI-3 context must leave what lies behind checked_reads alone)
         self._check(self._L.pjb_get_timing(self._h, C.byref(t)))
         return dict(total_ms=t.total_ms, stage_ms={STAGE_NAMES[i]: t.stage_ms[i] for i in range(N_STAGES)},
                     sort_passes=t.sort_passes, generic_pairs=t.generic_pairs, generic_reads=t.generic_reads, checked_reads=t.checked_reads,

@@ -455,3 +455,45 @@ def test_upload_contig_fasta(ffi, orc):
         ctx.submit_batch(0, batch)
         reg = ctx.finish_contig(0)
         assert_rows_equal(ctx.collect(), orows)
+
+
+def test_abi3_caller_is_still_served():
+    """A caller compiled against ABI 3 (pjb_batch ends at name_hash, pjb_timing at checked_reads): the library must not read the two pointers
+    ABI 4 added to the batch -- the stub puts a wild address there -- nor write the two counters it added to the timing; the rows are the
+    oracle's (the compares run on the 4-bit bases)."""
+    from fuzzgen import make_reads, to_batch
+    from oracle import oracle as orc
+    from parity import assert_rows_equal, region_equal
+    from portcullis_amd import ffi
+
+    genome, reads = make_reads(4242, n_reads=2500, paired=True)
+    batch = to_batch(reads)
+    orows, oreg = orc.find_juncs(0, len(genome), genome, batch, "FR")
+    with ffi.Context(0, "FR", abi_version=3) as ctx:
+        ctx.set_refs([len(genome)])
+        drows, dreg = ffi.run_contig(ctx, 0, genome.encode(), [batch])
+        region_equal(dreg, oreg)
+        assert_rows_equal(drows, orows)
+        t = ctx.timing()
+        assert t["repeats"] == -77 and t["repeat_reasons"] == -77 and t["sort_passes"] >= 1
+    with pytest.raises(ffi.PjbError):
+        ffi.Context(0, "FR", abi_version=2)
+
+
+def test_seq2_must_be_word_aligned():
+    """pjb_batch.seq2 is read as 32-bit words: a device batch whose seq2 starts on an odd 16-bit granule is refused (PJB_ERR_ARG), not misread."""
+    import torch
+    from portcullis_amd import ffi, synth
+
+    d = synth.generate(synth.CONFIGS["C2-tiny"], device="cuda")
+    b = dict(d["batch"])
+    odd = torch.zeros(b["seq2"].numel() + 1, dtype=torch.int16, device="cuda")
+    odd[1:] = b["seq2"]
+    b["seq2"] = odd[1:]  # (2 bytes past a 4-byte boundary)
+    assert b["seq2"].data_ptr() % 4 == 2
+    with ffi.Context(0, "UNKNOWN") as ctx:
+        ctx.set_refs([d["config"].contig_len])
+        ctx.upload_contig_device(0, d["genome"])
+        with pytest.raises(ffi.PjbError) as e:
+            ctx.submit_batch_device(0, b, d["n_reads"])
+        assert e.value.code == -16
