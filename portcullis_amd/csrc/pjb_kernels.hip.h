@@ -1861,12 +1861,34 @@ struct EmitShared {
     int32_t lo[KC_SLOTS], hi[KC_SLOTS];
     u32 set_n, base, scan[4];
 };
-struct EmitCtx {
+// A kernel argument fetched where it is needed, not kept: k1_emit's rarely used arguments (the candidate list's pointers, the error word, the
+// control block) cost it twelve scalar registers that it spilled into VGPR lanes and fetched back eight times a trip (round 6: the kernel is
+// bound by instruction issue).  The scalar load from the kernel-argument segment is cached and cheap; the empty asm keeps the compiler from
+// hoisting it out of the rare branch.
+template <class T>
+__device__ __forceinline__ T kernarg_at(u32 byte_off) {
+    const PJB_CONSTANT char *p = (const PJB_CONSTANT char *)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    T v;
+    __builtin_memcpy(&v, p + byte_off, sizeof(T));
+    return v;
+}
+// LAZY_E / LAZY_CS: byte offsets of the EmitLists / the ContigStats pointer among the kernel's arguments (-1: the members below are used)
+template <int LAZY_E = -1, int LAZY_CS = -1>
+struct EmitCtxT {
     EmitShared &sh;
-    const EmitLists &E;
+    const EmitLists &E; // (LAZY_E >= 0: only gen_list, gen_cnt, gen_cap, pack_nn are read through this)
     const KeyFmt kf;
-    ContigStats *cs;
+    ContigStats *cs_;
     const bool want_cand;
+    __device__ __forceinline__ EmitLists cold() const {
+        if constexpr (LAZY_E >= 0) return kernarg_at<EmitLists>((u32)LAZY_E);
+        else return E;
+    }
+    __device__ __forceinline__ ContigStats *cs() const {
+        if constexpr (LAZY_CS >= 0) return kernarg_at<ContigStats *>((u32)LAZY_CS);
+        else return cs_;
+    }
     __device__ __forceinline__ void init() {
         if (!want_cand) return;
 #pragma unroll
@@ -1877,17 +1899,18 @@ struct EmitCtx {
         }
         if (threadIdx.x == 0) sh.set_n = 0;
     }
-    __device__ __forceinline__ void cand_mark(u64 k) const { // (what kd_mark did in a launch of its own)
+    __device__ __forceinline__ void cand_mark(const EmitLists &C, u64 k) const { // (what kd_mark did in a launch of its own)
         int32_t ms, me;
         unpack_key(kf, k, ms, me);
         const u32 w = (u32)ms >> 6;
         const u64 bit = 1ull << (ms & 63);
-        const u64 old = atomicOr((unsigned long long *)(E.bitmap + w), (unsigned long long)bit);
-        if (!(old & bit)) atomicAdd(&E.page_cnt[w >> KD_PAGE_SHIFT], 1u); // (the ranks below are scanned over the pages, not over the words)
+        const u64 old = atomicOr((unsigned long long *)(C.bitmap + w), (unsigned long long)bit);
+        if (!(old & bit)) atomicAdd(&C.page_cnt[w >> KD_PAGE_SHIFT], 1u); // (the ranks below are scanned over the pages, not over the words)
     }
     __device__ __forceinline__ void cand_insert(u64 k, int32_t lstart, int32_t rend) const {
         if (!want_cand) return;
         u32 h = (u32)((k * 0x9E3779B97F4A7C15ull) >> 40) & (KC_SLOTS - 1);
+#pragma nounroll // (unrolled 24 times -- twice, a pair each -- the probes were a sixth of k1_emit's code: the first probe is the one that runs)
         for (int probe = 0; probe < 24; probe++) { // look first: most keys are there already, and a read of one address by many lanes is a broadcast
             u64 old = sh.set[h];
             if (old == KD_EMPTY) {
@@ -1905,10 +1928,11 @@ struct EmitCtx {
             h = (h + 1) & (KC_SLOTS - 1);
         }
         // a crowded set (reads with hundreds of introns): straight to the list, where duplicates do no harm
-        const u32 at = atomicAdd(&cs->n_cand, 1u);
-        E.cand[at] = k;
-        E.cand_anc[at] = (u64)(u32)lstart | ((u64)(u32)rend << 32);
-        cand_mark(k);
+        const EmitLists C = cold();
+        const u32 at = atomicAdd(&cs()->n_cand, 1u);
+        C.cand[at] = k;
+        C.cand_anc[at] = (u64)(u32)lstart | ((u64)(u32)rend << 32);
+        cand_mark(C, k);
     }
     // appends the wavefront's entries to list `kind` (1: reads for k4b_generic's walks, 2: for its window check, 3: reads for
     // k1_generic): one returning atomic per wavefront; sub-list `shard` (callers deal 256-entry chunks round-robin: gen_list_cap)
@@ -1970,21 +1994,23 @@ struct EmitCtx {
             u32 total;
             const u32 excl = block_escan<K1E_T / 64, u32, true>(cnt, sh.scan, &total);
             if (threadIdx.x == 0) {
-                sh.base = total ? atomicAdd(&cs->n_cand, total) : 0u;
+                sh.base = total ? atomicAdd(&cs()->n_cand, total) : 0u;
                 sh.set_n = 0;
             }
             lds_barrier();
+            const EmitLists C = cold();
             u32 o = sh.base + excl;
 #pragma unroll
             for (int i = 0; i < KC_SLOTS / K1E_T; i++)
                 if (mine[i] != KD_EMPTY) {
-                    E.cand[o] = mine[i];
-                    E.cand_anc[o++] = anc[i];
-                    cand_mark(mine[i]);
+                    C.cand[o] = mine[i];
+                    C.cand_anc[o++] = anc[i];
+                    cand_mark(C, mine[i]);
                 }
         }
     }
 };
+typedef EmitCtxT<> EmitCtx;
 
 // ---- bases in TWO bits (pjb_batch.seq2 / GroupTab::codes2).  Round 5 took the compares apart (profiles/r05_k1_experiments.txt sections
 // 9, 10, 13): they are bound twice -- by the texture addresser, which takes a 4-byte-aligned 16-byte gather one LANE a cycle (16 gathers a
@@ -2064,9 +2090,32 @@ struct EmitTrip { // (uniform)
     u32 chunk, s_begin, s_end;
 };
 #ifdef PJB_KERNELS_CHAIN
+// k1_emit's arguments as the kernel-argument segment lays them out (explicit arguments one after the other, each at its natural alignment):
+// what kernarg_at reads the rarely used ones from.  k1_emit's own parameter list below MUST stay in this order.
+struct K1EmitArgs {
+    const DevBatch *batches;
+    int n_batches;
+    u32 n_tiles_total;
+    const u32 *tile_off, *tile_soff, *chunk_tile, *spl_idx, *spl_poff;
+    const uint4 *spl_rec;
+    Pairs P;
+    EmitLists E;
+    KeyFmt kf;
+    GroupTab G;
+    int use_codes, orientation;
+    u64 *err;
+    ContigStats *cs;
+};
 __global__ __launch_bounds__(K1E_T) __attribute__((amdgpu_waves_per_eu(K1E_WAVES, K1E_WAVES))) void k1_emit(const DevBatch *batches, int n_batches, u32 n_tiles_total, const u32 *tile_off, const u32 *tile_soff,
                                                 const u32 *chunk_tile, const u32 *spl_idx, const u32 *spl_poff, const uint4 *spl_rec, Pairs P, EmitLists E, KeyFmt kf,
-                                                GroupTab G, int use_codes, int orientation, u64 *err, ContigStats *cs) {
+                                                GroupTab G, int use_codes, int orientation, u64 *err_unused, ContigStats *cs_unused) {
+    // (the error word, the control block, the candidate list's pointers and the read ordinals' array are fetched from the kernel-argument
+    // segment where they are used -- rare branches, the block's last flush --, not kept in scalar registers: see kernarg_at)
+    (void)err_unused;
+    (void)cs_unused;
+    auto err_ptr = [] { return kernarg_at<u64 *>((u32)offsetof(K1EmitArgs, err)); };
+    auto pg_ptr = [] { return kernarg_at<u32 *>((u32)(offsetof(K1EmitArgs, P) + offsetof(Pairs, g))); };
+    ContigStats *const cs = kernarg_at<ContigStats *>((u32)offsetof(K1EmitArgs, cs)); // (once: the test below)
     __shared__ u32 s_soff[K1E_LOOK];
     __shared__ EmitShared sh;
     __shared__ u32 s_cfirst[K1E_MAXB + 1]; // trips before batch i
@@ -2075,8 +2124,9 @@ __global__ __launch_bounds__(K1E_T) __attribute__((amdgpu_waves_per_eu(K1E_WAVES
     __shared__ u32 s_wsum[4];
     if (cs->P == 0) return; // no pairs, or a limit was exceeded: the contig is repeated with larger buffers
     K1E_T0();
-    const bool want_cand = E.cand != nullptr;
-    EmitCtx ctx{sh, E, kf, cs, want_cand};
+    const bool want_cand = kernarg_at<u64 *>((u32)(offsetof(K1EmitArgs, E) + offsetof(EmitLists, cand))) != nullptr;
+    const bool want_g = pg_ptr() != nullptr; // (--extra contexts: the pairs' read ordinals)
+    EmitCtxT<(int)offsetof(K1EmitArgs, E), (int)offsetof(K1EmitArgs, cs)> ctx{sh, E, kf, nullptr, want_cand};
     ctx.init();
     auto cand_insert = [&](u64 k, int32_t lstart, int32_t rend) { ctx.cand_insert(k, lstart, rend); };
     {
@@ -2335,7 +2385,7 @@ __global__ __launch_bounds__(K1E_T) __attribute__((amdgpu_waves_per_eu(K1E_WAVES
                     const int32_t iend = rStart - 1;
                     int32_t rEndExc = rStartU + (int32_t)lb;
                     if (rEndExc - 1 >= vlen) rEndExc = vlen; // junction_system.cc:172-174
-                    if (pr < npairs && rEndExc - 1 < iend) set_error(err, g, PJB_ERR_MIN_ANCHOR); // intron.cc:76
+                    if (pr < npairs && rEndExc - 1 < iend) set_error(err_ptr(), g, PJB_ERR_MIN_ANCHOR); // intron.cc:76
                     ist_[pr] = istart;
                     lst_[pr] = lst;
                     rend_[pr] = rEndExc - 1;
@@ -2473,7 +2523,7 @@ __global__ __launch_bounds__(K1E_T) __attribute__((amdgpu_waves_per_eu(K1E_WAVES
                 Q.aux = cmp_blocks_res(res[pr], res[pr + 1]);
                 const u64 key = make_key(kf, ist_[pr], iend_[pr]);
                 P.key[off + pr] = key;
-                if (P.g) P.g[off + pr] = g;
+                if (want_g) pg_ptr()[off + pr] = g;
                 rec_store(P.rec + off + pr, Q);
                 if (want_cand) cand_insert(key, Q.lstart, Q.rend);
             }
