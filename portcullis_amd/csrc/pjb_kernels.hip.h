@@ -1861,10 +1861,18 @@ struct EmitShared {
     int32_t lo[KC_SLOTS], hi[KC_SLOTS];
     u32 set_n, base, scan[4];
 };
-// A kernel argument fetched where it is needed, not kept: k1_emit's rarely used arguments (the candidate list's pointers, the error word, the
-// control block) cost it twelve scalar registers that it spilled into VGPR lanes and fetched back eight times a trip (round 6: the kernel is
-// bound by instruction issue).  The scalar load from the kernel-argument segment is cached and cheap; the empty asm keeps the compiler from
-// hoisting it out of the rare branch.
+// A kernel argument fetched where it is needed, not kept (-DK1E_LAZY_ARGS=1): k1_emit's rarely used arguments (the candidate list's pointers,
+// the error word, the control block) cost it twelve scalar registers that it spills into VGPR lanes and fetches back eight times a trip.  The
+// scalar load from the kernel-argument segment is cached; the empty asm keeps the compiler from hoisting it out of the rare branch.
+// (Both measured in round 6, profiles/r06_k1_experiments.txt section 6: fetching the rare arguments lazily takes the kernel's v_readlane from 150
+// to 59 a trip and makes it 15 % SLOWER -- 1 105 - 1 140 us a chain in the step against 940 - 970 --, not unrolling the probes halves its code and
+// changes nothing: both are off.)
+#ifndef K1E_PROBE_UNROLL
+#define K1E_PROBE_UNROLL 1
+#endif
+#ifndef K1E_LAZY_ARGS
+#define K1E_LAZY_ARGS 0
+#endif
 template <class T>
 __device__ __forceinline__ T kernarg_at(u32 byte_off) {
     const PJB_CONSTANT char *p = (const PJB_CONSTANT char *)__builtin_amdgcn_kernarg_segment_ptr();
@@ -1910,7 +1918,9 @@ struct EmitCtxT {
     __device__ __forceinline__ void cand_insert(u64 k, int32_t lstart, int32_t rend) const {
         if (!want_cand) return;
         u32 h = (u32)((k * 0x9E3779B97F4A7C15ull) >> 40) & (KC_SLOTS - 1);
-#pragma nounroll // (unrolled 24 times -- twice, a pair each -- the probes were a sixth of k1_emit's code: the first probe is the one that runs)
+#if !K1E_PROBE_UNROLL
+#pragma nounroll // (unrolled 24 times -- twice, a pair each -- the probes were half of k1_emit's code: the first probe is the one that runs)
+#endif
         for (int probe = 0; probe < 24; probe++) { // look first: most keys are there already, and a read of one address by many lanes is a broadcast
             u64 old = sh.set[h];
             if (old == KD_EMPTY) {
@@ -2111,11 +2121,17 @@ __global__ __launch_bounds__(K1E_T) __attribute__((amdgpu_waves_per_eu(K1E_WAVES
                                                 GroupTab G, int use_codes, int orientation, u64 *err_unused, ContigStats *cs_unused) {
     // (the error word, the control block, the candidate list's pointers and the read ordinals' array are fetched from the kernel-argument
     // segment where they are used -- rare branches, the block's last flush --, not kept in scalar registers: see kernarg_at)
+#if K1E_LAZY_ARGS
     (void)err_unused;
     (void)cs_unused;
     auto err_ptr = [] { return kernarg_at<u64 *>((u32)offsetof(K1EmitArgs, err)); };
     auto pg_ptr = [] { return kernarg_at<u32 *>((u32)(offsetof(K1EmitArgs, P) + offsetof(Pairs, g))); };
     ContigStats *const cs = kernarg_at<ContigStats *>((u32)offsetof(K1EmitArgs, cs)); // (once: the test below)
+#else
+    auto err_ptr = [=] { return err_unused; };
+    auto pg_ptr = [=] { return P.g; };
+    ContigStats *const cs = cs_unused;
+#endif
     __shared__ u32 s_soff[K1E_LOOK];
     __shared__ EmitShared sh;
     __shared__ u32 s_cfirst[K1E_MAXB + 1]; // trips before batch i
@@ -2124,9 +2140,14 @@ __global__ __launch_bounds__(K1E_T) __attribute__((amdgpu_waves_per_eu(K1E_WAVES
     __shared__ u32 s_wsum[4];
     if (cs->P == 0) return; // no pairs, or a limit was exceeded: the contig is repeated with larger buffers
     K1E_T0();
-    const bool want_cand = kernarg_at<u64 *>((u32)(offsetof(K1EmitArgs, E) + offsetof(EmitLists, cand))) != nullptr;
     const bool want_g = pg_ptr() != nullptr; // (--extra contexts: the pairs' read ordinals)
+#if K1E_LAZY_ARGS
+    const bool want_cand = kernarg_at<u64 *>((u32)(offsetof(K1EmitArgs, E) + offsetof(EmitLists, cand))) != nullptr;
     EmitCtxT<(int)offsetof(K1EmitArgs, E), (int)offsetof(K1EmitArgs, cs)> ctx{sh, E, kf, nullptr, want_cand};
+#else
+    const bool want_cand = E.cand != nullptr;
+    EmitCtx ctx{sh, E, kf, cs, want_cand};
+#endif
     ctx.init();
     auto cand_insert = [&](u64 k, int32_t lstart, int32_t rend) { ctx.cand_insert(k, lstart, rend); };
     {
