@@ -2092,7 +2092,9 @@ struct EmitRec { // a trip's list records (per lane)
 };
 struct EmitOps { // and what the records lead to: the read's first operations and its fixed-width fields
     u32 op[OPS_LDS];
-    u32 n, flag, xs, mapq; // (xs: bit 8 = the read is not to be compared in 2 bits -- its bit of seq_exc, or no 2-bit bases in the batch)
+    u32 n, flag, xs, mapq;
+    u32 excw; // the word of seq_exc that holds the read's bit (all ones: no 2-bit bases in the batch).  Kept as it was loaded: anything computed from
+              // it here would make fetch_ops WAIT for its loads -- they are asked for a trip ahead so that nothing waits for them
     int32_t mtid, mpos, lq;
 };
 struct EmitTrip { // (uniform)
@@ -2244,6 +2246,7 @@ __global__ __launch_bounds__(K1E_T) __attribute__((amdgpu_waves_per_eu(K1E_WAVES
 #pragma unroll
         for (int q = 0; q < OPS_LDS; q++) O.op[q] = 0;
         O.n = O.flag = O.xs = O.mapq = 0;
+        O.excw = 0xffffffffu;
         O.mtid = O.mpos = O.lq = 0;
         if (R.on) {
             const GBatch b = load_batch(batches + T.bi);
@@ -2253,11 +2256,11 @@ __global__ __launch_bounds__(K1E_T) __attribute__((amdgpu_waves_per_eu(K1E_WAVES
             if (n == 0x7fffu) n = b.cig_off[r + 1] - c0;
             O.n = n;
             O.flag = b.flag[r];
-            O.xs = (u32)b.xs[r] | 0x100u;
+            O.xs = b.xs[r];
             O.mapq = b.mapq[r];
             O.mtid = b.mtid[r];
             O.mpos = b.mpos[r];
-            if (b.seq2 != nullptr) O.xs = (O.xs & 0xffu) | (((b.seq_exc[r >> 5] >> (u32)(r & 31)) & 1u) << 8); // (uniform test: the batch either has 2-bit bases or not)
+            if (b.seq2 != nullptr) O.excw = b.seq_exc[r >> 5]; // (uniform test: the batch either has 2-bit bases or not)
             O.lq = (int32_t)(R.sr.w >> 16);
             if (O.lq == 0xffff) O.lq = b.l_qseq[r];
             static_assert(OPS_LDS == 8, "two 16-byte loads");
@@ -2322,7 +2325,7 @@ __global__ __launch_bounds__(K1E_T) __attribute__((amdgpu_waves_per_eu(K1E_WAVES
             const u32 (&op)[OPS_LDS] = O.op;
             g = b.base + R.r;
             off = R.toff + R.poff;
-            meta = read_meta(O.flag, O.xs & 0xffu, O.mapq, pos, O.mtid, O.mpos, tid, orientation);
+            meta = read_meta(O.flag, O.xs, O.mapq, pos, O.mtid, O.mpos, tid, orientation);
             const bool seq_ok = (R.sr.w & 0x8000u) != 0;
             // ---- shape: [S] M N M [S], or -- two introns, nothing clamped -- [S] M N M N M [S]
             if (gcodes != nullptr && n >= 3 && n <= 7) {
@@ -2358,7 +2361,7 @@ __global__ __launch_bounds__(K1E_T) __attribute__((amdgpu_waves_per_eu(K1E_WAVES
         // ---- in 2 bits: the read is pure ACGT, lies inside its target (nothing clamped: block k of its bases starts at g2s[k]), no block
         // longer than the bitmap load covers.  The exception bitmap under the blocks -- bits g2s >> 6 .. (g2s + len - 1) >> 6, at most 31 of
         // them, in the two words from word g2s >> 11 -- is asked for here and looked at just before the rounds.
-        bool use2 = simple && gcodes2 != nullptr && !(O.xs & 0x100u) && pos >= 0 && (int64_t)pos + a + nl + b2 + nl2 + b3 <= (int64_t)ref_len &&
+        bool use2 = simple && gcodes2 != nullptr && !((O.excw >> (R.r & 31u)) & 1u) && pos >= 0 && (int64_t)pos + a + nl + b2 + nl2 + b3 <= (int64_t)ref_len &&
                     a <= (u32)C2_MAX_BLOCK && b2 <= (u32)C2_MAX_BLOCK && b3 <= (u32)C2_MAX_BLOCK;
         const int64_t n2w = codes2_words(ref_len);
         const bool any_exc = (G.exc_members >> mem) & 1u; // (uniform)
