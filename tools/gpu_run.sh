@@ -56,6 +56,24 @@ PY
            n=${FUZZ_SEEDS:-1200}; q=$((n / 4))
            for k in 0 1 2 3; do ( timeout 3000 python tests/fuzz_campaign.py --seeds $q --start $((${FUZZ_START:-20000} + k * q)) 2>&1 | tail -8 > $OUT/${TAG}_fuzz_part$k.txt ) & done; wait
            ( cat $OUT/${TAG}_fuzz_part?.txt; timeout 1500 python tests/fuzz_groups.py --seeds ${FUZZ_GROUP_SEEDS:-300} --start 9000; timeout 1500 python tests/fuzz_extra.py ) 2>&1 | tail -40 | tee $OUT/${TAG}_fuzz.txt ;;
+    e2eab) # (behind `bench`) round 5's program (tools/variants/r05, built from commit 4d50d07 by hand) against this tree's, alternating: wall of the command
+           for k in 1 2 3 4 5 6; do for who in r05 now now_targets; do
+             exe=portcullis_amd/host/portcullis_amd; plan=groups
+             [ $who = r05 ] && exe=tools/variants/r05/host/portcullis_amd
+             [ $who = now_targets ] && plan=targets
+             s=$(date +%s.%N); PORTCULLIS_CHAIN_PLAN=$plan $exe junc -t $(nproc) --orientation FR -o /tmp/pjb_bench_e2e/prof/ab_$who /tmp/pjb_bench_e2e/prep > /dev/null 2>&1; e=$(date +%s.%N)
+             python3 -c "print('e2e $who: %.3f s' % ($e - $s))"; done; done | tee $OUT/${TAG}_e2e_ab.txt
+           python3 - $OUT/${TAG}_e2e_ab.txt <<'PY' | tee -a $OUT/${TAG}_e2e_ab.txt
+import sys, collections, statistics
+d = collections.defaultdict(list)
+for ln in open(sys.argv[1]):
+    if ln.startswith("e2e "):
+        k, v = ln[4:].split(": ")
+        d[k].append(float(v.split()[0]))
+for k, v in d.items():
+    print(f"median {k}: {statistics.median(v):.3f} s  (min {min(v):.3f}, max {max(v):.3f}, {len(v)} runs)")
+PY
+           md5sum /tmp/pjb_bench_e2e/prof/ab_*.junctions.tab | tee -a $OUT/${TAG}_e2e_ab.txt ;;
     inflate) # bgzf_decode at both launch sizes: ~6 k blocks a launch (the C2 file in 256 MB chunks) and ~130 k (the file four times over, one launch)
            python tools/bench_inflate.py > $OUT/${TAG}_inflate_small.json 2> $OUT/${TAG}_inflate.err
            python tools/bench_inflate.py --chunk-mb 8192 --times 4 > $OUT/${TAG}_inflate_large.json 2>> $OUT/${TAG}_inflate.err
