@@ -277,26 +277,29 @@ int pjb_set_refs(pjb_ctx *c, int32_t n_refs, const int32_t *ref_len) {
     return PJB_OK;
 }
 
-static int upload_common(pjb_ctx *c, int32_t tid, uint8_t *d, int64_t len, bool owned, bool do_upper, size_t d_cap = 0) {
+// fasta_flag: the upload came through k0_fasta, whose verdict -- word 3 of the flags, raised before this call -- is read with the others: a
+// record that was not laid out as stated returns 1 and leaves the context as it was
+static int upload_common(pjb_ctx *c, int32_t tid, uint8_t *d, int64_t len, bool owned, bool do_upper, size_t d_cap = 0, bool fasta_flag = false) {
     static const bool prof = getenv("PJB_PROFILE_HOST") != nullptr;
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t_up0 = now();
     double t_alloc = 0;
     HIP_TRY(c, hipSetDevice(c->cfg.device));
-    int rc = ensure(c, c->b_hasx, sizeof(int));
+    // the kernels' three flags (an 'X' among the bases, a character outside the 16-letter alphabet, a character outside ACGT) come back in
+    // ONE copy behind the last kernel: every copy to pageable memory makes this thread wait for the stream, and this is the thread that
+    // serves every target (three waits a genome were 0.2 s of a human run)
+    int rc = ensure(c, c->b_hasx, 4 * sizeof(int));
     if (rc) return rc;
-    HIP_TRY(c, hipMemsetAsync(c->b_hasx.p, 0, sizeof(int), c->stream));
+    int *d_flags = (int *)c->b_hasx.p;
+    HIP_TRY(c, hipMemsetAsync(d_flags, 0, 3 * sizeof(int), c->stream));
     if (len > 0) {
         const int64_t nthreads = (len + 15) / 16;
         const unsigned nblk = (unsigned)((nthreads + 255) / 256);
-        hipLaunchKernelGGL(k0_upper, dim3(nblk), dim3(256), 0, c->stream, d, len, do_upper ? 1 : 0, (int *)c->b_hasx.p);
+        hipLaunchKernelGGL(k0_upper, dim3(nblk), dim3(256), 0, c->stream, d, len, do_upper ? 1 : 0, d_flags + 0);
     }
-    int hx = 0;
-    HIP_TRY(c, hipMemcpyAsync(&hx, c->b_hasx.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     // 4-bit codes for the word-parallel compare in k4 (after upper-casing)
     u32 *codes = nullptr;
     size_t codes_cap = 0;
-    int exotic = 0;
     const int64_t n_words = (len + 7) / 8;
     static const bool no_seq2 = getenv("PJB_NO_SEQ2") && atoi(getenv("PJB_NO_SEQ2")) != 0;
     const size_t c2_at = ((size_t)(n_words + 2) + 3) & ~(size_t)3;                       // (the 2-bit codes start on a 16-byte boundary)
@@ -306,26 +309,23 @@ static int upload_common(pjb_ctx *c, int32_t tid, uint8_t *d, int64_t len, bool 
         codes = (u32 *)genome_take(c->genome_pool, (c2_at + c2_words) * 4, codes_cap);
         t_alloc = now() - ta;
         if (!codes) return fail(c, PJB_ERR_NOMEM, "hipMalloc(genome codes, %zu bytes) failed", (c2_at + c2_words) * 4);
-        (void)hipMemsetAsync(c->b_hasx.p, 0, sizeof(int), c->stream);
         (void)hipMemsetAsync(codes + n_words, 0, 8, c->stream);
         hipLaunchKernelGGL(k0_encode, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, c->stream, (const uint8_t *)d, len,
-                           codes, n_words, (int *)c->b_hasx.p);
-        (void)hipMemcpyAsync(&exotic, c->b_hasx.p, sizeof(int), hipMemcpyDeviceToHost, c->stream);
+                           codes, n_words, d_flags + 1);
     }
     // 2-bit codes and their exception bitmap for k1_emit's compares (PJB_NO_SEQ2=1: not built -- A/B runs): behind the 4-bit codes, in
     // the same allocation (a hipMalloc is milliseconds on the thread that serves every target)
     u32 *codes2 = nullptr;
-    int any_exc = 1;
     if (codes && c2_words) {
         codes2 = codes + c2_at;
-        (void)hipMemsetAsync(c->b_hasx.p, 0, sizeof(int), c->stream);
         const int64_t n2w = codes2_words(len), nxw = gexc_words(len);
         (void)hipMemsetAsync(codes2 + n2w, 0, (size_t)K0_CODES2_PAD * 4, c->stream);
         (void)hipMemsetAsync(codes2 + n2w + K0_CODES2_PAD + nxw, 0, (size_t)K0_GEXC_PAD * 4, c->stream);
         hipLaunchKernelGGL(k0_encode2, dim3((unsigned)(((len + 63) / 64 + 255) / 256)), dim3(256), 0, c->stream, (const uint8_t *)d, len, codes2,
-                           codes2 + n2w + K0_CODES2_PAD, (int *)c->b_hasx.p);
-        (void)hipMemcpyAsync(&any_exc, c->b_hasx.p, sizeof(int), hipMemcpyDeviceToHost, c->stream);
+                           codes2 + n2w + K0_CODES2_PAD, d_flags + 2);
     }
+    int flags[4] = {0, 0, 1, 0};
+    HIP_TRY(c, hipMemcpyAsync(flags, d_flags, (fasta_flag ? 4 : 3) * sizeof(int), hipMemcpyDeviceToHost, c->stream));
     const double t_sync0 = now();
     hipError_t se = hipStreamSynchronize(c->stream);
     if (se != hipSuccess) {
@@ -335,6 +335,11 @@ static int upload_common(pjb_ctx *c, int32_t tid, uint8_t *d, int64_t len, bool 
     if (prof)
         fprintf(stderr, "[host profile] genome tid %d (%lld bases): codes allocation %.4f, launches %.4f, wait for the stream %.4f s\n", tid, (long long)len, t_alloc,
                 t_sync0 - t_up0 - t_alloc, now() - t_sync0);
+    if (fasta_flag && flags[3]) { // (the bytes were not a FASTA record of that geometry: nothing of this upload is kept)
+        if (codes) (void)hipFree(codes);
+        return 1;
+    }
+    const int hx = flags[0], exotic = flags[1], any_exc = codes2 ? flags[2] : 1;
     if (exotic && codes) {
         (void)hipFree(codes);
         codes = nullptr;
@@ -409,7 +414,7 @@ int pjb_upload_contig_fasta(pjb_ctx *c, int32_t tid, const uint8_t *raw, int64_t
     HIP_TRY(c, hipSetDevice(c->cfg.device));
     int rc;
     if ((rc = ensure(c, c->b_fasta_raw, (size_t)std::max<int64_t>(raw_bytes, 16)))) return rc;
-    if ((rc = ensure(c, c->b_hasx, sizeof(int)))) return rc;
+    if ((rc = ensure(c, c->b_hasx, 4 * sizeof(int)))) return rc;
     size_t d_cap = 0;
     const double t_a0 = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
     uint8_t *d = (uint8_t *)genome_take(c->genome_pool, (size_t)std::max<int64_t>(len, 16), d_cap);
@@ -428,17 +433,15 @@ int pjb_upload_contig_fasta(pjb_ctx *c, int32_t tid, const uint8_t *raw, int64_t
     if (!pinned) (void)hipGetLastError();
     if (pinned) HIP_TRY(c, hipMemcpyAsync(c->b_fasta_raw.p, raw, (size_t)raw_bytes, hipMemcpyHostToDevice, c->stream));
     else if (raw_bytes > 0 && (rc = upload_staged(c, c->b_fasta_raw.p, raw, (size_t)raw_bytes))) return rc;
-    int bad = 0;
-    HIP_TRY(c, hipMemsetAsync(c->b_hasx.p, 0, sizeof(int), c->stream));
+    // (k0_fasta's verdict is read with the other kernels' flags, behind the last of them: one wait a genome)
+    HIP_TRY(c, hipMemsetAsync((int *)c->b_hasx.p + 3, 0, sizeof(int), c->stream));
     if (len > 0) {
         const int64_t nthreads = (len + 15) / 16;
         hipLaunchKernelGGL(k0_fasta, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, c->stream, (const uint8_t *)c->b_fasta_raw.p, raw_bytes, len,
-                           line_blen, line_len, d, (int *)c->b_hasx.p);
+                           line_blen, line_len, d, (int *)c->b_hasx.p + 3);
     }
-    HIP_TRY(c, hipMemcpyAsync(&bad, c->b_hasx.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    if (bad) return PJB_OK; // (*well_formed stays 0: nothing was uploaded)
-    rc = upload_common(c, tid, d, len, true, true, d_cap);
+    rc = upload_common(c, tid, d, len, true, true, d_cap, true);
+    if (rc == 1) return PJB_OK; // (*well_formed stays 0: nothing was uploaded)
     if (rc) return rc;
     guard.d = nullptr;
     *well_formed = 1;
