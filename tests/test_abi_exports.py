@@ -2,6 +2,8 @@
 declares; struct sizes seen from Python match the header."""
 import ctypes
 import os
+
+import pytest
 import re
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -65,3 +67,18 @@ def test_host_library_builds_and_links():
     host = os.path.join(ROOT, "portcullis_amd", "host")
     assert os.path.exists(os.path.join(host, "libportcullis_host.so"))
     ctypes.CDLL(os.path.join(host, "libportcullis_host.so"))
+
+
+def test_c_caller_of_plan_groups_and_merge_rows(tmp_path):
+    """A plain C program (gcc, no HIP headers) links the library and calls the two host-arithmetic entry points of ABI 4 -- the chain plan and
+    the receive side of the multi-GPU merge -- without a context or a device: tests/cpp/merge_plan_check.c."""
+    import subprocess
+
+    lib_dir = os.path.join(ROOT, "portcullis_amd", "csrc")
+    if not os.path.exists(os.path.join(lib_dir, "libportcullis_amd.so")):
+        pytest.skip("library not built")
+    exe = tmp_path / "merge_plan_check"
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), "-o", str(exe), os.path.join(ROOT, "tests", "cpp", "merge_plan_check.c"),
+                    "-L", lib_dir, "-lportcullis_amd", f"-Wl,-rpath,{lib_dir}"], check=True)
+    p = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert p.returncode == 0 and p.stdout.strip() == "ok", p.stdout + p.stderr
