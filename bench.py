@@ -882,6 +882,11 @@ def e2e_leg_once(contigs, cfgs, workdir, orientation, oracle_tab_md5, reads_arg,
         warmup_run_s = round(time.time() - t, 3)
         if p.returncode != 0:
             raise RuntimeError("portcullis_amd junc failed: " + (p.stderr or p.stdout)[-400:])
+    # A run that starts right behind another one is not a run of the program alone: the driver is still taking the earlier process's
+    # 100+ GB of device memory apart, and somewhere in the next run every copy to the device stands still for 1.5 - 2 s (at start-up, or
+    # with the first target half way across).  profiles/r06_e2e_pause.txt: 18 runs back to back, median 2.68 s, ten of them over 2.4 s;
+    # 18 runs with 3 s of nothing before each, median 1.85 s, none over 2.2 s.  So: a pause before every timed run (not timed).
+    settle_s = float(os.environ.get("PJB_BENCH_E2E_SETTLE_S", 3.0))
     for rep in range(max(1, int(os.environ.get("PJB_BENCH_E2E_REPS", 5)))):
         env = dict(os.environ)
         if os.environ.get("PJB_BENCH_E2E_SWEEP"):  # (experiment: "VAR=a,b,c": repeat k runs with VAR = the k-th value)
@@ -892,7 +897,8 @@ def e2e_leg_once(contigs, cfgs, workdir, orientation, oracle_tab_md5, reads_arg,
             os.remove(out + ".junctions.tab")
         except OSError:
             pass
-        quiet_s = wait_until_gone(cli)  # (nothing of an earlier run is left on the device)
+        quiet_s = wait_until_gone(cli)  # (nothing of an earlier run is left in the process table)
+        time.sleep(settle_s)
         t = time.time()
         p = subprocess.run([cli, "junc", "-t", str(cores), "--orientation", orientation, "-o", out, prep],
                            capture_output=True, text=True, env=env)
@@ -915,6 +921,7 @@ def e2e_leg_once(contigs, cfgs, workdir, orientation, oracle_tab_md5, reads_arg,
     early_closed, early_tree = [], []
     for rep in range(max(0, int(os.environ.get("PJB_BENCH_E2E_EARLY_REPS", 3)))):
         wait_until_gone(cli)
+        time.sleep(settle_s)
         try:
             os.remove(out + ".junctions.tab")
         except OSError:
@@ -941,7 +948,9 @@ def e2e_leg_once(contigs, cfgs, workdir, orientation, oracle_tab_md5, reads_arg,
         return (v[len(v) // 2] if len(v) % 2 else (v[len(v) // 2 - 1] + v[len(v) // 2]) / 2) if v else None
 
     slowest = max([med] + [x for x in (median(early_closed), median(early_tree)) if x])
-    res = {"wall_s": round(med, 3), "wall_is": f"median of {len(walls)} runs of the command as it is by default: one process, timed until it is gone",
+    res = {"wall_s": round(med, 3), "wall_is": f"median of {len(walls)} runs of the command as it is by default: one process, timed until it is gone; "
+                                               f"{settle_s:g} s of nothing before each run (the process before it has left the device by then)",
+           "pause_before_each_run_s": settle_s,
            "runs_s": [round(w, 3) for w in walls],
            "early_return": {"what": "PORTCULLIS_EARLY_RETURN=1: a child forked before the GPU is touched does the work, the command returns when "
                                     "the outputs are closed; the child's device memory goes back to the driver after that",
