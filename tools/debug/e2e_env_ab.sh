@@ -16,8 +16,8 @@ import sys, re
 cfg, s, e, f = sys.argv[1], float(sys.argv[2]), float(sys.argv[3]), sys.argv[4]
 t = open(f).read()
 g = lambda pat: (re.search(pat, t) or [None, '?'])[1]
-print('e2e [%s]: %.3f s | ready %s, workers done %s, workers %s | dev: idle %s GENOME %s BAM %s BAMEND %s FINISH %s collect %s' % (
-    cfg, e - s, g(r't=([\d.]+) s: device thread: context ready'), g(r't=([\d.]+) s: workers and device threads done'), g(r'workers ([\d.]+) s,'),
+print('e2e [%s]: %.3f s | ready %s, workers done %s, outputs written %s, workers %s | dev: idle %s GENOME %s BAM %s BAMEND %s FINISH %s collect %s' % (
+    cfg, e - s, g(r't=([\d.]+) s: device thread: context ready'), g(r't=([\d.]+) s: workers and device threads done'), g(r't=([\d.]+) s: outputs written'), g(r'workers ([\d.]+) s,'),
     g(r'idle ([\d.]+),'), g(r'GENOME ([\d.]+),'), g(r'BAM ([\d.]+),'), g(r'BAMEND ([\d.]+),'), g(r'FINISH ([\d.]+),'), g(r'collect ([\d.]+),')))
 PY
 done; done | tee $OUT/r06_e2e_$NAME.txt
