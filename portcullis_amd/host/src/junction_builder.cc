@@ -989,7 +989,10 @@ void JunctionBuilder::findJuncs(DeviceThread& device, BamReader& reader, GenomeM
                         }
                         if (dctx) {
                             int64_t ticket = 0;
-                            if (pjb_bam_piece(dctx, seq, buf, (int64_t)n, &ticket) != PJB_OK) {
+                            const double tp0 = HostProfile::now();
+                            const int prc = pjb_bam_piece(dctx, seq, buf, (int64_t)n, &ticket);
+                            if (HostProfile::now() - tp0 > 1e-3) g_prof.event(tp0, HostProfile::now(), "worker bam_piece call tid " + std::to_string(seq));
+                            if (prc != PJB_OK) {
                                 readError = std::string("pjb_bam_piece: ") + pjb_last_error(dctx);
                                 releaseDone(true);  // (a failing piece call has waited for the upload stream)
                                 pinnedPool->release(buf);
@@ -1014,12 +1017,16 @@ void JunctionBuilder::findJuncs(DeviceThread& device, BamReader& reader, GenomeM
                     c.tid = seq;
                     c.bamFirst = firstU;
                     c.bamDone = &got;
+                    const double tq0 = HostProfile::now();
                     device.push(std::move(c));
+                    if (HostProfile::now() - tq0 > 1e-3) g_prof.event(tq0, HostProfile::now(), "worker BAMEND push tid " + std::to_string(seq));
                     leave.now();  // the next target's pieces cross while this one is inflated and parsed
                     raisePiecesGone();
-                    // (Releasing the slot before the push, a command queue of 32 and one worker per target -- each harmless
-                    // alone -- together let the file run at 33-42 GB/s for half a second and then stand still for one or two:
-                    // runs of 2.1 or 4 s, profiles/r03v_e2e_scheduling_ab.txt.  More in flight is not more throughput here.)
+                    // (The push waits while the device thread's queue is full -- 0.4 s over a run, up to 0.13 s at a time -- and the slot
+                    // stays taken meanwhile.  Releasing the slot before the push and a queue of 32 were blamed in round 3 for runs that
+                    // stood still for a second or two (profiles/r03v_e2e_scheduling_ab.txt); those were runs right behind another
+                    // process (profiles/r06_e2e_pause.txt).  Measured again with a pause before every run, neither changes the wall:
+                    // medians 1.82 - 1.88 s for all four combinations, profiles/r06_e2e_slot_turnover.txt.  Left as it was.)
                     // (the ring gets this target's buffers back as their copies complete, not when its records are parsed)
                     while (f.wait_for(std::chrono::microseconds(200)) != std::future_status::ready) releaseDone(false);
                     any = f.get() > 0;
