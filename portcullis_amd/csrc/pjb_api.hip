@@ -180,6 +180,7 @@ void pjb_destroy(pjb_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->cfg.device);
     (void)hipDeviceSynchronize(); // (contigs may still be queued)
+    (void)exhume(c);
 #ifdef K1E_PROF
     {
         unsigned long long h[16] = {0};
@@ -584,6 +585,22 @@ static int mirror_header_only(pjb_ctx *c, const pjb_region_result &R) {
 static void wait_flight(pjb_ctx *c, Flight &f);
 
 
+// the host's row table holds `need` rows (the first c->rows_n of them are kept)
+static int rows_pinned_reserve(pjb_ctx *c, size_t need) {
+    if (need <= c->rows_pinned_cap && c->rows_pinned) return PJB_OK;
+    int rc = rows_sync(c); // (a DMA into the table that is about to move)
+    if (rc) return rc;
+    const size_t ncap = std::max<size_t>(need * 3 / 2, 1024);
+    pjb_junction_row *np = nullptr;
+    const hipError_t e = hipHostMalloc((void **)&np, ncap * sizeof(pjb_junction_row), hipHostMallocPortable);
+    if (e != hipSuccess) return fail(c, PJB_ERR_NOMEM, "hipHostMalloc(rows): %s", hipGetErrorString(e));
+    if (c->rows_pinned && c->rows_n) memcpy(np, c->rows_pinned, std::min(c->rows_n, c->rows_pinned_cap) * sizeof(pjb_junction_row));
+    if (c->rows_pinned) (void)hipHostFree(c->rows_pinned);
+    c->rows_pinned = np;
+    c->rows_pinned_cap = ncap;
+    return PJB_OK;
+}
+
 // rows of the contigs collected so far plus the most the queued ones can add
 static size_t rows_upper_bound(const pjb_ctx *c) {
     size_t n = c->rows_n;
@@ -717,28 +734,22 @@ static int queue_contig(pjb_ctx *c, Flight &f) {
     // and in page-locked host memory, filled by a DMA per contig once its row count is known (pjb_finish_contig_end).
     // (The kernel used to write the host table itself: 2 MB of PCIe stores per contig that slowed whatever ran beside
     // them -- the next contig's k1_count by 40 %.)
+    // The HBM table has room for the most the queued chains can bring (JL is a bound, 5 - 20 x what a chain brings); the host table
+    // grows when a chain is collected, to what it brought (rows_pinned_reserve) -- page-locking costs ~0.1 s per GB, and sized by the
+    // bound the host table of the first 1-Gb chain was 400 MB: 70 ms on the thread that queues the chains, with every copy of the
+    // program's run waiting behind it, for 17 MB of rows.
     size_t old = rows_upper_bound(c);
     if (old + JL > c->rows_cap) {
-        for (int k = 0; k < c->n_fl; k++) // (the tables move: nothing may be writing to them)
+        for (int k = 0; k < c->n_fl; k++) // (the table moves: nothing may be writing to it)
             if (c->fl[k].queued && &c->fl[k] != &f) wait_flight(c, c->fl[k]);
         if ((rc = rows_sync(c))) return rc;
         old = std::min(old, c->rows_cap);
         const size_t ncap = std::max<size_t>((old + JL) * 3 / 2, 1024);
-        pjb_junction_row *np = nullptr, *nd = nullptr;
-        hipError_t e = hipHostMalloc((void **)&np, ncap * sizeof(pjb_junction_row), hipHostMallocPortable);
-        if (e != hipSuccess) return fail(c, PJB_ERR_NOMEM, "hipHostMalloc(rows): %s", hipGetErrorString(e));
-        e = hipMalloc((void **)&nd, ncap * sizeof(pjb_junction_row));
-        if (e != hipSuccess) {
-            (void)hipHostFree(np);
-            return fail(c, PJB_ERR_NOMEM, "hipMalloc(row table): %s", hipGetErrorString(e));
-        }
-        if (old) {
-            memcpy(np, c->rows_pinned, old * sizeof(pjb_junction_row));
-            (void)hipMemcpy(nd, c->rows_table, old * sizeof(pjb_junction_row), hipMemcpyDeviceToDevice);
-        }
-        if (c->rows_pinned) (void)hipHostFree(c->rows_pinned);
-        if (c->rows_table) (void)hipFree(c->rows_table);
-        c->rows_pinned = np;
+        pjb_junction_row *nd = nullptr;
+        hipError_t e = hipMalloc((void **)&nd, ncap * sizeof(pjb_junction_row));
+        if (e != hipSuccess) return fail(c, PJB_ERR_NOMEM, "hipMalloc(row table): %s", hipGetErrorString(e));
+        if (old) (void)hipMemcpy(nd, c->rows_table, old * sizeof(pjb_junction_row), hipMemcpyDeviceToDevice);
+        if (c->rows_table) bury(c, c->rows_table); // (nothing reads it any more: the copy above has returned; hipFree would wait for the device)
         c->rows_table = nd;
         c->rows_cap = ncap;
     }
@@ -1479,6 +1490,7 @@ static int collect_flight(pjb_ctx *c, pjb_region_result *res, bool *redo_single)
         HIP_TRY(c, hipStreamSynchronize(c->stream4));
     }
     if (J) { // the chain's rows: HBM table -> host table, by DMA, behind whatever the caller does next
+        if ((rc = rows_pinned_reserve(c, old + J))) return rc;
         HIP_TRY(c, hipMemcpyAsync(c->rows_pinned + old, c->rows_table + old, (size_t)J * sizeof(pjb_junction_row), hipMemcpyDeviceToHost, c->stream4));
         c->rows_copy_pending = true;
     }
@@ -1593,8 +1605,9 @@ int pjb_finish_contig(pjb_ctx *c, int32_t tid, pjb_region_result *res) {
 
 int pjb_collect(pjb_ctx *c, const pjb_junction_row **rows, int64_t *n) {
     if (!c || !rows || !n) return PJB_ERR_ARG;
-    const int rc = rows_sync(c);
+    int rc = rows_sync(c);
     if (rc) return rc;
+    if (!c->rows_pinned && (rc = rows_pinned_reserve(c, 1))) return rc; // (a table, if an empty one: the pointer is never null)
     *rows = c->rows_pinned;
     *n = (int64_t)c->rows_n;
     return PJB_OK;
@@ -1701,6 +1714,7 @@ int pjb_clear_rows(pjb_ctx *c) {
     if (c->n_fl) return fail(c, PJB_ERR_STATE, "clear_rows: target %d is still queued", c->fl[0].tid);
     (void)rows_sync(c);
     c->rows_n = 0;
+    (void)exhume(c); // (nothing is queued: the buffers that were replaced while chains ran go back now)
     mirror_reset(c);
     if (c->extra) {
         (void)hipSetDevice(c->cfg.device);

@@ -275,7 +275,10 @@ struct pjb_ctx {
     bool dense_ids = true;                       // K2d (PJB_DENSE_IDS=0 sorts the full keys as round 1 did)
     u32 junc_seen = 0;                           // most junctions a contig has had so far (junction limit of the next contig)
     int lbits_seen = 18;                         // bits of the longest intron this context has met (key format of the next contig)
-    size_t rows_n = 0, rows_cap = 0;
+    size_t rows_n = 0, rows_cap = 0;             // rows collected so far; rows the HBM table holds
+    size_t rows_pinned_cap = 0;                  // rows the host table holds: grown when a chain is collected, to what it brought (rows_pinned_reserve)
+    std::vector<void *> graveyard;               // device buffers that were replaced by larger ones (ensure, the row table): freed by exhume()
+    std::mutex grave_mu;                         // (pjb_bam_* run on the caller's threads beside the thread that queues the chains)
     size_t last_rows_n = 0; // rows of the contig finished last (still in b_rows)
     uint8_t *mirror = nullptr; // caller's device buffer filled by every finish (header + rows)
     size_t mirror_cap = 0;
@@ -346,6 +349,20 @@ inline int fail(pjb_ctx *c, int code, const char *fmt, ...) {
                         __LINE__);                                                                         \
     } while (0)
 
+// the buffers ensure() has put aside go back to the device (hipFree waits for the device: call where that costs nothing)
+inline void bury(pjb_ctx *c, void *p) {
+    std::lock_guard<std::mutex> lk(c->grave_mu);
+    c->graveyard.push_back(p);
+}
+inline bool exhume(pjb_ctx *c) { // (true: something was freed)
+    std::vector<void *> g;
+    {
+        std::lock_guard<std::mutex> lk(c->grave_mu);
+        g.swap(c->graveyard);
+    }
+    for (void *p : g) (void)hipFree(p);
+    return !g.empty();
+}
 #ifdef PJB_DEBUG_ALLOC // (debug builds: every device buffer with its range on stderr, so that a "Memory access fault ... on address" can be placed)
 #define ensure(c, b, bytes) ensure_named((c), (b), (bytes), #b, __LINE__)
 inline int ensure_named(pjb_ctx *c, Buf &b, size_t bytes, const char *what, int line);
@@ -361,11 +378,19 @@ inline int ensure_impl(pjb_ctx *c, Buf &b, size_t bytes) {
 inline int ensure(pjb_ctx *c, Buf &b, size_t bytes) {
 #endif
     if (bytes <= b.cap && b.p) return PJB_OK;
-    if (b.p) HIP_TRY(c, hipFree(b.p));
+    // A buffer that has to grow is not freed here: hipFree waits for the whole device -- the inflate of the next targets, the copies in
+    // flight -- and every thread that calls into the runtime meanwhile waits with it (end to end: 15 - 40 ms of nothing at the first
+    // chains).  The old buffer goes to the context's graveyard, which is emptied where a wait costs nothing (exhume: pjb_clear_rows,
+    // pjb_destroy) or when an allocation fails.  A buffer grows by a quarter at least, so what lies there is a few times the live size at most.
+    if (b.p) bury(c, b.p);
     b.p = nullptr;
     b.cap = 0;
     size_t want = std::max<size_t>(bytes + bytes / 4, 256);
     hipError_t e = hipMalloc(&b.p, want);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        if (exhume(c)) e = hipMalloc(&b.p, want);
+    }
     if (e != hipSuccess) {
         want = std::max<size_t>(bytes, 256);
         e = hipMalloc(&b.p, want);

@@ -334,7 +334,7 @@ private:
             mine->cap = 0;
         }
         pjb_host_free(old);
-        const size_t cap = bytes + bytes / 8;
+        const size_t cap = pieceBytes ? bytes : bytes + bytes / 8;  // (the ring's pieces never grow; page-locking costs ~0.1 s per GB, twice: to get and to give back)
         uint8_t* np = (uint8_t*)pjb_host_alloc(cap);
         std::lock_guard<std::mutex> lk(mu);
         if (!np) {
