@@ -748,8 +748,14 @@ static int queue_contig(pjb_ctx *c, Flight &f) {
         pjb_junction_row *nd = nullptr;
         hipError_t e = hipMalloc((void **)&nd, ncap * sizeof(pjb_junction_row));
         if (e != hipSuccess) return fail(c, PJB_ERR_NOMEM, "hipMalloc(row table): %s", hipGetErrorString(e));
-        if (old) (void)hipMemcpy(nd, c->rows_table, old * sizeof(pjb_junction_row), hipMemcpyDeviceToDevice);
-        if (c->rows_table) bury(c, c->rows_table); // (nothing reads it any more: the copy above has returned; hipFree would wait for the device)
+        if (old) {
+            // (a device-to-device hipMemcpy may return before it has run, and the chains' streams do not wait for the null stream: without
+            // the wait the rows a chain appends below `old` -- `old` is a bound -- could be overwritten by the tail of this copy.  The
+            // hipFree that used to follow waited for the whole device; this waits for the copy.)
+            HIP_TRY(c, hipMemcpyAsync(nd, c->rows_table, old * sizeof(pjb_junction_row), hipMemcpyDeviceToDevice, c->stream4));
+            HIP_TRY(c, hipStreamSynchronize(c->stream4));
+        }
+        if (c->rows_table) bury(c, c->rows_table); // (nothing reads it any more; hipFree would wait for the device)
         c->rows_table = nd;
         c->rows_cap = ncap;
     }

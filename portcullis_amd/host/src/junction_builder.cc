@@ -1370,15 +1370,39 @@ void JunctionBuilder::findJunctions() {
             c.kind = DeviceThread::Cmd::FLUSH;
             dth->push(std::move(c));
         }
-    for (size_t i = 0; i < deferredTargets.size(); i++)
-        if (deferredTargets[i]) {
-            try {
-                completeTarget((int32_t)i, *deferredTargets[i]);
-            } catch (const std::exception& e) {
-                if (firstError.empty()) firstError = e.what();
+    {
+        // A few threads take the targets in index order: a target's rows become Junction objects as soon as its chain has been collected
+        // -- the first groups' while the last group's chain still runs -- instead of all 250 000 behind the last chain on this thread
+        // (50 ms of the run).  The first error in index order is the one reported, as before.
+        std::vector<std::string> errs(deferredTargets.size());
+        std::atomic<size_t> next{0};
+        auto work = [&] {
+            for (;;) {
+                const size_t i = next.fetch_add(1);
+                if (i >= deferredTargets.size()) break;
+                if (!deferredTargets[i]) continue;
+                try {
+                    completeTarget((int32_t)i, *deferredTargets[i]);
+                } catch (const std::exception& e) {
+                    errs[i] = e.what();
+                    if (errs[i].empty()) errs[i] = "unknown error";
+                }
+                deferredTargets[i].reset();
             }
-            deferredTargets[i].reset();
+        };
+        size_t waiting = 0;
+        for (auto& d : deferredTargets) waiting += d ? 1 : 0;
+        const size_t nt = std::min<size_t>(waiting, 16);
+        if (nt <= 1) {
+            work();
+        } else {
+            std::vector<std::thread> th;
+            for (size_t t = 0; t < nt; t++) th.emplace_back(work);
+            for (auto& x : th) x.join();
         }
+        for (auto& e : errs)
+            if (!e.empty() && firstError.empty()) firstError = e;
+    }
     if (extra && firstError.empty() && !deviceThreads.empty()) {
         // calcExtraMetrics (src/junction_builder.cc:293-312): multiple mapping score, flanking alignments, coverage
         cout << "Calculating extra junction metrics:" << endl;
@@ -1415,10 +1439,14 @@ void JunctionBuilder::findJunctions() {
         auto pp = std::move(pinnedPool);
         auto gp = std::move(genomePool);
         deviceThreads.clear();
-        std::thread([dts, pp, gp]() mutable {
-            dts->clear();
+        // (the page-locked rings first: giving 1.6 GB of them back takes ~0.15 s here or in the kernel when the process leaves, a context's
+        // device memory a third of that -- tools/debug/exit_probe.cc; PORTCULLIS_TEARDOWN_CONTEXTS_FIRST=1: the order until round 6)
+        const bool contextsFirst = getenv("PORTCULLIS_TEARDOWN_CONTEXTS_FIRST") != nullptr;
+        std::thread([dts, pp, gp, contextsFirst]() mutable {
+            if (contextsFirst) dts->clear();
             pp.reset();
             gp.reset();
+            dts->clear();
         }).detach();
     }
     if (!firstError.empty()) throw JunctionBuilderException(firstError);

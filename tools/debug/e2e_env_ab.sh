@@ -10,7 +10,8 @@ IFS=';' read -ra SETTINGS <<< "${ENVS:--}"
 for k in $(seq 1 ${REPS:-6}); do for i in "${!SETTINGS[@]}"; do
   cfg="${SETTINGS[$i]}"; [ "$cfg" = "-" ] && cfg="PJB_NONE=1"
   sleep ${PAUSE:-3}  # (a run right behind another one waits for the driver to take that one's device memory apart: profiles/r06_e2e_pause.txt)
-  s=$(date +%s.%N); env $cfg PJB_PROFILE_HOST=1 $EXE junc -t $(nproc) --orientation FR -o /tmp/pjb_bench_e2e/prof/ab$i /tmp/pjb_bench_e2e/prep > /tmp/ab_$i.txt 2>&1; e=$(date +%s.%N)
+  exe=$EXE; for kv in $cfg; do case $kv in EXE=*) exe=${kv#EXE=};; esac; done  # (a setting may name another build of the program: EXE=path)
+  s=$(date +%s.%N); env $cfg PJB_PROFILE_HOST=1 $exe junc -t $(nproc) --orientation FR -o /tmp/pjb_bench_e2e/prof/ab$i /tmp/pjb_bench_e2e/prep > /tmp/ab_$i.txt 2>&1; e=$(date +%s.%N)
   python3 - "$cfg" $s $e /tmp/ab_$i.txt <<'PY'
 import sys, re
 cfg, s, e, f = sys.argv[1], float(sys.argv[2]), float(sys.argv[3]), sys.argv[4]
