@@ -74,6 +74,7 @@ public:
 
     void addJunction(JunctionPtr j);
     void append(JunctionSystem& other);
+    void absorb(JunctionSystem& other);  // append(), moving the other system's intron map over (the other keeps its list only)
     // Append junctions delivered by the device path (pjb_collect rows of one or more contigs).
     void appendRows(const pjb_junction_row* rows, size_t n);
 

@@ -1440,14 +1440,25 @@ void JunctionBuilder::findJunctions() {
         auto gp = std::move(genomePool);
         deviceThreads.clear();
         // (the page-locked rings first: giving 1.6 GB of them back takes ~0.15 s here or in the kernel when the process leaves, a context's
-        // device memory a third of that -- tools/debug/exit_probe.cc; PORTCULLIS_TEARDOWN_CONTEXTS_FIRST=1: the order until round 6)
+        // device memory a third of that -- tools/debug/exit_probe.cc; PORTCULLIS_TEARDOWN_CONTEXTS_FIRST=1: the order until round 6.
+        // Giving the rings back EARLIER -- behind the last target's bytes, beside the last chains -- was measured twice and made the run
+        // longer both times: the unregister calls hold up the chains' launches, profiles/r06_e2e_pools.txt, r06_e2e_early_free.txt)
         const bool contextsFirst = getenv("PORTCULLIS_TEARDOWN_CONTEXTS_FIRST") != nullptr;
-        std::thread([dts, pp, gp, contextsFirst]() mutable {
-            if (contextsFirst) dts->clear();
-            pp.reset();
-            gp.reset();
-            dts->clear();
-        }).detach();
+        // (moved into the threads: the last owner frees, and that must not be this thread)
+        if (contextsFirst || getenv("PORTCULLIS_TEARDOWN_ONE_THREAD")) {
+            std::thread([dts = std::move(dts), pp = std::move(pp), gp = std::move(gp), contextsFirst]() mutable {
+                if (contextsFirst) dts->clear();
+                pp.reset();
+                gp.reset();
+                dts->clear();
+            }).detach();
+        } else {  // the rings on one thread, the contexts on another (1.67 against 1.70 s on one thread, profiles/r06_e2e_host_tail2.txt)
+            std::thread([pp = std::move(pp), gp = std::move(gp)]() mutable {
+                pp.reset();
+                gp.reset();
+            }).detach();
+            std::thread([dts = std::move(dts)]() mutable { dts->clear(); }).detach();
+        }
     }
     if (!firstError.empty()) throw JunctionBuilderException(firstError);
     const double t_workers1 = HostProfile::now();
@@ -1465,7 +1476,7 @@ void JunctionBuilder::findJunctions() {
         junctionSystem.reserve(total);
     }
     for (auto& res : results) {
-        junctionSystem.append(res.js);
+        junctionSystem.absorb(res.js);  // (the per-target systems keep their lists -- --extra walks them -- not their maps)
         unsplicedCount += res.unsplicedCount;
         splicedCount += res.splicedCount;
         sumQueryLengths += res.sumQueryLengths;

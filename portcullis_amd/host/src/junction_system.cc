@@ -22,13 +22,13 @@ std::string JunctionSystem::version = "";
 // junction_system.cc:55-70: chain of consecutive junctions sharing a donor or acceptor with the
 // previous member; returns the index of the last member
 size_t JunctionSystem::createJunctionGroup(size_t index, std::vector<JunctionPtr>& group) {
-    JunctionPtr cur = junctionList[index];
-    group.push_back(cur);
+    const JunctionPtr* cur = &junctionList[index];  // (by reference: a shared_ptr copy is two atomic operations, a quarter of a million times)
+    group.push_back(*cur);
     for (size_t j = index + 1; j < junctionList.size(); j++) {
-        JunctionPtr next = junctionList[j];
-        if (!cur->sharesDonorOrAcceptor(next)) return j - 1;
+        const JunctionPtr& next = junctionList[j];
+        if (!(*cur)->sharesDonorOrAcceptor(next)) return j - 1;
         group.push_back(next);
-        cur = next;
+        cur = &next;
     }
     return junctionList.size() - 1;
 }
@@ -46,6 +46,16 @@ void JunctionSystem::addJunction(JunctionPtr j) {
 
 void JunctionSystem::append(JunctionSystem& other) {
     for (const auto& j : other.getJunctions()) addJunction(j);
+}
+
+// append() for a system that is not needed as a map afterwards (the per-target systems of findJunctions): its list is copied behind this
+// one's, its map's NODES move over (no allocation, no copy of a key: a quarter of a million inserts were 40 ms of the merge) and whatever
+// stays behind -- an intron this system has already -- overwrites this system's entry, as addJunction would have
+void JunctionSystem::absorb(JunctionSystem& other) {
+    junctionList.insert(junctionList.end(), other.junctionList.begin(), other.junctionList.end());
+    distinctJunctions.merge(other.distinctJunctions);
+    for (auto& kv : other.distinctJunctions) distinctJunctions[kv.first] = kv.second;
+    other.distinctJunctions.clear();
 }
 
 void JunctionSystem::appendRows(const pjb_junction_row* rows, size_t n) {
@@ -137,8 +147,9 @@ JunctionPtr JunctionSystem::getJunction(const Intron& intron) const {
 void JunctionSystem::calcJunctionStats() {
     if (junctionList.empty()) return;
     const size_t n = junctionList.size();
+    std::vector<JunctionPtr> group;  // (one vector for every group: a quarter of a million allocations otherwise)
     for (size_t i = 0; i < n; i++) {
-        std::vector<JunctionPtr> group;
+        group.clear();
         i = createJunctionGroup(i, group);
         uint32_t maxReads = 0;
         size_t maxIndex = 0;
