@@ -1262,7 +1262,10 @@ void JunctionBuilder::findJunctions() {
             // PORTCULLIS_READ_THREADS threads.  FEW readers: four threads pread 31.6 GB/s out of the page cache into page-locked
             // buffers, eight 25.0, fifteen 24.8 (profiles/r03ap_register_probe.txt), and the run with 2 x 2 readers takes 2.03 s
             // where 3 x 5 took 2.3 - 2.6 (profiles/r03aq_e2e_readers.txt).
-            transferSlots = 2;
+            // (Round 6, every run behind a 3 s pause -- the stalls that made three slots look unstable were the process before the run,
+            // profiles/r06_e2e_pause.txt --: three targets in transfer, two readers each, against two: 1.61 / 1.63 s against 1.68 / 1.64 s
+            // median of eight in two calls, the workers' phase 1.17 against 1.21 - 1.24 s; four: as three.  profiles/r06_e2e_retune*.txt)
+            transferSlots = 3;
             if (const char* e = getenv("PORTCULLIS_TRANSFER_SLOTS")) transferSlots = atoi(e);
         }
     }
