@@ -1263,9 +1263,10 @@ void JunctionBuilder::findJunctions() {
             // buffers, eight 25.0, fifteen 24.8 (profiles/r03ap_register_probe.txt), and the run with 2 x 2 readers takes 2.03 s
             // where 3 x 5 took 2.3 - 2.6 (profiles/r03aq_e2e_readers.txt).
             // (Round 6, every run behind a 3 s pause -- the stalls that made three slots look unstable were the process before the run,
-            // profiles/r06_e2e_pause.txt --: three targets in transfer, two readers each, against two: 1.61 / 1.63 s against 1.68 / 1.64 s
-            // median of eight in two calls, the workers' phase 1.17 against 1.21 - 1.24 s; four: as three.  profiles/r06_e2e_retune*.txt)
-            transferSlots = 3;
+            // profiles/r06_e2e_pause.txt --: three targets in transfer against two, medians of 8 / 8 / 14 runs in three calls: 1.61 / 1.63 /
+            // 1.71 s against 1.68 / 1.64 / 1.68 s, and 1.69 s against 1.63 - 1.65 in the bench's own leg; four: as three.  A wash with the
+            // wider spread on three's side: two stays.  profiles/r06_e2e_retune*.txt)
+            transferSlots = 2;
             if (const char* e = getenv("PORTCULLIS_TRANSFER_SLOTS")) transferSlots = atoi(e);
         }
     }
