@@ -29,3 +29,18 @@ def test_formatters_under_sanitizers(tmp_path):
                           [f"-L{csrc}", "-lportcullis_amd", f"-Wl,-rpath,{csrc}", "-lz", "-lpthread"])
     out = subprocess.run([exe], capture_output=True, text=True)
     assert out.returncode == 0 and "mismatches: 0" in out.stdout, out.stdout + out.stderr[-2000:]
+
+
+def test_absorb_equals_append(tmp_path):
+    """JunctionSystem::absorb (findJunctions' merge: the per-target maps' nodes move over) against append on random per-target systems,
+    with and without introns in common; calcJunctionStats on both merged lists gives the same table."""
+    host = os.path.join(ROOT, "portcullis_amd", "host")
+    csrc = os.path.join(ROOT, "portcullis_amd", "csrc")
+    exe = str(tmp_path / "absorb")
+    src = [os.path.join(host, "src", f) for f in ("junction.cc", "junction_system.cc", "genome_mapper.cc", "bam_reader.cc", "fast_inflate.cc", "bam_writer.cc")]
+    subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+                           "-fno-omit-frame-pointer", f"-I{host}/include", f"-I{ROOT}/include", "-o", exe,
+                           os.path.join(ROOT, "tests", "cpp", "absorb_equivalence.cc")] + src +
+                          [f"-L{csrc}", "-lportcullis_amd", f"-Wl,-rpath,{csrc}", "-lz", "-lpthread"])
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0 and "mismatches: 0" in out.stdout, out.stdout + out.stderr[-2000:]
